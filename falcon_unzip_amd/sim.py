@@ -1,0 +1,173 @@
+"""Synthetic diploid + PacBio-CLR-like read simulator (numpy PCG64, deterministic).
+
+This is the input generator SURVEY.md section 8(d) prescribes for every config:
+hap0 = iid uniform ACGT (it is also the primary contig the reads are aligned to),
+hap1 = hap0 with SNPs at rate 1/500; reads of fixed template length R start
+uniformly, pick a haplotype with p=1/2, and go through a CLR error model
+(sub / ins / del).  The simulator knows the true alignment of every read, so it can
+emit the coordinate-sorted SAM text that `samtools view <bam> <ctg>` would hand to
+`make_het_call` (reference: falcon_unzip/phasing.py:27,42-59) without any aligner.
+
+Nothing here is on the product path: tests, the golden generator and bench.py use it
+to make inputs.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+_COMP = np.array([3, 2, 1, 0], dtype=np.uint8)  # A<->T, C<->G on 2-bit codes
+
+# op codes used internally (also the BAM op numbering the C-ABI uses)
+OP_M, OP_I, OP_D, OP_N, OP_S, OP_H, OP_P, OP_EQ, OP_X = range(9)
+OP_CHARS = "MIDNSHP=X"
+
+
+def rng_for(config: int, contig_idx: int = 0) -> np.random.Generator:
+    """seed = 20260000 + 1000*config + contig_idx."""
+    return np.random.Generator(np.random.PCG64(20260000 + 1000 * config + contig_idx))
+
+
+def make_diploid(L: int, rng: np.random.Generator, het_rate: float = 1.0 / 500):
+    """Return (hap0 codes, hap1 codes, sorted het positions)."""
+    hap0 = rng.integers(0, 4, size=L, dtype=np.uint8)
+    n_het = int(round(L * het_rate))
+    pos = np.sort(rng.choice(L, size=n_het, replace=False))
+    hap1 = hap0.copy()
+    hap1[pos] = (hap0[pos] + rng.integers(1, 4, size=n_het, dtype=np.uint8)) & 3
+    return hap0, hap1, pos
+
+
+def codes_to_str(codes: np.ndarray) -> str:
+    return ACGT[codes].tobytes().decode("ascii")
+
+
+def revcomp_codes(codes: np.ndarray) -> np.ndarray:
+    return _COMP[codes[::-1]]
+
+
+class SimRead:
+    __slots__ = ("name", "hap", "start", "strand", "seq", "ops", "lens", "clip5", "clip3")
+
+    def __init__(self, name, hap, start, strand, seq, ops, lens, clip5, clip3):
+        self.name = name      # QNAME
+        self.hap = hap        # 0/1 haplotype of origin
+        self.start = start    # 0-based contig position of the first aligned column
+        self.strand = strand  # 0 forward, 1 reverse (the *sequenced* read is revcomp)
+        self.seq = seq        # uint8 codes, on the CONTIG strand, incl. soft clips
+        self.ops = ops        # uint8 op codes (run-length encoded CIGAR)
+        self.lens = lens      # int32 run lengths
+        self.clip5 = clip5
+        self.clip3 = clip3
+
+    def cigar(self) -> str:
+        return "".join("%d%s" % (l, OP_CHARS[o]) for o, l in zip(self.ops, self.lens))
+
+    def raw_seq_codes(self) -> np.ndarray:
+        """Sequence as it came off the instrument (what <ctg>_reads.fa holds)."""
+        return revcomp_codes(self.seq) if self.strand else self.seq
+
+    def ref_span(self) -> int:
+        m = (self.ops == OP_EQ) | (self.ops == OP_X) | (self.ops == OP_D) | (self.ops == OP_M)
+        return int(self.lens[m].sum())
+
+
+def _rle(op_seq: np.ndarray):
+    if op_seq.size == 0:
+        return np.zeros(0, np.uint8), np.zeros(0, np.int32)
+    brk = np.flatnonzero(op_seq[1:] != op_seq[:-1]) + 1
+    starts = np.concatenate(([0], brk))
+    ends = np.concatenate((brk, [op_seq.size]))
+    return op_seq[starts].astype(np.uint8), (ends - starts).astype(np.int32)
+
+
+def simulate_read(contig, hap, start, R, rng, sub=0.01, ins=0.08, dele=0.04,
+                  clip5=0, clip3=0):
+    """One read of template length R from `hap` at `start`; CIGAR is vs `contig`.
+
+    Returns (seq codes on contig strand incl. clips, ops, lens).
+    """
+    t = hap[start:start + R]
+    c = contig[start:start + R]
+    R = t.size
+    u = rng.random(R)
+    is_del = u < dele
+    is_sub = (u >= dele) & (u < dele + sub)
+    n_ins = (rng.random(R) < ins).astype(np.int64)
+    # keep the alignment anchored: first/last template bases are emitted, no leading insert
+    is_del[0] = is_del[-1] = False
+    n_ins[0] = 0
+    base = t.copy()
+    nsub = int(is_sub.sum())
+    if nsub:
+        base[is_sub] = (t[is_sub] + rng.integers(1, 4, size=nsub, dtype=np.uint8)) & 3
+    emit = (~is_del).astype(np.int64)
+    per = n_ins + 1                       # path steps contributed by template base k
+    tot_steps = int(per.sum())
+    step_off = np.cumsum(per) - per       # first step of template base k
+    op_seq = np.full(tot_steps, OP_I, dtype=np.uint8)
+    last = step_off + n_ins               # the M/D step of base k
+    op_seq[last] = np.where(is_del, OP_D, np.where(base == c, OP_EQ, OP_X))
+    # read bases: inserted bases random, emitted bases = base
+    q_per = n_ins + emit
+    qlen = int(q_per.sum())
+    q_off = np.cumsum(q_per) - q_per
+    seq = rng.integers(0, 4, size=qlen, dtype=np.uint8)   # fills the insert slots
+    seq[(q_off + n_ins)[~is_del]] = base[~is_del]
+    ops, lens = _rle(op_seq)
+    if clip5:
+        seq = np.concatenate((rng.integers(0, 4, size=clip5, dtype=np.uint8), seq))
+        ops = np.concatenate(([OP_S], ops)).astype(np.uint8)
+        lens = np.concatenate(([clip5], lens)).astype(np.int32)
+    if clip3:
+        seq = np.concatenate((seq, rng.integers(0, 4, size=clip3, dtype=np.uint8)))
+        ops = np.concatenate((ops, [OP_S])).astype(np.uint8)
+        lens = np.concatenate((lens, [clip3])).astype(np.int32)
+    return seq, ops, lens
+
+
+def simulate_reads(hap0, hap1, n_reads, R, rng, sub=0.01, ins=0.08, dele=0.04,
+                   strand_mix=0.0, clip_frac=0.0, clip_max=300, name_prefix="sim"):
+    """`n_reads` reads vs contig = hap0.  Returned list is in simulation order."""
+    L = hap0.size
+    reads = []
+    starts = rng.integers(0, max(1, L - R + 1), size=n_reads)
+    haps = rng.integers(0, 2, size=n_reads)
+    strands = (rng.random(n_reads) < strand_mix).astype(np.int64)
+    for i in range(n_reads):
+        c5 = c3 = 0
+        if clip_frac > 0 and rng.random() < clip_frac:
+            c5 = int(rng.integers(0, clip_max))
+            c3 = int(rng.integers(0, clip_max))
+        hap = hap1 if haps[i] else hap0
+        seq, ops, lens = simulate_read(hap0, hap, int(starts[i]), R, rng, sub, ins, dele, c5, c3)
+        name = "%s/%d/0_%d" % (name_prefix, i, seq.size)
+        reads.append(SimRead(name, int(haps[i]), int(starts[i]), int(strands[i]), seq, ops, lens, c5, c3))
+    return reads
+
+
+def sam_lines(reads, ctg_id, header=True, L=None):
+    """Coordinate-sorted SAM text lines (sorted by (POS, simulation index))."""
+    out = []
+    if header:
+        out.append("@HD\tVN:1.5\tSO:coordinate")
+        if L is not None:
+            out.append("@SQ\tSN:%s\tLN:%d" % (ctg_id, L))
+    order = sorted(range(len(reads)), key=lambda i: (reads[i].start, i))
+    for i in order:
+        r = reads[i]
+        flag = 16 if r.strand else 0
+        out.append("\t".join((r.name, str(flag), ctg_id, str(r.start + 1), "254", r.cigar(),
+                              "*", "0", "0", codes_to_str(r.seq), "*")))
+    return out
+
+
+def write_fasta(path, records, width=0):
+    with open(path, "w") as f:
+        for name, seq in records:
+            f.write(">%s\n" % name)
+            if width:
+                for i in range(0, len(seq), width):
+                    f.write(seq[i:i + width] + "\n")
+            else:
+                f.write(seq + "\n")
