@@ -1,0 +1,376 @@
+"""ctypes binding of libfzphase.so (include/fzphase.h).  No torch, no CPU fallback.
+
+Records cross the boundary as numpy structured arrays whose dtypes mirror the C structs.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfzphase.so")
+
+FZP_OK = 0
+FZP_EINVAL, FZP_EZERODIV, FZP_ENOMEM, FZP_EUNSORTED, FZP_EDEVICE, FZP_ENODEVICE = -1, -2, -3, -4, -5, -6
+STAGE_HET, STAGE_ASSOC, STAGE_BLOCKS, STAGE_READS, STAGE_ALL = 1, 2, 4, 8, 15
+
+SITE = np.dtype([("pos", "<i4"), ("ref_base", "u1"), ("base", "u1", (4,)), ("pad_", "u1", (3,)), ("total", "<i4"),
+                 ("count", "<i4", (4,)), ("row_off", "<i8")], align=True)
+AROW = np.dtype([("site1", "<i4"), ("site2", "<i4"), ("n", "<i4", (4,))], align=True)
+PVAR = np.dtype([("block", "<i4"), ("site", "<i4"), ("b1", "u1"), ("b2", "u1"), ("pad_", "u1", (2,)), ("lext", "<i4"),
+                 ("rext", "<i4"), ("lscore", "<i4"), ("rscore", "<i4")], align=True)
+PREAD = np.dtype([("q_id", "<i4"), ("block", "<i4"), ("phase", "<i4"), ("n0", "<i4"), ("n1", "<i4")], align=True)
+R2P = np.dtype([("arid", "<i4"), ("ctg", "<i4"), ("block", "<i4"), ("phase", "<i4")], align=True)
+ALN_SUMMARY = np.dtype([("aligned", "<i4"), ("strand", "<i4"), ("pos", "<i4"), ("ref_end", "<i4"), ("q_start", "<i4"),
+                        ("q_end", "<i4"), ("score", "<i4"), ("n_cigar", "<i4"), ("cells", "<i8")], align=True)
+assert SITE.itemsize == 40 and AROW.itemsize == 24 and PVAR.itemsize == 28 and PREAD.itemsize == 20
+assert R2P.itemsize == 16 and ALN_SUMMARY.itemsize == 40
+
+
+class FzpError(RuntimeError):
+    def __init__(self, code, msg):
+        RuntimeError.__init__(self, "libfzphase error %d: %s" % (code, msg))
+        self.code = code
+
+
+class AlnSetStruct(C.Structure):
+    _fields_ = [("n_rec", C.c_int64), ("rec_qid", C.POINTER(C.c_int32)), ("rec_pos", C.POINTER(C.c_int32)),
+                ("cig_off", C.POINTER(C.c_int64)), ("cigar", C.POINTER(C.c_uint32)), ("seq_off", C.POINTER(C.c_int64)),
+                ("seq", C.POINTER(C.c_uint8)), ("n_qid", C.c_int32), ("qname_off", C.POINTER(C.c_int64)),
+                ("qnames", C.POINTER(C.c_char)), ("last_pos", C.c_int32), ("max_ref_span", C.c_int32),
+                ("n_columns", C.c_int64)]
+
+
+class ResultStruct(C.Structure):
+    _fields_ = [("n_sites", C.c_int64), ("sites", C.c_void_p), ("n_rows", C.c_int64), ("vmap_qid", C.c_void_p),
+                ("n_arows", C.c_int64), ("arows", C.c_void_p), ("n_pvars", C.c_int64), ("pvars", C.c_void_p),
+                ("n_preads", C.c_int64), ("preads", C.c_void_p)]
+
+
+class AlignParams(C.Structure):
+    _fields_ = [("kmer", C.c_int32), ("seed_stride", C.c_int32), ("match", C.c_int32), ("mismatch", C.c_int32),
+                ("gap", C.c_int32), ("min_seed_hits", C.c_int32), ("reserved", C.c_int32 * 10)]
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library; raises (loudly) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(make -C falcon_unzip_amd/csrc).  There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    VP, I32, I64, SZ, PP = C.c_void_p, C.c_int32, C.c_int64, C.c_size_t, C.POINTER(C.c_void_p)
+    PI64, PSZ, CP = C.POINTER(C.c_int64), C.POINTER(C.c_size_t), C.c_char_p
+    sigs = {
+        "fzp_free": (None, [VP]),
+        "fzp_ctx_create": (C.c_int, [C.c_int, C.c_uint, PP]),
+        "fzp_ctx_destroy": (None, [VP]),
+        "fzp_ctx_synchronize": (C.c_int, [VP]),
+        "fzp_prof_enable": (C.c_int, [VP, C.c_int]),
+        "fzp_prof_reset": (C.c_int, [VP]),
+        "fzp_prof_get": (C.c_int, [VP, CP, C.POINTER(C.c_double), PI64]),
+        "fzp_prof_names": (C.c_int, [VP, PP]),
+        "fzp_parse_sam": (C.c_int, [CP, SZ, PP]),
+        "fzp_alnset_free": (None, [VP]),
+        "fzp_result_free": (None, [VP]),
+        "fzp_het_call": (C.c_int, [VP, VP, CP, I64, PP, PI64, PP, PI64]),
+        "fzp_assoc_table": (C.c_int, [VP, VP, I64, VP, I64, PP, PI64]),
+        "fzp_phase_blocks": (C.c_int, [VP, VP, I64, VP, I64, PP, PI64]),
+        "fzp_phase_reads": (C.c_int, [VP, VP, I64, VP, I64, VP, I64, I32, PP, PI64]),
+        "fzp_batch_create": (C.c_int, [VP, I32, VP, VP, VP, PP]),
+        "fzp_batch_run": (C.c_int, [VP, VP, C.c_uint]),
+        "fzp_batch_result": (C.c_int, [VP, VP, I32, VP]),
+        "fzp_batch_counts": (C.c_int, [VP, VP] + [PI64] * 8),
+        "fzp_batch_destroy": (None, [VP, VP]),
+        "fzp_format_variant_pos": (C.c_int, [VP, I64, PP, PSZ]),
+        "fzp_format_variant_map": (C.c_int, [VP, I64, VP, PP, PSZ]),
+        "fzp_format_q_id_map": (C.c_int, [VP, PP, PSZ]),
+        "fzp_format_atable": (C.c_int, [VP, VP, I64, PP, PSZ]),
+        "fzp_format_phased_variants": (C.c_int, [VP, VP, I64, PP, PSZ]),
+        "fzp_format_phased_reads": (C.c_int, [VP, I64, CP, VP, CP, I32, PP, PSZ]),
+        "fzp_format_sam": (C.c_int, [VP, CP, VP, PP, PSZ]),
+        "fzp_readmap": (C.c_int, [CP, SZ, CP, SZ, CP, SZ, CP, SZ, CP, I32, PP, PI64, PP, PSZ]),
+        "fzp_align_params_default": (None, [VP]),
+        "fzp_align_create": (C.c_int, [VP, I32, VP, VP, I64, VP, VP, VP, VP, PP]),
+        "fzp_align_run": (C.c_int, [VP, VP]),
+        "fzp_align_summaries": (C.c_int, [VP, VP, VP]),
+        "fzp_align_alnset": (C.c_int, [VP, VP, I32, VP, CP, PP, PP]),
+        "fzp_align_to_batch": (C.c_int, [VP, VP, PP]),
+        "fzp_align_destroy": (None, [VP, VP]),
+    }
+    lib.fzp_last_error.restype = C.c_char_p
+    lib.fzp_version.restype = C.c_char_p
+    for name, (res, args) in sigs.items():
+        if hasattr(lib, name):
+            f = getattr(lib, name)
+            f.restype = res
+            f.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc != FZP_OK:
+        raise FzpError(rc, load().fzp_last_error().decode("utf-8", "replace"))
+
+
+def _take(ptr, n, dtype):
+    """Copy a library-allocated array into numpy and free it."""
+    lib = load()
+    n = int(n)
+    if not ptr:
+        return np.zeros(0, dtype=dtype)
+    arr = np.frombuffer(C.string_at(ptr, n * np.dtype(dtype).itemsize), dtype=dtype).copy() if n else np.zeros(0, dtype=dtype)
+    lib.fzp_free(ptr)
+    return arr
+
+
+def _take_text(ptr, n):
+    lib = load()
+    s = C.string_at(ptr, n.value)
+    lib.fzp_free(ptr)
+    return s
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class AlnSet:
+    """Owning handle of a fzp_alnset (accepted alignment records of one contig + the q_id table)."""
+
+    def __init__(self, ptr):
+        self._p = ptr
+        self.s = C.cast(ptr, C.POINTER(AlnSetStruct)).contents
+
+    def __del__(self):
+        if getattr(self, "_p", None):
+            load().fzp_alnset_free(self._p)
+            self._p = None
+
+    n_rec = property(lambda self: int(self.s.n_rec))
+    n_qid = property(lambda self: int(self.s.n_qid))
+    last_pos = property(lambda self: int(self.s.last_pos))
+    n_columns = property(lambda self: int(self.s.n_columns))
+
+    def qname_table(self):
+        off = np.ctypeslib.as_array(self.s.qname_off, shape=(self.n_qid + 1,)).copy()
+        names = C.string_at(self.s.qnames, int(off[-1]))
+        return off, names
+
+    def qnames(self):
+        off, names = self.qname_table()
+        return [names[off[i]:off[i + 1]].decode() for i in range(self.n_qid)]
+
+    def rec_pos(self):
+        return np.ctypeslib.as_array(self.s.rec_pos, shape=(self.n_rec,)).copy() if self.n_rec else np.zeros(0, np.int32)
+
+    def rec_qid(self):
+        return np.ctypeslib.as_array(self.s.rec_qid, shape=(self.n_rec,)).copy() if self.n_rec else np.zeros(0, np.int32)
+
+    def cigar_of(self, r):
+        a, b = int(self.s.cig_off[r]), int(self.s.cig_off[r + 1])
+        return [(int(self.s.cigar[k]) >> 4, int(self.s.cigar[k]) & 15) for k in range(a, b)]
+
+    def seq_of(self, r):
+        a, b = int(self.s.seq_off[r]), int(self.s.seq_off[r + 1])
+        return C.string_at(C.addressof(self.s.seq.contents) + a, b - a) if b > a else b""
+
+
+def parse_sam(sam: bytes) -> AlnSet:
+    lib = load()
+    p = C.c_void_p()
+    _check(lib.fzp_parse_sam(sam, C.c_size_t(len(sam)), C.byref(p)))
+    return AlnSet(p.value)
+
+
+class Result:
+    """Records of one contig (numpy copies)."""
+
+    def __init__(self, rs: ResultStruct):
+        def grab(ptr, n, dt):
+            n = int(n)
+            if not ptr or n == 0:
+                return np.zeros(0, dtype=dt)
+            return np.frombuffer(C.string_at(ptr, n * np.dtype(dt).itemsize), dtype=dt).copy()
+        self.sites = grab(rs.sites, rs.n_sites, SITE)
+        self.vmap_qid = grab(rs.vmap_qid, rs.n_rows, np.int32)
+        self.arows = grab(rs.arows, rs.n_arows, AROW)
+        self.pvars = grab(rs.pvars, rs.n_pvars, PVAR)
+        self.preads = grab(rs.preads, rs.n_preads, PREAD)
+
+
+class Batch:
+    def __init__(self, eng, ptr, alnsets):
+        self.eng, self._p, self._keep = eng, ptr, alnsets
+        self.n_ctg = len(alnsets)
+
+    def run(self, stages=STAGE_ALL):
+        _check(load().fzp_batch_run(self.eng._p, self._p, C.c_uint(stages)))
+
+    def result(self, ctg) -> Result:
+        rs = ResultStruct()
+        _check(load().fzp_batch_result(self.eng._p, self._p, C.c_int32(ctg), C.byref(rs)))
+        r = Result(rs)
+        load().fzp_result_free(C.byref(rs))
+        return r
+
+    def counts(self):
+        v = [C.c_int64() for _ in range(8)]
+        _check(load().fzp_batch_counts(self.eng._p, self._p, *[C.byref(x) for x in v]))
+        keys = ("n_rec", "n_columns", "n_positions", "n_sites", "n_rows", "n_arows", "n_pvars", "n_preads")
+        return dict(zip(keys, (int(x.value) for x in v)))
+
+    def close(self):
+        if self._p:
+            load().fzp_batch_destroy(self.eng._p, self._p)
+            self._p = None
+
+    __del__ = close
+
+
+class Engine:
+    """One fzp_ctx: a (process, device) pair.  Fails loudly when no gfx950 device is usable."""
+
+    def __init__(self, device=0):
+        lib = load()
+        p = C.c_void_p()
+        _check(lib.fzp_ctx_create(C.c_int(device), C.c_uint(0), C.byref(p)))
+        self._p = p.value
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_p", None):
+            load().fzp_ctx_destroy(self._p)
+            self._p = None
+
+    __del__ = close
+
+    def synchronize(self):
+        _check(load().fzp_ctx_synchronize(self._p))
+
+    # ---- profiling
+    def prof_enable(self, on=True):
+        _check(load().fzp_prof_enable(self._p, C.c_int(1 if on else 0)))
+
+    def prof_reset(self):
+        _check(load().fzp_prof_reset(self._p))
+
+    def prof(self):
+        lib = load()
+        p = C.c_void_p()
+        _check(lib.fzp_prof_names(self._p, C.byref(p)))
+        names = C.string_at(p).decode().split("\n")
+        lib.fzp_free(p)
+        out = {}
+        for nme in names:
+            if not nme:
+                continue
+            ms, cnt = C.c_double(), C.c_int64()
+            _check(lib.fzp_prof_get(self._p, nme.encode(), C.byref(ms), C.byref(cnt)))
+            out[nme] = (ms.value, cnt.value)
+        return out
+
+    # ---- stages (single contig, host records)
+    def het_call(self, aln: AlnSet, ref_seq: bytes):
+        lib = load()
+        sp, ns, qp, nr = C.c_void_p(), C.c_int64(), C.c_void_p(), C.c_int64()
+        _check(lib.fzp_het_call(self._p, aln._p, ref_seq, len(ref_seq), C.byref(sp), C.byref(ns), C.byref(qp), C.byref(nr)))
+        return _take(sp.value, ns.value, SITE), _take(qp.value, nr.value, np.int32)
+
+    def assoc_table(self, sites, vmap_qid):
+        lib = load()
+        sites = np.ascontiguousarray(sites, dtype=SITE)
+        vmap_qid = np.ascontiguousarray(vmap_qid, dtype=np.int32)
+        ap, na = C.c_void_p(), C.c_int64()
+        _check(lib.fzp_assoc_table(self._p, _ptr(sites), C.c_int64(len(sites)), _ptr(vmap_qid), C.c_int64(len(vmap_qid)), C.byref(ap), C.byref(na)))
+        return _take(ap.value, na.value, AROW)
+
+    def phase_blocks(self, sites, arows):
+        lib = load()
+        sites = np.ascontiguousarray(sites, dtype=SITE)
+        arows = np.ascontiguousarray(arows, dtype=AROW)
+        pp, npv = C.c_void_p(), C.c_int64()
+        _check(lib.fzp_phase_blocks(self._p, _ptr(sites), C.c_int64(len(sites)), _ptr(arows), C.c_int64(len(arows)), C.byref(pp), C.byref(npv)))
+        return _take(pp.value, npv.value, PVAR)
+
+    def phase_reads(self, sites, vmap_qid, pvars, n_qid):
+        lib = load()
+        sites = np.ascontiguousarray(sites, dtype=SITE)
+        vmap_qid = np.ascontiguousarray(vmap_qid, dtype=np.int32)
+        pvars = np.ascontiguousarray(pvars, dtype=PVAR)
+        rp, nr = C.c_void_p(), C.c_int64()
+        _check(lib.fzp_phase_reads(self._p, _ptr(sites), C.c_int64(len(sites)), _ptr(vmap_qid), C.c_int64(len(vmap_qid)), _ptr(pvars),
+                                   C.c_int64(len(pvars)), C.c_int32(n_qid), C.byref(rp), C.byref(nr)))
+        return _take(rp.value, nr.value, PREAD)
+
+    # ---- many contigs, HBM-resident
+    def batch(self, alnsets, ref_seqs) -> Batch:
+        lib = load()
+        n = len(alnsets)
+        aptr = (C.c_void_p * n)(*[a._p for a in alnsets])
+        bufs = [C.create_string_buffer(r, len(r)) if len(r) else C.create_string_buffer(1) for r in ref_seqs]
+        rptr = (C.c_void_p * n)(*[C.cast(b, C.c_void_p).value for b in bufs])
+        lens = (C.c_int64 * n)(*[len(r) for r in ref_seqs])
+        p = C.c_void_p()
+        _check(lib.fzp_batch_create(self._p, C.c_int32(n), aptr, rptr, lens, C.byref(p)))
+        return Batch(self, p.value, list(alnsets))
+
+
+# ---------------------------------------------------------------------------- serializers
+def _fmt(fname, *args):
+    lib = load()
+    tp, tn = C.c_void_p(), C.c_size_t()
+    _check(getattr(lib, fname)(*args, C.byref(tp), C.byref(tn)))
+    return _take_text(tp, tn)
+
+
+def format_variant_pos(sites):
+    sites = np.ascontiguousarray(sites, dtype=SITE)
+    return _fmt("fzp_format_variant_pos", _ptr(sites), C.c_int64(len(sites)))
+
+
+def format_variant_map(sites, vmap_qid):
+    sites = np.ascontiguousarray(sites, dtype=SITE)
+    vmap_qid = np.ascontiguousarray(vmap_qid, dtype=np.int32)
+    return _fmt("fzp_format_variant_map", _ptr(sites), C.c_int64(len(sites)), _ptr(vmap_qid))
+
+
+def format_q_id_map(aln: AlnSet):
+    return _fmt("fzp_format_q_id_map", C.c_void_p(aln._p))
+
+
+def format_atable(sites, arows):
+    sites = np.ascontiguousarray(sites, dtype=SITE)
+    arows = np.ascontiguousarray(arows, dtype=AROW)
+    return _fmt("fzp_format_atable", _ptr(sites), _ptr(arows), C.c_int64(len(arows)))
+
+
+def format_phased_variants(sites, pvars):
+    sites = np.ascontiguousarray(sites, dtype=SITE)
+    pvars = np.ascontiguousarray(pvars, dtype=PVAR)
+    return _fmt("fzp_format_phased_variants", _ptr(sites), _ptr(pvars), C.c_int64(len(pvars)))
+
+
+def format_phased_reads(preads, ctg_id: str, qname_off, qnames: bytes):
+    preads = np.ascontiguousarray(preads, dtype=PREAD)
+    qname_off = np.ascontiguousarray(qname_off, dtype=np.int64)
+    return _fmt("fzp_format_phased_reads", _ptr(preads), C.c_int64(len(preads)), ctg_id.encode(), _ptr(qname_off), qnames,
+                C.c_int32(len(qname_off) - 1))
+
+
+def readmap(phased_reads: bytes, rawread_ids: bytes, pread_ids: bytes, pread_to_contigs: bytes, ctg_id: str, ctg_index=0):
+    """-> (records ndarray[R2P], rid_to_phase text)"""
+    lib = load()
+    rp, nr, tp, tn = C.c_void_p(), C.c_int64(), C.c_void_p(), C.c_size_t()
+    _check(lib.fzp_readmap(phased_reads, C.c_size_t(len(phased_reads)), rawread_ids, C.c_size_t(len(rawread_ids)), pread_ids,
+                           C.c_size_t(len(pread_ids)), pread_to_contigs, C.c_size_t(len(pread_to_contigs)), ctg_id.encode(),
+                           C.c_int32(ctg_index), C.byref(rp), C.byref(nr), C.byref(tp), C.byref(tn)))
+    return _take(rp.value, nr.value, R2P), _take_text(tp, tn)

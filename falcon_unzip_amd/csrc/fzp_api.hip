@@ -1,0 +1,336 @@
+// fzp_api.hip -- batch management and the C-ABI stage entry points (include/fzphase.h).
+#include <algorithm>
+
+#include "fzp_batch.h"
+
+namespace {
+template <class T>
+T *host_copy(const DevBuf<T> &d, size_t off, size_t n, hipStream_t st, int *rc) {
+    T *h = (T *)malloc((n ? n : 1) * sizeof(T));
+    if (!h) { *rc = FZP_ENOMEM; return nullptr; }
+    if (n) {
+        hipError_t e = hipMemcpyAsync(h, d.p + off, n * sizeof(T), hipMemcpyDeviceToHost, st);
+        if (e != hipSuccess) { fzp_set_error("D2H copy: %s", hipGetErrorString(e)); free(h); *rc = FZP_EDEVICE; return nullptr; }
+    }
+    *rc = FZP_OK;
+    return h;
+}
+
+int upload_contig_tables(fzp_ctx *ctx, fzp_batch *b) {
+    hipStream_t st = ctx->stream;
+    FZP_TRY(b->ctg_goff.upload(b->h_goff.data(), b->h_goff.size(), st));
+    FZP_TRY(b->ctg_qoff.upload(b->h_qid_off.data(), b->h_qid_off.size(), st));
+    FZP_TRY(b->ctg_limit.upload(b->h_limit.data(), b->h_limit.size(), st));
+    return FZP_OK;
+}
+}  // namespace
+
+// ================================================================================ batch
+extern "C" int fzp_batch_create(fzp_ctx *ctx, int32_t n_ctg, const fzp_alnset *const *aln, const uint8_t *const *ref_seq, const int64_t *ref_len,
+                                fzp_batch **out) {
+    if (!ctx || !out || n_ctg <= 0 || !aln || !ref_seq || !ref_len) { fzp_set_error("fzp_batch_create: bad arguments"); return FZP_EINVAL; }
+    *out = nullptr;
+    FZP_HIP(hipSetDevice(ctx->device));
+    fzp_batch *b = new fzp_batch();
+    b->n_ctg = n_ctg;
+    b->h_rec_begin.assign(1, 0); b->h_goff.assign(1, 0); b->h_qid_off.assign(1, 0);
+    int64_t n_cig = 0, n_seq = 0;
+    for (int c = 0; c < n_ctg; c++) {
+        const fzp_alnset *a = aln[c];
+        if (!a) { delete b; fzp_set_error("contig %d: null alnset", c); return FZP_EINVAL; }
+        int32_t limit = a->last_pos > 0 ? a->last_pos : 0;
+        if ((int64_t)limit > ref_len[c]) {
+            delete b;
+            fzp_set_error("contig %d: last record starts at %d, beyond the contig end %lld (reference: IndexError on ref_seq[pos])", c, limit + 1, (long long)ref_len[c]);
+            return FZP_EINVAL;
+        }
+        b->h_limit.push_back(limit);
+        b->h_ref_len.push_back(ref_len[c]);
+        b->h_rec_begin.push_back(b->h_rec_begin.back() + a->n_rec);
+        b->h_goff.push_back(b->h_goff.back() + limit);
+        b->h_qid_off.push_back(b->h_qid_off.back() + a->n_qid);
+        n_cig += a->cig_off[a->n_rec];
+        n_seq += a->seq_off[a->n_rec];
+        b->n_columns += a->n_columns;
+    }
+    b->n_rec = b->h_rec_begin.back();
+    b->n_pos = b->h_goff.back();
+    b->n_qid = b->h_qid_off.back();
+    b->n_cig = n_cig; b->n_seq = n_seq;
+    // concatenate on the host, then one upload per array
+    std::vector<int32_t> rec_pos((size_t)b->n_rec), rec_qid((size_t)b->n_rec), rec_ctg((size_t)b->n_rec);
+    std::vector<int64_t> cig_off((size_t)b->n_rec + 1), seq_off((size_t)b->n_rec + 1);
+    std::vector<uint32_t> cigar((size_t)n_cig);
+    std::vector<uint8_t> seq((size_t)n_seq), ref((size_t)b->n_pos);
+    int64_t r0 = 0, c0 = 0, s0 = 0;
+    for (int c = 0; c < n_ctg; c++) {
+        const fzp_alnset *a = aln[c];
+        for (int64_t r = 0; r < a->n_rec; r++) {
+            rec_pos[(size_t)(r0 + r)] = a->rec_pos[r];
+            rec_qid[(size_t)(r0 + r)] = a->rec_qid[r];
+            rec_ctg[(size_t)(r0 + r)] = c;
+            cig_off[(size_t)(r0 + r)] = c0 + a->cig_off[r];
+            seq_off[(size_t)(r0 + r)] = s0 + a->seq_off[r];
+        }
+        if (a->cig_off[a->n_rec]) memcpy(cigar.data() + c0, a->cigar, (size_t)a->cig_off[a->n_rec] * sizeof(uint32_t));
+        if (a->seq_off[a->n_rec]) memcpy(seq.data() + s0, a->seq, (size_t)a->seq_off[a->n_rec]);
+        if (b->h_limit[c]) memcpy(ref.data() + b->h_goff[c], ref_seq[c], (size_t)b->h_limit[c]);
+        r0 += a->n_rec; c0 += a->cig_off[a->n_rec]; s0 += a->seq_off[a->n_rec];
+    }
+    cig_off[(size_t)b->n_rec] = c0;
+    seq_off[(size_t)b->n_rec] = s0;
+    hipStream_t st = ctx->stream;
+    int rc = FZP_OK;
+    if ((rc = b->rec_pos.upload(rec_pos.data(), rec_pos.size(), st)) || (rc = b->rec_qid.upload(rec_qid.data(), rec_qid.size(), st)) ||
+        (rc = b->rec_ctg.upload(rec_ctg.data(), rec_ctg.size(), st)) || (rc = b->cig_off.upload(cig_off.data(), cig_off.size(), st)) ||
+        (rc = b->seq_off.upload(seq_off.data(), seq_off.size(), st)) || (rc = b->cigar.upload(cigar.data(), cigar.size(), st)) ||
+        (rc = b->seq.upload(seq.data(), seq.size(), st)) || (rc = b->ref.upload(ref.data(), ref.size(), st)) || (rc = upload_contig_tables(ctx, b))) {
+        delete b;
+        return rc;
+    }
+    hipError_t e = hipStreamSynchronize(st);   // host vectors go out of scope
+    if (e != hipSuccess) { delete b; fzp_set_error("upload: %s", hipGetErrorString(e)); return FZP_EDEVICE; }
+    b->have_aln = true;
+    *out = b;
+    return FZP_OK;
+}
+
+extern "C" void fzp_batch_destroy(fzp_ctx *ctx, fzp_batch *b) {
+    if (!b) return;
+    if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
+    delete b;
+}
+
+extern "C" int fzp_batch_run(fzp_ctx *ctx, fzp_batch *b, unsigned stages) {
+    if (!ctx || !b) return FZP_EINVAL;
+    FZP_HIP(hipSetDevice(ctx->device));
+    if (stages & FZP_STAGE_HET) {
+        if (!b->have_aln) { fzp_set_error("batch holds no alignment records"); return FZP_EINVAL; }
+        FZP_TRY(fzp_k2_het_call(ctx, b));
+    }
+    if (stages & FZP_STAGE_ASSOC) FZP_TRY(fzp_k3_assoc(ctx, b));
+    if (stages & FZP_STAGE_BLOCKS) FZP_TRY(fzp_k4_blocks(ctx, b));
+    if (stages & FZP_STAGE_READS) FZP_TRY(fzp_k5_reads(ctx, b));
+    return FZP_OK;
+}
+
+extern "C" int fzp_batch_counts(fzp_ctx *ctx, fzp_batch *b, int64_t *n_rec, int64_t *n_columns, int64_t *n_positions, int64_t *n_sites, int64_t *n_rows,
+                                int64_t *n_arows, int64_t *n_pvars, int64_t *n_preads) {
+    (void)ctx;
+    if (!b) return FZP_EINVAL;
+    if (n_rec) *n_rec = b->n_rec;
+    if (n_columns) *n_columns = b->n_columns;
+    if (n_positions) *n_positions = b->n_pos;
+    if (n_sites) *n_sites = b->n_sites;
+    if (n_rows) *n_rows = b->n_rows;
+    if (n_arows) *n_arows = b->n_arows;
+    if (n_pvars) *n_pvars = b->n_pvars;
+    if (n_preads) *n_preads = b->n_preads;
+    return FZP_OK;
+}
+
+extern "C" int fzp_batch_result(fzp_ctx *ctx, fzp_batch *b, int32_t ctg, fzp_result *out) {
+    if (!ctx || !b || !out || ctg < 0 || ctg >= b->n_ctg) return FZP_EINVAL;
+    FZP_HIP(hipSetDevice(ctx->device));
+    memset(out, 0, sizeof *out);
+    hipStream_t st = ctx->stream;
+    int rc = FZP_OK;
+    int64_t sb = 0, row_base = 0;
+    if (b->have_sites) {
+        sb = b->h_site_begin[ctg];
+        int64_t se = b->h_site_begin[ctg + 1];
+        out->n_sites = se - sb;
+        out->sites = host_copy(b->sites, (size_t)sb, (size_t)(se - sb), st, &rc);
+        if (rc) { fzp_result_free(out); return rc; }
+        // row range of this contig: [row_off(first site), row_off(first site of the next contig))
+        int64_t row_end = b->n_rows;
+        fzp_site nxt;
+        if (se < b->n_sites) {
+            FZP_HIP(hipMemcpyAsync(&nxt, b->sites.p + se, sizeof nxt, hipMemcpyDeviceToHost, st));
+        }
+        FZP_HIP(hipStreamSynchronize(st));
+        if (se < b->n_sites) row_end = nxt.row_off;
+        row_base = out->n_sites ? out->sites[0].row_off : row_end;
+        for (int64_t i = 0; i < out->n_sites; i++) out->sites[i].row_off -= row_base;
+        out->n_rows = row_end - row_base;
+        out->vmap_qid = host_copy(b->vmap_qid, (size_t)row_base, (size_t)out->n_rows, st, &rc);
+        if (rc) { fzp_result_free(out); return rc; }
+    }
+    if (b->have_arows) {
+        int64_t ab = b->h_arow_begin[ctg], ae = b->h_arow_begin[ctg + 1];
+        out->n_arows = ae - ab;
+        out->arows = host_copy(b->arows, (size_t)ab, (size_t)(ae - ab), st, &rc);
+        if (rc) { fzp_result_free(out); return rc; }
+        FZP_HIP(hipStreamSynchronize(st));
+        for (int64_t i = 0; i < out->n_arows; i++) { out->arows[i].site1 -= (int32_t)sb; out->arows[i].site2 -= (int32_t)sb; }
+    }
+    if (b->have_blocks) {
+        int64_t pb = b->h_pvar_begin[ctg], pe = b->h_pvar_begin[ctg + 1];
+        out->n_pvars = pe - pb;
+        out->pvars = host_copy(b->pvars, (size_t)pb, (size_t)(pe - pb), st, &rc);
+        if (rc) { fzp_result_free(out); return rc; }
+        FZP_HIP(hipStreamSynchronize(st));
+        for (int64_t i = 0; i < out->n_pvars; i++) out->pvars[i].site -= (int32_t)sb;
+    }
+    if (b->have_preads) {
+        int64_t rb = b->h_pread_begin[ctg], re = b->h_pread_begin[ctg + 1];
+        out->n_preads = re - rb;
+        out->preads = host_copy(b->preads, (size_t)rb, (size_t)(re - rb), st, &rc);
+        if (rc) { fzp_result_free(out); return rc; }
+    }
+    FZP_HIP(hipStreamSynchronize(st));
+    return FZP_OK;
+}
+
+// ================================================================================ stage injection
+namespace {
+// a 1-contig batch that starts from het-call output instead of alignment records
+int batch_from_sites(fzp_ctx *ctx, const fzp_site *sites, int64_t n_sites, const int32_t *vmap_qid, int64_t n_rows, int32_t n_qid, fzp_batch **out) {
+    if (n_sites < 0 || n_rows < 0 || (n_sites && !sites) || (n_rows && !vmap_qid)) { fzp_set_error("bad site/variant_map arguments"); return FZP_EINVAL; }
+    int64_t rows = 0;
+    int32_t max_q = -1;
+    for (int64_t i = 0; i < n_sites; i++) {
+        if (i && sites[i].pos <= sites[i - 1].pos) { fzp_set_error("sites must be in ascending position order (site %lld)", (long long)i); return FZP_EINVAL; }
+        if (sites[i].row_off != rows || sites[i].count[0] < 0 || sites[i].count[1] < 0) { fzp_set_error("site %lld: variant_map rows are not contiguous", (long long)i); return FZP_EINVAL; }
+        rows += (int64_t)sites[i].count[0] + sites[i].count[1];
+    }
+    if (rows != n_rows) { fzp_set_error("variant_map has %lld rows, sites account for %lld", (long long)n_rows, (long long)rows); return FZP_EINVAL; }
+    for (int64_t i = 0; i < n_rows; i++) {
+        if (vmap_qid[i] < 0) { fzp_set_error("negative q_id in variant_map"); return FZP_EINVAL; }
+        max_q = std::max(max_q, vmap_qid[i]);
+    }
+    if (n_qid < max_q + 1) n_qid = max_q + 1;
+    fzp_batch *b = new fzp_batch();
+    b->n_ctg = 1;
+    int64_t span = n_sites ? (int64_t)sites[n_sites - 1].pos + 1 : 0;
+    b->h_goff = {0, span};
+    b->h_qid_off = {0, n_qid};
+    b->h_limit = {(int32_t)span};
+    b->h_rec_begin = {0, 0};
+    b->h_site_begin = {0, n_sites};
+    b->n_pos = span; b->n_qid = n_qid; b->n_sites = n_sites; b->n_rows = n_rows;
+    hipStream_t st = ctx->stream;
+    std::vector<int64_t> site_g((size_t)n_sites);
+    std::vector<int32_t> site_ctg((size_t)n_sites, 0);
+    for (int64_t i = 0; i < n_sites; i++) site_g[(size_t)i] = sites[i].pos;
+    int rc;
+    if ((rc = upload_contig_tables(ctx, b)) || (rc = b->sites.upload(sites, (size_t)n_sites, st)) || (rc = b->site_g.upload(site_g.data(), (size_t)n_sites, st)) ||
+        (rc = b->site_ctg.upload(site_ctg.data(), (size_t)n_sites, st)) || (rc = b->site_begin.upload(b->h_site_begin.data(), 2, st)) ||
+        (rc = b->vmap_qid.upload(vmap_qid, (size_t)n_rows, st))) {
+        delete b;
+        return rc;
+    }
+    hipError_t e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { delete b; fzp_set_error("upload: %s", hipGetErrorString(e)); return FZP_EDEVICE; }
+    b->have_sites = true;
+    *out = b;
+    return FZP_OK;
+}
+
+int batch_add_arows(fzp_ctx *ctx, fzp_batch *b, const fzp_arow *arows, int64_t n_arows) {
+    if (n_arows < 0 || (n_arows && !arows)) return FZP_EINVAL;
+    for (int64_t i = 0; i < n_arows; i++) {
+        const fzp_arow &r = arows[i];
+        if (r.site1 < 0 || r.site2 <= r.site1 || r.site2 >= b->n_sites) { fzp_set_error("atable row %lld: site indices out of order/range", (long long)i); return FZP_EINVAL; }
+        if (i && (r.site1 < arows[i - 1].site1 || (r.site1 == arows[i - 1].site1 && r.site2 <= arows[i - 1].site2))) {
+            fzp_set_error("atable row %lld: rows must ascend by (site1, site2)", (long long)i);
+            return FZP_EINVAL;
+        }
+    }
+    hipStream_t st = ctx->stream;
+    FZP_TRY(b->arows.upload(arows, (size_t)n_arows, st));
+    b->n_arows = n_arows;
+    b->h_arow_begin = {0, n_arows};
+    FZP_TRY(b->arow_begin.upload(b->h_arow_begin.data(), 2, st));
+    FZP_HIP(hipStreamSynchronize(st));
+    b->have_arows = true;
+    return FZP_OK;
+}
+}  // namespace
+
+extern "C" int fzp_het_call(fzp_ctx *ctx, const fzp_alnset *aln, const uint8_t *ref_seq, int64_t ref_len, fzp_site **sites, int64_t *n_sites,
+                            int32_t **vmap_qid, int64_t *n_rows) {
+    if (!ctx || !aln || !sites || !n_sites || !vmap_qid || !n_rows) return FZP_EINVAL;
+    fzp_batch *b = nullptr;
+    FZP_TRY(fzp_batch_create(ctx, 1, &aln, &ref_seq, &ref_len, &b));
+    int rc = fzp_batch_run(ctx, b, FZP_STAGE_HET);
+    fzp_result r;
+    if (rc == FZP_OK) rc = fzp_batch_result(ctx, b, 0, &r);
+    fzp_batch_destroy(ctx, b);
+    if (rc) return rc;
+    *sites = r.sites; *n_sites = r.n_sites; *vmap_qid = r.vmap_qid; *n_rows = r.n_rows;
+    return FZP_OK;
+}
+
+extern "C" int fzp_assoc_table(fzp_ctx *ctx, const fzp_site *sites, int64_t n_sites, const int32_t *vmap_qid, int64_t n_rows, fzp_arow **arows,
+                               int64_t *n_arows) {
+    if (!ctx || !arows || !n_arows) return FZP_EINVAL;
+    FZP_HIP(hipSetDevice(ctx->device));
+    fzp_batch *b = nullptr;
+    FZP_TRY(batch_from_sites(ctx, sites, n_sites, vmap_qid, n_rows, 0, &b));
+    int rc = fzp_batch_run(ctx, b, FZP_STAGE_ASSOC);
+    fzp_result r;
+    if (rc == FZP_OK) rc = fzp_batch_result(ctx, b, 0, &r);
+    fzp_batch_destroy(ctx, b);
+    if (rc) return rc;
+    *arows = r.arows; *n_arows = r.n_arows;
+    r.arows = nullptr;
+    fzp_result_free(&r);
+    return FZP_OK;
+}
+
+extern "C" int fzp_phase_blocks(fzp_ctx *ctx, const fzp_site *sites, int64_t n_sites, const fzp_arow *arows, int64_t n_arows, fzp_pvar **pvars,
+                                int64_t *n_pvars) {
+    if (!ctx || !pvars || !n_pvars) return FZP_EINVAL;
+    FZP_HIP(hipSetDevice(ctx->device));
+    // the variant_map rows are not needed here (the reference only reads ref_base from it, phasing.py:230-238)
+    std::vector<fzp_site> s2(sites, sites + n_sites);
+    for (auto &s : s2) { s.row_off = 0; s.count[0] = 0; s.count[1] = 0; }
+    fzp_batch *b = nullptr;
+    FZP_TRY(batch_from_sites(ctx, s2.data(), n_sites, nullptr, 0, 0, &b));
+    int rc = batch_add_arows(ctx, b, arows, n_arows);
+    if (rc == FZP_OK) rc = fzp_batch_run(ctx, b, FZP_STAGE_BLOCKS);
+    fzp_result r;
+    if (rc == FZP_OK) rc = fzp_batch_result(ctx, b, 0, &r);
+    fzp_batch_destroy(ctx, b);
+    if (rc) return rc;
+    *pvars = r.pvars; *n_pvars = r.n_pvars;
+    r.pvars = nullptr;
+    fzp_result_free(&r);
+    return FZP_OK;
+}
+
+extern "C" int fzp_phase_reads(fzp_ctx *ctx, const fzp_site *sites, int64_t n_sites, const int32_t *vmap_qid, int64_t n_rows, const fzp_pvar *pvars,
+                               int64_t n_pvars, int32_t n_qid, fzp_pread **preads, int64_t *n_preads) {
+    if (!ctx || !preads || !n_preads || n_pvars < 0 || (n_pvars && !pvars)) return FZP_EINVAL;
+    FZP_HIP(hipSetDevice(ctx->device));
+    fzp_batch *b = nullptr;
+    FZP_TRY(batch_from_sites(ctx, sites, n_sites, vmap_qid, n_rows, n_qid, &b));
+    // variant_to_phase (phasing.py:454-463): block and phase-0 allele per site
+    std::vector<int32_t> blk((size_t)n_sites, 0);
+    std::vector<uint8_t> b1((size_t)n_sites, 0);
+    int rc = FZP_OK;
+    for (int64_t i = 0; i < n_pvars && rc == FZP_OK; i++) {
+        if (pvars[i].site < 0 || pvars[i].site >= n_sites || pvars[i].block <= 0) { fzp_set_error("phased variant %lld: bad site/block", (long long)i); rc = FZP_EINVAL; break; }
+        blk[(size_t)pvars[i].site] = pvars[i].block;
+        b1[(size_t)pvars[i].site] = pvars[i].b1;
+    }
+    hipStream_t st = ctx->stream;
+    if (rc == FZP_OK) rc = b->site_blk.upload(blk.data(), (size_t)n_sites, st);
+    if (rc == FZP_OK) rc = b->site_b1.upload(b1.data(), (size_t)n_sites, st);
+    if (rc == FZP_OK && hipStreamSynchronize(st) != hipSuccess) rc = FZP_EDEVICE;
+    if (rc == FZP_OK) { b->have_blocks = true; b->h_pvar_begin = {0, 0}; b->n_pvars = 0; b->have_blocks = true; }
+    if (rc == FZP_OK) rc = fzp_k5_reads(ctx, b);
+    fzp_result r;
+    memset(&r, 0, sizeof r);
+    if (rc == FZP_OK) {
+        b->have_blocks = false;   // nothing to download for that stage
+        rc = fzp_batch_result(ctx, b, 0, &r);
+    }
+    fzp_batch_destroy(ctx, b);
+    if (rc) return rc;
+    *preads = r.preads; *n_preads = r.n_preads;
+    r.preads = nullptr;
+    fzp_result_free(&r);
+    return FZP_OK;
+}

@@ -1,0 +1,80 @@
+// fzp_batch.h -- device-resident state of a batch of contigs going through K2..K5.
+//
+// HBM layout (all struct-of-arrays, contigs concatenated):
+//   records      rec_pos/rec_qid/rec_ctg [n_rec], cig_off/seq_off [n_rec+1], cigar (u32 len<<4|op), seq (u8)
+//   positions    one global index g = ctg_goff[c] + p for every EVALUATED contig position p < limit[c]
+//                (limit = POS of the last accepted record: later positions are never evaluated,
+//                phasing.py:98-102).  cnt[4g..4g+3] = A,C,G,T column counts, oth[g] = non-ACGT symbol
+//                tracker, flag8[g] = het call, site_idx[g] / row_off[g] = exclusive scans.
+//   sites        fzp_site[n_sites] ascending g; site_g[s]; site_begin[c]
+//   variant_map  vmap_qid[n_rows] grouped per site (major allele rows, then minor), record order
+//   sets         setq[n_rows]: per site the two alleles' DISTINCT q_ids, ascending, in A<C<T<G allele
+//                order: allele x=0 at row_off, x=1 at row_off + count[allele of x=0]; set_n[2s+x]
+//   atable       fzp_arow[n_arows] (global site indices on the device), arow_begin[c]
+//   blocks       fzp_pvar[n_pvars], pvar_begin[c]; site_blk[s], site_b1[s]
+//   reads        fzp_pread[n_preads], pread_begin[c]; q indices are global: qid_off[c] + q_id
+#pragma once
+#include "fzp_common.h"
+
+struct fzp_batch {
+    int32_t n_ctg = 0;
+    // host mirrors
+    std::vector<int64_t> h_rec_begin, h_goff, h_qid_off, h_ref_len;
+    std::vector<int32_t> h_limit;
+    std::vector<int64_t> h_site_begin, h_arow_begin, h_pvar_begin, h_pread_begin;
+    int64_t n_rec = 0, n_cig = 0, n_seq = 0, n_pos = 0, n_columns = 0, n_qid = 0;
+    int64_t n_sites = 0, n_rows = 0, n_arows = 0, n_pvars = 0, n_preads = 0;
+    bool have_aln = false, have_sites = false, have_sets = false, have_arows = false, have_blocks = false,
+         have_preads = false;
+    // inputs
+    DevBuf<int32_t> rec_pos, rec_qid, rec_ctg;
+    DevBuf<int64_t> cig_off, seq_off;
+    DevBuf<uint32_t> cigar;
+    DevBuf<uint8_t> seq, ref;
+    DevBuf<int64_t> ctg_goff, ctg_qoff;
+    DevBuf<int32_t> ctg_limit;
+    // K2
+    DevBuf<uint32_t> cnt, oth, site_idx, row_off32;
+    DevBuf<uint8_t> flag8;
+    DevBuf<fzp_site> sites;
+    DevBuf<int64_t> site_g;
+    DevBuf<int32_t> site_ctg;
+    DevBuf<int64_t> site_begin;
+    DevBuf<uint64_t> vtmp;
+    DevBuf<uint32_t> vfill;
+    DevBuf<int32_t> vmap_qid;
+    // K3
+    DevBuf<int32_t> setq;
+    DevBuf<uint32_t> set_n;
+    DevBuf<uint32_t> cand_n, cap_off, nkept, kept_off;
+    DevBuf<fzp_arow> arows_tmp, arows;
+    DevBuf<int64_t> arow_begin;
+    // K4
+    DevBuf<uint32_t> lk_flag, lk_idx;
+    DevBuf<int32_t> lk_i1, lk_i2, lk_cis, lk_trans;
+    DevBuf<uint32_t> left_n, left_off, left_fill, right_n, right_off, fr2;
+    DevBuf<int32_t> left_lk;
+    DevBuf<uint32_t> pj;              // pointer-jumping words: parent<<1 | flip
+    DevBuf<uint8_t> orient;
+    DevBuf<int32_t> lext, rext, lscore, rscore, rawblk, blkcnt, blknew;
+    DevBuf<fzp_pvar> pvars_tmp, pvars;
+    DevBuf<uint32_t> pv_n, pv_off;
+    DevBuf<int64_t> pvar_begin;
+    DevBuf<int32_t> site_blk;
+    DevBuf<uint8_t> site_b1;
+    // K5
+    DevBuf<int32_t> bmin, bmax;
+    DevBuf<uint32_t> rng_n, rng_off, c0, c1, pr_flag, pr_idx;
+    DevBuf<fzp_pread> preads;
+    DevBuf<int64_t> pread_begin;
+    // scratch
+    DevBuf<uint64_t> totals;          // a few device u64 scalars
+    DevBuf<int32_t> errflag;
+};
+
+// stage drivers (fzp_phase.hip)
+int fzp_k2_het_call(fzp_ctx *ctx, fzp_batch *b);
+int fzp_k3_sets(fzp_ctx *ctx, fzp_batch *b);
+int fzp_k3_assoc(fzp_ctx *ctx, fzp_batch *b);
+int fzp_k4_blocks(fzp_ctx *ctx, fzp_batch *b);
+int fzp_k5_reads(fzp_ctx *ctx, fzp_batch *b);

@@ -1,0 +1,516 @@
+// fzp_blocks.hip -- K4: phase-block assignment (get_score + get_phased_blocks, phasing.py:208-421)
+//                   K5: read phasing vote (get_phased_reads, phasing.py:423-480)
+//
+// K4 restated for the GPU (derivations in DESIGN.md section 5):
+//  * a site's state is one orientation bit o[s] relative to the atable's A<C<T<G allele order;
+//    get_score(link, s1, s2) == cis if o[s1]==o[s2] else trans.
+//  * the streaming greedy initialisation (phasing.py:259-309) decides every site from exactly ONE
+//    link -- the link of its first appearance -- so it is a forest: o[s] = o[parent] ^ (cis<trans),
+//    roots 0.  Resolved by pointer jumping (order-free, deterministic).
+//  * the <=10 Gauss-Seidel sweeps (phasing.py:315-344) are order-dependent: sequential over the
+//    sites of a contig, wave-parallel over a site's left links, contigs in parallel.
+//  * extents are per-site reductions; block segmentation (phasing.py:388-408) is a prefix-max scan
+//    because max_right_ext is never reset.
+// All integer; outputs are bit-exact by construction, no atomics decide any order.
+#include "fzp_batch.h"
+
+namespace {
+
+inline unsigned grid_for(int64_t items, int per_block, int64_t cap = 1 << 20) {
+    int64_t g = (items + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (unsigned)g;
+}
+
+constexpr uint32_t NOLINK = 0xffffffffu;
+
+// ---- links: atable rows with |cis - trans| >= 6 (phasing.py:245)
+__global__ void __launch_bounds__(256) k_link_flag(const fzp_arow *__restrict__ rows, int64_t n, uint32_t *__restrict__ flag) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int cis = rows[i].n[0] + rows[i].n[3], trans = rows[i].n[1] + rows[i].n[2];
+    int d = cis - trans;
+    flag[i] = (d >= 6 || d <= -6) ? 1u : 0u;
+}
+
+__global__ void __launch_bounds__(256) k_link_emit(const fzp_arow *__restrict__ rows, int64_t n, const uint32_t *__restrict__ idx, int64_t n_links,
+                                                   int32_t *__restrict__ lk_i1, int32_t *__restrict__ lk_i2, int32_t *__restrict__ lk_cis, int32_t *__restrict__ lk_trans,
+                                                   uint32_t *__restrict__ left_n, uint32_t *__restrict__ right_n, uint32_t *__restrict__ fr2) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    uint32_t l = idx[i];
+    uint32_t nxt = (i + 1 < n) ? idx[i + 1] : (uint32_t)n_links;
+    if (nxt == l) return;   // not kept
+    fzp_arow r = rows[i];
+    lk_i1[l] = r.site1; lk_i2[l] = r.site2;
+    lk_cis[l] = r.n[0] + r.n[3]; lk_trans[l] = r.n[1] + r.n[2];
+    atomicAdd(&left_n[r.site2], 1u);
+    atomicAdd(&right_n[r.site1], 1u);
+    atomicMin(&fr2[r.site2], l);
+}
+
+__global__ void __launch_bounds__(256) k_left_fill(int64_t n_links, const int32_t *__restrict__ lk_i2, const uint32_t *__restrict__ left_off,
+                                                   uint32_t *__restrict__ left_fill, int32_t *__restrict__ left_lk) {
+    int64_t l = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (l >= n_links) return;
+    int32_t s = lk_i2[l];
+    uint32_t slot = atomicAdd(&left_fill[s], 1u);
+    left_lk[left_off[s] + slot] = (int32_t)l;
+}
+
+// ---- greedy initialisation as a forest (phasing.py:259-309)
+__global__ void __launch_bounds__(256) k_pj_init(int64_t n_sites, const uint32_t *__restrict__ right_n, const uint32_t *__restrict__ right_off,
+                                                 const uint32_t *__restrict__ fr2, const int32_t *__restrict__ lk_i1, const int32_t *__restrict__ lk_i2,
+                                                 const int32_t *__restrict__ lk_cis, const int32_t *__restrict__ lk_trans, uint32_t *__restrict__ pj) {
+    int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= n_sites) return;
+    uint32_t f1 = right_n[s] ? right_off[s] : NOLINK;   // first link with this site as pos1
+    uint32_t f2 = fr2[s];                                // first link with this site as pos2
+    uint32_t parent = (uint32_t)s, flip = 0;
+    if (f2 < f1) {                       // first seen as pos2: its only neighbour so far is that link's pos1
+        parent = (uint32_t)lk_i1[f2];
+        flip = lk_cis[f2] < lk_trans[f2] ? 1u : 0u;
+    } else if (f1 != NOLINK) {           // first seen as pos1: the partner counts only if it already has a state
+        uint32_t i2 = (uint32_t)lk_i2[f1];
+        if (fr2[i2] < f1) {
+            parent = i2;
+            flip = lk_cis[f1] < lk_trans[f1] ? 1u : 0u;
+        }
+    }
+    pj[s] = (parent << 1) | flip;
+}
+
+__global__ void __launch_bounds__(256) k_pj_resolve(int64_t n_sites, uint32_t *__restrict__ pj, uint8_t *__restrict__ orient) {
+    int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= n_sites) return;
+    // invariant at all times: o[s] = o[parent(s)] ^ flip(s); every stored parent is an ancestor
+    uint32_t w = __hip_atomic_load(&pj[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t a = w >> 1, f = w & 1u;
+    for (;;) {
+        if (a == (uint32_t)s) break;
+        uint32_t wa = __hip_atomic_load(&pj[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t pa = wa >> 1;
+        if (pa == a) break;              // a is a root (o = 0)
+        f ^= (wa & 1u);
+        a = pa;
+        __hip_atomic_store(&pj[s], (a << 1) | f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    orient[s] = (uint8_t)f;
+}
+
+// ---- refinement sweeps (phasing.py:315-344): one wave per contig
+template <bool USE_LDS>
+__global__ void __launch_bounds__(64) k_sweep(const int64_t *__restrict__ site_begin, const uint32_t *__restrict__ left_n, const uint32_t *__restrict__ left_off,
+                                              const int32_t *__restrict__ left_lk, const int32_t *__restrict__ lk_i1, const int32_t *__restrict__ lk_cis,
+                                              const int32_t *__restrict__ lk_trans, uint8_t *__restrict__ orient) {
+    extern __shared__ uint8_t o_lds[];
+    const int lane = lane_id();
+    const int c = blockIdx.x;
+    const int64_t sb = site_begin[c], se = site_begin[c + 1];
+    const int64_t n = se - sb;
+    if (n <= 0) return;
+    uint8_t *o = USE_LDS ? o_lds : (orient + sb);
+    if (USE_LDS) {
+        for (int64_t i = lane; i < n; i += 64) o_lds[i] = orient[sb + i];
+        __syncthreads();
+    }
+    for (int iter = 1; iter <= 10; iter++) {
+        int updates = 0;
+        for (int64_t p = 0; p < n; p++) {
+            const uint32_t nl = left_n[sb + p];
+            if (nl == 0) continue;
+            const uint32_t lo = left_off[sb + p];
+            const uint8_t op = o[p];
+            int s1 = 0, s2 = 0;
+            for (uint32_t k = lane; k < nl; k += 64) {
+                int32_t l = left_lk[lo + k];
+                int64_t pp = lk_i1[l] - sb;
+                bool same = o[pp] == op;
+                int cis = lk_cis[l], trans = lk_trans[l];
+                s1 += same ? cis : trans;
+                s2 += same ? trans : cis;
+            }
+            s1 = wave_sum_i32(s1);
+            s2 = wave_sum_i32(s2);
+            if (s1 < s2) {               // score1 >= score2 keeps the state (phasing.py:338-342)
+                if (lane == 0) o[p] = op ^ 1;
+                updates++;
+                if (!USE_LDS) __threadfence_block();
+            }
+            if (USE_LDS) __syncthreads();
+        }
+        if (updates == 0) break;
+    }
+    if (USE_LDS) {
+        __syncthreads();
+        for (int64_t i = lane; i < n; i += 64) orient[sb + i] = o_lds[i];
+    }
+}
+
+// ---- per-site scores and extents (phasing.py:353-383): one wave per site
+__global__ void __launch_bounds__(256) k_extents(int64_t n_sites, const fzp_site *__restrict__ sites, const uint32_t *__restrict__ left_n, const uint32_t *__restrict__ left_off,
+                                                 const int32_t *__restrict__ left_lk, const uint32_t *__restrict__ right_n, const uint32_t *__restrict__ right_off,
+                                                 const int32_t *__restrict__ lk_i1, const int32_t *__restrict__ lk_i2, const int32_t *__restrict__ lk_cis,
+                                                 const int32_t *__restrict__ lk_trans, const uint8_t *__restrict__ orient, int32_t *__restrict__ lext,
+                                                 int32_t *__restrict__ rext, int32_t *__restrict__ lscore, int32_t *__restrict__ rscore) {
+    const int lane = lane_id();
+    int64_t p = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    if (p >= n_sites) return;
+    const uint8_t op = orient[p];
+    int sc = 0;
+    int32_t ext = (int32_t)p;
+    for (uint32_t k = lane; k < left_n[p]; k += 64) {
+        int32_t l = left_lk[left_off[p] + k];
+        int32_t pp = lk_i1[l];
+        bool same = orient[pp] == op;
+        int d = same ? lk_cis[l] - lk_trans[l] : lk_trans[l] - lk_cis[l];   // s - s_
+        sc += d;
+        if (d > 0 && pp < ext) ext = pp;
+    }
+    sc = wave_sum_i32(sc);
+    ext = wave_min_i32(ext);
+    if (lane == 0) { lscore[p] = sc; lext[p] = sites[ext].pos + 1; }
+    sc = 0;
+    ext = (int32_t)p;
+    for (uint32_t k = lane; k < right_n[p]; k += 64) {
+        int32_t l = (int32_t)(right_off[p] + k);
+        int32_t pp = lk_i2[l];
+        bool same = orient[pp] == op;
+        int d = same ? lk_cis[l] - lk_trans[l] : lk_trans[l] - lk_cis[l];
+        sc += d;
+        if (d > 0 && pp > ext) ext = pp;
+    }
+    sc = wave_sum_i32(sc);
+    ext = wave_max_i32(ext);
+    if (lane == 0) { rscore[p] = sc; rext[p] = sites[ext].pos + 1; }
+}
+
+// ---- block segmentation (phasing.py:388-408) and 'V' records: one wave per contig
+__global__ void __launch_bounds__(64) k_segment(const int64_t *__restrict__ site_begin, const fzp_site *__restrict__ sites, const uint8_t *__restrict__ orient,
+                                                const int32_t *__restrict__ lext, const int32_t *__restrict__ rext, const int32_t *__restrict__ lscore,
+                                                const int32_t *__restrict__ rscore, int32_t *__restrict__ rawblk, int32_t *__restrict__ blkcnt,
+                                                int32_t *__restrict__ blknew, fzp_pvar *__restrict__ pv_tmp, uint32_t *__restrict__ pv_n,
+                                                int32_t *__restrict__ site_blk, uint8_t *__restrict__ site_b1) {
+    const int lane = lane_id();
+    const int c = blockIdx.x;
+    const int64_t sb = site_begin[c], se = site_begin[c + 1];
+    const int64_t n = se - sb;
+    if (n <= 0) { if (lane == 0) pv_n[c] = 0; return; }
+    // pass A: raw block ids.  max_right_ext is a running max over qualifying sites, never reset.
+    int32_t carryM = 0, carryB = 0;
+    for (int64_t base = 0; base < n; base += 64) {
+        int64_t s = sb + base + lane;
+        bool in = base + lane < n;
+        bool q = in && !(rscore[s] < 10 || lscore[s] < 10);
+        int32_t r = q ? rext[s] : 0;
+        int32_t incl = r;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            int32_t t = __shfl_up(incl, d, 64);
+            if (lane >= d) incl = max(incl, t);
+        }
+        int32_t excl = __shfl_up(incl, 1, 64);
+        if (lane == 0) excl = 0;
+        excl = max(excl, carryM);
+        bool nb = q && (excl < lext[s]);
+        uint64_t m = __ballot(nb);
+        int32_t id = carryB + __popcll(m & ((2ull << lane) - 1ull));   // inclusive count
+        if (in) rawblk[s] = q ? id : 0;
+        if (q) atomicAdd(&blkcnt[sb + id - 1], 1);
+        carryM = max(carryM, __shfl(incl, 63, 64));
+        carryB += __popcll(m);
+    }
+    __threadfence_block();
+    __syncthreads();
+    // pass B: blocks with more than 3 variants get dense ids from 1 (phasing.py:398-408)
+    int32_t carryI = 0;
+    for (int32_t base = 0; base < carryB; base += 64) {
+        int32_t j = base + lane;
+        bool keep = j < carryB && blkcnt[sb + j] > 3;
+        uint64_t m = __ballot(keep);
+        if (j < carryB) blknew[sb + j] = keep ? carryI + 1 + __popcll(m & ((1ull << lane) - 1ull)) : 0;
+        carryI += __popcll(m);
+    }
+    __threadfence_block();
+    __syncthreads();
+    // pass C: 'V' records in site order
+    uint32_t out = 0;
+    for (int64_t base = 0; base < n; base += 64) {
+        int64_t s = sb + base + lane;
+        bool in = base + lane < n;
+        int32_t rb = in ? rawblk[s] : 0;
+        int32_t nid = rb > 0 ? blknew[sb + rb - 1] : 0;
+        bool has = nid > 0;
+        uint64_t m = __ballot(has);
+        uint8_t b1 = 0, b2 = 0;
+        if (in) {
+            const fzp_site &st = sites[s];
+            uint8_t x = st.base[0], y = st.base[1];
+            if (py2_rank(y) < py2_rank(x)) { uint8_t t = x; x = y; y = t; }   // atable allele order
+            if (orient[s]) { b1 = y; b2 = x; } else { b1 = x; b2 = y; }
+            site_blk[s] = nid;
+            site_b1[s] = b1;
+        }
+        if (has) {
+            fzp_pvar v;
+            v.block = nid; v.site = (int32_t)s; v.b1 = b1; v.b2 = b2; v.pad_[0] = v.pad_[1] = 0;
+            v.lext = lext[s]; v.rext = rext[s]; v.lscore = lscore[s]; v.rscore = rscore[s];
+            pv_tmp[sb + out + __popcll(m & ((1ull << lane) - 1ull))] = v;
+        }
+        out += __popcll(m);
+    }
+    if (lane == 0) pv_n[c] = out;
+}
+
+__global__ void __launch_bounds__(256) k_pv_compact(const int64_t *__restrict__ site_begin, const uint32_t *__restrict__ pv_n, const uint32_t *__restrict__ pv_off,
+                                                    const fzp_pvar *__restrict__ tmp, fzp_pvar *__restrict__ out) {
+    const int c = blockIdx.x;
+    const fzp_pvar *src = tmp + site_begin[c];
+    fzp_pvar *dst = out + pv_off[c];
+    for (uint32_t k = threadIdx.x; k < pv_n[c]; k += 256) dst[k] = src[k];
+}
+
+__global__ void k_u32_to_i64_begin(const uint32_t *__restrict__ off, int n, int64_t total, int64_t *__restrict__ begin) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > n) return;
+    begin[c] = c < n ? (int64_t)off[c] : total;
+}
+
+// ================================================================================ K5
+__device__ __forceinline__ int find_ctg_q(const int64_t *qoff, int n_ctg, int64_t Q) {
+    int lo = 0, hi = n_ctg;
+    while (hi - lo > 1) {
+        int m = (lo + hi) >> 1;
+        if (qoff[m] <= Q) lo = m; else hi = m;
+    }
+    return lo;
+}
+
+// Every DISTINCT (read, site, allele) of a phased site votes (set semantics, phasing.py:448-449,469-473).
+// MODE 0: per-read block range; MODE 1: per (read, block) phase counts.
+template <int MODE>
+__global__ void __launch_bounds__(256) k_read_votes(int64_t n_sites, const fzp_site *__restrict__ sites, const int32_t *__restrict__ site_ctg, const int64_t *__restrict__ ctg_qoff,
+                                                    const int32_t *__restrict__ setq, const uint32_t *__restrict__ set_n, const uint32_t *__restrict__ set_off,
+                                                    const int32_t *__restrict__ site_blk, const uint8_t *__restrict__ site_b1, int32_t *__restrict__ bmin,
+                                                    int32_t *__restrict__ bmax, const uint32_t *__restrict__ rng_off, uint32_t *__restrict__ c0, uint32_t *__restrict__ c1) {
+    const int lane = lane_id();
+    int64_t w = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    if (w >= n_sites * 2) return;
+    const int64_t s = w >> 1;
+    const int32_t blk = site_blk[s];
+    if (blk <= 0) return;
+    const fzp_site &st = sites[s];
+    uint8_t x = st.base[0], y = st.base[1];
+    if (py2_rank(y) < py2_rank(x)) { uint8_t t = x; x = y; y = t; }
+    const uint8_t allele = (w & 1) ? y : x;
+    const int phase = allele == site_b1[s] ? 0 : 1;
+    const int64_t qbase = ctg_qoff[site_ctg[s]];
+    const int32_t *q = setq + set_off[w];
+    for (uint32_t k = lane; k < set_n[w]; k += 64) {
+        int64_t Q = qbase + q[k];
+        if (MODE == 0) {
+            atomicMin(&bmin[Q], blk);
+            atomicMax(&bmax[Q], blk);
+        } else {
+            uint32_t slot = rng_off[Q] + (uint32_t)(blk - bmin[Q]);
+            atomicAdd(phase == 0 ? &c0[slot] : &c1[slot], 1u);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_range_n(int64_t nq, const int32_t *__restrict__ bmin, const int32_t *__restrict__ bmax, uint32_t *__restrict__ rng_n) {
+    int64_t Q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (Q >= nq) return;
+    rng_n[Q] = bmax[Q] > 0 ? (uint32_t)(bmax[Q] - bmin[Q] + 1) : 0u;
+}
+
+__global__ void __launch_bounds__(256) k_read_flag(int64_t n_slots, const uint32_t *__restrict__ c0, const uint32_t *__restrict__ c1, uint32_t *__restrict__ flag) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_slots) return;
+    int d = (int)c0[i] - (int)c1[i];
+    flag[i] = (d > 1 || d < -1) ? 1u : 0u;   // phasing.py:477-480
+}
+
+__global__ void __launch_bounds__(256) k_read_emit(int64_t n_slots, int64_t nq, int64_t n_out, const uint32_t *__restrict__ idx, const uint32_t *__restrict__ rng_off,
+                                                   const int32_t *__restrict__ bmin, const uint32_t *__restrict__ c0, const uint32_t *__restrict__ c1,
+                                                   const int64_t *__restrict__ ctg_qoff, int n_ctg, fzp_pread *__restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_slots) return;
+    uint32_t o = idx[i];
+    uint32_t nxt = (i + 1 < n_slots) ? idx[i + 1] : (uint32_t)n_out;
+    if (nxt == o) return;
+    int64_t lo = 0, hi = nq;   // first Q with rng_off[Q] > i ; the owner is that - 1
+    while (lo < hi) {
+        int64_t m = (lo + hi) >> 1;
+        if (rng_off[m] <= (uint32_t)i) lo = m + 1; else hi = m;
+    }
+    int64_t Q = lo - 1;
+    int c = find_ctg_q(ctg_qoff, n_ctg, Q);
+    fzp_pread r;
+    r.q_id = (int32_t)(Q - ctg_qoff[c]);
+    r.block = bmin[Q] + (int32_t)((uint32_t)i - rng_off[Q]);
+    r.n0 = (int32_t)c0[i]; r.n1 = (int32_t)c1[i];
+    r.phase = r.n0 > r.n1 ? 0 : 1;
+    out[o] = r;
+}
+
+__global__ void k_pread_begin(const int64_t *__restrict__ ctg_qoff, int n_ctg, int64_t nq, int64_t n_slots, int64_t n_out, const uint32_t *__restrict__ rng_off,
+                              const uint32_t *__restrict__ idx, int64_t *__restrict__ begin) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > n_ctg) return;
+    int64_t Q0 = ctg_qoff[c];
+    int64_t v = n_out;
+    if (Q0 < nq) {
+        uint32_t slot = rng_off[Q0];
+        if ((int64_t)slot < n_slots) v = idx[slot];
+    }
+    begin[c] = v;
+}
+
+__global__ void __launch_bounds__(256) k_fill_i32(int32_t *p, int64_t n, int32_t v) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+}  // namespace
+
+// ================================================================================ K4 driver
+int fzp_k4_blocks(fzp_ctx *ctx, fzp_batch *b) {
+    hipStream_t st = ctx->stream;
+    if (!b->have_sites || !b->have_arows) { fzp_set_error("phase blocks need sites and an association table"); return FZP_EINVAL; }
+    const int64_t ns = b->n_sites, na = b->n_arows;
+    FZP_TRY(b->totals.alloc(8));
+    FZP_TRY(b->lk_flag.alloc((size_t)na));
+    FZP_TRY(b->left_n.alloc((size_t)ns)); FZP_TRY(b->left_off.alloc((size_t)ns)); FZP_TRY(b->left_fill.alloc((size_t)ns));
+    FZP_TRY(b->right_n.alloc((size_t)ns)); FZP_TRY(b->right_off.alloc((size_t)ns)); FZP_TRY(b->fr2.alloc((size_t)ns));
+    FZP_TRY(b->pj.alloc((size_t)ns)); FZP_TRY(b->orient.alloc((size_t)ns));
+    FZP_TRY(b->lext.alloc((size_t)ns)); FZP_TRY(b->rext.alloc((size_t)ns)); FZP_TRY(b->lscore.alloc((size_t)ns)); FZP_TRY(b->rscore.alloc((size_t)ns));
+    FZP_TRY(b->rawblk.alloc((size_t)ns)); FZP_TRY(b->blkcnt.alloc((size_t)ns)); FZP_TRY(b->blknew.alloc((size_t)ns));
+    FZP_TRY(b->pvars_tmp.alloc((size_t)ns)); FZP_TRY(b->site_blk.alloc((size_t)ns)); FZP_TRY(b->site_b1.alloc((size_t)ns));
+    FZP_TRY(b->pv_n.alloc((size_t)b->n_ctg + 1)); FZP_TRY(b->pv_off.alloc((size_t)b->n_ctg + 1)); FZP_TRY(b->pvar_begin.alloc((size_t)b->n_ctg + 1));
+    FZP_TRY(b->left_n.zero((size_t)ns, st)); FZP_TRY(b->left_fill.zero((size_t)ns, st)); FZP_TRY(b->right_n.zero((size_t)ns, st));
+    FZP_TRY(b->blkcnt.zero((size_t)ns, st));
+    if (ns > 0) FZP_HIP(hipMemsetAsync(b->fr2.p, 0xff, (size_t)ns * sizeof(uint32_t), st));
+    int64_t n_links = 0;
+    if (na > 0) {
+        hipLaunchKernelGGL(k_link_flag, dim3(grid_for(na, 256, 1 << 30)), dim3(256), 0, st, b->arows.p, na, b->lk_flag.p);
+        FZP_TRY(fzp_exclusive_scan_u32(ctx, b->lk_flag.p, b->lk_flag.p, (size_t)na, b->totals.p + 4));
+        uint64_t t = 0;
+        FZP_HIP(hipMemcpyAsync(&t, b->totals.p + 4, sizeof t, hipMemcpyDeviceToHost, st));
+        FZP_HIP(hipStreamSynchronize(st));
+        n_links = (int64_t)t;
+    }
+    FZP_TRY(b->lk_i1.alloc((size_t)n_links)); FZP_TRY(b->lk_i2.alloc((size_t)n_links));
+    FZP_TRY(b->lk_cis.alloc((size_t)n_links)); FZP_TRY(b->lk_trans.alloc((size_t)n_links)); FZP_TRY(b->left_lk.alloc((size_t)n_links));
+    if (n_links > 0) {
+        ProfScope ps(ctx, "k4_links");
+        hipLaunchKernelGGL(k_link_emit, dim3(grid_for(na, 256, 1 << 30)), dim3(256), 0, st, b->arows.p, na, b->lk_flag.p, n_links, b->lk_i1.p, b->lk_i2.p,
+                           b->lk_cis.p, b->lk_trans.p, b->left_n.p, b->right_n.p, b->fr2.p);
+    }
+    if (ns > 0) {
+        FZP_TRY(fzp_exclusive_scan_u32(ctx, b->left_n.p, b->left_off.p, (size_t)ns, nullptr));
+        FZP_TRY(fzp_exclusive_scan_u32(ctx, b->right_n.p, b->right_off.p, (size_t)ns, nullptr));
+        if (n_links > 0)
+            hipLaunchKernelGGL(k_left_fill, dim3(grid_for(n_links, 256, 1 << 30)), dim3(256), 0, st, n_links, b->lk_i2.p, b->left_off.p, b->left_fill.p, b->left_lk.p);
+        {
+            ProfScope ps(ctx, "k4_greedy");
+            hipLaunchKernelGGL(k_pj_init, dim3(grid_for(ns, 256, 1 << 30)), dim3(256), 0, st, ns, b->right_n.p, b->right_off.p, b->fr2.p, b->lk_i1.p, b->lk_i2.p,
+                               b->lk_cis.p, b->lk_trans.p, b->pj.p);
+            hipLaunchKernelGGL(k_pj_resolve, dim3(grid_for(ns, 256, 1 << 30)), dim3(256), 0, st, ns, b->pj.p, b->orient.p);
+        }
+        int64_t max_sites = 0;
+        for (int c = 0; c < b->n_ctg; c++) max_sites = std::max<int64_t>(max_sites, b->h_site_begin[c + 1] - b->h_site_begin[c]);
+        {
+            ProfScope ps(ctx, "k4_sweep");
+            if (max_sites <= 60 * 1024)
+                hipLaunchKernelGGL(k_sweep<true>, dim3(b->n_ctg), dim3(64), (size_t)((max_sites + 15) & ~15LL), st, b->site_begin.p, b->left_n.p, b->left_off.p,
+                                   b->left_lk.p, b->lk_i1.p, b->lk_cis.p, b->lk_trans.p, b->orient.p);
+            else
+                hipLaunchKernelGGL(k_sweep<false>, dim3(b->n_ctg), dim3(64), 0, st, b->site_begin.p, b->left_n.p, b->left_off.p, b->left_lk.p, b->lk_i1.p,
+                                   b->lk_cis.p, b->lk_trans.p, b->orient.p);
+        }
+        {
+            ProfScope ps(ctx, "k4_extents");
+            hipLaunchKernelGGL(k_extents, dim3(grid_for(ns, 4, 1 << 30)), dim3(256), 0, st, ns, b->sites.p, b->left_n.p, b->left_off.p, b->left_lk.p, b->right_n.p,
+                               b->right_off.p, b->lk_i1.p, b->lk_i2.p, b->lk_cis.p, b->lk_trans.p, b->orient.p, b->lext.p, b->rext.p, b->lscore.p, b->rscore.p);
+        }
+    }
+    {
+        ProfScope ps(ctx, "k4_segment");
+        hipLaunchKernelGGL(k_segment, dim3(b->n_ctg), dim3(64), 0, st, b->site_begin.p, b->sites.p, b->orient.p, b->lext.p, b->rext.p, b->lscore.p, b->rscore.p,
+                           b->rawblk.p, b->blkcnt.p, b->blknew.p, b->pvars_tmp.p, b->pv_n.p, b->site_blk.p, b->site_b1.p);
+    }
+    FZP_TRY(fzp_exclusive_scan_u32(ctx, b->pv_n.p, b->pv_off.p, (size_t)b->n_ctg, b->totals.p + 5));
+    uint64_t t = 0;
+    FZP_HIP(hipMemcpyAsync(&t, b->totals.p + 5, sizeof t, hipMemcpyDeviceToHost, st));
+    FZP_HIP(hipStreamSynchronize(st));
+    b->n_pvars = (int64_t)t;
+    FZP_TRY(b->pvars.alloc((size_t)b->n_pvars));
+    if (b->n_pvars > 0)
+        hipLaunchKernelGGL(k_pv_compact, dim3(b->n_ctg), dim3(256), 0, st, b->site_begin.p, b->pv_n.p, b->pv_off.p, b->pvars_tmp.p, b->pvars.p);
+    hipLaunchKernelGGL(k_u32_to_i64_begin, dim3((b->n_ctg + 1 + 63) / 64), dim3(64), 0, st, b->pv_off.p, b->n_ctg, b->n_pvars, b->pvar_begin.p);
+    b->h_pvar_begin.resize((size_t)b->n_ctg + 1);
+    FZP_TRY(b->pvar_begin.download(b->h_pvar_begin.data(), (size_t)b->n_ctg + 1, st));
+    FZP_HIP(hipStreamSynchronize(st));
+    FZP_HIP(hipGetLastError());
+    b->have_blocks = true;
+    return FZP_OK;
+}
+
+// ================================================================================ K5 driver
+int fzp_k5_reads(fzp_ctx *ctx, fzp_batch *b) {
+    hipStream_t st = ctx->stream;
+    if (!b->have_sites || !b->have_blocks) { fzp_set_error("read phasing needs sites and phase blocks"); return FZP_EINVAL; }
+    if (!b->have_sets) FZP_TRY(fzp_k3_sets(ctx, b));
+    const int64_t ns = b->n_sites, nq = b->n_qid;
+    FZP_TRY(b->totals.alloc(8));
+    FZP_TRY(b->bmin.alloc((size_t)nq)); FZP_TRY(b->bmax.alloc((size_t)nq)); FZP_TRY(b->rng_n.alloc((size_t)nq)); FZP_TRY(b->rng_off.alloc((size_t)nq));
+    FZP_TRY(b->pread_begin.alloc((size_t)b->n_ctg + 1));
+    int64_t n_slots = 0;
+    b->n_preads = 0;
+    if (nq > 0) {
+        hipLaunchKernelGGL(k_fill_i32, dim3(grid_for(nq, 256, 1 << 30)), dim3(256), 0, st, b->bmin.p, nq, 0x7fffffff);
+        FZP_TRY(b->bmax.zero((size_t)nq, st));
+        const uint32_t *set_n = b->set_n.p, *set_off = b->set_n.p + 2 * ns;
+        if (ns > 0) {
+            ProfScope ps(ctx, "k5_read_range");
+            hipLaunchKernelGGL(k_read_votes<0>, dim3(grid_for(ns * 2, 4, 1 << 30)), dim3(256), 0, st, ns, b->sites.p, b->site_ctg.p, b->ctg_qoff.p, b->setq.p, set_n,
+                               set_off, b->site_blk.p, b->site_b1.p, b->bmin.p, b->bmax.p, (const uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
+        }
+        hipLaunchKernelGGL(k_range_n, dim3(grid_for(nq, 256, 1 << 30)), dim3(256), 0, st, nq, b->bmin.p, b->bmax.p, b->rng_n.p);
+        FZP_TRY(fzp_exclusive_scan_u32(ctx, b->rng_n.p, b->rng_off.p, (size_t)nq, b->totals.p + 6));
+        uint64_t t = 0;
+        FZP_HIP(hipMemcpyAsync(&t, b->totals.p + 6, sizeof t, hipMemcpyDeviceToHost, st));
+        FZP_HIP(hipStreamSynchronize(st));
+        n_slots = (int64_t)t;
+        FZP_TRY(b->c0.alloc((size_t)n_slots)); FZP_TRY(b->c1.alloc((size_t)n_slots)); FZP_TRY(b->pr_flag.alloc((size_t)n_slots));
+        FZP_TRY(b->c0.zero((size_t)n_slots, st)); FZP_TRY(b->c1.zero((size_t)n_slots, st));
+        if (n_slots > 0) {
+            {
+                ProfScope ps(ctx, "k5_read_count");
+                hipLaunchKernelGGL(k_read_votes<1>, dim3(grid_for(ns * 2, 4, 1 << 30)), dim3(256), 0, st, ns, b->sites.p, b->site_ctg.p, b->ctg_qoff.p, b->setq.p, set_n,
+                                   set_off, b->site_blk.p, b->site_b1.p, b->bmin.p, b->bmax.p, b->rng_off.p, b->c0.p, b->c1.p);
+            }
+            hipLaunchKernelGGL(k_read_flag, dim3(grid_for(n_slots, 256, 1 << 30)), dim3(256), 0, st, n_slots, b->c0.p, b->c1.p, b->pr_flag.p);
+            FZP_TRY(fzp_exclusive_scan_u32(ctx, b->pr_flag.p, b->pr_flag.p, (size_t)n_slots, b->totals.p + 7));
+            FZP_HIP(hipMemcpyAsync(&t, b->totals.p + 7, sizeof t, hipMemcpyDeviceToHost, st));
+            FZP_HIP(hipStreamSynchronize(st));
+            b->n_preads = (int64_t)t;
+            FZP_TRY(b->preads.alloc((size_t)b->n_preads));
+            if (b->n_preads > 0) {
+                ProfScope ps(ctx, "k5_read_emit");
+                hipLaunchKernelGGL(k_read_emit, dim3(grid_for(n_slots, 256, 1 << 30)), dim3(256), 0, st, n_slots, nq, b->n_preads, b->pr_flag.p, b->rng_off.p, b->bmin.p,
+                                   b->c0.p, b->c1.p, b->ctg_qoff.p, b->n_ctg, b->preads.p);
+            }
+        }
+    }
+    FZP_TRY(b->preads.alloc((size_t)b->n_preads));
+    hipLaunchKernelGGL(k_pread_begin, dim3((b->n_ctg + 1 + 63) / 64), dim3(64), 0, st, b->ctg_qoff.p, b->n_ctg, nq, n_slots, b->n_preads, b->rng_off.p, b->pr_flag.p,
+                       b->pread_begin.p);
+    b->h_pread_begin.resize((size_t)b->n_ctg + 1);
+    FZP_TRY(b->pread_begin.download(b->h_pread_begin.data(), (size_t)b->n_ctg + 1, st));
+    FZP_HIP(hipStreamSynchronize(st));
+    FZP_HIP(hipGetLastError());
+    b->have_preads = true;
+    return FZP_OK;
+}

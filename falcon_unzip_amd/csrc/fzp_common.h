@@ -1,0 +1,146 @@
+// fzp_common.h -- internals shared by the HIP translation units of libfzphase.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "fzphase.h"
+
+void fzp_set_error(const char *fmt, ...);
+
+#define FZP_HIP(x)                                                                                   \
+    do {                                                                                             \
+        hipError_t e_ = (x);                                                                         \
+        if (e_ != hipSuccess) {                                                                      \
+            fzp_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #x, hipGetErrorString(e_));         \
+            return FZP_EDEVICE;                                                                      \
+        }                                                                                            \
+    } while (0)
+#define FZP_TRY(x)                 \
+    do {                           \
+        int rc_ = (x);             \
+        if (rc_ != FZP_OK) return rc_; \
+    } while (0)
+
+constexpr int WAVE = 64;
+
+// ---------------------------------------------------------------- device buffer
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;   // capacity in elements
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr; n = 0;
+    }
+    int alloc(size_t count) {   // grow-only
+        if (count <= n && p) return FZP_OK;
+        release();
+        size_t bytes = (count ? count : 1) * sizeof(T);
+        hipError_t e = hipMalloc((void **)&p, bytes);
+        if (e != hipSuccess) {
+            p = nullptr;
+            fzp_set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+            return FZP_ENOMEM;
+        }
+        n = count ? count : 1;
+        return FZP_OK;
+    }
+    int upload(const T *h, size_t count, hipStream_t s) {
+        FZP_TRY(alloc(count));
+        if (count) FZP_HIP(hipMemcpyAsync(p, h, count * sizeof(T), hipMemcpyHostToDevice, s));
+        return FZP_OK;
+    }
+    int download(T *h, size_t count, hipStream_t s, size_t off = 0) const {
+        if (count) FZP_HIP(hipMemcpyAsync(h, p + off, count * sizeof(T), hipMemcpyDeviceToHost, s));
+        return FZP_OK;
+    }
+    int zero(size_t count, hipStream_t s) {
+        if (count) FZP_HIP(hipMemsetAsync(p, 0, count * sizeof(T), s));
+        return FZP_OK;
+    }
+};
+
+// ---------------------------------------------------------------- context
+struct ProfEntry {
+    double ms = 0;
+    int64_t launches = 0;
+};
+struct PendingEvent {
+    std::string name;
+    hipEvent_t a, b;
+};
+
+struct fzp_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool prof = false;
+    std::map<std::string, ProfEntry> prof_tab;
+    std::vector<PendingEvent> pending;
+    std::vector<hipEvent_t> event_pool;
+    DevBuf<uint64_t> scan_tmp[3];
+    int n_cu = 256;
+};
+
+// RAII bracket: records HIP events on the ctx stream around a kernel launch when profiling is on.
+struct ProfScope {
+    fzp_ctx *c;
+    PendingEvent ev;
+    bool on;
+    ProfScope(fzp_ctx *ctx, const char *name);
+    ~ProfScope();
+};
+int fzp_prof_flush(fzp_ctx *ctx);
+
+// ---------------------------------------------------------------- scans (fzp_scan.hip)
+// out[i] = sum_{j<i} in[j] over n uint32 items (in may alias out); *total_dev (device u64) gets the sum.
+int fzp_exclusive_scan_u32(fzp_ctx *ctx, const uint32_t *in, uint32_t *out, size_t n, uint64_t *total_dev);
+
+// ---------------------------------------------------------------- wave helpers (device)
+#ifdef __HIPCC__
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(v, d, 64);
+        if (lane_id() >= d) v += t;
+    }
+    return v;
+}
+__device__ __forceinline__ int32_t wave_sum_i32(int32_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+__device__ __forceinline__ int32_t wave_min_i32(int32_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = min(v, __shfl_xor(v, d, 64));
+    return v;
+}
+__device__ __forceinline__ int32_t wave_max_i32(int32_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d, 64));
+    return v;
+}
+__device__ __forceinline__ uint32_t bcast_u32(uint32_t v, int src) { return __shfl(v, src, 64); }
+
+// base letter <-> 2-bit code in the order A C G T (the order phasing.py:108 counts in)
+__device__ __forceinline__ int sym_code(uint8_t s) {
+    return s == 'A' ? 0 : s == 'C' ? 1 : s == 'G' ? 2 : s == 'T' ? 3 : 4;
+}
+__device__ __host__ __forceinline__ uint8_t code_sym(int c) { return (uint8_t)("ACGT"[c & 3]); }
+// CPython-2.7 iteration order of a {allele: ...} dict: A < C < T < G (phasing.py:175,181)
+__device__ __host__ __forceinline__ int py2_rank(uint8_t b) { return b == 'A' ? 0 : b == 'C' ? 1 : b == 'T' ? 2 : b == 'G' ? 3 : 4; }
+#endif

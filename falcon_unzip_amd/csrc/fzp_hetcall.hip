@@ -1,0 +1,504 @@
+// fzp_hetcall.hip -- K2: pileup + het-SNP call + variant_map (make_het_call, phasing.py:14-135)
+//                    K3: per-site allele sets + association table (generate_association_table, phasing.py:137-206)
+//
+// Batch form of the reference's streaming sweep (valid because accepted records are POS-sorted,
+// enforced by fzp_parse_sam): count A/C/G/T (+ a non-ACGT symbol tracker) per evaluated position
+// over ALL accepted records, then call every position p < POS(last accepted record).
+//
+// Roofline: HBM-bound integer scans.  Algorithmic bytes per aligned column: 1 B symbol + the CIGAR
+// word stream (4 B/op); per evaluated position: 16 B counters + 4 B symbol tracker written by
+// atomics and read back once, + 9 B of flag/scan state.  No MFMA: nothing here is GEMM-shaped.
+#include "fzp_batch.h"
+
+namespace {
+
+struct RecView {
+    const int32_t *rec_pos, *rec_qid, *rec_ctg;
+    const int64_t *cig_off, *seq_off;
+    const uint32_t *cigar;
+    const uint8_t *seq;
+    const int64_t *ctg_goff;
+    const int32_t *ctg_limit;
+    int64_t n_rec;
+};
+
+// Wave-cooperative walk of one record's CIGAR (phasing.py:77-96): S,I advance the query; M,=,X emit
+// one column per base and advance both; D advances the reference; N,H,P do nothing.
+// 64 ops are loaded per step, their (ref, query, column) advances prefix-summed across the wave,
+// then the columns of those ops are dealt 64 at a time: lane t finds its op by a 6-step search.
+template <class Visit>
+__device__ __forceinline__ void expand_record(const RecView &v, int64_t r, Visit &&visit) {
+    const int lane = lane_id();
+    const int64_t c0 = v.cig_off[r], c1 = v.cig_off[r + 1];
+    const int64_t sbase = v.seq_off[r];
+    int32_t rp = v.rec_pos[r];
+    int64_t qp = 0;
+    for (int64_t cb = c0; cb < c1; cb += 64) {
+        uint32_t w = (cb + lane < c1) ? v.cigar[cb + lane] : 0u;
+        uint32_t len = w >> 4, t = w & 15u;
+        bool isM = (t == FZP_OP_M) | (t == FZP_OP_EQ) | (t == FZP_OP_X);
+        uint32_t radv = (isM | (t == FZP_OP_D)) ? len : 0u;
+        uint32_t qadv = (isM | (t == FZP_OP_I) | (t == FZP_OP_S)) ? len : 0u;
+        uint32_t cadv = isM ? len : 0u;
+        uint32_t rs = wave_incl_scan_u32(radv), qs = wave_incl_scan_u32(qadv), cs = wave_incl_scan_u32(cadv);
+        uint32_t ctot = bcast_u32(cs, 63);
+        uint32_t rex = rs - radv, qex = qs - qadv, cex = cs - cadv;
+        for (uint32_t base = 0; base < ctot; base += 64) {
+            uint32_t tc = base + lane;
+            int j = 0;   // smallest j with cs[j] > tc
+#pragma unroll
+            for (int s = 32; s >= 1; s >>= 1) {
+                uint32_t x = bcast_u32(cs, j + s - 1);
+                if (x <= tc) j += s;
+            }
+            j = min(j, 63);
+            uint32_t jc = bcast_u32(cex, j), jr = bcast_u32(rex, j), jq = bcast_u32(qex, j);
+            if (tc < ctot) {
+                uint32_t d = tc - jc;
+                visit((int32_t)(rp + jr + d), v.seq[sbase + qp + jq + d]);
+            }
+        }
+        rp += (int32_t)bcast_u32(rs, 63);
+        qp += bcast_u32(qs, 63);
+    }
+}
+
+// ---- K2a: column counts ------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_pileup_count(RecView v, uint32_t *__restrict__ cnt, uint32_t *__restrict__ oth) {
+    for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < v.n_rec; r += (int64_t)gridDim.x * 4) {
+        const int c = v.rec_ctg[r];
+        const int64_t goff = v.ctg_goff[c];
+        const int32_t lim = v.ctg_limit[c];
+        expand_record(v, r, [&](int32_t pos, uint8_t sym) {
+            if (pos >= lim) return;   // never evaluated by the reference (no final flush)
+            int64_t g = goff + pos;
+            int code = sym_code(sym);
+            if (code < 4) atomicAdd(&cnt[g * 4 + code], 1u);
+            else {
+                // distinct non-ACGT symbols at this position: 0, 1 (value kept) or >=2 (bit 8)
+                uint32_t old = atomicCAS(&oth[g], 0u, (uint32_t)sym);
+                if (old != 0u && (old & 0xffu) != (uint32_t)sym) atomicOr(&oth[g], 0x100u);
+            }
+        });
+    }
+}
+
+struct CallInfo {
+    bool called;
+    uint8_t ord[4];
+    uint32_t c[4];
+    uint32_t total;
+};
+
+// phasing.py:103-120 for one position
+__device__ __forceinline__ CallInfo evaluate_position(uint4 k, uint32_t oth) {
+    CallInfo ci;
+    uint32_t c[4] = {k.x, k.y, k.z, k.w};
+    int distinct = (c[0] > 0) + (c[1] > 0) + (c[2] > 0) + (c[3] > 0) + (oth == 0u ? 0 : ((oth & 0x100u) ? 2 : 1));
+    ci.total = c[0] + c[1] + c[2] + c[3];
+    ci.called = false;
+    // rank: count descending, ties larger letter first (sort ascending then reverse, phasing.py:116-117)
+    uint64_t key[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) key[i] = ((uint64_t)c[i] << 2) | (uint64_t)i;
+#define CSWAP(a, b) { uint64_t lo = key[a] < key[b] ? key[a] : key[b], hi = key[a] < key[b] ? key[b] : key[a]; key[a] = hi; key[b] = lo; }
+    CSWAP(0, 1) CSWAP(2, 3) CSWAP(0, 2) CSWAP(1, 3) CSWAP(1, 2)
+#undef CSWAP
+#pragma unroll
+    for (int i = 0; i < 4; i++) { ci.ord[i] = (uint8_t)(key[i] & 3); ci.c[i] = (uint32_t)(key[i] >> 2); }
+    if (distinct < 2 || ci.total < 10) return ci;
+    // p0 < 0.75 and p1 > 0.25 in IEEE double  <=>  4*c0 < 3*total and 4*c1 > total  (exact for total < 2^50)
+    ci.called = (4ull * ci.c[0] < 3ull * ci.total) && (4ull * ci.c[1] > (uint64_t)ci.total);
+    return ci;
+}
+
+// ---- K2b: per-position call flags + variant_map row counts ----------------------------------
+__global__ void __launch_bounds__(256) k_site_flag(const uint4 *__restrict__ cnt, const uint32_t *__restrict__ oth, int64_t n_pos,
+                                                   uint8_t *__restrict__ flag8, uint32_t *__restrict__ site_idx, uint32_t *__restrict__ row_off) {
+    int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= n_pos) return;
+    CallInfo ci = evaluate_position(cnt[g], oth[g]);
+    flag8[g] = ci.called ? 1 : 0;
+    site_idx[g] = ci.called ? 1u : 0u;
+    row_off[g] = ci.called ? ci.c[0] + ci.c[1] : 0u;
+}
+
+__device__ __forceinline__ int find_ctg(const int64_t *goff, int n_ctg, int64_t g) {
+    int lo = 0, hi = n_ctg;   // largest c with goff[c] <= g
+    while (hi - lo > 1) {
+        int m = (lo + hi) >> 1;
+        if (goff[m] <= g) lo = m; else hi = m;
+    }
+    return lo;
+}
+
+// ---- K2c: site records in ascending position order ------------------------------------------
+__global__ void __launch_bounds__(256) k_site_emit(const uint4 *__restrict__ cnt, const uint32_t *__restrict__ oth, const uint8_t *__restrict__ flag8,
+                                                   const uint32_t *__restrict__ site_idx, const uint32_t *__restrict__ row_off, const uint8_t *__restrict__ ref,
+                                                   const int64_t *__restrict__ goff, int n_ctg, int64_t n_pos, fzp_site *__restrict__ sites,
+                                                   int64_t *__restrict__ site_g, int32_t *__restrict__ site_ctg) {
+    int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= n_pos || !flag8[g]) return;
+    CallInfo ci = evaluate_position(cnt[g], oth[g]);
+    int c = find_ctg(goff, n_ctg, g);
+    fzp_site s;
+    s.pos = (int32_t)(g - goff[c]);
+    s.ref_base = ref[g];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { s.base[i] = code_sym(ci.ord[i]); s.count[i] = (int32_t)ci.c[i]; }
+    s.pad_[0] = s.pad_[1] = s.pad_[2] = 0;
+    s.total = (int32_t)ci.total;
+    s.row_off = (int64_t)row_off[g];
+    uint32_t si = site_idx[g];
+    sites[si] = s;
+    site_g[si] = g;
+    site_ctg[si] = c;
+}
+
+__global__ void k_site_begin(const int64_t *__restrict__ site_g, int64_t n_sites, const int64_t *__restrict__ goff, int n_ctg, int64_t *__restrict__ site_begin) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > n_ctg) return;
+    int64_t key = goff[c];
+    int64_t lo = 0, hi = n_sites;   // first site with site_g >= key
+    while (lo < hi) {
+        int64_t m = (lo + hi) >> 1;
+        if (site_g[m] < key) lo = m + 1; else hi = m;
+    }
+    site_begin[c] = lo;
+}
+
+// ---- K2d: scatter (record index, q_id) of every column that carries a called site's major/minor allele
+__global__ void __launch_bounds__(256) k_vmap_scatter(RecView v, const uint8_t *__restrict__ flag8, const uint32_t *__restrict__ site_idx,
+                                                      const fzp_site *__restrict__ sites, uint32_t *__restrict__ vfill, uint64_t *__restrict__ vtmp) {
+    for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < v.n_rec; r += (int64_t)gridDim.x * 4) {
+        const int c = v.rec_ctg[r];
+        const int64_t goff = v.ctg_goff[c];
+        const int32_t lim = v.ctg_limit[c];
+        const uint32_t qid = (uint32_t)v.rec_qid[r];
+        expand_record(v, r, [&](int32_t pos, uint8_t sym) {
+            if (pos >= lim) return;
+            int64_t g = goff + pos;
+            if (!flag8[g]) return;
+            uint32_t si = site_idx[g];
+            const fzp_site &s = sites[si];
+            int a = sym == s.base[0] ? 0 : (sym == s.base[1] ? 1 : -1);
+            if (a < 0) return;
+            uint32_t slot = atomicAdd(&vfill[2 * si + a], 1u);
+            vtmp[s.row_off + (a ? s.count[0] : 0) + slot] = ((uint64_t)r << 32) | qid;
+        });
+    }
+}
+
+// ---- K2e: order each (site, allele) segment by record index (== the reference's append order)
+__global__ void __launch_bounds__(256) k_vmap_sort(const fzp_site *__restrict__ sites, int64_t n_sites, const uint64_t *__restrict__ vtmp,
+                                                   int32_t *__restrict__ vmap_qid) {
+    const int lane = lane_id();
+    int64_t w = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    if (w >= n_sites * 2) return;
+    const fzp_site &s = sites[w >> 1];
+    const int a = (int)(w & 1);
+    const int64_t seg = s.row_off + (a ? s.count[0] : 0);
+    const int n = s.count[a];
+    for (int base = 0; base < n; base += 64) {
+        int idx = base + lane;
+        uint64_t my = idx < n ? vtmp[seg + idx] : ~0ull;
+        int rank = 0;
+        for (int j0 = 0; j0 < n; j0 += 64) {
+            uint64_t other = (j0 + lane < n) ? vtmp[seg + j0 + lane] : ~0ull;
+            int m = min(64, n - j0);
+            for (int k = 0; k < m; k++) {
+                uint64_t o = __shfl(other, k, 64);
+                rank += (o < my) ? 1 : 0;
+            }
+        }
+        if (idx < n) vmap_qid[seg + rank] = (int32_t)(uint32_t)(my & 0xffffffffu);
+    }
+}
+
+// ---- K3a: per site, the two alleles' DISTINCT q_ids (set semantics of phasing.py:189), ascending,
+//           alleles in CPython-2.7 dict order A < C < T < G (phasing.py:175,181)
+__global__ void __launch_bounds__(256) k_site_sets(const fzp_site *__restrict__ sites, int64_t n_sites, const int32_t *__restrict__ vq,
+                                                   int32_t *__restrict__ setq, uint32_t *__restrict__ set_n, uint32_t *__restrict__ set_off) {
+    const int lane = lane_id();
+    int64_t w = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    if (w >= n_sites * 2) return;
+    const int64_t si = w >> 1;
+    const fzp_site &s = sites[si];
+    const int x = (int)(w & 1);
+    const int a0 = py2_rank(s.base[0]) < py2_rank(s.base[1]) ? 0 : 1;   // ranked allele that comes first in dict order
+    const int a = x == 0 ? a0 : 1 - a0;
+    const int32_t *src = vq + s.row_off + (a ? s.count[0] : 0);
+    const int n = s.count[a];
+    const int64_t doff = s.row_off + (x == 0 ? 0 : s.count[a0]);
+    int32_t *dst = setq + doff;
+    // 1) rank sort by (q_id, index)
+    for (int base = 0; base < n; base += 64) {
+        int idx = base + lane;
+        int32_t my = idx < n ? src[idx] : 0x7fffffff;
+        int rank = 0;
+        for (int j0 = 0; j0 < n; j0 += 64) {
+            int32_t other = (j0 + lane < n) ? src[j0 + lane] : 0x7fffffff;
+            int m = min(64, n - j0);
+            for (int k = 0; k < m; k++) {
+                int32_t o = __shfl(other, k, 64);
+                rank += (o < my || (o == my && j0 + k < idx)) ? 1 : 0;
+            }
+        }
+        if (idx < n) dst[rank] = my;
+    }
+    __threadfence_block();
+    // 2) in-place unique compaction, 64 at a time (writes never pass unread data)
+    int out = 0;
+    int32_t prev = -1;   // q_ids are >= 0
+    for (int base = 0; base < n; base += 64) {
+        int idx = base + lane;
+        int32_t q = idx < n ? dst[idx] : 0x7fffffff;
+        int32_t left = __shfl_up(q, 1, 64);
+        if (lane == 0) left = prev;
+        bool keep = idx < n && (q != left);
+        uint64_t mask = __ballot(keep);
+        int before = __popcll(mask & ((1ull << lane) - 1ull));
+        prev = __shfl(q, 63, 64);
+        __threadfence_block();
+        if (keep) dst[out + before] = q;
+        out += __popcll(mask);
+    }
+    if (lane == 0) { set_n[w] = (uint32_t)out; set_off[w] = (uint32_t)doff; }
+}
+
+// ---- K3b: candidate partners within the 65 536 bp window (phasing.py:169) ----------------------
+__global__ void __launch_bounds__(256) k_cand(const int64_t *__restrict__ site_g, const int32_t *__restrict__ site_ctg, const int64_t *__restrict__ site_begin,
+                                              int64_t n_sites, uint32_t *__restrict__ cand_n, uint32_t *__restrict__ cap) {
+    int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= n_sites) return;
+    int64_t end = site_begin[site_ctg[s] + 1];
+    int64_t key = site_g[s] + 65536;   // partners with g2 <= key
+    int64_t lo = s + 1, hi = end;      // first index with site_g > key
+    while (lo < hi) {
+        int64_t m = (lo + hi) >> 1;
+        if (site_g[m] <= key) lo = m + 1; else hi = m;
+    }
+    uint32_t n = (uint32_t)(lo - (s + 1));
+    cand_n[s] = n;
+    cap[s] = n < 501u ? n : 501u;
+}
+
+__device__ __forceinline__ bool set_contains(const int32_t *__restrict__ a, int n, int32_t q) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        int m = (lo + hi) >> 1;
+        int32_t v = a[m];
+        if (v < q) lo = m + 1; else hi = m;
+    }
+    return lo < n && a[lo] == q;
+}
+
+// One wave per site i1; partners are visited in ascending order because the 501-row cap
+// (phasing.py:204-206) depends on how many earlier partners were kept.
+__global__ void __launch_bounds__(256) k_assoc(int64_t n_sites, const uint32_t *__restrict__ cand_n, const uint32_t *__restrict__ cap_off,
+                                               const int32_t *__restrict__ setq, const uint32_t *__restrict__ set_n, const uint32_t *__restrict__ set_off,
+                                               fzp_arow *__restrict__ tmp, uint32_t *__restrict__ nkept) {
+    const int lane = lane_id();
+    for (int64_t i1 = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6; i1 < n_sites; i1 += ((int64_t)gridDim.x * 256) >> 6) {
+        const uint32_t nc = cand_n[i1];
+        const int32_t *s1a = setq + set_off[2 * i1], *s1b = setq + set_off[2 * i1 + 1];
+        const int n1a = (int)set_n[2 * i1], n1b = (int)set_n[2 * i1 + 1];
+        fzp_arow *out = tmp + cap_off[i1];
+        uint32_t kept = 0;
+        for (uint32_t k = 0; k < nc && kept < 501u; k++) {
+            const int64_t i2 = i1 + 1 + k;
+            const int32_t *s2a = setq + set_off[2 * i2], *s2b = setq + set_off[2 * i2 + 1];
+            const int n2a = (int)set_n[2 * i2], n2b = (int)set_n[2 * i2 + 1];
+            const int m = n2a + n2b;
+            int n11 = 0, n12 = 0, n21 = 0, n22 = 0;
+            for (int e0 = 0; e0 < m; e0 += 64) {
+                int e = e0 + lane;
+                bool act = e < m;
+                bool y = e >= n2a;
+                int32_t q = act ? (y ? s2b[e - n2a] : s2a[e]) : -1;
+                bool ia = act && set_contains(s1a, n1a, q);
+                bool ib = act && set_contains(s1b, n1b, q);
+                n11 += __popcll(__ballot(ia && !y));
+                n12 += __popcll(__ballot(ia && y));
+                n21 += __popcll(__ballot(ib && !y));
+                n22 += __popcll(__ballot(ib && y));
+            }
+            if (n11 + n12 + n21 + n22 >= 6) {   // phasing.py:192
+                if (lane == 0) {
+                    fzp_arow r;
+                    r.site1 = (int32_t)i1; r.site2 = (int32_t)i2;
+                    r.n[0] = n11; r.n[1] = n12; r.n[2] = n21; r.n[3] = n22;
+                    out[kept] = r;
+                }
+                kept++;
+            }
+        }
+        if (lane == 0) nkept[i1] = kept;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_assoc_compact(int64_t n_sites, const uint32_t *__restrict__ cap_off, const uint32_t *__restrict__ nkept,
+                                                       const uint32_t *__restrict__ kept_off, const fzp_arow *__restrict__ tmp, fzp_arow *__restrict__ out) {
+    const int lane = lane_id();
+    int64_t i1 = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    if (i1 >= n_sites) return;
+    uint32_t n = nkept[i1];
+    const fzp_arow *src = tmp + cap_off[i1];
+    fzp_arow *dst = out + kept_off[i1];
+    for (uint32_t k = lane; k < n; k += 64) dst[k] = src[k];
+}
+
+__global__ void k_arow_begin(const uint32_t *__restrict__ kept_off, const int64_t *__restrict__ site_begin, int n_ctg, int64_t n_sites, int64_t n_arows,
+                             int64_t *__restrict__ arow_begin) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > n_ctg) return;
+    int64_t s = site_begin[c];
+    arow_begin[c] = s >= n_sites ? n_arows : (int64_t)kept_off[s];
+}
+
+inline unsigned grid_for(int64_t items, int per_block, int64_t cap = 1 << 20) {
+    int64_t g = (items + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (unsigned)g;
+}
+
+RecView rec_view(const fzp_batch *b) {
+    RecView v;
+    v.rec_pos = b->rec_pos.p; v.rec_qid = b->rec_qid.p; v.rec_ctg = b->rec_ctg.p;
+    v.cig_off = b->cig_off.p; v.seq_off = b->seq_off.p; v.cigar = b->cigar.p; v.seq = b->seq.p;
+    v.ctg_goff = b->ctg_goff.p; v.ctg_limit = b->ctg_limit.p; v.n_rec = b->n_rec;
+    return v;
+}
+
+int read_totals(fzp_ctx *ctx, fzp_batch *b, int n, uint64_t *out) {
+    FZP_HIP(hipMemcpyAsync(out, b->totals.p, n * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    FZP_HIP(hipStreamSynchronize(ctx->stream));
+    return FZP_OK;
+}
+}  // namespace
+
+// ================================================================================ K2 driver
+int fzp_k2_het_call(fzp_ctx *ctx, fzp_batch *b) {
+    hipStream_t st = ctx->stream;
+    const int64_t np = b->n_pos;
+    FZP_TRY(b->totals.alloc(8));
+    FZP_TRY(b->cnt.alloc((size_t)np * 4));
+    FZP_TRY(b->oth.alloc((size_t)np));
+    FZP_TRY(b->flag8.alloc((size_t)np));
+    FZP_TRY(b->site_idx.alloc((size_t)np));
+    FZP_TRY(b->row_off32.alloc((size_t)np));
+    FZP_TRY(b->cnt.zero((size_t)np * 4, st));
+    FZP_TRY(b->oth.zero((size_t)np, st));
+    RecView v = rec_view(b);
+    if (b->n_rec > 0 && np > 0) {
+        ProfScope ps(ctx, "k2_pileup_count");
+        hipLaunchKernelGGL(k_pileup_count, dim3(grid_for(b->n_rec, 4, 1 << 16)), dim3(256), 0, st, v, b->cnt.p, b->oth.p);
+    }
+    if (np > 0) {
+        ProfScope ps(ctx, "k2_site_flag");
+        hipLaunchKernelGGL(k_site_flag, dim3(grid_for(np, 256, 1 << 30)), dim3(256), 0, st, (const uint4 *)b->cnt.p, b->oth.p, np,
+                           b->flag8.p, b->site_idx.p, b->row_off32.p);
+    }
+    FZP_TRY(fzp_exclusive_scan_u32(ctx, b->site_idx.p, b->site_idx.p, (size_t)np, b->totals.p + 0));
+    FZP_TRY(fzp_exclusive_scan_u32(ctx, b->row_off32.p, b->row_off32.p, (size_t)np, b->totals.p + 1));
+    uint64_t tot[2];
+    FZP_TRY(read_totals(ctx, b, 2, tot));
+    if (tot[1] >= (1ull << 31)) { fzp_set_error("variant_map has %llu rows (> 2^31)", (unsigned long long)tot[1]); return FZP_EINVAL; }
+    b->n_sites = (int64_t)tot[0];
+    b->n_rows = (int64_t)tot[1];
+    FZP_TRY(b->sites.alloc((size_t)b->n_sites));
+    FZP_TRY(b->site_g.alloc((size_t)b->n_sites));
+    FZP_TRY(b->site_ctg.alloc((size_t)b->n_sites));
+    FZP_TRY(b->site_begin.alloc((size_t)b->n_ctg + 1));
+    FZP_TRY(b->vtmp.alloc((size_t)b->n_rows));
+    FZP_TRY(b->vmap_qid.alloc((size_t)b->n_rows));
+    FZP_TRY(b->vfill.alloc((size_t)b->n_sites * 2));
+    FZP_TRY(b->vfill.zero((size_t)b->n_sites * 2, st));
+    if (b->n_sites > 0) {
+        {
+            ProfScope ps(ctx, "k2_site_emit");
+            hipLaunchKernelGGL(k_site_emit, dim3(grid_for(np, 256, 1 << 30)), dim3(256), 0, st, (const uint4 *)b->cnt.p, b->oth.p, b->flag8.p,
+                               b->site_idx.p, b->row_off32.p, b->ref.p, b->ctg_goff.p, b->n_ctg, np, b->sites.p, b->site_g.p, b->site_ctg.p);
+        }
+        {
+            ProfScope ps(ctx, "k2_vmap_scatter");
+            hipLaunchKernelGGL(k_vmap_scatter, dim3(grid_for(b->n_rec, 4, 1 << 16)), dim3(256), 0, st, v, b->flag8.p, b->site_idx.p, b->sites.p,
+                               b->vfill.p, b->vtmp.p);
+        }
+        {
+            ProfScope ps(ctx, "k2_vmap_sort");
+            hipLaunchKernelGGL(k_vmap_sort, dim3(grid_for(b->n_sites * 2, 4, 1 << 30)), dim3(256), 0, st, b->sites.p, b->n_sites, b->vtmp.p, b->vmap_qid.p);
+        }
+    }
+    hipLaunchKernelGGL(k_site_begin, dim3((b->n_ctg + 1 + 63) / 64), dim3(64), 0, st, b->site_g.p, b->n_sites, b->ctg_goff.p, b->n_ctg, b->site_begin.p);
+    b->h_site_begin.resize((size_t)b->n_ctg + 1);
+    FZP_TRY(b->site_begin.download(b->h_site_begin.data(), (size_t)b->n_ctg + 1, st));
+    FZP_HIP(hipStreamSynchronize(st));
+    FZP_HIP(hipGetLastError());
+    b->have_sites = true;
+    b->have_sets = false;
+    return FZP_OK;
+}
+
+// ================================================================================ K3 drivers
+int fzp_k3_sets(fzp_ctx *ctx, fzp_batch *b) {
+    hipStream_t st = ctx->stream;
+    if (!b->have_sites) { fzp_set_error("association table needs het-call sites"); return FZP_EINVAL; }
+    FZP_TRY(b->setq.alloc((size_t)b->n_rows));
+    FZP_TRY(b->set_n.alloc((size_t)b->n_sites * 4));   // [0,2n): set_n, [2n,4n): set_off
+    if (b->n_sites > 0) {
+        ProfScope ps(ctx, "k3_site_sets");
+        hipLaunchKernelGGL(k_site_sets, dim3(grid_for(b->n_sites * 2, 4, 1 << 30)), dim3(256), 0, st, b->sites.p, b->n_sites, b->vmap_qid.p,
+                           b->setq.p, b->set_n.p, b->set_n.p + 2 * b->n_sites);
+    }
+    FZP_HIP(hipGetLastError());
+    b->have_sets = true;
+    return FZP_OK;
+}
+
+int fzp_k3_assoc(fzp_ctx *ctx, fzp_batch *b) {
+    hipStream_t st = ctx->stream;
+    if (!b->have_sets) FZP_TRY(fzp_k3_sets(ctx, b));
+    const int64_t ns = b->n_sites;
+    FZP_TRY(b->totals.alloc(8));
+    FZP_TRY(b->cand_n.alloc((size_t)ns));
+    FZP_TRY(b->cap_off.alloc((size_t)ns));
+    FZP_TRY(b->nkept.alloc((size_t)ns));
+    FZP_TRY(b->kept_off.alloc((size_t)ns));
+    FZP_TRY(b->arow_begin.alloc((size_t)b->n_ctg + 1));
+    uint64_t tot[1] = {0};
+    if (ns > 0) {
+        hipLaunchKernelGGL(k_cand, dim3(grid_for(ns, 256, 1 << 30)), dim3(256), 0, st, b->site_g.p, b->site_ctg.p, b->site_begin.p, ns, b->cand_n.p, b->cap_off.p);
+        FZP_TRY(fzp_exclusive_scan_u32(ctx, b->cap_off.p, b->cap_off.p, (size_t)ns, b->totals.p + 2));
+        FZP_HIP(hipMemcpyAsync(tot, b->totals.p + 2, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+        FZP_HIP(hipStreamSynchronize(st));
+        if (tot[0] >= (1ull << 31)) { fzp_set_error("association table bound %llu rows (> 2^31)", (unsigned long long)tot[0]); return FZP_EINVAL; }
+        FZP_TRY(b->arows_tmp.alloc((size_t)tot[0]));
+        {
+            ProfScope ps(ctx, "k3_assoc");
+            hipLaunchKernelGGL(k_assoc, dim3(grid_for(ns, 4, 1 << 16)), dim3(256), 0, st, ns, b->cand_n.p, b->cap_off.p, b->setq.p, b->set_n.p,
+                               b->set_n.p + 2 * ns, b->arows_tmp.p, b->nkept.p);
+        }
+        FZP_TRY(fzp_exclusive_scan_u32(ctx, b->nkept.p, b->kept_off.p, (size_t)ns, b->totals.p + 3));
+        FZP_HIP(hipMemcpyAsync(tot, b->totals.p + 3, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+        FZP_HIP(hipStreamSynchronize(st));
+        b->n_arows = (int64_t)tot[0];
+        FZP_TRY(b->arows.alloc((size_t)b->n_arows));
+        {
+            ProfScope ps(ctx, "k3_assoc_compact");
+            hipLaunchKernelGGL(k_assoc_compact, dim3(grid_for(ns, 4, 1 << 30)), dim3(256), 0, st, ns, b->cap_off.p, b->nkept.p, b->kept_off.p,
+                               b->arows_tmp.p, b->arows.p);
+        }
+    } else {
+        b->n_arows = 0;
+        FZP_TRY(b->arows.alloc(0));
+    }
+    hipLaunchKernelGGL(k_arow_begin, dim3((b->n_ctg + 1 + 63) / 64), dim3(64), 0, st, b->kept_off.p, b->site_begin.p, b->n_ctg, ns, b->n_arows, b->arow_begin.p);
+    b->h_arow_begin.resize((size_t)b->n_ctg + 1);
+    FZP_TRY(b->arow_begin.download(b->h_arow_begin.data(), (size_t)b->n_ctg + 1, st));
+    FZP_HIP(hipStreamSynchronize(st));
+    FZP_HIP(hipGetLastError());
+    b->have_arows = true;
+    return FZP_OK;
+}

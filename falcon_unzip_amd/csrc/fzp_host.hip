@@ -1,0 +1,562 @@
+// fzp_host.hip -- host side of libfzphase.so: context, errors, profiling, the SAM record parser
+// (phasing.py:42-75), the text serializers (the reference's `print >>f` statements) and
+// get_phasing_readmap (phasing_readmap.py:8-51, pure host bookkeeping).
+#include <algorithm>
+#include <unordered_map>
+
+#include "fzp_common.h"
+
+static thread_local char g_err[1024] = "";
+
+void fzp_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *fzp_last_error(void) { return g_err; }
+extern "C" const char *fzp_version(void) { return "fzphase 0.1.0 (gfx950)"; }
+extern "C" void fzp_free(void *p) { free(p); }
+
+// ---------------------------------------------------------------- context
+extern "C" int fzp_ctx_create(int device_id, unsigned flags, fzp_ctx **out) {
+    (void)flags;
+    if (!out) return FZP_EINVAL;
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        fzp_set_error("no HIP device available (%s); libfzphase has no CPU fallback",
+                      e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+        return FZP_ENODEVICE;
+    }
+    if (device_id < 0 || device_id >= n) {
+        fzp_set_error("device_id %d out of range (have %d)", device_id, n);
+        return FZP_EINVAL;
+    }
+    FZP_HIP(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    FZP_HIP(hipGetDeviceProperties(&prop, device_id));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        fzp_set_error("device %d is %s; libfzphase carries gfx950 code objects only", device_id, prop.gcnArchName);
+        return FZP_ENODEVICE;
+    }
+    fzp_ctx *c = new fzp_ctx();
+    c->device = device_id;
+    c->n_cu = prop.multiProcessorCount;
+    hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (se != hipSuccess) {
+        fzp_set_error("hipStreamCreate: %s", hipGetErrorString(se));
+        delete c;
+        return FZP_EDEVICE;
+    }
+    *out = c;
+    return FZP_OK;
+}
+
+extern "C" void fzp_ctx_destroy(fzp_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &p : ctx->pending) {
+        (void)hipEventDestroy(p.a);
+        (void)hipEventDestroy(p.b);
+    }
+    for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    for (auto &b : ctx->scan_tmp) b.release();
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int fzp_ctx_synchronize(fzp_ctx *ctx) {
+    FZP_HIP(hipStreamSynchronize(ctx->stream));
+    return FZP_OK;
+}
+
+// ---------------------------------------------------------------- profiling
+static hipEvent_t get_event(fzp_ctx *c) {
+    if (!c->event_pool.empty()) {
+        hipEvent_t e = c->event_pool.back();
+        c->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+ProfScope::ProfScope(fzp_ctx *ctx, const char *name) : c(ctx), on(ctx->prof) {
+    if (!on) return;
+    ev.name = name;
+    ev.a = get_event(c);
+    ev.b = get_event(c);
+    (void)hipEventRecord(ev.a, c->stream);
+}
+ProfScope::~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(ev.b, c->stream);
+    c->pending.push_back(ev);
+}
+int fzp_prof_flush(fzp_ctx *ctx) {
+    if (ctx->pending.empty()) return FZP_OK;
+    FZP_HIP(hipStreamSynchronize(ctx->stream));
+    for (auto &p : ctx->pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            auto &e = ctx->prof_tab[p.name];
+            e.ms += ms;
+            e.launches += 1;
+        }
+        ctx->event_pool.push_back(p.a);
+        ctx->event_pool.push_back(p.b);
+    }
+    ctx->pending.clear();
+    return FZP_OK;
+}
+extern "C" int fzp_prof_enable(fzp_ctx *ctx, int on) {
+    FZP_TRY(fzp_prof_flush(ctx));
+    ctx->prof = on != 0;
+    return FZP_OK;
+}
+extern "C" int fzp_prof_reset(fzp_ctx *ctx) {
+    FZP_TRY(fzp_prof_flush(ctx));
+    ctx->prof_tab.clear();
+    return FZP_OK;
+}
+extern "C" int fzp_prof_get(fzp_ctx *ctx, const char *name, double *total_ms, int64_t *launches) {
+    FZP_TRY(fzp_prof_flush(ctx));
+    auto it = ctx->prof_tab.find(name);
+    if (total_ms) *total_ms = it == ctx->prof_tab.end() ? 0.0 : it->second.ms;
+    if (launches) *launches = it == ctx->prof_tab.end() ? 0 : it->second.launches;
+    return FZP_OK;
+}
+extern "C" int fzp_prof_names(fzp_ctx *ctx, char **out) {
+    FZP_TRY(fzp_prof_flush(ctx));
+    std::string s;
+    for (auto &kv : ctx->prof_tab) s += kv.first + "\n";
+    *out = (char *)malloc(s.size() + 1);
+    memcpy(*out, s.c_str(), s.size() + 1);
+    return FZP_OK;
+}
+
+// ---------------------------------------------------------------- growing text buffer
+struct TextBuf {
+    char *p = nullptr;
+    size_t n = 0, cap = 0;
+    bool reserve(size_t extra) {
+        if (n + extra + 1 <= cap) return true;
+        size_t nc = cap ? cap * 2 : 1 << 16;
+        while (nc < n + extra + 1) nc *= 2;
+        char *q = (char *)realloc(p, nc);
+        if (!q) return false;
+        p = q;
+        cap = nc;
+        return true;
+    }
+    inline void putc_(char c) { p[n++] = c; }
+    inline void puti(long long v) {   // caller reserved >= 21 bytes
+        char t[24];
+        int k = 0;
+        bool neg = v < 0;
+        unsigned long long u = neg ? 0ULL - (unsigned long long)v : (unsigned long long)v;
+        do { t[k++] = (char)('0' + u % 10); u /= 10; } while (u);
+        if (neg) p[n++] = '-';
+        while (k) p[n++] = t[--k];
+    }
+    inline void put(const char *s, size_t len) { memcpy(p + n, s, len); n += len; }
+    int finish(char **text, size_t *len) {
+        if (!reserve(1)) return FZP_ENOMEM;
+        p[n] = 0;
+        *text = p;
+        *len = n;
+        return FZP_OK;
+    }
+};
+
+// ---------------------------------------------------------------- SAM parser (phasing.py:42-75)
+namespace {
+inline bool is_ws(char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\f' || c == '\v'; }
+struct Tok { const char *s; size_t n; };
+int split_ws(const char *l, size_t n, Tok *t, int maxt) {
+    int k = 0;
+    size_t i = 0;
+    while (i < n) {
+        while (i < n && is_ws(l[i])) i++;
+        if (i >= n) break;
+        size_t j = i;
+        while (j < n && !is_ws(l[j])) j++;
+        if (k < maxt) t[k] = {l + i, j - i};
+        k++;
+        i = j;
+    }
+    return k;
+}
+bool tok_int(Tok t, long long *v) {
+    if (t.n == 0 || t.n > 19) return false;
+    size_t i = 0;
+    bool neg = false;
+    if (t.s[0] == '-' || t.s[0] == '+') { neg = t.s[0] == '-'; i = 1; }
+    if (i == t.n) return false;
+    long long x = 0;
+    for (; i < t.n; i++) {
+        if (t.s[i] < '0' || t.s[i] > '9') return false;
+        x = x * 10 + (t.s[i] - '0');
+    }
+    *v = neg ? -x : x;
+    return true;
+}
+inline int op_code(char c) {
+    switch (c) {
+        case 'M': return FZP_OP_M;
+        case 'I': return FZP_OP_I;
+        case 'D': return FZP_OP_D;
+        case 'N': return FZP_OP_N;
+        case 'S': return FZP_OP_S;
+        case 'H': return FZP_OP_H;
+        case 'P': return FZP_OP_P;
+        case '=': return FZP_OP_EQ;
+        case 'X': return FZP_OP_X;
+    }
+    return -1;
+}
+// finditer over r"(\d+)([MIDNSHP=X])" (phasing.py:12): digits not followed by an op letter are skipped
+bool cigar_next(const char *c, size_t n, size_t *i, long long *adv, int *op) {
+    size_t k = *i;
+    while (k < n) {
+        if (c[k] < '0' || c[k] > '9') { k++; continue; }
+        long long v = 0;
+        while (k < n && c[k] >= '0' && c[k] <= '9') { v = v * 10 + (c[k] - '0'); k++; }
+        if (k < n) {
+            int o = op_code(c[k]);
+            if (o >= 0) { *adv = v; *op = o; *i = k + 1; return true; }
+        }
+    }
+    *i = n;
+    return false;
+}
+template <class T>
+T *dup_vec(const std::vector<T> &v) {
+    T *p = (T *)malloc((v.size() ? v.size() : 1) * sizeof(T));
+    if (p && !v.empty()) memcpy(p, v.data(), v.size() * sizeof(T));
+    return p;
+}
+}  // namespace
+
+extern "C" void fzp_alnset_free(fzp_alnset *a) {
+    if (!a) return;
+    free(a->rec_qid); free(a->rec_pos); free(a->cig_off); free(a->cigar); free(a->seq_off); free(a->seq);
+    free(a->qname_off); free(a->qnames);
+    free(a);
+}
+
+extern "C" int fzp_parse_sam(const char *sam, size_t len, fzp_alnset **out) {
+    if (!out || (!sam && len)) return FZP_EINVAL;
+    *out = nullptr;
+    std::vector<int32_t> rec_qid, rec_pos;
+    std::vector<int64_t> cig_off{0}, seq_off{0}, qname_off{0};
+    std::vector<uint32_t> cigar;
+    std::vector<uint8_t> seq;
+    std::string qnames;
+    std::unordered_map<std::string, int32_t> name_to_id;
+    int32_t last_pos = -1, max_span = 0;
+    int64_t n_columns = 0;
+    size_t off = 0;
+    long long line_no = 0;
+    while (off < len) {
+        const char *l = sam + off;
+        const char *e = (const char *)memchr(l, '\n', len - off);
+        size_t ln = e ? (size_t)(e - l) : len - off;
+        off += ln + (e ? 1 : 0);
+        line_no++;
+        Tok t[11];
+        int nt = split_ws(l, ln, t, 11);
+        if (nt == 0) { fzp_set_error("SAM line %lld is empty (reference: IndexError)", line_no); return FZP_EINVAL; }
+        if (t[0].s[0] == '@') continue;                                  // phasing.py:44-45
+        if (nt < 10) { fzp_set_error("SAM line %lld has %d fields", line_no, nt); return FZP_EINVAL; }
+        // phasing.py:47-54: q_id by first appearance, assigned BEFORE any filter
+        std::string qn(t[0].s, t[0].n);
+        auto it = name_to_id.find(qn);
+        int32_t q_id;
+        if (it == name_to_id.end()) {
+            q_id = (int32_t)name_to_id.size();
+            name_to_id.emplace(qn, q_id);
+            qnames += qn;
+            qname_off.push_back((int64_t)qnames.size());
+        } else q_id = it->second;
+        long long flag, pos1;
+        if (!tok_int(t[1], &flag) || !tok_int(t[3], &pos1)) { fzp_set_error("SAM line %lld: bad FLAG/POS", line_no); return FZP_EINVAL; }
+        long long POS = pos1 - 1;                                        // phasing.py:57
+        const char *cg = t[5].s; size_t cn = t[5].n;
+        // phasing.py:63-75
+        long long skip_base = 0, total_aln_pos = 0, adv; int op; size_t ci = 0;
+        while (cigar_next(cg, cn, &ci, &adv, &op)) { total_aln_pos += adv; if (op == FZP_OP_S) skip_base += adv; }
+        if (total_aln_pos == 0) { fzp_set_error("SAM line %lld: CIGAR has no ops (reference: ZeroDivisionError)", line_no); return FZP_EZERODIV; }
+        if (1.0 - 1.0 * (double)skip_base / (double)total_aln_pos < 0.1) continue;   // IEEE double, as written
+        if (total_aln_pos < 2000) continue;
+        if (POS < 0 || POS > 0x7ffffff0LL) { fzp_set_error("SAM line %lld: POS out of range", line_no); return FZP_EINVAL; }
+        if (POS < last_pos) {
+            fzp_set_error("SAM line %lld: POS %lld after %d -- input is not coordinate-sorted", line_no, POS + 1, last_pos + 1);
+            return FZP_EUNSORTED;
+        }
+        // ops are stored verbatim; the walk semantics (phasing.py:77-96) live in the kernels
+        long long rp = 0, qp = 0, cols = 0; ci = 0;
+        size_t sn = t[9].n;
+        while (cigar_next(cg, cn, &ci, &adv, &op)) {
+            if (adv >= (1LL << 28)) { fzp_set_error("SAM line %lld: CIGAR op length too large", line_no); return FZP_EINVAL; }
+            if (op == FZP_OP_S || op == FZP_OP_I) qp += adv;
+            else if (op == FZP_OP_M || op == FZP_OP_EQ || op == FZP_OP_X) { qp += adv; rp += adv; cols += adv; if ((size_t)qp > sn) { fzp_set_error("SAM line %lld: CIGAR consumes more bases than SEQ holds (reference: IndexError)", line_no); return FZP_EINVAL; } }
+            else if (op == FZP_OP_D) rp += adv;
+            if (adv > 0) cigar.push_back((uint32_t)(adv << 4) | (uint32_t)op);
+        }
+        if (POS + rp > 0x7ffffff0LL) { fzp_set_error("SAM line %lld: alignment runs past 2^31", line_no); return FZP_EINVAL; }
+        rec_qid.push_back(q_id);
+        rec_pos.push_back((int32_t)POS);
+        cig_off.push_back((int64_t)cigar.size());
+        seq.insert(seq.end(), (const uint8_t *)t[9].s, (const uint8_t *)t[9].s + sn);
+        seq_off.push_back((int64_t)seq.size());
+        last_pos = (int32_t)POS;
+        if (rp > max_span) max_span = (int32_t)rp;
+        n_columns += cols;
+    }
+    fzp_alnset *a = (fzp_alnset *)calloc(1, sizeof(fzp_alnset));
+    if (!a) return FZP_ENOMEM;
+    a->n_rec = (int64_t)rec_qid.size();
+    a->rec_qid = dup_vec(rec_qid); a->rec_pos = dup_vec(rec_pos);
+    a->cig_off = dup_vec(cig_off); a->cigar = dup_vec(cigar);
+    a->seq_off = dup_vec(seq_off); a->seq = dup_vec(seq);
+    a->n_qid = (int32_t)name_to_id.size();
+    a->qname_off = dup_vec(qname_off);
+    a->qnames = (char *)malloc(qnames.size() + 1);
+    if (a->qnames) memcpy(a->qnames, qnames.c_str(), qnames.size() + 1);
+    a->last_pos = last_pos;
+    a->max_ref_span = max_span;
+    a->n_columns = n_columns;
+    if (!a->rec_qid || !a->rec_pos || !a->cig_off || !a->cigar || !a->seq_off || !a->seq || !a->qname_off || !a->qnames) {
+        fzp_alnset_free(a);
+        return FZP_ENOMEM;
+    }
+    *out = a;
+    return FZP_OK;
+}
+
+extern "C" void fzp_result_free(fzp_result *r) {
+    if (!r) return;
+    free(r->sites); free(r->vmap_qid); free(r->arows); free(r->pvars); free(r->preads);
+    memset(r, 0, sizeof *r);
+}
+
+// ---------------------------------------------------------------- serializers
+extern "C" int fzp_format_variant_pos(const fzp_site *s, int64_t n, char **text, size_t *len) {
+    TextBuf b;
+    for (int64_t i = 0; i < n; i++) {                                    // phasing.py:124
+        if (!b.reserve(160)) return FZP_ENOMEM;
+        b.puti((long long)s[i].pos + 1); b.putc_(' '); b.putc_((char)s[i].ref_base); b.putc_(' '); b.puti(s[i].total);
+        for (int k = 0; k < 4; k++) { b.putc_(' '); b.putc_((char)s[i].base[k]); b.putc_(' '); b.puti(s[i].count[k]); }
+        b.putc_('\n');
+    }
+    return b.finish(text, len);
+}
+
+extern "C" int fzp_format_variant_map(const fzp_site *s, int64_t n, const int32_t *q, char **text, size_t *len) {
+    TextBuf b;
+    for (int64_t i = 0; i < n; i++) {                                    // phasing.py:125-128
+        int64_t r = s[i].row_off;
+        for (int a = 0; a < 2; a++)
+            for (int32_t k = 0; k < s[i].count[a]; k++, r++) {
+                if (!b.reserve(64)) return FZP_ENOMEM;
+                b.puti((long long)s[i].pos + 1); b.putc_(' '); b.putc_((char)s[i].ref_base); b.putc_(' ');
+                b.putc_((char)s[i].base[a]); b.putc_(' '); b.puti(q[r]); b.putc_('\n');
+            }
+    }
+    return b.finish(text, len);
+}
+
+extern "C" int fzp_format_q_id_map(const fzp_alnset *a, char **text, size_t *len) {
+    TextBuf b;
+    for (int32_t q = 0; q < a->n_qid; q++) {                             // phasing.py:132-134
+        size_t nl = (size_t)(a->qname_off[q + 1] - a->qname_off[q]);
+        if (!b.reserve(nl + 32)) return FZP_ENOMEM;
+        b.puti(q); b.putc_(' '); b.put(a->qnames + a->qname_off[q], nl); b.putc_('\n');
+    }
+    return b.finish(text, len);
+}
+
+static inline void actg_pair(const fzp_site &s, char *x, char *y) {
+    // the two alleles in CPython-2.7 dict order A < C < T < G (phasing.py:175,181)
+    char a = (char)s.base[0], c = (char)s.base[1];
+    if (py2_rank((uint8_t)a) < py2_rank((uint8_t)c)) { *x = a; *y = c; } else { *x = c; *y = a; }
+}
+
+extern "C" int fzp_format_atable(const fzp_site *s, const fzp_arow *r, int64_t n, char **text, size_t *len) {
+    TextBuf b;
+    for (int64_t i = 0; i < n; i++) {                                    // phasing.py:199
+        if (!b.reserve(160)) return FZP_ENOMEM;
+        char b11, b12, b21, b22;
+        actg_pair(s[r[i].site1], &b11, &b12);
+        actg_pair(s[r[i].site2], &b21, &b22);
+        b.puti((long long)s[r[i].site1].pos + 1); b.putc_(' '); b.putc_(b11); b.putc_(' '); b.putc_(b12); b.putc_(' ');
+        b.puti((long long)s[r[i].site2].pos + 1); b.putc_(' '); b.putc_(b21); b.putc_(' '); b.putc_(b22);
+        for (int k = 0; k < 4; k++) { b.putc_(' '); b.puti(r[i].n[k]); }
+        b.putc_('\n');
+    }
+    return b.finish(text, len);
+}
+
+extern "C" int fzp_format_phased_variants(const fzp_site *s, const fzp_pvar *v, int64_t n, char **text, size_t *len) {
+    TextBuf b;
+    int64_t i = 0;
+    while (i < n) {                                                      // phasing.py:411-421
+        int64_t j = i;
+        long long mn = 0, mx = 0;
+        while (j < n && v[j].block == v[i].block) {
+            long long p = (long long)s[v[j].site].pos + 1;
+            if (j == i || p < mn) mn = p;
+            if (j == i || p > mx) mx = p;
+            j++;
+        }
+        long long cnt = j - i;
+        if (!b.reserve(200)) return FZP_ENOMEM;
+        b.put("P ", 2); b.puti(v[i].block); b.putc_(' '); b.puti(mn); b.putc_(' '); b.puti(mx); b.putc_(' ');
+        b.puti(mx - mn); b.putc_(' '); b.puti(cnt); b.putc_(' ');
+        {   // Python-2 `print` of a float: '%.12g', plus '.0' when that looks like an int
+            char t[64];
+            snprintf(t, sizeof t, "%.12g", 1.0 * (double)(mx - mn) / (double)cnt);
+            if (!strpbrk(t, ".enN")) strcat(t, ".0");
+            b.put(t, strlen(t));
+        }
+        b.putc_('\n');
+        for (int64_t k = i; k < j; k++) {
+            if (!b.reserve(200)) return FZP_ENOMEM;
+            long long p = (long long)s[v[k].site].pos + 1;
+            char rb = (char)s[v[k].site].ref_base;
+            b.put("V ", 2); b.puti(v[k].block); b.putc_(' '); b.puti(p); b.putc_(' ');
+            b.puti(p); b.putc_('_'); b.putc_(rb); b.putc_('_'); b.putc_((char)v[k].b1); b.putc_(' ');
+            b.puti(p); b.putc_('_'); b.putc_(rb); b.putc_('_'); b.putc_((char)v[k].b2); b.putc_(' ');
+            b.puti(v[k].lext); b.putc_(' '); b.puti(v[k].rext); b.putc_(' '); b.puti(v[k].lscore); b.putc_(' '); b.puti(v[k].rscore);
+            b.putc_('\n');
+        }
+        i = j;
+    }
+    return b.finish(text, len);
+}
+
+extern "C" int fzp_format_phased_reads(const fzp_pread *r, int64_t n, const char *ctg_id, const int64_t *qname_off,
+                                       const char *qnames, int32_t n_qid, char **text, size_t *len) {
+    TextBuf b;
+    size_t cn = strlen(ctg_id);
+    for (int64_t i = 0; i < n; i++) {                                    // phasing.py:478-480
+        if (r[i].q_id < 0 || r[i].q_id >= n_qid) { free(b.p); fzp_set_error("phased read q_id %d not in q_id_map (reference: KeyError)", r[i].q_id); return FZP_EINVAL; }
+        size_t nl = (size_t)(qname_off[r[i].q_id + 1] - qname_off[r[i].q_id]);
+        if (!b.reserve(cn + nl + 128)) return FZP_ENOMEM;
+        b.puti(r[i].q_id); b.putc_(' '); b.put(ctg_id, cn); b.putc_(' '); b.puti(r[i].block); b.putc_(' '); b.puti(r[i].phase); b.putc_(' ');
+        b.puti(r[i].n0); b.putc_(' '); b.puti(r[i].n1); b.putc_(' '); b.put(qnames + qname_off[r[i].q_id], nl); b.putc_('\n');
+    }
+    return b.finish(text, len);
+}
+
+extern "C" int fzp_format_sam(const fzp_alnset *a, const char *ctg_id, const int32_t *flags, char **text, size_t *len) {
+    TextBuf b;
+    size_t cn = strlen(ctg_id);
+    static const char OPS[] = "MIDNSHP=X";
+    for (int64_t r = 0; r < a->n_rec; r++) {
+        int32_t q = a->rec_qid[r];
+        size_t nl = (size_t)(a->qname_off[q + 1] - a->qname_off[q]);
+        size_t sl = (size_t)(a->seq_off[r + 1] - a->seq_off[r]);
+        size_t nc = (size_t)(a->cig_off[r + 1] - a->cig_off[r]);
+        if (!b.reserve(nl + cn + sl + nc * 12 + 128)) return FZP_ENOMEM;
+        b.put(a->qnames + a->qname_off[q], nl); b.putc_('\t'); b.puti(flags ? flags[r] : 0); b.putc_('\t'); b.put(ctg_id, cn); b.putc_('\t');
+        b.puti((long long)a->rec_pos[r] + 1); b.put("\t254\t", 5);
+        for (int64_t k = a->cig_off[r]; k < a->cig_off[r + 1]; k++) { b.puti(a->cigar[k] >> 4); b.putc_(OPS[a->cigar[k] & 15]); }
+        b.put("\t*\t0\t0\t", 7); b.put((const char *)a->seq + a->seq_off[r], sl); b.put("\t*\n", 3);
+    }
+    return b.finish(text, len);
+}
+
+// ---------------------------------------------------------------- get_phasing_readmap (phasing_readmap.py:8-51)
+namespace {
+void split_nl(const char *s, size_t n, std::vector<Tok> &out) {   // text.split('\n')
+    size_t i = 0;
+    for (;;) {
+        const char *e = (const char *)memchr(s + i, '\n', n - i);
+        size_t ln = e ? (size_t)(e - (s + i)) : n - i;
+        out.push_back({s + i, ln});
+        if (!e) break;
+        i += ln + 1;
+    }
+}
+}  // namespace
+
+extern "C" int fzp_readmap(const char *phased_reads, size_t pr_len, const char *rawread_ids, size_t rr_len,
+                           const char *pread_ids, size_t pi_len, const char *p2c, size_t pc_len,
+                           const char *ctg_id, int32_t ctg_index, fzp_r2p **recs, int64_t *n_recs, char **text, size_t *len) {
+    std::vector<Tok> rid_to_oid, pid_to_fid;
+    split_nl(rawread_ids ? rawread_ids : "", rr_len, rid_to_oid);        // lines 17-18
+    split_nl(pread_ids ? pread_ids : "", pi_len, pid_to_fid);
+    std::unordered_map<std::string, std::pair<int, int>> rid_to_phase;   // lines 29-33, last line wins
+    size_t off = 0;
+    while (off < pr_len) {
+        const char *l = phased_reads + off;
+        const char *e = (const char *)memchr(l, '\n', pr_len - off);
+        size_t ln = e ? (size_t)(e - l) : pr_len - off;
+        off += ln + (e ? 1 : 0);
+        Tok t[7];
+        if (split_ws(l, ln, t, 7) < 7) { fzp_set_error("phased_reads: short row"); return FZP_EINVAL; }
+        long long bk, ph;
+        if (!tok_int(t[2], &bk) || !tok_int(t[3], &ph)) { fzp_set_error("phased_reads: bad block/phase"); return FZP_EINVAL; }
+        rid_to_phase[std::string(t[6].s, t[6].n)] = {(int)bk, (int)ph};
+    }
+    size_t cn = strlen(ctg_id);
+    std::unordered_map<long long, std::pair<int, int>> arid_to_phase;    // keyed by pread id ('%09d' is injective)
+    off = 0;
+    while (off < pc_len) {
+        const char *l = p2c + off;
+        const char *e = (const char *)memchr(l, '\n', pc_len - off);
+        size_t ln = e ? (size_t)(e - l) : pc_len - off;
+        off += ln + (e ? 1 : 0);
+        Tok t[4];
+        int nt = split_ws(l, ln, t, 4);
+        if (nt < 2) { fzp_set_error("pread_to_contigs: short row"); return FZP_EINVAL; }
+        if (!(t[1].n >= cn && memcmp(t[1].s, ctg_id, cn) == 0)) continue;            // startswith, line 41
+        long long rank, pid;
+        if (nt < 4 || !tok_int(t[3], &rank)) { fzp_set_error("pread_to_contigs: bad rank"); return FZP_EINVAL; }
+        if (rank != 0) continue;                                                      // line 43
+        if (!tok_int(t[0], &pid) || pid < 0 || (size_t)pid >= pid_to_fid.size() || pid > 0x7fffffffLL) { fzp_set_error("pread_to_contigs: pread id out of range"); return FZP_EINVAL; }
+        Tok fid = pid_to_fid[(size_t)pid];                                            // lines 20-23
+        const char *s1 = (const char *)memchr(fid.s, '/', fid.n);
+        if (!s1) { fzp_set_error("pread_ids: '%.*s' has no '/'", (int)fid.n, fid.s); return FZP_EINVAL; }
+        s1++;
+        size_t rem = fid.n - (size_t)(s1 - fid.s);
+        const char *s2 = (const char *)memchr(s1, '/', rem);
+        Tok mid = {s1, s2 ? (size_t)(s2 - s1) : rem};
+        long long raw;
+        if (!tok_int(mid, &raw) || raw < 0) { fzp_set_error("pread_ids: bad raw-read field"); return FZP_EINVAL; }
+        raw /= 10;                                                                    // py2 int division
+        if ((size_t)raw >= rid_to_oid.size()) { fzp_set_error("rawread_ids: id %lld out of range", raw); return FZP_EINVAL; }
+        Tok oid = rid_to_oid[(size_t)raw];
+        auto it = rid_to_phase.find(std::string(oid.s, oid.n));
+        arid_to_phase[pid] = it == rid_to_phase.end() ? std::pair<int, int>{-1, 0} : it->second;   // line 46
+    }
+    // canonical order: ascending '%09d' string == ascending pread id below 10^9 (py2 dict order is unspecified)
+    std::vector<std::pair<std::string, std::pair<long long, std::pair<int, int>>>> rows;
+    rows.reserve(arid_to_phase.size());
+    for (auto &kv : arid_to_phase) {
+        char key[32];
+        snprintf(key, sizeof key, "%09lld", kv.first);
+        rows.push_back({key, {kv.first, kv.second}});
+    }
+    std::sort(rows.begin(), rows.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+    TextBuf b;
+    fzp_r2p *rr = (fzp_r2p *)malloc((rows.size() ? rows.size() : 1) * sizeof(fzp_r2p));
+    if (!rr) return FZP_ENOMEM;
+    for (size_t i = 0; i < rows.size(); i++) {                                        // lines 49-51
+        if (!b.reserve(cn + 80)) { free(rr); return FZP_ENOMEM; }
+        b.put(rows[i].first.c_str(), rows[i].first.size()); b.putc_(' '); b.put(ctg_id, cn); b.putc_(' ');
+        b.puti(rows[i].second.second.first); b.putc_(' '); b.puti(rows[i].second.second.second); b.putc_('\n');
+        rr[i] = {(int32_t)rows[i].second.first, ctg_index, rows[i].second.second.first, rows[i].second.second.second};
+    }
+    if (recs) *recs = rr; else free(rr);
+    if (n_recs) *n_recs = (int64_t)rows.size();
+    if (text) return b.finish(text, len);
+    free(b.p);
+    return FZP_OK;
+}

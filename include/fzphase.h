@@ -1,0 +1,239 @@
+/*
+ * fzphase.h -- C-ABI of libfzphase.so, the MI355X (gfx950) phasing engine behind FALCON_unzip's
+ * per-contig task interface.
+ *
+ * The reference (PacificBiosciences/FALCON_unzip, /root/reference) has no FFI: its boundary is
+ * process + files.  Each entry point below therefore replaces the BODY of one
+ * reference task function and exchanges the same records that function reads/writes as text;
+ * the text formats themselves are produced by the fzp_format_* serializers, byte-for-byte.
+ *
+ *   entry point             replaces (reference file:line)
+ *   ----------------------  ---------------------------------------------------------------
+ *   fzp_parse_sam           falcon_unzip/phasing.py:42-75   (SAM text -> q_id, filters, CIGAR)
+ *   fzp_het_call            falcon_unzip/phasing.py:14-135  make_het_call
+ *   fzp_assoc_table         falcon_unzip/phasing.py:137-206 generate_association_table
+ *   fzp_phase_blocks        falcon_unzip/phasing.py:208-421 get_score + get_phased_blocks
+ *   fzp_phase_reads         falcon_unzip/phasing.py:423-480 get_phased_reads
+ *   fzp_batch_*             falcon_unzip/phasing.py:482-553 phasing() chain, many contigs per launch
+ *   fzp_readmap             falcon_unzip/phasing_readmap.py:8-51 get_phasing_readmap
+ *   fzp_align_*             falcon_unzip/unzip.py:61-99     task_run_blasr (blasr + samtools sort;
+ *                                                           own aligner spec, parity unpinned)
+ *   fzp_format_*            the `print >>f` statements at phasing.py:124-134,199,418-421,478-480
+ *                           and phasing_readmap.py:49-51
+ *
+ * Conventions: plain C, no exceptions cross the boundary; every function returns FZP_OK (0) or a
+ * negative FZP_E* code and records a message readable through fzp_last_error() (thread-local).
+ * Inputs are caller-owned host buffers; outputs are library-allocated host buffers released with
+ * fzp_free() (or the matching *_free).  One fzp_ctx per (process, device); a ctx is not
+ * thread-safe, different ctxs are independent.  All compute runs in HIP kernels on the ctx's
+ * device: there is NO CPU fallback -- without a usable gfx950 device fzp_ctx_create fails.
+ */
+#ifndef FZPHASE_H
+#define FZPHASE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FZP_OK 0
+#define FZP_EINVAL (-1)     /* malformed input (where the reference raises IndexError/KeyError/ValueError) */
+#define FZP_EZERODIV (-2)   /* CIGAR without ops: ZeroDivisionError at phasing.py:72 */
+#define FZP_ENOMEM (-3)
+#define FZP_EUNSORTED (-4)  /* accepted records not sorted by POS: reference behaviour is order-dependent
+                               (`--bam path to sorted bam file`, phasing.py:562); refused */
+#define FZP_EDEVICE (-5)    /* HIP runtime error */
+#define FZP_ENODEVICE (-6)  /* no gfx950 device / library built without device code */
+
+/* BAM CIGAR op numbering; a cigar word is  len << 4 | op  */
+enum { FZP_OP_M = 0, FZP_OP_I = 1, FZP_OP_D = 2, FZP_OP_N = 3, FZP_OP_S = 4, FZP_OP_H = 5, FZP_OP_P = 6,
+       FZP_OP_EQ = 7, FZP_OP_X = 8 };
+
+typedef struct fzp_ctx fzp_ctx;
+
+const char *fzp_version(void);
+const char *fzp_last_error(void);
+void fzp_free(void *p);
+
+int fzp_ctx_create(int device_id, unsigned flags, fzp_ctx **out);
+void fzp_ctx_destroy(fzp_ctx *ctx);
+int fzp_ctx_synchronize(fzp_ctx *ctx);
+
+/* Per-kernel device timing (HIP events on the ctx stream).  fzp_prof_enable(ctx,1) starts
+ * collecting; fzp_prof_get returns the summed duration and launch count of kernel `name`
+ * since the last fzp_prof_reset.  Names: see DESIGN.md section 5. */
+int fzp_prof_enable(fzp_ctx *ctx, int on);
+int fzp_prof_reset(fzp_ctx *ctx);
+int fzp_prof_get(fzp_ctx *ctx, const char *name, double *total_ms, int64_t *launches);
+int fzp_prof_names(fzp_ctx *ctx, char **names_nl_separated);
+
+/* ---------------------------------------------------------------------------------------------
+ * Alignment records of ONE contig: what make_het_call extracts from `samtools view` text
+ * (phasing.py:42-75).  Only ACCEPTED records (those passing the two filters at phasing.py:72-75)
+ * are listed, in input order; the q_id table lists every QNAME seen, accepted or not.
+ * --------------------------------------------------------------------------------------------- */
+typedef struct {
+    int64_t n_rec;
+    int32_t *rec_qid;     /* [n_rec]   q_id = order of first appearance of QNAME (phasing.py:47-54) */
+    int32_t *rec_pos;     /* [n_rec]   0-based POS (phasing.py:57) */
+    int64_t *cig_off;     /* [n_rec+1] */
+    uint32_t *cigar;      /* [cig_off[n_rec]]  len<<4|op */
+    int64_t *seq_off;     /* [n_rec+1] */
+    uint8_t *seq;         /* [seq_off[n_rec]]  raw SEQ bytes, any symbol */
+    int32_t n_qid;
+    int64_t *qname_off;   /* [n_qid+1] */
+    char *qnames;         /* concatenated, no separators */
+    int32_t last_pos;     /* POS of the last accepted record, -1 if none: only positions < last_pos
+                             are ever evaluated (phasing.py:98-102, no final flush) */
+    int32_t max_ref_span; /* max over records of reference bases consumed */
+    int64_t n_columns;    /* total aligned columns (M,=,X bases) of accepted records */
+} fzp_alnset;
+
+/* SAM text (header lines allowed) -> records.  Host-side C++; mirrors phasing.py:42-75 incl. the
+ * IEEE-double clip filter.  FZP_EUNSORTED if accepted records are not POS-sorted. */
+int fzp_parse_sam(const char *sam, size_t len, fzp_alnset **out);
+void fzp_alnset_free(fzp_alnset *a);
+
+/* ---------------------------------------------------------------------------------------------
+ * Stage records
+ * --------------------------------------------------------------------------------------------- */
+typedef struct {           /* one variant_pos row (phasing.py:124) + where its variant_map rows are */
+    int32_t pos;           /* 0-based */
+    uint8_t ref_base;
+    uint8_t base[4];       /* ranked: count desc, ties larger letter first (phasing.py:116-117) */
+    uint8_t pad_[3];
+    int32_t total;
+    int32_t count[4];
+    int64_t row_off;       /* variant_map rows [row_off, row_off+count[0]) carry base[0],
+                              the next count[1] rows carry base[1] (phasing.py:125-128) */
+} fzp_site;
+
+typedef struct {           /* one atable row (phasing.py:199); alleles in A<C<T<G order (py2 dict order) */
+    int32_t site1, site2;  /* indices into the contig's fzp_site array */
+    int32_t n[4];          /* n11 n12 n21 n22 */
+} fzp_arow;
+
+typedef struct {           /* one 'V' line of phased_variants (phasing.py:421) */
+    int32_t block;         /* 1-based phase block id */
+    int32_t site;
+    uint8_t b1, b2;        /* phase-0 allele, phase-1 allele */
+    uint8_t pad_[2];
+    int32_t lext, rext;    /* 1-based positions, as printed */
+    int32_t lscore, rscore;
+} fzp_pvar;
+
+typedef struct {           /* one phased_reads row (phasing.py:478-480) */
+    int32_t q_id, block, phase, n0, n1;
+} fzp_pread;
+
+typedef struct {           /* everything phasing() produces for one contig */
+    int64_t n_sites;  fzp_site *sites;
+    int64_t n_rows;   int32_t *vmap_qid;      /* variant_map q_id column, grouped per fzp_site.row_off */
+    int64_t n_arows;  fzp_arow *arows;
+    int64_t n_pvars;  fzp_pvar *pvars;
+    int64_t n_preads; fzp_pread *preads;      /* ascending (q_id, block) */
+} fzp_result;
+void fzp_result_free(fzp_result *r);           /* frees the arrays, not the struct */
+
+/* ---------------------------------------------------------------------------------------------
+ * Single-contig stage entry points (host buffers in, host records out).  Each one uploads, runs
+ * the HIP kernels of that stage and downloads.  ref_seq is the upper-cased contig (phasing.py:494).
+ * --------------------------------------------------------------------------------------------- */
+int fzp_het_call(fzp_ctx *ctx, const fzp_alnset *aln, const uint8_t *ref_seq, int64_t ref_len,
+                 fzp_site **sites, int64_t *n_sites, int32_t **vmap_qid, int64_t *n_rows);
+int fzp_assoc_table(fzp_ctx *ctx, const fzp_site *sites, int64_t n_sites, const int32_t *vmap_qid, int64_t n_rows,
+                    fzp_arow **arows, int64_t *n_arows);
+int fzp_phase_blocks(fzp_ctx *ctx, const fzp_site *sites, int64_t n_sites, const fzp_arow *arows, int64_t n_arows,
+                     fzp_pvar **pvars, int64_t *n_pvars);
+int fzp_phase_reads(fzp_ctx *ctx, const fzp_site *sites, int64_t n_sites, const int32_t *vmap_qid, int64_t n_rows,
+                    const fzp_pvar *pvars, int64_t n_pvars, int32_t n_qid, fzp_pread **preads, int64_t *n_preads);
+
+/* ---------------------------------------------------------------------------------------------
+ * Many contigs per launch, inputs resident in HBM (the phasing() chain, phasing.py:482-553).
+ *   fzp_batch_create   uploads the records of n_ctg contigs (one alnset + one ref_seq each)
+ *   fzp_batch_run      K2..K5 over all contigs in batched launches; results stay on the device
+ *   fzp_batch_result   downloads contig `ctg`'s records
+ * --------------------------------------------------------------------------------------------- */
+typedef struct fzp_batch fzp_batch;
+#define FZP_STAGE_HET 1u
+#define FZP_STAGE_ASSOC 2u
+#define FZP_STAGE_BLOCKS 4u
+#define FZP_STAGE_READS 8u
+#define FZP_STAGE_ALL 15u
+int fzp_batch_create(fzp_ctx *ctx, int32_t n_ctg, const fzp_alnset *const *aln, const uint8_t *const *ref_seq,
+                     const int64_t *ref_len, fzp_batch **out);
+int fzp_batch_run(fzp_ctx *ctx, fzp_batch *b, unsigned stages);
+int fzp_batch_result(fzp_ctx *ctx, fzp_batch *b, int32_t ctg, fzp_result *out);
+int fzp_batch_counts(fzp_ctx *ctx, fzp_batch *b, int64_t *n_rec, int64_t *n_columns, int64_t *n_positions,
+                     int64_t *n_sites, int64_t *n_rows, int64_t *n_arows, int64_t *n_pvars, int64_t *n_preads);
+void fzp_batch_destroy(fzp_ctx *ctx, fzp_batch *b);
+
+/* ---------------------------------------------------------------------------------------------
+ * Text serializers: the reference's on-disk formats, byte-for-byte (Python-2 `print`).
+ * --------------------------------------------------------------------------------------------- */
+int fzp_format_variant_pos(const fzp_site *sites, int64_t n_sites, char **text, size_t *len);
+int fzp_format_variant_map(const fzp_site *sites, int64_t n_sites, const int32_t *vmap_qid, char **text, size_t *len);
+int fzp_format_q_id_map(const fzp_alnset *aln, char **text, size_t *len);
+int fzp_format_atable(const fzp_site *sites, const fzp_arow *arows, int64_t n_arows, char **text, size_t *len);
+int fzp_format_phased_variants(const fzp_site *sites, const fzp_pvar *pvars, int64_t n_pvars, char **text, size_t *len);
+int fzp_format_phased_reads(const fzp_pread *preads, int64_t n_preads, const char *ctg_id,
+                            const int64_t *qname_off, const char *qnames, int32_t n_qid, char **text, size_t *len);
+
+/* get_phasing_readmap (phasing_readmap.py:8-51): text in, `rid_to_phase.<ctg>` text out plus the
+ * 16-byte records the multi-GPU gather carries: (pread id, contig index, block, phase). */
+typedef struct { int32_t arid, ctg, block, phase; } fzp_r2p;
+int fzp_readmap(const char *phased_reads, size_t pr_len, const char *rawread_ids, size_t rr_len,
+                const char *pread_ids, size_t pi_len, const char *pread_to_contigs, size_t pc_len,
+                const char *ctg_id, int32_t ctg_index, fzp_r2p **recs, int64_t *n_recs, char **text, size_t *len);
+
+/* ---------------------------------------------------------------------------------------------
+ * K1: read -> contig banded alignment (role of blasr + samtools sort, unzip.py:86-91).
+ * Own deterministic spec: k-mer seeding, adaptive anti-diagonal band of 64
+ * cells, linear-gap scores, traceback to =/X/I/D/S CIGARs.  Parity vs blasr is UNPINNED; the
+ * kernel is bit-exact against its scalar CPU twin in oracle/align_oracle.c.
+ * --------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t kmer;            /* seed length (<=16), default 16 */
+    int32_t seed_stride;     /* query every seed_stride-th read k-mer, default 4 */
+    int32_t match, mismatch, gap;   /* scores: +match, -mismatch, -gap (defaults 2,4,3) */
+    int32_t min_seed_hits;   /* reads with fewer votes in the best window are unaligned, default 8 */
+    int32_t reserved[10];
+} fzp_align_params;
+void fzp_align_params_default(fzp_align_params *p);
+
+typedef struct {             /* per read, input order */
+    int32_t aligned;         /* 0 = no placement */
+    int32_t strand;          /* 0 forward, 1 reverse-complement */
+    int32_t pos;             /* 0-based contig position of the first aligned column */
+    int32_t ref_end;         /* one past the last aligned contig position */
+    int32_t q_start, q_end;  /* aligned part of the (oriented) read */
+    int32_t score;
+    int32_t n_cigar;
+    int64_t cells;           /* DP cells evaluated for this read (steps * 64) */
+} fzp_aln_summary;
+
+/* reads/contigs are ASCII (ACGT, any case; other symbols are treated as 'A' for seeding/DP and
+ * reported verbatim in SEQ).  All reads in one call belong to contig `ctg_seq` (the reference
+ * aligns <ctg>_reads.fa to <ctg>_ref.fa, unzip.py:233-234). */
+typedef struct fzp_alnjob fzp_alnjob;
+int fzp_align_create(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *const *ctg_seq, const int64_t *ctg_len,
+                     int64_t n_reads, const int32_t *read_ctg, const int64_t *read_off, const uint8_t *read_seq,
+                     const fzp_align_params *params, fzp_alnjob **out);
+int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *job);
+int fzp_align_summaries(fzp_ctx *ctx, fzp_alnjob *job, fzp_aln_summary *out /* [n_reads] */);
+/* alignment records of contig `ctg` in (POS, read index) order, q_id = rank in that order; names
+ * (optional, may be NULL -> "read/<index>") fill the q_id table */
+int fzp_align_alnset(fzp_ctx *ctx, fzp_alnjob *job, int32_t ctg, const int64_t *name_off, const char *names,
+                     fzp_alnset **out, int64_t **read_index /* [n_rec] input index of each record, optional */);
+/* hand the aligned records of all contigs to the phasing stages without leaving the device */
+int fzp_align_to_batch(fzp_ctx *ctx, fzp_alnjob *job, fzp_batch **out);
+void fzp_align_destroy(fzp_ctx *ctx, fzp_alnjob *job);
+/* SAM text of an alnset (what `samtools view` would print), for users who want the alignments */
+int fzp_format_sam(const fzp_alnset *aln, const char *ctg_id, const int32_t *flags, char **text, size_t *len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FZPHASE_H */

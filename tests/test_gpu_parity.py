@@ -1,0 +1,147 @@
+"""Parity of the HIP path (through the C-ABI) against the reference-generated goldens and the oracle.
+
+Bit-exact: every file is compared byte-for-byte (phased_reads / rid_to_phase in canonical order)."""
+import os
+import stat
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests.golden_util import Case, cases
+
+pytestmark = pytest.mark.gpu
+CASES = cases()
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from falcon_unzip_amd import _lib
+    e = _lib.Engine(0)
+    yield e
+    e.close()
+
+
+def _phase_all(eng, sam, ref_seq, ctg_id):
+    from falcon_unzip_amd import _lib
+    aln = _lib.parse_sam(sam)
+    sites, q = eng.het_call(aln, ref_seq)
+    arows = eng.assoc_table(sites, q)
+    pvars = eng.phase_blocks(sites, arows)
+    preads = eng.phase_reads(sites, q, pvars, aln.n_qid)
+    off, names = aln.qname_table()
+    return {"variant_pos": _lib.format_variant_pos(sites), "variant_map": _lib.format_variant_map(sites, q),
+            "q_id_map": _lib.format_q_id_map(aln), "atable": _lib.format_atable(sites, arows),
+            "phased_variants": _lib.format_phased_variants(sites, pvars),
+            "phased_reads": _lib.format_phased_reads(preads, ctg_id, off, names)}
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_chain_vs_golden(eng, name):
+    c = Case(name)
+    out = _phase_all(eng, c.sam, c.ref_seq, c.ctg_id)
+    for k in ("variant_pos", "variant_map", "q_id_map", "atable", "phased_variants", "phased_reads"):
+        c.check(k, out[k])
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_stages_from_golden_inputs(eng, name):
+    """Each stage fed the GOLDEN output of the previous one, like the oracle test."""
+    from falcon_unzip_amd import _lib, textio
+    c = Case(name)
+    vmap = c.expected("variant_map")
+    if vmap is None:
+        pytest.skip("variant_map pinned by hash only")
+    sites, q = textio.parse_variant_map(vmap)
+    arows = eng.assoc_table(sites, q)
+    got_atable = _lib.format_atable(sites, arows)
+    c.check("atable", got_atable)
+    atable = c.expected("atable")
+    arows_in = textio.parse_atable(atable, sites) if atable is not None else arows
+    pvars = eng.phase_blocks(sites, arows_in)
+    c.check("phased_variants", _lib.format_phased_variants(sites, pvars))
+    pv_in = textio.parse_phased_variants(c.expected("phased_variants"), sites)
+    off, names = textio.parse_q_id_map(c.expected("q_id_map"))
+    preads = eng.phase_reads(sites, q, pv_in, len(off) - 1)
+    c.check("phased_reads", _lib.format_phased_reads(preads, c.ctg_id, off, names))
+
+
+def test_batch_all_contigs_one_launch(eng):
+    """All golden cases as ONE multi-contig batch (the fused per-contig pipeline)."""
+    from falcon_unzip_amd import _lib
+    cs = [Case(n) for n in CASES]
+    alns = [_lib.parse_sam(c.sam) for c in cs]
+    b = eng.batch(alns, [c.ref_seq for c in cs])
+    b.run(_lib.STAGE_ALL)
+    for i, c in enumerate(cs):
+        r = b.result(i)
+        off, names = alns[i].qname_table()
+        c.check("variant_pos", _lib.format_variant_pos(r.sites))
+        c.check("variant_map", _lib.format_variant_map(r.sites, r.vmap_qid))
+        c.check("atable", _lib.format_atable(r.sites, r.arows))
+        c.check("phased_variants", _lib.format_phased_variants(r.sites, r.pvars))
+        c.check("phased_reads", _lib.format_phased_reads(r.preads, c.ctg_id, off, names))
+    b.close()
+
+
+@pytest.mark.parametrize("seed,L,n,R,err", [(11, 30000, 150, 6000, True), (12, 200000, 900, 9000, True), (13, 8000, 40, 3000, False)])
+def test_vs_oracle_random(eng, oracle, seed, L, n, R, err):
+    """Seeded inputs that are NOT in the golden set: HIP path vs the pinned C oracle."""
+    from falcon_unzip_amd import sim
+    rng = np.random.Generator(np.random.PCG64(seed))
+    hap0, hap1, _ = sim.make_diploid(L, rng, het_rate=1.0 / 300)
+    kw = {} if err else dict(sub=0, ins=0, dele=0)
+    reads = sim.simulate_reads(hap0, hap1, n, R, rng, clip_frac=0.1, **kw)
+    sam = "".join(l + "\n" for l in sim.sam_lines(reads, "ctgR", L=L)).encode()
+    ref = sim.codes_to_str(hap0).encode()
+    exp = oracle.phase_all(sam, ref, "ctgR")
+    got = _phase_all(eng, sam, ref, "ctgR")
+    for k in exp:
+        assert got[k] == exp[k], k
+
+
+def test_errors(eng):
+    from falcon_unzip_amd import _lib
+    c = Case("g7b_tiny")
+    lines = [l for l in c.sam.split(b"\n") if l]
+    with pytest.raises(_lib.FzpError) as ei:
+        _lib.parse_sam(b"\n".join(lines[::-1]) + b"\n")
+    assert ei.value.code == _lib.FZP_EUNSORTED
+    bad = lines[0].split(b"\t")
+    bad[5] = b"*"
+    with pytest.raises(_lib.FzpError) as ei:
+        _lib.parse_sam(b"\t".join(bad) + b"\n")
+    assert ei.value.code == _lib.FZP_EZERODIV
+
+
+def test_cli_dropin(tmp_path):
+    """fc_phasing.py / fc_phasing_readmap.py with the reference's flags, files and layout (unzip.py:125-126)."""
+    c = Case("g2_cfg1_clr")
+    sam_fn = tmp_path / "aln.sam"
+    sam_fn.write_bytes(c.sam)
+    fa_fn = tmp_path / "ref.fa"
+    fa_fn.write_bytes(c.fasta)
+    fake = tmp_path / "samtools"
+    fake.write_text("#!/bin/sh\ncat \"$2\"\n")
+    fake.chmod(fake.stat().st_mode | stat.S_IEXEC)
+    base = tmp_path / "0-phasing"
+    wd = base / c.ctg_id
+    wd.mkdir(parents=True)
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=repo)
+    subprocess.check_call([sys.executable, os.path.join(repo, "scripts", "fc_phasing.py"), "--bam", str(sam_fn), "--fasta", str(fa_fn),
+                           "--ctg_id", c.ctg_id, "--base_dir", "..", "--samtools", str(fake)], cwd=str(wd), env=env)
+    for rel, key in (("het_call/variant_pos", "variant_pos"), ("het_call/variant_map", "variant_map"), ("het_call/q_id_map", "q_id_map"),
+                     ("g_atable/atable", "atable"), ("get_phased_blocks/phased_variants", "phased_variants"), ("phased_reads", "phased_reads")):
+        c.check(key, (wd / rel).read_bytes())
+    rm = c.readmap_inputs()
+    rmd = tmp_path / "read_maps"
+    (rmd / "dump_rawread_ids").mkdir(parents=True)
+    (rmd / "dump_pread_ids").mkdir(parents=True)
+    (rmd / "dump_rawread_ids" / "rawread_ids").write_bytes(rm["rawread_ids"])
+    (rmd / "dump_pread_ids" / "pread_ids").write_bytes(rm["pread_ids"])
+    (rmd / "pread_to_contigs").write_bytes(rm["pread_to_contigs"])
+    subprocess.check_call([sys.executable, os.path.join(repo, "scripts", "fc_phasing_readmap.py"), "--ctg_id", c.ctg_id, "--read_map_dir", str(rmd),
+                           "--phased_reads", "phased_reads"], cwd=str(wd), env=env)
+    c.check("rid_to_phase", (wd / ("rid_to_phase.%s" % c.ctg_id)).read_bytes())

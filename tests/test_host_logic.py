@@ -1,0 +1,99 @@
+"""CPU-side checks: host logic of the product (SAM parser, serializers, text parsers, readmap) and the
+C-ABI surface.  No GPU compute is called here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from tests.golden_util import Case, cases
+
+CASES = cases()
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    g.build()
+    from falcon_unzip_amd import _lib
+    return _lib
+
+
+def test_library_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(REPO, "include", "fzphase.h")).read()
+    names = sorted(set(re.findall(r"\b(fzp_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(names) > 25
+    so = ctypes.CDLL(lib.LIB_PATH)
+    missing = [n for n in names if not hasattr(so, n)]
+    assert not missing, missing
+
+
+def test_no_device_fails_loudly(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(lib.FzpError) as ei:
+        lib.Engine(0)
+    assert ei.value.code == lib.FZP_ENODEVICE
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_parse_sam_and_q_id_map(lib, name):
+    c = Case(name)
+    aln = lib.parse_sam(c.sam)
+    c.check("q_id_map", lib.format_q_id_map(aln))
+    pos = aln.rec_pos()
+    assert np.all(np.diff(pos) >= 0)
+    assert aln.last_pos == (int(pos[-1]) if len(pos) else -1)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_text_roundtrip(lib, name):
+    from falcon_unzip_amd import textio
+    c = Case(name)
+    vm = c.expected("variant_map")
+    if vm is None:
+        pytest.skip("hash-only")
+    sites, q = textio.parse_variant_map(vm)
+    assert lib.format_variant_map(sites, q) == vm
+    at = c.expected("atable")
+    if at is not None:
+        assert lib.format_atable(sites, textio.parse_atable(at, sites)) == at
+    pv = c.expected("phased_variants")
+    assert lib.format_phased_variants(sites, textio.parse_phased_variants(pv, sites)) == pv
+
+
+@pytest.mark.parametrize("name", [n for n in CASES if Case(n).has("rid_to_phase")])
+def test_readmap(lib, name):
+    c = Case(name)
+    rm = c.readmap_inputs()
+    recs, text = lib.readmap(c.expected("phased_reads"), rm["rawread_ids"], rm["pread_ids"], rm["pread_to_contigs"], c.ctg_id, 7)
+    c.check("rid_to_phase", text)
+    assert len(recs) == text.count(b"\n")
+    assert np.all(recs["ctg"] == 7)
+    assert np.all(np.diff(recs["arid"]) > 0)
+
+
+def test_parser_errors(lib):
+    with pytest.raises(lib.FzpError) as ei:
+        lib.parse_sam(b"r1\t0\tc\t1\t254\t*\t*\t0\t0\tACGT\t*\n")
+    assert ei.value.code == lib.FZP_EZERODIV
+    with pytest.raises(lib.FzpError) as ei:   # CIGAR longer than SEQ: IndexError in the reference
+        lib.parse_sam(b"r1\t0\tc\t1\t254\t3000M\t*\t0\t0\tACGT\t*\n")
+    assert ei.value.code == lib.FZP_EINVAL
+    a = b"r1\t0\tc\t500\t254\t2500M\t*\t0\t0\t" + b"A" * 2500 + b"\t*\n"
+    b = b"r2\t0\tc\t100\t254\t2500M\t*\t0\t0\t" + b"A" * 2500 + b"\t*\n"
+    with pytest.raises(lib.FzpError) as ei:
+        lib.parse_sam(a + b)
+    assert ei.value.code == lib.FZP_EUNSORTED
+
+
+def test_clip_filter_is_ieee_double(lib):
+    """phasing.py:72: total=10000, skip=9000 -> 1.0 - 0.9 = 0.0999.. < 0.1 -> dropped (an integer test would keep it)."""
+    rec = b"r1\t0\tc\t1\t254\t9000S1000M\t*\t0\t0\t" + b"A" * 10000 + b"\t*\n"
+    aln = lib.parse_sam(rec)
+    assert aln.n_rec == 0 and aln.n_qid == 1
+    rec = b"r1\t0\tc\t1\t254\t8999S1001M\t*\t0\t0\t" + b"A" * 10000 + b"\t*\n"
+    assert lib.parse_sam(rec).n_rec == 1
