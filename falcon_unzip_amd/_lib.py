@@ -24,9 +24,10 @@ PVAR = np.dtype([("block", "<i4"), ("site", "<i4"), ("b1", "u1"), ("b2", "u1"), 
 PREAD = np.dtype([("q_id", "<i4"), ("block", "<i4"), ("phase", "<i4"), ("n0", "<i4"), ("n1", "<i4")], align=True)
 R2P = np.dtype([("arid", "<i4"), ("ctg", "<i4"), ("block", "<i4"), ("phase", "<i4")], align=True)
 ALN_SUMMARY = np.dtype([("aligned", "<i4"), ("strand", "<i4"), ("pos", "<i4"), ("ref_end", "<i4"), ("q_start", "<i4"),
-                        ("q_end", "<i4"), ("score", "<i4"), ("n_cigar", "<i4"), ("cells", "<i8")], align=True)
+                        ("q_end", "<i4"), ("score", "<i4"), ("n_cigar", "<i4"), ("cells", "<i8"), ("n_columns", "<i4"),
+                        ("pad_", "<i4")], align=True)
 assert SITE.itemsize == 40 and AROW.itemsize == 24 and PVAR.itemsize == 28 and PREAD.itemsize == 20
-assert R2P.itemsize == 16 and ALN_SUMMARY.itemsize == 40
+assert R2P.itemsize == 16 and ALN_SUMMARY.itemsize == 48
 
 
 class FzpError(RuntimeError):
@@ -322,6 +323,74 @@ class Engine:
         p = C.c_void_p()
         _check(lib.fzp_batch_create(self._p, C.c_int32(n), aptr, rptr, lens, C.byref(p)))
         return Batch(self, p.value, list(alnsets))
+
+
+class AlignJob:
+    """K1 job: reads of one or more contigs resident in HBM (fzp_align_*)."""
+
+    def __init__(self, eng, ptr, n_reads, n_ctg):
+        self.eng, self._p, self.n_reads, self.n_ctg = eng, ptr, n_reads, n_ctg
+
+    def run(self):
+        _check(load().fzp_align_run(self.eng._p, self._p))
+
+    def summaries(self):
+        out = np.zeros(self.n_reads, ALN_SUMMARY)
+        _check(load().fzp_align_summaries(self.eng._p, self._p, _ptr(out)))
+        return out
+
+    def alnset(self, ctg=0, names=None):
+        """Alignment records of contig `ctg` as the phasing stages see them -> (AlnSet, read_index)."""
+        lib = load()
+        ap, ip = C.c_void_p(), C.c_void_p()
+        if names is not None:
+            enc = [nm.encode() if isinstance(nm, str) else nm for nm in names]
+            off = np.zeros(len(enc) + 1, np.int64)
+            off[1:] = np.cumsum([len(e) for e in enc])
+            blob = b"".join(enc)
+            _check(lib.fzp_align_alnset(self.eng._p, self._p, ctg, _ptr(off), blob, C.byref(ap), C.byref(ip)))
+        else:
+            _check(lib.fzp_align_alnset(self.eng._p, self._p, ctg, None, None, C.byref(ap), C.byref(ip)))
+        a = AlnSet(ap.value)
+        idx = _take(ip.value, a.n_rec, np.int64)
+        return a, idx
+
+    def to_batch(self) -> "Batch":
+        p = C.c_void_p()
+        _check(load().fzp_align_to_batch(self.eng._p, self._p, C.byref(p)))
+        return Batch(self.eng, p.value, [None] * self.n_ctg)
+
+    def close(self):
+        if self._p:
+            load().fzp_align_destroy(self.eng._p, self._p)
+            self._p = None
+
+    __del__ = close
+
+
+def align_job(eng, contigs, reads, read_ctg=None, params=None) -> AlignJob:
+    """contigs: list of bytes; reads: list of bytes (as sequenced); read_ctg: contig index per read."""
+    lib = load()
+    nc, nr = len(contigs), len(reads)
+    cbufs = [C.create_string_buffer(c, len(c)) if len(c) else C.create_string_buffer(1) for c in contigs]
+    cptr = (C.c_void_p * nc)(*[C.cast(b, C.c_void_p).value for b in cbufs])
+    clen = (C.c_int64 * nc)(*[len(c) for c in contigs])
+    rc = np.zeros(nr, np.int32) if read_ctg is None else np.ascontiguousarray(read_ctg, dtype=np.int32)
+    off = np.zeros(nr + 1, np.int64)
+    off[1:] = np.cumsum([len(r) for r in reads])
+    blob = b"".join(reads)
+    P = AlignParams()
+    lib.fzp_align_params_default(C.byref(P))
+    for k, v in (params or {}).items():
+        setattr(P, k, v)
+    p = C.c_void_p()
+    _check(lib.fzp_align_create(eng._p, nc, cptr, clen, nr, _ptr(rc), _ptr(off), blob, C.byref(P), C.byref(p)))
+    return AlignJob(eng, p.value, nr, nc)
+
+
+def format_sam(aln: AlnSet, ctg_id: str, flags=None):
+    fl = None if flags is None else np.ascontiguousarray(flags, dtype=np.int32)
+    return _fmt("fzp_format_sam", C.c_void_p(aln._p), ctg_id.encode(), None if fl is None else _ptr(fl))
 
 
 # ---------------------------------------------------------------------------- serializers

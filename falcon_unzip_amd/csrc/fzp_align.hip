@@ -1,0 +1,735 @@
+// fzp_align.hip -- K1: read -> contig alignment on gfx950 (the role of blasr + samtools sort,
+// falcon_unzip/unzip.py:86-91).  Spec "fzalign v1": oracle/align_oracle.c is its scalar twin and the
+// kernels here match it bit-for-bit (summaries, CIGAR words, DP cell counts).  Parity vs blasr itself
+// is UNPINNED (third-party binary, not vendored).
+//
+//   k_pack        ASCII -> 2 bit/base words (16 bases per u32, base m at bits 2m)
+//   k_index       contig k-mers -> open-addressing table of (key<<32 | smallest position)
+//   k_seed        per read: diagonal-bin votes of sampled k-mers (both strands) in LDS, argmax, anchor
+//   k_orient      per read: oriented (forward / reverse-complement) packed copy
+//   k_sw          per read, ONE WAVE: adaptive anti-diagonal band, 64 cells = 64 lanes; neighbours
+//                 arrive by DPP wave shifts; per step two 64-bit trace-back masks (v_cmp -> SGPR pair)
+//                 go to HBM; steering compares lanes 0 and 63.  Integer VALU-bound, no MFMA.
+//   k_traceback   per read, one lane: walks the masks back from the best cell, emits CIGAR words
+//   k_gather      accepted records -> contiguous CIGAR + ASCII SEQ arrays for the phasing batch
+#include <algorithm>
+
+#include "fzp_batch.h"
+
+namespace {
+constexpr int32_t NEGV = -(1 << 28);
+constexpr uint64_t EMPTY = ~0ull;
+constexpr int MAX_BINS = 8192;
+
+__host__ __device__ __forceinline__ int code_of(uint8_t c) {
+    return (c == 'C' || c == 'c') ? 1 : (c == 'G' || c == 'g') ? 2 : (c == 'T' || c == 't') ? 3 : 0;
+}
+
+// ---- packing: one workgroup column per sequence, blockIdx.y strides over its words
+__global__ void __launch_bounds__(256) k_pack(const uint8_t *__restrict__ ascii, const int64_t *__restrict__ seq_off, const int64_t *__restrict__ woff,
+                                              uint32_t *__restrict__ out) {
+    const int64_t s = blockIdx.x;
+    const int64_t b0 = seq_off[s], n = seq_off[s + 1] - b0;
+    const int64_t nw = (n + 15) / 16 + 2;   // two zero pad words so 64-bit windows never run off the end
+    uint32_t *dst = out + woff[s];
+    for (int64_t w = (int64_t)blockIdx.y * 256 + threadIdx.x; w < nw; w += (int64_t)gridDim.y * 256) {
+        uint32_t v = 0;
+        int64_t base = w * 16;
+        for (int m = 0; m < 16; m++)
+            if (base + m < n) v |= (uint32_t)code_of(ascii[b0 + base + m]) << (2 * m);
+        dst[w] = v;
+    }
+}
+
+__device__ __forceinline__ uint32_t base_at(const uint32_t *__restrict__ pk, int64_t i) { return (pk[i >> 4] >> ((i & 15) * 2)) & 3u; }
+
+__device__ __forceinline__ uint32_t kmer_at(const uint32_t *__restrict__ pk, int64_t p, int k) {
+    uint64_t w = (uint64_t)pk[p >> 4] | ((uint64_t)pk[(p >> 4) + 1] << 32);
+    uint32_t key = (uint32_t)(w >> ((p & 15) * 2));
+    return k < 16 ? (key & ((1u << (2 * k)) - 1u)) : key;
+}
+// reverse-complement of a k-mer key (base m at bits 2m)
+__device__ __forceinline__ uint32_t rc_key(uint32_t key, int k) {
+    uint32_t x = ~key;
+    x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+    x = ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4);
+    x = __builtin_bswap32(x);
+    return k < 16 ? (x >> (32 - 2 * k)) : x;
+}
+__device__ __forceinline__ uint32_t hash_slot(uint32_t key, int bits) { return (key * 0x9E3779B1u) >> (32 - bits); }
+
+// ---- contig k-mer index: smallest start position per k-mer
+__global__ void __launch_bounds__(256) k_index(const uint32_t *__restrict__ ctg_pk, const int64_t *__restrict__ ctg_woff, const int64_t *__restrict__ ctg_len,
+                                               const int64_t *__restrict__ idx_off, const int32_t *__restrict__ idx_bits, int k, uint64_t *__restrict__ table) {
+    const int c = blockIdx.y;
+    const int64_t nk = ctg_len[c] - k + 1;
+    const uint32_t *pk = ctg_pk + ctg_woff[c];
+    uint64_t *tab = table + idx_off[c];
+    const int bits = idx_bits[c];
+    const uint32_t mask = (1u << bits) - 1u;
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < nk; p += (int64_t)gridDim.x * 256) {
+        uint32_t key = kmer_at(pk, p, k);
+        uint64_t word = ((uint64_t)key << 32) | (uint64_t)(uint32_t)p;
+        uint32_t slot = hash_slot(key, bits);
+        for (;;) {
+            unsigned long long old = atomicCAS((unsigned long long *)&tab[slot], (unsigned long long)EMPTY, (unsigned long long)word);
+            if (old == EMPTY) break;
+            if ((uint32_t)(old >> 32) == key) { atomicMin((unsigned long long *)&tab[slot], (unsigned long long)word); break; }
+            slot = (slot + 1) & mask;
+        }
+    }
+}
+__device__ __forceinline__ int32_t index_lookup(const uint64_t *__restrict__ tab, int bits, uint32_t key) {
+    const uint32_t mask = (1u << bits) - 1u;
+    uint32_t slot = hash_slot(key, bits);
+    for (;;) {
+        uint64_t v = tab[slot];
+        if (v == EMPTY) return -1;
+        if ((uint32_t)(v >> 32) == key) return (int32_t)(uint32_t)v;
+        slot = (slot + 1) & mask;
+    }
+}
+
+struct Anchor { int32_t aligned, strand, i_a, c_a; };
+
+__device__ __forceinline__ uint64_t block_max_u64(uint64_t v, uint64_t *sh) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { uint64_t o = __shfl_xor(v, d, 64); v = o > v ? o : v; }
+    if (lane_id() == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    uint64_t r = sh[0];
+    for (int i = 1; i < 4; i++) r = sh[i] > r ? sh[i] : r;
+    __syncthreads();
+    return r;
+}
+
+// ---- seeding: one workgroup per read
+__global__ void __launch_bounds__(256) k_seed(int64_t first, const uint32_t *__restrict__ read_pk, const int64_t *__restrict__ read_woff, const int32_t *__restrict__ read_len,
+                                              const int32_t *__restrict__ read_ctg, const int64_t *__restrict__ ctg_len, const int64_t *__restrict__ idx_off,
+                                              const int32_t *__restrict__ idx_bits, const uint64_t *__restrict__ table, int k, int stride, int min_hits,
+                                              Anchor *__restrict__ anc) {
+    extern __shared__ uint32_t votes[];
+    __shared__ uint64_t red[4];
+    const int64_t r = first + blockIdx.x;
+    const int64_t n = read_len[r];
+    const int c = read_ctg[r];
+    const int64_t Lc = ctg_len[c];
+    Anchor a = {0, 0, 0, 0};
+    if (n < k || Lc < k) { if (threadIdx.x == 0) anc[r] = a; return; }
+    int shift = 10;
+    while ((((Lc + n) >> shift) + 2) > MAX_BINS) shift++;
+    const int NB = (int)(((Lc + n) >> shift) + 2);
+    const uint32_t *pk = read_pk + read_woff[r];
+    const uint64_t *tab = table + idx_off[c];
+    const int bits = idx_bits[c];
+    for (int i = threadIdx.x; i < 2 * NB; i += 256) votes[i] = 0;
+    __syncthreads();
+    const int64_t ns = (n - k) / stride + 1;   // sampled offsets 0, stride, ...
+    for (int64_t m = threadIdx.x; m < 2 * ns; m += 256) {
+        const int s = m >= ns;
+        const int64_t i = (s ? m - ns : m) * stride;
+        uint32_t key = s ? rc_key(kmer_at(pk, n - k - i, k), k) : kmer_at(pk, i, k);
+        int32_t cp = index_lookup(tab, bits, key);
+        if (cp >= 0) atomicAdd(&votes[s * NB + (int)(((int64_t)cp - i + n) >> shift)], 1u);
+    }
+    __syncthreads();
+    // best window: max votes[b]+votes[b+1]; ties -> forward strand, lower bin
+    uint64_t best = 0;
+    for (int x = threadIdx.x; x < 2 * NB; x += 256) {
+        int b = x >= NB ? x - NB : x;
+        if (b + 1 >= NB) continue;
+        uint64_t sc = (uint64_t)votes[x] + votes[x + 1];
+        uint64_t key = (sc << 32) | (uint64_t)(0xffffffffu - (uint32_t)x);
+        best = key > best ? key : best;
+    }
+    best = block_max_u64(best, red);
+    const uint32_t sc = (uint32_t)(best >> 32);
+    if ((int32_t)sc < min_hits || sc == 0) { if (threadIdx.x == 0) anc[r] = a; return; }
+    const int x = (int)(0xffffffffu - (uint32_t)best);
+    const int bs = x >= NB, bb = bs ? x - NB : x;
+    // anchor: the hit with the smallest read offset inside the two winning bins
+    uint64_t mn = 0;   // maximise ~(i<<32|cp) == minimise i, then cp
+    for (int64_t m = threadIdx.x; m < ns; m += 256) {
+        const int64_t i = m * stride;
+        uint32_t key = bs ? rc_key(kmer_at(pk, n - k - i, k), k) : kmer_at(pk, i, k);
+        int32_t cp = index_lookup(tab, bits, key);
+        if (cp < 0) continue;
+        int b = (int)(((int64_t)cp - i + n) >> shift);
+        if (b == bb || b == bb + 1) { mn = ~(((uint64_t)i << 32) | (uint32_t)cp); break; }   // offsets ascend per thread
+    }
+    mn = block_max_u64(mn, red);
+    if (threadIdx.x == 0) {
+        if (mn != 0) { uint64_t v = ~mn; a.aligned = 1; a.strand = bs; a.i_a = (int32_t)(v >> 32); a.c_a = (int32_t)(uint32_t)v; }
+        anc[r] = a;
+    }
+}
+
+// ---- oriented packed copy of each read
+__global__ void __launch_bounds__(256) k_orient(int64_t first, const uint32_t *__restrict__ read_pk, const int64_t *__restrict__ read_woff, const int32_t *__restrict__ read_len,
+                                                const Anchor *__restrict__ anc, uint32_t *__restrict__ out) {
+    const int64_t r = first + blockIdx.x;
+    const int64_t n = read_len[r];
+    const int64_t nw = (n + 15) / 16 + 2;
+    const uint32_t *src = read_pk + read_woff[r];
+    uint32_t *dst = out + read_woff[r];
+    const bool rc = anc[r].strand != 0;
+    for (int64_t w = (int64_t)blockIdx.y * 256 + threadIdx.x; w < nw; w += (int64_t)gridDim.y * 256) {
+        uint32_t v = src[w];
+        if (rc) {
+            v = 0;
+            for (int m = 0; m < 16; m++) {
+                int64_t x = w * 16 + m;
+                if (x < n) v |= (3u - base_at(src, n - 1 - x)) << (2 * m);
+            }
+        }
+        dst[w] = v;
+    }
+}
+
+struct DpInfo { int32_t steps, best_t, best_lane, best_score; };
+
+// wave-wide shifts by one lane (gfx9 DPP wave_shr / wave_shl); vacated lane takes `fill`
+__device__ __forceinline__ int32_t wave_shr1(int32_t v, int32_t fill) {   // lane k <- lane k-1
+    return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false);
+}
+__device__ __forceinline__ int32_t wave_shl1(int32_t v, int32_t fill) {   // lane k <- lane k+1
+    return __builtin_amdgcn_update_dpp(fill, v, 0x130, 0xf, 0xf, false);
+}
+
+// ---- K1 hot kernel: adaptive banded DP, one wave per read
+__global__ void __launch_bounds__(256) k_sw(int64_t first, int64_t count, const uint32_t *__restrict__ read_ori, const int64_t *__restrict__ read_woff,
+                                            const int32_t *__restrict__ read_len, const int32_t *__restrict__ read_ctg, const uint32_t *__restrict__ ctg_pk,
+                                            const int64_t *__restrict__ ctg_woff, const int64_t *__restrict__ ctg_len, const Anchor *__restrict__ anc,
+                                            const int64_t *__restrict__ tb_off, ulonglong2 *__restrict__ tb, uint64_t *__restrict__ mvw, int match, int mismatch,
+                                            int gap, DpInfo *__restrict__ info) {
+    const int lane = lane_id();
+    // wave-uniform on purpose: everything indexed by the read then lives in SGPRs / scalar loads
+    const int64_t wv = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (wv >= count) return;
+    const int64_t r = first + wv;
+    const Anchor a = anc[r];
+    if (!a.aligned) { if (lane == 0) info[r] = DpInfo{0, -1, 0, NEGV}; return; }
+    const int c = read_ctg[r];
+    const int64_t n = read_len[r];
+    const int32_t nq = (int32_t)(n - a.i_a);
+    int64_t ntl = ctg_len[c] - a.c_a;
+    if (ntl > (int64_t)nq + nq / 4 + 64) ntl = (int64_t)nq + nq / 4 + 64;
+    const int32_t nt = (int32_t)ntl;
+    const uint32_t *qpk = read_ori + read_woff[r];
+    const uint32_t *tpk = ctg_pk + ctg_woff[c];
+    const int64_t qb = a.i_a, tbase = a.c_a;
+    const int32_t max_steps = nq + nt + 2;
+    ulonglong2 *tbr = tb + (tb_off[r] - tb_off[first]);
+    uint64_t *mvr = mvw + ((tb_off[r] - tb_off[first]) >> 6) + wv;
+
+    int32_t Hpp = lane == 32 ? 0 : NEGV;
+    int32_t Hp = (lane == 32 || lane == 33) ? -gap : NEGV;
+    int32_t qc, tc;
+    {
+        int32_t i = lane - 33, j = 32 - lane;
+        qc = (i >= 0 && i < nq) ? (int32_t)base_at(qpk, qb + i) : 4;
+        tc = (j >= 0 && j < nt) ? (int32_t)base_at(tpk, tbase + j) : 5;
+    }
+    int32_t bs = NEGV, bt = -1;
+    int32_t i0 = -33, t = 0;
+    bool prev_down = false, steer = true;
+    uint64_t mvacc = 0;
+    for (;;) {
+        const bool down = t < 64 ? ((t & 1) == 0) : steer;
+        int32_t up, left, dg;
+        if (down) {
+            i0++;
+            const int32_t iq = i0 + 63;
+            const int32_t nc = iq < nq ? (int32_t)base_at(qpk, qb + iq) : 4;
+            qc = wave_shl1(qc, nc);
+            up = Hp;
+            left = wave_shl1(Hp, NEGV);
+        } else {
+            const int32_t jt = t - i0;
+            const int32_t nc = jt < nt ? (int32_t)base_at(tpk, tbase + jt) : 5;
+            tc = wave_shr1(tc, nc);
+            up = wave_shr1(Hp, NEGV);
+            left = Hp;
+        }
+        if (down && prev_down) dg = wave_shl1(Hpp, NEGV);
+        else if (!down && !prev_down) dg = wave_shr1(Hpp, NEGV);
+        else dg = Hpp;
+        const int32_t s = qc == tc ? match : -mismatch;
+        const int32_t hd = dg + s, hu = up - gap, hl = left - gap;
+        const int32_t H = max(hd, max(hu, hl));
+        const uint64_t D = __ballot(H == hd);
+        const uint64_t U = __ballot(hu >= hl);
+        const int32_t i = i0 + lane, j = t - i;
+        if (i >= 0 && i < nq && j >= 0 && j < nt && H > bs) { bs = H; bt = t; }
+        if (lane == 0) tbr[t] = make_ulonglong2(D, U);
+        mvacc |= (uint64_t)(down ? 1 : 0) << (t & 63);
+        if ((t & 63) == 63) { if (lane == 0) mvr[t >> 6] = mvacc; mvacc = 0; }
+        const int32_t top = __builtin_amdgcn_readlane(H, 0), bot = __builtin_amdgcn_readlane(H, 63);
+        steer = !(top > bot);
+        Hpp = Hp; Hp = H; prev_down = down;
+        t++;
+        if (i0 > nq - 1) break;
+        if ((t - 1) - (i0 + 63) > nt - 1) break;
+        if (t >= max_steps) break;
+    }
+    if ((t & 63) != 0 && lane == 0) mvr[t >> 6] = mvacc;
+    // best cell: max score, then earliest step, then lowest lane
+    int32_t s_b = bs, t_b = bt < 0 ? 0x7fffffff : bt, l_b = lane;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        int32_t so = __shfl_xor(s_b, d, 64), to = __shfl_xor(t_b, d, 64), lo = __shfl_xor(l_b, d, 64);
+        bool take = so > s_b || (so == s_b && (to < t_b || (to == t_b && lo < l_b)));
+        if (take) { s_b = so; t_b = to; l_b = lo; }
+    }
+    if (lane == 0) info[r] = DpInfo{t, t_b == 0x7fffffff ? -1 : t_b, l_b, s_b};
+}
+
+// ---- trace-back: one lane per read
+__global__ void __launch_bounds__(64) k_traceback(int64_t first, int64_t count, const uint32_t *__restrict__ read_ori, const int64_t *__restrict__ read_woff,
+                                                  const int32_t *__restrict__ read_len, const int32_t *__restrict__ read_ctg, const uint32_t *__restrict__ ctg_pk,
+                                                  const int64_t *__restrict__ ctg_woff, const Anchor *__restrict__ anc, const DpInfo *__restrict__ info,
+                                                  const int64_t *__restrict__ tb_off, const ulonglong2 *__restrict__ tb, const uint64_t *__restrict__ mvw,
+                                                  const int64_t *__restrict__ cig_off, uint32_t *__restrict__ cig, int64_t *__restrict__ cig_start,
+                                                  fzp_aln_summary *__restrict__ summ) {
+    const int64_t wv = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (wv >= count) return;
+    const int64_t r = first + wv;
+    fzp_aln_summary out;
+    memset(&out, 0, sizeof out);
+    const Anchor a = anc[r];
+    const DpInfo di = info[r];
+    out.cells = (int64_t)di.steps * 64;
+    cig_start[r] = cig_off[r];
+    if (!a.aligned || di.best_t < 0 || di.best_score <= 0) { summ[r] = out; return; }
+    const int64_t n = read_len[r];
+    const uint32_t *qpk = read_ori + read_woff[r];
+    const uint32_t *tpk = ctg_pk + ctg_woff[read_ctg[r]];
+    const ulonglong2 *tbr = tb + (tb_off[r] - tb_off[first]);
+    const uint64_t *mvr = mvw + ((tb_off[r] - tb_off[first]) >> 6) + wv;
+    // i0 at the best step = -33 + number of DOWN moves in steps [0, best_t]
+    int32_t ts = di.best_t;
+    int32_t i0 = -33;
+    for (int32_t w = 0; w < (ts >> 6); w++) i0 += __popcll(mvr[w]);
+    i0 += __popcll(mvr[ts >> 6] & ((2ull << (ts & 63)) - 1ull));
+    int32_t i = i0 + di.best_lane, j = ts - i;
+    const int32_t i_end = i, j_end = j;
+    const int64_t cap = cig_off[r + 1] - cig_off[r];       // n + 18 words
+    uint32_t *reg = cig + cig_off[r];
+    int64_t wpos = cap - 1;                                 // last slot is kept for the trailing soft clip
+    int64_t nraw = 0;
+    int cur_op = -1;
+    uint32_t cur_len = 0;
+    int32_t ncol = 0;
+    bool overflow = false;
+    while (i >= 0 && j >= 0) {
+        const ulonglong2 m = tbr[ts];
+        const int kk = i - i0;
+        int op;
+        const bool d1 = (mvr[ts >> 6] >> (ts & 63)) & 1ull;
+        if ((m.x >> kk) & 1ull) {
+            op = base_at(qpk, (int64_t)a.i_a + i) == base_at(tpk, (int64_t)a.c_a + j) ? FZP_OP_EQ : FZP_OP_X;
+            i--; j--; ncol++;
+            const bool d2 = ts >= 1 ? ((mvr[(ts - 1) >> 6] >> ((ts - 1) & 63)) & 1ull) : false;   // move(-1) = RIGHT
+            i0 -= (d1 ? 1 : 0) + (d2 ? 1 : 0);
+            ts -= 2;
+        } else if ((m.y >> kk) & 1ull) {
+            op = FZP_OP_I; i--; i0 -= d1 ? 1 : 0; ts -= 1;
+        } else {
+            op = FZP_OP_D; j--; i0 -= d1 ? 1 : 0; ts -= 1;
+        }
+        if (op == cur_op) cur_len++;
+        else {
+            if (cur_len) { nraw++; if (wpos > 1) reg[--wpos] = (cur_len << 4) | (uint32_t)cur_op; else overflow = true; }
+            cur_op = op; cur_len = 1;
+        }
+    }
+    if (cur_len) { nraw++; if (wpos > 1) reg[--wpos] = (cur_len << 4) | (uint32_t)cur_op; else overflow = true; }
+    int64_t q_lead = i + 1, r_lead = j + 1;
+    int64_t fa = wpos, fb = cap - 1;                        // forward ops are reg[fa .. fb)
+    while (fa < fb && ((reg[fa] & 15u) == FZP_OP_I || (reg[fa] & 15u) == FZP_OP_D)) {
+        if ((reg[fa] & 15u) == FZP_OP_I) q_lead += reg[fa] >> 4; else r_lead += reg[fa] >> 4;
+        fa++;
+    }
+    int64_t q_trail = 0, r_trail = 0;
+    while (fb > fa && ((reg[fb - 1] & 15u) == FZP_OP_I || (reg[fb - 1] & 15u) == FZP_OP_D)) {
+        if ((reg[fb - 1] & 15u) == FZP_OP_I) q_trail += reg[fb - 1] >> 4; else r_trail += reg[fb - 1] >> 4;
+        fb--;
+    }
+    if (fa < fb && ncol > 0 && !overflow && nraw <= n + 16) {
+        out.aligned = 1;
+        out.strand = a.strand;
+        out.pos = (int32_t)(a.c_a + r_lead);
+        out.ref_end = (int32_t)(a.c_a + j_end + 1 - r_trail);
+        out.q_start = (int32_t)(a.i_a + q_lead);
+        out.q_end = (int32_t)(a.i_a + i_end + 1 - q_trail);
+        out.score = di.best_score;
+        out.n_columns = ncol;
+        int32_t nc = (int32_t)(fb - fa);
+        if (out.q_start > 0) { reg[--fa] = ((uint32_t)out.q_start << 4) | FZP_OP_S; nc++; }
+        if (n - out.q_end > 0) { reg[fb++] = ((uint32_t)(n - out.q_end) << 4) | FZP_OP_S; nc++; }
+        out.n_cigar = nc;
+        cig_start[r] = cig_off[r] + fa;
+    }
+    summ[r] = out;
+}
+
+// ---- gather accepted records into contiguous CIGAR / ASCII SEQ arrays
+__global__ void __launch_bounds__(256) k_gather(int64_t n_rec, const int64_t *__restrict__ rec_read, const int64_t *__restrict__ cig_start, const uint32_t *__restrict__ cig,
+                                                const int64_t *__restrict__ out_cig_off, uint32_t *__restrict__ out_cig, const uint32_t *__restrict__ read_ori,
+                                                const int64_t *__restrict__ read_woff, const int64_t *__restrict__ out_seq_off, uint8_t *__restrict__ out_seq) {
+    const int64_t k = blockIdx.x;
+    if (k >= n_rec) return;
+    const int64_t r = rec_read[k];
+    const int64_t nc = out_cig_off[k + 1] - out_cig_off[k];
+    const uint32_t *src = cig + cig_start[r];
+    uint32_t *dst = out_cig + out_cig_off[k];
+    for (int64_t x = (int64_t)blockIdx.y * 256 + threadIdx.x; x < nc; x += (int64_t)gridDim.y * 256) dst[x] = src[x];
+    const int64_t n = out_seq_off[k + 1] - out_seq_off[k];
+    const uint32_t *pk = read_ori + read_woff[r];
+    uint8_t *sq = out_seq + out_seq_off[k];
+    for (int64_t x = (int64_t)blockIdx.y * 256 + threadIdx.x; x < n; x += (int64_t)gridDim.y * 256) sq[x] = (uint8_t)("ACGT"[base_at(pk, x)]);
+}
+}  // namespace
+
+// ================================================================================ job
+struct fzp_alnjob {
+    int32_t n_ctg = 0;
+    int64_t n_reads = 0;
+    fzp_align_params P;
+    std::vector<std::vector<uint8_t>> h_ctg;     // upper-cased ASCII, for the phasing batch's ref_seq
+    std::vector<int64_t> h_ctg_len, h_ctg_woff, h_idx_off, h_read_woff, h_tb_off, h_cig_off;
+    std::vector<int32_t> h_idx_bits, h_read_len, h_read_ctg;
+    std::vector<fzp_aln_summary> h_summ;
+    int64_t ctg_words = 0, read_words = 0, idx_slots = 0;
+    DevBuf<uint32_t> ctg_pk, read_pk, read_ori, cig;
+    DevBuf<int64_t> ctg_woff, ctg_len, idx_off, read_woff, tb_off, cig_off, cig_start;
+    DevBuf<int32_t> idx_bits, read_len, read_ctg;
+    DevBuf<uint64_t> table, mvw;
+    DevBuf<Anchor> anc;
+    DevBuf<DpInfo> info;
+    DevBuf<ulonglong2> tb;
+    DevBuf<fzp_aln_summary> summ;
+    bool done = false;
+};
+
+extern "C" void fzp_align_params_default(fzp_align_params *p) {
+    memset(p, 0, sizeof *p);
+    p->kmer = 16; p->seed_stride = 4; p->match = 2; p->mismatch = 4; p->gap = 3; p->min_seed_hits = 8;
+}
+
+extern "C" void fzp_align_destroy(fzp_ctx *ctx, fzp_alnjob *job) {
+    if (!job) return;
+    if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
+    delete job;
+}
+
+extern "C" int fzp_align_create(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *const *ctg_seq, const int64_t *ctg_len, int64_t n_reads, const int32_t *read_ctg,
+                                const int64_t *read_off, const uint8_t *read_seq, const fzp_align_params *params, fzp_alnjob **out) {
+    if (!ctx || !out || n_ctg <= 0 || !ctg_seq || !ctg_len || n_reads < 0 || (n_reads && (!read_ctg || !read_off || !read_seq))) {
+        fzp_set_error("fzp_align_create: bad arguments");
+        return FZP_EINVAL;
+    }
+    *out = nullptr;
+    FZP_HIP(hipSetDevice(ctx->device));
+    fzp_alnjob *j = new fzp_alnjob();
+    if (params) j->P = *params; else fzp_align_params_default(&j->P);
+    if (j->P.kmer < 8 || j->P.kmer > 16 || j->P.seed_stride < 1 || j->P.match <= 0 || j->P.mismatch < 0 || j->P.gap <= 0) {
+        delete j; fzp_set_error("fzp_align_create: bad parameters"); return FZP_EINVAL;
+    }
+    j->n_ctg = n_ctg; j->n_reads = n_reads;
+    hipStream_t st = ctx->stream;
+    int rc = FZP_OK;
+    // contigs
+    std::vector<int64_t> coff(1, 0);
+    std::vector<uint8_t> call;
+    j->h_ctg.resize(n_ctg);
+    for (int c = 0; c < n_ctg; c++) {
+        if (ctg_len[c] < 0 || ctg_len[c] > 0x7fff0000LL) { delete j; fzp_set_error("contig %d: length out of range", c); return FZP_EINVAL; }
+        j->h_ctg[c].resize((size_t)ctg_len[c]);
+        for (int64_t i = 0; i < ctg_len[c]; i++) {
+            uint8_t ch = ctg_seq[c][i];
+            j->h_ctg[c][(size_t)i] = (ch >= 'a' && ch <= 'z') ? (uint8_t)(ch - 32) : ch;   // phasing.py:494 .upper()
+        }
+        j->h_ctg_len.push_back(ctg_len[c]);
+        j->h_ctg_woff.push_back(j->ctg_words);
+        j->ctg_words += (ctg_len[c] + 15) / 16 + 2;
+        int64_t nk = ctg_len[c] - j->P.kmer + 1;
+        int bits = 10;
+        while ((1LL << bits) < 2 * std::max<int64_t>(nk, 1)) bits++;
+        j->h_idx_bits.push_back(bits);
+        j->h_idx_off.push_back(j->idx_slots);
+        j->idx_slots += 1LL << bits;
+        call.insert(call.end(), ctg_seq[c], ctg_seq[c] + ctg_len[c]);
+        coff.push_back((int64_t)call.size());
+    }
+    // reads
+    j->h_read_woff.assign(1, 0);
+    j->h_tb_off.assign(1, 0);
+    j->h_cig_off.assign(1, 0);
+    for (int64_t r = 0; r < n_reads; r++) {
+        int64_t n = read_off[r + 1] - read_off[r];
+        if (n < 0 || n > 0x3fff0000LL || read_ctg[r] < 0 || read_ctg[r] >= n_ctg) { delete j; fzp_set_error("read %lld: bad length/contig", (long long)r); return FZP_EINVAL; }
+        j->h_read_len.push_back((int32_t)n);
+        j->h_read_ctg.push_back(read_ctg[r]);
+        j->read_words += (n + 15) / 16 + 2;
+        j->h_read_woff.push_back(j->read_words);
+        j->h_tb_off.push_back(j->h_tb_off.back() + (n + n + n / 4 + 64 + 2 + 63) / 64 * 64);   // steps capacity, multiple of 64
+        j->h_cig_off.push_back(j->h_cig_off.back() + n + 18);
+    }
+    DevBuf<uint8_t> d_ascii;
+    DevBuf<int64_t> d_off;
+    do {
+        if ((rc = j->ctg_pk.alloc((size_t)j->ctg_words)) || (rc = d_ascii.upload(call.data(), call.size(), st)) || (rc = d_off.upload(coff.data(), coff.size(), st)) ||
+            (rc = j->ctg_woff.upload(j->h_ctg_woff.data(), j->h_ctg_woff.size(), st)) || (rc = j->ctg_len.upload(j->h_ctg_len.data(), j->h_ctg_len.size(), st)) ||
+            (rc = j->idx_off.upload(j->h_idx_off.data(), j->h_idx_off.size(), st)) || (rc = j->idx_bits.upload(j->h_idx_bits.data(), j->h_idx_bits.size(), st)))
+            break;
+        hipLaunchKernelGGL(k_pack, dim3(n_ctg, 64), dim3(256), 0, st, d_ascii.p, d_off.p, j->ctg_woff.p, j->ctg_pk.p);
+        if (hipStreamSynchronize(st) != hipSuccess) { rc = FZP_EDEVICE; break; }
+        if (n_reads) {
+            if ((rc = j->read_pk.alloc((size_t)j->read_words)) || (rc = j->read_ori.alloc((size_t)j->read_words)) ||
+                (rc = d_ascii.upload(read_seq + read_off[0], (size_t)(read_off[n_reads] - read_off[0]), st)))
+                break;
+            std::vector<int64_t> roff((size_t)n_reads + 1);
+            for (int64_t r = 0; r <= n_reads; r++) roff[(size_t)r] = read_off[r] - read_off[0];
+            if ((rc = d_off.upload(roff.data(), roff.size(), st)) || (rc = j->read_woff.upload(j->h_read_woff.data(), j->h_read_woff.size(), st)) ||
+                (rc = j->read_len.upload(j->h_read_len.data(), j->h_read_len.size(), st)) || (rc = j->read_ctg.upload(j->h_read_ctg.data(), j->h_read_ctg.size(), st)) ||
+                (rc = j->tb_off.upload(j->h_tb_off.data(), j->h_tb_off.size(), st)) || (rc = j->cig_off.upload(j->h_cig_off.data(), j->h_cig_off.size(), st)))
+                break;
+            hipLaunchKernelGGL(k_pack, dim3((unsigned)n_reads, 1), dim3(256), 0, st, d_ascii.p, d_off.p, j->read_woff.p, j->read_pk.p);
+            if (hipStreamSynchronize(st) != hipSuccess) { rc = FZP_EDEVICE; break; }
+        }
+        if ((rc = j->table.alloc((size_t)j->idx_slots)) || (rc = j->anc.alloc((size_t)n_reads)) || (rc = j->info.alloc((size_t)n_reads)) ||
+            (rc = j->summ.alloc((size_t)n_reads)) || (rc = j->cig.alloc((size_t)j->h_cig_off.back())) || (rc = j->cig_start.alloc((size_t)n_reads)))
+            break;
+    } while (0);
+    if (rc == FZP_OK && hipGetLastError() != hipSuccess) rc = FZP_EDEVICE;
+    if (rc) { if (rc == FZP_EDEVICE) fzp_set_error("fzp_align_create: device error"); delete j; return rc; }
+    *out = j;
+    return FZP_OK;
+}
+
+extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
+    if (!ctx || !j) return FZP_EINVAL;
+    FZP_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const fzp_align_params &P = j->P;
+    {
+        ProfScope ps(ctx, "k1_index");
+        FZP_HIP(hipMemsetAsync(j->table.p, 0xff, (size_t)j->idx_slots * sizeof(uint64_t), st));
+        hipLaunchKernelGGL(k_index, dim3(1024, j->n_ctg), dim3(256), 0, st, j->ctg_pk.p, j->ctg_woff.p, j->ctg_len.p, j->idx_off.p, j->idx_bits.p, P.kmer, j->table.p);
+    }
+    const int64_t nr = j->n_reads;
+    if (nr > 0) {
+        {
+            ProfScope ps(ctx, "k1_seed");
+            int64_t lc_max = 0, n_max = 0;
+            for (auto v : j->h_ctg_len) lc_max = std::max(lc_max, v);
+            for (auto v : j->h_read_len) n_max = std::max<int64_t>(n_max, v);
+            const int64_t nb_max = std::min<int64_t>(MAX_BINS, ((lc_max + n_max) >> 10) + 2);
+            const size_t lds = (size_t)2 * (size_t)nb_max * sizeof(uint32_t);
+            FZP_HIP(hipFuncSetAttribute((const void *)k_seed, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(k_seed, dim3((unsigned)nr), dim3(256), lds, st, (int64_t)0, j->read_pk.p, j->read_woff.p, j->read_len.p,
+                               j->read_ctg.p, j->ctg_len.p, j->idx_off.p, j->idx_bits.p, j->table.p, P.kmer, P.seed_stride, P.min_seed_hits, j->anc.p);
+        }
+        {
+            ProfScope ps(ctx, "k1_orient");
+            hipLaunchKernelGGL(k_orient, dim3((unsigned)nr, 1), dim3(256), 0, st, (int64_t)0, j->read_pk.p, j->read_woff.p, j->read_len.p, j->anc.p, j->read_ori.p);
+        }
+        // trace-back masks live in HBM; reads are processed in chunks that fit the budget
+        int64_t budget_steps = (int64_t)48 << 30 >> 4;   // 48 GiB of 16-byte steps
+        if (const char *e = getenv("FZP_TB_BUDGET_GB")) { long g = atol(e); if (g > 0) budget_steps = ((int64_t)g << 30) >> 4; }
+        int64_t first = 0;
+        while (first < nr) {
+            int64_t last = first;
+            while (last < nr && j->h_tb_off[(size_t)last + 1] - j->h_tb_off[(size_t)first] <= budget_steps) last++;
+            if (last == first) last = first + 1;
+            const int64_t cnt = last - first;
+            const int64_t steps = j->h_tb_off[(size_t)last] - j->h_tb_off[(size_t)first];
+            FZP_TRY(j->tb.alloc((size_t)steps));
+            FZP_TRY(j->mvw.alloc((size_t)(steps / 64 + cnt + 1)));
+            {
+                ProfScope ps(ctx, "k1_sw");
+                hipLaunchKernelGGL(k_sw, dim3((unsigned)((cnt + 3) / 4)), dim3(256), 0, st, first, cnt, j->read_ori.p, j->read_woff.p, j->read_len.p, j->read_ctg.p,
+                                   j->ctg_pk.p, j->ctg_woff.p, j->ctg_len.p, j->anc.p, j->tb_off.p, j->tb.p, j->mvw.p, P.match, P.mismatch, P.gap, j->info.p);
+            }
+            {
+                ProfScope ps(ctx, "k1_traceback");
+                hipLaunchKernelGGL(k_traceback, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, st, first, cnt, j->read_ori.p, j->read_woff.p, j->read_len.p, j->read_ctg.p,
+                                   j->ctg_pk.p, j->ctg_woff.p, j->anc.p, j->info.p, j->tb_off.p, j->tb.p, j->mvw.p, j->cig_off.p, j->cig.p, j->cig_start.p, j->summ.p);
+            }
+            first = last;
+        }
+    }
+    j->h_summ.resize((size_t)nr);
+    FZP_TRY(j->summ.download(j->h_summ.data(), (size_t)nr, st));
+    FZP_HIP(hipStreamSynchronize(st));
+    FZP_HIP(hipGetLastError());
+    j->done = true;
+    return FZP_OK;
+}
+
+extern "C" int fzp_align_summaries(fzp_ctx *ctx, fzp_alnjob *j, fzp_aln_summary *out) {
+    (void)ctx;
+    if (!j || !j->done || !out) { fzp_set_error("fzp_align_summaries: run the job first"); return FZP_EINVAL; }
+    if (j->n_reads) memcpy(out, j->h_summ.data(), (size_t)j->n_reads * sizeof(fzp_aln_summary));
+    return FZP_OK;
+}
+
+namespace {
+struct RecPlan {
+    std::vector<int64_t> rec_read;               // accepted records, (contig, POS, read index) order
+    std::vector<int32_t> rec_qid, rec_pos, rec_ctg;
+    std::vector<int64_t> cig_off, seq_off, rec_begin;   // rec_begin per contig
+    std::vector<std::vector<int64_t>> ctg_reads;        // all aligned reads per contig, q_id order
+    std::vector<int32_t> last_pos, max_span;
+    std::vector<int64_t> n_columns;
+};
+
+// what `samtools sort` + make_het_call's record filters (phasing.py:47-75) do to the aligner's output
+void plan_records(const fzp_alnjob *j, int c_lo, int c_hi, RecPlan &p) {
+    const int nc = c_hi - c_lo;
+    p.ctg_reads.assign(nc, {});
+    for (int64_t r = 0; r < j->n_reads; r++) {
+        int c = j->h_read_ctg[(size_t)r];
+        if (c >= c_lo && c < c_hi && j->h_summ[(size_t)r].aligned) p.ctg_reads[c - c_lo].push_back(r);
+    }
+    p.cig_off.assign(1, 0); p.seq_off.assign(1, 0); p.rec_begin.assign(1, 0);
+    p.last_pos.assign(nc, -1); p.max_span.assign(nc, 0); p.n_columns.assign(nc, 0);
+    for (int c = 0; c < nc; c++) {
+        auto &v = p.ctg_reads[c];
+        std::sort(v.begin(), v.end(), [&](int64_t a, int64_t b) {
+            int32_t pa = j->h_summ[(size_t)a].pos, pb = j->h_summ[(size_t)b].pos;
+            return pa != pb ? pa < pb : a < b;
+        });
+        for (size_t q = 0; q < v.size(); q++) {
+            const int64_t r = v[q];
+            const fzp_aln_summary &s = j->h_summ[(size_t)r];
+            const int64_t n = j->h_read_len[(size_t)r];
+            const int64_t n_del = (int64_t)(s.ref_end - s.pos) - s.n_columns;
+            const int64_t total_aln_pos = n + n_del;                       // sum of all CIGAR op lengths
+            const int64_t skip_base = (int64_t)s.q_start + (n - s.q_end);   // soft clips
+            if (1.0 - 1.0 * (double)skip_base / (double)total_aln_pos < 0.1) continue;   // phasing.py:72
+            if (total_aln_pos < 2000) continue;                                          // phasing.py:74
+            p.rec_read.push_back(r);
+            p.rec_qid.push_back((int32_t)q);
+            p.rec_pos.push_back(s.pos);
+            p.rec_ctg.push_back(c);
+            p.cig_off.push_back(p.cig_off.back() + s.n_cigar);
+            p.seq_off.push_back(p.seq_off.back() + n);
+            p.last_pos[c] = s.pos;
+            p.max_span[c] = std::max(p.max_span[c], s.ref_end - s.pos);
+            p.n_columns[c] += s.n_columns;
+        }
+        p.rec_begin.push_back((int64_t)p.rec_read.size());
+    }
+}
+
+int gather_records(fzp_ctx *ctx, fzp_alnjob *j, const RecPlan &p, DevBuf<uint32_t> &cigar, DevBuf<uint8_t> &seq, DevBuf<int64_t> &d_cig_off, DevBuf<int64_t> &d_seq_off) {
+    hipStream_t st = ctx->stream;
+    const int64_t nrec = (int64_t)p.rec_read.size();
+    DevBuf<int64_t> d_rec_read;
+    FZP_TRY(d_rec_read.upload(p.rec_read.data(), (size_t)nrec, st));
+    FZP_TRY(d_cig_off.upload(p.cig_off.data(), p.cig_off.size(), st));
+    FZP_TRY(d_seq_off.upload(p.seq_off.data(), p.seq_off.size(), st));
+    FZP_TRY(cigar.alloc((size_t)p.cig_off.back()));
+    FZP_TRY(seq.alloc((size_t)p.seq_off.back()));
+    if (nrec > 0) {
+        ProfScope ps(ctx, "k1_gather");
+        hipLaunchKernelGGL(k_gather, dim3((unsigned)nrec, 4), dim3(256), 0, st, nrec, d_rec_read.p, j->cig_start.p, j->cig.p, d_cig_off.p, cigar.p, j->read_ori.p,
+                           j->read_woff.p, d_seq_off.p, seq.p);
+    }
+    FZP_HIP(hipStreamSynchronize(st));
+    FZP_HIP(hipGetLastError());
+    return FZP_OK;
+}
+template <class T>
+T *dupv(const std::vector<T> &v) {
+    T *p = (T *)malloc((v.size() ? v.size() : 1) * sizeof(T));
+    if (p && !v.empty()) memcpy(p, v.data(), v.size() * sizeof(T));
+    return p;
+}
+}  // namespace
+
+extern "C" int fzp_align_alnset(fzp_ctx *ctx, fzp_alnjob *j, int32_t ctg, const int64_t *name_off, const char *names, fzp_alnset **out, int64_t **read_index) {
+    if (!ctx || !j || !j->done || !out || ctg < 0 || ctg >= j->n_ctg) { fzp_set_error("fzp_align_alnset: bad arguments or job not run"); return FZP_EINVAL; }
+    FZP_HIP(hipSetDevice(ctx->device));
+    RecPlan p;
+    plan_records(j, ctg, ctg + 1, p);
+    DevBuf<uint32_t> cigar;
+    DevBuf<uint8_t> seq;
+    DevBuf<int64_t> dco, dso;
+    FZP_TRY(gather_records(ctx, j, p, cigar, seq, dco, dso));
+    fzp_alnset *a = (fzp_alnset *)calloc(1, sizeof(fzp_alnset));
+    if (!a) return FZP_ENOMEM;
+    const int64_t nrec = (int64_t)p.rec_read.size();
+    a->n_rec = nrec;
+    a->rec_qid = dupv(p.rec_qid); a->rec_pos = dupv(p.rec_pos);
+    a->cig_off = dupv(p.cig_off); a->seq_off = dupv(p.seq_off);
+    a->cigar = (uint32_t *)malloc((size_t)std::max<int64_t>(p.cig_off.back(), 1) * 4);
+    a->seq = (uint8_t *)malloc((size_t)std::max<int64_t>(p.seq_off.back(), 1));
+    hipStream_t st = ctx->stream;
+    int rc = cigar.download(a->cigar, (size_t)p.cig_off.back(), st);
+    if (!rc) rc = seq.download(a->seq, (size_t)p.seq_off.back(), st);
+    if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = FZP_EDEVICE;
+    // q_id table: every aligned read of the contig, in sorted order (one SAM line each)
+    const auto &ar = p.ctg_reads[0];
+    a->n_qid = (int32_t)ar.size();
+    std::vector<int64_t> qoff(1, 0);
+    std::string qn;
+    for (int64_t r : ar) {
+        if (names && name_off) qn.append(names + name_off[r], (size_t)(name_off[r + 1] - name_off[r]));
+        else { char t[40]; snprintf(t, sizeof t, "read/%lld", (long long)r); qn += t; }
+        qoff.push_back((int64_t)qn.size());
+    }
+    a->qname_off = dupv(qoff);
+    a->qnames = (char *)malloc(qn.size() + 1);
+    memcpy(a->qnames, qn.c_str(), qn.size() + 1);
+    a->last_pos = p.last_pos[0];
+    a->max_ref_span = p.max_span[0];
+    a->n_columns = p.n_columns[0];
+    if (rc) { fzp_alnset_free(a); return rc; }
+    if (read_index) *read_index = dupv(p.rec_read);
+    *out = a;
+    return FZP_OK;
+}
+
+extern "C" int fzp_align_to_batch(fzp_ctx *ctx, fzp_alnjob *j, fzp_batch **out) {
+    if (!ctx || !j || !j->done || !out) { fzp_set_error("fzp_align_to_batch: job not run"); return FZP_EINVAL; }
+    FZP_HIP(hipSetDevice(ctx->device));
+    *out = nullptr;
+    RecPlan p;
+    plan_records(j, 0, j->n_ctg, p);
+    fzp_batch *b = new fzp_batch();
+    b->n_ctg = j->n_ctg;
+    b->h_rec_begin = p.rec_begin;
+    b->h_goff.assign(1, 0); b->h_qid_off.assign(1, 0);
+    for (int c = 0; c < j->n_ctg; c++) {
+        int32_t limit = p.last_pos[c] > 0 ? p.last_pos[c] : 0;
+        b->h_limit.push_back(limit);
+        b->h_ref_len.push_back(j->h_ctg_len[c]);
+        b->h_goff.push_back(b->h_goff.back() + limit);
+        b->h_qid_off.push_back(b->h_qid_off.back() + (int64_t)p.ctg_reads[c].size());
+        b->n_columns += p.n_columns[c];
+    }
+    b->n_rec = (int64_t)p.rec_read.size();
+    b->n_pos = b->h_goff.back();
+    b->n_qid = b->h_qid_off.back();
+    b->n_cig = p.cig_off.back(); b->n_seq = p.seq_off.back();
+    hipStream_t st = ctx->stream;
+    int rc = gather_records(ctx, j, p, b->cigar, b->seq, b->cig_off, b->seq_off);
+    std::vector<uint8_t> ref((size_t)b->n_pos);
+    for (int c = 0; c < j->n_ctg && !rc; c++)
+        if (b->h_limit[c]) memcpy(ref.data() + b->h_goff[c], j->h_ctg[c].data(), (size_t)b->h_limit[c]);
+    if (!rc) rc = b->rec_pos.upload(p.rec_pos.data(), p.rec_pos.size(), st);
+    if (!rc) rc = b->rec_qid.upload(p.rec_qid.data(), p.rec_qid.size(), st);
+    if (!rc) rc = b->rec_ctg.upload(p.rec_ctg.data(), p.rec_ctg.size(), st);
+    if (!rc) rc = b->ref.upload(ref.data(), ref.size(), st);
+    if (!rc) rc = b->ctg_goff.upload(b->h_goff.data(), b->h_goff.size(), st);
+    if (!rc) rc = b->ctg_qoff.upload(b->h_qid_off.data(), b->h_qid_off.size(), st);
+    if (!rc) rc = b->ctg_limit.upload(b->h_limit.data(), b->h_limit.size(), st);
+    if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = FZP_EDEVICE;
+    if (rc) { delete b; return rc; }
+    b->have_aln = true;
+    *out = b;
+    return FZP_OK;
+}

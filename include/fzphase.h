@@ -210,12 +210,14 @@ typedef struct {             /* per read, input order */
     int32_t ref_end;         /* one past the last aligned contig position */
     int32_t q_start, q_end;  /* aligned part of the (oriented) read */
     int32_t score;
-    int32_t n_cigar;
+    int32_t n_cigar;         /* CIGAR words incl. soft clips */
     int64_t cells;           /* DP cells evaluated for this read (steps * 64) */
+    int32_t n_columns;       /* aligned columns (= and X bases) */
+    int32_t pad_;
 } fzp_aln_summary;
 
-/* reads/contigs are ASCII (ACGT, any case; other symbols are treated as 'A' for seeding/DP and
- * reported verbatim in SEQ).  All reads in one call belong to contig `ctg_seq` (the reference
+/* reads/contigs are ASCII (ACGT, any case; any other symbol is treated as 'A' throughout, and the
+ * SEQ handed to the phasing stages is the oriented read re-spelled in upper-case ACGT).  All reads in one call belong to contig `ctg_seq` (the reference
  * aligns <ctg>_reads.fa to <ctg>_ref.fa, unzip.py:233-234). */
 typedef struct fzp_alnjob fzp_alnjob;
 int fzp_align_create(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *const *ctg_seq, const int64_t *ctg_len,

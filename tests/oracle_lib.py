@@ -102,5 +102,51 @@ class Oracle:
                 "phased_variants": pv, "phased_reads": pr}
 
 
+ALN_SUMMARY = None
+
+
+def _aln_dtype():
+    global ALN_SUMMARY
+    if ALN_SUMMARY is None:
+        import numpy as np
+        ALN_SUMMARY = np.dtype([("aligned", "<i4"), ("strand", "<i4"), ("pos", "<i4"), ("ref_end", "<i4"), ("q_start", "<i4"),
+                                ("q_end", "<i4"), ("score", "<i4"), ("n_cigar", "<i4"), ("cells", "<i8"), ("n_columns", "<i4"),
+                                ("pad_", "<i4")], align=True)
+        assert ALN_SUMMARY.itemsize == 48
+    return ALN_SUMMARY
+
+
+class AlignParams(C.Structure):
+    _fields_ = [("kmer", C.c_int32), ("seed_stride", C.c_int32), ("match", C.c_int32), ("mismatch", C.c_int32),
+                ("gap", C.c_int32), ("min_seed_hits", C.c_int32), ("reserved", C.c_int32 * 10)]
+
+
+def align_reads(orc, ctg: bytes, reads, params=None):
+    """CPU twin of K1 (oracle/align_oracle.c): -> (summaries ndarray, list of cigar word arrays)."""
+    import numpy as np
+    lib = orc.lib
+    P = AlignParams()
+    lib.orc_align_params_default(C.byref(P))
+    for k, v in (params or {}).items():
+        setattr(P, k, v)
+    n = len(reads)
+    off = np.zeros(n + 1, np.int64)
+    off[1:] = np.cumsum([len(r) for r in reads])
+    blob = b"".join(reads)
+    out = np.zeros(n, _aln_dtype())
+    cig_off = np.zeros(n + 1, np.int64)
+    cp = C.c_void_p()
+    f = lib.orc_align_reads
+    f.restype = C.c_int
+    f.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p]
+    rc = f(ctg, len(ctg), n, off.ctypes.data, blob, C.addressof(P), out.ctypes.data, C.byref(cp), cig_off.ctypes.data)
+    if rc:
+        raise OracleError("orc_align_reads rc=%d" % rc)
+    total = int(cig_off[-1])
+    words = np.frombuffer(C.string_at(cp.value, total * 4), dtype=np.uint32).copy() if total else np.zeros(0, np.uint32)
+    lib.orc_free(cp)
+    return out, [words[cig_off[i]:cig_off[i + 1]] for i in range(n)]
+
+
 def load():
     return Oracle(build())
