@@ -388,6 +388,25 @@ def align_job(eng, contigs, reads, read_ctg=None, params=None) -> AlignJob:
     return AlignJob(eng, p.value, nr, nc)
 
 
+def align_job_raw(eng, contigs, read_blob: bytes, read_off, read_ctg, params=None) -> AlignJob:
+    """Like align_job, with the reads already concatenated (read_off: int64 [n+1])."""
+    lib = load()
+    nc = len(contigs)
+    read_off = np.ascontiguousarray(read_off, dtype=np.int64)
+    nr = len(read_off) - 1
+    cbufs = [C.create_string_buffer(c, len(c)) if len(c) else C.create_string_buffer(1) for c in contigs]
+    cptr = (C.c_void_p * nc)(*[C.cast(b, C.c_void_p).value for b in cbufs])
+    clen = (C.c_int64 * nc)(*[len(c) for c in contigs])
+    rc = np.ascontiguousarray(read_ctg, dtype=np.int32)
+    P = AlignParams()
+    lib.fzp_align_params_default(C.byref(P))
+    for k, v in (params or {}).items():
+        setattr(P, k, v)
+    p = C.c_void_p()
+    _check(lib.fzp_align_create(eng._p, nc, cptr, clen, nr, _ptr(rc), _ptr(read_off), read_blob, C.byref(P), C.byref(p)))
+    return AlignJob(eng, p.value, nr, nc)
+
+
 def format_sam(aln: AlnSet, ctg_id: str, flags=None):
     fl = None if flags is None else np.ascontiguousarray(flags, dtype=np.int32)
     return _fmt("fzp_format_sam", C.c_void_p(aln._p), ctg_id.encode(), None if fl is None else _ptr(fl))

@@ -171,3 +171,44 @@ def write_fasta(path, records, width=0):
                     f.write(seq[i:i + width] + "\n")
             else:
                 f.write(seq + "\n")
+
+
+def simulate_raw_reads_bulk(hap0, hap1, n_reads, R, rng, lo=0, hi=None, sub=0.01, ins=0.08, dele=0.04, strand_mix=0.5):
+    """Vectorised generator for benchmarks: raw (as-sequenced) reads only, no truth CIGARs.
+
+    Same error model as simulate_read (per template base: optional 1-base insert, then match / sub / del),
+    with 16-bit thresholds; read starts are uniform in [lo, hi - R].
+    Returns (codes uint8 [total], off int64 [n+1], start, hap, strand)."""
+    L = hap0.size
+    hi = L if hi is None else hi
+    starts = rng.integers(lo, max(lo + 1, hi - R + 1), size=n_reads)
+    haps = rng.integers(0, 2, size=n_reads)
+    strands = (rng.random(n_reads) < strand_mix)
+    T = np.empty((n_reads, R), dtype=np.uint8)
+    for i in range(n_reads):
+        T[i] = (hap1 if haps[i] else hap0)[starts[i]:starts[i] + R]
+    u = rng.integers(0, 65536, size=(n_reads, R), dtype=np.uint16)
+    t_del, t_sub, t_ins = int(dele * 65536), int((dele + sub) * 65536), int(ins * 65536)
+    is_del = u < t_del
+    is_sub = (u >= t_del) & (u < t_sub)
+    v = rng.integers(0, 65536, size=(n_reads, R), dtype=np.uint16)
+    has_ins = v < t_ins
+    is_del[:, 0] = False
+    is_del[:, -1] = False
+    has_ins[:, 0] = False
+    rnd = rng.integers(0, 256, size=(n_reads, R), dtype=np.uint8)
+    T[is_sub] = (T[is_sub] + 1 + (rnd[is_sub] % 3)) & 3
+    E = np.empty((n_reads, R, 2), dtype=np.uint8)
+    E[:, :, 0] = (rnd >> 4) & 3            # inserted base
+    E[:, :, 1] = T
+    keep = np.empty((n_reads, R, 2), dtype=bool)
+    keep[:, :, 0] = has_ins
+    keep[:, :, 1] = ~is_del
+    lens = keep.reshape(n_reads, -1).sum(axis=1)
+    codes = E[keep]
+    off = np.zeros(n_reads + 1, np.int64)
+    off[1:] = np.cumsum(lens)
+    for i in np.flatnonzero(strands):
+        a, b = off[i], off[i + 1]
+        codes[a:b] = _COMP[codes[a:b][::-1]]
+    return codes, off, starts, haps, strands.astype(np.int64)
