@@ -30,7 +30,7 @@ __global__ void __launch_bounds__(256) k_pack(const uint8_t *__restrict__ ascii,
                                               uint32_t *__restrict__ out) {
     const int64_t s = blockIdx.x;
     const int64_t b0 = seq_off[s], n = seq_off[s + 1] - b0;
-    const int64_t nw = (n + 15) / 16 + 2;   // two zero pad words so 64-bit windows never run off the end
+    const int64_t nw = ((n + 15) / 16 + 8 + 1) & ~1LL;   // zero pad words: 64-bit base windows may run past the end
     uint32_t *dst = out + woff[s];
     for (int64_t w = (int64_t)blockIdx.y * 256 + threadIdx.x; w < nw; w += (int64_t)gridDim.y * 256) {
         uint32_t v = 0;
@@ -169,7 +169,7 @@ __global__ void __launch_bounds__(256) k_orient(int64_t first, const uint32_t *_
                                                 const Anchor *__restrict__ anc, uint32_t *__restrict__ out) {
     const int64_t r = first + blockIdx.x;
     const int64_t n = read_len[r];
-    const int64_t nw = (n + 15) / 16 + 2;
+    const int64_t nw = ((n + 15) / 16 + 8 + 1) & ~1LL;
     const uint32_t *src = read_pk + read_woff[r];
     uint32_t *dst = out + read_woff[r];
     const bool rc = anc[r].strand != 0;
@@ -197,6 +197,101 @@ __device__ __forceinline__ int32_t wave_shl1(int32_t v, int32_t fill) {   // lan
 }
 
 // ---- K1 hot kernel: adaptive banded DP, one wave per read
+//
+// Lane k of the wave owns cell (i = i0 + k, j = t - i) of anti-diagonal t.  Per step the band moves
+// DOWN (i0++) or RIGHT.  With A = the previous step's value in the same lane and B = the neighbour
+// lane's (lane k+1 after DOWN, k-1 after RIGHT), both already minus the gap penalty:
+//      H = max3(diag + s, A, B)
+// The diagonal operand is kept pre-shifted: X = H(t-2) moved by (previous move) so that this step needs
+// one more wave_shl only when it moves DOWN (after RIGHT->DOWN lane 63 sees the band edge).
+// Trace-back masks per step: D = (H == diag + s), G = (A >= B)  ("the gap comes from the same lane").
+// Upcoming read / contig bases sit in 64-bit SGPR windows (32 bases) refilled one window ahead, so no
+// step waits on memory; masks are parked in lane (t & 63) of four VGPRs by v_writelane and leave as
+// one coalesced 1 KB store per 64 steps.  The interior of the matrix runs a counted loop with no
+// range checks; the first ~130 and last ~64 steps run the checked variant.
+struct BaseStream {          // wave-uniform: lives in SGPRs
+    const uint64_t *pk;      // 32 bases per word
+    int64_t w;               // index of the word in `cur`
+    uint64_t cur, nxt;
+    int cnt;                 // bases left in cur
+    __device__ __forceinline__ void init(const uint32_t *pk32, int64_t abs_idx) {
+        pk = (const uint64_t *)pk32;
+        w = abs_idx >> 5;
+        cur = pk[w] >> ((abs_idx & 31) * 2);
+        cnt = 32 - (int)(abs_idx & 31);
+        nxt = pk[w + 1];
+    }
+    __device__ __forceinline__ int32_t pop() {
+        int32_t c = (int32_t)(cur & 3ull);
+        cur >>= 2;
+        if (--cnt == 0) { cur = nxt; cnt = 32; w++; nxt = pk[w + 1]; }
+        return c;
+    }
+};
+
+#define SW_PARK(sl)                                                                                                              \
+    asm volatile("s_mov_b32 m0, %8\n\t"                                                                                           \
+                 "v_writelane_b32 %0, %4, m0\n\t"                                                                                 \
+                 "v_writelane_b32 %1, %5, m0\n\t"                                                                                 \
+                 "v_writelane_b32 %2, %6, m0\n\t"                                                                                 \
+                 "v_writelane_b32 %3, %7, m0"                                                                                     \
+                 : "+v"(vD0), "+v"(vD1), "+v"(vG0), "+v"(vG1)                                                                     \
+                 : "s"((int32_t)(uint32_t)Dm), "s"((int32_t)(uint32_t)(Dm >> 32)), "s"((int32_t)(uint32_t)Gm),                   \
+                   "s"((int32_t)(uint32_t)(Gm >> 32)), "s"(sl)                                                                    \
+                 : "m0")
+
+// one DP step; FULL adds the sentinel / validity handling needed outside the matrix interior
+#define SW_STEP(FULL)                                                                                                            \
+    {                                                                                                                            \
+        int32_t B, dg, Xn;                                                                                                       \
+        if (down) {                                                                                                              \
+            int32_t c = qs.pop();                                                                                                \
+            if (FULL) c = qpos < nq ? c : 4;                                                                                     \
+            qpos++;                                                                                                              \
+            i0++;                                                                                                                \
+            qc = wave_shl1(qc, c);                                                                                               \
+            B = wave_shl1(Hg, NEGV);                                                                                             \
+            dg = wave_shl1(X, NEGV);                                                                                             \
+            Xn = Hp;                                                                                                             \
+        } else {                                                                                                                 \
+            int32_t c = ts.pop();                                                                                                \
+            if (FULL) c = tpos < nt ? c : 5;                                                                                     \
+            tpos++;                                                                                                              \
+            tc = wave_shr1(tc, c);                                                                                               \
+            B = wave_shr1(Hg, NEGV);                                                                                             \
+            dg = X;                                                                                                              \
+            Xn = wave_shr1(Hp, NEGV);                                                                                            \
+        }                                                                                                                        \
+        const int32_t hd = dg + (qc == tc ? match : -mismatch);                                                                  \
+        const int32_t H = max(hd, max(Hg, B));                                                                                   \
+        const uint64_t Dm = __ballot(H == hd);                                                                                   \
+        const uint64_t Gm = __ballot(Hg >= B);                                                                                   \
+        bool upd = H > bs;                                                                                                       \
+        if (FULL) {                                                                                                              \
+            const int32_t ci = i0 + lane, cj = t - ci;                                                                           \
+            upd = upd && ci >= 0 && ci < nq && cj >= 0 && cj < nt;                                                               \
+        }                                                                                                                        \
+        bs = upd ? H : bs;                                                                                                       \
+        bt = upd ? t : bt;                                                                                                       \
+        const int sl = t & 63;                                                                                                   \
+        SW_PARK(sl);                                                                                                             \
+        mvacc |= (uint64_t)(down ? 1 : 0) << sl;                                                                                 \
+        const int32_t top = __builtin_amdgcn_readlane(H, 0), bot = __builtin_amdgcn_readlane(H, 63);                             \
+        X = Xn;                                                                                                                  \
+        Hp = H;                                                                                                                  \
+        Hg = H - gap;                                                                                                            \
+        t++;                                                                                                                     \
+        down = t < 64 ? ((t & 1) == 0) : !(top > bot);                                                                           \
+    }
+
+#define SW_FLUSH()                                                                                                               \
+    {                                                                                                                            \
+        tbr[((t - 1) & ~63) + lane] = make_ulonglong2(((uint64_t)(uint32_t)vD1 << 32) | (uint32_t)vD0,                           \
+                                                      ((uint64_t)(uint32_t)vG1 << 32) | (uint32_t)vG0);                           \
+        if (lane == 0) mvr[(t - 1) >> 6] = mvacc;                                                                                \
+        mvacc = 0;                                                                                                               \
+    }
+
 __global__ void __launch_bounds__(256) k_sw(int64_t first, int64_t count, const uint32_t *__restrict__ read_ori, const int64_t *__restrict__ read_woff,
                                             const int32_t *__restrict__ read_len, const int32_t *__restrict__ read_ctg, const uint32_t *__restrict__ ctg_pk,
                                             const int64_t *__restrict__ ctg_woff, const int64_t *__restrict__ ctg_len, const Anchor *__restrict__ anc,
@@ -209,21 +304,23 @@ __global__ void __launch_bounds__(256) k_sw(int64_t first, int64_t count, const 
     const int64_t r = first + wv;
     const Anchor a = anc[r];
     if (!a.aligned) { if (lane == 0) info[r] = DpInfo{0, -1, 0, NEGV}; return; }
-    const int c = read_ctg[r];
+    const int c_idx = read_ctg[r];
     const int64_t n = read_len[r];
     const int32_t nq = (int32_t)(n - a.i_a);
-    int64_t ntl = ctg_len[c] - a.c_a;
+    int64_t ntl = ctg_len[c_idx] - a.c_a;
     if (ntl > (int64_t)nq + nq / 4 + 64) ntl = (int64_t)nq + nq / 4 + 64;
     const int32_t nt = (int32_t)ntl;
     const uint32_t *qpk = read_ori + read_woff[r];
-    const uint32_t *tpk = ctg_pk + ctg_woff[c];
+    const uint32_t *tpk = ctg_pk + ctg_woff[c_idx];
     const int64_t qb = a.i_a, tbase = a.c_a;
     const int32_t max_steps = nq + nt + 2;
     ulonglong2 *tbr = tb + (tb_off[r] - tb_off[first]);
     uint64_t *mvr = mvw + ((tb_off[r] - tb_off[first]) >> 6) + wv;
 
-    int32_t Hpp = lane == 32 ? 0 : NEGV;
+    // state before step 0: H(-1) in Hp, X = H(-2) as seen after the (virtual) RIGHT move of step -1
     int32_t Hp = (lane == 32 || lane == 33) ? -gap : NEGV;
+    int32_t Hg = Hp - gap;
+    int32_t X = lane == 33 ? 0 : NEGV;
     int32_t qc, tc;
     {
         int32_t i = lane - 33, j = 32 - lane;
@@ -231,48 +328,36 @@ __global__ void __launch_bounds__(256) k_sw(int64_t first, int64_t count, const 
         tc = (j >= 0 && j < nt) ? (int32_t)base_at(tpk, tbase + j) : 5;
     }
     int32_t bs = NEGV, bt = -1;
-    int32_t i0 = -33, t = 0;
-    bool prev_down = false, steer = true;
+    int32_t vD0 = 0, vD1 = 0, vG0 = 0, vG1 = 0;
+    int32_t i0 = -33, t = 0, qpos = 31, tpos = 33;
     uint64_t mvacc = 0;
-    for (;;) {
-        const bool down = t < 64 ? ((t & 1) == 0) : steer;
-        int32_t up, left, dg;
-        if (down) {
-            i0++;
-            const int32_t iq = i0 + 63;
-            const int32_t nc = iq < nq ? (int32_t)base_at(qpk, qb + iq) : 4;
-            qc = wave_shl1(qc, nc);
-            up = Hp;
-            left = wave_shl1(Hp, NEGV);
-        } else {
-            const int32_t jt = t - i0;
-            const int32_t nc = jt < nt ? (int32_t)base_at(tpk, tbase + jt) : 5;
-            tc = wave_shr1(tc, nc);
-            up = wave_shr1(Hp, NEGV);
-            left = Hp;
+    bool down = true;
+    BaseStream qs, ts;
+    qs.init(qpk, qb + 31);
+    ts.init(tpk, tbase + 33);
+    bool done = false;
+    while (!done) {
+        // how many steps can run with every lane strictly inside the matrix?  Each step advances i0 or
+        // lane 0's column by one, so min(rows left, columns left) steps are safe once the band is inside.
+        int32_t safe = 0;
+        if (t >= 64 && i0 >= 0 && (t - 1) - (i0 + 63) >= 0) {
+            const int32_t rows_left = nq - 1 - (i0 + 63), cols_left = nt - 1 - ((t - 1) - i0);
+            safe = min(rows_left, cols_left);
         }
-        if (down && prev_down) dg = wave_shl1(Hpp, NEGV);
-        else if (!down && !prev_down) dg = wave_shr1(Hpp, NEGV);
-        else dg = Hpp;
-        const int32_t s = qc == tc ? match : -mismatch;
-        const int32_t hd = dg + s, hu = up - gap, hl = left - gap;
-        const int32_t H = max(hd, max(hu, hl));
-        const uint64_t D = __ballot(H == hd);
-        const uint64_t U = __ballot(hu >= hl);
-        const int32_t i = i0 + lane, j = t - i;
-        if (i >= 0 && i < nq && j >= 0 && j < nt && H > bs) { bs = H; bt = t; }
-        if (lane == 0) tbr[t] = make_ulonglong2(D, U);
-        mvacc |= (uint64_t)(down ? 1 : 0) << (t & 63);
-        if ((t & 63) == 63) { if (lane == 0) mvr[t >> 6] = mvacc; mvacc = 0; }
-        const int32_t top = __builtin_amdgcn_readlane(H, 0), bot = __builtin_amdgcn_readlane(H, 63);
-        steer = !(top > bot);
-        Hpp = Hp; Hp = H; prev_down = down;
-        t++;
-        if (i0 > nq - 1) break;
-        if ((t - 1) - (i0 + 63) > nt - 1) break;
-        if (t >= max_steps) break;
+        if (safe > 0) {
+            while (safe > 0) {
+                int32_t m = min(safe, 64 - (t & 63));
+                safe -= m;
+                for (; m > 0; m--) SW_STEP(false)
+                if ((t & 63) == 0) SW_FLUSH()
+            }
+        } else {
+            SW_STEP(true)
+            if ((t & 63) == 0) SW_FLUSH()
+            if (i0 > nq - 1 || (t - 1) - (i0 + 63) > nt - 1 || t >= max_steps) done = true;
+        }
     }
-    if ((t & 63) != 0 && lane == 0) mvr[t >> 6] = mvacc;
+    if ((t & 63) != 0) SW_FLUSH()
     // best cell: max score, then earliest step, then lowest lane
     int32_t s_b = bs, t_b = bt < 0 ? 0x7fffffff : bt, l_b = lane;
 #pragma unroll
@@ -283,6 +368,9 @@ __global__ void __launch_bounds__(256) k_sw(int64_t first, int64_t count, const 
     }
     if (lane == 0) info[r] = DpInfo{t, t_b == 0x7fffffff ? -1 : t_b, l_b, s_b};
 }
+#undef SW_STEP
+#undef SW_FLUSH
+#undef SW_PARK
 
 // ---- trace-back: one lane per read
 __global__ void __launch_bounds__(64) k_traceback(int64_t first, int64_t count, const uint32_t *__restrict__ read_ori, const int64_t *__restrict__ read_woff,
@@ -332,7 +420,8 @@ __global__ void __launch_bounds__(64) k_traceback(int64_t first, int64_t count, 
             const bool d2 = ts >= 1 ? ((mvr[(ts - 1) >> 6] >> ((ts - 1) & 63)) & 1ull) : false;   // move(-1) = RIGHT
             i0 -= (d1 ? 1 : 0) + (d2 ? 1 : 0);
             ts -= 2;
-        } else if ((m.y >> kk) & 1ull) {
+        } else if ((((m.y >> kk) & 1ull) != 0) == d1) {
+            // G set after a DOWN move, or clear after a RIGHT move: the predecessor is the cell above
             op = FZP_OP_I; i--; i0 -= d1 ? 1 : 0; ts -= 1;
         } else {
             op = FZP_OP_D; j--; i0 -= d1 ? 1 : 0; ts -= 1;
@@ -452,7 +541,7 @@ extern "C" int fzp_align_create(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *cons
         }
         j->h_ctg_len.push_back(ctg_len[c]);
         j->h_ctg_woff.push_back(j->ctg_words);
-        j->ctg_words += (ctg_len[c] + 15) / 16 + 2;
+        j->ctg_words += ((ctg_len[c] + 15) / 16 + 8 + 1) & ~1LL;
         int64_t nk = ctg_len[c] - j->P.kmer + 1;
         int bits = 10;
         while ((1LL << bits) < 2 * std::max<int64_t>(nk, 1)) bits++;
@@ -471,7 +560,7 @@ extern "C" int fzp_align_create(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *cons
         if (n < 0 || n > 0x3fff0000LL || read_ctg[r] < 0 || read_ctg[r] >= n_ctg) { delete j; fzp_set_error("read %lld: bad length/contig", (long long)r); return FZP_EINVAL; }
         j->h_read_len.push_back((int32_t)n);
         j->h_read_ctg.push_back(read_ctg[r]);
-        j->read_words += (n + 15) / 16 + 2;
+        j->read_words += ((n + 15) / 16 + 8 + 1) & ~1LL;
         j->h_read_woff.push_back(j->read_words);
         j->h_tb_off.push_back(j->h_tb_off.back() + (n + n + n / 4 + 64 + 2 + 63) / 64 * 64);   // steps capacity, multiple of 64
         j->h_cig_off.push_back(j->h_cig_off.back() + n + 18);
@@ -479,14 +568,14 @@ extern "C" int fzp_align_create(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *cons
     DevBuf<uint8_t> d_ascii;
     DevBuf<int64_t> d_off;
     do {
-        if ((rc = j->ctg_pk.alloc((size_t)j->ctg_words)) || (rc = d_ascii.upload(call.data(), call.size(), st)) || (rc = d_off.upload(coff.data(), coff.size(), st)) ||
+        if ((rc = j->ctg_pk.alloc((size_t)j->ctg_words + 8)) || (rc = d_ascii.upload(call.data(), call.size(), st)) || (rc = d_off.upload(coff.data(), coff.size(), st)) ||
             (rc = j->ctg_woff.upload(j->h_ctg_woff.data(), j->h_ctg_woff.size(), st)) || (rc = j->ctg_len.upload(j->h_ctg_len.data(), j->h_ctg_len.size(), st)) ||
             (rc = j->idx_off.upload(j->h_idx_off.data(), j->h_idx_off.size(), st)) || (rc = j->idx_bits.upload(j->h_idx_bits.data(), j->h_idx_bits.size(), st)))
             break;
         hipLaunchKernelGGL(k_pack, dim3(n_ctg, 64), dim3(256), 0, st, d_ascii.p, d_off.p, j->ctg_woff.p, j->ctg_pk.p);
         if (hipStreamSynchronize(st) != hipSuccess) { rc = FZP_EDEVICE; break; }
         if (n_reads) {
-            if ((rc = j->read_pk.alloc((size_t)j->read_words)) || (rc = j->read_ori.alloc((size_t)j->read_words)) ||
+            if ((rc = j->read_pk.alloc((size_t)j->read_words + 8)) || (rc = j->read_ori.alloc((size_t)j->read_words + 8)) ||
                 (rc = d_ascii.upload(read_seq + read_off[0], (size_t)(read_off[n_reads] - read_off[0]), st)))
                 break;
             std::vector<int64_t> roff((size_t)n_reads + 1);

@@ -19,9 +19,13 @@
  *   extension adaptive anti-diagonal band of 64 cells (Suzuki-Kasahara style), forward from the
  *             anchor: linear gaps, H = max(diag + (match | -mismatch), up - gap, left - gap), no zero
  *             floor; the first 64 steps alternate down/right, afterwards the band moves RIGHT when
- *             H[lane 0] > H[lane 63], else DOWN.  The alignment ends at the best-scoring valid cell
+ *             H[lane 0] > H[lane 63], else DOWN.  The diagonal operand is carried pre-shifted by the
+ *             previous move, so after a RIGHT move followed by a DOWN move lane 63 has no diagonal
+ *             predecessor (band edge).  The alignment ends at the best-scoring valid cell
  *             (first in step order, then lowest lane); read bases before the anchor and after the
- *             end are soft-clipped.  Trace-back priority: diagonal, then up (insertion), then left.
+ *             end are soft-clipped.  Trace-back priority: diagonal, then the gap whose source is the
+ *             same lane of the previous step (the cell above after a DOWN move, the cell to the left
+ *             after a RIGHT move), then the other gap.
  */
 #define _GNU_SOURCE
 #include <stdint.h>
@@ -132,49 +136,47 @@ static void align_one(const ctg_index *ix, const uint8_t *fwd, int64_t n, const 
     uint8_t *mv = (uint8_t *)malloc((size_t)max_steps);
 #define QC(i) (((i) >= 0 && (i) < nq) ? q[i] : 4)
 #define TC(j) (((j) >= 0 && (j) < nt) ? t[j] : 5)
-    int32_t Hp[W], Hpp[W], H[W], bsc[W]; int64_t bt[W];
+    int32_t Hp[W], X[W], H[W], bsc[W]; int64_t bt[W];
     int qc[W], tc[W];
     int64_t i0 = -33;
     for (int kk = 0; kk < W; kk++) {
-        Hpp[kk] = kk == 32 ? 0 : NEG;
+        X[kk] = kk == 33 ? 0 : NEG;      /* H(-2) as seen after the virtual RIGHT move of step -1 */
         Hp[kk] = (kk == 32 || kk == 33) ? -P->gap : NEG;
         int64_t i = kk - 33, j = 32 - kk;
         qc[kk] = QC(i); tc[kk] = TC(j);
         bsc[kk] = NEG; bt[kk] = -1;
     }
-    int prev_down = 0, steer = 1;
+    int steer = 1;
     int64_t tt = 0;
     for (;;) {
         int down = tt < 64 ? ((tt & 1) == 0) : steer;
-        int32_t up[W], left[W], dg[W];
+        int32_t A[W], B[W], dg[W], Xn[W];   /* A: previous step, same lane; B: previous step, neighbour lane (both minus gap) */
         if (down) {
             i0++;
             for (int kk = 0; kk < W - 1; kk++) qc[kk] = qc[kk + 1];
             qc[W - 1] = QC(i0 + 63);
-            for (int kk = 0; kk < W; kk++) { up[kk] = Hp[kk]; left[kk] = kk < W - 1 ? Hp[kk + 1] : NEG; }
+            for (int kk = 0; kk < W; kk++) { A[kk] = Hp[kk] - P->gap; B[kk] = kk < W - 1 ? Hp[kk + 1] - P->gap : NEG; }
+            for (int kk = 0; kk < W; kk++) { dg[kk] = kk < W - 1 ? X[kk + 1] : NEG; Xn[kk] = Hp[kk]; }
         } else {
             for (int kk = W - 1; kk > 0; kk--) tc[kk] = tc[kk - 1];
             tc[0] = TC(tt - i0);
-            for (int kk = 0; kk < W; kk++) { up[kk] = kk > 0 ? Hp[kk - 1] : NEG; left[kk] = Hp[kk]; }
+            for (int kk = 0; kk < W; kk++) { A[kk] = Hp[kk] - P->gap; B[kk] = kk > 0 ? Hp[kk - 1] - P->gap : NEG; }
+            for (int kk = 0; kk < W; kk++) { dg[kk] = X[kk]; Xn[kk] = kk > 0 ? Hp[kk - 1] : NEG; }
         }
-        if (down && prev_down) for (int kk = 0; kk < W; kk++) dg[kk] = kk < W - 1 ? Hpp[kk + 1] : NEG;
-        else if (!down && !prev_down) for (int kk = 0; kk < W; kk++) dg[kk] = kk > 0 ? Hpp[kk - 1] : NEG;
-        else for (int kk = 0; kk < W; kk++) dg[kk] = Hpp[kk];
         uint64_t D = 0, U = 0;
         for (int kk = 0; kk < W; kk++) {
             int32_t s = qc[kk] == tc[kk] ? P->match : -P->mismatch;
-            int32_t hd = dg[kk] + s, hu = up[kk] - P->gap, hl = left[kk] - P->gap;
-            int32_t h = hd > hu ? hd : hu; if (hl > h) h = hl;
+            int32_t hd = dg[kk] + s;
+            int32_t h = hd > A[kk] ? hd : A[kk]; if (B[kk] > h) h = B[kk];
             H[kk] = h;
             if (h == hd) D |= 1ull << kk;
-            if (hu >= hl) U |= 1ull << kk;
+            if (A[kk] >= B[kk]) U |= 1ull << kk;       /* "the gap comes from the same lane" */
             int64_t i = i0 + kk, j = tt - i;
             if (i >= 0 && i < nq && j >= 0 && j < nt && h > bsc[kk]) { bsc[kk] = h; bt[kk] = tt; }
         }
         tbD[tt] = D; tbU[tt] = U; mv[tt] = (uint8_t)down;
         steer = !(H[0] > H[W - 1]);
-        memcpy(Hpp, Hp, sizeof Hp); memcpy(Hp, H, sizeof H);
-        prev_down = down;
+        memcpy(X, Xn, sizeof X); memcpy(Hp, H, sizeof H);
         tt++;
         if (i0 > nq - 1) break;
         if ((tt - 1) - (i0 + 63) > nt - 1) break;
@@ -204,7 +206,7 @@ static void align_one(const ctg_index *ix, const uint8_t *fwd, int64_t n, const 
             int kk = (int)(i - i0s[ts]);
             int op;
             if ((tbD[ts] >> kk) & 1) { op = q[i] == t[j] ? 7 : 8; i--; j--; ts -= 2; ncol++; }
-            else if ((tbU[ts] >> kk) & 1) { op = 1; i--; ts -= 1; }
+            else if ((((tbU[ts] >> kk) & 1) != 0) == (mv[ts] != 0)) { op = 1; i--; ts -= 1; }   /* the cell above */
             else { op = 2; j--; ts -= 1; }
             if (op == cur_op) cur_len++;
             else { if (cur_len) push(&rev, (cur_len << 4) | (uint32_t)cur_op); cur_op = op; cur_len = 1; }
