@@ -131,10 +131,16 @@ def main():
 
     stats = {}
 
+    host_t = {"align_run": 0.0, "to_batch": 0.0, "phase_run": 0.0, "results": 0.0, "allgather": 0.0}
+
     def step():
+        t_a = time.perf_counter()
         job.run()
+        t_b = time.perf_counter()
         b = job.to_batch()
+        t_c = time.perf_counter()
         b.run(_lib.STAGE_ALL)
+        t_d = time.perf_counter()
         recs = []
         n_phased = 0
         qoff = 0
@@ -147,11 +153,17 @@ def main():
         stats.update(b.counts())
         stats["reads_phased"] = n_phased
         b.close()
+        t_e = time.perf_counter()
         allr = fdist.allgather_r2p(np.concatenate(recs), device=("cuda:%d" % local_rank) if world > 1 else None)
         stats["r2p_records"] = len(allr)
+        t_f = time.perf_counter()
+        for k, v in zip(host_t, (t_b - t_a, t_c - t_b, t_d - t_c, t_e - t_d, t_f - t_e)):
+            host_t[k] += v
 
     for _ in range(args.warmup):
         step()
+    for k in host_t:
+        host_t[k] = 0.0
     eng.prof_reset()
     eng.prof_enable(True)
     barrier()
@@ -198,6 +210,7 @@ def main():
             "aligned_frac": round(float(summ["aligned"].mean()), 4),
             "stage_counts": {k: int(v) for k, v in stats.items()},
             "kernel_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in sorted(prof.items())},
+            "host_wall_ms_per_step": {k: round(v / args.steps * 1e3, 3) for k, v in host_t.items()},
             "roofline": {"bound": "hbm", "kernel": "k1_sw", "achieved": round(cells_per_launch * SW_BYTES_PER_CELL / (sw_avg_ms * 1e-3) / 1e9, 2) if sw_avg_ms else 0.0,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(cells_per_launch * SW_BYTES_PER_CELL / (sw_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if sw_avg_ms else 0.0,

@@ -288,14 +288,14 @@ struct BaseStream {          // wave-uniform: lives in SGPRs
     {                                                                                                                            \
         tbr[((t - 1) & ~63) + lane] = make_ulonglong2(((uint64_t)(uint32_t)vD1 << 32) | (uint32_t)vD0,                           \
                                                       ((uint64_t)(uint32_t)vG1 << 32) | (uint32_t)vG0);                           \
-        if (lane == 0) mvr[(t - 1) >> 6] = mvacc;                                                                                \
+        if (lane == 0) mvr[(t - 1) >> 6] = make_ulonglong2(mvacc, (uint64_t)(int64_t)(i0 - __popcll(mvacc)));                    \
         mvacc = 0;                                                                                                               \
     }
 
 __global__ void __launch_bounds__(256) k_sw(int64_t first, int64_t count, const uint32_t *__restrict__ read_ori, const int64_t *__restrict__ read_woff,
                                             const int32_t *__restrict__ read_len, const int32_t *__restrict__ read_ctg, const uint32_t *__restrict__ ctg_pk,
                                             const int64_t *__restrict__ ctg_woff, const int64_t *__restrict__ ctg_len, const Anchor *__restrict__ anc,
-                                            const int64_t *__restrict__ tb_off, ulonglong2 *__restrict__ tb, uint64_t *__restrict__ mvw, int match, int mismatch,
+                                            const int64_t *__restrict__ tb_off, ulonglong2 *__restrict__ tb, ulonglong2 *__restrict__ mvw, int match, int mismatch,
                                             int gap, DpInfo *__restrict__ info) {
     const int lane = lane_id();
     // wave-uniform on purpose: everything indexed by the read then lives in SGPRs / scalar loads
@@ -315,7 +315,7 @@ __global__ void __launch_bounds__(256) k_sw(int64_t first, int64_t count, const 
     const int64_t qb = a.i_a, tbase = a.c_a;
     const int32_t max_steps = nq + nt + 2;
     ulonglong2 *tbr = tb + (tb_off[r] - tb_off[first]);
-    uint64_t *mvr = mvw + ((tb_off[r] - tb_off[first]) >> 6) + wv;
+    ulonglong2 *mvr = mvw + ((tb_off[r] - tb_off[first]) >> 6) + wv;   // per 64 steps: {move bits, i0 before the chunk}
 
     // state before step 0: H(-1) in Hp, X = H(-2) as seen after the (virtual) RIGHT move of step -1
     int32_t Hp = (lane == 32 || lane == 33) ? -gap : NEGV;
@@ -372,66 +372,117 @@ __global__ void __launch_bounds__(256) k_sw(int64_t first, int64_t count, const 
 #undef SW_FLUSH
 #undef SW_PARK
 
-// ---- trace-back: one lane per read
+// ---- trace-back: one lane per read, masks staged through LDS
+//
+// The walk from the best cell back to the anchor is sequential per read, so a lane owns a read.  What
+// made the first version slow was a dependent HBM round trip per step.  Here the wave works in rounds:
+// for each of its 64 reads it loads the 64-step window of masks ending at that read's current step
+// (one coalesced 1 KB load per read) into LDS, then every lane walks inside its own window (32..64
+// steps) reading LDS only.  Move bits and the two base streams for the '=' / 'X' decision sit in
+// per-lane 64-bit register windows.  HBM-bound: the 16 B/step masks are read once (+ ~10 % overlap).
+constexpr int TB_WIN = 64;                       // steps per window
+constexpr int TB_LANE_STRIDE = TB_WIN * 16 + 16; // bytes; +16 spreads lock-step lanes over the LDS banks
+
+__device__ __forceinline__ uint64_t sel3(uint64_t a, uint64_t b, uint64_t c, int k) { return k == 0 ? a : (k == 1 ? b : c); }
+
 __global__ void __launch_bounds__(64) k_traceback(int64_t first, int64_t count, const uint32_t *__restrict__ read_ori, const int64_t *__restrict__ read_woff,
                                                   const int32_t *__restrict__ read_len, const int32_t *__restrict__ read_ctg, const uint32_t *__restrict__ ctg_pk,
                                                   const int64_t *__restrict__ ctg_woff, const Anchor *__restrict__ anc, const DpInfo *__restrict__ info,
-                                                  const int64_t *__restrict__ tb_off, const ulonglong2 *__restrict__ tb, const uint64_t *__restrict__ mvw,
+                                                  const int64_t *__restrict__ tb_off, const ulonglong2 *__restrict__ tb, const ulonglong2 *__restrict__ mvw,
                                                   const int64_t *__restrict__ cig_off, uint32_t *__restrict__ cig, int64_t *__restrict__ cig_start,
                                                   fzp_aln_summary *__restrict__ summ) {
-    const int64_t wv = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (wv >= count) return;
-    const int64_t r = first + wv;
+    extern __shared__ __attribute__((aligned(16))) uint8_t tb_lds[];
+    const int lane = threadIdx.x;
+    const int64_t wv = (int64_t)blockIdx.x * 64 + lane;
+    const bool have = wv < count;
+    const int64_t r = first + (have ? wv : 0);
     fzp_aln_summary out;
     memset(&out, 0, sizeof out);
-    const Anchor a = anc[r];
-    const DpInfo di = info[r];
-    out.cells = (int64_t)di.steps * 64;
-    cig_start[r] = cig_off[r];
-    if (!a.aligned || di.best_t < 0 || di.best_score <= 0) { summ[r] = out; return; }
-    const int64_t n = read_len[r];
-    const uint32_t *qpk = read_ori + read_woff[r];
-    const uint32_t *tpk = ctg_pk + ctg_woff[read_ctg[r]];
+    Anchor a = {0, 0, 0, 0};
+    DpInfo di = {0, -1, 0, NEGV};
+    if (have) { a = anc[r]; di = info[r]; out.cells = (int64_t)di.steps * 64; cig_start[r] = cig_off[r]; }
+    bool active = have && a.aligned && di.best_t >= 0 && di.best_score > 0;
+    const int64_t n = have ? read_len[r] : 0;
+    const uint64_t *qpk = (const uint64_t *)(read_ori + read_woff[r]);
+    const uint64_t *tpk = (const uint64_t *)(ctg_pk + ctg_woff[have ? read_ctg[r] : 0]);
     const ulonglong2 *tbr = tb + (tb_off[r] - tb_off[first]);
-    const uint64_t *mvr = mvw + ((tb_off[r] - tb_off[first]) >> 6) + wv;
-    // i0 at the best step = -33 + number of DOWN moves in steps [0, best_t]
-    int32_t ts = di.best_t;
+    const ulonglong2 *mvr = mvw + ((tb_off[r] - tb_off[first]) >> 6) + (have ? wv : 0);
+    int32_t ts = active ? di.best_t : -1;
     int32_t i0 = -33;
-    for (int32_t w = 0; w < (ts >> 6); w++) i0 += __popcll(mvr[w]);
-    i0 += __popcll(mvr[ts >> 6] & ((2ull << (ts & 63)) - 1ull));
+    if (active) {   // i0 at the best step = i0 before its 64-step chunk + DOWN moves up to and including it
+        const ulonglong2 mw = mvr[ts >> 6];
+        i0 = (int32_t)(int64_t)mw.y + __popcll(mw.x & ((2ull << (ts & 63)) - 1ull));
+    }
     int32_t i = i0 + di.best_lane, j = ts - i;
     const int32_t i_end = i, j_end = j;
-    const int64_t cap = cig_off[r + 1] - cig_off[r];       // n + 18 words
-    uint32_t *reg = cig + cig_off[r];
-    int64_t wpos = cap - 1;                                 // last slot is kept for the trailing soft clip
+    const int64_t cap = have ? cig_off[r + 1] - cig_off[r] : 2;   // n + 18 words
+    uint32_t *reg = cig + (have ? cig_off[r] : 0);
+    int64_t wpos = cap - 1;                                        // last slot is kept for the trailing soft clip
     int64_t nraw = 0;
     int cur_op = -1;
     uint32_t cur_len = 0;
     int32_t ncol = 0;
     bool overflow = false;
-    while (i >= 0 && j >= 0) {
-        const ulonglong2 m = tbr[ts];
-        const int kk = i - i0;
-        int op;
-        const bool d1 = (mvr[ts >> 6] >> (ts & 63)) & 1ull;
-        if ((m.x >> kk) & 1ull) {
-            op = base_at(qpk, (int64_t)a.i_a + i) == base_at(tpk, (int64_t)a.c_a + j) ? FZP_OP_EQ : FZP_OP_X;
-            i--; j--; ncol++;
-            const bool d2 = ts >= 1 ? ((mvr[(ts - 1) >> 6] >> ((ts - 1) & 63)) & 1ull) : false;   // move(-1) = RIGHT
-            i0 -= (d1 ? 1 : 0) + (d2 ? 1 : 0);
-            ts -= 2;
-        } else if ((((m.y >> kk) & 1ull) != 0) == d1) {
-            // G set after a DOWN move, or clear after a RIGHT move: the predecessor is the cell above
-            op = FZP_OP_I; i--; i0 -= d1 ? 1 : 0; ts -= 1;
-        } else {
-            op = FZP_OP_D; j--; i0 -= d1 ? 1 : 0; ts -= 1;
+    active = active && i >= 0 && j >= 0;
+    while (__any(active)) {
+        // ---- stage: window of read l = steps [hi_l - 63, hi_l], hi_l = that lane's current step
+        const int32_t hi = active ? ts : -1;
+        const int32_t plo = (int32_t)(uint32_t)(uint64_t)tbr, phi = (int32_t)((uint64_t)tbr >> 32);
+        // LDS-DMA: one global_load_lds_dwordx4 moves a read's whole 1 KB window (lane x -> slot x) with
+        // no VGPR staging, so all 64 windows are in flight before the single wait below
+        for (int l = 0; l < 64; l++) {
+            const int32_t hl = __builtin_amdgcn_readlane(hi, l);
+            if (hl < 0) continue;
+            const uint64_t pl = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(phi, l) << 32) | (uint32_t)__builtin_amdgcn_readlane(plo, l);
+            const int32_t st = max(hl - (TB_WIN - 1) + lane, 0);   // slots of negative steps are never read
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(((const ulonglong2 *)pl) + st),
+                                             (__attribute__((address_space(3))) void *)(tb_lds + l * TB_LANE_STRIDE), 16, 0, 0);
         }
-        if (op == cur_op) cur_len++;
-        else {
-            if (cur_len) { nraw++; if (wpos > 1) reg[--wpos] = (cur_len << 4) | (uint32_t)cur_op; else overflow = true; }
-            cur_op = op; cur_len = 1;
+        // everything else the next <= 64 steps can touch, loaded in one batch: move bits of steps
+        // [ts-64, ts] (2 words) and the bases q[i-64 .. i], t[j-64 .. j] (3 words of 32 bases each)
+        const int32_t mw0 = max(ts - 64, 0) >> 6;
+        const int64_t qw0 = ((int64_t)a.i_a + max(i - 64, 0)) >> 5, tw0 = ((int64_t)a.c_a + max(j - 64, 0)) >> 5;
+        uint64_t mvA = 0, mvB = 0, qA = 0, qB = 0, qC = 0, tA = 0, tB = 0, tC = 0;
+        if (active) {
+            mvA = mvr[mw0].x; mvB = mvr[mw0 + 1].x;
+            qA = qpk[qw0]; qB = qpk[qw0 + 1]; qC = qpk[qw0 + 2];
+            tA = tpk[tw0]; tB = tpk[tw0 + 1]; tC = tpk[tw0 + 2];
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // covers the LDS-DMA loads (hipcc does not track them)
+        __syncthreads();
+        // ---- walk inside the window
+        const int32_t wlo = hi - (TB_WIN - 1);
+        while (active && ts >= wlo && ts >= 0) {
+            const ulonglong2 m = *(const ulonglong2 *)(tb_lds + lane * TB_LANE_STRIDE + (ts - wlo) * 16);
+            const int kk = i - i0;
+            int op;
+            const bool d1 = (((ts >> 6) == mw0 ? mvA : mvB) >> (ts & 63)) & 1ull;
+            if ((m.x >> kk) & 1ull) {
+                const int64_t qi = (int64_t)a.i_a + i, tj = (int64_t)a.c_a + j;
+                const uint32_t qb_ = (uint32_t)(sel3(qA, qB, qC, (int)((qi >> 5) - qw0)) >> ((qi & 31) * 2)) & 3u;
+                const uint32_t tb_ = (uint32_t)(sel3(tA, tB, tC, (int)((tj >> 5) - tw0)) >> ((tj & 31) * 2)) & 3u;
+                op = qb_ == tb_ ? FZP_OP_EQ : FZP_OP_X;
+                i--; j--; ncol++;
+                const bool d2 = ts >= 1 ? ((((((ts - 1) >> 6) == mw0) ? mvA : mvB) >> ((ts - 1) & 63)) & 1ull) : false;   // move(-1) = RIGHT
+                i0 -= (d1 ? 1 : 0) + (d2 ? 1 : 0);
+                ts -= 2;
+            } else if ((((m.y >> kk) & 1ull) != 0) == d1) {
+                // G set after a DOWN move, or clear after a RIGHT move: the predecessor is the cell above
+                op = FZP_OP_I; i--; i0 -= d1 ? 1 : 0; ts -= 1;
+            } else {
+                op = FZP_OP_D; j--; i0 -= d1 ? 1 : 0; ts -= 1;
+            }
+            if (op == cur_op) cur_len++;
+            else {
+                if (cur_len) { nraw++; if (wpos > 1) reg[--wpos] = (cur_len << 4) | (uint32_t)cur_op; else overflow = true; }
+                cur_op = op; cur_len = 1;
+            }
+            active = i >= 0 && j >= 0;
+        }
+        __syncthreads();
     }
+    if (!have) return;
+    if (!(a.aligned && di.best_t >= 0 && di.best_score > 0 && i_end >= 0 && j_end >= 0)) { summ[r] = out; return; }
     if (cur_len) { nraw++; if (wpos > 1) reg[--wpos] = (cur_len << 4) | (uint32_t)cur_op; else overflow = true; }
     int64_t q_lead = i + 1, r_lead = j + 1;
     int64_t fa = wpos, fb = cap - 1;                        // forward ops are reg[fa .. fb)
@@ -491,9 +542,12 @@ struct fzp_alnjob {
     std::vector<fzp_aln_summary> h_summ;
     int64_t ctg_words = 0, read_words = 0, idx_slots = 0;
     DevBuf<uint32_t> ctg_pk, read_pk, read_ori, cig;
+    DevBuf<uint8_t> ctg_ascii;                   // upper-cased contigs, concatenated (ref_seq of the phasing batch)
+    std::vector<int64_t> h_ctg_aoff;
     DevBuf<int64_t> ctg_woff, ctg_len, idx_off, read_woff, tb_off, cig_off, cig_start;
     DevBuf<int32_t> idx_bits, read_len, read_ctg;
-    DevBuf<uint64_t> table, mvw;
+    DevBuf<uint64_t> table;
+    DevBuf<ulonglong2> mvw;
     DevBuf<Anchor> anc;
     DevBuf<DpInfo> info;
     DevBuf<ulonglong2> tb;
@@ -548,7 +602,7 @@ extern "C" int fzp_align_create(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *cons
         j->h_idx_bits.push_back(bits);
         j->h_idx_off.push_back(j->idx_slots);
         j->idx_slots += 1LL << bits;
-        call.insert(call.end(), ctg_seq[c], ctg_seq[c] + ctg_len[c]);
+        call.insert(call.end(), j->h_ctg[c].begin(), j->h_ctg[c].end());
         coff.push_back((int64_t)call.size());
     }
     // reads
@@ -573,6 +627,9 @@ extern "C" int fzp_align_create(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *cons
             (rc = j->idx_off.upload(j->h_idx_off.data(), j->h_idx_off.size(), st)) || (rc = j->idx_bits.upload(j->h_idx_bits.data(), j->h_idx_bits.size(), st)))
             break;
         hipLaunchKernelGGL(k_pack, dim3(n_ctg, 64), dim3(256), 0, st, d_ascii.p, d_off.p, j->ctg_woff.p, j->ctg_pk.p);
+        if ((rc = j->ctg_ascii.alloc(call.size()))) break;
+        if (hipMemcpyAsync(j->ctg_ascii.p, d_ascii.p, call.size(), hipMemcpyDeviceToDevice, st) != hipSuccess) { rc = FZP_EDEVICE; break; }
+        j->h_ctg_aoff = coff;
         if (hipStreamSynchronize(st) != hipSuccess) { rc = FZP_EDEVICE; break; }
         if (n_reads) {
             if ((rc = j->read_pk.alloc((size_t)j->read_words + 8)) || (rc = j->read_ori.alloc((size_t)j->read_words + 8)) ||
@@ -627,6 +684,7 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
         // trace-back masks live in HBM; reads are processed in chunks that fit the budget
         int64_t budget_steps = (int64_t)48 << 30 >> 4;   // 48 GiB of 16-byte steps
         if (const char *e = getenv("FZP_TB_BUDGET_GB")) { long g = atol(e); if (g > 0) budget_steps = ((int64_t)g << 30) >> 4; }
+        FZP_HIP(hipFuncSetAttribute((const void *)k_traceback, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * TB_LANE_STRIDE));
         int64_t first = 0;
         while (first < nr) {
             int64_t last = first;
@@ -635,7 +693,7 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
             const int64_t cnt = last - first;
             const int64_t steps = j->h_tb_off[(size_t)last] - j->h_tb_off[(size_t)first];
             FZP_TRY(j->tb.alloc((size_t)steps));
-            FZP_TRY(j->mvw.alloc((size_t)(steps / 64 + cnt + 1)));
+            FZP_TRY(j->mvw.alloc((size_t)(steps / 64 + cnt + 2)));
             {
                 ProfScope ps(ctx, "k1_sw");
                 hipLaunchKernelGGL(k_sw, dim3((unsigned)((cnt + 3) / 4)), dim3(256), 0, st, first, cnt, j->read_ori.p, j->read_woff.p, j->read_len.p, j->read_ctg.p,
@@ -643,7 +701,7 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
             }
             {
                 ProfScope ps(ctx, "k1_traceback");
-                hipLaunchKernelGGL(k_traceback, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, st, first, cnt, j->read_ori.p, j->read_woff.p, j->read_len.p, j->read_ctg.p,
+                hipLaunchKernelGGL(k_traceback, dim3((unsigned)((cnt + 63) / 64)), dim3(64), (size_t)64 * TB_LANE_STRIDE, st, first, cnt, j->read_ori.p, j->read_woff.p, j->read_len.p, j->read_ctg.p,
                                    j->ctg_pk.p, j->ctg_woff.p, j->anc.p, j->info.p, j->tb_off.p, j->tb.p, j->mvw.p, j->cig_off.p, j->cig.p, j->cig_start.p, j->summ.p);
             }
             first = last;
@@ -806,13 +864,12 @@ extern "C" int fzp_align_to_batch(fzp_ctx *ctx, fzp_alnjob *j, fzp_batch **out) 
     b->n_cig = p.cig_off.back(); b->n_seq = p.seq_off.back();
     hipStream_t st = ctx->stream;
     int rc = gather_records(ctx, j, p, b->cigar, b->seq, b->cig_off, b->seq_off);
-    std::vector<uint8_t> ref((size_t)b->n_pos);
-    for (int c = 0; c < j->n_ctg && !rc; c++)
-        if (b->h_limit[c]) memcpy(ref.data() + b->h_goff[c], j->h_ctg[c].data(), (size_t)b->h_limit[c]);
+    if (!rc) rc = b->ref.alloc((size_t)b->n_pos);
+    for (int c = 0; c < j->n_ctg && !rc; c++)   // evaluated prefix of every contig, device to device
+        if (b->h_limit[c] && hipMemcpyAsync(b->ref.p + b->h_goff[c], j->ctg_ascii.p + j->h_ctg_aoff[c], (size_t)b->h_limit[c], hipMemcpyDeviceToDevice, st) != hipSuccess) rc = FZP_EDEVICE;
     if (!rc) rc = b->rec_pos.upload(p.rec_pos.data(), p.rec_pos.size(), st);
     if (!rc) rc = b->rec_qid.upload(p.rec_qid.data(), p.rec_qid.size(), st);
     if (!rc) rc = b->rec_ctg.upload(p.rec_ctg.data(), p.rec_ctg.size(), st);
-    if (!rc) rc = b->ref.upload(ref.data(), ref.size(), st);
     if (!rc) rc = b->ctg_goff.upload(b->h_goff.data(), b->h_goff.size(), st);
     if (!rc) rc = b->ctg_qoff.upload(b->h_qid_off.data(), b->h_qid_off.size(), st);
     if (!rc) rc = b->ctg_limit.upload(b->h_limit.data(), b->h_limit.size(), st);

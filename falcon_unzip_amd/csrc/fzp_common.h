@@ -31,6 +31,14 @@ void fzp_set_error(const char *fmt, ...);
 
 constexpr int WAVE = 64;
 
+// ---------------------------------------------------------------- caching device allocator (fzp_host.hip)
+// Steady-state passes of the hot path must not call hipMalloc/hipFree (both are slow and hipFree
+// synchronises): freed blocks are kept in size buckets and handed out again.  Single stream per ctx,
+// so stream order protects reuse.
+void *fzp_dev_alloc(size_t bytes);   // nullptr on failure
+void fzp_dev_free(void *p);
+void fzp_dev_trim();                  // give everything cached back to the driver
+
 // ---------------------------------------------------------------- device buffer
 template <class T>
 struct DevBuf {
@@ -41,17 +49,16 @@ struct DevBuf {
     DevBuf &operator=(const DevBuf &) = delete;
     ~DevBuf() { release(); }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) fzp_dev_free(p);
         p = nullptr; n = 0;
     }
     int alloc(size_t count) {   // grow-only
         if (count <= n && p) return FZP_OK;
         release();
         size_t bytes = (count ? count : 1) * sizeof(T);
-        hipError_t e = hipMalloc((void **)&p, bytes);
-        if (e != hipSuccess) {
-            p = nullptr;
-            fzp_set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+        p = (T *)fzp_dev_alloc(bytes);
+        if (!p) {
+            fzp_set_error("device allocation of %zu bytes failed", bytes);
             return FZP_ENOMEM;
         }
         n = count ? count : 1;

@@ -19,6 +19,57 @@ extern "C" const char *fzp_last_error(void) { return g_err; }
 extern "C" const char *fzp_version(void) { return "fzphase 0.1.0 (gfx950)"; }
 extern "C" void fzp_free(void *p) { free(p); }
 
+// ---------------------------------------------------------------- caching device allocator
+namespace {
+struct DevPool {
+    std::multimap<size_t, void *> free_blocks;      // bucket size -> block
+    std::unordered_map<void *, size_t> live;         // block -> bucket size
+    ~DevPool() {}                                    // the driver reclaims at process exit
+};
+DevPool &pool() { static DevPool p; return p; }
+size_t bucket_of(size_t bytes) {
+    if (bytes < 256) bytes = 256;
+    size_t p2 = 256;
+    while (p2 < bytes) p2 <<= 1;
+    if (p2 <= (1u << 20)) return p2;                 // powers of two up to 1 MiB
+    size_t half = p2 >> 1;                           // above: 1/8-octave steps (<= 12.5 % slack)
+    for (int k = 1; k <= 8; k++) { size_t b = half + (half >> 3) * k; if (b >= bytes) return b; }
+    return p2;
+}
+}  // namespace
+void *fzp_dev_alloc(size_t bytes) {
+    DevPool &P = pool();
+    size_t b = bucket_of(bytes);
+    auto it = P.free_blocks.find(b);
+    if (it != P.free_blocks.end()) {
+        void *p = it->second;
+        P.free_blocks.erase(it);
+        P.live[p] = b;
+        return p;
+    }
+    void *p = nullptr;
+    if (hipMalloc(&p, b) != hipSuccess) {
+        (void)hipGetLastError();
+        fzp_dev_trim();                              // retry once with the cache emptied
+        if (hipMalloc(&p, b) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    }
+    P.live[p] = b;
+    return p;
+}
+void fzp_dev_free(void *p) {
+    if (!p) return;
+    DevPool &P = pool();
+    auto it = P.live.find(p);
+    if (it == P.live.end()) { (void)hipFree(p); return; }
+    P.free_blocks.emplace(it->second, p);
+    P.live.erase(it);
+}
+void fzp_dev_trim() {
+    DevPool &P = pool();
+    for (auto &kv : P.free_blocks) (void)hipFree(kv.second);
+    P.free_blocks.clear();
+}
+
 // ---------------------------------------------------------------- context
 extern "C" int fzp_ctx_create(int device_id, unsigned flags, fzp_ctx **out) {
     (void)flags;
@@ -65,6 +116,7 @@ extern "C" void fzp_ctx_destroy(fzp_ctx *ctx) {
     }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     for (auto &b : ctx->scan_tmp) b.release();
+    fzp_dev_trim();
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
