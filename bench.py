@@ -121,7 +121,10 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     eng = _lib.Engine(local_rank)
+    t_up = time.perf_counter()
     job = _lib.align_job_raw(eng, contigs, blob, off, read_ctg)     # upload + 2-bit pack: inputs now resident in HBM
+    eng.synchronize()
+    upload_ms = (time.perf_counter() - t_up) * 1e3                  # PCIe + packing, outside the timed region
 
     def barrier():
         eng.synchronize()
@@ -206,6 +209,7 @@ def main():
                                    % (args.contigs, args.contig_len, args.reads_per_contig, args.read_len, min(args.window, args.contig_len)),
                        "reads_per_gpu": n_reads, "parallelism": "contigs sharded, %d rank(s)" % world},
             "dp_gcell_per_s_per_gpu": round(dp_gcells, 2),
+            "upload_ms": round(upload_ms, 1),
             "dp_cells_per_step": cells_per_step,
             "aligned_frac": round(float(summ["aligned"].mean()), 4),
             "stage_counts": {k: int(v) for k, v in stats.items()},
