@@ -117,10 +117,17 @@ def main():
     import torch.distributed as dist
     from falcon_unzip_amd import _lib
     from falcon_unzip_amd import dist as fdist
+    backend = os.environ.get("FZP_BENCH_BACKEND", "nccl")     # "gloo": ranks may share a GPU (single-GPU dry run of the N>1 flow)
+    n_dev = torch.cuda.device_count()
+    dev_index = local_rank if backend == "nccl" else local_rank % max(1, n_dev)
+    coll_dev = ("cuda:%d" % dev_index) if backend == "nccl" else "cpu"
     if world > 1:
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    eng = _lib.Engine(local_rank)
+        if backend == "nccl":
+            torch.cuda.set_device(dev_index)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend=backend)
+    eng = _lib.Engine(dev_index)
     t_up = time.perf_counter()
     job = _lib.align_job_raw(eng, contigs, blob, off, read_ctg)     # upload + 2-bit pack: inputs now resident in HBM
     eng.synchronize()
@@ -130,7 +137,7 @@ def main():
         eng.synchronize()
         if world > 1:
             dist.barrier()
-            torch.cuda.synchronize()
+            torch.cuda.synchronize(dev_index)
 
     stats = {}
 
@@ -157,7 +164,7 @@ def main():
         stats["reads_phased"] = n_phased
         b.close()
         t_e = time.perf_counter()
-        allr = fdist.allgather_r2p(np.concatenate(recs), device=("cuda:%d" % local_rank) if world > 1 else None)
+        allr = fdist.allgather_r2p(np.concatenate(recs), device=coll_dev if world > 1 else None)
         stats["r2p_records"] = len(allr)
         t_f = time.perf_counter()
         for k, v in zip(host_t, (t_b - t_a, t_c - t_b, t_d - t_c, t_e - t_d, t_f - t_e)):
@@ -178,7 +185,7 @@ def main():
     eng.prof_enable(False)
     prof = eng.prof()
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
