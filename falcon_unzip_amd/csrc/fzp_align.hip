@@ -200,15 +200,20 @@ __device__ __forceinline__ int32_t wave_shl1(int32_t v, int32_t fill) {   // lan
 //
 // Lane k of the wave owns cell (i = i0 + k, j = t - i) of anti-diagonal t.  Per step the band moves
 // DOWN (i0++) or RIGHT.  With A = the previous step's value in the same lane and B = the neighbour
-// lane's (lane k+1 after DOWN, k-1 after RIGHT), both already minus the gap penalty:
-//      H = max3(diag + s, A, B)
+// lane's (lane k+1 after DOWN, k-1 after RIGHT):
+//      H = max(diag + s, max(A, B) - gap)
 // The diagonal operand is kept pre-shifted: X = H(t-2) moved by (previous move) so that this step needs
 // one more wave_shl only when it moves DOWN (after RIGHT->DOWN lane 63 sees the band edge).
-// Trace-back masks per step: D = (H == diag + s), G = (A >= B)  ("the gap comes from the same lane").
-// Upcoming read / contig bases sit in 64-bit SGPR windows (32 bases) refilled one window ahead, so no
-// step waits on memory; masks are parked in lane (t & 63) of four VGPRs by v_writelane and leave as
-// one coalesced 1 KB store per 64 steps.  The interior of the matrix runs a counted loop with no
-// range checks; the first ~130 and last ~64 steps run the checked variant.
+// Scores are stored biased by 2^28 so that the DPP zero fill (bound_ctrl) of a missing neighbour IS the
+// "minus infinity" of the spec; that lets the neighbour shifts ride on the add / max / compare
+// themselves (v_add_u32_dpp, v_max_i32_dpp; G = (A >= B) is read off as max(A,B) == A) instead of separate moves.
+// Trace-back masks per step: D = (H == diag + s), G = (A >= B) ("the gap comes from the same lane");
+// each lane shifts its two bits into two 32-bit accumulators (v_cmp -> vcc -> v_addc_co_u32) that
+// leave as one coalesced 512 B store per 32 steps.  Upcoming read / contig bases sit in 64-bit SGPR
+// windows refilled one window ahead, so no step waits on memory.  The interior of the matrix runs a
+// counted loop with no range checks; the first ~130 and last ~64 steps run the checked variant.
+constexpr int32_t SW_BIAS = 1 << 28;
+
 struct BaseStream {          // wave-uniform: lives in SGPRs
     const uint64_t *pk;      // 32 bases per word
     int64_t w;               // index of the word in `cur`
@@ -229,73 +234,174 @@ struct BaseStream {          // wave-uniform: lives in SGPRs
     }
 };
 
-#define SW_PARK(sl)                                                                                                              \
-    asm volatile("s_mov_b32 m0, %8\n\t"                                                                                           \
-                 "v_writelane_b32 %0, %4, m0\n\t"                                                                                 \
-                 "v_writelane_b32 %1, %5, m0\n\t"                                                                                 \
-                 "v_writelane_b32 %2, %6, m0\n\t"                                                                                 \
-                 "v_writelane_b32 %3, %7, m0"                                                                                     \
-                 : "+v"(vD0), "+v"(vD1), "+v"(vG0), "+v"(vG1)                                                                     \
-                 : "s"((int32_t)(uint32_t)Dm), "s"((int32_t)(uint32_t)(Dm >> 32)), "s"((int32_t)(uint32_t)Gm),                   \
-                   "s"((int32_t)(uint32_t)(Gm >> 32)), "s"(sl)                                                                    \
-                 : "m0")
+// DP core of one step.  Inputs: X (pre-shifted diagonal), H (previous step), sc (match / -mismatch);
+// outputs: Hn, and one more bit in each accumulator.  "s_nop 1": the DPP reads below must not follow a
+// VALU write of X / H by fewer than 2 wait states, and hipcc does not see inside the asm.
+#define SW_CORE_DOWN()                                                                                     \
+    asm volatile("s_nop 1\n\t"                                                                             \
+                 "v_add_u32_dpp %[hd], %[X], %[sc] wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t" \
+                 "v_max_i32_dpp %[m], %[H], %[H] wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"   \
+                 "v_cmp_eq_i32 vcc, %[m], %[H]\n\t"                                                        \
+                 "v_addc_co_u32 %[aG], vcc, %[aG], %[aG], vcc\n\t"                                         \
+                 "v_subrev_u32 %[m], %[gap], %[m]\n\t"                                                     \
+                 "v_max_i32 %[Hn], %[hd], %[m]\n\t"                                                        \
+                 "v_cmp_eq_i32 vcc, %[Hn], %[hd]\n\t"                                                      \
+                 "v_addc_co_u32 %[aD], vcc, %[aD], %[aD], vcc"                                             \
+                 : [hd] "=&v"(hd), [m] "=&v"(m), [Hn] "=&v"(Hn), [aG] "+v"(accG), [aD] "+v"(accD)          \
+                 : [X] "v"(X), [H] "v"(H), [sc] "v"(sc), [gap] "s"(gap)                                    \
+                 : "vcc")
+#define SW_CORE_RIGHT()                                                                                    \
+    asm volatile("s_nop 1\n\t"                                                                             \
+                 "v_add_u32 %[hd], %[X], %[sc]\n\t"                                                        \
+                 "v_max_i32_dpp %[m], %[H], %[H] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"   \
+                 "v_cmp_eq_i32 vcc, %[m], %[H]\n\t"                                                        \
+                 "v_addc_co_u32 %[aG], vcc, %[aG], %[aG], vcc\n\t"                                         \
+                 "v_mov_b32_dpp %[Xn], %[H] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"        \
+                 "v_subrev_u32 %[m], %[gap], %[m]\n\t"                                                     \
+                 "v_max_i32 %[Hn], %[hd], %[m]\n\t"                                                        \
+                 "v_cmp_eq_i32 vcc, %[Hn], %[hd]\n\t"                                                      \
+                 "v_addc_co_u32 %[aD], vcc, %[aD], %[aD], vcc"                                             \
+                 : [hd] "=&v"(hd), [m] "=&v"(m), [Hn] "=&v"(Hn), [Xn] "=&v"(Xn), [aG] "+v"(accG), [aD] "+v"(accD) \
+                 : [X] "v"(X), [H] "v"(H), [sc] "v"(sc), [gap] "s"(gap)                                    \
+                 : "vcc")
 
 // one DP step; FULL adds the sentinel / validity handling needed outside the matrix interior
-#define SW_STEP(FULL)                                                                                                            \
-    {                                                                                                                            \
-        int32_t B, dg, Xn;                                                                                                       \
-        if (down) {                                                                                                              \
-            int32_t c = qs.pop();                                                                                                \
-            if (FULL) c = qpos < nq ? c : 4;                                                                                     \
-            qpos++;                                                                                                              \
-            i0++;                                                                                                                \
-            qc = wave_shl1(qc, c);                                                                                               \
-            B = wave_shl1(Hg, NEGV);                                                                                             \
-            dg = wave_shl1(X, NEGV);                                                                                             \
-            Xn = Hp;                                                                                                             \
-        } else {                                                                                                                 \
-            int32_t c = ts.pop();                                                                                                \
-            if (FULL) c = tpos < nt ? c : 5;                                                                                     \
-            tpos++;                                                                                                              \
-            tc = wave_shr1(tc, c);                                                                                               \
-            B = wave_shr1(Hg, NEGV);                                                                                             \
-            dg = X;                                                                                                              \
-            Xn = wave_shr1(Hp, NEGV);                                                                                            \
-        }                                                                                                                        \
-        const int32_t hd = dg + (qc == tc ? match : -mismatch);                                                                  \
-        const int32_t H = max(hd, max(Hg, B));                                                                                   \
-        const uint64_t Dm = __ballot(H == hd);                                                                                   \
-        const uint64_t Gm = __ballot(Hg >= B);                                                                                   \
-        bool upd = H > bs;                                                                                                       \
-        if (FULL) {                                                                                                              \
-            const int32_t ci = i0 + lane, cj = t - ci;                                                                           \
-            upd = upd && ci >= 0 && ci < nq && cj >= 0 && cj < nt;                                                               \
-        }                                                                                                                        \
-        bs = upd ? H : bs;                                                                                                       \
-        bt = upd ? t : bt;                                                                                                       \
-        const int sl = t & 63;                                                                                                   \
-        SW_PARK(sl);                                                                                                             \
-        mvacc |= (uint64_t)(down ? 1 : 0) << sl;                                                                                 \
-        const int32_t top = __builtin_amdgcn_readlane(H, 0), bot = __builtin_amdgcn_readlane(H, 63);                             \
-        X = Xn;                                                                                                                  \
-        Hp = H;                                                                                                                  \
-        Hg = H - gap;                                                                                                            \
-        t++;                                                                                                                     \
-        down = t < 64 ? ((t & 1) == 0) : !(top > bot);                                                                           \
+#define SW_STEP(FULL)                                                                                      \
+    {                                                                                                      \
+        int32_t hd, m, Hn, Xn;                                                                             \
+        if (down) {                                                                                        \
+            int32_t c = qs.pop();                                                                          \
+            if (FULL) c = qpos < nq ? c : 4;                                                               \
+            qpos++;                                                                                        \
+            i0++;                                                                                          \
+            qc = wave_shl1(qc, c);                                                                         \
+            const int32_t sc = qc == tc ? match : -mismatch;                                               \
+            SW_CORE_DOWN();                                                                                \
+            Xn = H;                                                                                        \
+        } else {                                                                                           \
+            int32_t c = ts.pop();                                                                          \
+            if (FULL) c = tpos < nt ? c : 5;                                                               \
+            tpos++;                                                                                        \
+            tc = wave_shr1(tc, c);                                                                         \
+            const int32_t sc = qc == tc ? match : -mismatch;                                               \
+            SW_CORE_RIGHT();                                                                               \
+        }                                                                                                  \
+        bool upd = Hn > bs;                                                                                \
+        if (FULL) {                                                                                        \
+            const int32_t ci = i0 + lane, cj = t - ci;                                                     \
+            upd = upd && ci >= 0 && ci < nq && cj >= 0 && cj < nt;                                         \
+        }                                                                                                  \
+        bs = upd ? Hn : bs;                                                                                \
+        bt = upd ? t : bt;                                                                                 \
+        mvacc |= (uint64_t)(down ? 1 : 0) << (t & 63);                                                     \
+        const int32_t top = __builtin_amdgcn_readlane(Hn, 0), bot = __builtin_amdgcn_readlane(Hn, 63);     \
+        X = Xn;                                                                                            \
+        H = Hn;                                                                                            \
+        t++;                                                                                               \
+        down = t < 64 ? ((t & 1) == 0) : !(top > bot);                                                     \
     }
 
-#define SW_FLUSH()                                                                                                               \
-    {                                                                                                                            \
-        tbr[((t - 1) & ~63) + lane] = make_ulonglong2(((uint64_t)(uint32_t)vD1 << 32) | (uint32_t)vD0,                           \
-                                                      ((uint64_t)(uint32_t)vG1 << 32) | (uint32_t)vG0);                           \
-        if (lane == 0) mvr[(t - 1) >> 6] = make_ulonglong2(mvacc, (uint64_t)(int64_t)(i0 - __popcll(mvacc)));                    \
-        mvacc = 0;                                                                                                               \
+// after step t-1 completed a 32-step chunk (or at the very end): masks out, move record every 64 steps
+#define SW_FLUSH(PARTIAL)                                                                                  \
+    {                                                                                                      \
+        const int32_t done_ = (t - 1) & 31;                                                                \
+        const int sh_ = (PARTIAL) ? 31 - done_ : 0;   /* step s of a chunk always ends at bit 31 - s */    \
+        tbr[(((t - 1) >> 5) << 6) + lane] = make_uint2((uint32_t)accD << sh_, (uint32_t)accG << sh_);      \
+        if ((PARTIAL) || ((t - 1) & 63) == 63) {                                                           \
+            if (lane == 0) mvr[(t - 1) >> 6] = make_ulonglong2(mvacc, (uint64_t)(int64_t)(i0 - __popcll(mvacc))); \
+            mvacc = 0;                                                                                     \
+        }                                                                                                  \
     }
+
+// ---- interior block: up to 32 steps with every lane strictly inside the matrix, hand-scheduled.
+// Per step ~20 VALU and 6-7 SALU (the loop is otherwise scalar-issue bound: a SIMD issues one SALU op
+// per 4 cycles).  The bases entering the band come from two per-lane windows instead of scalar streams:
+//   qnx: lane L holds q[qpos + 63 - L]  -> the next base to enter at lane 63 sits in lane 63; wave_shr advances
+//   tnx: lane L holds t[tpos + L]       -> the next base to enter at lane 0 sits in lane 0; wave_shl advances
+// Moves are collected in a 32-bit shift register (first step of the block ends up in the highest used bit).
+// No DPP source is written fewer than two instructions before it is read (gfx9 DPP hazard).
+__device__ __forceinline__ void sw_block(int32_t &H, int32_t &X, int32_t &qc, int32_t &tc, int32_t &qnx, int32_t &tnx, int32_t &bs, int32_t &bt,
+                                         int32_t &vt, int32_t &accD, int32_t &accG, uint32_t &mv, int32_t &cnt, int32_t &dn, const int32_t gap,
+                                         const int32_t vmat, const int32_t vmis, const uint64_t m63, const uint64_t m0) {
+    int32_t hd, mm, sc, top, bot;
+    asm volatile(
+        "s_nop 1\n\t"
+        "s_cmp_eq_u32 %[dn], 0\n\t"
+        "s_cbranch_scc1 2f\n"
+        "1:\n\t"   // ------------------------------------------------ DOWN
+        "v_mov_b32_dpp %[qc], %[qc] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_e64 %[qc], %[qc], %[qnx], %[m63]\n\t"
+        "v_mov_b32_dpp %[qnx], %[qnx] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_cmp_eq_u32_e32 vcc, %[qc], %[tc]\n\t"
+        "v_cndmask_b32_e32 %[sc], %[vmis], %[vmat], vcc\n\t"
+        "v_add_u32_dpp %[hd], %[X], %[sc] wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "v_max_i32_dpp %[mm], %[H], %[H] wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "v_cmp_eq_i32_e32 vcc, %[mm], %[H]\n\t"
+        "v_addc_co_u32_e32 %[aG], vcc, %[aG], %[aG], vcc\n\t"
+        "v_mov_b32_e32 %[X], %[H]\n\t"
+        "v_subrev_u32_e32 %[mm], %[gap], %[mm]\n\t"
+        "v_max_i32_e32 %[H], %[hd], %[mm]\n\t"
+        "v_cmp_eq_i32_e32 vcc, %[H], %[hd]\n\t"
+        "v_addc_co_u32_e32 %[aD], vcc, %[aD], %[aD], vcc\n\t"
+        "s_lshl_b32 %[mv], %[mv], 1\n\t"
+        "s_or_b32 %[mv], %[mv], 1\n\t"
+        "v_cmp_gt_i32_e32 vcc, %[H], %[bs]\n\t"
+        "v_cndmask_b32_e32 %[bs], %[bs], %[H], vcc\n\t"
+        "v_cndmask_b32_e32 %[bt], %[bt], %[vt], vcc\n\t"
+        "v_add_u32_e32 %[vt], 1, %[vt]\n\t"
+        "v_readlane_b32 %[top], %[H], 0\n\t"
+        "v_readlane_b32 %[bot], %[H], 63\n\t"
+        "s_sub_u32 %[cnt], %[cnt], 1\n\t"
+        "s_cmp_eq_u32 %[cnt], 0\n\t"
+        "s_cbranch_scc1 3f\n\t"
+        "s_cmp_gt_i32 %[top], %[bot]\n\t"
+        "s_cbranch_scc0 1b\n"
+        "2:\n\t"   // ------------------------------------------------ RIGHT
+        "v_mov_b32_dpp %[tc], %[tc] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_e64 %[tc], %[tc], %[tnx], %[m0]\n\t"
+        "v_mov_b32_dpp %[tnx], %[tnx] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_cmp_eq_u32_e32 vcc, %[qc], %[tc]\n\t"
+        "v_cndmask_b32_e32 %[sc], %[vmis], %[vmat], vcc\n\t"
+        "v_add_u32_e32 %[hd], %[X], %[sc]\n\t"
+        "v_max_i32_dpp %[mm], %[H], %[H] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "v_cmp_eq_i32_e32 vcc, %[mm], %[H]\n\t"
+        "v_addc_co_u32_e32 %[aG], vcc, %[aG], %[aG], vcc\n\t"
+        "v_mov_b32_dpp %[X], %[H] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "v_subrev_u32_e32 %[mm], %[gap], %[mm]\n\t"
+        "v_max_i32_e32 %[H], %[hd], %[mm]\n\t"
+        "v_cmp_eq_i32_e32 vcc, %[H], %[hd]\n\t"
+        "v_addc_co_u32_e32 %[aD], vcc, %[aD], %[aD], vcc\n\t"
+        "s_lshl_b32 %[mv], %[mv], 1\n\t"
+        "v_cmp_gt_i32_e32 vcc, %[H], %[bs]\n\t"
+        "v_cndmask_b32_e32 %[bs], %[bs], %[H], vcc\n\t"
+        "v_cndmask_b32_e32 %[bt], %[bt], %[vt], vcc\n\t"
+        "v_add_u32_e32 %[vt], 1, %[vt]\n\t"
+        "v_readlane_b32 %[top], %[H], 0\n\t"
+        "v_readlane_b32 %[bot], %[H], 63\n\t"
+        "s_sub_u32 %[cnt], %[cnt], 1\n\t"
+        "s_cmp_eq_u32 %[cnt], 0\n\t"
+        "s_cbranch_scc1 3f\n\t"
+        "s_cmp_gt_i32 %[top], %[bot]\n\t"
+        "s_cbranch_scc1 2b\n\t"
+        "s_branch 1b\n"
+        "3:\n\t"
+        "s_cmp_gt_i32 %[top], %[bot]\n\t"
+        "s_cselect_b32 %[dn], 0, 1"
+        : [H] "+v"(H), [X] "+v"(X), [qc] "+v"(qc), [tc] "+v"(tc), [qnx] "+v"(qnx), [tnx] "+v"(tnx), [bs] "+v"(bs), [bt] "+v"(bt), [vt] "+v"(vt),
+          [aD] "+v"(accD), [aG] "+v"(accG), [mv] "+s"(mv), [cnt] "+s"(cnt), [dn] "+s"(dn), [hd] "=&v"(hd), [mm] "=&v"(mm), [sc] "=&v"(sc),
+          [top] "=&s"(top), [bot] "=&s"(bot)
+        : [gap] "s"(gap), [vmat] "v"(vmat), [vmis] "v"(vmis), [m63] "s"(m63), [m0] "s"(m0)
+        : "vcc", "scc", "memory");
+}
+
+// raw dword holding the base at packed index idx (extraction happens when the window is put to use)
+__device__ __forceinline__ uint32_t win_load(const uint32_t *__restrict__ pk, int64_t idx) { return pk[idx >> 4]; }
+__device__ __forceinline__ int32_t win_base(uint32_t raw, int64_t idx) { return (int32_t)((raw >> ((idx & 15) * 2)) & 3u); }
 
 __global__ void __launch_bounds__(256) k_sw(int64_t first, int64_t count, const uint32_t *__restrict__ read_ori, const int64_t *__restrict__ read_woff,
                                             const int32_t *__restrict__ read_len, const int32_t *__restrict__ read_ctg, const uint32_t *__restrict__ ctg_pk,
                                             const int64_t *__restrict__ ctg_woff, const int64_t *__restrict__ ctg_len, const Anchor *__restrict__ anc,
-                                            const int64_t *__restrict__ tb_off, ulonglong2 *__restrict__ tb, ulonglong2 *__restrict__ mvw, int match, int mismatch,
+                                            const int64_t *__restrict__ tb_off, uint2 *__restrict__ tb, ulonglong2 *__restrict__ mvw, int match, int mismatch,
                                             int gap, DpInfo *__restrict__ info) {
     const int lane = lane_id();
     // wave-uniform on purpose: everything indexed by the read then lives in SGPRs / scalar loads
@@ -314,21 +420,20 @@ __global__ void __launch_bounds__(256) k_sw(int64_t first, int64_t count, const 
     const uint32_t *tpk = ctg_pk + ctg_woff[c_idx];
     const int64_t qb = a.i_a, tbase = a.c_a;
     const int32_t max_steps = nq + nt + 2;
-    ulonglong2 *tbr = tb + (tb_off[r] - tb_off[first]);
+    uint2 *tbr = tb + 2 * (tb_off[r] - tb_off[first]);                 // per 32 steps: 64 lanes x {D bits, G bits}
     ulonglong2 *mvr = mvw + ((tb_off[r] - tb_off[first]) >> 6) + wv;   // per 64 steps: {move bits, i0 before the chunk}
 
-    // state before step 0: H(-1) in Hp, X = H(-2) as seen after the (virtual) RIGHT move of step -1
-    int32_t Hp = (lane == 32 || lane == 33) ? -gap : NEGV;
-    int32_t Hg = Hp - gap;
-    int32_t X = lane == 33 ? 0 : NEGV;
+    // state before step 0 (biased): H(-1), and X = H(-2) as seen after the (virtual) RIGHT move of step -1
+    int32_t H = (lane == 32 || lane == 33) ? SW_BIAS - gap : 0;
+    int32_t X = lane == 33 ? SW_BIAS : 0;
     int32_t qc, tc;
     {
         int32_t i = lane - 33, j = 32 - lane;
         qc = (i >= 0 && i < nq) ? (int32_t)base_at(qpk, qb + i) : 4;
         tc = (j >= 0 && j < nt) ? (int32_t)base_at(tpk, tbase + j) : 5;
     }
-    int32_t bs = NEGV, bt = -1;
-    int32_t vD0 = 0, vD1 = 0, vG0 = 0, vG1 = 0;
+    int32_t bs = 0, bt = -1;
+    int32_t accD = 0, accG = 0;
     int32_t i0 = -33, t = 0, qpos = 31, tpos = 33;
     uint64_t mvacc = 0;
     bool down = true;
@@ -345,19 +450,49 @@ __global__ void __launch_bounds__(256) k_sw(int64_t first, int64_t count, const 
             safe = min(rows_left, cols_left);
         }
         if (safe > 0) {
+            // ---- interior: asm blocks of <= 32 steps; base windows prefetched one block ahead
+            int32_t qpos_i = i0 + 64, tpos_i = t - i0;                 // next bases to enter at lane 63 / lane 0
+            int32_t qanchor = qpos_i, tanchor = tpos_i;
+            uint32_t qraw = win_load(qpk, qb + qanchor + (63 - lane));
+            uint32_t traw = win_load(tpk, tbase + tanchor + lane);
+            int32_t vt = t;
+            const int32_t vmat = match, vmis = -mismatch;
+            int32_t dn = down ? 1 : 0;
             while (safe > 0) {
-                int32_t m = min(safe, 64 - (t & 63));
-                safe -= m;
-                for (; m > 0; m--) SW_STEP(false)
-                if ((t & 63) == 0) SW_FLUSH()
+                // put the pending windows to use: extract the bases and rotate by what was consumed since they were anchored
+                const int32_t dq = qpos_i - qanchor, dt = tpos_i - tanchor;
+                int32_t qnx = __builtin_amdgcn_ds_bpermute(((lane - dq) & 63) << 2, win_base(qraw, qb + qanchor + (63 - lane)));
+                int32_t tnx = __builtin_amdgcn_ds_bpermute(((lane + dt) & 63) << 2, win_base(traw, tbase + tanchor + lane));
+                qanchor = qpos_i; tanchor = tpos_i;                     // ... and fetch the windows the block after this one will use
+                qraw = win_load(qpk, qb + qanchor + (63 - lane));
+                traw = win_load(tpk, tbase + tanchor + lane);
+                // (readfirstlane: these are wave-uniform, but hipcc's divergence analysis cannot always prove it)
+                int32_t cnt = __builtin_amdgcn_readfirstlane(min(safe, 32 - (t & 31)));
+                const int32_t n_steps = cnt;
+                safe -= n_steps;
+                uint32_t mv = 0;
+                dn = __builtin_amdgcn_readfirstlane(dn);
+                sw_block(H, X, qc, tc, qnx, tnx, bs, bt, vt, accD, accG, mv, cnt, dn, __builtin_amdgcn_readfirstlane(gap), vmat, vmis, 1ull << 63, 1ull);
+                const int32_t nd = __popc(mv);                          // DOWN moves of the block (mv holds exactly n_steps bits)
+                i0 += nd;
+                qpos_i += nd; tpos_i += n_steps - nd;
+                mvacc |= (uint64_t)(__brev(mv) >> (32 - n_steps)) << (t & 63);   // step s of the block -> bit (t + s) & 63
+                t += n_steps;
+                if ((t & 31) == 0) SW_FLUSH(false)
             }
+            down = dn != 0;
+            // back to the checked variant: scalar base streams resume at the current positions
+            qpos = i0 + 64; tpos = t - i0;
+            qs.init(qpk, qb + qpos);
+            ts.init(tpk, tbase + tpos);
         } else {
             SW_STEP(true)
-            if ((t & 63) == 0) SW_FLUSH()
+            if ((t & 31) == 0) SW_FLUSH(false)
             if (i0 > nq - 1 || (t - 1) - (i0 + 63) > nt - 1 || t >= max_steps) done = true;
         }
     }
-    if ((t & 63) != 0) SW_FLUSH()
+    if ((t & 31) != 0) SW_FLUSH(true)
+    else if ((t & 63) != 0) { if (lane == 0) mvr[(t - 1) >> 6] = make_ulonglong2(mvacc, (uint64_t)(int64_t)(i0 - __popcll(mvacc))); }
     // best cell: max score, then earliest step, then lowest lane
     int32_t s_b = bs, t_b = bt < 0 ? 0x7fffffff : bt, l_b = lane;
 #pragma unroll
@@ -366,35 +501,35 @@ __global__ void __launch_bounds__(256) k_sw(int64_t first, int64_t count, const 
         bool take = so > s_b || (so == s_b && (to < t_b || (to == t_b && lo < l_b)));
         if (take) { s_b = so; t_b = to; l_b = lo; }
     }
-    if (lane == 0) info[r] = DpInfo{t, t_b == 0x7fffffff ? -1 : t_b, l_b, s_b};
+    if (lane == 0) info[r] = DpInfo{t, t_b == 0x7fffffff ? -1 : t_b, l_b, s_b - SW_BIAS};
 }
 #undef SW_STEP
 #undef SW_FLUSH
-#undef SW_PARK
+#undef SW_CORE_DOWN
+#undef SW_CORE_RIGHT
 
 // ---- trace-back: one lane per read, masks staged through LDS
 //
-// The walk from the best cell back to the anchor is sequential per read, so a lane owns a read.  What
-// made the first version slow was a dependent HBM round trip per step.  Here the wave works in rounds:
-// for each of its 64 reads it loads the 64-step window of masks ending at that read's current step
-// (one coalesced 1 KB load per read) into LDS, then every lane walks inside its own window (32..64
-// steps) reading LDS only.  Move bits and the two base streams for the '=' / 'X' decision sit in
-// per-lane 64-bit register windows.  HBM-bound: the 16 B/step masks are read once (+ ~10 % overlap).
-constexpr int TB_WIN = 64;                       // steps per window
-constexpr int TB_LANE_STRIDE = TB_WIN * 16 + 16; // bytes; +16 spreads lock-step lanes over the LDS banks
-
-__device__ __forceinline__ uint64_t sel3(uint64_t a, uint64_t b, uint64_t c, int k) { return k == 0 ? a : (k == 1 ? b : c); }
+// The walk from the best cell back to the anchor is sequential per read, so a lane owns a read.  Rounds:
+// for each of its reads the wave pulls the two 32-step mask chunks ending at that read's current step
+// (1 KB, one LDS-DMA instruction, all in flight together), the lane parks the few words of move bits
+// and bases the next <= 64 steps can touch next to it, and then walks using LDS and registers only:
+// the bits / bases it consumes sit in 32-bit shift registers (next item at the top) reloaded from LDS
+// at word boundaries.  HBM traffic: the 16 B/step masks are read once (+ chunk re-reads at round edges).
+constexpr int TB_LANE_STRIDE = 1024 + 64 + 8;    // bytes per read: 2 mask chunks + aux words; +8 staggers LDS banks
+constexpr int TB_RPW = 16;                       // reads walked per wave (all 64 lanes stage)
+constexpr int TB_AUX = 1024;                     // aux area: 4 move dwords, 6 q dwords, 6 t dwords
 
 __global__ void __launch_bounds__(64) k_traceback(int64_t first, int64_t count, const uint32_t *__restrict__ read_ori, const int64_t *__restrict__ read_woff,
                                                   const int32_t *__restrict__ read_len, const int32_t *__restrict__ read_ctg, const uint32_t *__restrict__ ctg_pk,
                                                   const int64_t *__restrict__ ctg_woff, const Anchor *__restrict__ anc, const DpInfo *__restrict__ info,
-                                                  const int64_t *__restrict__ tb_off, const ulonglong2 *__restrict__ tb, const ulonglong2 *__restrict__ mvw,
+                                                  const int64_t *__restrict__ tb_off, const uint2 *__restrict__ tb, const ulonglong2 *__restrict__ mvw,
                                                   const int64_t *__restrict__ cig_off, uint32_t *__restrict__ cig, int64_t *__restrict__ cig_start,
-                                                  fzp_aln_summary *__restrict__ summ) {
+                                                  fzp_aln_summary *__restrict__ summ, int dbg_mode) {
     extern __shared__ __attribute__((aligned(16))) uint8_t tb_lds[];
     const int lane = threadIdx.x;
-    const int64_t wv = (int64_t)blockIdx.x * 64 + lane;
-    const bool have = wv < count;
+    const int64_t wv = (int64_t)blockIdx.x * TB_RPW + lane;
+    const bool have = lane < TB_RPW && wv < count;
     const int64_t r = first + (have ? wv : 0);
     fzp_aln_summary out;
     memset(&out, 0, sizeof out);
@@ -402,10 +537,10 @@ __global__ void __launch_bounds__(64) k_traceback(int64_t first, int64_t count, 
     DpInfo di = {0, -1, 0, NEGV};
     if (have) { a = anc[r]; di = info[r]; out.cells = (int64_t)di.steps * 64; cig_start[r] = cig_off[r]; }
     bool active = have && a.aligned && di.best_t >= 0 && di.best_score > 0;
-    const int64_t n = have ? read_len[r] : 0;
+    const int32_t n = have ? read_len[r] : 0;
     const uint64_t *qpk = (const uint64_t *)(read_ori + read_woff[r]);
     const uint64_t *tpk = (const uint64_t *)(ctg_pk + ctg_woff[have ? read_ctg[r] : 0]);
-    const ulonglong2 *tbr = tb + (tb_off[r] - tb_off[first]);
+    const uint2 *tbr = tb + 2 * (tb_off[r] - tb_off[first]);
     const ulonglong2 *mvr = mvw + ((tb_off[r] - tb_off[first]) >> 6) + (have ? wv : 0);
     int32_t ts = active ? di.best_t : -1;
     int32_t i0 = -33;
@@ -415,62 +550,87 @@ __global__ void __launch_bounds__(64) k_traceback(int64_t first, int64_t count, 
     }
     int32_t i = i0 + di.best_lane, j = ts - i;
     const int32_t i_end = i, j_end = j;
-    const int64_t cap = have ? cig_off[r + 1] - cig_off[r] : 2;   // n + 18 words
+    const int32_t cap = have ? (int32_t)(cig_off[r + 1] - cig_off[r]) : 2;   // n + 18 words
     uint32_t *reg = cig + (have ? cig_off[r] : 0);
-    int64_t wpos = cap - 1;                                        // last slot is kept for the trailing soft clip
-    int64_t nraw = 0;
-    int cur_op = -1;
+    int32_t wpos = cap - 1;                                                   // last slot is kept for the trailing soft clip
+    int32_t nraw = 0;
+    int32_t cur_op = -1;
     uint32_t cur_len = 0;
     int32_t ncol = 0;
     bool overflow = false;
     active = active && i >= 0 && j >= 0;
+    uint8_t *mine = tb_lds + lane * TB_LANE_STRIDE;
+    const int32_t plo = (int32_t)(uint32_t)(uint64_t)tbr, phi = (int32_t)((uint64_t)tbr >> 32);
     while (__any(active)) {
-        // ---- stage: window of read l = steps [hi_l - 63, hi_l], hi_l = that lane's current step
-        const int32_t hi = active ? ts : -1;
-        const int32_t plo = (int32_t)(uint32_t)(uint64_t)tbr, phi = (int32_t)((uint64_t)tbr >> 32);
-        // LDS-DMA: one global_load_lds_dwordx4 moves a read's whole 1 KB window (lane x -> slot x) with
-        // no VGPR staging, so all 64 windows are in flight before the single wait below
-        for (int l = 0; l < 64; l++) {
-            const int32_t hl = __builtin_amdgcn_readlane(hi, l);
-            if (hl < 0) continue;
+        // ---- stage: chunks cb, cb+1 of every active read, cb = max((ts >> 5) - 1, 0)
+        const int32_t cb = active ? max((ts >> 5) - 1, 0) : -1;
+        for (int l = 0; l < TB_RPW; l++) {
+            const int32_t cl = __builtin_amdgcn_readlane(cb, l);
+            if (cl < 0) continue;
             const uint64_t pl = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(phi, l) << 32) | (uint32_t)__builtin_amdgcn_readlane(plo, l);
-            const int32_t st = max(hl - (TB_WIN - 1) + lane, 0);   // slots of negative steps are never read
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(((const ulonglong2 *)pl) + st),
+            // lane x moves 16 B = the {D,G} words of lanes 2x, 2x+1 ... : 64 x 16 B = both chunks, contiguous
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(((const uint4 *)pl) + (int64_t)cl * 32 + lane),
                                              (__attribute__((address_space(3))) void *)(tb_lds + l * TB_LANE_STRIDE), 16, 0, 0);
         }
-        // everything else the next <= 64 steps can touch, loaded in one batch: move bits of steps
-        // [ts-64, ts] (2 words) and the bases q[i-64 .. i], t[j-64 .. j] (3 words of 32 bases each)
+        // move bits of steps [ts-64, ts] (2 words) and the bases q[i-64 .. i], t[j-64 .. j] (3 words each)
         const int32_t mw0 = max(ts - 64, 0) >> 6;
-        const int64_t qw0 = ((int64_t)a.i_a + max(i - 64, 0)) >> 5, tw0 = ((int64_t)a.c_a + max(j - 64, 0)) >> 5;
-        uint64_t mvA = 0, mvB = 0, qA = 0, qB = 0, qC = 0, tA = 0, tB = 0, tC = 0;
+        const int32_t qw0 = (int32_t)(((int64_t)a.i_a + max(i - 64, 0)) >> 5), tw0 = (int32_t)(((int64_t)a.c_a + max(j - 64, 0)) >> 5);
         if (active) {
-            mvA = mvr[mw0].x; mvB = mvr[mw0 + 1].x;
-            qA = qpk[qw0]; qB = qpk[qw0 + 1]; qC = qpk[qw0 + 2];
-            tA = tpk[tw0]; tB = tpk[tw0 + 1]; tC = tpk[tw0 + 2];
+            uint64_t *aux = (uint64_t *)(mine + TB_AUX);
+            aux[0] = mvr[mw0].x; aux[1] = mvr[mw0 + 1].x;
+            aux[2] = qpk[qw0]; aux[3] = qpk[qw0 + 1]; aux[4] = qpk[qw0 + 2];
+            aux[5] = tpk[tw0]; aux[6] = tpk[tw0 + 1]; aux[7] = tpk[tw0 + 2];
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // covers the LDS-DMA loads (hipcc does not track them)
         __syncthreads();
-        // ---- walk inside the window
-        const int32_t wlo = hi - (TB_WIN - 1);
-        while (active && ts >= wlo && ts >= 0) {
-            const ulonglong2 m = *(const ulonglong2 *)(tb_lds + lane * TB_LANE_STRIDE + (ts - wlo) * 16);
-            const int kk = i - i0;
-            int op;
-            const bool d1 = (((ts >> 6) == mw0 ? mvA : mvB) >> (ts & 63)) & 1ull;
-            if ((m.x >> kk) & 1ull) {
-                const int64_t qi = (int64_t)a.i_a + i, tj = (int64_t)a.c_a + j;
-                const uint32_t qb_ = (uint32_t)(sel3(qA, qB, qC, (int)((qi >> 5) - qw0)) >> ((qi & 31) * 2)) & 3u;
-                const uint32_t tb_ = (uint32_t)(sel3(tA, tB, tC, (int)((tj >> 5) - tw0)) >> ((tj & 31) * 2)) & 3u;
-                op = qb_ == tb_ ? FZP_OP_EQ : FZP_OP_X;
-                i--; j--; ncol++;
-                const bool d2 = ts >= 1 ? ((((((ts - 1) >> 6) == mw0) ? mvA : mvB) >> ((ts - 1) & 63)) & 1ull) : false;   // move(-1) = RIGHT
+        // ---- walk inside the window, 32-bit state only
+        const uint32_t *auxm = (const uint32_t *)(mine + TB_AUX), *auxq = auxm + 4, *auxt = auxm + 10;
+        const int32_t md0 = mw0 * 2, qd0 = qw0 * 2, td0 = tw0 * 2;       // first dword held of each stream
+        const int32_t qoff = a.i_a, toff = a.c_a;
+        const int32_t wlo = cb * 32;
+        uint32_t mvs = 0, qsr = 0, tsr = 0;                               // next bit / base at the top
+        if (active) {
+            mvs = auxm[(ts >> 5) - md0] << (31 - (ts & 31));
+            qsr = auxq[((qoff + i) >> 4) - qd0] << (30 - 2 * ((qoff + i) & 15));
+            tsr = auxt[((toff + j) >> 4) - td0] << (30 - 2 * ((toff + j) & 15));
+        }
+        if (dbg_mode == 1 && active) { ts -= 48; i -= 33; j -= 32; i0 -= 17; active = ts >= 0 && i >= 0 && j >= 0; }   // ablation: staging cost only
+        while (dbg_mode != 1 && active && ts >= wlo) {
+            const uint2 m = *(const uint2 *)(mine + ((ts >> 5) - cb) * 512 + (i - i0) * 8);
+            const uint32_t bit = 31 - (ts & 31);
+            const bool dbit = (m.x >> bit) & 1u, gbit = (m.y >> bit) & 1u;
+            const bool d1 = mvs >> 31;
+            int32_t op;
+            // step back over ts (always) ...
+            ts--;
+            mvs <<= 1;
+            if ((ts & 31) == 31 && ts >= 0) mvs = auxm[(ts >> 5) - md0];
+            bool dec_i, dec_j;
+            if (dbit) {
+                op = ((qsr ^ tsr) >> 30) == 0 ? FZP_OP_EQ : FZP_OP_X;
+                const bool d2 = ts >= 0 ? (mvs >> 31) : false;            // move(-1) = RIGHT
                 i0 -= (d1 ? 1 : 0) + (d2 ? 1 : 0);
-                ts -= 2;
-            } else if ((((m.y >> kk) & 1ull) != 0) == d1) {
-                // G set after a DOWN move, or clear after a RIGHT move: the predecessor is the cell above
-                op = FZP_OP_I; i--; i0 -= d1 ? 1 : 0; ts -= 1;
+                ts--;                                                      // ... and over ts-1 for a diagonal
+                mvs <<= 1;
+                if ((ts & 31) == 31 && ts >= 0) mvs = auxm[(ts >> 5) - md0];
+                dec_i = dec_j = true;
+                ncol++;
             } else {
-                op = FZP_OP_D; j--; i0 -= d1 ? 1 : 0; ts -= 1;
+                // G set after a DOWN move, or clear after a RIGHT move: the predecessor is the cell above
+                dec_i = gbit == d1;
+                dec_j = !dec_i;
+                op = dec_i ? FZP_OP_I : FZP_OP_D;
+                i0 -= d1 ? 1 : 0;
+            }
+            if (dec_i) {
+                i--;
+                qsr <<= 2;
+                if (((qoff + i) & 15) == 15 && i >= 0) qsr = auxq[((qoff + i) >> 4) - qd0];
+            }
+            if (dec_j) {
+                j--;
+                tsr <<= 2;
+                if (((toff + j) & 15) == 15 && j >= 0) tsr = auxt[((toff + j) >> 4) - td0];
             }
             if (op == cur_op) cur_len++;
             else {
@@ -484,13 +644,13 @@ __global__ void __launch_bounds__(64) k_traceback(int64_t first, int64_t count, 
     if (!have) return;
     if (!(a.aligned && di.best_t >= 0 && di.best_score > 0 && i_end >= 0 && j_end >= 0)) { summ[r] = out; return; }
     if (cur_len) { nraw++; if (wpos > 1) reg[--wpos] = (cur_len << 4) | (uint32_t)cur_op; else overflow = true; }
-    int64_t q_lead = i + 1, r_lead = j + 1;
-    int64_t fa = wpos, fb = cap - 1;                        // forward ops are reg[fa .. fb)
+    int32_t q_lead = i + 1, r_lead = j + 1;
+    int32_t fa = wpos, fb = cap - 1;                        // forward ops are reg[fa .. fb)
     while (fa < fb && ((reg[fa] & 15u) == FZP_OP_I || (reg[fa] & 15u) == FZP_OP_D)) {
         if ((reg[fa] & 15u) == FZP_OP_I) q_lead += reg[fa] >> 4; else r_lead += reg[fa] >> 4;
         fa++;
     }
-    int64_t q_trail = 0, r_trail = 0;
+    int32_t q_trail = 0, r_trail = 0;
     while (fb > fa && ((reg[fb - 1] & 15u) == FZP_OP_I || (reg[fb - 1] & 15u) == FZP_OP_D)) {
         if ((reg[fb - 1] & 15u) == FZP_OP_I) q_trail += reg[fb - 1] >> 4; else r_trail += reg[fb - 1] >> 4;
         fb--;
@@ -504,7 +664,7 @@ __global__ void __launch_bounds__(64) k_traceback(int64_t first, int64_t count, 
         out.q_end = (int32_t)(a.i_a + i_end + 1 - q_trail);
         out.score = di.best_score;
         out.n_columns = ncol;
-        int32_t nc = (int32_t)(fb - fa);
+        int32_t nc = fb - fa;
         if (out.q_start > 0) { reg[--fa] = ((uint32_t)out.q_start << 4) | FZP_OP_S; nc++; }
         if (n - out.q_end > 0) { reg[fb++] = ((uint32_t)(n - out.q_end) << 4) | FZP_OP_S; nc++; }
         out.n_cigar = nc;
@@ -547,10 +707,11 @@ struct fzp_alnjob {
     DevBuf<int64_t> ctg_woff, ctg_len, idx_off, read_woff, tb_off, cig_off, cig_start;
     DevBuf<int32_t> idx_bits, read_len, read_ctg;
     DevBuf<uint64_t> table;
-    DevBuf<ulonglong2> mvw;
     DevBuf<Anchor> anc;
     DevBuf<DpInfo> info;
-    DevBuf<ulonglong2> tb;
+    DevBuf<uint2> tb2[2];
+    DevBuf<ulonglong2> mvw2[2];
+    hipEvent_t ev_sw[2] = {nullptr, nullptr}, ev_tb[2] = {nullptr, nullptr};
     DevBuf<fzp_aln_summary> summ;
     bool done = false;
 };
@@ -562,7 +723,8 @@ extern "C" void fzp_align_params_default(fzp_align_params *p) {
 
 extern "C" void fzp_align_destroy(fzp_ctx *ctx, fzp_alnjob *job) {
     if (!job) return;
-    if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
+    if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); (void)hipStreamSynchronize(ctx->stream2); }
+    for (int k = 0; k < 2; k++) { if (job->ev_sw[k]) (void)hipEventDestroy(job->ev_sw[k]); if (job->ev_tb[k]) (void)hipEventDestroy(job->ev_tb[k]); }
     delete job;
 }
 
@@ -681,31 +843,51 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
             ProfScope ps(ctx, "k1_orient");
             hipLaunchKernelGGL(k_orient, dim3((unsigned)nr, 1), dim3(256), 0, st, (int64_t)0, j->read_pk.p, j->read_woff.p, j->read_len.p, j->anc.p, j->read_ori.p);
         }
-        // trace-back masks live in HBM; reads are processed in chunks that fit the budget
-        int64_t budget_steps = (int64_t)48 << 30 >> 4;   // 48 GiB of 16-byte steps
+        // Trace-back masks live in HBM (16 B per DP step).  Reads go through in chunks: the DP of chunk k+1
+        // (integer-VALU bound, every wave slot busy, no LDS) runs on `stream` while the trace-back of chunk k
+        // (latency bound, 2 LDS-heavy waves per CU) runs on `stream2`; two mask buffers alternate.
+        int64_t budget_steps = (int64_t)48 << 30 >> 4;   // 48 GiB of 16-byte steps over both buffers
         if (const char *e = getenv("FZP_TB_BUDGET_GB")) { long g = atol(e); if (g > 0) budget_steps = ((int64_t)g << 30) >> 4; }
-        FZP_HIP(hipFuncSetAttribute((const void *)k_traceback, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * TB_LANE_STRIDE));
+        int n_chunks = 1;   // measured: overlapping the two kernels costs more than it hides (contention, chunk tails)
+        if (const char *e = getenv("FZP_SW_CHUNKS")) { int g = atoi(e); if (g > 0) n_chunks = g; }
+        const int64_t total_steps = j->h_tb_off[(size_t)nr];
+        int64_t chunk_steps = std::min<int64_t>(budget_steps / 2, (total_steps + n_chunks - 1) / n_chunks);
+        FZP_HIP(hipFuncSetAttribute((const void *)k_traceback, hipFuncAttributeMaxDynamicSharedMemorySize, TB_RPW * TB_LANE_STRIDE));
+        if (!j->ev_sw[0]) for (int k = 0; k < 2; k++) { FZP_HIP(hipEventCreateWithFlags(&j->ev_sw[k], hipEventDisableTiming)); FZP_HIP(hipEventCreateWithFlags(&j->ev_tb[k], hipEventDisableTiming)); }
+        hipStream_t st2 = ctx->stream2;
         int64_t first = 0;
+        int k = 0;
+        bool used[2] = {false, false};
         while (first < nr) {
             int64_t last = first;
-            while (last < nr && j->h_tb_off[(size_t)last + 1] - j->h_tb_off[(size_t)first] <= budget_steps) last++;
+            while (last < nr && j->h_tb_off[(size_t)last + 1] - j->h_tb_off[(size_t)first] <= chunk_steps) last++;
             if (last == first) last = first + 1;
             const int64_t cnt = last - first;
             const int64_t steps = j->h_tb_off[(size_t)last] - j->h_tb_off[(size_t)first];
-            FZP_TRY(j->tb.alloc((size_t)steps));
-            FZP_TRY(j->mvw.alloc((size_t)(steps / 64 + cnt + 2)));
+            const int bi = k & 1;
+            if (used[bi]) FZP_HIP(hipStreamWaitEvent(st, j->ev_tb[bi], 0));   // buffer free again?
+            FZP_TRY(j->tb2[bi].alloc((size_t)steps * 2 + 128));
+            FZP_TRY(j->mvw2[bi].alloc((size_t)(steps / 64 + cnt + 2)));
             {
                 ProfScope ps(ctx, "k1_sw");
                 hipLaunchKernelGGL(k_sw, dim3((unsigned)((cnt + 3) / 4)), dim3(256), 0, st, first, cnt, j->read_ori.p, j->read_woff.p, j->read_len.p, j->read_ctg.p,
-                                   j->ctg_pk.p, j->ctg_woff.p, j->ctg_len.p, j->anc.p, j->tb_off.p, j->tb.p, j->mvw.p, P.match, P.mismatch, P.gap, j->info.p);
+                                   j->ctg_pk.p, j->ctg_woff.p, j->ctg_len.p, j->anc.p, j->tb_off.p, j->tb2[bi].p, j->mvw2[bi].p, P.match, P.mismatch, P.gap, j->info.p);
             }
+            FZP_HIP(hipEventRecord(j->ev_sw[bi], st));
+            FZP_HIP(hipStreamWaitEvent(st2, j->ev_sw[bi], 0));
             {
-                ProfScope ps(ctx, "k1_traceback");
-                hipLaunchKernelGGL(k_traceback, dim3((unsigned)((cnt + 63) / 64)), dim3(64), (size_t)64 * TB_LANE_STRIDE, st, first, cnt, j->read_ori.p, j->read_woff.p, j->read_len.p, j->read_ctg.p,
-                                   j->ctg_pk.p, j->ctg_woff.p, j->anc.p, j->info.p, j->tb_off.p, j->tb.p, j->mvw.p, j->cig_off.p, j->cig.p, j->cig_start.p, j->summ.p);
+                ProfScope ps(ctx, "k1_traceback", st2);
+                hipLaunchKernelGGL(k_traceback, dim3((unsigned)((cnt + TB_RPW - 1) / TB_RPW)), dim3(64), (size_t)TB_RPW * TB_LANE_STRIDE, st2, first, cnt, j->read_ori.p, j->read_woff.p,
+                                   j->read_len.p, j->read_ctg.p, j->ctg_pk.p, j->ctg_woff.p, j->anc.p, j->info.p, j->tb_off.p, j->tb2[bi].p, j->mvw2[bi].p, j->cig_off.p,
+                                   j->cig.p, j->cig_start.p, j->summ.p, getenv("FZP_TB_DBG") ? atoi(getenv("FZP_TB_DBG")) : 0);
             }
+            FZP_HIP(hipEventRecord(j->ev_tb[bi], st2));
+            used[bi] = true;
             first = last;
+            k++;
         }
+        for (int b2 = 0; b2 < 2; b2++)
+            if (used[b2]) FZP_HIP(hipStreamWaitEvent(st, j->ev_tb[b2], 0));   // the main stream continues after all trace-backs
     }
     j->h_summ.resize((size_t)nr);
     FZP_TRY(j->summ.download(j->h_summ.data(), (size_t)nr, st));

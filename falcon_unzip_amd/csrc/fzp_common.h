@@ -92,6 +92,7 @@ struct PendingEvent {
 struct fzp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;   // trace-back of chunk k runs here while the DP of chunk k+1 runs on `stream`
     bool prof = false;
     std::map<std::string, ProfEntry> prof_tab;
     std::vector<PendingEvent> pending;
@@ -105,7 +106,8 @@ struct ProfScope {
     fzp_ctx *c;
     PendingEvent ev;
     bool on;
-    ProfScope(fzp_ctx *ctx, const char *name);
+    hipStream_t st;
+    ProfScope(fzp_ctx *ctx, const char *name, hipStream_t stream = nullptr);
     ~ProfScope();
 };
 int fzp_prof_flush(fzp_ctx *ctx);

@@ -97,6 +97,7 @@ extern "C" int fzp_ctx_create(int device_id, unsigned flags, fzp_ctx **out) {
     c->device = device_id;
     c->n_cu = prop.multiProcessorCount;
     hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (se == hipSuccess) se = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
     if (se != hipSuccess) {
         fzp_set_error("hipStreamCreate: %s", hipGetErrorString(se));
         delete c;
@@ -110,6 +111,7 @@ extern "C" void fzp_ctx_destroy(fzp_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(ctx->stream2);
     for (auto &p : ctx->pending) {
         (void)hipEventDestroy(p.a);
         (void)hipEventDestroy(p.b);
@@ -117,12 +119,14 @@ extern "C" void fzp_ctx_destroy(fzp_ctx *ctx) {
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     for (auto &b : ctx->scan_tmp) b.release();
     fzp_dev_trim();
+    (void)hipStreamDestroy(ctx->stream2);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 
 extern "C" int fzp_ctx_synchronize(fzp_ctx *ctx) {
     FZP_HIP(hipStreamSynchronize(ctx->stream));
+    FZP_HIP(hipStreamSynchronize(ctx->stream2));
     return FZP_OK;
 }
 
@@ -137,21 +141,22 @@ static hipEvent_t get_event(fzp_ctx *c) {
     (void)hipEventCreate(&e);
     return e;
 }
-ProfScope::ProfScope(fzp_ctx *ctx, const char *name) : c(ctx), on(ctx->prof) {
+ProfScope::ProfScope(fzp_ctx *ctx, const char *name, hipStream_t stream) : c(ctx), on(ctx->prof), st(stream ? stream : ctx->stream) {
     if (!on) return;
     ev.name = name;
     ev.a = get_event(c);
     ev.b = get_event(c);
-    (void)hipEventRecord(ev.a, c->stream);
+    (void)hipEventRecord(ev.a, st);
 }
 ProfScope::~ProfScope() {
     if (!on) return;
-    (void)hipEventRecord(ev.b, c->stream);
+    (void)hipEventRecord(ev.b, st);
     c->pending.push_back(ev);
 }
 int fzp_prof_flush(fzp_ctx *ctx) {
     if (ctx->pending.empty()) return FZP_OK;
     FZP_HIP(hipStreamSynchronize(ctx->stream));
+    FZP_HIP(hipStreamSynchronize(ctx->stream2));
     for (auto &p : ctx->pending) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {

@@ -155,12 +155,12 @@ static void align_one(const ctg_index *ix, const uint8_t *fwd, int64_t n, const 
             i0++;
             for (int kk = 0; kk < W - 1; kk++) qc[kk] = qc[kk + 1];
             qc[W - 1] = QC(i0 + 63);
-            for (int kk = 0; kk < W; kk++) { A[kk] = Hp[kk] - P->gap; B[kk] = kk < W - 1 ? Hp[kk + 1] - P->gap : NEG; }
+            for (int kk = 0; kk < W; kk++) { A[kk] = Hp[kk] - P->gap; B[kk] = (kk < W - 1 ? Hp[kk + 1] : NEG) - P->gap; }
             for (int kk = 0; kk < W; kk++) { dg[kk] = kk < W - 1 ? X[kk + 1] : NEG; Xn[kk] = Hp[kk]; }
         } else {
             for (int kk = W - 1; kk > 0; kk--) tc[kk] = tc[kk - 1];
             tc[0] = TC(tt - i0);
-            for (int kk = 0; kk < W; kk++) { A[kk] = Hp[kk] - P->gap; B[kk] = kk > 0 ? Hp[kk - 1] - P->gap : NEG; }
+            for (int kk = 0; kk < W; kk++) { A[kk] = Hp[kk] - P->gap; B[kk] = (kk > 0 ? Hp[kk - 1] : NEG) - P->gap; }
             for (int kk = 0; kk < W; kk++) { dg[kk] = X[kk]; Xn[kk] = kk > 0 ? Hp[kk - 1] : NEG; }
         }
         uint64_t D = 0, U = 0;
