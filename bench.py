@@ -154,8 +154,9 @@ def main():
         recs = []
         n_phased = 0
         qoff = 0
+        res = b.results()
         for c in range(args.contigs):
-            r = b.result(c)
+            r = res[c]
             nq = int((read_ctg == c).sum())   # upper bound; aligned reads get q_ids
             recs.append(fdist.r2p_from_preads(r.preads, nq, rank * n_reads + qoff, rank * args.contigs + c))
             n_phased += len(np.unique(r.preads["q_id"]))

@@ -50,6 +50,11 @@ class ResultStruct(C.Structure):
                 ("n_preads", C.c_int64), ("preads", C.c_void_p)]
 
 
+class ResultAllStruct(C.Structure):
+    _fields_ = [("all", ResultStruct), ("site_begin", C.POINTER(C.c_int64)), ("row_begin", C.POINTER(C.c_int64)),
+                ("arow_begin", C.POINTER(C.c_int64)), ("pvar_begin", C.POINTER(C.c_int64)), ("pread_begin", C.POINTER(C.c_int64))]
+
+
 class AlignParams(C.Structure):
     _fields_ = [("kmer", C.c_int32), ("seed_stride", C.c_int32), ("match", C.c_int32), ("mismatch", C.c_int32),
                 ("gap", C.c_int32), ("min_seed_hits", C.c_int32), ("reserved", C.c_int32 * 10)]
@@ -89,6 +94,8 @@ def load():
         "fzp_batch_run": (C.c_int, [VP, VP, C.c_uint]),
         "fzp_batch_result": (C.c_int, [VP, VP, I32, VP]),
         "fzp_batch_counts": (C.c_int, [VP, VP] + [PI64] * 8),
+        "fzp_batch_result_all": (C.c_int, [VP, VP, VP]),
+        "fzp_result_all_free": (None, [VP]),
         "fzp_batch_destroy": (None, [VP, VP]),
         "fzp_format_variant_pos": (C.c_int, [VP, I64, PP, PSZ]),
         "fzp_format_variant_map": (C.c_int, [VP, I64, VP, PP, PSZ]),
@@ -200,7 +207,9 @@ class Result:
             n = int(n)
             if not ptr or n == 0:
                 return np.zeros(0, dtype=dt)
-            return np.frombuffer(C.string_at(ptr, n * np.dtype(dt).itemsize), dtype=dt).copy()
+            nbytes = n * np.dtype(dt).itemsize
+            raw = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(nbytes,))
+            return raw.view(dt).copy()          # one copy out of the library-owned buffer
         self.sites = grab(rs.sites, rs.n_sites, SITE)
         self.vmap_qid = grab(rs.vmap_qid, rs.n_rows, np.int32)
         self.arows = grab(rs.arows, rs.n_arows, AROW)
@@ -222,6 +231,38 @@ class Batch:
         r = Result(rs)
         load().fzp_result_free(C.byref(rs))
         return r
+
+    def results(self):
+        """Every contig's records with ONE device-to-host copy per array -> list of Result (local indices)."""
+        lib = load()
+        ra = ResultAllStruct()
+        _check(lib.fzp_batch_result_all(self.eng._p, self._p, C.byref(ra)))
+        full = Result(ra.all)
+        n = self.n_ctg
+
+        def beg(p):
+            return np.ctypeslib.as_array(p, shape=(n + 1,)).copy() if p else np.zeros(n + 1, np.int64)
+        sb, rb, ab, pb, qb = beg(ra.site_begin), beg(ra.row_begin), beg(ra.arow_begin), beg(ra.pvar_begin), beg(ra.pread_begin)
+        lib.fzp_result_all_free(C.byref(ra))
+        # contig-local indices, vectorised over the whole batch (views are handed out below)
+        if len(full.sites):
+            full.sites["row_off"] -= np.repeat(rb[:-1], np.diff(sb))
+        if len(full.arows):
+            shift = np.repeat(sb[:-1], np.diff(ab)).astype(np.int32)
+            full.arows["site1"] -= shift
+            full.arows["site2"] -= shift
+        if len(full.pvars):
+            full.pvars["site"] -= np.repeat(sb[:-1], np.diff(pb)).astype(np.int32)
+        out = []
+        for c in range(n):
+            r = Result.__new__(Result)
+            r.sites = full.sites[sb[c]:sb[c + 1]]
+            r.vmap_qid = full.vmap_qid[rb[c]:rb[c + 1]]
+            r.arows = full.arows[ab[c]:ab[c + 1]]
+            r.pvars = full.pvars[pb[c]:pb[c + 1]]
+            r.preads = full.preads[qb[c]:qb[c + 1]]
+            out.append(r)
+        return out
 
     def counts(self):
         v = [C.c_int64() for _ in range(8)]

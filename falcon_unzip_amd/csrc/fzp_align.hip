@@ -398,14 +398,14 @@ __device__ __forceinline__ void sw_block(int32_t &H, int32_t &X, int32_t &qc, in
 __device__ __forceinline__ uint32_t win_load(const uint32_t *__restrict__ pk, int64_t idx) { return pk[idx >> 4]; }
 __device__ __forceinline__ int32_t win_base(uint32_t raw, int64_t idx) { return (int32_t)((raw >> ((idx & 15) * 2)) & 3u); }
 
-__global__ void __launch_bounds__(256) k_sw(int64_t first, int64_t count, const uint32_t *__restrict__ read_ori, const int64_t *__restrict__ read_woff,
+__global__ void __launch_bounds__(64) k_sw(int64_t first, int64_t count, const uint32_t *__restrict__ read_ori, const int64_t *__restrict__ read_woff,
                                             const int32_t *__restrict__ read_len, const int32_t *__restrict__ read_ctg, const uint32_t *__restrict__ ctg_pk,
                                             const int64_t *__restrict__ ctg_woff, const int64_t *__restrict__ ctg_len, const Anchor *__restrict__ anc,
                                             const int64_t *__restrict__ tb_off, uint2 *__restrict__ tb, ulonglong2 *__restrict__ mvw, int match, int mismatch,
                                             int gap, DpInfo *__restrict__ info) {
     const int lane = lane_id();
     // wave-uniform on purpose: everything indexed by the read then lives in SGPRs / scalar loads
-    const int64_t wv = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t wv = (int64_t)blockIdx.x;   // one wave per workgroup: a finished read frees its slot at once
     if (wv >= count) return;
     const int64_t r = first + wv;
     const Anchor a = anc[r];
@@ -870,7 +870,7 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
             FZP_TRY(j->mvw2[bi].alloc((size_t)(steps / 64 + cnt + 2)));
             {
                 ProfScope ps(ctx, "k1_sw");
-                hipLaunchKernelGGL(k_sw, dim3((unsigned)((cnt + 3) / 4)), dim3(256), 0, st, first, cnt, j->read_ori.p, j->read_woff.p, j->read_len.p, j->read_ctg.p,
+                hipLaunchKernelGGL(k_sw, dim3((unsigned)cnt), dim3(64), 0, st, first, cnt, j->read_ori.p, j->read_woff.p, j->read_len.p, j->read_ctg.p,
                                    j->ctg_pk.p, j->ctg_woff.p, j->ctg_len.p, j->anc.p, j->tb_off.p, j->tb2[bi].p, j->mvw2[bi].p, P.match, P.mismatch, P.gap, j->info.p);
             }
             FZP_HIP(hipEventRecord(j->ev_sw[bi], st));

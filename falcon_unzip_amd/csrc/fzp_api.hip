@@ -182,6 +182,66 @@ extern "C" int fzp_batch_result(fzp_ctx *ctx, fzp_batch *b, int32_t ctg, fzp_res
     return FZP_OK;
 }
 
+extern "C" void fzp_result_all_free(fzp_result_all *r) {
+    if (!r) return;   // r->all is borrowed from the ctx's pinned buffer
+    free(r->site_begin); free(r->row_begin); free(r->arow_begin); free(r->pvar_begin); free(r->pread_begin);
+    memset(r, 0, sizeof *r);
+}
+
+extern "C" int fzp_batch_result_all(fzp_ctx *ctx, fzp_batch *b, fzp_result_all *out) {
+    if (!ctx || !b || !out) return FZP_EINVAL;
+    FZP_HIP(hipSetDevice(ctx->device));
+    memset(out, 0, sizeof *out);
+    hipStream_t st = ctx->stream;
+    const size_t nb = (size_t)b->n_ctg + 1;
+    auto dup = [&](const std::vector<int64_t> &v) {
+        int64_t *p = (int64_t *)calloc(nb, sizeof(int64_t));
+        if (p && v.size() == nb) memcpy(p, v.data(), nb * sizeof(int64_t));
+        return p;
+    };
+    fzp_result &r = out->all;
+    // one pinned staging area, five async copies, one sync, then plain memcpy into the caller's arrays
+    struct Part { const void *src; size_t bytes; void **dst; };
+    std::vector<Part> parts;
+    if (b->have_sites) {
+        r.n_sites = b->n_sites; r.n_rows = b->n_rows;
+        parts.push_back({b->sites.p, (size_t)b->n_sites * sizeof(fzp_site), (void **)&r.sites});
+        parts.push_back({b->vmap_qid.p, (size_t)b->n_rows * sizeof(int32_t), (void **)&r.vmap_qid});
+        out->site_begin = dup(b->h_site_begin);
+    }
+    if (b->have_arows) { r.n_arows = b->n_arows; parts.push_back({b->arows.p, (size_t)b->n_arows * sizeof(fzp_arow), (void **)&r.arows}); out->arow_begin = dup(b->h_arow_begin); }
+    if (b->have_blocks) { r.n_pvars = b->n_pvars; parts.push_back({b->pvars.p, (size_t)b->n_pvars * sizeof(fzp_pvar), (void **)&r.pvars}); out->pvar_begin = dup(b->h_pvar_begin); }
+    if (b->have_preads) { r.n_preads = b->n_preads; parts.push_back({b->preads.p, (size_t)b->n_preads * sizeof(fzp_pread), (void **)&r.preads}); out->pread_begin = dup(b->h_pread_begin); }
+    size_t total = 0;
+    for (auto &p : parts) total += (p.bytes + 63) & ~(size_t)63;
+    if (total > ctx->pinned_bytes) {
+        if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+        ctx->pinned = nullptr; ctx->pinned_bytes = 0;
+        size_t want = total + total / 4 + (1 << 20);
+        if (hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); fzp_result_all_free(out); fzp_set_error("pinned host allocation of %zu bytes failed", want); return FZP_ENOMEM; }
+        ctx->pinned_bytes = want;
+    }
+    size_t off = 0;
+    for (auto &p : parts) {
+        if (p.bytes && hipMemcpyAsync((char *)ctx->pinned + off, p.src, p.bytes, hipMemcpyDeviceToHost, st) != hipSuccess) { fzp_result_all_free(out); fzp_set_error("D2H copy failed"); return FZP_EDEVICE; }
+        off += (p.bytes + 63) & ~(size_t)63;
+    }
+    if (hipStreamSynchronize(st) != hipSuccess) { fzp_result_all_free(out); fzp_set_error("D2H sync failed"); return FZP_EDEVICE; }
+    off = 0;
+    for (auto &p : parts) {   // borrowed views into the pinned buffer
+        *p.dst = (char *)ctx->pinned + off;
+        off += (p.bytes + 63) & ~(size_t)63;
+    }
+    if (b->have_sites) {
+        out->row_begin = (int64_t *)calloc(nb, sizeof(int64_t));
+        for (int c = 0; c <= b->n_ctg; c++) {
+            int64_t s0 = b->h_site_begin[c];
+            out->row_begin[c] = s0 < b->n_sites ? r.sites[s0].row_off : b->n_rows;
+        }
+    }
+    return FZP_OK;
+}
+
 // ================================================================================ stage injection
 namespace {
 // a 1-contig batch that starts from het-call output instead of alignment records

@@ -98,6 +98,8 @@ struct fzp_ctx {
     std::vector<PendingEvent> pending;
     std::vector<hipEvent_t> event_pool;
     DevBuf<uint64_t> scan_tmp[3];
+    void *pinned = nullptr;          // pinned host staging for bulk device-to-host copies (grow-only)
+    size_t pinned_bytes = 0;
     int n_cu = 256;
 };
 

@@ -166,6 +166,17 @@ int fzp_batch_create(fzp_ctx *ctx, int32_t n_ctg, const fzp_alnset *const *aln, 
                      const int64_t *ref_len, fzp_batch **out);
 int fzp_batch_run(fzp_ctx *ctx, fzp_batch *b, unsigned stages);
 int fzp_batch_result(fzp_ctx *ctx, fzp_batch *b, int32_t ctg, fzp_result *out);
+/* all contigs at once: arrays concatenated in contig order with GLOBAL site / row indices (site indices in
+ * arows / pvars and row_off in sites count from the start of the batch); begin[] arrays have n_ctg+1 entries.
+ * One D2H copy per array instead of one per contig.  The record arrays in `all` are BORROWED: they point into
+ * the context's pinned staging buffer and stay valid until the next fzp_batch_result_all on this ctx (or
+ * fzp_ctx_destroy); fzp_result_all_free releases only the begin[] arrays. */
+typedef struct {
+    fzp_result all;
+    int64_t *site_begin, *row_begin, *arow_begin, *pvar_begin, *pread_begin;
+} fzp_result_all;
+int fzp_batch_result_all(fzp_ctx *ctx, fzp_batch *b, fzp_result_all *out);
+void fzp_result_all_free(fzp_result_all *r);
 int fzp_batch_counts(fzp_ctx *ctx, fzp_batch *b, int64_t *n_rec, int64_t *n_columns, int64_t *n_positions,
                      int64_t *n_sites, int64_t *n_rows, int64_t *n_arows, int64_t *n_pvars, int64_t *n_preads);
 void fzp_batch_destroy(fzp_ctx *ctx, fzp_batch *b);

@@ -74,8 +74,11 @@ def test_batch_all_contigs_one_launch(eng):
     alns = [_lib.parse_sam(c.sam) for c in cs]
     b = eng.batch(alns, [c.ref_seq for c in cs])
     b.run(_lib.STAGE_ALL)
+    bulk = b.results()
     for i, c in enumerate(cs):
         r = b.result(i)
+        for f in ("sites", "vmap_qid", "arows", "pvars", "preads"):
+            assert np.array_equal(getattr(bulk[i], f), getattr(r, f)), (c.name, f)
         off, names = alns[i].qname_table()
         c.check("variant_pos", _lib.format_variant_pos(r.sites))
         c.check("variant_map", _lib.format_variant_map(r.sites, r.vmap_qid))
