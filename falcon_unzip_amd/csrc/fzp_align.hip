@@ -513,12 +513,14 @@ __global__ void __launch_bounds__(64) k_sw(int64_t first, int64_t count, const u
 // The walk from the best cell back to the anchor is sequential per read, so a lane owns a read.  Rounds:
 // for each of its reads the wave pulls the two 32-step mask chunks ending at that read's current step
 // (1 KB, one LDS-DMA instruction, all in flight together), the lane parks the few words of move bits
-// and bases the next <= 64 steps can touch next to it, and then walks using LDS and registers only:
-// the bits / bases it consumes sit in 32-bit shift registers (next item at the top) reloaded from LDS
-// at word boundaries.  HBM traffic: the 16 B/step masks are read once (+ chunk re-reads at round edges).
-constexpr int TB_LANE_STRIDE = 1024 + 64 + 8;    // bytes per read: 2 mask chunks + aux words; +8 staggers LDS banks
+// the next <= 64 steps can touch next to it, and then walks using LDS and registers only (the move bits
+// it consumes sit in a 32-bit shift register, next bit at the top, reloaded from LDS at word
+// boundaries).  Diagonal steps are emitted as 'M': the '=' / 'X' split needs the bases and is done on the
+// host where SAM text / alnsets are produced (the phasing stages treat M, = and X alike, phasing.py:81).
+// HBM traffic: the 16 B/step masks are read once (+ chunk re-reads at round edges).
+constexpr int TB_LANE_STRIDE = 1024 + 16 + 8;    // bytes per read: 2 mask chunks + 4 move dwords; +8 staggers LDS banks
 constexpr int TB_RPW = 16;                       // reads walked per wave (all 64 lanes stage)
-constexpr int TB_AUX = 1024;                     // aux area: 4 move dwords, 6 q dwords, 6 t dwords
+constexpr int TB_AUX = 1024;                     // aux area: 4 move dwords
 
 __global__ void __launch_bounds__(64) k_traceback(int64_t first, int64_t count, const uint32_t *__restrict__ read_ori, const int64_t *__restrict__ read_woff,
                                                   const int32_t *__restrict__ read_len, const int32_t *__restrict__ read_ctg, const uint32_t *__restrict__ ctg_pk,
@@ -572,65 +574,46 @@ __global__ void __launch_bounds__(64) k_traceback(int64_t first, int64_t count, 
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(((const uint4 *)pl) + (int64_t)cl * 32 + lane),
                                              (__attribute__((address_space(3))) void *)(tb_lds + l * TB_LANE_STRIDE), 16, 0, 0);
         }
-        // move bits of steps [ts-64, ts] (2 words) and the bases q[i-64 .. i], t[j-64 .. j] (3 words each)
+        // move bits of steps [ts-64, ts] (2 words)
         const int32_t mw0 = max(ts - 64, 0) >> 6;
-        const int32_t qw0 = (int32_t)(((int64_t)a.i_a + max(i - 64, 0)) >> 5), tw0 = (int32_t)(((int64_t)a.c_a + max(j - 64, 0)) >> 5);
         if (active) {
             uint64_t *aux = (uint64_t *)(mine + TB_AUX);
             aux[0] = mvr[mw0].x; aux[1] = mvr[mw0 + 1].x;
-            aux[2] = qpk[qw0]; aux[3] = qpk[qw0 + 1]; aux[4] = qpk[qw0 + 2];
-            aux[5] = tpk[tw0]; aux[6] = tpk[tw0 + 1]; aux[7] = tpk[tw0 + 2];
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // covers the LDS-DMA loads (hipcc does not track them)
         __syncthreads();
         // ---- walk inside the window, 32-bit state only
-        const uint32_t *auxm = (const uint32_t *)(mine + TB_AUX), *auxq = auxm + 4, *auxt = auxm + 10;
-        const int32_t md0 = mw0 * 2, qd0 = qw0 * 2, td0 = tw0 * 2;       // first dword held of each stream
-        const int32_t qoff = a.i_a, toff = a.c_a;
+        const uint32_t *auxm = (const uint32_t *)(mine + TB_AUX);
+        const int32_t md0 = mw0 * 2;                                      // first move dword held
         const int32_t wlo = cb * 32;
-        uint32_t mvs = 0, qsr = 0, tsr = 0;                               // next bit / base at the top
-        if (active) {
-            mvs = auxm[(ts >> 5) - md0] << (31 - (ts & 31));
-            qsr = auxq[((qoff + i) >> 4) - qd0] << (30 - 2 * ((qoff + i) & 15));
-            tsr = auxt[((toff + j) >> 4) - td0] << (30 - 2 * ((toff + j) & 15));
-        }
+        uint32_t mvs = 0;                                                 // move bit of step ts at the top
+        if (active) mvs = auxm[(ts >> 5) - md0] << (31 - (ts & 31));
         if (dbg_mode == 1 && active) { ts -= 48; i -= 33; j -= 32; i0 -= 17; active = ts >= 0 && i >= 0 && j >= 0; }   // ablation: staging cost only
         while (dbg_mode != 1 && active && ts >= wlo) {
             const uint2 m = *(const uint2 *)(mine + ((ts >> 5) - cb) * 512 + (i - i0) * 8);
             const uint32_t bit = 31 - (ts & 31);
             const bool dbit = (m.x >> bit) & 1u, gbit = (m.y >> bit) & 1u;
-            const bool d1 = mvs >> 31;
-            int32_t op;
+            const int32_t d1 = (int32_t)(mvs >> 31);
             // step back over ts (always) ...
             ts--;
             mvs <<= 1;
             if ((ts & 31) == 31 && ts >= 0) mvs = auxm[(ts >> 5) - md0];
-            bool dec_i, dec_j;
+            int32_t op;
             if (dbit) {
-                op = ((qsr ^ tsr) >> 30) == 0 ? FZP_OP_EQ : FZP_OP_X;
-                const bool d2 = ts >= 0 ? (mvs >> 31) : false;            // move(-1) = RIGHT
-                i0 -= (d1 ? 1 : 0) + (d2 ? 1 : 0);
+                op = FZP_OP_M;
+                const int32_t d2 = ts >= 0 ? (int32_t)(mvs >> 31) : 0;   // move(-1) = RIGHT
+                i0 -= d1 + d2;
                 ts--;                                                      // ... and over ts-1 for a diagonal
                 mvs <<= 1;
                 if ((ts & 31) == 31 && ts >= 0) mvs = auxm[(ts >> 5) - md0];
-                dec_i = dec_j = true;
-                ncol++;
+                i--; j--; ncol++;
             } else {
                 // G set after a DOWN move, or clear after a RIGHT move: the predecessor is the cell above
-                dec_i = gbit == d1;
-                dec_j = !dec_i;
-                op = dec_i ? FZP_OP_I : FZP_OP_D;
-                i0 -= d1 ? 1 : 0;
-            }
-            if (dec_i) {
-                i--;
-                qsr <<= 2;
-                if (((qoff + i) & 15) == 15 && i >= 0) qsr = auxq[((qoff + i) >> 4) - qd0];
-            }
-            if (dec_j) {
-                j--;
-                tsr <<= 2;
-                if (((toff + j) & 15) == 15 && j >= 0) tsr = auxt[((toff + j) >> 4) - td0];
+                const bool up = (gbit ? 1 : 0) == d1;
+                op = up ? FZP_OP_I : FZP_OP_D;
+                i0 -= d1;
+                i -= up ? 1 : 0;
+                j -= up ? 0 : 1;
             }
             if (op == cur_op) cur_len++;
             else {
@@ -1000,6 +983,35 @@ extern "C" int fzp_align_alnset(fzp_ctx *ctx, fzp_alnjob *j, int32_t ctg, const 
     int rc = cigar.download(a->cigar, (size_t)p.cig_off.back(), st);
     if (!rc) rc = seq.download(a->seq, (size_t)p.seq_off.back(), st);
     if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = FZP_EDEVICE;
+    if (!rc) {
+        // device CIGARs carry diagonal runs as 'M'; split them into '=' / 'X' against the contig here
+        const std::vector<uint8_t> &ref = j->h_ctg[(size_t)ctg];
+        std::vector<uint32_t> out_c;
+        std::vector<int64_t> out_off(1, 0);
+        out_c.reserve((size_t)p.cig_off.back() * 2);
+        for (int64_t k = 0; k < nrec; k++) {
+            int64_t rp = a->rec_pos[k], qp = 0;
+            const uint8_t *sq = a->seq + a->seq_off[k];
+            for (int64_t w = a->cig_off[k]; w < a->cig_off[k + 1]; w++) {
+                const uint32_t len = a->cigar[w] >> 4, op = a->cigar[w] & 15u;
+                if (op != FZP_OP_M) {
+                    out_c.push_back(a->cigar[w]);
+                    if (op == FZP_OP_S || op == FZP_OP_I) qp += len; else if (op == FZP_OP_D) rp += len;
+                    continue;
+                }
+                uint32_t run = 0; int cur = -1;
+                for (uint32_t x = 0; x < len; x++, rp++, qp++) {
+                    const int eq = code_of(sq[qp]) == code_of(ref[(size_t)rp]) ? FZP_OP_EQ : FZP_OP_X;
+                    if (eq == cur) run++;
+                    else { if (run) out_c.push_back((run << 4) | (uint32_t)cur); cur = eq; run = 1; }
+                }
+                if (run) out_c.push_back((run << 4) | (uint32_t)cur);
+            }
+            out_off.push_back((int64_t)out_c.size());
+        }
+        free(a->cigar); free(a->cig_off);
+        a->cigar = dupv(out_c); a->cig_off = dupv(out_off);
+    }
     // q_id table: every aligned read of the contig, in sorted order (one SAM line each)
     const auto &ar = p.ctg_reads[0];
     a->n_qid = (int32_t)ar.size();

@@ -225,7 +225,14 @@ static void align_one(const ctg_index *ix, const uint8_t *fwd, int64_t n, const 
             if ((rev.v[b] & 15) == 1) q_trail += rev.v[b] >> 4; else r_trail += rev.v[b] >> 4;
             b++;
         }
-        if (a >= b && ncol > 0 && (rev.n <= n + 16)) {
+        /* the device emits diagonal runs as 'M' (the '=' / 'X' split is host work); the overflow rule and
+         * n_cigar are defined on those merged runs */
+        int64_t n_mraw = 0; int prev_m = -1;
+        for (int64_t f = 0; f < rev.n; f++) {
+            int o = (int)(rev.v[f] & 15); int mo = (o == 7 || o == 8) ? 0 : o;
+            if (mo != prev_m) { n_mraw++; prev_m = mo; }
+        }
+        if (a >= b && ncol > 0 && (n_mraw <= n + 16)) {
             out->aligned = 1;
             out->strand = bs_;
             out->pos = (int32_t)(c_a + r_lead);
@@ -234,11 +241,15 @@ static void align_one(const ctg_index *ix, const uint8_t *fwd, int64_t n, const 
             out->q_end = (int32_t)(i_a + i_end + 1 - q_trail);
             out->score = bsc[bk];
             out->n_columns = ncol;
-            int32_t nc = 0;
+            int32_t nc = 0; prev_m = -1;
             if (out->q_start > 0) { push(cig, ((uint32_t)out->q_start << 4) | 4u); nc++; }
-            for (int64_t f = a; f >= b; f--) { push(cig, rev.v[f]); nc++; }
+            for (int64_t f = a; f >= b; f--) {
+                push(cig, rev.v[f]);
+                int o = (int)(rev.v[f] & 15); int mo = (o == 7 || o == 8) ? 0 : o;
+                if (mo != prev_m) { nc++; prev_m = mo; }
+            }
             if (n - out->q_end > 0) { push(cig, ((uint32_t)(n - out->q_end) << 4) | 4u); nc++; }
-            out->n_cigar = nc;
+            out->n_cigar = nc;   /* words of the device CIGAR (M runs); the =/X CIGAR pushed above has more */
         }
         free(rev.v);
     }
