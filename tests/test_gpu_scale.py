@@ -1,0 +1,143 @@
+"""Size-independent properties of the whole path at BASELINE-scale shapes (5 Mb contigs, 15 kb reads):
+determinism, batch independence, structural invariants of every record type, and byte parity of the
+phasing stages against the oracle given the aligner's records."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from falcon_unzip_amd import _lib
+    e = _lib.Engine(0)
+    yield e
+    e.close()
+
+
+def _make(n_ctg, L, n_reads, R, win, cfg=7):
+    from falcon_unzip_amd import sim
+    contigs, blobs, offs, rctg, base = [], [], [np.zeros(1, np.int64)], [], 0
+    for c in range(n_ctg):
+        rng = sim.rng_for(cfg, c)
+        hap0, hap1, _ = sim.make_diploid(L, rng)
+        lo = int(rng.integers(0, L - win + 1))
+        codes, off, *_ = sim.simulate_raw_reads_bulk(hap0, hap1, n_reads, R, rng, lo=lo, hi=lo + win)
+        contigs.append(sim.ACGT[hap0].tobytes())
+        blobs.append(sim.ACGT[codes].tobytes())
+        offs.append(off[1:] + base)
+        base += int(off[-1])
+        rctg.append(np.full(n_reads, c, np.int32))
+    return contigs, b"".join(blobs), np.concatenate(offs), np.concatenate(rctg)
+
+
+def _check_invariants(r, n_qid):
+    s = r.sites
+    assert np.all(np.diff(s["pos"]) > 0)
+    assert np.all(s["total"] >= 10)
+    assert np.all(4 * s["count"][:, 0].astype(np.int64) < 3 * s["total"]) and np.all(4 * s["count"][:, 1].astype(np.int64) > s["total"])
+    assert np.all(s["count"][:, 0] >= s["count"][:, 1]) and np.all(s["count"][:, 1] >= s["count"][:, 2])
+    rows = s["count"][:, 0].astype(np.int64) + s["count"][:, 1]
+    assert np.array_equal(s["row_off"], np.concatenate(([0], np.cumsum(rows)[:-1])))
+    assert len(r.vmap_qid) == rows.sum() and (len(r.vmap_qid) == 0 or (r.vmap_qid.min() >= 0 and r.vmap_qid.max() < n_qid))
+    a = r.arows
+    if len(a):
+        assert np.all(a["site1"] < a["site2"])
+        key = a["site1"].astype(np.int64) * (1 << 32) + a["site2"]
+        assert np.all(np.diff(key) > 0)
+        assert np.all(s["pos"][a["site2"]] - s["pos"][a["site1"]] <= 65536)
+        assert np.all(a["n"].sum(axis=1) >= 6)
+        assert np.bincount(a["site1"]).max() <= 501
+    p = r.preads
+    if len(p):
+        key = p["q_id"].astype(np.int64) * (1 << 32) + p["block"]
+        assert np.all(np.diff(key) > 0)
+        assert np.all(np.abs(p["n0"] - p["n1"]) > 1)
+        assert np.all((p["phase"] == 0) == (p["n0"] > p["n1"]))
+    v = r.pvars
+    if len(v):
+        assert np.all(np.diff(v["block"]) >= 0) and v["block"].min() == 1
+        assert np.all(np.bincount(v["block"])[1:] > 3)
+        assert np.all(v["lscore"] >= 10) and np.all(v["rscore"] >= 10)
+
+
+def test_cfg2_shape_one_contig_vs_oracle(eng, oracle):
+    """One cfg2 contig at full size: 5 Mb contig, 2000 x 15 kb reads -> invariants + oracle parity of K2..K5."""
+    from falcon_unzip_amd import _lib
+    contigs, blob, off, rctg = _make(1, 5_000_000, 2000, 15000, 750_000)
+    job = _lib.align_job_raw(eng, contigs, blob, off, rctg)
+    job.run()
+    sm = job.summaries()
+    assert sm["aligned"].mean() > 0.995
+    assert np.all(sm["cells"][sm["aligned"] == 1] > 0)
+    aln, idx = job.alnset(0)
+    assert np.all(np.diff(aln.rec_pos()) >= 0) and len(np.unique(aln.rec_qid())) == aln.n_rec
+    b = job.to_batch()
+    b.run(_lib.STAGE_ALL)
+    r = b.results()[0]
+    _check_invariants(r, aln.n_qid)
+    assert len(r.sites) > 1000 and len(r.preads) > 1800
+    sam = _lib.format_sam(aln, "c0")
+    exp = oracle.phase_all(sam, contigs[0], "c0")
+    off_q, names = aln.qname_table()
+    assert _lib.format_variant_pos(r.sites) == exp["variant_pos"]
+    assert _lib.format_variant_map(r.sites, r.vmap_qid) == exp["variant_map"]
+    assert _lib.format_atable(r.sites, r.arows) == exp["atable"]
+    assert _lib.format_phased_variants(r.sites, r.pvars) == exp["phased_variants"]
+    assert _lib.format_phased_reads(r.preads, "c0", off_q, names) == exp["phased_reads"]
+    b.close()
+    job.close()
+
+
+def test_determinism_and_batch_independence(eng):
+    from falcon_unzip_amd import _lib
+    contigs, blob, off, rctg = _make(3, 1_000_000, 500, 15000, 200_000, cfg=8)
+    job = _lib.align_job_raw(eng, contigs, blob, off, rctg)
+    job.run()
+    s1 = job.summaries().copy()
+    b1 = job.to_batch()
+    b1.run(_lib.STAGE_ALL)
+    r1 = b1.results()
+    b1.close()
+    job.run()                                   # same resident inputs, second pass
+    assert np.array_equal(job.summaries(), s1)
+    b2 = job.to_batch()
+    b2.run(_lib.STAGE_ALL)
+    r2 = b2.results()
+    b2.close()
+    for a, b in zip(r1, r2):
+        for f in ("sites", "vmap_qid", "arows", "pvars", "preads"):
+            assert np.array_equal(getattr(a, f), getattr(b, f)), f
+    job.close()
+    # every contig alone == that contig inside the batch
+    for c in range(3):
+        m = rctg == c
+        lo, hi = off[:-1][m][0], off[1:][m][-1]
+        o = np.concatenate((off[:-1][m], [hi])) - lo
+        j1 = _lib.align_job_raw(eng, [contigs[c]], blob[lo:hi], o, np.zeros(int(m.sum()), np.int32))
+        j1.run()
+        assert np.array_equal(j1.summaries(), s1[m])
+        bb = j1.to_batch()
+        bb.run(_lib.STAGE_ALL)
+        rs = bb.results()[0]
+        for f in ("sites", "vmap_qid", "arows", "pvars", "preads"):
+            assert np.array_equal(getattr(rs, f), getattr(r1[c], f)), (c, f)
+        _check_invariants(rs, int(m.sum()))
+        bb.close()
+        j1.close()
+
+
+def test_chunked_traceback_budget_matches(eng, monkeypatch):
+    """A tiny trace-back budget forces many read chunks; results must not change."""
+    from falcon_unzip_amd import _lib
+    contigs, blob, off, rctg = _make(1, 300_000, 96, 8000, 100_000, cfg=9)
+    job = _lib.align_job_raw(eng, contigs, blob, off, rctg)
+    job.run()
+    ref = job.summaries().copy()
+    a_ref, _ = job.alnset(0)
+    monkeypatch.setenv("FZP_SW_CHUNKS", "7")
+    job.run()
+    assert np.array_equal(job.summaries(), ref)
+    a2, _ = job.alnset(0)
+    assert _lib.format_sam(a2, "x") == _lib.format_sam(a_ref, "x")
+    job.close()
