@@ -205,7 +205,9 @@ def main():
             with open(tf) as f:
                 traffic = json.load(f).get("bytes_per_launch")
         out = {
-            "metric": "reads_phased_per_sec (DP Gcell/s/GPU alongside), 15 kb reads x 5 Mb contigs",
+            # BASELINE.json's metric, verbatim; `value` is its reads-phased/sec half (whole job), the DP half is
+            # `dp_gcell_per_s_per_gpu` below
+            "metric": "DP Gcell/s/GPU + reads phased/sec, 15 kb reads x 5 Mb contigs, 1/2/4/8 GPUs",
             "value": round(world * n_reads * args.steps / dt, 2),
             "unit": "reads/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
