@@ -159,7 +159,13 @@ __global__ void __launch_bounds__(256) k_seed(int64_t first, const uint32_t *__r
     }
     mn = block_max_u64(mn, red);
     if (threadIdx.x == 0) {
-        if (mn != 0) { uint64_t v = ~mn; a.aligned = 1; a.strand = bs; a.i_a = (int32_t)(v >> 32); a.c_a = (int32_t)(uint32_t)v; }
+        if (mn != 0) {
+            // the seed fixes the diagonal; the extension itself starts at the read's first base on that diagonal
+            // (or at the contig's first base when the read overhangs it)
+            const uint64_t v = ~mn;
+            const int32_t d = (int32_t)(uint32_t)v - (int32_t)(v >> 32);
+            a.aligned = 1; a.strand = bs; a.i_a = d < 0 ? -d : 0; a.c_a = d < 0 ? 0 : d;
+        }
         anc[r] = a;
     }
 }

@@ -14,10 +14,11 @@
  *             position; every `stride`-th k-mer of the read, both orientations, votes for
  *             bin = (cpos - i + n) >> shift, shift = smallest s>=10 with ((Lc+n)>>s)+2 <= 8192;
  *             best (strand, bin) maximises votes[bin]+votes[bin+1] (ties: forward strand, lower bin);
- *             fewer than min_seed_hits votes -> unaligned.  Anchor = the hit with the smallest read
- *             offset i_a inside the two winning bins.
- *   extension adaptive anti-diagonal band of 64 cells (Suzuki-Kasahara style), forward from the
- *             anchor: linear gaps, H = max(diag + (match | -mismatch), up - gap, left - gap), no zero
+ *             fewer than min_seed_hits votes -> unaligned.  The hit with the smallest read offset inside
+ *             the two winning bins fixes the diagonal d = cpos - i; the extension starts at the read's
+ *             first base on that diagonal: origin (max(0,-d), max(0,d)).
+ *   extension adaptive anti-diagonal band of 64 cells (Suzuki-Kasahara style), forward from that
+ *             origin: linear gaps, H = max(diag + (match | -mismatch), up - gap, left - gap), no zero
  *             floor; the first 64 steps alternate down/right, afterwards the band moves RIGHT when
  *             H[lane 0] > H[lane 63], else DOWN.  The diagonal operand is carried pre-shifted by the
  *             previous move, so after a RIGHT move followed by a DOWN move lane 63 has no diagonal
@@ -124,6 +125,12 @@ static void align_one(const ctg_index *ix, const uint8_t *fwd, int64_t n, const 
         if (b == bb || b == bb + 1) { i_a = i; c_a = cp; break; }
     }
     if (i_a < 0) { free(ori[0]); free(ori[1]); return; }
+    {   /* the seed fixes the diagonal; the extension starts at the read's first base on that diagonal
+         * (or at the contig's first base when the read overhangs it) */
+        int64_t d = c_a - i_a;
+        i_a = d < 0 ? -d : 0;
+        c_a = d < 0 ? 0 : d;
+    }
 
     /* ---- adaptive banded extension from the anchor */
     const uint8_t *q = r + i_a;
