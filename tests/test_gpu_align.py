@@ -109,3 +109,70 @@ def test_align_then_phase_matches_oracle_chain(eng, oracle):
     assert agree >= 0.97 * len(r.preads)
     b.close()
     job.close()
+
+
+def test_edge_cases_match_twin(eng, oracle):
+    """Overhangs at both contig ends, a read longer than the contig, lower-case / non-ACGT symbols, junk."""
+    from falcon_unzip_amd import _lib, sim
+    rng = np.random.Generator(np.random.PCG64(77))
+    L = 40000
+    hap0, hap1, _ = sim.make_diploid(L, rng)
+    big = np.concatenate((rng.integers(0, 4, 3000, dtype=np.uint8), hap0, rng.integers(0, 4, 3000, dtype=np.uint8)))
+    ctg = sim.codes_to_str(hap0).encode()
+
+    def noisy(codes):
+        seq, _, _ = sim.simulate_read(codes, codes, 0, len(codes), rng)
+        return sim.codes_to_str(seq).encode()
+
+    raw = [
+        noisy(big[1000:9000]),                 # hangs over the contig start by 2000 bases
+        noisy(big[L - 2000:L + 5500]),         # hangs over the contig end
+        noisy(big),                            # longer than the whole contig
+        noisy(sim.revcomp_codes(big[500:8000])),
+        noisy(hap0[5000:12000]).lower(),       # lower case
+        noisy(hap0[15000:22000]).replace(b"A", b"N", 40),   # other symbols are read as 'A'
+        bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), size=5000)),   # junk
+        b"ACGT" * 3, b"",                      # shorter than k, empty
+    ]
+    exp, exp_cig = oracle_lib.align_reads(oracle, ctg, raw)
+    job = _lib.align_job(eng, [ctg], raw)
+    job.run()
+    got = job.summaries()
+    for f in FIELDS:
+        assert np.array_equal(got[f], exp[f]), (f, got[f], exp[f])
+    assert list(got["aligned"]) == [1, 1, 1, 1, 1, 1, 0, 0, 0]
+    assert got["q_start"][0] > 1500 and got["pos"][0] < 20          # clipped prefix, starts at the contig's first bases
+    assert got["ref_end"][1] > L - 20 and got["ref_end"][2] > L - 20
+    assert got["strand"][3] == 1
+    aln, idx = job.alnset(0)
+    for k, r in enumerate(idx):
+        words = np.array([(l << 4) | o for l, o in aln.cigar_of(k)], dtype=np.uint32)
+        assert np.array_equal(words, exp_cig[r]), (k, r)
+    job.close()
+
+
+def test_empty_and_unaligned_only_jobs(eng):
+    from falcon_unzip_amd import _lib
+    ctg = b"ACGTTGCA" * 500
+    job = _lib.align_job(eng, [ctg], [])
+    job.run()
+    assert len(job.summaries()) == 0
+    b = job.to_batch()
+    b.run(_lib.STAGE_ALL)
+    r = b.results()[0]
+    assert len(r.sites) == len(r.preads) == 0
+    b.close()
+    job.close()
+    rng = np.random.Generator(np.random.PCG64(3))
+    junk = [bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), size=3000)) for _ in range(5)]
+    ctg2 = bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), size=50000))
+    job = _lib.align_job(eng, [ctg2], junk)
+    job.run()
+    assert job.summaries()["aligned"].sum() == 0
+    a, idx = job.alnset(0)
+    assert a.n_rec == 0 and a.n_qid == 0
+    b = job.to_batch()
+    b.run(_lib.STAGE_ALL)
+    assert b.counts()["n_sites"] == 0
+    b.close()
+    job.close()
