@@ -17,7 +17,7 @@
 #include "fzp_batch.h"
 
 namespace {
-constexpr int32_t NEGV = -(1 << 28);
+constexpr int32_t NEGV = -(1 << 26);
 constexpr uint64_t EMPTY = ~0ull;
 constexpr int MAX_BINS = 8192;
 
@@ -210,7 +210,7 @@ __device__ __forceinline__ int32_t wave_shl1(int32_t v, int32_t fill) {   // lan
 //      H = max(diag + s, max(A, B) - gap)
 // The diagonal operand is kept pre-shifted: X = H(t-2) moved by (previous move) so that this step needs
 // one more wave_shl only when it moves DOWN (after RIGHT->DOWN lane 63 sees the band edge).
-// Scores are stored biased by 2^28 so that the DPP zero fill (bound_ctrl) of a missing neighbour IS the
+// Scores are stored biased by 2^26 so that the DPP zero fill (bound_ctrl) of a missing neighbour IS the
 // "minus infinity" of the spec; that lets the neighbour shifts ride on the add / max / compare
 // themselves (v_add_u32_dpp, v_max_i32_dpp; G = (A >= B) is read off as max(A,B) == A) instead of separate moves.
 // Trace-back masks per step: D = (H == diag + s), G = (A >= B) ("the gap comes from the same lane");
@@ -218,7 +218,7 @@ __device__ __forceinline__ int32_t wave_shl1(int32_t v, int32_t fill) {   // lan
 // leave as one coalesced 512 B store per 32 steps.  Upcoming read / contig bases sit in 64-bit SGPR
 // windows refilled one window ahead, so no step waits on memory.  The interior of the matrix runs a
 // counted loop with no range checks; the first ~130 and last ~64 steps run the checked variant.
-constexpr int32_t SW_BIAS = 1 << 28;
+constexpr int32_t SW_BIAS = 1 << 26;   // = -NEGV; small enough that (H << 5) | 5 bits fits 32 bits for reads < 2^17 bases
 
 struct BaseStream {          // wave-uniform: lives in SGPRs
     const uint64_t *pk;      // 32 bases per word
@@ -325,9 +325,10 @@ struct BaseStream {          // wave-uniform: lives in SGPRs
 //   qnx: lane L holds q[qpos + 63 - L]  -> the next base to enter at lane 63 sits in lane 63; wave_shr advances
 //   tnx: lane L holds t[tpos + L]       -> the next base to enter at lane 0 sits in lane 0; wave_shl advances
 // Moves are collected in a 32-bit shift register (first step of the block ends up in the highest used bit).
+// `cnt` enters as (steps - 1) and counts down; the best cell of the block is kept as max over (H << 5 | cnt).
 // No DPP source is written fewer than two instructions before it is read (gfx9 DPP hazard).
-__device__ __forceinline__ void sw_block(int32_t &H, int32_t &X, int32_t &qc, int32_t &tc, int32_t &qnx, int32_t &tnx, int32_t &bs, int32_t &bt,
-                                         int32_t &vt, int32_t &accD, int32_t &accG, uint32_t &mv, int32_t &cnt, int32_t &dn, const int32_t gap,
+__device__ __forceinline__ void sw_block(int32_t &H, int32_t &X, int32_t &qc, int32_t &tc, int32_t &qnx, int32_t &tnx, uint32_t &kb,
+                                         int32_t &accD, int32_t &accG, uint32_t &mv, int32_t &cnt, int32_t &dn, const int32_t gap,
                                          const int32_t vmat, const int32_t vmis, const uint64_t m63, const uint64_t m0) {
     int32_t hd, mm, sc, top, bot;
     asm volatile(
@@ -349,16 +350,12 @@ __device__ __forceinline__ void sw_block(int32_t &H, int32_t &X, int32_t &qc, in
         "v_max_i32_e32 %[H], %[hd], %[mm]\n\t"
         "v_cmp_eq_i32_e32 vcc, %[H], %[hd]\n\t"
         "v_addc_co_u32_e32 %[aD], vcc, %[aD], %[aD], vcc\n\t"
-        "s_lshl_b32 %[mv], %[mv], 1\n\t"
-        "s_or_b32 %[mv], %[mv], 1\n\t"
-        "v_cmp_gt_i32_e32 vcc, %[H], %[bs]\n\t"
-        "v_cndmask_b32_e32 %[bs], %[bs], %[H], vcc\n\t"
-        "v_cndmask_b32_e32 %[bt], %[bt], %[vt], vcc\n\t"
-        "v_add_u32_e32 %[vt], 1, %[vt]\n\t"
+        "s_lshl1_add_u32 %[mv], %[mv], 1\n\t"
+        "v_lshl_or_b32 %[hd], %[H], 5, %[cnt]\n\t"          // key = score << 5 | steps left: max -> best score, earliest step
+        "v_max_u32_e32 %[kb], %[kb], %[hd]\n\t"
         "v_readlane_b32 %[top], %[H], 0\n\t"
         "v_readlane_b32 %[bot], %[H], 63\n\t"
-        "s_sub_u32 %[cnt], %[cnt], 1\n\t"
-        "s_cmp_eq_u32 %[cnt], 0\n\t"
+        "s_sub_u32 %[cnt], %[cnt], 1\n\t"                    // borrow out of the last step ends the block
         "s_cbranch_scc1 3f\n\t"
         "s_cmp_gt_i32 %[top], %[bot]\n\t"
         "s_cbranch_scc0 1b\n"
@@ -378,14 +375,11 @@ __device__ __forceinline__ void sw_block(int32_t &H, int32_t &X, int32_t &qc, in
         "v_cmp_eq_i32_e32 vcc, %[H], %[hd]\n\t"
         "v_addc_co_u32_e32 %[aD], vcc, %[aD], %[aD], vcc\n\t"
         "s_lshl_b32 %[mv], %[mv], 1\n\t"
-        "v_cmp_gt_i32_e32 vcc, %[H], %[bs]\n\t"
-        "v_cndmask_b32_e32 %[bs], %[bs], %[H], vcc\n\t"
-        "v_cndmask_b32_e32 %[bt], %[bt], %[vt], vcc\n\t"
-        "v_add_u32_e32 %[vt], 1, %[vt]\n\t"
+        "v_lshl_or_b32 %[hd], %[H], 5, %[cnt]\n\t"
+        "v_max_u32_e32 %[kb], %[kb], %[hd]\n\t"
         "v_readlane_b32 %[top], %[H], 0\n\t"
         "v_readlane_b32 %[bot], %[H], 63\n\t"
         "s_sub_u32 %[cnt], %[cnt], 1\n\t"
-        "s_cmp_eq_u32 %[cnt], 0\n\t"
         "s_cbranch_scc1 3f\n\t"
         "s_cmp_gt_i32 %[top], %[bot]\n\t"
         "s_cbranch_scc1 2b\n\t"
@@ -393,7 +387,7 @@ __device__ __forceinline__ void sw_block(int32_t &H, int32_t &X, int32_t &qc, in
         "3:\n\t"
         "s_cmp_gt_i32 %[top], %[bot]\n\t"
         "s_cselect_b32 %[dn], 0, 1"
-        : [H] "+v"(H), [X] "+v"(X), [qc] "+v"(qc), [tc] "+v"(tc), [qnx] "+v"(qnx), [tnx] "+v"(tnx), [bs] "+v"(bs), [bt] "+v"(bt), [vt] "+v"(vt),
+        : [H] "+v"(H), [X] "+v"(X), [qc] "+v"(qc), [tc] "+v"(tc), [qnx] "+v"(qnx), [tnx] "+v"(tnx), [kb] "+v"(kb),
           [aD] "+v"(accD), [aG] "+v"(accG), [mv] "+s"(mv), [cnt] "+s"(cnt), [dn] "+s"(dn), [hd] "=&v"(hd), [mm] "=&v"(mm), [sc] "=&v"(sc),
           [top] "=&s"(top), [bot] "=&s"(bot)
         : [gap] "s"(gap), [vmat] "v"(vmat), [vmis] "v"(vmis), [m63] "s"(m63), [m0] "s"(m0)
@@ -461,7 +455,6 @@ __global__ void __launch_bounds__(64) k_sw(int64_t first, int64_t count, const u
             int32_t qanchor = qpos_i, tanchor = tpos_i;
             uint32_t qraw = win_load(qpk, qb + qanchor + (63 - lane));
             uint32_t traw = win_load(tpk, tbase + tanchor + lane);
-            int32_t vt = t;
             const int32_t vmat = match, vmis = -mismatch;
             int32_t dn = down ? 1 : 0;
             while (safe > 0) {
@@ -473,12 +466,18 @@ __global__ void __launch_bounds__(64) k_sw(int64_t first, int64_t count, const u
                 qraw = win_load(qpk, qb + qanchor + (63 - lane));
                 traw = win_load(tpk, tbase + tanchor + lane);
                 // (readfirstlane: these are wave-uniform, but hipcc's divergence analysis cannot always prove it)
-                int32_t cnt = __builtin_amdgcn_readfirstlane(min(safe, 32 - (t & 31)));
-                const int32_t n_steps = cnt;
+                const int32_t n_steps = __builtin_amdgcn_readfirstlane(min(safe, 32 - (t & 31)));
+                int32_t cnt = n_steps - 1;                               // counts down; the borrow ends the block
                 safe -= n_steps;
-                uint32_t mv = 0;
+                uint32_t mv = 0, kb = 0;
                 dn = __builtin_amdgcn_readfirstlane(dn);
-                sw_block(H, X, qc, tc, qnx, tnx, bs, bt, vt, accD, accG, mv, cnt, dn, __builtin_amdgcn_readfirstlane(gap), vmat, vmis, 1ull << 63, 1ull);
+                sw_block(H, X, qc, tc, qnx, tnx, kb, accD, accG, mv, cnt, dn, __builtin_amdgcn_readfirstlane(gap), vmat, vmis, 1ull << 63, 1ull);
+                {   // fold the block's best cell into the running best (strictly greater: the earliest step wins ties)
+                    const int32_t hb = (int32_t)(kb >> 5);
+                    const bool upd = hb > bs;
+                    bs = upd ? hb : bs;
+                    bt = upd ? t + (n_steps - 1 - (int32_t)(kb & 31u)) : bt;
+                }
                 const int32_t nd = __popc(mv);                          // DOWN moves of the block (mv holds exactly n_steps bits)
                 i0 += nd;
                 qpos_i += nd; tpos_i += n_steps - nd;

@@ -35,7 +35,7 @@
 #include <string.h>
 
 #define W 64
-#define NEG (-(1 << 28))
+#define NEG (-(1 << 26))
 
 typedef struct {
     int32_t kmer, seed_stride, match, mismatch, gap, min_seed_hits;
