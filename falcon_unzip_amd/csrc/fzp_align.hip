@@ -58,7 +58,14 @@ __device__ __forceinline__ uint32_t rc_key(uint32_t key, int k) {
 }
 __device__ __forceinline__ uint32_t hash_slot(uint32_t key, int bits) { return (key * 0x9E3779B1u) >> (32 - bits); }
 
-// ---- contig k-mer index: smallest start position per k-mer
+// ---- contig k-mer index: canonical k-mers (min of the k-mer and its reverse complement) of every
+// CTG_STRIDE-th contig position -> smallest (position << 1 | "the canonical form is the reverse complement")
+constexpr int CTG_STRIDE = 2;
+__device__ __forceinline__ uint32_t canonical(uint32_t key, int k, uint32_t *is_rc) {
+    uint32_t r = rc_key(key, k);
+    *is_rc = r < key ? 1u : 0u;
+    return r < key ? r : key;
+}
 __global__ void __launch_bounds__(256) k_index(const uint32_t *__restrict__ ctg_pk, const int64_t *__restrict__ ctg_woff, const int64_t *__restrict__ ctg_len,
                                                const int64_t *__restrict__ idx_off, const int32_t *__restrict__ idx_bits, int k, uint64_t *__restrict__ table) {
     const int c = blockIdx.y;
@@ -67,9 +74,10 @@ __global__ void __launch_bounds__(256) k_index(const uint32_t *__restrict__ ctg_
     uint64_t *tab = table + idx_off[c];
     const int bits = idx_bits[c];
     const uint32_t mask = (1u << bits) - 1u;
-    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < nk; p += (int64_t)gridDim.x * 256) {
-        uint32_t key = kmer_at(pk, p, k);
-        uint64_t word = ((uint64_t)key << 32) | (uint64_t)(uint32_t)p;
+    for (int64_t p = ((int64_t)blockIdx.x * 256 + threadIdx.x) * CTG_STRIDE; p < nk; p += (int64_t)gridDim.x * 256 * CTG_STRIDE) {
+        uint32_t orc;
+        uint32_t key = canonical(kmer_at(pk, p, k), k, &orc);
+        uint64_t word = ((uint64_t)key << 32) | (uint64_t)(((uint32_t)p << 1) | orc);
         uint32_t slot = hash_slot(key, bits);
         for (;;) {
             unsigned long long old = atomicCAS((unsigned long long *)&tab[slot], (unsigned long long)EMPTY, (unsigned long long)word);
@@ -79,6 +87,7 @@ __global__ void __launch_bounds__(256) k_index(const uint32_t *__restrict__ ctg_
         }
     }
 }
+// -> (position << 1 | orientation bit) or -1
 __device__ __forceinline__ int32_t index_lookup(const uint64_t *__restrict__ tab, int bits, uint32_t key) {
     const uint32_t mask = (1u << bits) - 1u;
     uint32_t slot = hash_slot(key, bits);
@@ -124,13 +133,18 @@ __global__ void __launch_bounds__(256) k_seed(int64_t first, const uint32_t *__r
     const int bits = idx_bits[c];
     for (int i = threadIdx.x; i < 2 * NB; i += 256) votes[i] = 0;
     __syncthreads();
-    const int64_t ns = (n - k) / stride + 1;   // sampled offsets 0, stride, ...
-    for (int64_t m = threadIdx.x; m < 2 * ns; m += 256) {
-        const int s = m >= ns;
-        const int64_t i = (s ? m - ns : m) * stride;
-        uint32_t key = s ? rc_key(kmer_at(pk, n - k - i, k), k) : kmer_at(pk, i, k);
-        int32_t cp = index_lookup(tab, bits, key);
-        if (cp >= 0) atomicAdd(&votes[s * NB + (int)(((int64_t)cp - i + n) >> shift)], 1u);
+    const int64_t ns = (n - k) / stride + 1;   // sampled FORWARD read offsets 0, stride, ...
+    // one canonical lookup serves both strands: same orientation bit on both sides -> the read matches as
+    // sequenced (strand 0, oriented offset = pf); different -> its reverse complement does (offset n-k-pf)
+    for (int64_t m = threadIdx.x; m < ns; m += 256) {
+        const int64_t pf = m * stride;
+        uint32_t orr;
+        const uint32_t key = canonical(kmer_at(pk, pf, k), k, &orr);
+        const int32_t hit = index_lookup(tab, bits, key);
+        if (hit < 0) continue;
+        const int s = (int)(((uint32_t)hit & 1u) ^ orr);
+        const int64_t cp = (uint32_t)hit >> 1, i = s ? n - k - pf : pf;
+        atomicAdd(&votes[s * NB + (int)((cp - i + n) >> shift)], 1u);
     }
     __syncthreads();
     // best window: max votes[b]+votes[b+1]; ties -> forward strand, lower bin
@@ -147,15 +161,20 @@ __global__ void __launch_bounds__(256) k_seed(int64_t first, const uint32_t *__r
     if ((int32_t)sc < min_hits || sc == 0) { if (threadIdx.x == 0) anc[r] = a; return; }
     const int x = (int)(0xffffffffu - (uint32_t)best);
     const int bs = x >= NB, bb = bs ? x - NB : x;
-    // anchor: the hit with the smallest read offset inside the two winning bins
+    // the hit with the smallest ORIENTED read offset inside the two winning bins fixes the diagonal
     uint64_t mn = 0;   // maximise ~(i<<32|cp) == minimise i, then cp
     for (int64_t m = threadIdx.x; m < ns; m += 256) {
-        const int64_t i = m * stride;
-        uint32_t key = bs ? rc_key(kmer_at(pk, n - k - i, k), k) : kmer_at(pk, i, k);
-        int32_t cp = index_lookup(tab, bits, key);
-        if (cp < 0) continue;
-        int b = (int)(((int64_t)cp - i + n) >> shift);
-        if (b == bb || b == bb + 1) { mn = ~(((uint64_t)i << 32) | (uint32_t)cp); break; }   // offsets ascend per thread
+        // each thread visits its samples in order of increasing oriented offset and stops at its first hit
+        const int64_t pf = (bs ? ns - 1 - m : m) * stride;
+        uint32_t orr;
+        const uint32_t key = canonical(kmer_at(pk, pf, k), k, &orr);
+        const int32_t hit = index_lookup(tab, bits, key);
+        if (hit < 0) continue;
+        const int s = (int)(((uint32_t)hit & 1u) ^ orr);
+        if (s != bs) continue;
+        const int64_t cp = (uint32_t)hit >> 1, i = s ? n - k - pf : pf;
+        const int b = (int)((cp - i + n) >> shift);
+        if (b == bb || b == bb + 1) { mn = ~(((uint64_t)i << 32) | (uint32_t)cp); break; }
     }
     mn = block_max_u64(mn, red);
     if (threadIdx.x == 0) {
@@ -748,7 +767,7 @@ extern "C" int fzp_align_create(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *cons
         j->ctg_words += ((ctg_len[c] + 15) / 16 + 8 + 1) & ~1LL;
         int64_t nk = ctg_len[c] - j->P.kmer + 1;
         int bits = 10;
-        while ((1LL << bits) < 2 * std::max<int64_t>(nk, 1)) bits++;
+        while ((1LL << bits) < 2 * std::max<int64_t>((nk + CTG_STRIDE - 1) / CTG_STRIDE, 1)) bits++;
         j->h_idx_bits.push_back(bits);
         j->h_idx_off.push_back(j->idx_slots);
         j->idx_slots += 1LL << bits;

@@ -10,8 +10,11 @@
  *
  * fzalign v1
  *   bases     A/a C/c G/g T/t -> 0..3, anything else -> 0
- *   seeding   k-mers (k<=16, 2 bits/base, base m of a k-mer at bits 2m) of the contig -> smallest start
- *             position; every `stride`-th k-mer of the read, both orientations, votes for
+ *   seeding   canonical k-mers (k<=16, 2 bits/base, base m of a k-mer at bits 2m; canonical = the smaller of
+ *             the k-mer and its reverse complement) of every 2nd contig position -> smallest start position
+ *             (+ whether the canonical form was the reverse complement); every `stride`-th FORWARD read
+ *             k-mer is looked up once: equal orientation bits -> the read matches as sequenced (strand 0,
+ *             oriented offset i = pf), different -> its reverse complement does (i = n-k-pf); it votes for
  *             bin = (cpos - i + n) >> shift, shift = smallest s>=10 with ((Lc+n)>>s)+2 <= 8192;
  *             best (strand, bin) maximises votes[bin]+votes[bin+1] (ties: forward strand, lower bin);
  *             fewer than min_seed_hits votes -> unaligned.  The hit with the smallest read offset inside
@@ -75,6 +78,13 @@ static uint32_t kmer_at(const uint8_t *codes, int64_t p, int k) {
     return key;
 }
 
+static uint32_t rc_of(uint32_t key, int k) {
+    uint32_t r = 0;
+    for (int m = 0; m < k; m++) r |= (3u - ((key >> (2 * m)) & 3u)) << (2 * (k - 1 - m));
+    return r;
+}
+
+/* -> (position << 1 | orientation bit) of the smallest position holding the canonical key, or -1 */
 static int32_t index_lookup(const ctg_index *ix, uint32_t key) {
     int64_t lo = 0, hi = ix->n;
     while (lo < hi) { int64_t m = (lo + hi) >> 1; if (ix->kp[m].key < key) lo = m + 1; else hi = m; }
@@ -101,13 +111,15 @@ static void align_one(const ctg_index *ix, const uint8_t *fwd, int64_t n, const 
     while ((((Lc + n) >> shift) + 2) > 8192) shift++;
     const int64_t NB = ((Lc + n) >> shift) + 2;
     uint32_t *votes = (uint32_t *)calloc((size_t)(2 * NB), 4);
-    for (int s = 0; s < 2; s++)
-        for (int64_t i = 0; i + k <= n; i += stride) {
-            int32_t cp = index_lookup(ix, kmer_at(ori[s], i, k));
-            if (cp < 0) continue;
-            int64_t d = (int64_t)cp - i + n;
-            votes[s * NB + (d >> shift)]++;
-        }
+    for (int64_t pf = 0; pf + k <= n; pf += stride) {
+        uint32_t kf = kmer_at(ori[0], pf, k), kr = rc_of(kf, k);
+        uint32_t orr = kr < kf ? 1u : 0u;
+        int32_t hit = index_lookup(ix, kr < kf ? kr : kf);
+        if (hit < 0) continue;
+        int s = (int)(((uint32_t)hit & 1u) ^ orr);
+        int64_t cp = (uint32_t)hit >> 1, i = s ? n - k - pf : pf;
+        votes[s * NB + ((cp - i + n) >> shift)]++;
+    }
     uint32_t best = 0; int bs_ = 0; int64_t bb = 0;
     for (int s = 0; s < 2; s++)
         for (int64_t b = 0; b + 1 < NB; b++) {
@@ -118,11 +130,16 @@ static void align_one(const ctg_index *ix, const uint8_t *fwd, int64_t n, const 
     if ((int32_t)best < P->min_seed_hits || best == 0) { free(ori[0]); free(ori[1]); return; }
     const uint8_t *r = ori[bs_];
     int64_t i_a = -1, c_a = -1;
-    for (int64_t i = 0; i + k <= n; i += stride) {
-        int32_t cp = index_lookup(ix, kmer_at(r, i, k));
-        if (cp < 0) continue;
-        int64_t b = ((int64_t)cp - i + n) >> shift;
-        if (b == bb || b == bb + 1) { i_a = i; c_a = cp; break; }
+    for (int64_t pf = 0; pf + k <= n; pf += stride) {      /* smallest oriented offset, then smallest position */
+        uint32_t kf = kmer_at(ori[0], pf, k), kr = rc_of(kf, k);
+        uint32_t orr = kr < kf ? 1u : 0u;
+        int32_t hit = index_lookup(ix, kr < kf ? kr : kf);
+        if (hit < 0) continue;
+        int s = (int)(((uint32_t)hit & 1u) ^ orr);
+        if (s != bs_) continue;
+        int64_t cp = (uint32_t)hit >> 1, i = s ? n - k - pf : pf;
+        int64_t b = (cp - i + n) >> shift;
+        if ((b == bb || b == bb + 1) && (i_a < 0 || i < i_a || (i == i_a && cp < c_a))) { i_a = i; c_a = cp; }
     }
     if (i_a < 0) { free(ori[0]); free(ori[1]); return; }
     {   /* the seed fixes the diagonal; the extension starts at the read's first base on that diagonal
@@ -280,9 +297,17 @@ int orc_align_reads(const uint8_t *ctg_ascii, int64_t ctg_len, int64_t n_reads, 
     uint8_t *codes = (uint8_t *)malloc((size_t)(ctg_len ? ctg_len : 1));
     for (int64_t i = 0; i < ctg_len; i++) codes[i] = (uint8_t)code_of(ctg_ascii[i]);
     ix.codes = codes; ix.len = ctg_len;
-    ix.n = ctg_len >= P->kmer ? ctg_len - P->kmer + 1 : 0;
-    ix.kp = (kp_t *)malloc((size_t)(ix.n ? ix.n : 1) * sizeof(kp_t));
-    for (int64_t p = 0; p < ix.n; p++) { ix.kp[p].key = kmer_at(codes, p, P->kmer); ix.kp[p].pos = (int32_t)p; }
+    {
+        int64_t nk = ctg_len >= P->kmer ? ctg_len - P->kmer + 1 : 0;
+        ix.n = (nk + 1) / 2;                                  /* every 2nd position */
+        ix.kp = (kp_t *)malloc((size_t)(ix.n ? ix.n : 1) * sizeof(kp_t));
+        for (int64_t q = 0; q < ix.n; q++) {
+            int64_t p = 2 * q;
+            uint32_t kf = kmer_at(codes, p, P->kmer), kr = rc_of(kf, P->kmer);
+            ix.kp[q].key = kr < kf ? kr : kf;
+            ix.kp[q].pos = (int32_t)((p << 1) | (kr < kf ? 1 : 0));
+        }
+    }
     qsort(ix.kp, (size_t)ix.n, sizeof(kp_t), cmp_kp);
     u32vec cig = {0};
     cig_off[0] = 0;

