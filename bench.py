@@ -140,6 +140,7 @@ def main():
             torch.cuda.synchronize(dev_index)
 
     stats = {}
+    reads_per_ctg = np.bincount(read_ctg, minlength=args.contigs).tolist()
 
     host_t = {"align_run": 0.0, "to_batch": 0.0, "phase_run": 0.0, "results": 0.0, "allgather": 0.0}
 
@@ -154,12 +155,13 @@ def main():
         recs = []
         n_phased = 0
         qoff = 0
-        res = b.results()
+        res = b.results(copy=False)
         for c in range(args.contigs):
             r = res[c]
-            nq = int((read_ctg == c).sum())   # upper bound; aligned reads get q_ids
+            nq = reads_per_ctg[c]             # upper bound; aligned reads get q_ids
             recs.append(fdist.r2p_from_preads(r.preads, nq, rank * n_reads + qoff, rank * args.contigs + c))
-            n_phased += len(np.unique(r.preads["q_id"]))
+            q = r.preads["q_id"]
+            n_phased += int((q[1:] != q[:-1]).sum()) + (1 if len(q) else 0)     # rows ascend by (q_id, block)
             qoff += nq
         stats.update(b.counts())
         stats["reads_phased"] = n_phased

@@ -200,16 +200,16 @@ def parse_sam(sam: bytes) -> AlnSet:
 
 
 class Result:
-    """Records of one contig (numpy copies)."""
+    """Records of one contig (numpy copies; views of the library's pinned buffer when copy=False)."""
 
-    def __init__(self, rs: ResultStruct):
+    def __init__(self, rs: ResultStruct, copy=True):
         def grab(ptr, n, dt):
             n = int(n)
             if not ptr or n == 0:
                 return np.zeros(0, dtype=dt)
             nbytes = n * np.dtype(dt).itemsize
             raw = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(nbytes,))
-            return raw.view(dt).copy()          # one copy out of the library-owned buffer
+            return raw.view(dt).copy() if copy else raw.view(dt)
         self.sites = grab(rs.sites, rs.n_sites, SITE)
         self.vmap_qid = grab(rs.vmap_qid, rs.n_rows, np.int32)
         self.arows = grab(rs.arows, rs.n_arows, AROW)
@@ -232,12 +232,15 @@ class Batch:
         load().fzp_result_free(C.byref(rs))
         return r
 
-    def results(self):
-        """Every contig's records with ONE device-to-host copy per array -> list of Result (local indices)."""
+    def results(self, copy=True):
+        """Every contig's records with ONE device-to-host copy per array -> list of Result (local indices).
+
+        copy=False hands out views of the context's pinned staging buffer: valid only until the next
+        results() call on this engine (the zero-copy path bench.py uses)."""
         lib = load()
         ra = ResultAllStruct()
         _check(lib.fzp_batch_result_all(self.eng._p, self._p, C.byref(ra)))
-        full = Result(ra.all)
+        full = Result(ra.all, copy=copy)
         n = self.n_ctg
 
         def beg(p):

@@ -542,9 +542,8 @@ __global__ void __launch_bounds__(64) k_sw(int64_t first, int64_t count, const u
 // boundaries).  Diagonal steps are emitted as 'M': the '=' / 'X' split needs the bases and is done on the
 // host where SAM text / alnsets are produced (the phasing stages treat M, = and X alike, phasing.py:81).
 // HBM traffic: the 16 B/step masks are read once (+ chunk re-reads at round edges).
-constexpr int TB_LANE_STRIDE = 1024 + 16 + 8;    // bytes per read: 2 mask chunks + 4 move dwords; +8 staggers LDS banks
+constexpr int TB_LANE_STRIDE = 1024 + 8;         // bytes per read: 2 mask chunks; +8 staggers LDS banks
 constexpr int TB_RPW = 16;                       // reads walked per wave (all 64 lanes stage)
-constexpr int TB_AUX = 1024;                     // aux area: 4 move dwords
 
 __global__ void __launch_bounds__(64) k_traceback(int64_t first, int64_t count, const uint32_t *__restrict__ read_ori, const int64_t *__restrict__ read_woff,
                                                   const int32_t *__restrict__ read_len, const int32_t *__restrict__ read_ctg, const uint32_t *__restrict__ ctg_pk,
@@ -598,47 +597,38 @@ __global__ void __launch_bounds__(64) k_traceback(int64_t first, int64_t count, 
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(((const uint4 *)pl) + (int64_t)cl * 32 + lane),
                                              (__attribute__((address_space(3))) void *)(tb_lds + l * TB_LANE_STRIDE), 16, 0, 0);
         }
-        // move bits of steps [ts-64, ts] (2 words)
-        const int32_t mw0 = max(ts - 64, 0) >> 6;
+        // move bits of steps [hi-63, hi] as one 64-bit shift register: the bit of the current step is always at
+        // the top, the one below it is the previous step's; steps before 0 read as RIGHT (0), like move(-1)
+        const int32_t base = ts - 63;     // ts = the step this round starts at
+        uint64_t mvs = 0;
         if (active) {
-            uint64_t *aux = (uint64_t *)(mine + TB_AUX);
-            aux[0] = mvr[mw0].x; aux[1] = mvr[mw0 + 1].x;
+            if (base < 0) mvs = mvr[0].x << (-base);
+            else {
+                const int32_t w0 = base >> 6, sh = base & 63;
+                const uint64_t lo = mvr[w0].x, hi64 = mvr[w0 + 1].x;
+                mvs = sh ? (lo >> sh) | (hi64 << (64 - sh)) : lo;
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // covers the LDS-DMA loads (hipcc does not track them)
         __syncthreads();
-        // ---- walk inside the window, 32-bit state only
-        const uint32_t *auxm = (const uint32_t *)(mine + TB_AUX);
-        const int32_t md0 = mw0 * 2;                                      // first move dword held
-        const int32_t wlo = cb * 32;
-        uint32_t mvs = 0;                                                 // move bit of step ts at the top
-        if (active) mvs = auxm[(ts >> 5) - md0] << (31 - (ts & 31));
+        // ---- walk inside the window: one LDS read per step, everything else in registers, no inner branches
+        const int32_t lo_lim = max(cb * 32, base + 1);     // a diagonal at `base` would need the move bit of base-1
         if (dbg_mode == 1 && active) { ts -= 48; i -= 33; j -= 32; i0 -= 17; active = ts >= 0 && i >= 0 && j >= 0; }   // ablation: staging cost only
-        while (dbg_mode != 1 && active && ts >= wlo) {
+        while (dbg_mode != 1 && active && ts >= lo_lim) {
             const uint2 m = *(const uint2 *)(mine + ((ts >> 5) - cb) * 512 + (i - i0) * 8);
-            const uint32_t bit = 31 - (ts & 31);
-            const bool dbit = (m.x >> bit) & 1u, gbit = (m.y >> bit) & 1u;
-            const int32_t d1 = (int32_t)(mvs >> 31);
-            // step back over ts (always) ...
-            ts--;
-            mvs <<= 1;
-            if ((ts & 31) == 31 && ts >= 0) mvs = auxm[(ts >> 5) - md0];
-            int32_t op;
-            if (dbit) {
-                op = FZP_OP_M;
-                const int32_t d2 = ts >= 0 ? (int32_t)(mvs >> 31) : 0;   // move(-1) = RIGHT
-                i0 -= d1 + d2;
-                ts--;                                                      // ... and over ts-1 for a diagonal
-                mvs <<= 1;
-                if ((ts & 31) == 31 && ts >= 0) mvs = auxm[(ts >> 5) - md0];
-                i--; j--; ncol++;
-            } else {
-                // G set after a DOWN move, or clear after a RIGHT move: the predecessor is the cell above
-                const bool up = (gbit ? 1 : 0) == d1;
-                op = up ? FZP_OP_I : FZP_OP_D;
-                i0 -= d1;
-                i -= up ? 1 : 0;
-                j -= up ? 0 : 1;
-            }
+            const uint32_t bit = (~(uint32_t)ts) & 31u;                      // 31 - (ts & 31)
+            const uint32_t db = (m.x >> bit) & 1u, gb = (m.y >> bit) & 1u;
+            const uint32_t d1 = (uint32_t)(mvs >> 63), d2 = (uint32_t)(mvs >> 62) & 1u;
+            // not diagonal: G set after a DOWN move, or clear after a RIGHT move -> the predecessor is the cell above
+            const uint32_t up = db ? 0u : (gb == d1 ? 1u : 0u);
+            const uint32_t lf = 1u - (db | up);
+            const int32_t op = db ? FZP_OP_M : (up ? FZP_OP_I : FZP_OP_D);
+            i0 -= (int32_t)(d1 + (db ? d2 : 0u));
+            i -= (int32_t)(db + up);
+            j -= (int32_t)(db + lf);
+            ts -= (int32_t)(1u + db);
+            mvs <<= (1u + db);
+            ncol += (int32_t)db;
             if (op == cur_op) cur_len++;
             else {
                 if (cur_len) { nraw++; if (wpos > 1) reg[--wpos] = (cur_len << 4) | (uint32_t)cur_op; else overflow = true; }
