@@ -615,32 +615,37 @@ __global__ void __launch_bounds__(64) k_traceback(int64_t first, int64_t count, 
         const int32_t lo_lim = max(cb * 32, base + 1);     // a diagonal at `base` would need the move bit of base-1
         if (dbg_mode == 1 && active) { ts -= 48; i -= 33; j -= 32; i0 -= 17; active = ts >= 0 && i >= 0 && j >= 0; }   // ablation: staging cost only
         while (dbg_mode != 1 && active && ts >= lo_lim) {
-            const uint2 m = *(const uint2 *)(mine + ((ts >> 5) - cb) * 512 + (i - i0) * 8);
+            const uint64_t m64 = *(const uint64_t *)(mine + ((ts >> 5) - cb) * 512 + (i - i0) * 8);   // {D word, G word}
             const uint32_t bit = (~(uint32_t)ts) & 31u;                      // 31 - (ts & 31)
-            const uint32_t db = (m.x >> bit) & 1u, gb = (m.y >> bit) & 1u;
+            const uint32_t db = ((uint32_t)m64 >> bit) & 1u, gb = ((uint32_t)(m64 >> 32) >> bit) & 1u;
             const uint32_t d1 = (uint32_t)(mvs >> 63), d2 = (uint32_t)(mvs >> 62) & 1u;
             // not diagonal: G set after a DOWN move, or clear after a RIGHT move -> the predecessor is the cell above
-            const uint32_t up = db ? 0u : (gb == d1 ? 1u : 0u);
-            const uint32_t lf = 1u - (db | up);
-            const int32_t op = db ? FZP_OP_M : (up ? FZP_OP_I : FZP_OP_D);
-            i0 -= (int32_t)(d1 + (db ? d2 : 0u));
+            const uint32_t ndb = db ^ 1u;
+            const uint32_t up = ndb & ((gb ^ d1) ^ 1u);
+            const uint32_t lf = ndb ^ up;
+            const int32_t op = (int32_t)(ndb * (2u - up));                   // M = 0, I = 1, D = 2
+            i0 -= (int32_t)(d1 + (db & d2));
             i -= (int32_t)(db + up);
             j -= (int32_t)(db + lf);
             ts -= (int32_t)(1u + db);
             mvs <<= (1u + db);
             ncol += (int32_t)db;
-            if (op == cur_op) cur_len++;
-            else {
-                if (cur_len) { nraw++; if (wpos > 1) reg[--wpos] = (cur_len << 4) | (uint32_t)cur_op; else overflow = true; }
-                cur_op = op; cur_len = 1;
-            }
-            active = i >= 0 && j >= 0;
+            // run-length encode; a finished run goes out with one predicated store (index clamped, overflow sticky)
+            const bool flush = (op != cur_op) & (cur_len != 0u);
+            const uint32_t word = (cur_len << 4) | (uint32_t)cur_op;
+            wpos -= flush ? 1 : 0;
+            nraw += flush ? 1 : 0;
+            overflow |= flush & (wpos < 1);
+            if (flush) reg[max(wpos, 1)] = word;
+            cur_len = (op == cur_op) ? cur_len + 1u : 1u;
+            cur_op = op;
+            active = (i | j) >= 0;
         }
         __syncthreads();
     }
     if (!have) return;
     if (!(a.aligned && di.best_t >= 0 && di.best_score > 0 && i_end >= 0 && j_end >= 0)) { summ[r] = out; return; }
-    if (cur_len) { nraw++; if (wpos > 1) reg[--wpos] = (cur_len << 4) | (uint32_t)cur_op; else overflow = true; }
+    if (cur_len) { nraw++; wpos--; overflow |= wpos < 1; reg[max(wpos, 1)] = (cur_len << 4) | (uint32_t)cur_op; }
     int32_t q_lead = i + 1, r_lead = j + 1;
     int32_t fa = wpos, fb = cap - 1;                        // forward ops are reg[fa .. fb)
     while (fa < fb && ((reg[fa] & 15u) == FZP_OP_I || (reg[fa] & 15u) == FZP_OP_D)) {
