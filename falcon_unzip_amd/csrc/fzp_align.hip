@@ -776,6 +776,9 @@ extern "C" int fzp_align_create(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *cons
     for (int64_t r = 0; r < n_reads; r++) {
         int64_t n = read_off[r + 1] - read_off[r];
         if (n < 0 || n > 0x3fff0000LL || read_ctg[r] < 0 || read_ctg[r] >= n_ctg) { delete j; fzp_set_error("read %lld: bad length/contig", (long long)r); return FZP_EINVAL; }
+        if (n * (int64_t)j->P.match >= (1LL << 26) - (1 << 20)) {   // biased score << 5 must fit 32 bits (k_sw best-cell key)
+            delete j; fzp_set_error("read %lld: %lld bases x match %d exceeds the score range of the DP kernel", (long long)r, (long long)n, j->P.match); return FZP_EINVAL;
+        }
         j->h_read_len.push_back((int32_t)n);
         j->h_read_ctg.push_back(read_ctg[r]);
         j->read_words += ((n + 15) / 16 + 8 + 1) & ~1LL;

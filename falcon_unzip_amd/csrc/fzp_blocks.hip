@@ -50,13 +50,15 @@ __global__ void __launch_bounds__(256) k_link_emit(const fzp_arow *__restrict__ 
     atomicMin(&fr2[r.site2], l);
 }
 
-__global__ void __launch_bounds__(256) k_left_fill(int64_t n_links, const int32_t *__restrict__ lk_i2, const uint32_t *__restrict__ left_off,
-                                                   uint32_t *__restrict__ left_fill, int32_t *__restrict__ left_lk) {
+__global__ void __launch_bounds__(256) k_left_fill(int64_t n_links, const int32_t *__restrict__ lk_i1, const int32_t *__restrict__ lk_i2,
+                                                   const int32_t *__restrict__ lk_cis, const int32_t *__restrict__ lk_trans, const uint32_t *__restrict__ left_off,
+                                                   uint32_t *__restrict__ left_fill, int32_t *__restrict__ left_lk, int4 *__restrict__ left_pk) {
     int64_t l = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (l >= n_links) return;
     int32_t s = lk_i2[l];
     uint32_t slot = atomicAdd(&left_fill[s], 1u);
     left_lk[left_off[s] + slot] = (int32_t)l;
+    left_pk[left_off[s] + slot] = make_int4(lk_i1[l], lk_cis[l], lk_trans[l], 0);   // the sweep reads one stream per site
 }
 
 // ---- greedy initialisation as a forest (phasing.py:259-309)
@@ -102,8 +104,7 @@ __global__ void __launch_bounds__(256) k_pj_resolve(int64_t n_sites, uint32_t *_
 // ---- refinement sweeps (phasing.py:315-344): one wave per contig
 template <bool USE_LDS>
 __global__ void __launch_bounds__(64) k_sweep(const int64_t *__restrict__ site_begin, const uint32_t *__restrict__ left_n, const uint32_t *__restrict__ left_off,
-                                              const int32_t *__restrict__ left_lk, const int32_t *__restrict__ lk_i1, const int32_t *__restrict__ lk_cis,
-                                              const int32_t *__restrict__ lk_trans, uint8_t *__restrict__ orient) {
+                                              const int4 *__restrict__ left_pk, uint8_t *__restrict__ orient) {
     extern __shared__ uint8_t o_lds[];
     const int lane = lane_id();
     const int c = blockIdx.x;
@@ -117,23 +118,21 @@ __global__ void __launch_bounds__(64) k_sweep(const int64_t *__restrict__ site_b
     }
     for (int iter = 1; iter <= 10; iter++) {
         int updates = 0;
+        uint32_t nl_next = left_n[sb], lo_next = left_off[sb];          // the next site's link range is fetched one site ahead
         for (int64_t p = 0; p < n; p++) {
-            const uint32_t nl = left_n[sb + p];
+            const uint32_t nl = nl_next, lo = lo_next;
+            if (p + 1 < n) { nl_next = left_n[sb + p + 1]; lo_next = left_off[sb + p + 1]; }
             if (nl == 0) continue;
-            const uint32_t lo = left_off[sb + p];
             const uint8_t op = o[p];
             int s1 = 0, s2 = 0;
             for (uint32_t k = lane; k < nl; k += 64) {
-                int32_t l = left_lk[lo + k];
-                int64_t pp = lk_i1[l] - sb;
-                bool same = o[pp] == op;
-                int cis = lk_cis[l], trans = lk_trans[l];
-                s1 += same ? cis : trans;
-                s2 += same ? trans : cis;
+                const int4 e = left_pk[lo + k];                           // (site of the left neighbour, cis, trans)
+                const bool same = o[e.x - sb] == op;
+                s1 += same ? e.y : e.z;
+                s2 += same ? e.z : e.y;
             }
-            s1 = wave_sum_i32(s1);
-            s2 = wave_sum_i32(s2);
-            if (s1 < s2) {               // score1 >= score2 keeps the state (phasing.py:338-342)
+            const int d = wave_sum_i32_dpp(s1 - s2);
+            if (d < 0) {               // score1 >= score2 keeps the state (phasing.py:338-342)
                 if (lane == 0) o[p] = op ^ 1;
                 updates++;
                 if (!USE_LDS) __threadfence_block();
@@ -402,6 +401,7 @@ int fzp_k4_blocks(fzp_ctx *ctx, fzp_batch *b) {
     }
     FZP_TRY(b->lk_i1.alloc((size_t)n_links)); FZP_TRY(b->lk_i2.alloc((size_t)n_links));
     FZP_TRY(b->lk_cis.alloc((size_t)n_links)); FZP_TRY(b->lk_trans.alloc((size_t)n_links)); FZP_TRY(b->left_lk.alloc((size_t)n_links));
+    FZP_TRY(b->left_pk.alloc((size_t)n_links));
     if (n_links > 0) {
         ProfScope ps(ctx, "k4_links");
         hipLaunchKernelGGL(k_link_emit, dim3(grid_for(na, 256, 1 << 30)), dim3(256), 0, st, b->arows.p, na, b->lk_flag.p, n_links, b->lk_i1.p, b->lk_i2.p,
@@ -411,7 +411,8 @@ int fzp_k4_blocks(fzp_ctx *ctx, fzp_batch *b) {
         FZP_TRY(fzp_exclusive_scan_u32(ctx, b->left_n.p, b->left_off.p, (size_t)ns, nullptr));
         FZP_TRY(fzp_exclusive_scan_u32(ctx, b->right_n.p, b->right_off.p, (size_t)ns, nullptr));
         if (n_links > 0)
-            hipLaunchKernelGGL(k_left_fill, dim3(grid_for(n_links, 256, 1 << 30)), dim3(256), 0, st, n_links, b->lk_i2.p, b->left_off.p, b->left_fill.p, b->left_lk.p);
+            hipLaunchKernelGGL(k_left_fill, dim3(grid_for(n_links, 256, 1 << 30)), dim3(256), 0, st, n_links, b->lk_i1.p, b->lk_i2.p, b->lk_cis.p, b->lk_trans.p,
+                               b->left_off.p, b->left_fill.p, b->left_lk.p, b->left_pk.p);
         {
             ProfScope ps(ctx, "k4_greedy");
             hipLaunchKernelGGL(k_pj_init, dim3(grid_for(ns, 256, 1 << 30)), dim3(256), 0, st, ns, b->right_n.p, b->right_off.p, b->fr2.p, b->lk_i1.p, b->lk_i2.p,
@@ -424,10 +425,9 @@ int fzp_k4_blocks(fzp_ctx *ctx, fzp_batch *b) {
             ProfScope ps(ctx, "k4_sweep");
             if (max_sites <= 60 * 1024)
                 hipLaunchKernelGGL(k_sweep<true>, dim3(b->n_ctg), dim3(64), (size_t)((max_sites + 15) & ~15LL), st, b->site_begin.p, b->left_n.p, b->left_off.p,
-                                   b->left_lk.p, b->lk_i1.p, b->lk_cis.p, b->lk_trans.p, b->orient.p);
+                                   b->left_pk.p, b->orient.p);
             else
-                hipLaunchKernelGGL(k_sweep<false>, dim3(b->n_ctg), dim3(64), 0, st, b->site_begin.p, b->left_n.p, b->left_off.p, b->left_lk.p, b->lk_i1.p,
-                                   b->lk_cis.p, b->lk_trans.p, b->orient.p);
+                hipLaunchKernelGGL(k_sweep<false>, dim3(b->n_ctg), dim3(64), 0, st, b->site_begin.p, b->left_n.p, b->left_off.p, b->left_pk.p, b->orient.p);
         }
         {
             ProfScope ps(ctx, "k4_extents");

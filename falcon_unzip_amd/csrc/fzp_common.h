@@ -135,6 +135,14 @@ __device__ __forceinline__ int32_t wave_sum_i32(int32_t v) {
     for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
     return v;
 }
+// wave-uniform sum without LDS traffic: 4 DPP butterfly steps inside each row of 16 lanes, then the 4 rows via SGPRs
+__device__ __forceinline__ int32_t wave_sum_i32_dpp(int32_t v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);    // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);    // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true);   // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, true);   // row_mirror
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
+}
 __device__ __forceinline__ int32_t wave_min_i32(int32_t v) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) v = min(v, __shfl_xor(v, d, 64));
