@@ -283,7 +283,7 @@ bool cigar_next(const char *c, size_t n, size_t *i, long long *adv, int *op) {
     while (k < n) {
         if (c[k] < '0' || c[k] > '9') { k++; continue; }
         long long v = 0;
-        while (k < n && c[k] >= '0' && c[k] <= '9') { v = v * 10 + (c[k] - '0'); k++; }
+        while (k < n && c[k] >= '0' && c[k] <= '9') { if (v < (1LL << 40)) v = v * 10 + (c[k] - '0'); k++; }   // saturates: such lengths are refused below
         if (k < n) {
             int o = op_code(c[k]);
             if (o >= 0) { *adv = v; *op = o; *i = k + 1; return true; }
