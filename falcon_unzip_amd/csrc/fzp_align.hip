@@ -563,8 +563,6 @@ __global__ void __launch_bounds__(64) k_traceback(int64_t first, int64_t count, 
     if (have) { a = anc[r]; di = info[r]; out.cells = (int64_t)di.steps * 64; cig_start[r] = cig_off[r]; }
     bool active = have && a.aligned && di.best_t >= 0 && di.best_score > 0;
     const int32_t n = have ? read_len[r] : 0;
-    const uint64_t *qpk = (const uint64_t *)(read_ori + read_woff[r]);
-    const uint64_t *tpk = (const uint64_t *)(ctg_pk + ctg_woff[have ? read_ctg[r] : 0]);
     const uint2 *tbr = tb + 2 * (tb_off[r] - tb_off[first]);
     const ulonglong2 *mvr = mvw + ((tb_off[r] - tb_off[first]) >> 6) + (have ? wv : 0);
     int32_t ts = active ? di.best_t : -1;
@@ -1086,6 +1084,10 @@ extern "C" int fzp_align_to_batch(fzp_ctx *ctx, fzp_alnjob *j, fzp_batch **out) 
     if (!rc) rc = b->rec_pos.upload(p.rec_pos.data(), p.rec_pos.size(), st);
     if (!rc) rc = b->rec_qid.upload(p.rec_qid.data(), p.rec_qid.size(), st);
     if (!rc) rc = b->rec_ctg.upload(p.rec_ctg.data(), p.rec_ctg.size(), st);
+    b->h_ck_off.assign(p.rec_read.size() + 1, 0);
+    for (size_t r = 0; r < p.rec_read.size(); r++) b->h_ck_off[r + 1] = b->h_ck_off[r] + (p.cig_off[r + 1] - p.cig_off[r] + 63) / 64;
+    if (!rc) rc = b->ck_off.upload(b->h_ck_off.data(), b->h_ck_off.size(), st);
+    if (!rc) rc = b->ctg_rec_begin.upload(b->h_rec_begin.data(), b->h_rec_begin.size(), st);
     if (!rc) rc = b->ctg_goff.upload(b->h_goff.data(), b->h_goff.size(), st);
     if (!rc) rc = b->ctg_qoff.upload(b->h_qid_off.data(), b->h_qid_off.size(), st);
     if (!rc) rc = b->ctg_limit.upload(b->h_limit.data(), b->h_limit.size(), st);

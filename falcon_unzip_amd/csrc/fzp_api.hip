@@ -79,12 +79,15 @@ extern "C" int fzp_batch_create(fzp_ctx *ctx, int32_t n_ctg, const fzp_alnset *c
     }
     cig_off[(size_t)b->n_rec] = c0;
     seq_off[(size_t)b->n_rec] = s0;
+    b->h_ck_off.assign((size_t)b->n_rec + 1, 0);
+    for (int64_t r = 0; r < b->n_rec; r++) b->h_ck_off[(size_t)r + 1] = b->h_ck_off[(size_t)r] + (cig_off[(size_t)r + 1] - cig_off[(size_t)r] + 63) / 64;
     hipStream_t st = ctx->stream;
     int rc = FZP_OK;
     if ((rc = b->rec_pos.upload(rec_pos.data(), rec_pos.size(), st)) || (rc = b->rec_qid.upload(rec_qid.data(), rec_qid.size(), st)) ||
         (rc = b->rec_ctg.upload(rec_ctg.data(), rec_ctg.size(), st)) || (rc = b->cig_off.upload(cig_off.data(), cig_off.size(), st)) ||
         (rc = b->seq_off.upload(seq_off.data(), seq_off.size(), st)) || (rc = b->cigar.upload(cigar.data(), cigar.size(), st)) ||
-        (rc = b->seq.upload(seq.data(), seq.size(), st)) || (rc = b->ref.upload(ref.data(), ref.size(), st)) || (rc = upload_contig_tables(ctx, b))) {
+        (rc = b->seq.upload(seq.data(), seq.size(), st)) || (rc = b->ref.upload(ref.data(), ref.size(), st)) || (rc = upload_contig_tables(ctx, b)) ||
+        (rc = b->ck_off.upload(b->h_ck_off.data(), b->h_ck_off.size(), st)) || (rc = b->ctg_rec_begin.upload(b->h_rec_begin.data(), b->h_rec_begin.size(), st))) {
         delete b;
         return rc;
     }

@@ -31,8 +31,14 @@ struct fzp_batch {
     DevBuf<int64_t> cig_off, seq_off;
     DevBuf<uint32_t> cigar;
     DevBuf<uint8_t> seq, ref;
-    DevBuf<int64_t> ctg_goff, ctg_qoff;
+    DevBuf<int64_t> ctg_goff, ctg_qoff, ctg_rec_begin;
     DevBuf<int32_t> ctg_limit;
+    // CIGAR checkpoints: per record, per 64-op chunk, the (reference, query) offsets at the chunk's start
+    std::vector<int64_t> h_ck_off;     // [n_rec+1] prefix of ceil(n_ops/64)
+    DevBuf<int64_t> ck_off;
+    DevBuf<int32_t> ck_ref, ck_q, rec_span, ctg_maxspan;
+    std::vector<int32_t> h_tile_ctg, h_tile_start;   // K2 position tiles (never span contigs)
+    DevBuf<int32_t> tile_ctg, tile_start;
     // K2
     DevBuf<uint32_t> cnt, oth, site_idx, row_off32;
     DevBuf<uint8_t> flag8;

@@ -6,8 +6,8 @@
 // over ALL accepted records, then call every position p < POS(last accepted record).
 //
 // Roofline: HBM-bound integer scans.  Algorithmic bytes per aligned column: 1 B symbol + the CIGAR
-// word stream (4 B/op); per evaluated position: 16 B counters + 4 B symbol tracker written by
-// atomics and read back once, + 9 B of flag/scan state.  No MFMA: nothing here is GEMM-shaped.
+// word stream (4 B/op); per evaluated position: 16 B counters + 4 B symbol tracker written once
+// from LDS tiles and read back once, + 9 B of flag/scan state.  No MFMA: nothing here is GEMM-shaped.
 #include "fzp_batch.h"
 
 namespace {
@@ -27,13 +27,16 @@ struct RecView {
 // 64 ops are loaded per step, their (ref, query, column) advances prefix-summed across the wave,
 // then the columns of those ops are dealt 64 at a time: lane t finds its op by a 6-step search.
 template <class Visit>
-__device__ __forceinline__ void expand_record(const RecView &v, int64_t r, Visit &&visit) {
+__device__ __forceinline__ void expand_record(const RecView &v, int64_t r, Visit &&visit, int64_t first_chunk = 0, int32_t rp0 = 0, int32_t qp0 = 0,
+                                              int32_t stop_pos = 0x7fffffff) {
+    // first_chunk / rp0 / qp0: resume at a 64-op checkpoint (offsets relative to the record's POS / SEQ start);
+    // stop_pos: no column at or beyond it is wanted (wave-uniform early exit)
     const int lane = lane_id();
-    const int64_t c0 = v.cig_off[r], c1 = v.cig_off[r + 1];
+    const int64_t c0 = v.cig_off[r] + first_chunk * 64, c1 = v.cig_off[r + 1];
     const int64_t sbase = v.seq_off[r];
-    int32_t rp = v.rec_pos[r];
-    int64_t qp = 0;
-    for (int64_t cb = c0; cb < c1; cb += 64) {
+    int32_t rp = v.rec_pos[r] + rp0;
+    int64_t qp = qp0;
+    for (int64_t cb = c0; cb < c1 && rp < stop_pos; cb += 64) {
         uint32_t w = (cb + lane < c1) ? v.cigar[cb + lane] : 0u;
         uint32_t len = w >> 4, t = w & 15u;
         bool isM = (t == FZP_OP_M) | (t == FZP_OP_EQ) | (t == FZP_OP_X);
@@ -63,24 +66,81 @@ __device__ __forceinline__ void expand_record(const RecView &v, int64_t r, Visit
     }
 }
 
-// ---- K2a: column counts ------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_pileup_count(RecView v, uint32_t *__restrict__ cnt, uint32_t *__restrict__ oth) {
+// ---- CIGAR checkpoints: (reference, query) offsets at the start of every 64-op chunk of every record
+__global__ void __launch_bounds__(256) k_cig_ckpt(RecView v, const int64_t *__restrict__ ck_off, int32_t *__restrict__ ck_ref, int32_t *__restrict__ ck_q,
+                                                  int32_t *__restrict__ rec_span, int32_t *__restrict__ ctg_maxspan) {
+    const int lane = lane_id();
     for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < v.n_rec; r += (int64_t)gridDim.x * 4) {
-        const int c = v.rec_ctg[r];
-        const int64_t goff = v.ctg_goff[c];
-        const int32_t lim = v.ctg_limit[c];
-        expand_record(v, r, [&](int32_t pos, uint8_t sym) {
-            if (pos >= lim) return;   // never evaluated by the reference (no final flush)
-            int64_t g = goff + pos;
-            int code = sym_code(sym);
-            if (code < 4) atomicAdd(&cnt[g * 4 + code], 1u);
-            else {
-                // distinct non-ACGT symbols at this position: 0, 1 (value kept) or >=2 (bit 8)
-                uint32_t old = atomicCAS(&oth[g], 0u, (uint32_t)sym);
-                if (old != 0u && (old & 0xffu) != (uint32_t)sym) atomicOr(&oth[g], 0x100u);
-            }
-        });
+        const int64_t c0 = v.cig_off[r], c1 = v.cig_off[r + 1];
+        int64_t ck = ck_off[r];
+        int32_t rp = 0, qp = 0;
+        for (int64_t cb = c0; cb < c1; cb += 64, ck++) {
+            if (lane == 0) { ck_ref[ck] = rp; ck_q[ck] = qp; }
+            uint32_t w = (cb + lane < c1) ? v.cigar[cb + lane] : 0u;
+            uint32_t len = w >> 4, t = w & 15u;
+            bool isM = (t == FZP_OP_M) | (t == FZP_OP_EQ) | (t == FZP_OP_X);
+            rp += wave_sum_i32_dpp((int32_t)((isM | (t == FZP_OP_D)) ? len : 0u));
+            qp += wave_sum_i32_dpp((int32_t)((isM | (t == FZP_OP_I) | (t == FZP_OP_S)) ? len : 0u));
+        }
+        if (lane == 0) { rec_span[r] = rp; atomicMax(&ctg_maxspan[v.rec_ctg[r]], rp); }
     }
+}
+
+// ---- K2a: column counts by position tile.  A workgroup owns TILE consecutive positions of one contig, keeps
+// their A/C/G/T counters (and the non-ACGT tracker) in LDS, lets its waves walk the records that overlap the tile
+// -- each from the CIGAR checkpoint just before the tile -- and writes the counters out once, coalesced.  No global
+// atomics: HBM sees the symbols (1 B/column), the CIGAR words and 20 B per position, about the algorithmic minimum.
+constexpr int PILE_TILE = 2048;
+__global__ void __launch_bounds__(256) k_pileup_tiles(RecView v, const int32_t *__restrict__ tile_ctg, const int32_t *__restrict__ tile_start,
+                                                      const int64_t *__restrict__ ctg_rec_begin, const int32_t *__restrict__ ctg_maxspan,
+                                                      const int32_t *__restrict__ rec_span, const int64_t *__restrict__ ck_off, const int32_t *__restrict__ ck_ref,
+                                                      const int32_t *__restrict__ ck_q, uint32_t *__restrict__ cnt, uint32_t *__restrict__ oth) {
+    __shared__ uint32_t l_cnt[PILE_TILE * 4];
+    __shared__ uint32_t l_oth[PILE_TILE];
+    const int c = tile_ctg[blockIdx.x];
+    const int32_t ts = tile_start[blockIdx.x];
+    const int32_t lim = v.ctg_limit[c];
+    const int32_t te = min(ts + PILE_TILE, lim);
+    for (int i = threadIdx.x; i < PILE_TILE * 4; i += 256) l_cnt[i] = 0;
+    for (int i = threadIdx.x; i < PILE_TILE; i += 256) l_oth[i] = 0;
+    __syncthreads();
+    // records of this contig that can overlap [ts, te): POS < te and POS > ts - max_span
+    const int64_t rb = ctg_rec_begin[c], re = ctg_rec_begin[c + 1];
+    const int32_t ms = ctg_maxspan[c];
+    int64_t lo = rb, hi = re;
+    {   // first record with POS > ts - ms
+        int64_t a = rb, b = re;
+        while (a < b) { int64_t m = (a + b) >> 1; if (v.rec_pos[m] <= ts - ms) a = m + 1; else b = m; }
+        lo = a;
+        a = lo; b = re;   // first record with POS >= te
+        while (a < b) { int64_t m = (a + b) >> 1; if (v.rec_pos[m] < te) a = m + 1; else b = m; }
+        hi = a;
+    }
+    const int wave = threadIdx.x >> 6;
+    for (int64_t r = lo + wave; r < hi; r += 4) {
+        const int32_t pos0 = v.rec_pos[r];
+        if (pos0 + rec_span[r] <= ts) continue;
+        // last checkpoint whose reference offset is <= ts - pos0 (chunk 0 if the record starts inside the tile)
+        const int64_t k0 = ck_off[r], k1 = ck_off[r + 1];
+        int64_t a = 0, b = k1 - k0;   // chunks
+        const int32_t want = ts - pos0;
+        while (b - a > 1) { int64_t m = (a + b) >> 1; if (ck_ref[k0 + m] <= want) a = m; else b = m; }
+        expand_record(v, r, [&](int32_t pos, uint8_t sym) {
+            if (pos < ts || pos >= te) return;
+            const int p = pos - ts;
+            const int code = sym_code(sym);
+            if (code < 4) atomicAdd(&l_cnt[p * 4 + code], 1u);
+            else {
+                uint32_t old = atomicCAS(&l_oth[p], 0u, (uint32_t)sym);
+                if (old != 0u && (old & 0xffu) != (uint32_t)sym) atomicOr(&l_oth[p], 0x100u);
+            }
+        }, a, ck_ref[k0 + a], ck_q[k0 + a], te);
+    }
+    __syncthreads();
+    const int64_t g0 = v.ctg_goff[c] + ts;
+    const int np = te - ts;
+    for (int i = threadIdx.x; i < np * 4; i += 256) cnt[g0 * 4 + i] = l_cnt[i];
+    for (int i = threadIdx.x; i < np; i += 256) oth[g0 + i] = l_oth[i];
 }
 
 struct CallInfo {
@@ -388,12 +448,31 @@ int fzp_k2_het_call(fzp_ctx *ctx, fzp_batch *b) {
     FZP_TRY(b->flag8.alloc((size_t)np));
     FZP_TRY(b->site_idx.alloc((size_t)np));
     FZP_TRY(b->row_off32.alloc((size_t)np));
-    FZP_TRY(b->cnt.zero((size_t)np * 4, st));
-    FZP_TRY(b->oth.zero((size_t)np, st));
     RecView v = rec_view(b);
     if (b->n_rec > 0 && np > 0) {
-        ProfScope ps(ctx, "k2_pileup_count");
-        hipLaunchKernelGGL(k_pileup_count, dim3(grid_for(b->n_rec, 4, 1 << 16)), dim3(256), 0, st, v, b->cnt.p, b->oth.p);
+        // checkpoints + per-contig maximum reference span
+        const int64_t n_ck = b->h_ck_off.empty() ? 0 : b->h_ck_off.back();
+        FZP_TRY(b->ck_ref.alloc((size_t)n_ck)); FZP_TRY(b->ck_q.alloc((size_t)n_ck));
+        FZP_TRY(b->rec_span.alloc((size_t)b->n_rec)); FZP_TRY(b->ctg_maxspan.alloc((size_t)b->n_ctg));
+        FZP_TRY(b->ctg_maxspan.zero((size_t)b->n_ctg, st));
+        {
+            ProfScope ps(ctx, "k2_cig_ckpt");
+            hipLaunchKernelGGL(k_cig_ckpt, dim3(grid_for(b->n_rec, 4, 1 << 16)), dim3(256), 0, st, v, b->ck_off.p, b->ck_ref.p, b->ck_q.p, b->rec_span.p, b->ctg_maxspan.p);
+        }
+        // tiles never span contigs
+        b->h_tile_ctg.clear(); b->h_tile_start.clear();
+        for (int c = 0; c < b->n_ctg; c++)
+            for (int32_t t0 = 0; t0 < b->h_limit[c]; t0 += PILE_TILE) { b->h_tile_ctg.push_back(c); b->h_tile_start.push_back(t0); }
+        FZP_TRY(b->tile_ctg.upload(b->h_tile_ctg.data(), b->h_tile_ctg.size(), st));
+        FZP_TRY(b->tile_start.upload(b->h_tile_start.data(), b->h_tile_start.size(), st));
+        {
+            ProfScope ps(ctx, "k2_pileup_count");
+            hipLaunchKernelGGL(k_pileup_tiles, dim3((unsigned)b->h_tile_ctg.size()), dim3(256), 0, st, v, b->tile_ctg.p, b->tile_start.p, b->ctg_rec_begin.p, b->ctg_maxspan.p,
+                               b->rec_span.p, b->ck_off.p, b->ck_ref.p, b->ck_q.p, b->cnt.p, b->oth.p);
+        }
+    } else if (np > 0) {
+        FZP_TRY(b->cnt.zero((size_t)np * 4, st));
+        FZP_TRY(b->oth.zero((size_t)np, st));
     }
     if (np > 0) {
         ProfScope ps(ctx, "k2_site_flag");
