@@ -229,7 +229,7 @@ __device__ __forceinline__ int32_t wave_shl1(int32_t v, int32_t fill) {   // lan
 //      H = max(diag + s, max(A, B) - gap)
 // The diagonal operand is kept pre-shifted: X = H(t-2) moved by (previous move) so that this step needs
 // one more wave_shl only when it moves DOWN (after RIGHT->DOWN lane 63 sees the band edge).
-// Scores are stored biased by 2^26 so that the DPP zero fill (bound_ctrl) of a missing neighbour IS the
+// Scores are stored biased by 2^24 so that the DPP zero fill (bound_ctrl) of a missing neighbour IS the
 // "minus infinity" of the spec; that lets the neighbour shifts ride on the add / max / compare
 // themselves (v_add_u32_dpp, v_max_i32_dpp; G = (A >= B) is read off as max(A,B) == A) instead of separate moves.
 // Trace-back masks per step: D = (H == diag + s), G = (A >= B) ("the gap comes from the same lane");
@@ -237,7 +237,8 @@ __device__ __forceinline__ int32_t wave_shl1(int32_t v, int32_t fill) {   // lan
 // leave as one coalesced 512 B store per 32 steps.  Upcoming read / contig bases sit in 64-bit SGPR
 // windows refilled one window ahead, so no step waits on memory.  The interior of the matrix runs a
 // counted loop with no range checks; the first ~130 and last ~64 steps run the checked variant.
-constexpr int32_t SW_BIAS = 1 << 26;   // = -NEGV; small enough that (H << 5) | 5 bits fits 32 bits for reads < 2^17 bases
+constexpr int32_t SW_BIAS = 1 << 24;   // stands in for the spec's -2^26 (any value far below every real score gives the same masks on
+                                       // reachable cells); small enough that (H << 6) + 6 bits stays below 2^31 for scores < 2^24
 
 struct BaseStream {          // wave-uniform: lives in SGPRs
     const uint64_t *pk;      // 32 bases per word
@@ -339,39 +340,44 @@ struct BaseStream {          // wave-uniform: lives in SGPRs
     }
 
 // ---- interior block: up to 32 steps with every lane strictly inside the matrix, hand-scheduled.
-// Per step ~20 VALU and 6-7 SALU (the loop is otherwise scalar-issue bound: a SIMD issues one SALU op
-// per 4 cycles).  The bases entering the band come from two per-lane windows instead of scalar streams:
-//   qnx: lane L holds q[qpos + 63 - L]  -> the next base to enter at lane 63 sits in lane 63; wave_shr advances
-//   tnx: lane L holds t[tpos + L]       -> the next base to enter at lane 0 sits in lane 0; wave_shl advances
-// Moves are collected in a 32-bit shift register (first step of the block ends up in the highest used bit).
-// `cnt` enters as (steps - 1) and counts down; the best cell of the block is kept as max over (H << 5 | cnt).
+// The block is VALU-issue bound (a SIMD issues one wave64 VALU op per 4 cycles), so the point is the VALU count
+// per step: 16 (DOWN) / 16 (RIGHT), with 7 SALU ops riding along on the scalar port.
+//   * bases entering the band come from two 64-bit SGPR windows (32 bases each, enough for a whole block):
+//     s_bfe_u64 picks the next one, v_writelane drops it into lane 63 (DOWN) / lane 0 (RIGHT);
+//   * scores run scaled by 64 with the block's step countdown riding in the low bits -- Hs = (H << 6) + cnt --
+//     which makes "best cell of the block, earliest step first" a single v_max per step.  Offsets stay
+//     consistent because every value of a step carries the same one: a gap move costs (gap << 6) + 1 (one step
+//     later), a diagonal move adds (s << 6) - 2 (two steps later); equality tests are unaffected.
+//   * moves are collected in a 32-bit shift register (first step of the block ends up in the highest used bit).
+// `cnt` enters as (steps - 1) and counts down; the borrow ends the block.
 // No DPP source is written fewer than two instructions before it is read (gfx9 DPP hazard).
-__device__ __forceinline__ void sw_block(int32_t &H, int32_t &X, int32_t &qc, int32_t &tc, int32_t &qnx, int32_t &tnx, uint32_t &kb,
-                                         int32_t &accD, int32_t &accG, uint32_t &mv, int32_t &cnt, int32_t &dn, const int32_t gap,
-                                         const int32_t vmat, const int32_t vmis, const uint64_t m63, const uint64_t m0) {
+__device__ __forceinline__ void sw_block(int32_t &H, int32_t &X, int32_t &qc, int32_t &tc, const uint64_t qbits, const uint64_t tbits, int32_t &kb,
+                                         int32_t &accD, int32_t &accG, uint32_t &mv, int32_t &cnt, int32_t &dn, const int32_t gapS,
+                                         const int32_t vmatS, const int32_t vmisS) {
     int32_t hd, mm, sc, top, bot;
+    uint32_t qsel = 2u << 16, tsel = 2u << 16;   // s_bfe_u64 operand: width 2, offset 0
     asm volatile(
         "s_nop 1\n\t"
         "s_cmp_eq_u32 %[dn], 0\n\t"
         "s_cbranch_scc1 2f\n"
         "1:\n\t"   // ------------------------------------------------ DOWN
+        "s_bfe_u64 s[60:61], %[qb], %[qsel]\n\t"
         "v_mov_b32_dpp %[qc], %[qc] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
-        "v_cndmask_b32_e64 %[qc], %[qc], %[qnx], %[m63]\n\t"
-        "v_mov_b32_dpp %[qnx], %[qnx] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_add_u32 %[qsel], %[qsel], 2\n\t"
+        "v_max_i32_dpp %[mm], %[H], %[H] wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "v_writelane_b32 %[qc], s60, 63\n\t"
+        "v_cmp_eq_i32_e32 vcc, %[mm], %[H]\n\t"
+        "v_addc_co_u32_e32 %[aG], vcc, %[aG], %[aG], vcc\n\t"
         "v_cmp_eq_u32_e32 vcc, %[qc], %[tc]\n\t"
         "v_cndmask_b32_e32 %[sc], %[vmis], %[vmat], vcc\n\t"
         "v_add_u32_dpp %[hd], %[X], %[sc] wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-        "v_max_i32_dpp %[mm], %[H], %[H] wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-        "v_cmp_eq_i32_e32 vcc, %[mm], %[H]\n\t"
-        "v_addc_co_u32_e32 %[aG], vcc, %[aG], %[aG], vcc\n\t"
         "v_mov_b32_e32 %[X], %[H]\n\t"
         "v_subrev_u32_e32 %[mm], %[gap], %[mm]\n\t"
         "v_max_i32_e32 %[H], %[hd], %[mm]\n\t"
         "v_cmp_eq_i32_e32 vcc, %[H], %[hd]\n\t"
         "v_addc_co_u32_e32 %[aD], vcc, %[aD], %[aD], vcc\n\t"
         "s_lshl1_add_u32 %[mv], %[mv], 1\n\t"
-        "v_lshl_or_b32 %[hd], %[H], 5, %[cnt]\n\t"          // key = score << 5 | steps left: max -> best score, earliest step
-        "v_max_u32_e32 %[kb], %[kb], %[hd]\n\t"
+        "v_max_i32_e32 %[kb], %[kb], %[H]\n\t"
         "v_readlane_b32 %[top], %[H], 0\n\t"
         "v_readlane_b32 %[bot], %[H], 63\n\t"
         "s_sub_u32 %[cnt], %[cnt], 1\n\t"                    // borrow out of the last step ends the block
@@ -379,23 +385,23 @@ __device__ __forceinline__ void sw_block(int32_t &H, int32_t &X, int32_t &qc, in
         "s_cmp_gt_i32 %[top], %[bot]\n\t"
         "s_cbranch_scc0 1b\n"
         "2:\n\t"   // ------------------------------------------------ RIGHT
+        "s_bfe_u64 s[60:61], %[tb], %[tsel]\n\t"
         "v_mov_b32_dpp %[tc], %[tc] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-        "v_cndmask_b32_e64 %[tc], %[tc], %[tnx], %[m0]\n\t"
-        "v_mov_b32_dpp %[tnx], %[tnx] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_add_u32 %[tsel], %[tsel], 2\n\t"
+        "v_max_i32_dpp %[mm], %[H], %[H] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "v_writelane_b32 %[tc], s60, 0\n\t"
+        "v_cmp_eq_i32_e32 vcc, %[mm], %[H]\n\t"
+        "v_addc_co_u32_e32 %[aG], vcc, %[aG], %[aG], vcc\n\t"
         "v_cmp_eq_u32_e32 vcc, %[qc], %[tc]\n\t"
         "v_cndmask_b32_e32 %[sc], %[vmis], %[vmat], vcc\n\t"
         "v_add_u32_e32 %[hd], %[X], %[sc]\n\t"
-        "v_max_i32_dpp %[mm], %[H], %[H] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-        "v_cmp_eq_i32_e32 vcc, %[mm], %[H]\n\t"
-        "v_addc_co_u32_e32 %[aG], vcc, %[aG], %[aG], vcc\n\t"
         "v_mov_b32_dpp %[X], %[H] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
         "v_subrev_u32_e32 %[mm], %[gap], %[mm]\n\t"
         "v_max_i32_e32 %[H], %[hd], %[mm]\n\t"
         "v_cmp_eq_i32_e32 vcc, %[H], %[hd]\n\t"
         "v_addc_co_u32_e32 %[aD], vcc, %[aD], %[aD], vcc\n\t"
         "s_lshl_b32 %[mv], %[mv], 1\n\t"
-        "v_lshl_or_b32 %[hd], %[H], 5, %[cnt]\n\t"
-        "v_max_u32_e32 %[kb], %[kb], %[hd]\n\t"
+        "v_max_i32_e32 %[kb], %[kb], %[H]\n\t"
         "v_readlane_b32 %[top], %[H], 0\n\t"
         "v_readlane_b32 %[bot], %[H], 63\n\t"
         "s_sub_u32 %[cnt], %[cnt], 1\n\t"
@@ -406,16 +412,21 @@ __device__ __forceinline__ void sw_block(int32_t &H, int32_t &X, int32_t &qc, in
         "3:\n\t"
         "s_cmp_gt_i32 %[top], %[bot]\n\t"
         "s_cselect_b32 %[dn], 0, 1"
-        : [H] "+v"(H), [X] "+v"(X), [qc] "+v"(qc), [tc] "+v"(tc), [qnx] "+v"(qnx), [tnx] "+v"(tnx), [kb] "+v"(kb),
-          [aD] "+v"(accD), [aG] "+v"(accG), [mv] "+s"(mv), [cnt] "+s"(cnt), [dn] "+s"(dn), [hd] "=&v"(hd), [mm] "=&v"(mm), [sc] "=&v"(sc),
-          [top] "=&s"(top), [bot] "=&s"(bot)
-        : [gap] "s"(gap), [vmat] "v"(vmat), [vmis] "v"(vmis), [m63] "s"(m63), [m0] "s"(m0)
-        : "vcc", "scc", "memory");
+        : [H] "+v"(H), [X] "+v"(X), [qc] "+v"(qc), [tc] "+v"(tc), [kb] "+v"(kb), [aD] "+v"(accD), [aG] "+v"(accG), [mv] "+s"(mv), [cnt] "+s"(cnt),
+          [dn] "+s"(dn), [qsel] "+s"(qsel), [tsel] "+s"(tsel), [hd] "=&v"(hd), [mm] "=&v"(mm), [sc] "=&v"(sc), [top] "=&s"(top), [bot] "=&s"(bot)
+        : [gap] "s"(gapS), [vmat] "v"(vmatS), [vmis] "v"(vmisS), [qb] "s"(qbits), [tb] "s"(tbits)
+        : "vcc", "scc", "s60", "s61", "memory");
 }
 
-// raw dword holding the base at packed index idx (extraction happens when the window is put to use)
-__device__ __forceinline__ uint32_t win_load(const uint32_t *__restrict__ pk, int64_t idx) { return pk[idx >> 4]; }
-__device__ __forceinline__ int32_t win_base(uint32_t raw, int64_t idx) { return (int32_t)((raw >> ((idx & 15) * 2)) & 3u); }
+// 32 bases starting at packed index idx, as a wave-uniform 64-bit window (three scalar dword loads)
+__device__ __forceinline__ uint64_t base_window(const uint32_t *__restrict__ pk, int64_t idx) {
+    const int64_t w = idx >> 4;
+    const uint32_t sh = (uint32_t)(idx & 15) * 2u;
+    const uint64_t lo = (uint64_t)pk[w] | ((uint64_t)pk[w + 1] << 32);
+    const uint64_t hi = pk[w + 2];
+    const uint64_t v = sh ? (lo >> sh) | (hi << (64u - sh)) : lo;
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)v);
+}
 
 __global__ void __launch_bounds__(64) k_sw(int64_t first, int64_t count, const uint32_t *__restrict__ read_ori, const int64_t *__restrict__ read_woff,
                                             const int32_t *__restrict__ read_len, const int32_t *__restrict__ read_ctg, const uint32_t *__restrict__ ctg_pk,
@@ -469,33 +480,31 @@ __global__ void __launch_bounds__(64) k_sw(int64_t first, int64_t count, const u
             safe = min(rows_left, cols_left);
         }
         if (safe > 0) {
-            // ---- interior: asm blocks of <= 32 steps; base windows prefetched one block ahead
+            // ---- interior: asm blocks of <= 32 steps
             int32_t qpos_i = i0 + 64, tpos_i = t - i0;                 // next bases to enter at lane 63 / lane 0
-            int32_t qanchor = qpos_i, tanchor = tpos_i;
-            uint32_t qraw = win_load(qpk, qb + qanchor + (63 - lane));
-            uint32_t traw = win_load(tpk, tbase + tanchor + lane);
-            const int32_t vmat = match, vmis = -mismatch;
+            const int32_t vmatS = (match << 6) - 2, vmisS = -(mismatch << 6) - 2;
+            const int32_t gapS = __builtin_amdgcn_readfirstlane((gap << 6) + 1);
             int32_t dn = down ? 1 : 0;
             while (safe > 0) {
-                // put the pending windows to use: extract the bases and rotate by what was consumed since they were anchored
-                const int32_t dq = qpos_i - qanchor, dt = tpos_i - tanchor;
-                int32_t qnx = __builtin_amdgcn_ds_bpermute(((lane - dq) & 63) << 2, win_base(qraw, qb + qanchor + (63 - lane)));
-                int32_t tnx = __builtin_amdgcn_ds_bpermute(((lane + dt) & 63) << 2, win_base(traw, tbase + tanchor + lane));
-                qanchor = qpos_i; tanchor = tpos_i;                     // ... and fetch the windows the block after this one will use
-                qraw = win_load(qpk, qb + qanchor + (63 - lane));
-                traw = win_load(tpk, tbase + tanchor + lane);
                 // (readfirstlane: these are wave-uniform, but hipcc's divergence analysis cannot always prove it)
+                const uint64_t qbits = base_window(qpk, __builtin_amdgcn_readfirstlane((int32_t)qb + qpos_i));
+                const uint64_t tbits = base_window(tpk, tbase + __builtin_amdgcn_readfirstlane(tpos_i));
                 const int32_t n_steps = __builtin_amdgcn_readfirstlane(min(safe, 32 - (t & 31)));
                 int32_t cnt = n_steps - 1;                               // counts down; the borrow ends the block
                 safe -= n_steps;
-                uint32_t mv = 0, kb = 0;
+                uint32_t mv = 0;
+                int32_t kb = 0;
                 dn = __builtin_amdgcn_readfirstlane(dn);
-                sw_block(H, X, qc, tc, qnx, tnx, kb, accD, accG, mv, cnt, dn, __builtin_amdgcn_readfirstlane(gap), vmat, vmis, 1ull << 63, 1ull);
+                H = (H << 6) + n_steps;                                  // previous step: countdown n_steps
+                X = (X << 6) + n_steps + 1;                              // the one before
+                sw_block(H, X, qc, tc, qbits, tbits, kb, accD, accG, mv, cnt, dn, gapS, vmatS, vmisS);
+                H >>= 6;                                                 // the last step's countdown is 0, X's is 1
+                X >>= 6;
                 {   // fold the block's best cell into the running best (strictly greater: the earliest step wins ties)
-                    const int32_t hb = (int32_t)(kb >> 5);
+                    const int32_t hb = kb >> 6;
                     const bool upd = hb > bs;
                     bs = upd ? hb : bs;
-                    bt = upd ? t + (n_steps - 1 - (int32_t)(kb & 31u)) : bt;
+                    bt = upd ? t + (n_steps - 1 - (kb & 63)) : bt;
                 }
                 const int32_t nd = __popc(mv);                          // DOWN moves of the block (mv holds exactly n_steps bits)
                 i0 += nd;

@@ -36,8 +36,9 @@ __device__ __forceinline__ void expand_record(const RecView &v, int64_t r, Visit
     const int64_t sbase = v.seq_off[r];
     int32_t rp = v.rec_pos[r] + rp0;
     int64_t qp = qp0;
+    uint32_t w = (c0 + lane < c1) ? v.cigar[c0 + lane] : 0u;
     for (int64_t cb = c0; cb < c1 && rp < stop_pos; cb += 64) {
-        uint32_t w = (cb + lane < c1) ? v.cigar[cb + lane] : 0u;
+        const uint32_t w_next = (cb + 64 + lane < c1) ? v.cigar[cb + 64 + lane] : 0u;   // in flight while this chunk is dealt
         uint32_t len = w >> 4, t = w & 15u;
         bool isM = (t == FZP_OP_M) | (t == FZP_OP_EQ) | (t == FZP_OP_X);
         uint32_t radv = (isM | (t == FZP_OP_D)) ? len : 0u;
@@ -46,23 +47,39 @@ __device__ __forceinline__ void expand_record(const RecView &v, int64_t r, Visit
         uint32_t rs = wave_incl_scan_u32(radv), qs = wave_incl_scan_u32(qadv), cs = wave_incl_scan_u32(cadv);
         uint32_t ctot = bcast_u32(cs, 63);
         uint32_t rex = rs - radv, qex = qs - qadv, cex = cs - cadv;
-        for (uint32_t base = 0; base < ctot; base += 64) {
-            uint32_t tc = base + lane;
-            int j = 0;   // smallest j with cs[j] > tc
+        // four groups of 64 columns per round so that four symbol loads are in flight per wave
+        for (uint32_t base = 0; base < ctot; base += 256) {
+            int32_t cpos[4];
+            int64_t coff[4];
+            bool cval[4];
 #pragma unroll
-            for (int s = 32; s >= 1; s >>= 1) {
-                uint32_t x = bcast_u32(cs, j + s - 1);
-                if (x <= tc) j += s;
-            }
-            j = min(j, 63);
-            uint32_t jc = bcast_u32(cex, j), jr = bcast_u32(rex, j), jq = bcast_u32(qex, j);
-            if (tc < ctot) {
+            for (int u = 0; u < 4; u++) {
+                cval[u] = false; cpos[u] = 0; coff[u] = 0;
+                if (base + u * 64 >= ctot) continue;   // wave-uniform
+                uint32_t tc = base + u * 64 + lane;
+                int j = 0;   // smallest j with cs[j] > tc
+#pragma unroll
+                for (int s = 32; s >= 1; s >>= 1) {
+                    uint32_t x = bcast_u32(cs, j + s - 1);
+                    if (x <= tc) j += s;
+                }
+                j = min(j, 63);
+                uint32_t jc = bcast_u32(cex, j), jr = bcast_u32(rex, j), jq = bcast_u32(qex, j);
                 uint32_t d = tc - jc;
-                visit((int32_t)(rp + jr + d), v.seq[sbase + qp + jq + d]);
+                cval[u] = tc < ctot;
+                cpos[u] = (int32_t)(rp + jr + d);
+                coff[u] = sbase + qp + jq + d;
             }
+            uint8_t csym[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) csym[u] = cval[u] ? v.seq[coff[u]] : (uint8_t)0;
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (cval[u]) visit(cpos[u], csym[u]);
         }
         rp += (int32_t)bcast_u32(rs, 63);
         qp += bcast_u32(qs, 63);
+        w = w_next;
     }
 }
 
@@ -90,19 +107,19 @@ __global__ void __launch_bounds__(256) k_cig_ckpt(RecView v, const int64_t *__re
 // their A/C/G/T counters (and the non-ACGT tracker) in LDS, lets its waves walk the records that overlap the tile
 // -- each from the CIGAR checkpoint just before the tile -- and writes the counters out once, coalesced.  No global
 // atomics: HBM sees the symbols (1 B/column), the CIGAR words and 20 B per position, about the algorithmic minimum.
-constexpr int PILE_TILE = 2048;
-__global__ void __launch_bounds__(256) k_pileup_tiles(RecView v, const int32_t *__restrict__ tile_ctg, const int32_t *__restrict__ tile_start,
+constexpr int PILE_TILE = 2048, PILE_THREADS = 512;
+__global__ void __launch_bounds__(PILE_THREADS) k_pileup_tiles(RecView v, const int32_t *__restrict__ tile_ctg, const int32_t *__restrict__ tile_start,
                                                       const int64_t *__restrict__ ctg_rec_begin, const int32_t *__restrict__ ctg_maxspan,
                                                       const int32_t *__restrict__ rec_span, const int64_t *__restrict__ ck_off, const int32_t *__restrict__ ck_ref,
                                                       const int32_t *__restrict__ ck_q, uint32_t *__restrict__ cnt, uint32_t *__restrict__ oth) {
-    __shared__ uint32_t l_cnt[PILE_TILE * 4];
+    __shared__ uint32_t l_cnt[4 * PILE_TILE];   // [code][position]: consecutive lanes = consecutive positions = distinct banks
     __shared__ uint32_t l_oth[PILE_TILE];
     const int c = tile_ctg[blockIdx.x];
     const int32_t ts = tile_start[blockIdx.x];
     const int32_t lim = v.ctg_limit[c];
     const int32_t te = min(ts + PILE_TILE, lim);
-    for (int i = threadIdx.x; i < PILE_TILE * 4; i += 256) l_cnt[i] = 0;
-    for (int i = threadIdx.x; i < PILE_TILE; i += 256) l_oth[i] = 0;
+    for (int i = threadIdx.x; i < PILE_TILE * 4; i += PILE_THREADS) l_cnt[i] = 0;
+    for (int i = threadIdx.x; i < PILE_TILE; i += PILE_THREADS) l_oth[i] = 0;
     __syncthreads();
     // records of this contig that can overlap [ts, te): POS < te and POS > ts - max_span
     const int64_t rb = ctg_rec_begin[c], re = ctg_rec_begin[c + 1];
@@ -116,31 +133,47 @@ __global__ void __launch_bounds__(256) k_pileup_tiles(RecView v, const int32_t *
         while (a < b) { int64_t m = (a + b) >> 1; if (v.rec_pos[m] < te) a = m + 1; else b = m; }
         hi = a;
     }
-    const int wave = threadIdx.x >> 6;
-    for (int64_t r = lo + wave; r < hi; r += 4) {
-        const int32_t pos0 = v.rec_pos[r];
-        if (pos0 + rec_span[r] <= ts) continue;
-        // last checkpoint whose reference offset is <= ts - pos0 (chunk 0 if the record starts inside the tile)
-        const int64_t k0 = ck_off[r], k1 = ck_off[r + 1];
-        int64_t a = 0, b = k1 - k0;   // chunks
-        const int32_t want = ts - pos0;
-        while (b - a > 1) { int64_t m = (a + b) >> 1; if (ck_ref[k0 + m] <= want) a = m; else b = m; }
-        expand_record(v, r, [&](int32_t pos, uint8_t sym) {
-            if (pos < ts || pos >= te) return;
-            const int p = pos - ts;
-            const int code = sym_code(sym);
-            if (code < 4) atomicAdd(&l_cnt[p * 4 + code], 1u);
-            else {
-                uint32_t old = atomicCAS(&l_oth[p], 0u, (uint32_t)sym);
-                if (old != 0u && (old & 0xffu) != (uint32_t)sym) atomicOr(&l_oth[p], 0x100u);
+    // candidate lo + i*NW + wave belongs to lane i of this wave: the per-record look-ups (span test, checkpoint
+    // search) run lane-parallel, then the wave walks its records one at a time
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    constexpr int NW = PILE_THREADS / 64;
+    for (int64_t i0 = 0; lo + i0 * NW + wave < hi; i0 += 64) {
+        const int64_t r = lo + (i0 + lane) * NW + wave;
+        bool ok = r < hi;
+        int32_t a = 0, cr = 0, cq = 0;
+        if (ok) {
+            const int32_t pos0 = v.rec_pos[r];
+            ok = pos0 + rec_span[r] > ts;
+            if (ok) {
+                // last checkpoint whose reference offset is <= ts - pos0 (chunk 0 if the record starts inside the tile)
+                const int64_t k0 = ck_off[r];
+                int32_t b = (int32_t)(ck_off[r + 1] - k0);
+                const int32_t want = ts - pos0;
+                while (b - a > 1) { int32_t m = (a + b) >> 1; if (ck_ref[k0 + m] <= want) a = m; else b = m; }
+                cr = ck_ref[k0 + a]; cq = ck_q[k0 + a];
             }
-        }, a, ck_ref[k0 + a], ck_q[k0 + a], te);
+        }
+        const int32_t rel = (int32_t)(r - lo);
+        for (uint64_t todo = __ballot(ok); todo; todo &= todo - 1) {
+            const int l = __builtin_ctzll(todo);
+            const int64_t ru = lo + __builtin_amdgcn_readlane(rel, l);
+            expand_record(v, ru, [&](int32_t pos, uint8_t sym) {
+                if (pos < ts || pos >= te) return;
+                const int p = pos - ts;
+                const int code = sym_code(sym);
+                if (code < 4) atomicAdd(&l_cnt[code * PILE_TILE + p], 1u);
+                else {
+                    uint32_t old = atomicCAS(&l_oth[p], 0u, (uint32_t)sym);
+                    if (old != 0u && (old & 0xffu) != (uint32_t)sym) atomicOr(&l_oth[p], 0x100u);
+                }
+            }, __builtin_amdgcn_readlane(a, l), __builtin_amdgcn_readlane(cr, l), __builtin_amdgcn_readlane(cq, l), te);
+        }
     }
     __syncthreads();
     const int64_t g0 = v.ctg_goff[c] + ts;
     const int np = te - ts;
-    for (int i = threadIdx.x; i < np * 4; i += 256) cnt[g0 * 4 + i] = l_cnt[i];
-    for (int i = threadIdx.x; i < np; i += 256) oth[g0 + i] = l_oth[i];
+    for (int i = threadIdx.x; i < np * 4; i += PILE_THREADS) cnt[g0 * 4 + i] = l_cnt[(i & 3) * PILE_TILE + (i >> 2)];
+    for (int i = threadIdx.x; i < np; i += PILE_THREADS) oth[g0 + i] = l_oth[i];
 }
 
 struct CallInfo {
@@ -467,7 +500,7 @@ int fzp_k2_het_call(fzp_ctx *ctx, fzp_batch *b) {
         FZP_TRY(b->tile_start.upload(b->h_tile_start.data(), b->h_tile_start.size(), st));
         {
             ProfScope ps(ctx, "k2_pileup_count");
-            hipLaunchKernelGGL(k_pileup_tiles, dim3((unsigned)b->h_tile_ctg.size()), dim3(256), 0, st, v, b->tile_ctg.p, b->tile_start.p, b->ctg_rec_begin.p, b->ctg_maxspan.p,
+            hipLaunchKernelGGL(k_pileup_tiles, dim3((unsigned)b->h_tile_ctg.size()), dim3(PILE_THREADS), 0, st, v, b->tile_ctg.p, b->tile_start.p, b->ctg_rec_begin.p, b->ctg_maxspan.p,
                                b->rec_span.p, b->ck_off.p, b->ck_ref.p, b->ck_q.p, b->cnt.p, b->oth.p);
         }
     } else if (np > 0) {
