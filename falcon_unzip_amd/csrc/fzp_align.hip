@@ -232,10 +232,9 @@ __device__ __forceinline__ int32_t wave_shl1(int32_t v, int32_t fill) {   // lan
 // Scores are stored biased by 2^24 so that the DPP zero fill (bound_ctrl) of a missing neighbour IS the
 // "minus infinity" of the spec; that lets the neighbour shifts ride on the add / max / compare
 // themselves (v_add_u32_dpp, v_max_i32_dpp; G = (A >= B) is read off as max(A,B) == A) instead of separate moves.
-// Trace-back masks per step: D = (H == diag + s), G = (A >= B) ("the gap comes from the same lane");
-// each lane shifts its two bits into two 32-bit accumulators (v_cmp -> vcc -> v_addc_co_u32) that
-// leave as one coalesced 512 B store per 32 steps.  Upcoming read / contig bases sit in 64-bit SGPR
-// windows refilled one window ahead, so no step waits on memory.  The interior of the matrix runs a
+// Trace-back masks per step: D = (H == diag + s), G = (A >= B) ("the gap comes from the same lane"), each a
+// 64-bit lane mask; a step's pair is 16 B, stored step-major through the scalar cache.  Upcoming read / contig
+// bases sit in 64-bit SGPR windows, so no step waits on memory.  The interior of the matrix runs a
 // counted loop with no range checks; the first ~130 and last ~64 steps run the checked variant.
 constexpr int32_t SW_BIAS = 1 << 24;   // stands in for the spec's -2^26 (any value far below every real score gives the same masks on
                                        // reachable cells); small enough that (H << 6) + 6 bits stays below 2^31 for scores < 2^24
@@ -260,60 +259,45 @@ struct BaseStream {          // wave-uniform: lives in SGPRs
     }
 };
 
-// DP core of one step.  Inputs: X (pre-shifted diagonal), H (previous step), sc (match / -mismatch);
-// outputs: Hn, and one more bit in each accumulator.  "s_nop 1": the DPP reads below must not follow a
-// VALU write of X / H by fewer than 2 wait states, and hipcc does not see inside the asm.
-#define SW_CORE_DOWN()                                                                                     \
-    asm volatile("s_nop 1\n\t"                                                                             \
-                 "v_add_u32_dpp %[hd], %[X], %[sc] wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t" \
-                 "v_max_i32_dpp %[m], %[H], %[H] wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"   \
-                 "v_cmp_eq_i32 vcc, %[m], %[H]\n\t"                                                        \
-                 "v_addc_co_u32 %[aG], vcc, %[aG], %[aG], vcc\n\t"                                         \
-                 "v_subrev_u32 %[m], %[gap], %[m]\n\t"                                                     \
-                 "v_max_i32 %[Hn], %[hd], %[m]\n\t"                                                        \
-                 "v_cmp_eq_i32 vcc, %[Hn], %[hd]\n\t"                                                      \
-                 "v_addc_co_u32 %[aD], vcc, %[aD], %[aD], vcc"                                             \
-                 : [hd] "=&v"(hd), [m] "=&v"(m), [Hn] "=&v"(Hn), [aG] "+v"(accG), [aD] "+v"(accD)          \
-                 : [X] "v"(X), [H] "v"(H), [sc] "v"(sc), [gap] "s"(gap)                                    \
-                 : "vcc")
-#define SW_CORE_RIGHT()                                                                                    \
-    asm volatile("s_nop 1\n\t"                                                                             \
-                 "v_add_u32 %[hd], %[X], %[sc]\n\t"                                                        \
-                 "v_max_i32_dpp %[m], %[H], %[H] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"   \
-                 "v_cmp_eq_i32 vcc, %[m], %[H]\n\t"                                                        \
-                 "v_addc_co_u32 %[aG], vcc, %[aG], %[aG], vcc\n\t"                                         \
-                 "v_mov_b32_dpp %[Xn], %[H] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"        \
-                 "v_subrev_u32 %[m], %[gap], %[m]\n\t"                                                     \
-                 "v_max_i32 %[Hn], %[hd], %[m]\n\t"                                                        \
-                 "v_cmp_eq_i32 vcc, %[Hn], %[hd]\n\t"                                                      \
-                 "v_addc_co_u32 %[aD], vcc, %[aD], %[aD], vcc"                                             \
-                 : [hd] "=&v"(hd), [m] "=&v"(m), [Hn] "=&v"(Hn), [Xn] "=&v"(Xn), [aG] "+v"(accG), [aD] "+v"(accD) \
-                 : [X] "v"(X), [H] "v"(H), [sc] "v"(sc), [gap] "s"(gap)                                    \
-                 : "vcc")
+// wave-uniform 16-byte store through the scalar data cache (s_store_dwordx4): the per-step trace-back masks
+// leave the DP kernel this way, off the vector path.  The data SGPRs are read at issue, so they may be reused at
+// once; the kernel ends with s_dcache_wb.
+__device__ __forceinline__ void scalar_store16(void *base, uint32_t byte_off, uint64_t lo, uint64_t hi) {
+    const __uint128_t v = ((__uint128_t)hi << 64) | lo;
+    asm volatile("s_store_dwordx4 %[v], %[p], %[o]" ::[v] "s"(v), [p] "s"(base), [o] "s"(byte_off) : "memory");
+}
 
-// one DP step; FULL adds the sentinel / validity handling needed outside the matrix interior
-#define SW_STEP(FULL)                                                                                      \
+// one DP step of the checked variant (first ~130 and last ~64 steps of a read): plain HIP, sentinels and validity
+// handled explicitly.  The masks of the step are wave ballots.
+#define SW_STEP()                                                                                          \
     {                                                                                                      \
         int32_t hd, m, Hn, Xn;                                                                             \
         if (down) {                                                                                        \
             int32_t c = qs.pop();                                                                          \
-            if (FULL) c = qpos < nq ? c : 4;                                                               \
+            c = qpos < nq ? c : 4;                                                                         \
             qpos++;                                                                                        \
             i0++;                                                                                          \
             qc = wave_shl1(qc, c);                                                                         \
             const int32_t sc = qc == tc ? match : -mismatch;                                               \
-            SW_CORE_DOWN();                                                                                \
+            hd = wave_shl1(X, 0) + sc;                                                                     \
+            m = max(H, wave_shl1(H, 0));                                                                   \
             Xn = H;                                                                                        \
         } else {                                                                                           \
             int32_t c = ts.pop();                                                                          \
-            if (FULL) c = tpos < nt ? c : 5;                                                               \
+            c = tpos < nt ? c : 5;                                                                         \
             tpos++;                                                                                        \
             tc = wave_shr1(tc, c);                                                                         \
             const int32_t sc = qc == tc ? match : -mismatch;                                               \
-            SW_CORE_RIGHT();                                                                               \
+            hd = X + sc;                                                                                   \
+            m = max(H, wave_shr1(H, 0));                                                                   \
+            Xn = wave_shr1(H, 0);                                                                          \
         }                                                                                                  \
+        const uint64_t gmask = __ballot(m == H);                                                           \
+        Hn = max(hd, m - gap);                                                                             \
+        const uint64_t dmask = __ballot(Hn == hd);                                                         \
+        scalar_store16(tbr, (uint32_t)__builtin_amdgcn_readfirstlane(t) * 16u, dmask, gmask);              \
         bool upd = Hn > bs;                                                                                \
-        if (FULL) {                                                                                        \
+        {                                                                                                  \
             const int32_t ci = i0 + lane, cj = t - ci;                                                     \
             upd = upd && ci >= 0 && ci < nq && cj >= 0 && cj < nt;                                         \
         }                                                                                                  \
@@ -327,12 +311,9 @@ struct BaseStream {          // wave-uniform: lives in SGPRs
         down = t < 64 ? ((t & 1) == 0) : !(top > bot);                                                     \
     }
 
-// after step t-1 completed a 32-step chunk (or at the very end): masks out, move record every 64 steps
+// after step t-1 completed a 64-step chunk (or at the very end): the chunk's move record
 #define SW_FLUSH(PARTIAL)                                                                                  \
     {                                                                                                      \
-        const int32_t done_ = (t - 1) & 31;                                                                \
-        const int sh_ = (PARTIAL) ? 31 - done_ : 0;   /* step s of a chunk always ends at bit 31 - s */    \
-        tbr[(((t - 1) >> 5) << 6) + lane] = make_uint2((uint32_t)accD << sh_, (uint32_t)accG << sh_);      \
         if ((PARTIAL) || ((t - 1) & 63) == 63) {                                                           \
             if (lane == 0) mvr[(t - 1) >> 6] = make_ulonglong2(mvacc, (uint64_t)(int64_t)(i0 - __popcll(mvacc))); \
             mvacc = 0;                                                                                     \
@@ -341,7 +322,9 @@ struct BaseStream {          // wave-uniform: lives in SGPRs
 
 // ---- interior block: up to 32 steps with every lane strictly inside the matrix, hand-scheduled.
 // The block is VALU-issue bound (a SIMD issues one wave64 VALU op per 4 cycles), so the point is the VALU count
-// per step: 16 (DOWN) / 16 (RIGHT), with 7 SALU ops riding along on the scalar port.
+// per step: 14 (DOWN) / 14 (RIGHT), with 8 SALU and one scalar-memory op riding along on their own ports.
+//   * the two trace-back masks of a step are the 64-bit results of v_cmp_e64 landing in an SGPR quad that
+//     goes out with one s_store_dwordx4 (16 B per step, step-major) -- no per-lane bit accumulators;
 //   * bases entering the band come from two 64-bit SGPR windows (32 bases each, enough for a whole block):
 //     s_bfe_u64 picks the next one, v_writelane drops it into lane 63 (DOWN) / lane 0 (RIGHT);
 //   * scores run scaled by 64 with the block's step countdown riding in the low bits -- Hs = (H << 6) + cnt --
@@ -352,7 +335,7 @@ struct BaseStream {          // wave-uniform: lives in SGPRs
 // `cnt` enters as (steps - 1) and counts down; the borrow ends the block.
 // No DPP source is written fewer than two instructions before it is read (gfx9 DPP hazard).
 __device__ __forceinline__ void sw_block(int32_t &H, int32_t &X, int32_t &qc, int32_t &tc, const uint64_t qbits, const uint64_t tbits, int32_t &kb,
-                                         int32_t &accD, int32_t &accG, uint32_t &mv, int32_t &cnt, int32_t &dn, const int32_t gapS,
+                                         void *tbp, uint32_t &soff, uint32_t &mv, int32_t &cnt, int32_t &dn, const int32_t gapS,
                                          const int32_t vmatS, const int32_t vmisS) {
     int32_t hd, mm, sc, top, bot;
     uint32_t qsel = 2u << 16, tsel = 2u << 16;   // s_bfe_u64 operand: width 2, offset 0
@@ -361,49 +344,49 @@ __device__ __forceinline__ void sw_block(int32_t &H, int32_t &X, int32_t &qc, in
         "s_cmp_eq_u32 %[dn], 0\n\t"
         "s_cbranch_scc1 2f\n"
         "1:\n\t"   // ------------------------------------------------ DOWN
-        "s_bfe_u64 s[60:61], %[qb], %[qsel]\n\t"
+        "s_bfe_u64 s[56:57], %[qb], %[qsel]\n\t"
         "v_mov_b32_dpp %[qc], %[qc] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
         "s_add_u32 %[qsel], %[qsel], 2\n\t"
         "v_max_i32_dpp %[mm], %[H], %[H] wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-        "v_writelane_b32 %[qc], s60, 63\n\t"
-        "v_cmp_eq_i32_e32 vcc, %[mm], %[H]\n\t"
-        "v_addc_co_u32_e32 %[aG], vcc, %[aG], %[aG], vcc\n\t"
+        "v_writelane_b32 %[qc], s56, 63\n\t"
+        "v_cmp_eq_i32_e64 s[62:63], %[mm], %[H]\n\t"
         "v_cmp_eq_u32_e32 vcc, %[qc], %[tc]\n\t"
         "v_cndmask_b32_e32 %[sc], %[vmis], %[vmat], vcc\n\t"
         "v_add_u32_dpp %[hd], %[X], %[sc] wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
         "v_mov_b32_e32 %[X], %[H]\n\t"
         "v_subrev_u32_e32 %[mm], %[gap], %[mm]\n\t"
         "v_max_i32_e32 %[H], %[hd], %[mm]\n\t"
-        "v_cmp_eq_i32_e32 vcc, %[H], %[hd]\n\t"
-        "v_addc_co_u32_e32 %[aD], vcc, %[aD], %[aD], vcc\n\t"
+        "v_cmp_eq_i32_e64 s[60:61], %[H], %[hd]\n\t"
         "s_lshl1_add_u32 %[mv], %[mv], 1\n\t"
         "v_max_i32_e32 %[kb], %[kb], %[H]\n\t"
         "v_readlane_b32 %[top], %[H], 0\n\t"
+        "s_store_dwordx4 s[60:63], %[tbp], %[soff]\n\t"
         "v_readlane_b32 %[bot], %[H], 63\n\t"
+        "s_add_u32 %[soff], %[soff], 16\n\t"
         "s_sub_u32 %[cnt], %[cnt], 1\n\t"                    // borrow out of the last step ends the block
         "s_cbranch_scc1 3f\n\t"
         "s_cmp_gt_i32 %[top], %[bot]\n\t"
         "s_cbranch_scc0 1b\n"
         "2:\n\t"   // ------------------------------------------------ RIGHT
-        "s_bfe_u64 s[60:61], %[tb], %[tsel]\n\t"
+        "s_bfe_u64 s[56:57], %[tb], %[tsel]\n\t"
         "v_mov_b32_dpp %[tc], %[tc] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
         "s_add_u32 %[tsel], %[tsel], 2\n\t"
         "v_max_i32_dpp %[mm], %[H], %[H] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-        "v_writelane_b32 %[tc], s60, 0\n\t"
-        "v_cmp_eq_i32_e32 vcc, %[mm], %[H]\n\t"
-        "v_addc_co_u32_e32 %[aG], vcc, %[aG], %[aG], vcc\n\t"
+        "v_writelane_b32 %[tc], s56, 0\n\t"
+        "v_cmp_eq_i32_e64 s[62:63], %[mm], %[H]\n\t"
         "v_cmp_eq_u32_e32 vcc, %[qc], %[tc]\n\t"
         "v_cndmask_b32_e32 %[sc], %[vmis], %[vmat], vcc\n\t"
         "v_add_u32_e32 %[hd], %[X], %[sc]\n\t"
         "v_mov_b32_dpp %[X], %[H] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
         "v_subrev_u32_e32 %[mm], %[gap], %[mm]\n\t"
         "v_max_i32_e32 %[H], %[hd], %[mm]\n\t"
-        "v_cmp_eq_i32_e32 vcc, %[H], %[hd]\n\t"
-        "v_addc_co_u32_e32 %[aD], vcc, %[aD], %[aD], vcc\n\t"
+        "v_cmp_eq_i32_e64 s[60:61], %[H], %[hd]\n\t"
         "s_lshl_b32 %[mv], %[mv], 1\n\t"
         "v_max_i32_e32 %[kb], %[kb], %[H]\n\t"
         "v_readlane_b32 %[top], %[H], 0\n\t"
+        "s_store_dwordx4 s[60:63], %[tbp], %[soff]\n\t"
         "v_readlane_b32 %[bot], %[H], 63\n\t"
+        "s_add_u32 %[soff], %[soff], 16\n\t"
         "s_sub_u32 %[cnt], %[cnt], 1\n\t"
         "s_cbranch_scc1 3f\n\t"
         "s_cmp_gt_i32 %[top], %[bot]\n\t"
@@ -412,10 +395,10 @@ __device__ __forceinline__ void sw_block(int32_t &H, int32_t &X, int32_t &qc, in
         "3:\n\t"
         "s_cmp_gt_i32 %[top], %[bot]\n\t"
         "s_cselect_b32 %[dn], 0, 1"
-        : [H] "+v"(H), [X] "+v"(X), [qc] "+v"(qc), [tc] "+v"(tc), [kb] "+v"(kb), [aD] "+v"(accD), [aG] "+v"(accG), [mv] "+s"(mv), [cnt] "+s"(cnt),
+        : [H] "+v"(H), [X] "+v"(X), [qc] "+v"(qc), [tc] "+v"(tc), [kb] "+v"(kb), [mv] "+s"(mv), [cnt] "+s"(cnt), [soff] "+s"(soff),
           [dn] "+s"(dn), [qsel] "+s"(qsel), [tsel] "+s"(tsel), [hd] "=&v"(hd), [mm] "=&v"(mm), [sc] "=&v"(sc), [top] "=&s"(top), [bot] "=&s"(bot)
-        : [gap] "s"(gapS), [vmat] "v"(vmatS), [vmis] "v"(vmisS), [qb] "s"(qbits), [tb] "s"(tbits)
-        : "vcc", "scc", "s60", "s61", "memory");
+        : [gap] "s"(gapS), [vmat] "v"(vmatS), [vmis] "v"(vmisS), [qb] "s"(qbits), [tb] "s"(tbits), [tbp] "s"(tbp)
+        : "vcc", "scc", "s56", "s57", "s60", "s61", "s62", "s63", "memory");
 }
 
 // 32 bases starting at packed index idx, as a wave-uniform 64-bit window (three scalar dword loads)
@@ -450,7 +433,7 @@ __global__ void __launch_bounds__(64) k_sw(int64_t first, int64_t count, const u
     const uint32_t *tpk = ctg_pk + ctg_woff[c_idx];
     const int64_t qb = a.i_a, tbase = a.c_a;
     const int32_t max_steps = nq + nt + 2;
-    uint2 *tbr = tb + 2 * (tb_off[r] - tb_off[first]);                 // per 32 steps: 64 lanes x {D bits, G bits}
+    ulonglong2 *tbr = (ulonglong2 *)tb + (tb_off[r] - tb_off[first]);   // per step: {D mask, G mask} over the 64 band lanes
     ulonglong2 *mvr = mvw + ((tb_off[r] - tb_off[first]) >> 6) + wv;   // per 64 steps: {move bits, i0 before the chunk}
 
     // state before step 0 (biased): H(-1), and X = H(-2) as seen after the (virtual) RIGHT move of step -1
@@ -463,7 +446,6 @@ __global__ void __launch_bounds__(64) k_sw(int64_t first, int64_t count, const u
         tc = (j >= 0 && j < nt) ? (int32_t)base_at(tpk, tbase + j) : 5;
     }
     int32_t bs = 0, bt = -1;
-    int32_t accD = 0, accG = 0;
     int32_t i0 = -33, t = 0, qpos = 31, tpos = 33;
     uint64_t mvacc = 0;
     bool down = true;
@@ -497,7 +479,8 @@ __global__ void __launch_bounds__(64) k_sw(int64_t first, int64_t count, const u
                 dn = __builtin_amdgcn_readfirstlane(dn);
                 H = (H << 6) + n_steps;                                  // previous step: countdown n_steps
                 X = (X << 6) + n_steps + 1;                              // the one before
-                sw_block(H, X, qc, tc, qbits, tbits, kb, accD, accG, mv, cnt, dn, gapS, vmatS, vmisS);
+                uint32_t soff = (uint32_t)__builtin_amdgcn_readfirstlane(t) * 16u;
+                sw_block(H, X, qc, tc, qbits, tbits, kb, (void *)tbr, soff, mv, cnt, dn, gapS, vmatS, vmisS);
                 H >>= 6;                                                 // the last step's countdown is 0, X's is 1
                 X >>= 6;
                 {   // fold the block's best cell into the running best (strictly greater: the earliest step wins ties)
@@ -511,7 +494,7 @@ __global__ void __launch_bounds__(64) k_sw(int64_t first, int64_t count, const u
                 qpos_i += nd; tpos_i += n_steps - nd;
                 mvacc |= (uint64_t)(__brev(mv) >> (32 - n_steps)) << (t & 63);   // step s of the block -> bit (t + s) & 63
                 t += n_steps;
-                if ((t & 31) == 0) SW_FLUSH(false)
+                if ((t & 63) == 0) SW_FLUSH(false)
             }
             down = dn != 0;
             // back to the checked variant: scalar base streams resume at the current positions
@@ -519,13 +502,13 @@ __global__ void __launch_bounds__(64) k_sw(int64_t first, int64_t count, const u
             qs.init(qpk, qb + qpos);
             ts.init(tpk, tbase + tpos);
         } else {
-            SW_STEP(true)
-            if ((t & 31) == 0) SW_FLUSH(false)
+            SW_STEP()
+            if ((t & 63) == 0) SW_FLUSH(false)
             if (i0 > nq - 1 || (t - 1) - (i0 + 63) > nt - 1 || t >= max_steps) done = true;
         }
     }
-    if ((t & 31) != 0) SW_FLUSH(true)
-    else if ((t & 63) != 0) { if (lane == 0) mvr[(t - 1) >> 6] = make_ulonglong2(mvacc, (uint64_t)(int64_t)(i0 - __popcll(mvacc))); }
+    if ((t & 63) != 0) SW_FLUSH(true)
+    asm volatile("s_dcache_wb" ::: "memory");   // the masks went through the scalar cache
     // best cell: max score, then earliest step, then lowest lane
     int32_t s_b = bs, t_b = bt < 0 ? 0x7fffffff : bt, l_b = lane;
 #pragma unroll
@@ -538,13 +521,11 @@ __global__ void __launch_bounds__(64) k_sw(int64_t first, int64_t count, const u
 }
 #undef SW_STEP
 #undef SW_FLUSH
-#undef SW_CORE_DOWN
-#undef SW_CORE_RIGHT
 
 // ---- trace-back: one lane per read, masks staged through LDS
 //
 // The walk from the best cell back to the anchor is sequential per read, so a lane owns a read.  Rounds:
-// for each of its reads the wave pulls the two 32-step mask chunks ending at that read's current step
+// for each of its reads the wave pulls the 64 steps of masks ending at that read's current 32-step chunk
 // (1 KB, one LDS-DMA instruction, all in flight together), the lane parks the few words of move bits
 // the next <= 64 steps can touch next to it, and then walks using LDS and registers only (the move bits
 // it consumes sit in a 32-bit shift register, next bit at the top, reloaded from LDS at word
@@ -572,7 +553,7 @@ __global__ void __launch_bounds__(64) k_traceback(int64_t first, int64_t count, 
     if (have) { a = anc[r]; di = info[r]; out.cells = (int64_t)di.steps * 64; cig_start[r] = cig_off[r]; }
     bool active = have && a.aligned && di.best_t >= 0 && di.best_score > 0;
     const int32_t n = have ? read_len[r] : 0;
-    const uint2 *tbr = tb + 2 * (tb_off[r] - tb_off[first]);
+    const ulonglong2 *tbr = (const ulonglong2 *)tb + (tb_off[r] - tb_off[first]);   // per step {D mask, G mask}
     const ulonglong2 *mvr = mvw + ((tb_off[r] - tb_off[first]) >> 6) + (have ? wv : 0);
     int32_t ts = active ? di.best_t : -1;
     int32_t i0 = -33;
@@ -600,7 +581,7 @@ __global__ void __launch_bounds__(64) k_traceback(int64_t first, int64_t count, 
             const int32_t cl = __builtin_amdgcn_readlane(cb, l);
             if (cl < 0) continue;
             const uint64_t pl = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(phi, l) << 32) | (uint32_t)__builtin_amdgcn_readlane(plo, l);
-            // lane x moves 16 B = the {D,G} words of lanes 2x, 2x+1 ... : 64 x 16 B = both chunks, contiguous
+            // lane x moves the 16 B of step cl * 32 + x: 64 x 16 B = the window's 64 steps, contiguous
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(((const uint4 *)pl) + (int64_t)cl * 32 + lane),
                                              (__attribute__((address_space(3))) void *)(tb_lds + l * TB_LANE_STRIDE), 16, 0, 0);
         }
@@ -622,9 +603,10 @@ __global__ void __launch_bounds__(64) k_traceback(int64_t first, int64_t count, 
         const int32_t lo_lim = max(cb * 32, base + 1);     // a diagonal at `base` would need the move bit of base-1
         if (dbg_mode == 1 && active) { ts -= 48; i -= 33; j -= 32; i0 -= 17; active = ts >= 0 && i >= 0 && j >= 0; }   // ablation: staging cost only
         while (dbg_mode != 1 && active && ts >= lo_lim) {
-            const uint64_t m64 = *(const uint64_t *)(mine + ((ts >> 5) - cb) * 512 + (i - i0) * 8);   // {D word, G word}
-            const uint32_t bit = (~(uint32_t)ts) & 31u;                      // 31 - (ts & 31)
-            const uint32_t db = ((uint32_t)m64 >> bit) & 1u, gb = ((uint32_t)(m64 >> 32) >> bit) & 1u;
+            const int32_t k = i - i0;                                        // band lane of the current cell
+            const uint32_t *mw = (const uint32_t *)(mine + (ts - cb * 32) * 16 + ((k >> 5) << 2));   // the dword of each mask holding bit k
+            const uint32_t bit = (uint32_t)k & 31u;
+            const uint32_t db = (mw[0] >> bit) & 1u, gb = (mw[2] >> bit) & 1u;
             const uint32_t d1 = (uint32_t)(mvs >> 63), d2 = (uint32_t)(mvs >> 62) & 1u;
             // not diagonal: G set after a DOWN move, or clear after a RIGHT move -> the predecessor is the cell above
             const uint32_t ndb = db ^ 1u;
