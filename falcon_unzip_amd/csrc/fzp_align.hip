@@ -10,7 +10,8 @@
 //   k_sw          per read, ONE WAVE: adaptive anti-diagonal band, 64 cells = 64 lanes; neighbours
 //                 arrive by DPP wave shifts; per step two 64-bit trace-back masks (v_cmp -> SGPR pair)
 //                 go to HBM; steering compares lanes 0 and 63.  Integer VALU-bound, no MFMA.
-//   k_traceback   per read, one lane: walks the masks back from the best cell, emits CIGAR words
+//   k_tb_walk     per read, one lane: walks the masks back from the best cell, emits a 2-bit op stream
+//   k_tb_cigar    per read, one wave: op stream -> forward run-length CIGAR, clips, summary
 //   k_gather      accepted records -> contiguous CIGAR + ASCII SEQ arrays for the phasing batch
 #include <algorithm>
 
@@ -522,139 +523,232 @@ __global__ void __launch_bounds__(64) k_sw(int64_t first, int64_t count, const u
 #undef SW_STEP
 #undef SW_FLUSH
 
-// ---- trace-back: one lane per read, masks staged through LDS
+// ---- trace-back, part 1: the walk.  One lane per read, 16 reads per wave.
 //
-// The walk from the best cell back to the anchor is sequential per read, so a lane owns a read.  Rounds:
-// for each of its reads the wave pulls the 64 steps of masks ending at that read's current 32-step chunk
-// (1 KB, one LDS-DMA instruction, all in flight together), the lane parks the few words of move bits
-// the next <= 64 steps can touch next to it, and then walks using LDS and registers only (the move bits
-// it consumes sit in a 32-bit shift register, next bit at the top, reloaded from LDS at word
-// boundaries).  Diagonal steps are emitted as 'M': the '=' / 'X' split needs the bases and is done on the
-// host where SAM text / alnsets are produced (the phasing stages treat M, = and X alike, phasing.py:81).
-// HBM traffic: the 16 B/step masks are read once (+ chunk re-reads at round edges).
-constexpr int TB_LANE_STRIDE = 1024 + 8;         // bytes per read: 2 mask chunks; +8 staggers LDS banks
-constexpr int TB_RPW = 16;                       // reads walked per wave (all 64 lanes stage)
+// The walk from the best cell back to the anchor is sequential per read, so a lane owns a read; what the
+// kernel has to do is keep that serial chain short and never make it wait on memory.
+//   * masks are consumed in 64-step chunks (aligned to 64, like the move words).  A step's masks are 128 bits but
+//     the path only ever looks at band lanes near its own, so a staged chunk keeps, per step, the 32 bits of D
+//     and of G starting at band lane `sh` = clamp(k - 16, 0, 32): 8 B/step, 512 B/chunk, one chunk buffer per
+//     read in LDS.  While the lanes walk chunk c, the 16 B/step records of chunk c-1 are already in flight to
+//     registers (one coalesced 1 KB load per read); they are cut down and parked in LDS when the walk of
+//     chunk c is over.  Small LDS footprint = every read of a 40 000-read launch is resident at once.  A lane whose path left the staged 32 lanes (or whose prefetch was for the wrong
+//     chunk) takes a synchronous reload; that is rare.
+//   * per step: one LDS read, ~25 VALU ops, no branches.  The moves come from a 64-bit shift register (top bit =
+//     move of the step before the current one); the operation of the step (M / I / D) goes into a 2-bit stream,
+//     16 ops per word, flushed to HBM when full.  Run-length encoding is k_tb_cigar's job, off this chain.
+// HBM traffic: the 16 B/step masks are read once.
+constexpr int TBW_STRIDE = 512 + 8;              // bytes per read: one 64-step chunk of {D bits, G bits}; +8 staggers LDS banks
+constexpr int TBW_RPW = 16;                      // reads walked per wave
 
-__global__ void __launch_bounds__(64) k_traceback(int64_t first, int64_t count, const uint32_t *__restrict__ read_ori, const int64_t *__restrict__ read_woff,
-                                                  const int32_t *__restrict__ read_len, const int32_t *__restrict__ read_ctg, const uint32_t *__restrict__ ctg_pk,
-                                                  const int64_t *__restrict__ ctg_woff, const Anchor *__restrict__ anc, const DpInfo *__restrict__ info,
-                                                  const int64_t *__restrict__ tb_off, const uint2 *__restrict__ tb, const ulonglong2 *__restrict__ mvw,
-                                                  const int64_t *__restrict__ cig_off, uint32_t *__restrict__ cig, int64_t *__restrict__ cig_start,
-                                                  fzp_aln_summary *__restrict__ summ, int dbg_mode) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t tb_lds[];
+struct WalkOut { int32_t ok, i, ts, i_end, j_end, ncol, n_ops, pad_; };   // (i, ts - i) = the cell before the alignment's first
+
+__global__ void __launch_bounds__(64) k_tb_walk(int64_t first, int64_t count, const Anchor *__restrict__ anc, const DpInfo *__restrict__ info,
+                                                const int64_t *__restrict__ tb_off, const uint2 *__restrict__ tb, const ulonglong2 *__restrict__ mvw,
+                                                uint32_t *__restrict__ raw, WalkOut *__restrict__ wout) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[TBW_RPW * TBW_STRIDE];
     const int lane = threadIdx.x;
-    const int64_t wv = (int64_t)blockIdx.x * TB_RPW + lane;
-    const bool have = lane < TB_RPW && wv < count;
+    const int64_t wv = (int64_t)blockIdx.x * TBW_RPW + lane;
+    const bool have = lane < TBW_RPW && wv < count;
     const int64_t r = first + (have ? wv : 0);
-    fzp_aln_summary out;
-    memset(&out, 0, sizeof out);
     Anchor a = {0, 0, 0, 0};
     DpInfo di = {0, -1, 0, NEGV};
-    if (have) { a = anc[r]; di = info[r]; out.cells = (int64_t)di.steps * 64; cig_start[r] = cig_off[r]; }
+    if (have) { a = anc[r]; di = info[r]; }
     bool active = have && a.aligned && di.best_t >= 0 && di.best_score > 0;
-    const int32_t n = have ? read_len[r] : 0;
-    const ulonglong2 *tbr = (const ulonglong2 *)tb + (tb_off[r] - tb_off[first]);   // per step {D mask, G mask}
-    const ulonglong2 *mvr = mvw + ((tb_off[r] - tb_off[first]) >> 6) + (have ? wv : 0);
+    const int64_t soff = tb_off[r] - tb_off[first];                           // steps before this read in the chunk of reads
+    const ulonglong2 *tbr = (const ulonglong2 *)tb + soff;                    // per step {D mask, G mask}
+    const ulonglong2 *mvr = mvw + (soff >> 6) + (have ? wv : 0);              // per 64 steps {move bits, i0 before them}
+    uint32_t *rawp = raw + (soff >> 4);                                       // 16 ops per word
     int32_t ts = active ? di.best_t : -1;
-    int32_t i0 = -33;
+    int32_t k = di.best_lane, i = -1;
+    uint64_t w_prev = 0, pref_word = 0;      // move words: (after the first accept) w_cur = chunk of ts, w_prev = the one below
+    uint64_t w_cur = 0;
     if (active) {   // i0 at the best step = i0 before its 64-step chunk + DOWN moves up to and including it
         const ulonglong2 mw = mvr[ts >> 6];
-        i0 = (int32_t)(int64_t)mw.y + __popcll(mw.x & ((2ull << (ts & 63)) - 1ull));
+        i = (int32_t)(int64_t)mw.y + __popcll(mw.x & ((2ull << (ts & 63)) - 1ull)) + k;
+        w_prev = mw.x;
+        pref_word = (ts >> 6) > 0 ? mvr[(ts >> 6) - 1].x : 0ull;
     }
-    int32_t i = i0 + di.best_lane, j = ts - i;
-    const int32_t i_end = i, j_end = j;
-    const int32_t cap = have ? (int32_t)(cig_off[r + 1] - cig_off[r]) : 2;   // n + 18 words
-    uint32_t *reg = cig + (have ? cig_off[r] : 0);
-    int32_t wpos = cap - 1;                                                   // last slot is kept for the trailing soft clip
-    int32_t nraw = 0;
-    int32_t cur_op = -1;
-    uint32_t cur_len = 0;
-    int32_t ncol = 0;
-    bool overflow = false;
-    active = active && i >= 0 && j >= 0;
-    uint8_t *mine = tb_lds + lane * TB_LANE_STRIDE;
+    const int32_t i_end = i, j_end = ts - i;
+    active = active && i >= 0 && ts - i >= 0;
+    const bool walked = active;
+    int32_t ncol = 0, n_ops = 0, nw = 0;
+    uint32_t rawacc = 0, nb = 0;
     const int32_t plo = (int32_t)(uint32_t)(uint64_t)tbr, phi = (int32_t)((uint64_t)tbr >> 32);
-    while (__any(active)) {
-        // ---- stage: chunks cb, cb+1 of every active read, cb = max((ts >> 5) - 1, 0)
-        const int32_t cb = active ? max((ts >> 5) - 1, 0) : -1;
-        for (int l = 0; l < TB_RPW; l++) {
-            const int32_t cl = __builtin_amdgcn_readlane(cb, l);
-            if (cl < 0) continue;
-            const uint64_t pl = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(phi, l) << 32) | (uint32_t)__builtin_amdgcn_readlane(plo, l);
-            // lane x moves the 16 B of step cl * 32 + x: 64 x 16 B = the window's 64 steps, contiguous
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(((const uint4 *)pl) + (int64_t)cl * 32 + lane),
-                                             (__attribute__((address_space(3))) void *)(tb_lds + l * TB_LANE_STRIDE), 16, 0, 0);
-        }
-        // move bits of steps [hi-63, hi] as one 64-bit shift register: the bit of the current step is always at
-        // the top, the one below it is the previous step's; steps before 0 read as RIGHT (0), like move(-1)
-        const int32_t base = ts - 63;     // ts = the step this round starts at
-        uint64_t mvs = 0;
-        if (active) {
-            if (base < 0) mvs = mvr[0].x << (-base);
-            else {
-                const int32_t w0 = base >> 6, sh = base & 63;
-                const uint64_t lo = mvr[w0].x, hi64 = mvr[w0 + 1].x;
-                mvs = sh ? (lo >> sh) | (hi64 << (64 - sh)) : lo;
+    uint8_t *mine = lds + lane * TBW_STRIDE;
+    int32_t cur_chunk = -2, sh_cur = 0;
+    int32_t pref_chunk = active ? ts >> 6 : -1, pref_sh = min(max(k - 16, 0), 32);
+    uint4 pf[TBW_RPW];
+#pragma unroll
+    for (int l = 0; l < TBW_RPW; l++) pf[l] = make_uint4(0, 0, 0, 0);
+    // records of chunk pref_chunk of every read -> registers (lane x takes step x of the chunk)
+#define TBW_ISSUE()                                                                                                      \
+    _Pragma("unroll") for (int l = 0; l < TBW_RPW; l++) {                                                                \
+        const int32_t cl = __builtin_amdgcn_readlane(pref_chunk, l);                                                     \
+        if (cl >= 0) {                                                                                                   \
+            const uint64_t pl = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(phi, l) << 32) | (uint32_t)__builtin_amdgcn_readlane(plo, l); \
+            pf[l] = ((const uint4 *)pl)[(int64_t)cl * 64 + lane];                                                        \
+        }                                                                                                                \
+    }
+    TBW_ISSUE()
+    for (;;) {
+        if (!__any(active)) break;
+        const int32_t need = active ? ts >> 6 : -1;
+        // park the prefetched chunk: 32 lanes' worth of D and G per step (the walk is done with the old contents)
+        {
+#pragma unroll
+            for (int l = 0; l < TBW_RPW; l++) {
+                const int32_t cl = __builtin_amdgcn_readlane(pref_chunk, l);
+                if (cl >= 0) {
+                    const int32_t sh = __builtin_amdgcn_readlane(pref_sh, l);
+                    const uint64_t D = ((uint64_t)pf[l].y << 32) | pf[l].x, G = ((uint64_t)pf[l].w << 32) | pf[l].z;
+                    *(uint2 *)(lds + l * TBW_STRIDE + lane * 8) = make_uint2((uint32_t)(D >> sh), (uint32_t)(G >> sh));
+                }
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // covers the LDS-DMA loads (hipcc does not track them)
+        const bool ok = need < 0 || (need == pref_chunk && (uint32_t)(k - pref_sh) < 32u);
+        if (active && ok) { cur_chunk = pref_chunk; sh_cur = pref_sh; w_cur = w_prev; w_prev = pref_word; }
+        const uint64_t redo = __ballot(active && !ok);
+        if (redo) {   // rare: the path left the staged lanes, or stalled inside its chunk
+            if (active && !ok) {
+                cur_chunk = need; sh_cur = min(max(k - 16, 0), 32);
+                w_cur = mvr[need].x; w_prev = need > 0 ? mvr[need - 1].x : 0ull;
+            }
+            for (int l = 0; l < TBW_RPW; l++) {
+                if (!((redo >> l) & 1ull)) continue;
+                const uint64_t pl = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(phi, l) << 32) | (uint32_t)__builtin_amdgcn_readlane(plo, l);
+                const int32_t cl = __builtin_amdgcn_readlane(cur_chunk, l), sh = __builtin_amdgcn_readlane(sh_cur, l);
+                const uint4 v = ((const uint4 *)pl)[(int64_t)cl * 64 + lane];
+                const uint64_t D = ((uint64_t)v.y << 32) | v.x, G = ((uint64_t)v.w << 32) | v.z;
+                *(uint2 *)(lds + l * TBW_STRIDE + lane * 8) = make_uint2((uint32_t)(D >> sh), (uint32_t)(G >> sh));
+            }
+        }
+        // next prefetch: the chunk below, centred on where the path is now
+        pref_chunk = (active && cur_chunk > 0) ? cur_chunk - 1 : -1;
+        pref_sh = min(max(k - 16, 0), 32);
+        if (pref_chunk > 0) pref_word = mvr[pref_chunk - 1].x; else pref_word = 0ull;
+        TBW_ISSUE()
         __syncthreads();
-        // ---- walk inside the window: one LDS read per step, everything else in registers, no inner branches
-        const int32_t lo_lim = max(cb * 32, base + 1);     // a diagonal at `base` would need the move bit of base-1
-        if (dbg_mode == 1 && active) { ts -= 48; i -= 33; j -= 32; i0 -= 17; active = ts >= 0 && i >= 0 && j >= 0; }   // ablation: staging cost only
-        while (dbg_mode != 1 && active && ts >= lo_lim) {
-            const int32_t k = i - i0;                                        // band lane of the current cell
-            const uint32_t *mw = (const uint32_t *)(mine + (ts - cb * 32) * 16 + ((k >> 5) << 2));   // the dword of each mask holding bit k
-            const uint32_t bit = (uint32_t)k & 31u;
-            const uint32_t db = (mw[0] >> bit) & 1u, gb = (mw[2] >> bit) & 1u;
-            const uint32_t d1 = (uint32_t)(mvs >> 63), d2 = (uint32_t)(mvs >> 62) & 1u;
+        // ---- walk inside the chunk
+        uint32_t d1 = 0;
+        uint64_t P = 0;                    // moves of steps ts-1, ts-2, ... from the top bit down (steps before 0 read as RIGHT)
+        if (active) {
+            const int32_t s_ = ts & 63;
+            d1 = (uint32_t)(w_cur >> s_) & 1u;
+            P = s_ ? (w_cur << (64 - s_)) | (w_prev >> s_) : w_prev;
+        }
+        const uint8_t *win = mine;
+        while (active && (ts >> 6) == cur_chunk && (uint32_t)(k - sh_cur) < 32u) {
+            const uint2 m = *(const uint2 *)(win + (ts & 63) * 8);
+            const uint32_t kk = (uint32_t)(k - sh_cur);
+            const uint32_t db = (m.x >> kk) & 1u, gb = (m.y >> kk) & 1u;
+            const uint32_t hi = (uint32_t)(P >> 32);
+            const uint32_t d2 = hi >> 31, d3 = (hi >> 30) & 1u;
             // not diagonal: G set after a DOWN move, or clear after a RIGHT move -> the predecessor is the cell above
             const uint32_t ndb = db ^ 1u;
             const uint32_t up = ndb & ((gb ^ d1) ^ 1u);
-            const uint32_t lf = ndb ^ up;
-            const int32_t op = (int32_t)(ndb * (2u - up));                   // M = 0, I = 1, D = 2
-            i0 -= (int32_t)(d1 + (db & d2));
+            const uint32_t op = 2u * ndb - up;                                // M = 0, I = 1, D = 2
+            k += (int32_t)(d1 + (db & d2)) - (int32_t)(db + up);
             i -= (int32_t)(db + up);
-            j -= (int32_t)(db + lf);
             ts -= (int32_t)(1u + db);
-            mvs <<= (1u + db);
+            d1 = db ? d3 : d2;
+            P <<= (1u + db);
             ncol += (int32_t)db;
-            // run-length encode; a finished run goes out with one predicated store (index clamped, overflow sticky)
-            const bool flush = (op != cur_op) & (cur_len != 0u);
-            const uint32_t word = (cur_len << 4) | (uint32_t)cur_op;
-            wpos -= flush ? 1 : 0;
-            nraw += flush ? 1 : 0;
-            overflow |= flush & (wpos < 1);
-            if (flush) reg[max(wpos, 1)] = word;
-            cur_len = (op == cur_op) ? cur_len + 1u : 1u;
-            cur_op = op;
-            active = (i | j) >= 0;
+            n_ops++;
+            rawacc |= op << nb;
+            nb += 2u;
+            if (nb == 32u) { rawp[nw++] = rawacc; rawacc = 0u; nb = 0u; }
+            active = (i | (ts - i)) >= 0;
         }
         __syncthreads();
     }
+#undef TBW_ISSUE
     if (!have) return;
-    if (!(a.aligned && di.best_t >= 0 && di.best_score > 0 && i_end >= 0 && j_end >= 0)) { summ[r] = out; return; }
-    if (cur_len) { nraw++; wpos--; overflow |= wpos < 1; reg[max(wpos, 1)] = (cur_len << 4) | (uint32_t)cur_op; }
-    int32_t q_lead = i + 1, r_lead = j + 1;
-    int32_t fa = wpos, fb = cap - 1;                        // forward ops are reg[fa .. fb)
-    while (fa < fb && ((reg[fa] & 15u) == FZP_OP_I || (reg[fa] & 15u) == FZP_OP_D)) {
-        if ((reg[fa] & 15u) == FZP_OP_I) q_lead += reg[fa] >> 4; else r_lead += reg[fa] >> 4;
-        fa++;
+    if (nb) rawp[nw] = rawacc;
+    WalkOut o;
+    o.ok = walked ? 1 : 0; o.i = i; o.ts = ts; o.i_end = i_end; o.j_end = j_end; o.ncol = ncol; o.n_ops = n_ops; o.pad_ = 0;
+    wout[r] = o;
+}
+
+// ---- trace-back, part 2: one wave per read turns the walk's op stream (alignment end first) into the forward,
+// run-length encoded CIGAR (M/I/D; '=' / 'X' need the bases and are split on the host where SAM text / alnsets are
+// produced -- the phasing stages treat M, = and X alike, phasing.py:81), trims gap runs at both ends, adds the
+// soft clips and fills the read's summary.
+__global__ void __launch_bounds__(64) k_tb_cigar(int64_t first, int64_t count, const int32_t *__restrict__ read_len, const Anchor *__restrict__ anc,
+                                                 const DpInfo *__restrict__ info, const int64_t *__restrict__ tb_off, const uint32_t *__restrict__ raw,
+                                                 const WalkOut *__restrict__ wout, const int64_t *__restrict__ cig_off, uint32_t *__restrict__ cig,
+                                                 int64_t *__restrict__ cig_start, fzp_aln_summary *__restrict__ summ) {
+    const int lane = lane_id();
+    const int64_t wv = blockIdx.x;
+    if (wv >= count) return;
+    const int64_t r = first + wv;
+    const Anchor a = anc[r];
+    const DpInfo di = info[r];
+    const WalkOut w = wout[r];
+    const int32_t n = read_len[r];
+    fzp_aln_summary out;
+    memset(&out, 0, sizeof out);
+    out.cells = (int64_t)di.steps * 64;
+    if (lane == 0) cig_start[r] = cig_off[r];
+    if (!w.ok) { if (lane == 0) summ[r] = out; return; }
+    const uint32_t *rw = raw + ((tb_off[r] - tb_off[first]) >> 4);
+    uint32_t *reg = cig + cig_off[r];                     // capacity n + 18 words: [0] leading clip, runs from [1]
+    const int32_t L = w.n_ops;
+    auto op_at = [&](int32_t f) -> uint32_t {             // forward position f = L-1-f in the stream
+        const int32_t p = L - 1 - f;
+        return (rw[p >> 4] >> ((p & 15) * 2)) & 3u;
+    };
+    // pass A: first / last aligned column
+    int32_t f_first = 0x7fffffff, f_last = -1;
+    for (int32_t base = 0; base < L; base += 64) {
+        const int32_t f = base + lane;
+        const bool isM = f < L && op_at(f) == 0u;
+        if (isM) { f_first = min(f_first, f); f_last = max(f_last, f); }
     }
-    int32_t q_trail = 0, r_trail = 0;
-    while (fb > fa && ((reg[fb - 1] & 15u) == FZP_OP_I || (reg[fb - 1] & 15u) == FZP_OP_D)) {
-        if ((reg[fb - 1] & 15u) == FZP_OP_I) q_trail += reg[fb - 1] >> 4; else r_trail += reg[fb - 1] >> 4;
-        fb--;
+    f_first = wave_min_i32(f_first);
+    f_last = wave_max_i32(f_last);
+    // pass B: runs
+    const int32_t max_runs = n + 16;
+    int32_t runs = 0, carry_start = 0;
+    int32_t leadI = 0, leadD = 0, trailI = 0, trailD = 0, lead_runs = 0, trail_runs = 0;
+    for (int32_t base = 0; base < L; base += 64) {
+        const int32_t f = base + lane;
+        const bool valid = f < L;
+        const uint32_t op = valid ? op_at(f) : 3u;
+        const uint32_t prev = (valid && f > 0) ? op_at(f - 1) : 3u;
+        const bool start = valid && (f == 0 || op != prev);
+        const uint64_t B = __ballot(start);
+        const uint64_t below = B & ((1ull << lane) - 1ull);
+        if (start && f > 0) {   // this start closes the run before it
+            const int32_t ps = below ? base + 63 - __builtin_clzll(below) : carry_start;
+            const int32_t idx = runs + __popcll(below) - 1;
+            if (idx < max_runs) reg[1 + idx] = ((uint32_t)(f - ps) << 4) | prev;
+        }
+        leadI += (valid && f < f_first && op == 1u) ? 1 : 0;
+        leadD += (valid && f < f_first && op == 2u) ? 1 : 0;
+        trailI += (valid && f > f_last && op == 1u) ? 1 : 0;
+        trailD += (valid && f > f_last && op == 2u) ? 1 : 0;
+        lead_runs += (start && f < f_first) ? 1 : 0;
+        trail_runs += (start && f > f_last) ? 1 : 0;
+        runs += __popcll(B);
+        if (B) carry_start = base + 63 - __builtin_clzll(B);
     }
-    if (fa < fb && ncol > 0 && !overflow && nraw <= n + 16) {
+    if (L > 0 && lane == 0 && runs - 1 < max_runs) reg[runs] = ((uint32_t)(L - carry_start) << 4) | op_at(L - 1);
+    leadI = wave_sum_i32_dpp(leadI); leadD = wave_sum_i32_dpp(leadD);
+    trailI = wave_sum_i32_dpp(trailI); trailD = wave_sum_i32_dpp(trailD);
+    lead_runs = wave_sum_i32_dpp(lead_runs); trail_runs = wave_sum_i32_dpp(trail_runs);
+    if (lane != 0) return;
+    if (f_last >= 0 && w.ncol > 0 && runs <= max_runs) {
+        int32_t fa = 1 + lead_runs, fb = 1 + runs - trail_runs;       // forward ops are reg[fa .. fb)
+        const int32_t q_lead = w.i + 1 + leadI, r_lead = (w.ts - w.i) + 1 + leadD;
         out.aligned = 1;
         out.strand = a.strand;
         out.pos = (int32_t)(a.c_a + r_lead);
-        out.ref_end = (int32_t)(a.c_a + j_end + 1 - r_trail);
+        out.ref_end = (int32_t)(a.c_a + w.j_end + 1 - trailD);
         out.q_start = (int32_t)(a.i_a + q_lead);
-        out.q_end = (int32_t)(a.i_a + i_end + 1 - q_trail);
+        out.q_end = (int32_t)(a.i_a + w.i_end + 1 - trailI);
         out.score = di.best_score;
-        out.n_columns = ncol;
+        out.n_columns = w.ncol;
         int32_t nc = fb - fa;
         if (out.q_start > 0) { reg[--fa] = ((uint32_t)out.q_start << 4) | FZP_OP_S; nc++; }
         if (n - out.q_end > 0) { reg[fb++] = ((uint32_t)(n - out.q_end) << 4) | FZP_OP_S; nc++; }
@@ -701,6 +795,8 @@ struct fzp_alnjob {
     DevBuf<Anchor> anc;
     DevBuf<DpInfo> info;
     DevBuf<uint2> tb2[2];
+    DevBuf<uint32_t> raw2[2];                    // the walk's 2-bit op streams
+    DevBuf<WalkOut> wout;
     DevBuf<ulonglong2> mvw2[2];
     hipEvent_t ev_sw[2] = {nullptr, nullptr}, ev_tb[2] = {nullptr, nullptr};
     DevBuf<fzp_aln_summary> summ;
@@ -846,7 +942,7 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
         if (const char *e = getenv("FZP_SW_CHUNKS")) { int g = atoi(e); if (g > 0) n_chunks = g; }
         const int64_t total_steps = j->h_tb_off[(size_t)nr];
         int64_t chunk_steps = std::min<int64_t>(budget_steps / 2, (total_steps + n_chunks - 1) / n_chunks);
-        FZP_HIP(hipFuncSetAttribute((const void *)k_traceback, hipFuncAttributeMaxDynamicSharedMemorySize, TB_RPW * TB_LANE_STRIDE));
+        FZP_TRY(j->wout.alloc((size_t)nr));
         if (!j->ev_sw[0]) for (int k = 0; k < 2; k++) { FZP_HIP(hipEventCreateWithFlags(&j->ev_sw[k], hipEventDisableTiming)); FZP_HIP(hipEventCreateWithFlags(&j->ev_tb[k], hipEventDisableTiming)); }
         hipStream_t st2 = ctx->stream2;
         int64_t first = 0;
@@ -862,6 +958,7 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
             if (used[bi]) FZP_HIP(hipStreamWaitEvent(st, j->ev_tb[bi], 0));   // buffer free again?
             FZP_TRY(j->tb2[bi].alloc((size_t)steps * 2 + 128));
             FZP_TRY(j->mvw2[bi].alloc((size_t)(steps / 64 + cnt + 2)));
+            FZP_TRY(j->raw2[bi].alloc((size_t)(steps / 16 + 64)));
             {
                 ProfScope ps(ctx, "k1_sw");
                 hipLaunchKernelGGL(k_sw, dim3((unsigned)cnt), dim3(64), 0, st, first, cnt, j->read_ori.p, j->read_woff.p, j->read_len.p, j->read_ctg.p,
@@ -871,9 +968,13 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
             FZP_HIP(hipStreamWaitEvent(st2, j->ev_sw[bi], 0));
             {
                 ProfScope ps(ctx, "k1_traceback", st2);
-                hipLaunchKernelGGL(k_traceback, dim3((unsigned)((cnt + TB_RPW - 1) / TB_RPW)), dim3(64), (size_t)TB_RPW * TB_LANE_STRIDE, st2, first, cnt, j->read_ori.p, j->read_woff.p,
-                                   j->read_len.p, j->read_ctg.p, j->ctg_pk.p, j->ctg_woff.p, j->anc.p, j->info.p, j->tb_off.p, j->tb2[bi].p, j->mvw2[bi].p, j->cig_off.p,
-                                   j->cig.p, j->cig_start.p, j->summ.p, getenv("FZP_TB_DBG") ? atoi(getenv("FZP_TB_DBG")) : 0);
+                hipLaunchKernelGGL(k_tb_walk, dim3((unsigned)((cnt + TBW_RPW - 1) / TBW_RPW)), dim3(64), 0, st2, first, cnt, j->anc.p, j->info.p, j->tb_off.p,
+                                   j->tb2[bi].p, j->mvw2[bi].p, j->raw2[bi].p, j->wout.p);
+            }
+            {
+                ProfScope ps(ctx, "k1_cigar", st2);
+                hipLaunchKernelGGL(k_tb_cigar, dim3((unsigned)cnt), dim3(64), 0, st2, first, cnt, j->read_len.p, j->anc.p, j->info.p, j->tb_off.p, j->raw2[bi].p,
+                                   j->wout.p, j->cig_off.p, j->cig.p, j->cig_start.p, j->summ.p);
             }
             FZP_HIP(hipEventRecord(j->ev_tb[bi], st2));
             used[bi] = true;
