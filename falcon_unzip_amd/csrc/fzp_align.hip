@@ -117,9 +117,10 @@ __device__ __forceinline__ uint64_t block_max_u64(uint64_t v, uint64_t *sh) {
 __global__ void __launch_bounds__(256) k_seed(int64_t first, const uint32_t *__restrict__ read_pk, const int64_t *__restrict__ read_woff, const int32_t *__restrict__ read_len,
                                               const int32_t *__restrict__ read_ctg, const int64_t *__restrict__ ctg_len, const int64_t *__restrict__ idx_off,
                                               const int32_t *__restrict__ idx_bits, const uint64_t *__restrict__ table, int k, int stride, int min_hits,
-                                              Anchor *__restrict__ anc) {
-    extern __shared__ uint32_t votes[];
+                                              Anchor *__restrict__ anc, int nb_alloc, int hit_cap) {
+    extern __shared__ uint32_t votes[];   // [2 * nb_alloc] vote bins, then hit_cap hit records
     __shared__ uint64_t red[4];
+    __shared__ uint32_t n_hits;
     const int64_t r = first + blockIdx.x;
     const int64_t n = read_len[r];
     const int c = read_ctg[r];
@@ -132,20 +133,45 @@ __global__ void __launch_bounds__(256) k_seed(int64_t first, const uint32_t *__r
     const uint32_t *pk = read_pk + read_woff[r];
     const uint64_t *tab = table + idx_off[c];
     const int bits = idx_bits[c];
+    uint2 *hits = (uint2 *)(votes + 2 * nb_alloc);   // (strand << 31 | oriented offset, contig position) of every sampled k-mer found
     for (int i = threadIdx.x; i < 2 * NB; i += 256) votes[i] = 0;
+    if (threadIdx.x == 0) n_hits = 0;
     __syncthreads();
     const int64_t ns = (n - k) / stride + 1;   // sampled FORWARD read offsets 0, stride, ...
     // one canonical lookup serves both strands: same orientation bit on both sides -> the read matches as
-    // sequenced (strand 0, oriented offset = pf); different -> its reverse complement does (offset n-k-pf)
-    for (int64_t m = threadIdx.x; m < ns; m += 256) {
-        const int64_t pf = m * stride;
-        uint32_t orr;
-        const uint32_t key = canonical(kmer_at(pk, pf, k), k, &orr);
-        const int32_t hit = index_lookup(tab, bits, key);
-        if (hit < 0) continue;
-        const int s = (int)(((uint32_t)hit & 1u) ^ orr);
-        const int64_t cp = (uint32_t)hit >> 1, i = s ? n - k - pf : pf;
-        atomicAdd(&votes[s * NB + (int)((cp - i + n) >> shift)], 1u);
+    // sequenced (strand 0, oriented offset = pf); different -> its reverse complement does (offset n-k-pf).
+    // Four samples per thread and round: their first probes are in flight together (the table is ~30 % full,
+    // so the first probe nearly always decides).
+    for (int64_t m0 = threadIdx.x; m0 < ns; m0 += 4 * 256) {
+        uint32_t key[4], orr[4], slot[4];
+        uint64_t v[4];
+        const uint32_t mask = (1u << bits) - 1u;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int64_t m = m0 + u * 256;
+            key[u] = 0; orr[u] = 0; slot[u] = 0; v[u] = EMPTY;
+            if (m < ns) {
+                key[u] = canonical(kmer_at(pk, m * stride, k), k, &orr[u]);
+                slot[u] = hash_slot(key[u], bits);
+                v[u] = tab[slot[u]];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int64_t m = m0 + u * 256;
+            if (m >= ns) continue;
+            uint64_t x = v[u];
+            uint32_t sl = slot[u];
+            while (x != EMPTY && (uint32_t)(x >> 32) != key[u]) { sl = (sl + 1) & mask; x = tab[sl]; }
+            if (x == EMPTY) continue;
+            const uint32_t hit = (uint32_t)x;
+            const int64_t pf = m * stride;
+            const int s_ = (int)((hit & 1u) ^ orr[u]);
+            const int64_t cp = hit >> 1, i = s_ ? n - k - pf : pf;
+            atomicAdd(&votes[s_ * NB + (int)((cp - i + n) >> shift)], 1u);
+            const uint32_t at = atomicAdd(&n_hits, 1u);
+            if (at < (uint32_t)hit_cap) hits[at] = make_uint2(((uint32_t)s_ << 31) | (uint32_t)i, (uint32_t)cp);
+        }
     }
     __syncthreads();
     // best window: max votes[b]+votes[b+1]; ties -> forward strand, lower bin
@@ -164,18 +190,28 @@ __global__ void __launch_bounds__(256) k_seed(int64_t first, const uint32_t *__r
     const int bs = x >= NB, bb = bs ? x - NB : x;
     // the hit with the smallest ORIENTED read offset inside the two winning bins fixes the diagonal
     uint64_t mn = 0;   // maximise ~(i<<32|cp) == minimise i, then cp
-    for (int64_t m = threadIdx.x; m < ns; m += 256) {
-        // each thread visits its samples in order of increasing oriented offset and stops at its first hit
-        const int64_t pf = (bs ? ns - 1 - m : m) * stride;
-        uint32_t orr;
-        const uint32_t key = canonical(kmer_at(pk, pf, k), k, &orr);
-        const int32_t hit = index_lookup(tab, bits, key);
-        if (hit < 0) continue;
-        const int s = (int)(((uint32_t)hit & 1u) ^ orr);
-        if (s != bs) continue;
-        const int64_t cp = (uint32_t)hit >> 1, i = s ? n - k - pf : pf;
-        const int b = (int)((cp - i + n) >> shift);
-        if (b == bb || b == bb + 1) { mn = ~(((uint64_t)i << 32) | (uint32_t)cp); break; }
+    if (n_hits <= (uint32_t)hit_cap) {
+        for (uint32_t e = threadIdx.x; e < n_hits; e += 256) {
+            const uint2 h = hits[e];
+            if ((int)(h.x >> 31) != bs) continue;
+            const int64_t i = h.x & 0x7fffffffu, cp = h.y;
+            const int b = (int)((cp - i + n) >> shift);
+            if (b == bb || b == bb + 1) { const uint64_t c_ = ~(((uint64_t)i << 32) | (uint32_t)cp); mn = c_ > mn ? c_ : mn; }
+        }
+    } else {   // more hits than the list holds (near error-free reads): look them up again
+        for (int64_t m = threadIdx.x; m < ns; m += 256) {
+            // each thread visits its samples in order of increasing oriented offset and stops at its first hit
+            const int64_t pf = (bs ? ns - 1 - m : m) * stride;
+            uint32_t orr;
+            const uint32_t key = canonical(kmer_at(pk, pf, k), k, &orr);
+            const int32_t hit = index_lookup(tab, bits, key);
+            if (hit < 0) continue;
+            const int s = (int)(((uint32_t)hit & 1u) ^ orr);
+            if (s != bs) continue;
+            const int64_t cp = (uint32_t)hit >> 1, i = s ? n - k - pf : pf;
+            const int b = (int)((cp - i + n) >> shift);
+            if (b == bb || b == bb + 1) { mn = ~(((uint64_t)i << 32) | (uint32_t)cp); break; }
+        }
     }
     mn = block_max_u64(mn, red);
     if (threadIdx.x == 0) {
@@ -924,10 +960,11 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
             for (auto v : j->h_ctg_len) lc_max = std::max(lc_max, v);
             for (auto v : j->h_read_len) n_max = std::max<int64_t>(n_max, v);
             const int64_t nb_max = std::min<int64_t>(MAX_BINS, ((lc_max + n_max) >> 10) + 2);
-            const size_t lds = (size_t)2 * (size_t)nb_max * sizeof(uint32_t);
+            const int hit_cap = 1024;   // sampled k-mers found per read before the anchor search falls back to lookups (8 KB)
+            const size_t lds = (size_t)2 * (size_t)nb_max * sizeof(uint32_t) + (size_t)hit_cap * sizeof(uint2);
             FZP_HIP(hipFuncSetAttribute((const void *)k_seed, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(k_seed, dim3((unsigned)nr), dim3(256), lds, st, (int64_t)0, j->read_pk.p, j->read_woff.p, j->read_len.p,
-                               j->read_ctg.p, j->ctg_len.p, j->idx_off.p, j->idx_bits.p, j->table.p, P.kmer, P.seed_stride, P.min_seed_hits, j->anc.p);
+                               j->read_ctg.p, j->ctg_len.p, j->idx_off.p, j->idx_bits.p, j->table.p, P.kmer, P.seed_stride, P.min_seed_hits, j->anc.p, (int)nb_max, hit_cap);
         }
         {
             ProfScope ps(ctx, "k1_orient");
