@@ -29,10 +29,11 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-VALU_PEAK_TLANEOPS = 78.6        # 157.3 TFLOP/s fp32 vector / 2 (FMA) = lane-ops/s, same rate for int32 VALU
+VALU_PEAK_GINST = 614.4          # wave64 int32 VALU instructions/s: 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 op
+                                 # (the 157.3 TFLOP/s vector figure counts packed fp32, which integer ops do not have)
+SW_VALU_PER_STEP = 14            # VALU instructions per 64-cell band step in k_sw's interior block (fzp_align.hip: sw_block)
 SW_BYTES_PER_CELL = 0.25         # algorithmic: 2 trace-back bits per cell (16 B per 64-cell step); sequence
                                  # reads add 2 bits per band step, i.e. < 0.01 B/cell
-SW_INTOPS_PER_CELL = 12          # SURVEY.md section 8d accounting
 
 
 def gen_contig(args):
@@ -231,9 +232,9 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(cells_per_launch * SW_BYTES_PER_CELL / (sw_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if sw_avg_ms else 0.0,
                          "traffic": traffic, "avg_launch_ms": round(sw_avg_ms, 3), "launches": int(sw_launches),
-                         "note": "k1_sw is integer-VALU-bound by construction (0.25 algorithmic B/cell); the VALU view is in `valu`",
-                         "valu": {"achieved_tlaneops": round(dp_gcells * SW_INTOPS_PER_CELL / 1e3, 3), "peak_tlaneops": VALU_PEAK_TLANEOPS,
-                                  "frac": round(dp_gcells * SW_INTOPS_PER_CELL / 1e3 / VALU_PEAK_TLANEOPS, 4)}},
+                         "note": "k1_sw is VALU-issue-bound by construction (0.25 algorithmic B/cell); the issue view is in `valu`",
+                         "valu": {"insts_per_step": SW_VALU_PER_STEP, "achieved_ginst": round(dp_gcells / 64.0 * SW_VALU_PER_STEP, 2),
+                                  "peak_ginst": VALU_PEAK_GINST, "frac": round(dp_gcells / 64.0 * SW_VALU_PER_STEP / VALU_PEAK_GINST, 4)}},
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(contigs, blob, off, read_ctg, eng, args.cpu_sample_reads)

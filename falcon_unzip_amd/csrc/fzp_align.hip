@@ -706,10 +706,14 @@ __global__ void __launch_bounds__(64) k_tb_walk(int64_t first, int64_t count, co
     wout[r] = o;
 }
 
-// ---- trace-back, part 2: one wave per read turns the walk's op stream (alignment end first) into the forward,
-// run-length encoded CIGAR (M/I/D; '=' / 'X' need the bases and are split on the host where SAM text / alnsets are
-// produced -- the phasing stages treat M, = and X alike, phasing.py:81), trims gap runs at both ends, adds the
-// soft clips and fills the read's summary.
+// ---- trace-back, part 2: one wave per read turns the walk's op stream (alignment end first, 16 ops per word)
+// into the forward, run-length encoded CIGAR (M/I/D; '=' / 'X' need the bases and are split on the host where SAM
+// text / alnsets are produced -- the phasing stages treat M, = and X alike, phasing.py:81), trims gap runs at both
+// ends, adds the soft clips and fills the read's summary.
+// A lane owns a word.  Stream position p is forward position L-1-p, so forward runs start where op(p) != op(p+1):
+// the flags of a word come from one xor with the stream shifted by one op, and a run is written by the start BELOW
+// it (which knows where it ends); suffix scans over the lanes give each word the number of starts and the lowest
+// start above it.
 __global__ void __launch_bounds__(64) k_tb_cigar(int64_t first, int64_t count, const int32_t *__restrict__ read_len, const Anchor *__restrict__ anc,
                                                  const DpInfo *__restrict__ info, const int64_t *__restrict__ tb_off, const uint32_t *__restrict__ raw,
                                                  const WalkOut *__restrict__ wout, const int64_t *__restrict__ cig_off, uint32_t *__restrict__ cig,
@@ -727,54 +731,86 @@ __global__ void __launch_bounds__(64) k_tb_cigar(int64_t first, int64_t count, c
     out.cells = (int64_t)di.steps * 64;
     if (lane == 0) cig_start[r] = cig_off[r];
     if (!w.ok) { if (lane == 0) summ[r] = out; return; }
-    const uint32_t *rw = raw + ((tb_off[r] - tb_off[first]) >> 4);
+    const uint32_t *rg = raw + ((tb_off[r] - tb_off[first]) >> 4);
     uint32_t *reg = cig + cig_off[r];                     // capacity n + 18 words: [0] leading clip, runs from [1]
     const int32_t L = w.n_ops;
-    auto op_at = [&](int32_t f) -> uint32_t {             // forward position f = L-1-f in the stream
-        const int32_t p = L - 1 - f;
-        return (rw[p >> 4] >> ((p & 15) * 2)) & 3u;
+    const int32_t nW = (L + 15) >> 4;
+    constexpr uint32_t EVEN = 0x55555555u;
+    auto valid_mask = [&](int32_t wi) -> uint32_t {       // one bit (the even one) per op of word wi that belongs to the stream
+        const int32_t nv = min(16, L - 16 * wi);
+        return nv >= 16 ? EVEN : (((1u << (2 * nv)) - 1u) & EVEN);
     };
-    // pass A: first / last aligned column
-    int32_t f_first = 0x7fffffff, f_last = -1;
-    for (int32_t base = 0; base < L; base += 64) {
-        const int32_t f = base + lane;
-        const bool isM = f < L && op_at(f) == 0u;
-        if (isM) { f_first = min(f_first, f); f_last = max(f_last, f); }
-    }
-    f_first = wave_min_i32(f_first);
-    f_last = wave_max_i32(f_last);
-    // pass B: runs
-    const int32_t max_runs = n + 16;
-    int32_t runs = 0, carry_start = 0;
-    int32_t leadI = 0, leadD = 0, trailI = 0, trailD = 0, lead_runs = 0, trail_runs = 0;
-    for (int32_t base = 0; base < L; base += 64) {
-        const int32_t f = base + lane;
-        const bool valid = f < L;
-        const uint32_t op = valid ? op_at(f) : 3u;
-        const uint32_t prev = (valid && f > 0) ? op_at(f - 1) : 3u;
-        const bool start = valid && (f == 0 || op != prev);
-        const uint64_t B = __ballot(start);
-        const uint64_t below = B & ((1ull << lane) - 1ull);
-        if (start && f > 0) {   // this start closes the run before it
-            const int32_t ps = below ? base + 63 - __builtin_clzll(below) : carry_start;
-            const int32_t idx = runs + __popcll(below) - 1;
-            if (idx < max_runs) reg[1 + idx] = ((uint32_t)(f - ps) << 4) | prev;
+    // pass A: highest / lowest stream position holding an aligned column
+    int32_t pM_hi = -1, pM_lo = 0x7fffffff;
+    for (int32_t wb = 0; wb < nW; wb += 64) {
+        const int32_t wi = wb + lane;
+        if (wi < nW) {
+            const uint32_t x = rg[wi];
+            const uint32_t mf = ~(x | (x >> 1)) & valid_mask(wi);
+            if (mf) { pM_hi = max(pM_hi, 16 * wi + ((31 - __builtin_clz(mf)) >> 1)); pM_lo = min(pM_lo, 16 * wi + (__builtin_ctz(mf) >> 1)); }
         }
-        leadI += (valid && f < f_first && op == 1u) ? 1 : 0;
-        leadD += (valid && f < f_first && op == 2u) ? 1 : 0;
-        trailI += (valid && f > f_last && op == 1u) ? 1 : 0;
-        trailD += (valid && f > f_last && op == 2u) ? 1 : 0;
-        lead_runs += (start && f < f_first) ? 1 : 0;
-        trail_runs += (start && f > f_last) ? 1 : 0;
-        runs += __popcll(B);
-        if (B) carry_start = base + 63 - __builtin_clzll(B);
     }
-    if (L > 0 && lane == 0 && runs - 1 < max_runs) reg[runs] = ((uint32_t)(L - carry_start) << 4) | op_at(L - 1);
+    pM_hi = wave_max_i32(pM_hi);
+    pM_lo = wave_min_i32(pM_lo);
+    // pass B: runs, from the top of the stream (= the alignment's start) down
+    const int32_t max_runs = n + 16;
+    int32_t n_starts = 0;                 // starts seen in higher chunks
+    int32_t low_start = 0x7fffffff;       // lowest of them
+    int32_t leadI = 0, leadD = 0, trailI = 0, trailD = 0, lead_runs = 0, trail_runs = 0;
+    for (int32_t wtop = nW; wtop > 0; wtop -= 64) {
+        const int32_t wi = wtop - 64 + lane;              // lane 63 = highest word of the chunk
+        uint32_t sflag = 0, x = 0, above = 0;
+        if (wi >= 0) {
+            x = rg[wi];
+            const uint32_t nx = wi + 1 < nW ? rg[wi + 1] : 0u;
+            above = (x >> 2) | (nx << 30);                // op(p+1) lined up with op(p)
+            const uint32_t d = x ^ above;
+            const uint32_t vm = valid_mask(wi);
+            sflag = (d | (d >> 1)) & vm;
+            if (wi == ((L - 1) >> 4)) sflag |= 1u << (2 * ((L - 1) & 15));     // the first forward op always starts a run
+            // gap ops and run starts outside [pM_lo, pM_hi] are what the trimming removes
+            const int32_t p0 = 16 * wi;
+            const uint32_t fI = (x & ~(x >> 1)) & vm, fD = (~x & (x >> 1)) & vm;
+            const int32_t nh = pM_hi - p0 + 1, nl = pM_lo - p0;      // ops of this word at or below pM_hi / below pM_lo
+            const uint32_t m_lead = nh >= 16 ? 0u : (nh <= 0 ? EVEN : (EVEN & ~((1u << (2 * nh)) - 1u)));
+            const uint32_t m_trail = nl >= 16 ? EVEN : (nl <= 0 ? 0u : (EVEN & ((1u << (2 * nl)) - 1u)));
+            leadI += __popc(fI & m_lead); leadD += __popc(fD & m_lead); lead_runs += __popc(sflag & m_lead);
+            trailI += __popc(fI & m_trail); trailD += __popc(fD & m_trail); trail_runs += __popc(sflag & m_trail);
+        }
+        const int32_t cnt = __popc(sflag);
+        const int32_t mylow = sflag ? 16 * wi + (__builtin_ctz(sflag) >> 1) : 0x7fffffff;
+        // suffix scans over the lanes above this one
+        int32_t cs = cnt, lw = mylow;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int32_t oc = __shfl_down(cs, d, 64), ol = __shfl_down(lw, d, 64);
+            if (lane + d < 64) { cs += oc; lw = min(lw, ol); }
+        }
+        const int32_t tot = __builtin_amdgcn_readlane(cs, 0), chunk_low = __builtin_amdgcn_readlane(lw, 0);
+        int32_t k = n_starts + cs - cnt;                                    // starts above this word
+        const int32_t lw_up = __shfl_down(lw, 1, 64);                      // (executed by all lanes)
+        int32_t prevp = min(low_start, lane < 63 ? lw_up : 0x7fffffff);
+        {
+            uint32_t bits = sflag;
+            while (bits) {
+                const int b = 31 - __builtin_clz(bits);                      // even bit of the highest remaining start
+                const int32_t pp = 16 * wi + (b >> 1);
+                if (k > 0 && k - 1 < max_runs) reg[k] = ((uint32_t)(prevp - pp) << 4) | ((above >> b) & 3u);
+                prevp = pp;
+                k++;
+                bits &= ~(1u << b);
+            }
+        }
+        n_starts += tot;
+        low_start = min(low_start, chunk_low);
+    }
+    const int32_t runs = n_starts;
+    if (L > 0 && lane == 0 && runs >= 1 && runs - 1 < max_runs) reg[runs] = ((uint32_t)(low_start + 1) << 4) | (rg[0] & 3u);
     leadI = wave_sum_i32_dpp(leadI); leadD = wave_sum_i32_dpp(leadD);
     trailI = wave_sum_i32_dpp(trailI); trailD = wave_sum_i32_dpp(trailD);
     lead_runs = wave_sum_i32_dpp(lead_runs); trail_runs = wave_sum_i32_dpp(trail_runs);
     if (lane != 0) return;
-    if (f_last >= 0 && w.ncol > 0 && runs <= max_runs) {
+    if (pM_hi >= 0 && w.ncol > 0 && runs <= max_runs) {
         int32_t fa = 1 + lead_runs, fb = 1 + runs - trail_runs;       // forward ops are reg[fa .. fb)
         const int32_t q_lead = w.i + 1 + leadI, r_lead = (w.ts - w.i) + 1 + leadD;
         out.aligned = 1;
