@@ -150,3 +150,31 @@ def align_reads(orc, ctg: bytes, reads, params=None):
 
 def load():
     return Oracle(build())
+
+
+class OvlpParams(C.Structure):
+    _fields_ = [("max_diff", C.c_longlong), ("max_cov", C.c_longlong), ("min_cov", C.c_longlong), ("min_len", C.c_longlong),
+                ("bestn", C.c_longlong)]
+
+
+def ovlp_filter(orc, files, rid_map: bytes, params: dict):
+    """oracle/ovlp_oracle.c: orc_ovlp_filter -> (stdout text, ignore ids, contained ids)"""
+    lib = orc.lib
+    n = len(files)
+    bufs = [C.create_string_buffer(f, len(f)) if len(f) else C.create_string_buffer(1) for f in files]
+    texts = (C.c_char_p * max(1, n))(*[C.cast(b, C.c_char_p) for b in bufs])
+    lens = (C.c_size_t * max(1, n))(*[len(f) for f in files])
+    mp = C.create_string_buffer(rid_map, len(rid_map)) if rid_map else C.create_string_buffer(1)
+    P = OvlpParams(params["max_diff"], params["max_cov"], params["min_cov"], params["min_len"], params["bestn"])
+    outs = [(C.c_void_p(), C.c_size_t()) for _ in range(3)]
+    f = lib.orc_ovlp_filter
+    f.restype = C.c_int
+    f.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t, C.POINTER(OvlpParams)] + [C.c_void_p] * 6
+    rc = f(n, texts, lens, C.cast(mp, C.c_char_p), len(rid_map), C.byref(P), *[x for p, q in outs for x in (C.byref(p), C.byref(q))])
+    if rc != 0:
+        raise OracleError("orc_ovlp_filter failed: rc=%d" % rc)
+    res = []
+    for p, q in outs:
+        res.append(C.string_at(p, q.value))
+        lib.orc_free(p)
+    return res[0], res[1].decode().split(), res[2].decode().split()
