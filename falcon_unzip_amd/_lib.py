@@ -55,6 +55,10 @@ class ResultAllStruct(C.Structure):
                 ("arow_begin", C.POINTER(C.c_int64)), ("pvar_begin", C.POINTER(C.c_int64)), ("pread_begin", C.POINTER(C.c_int64))]
 
 
+class OvlpParams(C.Structure):
+    _fields_ = [("max_diff", C.c_int64), ("max_cov", C.c_int64), ("min_cov", C.c_int64), ("min_len", C.c_int64), ("bestn", C.c_int64)]
+
+
 class AlignParams(C.Structure):
     _fields_ = [("kmer", C.c_int32), ("seed_stride", C.c_int32), ("match", C.c_int32), ("mismatch", C.c_int32),
                 ("gap", C.c_int32), ("min_seed_hits", C.c_int32), ("reserved", C.c_int32 * 10)]
@@ -112,6 +116,13 @@ def load():
         "fzp_align_alnset": (C.c_int, [VP, VP, I32, VP, CP, PP, PP]),
         "fzp_align_to_batch": (C.c_int, [VP, VP, PP]),
         "fzp_align_destroy": (None, [VP, VP]),
+        "fzp_ovl_parse": (C.c_int, [I32, VP, VP, CP, SZ, PP]),
+        "fzp_ovlset_free": (None, [VP]),
+        "fzp_ovl_n_lines": (I64, [VP]),
+        "fzp_ovl_n_rows": (I64, [VP]),
+        "fzp_ovl_filter": (C.c_int, [VP, VP, VP, PP, PI64, PP, PI64, PP, PI64]),
+        "fzp_ovl_format": (C.c_int, [VP, VP, I64, PP, PSZ]),
+        "fzp_ovl_id_name": (C.c_int, [VP, I32, PP, C.POINTER(I32)]),
     }
     lib.fzp_last_error.restype = C.c_char_p
     lib.fzp_version.restype = C.c_char_p
@@ -506,3 +517,52 @@ def readmap(phased_reads: bytes, rawread_ids: bytes, pread_ids: bytes, pread_to_
                            C.c_size_t(len(pread_ids)), pread_to_contigs, C.c_size_t(len(pread_to_contigs)), ctg_id.encode(),
                            C.c_int32(ctg_index), C.byref(rp), C.byref(nr), C.byref(tp), C.byref(tn)))
     return _take(rp.value, nr.value, R2P), _take_text(tp, tn)
+
+
+# ---------------------------------------------------------------------------- overlap filter (fzp_ovl_*)
+class OvlSet:
+    """Tokenised `LA4Falcon -mo` dumps + rid_to_phase.all (fzp_ovl_parse)."""
+
+    def __init__(self, files, rid_map: bytes):
+        lib = load()
+        n = len(files)
+        self._keep = [C.create_string_buffer(f, len(f)) if len(f) else C.create_string_buffer(1) for f in files]
+        texts = (C.c_char_p * max(1, n))(*[C.cast(b, C.c_char_p) for b in self._keep])
+        lens = (C.c_size_t * max(1, n))(*[len(f) for f in files])
+        p = C.c_void_p()
+        _check(lib.fzp_ovl_parse(n, texts, lens, rid_map, len(rid_map), C.byref(p)))
+        self._p = p.value
+        self._keep = None            # the library copied the texts
+
+    def close(self):
+        if getattr(self, "_p", None):
+            load().fzp_ovlset_free(self._p)
+            self._p = None
+
+    __del__ = close
+
+    @property
+    def n_lines(self):
+        return int(load().fzp_ovl_n_lines(self._p))
+
+    @property
+    def n_rows(self):
+        return int(load().fzp_ovl_n_rows(self._p))
+
+    def id_name(self, idx):
+        p, n = C.c_void_p(), C.c_int32()
+        _check(load().fzp_ovl_id_name(self._p, int(idx), C.byref(p), C.byref(n)))
+        return C.string_at(p, n.value)
+
+    def format(self, rows):
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        return _fmt("fzp_ovl_format", C.c_void_p(self._p), _ptr(rows), C.c_int64(len(rows)))
+
+
+def ovl_filter(eng, ovl: OvlSet, max_diff, max_cov, min_cov, min_len=2500, bestn=10):
+    """filter_stage1..3 on the device -> (selected line numbers in print order, ignore ids, contained ids)"""
+    lib = load()
+    P = OvlpParams(int(max_diff), int(max_cov), int(min_cov), int(min_len), int(bestn))
+    r, nr, ig, nig, ct, nct = C.c_void_p(), C.c_int64(), C.c_void_p(), C.c_int64(), C.c_void_p(), C.c_int64()
+    _check(lib.fzp_ovl_filter(eng._p, ovl._p, C.byref(P), C.byref(r), C.byref(nr), C.byref(ig), C.byref(nig), C.byref(ct), C.byref(nct)))
+    return _take(r, nr.value, np.int64), _take(ig, nig.value, np.int32), _take(ct, nct.value, np.int32)

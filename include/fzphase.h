@@ -246,6 +246,40 @@ void fzp_align_destroy(fzp_ctx *ctx, fzp_alnjob *job);
 /* SAM text of an alnset (what `samtools view` would print), for users who want the alignments */
 int fzp_format_sam(const fzp_alnset *aln, const char *ctg_id, const int32_t *flags, char **text, size_t *len);
 
+/* ======================================================================== overlap filter ("next" row n2)
+ * falcon_unzip/ovlp_filter_with_phase.py: the consumer of rid_to_phase.all.  It reads `LA4Falcon -mo` text
+ * (13 whitespace-separated columns per overlap: q_id t_id -len idt q_strand q_s q_e q_l t_strand t_s t_e t_l tag)
+ * three times: filter_stage1 (:49-143) counts 5'/3' overlaps per query and builds the ignore list, filter_stage2
+ * (:145-186) collects contained reads, filter_stage3 (:188-277) keeps the best-n overlaps per read end with
+ * in-phase partners first.  Here the text is tokenised once on the host, the three stages run on the device. */
+typedef struct {
+    int64_t max_diff;   /* --max_diff  :285 */
+    int64_t max_cov;    /* --max_cov   :286 */
+    int64_t min_cov;    /* --min_cov   :287 */
+    int64_t min_len;    /* --min_len   :288 (default 2500) */
+    int64_t bestn;      /* --bestn     :289 (default 10) */
+} fzp_ovlp_params;
+typedef struct fzp_ovlset fzp_ovlset;
+/* Tokenise the dumps of n_files .las files (in fofn order) and the rid_to_phase.all map (main :306-309: later rows
+ * overwrite earlier ones; ids, contigs, blocks and phases are compared as strings).  The texts are copied.
+ * FZP_EINVAL where the reference would raise while reading (a line with fewer than 2 tokens, a map row with fewer
+ * than 4). */
+int fzp_ovl_parse(int32_t n_files, const char *const *texts, const size_t *lens, const char *rid_map, size_t map_len,
+                  fzp_ovlset **out);
+void fzp_ovlset_free(fzp_ovlset *s);
+int64_t fzp_ovl_n_lines(const fzp_ovlset *s);   /* input lines */
+int64_t fzp_ovl_n_rows(const fzp_ovlset *s);    /* lines whose q_id and t_id are both in the map (the rest never matter) */
+/* filter_stage1..3 on the device.  rows: selected input lines (global 0-based line numbers over all files) in the
+ * order the reference prints them; ignore / contained: the ids of the two sets as indices into the map's distinct
+ * keys in first-appearance order (fzp_ovl_id_name).  All three are malloc'ed; release with fzp_free.  FZP_EINVAL if
+ * a line that passes the phase checks has a field the reference's int()/float() would reject (or an integer beyond
+ * 32 bits -- deliberate limit). */
+int fzp_ovl_filter(fzp_ctx *ctx, const fzp_ovlset *s, const fzp_ovlp_params *params, int64_t **rows, int64_t *n_rows,
+                   int32_t **ignore, int64_t *n_ignore, int32_t **contained, int64_t *n_contained);
+/* the `print " ".join(l)` at :353 for the selected lines: the line's tokens, then "ctg.block.phase" of q and of t */
+int fzp_ovl_format(const fzp_ovlset *s, const int64_t *rows, int64_t n_rows, char **text, size_t *len);
+int fzp_ovl_id_name(const fzp_ovlset *s, int32_t id, const char **name, int32_t *len);
+
 #ifdef __cplusplus
 }
 #endif
