@@ -116,7 +116,7 @@ def load():
         "fzp_align_alnset": (C.c_int, [VP, VP, I32, VP, CP, PP, PP]),
         "fzp_align_to_batch": (C.c_int, [VP, VP, PP]),
         "fzp_align_destroy": (None, [VP, VP]),
-        "fzp_ovl_parse": (C.c_int, [I32, VP, VP, CP, SZ, PP]),
+        "fzp_ovl_parse": (C.c_int, [VP, I32, VP, VP, CP, SZ, PP]),
         "fzp_ovlset_free": (None, [VP]),
         "fzp_ovl_n_lines": (I64, [VP]),
         "fzp_ovl_n_rows": (I64, [VP]),
@@ -523,14 +523,14 @@ def readmap(phased_reads: bytes, rawread_ids: bytes, pread_ids: bytes, pread_to_
 class OvlSet:
     """Tokenised `LA4Falcon -mo` dumps + rid_to_phase.all (fzp_ovl_parse)."""
 
-    def __init__(self, files, rid_map: bytes):
+    def __init__(self, eng, files, rid_map: bytes):
         lib = load()
         n = len(files)
         self._keep = [C.create_string_buffer(f, len(f)) if len(f) else C.create_string_buffer(1) for f in files]
         texts = (C.c_char_p * max(1, n))(*[C.cast(b, C.c_char_p) for b in self._keep])
         lens = (C.c_size_t * max(1, n))(*[len(f) for f in files])
         p = C.c_void_p()
-        _check(lib.fzp_ovl_parse(n, texts, lens, rid_map, len(rid_map), C.byref(p)))
+        _check(lib.fzp_ovl_parse(eng._p, n, texts, lens, rid_map, len(rid_map), C.byref(p)))
         self._p = p.value
         self._keep = None            # the library copied the texts
 

@@ -1,11 +1,16 @@
 // fzp_ovlp.hip -- overlap filter with phase (falcon_unzip/ovlp_filter_with_phase.py:49-354), SURVEY section 8f row n2.
 //
 // The reference streams `LA4Falcon -mo` text three times and keeps Python dicts / sets keyed by id strings.  Here:
-//   host    one pass over the text: tokenise, intern ids / contigs / blocks / phases (strings stay strings: they are
-//           only ever compared for equality, plus one lexicographic rank for sort ties), parse the numeric columns of
-//           every line whose two ids are in the map (leniently: a bad field only matters if the line passes the phase
-//           checks, which is decided on the device, as in the reference where such lines are never parsed);
-//   device  K_pre     the four phase checks of every stage (:64-73)
+//   host    the rid map (small): ids / contigs / blocks / phases interned (strings stay strings: they are only ever
+//           compared for equality, plus one lexicographic rank for sort ties);
+//   device  K_nl/K_ls the text goes to HBM once; newline counts per 16 B -> scan -> line starts
+//           K_tok     one thread per line: str.split() state machine, ids -> map entries through a direct table
+//                     (rid_to_phase.all keys are '%09d' decimals, phasing_readmap.py:47-51; when a map has any other
+//                     key shape the lines are tokenised on the host instead), int() / float() of the numeric columns
+//                     (leniently: a bad field only matters if the line passes the phase checks, as in the reference
+//                     where such lines are never parsed; `float(l[3]) < 90` is decided exactly in integers for plain
+//                     decimals of <= 15 digits, anything else is settled by the host's strtod)
+//           K_pre     the four phase checks of every stage (:64-73)
 //           K_heads   query groups = runs of equal q among the lines that passed, per file (:77, :215)
 //           K_stage1  5'/3' counts per group -> ignore flags (:79-87, :96-119)
 //           K_stage2  containment flags (:165-181)
@@ -14,7 +19,7 @@
 //           K_emit    selected lines in print order (slots from scans: no order depends on atomics)
 //   host    groups whose candidates tie on the whole numeric key AND partner id (the same pair listed twice with equal
 //           length and span) are re-ordered by the reference's last key, the comparison of the lines' token lists.
-// HBM-bound integer scans: 42 B per row in, 8 B per selected row out; groups are small (tens to hundreds of rows), so
+// HBM-bound byte / integer scans: the text once (1 B per byte), 42 B per line of columns, 8 B per selected line out; groups are small (tens to hundreds of rows), so
 // the all-pairs ranking inside a group is cheap and needs no global sort.
 #include <algorithm>
 #include <string_view>
@@ -72,20 +77,29 @@ constexpr uint8_t F_PARSE_OK = 1, F_IDT_OK = 2, F_CONTAINS = 4, F_CONTAINED = 8;
 }  // namespace
 
 struct fzp_ovlset {
+    int device = 0;
     std::string text;                       // all dumps, each ending with '\n'
+    std::vector<int64_t> file_end;          // end offset of every dump inside `text`
     std::vector<int64_t> line_off;          // [n_lines + 1]
     std::string map_text;
     std::vector<Tok> key, ctg, blk, ph;     // per distinct map key (first-appearance order), offsets into map_text
     std::vector<int32_t> ctg_code, blk_code, ph_code, lex_rank;
-    // rows: lines whose q_id and t_id are both map keys
-    std::vector<int64_t> row_line;
-    std::vector<int32_t> row_file, q, t, ovl, q_s, q_e, q_l, t_s, t_e, t_l;
-    std::vector<uint8_t> flags;
+    std::unordered_map<std::string_view, int32_t> ids;   // key string -> index (views into map_text)
+    int64_t n_lines = 0, n_rows = 0;        // rows = lines whose q_id and t_id are both map keys
+    bool tokenised_on_device = false;
+    // per line, resident in HBM: q / t = map entry or -1
+    DevBuf<int32_t> d_q, d_t, d_file, d_ovl, d_q_s, d_q_e, d_q_l, d_t_s, d_t_e, d_t_l;
+    DevBuf<uint8_t> d_flags;
+    DevBuf<int32_t> d_ctg, d_blk, d_ph, d_lex;
 };
 
-extern "C" void fzp_ovlset_free(fzp_ovlset *s) { delete s; }
-extern "C" int64_t fzp_ovl_n_lines(const fzp_ovlset *s) { return s ? (int64_t)s->line_off.size() - 1 : 0; }
-extern "C" int64_t fzp_ovl_n_rows(const fzp_ovlset *s) { return s ? (int64_t)s->row_line.size() : 0; }
+extern "C" void fzp_ovlset_free(fzp_ovlset *s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    delete s;
+}
+extern "C" int64_t fzp_ovl_n_lines(const fzp_ovlset *s) { return s ? s->n_lines : 0; }
+extern "C" int64_t fzp_ovl_n_rows(const fzp_ovlset *s) { return s ? s->n_rows : 0; }
 extern "C" int fzp_ovl_id_name(const fzp_ovlset *s, int32_t id, const char **name, int32_t *len) {
     if (!s || id < 0 || (size_t)id >= s->key.size() || !name || !len) { fzp_set_error("fzp_ovl_id_name: bad arguments"); return FZP_EINVAL; }
     *name = s->map_text.data() + s->key[(size_t)id].off;
@@ -93,13 +107,57 @@ extern "C" int fzp_ovl_id_name(const fzp_ovlset *s, int32_t id, const char **nam
     return FZP_OK;
 }
 
-extern "C" int fzp_ovl_parse(int32_t n_files, const char *const *texts, const size_t *lens, const char *rid_map, size_t map_len, fzp_ovlset **out) {
-    if (!out || n_files < 0 || (n_files && (!texts || !lens)) || (!rid_map && map_len)) { fzp_set_error("fzp_ovl_parse: bad arguments"); return FZP_EINVAL; }
+namespace {
+// one line on the host: what K_tok computes on the device (same rules), for the fallback tokeniser, the tie fix-up and
+// the formatter
+struct HostLine { int nt; int32_t q, t; int64_t v[7]; uint8_t flags; };
+bool host_line(const fzp_ovlset *s, int64_t line, HostLine *o, Tok *toks /* [MAXTOK] */) {
+    const char *tx = s->text.data();
+    const int nt = split_line(tx, s->line_off[(size_t)line], s->line_off[(size_t)line + 1], toks, MAXTOK);
+    o->nt = nt; o->q = o->t = -1; o->flags = 0;
+    for (int c = 0; c < 7; c++) o->v[c] = 0;
+    if (nt < 2) return false;
+    auto iq = s->ids.find(std::string_view(tx + toks[0].off, (size_t)toks[0].len));
+    auto it = s->ids.find(std::string_view(tx + toks[1].off, (size_t)toks[1].len));
+    o->q = iq == s->ids.end() ? -1 : iq->second;
+    o->t = it == s->ids.end() ? -1 : it->second;
+    static const int col[7] = {2, 5, 6, 7, 9, 10, 11};
+    double idt = 0;
+    bool ok = nt >= 12 && nt <= MAXTOK;
+    for (int c = 0; ok && c < 7; c++) ok = parse_int32(tx + toks[col[c]].off, toks[col[c]].len, &o->v[c]);
+    if (ok) ok = parse_float(tx + toks[3].off, toks[3].len, &idt);
+    if (ok) {
+        o->flags |= F_PARSE_OK;
+        if (!(idt < 90)) o->flags |= F_IDT_OK;
+        const std::string_view tag(tx + toks[nt - 1].off, (size_t)toks[nt - 1].len);
+        if (tag == "contains") o->flags |= F_CONTAINS;
+        if (tag == "contained") o->flags |= F_CONTAINED;
+    }
+    return true;
+}
+// '%09d'-shaped key: decimal digits, at least 9 of them, no leading zero beyond the padding
+bool canonical_id(const char *p, int n, int64_t *val) {
+    if (n < 9 || n > 10) return false;
+    if (n > 9 && p[0] == '0') return false;
+    int64_t v = 0;
+    for (int i = 0; i < n; i++) { if (p[i] < '0' || p[i] > '9') return false; v = v * 10 + (p[i] - '0'); }
+    if (v > 2147483646ll) return false;
+    *val = v;
+    return true;
+}
+int ovl_tokenise_device(fzp_ctx *ctx, fzp_ovlset *s, int64_t max_id, const std::vector<int32_t> &arid_of);
+int ovl_tokenise_host(fzp_ctx *ctx, fzp_ovlset *s);
+}  // namespace
+
+extern "C" int fzp_ovl_parse(fzp_ctx *ctx, int32_t n_files, const char *const *texts, const size_t *lens, const char *rid_map, size_t map_len, fzp_ovlset **out) {
+    if (!ctx || !out || n_files < 0 || (n_files && (!texts || !lens)) || (!rid_map && map_len)) { fzp_set_error("fzp_ovl_parse: bad arguments"); return FZP_EINVAL; }
     *out = nullptr;
+    FZP_HIP(hipSetDevice(ctx->device));
     fzp_ovlset *s = new fzp_ovlset();
+    s->device = ctx->device;
     // ---- rid_to_phase.all (:306-309)
     s->map_text.assign(rid_map ? rid_map : "", map_len);
-    std::unordered_map<std::string_view, int32_t> ids, strs;
+    std::unordered_map<std::string_view, int32_t> strs;
     auto intern = [&](Tok t) {
         std::string_view v(s->map_text.data() + t.off, (size_t)t.len);
         auto it = strs.find(v);
@@ -111,8 +169,7 @@ extern "C" int fzp_ovl_parse(int32_t n_files, const char *const *texts, const si
     {
         const char *mt = s->map_text.data();
         const int64_t n = (int64_t)s->map_text.size();
-        int64_t b = 0;
-        int64_t row = 0;
+        int64_t b = 0, row = 0;
         while (b < n) {
             const void *nlp = memchr(mt + b, '\n', (size_t)(n - b));
             const int64_t e = nlp ? (const char *)nlp - mt : n;
@@ -120,11 +177,11 @@ extern "C" int fzp_ovl_parse(int32_t n_files, const char *const *texts, const si
             const int nt = split_line(mt, b, e, t, 5);
             if (nt < 4) { fzp_set_error("rid_phase_map row %lld has %d fields (IndexError at ovlp_filter_with_phase.py:309)", (long long)row, nt); delete s; return FZP_EINVAL; }
             std::string_view k(mt + t[0].off, (size_t)t[0].len);
-            auto it = ids.find(k);
+            auto it = s->ids.find(k);
             size_t at;
-            if (it == ids.end()) {
+            if (it == s->ids.end()) {
                 at = s->key.size();
-                ids.emplace(k, (int32_t)at);
+                s->ids.emplace(k, (int32_t)at);
                 s->key.push_back(t[0]); s->ctg.push_back(t[1]); s->blk.push_back(t[2]); s->ph.push_back(t[3]);
             } else {
                 at = (size_t)it->second;
@@ -137,6 +194,8 @@ extern "C" int fzp_ovl_parse(int32_t n_files, const char *const *texts, const si
     const size_t na = s->key.size();
     s->ctg_code.resize(na); s->blk_code.resize(na); s->ph_code.resize(na); s->lex_rank.resize(na);
     for (size_t i = 0; i < na; i++) { s->ctg_code[i] = intern(s->ctg[i]); s->blk_code[i] = intern(s->blk[i]); s->ph_code[i] = intern(s->ph[i]); }
+    bool canonical = true;
+    int64_t max_id = -1;
     {
         std::vector<int32_t> ord(na);
         for (size_t i = 0; i < na; i++) ord[i] = (int32_t)i;
@@ -145,59 +204,38 @@ extern "C" int fzp_ovl_parse(int32_t n_files, const char *const *texts, const si
             return std::string_view(mt + s->key[(size_t)a].off, (size_t)s->key[(size_t)a].len) < std::string_view(mt + s->key[(size_t)b].off, (size_t)s->key[(size_t)b].len);
         });
         for (size_t r = 0; r < na; r++) s->lex_rank[(size_t)ord[r]] = (int32_t)r;
+        for (size_t i = 0; i < na && canonical; i++) {
+            int64_t v;
+            canonical = canonical_id(mt + s->key[i].off, s->key[i].len, &v);
+            if (canonical) max_id = std::max(max_id, v);
+        }
     }
-    // ---- the dumps
+    // ---- the dumps: one buffer, every dump ending with '\n'
     size_t total = 0;
     for (int k = 0; k < n_files; k++) total += lens[k] + 1;
-    s->text.reserve(total);
-    std::vector<int64_t> file_end;
+    s->text.reserve(total + 16);
     for (int k = 0; k < n_files; k++) {
         if (lens[k]) s->text.append(texts[k], lens[k]);
         if (lens[k] && s->text.back() != '\n') s->text.push_back('\n');
-        file_end.push_back((int64_t)s->text.size());
+        s->file_end.push_back((int64_t)s->text.size());
     }
-    const char *tx = s->text.data();
-    const int64_t n = (int64_t)s->text.size();
-    int64_t b = 0;
-    int file = 0;
-    s->line_off.push_back(0);
-    while (b < n) {
-        while (file < n_files && b >= file_end[(size_t)file]) file++;
-        const void *nlp = memchr(tx + b, '\n', (size_t)(n - b));
-        const int64_t e = nlp ? (const char *)nlp - tx : n;
-        Tok t[MAXTOK];
-        const int nt = split_line(tx, b, e, t, MAXTOK);
-        const int64_t line = (int64_t)s->line_off.size() - 1;
-        if (nt < 2) { fzp_set_error("overlap line %lld has %d tokens (ValueError at ovlp_filter_with_phase.py:62)", (long long)line, nt); delete s; return FZP_EINVAL; }
-        auto iq = ids.find(std::string_view(tx + t[0].off, (size_t)t[0].len));
-        auto it = iq == ids.end() ? ids.end() : ids.find(std::string_view(tx + t[1].off, (size_t)t[1].len));
-        if (iq != ids.end() && it != ids.end()) {
-            int64_t v[7] = {0, 0, 0, 0, 0, 0, 0};
-            double idt = 0;
-            uint8_t fl = 0;
-            static const int col[7] = {2, 5, 6, 7, 9, 10, 11};
-            bool ok = nt >= 12 && nt <= MAXTOK;
-            for (int c = 0; ok && c < 7; c++) ok = parse_int32(tx + t[col[c]].off, t[col[c]].len, &v[c]);
-            if (ok) ok = parse_float(tx + t[3].off, t[3].len, &idt);
-            if (ok && -v[0] > 2147483647ll) ok = false;
-            if (ok) {
-                fl |= F_PARSE_OK;
-                if (!(idt < 90)) fl |= F_IDT_OK;
-                const std::string_view tag(tx + t[nt - 1].off, (size_t)t[nt - 1].len);
-                if (tag == "contains") fl |= F_CONTAINS;
-                if (tag == "contained") fl |= F_CONTAINED;
-            }
-            s->row_line.push_back(line);
-            s->row_file.push_back(file);
-            s->q.push_back(iq->second); s->t.push_back(it->second);
-            s->ovl.push_back((int32_t)-v[0]);
-            s->q_s.push_back((int32_t)v[1]); s->q_e.push_back((int32_t)v[2]); s->q_l.push_back((int32_t)v[3]);
-            s->t_s.push_back((int32_t)v[4]); s->t_e.push_back((int32_t)v[5]); s->t_l.push_back((int32_t)v[6]);
-            s->flags.push_back(fl);
+    if (s->text.size() >= (1ull << 32)) { fzp_set_error("fzp_ovl_parse: %zu bytes of text (limit 4 GiB per call; split the fofn)", s->text.size()); delete s; return FZP_EINVAL; }
+    hipStream_t st = ctx->stream;
+    int rc = FZP_OK;
+    if (!(rc = s->d_ctg.upload(s->ctg_code.data(), na, st)) && !(rc = s->d_blk.upload(s->blk_code.data(), na, st)) && !(rc = s->d_ph.upload(s->ph_code.data(), na, st)))
+        rc = s->d_lex.upload(s->lex_rank.data(), na, st);
+    if (!rc) {
+        const bool force_host = getenv("FZP_OVL_HOST_TOKENISER") != nullptr;
+        if (canonical && max_id <= (1 << 28) && !force_host) {      // direct table <= 1 GiB
+            std::vector<int32_t> arid_of((size_t)max_id + 2, -1);
+            const char *mt = s->map_text.data();
+            for (size_t i = 0; i < na; i++) { int64_t v = 0; canonical_id(mt + s->key[i].off, s->key[i].len, &v); arid_of[(size_t)v] = (int32_t)i; }
+            rc = ovl_tokenise_device(ctx, s, max_id, arid_of);
+        } else {
+            rc = ovl_tokenise_host(ctx, s);
         }
-        b = nlp ? e + 1 : n;
-        s->line_off.push_back(b);
     }
+    if (rc) { delete s; return rc; }
     *out = s;
     return FZP_OK;
 }
@@ -211,12 +249,254 @@ struct OvlView {
     int64_t n;
 };
 
+constexpr uint8_t F_NEED_HOST = 16;   // idt is not a plain short decimal: the host's strtod decides
+
+// K_nl: newlines per 16 bytes;  K_ls: line k+1 starts after the k-th newline
+__global__ void __launch_bounds__(256) k_ovl_nl(const uint4 *__restrict__ text16, int64_t n16, uint32_t *__restrict__ cnt) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n16) return;
+    const uint4 w = text16[j];
+    const uint32_t x[4] = {w.x, w.y, w.z, w.w};
+    uint32_t c = 0;
+#pragma unroll
+    for (int z = 0; z < 4; z++)
+#pragma unroll
+        for (int y = 0; y < 4; y++) c += ((x[z] >> (8 * y)) & 0xffu) == (uint32_t)'\n';
+    cnt[j] = c;
+}
+__global__ void __launch_bounds__(256) k_ovl_ls(const uint4 *__restrict__ text16, int64_t n16, const uint32_t *__restrict__ pos, int64_t *__restrict__ ls) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n16) return;
+    const uint4 w = text16[j];
+    const uint32_t x[4] = {w.x, w.y, w.z, w.w};
+    int64_t k = pos[j];
+#pragma unroll
+    for (int z = 0; z < 4; z++)
+#pragma unroll
+        for (int y = 0; y < 4; y++)
+            if (((x[z] >> (8 * y)) & 0xffu) == (uint32_t)'\n') ls[++k] = j * 16 + z * 4 + y + 1;
+}
+
+struct OvlCols { int32_t *q, *t, *file, *ovl, *q_s, *q_e, *q_l, *t_s, *t_e, *t_l; uint8_t *flags; };
+
+// K_tok: one thread per line -- str.split(), the two ids, int() of columns 2,5,6,7,9,10,11, float() of column 3, the tag
+__global__ void __launch_bounds__(256) k_ovl_tok(const uint8_t *__restrict__ text, const int64_t *__restrict__ ls, int64_t n_lines, const int64_t *__restrict__ file_end,
+                                                 int n_files, const int32_t *__restrict__ arid_of, int64_t max_id, OvlCols o, int32_t *__restrict__ err,
+                                                 uint32_t *__restrict__ counters /* [0] rows, [1] lines for the host */) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    bool is_row = false, need_host = false;
+    if (i < n_lines) {
+        const int64_t b = ls[i], e = ls[i + 1];
+        int tk = -1;                       // index of the current token
+        bool in_tok = false;
+        int64_t ids[2] = {-1, -1};
+        int64_t v[7] = {0, 0, 0, 0, 0, 0, 0};
+        uint32_t ok_mask = 0;              // bit c: integer column c parsed
+        // current token
+        int64_t acc = 0;
+        int nd = 0, len = 0, fd = 0, ns = 0;
+        bool neg = false, good = true, dot = false, plain = true;
+        uint8_t first = 0;
+        int64_t last_start = b;
+        int last_len = 0;
+        int f_state = 0;                   // 0 not seen, 1 decided by the device, 2 host, 3 invalid
+        bool idt_lt90 = false;
+        auto finish = [&]() {
+            if (tk == 0 || tk == 1) {
+                bool canon = good && len >= 9 && len <= 10 && (len == 9 || first != (uint8_t)'0') && acc <= max_id;
+                ids[tk] = canon ? (int64_t)arid_of[acc] : -1;
+            } else if (tk == 3) {
+                if (!plain || ns > 15 || fd > 15) f_state = 2;
+                else if (nd == 0) f_state = 3;                       // no digit at all: float() raises
+                else {
+                    f_state = 1;
+                    int64_t lim = 90;
+                    for (int z = 0; z < fd; z++) lim *= 10;
+                    idt_lt90 = neg ? true : acc < lim;
+                }
+            } else {
+                int c = tk == 2 ? 0 : (tk >= 5 && tk <= 7) ? tk - 4 : (tk >= 9 && tk <= 11) ? tk - 5 : -1;
+                if (c >= 0) {
+                    const int64_t val = neg ? -acc : acc;
+                    if (good && nd > 0 && nd <= 10 && val >= -2147483647ll && val <= 2147483647ll) { v[c] = val; ok_mask |= 1u << c; }
+                }
+            }
+            last_len = len;
+        };
+        for (int64_t p = b; p < e; p++) {
+            const uint8_t c = text[p];
+            const bool sp = c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f' || c == '\n';
+            if (sp) {
+                if (in_tok) { finish(); in_tok = false; }
+                continue;
+            }
+            if (!in_tok) {
+                in_tok = true; tk++;
+                acc = 0; nd = 0; len = 0; fd = 0; ns = 0; neg = false; good = true; dot = false; plain = true; first = c;
+                last_start = p;
+            }
+            const bool dg = c >= (uint8_t)'0' && c <= (uint8_t)'9';
+            if (tk == 3) {
+                if (dg) {
+                    if (ns > 0 || c != (uint8_t)'0') ns++;
+                    if (ns <= 17) acc = acc * 10 + (c - (uint8_t)'0');
+                    nd++;
+                    if (dot) fd++;
+                } else if (c == (uint8_t)'.' && !dot) dot = true;
+                else if ((c == (uint8_t)'+' || c == (uint8_t)'-') && len == 0) neg = c == (uint8_t)'-';
+                else plain = false;
+            } else {
+                if (dg) { if (nd < 12) acc = acc * 10 + (c - (uint8_t)'0'); nd++; }
+                else if ((c == (uint8_t)'+' || c == (uint8_t)'-') && len == 0 && tk >= 2) neg = c == (uint8_t)'-';
+                else good = false;
+                if (tk < 2 && nd > 10) good = false;
+            }
+            len++;
+        }
+        if (in_tok) finish();
+        const int nt = tk + 1;
+        if (nt < 2) atomicMin(err, (int32_t)min(i, (int64_t)0x7ffffffe));
+        uint8_t fl = 0;
+        if (nt >= 12 && nt <= MAXTOK && ok_mask == 0x7fu && (f_state == 1 || f_state == 2)) {
+            fl |= F_PARSE_OK;
+            if (f_state == 2) { fl |= F_NEED_HOST; need_host = true; }
+            else if (!idt_lt90) fl |= F_IDT_OK;
+            // tag = the last token
+            const char *t1 = "contains", *t2 = "contained";
+            bool m1 = last_len == 8, m2 = last_len == 9;
+            for (int z = 0; z < 9 && z < last_len; z++) {
+                const uint8_t c = text[last_start + z];
+                if (z < 8 && c != (uint8_t)t1[z]) m1 = false;
+                if (c != (uint8_t)t2[z]) m2 = false;
+            }
+            if (m1) fl |= F_CONTAINS;
+            if (m2) fl |= F_CONTAINED;
+        }
+        int lo = 0, hi = n_files - 1;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (file_end[mid] > b) hi = mid; else lo = mid + 1; }
+        o.q[i] = (int32_t)ids[0]; o.t[i] = (int32_t)ids[1]; o.file[i] = lo;
+        o.ovl[i] = (int32_t)-v[0];
+        o.q_s[i] = (int32_t)v[1]; o.q_e[i] = (int32_t)v[2]; o.q_l[i] = (int32_t)v[3];
+        o.t_s[i] = (int32_t)v[4]; o.t_e[i] = (int32_t)v[5]; o.t_l[i] = (int32_t)v[6];
+        o.flags[i] = fl;
+        is_row = ids[0] >= 0 && ids[1] >= 0;
+        need_host = need_host && is_row;
+    }
+    const uint64_t br = __ballot(is_row), bh = __ballot(need_host);
+    if (lane_id() == 0) {
+        if (br) atomicAdd(&counters[0], (uint32_t)__popcll(br));
+        if (bh) atomicAdd(&counters[1], (uint32_t)__popcll(bh));
+    }
+}
+
+int alloc_cols(fzp_ovlset *s, size_t n) {
+    FZP_TRY(s->d_q.alloc(n)); FZP_TRY(s->d_t.alloc(n)); FZP_TRY(s->d_file.alloc(n)); FZP_TRY(s->d_ovl.alloc(n));
+    FZP_TRY(s->d_q_s.alloc(n)); FZP_TRY(s->d_q_e.alloc(n)); FZP_TRY(s->d_q_l.alloc(n));
+    FZP_TRY(s->d_t_s.alloc(n)); FZP_TRY(s->d_t_e.alloc(n)); FZP_TRY(s->d_t_l.alloc(n)); FZP_TRY(s->d_flags.alloc(n));
+    return FZP_OK;
+}
+inline unsigned blocks_for(int64_t n, int per) { return (unsigned)std::max<int64_t>(1, (n + per - 1) / per); }
+
+int ovl_tokenise_device(fzp_ctx *ctx, fzp_ovlset *s, int64_t max_id, const std::vector<int32_t> &arid_of) {
+    hipStream_t st = ctx->stream;
+    const int64_t nb = (int64_t)s->text.size();
+    s->tokenised_on_device = true;
+    if (nb == 0) { s->n_lines = 0; s->line_off.assign(1, 0); return FZP_OK; }
+    const int64_t n16 = (nb + 15) / 16;
+    DevBuf<uint8_t> text;
+    DevBuf<uint32_t> cnt, pos, counters;
+    DevBuf<uint64_t> totals;
+    DevBuf<int64_t> ls, fend;
+    DevBuf<int32_t> d_arid, err;
+    FZP_TRY(text.alloc((size_t)n16 * 16));
+    FZP_HIP(hipMemsetAsync(text.p + (n16 - 1) * 16, 0, 16, st));
+    FZP_HIP(hipMemcpyAsync(text.p, s->text.data(), (size_t)nb, hipMemcpyHostToDevice, st));
+    FZP_TRY(cnt.alloc((size_t)n16)); FZP_TRY(pos.alloc((size_t)n16)); FZP_TRY(totals.alloc(2)); FZP_TRY(counters.alloc(2)); FZP_TRY(err.alloc(1));
+    { ProfScope ps(ctx, "ovl_lines"); hipLaunchKernelGGL(k_ovl_nl, dim3(blocks_for(n16, 256)), dim3(256), 0, st, (const uint4 *)text.p, n16, cnt.p); }
+    FZP_TRY(fzp_exclusive_scan_u32(ctx, cnt.p, pos.p, (size_t)n16, totals.p));
+    uint64_t tot = 0;
+    FZP_HIP(hipMemcpyAsync(&tot, totals.p, 8, hipMemcpyDeviceToHost, st));
+    FZP_HIP(hipStreamSynchronize(st));
+    const int64_t nl = (int64_t)tot;
+    if (nl >= (1ll << 31) - 1) { fzp_set_error("fzp_ovl_parse: %lld lines (limit 2^31 per call)", (long long)nl); return FZP_EINVAL; }
+    s->n_lines = nl;
+    FZP_TRY(ls.alloc((size_t)nl + 1));
+    FZP_HIP(hipMemsetAsync(ls.p, 0, 8, st));
+    { ProfScope ps(ctx, "ovl_lines"); hipLaunchKernelGGL(k_ovl_ls, dim3(blocks_for(n16, 256)), dim3(256), 0, st, (const uint4 *)text.p, n16, pos.p, ls.p); }
+    FZP_TRY(alloc_cols(s, (size_t)nl));
+    FZP_TRY(d_arid.upload(arid_of.data(), arid_of.size(), st));
+    FZP_TRY(fend.upload(s->file_end.data(), s->file_end.size(), st));
+    const int32_t no_err = 0x7fffffff;
+    FZP_HIP(hipMemcpyAsync(err.p, &no_err, 4, hipMemcpyHostToDevice, st));
+    FZP_HIP(hipMemsetAsync(counters.p, 0, 8, st));
+    OvlCols o = {s->d_q.p, s->d_t.p, s->d_file.p, s->d_ovl.p, s->d_q_s.p, s->d_q_e.p, s->d_q_l.p, s->d_t_s.p, s->d_t_e.p, s->d_t_l.p, s->d_flags.p};
+    { ProfScope ps(ctx, "ovl_tokenise"); hipLaunchKernelGGL(k_ovl_tok, dim3(blocks_for(nl, 256)), dim3(256), 0, st, text.p, ls.p, nl, fend.p, (int)s->file_end.size(), d_arid.p, max_id, o, err.p, counters.p); }
+    s->line_off.resize((size_t)nl + 1);
+    uint32_t h_cnt[2] = {0, 0};
+    int32_t h_err = 0;
+    FZP_TRY(ls.download(s->line_off.data(), (size_t)nl + 1, st));
+    FZP_HIP(hipMemcpyAsync(h_cnt, counters.p, 8, hipMemcpyDeviceToHost, st));
+    FZP_HIP(hipMemcpyAsync(&h_err, err.p, 4, hipMemcpyDeviceToHost, st));
+    FZP_HIP(hipStreamSynchronize(st));
+    FZP_HIP(hipGetLastError());
+    if (h_err != no_err) { fzp_set_error("overlap line %d has fewer than 2 tokens (ValueError at ovlp_filter_with_phase.py:62)", h_err); return FZP_EINVAL; }
+    s->n_rows = h_cnt[0];
+    if (h_cnt[1]) {   // idt columns the device left to strtod (exponents, nan/inf, > 15 digits)
+        std::vector<uint8_t> fl((size_t)nl);
+        FZP_TRY(s->d_flags.download(fl.data(), (size_t)nl, st));
+        FZP_HIP(hipStreamSynchronize(st));
+        Tok toks[MAXTOK];
+        for (int64_t i = 0; i < nl; i++)
+            if (fl[(size_t)i] & F_NEED_HOST) { HostLine hl; host_line(s, i, &hl, toks); fl[(size_t)i] = hl.flags; }
+        FZP_TRY(s->d_flags.upload(fl.data(), (size_t)nl, st));
+        FZP_HIP(hipStreamSynchronize(st));
+    }
+    return FZP_OK;
+}
+
+int ovl_tokenise_host(fzp_ctx *ctx, fzp_ovlset *s) {
+    hipStream_t st = ctx->stream;
+    const char *tx = s->text.data();
+    const int64_t n = (int64_t)s->text.size();
+    s->line_off.assign(1, 0);
+    for (int64_t b = 0; b < n;) {
+        const void *nlp = memchr(tx + b, '\n', (size_t)(n - b));
+        b = nlp ? ((const char *)nlp - tx) + 1 : n;
+        s->line_off.push_back(b);
+    }
+    const int64_t nl = (int64_t)s->line_off.size() - 1;
+    if (nl >= (1ll << 31) - 1) { fzp_set_error("fzp_ovl_parse: %lld lines (limit 2^31 per call)", (long long)nl); return FZP_EINVAL; }
+    s->n_lines = nl;
+    std::vector<int32_t> q((size_t)nl), t((size_t)nl), file((size_t)nl), col[7];
+    for (auto &c : col) c.resize((size_t)nl);
+    std::vector<uint8_t> fl((size_t)nl);
+    Tok toks[MAXTOK];
+    int f = 0;
+    for (int64_t i = 0; i < nl; i++) {
+        HostLine hl;
+        if (!host_line(s, i, &hl, toks)) { fzp_set_error("overlap line %lld has fewer than 2 tokens (ValueError at ovlp_filter_with_phase.py:62)", (long long)i); return FZP_EINVAL; }
+        while (f + 1 < (int)s->file_end.size() && s->line_off[(size_t)i] >= s->file_end[(size_t)f]) f++;
+        q[(size_t)i] = hl.q; t[(size_t)i] = hl.t; file[(size_t)i] = f; fl[(size_t)i] = hl.flags;
+        col[0][(size_t)i] = (int32_t)-hl.v[0];
+        for (int c = 1; c < 7; c++) col[c][(size_t)i] = (int32_t)hl.v[c];
+        s->n_rows += hl.q >= 0 && hl.t >= 0;
+    }
+    if (nl) {
+        FZP_TRY(s->d_q.upload(q.data(), (size_t)nl, st)); FZP_TRY(s->d_t.upload(t.data(), (size_t)nl, st)); FZP_TRY(s->d_file.upload(file.data(), (size_t)nl, st));
+        FZP_TRY(s->d_ovl.upload(col[0].data(), (size_t)nl, st)); FZP_TRY(s->d_q_s.upload(col[1].data(), (size_t)nl, st)); FZP_TRY(s->d_q_e.upload(col[2].data(), (size_t)nl, st));
+        FZP_TRY(s->d_q_l.upload(col[3].data(), (size_t)nl, st)); FZP_TRY(s->d_t_s.upload(col[4].data(), (size_t)nl, st)); FZP_TRY(s->d_t_e.upload(col[5].data(), (size_t)nl, st));
+        FZP_TRY(s->d_t_l.upload(col[6].data(), (size_t)nl, st)); FZP_TRY(s->d_flags.upload(fl.data(), (size_t)nl, st));
+        FZP_HIP(hipStreamSynchronize(st));
+    }
+    return FZP_OK;
+}
+
 // K_pre: the four checks every stage starts with (:64-73)
 __global__ void __launch_bounds__(256) k_ovl_pre(OvlView v, uint32_t *__restrict__ pre, int32_t *__restrict__ err) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= v.n) return;
     const int32_t q = v.q[i], t = v.t[i];
-    const bool keep = v.ctg[q] == v.ctg[t] && !(v.blk[q] == v.blk[t] && v.ph[q] != v.ph[t]);
+    const bool keep = q >= 0 && t >= 0 && v.ctg[q] == v.ctg[t] && !(v.blk[q] == v.blk[t] && v.ph[q] != v.ph[t]);
     pre[i] = keep ? 1u : 0u;
     if (keep && !(v.flags[i] & F_PARSE_OK)) atomicMin(err, (int32_t)min(i, (int64_t)0x7ffffffe));
 }
@@ -354,7 +634,6 @@ __global__ void __launch_bounds__(256) k_ovl_gid(int64_t np, const uint32_t *__r
     const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (k < np) gid[k] = hscan[k] + head[k] - 1u;     // inclusive scan - 1
 }
-inline unsigned blocks_for(int64_t n, int per) { return (unsigned)std::max<int64_t>(1, (n + per - 1) / per); }
 }  // namespace
 
 extern "C" int fzp_ovl_filter(fzp_ctx *ctx, const fzp_ovlset *s, const fzp_ovlp_params *pr, int64_t **rows_out, int64_t *n_rows_out, int32_t **ignore_out,
@@ -365,9 +644,8 @@ extern "C" int fzp_ovl_filter(fzp_ctx *ctx, const fzp_ovlset *s, const fzp_ovlp_
     if (contained_out) { *contained_out = nullptr; if (n_contained) *n_contained = 0; }
     FZP_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    const int64_t n = (int64_t)s->row_line.size();
+    const int64_t n = s->n_lines;
     const size_t na = s->key.size();
-    if (n >= (1ll << 31)) { fzp_set_error("fzp_ovl_filter: %lld rows (limit 2^31 per call)", (long long)n); return FZP_EINVAL; }
     const int32_t min_len = (int32_t)std::max<int64_t>(-2147483647ll, std::min<int64_t>(pr->min_len, 2147483647ll));
     std::vector<uint8_t> h_ignore(na + 1, 0), h_contained(na + 1, 0);
     std::vector<int32_t> h_out;
@@ -376,17 +654,12 @@ extern "C" int fzp_ovl_filter(fzp_ctx *ctx, const fzp_ovlset *s, const fzp_ovlp_
     std::vector<uint8_t> h_tie;
     int64_t np = 0, ng = 0;
     if (n > 0) {
-        DevBuf<int32_t> q, t, file, ovl, q_s, q_e, q_l, t_s, t_e, t_l, ctg, blk, ph, lex, P, gstart, rank, out, err;
-        DevBuf<uint8_t> flags, ignore, contained, tie;
+        DevBuf<int32_t> P, gstart, rank, out, err;
+        DevBuf<uint8_t> ignore, contained, tie;
         DevBuf<uint32_t> pre, pos, head, hscan, gid, cnt, off;
         DevBuf<uint64_t> totals;
-        FZP_TRY(q.upload(s->q.data(), (size_t)n, st)); FZP_TRY(t.upload(s->t.data(), (size_t)n, st)); FZP_TRY(file.upload(s->row_file.data(), (size_t)n, st));
-        FZP_TRY(ovl.upload(s->ovl.data(), (size_t)n, st)); FZP_TRY(q_s.upload(s->q_s.data(), (size_t)n, st)); FZP_TRY(q_e.upload(s->q_e.data(), (size_t)n, st));
-        FZP_TRY(q_l.upload(s->q_l.data(), (size_t)n, st)); FZP_TRY(t_s.upload(s->t_s.data(), (size_t)n, st)); FZP_TRY(t_e.upload(s->t_e.data(), (size_t)n, st));
-        FZP_TRY(t_l.upload(s->t_l.data(), (size_t)n, st)); FZP_TRY(flags.upload(s->flags.data(), (size_t)n, st));
-        FZP_TRY(ctg.upload(s->ctg_code.data(), na, st)); FZP_TRY(blk.upload(s->blk_code.data(), na, st)); FZP_TRY(ph.upload(s->ph_code.data(), na, st));
-        FZP_TRY(lex.upload(s->lex_rank.data(), na, st));
-        OvlView v = {q.p, t.p, file.p, ovl.p, q_s.p, q_e.p, q_l.p, t_s.p, t_e.p, t_l.p, flags.p, ctg.p, blk.p, ph.p, lex.p, n};
+        OvlView v = {s->d_q.p, s->d_t.p, s->d_file.p, s->d_ovl.p, s->d_q_s.p, s->d_q_e.p, s->d_q_l.p, s->d_t_s.p, s->d_t_e.p, s->d_t_l.p, s->d_flags.p,
+                     s->d_ctg.p, s->d_blk.p, s->d_ph.p, s->d_lex.p, n};
         FZP_TRY(pre.alloc((size_t)n)); FZP_TRY(pos.alloc((size_t)n)); FZP_TRY(err.alloc(1)); FZP_TRY(totals.alloc(4));
         const int32_t no_err = 0x7fffffff;
         FZP_HIP(hipMemcpyAsync(err.p, &no_err, 4, hipMemcpyHostToDevice, st));
@@ -398,8 +671,7 @@ extern "C" int fzp_ovl_filter(fzp_ctx *ctx, const fzp_ovlset *s, const fzp_ovlp_
         FZP_HIP(hipMemcpyAsync(&h_err, err.p, 4, hipMemcpyDeviceToHost, st));
         FZP_HIP(hipStreamSynchronize(st));
         if (h_err != no_err) {
-            fzp_set_error("overlap line %lld passes the phase checks but has a field int()/float() would reject (ValueError/IndexError in filter_stage1) or an integer beyond 32 bits",
-                          (long long)s->row_line[(size_t)h_err]);
+            fzp_set_error("overlap line %d passes the phase checks but has a field int()/float() would reject (ValueError/IndexError in filter_stage1) or an integer beyond 32 bits", h_err);
             return FZP_EINVAL;
         }
         np = (int64_t)tot;
@@ -448,12 +720,14 @@ extern "C" int fzp_ovl_filter(fzp_ctx *ctx, const fzp_ovlset *s, const fzp_ovlp_
     // ---- lists that tie on (numeric key, partner): the reference falls through to comparing the token lists (:218-219)
     if (!h_P.empty()) {
         const char *tx = s->text.data();
-        auto cand = [&](int32_t i) -> int {
-            const int32_t q = s->q[(size_t)i], t = s->t[(size_t)i];
+        Tok toks[MAXTOK];
+        auto cand = [&](int32_t i, HostLine *hl) -> int {
+            host_line(s, i, hl, toks);
+            const int32_t q = hl->q, t = hl->t;
             if (h_contained[(size_t)q] || h_contained[(size_t)t] || h_ignore[(size_t)q] || h_ignore[(size_t)t]) return -1;
-            if (!(s->flags[(size_t)i] & F_IDT_OK) || s->q_l[(size_t)i] < min_len || s->t_l[(size_t)i] < min_len) return -1;
-            if (s->q_s[(size_t)i] == 0) return 0;
-            if (s->q_e[(size_t)i] == s->q_l[(size_t)i]) return 1;
+            if (!(hl->flags & F_IDT_OK) || hl->v[3] < min_len || hl->v[6] < min_len) return -1;
+            if (hl->v[1] == 0) return 0;
+            if (hl->v[2] == hl->v[3]) return 1;
             return -1;
         };
         struct HC { int32_t ninph, negovl, m_range, row; int64_t seq; };
@@ -463,17 +737,18 @@ extern "C" int fzp_ovl_filter(fzp_ctx *ctx, const fzp_ovlset *s, const fzp_ovlp_
                 std::vector<HC> c;
                 for (int32_t k = h_gstart[(size_t)g]; k < h_gstart[(size_t)g + 1]; k++) {
                     const int32_t i = h_P[(size_t)k];
-                    if (cand(i) != e) continue;
-                    const int32_t q = s->q[(size_t)i], t = s->t[(size_t)i];
+                    HostLine hl;
+                    if (cand(i, &hl) != e) continue;
+                    const int32_t q = hl.q, t = hl.t;
                     const bool inph = s->ctg_code[(size_t)q] == s->ctg_code[(size_t)t] && s->blk_code[(size_t)q] == s->blk_code[(size_t)t] && s->ph_code[(size_t)q] == s->ph_code[(size_t)t];
-                    c.push_back({inph ? 0 : 1, -s->ovl[(size_t)i], s->t_l[(size_t)i] - (s->t_e[(size_t)i] - s->t_s[(size_t)i]), i, (int64_t)k});
+                    c.push_back({inph ? 0 : 1, (int32_t)hl.v[0], (int32_t)(hl.v[6] - (hl.v[5] - hl.v[4])), i, (int64_t)k});
                 }
                 std::stable_sort(c.begin(), c.end(), [&](const HC &a, const HC &b) {
                     if (a.ninph != b.ninph) return a.ninph < b.ninph;
                     if (a.negovl != b.negovl) return a.negovl < b.negovl;
                     if (a.m_range != b.m_range) return a.m_range < b.m_range;
                     Tok ta[MAXTOK], tb[MAXTOK];
-                    const int64_t la = s->row_line[(size_t)a.row], lb = s->row_line[(size_t)b.row];
+                    const int64_t la = a.row, lb = b.row;
                     const int na_ = split_line(tx, s->line_off[(size_t)la], s->line_off[(size_t)la + 1], ta, MAXTOK);
                     const int nb_ = split_line(tx, s->line_off[(size_t)lb], s->line_off[(size_t)lb + 1], tb, MAXTOK);
                     for (int z = 0; z < std::min(na_, nb_); z++) {
@@ -489,7 +764,7 @@ extern "C" int fzp_ovl_filter(fzp_ctx *ctx, const fzp_ovlset *s, const fzp_ovlp_
     // ---- results
     int64_t *rows = (int64_t *)malloc((h_out.size() ? h_out.size() : 1) * sizeof(int64_t));
     if (!rows) return FZP_ENOMEM;
-    for (size_t z = 0; z < h_out.size(); z++) rows[z] = s->row_line[(size_t)h_out[z]];
+    for (size_t z = 0; z < h_out.size(); z++) rows[z] = h_out[z];
     *rows_out = rows; *n_rows_out = (int64_t)h_out.size();
     auto list = [&](const std::vector<uint8_t> &f, int32_t **o, int64_t *no) -> int {
         if (!o) return FZP_OK;
@@ -512,16 +787,13 @@ extern "C" int fzp_ovl_format(const fzp_ovlset *s, const int64_t *rows, int64_t 
     if (!s || (!rows && n_rows) || !text || !len || n_rows < 0) { fzp_set_error("fzp_ovl_format: bad arguments"); return FZP_EINVAL; }
     std::string out;
     const char *tx = s->text.data(), *mt = s->map_text.data();
-    // line -> row (for the ids of the line): rows are ascending by line
+    Tok t[MAXTOK];
     for (int64_t z = 0; z < n_rows; z++) {
         const int64_t line = rows[z];
-        auto it = std::lower_bound(s->row_line.begin(), s->row_line.end(), line);
-        if (line < 0 || it == s->row_line.end() || *it != line) { fzp_set_error("fzp_ovl_format: line %lld is not a filterable row", (long long)line); return FZP_EINVAL; }
-        const size_t r = (size_t)(it - s->row_line.begin());
-        Tok t[MAXTOK];
-        const int nt = split_line(tx, s->line_off[(size_t)line], s->line_off[(size_t)line + 1], t, MAXTOK);
-        for (int k = 0; k < nt && k < MAXTOK; k++) { if (k) out.push_back(' '); out.append(tx + t[k].off, (size_t)t[k].len); }
-        const int32_t ids[2] = {s->q[r], s->t[r]};
+        HostLine hl;
+        if (line < 0 || line >= s->n_lines || !host_line(s, line, &hl, t) || hl.q < 0 || hl.t < 0) { fzp_set_error("fzp_ovl_format: line %lld is not a filterable row", (long long)line); return FZP_EINVAL; }
+        for (int k = 0; k < hl.nt && k < MAXTOK; k++) { if (k) out.push_back(' '); out.append(tx + t[k].off, (size_t)t[k].len); }
+        const int32_t ids[2] = {hl.q, hl.t};
         for (int k = 0; k < 2; k++) {
             const size_t a = (size_t)ids[k];
             out.push_back(' ');

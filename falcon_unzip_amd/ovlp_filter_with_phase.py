@@ -44,7 +44,7 @@ def filter_dumps(files, rid_map, max_diff, max_cov, min_cov, min_len=2500, bestn
         if device is None:
             device = int(os.environ.get("FZP_DEVICE", os.environ.get("LOCAL_RANK", "0")))
         eng = _lib.Engine(device)
-    ovl = _lib.OvlSet(files, rid_map)
+    ovl = _lib.OvlSet(eng, files, rid_map)
     try:
         rows, _, _ = _lib.ovl_filter(eng, ovl, max_diff, max_cov, min_cov, min_len, bestn)
         return ovl.format(rows)

@@ -260,12 +260,14 @@ typedef struct {
     int64_t bestn;      /* --bestn     :289 (default 10) */
 } fzp_ovlp_params;
 typedef struct fzp_ovlset fzp_ovlset;
-/* Tokenise the dumps of n_files .las files (in fofn order) and the rid_to_phase.all map (main :306-309: later rows
- * overwrite earlier ones; ids, contigs, blocks and phases are compared as strings).  The texts are copied.
+/* Tokenise the dumps of n_files .las files (in fofn order) -- on the device: the text goes to HBM once and one thread
+ * per line does str.split(), the id look-ups and int()/float() -- and read the rid_to_phase.all map (main :306-309:
+ * later rows overwrite earlier ones; ids, contigs, blocks and phases are compared as strings).  The texts are copied;
+ * the parsed columns stay resident in HBM inside the ovlset.  At most 4 GiB of text / 2^31 lines per call.
  * FZP_EINVAL where the reference would raise while reading (a line with fewer than 2 tokens, a map row with fewer
  * than 4). */
-int fzp_ovl_parse(int32_t n_files, const char *const *texts, const size_t *lens, const char *rid_map, size_t map_len,
-                  fzp_ovlset **out);
+int fzp_ovl_parse(fzp_ctx *ctx, int32_t n_files, const char *const *texts, const size_t *lens, const char *rid_map,
+                  size_t map_len, fzp_ovlset **out);
 void fzp_ovlset_free(fzp_ovlset *s);
 int64_t fzp_ovl_n_lines(const fzp_ovlset *s);   /* input lines */
 int64_t fzp_ovl_n_rows(const fzp_ovlset *s);    /* lines whose q_id and t_id are both in the map (the rest never matter) */
