@@ -116,6 +116,8 @@ def load():
         "fzp_align_alnset": (C.c_int, [VP, VP, I32, VP, CP, PP, PP]),
         "fzp_align_to_batch": (C.c_int, [VP, VP, PP]),
         "fzp_align_destroy": (None, [VP, VP]),
+        "fzp_format_bam": (C.c_int, [VP, CP, I64, VP, PP, PSZ, PP, PSZ]),
+        "fzp_bam_to_sam": (C.c_int, [CP, SZ, CP, PP, PSZ]),
         "fzp_ovl_parse": (C.c_int, [VP, I32, VP, VP, CP, SZ, PP]),
         "fzp_ovlset_free": (None, [VP]),
         "fzp_ovl_n_lines": (I64, [VP]),
@@ -517,6 +519,22 @@ def readmap(phased_reads: bytes, rawread_ids: bytes, pread_ids: bytes, pread_to_
                            C.c_size_t(len(pread_ids)), pread_to_contigs, C.c_size_t(len(pread_to_contigs)), ctg_id.encode(),
                            C.c_int32(ctg_index), C.byref(rp), C.byref(nr), C.byref(tp), C.byref(tn)))
     return _take(rp.value, nr.value, R2P), _take_text(tp, tn)
+
+
+def format_bam(aln: AlnSet, ctg_id: str, ctg_len: int, flags=None, with_index=True):
+    """Coordinate-sorted BAM of an alnset (+ its .bai) -> (bam bytes, bai bytes or None)."""
+    lib = load()
+    fl = None if flags is None else np.ascontiguousarray(flags, dtype=np.int32)
+    b, nb, x, nx = C.c_void_p(), C.c_size_t(), C.c_void_p(), C.c_size_t()
+    _check(lib.fzp_format_bam(C.c_void_p(aln._p), ctg_id.encode(), C.c_int64(int(ctg_len)), None if fl is None else _ptr(fl), C.byref(b), C.byref(nb),
+                              C.byref(x) if with_index else None, C.byref(nx) if with_index else None))
+    bam = _take_text(b, nb)
+    return bam, (_take_text(x, nx) if with_index else None)
+
+
+def bam_to_sam(bam: bytes, region=None):
+    """`samtools view <bam> [region]` without samtools: SAM text lines (11 mandatory columns)."""
+    return _fmt("fzp_bam_to_sam", bam, C.c_size_t(len(bam)), None if region is None else region.encode())
 
 
 # ---------------------------------------------------------------------------- overlap filter (fzp_ovl_*)

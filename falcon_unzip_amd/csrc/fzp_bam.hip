@@ -1,0 +1,284 @@
+// fzp_bam.hip -- BAM / BGZF / BAI emitter and reader (host code).
+//
+// The reference's blasr task leaves `<ctg>_sorted.bam` + index behind (unzip.py:86-91) and make_het_call reads it back
+// through `samtools view <bam> <ctg>` (phasing.py:27,42-59).  K1 hands its records to K2 without leaving HBM, so these
+// files are only for users who want the alignments -- but they should exist and be real BAM: fzp_format_bam writes a
+// coordinate-sorted BAM (BGZF blocks <= 64 KiB, EOF marker) and its .bai (binning + 16 kb linear index); fzp_bam_to_sam
+// is the `samtools view [region]` role for installations without samtools (text lines of the 11 mandatory columns).
+// Formats per the SAM/BAM specification (SAMv1 sections 4.1, 4.2, 5.2); zlib does the deflate.
+#include <zlib.h>
+#include <algorithm>
+#include "fzp_common.h"
+
+namespace {
+struct Bytes {
+    std::vector<uint8_t> v;
+    void u8(uint8_t x) { v.push_back(x); }
+    void u16(uint16_t x) { v.push_back((uint8_t)x); v.push_back((uint8_t)(x >> 8)); }
+    void u32(uint32_t x) { for (int i = 0; i < 4; i++) v.push_back((uint8_t)(x >> (8 * i))); }
+    void i32(int32_t x) { u32((uint32_t)x); }
+    void u64(uint64_t x) { for (int i = 0; i < 8; i++) v.push_back((uint8_t)(x >> (8 * i))); }
+    void raw(const void *p, size_t n) { const uint8_t *b = (const uint8_t *)p; v.insert(v.end(), b, b + n); }
+};
+
+// SAMv1 5.3: bin of a zero-based half-open interval
+inline int reg2bin(int64_t beg, int64_t end) {
+    --end;
+    if (beg >> 14 == end >> 14) return (int)(((1 << 15) - 1) / 7 + (beg >> 14));
+    if (beg >> 17 == end >> 17) return (int)(((1 << 12) - 1) / 7 + (beg >> 17));
+    if (beg >> 20 == end >> 20) return (int)(((1 << 9) - 1) / 7 + (beg >> 20));
+    if (beg >> 23 == end >> 23) return (int)(((1 << 6) - 1) / 7 + (beg >> 23));
+    if (beg >> 26 == end >> 26) return (int)(((1 << 3) - 1) / 7 + (beg >> 26));
+    return 0;
+}
+
+struct Bgzf {
+    Bytes out;
+    std::vector<uint8_t> pend;            // uncompressed bytes of the block being filled
+    static constexpr size_t BLOCK = 0xff00;
+    uint64_t tell() const { return ((uint64_t)out.v.size() << 16) | (uint64_t)pend.size(); }
+    int flush() {
+        if (pend.empty()) return FZP_OK;
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        if (deflateInit2(&zs, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { fzp_set_error("deflateInit2 failed"); return FZP_ENOMEM; }
+        std::vector<uint8_t> comp(deflateBound(&zs, (uLong)pend.size()) + 16);
+        zs.next_in = pend.data(); zs.avail_in = (uInt)pend.size();
+        zs.next_out = comp.data(); zs.avail_out = (uInt)comp.size();
+        const int rc = deflate(&zs, Z_FINISH);
+        const size_t clen = comp.size() - zs.avail_out;
+        deflateEnd(&zs);
+        if (rc != Z_STREAM_END || clen + 26 > 65536) { fzp_set_error("BGZF block does not fit (%zu compressed bytes)", clen); return FZP_EINVAL; }
+        static const uint8_t hdr[12] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0};
+        out.raw(hdr, 12);
+        out.u8('B'); out.u8('C'); out.u16(2); out.u16((uint16_t)(clen + 25));      // BSIZE = block size - 1
+        out.raw(comp.data(), clen);
+        out.u32((uint32_t)crc32(crc32(0L, Z_NULL, 0), pend.data(), (uInt)pend.size()));
+        out.u32((uint32_t)pend.size());
+        pend.clear();
+        return FZP_OK;
+    }
+    int write(const void *p, size_t n) {
+        const uint8_t *b = (const uint8_t *)p;
+        while (n) {
+            const size_t k = std::min(n, BLOCK - pend.size());
+            pend.insert(pend.end(), b, b + k);
+            b += k; n -= k;
+            if (pend.size() == BLOCK) FZP_TRY(flush());
+        }
+        return FZP_OK;
+    }
+    int finish() {
+        FZP_TRY(flush());
+        static const uint8_t eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        out.raw(eof, 28);
+        return FZP_OK;
+    }
+};
+
+inline uint8_t nib(uint8_t c) {
+    switch (c) {
+        case 'A': case 'a': return 1;
+        case 'C': case 'c': return 2;
+        case 'G': case 'g': return 4;
+        case 'T': case 't': return 8;
+        case '=': return 0;
+        default: return 15;
+    }
+}
+int give(const std::vector<uint8_t> &v, uint8_t **out, size_t *len) {
+    uint8_t *p = (uint8_t *)malloc(v.size() ? v.size() : 1);
+    if (!p) return FZP_ENOMEM;
+    if (!v.empty()) memcpy(p, v.data(), v.size());
+    *out = p; *len = v.size();
+    return FZP_OK;
+}
+}  // namespace
+
+extern "C" int fzp_format_bam(const fzp_alnset *a, const char *ctg_id, int64_t ctg_len, const int32_t *flags, uint8_t **bam, size_t *bam_len, uint8_t **bai,
+                              size_t *bai_len) {
+    if (!a || !ctg_id || !bam || !bam_len || ctg_len < 0 || ctg_len > 0x7fffffff) { fzp_set_error("fzp_format_bam: bad arguments"); return FZP_EINVAL; }
+    Bgzf z;
+    {   // header
+        Bytes h;
+        char text[512];
+        const int tl = snprintf(text, sizeof text, "@HD\tVN:1.5\tSO:coordinate\n@SQ\tSN:%s\tLN:%lld\n@PG\tID:fzphase\tPN:fzphase\n", ctg_id, (long long)ctg_len);
+        if (tl <= 0 || tl >= (int)sizeof text) { fzp_set_error("contig id too long for the BAM header"); return FZP_EINVAL; }
+        h.raw("BAM\1", 4); h.i32(tl); h.raw(text, (size_t)tl);
+        h.i32(1); h.i32((int32_t)strlen(ctg_id) + 1); h.raw(ctg_id, strlen(ctg_id) + 1); h.i32((int32_t)ctg_len);
+        FZP_TRY(z.write(h.v.data(), h.v.size()));
+    }
+    // index state (one reference)
+    std::map<uint32_t, std::vector<std::pair<uint64_t, uint64_t>>> bins;
+    std::vector<uint64_t> linear;
+    uint64_t first_off = 0, last_off = 0;
+    int64_t n_mapped = 0;
+    int32_t prev_pos = -1;
+    for (int64_t r = 0; r < a->n_rec; r++) {
+        const int32_t q = a->rec_qid[r];
+        const size_t nl = (size_t)(a->qname_off[q + 1] - a->qname_off[q]);
+        const int64_t sl = a->seq_off[r + 1] - a->seq_off[r];
+        const int64_t nc = a->cig_off[r + 1] - a->cig_off[r];
+        const int32_t pos = a->rec_pos[r];
+        if (nl + 1 > 255 || nc > 65535 || pos < prev_pos) { fzp_set_error("record %lld: name longer than 254, more than 65535 CIGAR ops, or not coordinate-sorted", (long long)r); return FZP_EINVAL; }
+        prev_pos = pos;
+        int64_t rlen = 0;
+        for (int64_t k = a->cig_off[r]; k < a->cig_off[r + 1]; k++) {
+            const uint32_t op = a->cigar[k] & 15u;
+            if (op == FZP_OP_M || op == FZP_OP_D || op == FZP_OP_N || op == FZP_OP_EQ || op == FZP_OP_X) rlen += a->cigar[k] >> 4;
+        }
+        const int64_t end = pos + (rlen > 0 ? rlen : 1);
+        const int bin = reg2bin(pos, end);
+        Bytes rec;
+        rec.i32(0);                                   // block_size, patched below
+        rec.i32(0); rec.i32(pos);
+        rec.u8((uint8_t)(nl + 1)); rec.u8(254); rec.u16((uint16_t)bin); rec.u16((uint16_t)nc); rec.u16((uint16_t)(flags ? flags[r] : 0));
+        rec.i32((int32_t)sl); rec.i32(-1); rec.i32(-1); rec.i32(0);
+        rec.raw(a->qnames + a->qname_off[q], nl); rec.u8(0);
+        for (int64_t k = a->cig_off[r]; k < a->cig_off[r + 1]; k++) rec.u32(a->cigar[k]);
+        const uint8_t *sq = a->seq + a->seq_off[r];
+        for (int64_t k = 0; k < sl; k += 2) rec.u8((uint8_t)((nib(sq[k]) << 4) | (k + 1 < sl ? nib(sq[k + 1]) : 0)));
+        for (int64_t k = 0; k < sl; k++) rec.u8(0xff);
+        const uint32_t bs = (uint32_t)rec.v.size() - 4;
+        for (int i = 0; i < 4; i++) rec.v[(size_t)i] = (uint8_t)(bs >> (8 * i));
+        const uint64_t v0 = z.tell();
+        FZP_TRY(z.write(rec.v.data(), rec.v.size()));
+        const uint64_t v1 = z.tell();
+        // index: chunk list per bin (adjacent records of a bin merge), linear index per 16 kb window
+        auto &ch = bins[(uint32_t)bin];
+        if (!ch.empty() && ch.back().second == v0) ch.back().second = v1; else ch.push_back({v0, v1});
+        for (int64_t w = pos >> 14; w <= (end - 1) >> 14; w++) {
+            if ((size_t)w >= linear.size()) linear.resize((size_t)w + 1, 0);
+            if (linear[(size_t)w] == 0) linear[(size_t)w] = v0;
+        }
+        if (n_mapped == 0) first_off = v0;
+        last_off = v1;
+        n_mapped++;
+    }
+    FZP_TRY(z.finish());
+    FZP_TRY(give(z.out.v, bam, bam_len));
+    if (bai && bai_len) {
+        // a record's virtual offset recorded while its block was still open stays valid: the block's file offset is
+        // fixed at that moment (blocks are emitted in order), only a write that exactly fills a block moves `tell()`
+        // to the next block's start -- equally valid as an end offset.
+        Bytes ix;
+        ix.raw("BAI\1", 4); ix.i32(1);
+        ix.i32((int32_t)bins.size() + (n_mapped ? 1 : 0));
+        for (auto &kv : bins) {
+            ix.u32(kv.first); ix.i32((int32_t)kv.second.size());
+            for (auto &c : kv.second) { ix.u64(c.first); ix.u64(c.second); }
+        }
+        if (n_mapped) {   // samtools' metadata pseudo-bin
+            ix.u32(37450); ix.i32(2); ix.u64(first_off); ix.u64(last_off); ix.u64((uint64_t)n_mapped); ix.u64(0);
+        }
+        for (size_t w = linear.size(); w-- > 1;) if (linear[w - 1] == 0) linear[w - 1] = linear[w];   // empty windows take the next one's offset (htslib)
+        ix.i32((int32_t)linear.size());
+        for (uint64_t x : linear) ix.u64(x);
+        ix.u64(0);                                    // n_no_coor
+        int rc = give(ix.v, bai, bai_len);
+        if (rc) { free(*bam); *bam = nullptr; return rc; }
+    }
+    return FZP_OK;
+}
+
+// `samtools view <bam> [region]`: one text line per record (11 mandatory columns, optional fields dropped -- the
+// phasing code reads columns 0, 1, 2, 3, 5, 9 only, phasing.py:47-59).  region: NULL = every record, else RNAME.
+extern "C" int fzp_bam_to_sam(const uint8_t *bam, size_t len, const char *region, char **text, size_t *text_len) {
+    if ((!bam && len) || !text || !text_len) { fzp_set_error("fzp_bam_to_sam: bad arguments"); return FZP_EINVAL; }
+    // ---- BGZF -> one byte stream
+    std::vector<uint8_t> d;
+    size_t p = 0;
+    while (p < len) {
+        if (len - p < 18 || bam[p] != 0x1f || bam[p + 1] != 0x8b || bam[p + 2] != 8 || !(bam[p + 3] & 4)) { fzp_set_error("not a BGZF block at offset %zu", p); return FZP_EINVAL; }
+        const size_t xlen = bam[p + 10] | (bam[p + 11] << 8);
+        size_t bsize = 0;
+        for (size_t x = p + 12; x + 4 <= p + 12 + xlen && x + 4 <= len;) {
+            const size_t slen = bam[x + 2] | (bam[x + 3] << 8);
+            if (bam[x] == 'B' && bam[x + 1] == 'C' && slen == 2 && x + 6 <= len) bsize = (size_t)(bam[x + 4] | (bam[x + 5] << 8)) + 1;
+            x += 4 + slen;
+        }
+        if (!bsize || p + bsize > len || bsize < 12 + xlen + 8) { fzp_set_error("truncated BGZF block at offset %zu", p); return FZP_EINVAL; }
+        const uint8_t *cd = bam + p + 12 + xlen;
+        const size_t clen = bsize - 12 - xlen - 8;
+        const uint8_t *tail = bam + p + bsize - 8;
+        const uint32_t crc = tail[0] | (tail[1] << 8) | (tail[2] << 16) | ((uint32_t)tail[3] << 24);
+        const uint32_t isize = tail[4] | (tail[5] << 8) | (tail[6] << 16) | ((uint32_t)tail[7] << 24);
+        if (isize) {
+            const size_t at = d.size();
+            d.resize(at + isize);
+            z_stream zs;
+            memset(&zs, 0, sizeof zs);
+            if (inflateInit2(&zs, -15) != Z_OK) { fzp_set_error("inflateInit2 failed"); return FZP_ENOMEM; }
+            zs.next_in = (Bytef *)cd; zs.avail_in = (uInt)clen;
+            zs.next_out = d.data() + at; zs.avail_out = isize;
+            const int rc = inflate(&zs, Z_FINISH);
+            inflateEnd(&zs);
+            if (rc != Z_STREAM_END || zs.avail_out != 0 || (uint32_t)crc32(crc32(0L, Z_NULL, 0), d.data() + at, isize) != crc) { fzp_set_error("corrupt BGZF block at offset %zu", p); return FZP_EINVAL; }
+        }
+        p += bsize;
+    }
+    // ---- BAM
+    auto rd32 = [&](size_t o) { return (int32_t)(d[o] | (d[o + 1] << 8) | (d[o + 2] << 16) | ((uint32_t)d[o + 3] << 24)); };
+    if (d.size() < 12 || memcmp(d.data(), "BAM\1", 4) != 0) { fzp_set_error("not a BAM stream"); return FZP_EINVAL; }
+    size_t o = 4;
+    const int32_t l_text = rd32(o); o += 4;
+    if (l_text < 0 || o + (size_t)l_text + 4 > d.size()) { fzp_set_error("truncated BAM header"); return FZP_EINVAL; }
+    o += (size_t)l_text;
+    const int32_t n_ref = rd32(o); o += 4;
+    std::vector<std::string> names;
+    for (int32_t i = 0; i < n_ref; i++) {
+        if (o + 4 > d.size()) { fzp_set_error("truncated BAM reference list"); return FZP_EINVAL; }
+        const int32_t ln = rd32(o); o += 4;
+        if (ln < 1 || o + (size_t)ln + 4 > d.size()) { fzp_set_error("truncated BAM reference list"); return FZP_EINVAL; }
+        names.emplace_back((const char *)d.data() + o, (size_t)ln - 1);
+        o += (size_t)ln + 4;
+    }
+    int32_t want = -2;                                  // -2: all
+    if (region && *region) {
+        want = -3;                                      // named but absent: nothing matches
+        for (int32_t i = 0; i < n_ref; i++) if (names[(size_t)i] == region) want = i;
+    }
+    std::string out;
+    static const char OPS[] = "MIDNSHP=X???????";
+    static const char NIB[] = "=ACMGRSVTWYHKDBN";
+    char num[32];
+    while (o + 4 <= d.size()) {
+        const int32_t bs = rd32(o); o += 4;
+        if (bs < 32 || o + (size_t)bs > d.size()) { fzp_set_error("truncated BAM record"); return FZP_EINVAL; }
+        const size_t r0 = o;
+        o += (size_t)bs;
+        const int32_t ref = rd32(r0), pos = rd32(r0 + 4);
+        const uint32_t l_name = d[r0 + 8], mapq = d[r0 + 9];
+        const uint32_t n_cig = d[r0 + 12] | (d[r0 + 13] << 8), flag = d[r0 + 14] | (d[r0 + 15] << 8);
+        const int32_t l_seq = rd32(r0 + 16), nref = rd32(r0 + 20), npos = rd32(r0 + 24), tlen = rd32(r0 + 28);
+        if (l_seq < 0 || 32 + (size_t)l_name + 4 * (size_t)n_cig + ((size_t)l_seq + 1) / 2 + (size_t)l_seq > (size_t)bs || l_name < 1) { fzp_set_error("malformed BAM record"); return FZP_EINVAL; }
+        if (want != -2 && ref != want) continue;
+        out.append((const char *)d.data() + r0 + 32, l_name - 1); out.push_back('\t');
+        out.append(num, (size_t)snprintf(num, sizeof num, "%u\t", flag));
+        if (ref >= 0 && ref < n_ref) out.append(names[(size_t)ref]); else out.push_back('*');
+        out.append(num, (size_t)snprintf(num, sizeof num, "\t%d\t%u\t", pos + 1, mapq));
+        const size_t c0 = r0 + 32 + l_name;
+        if (!n_cig) out.push_back('*');
+        for (uint32_t k = 0; k < n_cig; k++) {
+            const uint32_t w = (uint32_t)rd32(c0 + 4 * k);
+            out.append(num, (size_t)snprintf(num, sizeof num, "%u%c", w >> 4, OPS[w & 15]));
+        }
+        out.push_back('\t');
+        if (nref < 0) out.push_back('*'); else if (nref == ref) out.push_back('='); else if (nref < n_ref) out.append(names[(size_t)nref]); else out.push_back('*');
+        out.append(num, (size_t)snprintf(num, sizeof num, "\t%d\t%d\t", npos + 1, tlen));
+        const size_t s0 = c0 + 4 * (size_t)n_cig;
+        if (!l_seq) out.push_back('*');
+        for (int32_t k = 0; k < l_seq; k++) out.push_back(NIB[(d[s0 + (size_t)k / 2] >> ((k & 1) ? 0 : 4)) & 15]);
+        out.push_back('\t');
+        const size_t q0 = s0 + ((size_t)l_seq + 1) / 2;
+        if (!l_seq || d[q0] == 0xff) out.push_back('*');
+        else for (int32_t k = 0; k < l_seq; k++) out.push_back((char)(d[q0 + (size_t)k] + 33));
+        out.push_back('\n');
+    }
+    char *t = (char *)malloc(out.size() + 1);
+    if (!t) return FZP_ENOMEM;
+    memcpy(t, out.data(), out.size());
+    t[out.size()] = 0;
+    *text = t; *text_len = out.size();
+    return FZP_OK;
+}

@@ -67,8 +67,13 @@ def make_het_call(self):
     vpos_fn = fn(self.vpos_file)
     q_id_map_fn = fn(self.q_id_map_file)
 
-    p = subprocess.Popen(shlex.split("%s view %s %s" % (samtools, bam_fn, ctg_id)), stdout=subprocess.PIPE)
-    sam, _ = p.communicate()
+    if samtools == "builtin":
+        # no samtools on the node: the library's own BGZF/BAM reader plays `samtools view <bam> <ctg>`
+        with open(bam_fn, "rb") as f:
+            sam = _lib.bam_to_sam(f.read(), ctg_id)
+    else:
+        p = subprocess.Popen(shlex.split("%s view %s %s" % (samtools, bam_fn, ctg_id)), stdout=subprocess.PIPE)
+        sam, _ = p.communicate()
 
     try:
         os.makedirs("%s/%s" % (base_dir, ctg_id))
@@ -202,7 +207,7 @@ def parse_args(argv):
     parser.add_argument('--fasta', type=str, help='path to the fasta file of contain the contig', required=True)
     parser.add_argument('--ctg_id', type=str, help='contig identifier in the bam file', required=True)
     parser.add_argument('--base_dir', type=str, default="./", help='the output base_dir, default to current working directory')
-    parser.add_argument('--samtools', type=str, default="samtools", help='path to samtools')
+    parser.add_argument('--samtools', type=str, default="samtools", help='path to samtools ("builtin": read the BAM with the library instead)')
     args = parser.parse_args(argv[1:])
     return args
 

@@ -10,9 +10,8 @@ files the reference would have written are produced from the records, and one al
 Inputs and outputs use the reference's directory contract:
     <unzip_dir>/reads/ctg_list, <ctg>_ref.fa, <ctg>_reads.fa                       (unzip.py:204,233-234)
     <unzip_dir>/0-phasing/<ctg>/{het_call/*, g_atable/atable, get_phased_blocks/phased_variants,
-                                  phased_reads, rid_to_phase.<ctg>, blasr/<ctg>_sorted.sam}
+                                  phased_reads, rid_to_phase.<ctg>, blasr/<ctg>_sorted.bam(.bai)}
     <unzip_dir>/1-hasm/rid-to-phase-all/rid_to_phase.all                          (unzip.py:285)
-(`<ctg>_sorted.sam` is SAM text where the reference has a BAM: there is no BGZF encoder here.)
 """
 from __future__ import annotations
 
@@ -104,9 +103,11 @@ def phase_contigs(eng, jobs, unzip_dir, read_map_dir=None, write_sam=True, ctg_i
         put("get_phased_blocks/phased_variants", _lib.format_phased_variants(r.sites, r.pvars))
         phased_reads = _lib.format_phased_reads(r.preads, ctg, qoff, qnames)
         put("phased_reads", phased_reads)
-        if write_sam:
+        if write_sam:                                        # the blasr task's artefacts (unzip.py:86-91): sorted BAM + index
             flags = (summ["strand"][idx] * 16).astype(np.int32)
-            put("blasr/%s_sorted.sam" % ctg, _lib.format_sam(aln, ctg, flags))
+            bam, bai = _lib.format_bam(aln, ctg, len(ref), flags)
+            put("blasr/%s_sorted.bam" % ctg, bam)
+            put("blasr/%s_sorted.bam.bai" % ctg, bai)
         if read_map_dir is not None:                         # fc_phasing_readmap.py (unzip.py:126)
             def slurp(p):
                 with open(p, "rb") as f:

@@ -246,6 +246,16 @@ void fzp_align_destroy(fzp_ctx *ctx, fzp_alnjob *job);
 /* SAM text of an alnset (what `samtools view` would print), for users who want the alignments */
 int fzp_format_sam(const fzp_alnset *aln, const char *ctg_id, const int32_t *flags, char **text, size_t *len);
 
+/* ---- BAM emitter / reader ("next" row n1).  The reference's blasr task writes <ctg>_sorted.bam + index
+ * (unzip.py:86-91) and make_het_call reads it through `samtools view <bam> <ctg>` (phasing.py:27).
+ * fzp_format_bam: coordinate-sorted BAM (BGZF, EOF marker) of an alnset and, if bai != NULL, its .bai; MAPQ 254,
+ * QUAL absent, as fzp_format_sam prints them.  fzp_bam_to_sam: the `samtools view [region]` role -- text lines of the
+ * 11 mandatory columns (optional fields dropped; phasing.py reads columns 0,1,2,3,5,9); region NULL or "" = all
+ * records, else RNAME.  Outputs are malloc'ed (fzp_free). */
+int fzp_format_bam(const fzp_alnset *aln, const char *ctg_id, int64_t ctg_len, const int32_t *flags,
+                   uint8_t **bam, size_t *bam_len, uint8_t **bai, size_t *bai_len);
+int fzp_bam_to_sam(const uint8_t *bam, size_t len, const char *region, char **text, size_t *text_len);
+
 /* ======================================================================== overlap filter ("next" row n2)
  * falcon_unzip/ovlp_filter_with_phase.py: the consumer of rid_to_phase.all.  It reads `LA4Falcon -mo` text
  * (13 whitespace-separated columns per overlap: q_id t_id -len idt q_strand q_s q_e q_l t_strand t_s t_e t_l tag)

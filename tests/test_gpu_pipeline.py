@@ -1,15 +1,18 @@
 """The batched driver (falcon_unzip_amd/pipeline.py) on a miniature 3-unzip tree: FASTA in, the reference's file
 layout out; every file compared with the oracle run on the SAM the aligner produced."""
 import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_unzip_tree_end_to_end(tmp_path, oracle):
-    from falcon_unzip_amd import pipeline, sim
+    from falcon_unzip_amd import _lib, pipeline, sim
     from tests.golden.make_golden import make_readmap
     unzip = tmp_path / "3-unzip"
     (unzip / "reads").mkdir(parents=True)
@@ -52,7 +55,9 @@ def test_unzip_tree_end_to_end(tmp_path, oracle):
     cat = b""
     for ctg in sorted(ctgs):
         base = unzip / "0-phasing" / ctg
-        sam = (base / "blasr" / ("%s_sorted.sam" % ctg)).read_bytes()
+        bam = (base / "blasr" / ("%s_sorted.bam" % ctg)).read_bytes()      # what the blasr task leaves behind (unzip.py:86-91)
+        assert (base / "blasr" / ("%s_sorted.bam.bai" % ctg)).read_bytes()[:4] == b"BAI\x01"
+        sam = _lib.bam_to_sam(bam, ctg)                                     # `samtools view <bam> <ctg>` (phasing.py:27)
         assert sam.count(b"\n") >= 175
         ref = sim.codes_to_str(sim.make_diploid(40000 + 5000 * ctgs.index(ctg), np.random.Generator(np.random.PCG64(100 + ctgs.index(ctg))), het_rate=1.0 / 300)[0]).encode()
         exp = oracle.phase_all(sam, ref, ctg)
@@ -65,4 +70,15 @@ def test_unzip_tree_end_to_end(tmp_path, oracle):
         assert (base / ("rid_to_phase.%s" % ctg)).read_bytes() == r2p
         cat += r2p
     assert (unzip / "1-hasm" / "rid-to-phase-all" / "rid_to_phase.all").read_bytes() == cat     # unzip.py:303-314
+    # the emitted BAM closes the loop: the per-contig CLI (task_phasing's script, unzip.py:125) run on it without
+    # samtools writes the same files the batched pipeline wrote
+    ctg = sorted(ctgs)[0]
+    again = tmp_path / "again"
+    (again / ctg).mkdir(parents=True)
+    env = dict(os.environ, PYTHONPATH=REPO + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    subprocess.check_call([sys.executable, os.path.join(REPO, "scripts", "fc_phasing.py"), "--bam", str(unzip / "0-phasing" / ctg / "blasr" / ("%s_sorted.bam" % ctg)),
+                           "--fasta", str(unzip / "reads" / ("%s_ref.fa" % ctg)), "--ctg_id", ctg, "--base_dir", "..", "--samtools", "builtin"],
+                          cwd=str(again / ctg), env=env)
+    for rel in ("het_call/variant_pos", "het_call/variant_map", "het_call/q_id_map", "g_atable/atable", "get_phased_blocks/phased_variants", "phased_reads"):
+        assert (again / ctg / rel).read_bytes() == (unzip / "0-phasing" / ctg / rel).read_bytes(), rel
     assert len(allr) == cat.count(b"\n")
