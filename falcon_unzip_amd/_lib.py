@@ -55,6 +55,39 @@ class ResultAllStruct(C.Structure):
                 ("arow_begin", C.POINTER(C.c_int64)), ("pvar_begin", C.POINTER(C.c_int64)), ("pread_begin", C.POINTER(C.c_int64))]
 
 
+TIG = np.dtype([("ctg", "<i4"), ("block", "<i4"), ("phase", "<i4"), ("lo", "<i4"), ("hi", "<i4"), ("n_records", "<i4"),
+                ("seq_off", "<i8"), ("seq_len", "<i8")], align=True)
+assert TIG.itemsize == 40
+
+
+class TigsStruct(C.Structure):
+    _fields_ = [("n_tigs", C.c_int64), ("tigs", C.c_void_p), ("n_seq", C.c_int64), ("seq", C.c_void_p)]
+
+
+class Tigs:
+    """K6 results of a batch: one consensus sequence per (contig, block, phase) with a non-empty pile."""
+
+    def __init__(self, ts: TigsStruct):
+        self._ts = ts
+        n = int(ts.n_tigs)
+        self.tigs = np.frombuffer(C.string_at(ts.tigs, n * TIG.itemsize), dtype=TIG).copy() if n else np.zeros(0, TIG)
+        self.seq = C.string_at(ts.seq, int(ts.n_seq)) if ts.n_seq else b""
+
+    def sequence(self, i):
+        t = self.tigs[i]
+        return self.seq[int(t["seq_off"]):int(t["seq_off"] + t["seq_len"])]
+
+    def fasta(self, ctg, ctg_id: str):
+        return _fmt("fzp_format_tigs", C.byref(self._ts), C.c_int32(ctg), ctg_id.encode())
+
+    def close(self):
+        if self._ts is not None:
+            load().fzp_tigs_free(C.byref(self._ts))
+            self._ts = None
+
+    __del__ = close
+
+
 class OvlpParams(C.Structure):
     _fields_ = [("max_diff", C.c_int64), ("max_cov", C.c_int64), ("min_cov", C.c_int64), ("min_len", C.c_int64), ("bestn", C.c_int64)]
 
@@ -116,6 +149,9 @@ def load():
         "fzp_align_alnset": (C.c_int, [VP, VP, I32, VP, CP, PP, PP]),
         "fzp_align_to_batch": (C.c_int, [VP, VP, PP]),
         "fzp_align_destroy": (None, [VP, VP]),
+        "fzp_batch_consensus": (C.c_int, [VP, VP, VP]),
+        "fzp_tigs_free": (None, [VP]),
+        "fzp_format_tigs": (C.c_int, [VP, I32, CP, PP, PSZ]),
         "fzp_format_bam": (C.c_int, [VP, CP, I64, VP, PP, PSZ, PP, PSZ]),
         "fzp_bam_to_sam": (C.c_int, [CP, SZ, CP, PP, PSZ]),
         "fzp_ovl_parse": (C.c_int, [VP, I32, VP, VP, CP, SZ, PP]),
@@ -279,6 +315,12 @@ class Batch:
             r.preads = full.preads[qb[c]:qb[c + 1]]
             out.append(r)
         return out
+
+    def consensus(self) -> "Tigs":
+        """K6: phased-pile consensus of every (block, phase); run(STAGE_ALL) first."""
+        ts = TigsStruct()
+        _check(load().fzp_batch_consensus(self.eng._p, self._p, C.byref(ts)))
+        return Tigs(ts)
 
     def counts(self):
         v = [C.c_int64() for _ in range(8)]

@@ -246,6 +246,23 @@ void fzp_align_destroy(fzp_ctx *ctx, fzp_alnjob *job);
 /* SAM text of an alnset (what `samtools view` would print), for users who want the alignments */
 int fzp_format_sam(const fzp_alnset *aln, const char *ctg_id, const int32_t *flags, char **text, size_t *len);
 
+/* ---- K6: phased-pile consensus (BASELINE config 4; "next" row n3's device part).  The reference has no consensus code
+ * of its own (falcon_sense is falcon_kit's, Arrow is `variantCaller`'s, run_quiver.py:82-97): parity unpinned, the
+ * definition is oracle/cns_oracle.c ("fzcns v1").  For every (contig, block, phase) with at least one record
+ * in its pile: the consensus of the block's span [first site, last site] over the records of the reads K5 gave that
+ * phase.  Needs a batch with alignment records on which FZP_STAGE_ALL has run. */
+typedef struct {
+    int32_t ctg, block, phase;   /* block ids as in phased_variants (1-based, per contig) */
+    int32_t lo, hi;              /* 0-based inclusive span on the contig */
+    int32_t n_records;           /* alignment records in the pile */
+    int64_t seq_off, seq_len;    /* into fzp_tigs.seq */
+} fzp_tig;
+typedef struct { int64_t n_tigs; fzp_tig *tigs; int64_t n_seq; uint8_t *seq; } fzp_tigs;
+int fzp_batch_consensus(fzp_ctx *ctx, fzp_batch *b, fzp_tigs *out);
+void fzp_tigs_free(fzp_tigs *t);     /* frees the arrays, not the struct */
+/* FASTA of one contig's tigs: ">{ctg_id}_{block:03d}_{phase} {lo+1} {hi+1} {n_records}\n{sequence}\n" */
+int fzp_format_tigs(const fzp_tigs *t, int32_t ctg, const char *ctg_id, char **text, size_t *len);
+
 /* ---- BAM emitter / reader ("next" row n1).  The reference's blasr task writes <ctg>_sorted.bam + index
  * (unzip.py:86-91) and make_het_call reads it through `samtools view <bam> <ctg>` (phasing.py:27).
  * fzp_format_bam: coordinate-sorted BAM (BGZF, EOF marker) of an alnset and, if bai != NULL, its .bai; MAPQ 254,

@@ -1,0 +1,210 @@
+/* cns_oracle.c -- scalar CPU twin of K6, the phased-pile consensus ("fzcns v1").
+ * TEST INFRASTRUCTURE: only tests/, __graft_entry__.smoke() and bench cpu_baseline legs may use it.
+ *
+ * PARITY UNPINNED against the reference: FALCON_unzip has no consensus code of its own -- haplotig consensus is
+ * falcon_kit's falcon_sense / Arrow via `variantCaller` (run_quiver.py:82-97), external and absent.  This file
+ * DEFINES the consensus the HIP kernels implement; HIP == twin byte for byte, accuracy is asserted against the
+ * simulator's true haplotypes.
+ *
+ * Inputs are the texts the phasing chain already has: the SAM lines (records accepted exactly as make_het_call
+ * accepts them, phasing.py:47-75), `phased_reads` (q_id ctg block phase n0 n1 QNAME, phasing.py:478-480) and
+ * `phased_variants` (P lines: id min max ..., phasing.py:418, 1-based positions).
+ * For block b and phase p the pile is every accepted record whose q_id has a (b, p) row; over the block's span
+ * [min, max] each reference position tallies A/C/G/T and deletions from the records' CIGAR walk (S, I advance the query;
+ * M,=,X one column per base; D advances the reference; N,H,P nothing -- the walk of phasing.py:77-96), and every I op
+ * that follows a consumed reference position tallies one insertion (and its first base) on that position.
+ * Call per position, cov = A+C+G+T+del:
+ *     cov == 0            -> the contig's base
+ *     2*del > cov         -> nothing
+ *     else                -> the most frequent base (ties: the contig's base if it is among them, else A<C<G<T)
+ *     then 2*ins > cov    -> the most frequent first inserted base (ties A<C<G<T)
+ * Output: one FASTA record per (block, phase) with at least one record in its pile, blocks ascending, phase 0 then 1:
+ *     >{ctg}_{block:03d}_{phase} {min} {max} {n_records}\n{sequence}\n
+ */
+#include <ctype.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct { const char *s; size_t n; } ctok;
+static int c_split(const char *l, size_t n, ctok *t, int maxt, int tabs_only) {
+    int k = 0;
+    size_t i = 0;
+    while (i < n && k < maxt) {
+        if (!tabs_only) while (i < n && isspace((unsigned char)l[i])) i++;
+        if (i >= n && !tabs_only) break;
+        size_t b = i;
+        if (tabs_only) while (i < n && l[i] != '\t') i++; else while (i < n && !isspace((unsigned char)l[i])) i++;
+        t[k].s = l + b; t[k].n = i - b; k++;
+        if (tabs_only) { if (i < n) i++; else break; }
+    }
+    return k;
+}
+static long long c_int(ctok t) { char b[32]; size_t n = t.n < 31 ? t.n : 31; memcpy(b, t.s, n); b[n] = 0; return atoll(b); }
+
+typedef struct { char *name; size_t nlen; } qname_t;
+typedef struct { int qid; long long pos; const char *cig; size_t cn; const char *seq; size_t sn; } crec;
+typedef struct { int qid, block, phase; } prow;
+typedef struct { int id; long long lo, hi; } blk_t;
+
+static int code_of(unsigned char c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 4; }
+
+int orc_consensus(const char *sam, size_t sam_len, const char *ref_seq, size_t ref_len, const char *phased_reads, size_t pr_len,
+                  const char *phased_variants, size_t pv_len, const char *ctg_id, char **out_txt, size_t *out_len) {
+    /* ---- records (phasing.py:42-75) */
+    size_t n_lines = 1;
+    for (size_t i = 0; i < sam_len; i++) n_lines += sam[i] == '\n';
+    crec *rec = (crec *)malloc(n_lines * sizeof(crec));
+    qname_t *qn = (qname_t *)malloc(n_lines * sizeof(qname_t));
+    size_t n_rec = 0, n_q = 0;
+    size_t off = 0;
+    while (off < sam_len) {
+        const char *l = sam + off;
+        const char *e = memchr(l, '\n', sam_len - off);
+        size_t ln = e ? (size_t)(e - l) : sam_len - off;
+        off += ln + (e ? 1 : 0);
+        while (ln && (l[ln - 1] == '\r' || l[ln - 1] == ' ' || l[ln - 1] == '\t')) ln--;
+        if (!ln || l[0] == '@') continue;
+        ctok t[12];
+        int nt = c_split(l, ln, t, 12, 0);
+        if (nt < 10) { free(rec); free(qn); return -1; }
+        int qid = -1;
+        for (size_t k = 0; k < n_q; k++) if (qn[k].nlen == t[0].n && memcmp(qn[k].name, t[0].s, t[0].n) == 0) { qid = (int)k; break; }
+        if (qid < 0) { qn[n_q].name = (char *)t[0].s; qn[n_q].nlen = t[0].n; qid = (int)n_q++; }
+        long long total = 0, skip = 0;
+        for (size_t i = 0; i < t[5].n;) {
+            long long v = 0; size_t j = i;
+            while (j < t[5].n && isdigit((unsigned char)t[5].s[j])) v = v * 10 + (t[5].s[j++] - '0');
+            if (j == i || j >= t[5].n) break;
+            if (strchr("MIDNSHP=X", t[5].s[j])) { total += v; if (t[5].s[j] == 'S') skip += v; }
+            i = j + 1;
+        }
+        if (total == 0) { free(rec); free(qn); return -1; }
+        if (1.0 - 1.0 * (double)skip / (double)total < 0.1) continue;
+        if (total < 2000) continue;
+        rec[n_rec].qid = qid; rec[n_rec].pos = c_int(t[3]) - 1; rec[n_rec].cig = t[5].s; rec[n_rec].cn = t[5].n; rec[n_rec].seq = t[9].s; rec[n_rec].sn = t[9].n;
+        n_rec++;
+    }
+    /* ---- phased_reads rows and blocks */
+    size_t pcap = 1;
+    for (size_t i = 0; i < pr_len; i++) pcap += phased_reads[i] == '\n';
+    prow *pr = (prow *)malloc(pcap * sizeof(prow));
+    size_t n_pr = 0;
+    off = 0;
+    while (off < pr_len) {
+        const char *l = phased_reads + off;
+        const char *e = memchr(l, '\n', pr_len - off);
+        size_t ln = e ? (size_t)(e - l) : pr_len - off;
+        off += ln + (e ? 1 : 0);
+        ctok t[8];
+        if (c_split(l, ln, t, 8, 0) < 4) continue;
+        pr[n_pr].qid = (int)c_int(t[0]); pr[n_pr].block = (int)c_int(t[2]); pr[n_pr].phase = (int)c_int(t[3]); n_pr++;
+    }
+    size_t bcap = 1;
+    for (size_t i = 0; i < pv_len; i++) bcap += phased_variants[i] == '\n';
+    blk_t *blk = (blk_t *)malloc(bcap * sizeof(blk_t));
+    size_t n_blk = 0;
+    off = 0;
+    while (off < pv_len) {
+        const char *l = phased_variants + off;
+        const char *e = memchr(l, '\n', pv_len - off);
+        size_t ln = e ? (size_t)(e - l) : pv_len - off;
+        off += ln + (e ? 1 : 0);
+        ctok t[8];
+        if (c_split(l, ln, t, 8, 0) < 4 || t[0].n != 1 || t[0].s[0] != 'P') continue;
+        blk[n_blk].id = (int)c_int(t[1]); blk[n_blk].lo = c_int(t[2]) - 1; blk[n_blk].hi = c_int(t[3]) - 1; n_blk++;
+    }
+    /* ---- tally and call */
+    size_t cap = 1 << 16, n_out = 0;
+    char *out = (char *)malloc(cap);
+#define PUT(ptr, len_)                                                              \
+    do {                                                                            \
+        size_t l__ = (len_);                                                        \
+        if (n_out + l__ + 1 > cap) { while (n_out + l__ + 1 > cap) cap *= 2; out = (char *)realloc(out, cap); } \
+        memcpy(out + n_out, (ptr), l__); n_out += l__;                              \
+    } while (0)
+    for (size_t b = 0; b < n_blk; b++) {
+        const long long lo = blk[b].lo, hi = blk[b].hi;
+        if (hi < lo || lo < 0 || (size_t)hi >= ref_len) continue;
+        const size_t L = (size_t)(hi - lo + 1);
+        for (int ph = 0; ph < 2; ph++) {
+            uint32_t *cnt = (uint32_t *)calloc(L * 10, sizeof(uint32_t));
+            long long n_used = 0;
+            for (size_t r = 0; r < n_rec; r++) {
+                int use = 0;
+                for (size_t k = 0; k < n_pr; k++) if (pr[k].qid == rec[r].qid && pr[k].block == blk[b].id && pr[k].phase == ph) { use = 1; break; }
+                if (!use) continue;
+                /* reference span, to count a record only if it reaches the block */
+                long long rp = rec[r].pos, qp = 0, span = 0;
+                for (size_t i = 0; i < rec[r].cn;) {
+                    long long v = 0; size_t j = i;
+                    while (j < rec[r].cn && isdigit((unsigned char)rec[r].cig[j])) v = v * 10 + (rec[r].cig[j++] - '0');
+                    if (j == i || j >= rec[r].cn) break;
+                    char op = rec[r].cig[j];
+                    if (op == 'M' || op == '=' || op == 'X' || op == 'D') span += v;
+                    i = j + 1;
+                }
+                if (rec[r].pos > hi || rec[r].pos + span <= lo) continue;
+                n_used++;
+                for (size_t i = 0; i < rec[r].cn;) {
+                    long long v = 0; size_t j = i;
+                    while (j < rec[r].cn && isdigit((unsigned char)rec[r].cig[j])) v = v * 10 + (rec[r].cig[j++] - '0');
+                    if (j == i || j >= rec[r].cn) break;
+                    char op = rec[r].cig[j];
+                    i = j + 1;
+                    if (op == 'S') qp += v;
+                    else if (op == 'I') {
+                        long long pp = rp - 1;
+                        if (pp >= rec[r].pos && pp >= lo && pp <= hi && v > 0 && (size_t)qp < rec[r].sn) {
+                            cnt[(size_t)(pp - lo) * 10 + 5]++;
+                            int c = code_of((unsigned char)rec[r].seq[qp]);
+                            if (c < 4) cnt[(size_t)(pp - lo) * 10 + 6 + c]++;
+                        }
+                        qp += v;
+                    } else if (op == 'M' || op == '=' || op == 'X') {
+                        for (long long d = 0; d < v; d++, rp++, qp++) {
+                            if (rp < lo || rp > hi || (size_t)qp >= rec[r].sn) continue;
+                            int c = code_of((unsigned char)rec[r].seq[qp]);
+                            if (c < 4) cnt[(size_t)(rp - lo) * 10 + c]++;
+                        }
+                    } else if (op == 'D') {
+                        for (long long d = 0; d < v; d++, rp++) if (rp >= lo && rp <= hi) cnt[(size_t)(rp - lo) * 10 + 4]++;
+                    }
+                }
+            }
+            if (n_used > 0) {
+                char hdr[256];
+                int hl = snprintf(hdr, sizeof hdr, ">%s_%03d_%d %lld %lld %lld\n", ctg_id, blk[b].id, ph, lo + 1, hi + 1, n_used);
+                PUT(hdr, (size_t)hl);
+                for (size_t x = 0; x < L; x++) {
+                    const uint32_t *c = cnt + x * 10;
+                    uint32_t cov = c[0] + c[1] + c[2] + c[3] + c[4];
+                    char refb = (char)toupper((unsigned char)ref_seq[lo + (long long)x]);
+                    if (cov == 0) { PUT(&refb, 1); continue; }
+                    if (2 * c[4] <= cov) {
+                        uint32_t mx = c[0];
+                        for (int k = 1; k < 4; k++) if (c[k] > mx) mx = c[k];
+                        int rc = code_of((unsigned char)refb), pick = -1;
+                        if (rc < 4 && c[rc] == mx) pick = rc;
+                        for (int k = 0; k < 4 && pick < 0; k++) if (c[k] == mx) pick = k;
+                        char ch = "ACGT"[pick];
+                        PUT(&ch, 1);
+                    }
+                    if (2 * c[5] > cov) {
+                        uint32_t mx = c[6];
+                        int pick = 0;
+                        for (int k = 1; k < 4; k++) if (c[6 + k] > mx) { mx = c[6 + k]; pick = k; }
+                        if (mx > 0) { char ch = "ACGT"[pick]; PUT(&ch, 1); }
+                    }
+                }
+                PUT("\n", 1);
+            }
+            free(cnt);
+        }
+    }
+    out[n_out] = 0;
+    free(rec); free(qn); free(pr); free(blk);
+    *out_txt = out; *out_len = n_out;
+    return 0;
+}

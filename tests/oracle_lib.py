@@ -178,3 +178,8 @@ def ovlp_filter(orc, files, rid_map: bytes, params: dict):
         res.append(C.string_at(p, q.value))
         lib.orc_free(p)
     return res[0], res[1].decode().split(), res[2].decode().split()
+
+
+def consensus(orc, sam: bytes, ref_seq: bytes, phased_reads: bytes, phased_variants: bytes, ctg_id: str):
+    """oracle/cns_oracle.c: orc_consensus -> FASTA text of the (block, phase) consensus sequences"""
+    return orc._call("orc_consensus", [sam, ref_seq, phased_reads, phased_variants], 1, extra=[ctg_id.encode()])[0]

@@ -1,0 +1,87 @@
+"""K6, the phased-pile consensus (fzp_batch_consensus): HIP == CPU twin byte for byte, and accuracy of the whole chain
+K1 -> K5 -> K6 against the simulator's true haplotypes."""
+import numpy as np
+import pytest
+
+from tests import cns_util, oracle_lib
+from tests.golden_util import Case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from falcon_unzip_amd import _lib
+    e = _lib.Engine(0)
+    yield e
+    e.close()
+
+
+def hip_fasta(eng, alns, refs, ids):
+    from falcon_unzip_amd import _lib
+    b = eng.batch(alns, refs)
+    b.run(_lib.STAGE_ALL)
+    t = b.consensus()
+    out = [t.fasta(c, ids[c]) for c in range(len(ids))]
+    n = len(t.tigs)
+    t.close()
+    b.close()
+    return out, n
+
+
+@pytest.mark.parametrize("name", ["g1_cfg1_clean", "g2_cfg1_clr", "g4_multiblock", "g7_lowcov", "g8_noisy", "g9_fragmented", "g3_quirks"])
+def test_matches_twin_on_goldens(eng, oracle, name):
+    from falcon_unzip_amd import _lib
+    c = Case(name)
+    aln = _lib.parse_sam(c.sam)
+    got, n = hip_fasta(eng, [aln], [c.ref_seq], [c.ctg_id])
+    res = oracle.phase_all(c.sam, c.ref_seq, c.ctg_id)
+    exp = oracle_lib.consensus(oracle, c.sam, c.ref_seq, res["phased_reads"], res["phased_variants"], c.ctg_id)
+    assert got[0] == exp
+    assert n == exp.count(b">")
+
+
+def test_batch_of_contigs_matches_twin(eng, oracle):
+    """Several contigs in one batch (block ids restart per contig)."""
+    from falcon_unzip_amd import _lib, sim
+    alns, refs, ids, exps = [], [], [], []
+    for k in range(3):
+        hap0, hap1, het, reads = cns_util.diploid_case(40 + k, L=30000 + 7000 * k, n_reads=150 + 40 * k, R=7000)
+        ctg = sim.codes_to_str(hap0).encode()
+        sam = ("\n".join(sim.sam_lines(reads, "c%d" % k, header=False)) + "\n").encode()
+        res = oracle.phase_all(sam, ctg, "c%d" % k)
+        exps.append(oracle_lib.consensus(oracle, sam, ctg, res["phased_reads"], res["phased_variants"], "c%d" % k))
+        alns.append(_lib.parse_sam(sam)); refs.append(ctg); ids.append("c%d" % k)
+    got, n = hip_fasta(eng, alns, refs, ids)
+    assert got == exps
+    assert n == sum(e.count(b">") for e in exps) and n >= 6
+
+
+def test_chain_from_raw_reads_recovers_haplotypes(eng):
+    """K1 aligns the raw reads, K2..K5 phase them, K6 calls the consensus: each tig must be one of the two true
+    haplotypes over its span (>= 99.5 % identical) and clearly not the other."""
+    from falcon_unzip_amd import _lib, sim
+    rng = np.random.Generator(np.random.PCG64(77))
+    L = 80000
+    hap0, hap1, het = sim.make_diploid(L, rng, het_rate=1.0 / 400)
+    reads = sim.simulate_reads(hap0, hap1, 520, 9000, rng, strand_mix=0.5)
+    ctg = sim.codes_to_str(hap0).encode()
+    raw = [sim.codes_to_str(r.raw_seq_codes()).encode() for r in reads]
+    job = _lib.align_job(eng, [ctg], raw)
+    job.run()
+    b = job.to_batch()
+    b.run(_lib.STAGE_ALL)
+    t = b.consensus()
+    truth = [sim.codes_to_str(hap0).encode(), sim.codes_to_str(hap1).encode()]
+    assert len(t.tigs) >= 2
+    covered = 0
+    for i, tig in enumerate(t.tigs):
+        lo, hi = int(tig["lo"]), int(tig["hi"])
+        s = t.sequence(i)
+        d = [cns_util.banded_edit_distance(s, tr[lo:hi + 1]) for tr in truth]
+        n_het = int(((het >= lo) & (het <= hi)).sum())
+        assert min(d) <= 0.005 * (hi - lo + 1), (tig, d)
+        assert max(d) >= min(d) + 0.6 * n_het, (tig, d, n_het)
+        covered += hi - lo + 1
+    assert covered >= 2 * 0.8 * L            # both phases of blocks spanning most of the contig
+    t.close(); b.close(); job.close()
