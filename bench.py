@@ -101,6 +101,7 @@ def main():
     ap.add_argument("--window", type=int, default=750_000)
     ap.add_argument("--cpu-sample-reads", type=int, default=400)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--with-consensus", action="store_true", help="also run K6 (phased-pile consensus, BASELINE config 4) inside every step")
     ap.add_argument("--gen-workers", type=int, default=0, help="processes for input generation (0 = auto; forced to 1 under rocprofv3)")
     args = ap.parse_args()
 
@@ -156,6 +157,11 @@ def main():
         recs = []
         n_phased = 0
         qoff = 0
+        if args.with_consensus:
+            tg = b.consensus()
+            stats["n_tigs"] = len(tg.tigs)
+            stats["tig_bases"] = len(tg.seq)
+            tg.close()
         res = b.results(copy=False)
         for c in range(args.contigs):
             r = res[c]
@@ -219,7 +225,8 @@ def main():
             "dtype": "int32", "data": "synthetic",
             "config": {"workload": "cfg2: per GPU %d contigs x %d bp, %d reads x %d bp template each (CLR 1/8/4 %% errors, both strands), "
                                    "reads drawn from a %d bp window per contig; K1 align + K2 het call + K3 atable + K4 blocks + K5 reads + r2p all-gather"
-                                   % (args.contigs, args.contig_len, args.reads_per_contig, args.read_len, min(args.window, args.contig_len)),
+                                   % (args.contigs, args.contig_len, args.reads_per_contig, args.read_len, min(args.window, args.contig_len))
+                                   + (" + K6 consensus" if args.with_consensus else ""),
                        "reads_per_gpu": n_reads, "parallelism": "contigs sharded, %d rank(s)" % world},
             "dp_gcell_per_s_per_gpu": round(dp_gcells, 2),
             "upload_ms": round(upload_ms, 1),

@@ -4,14 +4,16 @@
 // consensus code of its own (falcon_sense lives in falcon_kit, Arrow in `variantCaller`, run_quiver.py:82-97), so this
 // is this repo's own definition; the records, phases and blocks it consumes are the K1..K5 results already in HBM.
 //   k_cns_extent   block spans [min site, max site] from K4's per-site block ids
-//   k_cns_tally    one wave per alignment record: for every (block, phase) row K5 gave its read, walk the CIGAR from
-//                  the checkpoint before the block (K2's 64-op checkpoints), one op per lane, and add the record's
-//                  columns / deletions / insertions to the block's counters (10 x u32 per position and phase)
+//   k_cns_nrec     records per (block, phase) pile
+//   k_cns_tiles    a workgroup owns 512 consecutive positions of one block: both phases' counters (10 x u32 per
+//                  position and phase) live in LDS, its waves walk the records that overlap the tile -- phase looked
+//                  up in K5's rows, CIGAR resumed at K2's 64-op checkpoint before the tile, columns dealt 64 at a time
+//                  by the shared expander, D / I ops one per lane -- and the tile is written once, coalesced
 //   k_cns_call     per position: 0..2 output bases (deletion / majority base / majority inserted base)
 //   scan + k_cns_emit   sequences laid out per (block, phase), order fixed by the scan
 // HBM-bound integer work: 1 B symbol + 4 B/op in, 40 B of counters per (position, phase) touched by atomics, 1 B out.
 #include <algorithm>
-#include "fzp_batch.h"
+#include "fzp_expand.h"
 
 namespace {
 constexpr int CN = 10;   // counters per (position, phase): A C G T del ins insA insC insG insT
@@ -45,63 +47,111 @@ struct CnsView {
     int64_t n_rec;
 };
 
-__global__ void __launch_bounds__(256) k_cns_tally(CnsView v, uint32_t *__restrict__ cnt, uint32_t *__restrict__ n_records) {
-    const int lane = lane_id();
-    for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < v.n_rec; r += (int64_t)gridDim.x * 4) {
-        const int c = v.rec_ctg[r];
-        const int32_t q = v.rec_qid[r], pos0 = v.rec_pos[r], span = v.rec_span[r];
-        // this read's phased_reads rows: preads of the contig ascend by (q_id, block)
-        int64_t a = v.pread_begin[c], b = v.pread_begin[c + 1];
-        while (a < b) { const int64_t m = (a + b) >> 1; if (v.preads[m].q_id < q) a = m + 1; else b = m; }
-        const int64_t pe = v.pread_begin[c + 1];
-        for (int64_t e = a; e < pe && v.preads[e].q_id == q; e++) {
-            const int32_t g = v.blk_base[c] + v.preads[e].block - 1, ph = v.preads[e].phase;
-            const int32_t lo = v.lo[g], hi = v.hi[g];
-            if (pos0 > hi || pos0 + span <= lo) continue;
-            if (lane == 0) atomicAdd(&n_records[2 * g + ph], 1u);
-            const int64_t len = (int64_t)hi - lo + 1;
-            uint32_t *base = cnt + (2 * v.cnt_off[g] + (int64_t)ph * len) * CN;
-            // last checkpoint at or before the block's first position
-            const int64_t k0 = v.ck_off[r];
-            int32_t ca = 0, cb = (int32_t)(v.ck_off[r + 1] - k0);
-            const int32_t want = lo - pos0;
-            while (cb - ca > 1) { const int32_t m = (ca + cb) >> 1; if (v.ck_ref[k0 + m] <= want) ca = m; else cb = m; }
-            int32_t rp = pos0 + v.ck_ref[k0 + ca];
-            int64_t qp = v.ck_q[k0 + ca];
-            const int64_t c1 = v.cig_off[r + 1], sbase = v.seq_off[r];
-            for (int64_t cbase = v.cig_off[r] + (int64_t)ca * 64; cbase < c1 && rp <= hi; cbase += 64) {
-                const uint32_t w = (cbase + lane < c1) ? v.cigar[cbase + lane] : 0u;
-                const uint32_t n = w >> 4, t = w & 15u;
-                const bool isM = (t == FZP_OP_M) | (t == FZP_OP_EQ) | (t == FZP_OP_X);
-                const uint32_t radv = (isM | (t == FZP_OP_D)) ? n : 0u;
-                const uint32_t qadv = (isM | (t == FZP_OP_I) | (t == FZP_OP_S)) ? n : 0u;
-                const uint32_t rs = wave_incl_scan_u32(radv), qs = wave_incl_scan_u32(qadv);
-                const int32_t r0 = rp + (int32_t)(rs - radv);       // first reference position of this lane's op
-                const int64_t q0 = qp + (qs - qadv);
-                if (isM) {
-                    for (uint32_t d = 0; d < n; d++) {
-                        const int32_t p = r0 + (int32_t)d;
-                        if (p < lo || p > hi) continue;
-                        const int code = sym_code(v.seq[sbase + q0 + d]);
-                        if (code < 4) atomicAdd(&base[(int64_t)(p - lo) * CN + code], 1u);
-                    }
-                } else if (t == FZP_OP_D) {
-                    for (uint32_t d = 0; d < n; d++) {
-                        const int32_t p = r0 + (int32_t)d;
-                        if (p >= lo && p <= hi) atomicAdd(&base[(int64_t)(p - lo) * CN + 4], 1u);
-                    }
-                } else if (t == FZP_OP_I && n > 0) {
-                    const int32_t p = r0 - 1;
-                    if (p >= pos0 && p >= lo && p <= hi) {
-                        atomicAdd(&base[(int64_t)(p - lo) * CN + 5], 1u);
-                        const int code = sym_code(v.seq[sbase + q0]);
-                        if (code < 4) atomicAdd(&base[(int64_t)(p - lo) * CN + 6 + code], 1u);
-                    }
+// records per pile (the header's n_records, and "is there a pile at all")
+__global__ void __launch_bounds__(256) k_cns_nrec(CnsView v, uint32_t *__restrict__ n_records) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= v.n_rec) return;
+    const int c = v.rec_ctg[r];
+    const int32_t q = v.rec_qid[r], pos0 = v.rec_pos[r], span = v.rec_span[r];
+    int64_t a = v.pread_begin[c], b = v.pread_begin[c + 1];
+    const int64_t pe = b;
+    while (a < b) { const int64_t m = (a + b) >> 1; if (v.preads[m].q_id < q) a = m + 1; else b = m; }
+    for (int64_t e = a; e < pe && v.preads[e].q_id == q; e++) {
+        const int32_t g = v.blk_base[c] + v.preads[e].block - 1;
+        if (pos0 > v.hi[g] || pos0 + span <= v.lo[g]) continue;
+        atomicAdd(&n_records[2 * g + v.preads[e].phase], 1u);
+    }
+}
+
+constexpr int CNS_TILE = 512, CNS_THREADS = 512;
+__global__ void __launch_bounds__(CNS_THREADS) k_cns_tiles(RecView rv, CnsView v, const int32_t *__restrict__ tile_blk, const int32_t *__restrict__ tile_start,
+                                                           const int32_t *__restrict__ blk_ctg, const int64_t *__restrict__ ctg_rec_begin,
+                                                           const int32_t *__restrict__ ctg_maxspan, uint32_t *__restrict__ cnt) {
+    __shared__ uint32_t l_cnt[2 * CN * CNS_TILE];      // [phase][counter][position]: consecutive lanes -> distinct banks
+    const int32_t g = tile_blk[blockIdx.x], ts = tile_start[blockIdx.x];
+    const int c = blk_ctg[g];
+    const int32_t lo = v.lo[g], hi = v.hi[g];
+    const int32_t te = min(ts + CNS_TILE, hi + 1);      // exclusive
+    for (int i = threadIdx.x; i < 2 * CN * CNS_TILE; i += CNS_THREADS) l_cnt[i] = 0;
+    __syncthreads();
+    // records of this contig that can overlap [ts, te): POS < te and POS > ts - max_span
+    const int64_t rb = ctg_rec_begin[c], re = ctg_rec_begin[c + 1];
+    const int32_t ms = ctg_maxspan[c];
+    int64_t first, last;
+    {
+        int64_t a = rb, b = re;
+        while (a < b) { const int64_t m = (a + b) >> 1; if (v.rec_pos[m] <= ts - ms) a = m + 1; else b = m; }
+        first = a;
+        b = re;
+        while (a < b) { const int64_t m = (a + b) >> 1; if (v.rec_pos[m] < te) a = m + 1; else b = m; }
+        last = a;
+    }
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    constexpr int NW = CNS_THREADS / 64;
+    const int32_t blk_id = g - v.blk_base[c] + 1;
+    for (int64_t i0 = 0; first + i0 * NW + wave < last; i0 += 64) {
+        // lane i prepares candidate first + (i0 + i) * NW + wave: overlap test, phase look-up, checkpoint search
+        const int64_t r = first + (i0 + lane) * NW + wave;
+        bool ok = r < last;
+        int32_t ca = 0, cr = 0, cq = 0, ph = 0;
+        if (ok) {
+            const int32_t pos0 = v.rec_pos[r];
+            ok = pos0 + v.rec_span[r] > ts;
+            if (ok) {
+                const int32_t q = v.rec_qid[r];
+                int64_t a = v.pread_begin[c], b = v.pread_begin[c + 1];
+                while (a < b) {      // first row with (q_id, block) >= (q, blk_id)
+                    const int64_t m = (a + b) >> 1;
+                    const fzp_pread pr = v.preads[m];
+                    if (pr.q_id < q || (pr.q_id == q && pr.block < blk_id)) a = m + 1; else b = m;
                 }
-                rp += (int32_t)bcast_u32(rs, 63);
-                qp += bcast_u32(qs, 63);
+                ok = a < v.pread_begin[c + 1] && v.preads[a].q_id == q && v.preads[a].block == blk_id;
+                if (ok) {
+                    ph = v.preads[a].phase;
+                    const int64_t k0 = v.ck_off[r];
+                    int32_t cb = (int32_t)(v.ck_off[r + 1] - k0);
+                    const int32_t want = ts - pos0;
+                    while (cb - ca > 1) { const int32_t m = (ca + cb) >> 1; if (v.ck_ref[k0 + m] <= want) ca = m; else cb = m; }
+                    cr = v.ck_ref[k0 + ca]; cq = v.ck_q[k0 + ca];
+                }
             }
         }
+        const int32_t rel = (int32_t)(r - first);
+        for (uint64_t todo = __ballot(ok); todo; todo &= todo - 1) {
+            const int l = __builtin_ctzll(todo);
+            const int64_t ru = first + __builtin_amdgcn_readlane(rel, l);
+            uint32_t *lc = l_cnt + __builtin_amdgcn_readlane(ph, l) * (CN * CNS_TILE);
+            const int32_t pos0 = rv.rec_pos[ru];
+            expand_record(rv, ru,
+                [&](int32_t pos, uint8_t sym) {
+                    if (pos < ts || pos >= te) return;
+                    const int code = sym_code(sym);
+                    if (code < 4) atomicAdd(&lc[code * CNS_TILE + (pos - ts)], 1u);
+                },
+                __builtin_amdgcn_readlane(ca, l), __builtin_amdgcn_readlane(cr, l), __builtin_amdgcn_readlane(cq, l), te + 1,
+                [&](uint32_t op, int32_t r0, uint32_t n, int64_t qidx) {
+                    if (op == FZP_OP_D) {
+                        for (uint32_t d = 0; d < n; d++) {
+                            const int32_t p = r0 + (int32_t)d;
+                            if (p >= ts && p < te) atomicAdd(&lc[4 * CNS_TILE + (p - ts)], 1u);
+                        }
+                    } else {
+                        const int32_t p = r0 - 1;                    // the insertion follows position p
+                        if (p >= pos0 && p >= ts && p < te) {
+                            atomicAdd(&lc[5 * CNS_TILE + (p - ts)], 1u);
+                            const int code = sym_code(rv.seq[qidx]);
+                            if (code < 4) atomicAdd(&lc[(6 + code) * CNS_TILE + (p - ts)], 1u);
+                        }
+                    }
+                });
+        }
+    }
+    __syncthreads();
+    const int64_t len = (int64_t)hi - lo + 1;
+    const int np = te - ts;
+    for (int ph = 0; ph < 2; ph++) {
+        uint32_t *dst = cnt + (2 * v.cnt_off[g] + (int64_t)ph * len + (ts - lo)) * CN;
+        for (int i = threadIdx.x; i < np * CN; i += CNS_THREADS) dst[i] = l_cnt[ph * (CN * CNS_TILE) + (i % CN) * CNS_TILE + (i / CN)];
     }
 }
 
@@ -154,6 +204,14 @@ __global__ void __launch_bounds__(256) k_cns_emit(int64_t n_slots, const uint32_
     if (n > 0) seq[o] = sym2[2 * i];
     if (n > 1) seq[o + 1] = sym2[2 * i + 1];
 }
+// first output offset of every (block, phase): one gathered array instead of 2 * blocks tiny copies
+__global__ void k_cns_first(int n_blk, const int64_t *__restrict__ cnt_off, const uint32_t *__restrict__ off, uint32_t total, uint32_t *__restrict__ first) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * n_blk) return;
+    const int g = i >> 1, ph = i & 1;
+    const int64_t len = cnt_off[g + 1] - cnt_off[g];
+    first[i] = len > 0 ? off[2 * cnt_off[g] + (int64_t)ph * len] : total;
+}
 __global__ void k_fill32(int32_t *p, int64_t n, int32_t v) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -205,14 +263,25 @@ extern "C" int fzp_batch_consensus(fzp_ctx *ctx, fzp_batch *b, fzp_tigs *out) {
     DevBuf<uint8_t> sym2, seq;
     DevBuf<uint64_t> total;
     FZP_TRY(d_cnt_off.upload(cnt_off.data(), (size_t)NB + 1, st));
-    FZP_TRY(cnt.alloc((size_t)n_slots * CN)); FZP_TRY(cnt.zero((size_t)n_slots * CN, st));
+    FZP_TRY(cnt.alloc((size_t)n_slots * CN));
     FZP_TRY(n_records.alloc((size_t)NB * 2)); FZP_TRY(n_records.zero((size_t)NB * 2, st));
     CnsView v = {b->rec_pos.p, b->rec_qid.p, b->rec_ctg.p, b->rec_span.p, b->cig_off.p, b->seq_off.p, b->ck_off.p, b->ck_ref.p, b->ck_q.p, b->cigar.p, b->seq.p,
                  b->preads.p, b->pread_begin.p, d_base.p, d_lo.p, d_hi.p, d_cnt_off.p, b->n_rec};
-    if (b->n_rec > 0 && b->n_preads > 0) {
+    RecView rv = {b->rec_pos.p, b->rec_qid.p, b->rec_ctg.p, b->cig_off.p, b->seq_off.p, b->cigar.p, b->seq.p, b->ctg_goff.p, b->ctg_limit.p, b->n_rec};
+    std::vector<int32_t> tblk, tstart;                    // tiles never span blocks
+    for (int g = 0; g < NB; g++)
+        for (int64_t t0 = lo[(size_t)g]; t0 <= hi[(size_t)g]; t0 += CNS_TILE) { tblk.push_back(g); tstart.push_back((int32_t)t0); }
+    DevBuf<int32_t> d_tblk, d_tstart;
+    FZP_TRY(d_tblk.upload(tblk.data(), tblk.size(), st)); FZP_TRY(d_tstart.upload(tstart.data(), tstart.size(), st));
+    if (b->n_rec > 0) {
         ProfScope ps(ctx, "k6_tally");
-        hipLaunchKernelGGL(k_cns_tally, dim3((unsigned)std::min<int64_t>(nblocks(b->n_rec, 4), 1 << 16)), dim3(256), 0, st, v, cnt.p, n_records.p);
+        hipLaunchKernelGGL(k_cns_nrec, dim3(nblocks(b->n_rec, 256)), dim3(256), 0, st, v, n_records.p);
+        if (!tblk.empty())
+            hipLaunchKernelGGL(k_cns_tiles, dim3((unsigned)tblk.size()), dim3(CNS_THREADS), 0, st, rv, v, d_tblk.p, d_tstart.p, d_bctg.p, b->ctg_rec_begin.p, b->ctg_maxspan.p, cnt.p);
+    } else {
+        FZP_TRY(cnt.zero((size_t)n_slots * CN, st));
     }
+    FZP_HIP(hipStreamSynchronize(st));                       // the tile vectors go out of scope
     // ---- call + layout
     FZP_TRY(n_out.alloc((size_t)n_slots)); FZP_TRY(off.alloc((size_t)n_slots)); FZP_TRY(sym2.alloc((size_t)n_slots * 2)); FZP_TRY(total.alloc(1));
     {
@@ -232,12 +301,10 @@ extern "C" int fzp_batch_consensus(fzp_ctx *ctx, fzp_batch *b, fzp_tigs *out) {
     // ---- results: sequence bytes, and per (block, phase) its offset = off[] at its first slot
     std::vector<uint32_t> h_nrec((size_t)NB * 2), h_first((size_t)NB * 2 + 1, (uint32_t)tot);
     FZP_TRY(n_records.download(h_nrec.data(), (size_t)NB * 2, st));
-    for (int g = 0; g < NB; g++) {
-        const int64_t len = cnt_off[(size_t)g + 1] - cnt_off[(size_t)g];
-        if (len <= 0) continue;
-        for (int ph = 0; ph < 2; ph++)
-            FZP_HIP(hipMemcpyAsync(&h_first[(size_t)(2 * g + ph)], off.p + 2 * cnt_off[(size_t)g] + (int64_t)ph * len, 4, hipMemcpyDeviceToHost, st));
-    }
+    DevBuf<uint32_t> d_first;
+    FZP_TRY(d_first.alloc((size_t)NB * 2));
+    hipLaunchKernelGGL(k_cns_first, dim3(nblocks(2 * NB, 256)), dim3(256), 0, st, NB, d_cnt_off.p, off.p, (uint32_t)tot, d_first.p);
+    FZP_TRY(d_first.download(h_first.data(), (size_t)NB * 2, st));
     uint8_t *hseq = (uint8_t *)malloc((size_t)(tot ? tot : 1));
     if (!hseq) return FZP_ENOMEM;
     if (tot && hipMemcpyAsync(hseq, seq.p, (size_t)tot, hipMemcpyDeviceToHost, st) != hipSuccess) { free(hseq); fzp_set_error("consensus download failed"); return FZP_EDEVICE; }

@@ -10,7 +10,7 @@ files the reference would have written are produced from the records, and one al
 Inputs and outputs use the reference's directory contract:
     <unzip_dir>/reads/ctg_list, <ctg>_ref.fa, <ctg>_reads.fa                       (unzip.py:204,233-234)
     <unzip_dir>/0-phasing/<ctg>/{het_call/*, g_atable/atable, get_phased_blocks/phased_variants,
-                                  phased_reads, rid_to_phase.<ctg>, blasr/<ctg>_sorted.bam(.bai)}
+                                  phased_reads, rid_to_phase.<ctg>, blasr/<ctg>_sorted.bam(.bai), cns/phased_blocks.fa}
     <unzip_dir>/1-hasm/rid-to-phase-all/rid_to_phase.all                          (unzip.py:285)
 """
 from __future__ import annotations
@@ -64,7 +64,7 @@ def _mkdirs(*paths):
         os.makedirs(p, exist_ok=True)
 
 
-def phase_contigs(eng, jobs, unzip_dir, read_map_dir=None, write_sam=True, ctg_indices=None):
+def phase_contigs(eng, jobs, unzip_dir, read_map_dir=None, write_sam=True, ctg_indices=None, consensus=True):
     """K1 -> K5 for `jobs` (list of (ctg_id, ref bytes, [(read name, seq)])) on one GPU, all contigs in the same
     launches; writes the per-contig files; returns the rid_to_phase records of these contigs (empty unless
     read_map_dir is given).  ctg_indices: the contigs' indices in the job-wide sorted contig list."""
@@ -83,6 +83,7 @@ def phase_contigs(eng, jobs, unzip_dir, read_map_dir=None, write_sam=True, ctg_i
     summ = job.summaries()
     batch = job.to_batch()
     batch.run(_lib.STAGE_ALL)
+    tigs = batch.consensus() if consensus else None          # K6 before results(): results() hands out pinned views
     results = batch.results()
     all_recs = []
     for c, (ctg, ref, reads) in enumerate(jobs):
@@ -103,6 +104,9 @@ def phase_contigs(eng, jobs, unzip_dir, read_map_dir=None, write_sam=True, ctg_i
         put("get_phased_blocks/phased_variants", _lib.format_phased_variants(r.sites, r.pvars))
         phased_reads = _lib.format_phased_reads(r.preads, ctg, qoff, qnames)
         put("phased_reads", phased_reads)
+        if tigs is not None:                                 # K6: consensus of every (block, phase) pile
+            _mkdirs(os.path.join(base, "cns"))
+            put("cns/phased_blocks.fa", tigs.fasta(c, ctg))
         if write_sam:                                        # the blasr task's artefacts (unzip.py:86-91): sorted BAM + index
             flags = (summ["strand"][idx] * 16).astype(np.int32)
             bam, bai = _lib.format_bam(aln, ctg, len(ref), flags)
@@ -117,6 +121,8 @@ def phase_contigs(eng, jobs, unzip_dir, read_map_dir=None, write_sam=True, ctg_i
                                       slurp(os.path.join(read_map_dir, "pread_to_contigs")), ctg, ctg_indices[c])
             put("rid_to_phase.%s" % ctg, text)
             all_recs.append(recs)
+    if tigs is not None:
+        tigs.close()
     batch.close()
     job.close()
     return np.concatenate(all_recs) if all_recs else np.zeros(0, _lib.R2P)

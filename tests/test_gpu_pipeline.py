@@ -65,6 +65,9 @@ def test_unzip_tree_end_to_end(tmp_path, oracle):
                          ("g_atable/atable", "atable"), ("get_phased_blocks/phased_variants", "phased_variants"), ("phased_reads", "phased_reads")):
             assert (base / rel).read_bytes() == exp[key], (ctg, key)
         assert exp["phased_reads"].count(b"\n") > 100
+        from tests import oracle_lib
+        cns = oracle_lib.consensus(oracle, sam, ref, exp["phased_reads"], exp["phased_variants"], ctg)     # K6 == its twin
+        assert (base / "cns" / "phased_blocks.fa").read_bytes() == cns and cns.count(b">") >= 2
         r2p = oracle.phasing_readmap(exp["phased_reads"], rm["rawread_ids"].encode(), rm["pread_ids"].encode(),
                                      (rmd / "pread_to_contigs").read_bytes(), ctg)
         assert (base / ("rid_to_phase.%s" % ctg)).read_bytes() == r2p
