@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfzphase.so")
+LIB_PATH = os.environ.get("FZP_LIB") or os.path.join(_HERE, "libfzphase.so")   # FZP_LIB: another build of the same library (experiments)
 
 FZP_OK = 0
 FZP_EINVAL, FZP_EZERODIV, FZP_ENOMEM, FZP_EUNSORTED, FZP_EDEVICE, FZP_ENODEVICE = -1, -2, -3, -4, -5, -6
