@@ -308,7 +308,7 @@ __device__ __forceinline__ void scalar_store16(void *base, uint32_t byte_off, ui
 // handled explicitly.  The masks of the step are wave ballots.
 #define SW_STEP()                                                                                          \
     {                                                                                                      \
-        int32_t hd, m, Hn, Xn;                                                                             \
+        int32_t hd, m, Hn;                                                                                 \
         if (down) {                                                                                        \
             int32_t c = qs.pop();                                                                          \
             c = qpos < nq ? c : 4;                                                                         \
@@ -316,18 +316,16 @@ __device__ __forceinline__ void scalar_store16(void *base, uint32_t byte_off, ui
             i0++;                                                                                          \
             qc = wave_shl1(qc, c);                                                                         \
             const int32_t sc = qc == tc ? match : -mismatch;                                               \
-            hd = wave_shl1(X, 0) + sc;                                                                     \
+            hd = (pdown ? wave_shl1(X, 0) : X) + sc;                                                       \
             m = max(H, wave_shl1(H, 0));                                                                   \
-            Xn = H;                                                                                        \
         } else {                                                                                           \
             int32_t c = ts.pop();                                                                          \
             c = tpos < nt ? c : 5;                                                                         \
             tpos++;                                                                                        \
             tc = wave_shr1(tc, c);                                                                         \
             const int32_t sc = qc == tc ? match : -mismatch;                                               \
-            hd = X + sc;                                                                                   \
+            hd = (pdown ? X : wave_shr1(X, 0)) + sc;                                                       \
             m = max(H, wave_shr1(H, 0));                                                                   \
-            Xn = wave_shr1(H, 0);                                                                          \
         }                                                                                                  \
         const uint64_t gmask = __ballot(m == H);                                                           \
         Hn = max(hd, m - gap);                                                                             \
@@ -342,8 +340,9 @@ __device__ __forceinline__ void scalar_store16(void *base, uint32_t byte_off, ui
         bt = upd ? t : bt;                                                                                 \
         mvacc |= (uint64_t)(down ? 1 : 0) << (t & 63);                                                     \
         const int32_t top = __builtin_amdgcn_readlane(Hn, 0), bot = __builtin_amdgcn_readlane(Hn, 63);     \
-        X = Xn;                                                                                            \
+        X = H;            /* H(t-2) stays in its own lane layout: the next step shifts it as its two moves say */ \
         H = Hn;                                                                                            \
+        pdown = down;                                                                                      \
         t++;                                                                                               \
         down = t < 64 ? ((t & 1) == 0) : !(top > bot);                                                     \
     }
@@ -359,7 +358,9 @@ __device__ __forceinline__ void scalar_store16(void *base, uint32_t byte_off, ui
 
 // ---- interior block: up to 32 steps with every lane strictly inside the matrix, hand-scheduled.
 // The block is VALU-issue bound (a SIMD issues one wave64 VALU op per 4 cycles), so the point is the VALU count
-// per step: 14 (DOWN) / 14 (RIGHT), with 8 SALU and one scalar-memory op riding along on their own ports.
+// per step: 13, with 9 SALU and one scalar-memory op riding along on their own ports.
+//   * H of two steps ago is never copied or shifted: the two registers swap roles every step (hence two code
+//     parities) and the diagonal's lane shift rides on the add (hence a variant per pair of moves): 8 step variants;
 //   * the two trace-back masks of a step are the 64-bit results of v_cmp_e64 landing in an SGPR quad that
 //     goes out with one s_store_dwordx4 (16 B per step, step-major) -- no per-lane bit accumulators;
 //   * bases entering the band come from two 64-bit SGPR windows (32 bases each, enough for a whole block):
@@ -371,72 +372,103 @@ __device__ __forceinline__ void scalar_store16(void *base, uint32_t byte_off, ui
 //   * moves are collected in a 32-bit shift register (first step of the block ends up in the highest used bit).
 // `cnt` enters as (steps - 1) and counts down; the borrow ends the block.
 // No DPP source is written fewer than two instructions before it is read (gfx9 DPP hazard).
+#define SWB_DPP_SHL " wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0"
+#define SWB_DPP_SHR " wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0"
+// one DOWN step.  HC: operand holding H of the previous step; XC: operand holding H of two steps ago, receives the new H;
+// HDADD: the add that forms the diagonal operand (shifted by what the last two moves say); NP: parity after this step;
+// the step ends by jumping to the variant (NP, previous = DOWN, next move) or to the exit of parity NP.
+#define SWB_DOWN(LBL, HC, XC, HDADD, NP)                                                         \
+    "Lsw%=_" LBL ":\n\t"                                                                          \
+    "s_bfe_u64 s[56:57], %[qb], %[qsel]\n\t"                                                      \
+    "v_mov_b32_dpp %[qc], %[qc] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"                        \
+    "s_add_u32 %[qsel], %[qsel], 2\n\t"                                                           \
+    "v_max_i32_dpp %[mm], " HC ", " HC SWB_DPP_SHL "\n\t"                                         \
+    "v_writelane_b32 %[qc], s56, 63\n\t"                                                          \
+    "v_cmp_eq_i32_e64 s[62:63], %[mm], " HC "\n\t"                                                \
+    "v_cmp_eq_u32_e32 vcc, %[qc], %[tc]\n\t"                                                      \
+    "v_cndmask_b32_e32 %[sc], %[vmis], %[vmat], vcc\n\t"                                          \
+    HDADD "\n\t"                                                                                  \
+    "v_subrev_u32_e32 %[mm], %[gap], %[mm]\n\t"                                                   \
+    "s_mov_b32 %[pm], 1\n\t"                                                                      \
+    "v_max_i32_e32 " XC ", %[hd], %[mm]\n\t"                                                      \
+    "v_cmp_eq_i32_e64 s[60:61], " XC ", %[hd]\n\t"                                                \
+    "s_lshl1_add_u32 %[mv], %[mv], 1\n\t"                                                         \
+    "v_max_i32_e32 %[kb], %[kb], " XC "\n\t"                                                      \
+    "v_readlane_b32 %[top], " XC ", 0\n\t"                                                        \
+    "s_store_dwordx4 s[60:63], %[tbp], %[soff]\n\t"                                               \
+    "v_readlane_b32 %[bot], " XC ", 63\n\t"                                                       \
+    "s_add_u32 %[soff], %[soff], 16\n\t"                                                          \
+    "s_sub_u32 %[cnt], %[cnt], 1\n\t"                                                             \
+    "s_cbranch_scc1 Lsw%=_end" NP "\n\t"                                                          \
+    "s_cmp_gt_i32 %[top], %[bot]\n\t"                                                             \
+    "s_cbranch_scc1 Lsw%=_p" NP "DR\n\t"                                                          \
+    "s_branch Lsw%=_p" NP "DD\n"
+#define SWB_RIGHT(LBL, HC, XC, HDADD, NP)                                                        \
+    "Lsw%=_" LBL ":\n\t"                                                                          \
+    "s_bfe_u64 s[56:57], %[tb], %[tsel]\n\t"                                                      \
+    "v_mov_b32_dpp %[tc], %[tc] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"                        \
+    "s_add_u32 %[tsel], %[tsel], 2\n\t"                                                           \
+    "v_max_i32_dpp %[mm], " HC ", " HC SWB_DPP_SHR "\n\t"                                         \
+    "v_writelane_b32 %[tc], s56, 0\n\t"                                                           \
+    "v_cmp_eq_i32_e64 s[62:63], %[mm], " HC "\n\t"                                                \
+    "v_cmp_eq_u32_e32 vcc, %[qc], %[tc]\n\t"                                                      \
+    "v_cndmask_b32_e32 %[sc], %[vmis], %[vmat], vcc\n\t"                                          \
+    HDADD "\n\t"                                                                                  \
+    "v_subrev_u32_e32 %[mm], %[gap], %[mm]\n\t"                                                   \
+    "s_mov_b32 %[pm], 0\n\t"                                                                      \
+    "v_max_i32_e32 " XC ", %[hd], %[mm]\n\t"                                                      \
+    "v_cmp_eq_i32_e64 s[60:61], " XC ", %[hd]\n\t"                                                \
+    "s_lshl_b32 %[mv], %[mv], 1\n\t"                                                              \
+    "v_max_i32_e32 %[kb], %[kb], " XC "\n\t"                                                      \
+    "v_readlane_b32 %[top], " XC ", 0\n\t"                                                        \
+    "s_store_dwordx4 s[60:63], %[tbp], %[soff]\n\t"                                               \
+    "v_readlane_b32 %[bot], " XC ", 63\n\t"                                                       \
+    "s_add_u32 %[soff], %[soff], 16\n\t"                                                          \
+    "s_sub_u32 %[cnt], %[cnt], 1\n\t"                                                             \
+    "s_cbranch_scc1 Lsw%=_end" NP "\n\t"                                                          \
+    "s_cmp_gt_i32 %[top], %[bot]\n\t"                                                             \
+    "s_cbranch_scc1 Lsw%=_p" NP "RR\n\t"                                                          \
+    "s_branch Lsw%=_p" NP "RD\n"
+// label "pPab": parity P (0: H in %[H], X in %[X]; 1: swapped), a = previous move, b = this move
 __device__ __forceinline__ void sw_block(int32_t &H, int32_t &X, int32_t &qc, int32_t &tc, const uint64_t qbits, const uint64_t tbits, int32_t &kb,
-                                         void *tbp, uint32_t &soff, uint32_t &mv, int32_t &cnt, int32_t &dn, const int32_t gapS,
+                                         void *tbp, uint32_t &soff, uint32_t &mv, int32_t &cnt, int32_t &dn, int32_t &pm, const int32_t gapS,
                                          const int32_t vmatS, const int32_t vmisS) {
     int32_t hd, mm, sc, top, bot;
     uint32_t qsel = 2u << 16, tsel = 2u << 16;   // s_bfe_u64 operand: width 2, offset 0
     asm volatile(
         "s_nop 1\n\t"
         "s_cmp_eq_u32 %[dn], 0\n\t"
-        "s_cbranch_scc1 2f\n"
-        "1:\n\t"   // ------------------------------------------------ DOWN
-        "s_bfe_u64 s[56:57], %[qb], %[qsel]\n\t"
-        "v_mov_b32_dpp %[qc], %[qc] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
-        "s_add_u32 %[qsel], %[qsel], 2\n\t"
-        "v_max_i32_dpp %[mm], %[H], %[H] wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-        "v_writelane_b32 %[qc], s56, 63\n\t"
-        "v_cmp_eq_i32_e64 s[62:63], %[mm], %[H]\n\t"
-        "v_cmp_eq_u32_e32 vcc, %[qc], %[tc]\n\t"
-        "v_cndmask_b32_e32 %[sc], %[vmis], %[vmat], vcc\n\t"
-        "v_add_u32_dpp %[hd], %[X], %[sc] wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-        "v_mov_b32_e32 %[X], %[H]\n\t"
-        "v_subrev_u32_e32 %[mm], %[gap], %[mm]\n\t"
-        "v_max_i32_e32 %[H], %[hd], %[mm]\n\t"
-        "v_cmp_eq_i32_e64 s[60:61], %[H], %[hd]\n\t"
-        "s_lshl1_add_u32 %[mv], %[mv], 1\n\t"
-        "v_max_i32_e32 %[kb], %[kb], %[H]\n\t"
-        "v_readlane_b32 %[top], %[H], 0\n\t"
-        "s_store_dwordx4 s[60:63], %[tbp], %[soff]\n\t"
-        "v_readlane_b32 %[bot], %[H], 63\n\t"
-        "s_add_u32 %[soff], %[soff], 16\n\t"
-        "s_sub_u32 %[cnt], %[cnt], 1\n\t"                    // borrow out of the last step ends the block
-        "s_cbranch_scc1 3f\n\t"
-        "s_cmp_gt_i32 %[top], %[bot]\n\t"
-        "s_cbranch_scc0 1b\n"
-        "2:\n\t"   // ------------------------------------------------ RIGHT
-        "s_bfe_u64 s[56:57], %[tb], %[tsel]\n\t"
-        "v_mov_b32_dpp %[tc], %[tc] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-        "s_add_u32 %[tsel], %[tsel], 2\n\t"
-        "v_max_i32_dpp %[mm], %[H], %[H] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-        "v_writelane_b32 %[tc], s56, 0\n\t"
-        "v_cmp_eq_i32_e64 s[62:63], %[mm], %[H]\n\t"
-        "v_cmp_eq_u32_e32 vcc, %[qc], %[tc]\n\t"
-        "v_cndmask_b32_e32 %[sc], %[vmis], %[vmat], vcc\n\t"
-        "v_add_u32_e32 %[hd], %[X], %[sc]\n\t"
-        "v_mov_b32_dpp %[X], %[H] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-        "v_subrev_u32_e32 %[mm], %[gap], %[mm]\n\t"
-        "v_max_i32_e32 %[H], %[hd], %[mm]\n\t"
-        "v_cmp_eq_i32_e64 s[60:61], %[H], %[hd]\n\t"
-        "s_lshl_b32 %[mv], %[mv], 1\n\t"
-        "v_max_i32_e32 %[kb], %[kb], %[H]\n\t"
-        "v_readlane_b32 %[top], %[H], 0\n\t"
-        "s_store_dwordx4 s[60:63], %[tbp], %[soff]\n\t"
-        "v_readlane_b32 %[bot], %[H], 63\n\t"
-        "s_add_u32 %[soff], %[soff], 16\n\t"
-        "s_sub_u32 %[cnt], %[cnt], 1\n\t"
-        "s_cbranch_scc1 3f\n\t"
-        "s_cmp_gt_i32 %[top], %[bot]\n\t"
-        "s_cbranch_scc1 2b\n\t"
-        "s_branch 1b\n"
-        "3:\n\t"
+        "s_cbranch_scc1 Lsw%=_enterR\n\t"
+        "s_cmp_eq_u32 %[pm], 0\n\t"
+        "s_cbranch_scc1 Lsw%=_p0RD\n\t"
+        "s_branch Lsw%=_p0DD\n"
+        "Lsw%=_enterR:\n\t"
+        "s_cmp_eq_u32 %[pm], 0\n\t"
+        "s_cbranch_scc1 Lsw%=_p0RR\n\t"
+        "s_branch Lsw%=_p0DR\n"
+        // the diagonal predecessor of lane k is lane k - 1 + (DOWN moves among the last two) of H(t-2)
+        SWB_DOWN("p0DD", "%[H]", "%[X]", "v_add_u32_dpp %[hd], %[X], %[sc]" SWB_DPP_SHL, "1")
+        SWB_DOWN("p0RD", "%[H]", "%[X]", "v_add_u32_e32 %[hd], %[X], %[sc]", "1")
+        SWB_RIGHT("p0DR", "%[H]", "%[X]", "v_add_u32_e32 %[hd], %[X], %[sc]", "1")
+        SWB_RIGHT("p0RR", "%[H]", "%[X]", "v_add_u32_dpp %[hd], %[X], %[sc]" SWB_DPP_SHR, "1")
+        SWB_DOWN("p1DD", "%[X]", "%[H]", "v_add_u32_dpp %[hd], %[H], %[sc]" SWB_DPP_SHL, "0")
+        SWB_DOWN("p1RD", "%[X]", "%[H]", "v_add_u32_e32 %[hd], %[H], %[sc]", "0")
+        SWB_RIGHT("p1DR", "%[X]", "%[H]", "v_add_u32_e32 %[hd], %[H], %[sc]", "0")
+        SWB_RIGHT("p1RR", "%[X]", "%[H]", "v_add_u32_dpp %[hd], %[H], %[sc]" SWB_DPP_SHR, "0")
+        "Lsw%=_end1:\n\t"                                    // an odd number of steps: the roles are swapped
+        "v_swap_b32 %[H], %[X]\n"
+        "Lsw%=_end0:\n\t"
         "s_cmp_gt_i32 %[top], %[bot]\n\t"
         "s_cselect_b32 %[dn], 0, 1"
         : [H] "+v"(H), [X] "+v"(X), [qc] "+v"(qc), [tc] "+v"(tc), [kb] "+v"(kb), [mv] "+s"(mv), [cnt] "+s"(cnt), [soff] "+s"(soff),
-          [dn] "+s"(dn), [qsel] "+s"(qsel), [tsel] "+s"(tsel), [hd] "=&v"(hd), [mm] "=&v"(mm), [sc] "=&v"(sc), [top] "=&s"(top), [bot] "=&s"(bot)
+          [dn] "+s"(dn), [pm] "+s"(pm), [qsel] "+s"(qsel), [tsel] "+s"(tsel), [hd] "=&v"(hd), [mm] "=&v"(mm), [sc] "=&v"(sc), [top] "=&s"(top), [bot] "=&s"(bot)
         : [gap] "s"(gapS), [vmat] "v"(vmatS), [vmis] "v"(vmisS), [qb] "s"(qbits), [tb] "s"(tbits), [tbp] "s"(tbp)
         : "vcc", "scc", "s56", "s57", "s60", "s61", "s62", "s63", "memory");
 }
+#undef SWB_DOWN
+#undef SWB_RIGHT
+#undef SWB_DPP_SHL
+#undef SWB_DPP_SHR
 
 // 32 bases starting at packed index idx, as a wave-uniform 64-bit window (three scalar dword loads)
 __device__ __forceinline__ uint64_t base_window(const uint32_t *__restrict__ pk, int64_t idx) {
@@ -473,9 +505,10 @@ __global__ void __launch_bounds__(64) k_sw(int64_t first, int64_t count, const u
     ulonglong2 *tbr = (ulonglong2 *)tb + (tb_off[r] - tb_off[first]);   // per step: {D mask, G mask} over the 64 band lanes
     ulonglong2 *mvr = mvw + ((tb_off[r] - tb_off[first]) >> 6) + wv;   // per 64 steps: {move bits, i0 before the chunk}
 
-    // state before step 0 (biased): H(-1), and X = H(-2) as seen after the (virtual) RIGHT move of step -1
+    // state before step 0 (biased): H(-1), and X = H(-2) in the lane layout it was computed in
     int32_t H = (lane == 32 || lane == 33) ? SW_BIAS - gap : 0;
-    int32_t X = lane == 33 ? SW_BIAS : 0;
+    int32_t X = lane == 32 ? SW_BIAS : 0;
+    bool pdown = false;                                // move of the (virtual) step -1: RIGHT
     int32_t qc, tc;
     {
         int32_t i = lane - 33, j = 32 - lane;
@@ -504,6 +537,7 @@ __global__ void __launch_bounds__(64) k_sw(int64_t first, int64_t count, const u
             const int32_t vmatS = (match << 6) - 2, vmisS = -(mismatch << 6) - 2;
             const int32_t gapS = __builtin_amdgcn_readfirstlane((gap << 6) + 1);
             int32_t dn = down ? 1 : 0;
+            int32_t pm = pdown ? 1 : 0;
             while (safe > 0) {
                 // (readfirstlane: these are wave-uniform, but hipcc's divergence analysis cannot always prove it)
                 const uint64_t qbits = base_window(qpk, __builtin_amdgcn_readfirstlane((int32_t)qb + qpos_i));
@@ -514,10 +548,11 @@ __global__ void __launch_bounds__(64) k_sw(int64_t first, int64_t count, const u
                 uint32_t mv = 0;
                 int32_t kb = 0;
                 dn = __builtin_amdgcn_readfirstlane(dn);
+                pm = __builtin_amdgcn_readfirstlane(pm);
                 H = (H << 6) + n_steps;                                  // previous step: countdown n_steps
                 X = (X << 6) + n_steps + 1;                              // the one before
                 uint32_t soff = (uint32_t)__builtin_amdgcn_readfirstlane(t) * 16u;
-                sw_block(H, X, qc, tc, qbits, tbits, kb, (void *)tbr, soff, mv, cnt, dn, gapS, vmatS, vmisS);
+                sw_block(H, X, qc, tc, qbits, tbits, kb, (void *)tbr, soff, mv, cnt, dn, pm, gapS, vmatS, vmisS);
                 H >>= 6;                                                 // the last step's countdown is 0, X's is 1
                 X >>= 6;
                 {   // fold the block's best cell into the running best (strictly greater: the earliest step wins ties)
@@ -534,6 +569,7 @@ __global__ void __launch_bounds__(64) k_sw(int64_t first, int64_t count, const u
                 if ((t & 63) == 0) SW_FLUSH(false)
             }
             down = dn != 0;
+            pdown = pm != 0;
             // back to the checked variant: scalar base streams resume at the current positions
             qpos = i0 + 64; tpos = t - i0;
             qs.init(qpk, qb + qpos);

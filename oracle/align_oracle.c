@@ -4,11 +4,11 @@
  * PARITY UNPINNED vs the reference: FALCON_unzip shells out to `blasr` (falcon_unzip/unzip.py:86-88),
  * a third-party C++ aligner that is not vendored under /root/reference and whose results
  * (placement, clipping, `--hitPolicy randombest --randomSeed 42` tie-breaks) cannot be reproduced
- * here.  This file therefore DEFINES the aligner ("fzalign v1"); the HIP kernels in
+ * here.  This file therefore DEFINES the aligner ("fzalign v1.1"); the HIP kernels in
  * falcon_unzip_amd/csrc/fzp_align.hip must match it bit-for-bit (summaries, CIGARs, DP cell counts),
  * and its quality is judged against the simulator's true alignments.
  *
- * fzalign v1
+ * fzalign v1.1  (v1 dropped the diagonal predecessor of lane 63 after a RIGHT move followed by a DOWN move)
  *   bases     A/a C/c G/g T/t -> 0..3, anything else -> 0
  *   seeding   canonical k-mers (k<=16, 2 bits/base, base m of a k-mer at bits 2m; canonical = the smaller of
  *             the k-mer and its reverse complement) of every 2nd contig position -> smallest start position
@@ -23,9 +23,9 @@
  *   extension adaptive anti-diagonal band of 64 cells (Suzuki-Kasahara style), forward from that
  *             origin: linear gaps, H = max(diag + (match | -mismatch), up - gap, left - gap), no zero
  *             floor; the first 64 steps alternate down/right, afterwards the band moves RIGHT when
- *             H[lane 0] > H[lane 63], else DOWN.  The diagonal operand is carried pre-shifted by the
- *             previous move, so after a RIGHT move followed by a DOWN move lane 63 has no diagonal
- *             predecessor (band edge).  The alignment ends at the best-scoring valid cell
+ *             H[lane 0] > H[lane 63], else DOWN.  The diagonal operand is H of two steps ago in that
+ *             step's own lane layout: the predecessor of lane k sits in lane k - 1 + (number of DOWN
+ *             moves among the last two); a lane outside 0..63 reads as minus infinity.  The alignment ends at the best-scoring valid cell
  *             (first in step order, then lowest lane); read bases before the anchor and after the
  *             end are soft-clipped.  Trace-back priority: diagonal, then the gap whose source is the
  *             same lane of the previous step (the cell above after a DOWN move, the cell to the left
@@ -164,13 +164,14 @@ static void align_one(const ctg_index *ix, const uint8_t *fwd, int64_t n, const 
     int qc[W], tc[W];
     int64_t i0 = -33;
     for (int kk = 0; kk < W; kk++) {
-        X[kk] = kk == 33 ? 0 : NEG;      /* H(-2) as seen after the virtual RIGHT move of step -1 */
+        X[kk] = kk == 32 ? 0 : NEG;      /* H(-2), in the lane layout before the virtual RIGHT move of step -1 */
         Hp[kk] = (kk == 32 || kk == 33) ? -P->gap : NEG;
         int64_t i = kk - 33, j = 32 - kk;
         qc[kk] = QC(i); tc[kk] = TC(j);
         bsc[kk] = NEG; bt[kk] = -1;
     }
     int steer = 1;
+    int prev_down = 0;                   /* move of step -1 (virtual RIGHT) */
     int64_t tt = 0;
     for (;;) {
         int down = tt < 64 ? ((tt & 1) == 0) : steer;
@@ -180,12 +181,14 @@ static void align_one(const ctg_index *ix, const uint8_t *fwd, int64_t n, const 
             for (int kk = 0; kk < W - 1; kk++) qc[kk] = qc[kk + 1];
             qc[W - 1] = QC(i0 + 63);
             for (int kk = 0; kk < W; kk++) { A[kk] = Hp[kk] - P->gap; B[kk] = (kk < W - 1 ? Hp[kk + 1] : NEG) - P->gap; }
-            for (int kk = 0; kk < W; kk++) { dg[kk] = kk < W - 1 ? X[kk + 1] : NEG; Xn[kk] = Hp[kk]; }
+            /* X = H(t-2) in ITS lane layout; the two moves since shift the diagonal predecessor of lane kk to
+             * lane kk - 1 + (#DOWN among them): DOWN,DOWN -> kk+1; one of each -> kk; RIGHT,RIGHT -> kk-1 */
+            for (int kk = 0; kk < W; kk++) { int s_ = kk + prev_down; dg[kk] = s_ < W ? X[s_] : NEG; Xn[kk] = Hp[kk]; }
         } else {
             for (int kk = W - 1; kk > 0; kk--) tc[kk] = tc[kk - 1];
             tc[0] = TC(tt - i0);
             for (int kk = 0; kk < W; kk++) { A[kk] = Hp[kk] - P->gap; B[kk] = (kk > 0 ? Hp[kk - 1] : NEG) - P->gap; }
-            for (int kk = 0; kk < W; kk++) { dg[kk] = X[kk]; Xn[kk] = kk > 0 ? Hp[kk - 1] : NEG; }
+            for (int kk = 0; kk < W; kk++) { int s_ = kk - 1 + prev_down; dg[kk] = s_ >= 0 ? X[s_] : NEG; Xn[kk] = Hp[kk]; }
         }
         uint64_t D = 0, U = 0;
         for (int kk = 0; kk < W; kk++) {
@@ -200,6 +203,7 @@ static void align_one(const ctg_index *ix, const uint8_t *fwd, int64_t n, const 
         }
         tbD[tt] = D; tbU[tt] = U; mv[tt] = (uint8_t)down;
         steer = !(H[0] > H[W - 1]);
+        prev_down = down;
         memcpy(X, Xn, sizeof X); memcpy(Hp, H, sizeof H);
         tt++;
         if (i0 > nq - 1) break;
