@@ -31,7 +31,7 @@ sys.path.insert(0, REPO)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_GINST = 614.4          # wave64 int32 VALU instructions/s: 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 op
                                  # (the 157.3 TFLOP/s vector figure counts packed fp32, which integer ops do not have)
-SW_VALU_PER_STEP = 13            # VALU instructions per 64-cell band step in k_sw's interior block (fzp_align.hip: sw_block)
+SW_VALU_PER_STEP = 12.5            # VALU instructions per 64-cell band step in k_sw's interior block (fzp_align.hip: sw_block)
 SW_BYTES_PER_CELL = 0.25         # algorithmic: 2 trace-back bits per cell (16 B per 64-cell step); sequence
                                  # reads add 2 bits per band step, i.e. < 0.01 B/cell
 

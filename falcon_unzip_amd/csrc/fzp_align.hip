@@ -358,7 +358,7 @@ __device__ __forceinline__ void scalar_store16(void *base, uint32_t byte_off, ui
 
 // ---- interior block: up to 32 steps with every lane strictly inside the matrix, hand-scheduled.
 // The block is VALU-issue bound (a SIMD issues one wave64 VALU op per 4 cycles), so the point is the VALU count
-// per step: 13, with 9 SALU and one scalar-memory op riding along on their own ports.
+// per step: 12.5 (the best-cell key takes the last two steps' H in one v_max3 every other step), with 9 SALU and one scalar-memory op riding along on their own ports.
 //   * H of two steps ago is never copied or shifted: the two registers swap roles every step (hence two code
 //     parities) and the diagonal's lane shift rides on the add (hence a variant per pair of moves): 8 step variants;
 //   * the two trace-back masks of a step are the 64-bit results of v_cmp_e64 landing in an SGPR quad that
@@ -377,7 +377,7 @@ __device__ __forceinline__ void scalar_store16(void *base, uint32_t byte_off, ui
 // one DOWN step.  HC: operand holding H of the previous step; XC: operand holding H of two steps ago, receives the new H;
 // HDADD: the add that forms the diagonal operand (shifted by what the last two moves say); NP: parity after this step;
 // the step ends by jumping to the variant (NP, previous = DOWN, next move) or to the exit of parity NP.
-#define SWB_DOWN(LBL, HC, XC, HDADD, NP)                                                         \
+#define SWB_DOWN(LBL, HC, XC, HDADD, NP, KB)                                                       \
     "Lsw%=_" LBL ":\n\t"                                                                          \
     "s_bfe_u64 s[56:57], %[qb], %[qsel]\n\t"                                                      \
     "v_mov_b32_dpp %[qc], %[qc] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"                        \
@@ -393,7 +393,7 @@ __device__ __forceinline__ void scalar_store16(void *base, uint32_t byte_off, ui
     "v_max_i32_e32 " XC ", %[hd], %[mm]\n\t"                                                      \
     "v_cmp_eq_i32_e64 s[60:61], " XC ", %[hd]\n\t"                                                \
     "s_lshl1_add_u32 %[mv], %[mv], 1\n\t"                                                         \
-    "v_max_i32_e32 %[kb], %[kb], " XC "\n\t"                                                      \
+    KB                                                      \
     "v_readlane_b32 %[top], " XC ", 0\n\t"                                                        \
     "s_store_dwordx4 s[60:63], %[tbp], %[soff]\n\t"                                               \
     "v_readlane_b32 %[bot], " XC ", 63\n\t"                                                       \
@@ -403,7 +403,7 @@ __device__ __forceinline__ void scalar_store16(void *base, uint32_t byte_off, ui
     "s_cmp_gt_i32 %[top], %[bot]\n\t"                                                             \
     "s_cbranch_scc1 Lsw%=_p" NP "DR\n\t"                                                          \
     "s_branch Lsw%=_p" NP "DD\n"
-#define SWB_RIGHT(LBL, HC, XC, HDADD, NP)                                                        \
+#define SWB_RIGHT(LBL, HC, XC, HDADD, NP, KB)                                                       \
     "Lsw%=_" LBL ":\n\t"                                                                          \
     "s_bfe_u64 s[56:57], %[tb], %[tsel]\n\t"                                                      \
     "v_mov_b32_dpp %[tc], %[tc] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"                        \
@@ -419,7 +419,7 @@ __device__ __forceinline__ void scalar_store16(void *base, uint32_t byte_off, ui
     "v_max_i32_e32 " XC ", %[hd], %[mm]\n\t"                                                      \
     "v_cmp_eq_i32_e64 s[60:61], " XC ", %[hd]\n\t"                                                \
     "s_lshl_b32 %[mv], %[mv], 1\n\t"                                                              \
-    "v_max_i32_e32 %[kb], %[kb], " XC "\n\t"                                                      \
+    KB                                                      \
     "v_readlane_b32 %[top], " XC ", 0\n\t"                                                        \
     "s_store_dwordx4 s[60:63], %[tbp], %[soff]\n\t"                                               \
     "v_readlane_b32 %[bot], " XC ", 63\n\t"                                                       \
@@ -447,15 +447,16 @@ __device__ __forceinline__ void sw_block(int32_t &H, int32_t &X, int32_t &qc, in
         "s_cbranch_scc1 Lsw%=_p0RR\n\t"
         "s_branch Lsw%=_p0DR\n"
         // the diagonal predecessor of lane k is lane k - 1 + (DOWN moves among the last two) of H(t-2)
-        SWB_DOWN("p0DD", "%[H]", "%[X]", "v_add_u32_dpp %[hd], %[X], %[sc]" SWB_DPP_SHL, "1")
-        SWB_DOWN("p0RD", "%[H]", "%[X]", "v_add_u32_e32 %[hd], %[X], %[sc]", "1")
-        SWB_RIGHT("p0DR", "%[H]", "%[X]", "v_add_u32_e32 %[hd], %[X], %[sc]", "1")
-        SWB_RIGHT("p0RR", "%[H]", "%[X]", "v_add_u32_dpp %[hd], %[X], %[sc]" SWB_DPP_SHR, "1")
-        SWB_DOWN("p1DD", "%[X]", "%[H]", "v_add_u32_dpp %[hd], %[H], %[sc]" SWB_DPP_SHL, "0")
-        SWB_DOWN("p1RD", "%[X]", "%[H]", "v_add_u32_e32 %[hd], %[H], %[sc]", "0")
-        SWB_RIGHT("p1DR", "%[X]", "%[H]", "v_add_u32_e32 %[hd], %[H], %[sc]", "0")
-        SWB_RIGHT("p1RR", "%[X]", "%[H]", "v_add_u32_dpp %[hd], %[H], %[sc]" SWB_DPP_SHR, "0")
-        "Lsw%=_end1:\n\t"                                    // an odd number of steps: the roles are swapped
+        SWB_DOWN("p0DD", "%[H]", "%[X]", "v_add_u32_dpp %[hd], %[X], %[sc]" SWB_DPP_SHL, "1", "")
+        SWB_DOWN("p0RD", "%[H]", "%[X]", "v_add_u32_e32 %[hd], %[X], %[sc]", "1", "")
+        SWB_RIGHT("p0DR", "%[H]", "%[X]", "v_add_u32_e32 %[hd], %[X], %[sc]", "1", "")
+        SWB_RIGHT("p0RR", "%[H]", "%[X]", "v_add_u32_dpp %[hd], %[X], %[sc]" SWB_DPP_SHR, "1", "")
+        SWB_DOWN("p1DD", "%[X]", "%[H]", "v_add_u32_dpp %[hd], %[H], %[sc]" SWB_DPP_SHL, "0", "v_max3_i32 %[kb], %[kb], %[X], %[H]\n\t")
+        SWB_DOWN("p1RD", "%[X]", "%[H]", "v_add_u32_e32 %[hd], %[H], %[sc]", "0", "v_max3_i32 %[kb], %[kb], %[X], %[H]\n\t")
+        SWB_RIGHT("p1DR", "%[X]", "%[H]", "v_add_u32_e32 %[hd], %[H], %[sc]", "0", "v_max3_i32 %[kb], %[kb], %[X], %[H]\n\t")
+        SWB_RIGHT("p1RR", "%[X]", "%[H]", "v_add_u32_dpp %[hd], %[H], %[sc]" SWB_DPP_SHR, "0", "v_max3_i32 %[kb], %[kb], %[X], %[H]\n\t")
+        "Lsw%=_end1:\n\t"                                    // an odd number of steps: the last H is not in the best-cell
+        "v_max_i32_e32 %[kb], %[kb], %[X]\n\t"              // key yet, and the roles are swapped
         "v_swap_b32 %[H], %[X]\n"
         "Lsw%=_end0:\n\t"
         "s_cmp_gt_i32 %[top], %[bot]\n\t"
