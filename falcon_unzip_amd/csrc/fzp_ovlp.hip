@@ -76,9 +76,28 @@ constexpr int MAXTOK = 64;
 constexpr uint8_t F_PARSE_OK = 1, F_IDT_OK = 2, F_CONTAINS = 4, F_CONTAINED = 8;
 }  // namespace
 
+// host copy of the dumps (the formatter and the tie fix-up read lines back from it).  Plain pageable memory: pinning
+// ~100 MB per call costs more (tens of ms) than the staged upload it would save.
+struct HostText {
+    char *p = nullptr;
+    size_t n = 0, cap = 0;
+    bool pinned = false;
+    ~HostText() { if (p) { if (pinned) (void)hipHostFree(p); else free(p); } }
+    bool reserve(size_t c) {
+        p = (char *)malloc(c ? c : 1);
+        cap = c;
+        return p != nullptr;
+    }
+    void append(const char *s, size_t k) { memcpy(p + n, s, k); n += k; }
+    void push_back(char c) { p[n++] = c; }
+    const char *data() const { return p; }
+    size_t size() const { return n; }
+    char back() const { return p[n - 1]; }
+};
+
 struct fzp_ovlset {
     int device = 0;
-    std::string text;                       // all dumps, each ending with '\n'
+    HostText text;                          // all dumps, each ending with '\n'
     std::vector<int64_t> file_end;          // end offset of every dump inside `text`
     std::vector<int64_t> line_off;          // [n_lines + 1]
     std::string map_text;
@@ -145,7 +164,7 @@ bool canonical_id(const char *p, int n, int64_t *val) {
     *val = v;
     return true;
 }
-int ovl_tokenise_device(fzp_ctx *ctx, fzp_ovlset *s, int64_t max_id, const std::vector<int32_t> &arid_of);
+int ovl_tokenise_device(fzp_ctx *ctx, fzp_ovlset *s, int64_t max_id, const std::vector<int32_t> &arid_of, DevBuf<uint8_t> &text);
 int ovl_tokenise_host(fzp_ctx *ctx, fzp_ovlset *s);
 }  // namespace
 
@@ -155,6 +174,26 @@ extern "C" int fzp_ovl_parse(fzp_ctx *ctx, int32_t n_files, const char *const *t
     FZP_HIP(hipSetDevice(ctx->device));
     fzp_ovlset *s = new fzp_ovlset();
     s->device = ctx->device;
+    // ---- the dumps: one buffer, every dump ending with '\n'
+    size_t total = 0;
+    for (int k = 0; k < n_files; k++) total += lens[k] + 1;
+    if (!s->text.reserve(total + 16)) { delete s; fzp_set_error("fzp_ovl_parse: host allocation of %zu bytes failed", total + 16); return FZP_ENOMEM; }
+    for (int k = 0; k < n_files; k++) {
+        if (lens[k]) s->text.append(texts[k], lens[k]);
+        if (lens[k] && s->text.back() != '\n') s->text.push_back('\n');
+        s->file_end.push_back((int64_t)s->text.size());
+    }
+    if (s->text.size() >= (1ull << 32)) { fzp_set_error("fzp_ovl_parse: %zu bytes of text (limit 4 GiB per call; split the fofn)", s->text.size()); delete s; return FZP_EINVAL; }
+    // the text starts its way to HBM now; the map is read while the DMA runs
+    hipStream_t st = ctx->stream;
+    DevBuf<uint8_t> d_text;
+    const int64_t n16 = ((int64_t)s->text.size() + 15) / 16;
+    if (n16 > 0) {
+        int rc0 = d_text.alloc((size_t)n16 * 16);
+        if (rc0) { delete s; return rc0; }
+        if (hipMemsetAsync(d_text.p + (n16 - 1) * 16, 0, 16, st) != hipSuccess ||
+            hipMemcpyAsync(d_text.p, s->text.data(), s->text.size(), hipMemcpyHostToDevice, st) != hipSuccess) { delete s; fzp_set_error("text upload failed"); return FZP_EDEVICE; }
+    }
     // ---- rid_to_phase.all (:306-309)
     s->map_text.assign(rid_map ? rid_map : "", map_len);
     std::unordered_map<std::string_view, int32_t> strs;
@@ -210,17 +249,6 @@ extern "C" int fzp_ovl_parse(fzp_ctx *ctx, int32_t n_files, const char *const *t
             if (canonical) max_id = std::max(max_id, v);
         }
     }
-    // ---- the dumps: one buffer, every dump ending with '\n'
-    size_t total = 0;
-    for (int k = 0; k < n_files; k++) total += lens[k] + 1;
-    s->text.reserve(total + 16);
-    for (int k = 0; k < n_files; k++) {
-        if (lens[k]) s->text.append(texts[k], lens[k]);
-        if (lens[k] && s->text.back() != '\n') s->text.push_back('\n');
-        s->file_end.push_back((int64_t)s->text.size());
-    }
-    if (s->text.size() >= (1ull << 32)) { fzp_set_error("fzp_ovl_parse: %zu bytes of text (limit 4 GiB per call; split the fofn)", s->text.size()); delete s; return FZP_EINVAL; }
-    hipStream_t st = ctx->stream;
     int rc = FZP_OK;
     if (!(rc = s->d_ctg.upload(s->ctg_code.data(), na, st)) && !(rc = s->d_blk.upload(s->blk_code.data(), na, st)) && !(rc = s->d_ph.upload(s->ph_code.data(), na, st)))
         rc = s->d_lex.upload(s->lex_rank.data(), na, st);
@@ -230,7 +258,7 @@ extern "C" int fzp_ovl_parse(fzp_ctx *ctx, int32_t n_files, const char *const *t
             std::vector<int32_t> arid_of((size_t)max_id + 2, -1);
             const char *mt = s->map_text.data();
             for (size_t i = 0; i < na; i++) { int64_t v = 0; canonical_id(mt + s->key[i].off, s->key[i].len, &v); arid_of[(size_t)v] = (int32_t)i; }
-            rc = ovl_tokenise_device(ctx, s, max_id, arid_of);
+            rc = ovl_tokenise_device(ctx, s, max_id, arid_of, d_text);
         } else {
             rc = ovl_tokenise_host(ctx, s);
         }
@@ -397,20 +425,16 @@ int alloc_cols(fzp_ovlset *s, size_t n) {
 }
 inline unsigned blocks_for(int64_t n, int per) { return (unsigned)std::max<int64_t>(1, (n + per - 1) / per); }
 
-int ovl_tokenise_device(fzp_ctx *ctx, fzp_ovlset *s, int64_t max_id, const std::vector<int32_t> &arid_of) {
+int ovl_tokenise_device(fzp_ctx *ctx, fzp_ovlset *s, int64_t max_id, const std::vector<int32_t> &arid_of, DevBuf<uint8_t> &text) {
     hipStream_t st = ctx->stream;
     const int64_t nb = (int64_t)s->text.size();
     s->tokenised_on_device = true;
     if (nb == 0) { s->n_lines = 0; s->line_off.assign(1, 0); return FZP_OK; }
     const int64_t n16 = (nb + 15) / 16;
-    DevBuf<uint8_t> text;
     DevBuf<uint32_t> cnt, pos, counters;
     DevBuf<uint64_t> totals;
     DevBuf<int64_t> ls, fend;
     DevBuf<int32_t> d_arid, err;
-    FZP_TRY(text.alloc((size_t)n16 * 16));
-    FZP_HIP(hipMemsetAsync(text.p + (n16 - 1) * 16, 0, 16, st));
-    FZP_HIP(hipMemcpyAsync(text.p, s->text.data(), (size_t)nb, hipMemcpyHostToDevice, st));
     FZP_TRY(cnt.alloc((size_t)n16)); FZP_TRY(pos.alloc((size_t)n16)); FZP_TRY(totals.alloc(2)); FZP_TRY(counters.alloc(2)); FZP_TRY(err.alloc(1));
     { ProfScope ps(ctx, "ovl_lines"); hipLaunchKernelGGL(k_ovl_nl, dim3(blocks_for(n16, 256)), dim3(256), 0, st, (const uint4 *)text.p, n16, cnt.p); }
     FZP_TRY(fzp_exclusive_scan_u32(ctx, cnt.p, pos.p, (size_t)n16, totals.p));
