@@ -14,6 +14,7 @@
 //   k_tb_cigar    per read, one wave: op stream -> forward run-length CIGAR, clips, summary
 //   k_gather      accepted records -> contiguous CIGAR + ASCII SEQ arrays for the phasing batch
 #include <algorithm>
+#include <ctime>
 
 #include "fzp_batch.h"
 
@@ -1122,21 +1123,37 @@ struct RecPlan {
 // what `samtools sort` + make_het_call's record filters (phasing.py:47-75) do to the aligner's output
 void plan_records(const fzp_alnjob *j, int c_lo, int c_hi, RecPlan &p) {
     const int nc = c_hi - c_lo;
-    p.ctg_reads.assign(nc, {});
+    // bucket the aligned reads by contig (counting sort), then order every bucket by (POS, read index) through one
+    // 64-bit key per read
+    std::vector<int64_t> cnt((size_t)nc + 1, 0);
     for (int64_t r = 0; r < j->n_reads; r++) {
-        int c = j->h_read_ctg[(size_t)r];
-        if (c >= c_lo && c < c_hi && j->h_summ[(size_t)r].aligned) p.ctg_reads[c - c_lo].push_back(r);
+        const int c = j->h_read_ctg[(size_t)r];
+        if (c >= c_lo && c < c_hi && j->h_summ[(size_t)r].aligned) cnt[(size_t)(c - c_lo) + 1]++;
     }
+    for (int c = 0; c < nc; c++) cnt[(size_t)c + 1] += cnt[(size_t)c];
+    const int64_t n_al = cnt[(size_t)nc];
+    std::vector<uint64_t> keys((size_t)n_al);
+    {
+        std::vector<int64_t> fill(cnt.begin(), cnt.end() - 1);
+        for (int64_t r = 0; r < j->n_reads; r++) {
+            const int c = j->h_read_ctg[(size_t)r];
+            if (c >= c_lo && c < c_hi && j->h_summ[(size_t)r].aligned)
+                keys[(size_t)fill[(size_t)(c - c_lo)]++] = ((uint64_t)(uint32_t)j->h_summ[(size_t)r].pos << 32) | (uint32_t)r;   // POS >= 0
+        }
+    }
+    p.ctg_reads.assign(nc, {});
     p.cig_off.assign(1, 0); p.seq_off.assign(1, 0); p.rec_begin.assign(1, 0);
     p.last_pos.assign(nc, -1); p.max_span.assign(nc, 0); p.n_columns.assign(nc, 0);
+    p.rec_read.reserve((size_t)n_al); p.rec_qid.reserve((size_t)n_al); p.rec_pos.reserve((size_t)n_al); p.rec_ctg.reserve((size_t)n_al);
+    p.cig_off.reserve((size_t)n_al + 1); p.seq_off.reserve((size_t)n_al + 1);
     for (int c = 0; c < nc; c++) {
+        uint64_t *k0 = keys.data() + cnt[(size_t)c], *k1 = keys.data() + cnt[(size_t)c + 1];
+        std::sort(k0, k1);
         auto &v = p.ctg_reads[c];
-        std::sort(v.begin(), v.end(), [&](int64_t a, int64_t b) {
-            int32_t pa = j->h_summ[(size_t)a].pos, pb = j->h_summ[(size_t)b].pos;
-            return pa != pb ? pa < pb : a < b;
-        });
+        v.resize((size_t)(k1 - k0));
         for (size_t q = 0; q < v.size(); q++) {
-            const int64_t r = v[q];
+            const int64_t r = (int64_t)(uint32_t)k0[q];
+            v[q] = r;
             const fzp_aln_summary &s = j->h_summ[(size_t)r];
             const int64_t n = j->h_read_len[(size_t)r];
             const int64_t n_del = (int64_t)(s.ref_end - s.pos) - s.n_columns;
@@ -1260,8 +1277,12 @@ extern "C" int fzp_align_to_batch(fzp_ctx *ctx, fzp_alnjob *j, fzp_batch **out) 
     if (!ctx || !j || !j->done || !out) { fzp_set_error("fzp_align_to_batch: job not run"); return FZP_EINVAL; }
     FZP_HIP(hipSetDevice(ctx->device));
     *out = nullptr;
+    const bool tim = getenv("FZP_TIMING") != nullptr;
+    auto now = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+    const double t0 = now();
     RecPlan p;
     plan_records(j, 0, j->n_ctg, p);
+    const double t1 = now();
     fzp_batch *b = new fzp_batch();
     b->n_ctg = j->n_ctg;
     b->h_rec_begin = p.rec_begin;
@@ -1280,6 +1301,7 @@ extern "C" int fzp_align_to_batch(fzp_ctx *ctx, fzp_alnjob *j, fzp_batch **out) 
     b->n_cig = p.cig_off.back(); b->n_seq = p.seq_off.back();
     hipStream_t st = ctx->stream;
     int rc = gather_records(ctx, j, p, b->cigar, b->seq, b->cig_off, b->seq_off);
+    const double t2 = now();
     if (!rc) rc = b->ref.alloc((size_t)b->n_pos);
     for (int c = 0; c < j->n_ctg && !rc; c++)   // evaluated prefix of every contig, device to device
         if (b->h_limit[c] && hipMemcpyAsync(b->ref.p + b->h_goff[c], j->ctg_ascii.p + j->h_ctg_aoff[c], (size_t)b->h_limit[c], hipMemcpyDeviceToDevice, st) != hipSuccess) rc = FZP_EDEVICE;
@@ -1293,7 +1315,9 @@ extern "C" int fzp_align_to_batch(fzp_ctx *ctx, fzp_alnjob *j, fzp_batch **out) 
     if (!rc) rc = b->ctg_goff.upload(b->h_goff.data(), b->h_goff.size(), st);
     if (!rc) rc = b->ctg_qoff.upload(b->h_qid_off.data(), b->h_qid_off.size(), st);
     if (!rc) rc = b->ctg_limit.upload(b->h_limit.data(), b->h_limit.size(), st);
+    const double t3 = now();
     if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = FZP_EDEVICE;
+    if (tim) fprintf(stderr, "[to_batch] plan %.2f gather %.2f uploads %.2f sync %.2f ms\n", t1 - t0, t2 - t1, t3 - t2, now() - t3);
     if (rc) { delete b; return rc; }
     b->have_aln = true;
     *out = b;
