@@ -20,3 +20,15 @@ def load(name):
     expected = gzip.open(os.path.join(d, "expected.out.gz")).read()
     ignore = sorted(set(x for x in meta["ignore"] if x != "None"))
     return dict(files=files, rid_map=rid_map, params=meta["params"], expected=expected, ignore=ignore, contained=sorted(meta["contained"]))
+
+
+def track_cases():
+    return sorted(json.load(open(os.path.join(HERE, "manifest_track.json"))))
+
+
+def load_track(name):
+    d = os.path.join(HERE, name)
+    meta = json.load(open(os.path.join(d, "case.json")))
+    rd = lambda fn: gzip.open(os.path.join(d, fn)).read()
+    return dict(files=[rd("ovl.%d.txt.gz" % k) for k in range(meta["n_files"])], rawread_ids=rd("rawread_ids.gz"), phased_reads=rd("phased_reads.gz"),
+                read_to_contig_map=rd("read_to_contig_map.gz"), params=meta["params"], expected=rd("expected.canonical.gz"))

@@ -183,3 +183,24 @@ def ovlp_filter(orc, files, rid_map: bytes, params: dict):
 def consensus(orc, sam: bytes, ref_seq: bytes, phased_reads: bytes, phased_variants: bytes, ctg_id: str):
     """oracle/cns_oracle.c: orc_consensus -> FASTA text of the (block, phase) consensus sequences"""
     return orc._call("orc_consensus", [sam, ref_seq, phased_reads, phased_variants], 1, extra=[ctg_id.encode()])[0]
+
+
+def track_reads(orc, files, phased_reads: bytes, read_to_contig_map: bytes, rawread_ids: bytes, min_len: int, bestn: int):
+    """oracle/track_oracle.c: orc_track_reads -> rawread_to_contigs text in canonical order"""
+    lib = orc.lib
+    n = len(files)
+    bufs = [C.create_string_buffer(f, len(f)) if len(f) else C.create_string_buffer(1) for f in files]
+    texts = (C.c_char_p * max(1, n))(*[C.cast(b, C.c_char_p) for b in bufs])
+    lens = (C.c_size_t * max(1, n))(*[len(f) for f in files])
+    p, q = C.c_void_p(), C.c_size_t()
+    f = lib.orc_track_reads
+    f.restype = C.c_int
+    f.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t,
+                  C.c_longlong, C.c_longlong, C.c_void_p, C.c_void_p]
+    rc = f(n, texts, lens, phased_reads, len(phased_reads), read_to_contig_map, len(read_to_contig_map), rawread_ids, len(rawread_ids), min_len, bestn,
+           C.byref(p), C.byref(q))
+    if rc != 0:
+        raise OracleError("orc_track_reads failed: rc=%d" % rc)
+    out = C.string_at(p, q.value)
+    lib.orc_free(p)
+    return out
