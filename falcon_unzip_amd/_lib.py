@@ -161,6 +161,7 @@ def load():
         "fzp_ovl_filter": (C.c_int, [VP, VP, VP, PP, PI64, PP, PI64, PP, PI64]),
         "fzp_ovl_format": (C.c_int, [VP, VP, I64, PP, PSZ]),
         "fzp_ovl_id_name": (C.c_int, [VP, I32, PP, C.POINTER(I32)]),
+        "fzp_track_reads": (C.c_int, [VP, I32, VP, VP, CP, SZ, CP, SZ, CP, SZ, I64, I64, PP, PSZ]),
     }
     lib.fzp_last_error.restype = C.c_char_p
     lib.fzp_version.restype = C.c_char_p
@@ -626,3 +627,13 @@ def ovl_filter(eng, ovl: OvlSet, max_diff, max_cov, min_cov, min_len=2500, bestn
     r, nr, ig, nig, ct, nct = C.c_void_p(), C.c_int64(), C.c_void_p(), C.c_int64(), C.c_void_p(), C.c_int64()
     _check(lib.fzp_ovl_filter(eng._p, ovl._p, C.byref(P), C.byref(r), C.byref(nr), C.byref(ig), C.byref(nig), C.byref(ct), C.byref(nct)))
     return _take(r, nr.value, np.int64), _take(ig, nig.value, np.int32), _take(ct, nct.value, np.int32)
+
+
+def track_reads(eng, files, phased_reads: bytes, read_to_contig_map: bytes, rawread_ids: bytes, min_len=2500, bestn=40):
+    """rr_hctg_track.py's run_track_reads on the device -> the rawread_to_contigs text (canonical line order)."""
+    n = len(files)
+    keep = [C.create_string_buffer(f, len(f)) if len(f) else C.create_string_buffer(1) for f in files]
+    texts = (C.c_char_p * max(1, n))(*[C.cast(b, C.c_char_p) for b in keep])
+    lens = (C.c_size_t * max(1, n))(*[len(f) for f in files])
+    return _fmt("fzp_track_reads", eng._p, C.c_int32(n), texts, lens, phased_reads, C.c_size_t(len(phased_reads)), read_to_contig_map,
+                C.c_size_t(len(read_to_contig_map)), rawread_ids, C.c_size_t(len(rawread_ids)), C.c_int64(int(min_len)), C.c_int64(int(bestn)))

@@ -331,8 +331,9 @@ __global__ void __launch_bounds__(256) k_ovl_tok(const uint8_t *__restrict__ tex
         bool idt_lt90 = false;
         auto finish = [&]() {
             if (tk == 0 || tk == 1) {
-                bool canon = good && len >= 9 && len <= 10 && (len == 9 || first != (uint8_t)'0') && acc <= max_id;
-                ids[tk] = canon ? (int64_t)arid_of[acc] : -1;
+                const bool shape = good && len >= 9 && len <= 10 && (len == 9 || first != (uint8_t)'0');
+                if (arid_of) ids[tk] = (shape && acc <= max_id) ? (int64_t)arid_of[acc] : -1;
+                else ids[tk] = (shape && acc <= 0x7ffffffe) ? acc : -1;           // raw mode: the id's value (-1: not '%09d'-shaped)
             } else if (tk == 3) {
                 if (!plain || ns > 15 || fd > 15) f_state = 2;
                 else if (nd == 0) f_state = 3;                       // no digit at all: float() raises
@@ -454,7 +455,7 @@ int ovl_tokenise_device(fzp_ctx *ctx, fzp_ovlset *s, int64_t max_id, const std::
     FZP_HIP(hipMemcpyAsync(err.p, &no_err, 4, hipMemcpyHostToDevice, st));
     FZP_HIP(hipMemsetAsync(counters.p, 0, 8, st));
     OvlCols o = {s->d_q.p, s->d_t.p, s->d_file.p, s->d_ovl.p, s->d_q_s.p, s->d_q_e.p, s->d_q_l.p, s->d_t_s.p, s->d_t_e.p, s->d_t_l.p, s->d_flags.p};
-    { ProfScope ps(ctx, "ovl_tokenise"); hipLaunchKernelGGL(k_ovl_tok, dim3(blocks_for(nl, 256)), dim3(256), 0, st, text.p, ls.p, nl, fend.p, (int)s->file_end.size(), d_arid.p, max_id, o, err.p, counters.p); }
+    { ProfScope ps(ctx, "ovl_tokenise"); hipLaunchKernelGGL(k_ovl_tok, dim3(blocks_for(nl, 256)), dim3(256), 0, st, text.p, ls.p, nl, fend.p, (int)s->file_end.size(), arid_of.empty() ? (const int32_t *)nullptr : d_arid.p, max_id, o, err.p, counters.p); }
     s->line_off.resize((size_t)nl + 1);
     uint32_t h_cnt[2] = {0, 0};
     int32_t h_err = 0;
@@ -832,5 +833,310 @@ extern "C" int fzp_ovl_format(const fzp_ovlset *s, const int64_t *rows, int64_t 
     memcpy(p, out.data(), out.size());
     p[out.size()] = 0;
     *text = p; *len = out.size();
+    return FZP_OK;
+}
+
+
+// ================================================================================ raw-read tracker (rr_hctg_track.py)
+// run_track_reads (:68-139): for every raw read that shows up as the B-read of an overlap keep its bestn best A-reads
+// -- the heap of (overlap_len, q_id) tuples at :60-64 / :99-106 is "the bestn largest tuples" -- then score the contigs
+// those A-reads map to.  Same dumps, same tokeniser as the overlap filter (ids in raw mode).  Device: filter + phase
+// veto per line -> histogram of B-reads -> scan -> scatter into per-B-read segments -> one wave per B-read: rank the
+// segment, keep bestn, accumulate (contig -> score, count) in LDS, rank the contigs -> rows.  The reference's line
+// order is a dict order (:111), contigs of equal score keep dict order (:125): unspecified -> canonical order here
+// (B-read, score, contig string), as in the oracle and the fixtures.
+namespace {
+struct TrkPhase { int32_t has, ctg, block, phase; };
+
+__global__ void __launch_bounds__(256) k_trk_filter(int64_t n, const int32_t *__restrict__ qv, const int32_t *__restrict__ tv, const int32_t *__restrict__ t_l,
+                                                    const uint8_t *__restrict__ flags, int32_t min_len, const int32_t *__restrict__ rid_of, int64_t max_rid,
+                                                    const TrkPhase *__restrict__ rph, int64_t n_rid, uint32_t *__restrict__ pass, uint32_t *__restrict__ bcount,
+                                                    int32_t *__restrict__ err_parse, int32_t *__restrict__ err_id) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    uint32_t ok = 0;
+    if (!(flags[i] & F_PARSE_OK)) atomicMin(err_parse, (int32_t)i);            // every line is parsed before any test (:38-42)
+    else if (t_l[i] >= min_len) {
+        const int32_t q = qv[i], t = tv[i];
+        if (q < 0 || t < 0) atomicMin(err_id, (int32_t)i);                     // not a '%09d' id: outside this implementation
+        else if (q <= max_rid && rid_of[q] >= 0) {                             // `q_id in rid_to_ctg`
+            if (t >= n_rid) atomicMin(err_id, (int32_t)i);                     // IndexError at :50
+            else {
+                ok = 1;
+                const TrkPhase tp = rph[t];
+                if (tp.has && tp.block != -1) {
+                    if (q >= n_rid) atomicMin(err_id, (int32_t)i);
+                    else {
+                        const TrkPhase qp = rph[q];
+                        if (qp.has && qp.ctg == tp.ctg && qp.block == tp.block && qp.phase != tp.phase) ok = 0;
+                    }
+                }
+                if (ok) atomicAdd(&bcount[t], 1u);
+            }
+        }
+    }
+    pass[i] = ok;
+}
+__global__ void __launch_bounds__(256) k_trk_scatter(int64_t n, const uint32_t *__restrict__ pass, const int32_t *__restrict__ qv, const int32_t *__restrict__ tv,
+                                                     const int32_t *__restrict__ ovl, const uint32_t *__restrict__ boff, uint32_t *__restrict__ bfill,
+                                                     int2 *__restrict__ seg) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || !pass[i]) return;
+    const int32_t t = tv[i];
+    seg[boff[t] + atomicAdd(&bfill[t], 1u)] = make_int2(ovl[i], qv[i]);
+}
+struct TrkRow { int32_t bread, ctg, count, rank; int64_t score; int32_t in_ctg, pad_; };
+constexpr int TRK_CAP = 64;     // distinct contigs one B-read's kept A-reads may map to
+
+// one wave per B-read with hits
+__global__ void __launch_bounds__(256) k_trk_reads(int64_t n_b, const int32_t *__restrict__ blist, const uint32_t *__restrict__ boff, const uint32_t *__restrict__ bcount,
+                                                   const int2 *__restrict__ seg, int64_t bestn, const int32_t *__restrict__ rid_of, int64_t max_rid,
+                                                   const int64_t *__restrict__ rc_off, const int32_t *__restrict__ rc_ctg, const int32_t *__restrict__ ctg_lex,
+                                                   TrkRow *__restrict__ rows, uint32_t *__restrict__ n_rows, uint32_t row_cap, int32_t *__restrict__ err_cap) {
+    __shared__ int32_t l_key[4][TRK_CAP];
+    __shared__ int32_t l_cnt[4][TRK_CAP];
+    __shared__ long long l_score[4][TRK_CAP];
+    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    for (int64_t bi = (int64_t)blockIdx.x * 4 + wv; bi < n_b; bi += (int64_t)gridDim.x * 4) {
+        const int32_t t = blist[bi];
+        const uint32_t s0 = boff[t], m = bcount[t];
+        for (int x = lane; x < TRK_CAP; x += 64) { l_key[wv][x] = -1; l_cnt[wv][x] = 0; l_score[wv][x] = 0; }
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t k0 = 0; k0 < m; k0 += 64) {
+            const uint32_t k = k0 + lane;
+            int2 a = make_int2(0, 0);
+            uint32_t r = 0;
+            if (k < m) a = seg[s0 + k];
+            for (uint32_t kb = 0; kb < m; kb++) {               // the heap keeps the largest (overlap_len, q_id) tuples
+                const int2 b = seg[s0 + kb];
+                r += (b.x > a.x || (b.x == a.x && (b.y > a.y || (b.y == a.y && kb < k)))) ? 1u : 0u;
+            }
+            if (k < m && (int64_t)r < bestn) {
+                const int32_t rq = rid_of[a.y];                  // >= 0: the line passed `q_id in rid_to_ctg`
+                for (int64_t z = rc_off[rq]; z < rc_off[rq + 1]; z++) {
+                    const int32_t c = rc_ctg[z];
+                    int slot = c & (TRK_CAP - 1), tries = 0;
+                    for (; tries < TRK_CAP; tries++, slot = (slot + 1) & (TRK_CAP - 1)) {
+                        const int32_t old = atomicCAS(&l_key[wv][slot], -1, c);
+                        if (old == -1 || old == c) break;
+                    }
+                    if (tries == TRK_CAP) { atomicMin(err_cap, t); continue; }
+                    atomicAdd(&l_cnt[wv][slot], 1);
+                    atomicAdd((unsigned long long *)&l_score[wv][slot], (unsigned long long)(long long)(-(long long)a.x));
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // rank the contigs by (score, contig string) and write the rows
+        const int32_t c = lane < TRK_CAP ? l_key[wv][lane] : -1;
+        const long long sc = lane < TRK_CAP ? l_score[wv][lane] : 0;
+        int32_t rk = 0;
+        for (int x = 0; x < TRK_CAP; x++) {
+            const int32_t oc = l_key[wv][x];
+            if (oc < 0 || oc == c) continue;
+            const long long os = l_score[wv][x];
+            rk += (os < sc || (os == sc && ctg_lex[oc] < ctg_lex[c < 0 ? 0 : c])) ? 1 : 0;
+        }
+        const uint64_t have = __ballot(c >= 0);
+        uint32_t base = 0;
+        if (lane == 0 && have) base = atomicAdd(n_rows, (uint32_t)__popcll(have));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (c >= 0) {
+            const uint32_t at = base + (uint32_t)__popcll(have & ((1ull << lane) - 1ull));
+            if (at < row_cap) {
+                TrkRow o;
+                o.bread = t; o.ctg = c; o.count = l_cnt[wv][lane]; o.rank = rk; o.score = sc; o.pad_ = 0;
+                o.in_ctg = 0;
+                if (t <= max_rid && rid_of[t] >= 0) {
+                    const int32_t rt = rid_of[t];
+                    for (int64_t z = rc_off[rt]; z < rc_off[rt + 1]; z++) if (rc_ctg[z] == c) o.in_ctg = 1;
+                }
+                rows[at] = o;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+__global__ void __launch_bounds__(256) k_trk_blist(int64_t n_rid, const uint32_t *__restrict__ bcount, const uint32_t *__restrict__ pos, int32_t *__restrict__ blist,
+                                                   uint32_t *__restrict__ flag) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_rid) return;
+    if (flag) { flag[t] = bcount[t] ? 1u : 0u; return; }
+    if (bcount[t]) blist[pos[t]] = (int32_t)t;
+}
+}  // namespace
+
+extern "C" int fzp_track_reads(fzp_ctx *ctx, int32_t n_files, const char *const *texts, const size_t *lens, const char *phased_reads, size_t pr_len,
+                               const char *read_to_contig_map, size_t rc_len, const char *rawread_ids, size_t ri_len, int64_t min_len, int64_t bestn,
+                               char **text_out, size_t *len_out) {
+    if (!ctx || n_files < 0 || (n_files && (!texts || !lens)) || !text_out || !len_out) { fzp_set_error("fzp_track_reads: bad arguments"); return FZP_EINVAL; }
+    *text_out = nullptr; *len_out = 0;
+    FZP_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    // ---- read_to_contig_map (:14-23): rid -> set of contigs.  rids must be '%09d'-shaped (fc_get_read_hctg_map writes them so)
+    std::string rc_text(read_to_contig_map ? read_to_contig_map : "", rc_len), pr_text(phased_reads ? phased_reads : "", pr_len);
+    std::unordered_map<std::string_view, int32_t> ctg_ids;
+    std::vector<std::string_view> ctg_names;
+    auto ctg_of = [&](std::string_view v) {
+        auto it = ctg_ids.find(v);
+        if (it != ctg_ids.end()) return it->second;
+        const int32_t c = (int32_t)ctg_names.size();
+        ctg_ids.emplace(v, c); ctg_names.push_back(v);
+        return c;
+    };
+    std::vector<std::pair<int32_t, int32_t>> pairs;     // (rid value, contig)
+    int64_t max_rid = -1;
+    {
+        const char *mt = rc_text.data();
+        const int64_t n = (int64_t)rc_text.size();
+        for (int64_t b = 0, row = 0; b < n; row++) {
+            const void *nlp = memchr(mt + b, '\n', (size_t)(n - b));
+            const int64_t e = nlp ? (const char *)nlp - mt : n;
+            Tok t[6];
+            const int nt = split_line(mt, b, e, t, 6);
+            b = nlp ? e + 1 : n;
+            if (nt != 4) { fzp_set_error("read_to_contig_map row %lld has %d fields (ValueError at rr_hctg_track.py:20)", (long long)row, nt); return FZP_EINVAL; }
+            int64_t v;
+            if (!canonical_id(mt + t[1].off, t[1].len, &v) || t[1].len != 9) { fzp_set_error("read_to_contig_map row %lld: read id is not a 9-digit decimal (unsupported)", (long long)row); return FZP_EINVAL; }
+            pairs.push_back({(int32_t)v, ctg_of(std::string_view(mt + t[3].off, (size_t)t[3].len))});
+            max_rid = std::max(max_rid, v);
+        }
+    }
+    // ---- phased reads -> oid -> (ctg, block, phase), later rows win (:73-81); rawread_ids.split('\n') (:83)
+    std::unordered_map<std::string_view, TrkPhase> oid_phase;
+    {
+        const char *mt = pr_text.data();
+        const int64_t n = (int64_t)pr_text.size();
+        for (int64_t b = 0, row = 0; b < n; row++) {
+            const void *nlp = memchr(mt + b, '\n', (size_t)(n - b));
+            const int64_t e = nlp ? (const char *)nlp - mt : n;
+            Tok t[8];
+            const int nt = split_line(mt, b, e, t, 8);
+            b = nlp ? e + 1 : n;
+            int64_t blk, ph;
+            if (nt < 7 || !parse_int32(mt + t[2].off, t[2].len, &blk) || !parse_int32(mt + t[3].off, t[3].len, &ph)) {
+                fzp_set_error("phased-read-file row %lld is malformed (IndexError/ValueError at rr_hctg_track.py:76-80)", (long long)row);
+                return FZP_EINVAL;
+            }
+            oid_phase[std::string_view(mt + t[6].off, (size_t)t[6].len)] = TrkPhase{1, ctg_of(std::string_view(mt + t[1].off, (size_t)t[1].len)), (int32_t)blk, (int32_t)ph};
+        }
+    }
+    std::vector<TrkPhase> rph;
+    {
+        size_t b = 0;
+        for (size_t i = 0; i <= ri_len; i++)
+            if (i == ri_len || rawread_ids[i] == '\n') {
+                auto it = oid_phase.find(std::string_view(rawread_ids + b, i - b));
+                rph.push_back(it == oid_phase.end() ? TrkPhase{0, 0, 0, 0} : it->second);
+                b = i + 1;
+            }
+    }
+    const int64_t n_rid = (int64_t)rph.size();
+    // CSR rid value -> distinct contigs; contig lexicographic ranks
+    std::sort(pairs.begin(), pairs.end());
+    pairs.erase(std::unique(pairs.begin(), pairs.end()), pairs.end());
+    std::vector<int32_t> rid_of((size_t)max_rid + 2, -1), rc_ctg;
+    std::vector<int64_t> rc_off(1, 0);
+    int64_t k_max = 1;
+    for (size_t i = 0; i < pairs.size();) {
+        size_t j2 = i;
+        while (j2 < pairs.size() && pairs[j2].first == pairs[i].first) { rc_ctg.push_back(pairs[j2].second); j2++; }
+        rid_of[(size_t)pairs[i].first] = (int32_t)rc_off.size() - 1;
+        rc_off.push_back((int64_t)rc_ctg.size());
+        k_max = std::max<int64_t>(k_max, (int64_t)(j2 - i));
+        i = j2;
+    }
+    std::vector<int32_t> ctg_lex(ctg_names.size() + 1, 0);
+    {
+        std::vector<int32_t> ord(ctg_names.size());
+        for (size_t i = 0; i < ord.size(); i++) ord[i] = (int32_t)i;
+        std::sort(ord.begin(), ord.end(), [&](int32_t a, int32_t b) { return ctg_names[(size_t)a] < ctg_names[(size_t)b]; });
+        for (size_t r = 0; r < ord.size(); r++) ctg_lex[(size_t)ord[r]] = (int32_t)r;
+    }
+    // ---- the dumps: tokenise on the device (raw-id mode)
+    fzp_ovlset *s = new fzp_ovlset();
+    struct Guard { fzp_ovlset *p; ~Guard() { delete p; } } guard{s};
+    s->device = ctx->device;
+    size_t total = 0;
+    for (int k = 0; k < n_files; k++) total += lens[k] + 1;
+    if (!s->text.reserve(total + 16)) { fzp_set_error("fzp_track_reads: host allocation failed"); return FZP_ENOMEM; }
+    for (int k = 0; k < n_files; k++) {
+        if (lens[k]) s->text.append(texts[k], lens[k]);
+        if (lens[k] && s->text.back() != '\n') s->text.push_back('\n');
+        s->file_end.push_back((int64_t)s->text.size());
+    }
+    if (s->text.size() >= (1ull << 32)) { fzp_set_error("fzp_track_reads: %zu bytes of text (limit 4 GiB per call)", s->text.size()); return FZP_EINVAL; }
+    std::vector<TrkRow> h_rows;
+    if (s->text.size() > 0) {
+        DevBuf<uint8_t> d_text;
+        const int64_t n16 = ((int64_t)s->text.size() + 15) / 16;
+        FZP_TRY(d_text.alloc((size_t)n16 * 16));
+        FZP_HIP(hipMemsetAsync(d_text.p + (n16 - 1) * 16, 0, 16, st));
+        FZP_HIP(hipMemcpyAsync(d_text.p, s->text.data(), s->text.size(), hipMemcpyHostToDevice, st));
+        FZP_TRY(ovl_tokenise_device(ctx, s, 0, std::vector<int32_t>(), d_text));
+        const int64_t n = s->n_lines;
+        DevBuf<int32_t> d_rid_of, d_rc_ctg, d_ctg_lex, d_blist, e1, e2, e3;
+        DevBuf<int64_t> d_rc_off;
+        DevBuf<TrkPhase> d_rph;
+        DevBuf<uint32_t> pass, bcount, boff, bfill, bflag, bpos, n_rows;
+        DevBuf<int2> seg;
+        DevBuf<TrkRow> rows;
+        DevBuf<uint64_t> totals;
+        FZP_TRY(d_rid_of.upload(rid_of.data(), rid_of.size(), st)); FZP_TRY(d_rc_ctg.upload(rc_ctg.data(), rc_ctg.size(), st)); FZP_TRY(d_rc_off.upload(rc_off.data(), rc_off.size(), st));
+        FZP_TRY(d_ctg_lex.upload(ctg_lex.data(), ctg_lex.size(), st)); FZP_TRY(d_rph.upload(rph.data(), rph.size(), st));
+        FZP_TRY(pass.alloc((size_t)n)); FZP_TRY(bcount.alloc((size_t)n_rid)); FZP_TRY(boff.alloc((size_t)n_rid)); FZP_TRY(bfill.alloc((size_t)n_rid));
+        FZP_TRY(bflag.alloc((size_t)n_rid)); FZP_TRY(bpos.alloc((size_t)n_rid)); FZP_TRY(totals.alloc(2)); FZP_TRY(n_rows.alloc(1));
+        FZP_TRY(e1.alloc(1)); FZP_TRY(e2.alloc(1)); FZP_TRY(e3.alloc(1));
+        FZP_TRY(bcount.zero((size_t)n_rid, st)); FZP_TRY(bfill.zero((size_t)n_rid, st)); FZP_TRY(n_rows.zero(1, st));
+        const int32_t none = 0x7fffffff;
+        FZP_HIP(hipMemcpyAsync(e1.p, &none, 4, hipMemcpyHostToDevice, st)); FZP_HIP(hipMemcpyAsync(e2.p, &none, 4, hipMemcpyHostToDevice, st));
+        FZP_HIP(hipMemcpyAsync(e3.p, &none, 4, hipMemcpyHostToDevice, st));
+        const int32_t ml = (int32_t)std::max<int64_t>(-2147483647ll, std::min<int64_t>(min_len, 2147483647ll));
+        { ProfScope ps(ctx, "trk_filter"); hipLaunchKernelGGL(k_trk_filter, dim3(blocks_for(n, 256)), dim3(256), 0, st, n, s->d_q.p, s->d_t.p, s->d_t_l.p, s->d_flags.p, ml, d_rid_of.p, max_rid, d_rph.p, n_rid, pass.p, bcount.p, e1.p, e2.p); }
+        FZP_TRY(fzp_exclusive_scan_u32(ctx, bcount.p, boff.p, (size_t)n_rid, totals.p));
+        hipLaunchKernelGGL(k_trk_blist, dim3(blocks_for(n_rid, 256)), dim3(256), 0, st, n_rid, bcount.p, (const uint32_t *)nullptr, (int32_t *)nullptr, bflag.p);
+        FZP_TRY(fzp_exclusive_scan_u32(ctx, bflag.p, bpos.p, (size_t)n_rid, totals.p + 1));
+        uint64_t tot[2] = {0, 0};
+        int32_t h_e1 = 0, h_e2 = 0;
+        FZP_HIP(hipMemcpyAsync(tot, totals.p, 16, hipMemcpyDeviceToHost, st));
+        FZP_HIP(hipMemcpyAsync(&h_e1, e1.p, 4, hipMemcpyDeviceToHost, st)); FZP_HIP(hipMemcpyAsync(&h_e2, e2.p, 4, hipMemcpyDeviceToHost, st));
+        FZP_HIP(hipStreamSynchronize(st));
+        if (h_e1 != none) { fzp_set_error("overlap line %d has a field int()/float() rejects or fewer than 12 columns (rr_hctg_track.py:36-42)", h_e1); return FZP_EINVAL; }
+        if (h_e2 != none) { fzp_set_error("overlap line %d: read id is not a 9-digit decimal, or is beyond rawread_ids (IndexError at rr_hctg_track.py:50)", h_e2); return FZP_EINVAL; }
+        const int64_t n_hits = (int64_t)tot[0], n_b = (int64_t)tot[1];
+        if (n_b > 0) {
+            const uint64_t cap64 = (uint64_t)std::min<int64_t>(n_hits, n_b * std::max<int64_t>(bestn, 0)) * (uint64_t)k_max + 64;
+            if (cap64 >= (1ull << 31)) { fzp_set_error("fzp_track_reads: output bound of %llu rows is too large for one call", (unsigned long long)cap64); return FZP_EINVAL; }
+            FZP_TRY(seg.alloc((size_t)n_hits)); FZP_TRY(d_blist.alloc((size_t)n_b)); FZP_TRY(rows.alloc((size_t)cap64));
+            hipLaunchKernelGGL(k_trk_scatter, dim3(blocks_for(n, 256)), dim3(256), 0, st, n, pass.p, s->d_q.p, s->d_t.p, s->d_ovl.p, boff.p, bfill.p, seg.p);
+            hipLaunchKernelGGL(k_trk_blist, dim3(blocks_for(n_rid, 256)), dim3(256), 0, st, n_rid, bcount.p, bpos.p, d_blist.p, (uint32_t *)nullptr);
+            { ProfScope ps(ctx, "trk_reads"); hipLaunchKernelGGL(k_trk_reads, dim3((unsigned)std::min<int64_t>(blocks_for(n_b, 4), 1 << 16)), dim3(256), 0, st, n_b, d_blist.p, boff.p, bcount.p, seg.p, bestn, d_rid_of.p, max_rid, d_rc_off.p, d_rc_ctg.p, d_ctg_lex.p, rows.p, n_rows.p, (uint32_t)cap64, e3.p); }
+            uint32_t h_n = 0;
+            int32_t h_e3 = 0;
+            FZP_HIP(hipMemcpyAsync(&h_n, n_rows.p, 4, hipMemcpyDeviceToHost, st)); FZP_HIP(hipMemcpyAsync(&h_e3, e3.p, 4, hipMemcpyDeviceToHost, st));
+            FZP_HIP(hipStreamSynchronize(st));
+            if (h_e3 != none) { fzp_set_error("read %d: its best hits map to more than %d contigs (limit of this implementation)", h_e3, TRK_CAP); return FZP_EINVAL; }
+            h_rows.resize(h_n);
+            FZP_TRY(rows.download(h_rows.data(), h_n, st));
+            FZP_HIP(hipStreamSynchronize(st));
+        }
+        FZP_HIP(hipGetLastError());
+    }
+    // ---- canonical order and text (:134): bread ctg count rank score in_ctg
+    std::sort(h_rows.begin(), h_rows.end(), [](const TrkRow &a, const TrkRow &b) { return a.bread != b.bread ? a.bread < b.bread : a.rank < b.rank; });
+    std::string out;
+    char num[160];
+    for (const TrkRow &r : h_rows) {
+        const int k = snprintf(num, sizeof num, "%09d ", r.bread);
+        out.append(num, (size_t)k);
+        out.append(ctg_names[(size_t)r.ctg]);
+        const int k2 = snprintf(num, sizeof num, " %d %d %lld %d\n", r.count, r.rank, (long long)r.score, r.in_ctg);
+        out.append(num, (size_t)k2);
+    }
+    char *p = (char *)malloc(out.size() + 1);
+    if (!p) return FZP_ENOMEM;
+    memcpy(p, out.data(), out.size());
+    p[out.size()] = 0;
+    *text_out = p; *len_out = out.size();
     return FZP_OK;
 }

@@ -309,6 +309,16 @@ int fzp_ovl_filter(fzp_ctx *ctx, const fzp_ovlset *s, const fzp_ovlp_params *par
 int fzp_ovl_format(const fzp_ovlset *s, const int64_t *rows, int64_t n_rows, char **text, size_t *len);
 int fzp_ovl_id_name(const fzp_ovlset *s, int32_t id, const char **name, int32_t *len);
 
+/* ======================================================================== raw-read tracker ("next" row n4)
+ * falcon_unzip/rr_hctg_track.py (run_track_reads :68-139, tr_stage1 :31-66): from `LA4Falcon -m` dumps of the raw-read
+ * overlaps, keep for every B-read its bestn best A-reads (phase-incompatible pairs vetoed, :49-57) and score the contigs
+ * those A-reads map to.  text = the rawread_to_contigs file, "bread ctg count rank score in_ctg" per line, in CANONICAL
+ * order (B-read id, score, contig name): the reference's own line order is a Python dict order.  Read ids must be
+ * 9-digit decimals (what LA4Falcon and fc_get_read_hctg_map write); anything else is FZP_EINVAL. */
+int fzp_track_reads(fzp_ctx *ctx, int32_t n_files, const char *const *texts, const size_t *lens,
+                    const char *phased_reads, size_t pr_len, const char *read_to_contig_map, size_t rc_len,
+                    const char *rawread_ids, size_t ri_len, int64_t min_len, int64_t bestn, char **text, size_t *len);
+
 #ifdef __cplusplus
 }
 #endif
