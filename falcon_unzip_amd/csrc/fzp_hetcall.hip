@@ -190,50 +190,66 @@ __global__ void k_site_begin(const int64_t *__restrict__ site_g, int64_t n_sites
 }
 
 // ---- K2d: scatter (record index, q_id) of every column that carries a called site's major/minor allele
-__global__ void __launch_bounds__(256) k_vmap_scatter(RecView v, const uint8_t *__restrict__ flag8, const uint32_t *__restrict__ site_idx,
-                                                      const fzp_site *__restrict__ sites, uint32_t *__restrict__ vfill, uint64_t *__restrict__ vtmp) {
-    for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < v.n_rec; r += (int64_t)gridDim.x * 4) {
-        const int c = v.rec_ctg[r];
-        const int64_t goff = v.ctg_goff[c];
-        const int32_t lim = v.ctg_limit[c];
-        const uint32_t qid = (uint32_t)v.rec_qid[r];
-        expand_record(v, r, [&](int32_t pos, uint8_t sym) {
-            if (pos >= lim) return;
-            int64_t g = goff + pos;
-            if (!flag8[g]) return;
-            uint32_t si = site_idx[g];
-            const fzp_site &s = sites[si];
-            int a = sym == s.base[0] ? 0 : (sym == s.base[1] ? 1 : -1);
-            if (a < 0) return;
-            uint32_t slot = atomicAdd(&vfill[2 * si + a], 1u);
-            vtmp[s.row_off + (a ? s.count[0] : 0) + slot] = ((uint64_t)r << 32) | qid;
-        });
-    }
-}
-
-// ---- K2e: order each (site, allele) segment by record index (== the reference's append order)
-__global__ void __launch_bounds__(256) k_vmap_sort(const fzp_site *__restrict__ sites, int64_t n_sites, const uint64_t *__restrict__ vtmp,
-                                                   int32_t *__restrict__ vmap_qid) {
+// variant_map rows (phasing.py:125-128), site-centric: one wave per called site.  The records covering the site are
+// a contiguous candidate range (POS-sorted, bounded by the contig's longest reference span); lane = candidate: it finds
+// the record's symbol at the site through the 64-op CIGAR checkpoints (one binary search + a walk of at most one
+// chunk), and the rows of each allele come out in record order by ballot ranks -- no atomics, no sort, and the
+// 581 M columns of the batch are not expanded a second time for ~1 M rows.
+__global__ void __launch_bounds__(256) k_vmap_sites(RecView v, int64_t n_sites, const fzp_site *__restrict__ sites, const int32_t *__restrict__ site_ctg,
+                                                    const int64_t *__restrict__ ctg_rec_begin, const int32_t *__restrict__ ctg_maxspan,
+                                                    const int32_t *__restrict__ rec_span, const int64_t *__restrict__ ck_off, const int32_t *__restrict__ ck_ref,
+                                                    const int32_t *__restrict__ ck_q, int32_t *__restrict__ vmap_qid) {
     const int lane = lane_id();
-    int64_t w = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
-    if (w >= n_sites * 2) return;
-    const fzp_site &s = sites[w >> 1];
-    const int a = (int)(w & 1);
-    const int64_t seg = s.row_off + (a ? s.count[0] : 0);
-    const int n = s.count[a];
-    for (int base = 0; base < n; base += 64) {
-        int idx = base + lane;
-        uint64_t my = idx < n ? vtmp[seg + idx] : ~0ull;
-        int rank = 0;
-        for (int j0 = 0; j0 < n; j0 += 64) {
-            uint64_t other = (j0 + lane < n) ? vtmp[seg + j0 + lane] : ~0ull;
-            int m = min(64, n - j0);
-            for (int k = 0; k < m; k++) {
-                uint64_t o = __shfl(other, k, 64);
-                rank += (o < my) ? 1 : 0;
-            }
+    for (int64_t si = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); si < n_sites; si += (int64_t)gridDim.x * 4) {
+        const fzp_site s = sites[si];
+        const int c = site_ctg[si];
+        const int32_t pos = s.pos;
+        const int64_t rb = ctg_rec_begin[c], re = ctg_rec_begin[c + 1];
+        int64_t lo, hi;
+        {
+            const int32_t ms = ctg_maxspan[c];
+            int64_t a = rb, b = re;
+            while (a < b) { const int64_t m = (a + b) >> 1; if (v.rec_pos[m] <= pos - ms) a = m + 1; else b = m; }
+            lo = a;
+            b = re;
+            while (a < b) { const int64_t m = (a + b) >> 1; if (v.rec_pos[m] <= pos) a = m + 1; else b = m; }
+            hi = a;
         }
-        if (idx < n) vmap_qid[seg + rank] = (int32_t)(uint32_t)(my & 0xffffffffu);
+        int32_t base0 = 0, base1 = 0;                      // rows of each allele written so far
+        for (int64_t r0 = lo; r0 < hi; r0 += 64) {
+            const int64_t r = r0 + lane;
+            int al = -1;
+            if (r < hi) {
+                const int32_t rel = pos - v.rec_pos[r];
+                if (rel < rec_span[r]) {
+                    const int64_t k0 = ck_off[r];
+                    int32_t ca = 0, cb = (int32_t)(ck_off[r + 1] - k0);
+                    while (cb - ca > 1) { const int32_t m = (ca + cb) >> 1; if (ck_ref[k0 + m] <= rel) ca = m; else cb = m; }
+                    int32_t rp = ck_ref[k0 + ca], qp = ck_q[k0 + ca];
+                    const int64_t c1 = v.cig_off[r + 1];
+                    for (int64_t k = v.cig_off[r] + (int64_t)ca * 64; k < c1; k++) {
+                        const uint32_t w = v.cigar[k], len = w >> 4, t = w & 15u;
+                        const bool isM = (t == FZP_OP_M) | (t == FZP_OP_EQ) | (t == FZP_OP_X);
+                        if (isM | (t == FZP_OP_D)) {
+                            if (rel < rp + (int32_t)len) {
+                                if (isM) {
+                                    const uint8_t sym = v.seq[v.seq_off[r] + qp + (rel - rp)];
+                                    al = sym == s.base[0] ? 0 : (sym == s.base[1] ? 1 : -1);
+                                }
+                                break;
+                            }
+                            rp += (int32_t)len;
+                        }
+                        if (isM | (t == FZP_OP_I) | (t == FZP_OP_S)) qp += (int32_t)len;
+                    }
+                }
+            }
+            const uint64_t m0 = __ballot(al == 0), m1 = __ballot(al == 1);
+            const uint64_t below = (1ull << lane) - 1ull;
+            if (al == 0) vmap_qid[s.row_off + base0 + __popcll(m0 & below)] = v.rec_qid[r];
+            if (al == 1) vmap_qid[s.row_off + s.count[0] + base1 + __popcll(m1 & below)] = v.rec_qid[r];
+            base0 += __popcll(m0); base1 += __popcll(m1);
+        }
     }
 }
 
@@ -452,10 +468,7 @@ int fzp_k2_het_call(fzp_ctx *ctx, fzp_batch *b) {
     FZP_TRY(b->site_g.alloc((size_t)b->n_sites));
     FZP_TRY(b->site_ctg.alloc((size_t)b->n_sites));
     FZP_TRY(b->site_begin.alloc((size_t)b->n_ctg + 1));
-    FZP_TRY(b->vtmp.alloc((size_t)b->n_rows));
     FZP_TRY(b->vmap_qid.alloc((size_t)b->n_rows));
-    FZP_TRY(b->vfill.alloc((size_t)b->n_sites * 2));
-    FZP_TRY(b->vfill.zero((size_t)b->n_sites * 2, st));
     if (b->n_sites > 0) {
         {
             ProfScope ps(ctx, "k2_site_emit");
@@ -464,12 +477,8 @@ int fzp_k2_het_call(fzp_ctx *ctx, fzp_batch *b) {
         }
         {
             ProfScope ps(ctx, "k2_vmap_scatter");
-            hipLaunchKernelGGL(k_vmap_scatter, dim3(grid_for(b->n_rec, 4, 1 << 16)), dim3(256), 0, st, v, b->flag8.p, b->site_idx.p, b->sites.p,
-                               b->vfill.p, b->vtmp.p);
-        }
-        {
-            ProfScope ps(ctx, "k2_vmap_sort");
-            hipLaunchKernelGGL(k_vmap_sort, dim3(grid_for(b->n_sites * 2, 4, 1 << 30)), dim3(256), 0, st, b->sites.p, b->n_sites, b->vtmp.p, b->vmap_qid.p);
+            hipLaunchKernelGGL(k_vmap_sites, dim3(grid_for(b->n_sites, 4, 1 << 16)), dim3(256), 0, st, v, b->n_sites, b->sites.p, b->site_ctg.p, b->ctg_rec_begin.p,
+                               b->ctg_maxspan.p, b->rec_span.p, b->ck_off.p, b->ck_ref.p, b->ck_q.p, b->vmap_qid.p);
         }
     }
     hipLaunchKernelGGL(k_site_begin, dim3((b->n_ctg + 1 + 63) / 64), dim3(64), 0, st, b->site_g.p, b->n_sites, b->ctg_goff.p, b->n_ctg, b->site_begin.p);
