@@ -176,3 +176,34 @@ def test_empty_and_unaligned_only_jobs(eng):
     assert b.counts()["n_sites"] == 0
     b.close()
     job.close()
+
+
+def test_long_reads_match_twin(eng, oracle):
+    """Reads of 40-110 kb (masks of one read: up to ~4 MB, op streams past one LDS load) against the twin, then K2..K6 run."""
+    from falcon_unzip_amd import _lib, sim
+    rng = np.random.Generator(np.random.PCG64(123))
+    L = 260000
+    hap0, hap1, _ = sim.make_diploid(L, rng, het_rate=1.0 / 400)
+    ctg = sim.codes_to_str(hap0).encode()
+    raw = []
+    for n, strand in ((40000, 0), (65000, 1), (110000, 0), (90000, 1)):
+        s0 = int(rng.integers(0, L - n))
+        codes = hap0[s0:s0 + n]
+        seq, _, _ = sim.simulate_read(codes, codes, 0, n, rng)
+        raw.append(sim.codes_to_str(sim.revcomp_codes(seq) if strand else seq).encode())
+    exp, exp_cig = oracle_lib.align_reads(oracle, ctg, raw)
+    job = _lib.align_job(eng, [ctg], raw)
+    job.run()
+    got = job.summaries()
+    for f in FIELDS:
+        assert np.array_equal(got[f], exp[f]), (f, got[f], exp[f])
+    assert got["aligned"].all() and (got["q_end"] - got["q_start"] > 0.98 * np.array([len(r) for r in raw])).all()
+    aln, idx = job.alnset(0)
+    for k, r in enumerate(idx):
+        words = np.array([(l << 4) | o for l, o in aln.cigar_of(k)], dtype=np.uint32)
+        assert np.array_equal(words, exp_cig[r]), (k, r)
+    b = job.to_batch()
+    b.run(_lib.STAGE_ALL)
+    t = b.consensus()
+    assert len(b.results()[0].sites) == 0 and len(t.tigs) == 0        # 4-fold coverage: nothing reaches total >= 10
+    t.close(); b.close(); job.close()
