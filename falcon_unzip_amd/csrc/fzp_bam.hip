@@ -203,6 +203,7 @@ extern "C" int fzp_bam_to_sam(const uint8_t *bam, size_t len, const char *region
         const uint8_t *tail = bam + p + bsize - 8;
         const uint32_t crc = tail[0] | (tail[1] << 8) | (tail[2] << 16) | ((uint32_t)tail[3] << 24);
         const uint32_t isize = tail[4] | (tail[5] << 8) | (tail[6] << 16) | ((uint32_t)tail[7] << 24);
+        if (isize > 65536) { fzp_set_error("BGZF block at offset %zu claims %u bytes (limit 65536)", p, isize); return FZP_EINVAL; }
         if (isize) {
             const size_t at = d.size();
             d.resize(at + isize);
