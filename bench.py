@@ -235,6 +235,9 @@ def main():
             "stage_counts": {k: int(v) for k, v in stats.items()},
             "kernel_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in sorted(prof.items())},
             "host_wall_ms_per_step": {k: round(v / args.steps * 1e3, 3) for k, v in host_t.items()},
+            # the segment that is bit-exact against the reference (alignments given -> phased reads): K2..K5 + record download
+            "phasing_only": {"ms_per_step": round((host_t["phase_run"] + host_t["results"]) / args.steps * 1e3, 3),
+                             "reads_per_s": round(n_reads * args.steps / max(1e-9, host_t["phase_run"] + host_t["results"]), 1)},
             "roofline": {"bound": "hbm", "kernel": "k1_sw", "achieved": round(cells_per_launch * SW_BYTES_PER_CELL / (sw_avg_ms * 1e-3) / 1e9, 2) if sw_avg_ms else 0.0,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(cells_per_launch * SW_BYTES_PER_CELL / (sw_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if sw_avg_ms else 0.0,
