@@ -1,0 +1,39 @@
+"""bench.py's N > 1 flow on a one-GPU box: two ranks under torch.distributed.run share GPU 0 (gloo for the exchange
+step; on a multi-GPU node the same code path runs over RCCL).  Checks the JSON contract and that both ranks' work is in
+`value`."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--contigs", "2", "--contig-len", "300000", "--reads-per-contig", "150", "--read-len", "8000", "--window", "120000", "--steps", "2", "--warmup", "1",
+         "--no-cpu-baseline", "--gen-workers", "1"]
+
+
+def run_bench(nproc):
+    env = dict(os.environ, FZP_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    if nproc == 1:
+        cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1"] + SMALL
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1", "--master-port", "29741",
+               os.path.join(REPO, "bench.py"), "--gpus", str(nproc)] + SMALL
+    out = subprocess.check_output(cmd, env=env, cwd=REPO, stderr=subprocess.DEVNULL, timeout=600).decode()
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out
+    return json.loads(lines[0])
+
+
+def test_two_ranks_share_one_gpu():
+    one = run_bench(1)
+    two = run_bench(2)
+    for d, n in ((one, 1), (two, 2)):
+        assert d["n_gpus"] == n and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["higher_is_better"] is True
+        assert d["unit"] == "reads/s" and d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"]
+        assert d["roofline"]["bound"] == "hbm" and d["roofline"]["launches"] >= 2
+        assert d["aligned_frac"] > 0.98
+    assert one["stage_counts"]["r2p_records"] == 300 and two["stage_counts"]["r2p_records"] == 600      # the all-gather saw both shards
+    assert two["config"]["reads_per_gpu"] == one["config"]["reads_per_gpu"] == 300
