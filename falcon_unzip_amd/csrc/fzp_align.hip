@@ -884,6 +884,67 @@ __global__ void __launch_bounds__(256) k_gather(int64_t n_rec, const int64_t *__
     uint8_t *sq = out_seq + out_seq_off[k];
     for (int64_t x = (int64_t)blockIdx.y * 256 + threadIdx.x; x < n; x += (int64_t)gridDim.y * 256) sq[x] = (uint8_t)("ACGT"[base_at(pk, x)]);
 }
+// ---- record planning on the device (what `samtools sort` + make_het_call's record filters do to the aligner's output,
+// phasing.py:47-75): per contig the aligned reads ordered by (POS, read index) -- q_id = rank in that order -- the
+// filters, and the offsets of every accepted record's CIGAR words, SEQ bytes and 64-op checkpoint chunks.
+// Slots: the reads of contig c own slots [slot_off[c], slot_off[c+1]); an aligned read lands in slot_off[c] + rank.
+struct PlanSlot { uint64_t rec, cig, seq, ck; };           // scanned in place: flags / sizes -> exclusive prefixes
+__global__ void __launch_bounds__(256) k_plan_keys(int64_t n, const int32_t *__restrict__ slot_read, const fzp_aln_summary *__restrict__ summ, uint64_t *__restrict__ key) {
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= n) return;
+    const int32_t r = slot_read[s];
+    key[s] = summ[r].aligned ? (((uint64_t)(uint32_t)summ[r].pos << 32) | (uint32_t)r) : ~0ull;
+}
+__global__ void __launch_bounds__(256) k_plan_rank(int64_t n, const int32_t *__restrict__ slot_read, const int32_t *__restrict__ slot_ctg, const int64_t *__restrict__ slot_off,
+                                                   const uint64_t *__restrict__ key, const fzp_aln_summary *__restrict__ summ, const int32_t *__restrict__ read_len,
+                                                   uint64_t *__restrict__ v_rec, uint64_t *__restrict__ v_cig, uint64_t *__restrict__ v_seq, uint64_t *__restrict__ v_ck,
+                                                   int32_t *__restrict__ g_read, int32_t *__restrict__ g_qid, uint8_t *__restrict__ g_acc, int32_t *__restrict__ last_pos,
+                                                   uint32_t *__restrict__ n_aligned, unsigned long long *__restrict__ n_cols) {
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= n) return;
+    const uint64_t k = key[s];
+    if (k == ~0ull) return;
+    const int c = slot_ctg[s];
+    uint32_t rank = 0;
+    for (int64_t x = slot_off[c]; x < slot_off[c + 1]; x++) rank += key[x] < k ? 1u : 0u;
+    const int32_t r = slot_read[s];
+    const fzp_aln_summary sm = summ[r];
+    const int64_t nlen = read_len[r];
+    const int64_t n_del = (int64_t)(sm.ref_end - sm.pos) - sm.n_columns;
+    const int64_t total_aln_pos = nlen + n_del;                       // sum of all CIGAR op lengths
+    const int64_t skip_base = (int64_t)sm.q_start + (nlen - sm.q_end);   // soft clips
+    // phasing.py:72 in IEEE double exactly as written (no contraction: explicit round-to-nearest ops)
+    const double frac = __dsub_rn(1.0, __ddiv_rn(__dmul_rn(1.0, (double)skip_base), (double)total_aln_pos));
+    const bool acc = !(frac < 0.1) && !(total_aln_pos < 2000);      // phasing.py:72, 74
+    const int64_t g = slot_off[c] + rank;
+    g_read[g] = r; g_qid[g] = (int32_t)rank; g_acc[g] = acc ? 1 : 0;
+    atomicAdd(&n_aligned[c], 1u);
+    if (acc) {
+        v_rec[g] = 1; v_cig[g] = (uint64_t)sm.n_cigar; v_seq[g] = (uint64_t)nlen; v_ck[g] = (uint64_t)((sm.n_cigar + 63) / 64);
+        atomicMax(&last_pos[c], sm.pos);
+        atomicAdd(&n_cols[c], (unsigned long long)sm.n_columns);
+    }
+}
+__global__ void __launch_bounds__(256) k_plan_emit(int64_t n, int n_ctg, const int32_t *__restrict__ slot_ctg_of_g, const int64_t *__restrict__ slot_off,
+                                                   const uint64_t *__restrict__ v_rec, const uint64_t *__restrict__ v_cig, const uint64_t *__restrict__ v_seq,
+                                                   const uint64_t *__restrict__ v_ck, const int32_t *__restrict__ g_read, const int32_t *__restrict__ g_qid,
+                                                   const uint8_t *__restrict__ g_acc, const fzp_aln_summary *__restrict__ summ, const uint64_t *__restrict__ totals,
+                                                   int64_t *__restrict__ rec_read, int32_t *__restrict__ rec_qid, int32_t *__restrict__ rec_pos, int32_t *__restrict__ rec_ctg,
+                                                   int64_t *__restrict__ cig_off, int64_t *__restrict__ seq_off, int64_t *__restrict__ ck_off, int64_t *__restrict__ rec_begin) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g == 0) {
+        const int64_t nr = (int64_t)totals[0];
+        cig_off[nr] = (int64_t)totals[1]; seq_off[nr] = (int64_t)totals[2]; ck_off[nr] = (int64_t)totals[3];
+    }
+    if (g <= n_ctg) { const int64_t so = slot_off[g]; rec_begin[g] = so < n ? (int64_t)v_rec[so] : (int64_t)totals[0]; }   // also right for contigs without reads
+    if (g >= n) return;
+    const int c = slot_ctg_of_g[g];
+    if (!g_acc[g]) return;
+    const int64_t k = (int64_t)v_rec[g];
+    const int32_t r = g_read[g];
+    rec_read[k] = r; rec_qid[k] = g_qid[g]; rec_pos[k] = summ[r].pos; rec_ctg[k] = c;
+    cig_off[k] = (int64_t)v_cig[g]; seq_off[k] = (int64_t)v_seq[g]; ck_off[k] = (int64_t)v_ck[g];
+}
 }  // namespace
 
 // ================================================================================ job
@@ -907,6 +968,11 @@ struct fzp_alnjob {
     DevBuf<uint2> tb2[2];
     DevBuf<uint32_t> raw2[2];                    // the walk's 2-bit op streams
     DevBuf<WalkOut> wout;
+    // record planning: reads grouped by contig (input order inside a contig); built on first use
+    DevBuf<int32_t> slot_read, slot_ctg;
+    DevBuf<int64_t> slot_off;
+    bool have_slots = false;
+    bool summ_on_host = false;
     DevBuf<ulonglong2> mvw2[2];
     hipEvent_t ev_sw[2] = {nullptr, nullptr}, ev_tb[2] = {nullptr, nullptr};
     DevBuf<fzp_aln_summary> summ;
@@ -1095,17 +1161,28 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
         for (int b2 = 0; b2 < 2; b2++)
             if (used[b2]) FZP_HIP(hipStreamWaitEvent(st, j->ev_tb[b2], 0));   // the main stream continues after all trace-backs
     }
-    j->h_summ.resize((size_t)nr);
-    FZP_TRY(j->summ.download(j->h_summ.data(), (size_t)nr, st));
     FZP_HIP(hipStreamSynchronize(st));
     FZP_HIP(hipGetLastError());
+    j->summ_on_host = false;      // the batch path plans on the device; the summaries come to the host when someone asks
     j->done = true;
     return FZP_OK;
 }
 
+namespace {
+int fetch_summaries(fzp_ctx *ctx, fzp_alnjob *j) {
+    if (j->summ_on_host) return FZP_OK;
+    FZP_HIP(hipSetDevice(ctx->device));
+    j->h_summ.resize((size_t)j->n_reads);
+    FZP_TRY(j->summ.download(j->h_summ.data(), (size_t)j->n_reads, ctx->stream));
+    FZP_HIP(hipStreamSynchronize(ctx->stream));
+    j->summ_on_host = true;
+    return FZP_OK;
+}
+}  // namespace
+
 extern "C" int fzp_align_summaries(fzp_ctx *ctx, fzp_alnjob *j, fzp_aln_summary *out) {
-    (void)ctx;
-    if (!j || !j->done || !out) { fzp_set_error("fzp_align_summaries: run the job first"); return FZP_EINVAL; }
+    if (!ctx || !j || !j->done || !out) { fzp_set_error("fzp_align_summaries: run the job first"); return FZP_EINVAL; }
+    FZP_TRY(fetch_summaries(ctx, j));
     if (j->n_reads) memcpy(out, j->h_summ.data(), (size_t)j->n_reads * sizeof(fzp_aln_summary));
     return FZP_OK;
 }
@@ -1204,6 +1281,7 @@ T *dupv(const std::vector<T> &v) {
 extern "C" int fzp_align_alnset(fzp_ctx *ctx, fzp_alnjob *j, int32_t ctg, const int64_t *name_off, const char *names, fzp_alnset **out, int64_t **read_index) {
     if (!ctx || !j || !j->done || !out || ctg < 0 || ctg >= j->n_ctg) { fzp_set_error("fzp_align_alnset: bad arguments or job not run"); return FZP_EINVAL; }
     FZP_HIP(hipSetDevice(ctx->device));
+    FZP_TRY(fetch_summaries(ctx, j));
     RecPlan p;
     plan_records(j, ctg, ctg + 1, p);
     DevBuf<uint32_t> cigar;
@@ -1277,49 +1355,91 @@ extern "C" int fzp_align_to_batch(fzp_ctx *ctx, fzp_alnjob *j, fzp_batch **out) 
     if (!ctx || !j || !j->done || !out) { fzp_set_error("fzp_align_to_batch: job not run"); return FZP_EINVAL; }
     FZP_HIP(hipSetDevice(ctx->device));
     *out = nullptr;
-    const bool tim = getenv("FZP_TIMING") != nullptr;
-    auto now = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
-    const double t0 = now();
-    RecPlan p;
-    plan_records(j, 0, j->n_ctg, p);
-    const double t1 = now();
-    fzp_batch *b = new fzp_batch();
-    b->n_ctg = j->n_ctg;
-    b->h_rec_begin = p.rec_begin;
-    b->h_goff.assign(1, 0); b->h_qid_off.assign(1, 0);
-    for (int c = 0; c < j->n_ctg; c++) {
-        int32_t limit = p.last_pos[c] > 0 ? p.last_pos[c] : 0;
-        b->h_limit.push_back(limit);
-        b->h_ref_len.push_back(j->h_ctg_len[c]);
-        b->h_goff.push_back(b->h_goff.back() + limit);
-        b->h_qid_off.push_back(b->h_qid_off.back() + (int64_t)p.ctg_reads[c].size());
-        b->n_columns += p.n_columns[c];
+    hipStream_t st = ctx->stream;
+    const int nc = j->n_ctg;
+    const int64_t nr = j->n_reads;
+    if (!j->have_slots) {      // reads grouped by contig, once per job
+        std::vector<int64_t> off((size_t)nc + 1, 0);
+        for (int64_t r = 0; r < nr; r++) off[(size_t)j->h_read_ctg[(size_t)r] + 1]++;
+        for (int c = 0; c < nc; c++) off[(size_t)c + 1] += off[(size_t)c];
+        std::vector<int32_t> rd((size_t)nr), sc((size_t)nr);
+        std::vector<int64_t> fill(off.begin(), off.end() - 1);
+        for (int64_t r = 0; r < nr; r++) { const int c = j->h_read_ctg[(size_t)r]; const int64_t s_ = fill[(size_t)c]++; rd[(size_t)s_] = (int32_t)r; sc[(size_t)s_] = c; }
+        FZP_TRY(j->slot_read.upload(rd.data(), (size_t)nr, st)); FZP_TRY(j->slot_ctg.upload(sc.data(), (size_t)nr, st)); FZP_TRY(j->slot_off.upload(off.data(), (size_t)nc + 1, st));
+        FZP_HIP(hipStreamSynchronize(st));
+        j->have_slots = true;
     }
-    b->n_rec = (int64_t)p.rec_read.size();
+    fzp_batch *b = new fzp_batch();
+    struct Guard { fzp_batch *p; ~Guard() { delete p; } } guard{b};
+    b->n_ctg = nc;
+    // ---- plan on the device
+    DevBuf<uint64_t> key, v_rec, v_cig, v_seq, v_ck, totals;
+    DevBuf<int32_t> g_read, g_qid, last_pos;
+    DevBuf<uint8_t> g_acc;
+    DevBuf<uint32_t> n_aligned;
+    DevBuf<unsigned long long> n_cols;
+    DevBuf<int64_t> rec_read;
+    const size_t ns = (size_t)std::max<int64_t>(nr, 1);
+    FZP_TRY(key.alloc(ns)); FZP_TRY(v_rec.alloc(ns)); FZP_TRY(v_cig.alloc(ns)); FZP_TRY(v_seq.alloc(ns)); FZP_TRY(v_ck.alloc(ns)); FZP_TRY(totals.alloc(4));
+    FZP_TRY(g_read.alloc(ns)); FZP_TRY(g_qid.alloc(ns)); FZP_TRY(g_acc.alloc(ns)); FZP_TRY(last_pos.alloc((size_t)nc)); FZP_TRY(n_aligned.alloc((size_t)nc)); FZP_TRY(n_cols.alloc((size_t)nc));
+    FZP_TRY(v_rec.zero(ns, st)); FZP_TRY(v_cig.zero(ns, st)); FZP_TRY(v_seq.zero(ns, st)); FZP_TRY(v_ck.zero(ns, st)); FZP_TRY(g_acc.zero(ns, st));
+    FZP_TRY(n_aligned.zero((size_t)nc, st)); FZP_TRY(n_cols.zero((size_t)nc, st));
+    FZP_HIP(hipMemsetAsync(last_pos.p, 0xff, (size_t)nc * 4, st));       // -1
+    const unsigned gb = (unsigned)std::max<int64_t>(1, (nr + 255) / 256);
+    if (nr > 0) {
+        ProfScope ps(ctx, "k1_plan");
+        hipLaunchKernelGGL(k_plan_keys, dim3(gb), dim3(256), 0, st, nr, j->slot_read.p, j->summ.p, key.p);
+        hipLaunchKernelGGL(k_plan_rank, dim3(gb), dim3(256), 0, st, nr, j->slot_read.p, j->slot_ctg.p, j->slot_off.p, key.p, j->summ.p, j->read_len.p, v_rec.p, v_cig.p, v_seq.p,
+                           v_ck.p, g_read.p, g_qid.p, g_acc.p, last_pos.p, n_aligned.p, n_cols.p);
+    }
+    FZP_TRY(fzp_exclusive_scan_u64_inplace(ctx, v_rec.p, (size_t)nr, totals.p + 0));
+    FZP_TRY(fzp_exclusive_scan_u64_inplace(ctx, v_cig.p, (size_t)nr, totals.p + 1));
+    FZP_TRY(fzp_exclusive_scan_u64_inplace(ctx, v_seq.p, (size_t)nr, totals.p + 2));
+    FZP_TRY(fzp_exclusive_scan_u64_inplace(ctx, v_ck.p, (size_t)nr, totals.p + 3));
+    uint64_t tot[4] = {0, 0, 0, 0};
+    std::vector<int32_t> h_last((size_t)nc);
+    std::vector<uint32_t> h_nal((size_t)nc);
+    std::vector<unsigned long long> h_cols((size_t)nc);
+    FZP_HIP(hipMemcpyAsync(tot, totals.p, 32, hipMemcpyDeviceToHost, st));
+    FZP_TRY(last_pos.download(h_last.data(), (size_t)nc, st)); FZP_TRY(n_aligned.download(h_nal.data(), (size_t)nc, st)); FZP_TRY(n_cols.download(h_cols.data(), (size_t)nc, st));
+    FZP_HIP(hipStreamSynchronize(st));
+    b->n_rec = (int64_t)tot[0]; b->n_cig = (int64_t)tot[1]; b->n_seq = (int64_t)tot[2]; b->n_ck = (int64_t)tot[3];
+    if (b->n_rec >= (1ll << 31)) { fzp_set_error("fzp_align_to_batch: %lld records (limit 2^31 per batch)", (long long)b->n_rec); return FZP_EINVAL; }
+    b->h_goff.assign(1, 0); b->h_qid_off.assign(1, 0);
+    for (int c = 0; c < nc; c++) {
+        const int32_t limit = h_last[(size_t)c] > 0 ? h_last[(size_t)c] : 0;
+        b->h_limit.push_back(limit);
+        b->h_ref_len.push_back(j->h_ctg_len[(size_t)c]);
+        b->h_goff.push_back(b->h_goff.back() + limit);
+        b->h_qid_off.push_back(b->h_qid_off.back() + (int64_t)h_nal[(size_t)c]);
+        b->n_columns += (int64_t)h_cols[(size_t)c];
+    }
     b->n_pos = b->h_goff.back();
     b->n_qid = b->h_qid_off.back();
-    b->n_cig = p.cig_off.back(); b->n_seq = p.seq_off.back();
-    hipStream_t st = ctx->stream;
-    int rc = gather_records(ctx, j, p, b->cigar, b->seq, b->cig_off, b->seq_off);
-    const double t2 = now();
-    if (!rc) rc = b->ref.alloc((size_t)b->n_pos);
-    for (int c = 0; c < j->n_ctg && !rc; c++)   // evaluated prefix of every contig, device to device
-        if (b->h_limit[c] && hipMemcpyAsync(b->ref.p + b->h_goff[c], j->ctg_ascii.p + j->h_ctg_aoff[c], (size_t)b->h_limit[c], hipMemcpyDeviceToDevice, st) != hipSuccess) rc = FZP_EDEVICE;
-    if (!rc) rc = b->rec_pos.upload(p.rec_pos.data(), p.rec_pos.size(), st);
-    if (!rc) rc = b->rec_qid.upload(p.rec_qid.data(), p.rec_qid.size(), st);
-    if (!rc) rc = b->rec_ctg.upload(p.rec_ctg.data(), p.rec_ctg.size(), st);
-    b->h_ck_off.assign(p.rec_read.size() + 1, 0);
-    for (size_t r = 0; r < p.rec_read.size(); r++) b->h_ck_off[r + 1] = b->h_ck_off[r] + (p.cig_off[r + 1] - p.cig_off[r] + 63) / 64;
-    if (!rc) rc = b->ck_off.upload(b->h_ck_off.data(), b->h_ck_off.size(), st);
-    if (!rc) rc = b->ctg_rec_begin.upload(b->h_rec_begin.data(), b->h_rec_begin.size(), st);
-    if (!rc) rc = b->ctg_goff.upload(b->h_goff.data(), b->h_goff.size(), st);
-    if (!rc) rc = b->ctg_qoff.upload(b->h_qid_off.data(), b->h_qid_off.size(), st);
-    if (!rc) rc = b->ctg_limit.upload(b->h_limit.data(), b->h_limit.size(), st);
-    const double t3 = now();
-    if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = FZP_EDEVICE;
-    if (tim) fprintf(stderr, "[to_batch] plan %.2f gather %.2f uploads %.2f sync %.2f ms\n", t1 - t0, t2 - t1, t3 - t2, now() - t3);
-    if (rc) { delete b; return rc; }
+    const size_t nrec1 = (size_t)b->n_rec + 1;
+    FZP_TRY(rec_read.alloc(nrec1)); FZP_TRY(b->rec_qid.alloc(nrec1)); FZP_TRY(b->rec_pos.alloc(nrec1)); FZP_TRY(b->rec_ctg.alloc(nrec1));
+    FZP_TRY(b->cig_off.alloc(nrec1)); FZP_TRY(b->seq_off.alloc(nrec1)); FZP_TRY(b->ck_off.alloc(nrec1)); FZP_TRY(b->ctg_rec_begin.alloc((size_t)nc + 1));
+    hipLaunchKernelGGL(k_plan_emit, dim3((unsigned)((std::max<int64_t>(nr, nc + 1) + 255) / 256)), dim3(256), 0, st, nr, nc, j->slot_ctg.p, j->slot_off.p, v_rec.p, v_cig.p, v_seq.p, v_ck.p, g_read.p, g_qid.p, g_acc.p, j->summ.p, totals.p,
+                       rec_read.p, b->rec_qid.p, b->rec_pos.p, b->rec_ctg.p, b->cig_off.p, b->seq_off.p, b->ck_off.p, b->ctg_rec_begin.p);
+    b->h_rec_begin.resize((size_t)nc + 1);
+    FZP_TRY(b->ctg_rec_begin.download(b->h_rec_begin.data(), (size_t)nc + 1, st));
+    // ---- gather the accepted records' CIGAR words and SEQ bytes
+    FZP_TRY(b->cigar.alloc((size_t)b->n_cig)); FZP_TRY(b->seq.alloc((size_t)b->n_seq));
+    if (b->n_rec > 0) {
+        ProfScope ps(ctx, "k1_gather");
+        hipLaunchKernelGGL(k_gather, dim3((unsigned)b->n_rec, 4), dim3(256), 0, st, b->n_rec, rec_read.p, j->cig_start.p, j->cig.p, b->cig_off.p, b->cigar.p, j->read_ori.p,
+                           j->read_woff.p, b->seq_off.p, b->seq.p);
+    }
+    FZP_TRY(b->ref.alloc((size_t)b->n_pos));
+    for (int c = 0; c < nc; c++)   // evaluated prefix of every contig, device to device
+        if (b->h_limit[(size_t)c]) FZP_HIP(hipMemcpyAsync(b->ref.p + b->h_goff[(size_t)c], j->ctg_ascii.p + j->h_ctg_aoff[(size_t)c], (size_t)b->h_limit[(size_t)c], hipMemcpyDeviceToDevice, st));
+    FZP_TRY(b->ctg_goff.upload(b->h_goff.data(), b->h_goff.size(), st));
+    FZP_TRY(b->ctg_qoff.upload(b->h_qid_off.data(), b->h_qid_off.size(), st));
+    FZP_TRY(b->ctg_limit.upload(b->h_limit.data(), b->h_limit.size(), st));
+    FZP_HIP(hipStreamSynchronize(st));
+    FZP_HIP(hipGetLastError());
     b->have_aln = true;
+    guard.p = nullptr;
     *out = b;
     return FZP_OK;
 }

@@ -81,6 +81,7 @@ extern "C" int fzp_batch_create(fzp_ctx *ctx, int32_t n_ctg, const fzp_alnset *c
     seq_off[(size_t)b->n_rec] = s0;
     b->h_ck_off.assign((size_t)b->n_rec + 1, 0);
     for (int64_t r = 0; r < b->n_rec; r++) b->h_ck_off[(size_t)r + 1] = b->h_ck_off[(size_t)r] + (cig_off[(size_t)r + 1] - cig_off[(size_t)r] + 63) / 64;
+    b->n_ck = b->h_ck_off.back();
     hipStream_t st = ctx->stream;
     int rc = FZP_OK;
     if ((rc = b->rec_pos.upload(rec_pos.data(), rec_pos.size(), st)) || (rc = b->rec_qid.upload(rec_qid.data(), rec_qid.size(), st)) ||

@@ -34,7 +34,8 @@ struct fzp_batch {
     DevBuf<int64_t> ctg_goff, ctg_qoff, ctg_rec_begin;
     DevBuf<int32_t> ctg_limit;
     // CIGAR checkpoints: per record, per 64-op chunk, the (reference, query) offsets at the chunk's start
-    std::vector<int64_t> h_ck_off;     // [n_rec+1] prefix of ceil(n_ops/64)
+    std::vector<int64_t> h_ck_off;     // [n_rec+1] prefix of ceil(n_ops/64) (batches built from host records)
+    int64_t n_ck = 0;                  // total 64-op chunks = size of ck_ref / ck_q
     DevBuf<int64_t> ck_off;
     DevBuf<int32_t> ck_ref, ck_q, rec_span, ctg_maxspan;
     std::vector<int32_t> h_tile_ctg, h_tile_start;   // K2 position tiles (never span contigs)

@@ -117,6 +117,7 @@ int fzp_prof_flush(fzp_ctx *ctx);
 // ---------------------------------------------------------------- scans (fzp_scan.hip)
 // out[i] = sum_{j<i} in[j] over n uint32 items (in may alias out); *total_dev (device u64) gets the sum.
 int fzp_exclusive_scan_u32(fzp_ctx *ctx, const uint32_t *in, uint32_t *out, size_t n, uint64_t *total_dev);
+int fzp_exclusive_scan_u64_inplace(fzp_ctx *ctx, uint64_t *v, size_t n, uint64_t *total_dev);
 
 // ---------------------------------------------------------------- wave helpers (device)
 #ifdef __HIPCC__

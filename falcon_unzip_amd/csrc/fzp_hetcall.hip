@@ -429,7 +429,7 @@ int fzp_k2_het_call(fzp_ctx *ctx, fzp_batch *b) {
     RecView v = rec_view(b);
     if (b->n_rec > 0 && np > 0) {
         // checkpoints + per-contig maximum reference span
-        const int64_t n_ck = b->h_ck_off.empty() ? 0 : b->h_ck_off.back();
+        const int64_t n_ck = b->n_ck;
         FZP_TRY(b->ck_ref.alloc((size_t)n_ck)); FZP_TRY(b->ck_q.alloc((size_t)n_ck));
         FZP_TRY(b->rec_span.alloc((size_t)b->n_rec)); FZP_TRY(b->ctg_maxspan.alloc((size_t)b->n_ctg));
         FZP_TRY(b->ctg_maxspan.zero((size_t)b->n_ctg, st));

@@ -143,3 +143,14 @@ int fzp_exclusive_scan_u32(fzp_ctx *ctx, const uint32_t *in, uint32_t *out, size
     FZP_HIP(hipGetLastError());
     return FZP_OK;
 }
+
+int fzp_exclusive_scan_u64_inplace(fzp_ctx *ctx, uint64_t *v, size_t n, uint64_t *total_dev) {
+    if (n == 0) {
+        if (total_dev) FZP_HIP(hipMemsetAsync(total_dev, 0, sizeof(uint64_t), ctx->stream));
+        return FZP_OK;
+    }
+    ProfScope ps(ctx, "scan");
+    FZP_TRY(scan_u64_inplace(ctx, v, n, total_dev, 0));
+    FZP_HIP(hipGetLastError());
+    return FZP_OK;
+}
