@@ -306,6 +306,7 @@ class Batch:
             full.arows["site2"] -= shift
         if len(full.pvars):
             full.pvars["site"] -= np.repeat(sb[:-1], np.diff(pb)).astype(np.int32)
+        self.last_full = (full, {"site": sb, "row": rb, "arow": ab, "pvar": pb, "pread": qb})   # whole-batch arrays + per-contig begins
         out = []
         for c in range(n):
             r = Result.__new__(Result)

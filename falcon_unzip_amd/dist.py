@@ -49,6 +49,25 @@ def r2p_from_preads(preads, n_reads, arid_base, ctg_index):
     return out
 
 
+def r2p_from_batch(preads_all, pread_begin, reads_per_ctg, arid_base, ctg_index_base):
+    """r2p_from_preads for every contig of a batch at once.  preads_all: the batch's phased_reads rows (contig-local
+    q_ids, contigs concatenated, pread_begin[c] = first row of contig c); reads_per_ctg[c] reads get consecutive arids."""
+    reads_per_ctg = np.asarray(reads_per_ctg, dtype=np.int64)
+    qoff = np.concatenate(([0], np.cumsum(reads_per_ctg)))
+    n = int(qoff[-1])
+    out = np.zeros(n, R2P)
+    out["arid"] = arid_base + np.arange(n, dtype=np.int64)
+    out["ctg"] = ctg_index_base + np.repeat(np.arange(len(reads_per_ctg), dtype=np.int32), reads_per_ctg)
+    out["block"] = -1
+    if len(preads_all):
+        q = preads_all["q_id"].astype(np.int64) + np.repeat(qoff[:-1], np.diff(np.asarray(pread_begin, dtype=np.int64)))
+        last = np.ones(len(q), bool)
+        last[:-1] = q[1:] != q[:-1]
+        out["block"][q[last]] = preads_all["block"][last]
+        out["phase"][q[last]] = preads_all["phase"][last]
+    return out
+
+
 def allgather_r2p(local, device=None):
     """All ranks contribute their shard's records; every rank gets all of them, ordered by
     (contig index, arid) -- the order of `rid_to_phase.all` (sorted per-contig paths, unzip.py:306-307).

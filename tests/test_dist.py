@@ -113,3 +113,23 @@ def test_allgather_without_process_group():
     r["arid"] = [5, 1, 3]
     out = allgather_r2p(r)
     assert list(out["arid"]) == [1, 3, 5]
+
+
+def test_r2p_from_batch_equals_per_contig():
+    from falcon_unzip_amd import _lib
+    from falcon_unzip_amd import dist as fdist
+    rng = np.random.default_rng(5)
+    reads_per_ctg = [7, 0, 12, 5]
+    parts, begins, exp = [], [0], []
+    for c, nq in enumerate(reads_per_ctg):
+        rows = []
+        for q in range(nq):
+            for blk in sorted(rng.choice(np.arange(1, 6), size=int(rng.integers(0, 3)), replace=False)):
+                rows.append((q, int(blk), int(rng.integers(0, 2)), 3, 1))
+        pr = np.array(rows, dtype=_lib.PREAD) if rows else np.zeros(0, _lib.PREAD)
+        parts.append(pr)
+        begins.append(begins[-1] + len(pr))
+        exp.append(fdist.r2p_from_preads(pr, nq, 100 + sum(reads_per_ctg[:c]), 40 + c))
+    got = fdist.r2p_from_batch(np.concatenate(parts), begins, reads_per_ctg, 100, 40)
+    assert np.array_equal(got, np.concatenate(exp))
+    assert len(fdist.r2p_from_batch(np.zeros(0, _lib.PREAD), [0, 0], [0], 0, 0)) == 0
