@@ -25,6 +25,37 @@ int upload_contig_tables(fzp_ctx *ctx, fzp_batch *b) {
 }
 }  // namespace
 
+// Sites, variant_map rows and atable rows are final after K3: start their way to the host on stream2 while K4 / K5 run on
+// the main stream.  fzp_batch_result_all then only adds the (small) block and read records.  Best effort: on any
+// failure the records are simply downloaded later.
+namespace {
+inline size_t al64(size_t x) { return (x + 63) & ~(size_t)63; }
+void prefetch_early_records(fzp_ctx *ctx, fzp_batch *b) {
+    b->pf_base = nullptr;
+    const size_t s_sites = (size_t)b->n_sites * sizeof(fzp_site), s_vmap = (size_t)b->n_rows * sizeof(int32_t), s_arows = (size_t)b->n_arows * sizeof(fzp_arow);
+    // room for what comes later as well: at most one block record per site, one read record per variant_map row
+    const size_t need = al64(s_sites) + al64(s_vmap) + al64(s_arows) + al64((size_t)b->n_sites * sizeof(fzp_pvar)) + al64((size_t)b->n_rows * sizeof(fzp_pread)) + 4096;
+    if (need > ctx->pinned_bytes) {
+        (void)hipStreamSynchronize(ctx->stream2);     // an earlier batch's early copies may still target the old buffer
+        if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+        ctx->pinned = nullptr; ctx->pinned_bytes = 0;
+        const size_t want = need + need / 4;
+        if (hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); ctx->pinned = nullptr; return; }
+        ctx->pinned_bytes = want;
+    }
+    if (!ctx->ev_pf && hipEventCreateWithFlags(&ctx->ev_pf, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ctx->ev_pf = nullptr; return; }
+    if (hipEventRecord(ctx->ev_pf, ctx->stream) != hipSuccess || hipStreamWaitEvent(ctx->stream2, ctx->ev_pf, 0) != hipSuccess) { (void)hipGetLastError(); return; }
+    char *base = (char *)ctx->pinned;
+    b->pf_sites = 0; b->pf_vmap = al64(s_sites); b->pf_arows = b->pf_vmap + al64(s_vmap); b->pf_end = b->pf_arows + al64(s_arows);
+    bool ok = true;
+    if (s_sites) ok = ok && hipMemcpyAsync(base + b->pf_sites, b->sites.p, s_sites, hipMemcpyDeviceToHost, ctx->stream2) == hipSuccess;
+    if (s_vmap) ok = ok && hipMemcpyAsync(base + b->pf_vmap, b->vmap_qid.p, s_vmap, hipMemcpyDeviceToHost, ctx->stream2) == hipSuccess;
+    if (s_arows) ok = ok && hipMemcpyAsync(base + b->pf_arows, b->arows.p, s_arows, hipMemcpyDeviceToHost, ctx->stream2) == hipSuccess;
+    if (!ok) { (void)hipGetLastError(); return; }
+    b->pf_base = ctx->pinned;
+}
+}  // namespace
+
 // ================================================================================ batch
 extern "C" int fzp_batch_create(fzp_ctx *ctx, int32_t n_ctg, const fzp_alnset *const *aln, const uint8_t *const *ref_seq, const int64_t *ref_len,
                                 fzp_batch **out) {
@@ -101,7 +132,7 @@ extern "C" int fzp_batch_create(fzp_ctx *ctx, int32_t n_ctg, const fzp_alnset *c
 
 extern "C" void fzp_batch_destroy(fzp_ctx *ctx, fzp_batch *b) {
     if (!b) return;
-    if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
+    if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); if (b->pf_base) (void)hipStreamSynchronize(ctx->stream2); }
     delete b;
 }
 
@@ -113,6 +144,7 @@ extern "C" int fzp_batch_run(fzp_ctx *ctx, fzp_batch *b, unsigned stages) {
         FZP_TRY(fzp_k2_het_call(ctx, b));
     }
     if (stages & FZP_STAGE_ASSOC) FZP_TRY(fzp_k3_assoc(ctx, b));
+    if ((stages & FZP_STAGE_ALL) == FZP_STAGE_ALL && b->have_sites && b->have_arows) prefetch_early_records(ctx, b);   // best effort
     if (stages & FZP_STAGE_BLOCKS) FZP_TRY(fzp_k4_blocks(ctx, b));
     if (stages & FZP_STAGE_READS) FZP_TRY(fzp_k5_reads(ctx, b));
     return FZP_OK;
@@ -216,26 +248,36 @@ extern "C" int fzp_batch_result_all(fzp_ctx *ctx, fzp_batch *b, fzp_result_all *
     if (b->have_arows) { r.n_arows = b->n_arows; parts.push_back({b->arows.p, (size_t)b->n_arows * sizeof(fzp_arow), (void **)&r.arows}); out->arow_begin = dup(b->h_arow_begin); }
     if (b->have_blocks) { r.n_pvars = b->n_pvars; parts.push_back({b->pvars.p, (size_t)b->n_pvars * sizeof(fzp_pvar), (void **)&r.pvars}); out->pvar_begin = dup(b->h_pvar_begin); }
     if (b->have_preads) { r.n_preads = b->n_preads; parts.push_back({b->preads.p, (size_t)b->n_preads * sizeof(fzp_pread), (void **)&r.preads}); out->pread_begin = dup(b->h_pread_begin); }
-    size_t total = 0;
-    for (auto &p : parts) total += (p.bytes + 63) & ~(size_t)63;
-    if (total > ctx->pinned_bytes) {
-        if (ctx->pinned) (void)hipHostFree(ctx->pinned);
-        ctx->pinned = nullptr; ctx->pinned_bytes = 0;
-        size_t want = total + total / 4 + (1 << 20);
-        if (hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); fzp_result_all_free(out); fzp_set_error("pinned host allocation of %zu bytes failed", want); return FZP_ENOMEM; }
-        ctx->pinned_bytes = want;
+    // parts 0..2 (sites, variant_map, atable) may already be on their way (prefetch_early_records)
+    const bool early = b->pf_base && b->pf_base == ctx->pinned && b->have_sites && b->have_arows && parts.size() >= 3;
+    size_t total = early ? b->pf_end : 0;
+    for (size_t k = early ? 3 : 0; k < parts.size(); k++) total += (parts[k].bytes + 63) & ~(size_t)63;
+    const bool use_early = early && total <= ctx->pinned_bytes;
+    if (!use_early) {
+        (void)hipStreamSynchronize(ctx->stream2);                     // nothing may still be writing into a buffer we are about to reuse or free
+        total = 0;
+        for (auto &p : parts) total += (p.bytes + 63) & ~(size_t)63;
+        if (total > ctx->pinned_bytes) {
+            if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+            ctx->pinned = nullptr; ctx->pinned_bytes = 0;
+            size_t want = total + total / 4 + (1 << 20);
+            if (hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); fzp_result_all_free(out); fzp_set_error("pinned host allocation of %zu bytes failed", want); return FZP_ENOMEM; }
+            ctx->pinned_bytes = want;
+        }
     }
-    size_t off = 0;
-    for (auto &p : parts) {
-        if (p.bytes && hipMemcpyAsync((char *)ctx->pinned + off, p.src, p.bytes, hipMemcpyDeviceToHost, st) != hipSuccess) { fzp_result_all_free(out); fzp_set_error("D2H copy failed"); return FZP_EDEVICE; }
-        off += (p.bytes + 63) & ~(size_t)63;
+    std::vector<size_t> offs(parts.size());
+    {
+        size_t off = use_early ? b->pf_end : 0;
+        for (size_t k = 0; k < parts.size(); k++) {
+            if (use_early && k < 3) { offs[k] = k == 0 ? b->pf_sites : (k == 1 ? b->pf_vmap : b->pf_arows); continue; }
+            offs[k] = off;
+            if (parts[k].bytes && hipMemcpyAsync((char *)ctx->pinned + off, parts[k].src, parts[k].bytes, hipMemcpyDeviceToHost, st) != hipSuccess) { fzp_result_all_free(out); fzp_set_error("D2H copy failed"); return FZP_EDEVICE; }
+            off += (parts[k].bytes + 63) & ~(size_t)63;
+        }
     }
-    if (hipStreamSynchronize(st) != hipSuccess) { fzp_result_all_free(out); fzp_set_error("D2H sync failed"); return FZP_EDEVICE; }
-    off = 0;
-    for (auto &p : parts) {   // borrowed views into the pinned buffer
-        *p.dst = (char *)ctx->pinned + off;
-        off += (p.bytes + 63) & ~(size_t)63;
-    }
+    if (hipStreamSynchronize(st) != hipSuccess || (use_early && hipStreamSynchronize(ctx->stream2) != hipSuccess)) { fzp_result_all_free(out); fzp_set_error("D2H sync failed"); return FZP_EDEVICE; }
+    b->pf_base = nullptr;                                              // the views below are handed out once
+    for (size_t k = 0; k < parts.size(); k++) *parts[k].dst = (char *)ctx->pinned + offs[k];   // borrowed views into the pinned buffer
     if (b->have_sites) {
         out->row_begin = (int64_t *)calloc(nb, sizeof(int64_t));
         for (int c = 0; c <= b->n_ctg; c++) {

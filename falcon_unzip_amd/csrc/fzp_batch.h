@@ -75,6 +75,9 @@ struct fzp_batch {
     DevBuf<uint32_t> rng_n, rng_off, c0, c1, pr_flag, pr_idx;
     DevBuf<fzp_pread> preads;
     DevBuf<int64_t> pread_begin;
+    // early download of the K2/K3 records into the ctx's pinned buffer (valid while pf_base == ctx->pinned)
+    void *pf_base = nullptr;
+    size_t pf_sites = 0, pf_vmap = 0, pf_arows = 0, pf_end = 0;
     // scratch
     DevBuf<uint64_t> totals;          // a few device u64 scalars
     DevBuf<int32_t> errflag;

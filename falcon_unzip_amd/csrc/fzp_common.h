@@ -100,6 +100,7 @@ struct fzp_ctx {
     DevBuf<uint64_t> scan_tmp[3];
     void *pinned = nullptr;          // pinned host staging for bulk device-to-host copies (grow-only)
     size_t pinned_bytes = 0;
+    hipEvent_t ev_pf = nullptr;      // "K2/K3 results are final": their download starts on stream2 while K4/K5 run
     int n_cu = 256;
 };
 

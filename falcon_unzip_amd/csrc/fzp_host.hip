@@ -119,6 +119,7 @@ extern "C" void fzp_ctx_destroy(fzp_ctx *ctx) {
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     for (auto &b : ctx->scan_tmp) b.release();
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->ev_pf) (void)hipEventDestroy(ctx->ev_pf);
     fzp_dev_trim();
     (void)hipStreamDestroy(ctx->stream2);
     (void)hipStreamDestroy(ctx->stream);
