@@ -886,7 +886,7 @@ __global__ void __launch_bounds__(256) k_gather(int64_t n_rec, const int64_t *__
 }
 // ---- record planning on the device (what `samtools sort` + make_het_call's record filters do to the aligner's output,
 // phasing.py:47-75): per contig the aligned reads ordered by (POS, read index) -- q_id = rank in that order -- the
-// filters, and the offsets of every accepted record's CIGAR words, SEQ bytes and 64-op checkpoint chunks.
+// filters, and the offsets of every accepted record's CIGAR words, SEQ bytes (segments padded to 16) and 64-op checkpoint chunks.
 // Slots: the reads of contig c own slots [slot_off[c], slot_off[c+1]); an aligned read lands in slot_off[c] + rank.
 struct PlanSlot { uint64_t rec, cig, seq, ck; };           // scanned in place: flags / sizes -> exclusive prefixes
 __global__ void __launch_bounds__(256) k_plan_keys(int64_t n, const int32_t *__restrict__ slot_read, const fzp_aln_summary *__restrict__ summ, uint64_t *__restrict__ key) {
@@ -920,7 +920,7 @@ __global__ void __launch_bounds__(256) k_plan_rank(int64_t n, const int32_t *__r
     g_read[g] = r; g_qid[g] = (int32_t)rank; g_acc[g] = acc ? 1 : 0;
     atomicAdd(&n_aligned[c], 1u);
     if (acc) {
-        v_rec[g] = 1; v_cig[g] = (uint64_t)sm.n_cigar; v_seq[g] = (uint64_t)nlen; v_ck[g] = (uint64_t)((sm.n_cigar + 63) / 64);
+        v_rec[g] = 1; v_cig[g] = (uint64_t)sm.n_cigar; v_seq[g] = (uint64_t)((nlen + 15) & ~15ll); v_ck[g] = (uint64_t)((sm.n_cigar + 63) / 64);
         atomicMax(&last_pos[c], sm.pos);
         atomicAdd(&n_cols[c], (unsigned long long)sm.n_columns);
     }
@@ -944,6 +944,34 @@ __global__ void __launch_bounds__(256) k_plan_emit(int64_t n, int n_ctg, const i
     const int32_t r = g_read[g];
     rec_read[k] = r; rec_qid[k] = g_qid[g]; rec_pos[k] = summ[r].pos; rec_ctg[k] = c;
     cig_off[k] = (int64_t)v_cig[g]; seq_off[k] = (int64_t)v_seq[g]; ck_off[k] = (int64_t)v_ck[g];
+}
+// the batch path's variant: SEQ segments are padded to 16 bytes, so a thread turns one packed word into one 16-byte store
+__global__ void __launch_bounds__(256) k_gather16(int64_t n_rec, const int64_t *__restrict__ rec_read, const int64_t *__restrict__ cig_start, const uint32_t *__restrict__ cig,
+                                                  const int64_t *__restrict__ out_cig_off, uint32_t *__restrict__ out_cig, const uint32_t *__restrict__ read_ori,
+                                                  const int64_t *__restrict__ read_woff, const int64_t *__restrict__ out_seq_off, uint8_t *__restrict__ out_seq) {
+    const int64_t k = blockIdx.x;
+    if (k >= n_rec) return;
+    const int64_t r = rec_read[k];
+    const int64_t nc = out_cig_off[k + 1] - out_cig_off[k];
+    const uint32_t *src = cig + cig_start[r];
+    uint32_t *dst = out_cig + out_cig_off[k];
+    for (int64_t x = (int64_t)blockIdx.y * 256 + threadIdx.x; x < nc; x += (int64_t)gridDim.y * 256) dst[x] = src[x];
+    const int64_t nw = (out_seq_off[k + 1] - out_seq_off[k]) >> 4;
+    const uint32_t *pk = read_ori + read_woff[r];
+    uint4 *sq = (uint4 *)(out_seq + out_seq_off[k]);
+    for (int64_t w = (int64_t)blockIdx.y * 256 + threadIdx.x; w < nw; w += (int64_t)gridDim.y * 256) {
+        const uint32_t x = pk[w];
+        uint32_t o[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            uint32_t t = (x >> (8 * q)) & 0xffu;                 // four 2-bit codes -> one per byte
+            t = (t | (t << 12)) & 0x000F000Fu;
+            t = (t | (t << 6)) & 0x03030303u;
+            const uint32_t c2 = (t >> 1) & 0x01010101u, c3 = c2 & t;     // code >= 2, code == 3
+            o[q] = 0x41414141u + 2u * t + 2u * c2 + 11u * c3;            // A=65 C=67 G=71 T=84
+        }
+        sq[w] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
 }
 }  // namespace
 
@@ -1427,7 +1455,7 @@ extern "C" int fzp_align_to_batch(fzp_ctx *ctx, fzp_alnjob *j, fzp_batch **out) 
     FZP_TRY(b->cigar.alloc((size_t)b->n_cig)); FZP_TRY(b->seq.alloc((size_t)b->n_seq));
     if (b->n_rec > 0) {
         ProfScope ps(ctx, "k1_gather");
-        hipLaunchKernelGGL(k_gather, dim3((unsigned)b->n_rec, 4), dim3(256), 0, st, b->n_rec, rec_read.p, j->cig_start.p, j->cig.p, b->cig_off.p, b->cigar.p, j->read_ori.p,
+        hipLaunchKernelGGL(k_gather16, dim3((unsigned)b->n_rec, 4), dim3(256), 0, st, b->n_rec, rec_read.p, j->cig_start.p, j->cig.p, b->cig_off.p, b->cigar.p, j->read_ori.p,
                            j->read_woff.p, b->seq_off.p, b->seq.p);
     }
     FZP_TRY(b->ref.alloc((size_t)b->n_pos));
