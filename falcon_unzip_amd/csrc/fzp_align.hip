@@ -900,13 +900,24 @@ __global__ void __launch_bounds__(256) k_plan_rank(int64_t n, const int32_t *__r
                                                    uint64_t *__restrict__ v_rec, uint64_t *__restrict__ v_cig, uint64_t *__restrict__ v_seq, uint64_t *__restrict__ v_ck,
                                                    int32_t *__restrict__ g_read, int32_t *__restrict__ g_qid, uint8_t *__restrict__ g_acc, int32_t *__restrict__ last_pos,
                                                    uint32_t *__restrict__ n_aligned, unsigned long long *__restrict__ n_cols) {
-    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (s >= n) return;
-    const uint64_t k = key[s];
-    if (k == ~0ull) return;
-    const int c = slot_ctg[s];
+    // grid (x: 256-slot pieces of a contig, y: contig): the contig's keys pass through LDS in tiles of 1024, every
+    // thread counts the keys below its own -- all-pairs, but each key is fetched from HBM once per workgroup
+    __shared__ uint64_t tile[1024];
+    const int c = blockIdx.y;
+    const int64_t s0 = slot_off[c], s1 = slot_off[c + 1];
+    if ((int64_t)blockIdx.x * 256 >= s1 - s0) return;
+    const int64_t s = s0 + (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t k = s < s1 ? key[s] : ~0ull;
     uint32_t rank = 0;
-    for (int64_t x = slot_off[c]; x < slot_off[c + 1]; x++) rank += key[x] < k ? 1u : 0u;
+    for (int64_t t0 = s0; t0 < s1; t0 += 1024) {
+        const int m = (int)min((int64_t)1024, s1 - t0);
+        __syncthreads();
+        for (int x = threadIdx.x; x < m; x += 256) tile[x] = key[t0 + x];
+        __syncthreads();
+        if (k != ~0ull)
+            for (int x = 0; x < m; x++) rank += tile[x] < k ? 1u : 0u;
+    }
+    if (k == ~0ull) return;
     const int32_t r = slot_read[s];
     const fzp_aln_summary sm = summ[r];
     const int64_t nlen = read_len[r];
@@ -1000,6 +1011,7 @@ struct fzp_alnjob {
     DevBuf<int32_t> slot_read, slot_ctg;
     DevBuf<int64_t> slot_off;
     bool have_slots = false;
+    int64_t max_reads_per_ctg = 1;
     bool summ_on_host = false;
     DevBuf<ulonglong2> mvw2[2];
     hipEvent_t ev_sw[2] = {nullptr, nullptr}, ev_tb[2] = {nullptr, nullptr};
@@ -1389,7 +1401,8 @@ extern "C" int fzp_align_to_batch(fzp_ctx *ctx, fzp_alnjob *j, fzp_batch **out) 
     if (!j->have_slots) {      // reads grouped by contig, once per job
         std::vector<int64_t> off((size_t)nc + 1, 0);
         for (int64_t r = 0; r < nr; r++) off[(size_t)j->h_read_ctg[(size_t)r] + 1]++;
-        for (int c = 0; c < nc; c++) off[(size_t)c + 1] += off[(size_t)c];
+        for (int c = 0; c < nc; c++) { j->max_reads_per_ctg = std::max(j->max_reads_per_ctg, off[(size_t)c + 1]); off[(size_t)c + 1] += off[(size_t)c]; }
+        if (nc > 65535) { fzp_set_error("fzp_align_to_batch: %d contigs in one job (limit 65535)", nc); return FZP_EINVAL; }
         std::vector<int32_t> rd((size_t)nr), sc((size_t)nr);
         std::vector<int64_t> fill(off.begin(), off.end() - 1);
         for (int64_t r = 0; r < nr; r++) { const int c = j->h_read_ctg[(size_t)r]; const int64_t s_ = fill[(size_t)c]++; rd[(size_t)s_] = (int32_t)r; sc[(size_t)s_] = c; }
@@ -1417,7 +1430,7 @@ extern "C" int fzp_align_to_batch(fzp_ctx *ctx, fzp_alnjob *j, fzp_batch **out) 
     if (nr > 0) {
         ProfScope ps(ctx, "k1_plan");
         hipLaunchKernelGGL(k_plan_keys, dim3(gb), dim3(256), 0, st, nr, j->slot_read.p, j->summ.p, key.p);
-        hipLaunchKernelGGL(k_plan_rank, dim3(gb), dim3(256), 0, st, nr, j->slot_read.p, j->slot_ctg.p, j->slot_off.p, key.p, j->summ.p, j->read_len.p, v_rec.p, v_cig.p, v_seq.p,
+        hipLaunchKernelGGL(k_plan_rank, dim3((unsigned)((j->max_reads_per_ctg + 255) / 256), (unsigned)nc), dim3(256), 0, st, nr, j->slot_read.p, j->slot_ctg.p, j->slot_off.p, key.p, j->summ.p, j->read_len.p, v_rec.p, v_cig.p, v_seq.p,
                            v_ck.p, g_read.p, g_qid.p, g_acc.p, last_pos.p, n_aligned.p, n_cols.p);
     }
     FZP_TRY(fzp_exclusive_scan_u64_inplace(ctx, v_rec.p, (size_t)nr, totals.p + 0));
