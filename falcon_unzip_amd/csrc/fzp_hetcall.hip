@@ -20,13 +20,20 @@ __global__ void __launch_bounds__(256) k_cig_ckpt(RecView v, const int64_t *__re
         const int64_t c0 = v.cig_off[r], c1 = v.cig_off[r + 1];
         int64_t ck = ck_off[r];
         int32_t rp = 0, qp = 0;
-        for (int64_t cb = c0; cb < c1; cb += 64, ck++) {
-            if (lane == 0) { ck_ref[ck] = rp; ck_q[ck] = qp; }
-            uint32_t w = (cb + lane < c1) ? v.cigar[cb + lane] : 0u;
-            uint32_t len = w >> 4, t = w & 15u;
-            bool isM = (t == FZP_OP_M) | (t == FZP_OP_EQ) | (t == FZP_OP_X);
-            rp += wave_sum_i32_dpp((int32_t)((isM | (t == FZP_OP_D)) ? len : 0u));
-            qp += wave_sum_i32_dpp((int32_t)((isM | (t == FZP_OP_I) | (t == FZP_OP_S)) ? len : 0u));
+        for (int64_t cb = c0; cb < c1; cb += 256) {         // four 64-op chunks per round: their loads are in flight together
+            uint32_t w[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) w[u] = (cb + u * 64 + lane < c1) ? v.cigar[cb + u * 64 + lane] : 0u;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (cb + u * 64 >= c1) break;
+                if (lane == 0) { ck_ref[ck] = rp; ck_q[ck] = qp; }
+                ck++;
+                const uint32_t len = w[u] >> 4, t = w[u] & 15u;
+                const bool isM = (t == FZP_OP_M) | (t == FZP_OP_EQ) | (t == FZP_OP_X);
+                rp += wave_sum_i32_dpp((int32_t)((isM | (t == FZP_OP_D)) ? len : 0u));
+                qp += wave_sum_i32_dpp((int32_t)((isM | (t == FZP_OP_I) | (t == FZP_OP_S)) ? len : 0u));
+            }
         }
         if (lane == 0) { rec_span[r] = rp; atomicMax(&ctg_maxspan[v.rec_ctg[r]], rp); }
     }
