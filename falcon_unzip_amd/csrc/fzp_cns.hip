@@ -124,9 +124,9 @@ __global__ void __launch_bounds__(CNS_THREADS) k_cns_tiles(RecView rv, CnsView v
             const int32_t pos0 = rv.rec_pos[ru];
             expand_record(rv, ru,
                 [&](int32_t pos, uint8_t sym) {
-                    if (pos < ts || pos >= te) return;
+                    const uint32_t p = (uint32_t)(pos - ts);
                     const int code = sym_code(sym);
-                    if (code < 4) atomicAdd(&lc[code * CNS_TILE + (pos - ts)], 1u);
+                    if ((p < (uint32_t)(te - ts)) & (code < 4)) atomicAdd(&lc[code * CNS_TILE + p], 1u);
                 },
                 __builtin_amdgcn_readlane(ca, l), __builtin_amdgcn_readlane(cr, l), __builtin_amdgcn_readlane(cq, l), te + 1,
                 [&](uint32_t op, int32_t r0, uint32_t n, int64_t qidx) {

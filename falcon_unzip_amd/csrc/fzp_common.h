@@ -159,7 +159,11 @@ __device__ __forceinline__ uint32_t bcast_u32(uint32_t v, int src) { return __sh
 
 // base letter <-> 2-bit code in the order A C G T (the order phasing.py:108 counts in)
 __device__ __forceinline__ int sym_code(uint8_t s) {
-    return s == 'A' ? 0 : s == 'C' ? 1 : s == 'G' ? 2 : s == 'T' ? 3 : 4;
+    // branch-free: bits 1-2 of the letter give A 0, C 1, T 2, G 3; one xor puts G before T; the letter is then checked
+    const uint32_t x = ((uint32_t)s >> 1) & 3u;
+    const uint32_t code = x ^ (x >> 1);
+    const uint32_t expect = (0x54474341u >> (code * 8u)) & 0xffu;      // 'A' 'C' 'G' 'T'
+    return expect == (uint32_t)s ? (int)code : 4;
 }
 __device__ __host__ __forceinline__ uint8_t code_sym(int c) { return (uint8_t)("ACGT"[c & 3]); }
 // CPython-2.7 iteration order of a {allele: ...} dict: A < C < T < G (phasing.py:175,181)

@@ -17,6 +17,7 @@ struct RecView {
 // one column per base and advance both; D advances the reference; N,H,P do nothing.
 // 64 ops are loaded per step, their (ref, query, column) advances prefix-summed across the wave,
 // then the columns of those ops are dealt 64 at a time: lane t finds its op by a 6-step search.
+// visit(pos, sym) is called by every lane of a group; lanes that hold no column get pos = INT_MIN.
 struct NoGapOps { __device__ __forceinline__ void operator()(uint32_t, int32_t, uint32_t, int64_t) const {} };
 // gap_op(op, first reference position of the op (for I: the position AFTER the insertion point), length, index of the
 // op's first query base in v.seq) is called by the lane that holds a D or I op.
@@ -68,8 +69,7 @@ __device__ __forceinline__ void expand_record(const RecView &v, int64_t r, Visit
 #pragma unroll
             for (int u = 0; u < 4; u++) csym[u] = cval[u] ? v.seq[coff[u]] : (uint8_t)0;
 #pragma unroll
-            for (int u = 0; u < 4; u++)
-                if (cval[u]) visit(cpos[u], csym[u]);
+            for (int u = 0; u < 4; u++) visit(cval[u] ? cpos[u] : (int32_t)0x80000000, csym[u]);   // lanes without a column see a position no tile holds
         }
         // deletions and insertions of this chunk, one op per lane (short runs; K6 tallies them, K2 ignores them)
         if ((t == FZP_OP_D || t == FZP_OP_I) && len > 0) gap_op(t, (int32_t)(rp + rex), len, sbase + qp + qex);

@@ -94,13 +94,15 @@ __global__ void __launch_bounds__(PILE_THREADS) k_pileup_tiles(RecView v, const 
             const int l = __builtin_ctzll(todo);
             const int64_t ru = lo + __builtin_amdgcn_readlane(rel, l);
             expand_record(v, ru, [&](int32_t pos, uint8_t sym) {
-                if (pos < ts || pos >= te) return;
-                const int p = pos - ts;
+                const uint32_t p = (uint32_t)(pos - ts);
+                const bool in = p < (uint32_t)(te - ts);
                 const int code = sym_code(sym);
-                if (code < 4) atomicAdd(&l_cnt[code * PILE_TILE + p], 1u);
-                else {
-                    uint32_t old = atomicCAS(&l_oth[p], 0u, (uint32_t)sym);
-                    if (old != 0u && (old & 0xffu) != (uint32_t)sym) atomicOr(&l_oth[p], 0x100u);
+                if (in & (code < 4)) atomicAdd(&l_cnt[code * PILE_TILE + p], 1u);
+                if (__any(in & (code == 4))) {          // symbols other than ACGT: rare, kept off the common path
+                    if (in & (code == 4)) {
+                        uint32_t old = atomicCAS(&l_oth[p], 0u, (uint32_t)sym);
+                        if (old != 0u && (old & 0xffu) != (uint32_t)sym) atomicOr(&l_oth[p], 0x100u);
+                    }
                 }
             }, __builtin_amdgcn_readlane(a, l), __builtin_amdgcn_readlane(cr, l), __builtin_amdgcn_readlane(cq, l), te);
         }
