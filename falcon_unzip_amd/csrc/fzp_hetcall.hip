@@ -144,16 +144,6 @@ __device__ __forceinline__ CallInfo evaluate_position(uint4 k, uint32_t oth) {
 }
 
 // ---- K2b: per-position call flags + variant_map row counts ----------------------------------
-__global__ void __launch_bounds__(256) k_site_flag(const uint4 *__restrict__ cnt, const uint32_t *__restrict__ oth, int64_t n_pos,
-                                                   uint8_t *__restrict__ flag8, uint32_t *__restrict__ site_idx, uint32_t *__restrict__ row_off) {
-    int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (g >= n_pos) return;
-    CallInfo ci = evaluate_position(cnt[g], oth[g]);
-    flag8[g] = ci.called ? 1 : 0;
-    site_idx[g] = ci.called ? 1u : 0u;
-    row_off[g] = ci.called ? ci.c[0] + ci.c[1] : 0u;
-}
-
 __device__ __forceinline__ int find_ctg(const int64_t *goff, int n_ctg, int64_t g) {
     int lo = 0, hi = n_ctg;   // largest c with goff[c] <= g
     while (hi - lo > 1) {
@@ -163,15 +153,48 @@ __device__ __forceinline__ int find_ctg(const int64_t *goff, int n_ctg, int64_t 
     return lo;
 }
 
-// ---- K2c: site records in ascending position order ------------------------------------------
+// Called sites are sparse (one per few thousand positions), so the ordered compaction does not scan per-position
+// arrays: k_site_flag leaves one flag byte per position and, per 256-position block, the number of sites and of
+// variant_map rows; the two short block arrays are scanned; k_site_emit ranks the sites inside their block.
+__global__ void __launch_bounds__(256) k_site_flag(const uint4 *__restrict__ cnt, const uint32_t *__restrict__ oth, int64_t n_pos,
+                                                   uint8_t *__restrict__ flag8, uint32_t *__restrict__ blk_sites, uint32_t *__restrict__ blk_rows) {
+    __shared__ uint32_t ws[4], wr[4];
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    bool called = false;
+    uint32_t rows = 0;
+    if (g < n_pos) {
+        const CallInfo ci = evaluate_position(cnt[g], oth[g]);
+        called = ci.called;
+        rows = ci.called ? ci.c[0] + ci.c[1] : 0u;
+        flag8[g] = called ? 1 : 0;
+    }
+    const uint32_t ns = (uint32_t)__popcll(__ballot(called));
+    const uint32_t nr = (uint32_t)wave_sum_i32_dpp((int32_t)rows);
+    if (lane_id() == 0) { ws[threadIdx.x >> 6] = ns; wr[threadIdx.x >> 6] = nr; }
+    __syncthreads();
+    if (threadIdx.x == 0) { blk_sites[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3]; blk_rows[blockIdx.x] = wr[0] + wr[1] + wr[2] + wr[3]; }
+}
 __global__ void __launch_bounds__(256) k_site_emit(const uint4 *__restrict__ cnt, const uint32_t *__restrict__ oth, const uint8_t *__restrict__ flag8,
-                                                   const uint32_t *__restrict__ site_idx, const uint32_t *__restrict__ row_off, const uint8_t *__restrict__ ref,
+                                                   const uint32_t *__restrict__ blk_sites_off, const uint32_t *__restrict__ blk_rows_off, const uint8_t *__restrict__ ref,
                                                    const int64_t *__restrict__ goff, int n_ctg, int64_t n_pos, fzp_site *__restrict__ sites,
                                                    int64_t *__restrict__ site_g, int32_t *__restrict__ site_ctg) {
-    int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (g >= n_pos || !flag8[g]) return;
-    CallInfo ci = evaluate_position(cnt[g], oth[g]);
-    int c = find_ctg(goff, n_ctg, g);
+    __shared__ uint32_t ws[4], wr[4];
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    const bool called = g < n_pos && flag8[g];
+    const uint64_t bal = __ballot(called);
+    if (__syncthreads_or(called ? 1 : 0) == 0) return;                 // nothing called in this block (the usual case)
+    CallInfo ci;
+    uint32_t rows = 0;
+    if (called) { ci = evaluate_position(cnt[g], oth[g]); rows = ci.c[0] + ci.c[1]; }
+    const uint32_t incl = wave_incl_scan_u32(rows);
+    if (lane == 63) wr[wv] = incl;
+    if (lane == 0) ws[wv] = (uint32_t)__popcll(bal);
+    __syncthreads();
+    if (!called) return;
+    uint32_t si = blk_sites_off[blockIdx.x] + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull)), ro = blk_rows_off[blockIdx.x] + incl - rows;
+    for (int w = 0; w < wv; w++) { si += ws[w]; ro += wr[w]; }
+    const int c = find_ctg(goff, n_ctg, g);
     fzp_site s;
     s.pos = (int32_t)(g - goff[c]);
     s.ref_base = ref[g];
@@ -179,8 +202,7 @@ __global__ void __launch_bounds__(256) k_site_emit(const uint4 *__restrict__ cnt
     for (int i = 0; i < 4; i++) { s.base[i] = code_sym(ci.ord[i]); s.count[i] = (int32_t)ci.c[i]; }
     s.pad_[0] = s.pad_[1] = s.pad_[2] = 0;
     s.total = (int32_t)ci.total;
-    s.row_off = (int64_t)row_off[g];
-    uint32_t si = site_idx[g];
+    s.row_off = (int64_t)ro;
     sites[si] = s;
     site_g[si] = g;
     site_ctg[si] = c;
@@ -433,8 +455,9 @@ int fzp_k2_het_call(fzp_ctx *ctx, fzp_batch *b) {
     FZP_TRY(b->cnt.alloc((size_t)np * 4));
     FZP_TRY(b->oth.alloc((size_t)np));
     FZP_TRY(b->flag8.alloc((size_t)np));
-    FZP_TRY(b->site_idx.alloc((size_t)np));
-    FZP_TRY(b->row_off32.alloc((size_t)np));
+    const size_t nblk = (size_t)((np + 255) / 256);
+    FZP_TRY(b->site_idx.alloc(nblk));      // per 256-position block: sites, then their exclusive scan
+    FZP_TRY(b->row_off32.alloc(nblk));     // per block: variant_map rows, then their exclusive scan
     RecView v = rec_view(b);
     if (b->n_rec > 0 && np > 0) {
         // checkpoints + per-contig maximum reference span
@@ -466,8 +489,8 @@ int fzp_k2_het_call(fzp_ctx *ctx, fzp_batch *b) {
         hipLaunchKernelGGL(k_site_flag, dim3(grid_for(np, 256, 1 << 30)), dim3(256), 0, st, (const uint4 *)b->cnt.p, b->oth.p, np,
                            b->flag8.p, b->site_idx.p, b->row_off32.p);
     }
-    FZP_TRY(fzp_exclusive_scan_u32(ctx, b->site_idx.p, b->site_idx.p, (size_t)np, b->totals.p + 0));
-    FZP_TRY(fzp_exclusive_scan_u32(ctx, b->row_off32.p, b->row_off32.p, (size_t)np, b->totals.p + 1));
+    FZP_TRY(fzp_exclusive_scan_u32(ctx, b->site_idx.p, b->site_idx.p, nblk, b->totals.p + 0));
+    FZP_TRY(fzp_exclusive_scan_u32(ctx, b->row_off32.p, b->row_off32.p, nblk, b->totals.p + 1));
     uint64_t tot[2];
     FZP_TRY(read_totals(ctx, b, 2, tot));
     if (tot[1] >= (1ull << 31)) { fzp_set_error("variant_map has %llu rows (> 2^31)", (unsigned long long)tot[1]); return FZP_EINVAL; }
