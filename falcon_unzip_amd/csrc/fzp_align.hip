@@ -1,5 +1,5 @@
 // fzp_align.hip -- K1: read -> contig alignment on gfx950 (the role of blasr + samtools sort,
-// falcon_unzip/unzip.py:86-91).  Spec "fzalign v1": oracle/align_oracle.c is its scalar twin and the
+// falcon_unzip/unzip.py:86-91).  Spec "fzalign v1.1": oracle/align_oracle.c is its scalar twin and the
 // kernels here match it bit-for-bit (summaries, CIGAR words, DP cell counts).  Parity vs blasr itself
 // is UNPINNED (third-party binary, not vendored).
 //
@@ -12,9 +12,9 @@
 //                 go to HBM; steering compares lanes 0 and 63.  Integer VALU-bound, no MFMA.
 //   k_tb_walk     per read, one lane: walks the masks back from the best cell, emits a 2-bit op stream
 //   k_tb_cigar    per read, one wave: op stream -> forward run-length CIGAR, clips, summary
-//   k_gather      accepted records -> contiguous CIGAR + ASCII SEQ arrays for the phasing batch
+//   k_plan_*      per contig: aligned reads ordered by (POS, read), record filters (phasing.py:72-75), record offsets
+//   k_gather(16)  accepted records -> contiguous CIGAR + ASCII SEQ arrays for an alnset / the phasing batch
 #include <algorithm>
-#include <ctime>
 
 #include "fzp_batch.h"
 
