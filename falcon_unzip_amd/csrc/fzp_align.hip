@@ -655,13 +655,15 @@ __global__ void __launch_bounds__(64) k_tb_walk(int64_t first, int64_t count, co
     uint4 pf[TBW_RPW];
 #pragma unroll
     for (int l = 0; l < TBW_RPW; l++) pf[l] = make_uint4(0, 0, 0, 0);
+    uint64_t rec_base[TBW_RPW];      // every read's mask records: wave-uniform, fetched from the owning lanes once
+#pragma unroll
+    for (int l = 0; l < TBW_RPW; l++) rec_base[l] = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(phi, l) << 32) | (uint32_t)__builtin_amdgcn_readlane(plo, l);
     // records of chunk pref_chunk of every read -> registers (lane x takes step x of the chunk)
 #define TBW_ISSUE()                                                                                                      \
     _Pragma("unroll") for (int l = 0; l < TBW_RPW; l++) {                                                                \
         const int32_t cl = __builtin_amdgcn_readlane(pref_chunk, l);                                                     \
         if (cl >= 0) {                                                                                                   \
-            const uint64_t pl = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(phi, l) << 32) | (uint32_t)__builtin_amdgcn_readlane(plo, l); \
-            pf[l] = ((const uint4 *)pl)[(int64_t)cl * 64 + lane];                                                        \
+            pf[l] = ((const uint4 *)rec_base[l])[(int64_t)cl * 64 + lane];                                                        \
         }                                                                                                                \
     }
     TBW_ISSUE()
