@@ -25,7 +25,7 @@ PREAD = np.dtype([("q_id", "<i4"), ("block", "<i4"), ("phase", "<i4"), ("n0", "<
 R2P = np.dtype([("arid", "<i4"), ("ctg", "<i4"), ("block", "<i4"), ("phase", "<i4")], align=True)
 ALN_SUMMARY = np.dtype([("aligned", "<i4"), ("strand", "<i4"), ("pos", "<i4"), ("ref_end", "<i4"), ("q_start", "<i4"),
                         ("q_end", "<i4"), ("score", "<i4"), ("n_cigar", "<i4"), ("cells", "<i8"), ("n_columns", "<i4"),
-                        ("pad_", "<i4")], align=True)
+                        ("n_match", "<i4")], align=True)
 assert SITE.itemsize == 40 and AROW.itemsize == 24 and PVAR.itemsize == 28 and PREAD.itemsize == 20
 assert R2P.itemsize == 16 and ALN_SUMMARY.itemsize == 48
 
@@ -94,7 +94,7 @@ class OvlpParams(C.Structure):
 
 class AlignParams(C.Structure):
     _fields_ = [("kmer", C.c_int32), ("seed_stride", C.c_int32), ("match", C.c_int32), ("mismatch", C.c_int32),
-                ("gap", C.c_int32), ("min_seed_hits", C.c_int32), ("reserved", C.c_int32 * 10)]
+                ("gap", C.c_int32), ("min_seed_hits", C.c_int32), ("min_pct_identity", C.c_int32), ("reserved", C.c_int32 * 9)]
 
 
 _lib = None
@@ -146,6 +146,7 @@ def load():
         "fzp_align_create": (C.c_int, [VP, I32, VP, VP, I64, VP, VP, VP, VP, PP]),
         "fzp_align_run": (C.c_int, [VP, VP]),
         "fzp_align_summaries": (C.c_int, [VP, VP, VP]),
+        "fzp_align_n_second": (I64, [VP]),
         "fzp_align_alnset": (C.c_int, [VP, VP, I32, VP, CP, PP, PP]),
         "fzp_align_to_batch": (C.c_int, [VP, VP, PP]),
         "fzp_align_destroy": (None, [VP, VP]),
@@ -434,6 +435,10 @@ class AlignJob:
 
     def run(self):
         _check(load().fzp_align_run(self.eng._p, self._p))
+
+    def n_second(self):
+        """reads of the last run whose second candidate placement was extended as well"""
+        return int(load().fzp_align_n_second(self._p))
 
     def summaries(self):
         out = np.zeros(self.n_reads, ALN_SUMMARY)

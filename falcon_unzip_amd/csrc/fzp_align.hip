@@ -61,8 +61,15 @@ __device__ __forceinline__ uint32_t rc_key(uint32_t key, int k) {
 __device__ __forceinline__ uint32_t hash_slot(uint32_t key, int bits) { return (key * 0x9E3779B1u) >> (32 - bits); }
 
 // ---- contig k-mer index: canonical k-mers (min of the k-mer and its reverse complement) of every
-// CTG_STRIDE-th contig position -> smallest (position << 1 | "the canonical form is the reverse complement")
+// CTG_STRIDE-th contig position -> EVERY such (position << 1 | "the canonical form is the reverse complement").
+// Table: buckets of 4 entries (32 B, one sector per probe), entry = key << 32 | value; a key's entries fill the
+// first free slots along its bucket chain (linear probing over buckets), so a look-up may stop at the first
+// bucket that still has a free slot: it has then seen every entry of the key.  Insertion order (a race) only
+// decides which slot an entry lands in, never which entries a look-up finds.
 constexpr int CTG_STRIDE = 2;
+constexpr int MAX_OCC = 8;          // spec: k-mers with more index entries never produce a hit
+constexpr int HIT_CAP = 4096;       // spec: hits of a read beyond the first HIT_CAP (sample order, then position) do not exist
+constexpr int CHAIN_MAX_GAP = 2048;
 __device__ __forceinline__ uint32_t canonical(uint32_t key, int k, uint32_t *is_rc) {
     uint32_t r = rc_key(key, k);
     *is_rc = r < key ? 1u : 0u;
@@ -74,31 +81,47 @@ __global__ void __launch_bounds__(256) k_index(const uint32_t *__restrict__ ctg_
     const int64_t nk = ctg_len[c] - k + 1;
     const uint32_t *pk = ctg_pk + ctg_woff[c];
     uint64_t *tab = table + idx_off[c];
-    const int bits = idx_bits[c];
-    const uint32_t mask = (1u << bits) - 1u;
+    const int bbits = idx_bits[c] - 2;                    // buckets
+    const uint32_t bmask = (1u << bbits) - 1u;
     for (int64_t p = ((int64_t)blockIdx.x * 256 + threadIdx.x) * CTG_STRIDE; p < nk; p += (int64_t)gridDim.x * 256 * CTG_STRIDE) {
         uint32_t orc;
         uint32_t key = canonical(kmer_at(pk, p, k), k, &orc);
         uint64_t word = ((uint64_t)key << 32) | (uint64_t)(((uint32_t)p << 1) | orc);
-        uint32_t slot = hash_slot(key, bits);
+        uint32_t bkt = hash_slot(key, bbits);
+        uint32_t s0 = (key >> 3) & 3u;                   // first slot tried: spreads the first attempts over the bucket
         for (;;) {
-            unsigned long long old = atomicCAS((unsigned long long *)&tab[slot], (unsigned long long)EMPTY, (unsigned long long)word);
-            if (old == EMPTY) break;
-            if ((uint32_t)(old >> 32) == key) { atomicMin((unsigned long long *)&tab[slot], (unsigned long long)word); break; }
-            slot = (slot + 1) & mask;
+            bool placed = false;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t sl = (s0 + q) & 3u;
+                unsigned long long old = atomicCAS((unsigned long long *)&tab[(size_t)bkt * 4 + sl], (unsigned long long)EMPTY, (unsigned long long)word);
+                if (old == EMPTY) { placed = true; break; }
+            }
+            if (placed) break;
+            bkt = (bkt + 1) & bmask;
+            s0 = 0;
         }
     }
 }
-// -> (position << 1 | orientation bit) or -1
-__device__ __forceinline__ int32_t index_lookup(const uint64_t *__restrict__ tab, int bits, uint32_t key) {
-    const uint32_t mask = (1u << bits) - 1u;
-    uint32_t slot = hash_slot(key, bits);
+// every index entry of `key` (values, unsorted) into e[0..MAX_OCC); returns the count, MAX_OCC + 1 if there are more.
+// b0 = the key's first bucket, already loaded by the caller (several probes are kept in flight).
+__device__ __forceinline__ int index_collect(const uint64_t *__restrict__ tab, int bbits, uint32_t key, uint32_t bkt, uint4 lo, uint4 hi, uint32_t *e) {
+    const uint32_t bmask = (1u << bbits) - 1u;
+    int cnt = 0;
     for (;;) {
-        uint64_t v = tab[slot];
-        if (v == EMPTY) return -1;
-        if ((uint32_t)(v >> 32) == key) return (int32_t)(uint32_t)v;
-        slot = (slot + 1) & mask;
+        const uint32_t kk[4] = {lo.y, lo.w, hi.y, hi.w}, vv[4] = {lo.x, lo.z, hi.x, hi.z};
+        bool open = false;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (kk[q] == 0xffffffffu && vv[q] == 0xffffffffu) open = true;
+            else if (kk[q] == key) { if (cnt < MAX_OCC) e[cnt] = vv[q]; cnt++; }
+        }
+        if (open || cnt > MAX_OCC) break;
+        bkt = (bkt + 1) & bmask;
+        const uint4 *bp = (const uint4 *)(tab + (size_t)bkt * 4);
+        lo = bp[0]; hi = bp[1];
     }
+    return cnt > MAX_OCC ? MAX_OCC + 1 : cnt;
 }
 
 struct Anchor { int32_t aligned, strand, i_a, c_a; };
@@ -114,68 +137,95 @@ __device__ __forceinline__ uint64_t block_max_u64(uint64_t v, uint64_t *sh) {
     return r;
 }
 
-// ---- seeding: one workgroup per read
+// ---- seeding, part 1: one workgroup per read (spec: oracle/align_oracle.c header, "hits", "windows")
+//   A. rounds of 1024 samples, four consecutive samples per thread (their first bucket loads in flight together);
+//      a block scan of the per-thread hit counts puts the hits into the read's hit list (HBM, HIT_CAP slots per read of
+//      the launch) in (sample, position) order -- the order the HIT_CAP of the spec is defined on -- and every stored
+//      hit votes for its (strand, diagonal bin) in LDS;
+//   B. W1 / W2 by block-wide argmax over the vote bins -> SeedWin.
+struct SeedWin { int32_t n_hits, shift, s1, b1, have2, s2, b2, pad_; };
 __global__ void __launch_bounds__(256) k_seed(int64_t first, const uint32_t *__restrict__ read_pk, const int64_t *__restrict__ read_woff, const int32_t *__restrict__ read_len,
                                               const int32_t *__restrict__ read_ctg, const int64_t *__restrict__ ctg_len, const int64_t *__restrict__ idx_off,
                                               const int32_t *__restrict__ idx_bits, const uint64_t *__restrict__ table, int k, int stride, int min_hits,
-                                              Anchor *__restrict__ anc, int nb_alloc, int hit_cap) {
-    extern __shared__ uint32_t votes[];   // [2 * nb_alloc] vote bins, then hit_cap hit records
+                                              uint2 *__restrict__ hits_g, SeedWin *__restrict__ win) {
+    extern __shared__ uint32_t votes[];   // [2 * NB] vote bins
     __shared__ uint64_t red[4];
-    __shared__ uint32_t n_hits;
+    __shared__ uint32_t wsum[4];
     const int64_t r = first + blockIdx.x;
     const int64_t n = read_len[r];
     const int c = read_ctg[r];
     const int64_t Lc = ctg_len[c];
-    Anchor a = {0, 0, 0, 0};
-    if (n < k || Lc < k) { if (threadIdx.x == 0) anc[r] = a; return; }
+    SeedWin sw = {0, 10, 0, 0, 0, 0, 0, 0};
+    if (n < k || Lc < k) { if (threadIdx.x == 0) win[blockIdx.x] = sw; return; }
     int shift = 10;
     while ((((Lc + n) >> shift) + 2) > MAX_BINS) shift++;
     const int NB = (int)(((Lc + n) >> shift) + 2);
     const uint32_t *pk = read_pk + read_woff[r];
     const uint64_t *tab = table + idx_off[c];
-    const int bits = idx_bits[c];
-    uint2 *hits = (uint2 *)(votes + 2 * nb_alloc);   // (strand << 31 | oriented offset, contig position) of every sampled k-mer found
+    const int bbits = idx_bits[c] - 2;
+    uint2 *hits = hits_g + (size_t)blockIdx.x * HIT_CAP;   // (strand << 31 | oriented offset, contig position), spec order
     for (int i = threadIdx.x; i < 2 * NB; i += 256) votes[i] = 0;
-    if (threadIdx.x == 0) n_hits = 0;
     __syncthreads();
     const int64_t ns = (n - k) / stride + 1;   // sampled FORWARD read offsets 0, stride, ...
-    // one canonical lookup serves both strands: same orientation bit on both sides -> the read matches as
-    // sequenced (strand 0, oriented offset = pf); different -> its reverse complement does (offset n-k-pf).
-    // Four samples per thread and round: their first probes are in flight together (the table is ~30 % full,
-    // so the first probe nearly always decides).
-    for (int64_t m0 = threadIdx.x; m0 < ns; m0 += 4 * 256) {
-        uint32_t key[4], orr[4], slot[4];
-        uint64_t v[4];
-        const uint32_t mask = (1u << bits) - 1u;
+    uint32_t n_hits = 0;                       // block-uniform
+    const int lane = lane_id(), wid = threadIdx.x >> 6;
+    for (int64_t base = 0; base < ns && n_hits < (uint32_t)HIT_CAP; base += 1024) {
+        uint32_t key[4], orr[4], bkt[4];
+        uint4 lo[4], hi[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const int64_t m = m0 + u * 256;
-            key[u] = 0; orr[u] = 0; slot[u] = 0; v[u] = EMPTY;
+            const int64_t m = base + 4 * threadIdx.x + u;
+            key[u] = 0; orr[u] = 0; bkt[u] = 0;
+            lo[u] = hi[u] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
             if (m < ns) {
                 key[u] = canonical(kmer_at(pk, m * stride, k), k, &orr[u]);
-                slot[u] = hash_slot(key[u], bits);
-                v[u] = tab[slot[u]];
+                bkt[u] = hash_slot(key[u], bbits);
+                const uint4 *bp = (const uint4 *)(tab + (size_t)bkt[u] * 4);
+                lo[u] = bp[0]; hi[u] = bp[1];
             }
         }
+        uint32_t ent[4][MAX_OCC];
+        int cnt[4];
+        uint32_t mine = 0;
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const int64_t m = m0 + u * 256;
-            if (m >= ns) continue;
-            uint64_t x = v[u];
-            uint32_t sl = slot[u];
-            while (x != EMPTY && (uint32_t)(x >> 32) != key[u]) { sl = (sl + 1) & mask; x = tab[sl]; }
-            if (x == EMPTY) continue;
-            const uint32_t hit = (uint32_t)x;
-            const int64_t pf = m * stride;
-            const int s_ = (int)((hit & 1u) ^ orr[u]);
-            const int64_t cp = hit >> 1, i = s_ ? n - k - pf : pf;
-            atomicAdd(&votes[s_ * NB + (int)((cp - i + n) >> shift)], 1u);
-            const uint32_t at = atomicAdd(&n_hits, 1u);
-            if (at < (uint32_t)hit_cap) hits[at] = make_uint2(((uint32_t)s_ << 31) | (uint32_t)i, (uint32_t)cp);
+            const int64_t m = base + 4 * threadIdx.x + u;
+            cnt[u] = 0;
+            if (m < ns) {
+                cnt[u] = index_collect(tab, bbits, key[u], bkt[u], lo[u], hi[u], ent[u]);
+                if (cnt[u] > MAX_OCC) cnt[u] = 0;
+                for (int a = 1; a < cnt[u]; a++) {           // by position (insertion sort; almost always one entry)
+                    const uint32_t v = ent[u][a];
+                    int b = a - 1;
+                    while (b >= 0 && ent[u][b] > v) { ent[u][b + 1] = ent[u][b]; b--; }
+                    ent[u][b + 1] = v;
+                }
+            }
+            mine += (uint32_t)cnt[u];
         }
+        // slots in (sample, position) order: exclusive scan of the per-thread counts
+        const uint32_t incl = wave_incl_scan_u32(mine);
+        if (lane == 63) wsum[wid] = incl;
+        __syncthreads();
+        uint32_t off = n_hits + incl - mine, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) { if (w < wid) off += wsum[w]; tot += wsum[w]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int64_t pf = (base + 4 * threadIdx.x + u) * stride;
+            for (int a = 0; a < cnt[u]; a++, off++) {
+                if (off >= (uint32_t)HIT_CAP) break;
+                const uint32_t hit = ent[u][a];
+                const int s_ = (int)((hit & 1u) ^ orr[u]);
+                const int64_t cp = hit >> 1, i = s_ ? n - k - pf : pf;
+                hits[off] = make_uint2(((uint32_t)s_ << 31) | (uint32_t)i, (uint32_t)cp);
+                atomicAdd(&votes[s_ * NB + (int)((cp - i + n) >> shift)], 1u);
+            }
+        }
+        n_hits = min(n_hits + tot, (uint32_t)HIT_CAP);
+        __syncthreads();
     }
-    __syncthreads();
-    // best window: max votes[b]+votes[b+1]; ties -> forward strand, lower bin
+    // W1: max votes[b]+votes[b+1]; ties -> forward strand, lower bin
     uint64_t best = 0;
     for (int x = threadIdx.x; x < 2 * NB; x += 256) {
         int b = x >= NB ? x - NB : x;
@@ -185,57 +235,118 @@ __global__ void __launch_bounds__(256) k_seed(int64_t first, const uint32_t *__r
         best = key > best ? key : best;
     }
     best = block_max_u64(best, red);
-    const uint32_t sc = (uint32_t)(best >> 32);
-    if ((int32_t)sc < min_hits || sc == 0) { if (threadIdx.x == 0) anc[r] = a; return; }
-    const int x = (int)(0xffffffffu - (uint32_t)best);
-    const int bs = x >= NB, bb = bs ? x - NB : x;
-    // the hit with the smallest ORIENTED read offset inside the two winning bins fixes the diagonal
-    uint64_t mn = 0;   // maximise ~(i<<32|cp) == minimise i, then cp
-    if (n_hits <= (uint32_t)hit_cap) {
-        for (uint32_t e = threadIdx.x; e < n_hits; e += 256) {
-            const uint2 h = hits[e];
-            if ((int)(h.x >> 31) != bs) continue;
-            const int64_t i = h.x & 0x7fffffffu, cp = h.y;
-            const int b = (int)((cp - i + n) >> shift);
-            if (b == bb || b == bb + 1) { const uint64_t c_ = ~(((uint64_t)i << 32) | (uint32_t)cp); mn = c_ > mn ? c_ : mn; }
-        }
-    } else {   // more hits than the list holds (near error-free reads): look them up again
-        for (int64_t m = threadIdx.x; m < ns; m += 256) {
-            // each thread visits its samples in order of increasing oriented offset and stops at its first hit
-            const int64_t pf = (bs ? ns - 1 - m : m) * stride;
-            uint32_t orr;
-            const uint32_t key = canonical(kmer_at(pk, pf, k), k, &orr);
-            const int32_t hit = index_lookup(tab, bits, key);
-            if (hit < 0) continue;
-            const int s = (int)(((uint32_t)hit & 1u) ^ orr);
-            if (s != bs) continue;
-            const int64_t cp = (uint32_t)hit >> 1, i = s ? n - k - pf : pf;
-            const int b = (int)((cp - i + n) >> shift);
-            if (b == bb || b == bb + 1) { mn = ~(((uint64_t)i << 32) | (uint32_t)cp); break; }
-        }
+    const uint32_t w1 = (uint32_t)(best >> 32);
+    if ((int32_t)w1 < min_hits || w1 == 0) { if (threadIdx.x == 0) win[blockIdx.x] = sw; return; }
+    const int x1 = (int)(0xffffffffu - (uint32_t)best);
+    const int s1 = x1 >= NB, b1 = s1 ? x1 - NB : x1;
+    // W2: the best window on the other strand or at least 3 bins away
+    uint64_t best2 = 0;
+    for (int x = threadIdx.x; x < 2 * NB; x += 256) {
+        const int sx = x >= NB, b = sx ? x - NB : x;
+        if (b + 1 >= NB) continue;
+        if (sx == s1 && b - b1 < 3 && b1 - b < 3) continue;
+        uint64_t sc = (uint64_t)votes[x] + votes[x + 1];
+        uint64_t key = (sc << 32) | (uint64_t)(0xffffffffu - (uint32_t)x);
+        best2 = key > best2 ? key : best2;
     }
-    mn = block_max_u64(mn, red);
+    best2 = block_max_u64(best2, red);
     if (threadIdx.x == 0) {
-        if (mn != 0) {
-            // the seed fixes the diagonal; the extension itself starts at the read's first base on that diagonal
-            // (or at the contig's first base when the read overhangs it)
-            const uint64_t v = ~mn;
-            const int32_t d = (int32_t)(uint32_t)v - (int32_t)(v >> 32);
-            a.aligned = 1; a.strand = bs; a.i_a = d < 0 ? -d : 0; a.c_a = d < 0 ? 0 : d;
-        }
-        anc[r] = a;
+        const uint32_t w2 = (uint32_t)(best2 >> 32);
+        const int x2 = (int)(0xffffffffu - (uint32_t)best2);
+        sw.n_hits = (int32_t)n_hits; sw.shift = shift; sw.s1 = s1; sw.b1 = b1;
+        sw.have2 = ((int32_t)w2 >= min_hits && w2 > 0 && 4ull * w2 >= (uint64_t)w1) ? 1 : 0;
+        sw.s2 = x2 >= NB; sw.b2 = sw.s2 ? x2 - NB : x2;
+        win[blockIdx.x] = sw;
     }
 }
 
-// ---- oriented packed copy of each read
+// wave-uniform max of non-negative keys without LDS traffic: 4 DPP steps inside each row of 16 lanes, the 4 rows via SGPRs
+__device__ __forceinline__ int32_t wave_max_nonneg_dpp(int32_t v) {
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true));   // row_half_mirror
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, true));   // row_mirror
+    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+
+// ---- seeding, part 2 (spec "chains"): one wave per (read, window).  The window's hits are walked in list order (reversed on
+// the reverse strand), 64 list entries per load; the last 64 window hits sit one per lane (lane = running index mod 64), the
+// new hit is tested against all of them at once and the best predecessor comes out of one wave-wide max.  The chain is a
+// serial dependence per read: thousands of waves in flight hide it.
+__global__ void __launch_bounds__(64) k_chain(int64_t first, int64_t count, const int32_t *__restrict__ read_len, const uint2 *__restrict__ hits_g,
+                                              const SeedWin *__restrict__ win, Anchor *__restrict__ anc, Anchor *__restrict__ ancB) {
+    const int64_t wv = blockIdx.x;
+    if (wv >= 2 * count) return;
+    const int64_t slot = wv >> 1;
+    const int which = (int)(wv & 1);
+    const int64_t r = first + slot;
+    const int lane = lane_id();
+    const SeedWin sw = win[slot];
+    Anchor *out = which ? ancB : anc;
+    const Anchor none = {0, 0, 0, 0};
+    if (sw.n_hits == 0 || (which && !sw.have2)) { if (lane == 0) out[r] = none; return; }
+    const int32_t n = read_len[r];
+    const int ws = which ? sw.s2 : sw.s1, wb = which ? sw.b2 : sw.b1, shift = sw.shift;
+    const uint2 *hits = hits_g + (size_t)slot * HIT_CAP;
+    const int32_t nh = sw.n_hits;
+    int32_t ri = 0, rcp = 0, rd = 0, rf = 0, rst = 0;      // ring: lane L holds window hit number e with e % 64 == L
+    int32_t e = 0, best_f = 0, best_st = -1;
+    for (int32_t x0 = 0; x0 < nh; x0 += 64) {
+        const int32_t xl = x0 + lane;
+        const int32_t hl = ws ? nh - 1 - xl : xl;
+        uint2 hv = make_uint2(0, 0);
+        if (xl < nh) hv = hits[hl];
+        const int m = min(64, nh - x0);
+        for (int jx = 0; jx < m; jx++) {
+            const uint32_t hx = (uint32_t)__builtin_amdgcn_readlane((int32_t)hv.x, jx), hy = (uint32_t)__builtin_amdgcn_readlane((int32_t)hv.y, jx);
+            if ((int)(hx >> 31) != ws) continue;
+            const int32_t i = (int32_t)(hx & 0x7fffffffu), cp = (int32_t)hy;
+            const int64_t dv = (int64_t)cp - i + n;
+            const int b = (int)(dv >> shift);
+            if (b < wb - 1 || b > wb + 2) continue;
+            const int32_t h = ws ? nh - 1 - (x0 + jx) : x0 + jx;
+            const int32_t d = cp - i;
+            const int32_t dist = (e - 1 - lane) & 63;           // this lane's hit is `dist + 1` window hits back
+            const int32_t di = i - ri;
+            int32_t dd = d - rd; dd = dd < 0 ? -dd : dd;
+            const bool ok = dist < e && di >= 1 && di <= CHAIN_MAX_GAP && cp > rcp && dd <= 16 + (di >> 4);
+            const int32_t key = ok ? ((rf << 6) | (63 - dist)) : 0;
+            const int32_t K = wave_max_nonneg_dpp(key);
+            int32_t f = 1, st = h;
+            if (K > 0) {
+                f = (K >> 6) + 1;
+                const int32_t src = (e - 1 - (63 - (K & 63))) & 63;
+                st = __builtin_amdgcn_readlane(rst, src);
+            }
+            if (lane == (e & 63)) { ri = i; rcp = cp; rd = d; rf = f; rst = st; }
+            if (f > best_f) { best_f = f; best_st = st; }
+            e++;
+        }
+    }
+    if (lane == 0) {
+        Anchor a = none;
+        if (best_st >= 0) {
+            // the chain's first hit fixes the diagonal; the extension itself starts at the read's first base on that diagonal
+            // (or at the contig's first base when the read overhangs it)
+            const uint2 hv = hits[best_st];
+            const int32_t d = (int32_t)hv.y - (int32_t)(hv.x & 0x7fffffffu);
+            a.aligned = 1; a.strand = ws; a.i_a = d < 0 ? -d : 0; a.c_a = d < 0 ? 0 : d;
+        }
+        out[r] = a;
+    }
+}
+
+// ---- oriented packed copy of each read (slot = read for the first candidates; the second candidates of the few reads
+// that have one are compacted: slot w -> read ridx[w], own word offsets)
 __global__ void __launch_bounds__(256) k_orient(int64_t first, const uint32_t *__restrict__ read_pk, const int64_t *__restrict__ read_woff, const int32_t *__restrict__ read_len,
-                                                const Anchor *__restrict__ anc, uint32_t *__restrict__ out) {
-    const int64_t r = first + blockIdx.x;
+                                                const Anchor *__restrict__ anc, const int32_t *__restrict__ ridx, const int64_t *__restrict__ out_woff, uint32_t *__restrict__ out) {
+    const int64_t sl = first + blockIdx.x;
+    const int64_t r = ridx ? ridx[sl] : sl;
     const int64_t n = read_len[r];
     const int64_t nw = ((n + 15) / 16 + 8 + 1) & ~1LL;
     const uint32_t *src = read_pk + read_woff[r];
-    uint32_t *dst = out + read_woff[r];
-    const bool rc = anc[r].strand != 0;
+    uint32_t *dst = out + out_woff[sl];
+    const bool rc = anc[sl].strand != 0;
     for (int64_t w = (int64_t)blockIdx.y * 256 + threadIdx.x; w < nw; w += (int64_t)gridDim.y * 256) {
         uint32_t v = src[w];
         if (rc) {
@@ -482,30 +593,33 @@ __device__ __forceinline__ uint64_t base_window(const uint32_t *__restrict__ pk,
     return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)v);
 }
 
-__global__ void __launch_bounds__(64) k_sw(int64_t first, int64_t count, const uint32_t *__restrict__ read_ori, const int64_t *__restrict__ read_woff,
-                                            const int32_t *__restrict__ read_len, const int32_t *__restrict__ read_ctg, const uint32_t *__restrict__ ctg_pk,
-                                            const int64_t *__restrict__ ctg_woff, const int64_t *__restrict__ ctg_len, const Anchor *__restrict__ anc,
-                                            const int64_t *__restrict__ tb_off, uint2 *__restrict__ tb, ulonglong2 *__restrict__ mvw, int match, int mismatch,
-                                            int gap, DpInfo *__restrict__ info) {
+__global__ void __launch_bounds__(64) k_sw(int64_t first, int64_t count, const int32_t *__restrict__ ridx, const uint32_t *__restrict__ read_ori,
+                                            const int64_t *__restrict__ ori_woff, const int32_t *__restrict__ read_len, const int32_t *__restrict__ read_ctg,
+                                            const uint32_t *__restrict__ ctg_pk, const int64_t *__restrict__ ctg_woff, const int64_t *__restrict__ ctg_len,
+                                            const Anchor *__restrict__ anc, const int64_t *__restrict__ tb_off, uint2 *__restrict__ tb, ulonglong2 *__restrict__ mvw,
+                                            int match, int mismatch, int gap, DpInfo *__restrict__ info, int64_t *__restrict__ tbo, int64_t *__restrict__ mvo) {
     const int lane = lane_id();
     // wave-uniform on purpose: everything indexed by the read then lives in SGPRs / scalar loads
     const int64_t wv = (int64_t)blockIdx.x;   // one wave per workgroup: a finished read frees its slot at once
     if (wv >= count) return;
-    const int64_t r = first + wv;
-    const Anchor a = anc[r];
-    if (!a.aligned) { if (lane == 0) info[r] = DpInfo{0, -1, 0, NEGV}; return; }
+    // slot = candidate: the read itself for first candidates, an entry of the compacted list for second ones
+    const int64_t sl = first + wv;
+    const int64_t r = ridx ? ridx[sl] : sl;
+    const Anchor a = anc[sl];
+    ulonglong2 *tbr = (ulonglong2 *)tb + (tb_off[sl] - tb_off[first]);   // per step: {D mask, G mask} over the 64 band lanes
+    ulonglong2 *mvr = mvw + ((tb_off[sl] - tb_off[first]) >> 6) + wv;   // per 64 steps: {move bits, i0 before the chunk}
+    if (tbo && lane == 0) { tbo[sl] = tb_off[sl] - tb_off[first]; mvo[sl] = ((tb_off[sl] - tb_off[first]) >> 6) + wv; }   // element offsets into the chunk's buffers
+    if (!a.aligned) { if (lane == 0) info[sl] = DpInfo{0, -1, 0, NEGV}; return; }
     const int c_idx = read_ctg[r];
     const int64_t n = read_len[r];
     const int32_t nq = (int32_t)(n - a.i_a);
     int64_t ntl = ctg_len[c_idx] - a.c_a;
     if (ntl > (int64_t)nq + nq / 4 + 64) ntl = (int64_t)nq + nq / 4 + 64;
     const int32_t nt = (int32_t)ntl;
-    const uint32_t *qpk = read_ori + read_woff[r];
+    const uint32_t *qpk = read_ori + ori_woff[sl];
     const uint32_t *tpk = ctg_pk + ctg_woff[c_idx];
     const int64_t qb = a.i_a, tbase = a.c_a;
     const int32_t max_steps = nq + nt + 2;
-    ulonglong2 *tbr = (ulonglong2 *)tb + (tb_off[r] - tb_off[first]);   // per step: {D mask, G mask} over the 64 band lanes
-    ulonglong2 *mvr = mvw + ((tb_off[r] - tb_off[first]) >> 6) + wv;   // per 64 steps: {move bits, i0 before the chunk}
 
     // state before step 0 (biased): H(-1), and X = H(-2) in the lane layout it was computed in
     int32_t H = (lane == 32 || lane == 33) ? SW_BIAS - gap : 0;
@@ -592,7 +706,7 @@ __global__ void __launch_bounds__(64) k_sw(int64_t first, int64_t count, const u
         bool take = so > s_b || (so == s_b && (to < t_b || (to == t_b && lo < l_b)));
         if (take) { s_b = so; t_b = to; l_b = lo; }
     }
-    if (lane == 0) info[r] = DpInfo{t, t_b == 0x7fffffff ? -1 : t_b, l_b, s_b - SW_BIAS};
+    if (lane == 0) info[sl] = DpInfo{t, t_b == 0x7fffffff ? -1 : t_b, l_b, s_b - SW_BIAS};
 }
 #undef SW_STEP
 #undef SW_FLUSH
@@ -618,8 +732,9 @@ constexpr int TBW_RPW = 16;                      // reads walked per wave
 struct WalkOut { int32_t ok, i, ts, i_end, j_end, ncol, n_ops, pad_; };   // (i, ts - i) = the cell before the alignment's first
 
 __global__ void __launch_bounds__(64) k_tb_walk(int64_t first, int64_t count, const Anchor *__restrict__ anc, const DpInfo *__restrict__ info,
-                                                const int64_t *__restrict__ tb_off, const uint2 *__restrict__ tb, const ulonglong2 *__restrict__ mvw,
-                                                uint32_t *__restrict__ raw, WalkOut *__restrict__ wout) {
+                                                const int64_t *__restrict__ tb_off, const int64_t *__restrict__ tbo, const int64_t *__restrict__ mvo,
+                                                const ulonglong2 *__restrict__ tb, const ulonglong2 *__restrict__ mvw, uint32_t *__restrict__ raw,
+                                                WalkOut *__restrict__ wout) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[TBW_RPW * TBW_STRIDE];
     const int lane = threadIdx.x;
     const int64_t wv = (int64_t)blockIdx.x * TBW_RPW + lane;
@@ -630,8 +745,11 @@ __global__ void __launch_bounds__(64) k_tb_walk(int64_t first, int64_t count, co
     if (have) { a = anc[r]; di = info[r]; }
     bool active = have && a.aligned && di.best_t >= 0 && di.best_score > 0;
     const int64_t soff = tb_off[r] - tb_off[first];                           // steps before this read in the chunk of reads
-    const ulonglong2 *tbr = (const ulonglong2 *)tb + soff;                    // per step {D mask, G mask}
-    const ulonglong2 *mvr = mvw + (soff >> 6) + (have ? wv : 0);              // per 64 steps {move bits, i0 before them}
+    // masks / move words of the winning candidate (second candidates sit behind the first ones in the same buffers)
+    int64_t to_ = tbo[r], mo_ = mvo[r];
+    asm volatile("" : "+v"(to_), "+v"(mo_));      // both offsets are in registers from here on: no pending load is attributed to the pointers below
+    const ulonglong2 *tbr = tb + to_;                                         // per step {D mask, G mask}
+    const ulonglong2 *mvr = mvw + mo_;                                        // per 64 steps {move bits, i0 before them}
     uint32_t *rawp = raw + (soff >> 4);                                       // 16 ops per word
     int32_t ts = active ? di.best_t : -1;
     int32_t k = di.best_lane, i = -1;
@@ -757,7 +875,8 @@ __global__ void __launch_bounds__(64) k_tb_walk(int64_t first, int64_t count, co
 __global__ void __launch_bounds__(64) k_tb_cigar(int64_t first, int64_t count, const int32_t *__restrict__ read_len, const Anchor *__restrict__ anc,
                                                  const DpInfo *__restrict__ info, const int64_t *__restrict__ tb_off, const uint32_t *__restrict__ raw,
                                                  const WalkOut *__restrict__ wout, const int64_t *__restrict__ cig_off, uint32_t *__restrict__ cig,
-                                                 int64_t *__restrict__ cig_start, fzp_aln_summary *__restrict__ summ) {
+                                                 int64_t *__restrict__ cig_start, fzp_aln_summary *__restrict__ summ, int match, int mismatch, int gap,
+                                                 int min_pct_identity) {
     const int lane = lane_id();
     const int64_t wv = blockIdx.x;
     if (wv >= count) return;
@@ -853,21 +972,71 @@ __global__ void __launch_bounds__(64) k_tb_cigar(int64_t first, int64_t count, c
     if (pM_hi >= 0 && w.ncol > 0 && runs <= max_runs) {
         int32_t fa = 1 + lead_runs, fb = 1 + runs - trail_runs;       // forward ops are reg[fa .. fb)
         const int32_t q_lead = w.i + 1 + leadI, r_lead = (w.ts - w.i) + 1 + leadD;
-        out.aligned = 1;
-        out.strand = a.strand;
-        out.pos = (int32_t)(a.c_a + r_lead);
-        out.ref_end = (int32_t)(a.c_a + w.j_end + 1 - trailD);
-        out.q_start = (int32_t)(a.i_a + q_lead);
-        out.q_end = (int32_t)(a.i_a + w.i_end + 1 - trailI);
-        out.score = di.best_score;
-        out.n_columns = w.ncol;
-        int32_t nc = fb - fa;
-        if (out.q_start > 0) { reg[--fa] = ((uint32_t)out.q_start << 4) | FZP_OP_S; nc++; }
-        if (n - out.q_end > 0) { reg[fb++] = ((uint32_t)(n - out.q_end) << 4) | FZP_OP_S; nc++; }
-        out.n_cigar = nc;
-        cig_start[r] = cig_off[r] + fa;
+        const int32_t pos = (int32_t)(a.c_a + r_lead), ref_end = (int32_t)(a.c_a + w.j_end + 1 - trailD);
+        const int32_t q_start = (int32_t)(a.i_a + q_lead), q_end = (int32_t)(a.i_a + w.i_end + 1 - trailI);
+        // matches from the score (the walk never sees the bases): the path from the origin consumes i_end + 1 read and
+        // j_end + 1 contig bases, ncol of each on diagonals, the rest in gaps -- exact, the twin checks it against a direct count
+        const int64_t num = (int64_t)di.best_score + (int64_t)mismatch * w.ncol + (int64_t)gap * ((int64_t)w.i_end + w.j_end + 2 - 2 * (int64_t)w.ncol);
+        const int32_t n_match = (int32_t)(num / (match + mismatch));
+        const int64_t aln_len = (int64_t)(q_end - q_start) + (ref_end - pos) - w.ncol;      // columns + inserted + deleted bases
+        if (min_pct_identity <= 0 || 100 * (int64_t)n_match >= (int64_t)min_pct_identity * aln_len) {   // blasr --minPctIdentity (unzip.py:87)
+            out.aligned = 1;
+            out.strand = a.strand;
+            out.pos = pos;
+            out.ref_end = ref_end;
+            out.q_start = q_start;
+            out.q_end = q_end;
+            out.score = di.best_score;
+            out.n_columns = w.ncol;
+            out.n_match = n_match;
+            int32_t nc = fb - fa;
+            if (out.q_start > 0) { reg[--fa] = ((uint32_t)out.q_start << 4) | FZP_OP_S; nc++; }
+            if (n - out.q_end > 0) { reg[fb++] = ((uint32_t)(n - out.q_end) << 4) | FZP_OP_S; nc++; }
+            out.n_cigar = nc;
+            cig_start[r] = cig_off[r] + fa;
+        }
     }
     summ[r] = out;
+}
+
+__global__ void __launch_bounds__(256) k_sec_count(int64_t n, const Anchor *__restrict__ ancB, uint32_t *__restrict__ count) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t m = __ballot(r < n && ancB[r].aligned != 0);
+    if (lane_id() == 0 && m) atomicAdd(count, (uint32_t)__popcll(m));
+}
+// ---- candidate selection (blasr --bestn 1, unzip.py:86): a read's second candidate replaces the first when its extension
+// scored strictly higher; `steps` of the survivor counts the DP steps of both (fzp_aln_summary.cells)
+__global__ void __launch_bounds__(256) k_pick(int64_t w_lo, int64_t w_hi, const int32_t *__restrict__ ridx, const Anchor *__restrict__ anc2, const DpInfo *__restrict__ info2,
+                                              const int64_t *__restrict__ tb_off2, int64_t tb_base, int64_t mv_base, Anchor *__restrict__ anc, DpInfo *__restrict__ info,
+                                              int64_t *__restrict__ tbo, int64_t *__restrict__ mvo, uint8_t *__restrict__ won) {
+    const int64_t w = w_lo + (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (w >= w_hi) return;
+    const int32_t r = ridx[w];
+    DpInfo a = info[r];
+    const DpInfo b = info2[w];
+    const int32_t total = a.steps + b.steps;
+    const bool take = b.best_score > a.best_score;
+    if (take) {
+        a = b;
+        anc[r] = anc2[w];
+        const int64_t so = tb_off2[w] - tb_off2[w_lo];
+        tbo[r] = tb_base + so;
+        mvo[r] = mv_base + (so >> 6) + (w - w_lo);
+    }
+    a.steps = total;
+    info[r] = a;
+    won[w] = take ? 1 : 0;
+}
+__global__ void __launch_bounds__(256) k_pick_copy(int64_t w_lo, const int32_t *__restrict__ ridx, const uint8_t *__restrict__ won, const int32_t *__restrict__ read_len,
+                                                   const uint32_t *__restrict__ sec_ori, const int64_t *__restrict__ sec_woff, const int64_t *__restrict__ read_woff,
+                                                   uint32_t *__restrict__ read_ori) {
+    const int64_t w = w_lo + blockIdx.x;
+    if (!won[w]) return;
+    const int32_t r = ridx[w];
+    const int64_t nw = (((int64_t)read_len[r] + 15) / 16 + 8 + 1) & ~1LL;
+    const uint32_t *src = sec_ori + sec_woff[w];
+    uint32_t *dst = read_ori + read_woff[r];
+    for (int64_t x = threadIdx.x; x < nw; x += 256) dst[x] = src[x];
 }
 
 // ---- gather accepted records into contiguous CIGAR / ASCII SEQ arrays
@@ -1004,7 +1173,17 @@ struct fzp_alnjob {
     DevBuf<int64_t> ctg_woff, ctg_len, idx_off, read_woff, tb_off, cig_off, cig_start;
     DevBuf<int32_t> idx_bits, read_len, read_ctg;
     DevBuf<uint64_t> table;
-    DevBuf<Anchor> anc;
+    DevBuf<Anchor> anc, ancB, anc2;              // first candidates (per read), second candidates (per read; compacted)
+    DevBuf<int64_t> tbo, mvo;                    // per read: where the winning candidate's trace-back masks / move words are
+    DevBuf<uint2> hits;                          // seeding: HIT_CAP hit slots per read of a seeding launch
+    DevBuf<SeedWin> win;
+    DevBuf<uint32_t> n_sec;                      // reads with a second candidate
+    DevBuf<int32_t> ridx;                        // compacted second candidates -> read
+    DevBuf<int64_t> sec_woff, tb_off2;
+    DevBuf<uint32_t> sec_ori;
+    DevBuf<DpInfo> info2;
+    DevBuf<uint8_t> won;
+    int64_t n_second = 0;                        // of the last run
     DevBuf<DpInfo> info;
     DevBuf<uint2> tb2[2];
     DevBuf<uint32_t> raw2[2];                    // the walk's 2-bit op streams
@@ -1024,6 +1203,7 @@ struct fzp_alnjob {
 extern "C" void fzp_align_params_default(fzp_align_params *p) {
     memset(p, 0, sizeof *p);
     p->kmer = 16; p->seed_stride = 4; p->match = 2; p->mismatch = 4; p->gap = 3; p->min_seed_hits = 8;
+    p->min_pct_identity = 70;
 }
 
 extern "C" void fzp_align_destroy(fzp_ctx *ctx, fzp_alnjob *job) {
@@ -1043,7 +1223,8 @@ extern "C" int fzp_align_create(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *cons
     FZP_HIP(hipSetDevice(ctx->device));
     fzp_alnjob *j = new fzp_alnjob();
     if (params) j->P = *params; else fzp_align_params_default(&j->P);
-    if (j->P.kmer < 8 || j->P.kmer > 16 || j->P.seed_stride < 1 || j->P.match <= 0 || j->P.mismatch < 0 || j->P.gap <= 0) {
+    if (j->P.kmer < 8 || j->P.kmer > 16 || j->P.seed_stride < 1 || j->P.match <= 0 || j->P.mismatch < 0 || j->P.gap <= 0 || j->P.min_pct_identity < 0 ||
+        j->P.min_pct_identity > 100) {
         delete j; fzp_set_error("fzp_align_create: bad parameters"); return FZP_EINVAL;
     }
     j->n_ctg = n_ctg; j->n_reads = n_reads;
@@ -1114,7 +1295,8 @@ extern "C" int fzp_align_create(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *cons
             hipLaunchKernelGGL(k_pack, dim3((unsigned)n_reads, 1), dim3(256), 0, st, d_ascii.p, d_off.p, j->read_woff.p, j->read_pk.p);
             if (hipStreamSynchronize(st) != hipSuccess) { rc = FZP_EDEVICE; break; }
         }
-        if ((rc = j->table.alloc((size_t)j->idx_slots)) || (rc = j->anc.alloc((size_t)n_reads)) || (rc = j->info.alloc((size_t)n_reads)) ||
+        if ((rc = j->table.alloc((size_t)j->idx_slots)) || (rc = j->anc.alloc((size_t)n_reads)) || (rc = j->ancB.alloc((size_t)n_reads)) || (rc = j->tbo.alloc((size_t)n_reads)) ||
+            (rc = j->mvo.alloc((size_t)n_reads)) || (rc = j->n_sec.alloc(1)) || (rc = j->info.alloc((size_t)n_reads)) ||
             (rc = j->summ.alloc((size_t)n_reads)) || (rc = j->cig.alloc((size_t)j->h_cig_off.back())) || (rc = j->cig_start.alloc((size_t)n_reads)))
             break;
     } while (0);
@@ -1142,15 +1324,52 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
             for (auto v : j->h_ctg_len) lc_max = std::max(lc_max, v);
             for (auto v : j->h_read_len) n_max = std::max<int64_t>(n_max, v);
             const int64_t nb_max = std::min<int64_t>(MAX_BINS, ((lc_max + n_max) >> 10) + 2);
-            const int hit_cap = 1024;   // sampled k-mers found per read before the anchor search falls back to lookups (8 KB)
-            const size_t lds = (size_t)2 * (size_t)nb_max * sizeof(uint32_t) + (size_t)hit_cap * sizeof(uint2);
+            const size_t lds = (size_t)2 * (size_t)nb_max * sizeof(uint32_t);
             FZP_HIP(hipFuncSetAttribute((const void *)k_seed, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(k_seed, dim3((unsigned)nr), dim3(256), lds, st, (int64_t)0, j->read_pk.p, j->read_woff.p, j->read_len.p,
-                               j->read_ctg.p, j->ctg_len.p, j->idx_off.p, j->idx_bits.p, j->table.p, P.kmer, P.seed_stride, P.min_seed_hits, j->anc.p, (int)nb_max, hit_cap);
+            FZP_HIP(hipMemsetAsync(j->n_sec.p, 0, 4, st));
+            const int64_t seed_chunk = 65536;            // reads per seeding launch: HIT_CAP x 8 B of hit list each (2 GiB)
+            FZP_TRY(j->hits.alloc((size_t)std::min<int64_t>(nr, seed_chunk) * HIT_CAP));
+            FZP_TRY(j->win.alloc((size_t)std::min<int64_t>(nr, seed_chunk)));
+            for (int64_t f0 = 0; f0 < nr; f0 += seed_chunk) {
+                const int64_t cn = std::min<int64_t>(seed_chunk, nr - f0);
+                hipLaunchKernelGGL(k_seed, dim3((unsigned)cn), dim3(256), lds, st, f0, j->read_pk.p, j->read_woff.p, j->read_len.p,
+                                   j->read_ctg.p, j->ctg_len.p, j->idx_off.p, j->idx_bits.p, j->table.p, P.kmer, P.seed_stride, P.min_seed_hits, j->hits.p, j->win.p);
+                hipLaunchKernelGGL(k_chain, dim3((unsigned)(2 * cn)), dim3(64), 0, st, f0, cn, j->read_len.p, j->hits.p, j->win.p, j->anc.p, j->ancB.p);
+            }
+            hipLaunchKernelGGL(k_sec_count, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, st, nr, j->ancB.p, j->n_sec.p);
         }
         {
             ProfScope ps(ctx, "k1_orient");
-            hipLaunchKernelGGL(k_orient, dim3((unsigned)nr, 1), dim3(256), 0, st, (int64_t)0, j->read_pk.p, j->read_woff.p, j->read_len.p, j->anc.p, j->read_ori.p);
+            hipLaunchKernelGGL(k_orient, dim3((unsigned)nr, 1), dim3(256), 0, st, (int64_t)0, j->read_pk.p, j->read_woff.p, j->read_len.p, j->anc.p, (const int32_t *)nullptr,
+                               j->read_woff.p, j->read_ori.p);
+        }
+        // second candidates (reads whose votes show a second placement: repeats).  Usually none; then nothing below runs.
+        uint32_t n2 = 0;
+        FZP_HIP(hipMemcpyAsync(&n2, j->n_sec.p, 4, hipMemcpyDeviceToHost, st));
+        FZP_HIP(hipStreamSynchronize(st));
+        j->n_second = n2;
+        std::vector<int32_t> h_ridx;
+        std::vector<int64_t> h_tb_off2(1, 0);
+        if (n2) {
+            std::vector<Anchor> hb((size_t)nr), h2;
+            FZP_TRY(j->ancB.download(hb.data(), (size_t)nr, st));
+            FZP_HIP(hipStreamSynchronize(st));
+            std::vector<int64_t> h_woff2(1, 0);
+            for (int64_t r = 0; r < nr; r++) {
+                if (!hb[(size_t)r].aligned) continue;
+                const int64_t n = j->h_read_len[(size_t)r];
+                h_ridx.push_back((int32_t)r);
+                h2.push_back(hb[(size_t)r]);
+                h_woff2.push_back(h_woff2.back() + (((n + 15) / 16 + 8 + 1) & ~1LL));
+                h_tb_off2.push_back(h_tb_off2.back() + (n + n + n / 4 + 64 + 2 + 63) / 64 * 64);
+            }
+            n2 = (uint32_t)h_ridx.size();
+            FZP_TRY(j->ridx.upload(h_ridx.data(), n2, st)); FZP_TRY(j->anc2.upload(h2.data(), n2, st));
+            FZP_TRY(j->sec_woff.upload(h_woff2.data(), h_woff2.size(), st)); FZP_TRY(j->tb_off2.upload(h_tb_off2.data(), h_tb_off2.size(), st));
+            FZP_TRY(j->sec_ori.alloc((size_t)h_woff2.back() + 8)); FZP_TRY(j->info2.alloc(n2)); FZP_TRY(j->won.alloc(n2));
+            FZP_HIP(hipStreamSynchronize(st));      // the staging vectors die with this scope
+            ProfScope ps(ctx, "k1_orient");
+            hipLaunchKernelGGL(k_orient, dim3(n2, 1), dim3(256), 0, st, (int64_t)0, j->read_pk.p, j->read_woff.p, j->read_len.p, j->anc2.p, j->ridx.p, j->sec_woff.p, j->sec_ori.p);
         }
         // Trace-back masks live in HBM (16 B per DP step).  Reads go through in chunks: the DP of chunk k+1
         // (integer-VALU bound, every wave slot busy, no LDS) runs on `stream` while the trace-back of chunk k
@@ -1167,6 +1386,7 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
         int64_t first = 0;
         int k = 0;
         bool used[2] = {false, false};
+        size_t w_lo = 0;
         while (first < nr) {
             int64_t last = first;
             while (last < nr && j->h_tb_off[(size_t)last + 1] - j->h_tb_off[(size_t)first] <= chunk_steps) last++;
@@ -1175,25 +1395,43 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
             const int64_t steps = j->h_tb_off[(size_t)last] - j->h_tb_off[(size_t)first];
             const int bi = k & 1;
             if (used[bi]) FZP_HIP(hipStreamWaitEvent(st, j->ev_tb[bi], 0));   // buffer free again?
-            FZP_TRY(j->tb2[bi].alloc((size_t)steps * 2 + 128));
-            FZP_TRY(j->mvw2[bi].alloc((size_t)(steps / 64 + cnt + 2)));
+            // the chunk's second candidates sit behind the first ones in the same mask / move-word buffers
+            size_t w_hi = w_lo;
+            while (w_hi < h_ridx.size() && h_ridx[w_hi] < last) w_hi++;
+            const int64_t c2 = (int64_t)(w_hi - w_lo), steps2 = h_tb_off2[w_hi] - h_tb_off2[w_lo];
+            const int64_t tb_base = steps + 64, mv_base = steps / 64 + cnt + 2;
+            FZP_TRY(j->tb2[bi].alloc((size_t)(tb_base + steps2) * 2 + 128));
+            FZP_TRY(j->mvw2[bi].alloc((size_t)(mv_base + steps2 / 64 + c2 + 2)));
             FZP_TRY(j->raw2[bi].alloc((size_t)(steps / 16 + 64)));
             {
                 ProfScope ps(ctx, "k1_sw");
-                hipLaunchKernelGGL(k_sw, dim3((unsigned)cnt), dim3(64), 0, st, first, cnt, j->read_ori.p, j->read_woff.p, j->read_len.p, j->read_ctg.p,
-                                   j->ctg_pk.p, j->ctg_woff.p, j->ctg_len.p, j->anc.p, j->tb_off.p, j->tb2[bi].p, j->mvw2[bi].p, P.match, P.mismatch, P.gap, j->info.p);
+                hipLaunchKernelGGL(k_sw, dim3((unsigned)cnt), dim3(64), 0, st, first, cnt, (const int32_t *)nullptr, j->read_ori.p, j->read_woff.p, j->read_len.p, j->read_ctg.p,
+                                   j->ctg_pk.p, j->ctg_woff.p, j->ctg_len.p, j->anc.p, j->tb_off.p, j->tb2[bi].p, j->mvw2[bi].p, P.match, P.mismatch, P.gap, j->info.p, j->tbo.p, j->mvo.p);
             }
+            if (c2 > 0) {     // same kernel over the compacted list, then the better extension of each read survives
+                {
+                    ProfScope ps(ctx, "k1_sw2");
+                    hipLaunchKernelGGL(k_sw, dim3((unsigned)c2), dim3(64), 0, st, (int64_t)w_lo, c2, j->ridx.p, j->sec_ori.p, j->sec_woff.p, j->read_len.p, j->read_ctg.p,
+                                       j->ctg_pk.p, j->ctg_woff.p, j->ctg_len.p, j->anc2.p, j->tb_off2.p, j->tb2[bi].p + 2 * tb_base, j->mvw2[bi].p + mv_base, P.match, P.mismatch,
+                                       P.gap, j->info2.p, (int64_t *)nullptr, (int64_t *)nullptr);
+                }
+                ProfScope ps(ctx, "k1_pick");
+                hipLaunchKernelGGL(k_pick, dim3((unsigned)((c2 + 255) / 256)), dim3(256), 0, st, (int64_t)w_lo, (int64_t)w_hi, j->ridx.p, j->anc2.p, j->info2.p, j->tb_off2.p,
+                                   tb_base, mv_base, j->anc.p, j->info.p, j->tbo.p, j->mvo.p, j->won.p);
+                hipLaunchKernelGGL(k_pick_copy, dim3((unsigned)c2), dim3(256), 0, st, (int64_t)w_lo, j->ridx.p, j->won.p, j->read_len.p, j->sec_ori.p, j->sec_woff.p, j->read_woff.p, j->read_ori.p);
+            }
+            w_lo = w_hi;
             FZP_HIP(hipEventRecord(j->ev_sw[bi], st));
             FZP_HIP(hipStreamWaitEvent(st2, j->ev_sw[bi], 0));
             {
                 ProfScope ps(ctx, "k1_traceback", st2);
                 hipLaunchKernelGGL(k_tb_walk, dim3((unsigned)((cnt + TBW_RPW - 1) / TBW_RPW)), dim3(64), 0, st2, first, cnt, j->anc.p, j->info.p, j->tb_off.p,
-                                   j->tb2[bi].p, j->mvw2[bi].p, j->raw2[bi].p, j->wout.p);
+                                   j->tbo.p, j->mvo.p, (const ulonglong2 *)j->tb2[bi].p, (const ulonglong2 *)j->mvw2[bi].p, j->raw2[bi].p, j->wout.p);
             }
             {
                 ProfScope ps(ctx, "k1_cigar", st2);
                 hipLaunchKernelGGL(k_tb_cigar, dim3((unsigned)cnt), dim3(64), 0, st2, first, cnt, j->read_len.p, j->anc.p, j->info.p, j->tb_off.p, j->raw2[bi].p,
-                                   j->wout.p, j->cig_off.p, j->cig.p, j->cig_start.p, j->summ.p);
+                                   j->wout.p, j->cig_off.p, j->cig.p, j->cig_start.p, j->summ.p, P.match, P.mismatch, P.gap, P.min_pct_identity);
             }
             FZP_HIP(hipEventRecord(j->ev_tb[bi], st2));
             used[bi] = true;
@@ -1221,6 +1459,8 @@ int fetch_summaries(fzp_ctx *ctx, fzp_alnjob *j) {
     return FZP_OK;
 }
 }  // namespace
+
+extern "C" int64_t fzp_align_n_second(const fzp_alnjob *j) { return j ? j->n_second : 0; }
 
 extern "C" int fzp_align_summaries(fzp_ctx *ctx, fzp_alnjob *j, fzp_aln_summary *out) {
     if (!ctx || !j || !j->done || !out) { fzp_set_error("fzp_align_summaries: run the job first"); return FZP_EINVAL; }

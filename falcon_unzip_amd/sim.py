@@ -212,3 +212,69 @@ def simulate_raw_reads_bulk(hap0, hap1, n_reads, R, rng, lo=0, hi=None, sub=0.01
         a, b = off[i], off[i + 1]
         codes[a:b] = _COMP[codes[a:b][::-1]]
     return codes, off, starts, haps, strands.astype(np.int64)
+
+
+def _diverge(codes, rng, div, indel_frac=0.2):
+    """A diverged copy of `codes`: substitutions at rate div*(1-indel_frac), 1-base indels at rate div*indel_frac."""
+    n = codes.size
+    out = codes.copy()
+    u = rng.random(n)
+    sub = u < div * (1.0 - indel_frac)
+    k = int(sub.sum())
+    if k:
+        out[sub] = (out[sub] + rng.integers(1, 4, size=k, dtype=np.uint8)) & 3
+    v = rng.random(n)
+    dele = v < div * indel_frac * 0.5
+    ins = (v >= div * indel_frac * 0.5) & (v < div * indel_frac)
+    keep = ~dele
+    pieces = np.repeat(keep.astype(np.int64) + ins.astype(np.int64), 1)
+    res = np.empty(int(pieces.sum()), np.uint8)
+    off = np.cumsum(pieces) - pieces
+    res[off[keep]] = out[keep]
+    ni = int(ins.sum())
+    if ni:
+        res[(off + keep.astype(np.int64))[ins]] = rng.integers(0, 4, size=ni, dtype=np.uint8)
+    return res
+
+
+def make_repeat_diploid(L, rng, het_rate=1.0 / 500, n_families=6, copies=(2, 4), fam_len=(2000, 6000),
+                        n_tandem=6, unit_len=(80, 500), tandem_copies=(4, 10), divergence=(0.01, 0.05)):
+    """Diploid with repeats: interspersed families of 2-6 kb copies at 95-99 % identity and
+    tandem arrays (unit 80-500 bp, 4-10 copies, same divergence), written over an iid background; hap1 = hap0 + SNPs.
+    Returns (hap0, hap1, het positions, list of (start, end, kind) repeat intervals)."""
+    hap0 = rng.integers(0, 4, size=L, dtype=np.uint8)
+    spans = []
+
+    def place(seg):
+        for _ in range(200):
+            s = int(rng.integers(0, L - seg.size))
+            if all(s + seg.size <= a or s >= b for a, b, _k in spans):
+                return s
+        return None
+
+    for _ in range(n_families):
+        flen = int(rng.integers(fam_len[0], fam_len[1] + 1))
+        master = rng.integers(0, 4, size=flen, dtype=np.uint8)
+        for _c in range(int(rng.integers(copies[0], copies[1] + 1))):
+            seg = _diverge(master, rng, float(rng.uniform(*divergence)))
+            if rng.random() < 0.3:
+                seg = revcomp_codes(seg)
+            s = place(seg)
+            if s is None:
+                continue
+            hap0[s:s + seg.size] = seg
+            spans.append((s, s + seg.size, "interspersed"))
+    for _ in range(n_tandem):
+        ulen = int(rng.integers(unit_len[0], unit_len[1] + 1))
+        unit = rng.integers(0, 4, size=ulen, dtype=np.uint8)
+        arr = np.concatenate([_diverge(unit, rng, float(rng.uniform(*divergence))) for _c in range(int(rng.integers(tandem_copies[0], tandem_copies[1] + 1)))])
+        s = place(arr)
+        if s is None:
+            continue
+        hap0[s:s + arr.size] = arr
+        spans.append((s, s + arr.size, "tandem"))
+    n_het = int(round(L * het_rate))
+    pos = np.sort(rng.choice(L, size=n_het, replace=False))
+    hap1 = hap0.copy()
+    hap1[pos] = (hap0[pos] + rng.integers(1, 4, size=n_het, dtype=np.uint8)) & 3
+    return hap0, hap1, pos, sorted(spans)

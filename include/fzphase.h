@@ -201,8 +201,9 @@ int fzp_readmap(const char *phased_reads, size_t pr_len, const char *rawread_ids
 
 /* ---------------------------------------------------------------------------------------------
  * K1: read -> contig banded alignment (role of blasr + samtools sort, unzip.py:86-91).
- * Own deterministic spec: k-mer seeding, adaptive anti-diagonal band of 64
- * cells, linear-gap scores, traceback to =/X/I/D/S CIGARs.  Parity vs blasr is UNPINNED; the
+ * Own deterministic spec "fzalign v1.2" (DESIGN.md section 6): k-mer seeding over every indexed position, up to two
+ * candidate placements per read (chained anchors), adaptive anti-diagonal band of 64 cells, linear-gap scores,
+ * the better extension kept (--bestn 1), identity gate (--minPctIdentity 70), traceback to =/X/I/D/S CIGARs.  Parity vs blasr is UNPINNED; the
  * kernel is bit-exact against its scalar CPU twin in oracle/align_oracle.c.
  * --------------------------------------------------------------------------------------------- */
 typedef struct {
@@ -210,7 +211,8 @@ typedef struct {
     int32_t seed_stride;     /* query every seed_stride-th read k-mer, default 4 */
     int32_t match, mismatch, gap;   /* scores: +match, -mismatch, -gap (defaults 2,4,3) */
     int32_t min_seed_hits;   /* reads with fewer votes in the best window are unaligned, default 8 */
-    int32_t reserved[10];
+    int32_t min_pct_identity; /* alignments below this identity are dropped (blasr --minPctIdentity 70.0, unzip.py:87); default 70, 0 = off */
+    int32_t reserved[9];
 } fzp_align_params;
 void fzp_align_params_default(fzp_align_params *p);
 
@@ -224,7 +226,7 @@ typedef struct {             /* per read, input order */
     int32_t n_cigar;         /* CIGAR words incl. soft clips */
     int64_t cells;           /* DP cells evaluated for this read (steps * 64) */
     int32_t n_columns;       /* aligned columns (= and X bases) */
-    int32_t pad_;
+    int32_t n_match;         /* '=' columns; 100 * n_match / (columns + inserted + deleted bases) is the identity the gate tests */
 } fzp_aln_summary;
 
 /* reads/contigs are ASCII (ACGT, any case; any other symbol is treated as 'A' throughout, and the
@@ -236,6 +238,8 @@ int fzp_align_create(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *const *ctg_seq,
                      const fzp_align_params *params, fzp_alnjob **out);
 int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *job);
 int fzp_align_summaries(fzp_ctx *ctx, fzp_alnjob *job, fzp_aln_summary *out /* [n_reads] */);
+/* reads of the last run that had a second candidate placement extended (repeats; blasr --bestn 1 keeps the better one) */
+int64_t fzp_align_n_second(const fzp_alnjob *job);
 /* alignment records of contig `ctg` in (POS, read index) order, q_id = rank in that order; names
  * (optional, may be NULL -> "read/<index>") fill the q_id table */
 int fzp_align_alnset(fzp_ctx *ctx, fzp_alnjob *job, int32_t ctg, const int64_t *name_off, const char *names,

@@ -4,22 +4,40 @@
  * PARITY UNPINNED vs the reference: FALCON_unzip shells out to `blasr` (falcon_unzip/unzip.py:86-88),
  * a third-party C++ aligner that is not vendored under /root/reference and whose results
  * (placement, clipping, `--hitPolicy randombest --randomSeed 42` tie-breaks) cannot be reproduced
- * here.  This file therefore DEFINES the aligner ("fzalign v1.1"); the HIP kernels in
+ * here.  This file therefore DEFINES the aligner ("fzalign v1.2"); the HIP kernels in
  * falcon_unzip_amd/csrc/fzp_align.hip must match it bit-for-bit (summaries, CIGARs, DP cell counts),
  * and its quality is judged against the simulator's true alignments.
  *
- * fzalign v1.1  (v1 dropped the diagonal predecessor of lane 63 after a RIGHT move followed by a DOWN move)
+ * fzalign v1.2  (v1.1: one index position per k-mer, one candidate placement per read, no identity gate)
  *   bases     A/a C/c G/g T/t -> 0..3, anything else -> 0
- *   seeding   canonical k-mers (k<=16, 2 bits/base, base m of a k-mer at bits 2m; canonical = the smaller of
- *             the k-mer and its reverse complement) of every 2nd contig position -> smallest start position
- *             (+ whether the canonical form was the reverse complement); every `stride`-th FORWARD read
- *             k-mer is looked up once: equal orientation bits -> the read matches as sequenced (strand 0,
- *             oriented offset i = pf), different -> its reverse complement does (i = n-k-pf); it votes for
- *             bin = (cpos - i + n) >> shift, shift = smallest s>=10 with ((Lc+n)>>s)+2 <= 8192;
- *             best (strand, bin) maximises votes[bin]+votes[bin+1] (ties: forward strand, lower bin);
- *             fewer than min_seed_hits votes -> unaligned.  The hit with the smallest read offset inside
- *             the two winning bins fixes the diagonal d = cpos - i; the extension starts at the read's
- *             first base on that diagonal: origin (max(0,-d), max(0,d)).
+ *   index     canonical k-mers (k<=16, 2 bits/base, base m of a k-mer at bits 2m; canonical = the smaller of
+ *             the k-mer and its reverse complement) of every 2nd contig position -> EVERY such position
+ *             (+ whether the canonical form was the reverse complement).  A k-mer with more than MAX_OCC = 8
+ *             index entries is repetitive and never produces a hit.
+ *   hits      every `stride`-th FORWARD read k-mer (a "sample") is looked up once, samples in read order; each index
+ *             entry of it, by increasing contig position, is a hit: equal orientation bits -> the read matches as
+ *             sequenced (strand 0, oriented offset i = pf), different -> its reverse complement does
+ *             (i = n-k-pf); diagonal value dv = cpos - i + n.  Only the first HIT_CAP = 4096 hits of a read
+ *             in that order exist.  A hit votes for bin = dv >> shift, shift = smallest s>=10 with
+ *             ((Lc+n)>>s)+2 <= 8192.
+ *   windows   a window (strand, b) scores votes[b]+votes[b+1].  W1 = the best window (ties: forward strand,
+ *             lower bin); fewer than min_seed_hits votes -> unaligned.  W2 = the best window on the other
+ *             strand or at least 3 bins away from W1 (same ties); it counts only if it has >= min_seed_hits
+ *             votes and 4*votes(W2) >= votes(W1)  (the second placement of blasr's --bestn selection,
+ *             unzip.py:86-88).
+ *   chains    per window: its hits = those of its strand in bins b-1 .. b+2, by increasing oriented offset
+ *             (hit order on the forward strand, reversed hit order on the other).  Chain length f(h) = 1 +
+ *             max f(p) over the at most 64 preceding window hits p with 1 <= i_h - i_p <= 2048, cpos_p < cpos_h
+ *             and |dv_h - dv_p| <= 16 + (i_h - i_p)/16 (ties: the closest p), else 1; start(h) = start(p) or
+ *             h itself.  The longest chain (ties: the earliest end) gives the anchor = its first hit, which
+ *             fixes the diagonal d = cpos - i; the extension starts at the read's first base on that
+ *             diagonal: origin (max(0,-d), max(0,d)).  Candidates in order W1, W2.
+ *   selection every candidate is extended (below); the one with the highest extension score wins (ties: the
+ *             earlier candidate) -- blasr's --bestn 1.  `cells` counts the DP cells of all candidates.
+ *   identity  n_match = (score + mismatch*columns + gap*(path insertions + path deletions)) / (match + mismatch)
+ *             over the whole path from the origin (exact); the alignment is dropped (unaligned) when
+ *             100*n_match < 70*(columns + inserted + deleted bases of the trimmed alignment)
+ *             (blasr --minPctIdentity 70.0, unzip.py:87).
  *   extension adaptive anti-diagonal band of 64 cells (Suzuki-Kasahara style), forward from that
  *             origin: linear gaps, H = max(diag + (match | -mismatch), up - gap, left - gap), no zero
  *             floor; the first 64 steps alternate down/right, afterwards the band moves RIGHT when
@@ -42,14 +60,20 @@
 
 typedef struct {
     int32_t kmer, seed_stride, match, mismatch, gap, min_seed_hits;
-    int32_t reserved[10];
+    int32_t min_pct_identity;            /* 70 = blasr --minPctIdentity 70.0 (unzip.py:87); 0 disables the gate */
+    int32_t reserved[9];
 } orc_align_params;
 
 typedef struct {
     int32_t aligned, strand, pos, ref_end, q_start, q_end, score, n_cigar;
     int64_t cells;
-    int32_t n_columns, pad_;
+    int32_t n_columns, n_match;
 } orc_aln_summary;
+
+#define MAX_OCC 8
+#define HIT_CAP 4096
+#define CHAIN_LOOKBACK 64
+#define CHAIN_MAX_GAP 2048
 
 static inline int code_of(uint8_t c) {
     switch (c) {
@@ -84,11 +108,14 @@ static uint32_t rc_of(uint32_t key, int k) {
     return r;
 }
 
-/* -> (position << 1 | orientation bit) of the smallest position holding the canonical key, or -1 */
-static int32_t index_lookup(const ctg_index *ix, uint32_t key) {
+/* index entries of the canonical key: [*lo, *lo + return value) */
+static int64_t index_range(const ctg_index *ix, uint32_t key, int64_t *first) {
     int64_t lo = 0, hi = ix->n;
     while (lo < hi) { int64_t m = (lo + hi) >> 1; if (ix->kp[m].key < key) lo = m + 1; else hi = m; }
-    return (lo < ix->n && ix->kp[lo].key == key) ? ix->kp[lo].pos : -1;
+    int64_t e = lo;
+    while (e < ix->n && ix->kp[e].key == key) e++;
+    *first = lo;
+    return e - lo;
 }
 
 typedef struct { uint32_t *v; int64_t n, cap; } u32vec;
@@ -97,59 +124,99 @@ static void push(u32vec *v, uint32_t x) {
     v->v[v->n++] = x;
 }
 
-/* One read.  r = oriented read codes are derived on the fly from fwd codes. */
-static void align_one(const ctg_index *ix, const uint8_t *fwd, int64_t n, const orc_align_params *P,
-                      orc_aln_summary *out, u32vec *cig) {
-    memset(out, 0, sizeof *out);
+typedef struct { int32_t s; int64_t i, cp, dv; } hit_t;
+typedef struct { int strand; int64_t i_a, c_a; } anchor_t;
+
+/* ---- seeding: hits, coarse windows, one chain per window -> up to 2 anchors (spec in the header) */
+static int seed_candidates(const ctg_index *ix, const uint8_t *fwd, int64_t n, const orc_align_params *P, anchor_t *cand) {
     const int k = P->kmer, stride = P->seed_stride;
     const int64_t Lc = ix->len;
-    if (n < k || Lc < k) return;
-    uint8_t *ori[2];
-    ori[0] = (uint8_t *)malloc((size_t)n); ori[1] = (uint8_t *)malloc((size_t)n);
-    for (int64_t i = 0; i < n; i++) { ori[0][i] = fwd[i]; ori[1][i] = (uint8_t)(3 - fwd[n - 1 - i]); }
     int shift = 10;
     while ((((Lc + n) >> shift) + 2) > 8192) shift++;
     const int64_t NB = ((Lc + n) >> shift) + 2;
     uint32_t *votes = (uint32_t *)calloc((size_t)(2 * NB), 4);
-    for (int64_t pf = 0; pf + k <= n; pf += stride) {
-        uint32_t kf = kmer_at(ori[0], pf, k), kr = rc_of(kf, k);
+    hit_t *hits = (hit_t *)malloc((size_t)HIT_CAP * sizeof(hit_t));
+    int64_t nh = 0;
+    for (int64_t pf = 0; pf + k <= n && nh < HIT_CAP; pf += stride) {
+        uint32_t kf = kmer_at(fwd, pf, k), kr = rc_of(kf, k);
         uint32_t orr = kr < kf ? 1u : 0u;
-        int32_t hit = index_lookup(ix, kr < kf ? kr : kf);
-        if (hit < 0) continue;
-        int s = (int)(((uint32_t)hit & 1u) ^ orr);
-        int64_t cp = (uint32_t)hit >> 1, i = s ? n - k - pf : pf;
-        votes[s * NB + ((cp - i + n) >> shift)]++;
+        int64_t first, cnt = index_range(ix, kr < kf ? kr : kf, &first);
+        if (cnt == 0 || cnt > MAX_OCC) continue;
+        for (int64_t e = first; e < first + cnt && nh < HIT_CAP; e++) {      /* entries of a key are sorted by position */
+            uint32_t hit = (uint32_t)ix->kp[e].pos;
+            int s = (int)((hit & 1u) ^ orr);
+            int64_t cp = hit >> 1, i = s ? n - k - pf : pf;
+            hits[nh].s = s; hits[nh].i = i; hits[nh].cp = cp; hits[nh].dv = cp - i + n; nh++;
+            votes[s * NB + ((cp - i + n) >> shift)]++;
+        }
     }
-    uint32_t best = 0; int bs_ = 0; int64_t bb = 0;
+    int n_cand = 0;
+    uint32_t w1 = 0; int s1 = 0; int64_t b1 = 0;
     for (int s = 0; s < 2; s++)
         for (int64_t b = 0; b + 1 < NB; b++) {
             uint32_t sc = votes[s * NB + b] + votes[s * NB + b + 1];
-            if (sc > best) { best = sc; bs_ = s; bb = b; }
+            if (sc > w1) { w1 = sc; s1 = s; b1 = b; }
+        }
+    if ((int32_t)w1 < P->min_seed_hits || w1 == 0) { free(votes); free(hits); return 0; }
+    uint32_t w2 = 0; int s2 = 0; int64_t b2 = 0;
+    for (int s = 0; s < 2; s++)
+        for (int64_t b = 0; b + 1 < NB; b++) {
+            if (s == s1 && b - b1 < 3 && b1 - b < 3) continue;
+            uint32_t sc = votes[s * NB + b] + votes[s * NB + b + 1];
+            if (sc > w2) { w2 = sc; s2 = s; b2 = b; }
         }
     free(votes);
-    if ((int32_t)best < P->min_seed_hits || best == 0) { free(ori[0]); free(ori[1]); return; }
-    const uint8_t *r = ori[bs_];
-    int64_t i_a = -1, c_a = -1;
-    for (int64_t pf = 0; pf + k <= n; pf += stride) {      /* smallest oriented offset, then smallest position */
-        uint32_t kf = kmer_at(ori[0], pf, k), kr = rc_of(kf, k);
-        uint32_t orr = kr < kf ? 1u : 0u;
-        int32_t hit = index_lookup(ix, kr < kf ? kr : kf);
-        if (hit < 0) continue;
-        int s = (int)(((uint32_t)hit & 1u) ^ orr);
-        if (s != bs_) continue;
-        int64_t cp = (uint32_t)hit >> 1, i = s ? n - k - pf : pf;
-        int64_t b = (cp - i + n) >> shift;
-        if ((b == bb || b == bb + 1) && (i_a < 0 || i < i_a || (i == i_a && cp < c_a))) { i_a = i; c_a = cp; }
-    }
-    if (i_a < 0) { free(ori[0]); free(ori[1]); return; }
-    {   /* the seed fixes the diagonal; the extension starts at the read's first base on that diagonal
+    const int n_win = ((int32_t)w2 >= P->min_seed_hits && w2 > 0 && 4ull * w2 >= w1) ? 2 : 1;
+    int32_t *wh = (int32_t *)malloc((size_t)(nh ? nh : 1) * 4), *f = (int32_t *)malloc((size_t)(nh ? nh : 1) * 4), *st = (int32_t *)malloc((size_t)(nh ? nh : 1) * 4);
+    for (int w = 0; w < n_win; w++) {
+        const int ws = w ? s2 : s1;
+        const int64_t wb = w ? b2 : b1;
+        /* the window's hits (bins wb-1 .. wb+2) by increasing oriented offset: list order on the forward strand, reversed list order on the other */
+        int64_t m = 0;
+        for (int64_t x = 0; x < nh; x++) {
+            const int64_t h = ws ? nh - 1 - x : x;
+            if (hits[h].s != ws) continue;
+            const int64_t b = hits[h].dv >> shift;
+            if (b >= wb - 1 && b <= wb + 2) wh[m++] = (int32_t)h;
+        }
+        int32_t best_f = 0; int64_t best_e = -1;
+        for (int64_t e = 0; e < m; e++) {
+            const hit_t *H = &hits[wh[e]];
+            int32_t bf = 1, bst = (int32_t)e;
+            for (int64_t back = 1; back <= CHAIN_LOOKBACK && e - back >= 0; back++) {        /* closest predecessor first */
+                const hit_t *Q = &hits[wh[e - back]];
+                const int64_t di = H->i - Q->i;
+                if (di < 1 || di > CHAIN_MAX_GAP || H->cp <= Q->cp) continue;
+                int64_t dd = H->dv - Q->dv; if (dd < 0) dd = -dd;
+                if (dd > 16 + di / 16) continue;
+                if (f[e - back] + 1 > bf) { bf = f[e - back] + 1; bst = st[e - back]; }
+            }
+            f[e] = bf; st[e] = bst;
+            if (bf > best_f) { best_f = bf; best_e = e; }
+        }
+        if (best_e < 0) continue;                      /* cannot happen: the window has votes */
+        const hit_t *A = &hits[wh[st[best_e]]];
+        if (getenv("ORC_ALIGN_DEBUG")) fprintf(stderr, "window %d: strand %d bin %lld votes %u/%u hits %lld chain %d anchor (%lld, %lld)\n", w, ws, (long long)wb, w ? w2 : w1, w1, (long long)m, best_f, (long long)A->i, (long long)A->cp);
+        /* the chain's first hit fixes the diagonal; the extension starts at the read's first base on that diagonal
          * (or at the contig's first base when the read overhangs it) */
-        int64_t d = c_a - i_a;
-        i_a = d < 0 ? -d : 0;
-        c_a = d < 0 ? 0 : d;
+        const int64_t d = A->cp - A->i;
+        cand[n_cand].strand = ws;
+        cand[n_cand].i_a = d < 0 ? -d : 0;
+        cand[n_cand].c_a = d < 0 ? 0 : d;
+        n_cand++;
     }
+    free(wh); free(f); free(st);
+    free(hits);
+    return n_cand;
+}
 
-    /* ---- adaptive banded extension from the anchor */
+/* ---- adaptive banded extension of one candidate.  r = the oriented read codes. */
+static void extend_one(const ctg_index *ix, const uint8_t *r, int64_t n, const anchor_t *an, const orc_align_params *P,
+                       orc_aln_summary *out, u32vec *cig) {
+    memset(out, 0, sizeof *out);
+    const int64_t Lc = ix->len;
+    const int64_t i_a = an->i_a, c_a = an->c_a;
+    const int bs_ = an->strand;
     const uint8_t *q = r + i_a;
     const int64_t nq = n - i_a;
     int64_t nt = Lc - c_a;
@@ -218,6 +285,7 @@ static void align_one(const ctg_index *ix, const uint8_t *fwd, int64_t n, const 
         if (bt[kk] < 0) continue;
         if (bk < 0 || bsc[kk] > bsc[bk] || (bsc[kk] == bsc[bk] && bt[kk] < bt[bk])) bk = kk;
     }
+    out->score = bk >= 0 ? bsc[bk] : NEG;      /* what the candidate selection compares; 0 or less = no alignment */
     if (bk < 0 || bsc[bk] <= 0) goto done;
     {
         /* i0 at every step: replay the moves */
@@ -229,11 +297,11 @@ static void align_one(const ctg_index *ix, const uint8_t *fwd, int64_t n, const 
         const int64_t i_end = i, j_end = j;
         /* reversed raw op stream, run-length encoded on the fly: op codes 7 '=', 8 'X', 1 'I', 2 'D' */
         u32vec rev = {0};
-        int cur_op = -1; uint32_t cur_len = 0; int32_t ncol = 0;
+        int cur_op = -1; uint32_t cur_len = 0; int32_t ncol = 0, n_eq = 0;
         while (i >= 0 && j >= 0) {
             int kk = (int)(i - i0s[ts]);
             int op;
-            if ((tbD[ts] >> kk) & 1) { op = q[i] == t[j] ? 7 : 8; i--; j--; ts -= 2; ncol++; }
+            if ((tbD[ts] >> kk) & 1) { op = q[i] == t[j] ? 7 : 8; n_eq += op == 7; i--; j--; ts -= 2; ncol++; }
             else if ((((tbU[ts] >> kk) & 1) != 0) == (mv[ts] != 0)) { op = 1; i--; ts -= 1; }   /* the cell above */
             else { op = 2; j--; ts -= 1; }
             if (op == cur_op) cur_len++;
@@ -241,6 +309,13 @@ static void align_one(const ctg_index *ix, const uint8_t *fwd, int64_t n, const 
         }
         if (cur_len) push(&rev, (cur_len << 4) | (uint32_t)cur_op);
         free(i0s);
+        {   /* the device derives the match count from the score (it never sees the bases during trace-back): both must agree */
+            const int64_t num = (int64_t)bsc[bk] + (int64_t)P->mismatch * ncol + (int64_t)P->gap * (i_end + j_end + 2 - 2 * (int64_t)ncol);
+            if (num % (P->match + P->mismatch) != 0 || num / (P->match + P->mismatch) != n_eq) {
+                fprintf(stderr, "align_oracle: match-count identity violated (%lld vs %d)\n", (long long)num, n_eq);
+                abort();
+            }
+        }
         int64_t q_lead = i + 1, r_lead = j + 1;        /* bases before the first path op */
         /* forward order; strip leading / trailing non-match ops */
         int64_t a = rev.n - 1, b = 0;                   /* forward index f = rev[a - f] */
@@ -261,35 +336,72 @@ static void align_one(const ctg_index *ix, const uint8_t *fwd, int64_t n, const 
             if (mo != prev_m) { n_mraw++; prev_m = mo; }
         }
         if (a >= b && ncol > 0 && (n_mraw <= n + 16)) {
-            out->aligned = 1;
-            out->strand = bs_;
-            out->pos = (int32_t)(c_a + r_lead);
-            out->ref_end = (int32_t)(c_a + j_end + 1 - r_trail);
-            out->q_start = (int32_t)(i_a + q_lead);
-            out->q_end = (int32_t)(i_a + i_end + 1 - q_trail);
-            out->score = bsc[bk];
-            out->n_columns = ncol;
-            int32_t nc = 0; prev_m = -1;
-            if (out->q_start > 0) { push(cig, ((uint32_t)out->q_start << 4) | 4u); nc++; }
-            for (int64_t f = a; f >= b; f--) {
-                push(cig, rev.v[f]);
-                int o = (int)(rev.v[f] & 15); int mo = (o == 7 || o == 8) ? 0 : o;
-                if (mo != prev_m) { nc++; prev_m = mo; }
+            const int64_t pos = c_a + r_lead, ref_end = c_a + j_end + 1 - r_trail;
+            const int64_t q_start = i_a + q_lead, q_end = i_a + i_end + 1 - q_trail;
+            const int64_t aln_len = (q_end - q_start) + (ref_end - pos) - ncol;     /* columns + inserted + deleted bases */
+            if (P->min_pct_identity <= 0 || 100 * (int64_t)n_eq >= (int64_t)P->min_pct_identity * aln_len) {
+                out->aligned = 1;
+                out->strand = bs_;
+                out->pos = (int32_t)pos;
+                out->ref_end = (int32_t)ref_end;
+                out->q_start = (int32_t)q_start;
+                out->q_end = (int32_t)q_end;
+                out->n_columns = ncol;
+                out->n_match = n_eq;
+                int32_t nc = 0; prev_m = -1;
+                if (out->q_start > 0) { push(cig, ((uint32_t)out->q_start << 4) | 4u); nc++; }
+                for (int64_t f = a; f >= b; f--) {
+                    push(cig, rev.v[f]);
+                    int o = (int)(rev.v[f] & 15); int mo = (o == 7 || o == 8) ? 0 : o;
+                    if (mo != prev_m) { nc++; prev_m = mo; }
+                }
+                if (n - out->q_end > 0) { push(cig, ((uint32_t)(n - out->q_end) << 4) | 4u); nc++; }
+                out->n_cigar = nc;   /* words of the device CIGAR (M runs); the =/X CIGAR pushed above has more */
             }
-            if (n - out->q_end > 0) { push(cig, ((uint32_t)(n - out->q_end) << 4) | 4u); nc++; }
-            out->n_cigar = nc;   /* words of the device CIGAR (M runs); the =/X CIGAR pushed above has more */
         }
         free(rev.v);
     }
 done:
-    free(tbD); free(tbU); free(mv); free(ori[0]); free(ori[1]);
+    free(tbD); free(tbU); free(mv);
 #undef QC
 #undef TC
+}
+
+/* One read: candidates, extension of each, best extension score wins. */
+static void align_one(const ctg_index *ix, const uint8_t *fwd, int64_t n, const orc_align_params *P,
+                      orc_aln_summary *out, u32vec *cig) {
+    memset(out, 0, sizeof *out);
+    const int k = P->kmer;
+    if (n < k || ix->len < k) return;
+    anchor_t cand[2];
+    const int nc = seed_candidates(ix, fwd, n, P, cand);
+    if (nc == 0) return;
+    uint8_t *ori[2];
+    ori[0] = (uint8_t *)malloc((size_t)n); ori[1] = (uint8_t *)malloc((size_t)n);
+    for (int64_t i = 0; i < n; i++) { ori[0][i] = fwd[i]; ori[1][i] = (uint8_t)(3 - fwd[n - 1 - i]); }
+    orc_aln_summary best; u32vec bcig = {0};
+    memset(&best, 0, sizeof best);
+    int64_t cells = 0; int have = 0;
+    for (int c = 0; c < nc; c++) {
+        orc_aln_summary cur; u32vec ccig = {0};
+        extend_one(ix, ori[cand[c].strand], n, &cand[c], P, &cur, &ccig);
+        if (getenv("ORC_ALIGN_DEBUG")) fprintf(stderr, "cand %d: strand %d origin (%lld, %lld) -> score %d aligned %d pos %d q %d..%d\n", c, cand[c].strand, (long long)cand[c].i_a, (long long)cand[c].c_a, cur.score, cur.aligned, cur.pos, cur.q_start, cur.q_end);
+        cells += cur.cells;
+        if (!have || cur.score > best.score) { free(bcig.v); best = cur; bcig = ccig; have = 1; }
+        else free(ccig.v);
+    }
+    *out = best;
+    out->cells = cells;
+    if (!out->aligned) { out->score = 0; out->strand = 0; }
+    else for (int64_t x = 0; x < bcig.n; x++) push(cig, bcig.v[x]);
+    free(bcig.v);
+    free(ori[0]); free(ori[1]);
 }
 
 void orc_align_params_default(orc_align_params *p) {
     memset(p, 0, sizeof *p);
     p->kmer = 16; p->seed_stride = 4; p->match = 2; p->mismatch = 4; p->gap = 3; p->min_seed_hits = 8;
+    p->min_pct_identity = 70;
 }
 
 /* All reads against ONE contig.  cigar_out: concatenated BAM-style words; cig_off[n_reads+1]. */

@@ -111,14 +111,14 @@ def _aln_dtype():
         import numpy as np
         ALN_SUMMARY = np.dtype([("aligned", "<i4"), ("strand", "<i4"), ("pos", "<i4"), ("ref_end", "<i4"), ("q_start", "<i4"),
                                 ("q_end", "<i4"), ("score", "<i4"), ("n_cigar", "<i4"), ("cells", "<i8"), ("n_columns", "<i4"),
-                                ("pad_", "<i4")], align=True)
+                                ("n_match", "<i4")], align=True)
         assert ALN_SUMMARY.itemsize == 48
     return ALN_SUMMARY
 
 
 class AlignParams(C.Structure):
     _fields_ = [("kmer", C.c_int32), ("seed_stride", C.c_int32), ("match", C.c_int32), ("mismatch", C.c_int32),
-                ("gap", C.c_int32), ("min_seed_hits", C.c_int32), ("reserved", C.c_int32 * 10)]
+                ("gap", C.c_int32), ("min_seed_hits", C.c_int32), ("min_pct_identity", C.c_int32), ("reserved", C.c_int32 * 9)]
 
 
 def align_reads(orc, ctg: bytes, reads, params=None):

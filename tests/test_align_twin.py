@@ -1,0 +1,83 @@
+"""The K1 twin alone (CPU): spec "fzalign v1.2" against the simulator's truth, on an iid genome and on one with tandem arrays
+and interspersed repeats, plus the identity gate.  (HIP == twin is tests/test_gpu_align.py.)  The twin aborts if the
+score-derived match count ever differs from a direct count of '=' columns."""
+import numpy as np
+
+from tests import oracle_lib
+
+
+def _run(oracle, hap0, reads, params=None):
+    from falcon_unzip_amd import sim
+    ctg = sim.codes_to_str(hap0).encode()
+    raw = [sim.codes_to_str(r.raw_seq_codes()).encode() for r in reads]
+    s, cig = oracle_lib.align_reads(oracle, ctg, raw, params)
+    start = np.array([r.start for r in reads]); end = np.array([r.start + r.ref_span() for r in reads]); strand = np.array([r.strand for r in reads])
+    return s, cig, start, end, strand, raw
+
+
+def test_iid_genome(oracle):
+    from falcon_unzip_amd import sim
+    rng = np.random.Generator(np.random.PCG64(31))
+    hap0, hap1, _ = sim.make_diploid(400000, rng)
+    reads = sim.simulate_reads(hap0, hap1, 60, 15000, rng, strand_mix=0.5)
+    s, cig, start, end, strand, raw = _run(oracle, hap0, reads)
+    assert s["aligned"].all() and np.all(s["strand"] == strand)
+    assert np.all(np.abs(s["pos"] - start) <= 64) and np.mean(np.abs(s["ref_end"] - end) <= 5) >= 0.98
+    for k in range(len(reads)):        # '=' columns of the CIGAR == n_match; CIGAR consumes the read
+        ops = [(int(w) >> 4, int(w) & 15) for w in cig[k]]
+        assert sum(l for l, o in ops if o == 7) == s["n_match"][k]
+        assert sum(l for l, o in ops if o in (1, 4, 7, 8)) == len(raw[k])
+
+
+def test_repeat_genome(oracle):
+    from falcon_unzip_amd import sim
+    rng = np.random.Generator(np.random.PCG64(32))
+    hap0, hap1, _, spans = sim.make_repeat_diploid(1000000, rng, n_families=20, n_tandem=20)
+    reads = sim.simulate_reads(hap0, hap1, 150, 15000, rng, strand_mix=0.5)
+    s, cig, start, end, strand, raw = _run(oracle, hap0, reads)
+    ok = s["aligned"] == 1
+    assert ok.mean() >= 0.99 and np.all(s["strand"][ok] == strand[ok])
+    ov = np.minimum(s["ref_end"], end) - np.maximum(s["pos"], start)
+    assert np.mean(ov[ok] >= 0.97 * (end - start)[ok]) >= 0.99
+    assert np.mean(((s["q_end"] - s["q_start"]) / np.array([len(x) for x in raw]))[ok] >= 0.99) >= 0.99
+    assert len(spans) > 30
+
+
+def test_identity_gate(oracle):
+    from falcon_unzip_amd import sim
+    rng = np.random.Generator(np.random.PCG64(92))
+    hap0 = rng.integers(0, 4, size=100000, dtype=np.uint8)
+    ctg = sim.codes_to_str(hap0).encode()
+    seq, _, _ = sim.simulate_read(hap0, hap0, 30000, 8000, rng, sub=0.22, ins=0.14, dele=0.10)
+    raw = [sim.codes_to_str(seq).encode()]
+    off, _ = oracle_lib.align_reads(oracle, ctg, raw, {"min_pct_identity": 0})
+    on, _ = oracle_lib.align_reads(oracle, ctg, raw)
+    if off["aligned"][0]:
+        ident = 100.0 * off["n_match"][0] / ((off["q_end"][0] - off["q_start"][0]) + (off["ref_end"][0] - off["pos"][0]) - off["n_columns"][0])
+        assert (ident >= 70) == bool(on["aligned"][0])
+    assert on["cells"][0] == off["cells"][0]
+
+
+def test_twin_scores_equal_unbanded_dp(oracle):
+    """The twin's extension score == the optimum of a plain full-matrix DP from the same origin (reads of ~2.5 kb)."""
+    from falcon_unzip_amd import sim
+    from tests.test_gpu_align import _full_matrix_best
+    rng = np.random.Generator(np.random.PCG64(93))
+    L = 60000
+    hap0, hap1, _ = sim.make_diploid(L, rng)
+    reads = sim.simulate_reads(hap0, hap1, 12, 2300, rng, strand_mix=0.5)
+    s, cig, *_ = _run(oracle, hap0, reads)
+    for r, rd in enumerate(reads):
+        assert s["aligned"][r]
+        ops = [(int(w) >> 4, int(w) & 15) for w in cig[r]]
+        cs = sum(2 * l if o == 7 else -4 * l if o == 8 else -3 * l if o in (1, 2) else 0 for l, o in ops)
+        lead = (cs - int(s["score"][r])) // 3
+        found = False
+        for li in range(lead + 1):
+            i_a, c_a = int(s["q_start"][r]) - li, int(s["pos"][r]) - (lead - li)
+            if i_a < 0 or c_a < 0 or min(i_a, c_a) != 0:
+                continue
+            q = rd.seq[i_a:]
+            nt = min(L - c_a, len(q) + len(q) // 4 + 64)
+            found = found or _full_matrix_best(q, hap0[c_a:c_a + nt]) == int(s["score"][r])
+        assert found, (r, s[r])

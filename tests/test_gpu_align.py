@@ -26,7 +26,7 @@ def _sim(seed, L, n, R, strand_mix=0.5, **kw):
     return ctg, reads, raw
 
 
-FIELDS = ("aligned", "strand", "pos", "ref_end", "q_start", "q_end", "score", "n_cigar", "cells", "n_columns")
+FIELDS = ("aligned", "strand", "pos", "ref_end", "q_start", "q_end", "score", "n_cigar", "cells", "n_columns", "n_match")
 
 
 @pytest.mark.parametrize("seed,L,n,R", [(21, 60000, 48, 5000), (22, 400000, 64, 15000), (23, 30000, 40, 2500)])
@@ -207,3 +207,181 @@ def test_long_reads_match_twin(eng, oracle):
     t = b.consensus()
     assert len(b.results()[0].sites) == 0 and len(t.tigs) == 0        # 4-fold coverage: nothing reaches total >= 10
     t.close(); b.close(); job.close()
+
+
+def _cmp_twin(job, oracle, ctg, raw, params=None, cigars=True):
+    exp, exp_cig = oracle_lib.align_reads(oracle, ctg, raw, params)
+    got = job.summaries()
+    for f in FIELDS:
+        assert np.array_equal(got[f], exp[f]), (f, np.flatnonzero(got[f] != exp[f])[:5], got[f][:4], exp[f][:4])
+    if cigars:
+        aln, idx = job.alnset(0)
+        for k, r in enumerate(idx):
+            words = np.array([(l << 4) | o for l, o in aln.cigar_of(k)], dtype=np.uint32)
+            assert np.array_equal(words, exp_cig[r]), (k, r)
+    return got, exp
+
+
+def test_headline_shape_5mb_contig_matches_twin(eng, oracle):
+    """The bench's shape: 15 kb CLR reads, both strands, against a 5 Mb contig -- a 2^23-slot
+    k-mer table and ~4 900 vote bins -- summaries and CIGARs equal the twin's."""
+    from falcon_unzip_amd import _lib
+    ctg, reads, raw = _sim(51, 5_000_000, 120, 15000)
+    job = _lib.align_job(eng, [ctg], raw)
+    job.run()
+    got, _ = _cmp_twin(job, oracle, ctg, raw)
+    assert got["aligned"].mean() >= 0.99 and set(np.unique(got["strand"])) == {0, 1}
+    job.close()
+
+
+def test_vote_bin_shift_above_10_matches_twin(eng, oracle):
+    """A 9 Mb contig: (Lc + n) >> 10 exceeds the 8192 vote bins, so the bins are 2 048 diagonals wide (shift 11)."""
+    from falcon_unzip_amd import _lib
+    ctg, reads, raw = _sim(52, 9_000_000, 40, 15000)
+    job = _lib.align_job(eng, [ctg], raw)
+    job.run()
+    got, _ = _cmp_twin(job, oracle, ctg, raw)
+    assert got["aligned"].all()
+    job.close()
+
+
+def _sim_repeats(seed, L, n, R, **kw):
+    from falcon_unzip_amd import sim
+    rng = np.random.Generator(np.random.PCG64(seed))
+    hap0, hap1, _, spans = sim.make_repeat_diploid(L, rng, **kw)
+    reads = sim.simulate_reads(hap0, hap1, n, R, rng, strand_mix=0.5)
+    ctg = sim.codes_to_str(hap0).encode()
+    raw = [sim.codes_to_str(r.raw_seq_codes()).encode() for r in reads]
+    return ctg, reads, raw, spans
+
+
+def test_repeat_genome_matches_twin_and_truth(eng, oracle):
+    """Tandem arrays and 2-6 kb interspersed copies at 95-99 % identity: every position of a k-mer is
+    indexed, second placements are extended and the better one kept, anchors come from chains.  HIP == twin, and the
+    placements hold against the simulator's truth."""
+    from falcon_unzip_amd import _lib
+    ctg, reads, raw, spans = _sim_repeats(33, 300000, 300, 15000, n_families=10, n_tandem=12)
+    job = _lib.align_job(eng, [ctg], raw)
+    job.run()
+    s, _ = _cmp_twin(job, oracle, ctg, raw)
+    assert job.n_second() > 0                              # some reads did carry a second candidate
+    start = np.array([r.start for r in reads]); end = np.array([r.start + r.ref_span() for r in reads]); strand = np.array([r.strand for r in reads])
+    ok = s["aligned"] == 1
+    assert ok.mean() >= 0.99 and np.all(s["strand"][ok] == strand[ok])
+    # inside a tandem array a start / end may sit one unit off: judge by overlap with the true interval
+    ov = np.minimum(s["ref_end"], end) - np.maximum(s["pos"], start)
+    assert np.mean(ov[ok] >= 0.97 * (end - start)[ok]) >= 0.99
+    assert np.mean((np.abs(s["pos"] - start) <= 64)[ok]) >= 0.95
+    assert np.mean(((s["q_end"] - s["q_start"]) / np.array([len(x) for x in raw]))[ok] >= 0.99) >= 0.99
+    job.close()
+
+
+def test_second_candidate_can_win(eng, oracle):
+    """A read drawn from the diverged copy of a duplicated 12 kb segment: both copies collect votes; the extension score decides."""
+    from falcon_unzip_amd import _lib, sim
+    rng = np.random.Generator(np.random.PCG64(91))
+    L = 200000
+    hap0 = rng.integers(0, 4, size=L, dtype=np.uint8)
+    seg = hap0[20000:32000].copy()
+    hap0[120000:120000 + 12000] = sim._diverge(seg, rng, 0.02)[:12000]
+    ctg = sim.codes_to_str(hap0).encode()
+    raw, truth = [], []
+    for s0 in (20500, 120500, 21000, 121000, 19000, 119500):
+        seq, _, _ = sim.simulate_read(hap0, hap0, s0, 10000, rng)
+        raw.append(sim.codes_to_str(seq).encode()); truth.append(s0)
+    job = _lib.align_job(eng, [ctg], raw)
+    job.run()
+    got, _ = _cmp_twin(job, oracle, ctg, raw)
+    assert job.n_second() >= 4
+    assert np.all(np.abs(got["pos"] - np.array(truth)) <= 64), (got["pos"], truth)
+    job.close()
+
+
+def test_identity_gate(eng, oracle):
+    """--minPctIdentity 70 (unzip.py:87): a read at ~60 % identity is dropped by the gate and kept without it; n_match is exact."""
+    from falcon_unzip_amd import _lib, sim
+    rng = np.random.Generator(np.random.PCG64(92))
+    L = 100000
+    hap0 = rng.integers(0, 4, size=L, dtype=np.uint8)
+    ctg = sim.codes_to_str(hap0).encode()
+    raw = []
+    for sub, ins, dele in ((0.01, 0.08, 0.04), (0.16, 0.12, 0.08), (0.22, 0.14, 0.10)):
+        seq, _, _ = sim.simulate_read(hap0, hap0, 30000, 8000, rng, sub=sub, ins=ins, dele=dele)
+        raw.append(sim.codes_to_str(seq).encode())
+    for pid in (70, 0):
+        job = _lib.align_job(eng, [ctg], raw, params={"min_pct_identity": pid})
+        job.run()
+        got, _ = _cmp_twin(job, oracle, ctg, raw, {"min_pct_identity": pid})
+        ident = 100.0 * got["n_match"] / np.maximum(1, (got["q_end"] - got["q_start"]) + (got["ref_end"] - got["pos"]) - got["n_columns"])
+        if pid:
+            assert got["aligned"][0] == 1 and np.all(ident[got["aligned"] == 1] >= 70)
+        else:
+            assert got["aligned"][0] == 1
+        job.close()
+    # n_match against a direct count over the =/X CIGAR
+    job = _lib.align_job(eng, [ctg], raw[:1])
+    job.run()
+    aln, _ = job.alnset(0)
+    assert sum(l for l, o in aln.cigar_of(0) if o == 7) == job.summaries()["n_match"][0]
+    job.close()
+
+
+def _full_matrix_best(q, t, match=2, mismatch=4, gap=3):
+    """Unbanded extension DP from the origin, H(-1,-1) = 0, linear gaps, no zero floor: best score over all cells.
+    Independent of the band, the steering and the trace-back of the spec (numpy, row by row)."""
+    nq, nt = len(q), len(t)
+    ar = np.arange(nt + 1, dtype=np.int64)
+    prev = -gap * ar                      # row -1: H(-1, j-1) at index j, index 0 = the corner
+    best = -(1 << 60)
+    for i in range(nq):
+        s = np.where(t == q[i], match, -mismatch)
+        base = np.empty(nt + 1, np.int64)
+        base[0] = -gap * (i + 1)          # H(i, -1)
+        base[1:] = np.maximum(prev[:-1] + s, prev[1:] - gap)
+        cur = np.maximum.accumulate(base + gap * ar) - gap * ar      # the left-gap chain
+        best = max(best, int(cur[1:].max()))
+        prev = cur
+    return best
+
+
+def test_scores_equal_unbanded_dp_on_short_reads(eng):
+    """Spec-independent check: for reads of ~2.5 kb the kernel's score must be the optimum of a plain
+    full-matrix extension DP from the same origin -- the band never cut the best path, and twin and kernel do not share an
+    arithmetic bug."""
+    from falcon_unzip_amd import _lib, sim
+    rng = np.random.Generator(np.random.PCG64(93))
+    L = 60000
+    hap0, hap1, _ = sim.make_diploid(L, rng)
+    reads = sim.simulate_reads(hap0, hap1, 24, 2300, rng, strand_mix=0.5)
+    ctg = sim.codes_to_str(hap0).encode()
+    raw = [sim.codes_to_str(r.raw_seq_codes()).encode() for r in reads]
+    job = _lib.align_job(eng, [ctg], raw)
+    job.run()
+    s = job.summaries()
+    aln, idx = job.alnset(0)
+    assert s["aligned"].sum() >= 22
+    cig_of = {int(r): aln.cigar_of(k) for k, r in enumerate(idx)}
+    checked = 0
+    for r, rd in enumerate(reads):
+        if not s["aligned"][r] or r not in cig_of:
+            continue
+        ori = rd.seq                                        # on the contig strand = the oriented read
+        cg = cig_of[r]
+        cs = sum(2 * l if o == 7 else -4 * l if o == 8 else -3 * l if o in (1, 2) else 0 for l, o in cg)
+        lead = cs - int(s["score"][r])
+        assert lead >= 0 and lead % 3 == 0
+        lead //= 3
+        hit = False
+        for li in range(lead + 1):
+            i_a, c_a = int(s["q_start"][r]) - li, int(s["pos"][r]) - (lead - li)
+            if i_a < 0 or c_a < 0 or min(i_a, c_a) != 0:
+                continue
+            q = ori[i_a:]
+            nt = min(L - c_a, len(q) + len(q) // 4 + 64)
+            if _full_matrix_best(q, hap0[c_a:c_a + nt]) == int(s["score"][r]):
+                hit = True
+                break
+        assert hit, (r, s[r])
+        checked += 1
+    assert checked >= 20
+    job.close()
