@@ -100,6 +100,26 @@ class AlignParams(C.Structure):
 _lib = None
 
 
+PIPE_CONSENSUS = 1
+TEXT_VARIANT_MAP, TEXT_ATABLE = 1, 2
+
+
+class NamesStruct(C.Structure):
+    _fields_ = [("n_ctg", C.c_int32), ("ctg_id", C.POINTER(C.c_char_p)), ("name_off", C.c_void_p), ("names", C.c_char_p)]
+
+
+class PipeOpts(C.Structure):
+    _fields_ = [("out_dir", C.c_char_p), ("rawread_ids", C.c_char_p), ("rr_len", C.c_size_t), ("pread_ids", C.c_char_p), ("pi_len", C.c_size_t),
+                ("pread_to_contigs", C.c_char_p), ("pc_len", C.c_size_t), ("ctg_index", C.c_void_p), ("n_threads", C.c_int32), ("n_lanes", C.c_int32),
+                ("group_bases", C.c_int64), ("flags", C.c_uint), ("align", AlignParams)]
+
+
+class PipeOut(C.Structure):
+    _fields_ = [("r2p", C.c_void_p), ("n_r2p", C.c_int64)] + [(k, C.c_int64) for k in ("n_reads", "n_aligned", "n_rec", "n_sites", "n_rows", "n_arows", "n_pvars",
+                                                                                     "n_preads", "n_groups", "bytes_written")] + \
+               [(k, C.c_double) for k in ("dp_cells", "ms_upload", "ms_k1", "ms_phase", "ms_results", "ms_text")]
+
+
 def load():
     """Load the shared library; raises (loudly) when it has not been built."""
     global _lib
@@ -147,6 +167,11 @@ def load():
         "fzp_align_run": (C.c_int, [VP, VP]),
         "fzp_align_summaries": (C.c_int, [VP, VP, VP]),
         "fzp_align_n_second": (I64, [VP]),
+        "fzp_batch_text": (C.c_int, [VP, VP, C.c_int, PP, PSZ, PP]),
+        "fzp_pipe_opts_default": (None, [VP]),
+        "fzp_job_phase_write": (C.c_int, [VP, VP, VP, VP, VP]),
+        "fzp_phase_contigs": (C.c_int, [VP, I32, VP, VP, I64, VP, VP, VP, VP, VP, VP]),
+        "fzp_pipe_out_free": (None, [VP]),
         "fzp_align_alnset": (C.c_int, [VP, VP, I32, VP, CP, PP, PP]),
         "fzp_align_to_batch": (C.c_int, [VP, VP, PP]),
         "fzp_align_destroy": (None, [VP, VP]),
@@ -286,8 +311,8 @@ class Batch:
     def results(self, copy=True):
         """Every contig's records with ONE device-to-host copy per array -> list of Result (local indices).
 
-        copy=False hands out views of the context's pinned staging buffer: valid only until the next
-        results() call on this engine (the zero-copy path bench.py uses)."""
+        copy=False hands out views of the batch's pinned staging block: valid until the batch is run again,
+        asked for results again or closed."""
         lib = load()
         ra = ResultAllStruct()
         _check(lib.fzp_batch_result_all(self.eng._p, self._p, C.byref(ra)))
@@ -318,6 +343,13 @@ class Batch:
             r.preads = full.preads[qb[c]:qb[c + 1]]
             out.append(r)
         return out
+
+    def text(self, what):
+        """`het_call/variant_map` (what=1) or `g_atable/atable` (what=2) of all contigs, serialised on the device -> (bytes, ctg_begin)"""
+        p, n, cb = C.c_void_p(), C.c_size_t(), C.c_void_p()
+        _check(load().fzp_batch_text(self.eng._p, self._p, what, C.byref(p), C.byref(n), C.byref(cb)))
+        begin = _take(cb.value, self.n_ctg + 1, np.int64)
+        return _take_text(p.value, n.value), begin
 
     def consensus(self) -> "Tigs":
         """K6: phased-pile consensus of every (block, phase); run(STAGE_ALL) first."""
@@ -450,16 +482,27 @@ class AlignJob:
         lib = load()
         ap, ip = C.c_void_p(), C.c_void_p()
         if names is not None:
-            enc = [nm.encode() if isinstance(nm, str) else nm for nm in names]
-            off = np.zeros(len(enc) + 1, np.int64)
-            off[1:] = np.cumsum([len(e) for e in enc])
-            blob = b"".join(enc)
+            if isinstance(names, tuple):                      # (name_off, blob) built once by the caller
+                off, blob = names
+            else:
+                enc = [nm.encode() if isinstance(nm, str) else nm for nm in names]
+                off = np.zeros(len(enc) + 1, np.int64)
+                off[1:] = np.cumsum([len(e) for e in enc])
+                blob = b"".join(enc)
             _check(lib.fzp_align_alnset(self.eng._p, self._p, ctg, _ptr(off), blob, C.byref(ap), C.byref(ip)))
         else:
             _check(lib.fzp_align_alnset(self.eng._p, self._p, ctg, None, None, C.byref(ap), C.byref(ip)))
         a = AlnSet(ap.value)
         idx = _take(ip.value, a.n_rec, np.int64)
         return a, idx
+
+    def phase_write(self, ctg_ids, names=None, out_dir=None, read_maps=None, ctg_index=None, n_threads=0, consensus=False):
+        """fzp_job_phase_write: K1 -> K5 of every contig of the job, every file of every contig under out_dir, rid_to_phase records.
+        names: (name_off int64 [n_reads+1], blob) or a list; read_maps: (rawread_ids, pread_ids, pread_to_contigs) bytes.  -> (stats dict, R2P records)"""
+        nm, opts, keep = _pipe_args(ctg_ids, names, out_dir, read_maps, ctg_index, n_threads, 0, 0, None, PIPE_CONSENSUS if consensus else 0)
+        out = PipeOut()
+        _check(load().fzp_job_phase_write(self.eng._p, self._p, C.byref(nm), C.byref(opts), C.byref(out)))
+        return _pipe_result(out)
 
     def to_batch(self) -> "Batch":
         p = C.c_void_p()
@@ -511,6 +554,70 @@ def align_job_raw(eng, contigs, read_blob: bytes, read_off, read_ctg, params=Non
     p = C.c_void_p()
     _check(lib.fzp_align_create(eng._p, nc, cptr, clen, nr, _ptr(rc), _ptr(read_off), read_blob, C.byref(P), C.byref(p)))
     return AlignJob(eng, p.value, nr, nc)
+
+
+def _pipe_args(ctg_ids, names, out_dir, read_maps, ctg_index, n_threads, n_lanes, group_bases, params, flags=0):
+    lib = load()
+    keep = []
+    ids = [c.encode() if isinstance(c, str) else c for c in ctg_ids]
+    arr = (C.c_char_p * len(ids))(*ids)
+    nm = NamesStruct()
+    nm.n_ctg = len(ids)
+    nm.ctg_id = arr
+    if names is not None:
+        if isinstance(names, tuple):
+            off, blob = names
+            off = np.ascontiguousarray(off, dtype=np.int64)
+        else:
+            enc = [x.encode() if isinstance(x, str) else x for x in names]
+            off = np.zeros(len(enc) + 1, np.int64)
+            off[1:] = np.cumsum([len(e) for e in enc])
+            blob = b"".join(enc)
+        keep += [off, blob]
+        nm.name_off = off.ctypes.data
+        nm.names = blob
+    opts = PipeOpts()
+    lib.fzp_pipe_opts_default(C.byref(opts))
+    if out_dir is not None:
+        opts.out_dir = out_dir.encode() if isinstance(out_dir, str) else out_dir
+    if read_maps is not None:
+        rr, pi, pc = read_maps
+        keep += [rr, pi, pc]
+        opts.rawread_ids, opts.rr_len, opts.pread_ids, opts.pi_len, opts.pread_to_contigs, opts.pc_len = rr, len(rr), pi, len(pi), pc, len(pc)
+    if ctg_index is not None:
+        ci = np.ascontiguousarray(ctg_index, dtype=np.int32)
+        keep.append(ci)
+        opts.ctg_index = ci.ctypes.data
+    opts.n_threads, opts.n_lanes, opts.group_bases, opts.flags = n_threads, n_lanes, group_bases, flags
+    for k, v in (params or {}).items():
+        setattr(opts.align, k, v)
+    keep += [arr, ids]
+    return nm, opts, keep
+
+
+def _pipe_result(out):
+    recs = np.frombuffer(C.string_at(out.r2p, int(out.n_r2p) * R2P.itemsize), dtype=R2P).copy() if out.n_r2p else np.zeros(0, R2P)
+    stats = {k: getattr(out, k) for k, _ in PipeOut._fields_ if k not in ("r2p",)}
+    load().fzp_pipe_out_free(C.byref(out))
+    return stats, recs
+
+
+def phase_contigs(eng, contigs, read_blob: bytes, read_off, read_ctg, ctg_ids, names=None, out_dir=None, read_maps=None, ctg_index=None,
+                  n_threads=0, n_lanes=0, group_bases=0, params=None, consensus=False):
+    """fzp_phase_contigs: inputs in host memory -> every file of every contig + rid_to_phase records; contig groups are streamed through the
+    device on `n_lanes` lanes.  -> (stats dict, R2P records)"""
+    lib = load()
+    nc = len(contigs)
+    read_off = np.ascontiguousarray(read_off, dtype=np.int64)
+    nr = len(read_off) - 1
+    cbufs = [C.create_string_buffer(c, len(c)) if len(c) else C.create_string_buffer(1) for c in contigs]
+    cptr = (C.c_void_p * nc)(*[C.cast(b, C.c_void_p).value for b in cbufs])
+    clen = (C.c_int64 * nc)(*[len(c) for c in contigs])
+    rc = np.ascontiguousarray(read_ctg, dtype=np.int32)
+    nm, opts, keep = _pipe_args(ctg_ids, names, out_dir, read_maps, ctg_index, n_threads, n_lanes, group_bases, params, PIPE_CONSENSUS if consensus else 0)
+    out = PipeOut()
+    _check(lib.fzp_phase_contigs(eng._p, nc, cptr, clen, nr, _ptr(rc), _ptr(read_off), read_blob, C.byref(nm), C.byref(opts), C.byref(out)))
+    return _pipe_result(out)
 
 
 def format_sam(aln: AlnSet, ctg_id: str, flags=None):

@@ -27,12 +27,48 @@ __host__ __device__ __forceinline__ int code_of(uint8_t c) {
     return (c == 'C' || c == 'c') ? 1 : (c == 'G' || c == 'g') ? 2 : (c == 'T' || c == 't') ? 3 : 0;
 }
 
+// ---- contigs arrive as the caller spells them; the phasing stages read the upper-cased text (phasing.py:494 `.upper()`)
+__global__ void __launch_bounds__(256) k_upper(uint8_t *__restrict__ a, int64_t n) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 16;
+    if (i + 16 <= n) {
+        uint4 v = *(const uint4 *)(a + i);
+        uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t x = w[q];
+            // bytes in 'a'..'z': (x + 0x1f) has bit 7 set for >= 'a' (0x61 + 0x1f = 0x80), (x + 0x05) has it set for > 'z' (0x7b + 0x05 = 0x80); 7-bit input assumed per byte check below
+            const uint32_t hi = x & 0x80808080u, lo7 = x & 0x7f7f7f7fu;
+            const uint32_t ge_a = (lo7 + 0x1f1f1f1fu) & 0x80808080u, gt_z = (lo7 + 0x05050505u) & 0x80808080u;
+            const uint32_t is_lower = ge_a & ~gt_z & ~hi;
+            w[q] = x - (is_lower >> 2);                       // 0x80 >> 2 = 0x20
+        }
+        *(uint4 *)(a + i) = make_uint4(w[0], w[1], w[2], w[3]);
+    } else {
+        for (int64_t k = i; k < n; k++) { const uint8_t ch = a[k]; a[k] = (ch >= 'a' && ch <= 'z') ? (uint8_t)(ch - 32) : ch; }
+    }
+}
+
 // ---- packing: one workgroup column per sequence, blockIdx.y strides over its words
 __global__ void __launch_bounds__(256) k_pack(const uint8_t *__restrict__ ascii, const int64_t *__restrict__ seq_off, const int64_t *__restrict__ woff,
                                               uint32_t *__restrict__ out) {
     const int64_t s = blockIdx.x;
     const int64_t b0 = seq_off[s], n = seq_off[s + 1] - b0;
     const int64_t nw = ((n + 15) / 16 + 8 + 1) & ~1LL;   // zero pad words: 64-bit base windows may run past the end
+    uint32_t *dst = out + woff[s];
+    for (int64_t w = (int64_t)blockIdx.y * 256 + threadIdx.x; w < nw; w += (int64_t)gridDim.y * 256) {
+        uint32_t v = 0;
+        int64_t base = w * 16;
+        for (int m = 0; m < 16; m++)
+            if (base + m < n) v |= (uint32_t)code_of(ascii[b0 + base + m]) << (2 * m);
+        dst[w] = v;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_pack2(const uint8_t *__restrict__ ascii, const int64_t *__restrict__ seq_be, const int64_t *__restrict__ woff,
+                                               uint32_t *__restrict__ out) {      // like k_pack, sequence s = [seq_be[2s], seq_be[2s+1])
+    const int64_t s = blockIdx.x;
+    const int64_t b0 = seq_be[2 * s], n = seq_be[2 * s + 1] - b0;
+    const int64_t nw = ((n + 15) / 16 + 8 + 1) & ~1LL;
     uint32_t *dst = out + woff[s];
     for (int64_t w = (int64_t)blockIdx.y * 256 + threadIdx.x; w < nw; w += (int64_t)gridDim.y * 256) {
         uint32_t v = 0;
@@ -1191,6 +1227,7 @@ struct fzp_alnjob {
     // record planning: reads grouped by contig (input order inside a contig); built on first use
     DevBuf<int32_t> slot_read, slot_ctg;
     DevBuf<int64_t> slot_off;
+    std::vector<int64_t> h_slot_off;
     bool have_slots = false;
     int64_t max_reads_per_ctg = 1;
     bool summ_on_host = false;
@@ -1208,7 +1245,7 @@ extern "C" void fzp_align_params_default(fzp_align_params *p) {
 
 extern "C" void fzp_align_destroy(fzp_ctx *ctx, fzp_alnjob *job) {
     if (!job) return;
-    if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); (void)hipStreamSynchronize(ctx->stream2); }
+    if (ctx) { (void)fzp_bind(ctx); (void)hipStreamSynchronize(ctx->stream); (void)hipStreamSynchronize(ctx->stream2); }
     for (int k = 0; k < 2; k++) { if (job->ev_sw[k]) (void)hipEventDestroy(job->ev_sw[k]); if (job->ev_tb[k]) (void)hipEventDestroy(job->ev_tb[k]); }
     delete job;
 }
@@ -1220,7 +1257,7 @@ extern "C" int fzp_align_create(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *cons
         return FZP_EINVAL;
     }
     *out = nullptr;
-    FZP_HIP(hipSetDevice(ctx->device));
+    FZP_TRY(fzp_bind(ctx));
     fzp_alnjob *j = new fzp_alnjob();
     if (params) j->P = *params; else fzp_align_params_default(&j->P);
     if (j->P.kmer < 8 || j->P.kmer > 16 || j->P.seed_stride < 1 || j->P.match <= 0 || j->P.mismatch < 0 || j->P.gap <= 0 || j->P.min_pct_identity < 0 ||
@@ -1232,15 +1269,9 @@ extern "C" int fzp_align_create(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *cons
     int rc = FZP_OK;
     // contigs
     std::vector<int64_t> coff(1, 0);
-    std::vector<uint8_t> call;
-    j->h_ctg.resize(n_ctg);
+    j->h_ctg.resize(n_ctg);                       // upper-cased host copies: fetched from the device when fzp_align_alnset needs them
     for (int c = 0; c < n_ctg; c++) {
         if (ctg_len[c] < 0 || ctg_len[c] > 0x7fff0000LL) { delete j; fzp_set_error("contig %d: length out of range", c); return FZP_EINVAL; }
-        j->h_ctg[c].resize((size_t)ctg_len[c]);
-        for (int64_t i = 0; i < ctg_len[c]; i++) {
-            uint8_t ch = ctg_seq[c][i];
-            j->h_ctg[c][(size_t)i] = (ch >= 'a' && ch <= 'z') ? (uint8_t)(ch - 32) : ch;   // phasing.py:494 .upper()
-        }
         j->h_ctg_len.push_back(ctg_len[c]);
         j->h_ctg_woff.push_back(j->ctg_words);
         j->ctg_words += ((ctg_len[c] + 15) / 16 + 8 + 1) & ~1LL;
@@ -1250,8 +1281,7 @@ extern "C" int fzp_align_create(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *cons
         j->h_idx_bits.push_back(bits);
         j->h_idx_off.push_back(j->idx_slots);
         j->idx_slots += 1LL << bits;
-        call.insert(call.end(), j->h_ctg[c].begin(), j->h_ctg[c].end());
-        coff.push_back((int64_t)call.size());
+        coff.push_back(coff.back() + ((ctg_len[c] + 15) & ~15LL));      // 16-byte aligned segments (k_upper works on whole uint4s)
     }
     // reads
     j->h_read_woff.assign(1, 0);
@@ -1273,19 +1303,34 @@ extern "C" int fzp_align_create(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *cons
     DevBuf<uint8_t> d_ascii;
     DevBuf<int64_t> d_off;
     do {
-        if ((rc = j->ctg_pk.alloc((size_t)j->ctg_words + 8)) || (rc = d_ascii.upload(call.data(), call.size(), st)) || (rc = d_off.upload(coff.data(), coff.size(), st)) ||
+        // contigs: ASCII straight into ctg_ascii (pinned, chunked, threaded staging), upper-cased and packed on the device
+        if ((rc = j->ctg_pk.alloc((size_t)j->ctg_words + 8)) || (rc = j->ctg_ascii.alloc((size_t)coff.back() + 16)) || (rc = d_off.upload(coff.data(), coff.size(), st)) ||
             (rc = j->ctg_woff.upload(j->h_ctg_woff.data(), j->h_ctg_woff.size(), st)) || (rc = j->ctg_len.upload(j->h_ctg_len.data(), j->h_ctg_len.size(), st)) ||
             (rc = j->idx_off.upload(j->h_idx_off.data(), j->h_idx_off.size(), st)) || (rc = j->idx_bits.upload(j->h_idx_bits.data(), j->h_idx_bits.size(), st)))
             break;
-        hipLaunchKernelGGL(k_pack, dim3(n_ctg, 64), dim3(256), 0, st, d_ascii.p, d_off.p, j->ctg_woff.p, j->ctg_pk.p);
-        if ((rc = j->ctg_ascii.alloc(call.size()))) break;
-        if (hipMemcpyAsync(j->ctg_ascii.p, d_ascii.p, call.size(), hipMemcpyDeviceToDevice, st) != hipSuccess) { rc = FZP_EDEVICE; break; }
+        {
+            std::vector<const void *> srcs; std::vector<size_t> dsts, lens;
+            for (int c = 0; c < n_ctg; c++) { srcs.push_back(ctg_seq[c]); dsts.push_back((size_t)coff[(size_t)c]); lens.push_back((size_t)ctg_len[c]); }
+            if ((rc = fzp_upload_segments(ctx, j->ctg_ascii.p, srcs, dsts, lens, st))) break;
+        }
+        hipLaunchKernelGGL(k_upper, dim3((unsigned)((coff.back() / 16 + 255) / 256 + 1)), dim3(256), 0, st, j->ctg_ascii.p, coff.back());
+        {   // k_pack reads [seq_off[s], seq_off[s+1]): the contig lengths, not the padded segments -> per-contig begin / end pairs
+            std::vector<int64_t> be;
+            for (int c = 0; c < n_ctg; c++) { be.push_back(coff[(size_t)c]); be.push_back(coff[(size_t)c] + ctg_len[c]); }
+            DevBuf<int64_t> d_be;
+            if ((rc = d_be.upload(be.data(), be.size(), st))) break;
+            hipLaunchKernelGGL(k_pack2, dim3(n_ctg, 64), dim3(256), 0, st, j->ctg_ascii.p, d_be.p, j->ctg_woff.p, j->ctg_pk.p);
+            if (hipStreamSynchronize(st) != hipSuccess) { rc = FZP_EDEVICE; break; }
+        }
         j->h_ctg_aoff = coff;
-        if (hipStreamSynchronize(st) != hipSuccess) { rc = FZP_EDEVICE; break; }
         if (n_reads) {
-            if ((rc = j->read_pk.alloc((size_t)j->read_words + 8)) || (rc = j->read_ori.alloc((size_t)j->read_words + 8)) ||
-                (rc = d_ascii.upload(read_seq + read_off[0], (size_t)(read_off[n_reads] - read_off[0]), st)))
+            const size_t rbytes = (size_t)(read_off[n_reads] - read_off[0]);
+            if ((rc = j->read_pk.alloc((size_t)j->read_words + 8)) || (rc = j->read_ori.alloc((size_t)j->read_words + 8)) || (rc = d_ascii.alloc(rbytes + 16)))
                 break;
+            {
+                std::vector<const void *> srcs(1, read_seq + read_off[0]); std::vector<size_t> dsts(1, 0), lens(1, rbytes);
+                if ((rc = fzp_upload_segments(ctx, d_ascii.p, srcs, dsts, lens, st))) break;
+            }
             std::vector<int64_t> roff((size_t)n_reads + 1);
             for (int64_t r = 0; r <= n_reads; r++) roff[(size_t)r] = read_off[r] - read_off[0];
             if ((rc = d_off.upload(roff.data(), roff.size(), st)) || (rc = j->read_woff.upload(j->h_read_woff.data(), j->h_read_woff.size(), st)) ||
@@ -1308,7 +1353,7 @@ extern "C" int fzp_align_create(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *cons
 
 extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
     if (!ctx || !j) return FZP_EINVAL;
-    FZP_HIP(hipSetDevice(ctx->device));
+    FZP_TRY(fzp_bind(ctx));
     hipStream_t st = ctx->stream;
     const fzp_align_params &P = j->P;
     {
@@ -1451,7 +1496,7 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
 namespace {
 int fetch_summaries(fzp_ctx *ctx, fzp_alnjob *j) {
     if (j->summ_on_host) return FZP_OK;
-    FZP_HIP(hipSetDevice(ctx->device));
+    FZP_TRY(fzp_bind(ctx));
     j->h_summ.resize((size_t)j->n_reads);
     FZP_TRY(j->summ.download(j->h_summ.data(), (size_t)j->n_reads, ctx->stream));
     FZP_HIP(hipStreamSynchronize(ctx->stream));
@@ -1562,7 +1607,7 @@ T *dupv(const std::vector<T> &v) {
 
 extern "C" int fzp_align_alnset(fzp_ctx *ctx, fzp_alnjob *j, int32_t ctg, const int64_t *name_off, const char *names, fzp_alnset **out, int64_t **read_index) {
     if (!ctx || !j || !j->done || !out || ctg < 0 || ctg >= j->n_ctg) { fzp_set_error("fzp_align_alnset: bad arguments or job not run"); return FZP_EINVAL; }
-    FZP_HIP(hipSetDevice(ctx->device));
+    FZP_TRY(fzp_bind(ctx));
     FZP_TRY(fetch_summaries(ctx, j));
     RecPlan p;
     plan_records(j, ctg, ctg + 1, p);
@@ -1584,7 +1629,12 @@ extern "C" int fzp_align_alnset(fzp_ctx *ctx, fzp_alnjob *j, int32_t ctg, const 
     if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = FZP_EDEVICE;
     if (!rc) {
         // device CIGARs carry diagonal runs as 'M'; split them into '=' / 'X' against the contig here
-        const std::vector<uint8_t> &ref = j->h_ctg[(size_t)ctg];
+        std::vector<uint8_t> &ref = j->h_ctg[(size_t)ctg];
+        if (ref.size() != (size_t)j->h_ctg_len[(size_t)ctg]) {              // first use: the upper-cased contig comes back from the device
+            ref.resize((size_t)j->h_ctg_len[(size_t)ctg]);
+            if (!ref.empty() && (hipMemcpyAsync(ref.data(), j->ctg_ascii.p + j->h_ctg_aoff[(size_t)ctg], ref.size(), hipMemcpyDeviceToHost, st) != hipSuccess ||
+                                 hipStreamSynchronize(st) != hipSuccess)) rc = FZP_EDEVICE;
+        }
         std::vector<uint32_t> out_c;
         std::vector<int64_t> out_off(1, 0);
         out_c.reserve((size_t)p.cig_off.back() * 2);
@@ -1635,7 +1685,7 @@ extern "C" int fzp_align_alnset(fzp_ctx *ctx, fzp_alnjob *j, int32_t ctg, const 
 
 extern "C" int fzp_align_to_batch(fzp_ctx *ctx, fzp_alnjob *j, fzp_batch **out) {
     if (!ctx || !j || !j->done || !out) { fzp_set_error("fzp_align_to_batch: job not run"); return FZP_EINVAL; }
-    FZP_HIP(hipSetDevice(ctx->device));
+    FZP_TRY(fzp_bind(ctx));
     *out = nullptr;
     hipStream_t st = ctx->stream;
     const int nc = j->n_ctg;
@@ -1645,6 +1695,7 @@ extern "C" int fzp_align_to_batch(fzp_ctx *ctx, fzp_alnjob *j, fzp_batch **out) 
         for (int64_t r = 0; r < nr; r++) off[(size_t)j->h_read_ctg[(size_t)r] + 1]++;
         for (int c = 0; c < nc; c++) { j->max_reads_per_ctg = std::max(j->max_reads_per_ctg, off[(size_t)c + 1]); off[(size_t)c + 1] += off[(size_t)c]; }
         if (nc > 65535) { fzp_set_error("fzp_align_to_batch: %d contigs in one job (limit 65535)", nc); return FZP_EINVAL; }
+        j->h_slot_off = off;
         std::vector<int32_t> rd((size_t)nr), sc((size_t)nr);
         std::vector<int64_t> fill(off.begin(), off.end() - 1);
         for (int64_t r = 0; r < nr; r++) { const int c = j->h_read_ctg[(size_t)r]; const int64_t s_ = fill[(size_t)c]++; rd[(size_t)s_] = (int32_t)r; sc[(size_t)s_] = c; }
@@ -1657,7 +1708,8 @@ extern "C" int fzp_align_to_batch(fzp_ctx *ctx, fzp_alnjob *j, fzp_batch **out) 
     b->n_ctg = nc;
     // ---- plan on the device
     DevBuf<uint64_t> key, v_rec, v_cig, v_seq, v_ck, totals;
-    DevBuf<int32_t> g_read, g_qid, last_pos;
+    DevBuf<int32_t> &g_read = b->qid_read;      // stays with the batch: q_id q of contig c is read g_read[h_slot_off[c] + q]
+    DevBuf<int32_t> g_qid, last_pos;
     DevBuf<uint8_t> g_acc;
     DevBuf<uint32_t> n_aligned;
     DevBuf<unsigned long long> n_cols;
@@ -1699,6 +1751,7 @@ extern "C" int fzp_align_to_batch(fzp_ctx *ctx, fzp_alnjob *j, fzp_batch **out) 
     }
     b->n_pos = b->h_goff.back();
     b->n_qid = b->h_qid_off.back();
+    b->h_slot_off = j->h_slot_off;
     const size_t nrec1 = (size_t)b->n_rec + 1;
     FZP_TRY(rec_read.alloc(nrec1)); FZP_TRY(b->rec_qid.alloc(nrec1)); FZP_TRY(b->rec_pos.alloc(nrec1)); FZP_TRY(b->rec_ctg.alloc(nrec1));
     FZP_TRY(b->cig_off.alloc(nrec1)); FZP_TRY(b->seq_off.alloc(nrec1)); FZP_TRY(b->ck_off.alloc(nrec1)); FZP_TRY(b->ctg_rec_begin.alloc((size_t)nc + 1));

@@ -30,29 +30,29 @@ int upload_contig_tables(fzp_ctx *ctx, fzp_batch *b) {
 // failure the records are simply downloaded later.
 namespace {
 inline size_t al64(size_t x) { return (x + 63) & ~(size_t)63; }
+bool batch_pinned(fzp_ctx *ctx, fzp_batch *b, size_t need) {      // the batch's staging block holds `need` bytes (contents are not kept when it grows)
+    if (b->pin && b->pin_cap >= need) return true;
+    if (b->pin) { (void)hipStreamSynchronize(ctx->stream2); fzp_pinned_release(b->pin_ctx, b->pin); b->pin = nullptr; b->pin_cap = 0; b->pf_early = false; }
+    b->pin = fzp_pinned_acquire(ctx, need, &b->pin_cap);
+    b->pin_ctx = ctx;
+    return b->pin != nullptr;
+}
 void prefetch_early_records(fzp_ctx *ctx, fzp_batch *b) {
-    b->pf_base = nullptr;
+    b->pf_early = false;
     const size_t s_sites = (size_t)b->n_sites * sizeof(fzp_site), s_vmap = (size_t)b->n_rows * sizeof(int32_t), s_arows = (size_t)b->n_arows * sizeof(fzp_arow);
     // room for what comes later as well: at most one block record per site, one read record per variant_map row
     const size_t need = al64(s_sites) + al64(s_vmap) + al64(s_arows) + al64((size_t)b->n_sites * sizeof(fzp_pvar)) + al64((size_t)b->n_rows * sizeof(fzp_pread)) + 4096;
-    if (need > ctx->pinned_bytes) {
-        (void)hipStreamSynchronize(ctx->stream2);     // an earlier batch's early copies may still target the old buffer
-        if (ctx->pinned) (void)hipHostFree(ctx->pinned);
-        ctx->pinned = nullptr; ctx->pinned_bytes = 0;
-        const size_t want = need + need / 4;
-        if (hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); ctx->pinned = nullptr; return; }
-        ctx->pinned_bytes = want;
-    }
+    if (!batch_pinned(ctx, b, need)) return;
     if (!ctx->ev_pf && hipEventCreateWithFlags(&ctx->ev_pf, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ctx->ev_pf = nullptr; return; }
     if (hipEventRecord(ctx->ev_pf, ctx->stream) != hipSuccess || hipStreamWaitEvent(ctx->stream2, ctx->ev_pf, 0) != hipSuccess) { (void)hipGetLastError(); return; }
-    char *base = (char *)ctx->pinned;
+    char *base = (char *)b->pin;
     b->pf_sites = 0; b->pf_vmap = al64(s_sites); b->pf_arows = b->pf_vmap + al64(s_vmap); b->pf_end = b->pf_arows + al64(s_arows);
     bool ok = true;
     if (s_sites) ok = ok && hipMemcpyAsync(base + b->pf_sites, b->sites.p, s_sites, hipMemcpyDeviceToHost, ctx->stream2) == hipSuccess;
     if (s_vmap) ok = ok && hipMemcpyAsync(base + b->pf_vmap, b->vmap_qid.p, s_vmap, hipMemcpyDeviceToHost, ctx->stream2) == hipSuccess;
     if (s_arows) ok = ok && hipMemcpyAsync(base + b->pf_arows, b->arows.p, s_arows, hipMemcpyDeviceToHost, ctx->stream2) == hipSuccess;
     if (!ok) { (void)hipGetLastError(); return; }
-    b->pf_base = ctx->pinned;
+    b->pf_early = true;
 }
 }  // namespace
 
@@ -61,7 +61,7 @@ extern "C" int fzp_batch_create(fzp_ctx *ctx, int32_t n_ctg, const fzp_alnset *c
                                 fzp_batch **out) {
     if (!ctx || !out || n_ctg <= 0 || !aln || !ref_seq || !ref_len) { fzp_set_error("fzp_batch_create: bad arguments"); return FZP_EINVAL; }
     *out = nullptr;
-    FZP_HIP(hipSetDevice(ctx->device));
+    FZP_TRY(fzp_bind(ctx));
     fzp_batch *b = new fzp_batch();
     b->n_ctg = n_ctg;
     b->h_rec_begin.assign(1, 0); b->h_goff.assign(1, 0); b->h_qid_off.assign(1, 0);
@@ -132,13 +132,13 @@ extern "C" int fzp_batch_create(fzp_ctx *ctx, int32_t n_ctg, const fzp_alnset *c
 
 extern "C" void fzp_batch_destroy(fzp_ctx *ctx, fzp_batch *b) {
     if (!b) return;
-    if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); if (b->pf_base) (void)hipStreamSynchronize(ctx->stream2); }
+    if (ctx) { (void)fzp_bind(ctx); (void)hipStreamSynchronize(ctx->stream); if (b->pin) (void)hipStreamSynchronize(ctx->stream2); }
     delete b;
 }
 
 extern "C" int fzp_batch_run(fzp_ctx *ctx, fzp_batch *b, unsigned stages) {
     if (!ctx || !b) return FZP_EINVAL;
-    FZP_HIP(hipSetDevice(ctx->device));
+    FZP_TRY(fzp_bind(ctx));
     if (stages & FZP_STAGE_HET) {
         if (!b->have_aln) { fzp_set_error("batch holds no alignment records"); return FZP_EINVAL; }
         FZP_TRY(fzp_k2_het_call(ctx, b));
@@ -167,7 +167,7 @@ extern "C" int fzp_batch_counts(fzp_ctx *ctx, fzp_batch *b, int64_t *n_rec, int6
 
 extern "C" int fzp_batch_result(fzp_ctx *ctx, fzp_batch *b, int32_t ctg, fzp_result *out) {
     if (!ctx || !b || !out || ctg < 0 || ctg >= b->n_ctg) return FZP_EINVAL;
-    FZP_HIP(hipSetDevice(ctx->device));
+    FZP_TRY(fzp_bind(ctx));
     memset(out, 0, sizeof *out);
     hipStream_t st = ctx->stream;
     int rc = FZP_OK;
@@ -219,14 +219,14 @@ extern "C" int fzp_batch_result(fzp_ctx *ctx, fzp_batch *b, int32_t ctg, fzp_res
 }
 
 extern "C" void fzp_result_all_free(fzp_result_all *r) {
-    if (!r) return;   // r->all is borrowed from the ctx's pinned buffer
+    if (!r) return;   // r->all is borrowed from the batch's pinned block
     free(r->site_begin); free(r->row_begin); free(r->arow_begin); free(r->pvar_begin); free(r->pread_begin);
     memset(r, 0, sizeof *r);
 }
 
 extern "C" int fzp_batch_result_all(fzp_ctx *ctx, fzp_batch *b, fzp_result_all *out) {
     if (!ctx || !b || !out) return FZP_EINVAL;
-    FZP_HIP(hipSetDevice(ctx->device));
+    FZP_TRY(fzp_bind(ctx));
     memset(out, 0, sizeof *out);
     hipStream_t st = ctx->stream;
     const size_t nb = (size_t)b->n_ctg + 1;
@@ -249,21 +249,15 @@ extern "C" int fzp_batch_result_all(fzp_ctx *ctx, fzp_batch *b, fzp_result_all *
     if (b->have_blocks) { r.n_pvars = b->n_pvars; parts.push_back({b->pvars.p, (size_t)b->n_pvars * sizeof(fzp_pvar), (void **)&r.pvars}); out->pvar_begin = dup(b->h_pvar_begin); }
     if (b->have_preads) { r.n_preads = b->n_preads; parts.push_back({b->preads.p, (size_t)b->n_preads * sizeof(fzp_pread), (void **)&r.preads}); out->pread_begin = dup(b->h_pread_begin); }
     // parts 0..2 (sites, variant_map, atable) may already be on their way (prefetch_early_records)
-    const bool early = b->pf_base && b->pf_base == ctx->pinned && b->have_sites && b->have_arows && parts.size() >= 3;
+    const bool early = b->pf_early && b->pin && b->have_sites && b->have_arows && parts.size() >= 3;
     size_t total = early ? b->pf_end : 0;
     for (size_t k = early ? 3 : 0; k < parts.size(); k++) total += (parts[k].bytes + 63) & ~(size_t)63;
-    const bool use_early = early && total <= ctx->pinned_bytes;
+    const bool use_early = early && total <= b->pin_cap;
     if (!use_early) {
-        (void)hipStreamSynchronize(ctx->stream2);                     // nothing may still be writing into a buffer we are about to reuse or free
+        (void)hipStreamSynchronize(ctx->stream2);                     // nothing may still be writing into a block we are about to give back
         total = 0;
         for (auto &p : parts) total += (p.bytes + 63) & ~(size_t)63;
-        if (total > ctx->pinned_bytes) {
-            if (ctx->pinned) (void)hipHostFree(ctx->pinned);
-            ctx->pinned = nullptr; ctx->pinned_bytes = 0;
-            size_t want = total + total / 4 + (1 << 20);
-            if (hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); fzp_result_all_free(out); fzp_set_error("pinned host allocation of %zu bytes failed", want); return FZP_ENOMEM; }
-            ctx->pinned_bytes = want;
-        }
+        if (!batch_pinned(ctx, b, total)) { fzp_result_all_free(out); fzp_set_error("pinned host allocation of %zu bytes failed", total); return FZP_ENOMEM; }
     }
     std::vector<size_t> offs(parts.size());
     {
@@ -271,13 +265,13 @@ extern "C" int fzp_batch_result_all(fzp_ctx *ctx, fzp_batch *b, fzp_result_all *
         for (size_t k = 0; k < parts.size(); k++) {
             if (use_early && k < 3) { offs[k] = k == 0 ? b->pf_sites : (k == 1 ? b->pf_vmap : b->pf_arows); continue; }
             offs[k] = off;
-            if (parts[k].bytes && hipMemcpyAsync((char *)ctx->pinned + off, parts[k].src, parts[k].bytes, hipMemcpyDeviceToHost, st) != hipSuccess) { fzp_result_all_free(out); fzp_set_error("D2H copy failed"); return FZP_EDEVICE; }
+            if (parts[k].bytes && hipMemcpyAsync((char *)b->pin + off, parts[k].src, parts[k].bytes, hipMemcpyDeviceToHost, st) != hipSuccess) { fzp_result_all_free(out); fzp_set_error("D2H copy failed"); return FZP_EDEVICE; }
             off += (parts[k].bytes + 63) & ~(size_t)63;
         }
     }
     if (hipStreamSynchronize(st) != hipSuccess || (use_early && hipStreamSynchronize(ctx->stream2) != hipSuccess)) { fzp_result_all_free(out); fzp_set_error("D2H sync failed"); return FZP_EDEVICE; }
-    b->pf_base = nullptr;                                              // the views below are handed out once
-    for (size_t k = 0; k < parts.size(); k++) *parts[k].dst = (char *)ctx->pinned + offs[k];   // borrowed views into the pinned buffer
+    b->pf_early = false;                                               // a later run of the batch refills the block
+    for (size_t k = 0; k < parts.size(); k++) *parts[k].dst = (char *)b->pin + offs[k];   // borrowed views into the batch's pinned block
     if (b->have_sites) {
         out->row_begin = (int64_t *)calloc(nb, sizeof(int64_t));
         for (int c = 0; c <= b->n_ctg; c++) {
@@ -371,7 +365,7 @@ extern "C" int fzp_het_call(fzp_ctx *ctx, const fzp_alnset *aln, const uint8_t *
 extern "C" int fzp_assoc_table(fzp_ctx *ctx, const fzp_site *sites, int64_t n_sites, const int32_t *vmap_qid, int64_t n_rows, fzp_arow **arows,
                                int64_t *n_arows) {
     if (!ctx || !arows || !n_arows) return FZP_EINVAL;
-    FZP_HIP(hipSetDevice(ctx->device));
+    FZP_TRY(fzp_bind(ctx));
     fzp_batch *b = nullptr;
     FZP_TRY(batch_from_sites(ctx, sites, n_sites, vmap_qid, n_rows, 0, &b));
     int rc = fzp_batch_run(ctx, b, FZP_STAGE_ASSOC);
@@ -388,7 +382,7 @@ extern "C" int fzp_assoc_table(fzp_ctx *ctx, const fzp_site *sites, int64_t n_si
 extern "C" int fzp_phase_blocks(fzp_ctx *ctx, const fzp_site *sites, int64_t n_sites, const fzp_arow *arows, int64_t n_arows, fzp_pvar **pvars,
                                 int64_t *n_pvars) {
     if (!ctx || !pvars || !n_pvars) return FZP_EINVAL;
-    FZP_HIP(hipSetDevice(ctx->device));
+    FZP_TRY(fzp_bind(ctx));
     // the variant_map rows are not needed here (the reference only reads ref_base from it, phasing.py:230-238)
     std::vector<fzp_site> s2(sites, sites + n_sites);
     for (auto &s : s2) { s.row_off = 0; s.count[0] = 0; s.count[1] = 0; }
@@ -409,7 +403,7 @@ extern "C" int fzp_phase_blocks(fzp_ctx *ctx, const fzp_site *sites, int64_t n_s
 extern "C" int fzp_phase_reads(fzp_ctx *ctx, const fzp_site *sites, int64_t n_sites, const int32_t *vmap_qid, int64_t n_rows, const fzp_pvar *pvars,
                                int64_t n_pvars, int32_t n_qid, fzp_pread **preads, int64_t *n_preads) {
     if (!ctx || !preads || !n_preads || n_pvars < 0 || (n_pvars && !pvars)) return FZP_EINVAL;
-    FZP_HIP(hipSetDevice(ctx->device));
+    FZP_TRY(fzp_bind(ctx));
     fzp_batch *b = nullptr;
     FZP_TRY(batch_from_sites(ctx, sites, n_sites, vmap_qid, n_rows, n_qid, &b));
     // variant_to_phase (phasing.py:454-463): block and phase-0 allele per site

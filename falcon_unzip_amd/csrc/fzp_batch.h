@@ -33,6 +33,9 @@ struct fzp_batch {
     DevBuf<uint8_t> seq, ref;
     DevBuf<int64_t> ctg_goff, ctg_qoff, ctg_rec_begin;
     DevBuf<int32_t> ctg_limit;
+    // batches made by fzp_align_to_batch: the aligned reads of contig c in q_id order are qid_read[h_slot_off[c] .. + n_qid(c))
+    DevBuf<int32_t> qid_read;
+    std::vector<int64_t> h_slot_off;
     // CIGAR checkpoints: per record, per 64-op chunk, the (reference, query) offsets at the chunk's start
     std::vector<int64_t> h_ck_off;     // [n_rec+1] prefix of ceil(n_ops/64) (batches built from host records)
     int64_t n_ck = 0;                  // total 64-op chunks = size of ck_ref / ck_q
@@ -75,9 +78,14 @@ struct fzp_batch {
     DevBuf<uint32_t> rng_n, rng_off, c0, c1, pr_flag, pr_idx;
     DevBuf<fzp_pread> preads;
     DevBuf<int64_t> pread_begin;
-    // early download of the K2/K3 records into the ctx's pinned buffer (valid while pf_base == ctx->pinned)
-    void *pf_base = nullptr;
+    // this batch's pinned host staging block (from the ctx's cache, back to it when the batch dies): the K2/K3 records start
+    // their way into it early (pf_early), fzp_batch_result_all adds the rest and hands out views that live as long as the batch
+    fzp_ctx *pin_ctx = nullptr;
+    void *pin = nullptr;
+    size_t pin_cap = 0;
+    bool pf_early = false;
     size_t pf_sites = 0, pf_vmap = 0, pf_arows = 0, pf_end = 0;
+    ~fzp_batch() { if (pin) fzp_pinned_release(pin_ctx, pin); }
     // scratch
     DevBuf<uint64_t> totals;          // a few device u64 scalars
     DevBuf<int32_t> errflag;

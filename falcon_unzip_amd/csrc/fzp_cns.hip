@@ -229,7 +229,7 @@ extern "C" int fzp_batch_consensus(fzp_ctx *ctx, fzp_batch *b, fzp_tigs *out) {
     if (!ctx || !b || !out) { fzp_set_error("fzp_batch_consensus: bad arguments"); return FZP_EINVAL; }
     memset(out, 0, sizeof *out);
     if (!b->have_aln || !b->have_blocks || !b->have_preads || !b->have_sites) { fzp_set_error("fzp_batch_consensus: run FZP_STAGE_ALL on a batch with alignment records first"); return FZP_EINVAL; }
-    FZP_HIP(hipSetDevice(ctx->device));
+    FZP_TRY(fzp_bind(ctx));
     hipStream_t st = ctx->stream;
     const int nc = b->n_ctg;
     // ---- blocks per contig and their spans

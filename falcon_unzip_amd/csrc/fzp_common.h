@@ -8,6 +8,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -33,11 +35,23 @@ constexpr int WAVE = 64;
 
 // ---------------------------------------------------------------- caching device allocator (fzp_host.hip)
 // Steady-state passes of the hot path must not call hipMalloc/hipFree (both are slow and hipFree
-// synchronises): freed blocks are kept in size buckets and handed out again.  Single stream per ctx,
-// so stream order protects reuse.
-void *fzp_dev_alloc(size_t bytes);   // nullptr on failure
+// synchronises): freed blocks are kept in size buckets and handed out again.  Every ctx owns its pool:
+// fzp_bind(ctx) -- the first thing every entry point does -- selects the device and makes the ctx's pool the
+// calling thread's current one; a block always returns to the pool it came from, whoever frees it.  Inside a
+// ctx all work is ordered by its streams' events, which is what makes host-side reuse of a freed block safe;
+// two ctxs (same or different devices, same or different threads) never see each other's blocks.
+struct DevPool;
+struct fzp_ctx;
+int fzp_bind(fzp_ctx *ctx);          // hipSetDevice(ctx->device) + current pool = ctx's
+void *fzp_dev_alloc(size_t bytes);   // from the calling thread's current pool; nullptr on failure
 void fzp_dev_free(void *p);
-void fzp_dev_trim();                  // give everything cached back to the driver
+void fzp_dev_trim();                  // give everything cached in the current pool back to the driver
+// pinned host staging blocks (bulk D2H of results, H2D of inputs): cached per ctx like device blocks
+void *fzp_pinned_acquire(fzp_ctx *ctx, size_t bytes, size_t *cap);   // nullptr on failure
+void fzp_pinned_release(fzp_ctx *ctx, void *p);
+// host segments -> one device buffer at the given byte offsets: chunks staged through pinned blocks by a few threads,
+// H2D copies queued behind each other; returns when everything has arrived (`st` is only used for small inputs)
+int fzp_upload_segments(fzp_ctx *ctx, void *dst_dev, const std::vector<const void *> &src, const std::vector<size_t> &dst_off, const std::vector<size_t> &len, hipStream_t st);
 
 // ---------------------------------------------------------------- device buffer
 template <class T>
@@ -98,8 +112,9 @@ struct fzp_ctx {
     std::vector<PendingEvent> pending;
     std::vector<hipEvent_t> event_pool;
     DevBuf<uint64_t> scan_tmp[3];
-    void *pinned = nullptr;          // pinned host staging for bulk device-to-host copies (grow-only)
-    size_t pinned_bytes = 0;
+    std::shared_ptr<DevPool> pool;   // this ctx's cached device blocks
+    std::mutex pin_mu;
+    std::vector<std::pair<void *, size_t>> pin_free, pin_live;   // pinned host blocks: cached / handed out
     hipEvent_t ev_pf = nullptr;      // "K2/K3 results are final": their download starts on stream2 while K4/K5 run
     int n_cu = 256;
 };

@@ -2,6 +2,7 @@
 // (phasing.py:42-75), the text serializers (the reference's `print >>f` statements) and
 // get_phasing_readmap (phasing_readmap.py:8-51, pure host bookkeeping).
 #include <algorithm>
+#include <thread>
 #include <unordered_map>
 
 #include "fzp_common.h"
@@ -20,13 +21,18 @@ extern "C" const char *fzp_version(void) { return "fzphase 0.1.0 (gfx950)"; }
 extern "C" void fzp_free(void *p) { free(p); }
 
 // ---------------------------------------------------------------- caching device allocator
-namespace {
 struct DevPool {
+    std::mutex mu;
+    int device = 0;
     std::multimap<size_t, void *> free_blocks;      // bucket size -> block
-    std::unordered_map<void *, size_t> live;         // block -> bucket size
-    ~DevPool() {}                                    // the driver reclaims at process exit
 };
-DevPool &pool() { static DevPool p; return p; }
+namespace {
+struct LiveBlock { std::shared_ptr<DevPool> pool; size_t bucket; };
+std::mutex g_live_mu;
+std::unordered_map<void *, LiveBlock> g_live;        // every block handed out, whichever pool it belongs to
+std::mutex g_def_mu;
+std::map<int, std::shared_ptr<DevPool>> g_default;   // per device: for threads that never bound a ctx
+thread_local std::shared_ptr<DevPool> t_pool;
 size_t bucket_of(size_t bytes) {
     if (bytes < 256) bytes = 256;
     size_t p2 = 256;
@@ -36,38 +42,152 @@ size_t bucket_of(size_t bytes) {
     for (int k = 1; k <= 8; k++) { size_t b = half + (half >> 3) * k; if (b >= bytes) return b; }
     return p2;
 }
+std::shared_ptr<DevPool> current_pool() {
+    if (t_pool) return t_pool;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(g_def_mu);
+    auto &p = g_default[dev];
+    if (!p) { p = std::make_shared<DevPool>(); p->device = dev; }
+    return p;
+}
+void trim_pool(DevPool &P) {
+    std::lock_guard<std::mutex> lk(P.mu);
+    for (auto &kv : P.free_blocks) (void)hipFree(kv.second);
+    P.free_blocks.clear();
+}
 }  // namespace
+int fzp_bind(fzp_ctx *ctx) {
+    FZP_HIP(hipSetDevice(ctx->device));
+    t_pool = ctx->pool;
+    return FZP_OK;
+}
 void *fzp_dev_alloc(size_t bytes) {
-    DevPool &P = pool();
-    size_t b = bucket_of(bytes);
-    auto it = P.free_blocks.find(b);
-    if (it != P.free_blocks.end()) {
-        void *p = it->second;
-        P.free_blocks.erase(it);
-        P.live[p] = b;
-        return p;
-    }
+    std::shared_ptr<DevPool> P = current_pool();
+    const size_t b = bucket_of(bytes);
     void *p = nullptr;
-    if (hipMalloc(&p, b) != hipSuccess) {
-        (void)hipGetLastError();
-        fzp_dev_trim();                              // retry once with the cache emptied
-        if (hipMalloc(&p, b) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    {
+        std::lock_guard<std::mutex> lk(P->mu);
+        auto it = P->free_blocks.find(b);
+        if (it != P->free_blocks.end()) { p = it->second; P->free_blocks.erase(it); }
     }
-    P.live[p] = b;
+    if (!p) {
+        if (hipMalloc(&p, b) != hipSuccess) {
+            (void)hipGetLastError();
+            trim_pool(*P);                             // retry once with the cache emptied
+            if (hipMalloc(&p, b) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        }
+    }
+    std::lock_guard<std::mutex> lk(g_live_mu);
+    g_live[p] = LiveBlock{P, b};
     return p;
 }
 void fzp_dev_free(void *p) {
     if (!p) return;
-    DevPool &P = pool();
-    auto it = P.live.find(p);
-    if (it == P.live.end()) { (void)hipFree(p); return; }
-    P.free_blocks.emplace(it->second, p);
-    P.live.erase(it);
+    LiveBlock lb;
+    {
+        std::lock_guard<std::mutex> lk(g_live_mu);
+        auto it = g_live.find(p);
+        if (it == g_live.end()) { (void)hipFree(p); return; }
+        lb = it->second;
+        g_live.erase(it);
+    }
+    std::lock_guard<std::mutex> lk(lb.pool->mu);
+    lb.pool->free_blocks.emplace(lb.bucket, p);
 }
-void fzp_dev_trim() {
-    DevPool &P = pool();
-    for (auto &kv : P.free_blocks) (void)hipFree(kv.second);
-    P.free_blocks.clear();
+void fzp_dev_trim() { trim_pool(*current_pool()); }
+
+void *fzp_pinned_acquire(fzp_ctx *ctx, size_t bytes, size_t *cap) {
+    if (bytes < 4096) bytes = 4096;
+    {
+        std::lock_guard<std::mutex> lk(ctx->pin_mu);
+        size_t best = (size_t)-1;
+        for (size_t i = 0; i < ctx->pin_free.size(); i++)
+            if (ctx->pin_free[i].second >= bytes && (best == (size_t)-1 || ctx->pin_free[i].second < ctx->pin_free[best].second)) best = i;
+        if (best != (size_t)-1) {
+            auto blk = ctx->pin_free[best];
+            ctx->pin_free.erase(ctx->pin_free.begin() + (long)best);
+            ctx->pin_live.push_back(blk);
+            if (cap) *cap = blk.second;
+            return blk.first;
+        }
+    }
+    void *p = nullptr;
+    const size_t want = bytes + bytes / 4 + (1 << 20);
+    if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        std::vector<std::pair<void *, size_t>> drop;
+        { std::lock_guard<std::mutex> lk(ctx->pin_mu); drop.swap(ctx->pin_free); }
+        for (auto &d : drop) (void)hipHostFree(d.first);
+        if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    }
+    std::lock_guard<std::mutex> lk(ctx->pin_mu);
+    ctx->pin_live.push_back({p, want});
+    if (cap) *cap = want;
+    return p;
+}
+void fzp_pinned_release(fzp_ctx *ctx, void *p) {
+    if (!p || !ctx) return;
+    std::lock_guard<std::mutex> lk(ctx->pin_mu);
+    for (size_t i = 0; i < ctx->pin_live.size(); i++)
+        if (ctx->pin_live[i].first == p) {
+            ctx->pin_free.push_back(ctx->pin_live[i]);
+            ctx->pin_live.erase(ctx->pin_live.begin() + (long)i);
+            return;
+        }
+}
+
+// ---------------------------------------------------------------- big host -> device uploads
+// Pageable memory goes to the device through the driver's own staging at a few GB/s; here the caller's bytes are copied
+// into pinned blocks by UP_THREADS threads (each with two 8 MiB blocks and its own stream) while earlier chunks are in flight.
+int fzp_upload_segments(fzp_ctx *ctx, void *dst_dev, const std::vector<const void *> &src, const std::vector<size_t> &dst_off, const std::vector<size_t> &len, hipStream_t st) {
+    constexpr size_t CHUNK = 8u << 20;
+    size_t total = 0;
+    for (size_t v : len) total += v;
+    if (total < (4u << 20)) {
+        for (size_t k = 0; k < src.size(); k++)
+            if (len[k]) FZP_HIP(hipMemcpyAsync((char *)dst_dev + dst_off[k], src[k], len[k], hipMemcpyHostToDevice, st));
+        FZP_HIP(hipStreamSynchronize(st));
+        return FZP_OK;
+    }
+    struct Piece { const char *s; size_t d, n; };
+    std::vector<Piece> pieces;
+    for (size_t k = 0; k < src.size(); k++)
+        for (size_t o = 0; o < len[k]; o += CHUNK) pieces.push_back({(const char *)src[k] + o, dst_off[k] + o, std::min(CHUNK, len[k] - o)});
+    int T = (int)std::min<size_t>(4, std::max<size_t>(1, std::thread::hardware_concurrency() / 2));
+    if (const char *e = getenv("FZP_UPLOAD_THREADS")) { int g = atoi(e); if (g > 0 && g <= 16) T = g; }
+    T = (int)std::min<size_t>((size_t)T, pieces.size());
+    std::vector<int> rcs((size_t)T, FZP_OK);
+    std::vector<void *> blocks((size_t)T * 2, nullptr);
+    for (auto &b : blocks) { b = fzp_pinned_acquire(ctx, CHUNK, nullptr); if (!b) { for (auto q : blocks) if (q) fzp_pinned_release(ctx, q); fzp_set_error("pinned staging allocation failed"); return FZP_ENOMEM; } }
+    const int device = ctx->device;
+    auto work = [&](int t) {
+        if (hipSetDevice(device) != hipSuccess) { rcs[(size_t)t] = FZP_EDEVICE; return; }
+        hipStream_t s2 = nullptr;
+        hipEvent_t ev[2] = {nullptr, nullptr};
+        if (hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) != hipSuccess) { rcs[(size_t)t] = FZP_EDEVICE; }
+        bool used[2] = {false, false};
+        int k = 0;
+        for (size_t pi = (size_t)t; pi < pieces.size() && rcs[(size_t)t] == FZP_OK; pi += (size_t)T, k ^= 1) {
+            char *blk = (char *)blocks[(size_t)t * 2 + (size_t)k];
+            if (used[k] && hipEventSynchronize(ev[k]) != hipSuccess) { rcs[(size_t)t] = FZP_EDEVICE; break; }
+            memcpy(blk, pieces[pi].s, pieces[pi].n);
+            if (hipMemcpyAsync((char *)dst_dev + pieces[pi].d, blk, pieces[pi].n, hipMemcpyHostToDevice, s2) != hipSuccess || hipEventRecord(ev[k], s2) != hipSuccess) { rcs[(size_t)t] = FZP_EDEVICE; break; }
+            used[k] = true;
+        }
+        if (s2 && hipStreamSynchronize(s2) != hipSuccess) rcs[(size_t)t] = FZP_EDEVICE;
+        for (auto e : ev) if (e) (void)hipEventDestroy(e);
+        if (s2) (void)hipStreamDestroy(s2);
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; t++) th.emplace_back(work, t);
+    work(0);
+    for (auto &x : th) x.join();
+    for (auto q : blocks) fzp_pinned_release(ctx, q);
+    (void)hipSetDevice(ctx->device);
+    for (int rc : rcs) if (rc != FZP_OK) { fzp_set_error("upload: a staged copy failed"); return rc; }
+    return FZP_OK;
 }
 
 // ---------------------------------------------------------------- context
@@ -95,7 +215,10 @@ extern "C" int fzp_ctx_create(int device_id, unsigned flags, fzp_ctx **out) {
     }
     fzp_ctx *c = new fzp_ctx();
     c->device = device_id;
+    c->pool = std::make_shared<DevPool>();
+    c->pool->device = device_id;
     c->n_cu = prop.multiProcessorCount;
+    t_pool = c->pool;
     hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (se == hipSuccess) se = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
     if (se != hipSuccess) {
@@ -109,7 +232,7 @@ extern "C" int fzp_ctx_create(int device_id, unsigned flags, fzp_ctx **out) {
 
 extern "C" void fzp_ctx_destroy(fzp_ctx *ctx) {
     if (!ctx) return;
-    (void)hipSetDevice(ctx->device);
+    (void)fzp_bind(ctx);
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipStreamSynchronize(ctx->stream2);
     for (auto &p : ctx->pending) {
@@ -118,9 +241,11 @@ extern "C" void fzp_ctx_destroy(fzp_ctx *ctx) {
     }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     for (auto &b : ctx->scan_tmp) b.release();
-    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    for (auto &pb : ctx->pin_free) (void)hipHostFree(pb.first);
+    for (auto &pb : ctx->pin_live) (void)hipHostFree(pb.first);      // (views handed out die with the ctx, as documented)
     if (ctx->ev_pf) (void)hipEventDestroy(ctx->ev_pf);
-    fzp_dev_trim();
+    trim_pool(*ctx->pool);
+    t_pool.reset();
     (void)hipStreamDestroy(ctx->stream2);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;

@@ -171,7 +171,7 @@ int ovl_tokenise_host(fzp_ctx *ctx, fzp_ovlset *s);
 extern "C" int fzp_ovl_parse(fzp_ctx *ctx, int32_t n_files, const char *const *texts, const size_t *lens, const char *rid_map, size_t map_len, fzp_ovlset **out) {
     if (!ctx || !out || n_files < 0 || (n_files && (!texts || !lens)) || (!rid_map && map_len)) { fzp_set_error("fzp_ovl_parse: bad arguments"); return FZP_EINVAL; }
     *out = nullptr;
-    FZP_HIP(hipSetDevice(ctx->device));
+    FZP_TRY(fzp_bind(ctx));
     fzp_ovlset *s = new fzp_ovlset();
     s->device = ctx->device;
     // ---- the dumps: one buffer, every dump ending with '\n'
@@ -667,7 +667,7 @@ extern "C" int fzp_ovl_filter(fzp_ctx *ctx, const fzp_ovlset *s, const fzp_ovlp_
     *rows_out = nullptr; *n_rows_out = 0;
     if (ignore_out) { *ignore_out = nullptr; if (n_ignore) *n_ignore = 0; }
     if (contained_out) { *contained_out = nullptr; if (n_contained) *n_contained = 0; }
-    FZP_HIP(hipSetDevice(ctx->device));
+    FZP_TRY(fzp_bind(ctx));
     hipStream_t st = ctx->stream;
     const int64_t n = s->n_lines;
     const size_t na = s->key.size();
@@ -971,7 +971,7 @@ extern "C" int fzp_track_reads(fzp_ctx *ctx, int32_t n_files, const char *const 
                                char **text_out, size_t *len_out) {
     if (!ctx || n_files < 0 || (n_files && (!texts || !lens)) || !text_out || !len_out) { fzp_set_error("fzp_track_reads: bad arguments"); return FZP_EINVAL; }
     *text_out = nullptr; *len_out = 0;
-    FZP_HIP(hipSetDevice(ctx->device));
+    FZP_TRY(fzp_bind(ctx));
     hipStream_t st = ctx->stream;
     // ---- read_to_contig_map (:14-23): rid -> set of contigs.  rids must be '%09d'-shaped (fc_get_read_hctg_map writes them so)
     std::string rc_text(read_to_contig_map ? read_to_contig_map : "", rc_len), pr_text(phased_reads ? phased_reads : "", pr_len);

@@ -1,0 +1,483 @@
+// fzp_pipe.hip -- the per-contig task chain of unzip_all as ONE call over many contigs (host orchestration, C++).
+//
+// The reference starts, per contig, a blasr job (task_run_blasr, unzip.py:61-99) and a phasing job (task_phasing,
+// unzip.py:102-133 = fc_phasing.py + fc_phasing_readmap.py), each reading and writing files.  Here:
+//   fzp_job_phase_write   inputs resident in HBM (an fzp_alnjob): K1 -> K5 in batched launches, records to the host, the
+//                         two big files serialised on the device (fzp_text.hip), the small ones by host threads, every
+//                         file of every contig written, rid_to_phase records returned for the gather;
+//   fzp_phase_contigs     inputs in host memory: contigs are cut into groups sized to the trace-back budget and dealt to
+//                         `n_lanes` host threads, each with its own ctx (own streams and allocator caches): while one lane
+//                         stages, uploads or writes, the other lanes' kernels keep the GPU busy.
+// File layout = the reference's: <out_dir>/<ctg>/{het_call/{variant_pos,variant_map,q_id_map}, g_atable/atable,
+// get_phased_blocks/phased_variants, phased_reads, rid_to_phase.<ctg>}  (phasing.py:501-503,520,534,543; unzip.py:269).
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <thread>
+#include <unordered_map>
+
+#include "fzp_batch.h"
+
+int fzp_batch_text_dev(fzp_ctx *ctx, fzp_batch *b, int what, DevBuf<char> &text, size_t *bytes, std::vector<int64_t> &ctg_begin);
+
+namespace {
+using clk = std::chrono::steady_clock;
+double ms_since(clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); }
+
+struct Tok { const char *s; size_t n; };
+inline bool is_ws(char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\f' || c == '\v'; }
+int split_ws(const char *l, size_t n, Tok *t, int maxt) {
+    int k = 0;
+    size_t i = 0;
+    while (i < n) {
+        while (i < n && is_ws(l[i])) i++;
+        if (i >= n) break;
+        size_t j = i;
+        while (j < n && !is_ws(l[j])) j++;
+        if (k < maxt) t[k] = {l + i, j - i};
+        k++;
+        i = j;
+    }
+    return k;
+}
+bool tok_int(Tok t, long long *v) {
+    if (t.n == 0 || t.n > 19) return false;
+    size_t i = 0;
+    bool neg = false;
+    if (t.s[0] == '-' || t.s[0] == '+') { neg = t.s[0] == '-'; i = 1; }
+    if (i == t.n) return false;
+    long long x = 0;
+    for (; i < t.n; i++) {
+        if (t.s[i] < '0' || t.s[i] > '9') return false;
+        x = x * 10 + (t.s[i] - '0');
+    }
+    *v = neg ? -x : x;
+    return true;
+}
+void split_nl(const char *s, size_t n, std::vector<Tok> &out) {   // text.split('\n')
+    size_t off = 0;
+    for (;;) {
+        const char *e = (const char *)memchr(s + off, '\n', n - off);
+        if (!e) { out.push_back({s + off, n - off}); break; }
+        out.push_back({s + off, (size_t)(e - (s + off))});
+        off = (size_t)(e - s) + 1;
+    }
+}
+
+// ---- the three read_map tables of get_phasing_readmap (phasing_readmap.py:15-16,36), tokenised ONCE for all contigs
+struct ReadMaps {
+    std::vector<Tok> rid_to_oid, pid_to_fid;          // lines 17-18
+    struct Row { Tok pid, rank; int nt; };
+    std::vector<std::string> names;                   // distinct contig names of pread_to_contigs (column 1), sorted
+    std::vector<std::vector<Row>> rows;               // rows per name, file order
+    bool short_row = false;                           // a row with fewer than 2 tokens: the reference raises on it whatever the contig
+};
+void parse_maps(const fzp_pipe_opts *o, ReadMaps &m) {
+    split_nl(o->rawread_ids ? o->rawread_ids : "", o->rawread_ids ? o->rr_len : 0, m.rid_to_oid);
+    split_nl(o->pread_ids ? o->pread_ids : "", o->pread_ids ? o->pi_len : 0, m.pid_to_fid);
+    std::unordered_map<std::string, int> idx;
+    std::vector<std::pair<std::string, std::vector<ReadMaps::Row>>> tmp;
+    const char *p2c = o->pread_to_contigs;
+    size_t off = 0;
+    while (off < o->pc_len) {
+        const char *l = p2c + off;
+        const char *e = (const char *)memchr(l, '\n', o->pc_len - off);
+        size_t ln = e ? (size_t)(e - l) : o->pc_len - off;
+        off += ln + (e ? 1 : 0);
+        Tok t[4];
+        int nt = split_ws(l, ln, t, 4);
+        if (nt < 2) { m.short_row = true; continue; }
+        std::string name(t[1].s, t[1].n);
+        auto it = idx.find(name);
+        if (it == idx.end()) { it = idx.emplace(name, (int)tmp.size()).first; tmp.push_back({name, {}}); }
+        tmp[(size_t)it->second].second.push_back({t[0], nt >= 4 ? t[3] : Tok{nullptr, 0}, nt});
+    }
+    std::sort(tmp.begin(), tmp.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+    for (auto &kv : tmp) { m.names.push_back(kv.first); m.rows.push_back(std::move(kv.second)); }
+}
+
+struct TextBuf {
+    std::string s;
+    inline void puti(long long v) {
+        char t[24];
+        int k = 0;
+        bool neg = v < 0;
+        unsigned long long u = neg ? 0ULL - (unsigned long long)v : (unsigned long long)v;
+        do { t[k++] = (char)('0' + u % 10); u /= 10; } while (u);
+        if (neg) s.push_back('-');
+        while (k) s.push_back(t[--k]);
+    }
+};
+
+// get_phasing_readmap for one contig from records instead of text: preads = the contig's phased_reads rows (ascending
+// (q_id, block)), names by q_id.  -> rid_to_phase.<ctg> text + records.  Same semantics and messages as fzp_readmap.
+int readmap_apply(const ReadMaps &m, const char *ctg_id, int32_t ctg_index, const fzp_pread *pr, int64_t n_pr, const std::vector<int64_t> &qoff, const std::string &qnames,
+                  std::vector<fzp_r2p> &recs, std::string &text, std::string &err) {
+    if (m.short_row) { err = "pread_to_contigs: short row"; return FZP_EINVAL; }
+    std::unordered_map<std::string, std::pair<int, int>> rid_to_phase;    // lines 29-33, last line wins
+    for (int64_t i = 0; i < n_pr; i++) {
+        const int32_t q = pr[i].q_id;
+        rid_to_phase[qnames.substr((size_t)qoff[(size_t)q], (size_t)(qoff[(size_t)q + 1] - qoff[(size_t)q]))] = {pr[i].block, pr[i].phase};
+    }
+    const size_t cn = strlen(ctg_id);
+    std::vector<std::pair<long long, std::pair<int, int>>> out;           // (pread id, (block, phase)); later rows of a pread overwrite earlier ones
+    std::unordered_map<long long, size_t> at;
+    // names that start with ctg_id (startswith, line 41): a contiguous range of the sorted names
+    auto lo = std::lower_bound(m.names.begin(), m.names.end(), std::string(ctg_id));
+    struct Pick { size_t name, row; };
+    std::vector<std::pair<const char *, Pick>> order;                     // file order matters for "later rows overwrite": sort the picked rows by address
+    for (auto it = lo; it != m.names.end() && it->size() >= cn && memcmp(it->data(), ctg_id, cn) == 0; ++it) {
+        const size_t ni = (size_t)(it - m.names.begin());
+        for (size_t r = 0; r < m.rows[ni].size(); r++) order.push_back({m.rows[ni][r].pid.s, {ni, r}});
+    }
+    std::sort(order.begin(), order.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+    for (auto &o : order) {
+        const ReadMaps::Row &row = m.rows[o.second.name][o.second.row];
+        long long rank, pid;
+        if (row.nt < 4 || !tok_int(row.rank, &rank)) { err = "pread_to_contigs: bad rank"; return FZP_EINVAL; }
+        if (rank != 0) continue;                                                      // line 43
+        if (!tok_int(row.pid, &pid) || pid < 0 || (size_t)pid >= m.pid_to_fid.size() || pid > 0x7fffffffLL) { err = "pread_to_contigs: pread id out of range"; return FZP_EINVAL; }
+        Tok fid = m.pid_to_fid[(size_t)pid];                                          // lines 20-23
+        const char *s1 = (const char *)memchr(fid.s, '/', fid.n);
+        if (!s1) { err = "pread_ids: '" + std::string(fid.s, fid.n) + "' has no '/'"; return FZP_EINVAL; }
+        s1++;
+        size_t rem = fid.n - (size_t)(s1 - fid.s);
+        const char *s2 = (const char *)memchr(s1, '/', rem);
+        Tok mid = {s1, s2 ? (size_t)(s2 - s1) : rem};
+        long long raw;
+        if (!tok_int(mid, &raw) || raw < 0) { err = "pread_ids: bad raw-read field"; return FZP_EINVAL; }
+        raw /= 10;                                                                    // py2 int division
+        if ((size_t)raw >= m.rid_to_oid.size()) { err = "rawread_ids: id " + std::to_string(raw) + " out of range"; return FZP_EINVAL; }
+        Tok oid = m.rid_to_oid[(size_t)raw];
+        auto it = rid_to_phase.find(std::string(oid.s, oid.n));
+        const std::pair<int, int> v = it == rid_to_phase.end() ? std::pair<int, int>{-1, 0} : it->second;   // line 46
+        auto a = at.find(pid);
+        if (a == at.end()) { at.emplace(pid, out.size()); out.push_back({pid, v}); } else out[a->second].second = v;
+    }
+    // canonical order: ascending '%09d' string == ascending pread id below 10^9 (py2 dict order is unspecified)
+    std::sort(out.begin(), out.end(), [](const auto &a, const auto &b) {
+        char ka[32], kb[32];
+        snprintf(ka, sizeof ka, "%09lld", a.first); snprintf(kb, sizeof kb, "%09lld", b.first);
+        return strcmp(ka, kb) < 0;
+    });
+    TextBuf b;
+    for (auto &r : out) {                                                              // lines 49-51
+        char key[32];
+        snprintf(key, sizeof key, "%09lld", r.first);
+        b.s += key; b.s.push_back(' '); b.s.append(ctg_id, cn); b.s.push_back(' ');
+        b.puti(r.second.first); b.s.push_back(' '); b.puti(r.second.second); b.s.push_back('\n');
+        recs.push_back({(int32_t)r.first, ctg_index, r.second.first, r.second.second});
+    }
+    text.swap(b.s);
+    return FZP_OK;
+}
+
+bool mkdir_p(const std::string &path) {
+    std::string cur;
+    for (size_t i = 0; i <= path.size(); i++) {
+        if (i == path.size() || path[i] == '/') {
+            if (!cur.empty() && mkdir(cur.c_str(), 0777) != 0 && errno != EEXIST) return false;
+        }
+        if (i < path.size()) cur.push_back(path[i]);
+    }
+    return true;
+}
+bool write_file(const std::string &path, const char *data, size_t n, std::atomic<int64_t> &bytes) {
+    int fd = open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
+    if (fd < 0) return false;
+    size_t off = 0;
+    while (off < n) {
+        ssize_t w = write(fd, data + off, n - off);
+        if (w < 0) { if (errno == EINTR) continue; close(fd); return false; }
+        off += (size_t)w;
+    }
+    close(fd);
+    bytes += (int64_t)n;
+    return true;
+}
+void add(fzp_pipe_out *a, const fzp_pipe_out &b) {
+    a->n_reads += b.n_reads; a->n_aligned += b.n_aligned; a->n_rec += b.n_rec; a->n_sites += b.n_sites; a->n_rows += b.n_rows; a->n_arows += b.n_arows;
+    a->n_pvars += b.n_pvars; a->n_preads += b.n_preads; a->n_groups += b.n_groups; a->bytes_written += b.bytes_written; a->dp_cells += b.dp_cells;
+    a->ms_upload += b.ms_upload; a->ms_k1 += b.ms_k1; a->ms_phase += b.ms_phase; a->ms_results += b.ms_results; a->ms_text += b.ms_text;
+}
+}  // namespace
+
+extern "C" void fzp_pipe_opts_default(fzp_pipe_opts *o) {
+    memset(o, 0, sizeof *o);
+    fzp_align_params_default(&o->align);
+}
+
+// everything after the upload, for the contigs of one job
+static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, const fzp_pipe_opts *o, const ReadMaps *maps, const int32_t *ctg_index, fzp_pipe_out *out,
+                           std::vector<fzp_r2p> &r2p) {
+    FZP_TRY(fzp_bind(ctx));
+    auto t0 = clk::now();
+    FZP_TRY(fzp_align_run(ctx, job));
+    fzp_batch *b = nullptr;
+    FZP_TRY(fzp_align_to_batch(ctx, job, &b));
+    struct BG { fzp_ctx *c; fzp_batch *b; ~BG() { fzp_batch_destroy(c, b); } } bg{ctx, b};
+    out->ms_k1 += ms_since(t0);
+    t0 = clk::now();
+    FZP_TRY(fzp_batch_run(ctx, b, FZP_STAGE_ALL));
+    out->ms_phase += ms_since(t0);
+    t0 = clk::now();
+    const int nc = b->n_ctg;
+    fzp_tigs tigs;
+    memset(&tigs, 0, sizeof tigs);
+    const bool want_cns = (o->flags & FZP_PIPE_CONSENSUS) != 0;
+    if (want_cns) FZP_TRY(fzp_batch_consensus(ctx, b, &tigs));       // K6 of every (block, phase) pile -> <ctg>/cns/phased_blocks.fa
+    struct TG { fzp_tigs *t; ~TG() { fzp_tigs_free(t); } } tg{&tigs};
+    // the two big texts: serialised on the device, brought over while the records come
+    DevBuf<char> d_vmap, d_atab;
+    size_t n_vmap = 0, n_atab = 0;
+    std::vector<int64_t> vb, ab;
+    FZP_TRY(fzp_batch_text_dev(ctx, b, FZP_TEXT_VARIANT_MAP, d_vmap, &n_vmap, vb));
+    FZP_TRY(fzp_batch_text_dev(ctx, b, FZP_TEXT_ATABLE, d_atab, &n_atab, ab));
+    const int64_t n_slots = b->h_slot_off.empty() ? 0 : b->h_slot_off.back();
+    size_t pin_cap = 0;
+    const size_t o_atab = (n_vmap + 63) & ~(size_t)63, o_qr = o_atab + ((n_atab + 63) & ~(size_t)63);
+    char *pin = (char *)fzp_pinned_acquire(ctx, o_qr + (size_t)n_slots * 4 + 64, &pin_cap);
+    if (!pin) { fzp_set_error("pinned host allocation failed"); return FZP_ENOMEM; }
+    struct PG { fzp_ctx *c; void *p; ~PG() { fzp_pinned_release(c, p); } } pg{ctx, pin};
+    hipStream_t st2 = ctx->stream2;
+    FZP_HIP(hipStreamSynchronize(ctx->stream));
+    if (n_vmap) FZP_HIP(hipMemcpyAsync(pin, d_vmap.p, n_vmap, hipMemcpyDeviceToHost, st2));
+    if (n_atab) FZP_HIP(hipMemcpyAsync(pin + o_atab, d_atab.p, n_atab, hipMemcpyDeviceToHost, st2));
+    if (n_slots) FZP_HIP(hipMemcpyAsync(pin + o_qr, b->qid_read.p, (size_t)n_slots * 4, hipMemcpyDeviceToHost, st2));
+    fzp_result_all ra;
+    FZP_TRY(fzp_batch_result_all(ctx, b, &ra));                  // sites / variant_map ids / atable rows are not needed on the host here, but the views are free
+    struct RG { fzp_result_all *r; ~RG() { fzp_result_all_free(r); } } rg{&ra};
+    FZP_HIP(hipStreamSynchronize(st2));
+    const int32_t *qid_read = (const int32_t *)(pin + o_qr);
+    out->ms_results += ms_since(t0);
+    t0 = clk::now();
+    // ---- per contig: the small files on host threads, all files written
+    int T = o->n_threads > 0 ? o->n_threads : (int)std::max(1u, std::thread::hardware_concurrency());
+    T = std::min(T, std::max(1, nc));
+    std::atomic<int> next{0};
+    std::atomic<int64_t> bytes{0};
+    std::vector<int> rcs((size_t)T, FZP_OK);
+    std::vector<std::string> errs((size_t)T);
+    std::vector<std::vector<fzp_r2p>> recs((size_t)nc);
+    const std::string out_dir = o->out_dir ? o->out_dir : "";
+    auto work = [&](int t) {
+        for (;;) {
+            const int c = next.fetch_add(1);
+            if (c >= nc || rcs[(size_t)t] != FZP_OK) break;
+            const char *ctg = nm->ctg_id[c];
+            // q_id table of the contig: aligned reads in (POS, read) order
+            const int64_t nq = b->h_qid_off[(size_t)c + 1] - b->h_qid_off[(size_t)c];
+            const int32_t *qr = qid_read + b->h_slot_off[(size_t)c];
+            std::vector<int64_t> qoff((size_t)nq + 1, 0);
+            std::string qn;
+            for (int64_t q = 0; q < nq; q++) {
+                const int64_t r = qr[q];
+                if (nm->names && nm->name_off) qn.append(nm->names + nm->name_off[r], (size_t)(nm->name_off[r + 1] - nm->name_off[r]));
+                else { char tt[40]; snprintf(tt, sizeof tt, "read/%lld", (long long)r); qn += tt; }
+                qoff[(size_t)q + 1] = (int64_t)qn.size();
+            }
+            const int64_t s0 = ra.site_begin[c], s1 = ra.site_begin[c + 1], p0 = ra.pvar_begin[c], p1 = ra.pvar_begin[c + 1], r0 = ra.pread_begin[c], r1 = ra.pread_begin[c + 1];
+            char *txt[3] = {nullptr, nullptr, nullptr};
+            size_t len[3] = {0, 0, 0};
+            int rc = fzp_format_variant_pos(ra.all.sites + s0, s1 - s0, &txt[0], &len[0]);
+            if (rc == FZP_OK) rc = fzp_format_phased_variants(ra.all.sites, ra.all.pvars + p0, p1 - p0, &txt[1], &len[1]);       // pvars carry batch-wide site indices
+            if (rc == FZP_OK) rc = fzp_format_phased_reads(ra.all.preads + r0, r1 - r0, ctg, qoff.data(), qn.data(), (int32_t)nq, &txt[2], &len[2]);
+            std::string qmap;
+            {
+                TextBuf tb;
+                tb.s.reserve(qn.size() + (size_t)nq * 12);
+                for (int64_t q = 0; q < nq; q++) { tb.puti(q); tb.s.push_back(' '); tb.s.append(qn, (size_t)qoff[(size_t)q], (size_t)(qoff[(size_t)q + 1] - qoff[(size_t)q])); tb.s.push_back('\n'); }   // phasing.py:132-134
+                qmap.swap(tb.s);
+            }
+            std::string r2p_text;
+            bool have_r2p = false;
+            if (rc == FZP_OK && maps) {
+                rc = readmap_apply(*maps, ctg, ctg_index ? ctg_index[c] : c, ra.all.preads + r0, r1 - r0, qoff, qn, recs[(size_t)c], r2p_text, errs[(size_t)t]);
+                have_r2p = rc == FZP_OK;
+            } else if (rc != FZP_OK) errs[(size_t)t] = fzp_last_error();
+            if (rc == FZP_OK && o->out_dir) {
+                const std::string base = out_dir + "/" + ctg;
+                bool ok = mkdir_p(base + "/het_call") && mkdir_p(base + "/g_atable") && mkdir_p(base + "/get_phased_blocks");
+                ok = ok && write_file(base + "/het_call/variant_pos", txt[0], len[0], bytes) && write_file(base + "/het_call/variant_map", pin + vb[(size_t)c], (size_t)(vb[(size_t)c + 1] - vb[(size_t)c]), bytes) &&
+                     write_file(base + "/het_call/q_id_map", qmap.data(), qmap.size(), bytes) && write_file(base + "/g_atable/atable", pin + o_atab + ab[(size_t)c], (size_t)(ab[(size_t)c + 1] - ab[(size_t)c]), bytes) &&
+                     write_file(base + "/get_phased_blocks/phased_variants", txt[1], len[1], bytes) && write_file(base + "/phased_reads", txt[2], len[2], bytes);
+                if (ok && have_r2p) ok = write_file(base + "/rid_to_phase." + ctg, r2p_text.data(), r2p_text.size(), bytes);
+                if (ok && want_cns) {
+                    char *fa = nullptr; size_t fl = 0;
+                    if (fzp_format_tigs(&tigs, c, ctg, &fa, &fl) != FZP_OK) { rc = FZP_EINVAL; errs[(size_t)t] = fzp_last_error(); }
+                    else { ok = mkdir_p(base + "/cns") && write_file(base + "/cns/phased_blocks.fa", fa, fl, bytes); free(fa); }
+                }
+                if (!ok && rc == FZP_OK) { rc = FZP_EINVAL; errs[(size_t)t] = "cannot write under " + base + ": " + strerror(errno); }
+            }
+            for (auto p : txt) free(p);
+            if (rc != FZP_OK) rcs[(size_t)t] = rc;
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int t = 1; t < T; t++) th.emplace_back(work, t);
+        work(0);
+        for (auto &x : th) x.join();
+    }
+    for (int t = 0; t < T; t++) if (rcs[(size_t)t] != FZP_OK) { fzp_set_error("%s", errs[(size_t)t].c_str()); return rcs[(size_t)t]; }
+    for (int c = 0; c < nc; c++) r2p.insert(r2p.end(), recs[(size_t)c].begin(), recs[(size_t)c].end());
+    out->ms_text += ms_since(t0);
+    out->bytes_written += bytes.load();
+    out->n_groups += 1;
+    out->n_rec += b->n_rec; out->n_sites += b->n_sites; out->n_rows += b->n_rows; out->n_arows += b->n_arows; out->n_pvars += b->n_pvars; out->n_preads += b->n_preads;
+    out->n_aligned += b->n_qid;
+    return FZP_OK;
+}
+
+extern "C" int fzp_job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, const fzp_pipe_opts *opts, fzp_pipe_out *out) {
+    if (!ctx || !job || !nm || !nm->ctg_id || !out) { fzp_set_error("fzp_job_phase_write: bad arguments"); return FZP_EINVAL; }
+    fzp_pipe_opts o;
+    if (opts) o = *opts; else fzp_pipe_opts_default(&o);
+    memset(out, 0, sizeof *out);
+    ReadMaps maps;
+    const bool have_maps = o.pread_to_contigs != nullptr;
+    if (have_maps) parse_maps(&o, maps);
+    std::vector<fzp_r2p> r2p;
+    FZP_TRY(job_phase_write(ctx, job, nm, &o, have_maps ? &maps : nullptr, o.ctg_index, out, r2p));
+    out->n_r2p = (int64_t)r2p.size();
+    out->r2p = (fzp_r2p *)malloc((r2p.size() ? r2p.size() : 1) * sizeof(fzp_r2p));
+    if (!out->r2p) return FZP_ENOMEM;
+    if (!r2p.empty()) memcpy(out->r2p, r2p.data(), r2p.size() * sizeof(fzp_r2p));
+    return FZP_OK;
+}
+
+extern "C" int fzp_phase_contigs(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *const *ctg_seq, const int64_t *ctg_len, int64_t n_reads, const int32_t *read_ctg,
+                                 const int64_t *read_off, const uint8_t *read_seq, const fzp_names *nm, const fzp_pipe_opts *opts, fzp_pipe_out *out) {
+    if (!ctx || n_ctg <= 0 || !ctg_seq || !ctg_len || n_reads < 0 || (n_reads && (!read_ctg || !read_off || !read_seq)) || !nm || !nm->ctg_id || !out) {
+        fzp_set_error("fzp_phase_contigs: bad arguments");
+        return FZP_EINVAL;
+    }
+    fzp_pipe_opts o;
+    if (opts) o = *opts; else fzp_pipe_opts_default(&o);
+    memset(out, 0, sizeof *out);
+    for (int64_t r = 0; r < n_reads; r++) if (read_ctg[r] < 0 || read_ctg[r] >= n_ctg) { fzp_set_error("read %lld: bad contig", (long long)r); return FZP_EINVAL; }
+    ReadMaps maps;
+    const bool have_maps = o.pread_to_contigs != nullptr;
+    if (have_maps) parse_maps(&o, maps);
+    // reads of every contig (input order inside a contig), read bases per contig
+    std::vector<std::vector<int64_t>> ctg_reads((size_t)n_ctg);
+    std::vector<int64_t> bases((size_t)n_ctg, 0);
+    for (int64_t r = 0; r < n_reads; r++) { ctg_reads[(size_t)read_ctg[r]].push_back(r); bases[(size_t)read_ctg[r]] += read_off[r + 1] - read_off[r]; }
+    // groups of consecutive contigs: trace-back masks cost ~36 B per read base (16 B per DP step, ~2.25 steps per base)
+    int64_t group_bases = o.group_bases;
+    if (group_bases <= 0) {
+        size_t fr = 0, tot = 0;
+        FZP_TRY(fzp_bind(ctx));
+        FZP_HIP(hipMemGetInfo(&fr, &tot));
+        const int lanes = o.n_lanes > 0 ? o.n_lanes : 2;
+        int64_t all = 0;
+        for (auto v : bases) all += v;
+        // as large as the device allows (long launches, few tails), but at least two groups per lane so that uploads and file
+        // writes of one group hide behind the kernels of another
+        group_bases = std::min<int64_t>((int64_t)((double)tot * 0.55 / lanes / 40.0), std::max<int64_t>(64ll << 20, all / (2 * lanes)));
+    }
+    struct Group { int c0, c1; };
+    std::vector<Group> groups;
+    for (int c = 0; c < n_ctg;) {
+        int e = c;
+        int64_t acc = 0;
+        while (e < n_ctg && (e == c || acc + bases[(size_t)e] <= group_bases)) { acc += bases[(size_t)e]; e++; }
+        groups.push_back({c, e});
+        c = e;
+    }
+    int lanes = o.n_lanes > 0 ? o.n_lanes : 2;
+    lanes = std::min<int>(lanes, (int)groups.size());
+    std::atomic<size_t> next{0};
+    std::vector<int> rcs((size_t)lanes, FZP_OK);
+    std::vector<std::string> errs((size_t)lanes);
+    std::vector<fzp_pipe_out> outs((size_t)lanes);
+    std::vector<std::vector<std::vector<fzp_r2p>>> r2p_g(1);
+    r2p_g[0].resize(groups.size());
+    const int device = ctx->device;
+    auto lane = [&](int li) {
+        fzp_ctx *lc = ctx;
+        if (li > 0 && fzp_ctx_create(device, 0, &lc) != FZP_OK) { rcs[(size_t)li] = FZP_EDEVICE; errs[(size_t)li] = fzp_last_error(); return; }
+        fzp_pipe_out &po = outs[(size_t)li];
+        memset(&po, 0, sizeof po);
+        for (;;) {
+            const size_t g = next.fetch_add(1);
+            if (g >= groups.size()) break;
+            const Group &G = groups[g];
+            // the group's inputs: contig pointers as they are, reads gathered per contig (pointers into the caller's blob where they are contiguous)
+            const int gc = G.c1 - G.c0;
+            std::vector<int64_t> r_idx;
+            for (int c = G.c0; c < G.c1; c++) r_idx.insert(r_idx.end(), ctg_reads[(size_t)c].begin(), ctg_reads[(size_t)c].end());
+            const int64_t gr = (int64_t)r_idx.size();
+            std::vector<int32_t> g_ctg((size_t)gr);
+            std::vector<int64_t> g_off((size_t)gr + 1, 0), g_noff((size_t)gr + 1, 0);
+            bool contiguous = true;
+            for (int64_t k = 0; k < gr; k++) {
+                const int64_t r = r_idx[(size_t)k];
+                g_ctg[(size_t)k] = read_ctg[r] - G.c0;
+                g_off[(size_t)k + 1] = g_off[(size_t)k] + (read_off[r + 1] - read_off[r]);
+                if (k && r != r_idx[(size_t)k - 1] + 1) contiguous = false;
+            }
+            auto t0 = clk::now();
+            std::vector<uint8_t> gathered;
+            const uint8_t *g_seq = read_seq;
+            std::vector<int64_t> abs_off;
+            if (contiguous && gr) { abs_off.resize((size_t)gr + 1); for (int64_t k = 0; k <= gr; k++) abs_off[(size_t)k] = read_off[r_idx[0]] + g_off[(size_t)k]; }
+            else if (gr) {
+                gathered.resize((size_t)g_off[(size_t)gr]);
+                for (int64_t k = 0; k < gr; k++) memcpy(gathered.data() + g_off[(size_t)k], read_seq + read_off[r_idx[(size_t)k]], (size_t)(g_off[(size_t)k + 1] - g_off[(size_t)k]));
+                g_seq = gathered.data();
+                abs_off = g_off;
+            } else abs_off.assign(1, 0);
+            std::string g_names;
+            if (nm->names && nm->name_off)
+                for (int64_t k = 0; k < gr; k++) { const int64_t r = r_idx[(size_t)k]; g_names.append(nm->names + nm->name_off[r], (size_t)(nm->name_off[r + 1] - nm->name_off[r])); g_noff[(size_t)k + 1] = (int64_t)g_names.size(); }
+            fzp_alnjob *job = nullptr;
+            int rc = fzp_align_create(lc, gc, ctg_seq + G.c0, ctg_len + G.c0, gr, g_ctg.data(), abs_off.data(), g_seq, &o.align, &job);
+            po.ms_upload += ms_since(t0);
+            if (rc == FZP_OK) {
+                fzp_names gn;
+                gn.n_ctg = gc; gn.ctg_id = nm->ctg_id + G.c0;
+                gn.name_off = nm->names && nm->name_off ? g_noff.data() : nullptr;
+                gn.names = nm->names && nm->name_off ? g_names.data() : nullptr;
+                std::vector<int32_t> gi;
+                for (int c = G.c0; c < G.c1; c++) gi.push_back(o.ctg_index ? o.ctg_index[c] : c);
+                rc = job_phase_write(lc, job, &gn, &o, have_maps ? &maps : nullptr, gi.data(), &po, r2p_g[0][g]);
+                if (rc == FZP_OK) {
+                    std::vector<fzp_aln_summary> sm((size_t)gr);
+                    if (gr && fzp_align_summaries(lc, job, sm.data()) == FZP_OK) for (auto &s : sm) po.dp_cells += (double)s.cells;
+                }
+            }
+            if (rc != FZP_OK) errs[(size_t)li] = fzp_last_error();
+            fzp_align_destroy(lc, job);
+            po.n_reads += gr;
+            if (rc != FZP_OK) { rcs[(size_t)li] = rc; break; }
+        }
+        if (li > 0) fzp_ctx_destroy(lc);
+    };
+    {
+        std::vector<std::thread> th;
+        for (int li = 1; li < lanes; li++) th.emplace_back(lane, li);
+        lane(0);
+        for (auto &x : th) x.join();
+    }
+    (void)fzp_bind(ctx);
+    for (int li = 0; li < lanes; li++) if (rcs[(size_t)li] != FZP_OK) { fzp_set_error("%s", errs[(size_t)li].c_str()); return rcs[(size_t)li]; }
+    for (int li = 0; li < lanes; li++) add(out, outs[(size_t)li]);
+    std::vector<fzp_r2p> all;
+    for (auto &v : r2p_g[0]) all.insert(all.end(), v.begin(), v.end());
+    out->n_r2p = (int64_t)all.size();
+    out->r2p = (fzp_r2p *)malloc((all.size() ? all.size() : 1) * sizeof(fzp_r2p));
+    if (!out->r2p) return FZP_ENOMEM;
+    if (!all.empty()) memcpy(out->r2p, all.data(), all.size() * sizeof(fzp_r2p));
+    return FZP_OK;
+}
+
+extern "C" void fzp_pipe_out_free(fzp_pipe_out *o) {
+    if (!o) return;
+    free(o->r2p);
+    o->r2p = nullptr; o->n_r2p = 0;
+}

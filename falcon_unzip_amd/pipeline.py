@@ -64,71 +64,68 @@ def _mkdirs(*paths):
         os.makedirs(p, exist_ok=True)
 
 
-def phase_contigs(eng, jobs, unzip_dir, read_map_dir=None, write_sam=True, ctg_indices=None, consensus=True):
-    """K1 -> K5 for `jobs` (list of (ctg_id, ref bytes, [(read name, seq)])) on one GPU, all contigs in the same
-    launches; writes the per-contig files; returns the rid_to_phase records of these contigs (empty unless
-    read_map_dir is given).  ctg_indices: the contigs' indices in the job-wide sorted contig list."""
+def _slurp(p):
+    with open(p, "rb") as f:
+        return f.read()
+
+
+def load_read_maps(read_map_dir):
+    """The three files fc_phasing_readmap.py reads (phasing_readmap.py:15-16,36), once per rank."""
+    return (_slurp(os.path.join(read_map_dir, "dump_rawread_ids", "rawread_ids")), _slurp(os.path.join(read_map_dir, "dump_pread_ids", "pread_ids")),
+            _slurp(os.path.join(read_map_dir, "pread_to_contigs")))
+
+
+def phase_contigs(eng, jobs, unzip_dir, read_map_dir=None, write_sam=False, ctg_indices=None, consensus=True, n_lanes=0, group_bases=0):
+    """K1 -> K5 (+ K6) for `jobs` (list of (ctg_id, ref bytes, [(read name, seq)])) on one GPU; writes the per-contig files;
+    returns the rid_to_phase records of these contigs (empty unless read_map_dir is given).  ctg_indices: the contigs'
+    indices in the job-wide sorted contig list.
+
+    Everything runs inside the library (fzp_phase_contigs: contig groups streamed through the device, files written by
+    its host threads).  write_sam=True additionally leaves the blasr task's artefacts (<ctg>_sorted.bam + .bai,
+    unzip.py:86-91): those need the alignment records on the host, one contig at a time."""
     if ctg_indices is None:
         ctg_indices = list(range(len(jobs)))
     contigs = [j[1] for j in jobs]
-    names, blobs, offs, read_ctg = [], [], [0], []
+    names, blobs, lens, read_ctg = [], [], [], []
     for c, (_, _, reads) in enumerate(jobs):
         for nm, seq in reads:
             names.append(nm)
             blobs.append(seq)
-            offs.append(offs[-1] + len(seq))
+            lens.append(len(seq))
             read_ctg.append(c)
-    job = _lib.align_job_raw(eng, contigs, b"".join(blobs), np.array(offs, np.int64), np.array(read_ctg, np.int32))
-    job.run()
-    summ = job.summaries()
-    batch = job.to_batch()
-    batch.run(_lib.STAGE_ALL)
-    tigs = batch.consensus() if consensus else None          # K6 before results(): results() hands out pinned views
-    results = batch.results()
-    all_recs = []
-    for c, (ctg, ref, reads) in enumerate(jobs):
-        base = os.path.join(unzip_dir, "0-phasing", ctg)
-        _mkdirs(os.path.join(base, "het_call"), os.path.join(base, "g_atable"), os.path.join(base, "get_phased_blocks"),
-                os.path.join(base, "blasr"))
-        aln, idx = job.alnset(c, names)                      # records in (POS, read) order + the q_id table
-        r = results[c]
-        qoff, qnames = aln.qname_table()
-
-        def put(rel, data):
-            with open(os.path.join(base, rel), "wb") as f:
-                f.write(data)
-        put("het_call/variant_pos", _lib.format_variant_pos(r.sites))
-        put("het_call/variant_map", _lib.format_variant_map(r.sites, r.vmap_qid))
-        put("het_call/q_id_map", _lib.format_q_id_map(aln))
-        put("g_atable/atable", _lib.format_atable(r.sites, r.arows))
-        put("get_phased_blocks/phased_variants", _lib.format_phased_variants(r.sites, r.pvars))
-        phased_reads = _lib.format_phased_reads(r.preads, ctg, qoff, qnames)
-        put("phased_reads", phased_reads)
-        if tigs is not None:                                 # K6: consensus of every (block, phase) pile (DESIGN section 13)
-            _mkdirs(os.path.join(base, "cns"))
-            put("cns/phased_blocks.fa", tigs.fasta(c, ctg))
-        if write_sam:                                        # the blasr task's artefacts (unzip.py:86-91): sorted BAM + index
+    offs = np.zeros(len(lens) + 1, np.int64)
+    offs[1:] = np.cumsum(lens)
+    blob = b"".join(blobs)
+    read_ctg = np.array(read_ctg, np.int32)
+    enc = [nm.encode() if isinstance(nm, str) else nm for nm in names]
+    noff = np.zeros(len(enc) + 1, np.int64)
+    noff[1:] = np.cumsum([len(e) for e in enc])
+    name_tab = (noff, b"".join(enc))                          # built once for the whole rank
+    maps = load_read_maps(read_map_dir) if read_map_dir is not None else None
+    out_dir = os.path.join(unzip_dir, "0-phasing")
+    os.makedirs(out_dir, exist_ok=True)
+    stats, recs = _lib.phase_contigs(eng, contigs, blob, offs, read_ctg, [j[0] for j in jobs], names=name_tab, out_dir=out_dir, read_maps=maps,
+                                     ctg_index=ctg_indices, n_lanes=n_lanes, group_bases=group_bases, consensus=consensus)
+    if write_sam:
+        job = _lib.align_job_raw(eng, contigs, blob, offs, read_ctg)
+        job.run()
+        summ = job.summaries()
+        for c, (ctg, ref, _) in enumerate(jobs):
+            base = os.path.join(out_dir, ctg, "blasr")
+            os.makedirs(base, exist_ok=True)
+            aln, idx = job.alnset(c, name_tab)
             flags = (summ["strand"][idx] * 16).astype(np.int32)
             bam, bai = _lib.format_bam(aln, ctg, len(ref), flags)
-            put("blasr/%s_sorted.bam" % ctg, bam)
-            put("blasr/%s_sorted.bam.bai" % ctg, bai)
-        if read_map_dir is not None:                         # fc_phasing_readmap.py (unzip.py:126)
-            def slurp(p):
-                with open(p, "rb") as f:
-                    return f.read()
-            recs, text = _lib.readmap(phased_reads, slurp(os.path.join(read_map_dir, "dump_rawread_ids", "rawread_ids")),
-                                      slurp(os.path.join(read_map_dir, "dump_pread_ids", "pread_ids")),
-                                      slurp(os.path.join(read_map_dir, "pread_to_contigs")), ctg, ctg_indices[c])
-            put("rid_to_phase.%s" % ctg, text)
-            all_recs.append(recs)
-    if tigs is not None:
-        tigs.close()
-    batch.close()
-    job.close()
-    return np.concatenate(all_recs) if all_recs else np.zeros(0, _lib.R2P)
+            with open(os.path.join(base, "%s_sorted.bam" % ctg), "wb") as f:
+                f.write(bam)
+            with open(os.path.join(base, "%s_sorted.bam.bai" % ctg), "wb") as f:
+                f.write(bai)
+        job.close()
+    phase_contigs.last_stats = stats
+    return recs
 
 
-def run(unzip_dir, read_map_dir=None, ctg_ids=None, device=None):
+def run(unzip_dir, read_map_dir=None, ctg_ids=None, device=None, write_sam=True, consensus=True):
     """Whole phasing section of unzip_all for this rank (one process per GPU under torch.distributed.run)."""
     import torch.distributed as tdist
     rank = tdist.get_rank() if tdist.is_available() and tdist.is_initialized() else 0
@@ -149,7 +146,7 @@ def run(unzip_dir, read_map_dir=None, ctg_ids=None, device=None):
     if mine:
         jobs = load_contig_jobs(unzip_dir, [ctg_ids[i] for i in mine])
         # contig indices are global so that the gathered records sort like the reference's file list
-        local = phase_contigs(eng, jobs, unzip_dir, read_map_dir, ctg_indices=mine)
+        local = phase_contigs(eng, jobs, unzip_dir, read_map_dir, write_sam=write_sam, ctg_indices=mine, consensus=consensus)
     eng.close()
     allr = fdist.allgather_r2p(local)
     if rank == 0 and read_map_dir is not None:

@@ -24,8 +24,9 @@
  * Conventions: plain C, no exceptions cross the boundary; every function returns FZP_OK (0) or a
  * negative FZP_E* code and records a message readable through fzp_last_error() (thread-local).
  * Inputs are caller-owned host buffers; outputs are library-allocated host buffers released with
- * fzp_free() (or the matching *_free).  One fzp_ctx per (process, device); a ctx is not
- * thread-safe, different ctxs are independent.  All compute runs in HIP kernels on the ctx's
+ * fzp_free() (or the matching *_free).  Any number of fzp_ctx per process and device; a ctx is not
+ * thread-safe, different ctxs are independent (own streams, own device-block and pinned-block caches) and may be
+ * driven from different threads.  All compute runs in HIP kernels on the ctx's
  * device: there is NO CPU fallback -- without a usable gfx950 device fzp_ctx_create fails.
  */
 #ifndef FZPHASE_H
@@ -169,8 +170,9 @@ int fzp_batch_result(fzp_ctx *ctx, fzp_batch *b, int32_t ctg, fzp_result *out);
 /* all contigs at once: arrays concatenated in contig order with GLOBAL site / row indices (site indices in
  * arows / pvars and row_off in sites count from the start of the batch); begin[] arrays have n_ctg+1 entries.
  * One D2H copy per array instead of one per contig.  The record arrays in `all` are BORROWED: they point into
- * the context's pinned staging buffer and stay valid until the next fzp_batch_result_all on this ctx (or
- * fzp_ctx_destroy); fzp_result_all_free releases only the begin[] arrays. */
+ * the batch's own pinned staging block and stay valid until the next fzp_batch_run / fzp_batch_result_all on the
+ * SAME batch or its fzp_batch_destroy (other batches of the ctx do not touch them); fzp_result_all_free releases
+ * only the begin[] arrays. */
 typedef struct {
     fzp_result all;
     int64_t *site_begin, *row_begin, *arow_begin, *pvar_begin, *pread_begin;
@@ -266,6 +268,51 @@ int fzp_batch_consensus(fzp_ctx *ctx, fzp_batch *b, fzp_tigs *out);
 void fzp_tigs_free(fzp_tigs *t);     /* frees the arrays, not the struct */
 /* FASTA of one contig's tigs: ">{ctg_id}_{block:03d}_{phase} {lo+1} {hi+1} {n_records}\n{sequence}\n" */
 int fzp_format_tigs(const fzp_tigs *t, int32_t ctg, const char *ctg_id, char **text, size_t *len);
+
+/* ---- the two large files of a batch, serialised on the device: `het_call/variant_map` (phasing.py:125-128) and `g_atable/atable`
+ * (phasing.py:199) of ALL contigs, contig after contig, byte-identical to fzp_format_variant_map / fzp_format_atable;
+ * ctg_begin[n_ctg + 1] = byte offset of every contig's part.  text and ctg_begin are malloc'ed (fzp_free). */
+#define FZP_TEXT_VARIANT_MAP 1
+#define FZP_TEXT_ATABLE 2
+int fzp_batch_text(fzp_ctx *ctx, fzp_batch *b, int what, char **text, size_t *len, int64_t **ctg_begin);
+
+/* ---- many contigs, one call: the job fan-out of unzip_all (unzip.py:221-288: per contig one blasr task, unzip.py:61-99, and one
+ * phasing task, unzip.py:102-133 = fc_phasing.py + fc_phasing_readmap.py), files included.  SURVEY 8b's fzp_phase_contigs. */
+#define FZP_PIPE_CONSENSUS 1u     /* also K6 (fzp_batch_consensus): <ctg>/cns/phased_blocks.fa */
+typedef struct {
+    int32_t n_ctg;
+    const char *const *ctg_id;     /* [n_ctg] names: directory names and the ctg column of phased_reads / rid_to_phase */
+    const int64_t *name_off;       /* [n_reads + 1] read names by read index, concatenated (optional: NULL -> "read/<index>") */
+    const char *names;
+} fzp_names;
+typedef struct {
+    const char *out_dir;           /* files go to <out_dir>/<ctg_id>/{het_call/*, g_atable/atable, get_phased_blocks/phased_variants,
+                                      phased_reads, rid_to_phase.<ctg_id>} (phasing.py:501-503,520,534,543; unzip.py:269); NULL = texts are
+                                      produced but nothing is written */
+    const char *rawread_ids; size_t rr_len;       /* the three read_map files of fc_phasing_readmap.py (phasing_readmap.py:15-16,36), */
+    const char *pread_ids; size_t pi_len;         /* whole-file texts; pread_to_contigs == NULL: no rid_to_phase output */
+    const char *pread_to_contigs; size_t pc_len;
+    const int32_t *ctg_index;      /* [n_ctg] contig index stored in the rid_to_phase records (the job-wide sorted contig list); NULL = 0..n-1 */
+    int32_t n_threads;             /* host threads for the small files and the writes; 0 = all cores */
+    int32_t n_lanes;               /* fzp_phase_contigs: contig groups in flight (each lane = a host thread with its own ctx); 0 = 2 */
+    int64_t group_bases;           /* fzp_phase_contigs: read bases per contig group; 0 = from the device memory (trace-back masks ~36 B per read base) */
+    unsigned flags;                /* FZP_PIPE_* */
+    fzp_align_params align;        /* fzp_phase_contigs: aligner parameters */
+} fzp_pipe_opts;
+typedef struct {
+    fzp_r2p *r2p;                  /* rid_to_phase records of all contigs, contig order (fzp_pipe_out_free) */
+    int64_t n_r2p;
+    int64_t n_reads, n_aligned, n_rec, n_sites, n_rows, n_arows, n_pvars, n_preads, n_groups, bytes_written;
+    double dp_cells;
+    double ms_upload, ms_k1, ms_phase, ms_results, ms_text;   /* host wall per section, summed over groups (lanes overlap) */
+} fzp_pipe_out;
+void fzp_pipe_opts_default(fzp_pipe_opts *o);
+/* inputs resident in HBM: K1 -> K5 of every contig of `job`, all files, rid_to_phase records */
+int fzp_job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *names, const fzp_pipe_opts *opts, fzp_pipe_out *out);
+/* inputs in host memory (arguments as fzp_align_create): groups of contigs streamed through the device */
+int fzp_phase_contigs(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *const *ctg_seq, const int64_t *ctg_len, int64_t n_reads, const int32_t *read_ctg,
+                      const int64_t *read_off, const uint8_t *read_seq, const fzp_names *names, const fzp_pipe_opts *opts, fzp_pipe_out *out);
+void fzp_pipe_out_free(fzp_pipe_out *o);
 
 /* ---- BAM emitter / reader ("next" row n1).  The reference's blasr task writes <ctg>_sorted.bam + index
  * (unzip.py:86-91) and make_het_call reads it through `samtools view <bam> <ctg>` (phasing.py:27).

@@ -1,0 +1,186 @@
+"""The library's own multi-contig pipeline (fzp_job_phase_write / fzp_phase_contigs, csrc/fzp_pipe.hip) and the device text
+serialiser (csrc/fzp_text.hip): every file byte-identical to the per-contig path (host serialisers, fzp_readmap), whatever
+the grouping of contigs and the number of lanes; two engines in one process stay independent."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import golden_util
+
+pytestmark = pytest.mark.gpu
+FILES = ("het_call/variant_pos", "het_call/variant_map", "het_call/q_id_map", "g_atable/atable", "get_phased_blocks/phased_variants", "phased_reads")
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from falcon_unzip_amd import _lib
+    e = _lib.Engine(0)
+    yield e
+    e.close()
+
+
+def _make_job(n_ctg=4, seed=300, n_reads=150, R=6000):
+    from falcon_unzip_amd import sim
+    contigs, blobs, names, read_ctg, ids = [], [], [], [], []
+    for c in range(n_ctg):
+        rng = np.random.Generator(np.random.PCG64(seed + c))
+        L = 30000 + 4000 * c
+        hap0, hap1, _ = sim.make_diploid(L, rng, het_rate=1.0 / 300)
+        reads = sim.simulate_reads(hap0, hap1, n_reads - 10 * c, R, rng, strand_mix=0.5, name_prefix="m%d" % c)
+        contigs.append(sim.codes_to_str(hap0).encode() if c != 1 else sim.codes_to_str(hap0).lower().encode())     # one contig in lower case
+        for r in reads:
+            blobs.append(sim.codes_to_str(r.raw_seq_codes()).encode())
+            names.append(r.name)
+            read_ctg.append(c)
+        ids.append("%06dF" % c)
+    off = np.zeros(len(blobs) + 1, np.int64)
+    off[1:] = np.cumsum([len(b) for b in blobs])
+    return contigs, b"".join(blobs), off, np.array(read_ctg, np.int32), names, ids
+
+
+def _read_maps(names, read_ctg, ids):
+    """raw read i == pread i; pread_ids carries raw id * 10 in its second field (phasing_readmap.py:20-23)"""
+    rawread_ids = "\n".join(names) + "\n"
+    pread_ids = "\n".join("pread/%d/0_100" % (10 * i + 3) for i in range(len(names))) + "\n"
+    rows = []
+    for i, c in enumerate(read_ctg):
+        rows.append("%09d %s 12 0 100 1" % (i, ids[c]))
+        if i % 7 == 0:
+            rows.append("%09d %s 3 1 100 1" % (i, ids[(c + 1) % len(ids)]))      # a second-best hit elsewhere: rank 1, ignored
+    return rawread_ids.encode(), pread_ids.encode(), ("\n".join(rows) + "\n").encode()
+
+
+def _legacy(eng, contigs, blob, off, read_ctg, names, ids, maps):
+    """per-contig path: alnset + host serialisers + fzp_readmap"""
+    from falcon_unzip_amd import _lib
+    job = _lib.align_job_raw(eng, contigs, blob, off, read_ctg)
+    job.run()
+    b = job.to_batch()
+    b.run(_lib.STAGE_ALL)
+    res = b.results()
+    out, recs = {}, []
+    for c, ctg in enumerate(ids):
+        aln, idx = job.alnset(c, names)
+        qoff, qn = aln.qname_table()
+        r = res[c]
+        t = {"het_call/variant_pos": _lib.format_variant_pos(r.sites), "het_call/variant_map": _lib.format_variant_map(r.sites, r.vmap_qid),
+             "het_call/q_id_map": _lib.format_q_id_map(aln), "g_atable/atable": _lib.format_atable(r.sites, r.arows),
+             "get_phased_blocks/phased_variants": _lib.format_phased_variants(r.sites, r.pvars),
+             "phased_reads": _lib.format_phased_reads(r.preads, ctg, qoff, qn)}
+        rr, text = _lib.readmap(t["phased_reads"], maps[0], maps[1], maps[2], ctg, c)
+        t["rid_to_phase.%s" % ctg] = text
+        recs.append(rr)
+        out[ctg] = t
+    b.close()
+    job.close()
+    return out, np.concatenate(recs)
+
+
+def _check_tree(root, exp, ids):
+    for ctg in ids:
+        for rel, data in exp[ctg].items():
+            with open(os.path.join(root, ctg, rel), "rb") as f:
+                got = f.read()
+            assert got == data, (ctg, rel, len(got), len(data))
+
+
+def test_device_text_equals_host_serialisers(eng):
+    from falcon_unzip_amd import _lib
+    for name in golden_util.cases()[:6]:
+        case = golden_util.Case(name)
+        aln = _lib.parse_sam(case.sam)
+        b = eng.batch([aln], [case.ref_seq])
+        b.run(_lib.STAGE_ALL)
+        r = b.result(0)
+        vm, vb = b.text(_lib.TEXT_VARIANT_MAP)
+        at, ab = b.text(_lib.TEXT_ATABLE)
+        assert vm == _lib.format_variant_map(r.sites, r.vmap_qid), name
+        assert at == _lib.format_atable(r.sites, r.arows), name
+        assert list(vb) == [0, len(vm)] and list(ab) == [0, len(at)]
+        b.close()
+
+
+def test_job_phase_write_equals_per_contig_path(eng, tmp_path):
+    from falcon_unzip_amd import _lib
+    contigs, blob, off, read_ctg, names, ids = _make_job()
+    maps = _read_maps(names, read_ctg, ids)
+    exp, exp_recs = _legacy(eng, contigs, blob, off, read_ctg, names, ids, maps)
+    job = _lib.align_job_raw(eng, contigs, blob, off, read_ctg)
+    stats, recs = job.phase_write(ids, names=names, out_dir=str(tmp_path / "a"), read_maps=maps, consensus=True)
+    job.close()
+    _check_tree(str(tmp_path / "a"), exp, ids)
+    assert np.array_equal(recs, exp_recs) and len(recs) == len(names)
+    assert stats["n_groups"] == 1 and stats["n_preads"] > 300 and stats["bytes_written"] > 100000
+    for ctg in ids:
+        assert os.path.getsize(os.path.join(str(tmp_path / "a"), ctg, "cns", "phased_blocks.fa")) > 1000
+
+
+@pytest.mark.parametrize("lanes,group_bases", [(1, 0), (2, 1), (2, 1_500_000), (3, 900_000)])
+def test_phase_contigs_groups_and_lanes(eng, tmp_path, lanes, group_bases):
+    """host buffers in, files out: one group, one contig per group, two contigs per group -- on 1 to 3 lanes"""
+    from falcon_unzip_amd import _lib
+    contigs, blob, off, read_ctg, names, ids = _make_job()
+    maps = _read_maps(names, read_ctg, ids)
+    exp, exp_recs = _legacy(eng, contigs, blob, off, read_ctg, names, ids, maps)
+    out = str(tmp_path / "o")
+    stats, recs = _lib.phase_contigs(eng, contigs, blob, off, read_ctg, ids, names=names, out_dir=out, read_maps=maps, n_lanes=lanes, group_bases=group_bases)
+    _check_tree(out, exp, ids)
+    assert np.array_equal(recs, exp_recs)
+    assert stats["n_reads"] == len(names) and stats["n_groups"] == (4 if group_bases == 1 else 1 if group_bases == 0 else stats["n_groups"])
+    assert stats["dp_cells"] > 0
+
+
+def test_phase_contigs_interleaved_reads_and_empty_contig(eng, tmp_path):
+    """reads of the contigs interleaved in the input (gathered per group), a contig without reads, no read maps, no names"""
+    from falcon_unzip_amd import _lib
+    contigs, blob, off, read_ctg, names, ids = _make_job(n_ctg=3)
+    perm = np.random.Generator(np.random.PCG64(5)).permutation(len(read_ctg))
+    reads = [blob[off[i]:off[i + 1]] for i in perm]
+    off2 = np.zeros(len(reads) + 1, np.int64)
+    off2[1:] = np.cumsum([len(r) for r in reads])
+    blob2, ctg2 = b"".join(reads), read_ctg[perm]
+    contigs.append(b"ACGT" * 2000)
+    ids.append("999999F")
+    job = _lib.align_job_raw(eng, contigs, blob2, off2, ctg2)
+    st1, _ = job.phase_write(ids, out_dir=str(tmp_path / "a"))
+    job.close()
+    st2, recs = _lib.phase_contigs(eng, contigs, blob2, off2, ctg2, ids, out_dir=str(tmp_path / "b"), n_lanes=2, group_bases=1)
+    assert len(recs) == 0 and st2["n_groups"] == 4
+    for ctg in ids:
+        for rel in FILES:
+            with open(os.path.join(str(tmp_path / "a"), ctg, rel), "rb") as f, open(os.path.join(str(tmp_path / "b"), ctg, rel), "rb") as g:
+                assert f.read() == g.read(), (ctg, rel)
+    assert os.path.getsize(os.path.join(str(tmp_path / "b"), "999999F", "phased_reads")) == 0
+    with open(os.path.join(str(tmp_path / "b"), ids[0], "het_call", "q_id_map"), "rb") as f:
+        assert f.readline().split()[1].startswith(b"read/")
+
+
+def test_two_engines_in_one_process(oracle):
+    """Two contexts on the same device, used alternately: each has its own block caches and staging; results of
+    batches of both stay valid side by side."""
+    from falcon_unzip_amd import _lib
+    e1, e2 = _lib.Engine(0), _lib.Engine(0)
+    c1, c2 = golden_util.Case(golden_util.cases()[0]), golden_util.Case(golden_util.cases()[1])
+    a1, a2 = _lib.parse_sam(c1.sam), _lib.parse_sam(c2.sam)
+    b1 = e1.batch([a1], [c1.ref_seq])
+    b2 = e2.batch([a2], [c2.ref_seq])
+    b1.run(_lib.STAGE_ALL)
+    b2.run(_lib.STAGE_ALL)
+    r1 = b1.results(copy=False)[0]
+    r2 = b2.results(copy=False)[0]                        # second batch: must not disturb the first one's borrowed views
+    b3 = e1.batch([a2], [c2.ref_seq])                     # a third batch on the first engine, run while b1's views are alive
+    b3.run(_lib.STAGE_ALL)
+    r3 = b3.results(copy=False)[0]
+    c1.check("variant_pos", _lib.format_variant_pos(r1.sites))
+    c1.check("atable", _lib.format_atable(r1.sites, r1.arows))
+    c2.check("variant_pos", _lib.format_variant_pos(r2.sites))
+    c2.check("atable", _lib.format_atable(r3.sites, r3.arows))
+    for b in (b1, b2, b3):
+        b.close()
+    e2.close()
+    b4 = e1.batch([a1], [c1.ref_seq])                     # the first engine keeps working after the second is gone
+    b4.run(_lib.STAGE_ALL)
+    c1.check("variant_map", _lib.format_variant_map(b4.result(0).sites, b4.result(0).vmap_qid))
+    b4.close()
+    e1.close()
