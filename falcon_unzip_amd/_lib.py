@@ -349,7 +349,7 @@ class Batch:
         p, n, cb = C.c_void_p(), C.c_size_t(), C.c_void_p()
         _check(load().fzp_batch_text(self.eng._p, self._p, what, C.byref(p), C.byref(n), C.byref(cb)))
         begin = _take(cb.value, self.n_ctg + 1, np.int64)
-        return _take_text(p.value, n.value), begin
+        return _take_text(p, n), begin
 
     def consensus(self) -> "Tigs":
         """K6: phased-pile consensus of every (block, phase); run(STAGE_ALL) first."""

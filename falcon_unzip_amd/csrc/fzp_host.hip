@@ -232,6 +232,8 @@ extern "C" int fzp_ctx_create(int device_id, unsigned flags, fzp_ctx **out) {
 
 extern "C" void fzp_ctx_destroy(fzp_ctx *ctx) {
     if (!ctx) return;
+    for (auto l : ctx->lanes) fzp_ctx_destroy(l);
+    ctx->lanes.clear();
     (void)fzp_bind(ctx);
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipStreamSynchronize(ctx->stream2);

@@ -160,6 +160,7 @@ int readmap_apply(const ReadMaps &m, const char *ctg_id, int32_t ctg_index, cons
     }
     // canonical order: ascending '%09d' string == ascending pread id below 10^9 (py2 dict order is unspecified)
     std::sort(out.begin(), out.end(), [](const auto &a, const auto &b) {
+        if (a.first < 1000000000LL && b.first < 1000000000LL) return a.first < b.first;      // nine digits: string order == numeric order
         char ka[32], kb[32];
         snprintf(ka, sizeof ka, "%09lld", a.first); snprintf(kb, sizeof kb, "%09lld", b.first);
         return strcmp(ka, kb) < 0;
@@ -255,6 +256,8 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
     const int32_t *qid_read = (const int32_t *)(pin + o_qr);
     out->ms_results += ms_since(t0);
     t0 = clk::now();
+    static const bool timing = getenv("FZP_PIPE_TIMING") != nullptr;
+    std::atomic<int64_t> us_names{0}, us_fmt{0}, us_map{0}, us_write{0};
     // ---- per contig: the small files on host threads, all files written
     int T = o->n_threads > 0 ? o->n_threads : (int)std::max(1u, std::thread::hardware_concurrency());
     T = std::min(T, std::max(1, nc));
@@ -269,6 +272,7 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
             const int c = next.fetch_add(1);
             if (c >= nc || rcs[(size_t)t] != FZP_OK) break;
             const char *ctg = nm->ctg_id[c];
+            auto tq = clk::now();
             // q_id table of the contig: aligned reads in (POS, read) order
             const int64_t nq = b->h_qid_off[(size_t)c + 1] - b->h_qid_off[(size_t)c];
             const int32_t *qr = qid_read + b->h_slot_off[(size_t)c];
@@ -280,6 +284,7 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
                 else { char tt[40]; snprintf(tt, sizeof tt, "read/%lld", (long long)r); qn += tt; }
                 qoff[(size_t)q + 1] = (int64_t)qn.size();
             }
+            us_names += (int64_t)(ms_since(tq) * 1e3); tq = clk::now();
             const int64_t s0 = ra.site_begin[c], s1 = ra.site_begin[c + 1], p0 = ra.pvar_begin[c], p1 = ra.pvar_begin[c + 1], r0 = ra.pread_begin[c], r1 = ra.pread_begin[c + 1];
             char *txt[3] = {nullptr, nullptr, nullptr};
             size_t len[3] = {0, 0, 0};
@@ -293,12 +298,14 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
                 for (int64_t q = 0; q < nq; q++) { tb.puti(q); tb.s.push_back(' '); tb.s.append(qn, (size_t)qoff[(size_t)q], (size_t)(qoff[(size_t)q + 1] - qoff[(size_t)q])); tb.s.push_back('\n'); }   // phasing.py:132-134
                 qmap.swap(tb.s);
             }
+            us_fmt += (int64_t)(ms_since(tq) * 1e3); tq = clk::now();
             std::string r2p_text;
             bool have_r2p = false;
             if (rc == FZP_OK && maps) {
                 rc = readmap_apply(*maps, ctg, ctg_index ? ctg_index[c] : c, ra.all.preads + r0, r1 - r0, qoff, qn, recs[(size_t)c], r2p_text, errs[(size_t)t]);
                 have_r2p = rc == FZP_OK;
             } else if (rc != FZP_OK) errs[(size_t)t] = fzp_last_error();
+            us_map += (int64_t)(ms_since(tq) * 1e3); tq = clk::now();
             if (rc == FZP_OK && o->out_dir) {
                 const std::string base = out_dir + "/" + ctg;
                 bool ok = mkdir_p(base + "/het_call") && mkdir_p(base + "/g_atable") && mkdir_p(base + "/get_phased_blocks");
@@ -313,6 +320,7 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
                 }
                 if (!ok && rc == FZP_OK) { rc = FZP_EINVAL; errs[(size_t)t] = "cannot write under " + base + ": " + strerror(errno); }
             }
+            us_write += (int64_t)(ms_since(tq) * 1e3);
             for (auto p : txt) free(p);
             if (rc != FZP_OK) rcs[(size_t)t] = rc;
         }
@@ -326,6 +334,8 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
     for (int t = 0; t < T; t++) if (rcs[(size_t)t] != FZP_OK) { fzp_set_error("%s", errs[(size_t)t].c_str()); return rcs[(size_t)t]; }
     for (int c = 0; c < nc; c++) r2p.insert(r2p.end(), recs[(size_t)c].begin(), recs[(size_t)c].end());
     out->ms_text += ms_since(t0);
+    if (timing) fprintf(stderr, "[fzp_pipe] host section %.2f ms on %d threads; summed over contigs: names %.2f fmt %.2f readmap %.2f write %.2f ms\n", ms_since(t0), T,
+                        us_names.load() / 1e3, us_fmt.load() / 1e3, us_map.load() / 1e3, us_write.load() / 1e3);
     out->bytes_written += bytes.load();
     out->n_groups += 1;
     out->n_rec += b->n_rec; out->n_sites += b->n_sites; out->n_rows += b->n_rows; out->n_arows += b->n_arows; out->n_pvars += b->n_pvars; out->n_preads += b->n_preads;
@@ -398,9 +408,14 @@ extern "C" int fzp_phase_contigs(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *con
     std::vector<std::vector<std::vector<fzp_r2p>>> r2p_g(1);
     r2p_g[0].resize(groups.size());
     const int device = ctx->device;
+    while ((int)ctx->lanes.size() < lanes - 1) {           // the extra lanes' contexts live as long as `ctx` (warm caches on the next call)
+        fzp_ctx *lc = nullptr;
+        FZP_TRY(fzp_ctx_create(device, 0, &lc));
+        ctx->lanes.push_back(lc);
+    }
     auto lane = [&](int li) {
-        fzp_ctx *lc = ctx;
-        if (li > 0 && fzp_ctx_create(device, 0, &lc) != FZP_OK) { rcs[(size_t)li] = FZP_EDEVICE; errs[(size_t)li] = fzp_last_error(); return; }
+        fzp_ctx *lc = li == 0 ? ctx : ctx->lanes[(size_t)li - 1];
+        if (fzp_bind(lc) != FZP_OK) { rcs[(size_t)li] = FZP_EDEVICE; errs[(size_t)li] = fzp_last_error(); return; }
         fzp_pipe_out &po = outs[(size_t)li];
         memset(&po, 0, sizeof po);
         for (;;) {
@@ -433,16 +448,20 @@ extern "C" int fzp_phase_contigs(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *con
                 abs_off = g_off;
             } else abs_off.assign(1, 0);
             std::string g_names;
-            if (nm->names && nm->name_off)
-                for (int64_t k = 0; k < gr; k++) { const int64_t r = r_idx[(size_t)k]; g_names.append(nm->names + nm->name_off[r], (size_t)(nm->name_off[r + 1] - nm->name_off[r])); g_noff[(size_t)k + 1] = (int64_t)g_names.size(); }
+            for (int64_t k = 0; k < gr; k++) {        // names by the caller's read index ("read/<index>" when none were given)
+                const int64_t r = r_idx[(size_t)k];
+                if (nm->names && nm->name_off) g_names.append(nm->names + nm->name_off[r], (size_t)(nm->name_off[r + 1] - nm->name_off[r]));
+                else { char tt[40]; snprintf(tt, sizeof tt, "read/%lld", (long long)r); g_names += tt; }
+                g_noff[(size_t)k + 1] = (int64_t)g_names.size();
+            }
             fzp_alnjob *job = nullptr;
             int rc = fzp_align_create(lc, gc, ctg_seq + G.c0, ctg_len + G.c0, gr, g_ctg.data(), abs_off.data(), g_seq, &o.align, &job);
             po.ms_upload += ms_since(t0);
             if (rc == FZP_OK) {
                 fzp_names gn;
                 gn.n_ctg = gc; gn.ctg_id = nm->ctg_id + G.c0;
-                gn.name_off = nm->names && nm->name_off ? g_noff.data() : nullptr;
-                gn.names = nm->names && nm->name_off ? g_names.data() : nullptr;
+                gn.name_off = g_noff.data();
+                gn.names = g_names.data();
                 std::vector<int32_t> gi;
                 for (int c = G.c0; c < G.c1; c++) gi.push_back(o.ctg_index ? o.ctg_index[c] : c);
                 rc = job_phase_write(lc, job, &gn, &o, have_maps ? &maps : nullptr, gi.data(), &po, r2p_g[0][g]);
@@ -456,7 +475,6 @@ extern "C" int fzp_phase_contigs(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *con
             po.n_reads += gr;
             if (rc != FZP_OK) { rcs[(size_t)li] = rc; break; }
         }
-        if (li > 0) fzp_ctx_destroy(lc);
     };
     {
         std::vector<std::thread> th;

@@ -50,6 +50,7 @@
  *             after a RIGHT move), then the other gap.
  */
 #define _GNU_SOURCE
+#include <pthread.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -438,5 +439,63 @@ int orc_align_reads(const uint8_t *ctg_ascii, int64_t ctg_len, int64_t n_reads, 
     free(ix.kp); free(codes);
     if (!cig.v) cig.v = (uint32_t *)malloc(4);
     *cigar_out = cig.v;
+    return 0;
+}
+
+/* ---- the same over several host threads (the CPU baseline of bench.py uses every core): reads are dealt round-robin,
+ * results are identical to orc_align_reads. */
+typedef struct {
+    const ctg_index *ix; const orc_align_params *P; int64_t n_reads; const int64_t *read_off; const uint8_t *read_ascii;
+    orc_aln_summary *out; u32vec *cigs; int t, T;
+} mt_arg;
+static void *mt_worker(void *vp) {
+    mt_arg *a = (mt_arg *)vp;
+    for (int64_t r = a->t; r < a->n_reads; r += a->T) {
+        int64_t n = a->read_off[r + 1] - a->read_off[r];
+        uint8_t *fwd = (uint8_t *)malloc((size_t)(n ? n : 1));
+        for (int64_t i = 0; i < n; i++) fwd[i] = (uint8_t)code_of(a->read_ascii[a->read_off[r] + i]);
+        align_one(a->ix, fwd, n, a->P, &a->out[r], &a->cigs[r]);
+        free(fwd);
+    }
+    return NULL;
+}
+int orc_align_reads_mt(const uint8_t *ctg_ascii, int64_t ctg_len, int64_t n_reads, const int64_t *read_off,
+                       const uint8_t *read_ascii, const orc_align_params *P, orc_aln_summary *out,
+                       uint32_t **cigar_out, int64_t *cig_off, int n_threads) {
+    if (P->kmer < 8 || P->kmer > 16 || P->seed_stride < 1) return -1;
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > 256) n_threads = 256;
+    ctg_index ix;
+    uint8_t *codes = (uint8_t *)malloc((size_t)(ctg_len ? ctg_len : 1));
+    for (int64_t i = 0; i < ctg_len; i++) codes[i] = (uint8_t)code_of(ctg_ascii[i]);
+    ix.codes = codes; ix.len = ctg_len;
+    {
+        int64_t nk = ctg_len >= P->kmer ? ctg_len - P->kmer + 1 : 0;
+        ix.n = (nk + 1) / 2;
+        ix.kp = (kp_t *)malloc((size_t)(ix.n ? ix.n : 1) * sizeof(kp_t));
+        for (int64_t q = 0; q < ix.n; q++) {
+            int64_t p = 2 * q;
+            uint32_t kf = kmer_at(codes, p, P->kmer), kr = rc_of(kf, P->kmer);
+            ix.kp[q].key = kr < kf ? kr : kf;
+            ix.kp[q].pos = (int32_t)((p << 1) | (kr < kf ? 1 : 0));
+        }
+    }
+    qsort(ix.kp, (size_t)ix.n, sizeof(kp_t), cmp_kp);
+    u32vec *cigs = (u32vec *)calloc((size_t)(n_reads ? n_reads : 1), sizeof(u32vec));
+    pthread_t th[256];
+    mt_arg args[256];
+    for (int t = 0; t < n_threads; t++) {
+        mt_arg a = {&ix, P, n_reads, read_off, read_ascii, out, cigs, t, n_threads};
+        args[t] = a;
+        pthread_create(&th[t], NULL, mt_worker, &args[t]);
+    }
+    for (int t = 0; t < n_threads; t++) pthread_join(th[t], NULL);
+    int64_t total = 0;
+    cig_off[0] = 0;
+    for (int64_t r = 0; r < n_reads; r++) { total += cigs[r].n; cig_off[r + 1] = total; }
+    uint32_t *all = (uint32_t *)malloc((size_t)(total ? total : 1) * 4);
+    for (int64_t r = 0; r < n_reads; r++) { if (cigs[r].n) memcpy(all + cig_off[r], cigs[r].v, (size_t)cigs[r].n * 4); free(cigs[r].v); }
+    free(cigs); free(ix.kp); free(codes);
+    *cigar_out = all;
     return 0;
 }

@@ -121,8 +121,9 @@ class AlignParams(C.Structure):
                 ("gap", C.c_int32), ("min_seed_hits", C.c_int32), ("min_pct_identity", C.c_int32), ("reserved", C.c_int32 * 9)]
 
 
-def align_reads(orc, ctg: bytes, reads, params=None):
-    """CPU twin of K1 (oracle/align_oracle.c): -> (summaries ndarray, list of cigar word arrays)."""
+def align_reads(orc, ctg: bytes, reads, params=None, n_threads=1):
+    """CPU twin of K1 (oracle/align_oracle.c): -> (summaries ndarray, list of cigar word arrays).  n_threads > 1: the same
+    results from orc_align_reads_mt (reads dealt to host threads)."""
     import numpy as np
     lib = orc.lib
     P = AlignParams()
@@ -136,10 +137,16 @@ def align_reads(orc, ctg: bytes, reads, params=None):
     out = np.zeros(n, _aln_dtype())
     cig_off = np.zeros(n + 1, np.int64)
     cp = C.c_void_p()
-    f = lib.orc_align_reads
-    f.restype = C.c_int
-    f.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p]
-    rc = f(ctg, len(ctg), n, off.ctypes.data, blob, C.addressof(P), out.ctypes.data, C.byref(cp), cig_off.ctypes.data)
+    if n_threads > 1:
+        f = lib.orc_align_reads_mt
+        f.restype = C.c_int
+        f.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p, C.c_int]
+        rc = f(ctg, len(ctg), n, off.ctypes.data, blob, C.addressof(P), out.ctypes.data, C.byref(cp), cig_off.ctypes.data, n_threads)
+    else:
+        f = lib.orc_align_reads
+        f.restype = C.c_int
+        f.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p]
+        rc = f(ctg, len(ctg), n, off.ctypes.data, blob, C.addressof(P), out.ctypes.data, C.byref(cp), cig_off.ctypes.data)
     if rc:
         raise OracleError("orc_align_reads rc=%d" % rc)
     total = int(cig_off[-1])

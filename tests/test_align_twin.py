@@ -81,3 +81,15 @@ def test_twin_scores_equal_unbanded_dp(oracle):
             nt = min(L - c_a, len(q) + len(q) // 4 + 64)
             found = found or _full_matrix_best(q, hap0[c_a:c_a + nt]) == int(s["score"][r])
         assert found, (r, s[r])
+
+
+def test_threaded_twin_equals_single_thread(oracle):
+    from falcon_unzip_amd import sim
+    rng = np.random.Generator(np.random.PCG64(35))
+    hap0, hap1, _ = sim.make_diploid(200000, rng)
+    reads = sim.simulate_reads(hap0, hap1, 40, 8000, rng, strand_mix=0.5)
+    ctg = sim.codes_to_str(hap0).encode()
+    raw = [sim.codes_to_str(r.raw_seq_codes()).encode() for r in reads]
+    a, ca = oracle_lib.align_reads(oracle, ctg, raw)
+    b, cb = oracle_lib.align_reads(oracle, ctg, raw, n_threads=4)
+    assert a.tobytes() == b.tobytes() and all(np.array_equal(x, y) for x, y in zip(ca, cb))

@@ -36,4 +36,22 @@ def test_two_ranks_share_one_gpu():
         assert d["roofline"]["bound"] == "hbm" and d["roofline"]["launches"] >= 2
         assert d["aligned_frac"] > 0.98
     assert one["stage_counts"]["r2p_records"] == 300 and two["stage_counts"]["r2p_records"] == 600      # the all-gather saw both shards
-    assert two["config"]["reads_per_gpu"] == one["config"]["reads_per_gpu"] == 300
+    assert two["config"]["reads_per_gpu"] == one["config"]["reads_per_gpu"] == 300 and two["config"]["reads_total"] == 600
+    assert one["stage_counts"]["bytes_written"] > 10000 and one["end_to_end"]["reads_per_s"] > 0 and two["end_to_end"] is None
+    assert len(two["rank_load"]) == 2
+
+
+def test_strong_scaling_mode_two_ranks():
+    """--strong: a fixed set of uneven contigs dealt LPT over the ranks (BASELINE configs[2] shape); value = all reads / slowest rank"""
+    import subprocess
+    env = dict(os.environ, FZP_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    args = ["--strong", "--contigs", "5", "--contig-len", "300000", "--reads-per-contig", "100", "--read-len", "8000", "--window", "120000", "--steps", "1", "--warmup", "1",
+            "--no-cpu-baseline", "--gen-workers", "1"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29743",
+           os.path.join(REPO, "bench.py"), "--gpus", "2"] + args
+    out = subprocess.check_output(cmd, env=env, cwd=REPO, stderr=subprocess.DEVNULL, timeout=600).decode()
+    d = json.loads([l for l in out.splitlines() if l.startswith("{")][0])
+    assert d["scaling"] == "strong" and d["n_gpus"] == 2
+    loads = [r["reads"] for r in d["rank_load"]]
+    assert sum(loads) == d["config"]["reads_total"] == d["stage_counts"]["r2p_records"] and min(loads) > 0
+    assert abs(loads[0] - loads[1]) <= 0.4 * sum(loads)
