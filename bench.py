@@ -196,6 +196,28 @@ def main():
         else:
             dist.init_process_group(backend=backend)
     eng = _lib.Engine(dev_index)
+    # the exchange step: the library's own RCCL all-gather (fzp_allgather_rid_to_phase) when the ranks sit on their own GPUs;
+    # torch.distributed's all_gather otherwise (gloo dry runs) or if RCCL cannot be brought up identically on every rank
+    comm = None
+    if world > 1 and backend == "nccl" and os.environ.get("FZP_BENCH_GATHER", "cabi") == "cabi":
+        ok = 1
+        try:
+            box = [_lib.comm_unique_id() if rank == 0 else None]
+        except Exception:
+            box, ok = [None], 0
+        dist.broadcast_object_list(box, src=0)
+        if box[0] is None:
+            ok = 0
+        if ok:
+            try:
+                comm = _lib.Comm(eng, rank, world, box[0])
+            except Exception:
+                ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=coll_dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0 and comm is not None:
+            comm.close()
+            comm = None
     out_root = tempfile.mkdtemp(prefix="fzp_bench_r%d_" % rank, dir=args.out_root)
     t_up = time.perf_counter()
     job = _lib.align_job_raw(eng, contigs, blob, off, read_ctg)     # upload + 2-bit pack: inputs now resident in HBM
@@ -222,7 +244,7 @@ def main():
         st, recs = job.phase_write(ids, names=name_tab, out_dir=out_dir, read_maps=maps, ctg_index=mine, consensus=args.with_consensus)
         recs["arid"] += arid_base                      # the read_map files of a rank number its preads from 0: make the ids job-wide
         t_b = time.perf_counter()
-        allr = fdist.allgather_r2p(recs, device=coll_dev if world > 1 else None)
+        allr = comm.allgather_r2p(recs) if comm is not None else fdist.allgather_r2p(recs, device=coll_dev if world > 1 else None)
         t_c = time.perf_counter()
         stats.update({k: st[k] for k in ("n_aligned", "n_rec", "n_sites", "n_rows", "n_arows", "n_pvars", "n_preads", "bytes_written")})
         stats["reads_phased"] = int((recs["block"] != -1).sum())
@@ -321,6 +343,7 @@ def main():
             "kernel_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in sorted(prof.items())},
             "host_wall_ms_per_step": dict({k: round(v / args.steps * 1e3, 3) for k, v in host_t.items()}, **{k[3:]: round(v / args.steps, 3) for k, v in sect.items()}),
             "rank_load": rank_load,
+            "gather": "fzp_allgather_rid_to_phase (RCCL, C-ABI)" if comm is not None else ("torch.distributed all_gather (%s)" % backend if world > 1 else "none (1 rank)"),
             "end_to_end": e2e,
             "roofline": {"bound": "hbm", "kernel": "k1_sw", "achieved": round(cells_per_launch * SW_BYTES_PER_CELL / (sw_avg_ms * 1e-3) / 1e9, 2) if sw_avg_ms else 0.0,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -335,6 +358,8 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(contigs, blob, off, read_ctg, ids, eng, max(1, min(args.cpu_sample_contigs, len(contigs))))
         print(json.dumps(out))
+    if comm is not None:
+        comm.close()
     eng.close()
     shutil.rmtree(out_root, ignore_errors=True)
     if world > 1:

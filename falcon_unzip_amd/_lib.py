@@ -172,6 +172,10 @@ def load():
         "fzp_job_phase_write": (C.c_int, [VP, VP, VP, VP, VP]),
         "fzp_phase_contigs": (C.c_int, [VP, I32, VP, VP, I64, VP, VP, VP, VP, VP, VP]),
         "fzp_pipe_out_free": (None, [VP]),
+        "fzp_comm_unique_id": (C.c_int, [VP]),
+        "fzp_comm_create": (C.c_int, [VP, C.c_int, C.c_int, VP, PP]),
+        "fzp_comm_destroy": (None, [VP]),
+        "fzp_allgather_rid_to_phase": (C.c_int, [VP, VP, I64, PP, PI64]),
         "fzp_align_alnset": (C.c_int, [VP, VP, I32, VP, CP, PP, PP]),
         "fzp_align_to_batch": (C.c_int, [VP, VP, PP]),
         "fzp_align_destroy": (None, [VP, VP]),
@@ -618,6 +622,37 @@ def phase_contigs(eng, contigs, read_blob: bytes, read_off, read_ctg, ctg_ids, n
     out = PipeOut()
     _check(lib.fzp_phase_contigs(eng._p, nc, cptr, clen, nr, _ptr(rc), _ptr(read_off), read_blob, C.byref(nm), C.byref(opts), C.byref(out)))
     return _pipe_result(out)
+
+
+def comm_unique_id() -> bytes:
+    """RCCL unique id (rank 0 creates it and hands it to the other ranks)"""
+    buf = C.create_string_buffer(128)
+    _check(load().fzp_comm_unique_id(buf))
+    return buf.raw
+
+
+class Comm:
+    """fzp_comm: this rank's RCCL communicator for the rid_to_phase all-gather (one process per GPU)."""
+
+    def __init__(self, eng, rank, world, uid: bytes):
+        self._p = None
+        p = C.c_void_p()
+        self._keep = C.create_string_buffer(uid, 128)
+        _check(load().fzp_comm_create(eng._p, rank, world, self._keep, C.byref(p)))
+        self._p, self.eng = p.value, eng
+
+    def allgather_r2p(self, local):
+        local = np.ascontiguousarray(local, dtype=R2P)
+        p, n = C.c_void_p(), C.c_int64()
+        _check(load().fzp_allgather_rid_to_phase(self._p, _ptr(local), len(local), C.byref(p), C.byref(n)))
+        return _take(p.value, n.value, R2P)
+
+    def close(self):
+        if self._p:
+            load().fzp_comm_destroy(self._p)
+            self._p = None
+
+    __del__ = close
 
 
 def format_sam(aln: AlnSet, ctg_id: str, flags=None):

@@ -1,0 +1,137 @@
+// fzp_comm.hip -- the ONE exchange step of the multi-GPU path behind the C-ABI: all-gather of rid_to_phase records over RCCL.
+//
+// Reference: get_rid_to_phase_all (falcon_unzip/unzip.py:303-314) concatenates every rid_to_phase.<ctg> in sorted-path
+// order.  Here every rank holds the fixed 16-byte records of its contigs; one ncclAllGather of the counts, one of the
+// payload padded to the largest count, then every rank orders the records by (contig index, pread id) = the
+// order of rid_to_phase.all.  RCCL is loaded at run time (librccl.so.1, the ROCm one): the library itself carries no link
+// dependency on it, and a host in any language reaches the collective through these four calls.  falcon_unzip_amd/dist.py
+// does the same over torch.distributed (gloo in CPU tests).
+#include <dlfcn.h>
+
+#include <algorithm>
+
+#include "fzp_common.h"
+
+namespace {
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef int ncclResult_t;
+enum { ncclUint8 = 1, ncclUint64 = 5 };   // nccl.h ncclDataType_t
+struct Rccl {
+    void *h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl *rccl() {
+    static Rccl r;
+    static bool tried = false;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!tried) {
+        tried = true;
+        const char *names[] = {getenv("FZP_RCCL_LIB"), "librccl.so.1", "librccl.so"};
+        for (const char *n : names) {
+            if (!n) continue;
+            r.h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            if (r.h) break;
+        }
+        if (r.h) {
+            r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.h, "ncclGetUniqueId");
+            r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.h, "ncclCommInitRank");
+            r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.h, "ncclCommDestroy");
+            r.AllGather = (decltype(r.AllGather))dlsym(r.h, "ncclAllGather");
+            r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.h, "ncclGetErrorString");
+            if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather) { dlclose(r.h); r.h = nullptr; }
+        }
+    }
+    return r.h ? &r : nullptr;
+}
+int nccl_fail(Rccl *R, const char *what, ncclResult_t rc) {
+    fzp_set_error("%s: %s", what, R && R->GetErrorString ? R->GetErrorString(rc) : "RCCL error");
+    return FZP_EDEVICE;
+}
+}  // namespace
+
+struct fzp_comm {
+    fzp_ctx *ctx = nullptr;
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+};
+
+extern "C" int fzp_comm_unique_id(char id[FZP_COMM_ID_BYTES]) {
+    Rccl *R = rccl();
+    if (!R) { fzp_set_error("RCCL (librccl.so.1) could not be loaded: %s", dlerror() ? dlerror() : "not found"); return FZP_ENODEVICE; }
+    ncclUniqueId u;
+    ncclResult_t rc = R->GetUniqueId(&u);
+    if (rc) return nccl_fail(R, "ncclGetUniqueId", rc);
+    memcpy(id, u.internal, sizeof u.internal);
+    return FZP_OK;
+}
+
+extern "C" int fzp_comm_create(fzp_ctx *ctx, int rank, int world, const char id[FZP_COMM_ID_BYTES], fzp_comm **out) {
+    if (!ctx || !out || !id || world < 1 || rank < 0 || rank >= world) { fzp_set_error("fzp_comm_create: bad arguments"); return FZP_EINVAL; }
+    *out = nullptr;
+    Rccl *R = rccl();
+    if (!R) { fzp_set_error("RCCL (librccl.so.1) could not be loaded"); return FZP_ENODEVICE; }
+    FZP_TRY(fzp_bind(ctx));
+    ncclUniqueId u;
+    memcpy(u.internal, id, sizeof u.internal);
+    fzp_comm *c = new fzp_comm();
+    c->ctx = ctx; c->rank = rank; c->world = world;
+    ncclResult_t rc = R->CommInitRank(&c->comm, world, u, rank);
+    if (rc) { delete c; return nccl_fail(R, "ncclCommInitRank", rc); }
+    *out = c;
+    return FZP_OK;
+}
+
+extern "C" void fzp_comm_destroy(fzp_comm *c) {
+    if (!c) return;
+    Rccl *R = rccl();
+    if (R && c->comm) { (void)fzp_bind(c->ctx); (void)hipStreamSynchronize(c->ctx->stream); (void)R->CommDestroy(c->comm); }
+    delete c;
+}
+
+extern "C" int fzp_allgather_rid_to_phase(fzp_comm *c, const fzp_r2p *local, int64_t n_local, fzp_r2p **all, int64_t *n_all) {
+    if (!c || !all || !n_all || n_local < 0 || (n_local && !local)) { fzp_set_error("fzp_allgather_rid_to_phase: bad arguments"); return FZP_EINVAL; }
+    Rccl *R = rccl();
+    if (!R) { fzp_set_error("RCCL could not be loaded"); return FZP_ENODEVICE; }
+    fzp_ctx *ctx = c->ctx;
+    FZP_TRY(fzp_bind(ctx));
+    hipStream_t st = ctx->stream;
+    const int W = c->world;
+    // 1. counts
+    DevBuf<uint64_t> d_cnt, d_cnts;
+    FZP_TRY(d_cnt.alloc(1)); FZP_TRY(d_cnts.alloc((size_t)W));
+    const uint64_t mine = (uint64_t)n_local;
+    FZP_HIP(hipMemcpyAsync(d_cnt.p, &mine, 8, hipMemcpyHostToDevice, st));
+    ncclResult_t rc = R->AllGather(d_cnt.p, d_cnts.p, 1, ncclUint64, c->comm, st);
+    if (rc) return nccl_fail(R, "ncclAllGather(counts)", rc);
+    std::vector<uint64_t> cnts((size_t)W);
+    FZP_TRY(d_cnts.download(cnts.data(), (size_t)W, st));
+    FZP_HIP(hipStreamSynchronize(st));
+    uint64_t mx = 1, total = 0;
+    for (auto v : cnts) { mx = std::max(mx, v); total += v; }
+    // 2. payload, padded to the largest shard
+    DevBuf<fzp_r2p> d_loc, d_all;
+    FZP_TRY(d_loc.alloc((size_t)mx)); FZP_TRY(d_all.alloc((size_t)mx * (size_t)W));
+    FZP_HIP(hipMemsetAsync(d_loc.p, 0, (size_t)mx * sizeof(fzp_r2p), st));
+    if (n_local) FZP_HIP(hipMemcpyAsync(d_loc.p, local, (size_t)n_local * sizeof(fzp_r2p), hipMemcpyHostToDevice, st));
+    rc = R->AllGather(d_loc.p, d_all.p, (size_t)mx * sizeof(fzp_r2p), ncclUint8, c->comm, st);
+    if (rc) return nccl_fail(R, "ncclAllGather(records)", rc);
+    fzp_r2p *out = (fzp_r2p *)malloc((total ? total : 1) * sizeof(fzp_r2p));
+    if (!out) return FZP_ENOMEM;
+    size_t at = 0;
+    for (int r = 0; r < W; r++) {
+        if (cnts[(size_t)r] && hipMemcpyAsync(out + at, d_all.p + (size_t)r * mx, (size_t)cnts[(size_t)r] * sizeof(fzp_r2p), hipMemcpyDeviceToHost, st) != hipSuccess) { free(out); fzp_set_error("D2H copy failed"); return FZP_EDEVICE; }
+        at += (size_t)cnts[(size_t)r];
+    }
+    if (hipStreamSynchronize(st) != hipSuccess) { free(out); fzp_set_error("all-gather: stream failed"); return FZP_EDEVICE; }
+    // 3. the order of rid_to_phase.all: sorted per-contig paths (unzip.py:306-307) = contig index, then pread id
+    std::sort(out, out + total, [](const fzp_r2p &a, const fzp_r2p &b) { return a.ctg != b.ctg ? a.ctg < b.ctg : a.arid < b.arid; });
+    *all = out;
+    *n_all = (int64_t)total;
+    return FZP_OK;
+}

@@ -314,6 +314,18 @@ int fzp_phase_contigs(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *const *ctg_seq
                       const int64_t *read_off, const uint8_t *read_seq, const fzp_names *names, const fzp_pipe_opts *opts, fzp_pipe_out *out);
 void fzp_pipe_out_free(fzp_pipe_out *o);
 
+/* ---- the one exchange step of the multi-GPU path (get_rid_to_phase_all, unzip.py:303-314): every rank contributes the
+ * rid_to_phase records of its contigs, every rank receives all of them ordered by (contig index, pread id) -- the order of
+ * rid_to_phase.all.  Two ncclAllGather calls over RCCL (counts, then the payload padded to the largest shard) on the ctx's
+ * stream.  RCCL (librccl.so.1) is loaded at run time; FZP_ENODEVICE if it is missing.  One process per GPU: rank 0 obtains an id
+ * (fzp_comm_unique_id), hands it to the other ranks by any means, every rank calls fzp_comm_create. */
+#define FZP_COMM_ID_BYTES 128
+typedef struct fzp_comm fzp_comm;
+int fzp_comm_unique_id(char id[FZP_COMM_ID_BYTES]);
+int fzp_comm_create(fzp_ctx *ctx, int rank, int world, const char id[FZP_COMM_ID_BYTES], fzp_comm **out);
+void fzp_comm_destroy(fzp_comm *c);
+int fzp_allgather_rid_to_phase(fzp_comm *c, const fzp_r2p *local, int64_t n_local, fzp_r2p **all /* fzp_free */, int64_t *n_all);
+
 /* ---- BAM emitter / reader ("next" row n1).  The reference's blasr task writes <ctg>_sorted.bam + index
  * (unzip.py:86-91) and make_het_call reads it through `samtools view <bam> <ctg>` (phasing.py:27).
  * fzp_format_bam: coordinate-sorted BAM (BGZF, EOF marker) of an alnset and, if bai != NULL, its .bai; MAPQ 254,
