@@ -141,3 +141,47 @@ def test_chunked_traceback_budget_matches(eng, monkeypatch):
     a2, _ = job.alnset(0)
     assert _lib.format_sam(a2, "x") == _lib.format_sam(a_ref, "x")
     job.close()
+
+
+def test_cfg5_slice_streams_through_groups(tmp_path):
+    """BASELINE configs[4] at 1/10 scale: ~36 k reads x 15 kb against 13.6 Mb of contigs of 1-10 Mb at 40x, through
+    fzp_phase_contigs: contig groups on two lanes, K1..K6, every file written.  Size-independent properties: every read aligned and
+    accounted for in rid_to_phase, >= 99 % phased, the files of every contig present and consistent with the counts, and the same
+    bytes whether the groups run on one lane or two."""
+    import hashlib
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import run_cfg5
+
+    def digest(root):
+        h = hashlib.sha256()
+        n = 0
+        for d, _, files in sorted(os.walk(root)):
+            for f in sorted(files):
+                with open(os.path.join(d, f), "rb") as fh:
+                    h.update(os.path.relpath(os.path.join(d, f), root).encode())
+                    h.update(fh.read())
+                n += 1
+        return h.hexdigest(), n
+    res = {}
+    for lanes in (2, 1):
+        r = run_cfg5.run(scale=0.1, lanes=lanes, workers=1, out_root=str(tmp_path), keep=True)
+        res[lanes] = (r, digest(r["out_dir"]))
+    r, (dg, nfiles) = res[2]
+    st = r["stats"]
+    assert st["n_groups"] >= 2 and st["n_reads"] == st["n_aligned"] == r["r2p_records"] > 30000
+    assert r["reads_phased"] >= 0.99 * st["n_reads"] and st["n_preads"] >= r["reads_phased"]
+    assert nfiles == 8 * len([d for d in os.listdir(r["out_dir"])]) and r["peak_hbm_gb"] < 120
+    assert st["n_sites"] > 20000 and st["n_pvars"] <= st["n_sites"] and st["n_rows"] > 30 * st["n_sites"]
+    assert res[1][1] == (dg, nfiles)                       # lanes only change the schedule
+    ctg = sorted(os.listdir(r["out_dir"]))[0]
+    base = os.path.join(r["out_dir"], ctg)
+    with open(os.path.join(base, "phased_reads")) as f:
+        rows = [l.split() for l in f]
+    assert all(x[1] == ctg and abs(int(x[4]) - int(x[5])) > 1 for x in rows)
+    with open(os.path.join(base, "rid_to_phase.%s" % ctg)) as f:
+        r2p = [l.split() for l in f]
+    assert len(r2p) == len(set(x[0] for x in r2p)) and sum(x[2] != "-1" for x in r2p) == len(set(x[6] for x in rows))
+    with open(os.path.join(base, "cns", "phased_blocks.fa")) as f:
+        assert f.read().count(">") >= 2
