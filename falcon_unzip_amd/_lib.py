@@ -184,6 +184,9 @@ def load():
         "fzp_format_tigs": (C.c_int, [VP, I32, CP, PP, PSZ]),
         "fzp_format_bam": (C.c_int, [VP, CP, I64, VP, PP, PSZ, PP, PSZ]),
         "fzp_bam_to_sam": (C.c_int, [CP, SZ, CP, PP, PSZ]),
+        "fzp_bam_open": (C.c_int, [CP, SZ, PP]),
+        "fzp_bam_view_free": (None, [VP]),
+        "fzp_bam_write": (C.c_int, [CP, SZ, I32, CP, SZ, I32, VP, VP, PP, PSZ]),
         "fzp_ovl_parse": (C.c_int, [VP, I32, VP, VP, CP, SZ, PP]),
         "fzp_ovlset_free": (None, [VP]),
         "fzp_ovl_n_lines": (I64, [VP]),
@@ -729,6 +732,43 @@ def bam_to_sam(bam: bytes, region=None):
 
 
 # ---------------------------------------------------------------------------- overlap filter (fzp_ovl_*)
+class BamViewStruct(C.Structure):
+    _fields_ = [("header_text", C.c_void_p), ("header_len", C.c_size_t), ("n_ref", C.c_int32), ("ref_block", C.c_void_p), ("ref_block_len", C.c_size_t),
+                ("n_rec", C.c_int64), ("rec_off", C.c_void_p), ("records", C.c_void_p), ("records_len", C.c_size_t), ("name_off", C.c_void_p), ("names", C.c_void_p)]
+
+
+class BamView:
+    """Every record of a BAM file as raw bytes + read names (fzp_bam_open)."""
+
+    def __init__(self, bam: bytes):
+        p = C.c_void_p()
+        _check(load().fzp_bam_open(bam, len(bam), C.byref(p)))
+        v = C.cast(p, C.POINTER(BamViewStruct)).contents
+        self.header = C.string_at(v.header_text, v.header_len)
+        self.n_ref = int(v.n_ref)
+        self.ref_block = C.string_at(v.ref_block, v.ref_block_len)
+        n = int(v.n_rec)
+        self.rec_off = np.frombuffer(C.string_at(v.rec_off, (n + 1) * 8), dtype=np.int64).copy()
+        self.records = C.string_at(v.records, v.records_len)
+        noff = np.frombuffer(C.string_at(v.name_off, (n + 1) * 8), dtype=np.int64)
+        names = C.string_at(v.names, int(noff[-1]))
+        self.names = [names[noff[i]:noff[i + 1]] for i in range(n)]
+        load().fzp_bam_view_free(p)
+
+    def record(self, i) -> bytes:
+        return self.records[self.rec_off[i]:self.rec_off[i + 1]]
+
+
+def bam_write(header: bytes, n_ref: int, ref_block: bytes, parts) -> bytes:
+    """BAM file bytes: header + whole raw records (each part a run of records with their block_size prefixes)"""
+    n = len(parts)
+    arr = (C.c_char_p * max(1, n))(*parts)
+    lens = (C.c_size_t * max(1, n))(*[len(p) for p in parts])
+    out, ol = C.c_void_p(), C.c_size_t()
+    _check(load().fzp_bam_write(header, len(header), n_ref, ref_block, len(ref_block), n, arr, lens, C.byref(out), C.byref(ol)))
+    return _take_text(out, ol)
+
+
 class OvlSet:
     """Tokenised `LA4Falcon -mo` dumps + rid_to_phase.all (fzp_ovl_parse)."""
 

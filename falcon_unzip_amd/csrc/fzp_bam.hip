@@ -183,10 +183,9 @@ extern "C" int fzp_format_bam(const fzp_alnset *a, const char *ctg_id, int64_t c
 
 // `samtools view <bam> [region]`: one text line per record (11 mandatory columns, optional fields dropped -- the
 // phasing code reads columns 0, 1, 2, 3, 5, 9 only, phasing.py:47-59).  region: NULL = every record, else RNAME.
-extern "C" int fzp_bam_to_sam(const uint8_t *bam, size_t len, const char *region, char **text, size_t *text_len) {
-    if ((!bam && len) || !text || !text_len) { fzp_set_error("fzp_bam_to_sam: bad arguments"); return FZP_EINVAL; }
-    // ---- BGZF -> one byte stream
-    std::vector<uint8_t> d;
+namespace {
+// BGZF -> one byte stream (every block checked: header, BSIZE, ISIZE <= 64 KiB, CRC)
+int bgzf_inflate_all(const uint8_t *bam, size_t len, std::vector<uint8_t> &d) {
     size_t p = 0;
     while (p < len) {
         if (len - p < 18 || bam[p] != 0x1f || bam[p + 1] != 0x8b || bam[p + 2] != 8 || !(bam[p + 3] & 4)) { fzp_set_error("not a BGZF block at offset %zu", p); return FZP_EINVAL; }
@@ -218,6 +217,14 @@ extern "C" int fzp_bam_to_sam(const uint8_t *bam, size_t len, const char *region
         }
         p += bsize;
     }
+    return FZP_OK;
+}
+}  // namespace
+
+extern "C" int fzp_bam_to_sam(const uint8_t *bam, size_t len, const char *region, char **text, size_t *text_len) {
+    if ((!bam && len) || !text || !text_len) { fzp_set_error("fzp_bam_to_sam: bad arguments"); return FZP_EINVAL; }
+    std::vector<uint8_t> d;
+    FZP_TRY(bgzf_inflate_all(bam, len, d));
     // ---- BAM
     auto rd32 = [&](size_t o) { return (int32_t)(d[o] | (d[o + 1] << 8) | (d[o + 2] << 16) | ((uint32_t)d[o + 3] << 24)); };
     if (d.size() < 12 || memcmp(d.data(), "BAM\1", 4) != 0) { fzp_set_error("not a BAM stream"); return FZP_EINVAL; }
@@ -282,4 +289,91 @@ extern "C" int fzp_bam_to_sam(const uint8_t *bam, size_t len, const char *region
     t[out.size()] = 0;
     *text = t; *text_len = out.size();
     return FZP_OK;
+}
+
+// ---- raw record access: what select_reads_from_bam.py does through pysam (open every input BAM, route whole records by
+// read name into per-contig BAM files under one merged header, select_reads_from_bam.py:44-87)
+extern "C" int fzp_bam_open(const uint8_t *bam, size_t len, fzp_bam_view **out) {
+    if ((!bam && len) || !out) { fzp_set_error("fzp_bam_open: bad arguments"); return FZP_EINVAL; }
+    *out = nullptr;
+    std::vector<uint8_t> d;
+    FZP_TRY(bgzf_inflate_all(bam, len, d));
+    auto rd32 = [&](size_t o) { return (int32_t)(d[o] | (d[o + 1] << 8) | (d[o + 2] << 16) | ((uint32_t)d[o + 3] << 24)); };
+    if (d.size() < 12 || memcmp(d.data(), "BAM\1", 4) != 0) { fzp_set_error("not a BAM stream"); return FZP_EINVAL; }
+    size_t o = 4;
+    const int32_t l_text = rd32(o); o += 4;
+    if (l_text < 0 || o + (size_t)l_text + 4 > d.size()) { fzp_set_error("truncated BAM header"); return FZP_EINVAL; }
+    const size_t text_at = o;
+    o += (size_t)l_text;
+    const int32_t n_ref = rd32(o); o += 4;
+    const size_t ref_at = o;
+    for (int32_t i = 0; i < n_ref; i++) {
+        if (o + 4 > d.size()) { fzp_set_error("truncated BAM reference list"); return FZP_EINVAL; }
+        const int32_t ln = rd32(o); o += 4;
+        if (ln < 1 || o + (size_t)ln + 4 > d.size()) { fzp_set_error("truncated BAM reference list"); return FZP_EINVAL; }
+        o += (size_t)ln + 4;
+    }
+    const size_t rec_at = o;
+    std::vector<int64_t> rec_off(1, 0), name_off(1, 0);
+    std::string names;
+    while (o + 4 <= d.size()) {
+        const int32_t bs = rd32(o);
+        if (bs < 32 || o + 4 + (size_t)bs > d.size()) { fzp_set_error("truncated BAM record"); return FZP_EINVAL; }
+        const uint32_t l_name = d[o + 4 + 8];
+        if (l_name < 1 || 32 + (size_t)l_name > (size_t)bs) { fzp_set_error("malformed BAM record"); return FZP_EINVAL; }
+        names.append((const char *)d.data() + o + 4 + 32, l_name - 1);
+        name_off.push_back((int64_t)names.size());
+        o += 4 + (size_t)bs;
+        rec_off.push_back((int64_t)(o - rec_at));
+    }
+    if (o != d.size()) { fzp_set_error("trailing bytes after the last BAM record"); return FZP_EINVAL; }
+    fzp_bam_view *v = (fzp_bam_view *)calloc(1, sizeof(fzp_bam_view));
+    if (!v) return FZP_ENOMEM;
+    auto dup = [](const void *src, size_t n) { void *q = malloc(n ? n : 1); if (q && n) memcpy(q, src, n); return q; };
+    size_t tl = (size_t)l_text;
+    while (tl && d[text_at + tl - 1] == 0) tl--;                       // l_text may count NUL padding
+    v->header_text = (char *)dup(d.data() + text_at, tl); v->header_len = tl;
+    v->n_ref = n_ref;
+    v->ref_block = (uint8_t *)dup(d.data() + ref_at, rec_at - ref_at); v->ref_block_len = rec_at - ref_at;
+    v->n_rec = (int64_t)rec_off.size() - 1;
+    v->rec_off = (int64_t *)dup(rec_off.data(), rec_off.size() * 8);
+    v->records = (uint8_t *)dup(d.data() + rec_at, d.size() - rec_at); v->records_len = d.size() - rec_at;
+    v->name_off = (int64_t *)dup(name_off.data(), name_off.size() * 8);
+    v->names = (char *)dup(names.data(), names.size());
+    if (!v->header_text || !v->ref_block || !v->rec_off || !v->records || !v->name_off || !v->names) { fzp_bam_view_free(v); return FZP_ENOMEM; }
+    *out = v;
+    return FZP_OK;
+}
+
+extern "C" void fzp_bam_view_free(fzp_bam_view *v) {
+    if (!v) return;
+    free(v->header_text); free(v->ref_block); free(v->rec_off); free(v->records); free(v->name_off); free(v->names);
+    free(v);
+}
+
+extern "C" int fzp_bam_write(const char *header_text, size_t header_len, int32_t n_ref, const uint8_t *ref_block, size_t ref_block_len, int32_t n_parts,
+                             const uint8_t *const *parts, const size_t *part_lens, uint8_t **bam, size_t *bam_len) {
+    if ((!header_text && header_len) || n_ref < 0 || (!ref_block && ref_block_len) || n_parts < 0 || (n_parts && (!parts || !part_lens)) || !bam || !bam_len) {
+        fzp_set_error("fzp_bam_write: bad arguments");
+        return FZP_EINVAL;
+    }
+    Bgzf z;
+    Bytes h;
+    h.raw("BAM\1", 4); h.u32((uint32_t)header_len); h.raw(header_text, header_len); h.u32((uint32_t)n_ref); h.raw(ref_block, ref_block_len);
+    FZP_TRY(z.write(h.v.data(), h.v.size()));
+    FZP_TRY(z.flush());                                                  // records start on a block boundary, as samtools writes them
+    for (int32_t k = 0; k < n_parts; k++) {
+        // whole records only: walk the block_size prefixes
+        size_t o = 0;
+        while (o < part_lens[k]) {
+            if (o + 4 > part_lens[k]) { fzp_set_error("fzp_bam_write: part %d is not a sequence of BAM records", k); return FZP_EINVAL; }
+            const uint8_t *q = parts[k] + o;
+            const size_t bs = (size_t)(q[0] | (q[1] << 8) | (q[2] << 16) | ((uint32_t)q[3] << 24));
+            if (bs < 32 || o + 4 + bs > part_lens[k]) { fzp_set_error("fzp_bam_write: part %d is not a sequence of BAM records", k); return FZP_EINVAL; }
+            o += 4 + bs;
+        }
+        if (part_lens[k]) FZP_TRY(z.write(parts[k], part_lens[k]));
+    }
+    FZP_TRY(z.finish());
+    return give(z.out.v, bam, bam_len);
 }

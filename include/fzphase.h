@@ -336,6 +336,22 @@ int fzp_format_bam(const fzp_alnset *aln, const char *ctg_id, int64_t ctg_len, c
                    uint8_t **bam, size_t *bam_len, uint8_t **bai, size_t *bai_len);
 int fzp_bam_to_sam(const uint8_t *bam, size_t len, const char *region, char **text, size_t *text_len);
 
+/* raw record access for select_reads_from_bam.py (select_reads_from_bam.py:44-87 does this through pysam): every record of a BAM as its
+ * bytes (block_size prefix included) plus its read name; and a writer that puts whole records under a given header. */
+typedef struct {
+    char *header_text; size_t header_len;          /* SAM header text, NUL padding stripped */
+    int32_t n_ref; uint8_t *ref_block; size_t ref_block_len;   /* the reference dictionary as it sits in the file (after n_ref) */
+    int64_t n_rec;
+    int64_t *rec_off;                              /* [n_rec + 1] into records */
+    uint8_t *records; size_t records_len;
+    int64_t *name_off;                             /* [n_rec + 1] into names */
+    char *names;
+} fzp_bam_view;
+int fzp_bam_open(const uint8_t *bam, size_t len, fzp_bam_view **out);
+void fzp_bam_view_free(fzp_bam_view *v);
+int fzp_bam_write(const char *header_text, size_t header_len, int32_t n_ref, const uint8_t *ref_block, size_t ref_block_len, int32_t n_parts,
+                  const uint8_t *const *parts, const size_t *part_lens, uint8_t **bam, size_t *bam_len);
+
 /* ======================================================================== overlap filter ("next" row n2)
  * falcon_unzip/ovlp_filter_with_phase.py: the consumer of rid_to_phase.all.  It reads `LA4Falcon -mo` text
  * (13 whitespace-separated columns per overlap: q_id t_id -len idt q_strand q_s q_e q_l t_strand t_s t_e t_l tag)
