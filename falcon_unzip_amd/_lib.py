@@ -180,6 +180,7 @@ def load():
         "fzp_align_to_batch": (C.c_int, [VP, VP, PP]),
         "fzp_align_destroy": (None, [VP, VP]),
         "fzp_batch_consensus": (C.c_int, [VP, VP, VP]),
+        "fzp_batch_consensus_v": (C.c_int, [VP, VP, C.c_int, VP]),
         "fzp_tigs_free": (None, [VP]),
         "fzp_format_tigs": (C.c_int, [VP, I32, CP, PP, PSZ]),
         "fzp_format_bam": (C.c_int, [VP, CP, I64, VP, PP, PSZ, PP, PSZ]),
@@ -358,10 +359,10 @@ class Batch:
         begin = _take(cb.value, self.n_ctg + 1, np.int64)
         return _take_text(p, n), begin
 
-    def consensus(self) -> "Tigs":
-        """K6: phased-pile consensus of every (block, phase); run(STAGE_ALL) first."""
+    def consensus(self, version=2) -> "Tigs":
+        """K6: phased-pile consensus of every (block, phase) (fzcns v2; version=1: one inserted base at most); run(STAGE_ALL) first."""
         ts = TigsStruct()
-        _check(load().fzp_batch_consensus(self.eng._p, self._p, C.byref(ts)))
+        _check(load().fzp_batch_consensus_v(self.eng._p, self._p, version, C.byref(ts)))
         return Tigs(ts)
 
     def counts(self):

@@ -1,4 +1,4 @@
-// fzp_cns.hip -- K6: phased-pile consensus of every (block, phase) of a batch ("fzcns v1"; twin: oracle/cns_oracle.c).
+// fzp_cns.hip -- K6: phased-pile consensus of every (block, phase) of a batch ("fzcns v2", v1 kept as a flag; twin: oracle/cns_oracle.c).
 //
 // BASELINE north_star config 4 asks for a haplotig consensus kernel on the phased read piles.  The reference has no
 // consensus code of its own (falcon_sense lives in falcon_kit, Arrow in `variantCaller`, run_quiver.py:82-97), so this
@@ -9,7 +9,11 @@
 //                  position and phase) live in LDS, its waves walk the records that overlap the tile -- phase looked
 //                  up in K5's rows, CIGAR resumed at K2's 64-op checkpoint before the tile, columns dealt 64 at a time
 //                  by the shared expander, D / I ops one per lane -- and the tile is written once, coalesced
-//   k_cns_call     per position: 0..2 output bases (deletion / majority base / majority inserted base)
+//   k_cns_call     per position: deletion / majority base, and the first inserted base
+//   k_ins_*        v2: insertions longer than one base.  The tally also lists every I op of >= 2 bases (slot, first base, length);
+//                  level d = 2..8: the listed ops that still spell the chosen bases vote for their d-th base (global atomics on 4
+//                  counters per slot), every voter reads the verdict (2 * count > cov, the weight falcon_sense gives a tag link),
+//                  survivors go on to the next level.  A level costs three small launches over a quickly shrinking list.
 //   scan + k_cns_emit   sequences laid out per (block, phase), order fixed by the scan
 // HBM-bound integer work: 1 B symbol + 4 B/op in, 40 B of counters per (position, phase) touched by atomics, 1 B out.
 #include <algorithm>
@@ -63,10 +67,14 @@ __global__ void __launch_bounds__(256) k_cns_nrec(CnsView v, uint32_t *__restric
     }
 }
 
+struct LongIns { int64_t slot, qidx; uint32_t n, alive; };      // an I op of >= 2 bases: counter slot of the position it follows, its first base in seq
+constexpr int INS_MAX = 8;                                       // spec: at most 8 inserted bases per position
+
 constexpr int CNS_TILE = 512, CNS_THREADS = 512;
 __global__ void __launch_bounds__(CNS_THREADS) k_cns_tiles(RecView rv, CnsView v, const int32_t *__restrict__ tile_blk, const int32_t *__restrict__ tile_start,
                                                            const int32_t *__restrict__ blk_ctg, const int64_t *__restrict__ ctg_rec_begin,
-                                                           const int32_t *__restrict__ ctg_maxspan, uint32_t *__restrict__ cnt) {
+                                                           const int32_t *__restrict__ ctg_maxspan, uint32_t *__restrict__ cnt, LongIns *__restrict__ lins,
+                                                           unsigned long long *__restrict__ n_lins, unsigned long long lins_cap) {
     __shared__ uint32_t l_cnt[2 * CN * CNS_TILE];      // [phase][counter][position]: consecutive lanes -> distinct banks
     const int32_t g = tile_blk[blockIdx.x], ts = tile_start[blockIdx.x];
     const int c = blk_ctg[g];
@@ -120,8 +128,10 @@ __global__ void __launch_bounds__(CNS_THREADS) k_cns_tiles(RecView rv, CnsView v
         for (uint64_t todo = __ballot(ok); todo; todo &= todo - 1) {
             const int l = __builtin_ctzll(todo);
             const int64_t ru = first + __builtin_amdgcn_readlane(rel, l);
-            uint32_t *lc = l_cnt + __builtin_amdgcn_readlane(ph, l) * (CN * CNS_TILE);
+            const int phu = __builtin_amdgcn_readlane(ph, l);
+            uint32_t *lc = l_cnt + phu * (CN * CNS_TILE);
             const int32_t pos0 = rv.rec_pos[ru];
+            const int64_t seq_end = rv.seq_off[ru + 1];
             expand_record(rv, ru,
                 [&](int32_t pos, uint8_t sym) {
                     const uint32_t p = (uint32_t)(pos - ts);
@@ -141,6 +151,14 @@ __global__ void __launch_bounds__(CNS_THREADS) k_cns_tiles(RecView rv, CnsView v
                             atomicAdd(&lc[5 * CNS_TILE + (p - ts)], 1u);
                             const int code = sym_code(rv.seq[qidx]);
                             if (code < 4) atomicAdd(&lc[(6 + code) * CNS_TILE + (p - ts)], 1u);
+                            if (n >= 2 && lins) {
+                                const unsigned long long at = atomicAdd(n_lins, 1ull);
+                                if (at < lins_cap) {
+                                    const int64_t len_ = (int64_t)v.hi[g] - v.lo[g] + 1;
+                                    const int64_t room = seq_end - qidx;
+                                    lins[at] = LongIns{2 * v.cnt_off[g] + (int64_t)phu * len_ + (p - v.lo[g]), qidx, (uint32_t)(room < (int64_t)n ? room : (int64_t)n), 0u};
+                                }
+                            }
                         }
                     }
                 });
@@ -155,10 +173,12 @@ __global__ void __launch_bounds__(CNS_THREADS) k_cns_tiles(RecView rv, CnsView v
     }
 }
 
-// one thread per (block, phase, position): how many bases come out (0..2) and which
+// one thread per (block, phase, position): the delta-0 call (0 or 1 base) and the first inserted base
+// outputs: base0[i] (0 = nothing), ins_len[i] (0 / 1 after this kernel), ins_code[i] (2 bits per inserted base)
 __global__ void __launch_bounds__(256) k_cns_call(int64_t n_slots, int n_blk, const int64_t *__restrict__ cnt_off, const int32_t *__restrict__ lo, const int32_t *__restrict__ hi,
                                                   const int32_t *__restrict__ blk_ctg, const int64_t *__restrict__ ctg_goff, const uint8_t *__restrict__ ref,
-                                                  const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ n_records, uint32_t *__restrict__ n_out, uint8_t *__restrict__ sym2) {
+                                                  const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ n_records, int version, uint8_t *__restrict__ base0,
+                                                  uint8_t *__restrict__ ins_len, uint32_t *__restrict__ ins_code) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n_slots) return;
     int a = 0, b = n_blk;                                   // block g with 2*cnt_off[g] <= i < 2*cnt_off[g+1]
@@ -168,14 +188,14 @@ __global__ void __launch_bounds__(256) k_cns_call(int64_t n_slots, int n_blk, co
     const int64_t local = i - 2 * cnt_off[g];
     const int ph = local >= len ? 1 : 0;
     const int64_t x = local - (int64_t)ph * len;
-    uint32_t no = 0;
-    uint8_t s0 = 0, s1 = 0;
+    uint8_t s0 = 0, il = 0;
+    uint32_t ic = 0;
     if (n_records[2 * g + ph] > 0) {
         const uint32_t *c = cnt + i * CN;
         const uint32_t cov = c[0] + c[1] + c[2] + c[3] + c[4];
         uint8_t refb = ref[ctg_goff[blk_ctg[g]] + lo[g] + x];
         if (refb >= 'a' && refb <= 'z') refb -= 32;
-        if (cov == 0) { s0 = refb; no = 1; }
+        if (cov == 0) s0 = refb;
         else {
             if (2 * c[4] <= cov) {
                 uint32_t mx = max(max(c[0], c[1]), max(c[2], c[3]));
@@ -183,26 +203,81 @@ __global__ void __launch_bounds__(256) k_cns_call(int64_t n_slots, int n_blk, co
                 int pick = -1;
                 if (rc < 4 && c[rc] == mx) pick = rc;
                 for (int k = 0; k < 4 && pick < 0; k++) if (c[k] == mx) pick = k;
-                s0 = code_sym(pick); no = 1;
+                s0 = code_sym(pick);
             }
-            if (2 * c[5] > cov) {
-                uint32_t mx = c[6];
-                int pick = 0;
-                for (int k = 1; k < 4; k++) if (c[6 + k] > mx) { mx = c[6 + k]; pick = k; }
-                if (mx > 0) { if (no) s1 = code_sym(pick); else s0 = code_sym(pick); no++; }
-            }
+            uint32_t mx = c[6];
+            int pick = 0;
+            for (int k = 1; k < 4; k++) if (c[6 + k] > mx) { mx = c[6 + k]; pick = k; }
+            const bool ins = version == 1 ? (2 * c[5] > cov && mx > 0) : (2 * mx > cov);
+            if (ins) { il = 1; ic = (uint32_t)pick; }
         }
     }
-    n_out[i] = no;
-    sym2[2 * i] = s0; sym2[2 * i + 1] = s1;
+    base0[i] = s0; ins_len[i] = il; ins_code[i] = ic;
 }
-__global__ void __launch_bounds__(256) k_cns_emit(int64_t n_slots, const uint32_t *__restrict__ n_out, const uint32_t *__restrict__ off, const uint8_t *__restrict__ sym2,
-                                                  uint8_t *__restrict__ seq) {
+// ---- v2 insertion levels over the listed I ops
+__global__ void __launch_bounds__(256) k_ins_init(int64_t n, LongIns *__restrict__ e, const uint8_t *__restrict__ seq, const uint8_t *__restrict__ ins_len, const uint32_t *__restrict__ ins_code,
+                                                  unsigned long long *__restrict__ n_alive) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    bool al = false;
+    if (i < n) {
+        const LongIns x = e[i];
+        al = ins_len[x.slot] == 1 && sym_code(seq[x.qidx]) == (int)(ins_code[x.slot] & 3u) && x.n >= 2;
+        e[i].alive = al ? 1u : 0u;
+    }
+    const uint64_t m = __ballot(al);
+    if (lane_id() == 0 && m) atomicAdd(n_alive, (unsigned long long)__popcll(m));
+}
+__global__ void __launch_bounds__(256) k_ins_vote(int64_t n, const LongIns *__restrict__ e, const uint8_t *__restrict__ seq, int d, uint32_t *__restrict__ lv) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const LongIns x = e[i];
+    if (!x.alive || x.n < (uint32_t)d) return;
+    const int code = sym_code(seq[x.qidx + d - 1]);
+    if (code < 4) atomicAdd(&lv[x.slot * 4 + code], 1u);
+}
+__global__ void __launch_bounds__(256) k_ins_decide(int64_t n, LongIns *__restrict__ e, const uint8_t *__restrict__ seq, int d, const uint32_t *__restrict__ lv, const uint32_t *__restrict__ cnt,
+                                                    uint8_t *__restrict__ ins_len, uint32_t *__restrict__ ins_code, unsigned long long *__restrict__ n_alive) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    bool al = false;
+    if (i < n) {
+        const LongIns x = e[i];
+        if (x.alive && x.n >= (uint32_t)d) {
+            const uint32_t *l = lv + x.slot * 4;
+            uint32_t mx = l[0];
+            int pick = 0;
+            for (int k = 1; k < 4; k++) if (l[k] > mx) { mx = l[k]; pick = k; }
+            const uint32_t *c = cnt + x.slot * CN;
+            const uint32_t cov = c[0] + c[1] + c[2] + c[3] + c[4];
+            if (2 * mx > cov) {
+                // every voter of the slot writes the same values (the verdict is a function of the slot's counters)
+                ins_len[x.slot] = (uint8_t)d;
+                ins_code[x.slot] = (ins_code[x.slot] & ((1u << (2 * (d - 1))) - 1u)) | ((uint32_t)pick << (2 * (d - 1)));
+                al = sym_code(seq[x.qidx + d - 1]) == pick && x.n > (uint32_t)d && d < INS_MAX;
+            }
+        }
+        if (x.alive) e[i].alive = al ? 1u : 0u;
+    }
+    const uint64_t m = __ballot(al);
+    if (lane_id() == 0 && m) atomicAdd(n_alive, (unsigned long long)__popcll(m));
+}
+__global__ void __launch_bounds__(256) k_ins_clear(int64_t n, const LongIns *__restrict__ e, uint32_t *__restrict__ lv) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    uint4 *p = (uint4 *)(lv + e[i].slot * 4);
+    *p = make_uint4(0, 0, 0, 0);
+}
+__global__ void __launch_bounds__(256) k_cns_nout(int64_t n_slots, const uint8_t *__restrict__ base0, const uint8_t *__restrict__ ins_len, uint32_t *__restrict__ n_out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n_slots) n_out[i] = (base0[i] ? 1u : 0u) + ins_len[i];
+}
+__global__ void __launch_bounds__(256) k_cns_emit(int64_t n_slots, const uint32_t *__restrict__ off, const uint8_t *__restrict__ base0, const uint8_t *__restrict__ ins_len,
+                                                  const uint32_t *__restrict__ ins_code, uint8_t *__restrict__ seq) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n_slots) return;
-    const uint32_t n = n_out[i], o = off[i];
-    if (n > 0) seq[o] = sym2[2 * i];
-    if (n > 1) seq[o + 1] = sym2[2 * i + 1];
+    uint32_t o = off[i];
+    if (base0[i]) seq[o++] = base0[i];
+    const uint32_t n = ins_len[i], c = ins_code[i];
+    for (uint32_t k = 0; k < n; k++) seq[o++] = code_sym((int)((c >> (2 * k)) & 3u));
 }
 // first output offset of every (block, phase): one gathered array instead of 2 * blocks tiny copies
 __global__ void k_cns_first(int n_blk, const int64_t *__restrict__ cnt_off, const uint32_t *__restrict__ off, uint32_t total, uint32_t *__restrict__ first) {
@@ -225,8 +300,10 @@ extern "C" void fzp_tigs_free(fzp_tigs *t) {
     t->tigs = nullptr; t->seq = nullptr; t->n_tigs = 0; t->n_seq = 0;
 }
 
-extern "C" int fzp_batch_consensus(fzp_ctx *ctx, fzp_batch *b, fzp_tigs *out) {
-    if (!ctx || !b || !out) { fzp_set_error("fzp_batch_consensus: bad arguments"); return FZP_EINVAL; }
+extern "C" int fzp_batch_consensus(fzp_ctx *ctx, fzp_batch *b, fzp_tigs *out) { return fzp_batch_consensus_v(ctx, b, 2, out); }
+
+extern "C" int fzp_batch_consensus_v(fzp_ctx *ctx, fzp_batch *b, int version, fzp_tigs *out) {
+    if (!ctx || !b || !out || (version != 1 && version != 2)) { fzp_set_error("fzp_batch_consensus: bad arguments"); return FZP_EINVAL; }
     memset(out, 0, sizeof *out);
     if (!b->have_aln || !b->have_blocks || !b->have_preads || !b->have_sites) { fzp_set_error("fzp_batch_consensus: run FZP_STAGE_ALL on a batch with alignment records first"); return FZP_EINVAL; }
     FZP_TRY(fzp_bind(ctx));
@@ -259,9 +336,13 @@ extern "C" int fzp_batch_consensus(fzp_ctx *ctx, fzp_batch *b, fzp_tigs *out) {
     if (n_slots >= (1ll << 31)) { fzp_set_error("fzp_batch_consensus: %lld block positions (limit 2^30 per batch)", (long long)n_slots / 2); return FZP_EINVAL; }
     // ---- tally
     DevBuf<int64_t> d_cnt_off;
-    DevBuf<uint32_t> cnt, n_records, n_out, off;
-    DevBuf<uint8_t> sym2, seq;
+    DevBuf<uint32_t> cnt, n_records, n_out, off, ins_code, lv;
+    DevBuf<uint8_t> base0, ins_len, seq;
     DevBuf<uint64_t> total;
+    DevBuf<LongIns> lins;
+    DevBuf<unsigned long long> n_lins;
+    unsigned long long lins_cap = version == 2 ? (unsigned long long)std::max<int64_t>(b->n_cig / 8, 4096) : 0;
+    FZP_TRY(n_lins.alloc(2));
     FZP_TRY(d_cnt_off.upload(cnt_off.data(), (size_t)NB + 1, st));
     FZP_TRY(cnt.alloc((size_t)n_slots * CN));
     FZP_TRY(n_records.alloc((size_t)NB * 2)); FZP_TRY(n_records.zero((size_t)NB * 2, st));
@@ -273,22 +354,51 @@ extern "C" int fzp_batch_consensus(fzp_ctx *ctx, fzp_batch *b, fzp_tigs *out) {
         for (int64_t t0 = lo[(size_t)g]; t0 <= hi[(size_t)g]; t0 += CNS_TILE) { tblk.push_back(g); tstart.push_back((int32_t)t0); }
     DevBuf<int32_t> d_tblk, d_tstart;
     FZP_TRY(d_tblk.upload(tblk.data(), tblk.size(), st)); FZP_TRY(d_tstart.upload(tstart.data(), tstart.size(), st));
-    if (b->n_rec > 0) {
-        ProfScope ps(ctx, "k6_tally");
-        hipLaunchKernelGGL(k_cns_nrec, dim3(nblocks(b->n_rec, 256)), dim3(256), 0, st, v, n_records.p);
-        if (!tblk.empty())
-            hipLaunchKernelGGL(k_cns_tiles, dim3((unsigned)tblk.size()), dim3(CNS_THREADS), 0, st, rv, v, d_tblk.p, d_tstart.p, d_bctg.p, b->ctg_rec_begin.p, b->ctg_maxspan.p, cnt.p);
-    } else {
-        FZP_TRY(cnt.zero((size_t)n_slots * CN, st));
+    unsigned long long h_lins = 0;
+    for (int attempt = 0; attempt < 2; attempt++) {         // second attempt only if the list of long I ops overflowed its first capacity
+        if (version == 2) FZP_TRY(lins.alloc((size_t)lins_cap));
+        FZP_HIP(hipMemsetAsync(n_lins.p, 0, 16, st));
+        if (b->n_rec > 0) {
+            ProfScope ps(ctx, "k6_tally");
+            if (attempt == 0) hipLaunchKernelGGL(k_cns_nrec, dim3(nblocks(b->n_rec, 256)), dim3(256), 0, st, v, n_records.p);
+            if (!tblk.empty())
+                hipLaunchKernelGGL(k_cns_tiles, dim3((unsigned)tblk.size()), dim3(CNS_THREADS), 0, st, rv, v, d_tblk.p, d_tstart.p, d_bctg.p, b->ctg_rec_begin.p, b->ctg_maxspan.p, cnt.p,
+                                   version == 2 ? lins.p : (LongIns *)nullptr, n_lins.p, lins_cap);
+        } else {
+            FZP_TRY(cnt.zero((size_t)n_slots * CN, st));
+        }
+        FZP_HIP(hipMemcpyAsync(&h_lins, n_lins.p, 8, hipMemcpyDeviceToHost, st));
+        FZP_HIP(hipStreamSynchronize(st));                   // (the tile vectors also go out of scope below)
+        if (h_lins <= lins_cap) break;
+        lins_cap = h_lins;
     }
-    FZP_HIP(hipStreamSynchronize(st));                       // the tile vectors go out of scope
     // ---- call + layout
-    FZP_TRY(n_out.alloc((size_t)n_slots)); FZP_TRY(off.alloc((size_t)n_slots)); FZP_TRY(sym2.alloc((size_t)n_slots * 2)); FZP_TRY(total.alloc(1));
+    FZP_TRY(n_out.alloc((size_t)n_slots)); FZP_TRY(off.alloc((size_t)n_slots)); FZP_TRY(base0.alloc((size_t)n_slots)); FZP_TRY(ins_len.alloc((size_t)n_slots));
+    FZP_TRY(ins_code.alloc((size_t)n_slots)); FZP_TRY(total.alloc(1));
     {
         ProfScope ps(ctx, "k6_call");
         hipLaunchKernelGGL(k_cns_call, dim3(nblocks(n_slots, 256)), dim3(256), 0, st, n_slots, NB, d_cnt_off.p, d_lo.p, d_hi.p, d_bctg.p, b->ctg_goff.p, b->ref.p, cnt.p, n_records.p,
-                           n_out.p, sym2.p);
+                           version, base0.p, ins_len.p, ins_code.p);
     }
+    if (version == 2 && h_lins > 0) {
+        ProfScope ps(ctx, "k6_ins_levels");
+        const int64_t ne = (int64_t)h_lins;
+        FZP_TRY(lv.alloc((size_t)n_slots * 4)); FZP_TRY(lv.zero((size_t)n_slots * 4, st));
+        unsigned long long alive = 0;
+        FZP_HIP(hipMemsetAsync(n_lins.p + 1, 0, 8, st));
+        hipLaunchKernelGGL(k_ins_init, dim3(nblocks(ne, 256)), dim3(256), 0, st, ne, lins.p, b->seq.p, ins_len.p, ins_code.p, n_lins.p + 1);
+        FZP_HIP(hipMemcpyAsync(&alive, n_lins.p + 1, 8, hipMemcpyDeviceToHost, st));
+        FZP_HIP(hipStreamSynchronize(st));
+        for (int d = 2; d <= INS_MAX && alive > 0; d++) {
+            hipLaunchKernelGGL(k_ins_vote, dim3(nblocks(ne, 256)), dim3(256), 0, st, ne, lins.p, b->seq.p, d, lv.p);
+            FZP_HIP(hipMemsetAsync(n_lins.p + 1, 0, 8, st));
+            hipLaunchKernelGGL(k_ins_decide, dim3(nblocks(ne, 256)), dim3(256), 0, st, ne, lins.p, b->seq.p, d, lv.p, cnt.p, ins_len.p, ins_code.p, n_lins.p + 1);
+            hipLaunchKernelGGL(k_ins_clear, dim3(nblocks(ne, 256)), dim3(256), 0, st, ne, lins.p, lv.p);
+            FZP_HIP(hipMemcpyAsync(&alive, n_lins.p + 1, 8, hipMemcpyDeviceToHost, st));
+            FZP_HIP(hipStreamSynchronize(st));
+        }
+    }
+    hipLaunchKernelGGL(k_cns_nout, dim3(nblocks(n_slots, 256)), dim3(256), 0, st, n_slots, base0.p, ins_len.p, n_out.p);
     FZP_TRY(fzp_exclusive_scan_u32(ctx, n_out.p, off.p, (size_t)n_slots, total.p));
     uint64_t tot = 0;
     FZP_HIP(hipMemcpyAsync(&tot, total.p, 8, hipMemcpyDeviceToHost, st));
@@ -296,7 +406,7 @@ extern "C" int fzp_batch_consensus(fzp_ctx *ctx, fzp_batch *b, fzp_tigs *out) {
     FZP_TRY(seq.alloc((size_t)tot));
     {
         ProfScope ps(ctx, "k6_emit");
-        hipLaunchKernelGGL(k_cns_emit, dim3(nblocks(n_slots, 256)), dim3(256), 0, st, n_slots, n_out.p, off.p, sym2.p, seq.p);
+        hipLaunchKernelGGL(k_cns_emit, dim3(nblocks(n_slots, 256)), dim3(256), 0, st, n_slots, off.p, base0.p, ins_len.p, ins_code.p, seq.p);
     }
     // ---- results: sequence bytes, and per (block, phase) its offset = off[] at its first slot
     std::vector<uint32_t> h_nrec((size_t)NB * 2), h_first((size_t)NB * 2 + 1, (uint32_t)tot);

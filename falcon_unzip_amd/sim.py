@@ -82,7 +82,7 @@ def _rle(op_seq: np.ndarray):
 
 
 def simulate_read(contig, hap, start, R, rng, sub=0.01, ins=0.08, dele=0.04,
-                  clip5=0, clip3=0):
+                  clip5=0, clip3=0, hp_bias=1.0):
     """One read of template length R from `hap` at `start`; CIGAR is vs `contig`.
 
     Returns (seq codes on contig strand incl. clips, ops, lens).
@@ -91,9 +91,19 @@ def simulate_read(contig, hap, start, R, rng, sub=0.01, ins=0.08, dele=0.04,
     c = contig[start:start + R]
     R = t.size
     u = rng.random(R)
-    is_del = u < dele
-    is_sub = (u >= dele) & (u < dele + sub)
-    n_ins = (rng.random(R) < ins).astype(np.int64)
+    w = rng.random(R)
+    if hp_bias != 1.0:
+        # homopolymer-biased indels: inside a run (base equal to its predecessor) deletions and insertions are hp_bias times as likely,
+        # and an inserted base repeats the run's base -- the non-iid error shape of single-molecule reads
+        inrun = np.zeros(R, bool)
+        inrun[1:] = t[1:] == t[:-1]
+        dele_k = np.where(inrun, min(0.45, dele * hp_bias), dele)
+        ins_k = np.where(inrun, min(0.45, ins * hp_bias), ins)
+    else:
+        inrun, dele_k, ins_k = None, dele, ins
+    is_del = u < dele_k
+    is_sub = (u >= dele_k) & (u < dele_k + sub)
+    n_ins = (w < ins_k).astype(np.int64)
     # keep the alignment anchored: first/last template bases are emitted, no leading insert
     is_del[0] = is_del[-1] = False
     n_ins[0] = 0
@@ -113,6 +123,9 @@ def simulate_read(contig, hap, start, R, rng, sub=0.01, ins=0.08, dele=0.04,
     qlen = int(q_per.sum())
     q_off = np.cumsum(q_per) - q_per
     seq = rng.integers(0, 4, size=qlen, dtype=np.uint8)   # fills the insert slots
+    if inrun is not None:
+        sel = inrun & (n_ins > 0)
+        seq[q_off[sel]] = t[sel]
     seq[(q_off + n_ins)[~is_del]] = base[~is_del]
     ops, lens = _rle(op_seq)
     if clip5:
@@ -278,3 +291,56 @@ def make_repeat_diploid(L, rng, het_rate=1.0 / 500, n_families=6, copies=(2, 4),
     hap1 = hap0.copy()
     hap1[pos] = (hap0[pos] + rng.integers(1, 4, size=n_het, dtype=np.uint8)) & 3
     return hap0, hap1, pos, sorted(spans)
+
+
+def make_diploid_indels(L, rng, het_rate=1.0 / 400, indel_frac=0.25, indel_len=(2, 5)):
+    """hap0 iid; hap1 = hap0 with heterozygous SNPs and small insertions / deletions (indel_len bases).  Returns
+    (hap0, hap1, map01, events): map01[p] = index in hap1 of hap0 position p (length L + 1), events = [(pos, kind, length)]."""
+    hap0 = rng.integers(0, 4, size=L, dtype=np.uint8)
+    n_het = int(round(L * het_rate))
+    pos = np.sort(rng.choice(np.arange(50, L - 50), size=n_het, replace=False))
+    pieces, map01, events, prev, shift = [], np.zeros(L + 1, np.int64), [], 0, 0
+    for p in pos:
+        p = int(p)
+        if p < prev:
+            continue
+        pieces.append(hap0[prev:p])
+        map01[prev:p] = np.arange(prev, p) + shift
+        r = rng.random()
+        if r < indel_frac / 2:                              # insertion after p - 1 (kept away from homopolymer ambiguity: first inserted base differs from both neighbours)
+            n = int(rng.integers(indel_len[0], indel_len[1] + 1))
+            ins = rng.integers(0, 4, size=n, dtype=np.uint8)
+            while ins[0] == hap0[p - 1] or ins[-1] == hap0[p]:
+                ins = rng.integers(0, 4, size=n, dtype=np.uint8)
+            pieces.append(ins)
+            shift += n
+            events.append((p, "ins", n))
+            prev = p
+        elif r < indel_frac:                                # deletion of hap0[p : p + n]
+            n = int(rng.integers(indel_len[0], indel_len[1] + 1))
+            map01[p:p + n] = p + shift
+            shift -= n
+            events.append((p, "del", n))
+            prev = p + n
+        else:
+            pieces.append(np.array([(hap0[p] + rng.integers(1, 4)) & 3], dtype=np.uint8))
+            map01[p] = p + shift
+            events.append((p, "snp", 1))
+            prev = p + 1
+    pieces.append(hap0[prev:])
+    map01[prev:L] = np.arange(prev, L) + shift
+    map01[L] = L + shift
+    return hap0, np.concatenate(pieces).astype(np.uint8), map01, events
+
+
+def simulate_raw_reads_from(hap, n_reads, R, rng, strand_mix=0.5, hp_bias=1.0, name_prefix="sim"):
+    """raw reads (as sequenced) of template length R drawn from one haplotype sequence; -> [(name, bytes, start, strand)]"""
+    out = []
+    starts = rng.integers(0, max(1, hap.size - R + 1), size=n_reads)
+    strands = rng.random(n_reads) < strand_mix
+    for i in range(n_reads):
+        seq, _, _ = simulate_read(hap, hap, int(starts[i]), R, rng, hp_bias=hp_bias)
+        if strands[i]:
+            seq = revcomp_codes(seq)
+        out.append(("%s/%d/0_%d" % (name_prefix, i, seq.size), ACGT[seq].tobytes(), int(starts[i]), int(strands[i])))
+    return out

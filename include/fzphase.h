@@ -254,7 +254,7 @@ int fzp_format_sam(const fzp_alnset *aln, const char *ctg_id, const int32_t *fla
 
 /* ---- K6: phased-pile consensus (BASELINE config 4; "next" row n3's device part).  The reference has no consensus code
  * of its own (falcon_sense is falcon_kit's, Arrow is `variantCaller`'s, run_quiver.py:82-97): parity unpinned, the
- * definition is oracle/cns_oracle.c ("fzcns v1").  For every (contig, block, phase) with at least one record
+ * definition is oracle/cns_oracle.c ("fzcns v2").  For every (contig, block, phase) with at least one record
  * in its pile: the consensus of the block's span [first site, last site] over the records of the reads K5 gave that
  * phase.  Needs a batch with alignment records on which FZP_STAGE_ALL has run. */
 typedef struct {
@@ -264,7 +264,11 @@ typedef struct {
     int64_t seq_off, seq_len;    /* into fzp_tigs.seq */
 } fzp_tig;
 typedef struct { int64_t n_tigs; fzp_tig *tigs; int64_t n_seq; uint8_t *seq; } fzp_tigs;
-int fzp_batch_consensus(fzp_ctx *ctx, fzp_batch *b, fzp_tigs *out);
+int fzp_batch_consensus(fzp_ctx *ctx, fzp_batch *b, fzp_tigs *out);                 /* fzcns v2 */
+/* version 1: at most one inserted base per position, decided on the count of I ops (the first definition; faster);
+ * version 2: insertions of up to 8 bases, every base gated on the support of its prefix-linked tag (2 * count > coverage), the weight
+ * falcon_sense gives a tag link in its (t_pos, delta, base) graph */
+int fzp_batch_consensus_v(fzp_ctx *ctx, fzp_batch *b, int version, fzp_tigs *out);
 void fzp_tigs_free(fzp_tigs *t);     /* frees the arrays, not the struct */
 /* FASTA of one contig's tigs: ">{ctg_id}_{block:03d}_{phase} {lo+1} {hi+1} {n_records}\n{sequence}\n" */
 int fzp_format_tigs(const fzp_tigs *t, int32_t ctg, const char *ctg_id, char **text, size_t *len);

@@ -1,4 +1,4 @@
-/* cns_oracle.c -- scalar CPU twin of K6, the phased-pile consensus ("fzcns v1").
+/* cns_oracle.c -- scalar CPU twin of K6, the phased-pile consensus ("fzcns v2" and its one-base predecessor v1).
  * TEST INFRASTRUCTURE: only tests/, __graft_entry__.smoke() and bench cpu_baseline legs may use it.
  *
  * PARITY UNPINNED against the reference: FALCON_unzip has no consensus code of its own -- haplotig consensus is
@@ -17,7 +17,11 @@
  *     cov == 0            -> the contig's base
  *     2*del > cov         -> nothing
  *     else                -> the most frequent base (ties: the contig's base if it is among them, else A<C<G<T)
- *     then 2*ins > cov    -> the most frequent first inserted base (ties A<C<G<T)
+ *     v1: then 2*ins > cov -> the most frequent first inserted base (ties A<C<G<T)            [ins = I ops following the position]
+ *     v2: inserted bases are chosen one level at a time, the way falcon_sense's tag graph links (t_pos, delta, base) nodes to their
+ *         predecessors: level d = 1..8 looks at the I ops of the pile at this position that are at least d long and whose first
+ *         d-1 bases are the ones already chosen; the most frequent base at level d (ties A<C<G<T) is emitted if 2*count > cov,
+ *         otherwise the insertion ends.  (A tag's weight in falcon_sense is its link count minus half the coverage: the same gate.)
  * Output: one FASTA record per (block, phase) with at least one record in its pile, blocks ascending, phase 0 then 1:
  *     >{ctg}_{block:03d}_{phase} {min} {max} {n_records}\n{sequence}\n
  */
@@ -50,8 +54,10 @@ typedef struct { int id; long long lo, hi; } blk_t;
 
 static int code_of(unsigned char c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 4; }
 
-int orc_consensus(const char *sam, size_t sam_len, const char *ref_seq, size_t ref_len, const char *phased_reads, size_t pr_len,
-                  const char *phased_variants, size_t pv_len, const char *ctg_id, char **out_txt, size_t *out_len) {
+typedef struct { size_t x; const char *s; long long n; } ins_t;      /* an I op: position index in the block, its bases */
+
+int orc_consensus_v(int version, const char *sam, size_t sam_len, const char *ref_seq, size_t ref_len, const char *phased_reads, size_t pr_len,
+                    const char *phased_variants, size_t pv_len, const char *ctg_id, char **out_txt, size_t *out_len) {
     /* ---- records (phasing.py:42-75) */
     size_t n_lines = 1;
     for (size_t i = 0; i < sam_len; i++) n_lines += sam[i] == '\n';
@@ -131,6 +137,7 @@ int orc_consensus(const char *sam, size_t sam_len, const char *ref_seq, size_t r
         for (int ph = 0; ph < 2; ph++) {
             uint32_t *cnt = (uint32_t *)calloc(L * 10, sizeof(uint32_t));
             long long n_used = 0;
+            ins_t *ins = NULL; size_t n_ins = 0, ins_cap = 0;
             for (size_t r = 0; r < n_rec; r++) {
                 int use = 0;
                 for (size_t k = 0; k < n_pr; k++) if (pr[k].qid == rec[r].qid && pr[k].block == blk[b].id && pr[k].phase == ph) { use = 1; break; }
@@ -160,6 +167,12 @@ int orc_consensus(const char *sam, size_t sam_len, const char *ref_seq, size_t r
                             cnt[(size_t)(pp - lo) * 10 + 5]++;
                             int c = code_of((unsigned char)rec[r].seq[qp]);
                             if (c < 4) cnt[(size_t)(pp - lo) * 10 + 6 + c]++;
+                            if (v >= 2) {
+                                if (n_ins == ins_cap) { ins_cap = ins_cap ? ins_cap * 2 : 1024; ins = (ins_t *)realloc(ins, ins_cap * sizeof(ins_t)); }
+                                long long nn = v;
+                                if ((size_t)(qp + nn) > rec[r].sn) nn = (long long)rec[r].sn - qp;
+                                ins[n_ins].x = (size_t)(pp - lo); ins[n_ins].s = rec[r].seq + qp; ins[n_ins].n = nn; n_ins++;
+                            }
                         }
                         qp += v;
                     } else if (op == 'M' || op == '=' || op == 'X') {
@@ -191,20 +204,55 @@ int orc_consensus(const char *sam, size_t sam_len, const char *ref_seq, size_t r
                         char ch = "ACGT"[pick];
                         PUT(&ch, 1);
                     }
-                    if (2 * c[5] > cov) {
-                        uint32_t mx = c[6];
-                        int pick = 0;
-                        for (int k = 1; k < 4; k++) if (c[6 + k] > mx) { mx = c[6 + k]; pick = k; }
-                        if (mx > 0) { char ch = "ACGT"[pick]; PUT(&ch, 1); }
+                    if (version == 1) {
+                        if (2 * c[5] > cov) {
+                            uint32_t mx = c[6];
+                            int pick = 0;
+                            for (int k = 1; k < 4; k++) if (c[6 + k] > mx) { mx = c[6 + k]; pick = k; }
+                            if (mx > 0) { char ch = "ACGT"[pick]; PUT(&ch, 1); }
+                        }
+                    } else {
+                        int chosen[8];
+                        int nd = 0;
+                        uint32_t lv[4] = {c[6], c[7], c[8], c[9]};
+                        for (;;) {
+                            uint32_t mx = lv[0];
+                            int pick = 0;
+                            for (int k = 1; k < 4; k++) if (lv[k] > mx) { mx = lv[k]; pick = k; }
+                            if (!(2 * mx > cov)) break;
+                            chosen[nd++] = pick;
+                            char ch = "ACGT"[pick];
+                            PUT(&ch, 1);
+                            if (nd == 8) break;
+                            lv[0] = lv[1] = lv[2] = lv[3] = 0;       /* next level: I ops here that are longer and spell the chosen bases so far */
+                            for (size_t e = 0; e < n_ins; e++) {
+                                if (ins[e].x != x || ins[e].n <= nd) continue;
+                                int okp = 1;
+                                for (int q = 0; q < nd && okp; q++) okp = code_of((unsigned char)ins[e].s[q]) == chosen[q];
+                                if (!okp) continue;
+                                int cc = code_of((unsigned char)ins[e].s[nd]);
+                                if (cc < 4) lv[cc]++;
+                            }
+                        }
                     }
                 }
                 PUT("\n", 1);
             }
             free(cnt);
+            free(ins);
         }
     }
     out[n_out] = 0;
     free(rec); free(qn); free(pr); free(blk);
     *out_txt = out; *out_len = n_out;
     return 0;
+}
+
+int orc_consensus(const char *sam, size_t sam_len, const char *ref_seq, size_t ref_len, const char *phased_reads, size_t pr_len,
+                  const char *phased_variants, size_t pv_len, const char *ctg_id, char **out_txt, size_t *out_len) {
+    return orc_consensus_v(2, sam, sam_len, ref_seq, ref_len, phased_reads, pr_len, phased_variants, pv_len, ctg_id, out_txt, out_len);
+}
+int orc_consensus_v1(const char *sam, size_t sam_len, const char *ref_seq, size_t ref_len, const char *phased_reads, size_t pr_len,
+                     const char *phased_variants, size_t pv_len, const char *ctg_id, char **out_txt, size_t *out_len) {
+    return orc_consensus_v(1, sam, sam_len, ref_seq, ref_len, phased_reads, pr_len, phased_variants, pv_len, ctg_id, out_txt, out_len);
 }
