@@ -4,7 +4,7 @@
 // is UNPINNED (third-party binary, not vendored).
 //
 //   k_pack        ASCII -> 2 bit/base words (16 bases per u32, base m at bits 2m)
-//   k_index       contig k-mers -> open-addressing table of (key<<32 | smallest position)
+//   k_index_*     contig k-mers -> bucketed table of (key<<32 | position<<1 | strand bit), every sampled position, built partition by partition in LDS
 //   k_seed        per read: diagonal-bin votes of sampled k-mers (both strands) in LDS, argmax, anchor
 //   k_orient      per read: oriented (forward / reverse-complement) packed copy
 //   k_sw          per read, ONE WAVE: adaptive anti-diagonal band, 64 cells = 64 lanes; neighbours
@@ -99,9 +99,9 @@ __device__ __forceinline__ uint32_t hash_slot(uint32_t key, int bits) { return (
 // ---- contig k-mer index: canonical k-mers (min of the k-mer and its reverse complement) of every
 // CTG_STRIDE-th contig position -> EVERY such (position << 1 | "the canonical form is the reverse complement").
 // Table: buckets of 4 entries (32 B, one sector per probe), entry = key << 32 | value; a key's entries fill the
-// first free slots along its bucket chain (linear probing over buckets), so a look-up may stop at the first
-// bucket that still has a free slot: it has then seen every entry of the key.  Insertion order (a race) only
-// decides which slot an entry lands in, never which entries a look-up finds.
+// first free slots along its bucket chain (linear probing over the buckets of its partition), so a look-up may stop at the
+// first bucket that still has a free slot: it has then seen every entry of the key (or more than MAX_OCC of them).
+// Insertion order (a race) only decides which slot an entry lands in, never which entries a look-up finds.
 constexpr int CTG_STRIDE = 2;
 constexpr int MAX_OCC = 8;          // spec: k-mers with more index entries never produce a hit
 constexpr int HIT_CAP = 4096;       // spec: hits of a read beyond the first HIT_CAP (sample order, then position) do not exist
@@ -111,38 +111,104 @@ __device__ __forceinline__ uint32_t canonical(uint32_t key, int k, uint32_t *is_
     *is_rc = r < key ? 1u : 0u;
     return r < key ? r : key;
 }
-__global__ void __launch_bounds__(256) k_index(const uint32_t *__restrict__ ctg_pk, const int64_t *__restrict__ ctg_woff, const int64_t *__restrict__ ctg_len,
-                                               const int64_t *__restrict__ idx_off, const int32_t *__restrict__ idx_bits, int k, uint64_t *__restrict__ table) {
+// Build, two launches and no atomics on HBM beyond one per (workgroup, partition):
+//   the table is cut into partitions of 2^PART_BITS buckets (64 KB = one LDS image); a key's bucket chain wraps inside its partition;
+//   k_index_stage  a workgroup takes 65 536 consecutive sampled positions of a contig: LDS histogram over partitions -> one global
+//                  atomicAdd per touched partition reserves a run in that partition's own 64 KB (used as the staging area) -> entries
+//                  written there, unordered;
+//   k_index_build  a workgroup per partition: staged entries into registers, the partition's table built in LDS (ds 64-bit CAS),
+//                  written back as one coalesced 64 KB image (which also initialises every free slot: no memset).
+// A key keeps at most MAX_OCC + 1 entries (more are never looked at: such k-mers do not produce hits), so homopolymer / satellite
+// k-mers cannot flood a partition.
+constexpr int PART_BITS = 11;                       // buckets per partition: 2048 x 4 slots x 8 B = 64 KB
+constexpr int STAGE_KMERS = 65536;                  // sampled positions per k_index_stage workgroup
+__device__ __forceinline__ uint32_t next_bucket(uint32_t bkt, uint32_t pmask) { return (bkt & ~pmask) | ((bkt + 1) & pmask); }
+
+__global__ void __launch_bounds__(256) k_index_stage(const uint32_t *__restrict__ ctg_pk, const int64_t *__restrict__ ctg_woff, const int64_t *__restrict__ ctg_len,
+                                                     const int64_t *__restrict__ idx_off, const int32_t *__restrict__ idx_bits, const int64_t *__restrict__ part_off, int k,
+                                                     uint64_t *__restrict__ table, uint32_t *__restrict__ cursor, int32_t *__restrict__ overflow) {
+    __shared__ uint32_t hist[1 << 12], base[1 << 12];          // partitions of one contig (<= 4096: contigs up to 2^31 bases / 2 per 8192-slot partition... see host check)
     const int c = blockIdx.y;
     const int64_t nk = ctg_len[c] - k + 1;
+    const int64_t q0 = (int64_t)blockIdx.x * STAGE_KMERS;      // sampled index: position = 2 q
+    if (q0 * CTG_STRIDE >= nk) return;
     const uint32_t *pk = ctg_pk + ctg_woff[c];
+    const int bbits = idx_bits[c] - 2;
+    const int pbits = bbits < PART_BITS ? bbits : PART_BITS;
+    const int n_part = 1 << (bbits - pbits);
     uint64_t *tab = table + idx_off[c];
-    const int bbits = idx_bits[c] - 2;                    // buckets
-    const uint32_t bmask = (1u << bbits) - 1u;
-    for (int64_t p = ((int64_t)blockIdx.x * 256 + threadIdx.x) * CTG_STRIDE; p < nk; p += (int64_t)gridDim.x * 256 * CTG_STRIDE) {
-        uint32_t orc;
-        uint32_t key = canonical(kmer_at(pk, p, k), k, &orc);
-        uint64_t word = ((uint64_t)key << 32) | (uint64_t)(((uint32_t)p << 1) | orc);
-        uint32_t bkt = hash_slot(key, bbits);
-        uint32_t s0 = (key >> 3) & 3u;                   // first slot tried: spreads the first attempts over the bucket
-        for (;;) {
-            bool placed = false;
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const uint32_t sl = (s0 + q) & 3u;
-                unsigned long long old = atomicCAS((unsigned long long *)&tab[(size_t)bkt * 4 + sl], (unsigned long long)EMPTY, (unsigned long long)word);
-                if (old == EMPTY) { placed = true; break; }
+    uint32_t *cur = cursor + part_off[c];
+    for (int i = threadIdx.x; i < n_part; i += 256) hist[i] = 0;
+    __syncthreads();
+    for (int pass = 0; pass < 2; pass++) {
+        for (int64_t q = q0 + threadIdx.x; q < q0 + STAGE_KMERS; q += 256) {
+            const int64_t pos = q * CTG_STRIDE;
+            if (pos >= nk) break;
+            uint32_t orc;
+            const uint32_t key = canonical(kmer_at(pk, pos, k), k, &orc);
+            const uint32_t part = hash_slot(key, bbits) >> pbits;
+            if (pass == 0) atomicAdd(&hist[part], 1u);
+            else {
+                const uint32_t at = base[part] + atomicAdd(&hist[part], 1u);
+                if (at < (4u << pbits)) tab[((size_t)part << (pbits + 2)) + at] = ((uint64_t)key << 32) | (uint64_t)(((uint32_t)pos << 1) | orc);
+                else *overflow = 1;
             }
-            if (placed) break;
-            bkt = (bkt + 1) & bmask;
-            s0 = 0;
+        }
+        __syncthreads();
+        if (pass == 0) {
+            for (int i = threadIdx.x; i < n_part; i += 256) { const uint32_t h = hist[i]; base[i] = h ? atomicAdd(&cur[i], h) : 0u; hist[i] = 0; }
+            __syncthreads();
         }
     }
+}
+__global__ void __launch_bounds__(256) k_index_build(const int32_t *__restrict__ part_ctg, const int64_t *__restrict__ part_off, const int64_t *__restrict__ idx_off,
+                                                     const int32_t *__restrict__ idx_bits, uint64_t *__restrict__ table, const uint32_t *__restrict__ cursor,
+                                                     int32_t *__restrict__ overflow) {
+    extern __shared__ unsigned long long ltab[];               // 4 << pbits slots
+    const int64_t gp = blockIdx.x;
+    const int c = part_ctg[gp];
+    const uint32_t part = (uint32_t)(gp - part_off[c]);
+    const int bbits = idx_bits[c] - 2;
+    const int pbits = bbits < PART_BITS ? bbits : PART_BITS;
+    const uint32_t n_slots = 4u << pbits, pmask = (1u << pbits) - 1u;
+    uint64_t *img = table + idx_off[c] + ((size_t)part << (pbits + 2));
+    uint32_t cnt = cursor[gp];
+    if (cnt > n_slots) cnt = n_slots;
+    uint64_t mine[32];                                         // n_slots / 256 staged entries at most
+    int nm = 0;
+    for (uint32_t i = threadIdx.x; i < cnt; i += 256) mine[nm++] = img[i];
+    for (uint32_t i = threadIdx.x; i < n_slots; i += 256) ltab[i] = (unsigned long long)EMPTY;
+    __syncthreads();
+    for (int m = 0; m < nm; m++) {
+        const uint64_t word = mine[m];
+        const uint32_t key = (uint32_t)(word >> 32);
+        uint32_t bkt = hash_slot(key, bbits) & pmask;          // local bucket
+        uint32_t s0 = (key >> 3) & 3u, copies = 0, walked = 0;
+        bool done = false;
+        while (!done) {
+            for (int q = 0; q < 4 && !done; q++) {
+                const uint32_t sl = bkt * 4 + ((s0 + q) & 3u);
+                unsigned long long cur = ltab[sl];
+                if (cur == (unsigned long long)EMPTY) {
+                    if (copies > (uint32_t)MAX_OCC) { done = true; break; }      // the key already has MAX_OCC + 1 entries: enough to be ignored
+                    cur = atomicCAS(&ltab[sl], (unsigned long long)EMPTY, (unsigned long long)word);
+                    if (cur == (unsigned long long)EMPTY) { done = true; break; }
+                }
+                if ((uint32_t)(cur >> 32) == key) copies++;
+            }
+            if (done) break;
+            bkt = (bkt + 1) & pmask;
+            s0 = 0;
+            if (++walked > pmask) { *overflow = 1; break; }
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n_slots; i += 256) img[i] = ltab[i];
 }
 // every index entry of `key` (values, unsorted) into e[0..MAX_OCC); returns the count, MAX_OCC + 1 if there are more.
 // b0 = the key's first bucket, already loaded by the caller (several probes are kept in flight).
 __device__ __forceinline__ int index_collect(const uint64_t *__restrict__ tab, int bbits, uint32_t key, uint32_t bkt, uint4 lo, uint4 hi, uint32_t *e) {
-    const uint32_t bmask = (1u << bbits) - 1u;
+    const uint32_t pmask = (1u << (bbits < PART_BITS ? bbits : PART_BITS)) - 1u;
     int cnt = 0;
     for (;;) {
         const uint32_t kk[4] = {lo.y, lo.w, hi.y, hi.w}, vv[4] = {lo.x, lo.z, hi.x, hi.z};
@@ -153,7 +219,7 @@ __device__ __forceinline__ int index_collect(const uint64_t *__restrict__ tab, i
             else if (kk[q] == key) { if (cnt < MAX_OCC) e[cnt] = vv[q]; cnt++; }
         }
         if (open || cnt > MAX_OCC) break;
-        bkt = (bkt + 1) & bmask;
+        bkt = next_bucket(bkt, pmask);
         const uint4 *bp = (const uint4 *)(tab + (size_t)bkt * 4);
         lo = bp[0]; hi = bp[1];
     }
@@ -1209,6 +1275,11 @@ struct fzp_alnjob {
     DevBuf<int64_t> ctg_woff, ctg_len, idx_off, read_woff, tb_off, cig_off, cig_start;
     DevBuf<int32_t> idx_bits, read_len, read_ctg;
     DevBuf<uint64_t> table;
+    DevBuf<uint32_t> part_cursor;                // k-mer index build: staged entries per partition
+    DevBuf<int32_t> part_ctg, idx_overflow;
+    DevBuf<int64_t> part_off;
+    std::vector<int64_t> h_part_off;
+    int64_t n_parts = 0;
     DevBuf<Anchor> anc, ancB, anc2;              // first candidates (per read), second candidates (per read; compacted)
     DevBuf<int64_t> tbo, mvo;                    // per read: where the winning candidate's trace-back masks / move words are
     DevBuf<uint2> hits;                          // seeding: HIT_CAP hit slots per read of a seeding launch
@@ -1340,6 +1411,23 @@ extern "C" int fzp_align_create(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *cons
             hipLaunchKernelGGL(k_pack, dim3((unsigned)n_reads, 1), dim3(256), 0, st, d_ascii.p, d_off.p, j->read_woff.p, j->read_pk.p);
             if (hipStreamSynchronize(st) != hipSuccess) { rc = FZP_EDEVICE; break; }
         }
+        {   // partitions of every contig's table (k_index_stage / k_index_build)
+            std::vector<int32_t> pc;
+            j->h_part_off.assign(1, 0);
+            for (int c = 0; c < n_ctg; c++) {
+                const int bbits = j->h_idx_bits[(size_t)c] - 2;
+                const int np = 1 << (bbits - std::min(bbits, PART_BITS));
+                if (np > 4096) { rc = FZP_EINVAL; fzp_set_error("contig %d: k-mer index of %d partitions (limit 4096: contigs up to ~33 Mb)", c, np); break; }
+                for (int q = 0; q < np; q++) pc.push_back(c);
+                j->h_part_off.push_back(j->h_part_off.back() + np);
+            }
+            if (rc) break;
+            j->n_parts = j->h_part_off.back();
+            if ((rc = j->part_ctg.upload(pc.data(), pc.size(), st)) || (rc = j->part_off.upload(j->h_part_off.data(), j->h_part_off.size(), st)) ||
+                (rc = j->part_cursor.alloc((size_t)j->n_parts)) || (rc = j->idx_overflow.alloc(1)))
+                break;
+            if (hipStreamSynchronize(st) != hipSuccess) { rc = FZP_EDEVICE; break; }
+        }
         if ((rc = j->table.alloc((size_t)j->idx_slots)) || (rc = j->anc.alloc((size_t)n_reads)) || (rc = j->ancB.alloc((size_t)n_reads)) || (rc = j->tbo.alloc((size_t)n_reads)) ||
             (rc = j->mvo.alloc((size_t)n_reads)) || (rc = j->n_sec.alloc(1)) || (rc = j->info.alloc((size_t)n_reads)) ||
             (rc = j->summ.alloc((size_t)n_reads)) || (rc = j->cig.alloc((size_t)j->h_cig_off.back())) || (rc = j->cig_start.alloc((size_t)n_reads)))
@@ -1358,8 +1446,17 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
     const fzp_align_params &P = j->P;
     {
         ProfScope ps(ctx, "k1_index");
-        FZP_HIP(hipMemsetAsync(j->table.p, 0xff, (size_t)j->idx_slots * sizeof(uint64_t), st));
-        hipLaunchKernelGGL(k_index, dim3(1024, j->n_ctg), dim3(256), 0, st, j->ctg_pk.p, j->ctg_woff.p, j->ctg_len.p, j->idx_off.p, j->idx_bits.p, P.kmer, j->table.p);
+        int64_t lc_max = 0;
+        for (auto v : j->h_ctg_len) lc_max = std::max(lc_max, v);
+        const unsigned gx = (unsigned)std::max<int64_t>(1, ((lc_max + CTG_STRIDE - 1) / CTG_STRIDE + STAGE_KMERS - 1) / STAGE_KMERS);
+        FZP_HIP(hipMemsetAsync(j->part_cursor.p, 0, (size_t)j->n_parts * 4, st));
+        FZP_HIP(hipMemsetAsync(j->idx_overflow.p, 0, 4, st));
+        hipLaunchKernelGGL(k_index_stage, dim3(gx, j->n_ctg), dim3(256), 0, st, j->ctg_pk.p, j->ctg_woff.p, j->ctg_len.p, j->idx_off.p, j->idx_bits.p, j->part_off.p, P.kmer,
+                           j->table.p, j->part_cursor.p, j->idx_overflow.p);
+        const size_t lds = (size_t)(4u << PART_BITS) * 8;
+        FZP_HIP(hipFuncSetAttribute((const void *)k_index_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_index_build, dim3((unsigned)j->n_parts), dim3(256), lds, st, j->part_ctg.p, j->part_off.p, j->idx_off.p, j->idx_bits.p, j->table.p, j->part_cursor.p,
+                           j->idx_overflow.p);
     }
     const int64_t nr = j->n_reads;
     if (nr > 0) {
@@ -1390,8 +1487,11 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
         }
         // second candidates (reads whose votes show a second placement: repeats).  Usually none; then nothing below runs.
         uint32_t n2 = 0;
+        int32_t ovf = 0;
         FZP_HIP(hipMemcpyAsync(&n2, j->n_sec.p, 4, hipMemcpyDeviceToHost, st));
+        FZP_HIP(hipMemcpyAsync(&ovf, j->idx_overflow.p, 4, hipMemcpyDeviceToHost, st));
         FZP_HIP(hipStreamSynchronize(st));
+        if (ovf) { fzp_set_error("k-mer index: a table partition overflowed (more than %d distinct k-mers hash into one 64 KB partition)", 4 << PART_BITS); return FZP_EINVAL; }
         j->n_second = n2;
         std::vector<int32_t> h_ridx;
         std::vector<int64_t> h_tb_off2(1, 0);
