@@ -12,7 +12,9 @@ library's fzp_job_phase_write:
   K1 index + seed + chain + banded DP + trace-back -> records ("samtools sort" order, record filters)
   K2 pileup + het call -> K3 association table -> K4 phase blocks -> K5 read phasing
   text of all seven files of every contig (variant_map / atable serialised on the device, the rest by host threads),
-  the files WRITTEN under a scratch directory, get_phasing_readmap -> rid_to_phase records
+  the files WRITTEN under a scratch directory (the page-cache copies run on background threads of the library and may still be
+  going on while the next step's kernels start; the closing barrier waits for every file of every step: fzp_pipe_flush),
+  get_phasing_readmap -> rid_to_phase records
   -> one all-gather of the records across ranks (skipped at world size 1).
 `value` = reads processed by all ranks / max-over-ranks step time.  `dp_gcell_per_s_per_gpu` is the banded-DP rate of
 the dominant kernel (k1_sw) from HIP events on the library's stream.  `end_to_end` (not `value`: the bench contract keeps
@@ -226,6 +228,7 @@ def main():
 
     def barrier():
         eng.synchronize()
+        eng.pipe_flush()                               # every file of every step so far is on the file system
         if world > 1:
             dist.barrier()
             if backend == "nccl":
@@ -241,7 +244,7 @@ def main():
         step_no[0] += 1
         out_dir = os.path.join(out_root, "step%03d" % step_no[0])      # a fresh tree per step, as a job would write it (no re-truncation of old files)
         t_a = time.perf_counter()
-        st, recs = job.phase_write(ids, names=name_tab, out_dir=out_dir, read_maps=maps, ctg_index=mine, consensus=args.with_consensus)
+        st, recs = job.phase_write(ids, names=name_tab, out_dir=out_dir, read_maps=maps, ctg_index=mine, consensus=args.with_consensus, async_writes=True)
         recs["arid"] += arid_base                      # the read_map files of a rank number its preads from 0: make the ids job-wide
         t_b = time.perf_counter()
         allr = comm.allgather_r2p(recs) if comm is not None else fdist.allgather_r2p(recs, device=coll_dev if world > 1 else None)
@@ -300,7 +303,7 @@ def main():
         for k in range(3):
             t1 = time.perf_counter()
             st, recs = _lib.phase_contigs(eng, contigs, blob, off, read_ctg, ids, names=name_tab, out_dir=os.path.join(out_root, "e2e%d" % k), read_maps=maps, ctg_index=mine,
-                                          n_lanes=args.e2e_lanes, group_bases=gb, consensus=args.with_consensus)
+                                          n_lanes=args.e2e_lanes, group_bases=gb, consensus=args.with_consensus, async_writes=True)
             runs.append((time.perf_counter() - t1, st))
         best = min(runs[1:], key=lambda x: x[0])
         e2e = {"reads_per_s": round(n_reads / best[0], 1), "ms": round(best[0] * 1e3, 2), "lanes": args.e2e_lanes, "groups": int(best[1]["n_groups"]),

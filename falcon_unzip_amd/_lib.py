@@ -100,7 +100,7 @@ class AlignParams(C.Structure):
 _lib = None
 
 
-PIPE_CONSENSUS = 1
+PIPE_CONSENSUS, PIPE_ASYNC_WRITES = 1, 2
 TEXT_VARIANT_MAP, TEXT_ATABLE = 1, 2
 
 
@@ -172,6 +172,7 @@ def load():
         "fzp_job_phase_write": (C.c_int, [VP, VP, VP, VP, VP]),
         "fzp_phase_contigs": (C.c_int, [VP, I32, VP, VP, I64, VP, VP, VP, VP, VP, VP]),
         "fzp_pipe_out_free": (None, [VP]),
+        "fzp_pipe_flush": (C.c_int, [VP]),
         "fzp_comm_unique_id": (C.c_int, [VP]),
         "fzp_comm_create": (C.c_int, [VP, C.c_int, C.c_int, VP, PP]),
         "fzp_comm_destroy": (None, [VP]),
@@ -396,6 +397,10 @@ class Engine:
 
     __del__ = close
 
+    def pipe_flush(self):
+        """wait for the background file writes of phase_write(async_writes=True) calls; raises on the first write error"""
+        _check(load().fzp_pipe_flush(self._p))
+
     def synchronize(self):
         _check(load().fzp_ctx_synchronize(self._p))
 
@@ -504,10 +509,11 @@ class AlignJob:
         idx = _take(ip.value, a.n_rec, np.int64)
         return a, idx
 
-    def phase_write(self, ctg_ids, names=None, out_dir=None, read_maps=None, ctg_index=None, n_threads=0, consensus=False):
+    def phase_write(self, ctg_ids, names=None, out_dir=None, read_maps=None, ctg_index=None, n_threads=0, consensus=False, async_writes=False):
         """fzp_job_phase_write: K1 -> K5 of every contig of the job, every file of every contig under out_dir, rid_to_phase records.
         names: (name_off int64 [n_reads+1], blob) or a list; read_maps: (rawread_ids, pread_ids, pread_to_contigs) bytes.  -> (stats dict, R2P records)"""
-        nm, opts, keep = _pipe_args(ctg_ids, names, out_dir, read_maps, ctg_index, n_threads, 0, 0, None, PIPE_CONSENSUS if consensus else 0)
+        nm, opts, keep = _pipe_args(ctg_ids, names, out_dir, read_maps, ctg_index, n_threads, 0, 0, None,
+                                    (PIPE_CONSENSUS if consensus else 0) | (PIPE_ASYNC_WRITES if async_writes else 0))
         out = PipeOut()
         _check(load().fzp_job_phase_write(self.eng._p, self._p, C.byref(nm), C.byref(opts), C.byref(out)))
         return _pipe_result(out)
@@ -611,7 +617,7 @@ def _pipe_result(out):
 
 
 def phase_contigs(eng, contigs, read_blob: bytes, read_off, read_ctg, ctg_ids, names=None, out_dir=None, read_maps=None, ctg_index=None,
-                  n_threads=0, n_lanes=0, group_bases=0, params=None, consensus=False):
+                  n_threads=0, n_lanes=0, group_bases=0, params=None, consensus=False, async_writes=False):
     """fzp_phase_contigs: inputs in host memory -> every file of every contig + rid_to_phase records; contig groups are streamed through the
     device on `n_lanes` lanes.  -> (stats dict, R2P records)"""
     lib = load()
@@ -622,7 +628,8 @@ def phase_contigs(eng, contigs, read_blob: bytes, read_off, read_ctg, ctg_ids, n
     cptr = (C.c_void_p * nc)(*[C.cast(b, C.c_void_p).value for b in cbufs])
     clen = (C.c_int64 * nc)(*[len(c) for c in contigs])
     rc = np.ascontiguousarray(read_ctg, dtype=np.int32)
-    nm, opts, keep = _pipe_args(ctg_ids, names, out_dir, read_maps, ctg_index, n_threads, n_lanes, group_bases, params, PIPE_CONSENSUS if consensus else 0)
+    nm, opts, keep = _pipe_args(ctg_ids, names, out_dir, read_maps, ctg_index, n_threads, n_lanes, group_bases, params,
+                                (PIPE_CONSENSUS if consensus else 0) | (PIPE_ASYNC_WRITES if async_writes else 0))
     out = PipeOut()
     _check(lib.fzp_phase_contigs(eng._p, nc, cptr, clen, nr, _ptr(rc), _ptr(read_off), read_blob, C.byref(nm), C.byref(opts), C.byref(out)))
     return _pipe_result(out)

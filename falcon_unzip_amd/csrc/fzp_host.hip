@@ -234,6 +234,7 @@ extern "C" void fzp_ctx_destroy(fzp_ctx *ctx) {
     if (!ctx) return;
     for (auto l : ctx->lanes) fzp_ctx_destroy(l);
     ctx->lanes.clear();
+    fzp_writer_destroy(ctx);                         // joins outstanding background file writes
     (void)fzp_bind(ctx);
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipStreamSynchronize(ctx->stream2);

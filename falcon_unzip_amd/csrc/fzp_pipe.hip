@@ -17,12 +17,72 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <functional>
 #include <thread>
 #include <unordered_map>
 
 #include "fzp_batch.h"
 
 int fzp_batch_text_dev(fzp_ctx *ctx, fzp_batch *b, int what, DevBuf<char> &text, size_t *bytes, std::vector<int64_t> &ctg_begin);
+
+// ---- background file writes (FZP_PIPE_ASYNC_WRITES): a few threads per ctx drain a queue of per-contig write tasks, so that the
+// page-cache copies (and the file system's occasional throttling) of one call overlap the kernels of the next
+struct FileWriter {
+    std::mutex mu;
+    std::condition_variable cv, idle;
+    std::deque<std::function<void()>> q;
+    std::vector<std::thread> th;
+    int running = 0;
+    bool stop = false;
+    std::string first_error;
+    void start(int n) {
+        for (int i = 0; i < n; i++)
+            th.emplace_back([this] {
+                for (;;) {
+                    std::function<void()> job;
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv.wait(lk, [this] { return stop || !q.empty(); });
+                        if (q.empty()) return;
+                        job = std::move(q.front());
+                        q.pop_front();
+                        running++;
+                    }
+                    job();
+                    {
+                        std::lock_guard<std::mutex> lk(mu);
+                        running--;
+                        if (q.empty() && running == 0) idle.notify_all();
+                    }
+                }
+            });
+    }
+    void push(std::function<void()> f) {
+        { std::lock_guard<std::mutex> lk(mu); q.push_back(std::move(f)); }
+        cv.notify_one();
+    }
+    void fail(const std::string &e) { std::lock_guard<std::mutex> lk(mu); if (first_error.empty()) first_error = e; }
+    std::string drain() {
+        std::unique_lock<std::mutex> lk(mu);
+        idle.wait(lk, [this] { return q.empty() && running == 0; });
+        std::string e;
+        e.swap(first_error);
+        return e;
+    }
+    ~FileWriter() {
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cv.notify_all();
+        for (auto &t : th) t.join();
+    }
+};
+void fzp_writer_destroy(fzp_ctx *ctx) {
+    if (!ctx || !ctx->writer) return;
+    (void)ctx->writer->drain();
+    delete ctx->writer;
+    ctx->writer = nullptr;
+}
 
 namespace {
 using clk = std::chrono::steady_clock;
@@ -243,7 +303,16 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
     const size_t o_atab = (n_vmap + 63) & ~(size_t)63, o_qr = o_atab + ((n_atab + 63) & ~(size_t)63);
     char *pin = (char *)fzp_pinned_acquire(ctx, o_qr + (size_t)n_slots * 4 + 64, &pin_cap);
     if (!pin) { fzp_set_error("pinned host allocation failed"); return FZP_ENOMEM; }
-    struct PG { fzp_ctx *c; void *p; ~PG() { fzp_pinned_release(c, p); } } pg{ctx, pin};
+    // the block (and the small texts) live until their last file is written: shared by the per-contig write tasks
+    struct Owned {
+        fzp_ctx *c; void *pin; std::vector<char *> texts; std::mutex mu;
+        ~Owned() { fzp_pinned_release(c, pin); for (auto t : texts) free(t); }
+    };
+    std::shared_ptr<Owned> owned = std::make_shared<Owned>();
+    owned->c = ctx; owned->pin = pin;
+    const bool async = (o->flags & FZP_PIPE_ASYNC_WRITES) != 0 && o->out_dir;
+    if (async && !ctx->writer) { ctx->writer = new FileWriter(); ctx->writer->start((int)std::min(16u, std::max(2u, std::thread::hardware_concurrency() / 4))); }
+    if (async) { const std::string e = [&] { std::lock_guard<std::mutex> lk(ctx->writer->mu); std::string x; x.swap(ctx->writer->first_error); return x; }(); if (!e.empty()) { fzp_set_error("%s", e.c_str()); return FZP_EINVAL; } }
     hipStream_t st2 = ctx->stream2;
     FZP_HIP(hipStreamSynchronize(ctx->stream));
     if (n_vmap) FZP_HIP(hipMemcpyAsync(pin, d_vmap.p, n_vmap, hipMemcpyDeviceToHost, st2));
@@ -306,22 +375,39 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
                 have_r2p = rc == FZP_OK;
             } else if (rc != FZP_OK) errs[(size_t)t] = fzp_last_error();
             us_map += (int64_t)(ms_since(tq) * 1e3); tq = clk::now();
+            char *fa = nullptr; size_t fl = 0;
+            if (rc == FZP_OK && o->out_dir && want_cns && fzp_format_tigs(&tigs, c, ctg, &fa, &fl) != FZP_OK) { rc = FZP_EINVAL; errs[(size_t)t] = fzp_last_error(); }
             if (rc == FZP_OK && o->out_dir) {
-                const std::string base = out_dir + "/" + ctg;
-                bool ok = mkdir_p(base + "/het_call") && mkdir_p(base + "/g_atable") && mkdir_p(base + "/get_phased_blocks");
-                ok = ok && write_file(base + "/het_call/variant_pos", txt[0], len[0], bytes) && write_file(base + "/het_call/variant_map", pin + vb[(size_t)c], (size_t)(vb[(size_t)c + 1] - vb[(size_t)c]), bytes) &&
-                     write_file(base + "/het_call/q_id_map", qmap.data(), qmap.size(), bytes) && write_file(base + "/g_atable/atable", pin + o_atab + ab[(size_t)c], (size_t)(ab[(size_t)c + 1] - ab[(size_t)c]), bytes) &&
-                     write_file(base + "/get_phased_blocks/phased_variants", txt[1], len[1], bytes) && write_file(base + "/phased_reads", txt[2], len[2], bytes);
-                if (ok && have_r2p) ok = write_file(base + "/rid_to_phase." + ctg, r2p_text.data(), r2p_text.size(), bytes);
-                if (ok && want_cns) {
-                    char *fa = nullptr; size_t fl = 0;
-                    if (fzp_format_tigs(&tigs, c, ctg, &fa, &fl) != FZP_OK) { rc = FZP_EINVAL; errs[(size_t)t] = fzp_last_error(); }
-                    else { ok = mkdir_p(base + "/cns") && write_file(base + "/cns/phased_blocks.fa", fa, fl, bytes); free(fa); }
-                }
-                if (!ok && rc == FZP_OK) { rc = FZP_EINVAL; errs[(size_t)t] = "cannot write under " + base + ": " + strerror(errno); }
+                // everything the files need is owned by `owned` (pinned texts, malloc'ed small texts) or moved into the task (strings)
+                { std::lock_guard<std::mutex> lk(owned->mu); for (auto p : txt) owned->texts.push_back(p); if (fa) owned->texts.push_back(fa); }
+                const std::string base = out_dir + "/" + ctg, ctg_s = ctg;
+                const char *t0 = txt[0], *t1 = txt[1], *t2 = txt[2], *pv = pin + vb[(size_t)c], *pa = pin + o_atab + ab[(size_t)c];
+                const size_t l0 = len[0], l1 = len[1], l2 = len[2], lv = (size_t)(vb[(size_t)c + 1] - vb[(size_t)c]), la = (size_t)(ab[(size_t)c + 1] - ab[(size_t)c]);
+                auto qmap_p = std::make_shared<std::string>(std::move(qmap));
+                auto r2p_p = std::make_shared<std::string>(std::move(r2p_text));
+                std::atomic<int64_t> *bytes_p = &bytes;
+                FileWriter *fw = async ? ctx->writer : nullptr;
+                auto task = [owned, base, ctg_s, t0, t1, t2, pv, pa, l0, l1, l2, lv, la, qmap_p, r2p_p, have_r2p, want_cns, fa, fl, bytes_p, fw]() -> bool {
+                    std::atomic<int64_t> local{0};
+                    std::atomic<int64_t> &bt = fw ? local : *bytes_p;
+                    bool ok = mkdir_p(base + "/het_call") && mkdir_p(base + "/g_atable") && mkdir_p(base + "/get_phased_blocks");
+                    ok = ok && write_file(base + "/het_call/variant_pos", t0, l0, bt) && write_file(base + "/het_call/variant_map", pv, lv, bt) &&
+                         write_file(base + "/het_call/q_id_map", qmap_p->data(), qmap_p->size(), bt) && write_file(base + "/g_atable/atable", pa, la, bt) &&
+                         write_file(base + "/get_phased_blocks/phased_variants", t1, l1, bt) && write_file(base + "/phased_reads", t2, l2, bt);
+                    if (ok && have_r2p) ok = write_file(base + "/rid_to_phase." + ctg_s, r2p_p->data(), r2p_p->size(), bt);
+                    if (ok && want_cns) ok = mkdir_p(base + "/cns") && write_file(base + "/cns/phased_blocks.fa", fa, fl, bt);
+                    if (!ok && fw) fw->fail("cannot write under " + base + ": " + strerror(errno));
+                    return ok;
+                };
+                if (async) {
+                    bytes += (int64_t)(l0 + l1 + l2 + lv + la + qmap_p->size() + (have_r2p ? r2p_p->size() : 0) + (want_cns ? fl : 0));     // what the queued task will write
+                    ctx->writer->push([task]() { (void)task(); });
+                } else if (!task()) { rc = FZP_EINVAL; errs[(size_t)t] = "cannot write under " + base + ": " + strerror(errno); }
+            } else {
+                for (auto p : txt) free(p);
+                free(fa);
             }
             us_write += (int64_t)(ms_since(tq) * 1e3);
-            for (auto p : txt) free(p);
             if (rc != FZP_OK) rcs[(size_t)t] = rc;
         }
     };
@@ -483,7 +569,9 @@ extern "C" int fzp_phase_contigs(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *con
         for (auto &x : th) x.join();
     }
     (void)fzp_bind(ctx);
+    const int frc = fzp_pipe_flush(ctx);                    // FZP_PIPE_ASYNC_WRITES: the groups' files overlapped other groups' kernels; all are down now
     for (int li = 0; li < lanes; li++) if (rcs[(size_t)li] != FZP_OK) { fzp_set_error("%s", errs[(size_t)li].c_str()); return rcs[(size_t)li]; }
+    if (frc != FZP_OK) return frc;
     for (int li = 0; li < lanes; li++) add(out, outs[(size_t)li]);
     std::vector<fzp_r2p> all;
     for (auto &v : r2p_g[0]) all.insert(all.end(), v.begin(), v.end());
@@ -491,6 +579,15 @@ extern "C" int fzp_phase_contigs(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *con
     out->r2p = (fzp_r2p *)malloc((all.size() ? all.size() : 1) * sizeof(fzp_r2p));
     if (!out->r2p) return FZP_ENOMEM;
     if (!all.empty()) memcpy(out->r2p, all.data(), all.size() * sizeof(fzp_r2p));
+    return FZP_OK;
+}
+
+extern "C" int fzp_pipe_flush(fzp_ctx *ctx) {
+    if (!ctx) return FZP_EINVAL;
+    std::string err;
+    if (ctx->writer) err = ctx->writer->drain();
+    for (auto l : ctx->lanes) if (l->writer) { const std::string e = l->writer->drain(); if (err.empty()) err = e; }
+    if (!err.empty()) { fzp_set_error("%s", err.c_str()); return FZP_EINVAL; }
     return FZP_OK;
 }
 

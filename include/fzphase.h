@@ -283,6 +283,8 @@ int fzp_batch_text(fzp_ctx *ctx, fzp_batch *b, int what, char **text, size_t *le
 /* ---- many contigs, one call: the job fan-out of unzip_all (unzip.py:221-288: per contig one blasr task, unzip.py:61-99, and one
  * phasing task, unzip.py:102-133 = fc_phasing.py + fc_phasing_readmap.py), files included.  SURVEY 8b's fzp_phase_contigs. */
 #define FZP_PIPE_CONSENSUS 1u     /* also K6 (fzp_batch_consensus): <ctg>/cns/phased_blocks.fa */
+#define FZP_PIPE_ASYNC_WRITES 2u  /* the call returns once every text exists and its write is queued; a few background threads of the ctx write the files while
+                                     the caller goes on (e.g. with the next job's kernels); fzp_pipe_flush(ctx) waits for them and reports the first error */
 typedef struct {
     int32_t n_ctg;
     const char *const *ctg_id;     /* [n_ctg] names: directory names and the ctg column of phased_reads / rid_to_phase */
@@ -317,6 +319,7 @@ int fzp_job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *names, c
 int fzp_phase_contigs(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *const *ctg_seq, const int64_t *ctg_len, int64_t n_reads, const int32_t *read_ctg,
                       const int64_t *read_off, const uint8_t *read_seq, const fzp_names *names, const fzp_pipe_opts *opts, fzp_pipe_out *out);
 void fzp_pipe_out_free(fzp_pipe_out *o);
+int fzp_pipe_flush(fzp_ctx *ctx);   /* every queued file of FZP_PIPE_ASYNC_WRITES calls on this ctx (and its lanes) is on the file system when this returns */
 
 /* ---- the one exchange step of the multi-GPU path (get_rid_to_phase_all, unzip.py:303-314): every rank contributes the
  * rid_to_phase records of its contigs, every rank receives all of them ordered by (contig index, pread id) -- the order of

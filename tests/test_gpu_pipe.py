@@ -184,3 +184,26 @@ def test_two_engines_in_one_process(oracle):
     c1.check("variant_map", _lib.format_variant_map(b4.result(0).sites, b4.result(0).vmap_qid))
     b4.close()
     e1.close()
+
+
+def test_async_writes_are_complete_after_flush(eng, tmp_path):
+    """FZP_PIPE_ASYNC_WRITES: the call returns with the writes queued; after fzp_pipe_flush the trees equal the synchronous ones"""
+    from falcon_unzip_amd import _lib
+    contigs, blob, off, read_ctg, names, ids = _make_job(n_ctg=3)
+    maps = _read_maps(names, read_ctg, ids)
+    job = _lib.align_job_raw(eng, contigs, blob, off, read_ctg)
+    job.phase_write(ids, names=names, out_dir=str(tmp_path / "sync"), read_maps=maps)
+    for k in range(3):                                     # several calls in flight share the writer threads
+        st, recs = job.phase_write(ids, names=names, out_dir=str(tmp_path / ("async%d" % k)), read_maps=maps, async_writes=True)
+    eng.pipe_flush()
+    job.close()
+    for k in range(3):
+        for ctg in ids:
+            for rel in FILES + ("rid_to_phase.%s" % ctg,):
+                with open(os.path.join(str(tmp_path / "sync"), ctg, rel), "rb") as f, open(os.path.join(str(tmp_path / ("async%d" % k)), ctg, rel), "rb") as g:
+                    assert f.read() == g.read(), (k, ctg, rel)
+    assert st["bytes_written"] > 100000
+    with pytest.raises(_lib.FzpError):                     # an unwritable target surfaces at the flush
+        job2 = _lib.align_job_raw(eng, contigs, blob, off, read_ctg)
+        job2.phase_write(ids, names=names, out_dir="/proc/no_such_dir/x", read_maps=maps, async_writes=True)
+        eng.pipe_flush()

@@ -1,14 +1,18 @@
 #!/bin/bash
 # usage (on the GPU box, from the repo root): bash tools/profile_round.sh <tag>
-# kernel-trace stats of the bench, then the two HBM counter passes (each in its own rocprofv3 run, counters only)
+# kernel-trace stats of the bench, the two HBM counter passes and the SQ issue counters (each in its own rocprofv3 run, counters only;
+# the program sits directly after `--` and never forks: --gen-workers 1), then the default bench line
 tag=$1
 export TMPDIR=/tmp
 out=gpurun_out/prof_$tag
 mkdir -p $out
-rocprofv3 --kernel-trace --stats -d $out/kt -o kt --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $out/kt_bench_line.json 2> $out/kt.log
-rocprofv3 --pmc FETCH_SIZE -d $out/fetch -o p --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --gen-workers 1 > /dev/null 2> $out/fetch.log
-rocprofv3 --pmc WRITE_SIZE -d $out/write -o p --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --gen-workers 1 > /dev/null 2> $out/write.log
+B="--no-cpu-baseline --no-end-to-end --gen-workers 1"
+rocprofv3 --kernel-trace --stats -d $out/kt -o kt --output-format csv -- python3 bench.py --steps 2 --warmup 1 $B > $out/kt_bench_line.json 2> $out/kt.log
+rocprofv3 --pmc FETCH_SIZE -d $out/fetch -o p --output-format csv -- python3 bench.py --steps 1 --warmup 0 $B > /dev/null 2> $out/fetch.log
+rocprofv3 --pmc WRITE_SIZE -d $out/write -o p --output-format csv -- python3 bench.py --steps 1 --warmup 0 $B > /dev/null 2> $out/write.log
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVES -d $out/sq -o p --output-format csv -- python3 bench.py --steps 1 --warmup 0 $B > /dev/null 2> $out/sq.log
 python3 tools/pmc_hbm_summary.py $(find $out/fetch -name '*counter_collection.csv') $(find $out/write -name '*counter_collection.csv') $out/pmc_hbm_bytes.csv $out/k1_sw_hbm_traffic.json
 cp $(find $out/kt -name '*kernel_stats.csv') $out/kernel_stats.csv
+cp $(find $out/sq -name '*counter_collection.csv') $out/sq_counters.csv
 python3 bench.py > $out/bench_line.json 2> $out/bench.log
 ls $out
