@@ -178,6 +178,7 @@ def load():
         "fzp_comm_destroy": (None, [VP]),
         "fzp_allgather_rid_to_phase": (C.c_int, [VP, VP, I64, PP, PI64]),
         "fzp_align_alnset": (C.c_int, [VP, VP, I32, VP, CP, PP, PP]),
+        "fzp_align_alnset_all": (C.c_int, [VP, VP, I32, VP, CP, PP, PP]),
         "fzp_align_to_batch": (C.c_int, [VP, VP, PP]),
         "fzp_align_destroy": (None, [VP, VP]),
         "fzp_batch_consensus": (C.c_int, [VP, VP, VP]),
@@ -490,9 +491,11 @@ class AlignJob:
         _check(load().fzp_align_summaries(self.eng._p, self._p, _ptr(out)))
         return out
 
-    def alnset(self, ctg=0, names=None):
-        """Alignment records of contig `ctg` as the phasing stages see them -> (AlnSet, read_index)."""
+    def alnset(self, ctg=0, names=None, all_records=False):
+        """Alignment records of contig `ctg` as the phasing stages see them -> (AlnSet, read_index); all_records=True: also the
+        reads make_het_call's filters drop (what the blasr task's BAM holds)."""
         lib = load()
+        fn = lib.fzp_align_alnset_all if all_records else lib.fzp_align_alnset
         ap, ip = C.c_void_p(), C.c_void_p()
         if names is not None:
             if isinstance(names, tuple):                      # (name_off, blob) built once by the caller
@@ -502,9 +505,9 @@ class AlignJob:
                 off = np.zeros(len(enc) + 1, np.int64)
                 off[1:] = np.cumsum([len(e) for e in enc])
                 blob = b"".join(enc)
-            _check(lib.fzp_align_alnset(self.eng._p, self._p, ctg, _ptr(off), blob, C.byref(ap), C.byref(ip)))
+            _check(fn(self.eng._p, self._p, ctg, _ptr(off), blob, C.byref(ap), C.byref(ip)))
         else:
-            _check(lib.fzp_align_alnset(self.eng._p, self._p, ctg, None, None, C.byref(ap), C.byref(ip)))
+            _check(fn(self.eng._p, self._p, ctg, None, None, C.byref(ap), C.byref(ip)))
         a = AlnSet(ap.value)
         idx = _take(ip.value, a.n_rec, np.int64)
         return a, idx

@@ -1625,7 +1625,7 @@ struct RecPlan {
 };
 
 // what `samtools sort` + make_het_call's record filters (phasing.py:47-75) do to the aligner's output
-void plan_records(const fzp_alnjob *j, int c_lo, int c_hi, RecPlan &p) {
+void plan_records(const fzp_alnjob *j, int c_lo, int c_hi, RecPlan &p, bool apply_filters = true) {
     const int nc = c_hi - c_lo;
     // bucket the aligned reads by contig (counting sort), then order every bucket by (POS, read index) through one
     // 64-bit key per read
@@ -1663,8 +1663,8 @@ void plan_records(const fzp_alnjob *j, int c_lo, int c_hi, RecPlan &p) {
             const int64_t n_del = (int64_t)(s.ref_end - s.pos) - s.n_columns;
             const int64_t total_aln_pos = n + n_del;                       // sum of all CIGAR op lengths
             const int64_t skip_base = (int64_t)s.q_start + (n - s.q_end);   // soft clips
-            if (1.0 - 1.0 * (double)skip_base / (double)total_aln_pos < 0.1) continue;   // phasing.py:72
-            if (total_aln_pos < 2000) continue;                                          // phasing.py:74
+            if (apply_filters && 1.0 - 1.0 * (double)skip_base / (double)total_aln_pos < 0.1) continue;   // phasing.py:72
+            if (apply_filters && total_aln_pos < 2000) continue;                                          // phasing.py:74
             p.rec_read.push_back(r);
             p.rec_qid.push_back((int32_t)q);
             p.rec_pos.push_back(s.pos);
@@ -1705,12 +1705,19 @@ T *dupv(const std::vector<T> &v) {
 }
 }  // namespace
 
+static int align_alnset(fzp_ctx *ctx, fzp_alnjob *j, int32_t ctg, const int64_t *name_off, const char *names, fzp_alnset **out, int64_t **read_index, bool apply_filters);
 extern "C" int fzp_align_alnset(fzp_ctx *ctx, fzp_alnjob *j, int32_t ctg, const int64_t *name_off, const char *names, fzp_alnset **out, int64_t **read_index) {
+    return align_alnset(ctx, j, ctg, name_off, names, out, read_index, true);
+}
+extern "C" int fzp_align_alnset_all(fzp_ctx *ctx, fzp_alnjob *j, int32_t ctg, const int64_t *name_off, const char *names, fzp_alnset **out, int64_t **read_index) {
+    return align_alnset(ctx, j, ctg, name_off, names, out, read_index, false);
+}
+static int align_alnset(fzp_ctx *ctx, fzp_alnjob *j, int32_t ctg, const int64_t *name_off, const char *names, fzp_alnset **out, int64_t **read_index, bool apply_filters) {
     if (!ctx || !j || !j->done || !out || ctg < 0 || ctg >= j->n_ctg) { fzp_set_error("fzp_align_alnset: bad arguments or job not run"); return FZP_EINVAL; }
     FZP_TRY(fzp_bind(ctx));
     FZP_TRY(fetch_summaries(ctx, j));
     RecPlan p;
-    plan_records(j, ctg, ctg + 1, p);
+    plan_records(j, ctg, ctg + 1, p, apply_filters);
     DevBuf<uint32_t> cigar;
     DevBuf<uint8_t> seq;
     DevBuf<int64_t> dco, dso;

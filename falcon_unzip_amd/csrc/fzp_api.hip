@@ -69,12 +69,8 @@ extern "C" int fzp_batch_create(fzp_ctx *ctx, int32_t n_ctg, const fzp_alnset *c
     for (int c = 0; c < n_ctg; c++) {
         const fzp_alnset *a = aln[c];
         if (!a) { delete b; fzp_set_error("contig %d: null alnset", c); return FZP_EINVAL; }
-        int32_t limit = a->last_pos > 0 ? a->last_pos : 0;
-        if ((int64_t)limit > ref_len[c]) {
-            delete b;
-            fzp_set_error("contig %d: last record starts at %d, beyond the contig end %lld (reference: IndexError on ref_seq[pos])", c, limit + 1, (long long)ref_len[c]);
-            return FZP_EINVAL;
-        }
+        int32_t limit = a->last_pos > 0 ? a->last_pos : 0;     // positions beyond the contig's end may be piled up; only a het call there fails, as in
+                                                                // the reference (IndexError at ref_seq[pos], phasing.py:124) -- checked after K2
         b->h_limit.push_back(limit);
         b->h_ref_len.push_back(ref_len[c]);
         b->h_rec_begin.push_back(b->h_rec_begin.back() + a->n_rec);
@@ -105,7 +101,7 @@ extern "C" int fzp_batch_create(fzp_ctx *ctx, int32_t n_ctg, const fzp_alnset *c
         }
         if (a->cig_off[a->n_rec]) memcpy(cigar.data() + c0, a->cigar, (size_t)a->cig_off[a->n_rec] * sizeof(uint32_t));
         if (a->seq_off[a->n_rec]) memcpy(seq.data() + s0, a->seq, (size_t)a->seq_off[a->n_rec]);
-        if (b->h_limit[c]) memcpy(ref.data() + b->h_goff[c], ref_seq[c], (size_t)b->h_limit[c]);
+        if (b->h_limit[c]) memcpy(ref.data() + b->h_goff[c], ref_seq[c], (size_t)std::min<int64_t>(b->h_limit[c], ref_len[c]));      // the rest stays 0
         r0 += a->n_rec; c0 += a->cig_off[a->n_rec]; s0 += a->seq_off[a->n_rec];
     }
     cig_off[(size_t)b->n_rec] = c0;

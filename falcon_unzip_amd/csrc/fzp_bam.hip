@@ -120,7 +120,8 @@ extern "C" int fzp_format_bam(const fzp_alnset *a, const char *ctg_id, int64_t c
         const int64_t sl = a->seq_off[r + 1] - a->seq_off[r];
         const int64_t nc = a->cig_off[r + 1] - a->cig_off[r];
         const int32_t pos = a->rec_pos[r];
-        if (nl + 1 > 255 || nc > 65535 || pos < prev_pos) { fzp_set_error("record %lld: name longer than 254, more than 65535 CIGAR ops, or not coordinate-sorted", (long long)r); return FZP_EINVAL; }
+        if (nl + 1 > 255 || pos < prev_pos) { fzp_set_error("record %lld: name longer than 254 or not coordinate-sorted", (long long)r); return FZP_EINVAL; }
+        const bool long_cigar = nc > 65535;           // SAMv1 4.2.2: the real CIGAR goes into a CG:B,I tag, the CIGAR field holds <l_seq>S<ref_len>N
         prev_pos = pos;
         int64_t rlen = 0;
         for (int64_t k = a->cig_off[r]; k < a->cig_off[r + 1]; k++) {
@@ -132,13 +133,18 @@ extern "C" int fzp_format_bam(const fzp_alnset *a, const char *ctg_id, int64_t c
         Bytes rec;
         rec.i32(0);                                   // block_size, patched below
         rec.i32(0); rec.i32(pos);
-        rec.u8((uint8_t)(nl + 1)); rec.u8(254); rec.u16((uint16_t)bin); rec.u16((uint16_t)nc); rec.u16((uint16_t)(flags ? flags[r] : 0));
+        rec.u8((uint8_t)(nl + 1)); rec.u8(254); rec.u16((uint16_t)bin); rec.u16((uint16_t)(long_cigar ? 2 : nc)); rec.u16((uint16_t)(flags ? flags[r] : 0));
         rec.i32((int32_t)sl); rec.i32(-1); rec.i32(-1); rec.i32(0);
         rec.raw(a->qnames + a->qname_off[q], nl); rec.u8(0);
-        for (int64_t k = a->cig_off[r]; k < a->cig_off[r + 1]; k++) rec.u32(a->cigar[k]);
+        if (long_cigar) { rec.u32(((uint32_t)sl << 4) | FZP_OP_S); rec.u32(((uint32_t)(rlen > 0 ? rlen : 0) << 4) | FZP_OP_N); }
+        else for (int64_t k = a->cig_off[r]; k < a->cig_off[r + 1]; k++) rec.u32(a->cigar[k]);
         const uint8_t *sq = a->seq + a->seq_off[r];
         for (int64_t k = 0; k < sl; k += 2) rec.u8((uint8_t)((nib(sq[k]) << 4) | (k + 1 < sl ? nib(sq[k + 1]) : 0)));
         for (int64_t k = 0; k < sl; k++) rec.u8(0xff);
+        if (long_cigar) {
+            rec.u8('C'); rec.u8('G'); rec.u8('B'); rec.u8('I'); rec.i32((int32_t)nc);
+            for (int64_t k = a->cig_off[r]; k < a->cig_off[r + 1]; k++) rec.u32(a->cigar[k]);
+        }
         const uint32_t bs = (uint32_t)rec.v.size() - 4;
         for (int i = 0; i < 4; i++) rec.v[(size_t)i] = (uint8_t)(bs >> (8 * i));
         const uint64_t v0 = z.tell();
@@ -266,9 +272,20 @@ extern "C" int fzp_bam_to_sam(const uint8_t *bam, size_t len, const char *region
         if (ref >= 0 && ref < n_ref) out.append(names[(size_t)ref]); else out.push_back('*');
         out.append(num, (size_t)snprintf(num, sizeof num, "\t%d\t%u\t", pos + 1, mapq));
         const size_t c0 = r0 + 32 + l_name;
-        if (!n_cig) out.push_back('*');
-        for (uint32_t k = 0; k < n_cig; k++) {
-            const uint32_t w = (uint32_t)rd32(c0 + 4 * k);
+        size_t cg0 = c0;
+        uint32_t cg_n = n_cig;
+        if (n_cig == 2) {     // a CIGAR of more than 65535 ops lives in the CG:B,I tag (SAMv1 4.2.2): it is the first tag as written by fzp_format_bam
+            const size_t t0 = c0 + 8 + ((size_t)l_seq + 1) / 2 + (size_t)l_seq;
+            const uint32_t w0 = (uint32_t)rd32(c0), w1 = (uint32_t)rd32(c0 + 4);
+            if ((w0 & 15) == FZP_OP_S && (int32_t)(w0 >> 4) == l_seq && (w1 & 15) == FZP_OP_N && t0 + 8 <= r0 + (size_t)bs && d[t0] == 'C' && d[t0 + 1] == 'G' &&
+                d[t0 + 2] == 'B' && d[t0 + 3] == 'I') {
+                const int32_t cnt = rd32(t0 + 4);
+                if (cnt > 0 && t0 + 8 + 4 * (size_t)cnt <= r0 + (size_t)bs) { cg0 = t0 + 8; cg_n = (uint32_t)cnt; }
+            }
+        }
+        if (!cg_n) out.push_back('*');
+        for (uint32_t k = 0; k < cg_n; k++) {
+            const uint32_t w = (uint32_t)rd32(cg0 + 4 * k);
             out.append(num, (size_t)snprintf(num, sizeof num, "%u%c", w >> 4, OPS[w & 15]));
         }
         out.push_back('\t');

@@ -518,6 +518,17 @@ int fzp_k2_het_call(fzp_ctx *ctx, fzp_batch *b) {
     FZP_TRY(b->site_begin.download(b->h_site_begin.data(), (size_t)b->n_ctg + 1, st));
     FZP_HIP(hipStreamSynchronize(st));
     FZP_HIP(hipGetLastError());
+    for (int c = 0; c < b->n_ctg; c++) {     // a site called beyond the contig's end: the reference dies on ref_seq[pos] (phasing.py:124)
+        if ((int64_t)b->h_limit[(size_t)c] <= b->h_ref_len[(size_t)c] || b->h_site_begin[(size_t)c + 1] == b->h_site_begin[(size_t)c]) continue;
+        int64_t g = 0;
+        FZP_HIP(hipMemcpyAsync(&g, b->site_g.p + b->h_site_begin[(size_t)c + 1] - 1, 8, hipMemcpyDeviceToHost, st));
+        FZP_HIP(hipStreamSynchronize(st));
+        if (g - b->h_goff[(size_t)c] >= b->h_ref_len[(size_t)c]) {
+            fzp_set_error("contig %d: het site called at position %lld, beyond the contig end %lld (reference: IndexError on ref_seq[pos])", c,
+                          (long long)(g - b->h_goff[(size_t)c] + 1), (long long)b->h_ref_len[(size_t)c]);
+            return FZP_EINVAL;
+        }
+    }
     b->have_sites = true;
     b->have_sets = false;
     return FZP_OK;

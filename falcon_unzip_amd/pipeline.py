@@ -16,6 +16,7 @@ Inputs and outputs use the reference's directory contract:
 from __future__ import annotations
 
 import os
+import sys
 
 import numpy as np
 
@@ -113,13 +114,16 @@ def phase_contigs(eng, jobs, unzip_dir, read_map_dir=None, write_sam=False, ctg_
         for c, (ctg, ref, _) in enumerate(jobs):
             base = os.path.join(out_dir, ctg, "blasr")
             os.makedirs(base, exist_ok=True)
-            aln, idx = job.alnset(c, name_tab)
-            flags = (summ["strand"][idx] * 16).astype(np.int32)
-            bam, bai = _lib.format_bam(aln, ctg, len(ref), flags)
-            with open(os.path.join(base, "%s_sorted.bam" % ctg), "wb") as f:
-                f.write(bam)
-            with open(os.path.join(base, "%s_sorted.bam.bai" % ctg), "wb") as f:
-                f.write(bai)
+            try:                                              # the BAM is a by-product: a failure to write it must not stop the phasing outputs
+                aln, idx = job.alnset(c, name_tab, all_records=True)
+                flags = (summ["strand"][idx] * 16).astype(np.int32)
+                bam, bai = _lib.format_bam(aln, ctg, len(ref), flags)
+                with open(os.path.join(base, "%s_sorted.bam" % ctg), "wb") as f:
+                    f.write(bam)
+                with open(os.path.join(base, "%s_sorted.bam.bai" % ctg), "wb") as f:
+                    f.write(bai)
+            except (_lib.FzpError, OSError) as e:
+                sys.stderr.write("[fzphase] %s: no BAM written (%s)\n" % (ctg, e))
         job.close()
     phase_contigs.last_stats = stats
     return recs

@@ -246,6 +246,11 @@ int64_t fzp_align_n_second(const fzp_alnjob *job);
  * (optional, may be NULL -> "read/<index>") fill the q_id table */
 int fzp_align_alnset(fzp_ctx *ctx, fzp_alnjob *job, int32_t ctg, const int64_t *name_off, const char *names,
                      fzp_alnset **out, int64_t **read_index /* [n_rec] input index of each record, optional */);
+/* the same without make_het_call's two record filters (phasing.py:72-75): EVERY aligned read, which is what the blasr task's
+ * <ctg>_sorted.bam holds (unzip.py:86-91) -- the BAM must carry the filtered-out reads too, or a later `fc_phasing.py` run on it would
+ * number its q_ids differently */
+int fzp_align_alnset_all(fzp_ctx *ctx, fzp_alnjob *job, int32_t ctg, const int64_t *name_off, const char *names,
+                         fzp_alnset **out, int64_t **read_index);
 /* hand the aligned records of all contigs to the phasing stages without leaving the device */
 int fzp_align_to_batch(fzp_ctx *ctx, fzp_alnjob *job, fzp_batch **out);
 void fzp_align_destroy(fzp_ctx *ctx, fzp_alnjob *job);

@@ -148,3 +148,24 @@ def test_cli_dropin(tmp_path):
     subprocess.check_call([sys.executable, os.path.join(repo, "scripts", "fc_phasing_readmap.py"), "--ctg_id", c.ctg_id, "--read_map_dir", str(rmd),
                            "--phased_reads", "phased_reads"], cwd=str(wd), env=env)
     c.check("rid_to_phase", (wd / ("rid_to_phase.%s" % c.ctg_id)).read_bytes())
+
+
+def test_contig_shorter_than_the_last_record(eng):
+    """Records may start beyond the end of the contig text: only a het call there fails (the reference's IndexError at ref_seq[pos],
+    phasing.py:124) -- ADVICE r1: the batch used to be refused up front."""
+    from falcon_unzip_amd import _lib
+    c = Case("g1_cfg1_clean")
+    aln = _lib.parse_sam(c.sam)
+    last_site = int(c.expected("variant_pos").split(b"\n")[-2].split()[0])          # 1-based
+    assert aln.rec_pos()[-1] + 1 > last_site                                          # the last record starts after the last site
+    b = eng.batch([aln], [c.ref_seq[:last_site]])
+    b.run(_lib.STAGE_ALL)
+    r = b.result(0)
+    c.check("variant_pos", _lib.format_variant_pos(r.sites))
+    c.check("atable", _lib.format_atable(r.sites, r.arows))
+    b.close()
+    b = eng.batch([aln], [c.ref_seq[:last_site - 1]])
+    with pytest.raises(_lib.FzpError) as ei:
+        b.run(_lib.STAGE_HET)
+    assert "IndexError" in str(ei.value)
+    b.close()
