@@ -15,10 +15,10 @@
 #include <vector>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
-enum Kind { ADD = 0, MAX, ADD_DPP, MAX_DPP, MOV_DPP, CMP_SGPR, CMP_VCC, CNDMASK, MAX3, READLANE, WRITELANE, PK_ADD_I16, PK_MAX_I16, SW_MIX, SW_MIX_NOLANE, N_KINDS };
+enum Kind { ADD = 0, MAX, ADD_DPP, MAX_DPP, MOV_DPP, CMP_SGPR, CMP_VCC, CNDMASK, MAX3, READLANE, WRITELANE, PK_ADD_I16, PK_MAX_I16, SW_MIX, SW_MIX_NOLANE, SW_MIX_SEL, CNDMASK_E64, N_KINDS };
 static const char *kind_name[N_KINDS] = {"v_add_u32", "v_max_i32", "v_add_u32_dpp(wave_shl)", "v_max_i32_dpp(wave_shr)", "v_mov_b32_dpp(wave_shl)",
                                          "v_cmp_eq_i32_e64->sgpr", "v_cmp_eq_u32_e32->vcc", "v_cndmask_b32", "v_max3_i32", "v_readlane_b32",
-                                         "v_writelane_b32", "v_pk_add_i16", "v_pk_max_i16", "k_sw step mix (13 VALU + 9 SALU + s_store)", "k_sw step mix without readlane/writelane"};
+                                         "v_writelane_b32", "v_pk_add_i16", "v_pk_max_i16", "k_sw step mix (13 VALU + 9 SALU + s_store)", "k_sw step mix without readlane/writelane", "k_sw step mix, Hnew = cmp_ge + cndmask_e64 (no max + cmp_eq)", "v_cndmask_b32_e64 (sgpr pair mask)"};
 
 #define R8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
 
@@ -83,6 +83,44 @@ __global__ void __launch_bounds__(1024) k(uint32_t *out, int iters, uint64_t *si
 #define X(i) asm volatile("v_pk_max_i16 %0, %0, %1" : "+v"(v[i]) : "v"(w[i]));
                 R8(X)
 #undef X
+            } else if (KIND == CNDMASK_E64) {
+#define X(i) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(v[i]) : "v"(w[i]), "s"(sm));
+                R8(X)
+#undef X
+            } else if (KIND == SW_MIX_SEL) {
+#pragma unroll
+                for (int s4 = 0; s4 < 4; s4++) {
+                    int32_t top, bot;
+                    uint64_t m0, m1;
+                    asm volatile(
+                        "s_bfe_u64 s[56:57], %[sm], 0x20000\n\t"
+                        "v_mov_b32_dpp %[qc], %[qc] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+                        "s_add_u32 %[sx], %[sx], 2\n\t"
+                        "v_max_i32_dpp %[mm], %[H], %[H] wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                        "v_writelane_b32 %[qc], s56, 63\n\t"
+                        "v_cmp_eq_i32_e64 %[m1], %[mm], %[H]\n\t"
+                        "v_cmp_eq_u32_e32 vcc, %[qc], %[tc]\n\t"
+                        "v_cndmask_b32_e32 %[sc], %[vmis], %[vmat], vcc\n\t"
+                        "v_add_u32_dpp %[hd], %[X], %[sc] wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                        "v_subrev_u32_e32 %[mm], %[gap], %[mm]\n\t"
+                        "s_mov_b32 s58, 1\n\t"
+                        "v_cmp_ge_i32_e64 %[m0], %[hd], %[mm]\n\t"
+                        "s_lshl1_add_u32 s59, s59, 1\n\t"
+                        "v_cndmask_b32_e64 %[X], %[mm], %[hd], %[m0]\n\t"
+                        "v_max3_i32 %[kb], %[kb], %[X], %[H]\n\t"
+                        "v_readlane_b32 %[top], %[X], 0\n\t"
+                        "v_readlane_b32 %[bot], %[X], 63\n\t"
+                        "s_add_u32 %[sx], %[sx], 16\n\t"
+                        "s_sub_u32 %[sx], %[sx], 1\n\t"
+                        "s_cmp_gt_i32 %[top], %[bot]\n\t"
+                        "s_cselect_b32 s58, 0, 1\n\t"
+                        "v_swap_b32 %[H], %[X]\n\t"
+                        : [qc] "+v"(v[0]), [tc] "+v"(v[1]), [H] "+v"(v[2]), [X] "+v"(v[3]), [kb] "+v"(v[4]), [mm] "=&v"(v[5]), [sc] "=&v"(v[6]), [hd] "=&v"(v[7]),
+                          [sx] "+s"(sx), [top] "=&s"(top), [bot] "=&s"(bot), [m0] "=&s"(m0), [m1] "=&s"(m1)
+                        : [vmis] "v"(w[0]), [vmat] "v"(w[1]), [gap] "s"(193), [sm] "s"(sm)
+                        : "vcc", "scc", "s56", "s57", "s58", "s59");
+                    sm ^= m0 + m1;
+                }
             } else if (KIND == SW_MIX || KIND == SW_MIX_NOLANE) {
                 // four DP steps' worth of the interior block's instruction mix (fzp_align.hip SWB_DOWN), no memory:
                 // per step 13 VALU (mov_dpp, max_dpp, writelane, cmp->sgpr, cmp->vcc, cndmask, add(_dpp), subrev, max, cmp->sgpr,
@@ -299,6 +337,9 @@ int main(int argc, char **argv) {
     // the mixes: per outer iteration 8 x 4 steps; VALU per step 14 (13 + v_swap standing in for the role swap) / 11
     run_kind<SW_MIX>(d_out, n_cu, iters / 4, 8 * 4 * 14, 8 * 4 * 14, clk_ghz);
     run_kind<SW_MIX_NOLANE>(d_out, n_cu, iters / 4, 8 * 4 * 11, 8 * 4 * 11, clk_ghz);
+    run_kind<SW_MIX_SEL>(d_out, n_cu, iters / 4, 8 * 4 * 14, 8 * 4 * 14, clk_ghz);
+    run_kind<CNDMASK_E64>(d_out, n_cu, iters, 64, 64, clk_ghz);
+    if (argc > 2) { CK(hipFree(d_out)); return 0; }
 #define X(id, name, text) run_simple<id>(d_out, n_cu, iters, name, clk_ghz);
     SIMPLE_KINDS(X)
 #undef X
