@@ -173,6 +173,7 @@ def load():
         "fzp_phase_contigs": (C.c_int, [VP, I32, VP, VP, I64, VP, VP, VP, VP, VP, VP]),
         "fzp_pipe_out_free": (None, [VP]),
         "fzp_pipe_flush": (C.c_int, [VP]),
+        "fzp_mem_info": (C.c_int, [VP, PSZ, PSZ]),
         "fzp_comm_unique_id": (C.c_int, [VP]),
         "fzp_comm_create": (C.c_int, [VP, C.c_int, C.c_int, VP, PP]),
         "fzp_comm_destroy": (None, [VP]),
@@ -397,6 +398,12 @@ class Engine:
             self._p = None
 
     __del__ = close
+
+    def mem_info(self):
+        """(free, total) bytes of the engine's device"""
+        fr, tot = C.c_size_t(), C.c_size_t()
+        _check(load().fzp_mem_info(self._p, C.byref(fr), C.byref(tot)))
+        return int(fr.value), int(tot.value)
 
     def pipe_flush(self):
         """wait for the background file writes of phase_write(async_writes=True) calls; raises on the first write error"""

@@ -1168,13 +1168,39 @@ __global__ void __launch_bounds__(256) k_plan_keys(int64_t n, const int32_t *__r
     const int32_t r = slot_read[s];
     key[s] = summ[r].aligned ? (((uint64_t)(uint32_t)summ[r].pos << 32) | (uint32_t)r) : ~0ull;
 }
-__global__ void __launch_bounds__(256) k_plan_rank(int64_t n, const int32_t *__restrict__ slot_read, const int32_t *__restrict__ slot_ctg, const int64_t *__restrict__ slot_off,
-                                                   const uint64_t *__restrict__ key, const fzp_aln_summary *__restrict__ summ, const int32_t *__restrict__ read_len,
-                                                   uint64_t *__restrict__ v_rec, uint64_t *__restrict__ v_cig, uint64_t *__restrict__ v_seq, uint64_t *__restrict__ v_ck,
-                                                   int32_t *__restrict__ g_read, int32_t *__restrict__ g_qid, uint8_t *__restrict__ g_acc, int32_t *__restrict__ last_pos,
-                                                   uint32_t *__restrict__ n_aligned, unsigned long long *__restrict__ n_cols) {
-    // grid (x: 256-slot pieces of a contig, y: contig): the contig's keys pass through LDS in tiles of 1024, every
-    // thread counts the keys below its own -- all-pairs, but each key is fetched from HBM once per workgroup
+// rank of an aligned read among its contig's aligned reads by (POS, read index).  Contigs of more than 8192 reads: without comparing all
+// pairs -- reads are binned by POS >> 8 (k_rank_hist -> scan -> k_rank_scatter), a read's rank = reads in earlier bins + the smaller keys
+// inside its own bin (k_rank_binned); smaller ones: k_rank_allpairs
+constexpr int RANK_SHIFT = 8;
+__global__ void __launch_bounds__(256) k_rank_hist(int64_t n, const int32_t *__restrict__ slot_ctg, const uint64_t *__restrict__ key, const int64_t *__restrict__ bk_off,
+                                                   uint32_t *__restrict__ hist) {
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= n || key[s] == ~0ull) return;
+    atomicAdd(&hist[bk_off[slot_ctg[s]] + (int64_t)((uint32_t)(key[s] >> 32) >> RANK_SHIFT)], 1u);
+}
+__global__ void __launch_bounds__(256) k_rank_scatter(int64_t n, const int32_t *__restrict__ slot_ctg, const uint64_t *__restrict__ key, const int64_t *__restrict__ bk_off,
+                                                      const uint32_t *__restrict__ start, uint32_t *__restrict__ fill, uint64_t *__restrict__ members) {
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= n || key[s] == ~0ull) return;
+    const int64_t b = bk_off[slot_ctg[s]] + (int64_t)((uint32_t)(key[s] >> 32) >> RANK_SHIFT);
+    members[start[b] + atomicAdd(&fill[b], 1u)] = key[s];
+}
+__global__ void __launch_bounds__(256) k_rank_binned(int64_t n, const int32_t *__restrict__ slot_ctg, const uint64_t *__restrict__ key, const int64_t *__restrict__ bk_off,
+                                                     const uint32_t *__restrict__ start, const uint32_t *__restrict__ hist, const uint64_t *__restrict__ members,
+                                                     uint32_t *__restrict__ rank_out) {
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= n) return;
+    const uint64_t k = key[s];
+    if (k == ~0ull) return;
+    const int c = slot_ctg[s];
+    const int64_t b = bk_off[c] + (int64_t)((uint32_t)(k >> 32) >> RANK_SHIFT);
+    const uint32_t b0 = start[b], bn = hist[b];
+    uint32_t rank = b0 - start[bk_off[c]];
+    for (uint32_t x = 0; x < bn; x++) rank += members[b0 + x] < k ? 1u : 0u;
+    rank_out[s] = rank;
+}
+// small contigs (the usual case: a few thousand reads each): all pairs, the contig's keys passing through LDS in tiles of 1024
+__global__ void __launch_bounds__(256) k_rank_allpairs(const int64_t *__restrict__ slot_off, const uint64_t *__restrict__ key, uint32_t *__restrict__ rank_out) {
     __shared__ uint64_t tile[1024];
     const int c = blockIdx.y;
     const int64_t s0 = slot_off[c], s1 = slot_off[c + 1];
@@ -1190,23 +1216,54 @@ __global__ void __launch_bounds__(256) k_plan_rank(int64_t n, const int32_t *__r
         if (k != ~0ull)
             for (int x = 0; x < m; x++) rank += tile[x] < k ? 1u : 0u;
     }
-    if (k == ~0ull) return;
-    const int32_t r = slot_read[s];
-    const fzp_aln_summary sm = summ[r];
-    const int64_t nlen = read_len[r];
-    const int64_t n_del = (int64_t)(sm.ref_end - sm.pos) - sm.n_columns;
-    const int64_t total_aln_pos = nlen + n_del;                       // sum of all CIGAR op lengths
-    const int64_t skip_base = (int64_t)sm.q_start + (nlen - sm.q_end);   // soft clips
-    // phasing.py:72 in IEEE double exactly as written (no contraction: explicit round-to-nearest ops)
-    const double frac = __dsub_rn(1.0, __ddiv_rn(__dmul_rn(1.0, (double)skip_base), (double)total_aln_pos));
-    const bool acc = !(frac < 0.1) && !(total_aln_pos < 2000);      // phasing.py:72, 74
-    const int64_t g = slot_off[c] + rank;
-    g_read[g] = r; g_qid[g] = (int32_t)rank; g_acc[g] = acc ? 1 : 0;
-    atomicAdd(&n_aligned[c], 1u);
-    if (acc) {
-        v_rec[g] = 1; v_cig[g] = (uint64_t)sm.n_cigar; v_seq[g] = (uint64_t)((nlen + 15) & ~15ll); v_ck[g] = (uint64_t)((sm.n_cigar + 63) / 64);
-        atomicMax(&last_pos[c], sm.pos);
-        atomicAdd(&n_cols[c], (unsigned long long)sm.n_columns);
+    if (k != ~0ull) rank_out[s] = rank;
+}
+__global__ void __launch_bounds__(256) k_plan_rank(int64_t n, const int32_t *__restrict__ slot_read, const int32_t *__restrict__ slot_ctg, const int64_t *__restrict__ slot_off,
+                                                   const uint64_t *__restrict__ key, const uint32_t *__restrict__ rank_in, const fzp_aln_summary *__restrict__ summ,
+                                                   const int32_t *__restrict__ read_len,
+                                                   uint64_t *__restrict__ v_rec, uint64_t *__restrict__ v_cig, uint64_t *__restrict__ v_seq, uint64_t *__restrict__ v_ck,
+                                                   int32_t *__restrict__ g_read, int32_t *__restrict__ g_qid, uint8_t *__restrict__ g_acc, int32_t *__restrict__ last_pos,
+                                                   uint32_t *__restrict__ n_aligned, unsigned long long *__restrict__ n_cols) {
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool valid = s < n && key[s] != ~0ull;          // every lane stays to the end: the per-contig totals are reduced over the wave
+    int c = -1;
+    bool acc = false;
+    int32_t pos = -1, ncol = 0;
+    if (valid) {
+        c = slot_ctg[s];
+        const uint32_t rank = rank_in[s];
+        const int32_t r = slot_read[s];
+        const fzp_aln_summary sm = summ[r];
+        const int64_t nlen = read_len[r];
+        const int64_t n_del = (int64_t)(sm.ref_end - sm.pos) - sm.n_columns;
+        const int64_t total_aln_pos = nlen + n_del;                       // sum of all CIGAR op lengths
+        const int64_t skip_base = (int64_t)sm.q_start + (nlen - sm.q_end);   // soft clips
+        // phasing.py:72 in IEEE double exactly as written (no contraction: explicit round-to-nearest ops)
+        const double frac = __dsub_rn(1.0, __ddiv_rn(__dmul_rn(1.0, (double)skip_base), (double)total_aln_pos));
+        acc = !(frac < 0.1) && !(total_aln_pos < 2000);      // phasing.py:72, 74
+        const int64_t g = slot_off[c] + rank;
+        g_read[g] = r; g_qid[g] = (int32_t)rank; g_acc[g] = acc ? 1 : 0;
+        if (acc) { v_rec[g] = 1; v_cig[g] = (uint64_t)sm.n_cigar; v_seq[g] = (uint64_t)((nlen + 15) & ~15ll); v_ck[g] = (uint64_t)((sm.n_cigar + 63) / 64); }
+        pos = sm.pos; ncol = sm.n_columns;
+    }
+    // per-contig totals: the slots of a wave nearly always belong to one contig -> one atomic per wave, not per read
+    // (40 000 same-address atomics issued at once serialise: 0.5 ms)
+    const uint64_t vm = __ballot(valid);
+    if (vm == 0) return;
+    const int c0 = __builtin_amdgcn_readlane(c, __builtin_ctzll(vm));
+    if (__all(!valid || c == c0)) {
+        int32_t mp = (valid && acc) ? pos : -1;
+        unsigned long long cols = (valid && acc) ? (unsigned long long)ncol : 0ull;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { mp = max(mp, __shfl_xor(mp, d, 64)); cols += __shfl_xor(cols, d, 64); }
+        if (lane_id() == 0) {
+            atomicAdd(&n_aligned[c0], (uint32_t)__popcll(vm));
+            if (mp >= 0) atomicMax(&last_pos[c0], mp);
+            if (cols) atomicAdd(&n_cols[c0], cols);
+        }
+    } else if (valid) {
+        atomicAdd(&n_aligned[c], 1u);
+        if (acc) { atomicMax(&last_pos[c], pos); atomicAdd(&n_cols[c], (unsigned long long)ncol); }
     }
 }
 __global__ void __launch_bounds__(256) k_plan_emit(int64_t n, int n_ctg, const int32_t *__restrict__ slot_ctg_of_g, const int64_t *__restrict__ slot_off,
@@ -1299,6 +1356,8 @@ struct fzp_alnjob {
     DevBuf<int32_t> slot_read, slot_ctg;
     DevBuf<int64_t> slot_off;
     std::vector<int64_t> h_slot_off;
+    DevBuf<int64_t> rank_bk_off;                 // per contig: first POS bin of the record planning's rank (k_rank_*)
+    int64_t n_rank_buckets = 0;
     bool have_slots = false;
     int64_t max_reads_per_ctg = 1;
     bool summ_on_host = false;
@@ -1803,6 +1862,10 @@ extern "C" int fzp_align_to_batch(fzp_ctx *ctx, fzp_alnjob *j, fzp_batch **out) 
         for (int c = 0; c < nc; c++) { j->max_reads_per_ctg = std::max(j->max_reads_per_ctg, off[(size_t)c + 1]); off[(size_t)c + 1] += off[(size_t)c]; }
         if (nc > 65535) { fzp_set_error("fzp_align_to_batch: %d contigs in one job (limit 65535)", nc); return FZP_EINVAL; }
         j->h_slot_off = off;
+        std::vector<int64_t> bko((size_t)nc + 1, 0);
+        for (int c = 0; c < nc; c++) bko[(size_t)c + 1] = bko[(size_t)c] + (j->h_ctg_len[(size_t)c] >> RANK_SHIFT) + 2;
+        j->n_rank_buckets = bko.back();
+        FZP_TRY(j->rank_bk_off.upload(bko.data(), bko.size(), st));
         std::vector<int32_t> rd((size_t)nr), sc((size_t)nr);
         std::vector<int64_t> fill(off.begin(), off.end() - 1);
         for (int64_t r = 0; r < nr; r++) { const int c = j->h_read_ctg[(size_t)r]; const int64_t s_ = fill[(size_t)c]++; rd[(size_t)s_] = (int32_t)r; sc[(size_t)s_] = c; }
@@ -1814,7 +1877,8 @@ extern "C" int fzp_align_to_batch(fzp_ctx *ctx, fzp_alnjob *j, fzp_batch **out) 
     struct Guard { fzp_batch *p; ~Guard() { delete p; } } guard{b};
     b->n_ctg = nc;
     // ---- plan on the device
-    DevBuf<uint64_t> key, v_rec, v_cig, v_seq, v_ck, totals;
+    DevBuf<uint64_t> key, v_rec, v_cig, v_seq, v_ck, totals, rk_members, rk_total;
+    DevBuf<uint32_t> rk_hist, rk_start, rk_fill, rk_rank;
     DevBuf<int32_t> &g_read = b->qid_read;      // stays with the batch: q_id q of contig c is read g_read[h_slot_off[c] + q]
     DevBuf<int32_t> g_qid, last_pos;
     DevBuf<uint8_t> g_acc;
@@ -1831,8 +1895,20 @@ extern "C" int fzp_align_to_batch(fzp_ctx *ctx, fzp_alnjob *j, fzp_batch **out) 
     if (nr > 0) {
         ProfScope ps(ctx, "k1_plan");
         hipLaunchKernelGGL(k_plan_keys, dim3(gb), dim3(256), 0, st, nr, j->slot_read.p, j->summ.p, key.p);
-        hipLaunchKernelGGL(k_plan_rank, dim3((unsigned)((j->max_reads_per_ctg + 255) / 256), (unsigned)nc), dim3(256), 0, st, nr, j->slot_read.p, j->slot_ctg.p, j->slot_off.p, key.p, j->summ.p, j->read_len.p, v_rec.p, v_cig.p, v_seq.p,
-                           v_ck.p, g_read.p, g_qid.p, g_acc.p, last_pos.p, n_aligned.p, n_cols.p);
+        FZP_TRY(rk_rank.alloc(ns));
+        if (j->max_reads_per_ctg <= 8192) {
+            hipLaunchKernelGGL(k_rank_allpairs, dim3((unsigned)((j->max_reads_per_ctg + 255) / 256), (unsigned)nc), dim3(256), 0, st, j->slot_off.p, key.p, rk_rank.p);
+        } else {       // deep contigs: POS bins instead of all pairs
+            const size_t nbk = (size_t)j->n_rank_buckets + 1;
+            FZP_TRY(rk_hist.alloc(nbk)); FZP_TRY(rk_start.alloc(nbk)); FZP_TRY(rk_fill.alloc(nbk)); FZP_TRY(rk_members.alloc(ns)); FZP_TRY(rk_total.alloc(1));
+            FZP_TRY(rk_hist.zero(nbk, st)); FZP_TRY(rk_fill.zero(nbk, st));
+            hipLaunchKernelGGL(k_rank_hist, dim3(gb), dim3(256), 0, st, nr, j->slot_ctg.p, key.p, j->rank_bk_off.p, rk_hist.p);
+            FZP_TRY(fzp_exclusive_scan_u32(ctx, rk_hist.p, rk_start.p, nbk, rk_total.p));
+            hipLaunchKernelGGL(k_rank_scatter, dim3(gb), dim3(256), 0, st, nr, j->slot_ctg.p, key.p, j->rank_bk_off.p, rk_start.p, rk_fill.p, rk_members.p);
+            hipLaunchKernelGGL(k_rank_binned, dim3(gb), dim3(256), 0, st, nr, j->slot_ctg.p, key.p, j->rank_bk_off.p, rk_start.p, rk_hist.p, rk_members.p, rk_rank.p);
+        }
+        hipLaunchKernelGGL(k_plan_rank, dim3(gb), dim3(256), 0, st, nr, j->slot_read.p, j->slot_ctg.p, j->slot_off.p, key.p, rk_rank.p, j->summ.p, j->read_len.p,
+                           v_rec.p, v_cig.p, v_seq.p, v_ck.p, g_read.p, g_qid.p, g_acc.p, last_pos.p, n_aligned.p, n_cols.p);
     }
     FZP_TRY(fzp_exclusive_scan_u64_inplace(ctx, v_rec.p, (size_t)nr, totals.p + 0));
     FZP_TRY(fzp_exclusive_scan_u64_inplace(ctx, v_cig.p, (size_t)nr, totals.p + 1));

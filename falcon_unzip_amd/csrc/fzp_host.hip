@@ -254,6 +254,13 @@ extern "C" void fzp_ctx_destroy(fzp_ctx *ctx) {
     delete ctx;
 }
 
+extern "C" int fzp_mem_info(fzp_ctx *ctx, size_t *free_bytes, size_t *total_bytes) {
+    if (!ctx || !free_bytes || !total_bytes) return FZP_EINVAL;
+    FZP_HIP(hipSetDevice(ctx->device));
+    FZP_HIP(hipMemGetInfo(free_bytes, total_bytes));
+    return FZP_OK;
+}
+
 extern "C" int fzp_ctx_synchronize(fzp_ctx *ctx) {
     FZP_HIP(hipStreamSynchronize(ctx->stream));
     FZP_HIP(hipStreamSynchronize(ctx->stream2));

@@ -61,6 +61,7 @@ void fzp_free(void *p);
 int fzp_ctx_create(int device_id, unsigned flags, fzp_ctx **out);
 void fzp_ctx_destroy(fzp_ctx *ctx);
 int fzp_ctx_synchronize(fzp_ctx *ctx);
+int fzp_mem_info(fzp_ctx *ctx, size_t *free_bytes, size_t *total_bytes);   /* hipMemGetInfo of the ctx's device (blocks cached by the ctx count as used) */
 
 /* Per-kernel device timing (HIP events on the ctx stream).  fzp_prof_enable(ctx,1) starts
  * collecting; fzp_prof_get returns the summed duration and launch count of kernel `name`

@@ -385,3 +385,27 @@ def test_scores_equal_unbanded_dp_on_short_reads(eng):
         checked += 1
     assert checked >= 20
     job.close()
+
+
+def test_record_planning_at_deep_coverage(eng):
+    """A contig with 24 000 reads (many starting in the same 256-bp bin, many at the same POS): the device's record planning (binned rank,
+    fzp_align_to_batch) must order records exactly like the host's sort behind fzp_align_alnset ('samtools sort' order: POS, then read index)."""
+    from falcon_unzip_amd import _lib, sim
+    rng = np.random.Generator(np.random.PCG64(95))
+    L = 40000
+    hap0, hap1, _ = sim.make_diploid(L, rng, het_rate=1.0 / 300)
+    codes, off, *_ = sim.simulate_raw_reads_bulk(hap0, hap1, 24000, 2600, rng)
+    ctg = sim.ACGT[hap0].tobytes()
+    job = _lib.align_job_raw(eng, [ctg], sim.ACGT[codes].tobytes(), off, np.zeros(24000, np.int32))
+    job.run()
+    aln, idx = job.alnset(0)
+    assert aln.n_rec > 23000 and np.all(np.diff(aln.rec_pos()) >= 0)
+    b1 = job.to_batch()
+    b1.run(_lib.STAGE_ALL)
+    b2 = eng.batch([aln], [ctg])
+    b2.run(_lib.STAGE_ALL)
+    r1, r2 = b1.result(0), b2.result(0)
+    for f in ("sites", "vmap_qid", "arows", "pvars", "preads"):
+        assert np.array_equal(getattr(r1, f), getattr(r2, f)), f
+    assert len(r1.sites) > 50 and len(r1.preads) > 10000
+    b1.close(); b2.close(); job.close()

@@ -65,15 +65,15 @@ def run(scale=1.0, lanes=2, workers=8, out_root=None, keep=False, consensus=True
     t_gen = time.perf_counter() - t0
     from bench import make_names_and_maps
     name_tab, maps = make_names_and_maps(read_ctg, off, ids, 0)
-    import torch
     from falcon_unzip_amd import _lib
     eng = _lib.Engine(0)
-    total_mem = torch.cuda.mem_get_info(0)[1]
+    mon = _lib.Engine(0)                       # a second context only to read the device's memory counters from the sampling thread
+    total_mem = mon.mem_info()[1]
     peak = {"used": 0, "stop": False}
 
     def sample():
         while not peak["stop"]:
-            fr, tot = torch.cuda.mem_get_info(0)
+            fr, tot = mon.mem_info()
             peak["used"] = max(peak["used"], tot - fr)
             time.sleep(0.02)
     th = threading.Thread(target=sample, daemon=True)
@@ -92,6 +92,7 @@ def run(scale=1.0, lanes=2, workers=8, out_root=None, keep=False, consensus=True
            "dp_gcell_per_s_wall": round(stats["dp_cells"] / wall / 1e9, 1), "files_written": n_files, "r2p_records": int(len(recs)),
            "reads_phased": int((recs["block"] != -1).sum()), "stats": {k: (round(v, 2) if isinstance(v, float) else int(v)) for k, v in stats.items()},
            "longest_contig_reads": int(np.bincount(read_ctg).max())}
+    mon.close()
     eng.close()
     if keep:
         res["out_dir"] = out_dir
