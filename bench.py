@@ -220,7 +220,15 @@ def main():
         if int(flag.item()) == 0 and comm is not None:
             comm.close()
             comm = None
-    out_root = tempfile.mkdtemp(prefix="fzp_bench_r%d_" % rank, dir=args.out_root)
+    out_root = None
+    for cand in (args.out_root, None, "/dev/shm", REPO):          # --out-root, then $TMPDIR, then wherever a directory can be made
+        try:
+            out_root = tempfile.mkdtemp(prefix="fzp_bench_r%d_" % rank, dir=cand)
+            break
+        except OSError:
+            continue
+    if out_root is None:
+        raise SystemExit("bench.py: no writable scratch directory for the output trees")
     t_up = time.perf_counter()
     job = _lib.align_job_raw(eng, contigs, blob, off, read_ctg)     # upload + 2-bit pack: inputs now resident in HBM
     eng.synchronize()

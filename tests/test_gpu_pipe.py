@@ -207,3 +207,30 @@ def test_async_writes_are_complete_after_flush(eng, tmp_path):
         job2 = _lib.align_job_raw(eng, contigs, blob, off, read_ctg)
         job2.phase_write(ids, names=names, out_dir="/proc/no_such_dir/x", read_maps=maps, async_writes=True)
         eng.pipe_flush()
+
+
+def test_pipeline_edge_cases(eng, tmp_path):
+    """no reads at all; a malformed read map (the reference raises while reading it, whatever the contig); an unwritable target"""
+    from falcon_unzip_amd import _lib
+    contigs, blob, off, read_ctg, names, ids = _make_job(n_ctg=2)
+    # a job without reads: every file exists and is empty, no records
+    st, recs = _lib.phase_contigs(eng, contigs, b"", np.zeros(1, np.int64), np.zeros(0, np.int32), ids, out_dir=str(tmp_path / "empty"))
+    assert len(recs) == 0 and st["n_reads"] == 0
+    for ctg in ids:
+        for rel in FILES:
+            assert os.path.getsize(os.path.join(str(tmp_path / "empty"), ctg, rel)) == 0
+    # pread_to_contigs with a one-token row: IndexError in the reference at phasing_readmap.py:41 -> an error here, from the worker threads
+    maps = _read_maps(names, read_ctg, ids)
+    bad = (maps[0], maps[1], maps[2] + b"lonely\n")
+    with pytest.raises(_lib.FzpError) as ei:
+        _lib.phase_contigs(eng, contigs, blob, off, read_ctg, ids, names=names, out_dir=str(tmp_path / "bad"), read_maps=bad, n_lanes=2, group_bases=1)
+    assert "short row" in str(ei.value)
+    # pread id beyond pread_ids
+    bad2 = (maps[0], b"only/10/0_1\n", maps[2])
+    with pytest.raises(_lib.FzpError):
+        _lib.phase_contigs(eng, contigs, blob, off, read_ctg, ids, names=names, out_dir=str(tmp_path / "bad2"), read_maps=bad2)
+    with pytest.raises(_lib.FzpError):
+        _lib.phase_contigs(eng, contigs, blob, off, read_ctg, ids, names=names, out_dir="/proc/nope/x")
+    # the engine still works afterwards
+    st, recs = _lib.phase_contigs(eng, contigs, blob, off, read_ctg, ids, names=names, out_dir=str(tmp_path / "ok"), read_maps=maps)
+    assert len(recs) == len(names)
