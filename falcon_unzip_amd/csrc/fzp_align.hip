@@ -1582,6 +1582,8 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
         if (const char *e = getenv("FZP_TB_BUDGET_GB")) { long g = atol(e); if (g > 0) budget_steps = ((int64_t)g << 30) >> 4; }
         int n_chunks = 1;   // measured: overlapping the two kernels costs more than it hides (contention, chunk tails)
         if (const char *e = getenv("FZP_SW_CHUNKS")) { int g = atoi(e); if (g > 0) n_chunks = g; }
+        bool split_rounds = false;      // measured (r2): 43.4 vs 41.3 ms for K1 at cfg2 -- the trace-back under a second DP launch runs at 1/9 of a SIMD's issue slots
+        if (const char *e = getenv("FZP_SW_SPLIT_ROUNDS")) split_rounds = atoi(e) != 0;
         const int64_t total_steps = j->h_tb_off[(size_t)nr];
         int64_t chunk_steps = std::min<int64_t>(budget_steps / 2, (total_steps + n_chunks - 1) / n_chunks);
         FZP_TRY(j->wout.alloc((size_t)nr));
@@ -1595,6 +1597,14 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
             int64_t last = first;
             while (last < nr && j->h_tb_off[(size_t)last + 1] - j->h_tb_off[(size_t)first] <= chunk_steps) last++;
             if (last == first) last = first + 1;
+            // whole rounds first: k_sw runs one wave per read on n_CU x 32 wave slots, and reads of similar length finish round by round.
+            // Cutting the launch after the last FULL round lets the trace-back of those reads (HBM / latency bound, few waves) run under the
+            // DP of the remainder, which leaves slots free anyway.
+            if (split_rounds && first == 0 && last == nr) {
+                const int64_t slots = (int64_t)ctx->n_cu * 32;
+                const int64_t full = nr / slots * slots;
+                if (full >= slots && nr - full >= slots / 8) last = full;
+            }
             const int64_t cnt = last - first;
             const int64_t steps = j->h_tb_off[(size_t)last] - j->h_tb_off[(size_t)first];
             const int bi = k & 1;
