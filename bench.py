@@ -104,7 +104,7 @@ def cpu_baseline(contigs, blob, off, read_ctg, ids, eng, n_sample_ctg):
     from tests import oracle_lib
     orc = oracle_lib.load()
     cores = os.cpu_count() or 1
-    t_aln, cells, n_used, sams = 0.0, 0.0, 0, []
+    t_aln, cells, n_used, sams, mismatched = 0.0, 0.0, 0, [], 0
     for c in range(n_sample_ctg):
         idx = np.flatnonzero(read_ctg == c)
         reads = [blob[off[i]:off[i + 1]] for i in idx]
@@ -113,8 +113,10 @@ def cpu_baseline(contigs, blob, off, read_ctg, ids, eng, n_sample_ctg):
         t_aln += time.perf_counter() - t0
         cells += float(summ["cells"].sum())
         n_used += len(reads)
-        job = _lib.align_job(eng, [contigs[c]], reads)      # only to obtain the SAM text the oracle chain reads
+        job = _lib.align_job(eng, [contigs[c]], reads)      # the SAM text the oracle chain reads -- and, the checker's other use, a parity count
         job.run()
+        hip = job.summaries()
+        mismatched += int(sum(int((hip[f] != summ[f]).sum()) for f in ("aligned", "strand", "pos", "ref_end", "q_start", "q_end", "score", "n_cigar", "cells", "n_columns", "n_match")))
         aln, _ = job.alnset(0)
         sams.append((_lib.format_sam(aln, ids[c]), contigs[c], ids[c]))
         job.close()
@@ -134,7 +136,8 @@ def cpu_baseline(contigs, blob, off, read_ctg, ids, eng, n_sample_ctg):
     return {"value": round(n_used / (t_aln + t_ph), 3), "unit": "reads/s", "cores": cores, "kind": "port", "cpu_model": model,
             "sample": "all %d reads (15 kb) of the first %d contigs vs their 5 Mb contigs: oracle/align_oracle.c over %d threads, then the "
                       "oracle/phasing_oracle.c chain, one contig per thread; the reference's blasr and Python 2 cannot run here" % (n_used, n_sample_ctg, cores),
-            "align_s": round(t_aln, 3), "phasing_s": round(t_ph, 3), "dp_gcell_per_s": round(cells / t_aln / 1e9, 4)}
+            "align_s": round(t_aln, 3), "phasing_s": round(t_ph, 3), "dp_gcell_per_s": round(cells / t_aln / 1e9, 4),
+            "k1_fields_differing_from_hip": mismatched}
 
 
 def main():

@@ -185,3 +185,30 @@ def test_cfg5_slice_streams_through_groups(tmp_path):
     assert len(r2p) == len(set(x[0] for x in r2p)) and sum(x[2] != "-1" for x in r2p) == len(set(x[6] for x in rows))
     with open(os.path.join(base, "cns", "phased_blocks.fa")) as f:
         assert f.read().count(">") >= 2
+
+
+def test_cfg2_workload_k1_equals_twin_on_every_read(eng, oracle):
+    """The bench's own workload, read for read: as many cfg2 contigs (5 Mb, 2 000 x 15 kb reads each) as the host's cores pay for in a
+    few seconds -- all 20 on a 256-thread node -- aligned by the HIP path in one job and by the threaded CPU twin contig by contig:
+    every summary field of every read equal."""
+    import os
+    from falcon_unzip_amd import _lib
+    from tests import oracle_lib
+    cores = os.cpu_count() or 1
+    n_ctg = max(1, min(20, cores // 12))
+    contigs, blob, off, rctg = _make(n_ctg, 5_000_000, 2000, 15000, 750_000, cfg=2)
+    job = _lib.align_job_raw(eng, contigs, blob, off, rctg)
+    job.run()
+    got = job.summaries()
+    assert got["aligned"].mean() > 0.995
+    fields = ("aligned", "strand", "pos", "ref_end", "q_start", "q_end", "score", "n_cigar", "cells", "n_columns", "n_match")
+    n_checked = 0
+    for c in range(n_ctg):
+        idx = np.flatnonzero(rctg == c)
+        reads = [blob[off[i]:off[i + 1]] for i in idx]
+        exp, _ = oracle_lib.align_reads(oracle, contigs[c], reads, n_threads=cores)
+        for f in fields:
+            assert np.array_equal(got[f][idx], exp[f]), (c, f, np.flatnonzero(got[f][idx] != exp[f])[:5])
+        n_checked += len(idx)
+    assert n_checked == 2000 * n_ctg
+    job.close()
