@@ -187,10 +187,10 @@ def test_cfg5_slice_streams_through_groups(tmp_path):
         assert f.read().count(">") >= 2
 
 
-def test_cfg2_workload_k1_equals_twin_on_every_read(eng, oracle):
+def test_cfg2_workload_equals_oracles_on_every_read_and_contig(eng, oracle):
     """The bench's own workload, read for read: as many cfg2 contigs (5 Mb, 2 000 x 15 kb reads each) as the host's cores pay for in a
     few seconds -- all 20 on a 256-thread node -- aligned by the HIP path in one job and by the threaded CPU twin contig by contig:
-    every summary field of every read equal."""
+    every summary field of every read equal; then K2..K5 of every contig against the oracle chain."""
     import os
     from falcon_unzip_amd import _lib
     from tests import oracle_lib
@@ -211,4 +211,30 @@ def test_cfg2_workload_k1_equals_twin_on_every_read(eng, oracle):
             assert np.array_equal(got[f][idx], exp[f]), (c, f, np.flatnonzero(got[f][idx] != exp[f])[:5])
         n_checked += len(idx)
     assert n_checked == 2000 * n_ctg
+    # ... and the phasing chain of the same job, contig for contig, against the oracle chain fed the same records as SAM text
+    from concurrent.futures import ThreadPoolExecutor
+    b = job.to_batch()
+    b.run(_lib.STAGE_ALL)
+    res = b.results()
+
+    alns = [job.alnset(c)[0] for c in range(n_ctg)]        # one context: fetched in turn; only the oracle runs threaded
+
+    def one(c):
+        aln = alns[c]
+        name = "c%d" % c
+        exp = oracle.phase_all(_lib.format_sam(aln, name), contigs[c], name)
+        r = res[c]
+        off_q, names = aln.qname_table()
+        ok = (_lib.format_variant_pos(r.sites) == exp["variant_pos"]
+              and _lib.format_variant_map(r.sites, r.vmap_qid) == exp["variant_map"]
+              and _lib.format_atable(r.sites, r.arows) == exp["atable"]
+              and _lib.format_phased_variants(r.sites, r.pvars) == exp["phased_variants"]
+              and _lib.format_phased_reads(r.preads, name, off_q, names) == exp["phased_reads"])
+        return ok, len(r.sites), len(r.preads)
+
+    with ThreadPoolExecutor(max_workers=min(8, n_ctg)) as ex:
+        outs = list(ex.map(one, range(n_ctg)))
+    assert all(o[0] for o in outs), [c for c, o in enumerate(outs) if not o[0]]
+    assert all(o[1] > 1000 and o[2] > 1800 for o in outs)
+    b.close()
     job.close()
