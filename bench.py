@@ -309,18 +309,24 @@ def main():
     e2e = None
     if rank == 0 and world == 1 and not args.no_end_to_end:
         # the same workload from HOST buffers (never `value`): staging + H2D + packing inside, groups of contigs on lanes
-        gb = int(args.e2e_group_contigs * args.reads_per_contig * args.read_len * 1.06)
-        runs = []
-        for k in range(3):
-            t1 = time.perf_counter()
-            st, recs = _lib.phase_contigs(eng, contigs, blob, off, read_ctg, ids, names=name_tab, out_dir=os.path.join(out_root, "e2e%d" % k), read_maps=maps, ctg_index=mine,
-                                          n_lanes=args.e2e_lanes, group_bases=gb, consensus=args.with_consensus, async_writes=True)
-            runs.append((time.perf_counter() - t1, st))
-        best = min(runs[1:], key=lambda x: x[0])
-        e2e = {"reads_per_s": round(n_reads / best[0], 1), "ms": round(best[0] * 1e3, 2), "lanes": args.e2e_lanes, "groups": int(best[1]["n_groups"]),
-               "first_call_ms": round(runs[0][0] * 1e3, 2),
-               "host_section_ms_summed_over_lanes": {k: round(best[1][k], 2) for k in ("ms_upload", "ms_k1", "ms_phase", "ms_results", "ms_text")},
-               "note": "fzp_phase_contigs: host ASCII -> pinned staging -> H2D -> pack -> K1..K5 -> texts -> files; PCIe-inclusive, reported beside `value`, never as it"}
+        # two shapes -- the whole shard as one group on one lane, and groups of --e2e-group-contigs on --e2e-lanes lanes -- the faster is reported
+        shapes = [(len(mine), 1), (args.e2e_group_contigs, args.e2e_lanes)]
+        tried = []
+        for gc, lanes in shapes:
+            gb = int(gc * args.reads_per_contig * args.read_len * 1.06)
+            runs = []
+            for k in range(3):
+                t1 = time.perf_counter()
+                st, recs = _lib.phase_contigs(eng, contigs, blob, off, read_ctg, ids, names=name_tab, out_dir=os.path.join(out_root, "e2e_%d_%d_%d" % (gc, lanes, k)), read_maps=maps,
+                                              ctg_index=mine, n_lanes=lanes, group_bases=gb, consensus=args.with_consensus, async_writes=True)
+                runs.append((time.perf_counter() - t1, st))
+            best = min(runs[1:], key=lambda x: x[0])
+            tried.append({"reads_per_s": round(n_reads / best[0], 1), "ms": round(best[0] * 1e3, 2), "lanes": lanes, "groups": int(best[1]["n_groups"]),
+                          "first_call_ms": round(runs[0][0] * 1e3, 2),
+                          "host_section_ms_summed_over_lanes": {k: round(best[1][k], 2) for k in ("ms_upload", "ms_k1", "ms_phase", "ms_results", "ms_text")}})
+        e2e = dict(min(tried, key=lambda x: x["ms"]))
+        e2e["other_shape"] = {k: v for k, v in max(tried, key=lambda x: x["ms"]).items() if k in ("reads_per_s", "ms", "lanes", "groups")}
+        e2e["note"] = "fzp_phase_contigs: host ASCII -> H2D -> pack -> K1..K5 -> texts -> files; PCIe-inclusive, reported beside `value`, never as it"
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3

@@ -138,17 +138,36 @@ void fzp_pinned_release(fzp_ctx *ctx, void *p) {
 }
 
 // ---------------------------------------------------------------- big host -> device uploads
-// Pageable memory goes to the device through the driver's own staging at a few GB/s; here the caller's bytes are copied
-// into pinned blocks by UP_THREADS threads (each with two 8 MiB blocks and its own stream) while earlier chunks are in flight.
+// The staged variant copies the caller's bytes into pinned blocks with a few threads (each with two 8 MiB blocks and its own stream)
+// while earlier chunks are in flight; it is kept as an option for platforms whose pageable path is slow.
 int fzp_upload_segments(fzp_ctx *ctx, void *dst_dev, const std::vector<const void *> &src, const std::vector<size_t> &dst_off, const std::vector<size_t> &len, hipStream_t st) {
     constexpr size_t CHUNK = 8u << 20;
     size_t total = 0;
     for (size_t v : len) total += v;
-    if (total < (4u << 20)) {
+    // Default: hand the caller's (pageable) bytes to hipMemcpyAsync -- on this platform the runtime's own staging moves them at
+    // 40-45 GB/s, under both the ROCm 7.2 runtime and the 7.0 one torch ships (profiles/r2_h2d_staging_ubench.txt, tools/e2e_sweep.py).
+    // FZP_UPLOAD_MODE=staged: the library's own pinned, threaded staging below (21 ms vs 15 ms for the bench's 700 MB under 7.0, 48 ms
+    // under 7.2); =register: page-lock the caller's bytes in place first.
+    const char *mode = getenv("FZP_UPLOAD_MODE");
+    if (!mode || !strcmp(mode, "direct") || total < (4u << 20)) {
         for (size_t k = 0; k < src.size(); k++)
             if (len[k]) FZP_HIP(hipMemcpyAsync((char *)dst_dev + dst_off[k], src[k], len[k], hipMemcpyHostToDevice, st));
         FZP_HIP(hipStreamSynchronize(st));
         return FZP_OK;
+    }
+    if (!strcmp(mode, "register")) {
+        std::vector<void *> reg;
+        int rc = FZP_OK;
+        for (size_t k = 0; k < src.size() && rc == FZP_OK; k++) {
+            if (!len[k]) continue;
+            const uintptr_t a = (uintptr_t)src[k] & ~(uintptr_t)4095, e = ((uintptr_t)src[k] + len[k] + 4095) & ~(uintptr_t)4095;
+            if (hipHostRegister((void *)a, e - a, hipHostRegisterDefault) == hipSuccess) reg.push_back((void *)a); else (void)hipGetLastError();
+            if (hipMemcpyAsync((char *)dst_dev + dst_off[k], src[k], len[k], hipMemcpyHostToDevice, st) != hipSuccess) rc = FZP_EDEVICE;
+        }
+        if (hipStreamSynchronize(st) != hipSuccess) rc = FZP_EDEVICE;
+        for (void *q : reg) (void)hipHostUnregister(q);
+        if (rc) fzp_set_error("upload: a registered copy failed");
+        return rc;
     }
     struct Piece { const char *s; size_t d, n; };
     std::vector<Piece> pieces;

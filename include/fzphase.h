@@ -298,7 +298,7 @@ typedef struct {
     const char *names;
 } fzp_names;
 typedef struct {
-    const char *out_dir;           /* files go to <out_dir>/<ctg_id>/{het_call/*, g_atable/atable, get_phased_blocks/phased_variants,
+    const char *out_dir;           /* files go to <out_dir>/<ctg_id>/{het_call/<three files>, g_atable/atable, get_phased_blocks/phased_variants,
                                       phased_reads, rid_to_phase.<ctg_id>} (phasing.py:501-503,520,534,543; unzip.py:269); NULL = texts are
                                       produced but nothing is written */
     const char *rawread_ids; size_t rr_len;       /* the three read_map files of fc_phasing_readmap.py (phasing_readmap.py:15-16,36), */

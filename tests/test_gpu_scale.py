@@ -238,3 +238,20 @@ def test_cfg2_workload_equals_oracles_on_every_read_and_contig(eng, oracle):
     assert all(o[1] > 1000 and o[2] > 1800 for o in outs)
     b.close()
     job.close()
+
+
+def test_upload_modes_give_the_same_job(eng, monkeypatch):
+    """Big uploads (> 4 MiB) have three routes -- the runtime's pageable copy (default), the library's pinned threaded staging, an in-place
+    page lock -- chosen per call by FZP_UPLOAD_MODE: same device bytes, so the same alignments, whichever is taken."""
+    from falcon_unzip_amd import _lib
+    contigs, blob, off, rctg = _make(2, 3_000_000, 600, 15000, 400_000, cfg=12)      # 9 MB of reads, 6 MB of contigs
+    got = {}
+    for mode in ("direct", "staged", "register"):
+        monkeypatch.setenv("FZP_UPLOAD_MODE", mode)
+        job = _lib.align_job_raw(eng, contigs, blob, off, rctg)
+        job.run()
+        got[mode] = job.summaries().copy()
+        job.close()
+    monkeypatch.delenv("FZP_UPLOAD_MODE")
+    assert got["direct"]["aligned"].mean() > 0.99
+    assert np.array_equal(got["direct"], got["staged"]) and np.array_equal(got["direct"], got["register"])
