@@ -76,6 +76,7 @@ __global__ void __launch_bounds__(CNS_THREADS) k_cns_tiles(RecView rv, CnsView v
                                                            const int32_t *__restrict__ ctg_maxspan, uint32_t *__restrict__ cnt, LongIns *__restrict__ lins,
                                                            unsigned long long *__restrict__ n_lins, unsigned long long lins_cap) {
     __shared__ uint32_t l_cnt[2 * CN * CNS_TILE];      // [phase][counter][position]: consecutive lanes -> distinct banks
+    __shared__ __attribute__((aligned(16))) uint32_t l_win[(CNS_THREADS / 64) * EXP_WIN];   // expand_record's window, one per wave
     const int32_t g = tile_blk[blockIdx.x], ts = tile_start[blockIdx.x];
     const int c = blk_ctg[g];
     const int32_t lo = v.lo[g], hi = v.hi[g];
@@ -132,7 +133,7 @@ __global__ void __launch_bounds__(CNS_THREADS) k_cns_tiles(RecView rv, CnsView v
             uint32_t *lc = l_cnt + phu * (CN * CNS_TILE);
             const int32_t pos0 = rv.rec_pos[ru];
             const int64_t seq_end = rv.seq_off[ru + 1];
-            expand_record(rv, ru,
+            expand_record(rv, ru, l_win + wave * EXP_WIN,
                 [&](int32_t pos, uint8_t sym) {
                     const uint32_t p = (uint32_t)(pos - ts);
                     const int code = sym_code(sym);

@@ -40,7 +40,7 @@ __global__ void __launch_bounds__(256) k_cig_ckpt(RecView v, const int64_t *__re
 }
 
 // ---- K2a: column counts by position tile.  A workgroup owns TILE consecutive positions of one contig, keeps
-// their A/C/G/T counters (and the non-ACGT tracker) in LDS, lets its waves walk the records that overlap the tile
+// their A/C/G/T counters in LDS (the tracker of symbols other than ACGT -- rare -- lives in HBM, pre-zeroed, and takes global atomics), lets its waves walk the records that overlap the tile
 // -- each from the CIGAR checkpoint just before the tile -- and writes the counters out once, coalesced.  No global
 // atomics: HBM sees the symbols (1 B/column), the CIGAR words and 20 B per position, about the algorithmic minimum.
 constexpr int PILE_TILE = 2048, PILE_THREADS = 512;
@@ -49,14 +49,14 @@ __global__ void __launch_bounds__(PILE_THREADS) k_pileup_tiles(RecView v, const 
                                                       const int32_t *__restrict__ rec_span, const int64_t *__restrict__ ck_off, const int32_t *__restrict__ ck_ref,
                                                       const int32_t *__restrict__ ck_q, uint32_t *__restrict__ cnt, uint32_t *__restrict__ oth) {
     __shared__ uint32_t l_cnt[4 * PILE_TILE];   // [code][position]: consecutive lanes = consecutive positions = distinct banks
-    __shared__ uint32_t l_oth[PILE_TILE];
+    __shared__ __attribute__((aligned(16))) uint32_t l_win[(PILE_THREADS / 64) * EXP_WIN];   // expand_record's window, one per wave
     const int c = tile_ctg[blockIdx.x];
     const int32_t ts = tile_start[blockIdx.x];
     const int32_t lim = v.ctg_limit[c];
     const int32_t te = min(ts + PILE_TILE, lim);
     for (int i = threadIdx.x; i < PILE_TILE * 4; i += PILE_THREADS) l_cnt[i] = 0;
-    for (int i = threadIdx.x; i < PILE_TILE; i += PILE_THREADS) l_oth[i] = 0;
     __syncthreads();
+    uint32_t *oth_t = oth + v.ctg_goff[c] + ts;      // the tile's tracker words in HBM (zeroed by the host before the launch)
     // records of this contig that can overlap [ts, te): POS < te and POS > ts - max_span
     const int64_t rb = ctg_rec_begin[c], re = ctg_rec_begin[c + 1];
     const int32_t ms = ctg_maxspan[c];
@@ -93,15 +93,15 @@ __global__ void __launch_bounds__(PILE_THREADS) k_pileup_tiles(RecView v, const 
         for (uint64_t todo = __ballot(ok); todo; todo &= todo - 1) {
             const int l = __builtin_ctzll(todo);
             const int64_t ru = lo + __builtin_amdgcn_readlane(rel, l);
-            expand_record(v, ru, [&](int32_t pos, uint8_t sym) {
+            expand_record(v, ru, l_win + wave * EXP_WIN, [&](int32_t pos, uint8_t sym) {
                 const uint32_t p = (uint32_t)(pos - ts);
                 const bool in = p < (uint32_t)(te - ts);
                 const int code = sym_code(sym);
                 if (in & (code < 4)) atomicAdd(&l_cnt[code * PILE_TILE + p], 1u);
                 if (__any(in & (code == 4))) {          // symbols other than ACGT: rare, kept off the common path
                     if (in & (code == 4)) {
-                        uint32_t old = atomicCAS(&l_oth[p], 0u, (uint32_t)sym);
-                        if (old != 0u && (old & 0xffu) != (uint32_t)sym) atomicOr(&l_oth[p], 0x100u);
+                        uint32_t old = atomicCAS(&oth_t[p], 0u, (uint32_t)sym);
+                        if (old != 0u && (old & 0xffu) != (uint32_t)sym) atomicOr(&oth_t[p], 0x100u);
                     }
                 }
             }, __builtin_amdgcn_readlane(a, l), __builtin_amdgcn_readlane(cr, l), __builtin_amdgcn_readlane(cq, l), te);
@@ -111,7 +111,6 @@ __global__ void __launch_bounds__(PILE_THREADS) k_pileup_tiles(RecView v, const 
     const int64_t g0 = v.ctg_goff[c] + ts;
     const int np = te - ts;
     for (int i = threadIdx.x; i < np * 4; i += PILE_THREADS) cnt[g0 * 4 + i] = l_cnt[(i & 3) * PILE_TILE + (i >> 2)];
-    for (int i = threadIdx.x; i < np; i += PILE_THREADS) oth[g0 + i] = l_oth[i];
 }
 
 struct CallInfo {
@@ -475,6 +474,7 @@ int fzp_k2_het_call(fzp_ctx *ctx, fzp_batch *b) {
             for (int32_t t0 = 0; t0 < b->h_limit[c]; t0 += PILE_TILE) { b->h_tile_ctg.push_back(c); b->h_tile_start.push_back(t0); }
         FZP_TRY(b->tile_ctg.upload(b->h_tile_ctg.data(), b->h_tile_ctg.size(), st));
         FZP_TRY(b->tile_start.upload(b->h_tile_start.data(), b->h_tile_start.size(), st));
+        FZP_TRY(b->oth.zero((size_t)np, st));
         {
             ProfScope ps(ctx, "k2_pileup_count");
             hipLaunchKernelGGL(k_pileup_tiles, dim3((unsigned)b->h_tile_ctg.size()), dim3(PILE_THREADS), 0, st, v, b->tile_ctg.p, b->tile_start.p, b->ctg_rec_begin.p, b->ctg_maxspan.p,
