@@ -169,3 +169,50 @@ def test_contig_shorter_than_the_last_record(eng):
         b.run(_lib.STAGE_HET)
     assert "IndexError" in str(ei.value)
     b.close()
+
+
+def test_long_clips_and_gaps_take_the_search_path(eng, oracle):
+    """The CIGAR expander keeps, per 64-op chunk, the deleted and the inserted / clipped bases before an op in 16 bits each; a chunk that
+    holds a soft clip, an insertion or a deletion of 65 536+ bases takes the other route (a search per column).  Records of both kinds,
+    mixed, against the oracle."""
+    import re
+    from falcon_unzip_amd import sim
+    rng = np.random.Generator(np.random.PCG64(77))
+    L = 250_000
+    hap0, hap1, _ = sim.make_diploid(L, rng, het_rate=1.0 / 300)
+    reads = sim.simulate_reads(hap0, hap1, 700, 6000, rng, clip_frac=0.1)
+    lines = sim.sam_lines(reads, "ctgX", L=L)
+    out, n_clip, n_del, n_ins = [], 0, 0, 0
+    for k, ln in enumerate(lines):
+        f = ln.split("\t")
+        if f[0].startswith("@"):
+            out.append(ln)
+            continue
+        ops = re.findall(r"\d+[MIDNSHP=X]", f[5])
+        if k % 7 == 0 and not ops[0].endswith(("S", "H")):         # a 70 kb leading clip
+            pad = sim.codes_to_str(rng.integers(0, 4, 70_000).astype(np.uint8))
+            f[5] = "70000S" + f[5]
+            f[9] = pad + f[9]
+            if f[10] != "*":
+                f[10] = "!" * 70_000 + f[10]
+            n_clip += 1
+        elif k % 7 == 3 and int(f[3]) < 100_000 and len(ops) > 40:  # a 70 kb deletion after the 20th op: the tail lands 70 kb further on
+            f[5] = "".join(ops[:20]) + "70000D" + "".join(ops[20:])
+            n_del += 1
+        elif k % 7 == 5 and len(ops) > 40:                          # a 66 kb insertion in the middle of the first chunk
+            q_before = sum(int(o[:-1]) for o in ops[:30] if o[-1] in "MIS=X")
+            pad = sim.codes_to_str(rng.integers(0, 4, 66_000).astype(np.uint8))
+            f[5] = "".join(ops[:30]) + "66000I" + "".join(ops[30:])
+            f[9] = f[9][:q_before] + pad + f[9][q_before:]
+            if f[10] != "*":
+                f[10] = f[10][:q_before] + "!" * 66_000 + f[10][q_before:]
+            n_ins += 1
+        out.append("\t".join(f))
+    assert n_clip > 50 and n_del > 10 and n_ins > 50
+    sam = "".join(l + "\n" for l in out).encode()
+    ref = sim.codes_to_str(hap0).encode()
+    exp = oracle.phase_all(sam, ref, "ctgX")
+    got = _phase_all(eng, sam, ref, "ctgX")
+    assert len(exp["variant_pos"]) > 1000
+    for k in exp:
+        assert got[k] == exp[k], k
