@@ -352,7 +352,7 @@ def main():
                                     if args.strong else
                                     "cfg2: per GPU %d contigs x %d bp, %d reads x %d bp template each (CLR 1/8/4 %% errors, both strands), reads drawn from a %d bp window per contig; "
                                     % (args.contigs, args.contig_len, args.reads_per_contig, args.read_len, win))
-                                   + "inputs resident in HBM; inside the step: K1 align (fzalign v1.2) + K2 het call + K3 atable + K4 blocks + K5 reads + all seven files of every contig "
+                                   + "inputs resident in HBM (2-bit reads and contigs + the contigs' k-mer tables, all built by fzp_align_create); inside the step: K1 align (fzalign v1.2) + K2 het call + K3 atable + K4 blocks + K5 reads + all seven files of every contig "
                                      "serialised AND written + readmap + r2p all-gather" + (" + K6 consensus" if args.with_consensus else ""),
                        "reads_total": n_total, "reads_per_gpu": n_reads, "parallelism": "contigs sharded, %d rank(s)" % world},
             "dp_gcell_per_s_per_gpu": round(dp_gcells, 2),

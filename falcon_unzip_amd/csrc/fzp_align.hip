@@ -1334,6 +1334,7 @@ struct fzp_alnjob {
     DevBuf<uint64_t> table;
     DevBuf<uint32_t> part_cursor;                // k-mer index build: staged entries per partition
     DevBuf<int32_t> part_ctg, idx_overflow;
+    bool index_built = false;
     DevBuf<int64_t> part_off;
     std::vector<int64_t> h_part_off;
     int64_t n_parts = 0;
@@ -1378,6 +1379,29 @@ extern "C" void fzp_align_destroy(fzp_ctx *ctx, fzp_alnjob *job) {
     if (ctx) { (void)fzp_bind(ctx); (void)hipStreamSynchronize(ctx->stream); (void)hipStreamSynchronize(ctx->stream2); }
     for (int k = 0; k < 2; k++) { if (job->ev_sw[k]) (void)hipEventDestroy(job->ev_sw[k]); if (job->ev_tb[k]) (void)hipEventDestroy(job->ev_tb[k]); }
     delete job;
+}
+
+// The contigs' k-mer tables (k_index_stage + k_index_build).  They depend on the contigs and on P.kmer only, so they are built once, by
+// fzp_align_create right after the contigs are packed, and every fzp_align_run of the job reuses them (FZP_INDEX_PER_RUN=1: rebuilt per run).
+static int build_index(fzp_ctx *ctx, fzp_alnjob *j) {
+    hipStream_t st = ctx->stream;
+    const fzp_align_params &P = j->P;
+    {
+        ProfScope ps(ctx, "k1_index");
+        int64_t lc_max = 0;
+        for (auto v : j->h_ctg_len) lc_max = std::max(lc_max, v);
+        const unsigned gx = (unsigned)std::max<int64_t>(1, ((lc_max + CTG_STRIDE - 1) / CTG_STRIDE + STAGE_KMERS - 1) / STAGE_KMERS);
+        FZP_HIP(hipMemsetAsync(j->part_cursor.p, 0, (size_t)j->n_parts * 4, st));
+        FZP_HIP(hipMemsetAsync(j->idx_overflow.p, 0, 4, st));
+        hipLaunchKernelGGL(k_index_stage, dim3(gx, j->n_ctg), dim3(256), 0, st, j->ctg_pk.p, j->ctg_woff.p, j->ctg_len.p, j->idx_off.p, j->idx_bits.p, j->part_off.p, P.kmer,
+                           j->table.p, j->part_cursor.p, j->idx_overflow.p);
+        const size_t lds = (size_t)(4u << PART_BITS) * 8;
+        FZP_HIP(hipFuncSetAttribute((const void *)k_index_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_index_build, dim3((unsigned)j->n_parts), dim3(256), lds, st, j->part_ctg.p, j->part_off.p, j->idx_off.p, j->idx_bits.p, j->table.p, j->part_cursor.p,
+                           j->idx_overflow.p);
+    }
+    j->index_built = true;
+    return FZP_OK;
 }
 
 extern "C" int fzp_align_create(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *const *ctg_seq, const int64_t *ctg_len, int64_t n_reads, const int32_t *read_ctg,
@@ -1491,6 +1515,7 @@ extern "C" int fzp_align_create(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *cons
             (rc = j->mvo.alloc((size_t)n_reads)) || (rc = j->n_sec.alloc(1)) || (rc = j->info.alloc((size_t)n_reads)) ||
             (rc = j->summ.alloc((size_t)n_reads)) || (rc = j->cig.alloc((size_t)j->h_cig_off.back())) || (rc = j->cig_start.alloc((size_t)n_reads)))
             break;
+        if ((rc = build_index(ctx, j))) break;
     } while (0);
     if (rc == FZP_OK && hipGetLastError() != hipSuccess) rc = FZP_EDEVICE;
     if (rc) { if (rc == FZP_EDEVICE) fzp_set_error("fzp_align_create: device error"); delete j; return rc; }
@@ -1503,20 +1528,7 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
     FZP_TRY(fzp_bind(ctx));
     hipStream_t st = ctx->stream;
     const fzp_align_params &P = j->P;
-    {
-        ProfScope ps(ctx, "k1_index");
-        int64_t lc_max = 0;
-        for (auto v : j->h_ctg_len) lc_max = std::max(lc_max, v);
-        const unsigned gx = (unsigned)std::max<int64_t>(1, ((lc_max + CTG_STRIDE - 1) / CTG_STRIDE + STAGE_KMERS - 1) / STAGE_KMERS);
-        FZP_HIP(hipMemsetAsync(j->part_cursor.p, 0, (size_t)j->n_parts * 4, st));
-        FZP_HIP(hipMemsetAsync(j->idx_overflow.p, 0, 4, st));
-        hipLaunchKernelGGL(k_index_stage, dim3(gx, j->n_ctg), dim3(256), 0, st, j->ctg_pk.p, j->ctg_woff.p, j->ctg_len.p, j->idx_off.p, j->idx_bits.p, j->part_off.p, P.kmer,
-                           j->table.p, j->part_cursor.p, j->idx_overflow.p);
-        const size_t lds = (size_t)(4u << PART_BITS) * 8;
-        FZP_HIP(hipFuncSetAttribute((const void *)k_index_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_index_build, dim3((unsigned)j->n_parts), dim3(256), lds, st, j->part_ctg.p, j->part_off.p, j->idx_off.p, j->idx_bits.p, j->table.p, j->part_cursor.p,
-                           j->idx_overflow.p);
-    }
+    if (!j->index_built || getenv("FZP_INDEX_PER_RUN")) FZP_TRY(build_index(ctx, j));     // normally built by fzp_align_create
     const int64_t nr = j->n_reads;
     if (nr > 0) {
         {
