@@ -234,7 +234,9 @@ typedef struct {             /* per read, input order */
 
 /* reads/contigs are ASCII (ACGT, any case; any other symbol is treated as 'A' throughout, and the
  * SEQ handed to the phasing stages is the oriented read re-spelled in upper-case ACGT).  All reads in one call belong to contig `ctg_seq` (the reference
- * aligns <ctg>_reads.fa to <ctg>_ref.fa, unzip.py:233-234). */
+ * aligns <ctg>_reads.fa to <ctg>_ref.fa, unzip.py:233-234).
+ * fzp_align_create uploads and 2-bit-packs reads and contigs and builds the contigs' k-mer tables (they depend on the contigs and k only);
+ * fzp_align_run seeds, chains, extends and traces back, and may be repeated on the same job. */
 typedef struct fzp_alnjob fzp_alnjob;
 int fzp_align_create(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *const *ctg_seq, const int64_t *ctg_len,
                      int64_t n_reads, const int32_t *read_ctg, const int64_t *read_off, const uint8_t *read_seq,
