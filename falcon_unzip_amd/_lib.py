@@ -541,13 +541,21 @@ class AlignJob:
     __del__ = close
 
 
+def _contig_ptrs(contigs):
+    """-> (keep-alive list, void* array, int64 lengths) of the contigs' bytes where they are: bytes objects lend their buffer, anything
+    else goes through numpy; no copies"""
+    nc = len(contigs)
+    bufs = [c if isinstance(c, bytes) else np.ascontiguousarray(np.frombuffer(c, dtype=np.uint8)) for c in contigs]
+    empty = C.create_string_buffer(1)
+    ptr = (C.c_void_p * nc)(*[(C.cast(C.c_char_p(b), C.c_void_p).value if isinstance(b, bytes) else b.ctypes.data) if len(b) else C.addressof(empty) for b in bufs])
+    return (bufs, empty), ptr, (C.c_int64 * nc)(*[len(c) for c in contigs])
+
+
 def align_job(eng, contigs, reads, read_ctg=None, params=None) -> AlignJob:
     """contigs: list of bytes; reads: list of bytes (as sequenced); read_ctg: contig index per read."""
     lib = load()
     nc, nr = len(contigs), len(reads)
-    cbufs = [C.create_string_buffer(c, len(c)) if len(c) else C.create_string_buffer(1) for c in contigs]
-    cptr = (C.c_void_p * nc)(*[C.cast(b, C.c_void_p).value for b in cbufs])
-    clen = (C.c_int64 * nc)(*[len(c) for c in contigs])
+    cbufs, cptr, clen = _contig_ptrs(contigs)
     rc = np.zeros(nr, np.int32) if read_ctg is None else np.ascontiguousarray(read_ctg, dtype=np.int32)
     off = np.zeros(nr + 1, np.int64)
     off[1:] = np.cumsum([len(r) for r in reads])
@@ -567,9 +575,7 @@ def align_job_raw(eng, contigs, read_blob: bytes, read_off, read_ctg, params=Non
     nc = len(contigs)
     read_off = np.ascontiguousarray(read_off, dtype=np.int64)
     nr = len(read_off) - 1
-    cbufs = [C.create_string_buffer(c, len(c)) if len(c) else C.create_string_buffer(1) for c in contigs]
-    cptr = (C.c_void_p * nc)(*[C.cast(b, C.c_void_p).value for b in cbufs])
-    clen = (C.c_int64 * nc)(*[len(c) for c in contigs])
+    cbufs, cptr, clen = _contig_ptrs(contigs)
     rc = np.ascontiguousarray(read_ctg, dtype=np.int32)
     P = AlignParams()
     lib.fzp_align_params_default(C.byref(P))
@@ -634,9 +640,7 @@ def phase_contigs(eng, contigs, read_blob: bytes, read_off, read_ctg, ctg_ids, n
     nc = len(contigs)
     read_off = np.ascontiguousarray(read_off, dtype=np.int64)
     nr = len(read_off) - 1
-    cbufs = [C.create_string_buffer(c, len(c)) if len(c) else C.create_string_buffer(1) for c in contigs]
-    cptr = (C.c_void_p * nc)(*[C.cast(b, C.c_void_p).value for b in cbufs])
-    clen = (C.c_int64 * nc)(*[len(c) for c in contigs])
+    cbufs, cptr, clen = _contig_ptrs(contigs)
     rc = np.ascontiguousarray(read_ctg, dtype=np.int32)
     nm, opts, keep = _pipe_args(ctg_ids, names, out_dir, read_maps, ctg_index, n_threads, n_lanes, group_bases, params,
                                 (PIPE_CONSENSUS if consensus else 0) | (PIPE_ASYNC_WRITES if async_writes else 0))

@@ -456,9 +456,12 @@ extern "C" int fzp_phase_contigs(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *con
     if (opts) o = *opts; else fzp_pipe_opts_default(&o);
     memset(out, 0, sizeof *out);
     for (int64_t r = 0; r < n_reads; r++) if (read_ctg[r] < 0 || read_ctg[r] >= n_ctg) { fzp_set_error("read %lld: bad contig", (long long)r); return FZP_EINVAL; }
+    const bool timing = getenv("FZP_PIPE_TIMING") != nullptr;
+    const auto t_call = clk::now();
     ReadMaps maps;
     const bool have_maps = o.pread_to_contigs != nullptr;
     if (have_maps) parse_maps(&o, maps);
+    const double ms_maps = ms_since(t_call);
     // reads of every contig (input order inside a contig), read bases per contig
     std::vector<std::vector<int64_t>> ctg_reads((size_t)n_ctg);
     std::vector<int64_t> bases((size_t)n_ctg, 0);
@@ -562,14 +565,18 @@ extern "C" int fzp_phase_contigs(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *con
             if (rc != FZP_OK) { rcs[(size_t)li] = rc; break; }
         }
     };
+    const double ms_prep = ms_since(t_call);
     {
         std::vector<std::thread> th;
         for (int li = 1; li < lanes; li++) th.emplace_back(lane, li);
         lane(0);
         for (auto &x : th) x.join();
     }
+    const double ms_lanes = ms_since(t_call);
     (void)fzp_bind(ctx);
-    const int frc = fzp_pipe_flush(ctx);                    // FZP_PIPE_ASYNC_WRITES: the groups' files overlapped other groups' kernels; all are down now
+    const int frc = fzp_pipe_flush(ctx);
+    if (timing) fprintf(stderr, "[fzp_phase_contigs] read maps %.2f ms, grouping until %.2f, lanes until %.2f, flush until %.2f (%d lanes, %zu groups)\n", ms_maps, ms_prep, ms_lanes,
+                        ms_since(t_call), lanes, groups.size());                    // FZP_PIPE_ASYNC_WRITES: the groups' files overlapped other groups' kernels; all are down now
     for (int li = 0; li < lanes; li++) if (rcs[(size_t)li] != FZP_OK) { fzp_set_error("%s", errs[(size_t)li].c_str()); return rcs[(size_t)li]; }
     if (frc != FZP_OK) return frc;
     for (int li = 0; li < lanes; li++) add(out, outs[(size_t)li]);
