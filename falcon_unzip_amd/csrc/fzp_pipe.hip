@@ -502,6 +502,7 @@ extern "C" int fzp_phase_contigs(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *con
         FZP_TRY(fzp_ctx_create(device, 0, &lc));
         ctx->lanes.push_back(lc);
     }
+    std::mutex up_mu;
     auto lane = [&](int li) {
         fzp_ctx *lc = li == 0 ? ctx : ctx->lanes[(size_t)li - 1];
         if (fzp_bind(lc) != FZP_OK) { rcs[(size_t)li] = FZP_EDEVICE; errs[(size_t)li] = fzp_last_error(); return; }
@@ -544,7 +545,12 @@ extern "C" int fzp_phase_contigs(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *con
                 g_noff[(size_t)k + 1] = (int64_t)g_names.size();
             }
             fzp_alnjob *job = nullptr;
-            int rc = fzp_align_create(lc, gc, ctg_seq + G.c0, ctg_len + G.c0, gr, g_ctg.data(), abs_off.data(), g_seq, &o.align, &job);
+            int rc;
+            {   // one upload at a time: the first group then has the whole PCIe link and its kernels start early; the next group's upload
+                // runs under them (two uploads side by side would finish together and leave the device idle until then)
+                std::lock_guard<std::mutex> lk(up_mu);
+                rc = fzp_align_create(lc, gc, ctg_seq + G.c0, ctg_len + G.c0, gr, g_ctg.data(), abs_off.data(), g_seq, &o.align, &job);
+            }
             po.ms_upload += ms_since(t0);
             if (rc == FZP_OK) {
                 fzp_names gn;
