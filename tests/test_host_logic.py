@@ -97,3 +97,18 @@ def test_clip_filter_is_ieee_double(lib):
     assert aln.n_rec == 0 and aln.n_qid == 1
     rec = b"r1\t0\tc\t1\t254\t8999S1001M\t*\t0\t0\t" + b"A" * 10000 + b"\t*\n"
     assert lib.parse_sam(rec).n_rec == 1
+
+
+def test_contig_buffers_are_lent_not_copied():
+    """The binding hands the library the contigs' own bytes (no copy): pointers and lengths for bytes, bytearray, numpy and empty contigs"""
+    import ctypes as C
+    import numpy as np
+    from falcon_unzip_amd import _lib
+    contigs = [b"ACGTACGT", bytearray(b"TTGCA"), np.frombuffer(b"GGGCCC", dtype=np.uint8), b""]
+    keep, ptr, clen = _lib._contig_ptrs(contigs)
+    assert list(clen) == [8, 5, 6, 0]
+    for k, c in enumerate(contigs[:3]):
+        assert C.string_at(ptr[k], clen[k]) == bytes(c)
+    assert ptr[3]                                   # an empty contig still gets a valid address
+    assert ptr[0] == C.cast(C.c_char_p(contigs[0]), C.c_void_p).value       # the bytes object's own buffer
+    assert ptr[2] == contigs[2].ctypes.data
