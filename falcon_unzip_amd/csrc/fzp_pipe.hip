@@ -20,6 +20,7 @@
 #include <condition_variable>
 #include <deque>
 #include <functional>
+#include <future>
 #include <thread>
 #include <unordered_map>
 
@@ -160,6 +161,18 @@ void parse_maps(const fzp_pipe_opts *o, ReadMaps &m) {
     for (auto &kv : tmp) { m.names.push_back(kv.first); m.rows.push_back(std::move(kv.second)); }
 }
 
+// the read maps are parsed on their own thread while the device works (2 ms for 40 000 reads); whoever needs them first waits
+struct MapsHolder {
+    ReadMaps maps;
+    std::shared_future<void> ready;
+    bool have = false;
+    void start(const fzp_pipe_opts *o) {
+        have = o->pread_to_contigs != nullptr;
+        if (have) ready = std::async(std::launch::async, [this, o]() { parse_maps(o, maps); }).share();
+    }
+    const ReadMaps *get() const { if (!have) return nullptr; ready.wait(); return &maps; }
+};
+
 struct TextBuf {
     std::string s;
     inline void puti(long long v) {
@@ -273,7 +286,7 @@ extern "C" void fzp_pipe_opts_default(fzp_pipe_opts *o) {
 }
 
 // everything after the upload, for the contigs of one job
-static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, const fzp_pipe_opts *o, const ReadMaps *maps, const int32_t *ctg_index, fzp_pipe_out *out,
+static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, const fzp_pipe_opts *o, const MapsHolder &mh, const int32_t *ctg_index, fzp_pipe_out *out,
                            std::vector<fzp_r2p> &r2p) {
     FZP_TRY(fzp_bind(ctx));
     auto t0 = clk::now();
@@ -323,6 +336,7 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
     struct RG { fzp_result_all *r; ~RG() { fzp_result_all_free(r); } } rg{&ra};
     FZP_HIP(hipStreamSynchronize(st2));
     const int32_t *qid_read = (const int32_t *)(pin + o_qr);
+    const ReadMaps *maps = mh.get();
     out->ms_results += ms_since(t0);
     t0 = clk::now();
     static const bool timing = getenv("FZP_PIPE_TIMING") != nullptr;
@@ -434,11 +448,10 @@ extern "C" int fzp_job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_name
     fzp_pipe_opts o;
     if (opts) o = *opts; else fzp_pipe_opts_default(&o);
     memset(out, 0, sizeof *out);
-    ReadMaps maps;
-    const bool have_maps = o.pread_to_contigs != nullptr;
-    if (have_maps) parse_maps(&o, maps);
+    MapsHolder mh;
+    mh.start(&o);
     std::vector<fzp_r2p> r2p;
-    FZP_TRY(job_phase_write(ctx, job, nm, &o, have_maps ? &maps : nullptr, o.ctg_index, out, r2p));
+    FZP_TRY(job_phase_write(ctx, job, nm, &o, mh, o.ctg_index, out, r2p));
     out->n_r2p = (int64_t)r2p.size();
     out->r2p = (fzp_r2p *)malloc((r2p.size() ? r2p.size() : 1) * sizeof(fzp_r2p));
     if (!out->r2p) return FZP_ENOMEM;
@@ -458,9 +471,8 @@ extern "C" int fzp_phase_contigs(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *con
     for (int64_t r = 0; r < n_reads; r++) if (read_ctg[r] < 0 || read_ctg[r] >= n_ctg) { fzp_set_error("read %lld: bad contig", (long long)r); return FZP_EINVAL; }
     const bool timing = getenv("FZP_PIPE_TIMING") != nullptr;
     const auto t_call = clk::now();
-    ReadMaps maps;
-    const bool have_maps = o.pread_to_contigs != nullptr;
-    if (have_maps) parse_maps(&o, maps);
+    MapsHolder mh;
+    mh.start(&o);
     const double ms_maps = ms_since(t_call);
     // reads of every contig (input order inside a contig), read bases per contig
     std::vector<std::vector<int64_t>> ctg_reads((size_t)n_ctg);
@@ -559,7 +571,7 @@ extern "C" int fzp_phase_contigs(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *con
                 gn.names = g_names.data();
                 std::vector<int32_t> gi;
                 for (int c = G.c0; c < G.c1; c++) gi.push_back(o.ctg_index ? o.ctg_index[c] : c);
-                rc = job_phase_write(lc, job, &gn, &o, have_maps ? &maps : nullptr, gi.data(), &po, r2p_g[0][g]);
+                rc = job_phase_write(lc, job, &gn, &o, mh, gi.data(), &po, r2p_g[0][g]);
                 if (rc == FZP_OK) {
                     std::vector<fzp_aln_summary> sm((size_t)gr);
                     if (gr && fzp_align_summaries(lc, job, sm.data()) == FZP_OK) for (auto &s : sm) po.dp_cells += (double)s.cells;
@@ -581,7 +593,7 @@ extern "C" int fzp_phase_contigs(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *con
     const double ms_lanes = ms_since(t_call);
     (void)fzp_bind(ctx);
     const int frc = fzp_pipe_flush(ctx);
-    if (timing) fprintf(stderr, "[fzp_phase_contigs] read maps %.2f ms, grouping until %.2f, lanes until %.2f, flush until %.2f (%d lanes, %zu groups)\n", ms_maps, ms_prep, ms_lanes,
+    if (timing) fprintf(stderr, "[fzp_phase_contigs] read maps started by %.2f ms, grouping until %.2f, lanes until %.2f, flush until %.2f (%d lanes, %zu groups)\n", ms_maps, ms_prep, ms_lanes,
                         ms_since(t_call), lanes, groups.size());                    // FZP_PIPE_ASYNC_WRITES: the groups' files overlapped other groups' kernels; all are down now
     for (int li = 0; li < lanes; li++) if (rcs[(size_t)li] != FZP_OK) { fzp_set_error("%s", errs[(size_t)li].c_str()); return rcs[(size_t)li]; }
     if (frc != FZP_OK) return frc;
