@@ -328,13 +328,21 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
     if (async) { const std::string e = [&] { std::lock_guard<std::mutex> lk(ctx->writer->mu); std::string x; x.swap(ctx->writer->first_error); return x; }(); if (!e.empty()) { fzp_set_error("%s", e.c_str()); return FZP_EINVAL; } }
     hipStream_t st2 = ctx->stream2;
     FZP_HIP(hipStreamSynchronize(ctx->stream));
+    // the q_id -> read table first (the host threads need it at once), the two big texts behind it: they only have to be there when a
+    // contig's write task is made, so their copy runs under the formatting of the small files
+    struct Ev { hipEvent_t e = nullptr; ~Ev() { if (e) (void)hipEventDestroy(e); } } ev_q, ev_t;
+    FZP_HIP(hipEventCreateWithFlags(&ev_q.e, hipEventDisableTiming));
+    FZP_HIP(hipEventCreateWithFlags(&ev_t.e, hipEventDisableTiming));
+    if (n_slots) FZP_HIP(hipMemcpyAsync(pin + o_qr, b->qid_read.p, (size_t)n_slots * 4, hipMemcpyDeviceToHost, st2));
+    FZP_HIP(hipEventRecord(ev_q.e, st2));
     if (n_vmap) FZP_HIP(hipMemcpyAsync(pin, d_vmap.p, n_vmap, hipMemcpyDeviceToHost, st2));
     if (n_atab) FZP_HIP(hipMemcpyAsync(pin + o_atab, d_atab.p, n_atab, hipMemcpyDeviceToHost, st2));
-    if (n_slots) FZP_HIP(hipMemcpyAsync(pin + o_qr, b->qid_read.p, (size_t)n_slots * 4, hipMemcpyDeviceToHost, st2));
+    FZP_HIP(hipEventRecord(ev_t.e, st2));
+    struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamSynchronize(s); } } sg2{st2};     // nothing below may leave while copies into `pin` are in flight
     fzp_result_all ra;
     FZP_TRY(fzp_batch_result_all(ctx, b, &ra));                  // sites / variant_map ids / atable rows are not needed on the host here, but the views are free
     struct RG { fzp_result_all *r; ~RG() { fzp_result_all_free(r); } } rg{&ra};
-    FZP_HIP(hipStreamSynchronize(st2));
+    FZP_HIP(hipEventSynchronize(ev_q.e));
     const int32_t *qid_read = (const int32_t *)(pin + o_qr);
     const ReadMaps *maps = mh.get();
     out->ms_results += ms_since(t0);
@@ -391,6 +399,7 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
             us_map += (int64_t)(ms_since(tq) * 1e3); tq = clk::now();
             char *fa = nullptr; size_t fl = 0;
             if (rc == FZP_OK && o->out_dir && want_cns && fzp_format_tigs(&tigs, c, ctg, &fa, &fl) != FZP_OK) { rc = FZP_EINVAL; errs[(size_t)t] = fzp_last_error(); }
+            if (rc == FZP_OK && o->out_dir && hipEventSynchronize(ev_t.e) != hipSuccess) { rc = FZP_EDEVICE; errs[(size_t)t] = "text download failed"; }
             if (rc == FZP_OK && o->out_dir) {
                 // everything the files need is owned by `owned` (pinned texts, malloc'ed small texts) or moved into the task (strings)
                 { std::lock_guard<std::mutex> lk(owned->mu); for (auto p : txt) owned->texts.push_back(p); if (fa) owned->texts.push_back(fa); }
