@@ -336,7 +336,7 @@ def main():
         import threading
         eng2 = _lib.Engine(dev_index)
         jobs = [_lib.align_job_raw(eng, contigs, blob, off, read_ctg), _lib.align_job_raw(eng2, contigs, blob, off, read_ctg)]
-        n_each = max(2, (args.steps + 1) // 2)
+        n_each = max(2, min(4, (args.steps + 1) // 2))
         err = []
 
         def lane(li, n, tag):
