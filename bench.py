@@ -143,8 +143,8 @@ def cpu_baseline(contigs, blob, off, read_ctg, ids, eng, n_sample_ctg):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--contigs", type=int, default=20, help="contigs per GPU (weak scaling) or in total (--strong)")
     ap.add_argument("--contig-len", type=int, default=5_000_000)
     ap.add_argument("--reads-per-contig", type=int, default=2000)
