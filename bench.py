@@ -233,7 +233,8 @@ def main():
     if out_root is None:
         raise SystemExit("bench.py: no writable scratch directory for the output trees")
     t_up = time.perf_counter()
-    job = _lib.align_job_raw(eng, contigs, blob, off, read_ctg)     # upload + 2-bit pack: inputs now resident in HBM
+    # (a rank whose shard is empty -- --strong with fewer contigs than ranks -- has no job; it still takes part in every collective)
+    job = _lib.align_job_raw(eng, contigs, blob, off, read_ctg) if mine else None     # upload + 2-bit pack: inputs now resident in HBM
     eng.synchronize()
     upload_ms = (time.perf_counter() - t_up) * 1e3                  # PCIe + packing, outside the timed region
 
@@ -255,7 +256,10 @@ def main():
         step_no[0] += 1
         out_dir = os.path.join(out_root, "step%03d" % step_no[0])      # a fresh tree per step, as a job would write it (no re-truncation of old files)
         t_a = time.perf_counter()
-        st, recs = job.phase_write(ids, names=name_tab, out_dir=out_dir, read_maps=maps, ctg_index=mine, consensus=args.with_consensus, async_writes=True)
+        if job is not None:
+            st, recs = job.phase_write(ids, names=name_tab, out_dir=out_dir, read_maps=maps, ctg_index=mine, consensus=args.with_consensus, async_writes=True)
+        else:
+            st, recs = {k: 0 for k in ("n_aligned", "n_rec", "n_sites", "n_rows", "n_arows", "n_pvars", "n_preads", "bytes_written", "ms_k1", "ms_phase", "ms_results", "ms_text")}, np.zeros(0, _lib.R2P)
         recs["arid"] += arid_base                      # the read_map files of a rank number its preads from 0: make the ids job-wide
         t_b = time.perf_counter()
         allr = comm.allgather_r2p(recs) if comm is not None else fdist.allgather_r2p(recs, device=coll_dev if world > 1 else None)
@@ -297,14 +301,15 @@ def main():
     else:
         rank_load = [{"rank": 0, "reads": n_reads, "ms_per_step": round(dt / args.steps * 1e3, 3)}]
 
-    summ = job.summaries()
+    summ = job.summaries() if job is not None else np.zeros(0, dtype=[("cells", "<i8"), ("aligned", "<i4")])
     cells_per_step = float(summ["cells"].sum())
     sw_ms, sw_launches = prof.get("k1_sw", (0.0, 0))
     sw_avg_ms = sw_ms / max(1, sw_launches)
     cells_per_launch = cells_per_step * args.steps / max(1, sw_launches)
     dp_gcells = cells_per_launch / (sw_avg_ms * 1e-3) / 1e9 if sw_avg_ms > 0 else 0.0
     aligned_frac = float(summ["aligned"].mean()) if n_reads else 0.0
-    job.close()
+    if job is not None:
+        job.close()
 
     e2e = None
     if rank == 0 and world == 1 and not args.no_end_to_end:

@@ -55,3 +55,17 @@ def test_strong_scaling_mode_two_ranks():
     loads = [r["reads"] for r in d["rank_load"]]
     assert sum(loads) == d["config"]["reads_total"] == d["stage_counts"]["r2p_records"] and min(loads) > 0
     assert abs(loads[0] - loads[1]) <= 0.4 * sum(loads)
+
+
+def test_strong_mode_with_an_empty_shard():
+    """fewer contigs than ranks: the rank without a contig has no job but still takes part in every collective"""
+    import subprocess
+    env = dict(os.environ, FZP_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    args = ["--strong", "--contigs", "1", "--contig-len", "300000", "--reads-per-contig", "100", "--read-len", "8000", "--window", "120000", "--steps", "1", "--warmup", "1",
+            "--no-cpu-baseline", "--gen-workers", "1"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29747",
+           os.path.join(REPO, "bench.py"), "--gpus", "2"] + args
+    out = subprocess.check_output(cmd, env=env, cwd=REPO, stderr=subprocess.DEVNULL, timeout=600).decode()
+    d = json.loads([l for l in out.splitlines() if l.startswith("{")][0])
+    loads = sorted(r["reads"] for r in d["rank_load"])
+    assert loads[0] == 0 and loads[1] == d["config"]["reads_total"] == d["stage_counts"]["r2p_records"] > 0
