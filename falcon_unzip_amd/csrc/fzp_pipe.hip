@@ -78,11 +78,68 @@ struct FileWriter {
         for (auto &t : th) t.join();
     }
 };
+// The per-contig host work of a call (small texts, read map) runs on threads that live as long as the context: spawning twenty threads per
+// call costs about as much as the work they do.  run(n, fn): fn(worker, task) for every task in [0, n), the caller's thread included; returns
+// when all are done.  One run at a time per pool (a context is used by one host thread).
+struct WorkPool {
+    std::mutex mu;
+    std::condition_variable cv, done_cv;
+    std::vector<std::thread> th;
+    const std::function<void(int, int)> *fn = nullptr;
+    std::atomic<int> next{0};
+    int n = 0, active = 0;
+    uint64_t gen = 0;
+    bool stop = false;
+    int size() const { return (int)th.size() + 1; }
+    void start(int workers) {
+        for (int i = 0; i < workers; i++)
+            th.emplace_back([this, i] {
+                uint64_t seen = 0;
+                for (;;) {
+                    const std::function<void(int, int)> *f;
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv.wait(lk, [&] { return stop || gen != seen; });
+                        if (stop) return;
+                        seen = gen;
+                        f = fn;
+                        if (!f) continue;
+                        active++;
+                    }
+                    for (int t; (t = next.fetch_add(1)) < n;) (*f)(i + 1, t);
+                    {
+                        std::lock_guard<std::mutex> lk(mu);
+                        if (--active == 0) done_cv.notify_all();
+                    }
+                }
+            });
+    }
+    void run(int n_tasks, const std::function<void(int, int)> &f) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            fn = &f; n = n_tasks; next.store(0); gen++;
+        }
+        cv.notify_all();
+        for (int t; (t = next.fetch_add(1)) < n_tasks;) f(0, t);
+        std::unique_lock<std::mutex> lk(mu);
+        fn = nullptr;                                        // a worker that wakes up late finds nothing to do
+        done_cv.wait(lk, [&] { return active == 0; });
+    }
+    ~WorkPool() {
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cv.notify_all();
+        for (auto &t : th) t.join();
+    }
+};
 void fzp_writer_destroy(fzp_ctx *ctx) {
-    if (!ctx || !ctx->writer) return;
-    (void)ctx->writer->drain();
-    delete ctx->writer;
-    ctx->writer = nullptr;
+    if (!ctx) return;
+    if (ctx->writer) {
+        (void)ctx->writer->drain();
+        delete ctx->writer;
+        ctx->writer = nullptr;
+    }
+    delete ctx->workers;
+    ctx->workers = nullptr;
 }
 
 namespace {
@@ -192,6 +249,7 @@ int readmap_apply(const ReadMaps &m, const char *ctg_id, int32_t ctg_index, cons
                   std::vector<fzp_r2p> &recs, std::string &text, std::string &err) {
     if (m.short_row) { err = "pread_to_contigs: short row"; return FZP_EINVAL; }
     std::unordered_map<std::string, std::pair<int, int>> rid_to_phase;    // lines 29-33, last line wins
+    rid_to_phase.reserve((size_t)n_pr * 2 + 16);
     for (int64_t i = 0; i < n_pr; i++) {
         const int32_t q = pr[i].q_id;
         rid_to_phase[qnames.substr((size_t)qoff[(size_t)q], (size_t)(qoff[(size_t)q + 1] - qoff[(size_t)q]))] = {pr[i].block, pr[i].phase};
@@ -208,6 +266,8 @@ int readmap_apply(const ReadMaps &m, const char *ctg_id, int32_t ctg_index, cons
         for (size_t r = 0; r < m.rows[ni].size(); r++) order.push_back({m.rows[ni][r].pid.s, {ni, r}});
     }
     std::sort(order.begin(), order.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+    at.reserve(order.size() * 2 + 16);
+    out.reserve(order.size());
     for (auto &o : order) {
         const ReadMaps::Row &row = m.rows[o.second.name][o.second.row];
         long long rank, pid;
@@ -290,6 +350,7 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
                            std::vector<fzp_r2p> &r2p) {
     FZP_TRY(fzp_bind(ctx));
     auto t0 = clk::now();
+    const auto t_body = t0;
     FZP_TRY(fzp_align_run(ctx, job));
     fzp_batch *b = nullptr;
     FZP_TRY(fzp_align_to_batch(ctx, job, &b));
@@ -350,18 +411,21 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
     static const bool timing = getenv("FZP_PIPE_TIMING") != nullptr;
     std::atomic<int64_t> us_names{0}, us_fmt{0}, us_map{0}, us_write{0};
     // ---- per contig: the small files on host threads, all files written
-    int T = o->n_threads > 0 ? o->n_threads : (int)std::max(1u, std::thread::hardware_concurrency());
-    T = std::min(T, std::max(1, nc));
-    std::atomic<int> next{0};
+    int T = o->n_threads > 0 ? o->n_threads : (int)std::min(64u, std::max(1u, std::thread::hardware_concurrency()));
+    if (!ctx->workers || ctx->workers->size() < std::min(T, nc)) {        // grown on demand, kept for the next call
+        delete ctx->workers;
+        ctx->workers = new WorkPool();
+        ctx->workers->start(std::max(0, std::min(T, std::max(nc, 8)) - 1));
+    }
+    T = ctx->workers->size();
     std::atomic<int64_t> bytes{0};
     std::vector<int> rcs((size_t)T, FZP_OK);
     std::vector<std::string> errs((size_t)T);
     std::vector<std::vector<fzp_r2p>> recs((size_t)nc);
     const std::string out_dir = o->out_dir ? o->out_dir : "";
-    auto work = [&](int t) {
-        for (;;) {
-            const int c = next.fetch_add(1);
-            if (c >= nc || rcs[(size_t)t] != FZP_OK) break;
+    const std::function<void(int, int)> work = [&](int t, int c) {
+        {
+            if (rcs[(size_t)t] != FZP_OK) return;
             const char *ctg = nm->ctg_id[c];
             auto tq = clk::now();
             // q_id table of the contig: aligned reads in (POS, read) order
@@ -434,12 +498,7 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
             if (rc != FZP_OK) rcs[(size_t)t] = rc;
         }
     };
-    {
-        std::vector<std::thread> th;
-        for (int t = 1; t < T; t++) th.emplace_back(work, t);
-        work(0);
-        for (auto &x : th) x.join();
-    }
+    ctx->workers->run(nc, work);
     for (int t = 0; t < T; t++) if (rcs[(size_t)t] != FZP_OK) { fzp_set_error("%s", errs[(size_t)t].c_str()); return rcs[(size_t)t]; }
     for (int c = 0; c < nc; c++) r2p.insert(r2p.end(), recs[(size_t)c].begin(), recs[(size_t)c].end());
     out->ms_text += ms_since(t0);
@@ -449,6 +508,7 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
     out->n_groups += 1;
     out->n_rec += b->n_rec; out->n_sites += b->n_sites; out->n_rows += b->n_rows; out->n_arows += b->n_arows; out->n_pvars += b->n_pvars; out->n_preads += b->n_preads;
     out->n_aligned += b->n_qid;
+    if (timing) fprintf(stderr, "[fzp_pipe] body done at %.2f ms\n", ms_since(t_body));
     return FZP_OK;
 }
 
@@ -457,10 +517,13 @@ extern "C" int fzp_job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_name
     fzp_pipe_opts o;
     if (opts) o = *opts; else fzp_pipe_opts_default(&o);
     memset(out, 0, sizeof *out);
+    const auto t_call = clk::now();
     MapsHolder mh;
     mh.start(&o);
     std::vector<fzp_r2p> r2p;
     FZP_TRY(job_phase_write(ctx, job, nm, &o, mh, o.ctg_index, out, r2p));
+    if (getenv("FZP_PIPE_TIMING")) fprintf(stderr, "[fzp_job_phase_write] %.2f ms in the call: k1 %.2f phase %.2f results %.2f text %.2f\n", ms_since(t_call), out->ms_k1, out->ms_phase,
+                                           out->ms_results, out->ms_text);
     out->n_r2p = (int64_t)r2p.size();
     out->r2p = (fzp_r2p *)malloc((r2p.size() ? r2p.size() : 1) * sizeof(fzp_r2p));
     if (!out->r2p) return FZP_ENOMEM;
