@@ -91,9 +91,10 @@ struct WorkPool {
     uint64_t gen = 0;
     bool stop = false;
     int size() const { return (int)th.size() + 1; }
-    void start(int workers) {
+    void start(int workers, int device) {
         for (int i = 0; i < workers; i++)
-            th.emplace_back([this, i] {
+            th.emplace_back([this, i, device] {
+                (void)hipSetDevice(device);                  // the tasks wait on events of the context's device
                 uint64_t seen = 0;
                 for (;;) {
                     const std::function<void(int, int)> *f;
@@ -394,12 +395,12 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
     struct Ev { hipEvent_t e = nullptr; ~Ev() { if (e) (void)hipEventDestroy(e); } } ev_q, ev_t;
     FZP_HIP(hipEventCreateWithFlags(&ev_q.e, hipEventDisableTiming));
     FZP_HIP(hipEventCreateWithFlags(&ev_t.e, hipEventDisableTiming));
+    struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamSynchronize(s); } } sg2{st2};     // nothing below may leave while copies into `pin` are in flight
     if (n_slots) FZP_HIP(hipMemcpyAsync(pin + o_qr, b->qid_read.p, (size_t)n_slots * 4, hipMemcpyDeviceToHost, st2));
     FZP_HIP(hipEventRecord(ev_q.e, st2));
     if (n_vmap) FZP_HIP(hipMemcpyAsync(pin, d_vmap.p, n_vmap, hipMemcpyDeviceToHost, st2));
     if (n_atab) FZP_HIP(hipMemcpyAsync(pin + o_atab, d_atab.p, n_atab, hipMemcpyDeviceToHost, st2));
     FZP_HIP(hipEventRecord(ev_t.e, st2));
-    struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamSynchronize(s); } } sg2{st2};     // nothing below may leave while copies into `pin` are in flight
     fzp_result_all ra;
     FZP_TRY(fzp_batch_result_all(ctx, b, &ra));                  // sites / variant_map ids / atable rows are not needed on the host here, but the views are free
     struct RG { fzp_result_all *r; ~RG() { fzp_result_all_free(r); } } rg{&ra};
@@ -415,7 +416,7 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
     if (!ctx->workers || ctx->workers->size() < std::min(T, nc)) {        // grown on demand, kept for the next call
         delete ctx->workers;
         ctx->workers = new WorkPool();
-        ctx->workers->start(std::max(0, std::min(T, std::max(nc, 8)) - 1));
+        ctx->workers->start(std::max(0, std::min(T, std::max(nc, 8)) - 1), ctx->device);
     }
     T = ctx->workers->size();
     std::atomic<int64_t> bytes{0};
@@ -664,9 +665,9 @@ extern "C" int fzp_phase_contigs(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *con
     }
     const double ms_lanes = ms_since(t_call);
     (void)fzp_bind(ctx);
-    const int frc = fzp_pipe_flush(ctx);
+    const int frc = fzp_pipe_flush(ctx);                    // FZP_PIPE_ASYNC_WRITES: the groups' files overlapped other groups' kernels; all are down now
     if (timing) fprintf(stderr, "[fzp_phase_contigs] read maps started by %.2f ms, grouping until %.2f, lanes until %.2f, flush until %.2f (%d lanes, %zu groups)\n", ms_maps, ms_prep, ms_lanes,
-                        ms_since(t_call), lanes, groups.size());                    // FZP_PIPE_ASYNC_WRITES: the groups' files overlapped other groups' kernels; all are down now
+                        ms_since(t_call), lanes, groups.size());
     for (int li = 0; li < lanes; li++) if (rcs[(size_t)li] != FZP_OK) { fzp_set_error("%s", errs[(size_t)li].c_str()); return rcs[(size_t)li]; }
     if (frc != FZP_OK) return frc;
     for (int li = 0; li < lanes; li++) add(out, outs[(size_t)li]);
