@@ -797,18 +797,19 @@ class OvlSet:
     def __init__(self, eng, files, rid_map: bytes):
         lib = load()
         n = len(files)
-        self._keep = [C.create_string_buffer(f, len(f)) if len(f) else C.create_string_buffer(1) for f in files]
-        texts = (C.c_char_p * max(1, n))(*[C.cast(b, C.c_char_p) for b in self._keep])
-        lens = (C.c_size_t * max(1, n))(*[len(f) for f in files])
+        # the library BORROWS the dumps (no copy on either side): they stay referenced here until the set is closed
+        self._keep = [f if isinstance(f, bytes) else bytes(f) for f in files]
+        texts = (C.c_char_p * max(1, n))(*self._keep)
+        lens = (C.c_size_t * max(1, n))(*[len(f) for f in self._keep])
         p = C.c_void_p()
         _check(lib.fzp_ovl_parse(eng._p, n, texts, lens, rid_map, len(rid_map), C.byref(p)))
         self._p = p.value
-        self._keep = None            # the library copied the texts
 
     def close(self):
         if getattr(self, "_p", None):
             load().fzp_ovlset_free(self._p)
             self._p = None
+        self._keep = None
 
     __del__ = close
 
@@ -842,8 +843,8 @@ def ovl_filter(eng, ovl: OvlSet, max_diff, max_cov, min_cov, min_len=2500, bestn
 def track_reads(eng, files, phased_reads: bytes, read_to_contig_map: bytes, rawread_ids: bytes, min_len=2500, bestn=40):
     """rr_hctg_track.py's run_track_reads on the device -> the rawread_to_contigs text (canonical line order)."""
     n = len(files)
-    keep = [C.create_string_buffer(f, len(f)) if len(f) else C.create_string_buffer(1) for f in files]
-    texts = (C.c_char_p * max(1, n))(*[C.cast(b, C.c_char_p) for b in keep])
-    lens = (C.c_size_t * max(1, n))(*[len(f) for f in files])
+    keep = [f if isinstance(f, bytes) else bytes(f) for f in files]          # lent for the duration of the call
+    texts = (C.c_char_p * max(1, n))(*keep)
+    lens = (C.c_size_t * max(1, n))(*[len(f) for f in keep])
     return _fmt("fzp_track_reads", eng._p, C.c_int32(n), texts, lens, phased_reads, C.c_size_t(len(phased_reads)), read_to_contig_map,
                 C.c_size_t(len(read_to_contig_map)), rawread_ids, C.c_size_t(len(rawread_ids)), C.c_int64(int(min_len)), C.c_int64(int(bestn)))

@@ -22,6 +22,7 @@
 // HBM-bound byte / integer scans: the text once (1 B per byte), 42 B per line of columns, 8 B per selected line out; groups are small (tens to hundreds of rows), so
 // the all-pairs ranking inside a group is cheap and needs no global sort.
 #include <algorithm>
+#include <thread>
 #include <string_view>
 #include <unordered_map>
 #include "fzp_common.h"
@@ -76,28 +77,61 @@ constexpr int MAXTOK = 64;
 constexpr uint8_t F_PARSE_OK = 1, F_IDT_OK = 2, F_CONTAINS = 4, F_CONTAINED = 8;
 }  // namespace
 
-// host copy of the dumps (the formatter and the tie fix-up read lines back from it).  Plain pageable memory: pinning
-// ~100 MB per call costs more (tens of ms) than the staged upload it would save.
+// The dumps on the host, as the formatter, the tie fix-up and the fallback tokeniser read them back: one "text" made of the caller's
+// buffers laid end to end, each ending with '\n'.  The buffers are BORROWED (they stay valid until the set is freed: include/fzphase.h);
+// only a dump that lacks its final newline is copied (with one).  Offsets are global; base(off) gives a pointer p such that p + o is the
+// byte at global offset o for every o inside the segment that holds `off` (a line never spans segments).  materialise() makes the one
+// contiguous copy the host tokeniser wants.
 struct HostText {
-    char *p = nullptr;
-    size_t n = 0, cap = 0;
-    bool pinned = false;
-    ~HostText() { if (p) { if (pinned) (void)hipHostFree(p); else free(p); } }
-    bool reserve(size_t c) {
-        p = (char *)malloc(c ? c : 1);
-        cap = c;
-        return p != nullptr;
+    std::vector<const char *> seg;
+    std::vector<int64_t> beg;               // [n_seg + 1] global offset of every segment, then the total
+    std::vector<char *> owned;              // segments that had to be copied
+    char *whole = nullptr;                  // contiguous copy (materialise)
+    HostText() { beg.push_back(0); }
+    ~HostText() { for (auto q : owned) free(q); free(whole); }
+    bool add(const char *s, size_t k) {     // one dump
+        if (k && s[k - 1] != '\n') {
+            char *c = (char *)malloc(k + 1);
+            if (!c) return false;
+            memcpy(c, s, k); c[k] = '\n';
+            owned.push_back(c);
+            s = c; k++;
+        }
+        seg.push_back(s);
+        beg.push_back(beg.back() + (int64_t)k);
+        return true;
     }
-    void append(const char *s, size_t k) { memcpy(p + n, s, k); n += k; }
-    void push_back(char c) { p[n++] = c; }
-    const char *data() const { return p; }
-    size_t size() const { return n; }
-    char back() const { return p[n - 1]; }
+    size_t size() const { return (size_t)beg.back(); }
+    const char *base(int64_t off) const {
+        if (whole) return whole;
+        size_t k = (size_t)(std::upper_bound(beg.begin(), beg.end(), off) - beg.begin());
+        k = k ? k - 1 : 0;
+        if (k >= seg.size()) k = seg.size() - 1;
+        return seg[k] - beg[k];
+    }
+    bool materialise() {
+        if (whole) return true;
+        whole = (char *)malloc(size() + 16);
+        if (!whole) return false;
+        for (size_t k = 0; k < seg.size(); k++) memcpy(whole + beg[k], seg[k], (size_t)(beg[k + 1] - beg[k]));
+        return true;
+    }
+    const char *data() const { return whole; }    // after materialise()
 };
+// all segments into one device buffer (16-byte padded, the pad zeroed)
+static int upload_text(const HostText &t, DevBuf<uint8_t> &d_text, hipStream_t st) {
+    const int64_t n16 = ((int64_t)t.size() + 15) / 16;
+    if (n16 <= 0) return FZP_OK;
+    FZP_TRY(d_text.alloc((size_t)n16 * 16));
+    FZP_HIP(hipMemsetAsync(d_text.p + (n16 - 1) * 16, 0, 16, st));
+    for (size_t k = 0; k < t.seg.size(); k++)
+        if (t.beg[k + 1] > t.beg[k]) FZP_HIP(hipMemcpyAsync(d_text.p + t.beg[k], t.seg[k], (size_t)(t.beg[k + 1] - t.beg[k]), hipMemcpyHostToDevice, st));
+    return FZP_OK;
+}
 
 struct fzp_ovlset {
     int device = 0;
-    HostText text;                          // all dumps, each ending with '\n'
+    HostText text;                          // all dumps, each ending with '\n' (borrowed from the caller)
     std::vector<int64_t> file_end;          // end offset of every dump inside `text`
     std::vector<int64_t> line_off;          // [n_lines + 1]
     std::string map_text;
@@ -131,7 +165,7 @@ namespace {
 // the formatter
 struct HostLine { int nt; int32_t q, t; int64_t v[7]; uint8_t flags; };
 bool host_line(const fzp_ovlset *s, int64_t line, HostLine *o, Tok *toks /* [MAXTOK] */) {
-    const char *tx = s->text.data();
+    const char *tx = s->text.base(s->line_off[(size_t)line]);
     const int nt = split_line(tx, s->line_off[(size_t)line], s->line_off[(size_t)line + 1], toks, MAXTOK);
     o->nt = nt; o->q = o->t = -1; o->flags = 0;
     for (int c = 0; c < 7; c++) o->v[c] = 0;
@@ -174,26 +208,16 @@ extern "C" int fzp_ovl_parse(fzp_ctx *ctx, int32_t n_files, const char *const *t
     FZP_TRY(fzp_bind(ctx));
     fzp_ovlset *s = new fzp_ovlset();
     s->device = ctx->device;
-    // ---- the dumps: one buffer, every dump ending with '\n'
-    size_t total = 0;
-    for (int k = 0; k < n_files; k++) total += lens[k] + 1;
-    if (!s->text.reserve(total + 16)) { delete s; fzp_set_error("fzp_ovl_parse: host allocation of %zu bytes failed", total + 16); return FZP_ENOMEM; }
+    // ---- the dumps: the caller's buffers, end to end, every dump ending with '\n'
     for (int k = 0; k < n_files; k++) {
-        if (lens[k]) s->text.append(texts[k], lens[k]);
-        if (lens[k] && s->text.back() != '\n') s->text.push_back('\n');
+        if (!s->text.add(texts[k], lens[k])) { delete s; fzp_set_error("fzp_ovl_parse: host allocation failed"); return FZP_ENOMEM; }
         s->file_end.push_back((int64_t)s->text.size());
     }
     if (s->text.size() >= (1ull << 32)) { fzp_set_error("fzp_ovl_parse: %zu bytes of text (limit 4 GiB per call; split the fofn)", s->text.size()); delete s; return FZP_EINVAL; }
     // the text starts its way to HBM now; the map is read while the DMA runs
     hipStream_t st = ctx->stream;
     DevBuf<uint8_t> d_text;
-    const int64_t n16 = ((int64_t)s->text.size() + 15) / 16;
-    if (n16 > 0) {
-        int rc0 = d_text.alloc((size_t)n16 * 16);
-        if (rc0) { delete s; return rc0; }
-        if (hipMemsetAsync(d_text.p + (n16 - 1) * 16, 0, 16, st) != hipSuccess ||
-            hipMemcpyAsync(d_text.p, s->text.data(), s->text.size(), hipMemcpyHostToDevice, st) != hipSuccess) { delete s; fzp_set_error("text upload failed"); return FZP_EDEVICE; }
-    }
+    { const int rc0 = upload_text(s->text, d_text, st); if (rc0) { delete s; return rc0; } }
     // ---- rid_to_phase.all (:306-309)
     s->map_text.assign(rid_map ? rid_map : "", map_len);
     std::unordered_map<std::string_view, int32_t> strs;
@@ -481,6 +505,7 @@ int ovl_tokenise_device(fzp_ctx *ctx, fzp_ovlset *s, int64_t max_id, const std::
 
 int ovl_tokenise_host(fzp_ctx *ctx, fzp_ovlset *s) {
     hipStream_t st = ctx->stream;
+    if (!s->text.materialise()) { fzp_set_error("fzp_ovl_parse: host allocation failed"); return FZP_ENOMEM; }
     const char *tx = s->text.data();
     const int64_t n = (int64_t)s->text.size();
     s->line_off.assign(1, 0);
@@ -744,7 +769,6 @@ extern "C" int fzp_ovl_filter(fzp_ctx *ctx, const fzp_ovlset *s, const fzp_ovlp_
     }
     // ---- lists that tie on (numeric key, partner): the reference falls through to comparing the token lists (:218-219)
     if (!h_P.empty()) {
-        const char *tx = s->text.data();
         Tok toks[MAXTOK];
         auto cand = [&](int32_t i, HostLine *hl) -> int {
             host_line(s, i, hl, toks);
@@ -774,10 +798,11 @@ extern "C" int fzp_ovl_filter(fzp_ctx *ctx, const fzp_ovlset *s, const fzp_ovlp_
                     if (a.m_range != b.m_range) return a.m_range < b.m_range;
                     Tok ta[MAXTOK], tb[MAXTOK];
                     const int64_t la = a.row, lb = b.row;
-                    const int na_ = split_line(tx, s->line_off[(size_t)la], s->line_off[(size_t)la + 1], ta, MAXTOK);
-                    const int nb_ = split_line(tx, s->line_off[(size_t)lb], s->line_off[(size_t)lb + 1], tb, MAXTOK);
+                    const char *txa = s->text.base(s->line_off[(size_t)la]), *txb = s->text.base(s->line_off[(size_t)lb]);
+                    const int na_ = split_line(txa, s->line_off[(size_t)la], s->line_off[(size_t)la + 1], ta, MAXTOK);
+                    const int nb_ = split_line(txb, s->line_off[(size_t)lb], s->line_off[(size_t)lb + 1], tb, MAXTOK);
                     for (int z = 0; z < std::min(na_, nb_); z++) {
-                        const std::string_view x(tx + ta[z].off, (size_t)ta[z].len), y(tx + tb[z].off, (size_t)tb[z].len);
+                        const std::string_view x(txa + ta[z].off, (size_t)ta[z].len), y(txb + tb[z].off, (size_t)tb[z].len);
                         if (x != y) return x < y;
                     }
                     return na_ < nb_;
@@ -810,29 +835,54 @@ extern "C" int fzp_ovl_filter(fzp_ctx *ctx, const fzp_ovlset *s, const fzp_ovlp_
 
 extern "C" int fzp_ovl_format(const fzp_ovlset *s, const int64_t *rows, int64_t n_rows, char **text, size_t *len) {
     if (!s || (!rows && n_rows) || !text || !len || n_rows < 0) { fzp_set_error("fzp_ovl_format: bad arguments"); return FZP_EINVAL; }
-    std::string out;
-    const char *tx = s->text.data(), *mt = s->map_text.data();
-    Tok t[MAXTOK];
-    for (int64_t z = 0; z < n_rows; z++) {
-        const int64_t line = rows[z];
-        HostLine hl;
-        if (line < 0 || line >= s->n_lines || !host_line(s, line, &hl, t) || hl.q < 0 || hl.t < 0) { fzp_set_error("fzp_ovl_format: line %lld is not a filterable row", (long long)line); return FZP_EINVAL; }
-        for (int k = 0; k < hl.nt && k < MAXTOK; k++) { if (k) out.push_back(' '); out.append(tx + t[k].off, (size_t)t[k].len); }
-        const int32_t ids[2] = {hl.q, hl.t};
-        for (int k = 0; k < 2; k++) {
-            const size_t a = (size_t)ids[k];
-            out.push_back(' ');
-            out.append(mt + s->ctg[a].off, (size_t)s->ctg[a].len); out.push_back('.');
-            out.append(mt + s->blk[a].off, (size_t)s->blk[a].len); out.push_back('.');
-            out.append(mt + s->ph[a].off, (size_t)s->ph[a].len);
+    // the selected lines, re-split (tokens joined by single spaces, :277) with the two phase tags appended; chunks of rows on host threads
+    const char *mt = s->map_text.data();
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)16, (int64_t)std::max(1u, std::thread::hardware_concurrency()), n_rows / 2048 + 1}));
+    std::vector<std::string> part((size_t)T);
+    std::vector<int64_t> bad((size_t)T, -1);
+    auto work = [&](int w) {
+        const int64_t z0 = n_rows * w / T, z1 = n_rows * (w + 1) / T;
+        std::string &out = part[(size_t)w];
+        out.reserve((size_t)(z1 - z0) * 96);
+        Tok t[MAXTOK];
+        for (int64_t z = z0; z < z1; z++) {
+            const int64_t line = rows[z];
+            if (line < 0 || line >= s->n_lines) { bad[(size_t)w] = line; return; }
+            const char *tx = s->text.base(s->line_off[(size_t)line]);
+            const int nt = split_line(tx, s->line_off[(size_t)line], s->line_off[(size_t)line + 1], t, MAXTOK);
+            int32_t ids[2] = {-1, -1};
+            if (nt >= 2)
+                for (int k = 0; k < 2; k++) {
+                    auto it = s->ids.find(std::string_view(tx + t[k].off, (size_t)t[k].len));
+                    if (it != s->ids.end()) ids[k] = it->second;
+                }
+            if (ids[0] < 0 || ids[1] < 0) { bad[(size_t)w] = line; return; }
+            for (int k = 0; k < nt && k < MAXTOK; k++) { if (k) out.push_back(' '); out.append(tx + t[k].off, (size_t)t[k].len); }
+            for (int k = 0; k < 2; k++) {
+                const size_t a = (size_t)ids[k];
+                out.push_back(' ');
+                out.append(mt + s->ctg[a].off, (size_t)s->ctg[a].len); out.push_back('.');
+                out.append(mt + s->blk[a].off, (size_t)s->blk[a].len); out.push_back('.');
+                out.append(mt + s->ph[a].off, (size_t)s->ph[a].len);
+            }
+            out.push_back('\n');
         }
-        out.push_back('\n');
+    };
+    {
+        std::vector<std::thread> th;
+        for (int w = 1; w < T; w++) th.emplace_back(work, w);
+        work(0);
+        for (auto &x : th) x.join();
     }
-    char *p = (char *)malloc(out.size() + 1);
+    for (int w = 0; w < T; w++) if (bad[(size_t)w] != -1) { fzp_set_error("fzp_ovl_format: line %lld is not a filterable row", (long long)bad[(size_t)w]); return FZP_EINVAL; }
+    size_t total = 0;
+    for (auto &q : part) total += q.size();
+    char *p = (char *)malloc(total + 1);
     if (!p) return FZP_ENOMEM;
-    memcpy(p, out.data(), out.size());
-    p[out.size()] = 0;
-    *text = p; *len = out.size();
+    size_t at = 0;
+    for (auto &q : part) { memcpy(p + at, q.data(), q.size()); at += q.size(); }
+    p[total] = 0;
+    *text = p; *len = total;
     return FZP_OK;
 }
 
@@ -1057,22 +1107,15 @@ extern "C" int fzp_track_reads(fzp_ctx *ctx, int32_t n_files, const char *const 
     fzp_ovlset *s = new fzp_ovlset();
     struct Guard { fzp_ovlset *p; ~Guard() { delete p; } } guard{s};
     s->device = ctx->device;
-    size_t total = 0;
-    for (int k = 0; k < n_files; k++) total += lens[k] + 1;
-    if (!s->text.reserve(total + 16)) { fzp_set_error("fzp_track_reads: host allocation failed"); return FZP_ENOMEM; }
     for (int k = 0; k < n_files; k++) {
-        if (lens[k]) s->text.append(texts[k], lens[k]);
-        if (lens[k] && s->text.back() != '\n') s->text.push_back('\n');
+        if (!s->text.add(texts[k], lens[k])) { fzp_set_error("fzp_track_reads: host allocation failed"); return FZP_ENOMEM; }
         s->file_end.push_back((int64_t)s->text.size());
     }
     if (s->text.size() >= (1ull << 32)) { fzp_set_error("fzp_track_reads: %zu bytes of text (limit 4 GiB per call)", s->text.size()); return FZP_EINVAL; }
     std::vector<TrkRow> h_rows;
     if (s->text.size() > 0) {
         DevBuf<uint8_t> d_text;
-        const int64_t n16 = ((int64_t)s->text.size() + 15) / 16;
-        FZP_TRY(d_text.alloc((size_t)n16 * 16));
-        FZP_HIP(hipMemsetAsync(d_text.p + (n16 - 1) * 16, 0, 16, st));
-        FZP_HIP(hipMemcpyAsync(d_text.p, s->text.data(), s->text.size(), hipMemcpyHostToDevice, st));
+        FZP_TRY(upload_text(s->text, d_text, st));
         FZP_TRY(ovl_tokenise_device(ctx, s, 0, std::vector<int32_t>(), d_text));
         const int64_t n = s->n_lines;
         DevBuf<int32_t> d_rid_of, d_rc_ctg, d_ctg_lex, d_blist, e1, e2, e3;

@@ -383,8 +383,9 @@ typedef struct {
 typedef struct fzp_ovlset fzp_ovlset;
 /* Tokenise the dumps of n_files .las files (in fofn order) -- on the device: the text goes to HBM once and one thread
  * per line does str.split(), the id look-ups and int()/float() -- and read the rid_to_phase.all map (main :306-309:
- * later rows overwrite earlier ones; ids, contigs, blocks and phases are compared as strings).  The texts are copied;
- * the parsed columns stay resident in HBM inside the ovlset.  At most 4 GiB of text / 2^31 lines per call.
+ * later rows overwrite earlier ones; ids, contigs, blocks and phases are compared as strings).  The texts are BORROWED:
+ * `texts[k]` must stay valid and unchanged until fzp_ovlset_free (fzp_ovl_filter and fzp_ovl_format read lines back from them; only a dump
+ * without its final newline is copied); rid_map is copied.  The parsed columns stay resident in HBM inside the ovlset.  At most 4 GiB of text / 2^31 lines per call.
  * FZP_EINVAL where the reference would raise while reading (a line with fewer than 2 tokens, a map row with fewer
  * than 4). */
 int fzp_ovl_parse(fzp_ctx *ctx, int32_t n_files, const char *const *texts, const size_t *lens, const char *rid_map,
