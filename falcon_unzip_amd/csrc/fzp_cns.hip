@@ -5,7 +5,7 @@
 // is this repo's own definition; the records, phases and blocks it consumes are the K1..K5 results already in HBM.
 //   k_cns_extent   block spans [min site, max site] from K4's per-site block ids
 //   k_cns_nrec     records per (block, phase) pile
-//   k_cns_tiles    a workgroup owns 512 consecutive positions of one block: both phases' counters (10 x u32 per
+//   k_cns_tiles    a workgroup owns 448 consecutive positions of one block: both phases' counters (10 x u32 per
 //                  position and phase) live in LDS, its waves walk the records that overlap the tile -- phase looked
 //                  up in K5's rows, CIGAR resumed at K2's 64-op checkpoint before the tile, columns dealt 64 at a time
 //                  by the shared expander, D / I ops one per lane -- and the tile is written once, coalesced
@@ -70,13 +70,20 @@ __global__ void __launch_bounds__(256) k_cns_nrec(CnsView v, uint32_t *__restric
 struct LongIns { int64_t slot, qidx; uint32_t n, alive; };      // an I op of >= 2 bases: counter slot of the position it follows, its first base in seq
 constexpr int INS_MAX = 8;                                       // spec: at most 8 inserted bases per position
 
-constexpr int CNS_TILE = 512, CNS_THREADS = 512;
+// 448 positions per tile: 2 x 10 x 448 counters (35 KB) + the expander's windows (8 KB) + the staged list entries (4.5 KB) = 47.5 KB, three
+// workgroups per CU
+constexpr int CNS_TILE = 448, CNS_THREADS = 512, CNS_STAGE = 192;
 __global__ void __launch_bounds__(CNS_THREADS) k_cns_tiles(RecView rv, CnsView v, const int32_t *__restrict__ tile_blk, const int32_t *__restrict__ tile_start,
                                                            const int32_t *__restrict__ blk_ctg, const int64_t *__restrict__ ctg_rec_begin,
                                                            const int32_t *__restrict__ ctg_maxspan, uint32_t *__restrict__ cnt, LongIns *__restrict__ lins,
                                                            unsigned long long *__restrict__ n_lins, unsigned long long lins_cap) {
     __shared__ uint32_t l_cnt[2 * CN * CNS_TILE];      // [phase][counter][position]: consecutive lanes -> distinct banks
     __shared__ __attribute__((aligned(16))) uint32_t l_win[(CNS_THREADS / 64) * EXP_WIN];   // expand_record's window, one per wave
+    // long I ops of this tile are staged here and appended to the global list with ONE atomic per workgroup: an atomic per op on the
+    // list's counter -- 3.5 M of them on one address at cfg2 -- took 6 of this kernel's 8.6 ms
+    __shared__ LongIns l_stage[CNS_STAGE];
+    __shared__ uint32_t l_nstage, l_base_lo, l_base_hi;
+    if (threadIdx.x == 0) l_nstage = 0;
     const int32_t g = tile_blk[blockIdx.x], ts = tile_start[blockIdx.x];
     const int c = blk_ctg[g];
     const int32_t lo = v.lo[g], hi = v.hi[g];
@@ -153,11 +160,14 @@ __global__ void __launch_bounds__(CNS_THREADS) k_cns_tiles(RecView rv, CnsView v
                             const int code = sym_code(rv.seq[qidx]);
                             if (code < 4) atomicAdd(&lc[(6 + code) * CNS_TILE + (p - ts)], 1u);
                             if (n >= 2 && lins) {
-                                const unsigned long long at = atomicAdd(n_lins, 1ull);
-                                if (at < lins_cap) {
-                                    const int64_t len_ = (int64_t)v.hi[g] - v.lo[g] + 1;
-                                    const int64_t room = seq_end - qidx;
-                                    lins[at] = LongIns{2 * v.cnt_off[g] + (int64_t)phu * len_ + (p - v.lo[g]), qidx, (uint32_t)(room < (int64_t)n ? room : (int64_t)n), 0u};
+                                const int64_t len_ = (int64_t)v.hi[g] - v.lo[g] + 1;
+                                const int64_t room = seq_end - qidx;
+                                const LongIns e = LongIns{2 * v.cnt_off[g] + (int64_t)phu * len_ + (p - v.lo[g]), qidx, (uint32_t)(room < (int64_t)n ? room : (int64_t)n), 0u};
+                                const uint32_t k = atomicAdd(&l_nstage, 1u);
+                                if (k < (uint32_t)CNS_STAGE) l_stage[k] = e;
+                                else {                                       // a tile with more than CNS_STAGE of them: straight to the list
+                                    const unsigned long long at = atomicAdd(n_lins, 1ull);
+                                    if (at < lins_cap) lins[at] = e;
                                 }
                             }
                         }
@@ -166,6 +176,15 @@ __global__ void __launch_bounds__(CNS_THREADS) k_cns_tiles(RecView rv, CnsView v
         }
     }
     __syncthreads();
+    if (lins) {
+        const uint32_t ns = min(l_nstage, (uint32_t)CNS_STAGE);
+        if (threadIdx.x == 0 && ns) { const unsigned long long at = atomicAdd(n_lins, (unsigned long long)ns); l_base_lo = (uint32_t)at; l_base_hi = (uint32_t)(at >> 32); }
+        __syncthreads();
+        if (threadIdx.x < ns) {
+            const unsigned long long at = (((unsigned long long)l_base_hi << 32) | l_base_lo) + threadIdx.x;
+            if (at < lins_cap) lins[at] = l_stage[threadIdx.x];
+        }
+    }
     const int64_t len = (int64_t)hi - lo + 1;
     const int np = te - ts;
     for (int ph = 0; ph < 2; ph++) {
