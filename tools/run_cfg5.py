@@ -79,15 +79,21 @@ def run(scale=1.0, lanes=2, workers=8, out_root=None, keep=False, consensus=True
     th = threading.Thread(target=sample, daemon=True)
     th.start()
     out_dir = tempfile.mkdtemp(prefix="fzp_cfg5_", dir=out_root)
-    t1 = time.perf_counter()
-    stats, recs = _lib.phase_contigs(eng, contigs, blob, off, read_ctg, ids, names=name_tab, out_dir=out_dir, read_maps=maps, n_lanes=lanes, consensus=consensus)
-    wall = time.perf_counter() - t1
+    # the first call also fills the contexts' block caches (150 GB of hipMalloc: 0.6 - 1.8 s depending on the box); the second is the job itself
+    walls = []
+    for k in range(2):
+        t1 = time.perf_counter()
+        stats, recs = _lib.phase_contigs(eng, contigs, blob, off, read_ctg, ids, names=name_tab, out_dir=os.path.join(out_dir, "run%d" % k), read_maps=maps, n_lanes=lanes,
+                                         consensus=consensus)
+        walls.append(time.perf_counter() - t1)
+    wall = walls[1]
+    out_dir = os.path.join(out_dir, "run1")
     peak["stop"] = True
     th.join()
     n_files = sum(len(f) for _, _, f in os.walk(out_dir))
     res = {"config": "configs[4] at scale %.2f: %d contigs, %.1f Mb, %d reads x 15 kb (%.2f Gb), 40x; K1..K5 + K6 consensus + all files, fzp_phase_contigs on %d lanes"
                      % (scale, len(contigs), sum(len(c) for c in contigs) / 1e6, len(read_ctg), len(blob) / 1e9, lanes),
-           "wall_s": round(wall, 3), "reads_per_s": round(len(read_ctg) / wall, 1), "input_generation_s": round(t_gen, 1),
+           "wall_s": round(wall, 3), "first_call_wall_s": round(walls[0], 3), "reads_per_s": round(len(read_ctg) / wall, 1), "input_generation_s": round(t_gen, 1),
            "peak_hbm_gb": round(peak["used"] / 2**30, 2), "hbm_total_gb": round(total_mem / 2**30, 1),
            "dp_gcell_per_s_wall": round(stats["dp_cells"] / wall / 1e9, 1), "files_written": n_files, "r2p_records": int(len(recs)),
            "reads_phased": int((recs["block"] != -1).sum()), "stats": {k: (round(v, 2) if isinstance(v, float) else int(v)) for k, v in stats.items()},
@@ -97,7 +103,7 @@ def run(scale=1.0, lanes=2, workers=8, out_root=None, keep=False, consensus=True
     if keep:
         res["out_dir"] = out_dir
     else:
-        shutil.rmtree(out_dir, ignore_errors=True)
+        shutil.rmtree(os.path.dirname(out_dir), ignore_errors=True)
     return res
 
 
