@@ -583,7 +583,8 @@ __device__ __forceinline__ void scalar_store16(void *base, uint32_t byte_off, ui
 //     which makes "best cell of the block, earliest step first" a single v_max per step.  Offsets stay
 //     consistent because every value of a step carries the same one: a gap move costs (gap << 6) + 1 (one step
 //     later), a diagonal move adds (s << 6) - 2 (two steps later); equality tests are unaffected.
-//   * moves are collected in a 32-bit shift register (first step of the block ends up in the highest used bit).
+//   * moves are collected in a 32-bit shift register (first step of the block ends up in the highest used bit); its bit 0 is the block's last
+//     move, so the steps do not keep a "previous move" register up to date (one SALU less per step: the scalar port has no slack).
 // `cnt` enters as (steps - 1) and counts down; the borrow ends the block.
 // No DPP source is written fewer than two instructions before it is read (gfx9 DPP hazard).
 #define SWB_DPP_SHL " wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0"
@@ -603,7 +604,6 @@ __device__ __forceinline__ void scalar_store16(void *base, uint32_t byte_off, ui
     "v_cndmask_b32_e32 %[sc], %[vmis], %[vmat], vcc\n\t"                                          \
     HDADD "\n\t"                                                                                  \
     "v_subrev_u32_e32 %[mm], %[gap], %[mm]\n\t"                                                   \
-    "s_mov_b32 %[pm], 1\n\t"                                                                      \
     "v_max_i32_e32 " XC ", %[hd], %[mm]\n\t"                                                      \
     "v_cmp_eq_i32_e64 s[60:61], " XC ", %[hd]\n\t"                                                \
     "s_lshl1_add_u32 %[mv], %[mv], 1\n\t"                                                         \
@@ -629,7 +629,6 @@ __device__ __forceinline__ void scalar_store16(void *base, uint32_t byte_off, ui
     "v_cndmask_b32_e32 %[sc], %[vmis], %[vmat], vcc\n\t"                                          \
     HDADD "\n\t"                                                                                  \
     "v_subrev_u32_e32 %[mm], %[gap], %[mm]\n\t"                                                   \
-    "s_mov_b32 %[pm], 0\n\t"                                                                      \
     "v_max_i32_e32 " XC ", %[hd], %[mm]\n\t"                                                      \
     "v_cmp_eq_i32_e64 s[60:61], " XC ", %[hd]\n\t"                                                \
     "s_lshl_b32 %[mv], %[mv], 1\n\t"                                                              \
@@ -779,6 +778,7 @@ __global__ void __launch_bounds__(64) k_sw(int64_t first, int64_t count, const i
                     bs = upd ? hb : bs;
                     bt = upd ? t + (n_steps - 1 - (kb & 63)) : bt;
                 }
+                pm = (int32_t)(mv & 1u);                                 // the block's last move (the steps no longer keep it up to date)
                 const int32_t nd = __popc(mv);                          // DOWN moves of the block (mv holds exactly n_steps bits)
                 i0 += nd;
                 qpos_i += nd; tpos_i += n_steps - nd;
