@@ -585,7 +585,7 @@ __device__ __forceinline__ void scalar_store16(void *base, uint32_t byte_off, ui
 //     later), a diagonal move adds (s << 6) - 2 (two steps later); equality tests are unaffected.
 //   * moves are collected in a 32-bit shift register (first step of the block ends up in the highest used bit); its bit 0 is the block's last
 //     move, so the steps do not keep a "previous move" register up to date (one SALU less per step: the scalar port has no slack).
-// `cnt` enters as (steps - 1) and counts down; the borrow ends the block.
+// The store offset is the step counter: it enters 16 * steps below 2^31 and the signed overflow of its increment ends the block.
 // No DPP source is written fewer than two instructions before it is read (gfx9 DPP hazard).
 #define SWB_DPP_SHL " wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0"
 #define SWB_DPP_SHR " wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0"
@@ -611,8 +611,7 @@ __device__ __forceinline__ void scalar_store16(void *base, uint32_t byte_off, ui
     "v_readlane_b32 %[top], " XC ", 0\n\t"                                                        \
     "s_store_dwordx4 s[60:63], %[tbp], %[soff]\n\t"                                               \
     "v_readlane_b32 %[bot], " XC ", 63\n\t"                                                       \
-    "s_add_u32 %[soff], %[soff], 16\n\t"                                                          \
-    "s_sub_u32 %[cnt], %[cnt], 1\n\t"                                                             \
+    "s_addk_i32 %[soff], 16\n\t"                                                                  \
     "s_cbranch_scc1 Lsw%=_end" NP "\n\t"                                                          \
     "s_cmp_gt_i32 %[top], %[bot]\n\t"                                                             \
     "s_cbranch_scc1 Lsw%=_p" NP "DR\n\t"                                                          \
@@ -636,15 +635,14 @@ __device__ __forceinline__ void scalar_store16(void *base, uint32_t byte_off, ui
     "v_readlane_b32 %[top], " XC ", 0\n\t"                                                        \
     "s_store_dwordx4 s[60:63], %[tbp], %[soff]\n\t"                                               \
     "v_readlane_b32 %[bot], " XC ", 63\n\t"                                                       \
-    "s_add_u32 %[soff], %[soff], 16\n\t"                                                          \
-    "s_sub_u32 %[cnt], %[cnt], 1\n\t"                                                             \
+    "s_addk_i32 %[soff], 16\n\t"                                                                  \
     "s_cbranch_scc1 Lsw%=_end" NP "\n\t"                                                          \
     "s_cmp_gt_i32 %[top], %[bot]\n\t"                                                             \
     "s_cbranch_scc1 Lsw%=_p" NP "RR\n\t"                                                          \
     "s_branch Lsw%=_p" NP "RD\n"
 // label "pPab": parity P (0: H in %[H], X in %[X]; 1: swapped), a = previous move, b = this move
 __device__ __forceinline__ void sw_block(int32_t &H, int32_t &X, int32_t &qc, int32_t &tc, const uint64_t qbits, const uint64_t tbits, int32_t &kb,
-                                         void *tbp, uint32_t &soff, uint32_t &mv, int32_t &cnt, int32_t &dn, int32_t &pm, const int32_t gapS,
+                                         void *tbp, uint32_t &soff, uint32_t &mv, int32_t &dn, int32_t &pm, const int32_t gapS,
                                          const int32_t vmatS, const int32_t vmisS) {
     int32_t hd, mm, sc, top, bot;
     uint32_t qsel = 2u << 16, tsel = 2u << 16;   // s_bfe_u64 operand: width 2, offset 0
@@ -674,7 +672,7 @@ __device__ __forceinline__ void sw_block(int32_t &H, int32_t &X, int32_t &qc, in
         "Lsw%=_end0:\n\t"
         "s_cmp_gt_i32 %[top], %[bot]\n\t"
         "s_cselect_b32 %[dn], 0, 1"
-        : [H] "+v"(H), [X] "+v"(X), [qc] "+v"(qc), [tc] "+v"(tc), [kb] "+v"(kb), [mv] "+s"(mv), [cnt] "+s"(cnt), [soff] "+s"(soff),
+        : [H] "+v"(H), [X] "+v"(X), [qc] "+v"(qc), [tc] "+v"(tc), [kb] "+v"(kb), [mv] "+s"(mv), [soff] "+s"(soff),
           [dn] "+s"(dn), [pm] "+s"(pm), [qsel] "+s"(qsel), [tsel] "+s"(tsel), [hd] "=&v"(hd), [mm] "=&v"(mm), [sc] "=&v"(sc), [top] "=&s"(top), [bot] "=&s"(bot)
         : [gap] "s"(gapS), [vmat] "v"(vmatS), [vmis] "v"(vmisS), [qb] "s"(qbits), [tb] "s"(tbits), [tbp] "s"(tbp)
         : "vcc", "scc", "s56", "s57", "s60", "s61", "s62", "s63", "memory");
@@ -760,7 +758,6 @@ __global__ void __launch_bounds__(64) k_sw(int64_t first, int64_t count, const i
                 const uint64_t qbits = base_window(qpk, __builtin_amdgcn_readfirstlane((int32_t)qb + qpos_i));
                 const uint64_t tbits = base_window(tpk, tbase + __builtin_amdgcn_readfirstlane(tpos_i));
                 const int32_t n_steps = __builtin_amdgcn_readfirstlane(min(safe, 32 - (t & 31)));
-                int32_t cnt = n_steps - 1;                               // counts down; the borrow ends the block
                 safe -= n_steps;
                 uint32_t mv = 0;
                 int32_t kb = 0;
@@ -768,8 +765,11 @@ __global__ void __launch_bounds__(64) k_sw(int64_t first, int64_t count, const i
                 pm = __builtin_amdgcn_readfirstlane(pm);
                 H = (H << 6) + n_steps;                                  // previous step: countdown n_steps
                 X = (X << 6) + n_steps + 1;                              // the one before
-                uint32_t soff = (uint32_t)__builtin_amdgcn_readfirstlane(t) * 16u;
-                sw_block(H, X, qc, tc, qbits, tbits, kb, (void *)tbr, soff, mv, cnt, dn, pm, gapS, vmatS, vmisS);
+                // the store offset doubles as the block's step counter: it starts 16 * n_steps below 2^31 (the base pointer makes up for
+                // it), and the add that would carry it past 2^31 -- the signed overflow of s_addk_i32 -- ends the block
+                uint32_t soff = 0x80000000u - 16u * (uint32_t)n_steps;
+                void *tbp = (void *)((char *)tbr + ((int64_t)__builtin_amdgcn_readfirstlane(t) * 16 - (int64_t)soff));
+                sw_block(H, X, qc, tc, qbits, tbits, kb, tbp, soff, mv, dn, pm, gapS, vmatS, vmisS);
                 H >>= 6;                                                 // the last step's countdown is 0, X's is 1
                 X >>= 6;
                 {   // fold the block's best cell into the running best (strictly greater: the earliest step wins ties)
