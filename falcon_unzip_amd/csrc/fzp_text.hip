@@ -116,13 +116,19 @@ int fzp_batch_text_dev(fzp_ctx *ctx, fzp_batch *b, int what, DevBuf<char> &text,
     if (tot >= (1ull << 32)) { fzp_set_error("fzp_batch_text: %llu bytes of text (limit 4 GiB per batch)", (unsigned long long)tot); return FZP_EINVAL; }
     if (what == 1) {
         // row_off of the contigs' first sites: read back with the sites (tiny gather through the same kernel needs them on the device)
-        std::vector<fzp_site> first((size_t)nc + 1);
-        for (int c = 0; c <= nc; c++) {
-            const int64_t s0 = b->h_site_begin[(size_t)c];
-            if (s0 < b->n_sites) FZP_HIP(hipMemcpyAsync(&first[(size_t)c], b->sites.p + s0, sizeof(fzp_site), hipMemcpyDeviceToHost, st));
+        if (b->pf_early && b->pin) {      // the sites are (on their way) in the batch's pinned block already: fzp_batch_run's early download
+            FZP_HIP(hipStreamSynchronize(ctx->stream2));
+            const fzp_site *hs = (const fzp_site *)((const char *)b->pin + b->pf_sites);
+            for (int c = 0; c <= nc; c++) rb[(size_t)c] = b->h_site_begin[(size_t)c] < b->n_sites ? hs[b->h_site_begin[(size_t)c]].row_off : b->n_rows;
+        } else {
+            std::vector<fzp_site> first((size_t)nc + 1);
+            for (int c = 0; c <= nc; c++) {
+                const int64_t s0 = b->h_site_begin[(size_t)c];
+                if (s0 < b->n_sites) FZP_HIP(hipMemcpyAsync(&first[(size_t)c], b->sites.p + s0, sizeof(fzp_site), hipMemcpyDeviceToHost, st));
+            }
+            FZP_HIP(hipStreamSynchronize(st));
+            for (int c = 0; c <= nc; c++) rb[(size_t)c] = b->h_site_begin[(size_t)c] < b->n_sites ? first[(size_t)c].row_off : b->n_rows;
         }
-        FZP_HIP(hipStreamSynchronize(st));
-        for (int c = 0; c <= nc; c++) rb[(size_t)c] = b->h_site_begin[(size_t)c] < b->n_sites ? first[(size_t)c].row_off : b->n_rows;
         FZP_TRY(d_rb.upload(rb.data(), rb.size(), st));
     }
     FZP_TRY(text.alloc((size_t)tot + 16));
