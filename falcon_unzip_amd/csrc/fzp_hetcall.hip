@@ -373,7 +373,25 @@ __global__ void __launch_bounds__(256) k_assoc(int64_t n_sites, const uint32_t *
         const int n1a = (int)set_n[2 * i1], n1b = (int)set_n[2 * i1 + 1];
         fzp_arow *out = tmp + cap_off[i1];
         uint32_t kept = 0;
+        // q_id range of site i1's reads (the sets are sorted): a partner whose range does not meet it shares no read with i1, all four counts
+        // are 0 and the row is never kept (phasing.py:192) -- 64 partners are tested at once, lane per partner, and only the others are
+        // intersected.  (q_ids follow POS, so at 15 kb reads three quarters of the partners inside the 65 536 bp window go this way.)
+        const int32_t lo1 = min(n1a ? s1a[0] : 0x7fffffff, n1b ? s1b[0] : 0x7fffffff), hi1 = max(n1a ? s1a[n1a - 1] : -1, n1b ? s1b[n1b - 1] : -1);
+        uint64_t todo = 0;
         for (uint32_t k = 0; k < nc && kept < 501u; k++) {
+            if ((k & 63u) == 0) {
+                const uint32_t kk = k + (uint32_t)lane;
+                bool meet = false;
+                if (kk < nc) {
+                    const int64_t j = i1 + 1 + kk;
+                    const int na = (int)set_n[2 * j], nb = (int)set_n[2 * j + 1];
+                    const int32_t *pa = setq + set_off[2 * j], *pb = setq + set_off[2 * j + 1];
+                    const int32_t lo2 = min(na ? pa[0] : 0x7fffffff, nb ? pb[0] : 0x7fffffff), hi2 = max(na ? pa[na - 1] : -1, nb ? pb[nb - 1] : -1);
+                    meet = lo2 <= hi1 && lo1 <= hi2;
+                }
+                todo = __ballot(meet);
+            }
+            if (!((todo >> (k & 63u)) & 1ull)) continue;
             const int64_t i2 = i1 + 1 + k;
             const int32_t *s2a = setq + set_off[2 * i2], *s2b = setq + set_off[2 * i2 + 1];
             const int n2a = (int)set_n[2 * i2], n2b = (int)set_n[2 * i2 + 1];
