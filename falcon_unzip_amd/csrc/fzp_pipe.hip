@@ -87,7 +87,7 @@ struct WorkPool {
     std::vector<std::thread> th;
     const std::function<void(int, int)> *fn = nullptr;
     std::atomic<int> next{0};
-    int n = 0, active = 0;
+    int n = 0, active = 0, limit = 0;
     uint64_t gen = 0;
     bool stop = false;
     int size() const { return (int)th.size() + 1; }
@@ -104,7 +104,7 @@ struct WorkPool {
                         if (stop) return;
                         seen = gen;
                         f = fn;
-                        if (!f) continue;
+                        if (!f || i + 1 >= limit) continue;        // nothing left, or this run wants fewer threads than the pool has
                         active++;
                     }
                     for (int t; (t = next.fetch_add(1)) < n;) (*f)(i + 1, t);
@@ -115,10 +115,10 @@ struct WorkPool {
                 }
             });
     }
-    void run(int n_tasks, const std::function<void(int, int)> &f) {
+    void run(int n_tasks, const std::function<void(int, int)> &f, int max_threads) {
         {
             std::lock_guard<std::mutex> lk(mu);
-            fn = &f; n = n_tasks; next.store(0); gen++;
+            fn = &f; n = n_tasks; limit = max_threads; next.store(0); gen++;
         }
         cv.notify_all();
         for (int t; (t = next.fetch_add(1)) < n_tasks;) f(0, t);
@@ -418,6 +418,7 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
         ctx->workers = new WorkPool();
         ctx->workers->start(std::max(0, std::min(T, std::max(nc, 8)) - 1), ctx->device);
     }
+    const int want_threads = std::max(1, std::min(T, nc));
     T = ctx->workers->size();
     std::atomic<int64_t> bytes{0};
     std::vector<int> rcs((size_t)T, FZP_OK);
@@ -499,7 +500,7 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
             if (rc != FZP_OK) rcs[(size_t)t] = rc;
         }
     };
-    ctx->workers->run(nc, work);
+    ctx->workers->run(nc, work, want_threads);
     for (int t = 0; t < T; t++) if (rcs[(size_t)t] != FZP_OK) { fzp_set_error("%s", errs[(size_t)t].c_str()); return rcs[(size_t)t]; }
     for (int c = 0; c < nc; c++) r2p.insert(r2p.end(), recs[(size_t)c].begin(), recs[(size_t)c].end());
     out->ms_text += ms_since(t0);
