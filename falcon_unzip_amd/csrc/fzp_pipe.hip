@@ -424,6 +424,9 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
     std::vector<int> rcs((size_t)T, FZP_OK);
     std::vector<std::string> errs((size_t)T);
     std::vector<std::vector<fzp_r2p>> recs((size_t)nc);
+    // room for a record per aligned read, taken here: vectors grown by the workers would live in the workers' malloc arenas, and freeing
+    // twenty of those from this thread cost a millisecond of arena trimming at the end of every call
+    for (int c = 0; c < nc; c++) recs[(size_t)c].reserve((size_t)(b->h_qid_off[(size_t)c + 1] - b->h_qid_off[(size_t)c]) + 16);
     const std::string out_dir = o->out_dir ? o->out_dir : "";
     const std::function<void(int, int)> work = [&](int t, int c) {
         {
