@@ -25,7 +25,7 @@ def main():
     eng = _lib.Engine(0)
     out_root = tempfile.mkdtemp(prefix="fzp_e2e_", dir=os.environ.get("TMPDIR", "/tmp"))
     rows = []
-    for gc, lanes in ((20, 1), (10, 2), (5, 2), (5, 3), (4, 2)):
+    for gc, lanes in ((20, 1), (10, 2)):
         gb = int(gc * R * RL * 1.06)
         ts = []
         for k in range(4):

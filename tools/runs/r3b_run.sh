@@ -1,4 +1,2 @@
 export TMPDIR=/tmp
-SWEEP_TORCH_FIRST=1 timeout 900 python3 tools/e2e_sweep.py 2>&1 | grep "group_contigs" | cut -c1-250
-echo "--- system runtime"
-timeout 900 python3 tools/e2e_sweep.py 2>&1 | grep "group_contigs" | cut -c1-250
+FZP_PIPE_TIMING=1 SWEEP_TORCH_FIRST=1 timeout 900 python3 tools/e2e_sweep.py 2>&1 | grep "fzp_phase_contigs\|group_contigs\|fzp_job" | cut -c1-260
