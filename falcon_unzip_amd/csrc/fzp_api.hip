@@ -52,6 +52,8 @@ void prefetch_early_records(fzp_ctx *ctx, fzp_batch *b) {
     if (s_vmap) ok = ok && hipMemcpyAsync(base + b->pf_vmap, b->vmap_qid.p, s_vmap, hipMemcpyDeviceToHost, ctx->stream2) == hipSuccess;
     if (s_arows) ok = ok && hipMemcpyAsync(base + b->pf_arows, b->arows.p, s_arows, hipMemcpyDeviceToHost, ctx->stream2) == hipSuccess;
     if (!ok) { (void)hipGetLastError(); return; }
+    if (!ctx->ev_pf_done && hipEventCreateWithFlags(&ctx->ev_pf_done, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ctx->ev_pf_done = nullptr; }
+    if (ctx->ev_pf_done && hipEventRecord(ctx->ev_pf_done, ctx->stream2) != hipSuccess) { (void)hipGetLastError(); }
     b->pf_early = true;
 }
 }  // namespace
@@ -265,7 +267,9 @@ extern "C" int fzp_batch_result_all(fzp_ctx *ctx, fzp_batch *b, fzp_result_all *
             off += (parts[k].bytes + 63) & ~(size_t)63;
         }
     }
-    if (hipStreamSynchronize(st) != hipSuccess || (use_early && hipStreamSynchronize(ctx->stream2) != hipSuccess)) { fzp_result_all_free(out); fzp_set_error("D2H sync failed"); return FZP_EDEVICE; }
+    // the early records: wait for THEIR copies (the event recorded behind them), not for whatever else the caller has put on stream2 since
+    if (hipStreamSynchronize(st) != hipSuccess ||
+        (use_early && (ctx->ev_pf_done ? hipEventSynchronize(ctx->ev_pf_done) : hipStreamSynchronize(ctx->stream2)) != hipSuccess)) { fzp_result_all_free(out); fzp_set_error("D2H sync failed"); return FZP_EDEVICE; }
     b->pf_early = false;                                               // a later run of the batch refills the block
     for (size_t k = 0; k < parts.size(); k++) *parts[k].dst = (char *)b->pin + offs[k];   // borrowed views into the batch's pinned block
     if (b->have_sites) {

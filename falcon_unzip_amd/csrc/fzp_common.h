@@ -119,6 +119,7 @@ struct fzp_ctx {
     struct FileWriter *writer = nullptr;   // fzp_pipe.hip: background file writes of FZP_PIPE_ASYNC_WRITES calls (joined by fzp_pipe_flush / ctx destroy)
     std::vector<fzp_ctx *> lanes;    // fzp_phase_contigs: the extra lanes' contexts, kept (with their warm block caches) for the next call
     hipEvent_t ev_pf = nullptr;      // "K2/K3 results are final": their download starts on stream2 while K4/K5 run
+    hipEvent_t ev_pf_done = nullptr; // ... and "that download is over" (what fzp_batch_result_all waits for: stream2 may hold later copies)
     int n_cu = 256;
 };
 

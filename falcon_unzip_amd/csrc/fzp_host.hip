@@ -266,6 +266,7 @@ extern "C" void fzp_ctx_destroy(fzp_ctx *ctx) {
     for (auto &pb : ctx->pin_free) (void)hipHostFree(pb.first);
     for (auto &pb : ctx->pin_live) (void)hipHostFree(pb.first);      // (views handed out die with the ctx, as documented)
     if (ctx->ev_pf) (void)hipEventDestroy(ctx->ev_pf);
+    if (ctx->ev_pf_done) (void)hipEventDestroy(ctx->ev_pf_done);
     trim_pool(*ctx->pool);
     t_pool.reset();
     (void)hipStreamDestroy(ctx->stream2);

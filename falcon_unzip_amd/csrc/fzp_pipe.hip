@@ -428,6 +428,7 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
     // twenty of those from this thread cost a millisecond of arena trimming at the end of every call
     for (int c = 0; c < nc; c++) recs[(size_t)c].reserve((size_t)(b->h_qid_off[(size_t)c + 1] - b->h_qid_off[(size_t)c]) + 16);
     const std::string out_dir = o->out_dir ? o->out_dir : "";
+    std::vector<std::function<bool()>> tasks((size_t)nc);     // per contig: write its files
     const std::function<void(int, int)> work = [&](int t, int c) {
         {
             if (rcs[(size_t)t] != FZP_OK) return;
@@ -468,7 +469,6 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
             us_map += (int64_t)(ms_since(tq) * 1e3); tq = clk::now();
             char *fa = nullptr; size_t fl = 0;
             if (rc == FZP_OK && o->out_dir && want_cns && fzp_format_tigs(&tigs, c, ctg, &fa, &fl) != FZP_OK) { rc = FZP_EINVAL; errs[(size_t)t] = fzp_last_error(); }
-            if (rc == FZP_OK && o->out_dir && hipEventSynchronize(ev_t.e) != hipSuccess) { rc = FZP_EDEVICE; errs[(size_t)t] = "text download failed"; }
             if (rc == FZP_OK && o->out_dir) {
                 // everything the files need is owned by `owned` (pinned texts, malloc'ed small texts) or moved into the task (strings)
                 { std::lock_guard<std::mutex> lk(owned->mu); for (auto p : txt) owned->texts.push_back(p); if (fa) owned->texts.push_back(fa); }
@@ -491,10 +491,8 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
                     if (!ok && fw) fw->fail("cannot write under " + base + ": " + strerror(errno));
                     return ok;
                 };
-                if (async) {
-                    bytes += (int64_t)(l0 + l1 + l2 + lv + la + qmap_p->size() + (have_r2p ? r2p_p->size() : 0) + (want_cns ? fl : 0));     // what the queued task will write
-                    ctx->writer->push([task]() { (void)task(); });
-                } else if (!task()) { rc = FZP_EINVAL; errs[(size_t)t] = "cannot write under " + base + ": " + strerror(errno); }
+                if (async) bytes += (int64_t)(l0 + l1 + l2 + lv + la + qmap_p->size() + (have_r2p ? r2p_p->size() : 0) + (want_cns ? fl : 0));     // what the queued task will write
+                tasks[(size_t)c] = task;        // run (or queued) below, once the big texts have arrived
             } else {
                 for (auto p : txt) free(p);
                 free(fa);
@@ -505,6 +503,16 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
     };
     ctx->workers->run(nc, work, want_threads);
     for (int t = 0; t < T; t++) if (rcs[(size_t)t] != FZP_OK) { fzp_set_error("%s", errs[(size_t)t].c_str()); return rcs[(size_t)t]; }
+    if (o->out_dir) {
+        FZP_HIP(hipEventSynchronize(ev_t.e));                    // the two big texts are in the pinned block (their copy ran under the formatting above)
+        if (async) { for (int c = 0; c < nc; c++) if (tasks[(size_t)c]) ctx->writer->push([tk = std::move(tasks[(size_t)c])]() { (void)tk(); }); }
+        else {
+            std::atomic<int> failed{-1};
+            const std::function<void(int, int)> wr = [&](int, int c) { if (tasks[(size_t)c] && !tasks[(size_t)c]()) failed.store(c); };
+            ctx->workers->run(nc, wr, want_threads);
+            if (failed.load() >= 0) { fzp_set_error("cannot write under %s/%s: %s", out_dir.c_str(), nm->ctg_id[failed.load()], strerror(errno)); return FZP_EINVAL; }
+        }
+    }
     for (int c = 0; c < nc; c++) r2p.insert(r2p.end(), recs[(size_t)c].begin(), recs[(size_t)c].end());
     out->ms_text += ms_since(t0);
     if (timing) fprintf(stderr, "[fzp_pipe] host section %.2f ms on %d threads; summed over contigs: names %.2f fmt %.2f readmap %.2f write %.2f ms\n", ms_since(t0), T,

@@ -117,7 +117,7 @@ int fzp_batch_text_dev(fzp_ctx *ctx, fzp_batch *b, int what, DevBuf<char> &text,
     if (what == 1) {
         // row_off of the contigs' first sites: read back with the sites (tiny gather through the same kernel needs them on the device)
         if (b->pf_early && b->pin) {      // the sites are (on their way) in the batch's pinned block already: fzp_batch_run's early download
-            FZP_HIP(hipStreamSynchronize(ctx->stream2));
+            if (ctx->ev_pf_done) FZP_HIP(hipEventSynchronize(ctx->ev_pf_done)); else FZP_HIP(hipStreamSynchronize(ctx->stream2));
             const fzp_site *hs = (const fzp_site *)((const char *)b->pin + b->pf_sites);
             for (int c = 0; c <= nc; c++) rb[(size_t)c] = b->h_site_begin[(size_t)c] < b->n_sites ? hs[b->h_site_begin[(size_t)c]].row_off : b->n_rows;
         } else {
