@@ -879,11 +879,16 @@ __global__ void __launch_bounds__(64) k_tb_walk(int64_t first, int64_t count, co
 #pragma unroll
     for (int l = 0; l < TBW_RPW; l++) rec_base[l] = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(phi, l) << 32) | (uint32_t)__builtin_amdgcn_readlane(plo, l);
     // records of chunk pref_chunk of every read -> registers (lane x takes step x of the chunk)
+    // (the record pointers are rebuilt from lane reads, which leaves them in the generic address space; a FLAT load counts on lgkmcnt as
+    //  well as on vmcnt, so the walk's first wait for an LDS read would wait for the whole prefetch: load through global pointers)
+    typedef uint32_t tbw_u32x4 __attribute__((ext_vector_type(4)));
+    typedef const tbw_u32x4 __attribute__((address_space(1))) *tbw_gptr;
 #define TBW_ISSUE()                                                                                                      \
     _Pragma("unroll") for (int l = 0; l < TBW_RPW; l++) {                                                                \
         const int32_t cl = __builtin_amdgcn_readlane(pref_chunk, l);                                                     \
         if (cl >= 0) {                                                                                                   \
-            pf[l] = ((const uint4 *)rec_base[l])[(int64_t)cl * 64 + lane];                                                        \
+            const tbw_u32x4 q_ = ((tbw_gptr)rec_base[l])[(int64_t)cl * 64 + lane];                                              \
+            pf[l] = make_uint4(q_.x, q_.y, q_.z, q_.w);                                                                  \
         }                                                                                                                \
     }
     TBW_ISSUE()
