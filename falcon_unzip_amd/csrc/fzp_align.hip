@@ -398,14 +398,17 @@ __global__ void __launch_bounds__(64) k_chain(int64_t first, int64_t count, cons
         const int32_t hl = ws ? nh - 1 - xl : xl;
         uint2 hv = make_uint2(0, 0);
         if (xl < nh) hv = hits[hl];
-        const int m = min(64, nh - x0);
-        for (int jx = 0; jx < m; jx++) {
+        // which of the 64 loaded hits belong to this window (strand, bins wb-1 .. wb+2): tested lane-parallel, the serial part below only
+        // sees those (about a third of the list at cfg2; the per-hit scalar tests were most of this kernel's scalar instructions)
+        bool inw = false;
+        if (xl < nh && (int)(hv.x >> 31) == ws) {
+            const int b = (int)(((int64_t)(int32_t)hv.y - (int32_t)(hv.x & 0x7fffffffu) + n) >> shift);
+            inw = b >= wb - 1 && b <= wb + 2;
+        }
+        for (uint64_t todo = __ballot(inw); todo; todo &= todo - 1) {
+            const int jx = __builtin_ctzll(todo);
             const uint32_t hx = (uint32_t)__builtin_amdgcn_readlane((int32_t)hv.x, jx), hy = (uint32_t)__builtin_amdgcn_readlane((int32_t)hv.y, jx);
-            if ((int)(hx >> 31) != ws) continue;
             const int32_t i = (int32_t)(hx & 0x7fffffffu), cp = (int32_t)hy;
-            const int64_t dv = (int64_t)cp - i + n;
-            const int b = (int)(dv >> shift);
-            if (b < wb - 1 || b > wb + 2) continue;
             const int32_t h = ws ? nh - 1 - (x0 + jx) : x0 + jx;
             const int32_t d = cp - i;
             const int32_t dist = (e - 1 - lane) & 63;           // this lane's hit is `dist + 1` window hits back
