@@ -226,6 +226,28 @@ __device__ __forceinline__ int index_collect(const uint64_t *__restrict__ tab, i
     return cnt > MAX_OCC ? MAX_OCC + 1 : cnt;
 }
 
+// the same walk along the key's bucket chain, counting only: returns the number of entries (MAX_OCC + 1 if there are more) and the first
+// one's value.  Nearly every k-mer of a read has no entry or one; k_seed runs index_collect (arrays, ordering) only in waves where a
+// k-mer has several.
+__device__ __forceinline__ int index_count(const uint64_t *__restrict__ tab, int bbits, uint32_t key, uint32_t bkt, uint4 lo, uint4 hi, uint32_t *first) {
+    const uint32_t pmask = (1u << (bbits < PART_BITS ? bbits : PART_BITS)) - 1u;
+    int cnt = 0;
+    for (;;) {
+        const uint32_t kk[4] = {lo.y, lo.w, hi.y, hi.w}, vv[4] = {lo.x, lo.z, hi.x, hi.z};
+        bool open = false;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (kk[q] == 0xffffffffu && vv[q] == 0xffffffffu) open = true;
+            else if (kk[q] == key) { if (cnt == 0) *first = vv[q]; cnt++; }
+        }
+        if (open || cnt > MAX_OCC) break;
+        bkt = next_bucket(bkt, pmask);
+        const uint4 *bp = (const uint4 *)(tab + (size_t)bkt * 4);
+        lo = bp[0]; hi = bp[1];
+    }
+    return cnt > MAX_OCC ? MAX_OCC + 1 : cnt;
+}
+
 struct Anchor { int32_t aligned, strand, i_a, c_a; };
 
 __device__ __forceinline__ uint64_t block_max_u64(uint64_t v, uint64_t *sh) {
@@ -286,24 +308,34 @@ __global__ void __launch_bounds__(256) k_seed(int64_t first, const uint32_t *__r
                 lo[u] = bp[0]; hi[u] = bp[1];
             }
         }
-        uint32_t ent[4][MAX_OCC];
+        uint32_t ent[4][MAX_OCC], e0[4];
         int cnt[4];
         uint32_t mine = 0;
+        bool several = false;
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int64_t m = base + 4 * threadIdx.x + u;
-            cnt[u] = 0;
+            cnt[u] = 0; e0[u] = 0;
             if (m < ns) {
-                cnt[u] = index_collect(tab, bbits, key[u], bkt[u], lo[u], hi[u], ent[u]);
+                cnt[u] = index_count(tab, bbits, key[u], bkt[u], lo[u], hi[u], &e0[u]);
                 if (cnt[u] > MAX_OCC) cnt[u] = 0;
-                for (int a = 1; a < cnt[u]; a++) {           // by position (insertion sort; almost always one entry)
-                    const uint32_t v = ent[u][a];
-                    int b = a - 1;
-                    while (b >= 0 && ent[u][b] > v) { ent[u][b + 1] = ent[u][b]; b--; }
-                    ent[u][b + 1] = v;
-                }
+                several = several || cnt[u] > 1;
             }
             mine += (uint32_t)cnt[u];
+        }
+        if (__any(several)) {                                    // rare: a k-mer with 2..MAX_OCC entries -- all of them, by position
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (cnt[u] > 1) {
+                    (void)index_collect(tab, bbits, key[u], bkt[u], lo[u], hi[u], ent[u]);
+                    for (int a = 1; a < cnt[u]; a++) {           // insertion sort
+                        const uint32_t v = ent[u][a];
+                        int b = a - 1;
+                        while (b >= 0 && ent[u][b] > v) { ent[u][b + 1] = ent[u][b]; b--; }
+                        ent[u][b + 1] = v;
+                    }
+                }
+            }
         }
         // slots in (sample, position) order: exclusive scan of the per-thread counts
         const uint32_t incl = wave_incl_scan_u32(mine);
@@ -315,14 +347,18 @@ __global__ void __launch_bounds__(256) k_seed(int64_t first, const uint32_t *__r
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int64_t pf = (base + 4 * threadIdx.x + u) * stride;
-            for (int a = 0; a < cnt[u]; a++, off++) {
-                if (off >= (uint32_t)HIT_CAP) break;
-                const uint32_t hit = ent[u][a];
+            auto emit = [&](uint32_t hit) {
                 const int s_ = (int)((hit & 1u) ^ orr[u]);
                 const int64_t cp = hit >> 1, i = s_ ? n - k - pf : pf;
                 hits[off] = make_uint2(((uint32_t)s_ << 31) | (uint32_t)i, (uint32_t)cp);
                 atomicAdd(&votes[s_ * NB + (int)((cp - i + n) >> shift)], 1u);
-            }
+            };
+            if (cnt[u] == 1) { if (off < (uint32_t)HIT_CAP) emit(e0[u]); off++; }
+            else if (cnt[u] > 1)
+                for (int a = 0; a < cnt[u]; a++, off++) {
+                    if (off >= (uint32_t)HIT_CAP) break;
+                    emit(ent[u][a]);
+                }
         }
         n_hits = min(n_hits + tot, (uint32_t)HIT_CAP);
         __syncthreads();
