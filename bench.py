@@ -21,6 +21,12 @@ the dominant kernel (k1_sw) from HIP events on the library's stream.  `end_to_en
 inputs resident) times fzp_phase_contigs on the same workload from host buffers: pinned staging + H2D + 2-bit packing
 included, contig groups on two lanes so that uploads and file writes hide behind kernels.
 `--strong` switches to BASELINE configs[2]'s shape: a fixed set of contigs of uneven size dealt LPT over the ranks.
+
+Ranks.  `python bench.py --gpus N` with N > 1 and no torch.distributed environment starts its own N ranks: before torch is imported or
+anything touches the GPU, the process spawns `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+bench.py <same arguments>` as a CHILD, lets rank 0's JSON line through and exits with the children's code (never an exec).  Under a launcher
+(RANK / WORLD_SIZE set) WORLD_SIZE must equal --gpus.  An N > 1 run also carries `strong_cfg3`: BASELINE configs[2] (500 contigs x 750 kb,
+0.5x..2x 2 000 reads each, LPT over the ranks, streamed from host buffers through fzp_phase_contigs, one all-gather) inside the same line.
 """
 from __future__ import annotations
 
@@ -94,50 +100,178 @@ def make_names_and_maps(read_ctg, off, ids, arid_base):
     return (noff, b"".join(names)), (rawread_ids, pread_ids, p2c)
 
 
-def cpu_baseline(contigs, blob, off, read_ctg, ids, eng, n_sample_ctg):
-    """The oracle ("port": scalar C restatement) on a bounded sample over ALL host cores: every read of the first
-    `n_sample_ctg` contigs through the CPU twin aligner (reads dealt to nproc threads, oracle/align_oracle.c), then the
-    oracle phasing chain on the SAM text of those contigs, one contig per thread -- the reference's own shape
-    (phasing.py:496-498 max_jobs=1 per contig, unzip.py:255 contigs side by side)."""
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for l in f:
+                if l.startswith("model name"):
+                    return l.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return ""
+
+
+def cpu_baseline(contigs, blob, off, read_ctg, ids, job, hip_summ, budget_s=30.0):
+    """The oracle ("port": scalar C restatement) on the host's cores, the reference's own shape: contigs side by side (unzip.py:255), each
+    contig's reads on its share of the threads (blasr --nproc, unzip.py:88).  Sample = as many whole contigs of the workload as ~budget_s
+    of CPU time allow at 80 Mcell/s per thread (all of them on a many-core GPU host).  Per contig the twin aligner
+    (oracle/align_oracle.c) reports its index build and its seeding + DP separately; then the oracle/phasing_oracle.c chain runs on the
+    SAM text of those contigs, one contig per thread (phasing.py:496-498 max_jobs=1).  `job` (the HIP job of the timed run) supplies the
+    SAM text the chain reads and, the checker's other use, the parity count."""
     from concurrent.futures import ThreadPoolExecutor
     from falcon_unzip_amd import _lib
     from tests import oracle_lib
     orc = oracle_lib.load()
     cores = os.cpu_count() or 1
-    t_aln, cells, n_used, sams, mismatched = 0.0, 0.0, 0, [], 0
-    for c in range(n_sample_ctg):
-        idx = np.flatnonzero(read_ctg == c)
-        reads = [blob[off[i]:off[i + 1]] for i in idx]
-        t0 = time.perf_counter()
-        summ, _ = oracle_lib.align_reads(orc, contigs[c], reads, n_threads=cores)
-        t_aln += time.perf_counter() - t0
-        cells += float(summ["cells"].sum())
-        n_used += len(reads)
-        job = _lib.align_job(eng, [contigs[c]], reads)      # the SAM text the oracle chain reads -- and, the checker's other use, a parity count
-        job.run()
-        hip = job.summaries()
-        mismatched += int(sum(int((hip[f] != summ[f]).sum()) for f in ("aligned", "strand", "pos", "ref_end", "q_start", "q_end", "score", "n_cigar", "cells", "n_columns", "n_match")))
-        aln, _ = job.alnset(0)
-        sams.append((_lib.format_sam(aln, ids[c]), contigs[c], ids[c]))
-        job.close()
+    n_ctg = len(contigs)
+    cells_per_ctg = float(hip_summ["cells"].sum()) / max(1, n_ctg)
+    n_sample = max(1, min(n_ctg, int(budget_s * 80e6 * cores / max(1.0, cells_per_ctg))))
+    side = min(n_sample, cores)                                 # contigs in flight
+    thr = max(1, cores // side)                                 # threads per contig
+    idxs = [np.flatnonzero(read_ctg == c) for c in range(n_sample)]
+
+    def one(c):
+        reads = [blob[off[i]:off[i + 1]] for i in idxs[c]]
+        sec = []
+        summ, _ = oracle_lib.align_reads(orc, contigs[c], reads, n_threads=thr, seconds=sec)
+        return summ, sec
+
     t0 = time.perf_counter()
-    with ThreadPoolExecutor(max_workers=min(cores, len(sams))) as ex:
+    with ThreadPoolExecutor(max_workers=side) as ex:
+        res = list(ex.map(one, range(n_sample)))
+    t_aln = time.perf_counter() - t0
+    cells = float(sum(r[0]["cells"].sum() for r in res))
+    n_used = int(sum(len(x) for x in idxs))
+    t_index = max(r[1][0] for r in res)                         # the contigs' indexes are built side by side: the slowest one is on the clock
+    t_dp = max(1e-9, t_aln - t_index)
+    mismatched = 0
+    fields = ("aligned", "strand", "pos", "ref_end", "q_start", "q_end", "score", "n_cigar", "cells", "n_columns", "n_match")
+    for c in range(n_sample):
+        mismatched += int(sum(int((hip_summ[f][idxs[c]] != res[c][0][f]).sum()) for f in fields))
+    sams = []
+    for c in range(n_sample):
+        aln, _ = job.alnset(c)
+        sams.append((_lib.format_sam(aln, ids[c]), contigs[c], ids[c]))
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=side) as ex:
         list(ex.map(lambda a: orc.phase_all(*a), sams))
     t_ph = time.perf_counter() - t0
-    model = ""
-    try:
-        with open("/proc/cpuinfo") as f:
-            for l in f:
-                if l.startswith("model name"):
-                    model = l.split(":", 1)[1].strip()
-                    break
-    except OSError:
-        pass
-    return {"value": round(n_used / (t_aln + t_ph), 3), "unit": "reads/s", "cores": cores, "kind": "port", "cpu_model": model,
-            "sample": "all %d reads (15 kb) of the first %d contigs vs their 5 Mb contigs: oracle/align_oracle.c over %d threads, then the "
-                      "oracle/phasing_oracle.c chain, one contig per thread; the reference's blasr and Python 2 cannot run here" % (n_used, n_sample_ctg, cores),
-            "align_s": round(t_aln, 3), "phasing_s": round(t_ph, 3), "dp_gcell_per_s": round(cells / t_aln / 1e9, 4),
+    return {"value": round(n_used / (t_aln + t_ph), 3), "unit": "reads/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+            "sample": "all %d reads of %d of the %d contigs: %d contigs side by side x %d threads each -- oracle/align_oracle.c (index build, then seeding + DP + "
+                      "trace-back), then the oracle/phasing_oracle.c chain, one contig per thread; the reference's blasr and Python 2 cannot run here"
+                      % (n_used, n_sample, n_ctg, side, thr),
+            "contigs": n_sample, "threads_per_contig": thr,
+            "align_s": round(t_aln, 3), "index_s": round(t_index, 3), "dp_s": round(t_dp, 3), "phasing_s": round(t_ph, 3),
+            "dp_gcell_per_s": round(cells / t_dp / 1e9, 4), "dp_mcell_per_s_per_thread": round(cells / t_dp / 1e6 / min(cores, side * thr), 2),
             "k1_fields_differing_from_hip": mismatched}
+
+
+def roofline(cells_per_launch, sw_avg_ms, sw_launches, dp_gcells, traffic):
+    """k1_sw, the dominant kernel.  It is bound by VALU issue (integer DP; no MFMA, 0.25 algorithmic B/cell), so the headline fraction is
+    wave64 VALU instructions issued per second against the chip's issue peak: 256 CU x 4 SIMD x 2.4 GHz / 2 cycles per wave64 instruction
+    (SIMD-32 halves, MI355X_MICROARCH.md) = 1 228.8 G inst/s.  Instructions per band step come from SQ_INSTS_VALU (profiles/, named in
+    `source`).  The HBM view (north_star's figure) sits beside it in `hbm`; `traffic` = measured HBM bytes per launch (FETCH + WRITE)."""
+    counters = {"valu_per_step": SW_VALU_PER_STEP, "source": "profiles/r2_sq_counters_k1.json"}
+    cf = os.path.join(REPO, "profiles", "k1_sw_counters.json")
+    if os.path.exists(cf):
+        with open(cf) as f:
+            counters = json.load(f)
+    per_step = float(counters["valu_per_step"])
+    steps_per_s = dp_gcells * 1e9 / 64.0
+    achieved = steps_per_s * per_step / 1e9
+    peak = N_SIMD * CLK_GHZ / 2.0
+    mix_peak = N_SIMD * CLK_GHZ * SW_VALU_PER_STEP / SW_CYCLES_PER_STEP_AT_CLASS_RATES
+    gbs = cells_per_launch * SW_BYTES_PER_CELL / (sw_avg_ms * 1e-3) / 1e9 if sw_avg_ms else 0.0
+    return {"bound": "valu", "kernel": "k1_sw", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "G wave64-inst/s",
+            "frac": round(achieved / peak, 4), "traffic": traffic, "avg_launch_ms": round(sw_avg_ms, 3), "launches": int(sw_launches),
+            "valu_insts_per_band_step": per_step, "counter_source": counters.get("source"),
+            "ops_view": {"int_ops_per_cell": 12, "achieved_tlaneop": round(dp_gcells * 12 / 1e3, 2), "peak_tlaneop": round(256 * 4 * 32 * CLK_GHZ / 1e3, 2),
+                         "frac": round(dp_gcells * 12 / (256 * 4 * 32 * CLK_GHZ), 4), "note": "SURVEY 8d: 12 int ops per cell against 256 CU x 4 SIMD x 32 lanes x 2.4 GHz"},
+            "hbm": {"achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "bytes_per_cell": SW_BYTES_PER_CELL,
+                    "note": "algorithmic 0.25 B/cell (2 trace-back bits): small by construction"},
+            "valu_mix_ceiling": {"peak": round(mix_peak, 2), "frac": round(achieved / mix_peak, 4),
+                                 "note": "issue rate this instruction mix can reach at the per-class costs of tools/ubench/valu_issue.hip (not the chip's peak)"}}
+
+
+def strong_inputs(args, rank, world, workers):
+    """the strong_cfg3 leg's shard of this rank, generated BEFORE anything initialises the GPU (the generator forks workers)"""
+    from falcon_unzip_amd import dist as fdist
+    nc, L, R = args.strong_leg_contigs, args.strong_leg_contig_len, args.read_len
+    u = np.random.Generator(np.random.PCG64(20263000)).random(nc)
+    n_reads_c = (args.reads_per_contig * (0.5 + 1.5 * u)).astype(np.int64)
+    mine = fdist.shard_contigs((n_reads_c * R).tolist(), world)[rank]
+    try:
+        contigs, blob, off, read_ctg = make_inputs(3, mine, L, lambda ci: int(n_reads_c[ci]), R, L, workers)
+    except Exception as e:      # noqa: BLE001 -- e.g. MemoryError on a small host: the leg reports it, the main line is unaffected
+        return {"error": "rank %d: input generation: %r" % (rank, e), "mine": mine, "n_reads_c": n_reads_c}
+    return {"mine": mine, "n_reads_c": n_reads_c, "contigs": contigs, "blob": blob, "off": off, "read_ctg": read_ctg}
+
+
+def strong_leg(args, rank, world, eng, comm, coll_dev, inp, out_root):
+    """BASELINE configs[2] inside an N-rank run: a FIXED job of --strong-leg-contigs contigs (750 kb) with 0.5x..2x
+    --reads-per-contig reads each, dealt LPT by read bases (dist.shard_contigs), every rank streaming its shard from HOST buffers through
+    fzp_phase_contigs (contig groups on lanes; PCIe, packing and index inside), then the one all-gather.  Two passes, the second is timed;
+    the figure is all reads / slowest rank.  A rank that fails says so and the leg is reported as failed by every rank -- no collective is
+    entered unless all ranks got there."""
+    import torch
+    import torch.distributed as dist
+    from falcon_unzip_amd import _lib
+    from falcon_unzip_amd import dist as fdist
+    nc, L, R = args.strong_leg_contigs, args.strong_leg_contig_len, args.read_len
+    mine, n_reads_c = inp["mine"], inp["n_reads_c"]
+    err, dt, n_mine, recs, st = inp.get("error", ""), 0.0, 0, np.zeros(0, _lib.R2P), None
+    try:
+        if err:
+            raise RuntimeError(err)
+        contigs, blob, off, read_ctg = inp["contigs"], inp["blob"], inp["off"], inp["read_ctg"]
+        n_mine = len(read_ctg)
+        ids = ["%06dF" % ci for ci in mine]
+        name_tab, maps = make_names_and_maps(read_ctg, off, ids, 0)
+        for k in range(2):
+            eng.synchronize()
+            t0 = time.perf_counter()
+            if mine:
+                st, recs = _lib.phase_contigs(eng, contigs, blob, off, read_ctg, ids, names=name_tab, out_dir=os.path.join(out_root, "strong_%d" % k), read_maps=maps,
+                                              ctg_index=mine, n_lanes=args.e2e_lanes, consensus=args.with_consensus, async_writes=True)
+            recs["arid"] += 10_000_000 * rank
+            eng.synchronize()
+            eng.pipe_flush()
+            dt = time.perf_counter() - t0
+    except Exception as e:      # noqa: BLE001 -- reported in the line
+        err = err or "rank %d: %r" % (rank, e)
+        print("bench.py strong_cfg3: " + err, file=sys.stderr, flush=True)
+    ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=coll_dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) == 0:
+        return {"error": err or "another rank failed"}
+    t0 = time.perf_counter()
+    allr = comm.allgather_r2p(recs) if comm is not None else fdist.allgather_r2p(recs, device=coll_dev)
+    t_gather = time.perf_counter() - t0
+    per_rank = [torch.zeros(3, dtype=torch.float64, device=coll_dev) for _ in range(world)]
+    dist.all_gather(per_rank, torch.tensor([dt + t_gather, float(n_mine), float(len(mine))], dtype=torch.float64, device=coll_dev))
+    slowest = max(float(p[0].item()) for p in per_rank)
+    total = int(sum(float(p[1].item()) for p in per_rank))
+    return {"workload": "cfg3: %d contigs x %d bp IN TOTAL, %d..%d reads x %d bp each, LPT over %d ranks; host ASCII -> fzp_phase_contigs (upload, pack, k-mer tables, K1..K5, "
+                        "files written, readmap) -> one all-gather" % (nc, L, int(n_reads_c.min()), int(n_reads_c.max()), R, world),
+            "scaling": "strong", "n_gpus": world, "reads_total": total, "reads_per_s": round(total / slowest, 1), "s": round(slowest, 4),
+            "r2p_records": int(len(allr)), "gather_ms": round(t_gather * 1e3, 3),
+            "groups_rank0": int(st["n_groups"]) if st else 0,
+            "rank_load": [{"rank": r, "contigs": int(p[2].item()), "reads": int(p[1].item()), "s": round(float(p[0].item()), 4)} for r, p in enumerate(per_rank)]}
+
+
+def launch_ranks(n):
+    """--gpus N outside a launcher: N fresh ranks as children of this process, which has not imported torch nor touched the GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)        # stdout is inherited: rank 0's JSON line goes straight through
 
 
 def main():
@@ -151,8 +285,11 @@ def main():
     ap.add_argument("--read-len", type=int, default=15000)
     ap.add_argument("--window", type=int, default=750_000)
     ap.add_argument("--strong", action="store_true", help="configs[2] shape: --contigs contigs IN TOTAL with 0.5x..2x the reads each, dealt LPT over the ranks")
-    ap.add_argument("--cpu-sample-contigs", type=int, default=1)
+    ap.add_argument("--cpu-budget-s", type=float, default=30.0, help="CPU seconds the cpu_baseline sample is sized for (whole contigs; all of them on a many-core host)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--index-at-create", action="store_true", help="leave the k-mer tables fzp_align_create built in place (r2's step); default: the step rebuilds them, as a job that sees its contigs once would")
+    ap.add_argument("--strong-leg-contigs", type=int, default=500, help="N > 1 runs: contigs of the strong_cfg3 leg (0 = no such leg)")
+    ap.add_argument("--strong-leg-contig-len", type=int, default=750_000)
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--e2e-lanes", type=int, default=2)
     ap.add_argument("--e2e-group-contigs", type=int, default=10)
@@ -161,10 +298,14 @@ def main():
     ap.add_argument("--gen-workers", type=int, default=0, help="processes for input generation (0 = auto; forced to 1 under rocprofv3)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))          # nothing has touched the GPU yet; the ranks are children, this process only waits
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    workers = args.gen_workers or max(1, min(8, (os.cpu_count() or 1) // max(1, world)))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE); they must agree" % (args.gpus, world))
+    workers = args.gen_workers or max(1, min(16 if world > 1 else 8, (os.cpu_count() or 1) // max(1, world)))
     if "rocprof" in os.environ.get("LD_PRELOAD", "") or os.environ.get("ROCPROFILER_REGISTER_FORCE_LOAD") or os.environ.get("ROCP_TOOL_LIBRARIES"):
         workers = 1   # the profiler's preloaded library may have initialised the GPU already: do not fork
     from falcon_unzip_amd import dist as fdist
@@ -186,6 +327,7 @@ def main():
     ids = ["%06dF" % ci for ci in mine]
     arid_base = int(sum(reads_of(ci) for ci in range(mine[0]))) if (mine and not args.strong) else (1_000_000 * rank)
     name_tab, maps = make_names_and_maps(read_ctg, off, ids, arid_base)
+    s_inp = strong_inputs(args, rank, world, workers) if (world > 1 and not args.strong and args.strong_leg_contigs > 0) else None
 
     import torch
     import torch.distributed as dist
@@ -203,26 +345,37 @@ def main():
     eng = _lib.Engine(dev_index)
     # the exchange step: the library's own RCCL all-gather (fzp_allgather_rid_to_phase) when the ranks sit on their own GPUs;
     # torch.distributed's all_gather otherwise (gloo dry runs) or if RCCL cannot be brought up identically on every rank
-    comm = None
+    comm, gather_note = None, None
     if world > 1 and backend == "nccl" and os.environ.get("FZP_BENCH_GATHER", "cabi") == "cabi":
-        ok = 1
+        # ncclCommInitRank is itself collective: every rank first proves locally that RCCL loads and its ctx binds (its own unique id is
+        # the probe), the ranks agree on that with an all_reduce(MIN), and only then does anybody enter the communicator's creation
+        why = ""
         try:
-            box = [_lib.comm_unique_id() if rank == 0 else None]
-        except Exception:
-            box, ok = [None], 0
-        dist.broadcast_object_list(box, src=0)
-        if box[0] is None:
-            ok = 0
-        if ok:
+            my_id = _lib.comm_unique_id()
+        except Exception as e:      # noqa: BLE001
+            my_id, why = None, repr(e)
+        flag = torch.tensor([1 if my_id is not None else 0], dtype=torch.int32, device=coll_dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            box = [my_id if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
             try:
                 comm = _lib.Comm(eng, rank, world, box[0])
-            except Exception:
-                ok = 0
-        flag = torch.tensor([ok], dtype=torch.int32, device=coll_dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0 and comm is not None:
-            comm.close()
-            comm = None
+                if comm.ranks() != (rank, world):
+                    raise RuntimeError("communicator reports rank/size %r, expected %r" % (comm.ranks(), (rank, world)))
+            except Exception as e:      # noqa: BLE001
+                why = repr(e)
+                if comm is not None:
+                    comm.close()
+                comm = None
+            flag = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=coll_dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0 and comm is not None:
+                comm.close()
+                comm = None
+        if comm is None:
+            gather_note = "rank %d: RCCL C-ABI gather unavailable (%s); falling back to torch.distributed all_gather" % (rank, why or "another rank failed")
+            print("bench.py: " + gather_note, file=sys.stderr, flush=True)
     out_root = None
     for cand in (args.out_root, None, "/dev/shm", REPO):          # --out-root, then $TMPDIR, then wherever a directory can be made
         try:
@@ -232,11 +385,13 @@ def main():
             continue
     if out_root is None:
         raise SystemExit("bench.py: no writable scratch directory for the output trees")
+    eng.prof_enable(True)
     t_up = time.perf_counter()
     # (a rank whose shard is empty -- --strong with fewer contigs than ranks -- has no job; it still takes part in every collective)
     job = _lib.align_job_raw(eng, contigs, blob, off, read_ctg) if mine else None     # upload + 2-bit pack: inputs now resident in HBM
     eng.synchronize()
-    upload_ms = (time.perf_counter() - t_up) * 1e3                  # PCIe + packing, outside the timed region
+    upload_ms = (time.perf_counter() - t_up) * 1e3                  # PCIe + packing + the first k-mer tables, outside the timed region
+    index_ms_at_create = eng.prof().get("k1_index", (0.0, 0))[0] if args.index_at_create else 0.0
 
     def barrier():
         eng.synchronize()
@@ -257,7 +412,8 @@ def main():
         out_dir = os.path.join(out_root, "step%03d" % step_no[0])      # a fresh tree per step, as a job would write it (no re-truncation of old files)
         t_a = time.perf_counter()
         if job is not None:
-            st, recs = job.phase_write(ids, names=name_tab, out_dir=out_dir, read_maps=maps, ctg_index=mine, consensus=args.with_consensus, async_writes=True)
+            st, recs = job.phase_write(ids, names=name_tab, out_dir=out_dir, read_maps=maps, ctg_index=mine, consensus=args.with_consensus, async_writes=True,
+                                         rebuild_index=not args.index_at_create)
         else:
             st, recs = {k: 0 for k in ("n_aligned", "n_rec", "n_sites", "n_rows", "n_arows", "n_pvars", "n_preads", "bytes_written", "ms_k1", "ms_phase", "ms_results", "ms_text")}, np.zeros(0, _lib.R2P)
         recs["arid"] += arid_base                      # the read_map files of a rank number its preads from 0: make the ids job-wide
@@ -308,8 +464,15 @@ def main():
     cells_per_launch = cells_per_step * args.steps / max(1, sw_launches)
     dp_gcells = cells_per_launch / (sw_avg_ms * 1e-3) / 1e9 if sw_avg_ms > 0 else 0.0
     aligned_frac = float(summ["aligned"].mean()) if n_reads else 0.0
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline and job is not None and n_reads:
+        cpu = cpu_baseline(contigs, blob, off, read_ctg, ids, job, summ, args.cpu_budget_s)      # rank 0's host cores; the other ranks wait at the next collective
     if job is not None:
         job.close()
+
+    strong = None
+    if world > 1 and not args.strong and args.strong_leg_contigs > 0:
+        strong = strong_leg(args, rank, world, eng, comm, coll_dev, s_inp, out_root)
 
     e2e = None
     if rank == 0 and world == 1 and not args.no_end_to_end:
@@ -334,7 +497,7 @@ def main():
         e2e["note"] = "fzp_phase_contigs: host ASCII -> H2D -> pack -> K1..K5 -> texts -> files; PCIe-inclusive, reported beside `value`, never as it"
 
     pipelined = None
-    if rank == 0 and world == 1 and not args.no_end_to_end:
+    if rank == 0 and world == 1 and not args.no_end_to_end and not os.environ.get("FZP_BENCH_NO_PIPELINED"):
         # the resident step again, two steps in flight: two contexts, each with its own resident copy of the job, alternate steps on two host
         # threads, so the record / text downloads and the host formatting of one step run under the kernels of the next (what
         # fzp_phase_contigs' lanes do for a stream of contig groups).  Reported beside `value`, which stays the one-step-at-a-time figure.
@@ -379,9 +542,6 @@ def main():
         if os.path.exists(tf):
             with open(tf) as f:
                 traffic = json.load(f).get("bytes_per_launch")
-        steps_per_s = dp_gcells * 1e9 / 64.0
-        valu_achieved = steps_per_s * SW_VALU_PER_STEP / 1e9
-        valu_peak = N_SIMD * CLK_GHZ * SW_VALU_PER_STEP / SW_CYCLES_PER_STEP_AT_CLASS_RATES
         out = {
             # BASELINE.json's metric, verbatim; `value` is its reads-phased/sec half (whole job), the DP half is
             # `dp_gcell_per_s_per_gpu` below
@@ -396,7 +556,8 @@ def main():
                                     if args.strong else
                                     "cfg2: per GPU %d contigs x %d bp, %d reads x %d bp template each (CLR 1/8/4 %% errors, both strands), reads drawn from a %d bp window per contig; "
                                     % (args.contigs, args.contig_len, args.reads_per_contig, args.read_len, win))
-                                   + "inputs resident in HBM (2-bit reads and contigs + the contigs' k-mer tables, all built by fzp_align_create); inside the step: K1 align (fzalign v1.2) + K2 het call + K3 atable + K4 blocks + K5 reads + all seven files of every contig "
+                                   + "inputs resident in HBM (2-bit packed reads and contigs); inside the step: " + ("" if not args.index_at_create else "[k-mer tables from fzp_align_create, NOT in the step] ")
+                                   + "K1 " + ("k-mer tables + " if not args.index_at_create else "") + "align (fzalign) + K2 het call + K3 atable + K4 blocks + K5 reads + all seven files of every contig "
                                      "serialised AND written + readmap + r2p all-gather" + (" + K6 consensus" if args.with_consensus else ""),
                        "reads_total": n_total, "reads_per_gpu": n_reads, "parallelism": "contigs sharded, %d rank(s)" % world},
             "dp_gcell_per_s_per_gpu": round(dp_gcells, 2),
@@ -408,21 +569,20 @@ def main():
             "host_wall_ms_per_step": dict({k: round(v / args.steps * 1e3, 3) for k, v in host_t.items()}, **{k[3:]: round(v / args.steps, 3) for k, v in sect.items()}),
             "rank_load": rank_load,
             "gather": "fzp_allgather_rid_to_phase (RCCL, C-ABI)" if comm is not None else ("torch.distributed all_gather (%s)" % backend if world > 1 else "none (1 rank)"),
+            "rccl_ranks": comm.ranks()[1] if comm is not None else 0,      # size of the RCCL communicator as ncclCommCount reports it (0: no RCCL communicator in this run)
+            "gather_fallback": gather_note,
+            "index_in_step": not args.index_at_create,
+            "index_ms": round(prof.get("k1_index", (0.0, 0))[0] / args.steps, 3) if not args.index_at_create else round(index_ms_at_create, 3),
+            "value_end_to_end": e2e["reads_per_s"] if e2e else None,       # host ASCII in, PCIe + packing + index inside (SURVEY 8d's reads-phased/sec); `value` keeps inputs resident (bench contract)
             "end_to_end": e2e,
             "two_steps_in_flight": pipelined,
-            "roofline": {"bound": "hbm", "kernel": "k1_sw", "achieved": round(cells_per_launch * SW_BYTES_PER_CELL / (sw_avg_ms * 1e-3) / 1e9, 2) if sw_avg_ms else 0.0,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(cells_per_launch * SW_BYTES_PER_CELL / (sw_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if sw_avg_ms else 0.0,
-                         "traffic": traffic, "avg_launch_ms": round(sw_avg_ms, 3), "launches": int(sw_launches),
-                         "note": "k1_sw writes 0.25 algorithmic B/cell: its HBM fraction is small by construction; what limits it is VALU issue, priced in `valu` from counters",
-                         "valu": {"insts_per_step": SW_VALU_PER_STEP, "achieved_ginst": round(valu_achieved, 2), "peak_ginst": round(valu_peak, 2),
-                                  "frac": round(valu_achieved / valu_peak, 4),
-                                  "source": "SQ_INSTS_VALU per band step: profiles/r2_sq_counters_k1.json; issue cycles per instruction class at >= 2 waves/SIMD: "
-                                            "profiles/r2_valu_issue_ubench.txt (v_add/v_sub/logic 2.4, v_max/DPP/v_cmp/lane ops 4.2)"}},
+            "roofline": roofline(cells_per_launch, sw_avg_ms, sw_launches, dp_gcells, traffic),
         }
-        if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(contigs, blob, off, read_ctg, ids, eng, max(1, min(args.cpu_sample_contigs, len(contigs))))
-        print(json.dumps(out))
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        if strong is not None:
+            out["strong_cfg3"] = strong
+        print(json.dumps(out), flush=True)
     if comm is not None:
         comm.close()
     eng.close()

@@ -100,7 +100,7 @@ class AlignParams(C.Structure):
 _lib = None
 
 
-PIPE_CONSENSUS, PIPE_ASYNC_WRITES = 1, 2
+PIPE_CONSENSUS, PIPE_ASYNC_WRITES, PIPE_REBUILD_INDEX = 1, 2, 4
 TEXT_VARIANT_MAP, TEXT_ATABLE = 1, 2
 
 
@@ -165,6 +165,7 @@ def load():
         "fzp_align_params_default": (None, [VP]),
         "fzp_align_create": (C.c_int, [VP, I32, VP, VP, I64, VP, VP, VP, VP, PP]),
         "fzp_align_run": (C.c_int, [VP, VP]),
+        "fzp_align_invalidate_index": (C.c_int, [VP]),
         "fzp_align_summaries": (C.c_int, [VP, VP, VP]),
         "fzp_align_n_second": (I64, [VP]),
         "fzp_batch_text": (C.c_int, [VP, VP, C.c_int, PP, PSZ, PP]),
@@ -176,6 +177,7 @@ def load():
         "fzp_mem_info": (C.c_int, [VP, PSZ, PSZ]),
         "fzp_comm_unique_id": (C.c_int, [VP]),
         "fzp_comm_create": (C.c_int, [VP, C.c_int, C.c_int, VP, PP]),
+        "fzp_comm_ranks": (C.c_int, [VP, VP, VP]),
         "fzp_comm_destroy": (None, [VP]),
         "fzp_allgather_rid_to_phase": (C.c_int, [VP, VP, I64, PP, PI64]),
         "fzp_align_alnset": (C.c_int, [VP, VP, I32, VP, CP, PP, PP]),
@@ -519,11 +521,11 @@ class AlignJob:
         idx = _take(ip.value, a.n_rec, np.int64)
         return a, idx
 
-    def phase_write(self, ctg_ids, names=None, out_dir=None, read_maps=None, ctg_index=None, n_threads=0, consensus=False, async_writes=False):
+    def phase_write(self, ctg_ids, names=None, out_dir=None, read_maps=None, ctg_index=None, n_threads=0, consensus=False, async_writes=False, rebuild_index=False):
         """fzp_job_phase_write: K1 -> K5 of every contig of the job, every file of every contig under out_dir, rid_to_phase records.
         names: (name_off int64 [n_reads+1], blob) or a list; read_maps: (rawread_ids, pread_ids, pread_to_contigs) bytes.  -> (stats dict, R2P records)"""
         nm, opts, keep = _pipe_args(ctg_ids, names, out_dir, read_maps, ctg_index, n_threads, 0, 0, None,
-                                    (PIPE_CONSENSUS if consensus else 0) | (PIPE_ASYNC_WRITES if async_writes else 0))
+                                    (PIPE_CONSENSUS if consensus else 0) | (PIPE_ASYNC_WRITES if async_writes else 0) | (PIPE_REBUILD_INDEX if rebuild_index else 0))
         out = PipeOut()
         _check(load().fzp_job_phase_write(self.eng._p, self._p, C.byref(nm), C.byref(opts), C.byref(out)))
         return _pipe_result(out)
@@ -671,6 +673,12 @@ class Comm:
         p, n = C.c_void_p(), C.c_int64()
         _check(load().fzp_allgather_rid_to_phase(self._p, _ptr(local), len(local), C.byref(p), C.byref(n)))
         return _take(p.value, n.value, R2P)
+
+    def ranks(self):
+        """(rank, world) as the communicator itself reports them"""
+        r, w = C.c_int(), C.c_int()
+        _check(load().fzp_comm_ranks(self._p, C.cast(C.byref(r), C.c_void_p), C.cast(C.byref(w), C.c_void_p)))
+        return r.value, w.value
 
     def close(self):
         if self._p:

@@ -1567,6 +1567,13 @@ extern "C" int fzp_align_create(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *cons
     return FZP_OK;
 }
 
+// the next fzp_align_run rebuilds the k-mer tables (a job that sees its contigs once pays for them inside its run: bench.py's step)
+extern "C" int fzp_align_invalidate_index(fzp_alnjob *j) {
+    if (!j) return FZP_EINVAL;
+    j->index_built = false;
+    return FZP_OK;
+}
+
 extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
     if (!ctx || !j) return FZP_EINVAL;
     FZP_TRY(fzp_bind(ctx));

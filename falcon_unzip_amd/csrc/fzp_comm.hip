@@ -24,9 +24,14 @@ struct Rccl {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
+    std::string load_error;
 };
+Rccl &rccl_state() { static Rccl r; return r; }
+std::string rccl_why() { return rccl_state().load_error.empty() ? std::string("not found") : rccl_state().load_error; }
 Rccl *rccl() {
-    static Rccl r;
+    Rccl &r = rccl_state();
     static bool tried = false;
     static std::mutex mu;
     std::lock_guard<std::mutex> lk(mu);
@@ -37,6 +42,8 @@ Rccl *rccl() {
             if (!n) continue;
             r.h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
             if (r.h) break;
+            const char *e = dlerror();                       // read once: a second dlerror() returns NULL
+            r.load_error = e ? e : "not found";
         }
         if (r.h) {
             r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.h, "ncclGetUniqueId");
@@ -44,10 +51,18 @@ Rccl *rccl() {
             r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.h, "ncclCommDestroy");
             r.AllGather = (decltype(r.AllGather))dlsym(r.h, "ncclAllGather");
             r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.h, "ncclGetErrorString");
-            if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather) { dlclose(r.h); r.h = nullptr; }
+            r.CommCount = (decltype(r.CommCount))dlsym(r.h, "ncclCommCount");
+            r.CommUserRank = (decltype(r.CommUserRank))dlsym(r.h, "ncclCommUserRank");
+            if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather) { dlclose(r.h); r.h = nullptr; r.load_error = "a needed nccl* symbol is missing"; }
         }
     }
     return r.h ? &r : nullptr;
+}
+int rccl_missing(const char *who) {
+    Rccl *R = rccl();
+    if (R) return FZP_OK;
+    fzp_set_error("%s: RCCL (librccl.so.1) could not be loaded: %s", who, rccl_why().c_str());
+    return FZP_ENODEVICE;
 }
 int nccl_fail(Rccl *R, const char *what, ncclResult_t rc) {
     fzp_set_error("%s: %s", what, R && R->GetErrorString ? R->GetErrorString(rc) : "RCCL error");
@@ -62,8 +77,8 @@ struct fzp_comm {
 };
 
 extern "C" int fzp_comm_unique_id(char id[FZP_COMM_ID_BYTES]) {
+    FZP_TRY(rccl_missing("fzp_comm_unique_id"));
     Rccl *R = rccl();
-    if (!R) { fzp_set_error("RCCL (librccl.so.1) could not be loaded: %s", dlerror() ? dlerror() : "not found"); return FZP_ENODEVICE; }
     ncclUniqueId u;
     ncclResult_t rc = R->GetUniqueId(&u);
     if (rc) return nccl_fail(R, "ncclGetUniqueId", rc);
@@ -74,8 +89,8 @@ extern "C" int fzp_comm_unique_id(char id[FZP_COMM_ID_BYTES]) {
 extern "C" int fzp_comm_create(fzp_ctx *ctx, int rank, int world, const char id[FZP_COMM_ID_BYTES], fzp_comm **out) {
     if (!ctx || !out || !id || world < 1 || rank < 0 || rank >= world) { fzp_set_error("fzp_comm_create: bad arguments"); return FZP_EINVAL; }
     *out = nullptr;
+    FZP_TRY(rccl_missing("fzp_comm_create"));
     Rccl *R = rccl();
-    if (!R) { fzp_set_error("RCCL (librccl.so.1) could not be loaded"); return FZP_ENODEVICE; }
     FZP_TRY(fzp_bind(ctx));
     ncclUniqueId u;
     memcpy(u.internal, id, sizeof u.internal);
@@ -84,6 +99,21 @@ extern "C" int fzp_comm_create(fzp_ctx *ctx, int rank, int world, const char id[
     ncclResult_t rc = R->CommInitRank(&c->comm, world, u, rank);
     if (rc) { delete c; return nccl_fail(R, "ncclCommInitRank", rc); }
     *out = c;
+    return FZP_OK;
+}
+
+// rank and size as the COMMUNICATOR reports them (ncclCommUserRank / ncclCommCount), not as the caller passed them in: what bench.py
+// prints as `rccl_ranks`
+extern "C" int fzp_comm_ranks(fzp_comm *c, int *rank, int *world) {
+    if (!c || !rank || !world) { fzp_set_error("fzp_comm_ranks: bad arguments"); return FZP_EINVAL; }
+    Rccl *R = rccl();
+    *rank = c->rank; *world = c->world;
+    if (R && R->CommCount && R->CommUserRank && c->comm) {
+        ncclResult_t rc = R->CommCount(c->comm, world);
+        if (rc) return nccl_fail(R, "ncclCommCount", rc);
+        rc = R->CommUserRank(c->comm, rank);
+        if (rc) return nccl_fail(R, "ncclCommUserRank", rc);
+    }
     return FZP_OK;
 }
 

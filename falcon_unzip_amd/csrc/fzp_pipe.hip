@@ -352,6 +352,7 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
     FZP_TRY(fzp_bind(ctx));
     auto t0 = clk::now();
     const auto t_body = t0;
+    if (o->flags & FZP_PIPE_REBUILD_INDEX) FZP_TRY(fzp_align_invalidate_index(job));
     FZP_TRY(fzp_align_run(ctx, job));
     fzp_batch *b = nullptr;
     FZP_TRY(fzp_align_to_batch(ctx, job, &b));

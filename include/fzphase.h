@@ -242,6 +242,8 @@ int fzp_align_create(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *const *ctg_seq,
                      int64_t n_reads, const int32_t *read_ctg, const int64_t *read_off, const uint8_t *read_seq,
                      const fzp_align_params *params, fzp_alnjob **out);
 int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *job);
+/* forget the k-mer tables fzp_align_create built: the next fzp_align_run builds them again, inside the run */
+int fzp_align_invalidate_index(fzp_alnjob *job);
 int fzp_align_summaries(fzp_ctx *ctx, fzp_alnjob *job, fzp_aln_summary *out /* [n_reads] */);
 /* reads of the last run that had a second candidate placement extended (repeats; blasr --bestn 1 keeps the better one) */
 int64_t fzp_align_n_second(const fzp_alnjob *job);
@@ -293,6 +295,8 @@ int fzp_batch_text(fzp_ctx *ctx, fzp_batch *b, int what, char **text, size_t *le
 #define FZP_PIPE_CONSENSUS 1u     /* also K6 (fzp_batch_consensus): <ctg>/cns/phased_blocks.fa */
 #define FZP_PIPE_ASYNC_WRITES 2u  /* the call returns once every text exists and its write is queued; a few background threads of the ctx write the files while
                                      the caller goes on (e.g. with the next job's kernels); fzp_pipe_flush(ctx) waits for them and reports the first error */
+#define FZP_PIPE_REBUILD_INDEX 4u /* fzp_job_phase_write: build the contigs' k-mer tables again inside the call (fzp_align_create built them once; a job that
+                                     sees its contigs once pays for them in its one run, and bench.py's step asks for exactly that) */
 typedef struct {
     int32_t n_ctg;
     const char *const *ctg_id;     /* [n_ctg] names: directory names and the ctg column of phased_reads / rid_to_phase */
@@ -338,6 +342,7 @@ int fzp_pipe_flush(fzp_ctx *ctx);   /* every queued file of FZP_PIPE_ASYNC_WRITE
 typedef struct fzp_comm fzp_comm;
 int fzp_comm_unique_id(char id[FZP_COMM_ID_BYTES]);
 int fzp_comm_create(fzp_ctx *ctx, int rank, int world, const char id[FZP_COMM_ID_BYTES], fzp_comm **out);
+int fzp_comm_ranks(fzp_comm *c, int *rank, int *world);      /* as ncclCommUserRank / ncclCommCount report them */
 void fzp_comm_destroy(fzp_comm *c);
 int fzp_allgather_rid_to_phase(fzp_comm *c, const fzp_r2p *local, int64_t n_local, fzp_r2p **all /* fzp_free */, int64_t *n_all);
 

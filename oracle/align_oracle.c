@@ -55,6 +55,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #define W 64
 #define NEG (-(1 << 26))
@@ -459,10 +460,13 @@ static void *mt_worker(void *vp) {
     }
     return NULL;
 }
-int orc_align_reads_mt(const uint8_t *ctg_ascii, int64_t ctg_len, int64_t n_reads, const int64_t *read_off,
-                       const uint8_t *read_ascii, const orc_align_params *P, orc_aln_summary *out,
-                       uint32_t **cigar_out, int64_t *cig_off, int n_threads) {
+static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+/* seconds[0] = index build (serial, one contig), seconds[1] = seeding + DP + trace-back of all reads (n_threads threads); may be NULL */
+int orc_align_reads_mt_timed(const uint8_t *ctg_ascii, int64_t ctg_len, int64_t n_reads, const int64_t *read_off,
+                             const uint8_t *read_ascii, const orc_align_params *P, orc_aln_summary *out,
+                             uint32_t **cigar_out, int64_t *cig_off, int n_threads, double *seconds) {
     if (P->kmer < 8 || P->kmer > 16 || P->seed_stride < 1) return -1;
+    const double t_begin = now_s();
     if (n_threads < 1) n_threads = 1;
     if (n_threads > 256) n_threads = 256;
     ctg_index ix;
@@ -481,6 +485,7 @@ int orc_align_reads_mt(const uint8_t *ctg_ascii, int64_t ctg_len, int64_t n_read
         }
     }
     qsort(ix.kp, (size_t)ix.n, sizeof(kp_t), cmp_kp);
+    const double t_indexed = now_s();
     u32vec *cigs = (u32vec *)calloc((size_t)(n_reads ? n_reads : 1), sizeof(u32vec));
     pthread_t th[256];
     mt_arg args[256];
@@ -490,6 +495,7 @@ int orc_align_reads_mt(const uint8_t *ctg_ascii, int64_t ctg_len, int64_t n_read
         pthread_create(&th[t], NULL, mt_worker, &args[t]);
     }
     for (int t = 0; t < n_threads; t++) pthread_join(th[t], NULL);
+    if (seconds) { seconds[0] = t_indexed - t_begin; seconds[1] = now_s() - t_indexed; }
     int64_t total = 0;
     cig_off[0] = 0;
     for (int64_t r = 0; r < n_reads; r++) { total += cigs[r].n; cig_off[r + 1] = total; }
@@ -498,4 +504,9 @@ int orc_align_reads_mt(const uint8_t *ctg_ascii, int64_t ctg_len, int64_t n_read
     free(cigs); free(ix.kp); free(codes);
     *cigar_out = all;
     return 0;
+}
+int orc_align_reads_mt(const uint8_t *ctg_ascii, int64_t ctg_len, int64_t n_reads, const int64_t *read_off,
+                       const uint8_t *read_ascii, const orc_align_params *P, orc_aln_summary *out,
+                       uint32_t **cigar_out, int64_t *cig_off, int n_threads) {
+    return orc_align_reads_mt_timed(ctg_ascii, ctg_len, n_reads, read_off, read_ascii, P, out, cigar_out, cig_off, n_threads, NULL);
 }

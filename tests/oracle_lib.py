@@ -121,9 +121,9 @@ class AlignParams(C.Structure):
                 ("gap", C.c_int32), ("min_seed_hits", C.c_int32), ("min_pct_identity", C.c_int32), ("reserved", C.c_int32 * 9)]
 
 
-def align_reads(orc, ctg: bytes, reads, params=None, n_threads=1):
+def align_reads(orc, ctg: bytes, reads, params=None, n_threads=1, seconds=None):
     """CPU twin of K1 (oracle/align_oracle.c): -> (summaries ndarray, list of cigar word arrays).  n_threads > 1: the same
-    results from orc_align_reads_mt (reads dealt to host threads)."""
+    results from orc_align_reads_mt (reads dealt to host threads).  seconds: a list that receives [index build s, seeding + DP s]."""
     import numpy as np
     lib = orc.lib
     P = AlignParams()
@@ -137,11 +137,14 @@ def align_reads(orc, ctg: bytes, reads, params=None, n_threads=1):
     out = np.zeros(n, _aln_dtype())
     cig_off = np.zeros(n + 1, np.int64)
     cp = C.c_void_p()
-    if n_threads > 1:
-        f = lib.orc_align_reads_mt
+    if n_threads > 1 or seconds is not None:
+        f = lib.orc_align_reads_mt_timed
         f.restype = C.c_int
-        f.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p, C.c_int]
-        rc = f(ctg, len(ctg), n, off.ctypes.data, blob, C.addressof(P), out.ctypes.data, C.byref(cp), cig_off.ctypes.data, n_threads)
+        f.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_void_p]
+        sec = (C.c_double * 2)()
+        rc = f(ctg, len(ctg), n, off.ctypes.data, blob, C.addressof(P), out.ctypes.data, C.byref(cp), cig_off.ctypes.data, n_threads, C.addressof(sec))
+        if seconds is not None:
+            seconds[:] = [sec[0], sec[1]]
     else:
         f = lib.orc_align_reads
         f.restype = C.c_int

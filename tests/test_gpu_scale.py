@@ -187,7 +187,7 @@ def test_cfg5_slice_streams_through_groups(tmp_path):
         assert f.read().count(">") >= 2
 
 
-def test_cfg2_workload_equals_oracles_on_every_read_and_contig(eng, oracle):
+def test_cfg2_workload_equals_oracles_on_every_read_and_contig(eng, oracle, record_property):
     """The bench's own workload, read for read: as many cfg2 contigs (5 Mb, 2 000 x 15 kb reads each) as the host's cores pay for in a
     few seconds -- all 20 on a 256-thread node -- aligned by the HIP path in one job and by the threaded CPU twin contig by contig:
     every summary field of every read equal; then K2..K5 of every contig against the oracle chain."""
@@ -196,6 +196,15 @@ def test_cfg2_workload_equals_oracles_on_every_read_and_contig(eng, oracle):
     from tests import oracle_lib
     cores = os.cpu_count() or 1
     n_ctg = max(1, min(20, cores // 12))
+    record_property("cfg2_contigs_checked", n_ctg)
+    try:                                                    # how many contigs this box paid for, where the round's records can see it
+        rec = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(rec, exist_ok=True)
+        with open(os.path.join(rec, "test_cfg2_contigs_checked.json"), "w") as f:
+            f.write('{"host_threads": %d, "contigs_checked": %d, "reads_checked": %d}\n' % (cores, n_ctg, 2000 * n_ctg))
+    except OSError:
+        pass
+    print("test_cfg2_workload: %d host threads -> %d of 20 contigs (%d reads) checked read for read" % (cores, n_ctg, 2000 * n_ctg))
     contigs, blob, off, rctg = _make(n_ctg, 5_000_000, 2000, 15000, 750_000, cfg=2)
     job = _lib.align_job_raw(eng, contigs, blob, off, rctg)
     job.run()
