@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FZP_LIB") or os.path.join(_HERE, "libfzphase.so")   # FZP_LIB: another build of the same library (experiments)
 
 FZP_OK = 0
-FZP_EINVAL, FZP_EZERODIV, FZP_ENOMEM, FZP_EUNSORTED, FZP_EDEVICE, FZP_ENODEVICE = -1, -2, -3, -4, -5, -6
+FZP_EINVAL, FZP_EZERODIV, FZP_ENOMEM, FZP_EUNSORTED, FZP_EDEVICE, FZP_ENODEVICE, FZP_EIO = -1, -2, -3, -4, -5, -6, -7
 STAGE_HET, STAGE_ASSOC, STAGE_BLOCKS, STAGE_READS, STAGE_ALL = 1, 2, 4, 8, 15
 
 SITE = np.dtype([("pos", "<i4"), ("ref_base", "u1"), ("base", "u1", (4,)), ("pad_", "u1", (3,)), ("total", "<i4"),
@@ -193,6 +193,8 @@ def load():
         "fzp_bam_open": (C.c_int, [CP, SZ, PP]),
         "fzp_bam_view_free": (None, [VP]),
         "fzp_bam_write": (C.c_int, [CP, SZ, I32, CP, SZ, I32, VP, VP, PP, PSZ]),
+        "fzp_bam_read_header": (C.c_int, [CP, PP, PSZ, VP, PP, PSZ]),
+        "fzp_bam_route": (C.c_int, [I32, VP, C.c_int64, VP, CP, VP, I32, VP, CP, SZ, I32, CP, SZ, VP, VP]),
         "fzp_ovl_parse": (C.c_int, [VP, I32, VP, VP, CP, SZ, PP]),
         "fzp_ovlset_free": (None, [VP]),
         "fzp_ovl_n_lines": (I64, [VP]),
@@ -797,6 +799,30 @@ def bam_write(header: bytes, n_ref: int, ref_block: bytes, parts) -> bytes:
     out, ol = C.c_void_p(), C.c_size_t()
     _check(load().fzp_bam_write(header, len(header), n_ref, ref_block, len(ref_block), n, arr, lens, C.byref(out), C.byref(ol)))
     return _take_text(out, ol)
+
+
+def bam_read_header(path: str):
+    """(header text, n_ref, reference block) of a BAM file; only its first BGZF blocks are decoded (fzp_bam_read_header)"""
+    tp, tl, rp, rl, nr = C.c_void_p(), C.c_size_t(), C.c_void_p(), C.c_size_t(), C.c_int32()
+    _check(load().fzp_bam_read_header(os.fsencode(path), C.byref(tp), C.byref(tl), C.cast(C.byref(nr), C.c_void_p), C.byref(rp), C.byref(rl)))
+    return _take_text(tp, tl), int(nr.value), _take_text(rp, rl)
+
+
+def bam_route(in_paths, names, name_dest, dest_paths, header: bytes, n_ref: int, ref_block: bytes):
+    """fzp_bam_route: stream the records of `in_paths` (in order) into `dest_paths[name_dest[i]]` by read name `names[i]` (bytes); bounded
+    memory whatever the input sizes.  -> (records written per destination, destinations in order of first use)"""
+    n_in, n_dest, n_names = len(in_paths), len(dest_paths), len(names)
+    ins = (C.c_char_p * max(1, n_in))(*[os.fsencode(p) for p in in_paths])
+    outs = (C.c_char_p * max(1, n_dest))(*[os.fsencode(p) for p in dest_paths])
+    off = np.zeros(n_names + 1, np.int64)
+    off[1:] = np.cumsum([len(x) for x in names])
+    blob = b"".join(names)
+    dest = np.ascontiguousarray(name_dest, dtype=np.int32)
+    cnt = np.zeros(max(1, n_dest), np.int64)
+    first = np.full(max(1, n_dest), -1, np.int32)
+    _check(load().fzp_bam_route(n_in, ins, n_names, _ptr(off), blob, _ptr(dest) if n_names else None, n_dest, outs, header, len(header), n_ref, ref_block, len(ref_block),
+                                _ptr(cnt), _ptr(first)))
+    return cnt[:n_dest], [int(d) for d in first[:n_dest] if d >= 0]
 
 
 class OvlSet:

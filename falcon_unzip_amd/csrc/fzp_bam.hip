@@ -8,6 +8,8 @@
 // Formats per the SAM/BAM specification (SAMv1 sections 4.1, 4.2, 5.2); zlib does the deflate.
 #include <zlib.h>
 #include <algorithm>
+#include <cerrno>
+#include <unordered_map>
 #include "fzp_common.h"
 
 namespace {
@@ -393,4 +395,197 @@ extern "C" int fzp_bam_write(const char *header_text, size_t header_len, int32_t
     }
     FZP_TRY(z.finish());
     return give(z.out.v, bam, bam_len);
+}
+
+// ---- streaming routing of whole records from many BAM files into per-destination BAM files (select_reads_from_bam.py:69-90 does this
+// record by record through pysam).  Memory is bounded by one BGZF block per open input and one pending block per destination: input
+// files of any size go through; a destination's bytes are appended to its file as its blocks fill (opened per append: no descriptor is
+// held between blocks, so thousands of destinations are fine).
+namespace {
+struct BgzfIn {
+    FILE *f = nullptr;
+    std::string path;
+    std::vector<uint8_t> buf, blk;       // decoded bytes not yet consumed (from `at`), one compressed block
+    size_t at = 0;
+    bool eof = false;
+    ~BgzfIn() { if (f) fclose(f); }
+    int open(const char *p) {
+        path = p;
+        f = fopen(p, "rb");
+        if (!f) { fzp_set_error("cannot open %s: %s", p, strerror(errno)); return FZP_EIO; }
+        return FZP_OK;
+    }
+    // decode the next block behind the unconsumed bytes
+    int fill() {
+        if (at) { buf.erase(buf.begin(), buf.begin() + (long)at); at = 0; }
+        uint8_t h[12];
+        const size_t got = fread(h, 1, 12, f);
+        if (got == 0) { eof = true; return FZP_OK; }
+        if (got < 12 || h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) { fzp_set_error("%s: not a BGZF block", path.c_str()); return FZP_EINVAL; }
+        const size_t xlen = h[10] | (h[11] << 8);
+        blk.resize(xlen);
+        if (fread(blk.data(), 1, xlen, f) != xlen) { fzp_set_error("%s: truncated BGZF block", path.c_str()); return FZP_EINVAL; }
+        size_t bsize = 0;
+        for (size_t x = 0; x + 4 <= xlen;) {
+            const size_t slen = blk[x + 2] | (blk[x + 3] << 8);
+            if (blk[x] == 'B' && blk[x + 1] == 'C' && slen == 2 && x + 6 <= xlen) bsize = (size_t)(blk[x + 4] | (blk[x + 5] << 8)) + 1;
+            x += 4 + slen;
+        }
+        if (bsize < 12 + xlen + 8) { fzp_set_error("%s: BGZF block without a BC field", path.c_str()); return FZP_EINVAL; }
+        const size_t rest = bsize - 12 - xlen;
+        blk.resize(rest);
+        if (fread(blk.data(), 1, rest, f) != rest) { fzp_set_error("%s: truncated BGZF block", path.c_str()); return FZP_EINVAL; }
+        const uint8_t *tail = blk.data() + rest - 8;
+        const uint32_t crc = tail[0] | (tail[1] << 8) | (tail[2] << 16) | ((uint32_t)tail[3] << 24);
+        const uint32_t isize = tail[4] | (tail[5] << 8) | (tail[6] << 16) | ((uint32_t)tail[7] << 24);
+        if (isize > 65536) { fzp_set_error("%s: BGZF block claims %u bytes (limit 65536)", path.c_str(), isize); return FZP_EINVAL; }
+        if (!isize) return FZP_OK;
+        const size_t o = buf.size();
+        buf.resize(o + isize);
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        if (inflateInit2(&zs, -15) != Z_OK) { fzp_set_error("inflateInit2 failed"); return FZP_ENOMEM; }
+        zs.next_in = blk.data(); zs.avail_in = (uInt)(rest - 8);
+        zs.next_out = buf.data() + o; zs.avail_out = isize;
+        const int rc = inflate(&zs, Z_FINISH);
+        inflateEnd(&zs);
+        if (rc != Z_STREAM_END || zs.avail_out != 0 || (uint32_t)crc32(crc32(0L, Z_NULL, 0), buf.data() + o, isize) != crc) { fzp_set_error("%s: corrupt BGZF block", path.c_str()); return FZP_EINVAL; }
+        return FZP_OK;
+    }
+    // at least n unconsumed bytes, unless the file ends first
+    int need(size_t n) {
+        while (buf.size() - at < n && !eof) FZP_TRY(fill());
+        return FZP_OK;
+    }
+    size_t have() const { return buf.size() - at; }
+    const uint8_t *ptr() const { return buf.data() + at; }
+    static int32_t rd32(const uint8_t *p) { return (int32_t)(p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24)); }
+    // magic, header text, reference block; leaves the stream at the first record
+    int header(std::string &text, int32_t &n_ref, std::vector<uint8_t> &refs) {
+        FZP_TRY(need(12));
+        if (have() < 12 || memcmp(ptr(), "BAM\1", 4) != 0) { fzp_set_error("%s: not a BAM stream", path.c_str()); return FZP_EINVAL; }
+        const int32_t l_text = rd32(ptr() + 4);
+        if (l_text < 0) { fzp_set_error("%s: bad BAM header", path.c_str()); return FZP_EINVAL; }
+        FZP_TRY(need(8 + (size_t)l_text + 4));
+        if (have() < 8 + (size_t)l_text + 4) { fzp_set_error("%s: truncated BAM header", path.c_str()); return FZP_EINVAL; }
+        size_t tl = (size_t)l_text;
+        while (tl && ptr()[8 + tl - 1] == 0) tl--;                      // l_text may count NUL padding
+        text.assign((const char *)ptr() + 8, tl);
+        n_ref = rd32(ptr() + 8 + l_text);
+        at += 8 + (size_t)l_text + 4;
+        refs.clear();
+        for (int32_t i = 0; i < n_ref; i++) {
+            FZP_TRY(need(4));
+            if (have() < 4) { fzp_set_error("%s: truncated BAM reference list", path.c_str()); return FZP_EINVAL; }
+            const int32_t ln = rd32(ptr());
+            if (ln < 1) { fzp_set_error("%s: bad BAM reference list", path.c_str()); return FZP_EINVAL; }
+            FZP_TRY(need(8 + (size_t)ln));
+            if (have() < 8 + (size_t)ln) { fzp_set_error("%s: truncated BAM reference list", path.c_str()); return FZP_EINVAL; }
+            refs.insert(refs.end(), ptr(), ptr() + 8 + ln);
+            at += 8 + (size_t)ln;
+        }
+        return FZP_OK;
+    }
+};
+
+struct BamOut {
+    std::string path;
+    Bgzf z;
+    bool created = false;
+    int64_t n_rec = 0;
+    int spill() {
+        if (z.out.v.empty()) return FZP_OK;
+        FILE *f = fopen(path.c_str(), created ? "ab" : "wb");
+        if (!f) { fzp_set_error("cannot write %s: %s", path.c_str(), strerror(errno)); return FZP_EIO; }
+        const bool ok = fwrite(z.out.v.data(), 1, z.out.v.size(), f) == z.out.v.size();
+        const int e = errno;
+        if (fclose(f) != 0 || !ok) { fzp_set_error("write to %s failed: %s", path.c_str(), strerror(ok ? errno : e)); return FZP_EIO; }
+        created = true;
+        z.out.v.clear();
+        return FZP_OK;
+    }
+};
+}  // namespace
+
+extern "C" int fzp_bam_read_header(const char *path, char **text, size_t *text_len, int32_t *n_ref, uint8_t **ref_block, size_t *ref_block_len) {
+    if (!path || !text || !text_len || !n_ref || !ref_block || !ref_block_len) { fzp_set_error("fzp_bam_read_header: bad arguments"); return FZP_EINVAL; }
+    BgzfIn in;
+    FZP_TRY(in.open(path));
+    std::string t;
+    std::vector<uint8_t> refs;
+    FZP_TRY(in.header(t, *n_ref, refs));
+    char *tp = (char *)malloc(t.size() + 1);
+    if (!tp) return FZP_ENOMEM;
+    memcpy(tp, t.data(), t.size());
+    tp[t.size()] = 0;
+    size_t rl = 0;
+    int rc = give(refs, ref_block, &rl);
+    if (rc) { free(tp); return rc; }
+    *text = tp; *text_len = t.size(); *ref_block_len = rl;
+    return FZP_OK;
+}
+
+extern "C" int fzp_bam_route(int32_t n_in, const char *const *in_paths, int64_t n_names, const int64_t *name_off, const char *names, const int32_t *name_dest,
+                             int32_t n_dest, const char *const *dest_paths, const char *header_text, size_t header_len, int32_t n_ref, const uint8_t *ref_block,
+                             size_t ref_block_len, int64_t *dest_records, int32_t *first_use) {
+    if (n_in < 0 || (n_in && !in_paths) || n_names < 0 || (n_names && (!name_off || !names || !name_dest)) || n_dest < 0 || (n_dest && !dest_paths) ||
+        (!header_text && header_len) || n_ref < 0 || (!ref_block && ref_block_len)) {
+        fzp_set_error("fzp_bam_route: bad arguments");
+        return FZP_EINVAL;
+    }
+    std::unordered_map<std::string, int32_t> where;
+    where.reserve((size_t)n_names * 2);
+    for (int64_t i = 0; i < n_names; i++) {
+        if (name_dest[i] < 0 || name_dest[i] >= n_dest) { fzp_set_error("fzp_bam_route: name %lld has destination %d of %d", (long long)i, name_dest[i], n_dest); return FZP_EINVAL; }
+        where.emplace(std::string(names + name_off[i], (size_t)(name_off[i + 1] - name_off[i])), name_dest[i]);
+    }
+    std::vector<BamOut> outs((size_t)n_dest);
+    int32_t n_used = 0;
+    for (int32_t d = 0; d < n_dest; d++) { outs[(size_t)d].path = dest_paths[d]; if (first_use) first_use[d] = -1; if (dest_records) dest_records[d] = 0; }
+    std::string key;
+    for (int32_t k = 0; k < n_in; k++) {
+        BgzfIn in;
+        FZP_TRY(in.open(in_paths[k]));
+        std::string t;
+        int32_t nr = 0;
+        std::vector<uint8_t> refs;
+        FZP_TRY(in.header(t, nr, refs));
+        for (;;) {
+            FZP_TRY(in.need(4));
+            if (in.have() == 0) break;
+            if (in.have() < 4) { fzp_set_error("%s: truncated BAM record", in.path.c_str()); return FZP_EINVAL; }
+            const int32_t bs = BgzfIn::rd32(in.ptr());
+            if (bs < 32) { fzp_set_error("%s: malformed BAM record", in.path.c_str()); return FZP_EINVAL; }
+            FZP_TRY(in.need(4 + (size_t)bs));
+            if (in.have() < 4 + (size_t)bs) { fzp_set_error("%s: truncated BAM record", in.path.c_str()); return FZP_EINVAL; }
+            const uint8_t *r = in.ptr();
+            const uint32_t l_name = r[4 + 8];
+            if (l_name < 1 || 32 + (size_t)l_name > (size_t)bs) { fzp_set_error("%s: malformed BAM record", in.path.c_str()); return FZP_EINVAL; }
+            key.assign((const char *)r + 4 + 32, l_name - 1);
+            auto it = where.find(key);
+            if (it != where.end()) {
+                BamOut &o = outs[(size_t)it->second];
+                if (o.n_rec == 0) {                                    // first record of this destination: header first, records from a block boundary
+                    Bytes h;
+                    h.raw("BAM\1", 4); h.u32((uint32_t)header_len); h.raw(header_text, header_len); h.u32((uint32_t)n_ref); h.raw(ref_block, ref_block_len);
+                    FZP_TRY(o.z.write(h.v.data(), h.v.size()));
+                    FZP_TRY(o.z.flush());
+                    if (first_use) first_use[n_used] = it->second;
+                    n_used++;
+                }
+                FZP_TRY(o.z.write(r, 4 + (size_t)bs));
+                o.n_rec++;
+                if (o.z.out.v.size() >= (1u << 20)) FZP_TRY(o.spill());
+            }
+            in.at += 4 + (size_t)bs;
+        }
+    }
+    for (int32_t d = 0; d < n_dest; d++) {
+        BamOut &o = outs[(size_t)d];
+        if (!o.n_rec) continue;
+        FZP_TRY(o.z.finish());
+        FZP_TRY(o.spill());
+        if (dest_records) dest_records[d] = o.n_rec;
+    }
+    return FZP_OK;
 }

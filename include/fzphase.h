@@ -47,6 +47,7 @@ extern "C" {
                                (`--bam path to sorted bam file`, phasing.py:562); refused */
 #define FZP_EDEVICE (-5)    /* HIP runtime error */
 #define FZP_ENODEVICE (-6)  /* no gfx950 device / library built without device code */
+#define FZP_EIO (-7)        /* a file could not be opened, read or written (the message carries the path and strerror) */
 
 /* BAM CIGAR op numbering; a cigar word is  len << 4 | op  */
 enum { FZP_OP_M = 0, FZP_OP_I = 1, FZP_OP_D = 2, FZP_OP_N = 3, FZP_OP_S = 4, FZP_OP_H = 5, FZP_OP_P = 6,
@@ -371,6 +372,18 @@ int fzp_bam_open(const uint8_t *bam, size_t len, fzp_bam_view **out);
 void fzp_bam_view_free(fzp_bam_view *v);
 int fzp_bam_write(const char *header_text, size_t header_len, int32_t n_ref, const uint8_t *ref_block, size_t ref_block_len, int32_t n_parts,
                   const uint8_t *const *parts, const size_t *part_lens, uint8_t **bam, size_t *bam_len);
+/* the same job for inputs of ANY size (select_reads_from_bam.py:69-90 streams record by record through pysam; subreads BAMs are tens of GB):
+ * fzp_bam_read_header decodes only the first BGZF blocks of a file (header text without NUL padding, the reference block: n_ref x
+ * {l_name, name, l_ref}); fzp_bam_route reads the inputs in order, one BGZF block at a time, and appends every record whose read name is in
+ * the table (names[name_off[i] .. name_off[i+1]) -> destination name_dest[i]) to that destination's BAM -- header_text / ref_block first,
+ * records from a block boundary, EOF marker at the end; a destination that receives no record gets no file.  Memory: one block per input
+ * being read + one pending block per destination; no file descriptor is held between a destination's appends.
+ * dest_records[n_dest] (optional) = records written per destination; first_use[n_dest] (optional) = destinations in the order they
+ * received their first record, -1 padded.  FZP_EIO if a file cannot be opened / read / written, FZP_EINVAL on a malformed BAM. */
+int fzp_bam_read_header(const char *path, char **text /* fzp_free */, size_t *text_len, int32_t *n_ref, uint8_t **ref_block /* fzp_free */, size_t *ref_block_len);
+int fzp_bam_route(int32_t n_in, const char *const *in_paths, int64_t n_names, const int64_t *name_off, const char *names, const int32_t *name_dest,
+                  int32_t n_dest, const char *const *dest_paths, const char *header_text, size_t header_len, int32_t n_ref, const uint8_t *ref_block,
+                  size_t ref_block_len, int64_t *dest_records, int32_t *first_use);
 
 /* ======================================================================== overlap filter ("next" row n2)
  * falcon_unzip/ovlp_filter_with_phase.py: the consumer of rid_to_phase.all.  It reads `LA4Falcon -mo` text
