@@ -100,7 +100,7 @@ class AlignParams(C.Structure):
 _lib = None
 
 
-PIPE_CONSENSUS, PIPE_ASYNC_WRITES, PIPE_REBUILD_INDEX = 1, 2, 4
+PIPE_CONSENSUS, PIPE_ASYNC_WRITES, PIPE_REBUILD_INDEX, PIPE_BAM, PIPE_SENTINELS = 1, 2, 4, 8, 16
 TEXT_VARIANT_MAP, TEXT_ATABLE = 1, 2
 
 
@@ -523,11 +523,13 @@ class AlignJob:
         idx = _take(ip.value, a.n_rec, np.int64)
         return a, idx
 
-    def phase_write(self, ctg_ids, names=None, out_dir=None, read_maps=None, ctg_index=None, n_threads=0, consensus=False, async_writes=False, rebuild_index=False):
+    def phase_write(self, ctg_ids, names=None, out_dir=None, read_maps=None, ctg_index=None, n_threads=0, consensus=False, async_writes=False, rebuild_index=False,
+                    bam=False, sentinels=False):
         """fzp_job_phase_write: K1 -> K5 of every contig of the job, every file of every contig under out_dir, rid_to_phase records.
         names: (name_off int64 [n_reads+1], blob) or a list; read_maps: (rawread_ids, pread_ids, pread_to_contigs) bytes.  -> (stats dict, R2P records)"""
         nm, opts, keep = _pipe_args(ctg_ids, names, out_dir, read_maps, ctg_index, n_threads, 0, 0, None,
-                                    (PIPE_CONSENSUS if consensus else 0) | (PIPE_ASYNC_WRITES if async_writes else 0) | (PIPE_REBUILD_INDEX if rebuild_index else 0))
+                                    (PIPE_CONSENSUS if consensus else 0) | (PIPE_ASYNC_WRITES if async_writes else 0) | (PIPE_REBUILD_INDEX if rebuild_index else 0)
+                                    | (PIPE_BAM if bam else 0) | (PIPE_SENTINELS if sentinels else 0))
         out = PipeOut()
         _check(load().fzp_job_phase_write(self.eng._p, self._p, C.byref(nm), C.byref(opts), C.byref(out)))
         return _pipe_result(out)
@@ -637,9 +639,10 @@ def _pipe_result(out):
 
 
 def phase_contigs(eng, contigs, read_blob: bytes, read_off, read_ctg, ctg_ids, names=None, out_dir=None, read_maps=None, ctg_index=None,
-                  n_threads=0, n_lanes=0, group_bases=0, params=None, consensus=False, async_writes=False):
+                  n_threads=0, n_lanes=0, group_bases=0, params=None, consensus=False, async_writes=False, bam=False, sentinels=False):
     """fzp_phase_contigs: inputs in host memory -> every file of every contig + rid_to_phase records; contig groups are streamed through the
-    device on `n_lanes` lanes.  -> (stats dict, R2P records)"""
+    device on `n_lanes` lanes.  bam: also <ctg>/blasr/<ctg>_sorted.bam(.bai) from the same alignment pass; sentinels: the job_done files
+    of the reference's two per-contig tasks.  -> (stats dict, R2P records)"""
     lib = load()
     nc = len(contigs)
     read_off = np.ascontiguousarray(read_off, dtype=np.int64)
@@ -647,7 +650,7 @@ def phase_contigs(eng, contigs, read_blob: bytes, read_off, read_ctg, ctg_ids, n
     cbufs, cptr, clen = _contig_ptrs(contigs)
     rc = np.ascontiguousarray(read_ctg, dtype=np.int32)
     nm, opts, keep = _pipe_args(ctg_ids, names, out_dir, read_maps, ctg_index, n_threads, n_lanes, group_bases, params,
-                                (PIPE_CONSENSUS if consensus else 0) | (PIPE_ASYNC_WRITES if async_writes else 0))
+                                (PIPE_CONSENSUS if consensus else 0) | (PIPE_ASYNC_WRITES if async_writes else 0) | (PIPE_BAM if bam else 0) | (PIPE_SENTINELS if sentinels else 0))
     out = PipeOut()
     _check(lib.fzp_phase_contigs(eng._p, nc, cptr, clen, nr, _ptr(rc), _ptr(read_off), read_blob, C.byref(nm), C.byref(opts), C.byref(out)))
     return _pipe_result(out)

@@ -1837,14 +1837,50 @@ T *dupv(const std::vector<T> &v) {
 }
 }  // namespace
 
-static int align_alnset(fzp_ctx *ctx, fzp_alnjob *j, int32_t ctg, const int64_t *name_off, const char *names, fzp_alnset **out, int64_t **read_index, bool apply_filters);
+static int align_alnset(fzp_ctx *ctx, fzp_alnjob *j, int32_t ctg, const int64_t *name_off, const char *names, fzp_alnset **out, int64_t **read_index, bool apply_filters,
+                        std::vector<int32_t> *flags_out, std::shared_ptr<std::vector<uint8_t>> *ref_out);
 extern "C" int fzp_align_alnset(fzp_ctx *ctx, fzp_alnjob *j, int32_t ctg, const int64_t *name_off, const char *names, fzp_alnset **out, int64_t **read_index) {
-    return align_alnset(ctx, j, ctg, name_off, names, out, read_index, true);
+    return align_alnset(ctx, j, ctg, name_off, names, out, read_index, true, nullptr, nullptr);
 }
 extern "C" int fzp_align_alnset_all(fzp_ctx *ctx, fzp_alnjob *j, int32_t ctg, const int64_t *name_off, const char *names, fzp_alnset **out, int64_t **read_index) {
-    return align_alnset(ctx, j, ctg, name_off, names, out, read_index, false);
+    return align_alnset(ctx, j, ctg, name_off, names, out, read_index, false, nullptr, nullptr);
 }
-static int align_alnset(fzp_ctx *ctx, fzp_alnjob *j, int32_t ctg, const int64_t *name_off, const char *names, fzp_alnset **out, int64_t **read_index, bool apply_filters) {
+// every aligned read's record with the device's 'M' CIGARs (no '=' / 'X' split yet), the strand flags of the records and a copy of the upper-cased
+// contig: what fzp_pipe.hip hands to a writer thread, which splits (fzp_alnset_split_eqx) and compresses the BAM while the device goes on
+int fzp_align_alnset_unsplit(fzp_ctx *ctx, fzp_alnjob *j, int32_t ctg, const int64_t *name_off, const char *names, fzp_alnset **out, std::vector<int32_t> *flags,
+                             std::shared_ptr<std::vector<uint8_t>> *ref) {
+    return align_alnset(ctx, j, ctg, name_off, names, out, nullptr, false, flags, ref);
+}
+// device CIGARs carry diagonal runs as 'M'; split them into '=' / 'X' against the contig (host only: any thread)
+void fzp_alnset_split_eqx(fzp_alnset *a, const uint8_t *ref) {
+    std::vector<uint32_t> out_c;
+    std::vector<int64_t> out_off(1, 0);
+    out_c.reserve((size_t)a->cig_off[a->n_rec] * 2);
+    for (int64_t k = 0; k < a->n_rec; k++) {
+        int64_t rp = a->rec_pos[k], qp = 0;
+        const uint8_t *sq = a->seq + a->seq_off[k];
+        for (int64_t w = a->cig_off[k]; w < a->cig_off[k + 1]; w++) {
+            const uint32_t len = a->cigar[w] >> 4, op = a->cigar[w] & 15u;
+            if (op != FZP_OP_M) {
+                out_c.push_back(a->cigar[w]);
+                if (op == FZP_OP_S || op == FZP_OP_I) qp += len; else if (op == FZP_OP_D) rp += len;
+                continue;
+            }
+            uint32_t run = 0; int cur = -1;
+            for (uint32_t x = 0; x < len; x++, rp++, qp++) {
+                const int eq = code_of(sq[qp]) == code_of(ref[(size_t)rp]) ? FZP_OP_EQ : FZP_OP_X;
+                if (eq == cur) run++;
+                else { if (run) out_c.push_back((run << 4) | (uint32_t)cur); cur = eq; run = 1; }
+            }
+            if (run) out_c.push_back((run << 4) | (uint32_t)cur);
+        }
+        out_off.push_back((int64_t)out_c.size());
+    }
+    free(a->cigar); free(a->cig_off);
+    a->cigar = dupv(out_c); a->cig_off = dupv(out_off);
+}
+static int align_alnset(fzp_ctx *ctx, fzp_alnjob *j, int32_t ctg, const int64_t *name_off, const char *names, fzp_alnset **out, int64_t **read_index, bool apply_filters,
+                        std::vector<int32_t> *flags_out, std::shared_ptr<std::vector<uint8_t>> *ref_out) {
     if (!ctx || !j || !j->done || !out || ctg < 0 || ctg >= j->n_ctg) { fzp_set_error("fzp_align_alnset: bad arguments or job not run"); return FZP_EINVAL; }
     FZP_TRY(fzp_bind(ctx));
     FZP_TRY(fetch_summaries(ctx, j));
@@ -1867,38 +1903,20 @@ static int align_alnset(fzp_ctx *ctx, fzp_alnjob *j, int32_t ctg, const int64_t 
     if (!rc) rc = seq.download(a->seq, (size_t)p.seq_off.back(), st);
     if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = FZP_EDEVICE;
     if (!rc) {
-        // device CIGARs carry diagonal runs as 'M'; split them into '=' / 'X' against the contig here
         std::vector<uint8_t> &ref = j->h_ctg[(size_t)ctg];
         if (ref.size() != (size_t)j->h_ctg_len[(size_t)ctg]) {              // first use: the upper-cased contig comes back from the device
             ref.resize((size_t)j->h_ctg_len[(size_t)ctg]);
             if (!ref.empty() && (hipMemcpyAsync(ref.data(), j->ctg_ascii.p + j->h_ctg_aoff[(size_t)ctg], ref.size(), hipMemcpyDeviceToHost, st) != hipSuccess ||
                                  hipStreamSynchronize(st) != hipSuccess)) rc = FZP_EDEVICE;
         }
-        std::vector<uint32_t> out_c;
-        std::vector<int64_t> out_off(1, 0);
-        out_c.reserve((size_t)p.cig_off.back() * 2);
-        for (int64_t k = 0; k < nrec; k++) {
-            int64_t rp = a->rec_pos[k], qp = 0;
-            const uint8_t *sq = a->seq + a->seq_off[k];
-            for (int64_t w = a->cig_off[k]; w < a->cig_off[k + 1]; w++) {
-                const uint32_t len = a->cigar[w] >> 4, op = a->cigar[w] & 15u;
-                if (op != FZP_OP_M) {
-                    out_c.push_back(a->cigar[w]);
-                    if (op == FZP_OP_S || op == FZP_OP_I) qp += len; else if (op == FZP_OP_D) rp += len;
-                    continue;
-                }
-                uint32_t run = 0; int cur = -1;
-                for (uint32_t x = 0; x < len; x++, rp++, qp++) {
-                    const int eq = code_of(sq[qp]) == code_of(ref[(size_t)rp]) ? FZP_OP_EQ : FZP_OP_X;
-                    if (eq == cur) run++;
-                    else { if (run) out_c.push_back((run << 4) | (uint32_t)cur); cur = eq; run = 1; }
-                }
-                if (run) out_c.push_back((run << 4) | (uint32_t)cur);
-            }
-            out_off.push_back((int64_t)out_c.size());
+        if (!rc && ref_out) {
+            *ref_out = std::make_shared<std::vector<uint8_t>>(std::move(ref));   // the writer's copy is the only one kept
+            ref.clear();
+        } else if (!rc) fzp_alnset_split_eqx(a, ref.data());
+        if (!rc && flags_out) {
+            flags_out->resize((size_t)nrec);
+            for (int64_t k = 0; k < nrec; k++) (*flags_out)[(size_t)k] = j->h_summ[(size_t)p.rec_read[(size_t)k]].strand ? 16 : 0;
         }
-        free(a->cigar); free(a->cig_off);
-        a->cigar = dupv(out_c); a->cig_off = dupv(out_off);
     }
     // q_id table: every aligned read of the contig, in sorted order (one SAM line each)
     const auto &ar = p.ctg_reads[0];

@@ -134,6 +134,11 @@ struct ProfScope {
 };
 int fzp_prof_flush(fzp_ctx *ctx);
 void fzp_writer_destroy(fzp_ctx *ctx);   // fzp_pipe.hip
+// fzp_align.hip, for fzp_pipe.hip's BAM by-product: the records of every aligned read with 'M' CIGARs + strand flags + a copy of the contig (device
+// part, calling thread); the '=' / 'X' split is host-only and runs on a writer thread
+int fzp_align_alnset_unsplit(fzp_ctx *ctx, fzp_alnjob *j, int32_t ctg, const int64_t *name_off, const char *names, fzp_alnset **out, std::vector<int32_t> *flags,
+                             std::shared_ptr<std::vector<uint8_t>> *ref);
+void fzp_alnset_split_eqx(fzp_alnset *a, const uint8_t *ref);
 
 // ---------------------------------------------------------------- scans (fzp_scan.hip)
 // out[i] = sum_{j<i} in[j] over n uint32 items (in may alias out); *total_dev (device u64) gets the sum.

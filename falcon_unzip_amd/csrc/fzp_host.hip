@@ -33,6 +33,18 @@ std::unordered_map<void *, LiveBlock> g_live;        // every block handed out, 
 std::mutex g_def_mu;
 std::map<int, std::shared_ptr<DevPool>> g_default;   // per device: for threads that never bound a ctx
 thread_local std::shared_ptr<DevPool> t_pool;
+std::mutex g_pools_mu;
+std::vector<std::weak_ptr<DevPool>> g_pools;         // every pool ever made (contexts, lanes, defaults): the out-of-memory path trims ALL pools of the device
+std::shared_ptr<DevPool> new_pool(int dev) {
+    auto p = std::make_shared<DevPool>();
+    p->device = dev;
+    std::lock_guard<std::mutex> lk(g_pools_mu);
+    size_t keep = 0;
+    for (auto &w : g_pools) if (!w.expired()) g_pools[keep++] = w;
+    g_pools.resize(keep);
+    g_pools.push_back(p);
+    return p;
+}
 size_t bucket_of(size_t bytes) {
     if (bytes < 256) bytes = 256;
     size_t p2 = 256;
@@ -48,13 +60,22 @@ std::shared_ptr<DevPool> current_pool() {
     (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lk(g_def_mu);
     auto &p = g_default[dev];
-    if (!p) { p = std::make_shared<DevPool>(); p->device = dev; }
+    if (!p) p = new_pool(dev);
     return p;
 }
 void trim_pool(DevPool &P) {
-    std::lock_guard<std::mutex> lk(P.mu);
-    for (auto &kv : P.free_blocks) (void)hipFree(kv.second);
-    P.free_blocks.clear();
+    std::multimap<size_t, void *> drop;
+    { std::lock_guard<std::mutex> lk(P.mu); drop.swap(P.free_blocks); }
+    for (auto &kv : drop) (void)hipFree(kv.second);           // hipFree waits for the device: a cached block that is still read by a queued kernel is safe to drop
+}
+// idle sibling pools (the lane contexts of fzp_phase_contigs, a second engine) may hold most of HBM in their caches: give all of it back
+void trim_device_pools(int dev) {
+    std::vector<std::shared_ptr<DevPool>> all;
+    {
+        std::lock_guard<std::mutex> lk(g_pools_mu);
+        for (auto &w : g_pools) if (auto p = w.lock()) if (p->device == dev) all.push_back(p);
+    }
+    for (auto &p : all) trim_pool(*p);
 }
 }  // namespace
 int fzp_bind(fzp_ctx *ctx) {
@@ -74,8 +95,12 @@ void *fzp_dev_alloc(size_t bytes) {
     if (!p) {
         if (hipMalloc(&p, b) != hipSuccess) {
             (void)hipGetLastError();
-            trim_pool(*P);                             // retry once with the cache emptied
-            if (hipMalloc(&p, b) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+            trim_pool(*P);                             // retry with this pool's cache emptied ...
+            if (hipMalloc(&p, b) != hipSuccess) {
+                (void)hipGetLastError();
+                trim_device_pools(P->device);          // ... then with every pool of the device emptied (free lists only; live blocks stay)
+                if (hipMalloc(&p, b) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+            }
         }
     }
     std::lock_guard<std::mutex> lk(g_live_mu);
@@ -234,8 +259,7 @@ extern "C" int fzp_ctx_create(int device_id, unsigned flags, fzp_ctx **out) {
     }
     fzp_ctx *c = new fzp_ctx();
     c->device = device_id;
-    c->pool = std::make_shared<DevPool>();
-    c->pool->device = device_id;
+    c->pool = new_pool(device_id);
     c->n_cu = prop.multiProcessorCount;
     t_pool = c->pool;
     hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);

@@ -327,7 +327,7 @@ bool write_file(const std::string &path, const char *data, size_t n, std::atomic
     size_t off = 0;
     while (off < n) {
         ssize_t w = write(fd, data + off, n - off);
-        if (w < 0) { if (errno == EINTR) continue; close(fd); return false; }
+        if (w < 0) { if (errno == EINTR) continue; const int e = errno; close(fd); errno = e; return false; }
         off += (size_t)w;
     }
     close(fd);
@@ -408,6 +408,17 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
     FZP_HIP(hipEventSynchronize(ev_q.e));
     const int32_t *qid_read = (const int32_t *)(pin + o_qr);
     const ReadMaps *maps = mh.get();
+    // the blasr task's BAM from the same pass: records come down here (device part), are split into '=' / 'X' and compressed by the contig's write task
+    struct BamJob {
+        fzp_alnset *aln = nullptr; std::vector<int32_t> flags; std::shared_ptr<std::vector<uint8_t>> ref;
+        ~BamJob() { fzp_alnset_free(aln); }
+    };
+    const bool want_bam = (o->flags & FZP_PIPE_BAM) != 0 && o->out_dir, want_done = (o->flags & FZP_PIPE_SENTINELS) != 0 && o->out_dir;
+    std::vector<std::shared_ptr<BamJob>> bams((size_t)nc);
+    if (want_bam) for (int c = 0; c < nc; c++) {
+        bams[(size_t)c] = std::make_shared<BamJob>();
+        FZP_TRY(fzp_align_alnset_unsplit(ctx, job, c, nm->name_off, nm->names, &bams[(size_t)c]->aln, &bams[(size_t)c]->flags, &bams[(size_t)c]->ref));
+    }
     out->ms_results += ms_since(t0);
     t0 = clk::now();
     static const bool timing = getenv("FZP_PIPE_TIMING") != nullptr;
@@ -430,6 +441,8 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
     for (int c = 0; c < nc; c++) recs[(size_t)c].reserve((size_t)(b->h_qid_off[(size_t)c + 1] - b->h_qid_off[(size_t)c]) + 16);
     const std::string out_dir = o->out_dir ? o->out_dir : "";
     std::vector<std::function<bool()>> tasks((size_t)nc);     // per contig: write its files
+    std::vector<std::shared_ptr<std::string>> whys((size_t)nc);   // why a contig's write task failed, recorded by the thread it failed on
+    for (auto &w : whys) w = std::make_shared<std::string>();
     const std::function<void(int, int)> work = [&](int t, int c) {
         {
             if (rcs[(size_t)t] != FZP_OK) return;
@@ -480,17 +493,41 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
                 auto r2p_p = std::make_shared<std::string>(std::move(r2p_text));
                 std::atomic<int64_t> *bytes_p = &bytes;
                 FileWriter *fw = async ? ctx->writer : nullptr;
-                auto task = [owned, base, ctg_s, t0, t1, t2, pv, pa, l0, l1, l2, lv, la, qmap_p, r2p_p, have_r2p, want_cns, fa, fl, bytes_p, fw]() -> bool {
+                std::shared_ptr<BamJob> bam = bams[(size_t)c];
+                std::shared_ptr<std::string> why = whys[(size_t)c];
+                auto task = [owned, base, ctg_s, t0, t1, t2, pv, pa, l0, l1, l2, lv, la, qmap_p, r2p_p, have_r2p, want_cns, fa, fl, bytes_p, fw, bam, want_done, why]() -> bool {
                     std::atomic<int64_t> local{0};
                     std::atomic<int64_t> &bt = fw ? local : *bytes_p;
+                    const std::string aln_done = base + "/blasr/aln_" + ctg_s + "_done", p_done = base + "/phasing/p_" + ctg_s + "_done";
+                    auto failed = [&](const std::string &what) { *why = what; if (fw) fw->fail(what); return false; };      // the cause is taken where it happens, on this thread
+                    if (bam) {                                           // <ctg>_sorted.bam + index, then the blasr task's sentinels
+                        uint8_t *bb = nullptr, *bi = nullptr;
+                        size_t bl = 0, il = 0;
+                        bool okb = mkdir_p(base + "/blasr");
+                        std::string cause = okb ? "" : std::string("cannot create ") + base + "/blasr: " + strerror(errno);
+                        if (okb) {
+                            fzp_alnset_split_eqx(bam->aln, bam->ref->data());
+                            if (fzp_format_bam(bam->aln, ctg_s.c_str(), (int64_t)bam->ref->size(), bam->flags.data(), &bb, &bl, &bi, &il) != FZP_OK) { okb = false; cause = fzp_last_error(); }
+                        }
+                        if (okb && !(write_file(base + "/blasr/" + ctg_s + "_sorted.bam", (const char *)bb, bl, bt) && write_file(base + "/blasr/" + ctg_s + "_sorted.bam.bai", (const char *)bi, il, bt))) {
+                            okb = false; cause = std::string("cannot write under ") + base + "/blasr: " + strerror(errno);
+                        }
+                        free(bb); free(bi);
+                        if (want_done) { if (okb) (void)write_file(aln_done, "", 0, bt); (void)write_file(aln_done + ".exit", "", 0, bt); }
+                        if (!okb) {
+                            if (want_done) { (void)mkdir_p(base + "/phasing"); (void)write_file(p_done + ".exit", "", 0, bt); }      // the phasing task never ran
+                            return failed(cause);
+                        }
+                    }
                     bool ok = mkdir_p(base + "/het_call") && mkdir_p(base + "/g_atable") && mkdir_p(base + "/get_phased_blocks");
                     ok = ok && write_file(base + "/het_call/variant_pos", t0, l0, bt) && write_file(base + "/het_call/variant_map", pv, lv, bt) &&
                          write_file(base + "/het_call/q_id_map", qmap_p->data(), qmap_p->size(), bt) && write_file(base + "/g_atable/atable", pa, la, bt) &&
                          write_file(base + "/get_phased_blocks/phased_variants", t1, l1, bt) && write_file(base + "/phased_reads", t2, l2, bt);
                     if (ok && have_r2p) ok = write_file(base + "/rid_to_phase." + ctg_s, r2p_p->data(), r2p_p->size(), bt);
                     if (ok && want_cns) ok = mkdir_p(base + "/cns") && write_file(base + "/cns/phased_blocks.fa", fa, fl, bt);
-                    if (!ok && fw) fw->fail("cannot write under " + base + ": " + strerror(errno));
-                    return ok;
+                    const std::string cause = ok ? "" : "cannot write under " + base + ": " + strerror(errno);
+                    if (want_done && mkdir_p(base + "/phasing")) { if (ok) (void)write_file(p_done, "", 0, bt); (void)write_file(p_done + ".exit", "", 0, bt); }
+                    return ok ? true : failed(cause);
                 };
                 if (async) bytes += (int64_t)(l0 + l1 + l2 + lv + la + qmap_p->size() + (have_r2p ? r2p_p->size() : 0) + (want_cns ? fl : 0));     // what the queued task will write
                 tasks[(size_t)c] = task;        // run (or queued) below, once the big texts have arrived
@@ -511,7 +548,7 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
             std::atomic<int> failed{-1};
             const std::function<void(int, int)> wr = [&](int, int c) { if (tasks[(size_t)c] && !tasks[(size_t)c]()) failed.store(c); };
             ctx->workers->run(nc, wr, want_threads);
-            if (failed.load() >= 0) { fzp_set_error("cannot write under %s/%s: %s", out_dir.c_str(), nm->ctg_id[failed.load()], strerror(errno)); return FZP_EINVAL; }
+            if (failed.load() >= 0) { fzp_set_error("%s", whys[(size_t)failed.load()]->c_str()); return FZP_EIO; }
         }
     }
     for (int c = 0; c < nc; c++) r2p.insert(r2p.end(), recs[(size_t)c].begin(), recs[(size_t)c].end());
@@ -576,6 +613,18 @@ extern "C" int fzp_phase_contigs(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *con
         // as large as the device allows (long launches, few tails), but at least two groups per lane so that uploads and file
         // writes of one group hide behind the kernels of another
         group_bases = std::min<int64_t>((int64_t)((double)tot * 0.55 / lanes / 40.0), std::max<int64_t>(64ll << 20, all / (2 * lanes)));
+    }
+    {   // a contig is never split over groups (its reads are chunked inside K1 so that the trace-back masks fit); what must fit at once is
+        // the rest of its per-base state: ASCII + two packed copies + CIGAR room + hit lists ~ 8 B per read base
+        size_t fr = 0, tot = 0;
+        FZP_TRY(fzp_bind(ctx));
+        FZP_HIP(hipMemGetInfo(&fr, &tot));
+        for (int c = 0; c < n_ctg; c++)
+            if ((double)bases[(size_t)c] * 8.0 + (double)ctg_len[c] * 12.0 > 0.8 * (double)tot) {
+                fzp_set_error("fzp_phase_contigs: contig %s (%lld bp, %lld read bases) does not fit the device (%.0f GB) as one group", nm->ctg_id[c], (long long)ctg_len[c],
+                              (long long)bases[(size_t)c], (double)tot / 1e9);
+                return FZP_ENOMEM;
+            }
     }
     struct Group { int c0, c1; };
     std::vector<Group> groups;

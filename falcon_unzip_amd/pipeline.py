@@ -76,14 +76,23 @@ def load_read_maps(read_map_dir):
             _slurp(os.path.join(read_map_dir, "pread_to_contigs")))
 
 
-def phase_contigs(eng, jobs, unzip_dir, read_map_dir=None, write_sam=False, ctg_indices=None, consensus=True, n_lanes=0, group_bases=0):
+def _touch(path):
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, "a"):
+        pass
+
+
+def phase_contigs(eng, jobs, unzip_dir, read_map_dir=None, write_sam=False, ctg_indices=None, consensus=True, n_lanes=0, group_bases=0, sentinels=True):
     """K1 -> K5 (+ K6) for `jobs` (list of (ctg_id, ref bytes, [(read name, seq)])) on one GPU; writes the per-contig files;
     returns the rid_to_phase records of these contigs (empty unless read_map_dir is given).  ctg_indices: the contigs'
     indices in the job-wide sorted contig list.
 
-    Everything runs inside the library (fzp_phase_contigs: contig groups streamed through the device, files written by
-    its host threads).  write_sam=True additionally leaves the blasr task's artefacts (<ctg>_sorted.bam + .bai,
-    unzip.py:86-91): those need the alignment records on the host, one contig at a time."""
+    Everything runs inside the library in ONE alignment pass (fzp_phase_contigs: contig groups streamed through the device, files written
+    by its host threads).  write_sam=True additionally leaves the blasr task's artefacts (<ctg>/blasr/<ctg>_sorted.bam + .bai,
+    unzip.py:86-91) -- made from the same pass's records, group by group, compressed on the library's writer threads.  sentinels=True
+    leaves what an unchanged fc_unzip.py looks for to call the two per-contig tasks done (unzip.py:239-241,267-269):
+    <ctg>/blasr/aln_<ctg>_done (with write_sam) and <ctg>/phasing/p_<ctg>_done, each with its `.exit` twin (the scripts' `trap ... EXIT`,
+    unzip.py:81,120); if the call fails as a whole, every contig of it gets the `.exit` files only."""
     if ctg_indices is None:
         ctg_indices = list(range(len(jobs)))
     contigs = [j[1] for j in jobs]
@@ -105,26 +114,16 @@ def phase_contigs(eng, jobs, unzip_dir, read_map_dir=None, write_sam=False, ctg_
     maps = load_read_maps(read_map_dir) if read_map_dir is not None else None
     out_dir = os.path.join(unzip_dir, "0-phasing")
     os.makedirs(out_dir, exist_ok=True)
-    stats, recs = _lib.phase_contigs(eng, contigs, blob, offs, read_ctg, [j[0] for j in jobs], names=name_tab, out_dir=out_dir, read_maps=maps,
-                                     ctg_index=ctg_indices, n_lanes=n_lanes, group_bases=group_bases, consensus=consensus)
-    if write_sam:
-        job = _lib.align_job_raw(eng, contigs, blob, offs, read_ctg)
-        job.run()
-        summ = job.summaries()
-        for c, (ctg, ref, _) in enumerate(jobs):
-            base = os.path.join(out_dir, ctg, "blasr")
-            os.makedirs(base, exist_ok=True)
-            try:                                              # the BAM is a by-product: a failure to write it must not stop the phasing outputs
-                aln, idx = job.alnset(c, name_tab, all_records=True)
-                flags = (summ["strand"][idx] * 16).astype(np.int32)
-                bam, bai = _lib.format_bam(aln, ctg, len(ref), flags)
-                with open(os.path.join(base, "%s_sorted.bam" % ctg), "wb") as f:
-                    f.write(bam)
-                with open(os.path.join(base, "%s_sorted.bam.bai" % ctg), "wb") as f:
-                    f.write(bai)
-            except (_lib.FzpError, OSError) as e:
-                sys.stderr.write("[fzphase] %s: no BAM written (%s)\n" % (ctg, e))
-        job.close()
+    try:
+        stats, recs = _lib.phase_contigs(eng, contigs, blob, offs, read_ctg, [j[0] for j in jobs], names=name_tab, out_dir=out_dir, read_maps=maps,
+                                         ctg_index=ctg_indices, n_lanes=n_lanes, group_bases=group_bases, consensus=consensus, bam=write_sam, sentinels=sentinels)
+    except Exception:
+        if sentinels:                                          # the tasks exited without finishing: `.exit` only (contigs the library did finish keep their _done files)
+            for ctg, _, _ in jobs:
+                if write_sam:
+                    _touch(os.path.join(out_dir, ctg, "blasr", "aln_%s_done.exit" % ctg))
+                _touch(os.path.join(out_dir, ctg, "phasing", "p_%s_done.exit" % ctg))
+        raise
     phase_contigs.last_stats = stats
     return recs
 

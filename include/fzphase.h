@@ -298,6 +298,11 @@ int fzp_batch_text(fzp_ctx *ctx, fzp_batch *b, int what, char **text, size_t *le
                                      the caller goes on (e.g. with the next job's kernels); fzp_pipe_flush(ctx) waits for them and reports the first error */
 #define FZP_PIPE_REBUILD_INDEX 4u /* fzp_job_phase_write: build the contigs' k-mer tables again inside the call (fzp_align_create built them once; a job that
                                      sees its contigs once pays for them in its one run, and bench.py's step asks for exactly that) */
+#define FZP_PIPE_BAM 8u           /* also the blasr task's artefacts, from the SAME alignment pass: <ctg>/blasr/<ctg>_sorted.bam + .bai (unzip.py:86-91,239-240) with
+                                     every aligned read (fzp_align_alnset_all + fzp_format_bam); compressed on the writer threads */
+#define FZP_PIPE_SENTINELS 16u    /* the job_done files pypeflow looks for (unzip.py:241,268; scripts at unzip.py:81,94,120,128): <ctg>/phasing/p_<ctg>_done once every
+                                     phasing file of the contig is written, and with FZP_PIPE_BAM <ctg>/blasr/aln_<ctg>_done once the BAM is; `<job_done>.exit` is
+                                     touched whether or not the contig succeeded (the scripts' `trap ... EXIT`), `<job_done>` only on success */
 typedef struct {
     int32_t n_ctg;
     const char *const *ctg_id;     /* [n_ctg] names: directory names and the ctg column of phased_reads / rid_to_phase */

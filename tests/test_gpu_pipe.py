@@ -234,3 +234,55 @@ def test_pipeline_edge_cases(eng, tmp_path):
     # the engine still works afterwards
     st, recs = _lib.phase_contigs(eng, contigs, blob, off, read_ctg, ids, names=names, out_dir=str(tmp_path / "ok"), read_maps=maps)
     assert len(recs) == len(names)
+
+
+@pytest.mark.parametrize("async_writes", [False, True])
+def test_bam_and_sentinels_from_the_same_pass(eng, tmp_path, async_writes):
+    """FZP_PIPE_BAM | FZP_PIPE_SENTINELS: <ctg>/blasr/<ctg>_sorted.bam(.bai) are the bytes the per-contig route makes (alnset of every aligned
+    read + fzp_format_bam), written from the one alignment pass of the call, group by group; the job_done files of the reference's two tasks
+    (unzip.py:241,268) with their `.exit` twins (unzip.py:81,120) are there; a contig whose files cannot be written keeps the `.exit` files only."""
+    from falcon_unzip_amd import _lib
+    contigs, blob, off, read_ctg, names, ids = _make_job()
+    maps = _read_maps(names, read_ctg, ids)
+    exp, _ = _legacy(eng, contigs, blob, off, read_ctg, names, ids, maps)
+    job = _lib.align_job_raw(eng, contigs, blob, off, read_ctg)
+    job.run()
+    summ = job.summaries()
+    want = {}
+    enc = [n.encode() for n in names]
+    noff = np.zeros(len(enc) + 1, np.int64)
+    noff[1:] = np.cumsum([len(e) for e in enc])
+    for c, ctg in enumerate(ids):
+        aln, idx = job.alnset(c, (noff, b"".join(enc)), all_records=True)
+        want[ctg] = _lib.format_bam(aln, ctg, len(contigs[c]), (summ["strand"][idx] * 16).astype(np.int32))
+    job.close()
+    out = str(tmp_path / "o")
+    st, recs = _lib.phase_contigs(eng, contigs, blob, off, read_ctg, ids, names=names, out_dir=out, read_maps=maps, n_lanes=2, group_bases=1_500_000, bam=True, sentinels=True,
+                                  async_writes=async_writes)
+    eng.pipe_flush()
+    assert st["n_groups"] >= 2
+    _check_tree(out, exp, ids)
+    for ctg in ids:
+        base = os.path.join(out, ctg)
+        with open(os.path.join(base, "blasr", "%s_sorted.bam" % ctg), "rb") as f:
+            assert f.read() == want[ctg][0], ctg
+        with open(os.path.join(base, "blasr", "%s_sorted.bam.bai" % ctg), "rb") as f:
+            assert f.read() == want[ctg][1], ctg
+        for rel in ("blasr/aln_%s_done", "blasr/aln_%s_done.exit", "phasing/p_%s_done", "phasing/p_%s_done.exit"):
+            assert os.path.getsize(os.path.join(base, rel % ctg)) == 0
+    # sentinels without the BAM: only the phasing task's
+    out2 = str(tmp_path / "p")
+    _lib.phase_contigs(eng, contigs, blob, off, read_ctg, ids, names=names, out_dir=out2, read_maps=maps, sentinels=True, async_writes=async_writes)
+    eng.pipe_flush()
+    assert os.path.exists(os.path.join(out2, ids[0], "phasing", "p_%s_done" % ids[0])) and not os.path.exists(os.path.join(out2, ids[0], "blasr"))
+    # a contig whose het_call directory cannot be made (a FILE sits in its place): its task fails, `.exit` only; the error names the directory
+    out3 = str(tmp_path / "q")
+    os.makedirs(os.path.join(out3, ids[1]))
+    with open(os.path.join(out3, ids[1], "het_call"), "w") as f:
+        f.write("in the way\n")
+    with pytest.raises(_lib.FzpError) as ei:
+        _lib.phase_contigs(eng, contigs, blob, off, read_ctg, ids, names=names, out_dir=out3, read_maps=maps, bam=True, sentinels=True, async_writes=async_writes)
+        eng.pipe_flush()
+    assert ids[1] in str(ei.value) and "Success" not in str(ei.value)
+    assert os.path.exists(os.path.join(out3, ids[1], "phasing", "p_%s_done.exit" % ids[1])) and not os.path.exists(os.path.join(out3, ids[1], "phasing", "p_%s_done" % ids[1]))
+    assert os.path.exists(os.path.join(out3, ids[1], "blasr", "aln_%s_done" % ids[1]))          # the BAM itself was fine

@@ -59,6 +59,9 @@ def test_unzip_tree_end_to_end(tmp_path, oracle):
         assert (base / "blasr" / ("%s_sorted.bam.bai" % ctg)).read_bytes()[:4] == b"BAI\x01"
         sam = _lib.bam_to_sam(bam, ctg)                                     # `samtools view <bam> <ctg>` (phasing.py:27)
         assert sam.count(b"\n") >= 175
+        # what an unchanged fc_unzip.py checks to call the contig's two tasks done (unzip.py:239-241,267-269; `trap ... EXIT` at :81,:120)
+        for rel in ("blasr/aln_%s_done", "blasr/aln_%s_done.exit", "phasing/p_%s_done", "phasing/p_%s_done.exit"):
+            assert (base / (rel % ctg)).exists() and (base / (rel % ctg)).stat().st_size == 0, rel
         ref = sim.codes_to_str(sim.make_diploid(40000 + 5000 * ctgs.index(ctg), np.random.Generator(np.random.PCG64(100 + ctgs.index(ctg))), het_rate=1.0 / 300)[0]).encode()
         exp = oracle.phase_all(sam, ref, ctg)
         for rel, key in (("het_call/variant_pos", "variant_pos"), ("het_call/variant_map", "variant_map"), ("het_call/q_id_map", "q_id_map"),
