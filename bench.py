@@ -68,14 +68,27 @@ def gen_contig(args):
     return sim.ACGT[hap0].tobytes(), sim.ACGT[codes].tobytes(), off
 
 
-def make_inputs(cfg, contig_ids, L, reads_of, R, win, workers):
+def gen_contig_shaped(args):
+    """the same contig as gen_contig, with reads of real CLR shape (sim.simulate_raw_reads_shaped: log-normal lengths, bursty errors) adding up to about
+    the same number of bases"""
+    cfg, ci, L, n_reads, R, win = args
+    from falcon_unzip_amd import sim
+    rng = sim.rng_for(cfg, ci)
+    hap0, hap1, _ = sim.make_diploid(L, rng)
+    lo = int(rng.integers(0, L - win + 1))
+    lens = sim.lognormal_lengths(int(n_reads * R / 14200), rng)
+    codes, off, *_ = sim.simulate_raw_reads_shaped(hap0, hap1, len(lens), rng, lens=lens, lo=lo, hi=lo + win)
+    return sim.ACGT[hap0].tobytes(), sim.ACGT[codes].tobytes(), off
+
+
+def make_inputs(cfg, contig_ids, L, reads_of, R, win, workers, gen=None):
     """contig_ids: global contig indices this rank processes; reads_of(ci) -> number of reads of that contig"""
     jobs = [(cfg, ci, L, reads_of(ci), R, win) for ci in contig_ids]
     if workers > 1 and len(jobs) > 1:
         with mp.get_context("fork").Pool(min(workers, len(jobs))) as pool:     # before any GPU initialisation
-            res = pool.map(gen_contig, jobs)
+            res = pool.map(gen or gen_contig, jobs)
     else:
-        res = [gen_contig(j) for j in jobs]
+        res = [(gen or gen_contig)(j) for j in jobs]
     contigs = [r[0] for r in res]
     blob = b"".join(r[1] for r in res)
     offs, read_ctg, base = [np.zeros(1, np.int64)], [], 0
@@ -193,6 +206,41 @@ def roofline(cells_per_launch, sw_avg_ms, sw_launches, dp_gcells, traffic):
                                  "note": "issue rate this instruction mix can reach at the per-class costs of tools/ubench/valu_issue.hip (not the chip's peak)"}}
 
 
+def shaped_leg(eng, inp):
+    """K1 alone on the same contigs with reads of real CLR shape: k_sw's rate when read lengths are uneven, with the launch longest-first
+    (default) and in input order (FZP_SW_INPUT_ORDER=1, the r2 behaviour)."""
+    from falcon_unzip_amd import _lib
+    contigs, blob, off, read_ctg = inp
+    job = _lib.align_job_raw(eng, contigs, blob, off, read_ctg)
+    res = {}
+    for mode in ("longest_first", "input_order"):
+        if mode == "input_order":
+            os.environ["FZP_SW_INPUT_ORDER"] = "1"
+        try:
+            job.run()
+            eng.synchronize()
+            eng.prof_reset()
+            eng.prof_enable(True)
+            for _ in range(2):
+                job.run()
+            eng.synchronize()
+            eng.prof_enable(False)
+            pr = eng.prof()
+        finally:
+            os.environ.pop("FZP_SW_INPUT_ORDER", None)
+        summ = job.summaries()
+        sw_ms, sw_n = pr.get("k1_sw", (0.0, 0))
+        res[mode] = {"k1_sw_ms": round(sw_ms / max(1, sw_n), 3), "k1_traceback_ms": round(pr.get("k1_traceback", (0.0, 0))[0] / max(1, sw_n), 3),
+                     "dp_gcell_per_s": round(float(summ["cells"].sum()) / (sw_ms / max(1, sw_n) * 1e-3) / 1e9, 2) if sw_ms else 0.0}
+    lens = np.diff(off)
+    inside = (summ["q_end"] - summ["q_start"])[summ["aligned"] == 1]
+    job.close()
+    res.update({"reads": int(len(lens)), "read_len_min_median_max": [int(lens.min()), int(np.median(lens)), int(lens.max())], "aligned_frac": round(float(summ["aligned"].mean()), 4),
+                "bases_inside_alignments_frac": round(float(inside.sum()) / float(lens.sum()), 4),
+                "workload": "the step's contigs with log-normal read lengths (median 12 kb, 3-60 kb) and bursty errors (0.3-1 kb at 30 %, a quarter of the reads at their head), ~ the same bases; K1 only"})
+    return res
+
+
 def strong_inputs(args, rank, world, workers):
     """the strong_cfg3 leg's shard of this rank, generated BEFORE anything initialises the GPU (the generator forks workers)"""
     from falcon_unzip_amd import dist as fdist
@@ -288,6 +336,7 @@ def main():
     ap.add_argument("--cpu-budget-s", type=float, default=30.0, help="CPU seconds the cpu_baseline sample is sized for (whole contigs; all of them on a many-core host)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--index-at-create", action="store_true", help="leave the k-mer tables fzp_align_create built in place (r2's step); default: the step rebuilds them, as a job that sees its contigs once would")
+    ap.add_argument("--no-shaped-leg", action="store_true", help="skip the K1-only leg on reads of real CLR shape (log-normal lengths, bursty errors)")
     ap.add_argument("--strong-leg-contigs", type=int, default=500, help="N > 1 runs: contigs of the strong_cfg3 leg (0 = no such leg)")
     ap.add_argument("--strong-leg-contig-len", type=int, default=750_000)
     ap.add_argument("--no-end-to-end", action="store_true")
@@ -327,6 +376,9 @@ def main():
     ids = ["%06dF" % ci for ci in mine]
     arid_base = int(sum(reads_of(ci) for ci in range(mine[0]))) if (mine and not args.strong) else (1_000_000 * rank)
     name_tab, maps = make_names_and_maps(read_ctg, off, ids, arid_base)
+    shaped_inp = None
+    if rank == 0 and world == 1 and not args.strong and not args.no_shaped_leg:
+        shaped_inp = make_inputs(cfg, mine, args.contig_len, reads_of, args.read_len, win, workers, gen=gen_contig_shaped)      # before the GPU is touched (forks)
     s_inp = strong_inputs(args, rank, world, workers) if (world > 1 and not args.strong and args.strong_leg_contigs > 0) else None
 
     import torch
@@ -470,6 +522,10 @@ def main():
     if job is not None:
         job.close()
 
+    shaped = None
+    if shaped_inp is not None:
+        shaped = shaped_leg(eng, shaped_inp)
+        shaped_inp = None
     strong = None
     if world > 1 and not args.strong and args.strong_leg_contigs > 0:
         strong = strong_leg(args, rank, world, eng, comm, coll_dev, s_inp, out_root)
@@ -580,6 +636,8 @@ def main():
         }
         if cpu is not None:
             out["cpu_baseline"] = cpu
+        if shaped is not None:
+            out["k1_on_real_read_shape"] = shaped
         if strong is not None:
             out["strong_cfg3"] = strong
         print(json.dumps(out), flush=True)

@@ -735,11 +735,15 @@ __global__ void __launch_bounds__(64) k_sw(int64_t first, int64_t count, const i
                                             const int64_t *__restrict__ ori_woff, const int32_t *__restrict__ read_len, const int32_t *__restrict__ read_ctg,
                                             const uint32_t *__restrict__ ctg_pk, const int64_t *__restrict__ ctg_woff, const int64_t *__restrict__ ctg_len,
                                             const Anchor *__restrict__ anc, const int64_t *__restrict__ tb_off, uint2 *__restrict__ tb, ulonglong2 *__restrict__ mvw,
-                                            int match, int mismatch, int gap, DpInfo *__restrict__ info, int64_t *__restrict__ tbo, int64_t *__restrict__ mvo) {
+                                            int match, int mismatch, int gap, DpInfo *__restrict__ info, int64_t *__restrict__ tbo, int64_t *__restrict__ mvo,
+                                            const int32_t *__restrict__ order) {
     const int lane = lane_id();
     // wave-uniform on purpose: everything indexed by the read then lives in SGPRs / scalar loads
-    const int64_t wv = (int64_t)blockIdx.x;   // one wave per workgroup: a finished read frees its slot at once
-    if (wv >= count) return;
+    const int64_t wq = (int64_t)blockIdx.x;   // one wave per workgroup: a finished read frees its slot at once
+    if (wq >= count) return;
+    // workgroups start in blockIdx order, so `order` (slots by decreasing read length) makes the launch longest-first: the last
+    // waves to start are the shortest, and the tail of the grid is short however uneven the read lengths are
+    const int64_t wv = order ? (int64_t)order[wq] : wq;
     // slot = candidate: the read itself for first candidates, an entry of the compacted list for second ones
     const int64_t sl = first + wv;
     const int64_t r = ridx ? ridx[sl] : sl;
@@ -875,12 +879,15 @@ struct WalkOut { int32_t ok, i, ts, i_end, j_end, ncol, n_ops, pad_; };   // (i,
 __global__ void __launch_bounds__(64) k_tb_walk(int64_t first, int64_t count, const Anchor *__restrict__ anc, const DpInfo *__restrict__ info,
                                                 const int64_t *__restrict__ tb_off, const int64_t *__restrict__ tbo, const int64_t *__restrict__ mvo,
                                                 const ulonglong2 *__restrict__ tb, const ulonglong2 *__restrict__ mvw, uint32_t *__restrict__ raw,
-                                                WalkOut *__restrict__ wout) {
+                                                WalkOut *__restrict__ wout, const int32_t *__restrict__ order) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[TBW_RPW * TBW_STRIDE];
     const int lane = threadIdx.x;
-    const int64_t wv = (int64_t)blockIdx.x * TBW_RPW + lane;
-    const bool have = lane < TBW_RPW && wv < count;
-    const int64_t r = first + (have ? wv : 0);
+    const int64_t wq = (int64_t)blockIdx.x * TBW_RPW + lane;
+    const bool have = lane < TBW_RPW && wq < count;
+    // `order`: slots by decreasing read length -- the 16 reads of a wave are of similar length (a wave lasts as long as its longest walk)
+    // and the longest start first
+    const int64_t wv = have ? (order ? (int64_t)order[wq] : wq) : 0;
+    const int64_t r = first + wv;
     Anchor a = {0, 0, 0, 0};
     DpInfo di = {0, -1, 0, NEGV};
     if (have) { a = anc[r]; di = info[r]; }
@@ -1022,14 +1029,15 @@ __global__ void __launch_bounds__(64) k_tb_cigar(int64_t first, int64_t count, c
                                                  const DpInfo *__restrict__ info, const int64_t *__restrict__ tb_off, const uint32_t *__restrict__ raw,
                                                  const WalkOut *__restrict__ wout, const int64_t *__restrict__ cig_off, uint32_t *__restrict__ cig,
                                                  int64_t *__restrict__ cig_start, fzp_aln_summary *__restrict__ summ, int match, int mismatch, int gap,
-                                                 int min_pct_identity) {
+                                                 int min_pct_identity, const uint32_t *__restrict__ read_ori, const int64_t *__restrict__ read_woff,
+                                                 const int32_t *__restrict__ read_ctg, const uint32_t *__restrict__ ctg_pk, const int64_t *__restrict__ ctg_woff) {
     const int lane = lane_id();
     const int64_t wv = blockIdx.x;
     if (wv >= count) return;
     const int64_t r = first + wv;
     const Anchor a = anc[r];
     const DpInfo di = info[r];
-    const WalkOut w = wout[r];
+    WalkOut w = wout[r];
     const int32_t n = read_len[r];
     fzp_aln_summary out;
     memset(&out, 0, sizeof out);
@@ -1038,13 +1046,89 @@ __global__ void __launch_bounds__(64) k_tb_cigar(int64_t first, int64_t count, c
     if (!w.ok) { if (lane == 0) summ[r] = out; return; }
     const uint32_t *rg = raw + ((tb_off[r] - tb_off[first]) >> 4);
     uint32_t *reg = cig + cig_off[r];                     // capacity n + 18 words: [0] leading clip, runs from [1]
-    const int32_t L = w.n_ops;
-    const int32_t nW = (L + 15) >> 4;
+    int32_t L = w.n_ops;
+    int32_t nW = (L + 15) >> 4;
     constexpr uint32_t EVEN = 0x55555555u;
     auto valid_mask = [&](int32_t wi) -> uint32_t {       // one bit (the even one) per op of word wi that belongs to the stream
         const int32_t nv = min(16, L - 16 * wi);
-        return nv >= 16 ? EVEN : (((1u << (2 * nv)) - 1u) & EVEN);
+        return nv >= 16 ? EVEN : (nv <= 0 ? 0u : (((1u << (2 * nv)) - 1u) & EVEN));
     };
+    // pass 0 (fzalign v1.3, "best start"): S(p) = score of ops 0..p of the stream (p = 0 is the alignment's END); the alignment starts at the
+    // smallest p with the largest S -- a match column -- and what the walk found beyond it (a head that was dragged along the origin's
+    // diagonal: noisy first bases, an indel before the first seed) becomes soft clip.  A lane scores a word: its 16 ops consume at most 16
+    // read and 16 contig bases going down from the word's first cell, which exclusive scans of the words' consumption counts give.
+    int32_t S_star = 0;
+    {
+        const uint32_t *qpk = read_ori + read_woff[r];
+        const uint32_t *tpk = ctg_pk + ctg_woff[read_ctg[r]];
+        auto scan_incl = [&](int32_t v) -> int32_t {
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const int32_t o = __shfl_up(v, d, 64); if (lane >= d) v += o; }
+            return v;
+        };
+        auto window = [&](const uint32_t *pk, int64_t idx_hi, int64_t &lo_idx) -> uint64_t {     // the 32 bases ending in the u32 word of idx_hi
+            const int64_t w1 = idx_hi >> 4;
+            lo_idx = (w1 - 1) * 16;
+            return ((uint64_t)pk[w1] << 32) | (w1 > 0 ? pk[w1 - 1] : 0u);
+        };
+        int32_t base_S = 0, base_i = 0, base_j = 0, bestS = 0, bestP = -1;
+        for (int32_t wb = 0; wb < nW; wb += 64) {
+            const int32_t wi = wb + lane;
+            const uint32_t x = wi < nW ? rg[wi] : 0u, vm = wi < nW ? valid_mask(wi) : 0u;
+            const uint32_t fM = ~(x | (x >> 1)) & vm, fI = (x & ~(x >> 1)) & vm, fD = (~x & (x >> 1)) & vm;
+            const int32_t ci = __popc(fM | fI), cj = __popc(fM | fD);
+            const int32_t si = scan_incl(ci), sj = scan_incl(cj);
+            int32_t i = w.i_end - (base_i + si - ci), j = w.j_end - (base_j + sj - cj);       // the cell the word's first op leaves
+            int64_t qlo = 0, tlo = 0;
+            const uint64_t qw = (ci && i >= 0) ? window(qpk, (int64_t)a.i_a + i, qlo) : 0ull;
+            const uint64_t tw = (cj && j >= 0) ? window(tpk, (int64_t)a.c_a + j, tlo) : 0ull;
+            int32_t sl = 0, bl = 0, bp = -1;
+            bool have_b = false;
+#pragma unroll
+            for (int o = 0; o < 16; o++) {
+                if ((vm >> (2 * o)) & 1u) {
+                    const uint32_t op = (x >> (2 * o)) & 3u;
+                    if (op == 0u) {
+                        const uint32_t qb_ = (uint32_t)(qw >> (2 * (uint32_t)((int64_t)a.i_a + i - qlo))) & 3u, tb_ = (uint32_t)(tw >> (2 * (uint32_t)((int64_t)a.c_a + j - tlo))) & 3u;
+                        sl += qb_ == tb_ ? match : -mismatch;
+                        i--; j--;
+                    } else { sl -= gap; if (op == 1u) i--; else j--; }
+                    if (!have_b || sl > bl) { bl = sl; bp = o; have_b = true; }
+                }
+            }
+            const int32_t ss = scan_incl(sl);
+            const int32_t cand = base_S + ss - sl + bl;
+            if (have_b && cand > bestS) { bestS = cand; bestP = 16 * wi + bp; }      // words ascend within a lane: '>' keeps the smallest p
+            base_S += __builtin_amdgcn_readlane(ss, 63); base_i += __builtin_amdgcn_readlane(si, 63); base_j += __builtin_amdgcn_readlane(sj, 63);
+        }
+        // wave argmax: largest S, then smallest p
+        int32_t vS = bestS, vP = bestP < 0 ? 0x7fffffff : bestP;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const int32_t oS = __shfl_xor(vS, d, 64), oP = __shfl_xor(vP, d, 64);
+            if (oS > vS || (oS == vS && oP < vP)) { vS = oS; vP = oP; }
+        }
+        if (vP == 0x7fffffff || vS <= 0) { if (lane == 0) summ[r] = out; return; }       // cannot happen: the whole stream scores best_score > 0
+        S_star = vS;
+        L = vP + 1;
+        nW = (L + 15) >> 4;
+        // what the kept ops consume, and their aligned columns
+        int32_t ci2 = 0, cj2 = 0, nm2 = 0;
+        for (int32_t wb = 0; wb < nW; wb += 64) {
+            const int32_t wi = wb + lane;
+            if (wi < nW) {
+                const uint32_t x = rg[wi], vm = valid_mask(wi);
+                const uint32_t fM = ~(x | (x >> 1)) & vm, fI = (x & ~(x >> 1)) & vm, fD = (~x & (x >> 1)) & vm;
+                ci2 += __popc(fM | fI); cj2 += __popc(fM | fD); nm2 += __popc(fM);
+            }
+        }
+        ci2 = wave_sum_i32_dpp(ci2); cj2 = wave_sum_i32_dpp(cj2); nm2 = wave_sum_i32_dpp(nm2);
+        ci2 = __builtin_amdgcn_readfirstlane(ci2); cj2 = __builtin_amdgcn_readfirstlane(cj2); nm2 = __builtin_amdgcn_readfirstlane(nm2);
+        w.i = w.i_end - ci2;                      // the cell before the alignment's first op, as the walk would have left it
+        w.ts = w.i + (w.j_end - cj2);
+        w.ncol = nm2;
+        w.n_ops = L;
+    }
     // pass A: highest / lowest stream position holding an aligned column
     int32_t pM_hi = -1, pM_lo = 0x7fffffff;
     for (int32_t wb = 0; wb < nW; wb += 64) {
@@ -1120,9 +1204,9 @@ __global__ void __launch_bounds__(64) k_tb_cigar(int64_t first, int64_t count, c
         const int32_t q_lead = w.i + 1 + leadI, r_lead = (w.ts - w.i) + 1 + leadD;
         const int32_t pos = (int32_t)(a.c_a + r_lead), ref_end = (int32_t)(a.c_a + w.j_end + 1 - trailD);
         const int32_t q_start = (int32_t)(a.i_a + q_lead), q_end = (int32_t)(a.i_a + w.i_end + 1 - trailI);
-        // matches from the score (the walk never sees the bases): the path from the origin consumes i_end + 1 read and
-        // j_end + 1 contig bases, ncol of each on diagonals, the rest in gaps -- exact, the twin checks it against a direct count
-        const int64_t num = (int64_t)di.best_score + (int64_t)mismatch * w.ncol + (int64_t)gap * ((int64_t)w.i_end + w.j_end + 2 - 2 * (int64_t)w.ncol);
+        // matches from the score of the kept ops (pass 0): they consume i_end - i read and j_end - j contig bases, ncol of each on diagonals,
+        // the rest in gaps -- exact, the twin checks it against a direct count
+        const int64_t num = (int64_t)S_star + (int64_t)mismatch * w.ncol + (int64_t)gap * ((int64_t)(w.i_end - w.i) + (w.j_end - (w.ts - w.i)) - 2 * (int64_t)w.ncol);
         const int32_t n_match = (int32_t)(num / (match + mismatch));
         const int64_t aln_len = (int64_t)(q_end - q_start) + (ref_end - pos) - w.ncol;      // columns + inserted + deleted bases
         if (min_pct_identity <= 0 || 100 * (int64_t)n_match >= (int64_t)min_pct_identity * aln_len) {   // blasr --minPctIdentity (unzip.py:87)
@@ -1397,6 +1481,8 @@ struct fzp_alnjob {
     DevBuf<uint2> tb2[2];
     DevBuf<uint32_t> raw2[2];                    // the walk's 2-bit op streams
     DevBuf<WalkOut> wout;
+    DevBuf<int32_t> lpt;                         // per read: the slot (relative to its chunk's first read) that wave / lane number x of the chunk's launches takes --
+    int64_t lpt_chunk_steps = -1;                // longest reads first (k_sw, k_tb_walk); rebuilt when the chunking changes
     // record planning: reads grouped by contig (input order inside a contig); built on first use
     DevBuf<int32_t> slot_read, slot_ctg;
     DevBuf<int64_t> slot_off;
@@ -1652,6 +1738,26 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
         FZP_TRY(j->wout.alloc((size_t)nr));
         if (!j->ev_sw[0]) for (int k = 0; k < 2; k++) { FZP_HIP(hipEventCreateWithFlags(&j->ev_sw[k], hipEventDisableTiming)); FZP_HIP(hipEventCreateWithFlags(&j->ev_tb[k], hipEventDisableTiming)); }
         hipStream_t st2 = ctx->stream2;
+        if (j->lpt_chunk_steps != chunk_steps || split_rounds) {
+            // launch order inside every chunk of reads: longest first (LPT over the wave slots).  One wave per read, workgroups dispatched in
+            // index order: with reads of uneven length in input order the grid's tail is whatever long read happened to come last.
+            std::vector<int32_t> ord((size_t)nr);
+            for (int64_t f = 0; f < nr;) {
+                int64_t l = f;
+                while (l < nr && j->h_tb_off[(size_t)l + 1] - j->h_tb_off[(size_t)f] <= chunk_steps) l++;
+                if (l == f) l = f + 1;
+                if (split_rounds && f == 0 && l == nr) {
+                    const int64_t slots = (int64_t)ctx->n_cu * 32, full = nr / slots * slots;
+                    if (full >= slots && nr - full >= slots / 8) l = full;
+                }
+                for (int64_t r = f; r < l; r++) ord[(size_t)r] = (int32_t)(r - f);
+                std::stable_sort(ord.begin() + f, ord.begin() + l, [&](int32_t a, int32_t b) { return j->h_read_len[(size_t)(f + a)] > j->h_read_len[(size_t)(f + b)]; });
+                f = l;
+            }
+            FZP_TRY(j->lpt.upload(ord.data(), (size_t)nr, st));
+            j->lpt_chunk_steps = split_rounds ? -1 : chunk_steps;
+        }
+        const bool use_lpt = getenv("FZP_SW_INPUT_ORDER") == nullptr;      // FZP_SW_INPUT_ORDER=1: the r2 launch order, for comparisons
         int64_t first = 0;
         int k = 0;
         bool used[2] = {false, false};
@@ -1683,14 +1789,15 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
             {
                 ProfScope ps(ctx, "k1_sw");
                 hipLaunchKernelGGL(k_sw, dim3((unsigned)cnt), dim3(64), 0, st, first, cnt, (const int32_t *)nullptr, j->read_ori.p, j->read_woff.p, j->read_len.p, j->read_ctg.p,
-                                   j->ctg_pk.p, j->ctg_woff.p, j->ctg_len.p, j->anc.p, j->tb_off.p, j->tb2[bi].p, j->mvw2[bi].p, P.match, P.mismatch, P.gap, j->info.p, j->tbo.p, j->mvo.p);
+                                   j->ctg_pk.p, j->ctg_woff.p, j->ctg_len.p, j->anc.p, j->tb_off.p, j->tb2[bi].p, j->mvw2[bi].p, P.match, P.mismatch, P.gap, j->info.p, j->tbo.p, j->mvo.p,
+                                   use_lpt ? (const int32_t *)(j->lpt.p + first) : (const int32_t *)nullptr);
             }
             if (c2 > 0) {     // same kernel over the compacted list, then the better extension of each read survives
                 {
                     ProfScope ps(ctx, "k1_sw2");
                     hipLaunchKernelGGL(k_sw, dim3((unsigned)c2), dim3(64), 0, st, (int64_t)w_lo, c2, j->ridx.p, j->sec_ori.p, j->sec_woff.p, j->read_len.p, j->read_ctg.p,
                                        j->ctg_pk.p, j->ctg_woff.p, j->ctg_len.p, j->anc2.p, j->tb_off2.p, j->tb2[bi].p + 2 * tb_base, j->mvw2[bi].p + mv_base, P.match, P.mismatch,
-                                       P.gap, j->info2.p, (int64_t *)nullptr, (int64_t *)nullptr);
+                                       P.gap, j->info2.p, (int64_t *)nullptr, (int64_t *)nullptr, (const int32_t *)nullptr);
                 }
                 ProfScope ps(ctx, "k1_pick");
                 hipLaunchKernelGGL(k_pick, dim3((unsigned)((c2 + 255) / 256)), dim3(256), 0, st, (int64_t)w_lo, (int64_t)w_hi, j->ridx.p, j->anc2.p, j->info2.p, j->tb_off2.p,
@@ -1703,12 +1810,14 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
             {
                 ProfScope ps(ctx, "k1_traceback", st2);
                 hipLaunchKernelGGL(k_tb_walk, dim3((unsigned)((cnt + TBW_RPW - 1) / TBW_RPW)), dim3(64), 0, st2, first, cnt, j->anc.p, j->info.p, j->tb_off.p,
-                                   j->tbo.p, j->mvo.p, (const ulonglong2 *)j->tb2[bi].p, (const ulonglong2 *)j->mvw2[bi].p, j->raw2[bi].p, j->wout.p);
+                                   j->tbo.p, j->mvo.p, (const ulonglong2 *)j->tb2[bi].p, (const ulonglong2 *)j->mvw2[bi].p, j->raw2[bi].p, j->wout.p,
+                                   use_lpt ? (const int32_t *)(j->lpt.p + first) : (const int32_t *)nullptr);
             }
             {
                 ProfScope ps(ctx, "k1_cigar", st2);
                 hipLaunchKernelGGL(k_tb_cigar, dim3((unsigned)cnt), dim3(64), 0, st2, first, cnt, j->read_len.p, j->anc.p, j->info.p, j->tb_off.p, j->raw2[bi].p,
-                                   j->wout.p, j->cig_off.p, j->cig.p, j->cig_start.p, j->summ.p, P.match, P.mismatch, P.gap, P.min_pct_identity);
+                                   j->wout.p, j->cig_off.p, j->cig.p, j->cig_start.p, j->summ.p, P.match, P.mismatch, P.gap, P.min_pct_identity,
+                                   j->read_ori.p, j->read_woff.p, j->read_ctg.p, j->ctg_pk.p, j->ctg_woff.p);
             }
             FZP_HIP(hipEventRecord(j->ev_tb[bi], st2));
             used[bi] = true;

@@ -227,6 +227,106 @@ def simulate_raw_reads_bulk(hap0, hap1, n_reads, R, rng, lo=0, hi=None, sub=0.01
     return codes, off, starts, haps, strands.astype(np.int64)
 
 
+def lognormal_lengths(n, rng, median=12000, sigma=0.55, lo=3000, hi=60000):
+    """CLR-like subread lengths: log-normal around `median`, redrawn (clipped after 8 tries) into [lo, hi]"""
+    x = np.exp(rng.normal(np.log(median), sigma, size=n))
+    for _ in range(8):
+        bad = (x < lo) | (x > hi)
+        if not bad.any():
+            break
+        x[bad] = np.exp(rng.normal(np.log(median), sigma, size=int(bad.sum())))
+    return np.clip(x, lo, hi).astype(np.int64)
+
+
+def simulate_raw_reads_shaped(hap0, hap1, n_reads, rng, lens=None, lo=0, hi=None, length_model=None, batch=128, **kw):
+    """_shaped_flat in batches of `batch` reads (the flat arrays stay cache-sized); same return tuple.  with_truth=True appends the
+    template index of every emitted base, in TEMPLATE order (= the oriented read K1 reports q_start / q_end on): base q of oriented read i
+    sits at contig position start[i] + truth[off[i] + q]."""
+    L = hap0.size
+    hi = L if hi is None else hi
+    if lens is None:
+        lens = lognormal_lengths(n_reads, rng, **(length_model or {}))
+    lens = np.asarray(lens, dtype=np.int64)
+    parts = [_shaped_flat(hap0, hap1, min(batch, n_reads - b), rng, lens[b:b + batch], lo, hi, **kw) for b in range(0, n_reads, batch)]
+    if not parts:
+        z = np.zeros(0, np.int64)
+        return np.zeros(0, np.uint8), np.zeros(1, np.int64), z, z, z, z, np.zeros(0)
+    off = np.zeros(n_reads + 1, np.int64)
+    off[1:] = np.cumsum(np.concatenate([np.diff(p[1]) for p in parts]))
+    return (np.concatenate([p[0] for p in parts]), off) + tuple(np.concatenate([p[k] for p in parts]) for k in range(2, len(parts[0])))
+
+
+def _shaped_flat(hap0, hap1, n_reads, rng, lens, lo, hi, sub=0.01, ins=0.08, dele=0.04, strand_mix=0.5,
+                 burst_rate=1.0 / 10000, burst_len=(300, 1000), burst_err=(0.06, 0.16, 0.08), head_burst=0.25, with_truth=False):
+    """Reads of REAL shape for K1: template lengths from `lens` (default: lognormal_lengths -- median 12 kb, 3-60 kb) and
+    bursty errors: stretches of burst_len template bases at burst_err = (sub, ins, del) -- 30 % error -- starting at rate burst_rate per
+    base, and with probability head_burst one of them right at the read's head (the as-sequenced 5' end, whichever strand).  Outside the
+    bursts the iid CLR model of simulate_raw_reads_bulk.  Flat vectorisation over all template bases.
+    Returns (codes uint8 [total], off int64 [n+1], start, hap, strand, template length, burst fraction per read)."""
+    lens = np.minimum(np.asarray(lens, dtype=np.int64), hi - lo)
+    starts = (lo + rng.random(n_reads) * (hi - lo - lens + 1)).astype(np.int64)
+    haps = rng.integers(0, 2, size=n_reads)
+    strands = rng.random(n_reads) < strand_mix
+    toff = np.zeros(n_reads + 1, np.int64)
+    toff[1:] = np.cumsum(lens)
+    total = int(toff[-1])
+    rid = np.repeat(np.arange(n_reads), lens)
+    within = np.arange(total, dtype=np.int64) - toff[rid]
+    gpos = starts[rid] + within
+    T = np.where(haps[rid] == 1, hap1[gpos], hap0[gpos]).astype(np.uint8)
+    # burst intervals -> per-base flag (difference array)
+    diff = np.zeros(total + 1, np.int32)
+    n_b = rng.poisson(lens * burst_rate)
+    for r in np.flatnonzero(n_b):
+        for _ in range(int(n_b[r])):
+            bl = int(rng.integers(burst_len[0], burst_len[1] + 1))
+            b0 = int(rng.integers(0, max(1, lens[r] - bl)))
+            diff[toff[r] + b0] += 1
+            diff[min(toff[r] + b0 + bl, toff[r + 1])] -= 1
+    for r in np.flatnonzero(rng.random(n_reads) < head_burst):
+        bl = int(min(rng.integers(burst_len[0], burst_len[1] + 1), lens[r] // 2))
+        if strands[r]:                                   # sequenced 5' end = the template's far end
+            diff[toff[r + 1] - bl] += 1
+            diff[toff[r + 1]] -= 1
+        else:
+            diff[toff[r]] += 1
+            diff[toff[r] + bl] -= 1
+    inb = np.cumsum(diff[:-1]) > 0
+    t_del = np.where(inb, int(burst_err[2] * 65536), int(dele * 65536)).astype(np.uint32)
+    t_sub = t_del + np.where(inb, int(burst_err[0] * 65536), int(sub * 65536)).astype(np.uint32)
+    t_ins = np.where(inb, int(burst_err[1] * 65536), int(ins * 65536)).astype(np.uint32)
+    u = rng.integers(0, 65536, size=total, dtype=np.uint16).astype(np.uint32)
+    v = rng.integers(0, 65536, size=total, dtype=np.uint16).astype(np.uint32)
+    rnd = rng.integers(0, 256, size=total, dtype=np.uint8)
+    is_del = u < t_del
+    is_sub = (u >= t_del) & (u < t_sub)
+    has_ins = v < t_ins
+    first = toff[:-1]
+    last = toff[1:] - 1
+    is_del[first] = False
+    is_del[last] = False
+    has_ins[first] = False
+    T[is_sub] = (T[is_sub] + 1 + (rnd[is_sub] % 3)) & 3
+    E = np.empty((total, 2), dtype=np.uint8)
+    E[:, 0] = (rnd >> 4) & 3
+    E[:, 1] = T
+    keep = np.empty((total, 2), dtype=bool)
+    keep[:, 0] = has_ins
+    keep[:, 1] = ~is_del
+    per_base = keep.sum(axis=1)
+    rl = np.add.reduceat(per_base, toff[:-1]) if n_reads else np.zeros(0, np.int64)
+    codes = E[keep]
+    off = np.zeros(n_reads + 1, np.int64)
+    off[1:] = np.cumsum(rl)
+    for i in np.flatnonzero(strands):
+        a, b = off[i], off[i + 1]
+        codes[a:b] = _COMP[codes[a:b][::-1]]
+    bfrac = np.add.reduceat(inb.astype(np.int64), toff[:-1]) / np.maximum(lens, 1) if n_reads else np.zeros(0)
+    if with_truth:
+        return codes, off, starts, haps, strands.astype(np.int64), lens, bfrac, np.repeat(within, per_base).astype(np.int32)
+    return codes, off, starts, haps, strands.astype(np.int64), lens, bfrac
+
+
 def _diverge(codes, rng, div, indel_frac=0.2):
     """A diverged copy of `codes`: substitutions at rate div*(1-indel_frac), 1-base indels at rate div*indel_frac."""
     n = codes.size

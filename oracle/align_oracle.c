@@ -315,18 +315,26 @@ static void extend_one(const ctg_index *ix, const uint8_t *r, int64_t n, const a
         /* reversed raw op stream, run-length encoded on the fly: op codes 7 '=', 8 'X', 1 'I', 2 'D' */
         u32vec rev = {0};
         int cur_op = -1; uint32_t cur_len = 0; int32_t ncol = 0, n_eq = 0;
+        /* v1.3 "best start": S = score of the ops walked so far (from the alignment's end); the alignment starts at the op where S is
+         * largest (the first such op met, i.e. the shortest alignment among ties -- it is a match column), everything walked after it is
+         * soft-clipped: a head that was forced along the origin's diagonal (noisy first bases, an indel before the first seed) goes */
+        int64_t S = 0, bestS = 0;
+        int64_t snap_n = -1, snap_i = 0, snap_j = 0; int snap_op = -1; uint32_t snap_len = 0; int32_t snap_ncol = 0, snap_eq = 0;
         while (i >= 0 && j >= 0) {
             int kk = (int)(i - i0s[ts]);
             int op;
-            if ((tbD[ts] >> kk) & 1) { op = q[i] == t[j] ? 7 : 8; n_eq += op == 7; i--; j--; ts -= 2; ncol++; }
-            else if ((((tbU[ts] >> kk) & 1) != 0) == (mv[ts] != 0)) { op = 1; i--; ts -= 1; }   /* the cell above */
-            else { op = 2; j--; ts -= 1; }
+            if ((tbD[ts] >> kk) & 1) { op = q[i] == t[j] ? 7 : 8; n_eq += op == 7; S += op == 7 ? P->match : -P->mismatch; i--; j--; ts -= 2; ncol++; }
+            else if ((((tbU[ts] >> kk) & 1) != 0) == (mv[ts] != 0)) { op = 1; S -= P->gap; i--; ts -= 1; }   /* the cell above */
+            else { op = 2; S -= P->gap; j--; ts -= 1; }
             if (op == cur_op) cur_len++;
             else { if (cur_len) push(&rev, (cur_len << 4) | (uint32_t)cur_op); cur_op = op; cur_len = 1; }
+            if (S > bestS) { bestS = S; snap_n = rev.n; snap_i = i; snap_j = j; snap_op = cur_op; snap_len = cur_len; snap_ncol = ncol; snap_eq = n_eq; }
         }
+        if (snap_n < 0) { free(rev.v); goto done; }                   /* cannot happen: the whole path scores bsc[bk] > 0 */
+        rev.n = snap_n; i = snap_i; j = snap_j; cur_op = snap_op; cur_len = snap_len; ncol = snap_ncol; n_eq = snap_eq;
         if (cur_len) push(&rev, (cur_len << 4) | (uint32_t)cur_op);
-        {   /* the device derives the match count from the score (it never sees the bases during trace-back): both must agree */
-            const int64_t num = (int64_t)bsc[bk] + (int64_t)P->mismatch * ncol + (int64_t)P->gap * (i_end + j_end + 2 - 2 * (int64_t)ncol);
+        {   /* the device derives the match count from the score of the kept ops (it only sees the bases while scoring them): both must agree */
+            const int64_t num = bestS + (int64_t)P->mismatch * ncol + (int64_t)P->gap * ((i_end - i) + (j_end - j) - 2 * (int64_t)ncol);
             if (num % (P->match + P->mismatch) != 0 || num / (P->match + P->mismatch) != n_eq) {
                 fprintf(stderr, "align_oracle: match-count identity violated (%lld vs %d)\n", (long long)num, n_eq);
                 abort();
@@ -475,6 +483,35 @@ static void *mt_worker(void *vp) {
     scratch_release();
     return NULL;
 }
+/* test hook (tests/: the spec-independent full-matrix check needs the origin an extension started from; since v1.3 the reported alignment
+ * no longer reveals it): the candidate origins of one read as seed_candidates finds them, out[c] = {strand, i_a, c_a}; returns their number */
+int orc_align_origins(const uint8_t *ctg_ascii, int64_t ctg_len, const uint8_t *read_ascii, int64_t n, const orc_align_params *P, int64_t *out) {
+    if (P->kmer < 8 || P->kmer > 16 || P->seed_stride < 1) return -1;
+    ctg_index ix;
+    uint8_t *codes = (uint8_t *)malloc((size_t)(ctg_len ? ctg_len : 1));
+    for (int64_t i = 0; i < ctg_len; i++) codes[i] = (uint8_t)code_of(ctg_ascii[i]);
+    ix.codes = codes; ix.len = ctg_len;
+    int64_t nk = ctg_len >= P->kmer ? ctg_len - P->kmer + 1 : 0;
+    ix.n = (nk + 1) / 2;
+    ix.kp = (kp_t *)malloc((size_t)(ix.n ? ix.n : 1) * sizeof(kp_t));
+    for (int64_t q = 0; q < ix.n; q++) {
+        int64_t p = 2 * q;
+        uint32_t kf = kmer_at(codes, p, P->kmer), kr = rc_of(kf, P->kmer);
+        ix.kp[q].key = kr < kf ? kr : kf;
+        ix.kp[q].pos = (int32_t)((p << 1) | (kr < kf ? 1 : 0));
+    }
+    qsort(ix.kp, (size_t)ix.n, sizeof(kp_t), cmp_kp);
+    uint8_t *fwd = (uint8_t *)malloc((size_t)(n ? n : 1));
+    for (int64_t i = 0; i < n; i++) fwd[i] = (uint8_t)code_of(read_ascii[i]);
+    anchor_t cand[2];
+    int nc = 0;
+    if (n >= P->kmer && ix.len >= P->kmer) nc = seed_candidates(&ix, fwd, n, P, cand);
+    for (int c = 0; c < nc; c++) { out[3 * c] = cand[c].strand; out[3 * c + 1] = cand[c].i_a; out[3 * c + 2] = cand[c].c_a; }
+    scratch_release();
+    free(fwd); free(ix.kp); free(codes);
+    return nc;
+}
+
 static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 /* seconds[0] = index build (serial, one contig), seconds[1] = seeding + DP + trace-back of all reads (n_threads threads); may be NULL */
 int orc_align_reads_mt_timed(const uint8_t *ctg_ascii, int64_t ctg_len, int64_t n_reads, const int64_t *read_off,

@@ -344,10 +344,11 @@ def _full_matrix_best(q, t, match=2, mismatch=4, gap=3):
     return best
 
 
-def test_scores_equal_unbanded_dp_on_short_reads(eng):
+def test_scores_equal_unbanded_dp_on_short_reads(eng, oracle):
     """Spec-independent check: for reads of ~2.5 kb the kernel's score must be the optimum of a plain
     full-matrix extension DP from the same origin -- the band never cut the best path, and twin and kernel do not share an
-    arithmetic bug."""
+    arithmetic bug.  (The origin comes from the twin's seeding: since v1.3 the reported alignment starts at its best-scoring
+    column, not at the origin.)"""
     from falcon_unzip_amd import _lib, sim
     rng = np.random.Generator(np.random.PCG64(93))
     L = 60000
@@ -368,23 +369,69 @@ def test_scores_equal_unbanded_dp_on_short_reads(eng):
         ori = rd.seq                                        # on the contig strand = the oriented read
         cg = cig_of[r]
         cs = sum(2 * l if o == 7 else -4 * l if o == 8 else -3 * l if o in (1, 2) else 0 for l, o in cg)
-        lead = cs - int(s["score"][r])
-        assert lead >= 0 and lead % 3 == 0
-        lead //= 3
+        assert cs >= int(s["score"][r])                     # the kept piece of the path scores at least what the whole path did
         hit = False
-        for li in range(lead + 1):
-            i_a, c_a = int(s["q_start"][r]) - li, int(s["pos"][r]) - (lead - li)
-            if i_a < 0 or c_a < 0 or min(i_a, c_a) != 0:
-                continue
+        for strand, i_a, c_a in oracle_lib.align_origins(oracle, ctg, raw[r]):
             q = ori[i_a:]
             nt = min(L - c_a, len(q) + len(q) // 4 + 64)
-            if _full_matrix_best(q, hap0[c_a:c_a + nt]) == int(s["score"][r]):
+            if strand == rd.strand and _full_matrix_best(q, hap0[c_a:c_a + nt]) == int(s["score"][r]):
                 hit = True
                 break
         assert hit, (r, s[r])
         checked += 1
     assert checked >= 20
     job.close()
+
+
+def _shaped(seed, L, n, **kw):
+    from falcon_unzip_amd import sim
+    rng = np.random.Generator(np.random.PCG64(seed))
+    hap0, hap1, _ = sim.make_diploid(L, rng)
+    codes, off, st, hp, sd, lens, bf, truth = sim.simulate_raw_reads_shaped(hap0, hap1, n, rng, with_truth=True, **kw)
+    return sim.ACGT[hap0].tobytes(), sim.ACGT[codes].tobytes(), off, st, sd, lens, bf, truth
+
+
+def test_real_read_shape_matches_twin_and_truth(eng, oracle):
+    """Reads of real CLR shape: log-normal lengths (median 12 kb, 3-60 kb) and bursty errors (0.3-1 kb stretches at
+    30 %, a quarter of the reads with one at their head).  HIP == twin on every field; >= 99 % of the reads start within 64 bp of where
+    their first aligned base truly lies and end within 64 bp of their true end; >= 95 % of all read bases are inside alignments and
+    >= 98 % of the reads have >= 95 % of their own bases inside (the rest lost the band behind a noisy head: forward extension only)."""
+    from falcon_unzip_amd import _lib
+    n = 1200
+    ctg, blob, off, st, sd, lens, bf, truth = _shaped(47, 2_000_000, n)
+    rl = np.diff(off)
+    assert rl.min() < 4500 and rl.max() > 45000 and 11000 < np.median(lens) < 13500 and (bf > 0).mean() > 0.5
+    job = _lib.align_job_raw(eng, [ctg], blob, off, np.zeros(n, np.int32))
+    job.run()
+    s = job.summaries()
+    exp, _ = oracle_lib.align_reads(oracle, ctg, [blob[off[i]:off[i + 1]] for i in range(n)], n_threads=8)
+    for f in FIELDS:
+        assert np.array_equal(s[f], exp[f]), (f, np.flatnonzero(s[f] != exp[f])[:5])
+    ok = s["aligned"] == 1
+    assert ok.mean() >= 0.995 and np.all(s["strand"][ok] == sd[ok])
+    true_pos = st + truth[off[:-1] + np.clip(s["q_start"], 0, rl - 1)]
+    placed = (np.abs(s["pos"] - true_pos) <= 64) & (np.abs(s["ref_end"] - (st + lens)) <= 64)
+    assert placed[ok].mean() >= 0.99, placed[ok].mean()
+    inside = (s["q_end"] - s["q_start"])[ok]
+    assert inside.sum() >= 0.95 * rl[ok].sum() and np.mean(inside / rl[ok] >= 0.95) >= 0.98, (inside.sum() / rl[ok].sum(), np.mean(inside / rl[ok] >= 0.95))
+    job.close()
+
+
+def test_launch_order_does_not_change_results(eng, monkeypatch):
+    """k_sw and k_tb_walk take their reads longest first (LPT over the wave slots); FZP_SW_INPUT_ORDER=1 is the input order: same bytes"""
+    from falcon_unzip_amd import _lib
+    n = 600
+    ctg, blob, off, *_ = _shaped(48, 1_000_000, n)
+    got = {}
+    for mode in ("lpt", "input"):
+        if mode == "input":
+            monkeypatch.setenv("FZP_SW_INPUT_ORDER", "1")
+        job = _lib.align_job_raw(eng, [ctg], blob, off, np.zeros(n, np.int32))
+        job.run()
+        got[mode] = (job.summaries().copy(), [job.alnset(0)[0].cigar_of(k) for k in range(0, 500, 7)])
+        job.close()
+    monkeypatch.delenv("FZP_SW_INPUT_ORDER")
+    assert np.array_equal(got["lpt"][0], got["input"][0]) and got["lpt"][1] == got["input"][1]
 
 
 def test_record_planning_at_deep_coverage(eng):
