@@ -113,6 +113,24 @@ def make_names_and_maps(read_ctg, off, ids, arid_base):
     return (noff, b"".join(names)), (rawread_ids, pread_ids, p2c)
 
 
+def host_cores():
+    """threads this process may really use: the affinity mask and the cgroup CPU quota, not the machine's thread count (the GPU boxes show 256
+    hardware threads behind a 16-CPU quota)"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, p = f.read().split()[:2]
+            if q != "max":
+                n = min(n, max(1, int(int(q) / int(p) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -135,7 +153,7 @@ def cpu_baseline(contigs, blob, off, read_ctg, ids, job, hip_summ, budget_s=30.0
     from falcon_unzip_amd import _lib
     from tests import oracle_lib
     orc = oracle_lib.load()
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     n_ctg = len(contigs)
     cells_per_ctg = float(hip_summ["cells"].sum()) / max(1, n_ctg)
     n_sample = max(1, min(n_ctg, int(budget_s * 80e6 * cores / max(1.0, cells_per_ctg))))
@@ -169,7 +187,7 @@ def cpu_baseline(contigs, blob, off, read_ctg, ids, job, hip_summ, budget_s=30.0
     with ThreadPoolExecutor(max_workers=side) as ex:
         list(ex.map(lambda a: orc.phase_all(*a), sams))
     t_ph = time.perf_counter() - t0
-    return {"value": round(n_used / (t_aln + t_ph), 3), "unit": "reads/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+    return {"value": round(n_used / (t_aln + t_ph), 3), "unit": "reads/s", "cores": cores, "hardware_threads": os.cpu_count(), "kind": "port", "cpu_model": cpu_model(),
             "sample": "all %d reads of %d of the %d contigs: %d contigs side by side x %d threads each -- oracle/align_oracle.c (index build, then seeding + DP + "
                       "trace-back), then the oracle/phasing_oracle.c chain, one contig per thread; the reference's blasr and Python 2 cannot run here"
                       % (n_used, n_sample, n_ctg, side, thr),
@@ -213,9 +231,11 @@ def shaped_leg(eng, inp):
     contigs, blob, off, read_ctg = inp
     job = _lib.align_job_raw(eng, contigs, blob, off, read_ctg)
     res = {}
-    for mode in ("longest_first", "input_order"):
+    for mode in ("longest_first", "longest_first_no_priority", "input_order"):
         if mode == "input_order":
             os.environ["FZP_SW_INPUT_ORDER"] = "1"
+        if mode != "longest_first":
+            os.environ["FZP_SW_NO_PRIO"] = "1"
         try:
             job.run()
             eng.synchronize()
@@ -228,6 +248,7 @@ def shaped_leg(eng, inp):
             pr = eng.prof()
         finally:
             os.environ.pop("FZP_SW_INPUT_ORDER", None)
+            os.environ.pop("FZP_SW_NO_PRIO", None)
         summ = job.summaries()
         sw_ms, sw_n = pr.get("k1_sw", (0.0, 0))
         res[mode] = {"k1_sw_ms": round(sw_ms / max(1, sw_n), 3), "k1_traceback_ms": round(pr.get("k1_traceback", (0.0, 0))[0] / max(1, sw_n), 3),
@@ -354,7 +375,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE); they must agree" % (args.gpus, world))
-    workers = args.gen_workers or max(1, min(16 if world > 1 else 8, (os.cpu_count() or 1) // max(1, world)))
+    workers = args.gen_workers or max(1, min(16 if world > 1 else 8, host_cores() // max(1, world)))
     if "rocprof" in os.environ.get("LD_PRELOAD", "") or os.environ.get("ROCPROFILER_REGISTER_FORCE_LOAD") or os.environ.get("ROCP_TOOL_LIBRARIES"):
         workers = 1   # the profiler's preloaded library may have initialised the GPU already: do not fork
     from falcon_unzip_amd import dist as fdist

@@ -631,7 +631,7 @@ __device__ __forceinline__ void scalar_store16(void *base, uint32_t byte_off, ui
 // one DOWN step.  HC: operand holding H of the previous step; XC: operand holding H of two steps ago, receives the new H;
 // HDADD: the add that forms the diagonal operand (shifted by what the last two moves say); NP: parity after this step;
 // the step ends by jumping to the variant (NP, previous = DOWN, next move) or to the exit of parity NP.
-#define SWB_DOWN(LBL, HC, XC, HDADD, NP, KB)                                                       \
+#define SWB_DOWN(LBL, HC, XC, HDADD, NP, KB, ST)                                                       \
     "Lsw%=_" LBL ":\n\t"                                                                          \
     "s_bfe_u64 s[56:57], %[qb], %[qsel]\n\t"                                                      \
     "v_mov_b32_dpp %[qc], %[qc] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"                        \
@@ -648,14 +648,14 @@ __device__ __forceinline__ void scalar_store16(void *base, uint32_t byte_off, ui
     "s_lshl1_add_u32 %[mv], %[mv], 1\n\t"                                                         \
     KB                                                      \
     "v_readlane_b32 %[top], " XC ", 0\n\t"                                                        \
-    "s_store_dwordx4 s[60:63], %[tbp], %[soff]\n\t"                                               \
+    ST                                                                                            \
     "v_readlane_b32 %[bot], " XC ", 63\n\t"                                                       \
     "s_addk_i32 %[soff], 16\n\t"                                                                  \
     "s_cbranch_scc1 Lsw%=_end" NP "\n\t"                                                          \
     "s_cmp_gt_i32 %[top], %[bot]\n\t"                                                             \
     "s_cbranch_scc1 Lsw%=_p" NP "DR\n\t"                                                          \
     "s_branch Lsw%=_p" NP "DD\n"
-#define SWB_RIGHT(LBL, HC, XC, HDADD, NP, KB)                                                       \
+#define SWB_RIGHT(LBL, HC, XC, HDADD, NP, KB, ST)                                                       \
     "Lsw%=_" LBL ":\n\t"                                                                          \
     "s_bfe_u64 s[56:57], %[tb], %[tsel]\n\t"                                                      \
     "v_mov_b32_dpp %[tc], %[tc] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"                        \
@@ -672,7 +672,7 @@ __device__ __forceinline__ void scalar_store16(void *base, uint32_t byte_off, ui
     "s_lshl_b32 %[mv], %[mv], 1\n\t"                                                              \
     KB                                                      \
     "v_readlane_b32 %[top], " XC ", 0\n\t"                                                        \
-    "s_store_dwordx4 s[60:63], %[tbp], %[soff]\n\t"                                               \
+    ST                                                                                            \
     "v_readlane_b32 %[bot], " XC ", 63\n\t"                                                       \
     "s_addk_i32 %[soff], 16\n\t"                                                                  \
     "s_cbranch_scc1 Lsw%=_end" NP "\n\t"                                                          \
@@ -680,6 +680,8 @@ __device__ __forceinline__ void scalar_store16(void *base, uint32_t byte_off, ui
     "s_cbranch_scc1 Lsw%=_p" NP "RR\n\t"                                                          \
     "s_branch Lsw%=_p" NP "RD\n"
 // label "pPab": parity P (0: H in %[H], X in %[X]; 1: swapped), a = previous move, b = this move
+#define SWB_STORE "s_store_dwordx4 s[60:63], %[tbp], %[soff]\n\t"
+template <bool STORE>
 __device__ __forceinline__ void sw_block(int32_t &H, int32_t &X, int32_t &qc, int32_t &tc, const uint64_t qbits, const uint64_t tbits, int32_t &kb,
                                          void *tbp, uint32_t &soff, uint32_t &mv, int32_t &dn, int32_t &pm, const int32_t gapS,
                                          const int32_t vmatS, const int32_t vmisS) {
@@ -736,7 +738,7 @@ __global__ void __launch_bounds__(64) k_sw(int64_t first, int64_t count, const i
                                             const uint32_t *__restrict__ ctg_pk, const int64_t *__restrict__ ctg_woff, const int64_t *__restrict__ ctg_len,
                                             const Anchor *__restrict__ anc, const int64_t *__restrict__ tb_off, uint2 *__restrict__ tb, ulonglong2 *__restrict__ mvw,
                                             int match, int mismatch, int gap, DpInfo *__restrict__ info, int64_t *__restrict__ tbo, int64_t *__restrict__ mvo,
-                                            const int32_t *__restrict__ order) {
+                                            const int32_t *__restrict__ order, int32_t prio_len) {
     const int lane = lane_id();
     // wave-uniform on purpose: everything indexed by the read then lives in SGPRs / scalar loads
     const int64_t wq = (int64_t)blockIdx.x;   // one wave per workgroup: a finished read frees its slot at once
@@ -754,6 +756,13 @@ __global__ void __launch_bounds__(64) k_sw(int64_t first, int64_t count, const i
     if (!a.aligned) { if (lane == 0) info[sl] = DpInfo{0, -1, 0, NEGV}; return; }
     const int c_idx = read_ctg[r];
     const int64_t n = read_len[r];
+    // a read several times the usual length is a serial chain several times as long: its wave takes the SIMD's issue slots ahead of the
+    // seven waves it shares them with (they lose little, it finishes up to 8 x sooner), so the launch does not end on one long read
+    if (prio_len > 0) {
+        if (n >= 4 * (int64_t)prio_len) __builtin_amdgcn_s_setprio(3);
+        else if (n >= 3 * (int64_t)prio_len) __builtin_amdgcn_s_setprio(2);
+        else if (n >= 2 * (int64_t)prio_len) __builtin_amdgcn_s_setprio(1);
+    }
     const int32_t nq = (int32_t)(n - a.i_a);
     int64_t ntl = ctg_len[c_idx] - a.c_a;
     if (ntl > (int64_t)nq + nq / 4 + 64) ntl = (int64_t)nq + nq / 4 + 64;
@@ -1758,6 +1767,10 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
             j->lpt_chunk_steps = split_rounds ? -1 : chunk_steps;
         }
         const bool use_lpt = getenv("FZP_SW_INPUT_ORDER") == nullptr;      // FZP_SW_INPUT_ORDER=1: the r2 launch order, for comparisons
+        const bool use_prio = getenv("FZP_SW_NO_PRIO") == nullptr;
+        int64_t sum_len = 0;
+        for (int64_t r = 0; r < nr; r++) sum_len += j->h_read_len[(size_t)r];
+        const int32_t mean_len = (int32_t)std::max<int64_t>(1, sum_len / std::max<int64_t>(nr, 1));
         int64_t first = 0;
         int k = 0;
         bool used[2] = {false, false};
@@ -1790,14 +1803,14 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
                 ProfScope ps(ctx, "k1_sw");
                 hipLaunchKernelGGL(k_sw, dim3((unsigned)cnt), dim3(64), 0, st, first, cnt, (const int32_t *)nullptr, j->read_ori.p, j->read_woff.p, j->read_len.p, j->read_ctg.p,
                                    j->ctg_pk.p, j->ctg_woff.p, j->ctg_len.p, j->anc.p, j->tb_off.p, j->tb2[bi].p, j->mvw2[bi].p, P.match, P.mismatch, P.gap, j->info.p, j->tbo.p, j->mvo.p,
-                                   use_lpt ? (const int32_t *)(j->lpt.p + first) : (const int32_t *)nullptr);
+                                   use_lpt ? (const int32_t *)(j->lpt.p + first) : (const int32_t *)nullptr, use_prio ? mean_len : 0);
             }
             if (c2 > 0) {     // same kernel over the compacted list, then the better extension of each read survives
                 {
                     ProfScope ps(ctx, "k1_sw2");
                     hipLaunchKernelGGL(k_sw, dim3((unsigned)c2), dim3(64), 0, st, (int64_t)w_lo, c2, j->ridx.p, j->sec_ori.p, j->sec_woff.p, j->read_len.p, j->read_ctg.p,
                                        j->ctg_pk.p, j->ctg_woff.p, j->ctg_len.p, j->anc2.p, j->tb_off2.p, j->tb2[bi].p + 2 * tb_base, j->mvw2[bi].p + mv_base, P.match, P.mismatch,
-                                       P.gap, j->info2.p, (int64_t *)nullptr, (int64_t *)nullptr, (const int32_t *)nullptr);
+                                       P.gap, j->info2.p, (int64_t *)nullptr, (int64_t *)nullptr, (const int32_t *)nullptr, 0);
                 }
                 ProfScope ps(ctx, "k1_pick");
                 hipLaunchKernelGGL(k_pick, dim3((unsigned)((c2 + 255) / 256)), dim3(256), 0, st, (int64_t)w_lo, (int64_t)w_hi, j->ridx.p, j->anc2.p, j->info2.p, j->tb_off2.p,
@@ -2128,7 +2141,8 @@ extern "C" int fzp_align_to_batch(fzp_ctx *ctx, fzp_alnjob *j, fzp_batch **out) 
         const int32_t limit = h_last[(size_t)c] > 0 ? h_last[(size_t)c] : 0;
         b->h_limit.push_back(limit);
         b->h_ref_len.push_back(j->h_ctg_len[(size_t)c]);
-        b->h_goff.push_back(b->h_goff.back() + limit);
+        b->h_goff.push_back(b->h_goff.back() + fzp_pos_pad(limit));
+        b->n_eval += limit;
         b->h_qid_off.push_back(b->h_qid_off.back() + (int64_t)h_nal[(size_t)c]);
         b->n_columns += (int64_t)h_cols[(size_t)c];
     }

@@ -76,7 +76,8 @@ extern "C" int fzp_batch_create(fzp_ctx *ctx, int32_t n_ctg, const fzp_alnset *c
         b->h_limit.push_back(limit);
         b->h_ref_len.push_back(ref_len[c]);
         b->h_rec_begin.push_back(b->h_rec_begin.back() + a->n_rec);
-        b->h_goff.push_back(b->h_goff.back() + limit);
+        b->h_goff.push_back(b->h_goff.back() + fzp_pos_pad(limit));
+        b->n_eval += limit;
         b->h_qid_off.push_back(b->h_qid_off.back() + a->n_qid);
         n_cig += a->cig_off[a->n_rec];
         n_seq += a->seq_off[a->n_rec];
@@ -154,7 +155,7 @@ extern "C" int fzp_batch_counts(fzp_ctx *ctx, fzp_batch *b, int64_t *n_rec, int6
     if (!b) return FZP_EINVAL;
     if (n_rec) *n_rec = b->n_rec;
     if (n_columns) *n_columns = b->n_columns;
-    if (n_positions) *n_positions = b->n_pos;
+    if (n_positions) *n_positions = b->n_eval;
     if (n_sites) *n_sites = b->n_sites;
     if (n_rows) *n_rows = b->n_rows;
     if (n_arows) *n_arows = b->n_arows;
@@ -303,12 +304,12 @@ int batch_from_sites(fzp_ctx *ctx, const fzp_site *sites, int64_t n_sites, const
     fzp_batch *b = new fzp_batch();
     b->n_ctg = 1;
     int64_t span = n_sites ? (int64_t)sites[n_sites - 1].pos + 1 : 0;
-    b->h_goff = {0, span};
+    b->h_goff = {0, fzp_pos_pad(span)};
     b->h_qid_off = {0, n_qid};
     b->h_limit = {(int32_t)span};
     b->h_rec_begin = {0, 0};
     b->h_site_begin = {0, n_sites};
-    b->n_pos = span; b->n_qid = n_qid; b->n_sites = n_sites; b->n_rows = n_rows;
+    b->n_pos = fzp_pos_pad(span); b->n_eval = span; b->n_qid = n_qid; b->n_sites = n_sites; b->n_rows = n_rows;
     hipStream_t st = ctx->stream;
     std::vector<int64_t> site_g((size_t)n_sites);
     std::vector<int32_t> site_ctg((size_t)n_sites, 0);

@@ -16,6 +16,12 @@
 #pragma once
 #include "fzp_common.h"
 
+// K2's position tiles: every contig's evaluated range starts on a tile boundary of the global position index (ctg_goff is a multiple of
+// FZP_POS_TILE), so a tile is exactly FZP_POS_TILE / 256 of the 256-position blocks the call / compaction kernels work on, and a tile
+// that no record overlaps is never written, read or scanned (blk_live)
+constexpr int FZP_POS_TILE = 2048;
+inline int64_t fzp_pos_pad(int64_t limit) { return (limit + FZP_POS_TILE - 1) / FZP_POS_TILE * FZP_POS_TILE; }
+
 struct fzp_batch {
     int32_t n_ctg = 0;
     // host mirrors
@@ -23,6 +29,7 @@ struct fzp_batch {
     std::vector<int32_t> h_limit;
     std::vector<int64_t> h_site_begin, h_arow_begin, h_pvar_begin, h_pread_begin;
     int64_t n_rec = 0, n_cig = 0, n_seq = 0, n_pos = 0, n_columns = 0, n_qid = 0;
+    int64_t n_eval = 0;        // evaluated positions (sum of the contigs' limits); n_pos counts the tile-aligned layout
     int64_t n_sites = 0, n_rows = 0, n_arows = 0, n_pvars = 0, n_preads = 0;
     bool have_aln = false, have_sites = false, have_sets = false, have_arows = false, have_blocks = false,
          have_preads = false;
@@ -45,7 +52,7 @@ struct fzp_batch {
     DevBuf<int32_t> tile_ctg, tile_start;
     // K2
     DevBuf<uint32_t> cnt, oth, site_idx, row_off32;
-    DevBuf<uint8_t> flag8;
+    DevBuf<uint8_t> flag8, blk_live;         // blk_live: per 256-position block, 1 if its tile saw a record
     DevBuf<fzp_site> sites;
     DevBuf<int64_t> site_g;
     DevBuf<int32_t> site_ctg;

@@ -43,20 +43,18 @@ __global__ void __launch_bounds__(256) k_cig_ckpt(RecView v, const int64_t *__re
 // their A/C/G/T counters in LDS (the tracker of symbols other than ACGT -- rare -- lives in HBM, pre-zeroed, and takes global atomics), lets its waves walk the records that overlap the tile
 // -- each from the CIGAR checkpoint just before the tile -- and writes the counters out once, coalesced.  No global
 // atomics: HBM sees the symbols (1 B/column), the CIGAR words and 20 B per position, about the algorithmic minimum.
-constexpr int PILE_TILE = 2048, PILE_THREADS = 512;
+constexpr int PILE_TILE = FZP_POS_TILE, PILE_THREADS = 512;
 __global__ void __launch_bounds__(PILE_THREADS) k_pileup_tiles(RecView v, const int32_t *__restrict__ tile_ctg, const int32_t *__restrict__ tile_start,
                                                       const int64_t *__restrict__ ctg_rec_begin, const int32_t *__restrict__ ctg_maxspan,
                                                       const int32_t *__restrict__ rec_span, const int64_t *__restrict__ ck_off, const int32_t *__restrict__ ck_ref,
-                                                      const int32_t *__restrict__ ck_q, uint32_t *__restrict__ cnt, uint32_t *__restrict__ oth) {
+                                                      const int32_t *__restrict__ ck_q, uint32_t *__restrict__ cnt, uint32_t *__restrict__ oth,
+                                                      unsigned long long *__restrict__ blk_live) {
     __shared__ uint32_t l_cnt[4 * PILE_TILE];   // [code][position]: consecutive lanes = consecutive positions = distinct banks
     __shared__ __attribute__((aligned(16))) uint32_t l_win[(PILE_THREADS / 64) * EXP_WIN];   // expand_record's window, one per wave
     const int c = tile_ctg[blockIdx.x];
     const int32_t ts = tile_start[blockIdx.x];
     const int32_t lim = v.ctg_limit[c];
     const int32_t te = min(ts + PILE_TILE, lim);
-    for (int i = threadIdx.x; i < PILE_TILE * 4; i += PILE_THREADS) l_cnt[i] = 0;
-    __syncthreads();
-    uint32_t *oth_t = oth + v.ctg_goff[c] + ts;      // the tile's tracker words in HBM (zeroed by the host before the launch)
     // records of this contig that can overlap [ts, te): POS < te and POS > ts - max_span
     const int64_t rb = ctg_rec_begin[c], re = ctg_rec_begin[c + 1];
     const int32_t ms = ctg_maxspan[c];
@@ -69,6 +67,15 @@ __global__ void __launch_bounds__(PILE_THREADS) k_pileup_tiles(RecView v, const 
         while (a < b) { int64_t m = (a + b) >> 1; if (v.rec_pos[m] < te) a = m + 1; else b = m; }
         hi = a;
     }
+    // a tile no record can reach (the stretch before a contig's first read, a coverage hole) is left alone: its eight 256-position blocks
+    // stay marked dead (blk_live was zeroed) and neither k_site_flag nor k_site_emit nor anybody else touches its counters
+    if (lo >= hi) return;
+    const int64_t g0 = v.ctg_goff[c] + ts;           // multiple of PILE_TILE: the tile is blocks (g0 >> 8) .. + 7
+    if (threadIdx.x == 0) blk_live[g0 >> 11] = 0x0101010101010101ull;
+    uint32_t *oth_t = oth + g0;                      // the tile's tracker words in HBM: zeroed here, by the only workgroup that uses them
+    for (int i = threadIdx.x; i < PILE_TILE; i += PILE_THREADS) oth_t[i] = 0u;
+    for (int i = threadIdx.x; i < PILE_TILE * 4; i += PILE_THREADS) l_cnt[i] = 0;
+    __syncthreads();
     // candidate lo + i*NW + wave belongs to lane i of this wave: the per-record look-ups (span test, checkpoint
     // search) run lane-parallel, then the wave walks its records one at a time
     const int wave = threadIdx.x >> 6, lane = lane_id();
@@ -108,9 +115,8 @@ __global__ void __launch_bounds__(PILE_THREADS) k_pileup_tiles(RecView v, const 
         }
     }
     __syncthreads();
-    const int64_t g0 = v.ctg_goff[c] + ts;
-    const int np = te - ts;
-    for (int i = threadIdx.x; i < np * 4; i += PILE_THREADS) cnt[g0 * 4 + i] = l_cnt[(i & 3) * PILE_TILE + (i >> 2)];
+    // the whole tile goes out (positions at or beyond the contig's limit hold zeros: the blocks the call kernels read are complete)
+    for (int i = threadIdx.x; i < PILE_TILE * 4; i += PILE_THREADS) cnt[g0 * 4 + i] = l_cnt[(i & 3) * PILE_TILE + (i >> 2)];
 }
 
 struct CallInfo {
@@ -155,9 +161,13 @@ __device__ __forceinline__ int find_ctg(const int64_t *goff, int n_ctg, int64_t 
 // Called sites are sparse (one per few thousand positions), so the ordered compaction does not scan per-position
 // arrays: k_site_flag leaves one flag byte per position and, per 256-position block, the number of sites and of
 // variant_map rows; the two short block arrays are scanned; k_site_emit ranks the sites inside their block.
-__global__ void __launch_bounds__(256) k_site_flag(const uint4 *__restrict__ cnt, const uint32_t *__restrict__ oth, int64_t n_pos,
+__global__ void __launch_bounds__(256) k_site_flag(const uint4 *__restrict__ cnt, const uint32_t *__restrict__ oth, int64_t n_pos, const uint8_t *__restrict__ blk_live,
                                                    uint8_t *__restrict__ flag8, uint32_t *__restrict__ blk_sites, uint32_t *__restrict__ blk_rows) {
     __shared__ uint32_t ws[4], wr[4];
+    if (!blk_live[blockIdx.x]) {                      // no record reaches this block's tile: nothing to read, nothing called
+        if (threadIdx.x == 0) { blk_sites[blockIdx.x] = 0u; blk_rows[blockIdx.x] = 0u; }
+        return;
+    }
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
     bool called = false;
     uint32_t rows = 0;
@@ -176,8 +186,9 @@ __global__ void __launch_bounds__(256) k_site_flag(const uint4 *__restrict__ cnt
 __global__ void __launch_bounds__(256) k_site_emit(const uint4 *__restrict__ cnt, const uint32_t *__restrict__ oth, const uint8_t *__restrict__ flag8,
                                                    const uint32_t *__restrict__ blk_sites_off, const uint32_t *__restrict__ blk_rows_off, const uint8_t *__restrict__ ref,
                                                    const int64_t *__restrict__ goff, int n_ctg, int64_t n_pos, fzp_site *__restrict__ sites,
-                                                   int64_t *__restrict__ site_g, int32_t *__restrict__ site_ctg) {
+                                                   int64_t *__restrict__ site_g, int32_t *__restrict__ site_ctg, const uint8_t *__restrict__ blk_live) {
     __shared__ uint32_t ws[4], wr[4];
+    if (!blk_live[blockIdx.x]) return;                // its flags were never written
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int lane = lane_id(), wv = threadIdx.x >> 6;
     const bool called = g < n_pos && flag8[g];
@@ -472,7 +483,9 @@ int fzp_k2_het_call(fzp_ctx *ctx, fzp_batch *b) {
     FZP_TRY(b->cnt.alloc((size_t)np * 4));
     FZP_TRY(b->oth.alloc((size_t)np));
     FZP_TRY(b->flag8.alloc((size_t)np));
-    const size_t nblk = (size_t)((np + 255) / 256);
+    const size_t nblk = (size_t)((np + 255) / 256);      // np is a multiple of FZP_POS_TILE: nblk a multiple of 8
+    FZP_TRY(b->blk_live.alloc(nblk + 8));
+    FZP_TRY(b->blk_live.zero(nblk + 8, st));
     FZP_TRY(b->site_idx.alloc(nblk));      // per 256-position block: sites, then their exclusive scan
     FZP_TRY(b->row_off32.alloc(nblk));     // per block: variant_map rows, then their exclusive scan
     RecView v = rec_view(b);
@@ -492,19 +505,15 @@ int fzp_k2_het_call(fzp_ctx *ctx, fzp_batch *b) {
             for (int32_t t0 = 0; t0 < b->h_limit[c]; t0 += PILE_TILE) { b->h_tile_ctg.push_back(c); b->h_tile_start.push_back(t0); }
         FZP_TRY(b->tile_ctg.upload(b->h_tile_ctg.data(), b->h_tile_ctg.size(), st));
         FZP_TRY(b->tile_start.upload(b->h_tile_start.data(), b->h_tile_start.size(), st));
-        FZP_TRY(b->oth.zero((size_t)np, st));
         {
             ProfScope ps(ctx, "k2_pileup_count");
             hipLaunchKernelGGL(k_pileup_tiles, dim3((unsigned)b->h_tile_ctg.size()), dim3(PILE_THREADS), 0, st, v, b->tile_ctg.p, b->tile_start.p, b->ctg_rec_begin.p, b->ctg_maxspan.p,
-                               b->rec_span.p, b->ck_off.p, b->ck_ref.p, b->ck_q.p, b->cnt.p, b->oth.p);
+                               b->rec_span.p, b->ck_off.p, b->ck_ref.p, b->ck_q.p, b->cnt.p, b->oth.p, (unsigned long long *)b->blk_live.p);
         }
-    } else if (np > 0) {
-        FZP_TRY(b->cnt.zero((size_t)np * 4, st));
-        FZP_TRY(b->oth.zero((size_t)np, st));
-    }
+    }                                                   // (no records: every block stays dead)
     if (np > 0) {
         ProfScope ps(ctx, "k2_site_flag");
-        hipLaunchKernelGGL(k_site_flag, dim3(grid_for(np, 256, 1 << 30)), dim3(256), 0, st, (const uint4 *)b->cnt.p, b->oth.p, np,
+        hipLaunchKernelGGL(k_site_flag, dim3(grid_for(np, 256, 1 << 30)), dim3(256), 0, st, (const uint4 *)b->cnt.p, b->oth.p, np, b->blk_live.p,
                            b->flag8.p, b->site_idx.p, b->row_off32.p);
     }
     FZP_TRY(fzp_exclusive_scan_u32(ctx, b->site_idx.p, b->site_idx.p, nblk, b->totals.p + 0));
@@ -523,7 +532,7 @@ int fzp_k2_het_call(fzp_ctx *ctx, fzp_batch *b) {
         {
             ProfScope ps(ctx, "k2_site_emit");
             hipLaunchKernelGGL(k_site_emit, dim3(grid_for(np, 256, 1 << 30)), dim3(256), 0, st, (const uint4 *)b->cnt.p, b->oth.p, b->flag8.p,
-                               b->site_idx.p, b->row_off32.p, b->ref.p, b->ctg_goff.p, b->n_ctg, np, b->sites.p, b->site_g.p, b->site_ctg.p);
+                               b->site_idx.p, b->row_off32.p, b->ref.p, b->ctg_goff.p, b->n_ctg, np, b->sites.p, b->site_g.p, b->site_ctg.p, b->blk_live.p);
         }
         {
             ProfScope ps(ctx, "k2_vmap_scatter");
