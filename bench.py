@@ -158,7 +158,7 @@ def cpu_baseline(contigs, blob, off, read_ctg, ids, job, hip_summ, budget_s=30.0
     cells_per_ctg = float(hip_summ["cells"].sum()) / max(1, n_ctg)
     n_sample = max(1, min(n_ctg, int(budget_s * 80e6 * cores / max(1.0, cells_per_ctg))))
     side = min(n_sample, cores)                                 # contigs in flight
-    thr = max(1, cores // side)                                 # threads per contig
+    thr = max(1, -(-cores // side))                             # threads per contig (rounded up: 9 contigs on 16 cores take 2 each)
     idxs = [np.flatnonzero(read_ctg == c) for c in range(n_sample)]
 
     def one(c):

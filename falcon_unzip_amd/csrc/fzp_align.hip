@@ -583,7 +583,7 @@ __device__ __forceinline__ void scalar_store16(void *base, uint32_t byte_off, ui
         const uint64_t gmask = __ballot(m == H);                                                           \
         Hn = max(hd, m - gap);                                                                             \
         const uint64_t dmask = __ballot(Hn == hd);                                                         \
-        scalar_store16(tbr, (uint32_t)__builtin_amdgcn_readfirstlane(t) * 16u, dmask, gmask);              \
+        if (STORE) scalar_store16(tbr, (uint32_t)__builtin_amdgcn_readfirstlane(t) * 16u, dmask, gmask);   \
         bool upd = Hn > bs;                                                                                \
         {                                                                                                  \
             const int32_t ci = i0 + lane, cj = t - ci;                                                     \
@@ -680,6 +680,38 @@ __device__ __forceinline__ void scalar_store16(void *base, uint32_t byte_off, ui
     "s_cbranch_scc1 Lsw%=_p" NP "RR\n\t"                                                          \
     "s_branch Lsw%=_p" NP "RD\n"
 // label "pPab": parity P (0: H in %[H], X in %[X]; 1: swapped), a = previous move, b = this move
+// the diagonal predecessor of lane k is lane k - 1 + (DOWN moves among the last two) of H(t-2)
+#define SW_BLOCK_ASM(ST)                                                                            \
+    asm volatile(                                                                                                                                                                   \
+        "s_nop 1\n\t"                                                                                                                                                               \
+        "s_cmp_eq_u32 %[dn], 0\n\t"                                                                                                                                                 \
+        "s_cbranch_scc1 Lsw%=_enterR\n\t"                                                                                                                                           \
+        "s_cmp_eq_u32 %[pm], 0\n\t"                                                                                                                                                 \
+        "s_cbranch_scc1 Lsw%=_p0RD\n\t"                                                                                                                                             \
+        "s_branch Lsw%=_p0DD\n"                                                                                                                                                     \
+        "Lsw%=_enterR:\n\t"                                                                                                                                                         \
+        "s_cmp_eq_u32 %[pm], 0\n\t"                                                                                                                                                 \
+        "s_cbranch_scc1 Lsw%=_p0RR\n\t"                                                                                                                                             \
+        "s_branch Lsw%=_p0DR\n"                                                                                                                                                     \
+                                                                                                                                                                                    \
+        SWB_DOWN("p0DD", "%[H]", "%[X]", "v_add_u32_dpp %[hd], %[X], %[sc]" SWB_DPP_SHL, "1", "", ST)                                                                               \
+        SWB_DOWN("p0RD", "%[H]", "%[X]", "v_add_u32_e32 %[hd], %[X], %[sc]", "1", "", ST)                                                                                           \
+        SWB_RIGHT("p0DR", "%[H]", "%[X]", "v_add_u32_e32 %[hd], %[X], %[sc]", "1", "", ST)                                                                                          \
+        SWB_RIGHT("p0RR", "%[H]", "%[X]", "v_add_u32_dpp %[hd], %[X], %[sc]" SWB_DPP_SHR, "1", "", ST)                                                                              \
+        SWB_DOWN("p1DD", "%[X]", "%[H]", "v_add_u32_dpp %[hd], %[H], %[sc]" SWB_DPP_SHL, "0", "v_max3_i32 %[kb], %[kb], %[X], %[H]\n\t", ST)                                        \
+        SWB_DOWN("p1RD", "%[X]", "%[H]", "v_add_u32_e32 %[hd], %[H], %[sc]", "0", "v_max3_i32 %[kb], %[kb], %[X], %[H]\n\t", ST)                                                    \
+        SWB_RIGHT("p1DR", "%[X]", "%[H]", "v_add_u32_e32 %[hd], %[H], %[sc]", "0", "v_max3_i32 %[kb], %[kb], %[X], %[H]\n\t", ST)                                                   \
+        SWB_RIGHT("p1RR", "%[X]", "%[H]", "v_add_u32_dpp %[hd], %[H], %[sc]" SWB_DPP_SHR, "0", "v_max3_i32 %[kb], %[kb], %[X], %[H]\n\t", ST)                                       \
+        "Lsw%=_end1:\n\t"                                                                                                                                                           \
+        "v_max_i32_e32 %[kb], %[kb], %[X]\n\t"                                                                                                                                      \
+        "v_swap_b32 %[H], %[X]\n"                                                                                                                                                   \
+        "Lsw%=_end0:\n\t"                                                                                                                                                           \
+        "s_cmp_gt_i32 %[top], %[bot]\n\t"                                                                                                                                           \
+        "s_cselect_b32 %[dn], 0, 1"                                                                                                                                                 \
+        : [H] "+v"(H), [X] "+v"(X), [qc] "+v"(qc), [tc] "+v"(tc), [kb] "+v"(kb), [mv] "+s"(mv), [soff] "+s"(soff),                                                                  \
+          [dn] "+s"(dn), [pm] "+s"(pm), [qsel] "+s"(qsel), [tsel] "+s"(tsel), [hd] "=&v"(hd), [mm] "=&v"(mm), [sc] "=&v"(sc), [top] "=&s"(top), [bot] "=&s"(bot)                    \
+        : [gap] "s"(gapS), [vmat] "v"(vmatS), [vmis] "v"(vmisS), [qb] "s"(qbits), [tb] "s"(tbits), [tbp] "s"(tbp)                                                                   \
+        : "vcc", "scc", "s56", "s57", "s60", "s61", "s62", "s63", "memory");
 #define SWB_STORE "s_store_dwordx4 s[60:63], %[tbp], %[soff]\n\t"
 template <bool STORE>
 __device__ __forceinline__ void sw_block(int32_t &H, int32_t &X, int32_t &qc, int32_t &tc, const uint64_t qbits, const uint64_t tbits, int32_t &kb,
@@ -687,37 +719,9 @@ __device__ __forceinline__ void sw_block(int32_t &H, int32_t &X, int32_t &qc, in
                                          const int32_t vmatS, const int32_t vmisS) {
     int32_t hd, mm, sc, top, bot;
     uint32_t qsel = 2u << 16, tsel = 2u << 16;   // s_bfe_u64 operand: width 2, offset 0
-    asm volatile(
-        "s_nop 1\n\t"
-        "s_cmp_eq_u32 %[dn], 0\n\t"
-        "s_cbranch_scc1 Lsw%=_enterR\n\t"
-        "s_cmp_eq_u32 %[pm], 0\n\t"
-        "s_cbranch_scc1 Lsw%=_p0RD\n\t"
-        "s_branch Lsw%=_p0DD\n"
-        "Lsw%=_enterR:\n\t"
-        "s_cmp_eq_u32 %[pm], 0\n\t"
-        "s_cbranch_scc1 Lsw%=_p0RR\n\t"
-        "s_branch Lsw%=_p0DR\n"
-        // the diagonal predecessor of lane k is lane k - 1 + (DOWN moves among the last two) of H(t-2)
-        SWB_DOWN("p0DD", "%[H]", "%[X]", "v_add_u32_dpp %[hd], %[X], %[sc]" SWB_DPP_SHL, "1", "")
-        SWB_DOWN("p0RD", "%[H]", "%[X]", "v_add_u32_e32 %[hd], %[X], %[sc]", "1", "")
-        SWB_RIGHT("p0DR", "%[H]", "%[X]", "v_add_u32_e32 %[hd], %[X], %[sc]", "1", "")
-        SWB_RIGHT("p0RR", "%[H]", "%[X]", "v_add_u32_dpp %[hd], %[X], %[sc]" SWB_DPP_SHR, "1", "")
-        SWB_DOWN("p1DD", "%[X]", "%[H]", "v_add_u32_dpp %[hd], %[H], %[sc]" SWB_DPP_SHL, "0", "v_max3_i32 %[kb], %[kb], %[X], %[H]\n\t")
-        SWB_DOWN("p1RD", "%[X]", "%[H]", "v_add_u32_e32 %[hd], %[H], %[sc]", "0", "v_max3_i32 %[kb], %[kb], %[X], %[H]\n\t")
-        SWB_RIGHT("p1DR", "%[X]", "%[H]", "v_add_u32_e32 %[hd], %[H], %[sc]", "0", "v_max3_i32 %[kb], %[kb], %[X], %[H]\n\t")
-        SWB_RIGHT("p1RR", "%[X]", "%[H]", "v_add_u32_dpp %[hd], %[H], %[sc]" SWB_DPP_SHR, "0", "v_max3_i32 %[kb], %[kb], %[X], %[H]\n\t")
-        "Lsw%=_end1:\n\t"                                    // an odd number of steps: the last H is not in the best-cell
-        "v_max_i32_e32 %[kb], %[kb], %[X]\n\t"              // key yet, and the roles are swapped
-        "v_swap_b32 %[H], %[X]\n"
-        "Lsw%=_end0:\n\t"
-        "s_cmp_gt_i32 %[top], %[bot]\n\t"
-        "s_cselect_b32 %[dn], 0, 1"
-        : [H] "+v"(H), [X] "+v"(X), [qc] "+v"(qc), [tc] "+v"(tc), [kb] "+v"(kb), [mv] "+s"(mv), [soff] "+s"(soff),
-          [dn] "+s"(dn), [pm] "+s"(pm), [qsel] "+s"(qsel), [tsel] "+s"(tsel), [hd] "=&v"(hd), [mm] "=&v"(mm), [sc] "=&v"(sc), [top] "=&s"(top), [bot] "=&s"(bot)
-        : [gap] "s"(gapS), [vmat] "v"(vmatS), [vmis] "v"(vmisS), [qb] "s"(qbits), [tb] "s"(tbits), [tbp] "s"(tbp)
-        : "vcc", "scc", "s56", "s57", "s60", "s61", "s62", "s63", "memory");
+    if constexpr (STORE) { SW_BLOCK_ASM(SWB_STORE) } else { SW_BLOCK_ASM("") }     // the variant without mask stores exists for one measurement (FZP_SW_NO_MASKS)
 }
+#undef SW_BLOCK_ASM
 #undef SWB_DOWN
 #undef SWB_RIGHT
 #undef SWB_DPP_SHL
@@ -733,6 +737,7 @@ __device__ __forceinline__ uint64_t base_window(const uint32_t *__restrict__ pk,
     return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)v);
 }
 
+template <bool STORE>
 __global__ void __launch_bounds__(64) k_sw(int64_t first, int64_t count, const int32_t *__restrict__ ridx, const uint32_t *__restrict__ read_ori,
                                             const int64_t *__restrict__ ori_woff, const int32_t *__restrict__ read_len, const int32_t *__restrict__ read_ctg,
                                             const uint32_t *__restrict__ ctg_pk, const int64_t *__restrict__ ctg_woff, const int64_t *__restrict__ ctg_len,
@@ -821,7 +826,7 @@ __global__ void __launch_bounds__(64) k_sw(int64_t first, int64_t count, const i
                 // it), and the add that would carry it past 2^31 -- the signed overflow of s_addk_i32 -- ends the block
                 uint32_t soff = 0x80000000u - 16u * (uint32_t)n_steps;
                 void *tbp = (void *)((char *)tbr + ((int64_t)__builtin_amdgcn_readfirstlane(t) * 16 - (int64_t)soff));
-                sw_block(H, X, qc, tc, qbits, tbits, kb, tbp, soff, mv, dn, pm, gapS, vmatS, vmisS);
+                sw_block<STORE>(H, X, qc, tc, qbits, tbits, kb, tbp, soff, mv, dn, pm, gapS, vmatS, vmisS);
                 H >>= 6;                                                 // the last step's countdown is 0, X's is 1
                 X >>= 6;
                 {   // fold the block's best cell into the running best (strictly greater: the earliest step wins ties)
@@ -885,34 +890,57 @@ constexpr int TBW_RPW = 16;                      // reads walked per wave
 
 struct WalkOut { int32_t ok, i, ts, i_end, j_end, ncol, n_ops, pad_; };   // (i, ts - i) = the cell before the alignment's first
 
+// Segmented form (TBS_*, default): the walk of a read is cut at every TBS_SEG-th DP step.  The walker of the top segment starts at the
+// read's best cell; the walker of every other segment starts, at the same time, at the segment's top step in band lane 32 -- a GUESS: the
+// steering keeps the path near the band's centre, and trace-backs from neighbouring cells of one anti-diagonal run into each other within
+// a few dozen steps (the best way into a cell next to the optimal path is the optimal path plus a gap).  Every walker goes TBS_OV steps
+// past its segment's bottom and notes, for the first and the last TBS_OV steps of its walk, which lane it was in and how many ops it had
+// emitted (`trail`); k_tb_stitch then finds, boundary by boundary, the first step at which the upper walker and the lower one sit in the
+// same cell, takes the upper one's ops up to there and the lower one's from there on, and writes the read's one op stream.  The result
+// is the serial walk's, op for op; a read with a boundary that does not merge inside TBS_OV steps is walked again serially (k_tb_walk<false>
+// over the flagged reads).  A read's walk is no longer one chain of 2.25 x its length: all walkers are TBS_SEG + TBS_OV steps long.
+constexpr int TBS_SEG = 4096, TBS_SEG_SHIFT = 12, TBS_OV = 256, TBS_RAW_WORDS = (TBS_SEG + TBS_OV) / 16 + 2, TBS_MAX_PIECES = 256;
+struct SegOut { int32_t state, i, ts, n_ops, i_start, j_start; };   // state 0: no such segment, 1: ran to its lower bound, 2: reached the matrix edge
+
+template <bool SEGMENTED>
 __global__ void __launch_bounds__(64) k_tb_walk(int64_t first, int64_t count, const Anchor *__restrict__ anc, const DpInfo *__restrict__ info,
                                                 const int64_t *__restrict__ tb_off, const int64_t *__restrict__ tbo, const int64_t *__restrict__ mvo,
                                                 const ulonglong2 *__restrict__ tb, const ulonglong2 *__restrict__ mvw, uint32_t *__restrict__ raw,
-                                                WalkOut *__restrict__ wout, const int32_t *__restrict__ order) {
+                                                WalkOut *__restrict__ wout, const int32_t *__restrict__ order, const int32_t *__restrict__ seg_slot,
+                                                const int32_t *__restrict__ seg_idx, uint32_t *__restrict__ trail, SegOut *__restrict__ segout, int only_flagged, int guess_lane) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[TBW_RPW * TBW_STRIDE];
     const int lane = threadIdx.x;
     const int64_t wq = (int64_t)blockIdx.x * TBW_RPW + lane;
-    const bool have = lane < TBW_RPW && wq < count;
-    // `order`: slots by decreasing read length -- the 16 reads of a wave are of similar length (a wave lasts as long as its longest walk)
-    // and the longest start first
-    const int64_t wv = have ? (order ? (int64_t)order[wq] : wq) : 0;
+    bool have = lane < TBW_RPW && wq < count;
+    // serial form: `order` = slots by decreasing read length -- the 16 reads of a wave are of similar length (a wave lasts as long as its
+    // longest walk) and the longest start first.  Segmented form: `count` walkers, walker wq = segment seg_idx[wq] of slot seg_slot[wq]
+    const int64_t wv = have ? (SEGMENTED ? (int64_t)seg_slot[wq] : (order ? (int64_t)order[wq] : wq)) : 0;
+    const int32_t seg = (SEGMENTED && have) ? seg_idx[wq] : 0;
     const int64_t r = first + wv;
+    if (!SEGMENTED && only_flagged) have = have && wout[r].ok == 2;        // second pass: only the reads whose stitching failed
     Anchor a = {0, 0, 0, 0};
     DpInfo di = {0, -1, 0, NEGV};
     if (have) { a = anc[r]; di = info[r]; }
     bool active = have && a.aligned && di.best_t >= 0 && di.best_score > 0;
+    const int32_t seg_top = di.best_t >> TBS_SEG_SHIFT;
+    if (SEGMENTED) active = active && seg <= seg_top;
     const int64_t soff = tb_off[r] - tb_off[first];                           // steps before this read in the chunk of reads
     // masks / move words of the winning candidate (second candidates sit behind the first ones in the same buffers)
     int64_t to_ = tbo[r], mo_ = mvo[r];
     asm volatile("" : "+v"(to_), "+v"(mo_));      // both offsets are in registers from here on: no pending load is attributed to the pointers below
     const ulonglong2 *tbr = tb + to_;                                         // per step {D mask, G mask}
     const ulonglong2 *mvr = mvw + mo_;                                        // per 64 steps {move bits, i0 before them}
-    uint32_t *rawp = raw + (soff >> 4);                                       // 16 ops per word
-    int32_t ts = active ? di.best_t : -1;
-    int32_t k = di.best_lane, i = -1;
+    uint32_t *rawp = SEGMENTED ? raw + wq * TBS_RAW_WORDS : raw + (soff >> 4);     // 16 ops per word
+    const bool spec = SEGMENTED && seg < seg_top;                             // a walker that starts on the guess
+    const int32_t ts0 = spec ? (seg + 1) * TBS_SEG - 1 : di.best_t;
+    int32_t ts = active ? ts0 : -1;
+    int32_t k = spec ? guess_lane : di.best_lane, i = -1;
+    const int32_t stop_ts = (SEGMENTED && seg > 0) ? seg * TBS_SEG - TBS_OV : (int32_t)0x80000000;   // walk while ts >= stop_ts
+    uint32_t *tr_head = SEGMENTED ? trail + wq * (2 * TBS_OV) : nullptr, *tr_tail = SEGMENTED ? tr_head + TBS_OV : nullptr;
+    const int32_t tail_top = seg * TBS_SEG - 1;                               // the boundary below this segment
     uint64_t w_prev = 0, pref_word = 0;      // move words: (after the first accept) w_cur = chunk of ts, w_prev = the one below
     uint64_t w_cur = 0;
-    if (active) {   // i0 at the best step = i0 before its 64-step chunk + DOWN moves up to and including it
+    if (active) {   // i0 at the start step = i0 before its 64-step chunk + DOWN moves up to and including it
         const ulonglong2 mw = mvr[ts >> 6];
         i = (int32_t)(int64_t)mw.y + __popcll(mw.x & ((2ull << (ts & 63)) - 1ull)) + k;
         w_prev = mw.x;
@@ -997,6 +1025,11 @@ __global__ void __launch_bounds__(64) k_tb_walk(int64_t first, int64_t count, co
         while (active && (ts >> 6) == cur_chunk && (uint32_t)(k - sh_cur) < 32u) {
             const uint2 m = *(const uint2 *)(win + (ts & 63) * 8);
             const uint32_t kk = (uint32_t)(k - sh_cur);
+            if (SEGMENTED) {      // where this walker is, for the stitching: its first TBS_OV steps and the TBS_OV steps below its segment
+                const uint32_t note = ((uint32_t)n_ops << 8) | (uint32_t)k;
+                if (ts0 - ts < TBS_OV) tr_head[ts0 - ts] = note;
+                if ((uint32_t)(tail_top - ts) < (uint32_t)TBS_OV) tr_tail[tail_top - ts] = note;
+            }
             const uint32_t db = (m.x >> kk) & 1u, gb = (m.y >> kk) & 1u;
             const uint32_t hi = (uint32_t)(P >> 32);
             const uint32_t d2 = hi >> 31, d3 = (hi >> 30) & 1u;
@@ -1014,16 +1047,100 @@ __global__ void __launch_bounds__(64) k_tb_walk(int64_t first, int64_t count, co
             rawacc |= op << nb;
             nb += 2u;
             if (nb == 32u) { rawp[nw++] = rawacc; rawacc = 0u; nb = 0u; }
-            active = (i | (ts - i)) >= 0;
+            active = (i | (ts - i)) >= 0 && ts >= stop_ts;
         }
         __syncthreads();
     }
 #undef TBW_ISSUE
     if (!have) return;
     if (nb) rawp[nw] = rawacc;
+    if (SEGMENTED) {
+        SegOut so;
+        so.state = !walked ? 0 : ((i | (ts - i)) < 0 ? 2 : 1);
+        so.i = i; so.ts = ts; so.n_ops = n_ops; so.i_start = i_end; so.j_start = j_end;
+        segout[wq] = so;
+        return;
+    }
     WalkOut o;
     o.ok = walked ? 1 : 0; o.i = i; o.ts = ts; o.i_end = i_end; o.j_end = j_end; o.ncol = ncol; o.n_ops = n_ops; o.pad_ = 0;
     wout[r] = o;
+}
+
+// ---- trace-back, part 1b: one wave per read joins its segments' walks (k_tb_walk<true>) into the read's op stream.
+__global__ void __launch_bounds__(64) k_tb_stitch(int64_t first, int64_t count, const Anchor *__restrict__ anc, const DpInfo *__restrict__ info,
+                                                  const int64_t *__restrict__ tb_off, const int32_t *__restrict__ seg_off, const uint32_t *__restrict__ trail,
+                                                  const SegOut *__restrict__ segout, const uint32_t *__restrict__ raw_seg, uint32_t *__restrict__ raw,
+                                                  WalkOut *__restrict__ wout) {
+    __shared__ int32_t p_w[TBS_MAX_PIECES], p_a[TBS_MAX_PIECES], p_out[TBS_MAX_PIECES + 1];     // piece: walker, first op taken from it, first op of the output it fills
+    const int lane = lane_id();
+    const int64_t wv = blockIdx.x;
+    if (wv >= count) return;
+    const int64_t r = first + wv;
+    const Anchor a = anc[r];
+    const DpInfo di = info[r];
+    WalkOut o;
+    memset(&o, 0, sizeof o);
+    if (!(a.aligned && di.best_t >= 0 && di.best_score > 0)) { if (lane == 0) wout[r] = o; return; }
+    const int32_t S = di.best_t >> TBS_SEG_SHIFT;
+    const int32_t w0 = seg_off[wv];
+    const SegOut top = segout[w0 + S];
+    if (top.state == 0) { if (lane == 0) wout[r] = o; return; }                 // the best cell itself is outside the matrix: no walk (as the serial form)
+    o.i_end = top.i_start; o.j_end = top.j_start;
+    bool fail = S + 1 > TBS_MAX_PIECES;
+    int32_t start = 0, outpos = 0, np = 0, fin_i = 0, fin_ts = 0;
+    for (int32_t sg = S; sg >= 0 && !fail; sg--) {                               // wave-uniform
+        const SegOut so = segout[w0 + sg];
+        if (so.state == 0) { fail = true; break; }
+        if (so.state == 2 || sg == 0) {                                          // the path ends inside this segment: its walker's remaining ops are the last piece
+            if (lane == 0) { p_w[np] = w0 + sg; p_a[np] = start; p_out[np] = outpos; }
+            outpos += so.n_ops - start; np++;
+            fin_i = so.i; fin_ts = so.ts;
+            break;
+        }
+        const uint32_t *ta = trail + (int64_t)(w0 + sg) * (2 * TBS_OV) + TBS_OV, *hb = trail + (int64_t)(w0 + sg - 1) * (2 * TBS_OV);
+        int32_t ia = -1, ib = -1;
+        for (int d0 = 0; d0 < TBS_OV; d0 += 64) {
+            const uint32_t ua = ta[d0 + lane], ub = hb[d0 + lane];
+            const uint64_t m = __ballot(ua != 0xffffffffu && ub != 0xffffffffu && (ua & 0xffu) == (ub & 0xffu));
+            if (m) {
+                const int l = __builtin_ctzll(m);                                 // the first common cell below the boundary
+                ia = __builtin_amdgcn_readlane((int32_t)(ua >> 8), l); ib = __builtin_amdgcn_readlane((int32_t)(ub >> 8), l);
+                break;
+            }
+        }
+        if (ia < start) { fail = true; break; }                                   // no common cell inside TBS_OV steps (ia = -1), or before this walker joined the path
+        if (lane == 0) { p_w[np] = w0 + sg; p_a[np] = start; p_out[np] = outpos; }
+        outpos += ia - start; np++;
+        start = ib;
+    }
+    if (fail) { o.ok = 2; if (lane == 0) wout[r] = o; return; }                   // k_tb_walk<false> walks this read serially
+    if (lane == 0) p_out[np] = outpos;
+    __syncthreads();
+    // the pieces, one after the other, into the read's stream: a lane builds an output word from the (at most two) source words under it
+    uint32_t *rg = raw + ((tb_off[r] - tb_off[first]) >> 4);
+    const int32_t L = outpos, nW = (L + 15) >> 4;
+    for (int32_t wi = lane; wi < nW; wi += 64) {
+        const int32_t o0 = 16 * wi, o1 = min(o0 + 16, L);
+        int32_t pc = 0;
+        while (pc + 1 < np && p_out[pc + 1] <= o0) pc++;
+        uint32_t word = 0;
+        int32_t oo = o0;
+        while (oo < o1) {
+            const int32_t pe = min(o1, p_out[pc + 1]);                            // ops [oo, pe) come from piece pc
+            const int32_t sa = p_a[pc] + (oo - p_out[pc]);                        // first source op
+            const uint32_t *src = raw_seg + (int64_t)p_w[pc] * TBS_RAW_WORDS;
+            const int32_t sw = sa >> 4, sb = (sa & 15) * 2;
+            const uint64_t two = (uint64_t)src[sw] | ((uint64_t)src[sw + 1] << 32);   // (a walker's buffer has a spare word)
+            uint32_t bits = (uint32_t)(two >> sb);
+            const int32_t cnt = pe - oo;
+            if (cnt < 16) bits &= (1u << (2 * cnt)) - 1u;
+            word |= bits << (2 * (oo - o0));
+            oo = pe; pc++;
+        }
+        rg[wi] = word;
+    }
+    o.ok = 1; o.i = fin_i; o.ts = fin_ts; o.ncol = 0; o.n_ops = L;               // ncol (and i, ts after trimming) are k_tb_cigar's pass 0's
+    if (lane == 0) wout[r] = o;
 }
 
 // ---- trace-back, part 2: one wave per read turns the walk's op stream (alignment end first, 16 ops per word)
@@ -1490,6 +1607,10 @@ struct fzp_alnjob {
     DevBuf<uint2> tb2[2];
     DevBuf<uint32_t> raw2[2];                    // the walk's 2-bit op streams
     DevBuf<WalkOut> wout;
+    DevBuf<int32_t> seg_off, seg_slot, seg_idx;  // segmented trace-back: per read its first walker (chunk-relative); per walker its slot (chunk-relative) and segment
+    std::vector<int64_t> h_seg_base, h_seg_cnt;  // per chunk start (indexed by its first read): first walker in seg_slot / seg_idx, number of walkers
+    DevBuf<uint32_t> raw_seg2[2], trail2[2];
+    DevBuf<SegOut> segout2[2];
     DevBuf<int32_t> lpt;                         // per read: the slot (relative to its chunk's first read) that wave / lane number x of the chunk's launches takes --
     int64_t lpt_chunk_steps = -1;                // longest reads first (k_sw, k_tb_walk); rebuilt when the chunking changes
     // record planning: reads grouped by contig (input order inside a contig); built on first use
@@ -1750,7 +1871,8 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
         if (j->lpt_chunk_steps != chunk_steps || split_rounds) {
             // launch order inside every chunk of reads: longest first (LPT over the wave slots).  One wave per read, workgroups dispatched in
             // index order: with reads of uneven length in input order the grid's tail is whatever long read happened to come last.
-            std::vector<int32_t> ord((size_t)nr);
+            std::vector<int32_t> ord((size_t)nr), sgo((size_t)nr), sgs, sgi;
+            j->h_seg_base.assign((size_t)nr + 1, 0); j->h_seg_cnt.assign((size_t)nr + 1, 0);
             for (int64_t f = 0; f < nr;) {
                 int64_t l = f;
                 while (l < nr && j->h_tb_off[(size_t)l + 1] - j->h_tb_off[(size_t)f] <= chunk_steps) l++;
@@ -1761,13 +1883,31 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
                 }
                 for (int64_t r = f; r < l; r++) ord[(size_t)r] = (int32_t)(r - f);
                 std::stable_sort(ord.begin() + f, ord.begin() + l, [&](int32_t a, int32_t b) { return j->h_read_len[(size_t)(f + a)] > j->h_read_len[(size_t)(f + b)]; });
+                // walkers of the segmented trace-back: one per TBS_SEG steps of every read's step capacity, longest reads first
+                j->h_seg_base[(size_t)f] = (int64_t)sgs.size();
+                std::vector<int32_t> w_first((size_t)(l - f));
+                int64_t nw_chunk = 0;
+                for (int64_t r = f; r < l; r++) { sgo[(size_t)r] = (int32_t)nw_chunk; nw_chunk += (j->h_tb_off[(size_t)r + 1] - j->h_tb_off[(size_t)r] + TBS_SEG - 1) / TBS_SEG; }
+                if (nw_chunk >= (1ll << 31)) { fzp_set_error("fzp_align_run: too many trace-back segments in one chunk"); return FZP_EINVAL; }
+                sgs.resize(sgs.size() + (size_t)nw_chunk); sgi.resize(sgs.size());
+                for (int64_t r = f; r < l; r++) {
+                    const int64_t ns = (j->h_tb_off[(size_t)r + 1] - j->h_tb_off[(size_t)r] + TBS_SEG - 1) / TBS_SEG;
+                    for (int64_t x = 0; x < ns; x++) { sgs[(size_t)(j->h_seg_base[(size_t)f] + sgo[(size_t)r] + x)] = (int32_t)(r - f); sgi[(size_t)(j->h_seg_base[(size_t)f] + sgo[(size_t)r] + x)] = (int32_t)x; }
+                }
+                j->h_seg_cnt[(size_t)f] = nw_chunk;
                 f = l;
             }
             FZP_TRY(j->lpt.upload(ord.data(), (size_t)nr, st));
+            FZP_TRY(j->seg_off.upload(sgo.data(), (size_t)nr, st));
+            FZP_TRY(j->seg_slot.upload(sgs.data(), sgs.size(), st)); FZP_TRY(j->seg_idx.upload(sgi.data(), sgi.size(), st));
             j->lpt_chunk_steps = split_rounds ? -1 : chunk_steps;
         }
         const bool use_lpt = getenv("FZP_SW_INPUT_ORDER") == nullptr;      // FZP_SW_INPUT_ORDER=1: the r2 launch order, for comparisons
         const bool use_prio = getenv("FZP_SW_NO_PRIO") == nullptr;
+        int guess_lane = 32;                                                    // where the speculative walkers start (tests push it to the band's edge to exercise the fallback)
+        if (const char *e = getenv("FZP_TB_GUESS_LANE")) { const int g = atoi(e); if (g >= 0 && g < 64) guess_lane = g; }
+        const bool tb_serial = getenv("FZP_TB_SERIAL") != nullptr;             // FZP_TB_SERIAL=1: the r2 trace-back (one walker per read), for comparisons
+        const bool no_masks = getenv("FZP_SW_NO_MASKS") != nullptr;          // MEASUREMENT ONLY: the DP without its trace-back stores; the alignments that follow are garbage
         int64_t sum_len = 0;
         for (int64_t r = 0; r < nr; r++) sum_len += j->h_read_len[(size_t)r];
         const int32_t mean_len = (int32_t)std::max<int64_t>(1, sum_len / std::max<int64_t>(nr, 1));
@@ -1801,14 +1941,14 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
             FZP_TRY(j->raw2[bi].alloc((size_t)(steps / 16 + 64)));
             {
                 ProfScope ps(ctx, "k1_sw");
-                hipLaunchKernelGGL(k_sw, dim3((unsigned)cnt), dim3(64), 0, st, first, cnt, (const int32_t *)nullptr, j->read_ori.p, j->read_woff.p, j->read_len.p, j->read_ctg.p,
+                hipLaunchKernelGGL(no_masks ? k_sw<false> : k_sw<true>, dim3((unsigned)cnt), dim3(64), 0, st, first, cnt, (const int32_t *)nullptr, j->read_ori.p, j->read_woff.p, j->read_len.p, j->read_ctg.p,
                                    j->ctg_pk.p, j->ctg_woff.p, j->ctg_len.p, j->anc.p, j->tb_off.p, j->tb2[bi].p, j->mvw2[bi].p, P.match, P.mismatch, P.gap, j->info.p, j->tbo.p, j->mvo.p,
                                    use_lpt ? (const int32_t *)(j->lpt.p + first) : (const int32_t *)nullptr, use_prio ? mean_len : 0);
             }
             if (c2 > 0) {     // same kernel over the compacted list, then the better extension of each read survives
                 {
                     ProfScope ps(ctx, "k1_sw2");
-                    hipLaunchKernelGGL(k_sw, dim3((unsigned)c2), dim3(64), 0, st, (int64_t)w_lo, c2, j->ridx.p, j->sec_ori.p, j->sec_woff.p, j->read_len.p, j->read_ctg.p,
+                    hipLaunchKernelGGL(k_sw<true>, dim3((unsigned)c2), dim3(64), 0, st, (int64_t)w_lo, c2, j->ridx.p, j->sec_ori.p, j->sec_woff.p, j->read_len.p, j->read_ctg.p,
                                        j->ctg_pk.p, j->ctg_woff.p, j->ctg_len.p, j->anc2.p, j->tb_off2.p, j->tb2[bi].p + 2 * tb_base, j->mvw2[bi].p + mv_base, P.match, P.mismatch,
                                        P.gap, j->info2.p, (int64_t *)nullptr, (int64_t *)nullptr, (const int32_t *)nullptr, 0);
                 }
@@ -1820,11 +1960,28 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
             w_lo = w_hi;
             FZP_HIP(hipEventRecord(j->ev_sw[bi], st));
             FZP_HIP(hipStreamWaitEvent(st2, j->ev_sw[bi], 0));
-            {
+            if (tb_serial) {
                 ProfScope ps(ctx, "k1_traceback", st2);
-                hipLaunchKernelGGL(k_tb_walk, dim3((unsigned)((cnt + TBW_RPW - 1) / TBW_RPW)), dim3(64), 0, st2, first, cnt, j->anc.p, j->info.p, j->tb_off.p,
+                hipLaunchKernelGGL(k_tb_walk<false>, dim3((unsigned)((cnt + TBW_RPW - 1) / TBW_RPW)), dim3(64), 0, st2, first, cnt, j->anc.p, j->info.p, j->tb_off.p,
                                    j->tbo.p, j->mvo.p, (const ulonglong2 *)j->tb2[bi].p, (const ulonglong2 *)j->mvw2[bi].p, j->raw2[bi].p, j->wout.p,
-                                   use_lpt ? (const int32_t *)(j->lpt.p + first) : (const int32_t *)nullptr);
+                                   use_lpt ? (const int32_t *)(j->lpt.p + first) : (const int32_t *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr,
+                                   (uint32_t *)nullptr, (SegOut *)nullptr, 0, 32);
+            } else {
+                const int64_t nwk = j->h_seg_cnt[(size_t)first], wbase = j->h_seg_base[(size_t)first];
+                FZP_TRY(j->raw_seg2[bi].alloc((size_t)nwk * TBS_RAW_WORDS + 64));
+                FZP_TRY(j->trail2[bi].alloc((size_t)nwk * 2 * TBS_OV + 64));
+                FZP_TRY(j->segout2[bi].alloc((size_t)nwk + 1));
+                ProfScope ps(ctx, "k1_traceback", st2);
+                FZP_HIP(hipMemsetAsync(j->trail2[bi].p, 0xff, (size_t)nwk * 2 * TBS_OV * 4, st2));
+                hipLaunchKernelGGL(k_tb_walk<true>, dim3((unsigned)((nwk + TBW_RPW - 1) / TBW_RPW)), dim3(64), 0, st2, first, nwk, j->anc.p, j->info.p, j->tb_off.p,
+                                   j->tbo.p, j->mvo.p, (const ulonglong2 *)j->tb2[bi].p, (const ulonglong2 *)j->mvw2[bi].p, j->raw_seg2[bi].p, j->wout.p,
+                                   (const int32_t *)nullptr, (const int32_t *)(j->seg_slot.p + wbase), (const int32_t *)(j->seg_idx.p + wbase), j->trail2[bi].p, j->segout2[bi].p, 0, guess_lane);
+                hipLaunchKernelGGL(k_tb_stitch, dim3((unsigned)cnt), dim3(64), 0, st2, first, cnt, j->anc.p, j->info.p, j->tb_off.p, (const int32_t *)(j->seg_off.p + first),
+                                   (const uint32_t *)j->trail2[bi].p, (const SegOut *)j->segout2[bi].p, (const uint32_t *)j->raw_seg2[bi].p, j->raw2[bi].p, j->wout.p);
+                // reads whose segments did not join (flagged by the stitching) are walked in one piece; every other wave of this launch leaves at once
+                hipLaunchKernelGGL(k_tb_walk<false>, dim3((unsigned)((cnt + TBW_RPW - 1) / TBW_RPW)), dim3(64), 0, st2, first, cnt, j->anc.p, j->info.p, j->tb_off.p,
+                                   j->tbo.p, j->mvo.p, (const ulonglong2 *)j->tb2[bi].p, (const ulonglong2 *)j->mvw2[bi].p, j->raw2[bi].p, j->wout.p,
+                                   (const int32_t *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr, (uint32_t *)nullptr, (SegOut *)nullptr, 1, 32);
             }
             {
                 ProfScope ps(ctx, "k1_cigar", st2);

@@ -434,6 +434,30 @@ def test_launch_order_does_not_change_results(eng, monkeypatch):
     assert np.array_equal(got["lpt"][0], got["input"][0]) and got["lpt"][1] == got["input"][1]
 
 
+def test_segmented_traceback_equals_serial_walk(eng, monkeypatch):
+    """The trace-back walks a read as segments of 4 096 DP steps at once (speculative starts in the band's centre, stitched where neighbouring
+    walkers meet) -- the op stream must be the serial walk's (FZP_TB_SERIAL=1), also when the guesses are bad: FZP_TB_GUESS_LANE=1 starts the
+    walkers at the band's edge, where some do not meet their neighbour inside the overlap and the read falls back to the serial walk."""
+    from falcon_unzip_amd import _lib
+    n = 500
+    ctg, blob, off, *_ = _shaped(49, 1_000_000, n)
+    got = {}
+    for mode, env in (("segmented", {}), ("serial", {"FZP_TB_SERIAL": "1"}), ("edge_guess", {"FZP_TB_GUESS_LANE": "1"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        job = _lib.align_job_raw(eng, [ctg], blob, off, np.zeros(n, np.int32))
+        job.run()
+        aln = job.alnset(0)[0]
+        got[mode] = (job.summaries().copy(), [aln.cigar_of(k) for k in range(aln.n_rec)])
+        job.close()
+        for k in env:
+            monkeypatch.delenv(k)
+    assert got["serial"][0]["aligned"].mean() > 0.99 and (np.diff(off) > 40000).sum() >= 3       # reads of a dozen and more segments are in
+    for mode in ("segmented", "edge_guess"):
+        assert np.array_equal(got[mode][0], got["serial"][0]), mode
+        assert got[mode][1] == got["serial"][1], mode
+
+
 def test_record_planning_at_deep_coverage(eng):
     """A contig with 24 000 reads (many starting in the same 256-bp bin, many at the same POS): the device's record planning (binned rank,
     fzp_align_to_batch) must order records exactly like the host's sort behind fzp_align_alnset ('samtools sort' order: POS, then read index)."""
