@@ -251,7 +251,8 @@ def shaped_leg(eng, inp):
             os.environ.pop("FZP_SW_NO_PRIO", None)
         summ = job.summaries()
         sw_ms, sw_n = pr.get("k1_sw", (0.0, 0))
-        res[mode] = {"k1_sw_ms": round(sw_ms / max(1, sw_n), 3), "k1_traceback_ms": round(pr.get("k1_traceback", (0.0, 0))[0] / max(1, sw_n), 3),
+        fb = job.tb_fallbacks()
+        res[mode] = {"traceback_serial_fallback_reads": fb, "k1_sw_ms": round(sw_ms / max(1, sw_n), 3), "k1_traceback_ms": round(pr.get("k1_traceback", (0.0, 0))[0] / max(1, sw_n), 3),
                      "dp_gcell_per_s": round(float(summ["cells"].sum()) / (sw_ms / max(1, sw_n) * 1e-3) / 1e9, 2) if sw_ms else 0.0}
     lens = np.diff(off)
     inside = (summ["q_end"] - summ["q_start"])[summ["aligned"] == 1]

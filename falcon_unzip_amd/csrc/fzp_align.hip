@@ -502,6 +502,8 @@ __global__ void __launch_bounds__(256) k_orient(int64_t first, const uint32_t *_
 }
 
 struct DpInfo { int32_t steps, best_t, best_lane, best_score; };
+// segmented trace-back (k_tb_walk<true>, below): segment length in DP steps, overlap, ops buffer per walker, pieces per read
+constexpr int TBS_SEG = 4096, TBS_SEG_SHIFT = 12, TBS_OV = 256, TBS_RAW_WORDS = (TBS_SEG + TBS_OV) / 16 + 2, TBS_MAX_PIECES = 256;
 
 // wave-wide shifts by one lane (gfx9 DPP wave_shr / wave_shl); vacated lane takes `fill`
 __device__ __forceinline__ int32_t wave_shr1(int32_t v, int32_t fill) {   // lane k <- lane k-1
@@ -604,7 +606,16 @@ __device__ __forceinline__ void scalar_store16(void *base, uint32_t byte_off, ui
 #define SW_FLUSH(PARTIAL)                                                                                  \
     {                                                                                                      \
         if ((PARTIAL) || ((t - 1) & 63) == 63) {                                                           \
-            if (lane == 0) mvr[(t - 1) >> 6] = make_ulonglong2(mvacc, (uint64_t)(int64_t)(i0 - __popcll(mvacc))); \
+            uint32_t glane = 32u;                                                                          \
+            if ((t & (TBS_SEG - 1)) == 0) {   /* step t-1 tops a trace-back segment: the lane of its best H is where that segment's walker starts */ \
+                int32_t hv = H, hl = lane;                                                                 \
+                _Pragma("unroll") for (int d_ = 32; d_ >= 1; d_ >>= 1) {                                   \
+                    const int32_t ov_ = __shfl_xor(hv, d_, 64), ol_ = __shfl_xor(hl, d_, 64);              \
+                    if (ov_ > hv || (ov_ == hv && ol_ < hl)) { hv = ov_; hl = ol_; }                       \
+                }                                                                                          \
+                glane = (uint32_t)hl;                                                                      \
+            }                                                                                              \
+            if (lane == 0) mvr[(t - 1) >> 6] = make_ulonglong2(mvacc, (uint64_t)(uint32_t)(i0 - __popcll(mvacc)) | ((uint64_t)glane << 32)); \
             mvacc = 0;                                                                                     \
         }                                                                                                  \
     }
@@ -899,7 +910,6 @@ struct WalkOut { int32_t ok, i, ts, i_end, j_end, ncol, n_ops, pad_; };   // (i,
 // same cell, takes the upper one's ops up to there and the lower one's from there on, and writes the read's one op stream.  The result
 // is the serial walk's, op for op; a read with a boundary that does not merge inside TBS_OV steps is walked again serially (k_tb_walk<false>
 // over the flagged reads).  A read's walk is no longer one chain of 2.25 x its length: all walkers are TBS_SEG + TBS_OV steps long.
-constexpr int TBS_SEG = 4096, TBS_SEG_SHIFT = 12, TBS_OV = 256, TBS_RAW_WORDS = (TBS_SEG + TBS_OV) / 16 + 2, TBS_MAX_PIECES = 256;
 struct SegOut { int32_t state, i, ts, n_ops, i_start, j_start; };   // state 0: no such segment, 1: ran to its lower bound, 2: reached the matrix edge
 
 template <bool SEGMENTED>
@@ -934,7 +944,7 @@ __global__ void __launch_bounds__(64) k_tb_walk(int64_t first, int64_t count, co
     const bool spec = SEGMENTED && seg < seg_top;                             // a walker that starts on the guess
     const int32_t ts0 = spec ? (seg + 1) * TBS_SEG - 1 : di.best_t;
     int32_t ts = active ? ts0 : -1;
-    int32_t k = spec ? guess_lane : di.best_lane, i = -1;
+    int32_t k = di.best_lane, i = -1;
     const int32_t stop_ts = (SEGMENTED && seg > 0) ? seg * TBS_SEG - TBS_OV : (int32_t)0x80000000;   // walk while ts >= stop_ts
     uint32_t *tr_head = SEGMENTED ? trail + wq * (2 * TBS_OV) : nullptr, *tr_tail = SEGMENTED ? tr_head + TBS_OV : nullptr;
     const int32_t tail_top = seg * TBS_SEG - 1;                               // the boundary below this segment
@@ -942,7 +952,8 @@ __global__ void __launch_bounds__(64) k_tb_walk(int64_t first, int64_t count, co
     uint64_t w_cur = 0;
     if (active) {   // i0 at the start step = i0 before its 64-step chunk + DOWN moves up to and including it
         const ulonglong2 mw = mvr[ts >> 6];
-        i = (int32_t)(int64_t)mw.y + __popcll(mw.x & ((2ull << (ts & 63)) - 1ull)) + k;
+        if (spec) k = guess_lane >= 0 ? guess_lane : (int32_t)(mw.y >> 32);      // k_sw left the lane of the best H of a segment's top step next to its move word
+        i = (int32_t)(uint32_t)mw.y + __popcll(mw.x & ((2ull << (ts & 63)) - 1ull)) + k;
         w_prev = mw.x;
         pref_word = (ts >> 6) > 0 ? mvr[(ts >> 6) - 1].x : 0ull;
     }
@@ -1070,7 +1081,7 @@ __global__ void __launch_bounds__(64) k_tb_walk(int64_t first, int64_t count, co
 __global__ void __launch_bounds__(64) k_tb_stitch(int64_t first, int64_t count, const Anchor *__restrict__ anc, const DpInfo *__restrict__ info,
                                                   const int64_t *__restrict__ tb_off, const int32_t *__restrict__ seg_off, const uint32_t *__restrict__ trail,
                                                   const SegOut *__restrict__ segout, const uint32_t *__restrict__ raw_seg, uint32_t *__restrict__ raw,
-                                                  WalkOut *__restrict__ wout) {
+                                                  WalkOut *__restrict__ wout, uint32_t *__restrict__ n_fallback) {
     __shared__ int32_t p_w[TBS_MAX_PIECES], p_a[TBS_MAX_PIECES], p_out[TBS_MAX_PIECES + 1];     // piece: walker, first op taken from it, first op of the output it fills
     const int lane = lane_id();
     const int64_t wv = blockIdx.x;
@@ -1113,7 +1124,7 @@ __global__ void __launch_bounds__(64) k_tb_stitch(int64_t first, int64_t count, 
         outpos += ia - start; np++;
         start = ib;
     }
-    if (fail) { o.ok = 2; if (lane == 0) wout[r] = o; return; }                   // k_tb_walk<false> walks this read serially
+    if (fail) { o.ok = 2; if (lane == 0) { wout[r] = o; atomicAdd(n_fallback, 1u); } return; }    // k_tb_walk<false> walks this read serially
     if (lane == 0) p_out[np] = outpos;
     __syncthreads();
     // the pieces, one after the other, into the read's stream: a lane builds an output word from the (at most two) source words under it
@@ -1611,6 +1622,7 @@ struct fzp_alnjob {
     std::vector<int64_t> h_seg_base, h_seg_cnt;  // per chunk start (indexed by its first read): first walker in seg_slot / seg_idx, number of walkers
     DevBuf<uint32_t> raw_seg2[2], trail2[2];
     DevBuf<SegOut> segout2[2];
+    DevBuf<uint32_t> tb_fallback;                // reads of the last run whose segments did not join and were walked serially
     DevBuf<int32_t> lpt;                         // per read: the slot (relative to its chunk's first read) that wave / lane number x of the chunk's launches takes --
     int64_t lpt_chunk_steps = -1;                // longest reads first (k_sw, k_tb_walk); rebuilt when the chunking changes
     // record planning: reads grouped by contig (input order inside a contig); built on first use
@@ -1866,6 +1878,8 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
         const int64_t total_steps = j->h_tb_off[(size_t)nr];
         int64_t chunk_steps = std::min<int64_t>(budget_steps / 2, (total_steps + n_chunks - 1) / n_chunks);
         FZP_TRY(j->wout.alloc((size_t)nr));
+        FZP_TRY(j->tb_fallback.alloc(2));
+        FZP_TRY(j->tb_fallback.zero(2, st));
         if (!j->ev_sw[0]) for (int k = 0; k < 2; k++) { FZP_HIP(hipEventCreateWithFlags(&j->ev_sw[k], hipEventDisableTiming)); FZP_HIP(hipEventCreateWithFlags(&j->ev_tb[k], hipEventDisableTiming)); }
         hipStream_t st2 = ctx->stream2;
         if (j->lpt_chunk_steps != chunk_steps || split_rounds) {
@@ -1904,7 +1918,7 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
         }
         const bool use_lpt = getenv("FZP_SW_INPUT_ORDER") == nullptr;      // FZP_SW_INPUT_ORDER=1: the r2 launch order, for comparisons
         const bool use_prio = getenv("FZP_SW_NO_PRIO") == nullptr;
-        int guess_lane = 32;                                                    // where the speculative walkers start (tests push it to the band's edge to exercise the fallback)
+        int guess_lane = -1;                                                    // -1: the lane k_sw recorded (best H of the segment's top step); tests push it to the band's edge to exercise the fallback
         if (const char *e = getenv("FZP_TB_GUESS_LANE")) { const int g = atoi(e); if (g >= 0 && g < 64) guess_lane = g; }
         const bool tb_serial = getenv("FZP_TB_SERIAL") != nullptr;             // FZP_TB_SERIAL=1: the r2 trace-back (one walker per read), for comparisons
         const bool no_masks = getenv("FZP_SW_NO_MASKS") != nullptr;          // MEASUREMENT ONLY: the DP without its trace-back stores; the alignments that follow are garbage
@@ -1977,7 +1991,7 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
                                    j->tbo.p, j->mvo.p, (const ulonglong2 *)j->tb2[bi].p, (const ulonglong2 *)j->mvw2[bi].p, j->raw_seg2[bi].p, j->wout.p,
                                    (const int32_t *)nullptr, (const int32_t *)(j->seg_slot.p + wbase), (const int32_t *)(j->seg_idx.p + wbase), j->trail2[bi].p, j->segout2[bi].p, 0, guess_lane);
                 hipLaunchKernelGGL(k_tb_stitch, dim3((unsigned)cnt), dim3(64), 0, st2, first, cnt, j->anc.p, j->info.p, j->tb_off.p, (const int32_t *)(j->seg_off.p + first),
-                                   (const uint32_t *)j->trail2[bi].p, (const SegOut *)j->segout2[bi].p, (const uint32_t *)j->raw_seg2[bi].p, j->raw2[bi].p, j->wout.p);
+                                   (const uint32_t *)j->trail2[bi].p, (const SegOut *)j->segout2[bi].p, (const uint32_t *)j->raw_seg2[bi].p, j->raw2[bi].p, j->wout.p, j->tb_fallback.p);
                 // reads whose segments did not join (flagged by the stitching) are walked in one piece; every other wave of this launch leaves at once
                 hipLaunchKernelGGL(k_tb_walk<false>, dim3((unsigned)((cnt + TBW_RPW - 1) / TBW_RPW)), dim3(64), 0, st2, first, cnt, j->anc.p, j->info.p, j->tb_off.p,
                                    j->tbo.p, j->mvo.p, (const ulonglong2 *)j->tb2[bi].p, (const ulonglong2 *)j->mvw2[bi].p, j->raw2[bi].p, j->wout.p,
@@ -2017,6 +2031,14 @@ int fetch_summaries(fzp_ctx *ctx, fzp_alnjob *j) {
 }  // namespace
 
 extern "C" int64_t fzp_align_n_second(const fzp_alnjob *j) { return j ? j->n_second : 0; }
+extern "C" int fzp_align_tb_fallbacks(fzp_ctx *ctx, fzp_alnjob *j, int64_t *n) {
+    if (!ctx || !j || !j->done || !n) { fzp_set_error("fzp_align_tb_fallbacks: run the job first"); return FZP_EINVAL; }
+    FZP_TRY(fzp_bind(ctx));
+    uint32_t v = 0;
+    if (j->tb_fallback.p) { FZP_HIP(hipMemcpyAsync(&v, j->tb_fallback.p, 4, hipMemcpyDeviceToHost, ctx->stream)); FZP_HIP(hipStreamSynchronize(ctx->stream)); }
+    *n = (int64_t)v;
+    return FZP_OK;
+}
 
 extern "C" int fzp_align_summaries(fzp_ctx *ctx, fzp_alnjob *j, fzp_aln_summary *out) {
     if (!ctx || !j || !j->done || !out) { fzp_set_error("fzp_align_summaries: run the job first"); return FZP_EINVAL; }
