@@ -535,11 +535,11 @@ class AlignJob:
         _check(load().fzp_job_phase_write(self.eng._p, self._p, C.byref(nm), C.byref(opts), C.byref(out)))
         return _pipe_result(out)
 
-    def tb_fallbacks(self) -> int:
-        """reads of the last run whose trace-back segments did not join and were walked serially (statistic only)"""
-        n = C.c_int64()
-        _check(load().fzp_align_tb_fallbacks(self.eng._p, self._p, C.cast(C.byref(n), C.c_void_p)))
-        return int(n.value)
+    def tb_fallbacks(self):
+        """(reads of the last run walked serially after all, trace-back segments walked a second time) -- statistics only"""
+        n = (C.c_int64 * 2)()
+        _check(load().fzp_align_tb_fallbacks(self.eng._p, self._p, C.cast(n, C.c_void_p)))
+        return int(n[0]), int(n[1])
 
     def to_batch(self) -> "Batch":
         p = C.c_void_p()

@@ -910,18 +910,26 @@ struct WalkOut { int32_t ok, i, ts, i_end, j_end, ncol, n_ops, pad_; };   // (i,
 // same cell, takes the upper one's ops up to there and the lower one's from there on, and writes the read's one op stream.  The result
 // is the serial walk's, op for op; a read with a boundary that does not merge inside TBS_OV steps is walked again serially (k_tb_walk<false>
 // over the flagged reads).  A read's walk is no longer one chain of 2.25 x its length: all walkers are TBS_SEG + TBS_OV steps long.
-struct SegOut { int32_t state, i, ts, n_ops, i_start, j_start; };   // state 0: no such segment, 1: ran to its lower bound, 2: reached the matrix edge
+struct SegOut { int32_t state, i, ts, n_ops, i_start, j_start, k, pad_; };   // state & 3: 0 no such segment, 1 ran to its lower bound, 2 reached the matrix edge; state & 4: a repair walk
+struct SegReq { int32_t walker, ts, k, pad_; };                                // repair request: walk this segment again from the cell (ts, k) its upper neighbour stopped in
 
 template <bool SEGMENTED>
 __global__ void __launch_bounds__(64) k_tb_walk(int64_t first, int64_t count, const Anchor *__restrict__ anc, const DpInfo *__restrict__ info,
                                                 const int64_t *__restrict__ tb_off, const int64_t *__restrict__ tbo, const int64_t *__restrict__ mvo,
                                                 const ulonglong2 *__restrict__ tb, const ulonglong2 *__restrict__ mvw, uint32_t *__restrict__ raw,
                                                 WalkOut *__restrict__ wout, const int32_t *__restrict__ order, const int32_t *__restrict__ seg_slot,
-                                                const int32_t *__restrict__ seg_idx, uint32_t *__restrict__ trail, SegOut *__restrict__ segout, int only_flagged, int guess_lane) {
+                                                const int32_t *__restrict__ seg_idx, uint32_t *__restrict__ trail, SegOut *__restrict__ segout, int only_flagged, int guess_lane,
+                                                const SegReq *__restrict__ req, const uint32_t *__restrict__ n_req) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[TBW_RPW * TBW_STRIDE];
     const int lane = threadIdx.x;
-    const int64_t wq = (int64_t)blockIdx.x * TBW_RPW + lane;
+    int64_t wq = (int64_t)blockIdx.x * TBW_RPW + lane;
+    // repair launch (segmented form, req != nullptr): lane x walks request x -- the segment of walker req[x].walker again, from the exact cell
+    // its upper neighbour stopped in; everything it leaves behind (ops, trail, SegOut) goes where that walker's went
+    const bool repair = SEGMENTED && req != nullptr;
+    if (repair) count = (int64_t)min(*n_req, (uint32_t)count);
     bool have = lane < TBW_RPW && wq < count;
+    SegReq rq = {0, 0, 0, 0};
+    if (repair && have) { rq = req[wq]; wq = rq.walker; }
     // serial form: `order` = slots by decreasing read length -- the 16 reads of a wave are of similar length (a wave lasts as long as its
     // longest walk) and the longest start first.  Segmented form: `count` walkers, walker wq = segment seg_idx[wq] of slot seg_slot[wq]
     const int64_t wv = have ? (SEGMENTED ? (int64_t)seg_slot[wq] : (order ? (int64_t)order[wq] : wq)) : 0;
@@ -941,10 +949,10 @@ __global__ void __launch_bounds__(64) k_tb_walk(int64_t first, int64_t count, co
     const ulonglong2 *tbr = tb + to_;                                         // per step {D mask, G mask}
     const ulonglong2 *mvr = mvw + mo_;                                        // per 64 steps {move bits, i0 before them}
     uint32_t *rawp = SEGMENTED ? raw + wq * TBS_RAW_WORDS : raw + (soff >> 4);     // 16 ops per word
-    const bool spec = SEGMENTED && seg < seg_top;                             // a walker that starts on the guess
-    const int32_t ts0 = spec ? (seg + 1) * TBS_SEG - 1 : di.best_t;
+    const bool spec = SEGMENTED && !repair && seg < seg_top;                  // a walker that starts on the guess
+    const int32_t ts0 = repair ? rq.ts : (spec ? (seg + 1) * TBS_SEG - 1 : di.best_t);
     int32_t ts = active ? ts0 : -1;
-    int32_t k = di.best_lane, i = -1;
+    int32_t k = repair ? rq.k : di.best_lane, i = -1;
     const int32_t stop_ts = (SEGMENTED && seg > 0) ? seg * TBS_SEG - TBS_OV : (int32_t)0x80000000;   // walk while ts >= stop_ts
     uint32_t *tr_head = SEGMENTED ? trail + wq * (2 * TBS_OV) : nullptr, *tr_tail = SEGMENTED ? tr_head + TBS_OV : nullptr;
     const int32_t tail_top = seg * TBS_SEG - 1;                               // the boundary below this segment
@@ -1037,8 +1045,8 @@ __global__ void __launch_bounds__(64) k_tb_walk(int64_t first, int64_t count, co
             const uint2 m = *(const uint2 *)(win + (ts & 63) * 8);
             const uint32_t kk = (uint32_t)(k - sh_cur);
             if (SEGMENTED) {      // where this walker is, for the stitching: its first TBS_OV steps and the TBS_OV steps below its segment
-                const uint32_t note = ((uint32_t)n_ops << 8) | (uint32_t)k;
-                if (ts0 - ts < TBS_OV) tr_head[ts0 - ts] = note;
+                const uint32_t note = (repair ? 0x80000000u : 0u) | ((uint32_t)n_ops << 8) | (uint32_t)k;      // (a repair walk's notes are told from the stale ones around them by bit 31)
+                if (!repair && ts0 - ts < TBS_OV) tr_head[ts0 - ts] = note;
                 if ((uint32_t)(tail_top - ts) < (uint32_t)TBS_OV) tr_tail[tail_top - ts] = note;
             }
             const uint32_t db = (m.x >> kk) & 1u, gb = (m.y >> kk) & 1u;
@@ -1067,8 +1075,8 @@ __global__ void __launch_bounds__(64) k_tb_walk(int64_t first, int64_t count, co
     if (nb) rawp[nw] = rawacc;
     if (SEGMENTED) {
         SegOut so;
-        so.state = !walked ? 0 : ((i | (ts - i)) < 0 ? 2 : 1);
-        so.i = i; so.ts = ts; so.n_ops = n_ops; so.i_start = i_end; so.j_start = j_end;
+        so.state = !walked ? 0 : (((i | (ts - i)) < 0 ? 2 : 1) | (repair ? 4 : 0));
+        so.i = i; so.ts = ts; so.n_ops = n_ops; so.i_start = i_end; so.j_start = j_end; so.k = k; so.pad_ = 0;
         segout[wq] = so;
         return;
     }
@@ -1078,15 +1086,19 @@ __global__ void __launch_bounds__(64) k_tb_walk(int64_t first, int64_t count, co
 }
 
 // ---- trace-back, part 1b: one wave per read joins its segments' walks (k_tb_walk<true>) into the read's op stream.
+// pass 1: every read.  A boundary whose two walkers share no cell inside the overlap asks for a repair walk of the lower segment from the
+// cell the upper walker stopped in (if the upper walker is known to be on the path there); the read waits (ok = 3).  pass 2, after the repair
+// launch: the waiting reads again; what still does not join is left to the serial walk (ok = 2).
 __global__ void __launch_bounds__(64) k_tb_stitch(int64_t first, int64_t count, const Anchor *__restrict__ anc, const DpInfo *__restrict__ info,
                                                   const int64_t *__restrict__ tb_off, const int32_t *__restrict__ seg_off, const uint32_t *__restrict__ trail,
                                                   const SegOut *__restrict__ segout, const uint32_t *__restrict__ raw_seg, uint32_t *__restrict__ raw,
-                                                  WalkOut *__restrict__ wout, uint32_t *__restrict__ n_fallback) {
+                                                  WalkOut *__restrict__ wout, uint32_t *__restrict__ counters, SegReq *__restrict__ req, uint32_t req_cap, int pass) {
     __shared__ int32_t p_w[TBS_MAX_PIECES], p_a[TBS_MAX_PIECES], p_out[TBS_MAX_PIECES + 1];     // piece: walker, first op taken from it, first op of the output it fills
     const int lane = lane_id();
     const int64_t wv = blockIdx.x;
     if (wv >= count) return;
     const int64_t r = first + wv;
+    if (pass == 2 && wout[r].ok != 3) return;
     const Anchor a = anc[r];
     const DpInfo di = info[r];
     WalkOut o;
@@ -1097,34 +1109,54 @@ __global__ void __launch_bounds__(64) k_tb_stitch(int64_t first, int64_t count, 
     const SegOut top = segout[w0 + S];
     if (top.state == 0) { if (lane == 0) wout[r] = o; return; }                 // the best cell itself is outside the matrix: no walk (as the serial form)
     o.i_end = top.i_start; o.j_end = top.j_start;
-    bool fail = S + 1 > TBS_MAX_PIECES;
+    bool hard = S + 1 > TBS_MAX_PIECES, fail = false;
+    bool anchored = true;                                                        // the upper walker of the boundary at hand is on the path where it stopped
     int32_t start = 0, outpos = 0, np = 0, fin_i = 0, fin_ts = 0;
-    for (int32_t sg = S; sg >= 0 && !fail; sg--) {                               // wave-uniform
+    for (int32_t sg = S; sg >= 0 && !hard; sg--) {                               // wave-uniform
         const SegOut so = segout[w0 + sg];
-        if (so.state == 0) { fail = true; break; }
-        if (so.state == 2 || sg == 0) {                                          // the path ends inside this segment: its walker's remaining ops are the last piece
+        if ((so.state & 3) == 0) { hard = true; break; }
+        if ((so.state & 3) == 2 || sg == 0) {                                    // the path ends inside this segment: its walker's remaining ops are the last piece
             if (lane == 0) { p_w[np] = w0 + sg; p_a[np] = start; p_out[np] = outpos; }
             outpos += so.n_ops - start; np++;
             fin_i = so.i; fin_ts = so.ts;
             break;
         }
+        const SegOut lo = segout[w0 + sg - 1];
+        if (lo.state & 4) {                                                      // the lower segment was walked again from this walker's last cell: they join there
+            if (lane == 0) { p_w[np] = w0 + sg; p_a[np] = start; p_out[np] = outpos; }
+            outpos += so.n_ops - start; np++;
+            start = 0; anchored = true;
+            continue;
+        }
         const uint32_t *ta = trail + (int64_t)(w0 + sg) * (2 * TBS_OV) + TBS_OV, *hb = trail + (int64_t)(w0 + sg - 1) * (2 * TBS_OV);
+        const uint32_t want31 = (so.state & 4) ? 1u : 0u;
         int32_t ia = -1, ib = -1;
         for (int d0 = 0; d0 < TBS_OV; d0 += 64) {
             const uint32_t ua = ta[d0 + lane], ub = hb[d0 + lane];
-            const uint64_t m = __ballot(ua != 0xffffffffu && ub != 0xffffffffu && (ua & 0xffu) == (ub & 0xffu));
+            const uint64_t m = __ballot(ua != 0xffffffffu && ub != 0xffffffffu && (ua >> 31) == want31 && (ua & 0xffu) == (ub & 0xffu));
             if (m) {
                 const int l = __builtin_ctzll(m);                                 // the first common cell below the boundary
-                ia = __builtin_amdgcn_readlane((int32_t)(ua >> 8), l); ib = __builtin_amdgcn_readlane((int32_t)(ub >> 8), l);
+                ia = __builtin_amdgcn_readlane((int32_t)((ua >> 8) & 0x7fffffu), l); ib = __builtin_amdgcn_readlane((int32_t)((ub >> 8) & 0x7fffffu), l);
                 break;
             }
         }
-        if (ia < start) { fail = true; break; }                                   // no common cell inside TBS_OV steps (ia = -1), or before this walker joined the path
-        if (lane == 0) { p_w[np] = w0 + sg; p_a[np] = start; p_out[np] = outpos; }
-        outpos += ia - start; np++;
-        start = ib;
+        if (ia >= start && !fail) {
+            if (lane == 0) { p_w[np] = w0 + sg; p_a[np] = start; p_out[np] = outpos; }
+            outpos += ia - start; np++;
+            start = ib;
+        } else if (ia >= 0 && fail) {                                             // below an open boundary: the pieces are not built any more, but this one joins
+            anchored = true;
+        } else {                                                                  // no common cell inside TBS_OV steps (or one above where this walker joined the path)
+            if (pass == 1 && anchored && lane == 0) {
+                const uint32_t q = atomicAdd(&counters[1], 1u);
+                atomicAdd(&counters[2], 1u);
+                if (q < req_cap) { SegReq rq; rq.walker = w0 + sg - 1; rq.ts = so.ts; rq.k = so.k; rq.pad_ = 0; req[q] = rq; }
+            }
+            fail = true; anchored = false;
+        }
     }
-    if (fail) { o.ok = 2; if (lane == 0) { wout[r] = o; atomicAdd(n_fallback, 1u); } return; }    // k_tb_walk<false> walks this read serially
+    if (hard || (fail && pass == 2)) { o.ok = 2; if (lane == 0) { wout[r] = o; atomicAdd(&counters[0], 1u); } return; }    // k_tb_walk<false> walks this read serially
+    if (fail) { o.ok = 3; if (lane == 0) wout[r] = o; return; }                  // waits for the repair walks
     if (lane == 0) p_out[np] = outpos;
     __syncthreads();
     // the pieces, one after the other, into the read's stream: a lane builds an output word from the (at most two) source words under it
@@ -1622,7 +1654,8 @@ struct fzp_alnjob {
     std::vector<int64_t> h_seg_base, h_seg_cnt;  // per chunk start (indexed by its first read): first walker in seg_slot / seg_idx, number of walkers
     DevBuf<uint32_t> raw_seg2[2], trail2[2];
     DevBuf<SegOut> segout2[2];
-    DevBuf<uint32_t> tb_fallback;                // reads of the last run whose segments did not join and were walked serially
+    DevBuf<uint32_t> tb_fallback;                // [0] reads of the last run walked serially after all, [1] repair walks asked for in the chunk at hand, [2] in the whole run
+    DevBuf<SegReq> seg_req;
     DevBuf<int32_t> lpt;                         // per read: the slot (relative to its chunk's first read) that wave / lane number x of the chunk's launches takes --
     int64_t lpt_chunk_steps = -1;                // longest reads first (k_sw, k_tb_walk); rebuilt when the chunking changes
     // record planning: reads grouped by contig (input order inside a contig); built on first use
@@ -1878,8 +1911,8 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
         const int64_t total_steps = j->h_tb_off[(size_t)nr];
         int64_t chunk_steps = std::min<int64_t>(budget_steps / 2, (total_steps + n_chunks - 1) / n_chunks);
         FZP_TRY(j->wout.alloc((size_t)nr));
-        FZP_TRY(j->tb_fallback.alloc(2));
-        FZP_TRY(j->tb_fallback.zero(2, st));
+        FZP_TRY(j->tb_fallback.alloc(4));
+        FZP_TRY(j->tb_fallback.zero(4, st));
         if (!j->ev_sw[0]) for (int k = 0; k < 2; k++) { FZP_HIP(hipEventCreateWithFlags(&j->ev_sw[k], hipEventDisableTiming)); FZP_HIP(hipEventCreateWithFlags(&j->ev_tb[k], hipEventDisableTiming)); }
         hipStream_t st2 = ctx->stream2;
         if (j->lpt_chunk_steps != chunk_steps || split_rounds) {
@@ -1979,7 +2012,7 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
                 hipLaunchKernelGGL(k_tb_walk<false>, dim3((unsigned)((cnt + TBW_RPW - 1) / TBW_RPW)), dim3(64), 0, st2, first, cnt, j->anc.p, j->info.p, j->tb_off.p,
                                    j->tbo.p, j->mvo.p, (const ulonglong2 *)j->tb2[bi].p, (const ulonglong2 *)j->mvw2[bi].p, j->raw2[bi].p, j->wout.p,
                                    use_lpt ? (const int32_t *)(j->lpt.p + first) : (const int32_t *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr,
-                                   (uint32_t *)nullptr, (SegOut *)nullptr, 0, 32);
+                                   (uint32_t *)nullptr, (SegOut *)nullptr, 0, 32, (const SegReq *)nullptr, (const uint32_t *)nullptr);
             } else {
                 const int64_t nwk = j->h_seg_cnt[(size_t)first], wbase = j->h_seg_base[(size_t)first];
                 FZP_TRY(j->raw_seg2[bi].alloc((size_t)nwk * TBS_RAW_WORDS + 64));
@@ -1989,13 +2022,25 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
                 FZP_HIP(hipMemsetAsync(j->trail2[bi].p, 0xff, (size_t)nwk * 2 * TBS_OV * 4, st2));
                 hipLaunchKernelGGL(k_tb_walk<true>, dim3((unsigned)((nwk + TBW_RPW - 1) / TBW_RPW)), dim3(64), 0, st2, first, nwk, j->anc.p, j->info.p, j->tb_off.p,
                                    j->tbo.p, j->mvo.p, (const ulonglong2 *)j->tb2[bi].p, (const ulonglong2 *)j->mvw2[bi].p, j->raw_seg2[bi].p, j->wout.p,
-                                   (const int32_t *)nullptr, (const int32_t *)(j->seg_slot.p + wbase), (const int32_t *)(j->seg_idx.p + wbase), j->trail2[bi].p, j->segout2[bi].p, 0, guess_lane);
+                                   (const int32_t *)nullptr, (const int32_t *)(j->seg_slot.p + wbase), (const int32_t *)(j->seg_idx.p + wbase), j->trail2[bi].p, j->segout2[bi].p, 0, guess_lane, (const SegReq *)nullptr, (const uint32_t *)nullptr);
+                const uint32_t req_cap = (uint32_t)std::min<int64_t>(nwk, 1 << 20);
+                FZP_TRY(j->seg_req.alloc((size_t)req_cap + 1));
+                FZP_HIP(hipMemsetAsync(j->tb_fallback.p + 1, 0, 4, st2));      // this chunk's repair requests
                 hipLaunchKernelGGL(k_tb_stitch, dim3((unsigned)cnt), dim3(64), 0, st2, first, cnt, j->anc.p, j->info.p, j->tb_off.p, (const int32_t *)(j->seg_off.p + first),
-                                   (const uint32_t *)j->trail2[bi].p, (const SegOut *)j->segout2[bi].p, (const uint32_t *)j->raw_seg2[bi].p, j->raw2[bi].p, j->wout.p, j->tb_fallback.p);
+                                   (const uint32_t *)j->trail2[bi].p, (const SegOut *)j->segout2[bi].p, (const uint32_t *)j->raw_seg2[bi].p, j->raw2[bi].p, j->wout.p, j->tb_fallback.p,
+                                   j->seg_req.p, req_cap, 1);
+                // boundaries that did not join: their lower segments again, from the exact cell (a launch of empty waves when there are none)
+                hipLaunchKernelGGL(k_tb_walk<true>, dim3((unsigned)((std::min<int64_t>(req_cap, cnt) + TBW_RPW - 1) / TBW_RPW)), dim3(64), 0, st2, first, (int64_t)req_cap, j->anc.p, j->info.p,
+                                   j->tb_off.p, j->tbo.p, j->mvo.p, (const ulonglong2 *)j->tb2[bi].p, (const ulonglong2 *)j->mvw2[bi].p, j->raw_seg2[bi].p, j->wout.p,
+                                   (const int32_t *)nullptr, (const int32_t *)(j->seg_slot.p + wbase), (const int32_t *)(j->seg_idx.p + wbase), j->trail2[bi].p, j->segout2[bi].p, 0, guess_lane,
+                                   (const SegReq *)j->seg_req.p, (const uint32_t *)(j->tb_fallback.p + 1));
+                hipLaunchKernelGGL(k_tb_stitch, dim3((unsigned)cnt), dim3(64), 0, st2, first, cnt, j->anc.p, j->info.p, j->tb_off.p, (const int32_t *)(j->seg_off.p + first),
+                                   (const uint32_t *)j->trail2[bi].p, (const SegOut *)j->segout2[bi].p, (const uint32_t *)j->raw_seg2[bi].p, j->raw2[bi].p, j->wout.p, j->tb_fallback.p,
+                                   j->seg_req.p, req_cap, 2);
                 // reads whose segments did not join (flagged by the stitching) are walked in one piece; every other wave of this launch leaves at once
                 hipLaunchKernelGGL(k_tb_walk<false>, dim3((unsigned)((cnt + TBW_RPW - 1) / TBW_RPW)), dim3(64), 0, st2, first, cnt, j->anc.p, j->info.p, j->tb_off.p,
                                    j->tbo.p, j->mvo.p, (const ulonglong2 *)j->tb2[bi].p, (const ulonglong2 *)j->mvw2[bi].p, j->raw2[bi].p, j->wout.p,
-                                   (const int32_t *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr, (uint32_t *)nullptr, (SegOut *)nullptr, 1, 32);
+                                   (const int32_t *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr, (uint32_t *)nullptr, (SegOut *)nullptr, 1, 32, (const SegReq *)nullptr, (const uint32_t *)nullptr);
             }
             {
                 ProfScope ps(ctx, "k1_cigar", st2);
@@ -2034,9 +2079,10 @@ extern "C" int64_t fzp_align_n_second(const fzp_alnjob *j) { return j ? j->n_sec
 extern "C" int fzp_align_tb_fallbacks(fzp_ctx *ctx, fzp_alnjob *j, int64_t *n) {
     if (!ctx || !j || !j->done || !n) { fzp_set_error("fzp_align_tb_fallbacks: run the job first"); return FZP_EINVAL; }
     FZP_TRY(fzp_bind(ctx));
-    uint32_t v = 0;
-    if (j->tb_fallback.p) { FZP_HIP(hipMemcpyAsync(&v, j->tb_fallback.p, 4, hipMemcpyDeviceToHost, ctx->stream)); FZP_HIP(hipStreamSynchronize(ctx->stream)); }
-    *n = (int64_t)v;
+    uint32_t v[4] = {0, 0, 0, 0};
+    if (j->tb_fallback.p) { FZP_HIP(hipMemcpyAsync(v, j->tb_fallback.p, 16, hipMemcpyDeviceToHost, ctx->stream)); FZP_HIP(hipStreamSynchronize(ctx->stream)); }
+    n[0] = (int64_t)v[0];
+    n[1] = (int64_t)v[2];
     return FZP_OK;
 }
 

@@ -248,9 +248,9 @@ int fzp_align_invalidate_index(fzp_alnjob *job);
 int fzp_align_summaries(fzp_ctx *ctx, fzp_alnjob *job, fzp_aln_summary *out /* [n_reads] */);
 /* reads of the last run that had a second candidate placement extended (repeats; blasr --bestn 1 keeps the better one) */
 int64_t fzp_align_n_second(const fzp_alnjob *job);
-/* reads of the last run whose trace-back segments did not join within the overlap and were walked in one piece instead (a statistic:
- * the alignments are the same either way) */
-int fzp_align_tb_fallbacks(fzp_ctx *ctx, fzp_alnjob *job, int64_t *n);
+/* statistics of the last run's segmented trace-back (the alignments are the same either way): n[0] = reads that were walked in one piece
+ * after all, n[1] = segments that were walked a second time because they did not join their upper neighbour inside the overlap */
+int fzp_align_tb_fallbacks(fzp_ctx *ctx, fzp_alnjob *job, int64_t n[2]);
 /* alignment records of contig `ctg` in (POS, read index) order, q_id = rank in that order; names
  * (optional, may be NULL -> "read/<index>") fill the q_id table */
 int fzp_align_alnset(fzp_ctx *ctx, fzp_alnjob *job, int32_t ctg, const int64_t *name_off, const char *names,
