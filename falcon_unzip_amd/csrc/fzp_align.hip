@@ -503,7 +503,7 @@ __global__ void __launch_bounds__(256) k_orient(int64_t first, const uint32_t *_
 
 struct DpInfo { int32_t steps, best_t, best_lane, best_score; };
 // segmented trace-back (k_tb_walk<true>, below): segment length in DP steps, overlap, ops buffer per walker, pieces per read
-constexpr int TBS_SEG = 4096, TBS_SEG_SHIFT = 12, TBS_OV = 256, TBS_RAW_WORDS = (TBS_SEG + TBS_OV) / 16 + 2, TBS_MAX_PIECES = 256;
+constexpr int TBS_SEG = 4096, TBS_SEG_SHIFT = 12, TBS_OV = 512, TBS_RAW_WORDS = (TBS_SEG + TBS_OV) / 16 + 2, TBS_MAX_PIECES = 256;
 
 // wave-wide shifts by one lane (gfx9 DPP wave_shr / wave_shl); vacated lane takes `fill`
 __device__ __forceinline__ int32_t wave_shr1(int32_t v, int32_t fill) {   // lane k <- lane k-1
@@ -1085,10 +1085,13 @@ __global__ void __launch_bounds__(64) k_tb_walk(int64_t first, int64_t count, co
     wout[r] = o;
 }
 
+__global__ void k_tb_req_reset(uint32_t *counters) { if (threadIdx.x == 0) counters[1] = 0u; }
+
 // ---- trace-back, part 1b: one wave per read joins its segments' walks (k_tb_walk<true>) into the read's op stream.
 // pass 1: every read.  A boundary whose two walkers share no cell inside the overlap asks for a repair walk of the lower segment from the
-// cell the upper walker stopped in (if the upper walker is known to be on the path there); the read waits (ok = 3).  pass 2, after the repair
-// launch: the waiting reads again; what still does not join is left to the serial walk (ok = 2).
+// cell the upper walker stopped in (if the upper walker is known to be on the path there); the read waits (ok = 3).  pass 3, after a repair
+// launch: the waiting reads again, asking again where needed.  pass 2, after the last repair launch: the waiting reads; what still does not join
+// is left to the serial walk (ok = 2).
 __global__ void __launch_bounds__(64) k_tb_stitch(int64_t first, int64_t count, const Anchor *__restrict__ anc, const DpInfo *__restrict__ info,
                                                   const int64_t *__restrict__ tb_off, const int32_t *__restrict__ seg_off, const uint32_t *__restrict__ trail,
                                                   const SegOut *__restrict__ segout, const uint32_t *__restrict__ raw_seg, uint32_t *__restrict__ raw,
@@ -1098,7 +1101,7 @@ __global__ void __launch_bounds__(64) k_tb_stitch(int64_t first, int64_t count, 
     const int64_t wv = blockIdx.x;
     if (wv >= count) return;
     const int64_t r = first + wv;
-    if (pass == 2 && wout[r].ok != 3) return;
+    if (pass != 1 && wout[r].ok != 3) return;
     const Anchor a = anc[r];
     const DpInfo di = info[r];
     WalkOut o;
@@ -1147,7 +1150,7 @@ __global__ void __launch_bounds__(64) k_tb_stitch(int64_t first, int64_t count, 
         } else if (ia >= 0 && fail) {                                             // below an open boundary: the pieces are not built any more, but this one joins
             anchored = true;
         } else {                                                                  // no common cell inside TBS_OV steps (or one above where this walker joined the path)
-            if (pass == 1 && anchored && lane == 0) {
+            if (pass != 2 && anchored && lane == 0) {
                 const uint32_t q = atomicAdd(&counters[1], 1u);
                 atomicAdd(&counters[2], 1u);
                 if (q < req_cap) { SegReq rq; rq.walker = w0 + sg - 1; rq.ts = so.ts; rq.k = so.k; rq.pad_ = 0; req[q] = rq; }
@@ -2026,17 +2029,19 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
                 const uint32_t req_cap = (uint32_t)std::min<int64_t>(nwk, 1 << 20);
                 FZP_TRY(j->seg_req.alloc((size_t)req_cap + 1));
                 FZP_HIP(hipMemsetAsync(j->tb_fallback.p + 1, 0, 4, st2));      // this chunk's repair requests
-                hipLaunchKernelGGL(k_tb_stitch, dim3((unsigned)cnt), dim3(64), 0, st2, first, cnt, j->anc.p, j->info.p, j->tb_off.p, (const int32_t *)(j->seg_off.p + first),
-                                   (const uint32_t *)j->trail2[bi].p, (const SegOut *)j->segout2[bi].p, (const uint32_t *)j->raw_seg2[bi].p, j->raw2[bi].p, j->wout.p, j->tb_fallback.p,
-                                   j->seg_req.p, req_cap, 1);
-                // boundaries that did not join: their lower segments again, from the exact cell (a launch of empty waves when there are none)
-                hipLaunchKernelGGL(k_tb_walk<true>, dim3((unsigned)((std::min<int64_t>(req_cap, cnt) + TBW_RPW - 1) / TBW_RPW)), dim3(64), 0, st2, first, (int64_t)req_cap, j->anc.p, j->info.p,
-                                   j->tb_off.p, j->tbo.p, j->mvo.p, (const ulonglong2 *)j->tb2[bi].p, (const ulonglong2 *)j->mvw2[bi].p, j->raw_seg2[bi].p, j->wout.p,
-                                   (const int32_t *)nullptr, (const int32_t *)(j->seg_slot.p + wbase), (const int32_t *)(j->seg_idx.p + wbase), j->trail2[bi].p, j->segout2[bi].p, 0, guess_lane,
-                                   (const SegReq *)j->seg_req.p, (const uint32_t *)(j->tb_fallback.p + 1));
-                hipLaunchKernelGGL(k_tb_stitch, dim3((unsigned)cnt), dim3(64), 0, st2, first, cnt, j->anc.p, j->info.p, j->tb_off.p, (const int32_t *)(j->seg_off.p + first),
-                                   (const uint32_t *)j->trail2[bi].p, (const SegOut *)j->segout2[bi].p, (const uint32_t *)j->raw_seg2[bi].p, j->raw2[bi].p, j->wout.p, j->tb_fallback.p,
-                                   j->seg_req.p, req_cap, 2);
+                constexpr int REPAIR_ROUNDS = 3;
+                for (int round = 0; round <= REPAIR_ROUNDS; round++) {
+                    hipLaunchKernelGGL(k_tb_stitch, dim3((unsigned)cnt), dim3(64), 0, st2, first, cnt, j->anc.p, j->info.p, j->tb_off.p, (const int32_t *)(j->seg_off.p + first),
+                                       (const uint32_t *)j->trail2[bi].p, (const SegOut *)j->segout2[bi].p, (const uint32_t *)j->raw_seg2[bi].p, j->raw2[bi].p, j->wout.p, j->tb_fallback.p,
+                                       j->seg_req.p, req_cap, round == 0 ? 1 : (round == REPAIR_ROUNDS ? 2 : 3));
+                    if (round == REPAIR_ROUNDS) break;
+                    // boundaries that did not join: their lower segments again, from the exact cell (a launch of empty waves when there are none)
+                    hipLaunchKernelGGL(k_tb_walk<true>, dim3((unsigned)((std::min<int64_t>(req_cap, cnt) + TBW_RPW - 1) / TBW_RPW)), dim3(64), 0, st2, first, (int64_t)req_cap, j->anc.p, j->info.p,
+                                       j->tb_off.p, j->tbo.p, j->mvo.p, (const ulonglong2 *)j->tb2[bi].p, (const ulonglong2 *)j->mvw2[bi].p, j->raw_seg2[bi].p, j->wout.p,
+                                       (const int32_t *)nullptr, (const int32_t *)(j->seg_slot.p + wbase), (const int32_t *)(j->seg_idx.p + wbase), j->trail2[bi].p, j->segout2[bi].p, 0, guess_lane,
+                                       (const SegReq *)j->seg_req.p, (const uint32_t *)(j->tb_fallback.p + 1));
+                    hipLaunchKernelGGL(k_tb_req_reset, dim3(1), dim3(64), 0, st2, j->tb_fallback.p);   // the walks are queued behind it: the next stitch pass counts from 0
+                }
                 // reads whose segments did not join (flagged by the stitching) are walked in one piece; every other wave of this launch leaves at once
                 hipLaunchKernelGGL(k_tb_walk<false>, dim3((unsigned)((cnt + TBW_RPW - 1) / TBW_RPW)), dim3(64), 0, st2, first, cnt, j->anc.p, j->info.p, j->tb_off.p,
                                    j->tbo.p, j->mvo.p, (const ulonglong2 *)j->tb2[bi].p, (const ulonglong2 *)j->mvw2[bi].p, j->raw2[bi].p, j->wout.p,
