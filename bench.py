@@ -532,6 +532,7 @@ def main():
         rank_load = [{"rank": 0, "reads": n_reads, "ms_per_step": round(dt / args.steps * 1e3, 3)}]
 
     summ = job.summaries() if job is not None else np.zeros(0, dtype=[("cells", "<i8"), ("aligned", "<i4")])
+    tb_stats = job.tb_fallbacks() if job is not None else (0, 0)
     cells_per_step = float(summ["cells"].sum())
     sw_ms, sw_launches = prof.get("k1_sw", (0.0, 0))
     sw_avg_ms = sw_ms / max(1, sw_launches)
@@ -642,6 +643,7 @@ def main():
             "upload_ms": round(upload_ms, 1),
             "dp_cells_per_step": cells_per_step,
             "aligned_frac": round(aligned_frac, 4),
+            "traceback": {"reads_walked_serially_after_all": tb_stats[0], "segments_walked_twice": tb_stats[1]},
             "stage_counts": {k: int(v) for k, v in stats.items()},
             "kernel_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in sorted(prof.items())},
             "host_wall_ms_per_step": dict({k: round(v / args.steps * 1e3, 3) for k, v in host_t.items()}, **{k[3:]: round(v / args.steps, 3) for k, v in sect.items()}),

@@ -504,6 +504,7 @@ __global__ void __launch_bounds__(256) k_orient(int64_t first, const uint32_t *_
 struct DpInfo { int32_t steps, best_t, best_lane, best_score; };
 // segmented trace-back (k_tb_walk<true>, below): segment length in DP steps, overlap, ops buffer per walker, pieces per read
 constexpr int TBS_SEG = 4096, TBS_SEG_SHIFT = 12, TBS_OV = 512, TBS_RAW_WORDS = (TBS_SEG + TBS_OV) / 16 + 2, TBS_MAX_PIECES = 256;
+constexpr int64_t TBS_SINGLE_STEPS = 40960;     // a read with at most this many DP steps of capacity is one walker's work (its serial walk is no longer than the launch anyway)
 
 // wave-wide shifts by one lane (gfx9 DPP wave_shr / wave_shl); vacated lane takes `fill`
 __device__ __forceinline__ int32_t wave_shr1(int32_t v, int32_t fill) {   // lane k <- lane k-1
@@ -919,7 +920,7 @@ __global__ void __launch_bounds__(64) k_tb_walk(int64_t first, int64_t count, co
                                                 const ulonglong2 *__restrict__ tb, const ulonglong2 *__restrict__ mvw, uint32_t *__restrict__ raw,
                                                 WalkOut *__restrict__ wout, const int32_t *__restrict__ order, const int32_t *__restrict__ seg_slot,
                                                 const int32_t *__restrict__ seg_idx, uint32_t *__restrict__ trail, SegOut *__restrict__ segout, int only_flagged, int guess_lane,
-                                                const SegReq *__restrict__ req, const uint32_t *__restrict__ n_req) {
+                                                const SegReq *__restrict__ req, const uint32_t *__restrict__ n_req, uint32_t *__restrict__ raw_final) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[TBW_RPW * TBW_STRIDE];
     const int lane = threadIdx.x;
     int64_t wq = (int64_t)blockIdx.x * TBW_RPW + lane;
@@ -933,14 +934,16 @@ __global__ void __launch_bounds__(64) k_tb_walk(int64_t first, int64_t count, co
     // serial form: `order` = slots by decreasing read length -- the 16 reads of a wave are of similar length (a wave lasts as long as its
     // longest walk) and the longest start first.  Segmented form: `count` walkers, walker wq = segment seg_idx[wq] of slot seg_slot[wq]
     const int64_t wv = have ? (SEGMENTED ? (int64_t)seg_slot[wq] : (order ? (int64_t)order[wq] : wq)) : 0;
-    const int32_t seg = (SEGMENTED && have) ? seg_idx[wq] : 0;
+    int32_t seg = (SEGMENTED && have) ? seg_idx[wq] : 0;
+    const bool single = SEGMENTED && seg < 0;       // a short read: this walker does all of it, as the serial form would (its ops go to the read's own stream)
+    if (single) seg = 0;
     const int64_t r = first + wv;
     if (!SEGMENTED && only_flagged) have = have && wout[r].ok == 2;        // second pass: only the reads whose stitching failed
     Anchor a = {0, 0, 0, 0};
     DpInfo di = {0, -1, 0, NEGV};
     if (have) { a = anc[r]; di = info[r]; }
     bool active = have && a.aligned && di.best_t >= 0 && di.best_score > 0;
-    const int32_t seg_top = di.best_t >> TBS_SEG_SHIFT;
+    const int32_t seg_top = single ? 0 : di.best_t >> TBS_SEG_SHIFT;
     if (SEGMENTED) active = active && seg <= seg_top;
     const int64_t soff = tb_off[r] - tb_off[first];                           // steps before this read in the chunk of reads
     // masks / move words of the winning candidate (second candidates sit behind the first ones in the same buffers)
@@ -948,7 +951,7 @@ __global__ void __launch_bounds__(64) k_tb_walk(int64_t first, int64_t count, co
     asm volatile("" : "+v"(to_), "+v"(mo_));      // both offsets are in registers from here on: no pending load is attributed to the pointers below
     const ulonglong2 *tbr = tb + to_;                                         // per step {D mask, G mask}
     const ulonglong2 *mvr = mvw + mo_;                                        // per 64 steps {move bits, i0 before them}
-    uint32_t *rawp = SEGMENTED ? raw + wq * TBS_RAW_WORDS : raw + (soff >> 4);     // 16 ops per word
+    uint32_t *rawp = (SEGMENTED && !single) ? raw + wq * TBS_RAW_WORDS : (SEGMENTED ? raw_final : raw) + (soff >> 4);     // 16 ops per word
     const bool spec = SEGMENTED && !repair && seg < seg_top;                  // a walker that starts on the guess
     const int32_t ts0 = repair ? rq.ts : (spec ? (seg + 1) * TBS_SEG - 1 : di.best_t);
     int32_t ts = active ? ts0 : -1;
@@ -1044,7 +1047,7 @@ __global__ void __launch_bounds__(64) k_tb_walk(int64_t first, int64_t count, co
         while (active && (ts >> 6) == cur_chunk && (uint32_t)(k - sh_cur) < 32u) {
             const uint2 m = *(const uint2 *)(win + (ts & 63) * 8);
             const uint32_t kk = (uint32_t)(k - sh_cur);
-            if (SEGMENTED) {      // where this walker is, for the stitching: its first TBS_OV steps and the TBS_OV steps below its segment
+            if (SEGMENTED && !single) {      // where this walker is, for the stitching: its first TBS_OV steps and the TBS_OV steps below its segment
                 const uint32_t note = (repair ? 0x80000000u : 0u) | ((uint32_t)n_ops << 8) | (uint32_t)k;      // (a repair walk's notes are told from the stale ones around them by bit 31)
                 if (!repair && ts0 - ts < TBS_OV) tr_head[ts0 - ts] = note;
                 if ((uint32_t)(tail_top - ts) < (uint32_t)TBS_OV) tr_tail[tail_top - ts] = note;
@@ -1073,7 +1076,7 @@ __global__ void __launch_bounds__(64) k_tb_walk(int64_t first, int64_t count, co
 #undef TBW_ISSUE
     if (!have) return;
     if (nb) rawp[nw] = rawacc;
-    if (SEGMENTED) {
+    if (SEGMENTED && !single) {
         SegOut so;
         so.state = !walked ? 0 : (((i | (ts - i)) < 0 ? 2 : 1) | (repair ? 4 : 0));
         so.i = i; so.ts = ts; so.n_ops = n_ops; so.i_start = i_end; so.j_start = j_end; so.k = k; so.pad_ = 0;
@@ -1095,12 +1098,14 @@ __global__ void k_tb_req_reset(uint32_t *counters) { if (threadIdx.x == 0) count
 __global__ void __launch_bounds__(64) k_tb_stitch(int64_t first, int64_t count, const Anchor *__restrict__ anc, const DpInfo *__restrict__ info,
                                                   const int64_t *__restrict__ tb_off, const int32_t *__restrict__ seg_off, const uint32_t *__restrict__ trail,
                                                   const SegOut *__restrict__ segout, const uint32_t *__restrict__ raw_seg, uint32_t *__restrict__ raw,
-                                                  WalkOut *__restrict__ wout, uint32_t *__restrict__ counters, SegReq *__restrict__ req, uint32_t req_cap, int pass) {
+                                                  WalkOut *__restrict__ wout, uint32_t *__restrict__ counters, SegReq *__restrict__ req, uint32_t req_cap, int pass,
+                                                  const uint8_t *__restrict__ seg_single) {
     __shared__ int32_t p_w[TBS_MAX_PIECES], p_a[TBS_MAX_PIECES], p_out[TBS_MAX_PIECES + 1];     // piece: walker, first op taken from it, first op of the output it fills
     const int lane = lane_id();
     const int64_t wv = blockIdx.x;
     if (wv >= count) return;
     const int64_t r = first + wv;
+    if (seg_single[wv]) return;                       // one walker did the whole read and left the stream and the WalkOut itself
     if (pass != 1 && wout[r].ok != 3) return;
     const Anchor a = anc[r];
     const DpInfo di = info[r];
@@ -1653,6 +1658,7 @@ struct fzp_alnjob {
     DevBuf<uint2> tb2[2];
     DevBuf<uint32_t> raw2[2];                    // the walk's 2-bit op streams
     DevBuf<WalkOut> wout;
+    DevBuf<uint8_t> seg_single;                  // per read: 1 = short enough for one walker
     DevBuf<int32_t> seg_off, seg_slot, seg_idx;  // segmented trace-back: per read its first walker (chunk-relative); per walker its slot (chunk-relative) and segment
     std::vector<int64_t> h_seg_base, h_seg_cnt;  // per chunk start (indexed by its first read): first walker in seg_slot / seg_idx, number of walkers
     DevBuf<uint32_t> raw_seg2[2], trail2[2];
@@ -1922,6 +1928,7 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
             // launch order inside every chunk of reads: longest first (LPT over the wave slots).  One wave per read, workgroups dispatched in
             // index order: with reads of uneven length in input order the grid's tail is whatever long read happened to come last.
             std::vector<int32_t> ord((size_t)nr), sgo((size_t)nr), sgs, sgi;
+            std::vector<uint8_t> sg1((size_t)nr);
             j->h_seg_base.assign((size_t)nr + 1, 0); j->h_seg_cnt.assign((size_t)nr + 1, 0);
             for (int64_t f = 0; f < nr;) {
                 int64_t l = f;
@@ -1937,18 +1944,22 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
                 j->h_seg_base[(size_t)f] = (int64_t)sgs.size();
                 std::vector<int32_t> w_first((size_t)(l - f));
                 int64_t nw_chunk = 0;
-                for (int64_t r = f; r < l; r++) { sgo[(size_t)r] = (int32_t)nw_chunk; nw_chunk += (j->h_tb_off[(size_t)r + 1] - j->h_tb_off[(size_t)r] + TBS_SEG - 1) / TBS_SEG; }
+                auto n_walkers = [&](int64_t r) { const int64_t cap = j->h_tb_off[(size_t)r + 1] - j->h_tb_off[(size_t)r]; return cap <= TBS_SINGLE_STEPS ? (int64_t)1 : (cap + TBS_SEG - 1) / TBS_SEG; };
+                for (int64_t r = f; r < l; r++) { sgo[(size_t)r] = (int32_t)nw_chunk; nw_chunk += n_walkers(r); }
                 if (nw_chunk >= (1ll << 31)) { fzp_set_error("fzp_align_run: too many trace-back segments in one chunk"); return FZP_EINVAL; }
                 sgs.resize(sgs.size() + (size_t)nw_chunk); sgi.resize(sgs.size());
                 for (int64_t r = f; r < l; r++) {
-                    const int64_t ns = (j->h_tb_off[(size_t)r + 1] - j->h_tb_off[(size_t)r] + TBS_SEG - 1) / TBS_SEG;
-                    for (int64_t x = 0; x < ns; x++) { sgs[(size_t)(j->h_seg_base[(size_t)f] + sgo[(size_t)r] + x)] = (int32_t)(r - f); sgi[(size_t)(j->h_seg_base[(size_t)f] + sgo[(size_t)r] + x)] = (int32_t)x; }
+                    const int64_t ns = n_walkers(r);
+                    const bool one = j->h_tb_off[(size_t)r + 1] - j->h_tb_off[(size_t)r] <= TBS_SINGLE_STEPS;
+                    sg1[(size_t)r] = one ? 1 : 0;
+                    for (int64_t x = 0; x < ns; x++) { sgs[(size_t)(j->h_seg_base[(size_t)f] + sgo[(size_t)r] + x)] = (int32_t)(r - f); sgi[(size_t)(j->h_seg_base[(size_t)f] + sgo[(size_t)r] + x)] = one ? -1 : (int32_t)x; }
                 }
                 j->h_seg_cnt[(size_t)f] = nw_chunk;
                 f = l;
             }
             FZP_TRY(j->lpt.upload(ord.data(), (size_t)nr, st));
             FZP_TRY(j->seg_off.upload(sgo.data(), (size_t)nr, st));
+            FZP_TRY(j->seg_single.upload(sg1.data(), (size_t)nr, st));
             FZP_TRY(j->seg_slot.upload(sgs.data(), sgs.size(), st)); FZP_TRY(j->seg_idx.upload(sgi.data(), sgi.size(), st));
             j->lpt_chunk_steps = split_rounds ? -1 : chunk_steps;
         }
@@ -2015,7 +2026,7 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
                 hipLaunchKernelGGL(k_tb_walk<false>, dim3((unsigned)((cnt + TBW_RPW - 1) / TBW_RPW)), dim3(64), 0, st2, first, cnt, j->anc.p, j->info.p, j->tb_off.p,
                                    j->tbo.p, j->mvo.p, (const ulonglong2 *)j->tb2[bi].p, (const ulonglong2 *)j->mvw2[bi].p, j->raw2[bi].p, j->wout.p,
                                    use_lpt ? (const int32_t *)(j->lpt.p + first) : (const int32_t *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr,
-                                   (uint32_t *)nullptr, (SegOut *)nullptr, 0, 32, (const SegReq *)nullptr, (const uint32_t *)nullptr);
+                                   (uint32_t *)nullptr, (SegOut *)nullptr, 0, 32, (const SegReq *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr);
             } else {
                 const int64_t nwk = j->h_seg_cnt[(size_t)first], wbase = j->h_seg_base[(size_t)first];
                 FZP_TRY(j->raw_seg2[bi].alloc((size_t)nwk * TBS_RAW_WORDS + 64));
@@ -2025,7 +2036,7 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
                 FZP_HIP(hipMemsetAsync(j->trail2[bi].p, 0xff, (size_t)nwk * 2 * TBS_OV * 4, st2));
                 hipLaunchKernelGGL(k_tb_walk<true>, dim3((unsigned)((nwk + TBW_RPW - 1) / TBW_RPW)), dim3(64), 0, st2, first, nwk, j->anc.p, j->info.p, j->tb_off.p,
                                    j->tbo.p, j->mvo.p, (const ulonglong2 *)j->tb2[bi].p, (const ulonglong2 *)j->mvw2[bi].p, j->raw_seg2[bi].p, j->wout.p,
-                                   (const int32_t *)nullptr, (const int32_t *)(j->seg_slot.p + wbase), (const int32_t *)(j->seg_idx.p + wbase), j->trail2[bi].p, j->segout2[bi].p, 0, guess_lane, (const SegReq *)nullptr, (const uint32_t *)nullptr);
+                                   (const int32_t *)nullptr, (const int32_t *)(j->seg_slot.p + wbase), (const int32_t *)(j->seg_idx.p + wbase), j->trail2[bi].p, j->segout2[bi].p, 0, guess_lane, (const SegReq *)nullptr, (const uint32_t *)nullptr, j->raw2[bi].p);
                 const uint32_t req_cap = (uint32_t)std::min<int64_t>(nwk, 1 << 20);
                 FZP_TRY(j->seg_req.alloc((size_t)req_cap + 1));
                 FZP_HIP(hipMemsetAsync(j->tb_fallback.p + 1, 0, 4, st2));      // this chunk's repair requests
@@ -2033,19 +2044,19 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
                 for (int round = 0; round <= REPAIR_ROUNDS; round++) {
                     hipLaunchKernelGGL(k_tb_stitch, dim3((unsigned)cnt), dim3(64), 0, st2, first, cnt, j->anc.p, j->info.p, j->tb_off.p, (const int32_t *)(j->seg_off.p + first),
                                        (const uint32_t *)j->trail2[bi].p, (const SegOut *)j->segout2[bi].p, (const uint32_t *)j->raw_seg2[bi].p, j->raw2[bi].p, j->wout.p, j->tb_fallback.p,
-                                       j->seg_req.p, req_cap, round == 0 ? 1 : (round == REPAIR_ROUNDS ? 2 : 3));
+                                       j->seg_req.p, req_cap, round == 0 ? 1 : (round == REPAIR_ROUNDS ? 2 : 3), (const uint8_t *)(j->seg_single.p + first));
                     if (round == REPAIR_ROUNDS) break;
                     // boundaries that did not join: their lower segments again, from the exact cell (a launch of empty waves when there are none)
                     hipLaunchKernelGGL(k_tb_walk<true>, dim3((unsigned)((std::min<int64_t>(req_cap, cnt) + TBW_RPW - 1) / TBW_RPW)), dim3(64), 0, st2, first, (int64_t)req_cap, j->anc.p, j->info.p,
                                        j->tb_off.p, j->tbo.p, j->mvo.p, (const ulonglong2 *)j->tb2[bi].p, (const ulonglong2 *)j->mvw2[bi].p, j->raw_seg2[bi].p, j->wout.p,
                                        (const int32_t *)nullptr, (const int32_t *)(j->seg_slot.p + wbase), (const int32_t *)(j->seg_idx.p + wbase), j->trail2[bi].p, j->segout2[bi].p, 0, guess_lane,
-                                       (const SegReq *)j->seg_req.p, (const uint32_t *)(j->tb_fallback.p + 1));
+                                       (const SegReq *)j->seg_req.p, (const uint32_t *)(j->tb_fallback.p + 1), j->raw2[bi].p);
                     hipLaunchKernelGGL(k_tb_req_reset, dim3(1), dim3(64), 0, st2, j->tb_fallback.p);   // the walks are queued behind it: the next stitch pass counts from 0
                 }
                 // reads whose segments did not join (flagged by the stitching) are walked in one piece; every other wave of this launch leaves at once
                 hipLaunchKernelGGL(k_tb_walk<false>, dim3((unsigned)((cnt + TBW_RPW - 1) / TBW_RPW)), dim3(64), 0, st2, first, cnt, j->anc.p, j->info.p, j->tb_off.p,
                                    j->tbo.p, j->mvo.p, (const ulonglong2 *)j->tb2[bi].p, (const ulonglong2 *)j->mvw2[bi].p, j->raw2[bi].p, j->wout.p,
-                                   (const int32_t *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr, (uint32_t *)nullptr, (SegOut *)nullptr, 1, 32, (const SegReq *)nullptr, (const uint32_t *)nullptr);
+                                   (const int32_t *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr, (uint32_t *)nullptr, (SegOut *)nullptr, 1, 32, (const SegReq *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr);
             }
             {
                 ProfScope ps(ctx, "k1_cigar", st2);
