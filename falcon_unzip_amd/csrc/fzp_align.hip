@@ -931,6 +931,7 @@ __global__ void __launch_bounds__(64) k_tb_walk(int64_t first, int64_t count, co
     bool have = lane < TBW_RPW && wq < count;
     SegReq rq = {0, 0, 0, 0};
     if (repair && have) { rq = req[wq]; wq = rq.walker; }
+    else if (SEGMENTED && have && order) wq = order[wq];     // launch order: the one-walker reads first (longest first), sixteen to a wave, then the segments
     // serial form: `order` = slots by decreasing read length -- the 16 reads of a wave are of similar length (a wave lasts as long as its
     // longest walk) and the longest start first.  Segmented form: `count` walkers, walker wq = segment seg_idx[wq] of slot seg_slot[wq]
     const int64_t wv = have ? (SEGMENTED ? (int64_t)seg_slot[wq] : (order ? (int64_t)order[wq] : wq)) : 0;
@@ -1659,6 +1660,7 @@ struct fzp_alnjob {
     DevBuf<uint32_t> raw2[2];                    // the walk's 2-bit op streams
     DevBuf<WalkOut> wout;
     DevBuf<uint8_t> seg_single;                  // per read: 1 = short enough for one walker
+    DevBuf<int32_t> seg_order;                   // per launched walker slot: the walker that takes it
     DevBuf<int32_t> seg_off, seg_slot, seg_idx;  // segmented trace-back: per read its first walker (chunk-relative); per walker its slot (chunk-relative) and segment
     std::vector<int64_t> h_seg_base, h_seg_cnt;  // per chunk start (indexed by its first read): first walker in seg_slot / seg_idx, number of walkers
     DevBuf<uint32_t> raw_seg2[2], trail2[2];
@@ -1927,7 +1929,7 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
         if (j->lpt_chunk_steps != chunk_steps || split_rounds) {
             // launch order inside every chunk of reads: longest first (LPT over the wave slots).  One wave per read, workgroups dispatched in
             // index order: with reads of uneven length in input order the grid's tail is whatever long read happened to come last.
-            std::vector<int32_t> ord((size_t)nr), sgo((size_t)nr), sgs, sgi;
+            std::vector<int32_t> ord((size_t)nr), sgo((size_t)nr), sgs, sgi, sgw;
             std::vector<uint8_t> sg1((size_t)nr);
             j->h_seg_base.assign((size_t)nr + 1, 0); j->h_seg_cnt.assign((size_t)nr + 1, 0);
             for (int64_t f = 0; f < nr;) {
@@ -1955,11 +1957,19 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
                     for (int64_t x = 0; x < ns; x++) { sgs[(size_t)(j->h_seg_base[(size_t)f] + sgo[(size_t)r] + x)] = (int32_t)(r - f); sgi[(size_t)(j->h_seg_base[(size_t)f] + sgo[(size_t)r] + x)] = one ? -1 : (int32_t)x; }
                 }
                 j->h_seg_cnt[(size_t)f] = nw_chunk;
+                {   // launch order of the chunk's walkers: whole-read walkers by decreasing read length, then the segment walkers
+                    sgw.resize(sgs.size());
+                    int32_t *wo = sgw.data() + j->h_seg_base[(size_t)f];
+                    int64_t at = 0;
+                    for (int64_t x = 0; x < l - f; x++) { const int64_t r = f + ord[(size_t)(f + x)]; if (sg1[(size_t)r]) wo[at++] = sgo[(size_t)r]; }
+                    for (int64_t r = f; r < l; r++) if (!sg1[(size_t)r]) for (int64_t x = 0; x < n_walkers(r); x++) wo[at++] = (int32_t)(sgo[(size_t)r] + x);
+                }
                 f = l;
             }
             FZP_TRY(j->lpt.upload(ord.data(), (size_t)nr, st));
             FZP_TRY(j->seg_off.upload(sgo.data(), (size_t)nr, st));
             FZP_TRY(j->seg_single.upload(sg1.data(), (size_t)nr, st));
+            FZP_TRY(j->seg_order.upload(sgw.data(), sgw.size(), st));
             FZP_TRY(j->seg_slot.upload(sgs.data(), sgs.size(), st)); FZP_TRY(j->seg_idx.upload(sgi.data(), sgi.size(), st));
             j->lpt_chunk_steps = split_rounds ? -1 : chunk_steps;
         }
@@ -2036,7 +2046,7 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
                 FZP_HIP(hipMemsetAsync(j->trail2[bi].p, 0xff, (size_t)nwk * 2 * TBS_OV * 4, st2));
                 hipLaunchKernelGGL(k_tb_walk<true>, dim3((unsigned)((nwk + TBW_RPW - 1) / TBW_RPW)), dim3(64), 0, st2, first, nwk, j->anc.p, j->info.p, j->tb_off.p,
                                    j->tbo.p, j->mvo.p, (const ulonglong2 *)j->tb2[bi].p, (const ulonglong2 *)j->mvw2[bi].p, j->raw_seg2[bi].p, j->wout.p,
-                                   (const int32_t *)nullptr, (const int32_t *)(j->seg_slot.p + wbase), (const int32_t *)(j->seg_idx.p + wbase), j->trail2[bi].p, j->segout2[bi].p, 0, guess_lane, (const SegReq *)nullptr, (const uint32_t *)nullptr, j->raw2[bi].p);
+                                   (const int32_t *)(j->seg_order.p + wbase), (const int32_t *)(j->seg_slot.p + wbase), (const int32_t *)(j->seg_idx.p + wbase), j->trail2[bi].p, j->segout2[bi].p, 0, guess_lane, (const SegReq *)nullptr, (const uint32_t *)nullptr, j->raw2[bi].p);
                 const uint32_t req_cap = (uint32_t)std::min<int64_t>(nwk, 1 << 20);
                 FZP_TRY(j->seg_req.alloc((size_t)req_cap + 1));
                 FZP_HIP(hipMemsetAsync(j->tb_fallback.p + 1, 0, 4, st2));      // this chunk's repair requests
