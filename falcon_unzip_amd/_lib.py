@@ -367,8 +367,9 @@ class Batch:
         begin = _take(cb.value, self.n_ctg + 1, np.int64)
         return _take_text(p, n), begin
 
-    def consensus(self, version=2) -> "Tigs":
-        """K6: phased-pile consensus of every (block, phase) (fzcns v2; version=1: one inserted base at most); run(STAGE_ALL) first."""
+    def consensus(self, version=3) -> "Tigs":
+        """K6: phased-pile consensus of every (block, phase) (fzcns v3: insertion length by the pile's median, then its bases; version=2: bases gated
+        on prefix-linked majorities; version=1: one inserted base at most); run(STAGE_ALL) first."""
         ts = TigsStruct()
         _check(load().fzp_batch_consensus_v(self.eng._p, self._p, version, C.byref(ts)))
         return Tigs(ts)

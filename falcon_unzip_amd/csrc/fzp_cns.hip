@@ -198,7 +198,7 @@ __global__ void __launch_bounds__(CNS_THREADS) k_cns_tiles(RecView rv, CnsView v
 __global__ void __launch_bounds__(256) k_cns_call(int64_t n_slots, int n_blk, const int64_t *__restrict__ cnt_off, const int32_t *__restrict__ lo, const int32_t *__restrict__ hi,
                                                   const int32_t *__restrict__ blk_ctg, const int64_t *__restrict__ ctg_goff, const uint8_t *__restrict__ ref,
                                                   const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ n_records, int version, uint8_t *__restrict__ base0,
-                                                  uint8_t *__restrict__ ins_len, uint32_t *__restrict__ ins_code) {
+                                                  uint8_t *__restrict__ ins_len, uint32_t *__restrict__ ins_code, uint32_t *__restrict__ cand) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n_slots) return;
     int a = 0, b = n_blk;                                   // block g with 2*cnt_off[g] <= i < 2*cnt_off[g+1]
@@ -209,7 +209,7 @@ __global__ void __launch_bounds__(256) k_cns_call(int64_t n_slots, int n_blk, co
     const int ph = local >= len ? 1 : 0;
     const int64_t x = local - (int64_t)ph * len;
     uint8_t s0 = 0, il = 0;
-    uint32_t ic = 0;
+    uint32_t ic = 0, cd = 0;
     if (n_records[2 * g + ph] > 0) {
         const uint32_t *c = cnt + i * CN;
         const uint32_t cov = c[0] + c[1] + c[2] + c[3] + c[4];
@@ -228,11 +228,61 @@ __global__ void __launch_bounds__(256) k_cns_call(int64_t n_slots, int n_blk, co
             uint32_t mx = c[6];
             int pick = 0;
             for (int k = 1; k < 4; k++) if (c[6 + k] > mx) { mx = c[6 + k]; pick = k; }
-            const bool ins = version == 1 ? (2 * c[5] > cov && mx > 0) : (2 * mx > cov);
-            if (ins) { il = 1; ic = (uint32_t)pick; }
+            if (version >= 3) cd = 2 * c[5] > cov ? 1u : 0u;       // v3: more than half of the coverage carries an I op here -- length and bases come from k_ins_tally3 / k_ins_decide3
+            else {
+                const bool ins = version == 1 ? (2 * c[5] > cov && mx > 0) : (2 * mx > cov);
+                if (ins) { il = 1; ic = (uint32_t)pick; }
+            }
         }
     }
     base0[i] = s0; ins_len[i] = il; ins_code[i] = ic;
+    if (cand) cand[i] = cd;
+}
+// ---- v3 ("fzcns v3", oracle/cns_oracle.c): per candidate position 8 length counters (I ops of exactly l bases, l = 2..8 counted here, l = 1 is the
+// rest of the position's I ops) and 7 x 4 base counters (levels 2..8; level 1 is the tally's first-base counters) -- one pass over the list of long I ops
+constexpr int V3_STRIDE = 40;      // [0..7] length l at [l - 1]; [8 + 4 q + base] level q + 1, q = 1..7
+__global__ void __launch_bounds__(256) k_ins_tally3(int64_t n, const LongIns *__restrict__ e, const uint8_t *__restrict__ seq, const uint32_t *__restrict__ cand,
+                                                    const uint32_t *__restrict__ cand_idx, uint32_t *__restrict__ ih) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const LongIns x = e[i];
+    if (!cand[x.slot] || x.n < 2u) return;
+    uint32_t *h = ih + (int64_t)cand_idx[x.slot] * V3_STRIDE;
+    const uint32_t ln = min(x.n, (uint32_t)INS_MAX);
+    atomicAdd(&h[ln - 1], 1u);
+    for (uint32_t q = 1; q < ln; q++) {
+        const int code = sym_code(seq[x.qidx + q]);
+        if (code < 4) atomicAdd(&h[8 + 4 * q + code], 1u);
+    }
+}
+__global__ void __launch_bounds__(256) k_ins_decide3(int64_t n_slots, const uint32_t *__restrict__ cand, const uint32_t *__restrict__ cand_idx, const uint32_t *__restrict__ ih,
+                                                     const uint32_t *__restrict__ cnt, uint8_t *__restrict__ ins_len, uint32_t *__restrict__ ins_code) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_slots || !cand[i]) return;
+    const uint32_t *c = cnt + i * CN;
+    const uint32_t *h = ih + (int64_t)cand_idx[i] * V3_STRIDE;
+    const uint32_t cov = c[0] + c[1] + c[2] + c[3] + c[4];
+    uint32_t hist[9];
+    uint32_t n_long = 0;
+#pragma unroll
+    for (int l = 2; l <= 8; l++) { hist[l] = h[l - 1]; n_long += hist[l]; }
+    hist[1] = c[5] - n_long;
+    uint32_t ge = c[5];
+    int L = 0;
+    for (int l = 1; l <= 8; l++) { if (2 * ge > cov) L = l; else break; ge -= hist[l]; }     // the median inserted length over the pile's reads
+    if (L == 1) { const uint32_t mx1 = max(max(c[6], c[7]), max(c[8], c[9])); if (!(2 * mx1 > cov)) L = 0; }   // a single base: only with a majority for the same base
+    uint32_t code = 0;
+    int n = 0;
+    for (int q = 0; q < L; q++) {
+        const uint32_t *lv = q == 0 ? c + 6 : h + 8 + 4 * q;
+        uint32_t mx = lv[0];
+        int pick = 0;
+        for (int k = 1; k < 4; k++) if (lv[k] > mx) { mx = lv[k]; pick = k; }
+        if (mx == 0) break;
+        code |= (uint32_t)pick << (2 * q);
+        n++;
+    }
+    ins_len[i] = (uint8_t)n; ins_code[i] = code;
 }
 // ---- v2 insertion levels over the listed I ops
 __global__ void __launch_bounds__(256) k_ins_init(int64_t n, LongIns *__restrict__ e, const uint8_t *__restrict__ seq, const uint8_t *__restrict__ ins_len, const uint32_t *__restrict__ ins_code,
@@ -320,10 +370,10 @@ extern "C" void fzp_tigs_free(fzp_tigs *t) {
     t->tigs = nullptr; t->seq = nullptr; t->n_tigs = 0; t->n_seq = 0;
 }
 
-extern "C" int fzp_batch_consensus(fzp_ctx *ctx, fzp_batch *b, fzp_tigs *out) { return fzp_batch_consensus_v(ctx, b, 2, out); }
+extern "C" int fzp_batch_consensus(fzp_ctx *ctx, fzp_batch *b, fzp_tigs *out) { return fzp_batch_consensus_v(ctx, b, 3, out); }
 
 extern "C" int fzp_batch_consensus_v(fzp_ctx *ctx, fzp_batch *b, int version, fzp_tigs *out) {
-    if (!ctx || !b || !out || (version != 1 && version != 2)) { fzp_set_error("fzp_batch_consensus: bad arguments"); return FZP_EINVAL; }
+    if (!ctx || !b || !out || version < 1 || version > 3) { fzp_set_error("fzp_batch_consensus: bad arguments"); return FZP_EINVAL; }
     memset(out, 0, sizeof *out);
     if (!b->have_aln || !b->have_blocks || !b->have_preads || !b->have_sites) { fzp_set_error("fzp_batch_consensus: run FZP_STAGE_ALL on a batch with alignment records first"); return FZP_EINVAL; }
     FZP_TRY(fzp_bind(ctx));
@@ -361,7 +411,7 @@ extern "C" int fzp_batch_consensus_v(fzp_ctx *ctx, fzp_batch *b, int version, fz
     DevBuf<uint64_t> total;
     DevBuf<LongIns> lins;
     DevBuf<unsigned long long> n_lins;
-    unsigned long long lins_cap = version == 2 ? (unsigned long long)std::max<int64_t>(b->n_cig / 8, 4096) : 0;
+    unsigned long long lins_cap = version >= 2 ? (unsigned long long)std::max<int64_t>(b->n_cig / 8, 4096) : 0;
     FZP_TRY(n_lins.alloc(2));
     FZP_TRY(d_cnt_off.upload(cnt_off.data(), (size_t)NB + 1, st));
     FZP_TRY(cnt.alloc((size_t)n_slots * CN));
@@ -376,14 +426,14 @@ extern "C" int fzp_batch_consensus_v(fzp_ctx *ctx, fzp_batch *b, int version, fz
     FZP_TRY(d_tblk.upload(tblk.data(), tblk.size(), st)); FZP_TRY(d_tstart.upload(tstart.data(), tstart.size(), st));
     unsigned long long h_lins = 0;
     for (int attempt = 0; attempt < 2; attempt++) {         // second attempt only if the list of long I ops overflowed its first capacity
-        if (version == 2) FZP_TRY(lins.alloc((size_t)lins_cap));
+        if (version >= 2) FZP_TRY(lins.alloc((size_t)lins_cap));
         FZP_HIP(hipMemsetAsync(n_lins.p, 0, 16, st));
         if (b->n_rec > 0) {
             ProfScope ps(ctx, "k6_tally");
             if (attempt == 0) hipLaunchKernelGGL(k_cns_nrec, dim3(nblocks(b->n_rec, 256)), dim3(256), 0, st, v, n_records.p);
             if (!tblk.empty())
                 hipLaunchKernelGGL(k_cns_tiles, dim3((unsigned)tblk.size()), dim3(CNS_THREADS), 0, st, rv, v, d_tblk.p, d_tstart.p, d_bctg.p, b->ctg_rec_begin.p, b->ctg_maxspan.p, cnt.p,
-                                   version == 2 ? lins.p : (LongIns *)nullptr, n_lins.p, lins_cap);
+                                   version >= 2 ? lins.p : (LongIns *)nullptr, n_lins.p, lins_cap);
         } else {
             FZP_TRY(cnt.zero((size_t)n_slots * CN, st));
         }
@@ -398,7 +448,20 @@ extern "C" int fzp_batch_consensus_v(fzp_ctx *ctx, fzp_batch *b, int version, fz
     {
         ProfScope ps(ctx, "k6_call");
         hipLaunchKernelGGL(k_cns_call, dim3(nblocks(n_slots, 256)), dim3(256), 0, st, n_slots, NB, d_cnt_off.p, d_lo.p, d_hi.p, d_bctg.p, b->ctg_goff.p, b->ref.p, cnt.p, n_records.p,
-                           version, base0.p, ins_len.p, ins_code.p);
+                           version, base0.p, ins_len.p, ins_code.p, version >= 3 ? n_out.p : (uint32_t *)nullptr);
+    }
+    if (version >= 3) {
+        // candidate positions (more than half of the coverage inserts something) -> dense indices -> length and level counters -> the call
+        ProfScope ps(ctx, "k6_ins_levels");
+        FZP_TRY(fzp_exclusive_scan_u32(ctx, n_out.p, off.p, (size_t)n_slots, total.p));
+        uint64_t n_cand = 0;
+        FZP_HIP(hipMemcpyAsync(&n_cand, total.p, 8, hipMemcpyDeviceToHost, st));
+        FZP_HIP(hipStreamSynchronize(st));
+        if (n_cand > 0) {
+            FZP_TRY(lv.alloc((size_t)n_cand * V3_STRIDE)); FZP_TRY(lv.zero((size_t)n_cand * V3_STRIDE, st));
+            if (h_lins > 0) hipLaunchKernelGGL(k_ins_tally3, dim3(nblocks((int64_t)h_lins, 256)), dim3(256), 0, st, (int64_t)h_lins, lins.p, b->seq.p, n_out.p, off.p, lv.p);
+            hipLaunchKernelGGL(k_ins_decide3, dim3(nblocks(n_slots, 256)), dim3(256), 0, st, n_slots, n_out.p, off.p, lv.p, cnt.p, ins_len.p, ins_code.p);
+        }
     }
     if (version == 2 && h_lins > 0) {
         ProfScope ps(ctx, "k6_ins_levels");

@@ -278,10 +278,13 @@ typedef struct {
     int64_t seq_off, seq_len;    /* into fzp_tigs.seq */
 } fzp_tig;
 typedef struct { int64_t n_tigs; fzp_tig *tigs; int64_t n_seq; uint8_t *seq; } fzp_tigs;
-int fzp_batch_consensus(fzp_ctx *ctx, fzp_batch *b, fzp_tigs *out);                 /* fzcns v2 */
+int fzp_batch_consensus(fzp_ctx *ctx, fzp_batch *b, fzp_tigs *out);                 /* fzcns v3 */
 /* version 1: at most one inserted base per position, decided on the count of I ops (the first definition; faster);
  * version 2: insertions of up to 8 bases, every base gated on the support of its prefix-linked tag (2 * count > coverage), the weight
  * falcon_sense gives a tag link in its (t_pos, delta, base) graph */
+/* version 3 (the default): the LENGTH of an insertion is decided first -- the median inserted length over the pile's reads, i.e. the largest l with more than half of
+ * the coverage carrying an I op of at least l bases (one base only with a majority for the same base) -- then its bases level by level among the I ops long enough
+ * to have one: an inserted het that noisy reads spell as 2, 3, 4 or 5 bases is still called */
 int fzp_batch_consensus_v(fzp_ctx *ctx, fzp_batch *b, int version, fzp_tigs *out);
 void fzp_tigs_free(fzp_tigs *t);     /* frees the arrays, not the struct */
 /* FASTA of one contig's tigs: ">{ctg_id}_{block:03d}_{phase} {lo+1} {hi+1} {n_records}\n{sequence}\n" */

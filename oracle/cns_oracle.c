@@ -22,6 +22,12 @@
  *         predecessors: level d = 1..8 looks at the I ops of the pile at this position that are at least d long and whose first
  *         d-1 bases are the ones already chosen; the most frequent base at level d (ties A<C<G<T) is emitted if 2*count > cov,
  *         otherwise the insertion ends.  (A tag's weight in falcon_sense is its link count minus half the coverage: the same gate.)
+ *     v3 (the default, "fzcns v3"): noisy reads spell a 3-base inserted het as 2, 3, 4 or 5 bases -- no single spelling reaches half of the
+ *         coverage, and v2 loses the insertion.  v3 decides the LENGTH first: L = the largest l <= 8 such that more than half of the
+ *         coverage carries an I op of at least l bases at this position (the median inserted length over the pile's reads, 0 for a read
+ *         without one); a one-base insertion is what single-molecule reads produce by themselves (homopolymers above all), so L = 1 is kept
+ *         only with v2's gate, more than half of the coverage inserting the SAME base; then the bases, level d = 1..L: the most
+ *         frequent base at level d among the position's I ops that are at least d long (ties A<C<G<T).
  * Output: one FASTA record per (block, phase) with at least one record in its pile, blocks ascending, phase 0 then 1:
  *     >{ctg}_{block:03d}_{phase} {min} {max} {n_records}\n{sequence}\n
  */
@@ -163,15 +169,16 @@ int orc_consensus_v(int version, const char *sam, size_t sam_len, const char *re
                     if (op == 'S') qp += v;
                     else if (op == 'I') {
                         long long pp = rp - 1;
-                        if (pp >= rec[r].pos && pp >= lo && pp <= hi && v > 0 && (size_t)qp < rec[r].sn) {
+                        long long qi = qp;                      /* first inserted base */
+                        if (pp >= rec[r].pos && pp >= lo && pp <= hi && v > 0 && (size_t)qi < rec[r].sn) {
                             cnt[(size_t)(pp - lo) * 10 + 5]++;
-                            int c = code_of((unsigned char)rec[r].seq[qp]);
+                            int c = code_of((unsigned char)rec[r].seq[qi]);
                             if (c < 4) cnt[(size_t)(pp - lo) * 10 + 6 + c]++;
                             if (v >= 2) {
                                 if (n_ins == ins_cap) { ins_cap = ins_cap ? ins_cap * 2 : 1024; ins = (ins_t *)realloc(ins, ins_cap * sizeof(ins_t)); }
                                 long long nn = v;
-                                if ((size_t)(qp + nn) > rec[r].sn) nn = (long long)rec[r].sn - qp;
-                                ins[n_ins].x = (size_t)(pp - lo); ins[n_ins].s = rec[r].seq + qp; ins[n_ins].n = nn; n_ins++;
+                                if ((size_t)(qi + nn) > rec[r].sn) nn = (long long)rec[r].sn - qi;
+                                ins[n_ins].x = (size_t)(pp - lo); ins[n_ins].s = rec[r].seq + qi; ins[n_ins].n = nn; n_ins++;
                             }
                         }
                         qp += v;
@@ -210,6 +217,37 @@ int orc_consensus_v(int version, const char *sam, size_t sam_len, const char *re
                             int pick = 0;
                             for (int k = 1; k < 4; k++) if (c[6 + k] > mx) { mx = c[6 + k]; pick = k; }
                             if (mx > 0) { char ch = "ACGT"[pick]; PUT(&ch, 1); }
+                        }
+                    } else if (version >= 3) {
+                        /* v3: WHETHER there is an insertion is decided on all I ops of the (left-normalised) column -- more than half of the
+                         * coverage, as v1; HOW LONG it is, by their lower median length (noisy reads spell a 3-base insertion as 2, 3, 4 or 5
+                         * bases: no single spelling has a majority, the length does); WHICH bases, level by level, by the most frequent base at
+                         * that level among the ops long enough to have one (ties A<C<G<T).  Lengths above 8 count as 8. */
+                        if (2 * c[5] > cov) {
+                            uint32_t hist[9] = {0};
+                            uint32_t lvl[8][4];
+                            memset(lvl, 0, sizeof lvl);
+                            uint32_t n_long = 0;
+                            for (size_t e = 0; e < n_ins; e++) {
+                                if (ins[e].x != x) continue;
+                                long long ln = ins[e].n > 8 ? 8 : ins[e].n;
+                                hist[ln]++; n_long++;
+                                for (long long q = 1; q < ln; q++) { int cc = code_of((unsigned char)ins[e].s[q]); if (cc < 4) lvl[q][cc]++; }
+                            }
+                            hist[1] = c[5] - n_long;
+                            for (int k = 0; k < 4; k++) lvl[0][k] = c[6 + k];
+                            uint32_t ge = c[5]; int Ls = 0;                        /* ge = I ops at least ln long */
+                            for (int ln = 1; ln <= 8; ln++) { if (2 * ge > cov) Ls = ln; else break; ge -= hist[ln]; }   /* the median inserted length over the pile's reads (0 for a read without one) */
+                            /* a one-base insertion is what single-molecule reads produce by themselves, above all inside homopolymers (a run of
+                             * five sees one in most reads): it is believed only with v2's gate, more than half of the coverage inserting the SAME base */
+                            if (Ls == 1) { uint32_t mx1 = c[6]; for (int k = 1; k < 4; k++) if (c[6 + k] > mx1) mx1 = c[6 + k]; if (!(2 * mx1 > cov)) Ls = 0; }
+                            for (int q = 0; q < Ls; q++) {
+                                uint32_t mx = lvl[q][0]; int pick = 0;
+                                for (int k = 1; k < 4; k++) if (lvl[q][k] > mx) { mx = lvl[q][k]; pick = k; }
+                                if (mx == 0) break;
+                                char ch = "ACGT"[pick];
+                                PUT(&ch, 1);
+                            }
                         }
                     } else {
                         int chosen[8];
@@ -250,6 +288,10 @@ int orc_consensus_v(int version, const char *sam, size_t sam_len, const char *re
 
 int orc_consensus(const char *sam, size_t sam_len, const char *ref_seq, size_t ref_len, const char *phased_reads, size_t pr_len,
                   const char *phased_variants, size_t pv_len, const char *ctg_id, char **out_txt, size_t *out_len) {
+    return orc_consensus_v(3, sam, sam_len, ref_seq, ref_len, phased_reads, pr_len, phased_variants, pv_len, ctg_id, out_txt, out_len);
+}
+int orc_consensus_v2(const char *sam, size_t sam_len, const char *ref_seq, size_t ref_len, const char *phased_reads, size_t pr_len,
+                     const char *phased_variants, size_t pv_len, const char *ctg_id, char **out_txt, size_t *out_len) {
     return orc_consensus_v(2, sam, sam_len, ref_seq, ref_len, phased_reads, pr_len, phased_variants, pv_len, ctg_id, out_txt, out_len);
 }
 int orc_consensus_v1(const char *sam, size_t sam_len, const char *ref_seq, size_t ref_len, const char *phased_reads, size_t pr_len,

@@ -207,9 +207,9 @@ def ovlp_filter(orc, files, rid_map: bytes, params: dict):
     return res[0], res[1].decode().split(), res[2].decode().split()
 
 
-def consensus(orc, sam: bytes, ref_seq: bytes, phased_reads: bytes, phased_variants: bytes, ctg_id: str, version=2):
-    """oracle/cns_oracle.c: orc_consensus (fzcns v2) / orc_consensus_v1 -> FASTA text of the (block, phase) consensus sequences"""
-    return orc._call("orc_consensus" if version == 2 else "orc_consensus_v1", [sam, ref_seq, phased_reads, phased_variants], 1, extra=[ctg_id.encode()])[0]
+def consensus(orc, sam: bytes, ref_seq: bytes, phased_reads: bytes, phased_variants: bytes, ctg_id: str, version=3):
+    """oracle/cns_oracle.c: orc_consensus (fzcns v3, the default) / orc_consensus_v2 / orc_consensus_v1 -> FASTA text of the (block, phase) consensus sequences"""
+    return orc._call({1: "orc_consensus_v1", 2: "orc_consensus_v2", 3: "orc_consensus"}[version], [sam, ref_seq, phased_reads, phased_variants], 1, extra=[ctg_id.encode()])[0]
 
 
 def track_reads(orc, files, phased_reads: bytes, read_to_contig_map: bytes, rawread_ids: bytes, min_len: int, bestn: int):

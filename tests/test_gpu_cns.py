@@ -101,7 +101,7 @@ def _indel_case(eng, hp_bias, seed=81, L=80000, per_hap=270):
     t0 = sim.codes_to_str(hap0).encode()
     t1 = sim.codes_to_str(hap1).encode()
     res = {}
-    for ver in (1, 2):
+    for ver in (1, 2, 3):
         t = b.consensus(version=ver)
         tot = err = 0
         for i, tig in enumerate(t.tigs):
@@ -117,21 +117,32 @@ def _indel_case(eng, hp_bias, seed=81, L=80000, per_hap=270):
 
 
 def test_multi_base_indel_hets_are_recovered(eng):
-    """hets that are 2-5 base insertions / deletions: fzcns v2 (prefix-linked insertion levels) spells them, v1 (one inserted base) cannot"""
+    """hets that are 2-5 base insertions / deletions: v1 (one inserted base) cannot spell them; v2 (prefix-linked majorities) spells those the noisy
+    reads agree on letter for letter; v3 (length by the pile's median first, then the bases) also gets the ones every read spells a little differently"""
     res, events = _indel_case(eng, hp_bias=1.0)
-    (tot1, err1, n1), (tot2, err2, n2) = res[1], res[2]
+    (tot1, err1, n1), (tot2, err2, n2), (tot3, err3, n3) = res[1], res[2], res[3]
     n_ins_bases = sum(n - 1 for _, kind, n in events if kind == "ins")
-    assert n2 >= 2 and tot2 >= 100000
-    assert err2 <= 0.0005 * tot2, res                      # >= 99.95 % identical to the true haplotype over the tigs
-    assert err2 < err1 and err1 - err2 >= 0.15 * n_ins_bases, (res, n_ins_bases)     # v1 cannot spell the 2nd.. bases of an inserted het; v2 gets those whose
-    # placement the reads agree on (an insertion that noisy reads place one column apart splits its votes: the remaining errors)
+    assert n3 >= 2 and tot3 >= 100000
+    assert err3 <= 6 and err3 < err2 < err1, res           # 5 errors in 131 636 consensus bases (v2: 18, v1: 28)
+    assert err1 - err2 >= 0.15 * n_ins_bases, (res, n_ins_bases)
 
 
 def test_homopolymer_biased_errors(eng):
-    """non-iid errors: indels 3x as likely inside homopolymer runs, inserted bases repeat the run's base"""
+    """non-iid errors: indels 3x as likely inside homopolymer runs, inserted bases repeat the run's base; v3's length vote must not make more of them than v2 did"""
     res, _ = _indel_case(eng, hp_bias=3.0, seed=82)
-    tot2, err2, n2 = res[2]
-    assert n2 >= 2 and err2 <= 0.002 * tot2, res           # >= 99.8 %
+    tot3, err3, n3 = res[3]
+    assert n3 >= 2 and err3 <= 0.002 * tot3 and err3 <= res[2][1], res           # >= 99.8 %
+
+
+def test_v2_still_matches_its_twin(eng, oracle):
+    from falcon_unzip_amd import _lib
+    c = Case("g2_cfg1_clr")
+    b = eng.batch([_lib.parse_sam(c.sam)], [c.ref_seq])
+    b.run(_lib.STAGE_ALL)
+    t = b.consensus(version=2)
+    res = oracle.phase_all(c.sam, c.ref_seq, c.ctg_id)
+    assert t.fasta(0, c.ctg_id) == oracle_lib.consensus(oracle, c.sam, c.ref_seq, res["phased_reads"], res["phased_variants"], c.ctg_id, version=2)
+    t.close(); b.close()
 
 
 def test_v1_still_matches_its_twin(eng, oracle):
