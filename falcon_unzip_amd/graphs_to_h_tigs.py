@@ -123,6 +123,40 @@ def _phase_graph(ctg_G, p_asm_G, h_asm_G, arid_to_phase):
     return sg
 
 
+def _best_path(G, source, target, weight=None):
+    """The reference's nx.shortest_path calls (graphs_to_h_tigs.py:238, 243, 354-356, 505) with the choice among equally cheap paths made
+    explicit, so that it does not depend on the networkx version at hand (1.x: heap ties fall to node comparison / adjacency hash order of
+    Python 2 -- unspecified; 2.x-3.x: first discovered, i.e. edge insertion order).  Pinned rule: least total weight (1 per edge without a
+    weight key); among those, fewest edges; among those, walking back from the target, the predecessor with the smallest name at every step.
+    Weights are the layout's integers (1 / 50 / 100000).  Raises nx.NetworkXNoPath like the call it replaces."""
+    import heapq
+    if source not in G or target not in G:
+        raise nx.exception.NodeNotFound("node not in graph")
+    best = {source: (0, 0)}
+    heap = [(0, 0, source)]
+    done = set()
+    while heap:
+        d, h, v = heapq.heappop(heap)
+        if v in done:
+            continue
+        done.add(v)
+        if v == target:
+            break
+        for _, w, data in G.out_edges(v, data=True):
+            cand = (d + (data.get(weight, 1) if weight else 1), h + 1)
+            if w not in best or cand < best[w]:
+                best[w] = cand
+                heapq.heappush(heap, (cand[0], cand[1], w))
+    if target not in done:
+        raise nx.exception.NetworkXNoPath("No path between %s and %s." % (source, target))
+    path, v = [target], target
+    while v != source:
+        d, h = best[v]
+        v = min(u for u, _, data in G.in_edges(v, data=True) if u in done and best[u] == (d - (data.get(weight, 1) if weight else 1), h - 1))
+        path.append(v)
+    return path[::-1]
+
+
 def _prune_strand_crossers(sg, ctg_G):
     """[203-258] haplotype components must hang on the contig's own strand: keep only shortest hooks of components that touch
     both strands, drop components that touch neither"""
@@ -147,7 +181,7 @@ def _prune_strand_crossers(sg, ctg_G):
                     path = []
                     if (v in ctg_nodes and w not in ctg_nodes_r) or (v not in ctg_nodes and w in ctg_nodes_r):
                         try:
-                            path = nx.shortest_path(comp, v, w)
+                            path = _best_path(comp, v, w)
                         except nx.exception.NetworkXNoPath:
                             path = []
                     if len(path) >= 2:
@@ -262,7 +296,7 @@ def _peel_haplotigs(rest):
                     if t in dead_sinks:
                         continue
                     try:
-                        found.append((nx.shortest_path(sub, s, t, weight="score"), t))
+                        found.append((_best_path(sub, s, t, weight="score"), t))
                     except nx.exception.NetworkXNoPath:
                         continue
                 found.sort(key=lambda x: -len(x[0]))
@@ -296,9 +330,9 @@ def generate_haplotigs_for_ctg(ctg_id, out_dir, p_asm_G, h_asm_G, arid_to_phase,
     nx.write_gexf(sg, os.path.join(out_dir, "sg.gexf"))
     nx.write_gexf(sg2, os.path.join(out_dir, "sg2.gexf"))
     try:
-        s_path = nx.shortest_path(sg2, source=s_node, target=t_node, weight="score")
+        s_path = _best_path(sg2, s_node, t_node, weight="score")
     except nx.exception.NetworkXNoPath:
-        s_path = nx.shortest_path(sg, source=s_node, target=t_node, weight="score")
+        s_path = _best_path(sg, s_node, t_node, weight="score")
     s_path_edges = list(zip(s_path[:-1], s_path[1:]))
     for v, w in s_path_edges:
         sg[v][w]["weight"] = 15

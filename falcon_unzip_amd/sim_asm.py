@@ -16,16 +16,20 @@ from . import sim
 
 
 def make_locus(rng, segments, read_len=8000, step=3000, het_rate=1.0 / 300, rid_base=0):
-    """segments: list of ('hom' | 'het', length).  -> dict with haplotypes, reads, phases, graph edge lists"""
+    """segments: list of ('hom' | 'het' | 'tie', length).  -> dict with haplotypes, reads, phases, graph edge lists.
+    'tie': a bubble like 'het' whose reads were NOT phased (no block for them in rid_to_phase): both branches score alike, the layout has to
+    break a tie between them"""
     L = sum(n for _, n in segments)
     hapA = rng.integers(0, 4, size=L, dtype=np.uint8)
     hapB = hapA.copy()
-    bubbles, pos = [], 0
+    bubbles, unphased, pos = [], set(), 0
     for kind, n in segments:
-        if kind == "het":
+        if kind in ("het", "tie"):
             k = max(3, int(n * het_rate))
             p = np.sort(rng.choice(np.arange(pos + 200, pos + n - 200), size=k, replace=False))
             hapB[p] = (hapA[p] + rng.integers(1, 4, size=k, dtype=np.uint8)) & 3
+            if kind == "tie":
+                unphased.add(len(bubbles))
             bubbles.append((pos, pos + n))
         pos += n
     reads = []          # (rid, hap, start, end)
@@ -33,7 +37,7 @@ def make_locus(rng, segments, read_len=8000, step=3000, het_rate=1.0 / 300, rid_
     def block_of(mid):
         for b, (u0, u1) in enumerate(bubbles):
             if u0 <= mid < u1:
-                return b + 1
+                return -1 if b in unphased else b + 1
         return -1
     rid = rid_base
     a_reads = []
@@ -44,12 +48,21 @@ def make_locus(rng, segments, read_len=8000, step=3000, het_rate=1.0 / 300, rid_
         a_reads.append(("%09d" % rid, 0, L - read_len, L))
         rid += 1
     b_paths = []
-    for (u0, u1) in bubbles:
-        path, s = [], u0 - 2 * step + step // 2
+    for bi, (u0, u1) in enumerate(bubbles):
+        starts, s = [], u0 - 2 * step + step // 2
         while s + read_len <= min(L, u1 + 2 * step):
+            starts.append(s)
+            s += step
+        if bi in unphased:
+            # one read fewer over the same span: the branch then has as many edges between its hooks as the primary path beside it -- with
+            # unphased reads on both (every edge scores 1) the two routes cost the same and the layout must break the tie
+            m = len(starts) - 1
+            assert m >= 3 and (starts[-1] - starts[0]) % (m - 1) == 0, "tie bubble: pick a length that lets the branch lose one read evenly"
+            starts = [starts[0] + i * (starts[-1] - starts[0]) // (m - 1) for i in range(m)]
+        path = []
+        for s in starts:
             path.append(("%09d" % rid, 1, s, s + read_len))
             rid += 1
-            s += step
         b_paths.append(path)
     phase = {}
     for r in a_reads:
@@ -58,7 +71,7 @@ def make_locus(rng, segments, read_len=8000, step=3000, het_rate=1.0 / 300, rid_
     for k, path in enumerate(b_paths):
         for r in path:
             mid = (r[2] + r[3]) // 2
-            phase[r[0]] = (k + 1, 1) if bubbles[k][0] <= mid < bubbles[k][1] else (-1, 0)
+            phase[r[0]] = (k + 1, 1) if (bubbles[k][0] <= mid < bubbles[k][1] and k not in unphased) else (-1, 0)
     seqs = {}
     for r in a_reads:
         seqs[r[0]] = sim.codes_to_str(hapA[r[2]:r[3]])

@@ -26,12 +26,18 @@ REPO = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, REPO)
 REF = "/root/reference/falcon_unzip/graphs_to_h_tigs.py"
 
-HOM, HET = "hom", "het"
+HOM, HET, TIE = "hom", "het", "tie"
 CASES = {
     "h1_two_bubbles": (11, [("000000F", [(HOM, 20000), (HET, 30000), (HOM, 15000), (HET, 25000), (HOM, 20000)])]),
     "h2_three_contigs": (12, [("000000F", [(HOM, 18000), (HET, 40000), (HOM, 18000)]), ("000001F", [(HOM, 30000)]),
                               ("000002F", [(HOM, 15000), (HET, 22000), (HOM, 12000), (HET, 21000), (HOM, 12000), (HET, 30000), (HOM, 15000)])]),
     "h3_short_bubble": (13, [("000000F", [(HOM, 25000), (HET, 9000), (HOM, 25000)])]),      # alternative path of <= 5 edges: no haplotig (:467)
+    # a bubble whose reads were not phased and whose two branches have the same number of edges: every edge scores 1, the source-to-sink routes through
+    # either branch cost the same (graphs_to_h_tigs.py:354), and so do the candidates of the haplotig peeling (:505).  Which one the reference takes is
+    # left to networkx (1.x under Python 2: heap ties by node comparison over hash-ordered adjacency -- unspecified; here, 3.x: first discovered = edge
+    # insertion order = the primary assembly's edges first).  The mirror pins: least score, then fewest edges, then smallest predecessor name walking
+    # back from the target -- on this case the same route (the primary assembly's reads carry the smaller ids).
+    "h4_tied_bubble": (14, [("000000F", [(HOM, 20000), (HET, 30000), (HOM, 15000), (TIE, 18000), (HOM, 20000)])]),
 }
 OUTPUTS = ("p_ctg.%s.fa", "p_ctg_path.%s", "p_ctg_edges.%s", "h_ctg_all.%s.fa", "h_ctg_path.%s", "h_ctg_edges.%s", "path_len.%s")
 

@@ -84,3 +84,31 @@ def test_consumes_rid_to_phase_written_by_the_pipeline_format(tmp_path):
     p.write_text("000000012 000000F 3 1\n000000013 000000F -1 0\n000000099 000001F 1 0\n")
     table, ids = graphs_to_h_tigs.load_rid_to_phase(str(p))
     assert table == {"000000F": {"000000012": (3, 1), "000000013": (-1, 0)}, "000001F": {"000000099": (1, 0)}} and len(ids) == 3
+
+
+def test_tied_routes_are_broken_by_the_pinned_rule_not_by_networkx(tmp_path, monkeypatch):
+    """h4: a bubble of unphased reads whose branches have the same number of edges -- two source-to-sink routes of equal score.  The mirror's choice
+    (least score, fewest edges, smallest predecessor name from the target back) equals the reference's output on networkx 3 (the golden), and it does
+    not move when the graph's edges are inserted in another order, which is what networkx's own tie-break follows."""
+    import networkx as nx
+    from falcon_unzip_amd import graphs_to_h_tigs as g
+    man, work, loci = _run("h4_tied_bubble", tmp_path)
+    loc = loci[0]
+    ctg = loc["ctg_id"]
+    assert any(seg[0] == "tie" for seg in man["layouts"][0][1])
+    with open(os.path.join(work, ctg, "p_ctg_path.%s" % ctg)) as f:
+        primary = [l.split()[1] for l in f]
+    a_names = {"%s:E" % r[0] for r in loc["a_reads"]}
+    assert set(primary) <= a_names                                   # through the tied bubble the primary tig keeps to the primary assembly's reads
+    # the rule itself, on a diamond with equal costs, whatever the insertion order
+    for order in (("s", "b", "t", "s", "a", "t"), ("s", "a", "t", "s", "b", "t")):
+        G = nx.DiGraph()
+        for v, w in zip(order[0:2] + order[3:5], order[1:3] + order[4:6]):
+            G.add_edge(v, w, score=1)
+        assert g._best_path(G, "s", "t", weight="score") == ["s", "a", "t"]
+    G = nx.DiGraph()
+    G.add_edge("s", "x", score=2); G.add_edge("x", "t", score=0)    # equal score, more edges than the direct one below: the shorter route wins
+    G.add_edge("s", "t", score=2)
+    assert g._best_path(G, "s", "t", weight="score") == ["s", "t"]
+    with pytest.raises(nx.exception.NetworkXNoPath):
+        g._best_path(G, "t", "s", weight="score")
