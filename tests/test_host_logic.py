@@ -112,3 +112,36 @@ def test_contig_buffers_are_lent_not_copied():
     assert ptr[3]                                   # an empty contig still gets a valid address
     assert ptr[0] == C.cast(C.c_char_p(contigs[0]), C.c_void_p).value       # the bytes object's own buffer
     assert ptr[2] == contigs[2].ctypes.data
+
+
+def test_unzip_config_hook_and_gpu_phasing_task(tmp_path):
+    """falcon_unzip_amd/unzip_tasks.py: the [Unzip] keys and the one pypeflow task that stands in for unzip_all's per-contig loops (unzip.py:231-288).
+    The task body only writes its script (as task_run_blasr / task_phasing do, unzip.py:61-133); what the script runs is covered on the GPU
+    (tests/test_gpu_pipeline.py)."""
+    import configparser
+    from falcon_unzip_amd import _miniflow, unzip_tasks
+    cfg = configparser.ConfigParser()
+    cfg.read_string("[General]\njob_type = local\n[Unzip]\nsmrt_bin = /opt/smrt/bin\n")
+    assert unzip_tasks.read_config(cfg)["phasing_backend"] == "blasr"                 # absent keys: the reference's own path
+    cfg.read_string("[Unzip]\nphasing_backend = HIP\nphasing_gpus = 8\n")
+    conf = unzip_tasks.read_config(cfg)
+    assert conf["phasing_backend"] == "hip" and conf["phasing_gpus"] == 8
+    cfg.read_string("[Unzip]\nphasing_backend = cuda\n")
+    with pytest.raises(ValueError):
+        unzip_tasks.read_config(cfg)
+    unzip = tmp_path / "3-unzip"
+    (unzip / "reads").mkdir(parents=True)
+    for c in ("000000F", "000001F"):
+        (unzip / "reads" / ("%s_ref.fa" % c)).write_text(">%s\nACGT\n" % c)
+        (unzip / "reads" / ("%s_reads.fa" % c)).write_text(">r/1/0_4\nACGT\n")
+    wf = _miniflow.PypeProcWatcherWorkflow()
+    out = unzip_tasks.add_gpu_phasing_task(wf, conf, ["000000F", "000001F"], _miniflow.PypeTask, _miniflow.makePypeLocalFile, unzip_dir=str(unzip),
+                                           read_map_dir=str(tmp_path / "read_maps"))
+    assert str(out).endswith("3-unzip/1-hasm/rid-to-phase-all/rid_to_phase.all")     # what task_hasm waits for (unzip.py:285,293)
+    task = wf._tasks[0]
+    assert len(task.inputs) == 4 and set(task.outputs) == {"rid_to_phase_all", "job_done"}
+    wf.refreshTargets()                                                                # runs the body: the script exists, nothing is executed
+    script = open(task.generated_script_fn).read()
+    done = str(task.outputs["job_done"])
+    assert script.startswith("set -vex\ntrap 'touch %s.exit' EXIT\n" % done) and script.rstrip().endswith("touch %s" % done)
+    assert "--nproc-per-node 8" in script and "fc_unzip_phase_gpu.py --unzip_dir %s --read_map_dir %s" % (unzip, tmp_path / "read_maps") in script

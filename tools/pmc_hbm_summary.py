@@ -12,13 +12,20 @@ import json
 import sys
 
 
+def kernel_key(name):
+    """'void (anonymous namespace)::k_sw<true>(long, ...)' -> 'k_sw'"""
+    k = name.replace("(anonymous namespace)::", "").split("(")[0].strip()
+    if k.startswith("void "):
+        k = k[5:]
+    return k.split("<")[0]
+
+
 def load(path, name):
     tot, calls, dur = collections.Counter(), collections.Counter(), collections.Counter()
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != name:
             continue
-        k = r["Kernel_Name"].split("(")[0].replace("(anonymous namespace)::", "").strip()
-        k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
+        k = kernel_key(r["Kernel_Name"])
         tot[k] += float(r["Counter_Value"])
         calls[k] += 1
         dur[k] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6

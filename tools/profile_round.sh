@@ -6,7 +6,7 @@ tag=$1
 export TMPDIR=/tmp
 out=gpurun_out/prof_$tag
 mkdir -p $out
-B="--no-cpu-baseline --no-end-to-end --gen-workers 1"
+B="--no-cpu-baseline --no-end-to-end --no-shaped-leg --gen-workers 1"
 rocprofv3 --kernel-trace --stats -d $out/kt -o kt --output-format csv -- python3 bench.py --steps 2 --warmup 1 $B > $out/kt_bench_line.json 2> $out/kt.log
 rocprofv3 --pmc FETCH_SIZE -d $out/fetch -o p --output-format csv -- python3 bench.py --steps 1 --warmup 0 $B > /dev/null 2> $out/fetch.log
 rocprofv3 --pmc WRITE_SIZE -d $out/write -o p --output-format csv -- python3 bench.py --steps 1 --warmup 0 $B > /dev/null 2> $out/write.log
@@ -14,5 +14,6 @@ rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVES -d $out/sq -o
 python3 tools/pmc_hbm_summary.py $(find $out/fetch -name '*counter_collection.csv') $(find $out/write -name '*counter_collection.csv') $out/pmc_hbm_bytes.csv $out/k1_sw_hbm_traffic.json
 cp $(find $out/kt -name '*kernel_stats.csv') $out/kernel_stats.csv
 cp $(find $out/sq -name '*counter_collection.csv') $out/sq_counters.csv
+(cd tools && python3 sq_counters_summary.py ../$out/sq_counters.csv ../$out/sq_counters.json ../$out/kt_bench_line.json ../$out/k1_sw_counters.json "profiles/${tag}_sq_counters.json (rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVES, bench.py --steps 1)")
 python3 bench.py > $out/bench_line.json 2> $out/bench.log
 ls $out

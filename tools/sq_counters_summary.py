@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVES (one pass) -> per-kernel sums as JSON, and -- given the bench line of the
+same workload -- profiles/k1_sw_counters.json: VALU / SALU / scalar-memory instructions of k_sw per 64-cell band step, which bench.py's roofline reads.
+usage: sq_counters_summary.py <counter_collection.csv> <out.json> [<bench_line.json> <k1_sw_counters.json> <source label>]"""
+import collections
+import csv
+import json
+import sys
+
+from pmc_hbm_summary import kernel_key
+
+
+def main():
+    tot = collections.defaultdict(lambda: collections.Counter())
+    calls = collections.Counter()
+    for r in csv.DictReader(open(sys.argv[1])):
+        k = kernel_key(r["Kernel_Name"])
+        tot[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        if r["Counter_Name"] == "SQ_WAVES":
+            calls[k] += 1
+    json.dump({k: dict(v, launches=calls[k]) for k, v in tot.items()}, open(sys.argv[2], "w"), indent=1)
+    if len(sys.argv) > 4:
+        line = json.load(open(sys.argv[3]))
+        steps = line["dp_cells_per_step"] / 64.0                     # band steps of one k_sw launch (first candidates; the second-candidate launch is part of the sum below)
+        sw = tot["k_sw"]
+        n = max(1, calls["k_sw"])
+        per_launch = {c: sw[c] / n for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM")}
+        json.dump({"kernel": "k_sw", "band_steps_per_launch": steps, "valu_per_step": round(per_launch["SQ_INSTS_VALU"] / steps, 3),
+                   "salu_per_step": round(per_launch["SQ_INSTS_SALU"] / steps, 3), "smem_per_step": round(per_launch["SQ_INSTS_SMEM"] / steps, 3),
+                   "launches_counted": n, "source": sys.argv[5] if len(sys.argv) > 5 else sys.argv[2]}, open(sys.argv[4], "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

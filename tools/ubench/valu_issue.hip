@@ -15,10 +15,10 @@
 #include <vector>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
-enum Kind { ADD = 0, MAX, ADD_DPP, MAX_DPP, MOV_DPP, CMP_SGPR, CMP_VCC, CNDMASK, MAX3, READLANE, WRITELANE, PK_ADD_I16, PK_MAX_I16, SW_MIX, SW_MIX_NOLANE, SW_MIX_SEL, CNDMASK_E64, N_KINDS };
+enum Kind { ADD = 0, MAX, ADD_DPP, MAX_DPP, MOV_DPP, CMP_SGPR, CMP_VCC, CNDMASK, MAX3, READLANE, WRITELANE, PK_ADD_I16, PK_MAX_I16, SW_MIX, SW_MIX_NOLANE, SW_MIX_SEL, CNDMASK_E64, MAX_3REG, N_KINDS };
 static const char *kind_name[N_KINDS] = {"v_add_u32", "v_max_i32", "v_add_u32_dpp(wave_shl)", "v_max_i32_dpp(wave_shr)", "v_mov_b32_dpp(wave_shl)",
-                                         "v_cmp_eq_i32_e64->sgpr", "v_cmp_eq_u32_e32->vcc", "v_cndmask_b32", "v_max3_i32", "v_readlane_b32",
-                                         "v_writelane_b32", "v_pk_add_i16", "v_pk_max_i16", "k_sw step mix (13 VALU + 9 SALU + s_store)", "k_sw step mix without readlane/writelane", "k_sw step mix, Hnew = cmp_ge + cndmask_e64 (no max + cmp_eq)", "v_cndmask_b32_e64 (sgpr pair mask)"};
+                                         "v_cmp_eq_i32_e64->sgpr", "v_cmp_eq_u32_e32->vcc", "v_cndmask_b32 (vcc written once, one asm statement)", "v_max3_i32", "v_readlane_b32",
+                                         "v_writelane_b32", "v_pk_add_i16", "v_pk_max_i16", "k_sw step mix (13 VALU + 9 SALU + s_store)", "k_sw step mix without readlane/writelane", "k_sw step mix, Hnew = cmp_ge + cndmask_e64 (no max + cmp_eq)", "v_cndmask_b32_e64 (sgpr pair mask)", "v_max_i32 (dst apart from both sources)"};
 
 #define R8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
 
@@ -28,6 +28,7 @@ __global__ void __launch_bounds__(1024) k(uint32_t *out, int iters, uint64_t *si
     for (int i = 0; i < 8; i++) { v[i] = threadIdx.x * (i + 3) + 1; w[i] = (threadIdx.x ^ (i * 5)) + 7; }
     uint64_t sm = 0;
     int32_t sx = 0;
+    asm volatile("v_cmp_gt_i32_e32 vcc, %0, %1" ::"v"(v[0]), "v"(w[0]) : "vcc");
     for (int it = 0; it < iters; it++) {
 #pragma unroll
         for (int u = 0; u < 8; u++) {
@@ -60,9 +61,19 @@ __global__ void __launch_bounds__(1024) k(uint32_t *out, int iters, uint64_t *si
                 R8(X)
 #undef X
             } else if (KIND == CNDMASK) {
-#define X(i) asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(v[i]) : "v"(w[i]) : "vcc");
-                R8(X)
-#undef X
+                // one asm statement for the eight of them: between separate statements that each declare vcc clobbered the compiler pads with
+                // s_nop (it has to assume a VALU write of vcc just before a read of it as a lane mask), and r2's row measured those pads --
+                // 23 cycles per instruction.  vcc is written once, before the loop.
+                asm volatile("v_cndmask_b32_e32 %0, %0, %8, vcc\n\tv_cndmask_b32_e32 %1, %1, %9, vcc\n\tv_cndmask_b32_e32 %2, %2, %10, vcc\n\tv_cndmask_b32_e32 %3, %3, %11, vcc\n\t"
+                             "v_cndmask_b32_e32 %4, %4, %12, vcc\n\tv_cndmask_b32_e32 %5, %5, %13, vcc\n\tv_cndmask_b32_e32 %6, %6, %14, vcc\n\tv_cndmask_b32_e32 %7, %7, %15, vcc"
+                             : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])
+                             : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]));
+            } else if (KIND == MAX_3REG) {
+                // v_max_i32 with a destination that is neither source (the plain row above reuses its first source)
+                asm volatile("v_max_i32 %0, %8, %9\n\tv_max_i32 %1, %9, %10\n\tv_max_i32 %2, %10, %11\n\tv_max_i32 %3, %11, %12\n\t"
+                             "v_max_i32 %4, %12, %13\n\tv_max_i32 %5, %13, %14\n\tv_max_i32 %6, %14, %15\n\tv_max_i32 %7, %15, %8"
+                             : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+                             : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]));
             } else if (KIND == MAX3) {
 #define X(i) asm volatile("v_max3_i32 %0, %0, %1, %2" : "+v"(v[i]) : "v"(w[i]), "v"(w[(i + 1) & 7]));
                 R8(X)
@@ -273,7 +284,8 @@ __global__ void __launch_bounds__(1024) k2(uint32_t *out, int iters) {
         if (id == 20) { _Pragma("unroll") for (int i = 0; i < 8; i++) asm volatile(text : "+v"(v64[i]) : "v"(w[i])); } \
         else if (id == 18) { _Pragma("unroll") for (int i = 0; i < 8; i++) asm volatile(text : "+v"(v[i & 1]) : "v"(w[i])); } \
         else if (id == 26) { _Pragma("unroll") for (int i = 0; i < 8; i++) asm volatile(text : "+v"(v[i]), "+v"(w[i])); } \
-        else if (id == 15 || id == 19 || id == 14) { _Pragma("unroll") for (int i = 0; i < 8; i++) asm volatile(text : "+v"(v[i]) : "v"(w[i]) : "vcc"); } \
+        else if (id == 14) { asm volatile("v_cndmask_b32_e32 %0, %0, %8, vcc\n\tv_cndmask_b32_e32 %1, %1, %9, vcc\n\tv_cndmask_b32_e32 %2, %2, %10, vcc\n\tv_cndmask_b32_e32 %3, %3, %11, vcc\n\tv_cndmask_b32_e32 %4, %4, %12, vcc\n\tv_cndmask_b32_e32 %5, %5, %13, vcc\n\tv_cndmask_b32_e32 %6, %6, %14, vcc\n\tv_cndmask_b32_e32 %7, %7, %15, vcc" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7])); } \
+        else if (id == 15 || id == 19) { _Pragma("unroll") for (int i = 0; i < 8; i++) asm volatile(text : "+v"(v[i]) : "v"(w[i]) : "vcc"); } \
         else { _Pragma("unroll") for (int i = 0; i < 8; i++) asm volatile(text : "+v"(v[i]) : "v"(w[i])); }          \
     }
             SIMPLE_KINDS(X)
@@ -339,6 +351,7 @@ int main(int argc, char **argv) {
     run_kind<SW_MIX_NOLANE>(d_out, n_cu, iters / 4, 8 * 4 * 11, 8 * 4 * 11, clk_ghz);
     run_kind<SW_MIX_SEL>(d_out, n_cu, iters / 4, 8 * 4 * 14, 8 * 4 * 14, clk_ghz);
     run_kind<CNDMASK_E64>(d_out, n_cu, iters, 64, 64, clk_ghz);
+    run_kind<MAX_3REG>(d_out, n_cu, iters, 64, 64, clk_ghz);
     if (argc > 2) { CK(hipFree(d_out)); return 0; }
 #define X(id, name, text) run_simple<id>(d_out, n_cu, iters, name, clk_ghz);
     SIMPLE_KINDS(X)
