@@ -609,6 +609,7 @@ __device__ __forceinline__ void scalar_store16(void *base, uint32_t byte_off, ui
         if ((PARTIAL) || ((t - 1) & 63) == 63) {                                                           \
             uint32_t glane = 32u;                                                                          \
             if ((t & (TBS_SEG - 1)) == 0) {   /* step t-1 tops a trace-back segment: the lane of its best H is where that segment's walker starts */ \
+                asm volatile("" ::: "memory");   /* keeps the compiler from running this reduction on every flush and selecting afterwards (it did: +0.7 VALU per step) */ \
                 int32_t hv = H, hl = lane;                                                                 \
                 _Pragma("unroll") for (int d_ = 32; d_ >= 1; d_ >>= 1) {                                   \
                     const int32_t ov_ = __shfl_xor(hv, d_, 64), ol_ = __shfl_xor(hl, d_, 64);              \
@@ -808,6 +809,7 @@ __global__ void __launch_bounds__(64) k_sw(int64_t first, int64_t count, const i
     ts.init(tpk, tbase + 33);
     bool done = false;
     while (!done) {
+        t = __builtin_amdgcn_readfirstlane(t); i0 = __builtin_amdgcn_readfirstlane(i0);
         // how many steps can run with every lane strictly inside the matrix?  Each step advances i0 or
         // lane 0's column by one, so min(rows left, columns left) steps are safe once the band is inside.
         int32_t safe = 0;
@@ -849,10 +851,10 @@ __global__ void __launch_bounds__(64) k_sw(int64_t first, int64_t count, const i
                 }
                 pm = (int32_t)(mv & 1u);                                 // the block's last move (the steps no longer keep it up to date)
                 const int32_t nd = __popc(mv);                          // DOWN moves of the block (mv holds exactly n_steps bits)
-                i0 += nd;
+                i0 = __builtin_amdgcn_readfirstlane(i0 + nd);
                 qpos_i += nd; tpos_i += n_steps - nd;
                 mvacc |= (uint64_t)(__brev(mv) >> (32 - n_steps)) << (t & 63);   // step s of the block -> bit (t + s) & 63
-                t += n_steps;
+                t = __builtin_amdgcn_readfirstlane(t + n_steps);         // (uniform; said aloud so that the counter and everything hanging off it stay scalar)
                 if ((t & 63) == 0) SW_FLUSH(false)
             }
             down = dn != 0;
