@@ -467,11 +467,10 @@ __global__ void __launch_bounds__(64) k_chain(int64_t first, int64_t count, cons
     if (lane == 0) {
         Anchor a = none;
         if (best_st >= 0) {
-            // the chain's first hit fixes the diagonal; the extension itself starts at the read's first base on that diagonal
-            // (or at the contig's first base when the read overhangs it)
+            // v1.4: the chain's first hit IS the anchor (a cell of the true path): the extension runs forward from it (k_sw) and, on the reversed
+            // read prefix and contig window, backward from it (k_back_prep -> k_sw again)
             const uint2 hv = hits[best_st];
-            const int32_t d = (int32_t)hv.y - (int32_t)(hv.x & 0x7fffffffu);
-            a.aligned = 1; a.strand = ws; a.i_a = d < 0 ? -d : 0; a.c_a = d < 0 ? 0 : d;
+            a.aligned = 1; a.strand = ws; a.i_a = (int32_t)(hv.x & 0x7fffffffu); a.c_a = (int32_t)hv.y;
         }
         out[r] = a;
     }
@@ -1409,6 +1408,87 @@ __global__ void __launch_bounds__(64) k_tb_cigar(int64_t first, int64_t count, c
     summ[r] = out;
 }
 
+// ---- backward extension (v1.4): inputs.  Per read of the chunk: the winner's anchor (i_h, c_h) -> the reversed oriented-read prefix [0, i_h) and the
+// reversed contig window of min(c_h, i_h + i_h / 4 + 64) bases before c_h, both 2-bit packed with zero padding, at offsets the host planned from the
+// candidates' anchors; k_sw then runs on them as on any read / contig pair (anchor (0, 0), the "contig" of slot r is its own window).
+__global__ void __launch_bounds__(256) k_back_prep(int64_t first, const Anchor *__restrict__ anc, const int32_t *__restrict__ read_ctg, const uint32_t *__restrict__ read_ori,
+                                                   const int64_t *__restrict__ read_woff, const uint32_t *__restrict__ ctg_pk, const int64_t *__restrict__ ctg_woff,
+                                                   const int64_t *__restrict__ bq_off, const int64_t *__restrict__ bt_off, uint32_t *__restrict__ bq, uint32_t *__restrict__ bt,
+                                                   Anchor *__restrict__ anc_b, int32_t *__restrict__ b_len, int64_t *__restrict__ b_tlen) {
+    const int64_t r = first + blockIdx.x;
+    const Anchor a = anc[r];
+    const int32_t nqb = (a.aligned && a.i_a > 0 && a.c_a > 0) ? a.i_a : 0;
+    const int32_t ntb = nqb ? min(a.c_a, nqb + nqb / 4 + 64) : 0;
+    if (threadIdx.x == 0) {
+        Anchor ab; ab.aligned = nqb > 0 ? 1 : 0; ab.strand = a.strand; ab.i_a = 0; ab.c_a = 0;
+        anc_b[r] = ab; b_len[r] = nqb; b_tlen[r] = ntb;
+    }
+    const uint32_t *q = read_ori + read_woff[r];
+    const uint32_t *t = ctg_pk + ctg_woff[read_ctg[r]];
+    uint32_t *dq = bq + bq_off[r], *dt = bt + bt_off[r];
+    const int64_t wq = bq_off[r + 1] - bq_off[r], wt = bt_off[r + 1] - bt_off[r];      // capacities: the used words first, zeros behind them
+    for (int64_t w = threadIdx.x; w < wq; w += 256) {
+        uint32_t v = 0;
+        for (int m = 0; m < 16; m++) { const int64_t x = w * 16 + m; if (x < nqb) v |= base_at(q, (int64_t)a.i_a - 1 - x) << (2 * m); }
+        dq[w] = v;
+    }
+    for (int64_t w = threadIdx.x; w < wt; w += 256) {
+        uint32_t v = 0;
+        for (int m = 0; m < 16; m++) { const int64_t x = w * 16 + m; if (x < ntb) v |= base_at(t, (int64_t)a.c_a - 1 - x) << (2 * m); }
+        dt[w] = v;
+    }
+}
+// ---- backward extension: its walk joins the forward one.  The read's op stream so far runs from the alignment's END to the forward walk's exit next to the
+// anchor; behind it go the gap moves that exit implies (a walk that leaves through row / column -1 skipped bases there), the ones the backward walk's exit
+// implies, and the backward walk's ops turned round (it came from the far end towards the anchor).  k_tb_cigar then sees one path.
+__global__ void __launch_bounds__(64) k_back_merge(int64_t first, int64_t count, const int64_t *__restrict__ tb_off, const int64_t *__restrict__ tb_off_b,
+                                                   const Anchor *__restrict__ anc_b, const DpInfo *__restrict__ info_b, const WalkOut *__restrict__ wout_b,
+                                                   const uint32_t *__restrict__ raw_b, uint32_t *__restrict__ raw, WalkOut *__restrict__ wout, DpInfo *__restrict__ info) {
+    const int lane = lane_id();
+    const int64_t wv = blockIdx.x;
+    if (wv >= count) return;
+    const int64_t r = first + wv;
+    WalkOut fw = wout[r];
+    if (fw.ok != 1 || !anc_b[r].aligned) return;
+    const DpInfo ib = info_b[r];
+    const WalkOut bw = wout_b[r];
+    DpInfo di = info[r];
+    di.steps += ib.steps;                                                // the cells of the backward DP count, whatever came of it
+    if (!(bw.ok == 1 && ib.best_score > 0)) { if (lane == 0) info[r] = di; return; }
+    const int32_t is = fw.i, js = fw.ts - fw.i, bis = bw.i, bjs = bw.ts - bw.i;
+    const int32_t nD = (is < 0 && js >= 0) ? js + 1 : 0, nI = (js < 0 && is >= 0) ? is + 1 : 0;
+    const int32_t bD = (bis < 0 && bjs >= 0) ? bjs + 1 : 0, bI = (bjs < 0 && bis >= 0) ? bis + 1 : 0;
+    const int32_t nb = bw.n_ops, m = nD + nI + bD + bI + nb, at = fw.n_ops;
+    const int64_t cap_ops = tb_off[r + 1] - tb_off[r];
+    if ((int64_t)at + m > cap_ops) { if (lane == 0) info[r] = di; return; }      // (cannot happen: a path has fewer ops than the DP had steps)
+    uint32_t *rg = raw + ((tb_off[r] - tb_off[first]) >> 4);
+    const uint32_t *rb = raw_b + ((tb_off_b[r] - tb_off_b[first]) >> 4);
+    const int32_t w0 = at >> 4, w1 = (at + m - 1) >> 4;
+    for (int32_t wi = w0 + lane; wi <= w1; wi += 64) {
+        uint32_t word = 0;
+        if (wi == w0 && (at & 15)) word = rg[wi] & ((1u << (2 * (at & 15))) - 1u);
+        for (int sl = 0; sl < 16; sl++) {
+            const int32_t p = 16 * wi + sl;
+            if (p < at || p >= at + m) continue;
+            int32_t x = p - at;
+            uint32_t op;
+            if (x < nD) op = 2u;
+            else if ((x -= nD) < nI) op = 1u;
+            else if ((x -= nI) < bD) op = 2u;
+            else if ((x -= bD) < bI) op = 1u;
+            else { x -= bI; const int32_t src = nb - 1 - x; op = (rb[src >> 4] >> (2 * (src & 15))) & 3u; }
+            word |= op << (2 * sl);
+        }
+        rg[wi] = word;
+    }
+    if (lane == 0) {
+        fw.n_ops = at + m;
+        wout[r] = fw;
+        di.best_score += ib.best_score;
+        info[r] = di;
+    }
+}
+
 __global__ void __launch_bounds__(256) k_sec_count(int64_t n, const Anchor *__restrict__ ancB, uint32_t *__restrict__ count) {
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const uint64_t m = __ballot(r < n && ancB[r].aligned != 0);
@@ -1681,6 +1761,16 @@ struct fzp_alnjob {
     int64_t max_reads_per_ctg = 1;
     bool summ_on_host = false;
     DevBuf<ulonglong2> mvw2[2];
+    // backward extension (v1.4): slot = read; capacities planned by the host from the candidates' anchors at every run
+    DevBuf<Anchor> anc_b;
+    DevBuf<DpInfo> info_b;
+    DevBuf<int32_t> b_len, b_iota, b_order;
+    DevBuf<int64_t> b_tlen, bq_off, bt_off, tb_off_b, tbo_b, mvo_b;
+    DevBuf<uint32_t> bq, bt, raw_b2[2];
+    DevBuf<uint2> tb_b2[2];
+    DevBuf<ulonglong2> mvw_b2[2];
+    DevBuf<WalkOut> wout_b;
+    std::vector<int64_t> h_tb_off_b;
     hipEvent_t ev_sw[2] = {nullptr, nullptr}, ev_tb[2] = {nullptr, nullptr};
     DevBuf<fzp_aln_summary> summ;
     bool done = false;
@@ -1884,9 +1974,13 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
         // second candidates (reads whose votes show a second placement: repeats).  Usually none; then nothing below runs.
         uint32_t n2 = 0;
         int32_t ovf = 0;
+        std::vector<Anchor> h_anc((size_t)nr);              // the first candidates' anchors: how far back an extension may have to reach (v1.4)
         FZP_HIP(hipMemcpyAsync(&n2, j->n_sec.p, 4, hipMemcpyDeviceToHost, st));
         FZP_HIP(hipMemcpyAsync(&ovf, j->idx_overflow.p, 4, hipMemcpyDeviceToHost, st));
+        FZP_TRY(j->anc.download(h_anc.data(), (size_t)nr, st));
         FZP_HIP(hipStreamSynchronize(st));
+        std::vector<int32_t> b_cap((size_t)nr);
+        for (int64_t r = 0; r < nr; r++) b_cap[(size_t)r] = (h_anc[(size_t)r].aligned && h_anc[(size_t)r].c_a > 0) ? h_anc[(size_t)r].i_a : 0;
         if (ovf) { fzp_set_error("k-mer index: a table partition overflowed (more than %d distinct k-mers hash into one 64 KB partition)", 4 << PART_BITS); return FZP_EINVAL; }
         j->n_second = n2;
         std::vector<int32_t> h_ridx;
@@ -1901,6 +1995,7 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
                 const int64_t n = j->h_read_len[(size_t)r];
                 h_ridx.push_back((int32_t)r);
                 h2.push_back(hb[(size_t)r]);
+                if (hb[(size_t)r].c_a > 0) b_cap[(size_t)r] = std::max(b_cap[(size_t)r], hb[(size_t)r].i_a);     // whichever candidate wins
                 h_woff2.push_back(h_woff2.back() + (((n + 15) / 16 + 8 + 1) & ~1LL));
                 h_tb_off2.push_back(h_tb_off2.back() + (n + n + n / 4 + 64 + 2 + 63) / 64 * 64);
             }
@@ -1911,6 +2006,29 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
             FZP_HIP(hipStreamSynchronize(st));      // the staging vectors die with this scope
             ProfScope ps(ctx, "k1_orient");
             hipLaunchKernelGGL(k_orient, dim3(n2, 1), dim3(256), 0, st, (int64_t)0, j->read_pk.p, j->read_woff.p, j->read_len.p, j->anc2.p, j->ridx.p, j->sec_woff.p, j->sec_ori.p);
+        }
+        // ---- backward extension (v1.4): per read room for the reversed prefix (as long as the deeper of its candidates' anchors), the reversed contig
+        // window and the masks of that DP.  Typical anchors sit a few hundred bases into the read: a few per cent of the forward work.
+        {
+            std::vector<int64_t> qo((size_t)nr + 1, 0), to((size_t)nr + 1, 0);
+            j->h_tb_off_b.assign((size_t)nr + 1, 0);
+            for (int64_t r = 0; r < nr; r++) {
+                const int64_t cq = b_cap[(size_t)r], ct = cq ? cq + cq / 4 + 64 : 0;
+                qo[(size_t)r + 1] = qo[(size_t)r] + (cq ? (((cq + 15) / 16 + 8 + 1) & ~1LL) : 0);
+                to[(size_t)r + 1] = to[(size_t)r] + (cq ? (((ct + 15) / 16 + 8 + 1) & ~1LL) : 0);
+                j->h_tb_off_b[(size_t)r + 1] = j->h_tb_off_b[(size_t)r] + (cq ? (cq + ct + 2 + 63) / 64 * 64 : 0);
+            }
+            FZP_TRY(j->bq_off.upload(qo.data(), qo.size(), st)); FZP_TRY(j->bt_off.upload(to.data(), to.size(), st));
+            FZP_TRY(j->tb_off_b.upload(j->h_tb_off_b.data(), j->h_tb_off_b.size(), st));
+            FZP_TRY(j->bq.alloc((size_t)qo.back() + 16)); FZP_TRY(j->bt.alloc((size_t)to.back() + 16));
+            FZP_TRY(j->anc_b.alloc((size_t)nr)); FZP_TRY(j->info_b.alloc((size_t)nr)); FZP_TRY(j->b_len.alloc((size_t)nr)); FZP_TRY(j->b_tlen.alloc((size_t)nr));
+            FZP_TRY(j->tbo_b.alloc((size_t)nr)); FZP_TRY(j->mvo_b.alloc((size_t)nr)); FZP_TRY(j->wout_b.alloc((size_t)nr));
+            if (j->b_iota.n < (size_t)nr) {
+                std::vector<int32_t> io((size_t)nr);
+                for (int64_t r = 0; r < nr; r++) io[(size_t)r] = (int32_t)r;
+                FZP_TRY(j->b_iota.upload(io.data(), (size_t)nr, st));
+            }
+            FZP_HIP(hipStreamSynchronize(st));      // the staging vectors die with this scope
         }
         // Trace-back masks live in HBM (16 B per DP step).  Reads go through in chunks: the DP of chunk k+1
         // (integer-VALU bound, every wave slot busy, no LDS) runs on `stream` while the trace-back of chunk k
@@ -2031,6 +2149,18 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
                 hipLaunchKernelGGL(k_pick_copy, dim3((unsigned)c2), dim3(256), 0, st, (int64_t)w_lo, j->ridx.p, j->won.p, j->read_len.p, j->sec_ori.p, j->sec_woff.p, j->read_woff.p, j->read_ori.p);
             }
             w_lo = w_hi;
+            const int64_t steps_b = j->h_tb_off_b[(size_t)last] - j->h_tb_off_b[(size_t)first];
+            FZP_TRY(j->tb_b2[bi].alloc((size_t)(steps_b + 64) * 2 + 128));
+            FZP_TRY(j->mvw_b2[bi].alloc((size_t)(steps_b / 64 + cnt + 2)));
+            FZP_TRY(j->raw_b2[bi].alloc((size_t)(steps_b / 16 + 64)));
+            {   // backward from the winner's anchor: reversed inputs, then the same DP kernel (slot = read; its "contig" is its own window)
+                ProfScope ps(ctx, "k1_back");
+                hipLaunchKernelGGL(k_back_prep, dim3((unsigned)cnt), dim3(256), 0, st, first, j->anc.p, j->read_ctg.p, j->read_ori.p, j->read_woff.p, j->ctg_pk.p, j->ctg_woff.p,
+                                   j->bq_off.p, j->bt_off.p, j->bq.p, j->bt.p, j->anc_b.p, j->b_len.p, j->b_tlen.p);
+                hipLaunchKernelGGL(k_sw<true>, dim3((unsigned)cnt), dim3(64), 0, st, first, cnt, (const int32_t *)nullptr, j->bq.p, j->bq_off.p, j->b_len.p, j->b_iota.p,
+                                   j->bt.p, j->bt_off.p, j->b_tlen.p, j->anc_b.p, j->tb_off_b.p, j->tb_b2[bi].p, j->mvw_b2[bi].p, P.match, P.mismatch, P.gap, j->info_b.p,
+                                   j->tbo_b.p, j->mvo_b.p, (const int32_t *)nullptr, 0);
+            }
             FZP_HIP(hipEventRecord(j->ev_sw[bi], st));
             FZP_HIP(hipStreamWaitEvent(st2, j->ev_sw[bi], 0));
             if (tb_serial) {
@@ -2069,6 +2199,15 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
                 hipLaunchKernelGGL(k_tb_walk<false>, dim3((unsigned)((cnt + TBW_RPW - 1) / TBW_RPW)), dim3(64), 0, st2, first, cnt, j->anc.p, j->info.p, j->tb_off.p,
                                    j->tbo.p, j->mvo.p, (const ulonglong2 *)j->tb2[bi].p, (const ulonglong2 *)j->mvw2[bi].p, j->raw2[bi].p, j->wout.p,
                                    (const int32_t *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr, (uint32_t *)nullptr, (SegOut *)nullptr, 1, 32, (const SegReq *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr);
+            }
+            {   // the backward parts: walked (one walker each: they are short), then joined to the forward streams
+                ProfScope ps(ctx, "k1_back_tb", st2);
+                hipLaunchKernelGGL(k_tb_walk<false>, dim3((unsigned)((cnt + TBW_RPW - 1) / TBW_RPW)), dim3(64), 0, st2, first, cnt, j->anc_b.p, j->info_b.p, j->tb_off_b.p,
+                                   j->tbo_b.p, j->mvo_b.p, (const ulonglong2 *)j->tb_b2[bi].p, (const ulonglong2 *)j->mvw_b2[bi].p, j->raw_b2[bi].p, j->wout_b.p,
+                                   (const int32_t *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr, (uint32_t *)nullptr, (SegOut *)nullptr, 0, 32,
+                                   (const SegReq *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr);
+                hipLaunchKernelGGL(k_back_merge, dim3((unsigned)cnt), dim3(64), 0, st2, first, cnt, j->tb_off.p, j->tb_off_b.p, j->anc_b.p, j->info_b.p, j->wout_b.p,
+                                   (const uint32_t *)j->raw_b2[bi].p, j->raw2[bi].p, j->wout.p, j->info.p);
             }
             {
                 ProfScope ps(ctx, "k1_cigar", st2);

@@ -133,7 +133,7 @@ typedef struct { int strand; int64_t i_a, c_a; } anchor_t;
 /* per-thread grow-only scratch for the per-read work arrays: hundreds of KB each, i.e. above malloc's mmap threshold -- 256 threads that
  * mmap / page-fault / munmap them for every read serialise on the process's address-space lock (measured on the 256-thread bench host:
  * 7.8 Mcell/s per thread against 97 single-threaded) */
-static __thread struct { void *p; size_t cap; } scratch_[8];
+static __thread struct { void *p; size_t cap; } scratch_[16];
 static void *scratch_get(int k, size_t bytes) {
     if (scratch_[k].cap < bytes) {
         free(scratch_[k].p);
@@ -143,7 +143,7 @@ static void *scratch_get(int k, size_t bytes) {
     return scratch_[k].p;
 }
 static void scratch_release(void) {
-    for (int k = 0; k < 8; k++) { free(scratch_[k].p); scratch_[k].p = NULL; scratch_[k].cap = 0; }
+    for (int k = 0; k < 16; k++) { free(scratch_[k].p); scratch_[k].p = NULL; scratch_[k].cap = 0; }
 }
 
 static int seed_candidates(const ctg_index *ix, const uint8_t *fwd, int64_t n, const orc_align_params *P, anchor_t *cand) {
@@ -215,33 +215,25 @@ static int seed_candidates(const ctg_index *ix, const uint8_t *fwd, int64_t n, c
         if (best_e < 0) continue;                      /* cannot happen: the window has votes */
         const hit_t *A = &hits[wh[st[best_e]]];
         if (getenv("ORC_ALIGN_DEBUG")) fprintf(stderr, "window %d: strand %d bin %lld votes %u/%u hits %lld chain %d anchor (%lld, %lld)\n", w, ws, (long long)wb, w ? w2 : w1, w1, (long long)m, best_f, (long long)A->i, (long long)A->cp);
-        /* the chain's first hit fixes the diagonal; the extension starts at the read's first base on that diagonal
-         * (or at the contig's first base when the read overhangs it) */
-        const int64_t d = A->cp - A->i;
+        /* v1.4: the chain's first hit IS the anchor -- a cell of the true path; the extension runs forward from it and backward from it */
         cand[n_cand].strand = ws;
-        cand[n_cand].i_a = d < 0 ? -d : 0;
-        cand[n_cand].c_a = d < 0 ? 0 : d;
+        cand[n_cand].i_a = A->i;
+        cand[n_cand].c_a = A->cp;
         n_cand++;
     }
     free(wh); free(f); free(st);
     return n_cand;
 }
 
-/* ---- adaptive banded extension of one candidate.  r = the oriented read codes. */
-static void extend_one(const ctg_index *ix, const uint8_t *r, int64_t n, const anchor_t *an, const orc_align_params *P,
-                       orc_aln_summary *out, u32vec *cig) {
-    memset(out, 0, sizeof *out);
-    const int64_t Lc = ix->len;
-    const int64_t i_a = an->i_a, c_a = an->c_a;
-    const int bs_ = an->strand;
-    const uint8_t *q = r + i_a;
-    const int64_t nq = n - i_a;
-    int64_t nt = Lc - c_a;
-    if (nt > nq + nq / 4 + 64) nt = nq + nq / 4 + 64;
-    const uint8_t *t = ix->codes + c_a;
+/* ---- the banded extension DP from the origin cell (-1, -1) of q[0..nq) x t[0..nt): fills the masks / moves of its scratch set `sb`
+ * (arrays sb, sb+1, sb+2), finds the best valid cell.  Used forward from the anchor and, on reversed sequences, backward from it. */
+typedef struct { int64_t steps; int32_t score; int64_t ts, lane; uint64_t *tbD, *tbU; uint8_t *mv; } dp_t;
+static dp_t dp_extend(const uint8_t *q, int64_t nq, const uint8_t *t, int64_t nt, const orc_align_params *P, int sb) {
+    dp_t R;
+    memset(&R, 0, sizeof R);
     const int64_t max_steps = nq + nt + 2;
-    uint64_t *tbD = (uint64_t *)scratch_get(0, (size_t)max_steps * 8), *tbU = (uint64_t *)scratch_get(1, (size_t)max_steps * 8);
-    uint8_t *mv = (uint8_t *)scratch_get(2, (size_t)max_steps);
+    uint64_t *tbD = (uint64_t *)scratch_get(sb, (size_t)max_steps * 8), *tbU = (uint64_t *)scratch_get(sb + 1, (size_t)max_steps * 8);
+    uint8_t *mv = (uint8_t *)scratch_get(sb + 2, (size_t)max_steps);
 #define QC(i) (((i) >= 0 && (i) < nq) ? q[i] : 4)
 #define TC(j) (((j) >= 0 && (j) < nt) ? t[j] : 5)
     int32_t Hp[W], X[W], H[W], bsc[W]; int64_t bt[W];
@@ -294,43 +286,105 @@ static void extend_one(const ctg_index *ix, const uint8_t *r, int64_t n, const a
         if ((tt - 1) - (i0 + 63) > nt - 1) break;
         if (tt >= max_steps) break;
     }
-    const int64_t steps = tt;
-    out->cells = steps * W;
+#undef QC
+#undef TC
+    R.steps = tt; R.tbD = tbD; R.tbU = tbU; R.mv = mv;
     /* best cell: max score, then earliest step, then lowest lane */
     int bk = -1;
     for (int kk = 0; kk < W; kk++) {
         if (bt[kk] < 0) continue;
         if (bk < 0 || bsc[kk] > bsc[bk] || (bsc[kk] == bsc[bk] && bt[kk] < bt[bk])) bk = kk;
     }
-    out->score = bk >= 0 ? bsc[bk] : NEG;      /* what the candidate selection compares; 0 or less = no alignment */
-    if (bk < 0 || bsc[bk] <= 0) goto done;
+    R.score = bk >= 0 ? bsc[bk] : NEG;
+    R.ts = bk >= 0 ? bt[bk] : -1; R.lane = bk;
+    return R;
+}
+/* walk the masks back from the DP's best cell: one byte per op, END first -- 0 column, 1 I (read base), 2 D (contig base).  *i_end, *j_end =
+ * the best cell; *i_stop, *j_stop = where the walk left the matrix (one of them is -1).  Scratch array `sb` holds i0 per step. */
+static int64_t dp_walk(const dp_t *R, int sb, uint8_t *ops, int64_t *i_end, int64_t *j_end, int64_t *i_stop, int64_t *j_stop) {
+    int64_t *i0s = (int64_t *)scratch_get(sb, (size_t)R->steps * 8);
+    int64_t cur = -33;
+    for (int64_t s2 = 0; s2 < R->steps; s2++) { cur += R->mv[s2]; i0s[s2] = cur; }
+    int64_t ts = R->ts;
+    int64_t i = i0s[ts] + R->lane, j = ts - i, n = 0;
+    *i_end = i; *j_end = j;
+    while (i >= 0 && j >= 0) {
+        int kk = (int)(i - i0s[ts]);
+        if ((R->tbD[ts] >> kk) & 1) { ops[n++] = 0; i--; j--; ts -= 2; }
+        else if ((((R->tbU[ts] >> kk) & 1) != 0) == (R->mv[ts] != 0)) { ops[n++] = 1; i--; ts -= 1; }   /* the cell above */
+        else { ops[n++] = 2; j--; ts -= 1; }
+    }
+    *i_stop = i; *j_stop = j;
+    return n;
+}
+
+/* ---- extension of one candidate (v1.4): forward from the anchor hit to the best cell, backward from it (the same DP on the reversed read prefix and
+ * contig window) to ITS best cell; the two walks and the gap moves their ends imply at the anchor's corner make one path.  r = the oriented read codes. */
+static void extend_one(const ctg_index *ix, const uint8_t *r, int64_t n, const anchor_t *an, const orc_align_params *P,
+                       orc_aln_summary *out, u32vec *cig, int32_t *sel_score) {
+    memset(out, 0, sizeof *out);
+    const int64_t Lc = ix->len;
+    const int64_t i_a = an->i_a, c_a = an->c_a;
+    const int bs_ = an->strand;
+    const uint8_t *q = r + i_a;
+    const int64_t nq = n - i_a;
+    int64_t nt = Lc - c_a;
+    if (nt > nq + nq / 4 + 64) nt = nq + nq / 4 + 64;
+    const uint8_t *t = ix->codes + c_a;
+    const dp_t F = dp_extend(q, nq, t, nt, P, 0);
+    out->cells = F.steps * W;
+    out->score = F.score;                       /* 0 or less = no alignment */
+    *sel_score = F.score;                       /* what the candidate selection compares: the FORWARD extension's score */
+    if (F.lane < 0 || F.score <= 0) return;
+    /* path ops, END first: forward walk, the gap moves its exit implies, the backward part from the anchor out */
+    uint8_t *ops = (uint8_t *)scratch_get(12, (size_t)(2 * n + 2 * (nt + 64) + 2 * (i_a + i_a / 4 + 128) + 64));
+    int64_t i_end, j_end, is, js;
+    int64_t L = dp_walk(&F, 3, ops, &i_end, &j_end, &is, &js);
+    for (int64_t x = 0; x <= js && is < 0; x++) ops[L++] = 2;     /* left through row -1: the contig bases 0..js were skipped */
+    for (int64_t x = 0; x <= is && js < 0; x++) ops[L++] = 1;     /* left through column -1 */
+    const int64_t L_fwd = L;
+    int32_t score_b = 0;
+    if (i_a > 0 && c_a > 0) {
+        const int64_t nqb = i_a;
+        int64_t ntb = c_a;
+        if (ntb > nqb + nqb / 4 + 64) ntb = nqb + nqb / 4 + 64;
+        uint8_t *qb = (uint8_t *)scratch_get(13, (size_t)nqb), *tb = (uint8_t *)scratch_get(14, (size_t)ntb);
+        for (int64_t x = 0; x < nqb; x++) qb[x] = r[i_a - 1 - x];
+        for (int64_t x = 0; x < ntb; x++) tb[x] = ix->codes[c_a - 1 - x];
+        const dp_t B = dp_extend(qb, nqb, tb, ntb, P, 8);
+        out->cells += B.steps * W;
+        if (B.lane >= 0 && B.score > 0) {
+            score_b = B.score;
+            uint8_t *ob = (uint8_t *)scratch_get(15, (size_t)(nqb + ntb + 64));
+            int64_t bie, bje, bis, bjs;
+            const int64_t nb = dp_walk(&B, 11, ob, &bie, &bje, &bis, &bjs);
+            for (int64_t x = 0; x <= bjs && bis < 0; x++) ops[L++] = 2;      /* next to the anchor, as above */
+            for (int64_t x = 0; x <= bis && bjs < 0; x++) ops[L++] = 1;
+            for (int64_t x = nb - 1; x >= 0; x--) ops[L++] = ob[x];         /* the walk came from the far end towards the anchor: turned round */
+        }
+    }
+    (void)L_fwd;
+    out->score = F.score + score_b;
     {
-        /* i0 at every step: replay the moves */
-        int64_t *i0s = (int64_t *)scratch_get(3, (size_t)steps * 8);
-        int64_t cur = -33;
-        for (int64_t s2 = 0; s2 < steps; s2++) { cur += mv[s2]; i0s[s2] = cur; }
-        int64_t ts = bt[bk];
-        int64_t i = i0s[ts] + bk, j = ts - i;
-        const int64_t i_end = i, j_end = j;
-        /* reversed raw op stream, run-length encoded on the fly: op codes 7 '=', 8 'X', 1 'I', 2 'D' */
+        /* op by op from the END: cell (i, j) relative to the forward anchor (negative in the backward part), best start, run-length encoding */
+        int64_t i = i_end, j = j_end;
         u32vec rev = {0};
         int cur_op = -1; uint32_t cur_len = 0; int32_t ncol = 0, n_eq = 0;
         /* v1.3 "best start": S = score of the ops walked so far (from the alignment's end); the alignment starts at the op where S is
          * largest (the first such op met, i.e. the shortest alignment among ties -- it is a match column), everything walked after it is
-         * soft-clipped: a head that was forced along the origin's diagonal (noisy first bases, an indel before the first seed) goes */
+         * soft-clipped: a head that was forced along a wrong diagonal goes */
         int64_t S = 0, bestS = 0;
         int64_t snap_n = -1, snap_i = 0, snap_j = 0; int snap_op = -1; uint32_t snap_len = 0; int32_t snap_ncol = 0, snap_eq = 0;
-        while (i >= 0 && j >= 0) {
-            int kk = (int)(i - i0s[ts]);
+        for (int64_t x = 0; x < L; x++) {
             int op;
-            if ((tbD[ts] >> kk) & 1) { op = q[i] == t[j] ? 7 : 8; n_eq += op == 7; S += op == 7 ? P->match : -P->mismatch; i--; j--; ts -= 2; ncol++; }
-            else if ((((tbU[ts] >> kk) & 1) != 0) == (mv[ts] != 0)) { op = 1; S -= P->gap; i--; ts -= 1; }   /* the cell above */
-            else { op = 2; S -= P->gap; j--; ts -= 1; }
+            if (ops[x] == 0) { op = r[i_a + i] == ix->codes[c_a + j] ? 7 : 8; n_eq += op == 7; S += op == 7 ? P->match : -P->mismatch; i--; j--; ncol++; }
+            else if (ops[x] == 1) { op = 1; S -= P->gap; i--; }
+            else { op = 2; S -= P->gap; j--; }
             if (op == cur_op) cur_len++;
             else { if (cur_len) push(&rev, (cur_len << 4) | (uint32_t)cur_op); cur_op = op; cur_len = 1; }
             if (S > bestS) { bestS = S; snap_n = rev.n; snap_i = i; snap_j = j; snap_op = cur_op; snap_len = cur_len; snap_ncol = ncol; snap_eq = n_eq; }
         }
-        if (snap_n < 0) { free(rev.v); goto done; }                   /* cannot happen: the whole path scores bsc[bk] > 0 */
+        if (snap_n < 0) { free(rev.v); return; }                      /* cannot happen: the forward path alone scores F.score > 0 */
         rev.n = snap_n; i = snap_i; j = snap_j; cur_op = snap_op; cur_len = snap_len; ncol = snap_ncol; n_eq = snap_eq;
         if (cur_len) push(&rev, (cur_len << 4) | (uint32_t)cur_op);
         {   /* the device derives the match count from the score of the kept ops (it only sees the bases while scoring them): both must agree */
@@ -340,7 +394,7 @@ static void extend_one(const ctg_index *ix, const uint8_t *r, int64_t n, const a
                 abort();
             }
         }
-        int64_t q_lead = i + 1, r_lead = j + 1;        /* bases before the first path op */
+        int64_t q_lead = i + 1, r_lead = j + 1;        /* bases before the first path op, relative to the anchor (negative when the path reaches back) */
         /* forward order; strip leading / trailing non-match ops */
         int64_t a = rev.n - 1, b = 0;                   /* forward index f = rev[a - f] */
         while (a >= b && ((rev.v[a] & 15) == 1 || (rev.v[a] & 15) == 2)) {
@@ -385,10 +439,6 @@ static void extend_one(const ctg_index *ix, const uint8_t *r, int64_t n, const a
         }
         free(rev.v);
     }
-done:
-    ;
-#undef QC
-#undef TC
 }
 
 /* One read: candidates, extension of each, best extension score wins. */
@@ -405,13 +455,14 @@ static void align_one(const ctg_index *ix, const uint8_t *fwd, int64_t n, const 
     for (int64_t i = 0; i < n; i++) { ori[0][i] = fwd[i]; ori[1][i] = (uint8_t)(3 - fwd[n - 1 - i]); }
     orc_aln_summary best; u32vec bcig = {0};
     memset(&best, 0, sizeof best);
-    int64_t cells = 0; int have = 0;
+    int64_t cells = 0; int have = 0; int32_t best_sel = NEG;
     for (int c = 0; c < nc; c++) {
         orc_aln_summary cur; u32vec ccig = {0};
-        extend_one(ix, ori[cand[c].strand], n, &cand[c], P, &cur, &ccig);
+        int32_t sel = NEG;
+        extend_one(ix, ori[cand[c].strand], n, &cand[c], P, &cur, &ccig, &sel);
         if (getenv("ORC_ALIGN_DEBUG")) fprintf(stderr, "cand %d: strand %d origin (%lld, %lld) -> score %d aligned %d pos %d q %d..%d\n", c, cand[c].strand, (long long)cand[c].i_a, (long long)cand[c].c_a, cur.score, cur.aligned, cur.pos, cur.q_start, cur.q_end);
         cells += cur.cells;
-        if (!have || cur.score > best.score) { free(bcig.v); best = cur; bcig = ccig; have = 1; }
+        if (!have || sel > best_sel) { free(bcig.v); best = cur; bcig = ccig; have = 1; best_sel = sel; }
         else free(ccig.v);
     }
     *out = best;

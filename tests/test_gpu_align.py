@@ -344,6 +344,21 @@ def _full_matrix_best(q, t, match=2, mismatch=4, gap=3):
     return best
 
 
+def _two_way_best(ori, ctg_codes, i_a, c_a):
+    """full-matrix optimum of the forward extension from the anchor (i_a, c_a) plus, when the anchor is inside both sequences, of the backward one
+    (the same DP on the reversed read prefix and contig window) if it is positive -- fzalign v1.4's extension score"""
+    L = len(ctg_codes)
+    q = ori[i_a:]
+    nt = min(L - c_a, len(q) + len(q) // 4 + 64)
+    tot = _full_matrix_best(q, ctg_codes[c_a:c_a + nt])
+    if i_a > 0 and c_a > 0:
+        ntb = min(c_a, i_a + i_a // 4 + 64)
+        b = _full_matrix_best(ori[:i_a][::-1], ctg_codes[c_a - ntb:c_a][::-1])
+        if b > 0:
+            tot += b
+    return tot
+
+
 def test_scores_equal_unbanded_dp_on_short_reads(eng, oracle):
     """Spec-independent check: for reads of ~2.5 kb the kernel's score must be the optimum of a plain
     full-matrix extension DP from the same origin -- the band never cut the best path, and twin and kernel do not share an
@@ -372,9 +387,7 @@ def test_scores_equal_unbanded_dp_on_short_reads(eng, oracle):
         assert cs >= int(s["score"][r])                     # the kept piece of the path scores at least what the whole path did
         hit = False
         for strand, i_a, c_a in oracle_lib.align_origins(oracle, ctg, raw[r]):
-            q = ori[i_a:]
-            nt = min(L - c_a, len(q) + len(q) // 4 + 64)
-            if strand == rd.strand and _full_matrix_best(q, hap0[c_a:c_a + nt]) == int(s["score"][r]):
+            if strand == rd.strand and _two_way_best(ori, hap0, i_a, c_a) == int(s["score"][r]):
                 hit = True
                 break
         assert hit, (r, s[r])
