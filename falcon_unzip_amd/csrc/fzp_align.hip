@@ -1259,8 +1259,8 @@ __global__ void __launch_bounds__(64) k_tb_cigar(int64_t first, int64_t count, c
             const int32_t si = scan_incl(ci), sj = scan_incl(cj);
             int32_t i = w.i_end - (base_i + si - ci), j = w.j_end - (base_j + sj - cj);       // the cell the word's first op leaves
             int64_t qlo = 0, tlo = 0;
-            const uint64_t qw = (ci && i >= 0) ? window(qpk, (int64_t)a.i_a + i, qlo) : 0ull;
-            const uint64_t tw = (cj && j >= 0) ? window(tpk, (int64_t)a.c_a + j, tlo) : 0ull;
+            const uint64_t qw = (ci && (int64_t)a.i_a + i >= 0) ? window(qpk, (int64_t)a.i_a + i, qlo) : 0ull;     // (i, j are relative to the anchor: negative in the backward part)
+            const uint64_t tw = (cj && (int64_t)a.c_a + j >= 0) ? window(tpk, (int64_t)a.c_a + j, tlo) : 0ull;
             int32_t sl = 0, bl = 0, bp = -1;
             bool have_b = false;
 #pragma unroll

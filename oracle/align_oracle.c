@@ -321,7 +321,7 @@ static int64_t dp_walk(const dp_t *R, int sb, uint8_t *ops, int64_t *i_end, int6
 /* ---- extension of one candidate (v1.4): forward from the anchor hit to the best cell, backward from it (the same DP on the reversed read prefix and
  * contig window) to ITS best cell; the two walks and the gap moves their ends imply at the anchor's corner make one path.  r = the oriented read codes. */
 static void extend_one(const ctg_index *ix, const uint8_t *r, int64_t n, const anchor_t *an, const orc_align_params *P,
-                       orc_aln_summary *out, u32vec *cig, int32_t *sel_score) {
+                       orc_aln_summary *out, u32vec *cig, int32_t *sel_score, int64_t *fwd_cells) {
     memset(out, 0, sizeof *out);
     const int64_t Lc = ix->len;
     const int64_t i_a = an->i_a, c_a = an->c_a;
@@ -333,6 +333,7 @@ static void extend_one(const ctg_index *ix, const uint8_t *r, int64_t n, const a
     const uint8_t *t = ix->codes + c_a;
     const dp_t F = dp_extend(q, nq, t, nt, P, 0);
     out->cells = F.steps * W;
+    *fwd_cells = F.steps * W;
     out->score = F.score;                       /* 0 or less = no alignment */
     *sel_score = F.score;                       /* what the candidate selection compares: the FORWARD extension's score */
     if (F.lane < 0 || F.score <= 0) return;
@@ -453,23 +454,26 @@ static void align_one(const ctg_index *ix, const uint8_t *fwd, int64_t n, const 
     uint8_t *ori[2];
     ori[0] = (uint8_t *)scratch_get(4, (size_t)n); ori[1] = (uint8_t *)scratch_get(5, (size_t)n);
     for (int64_t i = 0; i < n; i++) { ori[0][i] = fwd[i]; ori[1][i] = (uint8_t)(3 - fwd[n - 1 - i]); }
-    orc_aln_summary best; u32vec bcig = {0};
-    memset(&best, 0, sizeof best);
-    int64_t cells = 0; int have = 0; int32_t best_sel = NEG;
+    /* every candidate's FORWARD extension decides the selection (blasr --bestn 1); only the winner is extended backward and traced */
+    int64_t fwd_cells = 0; int win = 0; int32_t best_sel = NEG;
     for (int c = 0; c < nc; c++) {
-        orc_aln_summary cur; u32vec ccig = {0};
-        int32_t sel = NEG;
-        extend_one(ix, ori[cand[c].strand], n, &cand[c], P, &cur, &ccig, &sel);
-        if (getenv("ORC_ALIGN_DEBUG")) fprintf(stderr, "cand %d: strand %d origin (%lld, %lld) -> score %d aligned %d pos %d q %d..%d\n", c, cand[c].strand, (long long)cand[c].i_a, (long long)cand[c].c_a, cur.score, cur.aligned, cur.pos, cur.q_start, cur.q_end);
-        cells += cur.cells;
-        if (!have || sel > best_sel) { free(bcig.v); best = cur; bcig = ccig; have = 1; best_sel = sel; }
-        else free(ccig.v);
+        const uint8_t *r = ori[cand[c].strand];
+        const int64_t nq = n - cand[c].i_a;
+        int64_t nt = ix->len - cand[c].c_a;
+        if (nt > nq + nq / 4 + 64) nt = nq + nq / 4 + 64;
+        const dp_t F = dp_extend(r + cand[c].i_a, nq, ix->codes + cand[c].c_a, nt, P, 0);
+        fwd_cells += F.steps * W;
+        if (getenv("ORC_ALIGN_DEBUG")) fprintf(stderr, "cand %d: strand %d anchor (%lld, %lld) -> forward score %d\n", c, cand[c].strand, (long long)cand[c].i_a, (long long)cand[c].c_a, F.score);
+        if (c == 0 || F.score > best_sel) { best_sel = F.score; win = c; }
     }
-    *out = best;
-    out->cells = cells;
+    int32_t sel = NEG;
+    int64_t win_fwd = 0;
+    u32vec wcig = {0};
+    extend_one(ix, ori[cand[win].strand], n, &cand[win], P, out, &wcig, &sel, &win_fwd);
+    out->cells += fwd_cells - win_fwd;          /* cells: the forward DP of every candidate + the winner's backward DP */
     if (!out->aligned) { out->score = 0; out->strand = 0; }
-    else for (int64_t x = 0; x < bcig.n; x++) push(cig, bcig.v[x]);
-    free(bcig.v);
+    else for (int64_t x = 0; x < wcig.n; x++) push(cig, wcig.v[x]);
+    free(wcig.v);
 }
 
 void orc_align_params_default(orc_align_params *p) {
