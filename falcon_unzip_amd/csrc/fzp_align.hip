@@ -1093,22 +1093,21 @@ __global__ void __launch_bounds__(64) k_tb_walk(int64_t first, int64_t count, co
 __global__ void k_tb_req_reset(uint32_t *counters) { if (threadIdx.x == 0) counters[1] = 0u; }
 
 // ---- trace-back, part 1b: one wave per read joins its segments' walks (k_tb_walk<true>) into the read's op stream.
-// pass 1: every read.  A boundary whose two walkers share no cell inside the overlap asks for a repair walk of the lower segment from the
-// cell the upper walker stopped in (if the upper walker is known to be on the path there); the read waits (ok = 3).  pass 3, after a repair
-// launch: the waiting reads again, asking again where needed.  pass 2, after the last repair launch: the waiting reads; what still does not join
-// is left to the serial walk (ok = 2).
+// First pass (bit 0 of `pass`): every read.  While repair launches are still to come (bit 1), a boundary whose two walkers share no cell inside the
+// overlap asks for a repair walk of the lower segment from the cell the upper walker stopped in (if the upper walker is known to be on the path there)
+// and the read waits (ok = 3); later passes take the waiting reads only.  In the last pass what still does not join is left to the serial walk (ok = 2).
 __global__ void __launch_bounds__(64) k_tb_stitch(int64_t first, int64_t count, const Anchor *__restrict__ anc, const DpInfo *__restrict__ info,
                                                   const int64_t *__restrict__ tb_off, const int32_t *__restrict__ seg_off, const uint32_t *__restrict__ trail,
                                                   const SegOut *__restrict__ segout, const uint32_t *__restrict__ raw_seg, uint32_t *__restrict__ raw,
                                                   WalkOut *__restrict__ wout, uint32_t *__restrict__ counters, SegReq *__restrict__ req, uint32_t req_cap, int pass,
-                                                  const uint8_t *__restrict__ seg_single) {
+                                                  const uint8_t *__restrict__ seg_single, int ov_limit) {
     __shared__ int32_t p_w[TBS_MAX_PIECES], p_a[TBS_MAX_PIECES], p_out[TBS_MAX_PIECES + 1];     // piece: walker, first op taken from it, first op of the output it fills
     const int lane = lane_id();
     const int64_t wv = blockIdx.x;
     if (wv >= count) return;
     const int64_t r = first + wv;
     if (seg_single[wv]) return;                       // one walker did the whole read and left the stream and the WalkOut itself
-    if (pass != 1 && wout[r].ok != 3) return;
+    if (!(pass & 1) && wout[r].ok != 3) return;        // pass bit 0: the first pass (every read); bit 1: boundaries that do not join may ask for a repair walk
     const Anchor a = anc[r];
     const DpInfo di = info[r];
     WalkOut o;
@@ -1143,7 +1142,7 @@ __global__ void __launch_bounds__(64) k_tb_stitch(int64_t first, int64_t count, 
         int32_t ia = -1, ib = -1;
         for (int d0 = 0; d0 < TBS_OV; d0 += 64) {
             const uint32_t ua = ta[d0 + lane], ub = hb[d0 + lane];
-            const uint64_t m = __ballot(ua != 0xffffffffu && ub != 0xffffffffu && (ua >> 31) == want31 && (ua & 0xffu) == (ub & 0xffu));
+            const uint64_t m = __ballot(d0 + lane < ov_limit && ua != 0xffffffffu && ub != 0xffffffffu && (ua >> 31) == want31 && (ua & 0xffu) == (ub & 0xffu));
             if (m) {
                 const int l = __builtin_ctzll(m);                                 // the first common cell below the boundary
                 ia = __builtin_amdgcn_readlane((int32_t)((ua >> 8) & 0x7fffffu), l); ib = __builtin_amdgcn_readlane((int32_t)((ub >> 8) & 0x7fffffu), l);
@@ -1157,7 +1156,7 @@ __global__ void __launch_bounds__(64) k_tb_stitch(int64_t first, int64_t count, 
         } else if (ia >= 0 && fail) {                                             // below an open boundary: the pieces are not built any more, but this one joins
             anchored = true;
         } else {                                                                  // no common cell inside TBS_OV steps (or one above where this walker joined the path)
-            if (pass != 2 && anchored && lane == 0) {
+            if ((pass & 2) && anchored && lane == 0) {
                 const uint32_t q = atomicAdd(&counters[1], 1u);
                 atomicAdd(&counters[2], 1u);
                 if (q < req_cap) { SegReq rq; rq.walker = w0 + sg - 1; rq.ts = so.ts; rq.k = so.k; rq.pad_ = 0; req[q] = rq; }
@@ -1165,7 +1164,7 @@ __global__ void __launch_bounds__(64) k_tb_stitch(int64_t first, int64_t count, 
             fail = true; anchored = false;
         }
     }
-    if (hard || (fail && pass == 2)) { o.ok = 2; if (lane == 0) { wout[r] = o; atomicAdd(&counters[0], 1u); } return; }    // k_tb_walk<false> walks this read serially
+    if (hard || (fail && !(pass & 2))) { o.ok = 2; if (lane == 0) { wout[r] = o; atomicAdd(&counters[0], 1u); } return; }    // k_tb_walk<false> walks this read serially
     if (fail) { o.ok = 3; if (lane == 0) wout[r] = o; return; }                  // waits for the repair walks
     if (lane == 0) p_out[np] = outpos;
     __syncthreads();
@@ -2097,6 +2096,9 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
         const bool use_prio = getenv("FZP_SW_NO_PRIO") == nullptr;
         int guess_lane = -1;                                                    // -1: the lane k_sw recorded (best H of the segment's top step); tests push it to the band's edge to exercise the fallback
         if (const char *e = getenv("FZP_TB_GUESS_LANE")) { const int g = atoi(e); if (g >= 0 && g < 64) guess_lane = g; }
+        int ov_limit = TBS_OV, REPAIR_ROUNDS = 3;                               // test switches: a shorter search for the common cell (forces repair walks), fewer repair rounds (forces the serial walk)
+        if (const char *e = getenv("FZP_TB_OV_LIMIT")) { const int g = atoi(e); if (g >= 1 && g <= TBS_OV) ov_limit = g; }
+        if (const char *e = getenv("FZP_TB_REPAIR_ROUNDS")) { const int g = atoi(e); if (g >= 0 && g <= 8) REPAIR_ROUNDS = g; }
         const bool tb_serial = getenv("FZP_TB_SERIAL") != nullptr;             // FZP_TB_SERIAL=1: the r2 trace-back (one walker per read), for comparisons
         const bool no_masks = getenv("FZP_SW_NO_MASKS") != nullptr;          // MEASUREMENT ONLY: the DP without its trace-back stores; the alignments that follow are garbage
         int64_t sum_len = 0;
@@ -2182,11 +2184,10 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
                 const uint32_t req_cap = (uint32_t)std::min<int64_t>(nwk, 1 << 20);
                 FZP_TRY(j->seg_req.alloc((size_t)req_cap + 1));
                 FZP_HIP(hipMemsetAsync(j->tb_fallback.p + 1, 0, 4, st2));      // this chunk's repair requests
-                constexpr int REPAIR_ROUNDS = 3;
                 for (int round = 0; round <= REPAIR_ROUNDS; round++) {
                     hipLaunchKernelGGL(k_tb_stitch, dim3((unsigned)cnt), dim3(64), 0, st2, first, cnt, j->anc.p, j->info.p, j->tb_off.p, (const int32_t *)(j->seg_off.p + first),
                                        (const uint32_t *)j->trail2[bi].p, (const SegOut *)j->segout2[bi].p, (const uint32_t *)j->raw_seg2[bi].p, j->raw2[bi].p, j->wout.p, j->tb_fallback.p,
-                                       j->seg_req.p, req_cap, round == 0 ? 1 : (round == REPAIR_ROUNDS ? 2 : 3), (const uint8_t *)(j->seg_single.p + first));
+                                       j->seg_req.p, req_cap, (round == 0 ? 1 : 0) | (round < REPAIR_ROUNDS ? 2 : 0), (const uint8_t *)(j->seg_single.p + first), ov_limit);
                     if (round == REPAIR_ROUNDS) break;
                     // boundaries that did not join: their lower segments again, from the exact cell (a launch of empty waves when there are none)
                     hipLaunchKernelGGL(k_tb_walk<true>, dim3((unsigned)((std::min<int64_t>(req_cap, cnt) + TBW_RPW - 1) / TBW_RPW)), dim3(64), 0, st2, first, (int64_t)req_cap, j->anc.p, j->info.p,
@@ -2248,6 +2249,7 @@ extern "C" int fzp_align_tb_fallbacks(fzp_ctx *ctx, fzp_alnjob *j, int64_t *n) {
     FZP_TRY(fzp_bind(ctx));
     uint32_t v[4] = {0, 0, 0, 0};
     if (j->tb_fallback.p) { FZP_HIP(hipMemcpyAsync(v, j->tb_fallback.p, 16, hipMemcpyDeviceToHost, ctx->stream)); FZP_HIP(hipStreamSynchronize(ctx->stream)); }
+    if (getenv("FZP_TB_DEBUG")) fprintf(stderr, "[fzp_align_tb_fallbacks] counters %u %u %u %u\n", v[0], v[1], v[2], v[3]);
     n[0] = (int64_t)v[0];
     n[1] = (int64_t)v[2];
     return FZP_OK;

@@ -448,14 +448,17 @@ def test_launch_order_does_not_change_results(eng, monkeypatch):
 
 
 def test_segmented_traceback_equals_serial_walk(eng, monkeypatch):
-    """The trace-back walks a read as segments of 4 096 DP steps at once (speculative starts in the band's centre, stitched where neighbouring
-    walkers meet) -- the op stream must be the serial walk's (FZP_TB_SERIAL=1), also when the guesses are bad: FZP_TB_GUESS_LANE=1 starts the
-    walkers at the band's edge, where some do not meet their neighbour inside the overlap and the read falls back to the serial walk."""
+    """The trace-back walks a long read as segments of 4 096 DP steps at once (speculative starts, stitched where neighbouring walkers meet) -- the
+    op stream must be the serial walk's (FZP_TB_SERIAL=1), also when the machinery behind it has to work: FZP_TB_GUESS_LANE=1 starts the walkers at
+    the band's edge; FZP_TB_OV_LIMIT=2 lets neighbours meet only in the first two steps below a boundary, so nearly every boundary asks for a repair
+    walk; with FZP_TB_REPAIR_ROUNDS=0 on top, those reads end in the serial walk."""
     from falcon_unzip_amd import _lib
     n = 500
     ctg, blob, off, *_ = _shaped(49, 1_000_000, n)
     got = {}
-    for mode, env in (("segmented", {}), ("serial", {"FZP_TB_SERIAL": "1"}), ("edge_guess", {"FZP_TB_GUESS_LANE": "1"})):
+    modes = (("segmented", {}), ("serial", {"FZP_TB_SERIAL": "1"}), ("edge_guess", {"FZP_TB_GUESS_LANE": "1"}), ("repairs", {"FZP_TB_OV_LIMIT": "2"}),
+             ("fallback", {"FZP_TB_OV_LIMIT": "2", "FZP_TB_REPAIR_ROUNDS": "0"}))
+    for mode, env in modes:
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         job = _lib.align_job_raw(eng, [ctg], blob, off, np.zeros(n, np.int32))
@@ -465,12 +468,15 @@ def test_segmented_traceback_equals_serial_walk(eng, monkeypatch):
         job.close()
         for k in env:
             monkeypatch.delenv(k)
-    assert got["serial"][0]["aligned"].mean() > 0.99 and (np.diff(off) > 40000).sum() >= 3       # reads of a dozen and more segments are in
-    for mode in ("segmented", "edge_guess"):
+    n_long = int((np.diff(off) > 20000).sum())
+    assert got["serial"][0]["aligned"].mean() > 0.99 and (np.diff(off) > 40000).sum() >= 3 and n_long > 50     # reads of a dozen and more segments are in
+    for mode, _ in modes:
         assert np.array_equal(got[mode][0], got["serial"][0]), mode
         assert got[mode][1] == got["serial"][1], mode
-    # the recorded start lanes make the serial fallback rare; the edge guess makes it common (and still right)
-    assert got["segmented"][2][0] <= 0.01 * n and got["edge_guess"][2][1] > got["segmented"][2][1] and got["serial"][2] == (0, 0), [got[m][2] for m in got]
+    stats = {m: got[m][2] for m in got}
+    assert stats["serial"] == (0, 0) and stats["segmented"][0] == 0, stats
+    assert stats["repairs"][1] > n_long and stats["repairs"][0] <= stats["repairs"][1], stats          # boundaries were repaired, round after round
+    assert stats["fallback"][0] > 0.5 * n_long and stats["fallback"][1] == 0, stats                      # no repair launch: the flagged reads were walked serially
 
 
 def test_record_planning_at_deep_coverage(eng):
