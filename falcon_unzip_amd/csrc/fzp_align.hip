@@ -1770,7 +1770,7 @@ struct fzp_alnjob {
     DevBuf<ulonglong2> mvw_b2[2];
     DevBuf<WalkOut> wout_b;
     std::vector<int64_t> h_tb_off_b;
-    hipEvent_t ev_sw[2] = {nullptr, nullptr}, ev_tb[2] = {nullptr, nullptr};
+    hipEvent_t ev_sw[2] = {nullptr, nullptr}, ev_tb[2] = {nullptr, nullptr}, ev_bk[2] = {nullptr, nullptr};
     DevBuf<fzp_aln_summary> summ;
     bool done = false;
 };
@@ -1784,7 +1784,7 @@ extern "C" void fzp_align_params_default(fzp_align_params *p) {
 extern "C" void fzp_align_destroy(fzp_ctx *ctx, fzp_alnjob *job) {
     if (!job) return;
     if (ctx) { (void)fzp_bind(ctx); (void)hipStreamSynchronize(ctx->stream); (void)hipStreamSynchronize(ctx->stream2); }
-    for (int k = 0; k < 2; k++) { if (job->ev_sw[k]) (void)hipEventDestroy(job->ev_sw[k]); if (job->ev_tb[k]) (void)hipEventDestroy(job->ev_tb[k]); }
+    for (int k = 0; k < 2; k++) { if (job->ev_sw[k]) (void)hipEventDestroy(job->ev_sw[k]); if (job->ev_tb[k]) (void)hipEventDestroy(job->ev_tb[k]); if (job->ev_bk[k]) (void)hipEventDestroy(job->ev_bk[k]); }
     delete job;
 }
 
@@ -2043,7 +2043,7 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
         FZP_TRY(j->wout.alloc((size_t)nr));
         FZP_TRY(j->tb_fallback.alloc(4));
         FZP_TRY(j->tb_fallback.zero(4, st));
-        if (!j->ev_sw[0]) for (int k = 0; k < 2; k++) { FZP_HIP(hipEventCreateWithFlags(&j->ev_sw[k], hipEventDisableTiming)); FZP_HIP(hipEventCreateWithFlags(&j->ev_tb[k], hipEventDisableTiming)); }
+        if (!j->ev_sw[0]) for (int k = 0; k < 2; k++) { FZP_HIP(hipEventCreateWithFlags(&j->ev_sw[k], hipEventDisableTiming)); FZP_HIP(hipEventCreateWithFlags(&j->ev_tb[k], hipEventDisableTiming)); FZP_HIP(hipEventCreateWithFlags(&j->ev_bk[k], hipEventDisableTiming)); }
         hipStream_t st2 = ctx->stream2;
         if (j->lpt_chunk_steps != chunk_steps || split_rounds) {
             // launch order inside every chunk of reads: longest first (LPT over the wave slots).  One wave per read, workgroups dispatched in
@@ -2151,6 +2151,7 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
                 hipLaunchKernelGGL(k_pick_copy, dim3((unsigned)c2), dim3(256), 0, st, (int64_t)w_lo, j->ridx.p, j->won.p, j->read_len.p, j->sec_ori.p, j->sec_woff.p, j->read_woff.p, j->read_ori.p);
             }
             w_lo = w_hi;
+            FZP_HIP(hipEventRecord(j->ev_sw[bi], st));        // the forward extensions are final: their walk starts on the second stream while the backward ones run here
             const int64_t steps_b = j->h_tb_off_b[(size_t)last] - j->h_tb_off_b[(size_t)first];
             FZP_TRY(j->tb_b2[bi].alloc((size_t)(steps_b + 64) * 2 + 128));
             FZP_TRY(j->mvw_b2[bi].alloc((size_t)(steps_b / 64 + cnt + 2)));
@@ -2163,7 +2164,7 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
                                    j->bt.p, j->bt_off.p, j->b_tlen.p, j->anc_b.p, j->tb_off_b.p, j->tb_b2[bi].p, j->mvw_b2[bi].p, P.match, P.mismatch, P.gap, j->info_b.p,
                                    j->tbo_b.p, j->mvo_b.p, (const int32_t *)nullptr, 0);
             }
-            FZP_HIP(hipEventRecord(j->ev_sw[bi], st));
+            FZP_HIP(hipEventRecord(j->ev_bk[bi], st));
             FZP_HIP(hipStreamWaitEvent(st2, j->ev_sw[bi], 0));
             if (tb_serial) {
                 ProfScope ps(ctx, "k1_traceback", st2);
@@ -2201,6 +2202,7 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
                                    j->tbo.p, j->mvo.p, (const ulonglong2 *)j->tb2[bi].p, (const ulonglong2 *)j->mvw2[bi].p, j->raw2[bi].p, j->wout.p,
                                    (const int32_t *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr, (uint32_t *)nullptr, (SegOut *)nullptr, 1, 32, (const SegReq *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr);
             }
+            FZP_HIP(hipStreamWaitEvent(st2, j->ev_bk[bi], 0));
             {   // the backward parts: walked (one walker each: they are short), then joined to the forward streams
                 ProfScope ps(ctx, "k1_back_tb", st2);
                 hipLaunchKernelGGL(k_tb_walk<false>, dim3((unsigned)((cnt + TBW_RPW - 1) / TBW_RPW)), dim3(64), 0, st2, first, cnt, j->anc_b.p, j->info_b.p, j->tb_off_b.p,
