@@ -4,11 +4,12 @@
  * PARITY UNPINNED vs the reference: FALCON_unzip shells out to `blasr` (falcon_unzip/unzip.py:86-88),
  * a third-party C++ aligner that is not vendored under /root/reference and whose results
  * (placement, clipping, `--hitPolicy randombest --randomSeed 42` tie-breaks) cannot be reproduced
- * here.  This file therefore DEFINES the aligner ("fzalign v1.2"); the HIP kernels in
+ * here.  This file therefore DEFINES the aligner ("fzalign v1.4"); the HIP kernels in
  * falcon_unzip_amd/csrc/fzp_align.hip must match it bit-for-bit (summaries, CIGARs, DP cell counts),
  * and its quality is judged against the simulator's true alignments.
  *
- * fzalign v1.2  (v1.1: one index position per k-mer, one candidate placement per read, no identity gate)
+ * fzalign v1.4  (v1.1: one index position per k-mer, one candidate placement per read, no identity gate; v1.2: multi-position index, two
+ *               candidates, chains; v1.3: best-start soft clip; v1.4: anchor = the chain's first hit, extension forward AND backward from it)
  *   bases     A/a C/c G/g T/t -> 0..3, anything else -> 0
  *   index     canonical k-mers (k<=16, 2 bits/base, base m of a k-mer at bits 2m; canonical = the smaller of
  *             the k-mer and its reverse complement) of every 2nd contig position -> EVERY such position
@@ -29,17 +30,23 @@
  *             (hit order on the forward strand, reversed hit order on the other).  Chain length f(h) = 1 +
  *             max f(p) over the at most 64 preceding window hits p with 1 <= i_h - i_p <= 2048, cpos_p < cpos_h
  *             and |dv_h - dv_p| <= 16 + (i_h - i_p)/16 (ties: the closest p), else 1; start(h) = start(p) or
- *             h itself.  The longest chain (ties: the earliest end) gives the anchor = its first hit, which
- *             fixes the diagonal d = cpos - i; the extension starts at the read's first base on that
- *             diagonal: origin (max(0,-d), max(0,d)).  Candidates in order W1, W2.
- *   selection every candidate is extended (below); the one with the highest extension score wins (ties: the
- *             earlier candidate) -- blasr's --bestn 1.  `cells` counts the DP cells of all candidates.
+ *             h itself.  The longest chain (ties: the earliest end) gives the anchor = its first hit (i_h, c_h), a cell
+ *             of the true path.  Candidates in order W1, W2.
+ *   selection every candidate is extended FORWARD from its anchor (below); the one with the highest forward
+ *             extension score wins (ties: the earlier candidate) -- blasr's --bestn 1.  The winner is then
+ *             extended BACKWARD from its anchor: the same DP on the reversed read prefix [0, i_h) and the
+ *             reversed contig window of min(c_h, i_h + i_h/4 + 64) bases before c_h; if that scores more than 0
+ *             its path (to ITS best cell) is joined to the forward one at the anchor's corner, together with
+ *             the gap moves either walk's exit through row / column -1 implies.  `score` = forward + backward
+ *             score; `cells` counts the forward DP of all candidates and the winner's backward DP.
+ *   best start S(p) = score of the joined path's ops from its END up to op p; the alignment starts at the smallest p
+ *             with the largest S (a match column); what lies beyond is soft clip (v1.3).
  *   identity  n_match = (score + mismatch*columns + gap*(path insertions + path deletions)) / (match + mismatch)
  *             over the whole path from the origin (exact); the alignment is dropped (unaligned) when
  *             100*n_match < 70*(columns + inserted + deleted bases of the trimmed alignment)
  *             (blasr --minPctIdentity 70.0, unzip.py:87).
- *   extension adaptive anti-diagonal band of 64 cells (Suzuki-Kasahara style), forward from that
- *             origin: linear gaps, H = max(diag + (match | -mismatch), up - gap, left - gap), no zero
+ *   extension adaptive anti-diagonal band of 64 cells (Suzuki-Kasahara style) from the cell before the anchor
+ *             (origin (-1, -1) of the anchor-relative matrix): linear gaps, H = max(diag + (match | -mismatch), up - gap, left - gap), no zero
  *             floor; the first 64 steps alternate down/right, afterwards the band moves RIGHT when
  *             H[lane 0] > H[lane 63], else DOWN.  The diagonal operand is H of two steps ago in that
  *             step's own lane layout: the predecessor of lane k sits in lane k - 1 + (number of DOWN
