@@ -20,15 +20,22 @@ def kernel_key(name):
     return k.split("<")[0]
 
 
+BIGGEST = {}      # (counter, kernel) -> the largest single dispatch's value: k_sw is launched for the forward extensions (the dominant launch) AND the short backward ones
+
+
 def load(path, name):
     tot, calls, dur = collections.Counter(), collections.Counter(), collections.Counter()
+    per = collections.defaultdict(float)
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != name:
             continue
         k = kernel_key(r["Kernel_Name"])
         tot[k] += float(r["Counter_Value"])
+        per[(k, r.get("Dispatch_Id", r.get("Correlation_Id", "")))] += float(r["Counter_Value"])      # (a dispatch's value comes as one row per XCD / dimension)
         calls[k] += 1
         dur[k] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+    for (k, _), v in per.items():
+        BIGGEST[(name, k)] = max(BIGGEST.get((name, k), 0.0), v)
     return tot, calls, dur
 
 
@@ -47,7 +54,8 @@ def main():
     if len(sys.argv) > 4:
         for k, c, a, b, d, h in rows:
             if k == "k_sw":
-                json.dump({"kernel": "k_sw", "bytes_per_launch": h / c, "fetch_size_kb": a / c, "write_size_kb": b / c,
+                fa, wb = BIGGEST.get(("FETCH_SIZE", k), a / c), BIGGEST.get(("WRITE_SIZE", k), b / c)
+                json.dump({"kernel": "k_sw", "bytes_per_launch": (2 * fa + wb) * 1024, "fetch_size_kb": fa, "write_size_kb": wb, "launch": "the largest dispatch (forward extensions)",
                            "source": "%s (rocprofv3 --pmc, separate FETCH_SIZE and WRITE_SIZE passes; FETCH_SIZE x2 per the gfx950 correction)" % sys.argv[3]},
                           open(sys.argv[4], "w"), indent=1)
 

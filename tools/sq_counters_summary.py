@@ -21,13 +21,13 @@ def main():
     json.dump({k: dict(v, launches=calls[k]) for k, v in tot.items()}, open(sys.argv[2], "w"), indent=1)
     if len(sys.argv) > 4:
         line = json.load(open(sys.argv[3]))
-        steps = line["dp_cells_per_step"] / 64.0                     # band steps of one k_sw launch (first candidates; the second-candidate launch is part of the sum below)
+        # band steps of ONE bench step: forward extensions of all candidates + the backward extensions (fzp_aln_summary.cells counts them all); the counter pass
+        # ran exactly one step (bench.py --steps 1 --warmup 0), so the sums over every k_sw launch of the pass belong to these steps
+        steps = line["dp_cells_per_step"] / 64.0
         sw = tot["k_sw"]
-        n = max(1, calls["k_sw"])
-        per_launch = {c: sw[c] / n for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM")}
-        json.dump({"kernel": "k_sw", "band_steps_per_launch": steps, "valu_per_step": round(per_launch["SQ_INSTS_VALU"] / steps, 3),
-                   "salu_per_step": round(per_launch["SQ_INSTS_SALU"] / steps, 3), "smem_per_step": round(per_launch["SQ_INSTS_SMEM"] / steps, 3),
-                   "launches_counted": n, "source": sys.argv[5] if len(sys.argv) > 5 else sys.argv[2]}, open(sys.argv[4], "w"), indent=1)
+        json.dump({"kernel": "k_sw", "band_steps_per_bench_step": steps, "valu_per_step": round(sw["SQ_INSTS_VALU"] / steps, 3),
+                   "salu_per_step": round(sw["SQ_INSTS_SALU"] / steps, 3), "smem_per_step": round(sw["SQ_INSTS_SMEM"] / steps, 3),
+                   "launches_counted": calls["k_sw"], "source": sys.argv[5] if len(sys.argv) > 5 else sys.argv[2]}, open(sys.argv[4], "w"), indent=1)
 
 
 if __name__ == "__main__":
