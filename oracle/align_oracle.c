@@ -140,7 +140,7 @@ typedef struct { int strand; int64_t i_a, c_a; } anchor_t;
 /* per-thread grow-only scratch for the per-read work arrays: hundreds of KB each, i.e. above malloc's mmap threshold -- 256 threads that
  * mmap / page-fault / munmap them for every read serialise on the process's address-space lock (measured on the 256-thread bench host:
  * 7.8 Mcell/s per thread against 97 single-threaded) */
-static __thread struct { void *p; size_t cap; } scratch_[16];
+static __thread struct { void *p; size_t cap; } scratch_[24];
 static void *scratch_get(int k, size_t bytes) {
     if (scratch_[k].cap < bytes) {
         free(scratch_[k].p);
@@ -150,7 +150,7 @@ static void *scratch_get(int k, size_t bytes) {
     return scratch_[k].p;
 }
 static void scratch_release(void) {
-    for (int k = 0; k < 16; k++) { free(scratch_[k].p); scratch_[k].p = NULL; scratch_[k].cap = 0; }
+    for (int k = 0; k < 24; k++) { free(scratch_[k].p); scratch_[k].p = NULL; scratch_[k].cap = 0; }
 }
 
 static int seed_candidates(const ctg_index *ix, const uint8_t *fwd, int64_t n, const orc_align_params *P, anchor_t *cand) {
@@ -328,7 +328,7 @@ static int64_t dp_walk(const dp_t *R, int sb, uint8_t *ops, int64_t *i_end, int6
 /* ---- extension of one candidate (v1.4): forward from the anchor hit to the best cell, backward from it (the same DP on the reversed read prefix and
  * contig window) to ITS best cell; the two walks and the gap moves their ends imply at the anchor's corner make one path.  r = the oriented read codes. */
 static void extend_one(const ctg_index *ix, const uint8_t *r, int64_t n, const anchor_t *an, const orc_align_params *P,
-                       orc_aln_summary *out, u32vec *cig, int32_t *sel_score, int64_t *fwd_cells) {
+                       orc_aln_summary *out, u32vec *cig, int32_t *sel_score, int64_t *fwd_cells, const dp_t *Fpre) {
     memset(out, 0, sizeof *out);
     const int64_t Lc = ix->len;
     const int64_t i_a = an->i_a, c_a = an->c_a;
@@ -338,7 +338,7 @@ static void extend_one(const ctg_index *ix, const uint8_t *r, int64_t n, const a
     int64_t nt = Lc - c_a;
     if (nt > nq + nq / 4 + 64) nt = nq + nq / 4 + 64;
     const uint8_t *t = ix->codes + c_a;
-    const dp_t F = dp_extend(q, nq, t, nt, P, 0);
+    const dp_t F = Fpre ? *Fpre : dp_extend(q, nq, t, nt, P, 0);      /* the selection has run the winner's forward DP already: its masks are still in place */
     out->cells = F.steps * W;
     *fwd_cells = F.steps * W;
     out->score = F.score;                       /* 0 or less = no alignment */
@@ -463,20 +463,23 @@ static void align_one(const ctg_index *ix, const uint8_t *fwd, int64_t n, const 
     for (int64_t i = 0; i < n; i++) { ori[0][i] = fwd[i]; ori[1][i] = (uint8_t)(3 - fwd[n - 1 - i]); }
     /* every candidate's FORWARD extension decides the selection (blasr --bestn 1); only the winner is extended backward and traced */
     int64_t fwd_cells = 0; int win = 0; int32_t best_sel = NEG;
+    dp_t Fc[2];
+    static int dbg = -1;
+    if (dbg < 0) dbg = getenv("ORC_ALIGN_DEBUG") != NULL;
     for (int c = 0; c < nc; c++) {
         const uint8_t *r = ori[cand[c].strand];
         const int64_t nq = n - cand[c].i_a;
         int64_t nt = ix->len - cand[c].c_a;
         if (nt > nq + nq / 4 + 64) nt = nq + nq / 4 + 64;
-        const dp_t F = dp_extend(r + cand[c].i_a, nq, ix->codes + cand[c].c_a, nt, P, 0);
+        const dp_t F = Fc[c] = dp_extend(r + cand[c].i_a, nq, ix->codes + cand[c].c_a, nt, P, c ? 16 : 0);       /* own scratch set per candidate */
         fwd_cells += F.steps * W;
-        if (getenv("ORC_ALIGN_DEBUG")) fprintf(stderr, "cand %d: strand %d anchor (%lld, %lld) -> forward score %d\n", c, cand[c].strand, (long long)cand[c].i_a, (long long)cand[c].c_a, F.score);
+        if (dbg) fprintf(stderr, "cand %d: strand %d anchor (%lld, %lld) -> forward score %d\n", c, cand[c].strand, (long long)cand[c].i_a, (long long)cand[c].c_a, F.score);
         if (c == 0 || F.score > best_sel) { best_sel = F.score; win = c; }
     }
     int32_t sel = NEG;
     int64_t win_fwd = 0;
     u32vec wcig = {0};
-    extend_one(ix, ori[cand[win].strand], n, &cand[win], P, out, &wcig, &sel, &win_fwd);
+    extend_one(ix, ori[cand[win].strand], n, &cand[win], P, out, &wcig, &sel, &win_fwd, &Fc[win]);
     out->cells += fwd_cells - win_fwd;          /* cells: the forward DP of every candidate + the winner's backward DP */
     if (!out->aligned) { out->score = 0; out->strand = 0; }
     else for (int64_t x = 0; x < wcig.n; x++) push(cig, wcig.v[x]);
