@@ -589,7 +589,7 @@ __device__ __forceinline__ void scalar_store16(void *base, uint32_t byte_off, ui
         bool upd = Hn > bs;                                                                                \
         {                                                                                                  \
             const int32_t ci = i0 + lane, cj = t - ci;                                                     \
-            upd = upd && ci >= 0 && ci < nq && cj >= 0 && cj < nt;                                         \
+            upd = upd && ci >= 0 && ci < nq && cj >= 0 && cj < nt && (ci == nq - 1 || cj == nt - 1);       \
         }                                                                                                  \
         bs = upd ? Hn : bs;                                                                                \
         bt = upd ? t : bt;                                                                                 \
@@ -623,17 +623,13 @@ __device__ __forceinline__ void scalar_store16(void *base, uint32_t byte_off, ui
 
 // ---- interior block: up to 32 steps with every lane strictly inside the matrix, hand-scheduled.
 // The block is VALU-issue bound (a SIMD issues one wave64 VALU op per 4 cycles), so the point is the VALU count
-// per step: 12.5 (the best-cell key takes the last two steps' H in one v_max3 every other step), with 9 SALU and one scalar-memory op riding along on their own ports.
+// per step: 12 (v1.5: an interior block holds no border cell, so nothing of it can be the extension's terminal and it keeps no best-cell key), with 9 SALU and one scalar-memory op riding along on their own ports.
 //   * H of two steps ago is never copied or shifted: the two registers swap roles every step (hence two code
 //     parities) and the diagonal's lane shift rides on the add (hence a variant per pair of moves): 8 step variants;
 //   * the two trace-back masks of a step are the 64-bit results of v_cmp_e64 landing in an SGPR quad that
 //     goes out with one s_store_dwordx4 (16 B per step, step-major) -- no per-lane bit accumulators;
 //   * bases entering the band come from two 64-bit SGPR windows (32 bases each, enough for a whole block):
 //     s_bfe_u64 picks the next one, v_writelane drops it into lane 63 (DOWN) / lane 0 (RIGHT);
-//   * scores run scaled by 64 with the block's step countdown riding in the low bits -- Hs = (H << 6) + cnt --
-//     which makes "best cell of the block, earliest step first" a single v_max per step.  Offsets stay
-//     consistent because every value of a step carries the same one: a gap move costs (gap << 6) + 1 (one step
-//     later), a diagonal move adds (s << 6) - 2 (two steps later); equality tests are unaffected.
 //   * moves are collected in a 32-bit shift register (first step of the block ends up in the highest used bit); its bit 0 is the block's last
 //     move, so the steps do not keep a "previous move" register up to date (one SALU less per step: the scalar port has no slack).
 // The store offset is the step counter: it enters 16 * steps below 2^31 and the signed overflow of its increment ends the block.
@@ -710,12 +706,11 @@ __device__ __forceinline__ void scalar_store16(void *base, uint32_t byte_off, ui
         SWB_DOWN("p0RD", "%[H]", "%[X]", "v_add_u32_e32 %[hd], %[X], %[sc]", "1", "", ST)                                                                                           \
         SWB_RIGHT("p0DR", "%[H]", "%[X]", "v_add_u32_e32 %[hd], %[X], %[sc]", "1", "", ST)                                                                                          \
         SWB_RIGHT("p0RR", "%[H]", "%[X]", "v_add_u32_dpp %[hd], %[X], %[sc]" SWB_DPP_SHR, "1", "", ST)                                                                              \
-        SWB_DOWN("p1DD", "%[X]", "%[H]", "v_add_u32_dpp %[hd], %[H], %[sc]" SWB_DPP_SHL, "0", "v_max3_i32 %[kb], %[kb], %[X], %[H]\n\t", ST)                                        \
-        SWB_DOWN("p1RD", "%[X]", "%[H]", "v_add_u32_e32 %[hd], %[H], %[sc]", "0", "v_max3_i32 %[kb], %[kb], %[X], %[H]\n\t", ST)                                                    \
-        SWB_RIGHT("p1DR", "%[X]", "%[H]", "v_add_u32_e32 %[hd], %[H], %[sc]", "0", "v_max3_i32 %[kb], %[kb], %[X], %[H]\n\t", ST)                                                   \
-        SWB_RIGHT("p1RR", "%[X]", "%[H]", "v_add_u32_dpp %[hd], %[H], %[sc]" SWB_DPP_SHR, "0", "v_max3_i32 %[kb], %[kb], %[X], %[H]\n\t", ST)                                       \
+        SWB_DOWN("p1DD", "%[X]", "%[H]", "v_add_u32_dpp %[hd], %[H], %[sc]" SWB_DPP_SHL, "0", "", ST)                                        \
+        SWB_DOWN("p1RD", "%[X]", "%[H]", "v_add_u32_e32 %[hd], %[H], %[sc]", "0", "", ST)                                                    \
+        SWB_RIGHT("p1DR", "%[X]", "%[H]", "v_add_u32_e32 %[hd], %[H], %[sc]", "0", "", ST)                                                   \
+        SWB_RIGHT("p1RR", "%[X]", "%[H]", "v_add_u32_dpp %[hd], %[H], %[sc]" SWB_DPP_SHR, "0", "", ST)                                       \
         "Lsw%=_end1:\n\t"                                                                                                                                                           \
-        "v_max_i32_e32 %[kb], %[kb], %[X]\n\t"                                                                                                                                      \
         "v_swap_b32 %[H], %[X]\n"                                                                                                                                                   \
         "Lsw%=_end0:\n\t"                                                                                                                                                           \
         "s_cmp_gt_i32 %[top], %[bot]\n\t"                                                                                                                                           \
@@ -819,8 +814,8 @@ __global__ void __launch_bounds__(64) k_sw(int64_t first, int64_t count, const i
         if (safe > 0) {
             // ---- interior: asm blocks of <= 32 steps
             int32_t qpos_i = i0 + 64, tpos_i = t - i0;                 // next bases to enter at lane 63 / lane 0
-            const int32_t vmatS = (match << 6) - 2, vmisS = -(mismatch << 6) - 2;
-            const int32_t gapS = __builtin_amdgcn_readfirstlane((gap << 6) + 1);
+            const int32_t vmatS = match, vmisS = -mismatch;
+            const int32_t gapS = __builtin_amdgcn_readfirstlane(gap);
             int32_t dn = down ? 1 : 0;
             int32_t pm = pdown ? 1 : 0;
             while (safe > 0) {
@@ -833,21 +828,12 @@ __global__ void __launch_bounds__(64) k_sw(int64_t first, int64_t count, const i
                 int32_t kb = 0;
                 dn = __builtin_amdgcn_readfirstlane(dn);
                 pm = __builtin_amdgcn_readfirstlane(pm);
-                H = (H << 6) + n_steps;                                  // previous step: countdown n_steps
-                X = (X << 6) + n_steps + 1;                              // the one before
                 // the store offset doubles as the block's step counter: it starts 16 * n_steps below 2^31 (the base pointer makes up for
                 // it), and the add that would carry it past 2^31 -- the signed overflow of s_addk_i32 -- ends the block
                 uint32_t soff = 0x80000000u - 16u * (uint32_t)n_steps;
                 void *tbp = (void *)((char *)tbr + ((int64_t)__builtin_amdgcn_readfirstlane(t) * 16 - (int64_t)soff));
                 sw_block<STORE>(H, X, qc, tc, qbits, tbits, kb, tbp, soff, mv, dn, pm, gapS, vmatS, vmisS);
-                H >>= 6;                                                 // the last step's countdown is 0, X's is 1
-                X >>= 6;
-                {   // fold the block's best cell into the running best (strictly greater: the earliest step wins ties)
-                    const int32_t hb = kb >> 6;
-                    const bool upd = hb > bs;
-                    bs = upd ? hb : bs;
-                    bt = upd ? t + (n_steps - 1 - (kb & 63)) : bt;
-                }
+                // (v1.5: no cell of an interior block is a border cell, so the block has no terminal candidates to report)
                 pm = (int32_t)(mv & 1u);                                 // the block's last move (the steps no longer keep it up to date)
                 const int32_t nd = __popc(mv);                          // DOWN moves of the block (mv holds exactly n_steps bits)
                 i0 = __builtin_amdgcn_readfirstlane(i0 + nd);
@@ -944,7 +930,7 @@ __global__ void __launch_bounds__(64) k_tb_walk(int64_t first, int64_t count, co
     Anchor a = {0, 0, 0, 0};
     DpInfo di = {0, -1, 0, NEGV};
     if (have) { a = anc[r]; di = info[r]; }
-    bool active = have && a.aligned && di.best_t >= 0 && di.best_score > 0;
+    bool active = have && a.aligned && di.best_t >= 0;
     const int32_t seg_top = single ? 0 : di.best_t >> TBS_SEG_SHIFT;
     if (SEGMENTED) active = active && seg <= seg_top;
     const int64_t soff = tb_off[r] - tb_off[first];                           // steps before this read in the chunk of reads
@@ -1112,7 +1098,7 @@ __global__ void __launch_bounds__(64) k_tb_stitch(int64_t first, int64_t count, 
     const DpInfo di = info[r];
     WalkOut o;
     memset(&o, 0, sizeof o);
-    if (!(a.aligned && di.best_t >= 0 && di.best_score > 0)) { if (lane == 0) wout[r] = o; return; }
+    if (!(a.aligned && di.best_t >= 0)) { if (lane == 0) wout[r] = o; return; }
     const int32_t S = di.best_t >> TBS_SEG_SHIFT;
     const int32_t w0 = seg_off[wv];
     const SegOut top = segout[w0 + S];
@@ -1204,7 +1190,7 @@ __global__ void __launch_bounds__(64) k_tb_stitch(int64_t first, int64_t count, 
 // it (which knows where it ends); suffix scans over the lanes give each word the number of starts and the lowest
 // start above it.
 __global__ void __launch_bounds__(64) k_tb_cigar(int64_t first, int64_t count, const int32_t *__restrict__ read_len, const Anchor *__restrict__ anc,
-                                                 const DpInfo *__restrict__ info, const int64_t *__restrict__ tb_off, const uint32_t *__restrict__ raw,
+                                                 const DpInfo *__restrict__ info, const int64_t *__restrict__ tb_off, uint32_t *__restrict__ raw,
                                                  const WalkOut *__restrict__ wout, const int64_t *__restrict__ cig_off, uint32_t *__restrict__ cig,
                                                  int64_t *__restrict__ cig_start, fzp_aln_summary *__restrict__ summ, int match, int mismatch, int gap,
                                                  int min_pct_identity, const uint32_t *__restrict__ read_ori, const int64_t *__restrict__ read_woff,
@@ -1222,7 +1208,7 @@ __global__ void __launch_bounds__(64) k_tb_cigar(int64_t first, int64_t count, c
     out.cells = (int64_t)di.steps * 64;
     if (lane == 0) cig_start[r] = cig_off[r];
     if (!w.ok) { if (lane == 0) summ[r] = out; return; }
-    const uint32_t *rg = raw + ((tb_off[r] - tb_off[first]) >> 4);
+    uint32_t *rg = raw + ((tb_off[r] - tb_off[first]) >> 4);    // (pass 0 drops the ops before the alignment's end from it)
     uint32_t *reg = cig + cig_off[r];                     // capacity n + 18 words: [0] leading clip, runs from [1]
     int32_t L = w.n_ops;
     int32_t nW = (L + 15) >> 4;
@@ -1231,10 +1217,12 @@ __global__ void __launch_bounds__(64) k_tb_cigar(int64_t first, int64_t count, c
         const int32_t nv = min(16, L - 16 * wi);
         return nv >= 16 ? EVEN : (nv <= 0 ? 0u : (((1u << (2 * nv)) - 1u) & EVEN));
     };
-    // pass 0 (fzalign v1.3, "best start"): S(p) = score of ops 0..p of the stream (p = 0 is the alignment's END); the alignment starts at the
-    // smallest p with the largest S -- a match column -- and what the walk found beyond it (a head that was dragged along the origin's
-    // diagonal: noisy first bases, an indel before the first seed) becomes soft clip.  A lane scores a word: its 16 ops consume at most 16
-    // read and 16 contig bases going down from the word's first cell, which exclusive scans of the words' consumption counts give.
+    // pass 0 (fzalign v1.5, "best sub-path"): P(k) = score of ops 0..k-1 of the stream (op 0 leaves the forward terminal, the last op reaches the backward
+    // one); the alignment is ops e..s with the largest P(s+1) - P(e) (ties: the smallest s, then the largest e) -- both ends are match columns -- and what the
+    // walks found outside it (a tail dragged to the matrix border through noise, a head likewise) becomes soft clip.  A lane scores a word: its 16 ops consume at
+    // most 16 read and 16 contig bases going down from the word's first cell, which exclusive scans of the words' consumption counts give.  Two sweeps over the
+    // word's ops: the first leaves its score, the lowest prefix inside it and which ops are matching columns; a min-scan over the lanes (and the chunks before)
+    // then gives every word the lowest prefix before it, and the second sweep finds its best (e, s).
     int32_t S_star = 0;
     {
         const uint32_t *qpk = read_ori + read_woff[r];
@@ -1249,7 +1237,8 @@ __global__ void __launch_bounds__(64) k_tb_cigar(int64_t first, int64_t count, c
             lo_idx = (w1 - 1) * 16;
             return ((uint64_t)pk[w1] << 32) | (w1 > 0 ? pk[w1 - 1] : 0u);
         };
-        int32_t base_S = 0, base_i = 0, base_j = 0, bestS = 0, bestP = -1;
+        int32_t base_S = 0, base_i = 0, base_j = 0, bestS = 0, bestP = -1, bestE = 0;
+        int32_t base_min = 0, base_min_pos = 0;                  // lowest prefix P(e) over the chunks so far (P(0) = 0 at e = 0), the largest such e
         for (int32_t wb = 0; wb < nW; wb += 64) {
             const int32_t wi = wb + lane;
             const uint32_t x = wi < nW ? rg[wi] : 0u, vm = wi < nW ? valid_mask(wi) : 0u;
@@ -1260,35 +1249,90 @@ __global__ void __launch_bounds__(64) k_tb_cigar(int64_t first, int64_t count, c
             int64_t qlo = 0, tlo = 0;
             const uint64_t qw = (ci && (int64_t)a.i_a + i >= 0) ? window(qpk, (int64_t)a.i_a + i, qlo) : 0ull;     // (i, j are relative to the anchor: negative in the backward part)
             const uint64_t tw = (cj && (int64_t)a.c_a + j >= 0) ? window(tpk, (int64_t)a.c_a + j, tlo) : 0ull;
-            int32_t sl = 0, bl = 0, bp = -1;
-            bool have_b = false;
+            int32_t sl = 0, lmin = 0x3fffffff, lpos = 0;
+            uint32_t eq = 0;                                       // even bit of op o: a matching column
 #pragma unroll
             for (int o = 0; o < 16; o++) {
                 if ((vm >> (2 * o)) & 1u) {
+                    if (sl <= lmin) { lmin = sl; lpos = o; }       // prefix BEFORE op o ('<=': the largest e)
                     const uint32_t op = (x >> (2 * o)) & 3u;
                     if (op == 0u) {
                         const uint32_t qb_ = (uint32_t)(qw >> (2 * (uint32_t)((int64_t)a.i_a + i - qlo))) & 3u, tb_ = (uint32_t)(tw >> (2 * (uint32_t)((int64_t)a.c_a + j - tlo))) & 3u;
-                        sl += qb_ == tb_ ? match : -mismatch;
+                        if (qb_ == tb_) { sl += match; eq |= 1u << (2 * o); } else sl -= mismatch;
                         i--; j--;
                     } else { sl -= gap; if (op == 1u) i--; else j--; }
-                    if (!have_b || sl > bl) { bl = sl; bp = o; have_b = true; }
                 }
             }
             const int32_t ss = scan_incl(sl);
-            const int32_t cand = base_S + ss - sl + bl;
-            if (have_b && cand > bestS) { bestS = cand; bestP = 16 * wi + bp; }      // words ascend within a lane: '>' keeps the smallest p
+            const int32_t start = base_S + ss - sl;                // P(16 * wi)
+            // lowest prefix over the words up to and including this one: (value, position), later positions win ties
+            int32_t mv_ = vm ? start + lmin : 0x3fffffff, mp_ = 16 * wi + lpos;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int32_t ov_ = __shfl_up(mv_, d, 64), op_ = __shfl_up(mp_, d, 64);
+                if (lane >= d && ov_ < mv_) { mv_ = ov_; mp_ = op_; }
+            }
+            int32_t gm = __shfl_up(mv_, 1, 64), gp = __shfl_up(mp_, 1, 64);      // ... before this word
+            if (lane == 0 || base_min < gm) { gm = base_min; gp = base_min_pos; }      // (the chunks before hold earlier positions: they win only when strictly lower)
+            {
+                int32_t Pk = start;
+#pragma unroll
+                for (int o = 0; o < 16; o++) {
+                    if ((vm >> (2 * o)) & 1u) {
+                        if (Pk <= gm) { gm = Pk; gp = 16 * wi + o; }
+                        const uint32_t op = (x >> (2 * o)) & 3u;
+                        Pk += op == 0u ? (((eq >> (2 * o)) & 1u) ? match : -mismatch) : -gap;
+                        if (Pk - gm > bestS) { bestS = Pk - gm; bestP = 16 * wi + o; bestE = gp; }      // words ascend within a lane: '>' keeps the smallest s
+                    }
+                }
+            }
+            {
+                const int32_t cm = __builtin_amdgcn_readlane(mv_, 63), cp = __builtin_amdgcn_readlane(mp_, 63);
+                if (cm <= base_min) { base_min = cm; base_min_pos = cp; }
+            }
             base_S += __builtin_amdgcn_readlane(ss, 63); base_i += __builtin_amdgcn_readlane(si, 63); base_j += __builtin_amdgcn_readlane(sj, 63);
         }
-        // wave argmax: largest S, then smallest p
-        int32_t vS = bestS, vP = bestP < 0 ? 0x7fffffff : bestP;
+        // wave argmax: largest score, then smallest s
+        int32_t vS = bestS, vP = bestP < 0 ? 0x7fffffff : bestP, vE = bestE;
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) {
-            const int32_t oS = __shfl_xor(vS, d, 64), oP = __shfl_xor(vP, d, 64);
-            if (oS > vS || (oS == vS && oP < vP)) { vS = oS; vP = oP; }
+            const int32_t oS = __shfl_xor(vS, d, 64), oP = __shfl_xor(vP, d, 64), oE = __shfl_xor(vE, d, 64);
+            if (oS > vS || (oS == vS && oP < vP)) { vS = oS; vP = oP; vE = oE; }
         }
-        if (vP == 0x7fffffff || vS <= 0) { if (lane == 0) summ[r] = out; return; }       // cannot happen: the whole stream scores best_score > 0
+        if (vP == 0x7fffffff || vS <= 0) { if (lane == 0) summ[r] = out; return; }       // not one matching column on the path
         S_star = vS;
-        L = vP + 1;
+        const int32_t e0 = __builtin_amdgcn_readfirstlane(vE), s0 = __builtin_amdgcn_readfirstlane(vP);
+        if (e0 > 0) {
+            // the ops before e leave the stream: what they consume moves the alignment's end, the rest shifts down (in place: a chunk is read before it is
+            // written and only reads at or above what it writes)
+            int32_t ce_i = 0, ce_j = 0;
+            const int32_t we = e0 >> 4;
+            for (int32_t wb = 0; wb <= we; wb += 64) {
+                const int32_t wi = wb + lane;
+                if (wi <= we) {
+                    const uint32_t x = rg[wi];
+                    uint32_t vm = valid_mask(wi);
+                    if (wi == we) vm &= (1u << (2 * (e0 & 15))) - 1u;
+                    const uint32_t fM = ~(x | (x >> 1)) & vm, fI = (x & ~(x >> 1)) & vm, fD = (~x & (x >> 1)) & vm;
+                    ce_i += __popc(fM | fI); ce_j += __popc(fM | fD);
+                }
+            }
+            ce_i = wave_sum_i32_dpp(ce_i); ce_j = wave_sum_i32_dpp(ce_j);
+            w.i_end -= __builtin_amdgcn_readfirstlane(ce_i); w.j_end -= __builtin_amdgcn_readfirstlane(ce_j);
+            const int32_t Ln = s0 - e0 + 1, nWn = (Ln + 15) >> 4;
+            const uint32_t sh = 2u * (uint32_t)(e0 & 15);
+            for (int32_t wb = 0; wb < nWn; wb += 64) {
+                const int32_t wi = wb + lane;
+                uint32_t v = 0;
+                if (wi < nWn) {
+                    const uint32_t lo = rg[we + wi], hi = we + wi + 1 < nW ? rg[we + wi + 1] : 0u;
+                    v = sh ? (lo >> sh) | (hi << (32u - sh)) : lo;
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (wi < nWn) rg[wi] = v;
+            }
+            L = Ln;
+        } else L = s0 + 1;
         nW = (L + 15) >> 4;
         // what the kept ops consume, and their aligned columns
         int32_t ci2 = 0, cj2 = 0, nm2 = 0;
@@ -1394,7 +1438,7 @@ __global__ void __launch_bounds__(64) k_tb_cigar(int64_t first, int64_t count, c
             out.ref_end = ref_end;
             out.q_start = q_start;
             out.q_end = q_end;
-            out.score = di.best_score;
+            out.score = S_star;
             out.n_columns = w.ncol;
             out.n_match = n_match;
             int32_t nc = fb - fa;
@@ -1453,7 +1497,7 @@ __global__ void __launch_bounds__(64) k_back_merge(int64_t first, int64_t count,
     const WalkOut bw = wout_b[r];
     DpInfo di = info[r];
     di.steps += ib.steps;                                                // the cells of the backward DP count, whatever came of it
-    if (!(bw.ok == 1 && ib.best_score > 0)) { if (lane == 0) info[r] = di; return; }
+    if (bw.ok != 1) { if (lane == 0) info[r] = di; return; }
     const int32_t is = fw.i, js = fw.ts - fw.i, bis = bw.i, bjs = bw.ts - bw.i;
     const int32_t nD = (is < 0 && js >= 0) ? js + 1 : 0, nI = (js < 0 && is >= 0) ? is + 1 : 0;
     const int32_t bD = (bis < 0 && bjs >= 0) ? bjs + 1 : 0, bI = (bjs < 0 && bis >= 0) ? bis + 1 : 0;
@@ -1483,7 +1527,6 @@ __global__ void __launch_bounds__(64) k_back_merge(int64_t first, int64_t count,
     if (lane == 0) {
         fw.n_ops = at + m;
         wout[r] = fw;
-        di.best_score += ib.best_score;
         info[r] = di;
     }
 }

@@ -4,12 +4,13 @@
  * PARITY UNPINNED vs the reference: FALCON_unzip shells out to `blasr` (falcon_unzip/unzip.py:86-88),
  * a third-party C++ aligner that is not vendored under /root/reference and whose results
  * (placement, clipping, `--hitPolicy randombest --randomSeed 42` tie-breaks) cannot be reproduced
- * here.  This file therefore DEFINES the aligner ("fzalign v1.4"); the HIP kernels in
+ * here.  This file therefore DEFINES the aligner ("fzalign v1.5"); the HIP kernels in
  * falcon_unzip_amd/csrc/fzp_align.hip must match it bit-for-bit (summaries, CIGARs, DP cell counts),
  * and its quality is judged against the simulator's true alignments.
  *
- * fzalign v1.4  (v1.1: one index position per k-mer, one candidate placement per read, no identity gate; v1.2: multi-position index, two
- *               candidates, chains; v1.3: best-start soft clip; v1.4: anchor = the chain's first hit, extension forward AND backward from it)
+ * fzalign v1.5  (v1.1: one index position per k-mer, one candidate placement per read, no identity gate; v1.2: multi-position index, two
+ *               candidates, chains; v1.3: best-start soft clip; v1.4: anchor = the chain's first hit, extension forward AND backward from it;
+ *               v1.5: an extension runs to the matrix BORDER, the alignment is the best-scoring stretch of the joined path)
  *   bases     A/a C/c G/g T/t -> 0..3, anything else -> 0
  *   index     canonical k-mers (k<=16, 2 bits/base, base m of a k-mer at bits 2m; canonical = the smaller of
  *             the k-mer and its reverse complement) of every 2nd contig position -> EVERY such position
@@ -32,17 +33,19 @@
  *             and |dv_h - dv_p| <= 16 + (i_h - i_p)/16 (ties: the closest p), else 1; start(h) = start(p) or
  *             h itself.  The longest chain (ties: the earliest end) gives the anchor = its first hit (i_h, c_h), a cell
  *             of the true path.  Candidates in order W1, W2.
- *   selection every candidate is extended FORWARD from its anchor (below); the one with the highest forward
- *             extension score wins (ties: the earlier candidate) -- blasr's --bestn 1.  The winner is then
+ *   selection every candidate is extended FORWARD from its anchor (below); the one whose forward extension scores
+ *             highest at its terminal wins (ties: the earlier candidate) -- blasr's --bestn 1.  The winner is then
  *             extended BACKWARD from its anchor: the same DP on the reversed read prefix [0, i_h) and the
- *             reversed contig window of min(c_h, i_h + i_h/4 + 64) bases before c_h; if that scores more than 0
- *             its path (to ITS best cell) is joined to the forward one at the anchor's corner, together with
- *             the gap moves either walk's exit through row / column -1 implies.  `score` = forward + backward
- *             score; `cells` counts the forward DP of all candidates and the winner's backward DP.
- *   best start S(p) = score of the joined path's ops from its END up to op p; the alignment starts at the smallest p
- *             with the largest S (a match column); what lies beyond is soft clip (v1.3).
- *   identity  n_match = (score + mismatch*columns + gap*(path insertions + path deletions)) / (match + mismatch)
- *             over the whole path from the origin (exact); the alignment is dropped (unaligned) when
+ *             reversed contig window of min(c_h, i_h + i_h/4 + 64) bases before c_h; its path (from ITS terminal)
+ *             is joined to the forward one at the anchor's corner, together with the gap moves either walk's exit
+ *             through row / column -1 implies.  `cells` counts the forward DP of all candidates and the winner's
+ *             backward DP.
+ *   best sub-path (v1.5; v1.3's "best start" at both ends)  P(k) = score of the joined path's first k ops counted from the
+ *             forward terminal; the alignment is ops e..s with the largest P(s+1) - P(e) (ties: the smallest s, then
+ *             the largest e) -- it begins and ends with a match column; what the path holds outside is soft clip.
+ *             `score` = that stretch's score.  A path without a match column gives no alignment.
+ *   identity  n_match = (score + mismatch*columns + gap*(insertions + deletions)) / (match + mismatch)
+ *             over the alignment (exact); the alignment is dropped (unaligned) when
  *             100*n_match < 70*(columns + inserted + deleted bases of the trimmed alignment)
  *             (blasr --minPctIdentity 70.0, unzip.py:87).
  *   extension adaptive anti-diagonal band of 64 cells (Suzuki-Kasahara style) from the cell before the anchor
@@ -50,9 +53,9 @@
  *             floor; the first 64 steps alternate down/right, afterwards the band moves RIGHT when
  *             H[lane 0] > H[lane 63], else DOWN.  The diagonal operand is H of two steps ago in that
  *             step's own lane layout: the predecessor of lane k sits in lane k - 1 + (number of DOWN
- *             moves among the last two); a lane outside 0..63 reads as minus infinity.  The alignment ends at the best-scoring valid cell
- *             (first in step order, then lowest lane); read bases before the anchor and after the
- *             end are soft-clipped.  Trace-back priority: diagonal, then the gap whose source is the
+ *             moves among the last two); a lane outside 0..63 reads as minus infinity.  The extension's TERMINAL is the best-scoring valid cell
+ *             of the matrix border -- the read's last row or the window's last column -- (first in step order, then lowest lane): the
+ *             DP needs no score of any other cell, only which of the three moves won (v1.5).  Trace-back priority: diagonal, then the gap whose source is the
  *             same lane of the previous step (the cell above after a DOWN move, the cell to the left
  *             after a RIGHT move), then the other gap.
  */
@@ -282,7 +285,8 @@ static dp_t dp_extend(const uint8_t *q, int64_t nq, const uint8_t *t, int64_t nt
             if (h == hd) D |= 1ull << kk;
             if (A[kk] >= B[kk]) U |= 1ull << kk;       /* "the gap comes from the same lane" */
             int64_t i = i0 + kk, j = tt - i;
-            if (i >= 0 && i < nq && j >= 0 && j < nt && h > bsc[kk]) { bsc[kk] = h; bt[kk] = tt; }
+            /* v1.5: the extension runs to a BORDER of the matrix -- the read's last row or the window's last column; its terminal is the best valid cell there */
+            if (i >= 0 && i < nq && j >= 0 && j < nt && (i == nq - 1 || j == nt - 1) && h > bsc[kk]) { bsc[kk] = h; bt[kk] = tt; }
         }
         tbD[tt] = D; tbU[tt] = U; mv[tt] = (uint8_t)down;
         steer = !(H[0] > H[W - 1]);
@@ -296,7 +300,7 @@ static dp_t dp_extend(const uint8_t *q, int64_t nq, const uint8_t *t, int64_t nt
 #undef QC
 #undef TC
     R.steps = tt; R.tbD = tbD; R.tbU = tbU; R.mv = mv;
-    /* best cell: max score, then earliest step, then lowest lane */
+    /* terminal: max score among the valid border cells, then earliest step, then lowest lane */
     int bk = -1;
     for (int kk = 0; kk < W; kk++) {
         if (bt[kk] < 0) continue;
@@ -325,8 +329,8 @@ static int64_t dp_walk(const dp_t *R, int sb, uint8_t *ops, int64_t *i_end, int6
     return n;
 }
 
-/* ---- extension of one candidate (v1.4): forward from the anchor hit to the best cell, backward from it (the same DP on the reversed read prefix and
- * contig window) to ITS best cell; the two walks and the gap moves their ends imply at the anchor's corner make one path.  r = the oriented read codes. */
+/* ---- extension of one candidate (v1.5): forward from the anchor hit to the terminal, backward from it (the same DP on the reversed read prefix and
+ * contig window) to ITS terminal; the two walks and the gap moves their ends imply at the anchor's corner make one path.  r = the oriented read codes. */
 static void extend_one(const ctg_index *ix, const uint8_t *r, int64_t n, const anchor_t *an, const orc_align_params *P,
                        orc_aln_summary *out, u32vec *cig, int32_t *sel_score, int64_t *fwd_cells, const dp_t *Fpre) {
     memset(out, 0, sizeof *out);
@@ -341,17 +345,15 @@ static void extend_one(const ctg_index *ix, const uint8_t *r, int64_t n, const a
     const dp_t F = Fpre ? *Fpre : dp_extend(q, nq, t, nt, P, 0);      /* the selection has run the winner's forward DP already: its masks are still in place */
     out->cells = F.steps * W;
     *fwd_cells = F.steps * W;
-    out->score = F.score;                       /* 0 or less = no alignment */
-    *sel_score = F.score;                       /* what the candidate selection compares: the FORWARD extension's score */
-    if (F.lane < 0 || F.score <= 0) return;
+    out->score = 0;
+    *sel_score = F.score;                       /* what the candidate selection compares: the FORWARD extension's score at its terminal */
+    if (F.lane < 0) return;                     /* (no valid border cell: cannot happen for nq, nt >= 1) */
     /* path ops, END first: forward walk, the gap moves its exit implies, the backward part from the anchor out */
     uint8_t *ops = (uint8_t *)scratch_get(12, (size_t)(2 * n + 2 * (nt + 64) + 2 * (i_a + i_a / 4 + 128) + 64));
     int64_t i_end, j_end, is, js;
     int64_t L = dp_walk(&F, 3, ops, &i_end, &j_end, &is, &js);
     for (int64_t x = 0; x <= js && is < 0; x++) ops[L++] = 2;     /* left through row -1: the contig bases 0..js were skipped */
     for (int64_t x = 0; x <= is && js < 0; x++) ops[L++] = 1;     /* left through column -1 */
-    const int64_t L_fwd = L;
-    int32_t score_b = 0;
     if (i_a > 0 && c_a > 0) {
         const int64_t nqb = i_a;
         int64_t ntb = c_a;
@@ -361,8 +363,7 @@ static void extend_one(const ctg_index *ix, const uint8_t *r, int64_t n, const a
         for (int64_t x = 0; x < ntb; x++) tb[x] = ix->codes[c_a - 1 - x];
         const dp_t B = dp_extend(qb, nqb, tb, ntb, P, 8);
         out->cells += B.steps * W;
-        if (B.lane >= 0 && B.score > 0) {
-            score_b = B.score;
+        if (B.lane >= 0) {
             uint8_t *ob = (uint8_t *)scratch_get(15, (size_t)(nqb + ntb + 64));
             int64_t bie, bje, bis, bjs;
             const int64_t nb = dp_walk(&B, 11, ob, &bie, &bje, &bis, &bjs);
@@ -371,29 +372,37 @@ static void extend_one(const ctg_index *ix, const uint8_t *r, int64_t n, const a
             for (int64_t x = nb - 1; x >= 0; x--) ops[L++] = ob[x];         /* the walk came from the far end towards the anchor: turned round */
         }
     }
-    (void)L_fwd;
-    out->score = F.score + score_b;
     {
-        /* op by op from the END: cell (i, j) relative to the forward anchor (negative in the backward part), best start, run-length encoding */
+        /* v1.5 "best sub-path": the joined path runs from the forward terminal (op 0) to the backward one; with P(k) = score of ops 0..k-1, the
+         * alignment is ops e..s with the largest P(s+1) - P(e)  (ties: the smallest s, then the largest e): both of its ends are match columns, what
+         * the path holds outside it -- a tail dragged to the border through noise, a head likewise -- is soft clip. */
+        int64_t e_best = -1, s_best = -1, bestS = 0;
+        int64_t ci_e = 0, cj_e = 0;                 /* read / contig bases the ops before e_best consume */
+        {
+            int64_t i = i_end, j = j_end, Pk = 0, minP = 0, e_min = 0, ci = 0, cj = 0, ci_min = 0, cj_min = 0;
+            for (int64_t x = 0; x < L; x++) {
+                if (Pk <= minP) { minP = Pk; e_min = x; ci_min = ci; cj_min = cj; }          /* '<=': the largest e among equal prefixes */
+                if (ops[x] == 0) { Pk += r[i_a + i] == ix->codes[c_a + j] ? P->match : -P->mismatch; i--; j--; ci++; cj++; }
+                else if (ops[x] == 1) { Pk -= P->gap; i--; ci++; }
+                else { Pk -= P->gap; j--; cj++; }
+                if (Pk - minP > bestS) { bestS = Pk - minP; s_best = x; e_best = e_min; ci_e = ci_min; cj_e = cj_min; }
+            }
+        }
+        if (s_best < 0) return;                     /* not one match column on the path */
+        out->score = (int32_t)bestS;
+        i_end -= ci_e; j_end -= cj_e;
+        /* op by op from the alignment's END: cell (i, j) relative to the forward anchor (negative in the backward part), run-length encoding */
         int64_t i = i_end, j = j_end;
         u32vec rev = {0};
         int cur_op = -1; uint32_t cur_len = 0; int32_t ncol = 0, n_eq = 0;
-        /* v1.3 "best start": S = score of the ops walked so far (from the alignment's end); the alignment starts at the op where S is
-         * largest (the first such op met, i.e. the shortest alignment among ties -- it is a match column), everything walked after it is
-         * soft-clipped: a head that was forced along a wrong diagonal goes */
-        int64_t S = 0, bestS = 0;
-        int64_t snap_n = -1, snap_i = 0, snap_j = 0; int snap_op = -1; uint32_t snap_len = 0; int32_t snap_ncol = 0, snap_eq = 0;
-        for (int64_t x = 0; x < L; x++) {
+        for (int64_t x = e_best; x <= s_best; x++) {
             int op;
-            if (ops[x] == 0) { op = r[i_a + i] == ix->codes[c_a + j] ? 7 : 8; n_eq += op == 7; S += op == 7 ? P->match : -P->mismatch; i--; j--; ncol++; }
-            else if (ops[x] == 1) { op = 1; S -= P->gap; i--; }
-            else { op = 2; S -= P->gap; j--; }
+            if (ops[x] == 0) { op = r[i_a + i] == ix->codes[c_a + j] ? 7 : 8; n_eq += op == 7; i--; j--; ncol++; }
+            else if (ops[x] == 1) { op = 1; i--; }
+            else { op = 2; j--; }
             if (op == cur_op) cur_len++;
             else { if (cur_len) push(&rev, (cur_len << 4) | (uint32_t)cur_op); cur_op = op; cur_len = 1; }
-            if (S > bestS) { bestS = S; snap_n = rev.n; snap_i = i; snap_j = j; snap_op = cur_op; snap_len = cur_len; snap_ncol = ncol; snap_eq = n_eq; }
         }
-        if (snap_n < 0) { free(rev.v); return; }                      /* cannot happen: the forward path alone scores F.score > 0 */
-        rev.n = snap_n; i = snap_i; j = snap_j; cur_op = snap_op; cur_len = snap_len; ncol = snap_ncol; n_eq = snap_eq;
         if (cur_len) push(&rev, (cur_len << 4) | (uint32_t)cur_op);
         {   /* the device derives the match count from the score of the kept ops (it only sees the bases while scoring them): both must agree */
             const int64_t num = bestS + (int64_t)P->mismatch * ncol + (int64_t)P->gap * ((i_end - i) + (j_end - j) - 2 * (int64_t)ncol);
@@ -549,7 +558,7 @@ static void *mt_worker(void *vp) {
     return NULL;
 }
 /* test hook (tests/: the spec-independent full-matrix check needs the origin an extension started from; since v1.3 the reported alignment
- * no longer reveals it): the candidate origins of one read as seed_candidates finds them, out[c] = {strand, i_a, c_a}; returns their number */
+ * no longer reveals it): the candidate origins of one read as seed_candidates finds them, out[c] = {strand, i_a, c_a, forward terminal score, backward terminal score (or -2^26)}; returns their number */
 int orc_align_origins(const uint8_t *ctg_ascii, int64_t ctg_len, const uint8_t *read_ascii, int64_t n, const orc_align_params *P, int64_t *out) {
     if (P->kmer < 8 || P->kmer > 16 || P->seed_stride < 1) return -1;
     ctg_index ix;
@@ -571,7 +580,29 @@ int orc_align_origins(const uint8_t *ctg_ascii, int64_t ctg_len, const uint8_t *
     anchor_t cand[2];
     int nc = 0;
     if (n >= P->kmer && ix.len >= P->kmer) nc = seed_candidates(&ix, fwd, n, P, cand);
-    for (int c = 0; c < nc; c++) { out[3 * c] = cand[c].strand; out[3 * c + 1] = cand[c].i_a; out[3 * c + 2] = cand[c].c_a; }
+    for (int c = 0; c < nc; c++) {
+        out[5 * c] = cand[c].strand; out[5 * c + 1] = cand[c].i_a; out[5 * c + 2] = cand[c].c_a;
+        /* the two extensions' scores at their terminals (v1.5: the best valid border cell), as extend_one would run them */
+        uint8_t *ori = (uint8_t *)malloc((size_t)(n ? n : 1));
+        for (int64_t i = 0; i < n; i++) ori[i] = cand[c].strand ? (uint8_t)(3 - fwd[n - 1 - i]) : fwd[i];
+        const int64_t i_a = cand[c].i_a, c_a = cand[c].c_a, nq = n - i_a;
+        int64_t nt = ix.len - c_a;
+        if (nt > nq + nq / 4 + 64) nt = nq + nq / 4 + 64;
+        const dp_t F = dp_extend(ori + i_a, nq, codes + c_a, nt, P, 0);
+        out[5 * c + 3] = F.lane >= 0 ? F.score : NEG;
+        out[5 * c + 4] = NEG;
+        if (i_a > 0 && c_a > 0) {
+            int64_t ntb = c_a;
+            if (ntb > i_a + i_a / 4 + 64) ntb = i_a + i_a / 4 + 64;
+            uint8_t *qb = (uint8_t *)malloc((size_t)i_a), *tb = (uint8_t *)malloc((size_t)ntb);
+            for (int64_t x = 0; x < i_a; x++) qb[x] = ori[i_a - 1 - x];
+            for (int64_t x = 0; x < ntb; x++) tb[x] = codes[c_a - 1 - x];
+            const dp_t B = dp_extend(qb, i_a, tb, ntb, P, 8);
+            out[5 * c + 4] = B.lane >= 0 ? B.score : NEG;
+            free(qb); free(tb);
+        }
+        free(ori);
+    }
     scratch_release();
     free(fwd); free(ix.kp); free(codes);
     return nc;

@@ -159,20 +159,21 @@ def align_reads(orc, ctg: bytes, reads, params=None, n_threads=1, seconds=None):
 
 
 def align_origins(orc, ctg: bytes, read: bytes, params=None):
-    """candidate origins of one read as the twin's seeding finds them -> list of (strand, i_a, c_a) (orc_align_origins, a test hook)"""
+    """candidate origins of one read as the twin's seeding finds them -> list of (strand, i_a, c_a, forward terminal score, backward terminal
+    score or -2^26) (orc_align_origins, a test hook)"""
     import numpy as np
     P = AlignParams()
     orc.lib.orc_align_params_default(C.byref(P))
     for k, v in (params or {}).items():
         setattr(P, k, v)
-    out = np.zeros(6, np.int64)
+    out = np.zeros(10, np.int64)
     f = orc.lib.orc_align_origins
     f.restype = C.c_int
     f.argtypes = [C.c_char_p, C.c_int64, C.c_char_p, C.c_int64, C.c_void_p, C.c_void_p]
     n = f(ctg, len(ctg), read, len(read), C.addressof(P), out.ctypes.data)
     if n < 0:
         raise OracleError("orc_align_origins rc=%d" % n)
-    return [tuple(int(x) for x in out[3 * c:3 * c + 3]) for c in range(n)]
+    return [tuple(int(x) for x in out[5 * c:5 * c + 5]) for c in range(n)]
 
 
 def load():

@@ -59,9 +59,10 @@ def test_identity_gate(oracle):
 
 
 def test_twin_scores_equal_unbanded_dp(oracle):
-    """The twin's extension score == the optimum of a plain full-matrix DP from the same origin (reads of ~2.5 kb)."""
+    """The twin's extensions reach the optimum of a plain full-matrix DP from the same origin (reads of ~2.5 kb); the reported score is the
+    reported CIGAR's and lies within a few columns of the local optimum."""
     from falcon_unzip_amd import sim
-    from tests.test_gpu_align import _two_way_best
+    from tests.test_gpu_align import _check_against_full_matrix
     rng = np.random.Generator(np.random.PCG64(93))
     L = 60000
     hap0, hap1, _ = sim.make_diploid(L, rng)
@@ -71,15 +72,8 @@ def test_twin_scores_equal_unbanded_dp(oracle):
     for r, rd in enumerate(reads):
         assert s["aligned"][r]
         raw = sim.codes_to_str(rd.raw_seq_codes()).encode()
-        found = False
-        for strand, i_a, c_a in oracle_lib.align_origins(oracle, ctg, raw):      # since v1.3 the alignment itself no longer shows where the extension began
-            assert strand == rd.strand
-            found = found or _two_way_best(rd.seq, hap0, i_a, c_a) == int(s["score"][r])
-        assert found, (r, s[r])
-        # the reported alignment is the best-scoring suffix-to-end piece of the traced path: it scores at least the extension's score
         ops = [(int(w) >> 4, int(w) & 15) for w in cig[r]]
-        cs = sum(2 * l if o == 7 else -4 * l if o == 8 else -3 * l if o in (1, 2) else 0 for l, o in ops)
-        assert cs >= int(s["score"][r]) and ops[0][1] in (4, 7) and (ops[0][1] == 7 or ops[1][1] == 7)     # (the two extensions' corner gaps are part of the path, not of either score)
+        assert _check_against_full_matrix(oracle, ctg, raw, rd.seq, hap0, rd.strand, int(s["score"][r]), ops), (r, s[r])
 
 
 def test_threaded_twin_equals_single_thread(oracle):

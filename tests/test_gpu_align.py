@@ -326,9 +326,9 @@ def test_identity_gate(eng, oracle):
     job.close()
 
 
-def _full_matrix_best(q, t, match=2, mismatch=4, gap=3):
-    """Unbanded extension DP from the origin, H(-1,-1) = 0, linear gaps, no zero floor: best score over all cells.
-    Independent of the band, the steering and the trace-back of the spec (numpy, row by row)."""
+def _full_matrix_best(q, t, match=2, mismatch=4, gap=3, border=False):
+    """Unbanded extension DP from the origin, H(-1,-1) = 0, linear gaps, no zero floor: best score over all cells, or (border=True) over the
+    cells of the last row and the last column only.  Independent of the band, the steering and the trace-back of the spec (numpy, row by row)."""
     nq, nt = len(q), len(t)
     ar = np.arange(nt + 1, dtype=np.int64)
     prev = -gap * ar                      # row -1: H(-1, j-1) at index j, index 0 = the corner
@@ -339,31 +339,53 @@ def _full_matrix_best(q, t, match=2, mismatch=4, gap=3):
         base[0] = -gap * (i + 1)          # H(i, -1)
         base[1:] = np.maximum(prev[:-1] + s, prev[1:] - gap)
         cur = np.maximum.accumulate(base + gap * ar) - gap * ar      # the left-gap chain
-        best = max(best, int(cur[1:].max()))
+        if not border:
+            best = max(best, int(cur[1:].max()))
+        else:
+            best = max(best, int(cur[nt]), int(cur[1:].max()) if i == nq - 1 else best)
         prev = cur
     return best
 
 
-def _two_way_best(ori, ctg_codes, i_a, c_a):
-    """full-matrix optimum of the forward extension from the anchor (i_a, c_a) plus, when the anchor is inside both sequences, of the backward one
-    (the same DP on the reversed read prefix and contig window) if it is positive -- fzalign v1.4's extension score"""
+def _two_way(ori, ctg_codes, i_a, c_a, border=False):
+    """(forward, backward) full-matrix optimum of the extensions from the anchor (i_a, c_a): best over all cells (the local optimum) or over the border
+    cells (fzalign v1.5's terminal).  The backward one is the same DP on the reversed read prefix and contig window; None when the anchor is at an edge."""
     L = len(ctg_codes)
     q = ori[i_a:]
     nt = min(L - c_a, len(q) + len(q) // 4 + 64)
-    tot = _full_matrix_best(q, ctg_codes[c_a:c_a + nt])
+    f = _full_matrix_best(q, ctg_codes[c_a:c_a + nt], border=border)
+    b = None
     if i_a > 0 and c_a > 0:
         ntb = min(c_a, i_a + i_a // 4 + 64)
-        b = _full_matrix_best(ori[:i_a][::-1], ctg_codes[c_a - ntb:c_a][::-1])
-        if b > 0:
-            tot += b
-    return tot
+        b = _full_matrix_best(ori[:i_a][::-1], ctg_codes[c_a - ntb:c_a][::-1], border=border)
+    return f, b
+
+
+def _check_against_full_matrix(oracle, ctg, raw, ori, hap0, strand_true, score, cig):
+    """fzalign v1.5 against a plain full-matrix DP, for one aligned read: (1) an origin of the twin's seeding exists whose two extensions reach exactly the
+    full-matrix optimum over the border cells -- the band never cut the best path; (2) the reported score is the score of the reported CIGAR; (3) it is at
+    most the sum of the two local optima from that origin and, the reported piece being the best stretch of the path to the border, within a few columns of it."""
+    cs = sum(2 * l if o == 7 else -4 * l if o == 8 else -3 * l if o in (1, 2) else 0 for l, o in cig)
+    assert cs == score
+    first = [o for _, o in cig if o != 4]
+    assert first[0] == 7 and first[-1] == 7
+    for strand, i_a, c_a, tf, tb in oracle_lib.align_origins(oracle, ctg, raw):
+        if strand != strand_true:
+            continue
+        f, b = _two_way(ori, hap0, i_a, c_a, border=True)
+        if f != tf or (b is not None and b != tb):
+            continue
+        lf, lb = _two_way(ori, hap0, i_a, c_a)
+        top = lf + (lb if lb is not None and lb > 0 else 0)
+        if top - 40 <= score <= top:
+            return True
+    return False
 
 
 def test_scores_equal_unbanded_dp_on_short_reads(eng, oracle):
-    """Spec-independent check: for reads of ~2.5 kb the kernel's score must be the optimum of a plain
-    full-matrix extension DP from the same origin -- the band never cut the best path, and twin and kernel do not share an
-    arithmetic bug.  (The origin comes from the twin's seeding: since v1.3 the reported alignment starts at its best-scoring
-    column, not at the origin.)"""
+    """Spec-independent check: for reads of ~2.5 kb the extensions must reach the optimum of a plain full-matrix DP from the
+    same origin -- the band never cut the best path, and twin and kernel do not share an arithmetic bug (_check_against_full_matrix; the kernel's
+    fields equal the twin's, whose terminal scores the hook reports)."""
     from falcon_unzip_amd import _lib, sim
     rng = np.random.Generator(np.random.PCG64(93))
     L = 60000
@@ -374,6 +396,9 @@ def test_scores_equal_unbanded_dp_on_short_reads(eng, oracle):
     job = _lib.align_job(eng, [ctg], raw)
     job.run()
     s = job.summaries()
+    exp, _ = oracle_lib.align_reads(oracle, ctg, raw)
+    for f in FIELDS:
+        assert np.array_equal(s[f], exp[f]), f
     aln, idx = job.alnset(0)
     assert s["aligned"].sum() >= 22
     cig_of = {int(r): aln.cigar_of(k) for k, r in enumerate(idx)}
@@ -381,16 +406,7 @@ def test_scores_equal_unbanded_dp_on_short_reads(eng, oracle):
     for r, rd in enumerate(reads):
         if not s["aligned"][r] or r not in cig_of:
             continue
-        ori = rd.seq                                        # on the contig strand = the oriented read
-        cg = cig_of[r]
-        cs = sum(2 * l if o == 7 else -4 * l if o == 8 else -3 * l if o in (1, 2) else 0 for l, o in cg)
-        assert cs >= int(s["score"][r])                     # the kept piece of the path scores at least what the whole path did
-        hit = False
-        for strand, i_a, c_a in oracle_lib.align_origins(oracle, ctg, raw[r]):
-            if strand == rd.strand and _two_way_best(ori, hap0, i_a, c_a) == int(s["score"][r]):
-                hit = True
-                break
-        assert hit, (r, s[r])
+        assert _check_against_full_matrix(oracle, ctg, raw[r], rd.seq, hap0, rd.strand, int(s["score"][r]), cig_of[r]), (r, s[r])
         checked += 1
     assert checked >= 20
     job.close()

@@ -267,7 +267,13 @@ static void run_kind(uint32_t *d_out, int n_cu, int iters, int insts_per_iter_pe
     X(23, "v_med3_i32", "v_med3_i32 %0, %0, %1, %1") \
     X(24, "v_mad_i32_i24", "v_mad_i32_i24 %0, %0, %1, %1") \
     X(25, "v_pk_sub_i16", "v_pk_sub_i16 %0, %0, %1") \
-    X(26, "v_swap_b32", "v_swap_b32 %0, %1")
+    X(26, "v_swap_b32", "v_swap_b32 %0, %1") \
+    X(27, "v_bitop3_b32", "v_bitop3_b32 %0, %0, %1, %1 bitop3:0x96") \
+    X(28, "v_lshrrev_b64", "v_lshrrev_b64 %0, 1, %0") \
+    X(29, "v_bfi_b32", "v_bfi_b32 %0, %0, %1, %1") \
+    X(30, "v_xnor_b32", "v_xnor_b32 %0, %0, %1") \
+    X(31, "v_not_b32", "v_not_b32 %0, %0") \
+    X(32, "v_bcnt_u32_b32", "v_bcnt_u32_b32 %0, %0, %1")
 
 template <int K2>
 __global__ void __launch_bounds__(1024) k2(uint32_t *out, int iters) {
@@ -281,7 +287,7 @@ __global__ void __launch_bounds__(1024) k2(uint32_t *out, int iters) {
         for (int u = 0; u < 8; u++) {
 #define X(id, name, text)                                                                                             \
     if (K2 == id) {                                                                                                   \
-        if (id == 20) { _Pragma("unroll") for (int i = 0; i < 8; i++) asm volatile(text : "+v"(v64[i]) : "v"(w[i])); } \
+        if (id == 20 || id == 28) { _Pragma("unroll") for (int i = 0; i < 8; i++) asm volatile(text : "+v"(v64[i]) : "v"(w[i])); } \
         else if (id == 18) { _Pragma("unroll") for (int i = 0; i < 8; i++) asm volatile(text : "+v"(v[i & 1]) : "v"(w[i])); } \
         else if (id == 26) { _Pragma("unroll") for (int i = 0; i < 8; i++) asm volatile(text : "+v"(v[i]), "+v"(w[i])); } \
         else if (id == 14) { asm volatile("v_cndmask_b32_e32 %0, %0, %8, vcc\n\tv_cndmask_b32_e32 %1, %1, %9, vcc\n\tv_cndmask_b32_e32 %2, %2, %10, vcc\n\tv_cndmask_b32_e32 %3, %3, %11, vcc\n\tv_cndmask_b32_e32 %4, %4, %12, vcc\n\tv_cndmask_b32_e32 %5, %5, %13, vcc\n\tv_cndmask_b32_e32 %6, %6, %14, vcc\n\tv_cndmask_b32_e32 %7, %7, %15, vcc" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7])); } \
