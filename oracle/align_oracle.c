@@ -608,6 +608,16 @@ int orc_align_origins(const uint8_t *ctg_ascii, int64_t ctg_len, const uint8_t *
     return nc;
 }
 
+/* test hook (tests/test_swb_core.py: the bit-sliced cell function of falcon_unzip_amd/csrc/fzp_swb_core.h against this scalar DP): one extension of
+ * q[0..nq) x t[0..nt) (codes 0..3) -- per step the two masks and the move, out = {steps, terminal score, terminal step, terminal lane} */
+int orc_dp_extend_raw(const uint8_t *q, int64_t nq, const uint8_t *t, int64_t nt, const orc_align_params *P, uint64_t *tbD, uint64_t *tbU, uint8_t *mv, int64_t *out) {
+    const dp_t R = dp_extend(q, nq, t, nt, P, 0);
+    memcpy(tbD, R.tbD, (size_t)R.steps * 8); memcpy(tbU, R.tbU, (size_t)R.steps * 8); memcpy(mv, R.mv, (size_t)R.steps);
+    out[0] = R.steps; out[1] = R.score; out[2] = R.ts; out[3] = R.lane;
+    scratch_release();
+    return 0;
+}
+
 static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 /* seconds[0] = index build (serial, one contig), seconds[1] = seeding + DP + trace-back of all reads (n_threads threads); may be NULL */
 int orc_align_reads_mt_timed(const uint8_t *ctg_ascii, int64_t ctg_len, int64_t n_reads, const int64_t *read_off,
