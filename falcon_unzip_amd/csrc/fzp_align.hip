@@ -17,6 +17,7 @@
 #include <algorithm>
 
 #include "fzp_batch.h"
+#include "fzp_swb_core.h"
 
 namespace {
 constexpr int32_t NEGV = -(1 << 26);
@@ -750,7 +751,7 @@ __global__ void __launch_bounds__(64) k_sw(int64_t first, int64_t count, const i
                                             const uint32_t *__restrict__ ctg_pk, const int64_t *__restrict__ ctg_woff, const int64_t *__restrict__ ctg_len,
                                             const Anchor *__restrict__ anc, const int64_t *__restrict__ tb_off, uint2 *__restrict__ tb, ulonglong2 *__restrict__ mvw,
                                             int match, int mismatch, int gap, DpInfo *__restrict__ info, int64_t *__restrict__ tbo, int64_t *__restrict__ mvo,
-                                            const int32_t *__restrict__ order, int32_t prio_len) {
+                                            const int32_t *__restrict__ order, int32_t prio_len, const int64_t *__restrict__ m_off, const int64_t *__restrict__ mv_off) {
     const int lane = lane_id();
     // wave-uniform on purpose: everything indexed by the read then lives in SGPRs / scalar loads
     const int64_t wq = (int64_t)blockIdx.x;   // one wave per workgroup: a finished read frees its slot at once
@@ -762,9 +763,12 @@ __global__ void __launch_bounds__(64) k_sw(int64_t first, int64_t count, const i
     const int64_t sl = first + wv;
     const int64_t r = ridx ? ridx[sl] : sl;
     const Anchor a = anc[sl];
-    ulonglong2 *tbr = (ulonglong2 *)tb + (tb_off[sl] - tb_off[first]);   // per step: {D mask, G mask} over the 64 band lanes
-    ulonglong2 *mvr = mvw + ((tb_off[sl] - tb_off[first]) >> 6) + wv;   // per 64 steps: {move bits, i0 before the chunk}
-    if (tbo && lane == 0) { tbo[sl] = tb_off[sl] - tb_off[first]; mvo[sl] = ((tb_off[sl] - tb_off[first]) >> 6) + wv; }   // element offsets into the chunk's buffers
+    // where the slot's masks and move words go in the chunk's buffers: in slot order, or (m_off) where the job planned them -- in launch order, so that the
+    // streams of the reads that the bit-sliced kernel runs side by side in a wave lie side by side
+    const int64_t toff = m_off ? m_off[sl] : tb_off[sl] - tb_off[first], moff = m_off ? mv_off[sl] : (toff >> 6) + wv;
+    ulonglong2 *tbr = (ulonglong2 *)tb + toff;   // per step: {D mask, G mask} over the 64 band lanes
+    ulonglong2 *mvr = mvw + moff;                // per 64 steps: {move bits, i0 before the chunk}
+    if (tbo && lane == 0) { tbo[sl] = toff; mvo[sl] = moff; }   // element offsets into the chunk's buffers
     if (!a.aligned) { if (lane == 0) info[sl] = DpInfo{0, -1, 0, NEGV}; return; }
     const int c_idx = read_ctg[r];
     const int64_t n = read_len[r];
@@ -868,6 +872,187 @@ __global__ void __launch_bounds__(64) k_sw(int64_t first, int64_t count, const i
 }
 #undef SW_STEP
 #undef SW_FLUSH
+
+// ---- K1 hot kernel, bit-sliced form: one READ per lane (64 extensions per wave), the 64 cells of a read's anti-diagonal in the 64 bits of a register
+// pair, the DP values as differences in three bit planes (fzp_swb_core.h: the cell function, checked on the host against the scalar twin).  Same spec,
+// same outputs as k_sw -- per step the masks {D, G}, per 64 steps the move record, per read the terminal -- from a sixth of the instructions: k_sw spends
+// ~14 wave instructions on the 64 cells of one read's step, this kernel ~130 on the 4 096 cells of 64 reads' steps.  What the scores were needed for is
+// tracked apart: the steering compares the two edge cells of the band, whose scores advance by the difference the step just computed for them; the
+// terminal's candidates lie on the last row / last column, whose scores likewise accumulate while the band sweeps along them (v1.5 made that enough).
+// A wave's reads advance in lockstep (the step counter is wave-uniform); a read that is done idles its lane, so the launch lists reads of similar
+// length together.  A step costs a read's lane ~10x the latency it costs a k_sw wave: extensions longer than the caller's limit stay with k_sw, as do
+// those shorter than the band (nq or nt < 64).
+struct LaneStream {                // upcoming bases of one sequence, per lane: cur holds `have` (>= 1) of them, pend the 16 after those
+    const uint32_t *pk;
+    uint64_t cur;
+    uint32_t pend;
+    int32_t have;
+    __device__ __forceinline__ void init(const uint32_t *pk_, int64_t idx) {
+        const int64_t w = idx >> 4;
+        const uint32_t sh = (uint32_t)(idx & 15) * 2u;
+        cur = ((uint64_t)pk_[w] | ((uint64_t)pk_[w + 1] << 32)) >> sh;
+        have = 32 - (int32_t)(idx & 15);
+        pk = pk_ + w + 2;                                    // the word `pend` holds
+        pend = *pk;
+    }
+    __device__ __forceinline__ void refill() {              // every 16 steps (a step takes at most one base); branch-free: a lane that needs nothing loads its word again
+        const bool m = have <= 16;
+        cur |= m ? (uint64_t)pend << (2 * have) : 0ull;
+        have += m ? 16 : 0;
+        pk += m ? 1 : 0;
+        pend = *pk;
+    }
+    __device__ __forceinline__ uint32_t pop(uint32_t en) {  // en = 1: take a base; 0: leave the stream as it is (returns 0)
+        const uint32_t c = (uint32_t)cur & (0u - en) & 3u;
+        cur >>= 2u * en;
+        have -= (int32_t)en;
+        return c;
+    }
+};
+
+struct SwbLane {                   // one extension's state (a lane's registers)
+    swb::Planes P, Q;              // difference planes of the previous anti-diagonal
+    uint64_t R0, R1, C0, C1;       // base windows as bit planes: bit k = read base i0 + k / contig base t - i0 - k
+    LaneStream qs, ts;
+    int32_t i0, E2, sv0;           // E2 = (score of lane 63's cell - score of lane 0's) / 2;  sv0 = sum of lane 0's difference codes: its score is -259 + 2 sv0 - 3 (t + 1)
+    uint32_t down, pdown;
+    uint64_t mvacc;
+};
+
+// one DP step of every lane's extension.  CHECKED = false: the 64 steps of an interior block -- no lane of the wave can reach a border of its matrix in them, so
+// there is nothing to validate, no terminal candidate and no end; lanes whose extension is over run along on their stale state (nothing of theirs is stored).
+// CHECKED = true: validity of the bases near the ends, terminal candidates, the end of the extension.
+template <bool CHECKED>
+__device__ __forceinline__ void swb_step(SwbLane &L, const int32_t t, ulonglong2 &rec, const int32_t nq, const int32_t nt, const int32_t max_steps, bool &active,
+                                         bool &row_on, bool &col_on, int32_t &Hrow, int32_t &Hcol, int32_t &best, int32_t &bt, int32_t &bl, int32_t &steps) {
+    using namespace swb;
+    const uint32_t sd = L.down, sr = 1u - sd;
+    L.i0 += (int32_t)sd;
+    {   // the windows slide: a new read base enters at lane 63 (DOWN), a new contig base at lane 0 (RIGHT)
+        const uint32_t cq = L.qs.pop(sd), ct = L.ts.pop(sr);
+        L.R0 = (L.R0 >> sd) | ((uint64_t)(cq << 31) << 32); L.R1 = (L.R1 >> sd) | ((uint64_t)((cq << 30) & 0x80000000u) << 32);
+        L.C0 = (L.C0 << sr) | (uint64_t)(ct & 1u); L.C1 = (L.C1 << sr) | (uint64_t)(ct >> 1);
+    }
+    const Planes p = {L.P.v0 << sr, L.P.v1 << sr, L.P.v2 << sr}, q = {L.Q.v0 >> sd, L.Q.v1 >> sd, L.Q.v2 >> sd};
+    uint64_t xm = (L.R0 ^ L.C0) | (L.R1 ^ L.C1);
+    const int32_t kr = nq - 1 - L.i0, kc = t - (nt - 1) - L.i0;      // lanes of the last row / the last column
+    if (CHECKED) {   // bases past the read's / the window's end never match
+        const int32_t nv = kr + 1;                                    // lanes k < nv hold read bases
+        const uint64_t bad_r = nv >= 64 ? 0ull : (nv <= 0 ? ~0ull : ~0ull << nv);
+        const uint64_t bad_c = kc <= 0 ? 0ull : (kc >= 64 ? ~0ull : ~(~0ull << kc));   // lanes k >= kc hold contig bases
+        xm |= bad_r | bad_c;
+    }
+    const uint64_t f = ((uint64_t)((sd & L.pdown) << 31) << 32) | (uint64_t)(sr & (1u - L.pdown));      // two moves the same way: the edge lane's diagonal predecessor is outside the band
+    uint64_t D, G;
+    cells(xm, f, 0ull - (uint64_t)sd, p, q, &L.P, &L.Q, &D, &G);
+    rec = make_ulonglong2(D, G);
+    L.mvacc |= (uint64_t)sd << (t & 63);
+    // the edge cells' scores: every lane's cell moved down (its vertical difference) or right (its horizontal one)
+    const uint32_t dm = 0u - sd;
+    const uint32_t xl0 = ((uint32_t)L.Q.v0 & dm) | ((uint32_t)L.P.v0 & ~dm), xl1 = ((uint32_t)L.Q.v1 & dm) | ((uint32_t)L.P.v1 & ~dm), xl2 = ((uint32_t)L.Q.v2 & dm) | ((uint32_t)L.P.v2 & ~dm);
+    const uint32_t xh0 = ((uint32_t)(L.Q.v0 >> 32) & dm) | ((uint32_t)(L.P.v0 >> 32) & ~dm), xh1 = ((uint32_t)(L.Q.v1 >> 32) & dm) | ((uint32_t)(L.P.v1 >> 32) & ~dm),
+                   xh2 = ((uint32_t)(L.Q.v2 >> 32) & dm) | ((uint32_t)(L.P.v2 >> 32) & ~dm);
+    const int32_t v0 = (int32_t)((xl0 & 1u) | ((xl1 & 1u) << 1) | ((xl2 & 1u) << 2)), v63 = (int32_t)((xh0 >> 31) | ((xh1 >> 31) << 1) | ((xh2 >> 31) << 2));
+    L.sv0 += v0;
+    L.E2 += v63 - v0;
+    if (CHECKED) {   // terminal: the best valid cell of the last row / last column, their scores by differences along them
+        if (active) {
+            const int32_t S0 = -259 + 2 * L.sv0 - 3 * (t + 1);
+            const bool kc_in = kc >= 0 && kc <= 63, kr_in = kr >= 0 && kr <= 63;
+            const bool col_start = !col_on && sr && kc == 0, row_start = !row_on && sd && kr == 63;
+            if (col_start) Hcol = S0; else if (col_on && kc_in) Hcol += 2 * value_at(L.Q, kc & 63) - 3;
+            if (row_start) Hrow = S0 + 2 * L.E2; else if (row_on && kr_in) Hrow += 2 * value_at(L.P, kr & 63) - 3;
+            col_on = col_on || col_start; row_on = row_on || row_start;
+            { const int32_t i = L.i0 + kc; if (col_on && kc_in && i >= 0 && i < nq && Hcol > best) { best = Hcol; bt = t; bl = kc; } }
+            { const int32_t jj = t - (nq - 1); if (row_on && kr_in && jj >= 0 && jj < nt && Hrow > best) { best = Hrow; bt = t; bl = kr; } }
+            if (L.i0 > nq - 1 || t - (L.i0 + 63) > nt - 1 || t + 1 >= max_steps) { active = false; steps = t + 1; }
+        }
+    }
+    L.pdown = sd;
+    L.down = (CHECKED && (t + 1) < 64) ? (uint32_t)(((t + 1) & 1) == 0) : (uint32_t)(L.E2 >= 0);
+}
+
+__global__ void __launch_bounds__(64) k_swb(int64_t first, const int32_t *__restrict__ list, const int32_t *__restrict__ ridx, const uint32_t *__restrict__ read_ori,
+                                             const int64_t *__restrict__ ori_woff, const int32_t *__restrict__ read_len, const int32_t *__restrict__ read_ctg,
+                                             const uint32_t *__restrict__ ctg_pk, const int64_t *__restrict__ ctg_woff, const int64_t *__restrict__ ctg_len,
+                                             const Anchor *__restrict__ anc, const int64_t *__restrict__ tb_off, uint2 *__restrict__ tb, ulonglong2 *__restrict__ mvw,
+                                             DpInfo *__restrict__ info, int64_t *__restrict__ tbo, int64_t *__restrict__ mvo, const int64_t *__restrict__ m_off, const int64_t *__restrict__ mv_off, int dbg) {
+    using namespace swb;
+    const int64_t wv = list[(int64_t)blockIdx.x * 64 + threadIdx.x];       // the lane's slot in the chunk, -1: none
+    bool active = wv >= 0;
+    const int64_t sl = first + (active ? wv : 0);
+    const int64_t r = ridx ? ridx[sl] : sl;
+    const Anchor a = anc[sl];
+    // the lanes of a wave stand side by side in the launch list, and so do their mask streams (m_off: planned in launch order): 64 streams scattered over the
+    // buffer cost twice the time in address translation alone
+    const int64_t toff = m_off ? m_off[sl] : tb_off[sl] - tb_off[first], moff = m_off ? mv_off[sl] : (toff >> 6) + (active ? wv : 0);
+    ulonglong2 *tbr = (ulonglong2 *)tb + toff;
+    ulonglong2 *mvr = mvw + moff;
+    if (active && tbo) { tbo[sl] = toff; mvo[sl] = moff; }
+    if (active && !a.aligned) { info[sl] = DpInfo{0, -1, 0, NEGV}; active = false; }
+    const int c_idx = read_ctg[r];
+    const int64_t n = read_len[r];
+    const int32_t nq = (int32_t)(n - a.i_a);
+    int64_t ntl = ctg_len[c_idx] - a.c_a;
+    if (ntl > (int64_t)nq + nq / 4 + 64) ntl = (int64_t)nq + nq / 4 + 64;
+    const int32_t nt = (int32_t)ntl;
+    const uint32_t *qpk = read_ori + ori_woff[sl];
+    const uint32_t *tpk = ctg_pk + ctg_woff[c_idx];
+    const int64_t qb = a.i_a, tbase = a.c_a;
+    const int32_t max_steps = nq + nt + 2;
+    SwbLane L;
+    // step -1: the anti-diagonal i + j = -1 of the virtual border, lane k = cell (k - 33, 32 - k): Pv = 0 where j >= 0 (k <= 32) else 4, Qv = 0 where i >= 0 (k >= 33) else 4
+    L.P = {0, 0, ~0ull << 33}; L.Q = {0, 0, (1ull << 33) - 1};
+    L.R0 = L.R1 = L.C0 = L.C1 = 0;
+    for (int k = 33; k < 64; k++) { const uint32_t c = base_at(qpk, qb + (k - 33)); L.R0 |= (uint64_t)(c & 1u) << k; L.R1 |= (uint64_t)(c >> 1) << k; }
+    for (int k = 0; k <= 32; k++) { const uint32_t c = base_at(tpk, tbase + (32 - k)); L.C0 |= (uint64_t)(c & 1u) << k; L.C1 |= (uint64_t)(c >> 1) << k; }
+    L.qs.init(qpk, qb + 31);
+    L.ts.init(tpk, tbase + 33);
+    L.i0 = -33; L.E2 = 8; L.sv0 = 0;                            // at step -1 from the border's closed form: lane 0's cell scores -259, lane 63's -243
+    L.down = 1; L.pdown = 0;
+    bool row_on = false, col_on = false;
+    int32_t Hrow = 0, Hcol = 0, best = NEGV, bt = -1, bl = 0, steps = 0;
+    int32_t t = 0;                                            // wave-uniform
+    while (__ballot(active)) {
+        const bool blk_active = active;
+        const int32_t i0_blk = L.i0;
+        L.mvacc = 0;
+        // an interior block?  every running lane more than 64 steps away from its last row and its last column (a step brings either one closer by at most one)
+        const bool far = !active || (nq - 1 - (L.i0 + 63) > 64 && nt - 1 - (t - L.i0) > 64);
+        const bool interior = t >= 64 && __ballot(!far) == 0ull;
+        for (int g8 = 0; g8 < 8; g8++) {
+            const bool grp_active = active;
+            ulonglong2 rec[8];
+            if (interior) {
+#pragma unroll
+                for (int s8 = 0; s8 < 8; s8++) { swb_step<false>(L, t, rec[s8], nq, nt, max_steps, active, row_on, col_on, Hrow, Hcol, best, bt, bl, steps); if ((dbg & 4) && grp_active) tbr[t] = rec[s8]; t++; }
+            } else {
+#pragma unroll
+                for (int s8 = 0; s8 < 8; s8++) { swb_step<true>(L, t, rec[s8], nq, nt, max_steps, active, row_on, col_on, Hrow, Hcol, best, bt, bl, steps); t++; }
+            }
+            // the streams top up every 16 steps, and they do it HERE, ahead of a group's stores: taking the word loaded 16 steps ago means waiting on the vector-memory
+            // counter, which also counts the mask stores -- at this point the youngest of those are 8 steps old and done, right behind a group they would be in flight
+            if ((g8 & 1) && !(dbg & 2)) { L.qs.refill(); L.ts.refill(); }
+            if (grp_active && !(dbg & 5)) {
+#pragma unroll
+                for (int s8 = 0; s8 < 8; s8++) tbr[t - 8 + s8] = rec[s8];
+            }
+        }
+        if (blk_active) {
+            uint32_t glane = 32u;
+            if ((t & (TBS_SEG - 1)) == 0 && active) {      // step t-1 tops a trace-back segment: the lane of its best score is where that segment's walker starts
+                int32_t run = 0, bestv = 0;
+                glane = 0u;
+                for (int k = 0; k < 63; k++) {            // score(lane k+1) - score(lane k) = 2 (Qv[k+1] - Pv[k])
+                    run += value_at(L.Q, k + 1) - value_at(L.P, k);
+                    if (run > bestv) { bestv = run; glane = (uint32_t)(k + 1); }
+                }
+            }
+            mvr[(t - 1) >> 6] = make_ulonglong2(L.mvacc, (uint64_t)(uint32_t)i0_blk | ((uint64_t)glane << 32));
+            if (!active) info[sl] = DpInfo{steps, bt, bl, bt >= 0 ? best : NEGV};
+        }
+    }
+}
 
 // ---- trace-back, part 1: the walk.  One lane per read, 16 reads per wave.
 //
@@ -1791,6 +1976,10 @@ struct fzp_alnjob {
     DevBuf<SegOut> segout2[2];
     DevBuf<uint32_t> tb_fallback;                // [0] reads of the last run walked serially after all, [1] repair walks asked for in the chunk at hand, [2] in the whole run
     DevBuf<SegReq> seg_req;
+    DevBuf<int64_t> tbm_off, mvm_off;            // per read: where its masks / move words go in its chunk's buffers, planned in LAUNCH order (longest first)
+    DevBuf<int32_t> swb_list, sw_list;           // per run: the chunk's slots by DP kernel (k_swb: 64 per wave, -1 padded; k_sw: its launch order)
+    std::vector<int32_t> h_swb_list, h_sw_list, h_lpt;
+    std::vector<int64_t> h_swb_at, h_sw_at;      // per chunk (by its first read): where its lists start, and their sizes behind
     DevBuf<int32_t> lpt;                         // per read: the slot (relative to its chunk's first read) that wave / lane number x of the chunk's launches takes --
     int64_t lpt_chunk_steps = -1;                // longest reads first (k_sw, k_tb_walk); rebuilt when the chunking changes
     // record planning: reads grouped by contig (input order inside a contig); built on first use
@@ -2092,6 +2281,7 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
             // launch order inside every chunk of reads: longest first (LPT over the wave slots).  One wave per read, workgroups dispatched in
             // index order: with reads of uneven length in input order the grid's tail is whatever long read happened to come last.
             std::vector<int32_t> ord((size_t)nr), sgo((size_t)nr), sgs, sgi, sgw;
+            std::vector<int64_t> h_tbm((size_t)nr), h_mvm((size_t)nr);
             std::vector<uint8_t> sg1((size_t)nr);
             j->h_seg_base.assign((size_t)nr + 1, 0); j->h_seg_cnt.assign((size_t)nr + 1, 0);
             for (int64_t f = 0; f < nr;) {
@@ -2104,6 +2294,14 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
                 }
                 for (int64_t r = f; r < l; r++) ord[(size_t)r] = (int32_t)(r - f);
                 std::stable_sort(ord.begin() + f, ord.begin() + l, [&](int32_t a, int32_t b) { return j->h_read_len[(size_t)(f + a)] > j->h_read_len[(size_t)(f + b)]; });
+                {   // mask streams in the same order
+                    int64_t acc = 0;
+                    for (int64_t x = 0; x < l - f; x++) {
+                        const int64_t r = f + ord[(size_t)(f + x)];
+                        h_tbm[(size_t)r] = acc; h_mvm[(size_t)r] = (acc >> 6) + x;
+                        acc += j->h_tb_off[(size_t)r + 1] - j->h_tb_off[(size_t)r];
+                    }
+                }
                 // walkers of the segmented trace-back: one per TBS_SEG steps of every read's step capacity, longest reads first
                 j->h_seg_base[(size_t)f] = (int64_t)sgs.size();
                 std::vector<int32_t> w_first((size_t)(l - f));
@@ -2129,6 +2327,9 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
                 f = l;
             }
             FZP_TRY(j->lpt.upload(ord.data(), (size_t)nr, st));
+            j->h_lpt = ord;
+            FZP_TRY(j->tbm_off.upload(h_tbm.data(), (size_t)nr, st)); FZP_TRY(j->mvm_off.upload(h_mvm.data(), (size_t)nr, st));
+            FZP_HIP(hipStreamSynchronize(st));      // (staging vectors)
             FZP_TRY(j->seg_off.upload(sgo.data(), (size_t)nr, st));
             FZP_TRY(j->seg_single.upload(sg1.data(), (size_t)nr, st));
             FZP_TRY(j->seg_order.upload(sgw.data(), sgw.size(), st));
@@ -2147,14 +2348,45 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
         int64_t sum_len = 0;
         for (int64_t r = 0; r < nr; r++) sum_len += j->h_read_len[(size_t)r];
         const int32_t mean_len = (int32_t)std::max<int64_t>(1, sum_len / std::max<int64_t>(nr, 1));
+        // ---- which DP kernel runs which extension (fzalign scores 2 / -4 / -3 are built into the bit-sliced one's cell function)
+        bool use_bits = getenv("FZP_SW_NO_BITS") == nullptr && P.match == 2 && P.mismatch == 4 && P.gap == 3 && !split_rounds && use_lpt;
+        int64_t swb_max_steps = TBS_SINGLE_STEPS;
+        if (const char *e = getenv("FZP_SWB_MAX_STEPS")) { const long g = atol(e); if (g > 0) swb_max_steps = g; }
+        std::vector<int64_t> &swb_at = j->h_swb_at, &sw_at = j->h_sw_at;
+        if (use_bits) {
+            j->h_swb_list.clear(); j->h_sw_list.clear(); swb_at.assign(1, 0); sw_at.assign(1, 0);
+            const int32_t *ordp = j->h_lpt.data();              // the cached longest-first order of every chunk
+            for (int64_t f = 0; f < nr;) {
+                int64_t l = f;
+                while (l < nr && j->h_tb_off[(size_t)l + 1] - j->h_tb_off[(size_t)f] <= chunk_steps) l++;
+                if (l == f) l = f + 1;
+                const bool swb_in_order = getenv("FZP_SWB_INPUT_ORDER") != nullptr;
+                for (int64_t x = 0; x < l - f; x++) {
+                    const int32_t w = swb_in_order ? (int32_t)x : ordp[(size_t)(f + x)];
+                    const int64_t r = f + w;
+                    const Anchor &a = h_anc[(size_t)r];
+                    const int64_t nq = j->h_read_len[(size_t)r] - a.i_a, nt = std::min<int64_t>(j->h_ctg_len[(size_t)j->h_read_ctg[(size_t)r]] - a.c_a, nq + nq / 4 + 64);
+                    if (a.aligned && nq >= 64 && nt >= 64 && nq + nt + 2 <= swb_max_steps) j->h_swb_list.push_back(w); else j->h_sw_list.push_back(w);
+                }
+                while (j->h_swb_list.size() % 64) j->h_swb_list.push_back(-1);
+                swb_at.push_back((int64_t)j->h_swb_list.size()); sw_at.push_back((int64_t)j->h_sw_list.size());
+                f = l;
+            }
+            if (j->h_swb_list.empty()) j->h_swb_list.push_back(-1);
+            if (j->h_sw_list.empty()) j->h_sw_list.push_back(0);
+            FZP_TRY(j->swb_list.upload(j->h_swb_list.data(), j->h_swb_list.size(), st));
+            FZP_TRY(j->sw_list.upload(j->h_sw_list.data(), j->h_sw_list.size(), st));
+        }
         int64_t first = 0;
         int k = 0;
+        int ci = -1;
         bool used[2] = {false, false};
         size_t w_lo = 0;
         while (first < nr) {
             int64_t last = first;
             while (last < nr && j->h_tb_off[(size_t)last + 1] - j->h_tb_off[(size_t)first] <= chunk_steps) last++;
             if (last == first) last = first + 1;
+            ci++;
             // whole rounds first: k_sw runs one wave per read on n_CU x 32 wave slots, and reads of similar length finish round by round.
             // Cutting the launch after the last FULL round lets the trace-back of those reads (HBM / latency bound, few waves) run under the
             // DP of the remainder, which leaves slots free anyway.
@@ -2177,16 +2409,29 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
             FZP_TRY(j->raw2[bi].alloc((size_t)(steps / 16 + 64)));
             {
                 ProfScope ps(ctx, "k1_sw");
+                if (use_bits) {
+                    // every extension goes to one of the two DP kernels: the bit-sliced one (a read per lane) takes those that fit the band on both sides and
+                    // are short enough for its per-step latency; the rest -- the long reads first of all -- run a wave each, started before it
+                    const int64_t b_at = swb_at[(size_t)ci], b_n = swb_at[(size_t)ci + 1] - b_at, w_at = sw_at[(size_t)ci], w_n = sw_at[(size_t)ci + 1] - w_at;
+                    if (w_n > 0)
+                        hipLaunchKernelGGL(no_masks ? k_sw<false> : k_sw<true>, dim3((unsigned)w_n), dim3(64), 0, st, first, w_n, (const int32_t *)nullptr, j->read_ori.p, j->read_woff.p, j->read_len.p, j->read_ctg.p,
+                                           j->ctg_pk.p, j->ctg_woff.p, j->ctg_len.p, j->anc.p, j->tb_off.p, j->tb2[bi].p, j->mvw2[bi].p, P.match, P.mismatch, P.gap, j->info.p, j->tbo.p, j->mvo.p,
+                                           (const int32_t *)(j->sw_list.p + w_at), use_prio ? mean_len : 0, (const int64_t *)j->tbm_off.p, (const int64_t *)j->mvm_off.p);
+                    if (b_n > 0)
+                        hipLaunchKernelGGL(k_swb, dim3((unsigned)(b_n / 64)), dim3(64), 0, st, first, (const int32_t *)(j->swb_list.p + b_at), (const int32_t *)nullptr, j->read_ori.p, j->read_woff.p,
+                                           j->read_len.p, j->read_ctg.p, j->ctg_pk.p, j->ctg_woff.p, j->ctg_len.p, j->anc.p, j->tb_off.p, j->tb2[bi].p, j->mvw2[bi].p, j->info.p, j->tbo.p, j->mvo.p, (const int64_t *)j->tbm_off.p, (const int64_t *)j->mvm_off.p,
+                                           getenv("FZP_SWB_DBG") ? atoi(getenv("FZP_SWB_DBG")) : 0);
+                } else
                 hipLaunchKernelGGL(no_masks ? k_sw<false> : k_sw<true>, dim3((unsigned)cnt), dim3(64), 0, st, first, cnt, (const int32_t *)nullptr, j->read_ori.p, j->read_woff.p, j->read_len.p, j->read_ctg.p,
                                    j->ctg_pk.p, j->ctg_woff.p, j->ctg_len.p, j->anc.p, j->tb_off.p, j->tb2[bi].p, j->mvw2[bi].p, P.match, P.mismatch, P.gap, j->info.p, j->tbo.p, j->mvo.p,
-                                   use_lpt ? (const int32_t *)(j->lpt.p + first) : (const int32_t *)nullptr, use_prio ? mean_len : 0);
+                                   use_lpt ? (const int32_t *)(j->lpt.p + first) : (const int32_t *)nullptr, use_prio ? mean_len : 0, (const int64_t *)nullptr, (const int64_t *)nullptr);
             }
             if (c2 > 0) {     // same kernel over the compacted list, then the better extension of each read survives
                 {
                     ProfScope ps(ctx, "k1_sw2");
                     hipLaunchKernelGGL(k_sw<true>, dim3((unsigned)c2), dim3(64), 0, st, (int64_t)w_lo, c2, j->ridx.p, j->sec_ori.p, j->sec_woff.p, j->read_len.p, j->read_ctg.p,
                                        j->ctg_pk.p, j->ctg_woff.p, j->ctg_len.p, j->anc2.p, j->tb_off2.p, j->tb2[bi].p + 2 * tb_base, j->mvw2[bi].p + mv_base, P.match, P.mismatch,
-                                       P.gap, j->info2.p, (int64_t *)nullptr, (int64_t *)nullptr, (const int32_t *)nullptr, 0);
+                                       P.gap, j->info2.p, (int64_t *)nullptr, (int64_t *)nullptr, (const int32_t *)nullptr, 0, (const int64_t *)nullptr, (const int64_t *)nullptr);
                 }
                 ProfScope ps(ctx, "k1_pick");
                 hipLaunchKernelGGL(k_pick, dim3((unsigned)((c2 + 255) / 256)), dim3(256), 0, st, (int64_t)w_lo, (int64_t)w_hi, j->ridx.p, j->anc2.p, j->info2.p, j->tb_off2.p,
@@ -2205,7 +2450,7 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
                                    j->bq_off.p, j->bt_off.p, j->bq.p, j->bt.p, j->anc_b.p, j->b_len.p, j->b_tlen.p);
                 hipLaunchKernelGGL(k_sw<true>, dim3((unsigned)cnt), dim3(64), 0, st, first, cnt, (const int32_t *)nullptr, j->bq.p, j->bq_off.p, j->b_len.p, j->b_iota.p,
                                    j->bt.p, j->bt_off.p, j->b_tlen.p, j->anc_b.p, j->tb_off_b.p, j->tb_b2[bi].p, j->mvw_b2[bi].p, P.match, P.mismatch, P.gap, j->info_b.p,
-                                   j->tbo_b.p, j->mvo_b.p, (const int32_t *)nullptr, 0);
+                                   j->tbo_b.p, j->mvo_b.p, (const int32_t *)nullptr, 0, (const int64_t *)nullptr, (const int64_t *)nullptr);
             }
             FZP_HIP(hipEventRecord(j->ev_bk[bi], st));
             FZP_HIP(hipStreamWaitEvent(st2, j->ev_sw[bi], 0));
