@@ -751,7 +751,8 @@ __global__ void __launch_bounds__(64) k_sw(int64_t first, int64_t count, const i
                                             const uint32_t *__restrict__ ctg_pk, const int64_t *__restrict__ ctg_woff, const int64_t *__restrict__ ctg_len,
                                             const Anchor *__restrict__ anc, const int64_t *__restrict__ tb_off, uint2 *__restrict__ tb, ulonglong2 *__restrict__ mvw,
                                             int match, int mismatch, int gap, DpInfo *__restrict__ info, int64_t *__restrict__ tbo, int64_t *__restrict__ mvo,
-                                            const int32_t *__restrict__ order, int32_t prio_len, const int64_t *__restrict__ m_off, const int64_t *__restrict__ mv_off) {
+                                            const int32_t *__restrict__ order, int32_t prio_len, const int64_t *__restrict__ m_off, const int64_t *__restrict__ mv_off,
+                                            const uint8_t *__restrict__ skip) {
     const int lane = lane_id();
     // wave-uniform on purpose: everything indexed by the read then lives in SGPRs / scalar loads
     const int64_t wq = (int64_t)blockIdx.x;   // one wave per workgroup: a finished read frees its slot at once
@@ -761,6 +762,7 @@ __global__ void __launch_bounds__(64) k_sw(int64_t first, int64_t count, const i
     const int64_t wv = order ? (int64_t)order[wq] : wq;
     // slot = candidate: the read itself for first candidates, an entry of the compacted list for second ones
     const int64_t sl = first + wv;
+    if (skip && skip[sl]) return;              // the bit-sliced kernel ran this slot's extension
     const int64_t r = ridx ? ridx[sl] : sl;
     const Anchor a = anc[sl];
     // where the slot's masks and move words go in the chunk's buffers: in slot order, or (m_off) where the job planned them -- in launch order, so that the
@@ -972,13 +974,14 @@ __device__ __forceinline__ void swb_step(SwbLane &L, const int32_t t, ulonglong2
     L.down = (CHECKED && (t + 1) < 64) ? (uint32_t)(((t + 1) & 1) == 0) : (uint32_t)(L.E2 >= 0);
 }
 
-__global__ void __launch_bounds__(64) k_swb(int64_t first, const int32_t *__restrict__ list, const int32_t *__restrict__ ridx, const uint32_t *__restrict__ read_ori,
+__global__ void __launch_bounds__(64) k_swb(int64_t first, int64_t count, const int32_t *__restrict__ list, const int32_t *__restrict__ ridx, const uint32_t *__restrict__ read_ori,
                                              const int64_t *__restrict__ ori_woff, const int32_t *__restrict__ read_len, const int32_t *__restrict__ read_ctg,
                                              const uint32_t *__restrict__ ctg_pk, const int64_t *__restrict__ ctg_woff, const int64_t *__restrict__ ctg_len,
                                              const Anchor *__restrict__ anc, const int64_t *__restrict__ tb_off, uint2 *__restrict__ tb, ulonglong2 *__restrict__ mvw,
-                                             DpInfo *__restrict__ info, int64_t *__restrict__ tbo, int64_t *__restrict__ mvo, const int64_t *__restrict__ m_off, const int64_t *__restrict__ mv_off, int dbg) {
+                                             DpInfo *__restrict__ info, int64_t *__restrict__ tbo, int64_t *__restrict__ mvo, const int64_t *__restrict__ m_off, const int64_t *__restrict__ mv_off, uint8_t *__restrict__ handled, int32_t steps_limit, int dbg) {
     using namespace swb;
-    const int64_t wv = list[(int64_t)blockIdx.x * 64 + threadIdx.x];       // the lane's slot in the chunk, -1: none
+    const int64_t li = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const int64_t wv = li < count ? list[li] : -1;       // the lane's slot in the chunk, -1: none
     bool active = wv >= 0;
     const int64_t sl = first + (active ? wv : 0);
     const int64_t r = ridx ? ridx[sl] : sl;
@@ -988,14 +991,19 @@ __global__ void __launch_bounds__(64) k_swb(int64_t first, const int32_t *__rest
     const int64_t toff = m_off ? m_off[sl] : tb_off[sl] - tb_off[first], moff = m_off ? mv_off[sl] : (toff >> 6) + (active ? wv : 0);
     ulonglong2 *tbr = (ulonglong2 *)tb + toff;
     ulonglong2 *mvr = mvw + moff;
-    if (active && tbo) { tbo[sl] = toff; mvo[sl] = moff; }
-    if (active && !a.aligned) { info[sl] = DpInfo{0, -1, 0, NEGV}; active = false; }
     const int c_idx = read_ctg[r];
     const int64_t n = read_len[r];
     const int32_t nq = (int32_t)(n - a.i_a);
     int64_t ntl = ctg_len[c_idx] - a.c_a;
     if (ntl > (int64_t)nq + nq / 4 + 64) ntl = (int64_t)nq + nq / 4 + 64;
     const int32_t nt = (int32_t)ntl;
+    if (handled) {   // the caller did not sort the slots by kernel: this one takes what fits it and says so, k_sw runs the rest
+        const bool mine = active && (!a.aligned || (nq >= 64 && nt >= 64 && nq + nt + 2 <= steps_limit));
+        if (active) handled[sl] = mine ? 1 : 0;
+        active = mine;
+    }
+    if (active && tbo) { tbo[sl] = toff; mvo[sl] = moff; }
+    if (active && !a.aligned) { info[sl] = DpInfo{0, -1, 0, NEGV}; active = false; }
     const uint32_t *qpk = read_ori + ori_woff[sl];
     const uint32_t *tpk = ctg_pk + ctg_woff[c_idx];
     const int64_t qb = a.i_a, tbase = a.c_a;
@@ -1976,6 +1984,7 @@ struct fzp_alnjob {
     DevBuf<SegOut> segout2[2];
     DevBuf<uint32_t> tb_fallback;                // [0] reads of the last run walked serially after all, [1] repair walks asked for in the chunk at hand, [2] in the whole run
     DevBuf<SegReq> seg_req;
+    DevBuf<uint8_t> b_handled;                   // per read: its backward extension ran in the bit-sliced kernel
     DevBuf<int64_t> tbm_off, mvm_off;            // per read: where its masks / move words go in its chunk's buffers, planned in LAUNCH order (longest first)
     DevBuf<int32_t> swb_list, sw_list;           // per run: the chunk's slots by DP kernel (k_swb: 64 per wave, -1 padded; k_sw: its launch order)
     std::vector<int32_t> h_swb_list, h_sw_list, h_lpt;
@@ -2002,7 +2011,7 @@ struct fzp_alnjob {
     DevBuf<ulonglong2> mvw_b2[2];
     DevBuf<WalkOut> wout_b;
     std::vector<int64_t> h_tb_off_b;
-    hipEvent_t ev_sw[2] = {nullptr, nullptr}, ev_tb[2] = {nullptr, nullptr}, ev_bk[2] = {nullptr, nullptr};
+    hipEvent_t ev_sw[2] = {nullptr, nullptr}, ev_tb[2] = {nullptr, nullptr}, ev_bk[2] = {nullptr, nullptr}, ev_l[2] = {nullptr, nullptr};
     DevBuf<fzp_aln_summary> summ;
     bool done = false;
 };
@@ -2016,7 +2025,7 @@ extern "C" void fzp_align_params_default(fzp_align_params *p) {
 extern "C" void fzp_align_destroy(fzp_ctx *ctx, fzp_alnjob *job) {
     if (!job) return;
     if (ctx) { (void)fzp_bind(ctx); (void)hipStreamSynchronize(ctx->stream); (void)hipStreamSynchronize(ctx->stream2); }
-    for (int k = 0; k < 2; k++) { if (job->ev_sw[k]) (void)hipEventDestroy(job->ev_sw[k]); if (job->ev_tb[k]) (void)hipEventDestroy(job->ev_tb[k]); if (job->ev_bk[k]) (void)hipEventDestroy(job->ev_bk[k]); }
+    for (int k = 0; k < 2; k++) { if (job->ev_sw[k]) (void)hipEventDestroy(job->ev_sw[k]); if (job->ev_tb[k]) (void)hipEventDestroy(job->ev_tb[k]); if (job->ev_bk[k]) (void)hipEventDestroy(job->ev_bk[k]); if (job->ev_l[k]) (void)hipEventDestroy(job->ev_l[k]); }
     delete job;
 }
 
@@ -2275,7 +2284,7 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
         FZP_TRY(j->wout.alloc((size_t)nr));
         FZP_TRY(j->tb_fallback.alloc(4));
         FZP_TRY(j->tb_fallback.zero(4, st));
-        if (!j->ev_sw[0]) for (int k = 0; k < 2; k++) { FZP_HIP(hipEventCreateWithFlags(&j->ev_sw[k], hipEventDisableTiming)); FZP_HIP(hipEventCreateWithFlags(&j->ev_tb[k], hipEventDisableTiming)); FZP_HIP(hipEventCreateWithFlags(&j->ev_bk[k], hipEventDisableTiming)); }
+        if (!j->ev_sw[0]) for (int k = 0; k < 2; k++) { FZP_HIP(hipEventCreateWithFlags(&j->ev_l[k], hipEventDisableTiming)); FZP_HIP(hipEventCreateWithFlags(&j->ev_sw[k], hipEventDisableTiming)); FZP_HIP(hipEventCreateWithFlags(&j->ev_tb[k], hipEventDisableTiming)); FZP_HIP(hipEventCreateWithFlags(&j->ev_bk[k], hipEventDisableTiming)); }
         hipStream_t st2 = ctx->stream2;
         if (j->lpt_chunk_steps != chunk_steps || split_rounds) {
             // launch order inside every chunk of reads: longest first (LPT over the wave slots).  One wave per read, workgroups dispatched in
@@ -2413,25 +2422,30 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
                     // every extension goes to one of the two DP kernels: the bit-sliced one (a read per lane) takes those that fit the band on both sides and
                     // are short enough for its per-step latency; the rest -- the long reads first of all -- run a wave each, started before it
                     const int64_t b_at = swb_at[(size_t)ci], b_n = swb_at[(size_t)ci + 1] - b_at, w_at = sw_at[(size_t)ci], w_n = sw_at[(size_t)ci + 1] - w_at;
-                    if (w_n > 0)
-                        hipLaunchKernelGGL(no_masks ? k_sw<false> : k_sw<true>, dim3((unsigned)w_n), dim3(64), 0, st, first, w_n, (const int32_t *)nullptr, j->read_ori.p, j->read_woff.p, j->read_len.p, j->read_ctg.p,
+                    if (w_n > 0) {   // on its own stream: the two kernels share the chip (this one latency-bound waves of long reads, the other one wave per SIMD)
+                        FZP_HIP(hipEventRecord(j->ev_l[0], st));
+                        FZP_HIP(hipStreamWaitEvent(ctx->stream3, j->ev_l[0], 0));
+                        hipLaunchKernelGGL(no_masks ? k_sw<false> : k_sw<true>, dim3((unsigned)w_n), dim3(64), 0, ctx->stream3, first, w_n, (const int32_t *)nullptr, j->read_ori.p, j->read_woff.p, j->read_len.p, j->read_ctg.p,
                                            j->ctg_pk.p, j->ctg_woff.p, j->ctg_len.p, j->anc.p, j->tb_off.p, j->tb2[bi].p, j->mvw2[bi].p, P.match, P.mismatch, P.gap, j->info.p, j->tbo.p, j->mvo.p,
-                                           (const int32_t *)(j->sw_list.p + w_at), use_prio ? mean_len : 0, (const int64_t *)j->tbm_off.p, (const int64_t *)j->mvm_off.p);
+                                           (const int32_t *)(j->sw_list.p + w_at), use_prio ? mean_len : 0, (const int64_t *)j->tbm_off.p, (const int64_t *)j->mvm_off.p, (const uint8_t *)nullptr);
+                        FZP_HIP(hipEventRecord(j->ev_l[1], ctx->stream3));
+                    }
                     if (b_n > 0)
-                        hipLaunchKernelGGL(k_swb, dim3((unsigned)(b_n / 64)), dim3(64), 0, st, first, (const int32_t *)(j->swb_list.p + b_at), (const int32_t *)nullptr, j->read_ori.p, j->read_woff.p,
+                        hipLaunchKernelGGL(k_swb, dim3((unsigned)(b_n / 64)), dim3(64), 0, st, first, b_n, (const int32_t *)(j->swb_list.p + b_at), (const int32_t *)nullptr, j->read_ori.p, j->read_woff.p,
                                            j->read_len.p, j->read_ctg.p, j->ctg_pk.p, j->ctg_woff.p, j->ctg_len.p, j->anc.p, j->tb_off.p, j->tb2[bi].p, j->mvw2[bi].p, j->info.p, j->tbo.p, j->mvo.p, (const int64_t *)j->tbm_off.p, (const int64_t *)j->mvm_off.p,
-                                           getenv("FZP_SWB_DBG") ? atoi(getenv("FZP_SWB_DBG")) : 0);
+                                           (uint8_t *)nullptr, 0x7fffffff, getenv("FZP_SWB_DBG") ? atoi(getenv("FZP_SWB_DBG")) : 0);
+                    if (w_n > 0) FZP_HIP(hipStreamWaitEvent(st, j->ev_l[1], 0));
                 } else
                 hipLaunchKernelGGL(no_masks ? k_sw<false> : k_sw<true>, dim3((unsigned)cnt), dim3(64), 0, st, first, cnt, (const int32_t *)nullptr, j->read_ori.p, j->read_woff.p, j->read_len.p, j->read_ctg.p,
                                    j->ctg_pk.p, j->ctg_woff.p, j->ctg_len.p, j->anc.p, j->tb_off.p, j->tb2[bi].p, j->mvw2[bi].p, P.match, P.mismatch, P.gap, j->info.p, j->tbo.p, j->mvo.p,
-                                   use_lpt ? (const int32_t *)(j->lpt.p + first) : (const int32_t *)nullptr, use_prio ? mean_len : 0, (const int64_t *)nullptr, (const int64_t *)nullptr);
+                                   use_lpt ? (const int32_t *)(j->lpt.p + first) : (const int32_t *)nullptr, use_prio ? mean_len : 0, (const int64_t *)nullptr, (const int64_t *)nullptr, (const uint8_t *)nullptr);
             }
             if (c2 > 0) {     // same kernel over the compacted list, then the better extension of each read survives
                 {
                     ProfScope ps(ctx, "k1_sw2");
                     hipLaunchKernelGGL(k_sw<true>, dim3((unsigned)c2), dim3(64), 0, st, (int64_t)w_lo, c2, j->ridx.p, j->sec_ori.p, j->sec_woff.p, j->read_len.p, j->read_ctg.p,
                                        j->ctg_pk.p, j->ctg_woff.p, j->ctg_len.p, j->anc2.p, j->tb_off2.p, j->tb2[bi].p + 2 * tb_base, j->mvw2[bi].p + mv_base, P.match, P.mismatch,
-                                       P.gap, j->info2.p, (int64_t *)nullptr, (int64_t *)nullptr, (const int32_t *)nullptr, 0, (const int64_t *)nullptr, (const int64_t *)nullptr);
+                                       P.gap, j->info2.p, (int64_t *)nullptr, (int64_t *)nullptr, (const int32_t *)nullptr, 0, (const int64_t *)nullptr, (const int64_t *)nullptr, (const uint8_t *)nullptr);
                 }
                 ProfScope ps(ctx, "k1_pick");
                 hipLaunchKernelGGL(k_pick, dim3((unsigned)((c2 + 255) / 256)), dim3(256), 0, st, (int64_t)w_lo, (int64_t)w_hi, j->ridx.p, j->anc2.p, j->info2.p, j->tb_off2.p,
@@ -2448,9 +2462,17 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
                 ProfScope ps(ctx, "k1_back");
                 hipLaunchKernelGGL(k_back_prep, dim3((unsigned)cnt), dim3(256), 0, st, first, j->anc.p, j->read_ctg.p, j->read_ori.p, j->read_woff.p, j->ctg_pk.p, j->ctg_woff.p,
                                    j->bq_off.p, j->bt_off.p, j->bq.p, j->bt.p, j->anc_b.p, j->b_len.p, j->b_tlen.p);
+                // the backward extensions are short (an anchor sits a few hundred bases into its read): the bit-sliced kernel takes every one that spans the band
+                // (lanes in slot order: their mask streams lie side by side), k_sw the rest -- which of the two is decided on the device, the winner's anchor never came to the host
+                if (use_bits) {
+                    FZP_TRY(j->b_handled.alloc((size_t)nr));
+                    hipLaunchKernelGGL(k_swb, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, st, first, cnt, (const int32_t *)j->b_iota.p, (const int32_t *)nullptr, j->bq.p, j->bq_off.p, j->b_len.p, j->b_iota.p,
+                                       j->bt.p, j->bt_off.p, j->b_tlen.p, j->anc_b.p, j->tb_off_b.p, j->tb_b2[bi].p, j->mvw_b2[bi].p, j->info_b.p, j->tbo_b.p, j->mvo_b.p,
+                                       (const int64_t *)nullptr, (const int64_t *)nullptr, j->b_handled.p, (int32_t)swb_max_steps, 0);
+                }
                 hipLaunchKernelGGL(k_sw<true>, dim3((unsigned)cnt), dim3(64), 0, st, first, cnt, (const int32_t *)nullptr, j->bq.p, j->bq_off.p, j->b_len.p, j->b_iota.p,
                                    j->bt.p, j->bt_off.p, j->b_tlen.p, j->anc_b.p, j->tb_off_b.p, j->tb_b2[bi].p, j->mvw_b2[bi].p, P.match, P.mismatch, P.gap, j->info_b.p,
-                                   j->tbo_b.p, j->mvo_b.p, (const int32_t *)nullptr, 0, (const int64_t *)nullptr, (const int64_t *)nullptr);
+                                   j->tbo_b.p, j->mvo_b.p, (const int32_t *)nullptr, 0, (const int64_t *)nullptr, (const int64_t *)nullptr, use_bits ? (const uint8_t *)j->b_handled.p : (const uint8_t *)nullptr);
             }
             FZP_HIP(hipEventRecord(j->ev_bk[bi], st));
             FZP_HIP(hipStreamWaitEvent(st2, j->ev_sw[bi], 0));

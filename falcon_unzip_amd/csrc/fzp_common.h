@@ -107,6 +107,7 @@ struct fzp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;   // trace-back of chunk k runs here while the DP of chunk k+1 runs on `stream`
+    hipStream_t stream3 = nullptr;   // K1: the wave-per-read DP of the long reads runs here beside the bit-sliced DP of the others on `stream`
     bool prof = false;
     std::map<std::string, ProfEntry> prof_tab;
     std::vector<PendingEvent> pending;

@@ -264,6 +264,7 @@ extern "C" int fzp_ctx_create(int device_id, unsigned flags, fzp_ctx **out) {
     t_pool = c->pool;
     hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (se == hipSuccess) se = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
+    if (se == hipSuccess) se = hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking);
     if (se != hipSuccess) {
         fzp_set_error("hipStreamCreate: %s", hipGetErrorString(se));
         delete c;
@@ -281,6 +282,7 @@ extern "C" void fzp_ctx_destroy(fzp_ctx *ctx) {
     (void)fzp_bind(ctx);
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipStreamSynchronize(ctx->stream2);
+    if (ctx->stream3) (void)hipStreamSynchronize(ctx->stream3);
     for (auto &p : ctx->pending) {
         (void)hipEventDestroy(p.a);
         (void)hipEventDestroy(p.b);
@@ -293,6 +295,7 @@ extern "C" void fzp_ctx_destroy(fzp_ctx *ctx) {
     if (ctx->ev_pf_done) (void)hipEventDestroy(ctx->ev_pf_done);
     trim_pool(*ctx->pool);
     t_pool.reset();
+    if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
     (void)hipStreamDestroy(ctx->stream2);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -308,6 +311,7 @@ extern "C" int fzp_mem_info(fzp_ctx *ctx, size_t *free_bytes, size_t *total_byte
 extern "C" int fzp_ctx_synchronize(fzp_ctx *ctx) {
     FZP_HIP(hipStreamSynchronize(ctx->stream));
     FZP_HIP(hipStreamSynchronize(ctx->stream2));
+    FZP_HIP(hipStreamSynchronize(ctx->stream3));
     return FZP_OK;
 }
 
