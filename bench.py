@@ -47,14 +47,9 @@ sys.path.insert(0, REPO)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 SW_BYTES_PER_CELL = 0.25         # algorithmic: 2 trace-back bits per cell (16 B per 64-cell step); sequence
                                  # reads add 2 bits per band step, i.e. < 0.01 B/cell
-# VALU view of k1_sw, from measurements kept under profiles/ (not from assumptions):
-#   profiles/r2_sq_counters_k1.json  SQ_INSTS_VALU / band steps of the launch = 13.93 VALU instructions per 64-cell step
-#                                    (12.5 in the asm interior block + block set-up + the checked first / last steps)
-#   profiles/r2_valu_issue_ubench.txt  wave64 issue cost by instruction class at 2..8 waves per SIMD: v_add_u32 / v_sub / logic ops
-#                                    2.4 cycles; v_max_i32, every DPP form, v_cmp (SGPR or VCC result), v_max3, v_readlane, v_writelane 4.15-4.2
-# k_sw's step is 10.9 instructions of the 4.2-cycle class + 3 of the 2.4-cycle class -> 53 cycles per step per SIMD
-SW_VALU_PER_STEP = 13.93
-SW_CYCLES_PER_STEP_AT_CLASS_RATES = 10.93 * 4.2 + 3.0 * 2.4
+# VALU view of k1_sw (the DP stage: k_swb, the bit-sliced kernel with one read per lane, + k_sw for long reads), from measurements kept under profiles/:
+#   profiles/k1_sw_counters.json     SQ_INSTS_VALU of both kernels / 64-cell band steps of the bench step (k_swb: ~135 wave instructions per step of 64 reads)
+SW_VALU_PER_STEP = 2.2
 N_SIMD, CLK_GHZ = 1024, 2.4
 
 
@@ -198,30 +193,30 @@ def cpu_baseline(contigs, blob, off, read_ctg, ids, job, hip_summ, budget_s=30.0
 
 
 def roofline(cells_per_launch, sw_avg_ms, sw_launches, dp_gcells, traffic):
-    """k1_sw, the dominant kernel.  It is bound by VALU issue (integer DP; no MFMA, 0.25 algorithmic B/cell), so the headline fraction is
-    wave64 VALU instructions issued per second against the chip's issue peak: 256 CU x 4 SIMD x 2.4 GHz / 2 cycles per wave64 instruction
-    (SIMD-32 halves, MI355X_MICROARCH.md) = 1 228.8 G inst/s.  Instructions per band step come from SQ_INSTS_VALU (profiles/, named in
-    `source`).  The HBM view (north_star's figure) sits beside it in `hbm`; `traffic` = measured HBM bytes per launch (FETCH + WRITE)."""
-    counters = {"valu_per_step": SW_VALU_PER_STEP, "source": "profiles/r2_sq_counters_k1.json"}
+    """k1_sw, the dominant stage: the banded DP (k_swb, bit-sliced, one read per lane; k_sw, one wave per read, for long reads -- DESIGN section 5).
+    Its only bulk memory traffic is the trace-back masks it writes, 0.25 algorithmic B per cell (2 bits), so the headline fraction is the north star's:
+    algorithmic bytes per launch / the stage's duration against the HBM peak.  Beside it `valu`: wave64 VALU instructions per second (SQ_INSTS_VALU from
+    profiles/, named in `counter_source`) against the chip's issue peak, 256 CU x 4 SIMD x 2.4 GHz / 2 cycles per wave64 instruction on a SIMD-32
+    (MI355X_MICROARCH.md).  `traffic` = measured HBM bytes of the largest DP dispatch (FETCH + WRITE)."""
+    counters = {"valu_per_step": SW_VALU_PER_STEP, "source": "(default: no profiles/k1_sw_counters.json)"}
     cf = os.path.join(REPO, "profiles", "k1_sw_counters.json")
     if os.path.exists(cf):
         with open(cf) as f:
             counters = json.load(f)
     per_step = float(counters["valu_per_step"])
     steps_per_s = dp_gcells * 1e9 / 64.0
-    achieved = steps_per_s * per_step / 1e9
-    peak = N_SIMD * CLK_GHZ / 2.0
-    mix_peak = N_SIMD * CLK_GHZ * SW_VALU_PER_STEP / SW_CYCLES_PER_STEP_AT_CLASS_RATES
+    valu = steps_per_s * per_step / 1e9
+    valu_peak = N_SIMD * CLK_GHZ / 2.0
     gbs = cells_per_launch * SW_BYTES_PER_CELL / (sw_avg_ms * 1e-3) / 1e9 if sw_avg_ms else 0.0
-    return {"bound": "valu", "kernel": "k1_sw", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "G wave64-inst/s",
-            "frac": round(achieved / peak, 4), "traffic": traffic, "avg_launch_ms": round(sw_avg_ms, 3), "launches": int(sw_launches),
-            "valu_insts_per_band_step": per_step, "counter_source": counters.get("source"),
+    return {"bound": "hbm", "kernel": "k1_sw (k_swb + k_sw)", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+            "traffic": traffic, "avg_launch_ms": round(sw_avg_ms, 3), "launches": int(sw_launches), "bytes_per_cell": SW_BYTES_PER_CELL,
+            "note": "algorithmic 0.25 B/cell: the 2 trace-back bits of every cell, written once; at this job size the kernel runs one wave per SIMD (625 waves of 64 reads) and is "
+                    "bound by that wave's issue latency, not yet by either peak",
+            "valu": {"achieved": round(valu, 2), "peak": round(valu_peak, 1), "unit": "G wave64-inst/s", "frac": round(valu / valu_peak, 4),
+                     "valu_insts_per_band_step": per_step, "counter_source": counters.get("source")},
             "ops_view": {"int_ops_per_cell": 12, "achieved_tlaneop": round(dp_gcells * 12 / 1e3, 2), "peak_tlaneop": round(256 * 4 * 32 * CLK_GHZ / 1e3, 2),
-                         "frac": round(dp_gcells * 12 / (256 * 4 * 32 * CLK_GHZ), 4), "note": "SURVEY 8d: 12 int ops per cell against 256 CU x 4 SIMD x 32 lanes x 2.4 GHz"},
-            "hbm": {"achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "bytes_per_cell": SW_BYTES_PER_CELL,
-                    "note": "algorithmic 0.25 B/cell (2 trace-back bits): small by construction"},
-            "valu_mix_ceiling": {"peak": round(mix_peak, 2), "frac": round(achieved / mix_peak, 4),
-                                 "note": "issue rate this instruction mix can reach at the per-class costs of tools/ubench/valu_issue.hip (not the chip's peak)"}}
+                         "frac": round(dp_gcells * 12 / (256 * 4 * 32 * CLK_GHZ), 4),
+                         "note": "SURVEY 8d: 12 int ops per cell against 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (the bit-sliced kernel spends ~2 lane-ops per cell)"}}
 
 
 def shaped_leg(eng, inp):

@@ -946,7 +946,7 @@ __device__ __forceinline__ void swb_step(SwbLane &L, const int32_t t, ulonglong2
     }
     const uint64_t f = ((uint64_t)((sd & L.pdown) << 31) << 32) | (uint64_t)(sr & (1u - L.pdown));      // two moves the same way: the edge lane's diagonal predecessor is outside the band
     uint64_t D, G;
-    cells(xm, f, 0ull - (uint64_t)sd, p, q, &L.P, &L.Q, &D, &G);
+    cells<uint64_t>(xm, f, (uint64_t)0 - (uint64_t)sd, p, q, &L.P, &L.Q, &D, &G);
     rec = make_ulonglong2(D, G);
     L.mvacc |= (uint64_t)sd << (t & 63);
     // the edge cells' scores: every lane's cell moved down (its vertical difference) or right (its horizontal one)

@@ -28,6 +28,17 @@ namespace swb {
 // three-input boolean function by truth table: bit (a << 2 | b << 1 | c) of TT (the v_bitop3_b32 convention: evaluate the formula on TA, TB, TC)
 constexpr uint8_t TA = 0xF0, TB = 0xCC, TC = 0xAA;
 template <uint8_t TT>
+FZP_HD uint32_t lut3(uint32_t a, uint32_t b, uint32_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_bitop3_b32(a, b, c, TT);
+#else
+    uint32_t r = 0;
+    for (int m = 0; m < 8; m++)
+        if ((TT >> m) & 1) r |= ((m & 4) ? a : ~a) & ((m & 2) ? b : ~b) & ((m & 1) ? c : ~c);
+    return r;
+#endif
+}
+template <uint8_t TT>
 FZP_HD uint64_t lut3(uint64_t a, uint64_t b, uint64_t c) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const uint32_t lo = __builtin_amdgcn_bitop3_b32((uint32_t)a, (uint32_t)b, (uint32_t)c, TT);
@@ -41,16 +52,19 @@ FZP_HD uint64_t lut3(uint64_t a, uint64_t b, uint64_t c) {
 #endif
 }
 
-struct Planes { uint64_t v0, v1, v2; };      // a value 0..4 per bit position: v0 + 2 v1 + 4 v2
+template <class W> struct PlanesT { W v0, v1, v2; };      // a value 0..4 per bit position: v0 + 2 v1 + 4 v2
+using Planes = PlanesT<uint64_t>;                        // 64 cells of a band in one lane (k_swb)
+using Planes32 = PlanesT<uint32_t>;                      // half a band per lane (k_swb2)
 
 // a -. b = max(a - b, 0) on planes (a, b in 0..4); *borrow = (a < b)
-FZP_HD Planes monus(const Planes a, const Planes b, uint64_t *borrow) {
+template <class W>
+FZP_HD PlanesT<W> monus(const PlanesT<W> a, const PlanesT<W> b, W *borrow) {
     constexpr uint8_t BORROW = (uint8_t)((~TA & TB) | (~(TA ^ TB) & TC));       // borrow out of a - b - c
     constexpr uint8_t XOR3 = (uint8_t)(TA ^ TB ^ TC);
-    const uint64_t br0 = ~a.v0 & b.v0;
-    const uint64_t br1 = lut3<BORROW>(a.v1, b.v1, br0);
-    const uint64_t B = lut3<BORROW>(a.v2, b.v2, br1);
-    Planes r;
+    const W br0 = ~a.v0 & b.v0;
+    const W br1 = lut3<BORROW>(a.v1, b.v1, br0);
+    const W B = lut3<BORROW>(a.v2, b.v2, br1);
+    PlanesT<W> r;
     r.v0 = lut3<(uint8_t)((TA ^ TB) & ~TC)>(a.v0, b.v0, B);
     r.v1 = lut3<XOR3>(a.v1, b.v1, br0) & ~B;
     r.v2 = lut3<XOR3>(a.v2, b.v2, br1) & ~B;
@@ -62,16 +76,17 @@ FZP_HD Planes monus(const Planes a, const Planes b, uint64_t *borrow) {
 // p, q: the neighbours' planes lined up with the cells (already shifted).  Returns the cells' planes and the two trace-back masks of the step:
 // D = diagonal chosen, G = "the gap comes from the same lane of the previous step" (the cell above after DOWN, the one to the left after RIGHT;
 // defined where D = 0, the only place the walk looks at it).
-FZP_HD void cells(const uint64_t xm, const uint64_t f, const uint64_t dn, const Planes p, const Planes q, Planes *Pv, Planes *Qv, uint64_t *D, uint64_t *G) {
-    const uint64_t x = xm | f;                       // "not a match" for the value logic
-    Planes ph, qh;                                   // match ? 4 : p
+template <class W>
+FZP_HD void cells(const W xm, const W f, const W dn, const PlanesT<W> p, const PlanesT<W> q, PlanesT<W> *Pv, PlanesT<W> *Qv, W *D, W *G) {
+    const W x = xm | f;                              // "not a match" for the value logic
+    PlanesT<W> ph, qh;                               // match ? 4 : p
     ph.v0 = p.v0 & x; ph.v1 = p.v1 & x; ph.v2 = p.v2 | ~x;
     qh.v0 = q.v0 & x; qh.v1 = q.v1 & x; qh.v2 = q.v2 | ~x;
-    uint64_t b_pq, b_qp;
-    Planes P = monus(ph, q, &b_pq), Q = monus(qh, p, &b_qp);
-    const uint64_t tp = p.v1 | p.v2, tq = q.v1 | q.v2;
-    const uint64_t le1 = ~(tp | tq);                                                 // p <= 1 and q <= 1
-    const uint64_t z = lut3<(uint8_t)(TA & ~TB & ~TC)>(le1, p.v0, q.v0) & xm & ~f;   // mismatch with p = q = 0: M = 1
+    W b_pq, b_qp;
+    PlanesT<W> P = monus(ph, q, &b_pq), Q = monus(qh, p, &b_qp);
+    const W tp = p.v1 | p.v2, tq = q.v1 | q.v2;
+    const W le1 = ~(tp | tq);                                                 // p <= 1 and q <= 1
+    const W z = lut3<(uint8_t)(TA & ~TB & ~TC)>(le1, p.v0, q.v0) & xm & ~f;   // mismatch with p = q = 0: M = 1
     P.v0 |= z; Q.v0 |= z;
     *Pv = P; *Qv = Q;
     *D = lut3<(uint8_t)(~TA & (~TB | TC))>(f, xm, le1);                              // ~f & (match | le1)
@@ -79,6 +94,41 @@ FZP_HD void cells(const uint64_t xm, const uint64_t f, const uint64_t dn, const 
 }
 
 // value 0..4 at bit position k of planes
-FZP_HD int32_t value_at(const Planes v, int k) { return (int32_t)(((v.v0 >> k) & 1) | (((v.v1 >> k) & 1) << 1) | (((v.v2 >> k) & 1) << 2)); }
+template <class W>
+FZP_HD int32_t value_at(const PlanesT<W> v, int k) { return (int32_t)(((v.v0 >> k) & 1) | (((v.v1 >> k) & 1) << 1) | (((v.v2 >> k) & 1) << 2)); }
+
+// ---- half a band per lane (k_swb2): lanes 2r and 2r+1 share a read.  The LOW lane holds cells 0..31 with cell c at bit c, the HIGH lane cells 32..63 MIRRORED
+// (cell c at bit 63 - c) and TRANSPOSED (P and Q swap roles, DOWN and RIGHT swap roles): the recurrence is symmetric under that, so both lanes run the same
+// code on "my move" (RIGHT for the low lane: a contig base enters at cell 0; DOWN for the high lane: a read base enters at cell 63 -- bit 0 in both) and the
+// "other move".  Planes: A shifts on my move (low: P, high: Q), B on the other one (low: Q, high: P); windows: Wm = the sequence that enters in this lane, Wo = the
+// other.  What crosses the middle of the band -- the bit a left shift pushes out of A / Wm at bit 31 -- enters the partner's B / Wo at ITS bit 31.
+struct Half {
+    Planes32 A, B;
+    uint32_t Wm0, Wm1, Wo0, Wo1;
+};
+struct HalfOut { uint32_t a0, a1, a2, w0, w1; };      // bit 31 of A's planes and of Wm's, as 0 / 1: what the partner takes in on its other move
+
+FZP_HD HalfOut half_out(const Half &h) { return HalfOut{h.A.v0 >> 31, h.A.v1 >> 31, h.A.v2 >> 31, h.Wm0 >> 31, h.Wm1 >> 31}; }
+
+// my = 1: this step is my move (the partner's other move); base = the 2-bit code entering (my move only); in = the partner's half_out before the step;
+// f = 1: two moves of my kind in a row (the edge cell's diagonal predecessor is outside the band); bad = cells whose bases lie past an end (tail of the extension).
+// Returns the step's masks for this half (bit = this lane's bit order) and leaves the new planes in h.
+FZP_HD void half_step(Half &h, const uint32_t my, const uint32_t base, const HalfOut in, const uint32_t f, const uint32_t bad, uint32_t *D, uint32_t *G) {
+    const uint32_t ot = 1u - my;
+    h.A.v0 <<= my; h.A.v1 <<= my; h.A.v2 <<= my;
+    h.Wm0 = (h.Wm0 << my) | (base & 1u); h.Wm1 = (h.Wm1 << my) | (base >> 1);
+    h.B.v0 = (h.B.v0 >> ot) | ((in.a0 & ot) << 31); h.B.v1 = (h.B.v1 >> ot) | ((in.a1 & ot) << 31); h.B.v2 = (h.B.v2 >> ot) | ((in.a2 & ot) << 31);
+    h.Wo0 = (h.Wo0 >> ot) | ((in.w0 & ot) << 31); h.Wo1 = (h.Wo1 >> ot) | ((in.w1 & ot) << 31);
+    const uint32_t xm = ((h.Wm0 ^ h.Wo0) | (h.Wm1 ^ h.Wo1)) | bad;
+    Planes32 nA, nB;
+    cells<uint32_t>(xm, f, 0u - ot, h.A, h.B, &nA, &nB, D, G);
+    h.A = nA; h.B = nB;
+}
+// the band-edge cell of this half (cell 0 / cell 63: bit 0 either way) moved along my plane on my move, along the other one else: its difference code
+FZP_HD int32_t half_edge(const Half &h, const uint32_t my) {
+    const uint32_t m = 0u - my;
+    const uint32_t x0 = (h.A.v0 & m) | (h.B.v0 & ~m), x1 = (h.A.v1 & m) | (h.B.v1 & ~m), x2 = (h.A.v2 & m) | (h.B.v2 & ~m);
+    return (int32_t)((x0 & 1u) | ((x1 & 1u) << 1) | ((x2 & 1u) << 2));
+}
 
 }   // namespace swb

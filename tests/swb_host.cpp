@@ -46,7 +46,7 @@ extern "C" int swb_extend_host(const uint8_t *q, int64_t nq, const uint8_t *t, i
         }
         const uint64_t f = (down && pdown) ? 1ull << 63 : ((!down && !pdown) ? 1ull : 0ull);
         uint64_t D, G;
-        cells(xm, f, down ? ~0ull : 0ull, p, qq, &P, &Q, &D, &G);
+        cells<uint64_t>(xm, f, down ? ~(uint64_t)0 : (uint64_t)0, p, qq, &P, &Q, &D, &G);
         tbD[tt] = D; tbG[tt] = G; mv[tt] = down ? 1 : 0;
         // edge scores: every lane's cell moved down (vertical difference) or right (horizontal)
         const Planes &X = down ? Q : P;
@@ -60,6 +60,74 @@ extern "C" int swb_extend_host(const uint8_t *q, int64_t nq, const uint8_t *t, i
             else if (col_on && kc >= 0 && kc <= 63) Hcol += 2 * value_at(Q, (int)kc) - 3;
             if (!row_on && down && kr == 63) { row_on = true; Hrow = S0 + 2 * E2; }
             else if (row_on && kr >= 0 && kr <= 63) Hrow += 2 * value_at(P, (int)kr) - 3;
+            if (col_on && kc >= 0 && kc <= 63) { const int64_t i = i0 + kc; if (i >= 0 && i < nq && Hcol > best) { best = Hcol; bt = tt; bl = kc; } }
+            if (row_on && kr >= 0 && kr <= 63) { const int64_t j = tt - (nq - 1); if (j >= 0 && j < nt && Hrow > best) { best = Hrow; bt = tt; bl = kr; } }
+        }
+        pdown = down;
+        tt++;
+        down = tt < 64 ? ((tt & 1) == 0) : (E2 >= 0);
+        if (i0 > nq - 1) break;
+        if ((tt - 1) - (i0 + 63) > nt - 1) break;
+        if (tt >= max_steps) break;
+    }
+    out[0] = tt; out[1] = bl >= 0 ? best : -(1 << 26); out[2] = bt; out[3] = bl;
+    return 0;
+}
+
+
+// ---- the same extension with the band split over a pair of lanes (k_swb2's form): two Half states, explicit exchange where the kernel uses a DPP swap
+static uint32_t rev32(uint32_t v) { uint32_t r = 0; for (int b = 0; b < 32; b++) r |= ((v >> b) & 1u) << (31 - b); return r; }
+
+extern "C" int swb_extend_pair_host(const uint8_t *q, int64_t nq, const uint8_t *t, int64_t nt, uint64_t *tbD, uint64_t *tbG, uint8_t *mv, int64_t *out) {
+    using namespace swb;
+    if (nq < 64 || nt < 64) return -1;
+    const int64_t max_steps = nq + nt + 2;
+    Half h[2];
+    // step -1 (see swb_extend_host): P value 4 on cells >= 33, Q value 4 on cells <= 32.  Low: A = P, B = Q, bit = cell; high: A = Q, B = P, bit = 63 - cell
+    h[0].A = {0, 0, 0}; h[0].B = {0, 0, ~0u};                   // cells 0..31: P = 0, Q = 4
+    h[1].A = {0, 0, 1u << 31}; h[1].B = {0, 0, ~0u >> 1};       // Q = 4 on cell 32 only (bit 31); P = 4 on cells 33..63 (bits 30..0)
+    for (int l = 0; l < 2; l++) h[l].Wm0 = h[l].Wm1 = h[l].Wo0 = h[l].Wo1 = 0;
+    for (int k = 0; k < 64; k++) {
+        const int64_t i = k - 33, j = 32 - k;
+        const int l = k >> 5, b = l ? 63 - k : k;
+        if (i >= 0 && i < nq) { uint32_t &w0 = l ? h[1].Wm0 : h[0].Wo0, &w1 = l ? h[1].Wm1 : h[0].Wo1; w0 |= (uint32_t)(q[i] & 1) << b; w1 |= (uint32_t)(q[i] >> 1) << b; }   // read: low's other window, high's own
+        if (j >= 0 && j < nt) { uint32_t &w0 = l ? h[1].Wo0 : h[0].Wm0, &w1 = l ? h[1].Wo1 : h[0].Wm1; w0 |= (uint32_t)(t[j] & 1) << b; w1 |= (uint32_t)(t[j] >> 1) << b; }   // contig: low's own, high's other
+    }
+    int64_t i0 = -33, tt = 0;
+    int32_t sv0 = 0, E2 = 8;
+    bool down = true, pdown = false;
+    bool row_on = false, col_on = false;
+    int32_t Hrow = 0, Hcol = 0, best = -(1 << 26);
+    int64_t bt = -1, bl = -1;
+    for (;;) {
+        const uint32_t sd = down ? 1u : 0u, sr = 1u - sd;
+        if (down) i0++;
+        const int64_t kr = nq - 1 - i0, kc = tt - (nt - 1) - i0, nv = kr + 1;
+        const HalfOut o0 = half_out(h[0]), o1 = half_out(h[1]);
+        uint32_t base0 = 0, base1 = 0;
+        if (!down) { const int64_t j = tt - i0; if (j >= 0 && j < nt) base0 = t[j]; }
+        else { const int64_t i = i0 + 63; if (i >= 0 && i < nq) base1 = q[i]; }
+        // cells past the ends: low lane bit c = cell c, high lane bit b = cell 63 - b
+        uint32_t bad0 = 0, bad1 = 0;
+        if (nv < 32) bad0 |= nv <= 0 ? ~0u : ~0u << nv;
+        if (nv < 64) bad1 |= nv <= 32 ? ~0u : (1u << (64 - nv)) - 1u;
+        if (kc > 0) bad0 |= kc >= 32 ? ~0u : (1u << kc) - 1u;
+        if (kc > 32) bad1 |= kc >= 64 ? ~0u : ~0u << (64 - kc);
+        uint32_t D0, G0, D1, G1;
+        half_step(h[0], sr, base0, o1, sr & (pdown ? 0u : 1u), bad0, &D0, &G0);
+        half_step(h[1], sd, base1, o0, sd & (pdown ? 1u : 0u), bad1, &D1, &G1);
+        tbD[tt] = (uint64_t)D0 | ((uint64_t)rev32(D1) << 32); tbG[tt] = (uint64_t)G0 | ((uint64_t)rev32(G1) << 32); mv[tt] = down ? 1 : 0;
+        const int32_t v0 = half_edge(h[0], sr), v63 = half_edge(h[1], sd);
+        sv0 += v0;
+        E2 += v63 - v0;
+        {   // terminal: P at cell kr is the low lane's A / the high lane's B; Q at cell kc the low lane's B / the high lane's A
+            const int32_t S0 = -259 + 2 * sv0 - 3 * (int32_t)(tt + 1);
+            auto Pval = [&](int64_t c) { return c < 32 ? value_at(h[0].A, (int)c) : value_at(h[1].B, (int)(63 - c)); };
+            auto Qval = [&](int64_t c) { return c < 32 ? value_at(h[0].B, (int)c) : value_at(h[1].A, (int)(63 - c)); };
+            if (!col_on && !down && kc == 0) { col_on = true; Hcol = S0; }
+            else if (col_on && kc >= 0 && kc <= 63) Hcol += 2 * Qval(kc) - 3;
+            if (!row_on && down && kr == 63) { row_on = true; Hrow = S0 + 2 * E2; }
+            else if (row_on && kr >= 0 && kr <= 63) Hrow += 2 * Pval(kr) - 3;
             if (col_on && kc >= 0 && kc <= 63) { const int64_t i = i0 + kc; if (i >= 0 && i < nq && Hcol > best) { best = Hcol; bt = tt; bl = kc; } }
             if (row_on && kr >= 0 && kr <= 63) { const int64_t j = tt - (nq - 1); if (j >= 0 && j < nt && Hrow > best) { best = Hrow; bt = tt; bl = kr; } }
         }

@@ -1,4 +1,4 @@
-"""The bit-sliced cell function of the K1 DP (falcon_unzip_amd/csrc/fzp_swb_core.h, what k_swb runs per lane) on the host against the scalar twin's
+"""The bit-sliced cell function of the K1 DP (falcon_unzip_amd/csrc/fzp_swb_core.h, what k_swb runs per lane and k_swb2 per pair of lanes) on the host against the scalar twin's
 extension (oracle/align_oracle.c dp_extend): same moves at every step, same trace-back masks on every cell a walk can visit, same terminal."""
 import ctypes as C
 import os
@@ -43,7 +43,7 @@ def _both(oracle, swb, q, t):
     P = oracle_lib.AlignParams()
     oracle.lib.orc_align_params_default(C.byref(P))
     res = []
-    for fn, extra in ((oracle.lib.orc_dp_extend_raw, True), (swb.swb_extend_host, False)):
+    for fn, extra in ((oracle.lib.orc_dp_extend_raw, True), (swb.swb_extend_host, False), (swb.swb_extend_pair_host, False)):
         D = np.zeros(cap, np.uint64); G = np.zeros(cap, np.uint64); mv = np.zeros(cap, np.uint8); out = np.zeros(4, np.int64)
         fn.restype = C.c_int
         args = [q.ctypes.data_as(C.c_void_p), C.c_int64(nq), t.ctypes.data_as(C.c_void_p), C.c_int64(nt)]
@@ -86,8 +86,9 @@ def test_masks_moves_terminal_equal_the_twin(oracle, swb, seed, L, sub, ins, del
         nq = len(q)
         nt = min(len(ref), nq + nq // 4 + 64) if rep % 3 else min(len(ref), max(64, int(nq * (0.7 + 0.1 * rep))))     # also windows that end before the read does
         t = np.ascontiguousarray(ref[:nt])
-        a, b = _both(oracle, swb, q, t)
+        a, b, c = _both(oracle, swb, q, t)
         _compare(a, b, nq, nt)
+        _compare(a, c, nq, nt)
 
 
 def test_unrelated_sequences_and_low_complexity(oracle, swb):
@@ -98,5 +99,6 @@ def test_unrelated_sequences_and_low_complexity(oracle, swb):
         if rep >= 3:                       # homopolymers and dinucleotide repeats: ties everywhere
             q[:] = np.tile(np.array([0, 1], np.uint8), len(q))[:len(q)] if rep == 3 else 2
             t[:] = np.tile(np.array([0, 1], np.uint8), len(t))[:len(t)] if rep != 5 else 2
-        a, b = _both(oracle, swb, q, t)
+        a, b, c = _both(oracle, swb, q, t)
         _compare(a, b, len(q), len(t))
+        _compare(a, c, len(q), len(t))

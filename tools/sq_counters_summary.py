@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVES (one pass) -> per-kernel sums as JSON, and -- given the bench line of the
-same workload -- profiles/k1_sw_counters.json: VALU / SALU / scalar-memory instructions of k_sw per 64-cell band step, which bench.py's roofline reads.
+same workload -- profiles/k1_sw_counters.json: VALU / SALU / scalar-memory instructions of the two DP kernels (k_swb, k_sw) per 64-cell band step, which bench.py's roofline reads.
 usage: sq_counters_summary.py <counter_collection.csv> <out.json> [<bench_line.json> <k1_sw_counters.json> <source label>]"""
 import collections
 import csv
@@ -24,8 +24,9 @@ def main():
         # band steps of ONE bench step: forward extensions of all candidates + the backward extensions (fzp_aln_summary.cells counts them all); the counter pass
         # ran exactly one step (bench.py --steps 1 --warmup 0), so the sums over every k_sw launch of the pass belong to these steps
         steps = line["dp_cells_per_step"] / 64.0
-        sw = tot["k_sw"]
-        json.dump({"kernel": "k_sw", "band_steps_per_bench_step": steps, "valu_per_step": round(sw["SQ_INSTS_VALU"] / steps, 3),
+        sw = tot["k_sw"] + tot["k_swb"]          # the two DP kernels: the bit-sliced one (a read per lane) and the wave-per-read one
+        calls["k_sw"] += calls["k_swb"]
+        json.dump({"kernel": "k_swb + k_sw", "band_steps_per_bench_step": steps, "valu_k_swb": tot["k_swb"]["SQ_INSTS_VALU"], "valu_k_sw": tot["k_sw"]["SQ_INSTS_VALU"], "valu_per_step": round(sw["SQ_INSTS_VALU"] / steps, 3),
                    "salu_per_step": round(sw["SQ_INSTS_SALU"] / steps, 3), "smem_per_step": round(sw["SQ_INSTS_SMEM"] / steps, 3),
                    "launches_counted": calls["k_sw"], "source": sys.argv[5] if len(sys.argv) > 5 else sys.argv[2]}, open(sys.argv[4], "w"), indent=1)
 
