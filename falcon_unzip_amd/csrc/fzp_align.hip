@@ -1062,6 +1062,170 @@ __global__ void __launch_bounds__(64) k_swb(int64_t first, int64_t count, const 
     }
 }
 
+// ---- the same DP with the band split over a PAIR of lanes (fzp_swb_core.h, Half): 32 reads per wave, half the instructions per step on a wave's
+// critical path and twice the waves -- at the bench's job size the chip holds about one DP wave per SIMD, which makes a step's latency (instructions x the
+// ~5 cycles a lone wave needs per instruction), not the issue rate, what bounds the launch.  The low lane of a pair owns the contig stream, the high lane
+// the read stream; what crosses the middle of the band and the two edge differences the steering compares go through DPP quad swaps.
+__device__ __forceinline__ uint32_t pair_swap(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int32_t)v, 0xB1, 0xf, 0xf, false); }   // quad_perm [1,0,3,2]
+
+struct SwbPair {
+    swb::Half h;
+    LaneStream ss;                 // low lane: the contig's bases, high lane: the read's
+    int32_t i0, E2, sv0;
+    uint32_t down, pdown;
+    uint64_t mvacc;
+};
+
+template <bool CHECKED>
+__device__ __forceinline__ void swb2_step(SwbPair &L, const uint32_t is_hi, const int32_t t, uint2 &rec, const int32_t nq, const int32_t nt, const int32_t max_steps, bool &active,
+                                          bool &row_on, bool &col_on, int32_t &Hrow, int32_t &Hcol, int32_t &best, int32_t &bt, int32_t &bl, int32_t &steps) {
+    using namespace swb;
+    const uint32_t sd = L.down, sr = 1u - sd;
+    const uint32_t my = is_hi ? sd : sr, pmy = is_hi ? L.pdown : 1u - L.pdown;
+    L.i0 += (int32_t)sd;
+    const HalfOut o = half_out(L.h);
+    const HalfOut in = {pair_swap(o.a0), pair_swap(o.a1), pair_swap(o.a2), pair_swap(o.w0), pair_swap(o.w1)};
+    const uint32_t base = L.ss.pop(my);
+    const int32_t kr = nq - 1 - L.i0, kc = t - (nt - 1) - L.i0;      // lanes (cells) of the last row / the last column
+    uint32_t bad = 0;
+    if (CHECKED) {   // bases past the read's / the window's end never match; low lane: bit c = cell c, high lane: bit b = cell 63 - b
+        const int32_t nv = kr + 1;                                    // cells < nv hold read bases, cells >= kc contig bases
+        const uint32_t br_lo = nv >= 32 ? 0u : (nv <= 0 ? ~0u : ~0u << nv), br_hi = nv >= 64 ? 0u : (nv <= 32 ? ~0u : (1u << (64 - nv)) - 1u);
+        const uint32_t bc_lo = kc <= 0 ? 0u : (kc >= 32 ? ~0u : (1u << kc) - 1u), bc_hi = kc <= 32 ? 0u : (kc >= 64 ? ~0u : ~0u << (64 - kc));
+        bad = is_hi ? (br_hi | bc_hi) : (br_lo | bc_lo);
+    }
+    uint32_t D, G;
+    half_step(L.h, my, base, in, my & pmy, bad, &D, &G);
+    {   // the record of the step: {D, G} over the 64 cells; the low lane stores D (both halves), the high lane G
+        const uint32_t Dn = is_hi ? __brev(D) : D, Gn = is_hi ? __brev(G) : G;      // the high lane's bits are mirrored
+        const uint32_t got = pair_swap(is_hi ? Dn : Gn);
+        rec = is_hi ? make_uint2(got, Gn) : make_uint2(Dn, got);
+    }
+    L.mvacc |= (uint64_t)sd << (t & 63);
+    const int32_t v = half_edge(L.h, my), pv = (int32_t)pair_swap((uint32_t)v);
+    const int32_t v0 = is_hi ? pv : v, v63 = is_hi ? v : pv;
+    L.sv0 += v0;
+    L.E2 += v63 - v0;
+    if (CHECKED) {   // terminal: the best valid cell of the last row / last column (see swb_step); P at cell c: the low lane's A / the high lane's B, Q: B / A
+        if (active) {
+            const int32_t S0 = -259 + 2 * L.sv0 - 3 * (t + 1);
+            const bool kc_in = kc >= 0 && kc <= 63, kr_in = kr >= 0 && kr <= 63;
+            const bool col_start = !col_on && sr && kc == 0, row_start = !row_on && sd && kr == 63;
+            int32_t pq = 0, pp = 0;
+            if (kc_in && (uint32_t)(kc >> 5) == is_hi) pq = is_hi ? value_at(L.h.A, 63 - kc) : value_at(L.h.B, kc);
+            if (kr_in && (uint32_t)(kr >> 5) == is_hi) pp = is_hi ? value_at(L.h.B, 63 - kr) : value_at(L.h.A, kr);
+            pq += (int32_t)pair_swap((uint32_t)pq); pp += (int32_t)pair_swap((uint32_t)pp);
+            if (col_start) Hcol = S0; else if (col_on && kc_in) Hcol += 2 * pq - 3;
+            if (row_start) Hrow = S0 + 2 * L.E2; else if (row_on && kr_in) Hrow += 2 * pp - 3;
+            col_on = col_on || col_start; row_on = row_on || row_start;
+            { const int32_t i = L.i0 + kc; if (col_on && kc_in && i >= 0 && i < nq && Hcol > best) { best = Hcol; bt = t; bl = kc; } }
+            { const int32_t jj = t - (nq - 1); if (row_on && kr_in && jj >= 0 && jj < nt && Hrow > best) { best = Hrow; bt = t; bl = kr; } }
+            if (L.i0 > nq - 1 || t - (L.i0 + 63) > nt - 1 || t + 1 >= max_steps) { active = false; steps = t + 1; }
+        }
+    }
+    L.pdown = sd;
+    L.down = (CHECKED && (t + 1) < 64) ? (uint32_t)(((t + 1) & 1) == 0) : (uint32_t)(L.E2 >= 0);
+}
+
+__global__ void __launch_bounds__(64) k_swb2(int64_t first, int64_t count, const int32_t *__restrict__ list, const int32_t *__restrict__ ridx, const uint32_t *__restrict__ read_ori,
+                                              const int64_t *__restrict__ ori_woff, const int32_t *__restrict__ read_len, const int32_t *__restrict__ read_ctg,
+                                              const uint32_t *__restrict__ ctg_pk, const int64_t *__restrict__ ctg_woff, const int64_t *__restrict__ ctg_len,
+                                              const Anchor *__restrict__ anc, const int64_t *__restrict__ tb_off, uint2 *__restrict__ tb, ulonglong2 *__restrict__ mvw,
+                                              DpInfo *__restrict__ info, int64_t *__restrict__ tbo, int64_t *__restrict__ mvo, const int64_t *__restrict__ m_off, const int64_t *__restrict__ mv_off,
+                                              uint8_t *__restrict__ handled, int32_t steps_limit) {
+    using namespace swb;
+    const uint32_t is_hi = threadIdx.x & 1u;
+    const bool lo = is_hi == 0u;
+    const int64_t li = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 1);
+    const int64_t wv = li < count ? list[li] : -1;       // the pair's slot in the chunk, -1: none
+    bool active = wv >= 0;
+    const int64_t sl = first + (active ? wv : 0);
+    const int64_t r = ridx ? ridx[sl] : sl;
+    const Anchor a = anc[sl];
+    const int64_t toff = m_off ? m_off[sl] : tb_off[sl] - tb_off[first], moff = m_off ? mv_off[sl] : (toff >> 6) + (active ? wv : 0);
+    uint2 *tbr = tb + 2 * toff + is_hi;                  // per step 16 B {D, G}: this lane's 8 of them
+    ulonglong2 *mvr = mvw + moff;
+    const int c_idx = read_ctg[r];
+    const int64_t n = read_len[r];
+    const int32_t nq = (int32_t)(n - a.i_a);
+    int64_t ntl = ctg_len[c_idx] - a.c_a;
+    if (ntl > (int64_t)nq + nq / 4 + 64) ntl = (int64_t)nq + nq / 4 + 64;
+    const int32_t nt = (int32_t)ntl;
+    if (handled) {   // the caller did not sort the slots by kernel: this one takes what fits it and says so, k_sw runs the rest
+        const bool mine = active && (!a.aligned || (nq >= 64 && nt >= 64 && nq + nt + 2 <= steps_limit));
+        if (active && lo) handled[sl] = mine ? 1 : 0;
+        active = mine;
+    }
+    if (active && tbo && lo) { tbo[sl] = toff; mvo[sl] = moff; }
+    if (active && !a.aligned) { if (lo) info[sl] = DpInfo{0, -1, 0, NEGV}; active = false; }
+    const uint32_t *qpk = read_ori + ori_woff[sl];
+    const uint32_t *tpk = ctg_pk + ctg_woff[c_idx];
+    const int64_t qb = a.i_a, tbase = a.c_a;
+    const int32_t max_steps = nq + nt + 2;
+    SwbPair L;
+    // step -1 (see k_swb): P = 4 on cells >= 33, Q = 4 on cells <= 32; the read's bases 0..30 on cells 33..63, the contig's 32..0 on cells 0..32
+    if (lo) {
+        L.h.A = {0, 0, 0}; L.h.B = {0, 0, ~0u};
+        L.h.Wo0 = L.h.Wo1 = 0; L.h.Wm0 = L.h.Wm1 = 0;
+        for (int c = 0; c < 32; c++) { const uint32_t b = base_at(tpk, tbase + (32 - c)); L.h.Wm0 |= (b & 1u) << c; L.h.Wm1 |= (b >> 1) << c; }
+        L.ss.init(tpk, tbase + 33);
+    } else {
+        L.h.A = {0, 0, 1u << 31}; L.h.B = {0, 0, ~0u >> 1};
+        L.h.Wm0 = L.h.Wm1 = 0;
+        for (int c = 33; c < 64; c++) { const uint32_t b = base_at(qpk, qb + (c - 33)); L.h.Wm0 |= (b & 1u) << (63 - c); L.h.Wm1 |= (b >> 1) << (63 - c); }
+        { const uint32_t b = base_at(tpk, tbase); L.h.Wo0 = (b & 1u) << 31; L.h.Wo1 = (b >> 1) << 31; }
+        L.ss.init(qpk, qb + 31);
+    }
+    L.i0 = -33; L.E2 = 8; L.sv0 = 0;
+    L.down = 1; L.pdown = 0;
+    bool row_on = false, col_on = false;
+    int32_t Hrow = 0, Hcol = 0, best = NEGV, bt = -1, bl = 0, steps = 0;
+    int32_t t = 0;                                            // wave-uniform
+    while (__ballot(active)) {
+        const bool blk_active = active;
+        const int32_t i0_blk = L.i0;
+        L.mvacc = 0;
+        const bool far = !active || (nq - 1 - (L.i0 + 63) > 64 && nt - 1 - (t - L.i0) > 64);
+        const bool interior = t >= 64 && __ballot(!far) == 0ull;
+        for (int g8 = 0; g8 < 8; g8++) {
+            const bool grp_active = active;
+            uint2 rec[8];
+            if (interior) {
+#pragma unroll
+                for (int s8 = 0; s8 < 8; s8++) { swb2_step<false>(L, is_hi, t, rec[s8], nq, nt, max_steps, active, row_on, col_on, Hrow, Hcol, best, bt, bl, steps); t++; }
+            } else {
+#pragma unroll
+                for (int s8 = 0; s8 < 8; s8++) { swb2_step<true>(L, is_hi, t, rec[s8], nq, nt, max_steps, active, row_on, col_on, Hrow, Hcol, best, bt, bl, steps); t++; }
+            }
+            if (g8 & 1) L.ss.refill();      // (ahead of the stores: see k_swb)
+            if (grp_active) {
+#pragma unroll
+                for (int s8 = 0; s8 < 8; s8++) tbr[2 * (t - 8 + s8)] = rec[s8];
+            }
+        }
+        if (blk_active) {
+            uint32_t glane = 32u;
+            if ((t & (TBS_SEG - 1)) == 0 && active) {      // step t-1 tops a trace-back segment: the lane of its best score is where that segment's walker starts
+                // the whole band's planes, in the low lane's view (the high lane's result is not used): P = its A | the partner's B turned round, Q = its B | the partner's A
+                const Planes P = {(uint64_t)L.h.A.v0 | ((uint64_t)__brev(pair_swap(L.h.B.v0)) << 32), (uint64_t)L.h.A.v1 | ((uint64_t)__brev(pair_swap(L.h.B.v1)) << 32),
+                                  (uint64_t)L.h.A.v2 | ((uint64_t)__brev(pair_swap(L.h.B.v2)) << 32)};
+                const Planes Q = {(uint64_t)L.h.B.v0 | ((uint64_t)__brev(pair_swap(L.h.A.v0)) << 32), (uint64_t)L.h.B.v1 | ((uint64_t)__brev(pair_swap(L.h.A.v1)) << 32),
+                                  (uint64_t)L.h.B.v2 | ((uint64_t)__brev(pair_swap(L.h.A.v2)) << 32)};
+                int32_t run = 0, bestv = 0;
+                glane = 0u;
+                for (int k = 0; k < 63; k++) {            // score(lane k+1) - score(lane k) = 2 (Qv[k+1] - Pv[k])
+                    run += value_at(Q, k + 1) - value_at(P, k);
+                    if (run > bestv) { bestv = run; glane = (uint32_t)(k + 1); }
+                }
+            }
+            if (lo) {
+                mvr[(t - 1) >> 6] = make_ulonglong2(L.mvacc, (uint64_t)(uint32_t)i0_blk | ((uint64_t)glane << 32));
+                if (!active) info[sl] = DpInfo{steps, bt, bl, bt >= 0 ? best : NEGV};
+            }
+        }
+    }
+}
+
 // ---- trace-back, part 1: the walk.  One lane per read, 16 reads per wave.
 //
 // The walk from the best cell back to the anchor is sequential per read, so a lane owns a read; what the
@@ -2359,6 +2523,10 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
         const int32_t mean_len = (int32_t)std::max<int64_t>(1, sum_len / std::max<int64_t>(nr, 1));
         // ---- which DP kernel runs which extension (fzalign scores 2 / -4 / -3 are built into the bit-sliced one's cell function)
         bool use_bits = getenv("FZP_SW_NO_BITS") == nullptr && P.match == 2 && P.mismatch == 4 && P.gap == 3 && !split_rounds && use_lpt;
+        // the bit-sliced kernel has two forms.  A pair of lanes per read (k_swb2) has the shorter step (112 against 135 instructions on the wave's critical path) but twice the
+        // waves, and its instruction mix (v_bitop3, DPP, 3-operand forms) issues at ~4.5 cycles per SIMD however many waves share it: two such waves on one SIMD run at half
+        // speed each.  So it is taken when its waves get a SIMD each and nothing else runs beside them; else the whole band sits in one lane (k_swb).  FZP_SWB_64 / FZP_SWB_PAIR force one.
+        const int swb_force = getenv("FZP_SWB_64") ? 64 : (getenv("FZP_SWB_PAIR") ? 32 : 0);
         int64_t swb_max_steps = TBS_SINGLE_STEPS;
         if (const char *e = getenv("FZP_SWB_MAX_STEPS")) { const long g = atol(e); if (g > 0) swb_max_steps = g; }
         std::vector<int64_t> &swb_at = j->h_swb_at, &sw_at = j->h_sw_at;
@@ -2422,6 +2590,7 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
                     // every extension goes to one of the two DP kernels: the bit-sliced one (a read per lane) takes those that fit the band on both sides and
                     // are short enough for its per-step latency; the rest -- the long reads first of all -- run a wave each, started before it
                     const int64_t b_at = swb_at[(size_t)ci], b_n = swb_at[(size_t)ci + 1] - b_at, w_at = sw_at[(size_t)ci], w_n = sw_at[(size_t)ci + 1] - w_at;
+                    const bool swb64 = swb_force ? swb_force == 64 : !(w_n == 0 && b_n / 32 <= (int64_t)ctx->n_cu * 4);
                     if (w_n > 0) {   // on its own stream: the two kernels share the chip (this one latency-bound waves of long reads, the other one wave per SIMD)
                         FZP_HIP(hipEventRecord(j->ev_l[0], st));
                         FZP_HIP(hipStreamWaitEvent(ctx->stream3, j->ev_l[0], 0));
@@ -2430,7 +2599,11 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
                                            (const int32_t *)(j->sw_list.p + w_at), use_prio ? mean_len : 0, (const int64_t *)j->tbm_off.p, (const int64_t *)j->mvm_off.p, (const uint8_t *)nullptr);
                         FZP_HIP(hipEventRecord(j->ev_l[1], ctx->stream3));
                     }
-                    if (b_n > 0)
+                    if (b_n > 0 && !swb64)
+                        hipLaunchKernelGGL(k_swb2, dim3((unsigned)(b_n / 32)), dim3(64), 0, st, first, b_n, (const int32_t *)(j->swb_list.p + b_at), (const int32_t *)nullptr, j->read_ori.p, j->read_woff.p,
+                                           j->read_len.p, j->read_ctg.p, j->ctg_pk.p, j->ctg_woff.p, j->ctg_len.p, j->anc.p, j->tb_off.p, j->tb2[bi].p, j->mvw2[bi].p, j->info.p, j->tbo.p, j->mvo.p,
+                                           (const int64_t *)j->tbm_off.p, (const int64_t *)j->mvm_off.p, (uint8_t *)nullptr, 0x7fffffff);
+                    if (b_n > 0 && swb64)
                         hipLaunchKernelGGL(k_swb, dim3((unsigned)(b_n / 64)), dim3(64), 0, st, first, b_n, (const int32_t *)(j->swb_list.p + b_at), (const int32_t *)nullptr, j->read_ori.p, j->read_woff.p,
                                            j->read_len.p, j->read_ctg.p, j->ctg_pk.p, j->ctg_woff.p, j->ctg_len.p, j->anc.p, j->tb_off.p, j->tb2[bi].p, j->mvw2[bi].p, j->info.p, j->tbo.p, j->mvo.p, (const int64_t *)j->tbm_off.p, (const int64_t *)j->mvm_off.p,
                                            (uint8_t *)nullptr, 0x7fffffff, getenv("FZP_SWB_DBG") ? atoi(getenv("FZP_SWB_DBG")) : 0);
@@ -2464,7 +2637,14 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
                                    j->bq_off.p, j->bt_off.p, j->bq.p, j->bt.p, j->anc_b.p, j->b_len.p, j->b_tlen.p);
                 // the backward extensions are short (an anchor sits a few hundred bases into its read): the bit-sliced kernel takes every one that spans the band
                 // (lanes in slot order: their mask streams lie side by side), k_sw the rest -- which of the two is decided on the device, the winner's anchor never came to the host
-                if (use_bits) {
+                const bool swb64 = swb_force ? swb_force == 64 : !((cnt + 31) / 32 <= (int64_t)ctx->n_cu * 4);
+                if (use_bits && !swb64) {
+                    FZP_TRY(j->b_handled.alloc((size_t)nr));
+                    hipLaunchKernelGGL(k_swb2, dim3((unsigned)((cnt + 31) / 32)), dim3(64), 0, st, first, cnt, (const int32_t *)j->b_iota.p, (const int32_t *)nullptr, j->bq.p, j->bq_off.p, j->b_len.p, j->b_iota.p,
+                                       j->bt.p, j->bt_off.p, j->b_tlen.p, j->anc_b.p, j->tb_off_b.p, j->tb_b2[bi].p, j->mvw_b2[bi].p, j->info_b.p, j->tbo_b.p, j->mvo_b.p,
+                                       (const int64_t *)nullptr, (const int64_t *)nullptr, j->b_handled.p, (int32_t)swb_max_steps);
+                }
+                if (use_bits && swb64) {
                     FZP_TRY(j->b_handled.alloc((size_t)nr));
                     hipLaunchKernelGGL(k_swb, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, st, first, cnt, (const int32_t *)j->b_iota.p, (const int32_t *)nullptr, j->bq.p, j->bq_off.p, j->b_len.p, j->b_iota.p,
                                        j->bt.p, j->bt_off.p, j->b_tlen.p, j->anc_b.p, j->tb_off_b.p, j->tb_b2[bi].p, j->mvw_b2[bi].p, j->info_b.p, j->tbo_b.p, j->mvo_b.p,

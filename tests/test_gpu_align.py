@@ -463,6 +463,35 @@ def test_launch_order_does_not_change_results(eng, monkeypatch):
     assert np.array_equal(got["lpt"][0], got["input"][0]) and got["lpt"][1] == got["input"][1]
 
 
+def test_the_three_dp_kernels_agree(eng, oracle, monkeypatch):
+    """The banded DP exists three times: k_sw (a wave per read, integer scores), k_swb (bit-sliced, a read per lane) and k_swb2 (bit-sliced, a read per pair of
+    lanes).  Same reads through each (FZP_SW_NO_BITS / FZP_SWB_64 / FZP_SWB_PAIR; the default mixes them by read length): every summary field and every CIGAR equal, and
+    equal to the twin's.  Reads from 70 bases up, so that extensions shorter than the band (which stay with k_sw) and reads over the bit-sliced kernels' length
+    limit are both in the set."""
+    from falcon_unzip_amd import _lib
+    n = 400
+    ctg, blob, off, *_ = _shaped(51, 800_000, n, length_model={"median": 4000, "sigma": 1.3, "lo": 70, "hi": 30000})
+    reads = [blob[off[i]:off[i + 1]] for i in range(n)]
+    got = {}
+    for mode, env in (("default", {}), ("wave_per_read", {"FZP_SW_NO_BITS": "1"}), ("lane64", {"FZP_SWB_64": "1"}), ("pair", {"FZP_SWB_PAIR": "1"}),
+                      ("pair_short_limit", {"FZP_SWB_PAIR": "1", "FZP_SWB_MAX_STEPS": "9000"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        job = _lib.align_job_raw(eng, [ctg], blob, off, np.zeros(n, np.int32))
+        job.run()
+        aln, idx = job.alnset(0)
+        got[mode] = (job.summaries().copy(), {int(r): aln.cigar_of(k) for k, r in enumerate(idx)})
+        job.close()
+        for k in env:
+            monkeypatch.delenv(k)
+    exp, _ = oracle_lib.align_reads(oracle, ctg, reads, n_threads=8)
+    for mode, (s, cg) in got.items():
+        for f in FIELDS:
+            assert np.array_equal(s[f], exp[f]), (mode, f, np.flatnonzero(s[f] != exp[f])[:5])
+        assert cg == got["default"][1], mode
+    assert got["default"][0]["aligned"].mean() > 0.8            # (reads of a few hundred bases rarely gather 8 seed votes)
+
+
 def test_segmented_traceback_equals_serial_walk(eng, monkeypatch):
     """The trace-back walks a long read as segments of 4 096 DP steps at once (speculative starts, stitched where neighbouring walkers meet) -- the
     op stream must be the serial walk's (FZP_TB_SERIAL=1), also when the machinery behind it has to work: FZP_TB_GUESS_LANE=1 starts the walkers at
