@@ -34,7 +34,8 @@ def test_two_ranks_share_one_gpu():
     for d, n in ((one, 1), (two, 2)):
         assert d["n_gpus"] == n and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["higher_is_better"] is True
         assert d["unit"] == "reads/s" and d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"]
-        assert d["roofline"]["bound"] == "valu" and d["roofline"]["launches"] >= 2 and d["roofline"]["peak"] == 1228.8 and 0 < d["roofline"]["frac"] < 1
+        assert d["roofline"]["bound"] == "hbm" and d["roofline"]["launches"] >= 2 and d["roofline"]["peak"] == 8000.0 and 0 < d["roofline"]["frac"] < 1
+        assert d["roofline"]["valu"]["peak"] == 1228.8 and 0 < d["roofline"]["valu"]["frac"] < 1
         assert d["roofline"]["hbm"]["unit"] == "GB/s" and d["index_in_step"] is True and d["index_ms"] > 0
         assert d["aligned_frac"] > 0.98
     assert one["stage_counts"]["r2p_records"] == 300 and two["stage_counts"]["r2p_records"] == 600      # the all-gather saw both shards
