@@ -205,10 +205,12 @@ int fzp_readmap(const char *phased_reads, size_t pr_len, const char *rawread_ids
 
 /* ---------------------------------------------------------------------------------------------
  * K1: read -> contig banded alignment (role of blasr + samtools sort, unzip.py:86-91).
- * Own deterministic spec "fzalign v1.2" (DESIGN.md section 6): k-mer seeding over every indexed position, up to two
- * candidate placements per read (chained anchors), adaptive anti-diagonal band of 64 cells, linear-gap scores,
- * the better extension kept (--bestn 1), identity gate (--minPctIdentity 70), traceback to =/X/I/D/S CIGARs.  Parity vs blasr is UNPINNED; the
- * kernel is bit-exact against its scalar CPU twin in oracle/align_oracle.c.
+ * Own deterministic spec "fzalign v1.5" (DESIGN.md section 6): k-mer seeding over every indexed position, up to two
+ * candidate placements per read (chained anchors), extension forward and backward from the anchor in an adaptive anti-diagonal band of
+ * 64 cells with linear-gap scores, the better forward extension kept (--bestn 1), the best-scoring stretch of the joined path reported,
+ * identity gate (--minPctIdentity 70), traceback to =/X/I/D/S CIGARs.  Parity vs blasr is UNPINNED; the kernels are bit-exact against
+ * their scalar CPU twin in oracle/align_oracle.c.  With the default scores (2, 4, 3) the DP runs bit-sliced (one read per lane); other
+ * scores run the wave-per-read kernel: same spec, same results.
  * --------------------------------------------------------------------------------------------- */
 typedef struct {
     int32_t kmer;            /* seed length (<=16), default 16 */
