@@ -2479,13 +2479,14 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
                 j->h_seg_base[(size_t)f] = (int64_t)sgs.size();
                 std::vector<int32_t> w_first((size_t)(l - f));
                 int64_t nw_chunk = 0;
-                auto n_walkers = [&](int64_t r) { const int64_t cap = j->h_tb_off[(size_t)r + 1] - j->h_tb_off[(size_t)r]; return cap <= TBS_SINGLE_STEPS ? (int64_t)1 : (cap + TBS_SEG - 1) / TBS_SEG; };
+                const int64_t single_steps = getenv("FZP_TB_SINGLE_STEPS") ? atol(getenv("FZP_TB_SINGLE_STEPS")) : TBS_SINGLE_STEPS;
+                auto n_walkers = [&](int64_t r) { const int64_t cap = j->h_tb_off[(size_t)r + 1] - j->h_tb_off[(size_t)r]; return cap <= single_steps ? (int64_t)1 : (cap + TBS_SEG - 1) / TBS_SEG; };
                 for (int64_t r = f; r < l; r++) { sgo[(size_t)r] = (int32_t)nw_chunk; nw_chunk += n_walkers(r); }
                 if (nw_chunk >= (1ll << 31)) { fzp_set_error("fzp_align_run: too many trace-back segments in one chunk"); return FZP_EINVAL; }
                 sgs.resize(sgs.size() + (size_t)nw_chunk); sgi.resize(sgs.size());
                 for (int64_t r = f; r < l; r++) {
                     const int64_t ns = n_walkers(r);
-                    const bool one = j->h_tb_off[(size_t)r + 1] - j->h_tb_off[(size_t)r] <= TBS_SINGLE_STEPS;
+                    const bool one = j->h_tb_off[(size_t)r + 1] - j->h_tb_off[(size_t)r] <= single_steps;
                     sg1[(size_t)r] = one ? 1 : 0;
                     for (int64_t x = 0; x < ns; x++) { sgs[(size_t)(j->h_seg_base[(size_t)f] + sgo[(size_t)r] + x)] = (int32_t)(r - f); sgi[(size_t)(j->h_seg_base[(size_t)f] + sgo[(size_t)r] + x)] = one ? -1 : (int32_t)x; }
                 }
@@ -2527,7 +2528,7 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
         // waves, and its instruction mix (v_bitop3, DPP, 3-operand forms) issues at ~4.5 cycles per SIMD however many waves share it: two such waves on one SIMD run at half
         // speed each.  So it is taken when its waves get a SIMD each and nothing else runs beside them; else the whole band sits in one lane (k_swb).  FZP_SWB_64 / FZP_SWB_PAIR force one.
         const int swb_force = getenv("FZP_SWB_64") ? 64 : (getenv("FZP_SWB_PAIR") ? 32 : 0);
-        int64_t swb_max_steps = TBS_SINGLE_STEPS;
+        int64_t swb_max_steps = 40960;          // ~ 18 kb reads: a lane's step costs ~330 ns, the chain of a longer extension would outlast the rest of the launch
         if (const char *e = getenv("FZP_SWB_MAX_STEPS")) { const long g = atol(e); if (g > 0) swb_max_steps = g; }
         std::vector<int64_t> &swb_at = j->h_swb_at, &sw_at = j->h_sw_at;
         if (use_bits) {
