@@ -974,6 +974,7 @@ __device__ __forceinline__ void swb_step(SwbLane &L, const int32_t t, ulonglong2
     L.down = (CHECKED && (t + 1) < 64) ? (uint32_t)(((t + 1) & 1) == 0) : (uint32_t)(L.E2 >= 0);
 }
 
+constexpr int SWB_GROUP = 8;      // steps whose mask records leave together (64 B per lane)
 __global__ void __launch_bounds__(64) k_swb(int64_t first, int64_t count, const int32_t *__restrict__ list, const int32_t *__restrict__ ridx, const uint32_t *__restrict__ read_ori,
                                              const int64_t *__restrict__ ori_woff, const int32_t *__restrict__ read_len, const int32_t *__restrict__ read_ctg,
                                              const uint32_t *__restrict__ ctg_pk, const int64_t *__restrict__ ctg_woff, const int64_t *__restrict__ ctg_len,
@@ -1028,22 +1029,22 @@ __global__ void __launch_bounds__(64) k_swb(int64_t first, int64_t count, const 
         // an interior block?  every running lane more than 64 steps away from its last row and its last column (a step brings either one closer by at most one)
         const bool far = !active || (nq - 1 - (L.i0 + 63) > 64 && nt - 1 - (t - L.i0) > 64);
         const bool interior = t >= 64 && __ballot(!far) == 0ull;
-        for (int g8 = 0; g8 < 8; g8++) {
+        for (int g8 = 0; g8 < 64 / SWB_GROUP; g8++) {
             const bool grp_active = active;
-            ulonglong2 rec[8];
+            ulonglong2 rec[SWB_GROUP];
             if (interior) {
 #pragma unroll
-                for (int s8 = 0; s8 < 8; s8++) { swb_step<false>(L, t, rec[s8], nq, nt, max_steps, active, row_on, col_on, Hrow, Hcol, best, bt, bl, steps); if ((dbg & 4) && grp_active) tbr[t] = rec[s8]; t++; }
+                for (int s8 = 0; s8 < SWB_GROUP; s8++) { swb_step<false>(L, t, rec[s8], nq, nt, max_steps, active, row_on, col_on, Hrow, Hcol, best, bt, bl, steps); t++; }
             } else {
 #pragma unroll
-                for (int s8 = 0; s8 < 8; s8++) { swb_step<true>(L, t, rec[s8], nq, nt, max_steps, active, row_on, col_on, Hrow, Hcol, best, bt, bl, steps); t++; }
+                for (int s8 = 0; s8 < SWB_GROUP; s8++) { swb_step<true>(L, t, rec[s8], nq, nt, max_steps, active, row_on, col_on, Hrow, Hcol, best, bt, bl, steps); t++; }
             }
             // the streams top up every 16 steps, and they do it HERE, ahead of a group's stores: taking the word loaded 16 steps ago means waiting on the vector-memory
             // counter, which also counts the mask stores -- at this point the youngest of those are 8 steps old and done, right behind a group they would be in flight
-            if ((g8 & 1) && !(dbg & 2)) { L.qs.refill(); L.ts.refill(); }
-            if (grp_active && !(dbg & 5)) {
+            if ((g8 & (16 / SWB_GROUP - 1)) == 16 / SWB_GROUP - 1 && !(dbg & 2)) { L.qs.refill(); L.ts.refill(); }
+            if (grp_active && !(dbg & 1)) {
 #pragma unroll
-                for (int s8 = 0; s8 < 8; s8++) tbr[t - 8 + s8] = rec[s8];
+                for (int s8 = 0; s8 < SWB_GROUP; s8++) tbr[t - SWB_GROUP + s8] = rec[s8];
             }
         }
         if (blk_active) {

@@ -12,8 +12,7 @@
 //      D bit (diagonal chosen, ties included) = match | (mismatch & p <= 1 & q <= 1), never under forbid
 //      p >= q  <=>  the cell above is at least as good as the one to the left
 // A neighbour outside the band enters as p = 0 / q = 0 ("two worse than the diagonal": never chosen).  The function is closed on 0..4, so the planes never
-// overflow whatever the band edges do.  Equivalent forms used below: on a mismatch (Pv, Qv) = (p -. q, q -. p) (+1 each when p = q = 0), on a match
-// (4 - q, 4 - p) -- both are a -. b ("monus") with a = (match ? 4 : p).
+// overflow whatever the band edges do.
 #pragma once
 #include <cstdint>
 
@@ -56,41 +55,45 @@ template <class W> struct PlanesT { W v0, v1, v2; };      // a value 0..4 per bi
 using Planes = PlanesT<uint64_t>;                        // 64 cells of a band in one lane (k_swb)
 using Planes32 = PlanesT<uint32_t>;                      // half a band per lane (k_swb2)
 
-// a -. b = max(a - b, 0) on planes (a, b in 0..4); *borrow = (a < b)
+// a - b on planes for a >= b (no borrow out of the top)
 template <class W>
-FZP_HD PlanesT<W> monus(const PlanesT<W> a, const PlanesT<W> b, W *borrow) {
+FZP_HD PlanesT<W> minus(const PlanesT<W> a, const PlanesT<W> b) {
     constexpr uint8_t BORROW = (uint8_t)((~TA & TB) | (~(TA ^ TB) & TC));       // borrow out of a - b - c
     constexpr uint8_t XOR3 = (uint8_t)(TA ^ TB ^ TC);
-    const W br0 = ~a.v0 & b.v0;
+    const W br0 = lut3<(uint8_t)(~TA & TB)>(a.v0, b.v0, (W)0);
     const W br1 = lut3<BORROW>(a.v1, b.v1, br0);
-    const W B = lut3<BORROW>(a.v2, b.v2, br1);
     PlanesT<W> r;
-    r.v0 = lut3<(uint8_t)((TA ^ TB) & ~TC)>(a.v0, b.v0, B);
-    r.v1 = lut3<XOR3>(a.v1, b.v1, br0) & ~B;
-    r.v2 = lut3<XOR3>(a.v2, b.v2, br1) & ~B;
-    *borrow = B;
+    r.v0 = a.v0 ^ b.v0;
+    r.v1 = lut3<XOR3>(a.v1, b.v1, br0);
+    r.v2 = lut3<XOR3>(a.v2, b.v2, br1);
     return r;
 }
 
 // One anti-diagonal of cells.  xm: mismatch bits; f: forbid bits (at most the band-edge lane); dn: all ones when the step moved DOWN, else zero.
 // p, q: the neighbours' planes lined up with the cells (already shifted).  Returns the cells' planes and the two trace-back masks of the step:
 // D = diagonal chosen, G = "the gap comes from the same lane of the previous step" (the cell above after DOWN, the one to the left after RIGHT;
-// defined where D = 0, the only place the walk looks at it).
+// defined where D = 0, the only place the walk looks at it).  25 three-input functions: max(p, q) by a borrow chain and three selects, the step's e folded
+// into its planes, two borrow-free subtractions; D needs only "max(p, q) <= 1"; and where the diagonal lost, q >= p  <=>  Pv = 0, p >= q  <=>  Qv = 0.
 template <class W>
 FZP_HD void cells(const W xm, const W f, const W dn, const PlanesT<W> p, const PlanesT<W> q, PlanesT<W> *Pv, PlanesT<W> *Qv, W *D, W *G) {
+    constexpr uint8_t BORROW = (uint8_t)((~TA & TB) | (~(TA ^ TB) & TC));
+    constexpr uint8_t SEL = (uint8_t)((TA & TB) | (~TA & TC));                 // a ? b : c
     const W x = xm | f;                              // "not a match" for the value logic
-    PlanesT<W> ph, qh;                               // match ? 4 : p
-    ph.v0 = p.v0 & x; ph.v1 = p.v1 & x; ph.v2 = p.v2 | ~x;
-    qh.v0 = q.v0 & x; qh.v1 = q.v1 & x; qh.v2 = q.v2 | ~x;
-    W b_pq, b_qp;
-    PlanesT<W> P = monus(ph, q, &b_pq), Q = monus(qh, p, &b_qp);
-    const W tp = p.v1 | p.v2, tq = q.v1 | q.v2;
-    const W le1 = ~(tp | tq);                                                 // p <= 1 and q <= 1
-    const W z = lut3<(uint8_t)(TA & ~TB & ~TC)>(le1, p.v0, q.v0) & xm & ~f;   // mismatch with p = q = 0: M = 1
-    P.v0 |= z; Q.v0 |= z;
+    const W xz = lut3<(uint8_t)(TA & ~TB)>(xm, f, (W)0);      // a plain mismatch: e = 1
+    const W b0 = lut3<(uint8_t)(~TA & TB)>(p.v0, q.v0, (W)0);
+    const W b1 = lut3<BORROW>(p.v1, q.v1, b0);
+    const W lt = lut3<BORROW>(p.v2, q.v2, b1);       // p < q
+    const W m0 = lut3<SEL>(lt, q.v0, p.v0), m1 = lut3<SEL>(lt, q.v1, p.v1), m2 = lut3<SEL>(lt, q.v2, p.v2);      // max(p, q)
+    const W t = m1 | m2;                             // max(p, q) >= 2
+    PlanesT<W> M;                                    // max(p, q, e):  match -> 4;  mismatch -> at least 1;  forbid -> max(p, q)
+    M.v2 = lut3<(uint8_t)(TA | ~TB)>(m2, x, (W)0);
+    M.v1 = m1 & x;
+    M.v0 = lut3<(uint8_t)(TA | (TB & ~TC))>(m0 & x, xz, t);
+    const PlanesT<W> P = minus(M, q), Q = minus(M, p);
     *Pv = P; *Qv = Q;
-    *D = lut3<(uint8_t)(~TA & (~TB | TC))>(f, xm, le1);                              // ~f & (match | le1)
-    *G = lut3<(uint8_t)((TA & ~TB) | (~TA & ~TC))>(dn, b_pq, b_qp);                  // DOWN: p >= q (above is the same lane);  RIGHT: q >= p
+    *D = lut3<(uint8_t)(~TA & (~TB | ~TC))>(f, xm, t);                          // ~f & (match | max(p, q) <= 1)
+    const W nzP = lut3<(uint8_t)(TA | TB | TC)>(P.v0, P.v1, P.v2), nzQ = lut3<(uint8_t)(TA | TB | TC)>(Q.v0, Q.v1, Q.v2);
+    *G = lut3<(uint8_t)((TA & ~TB) | (~TA & ~TC))>(dn, nzQ, nzP);               // DOWN: p >= q (above is the same lane);  RIGHT: q >= p
 }
 
 // value 0..4 at bit position k of planes

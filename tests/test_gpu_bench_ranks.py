@@ -36,7 +36,7 @@ def test_two_ranks_share_one_gpu():
         assert d["unit"] == "reads/s" and d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"]
         assert d["roofline"]["bound"] == "hbm" and d["roofline"]["launches"] >= 2 and d["roofline"]["peak"] == 8000.0 and 0 < d["roofline"]["frac"] < 1
         assert d["roofline"]["valu"]["peak"] == 1228.8 and 0 < d["roofline"]["valu"]["frac"] < 1
-        assert d["roofline"]["hbm"]["unit"] == "GB/s" and d["index_in_step"] is True and d["index_ms"] > 0
+        assert d["roofline"]["unit"] == "GB/s" and d["index_in_step"] is True and d["index_ms"] > 0
         assert d["aligned_frac"] > 0.98
     assert one["stage_counts"]["r2p_records"] == 300 and two["stage_counts"]["r2p_records"] == 600      # the all-gather saw both shards
     assert two["config"]["reads_per_gpu"] == one["config"]["reads_per_gpu"] == 300 and two["config"]["reads_total"] == 600
