@@ -975,13 +975,14 @@ __device__ __forceinline__ void swb_step(SwbLane &L, const int32_t t, ulonglong2
 }
 
 constexpr int SWB_GROUP = 8;      // steps whose mask records leave together (64 B per lane)
-__global__ void __launch_bounds__(64) k_swb(int64_t first, int64_t count, const int32_t *__restrict__ list, const int32_t *__restrict__ ridx, const uint32_t *__restrict__ read_ori,
+__global__ void __launch_bounds__(256) k_swb(int64_t first, int64_t count, const int32_t *__restrict__ list, const int32_t *__restrict__ ridx, const uint32_t *__restrict__ read_ori,
                                              const int64_t *__restrict__ ori_woff, const int32_t *__restrict__ read_len, const int32_t *__restrict__ read_ctg,
                                              const uint32_t *__restrict__ ctg_pk, const int64_t *__restrict__ ctg_woff, const int64_t *__restrict__ ctg_len,
                                              const Anchor *__restrict__ anc, const int64_t *__restrict__ tb_off, uint2 *__restrict__ tb, ulonglong2 *__restrict__ mvw,
                                              DpInfo *__restrict__ info, int64_t *__restrict__ tbo, int64_t *__restrict__ mvo, const int64_t *__restrict__ m_off, const int64_t *__restrict__ mv_off, uint8_t *__restrict__ handled, int32_t steps_limit, int dbg) {
     using namespace swb;
-    const int64_t li = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    // (workgroups of one wave: four-wave workgroups, which suit k_swb2, put 256 mask streams on a CU and cost this kernel 10 % -- address translation again)
+    const int64_t li = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t wv = li < count ? list[li] : -1;       // the lane's slot in the chunk, -1: none
     bool active = wv >= 0;
     const int64_t sl = first + (active ? wv : 0);
@@ -1128,7 +1129,7 @@ __device__ __forceinline__ void swb2_step(SwbPair &L, const uint32_t is_hi, cons
     L.down = (CHECKED && (t + 1) < 64) ? (uint32_t)(((t + 1) & 1) == 0) : (uint32_t)(L.E2 >= 0);
 }
 
-__global__ void __launch_bounds__(64) k_swb2(int64_t first, int64_t count, const int32_t *__restrict__ list, const int32_t *__restrict__ ridx, const uint32_t *__restrict__ read_ori,
+__global__ void __launch_bounds__(256) k_swb2(int64_t first, int64_t count, const int32_t *__restrict__ list, const int32_t *__restrict__ ridx, const uint32_t *__restrict__ read_ori,
                                               const int64_t *__restrict__ ori_woff, const int32_t *__restrict__ read_len, const int32_t *__restrict__ read_ctg,
                                               const uint32_t *__restrict__ ctg_pk, const int64_t *__restrict__ ctg_woff, const int64_t *__restrict__ ctg_len,
                                               const Anchor *__restrict__ anc, const int64_t *__restrict__ tb_off, uint2 *__restrict__ tb, ulonglong2 *__restrict__ mvw,
@@ -1137,7 +1138,9 @@ __global__ void __launch_bounds__(64) k_swb2(int64_t first, int64_t count, const
     using namespace swb;
     const uint32_t is_hi = threadIdx.x & 1u;
     const bool lo = is_hi == 0u;
-    const int64_t li = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 1);
+    // workgroups of four waves -- independent of each other, no LDS, no barrier: a workgroup's waves are spread over its CU's four SIMDs, single-wave workgroups are not
+    // (625 of them on 256 CUs ran two to a SIMD here and there -- 12.2 ms instead of 7.4 -- and a SIMD shared by two of these waves runs each at little more than half speed)
+    const int64_t li = (int64_t)blockIdx.x * (blockDim.x >> 1) + (threadIdx.x >> 1);
     const int64_t wv = li < count ? list[li] : -1;       // the pair's slot in the chunk, -1: none
     bool active = wv >= 0;
     const int64_t sl = first + (active ? wv : 0);
@@ -2602,11 +2605,11 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
                         FZP_HIP(hipEventRecord(j->ev_l[1], ctx->stream3));
                     }
                     if (b_n > 0 && !swb64)
-                        hipLaunchKernelGGL(k_swb2, dim3((unsigned)(b_n / 32)), dim3(64), 0, st, first, b_n, (const int32_t *)(j->swb_list.p + b_at), (const int32_t *)nullptr, j->read_ori.p, j->read_woff.p,
+                        hipLaunchKernelGGL(k_swb2, dim3((unsigned)((b_n + 127) / 128)), dim3(256), 0, st, first, b_n, (const int32_t *)(j->swb_list.p + b_at), (const int32_t *)nullptr, j->read_ori.p, j->read_woff.p,
                                            j->read_len.p, j->read_ctg.p, j->ctg_pk.p, j->ctg_woff.p, j->ctg_len.p, j->anc.p, j->tb_off.p, j->tb2[bi].p, j->mvw2[bi].p, j->info.p, j->tbo.p, j->mvo.p,
                                            (const int64_t *)j->tbm_off.p, (const int64_t *)j->mvm_off.p, (uint8_t *)nullptr, 0x7fffffff);
                     if (b_n > 0 && swb64)
-                        hipLaunchKernelGGL(k_swb, dim3((unsigned)(b_n / 64)), dim3(64), 0, st, first, b_n, (const int32_t *)(j->swb_list.p + b_at), (const int32_t *)nullptr, j->read_ori.p, j->read_woff.p,
+                        hipLaunchKernelGGL(k_swb, dim3((unsigned)((b_n + 63) / 64)), dim3(64), 0, st, first, b_n, (const int32_t *)(j->swb_list.p + b_at), (const int32_t *)nullptr, j->read_ori.p, j->read_woff.p,
                                            j->read_len.p, j->read_ctg.p, j->ctg_pk.p, j->ctg_woff.p, j->ctg_len.p, j->anc.p, j->tb_off.p, j->tb2[bi].p, j->mvw2[bi].p, j->info.p, j->tbo.p, j->mvo.p, (const int64_t *)j->tbm_off.p, (const int64_t *)j->mvm_off.p,
                                            (uint8_t *)nullptr, 0x7fffffff, getenv("FZP_SWB_DBG") ? atoi(getenv("FZP_SWB_DBG")) : 0);
                     if (w_n > 0) FZP_HIP(hipStreamWaitEvent(st, j->ev_l[1], 0));
@@ -2642,7 +2645,7 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
                 const bool swb64 = swb_force ? swb_force == 64 : !((cnt + 31) / 32 <= (int64_t)ctx->n_cu * 4);
                 if (use_bits && !swb64) {
                     FZP_TRY(j->b_handled.alloc((size_t)nr));
-                    hipLaunchKernelGGL(k_swb2, dim3((unsigned)((cnt + 31) / 32)), dim3(64), 0, st, first, cnt, (const int32_t *)j->b_iota.p, (const int32_t *)nullptr, j->bq.p, j->bq_off.p, j->b_len.p, j->b_iota.p,
+                    hipLaunchKernelGGL(k_swb2, dim3((unsigned)((cnt + 127) / 128)), dim3(256), 0, st, first, cnt, (const int32_t *)j->b_iota.p, (const int32_t *)nullptr, j->bq.p, j->bq_off.p, j->b_len.p, j->b_iota.p,
                                        j->bt.p, j->bt_off.p, j->b_tlen.p, j->anc_b.p, j->tb_off_b.p, j->tb_b2[bi].p, j->mvw_b2[bi].p, j->info_b.p, j->tbo_b.p, j->mvo_b.p,
                                        (const int64_t *)nullptr, (const int64_t *)nullptr, j->b_handled.p, (int32_t)swb_max_steps);
                 }
