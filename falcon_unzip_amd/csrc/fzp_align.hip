@@ -586,7 +586,7 @@ __device__ __forceinline__ void scalar_store16(void *base, uint32_t byte_off, ui
         const uint64_t gmask = __ballot(m == H);                                                           \
         Hn = max(hd, m - gap);                                                                             \
         const uint64_t dmask = __ballot(Hn == hd);                                                         \
-        if (STORE) scalar_store16(tbr, (uint32_t)__builtin_amdgcn_readfirstlane(t) * 16u, dmask, gmask);   \
+        if (STORE) { const uint32_t t_ = (uint32_t)__builtin_amdgcn_readfirstlane(t); scalar_store16(tbr, ((t_ >> 6) * (uint32_t)stride + (t_ & 63u)) * 16u, dmask, gmask); } \
         bool upd = Hn > bs;                                                                                \
         {                                                                                                  \
             const int32_t ci = i0 + lane, cj = t - ci;                                                     \
@@ -752,7 +752,7 @@ __global__ void __launch_bounds__(64) k_sw(int64_t first, int64_t count, const i
                                             const Anchor *__restrict__ anc, const int64_t *__restrict__ tb_off, uint2 *__restrict__ tb, ulonglong2 *__restrict__ mvw,
                                             int match, int mismatch, int gap, DpInfo *__restrict__ info, int64_t *__restrict__ tbo, int64_t *__restrict__ mvo,
                                             const int32_t *__restrict__ order, int32_t prio_len, const int64_t *__restrict__ m_off, const int64_t *__restrict__ mv_off,
-                                            const uint8_t *__restrict__ skip) {
+                                            const uint8_t *__restrict__ skip, int32_t m_stride, int32_t *__restrict__ tbs) {
     const int lane = lane_id();
     // wave-uniform on purpose: everything indexed by the read then lives in SGPRs / scalar loads
     const int64_t wq = (int64_t)blockIdx.x;   // one wave per workgroup: a finished read frees its slot at once
@@ -770,7 +770,10 @@ __global__ void __launch_bounds__(64) k_sw(int64_t first, int64_t count, const i
     const int64_t toff = m_off ? m_off[sl] : tb_off[sl] - tb_off[first], moff = m_off ? mv_off[sl] : (toff >> 6) + wv;
     ulonglong2 *tbr = (ulonglong2 *)tb + toff;   // per step: {D mask, G mask} over the 64 band lanes
     ulonglong2 *mvr = mvw + moff;                // per 64 steps: {move bits, i0 before the chunk}
-    if (tbo && lane == 0) { tbo[sl] = toff; mvo[sl] = moff; }   // element offsets into the chunk's buffers
+    // the records of steps 64 b .. 64 b + 63 of a slot start at record b * stride of its stream: 64 for a stream of its own; planned streams (m_off) are interleaved
+    // block by block with the 63 others of their launch group (stride 64 x 64), so that what a wave of the bit-sliced kernel writes at a time lies within 64 KB
+    const int32_t stride = m_off ? m_stride : 64;
+    if (tbo && lane == 0) { tbo[sl] = toff; mvo[sl] = moff; if (tbs) tbs[sl] = stride; }   // element offsets into the chunk's buffers
     if (!a.aligned) { if (lane == 0) info[sl] = DpInfo{0, -1, 0, NEGV}; return; }
     const int c_idx = read_ctg[r];
     const int64_t n = read_len[r];
@@ -837,7 +840,8 @@ __global__ void __launch_bounds__(64) k_sw(int64_t first, int64_t count, const i
                 // the store offset doubles as the block's step counter: it starts 16 * n_steps below 2^31 (the base pointer makes up for
                 // it), and the add that would carry it past 2^31 -- the signed overflow of s_addk_i32 -- ends the block
                 uint32_t soff = 0x80000000u - 16u * (uint32_t)n_steps;
-                void *tbp = (void *)((char *)tbr + ((int64_t)__builtin_amdgcn_readfirstlane(t) * 16 - (int64_t)soff));
+                const int32_t t_ = __builtin_amdgcn_readfirstlane(t);      // (a block never crosses a multiple of 32 steps: its records are contiguous)
+                void *tbp = (void *)((char *)tbr + (((int64_t)(t_ >> 6) * stride + (t_ & 63)) * 16 - (int64_t)soff));
                 sw_block<STORE>(H, X, qc, tc, qbits, tbits, kb, tbp, soff, mv, dn, pm, gapS, vmatS, vmisS);
                 // (v1.5: no cell of an interior block is a border cell, so the block has no terminal candidates to report)
                 pm = (int32_t)(mv & 1u);                                 // the block's last move (the steps no longer keep it up to date)
@@ -974,12 +978,14 @@ __device__ __forceinline__ void swb_step(SwbLane &L, const int32_t t, ulonglong2
     L.down = (CHECKED && (t + 1) < 64) ? (uint32_t)(((t + 1) & 1) == 0) : (uint32_t)(L.E2 >= 0);
 }
 
+constexpr int SWB_WPG = 1;        // waves per workgroup of k_swb (four measured: 10.1 against 9.7 ms)
 constexpr int SWB_GROUP = 8;      // steps whose mask records leave together (64 B per lane)
 __global__ void __launch_bounds__(256) k_swb(int64_t first, int64_t count, const int32_t *__restrict__ list, const int32_t *__restrict__ ridx, const uint32_t *__restrict__ read_ori,
                                              const int64_t *__restrict__ ori_woff, const int32_t *__restrict__ read_len, const int32_t *__restrict__ read_ctg,
                                              const uint32_t *__restrict__ ctg_pk, const int64_t *__restrict__ ctg_woff, const int64_t *__restrict__ ctg_len,
                                              const Anchor *__restrict__ anc, const int64_t *__restrict__ tb_off, uint2 *__restrict__ tb, ulonglong2 *__restrict__ mvw,
-                                             DpInfo *__restrict__ info, int64_t *__restrict__ tbo, int64_t *__restrict__ mvo, const int64_t *__restrict__ m_off, const int64_t *__restrict__ mv_off, uint8_t *__restrict__ handled, int32_t steps_limit, int dbg) {
+                                             DpInfo *__restrict__ info, int64_t *__restrict__ tbo, int64_t *__restrict__ mvo, const int64_t *__restrict__ m_off, const int64_t *__restrict__ mv_off, uint8_t *__restrict__ handled, int32_t steps_limit, int dbg,
+                                             int32_t m_stride, int32_t *__restrict__ tbs) {
     using namespace swb;
     // (workgroups of one wave: four-wave workgroups, which suit k_swb2, put 256 mask streams on a CU and cost this kernel 10 % -- address translation again)
     const int64_t li = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1004,7 +1010,8 @@ __global__ void __launch_bounds__(256) k_swb(int64_t first, int64_t count, const
         if (active) handled[sl] = mine ? 1 : 0;
         active = mine;
     }
-    if (active && tbo) { tbo[sl] = toff; mvo[sl] = moff; }
+    const int32_t stride = m_off ? m_stride : 64;        // records from one 64-step block of this stream to the next (k_sw)
+    if (active && tbo) { tbo[sl] = toff; mvo[sl] = moff; if (tbs) tbs[sl] = stride; }
     if (active && !a.aligned) { info[sl] = DpInfo{0, -1, 0, NEGV}; active = false; }
     const uint32_t *qpk = read_ori + ori_woff[sl];
     const uint32_t *tpk = ctg_pk + ctg_woff[c_idx];
@@ -1045,7 +1052,7 @@ __global__ void __launch_bounds__(256) k_swb(int64_t first, int64_t count, const
             if ((g8 & (16 / SWB_GROUP - 1)) == 16 / SWB_GROUP - 1 && !(dbg & 2)) { L.qs.refill(); L.ts.refill(); }
             if (grp_active && !(dbg & 1)) {
 #pragma unroll
-                for (int s8 = 0; s8 < SWB_GROUP; s8++) tbr[t - SWB_GROUP + s8] = rec[s8];
+                for (int s8 = 0; s8 < SWB_GROUP; s8++) tbr[(int64_t)((t - SWB_GROUP) >> 6) * stride + ((t - SWB_GROUP) & 63) + s8] = rec[s8];
             }
         }
         if (blk_active) {
@@ -1134,7 +1141,7 @@ __global__ void __launch_bounds__(256) k_swb2(int64_t first, int64_t count, cons
                                               const uint32_t *__restrict__ ctg_pk, const int64_t *__restrict__ ctg_woff, const int64_t *__restrict__ ctg_len,
                                               const Anchor *__restrict__ anc, const int64_t *__restrict__ tb_off, uint2 *__restrict__ tb, ulonglong2 *__restrict__ mvw,
                                               DpInfo *__restrict__ info, int64_t *__restrict__ tbo, int64_t *__restrict__ mvo, const int64_t *__restrict__ m_off, const int64_t *__restrict__ mv_off,
-                                              uint8_t *__restrict__ handled, int32_t steps_limit) {
+                                              uint8_t *__restrict__ handled, int32_t steps_limit, int32_t m_stride, int32_t *__restrict__ tbs) {
     using namespace swb;
     const uint32_t is_hi = threadIdx.x & 1u;
     const bool lo = is_hi == 0u;
@@ -1160,7 +1167,8 @@ __global__ void __launch_bounds__(256) k_swb2(int64_t first, int64_t count, cons
         if (active && lo) handled[sl] = mine ? 1 : 0;
         active = mine;
     }
-    if (active && tbo && lo) { tbo[sl] = toff; mvo[sl] = moff; }
+    const int32_t stride = m_off ? m_stride : 64;
+    if (active && tbo && lo) { tbo[sl] = toff; mvo[sl] = moff; if (tbs) tbs[sl] = stride; }
     if (active && !a.aligned) { if (lo) info[sl] = DpInfo{0, -1, 0, NEGV}; active = false; }
     const uint32_t *qpk = read_ori + ori_woff[sl];
     const uint32_t *tpk = ctg_pk + ctg_woff[c_idx];
@@ -1204,7 +1212,7 @@ __global__ void __launch_bounds__(256) k_swb2(int64_t first, int64_t count, cons
             if (g8 & 1) L.ss.refill();      // (ahead of the stores: see k_swb)
             if (grp_active) {
 #pragma unroll
-                for (int s8 = 0; s8 < 8; s8++) tbr[2 * (t - 8 + s8)] = rec[s8];
+                for (int s8 = 0; s8 < 8; s8++) tbr[2 * ((int64_t)((t - 8) >> 6) * stride + ((t - 8) & 63) + s8)] = rec[s8];
             }
         }
         if (blk_active) {
@@ -1271,7 +1279,7 @@ __global__ void __launch_bounds__(64 * TBW_WPG) k_tb_walk(int64_t first, int64_t
                                                 const ulonglong2 *__restrict__ tb, const ulonglong2 *__restrict__ mvw, uint32_t *__restrict__ raw,
                                                 WalkOut *__restrict__ wout, const int32_t *__restrict__ order, const int32_t *__restrict__ seg_slot,
                                                 const int32_t *__restrict__ seg_idx, uint32_t *__restrict__ trail, SegOut *__restrict__ segout, int only_flagged, int guess_lane,
-                                                const SegReq *__restrict__ req, const uint32_t *__restrict__ n_req, uint32_t *__restrict__ raw_final) {
+                                                const SegReq *__restrict__ req, const uint32_t *__restrict__ n_req, uint32_t *__restrict__ raw_final, const int32_t *__restrict__ tbs) {
     // TBW_WPG independent waves per workgroup (a workgroup's waves are spread over its CU's SIMDs; single-wave workgroups land two and three to a SIMD while others idle):
     // every wave has its own slice of the LDS buffer and never waits for another
     __shared__ __attribute__((aligned(16))) uint8_t lds_all[TBW_WPG * TBW_RPW * TBW_STRIDE];
@@ -1329,6 +1337,7 @@ __global__ void __launch_bounds__(64 * TBW_WPG) k_tb_walk(int64_t first, int64_t
     int32_t ncol = 0, n_ops = 0, nw = 0;
     uint32_t rawacc = 0, nb = 0;
     const int32_t plo = (int32_t)(uint32_t)(uint64_t)tbr, phi = (int32_t)((uint64_t)tbr >> 32);
+    const int32_t rstride = (tbs && have) ? tbs[r] : 64;      // records from one 64-step chunk of the read's masks to the next
     uint8_t *mine = lds + lane * TBW_STRIDE;
     int32_t cur_chunk = -2, sh_cur = 0;
     int32_t pref_chunk = active ? ts >> 6 : -1, pref_sh = min(max(k - 16, 0), 32);
@@ -1347,7 +1356,7 @@ __global__ void __launch_bounds__(64 * TBW_WPG) k_tb_walk(int64_t first, int64_t
     _Pragma("unroll") for (int l = 0; l < TBW_RPW; l++) {                                                                \
         const int32_t cl = __builtin_amdgcn_readlane(pref_chunk, l);                                                     \
         if (cl >= 0) {                                                                                                   \
-            const tbw_u32x4 q_ = ((tbw_gptr)rec_base[l])[(int64_t)cl * 64 + lane];                                              \
+            const tbw_u32x4 q_ = ((tbw_gptr)rec_base[l])[(int64_t)cl * __builtin_amdgcn_readlane(rstride, l) + lane];            \
             pf[l] = make_uint4(q_.x, q_.y, q_.z, q_.w);                                                                  \
         }                                                                                                                \
     }
@@ -1379,7 +1388,7 @@ __global__ void __launch_bounds__(64 * TBW_WPG) k_tb_walk(int64_t first, int64_t
                 if (!((redo >> l) & 1ull)) continue;
                 const uint64_t pl = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(phi, l) << 32) | (uint32_t)__builtin_amdgcn_readlane(plo, l);
                 const int32_t cl = __builtin_amdgcn_readlane(cur_chunk, l), sh = __builtin_amdgcn_readlane(sh_cur, l);
-                const uint4 v = ((const uint4 *)pl)[(int64_t)cl * 64 + lane];
+                const uint4 v = ((const uint4 *)pl)[(int64_t)cl * __builtin_amdgcn_readlane(rstride, l) + lane];
                 const uint64_t D = ((uint64_t)v.y << 32) | v.x, G = ((uint64_t)v.w << 32) | v.z;
                 *(uint2 *)(lds + l * TBW_STRIDE + lane * 8) = make_uint2((uint32_t)(D >> sh), (uint32_t)(G >> sh));
             }
@@ -1907,7 +1916,7 @@ __global__ void __launch_bounds__(256) k_sec_count(int64_t n, const Anchor *__re
 // scored strictly higher; `steps` of the survivor counts the DP steps of both (fzp_aln_summary.cells)
 __global__ void __launch_bounds__(256) k_pick(int64_t w_lo, int64_t w_hi, const int32_t *__restrict__ ridx, const Anchor *__restrict__ anc2, const DpInfo *__restrict__ info2,
                                               const int64_t *__restrict__ tb_off2, int64_t tb_base, int64_t mv_base, Anchor *__restrict__ anc, DpInfo *__restrict__ info,
-                                              int64_t *__restrict__ tbo, int64_t *__restrict__ mvo, uint8_t *__restrict__ won) {
+                                              int64_t *__restrict__ tbo, int64_t *__restrict__ mvo, uint8_t *__restrict__ won, int32_t *__restrict__ tbs) {
     const int64_t w = w_lo + (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (w >= w_hi) return;
     const int32_t r = ridx[w];
@@ -1920,6 +1929,7 @@ __global__ void __launch_bounds__(256) k_pick(int64_t w_lo, int64_t w_hi, const 
         anc[r] = anc2[w];
         const int64_t so = tb_off2[w] - tb_off2[w_lo];
         tbo[r] = tb_base + so;
+        if (tbs) tbs[r] = 64;                      // the second candidates' streams are their own
         mvo[r] = mv_base + (so >> 6) + (w - w_lo);
     }
     a.steps = total;
@@ -2159,6 +2169,8 @@ struct fzp_alnjob {
     DevBuf<uint32_t> tb_fallback;                // [0] reads of the last run walked serially after all, [1] repair walks asked for in the chunk at hand, [2] in the whole run
     DevBuf<SegReq> seg_req;
     DevBuf<uint8_t> b_handled;                   // per read: its backward extension ran in the bit-sliced kernel
+    DevBuf<int32_t> tbs;                         // per read: records from one 64-step block of its masks to the next (64: a stream of its own; 4096: interleaved with its launch group)
+    std::vector<int64_t> h_tbm_total;            // per chunk (by its first read): records its planned mask streams span
     DevBuf<int64_t> tbm_off, mvm_off;            // per read: where its masks / move words go in its chunk's buffers, planned in LAUNCH order (longest first)
     DevBuf<int32_t> swb_list, sw_list;           // per run: the chunk's slots by DP kernel (k_swb: 64 per wave, -1 padded; k_sw: its launch order)
     std::vector<int32_t> h_swb_list, h_sw_list, h_lpt;
@@ -2477,13 +2489,23 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
                 }
                 for (int64_t r = f; r < l; r++) ord[(size_t)r] = (int32_t)(r - f);
                 std::stable_sort(ord.begin() + f, ord.begin() + l, [&](int32_t a, int32_t b) { return j->h_read_len[(size_t)(f + a)] > j->h_read_len[(size_t)(f + b)]; });
-                {   // mask streams in the same order
-                    int64_t acc = 0;
-                    for (int64_t x = 0; x < l - f; x++) {
-                        const int64_t r = f + ord[(size_t)(f + x)];
-                        h_tbm[(size_t)r] = acc; h_mvm[(size_t)r] = (acc >> 6) + x;
-                        acc += j->h_tb_off[(size_t)r + 1] - j->h_tb_off[(size_t)r];
+                {   // mask streams in the same order, interleaved block by block within every group of 64 (= a wave of the bit-sliced kernel, give or take the slots
+                    // that go to k_sw): block b of the group's x-th stream starts at record (b * 64 + x) * 64 of the group's region -- what a wave writes
+                    // during 64 steps lies within 64 KB instead of in 64 places half a megabyte apart (address translation was a third of that kernel's time)
+                    int64_t acc = 0, region = 0;
+                    if (j->h_tbm_total.size() < (size_t)nr + 1) j->h_tbm_total.assign((size_t)nr + 1, 0);
+                    for (int64_t g0 = 0; g0 < l - f; g0 += 64) {
+                        const int64_t gn = std::min<int64_t>(64, l - f - g0);
+                        int64_t cap_max = 0;
+                        for (int64_t x = g0; x < g0 + gn; x++) { const int64_t r = f + ord[(size_t)(f + x)]; cap_max = std::max(cap_max, j->h_tb_off[(size_t)r + 1] - j->h_tb_off[(size_t)r]); }
+                        for (int64_t x = g0; x < g0 + gn; x++) {
+                            const int64_t r = f + ord[(size_t)(f + x)];
+                            h_tbm[(size_t)r] = region + (x - g0) * 64; h_mvm[(size_t)r] = (acc >> 6) + x;
+                            acc += j->h_tb_off[(size_t)r + 1] - j->h_tb_off[(size_t)r];
+                        }
+                        region += 64 * cap_max;
                     }
+                    j->h_tbm_total[(size_t)f] = region;
                 }
                 // walkers of the segmented trace-back: one per TBS_SEG steps of every read's step capacity, longest reads first
                 j->h_seg_base[(size_t)f] = (int64_t)sgs.size();
@@ -2591,7 +2613,9 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
             size_t w_hi = w_lo;
             while (w_hi < h_ridx.size() && h_ridx[w_hi] < last) w_hi++;
             const int64_t c2 = (int64_t)(w_hi - w_lo), steps2 = h_tb_off2[w_hi] - h_tb_off2[w_lo];
-            const int64_t tb_base = steps + 64, mv_base = steps / 64 + cnt + 2;
+            const int64_t tsteps = use_bits ? j->h_tbm_total[(size_t)first] : steps;      // records the chunk's first-candidate masks span (planned streams have some slack)
+            const int64_t tb_base = tsteps + 64, mv_base = steps / 64 + cnt + 2;
+            FZP_TRY(j->tbs.alloc((size_t)nr));
             FZP_TRY(j->tb2[bi].alloc((size_t)(tb_base + steps2) * 2 + 128));
             FZP_TRY(j->mvw2[bi].alloc((size_t)(mv_base + steps2 / 64 + c2 + 2)));
             FZP_TRY(j->raw2[bi].alloc((size_t)(steps / 16 + 64)));
@@ -2607,33 +2631,33 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
                         FZP_HIP(hipStreamWaitEvent(ctx->stream3, j->ev_l[0], 0));
                         hipLaunchKernelGGL(no_masks ? k_sw<false> : k_sw<true>, dim3((unsigned)w_n), dim3(64), 0, ctx->stream3, first, w_n, (const int32_t *)nullptr, j->read_ori.p, j->read_woff.p, j->read_len.p, j->read_ctg.p,
                                            j->ctg_pk.p, j->ctg_woff.p, j->ctg_len.p, j->anc.p, j->tb_off.p, j->tb2[bi].p, j->mvw2[bi].p, P.match, P.mismatch, P.gap, j->info.p, j->tbo.p, j->mvo.p,
-                                           (const int32_t *)(j->sw_list.p + w_at), use_prio ? mean_len : 0, (const int64_t *)j->tbm_off.p, (const int64_t *)j->mvm_off.p, (const uint8_t *)nullptr);
+                                           (const int32_t *)(j->sw_list.p + w_at), use_prio ? mean_len : 0, (const int64_t *)j->tbm_off.p, (const int64_t *)j->mvm_off.p, (const uint8_t *)nullptr, 64 * 64, j->tbs.p);
                         FZP_HIP(hipEventRecord(j->ev_l[1], ctx->stream3));
                     }
                     if (b_n > 0 && !swb64)
                         hipLaunchKernelGGL(k_swb2, dim3((unsigned)((b_n + 127) / 128)), dim3(256), 0, st, first, b_n, (const int32_t *)(j->swb_list.p + b_at), (const int32_t *)nullptr, j->read_ori.p, j->read_woff.p,
                                            j->read_len.p, j->read_ctg.p, j->ctg_pk.p, j->ctg_woff.p, j->ctg_len.p, j->anc.p, j->tb_off.p, j->tb2[bi].p, j->mvw2[bi].p, j->info.p, j->tbo.p, j->mvo.p,
-                                           (const int64_t *)j->tbm_off.p, (const int64_t *)j->mvm_off.p, (uint8_t *)nullptr, 0x7fffffff);
+                                           (const int64_t *)j->tbm_off.p, (const int64_t *)j->mvm_off.p, (uint8_t *)nullptr, 0x7fffffff, 64 * 64, j->tbs.p);
                     if (b_n > 0 && swb64)
-                        hipLaunchKernelGGL(k_swb, dim3((unsigned)((b_n + 63) / 64)), dim3(64), 0, st, first, b_n, (const int32_t *)(j->swb_list.p + b_at), (const int32_t *)nullptr, j->read_ori.p, j->read_woff.p,
+                        hipLaunchKernelGGL(k_swb, dim3((unsigned)((b_n + 64 * SWB_WPG - 1) / (64 * SWB_WPG))), dim3(64 * SWB_WPG), 0, st, first, b_n, (const int32_t *)(j->swb_list.p + b_at), (const int32_t *)nullptr, j->read_ori.p, j->read_woff.p,
                                            j->read_len.p, j->read_ctg.p, j->ctg_pk.p, j->ctg_woff.p, j->ctg_len.p, j->anc.p, j->tb_off.p, j->tb2[bi].p, j->mvw2[bi].p, j->info.p, j->tbo.p, j->mvo.p, (const int64_t *)j->tbm_off.p, (const int64_t *)j->mvm_off.p,
-                                           (uint8_t *)nullptr, 0x7fffffff, getenv("FZP_SWB_DBG") ? atoi(getenv("FZP_SWB_DBG")) : 0);
+                                           (uint8_t *)nullptr, 0x7fffffff, getenv("FZP_SWB_DBG") ? atoi(getenv("FZP_SWB_DBG")) : 0, 64 * 64, j->tbs.p);
                     if (w_n > 0) FZP_HIP(hipStreamWaitEvent(st, j->ev_l[1], 0));
                 } else
                 hipLaunchKernelGGL(no_masks ? k_sw<false> : k_sw<true>, dim3((unsigned)cnt), dim3(64), 0, st, first, cnt, (const int32_t *)nullptr, j->read_ori.p, j->read_woff.p, j->read_len.p, j->read_ctg.p,
                                    j->ctg_pk.p, j->ctg_woff.p, j->ctg_len.p, j->anc.p, j->tb_off.p, j->tb2[bi].p, j->mvw2[bi].p, P.match, P.mismatch, P.gap, j->info.p, j->tbo.p, j->mvo.p,
-                                   use_lpt ? (const int32_t *)(j->lpt.p + first) : (const int32_t *)nullptr, use_prio ? mean_len : 0, (const int64_t *)nullptr, (const int64_t *)nullptr, (const uint8_t *)nullptr);
+                                   use_lpt ? (const int32_t *)(j->lpt.p + first) : (const int32_t *)nullptr, use_prio ? mean_len : 0, (const int64_t *)nullptr, (const int64_t *)nullptr, (const uint8_t *)nullptr, 64, j->tbs.p);
             }
             if (c2 > 0) {     // same kernel over the compacted list, then the better extension of each read survives
                 {
                     ProfScope ps(ctx, "k1_sw2");
                     hipLaunchKernelGGL(k_sw<true>, dim3((unsigned)c2), dim3(64), 0, st, (int64_t)w_lo, c2, j->ridx.p, j->sec_ori.p, j->sec_woff.p, j->read_len.p, j->read_ctg.p,
                                        j->ctg_pk.p, j->ctg_woff.p, j->ctg_len.p, j->anc2.p, j->tb_off2.p, j->tb2[bi].p + 2 * tb_base, j->mvw2[bi].p + mv_base, P.match, P.mismatch,
-                                       P.gap, j->info2.p, (int64_t *)nullptr, (int64_t *)nullptr, (const int32_t *)nullptr, 0, (const int64_t *)nullptr, (const int64_t *)nullptr, (const uint8_t *)nullptr);
+                                       P.gap, j->info2.p, (int64_t *)nullptr, (int64_t *)nullptr, (const int32_t *)nullptr, 0, (const int64_t *)nullptr, (const int64_t *)nullptr, (const uint8_t *)nullptr, 64, (int32_t *)nullptr);
                 }
                 ProfScope ps(ctx, "k1_pick");
                 hipLaunchKernelGGL(k_pick, dim3((unsigned)((c2 + 255) / 256)), dim3(256), 0, st, (int64_t)w_lo, (int64_t)w_hi, j->ridx.p, j->anc2.p, j->info2.p, j->tb_off2.p,
-                                   tb_base, mv_base, j->anc.p, j->info.p, j->tbo.p, j->mvo.p, j->won.p);
+                                   tb_base, mv_base, j->anc.p, j->info.p, j->tbo.p, j->mvo.p, j->won.p, j->tbs.p);
                 hipLaunchKernelGGL(k_pick_copy, dim3((unsigned)c2), dim3(256), 0, st, (int64_t)w_lo, j->ridx.p, j->won.p, j->read_len.p, j->sec_ori.p, j->sec_woff.p, j->read_woff.p, j->read_ori.p);
             }
             w_lo = w_hi;
@@ -2653,17 +2677,17 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
                     FZP_TRY(j->b_handled.alloc((size_t)nr));
                     hipLaunchKernelGGL(k_swb2, dim3((unsigned)((cnt + 127) / 128)), dim3(256), 0, st, first, cnt, (const int32_t *)j->b_iota.p, (const int32_t *)nullptr, j->bq.p, j->bq_off.p, j->b_len.p, j->b_iota.p,
                                        j->bt.p, j->bt_off.p, j->b_tlen.p, j->anc_b.p, j->tb_off_b.p, j->tb_b2[bi].p, j->mvw_b2[bi].p, j->info_b.p, j->tbo_b.p, j->mvo_b.p,
-                                       (const int64_t *)nullptr, (const int64_t *)nullptr, j->b_handled.p, (int32_t)swb_max_steps);
+                                       (const int64_t *)nullptr, (const int64_t *)nullptr, j->b_handled.p, (int32_t)swb_max_steps, 64, (int32_t *)nullptr);
                 }
                 if (use_bits && swb64) {
                     FZP_TRY(j->b_handled.alloc((size_t)nr));
-                    hipLaunchKernelGGL(k_swb, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, st, first, cnt, (const int32_t *)j->b_iota.p, (const int32_t *)nullptr, j->bq.p, j->bq_off.p, j->b_len.p, j->b_iota.p,
+                    hipLaunchKernelGGL(k_swb, dim3((unsigned)((cnt + 64 * SWB_WPG - 1) / (64 * SWB_WPG))), dim3(64 * SWB_WPG), 0, st, first, cnt, (const int32_t *)j->b_iota.p, (const int32_t *)nullptr, j->bq.p, j->bq_off.p, j->b_len.p, j->b_iota.p,
                                        j->bt.p, j->bt_off.p, j->b_tlen.p, j->anc_b.p, j->tb_off_b.p, j->tb_b2[bi].p, j->mvw_b2[bi].p, j->info_b.p, j->tbo_b.p, j->mvo_b.p,
-                                       (const int64_t *)nullptr, (const int64_t *)nullptr, j->b_handled.p, (int32_t)swb_max_steps, 0);
+                                       (const int64_t *)nullptr, (const int64_t *)nullptr, j->b_handled.p, (int32_t)swb_max_steps, 0, 64, (int32_t *)nullptr);
                 }
                 hipLaunchKernelGGL(k_sw<true>, dim3((unsigned)cnt), dim3(64), 0, st, first, cnt, (const int32_t *)nullptr, j->bq.p, j->bq_off.p, j->b_len.p, j->b_iota.p,
                                    j->bt.p, j->bt_off.p, j->b_tlen.p, j->anc_b.p, j->tb_off_b.p, j->tb_b2[bi].p, j->mvw_b2[bi].p, P.match, P.mismatch, P.gap, j->info_b.p,
-                                   j->tbo_b.p, j->mvo_b.p, (const int32_t *)nullptr, 0, (const int64_t *)nullptr, (const int64_t *)nullptr, use_bits ? (const uint8_t *)j->b_handled.p : (const uint8_t *)nullptr);
+                                   j->tbo_b.p, j->mvo_b.p, (const int32_t *)nullptr, 0, (const int64_t *)nullptr, (const int64_t *)nullptr, use_bits ? (const uint8_t *)j->b_handled.p : (const uint8_t *)nullptr, 64, (int32_t *)nullptr);
             }
             FZP_HIP(hipEventRecord(j->ev_bk[bi], st));
             FZP_HIP(hipStreamWaitEvent(st2, j->ev_sw[bi], 0));
@@ -2672,7 +2696,7 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
                 hipLaunchKernelGGL(k_tb_walk<false>, dim3((unsigned)((cnt + TBW_RPW * TBW_WPG - 1) / (TBW_RPW * TBW_WPG))), dim3(64 * TBW_WPG), 0, st2, first, cnt, j->anc.p, j->info.p, j->tb_off.p,
                                    j->tbo.p, j->mvo.p, (const ulonglong2 *)j->tb2[bi].p, (const ulonglong2 *)j->mvw2[bi].p, j->raw2[bi].p, j->wout.p,
                                    use_lpt ? (const int32_t *)(j->lpt.p + first) : (const int32_t *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr,
-                                   (uint32_t *)nullptr, (SegOut *)nullptr, 0, 32, (const SegReq *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr);
+                                   (uint32_t *)nullptr, (SegOut *)nullptr, 0, 32, (const SegReq *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr, (const int32_t *)j->tbs.p);
             } else {
                 const int64_t nwk = j->h_seg_cnt[(size_t)first], wbase = j->h_seg_base[(size_t)first];
                 FZP_TRY(j->raw_seg2[bi].alloc((size_t)nwk * TBS_RAW_WORDS + 64));
@@ -2682,7 +2706,7 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
                 FZP_HIP(hipMemsetAsync(j->trail2[bi].p, 0xff, (size_t)nwk * 2 * TBS_OV * 4, st2));
                 hipLaunchKernelGGL(k_tb_walk<true>, dim3((unsigned)((nwk + TBW_RPW * TBW_WPG - 1) / (TBW_RPW * TBW_WPG))), dim3(64 * TBW_WPG), 0, st2, first, nwk, j->anc.p, j->info.p, j->tb_off.p,
                                    j->tbo.p, j->mvo.p, (const ulonglong2 *)j->tb2[bi].p, (const ulonglong2 *)j->mvw2[bi].p, j->raw_seg2[bi].p, j->wout.p,
-                                   (const int32_t *)(j->seg_order.p + wbase), (const int32_t *)(j->seg_slot.p + wbase), (const int32_t *)(j->seg_idx.p + wbase), j->trail2[bi].p, j->segout2[bi].p, 0, guess_lane, (const SegReq *)nullptr, (const uint32_t *)nullptr, j->raw2[bi].p);
+                                   (const int32_t *)(j->seg_order.p + wbase), (const int32_t *)(j->seg_slot.p + wbase), (const int32_t *)(j->seg_idx.p + wbase), j->trail2[bi].p, j->segout2[bi].p, 0, guess_lane, (const SegReq *)nullptr, (const uint32_t *)nullptr, j->raw2[bi].p, (const int32_t *)j->tbs.p);
                 const uint32_t req_cap = (uint32_t)std::min<int64_t>(nwk, 1 << 20);
                 FZP_TRY(j->seg_req.alloc((size_t)req_cap + 1));
                 FZP_HIP(hipMemsetAsync(j->tb_fallback.p + 1, 0, 4, st2));      // this chunk's repair requests
@@ -2695,13 +2719,13 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
                     hipLaunchKernelGGL(k_tb_walk<true>, dim3((unsigned)((std::min<int64_t>(req_cap, cnt) + TBW_RPW * TBW_WPG - 1) / (TBW_RPW * TBW_WPG))), dim3(64 * TBW_WPG), 0, st2, first, (int64_t)req_cap, j->anc.p, j->info.p,
                                        j->tb_off.p, j->tbo.p, j->mvo.p, (const ulonglong2 *)j->tb2[bi].p, (const ulonglong2 *)j->mvw2[bi].p, j->raw_seg2[bi].p, j->wout.p,
                                        (const int32_t *)nullptr, (const int32_t *)(j->seg_slot.p + wbase), (const int32_t *)(j->seg_idx.p + wbase), j->trail2[bi].p, j->segout2[bi].p, 0, guess_lane,
-                                       (const SegReq *)j->seg_req.p, (const uint32_t *)(j->tb_fallback.p + 1), j->raw2[bi].p);
+                                       (const SegReq *)j->seg_req.p, (const uint32_t *)(j->tb_fallback.p + 1), j->raw2[bi].p, (const int32_t *)j->tbs.p);
                     hipLaunchKernelGGL(k_tb_req_reset, dim3(1), dim3(64), 0, st2, j->tb_fallback.p);   // the walks are queued behind it: the next stitch pass counts from 0
                 }
                 // reads whose segments did not join (flagged by the stitching) are walked in one piece; every other wave of this launch leaves at once
                 hipLaunchKernelGGL(k_tb_walk<false>, dim3((unsigned)((cnt + TBW_RPW * TBW_WPG - 1) / (TBW_RPW * TBW_WPG))), dim3(64 * TBW_WPG), 0, st2, first, cnt, j->anc.p, j->info.p, j->tb_off.p,
                                    j->tbo.p, j->mvo.p, (const ulonglong2 *)j->tb2[bi].p, (const ulonglong2 *)j->mvw2[bi].p, j->raw2[bi].p, j->wout.p,
-                                   (const int32_t *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr, (uint32_t *)nullptr, (SegOut *)nullptr, 1, 32, (const SegReq *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr);
+                                   (const int32_t *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr, (uint32_t *)nullptr, (SegOut *)nullptr, 1, 32, (const SegReq *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr, (const int32_t *)j->tbs.p);
             }
             FZP_HIP(hipStreamWaitEvent(st2, j->ev_bk[bi], 0));
             {   // the backward parts: walked (one walker each: they are short), then joined to the forward streams
@@ -2709,7 +2733,7 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
                 hipLaunchKernelGGL(k_tb_walk<false>, dim3((unsigned)((cnt + TBW_RPW * TBW_WPG - 1) / (TBW_RPW * TBW_WPG))), dim3(64 * TBW_WPG), 0, st2, first, cnt, j->anc_b.p, j->info_b.p, j->tb_off_b.p,
                                    j->tbo_b.p, j->mvo_b.p, (const ulonglong2 *)j->tb_b2[bi].p, (const ulonglong2 *)j->mvw_b2[bi].p, j->raw_b2[bi].p, j->wout_b.p,
                                    (const int32_t *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr, (uint32_t *)nullptr, (SegOut *)nullptr, 0, 32,
-                                   (const SegReq *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr);
+                                   (const SegReq *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr, (const int32_t *)nullptr);
                 hipLaunchKernelGGL(k_back_merge, dim3((unsigned)cnt), dim3(64), 0, st2, first, cnt, j->tb_off.p, j->tb_off_b.p, j->anc_b.p, j->info_b.p, j->wout_b.p,
                                    (const uint32_t *)j->raw_b2[bi].p, j->raw2[bi].p, j->wout.p, j->info.p);
             }
