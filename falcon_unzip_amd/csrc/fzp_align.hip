@@ -985,7 +985,8 @@ __global__ void __launch_bounds__(256) k_swb(int64_t first, int64_t count, const
                                              const uint32_t *__restrict__ ctg_pk, const int64_t *__restrict__ ctg_woff, const int64_t *__restrict__ ctg_len,
                                              const Anchor *__restrict__ anc, const int64_t *__restrict__ tb_off, uint2 *__restrict__ tb, ulonglong2 *__restrict__ mvw,
                                              DpInfo *__restrict__ info, int64_t *__restrict__ tbo, int64_t *__restrict__ mvo, const int64_t *__restrict__ m_off, const int64_t *__restrict__ mv_off, uint8_t *__restrict__ handled, int32_t steps_limit, int dbg,
-                                             int32_t m_stride, int32_t *__restrict__ tbs) {
+                                             int32_t m_stride, int32_t *__restrict__ tbs, uint32_t *__restrict__ start_flag, uint32_t start_val) {
+    if (start_flag && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(start_flag, start_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);      // "on the chip" (k_wait_started)
     using namespace swb;
     // (workgroups of one wave: four-wave workgroups, which suit k_swb2, put 256 mask streams on a CU and cost this kernel 10 % -- address translation again)
     const int64_t li = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1071,6 +1072,15 @@ __global__ void __launch_bounds__(256) k_swb(int64_t first, int64_t count, const
     }
 }
 
+// the two DP kernels of a launch run side by side, and it matters which gets onto the chip first: with the bit-sliced kernel's few hundred waves placed first (one to
+// a SIMD, spread over the CUs) and the wave-per-read kernel's thousands filling in around them the pair took 16.5 ms on reads of real shape, the other way round 22 ms,
+// left to race one or the other.  So the wave-per-read kernel's stream holds this one-thread kernel first, which returns when the bit-sliced kernel's first workgroup has
+// said it runs (or after ~2 ms, whatever happened).
+__global__ void k_wait_started(const uint32_t *flag, uint32_t val) {
+    const uint64_t t0 = __builtin_readcyclecounter();
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < val && __builtin_readcyclecounter() - t0 < 5000000ull) __builtin_amdgcn_s_sleep(16);
+}
+
 // ---- the same DP with the band split over a PAIR of lanes (fzp_swb_core.h, Half): 32 reads per wave, half the instructions per step on a wave's
 // critical path and twice the waves -- at the bench's job size the chip holds about one DP wave per SIMD, which makes a step's latency (instructions x the
 // ~5 cycles a lone wave needs per instruction), not the issue rate, what bounds the launch.  The low lane of a pair owns the contig stream, the high lane
@@ -1141,8 +1151,9 @@ __global__ void __launch_bounds__(256) k_swb2(int64_t first, int64_t count, cons
                                               const uint32_t *__restrict__ ctg_pk, const int64_t *__restrict__ ctg_woff, const int64_t *__restrict__ ctg_len,
                                               const Anchor *__restrict__ anc, const int64_t *__restrict__ tb_off, uint2 *__restrict__ tb, ulonglong2 *__restrict__ mvw,
                                               DpInfo *__restrict__ info, int64_t *__restrict__ tbo, int64_t *__restrict__ mvo, const int64_t *__restrict__ m_off, const int64_t *__restrict__ mv_off,
-                                              uint8_t *__restrict__ handled, int32_t steps_limit, int32_t m_stride, int32_t *__restrict__ tbs) {
+                                              uint8_t *__restrict__ handled, int32_t steps_limit, int32_t m_stride, int32_t *__restrict__ tbs, uint32_t *__restrict__ start_flag, uint32_t start_val) {
     using namespace swb;
+    if (start_flag && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(start_flag, start_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     const uint32_t is_hi = threadIdx.x & 1u;
     const bool lo = is_hi == 0u;
     // workgroups of four waves -- independent of each other, no LDS, no barrier: a workgroup's waves are spread over its CU's four SIMDs, single-wave workgroups are not
@@ -2168,6 +2179,8 @@ struct fzp_alnjob {
     DevBuf<SegOut> segout2[2];
     DevBuf<uint32_t> tb_fallback;                // [0] reads of the last run walked serially after all, [1] repair walks asked for in the chunk at hand, [2] in the whole run
     DevBuf<SegReq> seg_req;
+    DevBuf<uint32_t> dp_flag;                    // "the bit-sliced DP kernel of launch dp_seq runs" (k_wait_started)
+    uint32_t dp_seq = 0;
     DevBuf<uint8_t> b_handled;                   // per read: its backward extension ran in the bit-sliced kernel
     DevBuf<int32_t> tbs;                         // per read: records from one 64-step block of its masks to the next (64: a stream of its own; 4096: interleaved with its launch group)
     std::vector<int64_t> h_tbm_total;            // per chunk (by its first read): records its planned mask streams span
@@ -2493,6 +2506,7 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
                     // that go to k_sw): block b of the group's x-th stream starts at record (b * 64 + x) * 64 of the group's region -- what a wave writes
                     // during 64 steps lies within 64 KB instead of in 64 places half a megabyte apart (address translation was a third of that kernel's time)
                     int64_t acc = 0, region = 0;
+                    const bool contig = getenv("FZP_TB_CONTIG") != nullptr;      // comparison switch: every stream on its own, in launch order (stride 64)
                     if (j->h_tbm_total.size() < (size_t)nr + 1) j->h_tbm_total.assign((size_t)nr + 1, 0);
                     for (int64_t g0 = 0; g0 < l - f; g0 += 64) {
                         const int64_t gn = std::min<int64_t>(64, l - f - g0);
@@ -2500,12 +2514,12 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
                         for (int64_t x = g0; x < g0 + gn; x++) { const int64_t r = f + ord[(size_t)(f + x)]; cap_max = std::max(cap_max, j->h_tb_off[(size_t)r + 1] - j->h_tb_off[(size_t)r]); }
                         for (int64_t x = g0; x < g0 + gn; x++) {
                             const int64_t r = f + ord[(size_t)(f + x)];
-                            h_tbm[(size_t)r] = region + (x - g0) * 64; h_mvm[(size_t)r] = (acc >> 6) + x;
+                            h_tbm[(size_t)r] = contig ? acc : region + (x - g0) * 64; h_mvm[(size_t)r] = (acc >> 6) + x;
                             acc += j->h_tb_off[(size_t)r + 1] - j->h_tb_off[(size_t)r];
                         }
                         region += 64 * cap_max;
                     }
-                    j->h_tbm_total[(size_t)f] = region;
+                    j->h_tbm_total[(size_t)f] = contig ? acc : region;
                 }
                 // walkers of the segmented trace-back: one per TBS_SEG steps of every read's step capacity, longest reads first
                 j->h_seg_base[(size_t)f] = (int64_t)sgs.size();
@@ -2560,6 +2574,7 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
         // waves, and its instruction mix (v_bitop3, DPP, 3-operand forms) issues at ~4.5 cycles per SIMD however many waves share it: two such waves on one SIMD run at half
         // speed each.  So it is taken when its waves get a SIMD each and nothing else runs beside them; else the whole band sits in one lane (k_swb).  FZP_SWB_64 / FZP_SWB_PAIR force one.
         const int swb_force = getenv("FZP_SWB_64") ? 64 : (getenv("FZP_SWB_PAIR") ? 32 : 0);
+        const int32_t m_stride = getenv("FZP_TB_CONTIG") ? 64 : 64 * 64;
         int64_t swb_max_steps = 40960;          // ~ 18 kb reads: a lane's step costs ~330 ns, the chain of a longer extension would outlast the rest of the launch
         if (const char *e = getenv("FZP_SWB_MAX_STEPS")) { const long g = atol(e); if (g > 0) swb_max_steps = g; }
         std::vector<int64_t> &swb_at = j->h_swb_at, &sw_at = j->h_sw_at;
@@ -2626,22 +2641,29 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
                     // are short enough for its per-step latency; the rest -- the long reads first of all -- run a wave each, started before it
                     const int64_t b_at = swb_at[(size_t)ci], b_n = swb_at[(size_t)ci + 1] - b_at, w_at = sw_at[(size_t)ci], w_n = sw_at[(size_t)ci + 1] - w_at;
                     const bool swb64 = swb_force ? swb_force == 64 : !(w_n == 0 && b_n / 32 <= (int64_t)ctx->n_cu * 4);
-                    if (w_n > 0) {   // on its own stream: the two kernels share the chip (this one latency-bound waves of long reads, the other one wave per SIMD)
-                        FZP_HIP(hipEventRecord(j->ev_l[0], st));
-                        FZP_HIP(hipStreamWaitEvent(ctx->stream3, j->ev_l[0], 0));
-                        hipLaunchKernelGGL(no_masks ? k_sw<false> : k_sw<true>, dim3((unsigned)w_n), dim3(64), 0, ctx->stream3, first, w_n, (const int32_t *)nullptr, j->read_ori.p, j->read_woff.p, j->read_len.p, j->read_ctg.p,
-                                           j->ctg_pk.p, j->ctg_woff.p, j->ctg_len.p, j->anc.p, j->tb_off.p, j->tb2[bi].p, j->mvw2[bi].p, P.match, P.mismatch, P.gap, j->info.p, j->tbo.p, j->mvo.p,
-                                           (const int32_t *)(j->sw_list.p + w_at), use_prio ? mean_len : 0, (const int64_t *)j->tbm_off.p, (const int64_t *)j->mvm_off.p, (const uint8_t *)nullptr, 64 * 64, j->tbs.p);
-                        FZP_HIP(hipEventRecord(j->ev_l[1], ctx->stream3));
-                    }
+                    // the bit-sliced kernel first (k_wait_started: which of the two gets onto the chip first decides how the pair runs), the wave-per-read kernel on its
+                    // own stream as soon as that one's first workgroup runs: the two share the chip (latency-bound waves of long reads there, one wave per SIMD here)
+                    FZP_TRY(j->dp_flag.alloc(1));
+                    if (!j->dp_seq) FZP_TRY(j->dp_flag.zero(1, st));
+                    uint32_t *flag_p = (w_n > 0 && b_n > 0) ? j->dp_flag.p : (uint32_t *)nullptr;
+                    const uint32_t flag_v = ++j->dp_seq;
+                    if (w_n > 0) FZP_HIP(hipEventRecord(j->ev_l[0], st));
                     if (b_n > 0 && !swb64)
                         hipLaunchKernelGGL(k_swb2, dim3((unsigned)((b_n + 127) / 128)), dim3(256), 0, st, first, b_n, (const int32_t *)(j->swb_list.p + b_at), (const int32_t *)nullptr, j->read_ori.p, j->read_woff.p,
                                            j->read_len.p, j->read_ctg.p, j->ctg_pk.p, j->ctg_woff.p, j->ctg_len.p, j->anc.p, j->tb_off.p, j->tb2[bi].p, j->mvw2[bi].p, j->info.p, j->tbo.p, j->mvo.p,
-                                           (const int64_t *)j->tbm_off.p, (const int64_t *)j->mvm_off.p, (uint8_t *)nullptr, 0x7fffffff, 64 * 64, j->tbs.p);
+                                           (const int64_t *)j->tbm_off.p, (const int64_t *)j->mvm_off.p, (uint8_t *)nullptr, 0x7fffffff, m_stride, j->tbs.p, flag_p, flag_v);
                     if (b_n > 0 && swb64)
                         hipLaunchKernelGGL(k_swb, dim3((unsigned)((b_n + 64 * SWB_WPG - 1) / (64 * SWB_WPG))), dim3(64 * SWB_WPG), 0, st, first, b_n, (const int32_t *)(j->swb_list.p + b_at), (const int32_t *)nullptr, j->read_ori.p, j->read_woff.p,
                                            j->read_len.p, j->read_ctg.p, j->ctg_pk.p, j->ctg_woff.p, j->ctg_len.p, j->anc.p, j->tb_off.p, j->tb2[bi].p, j->mvw2[bi].p, j->info.p, j->tbo.p, j->mvo.p, (const int64_t *)j->tbm_off.p, (const int64_t *)j->mvm_off.p,
-                                           (uint8_t *)nullptr, 0x7fffffff, getenv("FZP_SWB_DBG") ? atoi(getenv("FZP_SWB_DBG")) : 0, 64 * 64, j->tbs.p);
+                                           (uint8_t *)nullptr, 0x7fffffff, getenv("FZP_SWB_DBG") ? atoi(getenv("FZP_SWB_DBG")) : 0, m_stride, j->tbs.p, flag_p, flag_v);
+                    if (w_n > 0) {
+                        FZP_HIP(hipStreamWaitEvent(ctx->stream3, j->ev_l[0], 0));
+                        if (flag_p) hipLaunchKernelGGL(k_wait_started, dim3(1), dim3(1), 0, ctx->stream3, (const uint32_t *)flag_p, flag_v);
+                        hipLaunchKernelGGL(no_masks ? k_sw<false> : k_sw<true>, dim3((unsigned)w_n), dim3(64), 0, ctx->stream3, first, w_n, (const int32_t *)nullptr, j->read_ori.p, j->read_woff.p, j->read_len.p, j->read_ctg.p,
+                                           j->ctg_pk.p, j->ctg_woff.p, j->ctg_len.p, j->anc.p, j->tb_off.p, j->tb2[bi].p, j->mvw2[bi].p, P.match, P.mismatch, P.gap, j->info.p, j->tbo.p, j->mvo.p,
+                                           (const int32_t *)(j->sw_list.p + w_at), use_prio ? mean_len : 0, (const int64_t *)j->tbm_off.p, (const int64_t *)j->mvm_off.p, (const uint8_t *)nullptr, m_stride, j->tbs.p);
+                        FZP_HIP(hipEventRecord(j->ev_l[1], ctx->stream3));
+                    }
                     if (w_n > 0) FZP_HIP(hipStreamWaitEvent(st, j->ev_l[1], 0));
                 } else
                 hipLaunchKernelGGL(no_masks ? k_sw<false> : k_sw<true>, dim3((unsigned)cnt), dim3(64), 0, st, first, cnt, (const int32_t *)nullptr, j->read_ori.p, j->read_woff.p, j->read_len.p, j->read_ctg.p,
@@ -2677,13 +2699,13 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
                     FZP_TRY(j->b_handled.alloc((size_t)nr));
                     hipLaunchKernelGGL(k_swb2, dim3((unsigned)((cnt + 127) / 128)), dim3(256), 0, st, first, cnt, (const int32_t *)j->b_iota.p, (const int32_t *)nullptr, j->bq.p, j->bq_off.p, j->b_len.p, j->b_iota.p,
                                        j->bt.p, j->bt_off.p, j->b_tlen.p, j->anc_b.p, j->tb_off_b.p, j->tb_b2[bi].p, j->mvw_b2[bi].p, j->info_b.p, j->tbo_b.p, j->mvo_b.p,
-                                       (const int64_t *)nullptr, (const int64_t *)nullptr, j->b_handled.p, (int32_t)swb_max_steps, 64, (int32_t *)nullptr);
+                                       (const int64_t *)nullptr, (const int64_t *)nullptr, j->b_handled.p, (int32_t)swb_max_steps, 64, (int32_t *)nullptr, (uint32_t *)nullptr, 0u);
                 }
                 if (use_bits && swb64) {
                     FZP_TRY(j->b_handled.alloc((size_t)nr));
                     hipLaunchKernelGGL(k_swb, dim3((unsigned)((cnt + 64 * SWB_WPG - 1) / (64 * SWB_WPG))), dim3(64 * SWB_WPG), 0, st, first, cnt, (const int32_t *)j->b_iota.p, (const int32_t *)nullptr, j->bq.p, j->bq_off.p, j->b_len.p, j->b_iota.p,
                                        j->bt.p, j->bt_off.p, j->b_tlen.p, j->anc_b.p, j->tb_off_b.p, j->tb_b2[bi].p, j->mvw_b2[bi].p, j->info_b.p, j->tbo_b.p, j->mvo_b.p,
-                                       (const int64_t *)nullptr, (const int64_t *)nullptr, j->b_handled.p, (int32_t)swb_max_steps, 0, 64, (int32_t *)nullptr);
+                                       (const int64_t *)nullptr, (const int64_t *)nullptr, j->b_handled.p, (int32_t)swb_max_steps, 0, 64, (int32_t *)nullptr, (uint32_t *)nullptr, 0u);
                 }
                 hipLaunchKernelGGL(k_sw<true>, dim3((unsigned)cnt), dim3(64), 0, st, first, cnt, (const int32_t *)nullptr, j->bq.p, j->bq_off.p, j->b_len.p, j->b_iota.p,
                                    j->bt.p, j->bt_off.p, j->b_tlen.p, j->anc_b.p, j->tb_off_b.p, j->tb_b2[bi].p, j->mvw_b2[bi].p, P.match, P.mismatch, P.gap, j->info_b.p,
