@@ -467,14 +467,15 @@ def test_the_three_dp_kernels_agree(eng, oracle, monkeypatch):
     """The banded DP exists three times: k_sw (a wave per read, integer scores), k_swb (bit-sliced, a read per lane) and k_swb2 (bit-sliced, a read per pair of
     lanes).  Same reads through each (FZP_SW_NO_BITS / FZP_SWB_64 / FZP_SWB_PAIR; the default mixes them by read length): every summary field and every CIGAR equal, and
     equal to the twin's.  Reads from 70 bases up, so that extensions shorter than the band (which stay with k_sw) and reads over the bit-sliced kernels' length
-    limit are both in the set; once more with the reads cut into three chunks (every chunk its own launch lists and mask buffers)."""
+    limit are both in the set; once more with the reads cut into three chunks (every chunk its own launch lists and mask buffers), and with
+    every read's mask stream on its own instead of interleaved with its launch group's (FZP_TB_CONTIG)."""
     from falcon_unzip_amd import _lib
     n = 400
     ctg, blob, off, *_ = _shaped(51, 800_000, n, length_model={"median": 4000, "sigma": 1.3, "lo": 70, "hi": 30000})
     reads = [blob[off[i]:off[i + 1]] for i in range(n)]
     got = {}
     for mode, env in (("default", {}), ("wave_per_read", {"FZP_SW_NO_BITS": "1"}), ("lane64", {"FZP_SWB_64": "1"}), ("pair", {"FZP_SWB_PAIR": "1"}),
-                      ("pair_short_limit", {"FZP_SWB_PAIR": "1", "FZP_SWB_MAX_STEPS": "9000"}), ("three_chunks", {"FZP_SW_CHUNKS": "3"})):
+                      ("pair_short_limit", {"FZP_SWB_PAIR": "1", "FZP_SWB_MAX_STEPS": "9000"}), ("three_chunks", {"FZP_SW_CHUNKS": "3"}), ("streams_on_their_own", {"FZP_TB_CONTIG": "1"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         job = _lib.align_job_raw(eng, [ctg], blob, off, np.zeros(n, np.int32))
