@@ -1419,10 +1419,11 @@ __global__ void __launch_bounds__(64 * TBW_WPG) k_tb_walk(int64_t first, int64_t
             P = s_ ? (w_cur << (64 - s_)) | (w_prev >> s_) : w_prev;
         }
         const uint8_t *win = mine;
+        const bool notes = SEGMENTED && __any(active && !single);      // (wave-uniform: a wave of whole-read walkers skips the note-taking with a scalar branch)
         while (active && (ts >> 6) == cur_chunk && (uint32_t)(k - sh_cur) < 32u) {
             const uint2 m = *(const uint2 *)(win + (ts & 63) * 8);
             const uint32_t kk = (uint32_t)(k - sh_cur);
-            if (SEGMENTED && !single) {      // where this walker is, for the stitching: its first TBS_OV steps and the TBS_OV steps below its segment
+            if (notes && !single) {      // where this walker is, for the stitching: its first TBS_OV steps and the TBS_OV steps below its segment
                 const uint32_t note = (repair ? 0x80000000u : 0u) | ((uint32_t)n_ops << 8) | (uint32_t)k;      // (a repair walk's notes are told from the stale ones around them by bit 31)
                 if (!repair && ts0 - ts < TBS_OV) tr_head[ts0 - ts] = note;
                 if ((uint32_t)(tail_top - ts) < (uint32_t)TBS_OV) tr_tail[tail_top - ts] = note;
