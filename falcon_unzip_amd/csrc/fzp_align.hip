@@ -988,6 +988,7 @@ __global__ void __launch_bounds__(256) k_swb(int64_t first, int64_t count, const
                                              int32_t m_stride, int32_t *__restrict__ tbs, uint32_t *__restrict__ start_flag, uint32_t start_val) {
     if (start_flag && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(start_flag, start_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);      // "on the chip" (k_wait_started)
     using namespace swb;
+    // dbg: MEASUREMENT switches (FZP_SWB_DBG, tools/runs/swb_probe.py; the results of such a run are not used): bit 0 = no mask stores, bit 1 = no stream refills
     // (workgroups of one wave: four-wave workgroups, which suit k_swb2, put 256 mask streams on a CU and cost this kernel 10 % -- address translation again)
     const int64_t li = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t wv = li < count ? list[li] : -1;       // the lane's slot in the chunk, -1: none
