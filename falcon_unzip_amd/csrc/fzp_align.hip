@@ -1076,7 +1076,7 @@ __global__ void __launch_bounds__(256) k_swb(int64_t first, int64_t count, const
 // the two DP kernels of a launch run side by side, and it matters which gets onto the chip first: with the bit-sliced kernel's few hundred waves placed first (one to
 // a SIMD, spread over the CUs) and the wave-per-read kernel's thousands filling in around them the pair took 16.5 ms on reads of real shape, the other way round 22 ms,
 // left to race one or the other.  So the wave-per-read kernel's stream holds this one-thread kernel first, which returns when the bit-sliced kernel's first workgroup has
-// said it runs (or after ~2 ms, whatever happened).
+// said it runs (or after 5 million ticks of the 100 MHz counter, whatever happened: a bound, not a wait anybody should see).
 __global__ void k_wait_started(const uint32_t *flag, uint32_t val) {
     const uint64_t t0 = __builtin_readcyclecounter();
     while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < val && __builtin_readcyclecounter() - t0 < 5000000ull) __builtin_amdgcn_s_sleep(16);
