@@ -15,6 +15,8 @@
 //   k_plan_*      per contig: aligned reads ordered by (POS, read), record filters (phasing.py:72-75), record offsets
 //   k_gather(16)  accepted records -> contiguous CIGAR + ASCII SEQ arrays for an alnset / the phasing batch
 #include <algorithm>
+#include <map>
+#include <mutex>
 
 #include "fzp_batch.h"
 #include "fzp_swb_core.h"
@@ -2137,6 +2139,12 @@ __global__ void __launch_bounds__(256) k_gather16(int64_t n_rec, const int64_t *
 }  // namespace
 
 // ================================================================================ job
+// One forward DP at a time per device.  The DP kernels of two jobs (two contexts in one process: the lanes of fzp_phase_contigs, two steps in flight) running side by side
+// land on each other's SIMDs and both run at little more than half speed; queued one behind the other each has the chip to itself, and everything else
+// of the two jobs still overlaps.  The chain is made of events: a job's DP launches wait for the event the previous job recorded behind its own (no host thread ever blocks).
+static std::mutex g_dp_mu;
+static std::map<int, hipEvent_t> g_dp_last;
+
 struct fzp_alnjob {
     int32_t n_ctg = 0;
     int64_t n_reads = 0;
@@ -2636,6 +2644,13 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
             FZP_TRY(j->tb2[bi].alloc((size_t)(tb_base + steps2) * 2 + 128));
             FZP_TRY(j->mvw2[bi].alloc((size_t)(mv_base + steps2 / 64 + c2 + 2)));
             FZP_TRY(j->raw2[bi].alloc((size_t)(steps / 16 + 64)));
+            const bool dp_chain = getenv("FZP_DP_NO_CHAIN") == nullptr;
+            std::unique_lock<std::mutex> dp_lk(g_dp_mu, std::defer_lock);
+            if (dp_chain) {
+                dp_lk.lock();
+                auto it = g_dp_last.find(ctx->device);
+                if (it != g_dp_last.end()) FZP_HIP(hipStreamWaitEvent(st, it->second, 0));
+            }
             {
                 ProfScope ps(ctx, "k1_sw");
                 if (use_bits) {
@@ -2686,6 +2701,12 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
             }
             w_lo = w_hi;
             FZP_HIP(hipEventRecord(j->ev_sw[bi], st));        // the forward extensions are final: their walk starts on the second stream while the backward ones run here
+            if (dp_chain) {
+                hipEvent_t &e = g_dp_last[ctx->device];
+                if (!e) FZP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                FZP_HIP(hipEventRecord(e, st));
+                dp_lk.unlock();
+            }
             const int64_t steps_b = j->h_tb_off_b[(size_t)last] - j->h_tb_off_b[(size_t)first];
             FZP_TRY(j->tb_b2[bi].alloc((size_t)(steps_b + 64) * 2 + 128));
             FZP_TRY(j->mvw_b2[bi].alloc((size_t)(steps_b / 64 + cnt + 2)));
