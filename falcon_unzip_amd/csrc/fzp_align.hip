@@ -15,6 +15,7 @@
 //   k_plan_*      per contig: aligned reads ordered by (POS, read), record filters (phasing.py:72-75), record offsets
 //   k_gather(16)  accepted records -> contiguous CIGAR + ASCII SEQ arrays for an alnset / the phasing batch
 #include <algorithm>
+#include <type_traits>
 #include <map>
 #include <mutex>
 
@@ -918,10 +919,74 @@ struct LaneStream {                // upcoming bases of one sequence, per lane: 
     }
 };
 
-struct SwbLane {                   // one extension's state (a lane's registers)
+struct LaneStreamL {
+    const uint32_t *pk;            // the sequence's words
+    uint32_t *ring;                // this lane's column of its stream's ring
+    uint64_t cur;
+    uint32_t pend, rd, wr, gw, lim;
+    uint32_t hold[16], hold_base;  // sixteen words on their way from HBM to the ring (bulk)
+    bool held;
+    int32_t have;
+    __device__ __forceinline__ void init(const uint32_t *pk_, int64_t idx, uint32_t lim_, uint32_t *ring_) {
+        pk = pk_; ring = ring_; lim = lim_; held = false; hold_base = 0;
+#pragma unroll
+        for (int q = 0; q < 16; q++) hold[q] = 0u;
+        const uint32_t w = (uint32_t)(idx >> 4);
+        const uint32_t sh = (uint32_t)(idx & 15) * 2u;
+        cur = ((uint64_t)pk[w] | ((uint64_t)pk[w + 1] << 32)) >> sh;
+        have = 32 - (int32_t)(idx & 15);
+        gw = w + 2;
+        for (int q0 = 0; q0 < 64; q0 += 16) {
+            uint32_t v[16];
+#pragma unroll
+            for (int q = 0; q < 16; q++) v[q] = 0u;
+            if (gw + q0 < lim) {      // (a short sequence -- the backward extensions' -- ends within the first words: nothing to fetch for the rest of the ring)
+#pragma unroll
+                for (int q = 0; q < 16; q++) { const uint32_t ix = gw + q0 + q; v[q] = pk[ix < lim ? ix : lim - 1u]; }      // (all sixteen in flight together)
+            }
+#pragma unroll
+            for (int q = 0; q < 16; q++) ring[(q0 + q) * 64] = gw + q0 + q < lim ? v[q] : 0u;
+        }
+        gw += 64; wr = 64; rd = 1;
+        pend = ring[0];
+    }
+    __device__ __forceinline__ void refill() {
+        const bool m = have <= 16;
+        cur |= m ? (uint64_t)pend << (2 * have) : 0ull;
+        have += m ? 16 : 0;
+        const uint32_t nx = ring[(rd & 63u) * 64];
+        pend = m ? nx : pend;
+        rd += m ? 1u : 0u;
+    }
+    // every 256 steps (at most 16 words leave the ring in between).  What a call loads goes into the ring at the NEXT call: by then more than 63 vector-memory operations
+    // have been issued behind the loads, which is more than can be outstanding -- no wait is needed to use them, and none is spent behind the mask stores.
+    __device__ __forceinline__ void bulk() {
+        if (held) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) ring[((wr + q) & 63u) * 64] = hold_base + q < lim ? hold[q] : 0u;
+            wr += 16u;
+        }
+        held = wr - rd <= 32u;
+        if (held) {
+            hold_base = gw;
+#pragma unroll
+            for (int q = 0; q < 16; q++) { const uint32_t ix = gw + q; hold[q] = pk[ix < lim ? ix : lim - 1u]; }
+            gw += 16u;
+        }
+    }
+    __device__ __forceinline__ uint32_t pop(uint32_t en) {
+        const uint32_t c = (uint32_t)cur & (0u - en) & 3u;
+        cur >>= 2u * en;
+        have -= (int32_t)en;
+        return c;
+    }
+};
+
+template <class STREAM>
+struct SwbLaneT {                  // one extension's state (a lane's registers)
     swb::Planes P, Q;              // difference planes of the previous anti-diagonal
     uint64_t R0, R1, C0, C1;       // base windows as bit planes: bit k = read base i0 + k / contig base t - i0 - k
-    LaneStream qs, ts;
+    STREAM qs, ts;
     int32_t i0, E2, sv0;           // E2 = (score of lane 63's cell - score of lane 0's) / 2;  sv0 = sum of lane 0's difference codes: its score is -259 + 2 sv0 - 3 (t + 1)
     uint32_t down, pdown;
     uint64_t mvacc;
@@ -930,8 +995,8 @@ struct SwbLane {                   // one extension's state (a lane's registers)
 // one DP step of every lane's extension.  CHECKED = false: the 64 steps of an interior block -- no lane of the wave can reach a border of its matrix in them, so
 // there is nothing to validate, no terminal candidate and no end; lanes whose extension is over run along on their stale state (nothing of theirs is stored).
 // CHECKED = true: validity of the bases near the ends, terminal candidates, the end of the extension.
-template <bool CHECKED>
-__device__ __forceinline__ void swb_step(SwbLane &L, const int32_t t, ulonglong2 &rec, const int32_t nq, const int32_t nt, const int32_t max_steps, bool &active,
+template <bool CHECKED, class LANE>
+__device__ __forceinline__ void swb_step(LANE &L, const int32_t t, ulonglong2 &rec, const int32_t nq, const int32_t nt, const int32_t max_steps, bool &active,
                                          bool &row_on, bool &col_on, int32_t &Hrow, int32_t &Hcol, int32_t &best, int32_t &bt, int32_t &bl, int32_t &steps) {
     using namespace swb;
     const uint32_t sd = L.down, sr = 1u - sd;
@@ -982,6 +1047,8 @@ __device__ __forceinline__ void swb_step(SwbLane &L, const int32_t t, ulonglong2
 
 constexpr int SWB_WPG = 1;        // waves per workgroup of k_swb (four measured: 10.1 against 9.7 ms)
 constexpr int SWB_GROUP = 8;      // steps whose mask records leave together (64 B per lane)
+// RING: the base streams through rings in LDS (LaneStreamL) or straight from HBM (LaneStream; FZP_SWB_NO_RING, for comparisons)
+template <bool RING>
 __global__ void __launch_bounds__(256) k_swb(int64_t first, int64_t count, const int32_t *__restrict__ list, const int32_t *__restrict__ ridx, const uint32_t *__restrict__ read_ori,
                                              const int64_t *__restrict__ ori_woff, const int32_t *__restrict__ read_len, const int32_t *__restrict__ read_ctg,
                                              const uint32_t *__restrict__ ctg_pk, const int64_t *__restrict__ ctg_woff, const int64_t *__restrict__ ctg_len,
@@ -1021,14 +1088,20 @@ __global__ void __launch_bounds__(256) k_swb(int64_t first, int64_t count, const
     const uint32_t *tpk = ctg_pk + ctg_woff[c_idx];
     const int64_t qb = a.i_a, tbase = a.c_a;
     const int32_t max_steps = nq + nt + 2;
-    SwbLane L;
+    SwbLaneT<typename std::conditional<RING, LaneStreamL, LaneStream>::type> L;
     // step -1: the anti-diagonal i + j = -1 of the virtual border, lane k = cell (k - 33, 32 - k): Pv = 0 where j >= 0 (k <= 32) else 4, Qv = 0 where i >= 0 (k >= 33) else 4
     L.P = {0, 0, ~0ull << 33}; L.Q = {0, 0, (1ull << 33) - 1};
     L.R0 = L.R1 = L.C0 = L.C1 = 0;
     for (int k = 33; k < 64; k++) { const uint32_t c = base_at(qpk, qb + (k - 33)); L.R0 |= (uint64_t)(c & 1u) << k; L.R1 |= (uint64_t)(c >> 1) << k; }
     for (int k = 0; k <= 32; k++) { const uint32_t c = base_at(tpk, tbase + (32 - k)); L.C0 |= (uint64_t)(c & 1u) << k; L.C1 |= (uint64_t)(c >> 1) << k; }
-    L.qs.init(qpk, qb + 31);
-    L.ts.init(tpk, tbase + 33);
+    __shared__ uint32_t srng[RING ? 2 * 64 * 64 : 1];                      // the two streams' rings (32 KB per wave)
+    if constexpr (RING) {
+        L.qs.init(qpk, qb + 31, (uint32_t)((qb + nq + 15) >> 4) + 1u, srng + threadIdx.x);
+        L.ts.init(tpk, tbase + 33, (uint32_t)((tbase + nt + 15) >> 4) + 1u, srng + 64 * 64 + threadIdx.x);
+    } else {
+        L.qs.init(qpk, qb + 31);
+        L.ts.init(tpk, tbase + 33);
+    }
     L.i0 = -33; L.E2 = 8; L.sv0 = 0;                            // at step -1 from the border's closed form: lane 0's cell scores -259, lane 63's -243
     L.down = 1; L.pdown = 0;
     bool row_on = false, col_on = false;
@@ -1041,6 +1114,7 @@ __global__ void __launch_bounds__(256) k_swb(int64_t first, int64_t count, const
         // an interior block?  every running lane more than 64 steps away from its last row and its last column (a step brings either one closer by at most one)
         const bool far = !active || (nq - 1 - (L.i0 + 63) > 64 && nt - 1 - (t - L.i0) > 64);
         const bool interior = t >= 64 && __ballot(!far) == 0ull;
+        if constexpr (RING) { if ((t & 255) == 0 && t > 0) { L.qs.bulk(); L.ts.bulk(); } }
         for (int g8 = 0; g8 < 64 / SWB_GROUP; g8++) {
             const bool grp_active = active;
             ulonglong2 rec[SWB_GROUP];
@@ -2585,6 +2659,7 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
         // speed each.  So it is taken when its waves get a SIMD each and nothing else runs beside them; else the whole band sits in one lane (k_swb).  FZP_SWB_64 / FZP_SWB_PAIR force one.
         const int swb_force = getenv("FZP_SWB_64") ? 64 : (getenv("FZP_SWB_PAIR") ? 32 : 0);
         const int32_t m_stride = getenv("FZP_TB_CONTIG") ? 64 : 64 * 64;
+        const bool swb_ring = getenv("FZP_SWB_NO_RING") == nullptr;        // k_swb's base streams through LDS rings (the backward extensions are too short to gain: straight from HBM)
         int64_t swb_max_steps = 40960;          // ~ 18 kb reads: a lane's step costs ~330 ns, the chain of a longer extension would outlast the rest of the launch
         if (const char *e = getenv("FZP_SWB_MAX_STEPS")) { const long g = atol(e); if (g > 0) swb_max_steps = g; }
         std::vector<int64_t> &swb_at = j->h_swb_at, &sw_at = j->h_sw_at;
@@ -2670,7 +2745,7 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
                                            j->read_len.p, j->read_ctg.p, j->ctg_pk.p, j->ctg_woff.p, j->ctg_len.p, j->anc.p, j->tb_off.p, j->tb2[bi].p, j->mvw2[bi].p, j->info.p, j->tbo.p, j->mvo.p,
                                            (const int64_t *)j->tbm_off.p, (const int64_t *)j->mvm_off.p, (uint8_t *)nullptr, 0x7fffffff, m_stride, j->tbs.p, flag_p, flag_v);
                     if (b_n > 0 && swb64)
-                        hipLaunchKernelGGL(k_swb, dim3((unsigned)((b_n + 64 * SWB_WPG - 1) / (64 * SWB_WPG))), dim3(64 * SWB_WPG), 0, st, first, b_n, (const int32_t *)(j->swb_list.p + b_at), (const int32_t *)nullptr, j->read_ori.p, j->read_woff.p,
+                        hipLaunchKernelGGL(swb_ring ? k_swb<true> : k_swb<false>, dim3((unsigned)((b_n + 64 * SWB_WPG - 1) / (64 * SWB_WPG))), dim3(64 * SWB_WPG), 0, st, first, b_n, (const int32_t *)(j->swb_list.p + b_at), (const int32_t *)nullptr, j->read_ori.p, j->read_woff.p,
                                            j->read_len.p, j->read_ctg.p, j->ctg_pk.p, j->ctg_woff.p, j->ctg_len.p, j->anc.p, j->tb_off.p, j->tb2[bi].p, j->mvw2[bi].p, j->info.p, j->tbo.p, j->mvo.p, (const int64_t *)j->tbm_off.p, (const int64_t *)j->mvm_off.p,
                                            (uint8_t *)nullptr, 0x7fffffff, getenv("FZP_SWB_DBG") ? atoi(getenv("FZP_SWB_DBG")) : 0, m_stride, j->tbs.p, flag_p, flag_v);
                     if (w_n > 0) {
@@ -2726,7 +2801,7 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
                 }
                 if (use_bits && swb64) {
                     FZP_TRY(j->b_handled.alloc((size_t)nr));
-                    hipLaunchKernelGGL(k_swb, dim3((unsigned)((cnt + 64 * SWB_WPG - 1) / (64 * SWB_WPG))), dim3(64 * SWB_WPG), 0, st, first, cnt, (const int32_t *)j->b_iota.p, (const int32_t *)nullptr, j->bq.p, j->bq_off.p, j->b_len.p, j->b_iota.p,
+                    hipLaunchKernelGGL(k_swb<false>, dim3((unsigned)((cnt + 64 * SWB_WPG - 1) / (64 * SWB_WPG))), dim3(64 * SWB_WPG), 0, st, first, cnt, (const int32_t *)j->b_iota.p, (const int32_t *)nullptr, j->bq.p, j->bq_off.p, j->b_len.p, j->b_iota.p,
                                        j->bt.p, j->bt_off.p, j->b_tlen.p, j->anc_b.p, j->tb_off_b.p, j->tb_b2[bi].p, j->mvw_b2[bi].p, j->info_b.p, j->tbo_b.p, j->mvo_b.p,
                                        (const int64_t *)nullptr, (const int64_t *)nullptr, j->b_handled.p, (int32_t)swb_max_steps, 0, 64, (int32_t *)nullptr, (uint32_t *)nullptr, 0u);
                 }
