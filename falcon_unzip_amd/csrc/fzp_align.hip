@@ -821,7 +821,7 @@ __global__ void __launch_bounds__(64) k_sw(int64_t first, int64_t count, const i
         int32_t safe = 0;
         if (t >= 64 && i0 >= 0 && (t - 1) - (i0 + 63) >= 0) {
             const int32_t rows_left = nq - 1 - (i0 + 63), cols_left = nt - 1 - ((t - 1) - i0);
-            safe = min(rows_left, cols_left);
+            safe = min(rows_left, cols_left) - 1;      // (- 1: after `rows_left` DOWN moves lane 63 sits ON the last row -- a terminal candidate, which only the checked steps look at)
         }
         if (safe > 0) {
             // ---- interior: asm blocks of <= 32 steps
@@ -894,22 +894,23 @@ __global__ void __launch_bounds__(64) k_sw(int64_t first, int64_t count, const i
 struct LaneStream {                // upcoming bases of one sequence, per lane: cur holds `have` (>= 1) of them, pend the 16 after those
     const uint32_t *pk;
     uint64_t cur;
-    uint32_t pend;
-    int32_t have;
-    __device__ __forceinline__ void init(const uint32_t *pk_, int64_t idx) {
-        const int64_t w = idx >> 4;
+    uint32_t pend, w, lim;         // w: the word `pend` holds; lim: words the sequence has (padding included) -- a lane whose extension is over, or that idles
+    int32_t have;                  // beside longer ones, keeps refilling and must not walk off its sequence (it reads its last word again)
+    __device__ __forceinline__ void init(const uint32_t *pk_, int64_t idx, uint32_t lim_) {
+        const uint32_t w0 = (uint32_t)(idx >> 4);
         const uint32_t sh = (uint32_t)(idx & 15) * 2u;
-        cur = ((uint64_t)pk_[w] | ((uint64_t)pk_[w + 1] << 32)) >> sh;
+        pk = pk_; lim = lim_;
+        cur = ((uint64_t)pk[w0] | ((uint64_t)pk[w0 + 1] << 32)) >> sh;
         have = 32 - (int32_t)(idx & 15);
-        pk = pk_ + w + 2;                                    // the word `pend` holds
-        pend = *pk;
+        w = w0 + 2;
+        pend = pk[w < lim ? w : lim - 1u];
     }
     __device__ __forceinline__ void refill() {              // every 16 steps (a step takes at most one base); branch-free: a lane that needs nothing loads its word again
         const bool m = have <= 16;
         cur |= m ? (uint64_t)pend << (2 * have) : 0ull;
         have += m ? 16 : 0;
-        pk += m ? 1 : 0;
-        pend = *pk;
+        w += m ? 1u : 0u;
+        pend = pk[w < lim ? w : lim - 1u];
     }
     __device__ __forceinline__ uint32_t pop(uint32_t en) {  // en = 1: take a base; 0: leave the stream as it is (returns 0)
         const uint32_t c = (uint32_t)cur & (0u - en) & 3u;
@@ -1099,8 +1100,8 @@ __global__ void __launch_bounds__(256) k_swb(int64_t first, int64_t count, const
         L.qs.init(qpk, qb + 31, (uint32_t)((qb + nq + 15) >> 4) + 1u, srng + threadIdx.x);
         L.ts.init(tpk, tbase + 33, (uint32_t)((tbase + nt + 15) >> 4) + 1u, srng + 64 * 64 + threadIdx.x);
     } else {
-        L.qs.init(qpk, qb + 31);
-        L.ts.init(tpk, tbase + 33);
+        L.qs.init(qpk, qb + 31, (uint32_t)((qb + nq + 15) >> 4) + 1u);
+        L.ts.init(tpk, tbase + 33, (uint32_t)((tbase + nt + 15) >> 4) + 1u);
     }
     L.i0 = -33; L.E2 = 8; L.sv0 = 0;                            // at step -1 from the border's closed form: lane 0's cell scores -259, lane 63's -243
     L.down = 1; L.pdown = 0;
@@ -1268,13 +1269,13 @@ __global__ void __launch_bounds__(256) k_swb2(int64_t first, int64_t count, cons
         L.h.A = {0, 0, 0}; L.h.B = {0, 0, ~0u};
         L.h.Wo0 = L.h.Wo1 = 0; L.h.Wm0 = L.h.Wm1 = 0;
         for (int c = 0; c < 32; c++) { const uint32_t b = base_at(tpk, tbase + (32 - c)); L.h.Wm0 |= (b & 1u) << c; L.h.Wm1 |= (b >> 1) << c; }
-        L.ss.init(tpk, tbase + 33);
+        L.ss.init(tpk, tbase + 33, (uint32_t)((tbase + nt + 15) >> 4) + 1u);
     } else {
         L.h.A = {0, 0, 1u << 31}; L.h.B = {0, 0, ~0u >> 1};
         L.h.Wm0 = L.h.Wm1 = 0;
         for (int c = 33; c < 64; c++) { const uint32_t b = base_at(qpk, qb + (c - 33)); L.h.Wm0 |= (b & 1u) << (63 - c); L.h.Wm1 |= (b >> 1) << (63 - c); }
         { const uint32_t b = base_at(tpk, tbase); L.h.Wo0 = (b & 1u) << 31; L.h.Wo1 = (b >> 1) << 31; }
-        L.ss.init(qpk, qb + 31);
+        L.ss.init(qpk, qb + 31, (uint32_t)((qb + nq + 15) >> 4) + 1u);
     }
     L.i0 = -33; L.E2 = 8; L.sv0 = 0;
     L.down = 1; L.pdown = 0;

@@ -4,13 +4,15 @@
  * PARITY UNPINNED vs the reference: FALCON_unzip shells out to `blasr` (falcon_unzip/unzip.py:86-88),
  * a third-party C++ aligner that is not vendored under /root/reference and whose results
  * (placement, clipping, `--hitPolicy randombest --randomSeed 42` tie-breaks) cannot be reproduced
- * here.  This file therefore DEFINES the aligner ("fzalign v1.5"); the HIP kernels in
+ * here.  This file therefore DEFINES the aligner ("fzalign v1.6"); the HIP kernels in
  * falcon_unzip_amd/csrc/fzp_align.hip must match it bit-for-bit (summaries, CIGARs, DP cell counts),
  * and its quality is judged against the simulator's true alignments.
  *
- * fzalign v1.5  (v1.1: one index position per k-mer, one candidate placement per read, no identity gate; v1.2: multi-position index, two
+ * fzalign v1.6  (v1.1: one index position per k-mer, one candidate placement per read, no identity gate; v1.2: multi-position index, two
  *               candidates, chains; v1.3: best-start soft clip; v1.4: anchor = the chain's first hit, extension forward AND backward from it;
- *               v1.5: an extension runs to the matrix BORDER, the alignment is the best-scoring stretch of the joined path)
+ *               v1.5: an extension runs to the matrix BORDER, the alignment is the best-scoring stretch of the joined path;
+ *               v1.6: the chain's hits every >= PIECE read bases are WAYPOINTS, the forward extension is a sequence of independent banded DPs from one
+ *               waypoint to the next (what blasr does between the anchors of its chain, unzip.py:86-88), free ends are limited)
  *   bases     A/a C/c G/g T/t -> 0..3, anything else -> 0
  *   index     canonical k-mers (k<=16, 2 bits/base, base m of a k-mer at bits 2m; canonical = the smaller of
  *             the k-mer and its reverse complement) of every 2nd contig position -> EVERY such position
@@ -33,13 +35,20 @@
  *             and |dv_h - dv_p| <= 16 + (i_h - i_p)/16 (ties: the closest p), else 1; start(h) = start(p) or
  *             h itself.  The longest chain (ties: the earliest end) gives the anchor = its first hit (i_h, c_h), a cell
  *             of the true path.  Candidates in order W1, W2.
- *   selection every candidate is extended FORWARD from its anchor (below); the one whose forward extension scores
- *             highest at its terminal wins (ties: the earlier candidate) -- blasr's --bestn 1.  The winner is then
- *             extended BACKWARD from its anchor: the same DP on the reversed read prefix [0, i_h) and the
- *             reversed contig window of min(c_h, i_h + i_h/4 + 64) bases before c_h; its path (from ITS terminal)
+ *   waypoints (v1.6) piece = max(3072, ceil(n / 31)).  Along a chain, its first hit is waypoint 0; a later hit of the chain is the next
+ *             waypoint when its oriented offset lies at least `piece` bases after the previous waypoint's (so a read has at most 32).
+ *             The longest chain's waypoints w_0 (the anchor) .. w_m cut the forward extension into pieces.
+ *   pieces    piece k < m is INNER: the extension DP (below) from w_k on the sub-matrix of the nq = i(w_k+1) - i(w_k) read bases and the
+ *             nt = c(w_k+1) - c(w_k) contig bases up to the next waypoint; its terminal is the valid border cell with the largest
+ *             H - gap * (distance to the sub-matrix's corner (nq-1, nt-1) along the border) -- the global alignment through the band --
+ *             and the path of the piece is the gap moves from the corner to the terminal, the walk, the gap moves its exit implies.
+ *             Piece m is FREE: from w_m over min(n - i(w_m), 2 * piece) read bases and min(Lc - c(w_m), nq + nq/4 + 64) contig bases,
+ *             terminal = the best valid border cell (v1.5).  BACKWARD from the anchor: the same free DP on the reversed read prefix of
+ *             min(i_h, piece) bases and the reversed contig window of min(c_h, nq + nq/4 + 64) bases before c_h; its path (from ITS terminal)
  *             is joined to the forward one at the anchor's corner, together with the gap moves either walk's exit
- *             through row / column -1 implies.  `cells` counts the forward DP of all candidates and the winner's
- *             backward DP.
+ *             through row / column -1 implies.  Read bases no piece reaches are soft clip.
+ *   selection every candidate is extended; the one whose FORWARD pieces' terminal scores sum highest wins (ties: the earlier
+ *             candidate) -- blasr's --bestn 1.  `cells` counts every DP of every candidate.
  *   best sub-path (v1.5; v1.3's "best start" at both ends)  P(k) = score of the joined path's first k ops counted from the
  *             forward terminal; the alignment is ops e..s with the largest P(s+1) - P(e) (ties: the smallest s, then
  *             the largest e) -- it begins and ends with a match column; what the path holds outside is soft clip.
@@ -86,6 +95,8 @@ typedef struct {
 #define HIT_CAP 4096
 #define CHAIN_LOOKBACK 64
 #define CHAIN_MAX_GAP 2048
+#define PIECE_LEN 3072      /* v1.6: read bases between waypoints (at least) */
+#define MAX_WP 32           /* waypoints per candidate */
 
 static inline int code_of(uint8_t c) {
     switch (c) {
@@ -137,7 +148,8 @@ static void push(u32vec *v, uint32_t x) {
 }
 
 typedef struct { int32_t s; int64_t i, cp, dv; } hit_t;
-typedef struct { int strand; int64_t i_a, c_a; } anchor_t;
+typedef struct { int strand; int64_t i_a, c_a; int n_wp; int64_t wi[MAX_WP], wc[MAX_WP]; } anchor_t;      /* (wi[0], wc[0]) = the anchor */
+static inline int64_t piece_len(int64_t n) { const int64_t p = (n + MAX_WP - 2) / (MAX_WP - 1); return p > PIECE_LEN ? p : PIECE_LEN; }
 
 /* ---- seeding: hits, coarse windows, one chain per window -> up to 2 anchors (spec in the header) */
 /* per-thread grow-only scratch for the per-read work arrays: hundreds of KB each, i.e. above malloc's mmap threshold -- 256 threads that
@@ -196,6 +208,8 @@ static int seed_candidates(const ctg_index *ix, const uint8_t *fwd, int64_t n, c
         }
     const int n_win = ((int32_t)w2 >= P->min_seed_hits && w2 > 0 && 4ull * w2 >= w1) ? 2 : 1;
     int32_t *wh = (int32_t *)malloc((size_t)(nh ? nh : 1) * 4), *f = (int32_t *)malloc((size_t)(nh ? nh : 1) * 4), *st = (int32_t *)malloc((size_t)(nh ? nh : 1) * 4);
+    int32_t *wl = (int32_t *)malloc((size_t)(nh ? nh : 1) * 4), *wprev = (int32_t *)malloc((size_t)(nh ? nh : 1) * 4);      /* v1.6: last waypoint of the chain ending in e; the waypoint before waypoint e */
+    const int64_t piece = piece_len(n);
     for (int w = 0; w < n_win; w++) {
         const int ws = w ? s2 : s1;
         const int64_t wb = w ? b2 : b1;
@@ -210,16 +224,19 @@ static int seed_candidates(const ctg_index *ix, const uint8_t *fwd, int64_t n, c
         int32_t best_f = 0; int64_t best_e = -1;
         for (int64_t e = 0; e < m; e++) {
             const hit_t *H = &hits[wh[e]];
-            int32_t bf = 1, bst = (int32_t)e;
+            int32_t bf = 1, bst = (int32_t)e; int64_t bp = -1;
             for (int64_t back = 1; back <= CHAIN_LOOKBACK && e - back >= 0; back++) {        /* closest predecessor first */
                 const hit_t *Q = &hits[wh[e - back]];
                 const int64_t di = H->i - Q->i;
                 if (di < 1 || di > CHAIN_MAX_GAP || H->cp <= Q->cp) continue;
                 int64_t dd = H->dv - Q->dv; if (dd < 0) dd = -dd;
                 if (dd > 16 + di / 16) continue;
-                if (f[e - back] + 1 > bf) { bf = f[e - back] + 1; bst = st[e - back]; }
+                if (f[e - back] + 1 > bf) { bf = f[e - back] + 1; bst = st[e - back]; bp = e - back; }
             }
             f[e] = bf; st[e] = bst;
+            if (bp < 0) { wl[e] = (int32_t)e; wprev[e] = -1; }
+            else if (H->i - hits[wh[wl[bp]]].i >= piece) { wl[e] = (int32_t)e; wprev[e] = wl[bp]; }
+            else wl[e] = wl[bp];
             if (bf > best_f) { best_f = bf; best_e = e; }
         }
         if (best_e < 0) continue;                      /* cannot happen: the window has votes */
@@ -229,16 +246,26 @@ static int seed_candidates(const ctg_index *ix, const uint8_t *fwd, int64_t n, c
         cand[n_cand].strand = ws;
         cand[n_cand].i_a = A->i;
         cand[n_cand].c_a = A->cp;
+        {   /* v1.6: the longest chain's waypoints, first to last */
+            int nw = 0;
+            for (int32_t x = wl[best_e]; x >= 0; x = wprev[x]) nw++;
+            if (nw > MAX_WP) { fprintf(stderr, "align_oracle: %d waypoints\n", nw); abort(); }      /* cannot happen: they lie `piece` bases apart */
+            cand[n_cand].n_wp = nw;
+            int at = nw;
+            for (int32_t x = wl[best_e]; x >= 0; x = wprev[x]) { at--; cand[n_cand].wi[at] = hits[wh[x]].i; cand[n_cand].wc[at] = hits[wh[x]].cp; }
+            if (cand[n_cand].wi[0] != A->i || cand[n_cand].wc[0] != A->cp) { fprintf(stderr, "align_oracle: waypoint 0 is not the anchor\n"); abort(); }
+        }
         n_cand++;
     }
-    free(wh); free(f); free(st);
+    free(wh); free(f); free(st); free(wl); free(wprev);
     return n_cand;
 }
 
 /* ---- the banded extension DP from the origin cell (-1, -1) of q[0..nq) x t[0..nt): fills the masks / moves of its scratch set `sb`
  * (arrays sb, sb+1, sb+2), finds the best valid cell.  Used forward from the anchor and, on reversed sequences, backward from it. */
 typedef struct { int64_t steps; int32_t score; int64_t ts, lane; uint64_t *tbD, *tbU; uint8_t *mv; } dp_t;
-static dp_t dp_extend(const uint8_t *q, int64_t nq, const uint8_t *t, int64_t nt, const orc_align_params *P, int sb) {
+/* inner (v1.6): the extension has to arrive at the sub-matrix's corner (nq-1, nt-1): a border cell is valued H - gap * (its distance to the corner) */
+static dp_t dp_extend(const uint8_t *q, int64_t nq, const uint8_t *t, int64_t nt, const orc_align_params *P, int sb, int inner) {
     dp_t R;
     memset(&R, 0, sizeof R);
     const int64_t max_steps = nq + nt + 2;
@@ -286,7 +313,10 @@ static dp_t dp_extend(const uint8_t *q, int64_t nq, const uint8_t *t, int64_t nt
             if (A[kk] >= B[kk]) U |= 1ull << kk;       /* "the gap comes from the same lane" */
             int64_t i = i0 + kk, j = tt - i;
             /* v1.5: the extension runs to a BORDER of the matrix -- the read's last row or the window's last column; its terminal is the best valid cell there */
-            if (i >= 0 && i < nq && j >= 0 && j < nt && (i == nq - 1 || j == nt - 1) && h > bsc[kk]) { bsc[kk] = h; bt[kk] = tt; }
+            if (i >= 0 && i < nq && j >= 0 && j < nt && (i == nq - 1 || j == nt - 1)) {
+                const int32_t v = inner ? h - P->gap * (int32_t)((nq - 1 - i) + (nt - 1 - j)) : h;
+                if (v > bsc[kk]) { bsc[kk] = v; bt[kk] = tt; }
+            }
         }
         tbD[tt] = D; tbU[tt] = U; mv[tt] = (uint8_t)down;
         steer = !(H[0] > H[W - 1]);
@@ -329,49 +359,77 @@ static int64_t dp_walk(const dp_t *R, int sb, uint8_t *ops, int64_t *i_end, int6
     return n;
 }
 
-/* ---- extension of one candidate (v1.5): forward from the anchor hit to the terminal, backward from it (the same DP on the reversed read prefix and
- * contig window) to ITS terminal; the two walks and the gap moves their ends imply at the anchor's corner make one path.  r = the oriented read codes. */
-static void extend_one(const ctg_index *ix, const uint8_t *r, int64_t n, const anchor_t *an, const orc_align_params *P,
-                       orc_aln_summary *out, u32vec *cig, int32_t *sel_score, int64_t *fwd_cells, const dp_t *Fpre) {
-    memset(out, 0, sizeof *out);
-    const int64_t Lc = ix->len;
+/* ---- the path of one candidate (v1.6): the forward pieces from the last waypoint's free extension down to the anchor, then the backward extension
+ * from the anchor out -- each piece its own DP and walk, joined by the gap moves their ends imply.  r = the oriented read codes.  ops (END first:
+ * 0 column, 1 I, 2 D) go to scratch array `ob`; (*i_end, *j_end) = the path's last cell in read / contig coordinates. */
+typedef struct { uint8_t *ops; int64_t L, i_end, j_end, cells; int32_t fwd_score, back_score; int ok; } path_t;
+static path_t build_path(const ctg_index *ix, const uint8_t *r, int64_t n, const anchor_t *an, const orc_align_params *P, int ob) {
+    path_t R;
+    memset(&R, 0, sizeof R);
+    R.back_score = NEG;
+    const int64_t Lc = ix->len, piece = piece_len(n);
     const int64_t i_a = an->i_a, c_a = an->c_a;
-    const int bs_ = an->strand;
-    const uint8_t *q = r + i_a;
-    const int64_t nq = n - i_a;
-    int64_t nt = Lc - c_a;
-    if (nt > nq + nq / 4 + 64) nt = nq + nq / 4 + 64;
-    const uint8_t *t = ix->codes + c_a;
-    const dp_t F = Fpre ? *Fpre : dp_extend(q, nq, t, nt, P, 0);      /* the selection has run the winner's forward DP already: its masks are still in place */
-    out->cells = F.steps * W;
-    *fwd_cells = F.steps * W;
-    out->score = 0;
-    *sel_score = F.score;                       /* what the candidate selection compares: the FORWARD extension's score at its terminal */
-    if (F.lane < 0) return;                     /* (no valid border cell: cannot happen for nq, nt >= 1) */
-    /* path ops, END first: forward walk, the gap moves its exit implies, the backward part from the anchor out */
-    uint8_t *ops = (uint8_t *)scratch_get(12, (size_t)(2 * n + 2 * (nt + 64) + 2 * (i_a + i_a / 4 + 128) + 64));
-    int64_t i_end, j_end, is, js;
-    int64_t L = dp_walk(&F, 3, ops, &i_end, &j_end, &is, &js);
-    for (int64_t x = 0; x <= js && is < 0; x++) ops[L++] = 2;     /* left through row -1: the contig bases 0..js were skipped */
-    for (int64_t x = 0; x <= is && js < 0; x++) ops[L++] = 1;     /* left through column -1 */
+    int64_t cap = 1024 + 2 * n + 2 * (n + n / 4 + 64) + 2 * (piece + piece / 4 + 64);      /* every piece: at most nq + nt ops and border moves */
+    if (an->n_wp > 1) cap += 2 * (an->wc[an->n_wp - 1] - c_a);
+    uint8_t *ops = (uint8_t *)scratch_get(ob, (size_t)cap);
+    uint8_t *po = NULL;
+    int64_t L = 0;
+    R.ops = ops; R.ok = 1;
+    for (int k = an->n_wp - 1; k >= 0; k--) {
+        const int inner = k < an->n_wp - 1;
+        const int64_t oi = an->wi[k], oc = an->wc[k];
+        int64_t nq, nt;
+        if (inner) { nq = an->wi[k + 1] - oi; nt = an->wc[k + 1] - oc; }
+        else {
+            nq = n - oi; if (nq > 2 * piece) nq = 2 * piece;
+            nt = Lc - oc; if (nt > nq + nq / 4 + 64) nt = nq + nq / 4 + 64;
+        }
+        const dp_t F = dp_extend(r + oi, nq, ix->codes + oc, nt, P, 0, inner);
+        R.cells += F.steps * W;
+        if (F.lane < 0) { R.ok = 0; R.fwd_score = NEG; break; }          /* (no valid border cell: cannot happen for nq, nt >= 1) */
+        R.fwd_score += F.score;
+        po = (uint8_t *)scratch_get(15, (size_t)(nq + nt + 64));
+        int64_t ie, je, is, js;
+        const int64_t np = dp_walk(&F, 3, po, &ie, &je, &is, &js);
+        if (!inner) { R.i_end = oi + ie; R.j_end = oc + je; }
+        else {      /* from the sub-matrix's corner to the terminal, along the border */
+            for (int64_t x = je; x < nt - 1; x++) ops[L++] = 2;
+            for (int64_t x = ie; x < nq - 1; x++) ops[L++] = 1;
+        }
+        memcpy(ops + L, po, (size_t)np); L += np;
+        for (int64_t x = 0; x <= js && is < 0; x++) ops[L++] = 2;     /* left through row -1: the contig bases 0..js were skipped */
+        for (int64_t x = 0; x <= is && js < 0; x++) ops[L++] = 1;     /* left through column -1 */
+    }
     if (i_a > 0 && c_a > 0) {
-        const int64_t nqb = i_a;
+        const int64_t nqb = i_a < piece ? i_a : piece;
         int64_t ntb = c_a;
         if (ntb > nqb + nqb / 4 + 64) ntb = nqb + nqb / 4 + 64;
         uint8_t *qb = (uint8_t *)scratch_get(13, (size_t)nqb), *tb = (uint8_t *)scratch_get(14, (size_t)ntb);
         for (int64_t x = 0; x < nqb; x++) qb[x] = r[i_a - 1 - x];
         for (int64_t x = 0; x < ntb; x++) tb[x] = ix->codes[c_a - 1 - x];
-        const dp_t B = dp_extend(qb, nqb, tb, ntb, P, 8);
-        out->cells += B.steps * W;
-        if (B.lane >= 0) {
-            uint8_t *ob = (uint8_t *)scratch_get(15, (size_t)(nqb + ntb + 64));
+        const dp_t B = dp_extend(qb, nqb, tb, ntb, P, 8, 0);
+        R.cells += B.steps * W;
+        if (B.lane >= 0 && R.ok) {
+            R.back_score = B.score;
+            po = (uint8_t *)scratch_get(15, (size_t)(nqb + ntb + 64));
             int64_t bie, bje, bis, bjs;
-            const int64_t nb = dp_walk(&B, 11, ob, &bie, &bje, &bis, &bjs);
+            const int64_t nb = dp_walk(&B, 11, po, &bie, &bje, &bis, &bjs);
             for (int64_t x = 0; x <= bjs && bis < 0; x++) ops[L++] = 2;      /* next to the anchor, as above */
             for (int64_t x = 0; x <= bis && bjs < 0; x++) ops[L++] = 1;
-            for (int64_t x = nb - 1; x >= 0; x--) ops[L++] = ob[x];         /* the walk came from the far end towards the anchor: turned round */
+            for (int64_t x = nb - 1; x >= 0; x--) ops[L++] = po[x];         /* the walk came from the far end towards the anchor: turned round */
         }
     }
+    R.L = L;
+    return R;
+}
+
+/* ---- from the winner's path to its alignment: best sub-path, CIGAR, summary */
+static void finish_path(const ctg_index *ix, const uint8_t *r, int64_t n, int strand, const path_t *Pt, const orc_align_params *P, orc_aln_summary *out, u32vec *cig) {
+    const uint8_t *ops = Pt->ops;
+    const int64_t L = Pt->L;
+    int64_t i_end = Pt->i_end, j_end = Pt->j_end;
+    out->score = 0;
+    if (!Pt->ok) return;
     {
         /* v1.5 "best sub-path": the joined path runs from the forward terminal (op 0) to the backward one; with P(k) = score of ops 0..k-1, the
          * alignment is ops e..s with the largest P(s+1) - P(e)  (ties: the smallest s, then the largest e): both of its ends are match columns, what
@@ -382,7 +440,7 @@ static void extend_one(const ctg_index *ix, const uint8_t *r, int64_t n, const a
             int64_t i = i_end, j = j_end, Pk = 0, minP = 0, e_min = 0, ci = 0, cj = 0, ci_min = 0, cj_min = 0;
             for (int64_t x = 0; x < L; x++) {
                 if (Pk <= minP) { minP = Pk; e_min = x; ci_min = ci; cj_min = cj; }          /* '<=': the largest e among equal prefixes */
-                if (ops[x] == 0) { Pk += r[i_a + i] == ix->codes[c_a + j] ? P->match : -P->mismatch; i--; j--; ci++; cj++; }
+                if (ops[x] == 0) { Pk += r[i] == ix->codes[j] ? P->match : -P->mismatch; i--; j--; ci++; cj++; }
                 else if (ops[x] == 1) { Pk -= P->gap; i--; ci++; }
                 else { Pk -= P->gap; j--; cj++; }
                 if (Pk - minP > bestS) { bestS = Pk - minP; s_best = x; e_best = e_min; ci_e = ci_min; cj_e = cj_min; }
@@ -391,13 +449,13 @@ static void extend_one(const ctg_index *ix, const uint8_t *r, int64_t n, const a
         if (s_best < 0) return;                     /* not one match column on the path */
         out->score = (int32_t)bestS;
         i_end -= ci_e; j_end -= cj_e;
-        /* op by op from the alignment's END: cell (i, j) relative to the forward anchor (negative in the backward part), run-length encoding */
+        /* op by op from the alignment's END: cell (i, j) in read / contig coordinates, run-length encoding */
         int64_t i = i_end, j = j_end;
         u32vec rev = {0};
         int cur_op = -1; uint32_t cur_len = 0; int32_t ncol = 0, n_eq = 0;
         for (int64_t x = e_best; x <= s_best; x++) {
             int op;
-            if (ops[x] == 0) { op = r[i_a + i] == ix->codes[c_a + j] ? 7 : 8; n_eq += op == 7; i--; j--; ncol++; }
+            if (ops[x] == 0) { op = r[i] == ix->codes[j] ? 7 : 8; n_eq += op == 7; i--; j--; ncol++; }
             else if (ops[x] == 1) { op = 1; i--; }
             else { op = 2; j--; }
             if (op == cur_op) cur_len++;
@@ -411,7 +469,7 @@ static void extend_one(const ctg_index *ix, const uint8_t *r, int64_t n, const a
                 abort();
             }
         }
-        int64_t q_lead = i + 1, r_lead = j + 1;        /* bases before the first path op, relative to the anchor (negative when the path reaches back) */
+        int64_t q_lead = i + 1, r_lead = j + 1;        /* the first read / contig base of the path's kept stretch */
         /* forward order; strip leading / trailing non-match ops */
         int64_t a = rev.n - 1, b = 0;                   /* forward index f = rev[a - f] */
         while (a >= b && ((rev.v[a] & 15) == 1 || (rev.v[a] & 15) == 2)) {
@@ -431,12 +489,12 @@ static void extend_one(const ctg_index *ix, const uint8_t *r, int64_t n, const a
             if (mo != prev_m) { n_mraw++; prev_m = mo; }
         }
         if (a >= b && ncol > 0 && (n_mraw <= n + 16)) {
-            const int64_t pos = c_a + r_lead, ref_end = c_a + j_end + 1 - r_trail;
-            const int64_t q_start = i_a + q_lead, q_end = i_a + i_end + 1 - q_trail;
+            const int64_t pos = r_lead, ref_end = j_end + 1 - r_trail;
+            const int64_t q_start = q_lead, q_end = i_end + 1 - q_trail;
             const int64_t aln_len = (q_end - q_start) + (ref_end - pos) - ncol;     /* columns + inserted + deleted bases */
             if (P->min_pct_identity <= 0 || 100 * (int64_t)n_eq >= (int64_t)P->min_pct_identity * aln_len) {
                 out->aligned = 1;
-                out->strand = bs_;
+                out->strand = strand;
                 out->pos = (int32_t)pos;
                 out->ref_end = (int32_t)ref_end;
                 out->q_start = (int32_t)q_start;
@@ -458,7 +516,7 @@ static void extend_one(const ctg_index *ix, const uint8_t *r, int64_t n, const a
     }
 }
 
-/* One read: candidates, extension of each, best extension score wins. */
+/* One read: candidates, the path of each, the best forward score wins. */
 static void align_one(const ctg_index *ix, const uint8_t *fwd, int64_t n, const orc_align_params *P,
                       orc_aln_summary *out, u32vec *cig) {
     memset(out, 0, sizeof *out);
@@ -470,26 +528,21 @@ static void align_one(const ctg_index *ix, const uint8_t *fwd, int64_t n, const 
     uint8_t *ori[2];
     ori[0] = (uint8_t *)scratch_get(4, (size_t)n); ori[1] = (uint8_t *)scratch_get(5, (size_t)n);
     for (int64_t i = 0; i < n; i++) { ori[0][i] = fwd[i]; ori[1][i] = (uint8_t)(3 - fwd[n - 1 - i]); }
-    /* every candidate's FORWARD extension decides the selection (blasr --bestn 1); only the winner is extended backward and traced */
-    int64_t fwd_cells = 0; int win = 0; int32_t best_sel = NEG;
-    dp_t Fc[2];
+    /* every candidate is extended piece by piece; the FORWARD pieces' scores decide the selection (blasr --bestn 1) */
+    int win = 0;
+    int64_t cells = 0;
+    path_t Pc[2];
     static int dbg = -1;
     if (dbg < 0) dbg = getenv("ORC_ALIGN_DEBUG") != NULL;
     for (int c = 0; c < nc; c++) {
-        const uint8_t *r = ori[cand[c].strand];
-        const int64_t nq = n - cand[c].i_a;
-        int64_t nt = ix->len - cand[c].c_a;
-        if (nt > nq + nq / 4 + 64) nt = nq + nq / 4 + 64;
-        const dp_t F = Fc[c] = dp_extend(r + cand[c].i_a, nq, ix->codes + cand[c].c_a, nt, P, c ? 16 : 0);       /* own scratch set per candidate */
-        fwd_cells += F.steps * W;
-        if (dbg) fprintf(stderr, "cand %d: strand %d anchor (%lld, %lld) -> forward score %d\n", c, cand[c].strand, (long long)cand[c].i_a, (long long)cand[c].c_a, F.score);
-        if (c == 0 || F.score > best_sel) { best_sel = F.score; win = c; }
+        Pc[c] = build_path(ix, ori[cand[c].strand], n, &cand[c], P, c ? 17 : 12);       /* own ops array per candidate */
+        cells += Pc[c].cells;
+        if (dbg) fprintf(stderr, "cand %d: strand %d anchor (%lld, %lld), %d waypoints -> forward score %d\n", c, cand[c].strand, (long long)cand[c].i_a, (long long)cand[c].c_a, cand[c].n_wp, Pc[c].fwd_score);
+        if (c > 0 && Pc[c].fwd_score > Pc[win].fwd_score) win = c;
     }
-    int32_t sel = NEG;
-    int64_t win_fwd = 0;
     u32vec wcig = {0};
-    extend_one(ix, ori[cand[win].strand], n, &cand[win], P, out, &wcig, &sel, &win_fwd, &Fc[win]);
-    out->cells += fwd_cells - win_fwd;          /* cells: the forward DP of every candidate + the winner's backward DP */
+    finish_path(ix, ori[cand[win].strand], n, cand[win].strand, &Pc[win], P, out, &wcig);
+    out->cells = cells;
     if (!out->aligned) { out->score = 0; out->strand = 0; }
     else for (int64_t x = 0; x < wcig.n; x++) push(cig, wcig.v[x]);
     free(wcig.v);
@@ -582,25 +635,12 @@ int orc_align_origins(const uint8_t *ctg_ascii, int64_t ctg_len, const uint8_t *
     if (n >= P->kmer && ix.len >= P->kmer) nc = seed_candidates(&ix, fwd, n, P, cand);
     for (int c = 0; c < nc; c++) {
         out[5 * c] = cand[c].strand; out[5 * c + 1] = cand[c].i_a; out[5 * c + 2] = cand[c].c_a;
-        /* the two extensions' scores at their terminals (v1.5: the best valid border cell), as extend_one would run them */
+        /* the extensions' scores at their terminals (forward: summed over the pieces), as align_one runs them */
         uint8_t *ori = (uint8_t *)malloc((size_t)(n ? n : 1));
         for (int64_t i = 0; i < n; i++) ori[i] = cand[c].strand ? (uint8_t)(3 - fwd[n - 1 - i]) : fwd[i];
-        const int64_t i_a = cand[c].i_a, c_a = cand[c].c_a, nq = n - i_a;
-        int64_t nt = ix.len - c_a;
-        if (nt > nq + nq / 4 + 64) nt = nq + nq / 4 + 64;
-        const dp_t F = dp_extend(ori + i_a, nq, codes + c_a, nt, P, 0);
-        out[5 * c + 3] = F.lane >= 0 ? F.score : NEG;
-        out[5 * c + 4] = NEG;
-        if (i_a > 0 && c_a > 0) {
-            int64_t ntb = c_a;
-            if (ntb > i_a + i_a / 4 + 64) ntb = i_a + i_a / 4 + 64;
-            uint8_t *qb = (uint8_t *)malloc((size_t)i_a), *tb = (uint8_t *)malloc((size_t)ntb);
-            for (int64_t x = 0; x < i_a; x++) qb[x] = ori[i_a - 1 - x];
-            for (int64_t x = 0; x < ntb; x++) tb[x] = codes[c_a - 1 - x];
-            const dp_t B = dp_extend(qb, i_a, tb, ntb, P, 8);
-            out[5 * c + 4] = B.lane >= 0 ? B.score : NEG;
-            free(qb); free(tb);
-        }
+        const path_t Pt = build_path(&ix, ori, n, &cand[c], P, 12);
+        out[5 * c + 3] = Pt.ok ? Pt.fwd_score : NEG;
+        out[5 * c + 4] = Pt.back_score;
         free(ori);
     }
     scratch_release();
@@ -610,8 +650,8 @@ int orc_align_origins(const uint8_t *ctg_ascii, int64_t ctg_len, const uint8_t *
 
 /* test hook (tests/test_swb_core.py: the bit-sliced cell function of falcon_unzip_amd/csrc/fzp_swb_core.h against this scalar DP): one extension of
  * q[0..nq) x t[0..nt) (codes 0..3) -- per step the two masks and the move, out = {steps, terminal score, terminal step, terminal lane} */
-int orc_dp_extend_raw(const uint8_t *q, int64_t nq, const uint8_t *t, int64_t nt, const orc_align_params *P, uint64_t *tbD, uint64_t *tbU, uint8_t *mv, int64_t *out) {
-    const dp_t R = dp_extend(q, nq, t, nt, P, 0);
+int orc_dp_extend_raw(const uint8_t *q, int64_t nq, const uint8_t *t, int64_t nt, const orc_align_params *P, uint64_t *tbD, uint64_t *tbU, uint8_t *mv, int64_t *out, int inner) {
+    const dp_t R = dp_extend(q, nq, t, nt, P, 0, inner);
     memcpy(tbD, R.tbD, (size_t)R.steps * 8); memcpy(tbU, R.tbU, (size_t)R.steps * 8); memcpy(mv, R.mv, (size_t)R.steps);
     out[0] = R.steps; out[1] = R.score; out[2] = R.ts; out[3] = R.lane;
     scratch_release();

@@ -493,6 +493,46 @@ def test_the_three_dp_kernels_agree(eng, oracle, monkeypatch):
     assert got["default"][0]["aligned"].mean() > 0.8            # (reads of a few hundred bases rarely gather 8 seed votes)
 
 
+def test_terminal_on_the_border_reached_along_the_band_edge(eng, oracle, monkeypatch):
+    """An extension whose last steps all go one way puts an edge lane of the band ON the matrix border at the very step a 32-step interior block would
+    have ended: that cell is a terminal candidate and only the checked steps look at it (k_sw's `safe` count let it into the unchecked
+    block).  Error-free reads with 16..31 extra bases 0..70 bases before their end (the path jumps towards lane 63 and the band runs DOWN after it, into
+    the read's last row) and, at the contig's end, with as many bases missing (it runs RIGHT into the last column); every DP kernel against the twin."""
+    from falcon_unzip_amd import _lib
+    rng = np.random.Generator(np.random.PCG64(97))
+    L = 24000
+    ctg_codes = rng.integers(0, 4, L, dtype=np.uint8)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    ctg = acgt[ctg_codes].tobytes()
+    reads = []
+    for x in range(16, 32):
+        for tail in range(0, 71):
+            s0 = 2 * int(rng.integers(0, (L - 9000) // 2))                          # (even: the index holds every 2nd contig position, an error-free read never changes parity)
+            n_body = 2400 + int(rng.integers(0, 64))
+            body = ctg_codes[s0:s0 + n_body]
+            reads.append(acgt[np.concatenate((body, rng.integers(0, 4, x, dtype=np.uint8), ctg_codes[s0 + n_body:s0 + n_body + tail]))].tobytes())
+            e0 = L - int(rng.integers(0, 8))                                        # the contig ends 0..7 bases after the read's last base ...
+            b2 = ctg_codes[(e0 - 2400 - int(rng.integers(0, 64))) & ~1:e0]
+            cut = len(b2) - tail
+            reads.append(acgt[np.concatenate((b2[:cut - x], b2[cut:]))].tobytes())  # ... and x contig bases are missing from the read `tail` bases before its end
+    exp, exp_cig = oracle_lib.align_reads(oracle, ctg, reads, n_threads=8)
+    assert exp["aligned"].mean() > 0.95
+    for mode, env in (("default", {}), ("wave_per_read", {"FZP_SW_NO_BITS": "1"}), ("lane64", {"FZP_SWB_64": "1"}), ("pair", {"FZP_SWB_PAIR": "1"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        job = _lib.align_job(eng, [ctg], reads)
+        job.run()
+        s = job.summaries()
+        aln, idx = job.alnset(0)
+        for f in FIELDS:
+            assert np.array_equal(s[f], exp[f]), (mode, f, np.flatnonzero(s[f] != exp[f])[:5])
+        for k, r in enumerate(idx):
+            assert np.array_equal(np.array([(l << 4) | o for l, o in aln.cigar_of(k)], dtype=np.uint32), exp_cig[r]), (mode, k, r)
+        job.close()
+        for k in env:
+            monkeypatch.delenv(k)
+
+
 def test_segmented_traceback_equals_serial_walk(eng, monkeypatch):
     """The trace-back walks a long read as segments of 4 096 DP steps at once (speculative starts, stitched where neighbouring walkers meet) -- the
     op stream must be the serial walk's (FZP_TB_SERIAL=1), also when the machinery behind it has to work: FZP_TB_GUESS_LANE=1 starts the walkers at
