@@ -220,35 +220,25 @@ def roofline(cells_per_launch, sw_avg_ms, sw_launches, dp_gcells, traffic):
 
 
 def shaped_leg(eng, inp):
-    """K1 alone on the same contigs with reads of real CLR shape: k_sw's rate when read lengths are uneven, with the launch longest-first
-    (default) and in input order (FZP_SW_INPUT_ORDER=1, the r2 behaviour)."""
+    """K1 alone on the same contigs with reads of real CLR shape (fzalign v1.6 cuts every read into pieces of ~3 kb, so uneven read lengths no longer
+    shape the DP launch: one figure, where r3 compared launch orders)."""
     from falcon_unzip_amd import _lib
     contigs, blob, off, read_ctg = inp
     job = _lib.align_job_raw(eng, contigs, blob, off, read_ctg)
-    res = {}
-    for mode in ("longest_first", "longest_first_no_priority", "input_order"):
-        if mode == "input_order":
-            os.environ["FZP_SW_INPUT_ORDER"] = "1"
-        if mode != "longest_first":
-            os.environ["FZP_SW_NO_PRIO"] = "1"
-        try:
-            job.run()
-            eng.synchronize()
-            eng.prof_reset()
-            eng.prof_enable(True)
-            for _ in range(2):
-                job.run()
-            eng.synchronize()
-            eng.prof_enable(False)
-            pr = eng.prof()
-        finally:
-            os.environ.pop("FZP_SW_INPUT_ORDER", None)
-            os.environ.pop("FZP_SW_NO_PRIO", None)
-        summ = job.summaries()
-        sw_ms, sw_n = pr.get("k1_sw", (0.0, 0))
-        fb = job.tb_fallbacks()
-        res[mode] = {"traceback_serial_fallback_reads": fb, "k1_sw_ms": round(sw_ms / max(1, sw_n), 3), "k1_traceback_ms": round(pr.get("k1_traceback", (0.0, 0))[0] / max(1, sw_n), 3),
-                     "dp_gcell_per_s": round(float(summ["cells"].sum()) / (sw_ms / max(1, sw_n) * 1e-3) / 1e9, 2) if sw_ms else 0.0}
+    job.run()
+    eng.synchronize()
+    eng.prof_reset()
+    eng.prof_enable(True)
+    for _ in range(2):
+        job.run()
+    eng.synchronize()
+    eng.prof_enable(False)
+    pr = eng.prof()
+    summ = job.summaries()
+    sw_ms, sw_n = pr.get("k1_sw", (0.0, 0))
+    res = {"k1_sw_ms": round(sw_ms / max(1, sw_n), 3), "k1_traceback_ms": round(pr.get("k1_traceback", (0.0, 0))[0] / max(1, sw_n), 3),
+           "k1_seed_ms": round(pr.get("k1_seed", (0.0, 0))[0] / max(1, sw_n), 3),
+           "dp_gcell_per_s": round(float(summ["cells"].sum()) / (sw_ms / max(1, sw_n) * 1e-3) / 1e9, 2) if sw_ms else 0.0}
     lens = np.diff(off)
     inside = (summ["q_end"] - summ["q_start"])[summ["aligned"] == 1]
     job.close()
@@ -527,7 +517,6 @@ def main():
         rank_load = [{"rank": 0, "reads": n_reads, "ms_per_step": round(dt / args.steps * 1e3, 3)}]
 
     summ = job.summaries() if job is not None else np.zeros(0, dtype=[("cells", "<i8"), ("aligned", "<i4")])
-    tb_stats = job.tb_fallbacks() if job is not None else (0, 0)
     cells_per_step = float(summ["cells"].sum())
     sw_ms, sw_launches = prof.get("k1_sw", (0.0, 0))
     sw_avg_ms = sw_ms / max(1, sw_launches)
@@ -638,7 +627,6 @@ def main():
             "upload_ms": round(upload_ms, 1),
             "dp_cells_per_step": cells_per_step,
             "aligned_frac": round(aligned_frac, 4),
-            "traceback": {"reads_walked_serially_after_all": tb_stats[0], "segments_walked_twice": tb_stats[1]},
             "stage_counts": {k: int(v) for k, v in stats.items()},
             "kernel_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in sorted(prof.items())},
             "host_wall_ms_per_step": dict({k: round(v / args.steps * 1e3, 3) for k, v in host_t.items()}, **{k[3:]: round(v / args.steps, 3) for k, v in sect.items()}),

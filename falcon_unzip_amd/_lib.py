@@ -166,7 +166,6 @@ def load():
         "fzp_align_create": (C.c_int, [VP, I32, VP, VP, I64, VP, VP, VP, VP, PP]),
         "fzp_align_run": (C.c_int, [VP, VP]),
         "fzp_align_invalidate_index": (C.c_int, [VP]),
-        "fzp_align_tb_fallbacks": (C.c_int, [VP, VP, VP]),
         "fzp_align_summaries": (C.c_int, [VP, VP, VP]),
         "fzp_align_n_second": (I64, [VP]),
         "fzp_batch_text": (C.c_int, [VP, VP, C.c_int, PP, PSZ, PP]),
@@ -535,12 +534,6 @@ class AlignJob:
         out = PipeOut()
         _check(load().fzp_job_phase_write(self.eng._p, self._p, C.byref(nm), C.byref(opts), C.byref(out)))
         return _pipe_result(out)
-
-    def tb_fallbacks(self):
-        """(reads of the last run walked serially after all, trace-back segments walked a second time) -- statistics only"""
-        n = (C.c_int64 * 2)()
-        _check(load().fzp_align_tb_fallbacks(self.eng._p, self._p, C.cast(n, C.c_void_p)))
-        return int(n[0]), int(n[1])
 
     def to_batch(self) -> "Batch":
         p = C.c_void_p()

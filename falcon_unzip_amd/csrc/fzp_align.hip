@@ -1,17 +1,19 @@
 // fzp_align.hip -- K1: read -> contig alignment on gfx950 (the role of blasr + samtools sort,
-// falcon_unzip/unzip.py:86-91).  Spec "fzalign v1.1": oracle/align_oracle.c is its scalar twin and the
+// falcon_unzip/unzip.py:86-91).  Spec "fzalign v1.6": oracle/align_oracle.c is its scalar twin and the
 // kernels here match it bit-for-bit (summaries, CIGAR words, DP cell counts).  Parity vs blasr itself
 // is UNPINNED (third-party binary, not vendored).
 //
-//   k_pack        ASCII -> 2 bit/base words (16 bases per u32, base m at bits 2m)
+//   k_pack        ASCII -> 2 bit/base words (16 bases per u32, base m at bits 2m); k_revcomp: the other orientation of every read and contig, once per job
 //   k_index_*     contig k-mers -> bucketed table of (key<<32 | position<<1 | strand bit), every sampled position, built partition by partition in LDS
-//   k_seed        per read: diagonal-bin votes of sampled k-mers (both strands) in LDS, argmax, anchor
-//   k_orient      per read: oriented (forward / reverse-complement) packed copy
-//   k_sw          per read, ONE WAVE: adaptive anti-diagonal band, 64 cells = 64 lanes; neighbours
-//                 arrive by DPP wave shifts; per step two 64-bit trace-back masks (v_cmp -> SGPR pair)
-//                 go to HBM; steering compares lanes 0 and 63.  Integer VALU-bound, no MFMA.
-//   k_tb_walk     per read, one lane: walks the masks back from the best cell, emits a 2-bit op stream
-//   k_tb_cigar    per read, one wave: op stream -> forward run-length CIGAR, clips, summary
+//   k_seed        per read: hit list + diagonal-bin votes of sampled k-mers (both strands) in LDS, the two best windows
+//   k_chain       per (read, window): the longest chain of hits (strict links, bridges over seedless stretches) -> anchor + WAYPOINTS every >= `piece` bases
+//   k_slot_*      per read: its extension PIECES (waypoint to waypoint, the free end, the backward extension; both candidates) as DP slots;
+//   k_sort_*, k_route, k_lists, k_plan_final: slots by decreasing length, dealt to the two DP kernels, their mask streams planned in launch order -- all on the device
+//   k_swb / k_swb2 the banded DP, bit-sliced: one slot per lane (per pair of lanes); k_sw: one wave per slot (slots narrower than the band).  Per step two
+//                 64-bit trace-back masks go to HBM.  Integer VALU-bound, no MFMA.
+//   k_tb_walk     per slot, one lane: walks the masks back from the terminal, emits a 2-bit op stream
+//   k_join        per read, one wave: candidate selection, the winner's pieces joined into one op stream
+//   k_tb_cigar    per read, one wave: best sub-path, op stream -> forward run-length CIGAR, clips, summary
 //   k_plan_*      per contig: aligned reads ordered by (POS, read), record filters (phasing.py:72-75), record offsets
 //   k_gather(16)  accepted records -> contiguous CIGAR + ASCII SEQ arrays for an alnset / the phasing batch
 #include <algorithm>
@@ -110,6 +112,11 @@ constexpr int CTG_STRIDE = 2;
 constexpr int MAX_OCC = 8;          // spec: k-mers with more index entries never produce a hit
 constexpr int HIT_CAP = 4096;       // spec: hits of a read beyond the first HIT_CAP (sample order, then position) do not exist
 constexpr int CHAIN_MAX_GAP = 2048;
+constexpr int BRIDGE_MAX_GAP = 4096;   // v1.6: a chain may cross a seedless stretch of up to this many read bases (looser diagonal tolerance) ...
+constexpr int BRIDGE_COST = 4;         // ... for the price of this many hits
+constexpr int PIECE_LEN = 3072;        // v1.6: read bases between waypoints (at least)
+constexpr int MAX_WP = 31;             // waypoints per candidate: a read has at most 2 x (MAX_WP + 1) = 64 slots, one per lane of k_join
+__host__ __device__ __forceinline__ int32_t piece_len(int64_t n) { const int64_t p = (n + MAX_WP - 2) / (MAX_WP - 1); return (int32_t)(p > PIECE_LEN ? p : PIECE_LEN); }
 __device__ __forceinline__ uint32_t canonical(uint32_t key, int k, uint32_t *is_rc) {
     uint32_t r = rc_key(key, k);
     *is_rc = r < key ? 1u : 0u;
@@ -381,12 +388,13 @@ __global__ void __launch_bounds__(256) k_seed(int64_t first, const uint32_t *__r
     if ((int32_t)w1 < min_hits || w1 == 0) { if (threadIdx.x == 0) win[blockIdx.x] = sw; return; }
     const int x1 = (int)(0xffffffffu - (uint32_t)best);
     const int s1 = x1 >= NB, b1 = s1 ? x1 - NB : x1;
-    // W2: the best window on the other strand or at least 3 bins away
+    // W2: the best window on the other strand or at least 3 (+ 1 per 16 384 read bases: k_chain's windows widen by as much) bins away
+    const int ext = (int)(n >> 14);
     uint64_t best2 = 0;
     for (int x = threadIdx.x; x < 2 * NB; x += 256) {
         const int sx = x >= NB, b = sx ? x - NB : x;
         if (b + 1 >= NB) continue;
-        if (sx == s1 && b - b1 < 3 && b1 - b < 3) continue;
+        if (sx == s1 && b - b1 < 3 + ext && b1 - b < 3 + ext) continue;
         uint64_t sc = (uint64_t)votes[x] + votes[x + 1];
         uint64_t key = (sc << 32) | (uint64_t)(0xffffffffu - (uint32_t)x);
         best2 = key > best2 ? key : best2;
@@ -411,12 +419,16 @@ __device__ __forceinline__ int32_t wave_max_nonneg_dpp(int32_t v) {
     return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 
-// ---- seeding, part 2 (spec "chains"): one wave per (read, window).  The window's hits are walked in list order (reversed on
+// ---- seeding, part 2 (spec "chains", "waypoints"): one wave per (read, window).  The window's hits are walked in list order (reversed on
 // the reverse strand), 64 list entries per load; the last 64 window hits sit one per lane (lane = running index mod 64), the
 // new hit is tested against all of them at once and the best predecessor comes out of one wave-wide max.  The chain is a
-// serial dependence per read: thousands of waves in flight hide it.
+// serial dependence per read: thousands of waves in flight hide it.  v1.6: a link is strict (as before) or a bridge (a gap of up to 4 096 bases, a
+// looser diagonal bound, BRIDGE_COST hits of penalty); every ring entry also carries the last waypoint of its chain -- a hit at least `piece` bases
+// after the waypoint before it becomes one, and says so in wpp[] (list index of the waypoint before it) -- so the longest chain's waypoints are a walk
+// of a few links from its last one.
 __global__ void __launch_bounds__(64) k_chain(int64_t first, int64_t count, const int32_t *__restrict__ read_len, const uint2 *__restrict__ hits_g,
-                                              const SeedWin *__restrict__ win, Anchor *__restrict__ anc, Anchor *__restrict__ ancB) {
+                                              const SeedWin *__restrict__ win, Anchor *__restrict__ anc, Anchor *__restrict__ ancB, int32_t *__restrict__ wpp_g,
+                                              int32_t *__restrict__ n_wp, int2 *__restrict__ wps) {
     const int64_t wv = blockIdx.x;
     if (wv >= 2 * count) return;
     const int64_t slot = wv >> 1;
@@ -426,13 +438,16 @@ __global__ void __launch_bounds__(64) k_chain(int64_t first, int64_t count, cons
     const SeedWin sw = win[slot];
     Anchor *out = which ? ancB : anc;
     const Anchor none = {0, 0, 0, 0};
-    if (sw.n_hits == 0 || (which && !sw.have2)) { if (lane == 0) out[r] = none; return; }
+    if (sw.n_hits == 0 || (which && !sw.have2)) { if (lane == 0) { out[r] = none; n_wp[2 * r + which] = 0; } return; }
     const int32_t n = read_len[r];
+    const int32_t piece = piece_len(n);
+    const int ext = n >> 14;      // a long read's diagonal drifts (CLR reads carry more inserted than deleted bases): its window widens by a bin per 16 384 bases
     const int ws = which ? sw.s2 : sw.s1, wb = which ? sw.b2 : sw.b1, shift = sw.shift;
     const uint2 *hits = hits_g + (size_t)slot * HIT_CAP;
+    int32_t *wpp = wpp_g + (size_t)slot * HIT_CAP;
     const int32_t nh = sw.n_hits;
-    int32_t ri = 0, rcp = 0, rd = 0, rf = 0, rst = 0;      // ring: lane L holds window hit number e with e % 64 == L
-    int32_t e = 0, best_f = 0, best_st = -1;
+    int32_t ri = 0, rcp = 0, rd = 0, rf = 0, rst = 0, rwp = 0, rwi = 0;      // ring: lane L holds window hit number e with e % 64 == L
+    int32_t e = 0, best_f = 0, best_st = -1, best_wp = -1;
     for (int32_t x0 = 0; x0 < nh; x0 += 64) {
         const int32_t xl = x0 + lane;
         const int32_t hl = ws ? nh - 1 - xl : xl;
@@ -443,7 +458,7 @@ __global__ void __launch_bounds__(64) k_chain(int64_t first, int64_t count, cons
         bool inw = false;
         if (xl < nh && (int)(hv.x >> 31) == ws) {
             const int b = (int)(((int64_t)(int32_t)hv.y - (int32_t)(hv.x & 0x7fffffffu) + n) >> shift);
-            inw = b >= wb - 1 && b <= wb + 2;
+            inw = b >= wb - 1 - ext && b <= wb + 2 + ext;
         }
         for (uint64_t todo = __ballot(inw); todo; todo &= todo - 1) {
             const int jx = __builtin_ctzll(todo);
@@ -454,60 +469,179 @@ __global__ void __launch_bounds__(64) k_chain(int64_t first, int64_t count, cons
             const int32_t dist = (e - 1 - lane) & 63;           // this lane's hit is `dist + 1` window hits back
             const int32_t di = i - ri;
             int32_t dd = d - rd; dd = dd < 0 ? -dd : dd;
-            const bool ok = dist < e && di >= 1 && di <= CHAIN_MAX_GAP && cp > rcp && dd <= 16 + (di >> 4);
-            const int32_t key = ok ? ((rf << 6) | (63 - dist)) : 0;
+            const bool near = dist < e && di >= 1 && di <= BRIDGE_MAX_GAP && cp > rcp;
+            const bool strict = near && di <= CHAIN_MAX_GAP && dd <= 16 + (di >> 4);
+            const bool bridge = near && !strict && dd <= 64 + (di >> 3);
+            const int32_t v = strict ? rf + 1 : (bridge ? rf + 1 - BRIDGE_COST : 0);      // (a hit alone is a chain of 1: only v > 1 links it)
+            const int32_t key = v > 1 ? ((v << 6) | (63 - dist)) : 0;
             const int32_t K = wave_max_nonneg_dpp(key);
-            int32_t f = 1, st = h;
+            int32_t f = 1, st = h, wp = h, wi = i, wprev = -1;
             if (K > 0) {
-                f = (K >> 6) + 1;
+                f = K >> 6;
                 const int32_t src = (e - 1 - (63 - (K & 63))) & 63;
                 st = __builtin_amdgcn_readlane(rst, src);
+                const int32_t pw = __builtin_amdgcn_readlane(rwp, src), pi = __builtin_amdgcn_readlane(rwi, src);
+                if (i - pi >= piece) wprev = pw; else { wp = pw; wi = pi; }
             }
-            if (lane == (e & 63)) { ri = i; rcp = cp; rd = d; rf = f; rst = st; }
-            if (f > best_f) { best_f = f; best_st = st; }
+            if (wp == h && lane == 0) wpp[h] = wprev;           // this hit is a waypoint of its chain: the one before it (-1: it starts the chain)
+            if (lane == (e & 63)) { ri = i; rcp = cp; rd = d; rf = f; rst = st; rwp = wp; rwi = wi; }
+            if (f > best_f) { best_f = f; best_st = st; best_wp = wp; }
             e++;
         }
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // lane 0 reads back below what it wrote to wpp[] above
     if (lane == 0) {
         Anchor a = none;
+        int32_t nw = 0;
         if (best_st >= 0) {
-            // v1.4: the chain's first hit IS the anchor (a cell of the true path): the extension runs forward from it (k_sw) and, on the reversed
-            // read prefix and contig window, backward from it (k_back_prep -> k_sw again)
+            // v1.4: the chain's first hit IS the anchor (a cell of the true path); v1.6: its waypoints, first to last
+            for (int32_t x = best_wp; x >= 0; x = wpp[x]) nw++;
+            int2 *wo = wps + (size_t)(2 * r + which) * MAX_WP;
+            int32_t at = nw;
+            for (int32_t x = best_wp; x >= 0; x = wpp[x]) { at--; if (at < MAX_WP) { const uint2 hv = hits[x]; wo[at] = make_int2((int32_t)(hv.x & 0x7fffffffu), (int32_t)hv.y); } }
             const uint2 hv = hits[best_st];
             a.aligned = 1; a.strand = ws; a.i_a = (int32_t)(hv.x & 0x7fffffffu); a.c_a = (int32_t)hv.y;
         }
         out[r] = a;
+        n_wp[2 * r + which] = nw < MAX_WP ? nw : MAX_WP;      // (more cannot be: they lie `piece` bases apart)
     }
 }
 
-// ---- oriented packed copy of each read (slot = read for the first candidates; the second candidates of the few reads
-// that have one are compacted: slot w -> read ridx[w], own word offsets)
-__global__ void __launch_bounds__(256) k_orient(int64_t first, const uint32_t *__restrict__ read_pk, const int64_t *__restrict__ read_woff, const int32_t *__restrict__ read_len,
-                                                const Anchor *__restrict__ anc, const int32_t *__restrict__ ridx, const int64_t *__restrict__ out_woff, uint32_t *__restrict__ out) {
-    const int64_t sl = first + blockIdx.x;
-    const int64_t r = ridx ? ridx[sl] : sl;
-    const int64_t n = read_len[r];
+// ---- the other orientation of every sequence, once per job: out = reverse complement of the packed sequence, same word offsets (LEN: the length array's type).
+// A read's alignment on strand s reads orientation s; the BACKWARD extension from an anchor is the forward DP on the opposite orientation of both the read and the
+// contig (both complemented: what matches still matches), so no reversed copies are made per run.
+template <class LEN>
+__global__ void __launch_bounds__(256) k_revcomp(const uint32_t *__restrict__ pk, const int64_t *__restrict__ woff, const LEN *__restrict__ len, uint32_t *__restrict__ out) {
+    const int64_t sq = blockIdx.x;
+    const int64_t n = (int64_t)len[sq];
     const int64_t nw = ((n + 15) / 16 + 8 + 1) & ~1LL;
-    const uint32_t *src = read_pk + read_woff[r];
-    uint32_t *dst = out + out_woff[sl];
-    const bool rc = anc[sl].strand != 0;
+    const uint32_t *src = pk + woff[sq];
+    uint32_t *dst = out + woff[sq];
     for (int64_t w = (int64_t)blockIdx.y * 256 + threadIdx.x; w < nw; w += (int64_t)gridDim.y * 256) {
-        uint32_t v = src[w];
-        if (rc) {
-            v = 0;
-            for (int m = 0; m < 16; m++) {
-                int64_t x = w * 16 + m;
-                if (x < n) v |= (3u - base_at(src, n - 1 - x)) << (2 * m);
-            }
+        uint32_t v = 0;
+        for (int m = 0; m < 16; m++) {
+            const int64_t x = w * 16 + m;
+            if (x < n) v |= (3u - base_at(src, n - 1 - x)) << (2 * m);
         }
         dst[w] = v;
     }
 }
 
+// ---- extension pieces as DP slots (v1.6).  A slot is one banded DP: a piece of a candidate's forward extension (from a waypoint to the next: INNER, it has to arrive
+// at the sub-matrix's corner; from the last waypoint on: free), or its backward extension (free, on the opposite orientations).
+struct Slot { int32_t read, flags, qb, tb, nq, nt, cap, ctg; };      // cap: DP steps it may take, a multiple of 64
+constexpr int SLOT_QRC = 1, SLOT_TRC = 2, SLOT_INNER = 4, SLOT_CAND = 8, SLOT_BACK = 16;
+__device__ __forceinline__ int32_t slot_cap(int32_t nq, int32_t nt) { return (nq + nt + 2 + 63) & ~63; }
+
+// the slots of one candidate, in the order [backward][forward 0 .. m]; emit(slot) is called for each
+template <class F>
+__device__ __forceinline__ void cand_slots(const Anchor a, int which, int32_t nw, const int2 *__restrict__ wp, int32_t r, int32_t n, int32_t c, int64_t Lc, F emit) {
+    if (!a.aligned || nw <= 0) return;
+    const int32_t piece = piece_len(n);
+    const int32_t fl = which ? SLOT_CAND : 0;
+    if (a.i_a > 0 && a.c_a > 0) {      // backward: the opposite orientation of the read from n - i_a on, the contig's from Lc - c_a on
+        const int32_t nq = min(a.i_a, piece), nt = (int32_t)min((int64_t)a.c_a, (int64_t)nq + nq / 4 + 64);
+        emit(Slot{r, fl | SLOT_BACK | (a.strand ? 0 : SLOT_QRC) | SLOT_TRC, n - a.i_a, (int32_t)(Lc - a.c_a), nq, nt, slot_cap(nq, nt), c});
+    }
+    for (int32_t k = 0; k < nw; k++) {
+        const int2 o = wp[k];
+        int32_t nq, nt, f2 = fl | (a.strand ? SLOT_QRC : 0);
+        if (k + 1 < nw) { nq = wp[k + 1].x - o.x; nt = wp[k + 1].y - o.y; f2 |= SLOT_INNER; }
+        else { nq = min(n - o.x, 2 * piece); nt = (int32_t)min(Lc - o.y, (int64_t)nq + nq / 4 + 64); }
+        emit(Slot{r, f2, o.x, o.y, nq, nt, slot_cap(nq, nt), c});
+    }
+}
+// per read: how many slots, how many DP steps of capacity
+__global__ void __launch_bounds__(256) k_slot_count(int64_t nr, const Anchor *__restrict__ anc, const Anchor *__restrict__ ancB, const int32_t *__restrict__ n_wp, const int2 *__restrict__ wps,
+                                                    const int32_t *__restrict__ read_len, const int32_t *__restrict__ read_ctg, const int64_t *__restrict__ ctg_len,
+                                                    uint32_t *__restrict__ cnt, uint32_t *__restrict__ capq, uint32_t *__restrict__ n_sec) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    bool second = false;
+    if (r < nr) {
+        uint32_t k = 0, cq = 0;
+        const int32_t n = read_len[r], c = read_ctg[r];
+        const int64_t Lc = ctg_len[c];
+        auto tally = [&](const Slot &sl) { k++; cq += (uint32_t)(sl.cap >> 6); };
+        cand_slots(anc[r], 0, n_wp[2 * r], wps + (size_t)(2 * r) * MAX_WP, (int32_t)r, n, c, Lc, tally);
+        cand_slots(ancB[r], 1, n_wp[2 * r + 1], wps + (size_t)(2 * r + 1) * MAX_WP, (int32_t)r, n, c, Lc, tally);
+        cnt[r] = k; capq[r] = cq;
+        second = ancB[r].aligned != 0;
+    }
+    const uint64_t m = __ballot(second);
+    if (lane_id() == 0 && m) atomicAdd(n_sec, (uint32_t)__popcll(m));
+}
+__global__ void __launch_bounds__(256) k_slot_emit(int64_t r_lo, int64_t r_hi, const Anchor *__restrict__ anc, const Anchor *__restrict__ ancB, const int32_t *__restrict__ n_wp, const int2 *__restrict__ wps,
+                                                   const int32_t *__restrict__ read_len, const int32_t *__restrict__ read_ctg, const int64_t *__restrict__ ctg_len,
+                                                   const uint32_t *__restrict__ slot_base, uint32_t s_lo, Slot *__restrict__ slots) {
+    const int64_t r = r_lo + (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= r_hi) return;
+    const int32_t n = read_len[r], c = read_ctg[r];
+    const int64_t Lc = ctg_len[c];
+    Slot *o = slots + (slot_base[r] - s_lo);
+    auto put = [&](const Slot &sl) { *o++ = sl; };
+    cand_slots(anc[r], 0, n_wp[2 * r], wps + (size_t)(2 * r) * MAX_WP, (int32_t)r, n, c, Lc, put);
+    cand_slots(ancB[r], 1, n_wp[2 * r + 1], wps + (size_t)(2 * r + 1) * MAX_WP, (int32_t)r, n, c, Lc, put);
+}
+
+// ---- the chunk's slots by decreasing capacity (a stable counting sort over cap / 64, 1 024 classes): the lanes of a bit-sliced wave run in lockstep, so a wave should
+// hold slots of one length; and the longest go first, so the launch's tail is short ones.
+constexpr int SORT_CLASSES = 1024;
+__device__ __forceinline__ uint32_t sort_class(int32_t cap) { const uint32_t q = (uint32_t)cap >> 6; return (uint32_t)(SORT_CLASSES - 1) - (q < (uint32_t)(SORT_CLASSES - 1) ? q : (uint32_t)(SORT_CLASSES - 1)); }
+__global__ void __launch_bounds__(256) k_sort_hist(uint32_t ns, uint32_t nblk, const Slot *__restrict__ slots, uint32_t *__restrict__ bh) {
+    __shared__ uint32_t hist[SORT_CLASSES];
+    for (int i = threadIdx.x; i < SORT_CLASSES; i += 256) hist[i] = 0;
+    __syncthreads();
+    const uint32_t x = blockIdx.x * 256 + threadIdx.x;
+    if (x < ns) atomicAdd(&hist[sort_class(slots[x].cap)], 1u);
+    __syncthreads();
+    for (int i = threadIdx.x; i < SORT_CLASSES; i += 256) bh[(size_t)i * nblk + blockIdx.x] = hist[i];
+}
+__global__ void __launch_bounds__(256) k_sort_scatter(uint32_t ns, uint32_t nblk, const Slot *__restrict__ slots, const uint32_t *__restrict__ bh_scan, uint32_t *__restrict__ sorted) {
+    __shared__ uint32_t keys[256];
+    const uint32_t x = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t key = x < ns ? sort_class(slots[x].cap) : 0xffffffffu;
+    keys[threadIdx.x] = key;
+    __syncthreads();
+    if (x >= ns) return;
+    uint32_t rank = 0;
+    for (uint32_t t = 0; t < threadIdx.x; t++) rank += keys[t] == key ? 1u : 0u;
+    sorted[bh_scan[(size_t)key * nblk + blockIdx.x] + rank] = x;
+}
+// which DP kernel takes a slot: the bit-sliced one what spans the band on both sides and fits its step limit, the wave-per-slot one the rest
+__global__ void __launch_bounds__(256) k_route(uint32_t ns, const Slot *__restrict__ slots, const uint32_t *__restrict__ sorted, int32_t swb_max_steps, int32_t use_bits, uint32_t *__restrict__ fits) {
+    const uint32_t x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= ns) return;
+    const Slot sl = slots[sorted[x]];
+    fits[x] = (use_bits && sl.nq >= 64 && sl.nt >= 64 && sl.nq + sl.nt + 2 <= swb_max_steps) ? 1u : 0u;
+}
+// the launch lists: list[0, n_b) = the bit-sliced kernel's slots, list[n_b, ns) the others', both in sorted order; lq[y] = cap / 64 of list[y]; gq[g] = cap / 64 of the
+// first (longest) slot of the g-th group of 64 bit-sliced slots = what every stream of that group's interleaved region gets
+struct PlanTotals { uint64_t n_b, n_groups_q, lq_total, pad_; };
+__global__ void __launch_bounds__(256) k_lists(uint32_t ns, const Slot *__restrict__ slots, const uint32_t *__restrict__ sorted, const uint32_t *__restrict__ fits, const uint32_t *__restrict__ pos_b,
+                                               const uint64_t *__restrict__ n_b_dev, uint32_t *__restrict__ list, uint32_t *__restrict__ lq, uint32_t *__restrict__ gq) {
+    const uint32_t x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= ns) return;
+    const uint32_t n_b = (uint32_t)*n_b_dev;
+    const uint32_t sl = sorted[x], q = (uint32_t)slots[sl].cap >> 6;
+    const uint32_t y = fits[x] ? pos_b[x] : n_b + (x - pos_b[x]);
+    list[y] = sl; lq[y] = q;
+    if (fits[x] && (y & 63u) == 0u) gq[y >> 6] = q;
+}
+// where every slot's masks, move words and op stream go.  Bit-sliced slots: group g's region starts at record 4096 * (sum of gq before g), the x-th stream of the group at
+// + 64 x, its 64-step blocks 4 096 records apart (what a wave writes during 64 steps lies within 64 KB); the others: streams of their own behind all groups.
+__global__ void __launch_bounds__(256) k_plan_final(uint32_t ns, const uint32_t *__restrict__ list, const uint32_t *__restrict__ lq_scan, const uint32_t *__restrict__ gq_scan,
+                                                    const uint64_t *__restrict__ n_b_dev, const uint64_t *__restrict__ gq_total_dev, int64_t *__restrict__ tbo, int64_t *__restrict__ mvo, int32_t *__restrict__ tbs) {
+    const uint32_t y = blockIdx.x * 256 + threadIdx.x;
+    if (y >= ns) return;
+    const uint32_t n_b = (uint32_t)*n_b_dev;
+    const uint32_t sl = list[y];
+    mvo[sl] = (int64_t)lq_scan[y];
+    if (y < n_b) { tbo[sl] = 4096ll * gq_scan[y >> 6] + 64ll * (y & 63u); tbs[sl] = 4096; }
+    else { tbo[sl] = 4096ll * (int64_t)*gq_total_dev + 64ll * ((int64_t)lq_scan[y] - (int64_t)lq_scan[n_b]); tbs[sl] = 64; }
+}
+
 struct DpInfo { int32_t steps, best_t, best_lane, best_score; };
-// segmented trace-back (k_tb_walk<true>, below): segment length in DP steps, overlap, ops buffer per walker, pieces per read
-constexpr int TBS_SEG = 4096, TBS_SEG_SHIFT = 12, TBS_OV = 512, TBS_RAW_WORDS = (TBS_SEG + TBS_OV) / 16 + 2, TBS_MAX_PIECES = 256;
-constexpr int64_t TBS_SINGLE_STEPS = 40960;     // a read with at most this many DP steps of capacity is one walker's work (its serial walk is no longer than the launch anyway)
+struct ReadPath { int32_t ok, strand, i_end, j_end, n_ops, pad_; int64_t steps; };      // a read's joined path (k_join -> k_tb_cigar): its end cell, its ops, the DP steps of all its slots
 
 // wave-wide shifts by one lane (gfx9 DPP wave_shr / wave_shl); vacated lane takes `fill`
 __device__ __forceinline__ int32_t wave_shr1(int32_t v, int32_t fill) {   // lane k <- lane k-1
@@ -590,12 +724,14 @@ __device__ __forceinline__ void scalar_store16(void *base, uint32_t byte_off, ui
         Hn = max(hd, m - gap);                                                                             \
         const uint64_t dmask = __ballot(Hn == hd);                                                         \
         if (STORE) { const uint32_t t_ = (uint32_t)__builtin_amdgcn_readfirstlane(t); scalar_store16(tbr, ((t_ >> 6) * (uint32_t)stride + (t_ & 63u)) * 16u, dmask, gmask); } \
-        bool upd = Hn > bs;                                                                                \
+        bool upd;                                                                                          \
+        int32_t val;                                                                                       \
         {                                                                                                  \
             const int32_t ci = i0 + lane, cj = t - ci;                                                     \
-            upd = upd && ci >= 0 && ci < nq && cj >= 0 && cj < nt && (ci == nq - 1 || cj == nt - 1);       \
+            val = inner ? Hn - gap * ((nq - 1 - ci) + (nt - 1 - cj)) : Hn;                                 \
+            upd = val > bs && ci >= 0 && ci < nq && cj >= 0 && cj < nt && (ci == nq - 1 || cj == nt - 1);  \
         }                                                                                                  \
-        bs = upd ? Hn : bs;                                                                                \
+        bs = upd ? val : bs;                                                                               \
         bt = upd ? t : bt;                                                                                 \
         mvacc |= (uint64_t)(down ? 1 : 0) << (t & 63);                                                     \
         const int32_t top = __builtin_amdgcn_readlane(Hn, 0), bot = __builtin_amdgcn_readlane(Hn, 63);     \
@@ -610,17 +746,7 @@ __device__ __forceinline__ void scalar_store16(void *base, uint32_t byte_off, ui
 #define SW_FLUSH(PARTIAL)                                                                                  \
     {                                                                                                      \
         if ((PARTIAL) || ((t - 1) & 63) == 63) {                                                           \
-            uint32_t glane = 32u;                                                                          \
-            if ((t & (TBS_SEG - 1)) == 0) {   /* step t-1 tops a trace-back segment: the lane of its best H is where that segment's walker starts */ \
-                asm volatile("" ::: "memory");   /* keeps the compiler from running this reduction on every flush and selecting afterwards (it did: +0.7 VALU per step) */ \
-                int32_t hv = H, hl = lane;                                                                 \
-                _Pragma("unroll") for (int d_ = 32; d_ >= 1; d_ >>= 1) {                                   \
-                    const int32_t ov_ = __shfl_xor(hv, d_, 64), ol_ = __shfl_xor(hl, d_, 64);              \
-                    if (ov_ > hv || (ov_ == hv && ol_ < hl)) { hv = ov_; hl = ol_; }                       \
-                }                                                                                          \
-                glane = (uint32_t)hl;                                                                      \
-            }                                                                                              \
-            if (lane == 0) mvr[(t - 1) >> 6] = make_ulonglong2(mvacc, (uint64_t)(uint32_t)(i0 - __popcll(mvacc)) | ((uint64_t)glane << 32)); \
+            if (lane == 0) mvr[(t - 1) >> 6] = make_ulonglong2(mvacc, (uint64_t)(uint32_t)(i0 - __popcll(mvacc))); \
             mvacc = 0;                                                                                     \
         }                                                                                                  \
     }
@@ -749,51 +875,28 @@ __device__ __forceinline__ uint64_t base_window(const uint32_t *__restrict__ pk,
 }
 
 template <bool STORE>
-__global__ void __launch_bounds__(64) k_sw(int64_t first, int64_t count, const int32_t *__restrict__ ridx, const uint32_t *__restrict__ read_ori,
-                                            const int64_t *__restrict__ ori_woff, const int32_t *__restrict__ read_len, const int32_t *__restrict__ read_ctg,
-                                            const uint32_t *__restrict__ ctg_pk, const int64_t *__restrict__ ctg_woff, const int64_t *__restrict__ ctg_len,
-                                            const Anchor *__restrict__ anc, const int64_t *__restrict__ tb_off, uint2 *__restrict__ tb, ulonglong2 *__restrict__ mvw,
-                                            int match, int mismatch, int gap, DpInfo *__restrict__ info, int64_t *__restrict__ tbo, int64_t *__restrict__ mvo,
-                                            const int32_t *__restrict__ order, int32_t prio_len, const int64_t *__restrict__ m_off, const int64_t *__restrict__ mv_off,
-                                            const uint8_t *__restrict__ skip, int32_t m_stride, int32_t *__restrict__ tbs) {
+__global__ void __launch_bounds__(64) k_sw(uint32_t ns, const uint64_t *__restrict__ n_b_dev, const uint32_t *__restrict__ list, const Slot *__restrict__ slots,
+                                            const uint32_t *__restrict__ read_pk, const uint32_t *__restrict__ read_rc, const int64_t *__restrict__ read_woff,
+                                            const uint32_t *__restrict__ ctg_pk, const uint32_t *__restrict__ ctg_rc, const int64_t *__restrict__ ctg_woff,
+                                            const int64_t *__restrict__ tbo, const int64_t *__restrict__ mvo, const int32_t *__restrict__ tbs, uint2 *__restrict__ tb, ulonglong2 *__restrict__ mvw,
+                                            int match, int mismatch, int gap, DpInfo *__restrict__ info) {
     const int lane = lane_id();
-    // wave-uniform on purpose: everything indexed by the read then lives in SGPRs / scalar loads
-    const int64_t wq = (int64_t)blockIdx.x;   // one wave per workgroup: a finished read frees its slot at once
-    if (wq >= count) return;
-    // workgroups start in blockIdx order, so `order` (slots by decreasing read length) makes the launch longest-first: the last
-    // waves to start are the shortest, and the tail of the grid is short however uneven the read lengths are
-    const int64_t wv = order ? (int64_t)order[wq] : wq;
-    // slot = candidate: the read itself for first candidates, an entry of the compacted list for second ones
-    const int64_t sl = first + wv;
-    if (skip && skip[sl]) return;              // the bit-sliced kernel ran this slot's extension
-    const int64_t r = ridx ? ridx[sl] : sl;
-    const Anchor a = anc[sl];
-    // where the slot's masks and move words go in the chunk's buffers: in slot order, or (m_off) where the job planned them -- in launch order, so that the
-    // streams of the reads that the bit-sliced kernel runs side by side in a wave lie side by side
-    const int64_t toff = m_off ? m_off[sl] : tb_off[sl] - tb_off[first], moff = m_off ? mv_off[sl] : (toff >> 6) + wv;
+    // wave-uniform on purpose: everything indexed by the slot then lives in SGPRs / scalar loads.  One wave per workgroup: a finished slot frees its place at once.
+    // This kernel's slots are the launch list behind the bit-sliced kernel's (list[n_b ..)): in sorted order, longest first.
+    const uint32_t y = (uint32_t)*n_b_dev + blockIdx.x;
+    if (y >= ns) return;
+    const uint32_t sl = list[y];
+    const Slot S = slots[sl];
+    // the records of steps 64 b .. 64 b + 63 of a slot start at record b * stride of its stream (64: a stream of its own)
+    const int64_t toff = tbo[sl], moff = mvo[sl];
+    const int32_t stride = tbs[sl];
     ulonglong2 *tbr = (ulonglong2 *)tb + toff;   // per step: {D mask, G mask} over the 64 band lanes
     ulonglong2 *mvr = mvw + moff;                // per 64 steps: {move bits, i0 before the chunk}
-    // the records of steps 64 b .. 64 b + 63 of a slot start at record b * stride of its stream: 64 for a stream of its own; planned streams (m_off) are interleaved
-    // block by block with the 63 others of their launch group (stride 64 x 64), so that what a wave of the bit-sliced kernel writes at a time lies within 64 KB
-    const int32_t stride = m_off ? m_stride : 64;
-    if (tbo && lane == 0) { tbo[sl] = toff; mvo[sl] = moff; if (tbs) tbs[sl] = stride; }   // element offsets into the chunk's buffers
-    if (!a.aligned) { if (lane == 0) info[sl] = DpInfo{0, -1, 0, NEGV}; return; }
-    const int c_idx = read_ctg[r];
-    const int64_t n = read_len[r];
-    // a read several times the usual length is a serial chain several times as long: its wave takes the SIMD's issue slots ahead of the
-    // seven waves it shares them with (they lose little, it finishes up to 8 x sooner), so the launch does not end on one long read
-    if (prio_len > 0) {
-        if (n >= 4 * (int64_t)prio_len) __builtin_amdgcn_s_setprio(3);
-        else if (n >= 3 * (int64_t)prio_len) __builtin_amdgcn_s_setprio(2);
-        else if (n >= 2 * (int64_t)prio_len) __builtin_amdgcn_s_setprio(1);
-    }
-    const int32_t nq = (int32_t)(n - a.i_a);
-    int64_t ntl = ctg_len[c_idx] - a.c_a;
-    if (ntl > (int64_t)nq + nq / 4 + 64) ntl = (int64_t)nq + nq / 4 + 64;
-    const int32_t nt = (int32_t)ntl;
-    const uint32_t *qpk = read_ori + ori_woff[sl];
-    const uint32_t *tpk = ctg_pk + ctg_woff[c_idx];
-    const int64_t qb = a.i_a, tbase = a.c_a;
+    const int32_t nq = S.nq, nt = S.nt;
+    const bool inner = (S.flags & SLOT_INNER) != 0;      // v1.6: the extension has to arrive at the sub-matrix's corner -- a border cell is valued H - gap x (its distance to the corner)
+    const uint32_t *qpk = ((S.flags & SLOT_QRC) ? read_rc : read_pk) + read_woff[S.read];
+    const uint32_t *tpk = ((S.flags & SLOT_TRC) ? ctg_rc : ctg_pk) + ctg_woff[S.ctg];
+    const int64_t qb = S.qb, tbase = S.tb;
     const int32_t max_steps = nq + nt + 2;
 
     // state before step 0 (biased): H(-1), and X = H(-2) in the lane layout it was computed in
@@ -997,7 +1100,7 @@ struct SwbLaneT {                  // one extension's state (a lane's registers)
 // there is nothing to validate, no terminal candidate and no end; lanes whose extension is over run along on their stale state (nothing of theirs is stored).
 // CHECKED = true: validity of the bases near the ends, terminal candidates, the end of the extension.
 template <bool CHECKED, class LANE>
-__device__ __forceinline__ void swb_step(LANE &L, const int32_t t, ulonglong2 &rec, const int32_t nq, const int32_t nt, const int32_t max_steps, bool &active,
+__device__ __forceinline__ void swb_step(LANE &L, const int32_t t, ulonglong2 &rec, const int32_t nq, const int32_t nt, const int32_t max_steps, const bool inner, bool &active,
                                          bool &row_on, bool &col_on, int32_t &Hrow, int32_t &Hcol, int32_t &best, int32_t &bt, int32_t &bl, int32_t &steps) {
     using namespace swb;
     const uint32_t sd = L.down, sr = 1u - sd;
@@ -1037,8 +1140,9 @@ __device__ __forceinline__ void swb_step(LANE &L, const int32_t t, ulonglong2 &r
             if (col_start) Hcol = S0; else if (col_on && kc_in) Hcol += 2 * value_at(L.Q, kc & 63) - 3;
             if (row_start) Hrow = S0 + 2 * L.E2; else if (row_on && kr_in) Hrow += 2 * value_at(L.P, kr & 63) - 3;
             col_on = col_on || col_start; row_on = row_on || row_start;
-            { const int32_t i = L.i0 + kc; if (col_on && kc_in && i >= 0 && i < nq && Hcol > best) { best = Hcol; bt = t; bl = kc; } }
-            { const int32_t jj = t - (nq - 1); if (row_on && kr_in && jj >= 0 && jj < nt && Hrow > best) { best = Hrow; bt = t; bl = kr; } }
+            // (v1.6, inner pieces: a border cell is valued by the global alignment through it -- its score minus the gap moves from it to the sub-matrix's corner)
+            { const int32_t i = L.i0 + kc, vc = inner ? Hcol - 3 * (nq - 1 - i) : Hcol; if (col_on && kc_in && i >= 0 && i < nq && vc > best) { best = vc; bt = t; bl = kc; } }
+            { const int32_t jj = t - (nq - 1), vr = inner ? Hrow - 3 * (nt - 1 - jj) : Hrow; if (row_on && kr_in && jj >= 0 && jj < nt && vr > best) { best = vr; bt = t; bl = kr; } }
             if (L.i0 > nq - 1 || t - (L.i0 + 63) > nt - 1 || t + 1 >= max_steps) { active = false; steps = t + 1; }
         }
     }
@@ -1050,44 +1154,28 @@ constexpr int SWB_WPG = 1;        // waves per workgroup of k_swb (four measured
 constexpr int SWB_GROUP = 8;      // steps whose mask records leave together (64 B per lane)
 // RING: the base streams through rings in LDS (LaneStreamL) or straight from HBM (LaneStream; FZP_SWB_NO_RING, for comparisons)
 template <bool RING>
-__global__ void __launch_bounds__(256) k_swb(int64_t first, int64_t count, const int32_t *__restrict__ list, const int32_t *__restrict__ ridx, const uint32_t *__restrict__ read_ori,
-                                             const int64_t *__restrict__ ori_woff, const int32_t *__restrict__ read_len, const int32_t *__restrict__ read_ctg,
-                                             const uint32_t *__restrict__ ctg_pk, const int64_t *__restrict__ ctg_woff, const int64_t *__restrict__ ctg_len,
-                                             const Anchor *__restrict__ anc, const int64_t *__restrict__ tb_off, uint2 *__restrict__ tb, ulonglong2 *__restrict__ mvw,
-                                             DpInfo *__restrict__ info, int64_t *__restrict__ tbo, int64_t *__restrict__ mvo, const int64_t *__restrict__ m_off, const int64_t *__restrict__ mv_off, uint8_t *__restrict__ handled, int32_t steps_limit, int dbg,
-                                             int32_t m_stride, int32_t *__restrict__ tbs, uint32_t *__restrict__ start_flag, uint32_t start_val) {
-    if (start_flag && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(start_flag, start_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);      // "on the chip" (k_wait_started)
+__global__ void __launch_bounds__(256) k_swb(const uint64_t *__restrict__ n_b_dev, const uint32_t *__restrict__ list, const Slot *__restrict__ slots,
+                                             const uint32_t *__restrict__ read_pk, const uint32_t *__restrict__ read_rc, const int64_t *__restrict__ read_woff,
+                                             const uint32_t *__restrict__ ctg_pk, const uint32_t *__restrict__ ctg_rc, const int64_t *__restrict__ ctg_woff,
+                                             const int64_t *__restrict__ tbo, const int64_t *__restrict__ mvo, uint2 *__restrict__ tb, ulonglong2 *__restrict__ mvw,
+                                             DpInfo *__restrict__ info, int dbg) {
     using namespace swb;
     // dbg: MEASUREMENT switches (FZP_SWB_DBG, tools/runs/swb_probe.py; the results of such a run are not used): bit 0 = no mask stores, bit 1 = no stream refills
     // (workgroups of one wave: four-wave workgroups, which suit k_swb2, put 256 mask streams on a CU and cost this kernel 10 % -- address translation again)
     const int64_t li = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t wv = li < count ? list[li] : -1;       // the lane's slot in the chunk, -1: none
-    bool active = wv >= 0;
-    const int64_t sl = first + (active ? wv : 0);
-    const int64_t r = ridx ? ridx[sl] : sl;
-    const Anchor a = anc[sl];
-    // the lanes of a wave stand side by side in the launch list, and so do their mask streams (m_off: planned in launch order): 64 streams scattered over the
-    // buffer cost twice the time in address translation alone
-    const int64_t toff = m_off ? m_off[sl] : tb_off[sl] - tb_off[first], moff = m_off ? mv_off[sl] : (toff >> 6) + (active ? wv : 0);
-    ulonglong2 *tbr = (ulonglong2 *)tb + toff;
-    ulonglong2 *mvr = mvw + moff;
-    const int c_idx = read_ctg[r];
-    const int64_t n = read_len[r];
-    const int32_t nq = (int32_t)(n - a.i_a);
-    int64_t ntl = ctg_len[c_idx] - a.c_a;
-    if (ntl > (int64_t)nq + nq / 4 + 64) ntl = (int64_t)nq + nq / 4 + 64;
-    const int32_t nt = (int32_t)ntl;
-    if (handled) {   // the caller did not sort the slots by kernel: this one takes what fits it and says so, k_sw runs the rest
-        const bool mine = active && (!a.aligned || (nq >= 64 && nt >= 64 && nq + nt + 2 <= steps_limit));
-        if (active) handled[sl] = mine ? 1 : 0;
-        active = mine;
-    }
-    const int32_t stride = m_off ? m_stride : 64;        // records from one 64-step block of this stream to the next (k_sw)
-    if (active && tbo) { tbo[sl] = toff; mvo[sl] = moff; if (tbs) tbs[sl] = stride; }
-    if (active && !a.aligned) { info[sl] = DpInfo{0, -1, 0, NEGV}; active = false; }
-    const uint32_t *qpk = read_ori + ori_woff[sl];
-    const uint32_t *tpk = ctg_pk + ctg_woff[c_idx];
-    const int64_t qb = a.i_a, tbase = a.c_a;
+    bool active = li < (int64_t)*n_b_dev;
+    if (!__ballot(active)) return;
+    const uint32_t sl = list[active ? li : 0];      // the lane's slot; the lanes of a wave stand side by side in the launch list, and so do their mask streams
+    const Slot S = slots[sl];
+    // (64 streams scattered over the buffer cost twice the time in address translation alone: the plan interleaves a wave's streams block by block, stride 4 096 records)
+    ulonglong2 *tbr = (ulonglong2 *)tb + tbo[sl];
+    ulonglong2 *mvr = mvw + mvo[sl];
+    const int32_t nq = S.nq, nt = S.nt;
+    const bool inner = (S.flags & SLOT_INNER) != 0;
+    constexpr int32_t stride = 64 * 64;                  // records from one 64-step block of this stream to the next
+    const uint32_t *qpk = ((S.flags & SLOT_QRC) ? read_rc : read_pk) + read_woff[S.read];
+    const uint32_t *tpk = ((S.flags & SLOT_TRC) ? ctg_rc : ctg_pk) + ctg_woff[S.ctg];
+    const int64_t qb = S.qb, tbase = S.tb;
     const int32_t max_steps = nq + nt + 2;
     SwbLaneT<typename std::conditional<RING, LaneStreamL, LaneStream>::type> L;
     // step -1: the anti-diagonal i + j = -1 of the virtual border, lane k = cell (k - 33, 32 - k): Pv = 0 where j >= 0 (k <= 32) else 4, Qv = 0 where i >= 0 (k >= 33) else 4
@@ -1121,10 +1209,10 @@ __global__ void __launch_bounds__(256) k_swb(int64_t first, int64_t count, const
             ulonglong2 rec[SWB_GROUP];
             if (interior) {
 #pragma unroll
-                for (int s8 = 0; s8 < SWB_GROUP; s8++) { swb_step<false>(L, t, rec[s8], nq, nt, max_steps, active, row_on, col_on, Hrow, Hcol, best, bt, bl, steps); t++; }
+                for (int s8 = 0; s8 < SWB_GROUP; s8++) { swb_step<false>(L, t, rec[s8], nq, nt, max_steps, inner, active, row_on, col_on, Hrow, Hcol, best, bt, bl, steps); t++; }
             } else {
 #pragma unroll
-                for (int s8 = 0; s8 < SWB_GROUP; s8++) { swb_step<true>(L, t, rec[s8], nq, nt, max_steps, active, row_on, col_on, Hrow, Hcol, best, bt, bl, steps); t++; }
+                for (int s8 = 0; s8 < SWB_GROUP; s8++) { swb_step<true>(L, t, rec[s8], nq, nt, max_steps, inner, active, row_on, col_on, Hrow, Hcol, best, bt, bl, steps); t++; }
             }
             // the streams top up every 16 steps, and they do it HERE, ahead of a group's stores: taking the word loaded 16 steps ago means waiting on the vector-memory
             // counter, which also counts the mask stores -- at this point the youngest of those are 8 steps old and done, right behind a group they would be in flight
@@ -1135,28 +1223,10 @@ __global__ void __launch_bounds__(256) k_swb(int64_t first, int64_t count, const
             }
         }
         if (blk_active) {
-            uint32_t glane = 32u;
-            if ((t & (TBS_SEG - 1)) == 0 && active) {      // step t-1 tops a trace-back segment: the lane of its best score is where that segment's walker starts
-                int32_t run = 0, bestv = 0;
-                glane = 0u;
-                for (int k = 0; k < 63; k++) {            // score(lane k+1) - score(lane k) = 2 (Qv[k+1] - Pv[k])
-                    run += value_at(L.Q, k + 1) - value_at(L.P, k);
-                    if (run > bestv) { bestv = run; glane = (uint32_t)(k + 1); }
-                }
-            }
-            mvr[(t - 1) >> 6] = make_ulonglong2(L.mvacc, (uint64_t)(uint32_t)i0_blk | ((uint64_t)glane << 32));
+            mvr[(t - 1) >> 6] = make_ulonglong2(L.mvacc, (uint64_t)(uint32_t)i0_blk);
             if (!active) info[sl] = DpInfo{steps, bt, bl, bt >= 0 ? best : NEGV};
         }
     }
-}
-
-// the two DP kernels of a launch run side by side, and it matters which gets onto the chip first: with the bit-sliced kernel's few hundred waves placed first (one to
-// a SIMD, spread over the CUs) and the wave-per-read kernel's thousands filling in around them the pair took 16.5 ms on reads of real shape, the other way round 22 ms,
-// left to race one or the other.  So the wave-per-read kernel's stream holds this one-thread kernel first, which returns when the bit-sliced kernel's first workgroup has
-// said it runs (or after 5 million ticks of the 100 MHz counter, whatever happened: a bound, not a wait anybody should see).
-__global__ void k_wait_started(const uint32_t *flag, uint32_t val) {
-    const uint64_t t0 = __builtin_readcyclecounter();
-    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < val && __builtin_readcyclecounter() - t0 < 5000000ull) __builtin_amdgcn_s_sleep(16);
 }
 
 // ---- the same DP with the band split over a PAIR of lanes (fzp_swb_core.h, Half): 32 reads per wave, half the instructions per step on a wave's
@@ -1174,7 +1244,7 @@ struct SwbPair {
 };
 
 template <bool CHECKED>
-__device__ __forceinline__ void swb2_step(SwbPair &L, const uint32_t is_hi, const int32_t t, uint2 &rec, const int32_t nq, const int32_t nt, const int32_t max_steps, bool &active,
+__device__ __forceinline__ void swb2_step(SwbPair &L, const uint32_t is_hi, const int32_t t, uint2 &rec, const int32_t nq, const int32_t nt, const int32_t max_steps, const bool inner, bool &active,
                                           bool &row_on, bool &col_on, int32_t &Hrow, int32_t &Hcol, int32_t &best, int32_t &bt, int32_t &bl, int32_t &steps) {
     using namespace swb;
     const uint32_t sd = L.down, sr = 1u - sd;
@@ -1215,8 +1285,8 @@ __device__ __forceinline__ void swb2_step(SwbPair &L, const uint32_t is_hi, cons
             if (col_start) Hcol = S0; else if (col_on && kc_in) Hcol += 2 * pq - 3;
             if (row_start) Hrow = S0 + 2 * L.E2; else if (row_on && kr_in) Hrow += 2 * pp - 3;
             col_on = col_on || col_start; row_on = row_on || row_start;
-            { const int32_t i = L.i0 + kc; if (col_on && kc_in && i >= 0 && i < nq && Hcol > best) { best = Hcol; bt = t; bl = kc; } }
-            { const int32_t jj = t - (nq - 1); if (row_on && kr_in && jj >= 0 && jj < nt && Hrow > best) { best = Hrow; bt = t; bl = kr; } }
+            { const int32_t i = L.i0 + kc, vc = inner ? Hcol - 3 * (nq - 1 - i) : Hcol; if (col_on && kc_in && i >= 0 && i < nq && vc > best) { best = vc; bt = t; bl = kc; } }
+            { const int32_t jj = t - (nq - 1), vr = inner ? Hrow - 3 * (nt - 1 - jj) : Hrow; if (row_on && kr_in && jj >= 0 && jj < nt && vr > best) { best = vr; bt = t; bl = kr; } }
             if (L.i0 > nq - 1 || t - (L.i0 + 63) > nt - 1 || t + 1 >= max_steps) { active = false; steps = t + 1; }
         }
     }
@@ -1224,44 +1294,29 @@ __device__ __forceinline__ void swb2_step(SwbPair &L, const uint32_t is_hi, cons
     L.down = (CHECKED && (t + 1) < 64) ? (uint32_t)(((t + 1) & 1) == 0) : (uint32_t)(L.E2 >= 0);
 }
 
-__global__ void __launch_bounds__(256) k_swb2(int64_t first, int64_t count, const int32_t *__restrict__ list, const int32_t *__restrict__ ridx, const uint32_t *__restrict__ read_ori,
-                                              const int64_t *__restrict__ ori_woff, const int32_t *__restrict__ read_len, const int32_t *__restrict__ read_ctg,
-                                              const uint32_t *__restrict__ ctg_pk, const int64_t *__restrict__ ctg_woff, const int64_t *__restrict__ ctg_len,
-                                              const Anchor *__restrict__ anc, const int64_t *__restrict__ tb_off, uint2 *__restrict__ tb, ulonglong2 *__restrict__ mvw,
-                                              DpInfo *__restrict__ info, int64_t *__restrict__ tbo, int64_t *__restrict__ mvo, const int64_t *__restrict__ m_off, const int64_t *__restrict__ mv_off,
-                                              uint8_t *__restrict__ handled, int32_t steps_limit, int32_t m_stride, int32_t *__restrict__ tbs, uint32_t *__restrict__ start_flag, uint32_t start_val) {
+__global__ void __launch_bounds__(256) k_swb2(const uint64_t *__restrict__ n_b_dev, const uint32_t *__restrict__ list, const Slot *__restrict__ slots,
+                                              const uint32_t *__restrict__ read_pk, const uint32_t *__restrict__ read_rc, const int64_t *__restrict__ read_woff,
+                                              const uint32_t *__restrict__ ctg_pk, const uint32_t *__restrict__ ctg_rc, const int64_t *__restrict__ ctg_woff,
+                                              const int64_t *__restrict__ tbo, const int64_t *__restrict__ mvo, uint2 *__restrict__ tb, ulonglong2 *__restrict__ mvw,
+                                              DpInfo *__restrict__ info) {
     using namespace swb;
-    if (start_flag && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(start_flag, start_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     const uint32_t is_hi = threadIdx.x & 1u;
     const bool lo = is_hi == 0u;
     // workgroups of four waves -- independent of each other, no LDS, no barrier: a workgroup's waves are spread over its CU's four SIMDs, single-wave workgroups are not
     // (625 of them on 256 CUs ran two to a SIMD here and there -- 12.2 ms instead of 7.4 -- and a SIMD shared by two of these waves runs each at little more than half speed)
     const int64_t li = (int64_t)blockIdx.x * (blockDim.x >> 1) + (threadIdx.x >> 1);
-    const int64_t wv = li < count ? list[li] : -1;       // the pair's slot in the chunk, -1: none
-    bool active = wv >= 0;
-    const int64_t sl = first + (active ? wv : 0);
-    const int64_t r = ridx ? ridx[sl] : sl;
-    const Anchor a = anc[sl];
-    const int64_t toff = m_off ? m_off[sl] : tb_off[sl] - tb_off[first], moff = m_off ? mv_off[sl] : (toff >> 6) + (active ? wv : 0);
-    uint2 *tbr = tb + 2 * toff + is_hi;                  // per step 16 B {D, G}: this lane's 8 of them
-    ulonglong2 *mvr = mvw + moff;
-    const int c_idx = read_ctg[r];
-    const int64_t n = read_len[r];
-    const int32_t nq = (int32_t)(n - a.i_a);
-    int64_t ntl = ctg_len[c_idx] - a.c_a;
-    if (ntl > (int64_t)nq + nq / 4 + 64) ntl = (int64_t)nq + nq / 4 + 64;
-    const int32_t nt = (int32_t)ntl;
-    if (handled) {   // the caller did not sort the slots by kernel: this one takes what fits it and says so, k_sw runs the rest
-        const bool mine = active && (!a.aligned || (nq >= 64 && nt >= 64 && nq + nt + 2 <= steps_limit));
-        if (active && lo) handled[sl] = mine ? 1 : 0;
-        active = mine;
-    }
-    const int32_t stride = m_off ? m_stride : 64;
-    if (active && tbo && lo) { tbo[sl] = toff; mvo[sl] = moff; if (tbs) tbs[sl] = stride; }
-    if (active && !a.aligned) { if (lo) info[sl] = DpInfo{0, -1, 0, NEGV}; active = false; }
-    const uint32_t *qpk = read_ori + ori_woff[sl];
-    const uint32_t *tpk = ctg_pk + ctg_woff[c_idx];
-    const int64_t qb = a.i_a, tbase = a.c_a;
+    bool active = li < (int64_t)*n_b_dev;
+    if (!__ballot(active)) return;
+    const uint32_t sl = list[active ? li : 0];      // the pair's slot
+    const Slot S = slots[sl];
+    uint2 *tbr = tb + 2 * tbo[sl] + is_hi;                // per step 16 B {D, G}: this lane's 8 of them
+    ulonglong2 *mvr = mvw + mvo[sl];
+    const int32_t nq = S.nq, nt = S.nt;
+    const bool inner = (S.flags & SLOT_INNER) != 0;
+    constexpr int32_t stride = 64 * 64;
+    const uint32_t *qpk = ((S.flags & SLOT_QRC) ? read_rc : read_pk) + read_woff[S.read];
+    const uint32_t *tpk = ((S.flags & SLOT_TRC) ? ctg_rc : ctg_pk) + ctg_woff[S.ctg];
+    const int64_t qb = S.qb, tbase = S.tb;
     const int32_t max_steps = nq + nt + 2;
     SwbPair L;
     // step -1 (see k_swb): P = 4 on cells >= 33, Q = 4 on cells <= 32; the read's bases 0..30 on cells 33..63, the contig's 32..0 on cells 0..32
@@ -1293,10 +1348,10 @@ __global__ void __launch_bounds__(256) k_swb2(int64_t first, int64_t count, cons
             uint2 rec[8];
             if (interior) {
 #pragma unroll
-                for (int s8 = 0; s8 < 8; s8++) { swb2_step<false>(L, is_hi, t, rec[s8], nq, nt, max_steps, active, row_on, col_on, Hrow, Hcol, best, bt, bl, steps); t++; }
+                for (int s8 = 0; s8 < 8; s8++) { swb2_step<false>(L, is_hi, t, rec[s8], nq, nt, max_steps, inner, active, row_on, col_on, Hrow, Hcol, best, bt, bl, steps); t++; }
             } else {
 #pragma unroll
-                for (int s8 = 0; s8 < 8; s8++) { swb2_step<true>(L, is_hi, t, rec[s8], nq, nt, max_steps, active, row_on, col_on, Hrow, Hcol, best, bt, bl, steps); t++; }
+                for (int s8 = 0; s8 < 8; s8++) { swb2_step<true>(L, is_hi, t, rec[s8], nq, nt, max_steps, inner, active, row_on, col_on, Hrow, Hcol, best, bt, bl, steps); t++; }
             }
             if (g8 & 1) L.ss.refill();      // (ahead of the stores: see k_swb)
             if (grp_active) {
@@ -1304,118 +1359,63 @@ __global__ void __launch_bounds__(256) k_swb2(int64_t first, int64_t count, cons
                 for (int s8 = 0; s8 < 8; s8++) tbr[2 * ((int64_t)((t - 8) >> 6) * stride + ((t - 8) & 63) + s8)] = rec[s8];
             }
         }
-        if (blk_active) {
-            uint32_t glane = 32u;
-            if ((t & (TBS_SEG - 1)) == 0 && active) {      // step t-1 tops a trace-back segment: the lane of its best score is where that segment's walker starts
-                // the whole band's planes, in the low lane's view (the high lane's result is not used): P = its A | the partner's B turned round, Q = its B | the partner's A
-                const Planes P = {(uint64_t)L.h.A.v0 | ((uint64_t)__brev(pair_swap(L.h.B.v0)) << 32), (uint64_t)L.h.A.v1 | ((uint64_t)__brev(pair_swap(L.h.B.v1)) << 32),
-                                  (uint64_t)L.h.A.v2 | ((uint64_t)__brev(pair_swap(L.h.B.v2)) << 32)};
-                const Planes Q = {(uint64_t)L.h.B.v0 | ((uint64_t)__brev(pair_swap(L.h.A.v0)) << 32), (uint64_t)L.h.B.v1 | ((uint64_t)__brev(pair_swap(L.h.A.v1)) << 32),
-                                  (uint64_t)L.h.B.v2 | ((uint64_t)__brev(pair_swap(L.h.A.v2)) << 32)};
-                int32_t run = 0, bestv = 0;
-                glane = 0u;
-                for (int k = 0; k < 63; k++) {            // score(lane k+1) - score(lane k) = 2 (Qv[k+1] - Pv[k])
-                    run += value_at(Q, k + 1) - value_at(P, k);
-                    if (run > bestv) { bestv = run; glane = (uint32_t)(k + 1); }
-                }
-            }
-            if (lo) {
-                mvr[(t - 1) >> 6] = make_ulonglong2(L.mvacc, (uint64_t)(uint32_t)i0_blk | ((uint64_t)glane << 32));
-                if (!active) info[sl] = DpInfo{steps, bt, bl, bt >= 0 ? best : NEGV};
-            }
+        if (blk_active && lo) {
+            mvr[(t - 1) >> 6] = make_ulonglong2(L.mvacc, (uint64_t)(uint32_t)i0_blk);
+            if (!active) info[sl] = DpInfo{steps, bt, bl, bt >= 0 ? best : NEGV};
         }
     }
 }
 
-// ---- trace-back, part 1: the walk.  One lane per read, 16 reads per wave.
+// ---- trace-back, part 1: the walk.  One lane per slot, 16 slots per wave.
 //
-// The walk from the best cell back to the anchor is sequential per read, so a lane owns a read; what the
-// kernel has to do is keep that serial chain short and never make it wait on memory.
+// The walk from a piece's terminal back to its origin is sequential, so a lane owns a slot; what the
+// kernel has to do is keep that serial chain short and never make it wait on memory.  (v1.6: a read is walked piece by piece -- every piece its own
+// walker, a few thousand steps each -- where v1.5 cut a read's one long walk into speculative segments and stitched them.)
 //   * masks are consumed in 64-step chunks (aligned to 64, like the move words).  A step's masks are 128 bits but
 //     the path only ever looks at band lanes near its own, so a staged chunk keeps, per step, the 32 bits of D
 //     and of G starting at band lane `sh` = clamp(k - 16, 0, 32): 8 B/step, 512 B/chunk, one chunk buffer per
-//     read in LDS.  While the lanes walk chunk c, the 16 B/step records of chunk c-1 are already in flight to
-//     registers (one coalesced 1 KB load per read); they are cut down and parked in LDS when the walk of
-//     chunk c is over.  Small LDS footprint = every read of a 40 000-read launch is resident at once.  A lane whose path left the staged 32 lanes (or whose prefetch was for the wrong
+//     slot in LDS.  While the lanes walk chunk c, the 16 B/step records of chunk c-1 are already in flight to
+//     registers (one coalesced 1 KB load per slot); they are cut down and parked in LDS when the walk of
+//     chunk c is over.  Small LDS footprint = every walker of a launch is resident at once.  A lane whose path left the staged 32 lanes (or whose prefetch was for the wrong
 //     chunk) takes a synchronous reload; that is rare.
 //   * per step: one LDS read, ~25 VALU ops, no branches.  The moves come from a 64-bit shift register (top bit =
 //     move of the step before the current one); the operation of the step (M / I / D) goes into a 2-bit stream,
 //     16 ops per word, flushed to HBM when full.  Run-length encoding is k_tb_cigar's job, off this chain.
 // HBM traffic: the 16 B/step masks are read once.
-constexpr int TBW_STRIDE = 512 + 8;              // bytes per read: one 64-step chunk of {D bits, G bits}; +8 staggers LDS banks
-constexpr int TBW_RPW = 16;                      // reads walked per wave
+constexpr int TBW_STRIDE = 512 + 8;              // bytes per slot: one 64-step chunk of {D bits, G bits}; +8 staggers LDS banks
+constexpr int TBW_RPW = 16;                      // slots walked per wave
 constexpr int TBW_WPG = 1;                       // waves per workgroup (four measured: no faster on uniform reads, 20 % slower on reads of real shape)
 // LDS traffic of one wave is processed in program order: what the wave's lanes wrote is there for its later reads; only the compiler has to keep the order
 #define TBW_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 
-struct WalkOut { int32_t ok, i, ts, i_end, j_end, ncol, n_ops, pad_; };   // (i, ts - i) = the cell before the alignment's first
+struct WalkOut { int32_t ok, i, ts, i_end, j_end, ncol, n_ops, pad_; };   // (i_end, j_end) = the terminal; (i, ts - i) = where the walk left the matrix (one of the two is -1)
 
-// Segmented form (TBS_*, default): the walk of a read is cut at every TBS_SEG-th DP step.  The walker of the top segment starts at the
-// read's best cell; the walker of every other segment starts, at the same time, at the segment's top step in band lane 32 -- a GUESS: the
-// steering keeps the path near the band's centre, and trace-backs from neighbouring cells of one anti-diagonal run into each other within
-// a few dozen steps (the best way into a cell next to the optimal path is the optimal path plus a gap).  Every walker goes TBS_OV steps
-// past its segment's bottom and notes, for the first and the last TBS_OV steps of its walk, which lane it was in and how many ops it had
-// emitted (`trail`); k_tb_stitch then finds, boundary by boundary, the first step at which the upper walker and the lower one sit in the
-// same cell, takes the upper one's ops up to there and the lower one's from there on, and writes the read's one op stream.  The result
-// is the serial walk's, op for op; a read with a boundary that does not merge inside TBS_OV steps is walked again serially (k_tb_walk<false>
-// over the flagged reads).  A read's walk is no longer one chain of 2.25 x its length: all walkers are TBS_SEG + TBS_OV steps long.
-struct SegOut { int32_t state, i, ts, n_ops, i_start, j_start, k, pad_; };   // state & 3: 0 no such segment, 1 ran to its lower bound, 2 reached the matrix edge; state & 4: a repair walk
-struct SegReq { int32_t walker, ts, k, pad_; };                                // repair request: walk this segment again from the cell (ts, k) its upper neighbour stopped in
-
-template <bool SEGMENTED>
-__global__ void __launch_bounds__(64 * TBW_WPG) k_tb_walk(int64_t first, int64_t count, const Anchor *__restrict__ anc, const DpInfo *__restrict__ info,
-                                                const int64_t *__restrict__ tb_off, const int64_t *__restrict__ tbo, const int64_t *__restrict__ mvo,
+__global__ void __launch_bounds__(64 * TBW_WPG) k_tb_walk(uint32_t ns, const uint32_t *__restrict__ order, const DpInfo *__restrict__ info,
+                                                const int64_t *__restrict__ tbo, const int64_t *__restrict__ mvo, const int32_t *__restrict__ tbs,
                                                 const ulonglong2 *__restrict__ tb, const ulonglong2 *__restrict__ mvw, uint32_t *__restrict__ raw,
-                                                WalkOut *__restrict__ wout, const int32_t *__restrict__ order, const int32_t *__restrict__ seg_slot,
-                                                const int32_t *__restrict__ seg_idx, uint32_t *__restrict__ trail, SegOut *__restrict__ segout, int only_flagged, int guess_lane,
-                                                const SegReq *__restrict__ req, const uint32_t *__restrict__ n_req, uint32_t *__restrict__ raw_final, const int32_t *__restrict__ tbs) {
-    // TBW_WPG independent waves per workgroup (a workgroup's waves are spread over its CU's SIMDs; single-wave workgroups land two and three to a SIMD while others idle):
-    // every wave has its own slice of the LDS buffer and never waits for another
+                                                WalkOut *__restrict__ wout) {
+    // TBW_WPG independent waves per workgroup: every wave has its own slice of the LDS buffer and never waits for another
     __shared__ __attribute__((aligned(16))) uint8_t lds_all[TBW_WPG * TBW_RPW * TBW_STRIDE];
     uint8_t *lds = lds_all + (threadIdx.x >> 6) * (TBW_RPW * TBW_STRIDE);
     const int lane = threadIdx.x & 63;
-    int64_t wq = ((int64_t)blockIdx.x * TBW_WPG + (threadIdx.x >> 6)) * TBW_RPW + lane;
-    // repair launch (segmented form, req != nullptr): lane x walks request x -- the segment of walker req[x].walker again, from the exact cell
-    // its upper neighbour stopped in; everything it leaves behind (ops, trail, SegOut) goes where that walker's went
-    const bool repair = SEGMENTED && req != nullptr;
-    if (repair) count = (int64_t)min(*n_req, (uint32_t)count);
-    bool have = lane < TBW_RPW && wq < count;
-    SegReq rq = {0, 0, 0, 0};
-    if (repair && have) { rq = req[wq]; wq = rq.walker; }
-    else if (SEGMENTED && have && order) wq = order[wq];     // launch order: the one-walker reads first (longest first), sixteen to a wave, then the segments
-    // serial form: `order` = slots by decreasing read length -- the 16 reads of a wave are of similar length (a wave lasts as long as its
-    // longest walk) and the longest start first.  Segmented form: `count` walkers, walker wq = segment seg_idx[wq] of slot seg_slot[wq]
-    const int64_t wv = have ? (SEGMENTED ? (int64_t)seg_slot[wq] : (order ? (int64_t)order[wq] : wq)) : 0;
-    int32_t seg = (SEGMENTED && have) ? seg_idx[wq] : 0;
-    const bool single = SEGMENTED && seg < 0;       // a short read: this walker does all of it, as the serial form would (its ops go to the read's own stream)
-    if (single) seg = 0;
-    const int64_t r = first + wv;
-    if (!SEGMENTED && only_flagged) have = have && wout[r].ok == 2;        // second pass: only the reads whose stitching failed
-    Anchor a = {0, 0, 0, 0};
+    const int64_t wq = ((int64_t)blockIdx.x * TBW_WPG + (threadIdx.x >> 6)) * TBW_RPW + lane;
+    const bool have = lane < TBW_RPW && wq < (int64_t)ns;
+    // `order` = the launch list (slots by decreasing capacity): the 16 walks of a wave are of similar length (a wave lasts as long as its longest) and the longest start first
+    const uint32_t sl = have ? order[wq] : 0u;
     DpInfo di = {0, -1, 0, NEGV};
-    if (have) { a = anc[r]; di = info[r]; }
-    bool active = have && a.aligned && di.best_t >= 0;
-    const int32_t seg_top = single ? 0 : di.best_t >> TBS_SEG_SHIFT;
-    if (SEGMENTED) active = active && seg <= seg_top;
-    const int64_t soff = tb_off[r] - tb_off[first];                           // steps before this read in the chunk of reads
-    // masks / move words of the winning candidate (second candidates sit behind the first ones in the same buffers)
-    int64_t to_ = tbo[r], mo_ = mvo[r];
+    if (have) di = info[sl];
+    bool active = have && di.best_t >= 0;
+    int64_t to_ = have ? tbo[sl] : 0, mo_ = have ? mvo[sl] : 0;
     asm volatile("" : "+v"(to_), "+v"(mo_));      // both offsets are in registers from here on: no pending load is attributed to the pointers below
     const ulonglong2 *tbr = tb + to_;                                         // per step {D mask, G mask}
     const ulonglong2 *mvr = mvw + mo_;                                        // per 64 steps {move bits, i0 before them}
-    uint32_t *rawp = (SEGMENTED && !single) ? raw + wq * TBS_RAW_WORDS : (SEGMENTED ? raw_final : raw) + (soff >> 4);     // 16 ops per word
-    const bool spec = SEGMENTED && !repair && seg < seg_top;                  // a walker that starts on the guess
-    const int32_t ts0 = repair ? rq.ts : (spec ? (seg + 1) * TBS_SEG - 1 : di.best_t);
-    int32_t ts = active ? ts0 : -1;
-    int32_t k = repair ? rq.k : di.best_lane, i = -1;
-    const int32_t stop_ts = (SEGMENTED && seg > 0) ? seg * TBS_SEG - TBS_OV : (int32_t)0x80000000;   // walk while ts >= stop_ts
-    uint32_t *tr_head = SEGMENTED ? trail + wq * (2 * TBS_OV) : nullptr, *tr_tail = SEGMENTED ? tr_head + TBS_OV : nullptr;
-    const int32_t tail_top = seg * TBS_SEG - 1;                               // the boundary below this segment
+    uint32_t *rawp = raw + 4 * mo_;                                           // 16 ops per word: cap / 16 words per slot
+    int32_t ts = active ? di.best_t : -1;
+    int32_t k = di.best_lane, i = -1;
     uint64_t w_prev = 0, pref_word = 0;      // move words: (after the first accept) w_cur = chunk of ts, w_prev = the one below
     uint64_t w_cur = 0;
     if (active) {   // i0 at the start step = i0 before its 64-step chunk + DOWN moves up to and including it
         const ulonglong2 mw = mvr[ts >> 6];
-        if (spec) k = guess_lane >= 0 ? guess_lane : (int32_t)(mw.y >> 32);      // k_sw left the lane of the best H of a segment's top step next to its move word
         i = (int32_t)(uint32_t)mw.y + __popcll(mw.x & ((2ull << (ts & 63)) - 1ull)) + k;
         w_prev = mw.x;
         pref_word = (ts >> 6) > 0 ? mvr[(ts >> 6) - 1].x : 0ull;
@@ -1426,17 +1426,17 @@ __global__ void __launch_bounds__(64 * TBW_WPG) k_tb_walk(int64_t first, int64_t
     int32_t ncol = 0, n_ops = 0, nw = 0;
     uint32_t rawacc = 0, nb = 0;
     const int32_t plo = (int32_t)(uint32_t)(uint64_t)tbr, phi = (int32_t)((uint64_t)tbr >> 32);
-    const int32_t rstride = (tbs && have) ? tbs[r] : 64;      // records from one 64-step chunk of the read's masks to the next
+    const int32_t rstride = have ? tbs[sl] : 64;      // records from one 64-step chunk of the slot's masks to the next
     uint8_t *mine = lds + lane * TBW_STRIDE;
     int32_t cur_chunk = -2, sh_cur = 0;
     int32_t pref_chunk = active ? ts >> 6 : -1, pref_sh = min(max(k - 16, 0), 32);
     uint4 pf[TBW_RPW];
 #pragma unroll
     for (int l = 0; l < TBW_RPW; l++) pf[l] = make_uint4(0, 0, 0, 0);
-    uint64_t rec_base[TBW_RPW];      // every read's mask records: wave-uniform, fetched from the owning lanes once
+    uint64_t rec_base[TBW_RPW];      // every slot's mask records: wave-uniform, fetched from the owning lanes once
 #pragma unroll
     for (int l = 0; l < TBW_RPW; l++) rec_base[l] = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(phi, l) << 32) | (uint32_t)__builtin_amdgcn_readlane(plo, l);
-    // records of chunk pref_chunk of every read -> registers (lane x takes step x of the chunk)
+    // records of chunk pref_chunk of every slot -> registers (lane x takes step x of the chunk)
     // (the record pointers are rebuilt from lane reads, which leaves them in the generic address space; a FLAT load counts on lgkmcnt as
     //  well as on vmcnt, so the walk's first wait for an LDS read would wait for the whole prefetch: load through global pointers)
     typedef uint32_t tbw_u32x4 __attribute__((ext_vector_type(4)));
@@ -1497,15 +1497,9 @@ __global__ void __launch_bounds__(64 * TBW_WPG) k_tb_walk(int64_t first, int64_t
             P = s_ ? (w_cur << (64 - s_)) | (w_prev >> s_) : w_prev;
         }
         const uint8_t *win = mine;
-        const bool notes = SEGMENTED && __any(active && !single);      // (wave-uniform: a wave of whole-read walkers skips the note-taking with a scalar branch)
         while (active && (ts >> 6) == cur_chunk && (uint32_t)(k - sh_cur) < 32u) {
             const uint2 m = *(const uint2 *)(win + (ts & 63) * 8);
             const uint32_t kk = (uint32_t)(k - sh_cur);
-            if (notes && !single) {      // where this walker is, for the stitching: its first TBS_OV steps and the TBS_OV steps below its segment
-                const uint32_t note = (repair ? 0x80000000u : 0u) | ((uint32_t)n_ops << 8) | (uint32_t)k;      // (a repair walk's notes are told from the stale ones around them by bit 31)
-                if (!repair && ts0 - ts < TBS_OV) tr_head[ts0 - ts] = note;
-                if ((uint32_t)(tail_top - ts) < (uint32_t)TBS_OV) tr_tail[tail_top - ts] = note;
-            }
             const uint32_t db = (m.x >> kk) & 1u, gb = (m.y >> kk) & 1u;
             const uint32_t hi = (uint32_t)(P >> 32);
             const uint32_t d2 = hi >> 31, d3 = (hi >> 30) & 1u;
@@ -1523,128 +1517,16 @@ __global__ void __launch_bounds__(64 * TBW_WPG) k_tb_walk(int64_t first, int64_t
             rawacc |= op << nb;
             nb += 2u;
             if (nb == 32u) { rawp[nw++] = rawacc; rawacc = 0u; nb = 0u; }
-            active = (i | (ts - i)) >= 0 && ts >= stop_ts;
+            active = (i | (ts - i)) >= 0;
         }
         TBW_WAVE_SYNC();
     }
 #undef TBW_ISSUE
     if (!have) return;
     if (nb) rawp[nw] = rawacc;
-    if (SEGMENTED && !single) {
-        SegOut so;
-        so.state = !walked ? 0 : (((i | (ts - i)) < 0 ? 2 : 1) | (repair ? 4 : 0));
-        so.i = i; so.ts = ts; so.n_ops = n_ops; so.i_start = i_end; so.j_start = j_end; so.k = k; so.pad_ = 0;
-        segout[wq] = so;
-        return;
-    }
     WalkOut o;
     o.ok = walked ? 1 : 0; o.i = i; o.ts = ts; o.i_end = i_end; o.j_end = j_end; o.ncol = ncol; o.n_ops = n_ops; o.pad_ = 0;
-    wout[r] = o;
-}
-
-__global__ void k_tb_req_reset(uint32_t *counters) { if (threadIdx.x == 0) counters[1] = 0u; }
-
-// ---- trace-back, part 1b: one wave per read joins its segments' walks (k_tb_walk<true>) into the read's op stream.
-// First pass (bit 0 of `pass`): every read.  While repair launches are still to come (bit 1), a boundary whose two walkers share no cell inside the
-// overlap asks for a repair walk of the lower segment from the cell the upper walker stopped in (if the upper walker is known to be on the path there)
-// and the read waits (ok = 3); later passes take the waiting reads only.  In the last pass what still does not join is left to the serial walk (ok = 2).
-__global__ void __launch_bounds__(64) k_tb_stitch(int64_t first, int64_t count, const Anchor *__restrict__ anc, const DpInfo *__restrict__ info,
-                                                  const int64_t *__restrict__ tb_off, const int32_t *__restrict__ seg_off, const uint32_t *__restrict__ trail,
-                                                  const SegOut *__restrict__ segout, const uint32_t *__restrict__ raw_seg, uint32_t *__restrict__ raw,
-                                                  WalkOut *__restrict__ wout, uint32_t *__restrict__ counters, SegReq *__restrict__ req, uint32_t req_cap, int pass,
-                                                  const uint8_t *__restrict__ seg_single, int ov_limit) {
-    __shared__ int32_t p_w[TBS_MAX_PIECES], p_a[TBS_MAX_PIECES], p_out[TBS_MAX_PIECES + 1];     // piece: walker, first op taken from it, first op of the output it fills
-    const int lane = lane_id();
-    const int64_t wv = blockIdx.x;
-    if (wv >= count) return;
-    const int64_t r = first + wv;
-    if (seg_single[wv]) return;                       // one walker did the whole read and left the stream and the WalkOut itself
-    if (!(pass & 1) && wout[r].ok != 3) return;        // pass bit 0: the first pass (every read); bit 1: boundaries that do not join may ask for a repair walk
-    const Anchor a = anc[r];
-    const DpInfo di = info[r];
-    WalkOut o;
-    memset(&o, 0, sizeof o);
-    if (!(a.aligned && di.best_t >= 0)) { if (lane == 0) wout[r] = o; return; }
-    const int32_t S = di.best_t >> TBS_SEG_SHIFT;
-    const int32_t w0 = seg_off[wv];
-    const SegOut top = segout[w0 + S];
-    if (top.state == 0) { if (lane == 0) wout[r] = o; return; }                 // the best cell itself is outside the matrix: no walk (as the serial form)
-    o.i_end = top.i_start; o.j_end = top.j_start;
-    bool hard = S + 1 > TBS_MAX_PIECES, fail = false;
-    bool anchored = true;                                                        // the upper walker of the boundary at hand is on the path where it stopped
-    int32_t start = 0, outpos = 0, np = 0, fin_i = 0, fin_ts = 0;
-    for (int32_t sg = S; sg >= 0 && !hard; sg--) {                               // wave-uniform
-        const SegOut so = segout[w0 + sg];
-        if ((so.state & 3) == 0) { hard = true; break; }
-        if ((so.state & 3) == 2 || sg == 0) {                                    // the path ends inside this segment: its walker's remaining ops are the last piece
-            if (lane == 0) { p_w[np] = w0 + sg; p_a[np] = start; p_out[np] = outpos; }
-            outpos += so.n_ops - start; np++;
-            fin_i = so.i; fin_ts = so.ts;
-            break;
-        }
-        const SegOut lo = segout[w0 + sg - 1];
-        if (lo.state & 4) {                                                      // the lower segment was walked again from this walker's last cell: they join there
-            if (lane == 0) { p_w[np] = w0 + sg; p_a[np] = start; p_out[np] = outpos; }
-            outpos += so.n_ops - start; np++;
-            start = 0; anchored = true;
-            continue;
-        }
-        const uint32_t *ta = trail + (int64_t)(w0 + sg) * (2 * TBS_OV) + TBS_OV, *hb = trail + (int64_t)(w0 + sg - 1) * (2 * TBS_OV);
-        const uint32_t want31 = (so.state & 4) ? 1u : 0u;
-        int32_t ia = -1, ib = -1;
-        for (int d0 = 0; d0 < TBS_OV; d0 += 64) {
-            const uint32_t ua = ta[d0 + lane], ub = hb[d0 + lane];
-            const uint64_t m = __ballot(d0 + lane < ov_limit && ua != 0xffffffffu && ub != 0xffffffffu && (ua >> 31) == want31 && (ua & 0xffu) == (ub & 0xffu));
-            if (m) {
-                const int l = __builtin_ctzll(m);                                 // the first common cell below the boundary
-                ia = __builtin_amdgcn_readlane((int32_t)((ua >> 8) & 0x7fffffu), l); ib = __builtin_amdgcn_readlane((int32_t)((ub >> 8) & 0x7fffffu), l);
-                break;
-            }
-        }
-        if (ia >= start && !fail) {
-            if (lane == 0) { p_w[np] = w0 + sg; p_a[np] = start; p_out[np] = outpos; }
-            outpos += ia - start; np++;
-            start = ib;
-        } else if (ia >= 0 && fail) {                                             // below an open boundary: the pieces are not built any more, but this one joins
-            anchored = true;
-        } else {                                                                  // no common cell inside TBS_OV steps (or one above where this walker joined the path)
-            if ((pass & 2) && anchored && lane == 0) {
-                const uint32_t q = atomicAdd(&counters[1], 1u);
-                atomicAdd(&counters[2], 1u);
-                if (q < req_cap) { SegReq rq; rq.walker = w0 + sg - 1; rq.ts = so.ts; rq.k = so.k; rq.pad_ = 0; req[q] = rq; }
-            }
-            fail = true; anchored = false;
-        }
-    }
-    if (hard || (fail && !(pass & 2))) { o.ok = 2; if (lane == 0) { wout[r] = o; atomicAdd(&counters[0], 1u); } return; }    // k_tb_walk<false> walks this read serially
-    if (fail) { o.ok = 3; if (lane == 0) wout[r] = o; return; }                  // waits for the repair walks
-    if (lane == 0) p_out[np] = outpos;
-    __syncthreads();
-    // the pieces, one after the other, into the read's stream: a lane builds an output word from the (at most two) source words under it
-    uint32_t *rg = raw + ((tb_off[r] - tb_off[first]) >> 4);
-    const int32_t L = outpos, nW = (L + 15) >> 4;
-    for (int32_t wi = lane; wi < nW; wi += 64) {
-        const int32_t o0 = 16 * wi, o1 = min(o0 + 16, L);
-        int32_t pc = 0;
-        while (pc + 1 < np && p_out[pc + 1] <= o0) pc++;
-        uint32_t word = 0;
-        int32_t oo = o0;
-        while (oo < o1) {
-            const int32_t pe = min(o1, p_out[pc + 1]);                            // ops [oo, pe) come from piece pc
-            const int32_t sa = p_a[pc] + (oo - p_out[pc]);                        // first source op
-            const uint32_t *src = raw_seg + (int64_t)p_w[pc] * TBS_RAW_WORDS;
-            const int32_t sw = sa >> 4, sb = (sa & 15) * 2;
-            const uint64_t two = (uint64_t)src[sw] | ((uint64_t)src[sw + 1] << 32);   // (a walker's buffer has a spare word)
-            uint32_t bits = (uint32_t)(two >> sb);
-            const int32_t cnt = pe - oo;
-            if (cnt < 16) bits &= (1u << (2 * cnt)) - 1u;
-            word |= bits << (2 * (oo - o0));
-            oo = pe; pc++;
-        }
-        rg[wi] = word;
-    }
-    o.ok = 1; o.i = fin_i; o.ts = fin_ts; o.ncol = 0; o.n_ops = L;               // ncol (and i, ts after trimming) are k_tb_cigar's pass 0's
-    if (lane == 0) wout[r] = o;
+    wout[sl] = o;
 }
 
 // ---- trace-back, part 2: one wave per read turns the walk's op stream (alignment end first, 16 ops per word)
@@ -1655,26 +1537,28 @@ __global__ void __launch_bounds__(64) k_tb_stitch(int64_t first, int64_t count, 
 // the flags of a word come from one xor with the stream shifted by one op, and a run is written by the start BELOW
 // it (which knows where it ends); suffix scans over the lanes give each word the number of starts and the lowest
 // start above it.
-__global__ void __launch_bounds__(64) k_tb_cigar(int64_t first, int64_t count, const int32_t *__restrict__ read_len, const Anchor *__restrict__ anc,
-                                                 const DpInfo *__restrict__ info, const int64_t *__restrict__ tb_off, uint32_t *__restrict__ raw,
-                                                 const WalkOut *__restrict__ wout, const int64_t *__restrict__ cig_off, uint32_t *__restrict__ cig,
+__global__ void __launch_bounds__(64) k_tb_cigar(int64_t first, int64_t count, const int32_t *__restrict__ read_len, const ReadPath *__restrict__ rpath,
+                                                 const uint32_t *__restrict__ rcapq_scan, uint32_t *__restrict__ raw,
+                                                 const int64_t *__restrict__ cig_off, uint32_t *__restrict__ cig,
                                                  int64_t *__restrict__ cig_start, fzp_aln_summary *__restrict__ summ, int match, int mismatch, int gap,
-                                                 int min_pct_identity, const uint32_t *__restrict__ read_ori, const int64_t *__restrict__ read_woff,
+                                                 int min_pct_identity, const uint32_t *__restrict__ read_pk, const uint32_t *__restrict__ read_rc, const int64_t *__restrict__ read_woff,
                                                  const int32_t *__restrict__ read_ctg, const uint32_t *__restrict__ ctg_pk, const int64_t *__restrict__ ctg_woff) {
     const int lane = lane_id();
     const int64_t wv = blockIdx.x;
     if (wv >= count) return;
     const int64_t r = first + wv;
-    const Anchor a = anc[r];
-    const DpInfo di = info[r];
-    WalkOut w = wout[r];
+    const ReadPath rp = rpath[wv];
+    // the joined path in the oriented read's / the contig's own coordinates (the anchor offsets of the pieces are folded in by k_join)
+    struct { int32_t i_a, c_a, strand; } a = {0, 0, rp.strand};
+    WalkOut w;
+    w.ok = rp.ok; w.i = 0; w.ts = 0; w.i_end = rp.i_end; w.j_end = rp.j_end; w.ncol = 0; w.n_ops = rp.n_ops; w.pad_ = 0;
     const int32_t n = read_len[r];
     fzp_aln_summary out;
     memset(&out, 0, sizeof out);
-    out.cells = (int64_t)di.steps * 64;
+    out.cells = rp.steps * 64;
     if (lane == 0) cig_start[r] = cig_off[r];
     if (!w.ok) { if (lane == 0) summ[r] = out; return; }
-    uint32_t *rg = raw + ((tb_off[r] - tb_off[first]) >> 4);    // (pass 0 drops the ops before the alignment's end from it)
+    uint32_t *rg = raw + 4 * (size_t)(rcapq_scan[r] - rcapq_scan[first]);    // the read's op stream (pass 0 drops the ops before the alignment's end from it)
     uint32_t *reg = cig + cig_off[r];                     // capacity n + 18 words: [0] leading clip, runs from [1]
     int32_t L = w.n_ops;
     int32_t nW = (L + 15) >> 4;
@@ -1691,7 +1575,7 @@ __global__ void __launch_bounds__(64) k_tb_cigar(int64_t first, int64_t count, c
     // then gives every word the lowest prefix before it, and the second sweep finds its best (e, s).
     int32_t S_star = 0;
     {
-        const uint32_t *qpk = read_ori + read_woff[r];
+        const uint32_t *qpk = (rp.strand ? read_rc : read_pk) + read_woff[r];
         const uint32_t *tpk = ctg_pk + ctg_woff[read_ctg[r]];
         auto scan_incl = [&](int32_t v) -> int32_t {
 #pragma unroll
@@ -1917,131 +1801,114 @@ __global__ void __launch_bounds__(64) k_tb_cigar(int64_t first, int64_t count, c
     summ[r] = out;
 }
 
-// ---- backward extension (v1.4): inputs.  Per read of the chunk: the winner's anchor (i_h, c_h) -> the reversed oriented-read prefix [0, i_h) and the
-// reversed contig window of min(c_h, i_h + i_h / 4 + 64) bases before c_h, both 2-bit packed with zero padding, at offsets the host planned from the
-// candidates' anchors; k_sw then runs on them as on any read / contig pair (anchor (0, 0), the "contig" of slot r is its own window).
-__global__ void __launch_bounds__(256) k_back_prep(int64_t first, const Anchor *__restrict__ anc, const int32_t *__restrict__ read_ctg, const uint32_t *__restrict__ read_ori,
-                                                   const int64_t *__restrict__ read_woff, const uint32_t *__restrict__ ctg_pk, const int64_t *__restrict__ ctg_woff,
-                                                   const int64_t *__restrict__ bq_off, const int64_t *__restrict__ bt_off, uint32_t *__restrict__ bq, uint32_t *__restrict__ bt,
-                                                   Anchor *__restrict__ anc_b, int32_t *__restrict__ b_len, int64_t *__restrict__ b_tlen) {
-    const int64_t r = first + blockIdx.x;
-    const Anchor a = anc[r];
-    const int32_t nqb = (a.aligned && a.i_a > 0 && a.c_a > 0) ? a.i_a : 0;
-    const int32_t ntb = nqb ? min(a.c_a, nqb + nqb / 4 + 64) : 0;
-    if (threadIdx.x == 0) {
-        Anchor ab; ab.aligned = nqb > 0 ? 1 : 0; ab.strand = a.strand; ab.i_a = 0; ab.c_a = 0;
-        anc_b[r] = ab; b_len[r] = nqb; b_tlen[r] = ntb;
-    }
-    const uint32_t *q = read_ori + read_woff[r];
-    const uint32_t *t = ctg_pk + ctg_woff[read_ctg[r]];
-    uint32_t *dq = bq + bq_off[r], *dt = bt + bt_off[r];
-    const int64_t wq = bq_off[r + 1] - bq_off[r], wt = bt_off[r + 1] - bt_off[r];      // capacities: the used words first, zeros behind them
-    for (int64_t w = threadIdx.x; w < wq; w += 256) {
-        uint32_t v = 0;
-        for (int m = 0; m < 16; m++) { const int64_t x = w * 16 + m; if (x < nqb) v |= base_at(q, (int64_t)a.i_a - 1 - x) << (2 * m); }
-        dq[w] = v;
-    }
-    for (int64_t w = threadIdx.x; w < wt; w += 256) {
-        uint32_t v = 0;
-        for (int m = 0; m < 16; m++) { const int64_t x = w * 16 + m; if (x < ntb) v |= base_at(t, (int64_t)a.c_a - 1 - x) << (2 * m); }
-        dt[w] = v;
-    }
-}
-// ---- backward extension: its walk joins the forward one.  The read's op stream so far runs from the alignment's END to the forward walk's exit next to the
-// anchor; behind it go the gap moves that exit implies (a walk that leaves through row / column -1 skipped bases there), the ones the backward walk's exit
-// implies, and the backward walk's ops turned round (it came from the far end towards the anchor).  k_tb_cigar then sees one path.
-__global__ void __launch_bounds__(64) k_back_merge(int64_t first, int64_t count, const int64_t *__restrict__ tb_off, const int64_t *__restrict__ tb_off_b,
-                                                   const Anchor *__restrict__ anc_b, const DpInfo *__restrict__ info_b, const WalkOut *__restrict__ wout_b,
-                                                   const uint32_t *__restrict__ raw_b, uint32_t *__restrict__ raw, WalkOut *__restrict__ wout, DpInfo *__restrict__ info) {
+// ---- candidate selection and joining (v1.6), one wave per read, one lane per slot of the read.  Selection (blasr --bestn 1, unzip.py:86): the candidate whose FORWARD
+// pieces' terminal scores sum highest (ties: the first).  Its path, END first: the forward pieces from the last (free) one down to the anchor's -- for an inner piece the gap
+// moves from the sub-matrix's corner to its terminal, then the walk, then the gap moves its exit through row / column -1 implies -- and behind them the backward piece: the
+// gap moves at the anchor's corner, then its walk turned round (it came from the far end towards the anchor).  k_tb_cigar then sees one path.
+constexpr int JOIN_SEGS = 5 * (MAX_WP + 1) + 8;
+__global__ void __launch_bounds__(64) k_join(int64_t r_lo, int64_t count, const uint32_t *__restrict__ slot_base, const uint32_t *__restrict__ cnt, uint32_t s_lo,
+                                             const Slot *__restrict__ slots, const DpInfo *__restrict__ info, const WalkOut *__restrict__ wout, const int64_t *__restrict__ mvo,
+                                             const uint32_t *__restrict__ raw, const uint32_t *__restrict__ rcapq_scan, uint32_t *__restrict__ rraw, ReadPath *__restrict__ rpath) {
+    __shared__ int32_t l_eD[64], l_eI[64], l_w[64], l_xD[64], l_xI[64];
+    __shared__ int64_t l_src[64];
+    __shared__ int32_t g_start[JOIN_SEGS + 1], g_kind[JOIN_SEGS];      // kind: 0 copy, 1 run of I, 2 run of D, 3 copy turned round
+    __shared__ int32_t g_len[JOIN_SEGS];
+    __shared__ int64_t g_src[JOIN_SEGS];
+    __shared__ int32_t g_n;
     const int lane = lane_id();
     const int64_t wv = blockIdx.x;
     if (wv >= count) return;
-    const int64_t r = first + wv;
-    WalkOut fw = wout[r];
-    if (fw.ok != 1 || !anc_b[r].aligned) return;
-    const DpInfo ib = info_b[r];
-    const WalkOut bw = wout_b[r];
-    DpInfo di = info[r];
-    di.steps += ib.steps;                                                // the cells of the backward DP count, whatever came of it
-    if (bw.ok != 1) { if (lane == 0) info[r] = di; return; }
-    const int32_t is = fw.i, js = fw.ts - fw.i, bis = bw.i, bjs = bw.ts - bw.i;
-    const int32_t nD = (is < 0 && js >= 0) ? js + 1 : 0, nI = (js < 0 && is >= 0) ? is + 1 : 0;
-    const int32_t bD = (bis < 0 && bjs >= 0) ? bjs + 1 : 0, bI = (bjs < 0 && bis >= 0) ? bis + 1 : 0;
-    const int32_t nb = bw.n_ops, m = nD + nI + bD + bI + nb, at = fw.n_ops;
-    const int64_t cap_ops = tb_off[r + 1] - tb_off[r];
-    if ((int64_t)at + m > cap_ops) { if (lane == 0) info[r] = di; return; }      // (cannot happen: a path has fewer ops than the DP had steps)
-    uint32_t *rg = raw + ((tb_off[r] - tb_off[first]) >> 4);
-    const uint32_t *rb = raw_b + ((tb_off_b[r] - tb_off_b[first]) >> 4);
-    const int32_t w0 = at >> 4, w1 = (at + m - 1) >> 4;
-    for (int32_t wi = w0 + lane; wi <= w1; wi += 64) {
+    const int64_t r = r_lo + wv;
+    const int32_t ns = (int32_t)cnt[r];
+    const uint32_t base = slot_base[r] - s_lo;
+    ReadPath out;
+    memset(&out, 0, sizeof out);
+    if (ns == 0) { if (lane == 0) rpath[wv] = out; return; }
+    const bool have = lane < ns;
+    Slot S = {0, 0, 0, 0, 0, 0, 0, 0};
+    DpInfo I = {0, -1, 0, NEGV};
+    WalkOut W;
+    memset(&W, 0, sizeof W);
+    if (have) { S = slots[base + lane]; I = info[base + lane]; W = wout[base + lane]; }
+    const bool back = have && (S.flags & SLOT_BACK) != 0;
+    const int cand = have ? ((S.flags & SLOT_CAND) ? 1 : 0) : -1;
+    out.steps = (int64_t)wave_sum_i32_dpp(have ? I.steps : 0);
+    const bool f0 = cand == 0 && !back, f1 = cand == 1 && !back;
+    const int32_t s0 = wave_sum_i32_dpp(f0 ? I.best_score : 0), s1 = wave_sum_i32_dpp(f1 ? I.best_score : 0);
+    const bool bad0 = __any(f0 && I.best_t < 0), bad1 = __any(f1 && I.best_t < 0), has1 = __any(cand == 1);
+    const int32_t sc0 = bad0 ? NEGV : s0, sc1 = bad1 ? NEGV : s1;
+    const int win = (has1 && sc1 > sc0) ? 1 : 0;
+    if (win ? bad1 : bad0) { if (lane == 0) rpath[wv] = out; return; }      // (a piece without a valid border cell: cannot happen for nq, nt >= 1)
+    const uint64_t mine = __ballot(cand == win);
+    const int w_first = __builtin_ctzll(mine), w_last = 63 - __builtin_clzll(mine);
+    const bool has_back = __builtin_amdgcn_readlane((int32_t)(back ? 1 : 0), w_first) != 0;
+    {   // what every piece of the winner contributes
+        const bool inner = (S.flags & SLOT_INNER) != 0;
+        const int32_t is = W.i, js = W.ts - W.i;
+        l_eD[lane] = inner ? S.nt - 1 - W.j_end : 0;
+        l_eI[lane] = inner ? S.nq - 1 - W.i_end : 0;
+        l_w[lane] = (have && I.best_t >= 0 && W.ok) ? W.n_ops : -1;
+        l_xD[lane] = (is < 0 && js >= 0) ? js + 1 : 0;
+        l_xI[lane] = (js < 0 && is >= 0) ? is + 1 : 0;
+        l_src[lane] = have ? 4 * mvo[base + lane] : 0;
+    }
+    // the path's end = the free piece's terminal, in the oriented read's / the contig's coordinates
+    out.strand = (__builtin_amdgcn_readlane(S.flags, w_last) & SLOT_QRC) ? 1 : 0;
+    out.i_end = __builtin_amdgcn_readlane(S.qb + W.i_end, w_last);
+    out.j_end = __builtin_amdgcn_readlane(S.tb + W.j_end, w_last);
+    __syncthreads();
+    if (lane == 0) {
+        int32_t ng = 0, at = 0;
+        auto seg = [&](int kind, int32_t len, int64_t src) { if (len > 0) { g_start[ng] = at; g_len[ng] = len; g_kind[ng] = kind; g_src[ng] = src; ng++; at += len; } };
+        for (int x = w_last; x >= w_first + (has_back ? 1 : 0); x--) {
+            seg(2, l_eD[x], 0); seg(1, l_eI[x], 0);
+            seg(0, l_w[x], l_src[x]);
+            seg(2, l_xD[x], 0); seg(1, l_xI[x], 0);
+        }
+        if (has_back && l_w[w_first] >= 0) {
+            seg(2, l_xD[w_first], 0); seg(1, l_xI[w_first], 0);
+            seg(3, l_w[w_first], l_src[w_first]);
+        }
+        g_start[ng] = at;
+        g_n = ng;
+    }
+    __syncthreads();
+    const int32_t ng = g_n, L = g_start[ng], nW = (L + 15) >> 4;
+    uint32_t *rg = rraw + 4 * (size_t)(rcapq_scan[r] - rcapq_scan[r_lo]);
+    for (int32_t wi = lane; wi < nW; wi += 64) {
+        const int32_t o0 = 16 * wi, o1 = min(o0 + 16, L);
+        int32_t lo = 0, hi = ng - 1;                       // the segment holding op o0
+        while (lo < hi) { const int32_t mid = (lo + hi + 1) >> 1; if (g_start[mid] <= o0) lo = mid; else hi = mid - 1; }
+        int32_t pc = lo, oo = o0;
         uint32_t word = 0;
-        if (wi == w0 && (at & 15)) word = rg[wi] & ((1u << (2 * (at & 15))) - 1u);
-        for (int sl = 0; sl < 16; sl++) {
-            const int32_t p = 16 * wi + sl;
-            if (p < at || p >= at + m) continue;
-            int32_t x = p - at;
-            uint32_t op;
-            if (x < nD) op = 2u;
-            else if ((x -= nD) < nI) op = 1u;
-            else if ((x -= nI) < bD) op = 2u;
-            else if ((x -= bD) < bI) op = 1u;
-            else { x -= bI; const int32_t src = nb - 1 - x; op = (rb[src >> 4] >> (2 * (src & 15))) & 3u; }
-            word |= op << (2 * sl);
+        while (oo < o1) {
+            const int32_t pe = min(o1, g_start[pc + 1]), c = pe - oo, sa = oo - g_start[pc];      // ops [oo, pe) come from segment pc, from its op sa on
+            const int kind = g_kind[pc];
+            uint32_t bits;
+            if (kind == 0) {
+                const uint32_t *src = raw + g_src[pc];
+                const int32_t sw = sa >> 4, sb = (sa & 15) * 2;
+                const uint64_t two = (uint64_t)src[sw] | ((uint64_t)src[sw + 1] << 32);          // (the op buffer has spare words behind every slot's stream)
+                bits = (uint32_t)(two >> sb);
+            } else if (kind == 3) {
+                const uint32_t *src = raw + g_src[pc];
+                const int32_t top = g_len[pc] - 1 - sa;                                           // source op of output op oo, going down from there
+                bits = 0;
+                for (int32_t q = 0; q < c; q++) { const int32_t so = top - q; bits |= ((src[so >> 4] >> (2 * (so & 15))) & 3u) << (2 * q); }
+            } else bits = kind == 1 ? 0x55555555u : 0xAAAAAAAAu;
+            if (c < 16) bits &= (1u << (2 * c)) - 1u;
+            word |= bits << (2 * (oo - o0));
+            oo = pe; pc++;
         }
         rg[wi] = word;
     }
-    if (lane == 0) {
-        fw.n_ops = at + m;
-        wout[r] = fw;
-        info[r] = di;
-    }
-}
-
-__global__ void __launch_bounds__(256) k_sec_count(int64_t n, const Anchor *__restrict__ ancB, uint32_t *__restrict__ count) {
-    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const uint64_t m = __ballot(r < n && ancB[r].aligned != 0);
-    if (lane_id() == 0 && m) atomicAdd(count, (uint32_t)__popcll(m));
-}
-// ---- candidate selection (blasr --bestn 1, unzip.py:86): a read's second candidate replaces the first when its extension
-// scored strictly higher; `steps` of the survivor counts the DP steps of both (fzp_aln_summary.cells)
-__global__ void __launch_bounds__(256) k_pick(int64_t w_lo, int64_t w_hi, const int32_t *__restrict__ ridx, const Anchor *__restrict__ anc2, const DpInfo *__restrict__ info2,
-                                              const int64_t *__restrict__ tb_off2, int64_t tb_base, int64_t mv_base, Anchor *__restrict__ anc, DpInfo *__restrict__ info,
-                                              int64_t *__restrict__ tbo, int64_t *__restrict__ mvo, uint8_t *__restrict__ won, int32_t *__restrict__ tbs) {
-    const int64_t w = w_lo + (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (w >= w_hi) return;
-    const int32_t r = ridx[w];
-    DpInfo a = info[r];
-    const DpInfo b = info2[w];
-    const int32_t total = a.steps + b.steps;
-    const bool take = b.best_score > a.best_score;
-    if (take) {
-        a = b;
-        anc[r] = anc2[w];
-        const int64_t so = tb_off2[w] - tb_off2[w_lo];
-        tbo[r] = tb_base + so;
-        if (tbs) tbs[r] = 64;                      // the second candidates' streams are their own
-        mvo[r] = mv_base + (so >> 6) + (w - w_lo);
-    }
-    a.steps = total;
-    info[r] = a;
-    won[w] = take ? 1 : 0;
-}
-__global__ void __launch_bounds__(256) k_pick_copy(int64_t w_lo, const int32_t *__restrict__ ridx, const uint8_t *__restrict__ won, const int32_t *__restrict__ read_len,
-                                                   const uint32_t *__restrict__ sec_ori, const int64_t *__restrict__ sec_woff, const int64_t *__restrict__ read_woff,
-                                                   uint32_t *__restrict__ read_ori) {
-    const int64_t w = w_lo + blockIdx.x;
-    if (!won[w]) return;
-    const int32_t r = ridx[w];
-    const int64_t nw = (((int64_t)read_len[r] + 15) / 16 + 8 + 1) & ~1LL;
-    const uint32_t *src = sec_ori + sec_woff[w];
-    uint32_t *dst = read_ori + read_woff[r];
-    for (int64_t x = threadIdx.x; x < nw; x += 256) dst[x] = src[x];
+    if (lane == 0) { out.ok = 1; out.n_ops = L; rpath[wv] = out; }
 }
 
 // ---- gather accepted records into contiguous CIGAR / ASCII SEQ arrays
 __global__ void __launch_bounds__(256) k_gather(int64_t n_rec, const int64_t *__restrict__ rec_read, const int64_t *__restrict__ cig_start, const uint32_t *__restrict__ cig,
-                                                const int64_t *__restrict__ out_cig_off, uint32_t *__restrict__ out_cig, const uint32_t *__restrict__ read_ori,
-                                                const int64_t *__restrict__ read_woff, const int64_t *__restrict__ out_seq_off, uint8_t *__restrict__ out_seq) {
+                                                const int64_t *__restrict__ out_cig_off, uint32_t *__restrict__ out_cig, const uint32_t *__restrict__ read_pk, const uint32_t *__restrict__ read_rc,
+                                                const fzp_aln_summary *__restrict__ summ, const int64_t *__restrict__ read_woff, const int64_t *__restrict__ out_seq_off, uint8_t *__restrict__ out_seq) {
     const int64_t k = blockIdx.x;
     if (k >= n_rec) return;
     const int64_t r = rec_read[k];
@@ -2050,7 +1917,7 @@ __global__ void __launch_bounds__(256) k_gather(int64_t n_rec, const int64_t *__
     uint32_t *dst = out_cig + out_cig_off[k];
     for (int64_t x = (int64_t)blockIdx.y * 256 + threadIdx.x; x < nc; x += (int64_t)gridDim.y * 256) dst[x] = src[x];
     const int64_t n = out_seq_off[k + 1] - out_seq_off[k];
-    const uint32_t *pk = read_ori + read_woff[r];
+    const uint32_t *pk = (summ[r].strand ? read_rc : read_pk) + read_woff[r];      // SEQ on the reference strand
     uint8_t *sq = out_seq + out_seq_off[k];
     for (int64_t x = (int64_t)blockIdx.y * 256 + threadIdx.x; x < n; x += (int64_t)gridDim.y * 256) sq[x] = (uint8_t)("ACGT"[base_at(pk, x)]);
 }
@@ -2185,8 +2052,8 @@ __global__ void __launch_bounds__(256) k_plan_emit(int64_t n, int n_ctg, const i
 }
 // the batch path's variant: SEQ segments are padded to 16 bytes, so a thread turns one packed word into one 16-byte store
 __global__ void __launch_bounds__(256) k_gather16(int64_t n_rec, const int64_t *__restrict__ rec_read, const int64_t *__restrict__ cig_start, const uint32_t *__restrict__ cig,
-                                                  const int64_t *__restrict__ out_cig_off, uint32_t *__restrict__ out_cig, const uint32_t *__restrict__ read_ori,
-                                                  const int64_t *__restrict__ read_woff, const int64_t *__restrict__ out_seq_off, uint8_t *__restrict__ out_seq) {
+                                                  const int64_t *__restrict__ out_cig_off, uint32_t *__restrict__ out_cig, const uint32_t *__restrict__ read_pk, const uint32_t *__restrict__ read_rc,
+                                                  const fzp_aln_summary *__restrict__ summ, const int64_t *__restrict__ read_woff, const int64_t *__restrict__ out_seq_off, uint8_t *__restrict__ out_seq) {
     const int64_t k = blockIdx.x;
     if (k >= n_rec) return;
     const int64_t r = rec_read[k];
@@ -2195,7 +2062,7 @@ __global__ void __launch_bounds__(256) k_gather16(int64_t n_rec, const int64_t *
     uint32_t *dst = out_cig + out_cig_off[k];
     for (int64_t x = (int64_t)blockIdx.y * 256 + threadIdx.x; x < nc; x += (int64_t)gridDim.y * 256) dst[x] = src[x];
     const int64_t nw = (out_seq_off[k + 1] - out_seq_off[k]) >> 4;
-    const uint32_t *pk = read_ori + read_woff[r];
+    const uint32_t *pk = (summ[r].strand ? read_rc : read_pk) + read_woff[r];      // SEQ on the reference strand
     uint4 *sq = (uint4 *)(out_seq + out_seq_off[k]);
     for (int64_t w = (int64_t)blockIdx.y * 256 + threadIdx.x; w < nw; w += (int64_t)gridDim.y * 256) {
         const uint32_t x = pk[w];
@@ -2220,19 +2087,34 @@ __global__ void __launch_bounds__(256) k_gather16(int64_t n_rec, const int64_t *
 static std::mutex g_dp_mu;
 static std::map<int, hipEvent_t> g_dp_last;
 
+// what one chunk of reads needs between its planning and its trace-back; two sets alternate, so that the DP of chunk k + 1 runs while chunk k is walked
+struct ChunkBufs {
+    DevBuf<Slot> slots;
+    DevBuf<uint32_t> bh, sorted, fits, pos_b, list, lq, lq_scan, gq, gq_scan;
+    DevBuf<uint64_t> ptot;                       // [0] slots of the bit-sliced kernel, [1] sum of gq (its mask regions, in units of 4 096 records), [2] sum of lq (cap / 64 over all slots)
+    DevBuf<int64_t> tbo, mvo;                    // per slot: where its trace-back masks / move words are
+    DevBuf<int32_t> tbs;                         // per slot: records from one 64-step block of its masks to the next (4 096: interleaved with its launch group; 64: a stream of its own)
+    DevBuf<DpInfo> info;
+    DevBuf<WalkOut> wout;
+    DevBuf<uint2> tb;                            // the masks, 16 B per DP step
+    DevBuf<ulonglong2> mvw;                      // move words, one per 64 steps
+    DevBuf<uint32_t> raw, rraw;                  // 2-bit op streams: per slot (the walks), per read (joined)
+    DevBuf<ReadPath> rpath;
+};
+
 struct fzp_alnjob {
     int32_t n_ctg = 0;
     int64_t n_reads = 0;
     fzp_align_params P;
     std::vector<std::vector<uint8_t>> h_ctg;     // upper-cased ASCII, for the phasing batch's ref_seq
-    std::vector<int64_t> h_ctg_len, h_ctg_woff, h_idx_off, h_read_woff, h_tb_off, h_cig_off;
+    std::vector<int64_t> h_ctg_len, h_ctg_woff, h_idx_off, h_read_woff, h_cig_off;
     std::vector<int32_t> h_idx_bits, h_read_len, h_read_ctg;
     std::vector<fzp_aln_summary> h_summ;
     int64_t ctg_words = 0, read_words = 0, idx_slots = 0;
-    DevBuf<uint32_t> ctg_pk, read_pk, read_ori, cig;
+    DevBuf<uint32_t> ctg_pk, ctg_rc, read_pk, read_rc, cig;      // 2-bit packed sequences, both orientations (the second one made once, by k_revcomp)
     DevBuf<uint8_t> ctg_ascii;                   // upper-cased contigs, concatenated (ref_seq of the phasing batch)
     std::vector<int64_t> h_ctg_aoff;
-    DevBuf<int64_t> ctg_woff, ctg_len, idx_off, read_woff, tb_off, cig_off, cig_start;
+    DevBuf<int64_t> ctg_woff, ctg_len, idx_off, read_woff, cig_off, cig_start;
     DevBuf<int32_t> idx_bits, read_len, read_ctg;
     DevBuf<uint64_t> table;
     DevBuf<uint32_t> part_cursor;                // k-mer index build: staged entries per partition
@@ -2241,40 +2123,17 @@ struct fzp_alnjob {
     DevBuf<int64_t> part_off;
     std::vector<int64_t> h_part_off;
     int64_t n_parts = 0;
-    DevBuf<Anchor> anc, ancB, anc2;              // first candidates (per read), second candidates (per read; compacted)
-    DevBuf<int64_t> tbo, mvo;                    // per read: where the winning candidate's trace-back masks / move words are
+    DevBuf<Anchor> anc, ancB;                    // first / second candidate per read
+    DevBuf<int32_t> n_wp, wpp;                   // waypoints per (read, candidate); seeding scratch: per hit of a seeding launch, the waypoint before it
+    DevBuf<int2> wps;                            // the waypoints (oriented read offset, contig position), MAX_WP per (read, candidate)
     DevBuf<uint2> hits;                          // seeding: HIT_CAP hit slots per read of a seeding launch
     DevBuf<SeedWin> win;
     DevBuf<uint32_t> n_sec;                      // reads with a second candidate
-    DevBuf<int32_t> ridx;                        // compacted second candidates -> read
-    DevBuf<int64_t> sec_woff, tb_off2;
-    DevBuf<uint32_t> sec_ori;
-    DevBuf<DpInfo> info2;
-    DevBuf<uint8_t> won;
     int64_t n_second = 0;                        // of the last run
-    DevBuf<DpInfo> info;
-    DevBuf<uint2> tb2[2];
-    DevBuf<uint32_t> raw2[2];                    // the walk's 2-bit op streams
-    DevBuf<WalkOut> wout;
-    DevBuf<uint8_t> seg_single;                  // per read: 1 = short enough for one walker
-    DevBuf<int32_t> seg_order;                   // per launched walker slot: the walker that takes it
-    DevBuf<int32_t> seg_off, seg_slot, seg_idx;  // segmented trace-back: per read its first walker (chunk-relative); per walker its slot (chunk-relative) and segment
-    std::vector<int64_t> h_seg_base, h_seg_cnt;  // per chunk start (indexed by its first read): first walker in seg_slot / seg_idx, number of walkers
-    DevBuf<uint32_t> raw_seg2[2], trail2[2];
-    DevBuf<SegOut> segout2[2];
-    DevBuf<uint32_t> tb_fallback;                // [0] reads of the last run walked serially after all, [1] repair walks asked for in the chunk at hand, [2] in the whole run
-    DevBuf<SegReq> seg_req;
-    DevBuf<uint32_t> dp_flag;                    // "the bit-sliced DP kernel of launch dp_seq runs" (k_wait_started)
-    uint32_t dp_seq = 0;
-    DevBuf<uint8_t> b_handled;                   // per read: its backward extension ran in the bit-sliced kernel
-    DevBuf<int32_t> tbs;                         // per read: records from one 64-step block of its masks to the next (64: a stream of its own; 4096: interleaved with its launch group)
-    std::vector<int64_t> h_tbm_total;            // per chunk (by its first read): records its planned mask streams span
-    DevBuf<int64_t> tbm_off, mvm_off;            // per read: where its masks / move words go in its chunk's buffers, planned in LAUNCH order (longest first)
-    DevBuf<int32_t> swb_list, sw_list;           // per run: the chunk's slots by DP kernel (k_swb: 64 per wave, -1 padded; k_sw: its launch order)
-    std::vector<int32_t> h_swb_list, h_sw_list, h_lpt;
-    std::vector<int64_t> h_swb_at, h_sw_at;      // per chunk (by its first read): where its lists start, and their sizes behind
-    DevBuf<int32_t> lpt;                         // per read: the slot (relative to its chunk's first read) that wave / lane number x of the chunk's launches takes --
-    int64_t lpt_chunk_steps = -1;                // longest reads first (k_sw, k_tb_walk); rebuilt when the chunking changes
+    DevBuf<uint32_t> r_cnt, r_capq, slot_base, rcapq_scan;      // per read: slots, their capacity / 64, and the exclusive scans of both
+    DevBuf<uint64_t> rtot;                       // [0] slots of the run, [1] capacity / 64 of the run
+    ChunkBufs cb[2];
+    bool summ_on_host = false;
     // record planning: reads grouped by contig (input order inside a contig); built on first use
     DevBuf<int32_t> slot_read, slot_ctg;
     DevBuf<int64_t> slot_off;
@@ -2283,19 +2142,7 @@ struct fzp_alnjob {
     int64_t n_rank_buckets = 0;
     bool have_slots = false;
     int64_t max_reads_per_ctg = 1;
-    bool summ_on_host = false;
-    DevBuf<ulonglong2> mvw2[2];
-    // backward extension (v1.4): slot = read; capacities planned by the host from the candidates' anchors at every run
-    DevBuf<Anchor> anc_b;
-    DevBuf<DpInfo> info_b;
-    DevBuf<int32_t> b_len, b_iota, b_order;
-    DevBuf<int64_t> b_tlen, bq_off, bt_off, tb_off_b, tbo_b, mvo_b;
-    DevBuf<uint32_t> bq, bt, raw_b2[2];
-    DevBuf<uint2> tb_b2[2];
-    DevBuf<ulonglong2> mvw_b2[2];
-    DevBuf<WalkOut> wout_b;
-    std::vector<int64_t> h_tb_off_b;
-    hipEvent_t ev_sw[2] = {nullptr, nullptr}, ev_tb[2] = {nullptr, nullptr}, ev_bk[2] = {nullptr, nullptr}, ev_l[2] = {nullptr, nullptr};
+    hipEvent_t ev_sw[2] = {nullptr, nullptr}, ev_tb[2] = {nullptr, nullptr}, ev_l[2] = {nullptr, nullptr};
     DevBuf<fzp_aln_summary> summ;
     bool done = false;
 };
@@ -2308,8 +2155,8 @@ extern "C" void fzp_align_params_default(fzp_align_params *p) {
 
 extern "C" void fzp_align_destroy(fzp_ctx *ctx, fzp_alnjob *job) {
     if (!job) return;
-    if (ctx) { (void)fzp_bind(ctx); (void)hipStreamSynchronize(ctx->stream); (void)hipStreamSynchronize(ctx->stream2); }
-    for (int k = 0; k < 2; k++) { if (job->ev_sw[k]) (void)hipEventDestroy(job->ev_sw[k]); if (job->ev_tb[k]) (void)hipEventDestroy(job->ev_tb[k]); if (job->ev_bk[k]) (void)hipEventDestroy(job->ev_bk[k]); if (job->ev_l[k]) (void)hipEventDestroy(job->ev_l[k]); }
+    if (ctx) { (void)fzp_bind(ctx); (void)hipStreamSynchronize(ctx->stream); (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamSynchronize(ctx->stream3); }
+    for (int k = 0; k < 2; k++) { if (job->ev_sw[k]) (void)hipEventDestroy(job->ev_sw[k]); if (job->ev_tb[k]) (void)hipEventDestroy(job->ev_tb[k]); if (job->ev_l[k]) (void)hipEventDestroy(job->ev_l[k]); }
     delete job;
 }
 
@@ -2371,7 +2218,6 @@ extern "C" int fzp_align_create(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *cons
     }
     // reads
     j->h_read_woff.assign(1, 0);
-    j->h_tb_off.assign(1, 0);
     j->h_cig_off.assign(1, 0);
     for (int64_t r = 0; r < n_reads; r++) {
         int64_t n = read_off[r + 1] - read_off[r];
@@ -2383,14 +2229,13 @@ extern "C" int fzp_align_create(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *cons
         j->h_read_ctg.push_back(read_ctg[r]);
         j->read_words += ((n + 15) / 16 + 8 + 1) & ~1LL;
         j->h_read_woff.push_back(j->read_words);
-        j->h_tb_off.push_back(j->h_tb_off.back() + (n + n + n / 4 + 64 + 2 + 63) / 64 * 64);   // steps capacity, multiple of 64
         j->h_cig_off.push_back(j->h_cig_off.back() + n + 18);
     }
     DevBuf<uint8_t> d_ascii;
     DevBuf<int64_t> d_off;
     do {
         // contigs: ASCII straight into ctg_ascii (pinned, chunked, threaded staging), upper-cased and packed on the device
-        if ((rc = j->ctg_pk.alloc((size_t)j->ctg_words + 8)) || (rc = j->ctg_ascii.alloc((size_t)coff.back() + 16)) || (rc = d_off.upload(coff.data(), coff.size(), st)) ||
+        if ((rc = j->ctg_pk.alloc((size_t)j->ctg_words + 8)) || (rc = j->ctg_rc.alloc((size_t)j->ctg_words + 8)) || (rc = j->ctg_ascii.alloc((size_t)coff.back() + 16)) || (rc = d_off.upload(coff.data(), coff.size(), st)) ||
             (rc = j->ctg_woff.upload(j->h_ctg_woff.data(), j->h_ctg_woff.size(), st)) || (rc = j->ctg_len.upload(j->h_ctg_len.data(), j->h_ctg_len.size(), st)) ||
             (rc = j->idx_off.upload(j->h_idx_off.data(), j->h_idx_off.size(), st)) || (rc = j->idx_bits.upload(j->h_idx_bits.data(), j->h_idx_bits.size(), st)))
             break;
@@ -2406,12 +2251,13 @@ extern "C" int fzp_align_create(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *cons
             DevBuf<int64_t> d_be;
             if ((rc = d_be.upload(be.data(), be.size(), st))) break;
             hipLaunchKernelGGL(k_pack2, dim3(n_ctg, 64), dim3(256), 0, st, j->ctg_ascii.p, d_be.p, j->ctg_woff.p, j->ctg_pk.p);
+            hipLaunchKernelGGL(k_revcomp<int64_t>, dim3(n_ctg, 64), dim3(256), 0, st, (const uint32_t *)j->ctg_pk.p, (const int64_t *)j->ctg_woff.p, (const int64_t *)j->ctg_len.p, j->ctg_rc.p);
             if (hipStreamSynchronize(st) != hipSuccess) { rc = FZP_EDEVICE; break; }
         }
         j->h_ctg_aoff = coff;
         if (n_reads) {
             const size_t rbytes = (size_t)(read_off[n_reads] - read_off[0]);
-            if ((rc = j->read_pk.alloc((size_t)j->read_words + 8)) || (rc = j->read_ori.alloc((size_t)j->read_words + 8)) || (rc = d_ascii.alloc(rbytes + 16)))
+            if ((rc = j->read_pk.alloc((size_t)j->read_words + 8)) || (rc = j->read_rc.alloc((size_t)j->read_words + 8)) || (rc = d_ascii.alloc(rbytes + 16)))
                 break;
             {
                 std::vector<const void *> srcs(1, read_seq + read_off[0]); std::vector<size_t> dsts(1, 0), lens(1, rbytes);
@@ -2421,9 +2267,10 @@ extern "C" int fzp_align_create(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *cons
             for (int64_t r = 0; r <= n_reads; r++) roff[(size_t)r] = read_off[r] - read_off[0];
             if ((rc = d_off.upload(roff.data(), roff.size(), st)) || (rc = j->read_woff.upload(j->h_read_woff.data(), j->h_read_woff.size(), st)) ||
                 (rc = j->read_len.upload(j->h_read_len.data(), j->h_read_len.size(), st)) || (rc = j->read_ctg.upload(j->h_read_ctg.data(), j->h_read_ctg.size(), st)) ||
-                (rc = j->tb_off.upload(j->h_tb_off.data(), j->h_tb_off.size(), st)) || (rc = j->cig_off.upload(j->h_cig_off.data(), j->h_cig_off.size(), st)))
+                (rc = j->cig_off.upload(j->h_cig_off.data(), j->h_cig_off.size(), st)))
                 break;
             hipLaunchKernelGGL(k_pack, dim3((unsigned)n_reads, 1), dim3(256), 0, st, d_ascii.p, d_off.p, j->read_woff.p, j->read_pk.p);
+            hipLaunchKernelGGL(k_revcomp<int32_t>, dim3((unsigned)n_reads, 1), dim3(256), 0, st, (const uint32_t *)j->read_pk.p, (const int64_t *)j->read_woff.p, (const int32_t *)j->read_len.p, j->read_rc.p);
             if (hipStreamSynchronize(st) != hipSuccess) { rc = FZP_EDEVICE; break; }
         }
         {   // partitions of every contig's table (k_index_stage / k_index_build)
@@ -2443,8 +2290,9 @@ extern "C" int fzp_align_create(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *cons
                 break;
             if (hipStreamSynchronize(st) != hipSuccess) { rc = FZP_EDEVICE; break; }
         }
-        if ((rc = j->table.alloc((size_t)j->idx_slots)) || (rc = j->anc.alloc((size_t)n_reads)) || (rc = j->ancB.alloc((size_t)n_reads)) || (rc = j->tbo.alloc((size_t)n_reads)) ||
-            (rc = j->mvo.alloc((size_t)n_reads)) || (rc = j->n_sec.alloc(1)) || (rc = j->info.alloc((size_t)n_reads)) ||
+        if ((rc = j->table.alloc((size_t)j->idx_slots)) || (rc = j->anc.alloc((size_t)n_reads)) || (rc = j->ancB.alloc((size_t)n_reads)) || (rc = j->n_sec.alloc(1)) ||
+            (rc = j->n_wp.alloc((size_t)2 * n_reads)) || (rc = j->wps.alloc((size_t)2 * n_reads * MAX_WP)) || (rc = j->r_cnt.alloc((size_t)n_reads + 1)) || (rc = j->r_capq.alloc((size_t)n_reads + 1)) ||
+            (rc = j->slot_base.alloc((size_t)n_reads + 1)) || (rc = j->rcapq_scan.alloc((size_t)n_reads + 1)) || (rc = j->rtot.alloc(2)) ||
             (rc = j->summ.alloc((size_t)n_reads)) || (rc = j->cig.alloc((size_t)j->h_cig_off.back())) || (rc = j->cig_start.alloc((size_t)n_reads)))
             break;
         if ((rc = build_index(ctx, j))) break;
@@ -2465,7 +2313,7 @@ extern "C" int fzp_align_invalidate_index(fzp_alnjob *j) {
 extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
     if (!ctx || !j) return FZP_EINVAL;
     FZP_TRY(fzp_bind(ctx));
-    hipStream_t st = ctx->stream;
+    hipStream_t st = ctx->stream, st2 = ctx->stream2, st3 = ctx->stream3;
     const fzp_align_params &P = j->P;
     if (!j->index_built || getenv("FZP_INDEX_PER_RUN")) FZP_TRY(build_index(ctx, j));     // normally built by fzp_align_create
     const int64_t nr = j->n_reads;
@@ -2479,390 +2327,165 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
             const size_t lds = (size_t)2 * (size_t)nb_max * sizeof(uint32_t);
             FZP_HIP(hipFuncSetAttribute((const void *)k_seed, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             FZP_HIP(hipMemsetAsync(j->n_sec.p, 0, 4, st));
-            const int64_t seed_chunk = 65536;            // reads per seeding launch: HIT_CAP x 8 B of hit list each (2 GiB)
+            const int64_t seed_chunk = 65536;            // reads per seeding launch: HIT_CAP x 12 B of hit list and waypoint links each (3 GiB)
             FZP_TRY(j->hits.alloc((size_t)std::min<int64_t>(nr, seed_chunk) * HIT_CAP));
+            FZP_TRY(j->wpp.alloc((size_t)std::min<int64_t>(nr, seed_chunk) * HIT_CAP));
             FZP_TRY(j->win.alloc((size_t)std::min<int64_t>(nr, seed_chunk)));
             for (int64_t f0 = 0; f0 < nr; f0 += seed_chunk) {
                 const int64_t cn = std::min<int64_t>(seed_chunk, nr - f0);
                 hipLaunchKernelGGL(k_seed, dim3((unsigned)cn), dim3(256), lds, st, f0, j->read_pk.p, j->read_woff.p, j->read_len.p,
                                    j->read_ctg.p, j->ctg_len.p, j->idx_off.p, j->idx_bits.p, j->table.p, P.kmer, P.seed_stride, P.min_seed_hits, j->hits.p, j->win.p);
-                hipLaunchKernelGGL(k_chain, dim3((unsigned)(2 * cn)), dim3(64), 0, st, f0, cn, j->read_len.p, j->hits.p, j->win.p, j->anc.p, j->ancB.p);
+                hipLaunchKernelGGL(k_chain, dim3((unsigned)(2 * cn)), dim3(64), 0, st, f0, cn, j->read_len.p, j->hits.p, j->win.p, j->anc.p, j->ancB.p, j->wpp.p, j->n_wp.p, j->wps.p);
             }
-            hipLaunchKernelGGL(k_sec_count, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, st, nr, j->ancB.p, j->n_sec.p);
         }
+        // ---- the extension pieces of every read (v1.6) as DP slots: counted per read on the device, the two scans give every read its first slot and its share of the
+        // mask capacity; the scans come to the host (8 bytes per read), which only cuts the reads into chunks that fit the mask budget -- everything else is planned on the device
+        std::vector<uint32_t> h_sb((size_t)nr + 1), h_cq((size_t)nr + 1);
         {
-            ProfScope ps(ctx, "k1_orient");
-            hipLaunchKernelGGL(k_orient, dim3((unsigned)nr, 1), dim3(256), 0, st, (int64_t)0, j->read_pk.p, j->read_woff.p, j->read_len.p, j->anc.p, (const int32_t *)nullptr,
-                               j->read_woff.p, j->read_ori.p);
+            ProfScope ps(ctx, "k1_plan_dp");
+            hipLaunchKernelGGL(k_slot_count, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, st, nr, j->anc.p, j->ancB.p, j->n_wp.p, j->wps.p, j->read_len.p, j->read_ctg.p, j->ctg_len.p,
+                               j->r_cnt.p, j->r_capq.p, j->n_sec.p);
         }
-        // second candidates (reads whose votes show a second placement: repeats).  Usually none; then nothing below runs.
+        FZP_TRY(fzp_exclusive_scan_u32(ctx, j->r_cnt.p, j->slot_base.p, (size_t)nr, j->rtot.p + 0));
+        FZP_TRY(fzp_exclusive_scan_u32(ctx, j->r_capq.p, j->rcapq_scan.p, (size_t)nr, j->rtot.p + 1));
         uint32_t n2 = 0;
         int32_t ovf = 0;
-        std::vector<Anchor> h_anc((size_t)nr);              // the first candidates' anchors: how far back an extension may have to reach (v1.4)
+        uint64_t rtot[2] = {0, 0};
         FZP_HIP(hipMemcpyAsync(&n2, j->n_sec.p, 4, hipMemcpyDeviceToHost, st));
         FZP_HIP(hipMemcpyAsync(&ovf, j->idx_overflow.p, 4, hipMemcpyDeviceToHost, st));
-        FZP_TRY(j->anc.download(h_anc.data(), (size_t)nr, st));
+        FZP_HIP(hipMemcpyAsync(rtot, j->rtot.p, 16, hipMemcpyDeviceToHost, st));
+        FZP_TRY(j->slot_base.download(h_sb.data(), (size_t)nr, st));
+        FZP_TRY(j->rcapq_scan.download(h_cq.data(), (size_t)nr, st));
         FZP_HIP(hipStreamSynchronize(st));
-        std::vector<int32_t> b_cap((size_t)nr);
-        for (int64_t r = 0; r < nr; r++) b_cap[(size_t)r] = (h_anc[(size_t)r].aligned && h_anc[(size_t)r].c_a > 0) ? h_anc[(size_t)r].i_a : 0;
         if (ovf) { fzp_set_error("k-mer index: a table partition overflowed (more than %d distinct k-mers hash into one 64 KB partition)", 4 << PART_BITS); return FZP_EINVAL; }
+        if (rtot[0] >= (1ull << 31) || rtot[1] >= (1ull << 31)) { fzp_set_error("fzp_align_run: %llu extension pieces / %llu x 64 DP steps in one job (limit 2^31 each)", (unsigned long long)rtot[0], (unsigned long long)rtot[1]); return FZP_EINVAL; }
+        h_sb[(size_t)nr] = (uint32_t)rtot[0]; h_cq[(size_t)nr] = (uint32_t)rtot[1];
+        FZP_HIP(hipMemcpyAsync(j->slot_base.p + nr, &h_sb[(size_t)nr], 4, hipMemcpyHostToDevice, st));
+        FZP_HIP(hipMemcpyAsync(j->rcapq_scan.p + nr, &h_cq[(size_t)nr], 4, hipMemcpyHostToDevice, st));
         j->n_second = n2;
-        std::vector<int32_t> h_ridx;
-        std::vector<int64_t> h_tb_off2(1, 0);
-        if (n2) {
-            std::vector<Anchor> hb((size_t)nr), h2;
-            FZP_TRY(j->ancB.download(hb.data(), (size_t)nr, st));
-            FZP_HIP(hipStreamSynchronize(st));
-            std::vector<int64_t> h_woff2(1, 0);
-            for (int64_t r = 0; r < nr; r++) {
-                if (!hb[(size_t)r].aligned) continue;
-                const int64_t n = j->h_read_len[(size_t)r];
-                h_ridx.push_back((int32_t)r);
-                h2.push_back(hb[(size_t)r]);
-                if (hb[(size_t)r].c_a > 0) b_cap[(size_t)r] = std::max(b_cap[(size_t)r], hb[(size_t)r].i_a);     // whichever candidate wins
-                h_woff2.push_back(h_woff2.back() + (((n + 15) / 16 + 8 + 1) & ~1LL));
-                h_tb_off2.push_back(h_tb_off2.back() + (n + n + n / 4 + 64 + 2 + 63) / 64 * 64);
-            }
-            n2 = (uint32_t)h_ridx.size();
-            FZP_TRY(j->ridx.upload(h_ridx.data(), n2, st)); FZP_TRY(j->anc2.upload(h2.data(), n2, st));
-            FZP_TRY(j->sec_woff.upload(h_woff2.data(), h_woff2.size(), st)); FZP_TRY(j->tb_off2.upload(h_tb_off2.data(), h_tb_off2.size(), st));
-            FZP_TRY(j->sec_ori.alloc((size_t)h_woff2.back() + 8)); FZP_TRY(j->info2.alloc(n2)); FZP_TRY(j->won.alloc(n2));
-            FZP_HIP(hipStreamSynchronize(st));      // the staging vectors die with this scope
-            ProfScope ps(ctx, "k1_orient");
-            hipLaunchKernelGGL(k_orient, dim3(n2, 1), dim3(256), 0, st, (int64_t)0, j->read_pk.p, j->read_woff.p, j->read_len.p, j->anc2.p, j->ridx.p, j->sec_woff.p, j->sec_ori.p);
-        }
-        // ---- backward extension (v1.4): per read room for the reversed prefix (as long as the deeper of its candidates' anchors), the reversed contig
-        // window and the masks of that DP.  Typical anchors sit a few hundred bases into the read: a few per cent of the forward work.
-        {
-            std::vector<int64_t> qo((size_t)nr + 1, 0), to((size_t)nr + 1, 0);
-            j->h_tb_off_b.assign((size_t)nr + 1, 0);
-            for (int64_t r = 0; r < nr; r++) {
-                const int64_t cq = b_cap[(size_t)r], ct = cq ? cq + cq / 4 + 64 : 0;
-                qo[(size_t)r + 1] = qo[(size_t)r] + (cq ? (((cq + 15) / 16 + 8 + 1) & ~1LL) : 0);
-                to[(size_t)r + 1] = to[(size_t)r] + (cq ? (((ct + 15) / 16 + 8 + 1) & ~1LL) : 0);
-                j->h_tb_off_b[(size_t)r + 1] = j->h_tb_off_b[(size_t)r] + (cq ? (cq + ct + 2 + 63) / 64 * 64 : 0);
-            }
-            FZP_TRY(j->bq_off.upload(qo.data(), qo.size(), st)); FZP_TRY(j->bt_off.upload(to.data(), to.size(), st));
-            FZP_TRY(j->tb_off_b.upload(j->h_tb_off_b.data(), j->h_tb_off_b.size(), st));
-            FZP_TRY(j->bq.alloc((size_t)qo.back() + 16)); FZP_TRY(j->bt.alloc((size_t)to.back() + 16));
-            FZP_TRY(j->anc_b.alloc((size_t)nr)); FZP_TRY(j->info_b.alloc((size_t)nr)); FZP_TRY(j->b_len.alloc((size_t)nr)); FZP_TRY(j->b_tlen.alloc((size_t)nr));
-            FZP_TRY(j->tbo_b.alloc((size_t)nr)); FZP_TRY(j->mvo_b.alloc((size_t)nr)); FZP_TRY(j->wout_b.alloc((size_t)nr));
-            if (j->b_iota.n < (size_t)nr) {
-                std::vector<int32_t> io((size_t)nr);
-                for (int64_t r = 0; r < nr; r++) io[(size_t)r] = (int32_t)r;
-                FZP_TRY(j->b_iota.upload(io.data(), (size_t)nr, st));
-            }
-            FZP_HIP(hipStreamSynchronize(st));      // the staging vectors die with this scope
-        }
-        // Trace-back masks live in HBM (16 B per DP step).  Reads go through in chunks: the DP of chunk k+1
-        // (integer-VALU bound, every wave slot busy, no LDS) runs on `stream` while the trace-back of chunk k
-        // (latency bound, 2 LDS-heavy waves per CU) runs on `stream2`; two mask buffers alternate.
+        // Trace-back masks live in HBM (16 B per DP step).  Reads go through in chunks: the DP of chunk k+1 runs on `stream` while the trace-back of chunk k
+        // runs on `stream2`; two sets of buffers alternate.
         int64_t budget_steps = (int64_t)48 << 30 >> 4;   // 48 GiB of 16-byte steps over both buffers
         if (const char *e = getenv("FZP_TB_BUDGET_GB")) { long g = atol(e); if (g > 0) budget_steps = ((int64_t)g << 30) >> 4; }
-        int n_chunks = 1;   // measured: overlapping the two kernels costs more than it hides (contention, chunk tails)
+        int n_chunks = 1;
         if (const char *e = getenv("FZP_SW_CHUNKS")) { int g = atoi(e); if (g > 0) n_chunks = g; }
-        bool split_rounds = false;      // measured (r2): 43.4 vs 41.3 ms for K1 at cfg2 -- the trace-back under a second DP launch runs at 1/9 of a SIMD's issue slots
-        if (const char *e = getenv("FZP_SW_SPLIT_ROUNDS")) split_rounds = atoi(e) != 0;
-        const int64_t total_steps = j->h_tb_off[(size_t)nr];
-        int64_t chunk_steps = std::min<int64_t>(budget_steps / 2, (total_steps + n_chunks - 1) / n_chunks);
-        FZP_TRY(j->wout.alloc((size_t)nr));
-        FZP_TRY(j->tb_fallback.alloc(4));
-        FZP_TRY(j->tb_fallback.zero(4, st));
-        if (!j->ev_sw[0]) for (int k = 0; k < 2; k++) { FZP_HIP(hipEventCreateWithFlags(&j->ev_l[k], hipEventDisableTiming)); FZP_HIP(hipEventCreateWithFlags(&j->ev_sw[k], hipEventDisableTiming)); FZP_HIP(hipEventCreateWithFlags(&j->ev_tb[k], hipEventDisableTiming)); FZP_HIP(hipEventCreateWithFlags(&j->ev_bk[k], hipEventDisableTiming)); }
-        hipStream_t st2 = ctx->stream2;
-        if (j->lpt_chunk_steps != chunk_steps || split_rounds) {
-            // launch order inside every chunk of reads: longest first (LPT over the wave slots).  One wave per read, workgroups dispatched in
-            // index order: with reads of uneven length in input order the grid's tail is whatever long read happened to come last.
-            std::vector<int32_t> ord((size_t)nr), sgo((size_t)nr), sgs, sgi, sgw;
-            std::vector<int64_t> h_tbm((size_t)nr), h_mvm((size_t)nr);
-            std::vector<uint8_t> sg1((size_t)nr);
-            j->h_seg_base.assign((size_t)nr + 1, 0); j->h_seg_cnt.assign((size_t)nr + 1, 0);
-            for (int64_t f = 0; f < nr;) {
-                int64_t l = f;
-                while (l < nr && j->h_tb_off[(size_t)l + 1] - j->h_tb_off[(size_t)f] <= chunk_steps) l++;
-                if (l == f) l = f + 1;
-                if (split_rounds && f == 0 && l == nr) {
-                    const int64_t slots = (int64_t)ctx->n_cu * 32, full = nr / slots * slots;
-                    if (full >= slots && nr - full >= slots / 8) l = full;
-                }
-                for (int64_t r = f; r < l; r++) ord[(size_t)r] = (int32_t)(r - f);
-                std::stable_sort(ord.begin() + f, ord.begin() + l, [&](int32_t a, int32_t b) { return j->h_read_len[(size_t)(f + a)] > j->h_read_len[(size_t)(f + b)]; });
-                {   // mask streams in the same order, interleaved block by block within every group of 64 (= a wave of the bit-sliced kernel, give or take the slots
-                    // that go to k_sw): block b of the group's x-th stream starts at record (b * 64 + x) * 64 of the group's region -- what a wave writes
-                    // during 64 steps lies within 64 KB instead of in 64 places half a megabyte apart (address translation was a third of that kernel's time)
-                    int64_t acc = 0, region = 0;
-                    const bool contig = getenv("FZP_TB_CONTIG") != nullptr;      // comparison switch: every stream on its own, in launch order (stride 64)
-                    if (j->h_tbm_total.size() < (size_t)nr + 1) j->h_tbm_total.assign((size_t)nr + 1, 0);
-                    for (int64_t g0 = 0; g0 < l - f; g0 += 64) {
-                        const int64_t gn = std::min<int64_t>(64, l - f - g0);
-                        int64_t cap_max = 0;
-                        for (int64_t x = g0; x < g0 + gn; x++) { const int64_t r = f + ord[(size_t)(f + x)]; cap_max = std::max(cap_max, j->h_tb_off[(size_t)r + 1] - j->h_tb_off[(size_t)r]); }
-                        for (int64_t x = g0; x < g0 + gn; x++) {
-                            const int64_t r = f + ord[(size_t)(f + x)];
-                            h_tbm[(size_t)r] = contig ? acc : region + (x - g0) * 64; h_mvm[(size_t)r] = (acc >> 6) + x;
-                            acc += j->h_tb_off[(size_t)r + 1] - j->h_tb_off[(size_t)r];
-                        }
-                        region += 64 * cap_max;
-                    }
-                    j->h_tbm_total[(size_t)f] = contig ? acc : region;
-                }
-                // walkers of the segmented trace-back: one per TBS_SEG steps of every read's step capacity, longest reads first
-                j->h_seg_base[(size_t)f] = (int64_t)sgs.size();
-                std::vector<int32_t> w_first((size_t)(l - f));
-                int64_t nw_chunk = 0;
-                const int64_t single_steps = getenv("FZP_TB_SINGLE_STEPS") ? atol(getenv("FZP_TB_SINGLE_STEPS")) : TBS_SINGLE_STEPS;
-                auto n_walkers = [&](int64_t r) { const int64_t cap = j->h_tb_off[(size_t)r + 1] - j->h_tb_off[(size_t)r]; return cap <= single_steps ? (int64_t)1 : (cap + TBS_SEG - 1) / TBS_SEG; };
-                for (int64_t r = f; r < l; r++) { sgo[(size_t)r] = (int32_t)nw_chunk; nw_chunk += n_walkers(r); }
-                if (nw_chunk >= (1ll << 31)) { fzp_set_error("fzp_align_run: too many trace-back segments in one chunk"); return FZP_EINVAL; }
-                sgs.resize(sgs.size() + (size_t)nw_chunk); sgi.resize(sgs.size());
-                for (int64_t r = f; r < l; r++) {
-                    const int64_t ns = n_walkers(r);
-                    const bool one = j->h_tb_off[(size_t)r + 1] - j->h_tb_off[(size_t)r] <= single_steps;
-                    sg1[(size_t)r] = one ? 1 : 0;
-                    for (int64_t x = 0; x < ns; x++) { sgs[(size_t)(j->h_seg_base[(size_t)f] + sgo[(size_t)r] + x)] = (int32_t)(r - f); sgi[(size_t)(j->h_seg_base[(size_t)f] + sgo[(size_t)r] + x)] = one ? -1 : (int32_t)x; }
-                }
-                j->h_seg_cnt[(size_t)f] = nw_chunk;
-                {   // launch order of the chunk's walkers: whole-read walkers by decreasing read length, then the segment walkers
-                    sgw.resize(sgs.size());
-                    int32_t *wo = sgw.data() + j->h_seg_base[(size_t)f];
-                    int64_t at = 0;
-                    for (int64_t x = 0; x < l - f; x++) { const int64_t r = f + ord[(size_t)(f + x)]; if (sg1[(size_t)r]) wo[at++] = sgo[(size_t)r]; }
-                    for (int64_t r = f; r < l; r++) if (!sg1[(size_t)r]) for (int64_t x = 0; x < n_walkers(r); x++) wo[at++] = (int32_t)(sgo[(size_t)r] + x);
-                }
-                f = l;
-            }
-            FZP_TRY(j->lpt.upload(ord.data(), (size_t)nr, st));
-            j->h_lpt = ord;
-            FZP_TRY(j->tbm_off.upload(h_tbm.data(), (size_t)nr, st)); FZP_TRY(j->mvm_off.upload(h_mvm.data(), (size_t)nr, st));
-            FZP_HIP(hipStreamSynchronize(st));      // (staging vectors)
-            FZP_TRY(j->seg_off.upload(sgo.data(), (size_t)nr, st));
-            FZP_TRY(j->seg_single.upload(sg1.data(), (size_t)nr, st));
-            FZP_TRY(j->seg_order.upload(sgw.data(), sgw.size(), st));
-            FZP_TRY(j->seg_slot.upload(sgs.data(), sgs.size(), st)); FZP_TRY(j->seg_idx.upload(sgi.data(), sgi.size(), st));
-            j->lpt_chunk_steps = split_rounds ? -1 : chunk_steps;
-        }
-        const bool use_lpt = getenv("FZP_SW_INPUT_ORDER") == nullptr;      // FZP_SW_INPUT_ORDER=1: the r2 launch order, for comparisons
-        const bool use_prio = getenv("FZP_SW_NO_PRIO") == nullptr;
-        int guess_lane = -1;                                                    // -1: the lane k_sw recorded (best H of the segment's top step); tests push it to the band's edge to exercise the fallback
-        if (const char *e = getenv("FZP_TB_GUESS_LANE")) { const int g = atoi(e); if (g >= 0 && g < 64) guess_lane = g; }
-        int ov_limit = TBS_OV, REPAIR_ROUNDS = 3;                               // test switches: a shorter search for the common cell (forces repair walks), fewer repair rounds (forces the serial walk)
-        if (const char *e = getenv("FZP_TB_OV_LIMIT")) { const int g = atoi(e); if (g >= 1 && g <= TBS_OV) ov_limit = g; }
-        if (const char *e = getenv("FZP_TB_REPAIR_ROUNDS")) { const int g = atoi(e); if (g >= 0 && g <= 8) REPAIR_ROUNDS = g; }
-        const bool tb_serial = getenv("FZP_TB_SERIAL") != nullptr;             // FZP_TB_SERIAL=1: the r2 trace-back (one walker per read), for comparisons
-        const bool no_masks = getenv("FZP_SW_NO_MASKS") != nullptr;          // MEASUREMENT ONLY: the DP without its trace-back stores; the alignments that follow are garbage
-        int64_t sum_len = 0;
-        for (int64_t r = 0; r < nr; r++) sum_len += j->h_read_len[(size_t)r];
-        const int32_t mean_len = (int32_t)std::max<int64_t>(1, sum_len / std::max<int64_t>(nr, 1));
-        // ---- which DP kernel runs which extension (fzalign scores 2 / -4 / -3 are built into the bit-sliced one's cell function)
-        bool use_bits = getenv("FZP_SW_NO_BITS") == nullptr && P.match == 2 && P.mismatch == 4 && P.gap == 3 && !split_rounds && use_lpt;
-        // the bit-sliced kernel has two forms.  A pair of lanes per read (k_swb2) has the shorter step (112 against 135 instructions on the wave's critical path) but twice the
-        // waves, and its instruction mix (v_bitop3, DPP, 3-operand forms) issues at ~4.5 cycles per SIMD however many waves share it: two such waves on one SIMD run at half
-        // speed each.  So it is taken when its waves get a SIMD each and nothing else runs beside them; else the whole band sits in one lane (k_swb).  FZP_SWB_64 / FZP_SWB_PAIR force one.
+        const int64_t total_steps = (int64_t)rtot[1] * 64;
+        const int64_t chunk_steps = std::min<int64_t>(budget_steps / 2, (total_steps + n_chunks - 1) / n_chunks);
+        if (!j->ev_sw[0]) for (int k = 0; k < 2; k++) { FZP_HIP(hipEventCreateWithFlags(&j->ev_l[k], hipEventDisableTiming)); FZP_HIP(hipEventCreateWithFlags(&j->ev_sw[k], hipEventDisableTiming)); FZP_HIP(hipEventCreateWithFlags(&j->ev_tb[k], hipEventDisableTiming)); }
+        // ---- which DP kernel runs which slot (fzalign scores 2 / -4 / -3 are built into the bit-sliced one's cell function)
+        const bool use_bits = getenv("FZP_SW_NO_BITS") == nullptr && P.match == 2 && P.mismatch == 4 && P.gap == 3;
+        // the bit-sliced kernel has two forms.  A pair of lanes per slot (k_swb2) has the shorter step but twice the waves, and its instruction mix issues at ~4.5 cycles per
+        // SIMD however many waves share it: two such waves on one SIMD run at half speed each.  So it is taken when its waves get a SIMD each; else the whole band sits in one
+        // lane (k_swb).  FZP_SWB_64 / FZP_SWB_PAIR force one.
         const int swb_force = getenv("FZP_SWB_64") ? 64 : (getenv("FZP_SWB_PAIR") ? 32 : 0);
-        const int32_t m_stride = getenv("FZP_TB_CONTIG") ? 64 : 64 * 64;
-        const bool swb_ring = getenv("FZP_SWB_NO_RING") == nullptr;        // k_swb's base streams through LDS rings (the backward extensions are too short to gain: straight from HBM)
-        int64_t swb_max_steps = 40960;          // ~ 18 kb reads: a lane's step costs ~330 ns, the chain of a longer extension would outlast the rest of the launch
+        const bool swb_ring = getenv("FZP_SWB_NO_RING") == nullptr;        // k_swb's base streams through LDS rings
+        int64_t swb_max_steps = 40960;          // a lane's step costs ~300 ns: a longer extension's chain would outlast the rest of the launch (pieces are a few thousand steps; only reads of > 90 kb have longer ones)
         if (const char *e = getenv("FZP_SWB_MAX_STEPS")) { const long g = atol(e); if (g > 0) swb_max_steps = g; }
-        std::vector<int64_t> &swb_at = j->h_swb_at, &sw_at = j->h_sw_at;
-        if (use_bits) {
-            j->h_swb_list.clear(); j->h_sw_list.clear(); swb_at.assign(1, 0); sw_at.assign(1, 0);
-            const int32_t *ordp = j->h_lpt.data();              // the cached longest-first order of every chunk
-            for (int64_t f = 0; f < nr;) {
-                int64_t l = f;
-                while (l < nr && j->h_tb_off[(size_t)l + 1] - j->h_tb_off[(size_t)f] <= chunk_steps) l++;
-                if (l == f) l = f + 1;
-                const bool swb_in_order = getenv("FZP_SWB_INPUT_ORDER") != nullptr;
-                for (int64_t x = 0; x < l - f; x++) {
-                    const int32_t w = swb_in_order ? (int32_t)x : ordp[(size_t)(f + x)];
-                    const int64_t r = f + w;
-                    const Anchor &a = h_anc[(size_t)r];
-                    const int64_t nq = j->h_read_len[(size_t)r] - a.i_a, nt = std::min<int64_t>(j->h_ctg_len[(size_t)j->h_read_ctg[(size_t)r]] - a.c_a, nq + nq / 4 + 64);
-                    if (a.aligned && nq >= 64 && nt >= 64 && nq + nt + 2 <= swb_max_steps) j->h_swb_list.push_back(w); else j->h_sw_list.push_back(w);
-                }
-                while (j->h_swb_list.size() % 64) j->h_swb_list.push_back(-1);
-                swb_at.push_back((int64_t)j->h_swb_list.size()); sw_at.push_back((int64_t)j->h_sw_list.size());
-                f = l;
-            }
-            if (j->h_swb_list.empty()) j->h_swb_list.push_back(-1);
-            if (j->h_sw_list.empty()) j->h_sw_list.push_back(0);
-            FZP_TRY(j->swb_list.upload(j->h_swb_list.data(), j->h_swb_list.size(), st));
-            FZP_TRY(j->sw_list.upload(j->h_sw_list.data(), j->h_sw_list.size(), st));
-        }
         int64_t first = 0;
         int k = 0;
-        int ci = -1;
         bool used[2] = {false, false};
-        size_t w_lo = 0;
         while (first < nr) {
             int64_t last = first;
-            while (last < nr && j->h_tb_off[(size_t)last + 1] - j->h_tb_off[(size_t)first] <= chunk_steps) last++;
+            while (last < nr && ((int64_t)h_cq[(size_t)last + 1] - (int64_t)h_cq[(size_t)first]) * 64 <= chunk_steps) last++;
             if (last == first) last = first + 1;
-            ci++;
-            // whole rounds first: k_sw runs one wave per read on n_CU x 32 wave slots, and reads of similar length finish round by round.
-            // Cutting the launch after the last FULL round lets the trace-back of those reads (HBM / latency bound, few waves) run under the
-            // DP of the remainder, which leaves slots free anyway.
-            if (split_rounds && first == 0 && last == nr) {
-                const int64_t slots = (int64_t)ctx->n_cu * 32;
-                const int64_t full = nr / slots * slots;
-                if (full >= slots && nr - full >= slots / 8) last = full;
-            }
             const int64_t cnt = last - first;
-            const int64_t steps = j->h_tb_off[(size_t)last] - j->h_tb_off[(size_t)first];
+            const uint32_t s_lo = h_sb[(size_t)first], ns = h_sb[(size_t)last] - s_lo;
+            const int64_t capq = (int64_t)h_cq[(size_t)last] - (int64_t)h_cq[(size_t)first];
             const int bi = k & 1;
-            if (used[bi]) FZP_HIP(hipStreamWaitEvent(st, j->ev_tb[bi], 0));   // buffer free again?
-            // the chunk's second candidates sit behind the first ones in the same mask / move-word buffers
-            size_t w_hi = w_lo;
-            while (w_hi < h_ridx.size() && h_ridx[w_hi] < last) w_hi++;
-            const int64_t c2 = (int64_t)(w_hi - w_lo), steps2 = h_tb_off2[w_hi] - h_tb_off2[w_lo];
-            const int64_t tsteps = use_bits ? j->h_tbm_total[(size_t)first] : steps;      // records the chunk's first-candidate masks span (planned streams have some slack)
-            const int64_t tb_base = tsteps + 64, mv_base = steps / 64 + cnt + 2;
-            FZP_TRY(j->tbs.alloc((size_t)nr));
-            FZP_TRY(j->tb2[bi].alloc((size_t)(tb_base + steps2) * 2 + 128));
-            FZP_TRY(j->mvw2[bi].alloc((size_t)(mv_base + steps2 / 64 + c2 + 2)));
-            FZP_TRY(j->raw2[bi].alloc((size_t)(steps / 16 + 64)));
-            const bool dp_chain = getenv("FZP_DP_NO_CHAIN") == nullptr;
-            std::unique_lock<std::mutex> dp_lk(g_dp_mu, std::defer_lock);
-            if (dp_chain) {
-                dp_lk.lock();
-                auto it = g_dp_last.find(ctx->device);
-                if (it != g_dp_last.end()) FZP_HIP(hipStreamWaitEvent(st, it->second, 0));
+            ChunkBufs &B = j->cb[bi];
+            if (used[bi]) FZP_HIP(hipStreamWaitEvent(st, j->ev_tb[bi], 0));   // buffers free again?
+            FZP_TRY(B.rpath.alloc((size_t)cnt));
+            FZP_TRY(B.rraw.alloc((size_t)capq * 4 + 64));
+            if (ns > 0) {
+                const uint32_t nblk = (ns + 255) / 256, ngrp = (ns + 63) / 64;
+                FZP_TRY(B.slots.alloc(ns)); FZP_TRY(B.bh.alloc((size_t)SORT_CLASSES * nblk)); FZP_TRY(B.sorted.alloc(ns)); FZP_TRY(B.fits.alloc(ns)); FZP_TRY(B.pos_b.alloc(ns));
+                FZP_TRY(B.list.alloc(ns)); FZP_TRY(B.lq.alloc(ns)); FZP_TRY(B.lq_scan.alloc(ns)); FZP_TRY(B.gq.alloc(ngrp)); FZP_TRY(B.gq_scan.alloc(ngrp)); FZP_TRY(B.ptot.alloc(4));
+                FZP_TRY(B.tbo.alloc(ns)); FZP_TRY(B.mvo.alloc(ns)); FZP_TRY(B.tbs.alloc(ns)); FZP_TRY(B.info.alloc(ns)); FZP_TRY(B.wout.alloc(ns));
+                // masks: the bit-sliced slots' interleaved groups take 64 x (their longest member) each -- in sorted order at most the slots' own capacity + one group of the longest
+                const int64_t swb_cap = (swb_max_steps + 2 + 63) / 64 * 64;
+                FZP_TRY(B.tb.alloc((size_t)(capq * 64 + 64 * swb_cap + 64) * 2 + 128));
+                FZP_TRY(B.mvw.alloc((size_t)capq + 2));
+                FZP_TRY(B.raw.alloc((size_t)capq * 4 + 64));
+                {
+                    ProfScope ps(ctx, "k1_plan_dp");
+                    hipLaunchKernelGGL(k_slot_emit, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, first, last, j->anc.p, j->ancB.p, j->n_wp.p, j->wps.p, j->read_len.p, j->read_ctg.p, j->ctg_len.p,
+                                       (const uint32_t *)j->slot_base.p, s_lo, B.slots.p);
+                    hipLaunchKernelGGL(k_sort_hist, dim3(nblk), dim3(256), 0, st, ns, nblk, (const Slot *)B.slots.p, B.bh.p);
+                }
+                FZP_TRY(fzp_exclusive_scan_u32(ctx, B.bh.p, B.bh.p, (size_t)SORT_CLASSES * nblk, nullptr));
+                {
+                    ProfScope ps(ctx, "k1_plan_dp");
+                    hipLaunchKernelGGL(k_sort_scatter, dim3(nblk), dim3(256), 0, st, ns, nblk, (const Slot *)B.slots.p, (const uint32_t *)B.bh.p, B.sorted.p);
+                    hipLaunchKernelGGL(k_route, dim3(nblk), dim3(256), 0, st, ns, (const Slot *)B.slots.p, (const uint32_t *)B.sorted.p, (int32_t)swb_max_steps, use_bits ? 1 : 0, B.fits.p);
+                }
+                FZP_TRY(fzp_exclusive_scan_u32(ctx, B.fits.p, B.pos_b.p, ns, B.ptot.p + 0));
+                {
+                    ProfScope ps(ctx, "k1_plan_dp");
+                    FZP_HIP(hipMemsetAsync(B.gq.p, 0, (size_t)ngrp * 4, st));
+                    hipLaunchKernelGGL(k_lists, dim3(nblk), dim3(256), 0, st, ns, (const Slot *)B.slots.p, (const uint32_t *)B.sorted.p, (const uint32_t *)B.fits.p, (const uint32_t *)B.pos_b.p,
+                                       (const uint64_t *)B.ptot.p, B.list.p, B.lq.p, B.gq.p);
+                }
+                FZP_TRY(fzp_exclusive_scan_u32(ctx, B.gq.p, B.gq_scan.p, ngrp, B.ptot.p + 1));
+                FZP_TRY(fzp_exclusive_scan_u32(ctx, B.lq.p, B.lq_scan.p, ns, B.ptot.p + 2));
+                {
+                    ProfScope ps(ctx, "k1_plan_dp");
+                    hipLaunchKernelGGL(k_plan_final, dim3(nblk), dim3(256), 0, st, ns, (const uint32_t *)B.list.p, (const uint32_t *)B.lq_scan.p, (const uint32_t *)B.gq_scan.p,
+                                       (const uint64_t *)B.ptot.p, (const uint64_t *)(B.ptot.p + 1), B.tbo.p, B.mvo.p, B.tbs.p);
+                }
+                // One forward DP at a time per device (g_dp_mu / g_dp_last above): a job's DP launches wait for the event the previous job recorded behind its own
+                const bool dp_chain = getenv("FZP_DP_NO_CHAIN") == nullptr;
+                std::unique_lock<std::mutex> dp_lk(g_dp_mu, std::defer_lock);
+                if (dp_chain) {
+                    dp_lk.lock();
+                    auto it = g_dp_last.find(ctx->device);
+                    if (it != g_dp_last.end()) FZP_HIP(hipStreamWaitEvent(st, it->second, 0));
+                }
+                {
+                    ProfScope ps(ctx, "k1_sw");
+                    // every slot goes to one of the two DP kernels (k_route): the bit-sliced one (a slot per lane) takes those that span the band on both sides, the
+                    // wave-per-slot one the rest -- mostly backward extensions of a few dozen bases -- beside it on a stream of its own
+                    const bool swb64 = swb_force ? swb_force == 64 : !((int64_t)ns / 32 <= (int64_t)ctx->n_cu * 4);
+                    FZP_HIP(hipEventRecord(j->ev_l[0], st));
+                    if (use_bits && !swb64)
+                        hipLaunchKernelGGL(k_swb2, dim3((ns + 127) / 128), dim3(256), 0, st, (const uint64_t *)B.ptot.p, (const uint32_t *)B.list.p, (const Slot *)B.slots.p,
+                                           (const uint32_t *)j->read_pk.p, (const uint32_t *)j->read_rc.p, (const int64_t *)j->read_woff.p, (const uint32_t *)j->ctg_pk.p, (const uint32_t *)j->ctg_rc.p,
+                                           (const int64_t *)j->ctg_woff.p, (const int64_t *)B.tbo.p, (const int64_t *)B.mvo.p, B.tb.p, B.mvw.p, B.info.p);
+                    if (use_bits && swb64)
+                        hipLaunchKernelGGL(swb_ring ? k_swb<true> : k_swb<false>, dim3((ns + 64 * SWB_WPG - 1) / (64 * SWB_WPG)), dim3(64 * SWB_WPG), 0, st, (const uint64_t *)B.ptot.p, (const uint32_t *)B.list.p,
+                                           (const Slot *)B.slots.p, (const uint32_t *)j->read_pk.p, (const uint32_t *)j->read_rc.p, (const int64_t *)j->read_woff.p, (const uint32_t *)j->ctg_pk.p,
+                                           (const uint32_t *)j->ctg_rc.p, (const int64_t *)j->ctg_woff.p, (const int64_t *)B.tbo.p, (const int64_t *)B.mvo.p, B.tb.p, B.mvw.p, B.info.p,
+                                           getenv("FZP_SWB_DBG") ? atoi(getenv("FZP_SWB_DBG")) : 0);
+                    FZP_HIP(hipStreamWaitEvent(st3, j->ev_l[0], 0));
+                    hipLaunchKernelGGL(k_sw<true>, dim3(ns), dim3(64), 0, st3, ns, (const uint64_t *)B.ptot.p, (const uint32_t *)B.list.p, (const Slot *)B.slots.p,
+                                       (const uint32_t *)j->read_pk.p, (const uint32_t *)j->read_rc.p, (const int64_t *)j->read_woff.p, (const uint32_t *)j->ctg_pk.p, (const uint32_t *)j->ctg_rc.p,
+                                       (const int64_t *)j->ctg_woff.p, (const int64_t *)B.tbo.p, (const int64_t *)B.mvo.p, (const int32_t *)B.tbs.p, B.tb.p, B.mvw.p, P.match, P.mismatch, P.gap, B.info.p);
+                    FZP_HIP(hipEventRecord(j->ev_l[1], st3));
+                    FZP_HIP(hipStreamWaitEvent(st, j->ev_l[1], 0));
+                }
+                if (dp_chain) {
+                    hipEvent_t &e = g_dp_last[ctx->device];
+                    if (!e) FZP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                    FZP_HIP(hipEventRecord(e, st));
+                    dp_lk.unlock();
+                }
+            }
+            FZP_HIP(hipEventRecord(j->ev_sw[bi], st));
+            FZP_HIP(hipStreamWaitEvent(st2, j->ev_sw[bi], 0));
+            if (ns > 0) {
+                ProfScope ps(ctx, "k1_traceback", st2);
+                hipLaunchKernelGGL(k_tb_walk, dim3((ns + TBW_RPW * TBW_WPG - 1) / (TBW_RPW * TBW_WPG)), dim3(64 * TBW_WPG), 0, st2, ns, (const uint32_t *)B.list.p, (const DpInfo *)B.info.p,
+                                   (const int64_t *)B.tbo.p, (const int64_t *)B.mvo.p, (const int32_t *)B.tbs.p, (const ulonglong2 *)B.tb.p, (const ulonglong2 *)B.mvw.p, B.raw.p, B.wout.p);
             }
             {
-                ProfScope ps(ctx, "k1_sw");
-                if (use_bits) {
-                    // every extension goes to one of the two DP kernels: the bit-sliced one (a read per lane) takes those that fit the band on both sides and
-                    // are short enough for its per-step latency; the rest -- the long reads first of all -- run a wave each, started before it
-                    const int64_t b_at = swb_at[(size_t)ci], b_n = swb_at[(size_t)ci + 1] - b_at, w_at = sw_at[(size_t)ci], w_n = sw_at[(size_t)ci + 1] - w_at;
-                    const bool swb64 = swb_force ? swb_force == 64 : !(w_n == 0 && b_n / 32 <= (int64_t)ctx->n_cu * 4);
-                    // the bit-sliced kernel first (k_wait_started: which of the two gets onto the chip first decides how the pair runs), the wave-per-read kernel on its
-                    // own stream as soon as that one's first workgroup runs: the two share the chip (latency-bound waves of long reads there, one wave per SIMD here)
-                    FZP_TRY(j->dp_flag.alloc(1));
-                    if (!j->dp_seq) FZP_TRY(j->dp_flag.zero(1, st));
-                    uint32_t *flag_p = (w_n > 0 && b_n > 0) ? j->dp_flag.p : (uint32_t *)nullptr;
-                    const uint32_t flag_v = ++j->dp_seq;
-                    if (w_n > 0) FZP_HIP(hipEventRecord(j->ev_l[0], st));
-                    if (b_n > 0 && !swb64)
-                        hipLaunchKernelGGL(k_swb2, dim3((unsigned)((b_n + 127) / 128)), dim3(256), 0, st, first, b_n, (const int32_t *)(j->swb_list.p + b_at), (const int32_t *)nullptr, j->read_ori.p, j->read_woff.p,
-                                           j->read_len.p, j->read_ctg.p, j->ctg_pk.p, j->ctg_woff.p, j->ctg_len.p, j->anc.p, j->tb_off.p, j->tb2[bi].p, j->mvw2[bi].p, j->info.p, j->tbo.p, j->mvo.p,
-                                           (const int64_t *)j->tbm_off.p, (const int64_t *)j->mvm_off.p, (uint8_t *)nullptr, 0x7fffffff, m_stride, j->tbs.p, flag_p, flag_v);
-                    if (b_n > 0 && swb64)
-                        hipLaunchKernelGGL(swb_ring ? k_swb<true> : k_swb<false>, dim3((unsigned)((b_n + 64 * SWB_WPG - 1) / (64 * SWB_WPG))), dim3(64 * SWB_WPG), 0, st, first, b_n, (const int32_t *)(j->swb_list.p + b_at), (const int32_t *)nullptr, j->read_ori.p, j->read_woff.p,
-                                           j->read_len.p, j->read_ctg.p, j->ctg_pk.p, j->ctg_woff.p, j->ctg_len.p, j->anc.p, j->tb_off.p, j->tb2[bi].p, j->mvw2[bi].p, j->info.p, j->tbo.p, j->mvo.p, (const int64_t *)j->tbm_off.p, (const int64_t *)j->mvm_off.p,
-                                           (uint8_t *)nullptr, 0x7fffffff, getenv("FZP_SWB_DBG") ? atoi(getenv("FZP_SWB_DBG")) : 0, m_stride, j->tbs.p, flag_p, flag_v);
-                    if (w_n > 0) {
-                        FZP_HIP(hipStreamWaitEvent(ctx->stream3, j->ev_l[0], 0));
-                        if (flag_p) hipLaunchKernelGGL(k_wait_started, dim3(1), dim3(1), 0, ctx->stream3, (const uint32_t *)flag_p, flag_v);
-                        hipLaunchKernelGGL(no_masks ? k_sw<false> : k_sw<true>, dim3((unsigned)w_n), dim3(64), 0, ctx->stream3, first, w_n, (const int32_t *)nullptr, j->read_ori.p, j->read_woff.p, j->read_len.p, j->read_ctg.p,
-                                           j->ctg_pk.p, j->ctg_woff.p, j->ctg_len.p, j->anc.p, j->tb_off.p, j->tb2[bi].p, j->mvw2[bi].p, P.match, P.mismatch, P.gap, j->info.p, j->tbo.p, j->mvo.p,
-                                           (const int32_t *)(j->sw_list.p + w_at), use_prio ? mean_len : 0, (const int64_t *)j->tbm_off.p, (const int64_t *)j->mvm_off.p, (const uint8_t *)nullptr, m_stride, j->tbs.p);
-                        FZP_HIP(hipEventRecord(j->ev_l[1], ctx->stream3));
-                    }
-                    if (w_n > 0) FZP_HIP(hipStreamWaitEvent(st, j->ev_l[1], 0));
-                } else
-                hipLaunchKernelGGL(no_masks ? k_sw<false> : k_sw<true>, dim3((unsigned)cnt), dim3(64), 0, st, first, cnt, (const int32_t *)nullptr, j->read_ori.p, j->read_woff.p, j->read_len.p, j->read_ctg.p,
-                                   j->ctg_pk.p, j->ctg_woff.p, j->ctg_len.p, j->anc.p, j->tb_off.p, j->tb2[bi].p, j->mvw2[bi].p, P.match, P.mismatch, P.gap, j->info.p, j->tbo.p, j->mvo.p,
-                                   use_lpt ? (const int32_t *)(j->lpt.p + first) : (const int32_t *)nullptr, use_prio ? mean_len : 0, (const int64_t *)nullptr, (const int64_t *)nullptr, (const uint8_t *)nullptr, 64, j->tbs.p);
-            }
-            if (c2 > 0) {     // same kernel over the compacted list, then the better extension of each read survives
-                {
-                    ProfScope ps(ctx, "k1_sw2");
-                    hipLaunchKernelGGL(k_sw<true>, dim3((unsigned)c2), dim3(64), 0, st, (int64_t)w_lo, c2, j->ridx.p, j->sec_ori.p, j->sec_woff.p, j->read_len.p, j->read_ctg.p,
-                                       j->ctg_pk.p, j->ctg_woff.p, j->ctg_len.p, j->anc2.p, j->tb_off2.p, j->tb2[bi].p + 2 * tb_base, j->mvw2[bi].p + mv_base, P.match, P.mismatch,
-                                       P.gap, j->info2.p, (int64_t *)nullptr, (int64_t *)nullptr, (const int32_t *)nullptr, 0, (const int64_t *)nullptr, (const int64_t *)nullptr, (const uint8_t *)nullptr, 64, (int32_t *)nullptr);
-                }
-                ProfScope ps(ctx, "k1_pick");
-                hipLaunchKernelGGL(k_pick, dim3((unsigned)((c2 + 255) / 256)), dim3(256), 0, st, (int64_t)w_lo, (int64_t)w_hi, j->ridx.p, j->anc2.p, j->info2.p, j->tb_off2.p,
-                                   tb_base, mv_base, j->anc.p, j->info.p, j->tbo.p, j->mvo.p, j->won.p, j->tbs.p);
-                hipLaunchKernelGGL(k_pick_copy, dim3((unsigned)c2), dim3(256), 0, st, (int64_t)w_lo, j->ridx.p, j->won.p, j->read_len.p, j->sec_ori.p, j->sec_woff.p, j->read_woff.p, j->read_ori.p);
-            }
-            w_lo = w_hi;
-            FZP_HIP(hipEventRecord(j->ev_sw[bi], st));        // the forward extensions are final: their walk starts on the second stream while the backward ones run here
-            if (dp_chain) {
-                hipEvent_t &e = g_dp_last[ctx->device];
-                if (!e) FZP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-                FZP_HIP(hipEventRecord(e, st));
-                dp_lk.unlock();
-            }
-            const int64_t steps_b = j->h_tb_off_b[(size_t)last] - j->h_tb_off_b[(size_t)first];
-            FZP_TRY(j->tb_b2[bi].alloc((size_t)(steps_b + 64) * 2 + 128));
-            FZP_TRY(j->mvw_b2[bi].alloc((size_t)(steps_b / 64 + cnt + 2)));
-            FZP_TRY(j->raw_b2[bi].alloc((size_t)(steps_b / 16 + 64)));
-            {   // backward from the winner's anchor: reversed inputs, then the same DP kernel (slot = read; its "contig" is its own window)
-                ProfScope ps(ctx, "k1_back");
-                hipLaunchKernelGGL(k_back_prep, dim3((unsigned)cnt), dim3(256), 0, st, first, j->anc.p, j->read_ctg.p, j->read_ori.p, j->read_woff.p, j->ctg_pk.p, j->ctg_woff.p,
-                                   j->bq_off.p, j->bt_off.p, j->bq.p, j->bt.p, j->anc_b.p, j->b_len.p, j->b_tlen.p);
-                // the backward extensions are short (an anchor sits a few hundred bases into its read): the bit-sliced kernel takes every one that spans the band
-                // (lanes in slot order: their mask streams lie side by side), k_sw the rest -- which of the two is decided on the device, the winner's anchor never came to the host
-                const bool swb64 = swb_force ? swb_force == 64 : !((cnt + 31) / 32 <= (int64_t)ctx->n_cu * 4);
-                if (use_bits && !swb64) {
-                    FZP_TRY(j->b_handled.alloc((size_t)nr));
-                    hipLaunchKernelGGL(k_swb2, dim3((unsigned)((cnt + 127) / 128)), dim3(256), 0, st, first, cnt, (const int32_t *)j->b_iota.p, (const int32_t *)nullptr, j->bq.p, j->bq_off.p, j->b_len.p, j->b_iota.p,
-                                       j->bt.p, j->bt_off.p, j->b_tlen.p, j->anc_b.p, j->tb_off_b.p, j->tb_b2[bi].p, j->mvw_b2[bi].p, j->info_b.p, j->tbo_b.p, j->mvo_b.p,
-                                       (const int64_t *)nullptr, (const int64_t *)nullptr, j->b_handled.p, (int32_t)swb_max_steps, 64, (int32_t *)nullptr, (uint32_t *)nullptr, 0u);
-                }
-                if (use_bits && swb64) {
-                    FZP_TRY(j->b_handled.alloc((size_t)nr));
-                    hipLaunchKernelGGL(k_swb<false>, dim3((unsigned)((cnt + 64 * SWB_WPG - 1) / (64 * SWB_WPG))), dim3(64 * SWB_WPG), 0, st, first, cnt, (const int32_t *)j->b_iota.p, (const int32_t *)nullptr, j->bq.p, j->bq_off.p, j->b_len.p, j->b_iota.p,
-                                       j->bt.p, j->bt_off.p, j->b_tlen.p, j->anc_b.p, j->tb_off_b.p, j->tb_b2[bi].p, j->mvw_b2[bi].p, j->info_b.p, j->tbo_b.p, j->mvo_b.p,
-                                       (const int64_t *)nullptr, (const int64_t *)nullptr, j->b_handled.p, (int32_t)swb_max_steps, 0, 64, (int32_t *)nullptr, (uint32_t *)nullptr, 0u);
-                }
-                hipLaunchKernelGGL(k_sw<true>, dim3((unsigned)cnt), dim3(64), 0, st, first, cnt, (const int32_t *)nullptr, j->bq.p, j->bq_off.p, j->b_len.p, j->b_iota.p,
-                                   j->bt.p, j->bt_off.p, j->b_tlen.p, j->anc_b.p, j->tb_off_b.p, j->tb_b2[bi].p, j->mvw_b2[bi].p, P.match, P.mismatch, P.gap, j->info_b.p,
-                                   j->tbo_b.p, j->mvo_b.p, (const int32_t *)nullptr, 0, (const int64_t *)nullptr, (const int64_t *)nullptr, use_bits ? (const uint8_t *)j->b_handled.p : (const uint8_t *)nullptr, 64, (int32_t *)nullptr);
-            }
-            FZP_HIP(hipEventRecord(j->ev_bk[bi], st));
-            FZP_HIP(hipStreamWaitEvent(st2, j->ev_sw[bi], 0));
-            if (tb_serial) {
-                ProfScope ps(ctx, "k1_traceback", st2);
-                hipLaunchKernelGGL(k_tb_walk<false>, dim3((unsigned)((cnt + TBW_RPW * TBW_WPG - 1) / (TBW_RPW * TBW_WPG))), dim3(64 * TBW_WPG), 0, st2, first, cnt, j->anc.p, j->info.p, j->tb_off.p,
-                                   j->tbo.p, j->mvo.p, (const ulonglong2 *)j->tb2[bi].p, (const ulonglong2 *)j->mvw2[bi].p, j->raw2[bi].p, j->wout.p,
-                                   use_lpt ? (const int32_t *)(j->lpt.p + first) : (const int32_t *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr,
-                                   (uint32_t *)nullptr, (SegOut *)nullptr, 0, 32, (const SegReq *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr, (const int32_t *)j->tbs.p);
-            } else {
-                const int64_t nwk = j->h_seg_cnt[(size_t)first], wbase = j->h_seg_base[(size_t)first];
-                FZP_TRY(j->raw_seg2[bi].alloc((size_t)nwk * TBS_RAW_WORDS + 64));
-                FZP_TRY(j->trail2[bi].alloc((size_t)nwk * 2 * TBS_OV + 64));
-                FZP_TRY(j->segout2[bi].alloc((size_t)nwk + 1));
-                ProfScope ps(ctx, "k1_traceback", st2);
-                FZP_HIP(hipMemsetAsync(j->trail2[bi].p, 0xff, (size_t)nwk * 2 * TBS_OV * 4, st2));
-                hipLaunchKernelGGL(k_tb_walk<true>, dim3((unsigned)((nwk + TBW_RPW * TBW_WPG - 1) / (TBW_RPW * TBW_WPG))), dim3(64 * TBW_WPG), 0, st2, first, nwk, j->anc.p, j->info.p, j->tb_off.p,
-                                   j->tbo.p, j->mvo.p, (const ulonglong2 *)j->tb2[bi].p, (const ulonglong2 *)j->mvw2[bi].p, j->raw_seg2[bi].p, j->wout.p,
-                                   (const int32_t *)(j->seg_order.p + wbase), (const int32_t *)(j->seg_slot.p + wbase), (const int32_t *)(j->seg_idx.p + wbase), j->trail2[bi].p, j->segout2[bi].p, 0, guess_lane, (const SegReq *)nullptr, (const uint32_t *)nullptr, j->raw2[bi].p, (const int32_t *)j->tbs.p);
-                const uint32_t req_cap = (uint32_t)std::min<int64_t>(nwk, 1 << 20);
-                FZP_TRY(j->seg_req.alloc((size_t)req_cap + 1));
-                FZP_HIP(hipMemsetAsync(j->tb_fallback.p + 1, 0, 4, st2));      // this chunk's repair requests
-                for (int round = 0; round <= REPAIR_ROUNDS; round++) {
-                    hipLaunchKernelGGL(k_tb_stitch, dim3((unsigned)cnt), dim3(64), 0, st2, first, cnt, j->anc.p, j->info.p, j->tb_off.p, (const int32_t *)(j->seg_off.p + first),
-                                       (const uint32_t *)j->trail2[bi].p, (const SegOut *)j->segout2[bi].p, (const uint32_t *)j->raw_seg2[bi].p, j->raw2[bi].p, j->wout.p, j->tb_fallback.p,
-                                       j->seg_req.p, req_cap, (round == 0 ? 1 : 0) | (round < REPAIR_ROUNDS ? 2 : 0), (const uint8_t *)(j->seg_single.p + first), ov_limit);
-                    if (round == REPAIR_ROUNDS) break;
-                    // boundaries that did not join: their lower segments again, from the exact cell (a launch of empty waves when there are none)
-                    hipLaunchKernelGGL(k_tb_walk<true>, dim3((unsigned)((std::min<int64_t>(req_cap, cnt) + TBW_RPW * TBW_WPG - 1) / (TBW_RPW * TBW_WPG))), dim3(64 * TBW_WPG), 0, st2, first, (int64_t)req_cap, j->anc.p, j->info.p,
-                                       j->tb_off.p, j->tbo.p, j->mvo.p, (const ulonglong2 *)j->tb2[bi].p, (const ulonglong2 *)j->mvw2[bi].p, j->raw_seg2[bi].p, j->wout.p,
-                                       (const int32_t *)nullptr, (const int32_t *)(j->seg_slot.p + wbase), (const int32_t *)(j->seg_idx.p + wbase), j->trail2[bi].p, j->segout2[bi].p, 0, guess_lane,
-                                       (const SegReq *)j->seg_req.p, (const uint32_t *)(j->tb_fallback.p + 1), j->raw2[bi].p, (const int32_t *)j->tbs.p);
-                    hipLaunchKernelGGL(k_tb_req_reset, dim3(1), dim3(64), 0, st2, j->tb_fallback.p);   // the walks are queued behind it: the next stitch pass counts from 0
-                }
-                // reads whose segments did not join (flagged by the stitching) are walked in one piece; every other wave of this launch leaves at once
-                hipLaunchKernelGGL(k_tb_walk<false>, dim3((unsigned)((cnt + TBW_RPW * TBW_WPG - 1) / (TBW_RPW * TBW_WPG))), dim3(64 * TBW_WPG), 0, st2, first, cnt, j->anc.p, j->info.p, j->tb_off.p,
-                                   j->tbo.p, j->mvo.p, (const ulonglong2 *)j->tb2[bi].p, (const ulonglong2 *)j->mvw2[bi].p, j->raw2[bi].p, j->wout.p,
-                                   (const int32_t *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr, (uint32_t *)nullptr, (SegOut *)nullptr, 1, 32, (const SegReq *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr, (const int32_t *)j->tbs.p);
-            }
-            FZP_HIP(hipStreamWaitEvent(st2, j->ev_bk[bi], 0));
-            {   // the backward parts: walked (one walker each: they are short), then joined to the forward streams
-                ProfScope ps(ctx, "k1_back_tb", st2);
-                hipLaunchKernelGGL(k_tb_walk<false>, dim3((unsigned)((cnt + TBW_RPW * TBW_WPG - 1) / (TBW_RPW * TBW_WPG))), dim3(64 * TBW_WPG), 0, st2, first, cnt, j->anc_b.p, j->info_b.p, j->tb_off_b.p,
-                                   j->tbo_b.p, j->mvo_b.p, (const ulonglong2 *)j->tb_b2[bi].p, (const ulonglong2 *)j->mvw_b2[bi].p, j->raw_b2[bi].p, j->wout_b.p,
-                                   (const int32_t *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr, (uint32_t *)nullptr, (SegOut *)nullptr, 0, 32,
-                                   (const SegReq *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr, (const int32_t *)nullptr);
-                hipLaunchKernelGGL(k_back_merge, dim3((unsigned)cnt), dim3(64), 0, st2, first, cnt, j->tb_off.p, j->tb_off_b.p, j->anc_b.p, j->info_b.p, j->wout_b.p,
-                                   (const uint32_t *)j->raw_b2[bi].p, j->raw2[bi].p, j->wout.p, j->info.p);
+                ProfScope ps(ctx, "k1_join", st2);
+                hipLaunchKernelGGL(k_join, dim3((unsigned)cnt), dim3(64), 0, st2, first, cnt, (const uint32_t *)j->slot_base.p, (const uint32_t *)j->r_cnt.p, s_lo, (const Slot *)B.slots.p,
+                                   (const DpInfo *)B.info.p, (const WalkOut *)B.wout.p, (const int64_t *)B.mvo.p, (const uint32_t *)B.raw.p, (const uint32_t *)j->rcapq_scan.p, B.rraw.p, B.rpath.p);
             }
             {
                 ProfScope ps(ctx, "k1_cigar", st2);
-                hipLaunchKernelGGL(k_tb_cigar, dim3((unsigned)cnt), dim3(64), 0, st2, first, cnt, j->read_len.p, j->anc.p, j->info.p, j->tb_off.p, j->raw2[bi].p,
-                                   j->wout.p, j->cig_off.p, j->cig.p, j->cig_start.p, j->summ.p, P.match, P.mismatch, P.gap, P.min_pct_identity,
-                                   j->read_ori.p, j->read_woff.p, j->read_ctg.p, j->ctg_pk.p, j->ctg_woff.p);
+                hipLaunchKernelGGL(k_tb_cigar, dim3((unsigned)cnt), dim3(64), 0, st2, first, cnt, j->read_len.p, (const ReadPath *)B.rpath.p, (const uint32_t *)j->rcapq_scan.p, B.rraw.p,
+                                   j->cig_off.p, j->cig.p, j->cig_start.p, j->summ.p, P.match, P.mismatch, P.gap, P.min_pct_identity,
+                                   (const uint32_t *)j->read_pk.p, (const uint32_t *)j->read_rc.p, (const int64_t *)j->read_woff.p, j->read_ctg.p, (const uint32_t *)j->ctg_pk.p, (const int64_t *)j->ctg_woff.p);
             }
             FZP_HIP(hipEventRecord(j->ev_tb[bi], st2));
             used[bi] = true;
@@ -2892,17 +2515,6 @@ int fetch_summaries(fzp_ctx *ctx, fzp_alnjob *j) {
 }  // namespace
 
 extern "C" int64_t fzp_align_n_second(const fzp_alnjob *j) { return j ? j->n_second : 0; }
-extern "C" int fzp_align_tb_fallbacks(fzp_ctx *ctx, fzp_alnjob *j, int64_t *n) {
-    if (!ctx || !j || !j->done || !n) { fzp_set_error("fzp_align_tb_fallbacks: run the job first"); return FZP_EINVAL; }
-    FZP_TRY(fzp_bind(ctx));
-    uint32_t v[4] = {0, 0, 0, 0};
-    if (j->tb_fallback.p) { FZP_HIP(hipMemcpyAsync(v, j->tb_fallback.p, 16, hipMemcpyDeviceToHost, ctx->stream)); FZP_HIP(hipStreamSynchronize(ctx->stream)); }
-    if (getenv("FZP_TB_DEBUG")) fprintf(stderr, "[fzp_align_tb_fallbacks] counters %u %u %u %u\n", v[0], v[1], v[2], v[3]);
-    n[0] = (int64_t)v[0];
-    n[1] = (int64_t)v[2];
-    return FZP_OK;
-}
-
 extern "C" int fzp_align_summaries(fzp_ctx *ctx, fzp_alnjob *j, fzp_aln_summary *out) {
     if (!ctx || !j || !j->done || !out) { fzp_set_error("fzp_align_summaries: run the job first"); return FZP_EINVAL; }
     FZP_TRY(fetch_summaries(ctx, j));
@@ -2986,8 +2598,8 @@ int gather_records(fzp_ctx *ctx, fzp_alnjob *j, const RecPlan &p, DevBuf<uint32_
     FZP_TRY(seq.alloc((size_t)p.seq_off.back()));
     if (nrec > 0) {
         ProfScope ps(ctx, "k1_gather");
-        hipLaunchKernelGGL(k_gather, dim3((unsigned)nrec, 4), dim3(256), 0, st, nrec, d_rec_read.p, j->cig_start.p, j->cig.p, d_cig_off.p, cigar.p, j->read_ori.p,
-                           j->read_woff.p, d_seq_off.p, seq.p);
+        hipLaunchKernelGGL(k_gather, dim3((unsigned)nrec, 4), dim3(256), 0, st, nrec, d_rec_read.p, j->cig_start.p, j->cig.p, d_cig_off.p, cigar.p, j->read_pk.p, j->read_rc.p,
+                           j->summ.p, j->read_woff.p, d_seq_off.p, seq.p);
     }
     FZP_HIP(hipStreamSynchronize(st));
     FZP_HIP(hipGetLastError());
@@ -3202,8 +2814,8 @@ extern "C" int fzp_align_to_batch(fzp_ctx *ctx, fzp_alnjob *j, fzp_batch **out) 
     FZP_TRY(b->cigar.alloc((size_t)b->n_cig)); FZP_TRY(b->seq.alloc((size_t)b->n_seq));
     if (b->n_rec > 0) {
         ProfScope ps(ctx, "k1_gather");
-        hipLaunchKernelGGL(k_gather16, dim3((unsigned)b->n_rec, 4), dim3(256), 0, st, b->n_rec, rec_read.p, j->cig_start.p, j->cig.p, b->cig_off.p, b->cigar.p, j->read_ori.p,
-                           j->read_woff.p, b->seq_off.p, b->seq.p);
+        hipLaunchKernelGGL(k_gather16, dim3((unsigned)b->n_rec, 4), dim3(256), 0, st, b->n_rec, rec_read.p, j->cig_start.p, j->cig.p, b->cig_off.p, b->cigar.p, j->read_pk.p, j->read_rc.p,
+                           j->summ.p, j->read_woff.p, b->seq_off.p, b->seq.p);
     }
     FZP_TRY(b->ref.alloc((size_t)b->n_pos));
     for (int c = 0; c < nc; c++)   // evaluated prefix of every contig, device to device

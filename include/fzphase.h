@@ -205,12 +205,13 @@ int fzp_readmap(const char *phased_reads, size_t pr_len, const char *rawread_ids
 
 /* ---------------------------------------------------------------------------------------------
  * K1: read -> contig banded alignment (role of blasr + samtools sort, unzip.py:86-91).
- * Own deterministic spec "fzalign v1.5" (DESIGN.md section 6): k-mer seeding over every indexed position, up to two
- * candidate placements per read (chained anchors), extension forward and backward from the anchor in an adaptive anti-diagonal band of
- * 64 cells with linear-gap scores, the better forward extension kept (--bestn 1), the best-scoring stretch of the joined path reported,
- * identity gate (--minPctIdentity 70), traceback to =/X/I/D/S CIGARs.  Parity vs blasr is UNPINNED; the kernels are bit-exact against
- * their scalar CPU twin in oracle/align_oracle.c.  With the default scores (2, 4, 3) the DP runs bit-sliced (one read per lane); other
- * scores run the wave-per-read kernel: same spec, same results.
+ * Own deterministic spec "fzalign v1.6" (DESIGN.md section 6): k-mer seeding over every indexed position, up to two
+ * candidate placements per read (chained anchors); the chain's hits every >= 3 072 read bases are waypoints and the extension is a sequence of
+ * independent banded DPs from one waypoint to the next (the role of blasr's alignment between chain anchors), a free one past the last waypoint and one
+ * backward from the anchor -- each in an adaptive anti-diagonal band of 64 cells with linear-gap scores --, the better forward extension kept
+ * (--bestn 1), the best-scoring stretch of the joined path reported, identity gate (--minPctIdentity 70), traceback to =/X/I/D/S CIGARs.
+ * Parity vs blasr is UNPINNED; the kernels are bit-exact against their scalar CPU twin in oracle/align_oracle.c.  With the default scores (2, 4, 3)
+ * the DP runs bit-sliced (one piece per lane); other scores run the wave-per-piece kernel: same spec, same results.
  * --------------------------------------------------------------------------------------------- */
 typedef struct {
     int32_t kmer;            /* seed length (<=16), default 16 */
@@ -230,7 +231,7 @@ typedef struct {             /* per read, input order */
     int32_t q_start, q_end;  /* aligned part of the (oriented) read */
     int32_t score;
     int32_t n_cigar;         /* CIGAR words incl. soft clips */
-    int64_t cells;           /* DP cells evaluated for this read (steps * 64) */
+    int64_t cells;           /* DP cells evaluated for this read (steps * 64 over all its extension pieces, both candidates) */
     int32_t n_columns;       /* aligned columns (= and X bases) */
     int32_t n_match;         /* '=' columns; 100 * n_match / (columns + inserted + deleted bases) is the identity the gate tests */
 } fzp_aln_summary;
@@ -250,9 +251,6 @@ int fzp_align_invalidate_index(fzp_alnjob *job);
 int fzp_align_summaries(fzp_ctx *ctx, fzp_alnjob *job, fzp_aln_summary *out /* [n_reads] */);
 /* reads of the last run that had a second candidate placement extended (repeats; blasr --bestn 1 keeps the better one) */
 int64_t fzp_align_n_second(const fzp_alnjob *job);
-/* statistics of the last run's segmented trace-back (the alignments are the same either way): n[0] = reads that were walked in one piece
- * after all, n[1] = segments that were walked a second time because they did not join their upper neighbour inside the overlap */
-int fzp_align_tb_fallbacks(fzp_ctx *ctx, fzp_alnjob *job, int64_t n[2]);
 /* alignment records of contig `ctg` in (POS, read index) order, q_id = rank in that order; names
  * (optional, may be NULL -> "read/<index>") fill the q_id table */
 int fzp_align_alnset(fzp_ctx *ctx, fzp_alnjob *job, int32_t ctg, const int64_t *name_off, const char *names,

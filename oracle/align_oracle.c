@@ -29,14 +29,15 @@
  *             strand or at least 3 bins away from W1 (same ties); it counts only if it has >= min_seed_hits
  *             votes and 4*votes(W2) >= votes(W1)  (the second placement of blasr's --bestn selection,
  *             unzip.py:86-88).
- *   chains    per window: its hits = those of its strand in bins b-1 .. b+2, by increasing oriented offset
+ *   chains    per window: its hits = those of its strand in bins b-1-ext .. b+2+ext, ext = n >> 14 (v1.6: a long read drifts across bins; W2 likewise lies
+ *             at least 3 + ext bins from W1), by increasing oriented offset
  *             (hit order on the forward strand, reversed hit order on the other).  Chain length f(h) = 1 +
  *             max f(p) over the at most 64 preceding window hits p with 1 <= i_h - i_p <= 2048, cpos_p < cpos_h
  *             and |dv_h - dv_p| <= 16 + (i_h - i_p)/16 (ties: the closest p), else 1; start(h) = start(p) or
  *             h itself.  The longest chain (ties: the earliest end) gives the anchor = its first hit (i_h, c_h), a cell
  *             of the true path.  Candidates in order W1, W2.
- *   waypoints (v1.6) piece = max(3072, ceil(n / 31)).  Along a chain, its first hit is waypoint 0; a later hit of the chain is the next
- *             waypoint when its oriented offset lies at least `piece` bases after the previous waypoint's (so a read has at most 32).
+ *   waypoints (v1.6) piece = max(3072, ceil(n / 30)).  Along a chain, its first hit is waypoint 0; a later hit of the chain is the next
+ *             waypoint when its oriented offset lies at least `piece` bases after the previous waypoint's (so a read has at most 31).
  *             The longest chain's waypoints w_0 (the anchor) .. w_m cut the forward extension into pieces.
  *   pieces    piece k < m is INNER: the extension DP (below) from w_k on the sub-matrix of the nq = i(w_k+1) - i(w_k) read bases and the
  *             nt = c(w_k+1) - c(w_k) contig bases up to the next waypoint; its terminal is the valid border cell with the largest
@@ -95,8 +96,10 @@ typedef struct {
 #define HIT_CAP 4096
 #define CHAIN_LOOKBACK 64
 #define CHAIN_MAX_GAP 2048
+#define BRIDGE_MAX_GAP 4096 /* v1.6: a chain may cross a seedless stretch of up to this many read bases ... */
+#define BRIDGE_COST 4       /* ... for the price of this many hits */
 #define PIECE_LEN 3072      /* v1.6: read bases between waypoints (at least) */
-#define MAX_WP 32           /* waypoints per candidate */
+#define MAX_WP 31           /* waypoints per candidate (the device joins a read's pieces one per lane: 2 x 32 slots) */
 
 static inline int code_of(uint8_t c) {
     switch (c) {
@@ -174,6 +177,7 @@ static int seed_candidates(const ctg_index *ix, const uint8_t *fwd, int64_t n, c
     int shift = 10;
     while ((((Lc + n) >> shift) + 2) > 8192) shift++;
     const int64_t NB = ((Lc + n) >> shift) + 2;
+    const int64_t ext = n >> 14;      /* v1.6: a long read's diagonal drifts (CLR reads carry more inserted than deleted bases): its window widens by a bin per 16 384 bases */
     uint32_t *votes = (uint32_t *)scratch_get(6, (size_t)(2 * NB) * 4);
     memset(votes, 0, (size_t)(2 * NB) * 4);
     hit_t *hits = (hit_t *)scratch_get(7, (size_t)HIT_CAP * sizeof(hit_t));
@@ -202,7 +206,7 @@ static int seed_candidates(const ctg_index *ix, const uint8_t *fwd, int64_t n, c
     uint32_t w2 = 0; int s2 = 0; int64_t b2 = 0;
     for (int s = 0; s < 2; s++)
         for (int64_t b = 0; b + 1 < NB; b++) {
-            if (s == s1 && b - b1 < 3 && b1 - b < 3) continue;
+            if (s == s1 && b - b1 < 3 + ext && b1 - b < 3 + ext) continue;
             uint32_t sc = votes[s * NB + b] + votes[s * NB + b + 1];
             if (sc > w2) { w2 = sc; s2 = s; b2 = b; }
         }
@@ -219,7 +223,7 @@ static int seed_candidates(const ctg_index *ix, const uint8_t *fwd, int64_t n, c
             const int64_t h = ws ? nh - 1 - x : x;
             if (hits[h].s != ws) continue;
             const int64_t b = hits[h].dv >> shift;
-            if (b >= wb - 1 && b <= wb + 2) wh[m++] = (int32_t)h;
+            if (b >= wb - 1 - ext && b <= wb + 2 + ext) wh[m++] = (int32_t)h;
         }
         int32_t best_f = 0; int64_t best_e = -1;
         for (int64_t e = 0; e < m; e++) {
@@ -228,10 +232,13 @@ static int seed_candidates(const ctg_index *ix, const uint8_t *fwd, int64_t n, c
             for (int64_t back = 1; back <= CHAIN_LOOKBACK && e - back >= 0; back++) {        /* closest predecessor first */
                 const hit_t *Q = &hits[wh[e - back]];
                 const int64_t di = H->i - Q->i;
-                if (di < 1 || di > CHAIN_MAX_GAP || H->cp <= Q->cp) continue;
+                if (di < 1 || di > BRIDGE_MAX_GAP || H->cp <= Q->cp) continue;
                 int64_t dd = H->dv - Q->dv; if (dd < 0) dd = -dd;
-                if (dd > 16 + di / 16) continue;
-                if (f[e - back] + 1 > bf) { bf = f[e - back] + 1; bst = st[e - back]; bp = e - back; }
+                int32_t v;
+                if (di <= CHAIN_MAX_GAP && dd <= 16 + di / 16) v = f[e - back] + 1;
+                else if (dd <= 64 + di / 8) v = f[e - back] + 1 - BRIDGE_COST;       /* v1.6: a bridge over a stretch too noisy for seeds (the diagonal may drift further there) */
+                else continue;
+                if (v > bf) { bf = v; bst = st[e - back]; bp = e - back; }
             }
             f[e] = bf; st[e] = bst;
             if (bp < 0) { wl[e] = (int32_t)e; wprev[e] = -1; }

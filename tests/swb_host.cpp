@@ -5,7 +5,7 @@
 #include <cstring>
 #include "../falcon_unzip_amd/csrc/fzp_swb_core.h"
 
-extern "C" int swb_extend_host(const uint8_t *q, int64_t nq, const uint8_t *t, int64_t nt, uint64_t *tbD, uint64_t *tbG, uint8_t *mv, int64_t *out) {
+extern "C" int swb_extend_host(const uint8_t *q, int64_t nq, const uint8_t *t, int64_t nt, uint64_t *tbD, uint64_t *tbG, uint8_t *mv, int64_t *out, int inner) {
     using namespace swb;
     if (nq < 64 || nt < 64) return -1;                        // (the kernel leaves such extensions to k_sw)
     const int64_t max_steps = nq + nt + 2;
@@ -60,8 +60,9 @@ extern "C" int swb_extend_host(const uint8_t *q, int64_t nq, const uint8_t *t, i
             else if (col_on && kc >= 0 && kc <= 63) Hcol += 2 * value_at(Q, (int)kc) - 3;
             if (!row_on && down && kr == 63) { row_on = true; Hrow = S0 + 2 * E2; }
             else if (row_on && kr >= 0 && kr <= 63) Hrow += 2 * value_at(P, (int)kr) - 3;
-            if (col_on && kc >= 0 && kc <= 63) { const int64_t i = i0 + kc; if (i >= 0 && i < nq && Hcol > best) { best = Hcol; bt = tt; bl = kc; } }
-            if (row_on && kr >= 0 && kr <= 63) { const int64_t j = tt - (nq - 1); if (j >= 0 && j < nt && Hrow > best) { best = Hrow; bt = tt; bl = kr; } }
+            // (inner pieces, fzalign v1.6: a border cell is valued by the global alignment through it -- minus the gap moves from it to the corner)
+            if (col_on && kc >= 0 && kc <= 63) { const int64_t i = i0 + kc; const int32_t vc = inner ? Hcol - 3 * (int32_t)(nq - 1 - i) : Hcol; if (i >= 0 && i < nq && vc > best) { best = vc; bt = tt; bl = kc; } }
+            if (row_on && kr >= 0 && kr <= 63) { const int64_t j = tt - (nq - 1); const int32_t vr = inner ? Hrow - 3 * (int32_t)(nt - 1 - j) : Hrow; if (j >= 0 && j < nt && vr > best) { best = vr; bt = tt; bl = kr; } }
         }
         pdown = down;
         tt++;
@@ -78,7 +79,7 @@ extern "C" int swb_extend_host(const uint8_t *q, int64_t nq, const uint8_t *t, i
 // ---- the same extension with the band split over a pair of lanes (k_swb2's form): two Half states, explicit exchange where the kernel uses a DPP swap
 static uint32_t rev32(uint32_t v) { uint32_t r = 0; for (int b = 0; b < 32; b++) r |= ((v >> b) & 1u) << (31 - b); return r; }
 
-extern "C" int swb_extend_pair_host(const uint8_t *q, int64_t nq, const uint8_t *t, int64_t nt, uint64_t *tbD, uint64_t *tbG, uint8_t *mv, int64_t *out) {
+extern "C" int swb_extend_pair_host(const uint8_t *q, int64_t nq, const uint8_t *t, int64_t nt, uint64_t *tbD, uint64_t *tbG, uint8_t *mv, int64_t *out, int inner) {
     using namespace swb;
     if (nq < 64 || nt < 64) return -1;
     const int64_t max_steps = nq + nt + 2;
@@ -128,8 +129,9 @@ extern "C" int swb_extend_pair_host(const uint8_t *q, int64_t nq, const uint8_t 
             else if (col_on && kc >= 0 && kc <= 63) Hcol += 2 * Qval(kc) - 3;
             if (!row_on && down && kr == 63) { row_on = true; Hrow = S0 + 2 * E2; }
             else if (row_on && kr >= 0 && kr <= 63) Hrow += 2 * Pval(kr) - 3;
-            if (col_on && kc >= 0 && kc <= 63) { const int64_t i = i0 + kc; if (i >= 0 && i < nq && Hcol > best) { best = Hcol; bt = tt; bl = kc; } }
-            if (row_on && kr >= 0 && kr <= 63) { const int64_t j = tt - (nq - 1); if (j >= 0 && j < nt && Hrow > best) { best = Hrow; bt = tt; bl = kr; } }
+            // (inner pieces, fzalign v1.6: a border cell is valued by the global alignment through it -- minus the gap moves from it to the corner)
+            if (col_on && kc >= 0 && kc <= 63) { const int64_t i = i0 + kc; const int32_t vc = inner ? Hcol - 3 * (int32_t)(nq - 1 - i) : Hcol; if (i >= 0 && i < nq && vc > best) { best = vc; bt = tt; bl = kc; } }
+            if (row_on && kr >= 0 && kr <= 63) { const int64_t j = tt - (nq - 1); const int32_t vr = inner ? Hrow - 3 * (int32_t)(nt - 1 - j) : Hrow; if (j >= 0 && j < nt && vr > best) { best = vr; bt = tt; bl = kr; } }
         }
         pdown = down;
         tt++;

@@ -446,36 +446,18 @@ def test_real_read_shape_matches_twin_and_truth(eng, oracle):
     job.close()
 
 
-def test_launch_order_does_not_change_results(eng, monkeypatch):
-    """k_sw and k_tb_walk take their reads longest first (LPT over the wave slots); FZP_SW_INPUT_ORDER=1 is the input order: same bytes"""
-    from falcon_unzip_amd import _lib
-    n = 600
-    ctg, blob, off, *_ = _shaped(48, 1_000_000, n)
-    got = {}
-    for mode in ("lpt", "input"):
-        if mode == "input":
-            monkeypatch.setenv("FZP_SW_INPUT_ORDER", "1")
-        job = _lib.align_job_raw(eng, [ctg], blob, off, np.zeros(n, np.int32))
-        job.run()
-        got[mode] = (job.summaries().copy(), [job.alnset(0)[0].cigar_of(k) for k in range(0, 500, 7)])
-        job.close()
-    monkeypatch.delenv("FZP_SW_INPUT_ORDER")
-    assert np.array_equal(got["lpt"][0], got["input"][0]) and got["lpt"][1] == got["input"][1]
-
-
 def test_the_three_dp_kernels_agree(eng, oracle, monkeypatch):
-    """The banded DP exists three times: k_sw (a wave per read, integer scores), k_swb (bit-sliced, a read per lane) and k_swb2 (bit-sliced, a read per pair of
-    lanes).  Same reads through each (FZP_SW_NO_BITS / FZP_SWB_64 / FZP_SWB_PAIR; the default mixes them by read length): every summary field and every CIGAR equal, and
-    equal to the twin's.  Reads from 70 bases up, so that extensions shorter than the band (which stay with k_sw) and reads over the bit-sliced kernels' length
-    limit are both in the set; once more with the reads cut into three chunks (every chunk its own launch lists and mask buffers), and with
-    every read's mask stream on its own instead of interleaved with its launch group's (FZP_TB_CONTIG)."""
+    """The banded DP exists three times: k_sw (a wave per piece, integer scores), k_swb (bit-sliced, a piece per lane) and k_swb2 (bit-sliced, a piece per pair of
+    lanes).  Same reads through each (FZP_SW_NO_BITS / FZP_SWB_64 / FZP_SWB_PAIR; the default mixes them by piece size): every summary field and every CIGAR equal, and
+    equal to the twin's.  Reads from 70 bases up, so that extensions narrower than the band (which stay with k_sw) and pieces over a (lowered) step
+    limit of the bit-sliced kernels are both in the set; once more with the reads cut into three chunks (every chunk its own slots, launch lists and mask buffers)."""
     from falcon_unzip_amd import _lib
     n = 400
     ctg, blob, off, *_ = _shaped(51, 800_000, n, length_model={"median": 4000, "sigma": 1.3, "lo": 70, "hi": 30000})
     reads = [blob[off[i]:off[i + 1]] for i in range(n)]
     got = {}
     for mode, env in (("default", {}), ("wave_per_read", {"FZP_SW_NO_BITS": "1"}), ("lane64", {"FZP_SWB_64": "1"}), ("pair", {"FZP_SWB_PAIR": "1"}),
-                      ("pair_short_limit", {"FZP_SWB_PAIR": "1", "FZP_SWB_MAX_STEPS": "9000"}), ("three_chunks", {"FZP_SW_CHUNKS": "3"}), ("streams_on_their_own", {"FZP_TB_CONTIG": "1"}), ("bases_from_hbm", {"FZP_SWB_NO_RING": "1", "FZP_SWB_64": "1"})):
+                      ("pair_short_limit", {"FZP_SWB_PAIR": "1", "FZP_SWB_MAX_STEPS": "9000"}), ("three_chunks", {"FZP_SW_CHUNKS": "3"}), ("bases_from_hbm", {"FZP_SWB_NO_RING": "1", "FZP_SWB_64": "1"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         job = _lib.align_job_raw(eng, [ctg], blob, off, np.zeros(n, np.int32))
@@ -531,38 +513,6 @@ def test_terminal_on_the_border_reached_along_the_band_edge(eng, oracle, monkeyp
         job.close()
         for k in env:
             monkeypatch.delenv(k)
-
-
-def test_segmented_traceback_equals_serial_walk(eng, monkeypatch):
-    """The trace-back walks a long read as segments of 4 096 DP steps at once (speculative starts, stitched where neighbouring walkers meet) -- the
-    op stream must be the serial walk's (FZP_TB_SERIAL=1), also when the machinery behind it has to work: FZP_TB_GUESS_LANE=1 starts the walkers at
-    the band's edge; FZP_TB_OV_LIMIT=2 lets neighbours meet only in the first two steps below a boundary, so nearly every boundary asks for a repair
-    walk; with FZP_TB_REPAIR_ROUNDS=0 on top, those reads end in the serial walk."""
-    from falcon_unzip_amd import _lib
-    n = 500
-    ctg, blob, off, *_ = _shaped(49, 1_000_000, n)
-    got = {}
-    modes = (("segmented", {}), ("serial", {"FZP_TB_SERIAL": "1"}), ("edge_guess", {"FZP_TB_GUESS_LANE": "1"}), ("repairs", {"FZP_TB_OV_LIMIT": "2"}),
-             ("fallback", {"FZP_TB_OV_LIMIT": "2", "FZP_TB_REPAIR_ROUNDS": "0"}))
-    for mode, env in modes:
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        job = _lib.align_job_raw(eng, [ctg], blob, off, np.zeros(n, np.int32))
-        job.run()
-        aln = job.alnset(0)[0]
-        got[mode] = (job.summaries().copy(), [aln.cigar_of(k) for k in range(aln.n_rec)], job.tb_fallbacks())
-        job.close()
-        for k in env:
-            monkeypatch.delenv(k)
-    n_long = int((np.diff(off) > 20000).sum())
-    assert got["serial"][0]["aligned"].mean() > 0.99 and (np.diff(off) > 40000).sum() >= 3 and n_long > 50     # reads of a dozen and more segments are in
-    for mode, _ in modes:
-        assert np.array_equal(got[mode][0], got["serial"][0]), mode
-        assert got[mode][1] == got["serial"][1], mode
-    stats = {m: got[m][2] for m in got}
-    assert stats["serial"] == (0, 0) and stats["segmented"][0] == 0, stats
-    assert stats["repairs"][1] > n_long and stats["repairs"][0] <= stats["repairs"][1], stats          # boundaries were repaired, round after round
-    assert stats["fallback"][0] > 0.5 * n_long and stats["fallback"][1] == 0, stats                      # no repair launch: the flagged reads were walked serially
 
 
 def test_record_planning_at_deep_coverage(eng):

@@ -37,7 +37,7 @@ def _mutate(rng, seq, sub, ins, dele):
     return np.array(out, np.uint8)
 
 
-def _both(oracle, swb, q, t):
+def _both(oracle, swb, q, t, inner=0):
     nq, nt = len(q), len(t)
     cap = nq + nt + 8
     P = oracle_lib.AlignParams()
@@ -49,7 +49,7 @@ def _both(oracle, swb, q, t):
         args = [q.ctypes.data_as(C.c_void_p), C.c_int64(nq), t.ctypes.data_as(C.c_void_p), C.c_int64(nt)]
         if extra:
             args.append(C.byref(P))
-        args += [D.ctypes.data_as(C.c_void_p), G.ctypes.data_as(C.c_void_p), mv.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)]
+        args += [D.ctypes.data_as(C.c_void_p), G.ctypes.data_as(C.c_void_p), mv.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), C.c_int(inner)]
         assert fn(*args) == 0
         res.append((D, G, mv, out))
     return res
@@ -87,6 +87,10 @@ def test_masks_moves_terminal_equal_the_twin(oracle, swb, seed, L, sub, ins, del
         nt = min(len(ref), nq + nq // 4 + 64) if rep % 3 else min(len(ref), max(64, int(nq * (0.7 + 0.1 * rep))))     # also windows that end before the read does
         t = np.ascontiguousarray(ref[:nt])
         a, b, c = _both(oracle, swb, q, t)
+        _compare(a, b, nq, nt)
+        _compare(a, c, nq, nt)
+        # the same sub-matrix as an INNER piece (fzalign v1.6): the terminal is the border cell the global alignment to the corner passes through
+        a, b, c = _both(oracle, swb, q, t, inner=1)
         _compare(a, b, nq, nt)
         _compare(a, c, nq, nt)
 
