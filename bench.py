@@ -406,34 +406,9 @@ def main():
     # torch.distributed's all_gather otherwise (gloo dry runs) or if RCCL cannot be brought up identically on every rank
     comm, gather_note = None, None
     if world > 1 and backend == "nccl" and os.environ.get("FZP_BENCH_GATHER", "cabi") == "cabi":
-        # ncclCommInitRank is itself collective: every rank first proves locally that RCCL loads and its ctx binds (its own unique id is
-        # the probe), the ranks agree on that with an all_reduce(MIN), and only then does anybody enter the communicator's creation
-        why = ""
-        try:
-            my_id = _lib.comm_unique_id()
-        except Exception as e:      # noqa: BLE001
-            my_id, why = None, repr(e)
-        flag = torch.tensor([1 if my_id is not None else 0], dtype=torch.int32, device=coll_dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 1:
-            box = [my_id if rank == 0 else None]
-            dist.broadcast_object_list(box, src=0)
-            try:
-                comm = _lib.Comm(eng, rank, world, box[0])
-                if comm.ranks() != (rank, world):
-                    raise RuntimeError("communicator reports rank/size %r, expected %r" % (comm.ranks(), (rank, world)))
-            except Exception as e:      # noqa: BLE001
-                why = repr(e)
-                if comm is not None:
-                    comm.close()
-                comm = None
-            flag = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=coll_dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 0 and comm is not None:
-                comm.close()
-                comm = None
+        from falcon_unzip_amd import dist as fdist
+        comm, gather_note = fdist.make_comm(eng, rank, world, coll_dev)      # the agree-before-ncclCommInitRank handshake (dist.make_comm)
         if comm is None:
-            gather_note = "rank %d: RCCL C-ABI gather unavailable (%s); falling back to torch.distributed all_gather" % (rank, why or "another rank failed")
             print("bench.py: " + gather_note, file=sys.stderr, flush=True)
     out_root = None
     for cand in (args.out_root, None, "/dev/shm", REPO):          # --out-root, then $TMPDIR, then wherever a directory can be made

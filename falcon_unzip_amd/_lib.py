@@ -172,6 +172,7 @@ def load():
         "fzp_pipe_opts_default": (None, [VP]),
         "fzp_job_phase_write": (C.c_int, [VP, VP, VP, VP, VP]),
         "fzp_phase_contigs": (C.c_int, [VP, I32, VP, VP, I64, VP, VP, VP, VP, VP, VP]),
+        "fzp_phase_contigs_files": (C.c_int, [VP, CP, VP, VP, VP]),
         "fzp_pipe_out_free": (None, [VP]),
         "fzp_pipe_flush": (C.c_int, [VP]),
         "fzp_mem_info": (C.c_int, [VP, PSZ, PSZ]),
@@ -180,6 +181,7 @@ def load():
         "fzp_comm_ranks": (C.c_int, [VP, VP, VP]),
         "fzp_comm_destroy": (None, [VP]),
         "fzp_allgather_rid_to_phase": (C.c_int, [VP, VP, I64, PP, PI64]),
+        "fzp_format_rid_to_phase_all": (C.c_int, [VP, I64, VP, I32, PP, PSZ]),
         "fzp_align_alnset": (C.c_int, [VP, VP, I32, VP, CP, PP, PP]),
         "fzp_align_alnset_all": (C.c_int, [VP, VP, I32, VP, CP, PP, PP]),
         "fzp_align_to_batch": (C.c_int, [VP, VP, PP]),
@@ -657,6 +659,16 @@ def phase_contigs(eng, contigs, read_blob: bytes, read_off, read_ctg, ctg_ids, n
     return _pipe_result(out)
 
 
+def phase_contigs_files(eng, reads_dir, ctg_ids, out_dir=None, read_maps=None, ctg_index=None, n_threads=0, n_lanes=0, group_bases=0, params=None, consensus=False,
+                        async_writes=False, bam=False, sentinels=False):
+    """fzp_phase_contigs_files: like phase_contigs, the inputs read by the library from <reads_dir>/<ctg>_ref.fa and <ctg>_reads.fa.  -> (stats dict, R2P records)"""
+    nm, opts, keep = _pipe_args(ctg_ids, None, out_dir, read_maps, ctg_index, n_threads, n_lanes, group_bases, params,
+                                (PIPE_CONSENSUS if consensus else 0) | (PIPE_ASYNC_WRITES if async_writes else 0) | (PIPE_BAM if bam else 0) | (PIPE_SENTINELS if sentinels else 0))
+    out = PipeOut()
+    _check(load().fzp_phase_contigs_files(eng._p, reads_dir.encode() if isinstance(reads_dir, str) else reads_dir, C.byref(nm), C.byref(opts), C.byref(out)))
+    return _pipe_result(out)
+
+
 def comm_unique_id() -> bytes:
     """RCCL unique id (rank 0 creates it and hands it to the other ranks)"""
     buf = C.create_string_buffer(128)
@@ -692,6 +704,14 @@ class Comm:
             self._p = None
 
     __del__ = close
+
+
+def format_rid_to_phase_all(records, ctg_ids):
+    """`rid_to_phase.all` (unzip.py:285) from gathered records in the order given: fzp_format_rid_to_phase_all"""
+    recs = np.ascontiguousarray(records, dtype=R2P)
+    enc = [c.encode() if isinstance(c, str) else c for c in ctg_ids]
+    arr = (C.c_char_p * max(1, len(enc)))(*enc)
+    return _fmt("fzp_format_rid_to_phase_all", _ptr(recs), C.c_int64(len(recs)), arr, C.c_int32(len(enc)))
 
 
 def format_sam(aln: AlnSet, ctg_id: str, flags=None):

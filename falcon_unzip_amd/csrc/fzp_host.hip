@@ -728,6 +728,24 @@ void split_nl(const char *s, size_t n, std::vector<Tok> &out) {   // text.split(
 }
 }  // namespace
 
+// rid_to_phase.all from the gathered records (get_rid_to_phase_all, unzip.py:303-314: the concatenation of every rid_to_phase.<ctg>, whose rows
+// phasing_readmap.py:47-51 prints as '%09d ctg block phase'); records in the order given -- fzp_allgather_rid_to_phase returns the file's order
+extern "C" int fzp_format_rid_to_phase_all(const fzp_r2p *recs, int64_t n, const char *const *ctg_ids, int32_t n_ctg, char **text, size_t *len) {
+    if ((n && !recs) || n < 0 || !ctg_ids || !text || !len) { fzp_set_error("fzp_format_rid_to_phase_all: bad arguments"); return FZP_EINVAL; }
+    std::vector<size_t> cl((size_t)(n_ctg > 0 ? n_ctg : 0));
+    for (int32_t c = 0; c < n_ctg; c++) cl[(size_t)c] = strlen(ctg_ids[c]);
+    TextBuf b;
+    for (int64_t i = 0; i < n; i++) {
+        const fzp_r2p &r = recs[i];
+        if (r.ctg < 0 || r.ctg >= n_ctg) { free(b.p); fzp_set_error("rid_to_phase record %lld: contig index %d of %d", (long long)i, r.ctg, n_ctg); return FZP_EINVAL; }
+        if (!b.reserve(cl[(size_t)r.ctg] + 64)) return FZP_ENOMEM;
+        char t[16];
+        const int k = snprintf(t, sizeof t, "%09d", r.arid);
+        b.put(t, (size_t)k); b.putc_(' '); b.put(ctg_ids[r.ctg], cl[(size_t)r.ctg]); b.putc_(' '); b.puti(r.block); b.putc_(' '); b.puti(r.phase); b.putc_('\n');
+    }
+    return b.finish(text, len);
+}
+
 extern "C" int fzp_readmap(const char *phased_reads, size_t pr_len, const char *rawread_ids, size_t rr_len,
                            const char *pread_ids, size_t pi_len, const char *p2c, size_t pc_len,
                            const char *ctg_id, int32_t ctg_index, fzp_r2p **recs, int64_t *n_recs, char **text, size_t *len) {

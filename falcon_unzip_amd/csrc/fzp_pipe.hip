@@ -742,6 +742,246 @@ extern "C" int fzp_phase_contigs(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *con
     return FZP_OK;
 }
 
+// ---- inputs from the reference's own files: <reads_dir>/<ctg>_ref.fa, <ctg>_reads.fa (unzip.py:204,233-234; read at phasing.py:489-494 and by blasr).
+// A FASTA file is mapped and scanned with memchr; a group's files are parsed side by side on host threads, one contig group AHEAD of the lanes that align
+// them, so what is in host memory at any time is the groups in flight -- not the rank's reads.
+#include <sys/mman.h>
+namespace {
+struct FastaRecs { std::vector<uint8_t> seq; std::vector<int64_t> off; std::string names; std::vector<int64_t> noff; };
+// every record of a FASTA file: name = first word of the header, sequence = its lines joined, white space at line ends dropped (falcon_kit's FastaReader as
+// phasing.py:490-494 uses it).  only_name != nullptr: keep only records of that name (the LAST one wins, as the loop at phasing.py:490-494 leaves it).
+int parse_fasta(const std::string &path, const char *only_name, FastaRecs &R, std::string &err) {
+    R.off.assign(1, 0); R.noff.assign(1, 0);
+    const int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) { err = path + ": " + strerror(errno); return FZP_EIO; }
+    struct stat sb;
+    if (fstat(fd, &sb) != 0) { err = path + ": " + strerror(errno); close(fd); return FZP_EIO; }
+    const size_t n = (size_t)sb.st_size;
+    if (n == 0) { close(fd); return FZP_OK; }
+    void *mp = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (mp == MAP_FAILED) { err = path + ": mmap: " + strerror(errno); return FZP_EIO; }
+    (void)madvise(mp, n, MADV_SEQUENTIAL);
+    const char *p = (const char *)mp, *end = p + n;
+    const size_t want = only_name ? strlen(only_name) : 0;
+    if (!only_name) R.seq.reserve(n);
+    bool keep = false, any = false;
+    auto is_sp = [](char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\n' || c == '\v' || c == '\f'; };
+    while (p < end) {
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+        const char *le = nl ? nl : end;
+        if (*p == '>') {
+            if (any && keep) { R.off.push_back((int64_t)R.seq.size()); R.noff.push_back((int64_t)R.names.size()); }
+            const char *a = p + 1;
+            while (a < le && is_sp(*a)) a++;
+            const char *b = a;
+            while (b < le && !is_sp(*b)) b++;
+            keep = !only_name || ((size_t)(b - a) == want && memcmp(a, only_name, want) == 0);
+            if (keep && only_name) { R.seq.clear(); R.names.clear(); R.off.assign(1, 0); R.noff.assign(1, 0); }      // a later record of the same name replaces the earlier one
+            if (keep) R.names.append(a, (size_t)(b - a));
+            any = true;
+        } else if (keep) {
+            const char *a = p, *b = le;
+            while (a < b && is_sp(*a)) a++;
+            while (b > a && is_sp(b[-1])) b--;
+            R.seq.insert(R.seq.end(), (const uint8_t *)a, (const uint8_t *)b);
+        }
+        p = nl ? nl + 1 : end;
+    }
+    if (any && keep) { R.off.push_back((int64_t)R.seq.size()); R.noff.push_back((int64_t)R.names.size()); }
+    munmap(mp, n);
+    return FZP_OK;
+}
+struct GroupIn {
+    std::vector<FastaRecs> ref, reads;           // per contig of the group
+    std::vector<uint8_t> blob;                   // the group's reads, contig after contig
+    std::vector<int64_t> off, noff;
+    std::vector<int32_t> read_ctg;
+    std::string names;
+    int rc = FZP_OK;
+    std::string err;
+};
+void load_group(const std::string &dir, const char *const *ctg_id, int c0, int c1, int n_threads, GroupIn &G) {
+    const int gc = c1 - c0;
+    G.ref.resize((size_t)gc); G.reads.resize((size_t)gc);
+    std::vector<int> rcs((size_t)2 * gc, FZP_OK);
+    std::vector<std::string> errs((size_t)2 * gc);
+    std::atomic<int> next{0};
+    auto work = [&]() {
+        for (int t; (t = next.fetch_add(1)) < 2 * gc;) {
+            const int c = t >> 1;
+            const std::string base = dir + "/" + ctg_id[c0 + c];
+            rcs[(size_t)t] = (t & 1) ? parse_fasta(base + "_ref.fa", ctg_id[c0 + c], G.ref[(size_t)c], errs[(size_t)t]) : parse_fasta(base + "_reads.fa", nullptr, G.reads[(size_t)c], errs[(size_t)t]);
+        }
+    };
+    std::vector<std::thread> th;
+    const int nt = std::max(1, std::min(n_threads, 2 * gc));
+    for (int i = 1; i < nt; i++) th.emplace_back(work);
+    work();
+    for (auto &x : th) x.join();
+    for (int t = 0; t < 2 * gc; t++) if (rcs[(size_t)t] != FZP_OK) { G.rc = rcs[(size_t)t]; G.err = errs[(size_t)t]; return; }
+    size_t nb = 0, nn = 0, nr = 0;
+    for (auto &R : G.reads) { nb += R.seq.size(); nn += R.names.size(); nr += R.off.size() - 1; }
+    G.blob.resize(nb); G.names.resize(nn);
+    G.off.assign(1, 0); G.noff.assign(1, 0);
+    G.off.reserve(nr + 1); G.noff.reserve(nr + 1); G.read_ctg.reserve(nr);
+    size_t ab = 0, an = 0;
+    for (int c = 0; c < gc; c++) {
+        FastaRecs &R = G.reads[(size_t)c];
+        if (!R.seq.empty()) memcpy(G.blob.data() + ab, R.seq.data(), R.seq.size());
+        if (!R.names.empty()) memcpy(&G.names[an], R.names.data(), R.names.size());
+        for (size_t k = 1; k < R.off.size(); k++) { G.off.push_back((int64_t)ab + R.off[k]); G.noff.push_back((int64_t)an + R.noff[k]); G.read_ctg.push_back(c); }
+        ab += R.seq.size(); an += R.names.size();
+        std::vector<uint8_t>().swap(R.seq);
+        std::string().swap(R.names);
+    }
+}
+}  // namespace
+
+extern "C" int fzp_phase_contigs_files(fzp_ctx *ctx, const char *reads_dir, const fzp_names *nm, const fzp_pipe_opts *opts, fzp_pipe_out *out) {
+    if (!ctx || !reads_dir || !nm || !nm->ctg_id || nm->n_ctg <= 0 || !out) { fzp_set_error("fzp_phase_contigs_files: bad arguments"); return FZP_EINVAL; }
+    fzp_pipe_opts o;
+    if (opts) o = *opts; else fzp_pipe_opts_default(&o);
+    memset(out, 0, sizeof *out);
+    const int n_ctg = nm->n_ctg;
+    const std::string dir(reads_dir);
+    const bool timing = getenv("FZP_PIPE_TIMING") != nullptr;
+    const auto t_call = clk::now();
+    MapsHolder mh;
+    mh.start(&o);
+    // read bases per contig ~ the size of its reads file (names are a few per cent of it): sizes the contig groups before anything is parsed
+    std::vector<int64_t> bases((size_t)n_ctg, 0);
+    for (int c = 0; c < n_ctg; c++) {
+        struct stat sb;
+        const std::string p = dir + "/" + nm->ctg_id[c] + "_reads.fa";
+        if (stat(p.c_str(), &sb) != 0) { fzp_set_error("%s: %s", p.c_str(), strerror(errno)); return FZP_EIO; }
+        bases[(size_t)c] = (int64_t)sb.st_size;
+    }
+    FZP_TRY(fzp_bind(ctx));
+    size_t fr = 0, tot = 0;
+    FZP_HIP(hipMemGetInfo(&fr, &tot));
+    int lanes = o.n_lanes > 0 ? o.n_lanes : 2;
+    int64_t group_bases = o.group_bases;
+    if (group_bases <= 0) {
+        int64_t all = 0;
+        for (auto v : bases) all += v;
+        group_bases = std::min<int64_t>((int64_t)((double)tot * 0.55 / lanes / 40.0), std::max<int64_t>(64ll << 20, all / (2 * lanes)));
+    }
+    struct Group { int c0, c1; };
+    std::vector<Group> groups;
+    for (int c = 0; c < n_ctg;) {
+        int e = c;
+        int64_t acc = 0;
+        while (e < n_ctg && (e == c || acc + bases[(size_t)e] <= group_bases)) { acc += bases[(size_t)e]; e++; }
+        groups.push_back({c, e});
+        c = e;
+    }
+    lanes = std::min<int>(lanes, (int)groups.size());
+    const int device = ctx->device;
+    while ((int)ctx->lanes.size() < lanes - 1) {
+        fzp_ctx *lc = nullptr;
+        FZP_TRY(fzp_ctx_create(device, 0, &lc));
+        ctx->lanes.push_back(lc);
+    }
+    const int host_threads = o.n_threads > 0 ? o.n_threads : std::max(2u, std::thread::hardware_concurrency());
+    // the loader: group g's files are parsed when a lane takes group g - (lanes + 1) at the latest
+    std::vector<std::shared_ptr<GroupIn>> gin(groups.size());
+    std::vector<std::future<void>> loading(groups.size());
+    std::mutex ld_mu;
+    size_t n_started = 0;
+    auto start_loads = [&](size_t upto) {        // (callers hold ld_mu)
+        for (; n_started < std::min(upto, groups.size()); n_started++) {
+            const size_t g = n_started;
+            gin[g] = std::make_shared<GroupIn>();
+            GroupIn *G = gin[g].get();
+            const Group gr = groups[g];
+            loading[g] = std::async(std::launch::async, [&, G, gr]() { load_group(dir, nm->ctg_id, gr.c0, gr.c1, std::max(2, host_threads / 2), *G); });
+        }
+    };
+    { std::lock_guard<std::mutex> lk(ld_mu); start_loads((size_t)lanes + 1); }
+    std::atomic<size_t> next{0};
+    std::vector<int> rcs((size_t)lanes, FZP_OK);
+    std::vector<std::string> errs((size_t)lanes);
+    std::vector<fzp_pipe_out> outs((size_t)lanes);
+    std::vector<std::vector<fzp_r2p>> r2p_g(groups.size());
+    std::vector<double> ms_parse((size_t)lanes, 0.0);
+    std::mutex up_mu;
+    auto lane = [&](int li) {
+        fzp_ctx *lc = li == 0 ? ctx : ctx->lanes[(size_t)li - 1];
+        if (fzp_bind(lc) != FZP_OK) { rcs[(size_t)li] = FZP_EDEVICE; errs[(size_t)li] = fzp_last_error(); return; }
+        fzp_pipe_out &po = outs[(size_t)li];
+        memset(&po, 0, sizeof po);
+        for (;;) {
+            const size_t g = next.fetch_add(1);
+            if (g >= groups.size()) break;
+            const Group &Gr = groups[g];
+            std::shared_ptr<GroupIn> G;
+            {
+                std::lock_guard<std::mutex> lk(ld_mu);
+                start_loads(g + (size_t)lanes + 1);
+                G = gin[g];
+            }
+            auto t0 = clk::now();
+            loading[g].wait();                                  // (normally done long ago: it was started a group ahead)
+            ms_parse[(size_t)li] += ms_since(t0);
+            int rc = G->rc;
+            if (rc != FZP_OK) { errs[(size_t)li] = G->err; rcs[(size_t)li] = rc; break; }
+            const int gc = Gr.c1 - Gr.c0;
+            const int64_t gr_n = (int64_t)G->read_ctg.size();
+            std::vector<const uint8_t *> cptr((size_t)gc);
+            std::vector<int64_t> clen((size_t)gc);
+            static const uint8_t none_[1] = {0};
+            for (int c = 0; c < gc; c++) { clen[(size_t)c] = (int64_t)G->ref[(size_t)c].seq.size(); cptr[(size_t)c] = clen[(size_t)c] ? G->ref[(size_t)c].seq.data() : none_; }
+            t0 = clk::now();
+            fzp_alnjob *job = nullptr;
+            {   // one upload at a time (see fzp_phase_contigs)
+                std::lock_guard<std::mutex> lk(up_mu);
+                rc = fzp_align_create(lc, gc, cptr.data(), clen.data(), gr_n, G->read_ctg.data(), G->off.data(), G->blob.data(), &o.align, &job);
+            }
+            po.ms_upload += ms_since(t0);
+            if (rc == FZP_OK) {
+                std::vector<uint8_t>().swap(G->blob);           // the reads are on the device now
+                fzp_names gn;
+                gn.n_ctg = gc; gn.ctg_id = nm->ctg_id + Gr.c0;
+                gn.name_off = G->noff.data();
+                gn.names = G->names.data();
+                std::vector<int32_t> gi;
+                for (int c = Gr.c0; c < Gr.c1; c++) gi.push_back(o.ctg_index ? o.ctg_index[c] : c);
+                rc = job_phase_write(lc, job, &gn, &o, mh, gi.data(), &po, r2p_g[g]);
+                if (rc == FZP_OK) {
+                    std::vector<fzp_aln_summary> sm((size_t)gr_n);
+                    if (gr_n && fzp_align_summaries(lc, job, sm.data()) == FZP_OK) for (auto &s : sm) po.dp_cells += (double)s.cells;
+                }
+            }
+            if (rc != FZP_OK) errs[(size_t)li] = fzp_last_error();
+            fzp_align_destroy(lc, job);
+            po.n_reads += gr_n;
+            { std::lock_guard<std::mutex> lk(ld_mu); gin[g].reset(); }
+            if (rc != FZP_OK) { rcs[(size_t)li] = rc; break; }
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int li = 1; li < lanes; li++) th.emplace_back(lane, li);
+        lane(0);
+        for (auto &x : th) x.join();
+    }
+    for (size_t g = 0; g < n_started; g++) if (loading[g].valid()) loading[g].wait();      // (after an error: loads still running hold references into this frame)
+    (void)fzp_bind(ctx);
+    const int frc = fzp_pipe_flush(ctx);
+    if (timing) { double w = 0; for (auto v : ms_parse) w += v; fprintf(stderr, "[fzp_phase_contigs_files] %.2f ms in the call, %.2f ms of it waiting for the parser (%d lanes, %zu groups)\n", ms_since(t_call), w, lanes, groups.size()); }
+    for (int li = 0; li < lanes; li++) if (rcs[(size_t)li] != FZP_OK) { fzp_set_error("%s", errs[(size_t)li].c_str()); return rcs[(size_t)li]; }
+    if (frc != FZP_OK) return frc;
+    for (int li = 0; li < lanes; li++) add(out, outs[(size_t)li]);
+    std::vector<fzp_r2p> all;
+    for (auto &v : r2p_g) all.insert(all.end(), v.begin(), v.end());
+    out->n_r2p = (int64_t)all.size();
+    out->r2p = (fzp_r2p *)malloc((all.size() ? all.size() : 1) * sizeof(fzp_r2p));
+    if (!out->r2p) return FZP_ENOMEM;
+    if (!all.empty()) memcpy(out->r2p, all.data(), all.size() * sizeof(fzp_r2p));
+    return FZP_OK;
+}
+
 extern "C" int fzp_pipe_flush(fzp_ctx *ctx) {
     if (!ctx) return FZP_EINVAL;
     std::string err;

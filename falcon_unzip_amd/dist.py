@@ -98,5 +98,51 @@ def allgather_r2p(local, device=None):
 
 
 def format_rid_to_phase_all(records, ctg_ids):
-    """`rid_to_phase.all` text: '%09d ctg block phase' rows (phasing_readmap.py:47-51)."""
-    return "".join("%09d %s %d %d\n" % (r["arid"], ctg_ids[r["ctg"]], r["block"], r["phase"]) for r in records).encode()
+    """`rid_to_phase.all` text: '%09d ctg block phase' rows (phasing_readmap.py:47-51), by the library's formatter (fzp_format_rid_to_phase_all)."""
+    from . import _lib
+    return _lib.format_rid_to_phase_all(records, ctg_ids)
+
+
+def make_comm(eng, rank, world, coll_dev):
+    """The library's own communicator for the exchange step (fzp_comm over RCCL, one process per GPU), brought up safely: ncclCommInitRank is itself
+    collective, so every rank first proves locally that RCCL loads and its context binds (its own unique id is the probe), the ranks agree on that
+    with an all_reduce(MIN) over the process group that started them, and only then does anybody enter the communicator's creation; a second
+    agreement afterwards.  -> (Comm or None, why-not text or None); None means: use allgather_r2p over torch.distributed (said out loud by the caller)."""
+    import torch
+    import torch.distributed as tdist
+    from . import _lib
+    comm, why = None, ""
+    try:
+        my_id = _lib.comm_unique_id()
+    except Exception as e:      # noqa: BLE001
+        my_id, why = None, repr(e)
+    flag = torch.tensor([1 if my_id is not None else 0], dtype=torch.int32, device=coll_dev)
+    tdist.all_reduce(flag, op=tdist.ReduceOp.MIN)
+    if int(flag.item()) == 1:
+        box = [my_id if rank == 0 else None]
+        tdist.broadcast_object_list(box, src=0)
+        try:
+            comm = _lib.Comm(eng, rank, world, box[0])
+            if comm.ranks() != (rank, world):
+                raise RuntimeError("communicator reports rank/size %r, expected %r" % (comm.ranks(), (rank, world)))
+        except Exception as e:      # noqa: BLE001
+            why = repr(e)
+            if comm is not None:
+                comm.close()
+            comm = None
+        flag = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=coll_dev)
+        tdist.all_reduce(flag, op=tdist.ReduceOp.MIN)
+        if int(flag.item()) == 0 and comm is not None:
+            comm.close()
+            comm = None
+    if comm is None:
+        return None, "rank %d: RCCL C-ABI gather unavailable (%s); falling back to torch.distributed all_gather" % (rank, why or "another rank failed")
+    return comm, None
+
+
+def gather_r2p(local, comm=None):
+    """The exchange step: fzp_allgather_rid_to_phase on the library's communicator when there is one, torch.distributed otherwise; either way every
+    rank gets all records in (contig index, arid) order."""
+    if comm is not None:
+        return comm.allgather_r2p(local)
+    return allgather_r2p(local)

@@ -128,8 +128,33 @@ def phase_contigs(eng, jobs, unzip_dir, read_map_dir=None, write_sam=False, ctg_
     return recs
 
 
+def phase_contigs_files(eng, unzip_dir, ctg_ids, read_map_dir=None, write_sam=False, ctg_indices=None, consensus=True, n_lanes=0, group_bases=0, sentinels=True):
+    """phase_contigs with the inputs read by the library itself from `<unzip_dir>/reads/<ctg>_ref.fa` / `<ctg>_reads.fa` (unzip.py:204,233-234; the
+    record of <ctg>_ref.fa named <ctg> is the contig, phasing.py:489-494): fzp_phase_contigs_files.  Same outputs, same sentinels."""
+    if ctg_indices is None:
+        ctg_indices = list(range(len(ctg_ids)))
+    maps = load_read_maps(read_map_dir) if read_map_dir is not None else None
+    out_dir = os.path.join(unzip_dir, "0-phasing")
+    os.makedirs(out_dir, exist_ok=True)
+    try:
+        stats, recs = _lib.phase_contigs_files(eng, os.path.join(unzip_dir, "reads"), list(ctg_ids), out_dir=out_dir, read_maps=maps, ctg_index=ctg_indices,
+                                               n_lanes=n_lanes, group_bases=group_bases, consensus=consensus, bam=write_sam, sentinels=sentinels)
+    except Exception:
+        if sentinels:
+            for ctg in ctg_ids:
+                if write_sam:
+                    _touch(os.path.join(out_dir, ctg, "blasr", "aln_%s_done.exit" % ctg))
+                _touch(os.path.join(out_dir, ctg, "phasing", "p_%s_done.exit" % ctg))
+        raise
+    phase_contigs_files.last_stats = stats
+    return recs
+
+
 def run(unzip_dir, read_map_dir=None, ctg_ids=None, device=None, write_sam=True, consensus=True):
-    """Whole phasing section of unzip_all for this rank (one process per GPU under torch.distributed.run)."""
+    """Whole phasing section of unzip_all for this rank (one process per GPU under torch.distributed.run): the rank's contigs streamed from
+    `reads/<ctg>_{ref,reads}.fa` by the library (fzp_phase_contigs_files: the FASTA files are parsed by its host threads a contig group ahead of the
+    device, no whole-rank lists in Python), one exchange step -- the library's own RCCL all-gather (fzp_allgather_rid_to_phase) when the ranks
+    sit on their own GPUs under backend nccl, torch.distributed's otherwise (gloo dry runs; said on stderr when it is a fallback)."""
     import torch.distributed as tdist
     rank = tdist.get_rank() if tdist.is_available() and tdist.is_initialized() else 0
     world = tdist.get_world_size() if tdist.is_available() and tdist.is_initialized() else 1
@@ -144,14 +169,25 @@ def run(unzip_dir, read_map_dir=None, ctg_ids=None, device=None, write_sam=True,
         except OSError:
             weights.append(0)
     mine = fdist.shard_contigs(weights, world)[rank]
-    eng = _lib.Engine(int(os.environ.get("LOCAL_RANK", "0")) if device is None else device)
+    dev = int(os.environ.get("LOCAL_RANK", "0")) if device is None else device
+    if world > 1 and tdist.get_backend() != "nccl":            # dry runs: several ranks share what devices there are
+        import torch
+        dev = dev % max(1, torch.cuda.device_count())
+    eng = _lib.Engine(dev)
+    comm, note = None, None
+    if world > 1 and tdist.get_backend() == "nccl" and os.environ.get("FZP_GATHER", "cabi") == "cabi":
+        comm, note = fdist.make_comm(eng, rank, world, "cuda:%d" % dev)
+        if comm is None:
+            print("pipeline.run: " + note, file=sys.stderr, flush=True)
     local = np.zeros(0, _lib.R2P)
     if mine:
-        jobs = load_contig_jobs(unzip_dir, [ctg_ids[i] for i in mine])
         # contig indices are global so that the gathered records sort like the reference's file list
-        local = phase_contigs(eng, jobs, unzip_dir, read_map_dir, write_sam=write_sam, ctg_indices=mine, consensus=consensus)
+        local = phase_contigs_files(eng, unzip_dir, [ctg_ids[i] for i in mine], read_map_dir, write_sam=write_sam, ctg_indices=mine, consensus=consensus)
+    allr = fdist.gather_r2p(local, comm)
+    run.last_gather = "fzp_allgather_rid_to_phase (RCCL)" if comm is not None else ("torch.distributed (%s)" % tdist.get_backend() if world > 1 else "none (1 rank)")
+    if comm is not None:
+        comm.close()
     eng.close()
-    allr = fdist.allgather_r2p(local)
     if rank == 0 and read_map_dir is not None:
         out_dir = os.path.join(unzip_dir, "1-hasm", "rid-to-phase-all")
         os.makedirs(out_dir, exist_ok=True)

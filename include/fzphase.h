@@ -342,6 +342,10 @@ int fzp_job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *names, c
 /* inputs in host memory (arguments as fzp_align_create): groups of contigs streamed through the device */
 int fzp_phase_contigs(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *const *ctg_seq, const int64_t *ctg_len, int64_t n_reads, const int32_t *read_ctg,
                       const int64_t *read_off, const uint8_t *read_seq, const fzp_names *names, const fzp_pipe_opts *opts, fzp_pipe_out *out);
+/* inputs in the reference's own files: <reads_dir>/<ctg_id>_ref.fa (the record named <ctg_id> is the contig, phasing.py:489-494) and <ctg_id>_reads.fa
+ * (unzip.py:204,233-234) for every names->ctg_id; names->name_off / names are ignored (read names come from the FASTA headers, first word).  The files are
+ * parsed by host threads one contig group ahead of the lanes; host memory holds the groups in flight, never the whole call's reads. */
+int fzp_phase_contigs_files(fzp_ctx *ctx, const char *reads_dir, const fzp_names *names, const fzp_pipe_opts *opts, fzp_pipe_out *out);
 void fzp_pipe_out_free(fzp_pipe_out *o);
 int fzp_pipe_flush(fzp_ctx *ctx);   /* every queued file of FZP_PIPE_ASYNC_WRITES calls on this ctx (and its lanes) is on the file system when this returns */
 
@@ -357,6 +361,8 @@ int fzp_comm_create(fzp_ctx *ctx, int rank, int world, const char id[FZP_COMM_ID
 int fzp_comm_ranks(fzp_comm *c, int *rank, int *world);      /* as ncclCommUserRank / ncclCommCount report them */
 void fzp_comm_destroy(fzp_comm *c);
 int fzp_allgather_rid_to_phase(fzp_comm *c, const fzp_r2p *local, int64_t n_local, fzp_r2p **all /* fzp_free */, int64_t *n_all);
+/* rid_to_phase.all (unzip.py:285, 303-314) from gathered records in the order given: '%09d ctg block phase' rows (phasing_readmap.py:47-51), ctg = ctg_ids[record.ctg] */
+int fzp_format_rid_to_phase_all(const fzp_r2p *recs, int64_t n, const char *const *ctg_ids, int32_t n_ctg, char **text, size_t *len);
 
 /* ---- BAM emitter / reader ("next" row n1).  The reference's blasr task writes <ctg>_sorted.bam + index
  * (unzip.py:86-91) and make_het_call reads it through `samtools view <bam> <ctg>` (phasing.py:27).

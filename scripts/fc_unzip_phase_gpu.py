@@ -22,8 +22,12 @@ def main(argv=sys.argv):
         import torch
         import torch.distributed as dist
         lr = int(os.environ.get("LOCAL_RANK", "0"))
-        torch.cuda.set_device(lr)
-        dist.init_process_group(backend=os.environ.get("FZP_BACKEND", "nccl"), device_id=torch.device("cuda", lr))
+        backend = os.environ.get("FZP_BACKEND", "nccl")
+        if backend == "nccl":                                  # one process per GPU; the exchange step is the library's own RCCL all-gather (pipeline.run)
+            torch.cuda.set_device(lr)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", lr))
+        else:                                                  # dry runs (gloo): the ranks share what devices there are
+            dist.init_process_group(backend=backend)
     from falcon_unzip_amd import pipeline
     pipeline.run(args.unzip_dir, args.read_map_dir)
     if world > 1:

@@ -45,7 +45,7 @@ def make_job(total_bases, cov=40, R=15000, workers=8, slab=2000, seed=20265000):
     Ls = contig_lengths(total_bases, rng)
     jobs = [(ci, L, cov, R, slab) for ci, L in enumerate(Ls)]
     if workers > 1:
-        with mp.get_context("fork").Pool(min(workers, len(jobs))) as pool:
+        with mp.get_context("spawn").Pool(min(workers, len(jobs))) as pool:      # (spawn: a caller that has initialised the GPU -- pytest -- must not fork)
             res = pool.map(gen_contig, jobs)
     else:
         res = [gen_contig(j) for j in jobs]

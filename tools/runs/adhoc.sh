@@ -1,7 +1,7 @@
 export TMPDIR=/tmp
-mkdir -p gpurun_out
-timeout 600 python3 -m pytest -m gpu -x -q tests/test_gpu_align.py -k "border_reached or three_dp" > gpurun_out/r4b_fixed.log 2>&1; echo "fixed rc=$?"
-sed -i 's/safe = min(rows_left, cols_left) - 1;/safe = min(rows_left, cols_left);/' falcon_unzip_amd/csrc/fzp_align.hip
-make -C falcon_unzip_amd/csrc -j4 > gpurun_out/r4b_make.log 2>&1; echo "make rc=$?"
-timeout 600 python3 -m pytest -m gpu -x -q tests/test_gpu_align.py -k "border_reached" > gpurun_out/r4b_old.log 2>&1; echo "old-safe rc=$? (expected non-zero)"
-tail -5 gpurun_out/r4b_fixed.log; grep -n "^E  " gpurun_out/r4b_old.log | head -5
+echo "mem.max: $(cat /sys/fs/cgroup/memory.max 2>/dev/null)"; free -g | head -2; df -h /tmp /dev/shm . | cat; nproc
+B="--no-cpu-baseline --no-end-to-end --no-shaped-leg --gen-workers 1 --steps 5 --warmup 2"
+for dbg in 0 1 2 3; do
+  FZP_SWB_DBG=$dbg timeout 100 python3 bench.py $B 2>/dev/null | python3 -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['kernel_ms_per_step']; print('dbg $dbg', 'ms', d['ms_per_step'], 'k1_sw', k['k1_sw'], 'tb', k['k1_traceback'], 'seed', k['k1_seed'])"
+done
