@@ -108,6 +108,36 @@ def make_names_and_maps(read_ctg, off, ids, arid_base):
     return (noff, b"".join(names)), (rawread_ids, pread_ids, p2c)
 
 
+def write_reads_tree(contigs, blob, off, read_ctg, ids, name_tab, root):
+    """<root>/fzp_bench_reads_*/: <ctg>_ref.fa and <ctg>_reads.fa as fc_unzip.py's fetch_reads leaves them (unzip.py:204,233-234): one line per sequence"""
+    import tempfile
+    d = tempfile.mkdtemp(prefix="fzp_bench_reads_", dir=root)
+    noff, nblob = name_tab
+    mv = memoryview(blob)
+    for c, cid in enumerate(ids):
+        with open(os.path.join(d, "%s_ref.fa" % cid), "wb") as f:
+            f.write(b">" + cid.encode() + b"\n")
+            f.write(contigs[c])
+            f.write(b"\n")
+        with open(os.path.join(d, "%s_reads.fa" % cid), "wb") as f:
+            parts = []
+            for r in np.flatnonzero(read_ctg == c):
+                parts += [b">", nblob[noff[r]:noff[r + 1]], b"\n", mv[off[r]:off[r + 1]], b"\n"]
+            f.write(b"".join(parts))
+    return d
+
+
+def tree_digest(root):
+    import hashlib
+    h = hashlib.sha256()
+    for d, _, files in sorted(os.walk(root)):
+        for fn in sorted(files):
+            with open(os.path.join(d, fn), "rb") as fh:
+                h.update(os.path.relpath(os.path.join(d, fn), root).encode())
+                h.update(fh.read())
+    return h.hexdigest()
+
+
 def host_cores():
     """threads this process may really use: the affinity mask and the cgroup CPU quota, not the machine's thread count (the GPU boxes show 256
     hardware threads behind a 16-CPU quota)"""
@@ -347,6 +377,7 @@ def main():
     ap.add_argument("--strong-leg-contigs", type=int, default=500, help="N > 1 runs: contigs of the strong_cfg3 leg (0 = no such leg)")
     ap.add_argument("--strong-leg-contig-len", type=int, default=750_000)
     ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--no-from-files", action="store_true", help="skip the from_files leg (the end-to-end workload from FASTA files on a memory file system)")
     ap.add_argument("--e2e-lanes", type=int, default=2)
     ap.add_argument("--e2e-group-contigs", type=int, default=10)
     ap.add_argument("--with-consensus", action="store_true", help="also run K6 (phased-pile consensus, BASELINE config 4) inside every step")
@@ -534,6 +565,37 @@ def main():
         e2e["other_shape"] = {k: v for k, v in max(tried, key=lambda x: x["ms"]).items() if k in ("reads_per_s", "ms", "lanes", "groups")}
         e2e["note"] = "fzp_phase_contigs: host ASCII -> H2D -> pack -> K1..K5 -> texts -> files; PCIe-inclusive, reported beside `value`, never as it"
 
+    from_files = None
+    if e2e is not None and not args.no_from_files:
+        # the same workload from the reference's own input files (unzip.py:204,233-234: reads/<ctg>_ref.fa, <ctg>_reads.fa) on a memory file system: FASTA parsing
+        # (the library's, a contig group ahead of the lanes) inside the clock as well -- what scripts/fc_unzip_phase_gpu.py does per rank.  Never `value`.
+        import shutil
+        reads_dir = None
+        try:
+            reads_dir = write_reads_tree(contigs, blob, off, read_ctg, ids, name_tab, "/dev/shm" if os.path.isdir("/dev/shm") else out_root)
+            gc, lanes = (len(mine), 1) if e2e["lanes"] == 1 else (args.e2e_group_contigs, args.e2e_lanes)
+            gb = int(gc * args.reads_per_contig * args.read_len * 1.09)      # (file sizes: bases + names)
+            runs = []
+            for k in range(3):
+                t1 = time.perf_counter()
+                st, recs_f = _lib.phase_contigs_files(eng, reads_dir, ids, out_dir=os.path.join(out_root, "files_%d" % k), read_maps=maps, ctg_index=mine, n_lanes=lanes, group_bases=gb,
+                                                      consensus=args.with_consensus, async_writes=True)
+                runs.append((time.perf_counter() - t1, st))
+            best = min(runs[1:], key=lambda x: x[0])
+            _, recs_m = _lib.phase_contigs(eng, contigs, blob, off, read_ctg, ids, names=name_tab, out_dir=os.path.join(out_root, "files_ref"), read_maps=maps, ctg_index=mine,
+                                           n_lanes=lanes, group_bases=int(gc * args.reads_per_contig * args.read_len * 1.06), consensus=args.with_consensus, async_writes=True)
+            same = bool(np.array_equal(recs_f, recs_m)) and tree_digest(os.path.join(out_root, "files_2")) == tree_digest(os.path.join(out_root, "files_ref"))
+            from_files = {"reads_per_s": round(n_reads / best[0], 1), "ms": round(best[0] * 1e3, 2), "lanes": lanes, "groups": int(best[1]["n_groups"]),
+                          "vs_end_to_end": round(best[0] * 1e3 / e2e["ms"], 3), "same_bytes_as_from_memory": same,
+                          "input_mb": round(sum(os.path.getsize(os.path.join(reads_dir, f)) for f in os.listdir(reads_dir)) / 1e6, 1),
+                          "note": "fzp_phase_contigs_files: <ctg>_ref.fa / <ctg>_reads.fa on a memory file system -> FASTA parsing by the library's host threads -> H2D -> pack -> K1..K5 "
+                                  "-> texts -> files; reported beside `value`, never as it"}
+        except Exception as e:      # noqa: BLE001 -- reported in the line
+            from_files = {"error": repr(e)}
+        finally:
+            if reads_dir:
+                shutil.rmtree(reads_dir, ignore_errors=True)
+
     pipelined = None
     if rank == 0 and world == 1 and not args.no_end_to_end and not os.environ.get("FZP_BENCH_NO_PIPELINED"):
         # the resident step again, two steps in flight: two contexts, each with its own resident copy of the job, alternate steps on two host
@@ -613,6 +675,7 @@ def main():
             "index_ms": round(prof.get("k1_index", (0.0, 0))[0] / args.steps, 3) if not args.index_at_create else round(index_ms_at_create, 3),
             "value_end_to_end": e2e["reads_per_s"] if e2e else None,       # host ASCII in, PCIe + packing + index inside (SURVEY 8d's reads-phased/sec); `value` keeps inputs resident (bench contract)
             "end_to_end": e2e,
+            "from_files": from_files,
             "two_steps_in_flight": pipelined,
             "roofline": roofline(cells_per_launch, sw_avg_ms, sw_launches, dp_gcells, traffic),
         }

@@ -59,13 +59,17 @@ def make_job(total_bases, cov=40, R=15000, workers=8, slab=2000, seed=20265000):
     return contigs, blob, off, read_ctg, ids
 
 
-def run(scale=1.0, lanes=2, workers=8, out_root=None, keep=False, consensus=True):
+def run(scale=1.0, lanes=2, workers=8, out_root=None, keep=False, consensus=True, from_files=False):
     t0 = time.perf_counter()
     contigs, blob, off, read_ctg, ids = make_job(int(120e6 * scale), workers=workers)
     t_gen = time.perf_counter() - t0
     from bench import make_names_and_maps
     name_tab, maps = make_names_and_maps(read_ctg, off, ids, 0)
     from falcon_unzip_amd import _lib
+    reads_dir = None
+    if from_files:      # the reference's own input files on a memory file system; the library parses them (fzp_phase_contigs_files)
+        from bench import write_reads_tree
+        reads_dir = write_reads_tree(contigs, blob, off, read_ctg, ids, name_tab, "/dev/shm" if os.path.isdir("/dev/shm") else out_root)
     eng = _lib.Engine(0)
     mon = _lib.Engine(0)                       # a second context only to read the device's memory counters from the sampling thread
     total_mem = mon.mem_info()[1]
@@ -83,8 +87,11 @@ def run(scale=1.0, lanes=2, workers=8, out_root=None, keep=False, consensus=True
     walls = []
     for k in range(2):
         t1 = time.perf_counter()
-        stats, recs = _lib.phase_contigs(eng, contigs, blob, off, read_ctg, ids, names=name_tab, out_dir=os.path.join(out_dir, "run%d" % k), read_maps=maps, n_lanes=lanes,
-                                         consensus=consensus)
+        if from_files:
+            stats, recs = _lib.phase_contigs_files(eng, reads_dir, ids, out_dir=os.path.join(out_dir, "run%d" % k), read_maps=maps, n_lanes=lanes, consensus=consensus)
+        else:
+            stats, recs = _lib.phase_contigs(eng, contigs, blob, off, read_ctg, ids, names=name_tab, out_dir=os.path.join(out_dir, "run%d" % k), read_maps=maps, n_lanes=lanes,
+                                             consensus=consensus)
         walls.append(time.perf_counter() - t1)
     wall = walls[1]
     out_dir = os.path.join(out_dir, "run1")
@@ -100,6 +107,9 @@ def run(scale=1.0, lanes=2, workers=8, out_root=None, keep=False, consensus=True
            "longest_contig_reads": int(np.bincount(read_ctg).max())}
     mon.close()
     eng.close()
+    if reads_dir:
+        res["inputs"] = "FASTA files on a memory file system (%s), parsed by the library" % os.path.dirname(reads_dir)
+        shutil.rmtree(reads_dir, ignore_errors=True)
     if keep:
         res["out_dir"] = out_dir
     else:
@@ -113,5 +123,6 @@ if __name__ == "__main__":
     ap.add_argument("--lanes", type=int, default=2)
     ap.add_argument("--workers", type=int, default=8)
     ap.add_argument("--out-root", default=None)
+    ap.add_argument("--from-files", action="store_true")
     a = ap.parse_args()
-    print(json.dumps(run(a.scale, a.lanes, a.workers, a.out_root)))
+    print(json.dumps(run(a.scale, a.lanes, a.workers, a.out_root, from_files=a.from_files)))
