@@ -117,6 +117,7 @@ struct fzp_ctx {
     std::mutex pin_mu;
     std::vector<std::pair<void *, size_t>> pin_free, pin_live;   // pinned host blocks: cached / handed out
     struct WorkPool *workers = nullptr;    // fzp_pipe.hip: host threads of the per-contig text / read-map work, kept between calls
+    struct GroupPool *gpool = nullptr;     // fzp_pipe.hip: host buffers of fzp_phase_contigs_files' contig groups, kept between calls (no fresh pages per call)
     struct FileWriter *writer = nullptr;   // fzp_pipe.hip: background file writes of FZP_PIPE_ASYNC_WRITES calls (joined by fzp_pipe_flush / ctx destroy)
     std::vector<fzp_ctx *> lanes;    // fzp_phase_contigs: the extra lanes' contexts, kept (with their warm block caches) for the next call
     hipEvent_t ev_pf = nullptr;      // "K2/K3 results are final": their download starts on stream2 while K4/K5 run

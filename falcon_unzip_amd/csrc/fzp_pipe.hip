@@ -132,8 +132,12 @@ struct WorkPool {
         for (auto &t : th) t.join();
     }
 };
+struct GroupPool;
+static void group_pool_destroy(GroupPool *p);
 void fzp_writer_destroy(fzp_ctx *ctx) {
     if (!ctx) return;
+    group_pool_destroy(ctx->gpool);
+    ctx->gpool = nullptr;
     if (ctx->writer) {
         (void)ctx->writer->drain();
         delete ctx->writer;
@@ -743,98 +747,221 @@ extern "C" int fzp_phase_contigs(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *con
 }
 
 // ---- inputs from the reference's own files: <reads_dir>/<ctg>_ref.fa, <ctg>_reads.fa (unzip.py:204,233-234; read at phasing.py:489-494 and by blasr).
-// A FASTA file is mapped and scanned with memchr; a group's files are parsed side by side on host threads, one contig group AHEAD of the lanes that align
-// them, so what is in host memory at any time is the groups in flight -- not the rank's reads.
-#include <sys/mman.h>
-namespace {
-struct FastaRecs { std::vector<uint8_t> seq; std::vector<int64_t> off; std::string names; std::vector<int64_t> noff; };
-// every record of a FASTA file: name = first word of the header, sequence = its lines joined, white space at line ends dropped (falcon_kit's FastaReader as
-// phasing.py:490-494 uses it).  only_name != nullptr: keep only records of that name (the LAST one wins, as the loop at phasing.py:490-494 leaves it).
-int parse_fasta(const std::string &path, const char *only_name, FastaRecs &R, std::string &err) {
-    R.off.assign(1, 0); R.noff.assign(1, 0);
-    const int fd = open(path.c_str(), O_RDONLY);
-    if (fd < 0) { err = path + ": " + strerror(errno); return FZP_EIO; }
-    struct stat sb;
-    if (fstat(fd, &sb) != 0) { err = path + ": " + strerror(errno); close(fd); return FZP_EIO; }
-    const size_t n = (size_t)sb.st_size;
-    if (n == 0) { close(fd); return FZP_OK; }
-    void *mp = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
-    close(fd);
-    if (mp == MAP_FAILED) { err = path + ": mmap: " + strerror(errno); return FZP_EIO; }
-    (void)madvise(mp, n, MADV_SEQUENTIAL);
-    const char *p = (const char *)mp, *end = p + n;
-    const size_t want = only_name ? strlen(only_name) : 0;
-    if (!only_name) R.seq.reserve(n);
-    bool keep = false, any = false;
-    auto is_sp = [](char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\n' || c == '\v' || c == '\f'; };
-    while (p < end) {
-        const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
-        const char *le = nl ? nl : end;
-        if (*p == '>') {
-            if (any && keep) { R.off.push_back((int64_t)R.seq.size()); R.noff.push_back((int64_t)R.names.size()); }
-            const char *a = p + 1;
-            while (a < le && is_sp(*a)) a++;
-            const char *b = a;
-            while (b < le && !is_sp(*b)) b++;
-            keep = !only_name || ((size_t)(b - a) == want && memcmp(a, only_name, want) == 0);
-            if (keep && only_name) { R.seq.clear(); R.names.clear(); R.off.assign(1, 0); R.noff.assign(1, 0); }      // a later record of the same name replaces the earlier one
-            if (keep) R.names.append(a, (size_t)(b - a));
-            any = true;
-        } else if (keep) {
-            const char *a = p, *b = le;
-            while (a < b && is_sp(*a)) a++;
-            while (b > a && is_sp(b[-1])) b--;
-            R.seq.insert(R.seq.end(), (const uint8_t *)a, (const uint8_t *)b);
-        }
-        p = nl ? nl + 1 : end;
-    }
-    if (any && keep) { R.off.push_back((int64_t)R.seq.size()); R.noff.push_back((int64_t)R.names.size()); }
-    munmap(mp, n);
-    return FZP_OK;
-}
+// A group's files are mapped and cut into pieces of a few megabytes at record starts; host threads scan the pieces (memchr) for their records, a prefix sum gives every
+// record its place in the group's buffers, the same threads copy the sequences there -- one copy, no per-file intermediates.  Groups are parsed one AHEAD of the lanes
+// that align them, and their buffers are kept with the context between calls, so what is in host memory at any time is the groups in flight -- not the rank's reads.
+#include <sched.h>
 struct GroupIn {
-    std::vector<FastaRecs> ref, reads;           // per contig of the group
+    std::vector<uint8_t> raw;                    // the group's files as they are
+    std::vector<uint8_t> ref;                    // the group's contigs, one after the other
+    std::vector<int64_t> ref_off;                // [gc + 1]
     std::vector<uint8_t> blob;                   // the group's reads, contig after contig
     std::vector<int64_t> off, noff;
     std::vector<int32_t> read_ctg;
-    std::string names;
+    std::vector<char> names;
     int rc = FZP_OK;
     std::string err;
 };
-void load_group(const std::string &dir, const char *const *ctg_id, int c0, int c1, int n_threads, GroupIn &G) {
-    const int gc = c1 - c0;
-    G.ref.resize((size_t)gc); G.reads.resize((size_t)gc);
-    std::vector<int> rcs((size_t)2 * gc, FZP_OK);
-    std::vector<std::string> errs((size_t)2 * gc);
-    std::atomic<int> next{0};
-    auto work = [&]() {
-        for (int t; (t = next.fetch_add(1)) < 2 * gc;) {
-            const int c = t >> 1;
-            const std::string base = dir + "/" + ctg_id[c0 + c];
-            rcs[(size_t)t] = (t & 1) ? parse_fasta(base + "_ref.fa", ctg_id[c0 + c], G.ref[(size_t)c], errs[(size_t)t]) : parse_fasta(base + "_reads.fa", nullptr, G.reads[(size_t)c], errs[(size_t)t]);
-        }
-    };
-    std::vector<std::thread> th;
-    const int nt = std::max(1, std::min(n_threads, 2 * gc));
-    for (int i = 1; i < nt; i++) th.emplace_back(work);
-    work();
-    for (auto &x : th) x.join();
-    for (int t = 0; t < 2 * gc; t++) if (rcs[(size_t)t] != FZP_OK) { G.rc = rcs[(size_t)t]; G.err = errs[(size_t)t]; return; }
-    size_t nb = 0, nn = 0, nr = 0;
-    for (auto &R : G.reads) { nb += R.seq.size(); nn += R.names.size(); nr += R.off.size() - 1; }
-    G.blob.resize(nb); G.names.resize(nn);
-    G.off.assign(1, 0); G.noff.assign(1, 0);
-    G.off.reserve(nr + 1); G.noff.reserve(nr + 1); G.read_ctg.reserve(nr);
-    size_t ab = 0, an = 0;
-    for (int c = 0; c < gc; c++) {
-        FastaRecs &R = G.reads[(size_t)c];
-        if (!R.seq.empty()) memcpy(G.blob.data() + ab, R.seq.data(), R.seq.size());
-        if (!R.names.empty()) memcpy(&G.names[an], R.names.data(), R.names.size());
-        for (size_t k = 1; k < R.off.size(); k++) { G.off.push_back((int64_t)ab + R.off[k]); G.noff.push_back((int64_t)an + R.noff[k]); G.read_ctg.push_back(c); }
-        ab += R.seq.size(); an += R.names.size();
-        std::vector<uint8_t>().swap(R.seq);
-        std::string().swap(R.names);
+struct GroupPool {
+    std::mutex mu;
+    std::vector<std::unique_ptr<GroupIn>> idle;
+    std::unique_ptr<GroupIn> take() {
+        std::lock_guard<std::mutex> lk(mu);
+        if (idle.empty()) return std::unique_ptr<GroupIn>(new GroupIn());
+        auto g = std::move(idle.back());
+        idle.pop_back();
+        return g;
     }
+    void give(std::unique_ptr<GroupIn> g) { std::lock_guard<std::mutex> lk(mu); if (idle.size() < 4) idle.push_back(std::move(g)); }
+};
+static void group_pool_destroy(GroupPool *p) { delete p; }
+namespace {
+// threads this process may really use: the affinity mask and the cgroup CPU quota, not the machine's thread count (a container that shows 256 hardware threads
+// behind a 16-CPU quota is throttled to a crawl by 256 busy threads)
+int usable_cores() {
+    int n = (int)std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t cs;
+    if (sched_getaffinity(0, sizeof cs, &cs) == 0) n = std::min(n, std::max(1, CPU_COUNT(&cs)));
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                       // cgroup v2: "<quota> <period>" or "max <period>"
+        char q[64]; long long per = 0;
+        if (fscanf(f, "%63s %lld", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) n = std::min<long long>(n, std::max<long long>(1, (atoll(q) + per - 1) / per));
+        fclose(f);
+    } else if (FILE *f1 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {  // cgroup v1
+        long long quota = -1, per = 0;
+        if (fscanf(f1, "%lld", &quota) != 1) quota = -1;
+        fclose(f1);
+        if (FILE *f2 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(f2, "%lld", &per) != 1) per = 0; fclose(f2); }
+        if (quota > 0 && per > 0) n = std::min<long long>(n, std::max<long long>(1, (quota + per - 1) / per));
+    }
+    return n;
+}
+struct FaRec { const char *name; int32_t name_len; const char *s0, *s1; int64_t len; };      // header's first word; the sequence's lines lie in [s0, s1); len = its bases
+struct FaPiece { int file; const char *a, *b; std::vector<FaRec> recs; int64_t bases = 0, name_bytes = 0; };
+inline bool fa_sp(char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\n' || c == '\v' || c == '\f'; }
+// the records that START in [a, b) of a mapped file [f0, f1): name = first word of the header, sequence = its lines joined, white space at line ends dropped
+// (falcon_kit's FastaReader as phasing.py:490-494 uses it)
+void scan_piece(const char *f0, const char *f1, FaPiece &P) {
+    const char *p = P.a;
+    if (p > f0) {      // the first record start at or after a: a '>' right behind a newline
+        p--;
+        for (;;) {
+            const char *nl = (const char *)memchr(p, '\n', (size_t)(f1 - p));
+            if (!nl || nl + 1 >= f1) { p = f1; break; }
+            if (nl[1] == '>') { p = nl + 1; break; }
+            p = nl + 1;
+        }
+    }
+    while (p < P.b && p < f1) {
+        if (*p != '>') {   // (only at the head of a file: lines before the first header belong to no record)
+            const char *nl = (const char *)memchr(p, '\n', (size_t)(f1 - p));
+            p = nl ? nl + 1 : f1;
+            continue;
+        }
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(f1 - p));
+        const char *le = nl ? nl : f1;
+        FaRec R;
+        const char *x = p + 1;
+        while (x < le && fa_sp(*x)) x++;
+        const char *y = x;
+        while (y < le && !fa_sp(*y)) y++;
+        R.name = x; R.name_len = (int32_t)(y - x);
+        R.s0 = nl ? nl + 1 : f1;
+        R.len = 0;
+        const char *q = R.s0;
+        while (q < f1 && *q != '>') {
+            const char *n2 = (const char *)memchr(q, '\n', (size_t)(f1 - q));
+            const char *e = n2 ? n2 : f1;
+            const char *u = q, *v = e;
+            while (u < v && fa_sp(*u)) u++;
+            while (v > u && fa_sp(v[-1])) v--;
+            R.len += v - u;
+            q = n2 ? n2 + 1 : f1;
+        }
+        R.s1 = q;
+        P.bases += R.len; P.name_bytes += R.name_len;
+        P.recs.push_back(R);
+        p = q;
+    }
+}
+inline void copy_seq(const FaRec &R, uint8_t *dst) {
+    const char *q = R.s0;
+    while (q < R.s1) {
+        const char *n2 = (const char *)memchr(q, '\n', (size_t)(R.s1 - q));
+        const char *e = n2 ? n2 : R.s1;
+        const char *u = q, *v = e;
+        while (u < v && fa_sp(*u)) u++;
+        while (v > u && fa_sp(v[-1])) v--;
+        memcpy(dst, u, (size_t)(v - u));
+        dst += v - u;
+        q = n2 ? n2 + 1 : R.s1;
+    }
+}
+struct Mapped { const char *p = nullptr; size_t n = 0; };
+void load_group(const std::string &dir, const char *const *ctg_id, int c0, int c1, int n_threads, GroupIn &G) {
+    const int gc = c1 - c0, nf = 2 * gc;            // file 2c: <ctg>_reads.fa, file 2c + 1: <ctg>_ref.fa
+    G.rc = FZP_OK; G.err.clear();
+    const bool timing = getenv("FZP_PIPE_TIMING") != nullptr;
+    const auto t_0 = clk::now();
+    double t_map = 0, t_scan = 0, t_alloc = 0;
+    // the files' bytes into one buffer of the group (kept with the context: warm pages), read in pieces of 4 MB by all threads -- mapping the files instead costs more
+    // in page-table set-up and tear-down (10 ms each way per 300 MB) than the copy does
+    std::vector<Mapped> mp((size_t)nf);
+    std::vector<int> fds((size_t)nf, -1);
+    std::vector<size_t> foff((size_t)nf + 1, 0);
+    std::vector<std::string> errs((size_t)nf);
+    std::atomic<int> next{0};
+    auto par = [&](const std::function<void()> &work) {
+        std::vector<std::thread> th;
+        for (int i = 1; i < n_threads; i++) th.emplace_back(work);
+        work();
+        for (auto &x : th) x.join();
+    };
+    auto unmap_all = [&]() { for (int &fd : fds) if (fd >= 0) { close(fd); fd = -1; } };
+    for (int t = 0; t < nf; t++) {
+        const std::string path = dir + "/" + ctg_id[c0 + (t >> 1)] + ((t & 1) ? "_ref.fa" : "_reads.fa");
+        fds[(size_t)t] = open(path.c_str(), O_RDONLY);
+        struct stat sb;
+        if (fds[(size_t)t] < 0 || fstat(fds[(size_t)t], &sb) != 0) { G.rc = FZP_EIO; G.err = path + ": " + strerror(errno); unmap_all(); return; }
+        mp[(size_t)t].n = (size_t)sb.st_size;
+        foff[(size_t)t + 1] = foff[(size_t)t] + mp[(size_t)t].n;
+    }
+    G.raw.resize(foff[(size_t)nf] + 1);
+    for (int t = 0; t < nf; t++) mp[(size_t)t].p = (const char *)G.raw.data() + foff[(size_t)t];
+    // pieces of ~4 MB, in file order
+    std::vector<FaPiece> pieces;
+    const size_t PIECE = 4u << 20;
+    for (int t = 0; t < nf; t++)
+        for (size_t a = 0; a < mp[(size_t)t].n; a += PIECE) {
+            FaPiece P;
+            P.file = t; P.a = mp[(size_t)t].p + a; P.b = mp[(size_t)t].p + std::min(mp[(size_t)t].n, a + PIECE);
+            pieces.push_back(std::move(P));
+        }
+    par([&]() {
+        for (int k; (k = next.fetch_add(1)) < (int)pieces.size();) {
+            const FaPiece &P = pieces[(size_t)k];
+            const int t = P.file;
+            size_t at = (size_t)(P.a - mp[(size_t)t].p);
+            const size_t end = (size_t)(P.b - mp[(size_t)t].p);
+            while (at < end) {
+                const ssize_t got = pread(fds[(size_t)t], (void *)(mp[(size_t)t].p + at), end - at, (off_t)at);
+                if (got <= 0) { errs[(size_t)t] = dir + "/" + ctg_id[c0 + (t >> 1)] + ((t & 1) ? "_ref.fa" : "_reads.fa") + ": " + (got < 0 ? strerror(errno) : "file shrank while it was read"); break; }
+                at += (size_t)got;
+            }
+        }
+    });
+    unmap_all();
+    t_map = ms_since(t_0);
+    for (int t = 0; t < nf; t++) if (!errs[(size_t)t].empty()) { G.rc = FZP_EIO; G.err = errs[(size_t)t]; return; }
+    next.store(0);
+    par([&]() { for (int k; (k = next.fetch_add(1)) < (int)pieces.size();) scan_piece(mp[(size_t)pieces[(size_t)k].file].p, mp[(size_t)pieces[(size_t)k].file].p + mp[(size_t)pieces[(size_t)k].file].n, pieces[(size_t)k]); });
+    t_scan = ms_since(t_0);
+    // the contigs: of <ctg>_ref.fa the LAST record named <ctg> (the loop at phasing.py:490-494 leaves that one); none -> an empty contig
+    std::vector<const FaRec *> ref_rec((size_t)gc, nullptr);
+    G.ref_off.assign((size_t)gc + 1, 0);
+    for (auto &P : pieces)
+        if (P.file & 1) {
+            const int c = P.file >> 1;
+            const size_t want = strlen(ctg_id[c0 + c]);
+            for (auto &R : P.recs) if ((size_t)R.name_len == want && memcmp(R.name, ctg_id[c0 + c], want) == 0) ref_rec[(size_t)c] = &R;
+        }
+    for (int c = 0; c < gc; c++) G.ref_off[(size_t)c + 1] = G.ref_off[(size_t)c] + (ref_rec[(size_t)c] ? ref_rec[(size_t)c]->len : 0);
+    G.ref.resize((size_t)G.ref_off[(size_t)gc] + 1);
+    // the reads: every record of <ctg>_reads.fa, file order; a prefix sum over the pieces gives every piece its first read, base and name byte
+    std::vector<int64_t> p_rec(pieces.size() + 1, 0), p_base(pieces.size() + 1, 0), p_name(pieces.size() + 1, 0);
+    for (size_t k = 0; k < pieces.size(); k++) {
+        const bool rd = !(pieces[k].file & 1);
+        p_rec[k + 1] = p_rec[k] + (rd ? (int64_t)pieces[k].recs.size() : 0);
+        p_base[k + 1] = p_base[k] + (rd ? pieces[k].bases : 0);
+        p_name[k + 1] = p_name[k] + (rd ? pieces[k].name_bytes : 0);
+    }
+    const int64_t nr = p_rec.back();
+    G.blob.resize((size_t)p_base.back() + 1); G.names.resize((size_t)p_name.back() + 1);
+    G.off.resize((size_t)nr + 1); G.noff.resize((size_t)nr + 1); G.read_ctg.resize((size_t)nr);
+    G.off[0] = 0; G.noff[0] = 0;
+    t_alloc = ms_since(t_0);
+    next.store(0);
+    const int n_work = (int)pieces.size() + gc;
+    par([&]() {
+        for (int k; (k = next.fetch_add(1)) < n_work;) {
+            if (k >= (int)pieces.size()) {      // a contig's sequence
+                const int c = k - (int)pieces.size();
+                if (ref_rec[(size_t)c]) copy_seq(*ref_rec[(size_t)c], G.ref.data() + G.ref_off[(size_t)c]);
+                continue;
+            }
+            const FaPiece &P = pieces[(size_t)k];
+            if (P.file & 1) continue;
+            int64_t r = p_rec[(size_t)k], ab = p_base[(size_t)k], an = p_name[(size_t)k];
+            for (const FaRec &R : P.recs) {
+                copy_seq(R, G.blob.data() + ab);
+                memcpy(G.names.data() + an, R.name, (size_t)R.name_len);
+                ab += R.len; an += R.name_len;
+                G.off[(size_t)r + 1] = ab; G.noff[(size_t)r + 1] = an; G.read_ctg[(size_t)r] = P.file >> 1;
+                r++;
+            }
+        }
+    });
+    if (timing) fprintf(stderr, "[load_group] %d contigs, %lld reads, %.1f MB on %d threads: read by %.2f ms, scanned by %.2f, buffers by %.2f, copied by %.2f\n", gc, (long long)nr,
+                        (double)p_base.back() / 1e6, n_threads, t_map, t_scan, t_alloc, ms_since(t_0));
 }
 }  // namespace
 
@@ -883,19 +1010,22 @@ extern "C" int fzp_phase_contigs_files(fzp_ctx *ctx, const char *reads_dir, cons
         FZP_TRY(fzp_ctx_create(device, 0, &lc));
         ctx->lanes.push_back(lc);
     }
-    const int host_threads = o.n_threads > 0 ? o.n_threads : std::max(2u, std::thread::hardware_concurrency());
-    // the loader: group g's files are parsed when a lane takes group g - (lanes + 1) at the latest
-    std::vector<std::shared_ptr<GroupIn>> gin(groups.size());
+    const int host_threads = o.n_threads > 0 ? o.n_threads : std::min(32, usable_cores());
+    // the loader: group g's files are parsed when a lane takes group g - 1 at the latest (one group ahead of every lane; each load uses every host thread, so
+    // loads run one after the other, in group order: the first group is there as soon as it can be)
+    if (!ctx->gpool) ctx->gpool = new GroupPool();
+    GroupPool *pool = ctx->gpool;
+    std::vector<std::unique_ptr<GroupIn>> gin(groups.size());
     std::vector<std::future<void>> loading(groups.size());
-    std::mutex ld_mu;
+    std::mutex ld_mu, ld_serial;
     size_t n_started = 0;
     auto start_loads = [&](size_t upto) {        // (callers hold ld_mu)
         for (; n_started < std::min(upto, groups.size()); n_started++) {
             const size_t g = n_started;
-            gin[g] = std::make_shared<GroupIn>();
+            gin[g] = pool->take();
             GroupIn *G = gin[g].get();
             const Group gr = groups[g];
-            loading[g] = std::async(std::launch::async, [&, G, gr]() { load_group(dir, nm->ctg_id, gr.c0, gr.c1, std::max(2, host_threads / 2), *G); });
+            loading[g] = std::async(std::launch::async, [&, G, gr]() { std::lock_guard<std::mutex> lk(ld_serial); load_group(dir, nm->ctg_id, gr.c0, gr.c1, host_threads, *G); });
         }
     };
     { std::lock_guard<std::mutex> lk(ld_mu); start_loads((size_t)lanes + 1); }
@@ -915,11 +1045,11 @@ extern "C" int fzp_phase_contigs_files(fzp_ctx *ctx, const char *reads_dir, cons
             const size_t g = next.fetch_add(1);
             if (g >= groups.size()) break;
             const Group &Gr = groups[g];
-            std::shared_ptr<GroupIn> G;
+            GroupIn *G;
             {
                 std::lock_guard<std::mutex> lk(ld_mu);
                 start_loads(g + (size_t)lanes + 1);
-                G = gin[g];
+                G = gin[g].get();
             }
             auto t0 = clk::now();
             loading[g].wait();                                  // (normally done long ago: it was started a group ahead)
@@ -930,8 +1060,7 @@ extern "C" int fzp_phase_contigs_files(fzp_ctx *ctx, const char *reads_dir, cons
             const int64_t gr_n = (int64_t)G->read_ctg.size();
             std::vector<const uint8_t *> cptr((size_t)gc);
             std::vector<int64_t> clen((size_t)gc);
-            static const uint8_t none_[1] = {0};
-            for (int c = 0; c < gc; c++) { clen[(size_t)c] = (int64_t)G->ref[(size_t)c].seq.size(); cptr[(size_t)c] = clen[(size_t)c] ? G->ref[(size_t)c].seq.data() : none_; }
+            for (int c = 0; c < gc; c++) { clen[(size_t)c] = G->ref_off[(size_t)c + 1] - G->ref_off[(size_t)c]; cptr[(size_t)c] = G->ref.data() + G->ref_off[(size_t)c]; }
             t0 = clk::now();
             fzp_alnjob *job = nullptr;
             {   // one upload at a time (see fzp_phase_contigs)
@@ -940,7 +1069,6 @@ extern "C" int fzp_phase_contigs_files(fzp_ctx *ctx, const char *reads_dir, cons
             }
             po.ms_upload += ms_since(t0);
             if (rc == FZP_OK) {
-                std::vector<uint8_t>().swap(G->blob);           // the reads are on the device now
                 fzp_names gn;
                 gn.n_ctg = gc; gn.ctg_id = nm->ctg_id + Gr.c0;
                 gn.name_off = G->noff.data();
@@ -956,7 +1084,7 @@ extern "C" int fzp_phase_contigs_files(fzp_ctx *ctx, const char *reads_dir, cons
             if (rc != FZP_OK) errs[(size_t)li] = fzp_last_error();
             fzp_align_destroy(lc, job);
             po.n_reads += gr_n;
-            { std::lock_guard<std::mutex> lk(ld_mu); gin[g].reset(); }
+            { std::lock_guard<std::mutex> lk(ld_mu); pool->give(std::move(gin[g])); }      // its buffers serve a later group (of this call or the next)
             if (rc != FZP_OK) { rcs[(size_t)li] = rc; break; }
         }
     };
@@ -967,6 +1095,7 @@ extern "C" int fzp_phase_contigs_files(fzp_ctx *ctx, const char *reads_dir, cons
         for (auto &x : th) x.join();
     }
     for (size_t g = 0; g < n_started; g++) if (loading[g].valid()) loading[g].wait();      // (after an error: loads still running hold references into this frame)
+    for (auto &g : gin) if (g) pool->give(std::move(g));
     (void)fzp_bind(ctx);
     const int frc = fzp_pipe_flush(ctx);
     if (timing) { double w = 0; for (auto v : ms_parse) w += v; fprintf(stderr, "[fzp_phase_contigs_files] %.2f ms in the call, %.2f ms of it waiting for the parser (%d lanes, %zu groups)\n", ms_since(t_call), w, lanes, groups.size()); }

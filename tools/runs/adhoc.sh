@@ -1,7 +1,4 @@
 export TMPDIR=/tmp
-echo "mem.max: $(cat /sys/fs/cgroup/memory.max 2>/dev/null)"; free -g | head -2; df -h /tmp /dev/shm . | cat; nproc
-B="--no-cpu-baseline --no-end-to-end --no-shaped-leg --gen-workers 1 --steps 5 --warmup 2"
-for dbg in 0 1 2 3; do
-  FZP_SWB_DBG=$dbg timeout 100 python3 bench.py $B 2>/dev/null | python3 -c "
-import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['kernel_ms_per_step']; print('dbg $dbg', 'ms', d['ms_per_step'], 'k1_sw', k['k1_sw'], 'tb', k['k1_traceback'], 'seed', k['k1_seed'])"
-done
+timeout 900 python3 -m pytest -m gpu -x -q tests/test_gpu_ranks.py tests/test_gpu_pipeline.py -k "files_entry or unzip_tree or two_ranks" 2>&1 | tail -3
+FZP_PIPE_TIMING=1 timeout 600 python3 bench.py --no-cpu-baseline --no-shaped-leg > gpurun_out/r4k_bench.json 2> gpurun_out/r4k_bench.err; grep "phase_contigs_files\|load_group" gpurun_out/r4k_bench.err | tail -3
+timeout 600 python3 tools/run_cfg5.py --from-files > gpurun_out/r4k_cfg5_files.json 2> gpurun_out/r4k_cfg5_files.err; tail -c 300 gpurun_out/r4k_cfg5_files.err
