@@ -1160,8 +1160,10 @@ __global__ void __launch_bounds__(256) k_swb(const uint64_t *__restrict__ n_b_de
                                              const uint32_t *__restrict__ read_pk, const uint32_t *__restrict__ read_rc, const int64_t *__restrict__ read_woff,
                                              const uint32_t *__restrict__ ctg_pk, const uint32_t *__restrict__ ctg_rc, const int64_t *__restrict__ ctg_woff,
                                              const int64_t *__restrict__ tbo, const int64_t *__restrict__ mvo, uint2 *__restrict__ tb, ulonglong2 *__restrict__ mvw,
-                                             DpInfo *__restrict__ info, int dbg) {
+                                             DpInfo *__restrict__ info, int dbg, uint64_t *__restrict__ wave_log) {
     using namespace swb;
+    // wave_log (FZP_SWB_WAVE_LOG, a measurement aid): per workgroup {start, end} of the 100 MHz counter, the hardware id, the steps it ran
+    const uint64_t t_begin = wave_log ? __builtin_amdgcn_s_memrealtime() : 0ull;
     // dbg: MEASUREMENT switches (FZP_SWB_DBG, tools/runs/swb_probe.py; the results of such a run are not used): bit 0 = no mask stores, bit 1 = no stream refills
     // (workgroups of one wave: four-wave workgroups, which suit k_swb2, put 256 mask streams on a CU and cost this kernel 10 % -- address translation again)
     const int64_t li = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1186,6 +1188,13 @@ __global__ void __launch_bounds__(256) k_swb(const uint64_t *__restrict__ n_b_de
     for (int k = 33; k < 64; k++) { const uint32_t c = base_at(qpk, qb + (k - 33)); L.R0 |= (uint64_t)(c & 1u) << k; L.R1 |= (uint64_t)(c >> 1) << k; }
     for (int k = 0; k <= 32; k++) { const uint32_t c = base_at(tpk, tbase + (32 - k)); L.C0 |= (uint64_t)(c & 1u) << k; L.C1 |= (uint64_t)(c >> 1) << k; }
     __shared__ uint32_t srng[RING ? 2 * 64 * 64 : 1];                      // the two streams' rings (32 KB per wave)
+    // the mask records of a group of 8 steps leave through a tile in LDS, turned round: a lane's own eight records are 128 B of ITS stream, so a store instruction of the
+    // plain form hands the memory pipeline 64 lanes x 16 B in 64 different lines; through the tile lane L carries record (stream L / 8 + 8 k, step L % 8) in the k-th of
+    // eight stores -- 8 whole lines per instruction.  Rows are swizzled by (row >> 1) & 7 so that neither side has a bank conflict.  (8 KB: with the rings exactly a
+    // quarter of a CU's LDS -- four waves per CU, one per SIMD, as the registers allow anyway.)
+    __shared__ uint4 tile[RING ? 64 * SWB_GROUP : 1];
+    const bool tile_stores = RING && !(dbg & 4);                            // FZP_SWB_DBG bit 2: the plain per-lane stores, for comparisons
+    ulonglong2 *gbase = (ulonglong2 *)tb + tbo[list[(int64_t)blockIdx.x * blockDim.x]];      // the wave's region: its first lane's stream (wave-uniform)
     if constexpr (RING) {
         L.qs.init(qpk, qb + 31, (uint32_t)((qb + nq + 15) >> 4) + 1u, srng + threadIdx.x);
         L.ts.init(tpk, tbase + 33, (uint32_t)((tbase + nt + 15) >> 4) + 1u, srng + 64 * 64 + threadIdx.x);
@@ -1200,7 +1209,7 @@ __global__ void __launch_bounds__(256) k_swb(const uint64_t *__restrict__ n_b_de
     int32_t t = 0;                                            // wave-uniform
     while (__ballot(active)) {
         const bool blk_active = active;
-        const int32_t i0_blk = L.i0;
+        const int32_t i0_blk = L.i0, e2_blk = L.E2;      // (E2 at the block's first step rides in the move word's spare half: where in the band the path is likely to be)
         L.mvacc = 0;
         // an interior block?  every running lane more than 64 steps away from its last row and its last column (a step brings either one closer by at most one)
         const bool far = !active || (nq - 1 - (L.i0 + 63) > 64 && nt - 1 - (t - L.i0) > 64);
@@ -1219,15 +1228,38 @@ __global__ void __launch_bounds__(256) k_swb(const uint64_t *__restrict__ n_b_de
             // the streams top up every 16 steps, and they do it HERE, ahead of a group's stores: taking the word loaded 16 steps ago means waiting on the vector-memory
             // counter, which also counts the mask stores -- at this point the youngest of those are 8 steps old and done, right behind a group they would be in flight
             if ((g8 & (16 / SWB_GROUP - 1)) == 16 / SWB_GROUP - 1 && !(dbg & 2)) { L.qs.refill(); L.ts.refill(); }
-            if (grp_active && !(dbg & 1)) {
+            if (tile_stores) {
+                if constexpr (RING) {
+                    if (!(dbg & 1)) {      // (every stream of the group has room for the group's longest extension: lanes that are done write into their own slack)
+                        const uint32_t lane = threadIdx.x & 63u, key = (lane >> 1) & 7u;
+#pragma unroll
+                        for (int s8 = 0; s8 < SWB_GROUP; s8++) tile[lane * SWB_GROUP + ((uint32_t)s8 ^ key)] = make_uint4((uint32_t)rec[s8].x, (uint32_t)(rec[s8].x >> 32), (uint32_t)rec[s8].y, (uint32_t)(rec[s8].y >> 32));
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        ulonglong2 *gb = gbase + (int64_t)((t - SWB_GROUP) >> 6) * stride + ((t - SWB_GROUP) & 63) + (lane & 7u);
+#pragma unroll
+                        for (int k = 0; k < 8; k++) {
+                            const uint32_t x = (lane >> 3) + 8u * (uint32_t)k;
+                            const uint4 v = tile[x * SWB_GROUP + ((lane & 7u) ^ ((x >> 1) & 7u))];
+                            gb[(int64_t)x * 64] = make_ulonglong2(((uint64_t)v.y << 32) | v.x, ((uint64_t)v.w << 32) | v.z);
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    }
+                }
+            } else if (grp_active && !(dbg & 1)) {
 #pragma unroll
                 for (int s8 = 0; s8 < SWB_GROUP; s8++) tbr[(int64_t)((t - SWB_GROUP) >> 6) * stride + ((t - SWB_GROUP) & 63) + s8] = rec[s8];
             }
         }
         if (blk_active) {
-            mvr[(t - 1) >> 6] = make_ulonglong2(L.mvacc, (uint64_t)(uint32_t)i0_blk);
+            mvr[(t - 1) >> 6] = make_ulonglong2(L.mvacc, (uint64_t)(uint32_t)i0_blk | ((uint64_t)(uint32_t)e2_blk << 32));
             if (!active) info[sl] = DpInfo{steps, bt, bl, bt >= 0 ? best : NEGV};
         }
+    }
+    if (wave_log && threadIdx.x == 0) {
+        uint32_t hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        uint64_t *o = wave_log + 4 * (size_t)blockIdx.x;
+        o[0] = t_begin; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = hw; o[3] = (uint64_t)t;
     }
 }
 
@@ -1392,10 +1424,12 @@ constexpr int TBW_WPG = 1;                       // waves per workgroup (four me
 
 struct WalkOut { int32_t ok, i, ts, i_end, j_end, ncol, n_ops, pad_; };   // (i_end, j_end) = the terminal; (i, ts - i) = where the walk left the matrix (one of the two is -1)
 
+// STATS (FZP_TB_STATS, a measurement aid): how often a path leaves the middle 32 lanes of the band, and a 32-lane window centred where the band's edge scores say the path is
+template <bool STATS>
 __global__ void __launch_bounds__(64 * TBW_WPG) k_tb_walk(uint32_t ns, const uint32_t *__restrict__ order, const DpInfo *__restrict__ info,
                                                 const int64_t *__restrict__ tbo, const int64_t *__restrict__ mvo, const int32_t *__restrict__ tbs,
                                                 const ulonglong2 *__restrict__ tb, const ulonglong2 *__restrict__ mvw, uint32_t *__restrict__ raw,
-                                                WalkOut *__restrict__ wout) {
+                                                WalkOut *__restrict__ wout, unsigned long long *__restrict__ stats) {
     // TBW_WPG independent waves per workgroup: every wave has its own slice of the LDS buffer and never waits for another
     __shared__ __attribute__((aligned(16))) uint8_t lds_all[TBW_WPG * TBW_RPW * TBW_STRIDE];
     uint8_t *lds = lds_all + (threadIdx.x >> 6) * (TBW_RPW * TBW_STRIDE);
@@ -1431,6 +1465,8 @@ __global__ void __launch_bounds__(64 * TBW_WPG) k_tb_walk(uint32_t ns, const uin
     const int32_t rstride = have ? tbs[sl] : 64;      // records from one 64-step chunk of the slot's masks to the next
     uint8_t *mine = lds + lane * TBW_STRIDE;
     int32_t cur_chunk = -2, sh_cur = 0;
+    uint32_t st_fixed = 0, st_adapt = 0, st_steps = 0, st_maxdev = 0;      // STATS: steps outside lanes [16, 48) / outside the adaptive window
+    int32_t st_centre = 32;
     int32_t pref_chunk = active ? ts >> 6 : -1, pref_sh = min(max(k - 16, 0), 32);
     uint4 pf[TBW_RPW];
 #pragma unroll
@@ -1500,7 +1536,9 @@ __global__ void __launch_bounds__(64 * TBW_WPG) k_tb_walk(uint32_t ns, const uin
             P = s_ ? (w_cur << (64 - s_)) | (w_prev >> s_) : w_prev;
         }
         const uint8_t *win = mine;
+        if (STATS && active) { const int32_t e2 = (int32_t)(mvr[ts >> 6].y >> 32); st_centre = min(max(32 + e2 / 3, 16), 48); }      // score(lane 63) - score(lane 0) = 2 E2 ~ 6 x (path's lane - 31.5)
         while (active && (ts >> 6) == cur_chunk && (uint32_t)(k - sh_cur) < 32u) {
+            if (STATS) { st_steps++; st_fixed += (uint32_t)(k - 16) >= 32u ? 1u : 0u; st_adapt += (uint32_t)(k - (st_centre - 16)) >= 32u ? 1u : 0u; st_maxdev = max(st_maxdev, (uint32_t)abs(k - st_centre)); }
             const uint2 m = *(const uint2 *)(win + (ts & 63) * 8);
             const uint32_t kk = (uint32_t)(k - sh_cur);
             const uint32_t db = (m.x >> kk) & 1u, gb = (m.y >> kk) & 1u;
@@ -1526,6 +1564,11 @@ __global__ void __launch_bounds__(64 * TBW_WPG) k_tb_walk(uint32_t ns, const uin
     }
 #undef TBW_ISSUE
     if (!have) return;
+    if (STATS && walked && rstride == 4096) {      // (the bit-sliced kernel's slots: the ones whose move words carry E2)
+        atomicAdd(&stats[0], 1ull); atomicAdd(&stats[1], st_fixed ? 1ull : 0ull); atomicAdd(&stats[2], st_adapt ? 1ull : 0ull);
+        atomicAdd(&stats[3], (unsigned long long)st_steps); atomicAdd(&stats[4], (unsigned long long)st_fixed); atomicAdd(&stats[5], (unsigned long long)st_adapt);
+        atomicAdd(&stats[6 + min(st_maxdev >> 2, 9u)], 1ull);      // slots by their largest distance from the estimated centre, in fours
+    }
     if (nb) rawp[nw] = rawacc;
     WalkOut o;
     o.ok = walked ? 1 : 0; o.i = i; o.ts = ts; o.i_end = i_end; o.j_end = j_end; o.ncol = ncol; o.n_ops = n_ops; o.pad_ = 0;
@@ -2136,6 +2179,9 @@ struct fzp_alnjob {
     DevBuf<uint32_t> r_cnt, r_capq, slot_base, rcapq_scan;      // per read: slots, their capacity / 64, and the exclusive scans of both
     DevBuf<uint64_t> rtot;                       // [0] slots of the run, [1] capacity / 64 of the run
     ChunkBufs cb[2];
+    DevBuf<unsigned long long> tb_stats;         // FZP_TB_STATS (measurement aid): how often a path leaves a 32-lane window of its band, summed over the job's runs
+    DevBuf<uint64_t> wave_log;                   // FZP_SWB_WAVE_LOG (measurement aid): per k_swb workgroup of the last chunk {start, end, hardware id, steps}
+    int64_t wave_log_n = 0;
     bool summ_on_host = false;
     // record planning: reads grouped by contig (input order inside a contig); built on first use
     DevBuf<int32_t> slot_read, slot_ctg;
@@ -2448,6 +2494,8 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
                     // every slot goes to one of the two DP kernels (k_route): the bit-sliced one (a slot per lane) takes those that span the band on both sides, the
                     // wave-per-slot one the rest -- mostly backward extensions of a few dozen bases -- beside it on a stream of its own
                     const bool swb64 = swb_force ? swb_force == 64 : !((int64_t)ns / 32 <= (int64_t)ctx->n_cu * 4);
+                    uint64_t *wave_log = nullptr;
+                    if (getenv("FZP_SWB_WAVE_LOG")) { FZP_TRY(j->wave_log.alloc((size_t)4 * ((ns + 63) / 64) + 4)); FZP_TRY(j->wave_log.zero((size_t)4 * ((ns + 63) / 64) + 4, st)); wave_log = j->wave_log.p; j->wave_log_n = (ns + 63) / 64; }
                     FZP_HIP(hipEventRecord(j->ev_l[0], st));
                     if (use_bits && !swb64)
                         hipLaunchKernelGGL(k_swb2, dim3((ns + 127) / 128), dim3(256), 0, st, (const uint64_t *)B.ptot.p, (const uint32_t *)B.list.p, (const Slot *)B.slots.p,
@@ -2457,7 +2505,7 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
                         hipLaunchKernelGGL(swb_ring ? k_swb<true> : k_swb<false>, dim3((ns + 64 * SWB_WPG - 1) / (64 * SWB_WPG)), dim3(64 * SWB_WPG), 0, st, (const uint64_t *)B.ptot.p, (const uint32_t *)B.list.p,
                                            (const Slot *)B.slots.p, (const uint32_t *)j->read_pk.p, (const uint32_t *)j->read_rc.p, (const int64_t *)j->read_woff.p, (const uint32_t *)j->ctg_pk.p,
                                            (const uint32_t *)j->ctg_rc.p, (const int64_t *)j->ctg_woff.p, (const int64_t *)B.tbo.p, (const int64_t *)B.mvo.p, B.tb.p, B.mvw.p, B.info.p,
-                                           getenv("FZP_SWB_DBG") ? atoi(getenv("FZP_SWB_DBG")) : 0);
+                                           getenv("FZP_SWB_DBG") ? atoi(getenv("FZP_SWB_DBG")) : 0, wave_log);
                     FZP_HIP(hipStreamWaitEvent(st3, j->ev_l[0], 0));
                     hipLaunchKernelGGL(k_sw<true>, dim3(ns), dim3(64), 0, st3, ns, (const uint64_t *)B.ptot.p, (const uint32_t *)B.list.p, (const Slot *)B.slots.p,
                                        (const uint32_t *)j->read_pk.p, (const uint32_t *)j->read_rc.p, (const int64_t *)j->read_woff.p, (const uint32_t *)j->ctg_pk.p, (const uint32_t *)j->ctg_rc.p,
@@ -2476,8 +2524,11 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
             FZP_HIP(hipStreamWaitEvent(st2, j->ev_sw[bi], 0));
             if (ns > 0) {
                 ProfScope ps(ctx, "k1_traceback", st2);
-                hipLaunchKernelGGL(k_tb_walk, dim3((ns + TBW_RPW * TBW_WPG - 1) / (TBW_RPW * TBW_WPG)), dim3(64 * TBW_WPG), 0, st2, ns, (const uint32_t *)B.list.p, (const DpInfo *)B.info.p,
-                                   (const int64_t *)B.tbo.p, (const int64_t *)B.mvo.p, (const int32_t *)B.tbs.p, (const ulonglong2 *)B.tb.p, (const ulonglong2 *)B.mvw.p, B.raw.p, B.wout.p);
+                const bool tb_stats = getenv("FZP_TB_STATS") != nullptr;
+                if (tb_stats && !j->tb_stats.p) { FZP_TRY(j->tb_stats.alloc(16)); FZP_TRY(j->tb_stats.zero(16, st2)); }
+                hipLaunchKernelGGL(tb_stats ? k_tb_walk<true> : k_tb_walk<false>, dim3((ns + TBW_RPW * TBW_WPG - 1) / (TBW_RPW * TBW_WPG)), dim3(64 * TBW_WPG), 0, st2, ns, (const uint32_t *)B.list.p, (const DpInfo *)B.info.p,
+                                   (const int64_t *)B.tbo.p, (const int64_t *)B.mvo.p, (const int32_t *)B.tbs.p, (const ulonglong2 *)B.tb.p, (const ulonglong2 *)B.mvw.p, B.raw.p, B.wout.p,
+                                   (unsigned long long *)j->tb_stats.p);
             }
             {
                 ProfScope ps(ctx, "k1_join", st2);
@@ -2518,6 +2569,18 @@ int fetch_summaries(fzp_ctx *ctx, fzp_alnjob *j) {
 }  // namespace
 
 extern "C" int64_t fzp_align_n_second(const fzp_alnjob *j) { return j ? j->n_second : 0; }
+// measurement aid (tools/runs/tb_window_stats.py): with FZP_TB_STATS set, the walkers' window statistics summed over the job's runs (16 counters)
+extern "C" int fzp_debug_tb_stats(fzp_ctx *ctx, fzp_alnjob *j, unsigned long long *out) {
+    if (!ctx || !j || !j->tb_stats.p || fzp_bind(ctx) != FZP_OK) return FZP_EINVAL;
+    return hipMemcpy(out, j->tb_stats.p, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? FZP_OK : FZP_EDEVICE;
+}
+// measurement aid (tools/runs/swb_waves.py): with FZP_SWB_WAVE_LOG set, the last run's k_swb workgroups as {start, end (100 MHz ticks), hardware id, steps}; returns their number
+extern "C" int64_t fzp_debug_swb_waves(fzp_ctx *ctx, fzp_alnjob *j, uint64_t *out, int64_t cap) {
+    if (!ctx || !j || !j->wave_log.p || fzp_bind(ctx) != FZP_OK) return 0;
+    const int64_t n = std::min<int64_t>(cap, j->wave_log_n);
+    if (n > 0 && (hipMemcpy(out, j->wave_log.p, (size_t)n * 32, hipMemcpyDeviceToHost) != hipSuccess)) return 0;
+    return n;
+}
 extern "C" int fzp_align_summaries(fzp_ctx *ctx, fzp_alnjob *j, fzp_aln_summary *out) {
     if (!ctx || !j || !j->done || !out) { fzp_set_error("fzp_align_summaries: run the job first"); return FZP_EINVAL; }
     FZP_TRY(fetch_summaries(ctx, j));
