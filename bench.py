@@ -569,7 +569,6 @@ def main():
     if e2e is not None and not args.no_from_files:
         # the same workload from the reference's own input files (unzip.py:204,233-234: reads/<ctg>_ref.fa, <ctg>_reads.fa) on a memory file system: FASTA parsing
         # (the library's, a contig group ahead of the lanes) inside the clock as well -- what scripts/fc_unzip_phase_gpu.py does per rank.  Never `value`.
-        import shutil
         reads_dir = None
         try:
             reads_dir = write_reads_tree(contigs, blob, off, read_ctg, ids, name_tab, "/dev/shm" if os.path.isdir("/dev/shm") else out_root)

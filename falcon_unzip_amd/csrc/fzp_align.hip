@@ -556,14 +556,16 @@ __device__ __forceinline__ void cand_slots(const Anchor a, int which, int32_t nw
 // per read: how many slots, how many DP steps of capacity
 __global__ void __launch_bounds__(256) k_slot_count(int64_t nr, const Anchor *__restrict__ anc, const Anchor *__restrict__ ancB, const int32_t *__restrict__ n_wp, const int2 *__restrict__ wps,
                                                     const int32_t *__restrict__ read_len, const int32_t *__restrict__ read_ctg, const int64_t *__restrict__ ctg_len,
-                                                    uint32_t *__restrict__ cnt, uint32_t *__restrict__ capq, uint32_t *__restrict__ n_sec) {
+                                                    uint32_t *__restrict__ cnt, uint32_t *__restrict__ capq, uint32_t *__restrict__ n_sec, int32_t swb_max_steps, int32_t use_bits,
+                                                    unsigned long long *__restrict__ sw_capq) {
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
     bool second = false;
+    uint32_t wq = 0;                                       // capacity / 64 of this read's slots that the wave-per-slot kernel will take (k_route's test): they keep whole masks
     if (r < nr) {
         uint32_t k = 0, cq = 0;
         const int32_t n = read_len[r], c = read_ctg[r];
         const int64_t Lc = ctg_len[c];
-        auto tally = [&](const Slot &sl) { k++; cq += (uint32_t)(sl.cap >> 6); };
+        auto tally = [&](const Slot &sl) { k++; cq += (uint32_t)(sl.cap >> 6); if (!(use_bits && sl.nq >= 64 && sl.nt >= 64 && sl.nq + sl.nt + 2 <= swb_max_steps)) wq += (uint32_t)(sl.cap >> 6); };
         cand_slots(anc[r], 0, n_wp[2 * r], wps + (size_t)(2 * r) * MAX_WP, (int32_t)r, n, c, Lc, tally);
         cand_slots(ancB[r], 1, n_wp[2 * r + 1], wps + (size_t)(2 * r + 1) * MAX_WP, (int32_t)r, n, c, Lc, tally);
         cnt[r] = k; capq[r] = cq;
@@ -571,6 +573,8 @@ __global__ void __launch_bounds__(256) k_slot_count(int64_t nr, const Anchor *__
     }
     const uint64_t m = __ballot(second);
     if (lane_id() == 0 && m) atomicAdd(n_sec, (uint32_t)__popcll(m));
+    const int32_t ws = wave_sum_i32_dpp((int32_t)wq);
+    if (lane_id() == 0 && ws) atomicAdd(sw_capq, (unsigned long long)(uint32_t)ws);
 }
 __global__ void __launch_bounds__(256) k_slot_emit(int64_t r_lo, int64_t r_hi, const Anchor *__restrict__ anc, const Anchor *__restrict__ ancB, const int32_t *__restrict__ n_wp, const int2 *__restrict__ wps,
                                                    const int32_t *__restrict__ read_len, const int32_t *__restrict__ read_ctg, const int64_t *__restrict__ ctg_len,
@@ -632,14 +636,16 @@ __global__ void __launch_bounds__(256) k_lists(uint32_t ns, const Slot *__restri
 // where every slot's masks, move words and op stream go.  Bit-sliced slots: group g's region starts at record 4096 * (sum of gq before g), the x-th stream of the group at
 // + 64 x, its 64-step blocks 4 096 records apart (what a wave writes during 64 steps lies within 64 KB); the others: streams of their own behind all groups.
 __global__ void __launch_bounds__(256) k_plan_final(uint32_t ns, const uint32_t *__restrict__ list, const uint32_t *__restrict__ lq_scan, const uint32_t *__restrict__ gq_scan,
-                                                    const uint64_t *__restrict__ n_b_dev, const uint64_t *__restrict__ gq_total_dev, int64_t *__restrict__ tbo, int64_t *__restrict__ mvo, int32_t *__restrict__ tbs) {
+                                                    uint64_t *__restrict__ ptot, int64_t *__restrict__ tbo, int64_t *__restrict__ mvo, int32_t *__restrict__ tbs) {
     const uint32_t y = blockIdx.x * 256 + threadIdx.x;
     if (y >= ns) return;
-    const uint32_t n_b = (uint32_t)*n_b_dev;
+    const uint32_t n_b = (uint32_t)ptot[0];
     const uint32_t sl = list[y];
     mvo[sl] = (int64_t)lq_scan[y];
+    // bit-sliced slots: 8-byte records in the chunk's mask buffer, interleaved by launch group; the others: 16-byte records, streams of their own, in the buffer of whole masks
     if (y < n_b) { tbo[sl] = 4096ll * gq_scan[y >> 6] + 64ll * (y & 63u); tbs[sl] = 4096; }
-    else { tbo[sl] = 4096ll * (int64_t)*gq_total_dev + 64ll * ((int64_t)lq_scan[y] - (int64_t)lq_scan[n_b]); tbs[sl] = 64; }
+    else { tbo[sl] = 64ll * ((int64_t)lq_scan[y] - (int64_t)lq_scan[n_b]); tbs[sl] = 64; }
+    if (y == 0) { ptot[3] = 0; ptot[4] = 64ull * (ptot[2] - (n_b < ns ? (uint64_t)lq_scan[n_b] : ptot[2])); }      // the fail list is empty; whole masks of slots that land on it go behind the others'
 }
 
 struct DpInfo { int32_t steps, best_t, best_lane, best_score; };
@@ -877,16 +883,16 @@ __device__ __forceinline__ uint64_t base_window(const uint32_t *__restrict__ pk,
 }
 
 template <bool STORE>
-__global__ void __launch_bounds__(64) k_sw(uint32_t ns, const uint64_t *__restrict__ n_b_dev, const uint32_t *__restrict__ list, const Slot *__restrict__ slots,
+__global__ void __launch_bounds__(64) k_sw(const uint64_t *__restrict__ lo_dev, const uint64_t *__restrict__ hi_dev, uint32_t hi_host, const uint32_t *__restrict__ list, const Slot *__restrict__ slots,
                                             const uint32_t *__restrict__ read_pk, const uint32_t *__restrict__ read_rc, const int64_t *__restrict__ read_woff,
                                             const uint32_t *__restrict__ ctg_pk, const uint32_t *__restrict__ ctg_rc, const int64_t *__restrict__ ctg_woff,
                                             const int64_t *__restrict__ tbo, const int64_t *__restrict__ mvo, const int32_t *__restrict__ tbs, uint2 *__restrict__ tb, ulonglong2 *__restrict__ mvw,
                                             int match, int mismatch, int gap, DpInfo *__restrict__ info) {
     const int lane = lane_id();
     // wave-uniform on purpose: everything indexed by the slot then lives in SGPRs / scalar loads.  One wave per workgroup: a finished slot frees its place at once.
-    // This kernel's slots are the launch list behind the bit-sliced kernel's (list[n_b ..)): in sorted order, longest first.
-    const uint32_t y = (uint32_t)*n_b_dev + blockIdx.x;
-    if (y >= ns) return;
+    // This kernel's slots are list[lo .. hi): the launch list behind the bit-sliced kernel's part (in sorted order, longest first), or the fail list of the 8-byte walk.
+    const uint32_t y = (lo_dev ? (uint32_t)*lo_dev : 0u) + blockIdx.x;
+    if (y >= (hi_dev ? (uint32_t)*hi_dev : hi_host)) return;
     const uint32_t sl = list[y];
     const Slot S = slots[sl];
     // the records of steps 64 b .. 64 b + 63 of a slot start at record b * stride of its stream (64: a stream of its own)
@@ -1172,7 +1178,7 @@ __global__ void __launch_bounds__(256) k_swb(const uint64_t *__restrict__ n_b_de
     const uint32_t sl = list[active ? li : 0];      // the lane's slot; the lanes of a wave stand side by side in the launch list, and so do their mask streams
     const Slot S = slots[sl];
     // (64 streams scattered over the buffer cost twice the time in address translation alone: the plan interleaves a wave's streams block by block, stride 4 096 records)
-    ulonglong2 *tbr = (ulonglong2 *)tb + tbo[sl];
+    uint2 *tbr = tb + tbo[sl];                            // per step {D, G} over band lanes 16..47
     ulonglong2 *mvr = mvw + mvo[sl];
     const int32_t nq = S.nq, nt = S.nt;
     const bool inner = (S.flags & SLOT_INNER) != 0;
@@ -1188,13 +1194,6 @@ __global__ void __launch_bounds__(256) k_swb(const uint64_t *__restrict__ n_b_de
     for (int k = 33; k < 64; k++) { const uint32_t c = base_at(qpk, qb + (k - 33)); L.R0 |= (uint64_t)(c & 1u) << k; L.R1 |= (uint64_t)(c >> 1) << k; }
     for (int k = 0; k <= 32; k++) { const uint32_t c = base_at(tpk, tbase + (32 - k)); L.C0 |= (uint64_t)(c & 1u) << k; L.C1 |= (uint64_t)(c >> 1) << k; }
     __shared__ uint32_t srng[RING ? 2 * 64 * 64 : 1];                      // the two streams' rings (32 KB per wave)
-    // the mask records of a group of 8 steps leave through a tile in LDS, turned round: a lane's own eight records are 128 B of ITS stream, so a store instruction of the
-    // plain form hands the memory pipeline 64 lanes x 16 B in 64 different lines; through the tile lane L carries record (stream L / 8 + 8 k, step L % 8) in the k-th of
-    // eight stores -- 8 whole lines per instruction.  Rows are swizzled by (row >> 1) & 7 so that neither side has a bank conflict.  (8 KB: with the rings exactly a
-    // quarter of a CU's LDS -- four waves per CU, one per SIMD, as the registers allow anyway.)
-    __shared__ uint4 tile[RING ? 64 * SWB_GROUP : 1];
-    const bool tile_stores = RING && !(dbg & 4);                            // FZP_SWB_DBG bit 2: the plain per-lane stores, for comparisons
-    ulonglong2 *gbase = (ulonglong2 *)tb + tbo[list[(int64_t)blockIdx.x * blockDim.x]];      // the wave's region: its first lane's stream (wave-uniform)
     if constexpr (RING) {
         L.qs.init(qpk, qb + 31, (uint32_t)((qb + nq + 15) >> 4) + 1u, srng + threadIdx.x);
         L.ts.init(tpk, tbase + 33, (uint32_t)((tbase + nt + 15) >> 4) + 1u, srng + 64 * 64 + threadIdx.x);
@@ -1228,26 +1227,11 @@ __global__ void __launch_bounds__(256) k_swb(const uint64_t *__restrict__ n_b_de
             // the streams top up every 16 steps, and they do it HERE, ahead of a group's stores: taking the word loaded 16 steps ago means waiting on the vector-memory
             // counter, which also counts the mask stores -- at this point the youngest of those are 8 steps old and done, right behind a group they would be in flight
             if ((g8 & (16 / SWB_GROUP - 1)) == 16 / SWB_GROUP - 1 && !(dbg & 2)) { L.qs.refill(); L.ts.refill(); }
-            if (tile_stores) {
-                if constexpr (RING) {
-                    if (!(dbg & 1)) {      // (every stream of the group has room for the group's longest extension: lanes that are done write into their own slack)
-                        const uint32_t lane = threadIdx.x & 63u, key = (lane >> 1) & 7u;
+            if (grp_active && !(dbg & 1)) {      // what leaves is the middle of the band: lanes 16..47 of D and of G, 8 B per step (the walker says so if its path ever needs more)
 #pragma unroll
-                        for (int s8 = 0; s8 < SWB_GROUP; s8++) tile[lane * SWB_GROUP + ((uint32_t)s8 ^ key)] = make_uint4((uint32_t)rec[s8].x, (uint32_t)(rec[s8].x >> 32), (uint32_t)rec[s8].y, (uint32_t)(rec[s8].y >> 32));
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                        ulonglong2 *gb = gbase + (int64_t)((t - SWB_GROUP) >> 6) * stride + ((t - SWB_GROUP) & 63) + (lane & 7u);
-#pragma unroll
-                        for (int k = 0; k < 8; k++) {
-                            const uint32_t x = (lane >> 3) + 8u * (uint32_t)k;
-                            const uint4 v = tile[x * SWB_GROUP + ((lane & 7u) ^ ((x >> 1) & 7u))];
-                            gb[(int64_t)x * 64] = make_ulonglong2(((uint64_t)v.y << 32) | v.x, ((uint64_t)v.w << 32) | v.z);
-                        }
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    }
-                }
-            } else if (grp_active && !(dbg & 1)) {
-#pragma unroll
-                for (int s8 = 0; s8 < SWB_GROUP; s8++) tbr[(int64_t)((t - SWB_GROUP) >> 6) * stride + ((t - SWB_GROUP) & 63) + s8] = rec[s8];
+                for (int s8 = 0; s8 < SWB_GROUP; s8 += 2)
+                    *(uint4 *)(tbr + (int64_t)((t - SWB_GROUP) >> 6) * stride + ((t - SWB_GROUP) & 63) + s8) =
+                        make_uint4((uint32_t)(rec[s8].x >> 16), (uint32_t)(rec[s8].y >> 16), (uint32_t)(rec[s8 + 1].x >> 16), (uint32_t)(rec[s8 + 1].y >> 16));
             }
         }
         if (blk_active) {
@@ -1343,7 +1327,7 @@ __global__ void __launch_bounds__(256) k_swb2(const uint64_t *__restrict__ n_b_d
     if (!__ballot(active)) return;
     const uint32_t sl = list[active ? li : 0];      // the pair's slot
     const Slot S = slots[sl];
-    uint2 *tbr = tb + 2 * tbo[sl] + is_hi;                // per step 16 B {D, G}: this lane's 8 of them
+    uint32_t *tbr = (uint32_t *)(tb + tbo[sl]) + is_hi;   // per step 8 B {D, G} over band lanes 16..47: this lane's 4 of them
     ulonglong2 *mvr = mvw + mvo[sl];
     const int32_t nq = S.nq, nt = S.nt;
     const bool inner = (S.flags & SLOT_INNER) != 0;
@@ -1390,7 +1374,7 @@ __global__ void __launch_bounds__(256) k_swb2(const uint64_t *__restrict__ n_b_d
             if (g8 & 1) L.ss.refill();      // (ahead of the stores: see k_swb)
             if (grp_active) {
 #pragma unroll
-                for (int s8 = 0; s8 < 8; s8++) tbr[2 * ((int64_t)((t - 8) >> 6) * stride + ((t - 8) & 63) + s8)] = rec[s8];
+                for (int s8 = 0; s8 < 8; s8++) tbr[2 * ((int64_t)((t - 8) >> 6) * stride + ((t - 8) & 63) + s8)] = (rec[s8].x >> 16) | (rec[s8].y << 16);      // (the low lane holds D, the high lane G, each as {cells 0..31, cells 32..63})
             }
         }
         if (blk_active && lo) {
@@ -1416,6 +1400,8 @@ __global__ void __launch_bounds__(256) k_swb2(const uint64_t *__restrict__ n_b_d
 //     move of the step before the current one); the operation of the step (M / I / D) goes into a 2-bit stream,
 //     16 ops per word, flushed to HBM when full.  Run-length encoding is k_tb_cigar's job, off this chain.
 // HBM traffic: the 16 B/step masks are read once.
+constexpr int FAIL_CAP = 8192;                   // slots that may come back from the 8-byte walk per chunk ...
+constexpr int64_t FAIL_ROOM = 4ll << 20;         // ... and the DP steps (16-byte records) there is room for
 constexpr int TBW_STRIDE = 512 + 8;              // bytes per slot: one 64-step chunk of {D bits, G bits}; +8 staggers LDS banks
 constexpr int TBW_RPW = 16;                      // slots walked per wave
 constexpr int TBW_WPG = 1;                       // waves per workgroup (four measured: no faster on uniform reads, 20 % slower on reads of real shape)
@@ -1424,18 +1410,24 @@ constexpr int TBW_WPG = 1;                       // waves per workgroup (four me
 
 struct WalkOut { int32_t ok, i, ts, i_end, j_end, ncol, n_ops, pad_; };   // (i_end, j_end) = the terminal; (i, ts - i) = where the walk left the matrix (one of the two is -1)
 
-// STATS (FZP_TB_STATS, a measurement aid): how often a path leaves the middle 32 lanes of the band, and a 32-lane window centred where the band's edge scores say the path is
-template <bool STATS>
-__global__ void __launch_bounds__(64 * TBW_WPG) k_tb_walk(uint32_t ns, const uint32_t *__restrict__ order, const DpInfo *__restrict__ info,
-                                                const int64_t *__restrict__ tbo, const int64_t *__restrict__ mvo, const int32_t *__restrict__ tbs,
-                                                const ulonglong2 *__restrict__ tb, const ulonglong2 *__restrict__ mvw, uint32_t *__restrict__ raw,
-                                                WalkOut *__restrict__ wout, unsigned long long *__restrict__ stats) {
+// FULL = false: the slot's masks are the bit-sliced kernel's 8-byte records (band lanes 16..47 of D and G); a path that leaves those lanes cannot be followed: the slot goes
+// on the fail list (WalkOut.ok = 2) and is computed again with whole masks (k_sw) and walked by the FULL form.  (Of 92 000 pieces measured, none left lanes 20..43.)
+// FULL = true: 16-byte records (k_sw's), the staged window of 32 lanes follows the path.
+// STATS (FZP_TB_STATS, a measurement aid): how far from the band's centre the paths run
+template <bool FULL, bool STATS>
+__global__ void __launch_bounds__(64 * TBW_WPG) k_tb_walk(const uint32_t *__restrict__ order, const uint64_t *__restrict__ lo_dev, const uint64_t *__restrict__ hi_dev, uint32_t hi_host,
+                                                const DpInfo *__restrict__ info, const int64_t *__restrict__ tbo, const int64_t *__restrict__ mvo, const int32_t *__restrict__ tbs,
+                                                const void *__restrict__ tb_, const ulonglong2 *__restrict__ mvw, uint32_t *__restrict__ raw,
+                                                WalkOut *__restrict__ wout, unsigned long long *__restrict__ stats, uint32_t *__restrict__ fail_list, uint64_t *__restrict__ n_fail,
+                                                uint32_t fail_cap, int32_t win_half) {
     // TBW_WPG independent waves per workgroup: every wave has its own slice of the LDS buffer and never waits for another
     __shared__ __attribute__((aligned(16))) uint8_t lds_all[TBW_WPG * TBW_RPW * TBW_STRIDE];
     uint8_t *lds = lds_all + (threadIdx.x >> 6) * (TBW_RPW * TBW_STRIDE);
     const int lane = threadIdx.x & 63;
-    const int64_t wq = ((int64_t)blockIdx.x * TBW_WPG + (threadIdx.x >> 6)) * TBW_RPW + lane;
-    const bool have = lane < TBW_RPW && wq < (int64_t)ns;
+    // this launch's slots: order[lo .. hi) (the bit-sliced kernel's part of the launch list, the rest of it, or the fail list)
+    const int64_t lo = lo_dev ? (int64_t)*lo_dev : 0, hi = hi_dev ? (int64_t)*hi_dev : (int64_t)hi_host;
+    const int64_t wq = lo + ((int64_t)blockIdx.x * TBW_WPG + (threadIdx.x >> 6)) * TBW_RPW + lane;
+    const bool have = lane < TBW_RPW && wq < hi;
     // `order` = the launch list (slots by decreasing capacity): the 16 walks of a wave are of similar length (a wave lasts as long as its longest) and the longest start first
     const uint32_t sl = have ? order[wq] : 0u;
     DpInfo di = {0, -1, 0, NEGV};
@@ -1443,7 +1435,8 @@ __global__ void __launch_bounds__(64 * TBW_WPG) k_tb_walk(uint32_t ns, const uin
     bool active = have && di.best_t >= 0;
     int64_t to_ = have ? tbo[sl] : 0, mo_ = have ? mvo[sl] : 0;
     asm volatile("" : "+v"(to_), "+v"(mo_));      // both offsets are in registers from here on: no pending load is attributed to the pointers below
-    const ulonglong2 *tbr = tb + to_;                                         // per step {D mask, G mask}
+    constexpr int REC = FULL ? 16 : 8;                                        // bytes per step
+    const uint8_t *tbr = (const uint8_t *)tb_ + to_ * REC;                    // per step {D mask, G mask}
     const ulonglong2 *mvr = mvw + mo_;                                        // per 64 steps {move bits, i0 before them}
     uint32_t *rawp = raw + 4 * mo_;                                           // 16 ops per word: cap / 16 words per slot
     int32_t ts = active ? di.best_t : -1;
@@ -1459,18 +1452,22 @@ __global__ void __launch_bounds__(64 * TBW_WPG) k_tb_walk(uint32_t ns, const uin
     const int32_t i_end = i, j_end = ts - i;
     active = active && i >= 0 && ts - i >= 0;
     const bool walked = active;
+    bool failed = false;
+    const int32_t wlo = 32 - win_half;                                       // FULL = false: the path may use band lanes [wlo, wlo + 2 win_half) (16..47; tests narrow it)
+    const uint32_t wn = 2u * (uint32_t)win_half;
     int32_t ncol = 0, n_ops = 0, nw = 0;
     uint32_t rawacc = 0, nb = 0;
     const int32_t plo = (int32_t)(uint32_t)(uint64_t)tbr, phi = (int32_t)((uint64_t)tbr >> 32);
     const int32_t rstride = have ? tbs[sl] : 64;      // records from one 64-step chunk of the slot's masks to the next
     uint8_t *mine = lds + lane * TBW_STRIDE;
-    int32_t cur_chunk = -2, sh_cur = 0;
+    int32_t cur_chunk = -2, sh_cur = FULL ? 0 : 16;
     uint32_t st_fixed = 0, st_adapt = 0, st_steps = 0, st_maxdev = 0;      // STATS: steps outside lanes [16, 48) / outside the adaptive window
     int32_t st_centre = 32;
-    int32_t pref_chunk = active ? ts >> 6 : -1, pref_sh = min(max(k - 16, 0), 32);
-    uint4 pf[TBW_RPW];
+    int32_t pref_chunk = active ? ts >> 6 : -1, pref_sh = FULL ? min(max(k - 16, 0), 32) : 16;
+    typedef typename std::conditional<FULL, uint4, uint2>::type rec_t;
+    rec_t pf[TBW_RPW];
 #pragma unroll
-    for (int l = 0; l < TBW_RPW; l++) pf[l] = make_uint4(0, 0, 0, 0);
+    for (int l = 0; l < TBW_RPW; l++) memset(&pf[l], 0, sizeof(rec_t));
     uint64_t rec_base[TBW_RPW];      // every slot's mask records: wave-uniform, fetched from the owning lanes once
 #pragma unroll
     for (int l = 0; l < TBW_RPW; l++) rec_base[l] = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(phi, l) << 32) | (uint32_t)__builtin_amdgcn_readlane(plo, l);
@@ -1478,30 +1475,36 @@ __global__ void __launch_bounds__(64 * TBW_WPG) k_tb_walk(uint32_t ns, const uin
     // (the record pointers are rebuilt from lane reads, which leaves them in the generic address space; a FLAT load counts on lgkmcnt as
     //  well as on vmcnt, so the walk's first wait for an LDS read would wait for the whole prefetch: load through global pointers)
     typedef uint32_t tbw_u32x4 __attribute__((ext_vector_type(4)));
-    typedef const tbw_u32x4 __attribute__((address_space(1))) *tbw_gptr;
+    typedef uint32_t tbw_u32x2 __attribute__((ext_vector_type(2)));
+    typedef const tbw_u32x4 __attribute__((address_space(1))) *tbw_gptr4;
+    typedef const tbw_u32x2 __attribute__((address_space(1))) *tbw_gptr2;
 #define TBW_ISSUE()                                                                                                      \
     _Pragma("unroll") for (int l = 0; l < TBW_RPW; l++) {                                                                \
         const int32_t cl = __builtin_amdgcn_readlane(pref_chunk, l);                                                     \
         if (cl >= 0) {                                                                                                   \
-            const tbw_u32x4 q_ = ((tbw_gptr)rec_base[l])[(int64_t)cl * __builtin_amdgcn_readlane(rstride, l) + lane];            \
-            pf[l] = make_uint4(q_.x, q_.y, q_.z, q_.w);                                                                  \
+            const int64_t at_ = (int64_t)cl * __builtin_amdgcn_readlane(rstride, l) + lane;                              \
+            if constexpr (FULL) { const tbw_u32x4 q_ = ((tbw_gptr4)rec_base[l])[at_]; pf[l] = make_uint4(q_.x, q_.y, q_.z, q_.w); }   \
+            else { const tbw_u32x2 q_ = ((tbw_gptr2)rec_base[l])[at_]; pf[l] = make_uint2(q_.x, q_.y); }               \
         }                                                                                                                \
     }
+    auto park = [&](int l, const rec_t &v, int32_t sh) {      // a chunk's records into slot l's LDS buffer: per step the 32 lanes of D and of G the walk will look at
+        if constexpr (FULL) {
+            const uint64_t D = ((uint64_t)v.y << 32) | v.x, G = ((uint64_t)v.w << 32) | v.z;
+            *(uint2 *)(lds + l * TBW_STRIDE + lane * 8) = make_uint2((uint32_t)(D >> sh), (uint32_t)(G >> sh));
+        } else *(uint2 *)(lds + l * TBW_STRIDE + lane * 8) = v;
+    };
     TBW_ISSUE()
     for (;;) {
         if ((uint32_t)k >= 64u) active = false;      // (masks that are not a DP's: a walk that has left the band ends here, marked by i, ts >= 0, instead of spinning on reloads)
+        if (!FULL && active && (uint32_t)(k - wlo) >= wn) { active = false; failed = true; }      // the path needs a lane the 8-byte records do not hold
         if (!__any(active)) break;
         const int32_t need = active ? ts >> 6 : -1;
-        // park the prefetched chunk: 32 lanes' worth of D and G per step (the walk is done with the old contents)
+        // park the prefetched chunk (the walk is done with the old contents)
         {
 #pragma unroll
             for (int l = 0; l < TBW_RPW; l++) {
                 const int32_t cl = __builtin_amdgcn_readlane(pref_chunk, l);
-                if (cl >= 0) {
-                    const int32_t sh = __builtin_amdgcn_readlane(pref_sh, l);
-                    const uint64_t D = ((uint64_t)pf[l].y << 32) | pf[l].x, G = ((uint64_t)pf[l].w << 32) | pf[l].z;
-                    *(uint2 *)(lds + l * TBW_STRIDE + lane * 8) = make_uint2((uint32_t)(D >> sh), (uint32_t)(G >> sh));
-                }
+                if (cl >= 0) park(l, pf[l], __builtin_amdgcn_readlane(pref_sh, l));
             }
         }
         const bool ok = need < 0 || (need == pref_chunk && (uint32_t)(k - pref_sh) < 32u);
@@ -1509,21 +1512,20 @@ __global__ void __launch_bounds__(64 * TBW_WPG) k_tb_walk(uint32_t ns, const uin
         const uint64_t redo = __ballot(active && !ok);
         if (redo) {   // rare: the path left the staged lanes, or stalled inside its chunk
             if (active && !ok) {
-                cur_chunk = need; sh_cur = min(max(k - 16, 0), 32);
+                cur_chunk = need; sh_cur = FULL ? min(max(k - 16, 0), 32) : 16;
                 w_cur = mvr[need].x; w_prev = need > 0 ? mvr[need - 1].x : 0ull;
             }
             for (int l = 0; l < TBW_RPW; l++) {
                 if (!((redo >> l) & 1ull)) continue;
                 const uint64_t pl = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(phi, l) << 32) | (uint32_t)__builtin_amdgcn_readlane(plo, l);
                 const int32_t cl = __builtin_amdgcn_readlane(cur_chunk, l), sh = __builtin_amdgcn_readlane(sh_cur, l);
-                const uint4 v = ((const uint4 *)pl)[(int64_t)cl * __builtin_amdgcn_readlane(rstride, l) + lane];
-                const uint64_t D = ((uint64_t)v.y << 32) | v.x, G = ((uint64_t)v.w << 32) | v.z;
-                *(uint2 *)(lds + l * TBW_STRIDE + lane * 8) = make_uint2((uint32_t)(D >> sh), (uint32_t)(G >> sh));
+                const rec_t v = ((const rec_t *)pl)[(int64_t)cl * __builtin_amdgcn_readlane(rstride, l) + lane];
+                park(l, v, sh);
             }
         }
         // next prefetch: the chunk below, centred on where the path is now
         pref_chunk = (active && cur_chunk > 0) ? cur_chunk - 1 : -1;
-        pref_sh = min(max(k - 16, 0), 32);
+        pref_sh = FULL ? min(max(k - 16, 0), 32) : 16;
         if (pref_chunk > 0) pref_word = mvr[pref_chunk - 1].x; else pref_word = 0ull;
         TBW_ISSUE()
         TBW_WAVE_SYNC();
@@ -1537,7 +1539,7 @@ __global__ void __launch_bounds__(64 * TBW_WPG) k_tb_walk(uint32_t ns, const uin
         }
         const uint8_t *win = mine;
         if (STATS && active) { const int32_t e2 = (int32_t)(mvr[ts >> 6].y >> 32); st_centre = min(max(32 + e2 / 3, 16), 48); }      // score(lane 63) - score(lane 0) = 2 E2 ~ 6 x (path's lane - 31.5)
-        while (active && (ts >> 6) == cur_chunk && (uint32_t)(k - sh_cur) < 32u) {
+        while (active && (ts >> 6) == cur_chunk && (FULL ? (uint32_t)(k - sh_cur) < 32u : (uint32_t)(k - wlo) < wn)) {
             if (STATS) { st_steps++; st_fixed += (uint32_t)(k - 16) >= 32u ? 1u : 0u; st_adapt += (uint32_t)(k - (st_centre - 16)) >= 32u ? 1u : 0u; st_maxdev = max(st_maxdev, (uint32_t)abs(k - st_centre)); }
             const uint2 m = *(const uint2 *)(win + (ts & 63) * 8);
             const uint32_t kk = (uint32_t)(k - sh_cur);
@@ -1569,10 +1571,28 @@ __global__ void __launch_bounds__(64 * TBW_WPG) k_tb_walk(uint32_t ns, const uin
         atomicAdd(&stats[3], (unsigned long long)st_steps); atomicAdd(&stats[4], (unsigned long long)st_fixed); atomicAdd(&stats[5], (unsigned long long)st_adapt);
         atomicAdd(&stats[6 + min(st_maxdev >> 2, 9u)], 1ull);      // slots by their largest distance from the estimated centre, in fours
     }
+    if (!FULL && failed) {
+        const uint32_t f = (uint32_t)atomicAdd((unsigned long long *)n_fail, 1ull);
+        if (f < fail_cap) fail_list[f] = sl;
+    }
     if (nb) rawp[nw] = rawacc;
     WalkOut o;
-    o.ok = walked ? 1 : 0; o.i = i; o.ts = ts; o.i_end = i_end; o.j_end = j_end; o.ncol = ncol; o.n_ops = n_ops; o.pad_ = 0;
+    o.ok = failed ? 2 : (walked ? 1 : 0); o.i = i; o.ts = ts; o.i_end = i_end; o.j_end = j_end; o.ncol = ncol; o.n_ops = n_ops; o.pad_ = 0;
     wout[sl] = o;
+}
+
+// the slots on the fail list get room for whole masks behind the wave-per-slot kernel's own (a bump allocation: which slot lands where is a race, what is computed is not)
+__global__ void __launch_bounds__(256) k_fail_plan(const uint32_t *__restrict__ fail_list, const uint64_t *__restrict__ n_fail, uint32_t fail_cap, const Slot *__restrict__ slots,
+                                                   unsigned long long *__restrict__ cursor, uint64_t room, int64_t *__restrict__ tbo, int32_t *__restrict__ tbs, uint32_t *__restrict__ overflow) {
+    const uint32_t f = blockIdx.x * 256 + threadIdx.x;
+    const uint64_t n = *n_fail;
+    if (f == 0 && n > fail_cap) atomicOr(overflow, 1u);
+    if (f >= n || f >= fail_cap) return;
+    const uint32_t sl = fail_list[f];
+    const uint64_t cap = (uint64_t)slots[sl].cap;
+    const uint64_t at = atomicAdd(cursor, (unsigned long long)cap);
+    if (at + cap > room) { atomicOr(overflow, 2u); tbo[sl] = 0; tbs[sl] = 64; return; }      // (the run fails with a message; the walk of this slot stays inside the buffer)
+    tbo[sl] = (int64_t)at; tbs[sl] = 64;
 }
 
 // ---- trace-back, part 2: one wave per read turns the walk's op stream (alignment end first, 16 ops per word)
@@ -2137,12 +2157,15 @@ static std::map<int, hipEvent_t> g_dp_last;
 struct ChunkBufs {
     DevBuf<Slot> slots;
     DevBuf<uint32_t> bh, sorted, fits, pos_b, list, lq, lq_scan, gq, gq_scan;
-    DevBuf<uint64_t> ptot;                       // [0] slots of the bit-sliced kernel, [1] sum of gq (its mask regions, in units of 4 096 records), [2] sum of lq (cap / 64 over all slots)
+    DevBuf<uint64_t> ptot;                       // [0] slots of the bit-sliced kernel, [1] sum of gq (its mask regions, in units of 4 096 records), [2] sum of lq (cap / 64 over all slots),
+                                                 // [3] slots on the fail list, [4] records used in tbw
     DevBuf<int64_t> tbo, mvo;                    // per slot: where its trace-back masks / move words are
     DevBuf<int32_t> tbs;                         // per slot: records from one 64-step block of its masks to the next (4 096: interleaved with its launch group; 64: a stream of its own)
     DevBuf<DpInfo> info;
     DevBuf<WalkOut> wout;
-    DevBuf<uint2> tb;                            // the masks, 16 B per DP step
+    DevBuf<uint2> tb;                            // the bit-sliced kernel's masks: 8 B per DP step (band lanes 16..47 of D and G)
+    DevBuf<ulonglong2> tbw;                      // whole masks, 16 B per DP step: the wave-per-slot kernel's slots, and behind them the slots whose walk needed more than the middle lanes
+    DevBuf<uint32_t> fail_list;                  // slots whose 8-byte walk left the recorded lanes (computed again with whole masks)
     DevBuf<ulonglong2> mvw;                      // move words, one per 64 steps
     DevBuf<uint32_t> raw, rraw;                  // 2-bit op streams: per slot (the walks), per read (joined)
     DevBuf<ReadPath> rpath;
@@ -2177,7 +2200,8 @@ struct fzp_alnjob {
     DevBuf<uint32_t> n_sec;                      // reads with a second candidate
     int64_t n_second = 0;                        // of the last run
     DevBuf<uint32_t> r_cnt, r_capq, slot_base, rcapq_scan;      // per read: slots, their capacity / 64, and the exclusive scans of both
-    DevBuf<uint64_t> rtot;                       // [0] slots of the run, [1] capacity / 64 of the run
+    DevBuf<uint64_t> rtot;                       // [0] slots of the run, [1] capacity / 64 of the run, [2] capacity / 64 of the slots the wave-per-slot kernel takes
+    DevBuf<uint32_t> fb_overflow;                // the fail list or its mask room overflowed (the run reports it)
     ChunkBufs cb[2];
     DevBuf<unsigned long long> tb_stats;         // FZP_TB_STATS (measurement aid): how often a path leaves a 32-lane window of its band, summed over the job's runs
     DevBuf<uint64_t> wave_log;                   // FZP_SWB_WAVE_LOG (measurement aid): per k_swb workgroup of the last chunk {start, end, hardware id, steps}
@@ -2341,7 +2365,7 @@ extern "C" int fzp_align_create(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *cons
         }
         if ((rc = j->table.alloc((size_t)j->idx_slots)) || (rc = j->anc.alloc((size_t)n_reads)) || (rc = j->ancB.alloc((size_t)n_reads)) || (rc = j->n_sec.alloc(1)) ||
             (rc = j->n_wp.alloc((size_t)2 * n_reads)) || (rc = j->wps.alloc((size_t)2 * n_reads * MAX_WP)) || (rc = j->r_cnt.alloc((size_t)n_reads + 1)) || (rc = j->r_capq.alloc((size_t)n_reads + 1)) ||
-            (rc = j->slot_base.alloc((size_t)n_reads + 1)) || (rc = j->rcapq_scan.alloc((size_t)n_reads + 1)) || (rc = j->rtot.alloc(2)) ||
+            (rc = j->slot_base.alloc((size_t)n_reads + 1)) || (rc = j->rcapq_scan.alloc((size_t)n_reads + 1)) || (rc = j->rtot.alloc(4)) || (rc = j->fb_overflow.alloc(1)) ||
             (rc = j->summ.alloc((size_t)n_reads)) || (rc = j->cig.alloc((size_t)j->h_cig_off.back())) || (rc = j->cig_start.alloc((size_t)n_reads)))
             break;
         if ((rc = build_index(ctx, j))) break;
@@ -2387,22 +2411,33 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
                 hipLaunchKernelGGL(k_chain, dim3((unsigned)(2 * cn)), dim3(64), 0, st, f0, cn, j->read_len.p, j->hits.p, j->win.p, j->anc.p, j->ancB.p, j->wpp.p, j->n_wp.p, j->wps.p);
             }
         }
+        // ---- which DP kernel runs which slot (fzalign scores 2 / -4 / -3 are built into the bit-sliced one's cell function)
+        const bool use_bits = getenv("FZP_SW_NO_BITS") == nullptr && P.match == 2 && P.mismatch == 4 && P.gap == 3;
+        // the bit-sliced kernel has two forms.  A pair of lanes per slot (k_swb2) has the shorter step but twice the waves, and its instruction mix issues at ~4.5 cycles per
+        // SIMD however many waves share it: two such waves on one SIMD run at half speed each.  So it is taken when its waves get a SIMD each; else the whole band sits in one
+        // lane (k_swb).  FZP_SWB_64 / FZP_SWB_PAIR force one.
+        const int swb_force = getenv("FZP_SWB_64") ? 64 : (getenv("FZP_SWB_PAIR") ? 32 : 0);
+        const bool swb_ring = getenv("FZP_SWB_NO_RING") == nullptr;        // k_swb's base streams through LDS rings
+        int64_t swb_max_steps = 40960;          // a lane's step costs ~300 ns: a longer extension's chain would outlast the rest of the launch (pieces are a few thousand steps; only reads of > 90 kb have longer ones)
+        if (const char *e = getenv("FZP_SWB_MAX_STEPS")) { const long g = atol(e); if (g > 0) swb_max_steps = g; }
         // ---- the extension pieces of every read (v1.6) as DP slots: counted per read on the device, the two scans give every read its first slot and its share of the
         // mask capacity; the scans come to the host (8 bytes per read), which only cuts the reads into chunks that fit the mask budget -- everything else is planned on the device
         std::vector<uint32_t> h_sb((size_t)nr + 1), h_cq((size_t)nr + 1);
         {
             ProfScope ps(ctx, "k1_plan_dp");
+            FZP_HIP(hipMemsetAsync(j->rtot.p, 0, 32, st));
+            FZP_HIP(hipMemsetAsync(j->fb_overflow.p, 0, 4, st));
             hipLaunchKernelGGL(k_slot_count, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, st, nr, j->anc.p, j->ancB.p, j->n_wp.p, j->wps.p, j->read_len.p, j->read_ctg.p, j->ctg_len.p,
-                               j->r_cnt.p, j->r_capq.p, j->n_sec.p);
+                               j->r_cnt.p, j->r_capq.p, j->n_sec.p, (int32_t)swb_max_steps, use_bits ? 1 : 0, (unsigned long long *)(j->rtot.p + 2));
         }
         FZP_TRY(fzp_exclusive_scan_u32(ctx, j->r_cnt.p, j->slot_base.p, (size_t)nr, j->rtot.p + 0));
         FZP_TRY(fzp_exclusive_scan_u32(ctx, j->r_capq.p, j->rcapq_scan.p, (size_t)nr, j->rtot.p + 1));
         uint32_t n2 = 0;
         int32_t ovf = 0;
-        uint64_t rtot[2] = {0, 0};
+        uint64_t rtot[3] = {0, 0, 0};
         FZP_HIP(hipMemcpyAsync(&n2, j->n_sec.p, 4, hipMemcpyDeviceToHost, st));
         FZP_HIP(hipMemcpyAsync(&ovf, j->idx_overflow.p, 4, hipMemcpyDeviceToHost, st));
-        FZP_HIP(hipMemcpyAsync(rtot, j->rtot.p, 16, hipMemcpyDeviceToHost, st));
+        FZP_HIP(hipMemcpyAsync(rtot, j->rtot.p, 24, hipMemcpyDeviceToHost, st));
         FZP_TRY(j->slot_base.download(h_sb.data(), (size_t)nr, st));
         FZP_TRY(j->rcapq_scan.download(h_cq.data(), (size_t)nr, st));
         FZP_HIP(hipStreamSynchronize(st));
@@ -2421,15 +2456,6 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
         const int64_t total_steps = (int64_t)rtot[1] * 64;
         const int64_t chunk_steps = std::min<int64_t>(budget_steps / 2, (total_steps + n_chunks - 1) / n_chunks);
         if (!j->ev_sw[0]) for (int k = 0; k < 2; k++) { FZP_HIP(hipEventCreateWithFlags(&j->ev_l[k], hipEventDisableTiming)); FZP_HIP(hipEventCreateWithFlags(&j->ev_sw[k], hipEventDisableTiming)); FZP_HIP(hipEventCreateWithFlags(&j->ev_tb[k], hipEventDisableTiming)); }
-        // ---- which DP kernel runs which slot (fzalign scores 2 / -4 / -3 are built into the bit-sliced one's cell function)
-        const bool use_bits = getenv("FZP_SW_NO_BITS") == nullptr && P.match == 2 && P.mismatch == 4 && P.gap == 3;
-        // the bit-sliced kernel has two forms.  A pair of lanes per slot (k_swb2) has the shorter step but twice the waves, and its instruction mix issues at ~4.5 cycles per
-        // SIMD however many waves share it: two such waves on one SIMD run at half speed each.  So it is taken when its waves get a SIMD each; else the whole band sits in one
-        // lane (k_swb).  FZP_SWB_64 / FZP_SWB_PAIR force one.
-        const int swb_force = getenv("FZP_SWB_64") ? 64 : (getenv("FZP_SWB_PAIR") ? 32 : 0);
-        const bool swb_ring = getenv("FZP_SWB_NO_RING") == nullptr;        // k_swb's base streams through LDS rings
-        int64_t swb_max_steps = 40960;          // a lane's step costs ~300 ns: a longer extension's chain would outlast the rest of the launch (pieces are a few thousand steps; only reads of > 90 kb have longer ones)
-        if (const char *e = getenv("FZP_SWB_MAX_STEPS")) { const long g = atol(e); if (g > 0) swb_max_steps = g; }
         int64_t first = 0;
         int k = 0;
         bool used[2] = {false, false};
@@ -2448,11 +2474,16 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
             if (ns > 0) {
                 const uint32_t nblk = (ns + 255) / 256, ngrp = (ns + 63) / 64;
                 FZP_TRY(B.slots.alloc(ns)); FZP_TRY(B.bh.alloc((size_t)SORT_CLASSES * nblk)); FZP_TRY(B.sorted.alloc(ns)); FZP_TRY(B.fits.alloc(ns)); FZP_TRY(B.pos_b.alloc(ns));
-                FZP_TRY(B.list.alloc(ns)); FZP_TRY(B.lq.alloc(ns)); FZP_TRY(B.lq_scan.alloc(ns)); FZP_TRY(B.gq.alloc(ngrp)); FZP_TRY(B.gq_scan.alloc(ngrp)); FZP_TRY(B.ptot.alloc(4));
+                FZP_TRY(B.list.alloc(ns)); FZP_TRY(B.lq.alloc(ns)); FZP_TRY(B.lq_scan.alloc(ns)); FZP_TRY(B.gq.alloc(ngrp)); FZP_TRY(B.gq_scan.alloc(ngrp)); FZP_TRY(B.ptot.alloc(8));
                 FZP_TRY(B.tbo.alloc(ns)); FZP_TRY(B.mvo.alloc(ns)); FZP_TRY(B.tbs.alloc(ns)); FZP_TRY(B.info.alloc(ns)); FZP_TRY(B.wout.alloc(ns));
-                // masks: the bit-sliced slots' interleaved groups take 64 x (their longest member) each -- in sorted order at most the slots' own capacity + one group of the longest
+                // masks: the bit-sliced slots' interleaved groups take 64 x (their longest member) each -- in sorted order at most the slots' own capacity + one group of the longest;
+                // whole masks: the wave-per-slot kernel's slots (their capacity over the whole run bounds every chunk's) and room for slots that come back from the 8-byte walk
                 const int64_t swb_cap = (swb_max_steps + 2 + 63) / 64 * 64;
-                FZP_TRY(B.tb.alloc((size_t)(capq * 64 + 64 * swb_cap + 64) * 2 + 128));
+                const int64_t tbw_room = (int64_t)rtot[2] * 64 + FAIL_ROOM;
+                FZP_TRY(B.tb.alloc((size_t)(capq * 64 + 64 * swb_cap + 64) + 128));
+                FZP_TRY(B.tbw.alloc((size_t)tbw_room + 64));
+                FZP_TRY(B.fail_list.alloc(FAIL_CAP));
+                FZP_TRY(B.ptot.alloc(8));
                 FZP_TRY(B.mvw.alloc((size_t)capq + 2));
                 FZP_TRY(B.raw.alloc((size_t)capq * 4 + 64));
                 {
@@ -2479,7 +2510,7 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
                 {
                     ProfScope ps(ctx, "k1_plan_dp");
                     hipLaunchKernelGGL(k_plan_final, dim3(nblk), dim3(256), 0, st, ns, (const uint32_t *)B.list.p, (const uint32_t *)B.lq_scan.p, (const uint32_t *)B.gq_scan.p,
-                                       (const uint64_t *)B.ptot.p, (const uint64_t *)(B.ptot.p + 1), B.tbo.p, B.mvo.p, B.tbs.p);
+                                       B.ptot.p, B.tbo.p, B.mvo.p, B.tbs.p);
                 }
                 // One forward DP at a time per device (g_dp_mu / g_dp_last above): a job's DP launches wait for the event the previous job recorded behind its own
                 const bool dp_chain = getenv("FZP_DP_NO_CHAIN") == nullptr;
@@ -2507,9 +2538,9 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
                                            (const uint32_t *)j->ctg_rc.p, (const int64_t *)j->ctg_woff.p, (const int64_t *)B.tbo.p, (const int64_t *)B.mvo.p, B.tb.p, B.mvw.p, B.info.p,
                                            getenv("FZP_SWB_DBG") ? atoi(getenv("FZP_SWB_DBG")) : 0, wave_log);
                     FZP_HIP(hipStreamWaitEvent(st3, j->ev_l[0], 0));
-                    hipLaunchKernelGGL(k_sw<true>, dim3(ns), dim3(64), 0, st3, ns, (const uint64_t *)B.ptot.p, (const uint32_t *)B.list.p, (const Slot *)B.slots.p,
+                    hipLaunchKernelGGL(k_sw<true>, dim3(ns), dim3(64), 0, st3, (const uint64_t *)B.ptot.p, (const uint64_t *)nullptr, ns, (const uint32_t *)B.list.p, (const Slot *)B.slots.p,
                                        (const uint32_t *)j->read_pk.p, (const uint32_t *)j->read_rc.p, (const int64_t *)j->read_woff.p, (const uint32_t *)j->ctg_pk.p, (const uint32_t *)j->ctg_rc.p,
-                                       (const int64_t *)j->ctg_woff.p, (const int64_t *)B.tbo.p, (const int64_t *)B.mvo.p, (const int32_t *)B.tbs.p, B.tb.p, B.mvw.p, P.match, P.mismatch, P.gap, B.info.p);
+                                       (const int64_t *)j->ctg_woff.p, (const int64_t *)B.tbo.p, (const int64_t *)B.mvo.p, (const int32_t *)B.tbs.p, (uint2 *)B.tbw.p, B.mvw.p, P.match, P.mismatch, P.gap, B.info.p);
                     FZP_HIP(hipEventRecord(j->ev_l[1], st3));
                     FZP_HIP(hipStreamWaitEvent(st, j->ev_l[1], 0));
                 }
@@ -2526,9 +2557,27 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
                 ProfScope ps(ctx, "k1_traceback", st2);
                 const bool tb_stats = getenv("FZP_TB_STATS") != nullptr;
                 if (tb_stats && !j->tb_stats.p) { FZP_TRY(j->tb_stats.alloc(16)); FZP_TRY(j->tb_stats.zero(16, st2)); }
-                hipLaunchKernelGGL(tb_stats ? k_tb_walk<true> : k_tb_walk<false>, dim3((ns + TBW_RPW * TBW_WPG - 1) / (TBW_RPW * TBW_WPG)), dim3(64 * TBW_WPG), 0, st2, ns, (const uint32_t *)B.list.p, (const DpInfo *)B.info.p,
-                                   (const int64_t *)B.tbo.p, (const int64_t *)B.mvo.p, (const int32_t *)B.tbs.p, (const ulonglong2 *)B.tb.p, (const ulonglong2 *)B.mvw.p, B.raw.p, B.wout.p,
-                                   (unsigned long long *)j->tb_stats.p);
+                int32_t win_half = 16;                                   // test switch: a narrower window sends paths to the fail list that the 8-byte records could follow
+                if (const char *e = getenv("FZP_TB_WINDOW")) { const int g = atoi(e); if (g >= 1 && g <= 16) win_half = g; }
+                const unsigned wg = (ns + TBW_RPW * TBW_WPG - 1) / (TBW_RPW * TBW_WPG);
+                auto kw_mid = tb_stats ? k_tb_walk<false, true> : k_tb_walk<false, false>;
+                auto kw_full = k_tb_walk<true, false>;
+                // the bit-sliced kernel's slots: 8-byte records; the others: whole masks
+                hipLaunchKernelGGL(kw_mid, dim3(wg), dim3(64 * TBW_WPG), 0, st2, (const uint32_t *)B.list.p, (const uint64_t *)nullptr, (const uint64_t *)B.ptot.p, 0u,
+                                   (const DpInfo *)B.info.p, (const int64_t *)B.tbo.p, (const int64_t *)B.mvo.p, (const int32_t *)B.tbs.p, (const void *)B.tb.p, (const ulonglong2 *)B.mvw.p, B.raw.p, B.wout.p,
+                                   (unsigned long long *)j->tb_stats.p, B.fail_list.p, B.ptot.p + 3, (uint32_t)FAIL_CAP, win_half);
+                hipLaunchKernelGGL(kw_full, dim3(wg), dim3(64 * TBW_WPG), 0, st2, (const uint32_t *)B.list.p, (const uint64_t *)B.ptot.p, (const uint64_t *)nullptr, ns,
+                                   (const DpInfo *)B.info.p, (const int64_t *)B.tbo.p, (const int64_t *)B.mvo.p, (const int32_t *)B.tbs.p, (const void *)B.tbw.p, (const ulonglong2 *)B.mvw.p, B.raw.p, B.wout.p,
+                                   (unsigned long long *)nullptr, (uint32_t *)nullptr, (uint64_t *)nullptr, 0u, 16);
+                // slots whose path left the recorded lanes (normally none: these launches find an empty list): whole masks from the wave-per-slot kernel, walked again
+                hipLaunchKernelGGL(k_fail_plan, dim3(FAIL_CAP / 256), dim3(256), 0, st2, (const uint32_t *)B.fail_list.p, (const uint64_t *)(B.ptot.p + 3), (uint32_t)FAIL_CAP, (const Slot *)B.slots.p,
+                                   (unsigned long long *)(B.ptot.p + 4), (uint64_t)((int64_t)rtot[2] * 64 + FAIL_ROOM), B.tbo.p, B.tbs.p, j->fb_overflow.p);
+                hipLaunchKernelGGL(k_sw<true>, dim3(FAIL_CAP), dim3(64), 0, st2, (const uint64_t *)nullptr, (const uint64_t *)(B.ptot.p + 3), (uint32_t)FAIL_CAP, (const uint32_t *)B.fail_list.p, (const Slot *)B.slots.p,
+                                   (const uint32_t *)j->read_pk.p, (const uint32_t *)j->read_rc.p, (const int64_t *)j->read_woff.p, (const uint32_t *)j->ctg_pk.p, (const uint32_t *)j->ctg_rc.p,
+                                   (const int64_t *)j->ctg_woff.p, (const int64_t *)B.tbo.p, (const int64_t *)B.mvo.p, (const int32_t *)B.tbs.p, (uint2 *)B.tbw.p, B.mvw.p, P.match, P.mismatch, P.gap, B.info.p);
+                hipLaunchKernelGGL(kw_full, dim3(FAIL_CAP / (TBW_RPW * TBW_WPG)), dim3(64 * TBW_WPG), 0, st2, (const uint32_t *)B.fail_list.p, (const uint64_t *)nullptr, (const uint64_t *)(B.ptot.p + 3), (uint32_t)FAIL_CAP,
+                                   (const DpInfo *)B.info.p, (const int64_t *)B.tbo.p, (const int64_t *)B.mvo.p, (const int32_t *)B.tbs.p, (const void *)B.tbw.p, (const ulonglong2 *)B.mvw.p, B.raw.p, B.wout.p,
+                                   (unsigned long long *)nullptr, (uint32_t *)nullptr, (uint64_t *)nullptr, 0u, 16);
             }
             {
                 ProfScope ps(ctx, "k1_join", st2);
@@ -2549,8 +2598,11 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
         for (int b2 = 0; b2 < 2; b2++)
             if (used[b2]) FZP_HIP(hipStreamWaitEvent(st, j->ev_tb[b2], 0));   // the main stream continues after all trace-backs
     }
+    uint32_t fbo = 0;
+    if (nr > 0) FZP_HIP(hipMemcpyAsync(&fbo, j->fb_overflow.p, 4, hipMemcpyDeviceToHost, st));
     FZP_HIP(hipStreamSynchronize(st));
     FZP_HIP(hipGetLastError());
+    if (fbo) { fzp_set_error("fzp_align_run: more than %d extension pieces (or %lld DP steps of them) per chunk needed whole trace-back masks; run with FZP_SW_NO_BITS=1", FAIL_CAP, (long long)FAIL_ROOM); return FZP_EINVAL; }
     j->summ_on_host = false;      // the batch path plans on the device; the summaries come to the host when someone asks
     j->done = true;
     return FZP_OK;

@@ -515,6 +515,37 @@ def test_terminal_on_the_border_reached_along_the_band_edge(eng, oracle, monkeyp
             monkeypatch.delenv(k)
 
 
+def test_paths_outside_the_recorded_lanes_are_computed_again(eng, oracle, monkeypatch):
+    """The bit-sliced DP records band lanes 16..47 of its masks (8 B per step); a walk that needs another lane puts its piece on the fail list, the piece is computed again
+    by the wave-per-piece kernel with whole masks and walked from those.  Real paths stay within ~12 lanes of the centre, so the test narrows what the walker accepts
+    (FZP_TB_WINDOW): with +-3 lanes most pieces come back -- same summaries, same CIGARs as the twin's; and more of them than there is room for is an error that says so."""
+    from falcon_unzip_amd import _lib
+    ctg, reads, raw = _sim(61, 400000, 50, 15000)
+    exp, exp_cig = oracle_lib.align_reads(oracle, ctg, raw, n_threads=8)
+    for mode, env in (("lane64", {"FZP_SWB_64": "1", "FZP_TB_WINDOW": "3"}), ("pair", {"FZP_SWB_PAIR": "1", "FZP_TB_WINDOW": "3"}), ("edge", {"FZP_SWB_64": "1", "FZP_TB_WINDOW": "9"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        job = _lib.align_job(eng, [ctg], raw)
+        job.run()
+        s = job.summaries()
+        aln, idx = job.alnset(0)
+        for f in FIELDS:
+            assert np.array_equal(s[f], exp[f]), (mode, f, np.flatnonzero(s[f] != exp[f])[:5])
+        for k, r in enumerate(idx):
+            assert np.array_equal(np.array([(l << 4) | o for l, o in aln.cigar_of(k)], dtype=np.uint32), exp_cig[r]), (mode, k, r)
+        job.close()
+        for k in env:
+            monkeypatch.delenv(k)
+    ctg, reads, raw = _sim(62, 1000000, 400, 15000)
+    monkeypatch.setenv("FZP_SWB_64", "1")
+    monkeypatch.setenv("FZP_TB_WINDOW", "2")
+    job = _lib.align_job(eng, [ctg], raw)
+    with pytest.raises(_lib.FzpError) as e:
+        job.run()
+    assert "FZP_SW_NO_BITS" in str(e.value)
+    job.close()
+
+
 def test_record_planning_at_deep_coverage(eng):
     """A contig with 24 000 reads (many starting in the same 256-bp bin, many at the same POS): the device's record planning (binned rank,
     fzp_align_to_batch) must order records exactly like the host's sort behind fzp_align_alnset ('samtools sort' order: POS, then read index)."""
