@@ -223,11 +223,12 @@ def cpu_baseline(contigs, blob, off, read_ctg, ids, job, hip_summ, budget_s=30.0
 
 
 def roofline(cells_per_launch, sw_avg_ms, sw_launches, dp_gcells, traffic):
-    """k1_sw, the dominant stage: the banded DP (k_swb, bit-sliced, one read per lane; k_sw, one wave per read, for long reads -- DESIGN section 5).
-    Its only bulk memory traffic is the trace-back masks it writes, 0.25 algorithmic B per cell (2 bits), so the headline fraction is the north star's:
-    algorithmic bytes per launch / the stage's duration against the HBM peak.  Beside it `valu`: wave64 VALU instructions per second (SQ_INSTS_VALU from
-    profiles/, named in `counter_source`) against the chip's issue peak, 256 CU x 4 SIMD x 2.4 GHz / 2 cycles per wave64 instruction on a SIMD-32
-    (MI355X_MICROARCH.md).  `traffic` = measured HBM bytes of the largest DP dispatch (FETCH + WRITE)."""
+    """k1_sw, the dominant stage: the banded DP of every extension piece of the step in ONE launch pair (k_swb, bit-sliced, one piece per lane; k_sw, one wave per
+    piece, for the pieces narrower than the band -- DESIGN section 5).  SURVEY 8d prices the stage at 0.25 algorithmic B per cell (the 2 trace-back bits of every
+    cell); the headline fraction is the north star's: that figure x cells per launch / the stage's duration against the HBM peak.  What the kernel really writes since
+    round 4 is HALF of it (band lanes 16..47 only, 0.125 B/cell: `bytes_per_cell_moved`), so `traffic` -- the measured HBM bytes of the largest DP dispatch
+    (FETCH + WRITE, from profiles/) -- sits below the algorithmic figure.  Beside it `valu`: wave64 VALU instructions per second (SQ_INSTS_VALU from profiles/, named in
+    `counter_source`) against the chip's issue peak, 256 CU x 4 SIMD x 2.4 GHz / 2 cycles per wave64 instruction on a SIMD-32 (MI355X_MICROARCH.md)."""
     counters = {"valu_per_step": SW_VALU_PER_STEP, "source": "(default: no profiles/k1_sw_counters.json)"}
     cf = os.path.join(REPO, "profiles", "k1_sw_counters.json")
     if os.path.exists(cf):
@@ -240,8 +241,9 @@ def roofline(cells_per_launch, sw_avg_ms, sw_launches, dp_gcells, traffic):
     gbs = cells_per_launch * SW_BYTES_PER_CELL / (sw_avg_ms * 1e-3) / 1e9 if sw_avg_ms else 0.0
     return {"bound": "hbm", "kernel": "k1_sw (k_swb + k_sw)", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
             "traffic": traffic, "avg_launch_ms": round(sw_avg_ms, 3), "launches": int(sw_launches), "bytes_per_cell": SW_BYTES_PER_CELL,
-            "note": "algorithmic 0.25 B/cell: the 2 trace-back bits of every cell, written once; at this job size the kernel runs one wave per SIMD (625 waves of 64 reads) and is "
-                    "bound by that wave's issue latency, not yet by either peak",
+            "bytes_per_cell_moved": 0.125,
+            "note": "algorithmic 0.25 B/cell (SURVEY 8d: the 2 trace-back bits of every cell); the kernel writes half of that (band lanes 16..47) and keeps every SIMD busy with one "
+                    "wave (~3 500 waves of 64 pieces on 1 024 SIMDs): it is bound by VALU issue (see `valu`), no longer by its stores",
             "valu": {"achieved": round(valu, 2), "peak": round(valu_peak, 1), "unit": "G wave64-inst/s", "frac": round(valu / valu_peak, 4),
                      "valu_insts_per_band_step": per_step, "counter_source": counters.get("source")},
             "ops_view": {"int_ops_per_cell": 12, "achieved_tlaneop": round(dp_gcells * 12 / 1e3, 2), "peak_tlaneop": round(256 * 4 * 32 * CLK_GHZ / 1e3, 2),

@@ -560,12 +560,12 @@ __global__ void __launch_bounds__(256) k_slot_count(int64_t nr, const Anchor *__
                                                     unsigned long long *__restrict__ sw_capq) {
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
     bool second = false;
-    uint32_t wq = 0;                                       // capacity / 64 of this read's slots that the wave-per-slot kernel will take (k_route's test): they keep whole masks
+    uint32_t wq = 0, wn = 0;                               // capacity / 64 and number of this read's slots that the wave-per-slot kernel will take (k_route's test): they keep whole masks
     if (r < nr) {
         uint32_t k = 0, cq = 0;
         const int32_t n = read_len[r], c = read_ctg[r];
         const int64_t Lc = ctg_len[c];
-        auto tally = [&](const Slot &sl) { k++; cq += (uint32_t)(sl.cap >> 6); if (!(use_bits && sl.nq >= 64 && sl.nt >= 64 && sl.nq + sl.nt + 2 <= swb_max_steps)) wq += (uint32_t)(sl.cap >> 6); };
+        auto tally = [&](const Slot &sl) { k++; cq += (uint32_t)(sl.cap >> 6); if (!(use_bits && sl.nq >= 64 && sl.nt >= 64 && sl.nq + sl.nt + 2 <= swb_max_steps)) { wq += (uint32_t)(sl.cap >> 6); wn++; } };
         cand_slots(anc[r], 0, n_wp[2 * r], wps + (size_t)(2 * r) * MAX_WP, (int32_t)r, n, c, Lc, tally);
         cand_slots(ancB[r], 1, n_wp[2 * r + 1], wps + (size_t)(2 * r + 1) * MAX_WP, (int32_t)r, n, c, Lc, tally);
         cnt[r] = k; capq[r] = cq;
@@ -573,8 +573,8 @@ __global__ void __launch_bounds__(256) k_slot_count(int64_t nr, const Anchor *__
     }
     const uint64_t m = __ballot(second);
     if (lane_id() == 0 && m) atomicAdd(n_sec, (uint32_t)__popcll(m));
-    const int32_t ws = wave_sum_i32_dpp((int32_t)wq);
-    if (lane_id() == 0 && ws) atomicAdd(sw_capq, (unsigned long long)(uint32_t)ws);
+    const int32_t ws = wave_sum_i32_dpp((int32_t)wq), wc = wave_sum_i32_dpp((int32_t)wn);
+    if (lane_id() == 0 && ws) { atomicAdd(sw_capq, (unsigned long long)(uint32_t)ws); atomicAdd(sw_capq + 1, (unsigned long long)(uint32_t)wc); }
 }
 __global__ void __launch_bounds__(256) k_slot_emit(int64_t r_lo, int64_t r_hi, const Anchor *__restrict__ anc, const Anchor *__restrict__ ancB, const int32_t *__restrict__ n_wp, const int2 *__restrict__ wps,
                                                    const int32_t *__restrict__ read_len, const int32_t *__restrict__ read_ctg, const int64_t *__restrict__ ctg_len,
@@ -2200,7 +2200,7 @@ struct fzp_alnjob {
     DevBuf<uint32_t> n_sec;                      // reads with a second candidate
     int64_t n_second = 0;                        // of the last run
     DevBuf<uint32_t> r_cnt, r_capq, slot_base, rcapq_scan;      // per read: slots, their capacity / 64, and the exclusive scans of both
-    DevBuf<uint64_t> rtot;                       // [0] slots of the run, [1] capacity / 64 of the run, [2] capacity / 64 of the slots the wave-per-slot kernel takes
+    DevBuf<uint64_t> rtot;                       // [0] slots of the run, [1] capacity / 64 of the run, [2] capacity / 64 and [3] number of the slots the wave-per-slot kernel takes
     DevBuf<uint32_t> fb_overflow;                // the fail list or its mask room overflowed (the run reports it)
     ChunkBufs cb[2];
     DevBuf<unsigned long long> tb_stats;         // FZP_TB_STATS (measurement aid): how often a path leaves a 32-lane window of its band, summed over the job's runs
@@ -2434,10 +2434,10 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
         FZP_TRY(fzp_exclusive_scan_u32(ctx, j->r_capq.p, j->rcapq_scan.p, (size_t)nr, j->rtot.p + 1));
         uint32_t n2 = 0;
         int32_t ovf = 0;
-        uint64_t rtot[3] = {0, 0, 0};
+        uint64_t rtot[4] = {0, 0, 0, 0};
         FZP_HIP(hipMemcpyAsync(&n2, j->n_sec.p, 4, hipMemcpyDeviceToHost, st));
         FZP_HIP(hipMemcpyAsync(&ovf, j->idx_overflow.p, 4, hipMemcpyDeviceToHost, st));
-        FZP_HIP(hipMemcpyAsync(rtot, j->rtot.p, 24, hipMemcpyDeviceToHost, st));
+        FZP_HIP(hipMemcpyAsync(rtot, j->rtot.p, 32, hipMemcpyDeviceToHost, st));
         FZP_TRY(j->slot_base.download(h_sb.data(), (size_t)nr, st));
         FZP_TRY(j->rcapq_scan.download(h_cq.data(), (size_t)nr, st));
         FZP_HIP(hipStreamSynchronize(st));
@@ -2538,7 +2538,7 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
                                            (const uint32_t *)j->ctg_rc.p, (const int64_t *)j->ctg_woff.p, (const int64_t *)B.tbo.p, (const int64_t *)B.mvo.p, B.tb.p, B.mvw.p, B.info.p,
                                            getenv("FZP_SWB_DBG") ? atoi(getenv("FZP_SWB_DBG")) : 0, wave_log);
                     FZP_HIP(hipStreamWaitEvent(st3, j->ev_l[0], 0));
-                    hipLaunchKernelGGL(k_sw<true>, dim3(ns), dim3(64), 0, st3, (const uint64_t *)B.ptot.p, (const uint64_t *)nullptr, ns, (const uint32_t *)B.list.p, (const Slot *)B.slots.p,
+                    hipLaunchKernelGGL(k_sw<true>, dim3((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(ns, rtot[3]))), dim3(64), 0, st3, (const uint64_t *)B.ptot.p, (const uint64_t *)nullptr, ns,      // (no chunk has more such slots than the run) (const uint32_t *)B.list.p, (const Slot *)B.slots.p,
                                        (const uint32_t *)j->read_pk.p, (const uint32_t *)j->read_rc.p, (const int64_t *)j->read_woff.p, (const uint32_t *)j->ctg_pk.p, (const uint32_t *)j->ctg_rc.p,
                                        (const int64_t *)j->ctg_woff.p, (const int64_t *)B.tbo.p, (const int64_t *)B.mvo.p, (const int32_t *)B.tbs.p, (uint2 *)B.tbw.p, B.mvw.p, P.match, P.mismatch, P.gap, B.info.p);
                     FZP_HIP(hipEventRecord(j->ev_l[1], st3));
