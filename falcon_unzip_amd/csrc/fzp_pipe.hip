@@ -965,6 +965,24 @@ void load_group(const std::string &dir, const char *const *ctg_id, int c0, int c
 }
 }  // namespace
 
+// test hook (tests/test_host_logic.py, CPU only): what the FASTA reader makes of <reads_dir>/<ctg>_{ref,reads}.fa of the given contigs -- one group, as fzp_phase_contigs_files
+// would hand it to fzp_align_create.  Outputs are malloc'ed (fzp_free): the contigs back to back with ref_off[n_ctg + 1], the reads with off / name offsets / contig per read.
+extern "C" int fzp_debug_load_fasta_group(const char *reads_dir, const char *const *ctg_id, int32_t n_ctg, int32_t n_threads, uint8_t **ref, int64_t **ref_off, uint8_t **blob,
+                                          int64_t **off, char **names, int64_t **name_off, int32_t **read_ctg, int64_t *n_reads) {
+    if (!reads_dir || !ctg_id || n_ctg <= 0 || !ref || !ref_off || !blob || !off || !names || !name_off || !read_ctg || !n_reads) { fzp_set_error("fzp_debug_load_fasta_group: bad arguments"); return FZP_EINVAL; }
+    GroupIn G;
+    load_group(reads_dir, ctg_id, 0, n_ctg, n_threads > 0 ? n_threads : std::min(32, usable_cores()), G);
+    if (G.rc != FZP_OK) { fzp_set_error("%s", G.err.c_str()); return G.rc; }
+    auto dup = [](const void *p, size_t bytes) { void *q = malloc(bytes ? bytes : 1); if (q && bytes) memcpy(q, p, bytes); return q; };
+    const size_t nr = G.read_ctg.size();
+    *ref = (uint8_t *)dup(G.ref.data(), (size_t)G.ref_off[(size_t)n_ctg]); *ref_off = (int64_t *)dup(G.ref_off.data(), ((size_t)n_ctg + 1) * 8);
+    *blob = (uint8_t *)dup(G.blob.data(), (size_t)G.off[nr]); *off = (int64_t *)dup(G.off.data(), (nr + 1) * 8);
+    *names = (char *)dup(G.names.data(), (size_t)G.noff[nr]); *name_off = (int64_t *)dup(G.noff.data(), (nr + 1) * 8);
+    *read_ctg = (int32_t *)dup(G.read_ctg.data(), nr * 4);
+    *n_reads = (int64_t)nr;
+    return FZP_OK;
+}
+
 extern "C" int fzp_phase_contigs_files(fzp_ctx *ctx, const char *reads_dir, const fzp_names *nm, const fzp_pipe_opts *opts, fzp_pipe_out *out) {
     if (!ctx || !reads_dir || !nm || !nm->ctg_id || nm->n_ctg <= 0 || !out) { fzp_set_error("fzp_phase_contigs_files: bad arguments"); return FZP_EINVAL; }
     fzp_pipe_opts o;

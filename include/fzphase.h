@@ -347,6 +347,9 @@ int fzp_phase_contigs(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *const *ctg_seq
  * parsed by host threads one contig group ahead of the lanes; host memory holds the groups in flight, never the whole call's reads. */
 int fzp_phase_contigs_files(fzp_ctx *ctx, const char *reads_dir, const fzp_names *names, const fzp_pipe_opts *opts, fzp_pipe_out *out);
 void fzp_pipe_out_free(fzp_pipe_out *o);
+/* test hook (CPU only): the FASTA reader's view of one contig group -- what fzp_phase_contigs_files hands to fzp_align_create; outputs malloc'ed (fzp_free) */
+int fzp_debug_load_fasta_group(const char *reads_dir, const char *const *ctg_id, int32_t n_ctg, int32_t n_threads, uint8_t **ref, int64_t **ref_off, uint8_t **blob,
+                               int64_t **off, char **names, int64_t **name_off, int32_t **read_ctg, int64_t *n_reads);
 int fzp_pipe_flush(fzp_ctx *ctx);   /* every queued file of FZP_PIPE_ASYNC_WRITES calls on this ctx (and its lanes) is on the file system when this returns */
 
 /* ---- the one exchange step of the multi-GPU path (get_rid_to_phase_all, unzip.py:303-314): every rank contributes the
