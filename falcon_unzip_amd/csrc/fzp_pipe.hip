@@ -751,14 +751,35 @@ extern "C" int fzp_phase_contigs(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *con
 // record its place in the group's buffers, the same threads copy the sequences there -- one copy, no per-file intermediates.  Groups are parsed one AHEAD of the lanes
 // that align them, and their buffers are kept with the context between calls, so what is in host memory at any time is the groups in flight -- not the rank's reads.
 #include <sched.h>
+#include <sys/mman.h>
+// a grow-only byte buffer that is neither zeroed nor copied when it grows: its pages are first touched by the threads that fill it (a std::vector's resize would
+// fill 1 GB from one thread -- 250 ms -- before sixteen threads overwrite it in 15)
+struct RawBuf {
+    uint8_t *p = nullptr;
+    size_t cap = 0;
+    RawBuf() = default;
+    RawBuf(const RawBuf &) = delete;
+    RawBuf &operator=(const RawBuf &) = delete;
+    ~RawBuf() { free(p); }
+    bool need(size_t n) {
+        if (n <= cap && p) return true;
+        free(p);
+        const size_t want = ((n + n / 8 + (2u << 20)) + ((2u << 20) - 1)) & ~(size_t)((2u << 20) - 1);      // some slack: the next group is rarely smaller
+        p = (uint8_t *)aligned_alloc(2u << 20, want);
+        cap = p ? want : 0;
+        if (p) (void)madvise(p, want, MADV_HUGEPAGE);
+        return p != nullptr;
+    }
+    uint8_t *data() { return p; }
+};
 struct GroupIn {
-    std::vector<uint8_t> raw;                    // the group's files as they are
-    std::vector<uint8_t> ref;                    // the group's contigs, one after the other
+    RawBuf raw;                                  // the group's files as they are
+    RawBuf ref;                                  // the group's contigs, one after the other
     std::vector<int64_t> ref_off;                // [gc + 1]
-    std::vector<uint8_t> blob;                   // the group's reads, contig after contig
+    RawBuf blob;                                 // the group's reads, contig after contig
     std::vector<int64_t> off, noff;
     std::vector<int32_t> read_ctg;
-    std::vector<char> names;
+    RawBuf names;
     int rc = FZP_OK;
     std::string err;
 };
@@ -885,7 +906,7 @@ void load_group(const std::string &dir, const char *const *ctg_id, int c0, int c
         mp[(size_t)t].n = (size_t)sb.st_size;
         foff[(size_t)t + 1] = foff[(size_t)t] + mp[(size_t)t].n;
     }
-    G.raw.resize(foff[(size_t)nf] + 1);
+    if (!G.raw.need(foff[(size_t)nf] + 1)) { G.rc = FZP_ENOMEM; G.err = "host memory for the group's files"; unmap_all(); return; }
     for (int t = 0; t < nf; t++) mp[(size_t)t].p = (const char *)G.raw.data() + foff[(size_t)t];
     // pieces of ~4 MB, in file order
     std::vector<FaPiece> pieces;
@@ -925,7 +946,7 @@ void load_group(const std::string &dir, const char *const *ctg_id, int c0, int c
             for (auto &R : P.recs) if ((size_t)R.name_len == want && memcmp(R.name, ctg_id[c0 + c], want) == 0) ref_rec[(size_t)c] = &R;
         }
     for (int c = 0; c < gc; c++) G.ref_off[(size_t)c + 1] = G.ref_off[(size_t)c] + (ref_rec[(size_t)c] ? ref_rec[(size_t)c]->len : 0);
-    G.ref.resize((size_t)G.ref_off[(size_t)gc] + 1);
+    if (!G.ref.need((size_t)G.ref_off[(size_t)gc] + 1)) { G.rc = FZP_ENOMEM; G.err = "host memory for the group's contigs"; return; }
     // the reads: every record of <ctg>_reads.fa, file order; a prefix sum over the pieces gives every piece its first read, base and name byte
     std::vector<int64_t> p_rec(pieces.size() + 1, 0), p_base(pieces.size() + 1, 0), p_name(pieces.size() + 1, 0);
     for (size_t k = 0; k < pieces.size(); k++) {
@@ -935,7 +956,7 @@ void load_group(const std::string &dir, const char *const *ctg_id, int c0, int c
         p_name[k + 1] = p_name[k] + (rd ? pieces[k].name_bytes : 0);
     }
     const int64_t nr = p_rec.back();
-    G.blob.resize((size_t)p_base.back() + 1); G.names.resize((size_t)p_name.back() + 1);
+    if (!G.blob.need((size_t)p_base.back() + 1) || !G.names.need((size_t)p_name.back() + 1)) { G.rc = FZP_ENOMEM; G.err = "host memory for the group's reads"; return; }
     G.off.resize((size_t)nr + 1); G.noff.resize((size_t)nr + 1); G.read_ctg.resize((size_t)nr);
     G.off[0] = 0; G.noff[0] = 0;
     t_alloc = ms_since(t_0);
@@ -1090,7 +1111,7 @@ extern "C" int fzp_phase_contigs_files(fzp_ctx *ctx, const char *reads_dir, cons
                 fzp_names gn;
                 gn.n_ctg = gc; gn.ctg_id = nm->ctg_id + Gr.c0;
                 gn.name_off = G->noff.data();
-                gn.names = G->names.data();
+                gn.names = (const char *)G->names.data();
                 std::vector<int32_t> gi;
                 for (int c = Gr.c0; c < Gr.c1; c++) gi.push_back(o.ctg_index ? o.ctg_index[c] : c);
                 rc = job_phase_write(lc, job, &gn, &o, mh, gi.data(), &po, r2p_g[g]);

@@ -1,2 +1,4 @@
 export TMPDIR=/tmp
-FZP_BENCH_BACKEND=gloo timeout 300 python3 bench.py --gpus 2 --contigs 2 --contig-len 300000 --reads-per-contig 150 --read-len 8000 --window 120000 --steps 2 --warmup 1 --no-cpu-baseline --gen-workers 1 --strong-leg-contigs 5 --strong-leg-contig-len 200000 2>&1 | grep -v "^{" | grep -B2 -A12 "Traceback" | head -60 | cut -c1-300
+FZP_PIPE_TIMING=1 timeout 600 python3 tools/run_cfg5.py --from-files > gpurun_out/r4s_cfg5_files.json 2> gpurun_out/r4s_cfg5_files.err; grep "load_group\|phase_contigs_files" gpurun_out/r4s_cfg5_files.err | tail -6
+FZP_PIPE_TIMING=1 timeout 600 python3 bench.py --no-cpu-baseline --no-shaped-leg > gpurun_out/r4k_bench.json 2> gpurun_out/r4k_bench.err; grep "phase_contigs_files\|load_group" gpurun_out/r4k_bench.err | tail -3
+timeout 300 python3 -m pytest -m gpu -x -q tests/test_gpu_ranks.py -k "files_entry or two_ranks" 2>&1 | tail -2
