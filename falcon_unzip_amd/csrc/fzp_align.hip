@@ -2447,10 +2447,10 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
         FZP_HIP(hipMemcpyAsync(j->slot_base.p + nr, &h_sb[(size_t)nr], 4, hipMemcpyHostToDevice, st));
         FZP_HIP(hipMemcpyAsync(j->rcapq_scan.p + nr, &h_cq[(size_t)nr], 4, hipMemcpyHostToDevice, st));
         j->n_second = n2;
-        // Trace-back masks live in HBM (16 B per DP step).  Reads go through in chunks: the DP of chunk k+1 runs on `stream` while the trace-back of chunk k
+        // Trace-back masks live in HBM (8 B per DP step).  Reads go through in chunks: the DP of chunk k+1 runs on `stream` while the trace-back of chunk k
         // runs on `stream2`; two sets of buffers alternate.
-        int64_t budget_steps = (int64_t)48 << 30 >> 4;   // 48 GiB of 16-byte steps over both buffers
-        if (const char *e = getenv("FZP_TB_BUDGET_GB")) { long g = atol(e); if (g > 0) budget_steps = ((int64_t)g << 30) >> 4; }
+        int64_t budget_steps = (int64_t)48 << 30 >> 3;   // 48 GiB of 8-byte steps over both buffers
+        if (const char *e = getenv("FZP_TB_BUDGET_GB")) { long g = atol(e); if (g > 0) budget_steps = ((int64_t)g << 30) >> 3; }
         int n_chunks = 1;
         if (const char *e = getenv("FZP_SW_CHUNKS")) { int g = atoi(e); if (g > 0) n_chunks = g; }
         const int64_t total_steps = (int64_t)rtot[1] * 64;

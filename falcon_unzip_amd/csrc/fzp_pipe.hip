@@ -605,7 +605,7 @@ extern "C" int fzp_phase_contigs(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *con
     std::vector<std::vector<int64_t>> ctg_reads((size_t)n_ctg);
     std::vector<int64_t> bases((size_t)n_ctg, 0);
     for (int64_t r = 0; r < n_reads; r++) { ctg_reads[(size_t)read_ctg[r]].push_back(r); bases[(size_t)read_ctg[r]] += read_off[r + 1] - read_off[r]; }
-    // groups of consecutive contigs: trace-back masks cost ~36 B per read base (16 B per DP step, ~2.25 steps per base)
+    // groups of consecutive contigs: trace-back masks cost ~18 B per read base (8 B per DP step, ~2.25 steps per base), everything else of K1 about as much again
     int64_t group_bases = o.group_bases;
     if (group_bases <= 0) {
         size_t fr = 0, tot = 0;

@@ -325,7 +325,7 @@ typedef struct {
     const int32_t *ctg_index;      /* [n_ctg] contig index stored in the rid_to_phase records (the job-wide sorted contig list); NULL = 0..n-1 */
     int32_t n_threads;             /* host threads for the small files and the writes; 0 = all cores */
     int32_t n_lanes;               /* fzp_phase_contigs: contig groups in flight (each lane = a host thread with its own ctx); 0 = 2 */
-    int64_t group_bases;           /* fzp_phase_contigs: read bases per contig group; 0 = from the device memory (trace-back masks ~36 B per read base) */
+    int64_t group_bases;           /* fzp_phase_contigs: read bases per contig group; 0 = from the device memory (~40 B of HBM per read base in flight) */
     unsigned flags;                /* FZP_PIPE_* */
     fzp_align_params align;        /* fzp_phase_contigs: aligner parameters */
 } fzp_pipe_opts;
