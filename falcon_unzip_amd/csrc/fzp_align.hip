@@ -2207,6 +2207,7 @@ struct fzp_alnjob {
     DevBuf<uint64_t> wave_log;                   // FZP_SWB_WAVE_LOG (measurement aid): per k_swb workgroup of the last chunk {start, end, hardware id, steps}
     int64_t wave_log_n = 0;
     bool summ_on_host = false;
+    bool whole_masks_only = false;               // the second attempt of a run whose fail list overflowed: no bit-sliced kernel, whole masks for every piece
     // record planning: reads grouped by contig (input order inside a contig); built on first use
     DevBuf<int32_t> slot_read, slot_ctg;
     DevBuf<int64_t> slot_off;
@@ -2412,7 +2413,7 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
             }
         }
         // ---- which DP kernel runs which slot (fzalign scores 2 / -4 / -3 are built into the bit-sliced one's cell function)
-        const bool use_bits = getenv("FZP_SW_NO_BITS") == nullptr && P.match == 2 && P.mismatch == 4 && P.gap == 3;
+        const bool use_bits = getenv("FZP_SW_NO_BITS") == nullptr && P.match == 2 && P.mismatch == 4 && P.gap == 3 && !j->whole_masks_only;
         // the bit-sliced kernel has two forms.  A pair of lanes per slot (k_swb2) has the shorter step but twice the waves, and its instruction mix issues at ~4.5 cycles per
         // SIMD however many waves share it: two such waves on one SIMD run at half speed each.  So it is taken when its waves get a SIMD each; else the whole band sits in one
         // lane (k_swb).  FZP_SWB_64 / FZP_SWB_PAIR force one.
@@ -2602,7 +2603,14 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
     if (nr > 0) FZP_HIP(hipMemcpyAsync(&fbo, j->fb_overflow.p, 4, hipMemcpyDeviceToHost, st));
     FZP_HIP(hipStreamSynchronize(st));
     FZP_HIP(hipGetLastError());
-    if (fbo) { fzp_set_error("fzp_align_run: more than %d extension pieces (or %lld DP steps of them) per chunk needed whole trace-back masks; run with FZP_SW_NO_BITS=1", FAIL_CAP, (long long)FAIL_ROOM); return FZP_EINVAL; }
+    if (fbo) {      // more pieces needed whole trace-back masks than there was room for (FAIL_CAP pieces / FAIL_ROOM steps per chunk): the run again, every piece through the wave-per-piece kernel
+        if (j->whole_masks_only) { fzp_set_error("fzp_align_run: the fail list overflowed although nothing is on it in this mode"); return FZP_EINVAL; }
+        if (getenv("FZP_TB_NO_RETRY")) { fzp_set_error("fzp_align_run: more than %d extension pieces (or %lld DP steps of them) per chunk needed whole trace-back masks (FZP_TB_NO_RETRY)", FAIL_CAP, (long long)FAIL_ROOM); return FZP_EINVAL; }
+        j->whole_masks_only = true;
+        const int rc = fzp_align_run(ctx, j);
+        j->whole_masks_only = false;
+        return rc;
+    }
     j->summ_on_host = false;      // the batch path plans on the device; the summaries come to the host when someone asks
     j->done = true;
     return FZP_OK;

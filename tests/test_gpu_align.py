@@ -518,7 +518,7 @@ def test_terminal_on_the_border_reached_along_the_band_edge(eng, oracle, monkeyp
 def test_paths_outside_the_recorded_lanes_are_computed_again(eng, oracle, monkeypatch):
     """The bit-sliced DP records band lanes 16..47 of its masks (8 B per step); a walk that needs another lane puts its piece on the fail list, the piece is computed again
     by the wave-per-piece kernel with whole masks and walked from those.  Real paths stay within ~12 lanes of the centre, so the test narrows what the walker accepts
-    (FZP_TB_WINDOW): with +-3 lanes most pieces come back -- same summaries, same CIGARs as the twin's; and more of them than there is room for is an error that says so."""
+    (FZP_TB_WINDOW): with +-3 lanes most pieces come back -- same summaries, same CIGARs as the twin's; more of them than there is room for and the run is done again with whole masks throughout."""
     from falcon_unzip_amd import _lib
     ctg, reads, raw = _sim(61, 400000, 50, 15000)
     exp, exp_cig = oracle_lib.align_reads(oracle, ctg, raw, n_threads=8)
@@ -536,13 +536,20 @@ def test_paths_outside_the_recorded_lanes_are_computed_again(eng, oracle, monkey
         job.close()
         for k in env:
             monkeypatch.delenv(k)
+    # more of them than there is room for: the run is done again with whole masks for every piece (or, with FZP_TB_NO_RETRY, refused with a message)
     ctg, reads, raw = _sim(62, 1000000, 400, 15000)
+    exp, _ = oracle_lib.align_reads(oracle, ctg, raw, n_threads=8)
     monkeypatch.setenv("FZP_SWB_64", "1")
     monkeypatch.setenv("FZP_TB_WINDOW", "2")
     job = _lib.align_job(eng, [ctg], raw)
+    job.run()
+    s = job.summaries()
+    for f in FIELDS:
+        assert np.array_equal(s[f], exp[f]), ("retry", f)
+    monkeypatch.setenv("FZP_TB_NO_RETRY", "1")
     with pytest.raises(_lib.FzpError) as e:
         job.run()
-    assert "FZP_SW_NO_BITS" in str(e.value)
+    assert "whole trace-back masks" in str(e.value)
     job.close()
 
 
