@@ -235,12 +235,18 @@ def roofline(cells_per_launch, sw_avg_ms, sw_launches, dp_gcells, traffic):
         with open(cf) as f:
             counters = json.load(f)
     per_step = float(counters["valu_per_step"])
+    # the committed counter files belong to a particular kernel and workload: say so when this run no longer looks like the one they were taken on
+    stale = []
+    if counters.get("band_steps_per_bench_step") and abs(counters["band_steps_per_bench_step"] * 64.0 / max(cells_per_launch, 1.0) - 1.0) > 0.02:
+        stale.append("counters: %.4g band steps per launch when they were taken, %.4g now" % (counters["band_steps_per_bench_step"], cells_per_launch / 64.0))
+    if traffic and abs(traffic / max(cells_per_launch * 0.125, 1.0) - 1.0) > 0.25:
+        stale.append("traffic: %.3g B per launch on file, %.3g B of mask records planned by this run" % (traffic, cells_per_launch * 0.125))
     steps_per_s = dp_gcells * 1e9 / 64.0
     valu = steps_per_s * per_step / 1e9
     valu_peak = N_SIMD * CLK_GHZ / 2.0
     gbs = cells_per_launch * SW_BYTES_PER_CELL / (sw_avg_ms * 1e-3) / 1e9 if sw_avg_ms else 0.0
     return {"bound": "hbm", "kernel": "k1_sw (k_swb + k_sw)", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-            "traffic": traffic, "avg_launch_ms": round(sw_avg_ms, 3), "launches": int(sw_launches), "bytes_per_cell": SW_BYTES_PER_CELL,
+            "traffic": traffic, "profile_files_stale": stale or None, "avg_launch_ms": round(sw_avg_ms, 3), "launches": int(sw_launches), "bytes_per_cell": SW_BYTES_PER_CELL,
             "bytes_per_cell_moved": 0.125,
             "note": "algorithmic 0.25 B/cell (SURVEY 8d: the 2 trace-back bits of every cell); the kernel writes half of that (band lanes 16..47) and keeps every SIMD busy with one "
                     "wave (~3 500 waves of 64 pieces on 1 024 SIMDs): it is bound by VALU issue (see `valu`), no longer by its stores",
