@@ -232,3 +232,21 @@ def test_fasta_reader_equals_the_python_reader_on_hostile_files(lib, tmp_path):
     with pytest.raises(lib.FzpError) as e:
         _load_group(lib, str(d), ids + ["999999F"])
     assert "999999F" in str(e.value)
+
+
+def test_rid_to_phase_all_formatter(lib):
+    """fzp_format_rid_to_phase_all == the rows phasing_readmap.py:47-51 prints ('%09d ctg block phase'), in the order given; a record of an unknown contig is an error"""
+    rng = np.random.Generator(np.random.PCG64(5))
+    n = 5000
+    recs = np.zeros(n, lib.R2P)
+    recs["arid"] = rng.integers(0, 10**9, n)
+    recs["ctg"] = np.sort(rng.integers(0, 3, n))
+    recs["block"] = rng.integers(-1, 40, n)
+    recs["phase"] = rng.integers(0, 2, n)
+    ids = ["000000F", "000001F_long_name", "x"]
+    exp = "".join("%09d %s %d %d\n" % (r["arid"], ids[r["ctg"]], r["block"], r["phase"]) for r in recs).encode()
+    assert lib.format_rid_to_phase_all(recs, ids) == exp
+    assert lib.format_rid_to_phase_all(recs[:0], ids) == b""
+    recs["ctg"][7] = 3
+    with pytest.raises(lib.FzpError):
+        lib.format_rid_to_phase_all(recs, ids)
