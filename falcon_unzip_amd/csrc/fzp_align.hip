@@ -429,7 +429,7 @@ __device__ __forceinline__ int32_t wave_max_nonneg_dpp(int32_t v) {
 // after the waypoint before it becomes one, and says so in wpp[] (list index of the waypoint before it) -- so the longest chain's waypoints are a walk
 // of a few links from its last one.
 __global__ void __launch_bounds__(64) k_chain(int64_t first, int64_t count, const int32_t *__restrict__ read_len, const uint2 *__restrict__ hits_g,
-                                              const SeedWin *__restrict__ win, Anchor *__restrict__ anc, Anchor *__restrict__ ancB, int32_t *__restrict__ wpp_g,
+                                              const SeedWin *__restrict__ win, Anchor *__restrict__ anc, Anchor *__restrict__ ancB, int16_t *__restrict__ wpp_g,
                                               int32_t *__restrict__ n_wp, int2 *__restrict__ wps) {
     const int64_t wv = blockIdx.x;
     if (wv >= 2 * count) return;
@@ -446,7 +446,7 @@ __global__ void __launch_bounds__(64) k_chain(int64_t first, int64_t count, cons
     const int ext = n >> 14;      // a long read's diagonal drifts (CLR reads carry more inserted than deleted bases): its window widens by a bin per 16 384 bases
     const int ws = which ? sw.s2 : sw.s1, wb = which ? sw.b2 : sw.b1, shift = sw.shift;
     const uint2 *hits = hits_g + (size_t)slot * HIT_CAP;
-    int32_t *wpp = wpp_g + (size_t)slot * HIT_CAP;
+    int16_t *wpp = wpp_g + ((size_t)slot * 2 + (size_t)which) * HIT_CAP;      // (a list of its own per window: the two windows of a read may share hits, and their waves run side by side)
     const int32_t nh = sw.n_hits;
     int32_t ri = 0, rcp = 0, rd = 0, rf = 0, rst = 0, rwp = 0, rwi = 0;      // ring: lane L holds window hit number e with e % 64 == L
     int32_t e = 0, best_f = 0, best_st = -1, best_wp = -1;
@@ -485,7 +485,7 @@ __global__ void __launch_bounds__(64) k_chain(int64_t first, int64_t count, cons
                 const int32_t pw = __builtin_amdgcn_readlane(rwp, src), pi = __builtin_amdgcn_readlane(rwi, src);
                 if (i - pi >= piece) wprev = pw; else { wp = pw; wi = pi; }
             }
-            if (wp == h && lane == 0) wpp[h] = wprev;           // this hit is a waypoint of its chain: the one before it (-1: it starts the chain)
+            if (wp == h && lane == 0) wpp[h] = (int16_t)wprev;  // this hit is a waypoint of its chain: the one before it (-1: it starts the chain)
             if (lane == (e & 63)) { ri = i; rcp = cp; rd = d; rf = f; rst = st; rwp = wp; rwi = wi; }
             if (f > best_f) { best_f = f; best_st = st; best_wp = wp; }
             e++;
@@ -2193,7 +2193,8 @@ struct fzp_alnjob {
     std::vector<int64_t> h_part_off;
     int64_t n_parts = 0;
     DevBuf<Anchor> anc, ancB;                    // first / second candidate per read
-    DevBuf<int32_t> n_wp, wpp;                   // waypoints per (read, candidate); seeding scratch: per hit of a seeding launch, the waypoint before it
+    DevBuf<int32_t> n_wp;                        // waypoints per (read, candidate)
+    DevBuf<int16_t> wpp;                         // seeding scratch: per (read, window, hit) of a seeding launch, the waypoint before it
     DevBuf<int2> wps;                            // the waypoints (oriented read offset, contig position), MAX_WP per (read, candidate)
     DevBuf<uint2> hits;                          // seeding: HIT_CAP hit slots per read of a seeding launch
     DevBuf<SeedWin> win;
@@ -2403,7 +2404,7 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
             FZP_HIP(hipMemsetAsync(j->n_sec.p, 0, 4, st));
             const int64_t seed_chunk = 65536;            // reads per seeding launch: HIT_CAP x 12 B of hit list and waypoint links each (3 GiB)
             FZP_TRY(j->hits.alloc((size_t)std::min<int64_t>(nr, seed_chunk) * HIT_CAP));
-            FZP_TRY(j->wpp.alloc((size_t)std::min<int64_t>(nr, seed_chunk) * HIT_CAP));
+            FZP_TRY(j->wpp.alloc((size_t)std::min<int64_t>(nr, seed_chunk) * 2 * HIT_CAP));
             FZP_TRY(j->win.alloc((size_t)std::min<int64_t>(nr, seed_chunk)));
             for (int64_t f0 = 0; f0 < nr; f0 += seed_chunk) {
                 const int64_t cn = std::min<int64_t>(seed_chunk, nr - f0);

@@ -297,6 +297,29 @@ def test_second_candidate_can_win(eng, oracle):
     job.close()
 
 
+def test_second_window_next_to_the_first(eng, oracle):
+    """Reads that skip 3-4 vote bins of the contig half way (a deletion of 3.3-4.6 kb): the second window lies on the same strand right next to the first, the two windows
+    share hits, and both chains hand out waypoints -- each window's chain must keep its own waypoint links (their waves run side by side).  HIP == twin on every field."""
+    from falcon_unzip_amd import _lib, sim
+    rng = np.random.Generator(np.random.PCG64(93))
+    L = 400000
+    hap0 = rng.integers(0, 4, size=L, dtype=np.uint8)
+    ctg = sim.codes_to_str(hap0).encode()
+    raw = []
+    for k in range(160):
+        s0 = int(rng.integers(0, L - 40000))
+        gap = 3300 + 10 * k
+        a = int(rng.integers(5000, 12000))
+        tpl = np.concatenate((hap0[s0:s0 + a], hap0[s0 + a + gap:s0 + a + gap + int(rng.integers(5000, 12000))]))
+        seq, _, _ = sim.simulate_read(tpl, tpl, 0, len(tpl), rng)
+        raw.append(sim.codes_to_str(sim.revcomp_codes(seq) if k % 2 else seq).encode())
+    job = _lib.align_job(eng, [ctg], raw)
+    job.run()
+    got, _ = _cmp_twin(job, oracle, ctg, raw)
+    assert job.n_second() >= 100 and got["aligned"].all()
+    job.close()
+
+
 def test_identity_gate(eng, oracle):
     """--minPctIdentity 70 (unzip.py:87): a read at ~60 % identity is dropped by the gate and kept without it; n_match is exact."""
     from falcon_unzip_amd import _lib, sim
