@@ -2539,12 +2539,12 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
                                            (const Slot *)B.slots.p, (const uint32_t *)j->read_pk.p, (const uint32_t *)j->read_rc.p, (const int64_t *)j->read_woff.p, (const uint32_t *)j->ctg_pk.p,
                                            (const uint32_t *)j->ctg_rc.p, (const int64_t *)j->ctg_woff.p, (const int64_t *)B.tbo.p, (const int64_t *)B.mvo.p, B.tb.p, B.mvw.p, B.info.p,
                                            getenv("FZP_SWB_DBG") ? atoi(getenv("FZP_SWB_DBG")) : 0, wave_log);
-                    FZP_HIP(hipStreamWaitEvent(st3, j->ev_l[0], 0));
-                    hipLaunchKernelGGL(k_sw<true>, dim3((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(ns, rtot[3]))), dim3(64), 0, st3, (const uint64_t *)B.ptot.p, (const uint64_t *)nullptr, ns, /* (no chunk has more such slots than the run) */ (const uint32_t *)B.list.p, (const Slot *)B.slots.p,
+                    hipStream_t st_sw = getenv("FZP_SW_SERIAL") ? st : st3;      // (comparison switch: the wave-per-piece kernel behind the bit-sliced one instead of beside it)
+                    if (st_sw == st3) FZP_HIP(hipStreamWaitEvent(st3, j->ev_l[0], 0));
+                    hipLaunchKernelGGL(k_sw<true>, dim3((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(ns, rtot[3]))), dim3(64), 0, st_sw, (const uint64_t *)B.ptot.p, (const uint64_t *)nullptr, ns, /* (no chunk has more such slots than the run) */ (const uint32_t *)B.list.p, (const Slot *)B.slots.p,
                                        (const uint32_t *)j->read_pk.p, (const uint32_t *)j->read_rc.p, (const int64_t *)j->read_woff.p, (const uint32_t *)j->ctg_pk.p, (const uint32_t *)j->ctg_rc.p,
                                        (const int64_t *)j->ctg_woff.p, (const int64_t *)B.tbo.p, (const int64_t *)B.mvo.p, (const int32_t *)B.tbs.p, (uint2 *)B.tbw.p, B.mvw.p, P.match, P.mismatch, P.gap, B.info.p);
-                    FZP_HIP(hipEventRecord(j->ev_l[1], st3));
-                    FZP_HIP(hipStreamWaitEvent(st, j->ev_l[1], 0));
+                    if (st_sw == st3) { FZP_HIP(hipEventRecord(j->ev_l[1], st3)); FZP_HIP(hipStreamWaitEvent(st, j->ev_l[1], 0)); }
                 }
                 if (dp_chain) {
                     hipEvent_t &e = g_dp_last[ctx->device];
