@@ -114,7 +114,7 @@ constexpr int HIT_CAP = 4096;       // spec: hits of a read beyond the first HIT
 constexpr int CHAIN_MAX_GAP = 2048;
 constexpr int BRIDGE_MAX_GAP = 4096;   // v1.6: a chain may cross a seedless stretch of up to this many read bases (looser diagonal tolerance) ...
 constexpr int BRIDGE_COST = 4;         // ... for the price of this many hits
-constexpr int LONG_READ = 8192;         // v1.6: reads of at least this many bases are sampled at twice the stride
+constexpr int LONG_READ = 8192, LONG_STRIDE = 3;      // v1.6: reads of at least LONG_READ bases are sampled at LONG_STRIDE times the stride
 constexpr int PIECE_LEN = 3072;        // v1.6: read bases between waypoints (at least)
 constexpr int MAX_WP = 31;             // waypoints per candidate: a read has at most 2 x (MAX_WP + 1) = 64 slots, one per lane of k_join
 __host__ __device__ __forceinline__ int32_t piece_len(int64_t n) { const int64_t p = (n + MAX_WP - 2) / (MAX_WP - 1); return (int32_t)(p > PIECE_LEN ? p : PIECE_LEN); }
@@ -302,7 +302,7 @@ __global__ void __launch_bounds__(256) k_seed(int64_t first, const uint32_t *__r
     uint2 *hits = hits_g + (size_t)blockIdx.x * HIT_CAP;   // (strand << 31 | oriented offset, contig position), spec order
     for (int i = threadIdx.x; i < 2 * NB; i += 256) votes[i] = 0;
     __syncthreads();
-    if (n >= LONG_READ) stride *= 2;          // v1.6: a long read has seeds to spare (a short one needs all of them)
+    if (n >= LONG_READ) stride *= LONG_STRIDE;  // v1.6: a long read has seeds to spare (a short one needs all of them)
     const int64_t ns = (n - k) / stride + 1;   // sampled FORWARD read offsets 0, stride, ...
     uint32_t n_hits = 0;                       // block-uniform
     const int lane = lane_id(), wid = threadIdx.x >> 6;

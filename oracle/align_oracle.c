@@ -18,7 +18,7 @@
  *             the k-mer and its reverse complement) of every 2nd contig position -> EVERY such position
  *             (+ whether the canonical form was the reverse complement).  A k-mer with more than MAX_OCC = 8
  *             index entries is repetitive and never produces a hit.
- *   hits      every `stride`-th FORWARD read k-mer (a "sample"; v1.6: every 2 x `stride`-th of a read of 8 192 bases or more -- a long read has
+ *   hits      every `stride`-th FORWARD read k-mer (a "sample"; v1.6: every 3 x `stride`-th of a read of 8 192 bases or more -- a long read has
  *             seeds to spare, a short one needs all of them) is looked up once, samples in read order; each index
  *             entry of it, by increasing contig position, is a hit: equal orientation bits -> the read matches as
  *             sequenced (strand 0, oriented offset i = pf), different -> its reverse complement does
@@ -99,7 +99,8 @@ typedef struct {
 #define CHAIN_MAX_GAP 2048
 #define BRIDGE_MAX_GAP 4096 /* v1.6: a chain may cross a seedless stretch of up to this many read bases ... */
 #define BRIDGE_COST 4       /* ... for the price of this many hits */
-#define LONG_READ 8192      /* v1.6: reads of at least this many bases are sampled at twice the stride */
+#define LONG_READ 8192      /* v1.6: reads of at least this many bases are sampled at LONG_STRIDE times the stride */
+#define LONG_STRIDE 3
 #define PIECE_LEN 3072      /* v1.6: read bases between waypoints (at least) */
 #define MAX_WP 31           /* waypoints per candidate (the device joins a read's pieces one per lane: 2 x 32 slots) */
 
@@ -174,7 +175,7 @@ static void scratch_release(void) {
 }
 
 static int seed_candidates(const ctg_index *ix, const uint8_t *fwd, int64_t n, const orc_align_params *P, anchor_t *cand) {
-    const int k = P->kmer, stride = P->seed_stride * (n >= LONG_READ ? 2 : 1);      /* v1.6: a long read has seeds to spare */
+    const int k = P->kmer, stride = P->seed_stride * (n >= LONG_READ ? LONG_STRIDE : 1);      /* v1.6: a long read has seeds to spare */
     const int64_t Lc = ix->len;
     int shift = 10;
     while ((((Lc + n) >> shift) + 2) > 8192) shift++;
