@@ -576,6 +576,70 @@ def test_paths_outside_the_recorded_lanes_are_computed_again(eng, oracle, monkey
     job.close()
 
 
+@pytest.mark.parametrize("seed", [201, 202])
+def test_randomized_reads_of_every_kind_match_the_twin(eng, oracle, seed, monkeypatch):
+    """A wide draw against a contig with repeats: read lengths log-uniform over 100 .. 120 000 bases (from fewer than one band width to 30 pieces), clean / CLR / bursty /
+    far diverged error profiles, both strands, reads hanging over either contig end, chimeras of two loci, junk, N's and lower case in reads and contig, duplicates -- every
+    summary field and every CIGAR equal to the twin's; the second seed also with the reads cut into chunks (several plans, fail lists, joins per run)."""
+    from falcon_unzip_amd import _lib, sim
+    rng = np.random.Generator(np.random.PCG64(seed))
+    L = 600000
+    hap0, hap1, _, spans = sim.make_repeat_diploid(L, rng, n_families=12, n_tandem=12)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    ctg_b = bytearray(acgt[hap0].tobytes())
+    for x in rng.integers(0, L, 40):                       # a few N's and a lower-case stretch in the contig
+        ctg_b[x] = ord("N")
+    ctg_b[5000:9000] = bytes(ctg_b[5000:9000]).lower()
+    ctg = bytes(ctg_b)
+    raw = []
+    n_reads = 700
+    for k in range(n_reads):
+        n = int(np.exp(rng.uniform(np.log(100), np.log(120000 if k % 9 == 0 else 30000))))
+        kind = k % 7
+        s0 = int(rng.integers(0, max(1, L - n)))
+        if kind == 5:                                       # hangs over an end of the contig
+            s0 = 0 if k % 2 else max(0, L - n)
+        tpl = hap0[s0:s0 + n] if k % 2 else hap1[s0:s0 + n]
+        if kind == 0:
+            seq = tpl.copy()                                # error-free
+        elif kind == 4:
+            seq, _, _ = sim.simulate_read(tpl, tpl, 0, len(tpl), rng, sub=0.10, ins=0.12, dele=0.08)        # far diverged (around the identity gate)
+        else:
+            seq, _, _ = sim.simulate_read(tpl, tpl, 0, len(tpl), rng)
+        if kind == 3 and len(seq) > 2000:                   # a burst of noise in the middle
+            b0 = int(rng.integers(0, len(seq) - 1000)); bl = int(rng.integers(200, 1000))
+            seq = np.concatenate((seq[:b0], rng.integers(0, 4, bl, dtype=np.uint8), seq[b0 + bl // 2:]))
+        if kind == 6 and len(seq) > 4000:                   # a chimera: the second half from elsewhere
+            s1 = int(rng.integers(0, L - len(seq)))
+            other, _, _ = sim.simulate_read(hap0[s1:s1 + len(seq) // 2], hap0[s1:s1 + len(seq) // 2], 0, len(seq) // 2, rng)
+            seq = np.concatenate((seq[:len(seq) // 2], other))
+        if kind == 5 and n > 500:                           # bases beyond the contig's end
+            ext = rng.integers(0, 4, int(rng.integers(50, 400)), dtype=np.uint8)
+            seq = np.concatenate((ext, seq)) if k % 2 else np.concatenate((seq, ext))
+        if k % 3 == 0:
+            seq = sim.revcomp_codes(seq)
+        b = bytearray(acgt[seq].tobytes())
+        if k % 11 == 0 and len(b) > 50:
+            for x in rng.integers(0, len(b), 5):
+                b[x] = ord("N")
+            b[10:40] = bytes(b[10:40]).lower()
+        raw.append(bytes(b))
+    raw += [bytes(rng.choice(acgt, size=5000)), raw[3], raw[3], b"ACGT" * 3, b""]      # junk, duplicates, a read shorter than a seed, an empty one
+    if seed == 202:
+        monkeypatch.setenv("FZP_SW_CHUNKS", "5")
+    exp, exp_cig = oracle_lib.align_reads(oracle, ctg, raw, n_threads=8)
+    job = _lib.align_job(eng, [ctg], raw)
+    job.run()
+    got = job.summaries()
+    for f in FIELDS:
+        assert np.array_equal(got[f], exp[f]), (f, np.flatnonzero(got[f] != exp[f])[:8])
+    aln, idx = job.alnset(0)
+    for k, r in enumerate(idx):
+        assert np.array_equal(np.array([(l << 4) | o for l, o in aln.cigar_of(k)], dtype=np.uint32), exp_cig[r]), (k, r)
+    assert got["aligned"].mean() > 0.5 and got["aligned"][-5] == 0 and got["aligned"][-1] == 0 and got["aligned"][-2] == 0      # (a third of the draw is too short, too diverged or junk)
+    job.close()
+
+
 def test_record_planning_at_deep_coverage(eng):
     """A contig with 24 000 reads (many starting in the same 256-bp bin, many at the same POS): the device's record planning (binned rank,
     fzp_align_to_batch) must order records exactly like the host's sort behind fzp_align_alnset ('samtools sort' order: POS, then read index)."""
