@@ -2453,6 +2453,7 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
         // runs on `stream2`; two sets of buffers alternate.
         int64_t budget_steps = (int64_t)48 << 30 >> 3;   // 48 GiB of 8-byte steps over both buffers
         if (const char *e = getenv("FZP_TB_BUDGET_GB")) { long g = atol(e); if (g > 0) budget_steps = ((int64_t)g << 30) >> 3; }
+        if (!use_bits) budget_steps /= 2;               // every piece keeps whole masks: 16 B per step
         int n_chunks = 1;
         if (const char *e = getenv("FZP_SW_CHUNKS")) { int g = atoi(e); if (g > 0) n_chunks = g; }
         const int64_t total_steps = (int64_t)rtot[1] * 64;
