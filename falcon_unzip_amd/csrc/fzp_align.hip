@@ -1540,7 +1540,7 @@ __global__ void __launch_bounds__(64 * TBW_WPG) k_tb_walk(const uint32_t *__rest
         const uint8_t *win = mine;
         if (STATS && active) { const int32_t e2 = (int32_t)(mvr[ts >> 6].y >> 32); st_centre = min(max(32 + e2 / 3, 16), 48); }      // score(lane 63) - score(lane 0) = 2 E2 ~ 6 x (path's lane - 31.5)
         while (active && (ts >> 6) == cur_chunk && (FULL ? (uint32_t)(k - sh_cur) < 32u : (uint32_t)(k - wlo) < wn)) {
-            if (STATS) { st_steps++; st_fixed += (uint32_t)(k - 16) >= 32u ? 1u : 0u; st_adapt += (uint32_t)(k - (st_centre - 16)) >= 32u ? 1u : 0u; st_maxdev = max(st_maxdev, (uint32_t)abs(k - st_centre)); }
+            if (STATS) { st_steps++; st_fixed += (uint32_t)(k - 16) >= 32u ? 1u : 0u; st_adapt += (uint32_t)(k - (st_centre - 16)) >= 32u ? 1u : 0u; st_maxdev = max(st_maxdev, (uint32_t)(k >= 32 ? k - 32 : 31 - k)); }
             const uint2 m = *(const uint2 *)(win + (ts & 63) * 8);
             const uint32_t kk = (uint32_t)(k - sh_cur);
             const uint32_t db = (m.x >> kk) & 1u, gb = (m.y >> kk) & 1u;
@@ -1569,7 +1569,7 @@ __global__ void __launch_bounds__(64 * TBW_WPG) k_tb_walk(const uint32_t *__rest
     if (STATS && walked && rstride == 4096) {      // (the bit-sliced kernel's slots: the ones whose move words carry E2)
         atomicAdd(&stats[0], 1ull); atomicAdd(&stats[1], st_fixed ? 1ull : 0ull); atomicAdd(&stats[2], st_adapt ? 1ull : 0ull);
         atomicAdd(&stats[3], (unsigned long long)st_steps); atomicAdd(&stats[4], (unsigned long long)st_fixed); atomicAdd(&stats[5], (unsigned long long)st_adapt);
-        atomicAdd(&stats[6 + min(st_maxdev >> 2, 9u)], 1ull);      // slots by their largest distance from the estimated centre, in fours
+        atomicAdd(&stats[6 + min(st_maxdev >> 1, 9u)], 1ull);      // slots by their largest distance from the band's centre (lanes 31 | 32), in twos
     }
     if (!FULL && failed) {
         const uint32_t f = (uint32_t)atomicAdd((unsigned long long *)n_fail, 1ull);

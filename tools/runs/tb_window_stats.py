@@ -28,5 +28,5 @@ for tag, gen in (("cfg2 (15 kb reads, 13 % error)", None), ("reads of real shape
     print("  pieces walked %d, steps %d" % (st[0], st[3]))
     print("  fixed window 16..47   : %.4f %% of the pieces leave it (%.5f %% of the steps)" % (100 * st[1] / st[0], 100 * st[4] / st[3]))
     print("  window around 32+E2/3 : %.4f %% of the pieces leave it (%.5f %% of the steps)" % (100 * st[2] / st[0], 100 * st[5] / st[3]))
-    print("  pieces by largest distance from the estimated centre (0-3, 4-7, ...):", [int(x) for x in st[6:16]])
+    print("  pieces by largest distance from the band's centre, lanes 31|32 (0-1, 2-3, ..., 18+):", [int(x) for x in st[6:16]])
     job.close()
