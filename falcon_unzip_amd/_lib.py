@@ -164,6 +164,7 @@ def load():
         "fzp_readmap": (C.c_int, [CP, SZ, CP, SZ, CP, SZ, CP, SZ, CP, I32, PP, PI64, PP, PSZ]),
         "fzp_align_params_default": (None, [VP]),
         "fzp_align_create": (C.c_int, [VP, I32, VP, VP, I64, VP, VP, VP, VP, PP]),
+        "fzp_align_create_spans": (C.c_int, [VP, I32, VP, VP, I64, VP, VP, VP, VP, PP]),
         "fzp_align_run": (C.c_int, [VP, VP]),
         "fzp_align_invalidate_index": (C.c_int, [VP]),
         "fzp_align_summaries": (C.c_int, [VP, VP, VP]),

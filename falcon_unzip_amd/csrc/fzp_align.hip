@@ -55,26 +55,11 @@ __global__ void __launch_bounds__(256) k_upper(uint8_t *__restrict__ a, int64_t 
 }
 
 // ---- packing: one workgroup column per sequence, blockIdx.y strides over its words
-__global__ void __launch_bounds__(256) k_pack(const uint8_t *__restrict__ ascii, const int64_t *__restrict__ seq_off, const int64_t *__restrict__ woff,
-                                              uint32_t *__restrict__ out) {
-    const int64_t s = blockIdx.x;
-    const int64_t b0 = seq_off[s], n = seq_off[s + 1] - b0;
-    const int64_t nw = ((n + 15) / 16 + 8 + 1) & ~1LL;   // zero pad words: 64-bit base windows may run past the end
-    uint32_t *dst = out + woff[s];
-    for (int64_t w = (int64_t)blockIdx.y * 256 + threadIdx.x; w < nw; w += (int64_t)gridDim.y * 256) {
-        uint32_t v = 0;
-        int64_t base = w * 16;
-        for (int m = 0; m < 16; m++)
-            if (base + m < n) v |= (uint32_t)code_of(ascii[b0 + base + m]) << (2 * m);
-        dst[w] = v;
-    }
-}
-
-__global__ void __launch_bounds__(256) k_pack2(const uint8_t *__restrict__ ascii, const int64_t *__restrict__ seq_be, const int64_t *__restrict__ woff,
-                                               uint32_t *__restrict__ out) {      // like k_pack, sequence s = [seq_be[2s], seq_be[2s+1])
+__global__ void __launch_bounds__(256) k_pack(const uint8_t *__restrict__ ascii, const int64_t *__restrict__ seq_be, const int64_t *__restrict__ woff,
+                                              uint32_t *__restrict__ out) {      // sequence s = ascii[seq_be[2s], seq_be[2s+1])
     const int64_t s = blockIdx.x;
     const int64_t b0 = seq_be[2 * s], n = seq_be[2 * s + 1] - b0;
-    const int64_t nw = ((n + 15) / 16 + 8 + 1) & ~1LL;
+    const int64_t nw = ((n + 15) / 16 + 8 + 1) & ~1LL;   // zero pad words: 64-bit base windows may run past the end
     uint32_t *dst = out + woff[s];
     for (int64_t w = (int64_t)blockIdx.y * 256 + threadIdx.x; w < nw; w += (int64_t)gridDim.y * 256) {
         uint32_t v = 0;
@@ -2258,9 +2243,11 @@ static int build_index(fzp_ctx *ctx, fzp_alnjob *j) {
     return FZP_OK;
 }
 
-extern "C" int fzp_align_create(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *const *ctg_seq, const int64_t *ctg_len, int64_t n_reads, const int32_t *read_ctg,
-                                const int64_t *read_off, const uint8_t *read_seq, const fzp_align_params *params, fzp_alnjob **out) {
-    if (!ctx || !out || n_ctg <= 0 || !ctg_seq || !ctg_len || n_reads < 0 || (n_reads && (!read_ctg || !read_off || !read_seq))) {
+// reads given as spans of one host buffer: read r = buf[read_be[2r], read_be[2r + 1]).  What lies between the spans travels with them (the bytes from the first span's
+// begin to the last span's end go to the device in one piece), so the caller can hand over a FASTA file's bytes as they are: headers and line ends stay behind at the pack.
+extern "C" int fzp_align_create_spans(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *const *ctg_seq, const int64_t *ctg_len, int64_t n_reads, const int32_t *read_ctg,
+                                      const int64_t *read_be, const uint8_t *buf, const fzp_align_params *params, fzp_alnjob **out) {
+    if (!ctx || !out || n_ctg <= 0 || !ctg_seq || !ctg_len || n_reads < 0 || (n_reads && (!read_ctg || !read_be || !buf))) {
         fzp_set_error("fzp_align_create: bad arguments");
         return FZP_EINVAL;
     }
@@ -2294,9 +2281,11 @@ extern "C" int fzp_align_create(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *cons
     // reads
     j->h_read_woff.assign(1, 0);
     j->h_cig_off.assign(1, 0);
+    int64_t span_lo = INT64_MAX, span_hi = 0;
     for (int64_t r = 0; r < n_reads; r++) {
-        int64_t n = read_off[r + 1] - read_off[r];
-        if (n < 0 || n > 0x3fff0000LL || read_ctg[r] < 0 || read_ctg[r] >= n_ctg) { delete j; fzp_set_error("read %lld: bad length/contig", (long long)r); return FZP_EINVAL; }
+        int64_t n = read_be[2 * r + 1] - read_be[2 * r];
+        if (n < 0 || n > 0x3fff0000LL || read_be[2 * r] < 0 || read_ctg[r] < 0 || read_ctg[r] >= n_ctg) { delete j; fzp_set_error("read %lld: bad length/contig", (long long)r); return FZP_EINVAL; }
+        span_lo = std::min(span_lo, read_be[2 * r]); span_hi = std::max(span_hi, read_be[2 * r + 1]);
         if (n * (int64_t)j->P.match >= (1LL << 26) - (1 << 20)) {   // biased score << 5 must fit 32 bits (k_sw best-cell key)
             delete j; fzp_set_error("read %lld: %lld bases x match %d exceeds the score range of the DP kernel", (long long)r, (long long)n, j->P.match); return FZP_EINVAL;
         }
@@ -2320,27 +2309,27 @@ extern "C" int fzp_align_create(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *cons
             if ((rc = fzp_upload_segments(ctx, j->ctg_ascii.p, srcs, dsts, lens, st))) break;
         }
         hipLaunchKernelGGL(k_upper, dim3((unsigned)((coff.back() / 16 + 255) / 256 + 1)), dim3(256), 0, st, j->ctg_ascii.p, coff.back());
-        {   // k_pack reads [seq_off[s], seq_off[s+1]): the contig lengths, not the padded segments -> per-contig begin / end pairs
+        {   // the contigs' own lengths, not the padded segments
             std::vector<int64_t> be;
             for (int c = 0; c < n_ctg; c++) { be.push_back(coff[(size_t)c]); be.push_back(coff[(size_t)c] + ctg_len[c]); }
             DevBuf<int64_t> d_be;
             if ((rc = d_be.upload(be.data(), be.size(), st))) break;
-            hipLaunchKernelGGL(k_pack2, dim3(n_ctg, 64), dim3(256), 0, st, j->ctg_ascii.p, d_be.p, j->ctg_woff.p, j->ctg_pk.p);
+            hipLaunchKernelGGL(k_pack, dim3(n_ctg, 64), dim3(256), 0, st, j->ctg_ascii.p, d_be.p, j->ctg_woff.p, j->ctg_pk.p);
             hipLaunchKernelGGL(k_revcomp<int64_t>, dim3(n_ctg, 64), dim3(256), 0, st, (const uint32_t *)j->ctg_pk.p, (const int64_t *)j->ctg_woff.p, (const int64_t *)j->ctg_len.p, j->ctg_rc.p);
             if (hipStreamSynchronize(st) != hipSuccess) { rc = FZP_EDEVICE; break; }
         }
         j->h_ctg_aoff = coff;
         if (n_reads) {
-            const size_t rbytes = (size_t)(read_off[n_reads] - read_off[0]);
+            const size_t rbytes = (size_t)(span_hi - span_lo);
             if ((rc = j->read_pk.alloc((size_t)j->read_words + 8)) || (rc = j->read_rc.alloc((size_t)j->read_words + 8)) || (rc = d_ascii.alloc(rbytes + 16)))
                 break;
             {
-                std::vector<const void *> srcs(1, read_seq + read_off[0]); std::vector<size_t> dsts(1, 0), lens(1, rbytes);
+                std::vector<const void *> srcs(1, buf + span_lo); std::vector<size_t> dsts(1, 0), lens(1, rbytes);
                 if ((rc = fzp_upload_segments(ctx, d_ascii.p, srcs, dsts, lens, st))) break;
             }
-            std::vector<int64_t> roff((size_t)n_reads + 1);
-            for (int64_t r = 0; r <= n_reads; r++) roff[(size_t)r] = read_off[r] - read_off[0];
-            if ((rc = d_off.upload(roff.data(), roff.size(), st)) || (rc = j->read_woff.upload(j->h_read_woff.data(), j->h_read_woff.size(), st)) ||
+            std::vector<int64_t> rbe((size_t)n_reads * 2);
+            for (int64_t r = 0; r < 2 * n_reads; r++) rbe[(size_t)r] = read_be[r] - span_lo;
+            if ((rc = d_off.upload(rbe.data(), rbe.size(), st)) || (rc = j->read_woff.upload(j->h_read_woff.data(), j->h_read_woff.size(), st)) ||
                 (rc = j->read_len.upload(j->h_read_len.data(), j->h_read_len.size(), st)) || (rc = j->read_ctg.upload(j->h_read_ctg.data(), j->h_read_ctg.size(), st)) ||
                 (rc = j->cig_off.upload(j->h_cig_off.data(), j->h_cig_off.size(), st)))
                 break;
@@ -2376,6 +2365,15 @@ extern "C" int fzp_align_create(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *cons
     if (rc) { if (rc == FZP_EDEVICE) fzp_set_error("fzp_align_create: device error"); delete j; return rc; }
     *out = j;
     return FZP_OK;
+}
+
+// the reads back to back in one buffer: read r = read_seq[read_off[r], read_off[r + 1])
+extern "C" int fzp_align_create(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *const *ctg_seq, const int64_t *ctg_len, int64_t n_reads, const int32_t *read_ctg,
+                                const int64_t *read_off, const uint8_t *read_seq, const fzp_align_params *params, fzp_alnjob **out) {
+    if (n_reads < 0 || (n_reads && !read_off)) { fzp_set_error("fzp_align_create: bad arguments"); return FZP_EINVAL; }
+    std::vector<int64_t> be((size_t)n_reads * 2);
+    for (int64_t r = 0; r < n_reads; r++) { be[(size_t)(2 * r)] = read_off[r]; be[(size_t)(2 * r + 1)] = read_off[r + 1]; }
+    return fzp_align_create_spans(ctx, n_ctg, ctg_seq, ctg_len, n_reads, read_ctg, be.data(), read_seq, params, out);
 }
 
 // the next fzp_align_run rebuilds the k-mer tables (a job that sees its contigs once pays for them inside its run: bench.py's step)

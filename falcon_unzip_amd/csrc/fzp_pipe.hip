@@ -773,13 +773,17 @@ struct RawBuf {
     uint8_t *data() { return p; }
 };
 struct GroupIn {
-    RawBuf raw;                                  // the group's files as they are
-    RawBuf ref;                                  // the group's contigs, one after the other
-    std::vector<int64_t> ref_off;                // [gc + 1]
-    RawBuf blob;                                 // the group's reads, contig after contig
-    std::vector<int64_t> off, noff;
+    RawBuf raw;                                  // the group's files as they are: the reads files first, contig after contig, then the contig files
+    RawBuf ref;                                  // contigs whose FASTA record is not one plain line, joined (normally empty: the others are used where they lie in `raw`)
+    std::vector<const uint8_t *> ctg_ptr;        // [gc] every contig's bases (in raw or in ref)
+    std::vector<int64_t> ctg_len;                // [gc]
+    RawBuf blob;                                 // the group's reads joined, contig after contig -- only when some read's record is not one plain line
+    const uint8_t *seq_base = nullptr;           // raw or blob: what the spans below index
+    std::vector<int64_t> be;                     // [2 n_reads] read r = seq_base[be[2r], be[2r + 1])
+    std::vector<int64_t> noff;
     std::vector<int32_t> read_ctg;
     RawBuf names;
+    bool in_place = false;                       // the reads are spans of `raw`
     int rc = FZP_OK;
     std::string err;
 };
@@ -816,54 +820,10 @@ int usable_cores() {
     }
     return n;
 }
-struct FaRec { const char *name; int32_t name_len; const char *s0, *s1; int64_t len; };      // header's first word; the sequence's lines lie in [s0, s1); len = its bases
-struct FaPiece { int file; const char *a, *b; std::vector<FaRec> recs; int64_t bases = 0, name_bytes = 0; };
+struct FaRec { const char *name; int32_t name_len; const char *s0, *s1; int64_t len; bool plain; };      // header's first word; the sequence's lines lie in [s0, s1); len = its bases; plain: one line, nothing to trim
+struct FaPiece { int file; const char *a, *b; std::vector<int64_t> nl; std::vector<FaRec> recs; int64_t bases = 0, name_bytes = 0; bool all_plain = true; };
 inline bool fa_sp(char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\n' || c == '\v' || c == '\f'; }
-// the records that START in [a, b) of a mapped file [f0, f1): name = first word of the header, sequence = its lines joined, white space at line ends dropped
-// (falcon_kit's FastaReader as phasing.py:490-494 uses it)
-void scan_piece(const char *f0, const char *f1, FaPiece &P) {
-    const char *p = P.a;
-    if (p > f0) {      // the first record start at or after a: a '>' right behind a newline
-        p--;
-        for (;;) {
-            const char *nl = (const char *)memchr(p, '\n', (size_t)(f1 - p));
-            if (!nl || nl + 1 >= f1) { p = f1; break; }
-            if (nl[1] == '>') { p = nl + 1; break; }
-            p = nl + 1;
-        }
-    }
-    while (p < P.b && p < f1) {
-        if (*p != '>') {   // (only at the head of a file: lines before the first header belong to no record)
-            const char *nl = (const char *)memchr(p, '\n', (size_t)(f1 - p));
-            p = nl ? nl + 1 : f1;
-            continue;
-        }
-        const char *nl = (const char *)memchr(p, '\n', (size_t)(f1 - p));
-        const char *le = nl ? nl : f1;
-        FaRec R;
-        const char *x = p + 1;
-        while (x < le && fa_sp(*x)) x++;
-        const char *y = x;
-        while (y < le && !fa_sp(*y)) y++;
-        R.name = x; R.name_len = (int32_t)(y - x);
-        R.s0 = nl ? nl + 1 : f1;
-        R.len = 0;
-        const char *q = R.s0;
-        while (q < f1 && *q != '>') {
-            const char *n2 = (const char *)memchr(q, '\n', (size_t)(f1 - q));
-            const char *e = n2 ? n2 : f1;
-            const char *u = q, *v = e;
-            while (u < v && fa_sp(*u)) u++;
-            while (v > u && fa_sp(v[-1])) v--;
-            R.len += v - u;
-            q = n2 ? n2 + 1 : f1;
-        }
-        R.s1 = q;
-        P.bases += R.len; P.name_bytes += R.name_len;
-        P.recs.push_back(R);
-        p = q;
-    }
-}
+// a record's sequence, joined: white space at line ends dropped (falcon_kit's FastaReader as phasing.py:490-494 uses it)
 inline void copy_seq(const FaRec &R, uint8_t *dst) {
     const char *q = R.s0;
     while (q < R.s1) {
@@ -877,13 +837,80 @@ inline void copy_seq(const FaRec &R, uint8_t *dst) {
         q = n2 ? n2 + 1 : R.s1;
     }
 }
+// The loader.  Pass 1, per 4 MB piece of a file: read it (pread into the group's buffer) and, while it is warm, note where its line ends are.  Pass 2, per piece: the
+// records whose header line STARTS in the piece, from the line ends alone (a record runs on into later pieces through their lists; only line starts and ends are looked at).
+// A record of one plain line -- what falcon_kit writes -- is used where it lies: its span of the buffer goes to fzp_align_create_spans, nothing is copied.
+struct LineCursor {      // line ends of a file at or after a position, across its pieces
+    const std::vector<FaPiece> *pieces; size_t k, k_end, i;
+    // the next line end at or after `from`, or f1 (the file's end) when there is none
+    const char *next(const char *base, const char *f1) {
+        while (k < k_end) {
+            const auto &v = (*pieces)[k].nl;
+            if (i < v.size()) return base + v[i++];
+            k++; i = 0;
+        }
+        return f1;
+    }
+};
+void records_of_piece(std::vector<FaPiece> &pieces, size_t k, size_t k_end, const char *base, const char *f0, const char *f1) {
+    FaPiece &P = pieces[k];
+    // line starts in [a, b): the file's start, and one behind every line end in [a - 1, b - 1)
+    LineCursor cur{&pieces, k, k_end, 0};
+    const char *s = nullptr;
+    if (P.a == f0) s = f0;
+    else if (P.a[-1] == '\n') s = P.a;
+    else {      // the first line start of this piece lies behind its first line end
+        const char *e = cur.k == k && !P.nl.empty() ? base + P.nl[0] : nullptr;
+        if (!e || e + 1 >= P.b) return;
+        cur.i = 1;
+        s = e + 1;
+    }
+    while (s < P.b && s < f1) {
+        const char *le = cur.next(base, f1);      // end of the line that starts at s
+        if (*s != '>') { s = le + 1; continue; }  // (a sequence line of a record an earlier piece owns, or lines before a file's first header)
+        FaRec R;
+        const char *x = s + 1;
+        while (x < le && fa_sp(*x)) x++;
+        const char *y = x;
+        while (y < le && !fa_sp(*y)) y++;
+        R.name = x; R.name_len = (int32_t)(y - x);
+        R.s0 = le < f1 ? le + 1 : f1;
+        R.len = 0;
+        int n_lines = 0;
+        bool trimmed = false;
+        const char *q = R.s0;
+        // (the cursor may run past this piece: a record belongs to the piece of its header; what it leaves behind in the later lists is skipped by their own pieces)
+        LineCursor c2 = cur;
+        while (q < f1 && *q != '>') {
+            const char *e = c2.next(base, f1);
+            const char *u = q, *v = e;
+            while (u < v && fa_sp(*u)) u++;
+            while (v > u && fa_sp(v[-1])) v--;
+            if (u != q || v != e) trimmed = true;
+            R.len += v - u;
+            n_lines++;
+            q = e < f1 ? e + 1 : f1;
+        }
+        R.s1 = q;
+        R.plain = n_lines == 1 && !trimmed;
+        if (!R.plain && R.len > 0) P.all_plain = false;
+        if (R.len == 0) R.plain = true;           // (nothing to copy either way)
+        P.bases += R.len; P.name_bytes += R.name_len;
+        P.recs.push_back(R);
+        // go on at the next header: only line starts inside this piece count
+        if (q >= P.b) break;
+        cur = c2;
+        s = q;
+    }
+}
 struct Mapped { const char *p = nullptr; size_t n = 0; };
 void load_group(const std::string &dir, const char *const *ctg_id, int c0, int c1, int n_threads, GroupIn &G) {
-    const int gc = c1 - c0, nf = 2 * gc;            // file 2c: <ctg>_reads.fa, file 2c + 1: <ctg>_ref.fa
+    const int gc = c1 - c0, nf = 2 * gc;            // file t < gc: <ctg t>_reads.fa, file gc + t: <ctg t>_ref.fa
     G.rc = FZP_OK; G.err.clear();
     const bool timing = getenv("FZP_PIPE_TIMING") != nullptr;
     const auto t_0 = clk::now();
-    double t_map = 0, t_scan = 0, t_alloc = 0;
+    double t_map = 0, t_scan = 0;
+    auto path_of = [&](int t) { return dir + "/" + ctg_id[c0 + (t < gc ? t : t - gc)] + (t < gc ? "_reads.fa" : "_ref.fa"); };
     // the files' bytes into one buffer of the group (kept with the context: warm pages), read in pieces of 4 MB by all threads -- mapping the files instead costs more
     // in page-table set-up and tear-down (10 ms each way per 300 MB) than the copy does
     std::vector<Mapped> mp((size_t)nf);
@@ -897,92 +924,126 @@ void load_group(const std::string &dir, const char *const *ctg_id, int c0, int c
         work();
         for (auto &x : th) x.join();
     };
-    auto unmap_all = [&]() { for (int &fd : fds) if (fd >= 0) { close(fd); fd = -1; } };
+    auto close_all = [&]() { for (int &fd : fds) if (fd >= 0) { close(fd); fd = -1; } };
     for (int t = 0; t < nf; t++) {
-        const std::string path = dir + "/" + ctg_id[c0 + (t >> 1)] + ((t & 1) ? "_ref.fa" : "_reads.fa");
+        const std::string path = path_of(t);
         fds[(size_t)t] = open(path.c_str(), O_RDONLY);
         struct stat sb;
-        if (fds[(size_t)t] < 0 || fstat(fds[(size_t)t], &sb) != 0) { G.rc = FZP_EIO; G.err = path + ": " + strerror(errno); unmap_all(); return; }
+        if (fds[(size_t)t] < 0 || fstat(fds[(size_t)t], &sb) != 0) { G.rc = FZP_EIO; G.err = path + ": " + strerror(errno); close_all(); return; }
         mp[(size_t)t].n = (size_t)sb.st_size;
         foff[(size_t)t + 1] = foff[(size_t)t] + mp[(size_t)t].n;
     }
-    if (!G.raw.need(foff[(size_t)nf] + 1)) { G.rc = FZP_ENOMEM; G.err = "host memory for the group's files"; unmap_all(); return; }
-    for (int t = 0; t < nf; t++) mp[(size_t)t].p = (const char *)G.raw.data() + foff[(size_t)t];
+    if (!G.raw.need(foff[(size_t)nf] + 1)) { G.rc = FZP_ENOMEM; G.err = "host memory for the group's files"; close_all(); return; }
+    const char *base = (const char *)G.raw.data();
+    for (int t = 0; t < nf; t++) mp[(size_t)t].p = base + foff[(size_t)t];
     // pieces of ~4 MB, in file order
     std::vector<FaPiece> pieces;
-    const size_t PIECE = 4u << 20;
-    for (int t = 0; t < nf; t++)
+    std::vector<size_t> file_piece0((size_t)nf + 1, 0);
+    size_t PIECE = 4u << 20;
+    if (const char *e = getenv("FZP_FASTA_PIECE")) { const long v = atol(e); if (v > 0) PIECE = (size_t)v; }      // (tests: records that straddle many pieces)
+    for (int t = 0; t < nf; t++) {
+        file_piece0[(size_t)t] = pieces.size();
         for (size_t a = 0; a < mp[(size_t)t].n; a += PIECE) {
             FaPiece P;
             P.file = t; P.a = mp[(size_t)t].p + a; P.b = mp[(size_t)t].p + std::min(mp[(size_t)t].n, a + PIECE);
             pieces.push_back(std::move(P));
         }
+    }
+    file_piece0[(size_t)nf] = pieces.size();
     par([&]() {
         for (int k; (k = next.fetch_add(1)) < (int)pieces.size();) {
-            const FaPiece &P = pieces[(size_t)k];
+            FaPiece &P = pieces[(size_t)k];
             const int t = P.file;
             size_t at = (size_t)(P.a - mp[(size_t)t].p);
             const size_t end = (size_t)(P.b - mp[(size_t)t].p);
+            bool ok = true;
             while (at < end) {
                 const ssize_t got = pread(fds[(size_t)t], (void *)(mp[(size_t)t].p + at), end - at, (off_t)at);
-                if (got <= 0) { errs[(size_t)t] = dir + "/" + ctg_id[c0 + (t >> 1)] + ((t & 1) ? "_ref.fa" : "_reads.fa") + ": " + (got < 0 ? strerror(errno) : "file shrank while it was read"); break; }
+                if (got <= 0) { errs[(size_t)t] = path_of(t) + ": " + (got < 0 ? strerror(errno) : "file shrank while it was read"); ok = false; break; }
                 at += (size_t)got;
+            }
+            if (!ok) continue;
+            for (const char *q = P.a; q < P.b;) {      // its line ends, as offsets into the group's buffer
+                const char *e = (const char *)memchr(q, '\n', (size_t)(P.b - q));
+                if (!e) break;
+                P.nl.push_back((int64_t)(e - base));
+                q = e + 1;
             }
         }
     });
-    unmap_all();
+    close_all();
     t_map = ms_since(t_0);
     for (int t = 0; t < nf; t++) if (!errs[(size_t)t].empty()) { G.rc = FZP_EIO; G.err = errs[(size_t)t]; return; }
     next.store(0);
-    par([&]() { for (int k; (k = next.fetch_add(1)) < (int)pieces.size();) scan_piece(mp[(size_t)pieces[(size_t)k].file].p, mp[(size_t)pieces[(size_t)k].file].p + mp[(size_t)pieces[(size_t)k].file].n, pieces[(size_t)k]); });
+    par([&]() {
+        for (int k; (k = next.fetch_add(1)) < (int)pieces.size();) {
+            const int t = pieces[(size_t)k].file;
+            records_of_piece(pieces, (size_t)k, file_piece0[(size_t)t + 1], base, mp[(size_t)t].p, mp[(size_t)t].p + mp[(size_t)t].n);
+        }
+    });
     t_scan = ms_since(t_0);
     // the contigs: of <ctg>_ref.fa the LAST record named <ctg> (the loop at phasing.py:490-494 leaves that one); none -> an empty contig
     std::vector<const FaRec *> ref_rec((size_t)gc, nullptr);
-    G.ref_off.assign((size_t)gc + 1, 0);
     for (auto &P : pieces)
-        if (P.file & 1) {
-            const int c = P.file >> 1;
+        if (P.file >= gc) {
+            const int c = P.file - gc;
             const size_t want = strlen(ctg_id[c0 + c]);
             for (auto &R : P.recs) if ((size_t)R.name_len == want && memcmp(R.name, ctg_id[c0 + c], want) == 0) ref_rec[(size_t)c] = &R;
         }
-    for (int c = 0; c < gc; c++) G.ref_off[(size_t)c + 1] = G.ref_off[(size_t)c] + (ref_rec[(size_t)c] ? ref_rec[(size_t)c]->len : 0);
-    if (!G.ref.need((size_t)G.ref_off[(size_t)gc] + 1)) { G.rc = FZP_ENOMEM; G.err = "host memory for the group's contigs"; return; }
+    G.ctg_ptr.assign((size_t)gc, (const uint8_t *)base);
+    G.ctg_len.assign((size_t)gc, 0);
+    std::vector<int64_t> ref_at((size_t)gc + 1, 0);      // room in G.ref for the contigs that have to be joined
+    for (int c = 0; c < gc; c++) {
+        const FaRec *R = ref_rec[(size_t)c];
+        G.ctg_len[(size_t)c] = R ? R->len : 0;
+        ref_at[(size_t)c + 1] = ref_at[(size_t)c] + (R && !R->plain ? R->len : 0);
+    }
+    if (!G.ref.need((size_t)ref_at[(size_t)gc] + 1)) { G.rc = FZP_ENOMEM; G.err = "host memory for the group's contigs"; return; }
+    for (int c = 0; c < gc; c++) {
+        const FaRec *R = ref_rec[(size_t)c];
+        if (R) G.ctg_ptr[(size_t)c] = R->plain ? (const uint8_t *)R->s0 : G.ref.data() + ref_at[(size_t)c];
+    }
     // the reads: every record of <ctg>_reads.fa, file order; a prefix sum over the pieces gives every piece its first read, base and name byte
     std::vector<int64_t> p_rec(pieces.size() + 1, 0), p_base(pieces.size() + 1, 0), p_name(pieces.size() + 1, 0);
+    bool in_place = true;
     for (size_t k = 0; k < pieces.size(); k++) {
-        const bool rd = !(pieces[k].file & 1);
+        const bool rd = pieces[k].file < gc;
         p_rec[k + 1] = p_rec[k] + (rd ? (int64_t)pieces[k].recs.size() : 0);
         p_base[k + 1] = p_base[k] + (rd ? pieces[k].bases : 0);
         p_name[k + 1] = p_name[k] + (rd ? pieces[k].name_bytes : 0);
+        if (rd && !pieces[k].all_plain) in_place = false;
     }
+    if (getenv("FZP_FASTA_JOIN")) in_place = false;      // (tests: the joining path on plain files)
     const int64_t nr = p_rec.back();
-    if (!G.blob.need((size_t)p_base.back() + 1) || !G.names.need((size_t)p_name.back() + 1)) { G.rc = FZP_ENOMEM; G.err = "host memory for the group's reads"; return; }
-    G.off.resize((size_t)nr + 1); G.noff.resize((size_t)nr + 1); G.read_ctg.resize((size_t)nr);
-    G.off[0] = 0; G.noff[0] = 0;
-    t_alloc = ms_since(t_0);
+    if ((!in_place && !G.blob.need((size_t)p_base.back() + 1)) || !G.names.need((size_t)p_name.back() + 1)) { G.rc = FZP_ENOMEM; G.err = "host memory for the group's reads"; return; }
+    G.in_place = in_place;
+    G.seq_base = in_place ? G.raw.data() : G.blob.data();
+    G.be.resize((size_t)nr * 2); G.noff.resize((size_t)nr + 1); G.read_ctg.resize((size_t)nr);
+    G.noff[0] = 0;
     next.store(0);
     const int n_work = (int)pieces.size() + gc;
     par([&]() {
         for (int k; (k = next.fetch_add(1)) < n_work;) {
-            if (k >= (int)pieces.size()) {      // a contig's sequence
+            if (k >= (int)pieces.size()) {      // a contig that has to be joined
                 const int c = k - (int)pieces.size();
-                if (ref_rec[(size_t)c]) copy_seq(*ref_rec[(size_t)c], G.ref.data() + G.ref_off[(size_t)c]);
+                if (ref_rec[(size_t)c] && !ref_rec[(size_t)c]->plain) copy_seq(*ref_rec[(size_t)c], G.ref.data() + ref_at[(size_t)c]);
                 continue;
             }
             const FaPiece &P = pieces[(size_t)k];
-            if (P.file & 1) continue;
+            if (P.file >= gc) continue;
             int64_t r = p_rec[(size_t)k], ab = p_base[(size_t)k], an = p_name[(size_t)k];
             for (const FaRec &R : P.recs) {
-                copy_seq(R, G.blob.data() + ab);
+                if (in_place) { const int64_t at = R.len ? (int64_t)(R.s0 - base) : 0; G.be[(size_t)(2 * r)] = at; G.be[(size_t)(2 * r + 1)] = at + R.len; }
+                else { copy_seq(R, G.blob.data() + ab); G.be[(size_t)(2 * r)] = ab; G.be[(size_t)(2 * r + 1)] = ab + R.len; }
                 memcpy(G.names.data() + an, R.name, (size_t)R.name_len);
                 ab += R.len; an += R.name_len;
-                G.off[(size_t)r + 1] = ab; G.noff[(size_t)r + 1] = an; G.read_ctg[(size_t)r] = P.file >> 1;
+                G.noff[(size_t)r + 1] = an; G.read_ctg[(size_t)r] = P.file;
                 r++;
             }
         }
     });
-    if (timing) fprintf(stderr, "[load_group] %d contigs, %lld reads, %.1f MB on %d threads: read by %.2f ms, scanned by %.2f, buffers by %.2f, copied by %.2f\n", gc, (long long)nr,
-                        (double)p_base.back() / 1e6, n_threads, t_map, t_scan, t_alloc, ms_since(t_0));
+    if (timing) fprintf(stderr, "[load_group] %d contigs, %lld reads, %.1f MB on %d threads: read + line ends by %.2f ms, records by %.2f, %s by %.2f\n", gc, (long long)nr,
+                        (double)p_base.back() / 1e6, n_threads, t_map, t_scan, in_place ? "spans (reads used in place)" : "reads joined", ms_since(t_0));
 }
 }  // namespace
 
@@ -996,8 +1057,17 @@ extern "C" int fzp_debug_load_fasta_group(const char *reads_dir, const char *con
     if (G.rc != FZP_OK) { fzp_set_error("%s", G.err.c_str()); return G.rc; }
     auto dup = [](const void *p, size_t bytes) { void *q = malloc(bytes ? bytes : 1); if (q && bytes) memcpy(q, p, bytes); return q; };
     const size_t nr = G.read_ctg.size();
-    *ref = (uint8_t *)dup(G.ref.data(), (size_t)G.ref_off[(size_t)n_ctg]); *ref_off = (int64_t *)dup(G.ref_off.data(), ((size_t)n_ctg + 1) * 8);
-    *blob = (uint8_t *)dup(G.blob.data(), (size_t)G.off[nr]); *off = (int64_t *)dup(G.off.data(), (nr + 1) * 8);
+    {   // contigs and reads joined back to back, whichever way the loader holds them
+        std::vector<int64_t> ro((size_t)n_ctg + 1, 0), o(nr + 1, 0);
+        for (int c = 0; c < n_ctg; c++) ro[(size_t)c + 1] = ro[(size_t)c] + G.ctg_len[(size_t)c];
+        for (size_t r = 0; r < nr; r++) o[r + 1] = o[r] + (G.be[2 * r + 1] - G.be[2 * r]);
+        uint8_t *rb = (uint8_t *)malloc((size_t)ro[(size_t)n_ctg] + 1), *bb = (uint8_t *)malloc((size_t)o[nr] + 1);
+        if (!rb || !bb) { free(rb); free(bb); fzp_set_error("fzp_debug_load_fasta_group: host memory"); return FZP_ENOMEM; }
+        for (int c = 0; c < n_ctg; c++) memcpy(rb + ro[(size_t)c], G.ctg_ptr[(size_t)c], (size_t)G.ctg_len[(size_t)c]);
+        for (size_t r = 0; r < nr; r++) memcpy(bb + o[r], G.seq_base + G.be[2 * r], (size_t)(o[r + 1] - o[r]));
+        *ref = rb; *ref_off = (int64_t *)dup(ro.data(), ro.size() * 8);
+        *blob = bb; *off = (int64_t *)dup(o.data(), o.size() * 8);
+    }
     *names = (char *)dup(G.names.data(), (size_t)G.noff[nr]); *name_off = (int64_t *)dup(G.noff.data(), (nr + 1) * 8);
     *read_ctg = (int32_t *)dup(G.read_ctg.data(), nr * 4);
     *n_reads = (int64_t)nr;
@@ -1099,12 +1169,12 @@ extern "C" int fzp_phase_contigs_files(fzp_ctx *ctx, const char *reads_dir, cons
             const int64_t gr_n = (int64_t)G->read_ctg.size();
             std::vector<const uint8_t *> cptr((size_t)gc);
             std::vector<int64_t> clen((size_t)gc);
-            for (int c = 0; c < gc; c++) { clen[(size_t)c] = G->ref_off[(size_t)c + 1] - G->ref_off[(size_t)c]; cptr[(size_t)c] = G->ref.data() + G->ref_off[(size_t)c]; }
+            for (int c = 0; c < gc; c++) { clen[(size_t)c] = G->ctg_len[(size_t)c]; cptr[(size_t)c] = G->ctg_ptr[(size_t)c]; }
             t0 = clk::now();
             fzp_alnjob *job = nullptr;
             {   // one upload at a time (see fzp_phase_contigs)
                 std::lock_guard<std::mutex> lk(up_mu);
-                rc = fzp_align_create(lc, gc, cptr.data(), clen.data(), gr_n, G->read_ctg.data(), G->off.data(), G->blob.data(), &o.align, &job);
+                rc = fzp_align_create_spans(lc, gc, cptr.data(), clen.data(), gr_n, G->read_ctg.data(), G->be.data(), G->seq_base, &o.align, &job);
             }
             po.ms_upload += ms_since(t0);
             if (rc == FZP_OK) {

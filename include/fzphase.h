@@ -245,6 +245,12 @@ typedef struct fzp_alnjob fzp_alnjob;
 int fzp_align_create(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *const *ctg_seq, const int64_t *ctg_len,
                      int64_t n_reads, const int32_t *read_ctg, const int64_t *read_off, const uint8_t *read_seq,
                      const fzp_align_params *params, fzp_alnjob **out);
+/* the same with the reads given as spans of one host buffer: read r = buf[read_be[2r], read_be[2r + 1]).  The bytes between the first span's begin and the last
+ * span's end go to the device in one piece, so a FASTA file's bytes can be handed over as they are (one line per sequence, as falcon_kit's
+ * fetch_reads -- unzip.py:49-50 -- writes <ctg>_reads.fa): headers and line ends are left behind when the reads are packed.  fzp_phase_contigs_files uses it. */
+int fzp_align_create_spans(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *const *ctg_seq, const int64_t *ctg_len,
+                           int64_t n_reads, const int32_t *read_ctg, const int64_t *read_be /* [2 n_reads] */, const uint8_t *buf,
+                           const fzp_align_params *params, fzp_alnjob **out);
 int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *job);
 /* forget the k-mer tables fzp_align_create built: the next fzp_align_run builds them again, inside the run */
 int fzp_align_invalidate_index(fzp_alnjob *job);

@@ -174,7 +174,7 @@ def _load_group(lib, reads_dir, ids, threads=0):
     return [ref[ref_off[c]:ref_off[c + 1]] for c in range(nc)], [(int(rctg[r]), names[noff[r]:noff[r + 1]], blob[off[r]:off[r + 1]]) for r in range(nr)]
 
 
-def test_fasta_reader_equals_the_python_reader_on_hostile_files(lib, tmp_path):
+def test_fasta_reader_equals_the_python_reader_on_hostile_files(lib, tmp_path, monkeypatch):
     """The library's FASTA reader (fzp_phase_contigs_files: files read in 4 MB pieces, records scanned and copied by several threads) against pipeline.read_fasta, the
     reader the in-memory path uses (falcon_kit's FastaReader as phasing.py:489-494 uses it): CRLF, blank lines, wrapped and unwrapped sequences, headers with descriptions,
     empty sequences, text before the first header, no newline at the end, an empty file, a reference file with several records (the LAST one named <ctg> is the contig) or
@@ -217,7 +217,9 @@ def test_fasta_reader_equals_the_python_reader_on_hostile_files(lib, tmp_path):
     (d / "000002F_ref.fa").write_bytes(b">000002F_not_it\n" + ref_b + b"\n")      # no record of that name: an empty contig
     (d / "000003F_ref.fa").write_bytes(b">000003F")                                # a header and nothing else
     write_reads(d / "000003F_reads.fa", 5, 200, 3)
-    for threads in (1, 3, 0):
+    for threads, piece in ((1, None), (3, None), (0, None), (4, "4099"), (2, "61"), (5, "17")):
+        if piece:
+            monkeypatch.setenv("FZP_FASTA_PIECE", piece)       # pieces smaller than a line, than a header
         ctgs, reads = _load_group(lib, str(d), ids, threads)
         exp_reads = []
         for c, cid in enumerate(ids):
@@ -229,9 +231,52 @@ def test_fasta_reader_equals_the_python_reader_on_hostile_files(lib, tmp_path):
             exp_reads += [(c, nm, sq) for nm, sq in pipeline.read_fasta(str(d / ("%s_reads.fa" % cid)))]
         assert len(reads) == len(exp_reads) > 2200 and reads == exp_reads, threads
     assert ctgs[0] == ref_a and ctgs[2] == b"" and ctgs[3] == b""
+    monkeypatch.delenv("FZP_FASTA_PIECE")
     with pytest.raises(lib.FzpError) as e:
         _load_group(lib, str(d), ids + ["999999F"])
     assert "999999F" in str(e.value)
+
+
+def test_fasta_reader_uses_one_line_records_where_they_lie(lib, tmp_path, monkeypatch, capfd):
+    """Files as falcon_kit's fetch_reads writes them (unzip.py:49-50: a header line, the sequence on one line): the reader hands the reads over as spans of the files' bytes
+    (fzp_align_create_spans) instead of joining them; same records either way, also when the pieces are smaller than the lines, and one wrapped read anywhere sends the group
+    through the joining path."""
+    from falcon_unzip_amd import pipeline
+    rng = np.random.Generator(np.random.PCG64(77))
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    d = tmp_path / "reads"
+    d.mkdir()
+    ids = ["000000F", "000001F", "000002F"]
+    exp_reads, exp_ctgs = [], []
+    for c, cid in enumerate(ids):
+        ref = acgt[rng.integers(0, 4, 20000 + 1000 * c)].tobytes()
+        exp_ctgs.append(ref)
+        (d / ("%s_ref.fa" % cid)).write_bytes(b">%s\n%s\n" % (cid.encode(), ref))
+        with open(d / ("%s_reads.fa" % cid), "wb") as f:
+            for i in range(300):
+                sq = acgt[rng.integers(0, 4, int(rng.integers(0 if i % 50 == 0 else 1, 3000)))].tobytes()
+                nm = b"m/%d/%d_%d" % (c, i, len(sq))
+                f.write(b">" + nm + b" RQ=0.8\n" + sq + (b"" if c == 2 and i == 299 else b"\n"))      # the last file ends without a newline
+                exp_reads.append((c, nm, sq))
+    monkeypatch.setenv("FZP_PIPE_TIMING", "1")
+    for threads, piece, join in ((0, None, False), (3, "1000", False), (2, "7", False), (2, "1", False), (4, None, True), (3, "129", True)):
+        monkeypatch.setenv("FZP_FASTA_PIECE", piece) if piece else monkeypatch.delenv("FZP_FASTA_PIECE", raising=False)
+        monkeypatch.setenv("FZP_FASTA_JOIN", "1") if join else monkeypatch.delenv("FZP_FASTA_JOIN", raising=False)
+        capfd.readouterr()
+        ctgs, reads = _load_group(lib, str(d), ids, threads)
+        err = capfd.readouterr().err
+        assert ("reads used in place" in err) == (not join) and ("reads joined" in err) == join, err
+        assert ctgs == exp_ctgs and reads == exp_reads, (threads, piece, join)
+    monkeypatch.delenv("FZP_FASTA_JOIN", raising=False)
+    monkeypatch.delenv("FZP_FASTA_PIECE", raising=False)
+    with open(d / "000001F_reads.fa", "ab") as f:             # one wrapped read: the whole group is joined
+        f.write(b">wrapped\nACGT\nACGT\n")
+    capfd.readouterr()
+    ctgs, reads = _load_group(lib, str(d), ids, 2)
+    assert "reads joined" in capfd.readouterr().err
+    at = 600
+    assert reads[:at] == exp_reads[:at] and reads[at] == (1, b"wrapped", b"ACGTACGT") and reads[at + 1:] == exp_reads[at:]
+    assert reads == [(c, nm, sq) for c, cid in enumerate(ids) for nm, sq in pipeline.read_fasta(str(d / ("%s_reads.fa" % cid)))]
 
 
 def test_rid_to_phase_all_formatter(lib):
