@@ -1016,24 +1016,27 @@ struct LaneStream {                // upcoming bases of one sequence, per lane: 
     }
 };
 
+constexpr int SWB_RING = 64;                          // words per lane in a stream's ring
+constexpr int SWB_HOLD = 16;                          // words a bulk load brings
+constexpr int SWB_BULK_STEPS = 16 * SWB_HOLD;         // steps between bulk loads (a step takes at most one base: SWB_HOLD words at most leave the ring in between)
 struct LaneStreamL {
     const uint32_t *pk;            // the sequence's words
     uint32_t *ring;                // this lane's column of its stream's ring
     uint64_t cur;
     uint32_t pend, rd, wr, gw, lim;
-    uint32_t hold[16], hold_base;  // sixteen words on their way from HBM to the ring (bulk)
+    uint32_t hold[SWB_HOLD], hold_base;  // sixteen words on their way from HBM to the ring (bulk)
     bool held;
     int32_t have;
     __device__ __forceinline__ void init(const uint32_t *pk_, int64_t idx, uint32_t lim_, uint32_t *ring_) {
         pk = pk_; ring = ring_; lim = lim_; held = false; hold_base = 0;
 #pragma unroll
-        for (int q = 0; q < 16; q++) hold[q] = 0u;
+        for (int q = 0; q < SWB_HOLD; q++) hold[q] = 0u;
         const uint32_t w = (uint32_t)(idx >> 4);
         const uint32_t sh = (uint32_t)(idx & 15) * 2u;
         cur = ((uint64_t)pk[w] | ((uint64_t)pk[w + 1] << 32)) >> sh;
         have = 32 - (int32_t)(idx & 15);
         gw = w + 2;
-        for (int q0 = 0; q0 < 64; q0 += 16) {
+        for (int q0 = 0; q0 < SWB_RING; q0 += 16) {
             uint32_t v[16];
 #pragma unroll
             for (int q = 0; q < 16; q++) v[q] = 0u;
@@ -1044,31 +1047,31 @@ struct LaneStreamL {
 #pragma unroll
             for (int q = 0; q < 16; q++) ring[(q0 + q) * 64] = gw + q0 + q < lim ? v[q] : 0u;
         }
-        gw += 64; wr = 64; rd = 1;
+        gw += SWB_RING; wr = SWB_RING; rd = 1;
         pend = ring[0];
     }
     __device__ __forceinline__ void refill() {
         const bool m = have <= 16;
         cur |= m ? (uint64_t)pend << (2 * have) : 0ull;
         have += m ? 16 : 0;
-        const uint32_t nx = ring[(rd & 63u) * 64];
+        const uint32_t nx = ring[(rd & (uint32_t)(SWB_RING - 1)) * 64];
         pend = m ? nx : pend;
         rd += m ? 1u : 0u;
     }
-    // every 256 steps (at most 16 words leave the ring in between).  What a call loads goes into the ring at the NEXT call: by then more than 63 vector-memory operations
+    // every SWB_BULK_STEPS steps (at most SWB_HOLD words leave the ring in between).  What a call loads goes into the ring at the NEXT call: by then more than 63 vector-memory operations
     // have been issued behind the loads, which is more than can be outstanding -- no wait is needed to use them, and none is spent behind the mask stores.
     __device__ __forceinline__ void bulk() {
         if (held) {
 #pragma unroll
-            for (int q = 0; q < 16; q++) ring[((wr + q) & 63u) * 64] = hold_base + q < lim ? hold[q] : 0u;
-            wr += 16u;
+            for (int q = 0; q < SWB_HOLD; q++) ring[((wr + q) & (uint32_t)(SWB_RING - 1)) * 64] = hold_base + q < lim ? hold[q] : 0u;
+            wr += (uint32_t)SWB_HOLD;
         }
-        held = wr - rd <= 32u;
+        held = wr - rd <= (uint32_t)(SWB_RING - 2 * SWB_HOLD);      // (room for these words when they arrive, and for what may still be on its way)
         if (held) {
             hold_base = gw;
 #pragma unroll
-            for (int q = 0; q < 16; q++) { const uint32_t ix = gw + q; hold[q] = pk[ix < lim ? ix : lim - 1u]; }
-            gw += 16u;
+            for (int q = 0; q < SWB_HOLD; q++) { const uint32_t ix = gw + q; hold[q] = pk[ix < lim ? ix : lim - 1u]; }
+            gw += (uint32_t)SWB_HOLD;
         }
     }
     __device__ __forceinline__ uint32_t pop(uint32_t en) {
@@ -1093,7 +1096,7 @@ struct SwbLaneT {                  // one extension's state (a lane's registers)
 // there is nothing to validate, no terminal candidate and no end; lanes whose extension is over run along on their stale state (nothing of theirs is stored).
 // CHECKED = true: validity of the bases near the ends, terminal candidates, the end of the extension.
 template <bool CHECKED, class LANE>
-__device__ __forceinline__ void swb_step(LANE &L, const int32_t t, ulonglong2 &rec, const int32_t nq, const int32_t nt, const int32_t max_steps, const bool inner, bool &active,
+__device__ __forceinline__ void swb_step(LANE &L, const int32_t t, uint2 &rec, const int32_t nq, const int32_t nt, const int32_t max_steps, const bool inner, bool &active,
                                          bool &row_on, bool &col_on, int32_t &Hrow, int32_t &Hcol, int32_t &best, int32_t &bt, int32_t &bl, int32_t &steps) {
     using namespace swb;
     const uint32_t sd = L.down, sr = 1u - sd;
@@ -1115,7 +1118,7 @@ __device__ __forceinline__ void swb_step(LANE &L, const int32_t t, ulonglong2 &r
     const uint64_t f = ((uint64_t)((sd & L.pdown) << 31) << 32) | (uint64_t)(sr & (1u - L.pdown));      // two moves the same way: the edge lane's diagonal predecessor is outside the band
     uint64_t D, G;
     cells<uint64_t>(xm, f, (uint64_t)0 - (uint64_t)sd, p, q, &L.P, &L.Q, &D, &G);
-    rec = make_ulonglong2(D, G);
+    rec = make_uint2((uint32_t)(D >> 16), (uint32_t)(G >> 16));      // what leaves is the middle of the band: lanes 16..47
     L.mvacc |= (uint64_t)sd << (t & 63);
     // the edge cells' scores: every lane's cell moved down (its vertical difference) or right (its horizontal one)
     const uint32_t dm = 0u - sd;
@@ -1178,10 +1181,10 @@ __global__ void __launch_bounds__(256) k_swb(const uint64_t *__restrict__ n_b_de
     L.R0 = L.R1 = L.C0 = L.C1 = 0;
     for (int k = 33; k < 64; k++) { const uint32_t c = base_at(qpk, qb + (k - 33)); L.R0 |= (uint64_t)(c & 1u) << k; L.R1 |= (uint64_t)(c >> 1) << k; }
     for (int k = 0; k <= 32; k++) { const uint32_t c = base_at(tpk, tbase + (32 - k)); L.C0 |= (uint64_t)(c & 1u) << k; L.C1 |= (uint64_t)(c >> 1) << k; }
-    __shared__ uint32_t srng[RING ? 2 * 64 * 64 : 1];                      // the two streams' rings (32 KB per wave)
+    __shared__ uint32_t srng[RING ? 2 * SWB_RING * 64 : 1];                // the two streams' rings
     if constexpr (RING) {
         L.qs.init(qpk, qb + 31, (uint32_t)((qb + nq + 15) >> 4) + 1u, srng + threadIdx.x);
-        L.ts.init(tpk, tbase + 33, (uint32_t)((tbase + nt + 15) >> 4) + 1u, srng + 64 * 64 + threadIdx.x);
+        L.ts.init(tpk, tbase + 33, (uint32_t)((tbase + nt + 15) >> 4) + 1u, srng + SWB_RING * 64 + threadIdx.x);
     } else {
         L.qs.init(qpk, qb + 31, (uint32_t)((qb + nq + 15) >> 4) + 1u);
         L.ts.init(tpk, tbase + 33, (uint32_t)((tbase + nt + 15) >> 4) + 1u);
@@ -1198,10 +1201,10 @@ __global__ void __launch_bounds__(256) k_swb(const uint64_t *__restrict__ n_b_de
         // an interior block?  every running lane more than 64 steps away from its last row and its last column (a step brings either one closer by at most one)
         const bool far = !active || (nq - 1 - (L.i0 + 63) > 64 && nt - 1 - (t - L.i0) > 64);
         const bool interior = t >= 64 && __ballot(!far) == 0ull;
-        if constexpr (RING) { if ((t & 255) == 0 && t > 0) { L.qs.bulk(); L.ts.bulk(); } }
+        if constexpr (RING) { if ((t & (SWB_BULK_STEPS - 1)) == 0 && t > 0) { L.qs.bulk(); L.ts.bulk(); } }
         for (int g8 = 0; g8 < 64 / SWB_GROUP; g8++) {
             const bool grp_active = active;
-            ulonglong2 rec[SWB_GROUP];
+            uint2 rec[SWB_GROUP];
             if (interior) {
 #pragma unroll
                 for (int s8 = 0; s8 < SWB_GROUP; s8++) { swb_step<false>(L, t, rec[s8], nq, nt, max_steps, inner, active, row_on, col_on, Hrow, Hcol, best, bt, bl, steps); t++; }
@@ -1216,7 +1219,7 @@ __global__ void __launch_bounds__(256) k_swb(const uint64_t *__restrict__ n_b_de
 #pragma unroll
                 for (int s8 = 0; s8 < SWB_GROUP; s8 += 2)
                     *(uint4 *)(tbr + (int64_t)((t - SWB_GROUP) >> 6) * stride + ((t - SWB_GROUP) & 63) + s8) =
-                        make_uint4((uint32_t)(rec[s8].x >> 16), (uint32_t)(rec[s8].y >> 16), (uint32_t)(rec[s8 + 1].x >> 16), (uint32_t)(rec[s8 + 1].y >> 16));
+                        make_uint4(rec[s8].x, rec[s8].y, rec[s8 + 1].x, rec[s8 + 1].y);
             }
         }
         if (blk_active) {
