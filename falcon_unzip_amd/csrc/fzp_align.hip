@@ -1050,7 +1050,8 @@ struct LaneStreamL {
         gw += SWB_RING; wr = SWB_RING; rd = 1;
         pend = ring[0];
     }
-    __device__ __forceinline__ void refill() {
+    __device__ __forceinline__ void refill(const int32_t popped) {      // popped: bases taken since the last call (the kernel knows from the moves: pop() does not count)
+        have -= popped;
         const bool m = have <= 16;
         cur |= m ? (uint64_t)pend << (2 * have) : 0ull;
         have += m ? 16 : 0;
@@ -1077,7 +1078,6 @@ struct LaneStreamL {
     __device__ __forceinline__ uint32_t pop(uint32_t en) {
         const uint32_t c = (uint32_t)cur & (0u - en) & 3u;
         cur >>= 2u * en;
-        have -= (int32_t)en;
         return c;
     }
 };
@@ -1096,7 +1096,7 @@ struct SwbLaneT {                  // one extension's state (a lane's registers)
 // there is nothing to validate, no terminal candidate and no end; lanes whose extension is over run along on their stale state (nothing of theirs is stored).
 // CHECKED = true: validity of the bases near the ends, terminal candidates, the end of the extension.
 template <bool CHECKED, class LANE>
-__device__ __forceinline__ void swb_step(LANE &L, const int32_t t, uint2 &rec, const int32_t nq, const int32_t nt, const int32_t max_steps, const bool inner, bool &active,
+__device__ __forceinline__ void swb_step(LANE &L, const int32_t t, const int s8, uint32_t &mv8, uint2 &rec, const int32_t nq, const int32_t nt, const int32_t max_steps, const bool inner, bool &active,
                                          bool &row_on, bool &col_on, int32_t &Hrow, int32_t &Hcol, int32_t &best, int32_t &bt, int32_t &bl, int32_t &steps) {
     using namespace swb;
     const uint32_t sd = L.down, sr = 1u - sd;
@@ -1107,7 +1107,7 @@ __device__ __forceinline__ void swb_step(LANE &L, const int32_t t, uint2 &rec, c
         L.C0 = (L.C0 << sr) | (uint64_t)(ct & 1u); L.C1 = (L.C1 << sr) | (uint64_t)(ct >> 1);
     }
     const Planes p = {L.P.v0 << sr, L.P.v1 << sr, L.P.v2 << sr}, q = {L.Q.v0 >> sd, L.Q.v1 >> sd, L.Q.v2 >> sd};
-    uint64_t xm = (L.R0 ^ L.C0) | (L.R1 ^ L.C1);
+    uint64_t xm = lut3<(uint8_t)((TA ^ TB) | TC)>(L.R0, L.C0, L.R1 ^ L.C1);
     const int32_t kr = nq - 1 - L.i0, kc = t - (nt - 1) - L.i0;      // lanes of the last row / the last column
     if (CHECKED) {   // bases past the read's / the window's end never match
         const int32_t nv = kr + 1;                                    // lanes k < nv hold read bases
@@ -1119,7 +1119,7 @@ __device__ __forceinline__ void swb_step(LANE &L, const int32_t t, uint2 &rec, c
     uint64_t D, G;
     cells<uint64_t>(xm, f, (uint64_t)0 - (uint64_t)sd, p, q, &L.P, &L.Q, &D, &G);
     rec = make_uint2((uint32_t)(D >> 16), (uint32_t)(G >> 16));      // what leaves is the middle of the band: lanes 16..47
-    L.mvacc |= (uint64_t)sd << (t & 63);
+    mv8 |= sd << s8;                                                 // the group's moves (the caller puts them into the block's move word)
     // the edge cells' scores: every lane's cell moved down (its vertical difference) or right (its horizontal one)
     const uint32_t dm = 0u - sd;
     const uint32_t xl0 = ((uint32_t)L.Q.v0 & dm) | ((uint32_t)L.P.v0 & ~dm), xl1 = ((uint32_t)L.Q.v1 & dm) | ((uint32_t)L.P.v1 & ~dm), xl2 = ((uint32_t)L.Q.v2 & dm) | ((uint32_t)L.P.v2 & ~dm);
@@ -1194,6 +1194,7 @@ __global__ void __launch_bounds__(256) k_swb(const uint64_t *__restrict__ n_b_de
     bool row_on = false, col_on = false;
     int32_t Hrow = 0, Hcol = 0, best = NEGV, bt = -1, bl = 0, steps = 0;
     int32_t t = 0;                                            // wave-uniform
+    int32_t i0_ref = L.i0;                                    // i0 when the streams were last topped up
     while (__ballot(active)) {
         const bool blk_active = active;
         const int32_t i0_blk = L.i0, e2_blk = L.E2;      // (E2 at the block's first step rides in the move word's spare half: where in the band the path is likely to be)
@@ -1205,16 +1206,21 @@ __global__ void __launch_bounds__(256) k_swb(const uint64_t *__restrict__ n_b_de
         for (int g8 = 0; g8 < 64 / SWB_GROUP; g8++) {
             const bool grp_active = active;
             uint2 rec[SWB_GROUP];
+            uint32_t mv8 = 0;
             if (interior) {
 #pragma unroll
-                for (int s8 = 0; s8 < SWB_GROUP; s8++) { swb_step<false>(L, t, rec[s8], nq, nt, max_steps, inner, active, row_on, col_on, Hrow, Hcol, best, bt, bl, steps); t++; }
+                for (int s8 = 0; s8 < SWB_GROUP; s8++) { swb_step<false>(L, t, s8, mv8, rec[s8], nq, nt, max_steps, inner, active, row_on, col_on, Hrow, Hcol, best, bt, bl, steps); t++; }
             } else {
 #pragma unroll
-                for (int s8 = 0; s8 < SWB_GROUP; s8++) { swb_step<true>(L, t, rec[s8], nq, nt, max_steps, inner, active, row_on, col_on, Hrow, Hcol, best, bt, bl, steps); t++; }
+                for (int s8 = 0; s8 < SWB_GROUP; s8++) { swb_step<true>(L, t, s8, mv8, rec[s8], nq, nt, max_steps, inner, active, row_on, col_on, Hrow, Hcol, best, bt, bl, steps); t++; }
             }
+            L.mvacc |= (uint64_t)mv8 << ((t - SWB_GROUP) & 63);
             // the streams top up every 16 steps, and they do it HERE, ahead of a group's stores: taking the word loaded 16 steps ago means waiting on the vector-memory
             // counter, which also counts the mask stores -- at this point the youngest of those are 8 steps old and done, right behind a group they would be in flight
-            if ((g8 & (16 / SWB_GROUP - 1)) == 16 / SWB_GROUP - 1 && !(dbg & 2)) { L.qs.refill(); L.ts.refill(); }
+            if ((g8 & (16 / SWB_GROUP - 1)) == 16 / SWB_GROUP - 1 && !(dbg & 2)) {
+                if constexpr (RING) { const int32_t dq = L.i0 - i0_ref; L.qs.refill(dq); L.ts.refill(16 - dq); i0_ref = L.i0; }      // (16 steps: one base each, a read base on a DOWN move)
+                else { L.qs.refill(); L.ts.refill(); }
+            }
             if (grp_active && !(dbg & 1)) {      // what leaves is the middle of the band: lanes 16..47 of D and of G, 8 B per step (the walker says so if its path ever needs more)
 #pragma unroll
                 for (int s8 = 0; s8 < SWB_GROUP; s8 += 2)

@@ -72,23 +72,21 @@ FZP_HD PlanesT<W> minus(const PlanesT<W> a, const PlanesT<W> b) {
 // One anti-diagonal of cells.  xm: mismatch bits; f: forbid bits (at most the band-edge lane); dn: all ones when the step moved DOWN, else zero.
 // p, q: the neighbours' planes lined up with the cells (already shifted).  Returns the cells' planes and the two trace-back masks of the step:
 // D = diagonal chosen, G = "the gap comes from the same lane of the previous step" (the cell above after DOWN, the one to the left after RIGHT;
-// defined where D = 0, the only place the walk looks at it).  25 three-input functions: max(p, q) by a borrow chain and three selects, the step's e folded
+// defined where D = 0, the only place the walk looks at it).  26 functions of up to three inputs: max(p, q) by a borrow chain and three selects, the step's e folded
 // into its planes, two borrow-free subtractions; D needs only "max(p, q) <= 1"; and where the diagonal lost, q >= p  <=>  Pv = 0, p >= q  <=>  Qv = 0.
 template <class W>
 FZP_HD void cells(const W xm, const W f, const W dn, const PlanesT<W> p, const PlanesT<W> q, PlanesT<W> *Pv, PlanesT<W> *Qv, W *D, W *G) {
     constexpr uint8_t BORROW = (uint8_t)((~TA & TB) | (~(TA ^ TB) & TC));
     constexpr uint8_t SEL = (uint8_t)((TA & TB) | (~TA & TC));                 // a ? b : c
-    const W x = xm | f;                              // "not a match" for the value logic
-    const W xz = lut3<(uint8_t)(TA & ~TB)>(xm, f, (W)0);      // a plain mismatch: e = 1
     const W b0 = lut3<(uint8_t)(~TA & TB)>(p.v0, q.v0, (W)0);
     const W b1 = lut3<BORROW>(p.v1, q.v1, b0);
     const W lt = lut3<BORROW>(p.v2, q.v2, b1);       // p < q
     const W m0 = lut3<SEL>(lt, q.v0, p.v0), m1 = lut3<SEL>(lt, q.v1, p.v1), m2 = lut3<SEL>(lt, q.v2, p.v2);      // max(p, q)
     const W t = m1 | m2;                             // max(p, q) >= 2
-    PlanesT<W> M;                                    // max(p, q, e):  match -> 4;  mismatch -> at least 1;  forbid -> max(p, q)
-    M.v2 = lut3<(uint8_t)(TA | ~TB)>(m2, x, (W)0);
-    M.v1 = m1 & x;
-    M.v0 = lut3<(uint8_t)(TA | (TB & ~TC))>(m0 & x, xz, t);
+    PlanesT<W> M;                                    // max(p, q, e):  match -> 4;  mismatch -> at least 1;  forbid -> max(p, q).  "Not a match" for the value logic: xm | f
+    M.v2 = lut3<(uint8_t)(TA | ~(TB | TC))>(m2, xm, f);
+    M.v1 = lut3<(uint8_t)(TA & (TB | TC))>(m1, xm, f);
+    M.v0 = lut3<(uint8_t)(TA & (TB | TC))>(m0, xm, f) | lut3<(uint8_t)(TA & ~TB & ~TC)>(xm, f, t);      // ... | a plain mismatch (e = 1) where max(p, q) < 2
     const PlanesT<W> P = minus(M, q), Q = minus(M, p);
     *Pv = P; *Qv = Q;
     *D = lut3<(uint8_t)(~TA & (~TB | ~TC))>(f, xm, t);                          // ~f & (match | max(p, q) <= 1)
@@ -122,7 +120,7 @@ FZP_HD void half_step(Half &h, const uint32_t my, const uint32_t base, const Hal
     h.Wm0 = (h.Wm0 << my) | (base & 1u); h.Wm1 = (h.Wm1 << my) | (base >> 1);
     h.B.v0 = (h.B.v0 >> ot) | ((in.a0 & ot) << 31); h.B.v1 = (h.B.v1 >> ot) | ((in.a1 & ot) << 31); h.B.v2 = (h.B.v2 >> ot) | ((in.a2 & ot) << 31);
     h.Wo0 = (h.Wo0 >> ot) | ((in.w0 & ot) << 31); h.Wo1 = (h.Wo1 >> ot) | ((in.w1 & ot) << 31);
-    const uint32_t xm = ((h.Wm0 ^ h.Wo0) | (h.Wm1 ^ h.Wo1)) | bad;
+    const uint32_t xm = lut3<(uint8_t)((TA ^ TB) | TC)>(h.Wm0, h.Wo0, h.Wm1 ^ h.Wo1) | bad;
     Planes32 nA, nB;
     cells<uint32_t>(xm, f, 0u - ot, h.A, h.B, &nA, &nB, D, G);
     h.A = nA; h.B = nB;
