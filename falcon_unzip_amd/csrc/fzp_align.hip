@@ -1014,6 +1014,8 @@ struct LaneStream {                // upcoming bases of one sequence, per lane: 
         have -= (int32_t)en;
         return c;
     }
+    __device__ __forceinline__ uint32_t peek() const { return (uint32_t)cur; }      // the next base in bits 1:0 (what lies above is the bases after it)
+    __device__ __forceinline__ void drop(uint32_t en) { cur >>= 2u * en; have -= (int32_t)en; }
 };
 
 constexpr int SWB_RING = 64;                          // words per lane in a stream's ring
@@ -1075,11 +1077,8 @@ struct LaneStreamL {
             gw += (uint32_t)SWB_HOLD;
         }
     }
-    __device__ __forceinline__ uint32_t pop(uint32_t en) {
-        const uint32_t c = (uint32_t)cur & (0u - en) & 3u;
-        cur >>= 2u * en;
-        return c;
-    }
+    __device__ __forceinline__ uint32_t peek() const { return (uint32_t)cur; }      // the next base in bits 1:0
+    __device__ __forceinline__ void drop(uint32_t en) { cur >>= 2u * en; }           // en = 1: that base is taken
 };
 
 template <class STREAM>
@@ -1102,9 +1101,13 @@ __device__ __forceinline__ void swb_step(LANE &L, const int32_t t, const int s8,
     const uint32_t sd = L.down, sr = 1u - sd;
     L.i0 += (int32_t)sd;
     {   // the windows slide: a new read base enters at lane 63 (DOWN), a new contig base at lane 0 (RIGHT)
-        const uint32_t cq = L.qs.pop(sd), ct = L.ts.pop(sr);
-        L.R0 = (L.R0 >> sd) | ((uint64_t)(cq << 31) << 32); L.R1 = (L.R1 >> sd) | ((uint64_t)((cq << 30) & 0x80000000u) << 32);
-        L.C0 = (L.C0 << sr) | (uint64_t)(ct & 1u); L.C1 = (L.C1 << sr) | (uint64_t)(ct >> 1);
+        // (funnel shifts take the entering read base straight from the stream's word: on a RIGHT move they shift by nothing and it stays where it is)
+        const uint32_t wq = L.qs.peek(), wt = L.ts.peek();      // the next base of either stream in bits 1:0
+        const uint32_t r0l = (uint32_t)L.R0, r0h = (uint32_t)(L.R0 >> 32), r1l = (uint32_t)L.R1, r1h = (uint32_t)(L.R1 >> 32);
+        L.R0 = ((uint64_t)__builtin_amdgcn_alignbit(wq, r0h, sd) << 32) | __builtin_amdgcn_alignbit(r0h, r0l, sd);
+        L.R1 = ((uint64_t)__builtin_amdgcn_alignbit(wq >> 1, r1h, sd) << 32) | __builtin_amdgcn_alignbit(r1h, r1l, sd);
+        L.C0 = (L.C0 << sr) | (uint64_t)(wt & sr); L.C1 = (L.C1 << sr) | (uint64_t)((wt >> 1) & sr);
+        L.qs.drop(sd); L.ts.drop(sr);
     }
     const Planes p = {L.P.v0 << sr, L.P.v1 << sr, L.P.v2 << sr}, q = {L.Q.v0 >> sd, L.Q.v1 >> sd, L.Q.v2 >> sd};
     uint64_t xm = lut3<(uint8_t)((TA ^ TB) | TC)>(L.R0, L.C0, L.R1 ^ L.C1);
@@ -1115,17 +1118,20 @@ __device__ __forceinline__ void swb_step(LANE &L, const int32_t t, const int s8,
         const uint64_t bad_c = kc <= 0 ? 0ull : (kc >= 64 ? ~0ull : ~(~0ull << kc));   // lanes k >= kc hold contig bases
         xm |= bad_r | bad_c;
     }
-    const uint64_t f = ((uint64_t)((sd & L.pdown) << 31) << 32) | (uint64_t)(sr & (1u - L.pdown));      // two moves the same way: the edge lane's diagonal predecessor is outside the band
+    const uint64_t f = ((uint64_t)((sd & L.pdown) << 31) << 32) | (uint64_t)lut3<(uint8_t)(TA & ~TB)>(sr, L.pdown, 0u);      // two moves the same way: the edge lane's diagonal predecessor is outside the band
     uint64_t D, G;
     cells<uint64_t>(xm, f, (uint64_t)0 - (uint64_t)sd, p, q, &L.P, &L.Q, &D, &G);
     rec = make_uint2((uint32_t)(D >> 16), (uint32_t)(G >> 16));      // what leaves is the middle of the band: lanes 16..47
     mv8 |= sd << s8;                                                 // the group's moves (the caller puts them into the block's move word)
-    // the edge cells' scores: every lane's cell moved down (its vertical difference) or right (its horizontal one)
+    // the edge cells' scores: every lane's cell moved down (its vertical difference) or right (its horizontal one).  (Spelled out as three-input selects: left to
+    // itself the compiler spends two instructions on each of the six words and as many again on putting the bits together.)
+    constexpr uint8_t SEL = (uint8_t)((TA & TB) | (~TA & TC));                 // a ? b : c
     const uint32_t dm = 0u - sd;
-    const uint32_t xl0 = ((uint32_t)L.Q.v0 & dm) | ((uint32_t)L.P.v0 & ~dm), xl1 = ((uint32_t)L.Q.v1 & dm) | ((uint32_t)L.P.v1 & ~dm), xl2 = ((uint32_t)L.Q.v2 & dm) | ((uint32_t)L.P.v2 & ~dm);
-    const uint32_t xh0 = ((uint32_t)(L.Q.v0 >> 32) & dm) | ((uint32_t)(L.P.v0 >> 32) & ~dm), xh1 = ((uint32_t)(L.Q.v1 >> 32) & dm) | ((uint32_t)(L.P.v1 >> 32) & ~dm),
-                   xh2 = ((uint32_t)(L.Q.v2 >> 32) & dm) | ((uint32_t)(L.P.v2 >> 32) & ~dm);
-    const int32_t v0 = (int32_t)((xl0 & 1u) | ((xl1 & 1u) << 1) | ((xl2 & 1u) << 2)), v63 = (int32_t)((xh0 >> 31) | ((xh1 >> 31) << 1) | ((xh2 >> 31) << 2));
+    const uint32_t xl0 = lut3<SEL>(dm, (uint32_t)L.Q.v0, (uint32_t)L.P.v0), xl1 = lut3<SEL>(dm, (uint32_t)L.Q.v1, (uint32_t)L.P.v1), xl2 = lut3<SEL>(dm, (uint32_t)L.Q.v2, (uint32_t)L.P.v2);
+    const uint32_t xh0 = lut3<SEL>(dm, (uint32_t)(L.Q.v0 >> 32), (uint32_t)(L.P.v0 >> 32)), xh1 = lut3<SEL>(dm, (uint32_t)(L.Q.v1 >> 32), (uint32_t)(L.P.v1 >> 32)),
+                   xh2 = lut3<SEL>(dm, (uint32_t)(L.Q.v2 >> 32), (uint32_t)(L.P.v2 >> 32));
+    const int32_t v0 = (int32_t)(lut3<SEL>(3u, lut3<SEL>(1u, xl0, xl1 << 1), xl2 << 2) & 7u);                 // bit 0 of the three low words
+    const int32_t v63 = (int32_t)lut3<SEL>(3u, lut3<SEL>(1u, xh0 >> 31, xh1 >> 30), xh2 >> 29);             // bit 31 of the three high words
     L.sv0 += v0;
     L.E2 += v63 - v0;
     if (CHECKED) {   // terminal: the best valid cell of the last row / last column, their scores by differences along them
@@ -1143,7 +1149,7 @@ __device__ __forceinline__ void swb_step(LANE &L, const int32_t t, const int s8,
         }
     }
     L.pdown = sd;
-    L.down = (CHECKED && (t + 1) < 64) ? (uint32_t)(((t + 1) & 1) == 0) : (uint32_t)(L.E2 >= 0);
+    L.down = (CHECKED && (t + 1) < 64) ? (uint32_t)(((t + 1) & 1) == 0) : ((uint32_t)L.E2 >> 31) ^ 1u;      // DOWN while lane 63's cell scores at least lane 0's
 }
 
 constexpr int SWB_WPG = 1;        // waves per workgroup of k_swb (four measured: 10.1 against 9.7 ms)
