@@ -21,6 +21,7 @@
 #include <deque>
 #include <functional>
 #include <future>
+#include <string_view>
 #include <thread>
 #include <unordered_map>
 
@@ -248,30 +249,57 @@ struct TextBuf {
     }
 };
 
-// get_phasing_readmap for one contig from records instead of text: preads = the contig's phased_reads rows (ascending
-// (q_id, block)), names by q_id.  -> rid_to_phase.<ctg> text + records.  Same semantics and messages as fzp_readmap.
-int readmap_apply(const ReadMaps &m, const char *ctg_id, int32_t ctg_index, const fzp_pread *pr, int64_t n_pr, const std::vector<int64_t> &qoff, const std::string &qnames,
-                  std::vector<fzp_r2p> &recs, std::string &text, std::string &err) {
+// get_phasing_readmap for one contig from records instead of text, in two halves.  readmap_rows: everything the contig's rows of pread_to_contigs decide on their
+// own -- which rows count (name starts with the contig id, rank 0: phasing_readmap.py:41-43), the raw read behind each pread (lines 20-23, 44-45), later rows of a pread
+// replacing earlier ones, the canonical output order -- resolved down to "the aligned read of this NAME, if there is one".  It needs the q_id -> name table only, so it
+// runs on the host threads while the device is still phasing.  readmap_fill: the phased reads (ascending (q_id, block); the last row of a name wins, lines 29-33) ->
+// rid_to_phase.<ctg> text + records.  Same semantics and messages as fzp_readmap.
+struct ReadmapRows {
+    std::vector<int32_t> name_of_q;              // per q_id: the id of its name among the contig's distinct read names
+    int32_t n_names = 0;
+    std::vector<long long> pid;                  // the rows that count, canonical order
+    std::vector<int32_t> nid;                    // ... and the name id of each one's raw read (-1: no aligned read of that name)
+};
+inline uint64_t name_hash(const char *s, size_t n) {      // FNV-1a, folded
+    uint64_t h = 1469598103934665603ull;
+    for (size_t i = 0; i < n; i++) { h ^= (uint8_t)s[i]; h *= 1099511628211ull; }
+    return h ^ (h >> 29);
+}
+int readmap_rows(const ReadMaps &m, const char *ctg_id, const std::vector<int64_t> &qoff, const std::string &qnames, ReadmapRows &R, std::string &err) {
     if (m.short_row) { err = "pread_to_contigs: short row"; return FZP_EINVAL; }
-    std::unordered_map<std::string, std::pair<int, int>> rid_to_phase;    // lines 29-33, last line wins
-    rid_to_phase.reserve((size_t)n_pr * 2 + 16);
-    for (int64_t i = 0; i < n_pr; i++) {
-        const int32_t q = pr[i].q_id;
-        rid_to_phase[qnames.substr((size_t)qoff[(size_t)q], (size_t)(qoff[(size_t)q + 1] - qoff[(size_t)q]))] = {pr[i].block, pr[i].phase};
+    const size_t nq = qoff.size() - 1;
+    // the contig's distinct read names: an open-addressing table of q ids (no node per name: twenty of these run side by side)
+    size_t cap = 16;
+    while (cap < 2 * nq + 2) cap <<= 1;
+    std::vector<int32_t> slot(cap, -1);                                    // -> the first q_id of the name
+    std::vector<int32_t> id_of_q(nq, 0);
+    auto name_of = [&](size_t q) { return std::string_view(qnames.data() + qoff[q], (size_t)(qoff[q + 1] - qoff[q])); };
+    auto find = [&](std::string_view nm) -> int32_t {                      // the slot of the name, or of the free place it would take
+        size_t h = (size_t)name_hash(nm.data(), nm.size()) & (cap - 1);
+        while (slot[h] >= 0 && name_of((size_t)slot[h]) != nm) h = (h + 1) & (cap - 1);
+        return (int32_t)h;
+    };
+    R.name_of_q.resize(nq);
+    int32_t n_names = 0;
+    for (size_t q = 0; q < nq; q++) {
+        const int32_t h = find(name_of(q));
+        if (slot[(size_t)h] < 0) { slot[(size_t)h] = (int32_t)q; id_of_q[q] = n_names++; }
+        R.name_of_q[q] = id_of_q[(size_t)slot[(size_t)h]];
     }
+    R.n_names = n_names;
     const size_t cn = strlen(ctg_id);
-    std::vector<std::pair<long long, std::pair<int, int>>> out;           // (pread id, (block, phase)); later rows of a pread overwrite earlier ones
-    std::unordered_map<long long, size_t> at;
     // names that start with ctg_id (startswith, line 41): a contiguous range of the sorted names
     auto lo = std::lower_bound(m.names.begin(), m.names.end(), std::string(ctg_id));
     struct Pick { size_t name, row; };
-    std::vector<std::pair<const char *, Pick>> order;                     // file order matters for "later rows overwrite": sort the picked rows by address
-    for (auto it = lo; it != m.names.end() && it->size() >= cn && memcmp(it->data(), ctg_id, cn) == 0; ++it) {
+    std::vector<std::pair<const char *, Pick>> order;                     // file order matters for "later rows overwrite": the picked rows by address
+    size_t n_match = 0;
+    for (auto it = lo; it != m.names.end() && it->size() >= cn && memcmp(it->data(), ctg_id, cn) == 0; ++it, ++n_match) {
         const size_t ni = (size_t)(it - m.names.begin());
         for (size_t r = 0; r < m.rows[ni].size(); r++) order.push_back({m.rows[ni][r].pid.s, {ni, r}});
     }
-    std::sort(order.begin(), order.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
-    at.reserve(order.size() * 2 + 16);
+    if (n_match > 1) std::sort(order.begin(), order.end(), [](const auto &a, const auto &b) { return a.first < b.first; });      // (one name: its rows are in file order already)
+    struct Out { long long pid; uint32_t seq; int32_t nid; };
+    std::vector<Out> out;
     out.reserve(order.size());
     for (auto &o : order) {
         const ReadMaps::Row &row = m.rows[o.second.name][o.second.row];
@@ -291,28 +319,38 @@ int readmap_apply(const ReadMaps &m, const char *ctg_id, int32_t ctg_index, cons
         raw /= 10;                                                                    // py2 int division
         if ((size_t)raw >= m.rid_to_oid.size()) { err = "rawread_ids: id " + std::to_string(raw) + " out of range"; return FZP_EINVAL; }
         Tok oid = m.rid_to_oid[(size_t)raw];
-        auto it = rid_to_phase.find(std::string(oid.s, oid.n));
-        const std::pair<int, int> v = it == rid_to_phase.end() ? std::pair<int, int>{-1, 0} : it->second;   // line 46
-        auto a = at.find(pid);
-        if (a == at.end()) { at.emplace(pid, out.size()); out.push_back({pid, v}); } else out[a->second].second = v;
+        const int32_t h = find(std::string_view(oid.s, oid.n));
+        out.push_back({pid, (uint32_t)out.size(), slot[(size_t)h] < 0 ? -1 : id_of_q[(size_t)slot[(size_t)h]]});      // line 46: .get(oid, (-1, 0)) once the phases are known
     }
-    // canonical order: ascending '%09d' string == ascending pread id below 10^9 (py2 dict order is unspecified)
-    std::sort(out.begin(), out.end(), [](const auto &a, const auto &b) {
-        if (a.first < 1000000000LL && b.first < 1000000000LL) return a.first < b.first;      // nine digits: string order == numeric order
+    // canonical order: ascending '%09d' string == ascending pread id below 10^9 (py2 dict order is unspecified); of a pread's rows the LAST one in the file counts
+    std::sort(out.begin(), out.end(), [](const Out &a, const Out &b) {
+        if (a.pid == b.pid) return a.seq < b.seq;
+        if (a.pid < 1000000000LL && b.pid < 1000000000LL) return a.pid < b.pid;      // nine digits: string order == numeric order
         char ka[32], kb[32];
-        snprintf(ka, sizeof ka, "%09lld", a.first); snprintf(kb, sizeof kb, "%09lld", b.first);
+        snprintf(ka, sizeof ka, "%09lld", a.pid); snprintf(kb, sizeof kb, "%09lld", b.pid);
         return strcmp(ka, kb) < 0;
     });
+    R.pid.clear(); R.nid.clear();
+    R.pid.reserve(out.size()); R.nid.reserve(out.size());
+    for (size_t i = 0; i < out.size(); i++)
+        if (i + 1 == out.size() || out[i + 1].pid != out[i].pid) { R.pid.push_back(out[i].pid); R.nid.push_back(out[i].nid); }
+    return FZP_OK;
+}
+void readmap_fill(const ReadmapRows &R, const char *ctg_id, int32_t ctg_index, const fzp_pread *pr, int64_t n_pr, std::vector<fzp_r2p> &recs, std::string &text) {
+    std::vector<std::pair<int, int>> val((size_t)R.n_names, {-1, 0});      // rid_to_phase by name (lines 29-33: the last line of a name wins; a name without one: (-1, 0), line 46)
+    for (int64_t i = 0; i < n_pr; i++) val[(size_t)R.name_of_q[(size_t)pr[i].q_id]] = {pr[i].block, pr[i].phase};
+    const size_t cn = strlen(ctg_id);
     TextBuf b;
-    for (auto &r : out) {                                                              // lines 49-51
+    b.s.reserve(R.pid.size() * (cn + 20));
+    for (size_t i = 0; i < R.pid.size(); i++) {                                        // lines 49-51
+        const std::pair<int, int> v = R.nid[i] < 0 ? std::pair<int, int>{-1, 0} : val[(size_t)R.nid[i]];
         char key[32];
-        snprintf(key, sizeof key, "%09lld", r.first);
+        snprintf(key, sizeof key, "%09lld", R.pid[i]);
         b.s += key; b.s.push_back(' '); b.s.append(ctg_id, cn); b.s.push_back(' ');
-        b.puti(r.second.first); b.s.push_back(' '); b.puti(r.second.second); b.s.push_back('\n');
-        recs.push_back({(int32_t)r.first, ctg_index, r.second.first, r.second.second});
+        b.puti(v.first); b.s.push_back(' '); b.puti(v.second); b.s.push_back('\n');
+        recs.push_back({(int32_t)R.pid[i], ctg_index, v.first, v.second});
     }
     text.swap(b.s);
-    return FZP_OK;
 }
 
 bool mkdir_p(const std::string &path) {
@@ -345,6 +383,35 @@ void add(fzp_pipe_out *a, const fzp_pipe_out &b) {
 }
 }  // namespace
 
+// test hook (tests/test_host_logic.py, CPU only): the read map of one contig the way fzp_job_phase_write makes it -- from phased-read RECORDS and the q_id name table, in its
+// two halves (readmap_rows under the phasing kernels, readmap_fill behind them) -- so that it can be held against fzp_readmap, which works from the files' text.
+extern "C" int fzp_debug_readmap_records(const char *rawread_ids, size_t rr_len, const char *pread_ids, size_t pi_len, const char *pread_to_contigs, size_t pc_len, const char *ctg_id,
+                                         int32_t ctg_index, const fzp_pread *preads, int64_t n_preads, const int64_t *name_off, const char *names, int32_t n_q, fzp_r2p **recs,
+                                         int64_t *n_recs, char **text, size_t *text_len) {
+    if (!ctg_id || !name_off || !names || n_q < 0 || n_preads < 0 || (n_preads && !preads) || !recs || !n_recs || !text || !text_len) { fzp_set_error("fzp_debug_readmap_records: bad arguments"); return FZP_EINVAL; }
+    fzp_pipe_opts o;
+    fzp_pipe_opts_default(&o);
+    o.rawread_ids = rawread_ids; o.rr_len = rr_len; o.pread_ids = pread_ids; o.pi_len = pi_len; o.pread_to_contigs = pread_to_contigs ? pread_to_contigs : ""; o.pc_len = pread_to_contigs ? pc_len : 0;
+    ReadMaps m;
+    parse_maps(&o, m);
+    for (int64_t i = 0; i < n_preads; i++) if (preads[i].q_id < 0 || preads[i].q_id >= n_q) { fzp_set_error("fzp_debug_readmap_records: q_id out of range"); return FZP_EINVAL; }
+    const std::vector<int64_t> qoff(name_off, name_off + n_q + 1);
+    const std::string qn(names, (size_t)name_off[n_q]);
+    ReadmapRows R;
+    std::string err, txt;
+    const int rc = readmap_rows(m, ctg_id, qoff, qn, R, err);
+    if (rc != FZP_OK) { fzp_set_error("%s", err.c_str()); return rc; }
+    std::vector<fzp_r2p> out;
+    readmap_fill(R, ctg_id, ctg_index, preads, n_preads, out, txt);
+    *recs = (fzp_r2p *)malloc((out.size() ? out.size() : 1) * sizeof(fzp_r2p));
+    *text = (char *)malloc(txt.size() + 1);
+    if (!*recs || !*text) { free(*recs); free(*text); fzp_set_error("fzp_debug_readmap_records: host memory"); return FZP_ENOMEM; }
+    if (!out.empty()) memcpy(*recs, out.data(), out.size() * sizeof(fzp_r2p));
+    memcpy(*text, txt.data(), txt.size()); (*text)[txt.size()] = 0;
+    *n_recs = (int64_t)out.size(); *text_len = txt.size();
+    return FZP_OK;
+}
+
 extern "C" void fzp_pipe_opts_default(fzp_pipe_opts *o) {
     memset(o, 0, sizeof *o);
     fzp_align_params_default(&o->align);
@@ -363,25 +430,85 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
     struct BG { fzp_ctx *c; fzp_batch *b; ~BG() { fzp_batch_destroy(c, b); } } bg{ctx, b};
     out->ms_k1 += ms_since(t0);
     t0 = clk::now();
+    const int nc = b->n_ctg;
+    static const bool timing = getenv("FZP_PIPE_TIMING") != nullptr;
+    std::atomic<int64_t> us_names{0}, us_fmt{0}, us_map{0}, us_write{0};
+    int T = o->n_threads > 0 ? o->n_threads : (int)std::min(64u, std::max(1u, std::thread::hardware_concurrency()));
+    if (!ctx->workers || ctx->workers->size() < std::min(T, nc)) {        // grown on demand, kept for the next call
+        delete ctx->workers;
+        ctx->workers = new WorkPool();
+        ctx->workers->start(std::max(0, std::min(T, std::max(nc, 8)) - 1), ctx->device);
+    }
+    const int want_threads = std::max(1, std::min(T, nc));
+    T = ctx->workers->size();
+    // ---- what K1 alone decides goes to the host threads NOW, under the phasing kernels: the q_id -> read table comes over, and per contig the q_id names, q_id_map and the
+    // read-map rows resolved down to read names (readmap_rows) are made while the device runs K2..K5
+    const int64_t n_slots = b->h_slot_off.empty() ? 0 : b->h_slot_off.back();
+    hipStream_t st2 = ctx->stream2;
+    struct Ev { hipEvent_t e = nullptr; ~Ev() { if (e) (void)hipEventDestroy(e); } } ev_k1, ev_q, ev_t;
+    FZP_HIP(hipEventCreateWithFlags(&ev_k1.e, hipEventDisableTiming));
+    FZP_HIP(hipEventCreateWithFlags(&ev_q.e, hipEventDisableTiming));
+    FZP_HIP(hipEventCreateWithFlags(&ev_t.e, hipEventDisableTiming));
+    struct PinQ { fzp_ctx *c; void *p = nullptr; ~PinQ() { if (p) fzp_pinned_release(c, p); } } pin_q{ctx};
+    size_t pin_q_cap = 0;
+    pin_q.p = fzp_pinned_acquire(ctx, (size_t)n_slots * 4 + 64, &pin_q_cap);
+    if (!pin_q.p) { fzp_set_error("pinned host allocation failed"); return FZP_ENOMEM; }
+    struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamSynchronize(s); } } sg2{st2};     // nothing below may leave while copies into pinned blocks are in flight
+    FZP_HIP(hipEventRecord(ev_k1.e, ctx->stream));
+    FZP_HIP(hipStreamWaitEvent(st2, ev_k1.e, 0));
+    if (n_slots) FZP_HIP(hipMemcpyAsync(pin_q.p, b->qid_read.p, (size_t)n_slots * 4, hipMemcpyDeviceToHost, st2));
+    FZP_HIP(hipEventRecord(ev_q.e, st2));
+    const int32_t *qid_read = (const int32_t *)pin_q.p;
+    struct PreCtg { std::vector<int64_t> qoff; std::string qn, qmap; ReadmapRows rows; int rc = FZP_OK; std::string err; };
+    std::vector<PreCtg> pre((size_t)nc);
+    const std::function<void(int, int)> pre_work = [&](int, int c) {
+        PreCtg &P = pre[(size_t)c];
+        auto tq = clk::now();
+        // q_id table of the contig: aligned reads in (POS, read) order
+        const int64_t nq = b->h_qid_off[(size_t)c + 1] - b->h_qid_off[(size_t)c];
+        const int32_t *qr = qid_read + b->h_slot_off[(size_t)c];
+        P.qoff.assign((size_t)nq + 1, 0);
+        for (int64_t q = 0; q < nq; q++) {
+            const int64_t r = qr[q];
+            if (nm->names && nm->name_off) P.qn.append(nm->names + nm->name_off[r], (size_t)(nm->name_off[r + 1] - nm->name_off[r]));
+            else { char tt[40]; snprintf(tt, sizeof tt, "read/%lld", (long long)r); P.qn += tt; }
+            P.qoff[(size_t)q + 1] = (int64_t)P.qn.size();
+        }
+        us_names += (int64_t)(ms_since(tq) * 1e3); tq = clk::now();
+        {
+            TextBuf tb;
+            tb.s.reserve(P.qn.size() + (size_t)nq * 12);
+            for (int64_t q = 0; q < nq; q++) { tb.puti(q); tb.s.push_back(' '); tb.s.append(P.qn, (size_t)P.qoff[(size_t)q], (size_t)(P.qoff[(size_t)q + 1] - P.qoff[(size_t)q])); tb.s.push_back('\n'); }   // phasing.py:132-134
+            P.qmap.swap(tb.s);
+        }
+        us_fmt += (int64_t)(ms_since(tq) * 1e3); tq = clk::now();
+        if (const ReadMaps *mp = mh.get()) P.rc = readmap_rows(*mp, nm->ctg_id[c], P.qoff, P.qn, P.rows, P.err);
+        us_map += (int64_t)(ms_since(tq) * 1e3);
+    };
+    std::string early_err;
+    std::thread early([&]() {
+        if (hipSetDevice(ctx->device) != hipSuccess || hipEventSynchronize(ev_q.e) != hipSuccess) { (void)hipGetLastError(); early_err = "the q_id table did not arrive"; return; }
+        ctx->workers->run(nc, pre_work, std::min(want_threads, 6));      // (a few threads: there are milliseconds to do this in, and the thread that launches the kernels wants a core)
+    });
+    struct Join { std::thread &t; ~Join() { if (t.joinable()) t.join(); } } early_join{early};      // (declared after everything the thread touches)
     FZP_TRY(fzp_batch_run(ctx, b, FZP_STAGE_ALL));
     out->ms_phase += ms_since(t0);
     t0 = clk::now();
-    const int nc = b->n_ctg;
     fzp_tigs tigs;
     memset(&tigs, 0, sizeof tigs);
     const bool want_cns = (o->flags & FZP_PIPE_CONSENSUS) != 0;
     if (want_cns) FZP_TRY(fzp_batch_consensus(ctx, b, &tigs));       // K6 of every (block, phase) pile -> <ctg>/cns/phased_blocks.fa
     struct TG { fzp_tigs *t; ~TG() { fzp_tigs_free(t); } } tg{&tigs};
-    // the two big texts: serialised on the device, brought over while the records come
+    // the two big texts: serialised on the device, brought over while the records come.  (Serialising them right behind K3 and copying them under K4 / K5 was
+    // measured: the phasing stage grew by more than the host section shrank -- that section is bound by its own formatting, not by these copies.)
     DevBuf<char> d_vmap, d_atab;
     size_t n_vmap = 0, n_atab = 0;
     std::vector<int64_t> vb, ab;
     FZP_TRY(fzp_batch_text_dev(ctx, b, FZP_TEXT_VARIANT_MAP, d_vmap, &n_vmap, vb));
     FZP_TRY(fzp_batch_text_dev(ctx, b, FZP_TEXT_ATABLE, d_atab, &n_atab, ab));
-    const int64_t n_slots = b->h_slot_off.empty() ? 0 : b->h_slot_off.back();
     size_t pin_cap = 0;
-    const size_t o_atab = (n_vmap + 63) & ~(size_t)63, o_qr = o_atab + ((n_atab + 63) & ~(size_t)63);
-    char *pin = (char *)fzp_pinned_acquire(ctx, o_qr + (size_t)n_slots * 4 + 64, &pin_cap);
+    const size_t o_atab = (n_vmap + 63) & ~(size_t)63, o_end = o_atab + ((n_atab + 63) & ~(size_t)63);
+    char *pin = (char *)fzp_pinned_acquire(ctx, o_end + 64, &pin_cap);
     if (!pin) { fzp_set_error("pinned host allocation failed"); return FZP_ENOMEM; }
     // the block (and the small texts) live until their last file is written: shared by the per-contig write tasks
     struct Owned {
@@ -393,24 +520,14 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
     const bool async = (o->flags & FZP_PIPE_ASYNC_WRITES) != 0 && o->out_dir;
     if (async && !ctx->writer) { ctx->writer = new FileWriter(); ctx->writer->start((int)std::min(16u, std::max(2u, std::thread::hardware_concurrency() / 4))); }
     if (async) { const std::string e = [&] { std::lock_guard<std::mutex> lk(ctx->writer->mu); std::string x; x.swap(ctx->writer->first_error); return x; }(); if (!e.empty()) { fzp_set_error("%s", e.c_str()); return FZP_EINVAL; } }
-    hipStream_t st2 = ctx->stream2;
     FZP_HIP(hipStreamSynchronize(ctx->stream));
-    // the q_id -> read table first (the host threads need it at once), the two big texts behind it: they only have to be there when a
-    // contig's write task is made, so their copy runs under the formatting of the small files
-    struct Ev { hipEvent_t e = nullptr; ~Ev() { if (e) (void)hipEventDestroy(e); } } ev_q, ev_t;
-    FZP_HIP(hipEventCreateWithFlags(&ev_q.e, hipEventDisableTiming));
-    FZP_HIP(hipEventCreateWithFlags(&ev_t.e, hipEventDisableTiming));
-    struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamSynchronize(s); } } sg2{st2};     // nothing below may leave while copies into `pin` are in flight
-    if (n_slots) FZP_HIP(hipMemcpyAsync(pin + o_qr, b->qid_read.p, (size_t)n_slots * 4, hipMemcpyDeviceToHost, st2));
-    FZP_HIP(hipEventRecord(ev_q.e, st2));
+    // they only have to be there when a contig's write task is made: their copy runs under the formatting of the small files
     if (n_vmap) FZP_HIP(hipMemcpyAsync(pin, d_vmap.p, n_vmap, hipMemcpyDeviceToHost, st2));
     if (n_atab) FZP_HIP(hipMemcpyAsync(pin + o_atab, d_atab.p, n_atab, hipMemcpyDeviceToHost, st2));
     FZP_HIP(hipEventRecord(ev_t.e, st2));
     fzp_result_all ra;
     FZP_TRY(fzp_batch_result_all(ctx, b, &ra));                  // sites / variant_map ids / atable rows are not needed on the host here, but the views are free
     struct RG { fzp_result_all *r; ~RG() { fzp_result_all_free(r); } } rg{&ra};
-    FZP_HIP(hipEventSynchronize(ev_q.e));
-    const int32_t *qid_read = (const int32_t *)(pin + o_qr);
     const ReadMaps *maps = mh.get();
     // the blasr task's BAM from the same pass: records come down here (device part), are split into '=' / 'X' and compressed by the contig's write task
     struct BamJob {
@@ -425,17 +542,9 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
     }
     out->ms_results += ms_since(t0);
     t0 = clk::now();
-    static const bool timing = getenv("FZP_PIPE_TIMING") != nullptr;
-    std::atomic<int64_t> us_names{0}, us_fmt{0}, us_map{0}, us_write{0};
     // ---- per contig: the small files on host threads, all files written
-    int T = o->n_threads > 0 ? o->n_threads : (int)std::min(64u, std::max(1u, std::thread::hardware_concurrency()));
-    if (!ctx->workers || ctx->workers->size() < std::min(T, nc)) {        // grown on demand, kept for the next call
-        delete ctx->workers;
-        ctx->workers = new WorkPool();
-        ctx->workers->start(std::max(0, std::min(T, std::max(nc, 8)) - 1), ctx->device);
-    }
-    const int want_threads = std::max(1, std::min(T, nc));
-    T = ctx->workers->size();
+    early.join();                                                // (the early half: long done)
+    if (!early_err.empty()) { fzp_set_error("%s", early_err.c_str()); return FZP_EDEVICE; }
     std::atomic<int64_t> bytes{0};
     std::vector<int> rcs((size_t)T, FZP_OK);
     std::vector<std::string> errs((size_t)T);
@@ -452,18 +561,10 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
             if (rcs[(size_t)t] != FZP_OK) return;
             const char *ctg = nm->ctg_id[c];
             auto tq = clk::now();
-            // q_id table of the contig: aligned reads in (POS, read) order
-            const int64_t nq = b->h_qid_off[(size_t)c + 1] - b->h_qid_off[(size_t)c];
-            const int32_t *qr = qid_read + b->h_slot_off[(size_t)c];
-            std::vector<int64_t> qoff((size_t)nq + 1, 0);
-            std::string qn;
-            for (int64_t q = 0; q < nq; q++) {
-                const int64_t r = qr[q];
-                if (nm->names && nm->name_off) qn.append(nm->names + nm->name_off[r], (size_t)(nm->name_off[r + 1] - nm->name_off[r]));
-                else { char tt[40]; snprintf(tt, sizeof tt, "read/%lld", (long long)r); qn += tt; }
-                qoff[(size_t)q + 1] = (int64_t)qn.size();
-            }
-            us_names += (int64_t)(ms_since(tq) * 1e3); tq = clk::now();
+            PreCtg &P = pre[(size_t)c];
+            const std::vector<int64_t> &qoff = P.qoff;           // the q_id names: made by the early half
+            const std::string &qn = P.qn;
+            const int64_t nq = (int64_t)qoff.size() - 1;
             const int64_t s0 = ra.site_begin[c], s1 = ra.site_begin[c + 1], p0 = ra.pvar_begin[c], p1 = ra.pvar_begin[c + 1], r0 = ra.pread_begin[c], r1 = ra.pread_begin[c + 1];
             char *txt[3] = {nullptr, nullptr, nullptr};
             size_t len[3] = {0, 0, 0};
@@ -471,17 +572,14 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
             if (rc == FZP_OK) rc = fzp_format_phased_variants(ra.all.sites, ra.all.pvars + p0, p1 - p0, &txt[1], &len[1]);       // pvars carry batch-wide site indices
             if (rc == FZP_OK) rc = fzp_format_phased_reads(ra.all.preads + r0, r1 - r0, ctg, qoff.data(), qn.data(), (int32_t)nq, &txt[2], &len[2]);
             std::string qmap;
-            {
-                TextBuf tb;
-                tb.s.reserve(qn.size() + (size_t)nq * 12);
-                for (int64_t q = 0; q < nq; q++) { tb.puti(q); tb.s.push_back(' '); tb.s.append(qn, (size_t)qoff[(size_t)q], (size_t)(qoff[(size_t)q + 1] - qoff[(size_t)q])); tb.s.push_back('\n'); }   // phasing.py:132-134
-                qmap.swap(tb.s);
-            }
+            qmap.swap(P.qmap);
             us_fmt += (int64_t)(ms_since(tq) * 1e3); tq = clk::now();
             std::string r2p_text;
             bool have_r2p = false;
             if (rc == FZP_OK && maps) {
-                rc = readmap_apply(*maps, ctg, ctg_index ? ctg_index[c] : c, ra.all.preads + r0, r1 - r0, qoff, qn, recs[(size_t)c], r2p_text, errs[(size_t)t]);
+                rc = P.rc;
+                if (rc == FZP_OK) readmap_fill(P.rows, ctg, ctg_index ? ctg_index[c] : c, ra.all.preads + r0, r1 - r0, recs[(size_t)c], r2p_text);
+                else errs[(size_t)t] = P.err;
                 have_r2p = rc == FZP_OK;
             } else if (rc != FZP_OK) errs[(size_t)t] = fzp_last_error();
             us_map += (int64_t)(ms_since(tq) * 1e3); tq = clk::now();

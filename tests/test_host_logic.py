@@ -76,6 +76,70 @@ def test_readmap(lib, name):
     assert np.all(np.diff(recs["arid"]) > 0)
 
 
+def _readmap_records(lib, rawread_ids, pread_ids, p2c, ctg_id, ctg_index, preads, name_off, names):
+    C = ctypes
+    so = lib.load()
+    f = so.fzp_debug_readmap_records
+    f.restype = C.c_int
+    f.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_char_p, C.c_int32,
+                  C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    preads = np.ascontiguousarray(preads, dtype=lib.PREAD)
+    name_off = np.ascontiguousarray(name_off, dtype=np.int64)
+    rp, nr, tp, tn = C.c_void_p(), C.c_int64(), C.c_void_p(), C.c_size_t()
+    rc = f(rawread_ids, len(rawread_ids), pread_ids, len(pread_ids), p2c, len(p2c), ctg_id.encode(), ctg_index, preads.ctypes.data, len(preads), name_off.ctypes.data, names,
+           len(name_off) - 1, C.byref(rp), C.byref(nr), C.byref(tp), C.byref(tn))
+    if rc != 0:
+        raise lib.FzpError(rc, so.fzp_last_error().decode())
+    recs = np.frombuffer(C.string_at(rp, nr.value * lib.R2P.itemsize), lib.R2P).copy()
+    text = C.string_at(tp, tn.value)
+    so.fzp_free(rp)
+    so.fzp_free(tp)
+    return recs, text
+
+
+def test_read_map_from_records_equals_read_map_from_text(lib):
+    """The read map fzp_job_phase_write makes per contig -- from phased-read RECORDS and the q_id name table, resolved in two halves (the rows of pread_to_contigs down to read
+    names while the device is still phasing; the phases filled in afterwards) -- against fzp_readmap, the restatement of phasing_readmap.py:8-51 that works from the files' text
+    and is pinned by the goldens: preads listed several times (the last row wins), rows of other ranks and of other contigs (also contigs whose id starts with this one's), reads
+    that share a name, reads that are aligned but not phased, raw reads that are not among the aligned ones."""
+    rng = np.random.Generator(np.random.PCG64(99))
+    for trial in range(6):
+        n_raw, n_q = 900, 400
+        rawread_ids = b"".join(b"m/%d/0_%d\n" % (i % 700, 1000 + i % 700) for i in range(n_raw))      # names repeat from 700 on
+        n_pread = 600
+        pread_ids = b"".join(b"x/%d/0_1\n" % (10 * int(rng.integers(0, n_raw)) + int(rng.integers(0, 10))) for _ in range(n_pread))
+        ctg = "000012F"
+        rows = []
+        for _ in range(1500):
+            pid = int(rng.integers(0, n_pread))
+            name = [ctg, ctg, ctg + "-001", "000013F", "0000"][int(rng.integers(0, 5))]
+            rows.append(b"%09d %s 5 %d" % (pid, name.encode(), int(rng.integers(0, 2)) * int(rng.integers(0, 3))))
+        p2c = b"\n".join(rows) + b"\n"
+        # the aligned reads of the contig: names from the raw reads (some shared), q ids in some order; phased reads: a subset, some in two blocks
+        qn = [b"m/%d/0_%d" % (i, 1000 + i) for i in rng.integers(0, 760, n_q)]
+        name_off = np.zeros(n_q + 1, np.int64)
+        name_off[1:] = np.cumsum([len(x) for x in qn])
+        names = b"".join(qn)
+        pr = []
+        for q in range(n_q):
+            for blk in sorted(set(int(x) for x in rng.integers(0, 6, int(rng.integers(0, 3))))):
+                pr.append((q, blk, int(rng.integers(0, 2)), int(rng.integers(0, 9)), int(rng.integers(0, 9))))
+        preads = np.array(pr, lib.PREAD)
+        text_pr = lib.format_phased_reads(preads, ctg, name_off, names)
+        exp_recs, exp_text = lib.readmap(text_pr, rawread_ids, pread_ids, p2c, ctg, 3)
+        recs, text = _readmap_records(lib, rawread_ids, pread_ids, p2c, ctg, 3, preads, name_off, names)
+        assert text == exp_text and len(text) > 3000, trial
+        assert recs.tobytes() == exp_recs.tobytes()
+        assert (recs["block"] == -1).any() and (recs["block"] >= 0).any()
+    # the same messages for the same bad inputs
+    for bad_p2c, bad_pid in ((b"000000005 000012F 5 x\n", pread_ids), (b"000000005 000012F\n", pread_ids), (b"000999999 000012F 5 0\n", pread_ids), (b"000000000 000012F 5 0\n", b"noslash\n")):
+        with pytest.raises(lib.FzpError) as e1:
+            lib.readmap(text_pr, rawread_ids, bad_pid, bad_p2c, ctg, 3)
+        with pytest.raises(lib.FzpError) as e2:
+            _readmap_records(lib, rawread_ids, bad_pid, bad_p2c, ctg, 3, preads, name_off, names)
+        assert str(e1.value) == str(e2.value)
+
+
 def test_parser_errors(lib):
     with pytest.raises(lib.FzpError) as ei:
         lib.parse_sam(b"r1\t0\tc\t1\t254\t*\t*\t0\t0\tACGT\t*\n")
