@@ -138,6 +138,22 @@ def tree_digest(root):
     return h.hexdigest()
 
 
+def thread_cpu():
+    """{tid: (name, user + system seconds)} of this process's threads (/proc/self/task)"""
+    out = {}
+    tck = os.sysconf("SC_CLK_TCK")
+    for t in os.listdir("/proc/self/task"):
+        try:
+            with open("/proc/self/task/%s/stat" % t) as f:
+                st = f.read()
+            nm = st[st.index("(") + 1:st.rindex(")")]
+            fld = st[st.rindex(")") + 2:].split()
+            out[int(t)] = (nm, (int(fld[11]) + int(fld[12])) / tck)
+        except (OSError, ValueError):
+            pass
+    return out
+
+
 def host_cores():
     """threads this process may really use: the affinity mask and the cgroup CPU quota, not the machine's thread count (the GPU boxes show 256
     hardware threads behind a 16-CPU quota)"""
@@ -510,11 +526,18 @@ def main():
     eng.prof_reset()
     eng.prof_enable(True)
     barrier()
+    thr0 = thread_cpu() if os.environ.get("FZP_BENCH_THREAD_CPU") else None
     t0 = time.perf_counter()
+    cpu0 = time.process_time()
     for _ in range(args.steps):
         step()
     barrier()
     dt = time.perf_counter() - t0
+    cpu_ms_per_step = (time.process_time() - cpu0) / args.steps * 1e3      # user + system time of every thread of this rank (launch thread, host workers, file writers)
+    if thr0 is not None and rank == 0:                                     # measurement aid: which threads that time belongs to
+        thr1 = thread_cpu()
+        rows = sorted(((thr1[t][1] - thr0.get(t, (thr1[t][0], 0.0))[1], thr1[t][0], t) for t in thr1), reverse=True)
+        print("thread cpu ms/step: " + ", ".join("%s[%d] %.2f" % (nm, t, d / args.steps * 1e3) for d, nm, t in rows[:24] if d > 0), file=sys.stderr, flush=True)
     eng.prof_enable(False)
     prof = eng.prof()
     n_total = n_reads
@@ -673,6 +696,7 @@ def main():
             "aligned_frac": round(aligned_frac, 4),
             "stage_counts": {k: int(v) for k, v in stats.items()},
             "kernel_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in sorted(prof.items())},
+            "host_cpu_ms_per_step": round(cpu_ms_per_step, 2),
             "host_wall_ms_per_step": dict({k: round(v / args.steps * 1e3, 3) for k, v in host_t.items()}, **{k[3:]: round(v / args.steps, 3) for k, v in sect.items()}),
             "rank_load": rank_load,
             "gather": "fzp_allgather_rid_to_phase (RCCL, C-ABI)" if comm is not None else ("torch.distributed all_gather (%s)" % backend if world > 1 else "none (1 rank)"),

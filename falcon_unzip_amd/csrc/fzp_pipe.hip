@@ -11,6 +11,8 @@
 // File layout = the reference's: <out_dir>/<ctg>/{het_call/{variant_pos,variant_map,q_id_map}, g_atable/atable,
 // get_phased_blocks/phased_variants, phased_reads, rid_to_phase.<ctg>}  (phasing.py:501-503,520,534,543; unzip.py:269).
 #include <fcntl.h>
+#include <sched.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -181,6 +183,25 @@ bool tok_int(Tok t, long long *v) {
     }
     *v = neg ? -x : x;
     return true;
+}
+// threads this process may really use: the affinity mask and the cgroup CPU quota, not the machine's thread count (a container that shows 256 hardware threads
+// behind a 16-CPU quota is throttled to a crawl by 256 busy threads)
+int usable_cores() {
+    int n = (int)std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t cs;
+    if (sched_getaffinity(0, sizeof cs, &cs) == 0) n = std::min(n, std::max(1, CPU_COUNT(&cs)));
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                       // cgroup v2: "<quota> <period>" or "max <period>"
+        char q[64]; long long per = 0;
+        if (fscanf(f, "%63s %lld", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) n = std::min<long long>(n, std::max<long long>(1, (atoll(q) + per - 1) / per));
+        fclose(f);
+    } else if (FILE *f1 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {  // cgroup v1
+        long long quota = -1, per = 0;
+        if (fscanf(f1, "%lld", &quota) != 1) quota = -1;
+        fclose(f1);
+        if (FILE *f2 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(f2, "%lld", &per) != 1) per = 0; fclose(f2); }
+        if (quota > 0 && per > 0) n = std::min<long long>(n, std::max<long long>(1, (quota + per - 1) / per));
+    }
+    return n;
 }
 void split_nl(const char *s, size_t n, std::vector<Tok> &out) {   // text.split('\n')
     size_t off = 0;
@@ -433,7 +454,7 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
     const int nc = b->n_ctg;
     static const bool timing = getenv("FZP_PIPE_TIMING") != nullptr;
     std::atomic<int64_t> us_names{0}, us_fmt{0}, us_map{0}, us_write{0};
-    int T = o->n_threads > 0 ? o->n_threads : (int)std::min(64u, std::max(1u, std::thread::hardware_concurrency()));
+    int T = o->n_threads > 0 ? o->n_threads : std::min(64, std::max(2, usable_cores()));      // (the cores this process may use, not the machine's: a rank of eight behind a CPU quota has two)
     if (!ctx->workers || ctx->workers->size() < std::min(T, nc)) {        // grown on demand, kept for the next call
         delete ctx->workers;
         ctx->workers = new WorkPool();
@@ -518,7 +539,7 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
     std::shared_ptr<Owned> owned = std::make_shared<Owned>();
     owned->c = ctx; owned->pin = pin;
     const bool async = (o->flags & FZP_PIPE_ASYNC_WRITES) != 0 && o->out_dir;
-    if (async && !ctx->writer) { ctx->writer = new FileWriter(); ctx->writer->start((int)std::min(16u, std::max(2u, std::thread::hardware_concurrency() / 4))); }
+    if (async && !ctx->writer) { ctx->writer = new FileWriter(); ctx->writer->start(std::min(16, std::max(2, usable_cores()))); }
     if (async) { const std::string e = [&] { std::lock_guard<std::mutex> lk(ctx->writer->mu); std::string x; x.swap(ctx->writer->first_error); return x; }(); if (!e.empty()) { fzp_set_error("%s", e.c_str()); return FZP_EINVAL; } }
     FZP_HIP(hipStreamSynchronize(ctx->stream));
     // they only have to be there when a contig's write task is made: their copy runs under the formatting of the small files
@@ -848,8 +869,6 @@ extern "C" int fzp_phase_contigs(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *con
 // A group's files are mapped and cut into pieces of a few megabytes at record starts; host threads scan the pieces (memchr) for their records, a prefix sum gives every
 // record its place in the group's buffers, the same threads copy the sequences there -- one copy, no per-file intermediates.  Groups are parsed one AHEAD of the lanes
 // that align them, and their buffers are kept with the context between calls, so what is in host memory at any time is the groups in flight -- not the rank's reads.
-#include <sched.h>
-#include <sys/mman.h>
 // a grow-only byte buffer that is neither zeroed nor copied when it grows: its pages are first touched by the threads that fill it (a std::vector's resize would
 // fill 1 GB from one thread -- 250 ms -- before sixteen threads overwrite it in 15)
 struct RawBuf {
@@ -899,25 +918,6 @@ struct GroupPool {
 };
 static void group_pool_destroy(GroupPool *p) { delete p; }
 namespace {
-// threads this process may really use: the affinity mask and the cgroup CPU quota, not the machine's thread count (a container that shows 256 hardware threads
-// behind a 16-CPU quota is throttled to a crawl by 256 busy threads)
-int usable_cores() {
-    int n = (int)std::max(1u, std::thread::hardware_concurrency());
-    cpu_set_t cs;
-    if (sched_getaffinity(0, sizeof cs, &cs) == 0) n = std::min(n, std::max(1, CPU_COUNT(&cs)));
-    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                       // cgroup v2: "<quota> <period>" or "max <period>"
-        char q[64]; long long per = 0;
-        if (fscanf(f, "%63s %lld", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) n = std::min<long long>(n, std::max<long long>(1, (atoll(q) + per - 1) / per));
-        fclose(f);
-    } else if (FILE *f1 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {  // cgroup v1
-        long long quota = -1, per = 0;
-        if (fscanf(f1, "%lld", &quota) != 1) quota = -1;
-        fclose(f1);
-        if (FILE *f2 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(f2, "%lld", &per) != 1) per = 0; fclose(f2); }
-        if (quota > 0 && per > 0) n = std::min<long long>(n, std::max<long long>(1, (quota + per - 1) / per));
-    }
-    return n;
-}
 struct FaRec { const char *name; int32_t name_len; const char *s0, *s1; int64_t len; bool plain; };      // header's first word; the sequence's lines lie in [s0, s1); len = its bases; plain: one line, nothing to trim
 struct FaPiece { int file; const char *a, *b; std::vector<int64_t> nl; std::vector<FaRec> recs; int64_t bases = 0, name_bytes = 0; bool all_plain = true; };
 inline bool fa_sp(char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\n' || c == '\v' || c == '\f'; }
