@@ -48,8 +48,8 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 SW_BYTES_PER_CELL = 0.25         # algorithmic: 2 trace-back bits per cell (16 B per 64-cell step); sequence
                                  # reads add 2 bits per band step, i.e. < 0.01 B/cell
 # VALU view of k1_sw (the DP stage: k_swb, the bit-sliced kernel with one read per lane, + k_sw for long reads), from measurements kept under profiles/:
-#   profiles/k1_sw_counters.json     SQ_INSTS_VALU of both kernels / 64-cell band steps of the bench step (k_swb: ~135 wave instructions per step of 64 reads)
-SW_VALU_PER_STEP = 2.2
+#   profiles/k1_sw_counters.json     SQ_INSTS_VALU of both kernels / 64-cell band steps of the bench step (k_swb: ~123 wave instructions per step of 64 pieces)
+SW_VALU_PER_STEP = 2.0
 N_SIMD, CLK_GHZ = 1024, 2.4
 
 
