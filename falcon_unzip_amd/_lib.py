@@ -596,6 +596,23 @@ def align_job_raw(eng, contigs, read_blob: bytes, read_off, read_ctg, params=Non
     return AlignJob(eng, p.value, nr, nc)
 
 
+def align_job_spans(eng, contigs, buf: bytes, read_be, read_ctg, params=None) -> AlignJob:
+    """fzp_align_create_spans: read r = buf[read_be[r, 0] : read_be[r, 1]] -- e.g. the bytes of a FASTA file as they are, with the spans of its sequence lines."""
+    lib = load()
+    nc = len(contigs)
+    be = np.ascontiguousarray(read_be, dtype=np.int64).reshape(-1, 2)
+    nr = len(be)
+    cbufs, cptr, clen = _contig_ptrs(contigs)
+    rc = np.ascontiguousarray(read_ctg, dtype=np.int32)
+    P = AlignParams()
+    lib.fzp_align_params_default(C.byref(P))
+    for k, v in (params or {}).items():
+        setattr(P, k, v)
+    p = C.c_void_p()
+    _check(lib.fzp_align_create_spans(eng._p, nc, cptr, clen, nr, _ptr(rc), _ptr(be), buf, C.byref(P), C.byref(p)))
+    return AlignJob(eng, p.value, nr, nc)
+
+
 def _pipe_args(ctg_ids, names, out_dir, read_maps, ctg_index, n_threads, n_lanes, group_bases, params, flags=0):
     lib = load()
     keep = []

@@ -151,6 +151,37 @@ def test_edge_cases_match_twin(eng, oracle):
     job.close()
 
 
+def test_reads_given_as_spans_of_a_buffer(eng):
+    """fzp_align_create_spans (what fzp_phase_contigs_files hands the bytes of <ctg>_reads.fa to): the reads as spans of one buffer -- FASTA headers and line ends between
+    them, the spans in any order, an empty one, two that share bytes -- give the job fzp_align_create makes from the same reads back to back: every summary field and every record."""
+    from falcon_unzip_amd import _lib
+    ctg, reads, raw = _sim(41, 80000, 40, 4000)
+    raw.append(b"")
+    raw.append(raw[3][100:2500])                       # lies inside another read's bytes
+    order = np.random.Generator(np.random.PCG64(5)).permutation(len(raw) - 1)
+    buf, where = bytearray(b"junk before the first record\n"), {}
+    for k in order:                                    # a FASTA file's bytes: one line per sequence, records in shuffled order
+        buf += b">read/%d some description\n" % k
+        where[int(k)] = (len(buf), len(buf) + len(raw[k]))
+        buf += raw[k] + b"\n"
+    where[len(raw) - 1] = (where[3][0] + 100, where[3][0] + 2500)
+    be = np.array([where[k] for k in range(len(raw))], np.int64)
+    a = _lib.align_job(eng, [ctg], raw)
+    b = _lib.align_job_spans(eng, [ctg], bytes(buf), be, np.zeros(len(raw), np.int32))
+    a.run()
+    b.run()
+    sa, sb = a.summaries(), b.summaries()
+    assert sa.tobytes() == sb.tobytes() and sa["aligned"].sum() >= 38
+    ra, ia = a.alnset(0)
+    rb, ib = b.alnset(0)
+    assert np.array_equal(ia, ib) and ra.n_rec == rb.n_rec
+    assert all(ra.cigar_of(k) == rb.cigar_of(k) for k in range(ra.n_rec))
+    a.close()
+    b.close()
+    with pytest.raises(_lib.FzpError):
+        _lib.align_job_spans(eng, [ctg], bytes(buf), np.array([[10, 5]], np.int64), np.zeros(1, np.int32))      # end before begin
+
+
 def test_empty_and_unaligned_only_jobs(eng):
     from falcon_unzip_amd import _lib
     ctg = b"ACGTTGCA" * 500
