@@ -2437,7 +2437,6 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
         if (const char *e = getenv("FZP_SWB_MAX_STEPS")) { const long g = atol(e); if (g > 0) swb_max_steps = g; }
         // ---- the extension pieces of every read (v1.6) as DP slots: counted per read on the device, the two scans give every read its first slot and its share of the
         // mask capacity; the scans come to the host (8 bytes per read), which only cuts the reads into chunks that fit the mask budget -- everything else is planned on the device
-        std::vector<uint32_t> h_sb((size_t)nr + 1), h_cq((size_t)nr + 1);
         {
             ProfScope ps(ctx, "k1_plan_dp");
             FZP_HIP(hipMemsetAsync(j->rtot.p, 0, 32, st));
@@ -2450,17 +2449,15 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
         uint32_t n2 = 0;
         int32_t ovf = 0;
         uint64_t rtot[4] = {0, 0, 0, 0};
-        FZP_HIP(hipMemcpyAsync(&n2, j->n_sec.p, 4, hipMemcpyDeviceToHost, st));
-        FZP_HIP(hipMemcpyAsync(&ovf, j->idx_overflow.p, 4, hipMemcpyDeviceToHost, st));
-        FZP_HIP(hipMemcpyAsync(rtot, j->rtot.p, 32, hipMemcpyDeviceToHost, st));
-        FZP_TRY(j->slot_base.download(h_sb.data(), (size_t)nr, st));
-        FZP_TRY(j->rcapq_scan.download(h_cq.data(), (size_t)nr, st));
-        FZP_HIP(hipStreamSynchronize(st));
+        {   // the run's totals: all the host needs unless the run has to be cut into chunks
+            const fzp_fetch_piece fp[3] = {{&n2, j->n_sec.p, 4}, {&ovf, j->idx_overflow.p, 4}, {rtot, j->rtot.p, 32}};
+            FZP_TRY(fzp_fetch(ctx, st, fp, 3));
+        }
         if (ovf) { fzp_set_error("k-mer index: a table partition overflowed (more than %d distinct k-mers hash into one 64 KB partition)", 4 << PART_BITS); return FZP_EINVAL; }
         if (rtot[0] >= (1ull << 31) || rtot[1] >= (1ull << 31)) { fzp_set_error("fzp_align_run: %llu extension pieces / %llu x 64 DP steps in one job (limit 2^31 each)", (unsigned long long)rtot[0], (unsigned long long)rtot[1]); return FZP_EINVAL; }
-        h_sb[(size_t)nr] = (uint32_t)rtot[0]; h_cq[(size_t)nr] = (uint32_t)rtot[1];
-        FZP_HIP(hipMemcpyAsync(j->slot_base.p + nr, &h_sb[(size_t)nr], 4, hipMemcpyHostToDevice, st));
-        FZP_HIP(hipMemcpyAsync(j->rcapq_scan.p + nr, &h_cq[(size_t)nr], 4, hipMemcpyHostToDevice, st));
+        const uint32_t end_sb = (uint32_t)rtot[0], end_cq = (uint32_t)rtot[1];
+        FZP_HIP(hipMemcpyAsync(j->slot_base.p + nr, &end_sb, 4, hipMemcpyHostToDevice, st));      // (4 bytes from the stack: the runtime copies them at the call)
+        FZP_HIP(hipMemcpyAsync(j->rcapq_scan.p + nr, &end_cq, 4, hipMemcpyHostToDevice, st));
         j->n_second = n2;
         // Trace-back masks live in HBM (8 B per DP step).  Reads go through in chunks: the DP of chunk k+1 runs on `stream` while the trace-back of chunk k
         // runs on `stream2`; two sets of buffers alternate.
@@ -2472,16 +2469,29 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
         const int64_t total_steps = (int64_t)rtot[1] * 64;
         const int64_t chunk_steps = std::min<int64_t>(budget_steps / 2, (total_steps + n_chunks - 1) / n_chunks);
         if (!j->ev_sw[0]) for (int k = 0; k < 2; k++) { FZP_HIP(hipEventCreateWithFlags(&j->ev_l[k], hipEventDisableTiming)); FZP_HIP(hipEventCreateWithFlags(&j->ev_sw[k], hipEventDisableTiming)); FZP_HIP(hipEventCreateWithFlags(&j->ev_tb[k], hipEventDisableTiming)); }
+        // one chunk for the whole run (the usual case): the scans stay on the device.  Otherwise they come over, to be cut where the mask budget says
+        const bool one_chunk = total_steps <= chunk_steps;
+        std::vector<uint32_t> h_sb, h_cq;
+        if (!one_chunk) {
+            h_sb.resize((size_t)nr + 1); h_cq.resize((size_t)nr + 1);
+            FZP_TRY(j->slot_base.download(h_sb.data(), (size_t)nr, st));
+            FZP_TRY(j->rcapq_scan.download(h_cq.data(), (size_t)nr, st));
+            FZP_HIP(hipStreamSynchronize(st));
+            h_sb[(size_t)nr] = end_sb; h_cq[(size_t)nr] = end_cq;
+        } else { h_sb = {0u, end_sb}; h_cq = {0u, end_cq}; }
+        auto sb_at = [&](int64_t r) { return one_chunk ? h_sb[r ? 1 : 0] : h_sb[(size_t)r]; };      // (one chunk: only r = 0 and r = nr are asked for)
+        auto cq_at = [&](int64_t r) { return one_chunk ? h_cq[r ? 1 : 0] : h_cq[(size_t)r]; };
         int64_t first = 0;
         int k = 0;
         bool used[2] = {false, false};
         while (first < nr) {
             int64_t last = first;
-            while (last < nr && ((int64_t)h_cq[(size_t)last + 1] - (int64_t)h_cq[(size_t)first]) * 64 <= chunk_steps) last++;
+            if (one_chunk) last = nr;
+            else while (last < nr && ((int64_t)h_cq[(size_t)last + 1] - (int64_t)h_cq[(size_t)first]) * 64 <= chunk_steps) last++;
             if (last == first) last = first + 1;
             const int64_t cnt = last - first;
-            const uint32_t s_lo = h_sb[(size_t)first], ns = h_sb[(size_t)last] - s_lo;
-            const int64_t capq = (int64_t)h_cq[(size_t)last] - (int64_t)h_cq[(size_t)first];
+            const uint32_t s_lo = sb_at(first), ns = sb_at(last) - s_lo;
+            const int64_t capq = (int64_t)cq_at(last) - (int64_t)cq_at(first);
             const int bi = k & 1;
             ChunkBufs &B = j->cb[bi];
             if (used[bi]) FZP_HIP(hipStreamWaitEvent(st, j->ev_tb[bi], 0));   // buffers free again?
@@ -2615,7 +2625,7 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
             if (used[b2]) FZP_HIP(hipStreamWaitEvent(st, j->ev_tb[b2], 0));   // the main stream continues after all trace-backs
     }
     uint32_t fbo = 0;
-    if (nr > 0) FZP_HIP(hipMemcpyAsync(&fbo, j->fb_overflow.p, 4, hipMemcpyDeviceToHost, st));
+    if (nr > 0) FZP_TRY(fzp_fetch(ctx, st, &fbo, j->fb_overflow.p, 4));
     FZP_HIP(hipStreamSynchronize(st));
     FZP_HIP(hipGetLastError());
     if (fbo) {      // more pieces needed whole trace-back masks than there was room for (FAIL_CAP pieces / FAIL_ROOM steps per chunk): the run again, every piece through the wave-per-piece kernel
@@ -2926,9 +2936,14 @@ extern "C" int fzp_align_to_batch(fzp_ctx *ctx, fzp_alnjob *j, fzp_batch **out) 
     std::vector<int32_t> h_last((size_t)nc);
     std::vector<uint32_t> h_nal((size_t)nc);
     std::vector<unsigned long long> h_cols((size_t)nc);
-    FZP_HIP(hipMemcpyAsync(tot, totals.p, 32, hipMemcpyDeviceToHost, st));
-    FZP_TRY(last_pos.download(h_last.data(), (size_t)nc, st)); FZP_TRY(n_aligned.download(h_nal.data(), (size_t)nc, st)); FZP_TRY(n_cols.download(h_cols.data(), (size_t)nc, st));
-    FZP_HIP(hipStreamSynchronize(st));
+    if (nc <= 32) {      // (a few contigs: everything the host needs here fits one fetch)
+        const fzp_fetch_piece fp[4] = {{tot, totals.p, 32}, {h_last.data(), last_pos.p, (size_t)nc * 4}, {h_nal.data(), n_aligned.p, (size_t)nc * 4}, {h_cols.data(), n_cols.p, (size_t)nc * 8}};
+        FZP_TRY(fzp_fetch(ctx, st, fp, 4));
+    } else {
+        FZP_HIP(hipMemcpyAsync(tot, totals.p, 32, hipMemcpyDeviceToHost, st));
+        FZP_TRY(last_pos.download(h_last.data(), (size_t)nc, st)); FZP_TRY(n_aligned.download(h_nal.data(), (size_t)nc, st)); FZP_TRY(n_cols.download(h_cols.data(), (size_t)nc, st));
+        FZP_HIP(hipStreamSynchronize(st));
+    }
     b->n_rec = (int64_t)tot[0]; b->n_cig = (int64_t)tot[1]; b->n_seq = (int64_t)tot[2]; b->n_ck = (int64_t)tot[3];
     if (b->n_rec >= (1ll << 31)) { fzp_set_error("fzp_align_to_batch: %lld records (limit 2^31 per batch)", (long long)b->n_rec); return FZP_EINVAL; }
     b->h_goff.assign(1, 0); b->h_qid_off.assign(1, 0);

@@ -395,8 +395,7 @@ int fzp_k4_blocks(fzp_ctx *ctx, fzp_batch *b) {
         hipLaunchKernelGGL(k_link_flag, dim3(grid_for(na, 256, 1 << 30)), dim3(256), 0, st, b->arows.p, na, b->lk_flag.p);
         FZP_TRY(fzp_exclusive_scan_u32(ctx, b->lk_flag.p, b->lk_flag.p, (size_t)na, b->totals.p + 4));
         uint64_t t = 0;
-        FZP_HIP(hipMemcpyAsync(&t, b->totals.p + 4, sizeof t, hipMemcpyDeviceToHost, st));
-        FZP_HIP(hipStreamSynchronize(st));
+        FZP_TRY(fzp_fetch(ctx, st, &t, b->totals.p + 4, sizeof t));
         n_links = (int64_t)t;
     }
     FZP_TRY(b->lk_i1.alloc((size_t)n_links)); FZP_TRY(b->lk_i2.alloc((size_t)n_links));
@@ -442,16 +441,14 @@ int fzp_k4_blocks(fzp_ctx *ctx, fzp_batch *b) {
     }
     FZP_TRY(fzp_exclusive_scan_u32(ctx, b->pv_n.p, b->pv_off.p, (size_t)b->n_ctg, b->totals.p + 5));
     uint64_t t = 0;
-    FZP_HIP(hipMemcpyAsync(&t, b->totals.p + 5, sizeof t, hipMemcpyDeviceToHost, st));
-    FZP_HIP(hipStreamSynchronize(st));
+    FZP_TRY(fzp_fetch(ctx, st, &t, b->totals.p + 5, sizeof t));
     b->n_pvars = (int64_t)t;
     FZP_TRY(b->pvars.alloc((size_t)b->n_pvars));
     if (b->n_pvars > 0)
         hipLaunchKernelGGL(k_pv_compact, dim3(b->n_ctg), dim3(256), 0, st, b->site_begin.p, b->pv_n.p, b->pv_off.p, b->pvars_tmp.p, b->pvars.p);
     hipLaunchKernelGGL(k_u32_to_i64_begin, dim3((b->n_ctg + 1 + 63) / 64), dim3(64), 0, st, b->pv_off.p, b->n_ctg, b->n_pvars, b->pvar_begin.p);
     b->h_pvar_begin.resize((size_t)b->n_ctg + 1);
-    FZP_TRY(b->pvar_begin.download(b->h_pvar_begin.data(), (size_t)b->n_ctg + 1, st));
-    FZP_HIP(hipStreamSynchronize(st));
+    FZP_TRY(fzp_read_back(ctx, st, b->h_pvar_begin.data(), b->pvar_begin.p, ((size_t)b->n_ctg + 1) * sizeof(b->h_pvar_begin[0])));
     FZP_HIP(hipGetLastError());
     b->have_blocks = true;
     return FZP_OK;
@@ -480,8 +477,7 @@ int fzp_k5_reads(fzp_ctx *ctx, fzp_batch *b) {
         hipLaunchKernelGGL(k_range_n, dim3(grid_for(nq, 256, 1 << 30)), dim3(256), 0, st, nq, b->bmin.p, b->bmax.p, b->rng_n.p);
         FZP_TRY(fzp_exclusive_scan_u32(ctx, b->rng_n.p, b->rng_off.p, (size_t)nq, b->totals.p + 6));
         uint64_t t = 0;
-        FZP_HIP(hipMemcpyAsync(&t, b->totals.p + 6, sizeof t, hipMemcpyDeviceToHost, st));
-        FZP_HIP(hipStreamSynchronize(st));
+        FZP_TRY(fzp_fetch(ctx, st, &t, b->totals.p + 6, sizeof t));
         n_slots = (int64_t)t;
         FZP_TRY(b->c0.alloc((size_t)n_slots)); FZP_TRY(b->c1.alloc((size_t)n_slots)); FZP_TRY(b->pr_flag.alloc((size_t)n_slots));
         FZP_TRY(b->c0.zero((size_t)n_slots, st)); FZP_TRY(b->c1.zero((size_t)n_slots, st));
@@ -493,8 +489,7 @@ int fzp_k5_reads(fzp_ctx *ctx, fzp_batch *b) {
             }
             hipLaunchKernelGGL(k_read_flag, dim3(grid_for(n_slots, 256, 1 << 30)), dim3(256), 0, st, n_slots, b->c0.p, b->c1.p, b->pr_flag.p);
             FZP_TRY(fzp_exclusive_scan_u32(ctx, b->pr_flag.p, b->pr_flag.p, (size_t)n_slots, b->totals.p + 7));
-            FZP_HIP(hipMemcpyAsync(&t, b->totals.p + 7, sizeof t, hipMemcpyDeviceToHost, st));
-            FZP_HIP(hipStreamSynchronize(st));
+            FZP_TRY(fzp_fetch(ctx, st, &t, b->totals.p + 7, sizeof t));
             b->n_preads = (int64_t)t;
             FZP_TRY(b->preads.alloc((size_t)b->n_preads));
             if (b->n_preads > 0) {
@@ -508,8 +503,7 @@ int fzp_k5_reads(fzp_ctx *ctx, fzp_batch *b) {
     hipLaunchKernelGGL(k_pread_begin, dim3((b->n_ctg + 1 + 63) / 64), dim3(64), 0, st, b->ctg_qoff.p, b->n_ctg, nq, n_slots, b->n_preads, b->rng_off.p, b->pr_flag.p,
                        b->pread_begin.p);
     b->h_pread_begin.resize((size_t)b->n_ctg + 1);
-    FZP_TRY(b->pread_begin.download(b->h_pread_begin.data(), (size_t)b->n_ctg + 1, st));
-    FZP_HIP(hipStreamSynchronize(st));
+    FZP_TRY(fzp_read_back(ctx, st, b->h_pread_begin.data(), b->pread_begin.p, ((size_t)b->n_ctg + 1) * sizeof(b->h_pread_begin[0])));
     FZP_HIP(hipGetLastError());
     b->have_preads = true;
     return FZP_OK;

@@ -43,6 +43,13 @@ constexpr int WAVE = 64;
 struct DevPool;
 struct fzp_ctx;
 int fzp_bind(fzp_ctx *ctx);          // hipSetDevice(ctx->device) + current pool = ctx's
+// A few words from the device, NOW: a one-wave kernel on `st` posts them (and a sequence number behind them) into mapped pinned memory and the calling thread spins on the
+// sequence number -- half the round trip of hipMemcpyAsync + hipStreamSynchronize (tools/ubench/fetch_latency.hip: 12 against 25 us between two dependent kernels), which
+// is what the count read-backs between the stages of a step cost.  Up to four pieces of up to 256 bytes, each a multiple of 4 bytes from a 4-byte aligned device address.
+struct fzp_fetch_piece { void *host; const void *dev; size_t bytes; };
+int fzp_fetch(fzp_ctx *ctx, hipStream_t st, const fzp_fetch_piece *pieces, int n_pieces);
+inline int fzp_fetch(fzp_ctx *ctx, hipStream_t st, void *host, const void *dev, size_t bytes) { const fzp_fetch_piece p{host, dev, bytes}; return fzp_fetch(ctx, st, &p, 1); }
+int fzp_read_back(fzp_ctx *ctx, hipStream_t st, void *host, const void *dev, size_t bytes);      // fzp_fetch where it fits (<= 256 bytes), copy + stream wait otherwise
 void *fzp_dev_alloc(size_t bytes);   // from the calling thread's current pool; nullptr on failure
 void fzp_dev_free(void *p);
 void fzp_dev_trim();                  // give everything cached in the current pool back to the driver
@@ -114,6 +121,8 @@ struct fzp_ctx {
     std::vector<hipEvent_t> event_pool;
     DevBuf<uint64_t> scan_tmp[3];
     std::shared_ptr<DevPool> pool;   // this ctx's cached device blocks
+    uint32_t *fetch_slot = nullptr;   // fzp_fetch: 4 x 64 payload words + a sequence number, in mapped pinned memory (fzp_host.hip)
+    uint64_t fetch_seq = 0;
     std::mutex pin_mu;
     std::vector<std::pair<void *, size_t>> pin_free, pin_live;   // pinned host blocks: cached / handed out
     struct WorkPool *workers = nullptr;    // fzp_pipe.hip: host threads of the per-contig text / read-map work, kept between calls

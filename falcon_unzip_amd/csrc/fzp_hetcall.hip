@@ -469,8 +469,7 @@ RecView rec_view(const fzp_batch *b) {
 }
 
 int read_totals(fzp_ctx *ctx, fzp_batch *b, int n, uint64_t *out) {
-    FZP_HIP(hipMemcpyAsync(out, b->totals.p, n * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-    FZP_HIP(hipStreamSynchronize(ctx->stream));
+    FZP_TRY(fzp_fetch(ctx, ctx->stream, out, b->totals.p, n * sizeof(uint64_t)));
     return FZP_OK;
 }
 }  // namespace
@@ -542,14 +541,12 @@ int fzp_k2_het_call(fzp_ctx *ctx, fzp_batch *b) {
     }
     hipLaunchKernelGGL(k_site_begin, dim3((b->n_ctg + 1 + 63) / 64), dim3(64), 0, st, b->site_g.p, b->n_sites, b->ctg_goff.p, b->n_ctg, b->site_begin.p);
     b->h_site_begin.resize((size_t)b->n_ctg + 1);
-    FZP_TRY(b->site_begin.download(b->h_site_begin.data(), (size_t)b->n_ctg + 1, st));
-    FZP_HIP(hipStreamSynchronize(st));
+    FZP_TRY(fzp_read_back(ctx, st, b->h_site_begin.data(), b->site_begin.p, ((size_t)b->n_ctg + 1) * sizeof(b->h_site_begin[0])));
     FZP_HIP(hipGetLastError());
     for (int c = 0; c < b->n_ctg; c++) {     // a site called beyond the contig's end: the reference dies on ref_seq[pos] (phasing.py:124)
         if ((int64_t)b->h_limit[(size_t)c] <= b->h_ref_len[(size_t)c] || b->h_site_begin[(size_t)c + 1] == b->h_site_begin[(size_t)c]) continue;
         int64_t g = 0;
-        FZP_HIP(hipMemcpyAsync(&g, b->site_g.p + b->h_site_begin[(size_t)c + 1] - 1, 8, hipMemcpyDeviceToHost, st));
-        FZP_HIP(hipStreamSynchronize(st));
+        FZP_TRY(fzp_fetch(ctx, st, &g, b->site_g.p + b->h_site_begin[(size_t)c + 1] - 1, 8));
         if (g - b->h_goff[(size_t)c] >= b->h_ref_len[(size_t)c]) {
             fzp_set_error("contig %d: het site called at position %lld, beyond the contig end %lld (reference: IndexError on ref_seq[pos])", c,
                           (long long)(g - b->h_goff[(size_t)c] + 1), (long long)b->h_ref_len[(size_t)c]);
@@ -591,8 +588,7 @@ int fzp_k3_assoc(fzp_ctx *ctx, fzp_batch *b) {
     if (ns > 0) {
         hipLaunchKernelGGL(k_cand, dim3(grid_for(ns, 256, 1 << 30)), dim3(256), 0, st, b->site_g.p, b->site_ctg.p, b->site_begin.p, ns, b->cand_n.p, b->cap_off.p);
         FZP_TRY(fzp_exclusive_scan_u32(ctx, b->cap_off.p, b->cap_off.p, (size_t)ns, b->totals.p + 2));
-        FZP_HIP(hipMemcpyAsync(tot, b->totals.p + 2, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-        FZP_HIP(hipStreamSynchronize(st));
+        FZP_TRY(fzp_fetch(ctx, st, tot, b->totals.p + 2, sizeof(uint64_t)));
         if (tot[0] >= (1ull << 31)) { fzp_set_error("association table bound %llu rows (> 2^31)", (unsigned long long)tot[0]); return FZP_EINVAL; }
         FZP_TRY(b->arows_tmp.alloc((size_t)tot[0]));
         {
@@ -601,8 +597,7 @@ int fzp_k3_assoc(fzp_ctx *ctx, fzp_batch *b) {
                                b->set_n.p + 2 * ns, b->arows_tmp.p, b->nkept.p);
         }
         FZP_TRY(fzp_exclusive_scan_u32(ctx, b->nkept.p, b->kept_off.p, (size_t)ns, b->totals.p + 3));
-        FZP_HIP(hipMemcpyAsync(tot, b->totals.p + 3, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-        FZP_HIP(hipStreamSynchronize(st));
+        FZP_TRY(fzp_fetch(ctx, st, tot, b->totals.p + 3, sizeof(uint64_t)));
         b->n_arows = (int64_t)tot[0];
         FZP_TRY(b->arows.alloc((size_t)b->n_arows));
         {
@@ -616,8 +611,7 @@ int fzp_k3_assoc(fzp_ctx *ctx, fzp_batch *b) {
     }
     hipLaunchKernelGGL(k_arow_begin, dim3((b->n_ctg + 1 + 63) / 64), dim3(64), 0, st, b->kept_off.p, b->site_begin.p, b->n_ctg, ns, b->n_arows, b->arow_begin.p);
     b->h_arow_begin.resize((size_t)b->n_ctg + 1);
-    FZP_TRY(b->arow_begin.download(b->h_arow_begin.data(), (size_t)b->n_ctg + 1, st));
-    FZP_HIP(hipStreamSynchronize(st));
+    FZP_TRY(fzp_read_back(ctx, st, b->h_arow_begin.data(), b->arow_begin.p, ((size_t)b->n_ctg + 1) * sizeof(b->h_arow_begin[0])));
     FZP_HIP(hipGetLastError());
     b->have_arows = true;
     return FZP_OK;

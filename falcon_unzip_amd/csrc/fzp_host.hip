@@ -78,6 +78,60 @@ void trim_device_pools(int dev) {
     for (auto &p : all) trim_pool(*p);
 }
 }  // namespace
+// ---------------------------------------------------------------- fzp_fetch (fzp_common.h)
+namespace {
+struct FetchArgs { const uint32_t *src[4]; int n[4]; };
+__global__ void __launch_bounds__(64) k_fetch_post(FetchArgs a, volatile uint32_t *slot, uint64_t seq) {
+    int base = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if ((int)threadIdx.x < a.n[k]) slot[base + (int)threadIdx.x] = a.src[k][threadIdx.x];
+        base += a.n[k];
+    }
+    __threadfence_system();                                        // the payload is out before the number that says so
+    if (threadIdx.x == 0) *(volatile uint64_t *)(slot + 256) = seq;
+}
+}  // namespace
+int fzp_fetch(fzp_ctx *ctx, hipStream_t st, const fzp_fetch_piece *pieces, int n_pieces) {
+    if (!ctx || !pieces || n_pieces < 1 || n_pieces > 4) { fzp_set_error("fzp_fetch: bad arguments"); return FZP_EINVAL; }
+    FetchArgs a;
+    for (int k = 0; k < 4; k++) {
+        a.src[k] = k < n_pieces ? (const uint32_t *)pieces[k].dev : nullptr;
+        a.n[k] = k < n_pieces ? (int)(pieces[k].bytes / 4) : 0;
+        if (k < n_pieces && ((pieces[k].bytes & 3) || pieces[k].bytes > 256 || !pieces[k].dev || !pieces[k].host)) { fzp_set_error("fzp_fetch: bad piece"); return FZP_EINVAL; }
+    }
+    if (!ctx->fetch_slot) {
+        void *p = nullptr;
+        if (hipHostMalloc(&p, 4096, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); fzp_set_error("fzp_fetch: pinned allocation failed"); return FZP_ENOMEM; }
+        memset(p, 0, 4096);
+        ctx->fetch_slot = (uint32_t *)p;
+    }
+    const uint64_t seq = ++ctx->fetch_seq;
+    hipLaunchKernelGGL(k_fetch_post, dim3(1), dim3(64), 0, st, a, (volatile uint32_t *)ctx->fetch_slot, seq);
+    if (hipGetLastError() != hipSuccess) { fzp_set_error("fzp_fetch: launch failed"); return FZP_EDEVICE; }
+    volatile uint64_t *sq = (volatile uint64_t *)(ctx->fetch_slot + 256);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spins = 0; __atomic_load_n((const uint64_t *)sq, __ATOMIC_ACQUIRE) != seq; spins++) {
+        if ((spins & 0xffff) == 0xffff) {      // (rarely: has the stream died under us?  a device fault must not leave the host spinning)
+            const hipError_t e = hipStreamQuery(st);
+            if (e != hipSuccess && e != hipErrorNotReady) { fzp_set_error("fzp_fetch: %s", hipGetErrorString(e)); return FZP_EDEVICE; }
+            (void)hipGetLastError();
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) { fzp_set_error("fzp_fetch: no answer from the device in 120 s"); return FZP_EDEVICE; }
+        }
+    }
+    int base = 0;
+    for (int k = 0; k < n_pieces; k++) { memcpy(pieces[k].host, ctx->fetch_slot + base, pieces[k].bytes); base += a.n[k]; }
+    return FZP_OK;
+}
+
+int fzp_read_back(fzp_ctx *ctx, hipStream_t st, void *host, const void *dev, size_t bytes) {
+    if (bytes == 0) return FZP_OK;
+    if (bytes <= 256 && !(bytes & 3)) return fzp_fetch(ctx, st, host, dev, bytes);
+    FZP_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, st));
+    FZP_HIP(hipStreamSynchronize(st));
+    return FZP_OK;
+}
+
 int fzp_bind(fzp_ctx *ctx) {
     FZP_HIP(hipSetDevice(ctx->device));
     t_pool = ctx->pool;
@@ -289,6 +343,7 @@ extern "C" void fzp_ctx_destroy(fzp_ctx *ctx) {
     }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     for (auto &b : ctx->scan_tmp) b.release();
+    if (ctx->fetch_slot) (void)hipHostFree(ctx->fetch_slot);
     for (auto &pb : ctx->pin_free) (void)hipHostFree(pb.first);
     for (auto &pb : ctx->pin_live) (void)hipHostFree(pb.first);      // (views handed out die with the ctx, as documented)
     if (ctx->ev_pf) (void)hipEventDestroy(ctx->ev_pf);

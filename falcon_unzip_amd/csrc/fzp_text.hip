@@ -109,10 +109,9 @@ int fzp_batch_text_dev(fzp_ctx *ctx, fzp_batch *b, int what, DevBuf<char> &text,
         FZP_TRY(fzp_exclusive_scan_u32(ctx, len.p, len.p, (size_t)n, total.p));
     }
     uint64_t tot = 0;
-    FZP_HIP(hipMemcpyAsync(&tot, total.p, 8, hipMemcpyDeviceToHost, st));
     // contig c's first row: variant_map -> row_off of its first site; atable -> arow_begin
     if (what == 2) { for (int c = 0; c <= nc; c++) rb[(size_t)c] = b->h_arow_begin[(size_t)c]; FZP_TRY(d_rb.upload(rb.data(), rb.size(), st)); }
-    FZP_HIP(hipStreamSynchronize(st));
+    FZP_TRY(fzp_fetch(ctx, st, &tot, total.p, 8));
     if (tot >= (1ull << 32)) { fzp_set_error("fzp_batch_text: %llu bytes of text (limit 4 GiB per batch)", (unsigned long long)tot); return FZP_EINVAL; }
     if (what == 1) {
         // row_off of the contigs' first sites: read back with the sites (tiny gather through the same kernel needs them on the device)
