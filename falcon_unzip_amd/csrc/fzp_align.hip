@@ -1539,29 +1539,39 @@ __global__ void __launch_bounds__(64 * TBW_WPG) k_tb_walk(const uint32_t *__rest
         }
         const uint8_t *win = mine;
         if (STATS && active) { const int32_t e2 = (int32_t)(mvr[ts >> 6].y >> 32); st_centre = min(max(32 + e2 / 3, 16), 48); }      // score(lane 63) - score(lane 0) = 2 E2 ~ 6 x (path's lane - 31.5)
-        while (active && (ts >> 6) == cur_chunk && (FULL ? (uint32_t)(k - sh_cur) < 32u : (uint32_t)(k - wlo) < wn)) {
+        // The loop runs while the walk is inside its matrix (i >= 0, j = ts - i >= 0), inside this chunk (ts >= c_lo: it only goes down) and inside the lanes the staged
+        // records hold: one OR of five differences, negative when any of them is -- and the record's LDS address steps down with ts instead of being made from it.
+        const int32_t c_lo = cur_chunk << 6;
+        const int32_t w_lo = FULL ? sh_cur : wlo, w_hi = FULL ? sh_cur + 31 : wlo + (int32_t)wn - 1;
+        const uint8_t *pm = win + (ts & 63) * 8;
+        int32_t bad = (active ? 0 : -1) | i | (ts - i) | (ts - c_lo) | (k - w_lo) | (w_hi - k);
+        while (bad >= 0) {
             if (STATS) { st_steps++; st_fixed += (uint32_t)(k - 16) >= 32u ? 1u : 0u; st_adapt += (uint32_t)(k - (st_centre - 16)) >= 32u ? 1u : 0u; st_maxdev = max(st_maxdev, (uint32_t)(k >= 32 ? k - 32 : 31 - k)); }
-            const uint2 m = *(const uint2 *)(win + (ts & 63) * 8);
+            const uint2 m = *(const uint2 *)pm;
             const uint32_t kk = (uint32_t)(k - sh_cur);
-            const uint32_t db = (m.x >> kk) & 1u, gb = (m.y >> kk) & 1u;
+            const uint32_t db = (m.x >> kk) & 1u;
+            const uint32_t gx = (m.y >> kk) ^ d1;                             // bit 0: G ^ the move before
             const uint32_t hi = (uint32_t)(P >> 32);
             const uint32_t d2 = hi >> 31, d3 = (hi >> 30) & 1u;
             // not diagonal: G set after a DOWN move, or clear after a RIGHT move -> the predecessor is the cell above
             const uint32_t ndb = db ^ 1u;
-            const uint32_t up = ndb & ((gb ^ d1) ^ 1u);
+            const uint32_t up = ndb & ~gx & 1u;
             const uint32_t op = 2u * ndb - up;                                // M = 0, I = 1, D = 2
-            k += (int32_t)(d1 + (db & d2)) - (int32_t)(db + up);
-            i -= (int32_t)(db + up);
-            ts -= (int32_t)(1u + db);
+            const uint32_t stp = 1u + db, dec = db + up;
+            k += (int32_t)(d1 + (db & d2)) - (int32_t)dec;
+            i -= (int32_t)dec;
+            ts -= (int32_t)stp;
+            pm -= 8u * stp;
             d1 = db ? d3 : d2;
-            P <<= (1u + db);
+            P <<= stp;
             ncol += (int32_t)db;
             n_ops++;
             rawacc |= op << nb;
             nb += 2u;
             if (nb == 32u) { rawp[nw++] = rawacc; rawacc = 0u; nb = 0u; }
-            active = (i | (ts - i)) >= 0;
+            bad = i | (ts - i) | (ts - c_lo) | (k - w_lo) | (w_hi - k);
         }
+        active = active && (i | (ts - i)) >= 0;
         TBW_WAVE_SYNC();
     }
 #undef TBW_ISSUE
