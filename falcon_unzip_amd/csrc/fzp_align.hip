@@ -1564,8 +1564,6 @@ __global__ void __launch_bounds__(64 * TBW_WPG) k_tb_walk(const uint32_t *__rest
             pm -= 8u * stp;
             d1 = db ? d3 : d2;
             P <<= stp;
-            ncol += (int32_t)db;
-            n_ops++;
             rawacc |= op << nb;
             nb += 2u;
             if (nb == 32u) { rawp[nw++] = rawacc; rawacc = 0u; nb = 0u; }
@@ -1586,6 +1584,9 @@ __global__ void __launch_bounds__(64 * TBW_WPG) k_tb_walk(const uint32_t *__rest
         if (f < fail_cap) fail_list[f] = sl;
     }
     if (nb) rawp[nw] = rawacc;
+    // (neither count is kept in the loop: the op stream knows how many ops went into it, and every op took ts down by one, a diagonal one by one more)
+    n_ops = 16 * nw + (int32_t)(nb >> 1);
+    ncol = walked ? (di.best_t - ts) - n_ops : 0;
     WalkOut o;
     o.ok = failed ? 2 : (walked ? 1 : 0); o.i = i; o.ts = ts; o.i_end = i_end; o.j_end = j_end; o.ncol = ncol; o.n_ops = n_ops; o.pad_ = 0;
     wout[sl] = o;
