@@ -184,25 +184,6 @@ bool tok_int(Tok t, long long *v) {
     *v = neg ? -x : x;
     return true;
 }
-// threads this process may really use: the affinity mask and the cgroup CPU quota, not the machine's thread count (a container that shows 256 hardware threads
-// behind a 16-CPU quota is throttled to a crawl by 256 busy threads)
-int usable_cores() {
-    int n = (int)std::max(1u, std::thread::hardware_concurrency());
-    cpu_set_t cs;
-    if (sched_getaffinity(0, sizeof cs, &cs) == 0) n = std::min(n, std::max(1, CPU_COUNT(&cs)));
-    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                       // cgroup v2: "<quota> <period>" or "max <period>"
-        char q[64]; long long per = 0;
-        if (fscanf(f, "%63s %lld", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) n = std::min<long long>(n, std::max<long long>(1, (atoll(q) + per - 1) / per));
-        fclose(f);
-    } else if (FILE *f1 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {  // cgroup v1
-        long long quota = -1, per = 0;
-        if (fscanf(f1, "%lld", &quota) != 1) quota = -1;
-        fclose(f1);
-        if (FILE *f2 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(f2, "%lld", &per) != 1) per = 0; fclose(f2); }
-        if (quota > 0 && per > 0) n = std::min<long long>(n, std::max<long long>(1, (quota + per - 1) / per));
-    }
-    return n;
-}
 void split_nl(const char *s, size_t n, std::vector<Tok> &out) {   // text.split('\n')
     size_t off = 0;
     for (;;) {
