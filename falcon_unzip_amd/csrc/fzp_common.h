@@ -44,6 +44,7 @@ struct DevPool;
 struct fzp_ctx;
 int fzp_bind(fzp_ctx *ctx);          // hipSetDevice(ctx->device) + current pool = ctx's
 int usable_cores();                  // threads this process may really use: affinity mask and cgroup CPU quota, not the machine's thread count (fzp_host.hip)
+int cores_per_rank();                // ... divided by the ranks of the node (LOCAL_WORLD_SIZE): what the host thread pools are sized by
 // A few words from the device, NOW: a one-wave kernel on `st` posts them (and a sequence number behind them) into mapped pinned memory and the calling thread spins on the
 // sequence number -- half the round trip of hipMemcpyAsync + hipStreamSynchronize (tools/ubench/fetch_latency.hip: 12 against 25 us between two dependent kernels), which
 // is what the count read-backs between the stages of a step cost.  Up to four pieces of up to 256 bytes, each a multiple of 4 bytes from a 4-byte aligned device address.

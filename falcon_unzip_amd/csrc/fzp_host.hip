@@ -99,6 +99,14 @@ int usable_cores() {
     return n;
 }
 
+// ... and this rank's share of them: the ranks of a node (LOCAL_WORLD_SIZE, as torch.distributed.run sets it) divide the usable cores among themselves.  Sizes the
+// host thread pools: eight ranks behind a 16-CPU quota get two workers each instead of sixteen that take turns.
+int cores_per_rank() {
+    int ranks = 1;
+    if (const char *w = getenv("LOCAL_WORLD_SIZE")) ranks = std::max(1, atoi(w));
+    return std::max(1, usable_cores() / ranks);
+}
+
 // ---------------------------------------------------------------- fzp_fetch (fzp_common.h)
 namespace {
 struct FetchArgs { const uint32_t *src[4]; int n[4]; };

@@ -435,7 +435,7 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
     const int nc = b->n_ctg;
     static const bool timing = getenv("FZP_PIPE_TIMING") != nullptr;
     std::atomic<int64_t> us_names{0}, us_fmt{0}, us_map{0}, us_write{0};
-    int T = o->n_threads > 0 ? o->n_threads : std::min(64, std::max(2, usable_cores()));      // (the cores this process may use, not the machine's: a rank of eight behind a CPU quota has two)
+    int T = o->n_threads > 0 ? o->n_threads : std::min(64, std::max(2, cores_per_rank()));      // (the cores this rank may use, not the machine's: a rank of eight behind a 16-CPU quota has two)
     if (!ctx->workers || ctx->workers->size() < std::min(T, nc)) {        // grown on demand, kept for the next call
         delete ctx->workers;
         ctx->workers = new WorkPool();
@@ -520,7 +520,7 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
     std::shared_ptr<Owned> owned = std::make_shared<Owned>();
     owned->c = ctx; owned->pin = pin;
     const bool async = (o->flags & FZP_PIPE_ASYNC_WRITES) != 0 && o->out_dir;
-    if (async && !ctx->writer) { ctx->writer = new FileWriter(); ctx->writer->start(std::min(16, std::max(2, usable_cores()))); }
+    if (async && !ctx->writer) { ctx->writer = new FileWriter(); ctx->writer->start(std::min(16, std::max(2, cores_per_rank()))); }
     if (async) { const std::string e = [&] { std::lock_guard<std::mutex> lk(ctx->writer->mu); std::string x; x.swap(ctx->writer->first_error); return x; }(); if (!e.empty()) { fzp_set_error("%s", e.c_str()); return FZP_EINVAL; } }
     FZP_HIP(hipStreamSynchronize(ctx->stream));
     // they only have to be there when a contig's write task is made: their copy runs under the formatting of the small files
@@ -1132,7 +1132,7 @@ extern "C" int fzp_debug_load_fasta_group(const char *reads_dir, const char *con
                                           int64_t **off, char **names, int64_t **name_off, int32_t **read_ctg, int64_t *n_reads) {
     if (!reads_dir || !ctg_id || n_ctg <= 0 || !ref || !ref_off || !blob || !off || !names || !name_off || !read_ctg || !n_reads) { fzp_set_error("fzp_debug_load_fasta_group: bad arguments"); return FZP_EINVAL; }
     GroupIn G;
-    load_group(reads_dir, ctg_id, 0, n_ctg, n_threads > 0 ? n_threads : std::min(32, usable_cores()), G);
+    load_group(reads_dir, ctg_id, 0, n_ctg, n_threads > 0 ? n_threads : std::min(32, cores_per_rank()), G);
     if (G.rc != FZP_OK) { fzp_set_error("%s", G.err.c_str()); return G.rc; }
     auto dup = [](const void *p, size_t bytes) { void *q = malloc(bytes ? bytes : 1); if (q && bytes) memcpy(q, p, bytes); return q; };
     const size_t nr = G.read_ctg.size();
@@ -1198,7 +1198,7 @@ extern "C" int fzp_phase_contigs_files(fzp_ctx *ctx, const char *reads_dir, cons
         FZP_TRY(fzp_ctx_create(device, 0, &lc));
         ctx->lanes.push_back(lc);
     }
-    const int host_threads = o.n_threads > 0 ? o.n_threads : std::min(32, usable_cores());
+    const int host_threads = o.n_threads > 0 ? o.n_threads : std::min(32, cores_per_rank());
     // the loader: group g's files are parsed when a lane takes group g - 1 at the latest (one group ahead of every lane; each load uses every host thread, so
     // loads run one after the other, in group order: the first group is there as soon as it can be)
     if (!ctx->gpool) ctx->gpool = new GroupPool();
