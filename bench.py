@@ -139,7 +139,7 @@ def tree_digest(root):
 
 
 def thread_cpu():
-    """{tid: (name, user + system seconds)} of this process's threads (/proc/self/task)"""
+    """{tid: (name, user + system seconds, system seconds)} of this process's threads (/proc/self/task)"""
     out = {}
     tck = os.sysconf("SC_CLK_TCK")
     for t in os.listdir("/proc/self/task"):
@@ -148,7 +148,7 @@ def thread_cpu():
                 st = f.read()
             nm = st[st.index("(") + 1:st.rindex(")")]
             fld = st[st.rindex(")") + 2:].split()
-            out[int(t)] = (nm, (int(fld[11]) + int(fld[12])) / tck)
+            out[int(t)] = (nm, (int(fld[11]) + int(fld[12])) / tck, int(fld[12]) / tck)
         except (OSError, ValueError):
             pass
     return out
@@ -170,6 +170,21 @@ def host_cores():
     except (OSError, ValueError):
         pass
     return max(1, n)
+
+
+def fs_of(path):
+    """file system type of the mount that holds `path` (/proc/mounts)"""
+    best, typ = "", ""
+    try:
+        rp = os.path.realpath(path)
+        with open("/proc/mounts") as f:
+            for l in f:
+                t = l.split()
+                if len(t) >= 3 and (rp == t[1] or rp.startswith(t[1].rstrip("/") + "/")) and len(t[1]) >= len(best):
+                    best, typ = t[1], t[2]
+    except OSError:
+        pass
+    return typ
 
 
 def cpu_model():
@@ -240,11 +255,10 @@ def cpu_baseline(contigs, blob, off, read_ctg, ids, job, hip_summ, budget_s=30.0
 
 def roofline(cells_per_launch, sw_avg_ms, sw_launches, dp_gcells, traffic):
     """k1_sw, the dominant stage: the banded DP of every extension piece of the step in ONE launch pair (k_swb, bit-sliced, one piece per lane; k_sw, one wave per
-    piece, for the pieces narrower than the band -- DESIGN section 5).  SURVEY 8d prices the stage at 0.25 algorithmic B per cell (the 2 trace-back bits of every
-    cell); the headline fraction is the north star's: that figure x cells per launch / the stage's duration against the HBM peak.  What the kernel really writes since
-    round 4 is HALF of it (band lanes 16..47 only, 0.125 B/cell: `bytes_per_cell_moved`), so `traffic` -- the measured HBM bytes of the largest DP dispatch
-    (FETCH + WRITE, from profiles/) -- sits below the algorithmic figure.  Beside it `valu`: wave64 VALU instructions per second (SQ_INSTS_VALU from profiles/, named in
-    `counter_source`) against the chip's issue peak, 256 CU x 4 SIMD x 2.4 GHz / 2 cycles per wave64 instruction on a SIMD-32 (MI355X_MICROARCH.md)."""
+    piece, for the pieces narrower than the band -- DESIGN section 5).  What binds it is VALU issue, so that is the headline: wave64 VALU instructions per second
+    (SQ_INSTS_VALU from profiles/, named in `counter_source`) against the chip's issue peak, 256 CU x 4 SIMD x 2.4 GHz / 2 cycles per wave64 instruction on a SIMD-32
+    (MI355X_MICROARCH.md).  Beside it the two HBM views: SURVEY 8d's algorithmic 0.25 B per cell (the north star's figure), and the bytes the kernel really moves since
+    round 4 -- band lanes 16..47 only, 0.125 B/cell; `traffic` = the measured HBM bytes of the largest DP dispatch (FETCH + WRITE, from profiles/)."""
     counters = {"valu_per_step": SW_VALU_PER_STEP, "source": "(default: no profiles/k1_sw_counters.json)"}
     cf = os.path.join(REPO, "profiles", "k1_sw_counters.json")
     if os.path.exists(cf):
@@ -260,14 +274,19 @@ def roofline(cells_per_launch, sw_avg_ms, sw_launches, dp_gcells, traffic):
     steps_per_s = dp_gcells * 1e9 / 64.0
     valu = steps_per_s * per_step / 1e9
     valu_peak = N_SIMD * CLK_GHZ / 2.0
-    gbs = cells_per_launch * SW_BYTES_PER_CELL / (sw_avg_ms * 1e-3) / 1e9 if sw_avg_ms else 0.0
-    return {"bound": "hbm", "kernel": "k1_sw (k_swb + k_sw)", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-            "traffic": traffic, "profile_files_stale": stale or None, "avg_launch_ms": round(sw_avg_ms, 3), "launches": int(sw_launches), "bytes_per_cell": SW_BYTES_PER_CELL,
-            "bytes_per_cell_moved": 0.125,
-            "note": "algorithmic 0.25 B/cell (SURVEY 8d: the 2 trace-back bits of every cell); the kernel writes half of that (band lanes 16..47) and keeps every SIMD busy with one "
-                    "wave (~3 500 waves of 64 pieces on 1 024 SIMDs): it is bound by VALU issue (see `valu`), no longer by its stores",
-            "valu": {"achieved": round(valu, 2), "peak": round(valu_peak, 1), "unit": "G wave64-inst/s", "frac": round(valu / valu_peak, 4),
-                     "valu_insts_per_band_step": per_step, "counter_source": counters.get("source")},
+    secs = sw_avg_ms * 1e-3 if sw_avg_ms else 0.0
+    gbs_alg = cells_per_launch * SW_BYTES_PER_CELL / secs / 1e9 if secs else 0.0
+    gbs_moved = (traffic / secs / 1e9) if (traffic and secs) else None
+    return {"bound": "valu", "kernel": "k1_sw (k_swb + k_sw)", "achieved": round(valu, 2), "peak": round(valu_peak, 1), "unit": "G wave64-inst/s", "frac": round(valu / valu_peak, 4),
+            "traffic": traffic, "profile_files_stale": stale or None, "avg_launch_ms": round(sw_avg_ms, 3), "launches": int(sw_launches),
+            "valu_insts_per_band_step": per_step, "counter_source": counters.get("source"),
+            "note": "the DP stage keeps every SIMD busy with one wave (~3 500 waves of 64 pieces on 1 024 SIMDs) and is bound by VALU issue: wave64 VALU instructions per second "
+                    "(SQ_INSTS_VALU of the committed counter pass x this run's band steps per second) against 256 CU x 4 SIMD x 2.4 GHz / 2 cycles per instruction.  The two HBM "
+                    "views sit beside it: `hbm_algorithmic` prices SURVEY 8d's 0.25 B per cell (the 2 trace-back bits of every cell), `hbm_moved` what the kernel really moves "
+                    "(`traffic`: band lanes 16..47 only, 0.125 B per cell + the base streams)",
+            "hbm_algorithmic": {"achieved": round(gbs_alg, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs_alg / HBM_PEAK_GBS, 4), "bytes_per_cell": SW_BYTES_PER_CELL},
+            "hbm_moved": {"achieved": round(gbs_moved, 2) if gbs_moved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs_moved / HBM_PEAK_GBS, 4) if gbs_moved else None,
+                          "bytes_per_cell": 0.125, "bytes_per_launch": traffic},
             "ops_view": {"int_ops_per_cell": 12, "achieved_tlaneop": round(dp_gcells * 12 / 1e3, 2), "peak_tlaneop": round(256 * 4 * 32 * CLK_GHZ / 1e3, 2),
                          "frac": round(dp_gcells * 12 / (256 * 4 * 32 * CLK_GHZ), 4),
                          "note": "SURVEY 8d: 12 int ops per cell against 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (the bit-sliced kernel spends ~2 lane-ops per cell)"}}
@@ -368,6 +387,86 @@ def strong_leg(args, rank, world, eng, comm, coll_dev, inp, out_root):
             "rank_load": [{"rank": r, "contigs": int(p[2].item()), "reads": int(p[1].item()), "s": round(float(p[0].item()), 4)} for r, p in enumerate(per_rank)]}
 
 
+def constrained_child(args, n_cores, contigs, blob, off, read_ctg, ids, name_tab, maps, mine):
+    """The resident step once more with the CPU a rank of a full node has: a CHILD forked here -- before this process imports torch or touches the GPU; a fork, never an
+    exec -- confines itself to `n_cores` CPUs (sched_setaffinity), says LOCAL_WORLD_SIZE=8 (the library sizes its host thread pools by the rank's share of the cores) and
+    runs warm-up + timed steps of the same fzp_job_phase_write on the same inputs (inherited copy-on-write), alone on the GPU; the parent waits for it and only then brings
+    up its own context.  8 ranks behind the GPU boxes' 16-CPU quota have two cores each: `two_core_step_ms` against `ms_per_step` is what the 8-GPU curve will feel first."""
+    rd, wr = os.pipe()
+    pid = os.fork()
+    if pid == 0:
+        code = 1
+        try:
+            os.close(rd)
+            os.sched_setaffinity(0, sorted(os.sched_getaffinity(0))[:n_cores])
+            os.environ["LOCAL_WORLD_SIZE"] = "8"
+            from falcon_unzip_amd import _lib
+            eng = _lib.Engine(0)
+            job = _lib.align_job_raw(eng, contigs, blob, off, read_ctg)
+            root = tempfile.mkdtemp(prefix="fzp_bench_2c_", dir="/dev/shm" if os.path.isdir("/dev/shm") and not args.out_root else args.out_root)
+            n_steps = max(4, min(args.steps, 10))
+
+            def one(k):
+                job.phase_write(ids, names=name_tab, out_dir=os.path.join(root, "s%03d" % k), read_maps=maps, ctg_index=mine, consensus=args.with_consensus, async_writes=True,
+                                rebuild_index=not args.index_at_create)
+            for k in range(2):
+                one(k)
+            eng.synchronize(); eng.pipe_flush()
+            t0, c0 = time.perf_counter(), time.process_time()
+            for k in range(n_steps):
+                one(2 + k)
+            eng.synchronize(); eng.pipe_flush()
+            dt, cpu = time.perf_counter() - t0, time.process_time() - c0
+            job.close(); eng.close()
+            shutil.rmtree(root, ignore_errors=True)
+            os.write(wr, json.dumps({"ms_per_step": round(dt / n_steps * 1e3, 3), "host_cpu_ms_per_step": round(cpu / n_steps * 1e3, 2), "steps": n_steps, "cpus": n_cores,
+                                     "local_world_size": 8}).encode())
+            code = 0
+        except BaseException as e:      # noqa: BLE001 -- reported by the parent
+            try:
+                os.write(wr, json.dumps({"error": repr(e)}).encode())
+            except OSError:
+                pass
+        finally:
+            os._exit(code)
+    os.close(wr)
+    data = b""
+    while True:
+        chunk = os.read(rd, 65536)
+        if not chunk:
+            break
+        data += chunk
+    os.close(rd)
+    os.waitpid(pid, 0)
+    try:
+        return json.loads(data.decode())
+    except ValueError:
+        return {"error": "the child left no result"}
+
+
+def files_leg(args, eng, contigs, blob, off, read_ctg, ids, name_tab, maps, mine, out_root, gc, lanes, sync=None):
+    """The workload from the reference's own input files (unzip.py:204,233-234: reads/<ctg>_ref.fa, <ctg>_reads.fa) on a memory file system: FASTA parsing (the library's,
+    a contig group ahead of the lanes) inside the clock -- what scripts/fc_unzip_phase_gpu.py does per rank.  Three calls, the best of the last two; `sync` (N > 1): called
+    before every call so that the ranks run theirs side by side on the node's shared host cores.  -> (seconds, stats, records, output dir of the last call)"""
+    from falcon_unzip_amd import _lib
+    reads_dir = write_reads_tree(contigs, blob, off, read_ctg, ids, name_tab, "/dev/shm" if os.path.isdir("/dev/shm") else out_root)
+    try:
+        gb = int(gc * args.reads_per_contig * args.read_len * 1.09)      # (file sizes: bases + names)
+        runs = []
+        for k in range(3):
+            if sync:
+                sync()
+            t1 = time.perf_counter()
+            st, recs_f = _lib.phase_contigs_files(eng, reads_dir, ids, out_dir=os.path.join(out_root, "files_%d" % k), read_maps=maps, ctg_index=mine, n_lanes=lanes, group_bases=gb,
+                                                  consensus=args.with_consensus, async_writes=True)
+            runs.append((time.perf_counter() - t1, st))
+        best = min(runs[1:], key=lambda x: x[0])
+        mb = sum(os.path.getsize(os.path.join(reads_dir, f)) for f in os.listdir(reads_dir)) / 1e6
+        return best[0], best[1], recs_f, os.path.join(out_root, "files_2"), mb
+    finally:
+        shutil.rmtree(reads_dir, ignore_errors=True)
+
+
 def launch_ranks(n):
     """--gpus N outside a launcher: N fresh ranks as children of this process, which has not imported torch nor touched the GPU."""
     import socket
@@ -402,6 +501,7 @@ def main():
     ap.add_argument("--strong-leg-contig-len", type=int, default=750_000)
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--no-from-files", action="store_true", help="skip the from_files leg (the end-to-end workload from FASTA files on a memory file system)")
+    ap.add_argument("--no-two-core", action="store_true", help="skip two_core_step_ms (the resident step in a child confined to two CPUs with LOCAL_WORLD_SIZE=8)")
     ap.add_argument("--e2e-lanes", type=int, default=2)
     ap.add_argument("--e2e-group-contigs", type=int, default=10)
     ap.add_argument("--with-consensus", action="store_true", help="also run K6 (phased-pile consensus, BASELINE config 4) inside every step")
@@ -442,6 +542,9 @@ def main():
     if rank == 0 and world == 1 and not args.strong and not args.no_shaped_leg:
         shaped_inp = make_inputs(cfg, mine, args.contig_len, reads_of, args.read_len, win, workers, gen=gen_contig_shaped)      # before the GPU is touched (forks)
     s_inp = strong_inputs(args, rank, world, workers) if (world > 1 and not args.strong and args.strong_leg_contigs > 0) else None
+    two_core = None
+    if rank == 0 and world == 1 and not args.strong and not args.no_two_core and workers > 1 and mine:      # (workers == 1: under a profiler -- no forks)
+        two_core = constrained_child(args, 2, contigs, blob, off, read_ctg, ids, name_tab, maps, mine)      # before torch is imported or the GPU touched; the child has the GPU to itself
 
     import torch
     import torch.distributed as dist
@@ -466,7 +569,9 @@ def main():
         if comm is None:
             print("bench.py: " + gather_note, file=sys.stderr, flush=True)
     out_root = None
-    for cand in (args.out_root, None, "/dev/shm", REPO):          # --out-root, then $TMPDIR, then wherever a directory can be made
+    # --out-root, else a memory file system (what the step's files cost on a disk-backed /tmp depends on what was written there before -- measured: the same step's
+    # writer threads took 2 ms or 30 ms of system time each, in the order the runs came), else $TMPDIR, else wherever a directory can be made
+    for cand in ((args.out_root,) if args.out_root else ()) + ("/dev/shm", None, REPO):
         try:
             out_root = tempfile.mkdtemp(prefix="fzp_bench_r%d_" % rank, dir=cand)
             break
@@ -474,7 +579,8 @@ def main():
             continue
     if out_root is None:
         raise SystemExit("bench.py: no writable scratch directory for the output trees")
-    eng.prof_enable(True)
+    prof_on = not os.environ.get("FZP_BENCH_NO_PROF")      # (measurement aid: the step without the library's HIP-event brackets; the line then has no kernel times)
+    eng.prof_enable(prof_on)
     t_up = time.perf_counter()
     # (a rank whose shard is empty -- --strong with fewer contigs than ranks -- has no job; it still takes part in every collective)
     job = _lib.align_job_raw(eng, contigs, blob, off, read_ctg) if mine else None     # upload + 2-bit pack: inputs now resident in HBM
@@ -524,7 +630,7 @@ def main():
     for k in sect:
         sect[k] = 0.0
     eng.prof_reset()
-    eng.prof_enable(True)
+    eng.prof_enable(2 if prof_on else 0)      # the timed steps bracket the DP stage only (what the roofline needs); every other kernel's time comes from an instrumented pass below
     barrier()
     thr0 = thread_cpu() if os.environ.get("FZP_BENCH_THREAD_CPU") else None
     t0 = time.perf_counter()
@@ -536,10 +642,26 @@ def main():
     cpu_ms_per_step = (time.process_time() - cpu0) / args.steps * 1e3      # user + system time of every thread of this rank (launch thread, host workers, file writers)
     if thr0 is not None and rank == 0:                                     # measurement aid: which threads that time belongs to
         thr1 = thread_cpu()
-        rows = sorted(((thr1[t][1] - thr0.get(t, (thr1[t][0], 0.0))[1], thr1[t][0], t) for t in thr1), reverse=True)
-        print("thread cpu ms/step: " + ", ".join("%s[%d] %.2f" % (nm, t, d / args.steps * 1e3) for d, nm, t in rows[:24] if d > 0), file=sys.stderr, flush=True)
+        rows = sorted(((thr1[t][1] - thr0.get(t, (thr1[t][0], 0.0, 0.0))[1], thr1[t][2] - thr0.get(t, (thr1[t][0], 0.0, 0.0))[2], thr1[t][0], t) for t in thr1), reverse=True)
+        print("thread cpu ms/step (of which system): " + ", ".join("%s[%d] %.2f (%.2f)" % (nm, t, d / args.steps * 1e3, sy / args.steps * 1e3) for d, sy, nm, t in rows[:40] if d > 0),
+              file=sys.stderr, flush=True)
     eng.prof_enable(False)
     prof = eng.prof()
+    # the same steps once more with every kernel bracketed by HIP events (outside the timed region: sixty brackets cost a step ~1.3 ms and the rank ~6 ms of CPU)
+    prof_all, ms_instr, n_instr = {}, None, 0
+    host_t_timed, sect_timed = dict(host_t), dict(sect)      # (the timed steps' host sections: `step` goes on adding to the dictionaries it closes over)
+    if prof_on and job is not None:
+        n_instr = max(2, min(args.steps, 5))
+        eng.prof_reset()
+        eng.prof_enable(1)
+        barrier()
+        t_i = time.perf_counter()
+        for _ in range(n_instr):
+            step()
+        barrier()
+        ms_instr = (time.perf_counter() - t_i) / n_instr * 1e3
+        eng.prof_enable(False)
+        prof_all = eng.prof()
     n_total = n_reads
     if world > 1:
         tt = torch.tensor([dt, float(n_reads)], dtype=torch.float64, device=coll_dev)
@@ -600,31 +722,42 @@ def main():
     if e2e is not None and not args.no_from_files:
         # the same workload from the reference's own input files (unzip.py:204,233-234: reads/<ctg>_ref.fa, <ctg>_reads.fa) on a memory file system: FASTA parsing
         # (the library's, a contig group ahead of the lanes) inside the clock as well -- what scripts/fc_unzip_phase_gpu.py does per rank.  Never `value`.
-        reads_dir = None
         try:
-            reads_dir = write_reads_tree(contigs, blob, off, read_ctg, ids, name_tab, "/dev/shm" if os.path.isdir("/dev/shm") else out_root)
             gc, lanes = (len(mine), 1) if e2e["lanes"] == 1 else (args.e2e_group_contigs, args.e2e_lanes)
-            gb = int(gc * args.reads_per_contig * args.read_len * 1.09)      # (file sizes: bases + names)
-            runs = []
-            for k in range(3):
-                t1 = time.perf_counter()
-                st, recs_f = _lib.phase_contigs_files(eng, reads_dir, ids, out_dir=os.path.join(out_root, "files_%d" % k), read_maps=maps, ctg_index=mine, n_lanes=lanes, group_bases=gb,
-                                                      consensus=args.with_consensus, async_writes=True)
-                runs.append((time.perf_counter() - t1, st))
-            best = min(runs[1:], key=lambda x: x[0])
+            t_best, st_best, recs_f, last_dir, mb = files_leg(args, eng, contigs, blob, off, read_ctg, ids, name_tab, maps, mine, out_root, gc, lanes)
             _, recs_m = _lib.phase_contigs(eng, contigs, blob, off, read_ctg, ids, names=name_tab, out_dir=os.path.join(out_root, "files_ref"), read_maps=maps, ctg_index=mine,
                                            n_lanes=lanes, group_bases=int(gc * args.reads_per_contig * args.read_len * 1.06), consensus=args.with_consensus, async_writes=True)
-            same = bool(np.array_equal(recs_f, recs_m)) and tree_digest(os.path.join(out_root, "files_2")) == tree_digest(os.path.join(out_root, "files_ref"))
-            from_files = {"reads_per_s": round(n_reads / best[0], 1), "ms": round(best[0] * 1e3, 2), "lanes": lanes, "groups": int(best[1]["n_groups"]),
-                          "vs_end_to_end": round(best[0] * 1e3 / e2e["ms"], 3), "same_bytes_as_from_memory": same,
-                          "input_mb": round(sum(os.path.getsize(os.path.join(reads_dir, f)) for f in os.listdir(reads_dir)) / 1e6, 1),
+            same = bool(np.array_equal(recs_f, recs_m)) and tree_digest(last_dir) == tree_digest(os.path.join(out_root, "files_ref"))
+            from_files = {"reads_per_s": round(n_reads / t_best, 1), "ms": round(t_best * 1e3, 2), "lanes": lanes, "groups": int(st_best["n_groups"]),
+                          "vs_end_to_end": round(t_best * 1e3 / e2e["ms"], 3), "same_bytes_as_from_memory": same, "input_mb": round(mb, 1),
                           "note": "fzp_phase_contigs_files: <ctg>_ref.fa / <ctg>_reads.fa on a memory file system -> FASTA parsing by the library's host threads -> H2D -> pack -> K1..K5 "
                                   "-> texts -> files; reported beside `value`, never as it"}
         except Exception as e:      # noqa: BLE001 -- reported in the line
             from_files = {"error": repr(e)}
-        finally:
-            if reads_dir:
-                shutil.rmtree(reads_dir, ignore_errors=True)
+    if world > 1 and not args.strong and not args.no_from_files:
+        # N > 1: every rank its own shard's files, all ranks side by side (a barrier before every call), all reads / the slowest rank -- SURVEY 8d's reads phased/sec
+        # "end-to-end incl. host I/O" for the whole node.  A rank that fails says so; the collectives below are entered by every rank either way.
+        err, t_mine, passed = "", 0.0, [0]
+
+        def side_by_side():
+            dist.barrier()
+            passed[0] += 1
+        try:
+            t_mine, st_best, _, _, mb = files_leg(args, eng, contigs, blob, off, read_ctg, ids, name_tab, maps, mine, out_root, args.e2e_group_contigs, args.e2e_lanes, sync=side_by_side)
+        except Exception as e:      # noqa: BLE001
+            err = "rank %d: %r" % (rank, e)
+            print("bench.py from_files: " + err, file=sys.stderr, flush=True)
+            while passed[0] < 3:
+                side_by_side()      # the barriers the other ranks' remaining calls wait at
+        per_rank = [torch.zeros(3, dtype=torch.float64, device=coll_dev) for _ in range(world)]
+        dist.all_gather(per_rank, torch.tensor([t_mine, float(n_reads), 0.0 if err else 1.0], dtype=torch.float64, device=coll_dev))
+        if all(float(p[2].item()) == 1.0 for p in per_rank):
+            slowest = max(float(p[0].item()) for p in per_rank)
+            from_files = {"reads_per_s": round(sum(float(p[1].item()) for p in per_rank) / slowest, 1), "ms": round(slowest * 1e3, 2), "lanes": args.e2e_lanes, "n_gpus": world,
+                          "rank_ms": [round(float(p[0].item()) * 1e3, 2) for p in per_rank],
+                          "note": "every rank its own 20 contigs from <ctg>_ref.fa / <ctg>_reads.fa on a memory file system through fzp_phase_contigs_files, all ranks at once: all reads / slowest rank"}
+        else:
+            from_files = {"error": err or "another rank failed"}
 
     pipelined = None
     if rank == 0 and world == 1 and not args.no_end_to_end and not os.environ.get("FZP_BENCH_NO_PIPELINED"):
@@ -695,15 +828,20 @@ def main():
             "dp_cells_per_step": cells_per_step,
             "aligned_frac": round(aligned_frac, 4),
             "stage_counts": {k: int(v) for k, v in stats.items()},
-            "kernel_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in sorted(prof.items())},
+            "kernel_ms_per_step": {k: round(v[0] / max(1, n_instr), 3) for k, v in sorted(prof_all.items())},      # from the instrumented pass (every kernel bracketed), not the timed steps
+            "ms_per_step_instrumented": round(ms_instr, 3) if ms_instr else None, "instrumented_steps": n_instr,
             "host_cpu_ms_per_step": round(cpu_ms_per_step, 2),
-            "host_wall_ms_per_step": dict({k: round(v / args.steps * 1e3, 3) for k, v in host_t.items()}, **{k[3:]: round(v / args.steps, 3) for k, v in sect.items()}),
+            "out_fs": fs_of(out_root),
+            "host_wall_ms_per_step": dict({k: round(v / args.steps * 1e3, 3) for k, v in host_t_timed.items()}, **{k[3:]: round(v / args.steps, 3) for k, v in sect_timed.items()}),
             "rank_load": rank_load,
             "gather": "fzp_allgather_rid_to_phase (RCCL, C-ABI)" if comm is not None else ("torch.distributed all_gather (%s)" % backend if world > 1 else "none (1 rank)"),
             "rccl_ranks": comm.ranks()[1] if comm is not None else 0,      # size of the RCCL communicator as ncclCommCount reports it (0: no RCCL communicator in this run)
             "gather_fallback": gather_note,
             "index_in_step": not args.index_at_create,
-            "index_ms": round(prof.get("k1_index", (0.0, 0))[0] / args.steps, 3) if not args.index_at_create else round(index_ms_at_create, 3),
+            "index_ms": round(prof_all.get("k1_index", (0.0, 0))[0] / max(1, n_instr), 3) if not args.index_at_create else round(index_ms_at_create, 3),
+            "value_from_files": from_files.get("reads_per_s") if from_files else None,      # SURVEY 8d's "reads phased/sec (end-to-end incl. host I/O)": FASTA files in, files out
+            "two_core_step_ms": two_core.get("ms_per_step") if two_core else None,           # the resident step on TWO CPUs with LOCAL_WORLD_SIZE=8 (a rank's share of a 16-CPU, 8-GPU node)
+            "two_core": dict(two_core, vs_unconstrained=round(two_core["ms_per_step"] / ms_per_step, 3)) if (two_core and "ms_per_step" in two_core) else two_core,
             "value_end_to_end": e2e["reads_per_s"] if e2e else None,       # host ASCII in, PCIe + packing + index inside (SURVEY 8d's reads-phased/sec); `value` keeps inputs resident (bench contract)
             "end_to_end": e2e,
             "from_files": from_files,

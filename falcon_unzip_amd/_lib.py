@@ -422,7 +422,8 @@ class Engine:
 
     # ---- profiling
     def prof_enable(self, on=True):
-        _check(load().fzp_prof_enable(self._p, C.c_int(1 if on else 0)))
+        """True / 1: every kernel bracket; 2: the DP stage (k1_sw) only; False / 0: off"""
+        _check(load().fzp_prof_enable(self._p, C.c_int(int(on) if not isinstance(on, bool) else (1 if on else 0))))
 
     def prof_reset(self):
         _check(load().fzp_prof_reset(self._p))

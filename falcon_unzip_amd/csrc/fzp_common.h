@@ -118,6 +118,7 @@ struct fzp_ctx {
     hipStream_t stream2 = nullptr;   // trace-back of chunk k runs here while the DP of chunk k+1 runs on `stream`
     hipStream_t stream3 = nullptr;   // K1: the wave-per-read DP of the long reads runs here beside the bit-sliced DP of the others on `stream`
     bool prof = false;
+    int prof_level = 0;               // fzp_prof_enable: 1 = every bracket, 2 = the DP stage (k1_sw) only
     std::map<std::string, ProfEntry> prof_tab;
     std::vector<PendingEvent> pending;
     std::vector<hipEvent_t> event_pool;

@@ -2,6 +2,7 @@
 // (phasing.py:42-75), the text serializers (the reference's `print >>f` statements) and
 // get_phasing_readmap (phasing_readmap.py:8-51, pure host bookkeeping).
 #include <algorithm>
+#include <chrono>
 #include <sched.h>
 #include <thread>
 #include <unordered_map>
@@ -121,6 +122,20 @@ __global__ void __launch_bounds__(64) k_fetch_post(FetchArgs a, volatile uint32_
     if (threadIdx.x == 0) *(volatile uint64_t *)(slot + 256) = seq;
 }
 }  // namespace
+// How the calling thread waits (r5).  The count it asks for is usually microseconds away (the stages of a step follow each other), so it looks at the mapped word for a
+// short while -- a look costs nothing and answers in ~1 us -- and then stops burning its core: it hands the wait to the runtime (hipStreamSynchronize), which under the
+// device's blocking-sync scheduling (fzp_ctx_create: hipDeviceScheduleBlockingSync) sleeps on the queue's completion signal.  The spin budget: FZP_FETCH_SPIN_US, default
+// 60 us (tools/ubench/fetch_latency.hip: a dependent kernel answers in 12); the step's long waits -- the DP behind the plan's counts, K2 behind the record counts -- are
+// what a launch thread used to spin through, 22 ms of a 22 ms step.  One fetching thread per ctx (a ctx is used by one host thread at a time: fzphase.h).
+static inline void cpu_relax() {
+#if !defined(__HIP_DEVICE_COMPILE__)      // (host code in a .hip file is parsed by the device pass too; the x86 builtin exists on the host side only)
+    __builtin_ia32_pause();
+#endif
+}
+static int64_t fetch_spin_ns() {
+    static const int64_t v = [] { const char *e = getenv("FZP_FETCH_SPIN_US"); const long g = e ? atol(e) : 60; return (int64_t)(g < 0 ? 0 : g) * 1000; }();
+    return v;
+}
 int fzp_fetch(fzp_ctx *ctx, hipStream_t st, const fzp_fetch_piece *pieces, int n_pieces) {
     if (!ctx || !pieces || n_pieces < 1 || n_pieces > 4) { fzp_set_error("fzp_fetch: bad arguments"); return FZP_EINVAL; }
     FetchArgs a;
@@ -131,7 +146,8 @@ int fzp_fetch(fzp_ctx *ctx, hipStream_t st, const fzp_fetch_piece *pieces, int n
     }
     if (!ctx->fetch_slot) {
         void *p = nullptr;
-        if (hipHostMalloc(&p, 4096, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); fzp_set_error("fzp_fetch: pinned allocation failed"); return FZP_ENOMEM; }
+        // coherent + mapped, whatever HIP_HOST_COHERENT says: the device's system-scope stores must be visible to the spinning host thread as they land
+        if (hipHostMalloc(&p, 4096, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); fzp_set_error("fzp_fetch: pinned allocation failed"); return FZP_ENOMEM; }
         memset(p, 0, 4096);
         ctx->fetch_slot = (uint32_t *)p;
     }
@@ -139,14 +155,19 @@ int fzp_fetch(fzp_ctx *ctx, hipStream_t st, const fzp_fetch_piece *pieces, int n
     hipLaunchKernelGGL(k_fetch_post, dim3(1), dim3(64), 0, st, a, (volatile uint32_t *)ctx->fetch_slot, seq);
     if (hipGetLastError() != hipSuccess) { fzp_set_error("fzp_fetch: launch failed"); return FZP_EDEVICE; }
     volatile uint64_t *sq = (volatile uint64_t *)(ctx->fetch_slot + 256);
+    const int64_t budget = fetch_spin_ns();
     const auto t0 = std::chrono::steady_clock::now();
-    for (uint32_t spins = 0; __atomic_load_n((const uint64_t *)sq, __ATOMIC_ACQUIRE) != seq; spins++) {
-        if ((spins & 0xffff) == 0xffff) {      // (rarely: has the stream died under us?  a device fault must not leave the host spinning)
-            const hipError_t e = hipStreamQuery(st);
-            if (e != hipSuccess && e != hipErrorNotReady) { fzp_set_error("fzp_fetch: %s", hipGetErrorString(e)); return FZP_EDEVICE; }
-            (void)hipGetLastError();
-            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) { fzp_set_error("fzp_fetch: no answer from the device in 120 s"); return FZP_EDEVICE; }
-        }
+    bool have = false;
+    for (uint32_t spins = 0;; spins++) {
+        if (__atomic_load_n((const uint64_t *)sq, __ATOMIC_ACQUIRE) == seq) { have = true; break; }
+        cpu_relax();
+        if ((spins & 63) == 63 && std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count() > budget) break;
+    }
+    if (!have) {
+        // the long wait: the runtime's (a sleep under blocking-sync scheduling); a dead stream comes back as its error instead of an endless spin
+        const hipError_t e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { (void)hipGetLastError(); fzp_set_error("fzp_fetch: %s", hipGetErrorString(e)); return FZP_EDEVICE; }
+        if (__atomic_load_n((const uint64_t *)sq, __ATOMIC_ACQUIRE) != seq) { fzp_set_error("fzp_fetch: the stream is idle and the words never arrived"); return FZP_EDEVICE; }
     }
     int base = 0;
     for (int k = 0; k < n_pieces; k++) { memcpy(pieces[k].host, ctx->fetch_slot + base, pieces[k].bytes); base += a.n[k]; }
@@ -322,6 +343,10 @@ extern "C" int fzp_ctx_create(int device_id, unsigned flags, fzp_ctx **out) {
     (void)flags;
     if (!out) return FZP_EINVAL;
     *out = nullptr;
+    // (before the runtime reads its settings, i.e. before this process's first HIP call -- a no-op otherwise, and never over the user's own value)  The runtime hands every
+    // queued command a completion signal from a pool of 64 and WAITS on the CPU when the pool wraps; a step queues several hundred commands ahead of the device, and the
+    // waits cost a rank 7-9 ms of system time per step on the runtime's completion thread (r5: tools/runs/who_is_busy.py, host_cpu_ab2.sh)
+    (void)setenv("ROC_SIGNAL_POOL_SIZE", "4096", 0);
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) {
@@ -334,6 +359,13 @@ extern "C" int fzp_ctx_create(int device_id, unsigned flags, fzp_ctx **out) {
         return FZP_EINVAL;
     }
     FZP_HIP(hipSetDevice(device_id));
+    {   // How this runtime waits is a property of the DEVICE (hipSetDeviceFlags), not of the event or the call: under the default (hipDeviceScheduleAuto) every
+        // hipStreamSynchronize / hipEventSynchronize spins for as long as the GPU works -- a core per rank gone, and eight ranks share a 16-CPU quota (unzip.py:255,342-350:
+        // the reference gives a phasing job its core budget too).  Blocking sync: a short look, then the thread sleeps on the completion signal.  FZP_SCHED=auto|spin|yield|blocking.
+        const char *m = getenv("FZP_SCHED");
+        const unsigned f = !m || !strcmp(m, "blocking") ? hipDeviceScheduleBlockingSync : !strcmp(m, "spin") ? hipDeviceScheduleSpin : !strcmp(m, "yield") ? hipDeviceScheduleYield : hipDeviceScheduleAuto;
+        if (hipSetDeviceFlags(f) != hipSuccess) (void)hipGetLastError();      // (a runtime that refuses keeps its default: slower to yield, not wrong)
+    }
     hipDeviceProp_t prop;
     FZP_HIP(hipGetDeviceProperties(&prop, device_id));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
@@ -411,6 +443,9 @@ static hipEvent_t get_event(fzp_ctx *c) {
     return e;
 }
 ProfScope::ProfScope(fzp_ctx *ctx, const char *name, hipStream_t stream) : c(ctx), on(ctx->prof), st(stream ? stream : ctx->stream) {
+    // level 2: the DP stage only.  A bracket is two event records: ~5 us of the stream and ~40 us of CPU each (calling thread + the runtime's completion thread) -- sixty
+    // of them per step cost the step 1.3 ms and the rank 6 ms of CPU (r5, FZP_BENCH_NO_PROF A/B); the roofline needs exactly one
+    if (on && ctx->prof_level == 2 && strcmp(name, "k1_sw") != 0) on = false;
     if (!on) return;
     ev.name = name;
     ev.a = get_event(c);
@@ -442,6 +477,7 @@ int fzp_prof_flush(fzp_ctx *ctx) {
 extern "C" int fzp_prof_enable(fzp_ctx *ctx, int on) {
     FZP_TRY(fzp_prof_flush(ctx));
     ctx->prof = on != 0;
+    ctx->prof_level = on;
     return FZP_OK;
 }
 extern "C" int fzp_prof_reset(fzp_ctx *ctx) {

@@ -11,6 +11,7 @@
 // File layout = the reference's: <out_dir>/<ctg>/{het_call/{variant_pos,variant_map,q_id_map}, g_atable/atable,
 // get_phased_blocks/phased_variants, phased_reads, rid_to_phase.<ctg>}  (phasing.py:501-503,520,534,543; unzip.py:269).
 #include <fcntl.h>
+#include <pthread.h>
 #include <sched.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -43,7 +44,8 @@ struct FileWriter {
     std::string first_error;
     void start(int n) {
         for (int i = 0; i < n; i++)
-            th.emplace_back([this] {
+            th.emplace_back([this, i] {
+                { char nm[16]; snprintf(nm, sizeof nm, "fzp-wr%d", i); (void)pthread_setname_np(pthread_self(), nm); }
                 for (;;) {
                     std::function<void()> job;
                     {
@@ -86,7 +88,9 @@ struct FileWriter {
 // when all are done.  One run at a time per pool (a context is used by one host thread).
 struct WorkPool {
     std::mutex mu;
-    std::condition_variable cv, done_cv;
+    std::condition_variable done_cv;
+    std::vector<std::unique_ptr<std::condition_variable>> wake;      // one per worker: a run wakes the workers it has tasks for, not the whole pool (r5: fifteen sleepers woken
+                                                                      // per run to find nothing cost a rank half a millisecond of CPU each and step)
     std::vector<std::thread> th;
     const std::function<void(int, int)> *fn = nullptr;
     std::atomic<int> next{0};
@@ -95,15 +99,17 @@ struct WorkPool {
     bool stop = false;
     int size() const { return (int)th.size() + 1; }
     void start(int workers, int device) {
+        for (int i = 0; i < workers; i++) wake.emplace_back(new std::condition_variable());
         for (int i = 0; i < workers; i++)
             th.emplace_back([this, i, device] {
+                { char nm[16]; snprintf(nm, sizeof nm, "fzp-wk%d", i); (void)pthread_setname_np(pthread_self(), nm); }
                 (void)hipSetDevice(device);                  // the tasks wait on events of the context's device
                 uint64_t seen = 0;
                 for (;;) {
                     const std::function<void(int, int)> *f;
                     {
                         std::unique_lock<std::mutex> lk(mu);
-                        cv.wait(lk, [&] { return stop || gen != seen; });
+                        wake[(size_t)i]->wait(lk, [&] { return stop || gen != seen; });
                         if (stop) return;
                         seen = gen;
                         f = fn;
@@ -119,11 +125,13 @@ struct WorkPool {
             });
     }
     void run(int n_tasks, const std::function<void(int, int)> &f, int max_threads) {
+        int helpers;
         {
             std::lock_guard<std::mutex> lk(mu);
             fn = &f; n = n_tasks; limit = max_threads; next.store(0); gen++;
+            helpers = std::min((int)th.size(), std::min(max_threads, n_tasks) - 1);      // the caller's thread takes tasks too
         }
-        cv.notify_all();
+        for (int i = 0; i < helpers; i++) wake[(size_t)i]->notify_one();
         for (int t; (t = next.fetch_add(1)) < n_tasks;) f(0, t);
         std::unique_lock<std::mutex> lk(mu);
         fn = nullptr;                                        // a worker that wakes up late finds nothing to do
@@ -131,10 +139,14 @@ struct WorkPool {
     }
     ~WorkPool() {
         { std::lock_guard<std::mutex> lk(mu); stop = true; }
-        cv.notify_all();
+        for (auto &w : wake) w->notify_all();
         for (auto &t : th) t.join();
     }
 };
+static int writer_threads() {      // background file writers of a context: FZP_WRITER_THREADS, default = the rank's cores (2..16)
+    if (const char *e = getenv("FZP_WRITER_THREADS")) { const int g = atoi(e); if (g >= 1 && g <= 64) return g; }
+    return std::min(4, std::max(2, cores_per_rank()));      // (r5: 16 writers cost a rank 13 ms of CPU per step in wake-ups and page-cache contention, 4 cost 9.6 and the files are down as soon)
+}
 struct GroupPool;
 static void group_pool_destroy(GroupPool *p);
 void fzp_writer_destroy(fzp_ctx *ctx) {
@@ -338,21 +350,28 @@ int readmap_rows(const ReadMaps &m, const char *ctg_id, const std::vector<int64_
         if (i + 1 == out.size() || out[i + 1].pid != out[i].pid) { R.pid.push_back(out[i].pid); R.nid.push_back(out[i].nid); }
     return FZP_OK;
 }
-void readmap_fill(const ReadmapRows &R, const char *ctg_id, int32_t ctg_index, const fzp_pread *pr, int64_t n_pr, std::vector<fzp_r2p> &recs, std::string &text) {
-    std::vector<std::pair<int, int>> val((size_t)R.n_names, {-1, 0});      // rid_to_phase by name (lines 29-33: the last line of a name wins; a name without one: (-1, 0), line 46)
-    for (int64_t i = 0; i < n_pr; i++) val[(size_t)R.name_of_q[(size_t)pr[i].q_id]] = {pr[i].block, pr[i].phase};
+// the records first (they are what the caller's gather needs), the text from them (lines 49-51) -- by a write task when the files are written in the background
+void readmap_text(const fzp_r2p *recs, size_t n, const char *ctg_id, std::string &text) {
     const size_t cn = strlen(ctg_id);
     TextBuf b;
-    b.s.reserve(R.pid.size() * (cn + 20));
-    for (size_t i = 0; i < R.pid.size(); i++) {                                        // lines 49-51
-        const std::pair<int, int> v = R.nid[i] < 0 ? std::pair<int, int>{-1, 0} : val[(size_t)R.nid[i]];
+    b.s.reserve(n * (cn + 20));
+    for (size_t i = 0; i < n; i++) {
         char key[32];
-        snprintf(key, sizeof key, "%09lld", R.pid[i]);
+        snprintf(key, sizeof key, "%09lld", (long long)recs[i].arid);
         b.s += key; b.s.push_back(' '); b.s.append(ctg_id, cn); b.s.push_back(' ');
-        b.puti(v.first); b.s.push_back(' '); b.puti(v.second); b.s.push_back('\n');
-        recs.push_back({(int32_t)R.pid[i], ctg_index, v.first, v.second});
+        b.puti(recs[i].block); b.s.push_back(' '); b.puti(recs[i].phase); b.s.push_back('\n');
     }
     text.swap(b.s);
+}
+void readmap_fill(const ReadmapRows &R, const char *ctg_id, int32_t ctg_index, const fzp_pread *pr, int64_t n_pr, std::vector<fzp_r2p> &recs, std::string *text) {
+    std::vector<std::pair<int, int>> val((size_t)R.n_names, {-1, 0});      // rid_to_phase by name (lines 29-33: the last line of a name wins; a name without one: (-1, 0), line 46)
+    for (int64_t i = 0; i < n_pr; i++) val[(size_t)R.name_of_q[(size_t)pr[i].q_id]] = {pr[i].block, pr[i].phase};
+    const size_t first = recs.size();
+    for (size_t i = 0; i < R.pid.size(); i++) {
+        const std::pair<int, int> v = R.nid[i] < 0 ? std::pair<int, int>{-1, 0} : val[(size_t)R.nid[i]];
+        recs.push_back({(int32_t)R.pid[i], ctg_index, v.first, v.second});
+    }
+    if (text) readmap_text(recs.data() + first, recs.size() - first, ctg_id, *text);
 }
 
 bool mkdir_p(const std::string &path) {
@@ -365,19 +384,31 @@ bool mkdir_p(const std::string &path) {
     }
     return true;
 }
-bool write_file(const std::string &path, const char *data, size_t n, std::atomic<int64_t> &bytes) {
-    int fd = open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
-    if (fd < 0) return false;
-    size_t off = 0;
-    while (off < n) {
-        ssize_t w = write(fd, data + off, n - off);
-        if (w < 0) { if (errno == EINTR) continue; const int e = errno; close(fd); errno = e; return false; }
-        off += (size_t)w;
+// A contig's files are made relative to ONE handle of its directory (mkdirat / openat): twenty writers that each resolved seven full paths -- and three mkdir -p walks
+// from the root -- took turns on the locks of the ancestors they all share; now a contig touches its parent once (mkdir of its own directory) and after that only itself.
+struct DirWriter {
+    int fd = -1;
+    ~DirWriter() { if (fd >= 0) close(fd); }
+    bool open_base(const std::string &base) {
+        if (mkdir(base.c_str(), 0777) != 0 && errno != EEXIST && !mkdir_p(base)) return false;      // (the parent is made once per call, by the calling thread)
+        fd = open(base.c_str(), O_RDONLY | O_DIRECTORY | O_CLOEXEC);
+        return fd >= 0;
     }
-    close(fd);
-    bytes += (int64_t)n;
-    return true;
-}
+    bool subdir(const char *name) { return mkdirat(fd, name, 0777) == 0 || errno == EEXIST; }
+    bool file(const char *rel, const char *data, size_t n, std::atomic<int64_t> &bytes) {
+        const int f = openat(fd, rel, O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);
+        if (f < 0) return false;
+        size_t off = 0;
+        while (off < n) {
+            const ssize_t w = write(f, data + off, n - off);
+            if (w < 0) { if (errno == EINTR) continue; const int e = errno; close(f); errno = e; return false; }
+            off += (size_t)w;
+        }
+        close(f);
+        bytes += (int64_t)n;
+        return true;
+    }
+};
 void add(fzp_pipe_out *a, const fzp_pipe_out &b) {
     a->n_reads += b.n_reads; a->n_aligned += b.n_aligned; a->n_rec += b.n_rec; a->n_sites += b.n_sites; a->n_rows += b.n_rows; a->n_arows += b.n_arows;
     a->n_pvars += b.n_pvars; a->n_preads += b.n_preads; a->n_groups += b.n_groups; a->bytes_written += b.bytes_written; a->dp_cells += b.dp_cells;
@@ -404,7 +435,7 @@ extern "C" int fzp_debug_readmap_records(const char *rawread_ids, size_t rr_len,
     const int rc = readmap_rows(m, ctg_id, qoff, qn, R, err);
     if (rc != FZP_OK) { fzp_set_error("%s", err.c_str()); return rc; }
     std::vector<fzp_r2p> out;
-    readmap_fill(R, ctg_id, ctg_index, preads, n_preads, out, txt);
+    readmap_fill(R, ctg_id, ctg_index, preads, n_preads, out, &txt);
     *recs = (fzp_r2p *)malloc((out.size() ? out.size() : 1) * sizeof(fzp_r2p));
     *text = (char *)malloc(txt.size() + 1);
     if (!*recs || !*text) { free(*recs); free(*text); fzp_set_error("fzp_debug_readmap_records: host memory"); return FZP_ENOMEM; }
@@ -447,15 +478,14 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
     // read-map rows resolved down to read names (readmap_rows) are made while the device runs K2..K5
     const int64_t n_slots = b->h_slot_off.empty() ? 0 : b->h_slot_off.back();
     hipStream_t st2 = ctx->stream2;
-    struct Ev { hipEvent_t e = nullptr; ~Ev() { if (e) (void)hipEventDestroy(e); } } ev_k1, ev_q, ev_t;
+    struct Ev { hipEvent_t e = nullptr; ~Ev() { if (e) (void)hipEventDestroy(e); } } ev_k1, ev_q;
     FZP_HIP(hipEventCreateWithFlags(&ev_k1.e, hipEventDisableTiming));
     FZP_HIP(hipEventCreateWithFlags(&ev_q.e, hipEventDisableTiming));
-    FZP_HIP(hipEventCreateWithFlags(&ev_t.e, hipEventDisableTiming));
     struct PinQ { fzp_ctx *c; void *p = nullptr; ~PinQ() { if (p) fzp_pinned_release(c, p); } } pin_q{ctx};
     size_t pin_q_cap = 0;
     pin_q.p = fzp_pinned_acquire(ctx, (size_t)n_slots * 4 + 64, &pin_q_cap);
     if (!pin_q.p) { fzp_set_error("pinned host allocation failed"); return FZP_ENOMEM; }
-    struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamSynchronize(s); } } sg2{st2};     // nothing below may leave while copies into pinned blocks are in flight
+    struct StreamGuard { hipStream_t s; bool armed = true; ~StreamGuard() { if (armed) (void)hipStreamSynchronize(s); } } sg2{st2};     // nothing below may leave while copies into pinned blocks are in flight
     FZP_HIP(hipEventRecord(ev_k1.e, ctx->stream));
     FZP_HIP(hipStreamWaitEvent(st2, ev_k1.e, 0));
     if (n_slots) FZP_HIP(hipMemcpyAsync(pin_q.p, b->qid_read.p, (size_t)n_slots * 4, hipMemcpyDeviceToHost, st2));
@@ -489,6 +519,7 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
     };
     std::string early_err;
     std::thread early([&]() {
+        (void)pthread_setname_np(pthread_self(), "fzp-early");
         if (hipSetDevice(ctx->device) != hipSuccess || hipEventSynchronize(ev_q.e) != hipSuccess) { (void)hipGetLastError(); early_err = "the q_id table did not arrive"; return; }
         ctx->workers->run(nc, pre_work, std::min(want_threads, 6));      // (a few threads: there are milliseconds to do this in, and the thread that launches the kernels wants a core)
     });
@@ -503,30 +534,39 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
     struct TG { fzp_tigs *t; ~TG() { fzp_tigs_free(t); } } tg{&tigs};
     // the two big texts: serialised on the device, brought over while the records come.  (Serialising them right behind K3 and copying them under K4 / K5 was
     // measured: the phasing stage grew by more than the host section shrank -- that section is bound by its own formatting, not by these copies.)
-    DevBuf<char> d_vmap, d_atab;
+    struct Owned {
+        fzp_ctx *c; void *pin; void *rec_pin = nullptr; std::vector<char *> texts; std::mutex mu;
+        std::vector<int64_t> site_begin, pvar_begin, pread_begin;      // per contig, into the batch-wide record arrays below
+        const fzp_site *sites = nullptr; const fzp_pvar *pvars = nullptr; const fzp_pread *preads = nullptr;      // views into rec_pin (the batch's pinned result block, taken over)
+        // the two device-made texts on their way into `pin`: the copy runs under whatever the device does next; a write task waits for `ev_text` before it touches them, and
+        // the device blocks they come from stay out of the allocator's hands until the last task is done
+        DevBuf<char> d_vmap, d_atab;
+        hipEvent_t ev_text = nullptr;
+        int device = 0;
+        bool texts_there() { return hipSetDevice(device) == hipSuccess && hipEventSynchronize(ev_text) == hipSuccess; }
+        ~Owned() { if (ev_text) { (void)hipEventSynchronize(ev_text); (void)hipEventDestroy(ev_text); } fzp_pinned_release(c, pin); if (rec_pin) fzp_pinned_release(c, rec_pin); for (auto t : texts) free(t); }
+    };
+    std::shared_ptr<Owned> owned = std::make_shared<Owned>();
+    owned->c = ctx; owned->pin = nullptr; owned->device = ctx->device;
+    FZP_HIP(hipEventCreateWithFlags(&owned->ev_text, hipEventDisableTiming));
     size_t n_vmap = 0, n_atab = 0;
     std::vector<int64_t> vb, ab;
-    FZP_TRY(fzp_batch_text_dev(ctx, b, FZP_TEXT_VARIANT_MAP, d_vmap, &n_vmap, vb));
-    FZP_TRY(fzp_batch_text_dev(ctx, b, FZP_TEXT_ATABLE, d_atab, &n_atab, ab));
+    FZP_TRY(fzp_batch_text_dev(ctx, b, FZP_TEXT_VARIANT_MAP, owned->d_vmap, &n_vmap, vb));
+    FZP_TRY(fzp_batch_text_dev(ctx, b, FZP_TEXT_ATABLE, owned->d_atab, &n_atab, ab));
     size_t pin_cap = 0;
     const size_t o_atab = (n_vmap + 63) & ~(size_t)63, o_end = o_atab + ((n_atab + 63) & ~(size_t)63);
     char *pin = (char *)fzp_pinned_acquire(ctx, o_end + 64, &pin_cap);
     if (!pin) { fzp_set_error("pinned host allocation failed"); return FZP_ENOMEM; }
+    owned->pin = pin;
     // the block (and the small texts) live until their last file is written: shared by the per-contig write tasks
-    struct Owned {
-        fzp_ctx *c; void *pin; std::vector<char *> texts; std::mutex mu;
-        ~Owned() { fzp_pinned_release(c, pin); for (auto t : texts) free(t); }
-    };
-    std::shared_ptr<Owned> owned = std::make_shared<Owned>();
-    owned->c = ctx; owned->pin = pin;
     const bool async = (o->flags & FZP_PIPE_ASYNC_WRITES) != 0 && o->out_dir;
-    if (async && !ctx->writer) { ctx->writer = new FileWriter(); ctx->writer->start(std::min(16, std::max(2, cores_per_rank()))); }
+    if (async && !ctx->writer) { ctx->writer = new FileWriter(); ctx->writer->start(writer_threads()); }
     if (async) { const std::string e = [&] { std::lock_guard<std::mutex> lk(ctx->writer->mu); std::string x; x.swap(ctx->writer->first_error); return x; }(); if (!e.empty()) { fzp_set_error("%s", e.c_str()); return FZP_EINVAL; } }
     FZP_HIP(hipStreamSynchronize(ctx->stream));
     // they only have to be there when a contig's write task is made: their copy runs under the formatting of the small files
-    if (n_vmap) FZP_HIP(hipMemcpyAsync(pin, d_vmap.p, n_vmap, hipMemcpyDeviceToHost, st2));
-    if (n_atab) FZP_HIP(hipMemcpyAsync(pin + o_atab, d_atab.p, n_atab, hipMemcpyDeviceToHost, st2));
-    FZP_HIP(hipEventRecord(ev_t.e, st2));
+    if (n_vmap) FZP_HIP(hipMemcpyAsync(pin, owned->d_vmap.p, n_vmap, hipMemcpyDeviceToHost, st2));
+    if (n_atab) FZP_HIP(hipMemcpyAsync(pin + o_atab, owned->d_atab.p, n_atab, hipMemcpyDeviceToHost, st2));
+    FZP_HIP(hipEventRecord(owned->ev_text, st2));
     fzp_result_all ra;
     FZP_TRY(fzp_batch_result_all(ctx, b, &ra));                  // sites / variant_map ids / atable rows are not needed on the host here, but the views are free
     struct RG { fzp_result_all *r; ~RG() { fzp_result_all_free(r); } } rg{&ra};
@@ -548,105 +588,95 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
     early.join();                                                // (the early half: long done)
     if (!early_err.empty()) { fzp_set_error("%s", early_err.c_str()); return FZP_EDEVICE; }
     std::atomic<int64_t> bytes{0};
-    std::vector<int> rcs((size_t)T, FZP_OK);
-    std::vector<std::string> errs((size_t)T);
     std::vector<std::vector<fzp_r2p>> recs((size_t)nc);
-    // room for a record per aligned read, taken here: vectors grown by the workers would live in the workers' malloc arenas, and freeing
-    // twenty of those from this thread cost a millisecond of arena trimming at the end of every call
-    for (int c = 0; c < nc; c++) recs[(size_t)c].reserve((size_t)(b->h_qid_off[(size_t)c + 1] - b->h_qid_off[(size_t)c]) + 16);
     const std::string out_dir = o->out_dir ? o->out_dir : "";
-    std::vector<std::function<bool()>> tasks((size_t)nc);     // per contig: write its files
+    if (o->out_dir && !mkdir_p(out_dir)) { fzp_set_error("cannot create %s: %s", out_dir.c_str(), strerror(errno)); return FZP_EIO; }      // once, here: the contigs' writers only make their own directories
+    // ---- what the caller waits for: the rid_to_phase RECORDS (an array pass per contig, on this thread).  The texts of the small files are made where the files are written:
+    // by the contig's write task -- on the background writers when FZP_PIPE_ASYNC_WRITES (under the next call's kernels: r5, the host section at the end of a step was 1.1 ms of
+    // idle GPU on sixteen cores and 3.5 ms on two), on the pool otherwise.  The records those texts are made from live in the batch's pinned result block, which the tasks take over.
+    {
+        owned->site_begin.assign(ra.site_begin, ra.site_begin + nc + 1); owned->pvar_begin.assign(ra.pvar_begin, ra.pvar_begin + nc + 1); owned->pread_begin.assign(ra.pread_begin, ra.pread_begin + nc + 1);
+        owned->sites = ra.all.sites; owned->pvars = ra.all.pvars; owned->preads = ra.all.preads;
+        owned->rec_pin = b->pin; b->pin = nullptr;                // (fzp_batch_result_all's views point into it; the batch no longer gives it back)
+    }
+    for (int c = 0; c < nc; c++) {
+        if (!maps) break;
+        PreCtg &P = pre[(size_t)c];
+        if (P.rc != FZP_OK) { fzp_set_error("%s", P.err.c_str()); return P.rc; }
+        recs[(size_t)c].reserve(P.rows.pid.size());
+        readmap_fill(P.rows, nm->ctg_id[c], ctg_index ? ctg_index[c] : c, owned->preads + owned->pread_begin[(size_t)c], owned->pread_begin[(size_t)c + 1] - owned->pread_begin[(size_t)c], recs[(size_t)c], nullptr);
+    }
+    std::vector<std::function<bool()>> tasks((size_t)nc);     // per contig: make the small texts, write all files
     std::vector<std::shared_ptr<std::string>> whys((size_t)nc);   // why a contig's write task failed, recorded by the thread it failed on
     for (auto &w : whys) w = std::make_shared<std::string>();
-    const std::function<void(int, int)> work = [&](int t, int c) {
-        {
-            if (rcs[(size_t)t] != FZP_OK) return;
-            const char *ctg = nm->ctg_id[c];
-            auto tq = clk::now();
-            PreCtg &P = pre[(size_t)c];
-            const std::vector<int64_t> &qoff = P.qoff;           // the q_id names: made by the early half
-            const std::string &qn = P.qn;
-            const int64_t nq = (int64_t)qoff.size() - 1;
-            const int64_t s0 = ra.site_begin[c], s1 = ra.site_begin[c + 1], p0 = ra.pvar_begin[c], p1 = ra.pvar_begin[c + 1], r0 = ra.pread_begin[c], r1 = ra.pread_begin[c + 1];
+    if (o->out_dir) for (int c = 0; c < nc; c++) {
+        const char *ctg = nm->ctg_id[c];
+        char *fa = nullptr; size_t fl = 0;
+        if (want_cns && fzp_format_tigs(&tigs, c, ctg, &fa, &fl) != FZP_OK) return FZP_EINVAL;      // (the tigs die with this call: their text is made here)
+        if (fa) { std::lock_guard<std::mutex> lk(owned->mu); owned->texts.push_back(fa); }
+        const std::string base = out_dir + "/" + ctg, ctg_s = ctg;
+        const char *pv = pin + vb[(size_t)c], *pa = pin + o_atab + ab[(size_t)c];
+        const size_t lv = (size_t)(vb[(size_t)c + 1] - vb[(size_t)c]), la = (size_t)(ab[(size_t)c + 1] - ab[(size_t)c]);
+        auto pre_p = std::make_shared<PreCtg>(std::move(pre[(size_t)c]));                    // q_id names, q_id_map
+        const bool have_r2p = maps != nullptr;
+        auto recs_p = std::make_shared<std::vector<fzp_r2p>>(have_r2p ? recs[(size_t)c] : std::vector<fzp_r2p>());
+        std::atomic<int64_t> *bytes_p = &bytes;
+        FileWriter *fw = async ? ctx->writer : nullptr;
+        std::shared_ptr<BamJob> bam = bams[(size_t)c];
+        std::shared_ptr<std::string> why = whys[(size_t)c];
+        if (async) bytes += (int64_t)(lv + la + pre_p->qmap.size() + (want_cns ? fl : 0));      // (what is known of the queued task's bytes when the call returns: the small texts do not exist yet)
+        tasks[(size_t)c] = [owned, c, base, ctg_s, pv, pa, lv, la, pre_p, recs_p, have_r2p, want_cns, fa, fl, bytes_p, fw, bam, want_done, why]() -> bool {
+            std::atomic<int64_t> local{0};
+            std::atomic<int64_t> &bt = fw ? local : *bytes_p;
+            const std::string aln_done = "blasr/aln_" + ctg_s + "_done", p_done = "phasing/p_" + ctg_s + "_done";
+            auto failed = [&](const std::string &what) { *why = what; if (fw) fw->fail(what); return false; };      // the cause is taken where it happens, on this thread
+            // the small texts (phasing.py:124, 412-421, 478-480; phasing_readmap.py:49-51)
+            const int64_t s0 = owned->site_begin[(size_t)c], s1 = owned->site_begin[(size_t)c + 1], p0 = owned->pvar_begin[(size_t)c], p1 = owned->pvar_begin[(size_t)c + 1],
+                          r0 = owned->pread_begin[(size_t)c], r1 = owned->pread_begin[(size_t)c + 1];
             char *txt[3] = {nullptr, nullptr, nullptr};
             size_t len[3] = {0, 0, 0};
-            int rc = fzp_format_variant_pos(ra.all.sites + s0, s1 - s0, &txt[0], &len[0]);
-            if (rc == FZP_OK) rc = fzp_format_phased_variants(ra.all.sites, ra.all.pvars + p0, p1 - p0, &txt[1], &len[1]);       // pvars carry batch-wide site indices
-            if (rc == FZP_OK) rc = fzp_format_phased_reads(ra.all.preads + r0, r1 - r0, ctg, qoff.data(), qn.data(), (int32_t)nq, &txt[2], &len[2]);
-            std::string qmap;
-            qmap.swap(P.qmap);
-            us_fmt += (int64_t)(ms_since(tq) * 1e3); tq = clk::now();
+            struct FreeTxt { char **t; ~FreeTxt() { for (int i = 0; i < 3; i++) free(t[i]); } } free_txt{txt};
+            const int64_t nq = (int64_t)pre_p->qoff.size() - 1;
+            int rc = fzp_format_variant_pos(owned->sites + s0, s1 - s0, &txt[0], &len[0]);
+            if (rc == FZP_OK) rc = fzp_format_phased_variants(owned->sites, owned->pvars + p0, p1 - p0, &txt[1], &len[1]);       // pvars carry batch-wide site indices
+            if (rc == FZP_OK) rc = fzp_format_phased_reads(owned->preads + r0, r1 - r0, ctg_s.c_str(), pre_p->qoff.data(), pre_p->qn.data(), (int32_t)nq, &txt[2], &len[2]);
+            if (rc != FZP_OK) return failed(fzp_last_error());
+            if (!owned->texts_there()) { (void)hipGetLastError(); return failed("the device-made texts of " + ctg_s + " did not arrive"); }
             std::string r2p_text;
-            bool have_r2p = false;
-            if (rc == FZP_OK && maps) {
-                rc = P.rc;
-                if (rc == FZP_OK) readmap_fill(P.rows, ctg, ctg_index ? ctg_index[c] : c, ra.all.preads + r0, r1 - r0, recs[(size_t)c], r2p_text);
-                else errs[(size_t)t] = P.err;
-                have_r2p = rc == FZP_OK;
-            } else if (rc != FZP_OK) errs[(size_t)t] = fzp_last_error();
-            us_map += (int64_t)(ms_since(tq) * 1e3); tq = clk::now();
-            char *fa = nullptr; size_t fl = 0;
-            if (rc == FZP_OK && o->out_dir && want_cns && fzp_format_tigs(&tigs, c, ctg, &fa, &fl) != FZP_OK) { rc = FZP_EINVAL; errs[(size_t)t] = fzp_last_error(); }
-            if (rc == FZP_OK && o->out_dir) {
-                // everything the files need is owned by `owned` (pinned texts, malloc'ed small texts) or moved into the task (strings)
-                { std::lock_guard<std::mutex> lk(owned->mu); for (auto p : txt) owned->texts.push_back(p); if (fa) owned->texts.push_back(fa); }
-                const std::string base = out_dir + "/" + ctg, ctg_s = ctg;
-                const char *t0 = txt[0], *t1 = txt[1], *t2 = txt[2], *pv = pin + vb[(size_t)c], *pa = pin + o_atab + ab[(size_t)c];
-                const size_t l0 = len[0], l1 = len[1], l2 = len[2], lv = (size_t)(vb[(size_t)c + 1] - vb[(size_t)c]), la = (size_t)(ab[(size_t)c + 1] - ab[(size_t)c]);
-                auto qmap_p = std::make_shared<std::string>(std::move(qmap));
-                auto r2p_p = std::make_shared<std::string>(std::move(r2p_text));
-                std::atomic<int64_t> *bytes_p = &bytes;
-                FileWriter *fw = async ? ctx->writer : nullptr;
-                std::shared_ptr<BamJob> bam = bams[(size_t)c];
-                std::shared_ptr<std::string> why = whys[(size_t)c];
-                auto task = [owned, base, ctg_s, t0, t1, t2, pv, pa, l0, l1, l2, lv, la, qmap_p, r2p_p, have_r2p, want_cns, fa, fl, bytes_p, fw, bam, want_done, why]() -> bool {
-                    std::atomic<int64_t> local{0};
-                    std::atomic<int64_t> &bt = fw ? local : *bytes_p;
-                    const std::string aln_done = base + "/blasr/aln_" + ctg_s + "_done", p_done = base + "/phasing/p_" + ctg_s + "_done";
-                    auto failed = [&](const std::string &what) { *why = what; if (fw) fw->fail(what); return false; };      // the cause is taken where it happens, on this thread
-                    if (bam) {                                           // <ctg>_sorted.bam + index, then the blasr task's sentinels
-                        uint8_t *bb = nullptr, *bi = nullptr;
-                        size_t bl = 0, il = 0;
-                        bool okb = mkdir_p(base + "/blasr");
-                        std::string cause = okb ? "" : std::string("cannot create ") + base + "/blasr: " + strerror(errno);
-                        if (okb) {
-                            fzp_alnset_split_eqx(bam->aln, bam->ref->data());
-                            if (fzp_format_bam(bam->aln, ctg_s.c_str(), (int64_t)bam->ref->size(), bam->flags.data(), &bb, &bl, &bi, &il) != FZP_OK) { okb = false; cause = fzp_last_error(); }
-                        }
-                        if (okb && !(write_file(base + "/blasr/" + ctg_s + "_sorted.bam", (const char *)bb, bl, bt) && write_file(base + "/blasr/" + ctg_s + "_sorted.bam.bai", (const char *)bi, il, bt))) {
-                            okb = false; cause = std::string("cannot write under ") + base + "/blasr: " + strerror(errno);
-                        }
-                        free(bb); free(bi);
-                        if (want_done) { if (okb) (void)write_file(aln_done, "", 0, bt); (void)write_file(aln_done + ".exit", "", 0, bt); }
-                        if (!okb) {
-                            if (want_done) { (void)mkdir_p(base + "/phasing"); (void)write_file(p_done + ".exit", "", 0, bt); }      // the phasing task never ran
-                            return failed(cause);
-                        }
-                    }
-                    bool ok = mkdir_p(base + "/het_call") && mkdir_p(base + "/g_atable") && mkdir_p(base + "/get_phased_blocks");
-                    ok = ok && write_file(base + "/het_call/variant_pos", t0, l0, bt) && write_file(base + "/het_call/variant_map", pv, lv, bt) &&
-                         write_file(base + "/het_call/q_id_map", qmap_p->data(), qmap_p->size(), bt) && write_file(base + "/g_atable/atable", pa, la, bt) &&
-                         write_file(base + "/get_phased_blocks/phased_variants", t1, l1, bt) && write_file(base + "/phased_reads", t2, l2, bt);
-                    if (ok && have_r2p) ok = write_file(base + "/rid_to_phase." + ctg_s, r2p_p->data(), r2p_p->size(), bt);
-                    if (ok && want_cns) ok = mkdir_p(base + "/cns") && write_file(base + "/cns/phased_blocks.fa", fa, fl, bt);
-                    const std::string cause = ok ? "" : "cannot write under " + base + ": " + strerror(errno);
-                    if (want_done && mkdir_p(base + "/phasing")) { if (ok) (void)write_file(p_done, "", 0, bt); (void)write_file(p_done + ".exit", "", 0, bt); }
-                    return ok ? true : failed(cause);
-                };
-                if (async) bytes += (int64_t)(l0 + l1 + l2 + lv + la + qmap_p->size() + (have_r2p ? r2p_p->size() : 0) + (want_cns ? fl : 0));     // what the queued task will write
-                tasks[(size_t)c] = task;        // run (or queued) below, once the big texts have arrived
-            } else {
-                for (auto p : txt) free(p);
-                free(fa);
+            if (have_r2p) readmap_text(recs_p->data(), recs_p->size(), ctg_s.c_str(), r2p_text);
+            DirWriter dw;
+            if (!dw.open_base(base)) return failed("cannot create " + base + ": " + strerror(errno));
+            if (bam) {                                           // <ctg>_sorted.bam + index, then the blasr task's sentinels
+                uint8_t *bb = nullptr, *bi = nullptr;
+                size_t bl = 0, il = 0;
+                bool okb = dw.subdir("blasr");
+                std::string cause = okb ? "" : std::string("cannot create ") + base + "/blasr: " + strerror(errno);
+                if (okb) {
+                    fzp_alnset_split_eqx(bam->aln, bam->ref->data());
+                    if (fzp_format_bam(bam->aln, ctg_s.c_str(), (int64_t)bam->ref->size(), bam->flags.data(), &bb, &bl, &bi, &il) != FZP_OK) { okb = false; cause = fzp_last_error(); }
+                }
+                if (okb && !(dw.file(("blasr/" + ctg_s + "_sorted.bam").c_str(), (const char *)bb, bl, bt) && dw.file(("blasr/" + ctg_s + "_sorted.bam.bai").c_str(), (const char *)bi, il, bt))) {
+                    okb = false; cause = std::string("cannot write under ") + base + "/blasr: " + strerror(errno);
+                }
+                free(bb); free(bi);
+                if (want_done) { if (okb) (void)dw.file(aln_done.c_str(), "", 0, bt); (void)dw.file((aln_done + ".exit").c_str(), "", 0, bt); }
+                if (!okb) {
+                    if (want_done) { (void)dw.subdir("phasing"); (void)dw.file((p_done + ".exit").c_str(), "", 0, bt); }      // the phasing task never ran
+                    return failed(cause);
+                }
             }
-            us_write += (int64_t)(ms_since(tq) * 1e3);
-            if (rc != FZP_OK) rcs[(size_t)t] = rc;
-        }
-    };
-    ctx->workers->run(nc, work, want_threads);
-    for (int t = 0; t < T; t++) if (rcs[(size_t)t] != FZP_OK) { fzp_set_error("%s", errs[(size_t)t].c_str()); return rcs[(size_t)t]; }
+            bool ok = dw.subdir("het_call") && dw.subdir("g_atable") && dw.subdir("get_phased_blocks");
+            ok = ok && dw.file("het_call/variant_pos", txt[0], len[0], bt) && dw.file("het_call/variant_map", pv, lv, bt) &&
+                 dw.file("het_call/q_id_map", pre_p->qmap.data(), pre_p->qmap.size(), bt) && dw.file("g_atable/atable", pa, la, bt) &&
+                 dw.file("get_phased_blocks/phased_variants", txt[1], len[1], bt) && dw.file("phased_reads", txt[2], len[2], bt);
+            if (ok && have_r2p) ok = dw.file(("rid_to_phase." + ctg_s).c_str(), r2p_text.data(), r2p_text.size(), bt);
+            if (ok && want_cns) ok = dw.subdir("cns") && dw.file("cns/phased_blocks.fa", fa, fl, bt);
+            const std::string cause = ok ? "" : "cannot write under " + base + ": " + strerror(errno);
+            if (want_done && dw.subdir("phasing")) { if (ok) (void)dw.file(p_done.c_str(), "", 0, bt); (void)dw.file((p_done + ".exit").c_str(), "", 0, bt); }
+            return ok ? true : failed(cause);
+        };
+    }
     if (o->out_dir) {
-        FZP_HIP(hipEventSynchronize(ev_t.e));                    // the two big texts are in the pinned block (their copy ran under the formatting above)
         if (async) { for (int c = 0; c < nc; c++) if (tasks[(size_t)c]) ctx->writer->push([tk = std::move(tasks[(size_t)c])]() { (void)tk(); }); }
         else {
             std::atomic<int> failed{-1};
@@ -664,6 +694,7 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
     out->n_rec += b->n_rec; out->n_sites += b->n_sites; out->n_rows += b->n_rows; out->n_arows += b->n_arows; out->n_pvars += b->n_pvars; out->n_preads += b->n_preads;
     out->n_aligned += b->n_qid;
     if (timing) fprintf(stderr, "[fzp_pipe] body done at %.2f ms\n", ms_since(t_body));
+    sg2.armed = false;      // what is still in flight on stream2 -- the two big texts -- lands in a block the write tasks own, and they wait for it themselves
     return FZP_OK;
 }
 

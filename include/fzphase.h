@@ -66,7 +66,8 @@ int fzp_mem_info(fzp_ctx *ctx, size_t *free_bytes, size_t *total_bytes);   /* hi
 
 /* Per-kernel device timing (HIP events on the ctx stream).  fzp_prof_enable(ctx,1) starts
  * collecting; fzp_prof_get returns the summed duration and launch count of kernel `name`
- * since the last fzp_prof_reset.  Names: see DESIGN.md section 5. */
+ * since the last fzp_prof_reset.  Names: see DESIGN.md section 5.  on = 2 brackets the DP stage ("k1_sw") only:
+ * every bracket costs the stream ~10 us and the host ~80 us of CPU, sixty of them per step are not free. */
 int fzp_prof_enable(fzp_ctx *ctx, int on);
 int fzp_prof_reset(fzp_ctx *ctx);
 int fzp_prof_get(fzp_ctx *ctx, const char *name, double *total_ms, int64_t *launches);

@@ -34,9 +34,12 @@ def test_two_ranks_share_one_gpu():
     for d, n in ((one, 1), (two, 2)):
         assert d["n_gpus"] == n and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["higher_is_better"] is True
         assert d["unit"] == "reads/s" and d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"]
-        assert d["roofline"]["bound"] == "hbm" and d["roofline"]["launches"] >= 2 and d["roofline"]["peak"] == 8000.0 and 0 < d["roofline"]["frac"] < 1
-        assert d["roofline"]["valu"]["peak"] == 1228.8 and 0 < d["roofline"]["valu"]["frac"] < 1
-        assert d["roofline"]["unit"] == "GB/s" and d["index_in_step"] is True and d["index_ms"] > 0
+        rl = d["roofline"]
+        assert rl["bound"] == "valu" and rl["launches"] >= 2 and rl["peak"] == 1228.8 and 0 < rl["frac"] < 1 and rl["unit"] == "G wave64-inst/s"
+        assert rl["hbm_algorithmic"]["peak"] == 8000.0 and 0 < rl["hbm_algorithmic"]["frac"] < 1 and rl["hbm_moved"]["peak"] == 8000.0
+        assert d["index_in_step"] is True and d["index_ms"] > 0 and d["ms_per_step_instrumented"] > 0 and d["kernel_ms_per_step"]["k1_sw"] > 0
+        if n == 2:
+            assert "error" not in d["from_files"] and d["from_files"]["n_gpus"] == 2 and d["value_from_files"] == d["from_files"]["reads_per_s"] > 0
         assert d["aligned_frac"] > 0.98
     assert one["stage_counts"]["r2p_records"] == 300 and two["stage_counts"]["r2p_records"] == 600      # the all-gather saw both shards
     assert two["config"]["reads_per_gpu"] == one["config"]["reads_per_gpu"] == 300 and two["config"]["reads_total"] == 600

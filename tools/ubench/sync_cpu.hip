@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>
+#include <cstring>
 #include <ctime>
 __global__ void k_spin(unsigned long long ticks, int *p) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
@@ -13,7 +14,15 @@ __global__ void k_spin(unsigned long long ticks, int *p) {
 }
 using clk = std::chrono::steady_clock;
 static double cpu_ms() { timespec ts; clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec / 1e6; }
-int main() {
+// argv[1]: auto | spin | yield | blocking -> hipSetDeviceFlags(hipDeviceSchedule*) before the first other HIP call of the process (r5: the DEVICE flag is what decides how
+// this runtime waits -- the event flag and ROC_ACTIVE_WAIT_TIMEOUT are not)
+int main(int argc, char **argv) {
+    if (argc > 1) {
+        const char *m = argv[1];
+        const unsigned f = !strcmp(m, "spin") ? hipDeviceScheduleSpin : !strcmp(m, "yield") ? hipDeviceScheduleYield : !strcmp(m, "blocking") ? hipDeviceScheduleBlockingSync : hipDeviceScheduleAuto;
+        const hipError_t e = hipSetDeviceFlags(f);
+        printf("--- hipSetDeviceFlags(%s) -> %s\n", m, hipGetErrorString(e));
+    }
     hipStream_t st; (void)hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
     hipEvent_t ev, evb;
     (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming);
