@@ -404,17 +404,17 @@ def constrained_child(args, n_cores, contigs, blob, off, read_ctg, ids, name_tab
             eng = _lib.Engine(0)
             job = _lib.align_job_raw(eng, contigs, blob, off, read_ctg)
             root = tempfile.mkdtemp(prefix="fzp_bench_2c_", dir="/dev/shm" if os.path.isdir("/dev/shm") and not args.out_root else args.out_root)
-            n_steps = max(4, min(args.steps, 10))
+            n_steps = int(os.environ.get("FZP_BENCH_2C_STEPS", "20"))      # (twenty: ten steps of a fresh process varied by +-2 ms run to run)
 
             def one(k):
                 job.phase_write(ids, names=name_tab, out_dir=os.path.join(root, "s%03d" % k), read_maps=maps, ctg_index=mine, consensus=args.with_consensus, async_writes=True,
                                 rebuild_index=not args.index_at_create)
-            for k in range(2):
+            for k in range(3):
                 one(k)
             eng.synchronize(); eng.pipe_flush()
             t0, c0 = time.perf_counter(), time.process_time()
             for k in range(n_steps):
-                one(2 + k)
+                one(3 + k)
             eng.synchronize(); eng.pipe_flush()
             dt, cpu = time.perf_counter() - t0, time.process_time() - c0
             job.close(); eng.close()
