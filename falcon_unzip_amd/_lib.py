@@ -542,7 +542,9 @@ class AlignJob:
     def to_batch(self) -> "Batch":
         p = C.c_void_p()
         _check(load().fzp_align_to_batch(self.eng._p, self._p, C.byref(p)))
-        return Batch(self.eng, p.value, [None] * self.n_ctg)
+        b = Batch(self.eng, p.value, [None] * self.n_ctg)
+        b._job = self      # the batch reads this job's packed records (2-bit op streams, 2-bit reads) where they lie: the job stays alive as long as the batch does
+        return b
 
     def close(self):
         if self._p:

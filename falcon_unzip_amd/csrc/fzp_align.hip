@@ -1619,7 +1619,8 @@ __global__ void __launch_bounds__(64) k_tb_cigar(int64_t first, int64_t count, c
                                                  const int64_t *__restrict__ cig_off, uint32_t *__restrict__ cig,
                                                  int64_t *__restrict__ cig_start, fzp_aln_summary *__restrict__ summ, int match, int mismatch, int gap,
                                                  int min_pct_identity, const uint32_t *__restrict__ read_pk, const uint32_t *__restrict__ read_rc, const int64_t *__restrict__ read_woff,
-                                                 const int32_t *__restrict__ read_ctg, const uint32_t *__restrict__ ctg_pk, const int64_t *__restrict__ ctg_woff) {
+                                                 const int32_t *__restrict__ read_ctg, const uint32_t *__restrict__ ctg_pk, const int64_t *__restrict__ ctg_woff,
+                                                 PkRec *__restrict__ pkrec, int2 *__restrict__ pck) {
     const int lane = lane_id();
     const int64_t wv = blockIdx.x;
     if (wv >= count) return;
@@ -1761,18 +1762,24 @@ __global__ void __launch_bounds__(64) k_tb_cigar(int64_t first, int64_t count, c
             L = Ln;
         } else L = s0 + 1;
         nW = (L + 15) >> 4;
-        // what the kept ops consume, and their aligned columns
+        // what the kept ops consume, and their aligned columns; on the way every 16th word's place -- {read bases, contig bases} consumed before it -- goes out as
+        // a checkpoint of the packed hand-off to K2 (fzp_batch.h: PkSrc; the stream itself stays where it is, in the job's op buffer)
         int32_t ci2 = 0, cj2 = 0, nm2 = 0;
+        int2 *ckp = pck + ((size_t)(rcapq_scan[r] >> 2) + (size_t)r);
         for (int32_t wb = 0; wb < nW; wb += 64) {
             const int32_t wi = wb + lane;
+            uint32_t ci = 0, cj = 0;
             if (wi < nW) {
                 const uint32_t x = rg[wi], vm = valid_mask(wi);
                 const uint32_t fM = ~(x | (x >> 1)) & vm, fI = (x & ~(x >> 1)) & vm, fD = (~x & (x >> 1)) & vm;
-                ci2 += __popc(fM | fI); cj2 += __popc(fM | fD); nm2 += __popc(fM);
+                ci = (uint32_t)__popc(fM | fI); cj = (uint32_t)__popc(fM | fD); nm2 += __popc(fM);
             }
+            const uint32_t si = wave_incl_scan_u32_dpp(ci), sj = wave_incl_scan_u32_dpp(cj);
+            if (wi < nW && (wi & 15) == 0) ckp[wi >> 4] = make_int2(ci2 + (int32_t)(si - ci), cj2 + (int32_t)(sj - cj));
+            ci2 += __builtin_amdgcn_readlane((int32_t)si, 63); cj2 += __builtin_amdgcn_readlane((int32_t)sj, 63);
         }
-        ci2 = wave_sum_i32_dpp(ci2); cj2 = wave_sum_i32_dpp(cj2); nm2 = wave_sum_i32_dpp(nm2);
-        ci2 = __builtin_amdgcn_readfirstlane(ci2); cj2 = __builtin_amdgcn_readfirstlane(cj2); nm2 = __builtin_amdgcn_readfirstlane(nm2);
+        nm2 = wave_sum_i32_dpp(nm2);
+        nm2 = __builtin_amdgcn_readfirstlane(nm2);
         w.i = w.i_end - ci2;                      // the cell before the alignment's first op, as the walk would have left it
         w.ts = w.i + (w.j_end - cj2);
         w.ncol = nm2;
@@ -1873,6 +1880,7 @@ __global__ void __launch_bounds__(64) k_tb_cigar(int64_t first, int64_t count, c
             if (n - out.q_end > 0) { reg[fb++] = ((uint32_t)(n - out.q_end) << 4) | FZP_OP_S; nc++; }
             out.n_cigar = nc;
             cig_start[r] = cig_off[r] + fa;
+            pkrec[r] = PkRec{w.i_end, w.j_end, L, a.strand};      // the packed hand-off: the kept stream rg[0 .. L) leaves cell (i_end, j_end)
         }
     }
     summ[r] = out;
@@ -2064,12 +2072,12 @@ __global__ void __launch_bounds__(256) k_plan_rank(int64_t n, const int32_t *__r
                                                    const int32_t *__restrict__ read_len,
                                                    uint64_t *__restrict__ v_rec, uint64_t *__restrict__ v_cig, uint64_t *__restrict__ v_seq, uint64_t *__restrict__ v_ck,
                                                    int32_t *__restrict__ g_read, int32_t *__restrict__ g_qid, uint8_t *__restrict__ g_acc, int32_t *__restrict__ last_pos,
-                                                   uint32_t *__restrict__ n_aligned, unsigned long long *__restrict__ n_cols) {
+                                                   uint32_t *__restrict__ n_aligned, unsigned long long *__restrict__ n_cols, int32_t *__restrict__ max_span) {
     const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const bool valid = s < n && key[s] != ~0ull;          // every lane stays to the end: the per-contig totals are reduced over the wave
     int c = -1;
     bool acc = false;
-    int32_t pos = -1, ncol = 0;
+    int32_t pos = -1, ncol = 0, rspan = 0;
     if (valid) {
         c = slot_ctg[s];
         const uint32_t rank = rank_in[s];
@@ -2085,7 +2093,7 @@ __global__ void __launch_bounds__(256) k_plan_rank(int64_t n, const int32_t *__r
         const int64_t g = slot_off[c] + rank;
         g_read[g] = r; g_qid[g] = (int32_t)rank; g_acc[g] = acc ? 1 : 0;
         if (acc) { v_rec[g] = 1; v_cig[g] = (uint64_t)sm.n_cigar; v_seq[g] = (uint64_t)((nlen + 15) & ~15ll); v_ck[g] = (uint64_t)((sm.n_cigar + 63) / 64); }
-        pos = sm.pos; ncol = sm.n_columns;
+        pos = sm.pos; ncol = sm.n_columns; rspan = sm.ref_end - sm.pos;
     }
     // per-contig totals: the slots of a wave nearly always belong to one contig -> one atomic per wave, not per read
     // (40 000 same-address atomics issued at once serialise: 0.5 ms)
@@ -2093,18 +2101,19 @@ __global__ void __launch_bounds__(256) k_plan_rank(int64_t n, const int32_t *__r
     if (vm == 0) return;
     const int c0 = __builtin_amdgcn_readlane(c, __builtin_ctzll(vm));
     if (__all(!valid || c == c0)) {
-        int32_t mp = (valid && acc) ? pos : -1;
+        int32_t mp = (valid && acc) ? pos : -1, msp = (valid && acc) ? rspan : 0;
         unsigned long long cols = (valid && acc) ? (unsigned long long)ncol : 0ull;
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) { mp = max(mp, __shfl_xor(mp, d, 64)); cols += __shfl_xor(cols, d, 64); }
+        for (int d = 32; d >= 1; d >>= 1) { mp = max(mp, __shfl_xor(mp, d, 64)); msp = max(msp, __shfl_xor(msp, d, 64)); cols += __shfl_xor(cols, d, 64); }
         if (lane_id() == 0) {
             atomicAdd(&n_aligned[c0], (uint32_t)__popcll(vm));
             if (mp >= 0) atomicMax(&last_pos[c0], mp);
+            if (msp > 0) atomicMax(&max_span[c0], msp);
             if (cols) atomicAdd(&n_cols[c0], cols);
         }
     } else if (valid) {
         atomicAdd(&n_aligned[c], 1u);
-        if (acc) { atomicMax(&last_pos[c], pos); atomicAdd(&n_cols[c], (unsigned long long)ncol); }
+        if (acc) { atomicMax(&last_pos[c], pos); atomicMax(&max_span[c], rspan); atomicAdd(&n_cols[c], (unsigned long long)ncol); }
     }
 }
 __global__ void __launch_bounds__(256) k_plan_emit(int64_t n, int n_ctg, const int32_t *__restrict__ slot_ctg_of_g, const int64_t *__restrict__ slot_off,
@@ -2112,7 +2121,8 @@ __global__ void __launch_bounds__(256) k_plan_emit(int64_t n, int n_ctg, const i
                                                    const uint64_t *__restrict__ v_ck, const int32_t *__restrict__ g_read, const int32_t *__restrict__ g_qid,
                                                    const uint8_t *__restrict__ g_acc, const fzp_aln_summary *__restrict__ summ, const uint64_t *__restrict__ totals,
                                                    int64_t *__restrict__ rec_read, int32_t *__restrict__ rec_qid, int32_t *__restrict__ rec_pos, int32_t *__restrict__ rec_ctg,
-                                                   int64_t *__restrict__ cig_off, int64_t *__restrict__ seq_off, int64_t *__restrict__ ck_off, int64_t *__restrict__ rec_begin) {
+                                                   int64_t *__restrict__ cig_off, int64_t *__restrict__ seq_off, int64_t *__restrict__ ck_off, int64_t *__restrict__ rec_begin,
+                                                   int32_t *__restrict__ rec_span) {
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (g == 0) {
         const int64_t nr = (int64_t)totals[0];
@@ -2124,7 +2134,7 @@ __global__ void __launch_bounds__(256) k_plan_emit(int64_t n, int n_ctg, const i
     if (!g_acc[g]) return;
     const int64_t k = (int64_t)v_rec[g];
     const int32_t r = g_read[g];
-    rec_read[k] = r; rec_qid[k] = g_qid[g]; rec_pos[k] = summ[r].pos; rec_ctg[k] = c;
+    rec_read[k] = r; rec_qid[k] = g_qid[g]; rec_pos[k] = summ[r].pos; rec_ctg[k] = c; rec_span[k] = summ[r].ref_end - summ[r].pos;
     cig_off[k] = (int64_t)v_cig[g]; seq_off[k] = (int64_t)v_seq[g]; ck_off[k] = (int64_t)v_ck[g];
 }
 // the batch path's variant: SEQ segments are padded to 16 bytes, so a thread turns one packed word into one 16-byte store
@@ -2178,7 +2188,7 @@ struct ChunkBufs {
     DevBuf<ulonglong2> tbw;                      // whole masks, 16 B per DP step: the wave-per-slot kernel's slots, and behind them the slots whose walk needed more than the middle lanes
     DevBuf<uint32_t> fail_list;                  // slots whose 8-byte walk left the recorded lanes (computed again with whole masks)
     DevBuf<ulonglong2> mvw;                      // move words, one per 64 steps
-    DevBuf<uint32_t> raw, rraw;                  // 2-bit op streams: per slot (the walks), per read (joined)
+    DevBuf<uint32_t> raw;                        // 2-bit op streams per slot (the walks); the reads' joined streams live with the job (opk)
     DevBuf<ReadPath> rpath;
 };
 
@@ -2215,6 +2225,11 @@ struct fzp_alnjob {
     DevBuf<uint64_t> rtot;                       // [0] slots of the run, [1] capacity / 64 of the run, [2] capacity / 64 and [3] number of the slots the wave-per-slot kernel takes
     DevBuf<uint32_t> fb_overflow;                // the fail list or its mask room overflowed (the run reports it)
     ChunkBufs cb[2];
+    // the packed hand-off to K2 (fzp_batch.h: PkSrc), for the whole run: every read's joined op stream at opk + 4 * rcapq_scan[read] (k_join writes it, k_tb_cigar
+    // keeps the alignment's stretch of it in place), its PkRec and its 256-op checkpoints
+    DevBuf<uint32_t> opk;
+    DevBuf<PkRec> pkrec;
+    DevBuf<int2> pck;
     DevBuf<unsigned long long> tb_stats;         // FZP_TB_STATS (measurement aid): how often a path leaves a 32-lane window of its band, summed over the job's runs
     DevBuf<uint64_t> wave_log;                   // FZP_SWB_WAVE_LOG (measurement aid): per k_swb workgroup of the last chunk {start, end, hardware id, steps}
     int64_t wave_log_n = 0;
@@ -2470,6 +2485,11 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
         FZP_HIP(hipMemcpyAsync(j->slot_base.p + nr, &end_sb, 4, hipMemcpyHostToDevice, st));      // (4 bytes from the stack: the runtime copies them at the call)
         FZP_HIP(hipMemcpyAsync(j->rcapq_scan.p + nr, &end_cq, 4, hipMemcpyHostToDevice, st));
         j->n_second = n2;
+        // the run's joined op streams + what K2 needs to read them (the packed hand-off): 16 B per 64 DP steps of capacity, 16 B per read, 8 B per 256 ops
+        FZP_TRY(j->opk.alloc((size_t)rtot[1] * 4 + 128));
+        FZP_TRY(j->pkrec.alloc((size_t)nr));
+        FZP_TRY(j->pck.alloc((size_t)(rtot[1] >> 2) + (size_t)nr + 2));
+        FZP_HIP(hipMemsetAsync(j->pkrec.p, 0, (size_t)nr * sizeof(PkRec), st));
         // Trace-back masks live in HBM (8 B per DP step).  Reads go through in chunks: the DP of chunk k+1 runs on `stream` while the trace-back of chunk k
         // runs on `stream2`; two sets of buffers alternate.
         int64_t budget_steps = (int64_t)48 << 30 >> 3;   // 48 GiB of 8-byte steps over both buffers
@@ -2507,7 +2527,7 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
             ChunkBufs &B = j->cb[bi];
             if (used[bi]) FZP_HIP(hipStreamWaitEvent(st, j->ev_tb[bi], 0));   // buffers free again?
             FZP_TRY(B.rpath.alloc((size_t)cnt));
-            FZP_TRY(B.rraw.alloc((size_t)capq * 4 + 64));
+            uint32_t *const rraw = j->opk.p + 4 * (size_t)cq_at(first);      // this chunk's reads' joined streams inside the job's buffer: read r at + 4 * (rcapq_scan[r] - rcapq_scan[first])
             if (ns > 0) {
                 const uint32_t nblk = (ns + 255) / 256, ngrp = (ns + 63) / 64;
                 FZP_TRY(B.slots.alloc(ns)); FZP_TRY(B.bh.alloc((size_t)SORT_CLASSES * nblk)); FZP_TRY(B.sorted.alloc(ns)); FZP_TRY(B.fits.alloc(ns)); FZP_TRY(B.pos_b.alloc(ns));
@@ -2619,13 +2639,14 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
             {
                 ProfScope ps(ctx, "k1_join", st2);
                 hipLaunchKernelGGL(k_join, dim3((unsigned)cnt), dim3(64), 0, st2, first, cnt, (const uint32_t *)j->slot_base.p, (const uint32_t *)j->r_cnt.p, s_lo, (const Slot *)B.slots.p,
-                                   (const DpInfo *)B.info.p, (const WalkOut *)B.wout.p, (const int64_t *)B.mvo.p, (const uint32_t *)B.raw.p, (const uint32_t *)j->rcapq_scan.p, B.rraw.p, B.rpath.p);
+                                   (const DpInfo *)B.info.p, (const WalkOut *)B.wout.p, (const int64_t *)B.mvo.p, (const uint32_t *)B.raw.p, (const uint32_t *)j->rcapq_scan.p, rraw, B.rpath.p);
             }
             {
                 ProfScope ps(ctx, "k1_cigar", st2);
-                hipLaunchKernelGGL(k_tb_cigar, dim3((unsigned)cnt), dim3(64), 0, st2, first, cnt, j->read_len.p, (const ReadPath *)B.rpath.p, (const uint32_t *)j->rcapq_scan.p, B.rraw.p,
+                hipLaunchKernelGGL(k_tb_cigar, dim3((unsigned)cnt), dim3(64), 0, st2, first, cnt, j->read_len.p, (const ReadPath *)B.rpath.p, (const uint32_t *)j->rcapq_scan.p, rraw,
                                    j->cig_off.p, j->cig.p, j->cig_start.p, j->summ.p, P.match, P.mismatch, P.gap, P.min_pct_identity,
-                                   (const uint32_t *)j->read_pk.p, (const uint32_t *)j->read_rc.p, (const int64_t *)j->read_woff.p, j->read_ctg.p, (const uint32_t *)j->ctg_pk.p, (const int64_t *)j->ctg_woff.p);
+                                   (const uint32_t *)j->read_pk.p, (const uint32_t *)j->read_rc.p, (const int64_t *)j->read_woff.p, j->read_ctg.p, (const uint32_t *)j->ctg_pk.p, (const int64_t *)j->ctg_woff.p,
+                                   j->pkrec.p, j->pck.p);
             }
             FZP_HIP(hipEventRecord(j->ev_tb[bi], st2));
             used[bi] = true;
@@ -2913,12 +2934,13 @@ extern "C" int fzp_align_to_batch(fzp_ctx *ctx, fzp_alnjob *j, fzp_batch **out) 
     DevBuf<uint8_t> g_acc;
     DevBuf<uint32_t> n_aligned;
     DevBuf<unsigned long long> n_cols;
-    DevBuf<int64_t> rec_read;
+    DevBuf<int64_t> &rec_read = b->rec_read;      // stays with the batch: K2 reads every record through its read
     const size_t ns = (size_t)std::max<int64_t>(nr, 1);
     FZP_TRY(key.alloc(ns)); FZP_TRY(v_rec.alloc(ns)); FZP_TRY(v_cig.alloc(ns)); FZP_TRY(v_seq.alloc(ns)); FZP_TRY(v_ck.alloc(ns)); FZP_TRY(totals.alloc(4));
     FZP_TRY(g_read.alloc(ns)); FZP_TRY(g_qid.alloc(ns)); FZP_TRY(g_acc.alloc(ns)); FZP_TRY(last_pos.alloc((size_t)nc)); FZP_TRY(n_aligned.alloc((size_t)nc)); FZP_TRY(n_cols.alloc((size_t)nc));
     FZP_TRY(v_rec.zero(ns, st)); FZP_TRY(v_cig.zero(ns, st)); FZP_TRY(v_seq.zero(ns, st)); FZP_TRY(v_ck.zero(ns, st)); FZP_TRY(g_acc.zero(ns, st));
     FZP_TRY(n_aligned.zero((size_t)nc, st)); FZP_TRY(n_cols.zero((size_t)nc, st));
+    FZP_TRY(b->ctg_maxspan.alloc((size_t)nc)); FZP_TRY(b->ctg_maxspan.zero((size_t)nc, st));      // the contigs' longest reference span: from the summaries, no CIGAR pass
     FZP_HIP(hipMemsetAsync(last_pos.p, 0xff, (size_t)nc * 4, st));       // -1
     const unsigned gb = (unsigned)std::max<int64_t>(1, (nr + 255) / 256);
     if (nr > 0) {
@@ -2937,7 +2959,7 @@ extern "C" int fzp_align_to_batch(fzp_ctx *ctx, fzp_alnjob *j, fzp_batch **out) 
             hipLaunchKernelGGL(k_rank_binned, dim3(gb), dim3(256), 0, st, nr, j->slot_ctg.p, key.p, j->rank_bk_off.p, rk_start.p, rk_hist.p, rk_members.p, rk_rank.p);
         }
         hipLaunchKernelGGL(k_plan_rank, dim3(gb), dim3(256), 0, st, nr, j->slot_read.p, j->slot_ctg.p, j->slot_off.p, key.p, rk_rank.p, j->summ.p, j->read_len.p,
-                           v_rec.p, v_cig.p, v_seq.p, v_ck.p, g_read.p, g_qid.p, g_acc.p, last_pos.p, n_aligned.p, n_cols.p);
+                           v_rec.p, v_cig.p, v_seq.p, v_ck.p, g_read.p, g_qid.p, g_acc.p, last_pos.p, n_aligned.p, n_cols.p, b->ctg_maxspan.p);
     }
     FZP_TRY(fzp_exclusive_scan_u64_inplace(ctx, v_rec.p, (size_t)nr, totals.p + 0));
     FZP_TRY(fzp_exclusive_scan_u64_inplace(ctx, v_cig.p, (size_t)nr, totals.p + 1));
@@ -2973,17 +2995,27 @@ extern "C" int fzp_align_to_batch(fzp_ctx *ctx, fzp_alnjob *j, fzp_batch **out) 
     const size_t nrec1 = (size_t)b->n_rec + 1;
     FZP_TRY(rec_read.alloc(nrec1)); FZP_TRY(b->rec_qid.alloc(nrec1)); FZP_TRY(b->rec_pos.alloc(nrec1)); FZP_TRY(b->rec_ctg.alloc(nrec1));
     FZP_TRY(b->cig_off.alloc(nrec1)); FZP_TRY(b->seq_off.alloc(nrec1)); FZP_TRY(b->ck_off.alloc(nrec1)); FZP_TRY(b->ctg_rec_begin.alloc((size_t)nc + 1));
+    FZP_TRY(b->rec_span.alloc(nrec1));
     hipLaunchKernelGGL(k_plan_emit, dim3((unsigned)((std::max<int64_t>(nr, nc + 1) + 255) / 256)), dim3(256), 0, st, nr, nc, j->slot_ctg.p, j->slot_off.p, v_rec.p, v_cig.p, v_seq.p, v_ck.p, g_read.p, g_qid.p, g_acc.p, j->summ.p, totals.p,
-                       rec_read.p, b->rec_qid.p, b->rec_pos.p, b->rec_ctg.p, b->cig_off.p, b->seq_off.p, b->ck_off.p, b->ctg_rec_begin.p);
+                       rec_read.p, b->rec_qid.p, b->rec_pos.p, b->rec_ctg.p, b->cig_off.p, b->seq_off.p, b->ck_off.p, b->ctg_rec_begin.p, b->rec_span.p);
     b->h_rec_begin.resize((size_t)nc + 1);
     FZP_TRY(b->ctg_rec_begin.download(b->h_rec_begin.data(), (size_t)nc + 1, st));
-    // ---- gather the accepted records' CIGAR words and SEQ bytes
-    FZP_TRY(b->cigar.alloc((size_t)b->n_cig)); FZP_TRY(b->seq.alloc((size_t)b->n_seq));
-    if (b->n_rec > 0) {
-        ProfScope ps(ctx, "k1_gather");
-        hipLaunchKernelGGL(k_gather16, dim3((unsigned)b->n_rec, 4), dim3(256), 0, st, b->n_rec, rec_read.p, j->cig_start.p, j->cig.p, b->cig_off.p, b->cigar.p, j->read_pk.p, j->read_rc.p,
-                           j->summ.p, j->read_woff.p, b->seq_off.p, b->seq.p);
-    }
+    // ---- the records stay in K1's own form (r5: the packed hand-off, fzp_batch.h): K2 reads the alignments' 2-bit op streams and the 2-bit reads where K1 left them.  The
+    // accepted records' run-length CIGAR words and byte SEQ (k_gather16: 1.1 GB written per bench step, and 0.44 ms of checkpoint pass behind it) are made only when
+    // somebody asks (fzp_batch_need_bytes: K6); the job must outlive the batch.
+    b->packed = true; b->have_bytes = false;
+    b->pk.ops = j->opk.p; b->pk.rcapq_scan = j->rcapq_scan.p; b->pk.prec = j->pkrec.p; b->pk.ck = j->pck.p;
+    b->pk.read_pk = j->read_pk.p; b->pk.read_rc = j->read_rc.p; b->pk.read_woff = j->read_woff.p;
+    b->make_bytes = [j](fzp_ctx *cx, fzp_batch *bb) -> int {
+        FZP_TRY(bb->cigar.alloc((size_t)bb->n_cig)); FZP_TRY(bb->seq.alloc((size_t)bb->n_seq));
+        if (bb->n_rec > 0) {
+            ProfScope ps(cx, "k1_gather");
+            hipLaunchKernelGGL(k_gather16, dim3((unsigned)bb->n_rec, 4), dim3(256), 0, cx->stream, bb->n_rec, bb->rec_read.p, j->cig_start.p, j->cig.p, bb->cig_off.p, bb->cigar.p, j->read_pk.p, j->read_rc.p,
+                               j->summ.p, j->read_woff.p, bb->seq_off.p, bb->seq.p);
+        }
+        FZP_HIP(hipGetLastError());
+        return FZP_OK;
+    };
     FZP_TRY(b->ref.alloc((size_t)b->n_pos));
     for (int c = 0; c < nc; c++)   // evaluated prefix of every contig, device to device
         if (b->h_limit[(size_t)c]) FZP_HIP(hipMemcpyAsync(b->ref.p + b->h_goff[(size_t)c], j->ctg_ascii.p + j->h_ctg_aoff[(size_t)c], (size_t)b->h_limit[(size_t)c], hipMemcpyDeviceToDevice, st));

@@ -14,7 +14,23 @@
 //   blocks       fzp_pvar[n_pvars], pvar_begin[c]; site_blk[s], site_b1[s]
 //   reads        fzp_pread[n_preads], pread_begin[c]; q indices are global: qid_off[c] + q_id
 #pragma once
+#include <functional>
+
 #include "fzp_common.h"
+
+// ---- the packed hand-off K1 -> K2 (r5; unzip.py:86-91 <-> phasing.py:27,42-96 without the BAM, the SAM text, the byte SEQ or the run-length CIGAR in between).
+// K1 leaves, per aligned read, the alignment's joined 2-bit op stream (0 = aligned column, 1 = inserted read base, 2 = deleted contig base; 16 ops per word, the
+// alignment's END first) at ops + 4 * rcapq_scan[read], a PkRec -- the cell the stream's first op leaves, in the oriented read's / the contig's own coordinates -- and
+// per 16 words (256 ops) a checkpoint {read bases, contig bases consumed before it} at ck + (rcapq_scan[read] >> 2) + read.  An aligned column of the CIGAR walk
+// (phasing.py:77-96) is an op 0 at cell (i, j): reference position j, symbol = base i of the oriented 2-bit read.  K2 reads exactly that.
+struct PkRec { int32_t i_end, j_end, n_ops, strand; };
+struct PkSrc {
+    const uint32_t *ops = nullptr, *rcapq_scan = nullptr;
+    const PkRec *prec = nullptr;
+    const int2 *ck = nullptr;
+    const uint32_t *read_pk = nullptr, *read_rc = nullptr;
+    const int64_t *read_woff = nullptr;
+};
 
 // K2's position tiles: every contig's evaluated range starts on a tile boundary of the global position index (ctg_goff is a multiple of
 // FZP_POS_TILE), so a tile is exactly FZP_POS_TILE / 256 of the 256-position blocks the call / compaction kernels work on, and a tile
@@ -43,6 +59,12 @@ struct fzp_batch {
     // batches made by fzp_align_to_batch: the aligned reads of contig c in q_id order are qid_read[h_slot_off[c] .. + n_qid(c))
     DevBuf<int32_t> qid_read;
     std::vector<int64_t> h_slot_off;
+    // ... and their records stay in K1's packed form (PkSrc points into the alnjob, which must outlive the batch): `cigar` / `seq` / the CIGAR checkpoints are made
+    // only when somebody asks for them (fzp_batch_need_bytes: K6, whose tally walks the D / I ops of the run-length form)
+    bool packed = false, have_bytes = true;
+    PkSrc pk;
+    DevBuf<int64_t> rec_read;          // [n_rec] the read behind every record
+    std::function<int(fzp_ctx *, fzp_batch *)> make_bytes;
     // CIGAR checkpoints: per record, per 64-op chunk, the (reference, query) offsets at the chunk's start
     std::vector<int64_t> h_ck_off;     // [n_rec+1] prefix of ceil(n_ops/64) (batches built from host records)
     int64_t n_ck = 0;                  // total 64-op chunks = size of ck_ref / ck_q
@@ -99,6 +121,7 @@ struct fzp_batch {
 };
 
 // stage drivers (fzp_phase.hip)
+int fzp_batch_need_bytes(fzp_ctx *ctx, fzp_batch *b);      // packed batches: run-length CIGAR words, byte SEQ and the 64-op checkpoints, now (fzp_hetcall.hip)
 int fzp_k2_het_call(fzp_ctx *ctx, fzp_batch *b);
 int fzp_k3_sets(fzp_ctx *ctx, fzp_batch *b);
 int fzp_k3_assoc(fzp_ctx *ctx, fzp_batch *b);

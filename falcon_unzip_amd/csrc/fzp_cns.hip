@@ -377,6 +377,7 @@ extern "C" int fzp_batch_consensus_v(fzp_ctx *ctx, fzp_batch *b, int version, fz
     memset(out, 0, sizeof *out);
     if (!b->have_aln || !b->have_blocks || !b->have_preads || !b->have_sites) { fzp_set_error("fzp_batch_consensus: run FZP_STAGE_ALL on a batch with alignment records first"); return FZP_EINVAL; }
     FZP_TRY(fzp_bind(ctx));
+    FZP_TRY(fzp_batch_need_bytes(ctx, b));      // the tally walks the D / I ops of the run-length records: a packed batch (fzp_align_to_batch) makes them now
     hipStream_t st = ctx->stream;
     const int nc = b->n_ctg;
     // ---- blocks per contig and their spans

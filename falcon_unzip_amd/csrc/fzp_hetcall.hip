@@ -119,6 +119,187 @@ __global__ void __launch_bounds__(PILE_THREADS) k_pileup_tiles(RecView v, const 
     for (int i = threadIdx.x; i < PILE_TILE * 4; i += PILE_THREADS) cnt[g0 * 4 + i] = l_cnt[(i & 3) * PILE_TILE + (i >> 2)];
 }
 
+
+// ================================================================================ K2 on K1's packed records (r5)
+// The same pileup and the same variant_map rows, read from what K1 already holds: the alignment's 2-bit op stream (END first) and the 2-bit oriented read -- no byte SEQ,
+// no run-length CIGAR, no 64-op checkpoint pass (PkRec / the 256-op checkpoints come out of k_tb_cigar's last sweep: fzp_batch.h).  A lane owns a WORD of 16 ops: two
+// popcounts say what the word consumes, a wave scan gives every word the cell its first op leaves, and the lane walks its 16 ops -- an aligned column is an op 0 at cell
+// (i, j): reference position j, symbol = base i of the read (phasing.py:77-96; the stream's I / D ops are the walk's `qp += n` / `rp += n`).  ~12 instructions per op and
+// lane against ~55 per 64 columns and wave for the run-length form's expansion, i.e. about a third of the issue slots per column.
+struct PkView {
+    const int32_t *rec_pos, *rec_qid, *rec_ctg;
+    const int64_t *rec_read;
+    PkSrc s;
+    const int64_t *ctg_goff;
+    const int32_t *ctg_limit;
+    int64_t n_rec;
+};
+constexpr uint32_t PK_EVEN = 0x55555555u;
+__device__ __forceinline__ uint32_t pk_valid(int32_t wi, int32_t L) {       // one (even) bit per op of word wi that belongs to the stream
+    const int32_t nv = L - 16 * wi;
+    return nv >= 16 ? PK_EVEN : (nv <= 0 ? 0u : (((1u << (2 * nv)) - 1u) & PK_EVEN));
+}
+// the 16 read bases ending at base i (i >= 0), base i in bits 30..31
+__device__ __forceinline__ uint32_t pk_bases16(const uint32_t *__restrict__ pk, int32_t i) {
+    const int32_t w1 = i >> 4;
+    const uint64_t two = ((uint64_t)pk[w1] << 32) | (w1 > 0 ? pk[w1 - 1] : 0u);
+    return (uint32_t)(two >> (2 * (i & 15) + 2));
+}
+// largest checkpoint k in [0, nck) whose contig consumption is <= want (checkpoint 0 consumes nothing)
+__device__ __forceinline__ int32_t pk_ck_search(const int2 *__restrict__ ck, int32_t nck, int32_t want) {
+    int32_t a = 0, b = nck;
+    while (b - a > 1) { const int32_t m = (a + b) >> 1; if (ck[m].y <= want) a = m; else b = m; }
+    return a;
+}
+
+__global__ void __launch_bounds__(PILE_THREADS) k_pileup_pk(PkView v, const int32_t *__restrict__ tile_ctg, const int32_t *__restrict__ tile_start,
+                                                            const int64_t *__restrict__ ctg_rec_begin, const int32_t *__restrict__ ctg_maxspan,
+                                                            const int32_t *__restrict__ rec_span, uint32_t *__restrict__ cnt, uint32_t *__restrict__ oth,
+                                                            unsigned long long *__restrict__ blk_live) {
+    __shared__ uint32_t l_cnt[4 * PILE_TILE];   // [code][position]
+    const int c = tile_ctg[blockIdx.x];
+    const int32_t ts = tile_start[blockIdx.x];
+    const int32_t lim = v.ctg_limit[c];
+    const int32_t te = min(ts + PILE_TILE, lim);
+    const int64_t rb = ctg_rec_begin[c], re = ctg_rec_begin[c + 1];
+    const int32_t ms = ctg_maxspan[c];
+    int64_t lo, hi;
+    {
+        int64_t a = rb, b = re;
+        while (a < b) { int64_t m = (a + b) >> 1; if (v.rec_pos[m] <= ts - ms) a = m + 1; else b = m; }
+        lo = a;
+        b = re;
+        while (a < b) { int64_t m = (a + b) >> 1; if (v.rec_pos[m] < te) a = m + 1; else b = m; }
+        hi = a;
+    }
+    if (lo >= hi) return;                            // (a tile no record reaches stays dead: k_pileup_tiles)
+    const int64_t g0 = v.ctg_goff[c] + ts;
+    if (threadIdx.x == 0) blk_live[g0 >> 11] = 0x0101010101010101ull;
+    uint32_t *oth_t = oth + g0;                      // packed reads hold A, C, G, T only: the tracker of other symbols stays zero
+    for (int i = threadIdx.x; i < PILE_TILE; i += PILE_THREADS) oth_t[i] = 0u;
+    for (int i = threadIdx.x; i < PILE_TILE * 4; i += PILE_THREADS) l_cnt[i] = 0;
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    constexpr int NW = PILE_THREADS / 64;
+    const uint32_t span = (uint32_t)(te - ts);
+    for (int64_t i0 = 0; lo + i0 * NW + wave < hi; i0 += 64) {
+        const int64_t r = lo + (i0 + lane) * NW + wave;
+        bool ok = r < hi;
+        int32_t ka = 0;
+        if (ok) {
+            ok = v.rec_pos[r] + rec_span[r] > ts;
+            if (ok) {
+                const int64_t rd = v.rec_read[r];
+                const PkRec p = v.s.prec[rd];
+                const int32_t nck = (((p.n_ops + 15) >> 4) + 15) >> 4;
+                // the stream runs from the alignment's end down: start at the last checkpoint that has not yet passed the tile's last position
+                ka = pk_ck_search(v.s.ck + ((size_t)(v.s.rcapq_scan[rd] >> 2) + (size_t)rd), nck, p.j_end - (te - 1));
+            }
+        }
+        const int32_t rel = (int32_t)(r - lo);
+        for (uint64_t todo = __ballot(ok); todo; todo &= todo - 1) {
+            const int l = __builtin_ctzll(todo);
+            const int64_t ru = lo + __builtin_amdgcn_readlane(rel, l);
+            const int32_t k0 = __builtin_amdgcn_readlane(ka, l);
+            const int64_t rd = v.rec_read[ru];
+            const PkRec p = v.s.prec[rd];
+            const uint32_t *__restrict__ ops = v.s.ops + 4 * (size_t)v.s.rcapq_scan[rd];
+            const int2 c0 = v.s.ck[(size_t)(v.s.rcapq_scan[rd] >> 2) + (size_t)rd + (size_t)k0];
+            const uint32_t *__restrict__ pk = (p.strand ? v.s.read_rc : v.s.read_pk) + v.s.read_woff[rd];
+            const int32_t nW = (p.n_ops + 15) >> 4;
+            int32_t ib = p.i_end - c0.x, jb = p.j_end - c0.y;              // the cell the chunk's first op leaves
+            for (int32_t w0 = 16 * k0; w0 < nW && jb >= ts; w0 += 64) {
+                const int32_t wi = w0 + lane;
+                const uint32_t x = wi < nW ? ops[wi] : 0u, vm = pk_valid(wi, p.n_ops);
+                const uint32_t fM = ~(x | (x >> 1)) & vm, cI = fM | ((x & ~(x >> 1)) & vm), cJ = fM | ((~x & (x >> 1)) & vm);
+                const uint32_t ci = (uint32_t)__popc(cI), cj = (uint32_t)__popc(cJ);
+                const uint32_t si = wave_incl_scan_u32_dpp(ci), sj = wave_incl_scan_u32_dpp(cj);
+                int32_t i = ib - (int32_t)(si - ci), j = jb - (int32_t)(sj - cj);
+                // this word's columns lie in [j - cj + 1, j]
+                if (fM != 0u && j >= ts && j - (int32_t)cj + 1 < te && i >= 0) {
+                    const uint32_t q16 = pk_bases16(pk, i);
+                    uint32_t bsh = 30u;                                        // bit offset of the base at the current i inside q16
+                    uint32_t pj = (uint32_t)(j - ts);                          // position inside the tile (wraps when outside)
+                    const uint32_t cI2 = cI << 1;
+#pragma unroll
+                    for (int o = 0; o < 16; o++) {
+                        if ((fM >> (2 * o)) & 1u) {
+                            if (pj < span) atomicAdd(&l_cnt[((q16 >> bsh) & 3u) * PILE_TILE + pj], 1u);
+                        }
+                        bsh -= (cI2 >> (2 * o)) & 2u;
+                        pj -= (cJ >> (2 * o)) & 1u;
+                    }
+                }
+                ib -= __builtin_amdgcn_readlane((int32_t)si, 63);
+                jb -= __builtin_amdgcn_readlane((int32_t)sj, 63);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < PILE_TILE * 4; i += PILE_THREADS) cnt[g0 * 4 + i] = l_cnt[(i & 3) * PILE_TILE + (i >> 2)];
+}
+
+// variant_map rows from the packed records: k_vmap_sites with the symbol looked up in the op stream -- the 256-op checkpoint, at most 16 words skipped by their popcounts,
+// then the ops of one word
+__global__ void __launch_bounds__(256) k_vmap_pk(PkView v, int64_t n_sites, const fzp_site *__restrict__ sites, const int32_t *__restrict__ site_ctg,
+                                                 const int64_t *__restrict__ ctg_rec_begin, const int32_t *__restrict__ ctg_maxspan,
+                                                 const int32_t *__restrict__ rec_span, int32_t *__restrict__ vmap_qid) {
+    const int lane = lane_id();
+    for (int64_t si = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); si < n_sites; si += (int64_t)gridDim.x * 4) {
+        const fzp_site s = sites[si];
+        const int c = site_ctg[si];
+        const int32_t pos = s.pos;
+        const int64_t rb = ctg_rec_begin[c], re = ctg_rec_begin[c + 1];
+        int64_t lo, hi;
+        {
+            const int32_t ms = ctg_maxspan[c];
+            int64_t a = rb, b = re;
+            while (a < b) { const int64_t m = (a + b) >> 1; if (v.rec_pos[m] <= pos - ms) a = m + 1; else b = m; }
+            lo = a;
+            b = re;
+            while (a < b) { const int64_t m = (a + b) >> 1; if (v.rec_pos[m] <= pos) a = m + 1; else b = m; }
+            hi = a;
+        }
+        int32_t base0 = 0, base1 = 0;
+        for (int64_t r0 = lo; r0 < hi; r0 += 64) {
+            const int64_t r = r0 + lane;
+            int al = -1;
+            if (r < hi && pos - v.rec_pos[r] < rec_span[r]) {
+                const int64_t rd = v.rec_read[r];
+                const PkRec p = v.s.prec[rd];
+                const int32_t nW = (p.n_ops + 15) >> 4, nck = (nW + 15) >> 4;
+                const int2 *ckp = v.s.ck + ((size_t)(v.s.rcapq_scan[rd] >> 2) + (size_t)rd);
+                const int32_t k0 = pk_ck_search(ckp, nck, p.j_end - pos);
+                const int2 c0 = ckp[k0];
+                const uint32_t *__restrict__ ops = v.s.ops + 4 * (size_t)v.s.rcapq_scan[rd];
+                int32_t i = p.i_end - c0.x, j = p.j_end - c0.y;
+                for (int32_t wi = 16 * k0; wi < nW && j >= pos; wi++) {
+                    const uint32_t x = ops[wi], vm = pk_valid(wi, p.n_ops);
+                    const uint32_t fM = ~(x | (x >> 1)) & vm, cI = fM | ((x & ~(x >> 1)) & vm), cJ = fM | ((~x & (x >> 1)) & vm);
+                    const int32_t cj = __popc(cJ);
+                    if (j - cj >= pos) { i -= __popc(cI); j -= cj; continue; }      // the op that consumes `pos` is not in this word
+                    // it is the (j - pos + 1)-th contig-consuming op of the word
+                    uint32_t m = cJ;
+                    for (int32_t k = j - pos; k > 0; k--) m &= m - 1;
+                    const int o2 = __builtin_ctz(m);                                   // its (even) bit
+                    if ((fM >> o2) & 1u) {
+                        const int32_t ii = i - __popc(cI & ((1u << o2) - 1u));
+                        const uint32_t *__restrict__ pk = (p.strand ? v.s.read_rc : v.s.read_pk) + v.s.read_woff[rd];
+                        const uint8_t sym = code_sym((int)((pk[ii >> 4] >> (2 * (ii & 15))) & 3u));
+                        al = sym == s.base[0] ? 0 : (sym == s.base[1] ? 1 : -1);
+                    }
+                    break;
+                }
+            }
+            const uint64_t m0 = __ballot(al == 0), m1 = __ballot(al == 1);
+            const uint64_t below = (1ull << lane) - 1ull;
+            if (al == 0) vmap_qid[s.row_off + base0 + __popcll(m0 & below)] = v.rec_qid[r];
+            if (al == 1) vmap_qid[s.row_off + s.count[0] + base1 + __popcll(m1 & below)] = v.rec_qid[r];
+            base0 += __popcll(m0); base1 += __popcll(m1);
+        }
+    }
+}
+
 struct CallInfo {
     bool called;
     uint8_t ord[4];
@@ -468,11 +649,40 @@ RecView rec_view(const fzp_batch *b) {
     return v;
 }
 
+PkView pk_view(const fzp_batch *b) {
+    PkView v;
+    v.rec_pos = b->rec_pos.p; v.rec_qid = b->rec_qid.p; v.rec_ctg = b->rec_ctg.p; v.rec_read = b->rec_read.p;
+    v.s = b->pk;
+    v.ctg_goff = b->ctg_goff.p; v.ctg_limit = b->ctg_limit.p; v.n_rec = b->n_rec;
+    return v;
+}
+
 int read_totals(fzp_ctx *ctx, fzp_batch *b, int n, uint64_t *out) {
     FZP_TRY(fzp_fetch(ctx, ctx->stream, out, b->totals.p, n * sizeof(uint64_t)));
     return FZP_OK;
 }
 }  // namespace
+
+// the 64-op checkpoints of the run-length records (+ every record's reference span and the contigs' longest one)
+static int k2_checkpoints(fzp_ctx *ctx, fzp_batch *b) {
+    hipStream_t st = ctx->stream;
+    FZP_TRY(b->ck_ref.alloc((size_t)b->n_ck)); FZP_TRY(b->ck_q.alloc((size_t)b->n_ck));
+    FZP_TRY(b->rec_span.alloc((size_t)b->n_rec)); FZP_TRY(b->ctg_maxspan.alloc((size_t)b->n_ctg));
+    FZP_TRY(b->ctg_maxspan.zero((size_t)b->n_ctg, st));
+    ProfScope ps(ctx, "k2_cig_ckpt");
+    hipLaunchKernelGGL(k_cig_ckpt, dim3(grid_for(b->n_rec, 4, 1 << 16)), dim3(256), 0, st, rec_view(b), b->ck_off.p, b->ck_ref.p, b->ck_q.p, b->rec_span.p, b->ctg_maxspan.p);
+    return FZP_OK;
+}
+// A batch that came from fzp_align_to_batch holds K1's packed records; whoever needs the run-length CIGAR words, the byte SEQ and their checkpoints (K6: its tally walks
+// the D / I ops) asks here, once.
+int fzp_batch_need_bytes(fzp_ctx *ctx, fzp_batch *b) {
+    if (!b->packed || b->have_bytes) return FZP_OK;
+    if (!b->make_bytes) { fzp_set_error("packed batch without a source job"); return FZP_EINVAL; }
+    FZP_TRY(b->make_bytes(ctx, b));
+    if (b->n_rec > 0 && b->n_pos > 0) FZP_TRY(k2_checkpoints(ctx, b));
+    b->have_bytes = true;
+    return FZP_OK;
+}
 
 // ================================================================================ K2 driver
 int fzp_k2_het_call(fzp_ctx *ctx, fzp_batch *b) {
@@ -487,17 +697,11 @@ int fzp_k2_het_call(fzp_ctx *ctx, fzp_batch *b) {
     FZP_TRY(b->blk_live.zero(nblk + 8, st));
     FZP_TRY(b->site_idx.alloc(nblk));      // per 256-position block: sites, then their exclusive scan
     FZP_TRY(b->row_off32.alloc(nblk));     // per block: variant_map rows, then their exclusive scan
+    const bool packed = b->packed && !b->have_bytes && getenv("FZP_K2_BYTES") == nullptr;      // (FZP_K2_BYTES: the run-length path on a packed batch, for A/B runs and the parity test)
+    if (b->packed && !packed) FZP_TRY(fzp_batch_need_bytes(ctx, b));
     RecView v = rec_view(b);
     if (b->n_rec > 0 && np > 0) {
-        // checkpoints + per-contig maximum reference span
-        const int64_t n_ck = b->n_ck;
-        FZP_TRY(b->ck_ref.alloc((size_t)n_ck)); FZP_TRY(b->ck_q.alloc((size_t)n_ck));
-        FZP_TRY(b->rec_span.alloc((size_t)b->n_rec)); FZP_TRY(b->ctg_maxspan.alloc((size_t)b->n_ctg));
-        FZP_TRY(b->ctg_maxspan.zero((size_t)b->n_ctg, st));
-        {
-            ProfScope ps(ctx, "k2_cig_ckpt");
-            hipLaunchKernelGGL(k_cig_ckpt, dim3(grid_for(b->n_rec, 4, 1 << 16)), dim3(256), 0, st, v, b->ck_off.p, b->ck_ref.p, b->ck_q.p, b->rec_span.p, b->ctg_maxspan.p);
-        }
+        if (!b->packed) FZP_TRY(k2_checkpoints(ctx, b));        // (packed batches: spans from K1's summaries, checkpoints made by fzp_batch_need_bytes when the bytes are)
         // tiles never span contigs
         b->h_tile_ctg.clear(); b->h_tile_start.clear();
         for (int c = 0; c < b->n_ctg; c++)
@@ -506,8 +710,12 @@ int fzp_k2_het_call(fzp_ctx *ctx, fzp_batch *b) {
         FZP_TRY(b->tile_start.upload(b->h_tile_start.data(), b->h_tile_start.size(), st));
         {
             ProfScope ps(ctx, "k2_pileup_count");
-            hipLaunchKernelGGL(k_pileup_tiles, dim3((unsigned)b->h_tile_ctg.size()), dim3(PILE_THREADS), 0, st, v, b->tile_ctg.p, b->tile_start.p, b->ctg_rec_begin.p, b->ctg_maxspan.p,
-                               b->rec_span.p, b->ck_off.p, b->ck_ref.p, b->ck_q.p, b->cnt.p, b->oth.p, (unsigned long long *)b->blk_live.p);
+            if (packed)
+                hipLaunchKernelGGL(k_pileup_pk, dim3((unsigned)b->h_tile_ctg.size()), dim3(PILE_THREADS), 0, st, pk_view(b), b->tile_ctg.p, b->tile_start.p, b->ctg_rec_begin.p, b->ctg_maxspan.p,
+                                   b->rec_span.p, b->cnt.p, b->oth.p, (unsigned long long *)b->blk_live.p);
+            else
+                hipLaunchKernelGGL(k_pileup_tiles, dim3((unsigned)b->h_tile_ctg.size()), dim3(PILE_THREADS), 0, st, v, b->tile_ctg.p, b->tile_start.p, b->ctg_rec_begin.p, b->ctg_maxspan.p,
+                                   b->rec_span.p, b->ck_off.p, b->ck_ref.p, b->ck_q.p, b->cnt.p, b->oth.p, (unsigned long long *)b->blk_live.p);
         }
     }                                                   // (no records: every block stays dead)
     if (np > 0) {
@@ -535,8 +743,12 @@ int fzp_k2_het_call(fzp_ctx *ctx, fzp_batch *b) {
         }
         {
             ProfScope ps(ctx, "k2_vmap_scatter");
-            hipLaunchKernelGGL(k_vmap_sites, dim3(grid_for(b->n_sites, 4, 1 << 16)), dim3(256), 0, st, v, b->n_sites, b->sites.p, b->site_ctg.p, b->ctg_rec_begin.p,
-                               b->ctg_maxspan.p, b->rec_span.p, b->ck_off.p, b->ck_ref.p, b->ck_q.p, b->vmap_qid.p);
+            if (packed)
+                hipLaunchKernelGGL(k_vmap_pk, dim3(grid_for(b->n_sites, 4, 1 << 16)), dim3(256), 0, st, pk_view(b), b->n_sites, b->sites.p, b->site_ctg.p, b->ctg_rec_begin.p,
+                                   b->ctg_maxspan.p, b->rec_span.p, b->vmap_qid.p);
+            else
+                hipLaunchKernelGGL(k_vmap_sites, dim3(grid_for(b->n_sites, 4, 1 << 16)), dim3(256), 0, st, v, b->n_sites, b->sites.p, b->site_ctg.p, b->ctg_rec_begin.p,
+                                   b->ctg_maxspan.p, b->rec_span.p, b->ck_off.p, b->ck_ref.p, b->ck_q.p, b->vmap_qid.p);
         }
     }
     hipLaunchKernelGGL(k_site_begin, dim3((b->n_ctg + 1 + 63) / 64), dim3(64), 0, st, b->site_g.p, b->n_sites, b->ctg_goff.p, b->n_ctg, b->site_begin.p);
