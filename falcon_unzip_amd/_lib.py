@@ -168,6 +168,7 @@ def load():
         "fzp_align_run": (C.c_int, [VP, VP]),
         "fzp_align_invalidate_index": (C.c_int, [VP]),
         "fzp_align_summaries": (C.c_int, [VP, VP, VP]),
+        "fzp_align_cigar_hashes": (C.c_int, [VP, VP, VP]),
         "fzp_align_n_second": (I64, [VP]),
         "fzp_batch_text": (C.c_int, [VP, VP, C.c_int, PP, PSZ, PP]),
         "fzp_pipe_opts_default": (None, [VP]),
@@ -507,6 +508,12 @@ class AlignJob:
         _check(load().fzp_align_summaries(self.eng._p, self._p, _ptr(out)))
         return out
 
+    def cigar_hashes(self):
+        """64-bit fingerprint of every read's CIGAR (M / I / D / S runs as the device keeps them; 0 = unaligned): see cigar_hash_of_words for the same over another aligner's words"""
+        out = np.zeros(self.n_reads, np.uint64)
+        _check(load().fzp_align_cigar_hashes(self.eng._p, self._p, _ptr(out)))
+        return out
+
     def alnset(self, ctg=0, names=None, all_records=False):
         """Alignment records of contig `ctg` as the phasing stages see them -> (AlnSet, read_index); all_records=True: also the
         reads make_het_call's filters drop (what the blasr task's BAM holds)."""
@@ -614,6 +621,39 @@ def align_job_spans(eng, contigs, buf: bytes, read_be, read_ctg, params=None) ->
     p = C.c_void_p()
     _check(lib.fzp_align_create_spans(eng._p, nc, cptr, clen, nr, _ptr(rc), _ptr(be), buf, C.byref(P), C.byref(p)))
     return AlignJob(eng, p.value, nr, nc)
+
+
+def cigar_hash_of_words(cigars):
+    """AlignJob.cigar_hashes() for CIGARs given as a list of uint32 word arrays (len << 4 | op) that may spell aligned columns as '=' / 'X' runs: those become M and adjacent M
+    runs merge (the form the device keeps), then sum over the words of splitmix64(index << 32 | word) mod 2^64; an empty CIGAR hashes to 0."""
+    n = len(cigars)
+    out = np.zeros(n, np.uint64)
+    lens = np.array([len(c) for c in cigars], np.int64)
+    if lens.sum() == 0:
+        return out
+    w = np.concatenate([np.asarray(c, np.uint32) for c in cigars if len(c)]).astype(np.uint64)
+    rid = np.repeat(np.arange(n), lens)
+    op = w & np.uint64(15)
+    op = np.where((op == 7) | (op == 8), np.uint64(0), op)
+    ln = w >> np.uint64(4)
+    start = np.ones(len(w), bool)
+    start[1:] = (op[1:] != op[:-1]) | (rid[1:] != rid[:-1]) | (op[1:] != 0)      # only M runs merge
+    idx = np.flatnonzero(start)
+    mlen = np.add.reduceat(ln, idx)
+    mw = (mlen << np.uint64(4)) | op[idx]
+    mr = rid[idx]
+    first = np.ones(len(idx), bool)
+    first[1:] = mr[1:] != mr[:-1]
+    fpos = np.flatnonzero(first)
+    k = np.arange(len(idx), dtype=np.int64) - np.repeat(fpos, np.diff(np.append(fpos, len(idx))))
+    with np.errstate(over="ignore"):
+        x = (k.astype(np.uint64) << np.uint64(32)) | mw
+        x = x + np.uint64(0x9E3779B97F4A7C15)
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        x = x ^ (x >> np.uint64(31))
+        out[mr[fpos]] = np.add.reduceat(x, fpos)
+    return out
 
 
 def _pipe_args(ctg_ids, names, out_dir, read_maps, ctg_index, n_threads, n_lanes, group_bases, params, flags=0):

@@ -914,11 +914,7 @@ __global__ void __launch_bounds__(64) k_sw(const uint64_t *__restrict__ lo_dev, 
         t = __builtin_amdgcn_readfirstlane(t); i0 = __builtin_amdgcn_readfirstlane(i0);
         // how many steps can run with every lane strictly inside the matrix?  Each step advances i0 or
         // lane 0's column by one, so min(rows left, columns left) steps are safe once the band is inside.
-        int32_t safe = 0;
-        if (t >= 64 && i0 >= 0 && (t - 1) - (i0 + 63) >= 0) {
-            const int32_t rows_left = nq - 1 - (i0 + 63), cols_left = nt - 1 - ((t - 1) - i0);
-            safe = min(rows_left, cols_left) - 1;      // (- 1: after `rows_left` DOWN moves lane 63 sits ON the last row -- a terminal candidate, which only the checked steps look at)
-        }
+        int32_t safe = swb::sw_interior_safe(t, i0, nq, nt);      // (fzp_swb_core.h: shared with the host test that pins it)
         if (safe > 0) {
             // ---- interior: asm blocks of <= 32 steps
             int32_t qpos_i = i0 + 64, tpos_i = t - i0;                 // next bases to enter at lane 63 / lane 0
@@ -2137,6 +2133,29 @@ __global__ void __launch_bounds__(256) k_plan_emit(int64_t n, int n_ctg, const i
     rec_read[k] = r; rec_qid[k] = g_qid[g]; rec_pos[k] = summ[r].pos; rec_ctg[k] = c; rec_span[k] = summ[r].ref_end - summ[r].pos;
     cig_off[k] = (int64_t)v_cig[g]; seq_off[k] = (int64_t)v_seq[g]; ck_off[k] = (int64_t)v_ck[g];
 }
+// ---- a 64-bit fingerprint of every read's CIGAR (checker's aid: tests and bench.py hold all 40 000 reads of the bench workload against the twin's CIGARs, gap placement
+// included, without bringing 800 MB of words over): sum over the words of splitmix64(index << 32 | word), wave per read.  Words as the device keeps them: M / I / D / S runs.
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__global__ void __launch_bounds__(256) k_cigar_hash(int64_t n_reads, const fzp_aln_summary *__restrict__ summ, const int64_t *__restrict__ cig_start, const uint32_t *__restrict__ cig,
+                                                    uint64_t *__restrict__ out) {
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_reads) return;
+    const int lane = lane_id();
+    uint64_t h = 0;
+    if (summ[r].aligned) {
+        const uint32_t *w = cig + cig_start[r];
+        const int32_t n = summ[r].n_cigar;
+        for (int32_t k = lane; k < n; k += 64) h += mix64(((uint64_t)(uint32_t)k << 32) | w[k]);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) h += __shfl_xor(h, d, 64);
+    if (lane == 0) out[r] = h;
+}
 // the batch path's variant: SEQ segments are padded to 16 bytes, so a thread turns one packed word into one 16-byte store
 __global__ void __launch_bounds__(256) k_gather16(int64_t n_rec, const int64_t *__restrict__ rec_read, const int64_t *__restrict__ cig_start, const uint32_t *__restrict__ cig,
                                                   const int64_t *__restrict__ out_cig_off, uint32_t *__restrict__ out_cig, const uint32_t *__restrict__ read_pk, const uint32_t *__restrict__ read_rc,
@@ -2527,6 +2546,10 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
             ChunkBufs &B = j->cb[bi];
             if (used[bi]) FZP_HIP(hipStreamWaitEvent(st, j->ev_tb[bi], 0));   // buffers free again?
             FZP_TRY(B.rpath.alloc((size_t)cnt));
+            // whole masks: the wave-per-slot kernel's slots + room for slots that come back from the 8-byte walk.  (the wave-per-slot slots of a CHUNK never hold more
+            // than the chunk's own capacity -- sizing their room by the run's total made a multi-chunk run in whole-mask mode ask for the whole run's masks twice over, exactly
+            // where chunking was meant to bound them)
+            const int64_t tbw_room = std::min<int64_t>((int64_t)rtot[2], capq) * 64 + FAIL_ROOM;
             uint32_t *const rraw = j->opk.p + 4 * (size_t)cq_at(first);      // this chunk's reads' joined streams inside the job's buffer: read r at + 4 * (rcapq_scan[r] - rcapq_scan[first])
             if (ns > 0) {
                 const uint32_t nblk = (ns + 255) / 256, ngrp = (ns + 63) / 64;
@@ -2536,8 +2559,8 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
                 // masks: the bit-sliced slots' interleaved groups take 64 x (their longest member) each -- in sorted order at most the slots' own capacity + one group of the longest;
                 // whole masks: the wave-per-slot kernel's slots (their capacity over the whole run bounds every chunk's) and room for slots that come back from the 8-byte walk
                 const int64_t swb_cap = (swb_max_steps + 2 + 63) / 64 * 64;
-                const int64_t tbw_room = (int64_t)rtot[2] * 64 + FAIL_ROOM;
-                FZP_TRY(B.tb.alloc((size_t)(capq * 64 + 64 * swb_cap + 64) + 128));
+                // (the 8-byte buffer is not used at all in whole-mask mode)
+                FZP_TRY(B.tb.alloc(use_bits ? (size_t)(capq * 64 + 64 * swb_cap + 64) + 128 : (size_t)128));
                 FZP_TRY(B.tbw.alloc((size_t)tbw_room + 64));
                 FZP_TRY(B.fail_list.alloc(FAIL_CAP));
                 FZP_TRY(B.ptot.alloc(8));
@@ -2628,7 +2651,7 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
                                    (unsigned long long *)nullptr, (uint32_t *)nullptr, (uint64_t *)nullptr, 0u, 16);
                 // slots whose path left the recorded lanes (normally none: these launches find an empty list): whole masks from the wave-per-slot kernel, walked again
                 hipLaunchKernelGGL(k_fail_plan, dim3(FAIL_CAP / 256), dim3(256), 0, st2, (const uint32_t *)B.fail_list.p, (const uint64_t *)(B.ptot.p + 3), (uint32_t)FAIL_CAP, (const Slot *)B.slots.p,
-                                   (unsigned long long *)(B.ptot.p + 4), (uint64_t)((int64_t)rtot[2] * 64 + FAIL_ROOM), B.tbo.p, B.tbs.p, j->fb_overflow.p);
+                                   (unsigned long long *)(B.ptot.p + 4), (uint64_t)tbw_room, B.tbo.p, B.tbs.p, j->fb_overflow.p);
                 hipLaunchKernelGGL(k_sw<true>, dim3(FAIL_CAP), dim3(64), 0, st2, (const uint64_t *)nullptr, (const uint64_t *)(B.ptot.p + 3), (uint32_t)FAIL_CAP, (const uint32_t *)B.fail_list.p, (const Slot *)B.slots.p,
                                    (const uint32_t *)j->read_pk.p, (const uint32_t *)j->read_rc.p, (const int64_t *)j->read_woff.p, (const uint32_t *)j->ctg_pk.p, (const uint32_t *)j->ctg_rc.p,
                                    (const int64_t *)j->ctg_woff.p, (const int64_t *)B.tbo.p, (const int64_t *)B.mvo.p, (const int32_t *)B.tbs.p, (uint2 *)B.tbw.p, B.mvw.p, P.match, P.mismatch, P.gap, B.info.p);
@@ -2697,6 +2720,18 @@ extern "C" int64_t fzp_debug_swb_waves(fzp_ctx *ctx, fzp_alnjob *j, uint64_t *ou
     const int64_t n = std::min<int64_t>(cap, j->wave_log_n);
     if (n > 0 && (hipMemcpy(out, j->wave_log.p, (size_t)n * 32, hipMemcpyDeviceToHost) != hipSuccess)) return 0;
     return n;
+}
+extern "C" int fzp_align_cigar_hashes(fzp_ctx *ctx, fzp_alnjob *j, uint64_t *out) {
+    if (!ctx || !j || !j->done || !out) { fzp_set_error("fzp_align_cigar_hashes: run the job first"); return FZP_EINVAL; }
+    FZP_TRY(fzp_bind(ctx));
+    if (j->n_reads == 0) return FZP_OK;
+    DevBuf<uint64_t> d;
+    FZP_TRY(d.alloc((size_t)j->n_reads));
+    hipLaunchKernelGGL(k_cigar_hash, dim3((unsigned)((j->n_reads + 3) / 4)), dim3(256), 0, ctx->stream, j->n_reads, (const fzp_aln_summary *)j->summ.p, (const int64_t *)j->cig_start.p,
+                       (const uint32_t *)j->cig.p, d.p);
+    FZP_TRY(d.download(out, (size_t)j->n_reads, ctx->stream));
+    FZP_HIP(hipStreamSynchronize(ctx->stream));
+    return FZP_OK;
 }
 extern "C" int fzp_align_summaries(fzp_ctx *ctx, fzp_alnjob *j, fzp_aln_summary *out) {
     if (!ctx || !j || !j->done || !out) { fzp_set_error("fzp_align_summaries: run the job first"); return FZP_EINVAL; }

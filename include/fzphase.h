@@ -256,6 +256,10 @@ int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *job);
 /* forget the k-mer tables fzp_align_create built: the next fzp_align_run builds them again, inside the run */
 int fzp_align_invalidate_index(fzp_alnjob *job);
 int fzp_align_summaries(fzp_ctx *ctx, fzp_alnjob *job, fzp_aln_summary *out /* [n_reads] */);
+/* a 64-bit fingerprint of every read's CIGAR as the device keeps it (runs of M / I / D / S, the clips included): sum over the words of
+ * splitmix64(index << 32 | word), 0 for a read without an alignment.  Lets a checker hold every CIGAR of a large run against another aligner's -- gap placement and
+ * all -- for 8 bytes per read (tests/test_gpu_scale.py, bench.py's cpu_baseline). */
+int fzp_align_cigar_hashes(fzp_ctx *ctx, fzp_alnjob *job, uint64_t *out /* [n_reads] */);
 /* reads of the last run that had a second candidate placement extended (repeats; blasr --bestn 1 keeps the better one) */
 int64_t fzp_align_n_second(const fzp_alnjob *job);
 /* alignment records of contig `ctg` in (POS, read index) order, q_id = rank in that order; names

@@ -143,3 +143,23 @@ extern "C" int swb_extend_pair_host(const uint8_t *q, int64_t nq, const uint8_t 
     out[0] = tt; out[1] = bl >= 0 ? best : -(1 << 26); out[2] = bt; out[3] = bl;
     return 0;
 }
+
+// k_sw's check-free stretch (fzp_swb_core.h: sw_interior_safe), pure geometry: from the band position (t, i0) on an nq x nt matrix, walk EVERY sequence of `steps` moves
+// (the band's cells only depend on how many of them were DOWN) and report whether any cell of any step lies on the last row or the last column -- or outside the matrix.
+// which = 0: the formula the kernel uses; 1: the r3 form without the "- 1" (the test's negative control).  Returns -1 when the band is not inside yet.
+extern "C" int sw_safe_probe(int32_t t, int32_t i0, int32_t nq, int32_t nt, int which, int32_t *safe_out) {
+    int32_t safe = swb::sw_interior_safe(t, i0, nq, nt);
+    if (which == 1 && safe > 0) safe += 1;
+    if (which == 1 && safe == 0 && t >= 64 && i0 >= 0 && (t - 1) - (i0 + 63) >= 0) {
+        const int32_t rl = nq - 1 - (i0 + 63), cl = nt - 1 - ((t - 1) - i0);
+        safe = rl < cl ? rl : cl;
+    }
+    *safe_out = safe;
+    if (safe <= 0) return -1;
+    for (int32_t s = 1; s <= safe; s++)            // after s steps ...
+        for (int32_t d = 0; d <= s; d++) {         // ... d of them DOWN: lane k holds cell (i0 + d + k, (t - 1 + s) - (i0 + d + k))
+            const int32_t row63 = i0 + d + 63, col0 = (t - 1 + s) - (i0 + d);
+            if (row63 >= nq - 1 || col0 >= nt - 1) return 1;      // lane 63 on (or past) the last row, or lane 0 on (or past) the last column
+        }
+    return 0;
+}

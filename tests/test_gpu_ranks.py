@@ -192,9 +192,10 @@ def test_cfg3_shape_500_contigs_on_one_gpu(tmp_path, oracle):
         job = _lib.align_job(eng, [contigs[ci]], reads)
         job.run()
         s = job.summaries()
-        exp, _ = oracle_lib.align_reads(oracle, contigs[ci], reads, n_threads=min(16, bench.host_cores()))
+        exp, exp_cig = oracle_lib.align_reads(oracle, contigs[ci], reads, n_threads=min(16, bench.host_cores()))
         for f in ("aligned", "strand", "pos", "ref_end", "q_start", "q_end", "score", "n_cigar", "cells", "n_columns", "n_match"):
             assert np.array_equal(s[f], exp[f]), (ci, f)
+        assert np.array_equal(job.cigar_hashes(), _lib.cigar_hash_of_words(exp_cig)), (ci, "cigar")      # every CIGAR word, through a 64-bit fingerprint per read
         nm = [name_tab[1][name_tab[0][r]:name_tab[0][r + 1]].decode() for r in m]
         aln, _ = job.alnset(0, nm)
         ref = oracle.phase_all(_lib.format_sam(aln, ids[ci]), contigs[ci], ids[ci])

@@ -209,15 +209,20 @@ def test_cfg2_workload_equals_oracles_on_every_read_and_contig(eng, oracle, reco
     job = _lib.align_job_raw(eng, contigs, blob, off, rctg)
     job.run()
     got = job.summaries()
+    got_hash = job.cigar_hashes()
     assert got["aligned"].mean() > 0.995
     fields = ("aligned", "strand", "pos", "ref_end", "q_start", "q_end", "score", "n_cigar", "cells", "n_columns", "n_match")
     n_checked = 0
     for c in range(n_ctg):
         idx = np.flatnonzero(rctg == c)
         reads = [blob[off[i]:off[i + 1]] for i in idx]
-        exp, _ = oracle_lib.align_reads(oracle, contigs[c], reads, n_threads=cores)
+        exp, exp_cig = oracle_lib.align_reads(oracle, contigs[c], reads, n_threads=cores)
         for f in fields:
             assert np.array_equal(got[f][idx], exp[f]), (c, f, np.flatnonzero(got[f][idx] != exp[f])[:5])
+        # ... and every CIGAR, gap placement included: 64-bit fingerprints of the device's words against the twin's (equal summaries do not prove equal gap placement)
+        eh = _lib.cigar_hash_of_words(exp_cig)
+        assert np.array_equal(got_hash[idx], eh), (c, "cigar", np.flatnonzero(got_hash[idx] != eh)[:5])
+        assert (eh != 0).mean() > 0.99
         n_checked += len(idx)
     assert n_checked == 2000 * n_ctg
     # ... and the phasing chain of the same job, contig for contig, against the oracle chain fed the same records as SAM text
@@ -264,3 +269,53 @@ def test_upload_modes_give_the_same_job(eng, monkeypatch):
     monkeypatch.delenv("FZP_UPLOAD_MODE")
     assert got["direct"]["aligned"].mean() > 0.99
     assert np.array_equal(got["direct"], got["staged"]) and np.array_equal(got["direct"], got["register"])
+
+
+def test_fail_list_overflow_at_20000_reads(eng, monkeypatch):
+    """The whole-masks retry at the size it exists for: 20 000 reads (ten cfg2 contigs) whose walks are told to accept +-2 lanes only (FZP_TB_WINDOW) -- far more than 8 192
+    pieces leave the recorded lanes, the fail list overflows and the run is done again with whole masks for every piece (k_sw throughout).  Same summaries, same CIGARs
+    (64-bit fingerprints of every read's words) as the default run, which test_cfg2_workload_equals_oracles_on_every_read_and_contig holds against the twin."""
+    from falcon_unzip_amd import _lib
+    contigs, blob, off, rctg = _make(10, 5_000_000, 2000, 15000, 750_000, cfg=2)
+    job = _lib.align_job_raw(eng, contigs, blob, off, rctg)
+    job.run()
+    s0, h0 = job.summaries().copy(), job.cigar_hashes().copy()
+    assert s0["aligned"].mean() > 0.995 and (h0 != 0).mean() > 0.995
+    monkeypatch.setenv("FZP_SWB_64", "1")
+    monkeypatch.setenv("FZP_TB_WINDOW", "2")
+    monkeypatch.setenv("FZP_TB_NO_RETRY", "1")
+    with pytest.raises(_lib.FzpError) as e:                     # it IS the overflow path: without the retry the run is refused
+        job.run()
+    assert "whole trace-back masks" in str(e.value)
+    monkeypatch.delenv("FZP_TB_NO_RETRY")
+    job.run()
+    s1, h1 = job.summaries(), job.cigar_hashes()
+    assert np.array_equal(s0, s1) and np.array_equal(h0, h1)
+    job.close()
+
+
+def test_whole_mask_mode_in_chunks_stays_inside_its_budget(monkeypatch):
+    """with whole masks for every piece (non-default scores, FZP_SW_NO_BITS, the retry after a fail-list overflow) a run cut into chunks sized each chunk's
+    16-byte mask room by the WHOLE run's capacity -- 2 x (run steps x 16 B) where the budget said 2 x (chunk steps x 16 B).  3 000 reads of 15 kb (~100 M DP steps, 1.6 GB of
+    whole masks) under a 1 GiB budget: several chunks, the same alignments as the one-chunk run, and the device memory the job took stays far below the whole run's masks twice."""
+    from falcon_unzip_amd import _lib
+    contigs, blob, off, rctg = _make(2, 3_000_000, 1500, 15000, 600_000, cfg=13)
+    e1 = _lib.Engine(0)
+    job = _lib.align_job_raw(e1, contigs, blob, off, rctg)
+    job.run()
+    s0, h0 = job.summaries().copy(), job.cigar_hashes().copy()
+    steps = int(s0["cells"].sum()) // 64
+    job.close(); e1.close()
+    monkeypatch.setenv("FZP_SW_NO_BITS", "1")
+    monkeypatch.setenv("FZP_TB_BUDGET_GB", "1")
+    e2 = _lib.Engine(0)
+    free0, _ = e2.mem_info()
+    job = _lib.align_job_raw(e2, contigs, blob, off, rctg)
+    job.run()
+    s1, h1 = job.summaries(), job.cigar_hashes()
+    free1, _ = e2.mem_info()
+    assert np.array_equal(s0, s1) and np.array_equal(h0, h1)
+    took = free0 - free1                                         # blocks the context keeps cached count as taken: this is the job's peak
+    assert steps * 16 > 1.2e9                                    # the whole run's masks, once
+    assert took < 1.5 * steps * 16, (took, steps * 16)           # measured 1.73 GB: two chunk buffers of 0.6 GB + the job's own 0.5 GB; before the fix 2 x 1.48 GB of masks + 0.5 GB of 8-byte room + the rest
+    job.close(); e2.close()

@@ -106,3 +106,29 @@ def test_unrelated_sequences_and_low_complexity(oracle, swb):
         a, b, c = _both(oracle, swb, q, t)
         _compare(a, b, len(q), len(t))
         _compare(a, c, len(q), len(t))
+
+
+def test_interior_block_never_touches_a_border(swb):
+    """k_sw runs `sw_interior_safe(t, i0, nq, nt)` steps without looking at borders (fzp_swb_core.h; the kernel calls the same function): in none of them -- whatever the
+    moves -- may a cell of the band lie on the matrix's last row or last column, because those cells are the terminal's candidates and only the checked steps see them.
+    Exhaustive over band positions on small matrices; the r3 form of the count (one step more: ADVICE r3) is the negative control and must be caught."""
+    f = swb.sw_safe_probe
+    f.restype = C.c_int
+    safe = C.c_int32()
+    seen_ok = caught = tight = 0
+    for nq in (70, 97, 128, 200):
+        for nt in (66, 90, 131, 260):
+            for t in range(64, nq + nt):
+                for i0 in range(0, t - 63):
+                    if i0 + 63 > nq - 1 or (t - 1) - i0 > nt - 1:
+                        continue                                     # the band already past a border: the kernel is in its checked steps
+                    r = f(t, i0, nq, nt, 0, C.byref(safe))
+                    assert r in (-1, 0), (nq, nt, t, i0, safe.value)
+                    seen_ok += r == 0
+                    s0 = safe.value
+                    r1 = f(t, i0, nq, nt, 1, C.byref(safe))
+                    if safe.value > 0:
+                        assert r1 == 1, (nq, nt, t, i0)              # one step more always CAN reach a border: the count is tight, and the r3 form is wrong
+                        caught += 1
+                        tight += safe.value == max(s0, 0) + 1
+    assert seen_ok > 10000 and caught > 10000 and tight == caught
