@@ -504,6 +504,7 @@ def main():
     ap.add_argument("--strong-leg-contig-len", type=int, default=750_000)
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--no-from-files", action="store_true", help="skip the from_files leg (the end-to-end workload from FASTA files on a memory file system)")
+    ap.add_argument("--no-kernel-breakdown", action="store_true", help="skip the instrumented pass behind the timed steps (counter-collection runs: the pass would add its launches to the sums)")
     ap.add_argument("--no-two-core", action="store_true", help="skip two_core_step_ms (the resident step in a child confined to two CPUs with LOCAL_WORLD_SIZE=8)")
     ap.add_argument("--e2e-lanes", type=int, default=2)
     ap.add_argument("--e2e-group-contigs", type=int, default=10)
@@ -571,6 +572,10 @@ def main():
         comm, gather_note = fdist.make_comm(eng, rank, world, coll_dev)      # the agree-before-ncclCommInitRank handshake (dist.make_comm)
         if comm is None:
             print("bench.py: " + gather_note, file=sys.stderr, flush=True)
+    try:
+        rccl_lib = _lib.comm_library()
+    except Exception as e:      # noqa: BLE001 -- reported in the line
+        rccl_lib = (None, repr(e))
     out_root = None
     # --out-root, else a memory file system (what the step's files cost on a disk-backed /tmp depends on what was written there before -- measured: the same step's
     # writer threads took 2 ms or 30 ms of system time each, in the order the runs came), else $TMPDIR, else wherever a directory can be made
@@ -653,7 +658,7 @@ def main():
     # the same steps once more with every kernel bracketed by HIP events (outside the timed region: sixty brackets cost a step ~1.3 ms and the rank ~6 ms of CPU)
     prof_all, ms_instr, n_instr = {}, None, 0
     host_t_timed, sect_timed = dict(host_t), dict(sect)      # (the timed steps' host sections: `step` goes on adding to the dictionaries it closes over)
-    if prof_on and job is not None:
+    if prof_on and not args.no_kernel_breakdown:      # (every rank, also one without a job: the steps hold collectives)
         n_instr = max(2, min(args.steps, 5))
         eng.prof_reset()
         eng.prof_enable(1)
@@ -839,7 +844,8 @@ def main():
             "rank_load": rank_load,
             "gather": "fzp_allgather_rid_to_phase (RCCL, C-ABI)" if comm is not None else ("torch.distributed all_gather (%s)" % backend if world > 1 else "none (1 rank)"),
             "rccl_ranks": comm.ranks()[1] if comm is not None else 0,      # size of the RCCL communicator as ncclCommCount reports it (0: no RCCL communicator in this run)
-            "gather_fallback": gather_note,
+            "gather_fallback": gather_note,                                  # why the C-ABI RCCL gather was not used (the library's own error text inside), or None
+            "rccl_path": rccl_lib[0], "rccl_version": rccl_lib[1],        # which RCCL the library bound in this process (dladdr of ncclAllGather, ncclGetVersion) -- or why none
             "index_in_step": not args.index_at_create,
             "index_ms": round(prof_all.get("k1_index", (0.0, 0))[0] / max(1, n_instr), 3) if not args.index_at_create else round(index_ms_at_create, 3),
             "value_from_files": from_files.get("reads_per_s") if from_files else None,      # SURVEY 8d's "reads phased/sec (end-to-end incl. host I/O)": FASTA files in, files out

@@ -737,6 +737,16 @@ def comm_unique_id() -> bytes:
     return buf.raw
 
 
+def comm_library():
+    """(path, version) of the RCCL the library bound in this process (fzp_comm_library); raises when RCCL cannot be loaded"""
+    lib = load()
+    lib.fzp_comm_library.restype = C.c_int
+    lib.fzp_comm_library.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]
+    buf, ver = C.create_string_buffer(1024), C.c_int()
+    _check(lib.fzp_comm_library(buf, 1024, C.byref(ver)))
+    return buf.value.decode(), int(ver.value)
+
+
 class Comm:
     """fzp_comm: this rank's RCCL communicator for the rid_to_phase all-gather (one process per GPU)."""
 

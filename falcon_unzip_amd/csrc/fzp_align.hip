@@ -1014,8 +1014,17 @@ struct LaneStream {                // upcoming bases of one sequence, per lane: 
     __device__ __forceinline__ void drop(uint32_t en) { cur >>= 2u * en; have -= (int32_t)en; }
 };
 
-constexpr int SWB_RING = 64;                          // words per lane in a stream's ring
-constexpr int SWB_HOLD = 16;                          // words a bulk load brings
+#ifndef FZP_SWB_RING      // (build-time experiments: -DFZP_SWB_RING=32 -DFZP_SWB_HOLD=8 -DFZP_SWB_GROUP=4 -DFZP_SWB_WAVES=2; the defaults are the measured best)
+#define FZP_SWB_RING 64
+#endif
+#ifndef FZP_SWB_HOLD
+#define FZP_SWB_HOLD 16
+#endif
+#ifndef FZP_SWB_GROUP
+#define FZP_SWB_GROUP 8
+#endif
+constexpr int SWB_RING = FZP_SWB_RING;                // words per lane in a stream's ring
+constexpr int SWB_HOLD = FZP_SWB_HOLD;                // words a bulk load brings
 constexpr int SWB_BULK_STEPS = 16 * SWB_HOLD;         // steps between bulk loads (a step takes at most one base: SWB_HOLD words at most leave the ring in between)
 struct LaneStreamL {
     const uint32_t *pk;            // the sequence's words
@@ -1149,10 +1158,15 @@ __device__ __forceinline__ void swb_step(LANE &L, const int32_t t, const int s8,
 }
 
 constexpr int SWB_WPG = 1;        // waves per workgroup of k_swb (four measured: 10.1 against 9.7 ms)
-constexpr int SWB_GROUP = 8;      // steps whose mask records leave together (64 B per lane)
+constexpr int SWB_GROUP = FZP_SWB_GROUP;      // steps whose mask records leave together (64 B per lane)
 // RING: the base streams through rings in LDS (LaneStreamL) or straight from HBM (LaneStream; FZP_SWB_NO_RING, for comparisons)
+#ifdef FZP_SWB_WAVES
+#define SWB_OCC __attribute__((amdgpu_waves_per_eu(FZP_SWB_WAVES, FZP_SWB_WAVES)))
+#else
+#define SWB_OCC
+#endif
 template <bool RING>
-__global__ void __launch_bounds__(256) k_swb(const uint64_t *__restrict__ n_b_dev, const uint32_t *__restrict__ list, const Slot *__restrict__ slots,
+__global__ void SWB_OCC __launch_bounds__(256) k_swb(const uint64_t *__restrict__ n_b_dev, const uint32_t *__restrict__ list, const Slot *__restrict__ slots,
                                              const uint32_t *__restrict__ read_pk, const uint32_t *__restrict__ read_rc, const int64_t *__restrict__ read_woff,
                                              const uint32_t *__restrict__ ctg_pk, const uint32_t *__restrict__ ctg_rc, const int64_t *__restrict__ ctg_woff,
                                              const int64_t *__restrict__ tbo, const int64_t *__restrict__ mvo, uint2 *__restrict__ tb, ulonglong2 *__restrict__ mvw,

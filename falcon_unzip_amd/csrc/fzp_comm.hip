@@ -9,6 +9,9 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <thread>
 
 #include "fzp_common.h"
 
@@ -26,7 +29,8 @@ struct Rccl {
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
     ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
-    std::string load_error;
+    ncclResult_t (*GetVersion)(int *) = nullptr;
+    std::string load_error, path;
 };
 Rccl &rccl_state() { static Rccl r; return r; }
 std::string rccl_why() { return rccl_state().load_error.empty() ? std::string("not found") : rccl_state().load_error; }
@@ -53,6 +57,10 @@ Rccl *rccl() {
             r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.h, "ncclGetErrorString");
             r.CommCount = (decltype(r.CommCount))dlsym(r.h, "ncclCommCount");
             r.CommUserRank = (decltype(r.CommUserRank))dlsym(r.h, "ncclCommUserRank");
+            r.GetVersion = (decltype(r.GetVersion))dlsym(r.h, "ncclGetVersion");
+            // WHICH library answered: a process that imported torch already has torch's own librccl.so mapped under the same soname, and dlopen hands that one back
+            Dl_info di;
+            if (r.AllGather && dladdr((void *)r.AllGather, &di) && di.dli_fname) r.path = di.dli_fname;
             if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather) { dlclose(r.h); r.h = nullptr; r.load_error = "a needed nccl* symbol is missing"; }
         }
     }
@@ -64,11 +72,26 @@ int rccl_missing(const char *who) {
     fzp_set_error("%s: RCCL (librccl.so.1) could not be loaded: %s", who, rccl_why().c_str());
     return FZP_ENODEVICE;
 }
+// how long a rank waits inside the communicator's creation or the collective before it gives up (FZP_COMM_TIMEOUT_S, default 600; 0 = for ever): a rank stuck there
+// would otherwise hang the node, and the blind N-GPU run could not say why
+int comm_timeout_s() {
+    if (const char *e = getenv("FZP_COMM_TIMEOUT_S")) { const long v = atol(e); if (v >= 0) return (int)v; }
+    return 600;
+}
 int nccl_fail(Rccl *R, const char *what, ncclResult_t rc) {
     fzp_set_error("%s: %s", what, R && R->GetErrorString ? R->GetErrorString(rc) : "RCCL error");
     return FZP_EDEVICE;
 }
 }  // namespace
+
+// which RCCL this process bound (path as dladdr sees ncclAllGather, version as ncclGetVersion says): for the bench line of a run nobody watches
+extern "C" int fzp_comm_library(char *path, size_t cap, int *version) {
+    FZP_TRY(rccl_missing("fzp_comm_library"));
+    Rccl *R = rccl();
+    if (path && cap) { snprintf(path, cap, "%s", R->path.c_str()); }
+    if (version) { *version = 0; if (R->GetVersion) (void)R->GetVersion(version); }
+    return FZP_OK;
+}
 
 struct fzp_comm {
     fzp_ctx *ctx = nullptr;
@@ -96,8 +119,31 @@ extern "C" int fzp_comm_create(fzp_ctx *ctx, int rank, int world, const char id[
     memcpy(u.internal, id, sizeof u.internal);
     fzp_comm *c = new fzp_comm();
     c->ctx = ctx; c->rank = rank; c->world = world;
-    ncclResult_t rc = R->CommInitRank(&c->comm, world, u, rank);
-    if (rc) { delete c; return nccl_fail(R, "ncclCommInitRank", rc); }
+    // ncclCommInitRank is collective: it returns when every rank has called it.  It runs on a helper thread so that a rank whose peers never arrive can say so and
+    // leave (the caller falls back to another gather or fails the job) instead of hanging the node; the helper is abandoned where it is.
+    struct Shared { std::mutex mu; std::condition_variable cv; bool done = false; ncclResult_t rc = 0; ncclComm_t comm = nullptr; };
+    auto sh = std::make_shared<Shared>();
+    const int device = ctx->device;
+    std::thread([sh, R, world, u, rank, device]() {
+        (void)hipSetDevice(device);
+        ncclComm_t cm = nullptr;
+        const ncclResult_t r2 = R->CommInitRank(&cm, world, u, rank);
+        { std::lock_guard<std::mutex> lk(sh->mu); sh->rc = r2; sh->comm = cm; sh->done = true; }
+        sh->cv.notify_all();
+    }).detach();
+    {
+        std::unique_lock<std::mutex> lk(sh->mu);
+        const int limit = comm_timeout_s();
+        if (limit > 0) {
+            if (!sh->cv.wait_for(lk, std::chrono::seconds(limit), [&] { return sh->done; })) {
+                delete c;
+                fzp_set_error("ncclCommInitRank (rank %d of %d, RCCL %s) did not return within %d s (FZP_COMM_TIMEOUT_S): a peer never arrived", rank, world, R->path.c_str(), limit);
+                return FZP_EDEVICE;
+            }
+        } else sh->cv.wait(lk, [&] { return sh->done; });
+        c->comm = sh->comm;
+        if (sh->rc) { const ncclResult_t r2 = sh->rc; delete c; return nccl_fail(R, "ncclCommInitRank", r2); }
+    }
     *out = c;
     return FZP_OK;
 }
@@ -124,6 +170,20 @@ extern "C" void fzp_comm_destroy(fzp_comm *c) {
     delete c;
 }
 
+// hipStreamSynchronize with a deadline: a collective a peer never joins would keep the stream busy for ever
+static int wait_stream(hipStream_t st, const char *what) {
+    const int limit = comm_timeout_s();
+    if (limit <= 0) { FZP_HIP(hipStreamSynchronize(st)); return FZP_OK; }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t e = hipStreamQuery(st);
+        if (e == hipSuccess) return FZP_OK;
+        if (e != hipErrorNotReady) { (void)hipGetLastError(); fzp_set_error("%s: %s", what, hipGetErrorString(e)); return FZP_EDEVICE; }
+        (void)hipGetLastError();
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(limit)) { fzp_set_error("%s did not finish within %d s (FZP_COMM_TIMEOUT_S): a peer never joined the collective", what, limit); return FZP_EDEVICE; }
+        std::this_thread::sleep_for(std::chrono::microseconds(200));
+    }
+}
 extern "C" int fzp_allgather_rid_to_phase(fzp_comm *c, const fzp_r2p *local, int64_t n_local, fzp_r2p **all, int64_t *n_all) {
     if (!c || !all || !n_all || n_local < 0 || (n_local && !local)) { fzp_set_error("fzp_allgather_rid_to_phase: bad arguments"); return FZP_EINVAL; }
     Rccl *R = rccl();
@@ -141,7 +201,7 @@ extern "C" int fzp_allgather_rid_to_phase(fzp_comm *c, const fzp_r2p *local, int
     if (rc) return nccl_fail(R, "ncclAllGather(counts)", rc);
     std::vector<uint64_t> cnts((size_t)W);
     FZP_TRY(d_cnts.download(cnts.data(), (size_t)W, st));
-    FZP_HIP(hipStreamSynchronize(st));
+    FZP_TRY(wait_stream(st, "ncclAllGather(counts)"));
     uint64_t mx = 1, total = 0;
     for (auto v : cnts) { mx = std::max(mx, v); total += v; }
     // 2. payload, padded to the largest shard
@@ -158,7 +218,7 @@ extern "C" int fzp_allgather_rid_to_phase(fzp_comm *c, const fzp_r2p *local, int
         if (cnts[(size_t)r] && hipMemcpyAsync(out + at, d_all.p + (size_t)r * mx, (size_t)cnts[(size_t)r] * sizeof(fzp_r2p), hipMemcpyDeviceToHost, st) != hipSuccess) { free(out); fzp_set_error("D2H copy failed"); return FZP_EDEVICE; }
         at += (size_t)cnts[(size_t)r];
     }
-    if (hipStreamSynchronize(st) != hipSuccess) { free(out); fzp_set_error("all-gather: stream failed"); return FZP_EDEVICE; }
+    { const int wrc = wait_stream(st, "ncclAllGather(records)"); if (wrc != FZP_OK) { free(out); return wrc; } }
     // 3. the order of rid_to_phase.all: sorted per-contig paths (unzip.py:306-307) = contig index, then pread id
     std::sort(out, out + total, [](const fzp_r2p &a, const fzp_r2p &b) { return a.ctg != b.ctg ? a.ctg < b.ctg : a.arid < b.arid; });
     *all = out;

@@ -1027,6 +1027,7 @@ void load_group(const std::string &dir, const char *const *ctg_id, int c0, int c
     std::vector<int> fds((size_t)nf, -1);
     std::vector<size_t> foff((size_t)nf + 1, 0);
     std::vector<std::string> errs((size_t)nf);
+    std::mutex err_mu;
     std::atomic<int> next{0};
     auto par = [&](const std::function<void()> &work) {
         std::vector<std::thread> th;
@@ -1069,7 +1070,12 @@ void load_group(const std::string &dir, const char *const *ctg_id, int c0, int c
             bool ok = true;
             while (at < end) {
                 const ssize_t got = pread(fds[(size_t)t], (void *)(mp[(size_t)t].p + at), end - at, (off_t)at);
-                if (got <= 0) { errs[(size_t)t] = path_of(t) + ": " + (got < 0 ? strerror(errno) : "file shrank while it was read"); ok = false; break; }
+                if (got <= 0) {      // (several pieces of one file are read by different threads: the first failure takes the file's slot, under a lock)
+                    const std::string why = path_of(t) + ": " + (got < 0 ? strerror(errno) : "file shrank while it was read");
+                    std::lock_guard<std::mutex> lk(err_mu);
+                    if (errs[(size_t)t].empty()) errs[(size_t)t] = why;
+                    ok = false; break;
+                }
                 at += (size_t)got;
             }
             if (!ok) continue;
@@ -1237,6 +1243,9 @@ extern "C" int fzp_phase_contigs_files(fzp_ctx *ctx, const char *reads_dir, cons
     std::vector<std::unique_ptr<GroupIn>> gin(groups.size());
     std::vector<std::future<void>> loading(groups.size());
     std::mutex ld_mu, ld_serial;
+    std::condition_variable ld_turn;
+    size_t ld_next = 0;                          // the group whose load may run: loads take every host thread, so they run one at a time -- and in group order (a ticket, not
+                                                 // just a mutex: group 1 must not slip in ahead of group 0 and keep the first lane waiting)
     size_t n_started = 0;
     auto start_loads = [&](size_t upto) {        // (callers hold ld_mu)
         for (; n_started < std::min(upto, groups.size()); n_started++) {
@@ -1244,7 +1253,12 @@ extern "C" int fzp_phase_contigs_files(fzp_ctx *ctx, const char *reads_dir, cons
             gin[g] = pool->take();
             GroupIn *G = gin[g].get();
             const Group gr = groups[g];
-            loading[g] = std::async(std::launch::async, [&, G, gr]() { std::lock_guard<std::mutex> lk(ld_serial); load_group(dir, nm->ctg_id, gr.c0, gr.c1, host_threads, *G); });
+            loading[g] = std::async(std::launch::async, [&, G, gr, g]() {
+                { std::unique_lock<std::mutex> lk(ld_serial); ld_turn.wait(lk, [&] { return ld_next == g; }); }
+                load_group(dir, nm->ctg_id, gr.c0, gr.c1, host_threads, *G);
+                { std::lock_guard<std::mutex> lk(ld_serial); ld_next = g + 1; }
+                ld_turn.notify_all();
+            });
         }
     };
     { std::lock_guard<std::mutex> lk(ld_mu); start_loads((size_t)lanes + 1); }

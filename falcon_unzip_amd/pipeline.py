@@ -179,15 +179,31 @@ def run(unzip_dir, read_map_dir=None, ctg_ids=None, device=None, write_sam=True,
         comm, note = fdist.make_comm(eng, rank, world, "cuda:%d" % dev)
         if comm is None:
             print("pipeline.run: " + note, file=sys.stderr, flush=True)
-    local = np.zeros(0, _lib.R2P)
-    if mine:
-        # contig indices are global so that the gathered records sort like the reference's file list
-        local = phase_contigs_files(eng, unzip_dir, [ctg_ids[i] for i in mine], read_map_dir, write_sam=write_sam, ctg_indices=mine, consensus=consensus)
-    allr = fdist.gather_r2p(local, comm)
-    run.last_gather = "fzp_allgather_rid_to_phase (RCCL)" if comm is not None else ("torch.distributed (%s)" % tdist.get_backend() if world > 1 else "none (1 rank)")
-    if comm is not None:
-        comm.close()
-    eng.close()
+    # A rank whose phasing fails must not leave its peers waiting in the exchange step (fzp_allgather_rid_to_phase has no watchdog of its own): every rank says how it
+    # went over the process group that started the ranks FIRST; the gather is entered only when all went well; the failing rank's exception is raised on it, the others
+    # raise a RuntimeError that names the failure; communicator and engine are closed either way.
+    local, failure = np.zeros(0, _lib.R2P), None
+    try:
+        try:
+            if mine:
+                # contig indices are global so that the gathered records sort like the reference's file list
+                local = phase_contigs_files(eng, unzip_dir, [ctg_ids[i] for i in mine], read_map_dir, write_sam=write_sam, ctg_indices=mine, consensus=consensus)
+        except Exception as e:      # noqa: BLE001 -- re-raised below, after the ranks have agreed not to gather
+            failure = e
+        if world > 1:
+            import torch
+            flag = torch.tensor([0 if failure is None else 1], dtype=torch.int32, device=("cuda:%d" % dev) if tdist.get_backend() == "nccl" else "cpu")
+            tdist.all_reduce(flag, op=tdist.ReduceOp.MAX)
+            if int(flag.item()) and failure is None:
+                failure = RuntimeError("pipeline.run: another rank failed in its phasing step; rid_to_phase.all was not assembled")
+        if failure is not None:
+            raise failure
+        allr = fdist.gather_r2p(local, comm)
+        run.last_gather = "fzp_allgather_rid_to_phase (RCCL)" if comm is not None else ("torch.distributed (%s)" % tdist.get_backend() if world > 1 else "none (1 rank)")
+    finally:
+        if comm is not None:
+            comm.close()
+        eng.close()
     if rank == 0 and read_map_dir is not None:
         out_dir = os.path.join(unzip_dir, "1-hasm", "rid-to-phase-all")
         os.makedirs(out_dir, exist_ok=True)

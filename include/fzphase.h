@@ -378,6 +378,9 @@ typedef struct fzp_comm fzp_comm;
 int fzp_comm_unique_id(char id[FZP_COMM_ID_BYTES]);
 int fzp_comm_create(fzp_ctx *ctx, int rank, int world, const char id[FZP_COMM_ID_BYTES], fzp_comm **out);
 int fzp_comm_ranks(fzp_comm *c, int *rank, int *world);      /* as ncclCommUserRank / ncclCommCount report them */
+/* which RCCL the process bound: the file ncclAllGather lives in (dladdr) and ncclGetVersion -- a process that imported torch first gets torch's copy under the same soname.
+ * FZP_COMM_TIMEOUT_S (default 600, 0 = none): fzp_comm_create and fzp_allgather_rid_to_phase return FZP_EDEVICE with a message instead of waiting for ever for a peer. */
+int fzp_comm_library(char *path, size_t cap, int *version);
 void fzp_comm_destroy(fzp_comm *c);
 int fzp_allgather_rid_to_phase(fzp_comm *c, const fzp_r2p *local, int64_t n_local, fzp_r2p **all /* fzp_free */, int64_t *n_all);
 /* rid_to_phase.all (unzip.py:285, 303-314) from gathered records in the order given: '%09d ctg block phase' rows (phasing_readmap.py:47-51), ctg = ctg_ids[record.ctg] */

@@ -35,6 +35,22 @@ def test_world_one():
     eng.close()
 
 
+def test_the_line_says_which_rccl_and_a_missing_peer_is_a_message_not_a_hang(monkeypatch):
+    """What a run nobody watches needs: the file and version of the RCCL the library bound (a process that imported torch gets torch's copy under the same soname), and
+    -- FZP_COMM_TIMEOUT_S -- a communicator whose peer never arrives ends as an error that says so."""
+    from falcon_unzip_amd import _lib
+    path, ver = _lib.comm_library()
+    assert os.path.isabs(path) and "rccl" in os.path.basename(path).lower() and ver > 20000, (path, ver)
+    monkeypatch.setenv("FZP_COMM_TIMEOUT_S", "3")
+    eng = _lib.Engine(0)
+    import time
+    t0 = time.time()
+    with pytest.raises(_lib.FzpError) as e:
+        _lib.Comm(eng, 0, 2, _lib.comm_unique_id())           # rank 1 of 2 never comes
+    assert "did not return within 3 s" in str(e.value) and "a peer never arrived" in str(e.value) and time.time() - t0 < 30
+    eng.close()
+
+
 CHILD = r"""
 import sys, os, time, numpy as np
 sys.path.insert(0, %r)

@@ -98,6 +98,22 @@ def test_driver_two_ranks_write_what_one_rank_writes(tmp_path):
     assert open(os.path.join(unzip, "1-hasm", "rid-to-phase-all", "rid_to_phase.all"), "rb").read() == cat
 
 
+def test_a_failing_rank_does_not_hang_the_exchange(tmp_path):
+    """a rank whose phasing step raises used to leave before the gather, and its peers waited in it for ever.  Two ranks, one contig's reads file gone: both
+    ranks end -- non-zero, within the time limit -- the failing one naming the file, the other one saying that a peer failed."""
+    unzip, rmd, ctgs, n_reads = _make_unzip_tree(str(tmp_path))
+    os.remove(os.path.join(unzip, "reads", "%s_reads.fa" % ctgs[0]))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(FZP_BACKEND="gloo", MASTER_ADDR="127.0.0.1", PYTHONPATH=REPO + os.pathsep + env.get("PYTHONPATH", ""))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29763",
+           os.path.join(REPO, "scripts", "fc_unzip_phase_gpu.py"), "--unzip_dir", unzip, "--read_map_dir", rmd]
+    p = subprocess.run(cmd, env=env, cwd=REPO, capture_output=True, timeout=300)
+    err = p.stderr.decode(errors="replace")
+    assert p.returncode != 0
+    assert "%s_reads.fa" % ctgs[0] in err and "another rank failed" in err, err[-3000:]
+    assert not os.path.exists(os.path.join(unzip, "1-hasm", "rid-to-phase-all", "rid_to_phase.all"))
+
+
 def test_files_entry_point_writes_what_the_memory_entry_point_writes(tmp_path):
     """fzp_phase_contigs_files (FASTA parsed by the library, a contig group ahead of the lanes) against fzp_phase_contigs fed by the Python reader: same files,
     same records; also with tiny groups on two lanes (several groups in flight) and with CRLF line ends / blank lines / lower case in the inputs."""
@@ -234,6 +250,7 @@ def test_eight_rank_dry_run_of_the_bench():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 8 and d["scaling"] == "weak" and len(d["rank_load"]) == 8 and d["stage_counts"]["r2p_records"] == 8 * 120
     assert d["config"]["reads_total"] == 960 and all(r["reads"] == 120 for r in d["rank_load"])
+    assert "rccl_path" in d and "rccl_version" in d and d["gather_fallback"] is None and "error" not in d["from_files"] and d["from_files"]["n_gpus"] == 8
     sc = d["strong_cfg3"]
     assert "error" not in sc, sc
     assert sc["n_gpus"] == 8 and sum(r["contigs"] for r in sc["rank_load"]) == 12 and sc["reads_total"] == sc["r2p_records"]
