@@ -100,6 +100,8 @@ constexpr int CHAIN_MAX_GAP = 2048;
 constexpr int BRIDGE_MAX_GAP = 4096;   // v1.6: a chain may cross a seedless stretch of up to this many read bases (looser diagonal tolerance) ...
 constexpr int BRIDGE_COST = 4;         // ... for the price of this many hits
 constexpr int LONG_READ = 8192, LONG_STRIDE = 3;      // v1.6: reads of at least LONG_READ bases are sampled at LONG_STRIDE times the stride
+constexpr int LONG_MS = 3, SAMPLE_CAP = 8192;         // v1.7: of a long read's selected k-mers every LONG_MS-th (x 2, x 3 .. per further 131 072 bases) is looked up, SAMPLE_CAP at most
+constexpr int ANCH_DIV = 8;                           // v1.7: table slots are sized for 2 x (k-mer positions / ANCH_DIV) entries (an eighth of the positions is selected on random sequence)
 constexpr int PIECE_LEN = 3072;        // v1.6: read bases between waypoints (at least)
 constexpr int MAX_WP = 31;             // waypoints per candidate: a read has at most 2 x (MAX_WP + 1) = 64 slots, one per lane of k_join
 __host__ __device__ __forceinline__ int32_t piece_len(int64_t n) { const int64_t p = (n + MAX_WP - 2) / (MAX_WP - 1); return (int32_t)(p > PIECE_LEN ? p : PIECE_LEN); }
@@ -120,6 +122,66 @@ __device__ __forceinline__ uint32_t canonical(uint32_t key, int k, uint32_t *is_
 constexpr int PART_BITS = 11;                       // buckets per partition: 2048 x 4 slots x 8 B = 64 KB
 constexpr int STAGE_KMERS = 65536;                  // sampled positions per k_index_stage workgroup
 __device__ __forceinline__ uint32_t next_bucket(uint32_t bkt, uint32_t pmask) { return (bkt & ~pmask) | ((bkt + 1) & pmask); }
+
+// ---- v1.7: anchored k-mers.  A k-mer is SELECTED iff it starts with AC or ends with GT (codes 0 1 / 2 3): decided by the k-mer alone -- contig and read pick the same
+// k-mers wherever they agree, on either strand (a k-mer ends with GT exactly when its reverse complement starts with AC) -- and by two of its bases: sixteen positions at
+// a time with a dozen bit operations on the packed words.  Bit 2m of the result: position 16 wq + m is selected (k >= 8: positions up to 16 wq + 30 lie in the two words).
+__device__ __forceinline__ uint32_t anchored_word(const uint32_t *__restrict__ pk, int64_t wq, int k) {
+    const uint64_t x = (uint64_t)pk[wq] | ((uint64_t)pk[wq + 1] << 32);
+    constexpr uint64_t M = 0x5555555555555555ull;
+    const uint64_t lo = x & M, hi = (x >> 1) & M;
+    const uint64_t isA = ~(lo | hi) & M, isC = lo & ~hi, isG = hi & ~lo, isT = hi & lo;
+    const uint64_t ac = isA & (isC >> 2), gt = isG & (isT >> 2);
+    return (uint32_t)(ac | (gt >> (2 * (k - 2))));
+}
+// ... restricted to the positions p <= last (= len - k) of the sequence
+__device__ __forceinline__ uint32_t anchored_word_upto(const uint32_t *__restrict__ pk, int64_t wq, int k, int64_t last) {
+    uint32_t f = anchored_word(pk, wq, k);
+    const int64_t nv = last - 16 * wq + 1;                 // valid positions in this word
+    if (nv < 16) f &= nv <= 0 ? 0u : ((1u << (2 * nv)) - 1u);
+    return f;
+}
+// k_index_stage's counterpart: a workgroup takes ANCH_WORDS packed words of a contig (16 positions each), every selected position is staged
+constexpr int ANCH_WORDS = 8192;
+__global__ void __launch_bounds__(256) k_index_stage_anch(const uint32_t *__restrict__ ctg_pk, const int64_t *__restrict__ ctg_woff, const int64_t *__restrict__ ctg_len,
+                                                          const int64_t *__restrict__ idx_off, const int32_t *__restrict__ idx_bits, const int64_t *__restrict__ part_off, int k,
+                                                          uint64_t *__restrict__ table, uint32_t *__restrict__ cursor, int32_t *__restrict__ overflow) {
+    __shared__ uint32_t hist[1 << 12], base[1 << 12];
+    const int c = blockIdx.y;
+    const int64_t nk = ctg_len[c] - k + 1;
+    const int64_t w0 = (int64_t)blockIdx.x * ANCH_WORDS;
+    if (w0 * 16 >= nk) return;
+    const uint32_t *pk = ctg_pk + ctg_woff[c];
+    const int bbits = idx_bits[c] - 2;
+    const int pbits = bbits < PART_BITS ? bbits : PART_BITS;
+    const int n_part = 1 << (bbits - pbits);
+    uint64_t *tab = table + idx_off[c];
+    uint32_t *cur = cursor + part_off[c];
+    for (int i = threadIdx.x; i < n_part; i += 256) hist[i] = 0;
+    __syncthreads();
+    for (int pass = 0; pass < 2; pass++) {
+        for (int64_t wq = w0 + threadIdx.x; wq < w0 + ANCH_WORDS && wq * 16 < nk; wq += 256) {
+            for (uint32_t f = anchored_word_upto(pk, wq, k, nk - 1); f; f &= f - 1) {
+                const int64_t pos = 16 * wq + (__builtin_ctz(f) >> 1);
+                uint32_t orc;
+                const uint32_t key = canonical(kmer_at(pk, pos, k), k, &orc);
+                const uint32_t part = hash_slot(key, bbits) >> pbits;
+                if (pass == 0) atomicAdd(&hist[part], 1u);
+                else {
+                    const uint32_t at = base[part] + atomicAdd(&hist[part], 1u);
+                    if (at < (4u << pbits)) tab[((size_t)part << (pbits + 2)) + at] = ((uint64_t)key << 32) | (uint64_t)(((uint32_t)pos << 1) | orc);
+                    else *overflow = 1;
+                }
+            }
+        }
+        __syncthreads();
+        if (pass == 0) {
+            for (int i = threadIdx.x; i < n_part; i += 256) { const uint32_t h = hist[i]; base[i] = h ? atomicAdd(&cur[i], h) : 0u; hist[i] = 0; }
+            __syncthreads();
+        }
+    }
+}
+
 
 __global__ void __launch_bounds__(256) k_index_stage(const uint32_t *__restrict__ ctg_pk, const int64_t *__restrict__ ctg_woff, const int64_t *__restrict__ ctg_len,
                                                      const int64_t *__restrict__ idx_off, const int32_t *__restrict__ idx_bits, const int64_t *__restrict__ part_off, int k,
@@ -268,7 +330,7 @@ struct SeedWin { int32_t n_hits, shift, s1, b1, have2, s2, b2, pad_; };
 __global__ void __launch_bounds__(256) k_seed(int64_t first, const uint32_t *__restrict__ read_pk, const int64_t *__restrict__ read_woff, const int32_t *__restrict__ read_len,
                                               const int32_t *__restrict__ read_ctg, const int64_t *__restrict__ ctg_len, const int64_t *__restrict__ idx_off,
                                               const int32_t *__restrict__ idx_bits, const uint64_t *__restrict__ table, int k, int stride, int min_hits,
-                                              uint2 *__restrict__ hits_g, SeedWin *__restrict__ win) {
+                                              uint2 *__restrict__ hits_g, SeedWin *__restrict__ win, int anchored) {
     extern __shared__ uint32_t votes[];   // [2 * NB] vote bins
     __shared__ uint64_t red[4];
     __shared__ uint32_t wsum[4];
@@ -288,19 +350,57 @@ __global__ void __launch_bounds__(256) k_seed(int64_t first, const uint32_t *__r
     for (int i = threadIdx.x; i < 2 * NB; i += 256) votes[i] = 0;
     __syncthreads();
     if (n >= LONG_READ) stride *= LONG_STRIDE;  // v1.6: a long read has seeds to spare (a short one needs all of them)
-    const int64_t ns = (n - k) / stride + 1;   // sampled FORWARD read offsets 0, stride, ...
+    int64_t ns = (n - k) / stride + 1;         // v1.6: sampled FORWARD read offsets 0, stride, ...
     uint32_t n_hits = 0;                       // block-uniform
     const int lane = lane_id(), wid = threadIdx.x >> 6;
+    // v1.7: the samples are the read's selected k-mers (start with AC / end with GT), every ms-th of them in read order.  What LDS keeps is one number per packed word -- how
+    // many selected positions lie before it (a thread takes a word, a block scan numbers them) --; sample m = selected position number m * ms is then found where it is
+    // needed: the word by bisection, the position inside it from the word's own bits (a few hundred samples of LDS instead of 32 KB: four workgroups still fit a CU).
+    uint32_t *pref = votes + 2 * NB;                                  // [n / 16 + 2] (the launch sized the dynamic LDS for its longest read)
+    const uint32_t ms = n >= LONG_READ ? (uint32_t)LONG_MS * (uint32_t)((n + 131071) / 131072) : 1u;
+    const int64_t last = n - k;                                       // last k-mer position
+    const int32_t n_words = (int32_t)(last / 16) + 1;
+    if (anchored) {
+        uint32_t n_sel = 0;                                           // block-uniform: selected positions before this round
+        for (int32_t wb = 0; wb < n_words; wb += 256) {
+            const int32_t wq = wb + threadIdx.x;
+            const uint32_t cnt = wq < n_words ? (uint32_t)__popc(anchored_word_upto(pk, wq, k, last)) : 0u;
+            const uint32_t incl = wave_incl_scan_u32(cnt);
+            if (lane == 63) wsum[wid] = incl;
+            __syncthreads();
+            uint32_t o = n_sel + incl - cnt, tot = 0;
+#pragma unroll
+            for (int w = 0; w < 4; w++) { if (w < wid) o += wsum[w]; tot += wsum[w]; }
+            if (wq < n_words) pref[wq] = o;
+            n_sel += tot;
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) pref[n_words] = n_sel;
+        __syncthreads();
+        ns = min((int64_t)SAMPLE_CAP, (int64_t)((n_sel + ms - 1) / ms));
+        stride = 1;
+    }
+    auto sample_pos = [&](int64_t m) -> int64_t {                     // forward offset of sample m < ns
+        if (!anchored) return m * stride;
+        const uint32_t o = (uint32_t)m * ms;
+        int32_t a = 0, b2 = n_words;                                  // largest word a with pref[a] <= o (pref[n_words] = n_sel > o)
+        while (b2 - a > 1) { const int32_t mid = (a + b2) >> 1; if (pref[mid] <= o) a = mid; else b2 = mid; }
+        uint32_t f = anchored_word_upto(pk, a, k, last);
+        for (uint32_t r = o - pref[a]; r; r--) f &= f - 1;
+        return 16 * (int64_t)a + (__builtin_ctz(f) >> 1);
+    };
     for (int64_t base = 0; base < ns && n_hits < (uint32_t)HIT_CAP; base += 1024) {
         uint32_t key[4], orr[4], bkt[4];
+        int64_t pfs[4];
         uint4 lo[4], hi[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int64_t m = base + 4 * threadIdx.x + u;
-            key[u] = 0; orr[u] = 0; bkt[u] = 0;
+            key[u] = 0; orr[u] = 0; bkt[u] = 0; pfs[u] = 0;
             lo[u] = hi[u] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
             if (m < ns) {
-                key[u] = canonical(kmer_at(pk, m * stride, k), k, &orr[u]);
+                pfs[u] = sample_pos(m);
+                key[u] = canonical(kmer_at(pk, pfs[u], k), k, &orr[u]);
                 bkt[u] = hash_slot(key[u], bbits);
                 const uint4 *bp = (const uint4 *)(tab + (size_t)bkt[u] * 4);
                 lo[u] = bp[0]; hi[u] = bp[1];
@@ -344,7 +444,7 @@ __global__ void __launch_bounds__(256) k_seed(int64_t first, const uint32_t *__r
         for (int w = 0; w < 4; w++) { if (w < wid) off += wsum[w]; tot += wsum[w]; }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const int64_t pf = (base + 4 * threadIdx.x + u) * stride;
+            const int64_t pf = pfs[u];
             auto emit = [&](uint32_t hit) {
                 const int s_ = (int)((hit & 1u) ^ orr[u]);
                 const int64_t cp = hit >> 1, i = s_ ? n - k - pf : pf;
@@ -630,7 +730,7 @@ __global__ void __launch_bounds__(256) k_plan_final(uint32_t ns, const uint32_t 
     // bit-sliced slots: 8-byte records in the chunk's mask buffer, interleaved by launch group; the others: 16-byte records, streams of their own, in the buffer of whole masks
     if (y < n_b) { tbo[sl] = 4096ll * gq_scan[y >> 6] + 64ll * (y & 63u); tbs[sl] = 4096; }
     else { tbo[sl] = 64ll * ((int64_t)lq_scan[y] - (int64_t)lq_scan[n_b]); tbs[sl] = 64; }
-    if (y == 0) { ptot[3] = 0; ptot[4] = 64ull * (ptot[2] - (n_b < ns ? (uint64_t)lq_scan[n_b] : ptot[2])); }      // the fail list is empty; whole masks of slots that land on it go behind the others'
+    if (y == 0) { ptot[3] = 0; ptot[4] = 64ull * (ptot[2] - (n_b < ns ? (uint64_t)lq_scan[n_b] : ptot[2])); ptot[5] = 0; }      // the fail list is empty; whole masks of slots that land on it go behind the others'; [5]: k_swb's group counter
 }
 
 struct DpInfo { int32_t steps, best_t, best_lane, best_score; };
@@ -1157,8 +1257,8 @@ __device__ __forceinline__ void swb_step(LANE &L, const int32_t t, const int s8,
     L.down = (CHECKED && (t + 1) < 64) ? (uint32_t)(((t + 1) & 1) == 0) : ((uint32_t)L.E2 >> 31) ^ 1u;      // DOWN while lane 63's cell scores at least lane 0's
 }
 
-constexpr int SWB_WPG = 1;        // waves per workgroup of k_swb (four measured: 10.1 against 9.7 ms)
 constexpr int SWB_GROUP = FZP_SWB_GROUP;      // steps whose mask records leave together (64 B per lane)
+constexpr int SWB_WAVES_PER_SIMD = (FZP_SWB_GROUP <= 4 && FZP_SWB_RING <= 32 && FZP_SWB_HOLD <= 8) ? 2 : 1;      // what the register and LDS budget of the build admits (checked with -Rpass-analysis=kernel-resource-usage)
 // RING: the base streams through rings in LDS (LaneStreamL) or straight from HBM (LaneStream; FZP_SWB_NO_RING, for comparisons)
 #ifdef FZP_SWB_WAVES
 #define SWB_OCC __attribute__((amdgpu_waves_per_eu(FZP_SWB_WAVES, FZP_SWB_WAVES)))
@@ -1170,15 +1270,25 @@ __global__ void SWB_OCC __launch_bounds__(256) k_swb(const uint64_t *__restrict_
                                              const uint32_t *__restrict__ read_pk, const uint32_t *__restrict__ read_rc, const int64_t *__restrict__ read_woff,
                                              const uint32_t *__restrict__ ctg_pk, const uint32_t *__restrict__ ctg_rc, const int64_t *__restrict__ ctg_woff,
                                              const int64_t *__restrict__ tbo, const int64_t *__restrict__ mvo, uint2 *__restrict__ tb, ulonglong2 *__restrict__ mvw,
-                                             DpInfo *__restrict__ info, int dbg, uint64_t *__restrict__ wave_log) {
+                                             DpInfo *__restrict__ info, int dbg, uint64_t *__restrict__ wave_log, unsigned long long *__restrict__ next_group) {
     using namespace swb;
-    // wave_log (FZP_SWB_WAVE_LOG, a measurement aid): per workgroup {start, end} of the 100 MHz counter, the hardware id, the steps it ran
+    __shared__ uint32_t srng[RING ? 2 * SWB_RING * 64 : 1];                // the two streams' rings
+    // PERSISTENT waves (r5): the launch has as many one-wave workgroups as the chip has wave slots for this kernel, and a wave PULLS launch groups of 64 slots -- the list is in
+    // decreasing length -- until none is left.  (A grid of one workgroup per group left the slots of the last round half empty: 3 536 groups on 1 024 slots ran at 926 busy
+    // slots on average, tools/runs/swb_waves.py; with work pulled the waves end within one short group of each other.)
+    const uint32_t n_groups = (uint32_t)((*n_b_dev + 63) / 64);
+  for (;;) {
+    uint32_t grp = 0;
+    if (threadIdx.x == 0) grp = (uint32_t)atomicAdd(next_group, 1ull);
+    grp = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)grp);
+    if (grp >= n_groups) break;
+    // wave_log (FZP_SWB_WAVE_LOG, a measurement aid): per launch group {start, end} of the 100 MHz counter, the hardware id, the steps it ran
     const uint64_t t_begin = wave_log ? __builtin_amdgcn_s_memrealtime() : 0ull;
     // dbg: MEASUREMENT switches (FZP_SWB_DBG, tools/runs/swb_probe.py; the results of such a run are not used): bit 0 = no mask stores, bit 1 = no stream refills
     // (workgroups of one wave: four-wave workgroups, which suit k_swb2, put 256 mask streams on a CU and cost this kernel 10 % -- address translation again)
-    const int64_t li = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t li = (int64_t)grp * 64 + threadIdx.x;
     bool active = li < (int64_t)*n_b_dev;
-    if (!__ballot(active)) return;
+    if (!__ballot(active)) continue;
     const uint32_t sl = list[active ? li : 0];      // the lane's slot; the lanes of a wave stand side by side in the launch list, and so do their mask streams
     const Slot S = slots[sl];
     // (64 streams scattered over the buffer cost twice the time in address translation alone: the plan interleaves a wave's streams block by block, stride 4 096 records)
@@ -1197,7 +1307,6 @@ __global__ void SWB_OCC __launch_bounds__(256) k_swb(const uint64_t *__restrict_
     L.R0 = L.R1 = L.C0 = L.C1 = 0;
     for (int k = 33; k < 64; k++) { const uint32_t c = base_at(qpk, qb + (k - 33)); L.R0 |= (uint64_t)(c & 1u) << k; L.R1 |= (uint64_t)(c >> 1) << k; }
     for (int k = 0; k <= 32; k++) { const uint32_t c = base_at(tpk, tbase + (32 - k)); L.C0 |= (uint64_t)(c & 1u) << k; L.C1 |= (uint64_t)(c >> 1) << k; }
-    __shared__ uint32_t srng[RING ? 2 * SWB_RING * 64 : 1];                // the two streams' rings
     if constexpr (RING) {
         L.qs.init(qpk, qb + 31, (uint32_t)((qb + nq + 15) >> 4) + 1u, srng + threadIdx.x);
         L.ts.init(tpk, tbase + 33, (uint32_t)((tbase + nt + 15) >> 4) + 1u, srng + SWB_RING * 64 + threadIdx.x);
@@ -1252,9 +1361,10 @@ __global__ void SWB_OCC __launch_bounds__(256) k_swb(const uint64_t *__restrict_
     if (wave_log && threadIdx.x == 0) {
         uint32_t hw;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        uint64_t *o = wave_log + 4 * (size_t)blockIdx.x;
+        uint64_t *o = wave_log + 4 * (size_t)grp;
         o[0] = t_begin; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = hw; o[3] = (uint64_t)t;
     }
+  }
 }
 
 // ---- the same DP with the band split over a PAIR of lanes (fzp_swb_core.h, Half): 32 reads per wave, half the instructions per step on a wave's
@@ -2285,6 +2395,8 @@ extern "C" void fzp_align_params_default(fzp_align_params *p) {
     memset(p, 0, sizeof *p);
     p->kmer = 16; p->seed_stride = 4; p->match = 2; p->mismatch = 4; p->gap = 3; p->min_seed_hits = 8;
     p->min_pct_identity = 70;
+    p->seed_anchored = 1;
+    if (const char *e = getenv("FZP_SEED_ANCHORED")) p->seed_anchored = atoi(e) != 0;      // (A/B runs: v1.6's fixed strides without touching the caller)
 }
 
 extern "C" void fzp_align_destroy(fzp_ctx *ctx, fzp_alnjob *job) {
@@ -2306,6 +2418,10 @@ static int build_index(fzp_ctx *ctx, fzp_alnjob *j) {
         const unsigned gx = (unsigned)std::max<int64_t>(1, ((lc_max + CTG_STRIDE - 1) / CTG_STRIDE + STAGE_KMERS - 1) / STAGE_KMERS);
         FZP_HIP(hipMemsetAsync(j->part_cursor.p, 0, (size_t)j->n_parts * 4, st));
         FZP_HIP(hipMemsetAsync(j->idx_overflow.p, 0, 4, st));
+        if (P.seed_anchored)
+            hipLaunchKernelGGL(k_index_stage_anch, dim3((unsigned)std::max<int64_t>(1, ((lc_max + 15) / 16 + ANCH_WORDS - 1) / ANCH_WORDS), j->n_ctg), dim3(256), 0, st, j->ctg_pk.p, j->ctg_woff.p,
+                               j->ctg_len.p, j->idx_off.p, j->idx_bits.p, j->part_off.p, P.kmer, j->table.p, j->part_cursor.p, j->idx_overflow.p);
+        else
         hipLaunchKernelGGL(k_index_stage, dim3(gx, j->n_ctg), dim3(256), 0, st, j->ctg_pk.p, j->ctg_woff.p, j->ctg_len.p, j->idx_off.p, j->idx_bits.p, j->part_off.p, P.kmer,
                            j->table.p, j->part_cursor.p, j->idx_overflow.p);
         const size_t lds = (size_t)(4u << PART_BITS) * 8;
@@ -2346,7 +2462,8 @@ extern "C" int fzp_align_create_spans(fzp_ctx *ctx, int32_t n_ctg, const uint8_t
         j->ctg_words += ((ctg_len[c] + 15) / 16 + 8 + 1) & ~1LL;
         int64_t nk = ctg_len[c] - j->P.kmer + 1;
         int bits = 10;
-        while ((1LL << bits) < 2 * std::max<int64_t>((nk + CTG_STRIDE - 1) / CTG_STRIDE, 1)) bits++;
+        const int64_t idx_div = j->P.seed_anchored ? ANCH_DIV : CTG_STRIDE;      // expected entries = positions / idx_div
+        while ((1LL << bits) < 2 * std::max<int64_t>((nk + idx_div - 1) / idx_div, 1)) bits++;
         j->h_idx_bits.push_back(bits);
         j->h_idx_off.push_back(j->idx_slots);
         j->idx_slots += 1LL << bits;
@@ -2471,7 +2588,8 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
             for (auto v : j->h_ctg_len) lc_max = std::max(lc_max, v);
             for (auto v : j->h_read_len) n_max = std::max<int64_t>(n_max, v);
             const int64_t nb_max = std::min<int64_t>(MAX_BINS, ((lc_max + n_max) >> 10) + 2);
-            const size_t lds = (size_t)2 * (size_t)nb_max * sizeof(uint32_t);
+            const size_t lds = ((size_t)2 * (size_t)nb_max + (size_t)(n_max / 16 + 4)) * sizeof(uint32_t);      // vote bins + (v1.7) one count per packed word of the longest read
+            if (lds > 150 * 1024) { fzp_set_error("fzp_align_run: a read of %lld bases against a contig of %lld: the seeding kernel's tables (%zu KB) do not fit a CU's LDS", (long long)n_max, (long long)lc_max, lds >> 10); return FZP_EINVAL; }
             FZP_HIP(hipFuncSetAttribute((const void *)k_seed, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             FZP_HIP(hipMemsetAsync(j->n_sec.p, 0, 4, st));
             const int64_t seed_chunk = 65536;            // reads per seeding launch: HIT_CAP x 12 B of hit list and waypoint links each (3 GiB)
@@ -2481,7 +2599,7 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
             for (int64_t f0 = 0; f0 < nr; f0 += seed_chunk) {
                 const int64_t cn = std::min<int64_t>(seed_chunk, nr - f0);
                 hipLaunchKernelGGL(k_seed, dim3((unsigned)cn), dim3(256), lds, st, f0, j->read_pk.p, j->read_woff.p, j->read_len.p,
-                                   j->read_ctg.p, j->ctg_len.p, j->idx_off.p, j->idx_bits.p, j->table.p, P.kmer, P.seed_stride, P.min_seed_hits, j->hits.p, j->win.p);
+                                   j->read_ctg.p, j->ctg_len.p, j->idx_off.p, j->idx_bits.p, j->table.p, P.kmer, P.seed_stride, P.min_seed_hits, j->hits.p, j->win.p, P.seed_anchored ? 1 : 0);
                 hipLaunchKernelGGL(k_chain, dim3((unsigned)(2 * cn)), dim3(64), 0, st, f0, cn, j->read_len.p, j->hits.p, j->win.p, j->anc.p, j->ancB.p, j->wpp.p, j->n_wp.p, j->wps.p);
             }
         }
@@ -2626,11 +2744,13 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
                         hipLaunchKernelGGL(k_swb2, dim3((ns + 127) / 128), dim3(256), 0, st, (const uint64_t *)B.ptot.p, (const uint32_t *)B.list.p, (const Slot *)B.slots.p,
                                            (const uint32_t *)j->read_pk.p, (const uint32_t *)j->read_rc.p, (const int64_t *)j->read_woff.p, (const uint32_t *)j->ctg_pk.p, (const uint32_t *)j->ctg_rc.p,
                                            (const int64_t *)j->ctg_woff.p, (const int64_t *)B.tbo.p, (const int64_t *)B.mvo.p, B.tb.p, B.mvw.p, B.info.p);
+                    // persistent waves: as many as the chip holds of this kernel (one per SIMD at the default register budget, two with the -DFZP_SWB_* two-wave build), no more than there are groups
+                    const unsigned swb_slots = (unsigned)ctx->n_cu * 4u * (unsigned)SWB_WAVES_PER_SIMD;
                     if (use_bits && swb64)
-                        hipLaunchKernelGGL(swb_ring ? k_swb<true> : k_swb<false>, dim3((ns + 64 * SWB_WPG - 1) / (64 * SWB_WPG)), dim3(64 * SWB_WPG), 0, st, (const uint64_t *)B.ptot.p, (const uint32_t *)B.list.p,
+                        hipLaunchKernelGGL(swb_ring ? k_swb<true> : k_swb<false>, dim3(std::min<unsigned>((ns + 63) / 64, swb_slots)), dim3(64), 0, st, (const uint64_t *)B.ptot.p, (const uint32_t *)B.list.p,
                                            (const Slot *)B.slots.p, (const uint32_t *)j->read_pk.p, (const uint32_t *)j->read_rc.p, (const int64_t *)j->read_woff.p, (const uint32_t *)j->ctg_pk.p,
                                            (const uint32_t *)j->ctg_rc.p, (const int64_t *)j->ctg_woff.p, (const int64_t *)B.tbo.p, (const int64_t *)B.mvo.p, B.tb.p, B.mvw.p, B.info.p,
-                                           getenv("FZP_SWB_DBG") ? atoi(getenv("FZP_SWB_DBG")) : 0, wave_log);
+                                           getenv("FZP_SWB_DBG") ? atoi(getenv("FZP_SWB_DBG")) : 0, wave_log, (unsigned long long *)(B.ptot.p + 5));
                     hipStream_t st_sw = getenv("FZP_SW_SERIAL") ? st : st3;      // (comparison switch: the wave-per-piece kernel behind the bit-sliced one instead of beside it)
                     if (st_sw == st3) FZP_HIP(hipStreamWaitEvent(st3, j->ev_l[0], 0));
                     hipLaunchKernelGGL(k_sw<true>, dim3((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(ns, rtot[3]))), dim3(64), 0, st_sw, (const uint64_t *)B.ptot.p, (const uint64_t *)nullptr, ns, /* (no chunk has more such slots than the run) */ (const uint32_t *)B.list.p, (const Slot *)B.slots.p,

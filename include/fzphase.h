@@ -206,7 +206,8 @@ int fzp_readmap(const char *phased_reads, size_t pr_len, const char *rawread_ids
 
 /* ---------------------------------------------------------------------------------------------
  * K1: read -> contig banded alignment (role of blasr + samtools sort, unzip.py:86-91).
- * Own deterministic spec "fzalign v1.6" (DESIGN.md section 6): k-mer seeding over every indexed position, up to two
+ * Own deterministic spec "fzalign v1.7" (DESIGN.md section 6): k-mer seeding over the ANCHORED k-mers (those that start with AC or end with GT: an eighth of the
+ * positions, the same ones on the contig and on a read wherever they agree; v1.6 -- seed_anchored = 0 -- indexed every 2nd position and looked up every 4th / 12th read k-mer), up to two
  * candidate placements per read (chained anchors); the chain's hits every >= 3 072 read bases are waypoints and the extension is a sequence of
  * independent banded DPs from one waypoint to the next (the role of blasr's alignment between chain anchors), a free one past the last waypoint and one
  * backward from the anchor -- each in an adaptive anti-diagonal band of 64 cells with linear-gap scores --, the better forward extension kept
@@ -220,7 +221,8 @@ typedef struct {
     int32_t match, mismatch, gap;   /* scores: +match, -mismatch, -gap (defaults 2,4,3) */
     int32_t min_seed_hits;   /* reads with fewer votes in the best window are unaligned, default 8 */
     int32_t min_pct_identity; /* alignments below this identity are dropped (blasr --minPctIdentity 70.0, unzip.py:87); default 70, 0 = off */
-    int32_t reserved[9];
+    int32_t seed_anchored;   /* 1 (default, v1.7): index and look-ups use the anchored k-mers; 0: v1.6's fixed strides (every 2nd contig position, every seed_stride-th read k-mer) */
+    int32_t reserved[8];
 } fzp_align_params;
 void fzp_align_params_default(fzp_align_params *p);
 

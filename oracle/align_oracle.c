@@ -4,22 +4,28 @@
  * PARITY UNPINNED vs the reference: FALCON_unzip shells out to `blasr` (falcon_unzip/unzip.py:86-88),
  * a third-party C++ aligner that is not vendored under /root/reference and whose results
  * (placement, clipping, `--hitPolicy randombest --randomSeed 42` tie-breaks) cannot be reproduced
- * here.  This file therefore DEFINES the aligner ("fzalign v1.6"); the HIP kernels in
+ * here.  This file therefore DEFINES the aligner ("fzalign v1.7"); the HIP kernels in
  * falcon_unzip_amd/csrc/fzp_align.hip must match it bit-for-bit (summaries, CIGARs, DP cell counts),
  * and its quality is judged against the simulator's true alignments.
  *
- * fzalign v1.6  (v1.1: one index position per k-mer, one candidate placement per read, no identity gate; v1.2: multi-position index, two
+ * fzalign v1.7  (v1.1: one index position per k-mer, one candidate placement per read, no identity gate; v1.2: multi-position index, two
  *               candidates, chains; v1.3: best-start soft clip; v1.4: anchor = the chain's first hit, extension forward AND backward from it;
  *               v1.5: an extension runs to the matrix BORDER, the alignment is the best-scoring stretch of the joined path;
  *               v1.6: the chain's hits every >= PIECE read bases are WAYPOINTS, the forward extension is a sequence of independent banded DPs from one
- *               waypoint to the next (what blasr does between the anchors of its chain, unzip.py:86-88), free ends are limited)
+ *               waypoint to the next (what blasr does between the anchors of its chain, unzip.py:86-88), free ends are limited;
+ *               v1.7: index and look-ups use the ANCHORED k-mers -- those that start with AC or end with GT -- instead of fixed strides)
  *   bases     A/a C/c G/g T/t -> 0..3, anything else -> 0
+ *   selected  (v1.7) a k-mer position p is SELECTED iff bases p, p+1 are A, C or bases p+k-2, p+k-1 are G, T: about an eighth of the positions, decided by the
+ *             k-mer alone -- the contig and a read select the same k-mers wherever they agree, on either strand (a k-mer ends with GT exactly when its reverse
+ *             complement starts with AC) -- and found sixteen positions at a time with a few bit operations on the packed words.  (seed_anchored = 0 keeps
+ *             v1.6: "selected" contig positions = every 2nd one, the samples of a read = every `stride`-th / 3 x `stride`-th k-mer.)
  *   index     canonical k-mers (k<=16, 2 bits/base, base m of a k-mer at bits 2m; canonical = the smaller of
- *             the k-mer and its reverse complement) of every 2nd contig position -> EVERY such position
+ *             the k-mer and its reverse complement) of every SELECTED contig position -> EVERY such position
  *             (+ whether the canonical form was the reverse complement).  A k-mer with more than MAX_OCC = 8
  *             index entries is repetitive and never produces a hit.
- *   hits      every `stride`-th FORWARD read k-mer (a "sample"; v1.6: every 3 x `stride`-th of a read of 8 192 bases or more -- a long read has
- *             seeds to spare, a short one needs all of them) is looked up once, samples in read order; each index
+ *   hits      the samples of a read = its selected FORWARD k-mers in read order -- all of them for a read below 8 192 bases, every ms-th
+ *             (ms = 3 x ceil(n / 131 072): a long read has seeds to spare, a short one needs all of them) otherwise, 8 192 samples at most;
+ *             every sample is looked up once; each index
  *             entry of it, by increasing contig position, is a hit: equal orientation bits -> the read matches as
  *             sequenced (strand 0, oriented offset i = pf), different -> its reverse complement does
  *             (i = n-k-pf); diagonal value dv = cpos - i + n.  Only the first HIT_CAP = 4096 hits of a read
@@ -84,7 +90,8 @@
 typedef struct {
     int32_t kmer, seed_stride, match, mismatch, gap, min_seed_hits;
     int32_t min_pct_identity;            /* 70 = blasr --minPctIdentity 70.0 (unzip.py:87); 0 disables the gate */
-    int32_t reserved[9];
+    int32_t seed_anchored;               /* v1.7 (default 1): index and samples are the ANCHORED k-mers (start with AC or end with GT); 0 = v1.6's fixed strides (every 2nd contig position, every stride-th read k-mer) */
+    int32_t reserved[8];
 } orc_align_params;
 
 typedef struct {
@@ -101,6 +108,8 @@ typedef struct {
 #define BRIDGE_COST 4       /* ... for the price of this many hits */
 #define LONG_READ 8192      /* v1.6: reads of at least this many bases are sampled at LONG_STRIDE times the stride */
 #define LONG_STRIDE 3
+#define LONG_MS 3           /* v1.7: ... and of their selected k-mers every LONG_MS-th (x 2, x 3 ... per further 131 072 bases) is looked up */
+#define SAMPLE_CAP 8192     /* v1.7: k-mers looked up per read at most (the first ones in read order) */
 #define PIECE_LEN 3072      /* v1.6: read bases between waypoints (at least) */
 #define MAX_WP 31           /* waypoints per candidate (the device joins a read's pieces one per lane: 2 x 32 slots) */
 
@@ -135,6 +144,20 @@ static uint32_t rc_of(uint32_t key, int k) {
     uint32_t r = 0;
     for (int m = 0; m < k; m++) r |= (3u - ((key >> (2 * m)) & 3u)) << (2 * (k - 1 - m));
     return r;
+}
+
+/* ---- v1.7: anchored k-mers.  A k-mer is SELECTED iff it starts with AC or ends with GT (codes 0 1 / 2 3): about an eighth of all positions, decided by the k-mer alone --
+ * so the contig and a read pick the SAME k-mers wherever they agree, on either strand (a k-mer ends with GT exactly when its reverse complement starts with AC) -- and by
+ * two bases of it: both sides find their selected positions with a few bit operations per 16 bases.  The index holds every selected contig position (v1.6: every 2nd
+ * position, four times as many entries); a read looks up its selected k-mers (v1.6: every 4th / 12th k-mer, of which only those on indexed positions could hit). */
+static inline int kmer_selected(const uint8_t *codes, int64_t p, int k) {
+    return (codes[p] == 0 && codes[p + 1] == 1) || (codes[p + k - 2] == 2 && codes[p + k - 1] == 3);
+}
+/* out[0 .. return value) = the selected positions of codes[0 .. len), increasing */
+static int64_t selected_positions(const uint8_t *codes, int64_t len, int k, int64_t *out) {
+    int64_t n = 0;
+    for (int64_t p = 0; p + k <= len; p++) if (kmer_selected(codes, p, k)) out[n++] = p;
+    return n;
 }
 
 /* index entries of the canonical key: [*lo, *lo + return value) */
@@ -185,7 +208,19 @@ static int seed_candidates(const ctg_index *ix, const uint8_t *fwd, int64_t n, c
     memset(votes, 0, (size_t)(2 * NB) * 4);
     hit_t *hits = (hit_t *)scratch_get(7, (size_t)HIT_CAP * sizeof(hit_t));
     int64_t nh = 0;
-    for (int64_t pf = 0; pf + k <= n && nh < HIT_CAP; pf += stride) {
+    /* the samples: v1.6 every stride-th forward k-mer; v1.7 the read's selected k-mers -- all of a short read's, every ms-th of a long one's, SAMPLE_CAP at most */
+    int64_t *samp = NULL, n_samp = 0;
+    if (P->seed_anchored) {
+        int64_t *mp = (int64_t *)scratch_get(8, (size_t)(n > 0 ? n : 1) * 8);
+        const int64_t nm = selected_positions(fwd, n, k, mp);
+        const int64_t ms = n >= LONG_READ ? (int64_t)LONG_MS * ((n + 131071) / 131072) : 1;
+        samp = mp;
+        for (int64_t o = 0; o < nm && n_samp < SAMPLE_CAP; o += ms) samp[n_samp++] = mp[o];      /* (in place: o >= n_samp) */
+    }
+    for (int64_t sx = 0, pf0 = 0; nh < HIT_CAP; sx++, pf0 += stride) {
+        int64_t pf;
+        if (samp) { if (sx >= n_samp) break; pf = samp[sx]; }
+        else { if (pf0 + k > n) break; pf = pf0; }
         uint32_t kf = kmer_at(fwd, pf, k), kr = rc_of(kf, k);
         uint32_t orr = kr < kf ? 1u : 0u;
         int64_t first, cnt = index_range(ix, kr < kf ? kr : kf, &first);
@@ -562,6 +597,27 @@ void orc_align_params_default(orc_align_params *p) {
     memset(p, 0, sizeof *p);
     p->kmer = 16; p->seed_stride = 4; p->match = 2; p->mismatch = 4; p->gap = 3; p->min_seed_hits = 8;
     p->min_pct_identity = 70;
+    p->seed_anchored = 1;
+    { const char *e = getenv("FZP_SEED_ANCHORED"); if (e) p->seed_anchored = atoi(e) != 0; }      /* (A/B runs: the same switch as the library's) */
+}
+
+/* the contig's index entries, sorted by (key, position): v1.6 every 2nd position, v1.7 the contig's selected (anchored) k-mers */
+static void build_index_entries(ctg_index *ix, const uint8_t *codes, int64_t ctg_len, const orc_align_params *P) {
+    const int64_t nk = ctg_len >= P->kmer ? ctg_len - P->kmer + 1 : 0;
+    int64_t *pos = (int64_t *)malloc((size_t)(nk ? nk : 1) * 8);
+    int64_t np = 0;
+    if (P->seed_anchored) np = selected_positions(codes, ctg_len, P->kmer, pos);
+    else for (int64_t p = 0; p < nk; p += 2) pos[np++] = p;
+    ix->n = np;
+    ix->kp = (kp_t *)malloc((size_t)(np ? np : 1) * sizeof(kp_t));
+    for (int64_t q = 0; q < np; q++) {
+        const int64_t p = pos[q];
+        uint32_t kf = kmer_at(codes, p, P->kmer), kr = rc_of(kf, P->kmer);
+        ix->kp[q].key = kr < kf ? kr : kf;
+        ix->kp[q].pos = (int32_t)((p << 1) | (kr < kf ? 1 : 0));
+    }
+    free(pos);
+    qsort(ix->kp, (size_t)ix->n, sizeof(kp_t), cmp_kp);
 }
 
 /* All reads against ONE contig.  cigar_out: concatenated BAM-style words; cig_off[n_reads+1]. */
@@ -573,18 +629,7 @@ int orc_align_reads(const uint8_t *ctg_ascii, int64_t ctg_len, int64_t n_reads, 
     uint8_t *codes = (uint8_t *)malloc((size_t)(ctg_len ? ctg_len : 1));
     for (int64_t i = 0; i < ctg_len; i++) codes[i] = (uint8_t)code_of(ctg_ascii[i]);
     ix.codes = codes; ix.len = ctg_len;
-    {
-        int64_t nk = ctg_len >= P->kmer ? ctg_len - P->kmer + 1 : 0;
-        ix.n = (nk + 1) / 2;                                  /* every 2nd position */
-        ix.kp = (kp_t *)malloc((size_t)(ix.n ? ix.n : 1) * sizeof(kp_t));
-        for (int64_t q = 0; q < ix.n; q++) {
-            int64_t p = 2 * q;
-            uint32_t kf = kmer_at(codes, p, P->kmer), kr = rc_of(kf, P->kmer);
-            ix.kp[q].key = kr < kf ? kr : kf;
-            ix.kp[q].pos = (int32_t)((p << 1) | (kr < kf ? 1 : 0));
-        }
-    }
-    qsort(ix.kp, (size_t)ix.n, sizeof(kp_t), cmp_kp);
+    build_index_entries(&ix, codes, ctg_len, P);
     u32vec cig = {0};
     cig_off[0] = 0;
     for (int64_t r = 0; r < n_reads; r++) {
@@ -628,16 +673,7 @@ int orc_align_origins(const uint8_t *ctg_ascii, int64_t ctg_len, const uint8_t *
     uint8_t *codes = (uint8_t *)malloc((size_t)(ctg_len ? ctg_len : 1));
     for (int64_t i = 0; i < ctg_len; i++) codes[i] = (uint8_t)code_of(ctg_ascii[i]);
     ix.codes = codes; ix.len = ctg_len;
-    int64_t nk = ctg_len >= P->kmer ? ctg_len - P->kmer + 1 : 0;
-    ix.n = (nk + 1) / 2;
-    ix.kp = (kp_t *)malloc((size_t)(ix.n ? ix.n : 1) * sizeof(kp_t));
-    for (int64_t q = 0; q < ix.n; q++) {
-        int64_t p = 2 * q;
-        uint32_t kf = kmer_at(codes, p, P->kmer), kr = rc_of(kf, P->kmer);
-        ix.kp[q].key = kr < kf ? kr : kf;
-        ix.kp[q].pos = (int32_t)((p << 1) | (kr < kf ? 1 : 0));
-    }
-    qsort(ix.kp, (size_t)ix.n, sizeof(kp_t), cmp_kp);
+    build_index_entries(&ix, codes, ctg_len, P);
     uint8_t *fwd = (uint8_t *)malloc((size_t)(n ? n : 1));
     for (int64_t i = 0; i < n; i++) fwd[i] = (uint8_t)code_of(read_ascii[i]);
     anchor_t cand[2];
@@ -681,18 +717,7 @@ int orc_align_reads_mt_timed(const uint8_t *ctg_ascii, int64_t ctg_len, int64_t 
     uint8_t *codes = (uint8_t *)malloc((size_t)(ctg_len ? ctg_len : 1));
     for (int64_t i = 0; i < ctg_len; i++) codes[i] = (uint8_t)code_of(ctg_ascii[i]);
     ix.codes = codes; ix.len = ctg_len;
-    {
-        int64_t nk = ctg_len >= P->kmer ? ctg_len - P->kmer + 1 : 0;
-        ix.n = (nk + 1) / 2;
-        ix.kp = (kp_t *)malloc((size_t)(ix.n ? ix.n : 1) * sizeof(kp_t));
-        for (int64_t q = 0; q < ix.n; q++) {
-            int64_t p = 2 * q;
-            uint32_t kf = kmer_at(codes, p, P->kmer), kr = rc_of(kf, P->kmer);
-            ix.kp[q].key = kr < kf ? kr : kf;
-            ix.kp[q].pos = (int32_t)((p << 1) | (kr < kf ? 1 : 0));
-        }
-    }
-    qsort(ix.kp, (size_t)ix.n, sizeof(kp_t), cmp_kp);
+    build_index_entries(&ix, codes, ctg_len, P);
     const double t_indexed = now_s();
     u32vec *cigs = (u32vec *)calloc((size_t)(n_reads ? n_reads : 1), sizeof(u32vec));
     pthread_t th[256];
