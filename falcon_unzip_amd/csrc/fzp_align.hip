@@ -2257,6 +2257,18 @@ __global__ void __launch_bounds__(256) k_plan_emit(int64_t n, int n_ctg, const i
     rec_read[k] = r; rec_qid[k] = g_qid[g]; rec_pos[k] = summ[r].pos; rec_ctg[k] = c; rec_span[k] = summ[r].ref_end - summ[r].pos;
     cig_off[k] = (int64_t)v_cig[g]; seq_off[k] = (int64_t)v_seq[g]; ck_off[k] = (int64_t)v_ck[g];
 }
+// the evaluated prefix of every contig (ref_seq of the phasing batch) from the job's upper-cased contigs into the batch's position layout: one launch for all contigs
+// (r5: a hipMemcpyAsync per contig was twenty dispatches of a few microseconds each with a gap behind every one)
+__global__ void __launch_bounds__(256) k_copy_ref(const uint8_t *__restrict__ src, const int64_t *__restrict__ aoff, const int64_t *__restrict__ goff, const int32_t *__restrict__ limit,
+                                                  uint8_t *__restrict__ dst) {
+    const int c = blockIdx.y;
+    const int64_t n = limit[c];
+    const uint8_t *s = src + aoff[c];          // 16-byte aligned segments on both sides (the positions are laid out tile-aligned)
+    uint8_t *d = dst + goff[c];
+    const int64_t n16 = n >> 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) ((uint4 *)d)[i] = ((const uint4 *)s)[i];
+    if (blockIdx.x == 0) for (int64_t i = (n16 << 4) + threadIdx.x; i < n; i += 256) d[i] = s[i];
+}
 // ---- a 64-bit fingerprint of every read's CIGAR (checker's aid: tests and bench.py hold all 40 000 reads of the bench workload against the twin's CIGARs, gap placement
 // included, without bringing 800 MB of words over): sum over the words of splitmix64(index << 32 | word), wave per read.  Words as the device keeps them: M / I / D / S runs.
 __device__ __forceinline__ uint64_t mix64(uint64_t x) {
@@ -2347,6 +2359,7 @@ struct fzp_alnjob {
     DevBuf<uint32_t> ctg_pk, ctg_rc, read_pk, read_rc, cig;      // 2-bit packed sequences, both orientations (the second one made once, by k_revcomp)
     DevBuf<uint8_t> ctg_ascii;                   // upper-cased contigs, concatenated (ref_seq of the phasing batch)
     std::vector<int64_t> h_ctg_aoff;
+    DevBuf<int64_t> ctg_aoff;
     DevBuf<int64_t> ctg_woff, ctg_len, idx_off, read_woff, cig_off, cig_start;
     DevBuf<int32_t> idx_bits, read_len, read_ctg;
     DevBuf<uint64_t> table;
@@ -2510,6 +2523,8 @@ extern "C" int fzp_align_create_spans(fzp_ctx *ctx, int32_t n_ctg, const uint8_t
             if (hipStreamSynchronize(st) != hipSuccess) { rc = FZP_EDEVICE; break; }
         }
         j->h_ctg_aoff = coff;
+        if ((rc = j->ctg_aoff.upload(coff.data(), coff.size(), st))) break;
+        if (hipStreamSynchronize(st) != hipSuccess) { rc = FZP_EDEVICE; break; }
         if (n_reads) {
             const size_t rbytes = (size_t)(span_hi - span_lo);
             if ((rc = j->read_pk.alloc((size_t)j->read_words + 8)) || (rc = j->read_rc.alloc((size_t)j->read_words + 8)) || (rc = d_ascii.alloc(rbytes + 16)))
@@ -3185,12 +3200,12 @@ extern "C" int fzp_align_to_batch(fzp_ctx *ctx, fzp_alnjob *j, fzp_batch **out) 
         FZP_HIP(hipGetLastError());
         return FZP_OK;
     };
-    FZP_TRY(b->ref.alloc((size_t)b->n_pos));
-    for (int c = 0; c < nc; c++)   // evaluated prefix of every contig, device to device
-        if (b->h_limit[(size_t)c]) FZP_HIP(hipMemcpyAsync(b->ref.p + b->h_goff[(size_t)c], j->ctg_ascii.p + j->h_ctg_aoff[(size_t)c], (size_t)b->h_limit[(size_t)c], hipMemcpyDeviceToDevice, st));
+    FZP_TRY(b->ref.alloc((size_t)b->n_pos + 16));
     FZP_TRY(b->ctg_goff.upload(b->h_goff.data(), b->h_goff.size(), st));
     FZP_TRY(b->ctg_qoff.upload(b->h_qid_off.data(), b->h_qid_off.size(), st));
     FZP_TRY(b->ctg_limit.upload(b->h_limit.data(), b->h_limit.size(), st));
+    if (b->n_pos > 0) hipLaunchKernelGGL(k_copy_ref, dim3(64, (unsigned)nc), dim3(256), 0, st, (const uint8_t *)j->ctg_ascii.p, (const int64_t *)j->ctg_aoff.p, (const int64_t *)b->ctg_goff.p,
+                                         (const int32_t *)b->ctg_limit.p, b->ref.p);      // evaluated prefix of every contig, device to device
     FZP_HIP(hipStreamSynchronize(st));
     FZP_HIP(hipGetLastError());
     b->have_aln = true;
