@@ -327,11 +327,17 @@ __device__ __forceinline__ uint64_t block_max_u64(uint64_t v, uint64_t *sh) {
 //      hit votes for its (strand, diagonal bin) in LDS;
 //   B. W1 / W2 by block-wide argmax over the vote bins -> SeedWin.
 struct SeedWin { int32_t n_hits, shift, s1, b1, have2, s2, b2, pad_; };
+#ifndef FZP_SEED_SPT
+#define FZP_SEED_SPT 2
+#endif
+constexpr int SEED_SPT = FZP_SEED_SPT;      // samples per thread and round (their bucket loads are in flight together).  r5, same box: 4 -> 110 registers, 4 waves per SIMD, k1_seed 1.79 ms; 2 -> 76 registers, 6 waves, 1.56 ms (the kernel waits on memory 60 % of its cycles: what counts is how many waves wait side by side)
 __global__ void __launch_bounds__(256) k_seed(int64_t first, const uint32_t *__restrict__ read_pk, const int64_t *__restrict__ read_woff, const int32_t *__restrict__ read_len,
                                               const int32_t *__restrict__ read_ctg, const int64_t *__restrict__ ctg_len, const int64_t *__restrict__ idx_off,
                                               const int32_t *__restrict__ idx_bits, const uint64_t *__restrict__ table, int k, int stride, int min_hits,
                                               uint2 *__restrict__ hits_g, SeedWin *__restrict__ win, int anchored) {
-    extern __shared__ uint32_t votes[];   // [2 * NB] vote bins
+    extern __shared__ uint32_t votes[];   // [NB] words: two vote bins of 16 bits each per word (a read has at most HIT_CAP = 4 096 hits: a bin never reaches 65 536) -- r5: half the LDS
+                                          // of 32-bit bins, six workgroups per CU instead of three: the kernel lives on how many bucket probes it keeps in flight
+    auto vote_at = [&](int x) -> uint32_t { return (votes[x >> 1] >> (16 * (x & 1))) & 0xffffu; };
     __shared__ uint64_t red[4];
     __shared__ uint32_t wsum[4];
     const int64_t r = first + blockIdx.x;
@@ -347,7 +353,7 @@ __global__ void __launch_bounds__(256) k_seed(int64_t first, const uint32_t *__r
     const uint64_t *tab = table + idx_off[c];
     const int bbits = idx_bits[c] - 2;
     uint2 *hits = hits_g + (size_t)blockIdx.x * HIT_CAP;   // (strand << 31 | oriented offset, contig position), spec order
-    for (int i = threadIdx.x; i < 2 * NB; i += 256) votes[i] = 0;
+    for (int i = threadIdx.x; i < NB; i += 256) votes[i] = 0;
     __syncthreads();
     if (n >= LONG_READ) stride *= LONG_STRIDE;  // v1.6: a long read has seeds to spare (a short one needs all of them)
     int64_t ns = (n - k) / stride + 1;         // v1.6: sampled FORWARD read offsets 0, stride, ...
@@ -356,24 +362,35 @@ __global__ void __launch_bounds__(256) k_seed(int64_t first, const uint32_t *__r
     // v1.7: the samples are the read's selected k-mers (start with AC / end with GT), every ms-th of them in read order.  What LDS keeps is one number per packed word -- how
     // many selected positions lie before it (a thread takes a word, a block scan numbers them) --; sample m = selected position number m * ms is then found where it is
     // needed: the word by bisection, the position inside it from the word's own bits (a few hundred samples of LDS instead of 32 KB: four workgroups still fit a CU).
-    uint32_t *pref = votes + 2 * NB;                                  // [n / 16 + 2] (the launch sized the dynamic LDS for its longest read)
+    uint32_t *pref = votes + NB;                                      // [n / 16 + 2] (the launch sized the dynamic LDS for its longest read)
     const uint32_t ms = n >= LONG_READ ? (uint32_t)LONG_MS * (uint32_t)((n + 131071) / 131072) : 1u;
     const int64_t last = n - k;                                       // last k-mer position
     const int32_t n_words = (int32_t)(last / 16) + 1;
     if (anchored) {
         uint32_t n_sel = 0;                                           // block-uniform: selected positions before this round
-        for (int32_t wb = 0; wb < n_words; wb += 256) {
-            const int32_t wq = wb + threadIdx.x;
-            const uint32_t cnt = wq < n_words ? (uint32_t)__popc(anchored_word_upto(pk, wq, k, last)) : 0u;
-            const uint32_t incl = wave_incl_scan_u32(cnt);
-            if (lane == 63) wsum[wid] = incl;
-            __syncthreads();
-            uint32_t o = n_sel + incl - cnt, tot = 0;
+        for (int32_t wb4 = 0; wb4 < n_words; wb4 += 1024) {           // four rounds' words are loaded before the first of their scans (a round is a barrier: their loads must not queue behind it)
+            uint32_t cnt4[4];
 #pragma unroll
-            for (int w = 0; w < 4; w++) { if (w < wid) o += wsum[w]; tot += wsum[w]; }
-            if (wq < n_words) pref[wq] = o;
-            n_sel += tot;
-            __syncthreads();
+            for (int u = 0; u < 4; u++) {
+                const int32_t wq = wb4 + u * 256 + threadIdx.x;
+                cnt4[u] = wq < n_words ? (uint32_t)__popc(anchored_word_upto(pk, wq, k, last)) : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int32_t wb = wb4 + u * 256;
+                if (wb >= n_words) break;
+                const int32_t wq = wb + threadIdx.x;
+                const uint32_t cnt = cnt4[u];
+                const uint32_t incl = wave_incl_scan_u32(cnt);
+                if (lane == 63) wsum[wid] = incl;
+                __syncthreads();
+                uint32_t o = n_sel + incl - cnt, tot = 0;
+#pragma unroll
+                for (int w = 0; w < 4; w++) { if (w < wid) o += wsum[w]; tot += wsum[w]; }
+                if (wq < n_words) pref[wq] = o;
+                n_sel += tot;
+                __syncthreads();
+            }
         }
         if (threadIdx.x == 0) pref[n_words] = n_sel;
         __syncthreads();
@@ -389,13 +406,13 @@ __global__ void __launch_bounds__(256) k_seed(int64_t first, const uint32_t *__r
         for (uint32_t r = o - pref[a]; r; r--) f &= f - 1;
         return 16 * (int64_t)a + (__builtin_ctz(f) >> 1);
     };
-    for (int64_t base = 0; base < ns && n_hits < (uint32_t)HIT_CAP; base += 1024) {
-        uint32_t key[4], orr[4], bkt[4];
-        int64_t pfs[4];
-        uint4 lo[4], hi[4];
+    for (int64_t base = 0; base < ns && n_hits < (uint32_t)HIT_CAP; base += 256 * SEED_SPT) {
+        uint32_t key[SEED_SPT], orr[SEED_SPT], bkt[SEED_SPT];
+        int64_t pfs[SEED_SPT];
+        uint4 lo[SEED_SPT], hi[SEED_SPT];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int64_t m = base + 4 * threadIdx.x + u;
+        for (int u = 0; u < SEED_SPT; u++) {
+            const int64_t m = base + SEED_SPT * threadIdx.x + u;
             key[u] = 0; orr[u] = 0; bkt[u] = 0; pfs[u] = 0;
             lo[u] = hi[u] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
             if (m < ns) {
@@ -406,34 +423,18 @@ __global__ void __launch_bounds__(256) k_seed(int64_t first, const uint32_t *__r
                 lo[u] = bp[0]; hi[u] = bp[1];
             }
         }
-        uint32_t ent[4][MAX_OCC], e0[4];
-        int cnt[4];
+        uint32_t e0[SEED_SPT];
+        int cnt[SEED_SPT];
         uint32_t mine = 0;
-        bool several = false;
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int64_t m = base + 4 * threadIdx.x + u;
+        for (int u = 0; u < SEED_SPT; u++) {
+            const int64_t m = base + SEED_SPT * threadIdx.x + u;
             cnt[u] = 0; e0[u] = 0;
             if (m < ns) {
                 cnt[u] = index_count(tab, bbits, key[u], bkt[u], lo[u], hi[u], &e0[u]);
                 if (cnt[u] > MAX_OCC) cnt[u] = 0;
-                several = several || cnt[u] > 1;
             }
             mine += (uint32_t)cnt[u];
-        }
-        if (__any(several)) {                                    // rare: a k-mer with 2..MAX_OCC entries -- all of them, by position
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                if (cnt[u] > 1) {
-                    (void)index_collect(tab, bbits, key[u], bkt[u], lo[u], hi[u], ent[u]);
-                    for (int a = 1; a < cnt[u]; a++) {           // insertion sort
-                        const uint32_t v = ent[u][a];
-                        int b = a - 1;
-                        while (b >= 0 && ent[u][b] > v) { ent[u][b + 1] = ent[u][b]; b--; }
-                        ent[u][b + 1] = v;
-                    }
-                }
-            }
         }
         // slots in (sample, position) order: exclusive scan of the per-thread counts
         const uint32_t incl = wave_incl_scan_u32(mine);
@@ -443,20 +444,29 @@ __global__ void __launch_bounds__(256) k_seed(int64_t first, const uint32_t *__r
 #pragma unroll
         for (int w = 0; w < 4; w++) { if (w < wid) off += wsum[w]; tot += wsum[w]; }
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < SEED_SPT; u++) {
             const int64_t pf = pfs[u];
             auto emit = [&](uint32_t hit) {
                 const int s_ = (int)((hit & 1u) ^ orr[u]);
                 const int64_t cp = hit >> 1, i = s_ ? n - k - pf : pf;
                 hits[off] = make_uint2(((uint32_t)s_ << 31) | (uint32_t)i, (uint32_t)cp);
-                atomicAdd(&votes[s_ * NB + (int)((cp - i + n) >> shift)], 1u);
+                { const int x_ = s_ * NB + (int)((cp - i + n) >> shift); atomicAdd(&votes[x_ >> 1], 1u << (16 * (x_ & 1))); }
             };
             if (cnt[u] == 1) { if (off < (uint32_t)HIT_CAP) emit(e0[u]); off++; }
-            else if (cnt[u] > 1)
+            else if (cnt[u] > 1) {                                   // rare: a k-mer with 2..MAX_OCC entries -- all of them, by position (collected here, one sample at a
+                uint32_t ent[MAX_OCC];                               // time: four such arrays held across the scan cost the kernel a fourth wave per SIMD)
+                (void)index_collect(tab, bbits, key[u], bkt[u], lo[u], hi[u], ent);
+                for (int a = 1; a < cnt[u]; a++) {                   // insertion sort
+                    const uint32_t v = ent[a];
+                    int b = a - 1;
+                    while (b >= 0 && ent[b] > v) { ent[b + 1] = ent[b]; b--; }
+                    ent[b + 1] = v;
+                }
                 for (int a = 0; a < cnt[u]; a++, off++) {
                     if (off >= (uint32_t)HIT_CAP) break;
-                    emit(ent[u][a]);
+                    emit(ent[a]);
                 }
+            }
         }
         n_hits = min(n_hits + tot, (uint32_t)HIT_CAP);
         __syncthreads();
@@ -466,7 +476,7 @@ __global__ void __launch_bounds__(256) k_seed(int64_t first, const uint32_t *__r
     for (int x = threadIdx.x; x < 2 * NB; x += 256) {
         int b = x >= NB ? x - NB : x;
         if (b + 1 >= NB) continue;
-        uint64_t sc = (uint64_t)votes[x] + votes[x + 1];
+        uint64_t sc = (uint64_t)vote_at(x) + vote_at(x + 1);
         uint64_t key = (sc << 32) | (uint64_t)(0xffffffffu - (uint32_t)x);
         best = key > best ? key : best;
     }
@@ -482,7 +492,7 @@ __global__ void __launch_bounds__(256) k_seed(int64_t first, const uint32_t *__r
         const int sx = x >= NB, b = sx ? x - NB : x;
         if (b + 1 >= NB) continue;
         if (sx == s1 && b - b1 < 3 + ext && b1 - b < 3 + ext) continue;
-        uint64_t sc = (uint64_t)votes[x] + votes[x + 1];
+        uint64_t sc = (uint64_t)vote_at(x) + vote_at(x + 1);
         uint64_t key = (sc << 32) | (uint64_t)(0xffffffffu - (uint32_t)x);
         best2 = key > best2 ? key : best2;
     }
@@ -2603,7 +2613,7 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
             for (auto v : j->h_ctg_len) lc_max = std::max(lc_max, v);
             for (auto v : j->h_read_len) n_max = std::max<int64_t>(n_max, v);
             const int64_t nb_max = std::min<int64_t>(MAX_BINS, ((lc_max + n_max) >> 10) + 2);
-            const size_t lds = ((size_t)2 * (size_t)nb_max + (size_t)(n_max / 16 + 4)) * sizeof(uint32_t);      // vote bins + (v1.7) one count per packed word of the longest read
+            const size_t lds = ((size_t)nb_max + (size_t)(n_max / 16 + 4)) * sizeof(uint32_t);      // vote bins (two strands x nb_max, 16 bits each) + (v1.7) one count per packed word of the longest read
             if (lds > 150 * 1024) { fzp_set_error("fzp_align_run: a read of %lld bases against a contig of %lld: the seeding kernel's tables (%zu KB) do not fit a CU's LDS", (long long)n_max, (long long)lc_max, lds >> 10); return FZP_EINVAL; }
             FZP_HIP(hipFuncSetAttribute((const void *)k_seed, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             FZP_HIP(hipMemsetAsync(j->n_sec.p, 0, 4, st));
