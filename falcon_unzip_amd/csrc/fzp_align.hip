@@ -1785,11 +1785,7 @@ __global__ void __launch_bounds__(64) k_tb_cigar(int64_t first, int64_t count, c
     {
         const uint32_t *qpk = (rp.strand ? read_rc : read_pk) + read_woff[r];
         const uint32_t *tpk = ctg_pk + ctg_woff[read_ctg[r]];
-        auto scan_incl = [&](int32_t v) -> int32_t {
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const int32_t o = __shfl_up(v, d, 64); if (lane >= d) v += o; }
-            return v;
-        };
+        auto scan_incl = [&](int32_t v) -> int32_t { return (int32_t)wave_incl_scan_u32_dpp((uint32_t)v); };      // (on the DPP network: __shfl_up is a trip through the LDS pipeline per step)
         auto window = [&](const uint32_t *pk, int64_t idx_hi, int64_t &lo_idx) -> uint64_t {     // the 32 bases ending in the u32 word of idx_hi
             const int64_t w1 = idx_hi >> 4;
             lo_idx = (w1 - 1) * 16;
@@ -1825,12 +1821,16 @@ __global__ void __launch_bounds__(64) k_tb_cigar(int64_t first, int64_t count, c
             const int32_t start = base_S + ss - sl;                // P(16 * wi)
             // lowest prefix over the words up to and including this one: (value, position), later positions win ties
             int32_t mv_ = vm ? start + lmin : 0x3fffffff, mp_ = 16 * wi + lpos;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const int32_t ov_ = __shfl_up(mv_, d, 64), op_ = __shfl_up(mp_, d, 64);
-                if (lane >= d && ov_ < mv_) { mv_ = ov_; mp_ = op_; }
+            {   // inclusive (min, position) scan over the lanes on the DPP network: four shifts inside each row of 16, then the row ends passed on (row_bcast 15 / 31); a lane
+                // without a source sees (+inf, -): "ov_ < mv_" then never holds.  (r5: twelve __shfl_up per chunk -- LDS-pipeline round trips on the wave's critical path -- gone)
+#define MINPOS_STEP(ctrl, row_mask)                                                                                                        \
+    { const int32_t ov_ = __builtin_amdgcn_update_dpp(0x3fffffff, mv_, ctrl, row_mask, 0xf, false), op_ = __builtin_amdgcn_update_dpp(0, mp_, ctrl, row_mask, 0xf, false); \
+      if (ov_ < mv_) { mv_ = ov_; mp_ = op_; } }
+                MINPOS_STEP(0x111, 0xf) MINPOS_STEP(0x112, 0xf) MINPOS_STEP(0x114, 0xf) MINPOS_STEP(0x118, 0xf)      // row_shr 1, 2, 4, 8
+                MINPOS_STEP(0x142, 0xa) MINPOS_STEP(0x143, 0xc)                                                        // row_bcast:15 (rows 1, 3), row_bcast:31 (rows 2, 3)
+#undef MINPOS_STEP
             }
-            int32_t gm = __shfl_up(mv_, 1, 64), gp = __shfl_up(mp_, 1, 64);      // ... before this word
+            int32_t gm = wave_shr1(mv_, 0x3fffffff), gp = wave_shr1(mp_, 0);      // ... before this word (lane 0 takes the chunks before, below)
             if (lane == 0 || base_min < gm) { gm = base_min; gp = base_min_pos; }      // (the chunks before hold earlier positions: they win only when strictly lower)
             {
                 int32_t Pk = start;
@@ -1933,7 +1933,8 @@ __global__ void __launch_bounds__(64) k_tb_cigar(int64_t first, int64_t count, c
     int32_t low_start = 0x7fffffff;       // lowest of them
     int32_t leadI = 0, leadD = 0, trailI = 0, trailD = 0, lead_runs = 0, trail_runs = 0;
     for (int32_t wtop = nW; wtop > 0; wtop -= 64) {
-        const int32_t wi = wtop - 64 + lane;              // lane 63 = highest word of the chunk
+        const int32_t wi = wtop - 1 - lane;               // lane 0 = highest word of the chunk: "the words above this one" are the lanes below, and the scans over them run
+                                                          // as prefix scans on the DPP network (r5: twelve __shfl_down per chunk were LDS-pipeline round trips)
         uint32_t sflag = 0, x = 0, above = 0;
         if (wi >= 0) {
             x = rg[wi];
@@ -1954,17 +1955,16 @@ __global__ void __launch_bounds__(64) k_tb_cigar(int64_t first, int64_t count, c
         }
         const int32_t cnt = __popc(sflag);
         const int32_t mylow = sflag ? 16 * wi + (__builtin_ctz(sflag) >> 1) : 0x7fffffff;
-        // suffix scans over the lanes above this one
-        int32_t cs = cnt, lw = mylow;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int32_t oc = __shfl_down(cs, d, 64), ol = __shfl_down(lw, d, 64);
-            if (lane + d < 64) { cs += oc; lw = min(lw, ol); }
-        }
-        const int32_t tot = __builtin_amdgcn_readlane(cs, 0), chunk_low = __builtin_amdgcn_readlane(lw, 0);
+        // inclusive scans over this word and the words above it (= lanes 0 .. lane): number of starts, lowest start
+        const int32_t cs = (int32_t)wave_incl_scan_u32_dpp((uint32_t)cnt);
+        int32_t lw = mylow;
+#define MIN_STEP(ctrl, row_mask) lw = min(lw, __builtin_amdgcn_update_dpp(0x7fffffff, lw, ctrl, row_mask, 0xf, false));
+        MIN_STEP(0x111, 0xf) MIN_STEP(0x112, 0xf) MIN_STEP(0x114, 0xf) MIN_STEP(0x118, 0xf) MIN_STEP(0x142, 0xa) MIN_STEP(0x143, 0xc)
+#undef MIN_STEP
+        const int32_t tot = __builtin_amdgcn_readlane(cs, 63), chunk_low = __builtin_amdgcn_readlane(lw, 63);
         int32_t k = n_starts + cs - cnt;                                    // starts above this word
-        const int32_t lw_up = __shfl_down(lw, 1, 64);                      // (executed by all lanes)
-        int32_t prevp = min(low_start, lane < 63 ? lw_up : 0x7fffffff);
+        const int32_t lw_up = wave_shr1(lw, 0x7fffffff);                   // lowest start among the words above this one in the chunk (lane 0: none)
+        int32_t prevp = min(low_start, lw_up);
         {
             uint32_t bits = sflag;
             while (bits) {

@@ -118,15 +118,37 @@ __global__ void __launch_bounds__(64) k_sweep(const int64_t *__restrict__ site_b
     }
     for (int iter = 1; iter <= 10; iter++) {
         int updates = 0;
-        uint32_t nl_next = left_n[sb], lo_next = left_off[sb];          // the next site's link range is fetched one site ahead
+        // a site's step is a chain of dependent accesses (its link range -> its links -> the neighbours' states).  The ranges of 64 sites at a time sit one per lane in
+        // registers (two coalesced vector loads per 64 sites, the next block's a block ahead; a site's range is a lane read), the first 64 links of a site are fetched one
+        // site ahead: nothing of it goes through the scalar cache, whose loads share a wait counter with LDS -- with scalar range loads every LDS wait of a step also waited
+        // for a trip to memory (r5)
+        uint32_t nA = (int64_t)lane < n ? left_n[sb + lane] : 0u, oA = (int64_t)lane < n ? left_off[sb + lane] : 0u;                       // sites 64 b .. 64 b + 63
+        uint32_t nB = 64 + (int64_t)lane < n ? left_n[sb + 64 + lane] : 0u, oB = 64 + (int64_t)lane < n ? left_off[sb + 64 + lane] : 0u;   // ... of the block after
+        uint32_t nl1 = (uint32_t)__builtin_amdgcn_readlane((int)nA, 0), lo1 = (uint32_t)__builtin_amdgcn_readlane((int)oA, 0);
+        int4 e1 = (uint32_t)lane < nl1 ? left_pk[lo1 + lane] : make_int4((int)sb, 0, 0, 0);
         for (int64_t p = 0; p < n; p++) {
-            const uint32_t nl = nl_next, lo = lo_next;
-            if (p + 1 < n) { nl_next = left_n[sb + p + 1]; lo_next = left_off[sb + p + 1]; }
+            const uint32_t nl = nl1, lo = lo1;
+            const int4 e0 = e1;
+            const int64_t q = p + 1;
+            if ((q & 63) == 0) {
+                nA = nB; oA = oB;
+                const int64_t b2 = q + 64 + lane;
+                nB = b2 < n ? left_n[sb + b2] : 0u; oB = b2 < n ? left_off[sb + b2] : 0u;
+            }
+            const int ql = (int)(q & 63);
+            nl1 = q < n ? (uint32_t)__builtin_amdgcn_readlane((int)nA, ql) : 0u;
+            lo1 = (uint32_t)__builtin_amdgcn_readlane((int)oA, ql);
+            e1 = (uint32_t)lane < nl1 ? left_pk[lo1 + lane] : make_int4((int)sb, 0, 0, 0);
             if (nl == 0) continue;
             const uint8_t op = o[p];
             int s1 = 0, s2 = 0;
-            for (uint32_t k = lane; k < nl; k += 64) {
-                const int4 e = left_pk[lo + k];                           // (site of the left neighbour, cis, trans)
+            if ((uint32_t)lane < nl) {
+                const bool same = o[e0.x - sb] == op;                     // (site of the left neighbour, cis, trans)
+                s1 += same ? e0.y : e0.z;
+                s2 += same ? e0.z : e0.y;
+            }
+            for (uint32_t k = lane + 64; k < nl; k += 64) {
+                const int4 e = left_pk[lo + k];
                 const bool same = o[e.x - sb] == op;
                 s1 += same ? e.y : e.z;
                 s2 += same ? e.z : e.y;

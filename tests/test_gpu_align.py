@@ -693,3 +693,38 @@ def test_record_planning_at_deep_coverage(eng):
         assert np.array_equal(getattr(r1, f), getattr(r2, f)), f
     assert len(r1.sites) > 50 and len(r1.preads) > 10000
     b1.close(); b2.close(); job.close()
+
+
+def test_packed_hand_off_equals_the_byte_hand_off(eng, monkeypatch):
+    """r5: K2 reads K1's alignments where K1 leaves them -- 2-bit op streams (END first), 2-bit reads, 256-op checkpoints -- instead of run-length CIGAR words and byte SEQ.
+    The same job through both forms (FZP_K2_BYTES makes the byte form and runs the byte kernels on it): every record of every stage equal.  Reads of real shape (3-60 kb,
+    bursts) so that streams end on and off word, checkpoint and tile boundaries, on both strands, with clips at either end; then K6, which asks a packed batch for its bytes."""
+    from falcon_unzip_amd import _lib
+    n = 900
+    ctg, blob, off, st, sd, lens, bf, truth = _shaped(53, 600_000, n)
+    job = _lib.align_job_raw(eng, [ctg], blob, off, np.zeros(n, np.int32))
+    job.run()
+    s = job.summaries()
+    assert (s["aligned"] == 1).mean() > 0.99 and (s["strand"] == 1).mean() > 0.3 and (s["q_start"] > 0).mean() > 0.05
+    res = {}
+    for form in ("packed", "bytes"):
+        if form == "bytes":
+            monkeypatch.setenv("FZP_K2_BYTES", "1")
+        b = job.to_batch()
+        b.run(_lib.STAGE_ALL)
+        res[form] = b.result(0)
+        if form == "packed":
+            tig_p = b.consensus()                      # (a packed batch makes its run-length records when K6 asks)
+            fa_p = tig_p.fasta(0, "c")
+            tig_p.close()
+        else:
+            tig_b = b.consensus()
+            assert tig_b.fasta(0, "c") == fa_p and len(fa_p) > 1000
+            tig_b.close()
+        b.close()
+    monkeypatch.delenv("FZP_K2_BYTES")
+    a, c = res["packed"], res["bytes"]
+    for f in ("sites", "vmap_qid", "arows", "pvars", "preads"):
+        assert np.array_equal(getattr(a, f), getattr(c, f)), f
+    assert len(a.sites) > 100 and len(a.vmap_qid) > 2000 and len(a.preads) > 300
+    job.close()
