@@ -550,6 +550,7 @@ def main():
     if rank == 0 and world == 1 and not args.strong and not args.no_two_core and workers > 1 and mine:      # (workers == 1: under a profiler -- no forks)
         two_core = constrained_child(args, 2, contigs, blob, off, read_ctg, ids, name_tab, maps, mine)      # before torch is imported or the GPU touched; the child has the GPU to itself
 
+    os.environ.setdefault("ROC_SIGNAL_POOL_SIZE", "4096")      # (before ANY HIP runtime of this process comes up -- under backend nccl torch's does first: include/fzphase.h, fzp_sched_status)
     import torch
     import torch.distributed as dist
     from falcon_unzip_amd import _lib
@@ -839,7 +840,7 @@ def main():
             "kernel_ms_per_step": {k: round(v[0] / max(1, n_instr), 3) for k, v in sorted(prof_all.items())},      # from the instrumented pass (every kernel bracketed), not the timed steps
             "ms_per_step_instrumented": round(ms_instr, 3) if ms_instr else None, "instrumented_steps": n_instr,
             "host_cpu_ms_per_step": round(cpu_ms_per_step, 2),
-            "out_fs": fs_of(out_root),
+            "out_fs": fs_of(out_root), "sched_flag_rc": _lib.sched_status(),      # 0: the runtime took the blocking-sync scheduling flag
             "host_wall_ms_per_step": dict({k: round(v / args.steps * 1e3, 3) for k, v in host_t_timed.items()}, **{k[3:]: round(v / args.steps, 3) for k, v in sect_timed.items()}),
             "rank_load": rank_load,
             "gather": "fzp_allgather_rid_to_phase (RCCL, C-ABI)" if comm is not None else ("torch.distributed all_gather (%s)" % backend if world > 1 else "none (1 rank)"),

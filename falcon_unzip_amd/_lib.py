@@ -737,6 +737,12 @@ def comm_unique_id() -> bytes:
     return buf.raw
 
 
+def sched_status():
+    lib = load()
+    lib.fzp_sched_status.restype = C.c_int
+    return int(lib.fzp_sched_status())
+
+
 def comm_library():
     """(path, version) of the RCCL the library bound in this process (fzp_comm_library); raises when RCCL cannot be loaded"""
     lib = load()

@@ -339,6 +339,10 @@ int fzp_upload_segments(fzp_ctx *ctx, void *dst_dev, const std::vector<const voi
 }
 
 // ---------------------------------------------------------------- context
+static int g_sched_rc = -1;      // what hipSetDeviceFlags answered the last time a context asked for its scheduling mode (-1: nobody asked yet)
+// 0 = the runtime accepted the scheduling flag (hipSuccess), otherwise its error code; -1 = never asked
+extern "C" int fzp_sched_status(void) { return g_sched_rc; }
+
 extern "C" int fzp_ctx_create(int device_id, unsigned flags, fzp_ctx **out) {
     (void)flags;
     if (!out) return FZP_EINVAL;
@@ -364,7 +368,8 @@ extern "C" int fzp_ctx_create(int device_id, unsigned flags, fzp_ctx **out) {
         // the reference gives a phasing job its core budget too).  Blocking sync: a short look, then the thread sleeps on the completion signal.  FZP_SCHED=auto|spin|yield|blocking.
         const char *m = getenv("FZP_SCHED");
         const unsigned f = !m || !strcmp(m, "blocking") ? hipDeviceScheduleBlockingSync : !strcmp(m, "spin") ? hipDeviceScheduleSpin : !strcmp(m, "yield") ? hipDeviceScheduleYield : hipDeviceScheduleAuto;
-        if (hipSetDeviceFlags(f) != hipSuccess) (void)hipGetLastError();      // (a runtime that refuses keeps its default: slower to yield, not wrong)
+        g_sched_rc = (int)hipSetDeviceFlags(f);
+        if (g_sched_rc != (int)hipSuccess) (void)hipGetLastError();      // (a runtime that refuses keeps its default: slower to yield, not wrong)
     }
     hipDeviceProp_t prop;
     FZP_HIP(hipGetDeviceProperties(&prop, device_id));

@@ -62,6 +62,10 @@ void fzp_free(void *p);
 int fzp_ctx_create(int device_id, unsigned flags, fzp_ctx **out);
 void fzp_ctx_destroy(fzp_ctx *ctx);
 int fzp_ctx_synchronize(fzp_ctx *ctx);
+/* What hipSetDeviceFlags answered when the last context asked for its scheduling mode (FZP_SCHED, default blocking sync): 0 = accepted, -1 = nobody asked yet.  A host that
+ * brought the device up before (torch under backend nccl) is fine -- measured: the flag is accepted afterwards; what must be in the environment BEFORE the runtime comes up is
+ * ROC_SIGNAL_POOL_SIZE (fzp_ctx_create sets 4096 when it is the first to touch HIP; a host that initialises HIP itself exports it: bench.py and scripts/ do). */
+int fzp_sched_status(void);
 int fzp_mem_info(fzp_ctx *ctx, size_t *free_bytes, size_t *total_bytes);   /* hipMemGetInfo of the ctx's device (blocks cached by the ctx count as used) */
 
 /* Per-kernel device timing (HIP events on the ctx stream).  fzp_prof_enable(ctx,1) starts

@@ -18,6 +18,7 @@ def main(argv=sys.argv):
     ap.add_argument("--read_map_dir", default=None, help="2-asm-falcon/read_maps (enables rid_to_phase.<ctg> and rid_to_phase.all)")
     args = ap.parse_args(argv[1:])
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    os.environ.setdefault("ROC_SIGNAL_POOL_SIZE", "4096")      # before any HIP runtime comes up in this process (under backend nccl torch's does first); include/fzphase.h
     if world > 1:
         import torch
         import torch.distributed as dist
