@@ -1533,7 +1533,10 @@ __global__ void __launch_bounds__(256) k_swb2(const uint64_t *__restrict__ n_b_d
 constexpr int FAIL_CAP = 8192;                   // slots that may come back from the 8-byte walk per chunk ...
 constexpr int64_t FAIL_ROOM = 4ll << 20;         // ... and the DP steps (16-byte records) there is room for
 constexpr int TBW_STRIDE = 512 + 8;              // bytes per slot: one 64-step chunk of {D bits, G bits}; +8 staggers LDS banks
-constexpr int TBW_RPW = 16;                      // slots walked per wave
+#ifndef FZP_TBW_RPW
+#define FZP_TBW_RPW 16
+#endif
+constexpr int TBW_RPW = FZP_TBW_RPW;             // slots walked per wave (build switch: tools/runs/tbw_variants.sh)
 constexpr int TBW_WPG = 1;                       // waves per workgroup (four measured: no faster on uniform reads, 20 % slower on reads of real shape)
 // LDS traffic of one wave is processed in program order: what the wave's lanes wrote is there for its later reads; only the compiler has to keep the order
 #define TBW_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
@@ -2202,7 +2205,8 @@ __global__ void __launch_bounds__(256) k_plan_rank(int64_t n, const int32_t *__r
                                                    const int32_t *__restrict__ read_len,
                                                    uint64_t *__restrict__ v_rec, uint64_t *__restrict__ v_cig, uint64_t *__restrict__ v_seq, uint64_t *__restrict__ v_ck,
                                                    int32_t *__restrict__ g_read, int32_t *__restrict__ g_qid, uint8_t *__restrict__ g_acc, int32_t *__restrict__ last_pos,
-                                                   uint32_t *__restrict__ n_aligned, unsigned long long *__restrict__ n_cols, int32_t *__restrict__ max_span) {
+                                                   uint32_t *__restrict__ n_aligned, unsigned long long *__restrict__ n_cols, int32_t *__restrict__ max_span, int n_ctg) {
+    // n_aligned: [c] aligned reads of contig c, [n_ctg + c] the accepted ones among them (= its records)
     const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const bool valid = s < n && key[s] != ~0ull;          // every lane stays to the end: the per-contig totals are reduced over the wave
     int c = -1;
@@ -2230,6 +2234,7 @@ __global__ void __launch_bounds__(256) k_plan_rank(int64_t n, const int32_t *__r
     const uint64_t vm = __ballot(valid);
     if (vm == 0) return;
     const int c0 = __builtin_amdgcn_readlane(c, __builtin_ctzll(vm));
+    const uint64_t am = __ballot(valid && acc);
     if (__all(!valid || c == c0)) {
         int32_t mp = (valid && acc) ? pos : -1, msp = (valid && acc) ? rspan : 0;
         unsigned long long cols = (valid && acc) ? (unsigned long long)ncol : 0ull;
@@ -2237,13 +2242,14 @@ __global__ void __launch_bounds__(256) k_plan_rank(int64_t n, const int32_t *__r
         for (int d = 32; d >= 1; d >>= 1) { mp = max(mp, __shfl_xor(mp, d, 64)); msp = max(msp, __shfl_xor(msp, d, 64)); cols += __shfl_xor(cols, d, 64); }
         if (lane_id() == 0) {
             atomicAdd(&n_aligned[c0], (uint32_t)__popcll(vm));
+            if (am) atomicAdd(&n_aligned[n_ctg + c0], (uint32_t)__popcll(am));
             if (mp >= 0) atomicMax(&last_pos[c0], mp);
             if (msp > 0) atomicMax(&max_span[c0], msp);
             if (cols) atomicAdd(&n_cols[c0], cols);
         }
     } else if (valid) {
         atomicAdd(&n_aligned[c], 1u);
-        if (acc) { atomicMax(&last_pos[c], pos); atomicMax(&max_span[c], rspan); atomicAdd(&n_cols[c], (unsigned long long)ncol); }
+        if (acc) { atomicAdd(&n_aligned[n_ctg + c], 1u); atomicMax(&last_pos[c], pos); atomicMax(&max_span[c], rspan); atomicAdd(&n_cols[c], (unsigned long long)ncol); }
     }
 }
 __global__ void __launch_bounds__(256) k_plan_emit(int64_t n, int n_ctg, const int32_t *__restrict__ slot_ctg_of_g, const int64_t *__restrict__ slot_off,
@@ -2439,8 +2445,7 @@ static int build_index(fzp_ctx *ctx, fzp_alnjob *j) {
         int64_t lc_max = 0;
         for (auto v : j->h_ctg_len) lc_max = std::max(lc_max, v);
         const unsigned gx = (unsigned)std::max<int64_t>(1, ((lc_max + CTG_STRIDE - 1) / CTG_STRIDE + STAGE_KMERS - 1) / STAGE_KMERS);
-        FZP_HIP(hipMemsetAsync(j->part_cursor.p, 0, (size_t)j->n_parts * 4, st));
-        FZP_HIP(hipMemsetAsync(j->idx_overflow.p, 0, 4, st));
+        { const fzp_fill_piece fl[2] = {fzp_zeroes(j->part_cursor, (size_t)j->n_parts), fzp_zeroes(j->idx_overflow, 1)}; FZP_TRY(fzp_fill(ctx, st, fl, 2)); }
         if (P.seed_anchored)
             hipLaunchKernelGGL(k_index_stage_anch, dim3((unsigned)std::max<int64_t>(1, ((lc_max + 15) / 16 + ANCH_WORDS - 1) / ANCH_WORDS), j->n_ctg), dim3(256), 0, st, j->ctg_pk.p, j->ctg_woff.p,
                                j->ctg_len.p, j->idx_off.p, j->idx_bits.p, j->part_off.p, P.kmer, j->table.p, j->part_cursor.p, j->idx_overflow.p);
@@ -2616,7 +2621,7 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
             const size_t lds = ((size_t)nb_max + (size_t)(n_max / 16 + 4)) * sizeof(uint32_t);      // vote bins (two strands x nb_max, 16 bits each) + (v1.7) one count per packed word of the longest read
             if (lds > 150 * 1024) { fzp_set_error("fzp_align_run: a read of %lld bases against a contig of %lld: the seeding kernel's tables (%zu KB) do not fit a CU's LDS", (long long)n_max, (long long)lc_max, lds >> 10); return FZP_EINVAL; }
             FZP_HIP(hipFuncSetAttribute((const void *)k_seed, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            FZP_HIP(hipMemsetAsync(j->n_sec.p, 0, 4, st));
+            { const fzp_fill_piece fl[3] = {fzp_zeroes(j->n_sec, 1), {j->rtot.p, 32, 0u}, fzp_zeroes(j->fb_overflow, 1)}; FZP_TRY(fzp_fill(ctx, st, fl, 3)); }      // (the plan's counters too: one launch)
             const int64_t seed_chunk = 65536;            // reads per seeding launch: HIT_CAP x 12 B of hit list and waypoint links each (3 GiB)
             FZP_TRY(j->hits.alloc((size_t)std::min<int64_t>(nr, seed_chunk) * HIT_CAP));
             FZP_TRY(j->wpp.alloc((size_t)std::min<int64_t>(nr, seed_chunk) * 2 * HIT_CAP));
@@ -2641,8 +2646,6 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
         // mask capacity; the scans come to the host (8 bytes per read), which only cuts the reads into chunks that fit the mask budget -- everything else is planned on the device
         {
             ProfScope ps(ctx, "k1_plan_dp");
-            FZP_HIP(hipMemsetAsync(j->rtot.p, 0, 32, st));
-            FZP_HIP(hipMemsetAsync(j->fb_overflow.p, 0, 4, st));
             hipLaunchKernelGGL(k_slot_count, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, st, nr, j->anc.p, j->ancB.p, j->n_wp.p, j->wps.p, j->read_len.p, j->read_ctg.p, j->ctg_len.p,
                                j->r_cnt.p, j->r_capq.p, j->n_sec.p, (int32_t)swb_max_steps, use_bits ? 1 : 0, (unsigned long long *)(j->rtot.p + 2));
         }
@@ -3131,11 +3134,15 @@ extern "C" int fzp_align_to_batch(fzp_ctx *ctx, fzp_alnjob *j, fzp_batch **out) 
     DevBuf<int64_t> &rec_read = b->rec_read;      // stays with the batch: K2 reads every record through its read
     const size_t ns = (size_t)std::max<int64_t>(nr, 1);
     FZP_TRY(key.alloc(ns)); FZP_TRY(v_rec.alloc(ns)); FZP_TRY(v_cig.alloc(ns)); FZP_TRY(v_seq.alloc(ns)); FZP_TRY(v_ck.alloc(ns)); FZP_TRY(totals.alloc(4));
-    FZP_TRY(g_read.alloc(ns)); FZP_TRY(g_qid.alloc(ns)); FZP_TRY(g_acc.alloc(ns)); FZP_TRY(last_pos.alloc((size_t)nc)); FZP_TRY(n_aligned.alloc((size_t)nc)); FZP_TRY(n_cols.alloc((size_t)nc));
-    FZP_TRY(v_rec.zero(ns, st)); FZP_TRY(v_cig.zero(ns, st)); FZP_TRY(v_seq.zero(ns, st)); FZP_TRY(v_ck.zero(ns, st)); FZP_TRY(g_acc.zero(ns, st));
-    FZP_TRY(n_aligned.zero((size_t)nc, st)); FZP_TRY(n_cols.zero((size_t)nc, st));
-    FZP_TRY(b->ctg_maxspan.alloc((size_t)nc)); FZP_TRY(b->ctg_maxspan.zero((size_t)nc, st));      // the contigs' longest reference span: from the summaries, no CIGAR pass
-    FZP_HIP(hipMemsetAsync(last_pos.p, 0xff, (size_t)nc * 4, st));       // -1
+    FZP_TRY(g_read.alloc(ns)); FZP_TRY(g_qid.alloc(ns)); FZP_TRY(last_pos.alloc((size_t)nc)); FZP_TRY(n_aligned.alloc((size_t)nc * 2)); FZP_TRY(n_cols.alloc((size_t)nc));
+    FZP_TRY(b->ctg_maxspan.alloc((size_t)nc));      // the contigs' longest reference span: from the summaries, no CIGAR pass
+    {
+        const size_t ns4 = (ns + 3) & ~(size_t)3;
+        FZP_TRY(g_acc.alloc(ns4));
+        const fzp_fill_piece fl[9] = {fzp_zeroes(v_rec, ns), fzp_zeroes(v_cig, ns), fzp_zeroes(v_seq, ns), fzp_zeroes(v_ck, ns), fzp_zeroes(g_acc, ns4), fzp_zeroes(n_aligned, (size_t)nc * 2),
+                                      fzp_zeroes(n_cols, (size_t)nc), fzp_zeroes(b->ctg_maxspan, (size_t)nc), fzp_ones(last_pos, (size_t)nc) /* -1 */};
+        FZP_TRY(fzp_fill(ctx, st, fl, 9));      // one launch (nine runtime fills before)
+    }
     const unsigned gb = (unsigned)std::max<int64_t>(1, (nr + 255) / 256);
     if (nr > 0) {
         ProfScope ps(ctx, "k1_plan");
@@ -3153,7 +3160,7 @@ extern "C" int fzp_align_to_batch(fzp_ctx *ctx, fzp_alnjob *j, fzp_batch **out) 
             hipLaunchKernelGGL(k_rank_binned, dim3(gb), dim3(256), 0, st, nr, j->slot_ctg.p, key.p, j->rank_bk_off.p, rk_start.p, rk_hist.p, rk_members.p, rk_rank.p);
         }
         hipLaunchKernelGGL(k_plan_rank, dim3(gb), dim3(256), 0, st, nr, j->slot_read.p, j->slot_ctg.p, j->slot_off.p, key.p, rk_rank.p, j->summ.p, j->read_len.p,
-                           v_rec.p, v_cig.p, v_seq.p, v_ck.p, g_read.p, g_qid.p, g_acc.p, last_pos.p, n_aligned.p, n_cols.p, b->ctg_maxspan.p);
+                           v_rec.p, v_cig.p, v_seq.p, v_ck.p, g_read.p, g_qid.p, g_acc.p, last_pos.p, n_aligned.p, n_cols.p, b->ctg_maxspan.p, nc);
     }
     FZP_TRY(fzp_exclusive_scan_u64_inplace(ctx, v_rec.p, (size_t)nr, totals.p + 0));
     FZP_TRY(fzp_exclusive_scan_u64_inplace(ctx, v_cig.p, (size_t)nr, totals.p + 1));
@@ -3161,14 +3168,14 @@ extern "C" int fzp_align_to_batch(fzp_ctx *ctx, fzp_alnjob *j, fzp_batch **out) 
     FZP_TRY(fzp_exclusive_scan_u64_inplace(ctx, v_ck.p, (size_t)nr, totals.p + 3));
     uint64_t tot[4] = {0, 0, 0, 0};
     std::vector<int32_t> h_last((size_t)nc);
-    std::vector<uint32_t> h_nal((size_t)nc);
+    std::vector<uint32_t> h_nal((size_t)nc * 2);      // aligned reads per contig, then accepted ones (records) per contig
     std::vector<unsigned long long> h_cols((size_t)nc);
     if (nc <= 32) {      // (a few contigs: everything the host needs here fits one fetch)
-        const fzp_fetch_piece fp[4] = {{tot, totals.p, 32}, {h_last.data(), last_pos.p, (size_t)nc * 4}, {h_nal.data(), n_aligned.p, (size_t)nc * 4}, {h_cols.data(), n_cols.p, (size_t)nc * 8}};
+        const fzp_fetch_piece fp[4] = {{tot, totals.p, 32}, {h_last.data(), last_pos.p, (size_t)nc * 4}, {h_nal.data(), n_aligned.p, (size_t)nc * 8}, {h_cols.data(), n_cols.p, (size_t)nc * 8}};
         FZP_TRY(fzp_fetch(ctx, st, fp, 4));
     } else {
         FZP_HIP(hipMemcpyAsync(tot, totals.p, 32, hipMemcpyDeviceToHost, st));
-        FZP_TRY(last_pos.download(h_last.data(), (size_t)nc, st)); FZP_TRY(n_aligned.download(h_nal.data(), (size_t)nc, st)); FZP_TRY(n_cols.download(h_cols.data(), (size_t)nc, st));
+        FZP_TRY(last_pos.download(h_last.data(), (size_t)nc, st)); FZP_TRY(n_aligned.download(h_nal.data(), (size_t)nc * 2, st)); FZP_TRY(n_cols.download(h_cols.data(), (size_t)nc, st));
         FZP_HIP(hipStreamSynchronize(st));
     }
     b->n_rec = (int64_t)tot[0]; b->n_cig = (int64_t)tot[1]; b->n_seq = (int64_t)tot[2]; b->n_ck = (int64_t)tot[3];
@@ -3192,8 +3199,9 @@ extern "C" int fzp_align_to_batch(fzp_ctx *ctx, fzp_alnjob *j, fzp_batch **out) 
     FZP_TRY(b->rec_span.alloc(nrec1));
     hipLaunchKernelGGL(k_plan_emit, dim3((unsigned)((std::max<int64_t>(nr, nc + 1) + 255) / 256)), dim3(256), 0, st, nr, nc, j->slot_ctg.p, j->slot_off.p, v_rec.p, v_cig.p, v_seq.p, v_ck.p, g_read.p, g_qid.p, g_acc.p, j->summ.p, totals.p,
                        rec_read.p, b->rec_qid.p, b->rec_pos.p, b->rec_ctg.p, b->cig_off.p, b->seq_off.p, b->ck_off.p, b->ctg_rec_begin.p, b->rec_span.p);
-    b->h_rec_begin.resize((size_t)nc + 1);
-    FZP_TRY(b->ctg_rec_begin.download(b->h_rec_begin.data(), (size_t)nc + 1, st));
+    b->h_rec_begin.assign((size_t)nc + 1, 0);      // (what k_plan_emit writes to ctg_rec_begin, from the per-contig record counts: no download, no wait)
+    for (int c = 0; c < nc; c++) b->h_rec_begin[(size_t)c + 1] = b->h_rec_begin[(size_t)c] + (int64_t)h_nal[(size_t)nc + c];
+    if (b->h_rec_begin[(size_t)nc] != b->n_rec) { fzp_set_error("fzp_align_to_batch: the contigs' records (%lld) do not add up to the batch's (%lld)", (long long)b->h_rec_begin[(size_t)nc], (long long)b->n_rec); return FZP_EDEVICE; }
     // ---- the records stay in K1's own form (r5: the packed hand-off, fzp_batch.h): K2 reads the alignments' 2-bit op streams and the 2-bit reads where K1 left them.  The
     // accepted records' run-length CIGAR words and byte SEQ (k_gather16: 1.1 GB written per bench step, and 0.44 ms of checkpoint pass behind it) are made only when
     // somebody asks (fzp_batch_need_bytes: K6); the job must outlive the batch.
@@ -3216,8 +3224,7 @@ extern "C" int fzp_align_to_batch(fzp_ctx *ctx, fzp_alnjob *j, fzp_batch **out) 
     FZP_TRY(b->ctg_limit.upload(b->h_limit.data(), b->h_limit.size(), st));
     if (b->n_pos > 0) hipLaunchKernelGGL(k_copy_ref, dim3(64, (unsigned)nc), dim3(256), 0, st, (const uint8_t *)j->ctg_ascii.p, (const int64_t *)j->ctg_aoff.p, (const int64_t *)b->ctg_goff.p,
                                          (const int32_t *)b->ctg_limit.p, b->ref.p);      // evaluated prefix of every contig, device to device
-    FZP_HIP(hipStreamSynchronize(st));
-    FZP_HIP(hipGetLastError());
+    FZP_HIP(hipGetLastError());      // (no wait here: what was uploaded lives in the batch, and whoever runs the batch next is on the same stream)
     b->have_aln = true;
     guard.p = nullptr;
     *out = b;

@@ -49,8 +49,8 @@ void prefetch_early_records(fzp_ctx *ctx, fzp_batch *b) {
     b->pf_sites = 0; b->pf_vmap = al64(s_sites); b->pf_arows = b->pf_vmap + al64(s_vmap); b->pf_end = b->pf_arows + al64(s_arows);
     bool ok = true;
     if (s_sites) ok = ok && hipMemcpyAsync(base + b->pf_sites, b->sites.p, s_sites, hipMemcpyDeviceToHost, ctx->stream2) == hipSuccess;
-    if (s_vmap) ok = ok && hipMemcpyAsync(base + b->pf_vmap, b->vmap_qid.p, s_vmap, hipMemcpyDeviceToHost, ctx->stream2) == hipSuccess;
-    if (s_arows) ok = ok && hipMemcpyAsync(base + b->pf_arows, b->arows.p, s_arows, hipMemcpyDeviceToHost, ctx->stream2) == hipSuccess;
+    if (s_vmap && !b->host_skip_rows) ok = ok && hipMemcpyAsync(base + b->pf_vmap, b->vmap_qid.p, s_vmap, hipMemcpyDeviceToHost, ctx->stream2) == hipSuccess;
+    if (s_arows && !b->host_skip_rows) ok = ok && hipMemcpyAsync(base + b->pf_arows, b->arows.p, s_arows, hipMemcpyDeviceToHost, ctx->stream2) == hipSuccess;
     if (!ok) { (void)hipGetLastError(); return; }
     if (!ctx->ev_pf_done && hipEventCreateWithFlags(&ctx->ev_pf_done, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ctx->ev_pf_done = nullptr; }
     if (ctx->ev_pf_done && hipEventRecord(ctx->ev_pf_done, ctx->stream2) != hipSuccess) { (void)hipGetLastError(); }
@@ -223,6 +223,48 @@ extern "C" void fzp_result_all_free(fzp_result_all *r) {
     memset(r, 0, sizeof *r);
 }
 
+namespace {
+struct ResPart { const void *src; size_t bytes; };
+// the record arrays a batch can hand to the host, in their fixed order: sites, variant_map q_ids, atable rows, block records, read records (bytes 0 = not there / not wanted)
+void result_parts(const fzp_batch *b, ResPart parts[5]) {
+    const bool rows = !b->host_skip_rows;
+    parts[0] = {b->sites.p, b->have_sites ? (size_t)b->n_sites * sizeof(fzp_site) : 0};
+    parts[1] = {b->vmap_qid.p, b->have_sites && rows ? (size_t)b->n_rows * sizeof(int32_t) : 0};
+    parts[2] = {b->arows.p, b->have_arows && rows ? (size_t)b->n_arows * sizeof(fzp_arow) : 0};
+    parts[3] = {b->pvars.p, b->have_blocks ? (size_t)b->n_pvars * sizeof(fzp_pvar) : 0};
+    parts[4] = {b->preads.p, b->have_preads ? (size_t)b->n_preads * sizeof(fzp_pread) : 0};
+}
+}  // namespace
+
+// The copies of whatever is not on its way yet, on the main stream, without waiting: a caller with device work still to launch (fzp_pipe.hip: the two texts) puts it behind them.
+int fzp_batch_result_begin(fzp_ctx *ctx, fzp_batch *b) {
+    if (!ctx || !b) return FZP_EINVAL;
+    FZP_TRY(fzp_bind(ctx));
+    hipStream_t st = ctx->stream;
+    ResPart parts[5];
+    result_parts(b, parts);
+    // parts 0..2 (sites, variant_map, atable) may already be on their way (prefetch_early_records)
+    const bool early = b->pf_early && b->pin && b->have_sites && b->have_arows;
+    size_t total = early ? b->pf_end : 0;
+    for (int k = early ? 3 : 0; k < 5; k++) total += al64(parts[k].bytes);
+    const bool use_early = early && total <= b->pin_cap;
+    if (!use_early) {
+        (void)hipStreamSynchronize(ctx->stream2);                     // nothing may still be writing into a block we are about to give back
+        total = 0;
+        for (int k = 0; k < 5; k++) total += al64(parts[k].bytes);
+        if (!batch_pinned(ctx, b, total + 64)) { fzp_set_error("pinned host allocation of %zu bytes failed", total); return FZP_ENOMEM; }
+    }
+    size_t off = use_early ? b->pf_end : 0;
+    for (int k = 0; k < 5; k++) {
+        if (use_early && k < 3) { b->late_off[k] = k == 0 ? b->pf_sites : (k == 1 ? b->pf_vmap : b->pf_arows); continue; }
+        b->late_off[k] = off;
+        if (parts[k].bytes && hipMemcpyAsync((char *)b->pin + off, parts[k].src, parts[k].bytes, hipMemcpyDeviceToHost, st) != hipSuccess) { (void)hipGetLastError(); fzp_set_error("D2H copy failed"); return FZP_EDEVICE; }
+        off += al64(parts[k].bytes);
+    }
+    b->late_begun = true; b->late_early = use_early;
+    return FZP_OK;
+}
+
 extern "C" int fzp_batch_result_all(fzp_ctx *ctx, fzp_batch *b, fzp_result_all *out) {
     if (!ctx || !b || !out) return FZP_EINVAL;
     FZP_TRY(fzp_bind(ctx));
@@ -235,44 +277,23 @@ extern "C" int fzp_batch_result_all(fzp_ctx *ctx, fzp_batch *b, fzp_result_all *
         return p;
     };
     fzp_result &r = out->all;
-    // one pinned staging area, five async copies, one sync, then plain memcpy into the caller's arrays
-    struct Part { const void *src; size_t bytes; void **dst; };
-    std::vector<Part> parts;
-    if (b->have_sites) {
-        r.n_sites = b->n_sites; r.n_rows = b->n_rows;
-        parts.push_back({b->sites.p, (size_t)b->n_sites * sizeof(fzp_site), (void **)&r.sites});
-        parts.push_back({b->vmap_qid.p, (size_t)b->n_rows * sizeof(int32_t), (void **)&r.vmap_qid});
-        out->site_begin = dup(b->h_site_begin);
-    }
-    if (b->have_arows) { r.n_arows = b->n_arows; parts.push_back({b->arows.p, (size_t)b->n_arows * sizeof(fzp_arow), (void **)&r.arows}); out->arow_begin = dup(b->h_arow_begin); }
-    if (b->have_blocks) { r.n_pvars = b->n_pvars; parts.push_back({b->pvars.p, (size_t)b->n_pvars * sizeof(fzp_pvar), (void **)&r.pvars}); out->pvar_begin = dup(b->h_pvar_begin); }
-    if (b->have_preads) { r.n_preads = b->n_preads; parts.push_back({b->preads.p, (size_t)b->n_preads * sizeof(fzp_pread), (void **)&r.preads}); out->pread_begin = dup(b->h_pread_begin); }
-    // parts 0..2 (sites, variant_map, atable) may already be on their way (prefetch_early_records)
-    const bool early = b->pf_early && b->pin && b->have_sites && b->have_arows && parts.size() >= 3;
-    size_t total = early ? b->pf_end : 0;
-    for (size_t k = early ? 3 : 0; k < parts.size(); k++) total += (parts[k].bytes + 63) & ~(size_t)63;
-    const bool use_early = early && total <= b->pin_cap;
-    if (!use_early) {
-        (void)hipStreamSynchronize(ctx->stream2);                     // nothing may still be writing into a block we are about to give back
-        total = 0;
-        for (auto &p : parts) total += (p.bytes + 63) & ~(size_t)63;
-        if (!batch_pinned(ctx, b, total)) { fzp_result_all_free(out); fzp_set_error("pinned host allocation of %zu bytes failed", total); return FZP_ENOMEM; }
-    }
-    std::vector<size_t> offs(parts.size());
-    {
-        size_t off = use_early ? b->pf_end : 0;
-        for (size_t k = 0; k < parts.size(); k++) {
-            if (use_early && k < 3) { offs[k] = k == 0 ? b->pf_sites : (k == 1 ? b->pf_vmap : b->pf_arows); continue; }
-            offs[k] = off;
-            if (parts[k].bytes && hipMemcpyAsync((char *)b->pin + off, parts[k].src, parts[k].bytes, hipMemcpyDeviceToHost, st) != hipSuccess) { fzp_result_all_free(out); fzp_set_error("D2H copy failed"); return FZP_EDEVICE; }
-            off += (parts[k].bytes + 63) & ~(size_t)63;
-        }
-    }
+    if (!b->late_begun) FZP_TRY(fzp_batch_result_begin(ctx, b));
     // the early records: wait for THEIR copies (the event recorded behind them), not for whatever else the caller has put on stream2 since
     if (hipStreamSynchronize(st) != hipSuccess ||
-        (use_early && (ctx->ev_pf_done ? hipEventSynchronize(ctx->ev_pf_done) : hipStreamSynchronize(ctx->stream2)) != hipSuccess)) { fzp_result_all_free(out); fzp_set_error("D2H sync failed"); return FZP_EDEVICE; }
+        (b->late_early && (ctx->ev_pf_done ? hipEventSynchronize(ctx->ev_pf_done) : hipStreamSynchronize(ctx->stream2)) != hipSuccess)) { (void)hipGetLastError(); fzp_set_error("D2H sync failed"); return FZP_EDEVICE; }
     b->pf_early = false;                                               // a later run of the batch refills the block
-    for (size_t k = 0; k < parts.size(); k++) *parts[k].dst = (char *)b->pin + offs[k];   // borrowed views into the batch's pinned block
+    b->late_begun = false;
+    ResPart parts[5];
+    result_parts(b, parts);
+    auto view = [&](int k) -> void * { return parts[k].bytes ? (char *)b->pin + b->late_off[k] : nullptr; };   // borrowed views into the batch's pinned block
+    if (b->have_sites) {
+        r.n_sites = b->n_sites; r.n_rows = b->n_rows;
+        r.sites = (fzp_site *)view(0); r.vmap_qid = (int32_t *)view(1);
+        out->site_begin = dup(b->h_site_begin);
+    }
+    if (b->have_arows) { r.n_arows = b->n_arows; r.arows = (fzp_arow *)view(2); out->arow_begin = dup(b->h_arow_begin); }
+    if (b->have_blocks) { r.n_pvars = b->n_pvars; r.pvars = (fzp_pvar *)view(3); out->pvar_begin = dup(b->h_pvar_begin); }
+    if (b->have_preads) { r.n_preads = b->n_preads; r.preads = (fzp_pread *)view(4); out->pread_begin = dup(b->h_pread_begin); }
     if (b->have_sites) {
         out->row_begin = (int64_t *)calloc(nb, sizeof(int64_t));
         for (int c = 0; c <= b->n_ctg; c++) {

@@ -389,10 +389,6 @@ __global__ void k_pread_begin(const int64_t *__restrict__ ctg_qoff, int n_ctg, i
     begin[c] = v;
 }
 
-__global__ void __launch_bounds__(256) k_fill_i32(int32_t *p, int64_t n, int32_t v) {
-    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) p[i] = v;
-}
 }  // namespace
 
 // ================================================================================ K4 driver
@@ -409,9 +405,11 @@ int fzp_k4_blocks(fzp_ctx *ctx, fzp_batch *b) {
     FZP_TRY(b->rawblk.alloc((size_t)ns)); FZP_TRY(b->blkcnt.alloc((size_t)ns)); FZP_TRY(b->blknew.alloc((size_t)ns));
     FZP_TRY(b->pvars_tmp.alloc((size_t)ns)); FZP_TRY(b->site_blk.alloc((size_t)ns)); FZP_TRY(b->site_b1.alloc((size_t)ns));
     FZP_TRY(b->pv_n.alloc((size_t)b->n_ctg + 1)); FZP_TRY(b->pv_off.alloc((size_t)b->n_ctg + 1)); FZP_TRY(b->pvar_begin.alloc((size_t)b->n_ctg + 1));
-    FZP_TRY(b->left_n.zero((size_t)ns, st)); FZP_TRY(b->left_fill.zero((size_t)ns, st)); FZP_TRY(b->right_n.zero((size_t)ns, st));
-    FZP_TRY(b->blkcnt.zero((size_t)ns, st));
-    if (ns > 0) FZP_HIP(hipMemsetAsync(b->fr2.p, 0xff, (size_t)ns * sizeof(uint32_t), st));
+    {
+        const fzp_fill_piece fl[5] = {fzp_zeroes(b->left_n, (size_t)ns), fzp_zeroes(b->left_fill, (size_t)ns), fzp_zeroes(b->right_n, (size_t)ns), fzp_zeroes(b->blkcnt, (size_t)ns),
+                                      fzp_ones(b->fr2, (size_t)ns)};
+        FZP_TRY(fzp_fill(ctx, st, fl, 5));      // one launch (the runtime made twelve fills of these five)
+    }
     int64_t n_links = 0;
     if (na > 0) {
         hipLaunchKernelGGL(k_link_flag, dim3(grid_for(na, 256, 1 << 30)), dim3(256), 0, st, b->arows.p, na, b->lk_flag.p);
@@ -488,8 +486,7 @@ int fzp_k5_reads(fzp_ctx *ctx, fzp_batch *b) {
     int64_t n_slots = 0;
     b->n_preads = 0;
     if (nq > 0) {
-        hipLaunchKernelGGL(k_fill_i32, dim3(grid_for(nq, 256, 1 << 30)), dim3(256), 0, st, b->bmin.p, nq, 0x7fffffff);
-        FZP_TRY(b->bmax.zero((size_t)nq, st));
+        { const fzp_fill_piece fl[2] = {{b->bmin.p, (size_t)nq * 4, 0x7fffffffu}, fzp_zeroes(b->bmax, (size_t)nq)}; FZP_TRY(fzp_fill(ctx, st, fl, 2)); }
         const uint32_t *set_n = b->set_n.p, *set_off = b->set_n.p + 2 * ns;
         if (ns > 0) {
             ProfScope ps(ctx, "k5_read_range");
@@ -502,7 +499,7 @@ int fzp_k5_reads(fzp_ctx *ctx, fzp_batch *b) {
         FZP_TRY(fzp_fetch(ctx, st, &t, b->totals.p + 6, sizeof t));
         n_slots = (int64_t)t;
         FZP_TRY(b->c0.alloc((size_t)n_slots)); FZP_TRY(b->c1.alloc((size_t)n_slots)); FZP_TRY(b->pr_flag.alloc((size_t)n_slots));
-        FZP_TRY(b->c0.zero((size_t)n_slots, st)); FZP_TRY(b->c1.zero((size_t)n_slots, st));
+        { const fzp_fill_piece fl[2] = {fzp_zeroes(b->c0, (size_t)n_slots), fzp_zeroes(b->c1, (size_t)n_slots)}; FZP_TRY(fzp_fill(ctx, st, fl, 2)); }
         if (n_slots > 0) {
             {
                 ProfScope ps(ctx, "k5_read_count");

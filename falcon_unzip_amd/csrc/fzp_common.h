@@ -51,6 +51,8 @@ int cores_per_rank();                // ... divided by the ranks of the node (LO
 struct fzp_fetch_piece { void *host; const void *dev; size_t bytes; };
 int fzp_fetch(fzp_ctx *ctx, hipStream_t st, const fzp_fetch_piece *pieces, int n_pieces);
 inline int fzp_fetch(fzp_ctx *ctx, hipStream_t st, void *host, const void *dev, size_t bytes) { const fzp_fetch_piece p{host, dev, bytes}; return fzp_fetch(ctx, st, &p, 1); }
+struct fzp_fill_piece { void *dev; size_t bytes; uint32_t word; };
+int fzp_fill(fzp_ctx *ctx, hipStream_t st, const fzp_fill_piece *pieces, int n_pieces);      // every region set to its 32-bit word, one launch per twelve regions (fzp_host.hip)
 int fzp_read_back(fzp_ctx *ctx, hipStream_t st, void *host, const void *dev, size_t bytes);      // fzp_fetch where it fits (<= 256 bytes), copy + stream wait otherwise
 void *fzp_dev_alloc(size_t bytes);   // from the calling thread's current pool; nullptr on failure
 void fzp_dev_free(void *p);
@@ -101,6 +103,9 @@ struct DevBuf {
         return FZP_OK;
     }
 };
+
+template <typename T> inline fzp_fill_piece fzp_zeroes(DevBuf<T> &b, size_t count) { return fzp_fill_piece{b.p, count * sizeof(T), 0u}; }
+template <typename T> inline fzp_fill_piece fzp_ones(DevBuf<T> &b, size_t count) { return fzp_fill_piece{b.p, count * sizeof(T), 0xffffffffu}; }
 
 // ---------------------------------------------------------------- context
 struct ProfEntry {

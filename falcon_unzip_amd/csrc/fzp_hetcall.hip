@@ -684,6 +684,18 @@ int fzp_batch_need_bytes(fzp_ctx *ctx, fzp_batch *b) {
     return FZP_OK;
 }
 
+namespace {
+__global__ void __launch_bounds__(256) k_tile_tables(const int64_t *__restrict__ ctg_goff, int n_ctg, int64_t n_tiles, int32_t *__restrict__ tile_ctg, int32_t *__restrict__ tile_start) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_tiles) return;
+    const int64_t g = t * PILE_TILE;
+    int lo = 0, hi = n_ctg;                       // the last contig whose first padded position is <= g (empty contigs in front of it share that position and lose)
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (ctg_goff[mid] <= g) lo = mid; else hi = mid; }
+    tile_ctg[t] = lo;
+    tile_start[t] = (int32_t)(g - ctg_goff[lo]);
+}
+}  // namespace
+
 // ================================================================================ K2 driver
 int fzp_k2_het_call(fzp_ctx *ctx, fzp_batch *b) {
     hipStream_t st = ctx->stream;
@@ -702,19 +714,18 @@ int fzp_k2_het_call(fzp_ctx *ctx, fzp_batch *b) {
     RecView v = rec_view(b);
     if (b->n_rec > 0 && np > 0) {
         if (!b->packed) FZP_TRY(k2_checkpoints(ctx, b));        // (packed batches: spans from K1's summaries, checkpoints made by fzp_batch_need_bytes when the bytes are)
-        // tiles never span contigs
-        b->h_tile_ctg.clear(); b->h_tile_start.clear();
-        for (int c = 0; c < b->n_ctg; c++)
-            for (int32_t t0 = 0; t0 < b->h_limit[c]; t0 += PILE_TILE) { b->h_tile_ctg.push_back(c); b->h_tile_start.push_back(t0); }
-        FZP_TRY(b->tile_ctg.upload(b->h_tile_ctg.data(), b->h_tile_ctg.size(), st));
-        FZP_TRY(b->tile_start.upload(b->h_tile_start.data(), b->h_tile_start.size(), st));
+        // tiles never span contigs: a contig's padded length is whole tiles, so tile T is padded position T * PILE_TILE, and its contig the one whose range holds it.  Made on
+        // the device (r5: the host loop over 49 000 tiles and the two uploads from pageable memory were 0.15 ms in which the GPU had nothing to do)
+        const int64_t n_tiles = np / PILE_TILE;
+        FZP_TRY(b->tile_ctg.alloc((size_t)n_tiles)); FZP_TRY(b->tile_start.alloc((size_t)n_tiles));
+        hipLaunchKernelGGL(k_tile_tables, dim3(grid_for(n_tiles, 256, 1 << 30)), dim3(256), 0, st, b->ctg_goff.p, b->n_ctg, n_tiles, b->tile_ctg.p, b->tile_start.p);
         {
             ProfScope ps(ctx, "k2_pileup_count");
             if (packed)
-                hipLaunchKernelGGL(k_pileup_pk, dim3((unsigned)b->h_tile_ctg.size()), dim3(PILE_THREADS), 0, st, pk_view(b), b->tile_ctg.p, b->tile_start.p, b->ctg_rec_begin.p, b->ctg_maxspan.p,
+                hipLaunchKernelGGL(k_pileup_pk, dim3((unsigned)n_tiles), dim3(PILE_THREADS), 0, st, pk_view(b), b->tile_ctg.p, b->tile_start.p, b->ctg_rec_begin.p, b->ctg_maxspan.p,
                                    b->rec_span.p, b->cnt.p, b->oth.p, (unsigned long long *)b->blk_live.p);
             else
-                hipLaunchKernelGGL(k_pileup_tiles, dim3((unsigned)b->h_tile_ctg.size()), dim3(PILE_THREADS), 0, st, v, b->tile_ctg.p, b->tile_start.p, b->ctg_rec_begin.p, b->ctg_maxspan.p,
+                hipLaunchKernelGGL(k_pileup_tiles, dim3((unsigned)n_tiles), dim3(PILE_THREADS), 0, st, v, b->tile_ctg.p, b->tile_start.p, b->ctg_rec_begin.p, b->ctg_maxspan.p,
                                    b->rec_span.p, b->ck_off.p, b->ck_ref.p, b->ck_q.p, b->cnt.p, b->oth.p, (unsigned long long *)b->blk_live.p);
         }
     }                                                   // (no records: every block stays dead)

@@ -174,6 +174,51 @@ int fzp_fetch(fzp_ctx *ctx, hipStream_t st, const fzp_fetch_piece *pieces, int n
     return FZP_OK;
 }
 
+// ---------------------------------------------------------------- fzp_fill (fzp_common.h)
+// Several regions set to a 32-bit word each by ONE launch.  A stage that clears six counters arrays used to put twelve runtime fills on the stream (hipMemsetAsync splits an
+// odd-sized region in two), 4-5 us each and each a launch the host thread pays for; regions whose size or address is not a multiple of four bytes still go to the runtime.
+namespace {
+constexpr int FILL_MAX = 12, FILL_TILE = 2048;      // words per workgroup
+struct FillArgs { uint32_t *p[FILL_MAX]; uint32_t n[FILL_MAX]; uint32_t v[FILL_MAX]; uint32_t first[FILL_MAX + 1]; int k; };
+__global__ void __launch_bounds__(256) k_fill_regions(FillArgs a) {
+    int r = 0;
+    while (r + 1 < a.k && blockIdx.x >= a.first[r + 1]) r++;
+    uint32_t *p = a.p[r];
+    const uint32_t n = a.n[r], v = a.v[r];
+    uint32_t i = (blockIdx.x - a.first[r]) * FILL_TILE + threadIdx.x;
+#pragma unroll
+    for (int t = 0; t < FILL_TILE / 256; t++, i += 256) if (i < n) p[i] = v;
+}
+}  // namespace
+int fzp_fill(fzp_ctx *ctx, hipStream_t st, const fzp_fill_piece *pieces, int n_pieces) {
+    if (!ctx || !pieces || n_pieces < 0) { fzp_set_error("fzp_fill: bad arguments"); return FZP_EINVAL; }
+    FillArgs a;
+    memset(&a, 0, sizeof a);
+    auto flush = [&]() -> int {
+        if (a.k == 0) return FZP_OK;
+        hipLaunchKernelGGL(k_fill_regions, dim3(a.first[a.k]), dim3(256), 0, st, a);
+        if (hipGetLastError() != hipSuccess) { fzp_set_error("fzp_fill: launch failed"); return FZP_EDEVICE; }
+        memset(&a, 0, sizeof a);
+        return FZP_OK;
+    };
+    for (int k = 0; k < n_pieces; k++) {
+        const fzp_fill_piece &f = pieces[k];
+        if (f.bytes == 0) continue;
+        if (!f.dev) { fzp_set_error("fzp_fill: null region"); return FZP_EINVAL; }
+        const uint32_t b0 = f.word & 0xff;
+        if ((f.bytes & 3) || ((uintptr_t)f.dev & 3) || f.bytes / 4 > 0xffffffffull) {      // the runtime's fill: byte-valued words only
+            if (f.word != b0 * 0x01010101u) { fzp_set_error("fzp_fill: a region of odd size or address takes a byte value"); return FZP_EINVAL; }
+            FZP_HIP(hipMemsetAsync(f.dev, (int)b0, f.bytes, st));
+            continue;
+        }
+        const uint32_t words = (uint32_t)(f.bytes / 4), blocks = (words + FILL_TILE - 1) / FILL_TILE;
+        a.p[a.k] = (uint32_t *)f.dev; a.n[a.k] = words; a.v[a.k] = f.word;
+        a.first[a.k + 1] = a.first[a.k] + blocks;
+        if (++a.k == FILL_MAX) FZP_TRY(flush());
+    }
+    return flush();
+}
+
 int fzp_read_back(fzp_ctx *ctx, hipStream_t st, void *host, const void *dev, size_t bytes) {
     if (bytes == 0) return FZP_OK;
     if (bytes <= 256 && !(bytes & 3)) return fzp_fetch(ctx, st, host, dev, bytes);

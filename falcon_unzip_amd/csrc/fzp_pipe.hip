@@ -524,6 +524,7 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
         ctx->workers->run(nc, pre_work, std::min(want_threads, 6));      // (a few threads: there are milliseconds to do this in, and the thread that launches the kernels wants a core)
     });
     struct Join { std::thread &t; ~Join() { if (t.joinable()) t.join(); } } early_join{early};      // (declared after everything the thread touches)
+    b->host_skip_rows = true;      // variant_map and atable leave as device-made text: their rows stay on the device
     FZP_TRY(fzp_batch_run(ctx, b, FZP_STAGE_ALL));
     out->ms_phase += ms_since(t0);
     t0 = clk::now();
@@ -549,9 +550,38 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
     std::shared_ptr<Owned> owned = std::make_shared<Owned>();
     owned->c = ctx; owned->pin = nullptr; owned->device = ctx->device;
     FZP_HIP(hipEventCreateWithFlags(&owned->ev_text, hipEventDisableTiming));
+    // ---- what the caller waits for comes over FIRST: the block and read records go onto the main stream right behind K5; the kernels that serialise the two big texts run behind
+    // them, and the texts' own copies (which only the file writers wait for) start when the records are here.  (r5: with the texts' 30 MB copied first the 1.6 MB of records
+    // queued behind and beside them for 0.7 ms -- a device-to-host copy in flight holds up everything else that moves memory.)
+    FZP_TRY(fzp_batch_result_begin(ctx, b));
     size_t n_vmap = 0, n_atab = 0;
     std::vector<int64_t> vb, ab;
-    FZP_TRY(fzp_batch_text_dev(ctx, b, FZP_TEXT_VARIANT_MAP, owned->d_vmap, &n_vmap, vb));
+    FZP_TRY(fzp_batch_text_dev(ctx, b, FZP_TEXT_VARIANT_MAP, owned->d_vmap, &n_vmap, vb));      // (its size comes back through a fetch on the same stream: the records are on the host when it returns)
+    fzp_result_all ra;
+    FZP_TRY(fzp_batch_result_all(ctx, b, &ra));
+    struct RG { fzp_result_all *r; ~RG() { fzp_result_all_free(r); } } rg{&ra};
+    const ReadMaps *maps = mh.get();
+    early.join();                                                // (the early half: long done)
+    if (!early_err.empty()) { fzp_set_error("%s", early_err.c_str()); return FZP_EDEVICE; }
+    // the rid_to_phase RECORDS (an array pass per contig) on the pool's threads while this one launches the second text
+    std::vector<std::vector<fzp_r2p>> recs((size_t)nc);
+    {
+        owned->site_begin.assign(ra.site_begin, ra.site_begin + nc + 1); owned->pvar_begin.assign(ra.pvar_begin, ra.pvar_begin + nc + 1); owned->pread_begin.assign(ra.pread_begin, ra.pread_begin + nc + 1);
+        owned->sites = ra.all.sites; owned->pvars = ra.all.pvars; owned->preads = ra.all.preads;
+        owned->rec_pin = b->pin; b->pin = nullptr;                // (fzp_batch_result_all's views point into it; the batch no longer gives it back)
+    }
+    for (int c = 0; c < nc && maps; c++) if (pre[(size_t)c].rc != FZP_OK) { fzp_set_error("%s", pre[(size_t)c].err.c_str()); return pre[(size_t)c].rc; }
+    const std::function<void(int, int)> fill_work = [&](int, int c) {
+        PreCtg &P = pre[(size_t)c];
+        recs[(size_t)c].reserve(P.rows.pid.size());
+        readmap_fill(P.rows, nm->ctg_id[c], ctg_index ? ctg_index[c] : c, owned->preads + owned->pread_begin[(size_t)c], owned->pread_begin[(size_t)c + 1] - owned->pread_begin[(size_t)c], recs[(size_t)c], nullptr);
+    };
+    // (a rank with two cores keeps the pass on this thread, behind the second text's launch: its cores are busy with the previous call's write tasks, and a thread that has to
+    // be woken there waits for a time slice -- measured on two cores: 22.5 ms per step with the hand-off, 1.34 x the unconstrained step instead of 1.12 x)
+    const bool fill_beside = maps && cores_per_rank() > 2;
+    std::thread filler;
+    if (fill_beside) filler = std::thread([&]() { (void)pthread_setname_np(pthread_self(), "fzp-fill"); ctx->workers->run(nc, fill_work, std::min(want_threads, 4)); });
+    struct JoinF { std::thread &t; ~JoinF() { if (t.joinable()) t.join(); } } filler_join{filler};
     FZP_TRY(fzp_batch_text_dev(ctx, b, FZP_TEXT_ATABLE, owned->d_atab, &n_atab, ab));
     size_t pin_cap = 0;
     const size_t o_atab = (n_vmap + 63) & ~(size_t)63, o_end = o_atab + ((n_atab + 63) & ~(size_t)63);
@@ -562,15 +592,10 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
     const bool async = (o->flags & FZP_PIPE_ASYNC_WRITES) != 0 && o->out_dir;
     if (async && !ctx->writer) { ctx->writer = new FileWriter(); ctx->writer->start(writer_threads()); }
     if (async) { const std::string e = [&] { std::lock_guard<std::mutex> lk(ctx->writer->mu); std::string x; x.swap(ctx->writer->first_error); return x; }(); if (!e.empty()) { fzp_set_error("%s", e.c_str()); return FZP_EINVAL; } }
-    FZP_HIP(hipStreamSynchronize(ctx->stream));
-    // they only have to be there when a contig's write task is made: their copy runs under the formatting of the small files
+    // (both text kernels are done: the atable's size came back through a fetch behind them.)  The texts only have to be there when a contig's write task reaches them
     if (n_vmap) FZP_HIP(hipMemcpyAsync(pin, owned->d_vmap.p, n_vmap, hipMemcpyDeviceToHost, st2));
     if (n_atab) FZP_HIP(hipMemcpyAsync(pin + o_atab, owned->d_atab.p, n_atab, hipMemcpyDeviceToHost, st2));
     FZP_HIP(hipEventRecord(owned->ev_text, st2));
-    fzp_result_all ra;
-    FZP_TRY(fzp_batch_result_all(ctx, b, &ra));                  // sites / variant_map ids / atable rows are not needed on the host here, but the views are free
-    struct RG { fzp_result_all *r; ~RG() { fzp_result_all_free(r); } } rg{&ra};
-    const ReadMaps *maps = mh.get();
     // the blasr task's BAM from the same pass: records come down here (device part), are split into '=' / 'X' and compressed by the contig's write task
     struct BamJob {
         fzp_alnset *aln = nullptr; std::vector<int32_t> flags; std::shared_ptr<std::vector<uint8_t>> ref;
@@ -585,27 +610,14 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
     out->ms_results += ms_since(t0);
     t0 = clk::now();
     // ---- per contig: the small files on host threads, all files written
-    early.join();                                                // (the early half: long done)
-    if (!early_err.empty()) { fzp_set_error("%s", early_err.c_str()); return FZP_EDEVICE; }
     std::atomic<int64_t> bytes{0};
-    std::vector<std::vector<fzp_r2p>> recs((size_t)nc);
     const std::string out_dir = o->out_dir ? o->out_dir : "";
     if (o->out_dir && !mkdir_p(out_dir)) { fzp_set_error("cannot create %s: %s", out_dir.c_str(), strerror(errno)); return FZP_EIO; }      // once, here: the contigs' writers only make their own directories
-    // ---- what the caller waits for: the rid_to_phase RECORDS (an array pass per contig, on this thread).  The texts of the small files are made where the files are written:
-    // by the contig's write task -- on the background writers when FZP_PIPE_ASYNC_WRITES (under the next call's kernels: r5, the host section at the end of a step was 1.1 ms of
-    // idle GPU on sixteen cores and 3.5 ms on two), on the pool otherwise.  The records those texts are made from live in the batch's pinned result block, which the tasks take over.
-    {
-        owned->site_begin.assign(ra.site_begin, ra.site_begin + nc + 1); owned->pvar_begin.assign(ra.pvar_begin, ra.pvar_begin + nc + 1); owned->pread_begin.assign(ra.pread_begin, ra.pread_begin + nc + 1);
-        owned->sites = ra.all.sites; owned->pvars = ra.all.pvars; owned->preads = ra.all.preads;
-        owned->rec_pin = b->pin; b->pin = nullptr;                // (fzp_batch_result_all's views point into it; the batch no longer gives it back)
-    }
-    for (int c = 0; c < nc; c++) {
-        if (!maps) break;
-        PreCtg &P = pre[(size_t)c];
-        if (P.rc != FZP_OK) { fzp_set_error("%s", P.err.c_str()); return P.rc; }
-        recs[(size_t)c].reserve(P.rows.pid.size());
-        readmap_fill(P.rows, nm->ctg_id[c], ctg_index ? ctg_index[c] : c, owned->preads + owned->pread_begin[(size_t)c], owned->pread_begin[(size_t)c + 1] - owned->pread_begin[(size_t)c], recs[(size_t)c], nullptr);
-    }
+    // The texts of the small files are made where the files are written: by the contig's write task -- on the background writers when FZP_PIPE_ASYNC_WRITES (under the next
+    // call's kernels: r5, the host section at the end of a step was 1.1 ms of idle GPU on sixteen cores and 3.5 ms on two), on the pool otherwise.  The records those texts are
+    // made from live in the batch's pinned result block, which the tasks have taken over.
+    if (filler.joinable()) filler.join();
+    else if (maps) for (int c = 0; c < nc; c++) fill_work(0, c);
     std::vector<std::function<bool()>> tasks((size_t)nc);     // per contig: make the small texts, write all files
     std::vector<std::shared_ptr<std::string>> whys((size_t)nc);   // why a contig's write task failed, recorded by the thread it failed on
     for (auto &w : whys) w = std::make_shared<std::string>();
