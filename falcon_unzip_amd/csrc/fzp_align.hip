@@ -738,10 +738,16 @@ __global__ void __launch_bounds__(256) k_plan_final(uint32_t ns, const uint32_t 
     const uint32_t sl = list[y];
     mvo[sl] = (int64_t)lq_scan[y];
     // bit-sliced slots: 8-byte records in the chunk's mask buffer, interleaved by launch group; the others: 16-byte records, streams of their own, in the buffer of whole masks
-    if (y < n_b) { tbo[sl] = 4096ll * gq_scan[y >> 6] + 64ll * (y & 63u); tbs[sl] = 4096; }
+    if (y < n_b) { tbo[sl] = 4096ll * gq_scan[y >> 6] + 32ll * (y & 63u); tbs[sl] = 4096; }      // (swb_rec below: a group's 64-step block is two halves of 32 steps x 64 lanes)
     else { tbo[sl] = 64ll * ((int64_t)lq_scan[y] - (int64_t)lq_scan[n_b]); tbs[sl] = 64; }
     if (y == 0) { ptot[3] = 0; ptot[4] = 64ull * (ptot[2] - (n_b < ns ? (uint64_t)lq_scan[n_b] : ptot[2])); ptot[5] = 0; }      // the fail list is empty; whole masks of slots that land on it go behind the others'; [5]: k_swb's group counter
 }
+
+// Where step t of a bit-sliced slot's 8-byte mask records lies, in records from the slot's first (tbo): the 64 slots of a launch group share blocks of 4 096 records per 64
+// steps, and inside a block the FIRST 32 steps of all 64 slots come before the second 32 -- [64-step block][half][slot][32 steps].  So the 32 slots one wave of walkers owns
+// have the pieces they stage at the same time side by side: 8 KB in one run (r5; [block][slot][64 steps] before: 256-byte pieces 512 bytes apart, which HBM serves at 4.3 TB/s
+// where runs of 1 KB and more get 6.1 -- tools/ubench/rand_block_bw.hip).
+__device__ __forceinline__ int64_t swb_rec(int32_t t) { return (int64_t)(t >> 6) * 4096 + ((t >> 5) & 1) * 2048 + (t & 31); }
 
 struct DpInfo { int32_t steps, best_t, best_lane, best_score; };
 struct ReadPath { int32_t ok, strand, i_end, j_end, n_ops, pad_; int64_t steps; };      // a read's joined path (k_join -> k_tb_cigar): its end cell, its ops, the DP steps of all its slots
@@ -1306,7 +1312,6 @@ __global__ void SWB_OCC __launch_bounds__(256) k_swb(const uint64_t *__restrict_
     ulonglong2 *mvr = mvw + mvo[sl];
     const int32_t nq = S.nq, nt = S.nt;
     const bool inner = (S.flags & SLOT_INNER) != 0;
-    constexpr int32_t stride = 64 * 64;                  // records from one 64-step block of this stream to the next
     const uint32_t *qpk = ((S.flags & SLOT_QRC) ? read_rc : read_pk) + read_woff[S.read];
     const uint32_t *tpk = ((S.flags & SLOT_TRC) ? ctg_rc : ctg_pk) + ctg_woff[S.ctg];
     const int64_t qb = S.qb, tbase = S.tb;
@@ -1359,8 +1364,7 @@ __global__ void SWB_OCC __launch_bounds__(256) k_swb(const uint64_t *__restrict_
             if (grp_active && !(dbg & 1)) {      // what leaves is the middle of the band: lanes 16..47 of D and of G, 8 B per step (the walker says so if its path ever needs more)
 #pragma unroll
                 for (int s8 = 0; s8 < SWB_GROUP; s8 += 2)
-                    *(uint4 *)(tbr + (int64_t)((t - SWB_GROUP) >> 6) * stride + ((t - SWB_GROUP) & 63) + s8) =
-                        make_uint4(rec[s8].x, rec[s8].y, rec[s8 + 1].x, rec[s8 + 1].y);
+                    *(uint4 *)(tbr + swb_rec(t - SWB_GROUP) + s8) = make_uint4(rec[s8].x, rec[s8].y, rec[s8 + 1].x, rec[s8 + 1].y);
             }
         }
         if (blk_active) {
@@ -1461,7 +1465,6 @@ __global__ void __launch_bounds__(256) k_swb2(const uint64_t *__restrict__ n_b_d
     ulonglong2 *mvr = mvw + mvo[sl];
     const int32_t nq = S.nq, nt = S.nt;
     const bool inner = (S.flags & SLOT_INNER) != 0;
-    constexpr int32_t stride = 64 * 64;
     const uint32_t *qpk = ((S.flags & SLOT_QRC) ? read_rc : read_pk) + read_woff[S.read];
     const uint32_t *tpk = ((S.flags & SLOT_TRC) ? ctg_rc : ctg_pk) + ctg_woff[S.ctg];
     const int64_t qb = S.qb, tbase = S.tb;
@@ -1504,7 +1507,7 @@ __global__ void __launch_bounds__(256) k_swb2(const uint64_t *__restrict__ n_b_d
             if (g8 & 1) L.ss.refill();      // (ahead of the stores: see k_swb)
             if (grp_active) {
 #pragma unroll
-                for (int s8 = 0; s8 < 8; s8++) tbr[2 * ((int64_t)((t - 8) >> 6) * stride + ((t - 8) & 63) + s8)] = (rec[s8].x >> 16) | (rec[s8].y << 16);      // (the low lane holds D, the high lane G, each as {cells 0..31, cells 32..63})
+                for (int s8 = 0; s8 < 8; s8++) tbr[2 * (swb_rec(t - 8) + s8)] = (rec[s8].x >> 16) | (rec[s8].y << 16);      // (the low lane holds D, the high lane G, each as {cells 0..31, cells 32..63})
             }
         }
         if (blk_active && lo) {
@@ -1599,6 +1602,7 @@ __global__ void __launch_bounds__(64 * TBW_WPG) k_tb_walk(const uint32_t *__rest
     int32_t pref_chunk = active ? ts >> 6 : -1, pref_sh = FULL ? min(max(k - 16, 0), 32) : 16;
     typedef typename std::conditional<FULL, uint4, uint2>::type rec_t;
     rec_t pf[TBW_RPW];
+    const int32_t lane_rec = FULL ? lane : (lane & 31) + (lane >> 5) * 2048;      // step `lane` of a 64-step block: whole masks lie step by step, the bit-sliced kernel's in two halves (swb_rec)
 #pragma unroll
     for (int l = 0; l < TBW_RPW; l++) memset(&pf[l], 0, sizeof(rec_t));
     uint64_t rec_base[TBW_RPW];      // every slot's mask records: wave-uniform, fetched from the owning lanes once
@@ -1615,7 +1619,7 @@ __global__ void __launch_bounds__(64 * TBW_WPG) k_tb_walk(const uint32_t *__rest
     _Pragma("unroll") for (int l = 0; l < TBW_RPW; l++) {                                                                \
         const int32_t cl = __builtin_amdgcn_readlane(pref_chunk, l);                                                     \
         if (cl >= 0) {                                                                                                   \
-            const int64_t at_ = (int64_t)cl * __builtin_amdgcn_readlane(rstride, l) + lane;                              \
+            const int64_t at_ = (int64_t)cl * __builtin_amdgcn_readlane(rstride, l) + lane_rec;                          \
             if constexpr (FULL) { const tbw_u32x4 q_ = ((tbw_gptr4)rec_base[l])[at_]; pf[l] = make_uint4(q_.x, q_.y, q_.z, q_.w); }   \
             else { const tbw_u32x2 q_ = ((tbw_gptr2)rec_base[l])[at_]; pf[l] = make_uint2(q_.x, q_.y); }               \
         }                                                                                                                \
@@ -1652,7 +1656,7 @@ __global__ void __launch_bounds__(64 * TBW_WPG) k_tb_walk(const uint32_t *__rest
                 if (!((redo >> l) & 1ull)) continue;
                 const uint64_t pl = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(phi, l) << 32) | (uint32_t)__builtin_amdgcn_readlane(plo, l);
                 const int32_t cl = __builtin_amdgcn_readlane(cur_chunk, l), sh = __builtin_amdgcn_readlane(sh_cur, l);
-                const rec_t v = ((const rec_t *)pl)[(int64_t)cl * __builtin_amdgcn_readlane(rstride, l) + lane];
+                const rec_t v = ((const rec_t *)pl)[(int64_t)cl * __builtin_amdgcn_readlane(rstride, l) + lane_rec];
                 park(l, v, sh);
             }
         }
@@ -1722,6 +1726,158 @@ __global__ void __launch_bounds__(64 * TBW_WPG) k_tb_walk(const uint32_t *__rest
     ncol = walked ? (di.best_t - ts) - n_ops : 0;
     WalkOut o;
     o.ok = failed ? 2 : (walked ? 1 : 0); o.i = i; o.ts = ts; o.i_end = i_end; o.j_end = j_end; o.ncol = ncol; o.n_ops = n_ops; o.pad_ = 0;
+    wout[sl] = o;
+}
+
+// ---- the walk of the bit-sliced kernel's slots, r5 form: 32 walkers per wave in step, 32-step staged pieces, 8 KB runs.
+// k_tb_walk<false> above keeps 16 of a wave's 64 lanes walking, and what bounds it is what a CU can hold: 520 B of LDS per walker = 256 walkers per CU, whose waves between
+// them keep the SIMDs' VALU 88 % busy (r5 counters) with a quarter of the lanes.  Measured on the way here (tools/runs/tbw_variants.sh, tbh_ab.sh, profiles/README.md):
+// 32 walkers per wave at the same 256 per CU: the same 3.1 ms; 64 per wave, one wave per SIMD: 3.6 ms; 32 per wave with HALF a 64-step block staged (264 B, 512 walkers
+// per CU): 2.7 ms and no longer issue-bound -- bound by HBM, which serves scattered 256-byte pieces at 4.3 TB/s (tools/ubench/rand_block_bw.hip; runs of 1 KB and more: 6.1).
+// Hence this form.  The 32 walkers of a wave are 32 neighbours of one launch group, whose mask records the plan lays out [64-step block][half][slot][32 steps] (swb_rec): the
+// pieces the wave stages for one half-block are ONE run of 8 KB.  The wave goes down the half-blocks in step -- all pieces end at step 0, a walker joins when the wave reaches
+// the half-block its path starts in -- so the 16 loads of an iteration are plain consecutive 512-byte rows off one wave-uniform base, and a walker's lane never has to tell
+// anyone where its piece is.  The step itself is k_tb_walk's, with two things taken off its chain: the LDS read (the next step's record is one of the two below the current
+// one: both are asked for at the top of a step, one is chosen at its end) and the op stream's store (a piece is at most 32 ops: a 64-bit register takes them, words are cut
+// off it once per piece).  WalkOut, the op stream and the fail list are k_tb_walk<false>'s.
+constexpr int TBH_RPW = 32;                      // walkers per wave
+constexpr int TBH_SUB = 32;                      // steps per staged piece
+constexpr int TBH_STRIDE = TBH_SUB * 8 + 8;      // bytes per walker: +8 staggers the banks
+__global__ void __launch_bounds__(64) k_tb_walk_h(const uint32_t *__restrict__ order, const uint64_t *__restrict__ hi_dev, const DpInfo *__restrict__ info, const int64_t *__restrict__ tbo,
+                                                  const int64_t *__restrict__ mvo, const void *__restrict__ tb_, const ulonglong2 *__restrict__ mvw,
+                                                  uint32_t *__restrict__ raw, WalkOut *__restrict__ wout, uint32_t *__restrict__ fail_list, uint64_t *__restrict__ n_fail, uint32_t fail_cap,
+                                                  int32_t win_half) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds_raw[16 + TBH_RPW * TBH_STRIDE];      // (16 bytes in front: the walk asks for the two records below its own, also from a piece's first)
+    uint8_t *lds = lds_raw + 16;
+    const int lane = threadIdx.x & 63;
+    const int64_t hi = (int64_t)*hi_dev;
+    const int64_t w0 = (int64_t)blockIdx.x * TBH_RPW;
+    if (w0 >= hi) return;                            // (the grid is sized for every slot of the chunk; the bit-sliced kernel's are the first *hi_dev of the launch list)
+    const int64_t wq = w0 + lane;
+    const bool have = lane < TBH_RPW && wq < hi;
+    const uint32_t sl = have ? order[wq] : 0u;
+    DpInfo di = {0, -1, 0, NEGV};
+    if (have) di = info[sl];
+    bool active = have && di.best_t >= 0;
+    int64_t mo_ = have ? mvo[sl] : 0;
+    // the wave's records: its first walker's (always there) are the run's start, walker l's pieces lie 32 l records on
+    const int64_t to0 = tbo[order[w0]];
+    const uint8_t *row0 = (const uint8_t *)tb_ + (to0 << 3);
+    asm volatile("" : "+v"(mo_));
+    const ulonglong2 *mvr = mvw + mo_;                                        // per 64 steps {move bits, i0 before them}
+    uint32_t *rawp = raw + 4 * mo_;
+    int32_t ts = active ? di.best_t : -1;
+    int32_t k = di.best_lane, i = -1;
+    uint64_t w_cur = 0, w_prev = 0, pref_word = 0;      // move words: w_cur = 64-step block `wchunk` (the one ts is in once the walker has joined), w_prev the one below, pref_word the one below that
+    int32_t wchunk = -1;
+    if (active) {   // i0 at the start step = i0 before its 64-step block + DOWN moves up to and including it
+        const ulonglong2 mw = mvr[ts >> 6];
+        i = (int32_t)(uint32_t)mw.y + __popcll(mw.x & ((2ull << (ts & 63)) - 1ull)) + k;
+        w_prev = mw.x;                                   // (joining shifts it into w_cur)
+        pref_word = (ts >> 6) > 0 ? mvr[(ts >> 6) - 1].x : 0ull;
+        wchunk = (ts >> 6) + 1;
+    }
+    const int32_t i_end = i, j_end = ts - i;
+    active = active && i >= 0 && ts - i >= 0;
+    const bool walked = active;
+    bool failed = false;
+    const int32_t wlo = 32 - win_half;                                        // the path may use band lanes [wlo, wlo + 2 win_half) (16..47; tests narrow it)
+    const uint32_t wn = 2u * (uint32_t)win_half;
+    int32_t nw = 0;
+    uint32_t rawacc = 0, nb = 0;
+    const uint8_t *mine = lds + (lane & (TBH_RPW - 1)) * TBH_STRIDE;          // (lanes 32..63 never walk)
+    // the half-block the wave starts in: the highest any of its walkers starts in
+    int32_t sc = active ? ts >> 5 : -1;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) sc = max(sc, __shfl_xor(sc, d, 64));
+    sc = __builtin_amdgcn_readfirstlane(sc);
+    typedef uint32_t tbh_u32x2 __attribute__((ext_vector_type(2)));
+    typedef const tbh_u32x2 __attribute__((address_space(1))) *tbh_gptr2;
+    uint2 pf[TBH_RPW / 2];
+    uint8_t *park0 = lds + (lane >> 5) * TBH_STRIDE + (lane & 31) * 8;        // load p holds the pieces of walkers 2p (lanes 0..31) and 2p + 1 (lanes 32..63)
+    // half-block s of the wave: 256 B per walker, 32 walkers side by side
+#define TBH_ISSUE(s_)                                                                                                                     \
+    {                                                                                                                                     \
+        const tbh_gptr2 r_ = (tbh_gptr2)(uint64_t)(row0 + ((int64_t)((s_) >> 1) * 4096 + ((s_) & 1) * 2048) * 8);                          \
+        _Pragma("unroll") for (int p = 0; p < TBH_RPW / 2; p++) { const tbh_u32x2 v_ = r_[64 * p + lane]; pf[p] = make_uint2(v_.x, v_.y); } \
+    }
+    if (sc >= 0) TBH_ISSUE(sc)
+    for (; sc >= 0; sc--) {
+        if ((uint32_t)k >= 64u) active = false;      // (masks that are not a DP's: a walk that has left the band ends here)
+        if (active && (uint32_t)(k - wlo) >= wn) { active = false; failed = true; }      // the path needs a lane the 8-byte records do not hold
+        if (!__any(active)) break;
+        // park the half-block (every walker is done with the old contents)
+#pragma unroll
+        for (int p = 0; p < TBH_RPW / 2; p++) *(uint2 *)(park0 + 2 * p * TBH_STRIDE) = pf[p];
+        if (active && (ts >> 5) > sc) { active = false; failed = true; }      // (cannot happen: a step goes down by one or two.  If it does the slot is computed and walked again with whole masks)
+        const bool now = active && (ts >> 5) == sc;                           // this walker's path is in the half-block (the others have not started yet)
+        if (now && (sc >> 1) != wchunk) {                                     // it has come down into the next 64-step block
+            w_cur = w_prev; w_prev = pref_word; wchunk = sc >> 1;
+            pref_word = wchunk >= 2 ? mvr[wchunk - 2].x : 0ull;
+        }
+        if (sc > 0) TBH_ISSUE(sc - 1)
+        TBW_WAVE_SYNC();
+        // ---- walk inside the piece
+        uint32_t d1 = 0;
+        uint64_t P = 0;                    // moves of steps ts-1, ts-2, ... from the top bit down (steps before 0 read as RIGHT)
+        if (now) {
+            const int32_t s_ = ts & 63;
+            d1 = (uint32_t)(w_cur >> s_) & 1u;
+            P = s_ ? (w_cur << (64 - s_)) | (w_prev >> s_) : w_prev;
+        }
+        const int32_t c_lo = sc << 5;
+        const int32_t w_lo = wlo, w_hi = wlo + (int32_t)wn - 1;
+        const uint8_t *pm = mine + (ts & (TBH_SUB - 1)) * 8;
+        int32_t bad = (now ? 0 : -1) | i | (ts - i) | (ts - c_lo) | (k - w_lo) | (w_hi - k);
+        uint64_t acc = 0;                  // this piece's ops, the newest in the top bits
+        uint32_t na = 0;
+        uint2 m = *(const uint2 *)pm;
+        while (bad >= 0) {
+            const uint2 n1 = *(const uint2 *)(pm - 8), n2 = *(const uint2 *)(pm - 16);
+            const uint32_t kk = (uint32_t)(k - 16);
+            const uint32_t db = (m.x >> kk) & 1u;
+            const uint32_t gx = (m.y >> kk) ^ d1;                             // bit 0: G ^ the move before
+            const uint32_t hi32 = (uint32_t)(P >> 32);
+            const uint32_t d2 = hi32 >> 31, d3 = (hi32 >> 30) & 1u;
+            const uint32_t ndb = db ^ 1u;
+            const uint32_t up = ndb & ~gx & 1u;                               // not diagonal: G set after a DOWN move, or clear after a RIGHT move -> the cell above
+            const uint32_t op = 2u * ndb - up;                                // M = 0, I = 1, D = 2
+            const uint32_t stp = 1u + db, dec = db + up;
+            k += (int32_t)(d1 + (db & d2)) - (int32_t)dec;
+            i -= (int32_t)dec;
+            ts -= (int32_t)stp;
+            pm -= 8u * stp;
+            d1 = db ? d3 : d2;
+            P <<= stp;
+            acc = (acc >> 2) | ((uint64_t)op << 62);
+            na++;
+            m = db ? n2 : n1;
+            bad = i | (ts - i) | (ts - c_lo) | (k - w_lo) | (w_hi - k);
+        }
+        if (na) {      // the piece's ops behind the pending bits (nb < 32 of them in rawacc): whole words out, the rest stays pending
+            const uint64_t ops = acc >> (64u - 2u * na);
+            const uint64_t lo64 = (uint64_t)rawacc | (ops << nb);
+            const uint32_t top = nb ? (uint32_t)(ops >> (64u - nb)) : 0u;
+            const uint32_t bits = nb + 2u * na, words = bits >> 5;
+            if (words >= 1u) rawp[nw] = (uint32_t)lo64;
+            if (words >= 2u) rawp[nw + 1] = (uint32_t)(lo64 >> 32);
+            nw += (int32_t)words;
+            rawacc = words == 0u ? (uint32_t)lo64 : (words == 1u ? (uint32_t)(lo64 >> 32) : top);
+            nb = bits & 31u;
+        }
+        active = active && (i | (ts - i)) >= 0;
+        TBW_WAVE_SYNC();
+    }
+#undef TBH_ISSUE
+    if (!have) return;
+    if (failed) {
+        const uint32_t f = (uint32_t)atomicAdd((unsigned long long *)n_fail, 1ull);
+        if (f < fail_cap) fail_list[f] = sl;
+    }
+    if (nb) rawp[nw] = rawacc;
+    const int32_t n_ops = 16 * nw + (int32_t)(nb >> 1);
+    WalkOut o;
+    o.ok = failed ? 2 : (walked ? 1 : 0); o.i = i; o.ts = ts; o.i_end = i_end; o.j_end = j_end; o.ncol = walked ? (di.best_t - ts) - n_ops : 0; o.n_ops = n_ops; o.pad_ = 0;
     wout[sl] = o;
 }
 
@@ -2805,9 +2961,15 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
                 auto kw_mid = tb_stats ? k_tb_walk<false, true> : k_tb_walk<false, false>;
                 auto kw_full = k_tb_walk<true, false>;
                 // the bit-sliced kernel's slots: 8-byte records; the others: whole masks
-                hipLaunchKernelGGL(kw_mid, dim3(wg), dim3(64 * TBW_WPG), 0, st2, (const uint32_t *)B.list.p, (const uint64_t *)nullptr, (const uint64_t *)B.ptot.p, 0u,
-                                   (const DpInfo *)B.info.p, (const int64_t *)B.tbo.p, (const int64_t *)B.mvo.p, (const int32_t *)B.tbs.p, (const void *)B.tb.p, (const ulonglong2 *)B.mvw.p, B.raw.p, B.wout.p,
-                                   (unsigned long long *)j->tb_stats.p, B.fail_list.p, B.ptot.p + 3, (uint32_t)FAIL_CAP, win_half);
+                static const bool walk_old = getenv("FZP_TBW_OLD") != nullptr;      // (A/B: the 16-walker form)
+                if (tb_stats || walk_old)
+                    hipLaunchKernelGGL(kw_mid, dim3(wg), dim3(64 * TBW_WPG), 0, st2, (const uint32_t *)B.list.p, (const uint64_t *)nullptr, (const uint64_t *)B.ptot.p, 0u,
+                                       (const DpInfo *)B.info.p, (const int64_t *)B.tbo.p, (const int64_t *)B.mvo.p, (const int32_t *)B.tbs.p, (const void *)B.tb.p, (const ulonglong2 *)B.mvw.p, B.raw.p, B.wout.p,
+                                       (unsigned long long *)j->tb_stats.p, B.fail_list.p, B.ptot.p + 3, (uint32_t)FAIL_CAP, win_half);
+                else
+                    hipLaunchKernelGGL(k_tb_walk_h, dim3((ns + TBH_RPW - 1) / TBH_RPW), dim3(64), 0, st2, (const uint32_t *)B.list.p, (const uint64_t *)B.ptot.p, (const DpInfo *)B.info.p,
+                                       (const int64_t *)B.tbo.p, (const int64_t *)B.mvo.p, (const void *)B.tb.p, (const ulonglong2 *)B.mvw.p, B.raw.p, B.wout.p,
+                                       B.fail_list.p, B.ptot.p + 3, (uint32_t)FAIL_CAP, win_half);
                 hipLaunchKernelGGL(kw_full, dim3(wg), dim3(64 * TBW_WPG), 0, st2, (const uint32_t *)B.list.p, (const uint64_t *)B.ptot.p, (const uint64_t *)nullptr, ns,
                                    (const DpInfo *)B.info.p, (const int64_t *)B.tbo.p, (const int64_t *)B.mvo.p, (const int32_t *)B.tbs.p, (const void *)B.tbw.p, (const ulonglong2 *)B.mvw.p, B.raw.p, B.wout.p,
                                    (unsigned long long *)nullptr, (uint32_t *)nullptr, (uint64_t *)nullptr, 0u, 16);
