@@ -1826,36 +1826,40 @@ __global__ void __launch_bounds__(64) k_tb_walk_h(const uint32_t *__restrict__ o
             P = s_ ? (w_cur << (64 - s_)) | (w_prev >> s_) : w_prev;
         }
         const int32_t c_lo = sc << 5;
-        const int32_t w_lo = wlo, w_hi = wlo + (int32_t)wn - 1;
-        const uint8_t *pm = mine + (ts & (TBH_SUB - 1)) * 8;
-        int32_t bad = (now ? 0 : -1) | i | (ts - i) | (ts - c_lo) | (k - w_lo) | (w_hi - k);
-        uint64_t acc = 0;                  // this piece's ops, the newest in the top bits
+        // (the loop's own variables: kk = k - 16 is the bit the step looks at, p16 the address of the record two below the current one -- both reads of a step hang off it)
+        int32_t kk = k - 16;
+        const int32_t kw_lo = wlo - 16, kw_hi = wlo + (int32_t)wn - 17;
+        const uint8_t *p16 = mine + (ts & (TBH_SUB - 1)) * 8 - 16;
+        int32_t bad = (now ? 0 : -1) | i | (ts - i) | (ts - c_lo) | (kk - kw_lo) | (kw_hi - kk);
+        uint64_t acc = 0;                  // this piece's ops, the OLDEST in the top bits (turned round behind the loop)
         uint32_t na = 0;
-        uint2 m = *(const uint2 *)pm;
+        uint2 m = *(const uint2 *)(p16 + 16);
         while (bad >= 0) {
-            const uint2 n1 = *(const uint2 *)(pm - 8), n2 = *(const uint2 *)(pm - 16);
-            const uint32_t kk = (uint32_t)(k - 16);
+            const uint2 n2 = *(const uint2 *)p16, n1 = *(const uint2 *)(p16 + 8);
             const uint32_t db = (m.x >> kk) & 1u;
             const uint32_t gx = (m.y >> kk) ^ d1;                             // bit 0: G ^ the move before
             const uint32_t hi32 = (uint32_t)(P >> 32);
-            const uint32_t d2 = hi32 >> 31, d3 = (hi32 >> 30) & 1u;
+            const uint32_t d2 = hi32 >> 31;
             const uint32_t ndb = db ^ 1u;
             const uint32_t up = ndb & ~gx & 1u;                               // not diagonal: G set after a DOWN move, or clear after a RIGHT move -> the cell above
             const uint32_t op = 2u * ndb - up;                                // M = 0, I = 1, D = 2
             const uint32_t stp = 1u + db, dec = db + up;
-            k += (int32_t)(d1 + (db & d2)) - (int32_t)dec;
+            kk += (int32_t)(d1 + (db & d2)) - (int32_t)dec;
             i -= (int32_t)dec;
             ts -= (int32_t)stp;
-            pm -= 8u * stp;
-            d1 = db ? d3 : d2;
+            p16 -= 8u * stp;
+            d1 = (hi32 << db) >> 31;                                          // the move before the new step: bit 63 of P after a single step, bit 62 after a diagonal one
             P <<= stp;
-            acc = (acc >> 2) | ((uint64_t)op << 62);
+            acc = (acc << 2) | op;
             na++;
             m = db ? n2 : n1;
-            bad = i | (ts - i) | (ts - c_lo) | (k - w_lo) | (w_hi - k);
+            bad = i | (ts - i) | (ts - c_lo) | (kk - kw_lo) | (kw_hi - kk);
         }
+        k = kk + 16;
         if (na) {      // the piece's ops behind the pending bits (nb < 32 of them in rawacc): whole words out, the rest stays pending
-            const uint64_t ops = acc >> (64u - 2u * na);
+            uint64_t r = __builtin_bitreverse64(acc);                         // op g of na -> group 31 - g, its two bits swapped ...
+            r = ((r & 0x5555555555555555ull) << 1) | ((r >> 1) & 0x5555555555555555ull);      // ... and swapped back
+            const uint64_t ops = r >> (64u - 2u * na);                        // the oldest op in bits 1:0
             const uint64_t lo64 = (uint64_t)rawacc | (ops << nb);
             const uint32_t top = nb ? (uint32_t)(ops >> (64u - nb)) : 0u;
             const uint32_t bits = nb + 2u * na, words = bits >> 5;
