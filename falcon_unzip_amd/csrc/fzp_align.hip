@@ -2567,6 +2567,7 @@ struct fzp_alnjob {
     int64_t wave_log_n = 0;
     bool summ_on_host = false;
     bool whole_masks_only = false;               // the second attempt of a run whose fail list overflowed: no bit-sliced kernel, whole masks for every piece
+    bool overflow_unchecked = false;             // fzp_align_run_deferred: nobody has asked the device yet whether the fail list overflowed (fzp_align_to_batch does)
     // record planning: reads grouped by contig (input order inside a contig); built on first use
     DevBuf<int32_t> slot_read, slot_ctg;
     DevBuf<int64_t> slot_off;
@@ -2764,8 +2765,14 @@ extern "C" int fzp_align_invalidate_index(fzp_alnjob *j) {
     return FZP_OK;
 }
 
-extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
+// defer_overflow (fzp_pipe.hip, through fzp_align_run_deferred): the run's one question to the device that nothing before fzp_align_to_batch needs answered -- "did the
+// fail list overflow?" -- rides in that call's fetch instead of costing the step a read-back of its own; fzp_align_to_batch does the retry when the answer is yes.
+static int align_run(fzp_ctx *ctx, fzp_alnjob *j, bool defer_overflow);
+extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) { return align_run(ctx, j, false); }
+int fzp_align_run_deferred(fzp_ctx *ctx, fzp_alnjob *j) { return align_run(ctx, j, true); }
+static int align_run(fzp_ctx *ctx, fzp_alnjob *j, bool defer_overflow) {
     if (!ctx || !j) return FZP_EINVAL;
+    j->overflow_unchecked = false;
     FZP_TRY(fzp_bind(ctx));
     hipStream_t st = ctx->stream, st2 = ctx->stream2, st3 = ctx->stream3;
     const fzp_align_params &P = j->P;
@@ -3008,6 +3015,13 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
             if (used[b2]) FZP_HIP(hipStreamWaitEvent(st, j->ev_tb[b2], 0));   // the main stream continues after all trace-backs
     }
     uint32_t fbo = 0;
+    if (nr > 0 && defer_overflow && !j->whole_masks_only) {
+        FZP_HIP(hipGetLastError());
+        j->overflow_unchecked = true;
+        j->summ_on_host = false;
+        j->done = true;
+        return FZP_OK;
+    }
     if (nr > 0) FZP_TRY(fzp_fetch(ctx, st, &fbo, j->fb_overflow.p, 4));
     FZP_HIP(hipStreamSynchronize(st));
     FZP_HIP(hipGetLastError());
@@ -3015,7 +3029,7 @@ extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) {
         if (j->whole_masks_only) { fzp_set_error("fzp_align_run: the fail list overflowed although nothing is on it in this mode"); return FZP_EINVAL; }
         if (getenv("FZP_TB_NO_RETRY")) { fzp_set_error("fzp_align_run: more than %d extension pieces (or %lld DP steps of them) per chunk needed whole trace-back masks (FZP_TB_NO_RETRY)", FAIL_CAP, (long long)FAIL_ROOM); return FZP_EINVAL; }
         j->whole_masks_only = true;
-        const int rc = fzp_align_run(ctx, j);
+        const int rc = align_run(ctx, j, false);
         j->whole_masks_only = false;
         return rc;
     }
@@ -3336,13 +3350,27 @@ extern "C" int fzp_align_to_batch(fzp_ctx *ctx, fzp_alnjob *j, fzp_batch **out) 
     std::vector<int32_t> h_last((size_t)nc);
     std::vector<uint32_t> h_nal((size_t)nc * 2);      // aligned reads per contig, then accepted ones (records) per contig
     std::vector<unsigned long long> h_cols((size_t)nc);
+    uint32_t fbo = 0;
+    const bool ask_overflow = j->overflow_unchecked && nr > 0;
     if (nc <= 32) {      // (a few contigs: everything the host needs here fits one fetch)
-        const fzp_fetch_piece fp[4] = {{tot, totals.p, 32}, {h_last.data(), last_pos.p, (size_t)nc * 4}, {h_nal.data(), n_aligned.p, (size_t)nc * 8}, {h_cols.data(), n_cols.p, (size_t)nc * 8}};
-        FZP_TRY(fzp_fetch(ctx, st, fp, 4));
+        const fzp_fetch_piece fp[5] = {{tot, totals.p, 32}, {h_last.data(), last_pos.p, (size_t)nc * 4}, {h_nal.data(), n_aligned.p, (size_t)nc * 8}, {h_cols.data(), n_cols.p, (size_t)nc * 8},
+                                       {&fbo, j->fb_overflow.p, 4}};
+        FZP_TRY(fzp_fetch(ctx, st, fp, ask_overflow ? 5 : 4));
     } else {
+        if (ask_overflow) FZP_HIP(hipMemcpyAsync(&fbo, j->fb_overflow.p, 4, hipMemcpyDeviceToHost, st));
         FZP_HIP(hipMemcpyAsync(tot, totals.p, 32, hipMemcpyDeviceToHost, st));
         FZP_TRY(last_pos.download(h_last.data(), (size_t)nc, st)); FZP_TRY(n_aligned.download(h_nal.data(), (size_t)nc * 2, st)); FZP_TRY(n_cols.download(h_cols.data(), (size_t)nc, st));
         FZP_HIP(hipStreamSynchronize(st));
+    }
+    j->overflow_unchecked = false;
+    if (fbo) {      // the deferred answer is "it overflowed": the run again with whole masks (fzp_align_run's own retry), then this call from the top
+        if (getenv("FZP_TB_NO_RETRY")) { fzp_set_error("fzp_align_run: more than %d extension pieces (or %lld DP steps of them) per chunk needed whole trace-back masks (FZP_TB_NO_RETRY)", FAIL_CAP, (long long)FAIL_ROOM); return FZP_EINVAL; }
+        FZP_HIP(hipStreamSynchronize(st));      // (the plan's buffers of this attempt die with this frame)
+        j->whole_masks_only = true;
+        const int rc = align_run(ctx, j, false);
+        j->whole_masks_only = false;
+        if (rc != FZP_OK) return rc;
+        return fzp_align_to_batch(ctx, j, out);
     }
     b->n_rec = (int64_t)tot[0]; b->n_cig = (int64_t)tot[1]; b->n_seq = (int64_t)tot[2]; b->n_ck = (int64_t)tot[3];
     if (b->n_rec >= (1ll << 31)) { fzp_set_error("fzp_align_to_batch: %lld records (limit 2^31 per batch)", (long long)b->n_rec); return FZP_EINVAL; }

@@ -261,6 +261,10 @@ int fzp_batch_result_begin(fzp_ctx *ctx, fzp_batch *b) {
         if (parts[k].bytes && hipMemcpyAsync((char *)b->pin + off, parts[k].src, parts[k].bytes, hipMemcpyDeviceToHost, st) != hipSuccess) { (void)hipGetLastError(); fzp_set_error("D2H copy failed"); return FZP_EDEVICE; }
         off += al64(parts[k].bytes);
     }
+    // "the late records are over": what fzp_batch_result_all waits for (not the stream: the caller may have put more work behind the copies)
+    if (!ctx->ev_late && hipEventCreateWithFlags(&ctx->ev_late, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ctx->ev_late = nullptr; }
+    b->late_event = ctx->ev_late && hipEventRecord(ctx->ev_late, st) == hipSuccess;
+    if (!b->late_event) (void)hipGetLastError();
     b->late_begun = true; b->late_early = use_early;
     return FZP_OK;
 }
@@ -279,7 +283,7 @@ extern "C" int fzp_batch_result_all(fzp_ctx *ctx, fzp_batch *b, fzp_result_all *
     fzp_result &r = out->all;
     if (!b->late_begun) FZP_TRY(fzp_batch_result_begin(ctx, b));
     // the early records: wait for THEIR copies (the event recorded behind them), not for whatever else the caller has put on stream2 since
-    if (hipStreamSynchronize(st) != hipSuccess ||
+    if ((b->late_event ? hipEventSynchronize(ctx->ev_late) : hipStreamSynchronize(st)) != hipSuccess ||
         (b->late_early && (ctx->ev_pf_done ? hipEventSynchronize(ctx->ev_pf_done) : hipStreamSynchronize(ctx->stream2)) != hipSuccess)) { (void)hipGetLastError(); fzp_set_error("D2H sync failed"); return FZP_EDEVICE; }
     b->pf_early = false;                                               // a later run of the batch refills the block
     b->late_begun = false;

@@ -118,7 +118,7 @@ struct fzp_batch {
     // device-to-host copy in flight holds up every kernel that writes memory beside it (measured: K4's 5 us fills took 77 and 266 us under these two copies)
     bool host_skip_rows = false;
     // fzp_batch_result_begin: the block and read records are on their way (main stream); fzp_batch_result_all then only waits
-    bool late_begun = false, late_early = false;
+    bool late_begun = false, late_early = false, late_event = false;
     size_t late_off[5] = {0, 0, 0, 0, 0};
     ~fzp_batch() { if (pin) fzp_pinned_release(pin_ctx, pin); }
     // scratch
@@ -127,6 +127,7 @@ struct fzp_batch {
 };
 
 // stage drivers (fzp_phase.hip)
+int fzp_align_run_deferred(fzp_ctx *ctx, fzp_alnjob *job);   // fzp_align_run whose fail-list overflow question is answered by the fzp_align_to_batch that follows (fzp_align.hip)
 int fzp_batch_result_begin(fzp_ctx *ctx, fzp_batch *b);     // the record copies fzp_batch_result_all waits for, started now on the main stream (fzp_api.hip)
 int fzp_batch_need_bytes(fzp_ctx *ctx, fzp_batch *b);      // packed batches: run-length CIGAR words, byte SEQ and the 64-op checkpoints, now (fzp_hetcall.hip)
 int fzp_k2_het_call(fzp_ctx *ctx, fzp_batch *b);

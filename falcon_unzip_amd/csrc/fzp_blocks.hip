@@ -292,10 +292,10 @@ __global__ void __launch_bounds__(256) k_pv_compact(const int64_t *__restrict__ 
     for (uint32_t k = threadIdx.x; k < pv_n[c]; k += 256) dst[k] = src[k];
 }
 
-__global__ void k_u32_to_i64_begin(const uint32_t *__restrict__ off, int n, int64_t total, int64_t *__restrict__ begin) {
+__global__ void k_u32_to_i64_begin(const uint32_t *__restrict__ off, int n, const uint64_t *__restrict__ total_dev, int64_t *__restrict__ begin) {      // (the total from where the scan left it)
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c > n) return;
-    begin[c] = c < n ? (int64_t)off[c] : total;
+    begin[c] = c < n ? (int64_t)off[c] : (int64_t)*total_dev;
 }
 
 // ================================================================================ K5
@@ -376,12 +376,12 @@ __global__ void __launch_bounds__(256) k_read_emit(int64_t n_slots, int64_t nq, 
     out[o] = r;
 }
 
-__global__ void k_pread_begin(const int64_t *__restrict__ ctg_qoff, int n_ctg, int64_t nq, int64_t n_slots, int64_t n_out, const uint32_t *__restrict__ rng_off,
-                              const uint32_t *__restrict__ idx, int64_t *__restrict__ begin) {
+__global__ void k_pread_begin(const int64_t *__restrict__ ctg_qoff, int n_ctg, int64_t nq, int64_t n_slots, const uint64_t *__restrict__ n_out_dev, const uint32_t *__restrict__ rng_off,
+                              const uint32_t *__restrict__ idx, int64_t *__restrict__ begin) {      // (n_out from where the scan left it; null: no slots, no records)
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c > n_ctg) return;
     int64_t Q0 = ctg_qoff[c];
-    int64_t v = n_out;
+    int64_t v = n_out_dev ? (int64_t)*n_out_dev : 0;
     if (Q0 < nq) {
         uint32_t slot = rng_off[Q0];
         if ((int64_t)slot < n_slots) v = idx[slot];
@@ -461,14 +461,13 @@ int fzp_k4_blocks(fzp_ctx *ctx, fzp_batch *b) {
     }
     FZP_TRY(fzp_exclusive_scan_u32(ctx, b->pv_n.p, b->pv_off.p, (size_t)b->n_ctg, b->totals.p + 5));
     uint64_t t = 0;
-    FZP_TRY(fzp_fetch(ctx, st, &t, b->totals.p + 5, sizeof t));
+    b->h_pvar_begin.resize((size_t)b->n_ctg + 1);
+    hipLaunchKernelGGL(k_u32_to_i64_begin, dim3((b->n_ctg + 1 + 63) / 64), dim3(64), 0, st, b->pv_off.p, b->n_ctg, b->totals.p + 5, b->pvar_begin.p);
+    FZP_TRY(fzp_fetch_with_begins(ctx, st, &t, b->totals.p + 5, 1, b->h_pvar_begin.data(), b->pvar_begin.p, b->n_ctg));      // the count and the contigs' begins in one
     b->n_pvars = (int64_t)t;
     FZP_TRY(b->pvars.alloc((size_t)b->n_pvars));
     if (b->n_pvars > 0)
         hipLaunchKernelGGL(k_pv_compact, dim3(b->n_ctg), dim3(256), 0, st, b->site_begin.p, b->pv_n.p, b->pv_off.p, b->pvars_tmp.p, b->pvars.p);
-    hipLaunchKernelGGL(k_u32_to_i64_begin, dim3((b->n_ctg + 1 + 63) / 64), dim3(64), 0, st, b->pv_off.p, b->n_ctg, b->n_pvars, b->pvar_begin.p);
-    b->h_pvar_begin.resize((size_t)b->n_ctg + 1);
-    FZP_TRY(fzp_read_back(ctx, st, b->h_pvar_begin.data(), b->pvar_begin.p, ((size_t)b->n_ctg + 1) * sizeof(b->h_pvar_begin[0])));
     FZP_HIP(hipGetLastError());
     b->have_blocks = true;
     return FZP_OK;
@@ -485,6 +484,7 @@ int fzp_k5_reads(fzp_ctx *ctx, fzp_batch *b) {
     FZP_TRY(b->pread_begin.alloc((size_t)b->n_ctg + 1));
     int64_t n_slots = 0;
     b->n_preads = 0;
+    bool begins_there = false;
     if (nq > 0) {
         { const fzp_fill_piece fl[2] = {{b->bmin.p, (size_t)nq * 4, 0x7fffffffu}, fzp_zeroes(b->bmax, (size_t)nq)}; FZP_TRY(fzp_fill(ctx, st, fl, 2)); }
         const uint32_t *set_n = b->set_n.p, *set_off = b->set_n.p + 2 * ns;
@@ -508,7 +508,11 @@ int fzp_k5_reads(fzp_ctx *ctx, fzp_batch *b) {
             }
             hipLaunchKernelGGL(k_read_flag, dim3(grid_for(n_slots, 256, 1 << 30)), dim3(256), 0, st, n_slots, b->c0.p, b->c1.p, b->pr_flag.p);
             FZP_TRY(fzp_exclusive_scan_u32(ctx, b->pr_flag.p, b->pr_flag.p, (size_t)n_slots, b->totals.p + 7));
-            FZP_TRY(fzp_fetch(ctx, st, &t, b->totals.p + 7, sizeof t));
+            b->h_pread_begin.resize((size_t)b->n_ctg + 1);
+            hipLaunchKernelGGL(k_pread_begin, dim3((b->n_ctg + 1 + 63) / 64), dim3(64), 0, st, b->ctg_qoff.p, b->n_ctg, nq, n_slots, b->totals.p + 7, b->rng_off.p, b->pr_flag.p,
+                               b->pread_begin.p);
+            FZP_TRY(fzp_fetch_with_begins(ctx, st, &t, b->totals.p + 7, 1, b->h_pread_begin.data(), b->pread_begin.p, b->n_ctg));      // the count and the contigs' begins in one
+            begins_there = true;
             b->n_preads = (int64_t)t;
             FZP_TRY(b->preads.alloc((size_t)b->n_preads));
             if (b->n_preads > 0) {
@@ -519,10 +523,10 @@ int fzp_k5_reads(fzp_ctx *ctx, fzp_batch *b) {
         }
     }
     FZP_TRY(b->preads.alloc((size_t)b->n_preads));
-    hipLaunchKernelGGL(k_pread_begin, dim3((b->n_ctg + 1 + 63) / 64), dim3(64), 0, st, b->ctg_qoff.p, b->n_ctg, nq, n_slots, b->n_preads, b->rng_off.p, b->pr_flag.p,
-                       b->pread_begin.p);
-    b->h_pread_begin.resize((size_t)b->n_ctg + 1);
-    FZP_TRY(fzp_read_back(ctx, st, b->h_pread_begin.data(), b->pread_begin.p, ((size_t)b->n_ctg + 1) * sizeof(b->h_pread_begin[0])));
+    if (!begins_there) {      // no reads or no slots: every contig begins (and ends) at 0
+        b->h_pread_begin.assign((size_t)b->n_ctg + 1, 0);
+        FZP_TRY(b->pread_begin.zero((size_t)b->n_ctg + 1, st));
+    }
     FZP_HIP(hipGetLastError());
     b->have_preads = true;
     return FZP_OK;

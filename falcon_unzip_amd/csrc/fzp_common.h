@@ -53,7 +53,16 @@ int fzp_fetch(fzp_ctx *ctx, hipStream_t st, const fzp_fetch_piece *pieces, int n
 inline int fzp_fetch(fzp_ctx *ctx, hipStream_t st, void *host, const void *dev, size_t bytes) { const fzp_fetch_piece p{host, dev, bytes}; return fzp_fetch(ctx, st, &p, 1); }
 struct fzp_fill_piece { void *dev; size_t bytes; uint32_t word; };
 int fzp_fill(fzp_ctx *ctx, hipStream_t st, const fzp_fill_piece *pieces, int n_pieces);      // every region set to its 32-bit word, one launch per twelve regions (fzp_host.hip)
-int fzp_read_back(fzp_ctx *ctx, hipStream_t st, void *host, const void *dev, size_t bytes);      // fzp_fetch where it fits (<= 256 bytes), copy + stream wait otherwise
+int fzp_read_back(fzp_ctx *ctx, hipStream_t st, void *host, const void *dev, size_t bytes);
+// a stage's total(s) and its per-contig begins in ONE fetch when the begins fit a piece (<= 31 contigs), the total first and the begins by copy otherwise (r5: K2..K5 each
+// read a count back, launched the kernel it sizes, and then read the per-contig begins back -- which the scan behind the count had already fixed)
+inline int fzp_fetch_with_begins(fzp_ctx *ctx, hipStream_t st, uint64_t *tot, const uint64_t *tot_dev, int n_tot, int64_t *h_begin, const int64_t *begin_dev, int n_ctg) {
+    const size_t bb = ((size_t)n_ctg + 1) * sizeof(int64_t);
+    if (bb <= 256) { const fzp_fetch_piece fp[2] = {{tot, tot_dev, (size_t)n_tot * 8}, {h_begin, begin_dev, bb}}; return fzp_fetch(ctx, st, fp, 2); }
+    FZP_TRY(fzp_fetch(ctx, st, tot, tot_dev, (size_t)n_tot * 8));
+    return fzp_read_back(ctx, st, h_begin, begin_dev, bb);
+}
+      // fzp_fetch where it fits (<= 256 bytes), copy + stream wait otherwise
 void *fzp_dev_alloc(size_t bytes);   // from the calling thread's current pool; nullptr on failure
 void fzp_dev_free(void *p);
 void fzp_dev_trim();                  // give everything cached in the current pool back to the driver
@@ -129,7 +138,7 @@ struct fzp_ctx {
     std::vector<hipEvent_t> event_pool;
     DevBuf<uint64_t> scan_tmp[3];
     std::shared_ptr<DevPool> pool;   // this ctx's cached device blocks
-    uint32_t *fetch_slot = nullptr;   // fzp_fetch: 4 x 64 payload words + a sequence number, in mapped pinned memory (fzp_host.hip)
+    uint32_t *fetch_slot = nullptr;   // fzp_fetch: 8 x 64 payload words + a sequence number, in mapped pinned memory (fzp_host.hip)
     uint64_t fetch_seq = 0;
     std::mutex pin_mu;
     std::vector<std::pair<void *, size_t>> pin_free, pin_live;   // pinned host blocks: cached / handed out
@@ -138,6 +147,7 @@ struct fzp_ctx {
     struct FileWriter *writer = nullptr;   // fzp_pipe.hip: background file writes of FZP_PIPE_ASYNC_WRITES calls (joined by fzp_pipe_flush / ctx destroy)
     std::vector<fzp_ctx *> lanes;    // fzp_phase_contigs: the extra lanes' contexts, kept (with their warm block caches) for the next call
     hipEvent_t ev_pf = nullptr;      // "K2/K3 results are final": their download starts on stream2 while K4/K5 run
+    hipEvent_t ev_late = nullptr;    // fzp_batch_result_begin: behind the block / read records' copies
     hipEvent_t ev_pf_done = nullptr; // ... and "that download is over" (what fzp_batch_result_all waits for: stream2 may hold later copies)
     int n_cu = 256;
 };

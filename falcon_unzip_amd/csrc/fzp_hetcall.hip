@@ -399,16 +399,14 @@ __global__ void __launch_bounds__(256) k_site_emit(const uint4 *__restrict__ cnt
     site_ctg[si] = c;
 }
 
-__global__ void k_site_begin(const int64_t *__restrict__ site_g, int64_t n_sites, const int64_t *__restrict__ goff, int n_ctg, int64_t *__restrict__ site_begin) {
+// the same from the per-block site counts' exclusive scan: a contig starts on a block boundary, so the sites before it are the sites before its first block (r5: known before
+// the sites themselves are written, i.e. in time for the fetch that brings the site count over)
+__global__ void k_site_begin_blk(const uint32_t *__restrict__ site_idx_scan, int64_t n_blk, const int64_t *__restrict__ goff, int n_ctg, const uint64_t *__restrict__ n_sites_dev,
+                                 int64_t *__restrict__ site_begin) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c > n_ctg) return;
-    int64_t key = goff[c];
-    int64_t lo = 0, hi = n_sites;   // first site with site_g >= key
-    while (lo < hi) {
-        int64_t m = (lo + hi) >> 1;
-        if (site_g[m] < key) lo = m + 1; else hi = m;
-    }
-    site_begin[c] = lo;
+    const int64_t blk = goff[c] >> 8;
+    site_begin[c] = blk < n_blk ? (int64_t)site_idx_scan[blk] : (int64_t)*n_sites_dev;
 }
 
 // ---- K2d: scatter (record index, q_id) of every column that carries a called site's major/minor allele
@@ -626,12 +624,12 @@ __global__ void __launch_bounds__(256) k_assoc_compact(int64_t n_sites, const ui
     for (uint32_t k = lane; k < n; k += 64) dst[k] = src[k];
 }
 
-__global__ void k_arow_begin(const uint32_t *__restrict__ kept_off, const int64_t *__restrict__ site_begin, int n_ctg, int64_t n_sites, int64_t n_arows,
-                             int64_t *__restrict__ arow_begin) {
+__global__ void k_arow_begin(const uint32_t *__restrict__ kept_off, const int64_t *__restrict__ site_begin, int n_ctg, int64_t n_sites, const uint64_t *__restrict__ n_arows_dev,
+                             int64_t *__restrict__ arow_begin) {      // (the total from where the scan left it: the kernel runs before the host knows it)
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c > n_ctg) return;
     int64_t s = site_begin[c];
-    arow_begin[c] = s >= n_sites ? n_arows : (int64_t)kept_off[s];
+    arow_begin[c] = s >= n_sites ? (n_arows_dev ? (int64_t)*n_arows_dev : 0) : (int64_t)kept_off[s];
 }
 
 inline unsigned grid_for(int64_t items, int per_block, int64_t cap = 1 << 20) {
@@ -657,10 +655,6 @@ PkView pk_view(const fzp_batch *b) {
     return v;
 }
 
-int read_totals(fzp_ctx *ctx, fzp_batch *b, int n, uint64_t *out) {
-    FZP_TRY(fzp_fetch(ctx, ctx->stream, out, b->totals.p, n * sizeof(uint64_t)));
-    return FZP_OK;
-}
 }  // namespace
 
 // the 64-op checkpoints of the run-length records (+ every record's reference span and the contigs' longest one)
@@ -737,14 +731,16 @@ int fzp_k2_het_call(fzp_ctx *ctx, fzp_batch *b) {
     FZP_TRY(fzp_exclusive_scan_u32(ctx, b->site_idx.p, b->site_idx.p, nblk, b->totals.p + 0));
     FZP_TRY(fzp_exclusive_scan_u32(ctx, b->row_off32.p, b->row_off32.p, nblk, b->totals.p + 1));
     uint64_t tot[2];
-    FZP_TRY(read_totals(ctx, b, 2, tot));
+    FZP_TRY(b->site_begin.alloc((size_t)b->n_ctg + 1));
+    b->h_site_begin.resize((size_t)b->n_ctg + 1);
+    hipLaunchKernelGGL(k_site_begin_blk, dim3((b->n_ctg + 1 + 63) / 64), dim3(64), 0, st, b->site_idx.p, (int64_t)nblk, b->ctg_goff.p, b->n_ctg, b->totals.p, b->site_begin.p);
+    FZP_TRY(fzp_fetch_with_begins(ctx, st, tot, b->totals.p, 2, b->h_site_begin.data(), b->site_begin.p, b->n_ctg));
     if (tot[1] >= (1ull << 31)) { fzp_set_error("variant_map has %llu rows (> 2^31)", (unsigned long long)tot[1]); return FZP_EINVAL; }
     b->n_sites = (int64_t)tot[0];
     b->n_rows = (int64_t)tot[1];
     FZP_TRY(b->sites.alloc((size_t)b->n_sites));
     FZP_TRY(b->site_g.alloc((size_t)b->n_sites));
     FZP_TRY(b->site_ctg.alloc((size_t)b->n_sites));
-    FZP_TRY(b->site_begin.alloc((size_t)b->n_ctg + 1));
     FZP_TRY(b->vmap_qid.alloc((size_t)b->n_rows));
     if (b->n_sites > 0) {
         {
@@ -762,9 +758,6 @@ int fzp_k2_het_call(fzp_ctx *ctx, fzp_batch *b) {
                                    b->ctg_maxspan.p, b->rec_span.p, b->ck_off.p, b->ck_ref.p, b->ck_q.p, b->vmap_qid.p);
         }
     }
-    hipLaunchKernelGGL(k_site_begin, dim3((b->n_ctg + 1 + 63) / 64), dim3(64), 0, st, b->site_g.p, b->n_sites, b->ctg_goff.p, b->n_ctg, b->site_begin.p);
-    b->h_site_begin.resize((size_t)b->n_ctg + 1);
-    FZP_TRY(fzp_read_back(ctx, st, b->h_site_begin.data(), b->site_begin.p, ((size_t)b->n_ctg + 1) * sizeof(b->h_site_begin[0])));
     FZP_HIP(hipGetLastError());
     for (int c = 0; c < b->n_ctg; c++) {     // a site called beyond the contig's end: the reference dies on ref_seq[pos] (phasing.py:124)
         if ((int64_t)b->h_limit[(size_t)c] <= b->h_ref_len[(size_t)c] || b->h_site_begin[(size_t)c + 1] == b->h_site_begin[(size_t)c]) continue;
@@ -820,7 +813,9 @@ int fzp_k3_assoc(fzp_ctx *ctx, fzp_batch *b) {
                                b->set_n.p + 2 * ns, b->arows_tmp.p, b->nkept.p);
         }
         FZP_TRY(fzp_exclusive_scan_u32(ctx, b->nkept.p, b->kept_off.p, (size_t)ns, b->totals.p + 3));
-        FZP_TRY(fzp_fetch(ctx, st, tot, b->totals.p + 3, sizeof(uint64_t)));
+        b->h_arow_begin.resize((size_t)b->n_ctg + 1);
+        hipLaunchKernelGGL(k_arow_begin, dim3((b->n_ctg + 1 + 63) / 64), dim3(64), 0, st, b->kept_off.p, b->site_begin.p, b->n_ctg, ns, b->totals.p + 3, b->arow_begin.p);
+        FZP_TRY(fzp_fetch_with_begins(ctx, st, tot, b->totals.p + 3, 1, b->h_arow_begin.data(), b->arow_begin.p, b->n_ctg));
         b->n_arows = (int64_t)tot[0];
         FZP_TRY(b->arows.alloc((size_t)b->n_arows));
         {
@@ -831,10 +826,9 @@ int fzp_k3_assoc(fzp_ctx *ctx, fzp_batch *b) {
     } else {
         b->n_arows = 0;
         FZP_TRY(b->arows.alloc(0));
+        b->h_arow_begin.assign((size_t)b->n_ctg + 1, 0);
+        FZP_TRY(b->arow_begin.zero((size_t)b->n_ctg + 1, st));
     }
-    hipLaunchKernelGGL(k_arow_begin, dim3((b->n_ctg + 1 + 63) / 64), dim3(64), 0, st, b->kept_off.p, b->site_begin.p, b->n_ctg, ns, b->n_arows, b->arow_begin.p);
-    b->h_arow_begin.resize((size_t)b->n_ctg + 1);
-    FZP_TRY(fzp_read_back(ctx, st, b->h_arow_begin.data(), b->arow_begin.p, ((size_t)b->n_ctg + 1) * sizeof(b->h_arow_begin[0])));
     FZP_HIP(hipGetLastError());
     b->have_arows = true;
     return FZP_OK;

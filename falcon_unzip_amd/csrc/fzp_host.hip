@@ -110,16 +110,17 @@ int cores_per_rank() {
 
 // ---------------------------------------------------------------- fzp_fetch (fzp_common.h)
 namespace {
-struct FetchArgs { const uint32_t *src[4]; int n[4]; };
+constexpr int FETCH_MAX = 8;                                       // pieces per fetch: 8 x 64 words of payload, the sequence number behind them
+struct FetchArgs { const uint32_t *src[FETCH_MAX]; int n[FETCH_MAX]; };
 __global__ void __launch_bounds__(64) k_fetch_post(FetchArgs a, volatile uint32_t *slot, uint64_t seq) {
     int base = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < FETCH_MAX; k++) {
         if ((int)threadIdx.x < a.n[k]) slot[base + (int)threadIdx.x] = a.src[k][threadIdx.x];
         base += a.n[k];
     }
     __threadfence_system();                                        // the payload is out before the number that says so
-    if (threadIdx.x == 0) *(volatile uint64_t *)(slot + 256) = seq;
+    if (threadIdx.x == 0) *(volatile uint64_t *)(slot + 64 * FETCH_MAX) = seq;
 }
 }  // namespace
 // How the calling thread waits (r5).  The count it asks for is usually microseconds away (the stages of a step follow each other), so it looks at the mapped word for a
@@ -137,9 +138,9 @@ static int64_t fetch_spin_ns() {
     return v;
 }
 int fzp_fetch(fzp_ctx *ctx, hipStream_t st, const fzp_fetch_piece *pieces, int n_pieces) {
-    if (!ctx || !pieces || n_pieces < 1 || n_pieces > 4) { fzp_set_error("fzp_fetch: bad arguments"); return FZP_EINVAL; }
+    if (!ctx || !pieces || n_pieces < 1 || n_pieces > FETCH_MAX) { fzp_set_error("fzp_fetch: bad arguments"); return FZP_EINVAL; }
     FetchArgs a;
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < FETCH_MAX; k++) {
         a.src[k] = k < n_pieces ? (const uint32_t *)pieces[k].dev : nullptr;
         a.n[k] = k < n_pieces ? (int)(pieces[k].bytes / 4) : 0;
         if (k < n_pieces && ((pieces[k].bytes & 3) || pieces[k].bytes > 256 || !pieces[k].dev || !pieces[k].host)) { fzp_set_error("fzp_fetch: bad piece"); return FZP_EINVAL; }
@@ -154,7 +155,7 @@ int fzp_fetch(fzp_ctx *ctx, hipStream_t st, const fzp_fetch_piece *pieces, int n
     const uint64_t seq = ++ctx->fetch_seq;
     hipLaunchKernelGGL(k_fetch_post, dim3(1), dim3(64), 0, st, a, (volatile uint32_t *)ctx->fetch_slot, seq);
     if (hipGetLastError() != hipSuccess) { fzp_set_error("fzp_fetch: launch failed"); return FZP_EDEVICE; }
-    volatile uint64_t *sq = (volatile uint64_t *)(ctx->fetch_slot + 256);
+    volatile uint64_t *sq = (volatile uint64_t *)(ctx->fetch_slot + 64 * FETCH_MAX);
     const int64_t budget = fetch_spin_ns();
     const auto t0 = std::chrono::steady_clock::now();
     bool have = false;
@@ -459,6 +460,7 @@ extern "C" void fzp_ctx_destroy(fzp_ctx *ctx) {
     for (auto &pb : ctx->pin_live) (void)hipHostFree(pb.first);      // (views handed out die with the ctx, as documented)
     if (ctx->ev_pf) (void)hipEventDestroy(ctx->ev_pf);
     if (ctx->ev_pf_done) (void)hipEventDestroy(ctx->ev_pf_done);
+    if (ctx->ev_late) (void)hipEventDestroy(ctx->ev_late);
     trim_pool(*ctx->pool);
     t_pool.reset();
     if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);

@@ -31,6 +31,7 @@
 #include "fzp_batch.h"
 
 int fzp_batch_text_dev(fzp_ctx *ctx, fzp_batch *b, int what, DevBuf<char> &text, size_t *bytes, std::vector<int64_t> &ctg_begin);
+int fzp_batch_texts_dev(fzp_ctx *ctx, fzp_batch *b, DevBuf<char> &t_vmap, size_t *n_vmap, std::vector<int64_t> &vb, DevBuf<char> &t_atab, size_t *n_atab, std::vector<int64_t> &ab);      // both, one wait (fzp_text.hip)
 
 // ---- background file writes (FZP_PIPE_ASYNC_WRITES): a few threads per ctx drain a queue of per-contig write tasks, so that the
 // page-cache copies (and the file system's occasional throttling) of one call overlap the kernels of the next
@@ -457,7 +458,7 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
     auto t0 = clk::now();
     const auto t_body = t0;
     if (o->flags & FZP_PIPE_REBUILD_INDEX) FZP_TRY(fzp_align_invalidate_index(job));
-    FZP_TRY(fzp_align_run(ctx, job));
+    FZP_TRY(fzp_align_run_deferred(ctx, job));      // (whether the fail list overflowed is asked by fzp_align_to_batch, in the fetch it makes anyway)
     fzp_batch *b = nullptr;
     FZP_TRY(fzp_align_to_batch(ctx, job, &b));
     struct BG { fzp_ctx *c; fzp_batch *b; ~BG() { fzp_batch_destroy(c, b); } } bg{ctx, b};
@@ -556,14 +557,17 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
     FZP_TRY(fzp_batch_result_begin(ctx, b));
     size_t n_vmap = 0, n_atab = 0;
     std::vector<int64_t> vb, ab;
-    FZP_TRY(fzp_batch_text_dev(ctx, b, FZP_TEXT_VARIANT_MAP, owned->d_vmap, &n_vmap, vb));      // (its size comes back through a fetch on the same stream: the records are on the host when it returns)
+    FZP_TRY(fzp_batch_texts_dev(ctx, b, owned->d_vmap, &n_vmap, vb, owned->d_atab, &n_atab, ab));      // (their sizes come back through ONE fetch on the same stream: the records are on the host when it returns; the kernels that write the texts are launched, not waited for)
+    struct Ev2 { hipEvent_t e = nullptr; ~Ev2() { if (e) (void)hipEventDestroy(e); } } ev_put;
+    FZP_HIP(hipEventCreateWithFlags(&ev_put.e, hipEventDisableTiming));
+    FZP_HIP(hipEventRecord(ev_put.e, ctx->stream));
     fzp_result_all ra;
     FZP_TRY(fzp_batch_result_all(ctx, b, &ra));
     struct RG { fzp_result_all *r; ~RG() { fzp_result_all_free(r); } } rg{&ra};
     const ReadMaps *maps = mh.get();
     early.join();                                                // (the early half: long done)
     if (!early_err.empty()) { fzp_set_error("%s", early_err.c_str()); return FZP_EDEVICE; }
-    // the rid_to_phase RECORDS (an array pass per contig) on the pool's threads while this one launches the second text
+    // the rid_to_phase RECORDS (an array pass per contig) on the pool's threads while this one queues the texts' copies and makes the write tasks
     std::vector<std::vector<fzp_r2p>> recs((size_t)nc);
     {
         owned->site_begin.assign(ra.site_begin, ra.site_begin + nc + 1); owned->pvar_begin.assign(ra.pvar_begin, ra.pvar_begin + nc + 1); owned->pread_begin.assign(ra.pread_begin, ra.pread_begin + nc + 1);
@@ -576,13 +580,12 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
         recs[(size_t)c].reserve(P.rows.pid.size());
         readmap_fill(P.rows, nm->ctg_id[c], ctg_index ? ctg_index[c] : c, owned->preads + owned->pread_begin[(size_t)c], owned->pread_begin[(size_t)c + 1] - owned->pread_begin[(size_t)c], recs[(size_t)c], nullptr);
     };
-    // (a rank with two cores keeps the pass on this thread, behind the second text's launch: its cores are busy with the previous call's write tasks, and a thread that has to
+    // (a rank with two cores keeps the pass on this thread: its cores are busy with the previous call's write tasks, and a thread that has to
     // be woken there waits for a time slice -- measured on two cores: 22.5 ms per step with the hand-off, 1.34 x the unconstrained step instead of 1.12 x)
     const bool fill_beside = maps && cores_per_rank() > 2;
     std::thread filler;
     if (fill_beside) filler = std::thread([&]() { (void)pthread_setname_np(pthread_self(), "fzp-fill"); ctx->workers->run(nc, fill_work, std::min(want_threads, 4)); });
     struct JoinF { std::thread &t; ~JoinF() { if (t.joinable()) t.join(); } } filler_join{filler};
-    FZP_TRY(fzp_batch_text_dev(ctx, b, FZP_TEXT_ATABLE, owned->d_atab, &n_atab, ab));
     size_t pin_cap = 0;
     const size_t o_atab = (n_vmap + 63) & ~(size_t)63, o_end = o_atab + ((n_atab + 63) & ~(size_t)63);
     char *pin = (char *)fzp_pinned_acquire(ctx, o_end + 64, &pin_cap);
@@ -592,7 +595,8 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
     const bool async = (o->flags & FZP_PIPE_ASYNC_WRITES) != 0 && o->out_dir;
     if (async && !ctx->writer) { ctx->writer = new FileWriter(); ctx->writer->start(writer_threads()); }
     if (async) { const std::string e = [&] { std::lock_guard<std::mutex> lk(ctx->writer->mu); std::string x; x.swap(ctx->writer->first_error); return x; }(); if (!e.empty()) { fzp_set_error("%s", e.c_str()); return FZP_EINVAL; } }
-    // (both text kernels are done: the atable's size came back through a fetch behind them.)  The texts only have to be there when a contig's write task reaches them
+    // The texts only have to be there when a contig's write task reaches them: their copies go behind the kernels that write them
+    FZP_HIP(hipStreamWaitEvent(st2, ev_put.e, 0));
     if (n_vmap) FZP_HIP(hipMemcpyAsync(pin, owned->d_vmap.p, n_vmap, hipMemcpyDeviceToHost, st2));
     if (n_atab) FZP_HIP(hipMemcpyAsync(pin + o_atab, owned->d_atab.p, n_atab, hipMemcpyDeviceToHost, st2));
     FZP_HIP(hipEventRecord(owned->ev_text, st2));

@@ -145,6 +145,61 @@ int fzp_batch_text_dev(fzp_ctx *ctx, fzp_batch *b, int what, DevBuf<char> &text,
     return FZP_OK;
 }
 
+// Both texts with ONE wait (r5; fzp_pipe.hip).  The lengths of both are scanned, the contigs' first rows are taken from where K2 / K3 left them on the device, the contigs'
+// byte offsets picked from the scans -- and only then the host asks: both totals and both offset tables in one fetch.  It sizes the two buffers and launches the kernels
+// that write the text; nothing waits for those here (the caller's copies go behind them on the stream, or behind an event recorded after this returns).
+namespace {
+__global__ void k_vmap_row_begin(const int64_t *__restrict__ site_begin, int n_ctg, const fzp_site *__restrict__ sites, int64_t n_sites, int64_t n_rows, int64_t *__restrict__ row_begin) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > n_ctg) return;
+    const int64_t s0 = site_begin[c];
+    row_begin[c] = s0 < n_sites ? (int64_t)sites[s0].row_off : n_rows;
+}
+}  // namespace
+int fzp_batch_texts_dev(fzp_ctx *ctx, fzp_batch *b, DevBuf<char> &t_vmap, size_t *n_vmap, std::vector<int64_t> &vb, DevBuf<char> &t_atab, size_t *n_atab, std::vector<int64_t> &ab) {
+    FZP_TRY(fzp_bind(ctx));
+    hipStream_t st = ctx->stream;
+    const int nc = b->n_ctg;
+    vb.assign((size_t)nc + 1, 0); ab.assign((size_t)nc + 1, 0);
+    *n_vmap = 0; *n_atab = 0;
+    if (!b->have_sites || !b->have_arows) { fzp_set_error("fzp_batch_texts: stage has not run"); return FZP_EINVAL; }
+    const int64_t nv = b->n_rows, na = b->n_arows;
+    if (nv >= (1ll << 31) || na >= (1ll << 31)) { fzp_set_error("fzp_batch_texts: %lld / %lld rows (limit 2^31 per batch)", (long long)nv, (long long)na); return FZP_EINVAL; }
+    if ((size_t)(nc + 1) * 8 > 256) {      // many contigs: the offset tables do not fit a fetch -- one text after the other, as before
+        FZP_TRY(fzp_batch_text_dev(ctx, b, FZP_TEXT_VARIANT_MAP, t_vmap, n_vmap, vb));
+        return fzp_batch_text_dev(ctx, b, FZP_TEXT_ATABLE, t_atab, n_atab, ab);
+    }
+    DevBuf<uint32_t> len_v, len_a;
+    DevBuf<uint64_t> totals;
+    DevBuf<int64_t> rb_v, out;      // out: [0, nc]: variant_map's byte offsets per contig, [nc + 1, 2 nc + 1]: atable's
+    FZP_TRY(len_v.alloc((size_t)std::max<int64_t>(nv, 1))); FZP_TRY(len_a.alloc((size_t)std::max<int64_t>(na, 1))); FZP_TRY(totals.alloc(2));
+    FZP_TRY(rb_v.alloc((size_t)nc + 1)); FZP_TRY(out.alloc(2 * ((size_t)nc + 1)));
+    const unsigned gv = (unsigned)((nv + 255) / 256), ga = (unsigned)((na + 255) / 256), gc = (unsigned)((nc + 256) / 256);
+    {
+        ProfScope ps(ctx, "text_vmap");
+        if (nv > 0) hipLaunchKernelGGL(k_vmap_len, dim3(gv), dim3(256), 0, st, nv, b->sites.p, b->n_sites, b->vmap_qid.p, len_v.p);
+        FZP_TRY(fzp_exclusive_scan_u32(ctx, len_v.p, len_v.p, (size_t)nv, totals.p + 0));
+    }
+    {
+        ProfScope ps(ctx, "text_atable");
+        if (na > 0) hipLaunchKernelGGL(k_arow_len, dim3(ga), dim3(256), 0, st, na, b->sites.p, b->arows.p, len_a.p);
+        FZP_TRY(fzp_exclusive_scan_u32(ctx, len_a.p, len_a.p, (size_t)na, totals.p + 1));
+    }
+    hipLaunchKernelGGL(k_vmap_row_begin, dim3((nc + 1 + 63) / 64), dim3(64), 0, st, b->site_begin.p, nc, b->sites.p, b->n_sites, nv, rb_v.p);
+    hipLaunchKernelGGL(k_pick_offsets, dim3(gc), dim3(256), 0, st, nc + 1, rb_v.p, nv, len_v.p, totals.p + 0, out.p);
+    hipLaunchKernelGGL(k_pick_offsets, dim3(gc), dim3(256), 0, st, nc + 1, b->arow_begin.p, na, len_a.p, totals.p + 1, out.p + nc + 1);
+    uint64_t tot[2] = {0, 0};
+    const fzp_fetch_piece fp[3] = {{tot, totals.p, 16}, {vb.data(), out.p, ((size_t)nc + 1) * 8}, {ab.data(), out.p + nc + 1, ((size_t)nc + 1) * 8}};
+    FZP_TRY(fzp_fetch(ctx, st, fp, 3));
+    if (tot[0] >= (1ull << 32) || tot[1] >= (1ull << 32)) { fzp_set_error("fzp_batch_texts: %llu / %llu bytes of text (limit 4 GiB per batch)", (unsigned long long)tot[0], (unsigned long long)tot[1]); return FZP_EINVAL; }
+    FZP_TRY(t_vmap.alloc((size_t)tot[0] + 16)); FZP_TRY(t_atab.alloc((size_t)tot[1] + 16));
+    if (nv > 0) { ProfScope ps(ctx, "text_vmap"); hipLaunchKernelGGL(k_vmap_put, dim3(gv), dim3(256), 0, st, nv, b->sites.p, b->n_sites, b->vmap_qid.p, len_v.p, t_vmap.p); }
+    if (na > 0) { ProfScope ps(ctx, "text_atable"); hipLaunchKernelGGL(k_arow_put, dim3(ga), dim3(256), 0, st, na, b->sites.p, b->arows.p, len_a.p, t_atab.p); }
+    FZP_HIP(hipGetLastError());
+    *n_vmap = (size_t)tot[0]; *n_atab = (size_t)tot[1];
+    return FZP_OK;      // (len_v / len_a go back to the pool here: whatever takes them next is launched on this stream, behind the kernels that read them)
+}
+
 extern "C" int fzp_batch_text(fzp_ctx *ctx, fzp_batch *b, int what, char **text, size_t *len, int64_t **ctg_begin) {
     if (!ctx || !b || !text || !len || (what != FZP_TEXT_VARIANT_MAP && what != FZP_TEXT_ATABLE)) { fzp_set_error("fzp_batch_text: bad arguments"); return FZP_EINVAL; }
     DevBuf<char> d;

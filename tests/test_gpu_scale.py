@@ -291,6 +291,14 @@ def test_fail_list_overflow_at_20000_reads(eng, monkeypatch):
     job.run()
     s1, h1 = job.summaries(), job.cigar_hashes()
     assert np.array_equal(s0, s1) and np.array_equal(h0, h1)
+    # the same question asked late: fzp_job_phase_write's run leaves "did the fail list overflow?" to the fetch of fzp_align_to_batch, which then does the retry itself
+    ids = ["%06dF" % c for c in range(10)]
+    st1, _ = job.phase_write(ids)
+    h2 = job.cigar_hashes().copy()
+    monkeypatch.delenv("FZP_TB_WINDOW"); monkeypatch.delenv("FZP_SWB_64")
+    st0, _ = job.phase_write(ids)
+    keys = ("n_aligned", "n_rec", "n_sites", "n_rows", "n_arows", "n_pvars", "n_preads")
+    assert np.array_equal(h0, h2) and {k: st1[k] for k in keys} == {k: st0[k] for k in keys} and st0["n_sites"] > 1000
     job.close()
 
 
