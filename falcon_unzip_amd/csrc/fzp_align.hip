@@ -2972,7 +2972,7 @@ static int align_run(fzp_ctx *ctx, fzp_alnjob *j, bool defer_overflow) {
                 auto kw_mid = tb_stats ? k_tb_walk<false, true> : k_tb_walk<false, false>;
                 auto kw_full = k_tb_walk<true, false>;
                 // the bit-sliced kernel's slots: 8-byte records; the others: whole masks
-                static const bool walk_old = getenv("FZP_TBW_OLD") != nullptr;      // (A/B: the 16-walker form)
+                const bool walk_old = getenv("FZP_TBW_OLD") != nullptr;      // (A/B and the parity test: the 16-walker form on the same records)
                 if (tb_stats || walk_old)
                     hipLaunchKernelGGL(kw_mid, dim3(wg), dim3(64 * TBW_WPG), 0, st2, (const uint32_t *)B.list.p, (const uint64_t *)nullptr, (const uint64_t *)B.ptot.p, 0u,
                                        (const DpInfo *)B.info.p, (const int64_t *)B.tbo.p, (const int64_t *)B.mvo.p, (const int32_t *)B.tbs.p, (const void *)B.tb.p, (const ulonglong2 *)B.mvw.p, B.raw.p, B.wout.p,

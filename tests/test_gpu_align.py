@@ -511,7 +511,8 @@ def test_the_three_dp_kernels_agree(eng, oracle, monkeypatch):
     reads = [blob[off[i]:off[i + 1]] for i in range(n)]
     got = {}
     for mode, env in (("default", {}), ("wave_per_read", {"FZP_SW_NO_BITS": "1"}), ("lane64", {"FZP_SWB_64": "1"}), ("pair", {"FZP_SWB_PAIR": "1"}),
-                      ("pair_short_limit", {"FZP_SWB_PAIR": "1", "FZP_SWB_MAX_STEPS": "9000"}), ("three_chunks", {"FZP_SW_CHUNKS": "3"}), ("bases_from_hbm", {"FZP_SWB_NO_RING": "1", "FZP_SWB_64": "1"})):
+                      ("pair_short_limit", {"FZP_SWB_PAIR": "1", "FZP_SWB_MAX_STEPS": "9000"}), ("three_chunks", {"FZP_SW_CHUNKS": "3"}), ("bases_from_hbm", {"FZP_SWB_NO_RING": "1", "FZP_SWB_64": "1"}),
+                      ("walk16", {"FZP_TBW_OLD": "1"})):      # (the 16-walkers-per-wave walk on the records laid out for the 32-walker one)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         job = _lib.align_job_raw(eng, [ctg], blob, off, np.zeros(n, np.int32))
