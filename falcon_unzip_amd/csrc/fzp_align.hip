@@ -1746,8 +1746,18 @@ constexpr int TBH_STRIDE = TBH_SUB * 8 + 8;      // bytes per walker: +8 stagger
 __global__ void __launch_bounds__(64) k_tb_walk_h(const uint32_t *__restrict__ order, const uint64_t *__restrict__ hi_dev, const DpInfo *__restrict__ info, const int64_t *__restrict__ tbo,
                                                   const int64_t *__restrict__ mvo, const void *__restrict__ tb_, const ulonglong2 *__restrict__ mvw,
                                                   uint32_t *__restrict__ raw, WalkOut *__restrict__ wout, uint32_t *__restrict__ fail_list, uint64_t *__restrict__ n_fail, uint32_t fail_cap,
-                                                  int32_t win_half) {
-    __shared__ __attribute__((aligned(16))) uint8_t lds_raw[16 + TBH_RPW * TBH_STRIDE];      // (16 bytes in front: the walk asks for the two records below its own, also from a piece's first)
+                                                  int32_t win_half, uint64_t *__restrict__ wlog) {
+    // wlog (builds with -DFZP_TBH_LOG, FZP_TBH_WAVE_LOG=1; tools/runs/tbh_waves.py): per wave {start, end of the 100 MHz counter, shader cycles inside the step loops,
+    // shader cycles between "park" and the walk (the prefetch's arrival, the move words, the next prefetch's issue)}
+#ifdef FZP_TBH_LOG
+    const uint64_t lg_t0 = __builtin_amdgcn_s_memrealtime();
+    uint64_t lg_inner = 0, lg_stage = 0, lg_iters = 0;
+#define TBH_CLK() __builtin_amdgcn_s_memtime()
+#endif
+#ifndef FZP_TBH_PAD
+#define FZP_TBH_PAD 0      // (measurement builds, tools/runs/tbw_variants.sh: extra LDS per wave = fewer walkers per CU)
+#endif
+    __shared__ __attribute__((aligned(16))) uint8_t lds_raw[16 + TBH_RPW * TBH_STRIDE + FZP_TBH_PAD];      // (16 bytes in front: the walk asks for the two records below its own, also from a piece's first)
     uint8_t *lds = lds_raw + 16;
     const int lane = threadIdx.x & 63;
     const int64_t hi = (int64_t)*hi_dev;
@@ -1769,6 +1779,8 @@ __global__ void __launch_bounds__(64) k_tb_walk_h(const uint32_t *__restrict__ o
     int32_t ts = active ? di.best_t : -1;
     int32_t k = di.best_lane, i = -1;
     uint64_t w_cur = 0, w_prev = 0, pref_word = 0;      // move words: w_cur = 64-step block `wchunk` (the one ts is in once the walker has joined), w_prev the one below, pref_word the one below that
+    uint64_t pend_word = 0;                             // ... and the one on its way to become pref_word
+    bool pend_take = false, pend_none = true;
     int32_t wchunk = -1;
     if (active) {   // i0 at the start step = i0 before its 64-step block + DOWN moves up to and including it
         const ulonglong2 mw = mvr[ts >> 6];
@@ -1796,10 +1808,16 @@ __global__ void __launch_bounds__(64) k_tb_walk_h(const uint32_t *__restrict__ o
     uint2 pf[TBH_RPW / 2];
     uint8_t *park0 = lds + (lane >> 5) * TBH_STRIDE + (lane & 31) * 8;        // load p holds the pieces of walkers 2p (lanes 0..31) and 2p + 1 (lanes 32..63)
     // half-block s of the wave: 256 B per walker, 32 walkers side by side
+    // (only the pieces somebody will walk: a walker that has not started yet -- its path begins further down -- or is done asks for nothing.  The wave log said why this
+    //  matters: 74 % of a wave's cycles went by between "park" and the walk, waiting for the 8 KB of the iteration -- the walk is bound by what HBM delivers, and part of
+    //  what it delivered was pieces of walkers that were not there)
 #define TBH_ISSUE(s_)                                                                                                                     \
     {                                                                                                                                     \
         const tbh_gptr2 r_ = (tbh_gptr2)(uint64_t)(row0 + ((int64_t)((s_) >> 1) * 4096 + ((s_) & 1) * 2048) * 8);                          \
-        _Pragma("unroll") for (int p = 0; p < TBH_RPW / 2; p++) { const tbh_u32x2 v_ = r_[64 * p + lane]; pf[p] = make_uint2(v_.x, v_.y); } \
+        const uint64_t want_ = __ballot(active && (ts >> 5) >= (s_));                                                                     \
+        const uint64_t mine_ = want_ >> (lane >> 5);      /* bit 2p: does the walker whose piece this lane fetches in load p want it? */   \
+        _Pragma("unroll") for (int p = 0; p < TBH_RPW / 2; p++)                                                                            \
+            if ((mine_ >> (2 * p)) & 1ull) { const tbh_u32x2 v_ = r_[64 * p + lane]; pf[p] = make_uint2(v_.x, v_.y); }                       \
     }
     if (sc >= 0) TBH_ISSUE(sc)
     for (; sc >= 0; sc--) {
@@ -1807,14 +1825,21 @@ __global__ void __launch_bounds__(64) k_tb_walk_h(const uint32_t *__restrict__ o
         if (active && (uint32_t)(k - wlo) >= wn) { active = false; failed = true; }      // the path needs a lane the 8-byte records do not hold
         if (!__any(active)) break;
         // park the half-block (every walker is done with the old contents)
+#ifdef FZP_TBH_LOG
+        const uint64_t lg_a = TBH_CLK();
+#endif
 #pragma unroll
         for (int p = 0; p < TBH_RPW / 2; p++) *(uint2 *)(park0 + 2 * p * TBH_STRIDE) = pf[p];
+        if (pend_take) pref_word = pend_none ? 0ull : pend_word;              // (asked for in the last iteration; the parks above have waited for every load of it)
         if (active && (ts >> 5) > sc) { active = false; failed = true; }      // (cannot happen: a step goes down by one or two.  If it does the slot is computed and walked again with whole masks)
         const bool now = active && (ts >> 5) == sc;                           // this walker's path is in the half-block (the others have not started yet)
-        if (now && (sc >> 1) != wchunk) {                                     // it has come down into the next 64-step block
-            w_cur = w_prev; w_prev = pref_word; wchunk = sc >> 1;
-            pref_word = wchunk >= 2 ? mvr[wchunk - 2].x : 0ull;
-        }
+        pend_take = now && (sc >> 1) != wchunk;
+        if (pend_take) { w_cur = w_prev; w_prev = pref_word; wchunk = sc >> 1; }      // it has come down into the next 64-step block
+        // The move word two blocks down, for the walkers that have just come down one; looked at in the NEXT iteration (a select right behind the load made the compiler wait
+        // for it there, a trip to memory in front of the prefetch's issue).  Only those walkers ask: every lane asking in every iteration was 4 KB of scattered lines per wave
+        // and iteration on top of the 8 KB the wave is there for -- and the walk is bound by what HBM delivers (k1_traceback 2.68 -> 2.87 ms)
+        if (pend_take) pend_word = mvr[max(wchunk - 2, 0)].x;
+        pend_none = wchunk < 2;
         if (sc > 0) TBH_ISSUE(sc - 1)
         TBW_WAVE_SYNC();
         // ---- walk inside the piece
@@ -1834,6 +1859,10 @@ __global__ void __launch_bounds__(64) k_tb_walk_h(const uint32_t *__restrict__ o
         uint64_t acc = 0;                  // this piece's ops, the OLDEST in the top bits (turned round behind the loop)
         uint32_t na = 0;
         uint2 m = *(const uint2 *)(p16 + 16);
+#ifdef FZP_TBH_LOG
+        const uint64_t lg_b = TBH_CLK();
+        lg_stage += lg_b - lg_a; lg_iters++;
+#endif
         while (bad >= 0) {
             const uint2 n2 = *(const uint2 *)p16, n1 = *(const uint2 *)(p16 + 8);
             const uint32_t db = (m.x >> kk) & 1u;
@@ -1856,6 +1885,9 @@ __global__ void __launch_bounds__(64) k_tb_walk_h(const uint32_t *__restrict__ o
             bad = i | (ts - i) | (ts - c_lo) | (kk - kw_lo) | (kw_hi - kk);
         }
         k = kk + 16;
+#ifdef FZP_TBH_LOG
+        lg_inner += TBH_CLK() - lg_b;
+#endif
         if (na) {      // the piece's ops behind the pending bits (nb < 32 of them in rawacc): whole words out, the rest stays pending
             uint64_t r = __builtin_bitreverse64(acc);                         // op g of na -> group 31 - g, its two bits swapped ...
             r = ((r & 0x5555555555555555ull) << 1) | ((r >> 1) & 0x5555555555555555ull);      // ... and swapped back
@@ -1873,6 +1905,9 @@ __global__ void __launch_bounds__(64) k_tb_walk_h(const uint32_t *__restrict__ o
         TBW_WAVE_SYNC();
     }
 #undef TBH_ISSUE
+#ifdef FZP_TBH_LOG
+    if (wlog && lane == 0) { uint64_t *o_ = wlog + 8 * (size_t)blockIdx.x; o_[0] = lg_t0; o_[1] = __builtin_amdgcn_s_memrealtime(); o_[2] = lg_inner; o_[3] = lg_stage; o_[4] = lg_iters; }
+#endif
     if (!have) return;
     if (failed) {
         const uint32_t f = (uint32_t)atomicAdd((unsigned long long *)n_fail, 1ull);
@@ -2972,6 +3007,11 @@ static int align_run(fzp_ctx *ctx, fzp_alnjob *j, bool defer_overflow) {
                 auto kw_mid = tb_stats ? k_tb_walk<false, true> : k_tb_walk<false, false>;
                 auto kw_full = k_tb_walk<true, false>;
                 // the bit-sliced kernel's slots: 8-byte records; the others: whole masks
+                uint64_t *tbh_log = nullptr;
+                if (getenv("FZP_TBH_WAVE_LOG")) {      // (measurement aid; the kernel writes it in -DFZP_TBH_LOG builds only)
+                    const size_t nwv = (size_t)(ns + TBH_RPW - 1) / TBH_RPW;
+                    FZP_TRY(j->wave_log.alloc(8 * nwv + 8)); FZP_TRY(j->wave_log.zero(8 * nwv + 8, st2)); tbh_log = j->wave_log.p; j->wave_log_n = (int64_t)(2 * nwv);
+                }
                 const bool walk_old = getenv("FZP_TBW_OLD") != nullptr;      // (A/B and the parity test: the 16-walker form on the same records)
                 if (tb_stats || walk_old)
                     hipLaunchKernelGGL(kw_mid, dim3(wg), dim3(64 * TBW_WPG), 0, st2, (const uint32_t *)B.list.p, (const uint64_t *)nullptr, (const uint64_t *)B.ptot.p, 0u,
@@ -2980,7 +3020,7 @@ static int align_run(fzp_ctx *ctx, fzp_alnjob *j, bool defer_overflow) {
                 else
                     hipLaunchKernelGGL(k_tb_walk_h, dim3((ns + TBH_RPW - 1) / TBH_RPW), dim3(64), 0, st2, (const uint32_t *)B.list.p, (const uint64_t *)B.ptot.p, (const DpInfo *)B.info.p,
                                        (const int64_t *)B.tbo.p, (const int64_t *)B.mvo.p, (const void *)B.tb.p, (const ulonglong2 *)B.mvw.p, B.raw.p, B.wout.p,
-                                       B.fail_list.p, B.ptot.p + 3, (uint32_t)FAIL_CAP, win_half);
+                                       B.fail_list.p, B.ptot.p + 3, (uint32_t)FAIL_CAP, win_half, tbh_log);
                 hipLaunchKernelGGL(kw_full, dim3(wg), dim3(64 * TBW_WPG), 0, st2, (const uint32_t *)B.list.p, (const uint64_t *)B.ptot.p, (const uint64_t *)nullptr, ns,
                                    (const DpInfo *)B.info.p, (const int64_t *)B.tbo.p, (const int64_t *)B.mvo.p, (const int32_t *)B.tbs.p, (const void *)B.tbw.p, (const ulonglong2 *)B.mvw.p, B.raw.p, B.wout.p,
                                    (unsigned long long *)nullptr, (uint32_t *)nullptr, (uint64_t *)nullptr, 0u, 16);
