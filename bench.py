@@ -415,15 +415,23 @@ def constrained_child(args, n_cores, contigs, blob, off, read_ctg, ids, name_tab
             for k in range(3):
                 one(k)
             eng.synchronize(); eng.pipe_flush()
+            th0 = thread_cpu()
             t0, c0 = time.perf_counter(), time.process_time()
             for k in range(n_steps):
                 one(3 + k)
             eng.synchronize(); eng.pipe_flush()
             dt, cpu = time.perf_counter() - t0, time.process_time() - c0
+            th1 = thread_cpu()
+            by_name = {}      # who burns the rank's two cores: CPU ms per step by thread name (the runtime's own threads carry the process's name)
+            for tid, (nm, tot, sy) in th1.items():
+                d = tot - th0.get(tid, (nm, 0.0, 0.0))[1]
+                key = nm.rstrip("0123456789") if nm.startswith("fzp-") else ("main" if tid == os.getpid() else "runtime/" + nm)
+                by_name[key] = by_name.get(key, 0.0) + d
+            by_name = {k: round(v / n_steps * 1e3, 2) for k, v in sorted(by_name.items(), key=lambda kv: -kv[1]) if v / n_steps * 1e3 >= 0.05}
             job.close(); eng.close()
             shutil.rmtree(root, ignore_errors=True)
             os.write(wr, json.dumps({"ms_per_step": round(dt / n_steps * 1e3, 3), "host_cpu_ms_per_step": round(cpu / n_steps * 1e3, 2), "steps": n_steps, "cpus": n_cores,
-                                     "local_world_size": 8}).encode())
+                                     "local_world_size": 8, "cpu_ms_per_step_by_thread": by_name}).encode())
             code = 0
         except BaseException as e:      # noqa: BLE001 -- reported by the parent
             try:
