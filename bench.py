@@ -172,6 +172,15 @@ def host_cores():
     return max(1, n)
 
 
+def shm_with_room(need_bytes):
+    """/dev/shm when it is there and has `need_bytes` free (a container's default one has 64 MB), else None"""
+    try:
+        st = os.statvfs("/dev/shm")
+        return "/dev/shm" if os.path.isdir("/dev/shm") and st.f_bavail * st.f_frsize >= need_bytes else None
+    except OSError:
+        return None
+
+
 def fs_of(path):
     """file system type of the mount that holds `path` (/proc/mounts)"""
     best, typ = "", ""
@@ -406,7 +415,7 @@ def constrained_child(args, n_cores, contigs, blob, off, read_ctg, ids, name_tab
             from falcon_unzip_amd import _lib
             eng = _lib.Engine(0)
             job = _lib.align_job_raw(eng, contigs, blob, off, read_ctg)
-            root = tempfile.mkdtemp(prefix="fzp_bench_2c_", dir="/dev/shm" if os.path.isdir("/dev/shm") and not args.out_root else args.out_root)
+            root = tempfile.mkdtemp(prefix="fzp_bench_2c_", dir=(shm_with_room(4 << 30) if not args.out_root else args.out_root))
             n_steps = int(os.environ.get("FZP_BENCH_2C_STEPS", "20"))      # (twenty: ten steps of a fresh process varied by +-2 ms run to run)
 
             def one(k):
@@ -460,7 +469,7 @@ def files_leg(args, eng, contigs, blob, off, read_ctg, ids, name_tab, maps, mine
     a contig group ahead of the lanes) inside the clock -- what scripts/fc_unzip_phase_gpu.py does per rank.  Three calls, the best of the last two; `sync` (N > 1): called
     before every call so that the ranks run theirs side by side on the node's shared host cores.  -> (seconds, stats, records, output dir of the last call)"""
     from falcon_unzip_amd import _lib
-    reads_dir = write_reads_tree(contigs, blob, off, read_ctg, ids, name_tab, "/dev/shm" if os.path.isdir("/dev/shm") else out_root)
+    reads_dir = write_reads_tree(contigs, blob, off, read_ctg, ids, name_tab, shm_with_room((2 << 30) * max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))) or out_root)
     try:
         gb = int(gc * args.reads_per_contig * args.read_len * 1.09)      # (file sizes: bases + names)
         runs = []
@@ -590,6 +599,11 @@ def main():
     # writer threads took 2 ms or 30 ms of system time each, in the order the runs came), else $TMPDIR, else wherever a directory can be made
     for cand in ((args.out_root,) if args.out_root else ()) + ("/dev/shm", None, REPO):
         try:
+            # (room for every step's tree, the from-files leg's inputs and trees of this rank AND of the ranks beside it: a memory file system of a few GB -- a container's
+            #  default /dev/shm -- is passed over rather than filled up in the middle of a run)
+            st_fs = os.statvfs(cand or tempfile.gettempdir())
+            if cand != args.out_root and st_fs.f_bavail * st_fs.f_frsize < (6 << 30) * max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world))):
+                continue
             out_root = tempfile.mkdtemp(prefix="fzp_bench_r%d_" % rank, dir=cand)
             break
         except OSError:
