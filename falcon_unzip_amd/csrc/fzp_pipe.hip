@@ -47,6 +47,15 @@ struct FileWriter {
         for (int i = 0; i < n; i++)
             th.emplace_back([this, i] {
                 { char nm[16]; snprintf(nm, sizeof nm, "fzp-wr%d", i); (void)pthread_setname_np(pthread_self(), nm); }
+                // A rank with few cores puts its writers into the IDLE scheduling class (r5): they write 39 MB per bench step and are the largest consumer of such a rank's CPU
+                // (13 of 28 ms), and whenever one of them holds a core the launch thread -- woken by the device, with a kernel to launch -- waits for a time slice.  Idle-class
+                // threads run when nothing else wants the core: the two-core step went 21.4 -> 18.6 ms (1.28 -> 1.12 x the unconstrained one; tools/runs/writer_sched_ab.sh);
+                // with sixteen cores nothing changes.  FZP_WRITER_SCHED = other | idle | batch overrides; push() below keeps a starved queue from growing.
+                {
+                    const char *e = getenv("FZP_WRITER_SCHED");
+                    const int cls = e ? (!strcmp(e, "idle") ? SCHED_IDLE : (!strcmp(e, "batch") ? SCHED_BATCH : SCHED_OTHER)) : (cores_per_rank() <= 4 ? SCHED_IDLE : SCHED_OTHER);
+                    if (cls != SCHED_OTHER) { struct sched_param sp; memset(&sp, 0, sizeof sp); (void)pthread_setschedparam(pthread_self(), cls, &sp); }
+                }
                 for (;;) {
                     std::function<void()> job;
                     {
@@ -66,9 +75,22 @@ struct FileWriter {
                 }
             });
     }
+    static constexpr size_t MAX_QUEUED = 160;      // tasks (eight bench steps' worth): beyond that the pushing thread writes the oldest one itself -- a queue whose writers get no
+                                                   // core (idle class on a saturated node) must not grow by a step's pinned blocks per step
     void push(std::function<void()> f) {
-        { std::lock_guard<std::mutex> lk(mu); q.push_back(std::move(f)); }
+        std::function<void()> mine;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            q.push_back(std::move(f));
+            if (q.size() > MAX_QUEUED) { mine = std::move(q.front()); q.pop_front(); running++; }
+        }
         cv.notify_one();
+        if (mine) {
+            mine();
+            std::lock_guard<std::mutex> lk(mu);
+            running--;
+            if (q.empty() && running == 0) idle.notify_all();
+        }
     }
     void fail(const std::string &e) { std::lock_guard<std::mutex> lk(mu); if (first_error.empty()) first_error = e; }
     std::string drain() {
