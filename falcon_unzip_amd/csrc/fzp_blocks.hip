@@ -34,13 +34,13 @@ __global__ void __launch_bounds__(256) k_link_flag(const fzp_arow *__restrict__ 
     flag[i] = (d >= 6 || d <= -6) ? 1u : 0u;
 }
 
-__global__ void __launch_bounds__(256) k_link_emit(const fzp_arow *__restrict__ rows, int64_t n, const uint32_t *__restrict__ idx, int64_t n_links,
+__global__ void __launch_bounds__(256) k_link_emit(const fzp_arow *__restrict__ rows, int64_t n, const uint32_t *__restrict__ idx, const uint64_t *__restrict__ n_links_dev,
                                                    int32_t *__restrict__ lk_i1, int32_t *__restrict__ lk_i2, int32_t *__restrict__ lk_cis, int32_t *__restrict__ lk_trans,
                                                    uint32_t *__restrict__ left_n, uint32_t *__restrict__ right_n, uint32_t *__restrict__ fr2) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     uint32_t l = idx[i];
-    uint32_t nxt = (i + 1 < n) ? idx[i + 1] : (uint32_t)n_links;
+    uint32_t nxt = (i + 1 < n) ? idx[i + 1] : (uint32_t)*n_links_dev;      // (the number of links from where the scan left it: the host never asks -- they are at most the rows)
     if (nxt == l) return;   // not kept
     fzp_arow r = rows[i];
     lk_i1[l] = r.site1; lk_i2[l] = r.site2;
@@ -50,11 +50,11 @@ __global__ void __launch_bounds__(256) k_link_emit(const fzp_arow *__restrict__ 
     atomicMin(&fr2[r.site2], l);
 }
 
-__global__ void __launch_bounds__(256) k_left_fill(int64_t n_links, const int32_t *__restrict__ lk_i1, const int32_t *__restrict__ lk_i2,
+__global__ void __launch_bounds__(256) k_left_fill(const uint64_t *__restrict__ n_links_dev, const int32_t *__restrict__ lk_i1, const int32_t *__restrict__ lk_i2,
                                                    const int32_t *__restrict__ lk_cis, const int32_t *__restrict__ lk_trans, const uint32_t *__restrict__ left_off,
                                                    uint32_t *__restrict__ left_fill, int32_t *__restrict__ left_lk, int4 *__restrict__ left_pk) {
     int64_t l = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (l >= n_links) return;
+    if (l >= (int64_t)*n_links_dev) return;
     int32_t s = lk_i2[l];
     uint32_t slot = atomicAdd(&left_fill[s], 1u);
     left_lk[left_off[s] + slot] = (int32_t)l;
@@ -410,27 +410,22 @@ int fzp_k4_blocks(fzp_ctx *ctx, fzp_batch *b) {
                                       fzp_ones(b->fr2, (size_t)ns)};
         FZP_TRY(fzp_fill(ctx, st, fl, 5));      // one launch (the runtime made twelve fills of these five)
     }
-    int64_t n_links = 0;
+    // the links: at most the rows, so everything that holds them is sized by the rows and the kernels read their number from where the scan left it (r5: one read-back less)
+    FZP_TRY(b->lk_i1.alloc((size_t)na)); FZP_TRY(b->lk_i2.alloc((size_t)na));
+    FZP_TRY(b->lk_cis.alloc((size_t)na)); FZP_TRY(b->lk_trans.alloc((size_t)na)); FZP_TRY(b->left_lk.alloc((size_t)na));
+    FZP_TRY(b->left_pk.alloc((size_t)na));
     if (na > 0) {
         hipLaunchKernelGGL(k_link_flag, dim3(grid_for(na, 256, 1 << 30)), dim3(256), 0, st, b->arows.p, na, b->lk_flag.p);
         FZP_TRY(fzp_exclusive_scan_u32(ctx, b->lk_flag.p, b->lk_flag.p, (size_t)na, b->totals.p + 4));
-        uint64_t t = 0;
-        FZP_TRY(fzp_fetch(ctx, st, &t, b->totals.p + 4, sizeof t));
-        n_links = (int64_t)t;
-    }
-    FZP_TRY(b->lk_i1.alloc((size_t)n_links)); FZP_TRY(b->lk_i2.alloc((size_t)n_links));
-    FZP_TRY(b->lk_cis.alloc((size_t)n_links)); FZP_TRY(b->lk_trans.alloc((size_t)n_links)); FZP_TRY(b->left_lk.alloc((size_t)n_links));
-    FZP_TRY(b->left_pk.alloc((size_t)n_links));
-    if (n_links > 0) {
         ProfScope ps(ctx, "k4_links");
-        hipLaunchKernelGGL(k_link_emit, dim3(grid_for(na, 256, 1 << 30)), dim3(256), 0, st, b->arows.p, na, b->lk_flag.p, n_links, b->lk_i1.p, b->lk_i2.p,
+        hipLaunchKernelGGL(k_link_emit, dim3(grid_for(na, 256, 1 << 30)), dim3(256), 0, st, b->arows.p, na, b->lk_flag.p, b->totals.p + 4, b->lk_i1.p, b->lk_i2.p,
                            b->lk_cis.p, b->lk_trans.p, b->left_n.p, b->right_n.p, b->fr2.p);
     }
     if (ns > 0) {
         FZP_TRY(fzp_exclusive_scan_u32(ctx, b->left_n.p, b->left_off.p, (size_t)ns, nullptr));
         FZP_TRY(fzp_exclusive_scan_u32(ctx, b->right_n.p, b->right_off.p, (size_t)ns, nullptr));
-        if (n_links > 0)
-            hipLaunchKernelGGL(k_left_fill, dim3(grid_for(n_links, 256, 1 << 30)), dim3(256), 0, st, n_links, b->lk_i1.p, b->lk_i2.p, b->lk_cis.p, b->lk_trans.p,
+        if (na > 0)
+            hipLaunchKernelGGL(k_left_fill, dim3(grid_for(na, 256, 1 << 30)), dim3(256), 0, st, b->totals.p + 4, b->lk_i1.p, b->lk_i2.p, b->lk_cis.p, b->lk_trans.p,
                                b->left_off.p, b->left_fill.p, b->left_lk.p, b->left_pk.p);
         {
             ProfScope ps(ctx, "k4_greedy");
