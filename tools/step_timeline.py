@@ -1,4 +1,4 @@
-"""where is the GPU idle inside a step?  usage: python3 tools/step_timeline.py <kernel_trace.csv> [min_gap_us]
+"""where is the GPU idle inside a step?  usage: python3 tools/step_timeline.py <kernel_trace.csv> [min_gap_us] [launches.txt: the step's launches, one per line]
 Takes rocprofv3's kernel trace of a bench run, finds the steps (from one k_index_stage* launch to the next), and for the LAST complete step lists every interval in which no kernel
 of the process was running, with the kernel before and after it; then the sums."""
 import csv, sys, re
@@ -41,3 +41,8 @@ for s, e, n in step:
 print("launches of the step by kernel (ms, count):")
 for n, (d, k) in sorted(dur.items(), key=lambda kv: -kv[1][0])[:40]:
     print("  %7.3f %4d  %s" % (d / 1e6, k, n[:80]))
+if len(sys.argv) > 3:
+    with open(sys.argv[3], "w") as f:
+        f.write("# start us (from the step's first kernel), duration us, kernel\n")
+        for st_, en_, n in step:
+            f.write("%9.1f %8.1f  %s\n" % ((st_ - step[0][0]) / 1e3, (en_ - st_) / 1e3, n[:70]))
