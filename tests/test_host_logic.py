@@ -359,3 +359,26 @@ def test_rid_to_phase_all_formatter(lib):
     recs["ctg"][7] = 3
     with pytest.raises(lib.FzpError):
         lib.format_rid_to_phase_all(recs, ids)
+
+
+def test_bench_scratch_choice_and_step_timeline(tmp_path):
+    """bench.py takes a memory file system for its trees only when it has room (a container's default /dev/shm has 64 MB); tools/step_timeline.py finds a step's idle
+    intervals in a kernel trace (here: a made-up one -- two steps of three launches with one 40 us hole)."""
+    import subprocess
+    import sys
+    import bench
+    assert bench.shm_with_room(1 << 62) is None
+    assert bench.shm_with_room(1) in ("/dev/shm", None)
+    rows = ['"Kind","Agent_Id","Queue_Id","Stream_Id","Thread_Id","Dispatch_Id","Kernel_Id","Kernel_Name","Correlation_Id","Start_Timestamp","End_Timestamp"']
+    t = 1_000_000
+    for step in range(3):
+        base = t + step * 5_000_000
+        for name, st, en in (("(anonymous namespace)::k_index_stage_anch(int)", 0, 100_000), ("void (anonymous namespace)::k_swb<true>(long)", 100_000, 2_000_000),
+                             ("(anonymous namespace)::k_tb_walk_h(int)", 2_040_000, 3_000_000)):
+            rows.append('"KERNEL_DISPATCH","Agent 2",1,1,1,1,1,"%s",1,%d,%d' % (name, base + st, base + en))
+    p = tmp_path / "kt.csv"
+    p.write_text("\n".join(rows) + "\n")
+    out = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "step_timeline.py"), str(p), "15", str(tmp_path / "l.txt")],
+                         capture_output=True, text=True, check=True).stdout
+    assert "3 launches" in out and "40.0  k_swb<true> -> k_tb_walk_h" in out
+    assert "k_tb_walk_h" in (tmp_path / "l.txt").read_text()
