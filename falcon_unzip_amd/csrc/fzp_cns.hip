@@ -372,9 +372,11 @@ extern "C" void fzp_tigs_free(fzp_tigs *t) {
 
 extern "C" int fzp_batch_consensus(fzp_ctx *ctx, fzp_batch *b, fzp_tigs *out) { return fzp_batch_consensus_v(ctx, b, 3, out); }
 
-extern "C" int fzp_batch_consensus_v(fzp_ctx *ctx, fzp_batch *b, int version, fzp_tigs *out) {
-    if (!ctx || !b || !out || version < 1 || version > 3) { fzp_set_error("fzp_batch_consensus: bad arguments"); return FZP_EINVAL; }
-    memset(out, 0, sizeof *out);
+// The consensus with its sequence bytes left ON THE DEVICE (r5; fzp_pipe.hip copies them into the pinned block its write tasks own, under whatever runs next, and the
+// tasks write every tig from where it lies -- the C-ABI entry below downloads them as before): the tig table (seq_off / seq_len into `seq`) comes back on the host.
+int fzp_batch_consensus_dev(fzp_ctx *ctx, fzp_batch *b, int version, std::vector<fzp_tig> &tigs, DevBuf<uint8_t> &seq, uint64_t *n_seq) {
+    if (!ctx || !b || version < 1 || version > 3) { fzp_set_error("fzp_batch_consensus: bad arguments"); return FZP_EINVAL; }
+    tigs.clear(); *n_seq = 0;
     if (!b->have_aln || !b->have_blocks || !b->have_preads || !b->have_sites) { fzp_set_error("fzp_batch_consensus: run FZP_STAGE_ALL on a batch with alignment records first"); return FZP_EINVAL; }
     FZP_TRY(fzp_bind(ctx));
     FZP_TRY(fzp_batch_need_bytes(ctx, b));      // the tally walks the D / I ops of the run-length records: a packed batch (fzp_align_to_batch) makes them now
@@ -408,7 +410,7 @@ extern "C" int fzp_batch_consensus_v(fzp_ctx *ctx, fzp_batch *b, int version, fz
     // ---- tally
     DevBuf<int64_t> d_cnt_off;
     DevBuf<uint32_t> cnt, n_records, n_out, off, ins_code, lv;
-    DevBuf<uint8_t> base0, ins_len, seq;
+    DevBuf<uint8_t> base0, ins_len;
     DevBuf<uint64_t> total;
     DevBuf<LongIns> lins;
     DevBuf<unsigned long long> n_lins;
@@ -499,12 +501,8 @@ extern "C" int fzp_batch_consensus_v(fzp_ctx *ctx, fzp_batch *b, int version, fz
     FZP_TRY(d_first.alloc((size_t)NB * 2));
     hipLaunchKernelGGL(k_cns_first, dim3(nblocks(2 * NB, 256)), dim3(256), 0, st, NB, d_cnt_off.p, off.p, (uint32_t)tot, d_first.p);
     FZP_TRY(d_first.download(h_first.data(), (size_t)NB * 2, st));
-    uint8_t *hseq = (uint8_t *)malloc((size_t)(tot ? tot : 1));
-    if (!hseq) return FZP_ENOMEM;
-    if (tot && hipMemcpyAsync(hseq, seq.p, (size_t)tot, hipMemcpyDeviceToHost, st) != hipSuccess) { free(hseq); fzp_set_error("consensus download failed"); return FZP_EDEVICE; }
-    if (hipStreamSynchronize(st) != hipSuccess) { free(hseq); fzp_set_error("consensus download failed"); return FZP_EDEVICE; }
+    if (hipStreamSynchronize(st) != hipSuccess) { fzp_set_error("consensus tables: download failed"); return FZP_EDEVICE; }
     // slot order == output order, so a tig ends where the next non-empty one starts
-    std::vector<fzp_tig> tigs;
     std::vector<int64_t> starts;
     for (int g = 0; g < NB; g++)
         for (int ph = 0; ph < 2; ph++) {
@@ -521,12 +519,28 @@ extern "C" int fzp_batch_consensus_v(fzp_ctx *ctx, fzp_batch *b, int version, fz
         }
     starts.push_back((int64_t)tot);
     for (auto &t : tigs) { const size_t k = (size_t)(-t.seq_len) - 1; t.seq_len = starts[k + 1] - starts[k]; }
+    *n_seq = tot;
+    FZP_HIP(hipGetLastError());
+    return FZP_OK;
+}
+
+extern "C" int fzp_batch_consensus_v(fzp_ctx *ctx, fzp_batch *b, int version, fzp_tigs *out) {
+    if (!ctx || !b || !out || version < 1 || version > 3) { fzp_set_error("fzp_batch_consensus: bad arguments"); return FZP_EINVAL; }
+    memset(out, 0, sizeof *out);
+    std::vector<fzp_tig> tigs;
+    DevBuf<uint8_t> seq;
+    uint64_t tot = 0;
+    FZP_TRY(fzp_batch_consensus_dev(ctx, b, version, tigs, seq, &tot));
+    uint8_t *hseq = (uint8_t *)malloc((size_t)(tot ? tot : 1));
+    if (!hseq) return FZP_ENOMEM;
+    if (tot && (hipMemcpyAsync(hseq, seq.p, (size_t)tot, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)) {
+        (void)hipGetLastError(); free(hseq); fzp_set_error("consensus download failed"); return FZP_EDEVICE;
+    }
     out->n_tigs = (int64_t)tigs.size();
     out->tigs = (fzp_tig *)malloc((tigs.size() ? tigs.size() : 1) * sizeof(fzp_tig));
     if (!out->tigs) { free(hseq); return FZP_ENOMEM; }
     if (!tigs.empty()) memcpy(out->tigs, tigs.data(), tigs.size() * sizeof(fzp_tig));
     out->seq = hseq; out->n_seq = (int64_t)tot;
-    FZP_HIP(hipGetLastError());
     return FZP_OK;
 }
 

@@ -13,6 +13,7 @@
 #include <fcntl.h>
 #include <pthread.h>
 #include <sched.h>
+#include <sys/uio.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -31,6 +32,7 @@
 #include "fzp_batch.h"
 
 int fzp_batch_text_dev(fzp_ctx *ctx, fzp_batch *b, int what, DevBuf<char> &text, size_t *bytes, std::vector<int64_t> &ctg_begin);
+int fzp_batch_consensus_dev(fzp_ctx *ctx, fzp_batch *b, int version, std::vector<fzp_tig> &tigs, DevBuf<uint8_t> &seq, uint64_t *n_seq);      // K6 with the sequence bytes left on the device (fzp_cns.hip)
 int fzp_batch_texts_dev(fzp_ctx *ctx, fzp_batch *b, DevBuf<char> &t_vmap, size_t *n_vmap, std::vector<int64_t> &vb, DevBuf<char> &t_atab, size_t *n_atab, std::vector<int64_t> &ab);      // both, one wait (fzp_text.hip)
 
 // ---- background file writes (FZP_PIPE_ASYNC_WRITES): a few threads per ctx drain a queue of per-contig write tasks, so that the
@@ -431,6 +433,25 @@ struct DirWriter {
         bytes += (int64_t)n;
         return true;
     }
+    // the same from pieces that lie where they lie (a contig's tigs in the pinned block, their headers beside them): writev, IOV_MAX pieces per call
+    bool filev(const char *rel, std::vector<struct iovec> &iov, std::atomic<int64_t> &bytes) {
+        const int f = openat(fd, rel, O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);
+        if (f < 0) return false;
+        size_t k = 0;
+        int64_t total = 0;
+        while (k < iov.size()) {
+            const int n = (int)std::min<size_t>(iov.size() - k, 1024);
+            const ssize_t w = writev(f, iov.data() + k, n);
+            if (w < 0) { if (errno == EINTR) continue; const int e = errno; close(f); errno = e; return false; }
+            total += w;
+            size_t left = (size_t)w;      // (a short write: step over what went out)
+            while (k < iov.size() && left >= iov[k].iov_len) { left -= iov[k].iov_len; k++; }
+            if (left) { iov[k].iov_base = (char *)iov[k].iov_base + left; iov[k].iov_len -= left; }
+        }
+        close(f);
+        bytes += total;
+        return true;
+    }
 };
 void add(fzp_pipe_out *a, const fzp_pipe_out &b) {
     a->n_reads += b.n_reads; a->n_aligned += b.n_aligned; a->n_rec += b.n_rec; a->n_sites += b.n_sites; a->n_rows += b.n_rows; a->n_arows += b.n_arows;
@@ -551,11 +572,11 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
     FZP_TRY(fzp_batch_run(ctx, b, FZP_STAGE_ALL));
     out->ms_phase += ms_since(t0);
     t0 = clk::now();
-    fzp_tigs tigs;
-    memset(&tigs, 0, sizeof tigs);
     const bool want_cns = (o->flags & FZP_PIPE_CONSENSUS) != 0;
-    if (want_cns) FZP_TRY(fzp_batch_consensus(ctx, b, &tigs));       // K6 of every (block, phase) pile -> <ctg>/cns/phased_blocks.fa
-    struct TG { fzp_tigs *t; ~TG() { fzp_tigs_free(t); } } tg{&tigs};
+    std::vector<fzp_tig> tigs;      // K6 of every (block, phase) pile -> <ctg>/cns/phased_blocks.fa; the sequence bytes stay on the device until they join the texts' copy (below)
+    DevBuf<uint8_t> d_cns_tmp;
+    uint64_t n_cns = 0;
+    if (want_cns) FZP_TRY(fzp_batch_consensus_dev(ctx, b, 3, tigs, d_cns_tmp, &n_cns));
     // the two big texts: serialised on the device, brought over while the records come.  (Serialising them right behind K3 and copying them under K4 / K5 was
     // measured: the phasing stage grew by more than the host section shrank -- that section is bound by its own formatting, not by these copies.)
     struct Owned {
@@ -565,6 +586,7 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
         // the two device-made texts on their way into `pin`: the copy runs under whatever the device does next; a write task waits for `ev_text` before it touches them, and
         // the device blocks they come from stay out of the allocator's hands until the last task is done
         DevBuf<char> d_vmap, d_atab;
+        DevBuf<uint8_t> d_cns;
         hipEvent_t ev_text = nullptr;
         int device = 0;
         bool texts_there() { return hipSetDevice(device) == hipSuccess && hipEventSynchronize(ev_text) == hipSuccess; }
@@ -609,7 +631,7 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
     if (fill_beside) filler = std::thread([&]() { (void)pthread_setname_np(pthread_self(), "fzp-fill"); ctx->workers->run(nc, fill_work, std::min(want_threads, 4)); });
     struct JoinF { std::thread &t; ~JoinF() { if (t.joinable()) t.join(); } } filler_join{filler};
     size_t pin_cap = 0;
-    const size_t o_atab = (n_vmap + 63) & ~(size_t)63, o_end = o_atab + ((n_atab + 63) & ~(size_t)63);
+    const size_t o_atab = (n_vmap + 63) & ~(size_t)63, o_cns = o_atab + ((n_atab + 63) & ~(size_t)63), o_end = o_cns + (((size_t)n_cns + 63) & ~(size_t)63);
     char *pin = (char *)fzp_pinned_acquire(ctx, o_end + 64, &pin_cap);
     if (!pin) { fzp_set_error("pinned host allocation failed"); return FZP_ENOMEM; }
     owned->pin = pin;
@@ -621,6 +643,10 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
     FZP_HIP(hipStreamWaitEvent(st2, ev_put.e, 0));
     if (n_vmap) FZP_HIP(hipMemcpyAsync(pin, owned->d_vmap.p, n_vmap, hipMemcpyDeviceToHost, st2));
     if (n_atab) FZP_HIP(hipMemcpyAsync(pin + o_atab, owned->d_atab.p, n_atab, hipMemcpyDeviceToHost, st2));
+    if (n_cns) {      // the tigs' bases with them (r5: they used to come over into pageable memory inside the consensus call and were copied twice more into the contig's FASTA text, on this thread)
+        std::swap(owned->d_cns.p, d_cns_tmp.p); std::swap(owned->d_cns.n, d_cns_tmp.n);
+        FZP_HIP(hipMemcpyAsync(pin + o_cns, owned->d_cns.p, (size_t)n_cns, hipMemcpyDeviceToHost, st2));
+    }
     FZP_HIP(hipEventRecord(owned->ev_text, st2));
     // the blasr task's BAM from the same pass: records come down here (device part), are split into '=' / 'X' and compressed by the contig's write task
     struct BamJob {
@@ -647,11 +673,24 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
     std::vector<std::function<bool()>> tasks((size_t)nc);     // per contig: make the small texts, write all files
     std::vector<std::shared_ptr<std::string>> whys((size_t)nc);   // why a contig's write task failed, recorded by the thread it failed on
     for (auto &w : whys) w = std::make_shared<std::string>();
+    size_t tig_at = 0;      // (the tigs come in contig order)
     if (o->out_dir) for (int c = 0; c < nc; c++) {
         const char *ctg = nm->ctg_id[c];
-        char *fa = nullptr; size_t fl = 0;
-        if (want_cns && fzp_format_tigs(&tigs, c, ctg, &fa, &fl) != FZP_OK) return FZP_EINVAL;      // (the tigs die with this call: their text is made here)
-        if (fa) { std::lock_guard<std::mutex> lk(owned->mu); owned->texts.push_back(fa); }
+        // the contig's tigs: the header lines are made here (a few dozen per contig), the bases are written from where the copy puts them
+        struct CnsFa { std::vector<std::string> hdr; std::vector<const char *> seq; std::vector<size_t> len; size_t bytes = 0; };
+        auto cns_p = std::make_shared<CnsFa>();
+        if (want_cns) {
+            char hdr[320];
+            for (; tig_at < tigs.size() && tigs[tig_at].ctg < c; tig_at++) {}
+            for (; tig_at < tigs.size() && tigs[tig_at].ctg == c; tig_at++) {
+                const fzp_tig &g = tigs[tig_at];
+                const int hl = snprintf(hdr, sizeof hdr, ">%s_%03d_%d %d %d %d\n", ctg, g.block, g.phase, g.lo + 1, g.hi + 1, g.n_records);      // (fzp_format_tigs' line)
+                if (hl <= 0 || hl >= (int)sizeof hdr) { fzp_set_error("contig id too long"); return FZP_EINVAL; }
+                cns_p->hdr.emplace_back(hdr, (size_t)hl); cns_p->seq.push_back(pin + o_cns + g.seq_off); cns_p->len.push_back((size_t)g.seq_len);
+                cns_p->bytes += (size_t)hl + (size_t)g.seq_len + 1;
+            }
+        }
+        const size_t fl = cns_p->bytes;
         const std::string base = out_dir + "/" + ctg, ctg_s = ctg;
         const char *pv = pin + vb[(size_t)c], *pa = pin + o_atab + ab[(size_t)c];
         const size_t lv = (size_t)(vb[(size_t)c + 1] - vb[(size_t)c]), la = (size_t)(ab[(size_t)c + 1] - ab[(size_t)c]);
@@ -663,7 +702,7 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
         std::shared_ptr<BamJob> bam = bams[(size_t)c];
         std::shared_ptr<std::string> why = whys[(size_t)c];
         if (async) bytes += (int64_t)(lv + la + pre_p->qmap.size() + (want_cns ? fl : 0));      // (what is known of the queued task's bytes when the call returns: the small texts do not exist yet)
-        tasks[(size_t)c] = [owned, c, base, ctg_s, pv, pa, lv, la, pre_p, recs_p, have_r2p, want_cns, fa, fl, bytes_p, fw, bam, want_done, why]() -> bool {
+        tasks[(size_t)c] = [owned, c, base, ctg_s, pv, pa, lv, la, pre_p, recs_p, have_r2p, want_cns, cns_p, bytes_p, fw, bam, want_done, why]() -> bool {
             std::atomic<int64_t> local{0};
             std::atomic<int64_t> &bt = fw ? local : *bytes_p;
             const std::string aln_done = "blasr/aln_" + ctg_s + "_done", p_done = "phasing/p_" + ctg_s + "_done";
@@ -708,7 +747,15 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
                  dw.file("het_call/q_id_map", pre_p->qmap.data(), pre_p->qmap.size(), bt) && dw.file("g_atable/atable", pa, la, bt) &&
                  dw.file("get_phased_blocks/phased_variants", txt[1], len[1], bt) && dw.file("phased_reads", txt[2], len[2], bt);
             if (ok && have_r2p) ok = dw.file(("rid_to_phase." + ctg_s).c_str(), r2p_text.data(), r2p_text.size(), bt);
-            if (ok && want_cns) ok = dw.subdir("cns") && dw.file("cns/phased_blocks.fa", fa, fl, bt);
+            if (ok && want_cns) {
+                std::vector<struct iovec> iov;
+                iov.reserve(3 * cns_p->hdr.size());
+                static const char nl = '\n';
+                for (size_t k = 0; k < cns_p->hdr.size(); k++) {
+                    iov.push_back({(void *)cns_p->hdr[k].data(), cns_p->hdr[k].size()}); iov.push_back({(void *)cns_p->seq[k], cns_p->len[k]}); iov.push_back({(void *)&nl, 1});
+                }
+                ok = dw.subdir("cns") && dw.filev("cns/phased_blocks.fa", iov, bt);
+            }
             const std::string cause = ok ? "" : "cannot write under " + base + ": " + strerror(errno);
             if (want_done && dw.subdir("phasing")) { if (ok) (void)dw.file(p_done.c_str(), "", 0, bt); (void)dw.file((p_done + ".exit").c_str(), "", 0, bt); }
             return ok ? true : failed(cause);
