@@ -93,7 +93,7 @@ struct fzp_batch {
     DevBuf<int32_t> lk_i1, lk_i2, lk_cis, lk_trans;
     DevBuf<uint32_t> left_n, left_off, left_fill, right_n, right_off, fr2;
     DevBuf<int32_t> left_lk;
-    DevBuf<int4> left_pk;             // per left link, CSR order: (left site, cis, trans, -)
+    DevBuf<int4> left_pk;             // per left link, CSR order: (left site, cis, trans, the site itself)
     DevBuf<uint32_t> pj;              // pointer-jumping words: parent<<1 | flip
     DevBuf<uint8_t> orient;
     DevBuf<int32_t> lext, rext, lscore, rscore, rawblk, blkcnt, blknew;

@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(256) k_left_fill(const uint64_t *__restrict__ 
     int32_t s = lk_i2[l];
     uint32_t slot = atomicAdd(&left_fill[s], 1u);
     left_lk[left_off[s] + slot] = (int32_t)l;
-    left_pk[left_off[s] + slot] = make_int4(lk_i1[l], lk_cis[l], lk_trans[l], 0);   // the sweep reads one stream per site
+    left_pk[left_off[s] + slot] = make_int4(lk_i1[l], lk_cis[l], lk_trans[l], s);   // the sweep reads the links of 64 sites as one run: (left site, cis, trans, the site itself)
 }
 
 // ---- greedy initialisation as a forest (phasing.py:259-309)
@@ -101,11 +101,26 @@ __global__ void __launch_bounds__(256) k_pj_resolve(int64_t n_sites, uint32_t *_
     orient[s] = (uint8_t)f;
 }
 
-// ---- refinement sweeps (phasing.py:315-344): one wave per contig
+// ---- refinement sweeps (phasing.py:315-344): one wave per contig, 64 sites at a time
+// The reference visits a contig's sites in order and flips a site when the links to its LEFT neighbours -- in their states of that moment, flips of this very sweep
+// included -- score higher the other way: a serial chain over the sites (up to ten sweeps).  One site per step with the wave spread over its links (r2..r5) costs ~0.5 us a
+// site in dependent accesses; a genome-scale group spends more time here than in the DP (configs[4], r5: 76 of 285 ms of kernels, ONE wave per contig).  This form takes 64
+// consecutive sites per step and stays exact:
+//   1. the links of the 64 sites are ONE run of the link array (CSR by site): the lanes read it coalesced, every link adds its score difference for its own site (the
+//      link's fourth word) into that site's cell of a 64-entry LDS table -- d[p] = sum over p's left links of (same state ? cis - trans : trans - cis), with the states as
+//      they are BEFORE the block;
+//   2. the lowest site of the block with d < 0 is the first the reference would flip (every site before it kept its state, so what it saw was right).  It flips; the
+//      links from it to LATER sites of the block (its "right" links, a run of the link arrays) change those sites' d by -2 x their contribution; then the next lowest
+//      site with d < 0 behind it, and so on.  Sites behind the block see the new states when their block is summed.
+// A block without flips -- nearly all of them after the first sweep -- costs its links once.
 template <bool USE_LDS>
 __global__ void __launch_bounds__(64) k_sweep(const int64_t *__restrict__ site_begin, const uint32_t *__restrict__ left_n, const uint32_t *__restrict__ left_off,
-                                              const int4 *__restrict__ left_pk, uint8_t *__restrict__ orient) {
-    extern __shared__ uint8_t o_lds[];
+                                              const int4 *__restrict__ left_pk, const uint32_t *__restrict__ right_n, const uint32_t *__restrict__ right_off,
+                                              const int32_t *__restrict__ lk_i2, const int32_t *__restrict__ lk_cis, const int32_t *__restrict__ lk_trans,
+                                              uint8_t *__restrict__ orient) {
+    extern __shared__ uint8_t sweep_lds[];
+    int32_t *d = (int32_t *)sweep_lds;                    // 64 sites' score differences
+    uint8_t *o_lds = sweep_lds + 256;
     const int lane = lane_id();
     const int c = blockIdx.x;
     const int64_t sb = site_begin[c], se = site_begin[c + 1];
@@ -118,48 +133,51 @@ __global__ void __launch_bounds__(64) k_sweep(const int64_t *__restrict__ site_b
     }
     for (int iter = 1; iter <= 10; iter++) {
         int updates = 0;
-        // a site's step is a chain of dependent accesses (its link range -> its links -> the neighbours' states).  The ranges of 64 sites at a time sit one per lane in
-        // registers (two coalesced vector loads per 64 sites, the next block's a block ahead; a site's range is a lane read), the first 64 links of a site are fetched one
-        // site ahead: nothing of it goes through the scalar cache, whose loads share a wait counter with LDS -- with scalar range loads every LDS wait of a step also waited
-        // for a trip to memory (r5)
-        uint32_t nA = (int64_t)lane < n ? left_n[sb + lane] : 0u, oA = (int64_t)lane < n ? left_off[sb + lane] : 0u;                       // sites 64 b .. 64 b + 63
-        uint32_t nB = 64 + (int64_t)lane < n ? left_n[sb + 64 + lane] : 0u, oB = 64 + (int64_t)lane < n ? left_off[sb + 64 + lane] : 0u;   // ... of the block after
-        uint32_t nl1 = (uint32_t)__builtin_amdgcn_readlane((int)nA, 0), lo1 = (uint32_t)__builtin_amdgcn_readlane((int)oA, 0);
-        int4 e1 = (uint32_t)lane < nl1 ? left_pk[lo1 + lane] : make_int4((int)sb, 0, 0, 0);
-        for (int64_t p = 0; p < n; p++) {
-            const uint32_t nl = nl1, lo = lo1;
-            const int4 e0 = e1;
-            const int64_t q = p + 1;
-            if ((q & 63) == 0) {
-                nA = nB; oA = oB;
-                const int64_t b2 = q + 64 + lane;
-                nB = b2 < n ? left_n[sb + b2] : 0u; oB = b2 < n ? left_off[sb + b2] : 0u;
+        for (int64_t p0 = 0; p0 < n; p0 += 64) {
+            const int nb = (int)min((int64_t)64, n - p0);
+            const int64_t g0 = sb + p0;                   // the block's first site
+            // 1. the block's links: [L0, L1) of the link array
+            const uint32_t L0 = left_off[g0], L1 = left_off[g0 + nb - 1] + left_n[g0 + nb - 1];
+            d[lane] = 0;
+            __syncthreads();
+            for (uint32_t j = L0 + (uint32_t)lane; j < L1; j += 256) {      // four loads of a lane in flight: a single wave has nothing else to hide their latency with
+                int4 e[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) e[u] = j + 64u * u < L1 ? left_pk[j + 64u * u] : make_int4((int)g0, 0, 0, (int)g0);      // (left site, cis, trans, this site); beyond the run: adds 0
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const bool same = o[e[u].x - sb] == o[e[u].w - sb];
+                    const int32_t cdiff = same ? e[u].y - e[u].z : e[u].z - e[u].y;
+                    if (cdiff) atomicAdd(&d[e[u].w - (int32_t)g0], cdiff);
+                }
             }
-            const int ql = (int)(q & 63);
-            nl1 = q < n ? (uint32_t)__builtin_amdgcn_readlane((int)nA, ql) : 0u;
-            lo1 = (uint32_t)__builtin_amdgcn_readlane((int)oA, ql);
-            e1 = (uint32_t)lane < nl1 ? left_pk[lo1 + lane] : make_int4((int)sb, 0, 0, 0);
-            if (nl == 0) continue;
-            const uint8_t op = o[p];
-            int s1 = 0, s2 = 0;
-            if ((uint32_t)lane < nl) {
-                const bool same = o[e0.x - sb] == op;                     // (site of the left neighbour, cis, trans)
-                s1 += same ? e0.y : e0.z;
-                s2 += same ? e0.z : e0.y;
-            }
-            for (uint32_t k = lane + 64; k < nl; k += 64) {
-                const int4 e = left_pk[lo + k];
-                const bool same = o[e.x - sb] == op;
-                s1 += same ? e.y : e.z;
-                s2 += same ? e.z : e.y;
-            }
-            const int d = wave_sum_i32_dpp(s1 - s2);
-            if (d < 0) {               // score1 >= score2 keeps the state (phasing.py:338-342)
-                if (lane == 0) o[p] = op ^ 1;
+            __syncthreads();
+            if (L1 == L0) continue;
+            // 2. flips, lowest site first
+            int start = 0;
+            for (;;) {
+                const int32_t dv = lane < nb ? d[lane] : 0;
+                const uint64_t m = __ballot(lane >= start && dv < 0);
+                if (!m) break;                            // score1 >= score2 keeps the state (phasing.py:338-342)
+                const int F = __builtin_ctzll(m);
+                const int64_t gF = g0 + F;
+                const uint8_t oF = o[p0 + F];
+                const uint32_t r0 = right_off[gF], rn = right_n[gF];
+                for (uint32_t k = (uint32_t)lane; k < rn; k += 64) {      // what F's flip does to the later sites of this block
+                    const int32_t t = lk_i2[r0 + k];
+                    if (t < g0 + nb) {
+                        const bool same = o[t - sb] == oF;
+                        const int32_t cdiff = lk_cis[r0 + k] - lk_trans[r0 + k];
+                        atomicAdd(&d[t - (int32_t)g0], same ? -2 * cdiff : 2 * cdiff);
+                    }
+                }
+                __syncthreads();
+                if (lane == 0) o[p0 + F] = oF ^ 1;
                 updates++;
                 if (!USE_LDS) __threadfence_block();
+                __syncthreads();
+                start = F + 1;
             }
-            if (USE_LDS) __syncthreads();
         }
         if (updates == 0) break;
     }
@@ -438,10 +456,11 @@ int fzp_k4_blocks(fzp_ctx *ctx, fzp_batch *b) {
         {
             ProfScope ps(ctx, "k4_sweep");
             if (max_sites <= 60 * 1024)
-                hipLaunchKernelGGL(k_sweep<true>, dim3(b->n_ctg), dim3(64), (size_t)((max_sites + 15) & ~15LL), st, b->site_begin.p, b->left_n.p, b->left_off.p,
-                                   b->left_pk.p, b->orient.p);
+                hipLaunchKernelGGL(k_sweep<true>, dim3(b->n_ctg), dim3(64), (size_t)(256 + ((max_sites + 15) & ~15LL)), st, b->site_begin.p, b->left_n.p, b->left_off.p,
+                                   b->left_pk.p, b->right_n.p, b->right_off.p, b->lk_i2.p, b->lk_cis.p, b->lk_trans.p, b->orient.p);
             else
-                hipLaunchKernelGGL(k_sweep<false>, dim3(b->n_ctg), dim3(64), 0, st, b->site_begin.p, b->left_n.p, b->left_off.p, b->left_pk.p, b->orient.p);
+                hipLaunchKernelGGL(k_sweep<false>, dim3(b->n_ctg), dim3(64), 256, st, b->site_begin.p, b->left_n.p, b->left_off.p, b->left_pk.p, b->right_n.p, b->right_off.p,
+                                   b->lk_i2.p, b->lk_cis.p, b->lk_trans.p, b->orient.p);
         }
         {
             ProfScope ps(ctx, "k4_extents");
