@@ -45,6 +45,7 @@ struct FileWriter {
     int running = 0;
     bool stop = false;
     std::string first_error;
+    std::atomic<int64_t> extra{0};      // bytes the tasks wrote beyond what their call had counted when it returned (the small texts are made by the task): taken by whoever flushes
     void start(int n) {
         for (int i = 0; i < n; i++)
             th.emplace_back([this, i] {
@@ -701,10 +702,12 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
         FileWriter *fw = async ? ctx->writer : nullptr;
         std::shared_ptr<BamJob> bam = bams[(size_t)c];
         std::shared_ptr<std::string> why = whys[(size_t)c];
-        if (async) bytes += (int64_t)(lv + la + pre_p->qmap.size() + (want_cns ? fl : 0));      // (what is known of the queued task's bytes when the call returns: the small texts do not exist yet)
-        tasks[(size_t)c] = [owned, c, base, ctg_s, pv, pa, lv, la, pre_p, recs_p, have_r2p, want_cns, cns_p, bytes_p, fw, bam, want_done, why]() -> bool {
+        const int64_t known = (int64_t)(lv + la + pre_p->qmap.size() + (want_cns ? fl : 0));
+        if (async) bytes += known;      // (what is known of the queued task's bytes when the call returns: the small texts do not exist yet -- the rest goes to the writer's `extra`)
+        tasks[(size_t)c] = [owned, c, base, ctg_s, pv, pa, lv, la, pre_p, recs_p, have_r2p, want_cns, cns_p, bytes_p, fw, bam, want_done, why, known]() -> bool {
             std::atomic<int64_t> local{0};
             std::atomic<int64_t> &bt = fw ? local : *bytes_p;
+            struct Extra { FileWriter *w; std::atomic<int64_t> &l; int64_t k; ~Extra() { if (w) w->extra += l.load() - k; } } extra_guard{fw, local, known};
             const std::string aln_done = "blasr/aln_" + ctg_s + "_done", p_done = "phasing/p_" + ctg_s + "_done";
             auto failed = [&](const std::string &what) { *why = what; if (fw) fw->fail(what); return false; };      // the cause is taken where it happens, on this thread
             // the small texts (phasing.py:124, 412-421, 478-480; phasing_readmap.py:49-51)
@@ -810,6 +813,9 @@ extern "C" int fzp_phase_contigs(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *con
     }
     fzp_pipe_opts o;
     if (opts) o = *opts; else fzp_pipe_opts_default(&o);
+    if (!getenv("FZP_PIPE_SYNC_WRITES")) o.flags |= FZP_PIPE_ASYNC_WRITES;      // (this call flushes before it returns: a group's files go down under the next group's kernels whether the caller asked or not)
+    if (ctx->writer) (void)ctx->writer->extra.exchange(0);                       // (what earlier fzp_job_phase_write calls left there is not this call's)
+    for (auto l : ctx->lanes) if (l->writer) (void)l->writer->extra.exchange(0);
     memset(out, 0, sizeof *out);
     for (int64_t r = 0; r < n_reads; r++) if (read_ctg[r] < 0 || read_ctg[r] >= n_ctg) { fzp_set_error("read %lld: bad contig", (long long)r); return FZP_EINVAL; }
     const bool timing = getenv("FZP_PIPE_TIMING") != nullptr;
@@ -947,12 +953,16 @@ extern "C" int fzp_phase_contigs(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *con
     }
     const double ms_lanes = ms_since(t_call);
     (void)fzp_bind(ctx);
-    const int frc = fzp_pipe_flush(ctx);                    // FZP_PIPE_ASYNC_WRITES: the groups' files overlapped other groups' kernels; all are down now
+    const int frc = fzp_pipe_flush(ctx);                    // the groups' files overlapped other groups' kernels; all are down now
+    int64_t late_bytes = 0;
+    if (ctx->writer) late_bytes += ctx->writer->extra.exchange(0);
+    for (auto l : ctx->lanes) if (l->writer) late_bytes += l->writer->extra.exchange(0);
     if (timing) fprintf(stderr, "[fzp_phase_contigs] read maps started by %.2f ms, grouping until %.2f, lanes until %.2f, flush until %.2f (%d lanes, %zu groups)\n", ms_maps, ms_prep, ms_lanes,
                         ms_since(t_call), lanes, groups.size());
     for (int li = 0; li < lanes; li++) if (rcs[(size_t)li] != FZP_OK) { fzp_set_error("%s", errs[(size_t)li].c_str()); return rcs[(size_t)li]; }
     if (frc != FZP_OK) return frc;
     for (int li = 0; li < lanes; li++) add(out, outs[(size_t)li]);
+    out->bytes_written += late_bytes;
     std::vector<fzp_r2p> all;
     for (auto &v : r2p_g[0]) all.insert(all.end(), v.begin(), v.end());
     out->n_r2p = (int64_t)all.size();
@@ -1279,6 +1289,9 @@ extern "C" int fzp_phase_contigs_files(fzp_ctx *ctx, const char *reads_dir, cons
     if (!ctx || !reads_dir || !nm || !nm->ctg_id || nm->n_ctg <= 0 || !out) { fzp_set_error("fzp_phase_contigs_files: bad arguments"); return FZP_EINVAL; }
     fzp_pipe_opts o;
     if (opts) o = *opts; else fzp_pipe_opts_default(&o);
+    if (!getenv("FZP_PIPE_SYNC_WRITES")) o.flags |= FZP_PIPE_ASYNC_WRITES;      // (as in fzp_phase_contigs: flushed before the call returns)
+    if (ctx->writer) (void)ctx->writer->extra.exchange(0);
+    for (auto l : ctx->lanes) if (l->writer) (void)l->writer->extra.exchange(0);
     memset(out, 0, sizeof *out);
     const int n_ctg = nm->n_ctg;
     const std::string dir(reads_dir);
@@ -1416,10 +1429,14 @@ extern "C" int fzp_phase_contigs_files(fzp_ctx *ctx, const char *reads_dir, cons
     for (auto &g : gin) if (g) pool->give(std::move(g));
     (void)fzp_bind(ctx);
     const int frc = fzp_pipe_flush(ctx);
+    int64_t late_bytes = 0;
+    if (ctx->writer) late_bytes += ctx->writer->extra.exchange(0);
+    for (auto l : ctx->lanes) if (l->writer) late_bytes += l->writer->extra.exchange(0);
     if (timing) { double w = 0; for (auto v : ms_parse) w += v; fprintf(stderr, "[fzp_phase_contigs_files] %.2f ms in the call, %.2f ms of it waiting for the parser (%d lanes, %zu groups)\n", ms_since(t_call), w, lanes, groups.size()); }
     for (int li = 0; li < lanes; li++) if (rcs[(size_t)li] != FZP_OK) { fzp_set_error("%s", errs[(size_t)li].c_str()); return rcs[(size_t)li]; }
     if (frc != FZP_OK) return frc;
     for (int li = 0; li < lanes; li++) add(out, outs[(size_t)li]);
+    out->bytes_written += late_bytes;
     std::vector<fzp_r2p> all;
     for (auto &v : r2p_g) all.insert(all.end(), v.begin(), v.end());
     out->n_r2p = (int64_t)all.size();
