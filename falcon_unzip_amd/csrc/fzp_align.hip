@@ -55,17 +55,34 @@ __global__ void __launch_bounds__(256) k_upper(uint8_t *__restrict__ a, int64_t 
 }
 
 // ---- packing: one workgroup column per sequence, blockIdx.y strides over its words
+// (r5: a thread takes its 16 bases as five aligned words shifted into place and classifies four bytes at a time -- exact byte equality by carry-free arithmetic, code_of's
+// table: C/c 1, G/g 2, T/t 3, everything else 0; sixteen byte loads and sixteen compare chains per word made this the slowest "streaming" kernel of a genome-scale run, 0.5 TB/s)
+__device__ __forceinline__ uint32_t codes4(uint32_t x) {      // four ASCII bytes -> 8 bits, byte 0's code in bits 1:0
+    const uint32_t y = x & 0xDFDFDFDFu;                       // either case
+    auto eq = [](uint32_t v, uint32_t k) { const uint32_t z = v ^ k; const uint32_t t = (z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu; return ~(t | z | 0x7F7F7F7Fu); };      // 0x80 in every byte that equals k's
+    const uint32_t c = eq(y, 0x43434343u), g = eq(y, 0x47474747u), t = eq(y, 0x54545454u);
+    const uint32_t code = (c >> 7) | (g >> 6) | (t >> 7) | (t >> 6);
+    return (code | (code >> 6) | (code >> 12) | (code >> 18)) & 0xffu;
+}
 __global__ void __launch_bounds__(256) k_pack(const uint8_t *__restrict__ ascii, const int64_t *__restrict__ seq_be, const int64_t *__restrict__ woff,
-                                              uint32_t *__restrict__ out) {      // sequence s = ascii[seq_be[2s], seq_be[2s+1])
+                                              uint32_t *__restrict__ out) {      // sequence s = ascii[seq_be[2s], seq_be[2s+1]); the buffer holds 32 bytes beyond its last sequence
     const int64_t s = blockIdx.x;
     const int64_t b0 = seq_be[2 * s], n = seq_be[2 * s + 1] - b0;
     const int64_t nw = ((n + 15) / 16 + 8 + 1) & ~1LL;   // zero pad words: 64-bit base windows may run past the end
     uint32_t *dst = out + woff[s];
     for (int64_t w = (int64_t)blockIdx.y * 256 + threadIdx.x; w < nw; w += (int64_t)gridDim.y * 256) {
         uint32_t v = 0;
-        int64_t base = w * 16;
-        for (int m = 0; m < 16; m++)
-            if (base + m < n) v |= (uint32_t)code_of(ascii[b0 + base + m]) << (2 * m);
+        const int64_t base = w * 16;
+        if (base < n) {
+            const uint8_t *a = ascii + b0 + base;
+            const uint32_t sh = (uint32_t)((uintptr_t)a & 3u);
+            const uint32_t *p = (const uint32_t *)(a - sh);
+            const uint32_t d0 = p[0], d1 = p[1], d2 = p[2], d3 = p[3], d4 = p[4];
+            v = codes4(__builtin_amdgcn_alignbyte(d1, d0, sh)) | (codes4(__builtin_amdgcn_alignbyte(d2, d1, sh)) << 8) |
+                (codes4(__builtin_amdgcn_alignbyte(d3, d2, sh)) << 16) | (codes4(__builtin_amdgcn_alignbyte(d4, d3, sh)) << 24);
+            const int64_t left = n - base;
+            if (left < 16) v &= (1u << (2 * (uint32_t)left)) - 1u;
+        }
         dst[w] = v;
     }
 }
@@ -615,10 +632,20 @@ __global__ void __launch_bounds__(256) k_revcomp(const uint32_t *__restrict__ pk
     const uint32_t *src = pk + woff[sq];
     uint32_t *dst = out + woff[sq];
     for (int64_t w = (int64_t)blockIdx.y * 256 + threadIdx.x; w < nw; w += (int64_t)gridDim.y * 256) {
+        // output bases 16 w .. 16 w + 15 are the complements of source bases n-1-16w down to n-16-16w: one 16-base window of the source, turned round (rc_key) -- r5: sixteen
+        // single-base look-ups per word before
         uint32_t v = 0;
-        for (int m = 0; m < 16; m++) {
-            const int64_t x = w * 16 + m;
-            if (x < n) v |= (3u - base_at(src, n - 1 - x)) << (2 * m);
+        const int64_t left = n - w * 16;                     // output bases of this word that exist
+        if (left > 0) {
+            const int64_t s0 = left - 16;                    // the window's first source base (negative: the window hangs over the sequence's start)
+            uint32_t key;
+            if (s0 >= 0) {      // (two plain word loads and a funnel shift: through kmer_at's 64-bit window this loop gave wrong upper halves now and then -- tools/ubench/revcomp_check.hip)
+                const uint32_t sh = (uint32_t)(s0 & 15) * 2u;
+                const uint32_t lo = src[s0 >> 4], hi = src[(s0 >> 4) + 1];
+                key = sh ? (lo >> sh) | (hi << (32u - sh)) : lo;
+            } else key = src[0] << (2 * (uint32_t)(-s0));
+            v = rc_key(key, 16);
+            if (left < 16) v &= (1u << (2 * (uint32_t)left)) - 1u;
         }
         dst[w] = v;
     }
@@ -2714,7 +2741,7 @@ extern "C" int fzp_align_create_spans(fzp_ctx *ctx, int32_t n_ctg, const uint8_t
     DevBuf<int64_t> d_off;
     do {
         // contigs: ASCII straight into ctg_ascii (pinned, chunked, threaded staging), upper-cased and packed on the device
-        if ((rc = j->ctg_pk.alloc((size_t)j->ctg_words + 8)) || (rc = j->ctg_rc.alloc((size_t)j->ctg_words + 8)) || (rc = j->ctg_ascii.alloc((size_t)coff.back() + 16)) || (rc = d_off.upload(coff.data(), coff.size(), st)) ||
+        if ((rc = j->ctg_pk.alloc((size_t)j->ctg_words + 8)) || (rc = j->ctg_rc.alloc((size_t)j->ctg_words + 8)) || (rc = j->ctg_ascii.alloc((size_t)coff.back() + 32)) || (rc = d_off.upload(coff.data(), coff.size(), st)) ||
             (rc = j->ctg_woff.upload(j->h_ctg_woff.data(), j->h_ctg_woff.size(), st)) || (rc = j->ctg_len.upload(j->h_ctg_len.data(), j->h_ctg_len.size(), st)) ||
             (rc = j->idx_off.upload(j->h_idx_off.data(), j->h_idx_off.size(), st)) || (rc = j->idx_bits.upload(j->h_idx_bits.data(), j->h_idx_bits.size(), st)))
             break;
@@ -2738,7 +2765,7 @@ extern "C" int fzp_align_create_spans(fzp_ctx *ctx, int32_t n_ctg, const uint8_t
         if (hipStreamSynchronize(st) != hipSuccess) { rc = FZP_EDEVICE; break; }
         if (n_reads) {
             const size_t rbytes = (size_t)(span_hi - span_lo);
-            if ((rc = j->read_pk.alloc((size_t)j->read_words + 8)) || (rc = j->read_rc.alloc((size_t)j->read_words + 8)) || (rc = d_ascii.alloc(rbytes + 16)))
+            if ((rc = j->read_pk.alloc((size_t)j->read_words + 8)) || (rc = j->read_rc.alloc((size_t)j->read_words + 8)) || (rc = d_ascii.alloc(rbytes + 32)))
                 break;
             {
                 std::vector<const void *> srcs(1, buf + span_lo); std::vector<size_t> dsts(1, 0), lens(1, rbytes);
