@@ -30,12 +30,27 @@ __global__ void k_cns_nblk(int n_ctg, const int64_t *__restrict__ pvar_begin, co
 __global__ void __launch_bounds__(256) k_cns_extent(int64_t n_pvars, const fzp_pvar *__restrict__ pvars, const fzp_site *__restrict__ sites, const int32_t *__restrict__ site_ctg,
                                                     const int32_t *__restrict__ blk_base, int32_t *__restrict__ lo, int32_t *__restrict__ hi) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n_pvars) return;
-    const fzp_pvar v = pvars[i];
-    const int32_t g = blk_base[site_ctg[v.site]] + v.block - 1;
-    const int32_t pos = sites[v.site].pos;
-    atomicMin(&lo[g], pos);
-    atomicMax(&hi[g], pos);
+    const bool have = i < n_pvars;
+    int32_t g = -1, pos = 0;
+    if (have) {
+        const fzp_pvar v = pvars[i];
+        g = blk_base[site_ctg[v.site]] + v.block - 1;
+        pos = sites[v.site].pos;
+    }
+    // a wave's records nearly always belong to one block: one pair of atomics per wave instead of sixty-four on the same two words (r5: 236 000 records on a few hundred
+    // addresses took this kernel 0.3 ms per call at genome scale)
+    const uint64_t m = __ballot(have);
+    if (!m) return;
+    const int32_t g0 = __builtin_amdgcn_readlane(g, __builtin_ctzll(m));
+    if (__all(!have || g == g0)) {
+        int32_t mn = have ? pos : 0x7fffffff, mx = have ? pos : -1;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { mn = min(mn, __shfl_xor(mn, d, 64)); mx = max(mx, __shfl_xor(mx, d, 64)); }
+        if (lane_id() == 0) { atomicMin(&lo[g0], mn); atomicMax(&hi[g0], mx); }
+    } else if (have) {
+        atomicMin(&lo[g], pos);
+        atomicMax(&hi[g], pos);
+    }
 }
 
 struct CnsView {
@@ -63,7 +78,14 @@ __global__ void __launch_bounds__(256) k_cns_nrec(CnsView v, uint32_t *__restric
     for (int64_t e = a; e < pe && v.preads[e].q_id == q; e++) {
         const int32_t g = v.blk_base[c] + v.preads[e].block - 1;
         if (pos0 > v.hi[g] || pos0 + span <= v.lo[g]) continue;
-        atomicAdd(&n_records[2 * g + v.preads[e].phase], 1u);
+        // (neighbouring records mostly add to the same pile: the lanes that do are counted by one of them)
+        const uint32_t key = (uint32_t)(2 * g + v.preads[e].phase);
+        for (uint64_t todo = __ballot(true); todo;) {
+            const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)key, __builtin_ctzll(todo));
+            const uint64_t same = __ballot(key == k0) & todo;
+            if (key == k0) { if (lane_id() == __builtin_ctzll(same)) atomicAdd(&n_records[k0], (uint32_t)__popcll(same)); break; }
+            todo &= ~same;
+        }
     }
 }
 
