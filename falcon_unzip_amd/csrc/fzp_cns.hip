@@ -18,6 +18,7 @@
 // HBM-bound integer work: 1 B symbol + 4 B/op in, 40 B of counters per (position, phase) touched by atomics, 1 B out.
 #include <algorithm>
 #include "fzp_expand.h"
+#include "fzp_pk.h"
 
 namespace {
 constexpr int CN = 10;   // counters per (position, phase): A C G T del ins insA insC insG insT
@@ -215,6 +216,160 @@ __global__ void __launch_bounds__(CNS_THREADS) k_cns_tiles(RecView rv, CnsView v
     }
 }
 
+// ---- the same tally from K1's packed records (r5): the alignment's 2-bit op stream (END first) and the 2-bit oriented read, as K2's k_pileup_pk reads them -- no byte
+// SEQ, no run-length CIGAR, no checkpoint pass in front of K6 (k_gather16 + k_cig_ckpt + this kernel's run-length form were a quarter of a genome-scale run's kernel time).
+// A lane owns a word of 16 ops.  An aligned column counts its base, a D op its position; an inserted base counts when it is the FIRST of its run in forward order -- the op
+// whose next stream op is not an I -- at the position it follows (the cell's contig coordinate), with the run's length read off the I bits below it (this word's and the
+// word's before) and, for runs of two and more, the run's first eight bases taken from the read and put INTO the list entry (qidx < 0: 2 bits per base from bit 0), so that
+// what consumes the list needs no sequence.
+__device__ __forceinline__ uint32_t even_bits16(uint32_t x) {      // the 16 even bits of x, packed
+    x &= 0x55555555u;
+    x = (x | (x >> 1)) & 0x33333333u; x = (x | (x >> 2)) & 0x0f0f0f0fu; x = (x | (x >> 4)) & 0x00ff00ffu; x = (x | (x >> 8)) & 0xffffu;
+    return x;
+}
+__global__ void __launch_bounds__(CNS_THREADS) k_cns_tiles_pk(PkView pv, CnsView v, const int32_t *__restrict__ tile_blk, const int32_t *__restrict__ tile_start,
+                                                              const int32_t *__restrict__ blk_ctg, const int64_t *__restrict__ ctg_rec_begin,
+                                                              const int32_t *__restrict__ ctg_maxspan, uint32_t *__restrict__ cnt, LongIns *__restrict__ lins,
+                                                              unsigned long long *__restrict__ n_lins, unsigned long long lins_cap) {
+    __shared__ uint32_t l_cnt[2 * CN * CNS_TILE];      // [phase][counter][position]
+    __shared__ LongIns l_stage[CNS_STAGE];
+    __shared__ uint32_t l_nstage, l_base_lo, l_base_hi;
+    if (threadIdx.x == 0) l_nstage = 0;
+    const int32_t g = tile_blk[blockIdx.x], ts = tile_start[blockIdx.x];
+    const int c = blk_ctg[g];
+    const int32_t lo = v.lo[g], hi = v.hi[g];
+    const int32_t te = min(ts + CNS_TILE, hi + 1);      // exclusive
+    for (int i = threadIdx.x; i < 2 * CN * CNS_TILE; i += CNS_THREADS) l_cnt[i] = 0;
+    __syncthreads();
+    const int64_t rb = ctg_rec_begin[c], re = ctg_rec_begin[c + 1];
+    const int32_t ms = ctg_maxspan[c];
+    int64_t first, last;
+    {
+        int64_t a = rb, b = re;
+        while (a < b) { const int64_t m = (a + b) >> 1; if (v.rec_pos[m] <= ts - ms) a = m + 1; else b = m; }
+        first = a;
+        b = re;
+        while (a < b) { const int64_t m = (a + b) >> 1; if (v.rec_pos[m] < te) a = m + 1; else b = m; }
+        last = a;
+    }
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    constexpr int NW = CNS_THREADS / 64;
+    const int32_t blk_id = g - v.blk_base[c] + 1;
+    const uint32_t span = (uint32_t)(te - ts);
+    const int64_t len_g = (int64_t)hi - lo + 1;
+    for (int64_t i0 = 0; first + i0 * NW + wave < last; i0 += 64) {
+        // lane i prepares candidate first + (i0 + i) * NW + wave: overlap test, phase look-up, checkpoint search
+        const int64_t r = first + (i0 + lane) * NW + wave;
+        bool ok = r < last;
+        int32_t ka = 0, ph = 0;
+        if (ok) {
+            const int32_t pos0 = v.rec_pos[r];
+            ok = pos0 + v.rec_span[r] > ts;
+            if (ok) {
+                const int32_t q = v.rec_qid[r];
+                int64_t a = v.pread_begin[c], b = v.pread_begin[c + 1];
+                while (a < b) {      // first row with (q_id, block) >= (q, blk_id)
+                    const int64_t m = (a + b) >> 1;
+                    const fzp_pread pr = v.preads[m];
+                    if (pr.q_id < q || (pr.q_id == q && pr.block < blk_id)) a = m + 1; else b = m;
+                }
+                ok = a < v.pread_begin[c + 1] && v.preads[a].q_id == q && v.preads[a].block == blk_id;
+                if (ok) {
+                    ph = v.preads[a].phase;
+                    const int64_t rd = pv.rec_read[r];
+                    const PkRec p = pv.s.prec[rd];
+                    const int32_t nck = (((p.n_ops + 15) >> 4) + 15) >> 4;
+                    // start one position ABOVE the tile's last: the inserted bases that follow position te - 1 stand in the stream in front of its column
+                    ka = pk_ck_search(pv.s.ck + ((size_t)(pv.s.rcapq_scan[rd] >> 2) + (size_t)rd), nck, p.j_end - te);
+                }
+            }
+        }
+        const int32_t rel = (int32_t)(r - first);
+        for (uint64_t todo = __ballot(ok); todo; todo &= todo - 1) {
+            const int l = __builtin_ctzll(todo);
+            const int64_t ru = first + __builtin_amdgcn_readlane(rel, l);
+            const int32_t k0 = __builtin_amdgcn_readlane(ka, l);
+            const int phu = __builtin_amdgcn_readlane(ph, l);
+            uint32_t *lc = l_cnt + phu * (CN * CNS_TILE);
+            const int32_t pos0 = v.rec_pos[ru];
+            const int64_t rd = pv.rec_read[ru];
+            const PkRec p = pv.s.prec[rd];
+            const uint32_t *__restrict__ ops = pv.s.ops + 4 * (size_t)pv.s.rcapq_scan[rd];
+            const int2 c0 = pv.s.ck[(size_t)(pv.s.rcapq_scan[rd] >> 2) + (size_t)rd + (size_t)k0];
+            const uint32_t *__restrict__ pk = (p.strand ? pv.s.read_rc : pv.s.read_pk) + pv.s.read_woff[rd];
+            const int32_t nW = (p.n_ops + 15) >> 4;
+            int32_t ib = p.i_end - c0.x, jb = p.j_end - c0.y;              // the cell the chunk's first op leaves
+            for (int32_t w0 = 16 * k0; w0 < nW && jb >= ts; w0 += 64) {
+                const int32_t wi = w0 + lane;
+                const uint32_t x = wi < nW ? ops[wi] : 0u, vm = pk_valid(wi, p.n_ops);
+                const uint32_t fM = ~(x | (x >> 1)) & vm, fI = (x & ~(x >> 1)) & vm, fD = (~x & (x >> 1)) & vm;
+                const uint32_t cI = fM | fI, cJ = fM | fD;
+                const uint32_t ci = (uint32_t)__popc(cI), cj = (uint32_t)__popc(cJ);
+                const uint32_t si = wave_incl_scan_u32_dpp(ci), sj = wave_incl_scan_u32_dpp(cj);
+                const int32_t i = ib - (int32_t)(si - ci), j = jb - (int32_t)(sj - cj);
+                // this word's ops stand at contig positions [j - cj, j]
+                if (vm != 0u && j >= ts && j - (int32_t)cj < te && i >= 0) {
+                    const uint32_t q16 = pk_bases16(pk, i);
+                    uint32_t bsh = 30u;                                        // bit offset of the base at the current read index inside q16
+                    uint32_t pj = (uint32_t)(j - ts);                          // position inside the tile (wraps when outside)
+                    int32_t ii = i;                                            // the current read index
+                    // run starts: an I whose next stream op (the op above it: op o + 1, or the next word's op 0) is not an I
+                    uint32_t above = fI >> 2;
+                    if (wi + 1 < nW) { const uint32_t xn = ops[wi + 1]; if ((xn & 3u) == 1u && (pk_valid(wi + 1, p.n_ops) & 1u)) above |= 1u << 30; }
+                    const uint32_t sI = fI & ~above;
+                    uint32_t runs = 0;                                         // I bits of the word before this one (below) and of this word, one per op: bit 16 + o = op o
+                    if (sI) runs = (even_bits16(fI) << 16) | (wi > 0 ? even_bits16(ops[wi - 1] & ~(ops[wi - 1] >> 1)) : 0u);
+                    const uint32_t cI2 = cI << 1;
+#pragma unroll
+                    for (int o = 0; o < 16; o++) {
+                        const uint32_t bit = 1u << (2 * o);
+                        if (fM & bit) {
+                            if (pj < span) atomicAdd(&lc[((q16 >> bsh) & 3u) * CNS_TILE + pj], 1u);
+                        } else if (fD & bit) {
+                            if (pj < span) atomicAdd(&lc[4 * CNS_TILE + pj], 1u);
+                        } else if (sI & bit) {
+                            if (pj < span && (int32_t)pj + ts >= pos0) {
+                                atomicAdd(&lc[5 * CNS_TILE + pj], 1u);
+                                atomicAdd(&lc[(6 + ((q16 >> bsh) & 3u)) * CNS_TILE + pj], 1u);
+                                const uint32_t n_run = (uint32_t)__clz((int)~(runs << (15 - o)));      // consecutive I bits from op o down (this word, then the word below)
+                                if (n_run >= 2u && lins) {
+                                    const uint64_t two = ((uint64_t)pk[(ii >> 4) + 1] << 32) | pk[ii >> 4];      // the read from base ii on: the run's bases in forward order
+                                    const uint32_t b16 = (uint32_t)(two >> (2 * (ii & 15))) & 0xffffu;
+                                    const LongIns e = LongIns{2 * v.cnt_off[g] + (int64_t)phu * len_g + ((int64_t)pj + ts - lo), (int64_t)(0x8000000000000000ull | b16), n_run, 0u};
+                                    const uint32_t k = atomicAdd(&l_nstage, 1u);
+                                    if (k < (uint32_t)CNS_STAGE) l_stage[k] = e;
+                                    else { const unsigned long long at = atomicAdd(n_lins, 1ull); if (at < lins_cap) lins[at] = e; }
+                                }
+                            }
+                        }
+                        const uint32_t took_i = (cI2 >> (2 * o)) & 2u;
+                        bsh -= took_i;
+                        ii -= (int32_t)(took_i >> 1);
+                        pj -= (cJ >> (2 * o)) & 1u;
+                    }
+                }
+                ib -= __builtin_amdgcn_readlane((int32_t)si, 63);
+                jb -= __builtin_amdgcn_readlane((int32_t)sj, 63);
+            }
+        }
+    }
+    __syncthreads();
+    if (lins) {
+        const uint32_t ns = min(l_nstage, (uint32_t)CNS_STAGE);
+        if (threadIdx.x == 0 && ns) { const unsigned long long at = atomicAdd(n_lins, (unsigned long long)ns); l_base_lo = (uint32_t)at; l_base_hi = (uint32_t)(at >> 32); }
+        __syncthreads();
+        if (threadIdx.x < ns) {
+            const unsigned long long at = (((unsigned long long)l_base_hi << 32) | l_base_lo) + threadIdx.x;
+            if (at < lins_cap) lins[at] = l_stage[threadIdx.x];
+        }
+    }
+    const int np = te - ts;
+    for (int ph = 0; ph < 2; ph++) {
+        uint32_t *dst = cnt + (2 * v.cnt_off[g] + (int64_t)ph * len_g + (ts - lo)) * CN;
+        for (int i = threadIdx.x; i < np * CN; i += CNS_THREADS) dst[i] = l_cnt[ph * (CN * CNS_TILE) + (i % CN) * CNS_TILE + (i / CN)];
+    }
+}
+
 // one thread per (block, phase, position): the delta-0 call (0 or 1 base) and the first inserted base
 // outputs: base0[i] (0 = nothing), ins_len[i] (0 / 1 after this kernel), ins_code[i] (2 bits per inserted base)
 __global__ void __launch_bounds__(256) k_cns_call(int64_t n_slots, int n_blk, const int64_t *__restrict__ cnt_off, const int32_t *__restrict__ lo, const int32_t *__restrict__ hi,
@@ -273,7 +428,7 @@ __global__ void __launch_bounds__(256) k_ins_tally3(int64_t n, const LongIns *__
     const uint32_t ln = min(x.n, (uint32_t)INS_MAX);
     atomicAdd(&h[ln - 1], 1u);
     for (uint32_t q = 1; q < ln; q++) {
-        const int code = sym_code(seq[x.qidx + q]);
+        const int code = x.qidx < 0 ? (int)(((uint64_t)x.qidx >> (2 * q)) & 3u) : sym_code(seq[x.qidx + q]);      // (the packed tally's entries carry the run's first eight bases)
         if (code < 4) atomicAdd(&h[8 + 4 * q + code], 1u);
     }
 }
@@ -401,7 +556,9 @@ int fzp_batch_consensus_dev(fzp_ctx *ctx, fzp_batch *b, int version, std::vector
     tigs.clear(); *n_seq = 0;
     if (!b->have_aln || !b->have_blocks || !b->have_preads || !b->have_sites) { fzp_set_error("fzp_batch_consensus: run FZP_STAGE_ALL on a batch with alignment records first"); return FZP_EINVAL; }
     FZP_TRY(fzp_bind(ctx));
-    FZP_TRY(fzp_batch_need_bytes(ctx, b));      // the tally walks the D / I ops of the run-length records: a packed batch (fzp_align_to_batch) makes them now
+    // a packed batch (fzp_align_to_batch) is tallied as it is by fzcns v3 (k_cns_tiles_pk); versions 1 and 2 walk the run-length records, which are made now (FZP_K6_BYTES: v3 too)
+    const bool packed = b->packed && !b->have_bytes && version >= 3 && getenv("FZP_K6_BYTES") == nullptr;
+    if (!packed) FZP_TRY(fzp_batch_need_bytes(ctx, b));
     hipStream_t st = ctx->stream;
     const int nc = b->n_ctg;
     // ---- blocks per contig and their spans
@@ -456,7 +613,10 @@ int fzp_batch_consensus_dev(fzp_ctx *ctx, fzp_batch *b, int version, std::vector
         if (b->n_rec > 0) {
             ProfScope ps(ctx, "k6_tally");
             if (attempt == 0) hipLaunchKernelGGL(k_cns_nrec, dim3(nblocks(b->n_rec, 256)), dim3(256), 0, st, v, n_records.p);
-            if (!tblk.empty())
+            if (!tblk.empty() && packed)
+                hipLaunchKernelGGL(k_cns_tiles_pk, dim3((unsigned)tblk.size()), dim3(CNS_THREADS), 0, st, pk_view(b), v, d_tblk.p, d_tstart.p, d_bctg.p, b->ctg_rec_begin.p, b->ctg_maxspan.p,
+                                   cnt.p, lins.p, n_lins.p, lins_cap);
+            else if (!tblk.empty())
                 hipLaunchKernelGGL(k_cns_tiles, dim3((unsigned)tblk.size()), dim3(CNS_THREADS), 0, st, rv, v, d_tblk.p, d_tstart.p, d_bctg.p, b->ctg_rec_begin.p, b->ctg_maxspan.p, cnt.p,
                                    version >= 2 ? lins.p : (LongIns *)nullptr, n_lins.p, lins_cap);
         } else {

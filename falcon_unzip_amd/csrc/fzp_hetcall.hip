@@ -9,6 +9,7 @@
 // word stream (4 B/op); per evaluated position: 16 B counters + 4 B symbol tracker written once
 // from LDS tiles and read back once, + 9 B of flag/scan state.  No MFMA: nothing here is GEMM-shaped.
 #include "fzp_expand.h"
+#include "fzp_pk.h"
 
 namespace {
 
@@ -126,32 +127,6 @@ __global__ void __launch_bounds__(PILE_THREADS) k_pileup_tiles(RecView v, const 
 // popcounts say what the word consumes, a wave scan gives every word the cell its first op leaves, and the lane walks its 16 ops -- an aligned column is an op 0 at cell
 // (i, j): reference position j, symbol = base i of the read (phasing.py:77-96; the stream's I / D ops are the walk's `qp += n` / `rp += n`).  ~12 instructions per op and
 // lane against ~55 per 64 columns and wave for the run-length form's expansion, i.e. about a third of the issue slots per column.
-struct PkView {
-    const int32_t *rec_pos, *rec_qid, *rec_ctg;
-    const int64_t *rec_read;
-    PkSrc s;
-    const int64_t *ctg_goff;
-    const int32_t *ctg_limit;
-    int64_t n_rec;
-};
-constexpr uint32_t PK_EVEN = 0x55555555u;
-__device__ __forceinline__ uint32_t pk_valid(int32_t wi, int32_t L) {       // one (even) bit per op of word wi that belongs to the stream
-    const int32_t nv = L - 16 * wi;
-    return nv >= 16 ? PK_EVEN : (nv <= 0 ? 0u : (((1u << (2 * nv)) - 1u) & PK_EVEN));
-}
-// the 16 read bases ending at base i (i >= 0), base i in bits 30..31
-__device__ __forceinline__ uint32_t pk_bases16(const uint32_t *__restrict__ pk, int32_t i) {
-    const int32_t w1 = i >> 4;
-    const uint64_t two = ((uint64_t)pk[w1] << 32) | (w1 > 0 ? pk[w1 - 1] : 0u);
-    return (uint32_t)(two >> (2 * (i & 15) + 2));
-}
-// largest checkpoint k in [0, nck) whose contig consumption is <= want (checkpoint 0 consumes nothing)
-__device__ __forceinline__ int32_t pk_ck_search(const int2 *__restrict__ ck, int32_t nck, int32_t want) {
-    int32_t a = 0, b = nck;
-    while (b - a > 1) { const int32_t m = (a + b) >> 1; if (ck[m].y <= want) a = m; else b = m; }
-    return a;
-}
-
 __global__ void __launch_bounds__(PILE_THREADS) k_pileup_pk(PkView v, const int32_t *__restrict__ tile_ctg, const int32_t *__restrict__ tile_start,
                                                             const int64_t *__restrict__ ctg_rec_begin, const int32_t *__restrict__ ctg_maxspan,
                                                             const int32_t *__restrict__ rec_span, uint32_t *__restrict__ cnt, uint32_t *__restrict__ oth,
@@ -647,13 +622,6 @@ RecView rec_view(const fzp_batch *b) {
     return v;
 }
 
-PkView pk_view(const fzp_batch *b) {
-    PkView v;
-    v.rec_pos = b->rec_pos.p; v.rec_qid = b->rec_qid.p; v.rec_ctg = b->rec_ctg.p; v.rec_read = b->rec_read.p;
-    v.s = b->pk;
-    v.ctg_goff = b->ctg_goff.p; v.ctg_limit = b->ctg_limit.p; v.n_rec = b->n_rec;
-    return v;
-}
 
 }  // namespace
 

@@ -154,3 +154,31 @@ def test_v1_still_matches_its_twin(eng, oracle):
     res = oracle.phase_all(c.sam, c.ref_seq, c.ctg_id)
     assert t.fasta(0, c.ctg_id) == oracle_lib.consensus(oracle, c.sam, c.ref_seq, res["phased_reads"], res["phased_variants"], c.ctg_id, version=1)
     t.close(); b.close()
+
+
+def test_packed_tally_equals_the_run_length_tally_on_indel_hets(eng, monkeypatch):
+    """r5: fzcns v3 tallies a batch that came from K1 in K1's own form -- 2-bit op streams, 2-bit reads (k_cns_tiles_pk) -- where it used to have the run-length CIGAR words and
+    byte SEQ made first.  Reads over a genome with multi-base indel hets and homopolymer-biased errors (insertion runs of every length, on and across word boundaries, on both
+    strands): the same tigs, byte for byte, as the run-length tally (FZP_K6_BYTES) of the same batch."""
+    from falcon_unzip_amd import _lib, sim
+    rng = np.random.Generator(np.random.PCG64(91))
+    L = 90000
+    hap0, hap1, map01, events = sim.make_diploid_indels(L, rng)
+    raw = [r[1] for r in sim.simulate_raw_reads_from(hap0, 300, 9000, rng, hp_bias=True, name_prefix="a")]
+    raw += [r[1] for r in sim.simulate_raw_reads_from(hap1, 300, 9000, rng, hp_bias=True, name_prefix="b")]
+    ctg = sim.codes_to_str(hap0).encode()
+    job = _lib.align_job(eng, [ctg], raw)
+    job.run()
+    fa = {}
+    for form in ("packed", "bytes"):
+        if form == "bytes":
+            monkeypatch.setenv("FZP_K6_BYTES", "1")
+        b = job.to_batch()
+        b.run(_lib.STAGE_ALL)
+        t = b.consensus()
+        fa[form] = t.fasta(0, "c")
+        assert len(t.tigs) >= 2
+        t.close(); b.close()
+    monkeypatch.delenv("FZP_K6_BYTES")
+    assert fa["packed"] == fa["bytes"] and len(fa["packed"]) > 100000
+    job.close()
