@@ -455,7 +455,7 @@ int fzp_k4_blocks(fzp_ctx *ctx, fzp_batch *b) {
         for (int c = 0; c < b->n_ctg; c++) max_sites = std::max<int64_t>(max_sites, b->h_site_begin[c + 1] - b->h_site_begin[c]);
         {
             ProfScope ps(ctx, "k4_sweep");
-            if (max_sites <= 60 * 1024)
+            if (max_sites <= 60 * 1024 && getenv("FZP_K4_SWEEP_GLOBAL") == nullptr)      // (FZP_K4_SWEEP_GLOBAL: the form for contigs whose states do not fit LDS, for the parity test)
                 hipLaunchKernelGGL(k_sweep<true>, dim3(b->n_ctg), dim3(64), (size_t)(256 + ((max_sites + 15) & ~15LL)), st, b->site_begin.p, b->left_n.p, b->left_off.p,
                                    b->left_pk.p, b->right_n.p, b->right_off.p, b->lk_i2.p, b->lk_cis.p, b->lk_trans.p, b->orient.p);
             else

@@ -46,6 +46,18 @@ def test_chain_vs_golden(eng, name):
 
 
 @pytest.mark.parametrize("name", CASES)
+def test_phase_blocks_with_the_states_in_global_memory(eng, name, monkeypatch):
+    """K4's sweep keeps a contig's site states in LDS when they fit (60 K sites) and in global memory otherwise; no golden contig has that many sites, so the second form is
+    asked for (FZP_K4_SWEEP_GLOBAL) and held against the same reference output."""
+    from falcon_unzip_amd import _lib
+    monkeypatch.setenv("FZP_K4_SWEEP_GLOBAL", "1")
+    c = Case(name)
+    out = _phase_all(eng, c.sam, c.ref_seq, c.ctg_id)
+    for k in ("phased_variants", "phased_reads"):
+        c.check(k, out[k])
+
+
+@pytest.mark.parametrize("name", CASES)
 def test_stages_from_golden_inputs(eng, name):
     """Each stage fed the GOLDEN output of the previous one, like the oracle test."""
     from falcon_unzip_amd import _lib, textio
