@@ -262,8 +262,13 @@ __global__ void __launch_bounds__(CNS_THREADS) k_cns_tiles_pk(PkView pv, CnsView
         const int64_t r = first + (i0 + lane) * NW + wave;
         bool ok = r < last;
         int32_t ka = 0, ph = 0;
+        // everything the walk of a record needs, fetched here by the record's lane and handed to the wave by lane reads: fetched in the walk, a record's five dependent loads
+        // (record -> read -> stream offset -> checkpoint -> ...) were most of its time -- a record is one or two steps of 64 words in a tile of 448 positions
+        int32_t L_iend = 0, L_jend = 0, L_nops = 0, L_strand = 0, L_cx = 0, L_cy = 0, L_pos0 = 0;
+        uint32_t L_rq = 0, L_wlo = 0, L_whi = 0;
         if (ok) {
             const int32_t pos0 = v.rec_pos[r];
+            L_pos0 = pos0;
             ok = pos0 + v.rec_span[r] > ts;
             if (ok) {
                 const int32_t q = v.rec_qid[r];
@@ -279,8 +284,13 @@ __global__ void __launch_bounds__(CNS_THREADS) k_cns_tiles_pk(PkView pv, CnsView
                     const int64_t rd = pv.rec_read[r];
                     const PkRec p = pv.s.prec[rd];
                     const int32_t nck = (((p.n_ops + 15) >> 4) + 15) >> 4;
+                    const uint32_t rq = pv.s.rcapq_scan[rd];
+                    const int2 *ckr = pv.s.ck + ((size_t)(rq >> 2) + (size_t)rd);
                     // start one position ABOVE the tile's last: the inserted bases that follow position te - 1 stand in the stream in front of its column
-                    ka = pk_ck_search(pv.s.ck + ((size_t)(pv.s.rcapq_scan[rd] >> 2) + (size_t)rd), nck, p.j_end - te);
+                    ka = pk_ck_search(ckr, nck, p.j_end - te);
+                    const int2 c0 = ckr[ka];
+                    const int64_t wo = pv.s.read_woff[rd];
+                    L_iend = p.i_end; L_jend = p.j_end; L_nops = p.n_ops; L_strand = p.strand; L_cx = c0.x; L_cy = c0.y; L_rq = rq; L_wlo = (uint32_t)wo; L_whi = (uint32_t)((uint64_t)wo >> 32);
                 }
             }
         }
@@ -291,12 +301,14 @@ __global__ void __launch_bounds__(CNS_THREADS) k_cns_tiles_pk(PkView pv, CnsView
             const int32_t k0 = __builtin_amdgcn_readlane(ka, l);
             const int phu = __builtin_amdgcn_readlane(ph, l);
             uint32_t *lc = l_cnt + phu * (CN * CNS_TILE);
-            const int32_t pos0 = v.rec_pos[ru];
-            const int64_t rd = pv.rec_read[ru];
-            const PkRec p = pv.s.prec[rd];
-            const uint32_t *__restrict__ ops = pv.s.ops + 4 * (size_t)pv.s.rcapq_scan[rd];
-            const int2 c0 = pv.s.ck[(size_t)(pv.s.rcapq_scan[rd] >> 2) + (size_t)rd + (size_t)k0];
-            const uint32_t *__restrict__ pk = (p.strand ? pv.s.read_rc : pv.s.read_pk) + pv.s.read_woff[rd];
+            (void)ru;
+            const int32_t pos0 = __builtin_amdgcn_readlane(L_pos0, l);
+            PkRec p;
+            p.i_end = __builtin_amdgcn_readlane(L_iend, l); p.j_end = __builtin_amdgcn_readlane(L_jend, l); p.n_ops = __builtin_amdgcn_readlane(L_nops, l); p.strand = __builtin_amdgcn_readlane(L_strand, l);
+            const uint32_t *__restrict__ ops = pv.s.ops + 4 * (size_t)(uint32_t)__builtin_amdgcn_readlane((int)L_rq, l);
+            const int2 c0 = make_int2(__builtin_amdgcn_readlane(L_cx, l), __builtin_amdgcn_readlane(L_cy, l));
+            const int64_t wo = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)L_whi, l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)L_wlo, l));
+            const uint32_t *__restrict__ pk = (p.strand ? pv.s.read_rc : pv.s.read_pk) + wo;
             const int32_t nW = (p.n_ops + 15) >> 4;
             int32_t ib = p.i_end - c0.x, jb = p.j_end - c0.y;              // the cell the chunk's first op leaves
             for (int32_t w0 = 16 * k0; w0 < nW && jb >= ts; w0 += 64) {

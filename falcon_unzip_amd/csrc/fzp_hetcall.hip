@@ -161,26 +161,34 @@ __global__ void __launch_bounds__(PILE_THREADS) k_pileup_pk(PkView v, const int3
         const int64_t r = lo + (i0 + lane) * NW + wave;
         bool ok = r < hi;
         int32_t ka = 0;
+        // (what a record's walk needs is fetched here, by the record's lane, and handed to the wave by lane reads: fetched in the walk, the record's dependent loads -- record ->
+        //  read -> stream offset -> checkpoint -- stood in front of every record's two or three steps of 64 words)
+        int32_t L_iend = 0, L_jend = 0, L_nops = 0, L_strand = 0, L_cx = 0, L_cy = 0;
+        uint32_t L_rq = 0, L_wlo = 0, L_whi = 0;
         if (ok) {
             ok = v.rec_pos[r] + rec_span[r] > ts;
             if (ok) {
                 const int64_t rd = v.rec_read[r];
                 const PkRec p = v.s.prec[rd];
                 const int32_t nck = (((p.n_ops + 15) >> 4) + 15) >> 4;
+                const uint32_t rq = v.s.rcapq_scan[rd];
+                const int2 *ckr = v.s.ck + ((size_t)(rq >> 2) + (size_t)rd);
                 // the stream runs from the alignment's end down: start at the last checkpoint that has not yet passed the tile's last position
-                ka = pk_ck_search(v.s.ck + ((size_t)(v.s.rcapq_scan[rd] >> 2) + (size_t)rd), nck, p.j_end - (te - 1));
+                ka = pk_ck_search(ckr, nck, p.j_end - (te - 1));
+                const int2 c0 = ckr[ka];
+                const int64_t wo = v.s.read_woff[rd];
+                L_iend = p.i_end; L_jend = p.j_end; L_nops = p.n_ops; L_strand = p.strand; L_cx = c0.x; L_cy = c0.y; L_rq = rq; L_wlo = (uint32_t)wo; L_whi = (uint32_t)((uint64_t)wo >> 32);
             }
         }
-        const int32_t rel = (int32_t)(r - lo);
         for (uint64_t todo = __ballot(ok); todo; todo &= todo - 1) {
             const int l = __builtin_ctzll(todo);
-            const int64_t ru = lo + __builtin_amdgcn_readlane(rel, l);
             const int32_t k0 = __builtin_amdgcn_readlane(ka, l);
-            const int64_t rd = v.rec_read[ru];
-            const PkRec p = v.s.prec[rd];
-            const uint32_t *__restrict__ ops = v.s.ops + 4 * (size_t)v.s.rcapq_scan[rd];
-            const int2 c0 = v.s.ck[(size_t)(v.s.rcapq_scan[rd] >> 2) + (size_t)rd + (size_t)k0];
-            const uint32_t *__restrict__ pk = (p.strand ? v.s.read_rc : v.s.read_pk) + v.s.read_woff[rd];
+            PkRec p;
+            p.i_end = __builtin_amdgcn_readlane(L_iend, l); p.j_end = __builtin_amdgcn_readlane(L_jend, l); p.n_ops = __builtin_amdgcn_readlane(L_nops, l); p.strand = __builtin_amdgcn_readlane(L_strand, l);
+            const uint32_t *__restrict__ ops = v.s.ops + 4 * (size_t)(uint32_t)__builtin_amdgcn_readlane((int)L_rq, l);
+            const int2 c0 = make_int2(__builtin_amdgcn_readlane(L_cx, l), __builtin_amdgcn_readlane(L_cy, l));
+            const int64_t wo = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)L_whi, l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)L_wlo, l));
+            const uint32_t *__restrict__ pk = (p.strand ? v.s.read_rc : v.s.read_pk) + wo;
             const int32_t nW = (p.n_ops + 15) >> 4;
             int32_t ib = p.i_end - c0.x, jb = p.j_end - c0.y;              // the cell the chunk's first op leaves
             for (int32_t w0 = 16 * k0; w0 < nW && jb >= ts; w0 += 64) {
