@@ -780,8 +780,14 @@ int fzp_k3_assoc(fzp_ctx *ctx, fzp_batch *b) {
     if (ns > 0) {
         hipLaunchKernelGGL(k_cand, dim3(grid_for(ns, 256, 1 << 30)), dim3(256), 0, st, b->site_g.p, b->site_ctg.p, b->site_begin.p, ns, b->cand_n.p, b->cap_off.p);
         FZP_TRY(fzp_exclusive_scan_u32(ctx, b->cap_off.p, b->cap_off.p, (size_t)ns, b->totals.p + 2));
-        FZP_TRY(fzp_fetch(ctx, st, tot, b->totals.p + 2, sizeof(uint64_t)));
-        if (tot[0] >= (1ull << 31)) { fzp_set_error("association table bound %llu rows (> 2^31)", (unsigned long long)tot[0]); return FZP_EINVAL; }
+        // room for the candidate rows: a site has at most 501 of them (k_cand), so 501 per site is room enough and the host need not ask how many there are (r5: one
+        // read-back less) -- unless that bound is itself too large a block (64 M rows), then it asks
+        const uint64_t bound = (uint64_t)ns * 501ull;
+        if (bound <= (64ull << 20)) tot[0] = bound;
+        else {
+            FZP_TRY(fzp_fetch(ctx, st, tot, b->totals.p + 2, sizeof(uint64_t)));
+            if (tot[0] >= (1ull << 31)) { fzp_set_error("association table bound %llu rows (> 2^31)", (unsigned long long)tot[0]); return FZP_EINVAL; }
+        }
         FZP_TRY(b->arows_tmp.alloc((size_t)tot[0]));
         {
             ProfScope ps(ctx, "k3_assoc");
