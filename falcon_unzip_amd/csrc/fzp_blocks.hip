@@ -114,21 +114,23 @@ __global__ void __launch_bounds__(256) k_pj_resolve(int64_t n_sites, uint32_t *_
 //      site with d < 0 behind it, and so on.  Sites behind the block see the new states when their block is summed.
 // A block without flips -- nearly all of them after the first sweep -- costs its links once.
 template <bool USE_LDS>
-__global__ void __launch_bounds__(64) k_sweep(const int64_t *__restrict__ site_begin, const uint32_t *__restrict__ left_n, const uint32_t *__restrict__ left_off,
-                                              const int4 *__restrict__ left_pk, const uint32_t *__restrict__ right_n, const uint32_t *__restrict__ right_off,
-                                              const int32_t *__restrict__ lk_i2, const int32_t *__restrict__ lk_cis, const int32_t *__restrict__ lk_trans,
-                                              uint8_t *__restrict__ orient) {
+__global__ void __launch_bounds__(256) k_sweep(const int64_t *__restrict__ site_begin, const uint32_t *__restrict__ left_n, const uint32_t *__restrict__ left_off,
+                                               const int4 *__restrict__ left_pk, const uint32_t *__restrict__ right_n, const uint32_t *__restrict__ right_off,
+                                               const int32_t *__restrict__ lk_i2, const int32_t *__restrict__ lk_cis, const int32_t *__restrict__ lk_trans,
+                                               uint8_t *__restrict__ orient) {
+    // four waves per contig: the links of a block are summed by all 256 threads (that sum is nearly all of the work); every wave then reads the same 64 cells and takes the
+    // same decisions, the flips' deltas are spread over the threads again
     extern __shared__ uint8_t sweep_lds[];
     int32_t *d = (int32_t *)sweep_lds;                    // 64 sites' score differences
     uint8_t *o_lds = sweep_lds + 256;
-    const int lane = lane_id();
+    const int tid = threadIdx.x, lane = tid & 63;
     const int c = blockIdx.x;
     const int64_t sb = site_begin[c], se = site_begin[c + 1];
     const int64_t n = se - sb;
     if (n <= 0) return;
     uint8_t *o = USE_LDS ? o_lds : (orient + sb);
     if (USE_LDS) {
-        for (int64_t i = lane; i < n; i += 64) o_lds[i] = orient[sb + i];
+        for (int64_t i = tid; i < n; i += 256) o_lds[i] = orient[sb + i];
         __syncthreads();
     }
     for (int iter = 1; iter <= 10; iter++) {
@@ -138,12 +140,12 @@ __global__ void __launch_bounds__(64) k_sweep(const int64_t *__restrict__ site_b
             const int64_t g0 = sb + p0;                   // the block's first site
             // 1. the block's links: [L0, L1) of the link array
             const uint32_t L0 = left_off[g0], L1 = left_off[g0 + nb - 1] + left_n[g0 + nb - 1];
-            d[lane] = 0;
+            if (tid < 64) d[tid] = 0;
             __syncthreads();
-            for (uint32_t j = L0 + (uint32_t)lane; j < L1; j += 256) {      // four loads of a lane in flight: a single wave has nothing else to hide their latency with
+            for (uint32_t j = L0 + (uint32_t)tid; j < L1; j += 1024) {      // four loads of a thread in flight
                 int4 e[4];
 #pragma unroll
-                for (int u = 0; u < 4; u++) e[u] = j + 64u * u < L1 ? left_pk[j + 64u * u] : make_int4((int)g0, 0, 0, (int)g0);      // (left site, cis, trans, this site); beyond the run: adds 0
+                for (int u = 0; u < 4; u++) e[u] = j + 256u * u < L1 ? left_pk[j + 256u * u] : make_int4((int)g0, 0, 0, (int)g0);      // (left site, cis, trans, this site); beyond the run: adds 0
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const bool same = o[e[u].x - sb] == o[e[u].w - sb];
@@ -157,13 +159,14 @@ __global__ void __launch_bounds__(64) k_sweep(const int64_t *__restrict__ site_b
             int start = 0;
             for (;;) {
                 const int32_t dv = lane < nb ? d[lane] : 0;
-                const uint64_t m = __ballot(lane >= start && dv < 0);
+                const uint64_t m = __ballot(lane >= start && dv < 0);      // (the same in every wave)
                 if (!m) break;                            // score1 >= score2 keeps the state (phasing.py:338-342)
                 const int F = __builtin_ctzll(m);
                 const int64_t gF = g0 + F;
                 const uint8_t oF = o[p0 + F];
                 const uint32_t r0 = right_off[gF], rn = right_n[gF];
-                for (uint32_t k = (uint32_t)lane; k < rn; k += 64) {      // what F's flip does to the later sites of this block
+                __syncthreads();                          // every wave has read the cells before any of them changes
+                for (uint32_t k = (uint32_t)tid; k < rn; k += 256) {      // what F's flip does to the later sites of this block
                     const int32_t t = lk_i2[r0 + k];
                     if (t < g0 + nb) {
                         const bool same = o[t - sb] == oF;
@@ -172,7 +175,7 @@ __global__ void __launch_bounds__(64) k_sweep(const int64_t *__restrict__ site_b
                     }
                 }
                 __syncthreads();
-                if (lane == 0) o[p0 + F] = oF ^ 1;
+                if (tid == 0) o[p0 + F] = oF ^ 1;
                 updates++;
                 if (!USE_LDS) __threadfence_block();
                 __syncthreads();
@@ -183,7 +186,7 @@ __global__ void __launch_bounds__(64) k_sweep(const int64_t *__restrict__ site_b
     }
     if (USE_LDS) {
         __syncthreads();
-        for (int64_t i = lane; i < n; i += 64) orient[sb + i] = o_lds[i];
+        for (int64_t i = tid; i < n; i += 256) orient[sb + i] = o_lds[i];
     }
 }
 
@@ -456,10 +459,10 @@ int fzp_k4_blocks(fzp_ctx *ctx, fzp_batch *b) {
         {
             ProfScope ps(ctx, "k4_sweep");
             if (max_sites <= 60 * 1024 && getenv("FZP_K4_SWEEP_GLOBAL") == nullptr)      // (FZP_K4_SWEEP_GLOBAL: the form for contigs whose states do not fit LDS, for the parity test)
-                hipLaunchKernelGGL(k_sweep<true>, dim3(b->n_ctg), dim3(64), (size_t)(256 + ((max_sites + 15) & ~15LL)), st, b->site_begin.p, b->left_n.p, b->left_off.p,
+                hipLaunchKernelGGL(k_sweep<true>, dim3(b->n_ctg), dim3(256), (size_t)(256 + ((max_sites + 15) & ~15LL)), st, b->site_begin.p, b->left_n.p, b->left_off.p,
                                    b->left_pk.p, b->right_n.p, b->right_off.p, b->lk_i2.p, b->lk_cis.p, b->lk_trans.p, b->orient.p);
             else
-                hipLaunchKernelGGL(k_sweep<false>, dim3(b->n_ctg), dim3(64), 256, st, b->site_begin.p, b->left_n.p, b->left_off.p, b->left_pk.p, b->right_n.p, b->right_off.p,
+                hipLaunchKernelGGL(k_sweep<false>, dim3(b->n_ctg), dim3(256), 256, st, b->site_begin.p, b->left_n.p, b->left_off.p, b->left_pk.p, b->right_n.p, b->right_off.p,
                                    b->lk_i2.p, b->lk_cis.p, b->lk_trans.p, b->orient.p);
         }
         {
