@@ -229,62 +229,86 @@ __global__ void __launch_bounds__(256) k_extents(int64_t n_sites, const fzp_site
 }
 
 // ---- block segmentation (phasing.py:388-408) and 'V' records: one wave per contig
-__global__ void __launch_bounds__(64) k_segment(const int64_t *__restrict__ site_begin, const fzp_site *__restrict__ sites, const uint8_t *__restrict__ orient,
-                                                const int32_t *__restrict__ lext, const int32_t *__restrict__ rext, const int32_t *__restrict__ lscore,
-                                                const int32_t *__restrict__ rscore, int32_t *__restrict__ rawblk, int32_t *__restrict__ blkcnt,
-                                                int32_t *__restrict__ blknew, fzp_pvar *__restrict__ pv_tmp, uint32_t *__restrict__ pv_n,
-                                                int32_t *__restrict__ site_blk, uint8_t *__restrict__ site_b1) {
-    const int lane = lane_id();
+__global__ void __launch_bounds__(256) k_segment(const int64_t *__restrict__ site_begin, const fzp_site *__restrict__ sites, const uint8_t *__restrict__ orient,
+                                                 const int32_t *__restrict__ lext, const int32_t *__restrict__ rext, const int32_t *__restrict__ lscore,
+                                                 const int32_t *__restrict__ rscore, int32_t *__restrict__ rawblk, int32_t *__restrict__ blkcnt,
+                                                 int32_t *__restrict__ blknew, fzp_pvar *__restrict__ pv_tmp, uint32_t *__restrict__ pv_n,
+                                                 int32_t *__restrict__ site_blk, uint8_t *__restrict__ site_b1) {
+    // (r5: 256 sites per step -- four waves whose running maxima and counts meet in LDS -- where one wave took 64; a genome-scale group spent 0.8 ms per call here on seven waves)
+    __shared__ int32_t w_max[4], w_cnt[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = blockIdx.x;
     const int64_t sb = site_begin[c], se = site_begin[c + 1];
     const int64_t n = se - sb;
-    if (n <= 0) { if (lane == 0) pv_n[c] = 0; return; }
+    if (n <= 0) { if (tid == 0) pv_n[c] = 0; return; }
     // pass A: raw block ids.  max_right_ext is a running max over qualifying sites, never reset.
     int32_t carryM = 0, carryB = 0;
-    for (int64_t base = 0; base < n; base += 64) {
-        int64_t s = sb + base + lane;
-        bool in = base + lane < n;
-        bool q = in && !(rscore[s] < 10 || lscore[s] < 10);
-        int32_t r = q ? rext[s] : 0;
+    for (int64_t base = 0; base < n; base += 256) {
+        const int64_t s = sb + base + tid;
+        const bool in = base + tid < n;
+        const bool q = in && !(rscore[s] < 10 || lscore[s] < 10);
+        const int32_t r = q ? rext[s] : 0;
         int32_t incl = r;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
-            int32_t t = __shfl_up(incl, d, 64);
+            const int32_t t = __shfl_up(incl, d, 64);
             if (lane >= d) incl = max(incl, t);
         }
+        if (lane == 63) w_max[wave] = incl;
+        __syncthreads();
+        int32_t before = carryM, all = carryM;              // the running maximum before this wave's first site / behind the step's last
+#pragma unroll
+        for (int w = 0; w < 4; w++) { const int32_t v = w_max[w]; if (w < wave) before = max(before, v); all = max(all, v); }
         int32_t excl = __shfl_up(incl, 1, 64);
         if (lane == 0) excl = 0;
-        excl = max(excl, carryM);
-        bool nb = q && (excl < lext[s]);
-        uint64_t m = __ballot(nb);
-        int32_t id = carryB + __popcll(m & ((2ull << lane) - 1ull));   // inclusive count
+        excl = max(excl, before);
+        const bool nb = q && (excl < lext[s]);
+        const uint64_t m = __ballot(nb);
+        if (lane == 0) w_cnt[wave] = __popcll(m);
+        __syncthreads();
+        int32_t cb = carryB, call = carryB;
+#pragma unroll
+        for (int w = 0; w < 4; w++) { const int32_t v = w_cnt[w]; if (w < wave) cb += v; call += v; }
+        const int32_t id = cb + __popcll(m & ((2ull << lane) - 1ull));   // inclusive count
         if (in) rawblk[s] = q ? id : 0;
         if (q) atomicAdd(&blkcnt[sb + id - 1], 1);
-        carryM = max(carryM, __shfl(incl, 63, 64));
-        carryB += __popcll(m);
+        carryM = all;
+        carryB = call;
+        __syncthreads();                                     // (w_max / w_cnt are written again in the next step)
     }
     __threadfence_block();
     __syncthreads();
     // pass B: blocks with more than 3 variants get dense ids from 1 (phasing.py:398-408)
     int32_t carryI = 0;
-    for (int32_t base = 0; base < carryB; base += 64) {
-        int32_t j = base + lane;
-        bool keep = j < carryB && blkcnt[sb + j] > 3;
-        uint64_t m = __ballot(keep);
-        if (j < carryB) blknew[sb + j] = keep ? carryI + 1 + __popcll(m & ((1ull << lane) - 1ull)) : 0;
-        carryI += __popcll(m);
+    for (int32_t base = 0; base < carryB; base += 256) {
+        const int32_t j = base + tid;
+        const bool keep = j < carryB && blkcnt[sb + j] > 3;
+        const uint64_t m = __ballot(keep);
+        if (lane == 0) w_cnt[wave] = __popcll(m);
+        __syncthreads();
+        int32_t ci = carryI, call = carryI;
+#pragma unroll
+        for (int w = 0; w < 4; w++) { const int32_t v = w_cnt[w]; if (w < wave) ci += v; call += v; }
+        if (j < carryB) blknew[sb + j] = keep ? ci + 1 + __popcll(m & ((1ull << lane) - 1ull)) : 0;
+        carryI = call;
+        __syncthreads();
     }
     __threadfence_block();
     __syncthreads();
     // pass C: 'V' records in site order
     uint32_t out = 0;
-    for (int64_t base = 0; base < n; base += 64) {
-        int64_t s = sb + base + lane;
-        bool in = base + lane < n;
-        int32_t rb = in ? rawblk[s] : 0;
-        int32_t nid = rb > 0 ? blknew[sb + rb - 1] : 0;
-        bool has = nid > 0;
-        uint64_t m = __ballot(has);
+    for (int64_t base = 0; base < n; base += 256) {
+        const int64_t s = sb + base + tid;
+        const bool in = base + tid < n;
+        const int32_t rb = in ? rawblk[s] : 0;
+        const int32_t nid = rb > 0 ? blknew[sb + rb - 1] : 0;
+        const bool has = nid > 0;
+        const uint64_t m = __ballot(has);
+        if (lane == 0) w_cnt[wave] = __popcll(m);
+        __syncthreads();
+        uint32_t at = out, call = out;
+#pragma unroll
+        for (int w = 0; w < 4; w++) { const uint32_t v = (uint32_t)w_cnt[w]; if (w < wave) at += v; call += v; }
         uint8_t b1 = 0, b2 = 0;
         if (in) {
             const fzp_site &st = sites[s];
@@ -298,11 +322,12 @@ __global__ void __launch_bounds__(64) k_segment(const int64_t *__restrict__ site
             fzp_pvar v;
             v.block = nid; v.site = (int32_t)s; v.b1 = b1; v.b2 = b2; v.pad_[0] = v.pad_[1] = 0;
             v.lext = lext[s]; v.rext = rext[s]; v.lscore = lscore[s]; v.rscore = rscore[s];
-            pv_tmp[sb + out + __popcll(m & ((1ull << lane) - 1ull))] = v;
+            pv_tmp[sb + at + __popcll(m & ((1ull << lane) - 1ull))] = v;
         }
-        out += __popcll(m);
+        out = call;
+        __syncthreads();
     }
-    if (lane == 0) pv_n[c] = out;
+    if (tid == 0) pv_n[c] = out;
 }
 
 __global__ void __launch_bounds__(256) k_pv_compact(const int64_t *__restrict__ site_begin, const uint32_t *__restrict__ pv_n, const uint32_t *__restrict__ pv_off,
@@ -473,7 +498,7 @@ int fzp_k4_blocks(fzp_ctx *ctx, fzp_batch *b) {
     }
     {
         ProfScope ps(ctx, "k4_segment");
-        hipLaunchKernelGGL(k_segment, dim3(b->n_ctg), dim3(64), 0, st, b->site_begin.p, b->sites.p, b->orient.p, b->lext.p, b->rext.p, b->lscore.p, b->rscore.p,
+        hipLaunchKernelGGL(k_segment, dim3(b->n_ctg), dim3(256), 0, st, b->site_begin.p, b->sites.p, b->orient.p, b->lext.p, b->rext.p, b->lscore.p, b->rscore.p,
                            b->rawblk.p, b->blkcnt.p, b->blknew.p, b->pvars_tmp.p, b->pv_n.p, b->site_blk.p, b->site_b1.p);
     }
     FZP_TRY(fzp_exclusive_scan_u32(ctx, b->pv_n.p, b->pv_off.p, (size_t)b->n_ctg, b->totals.p + 5));
