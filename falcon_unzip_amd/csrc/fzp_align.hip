@@ -1135,7 +1135,7 @@ struct LaneStream {                // upcoming bases of one sequence, per lane: 
         const uint32_t w0 = (uint32_t)(idx >> 4);
         const uint32_t sh = (uint32_t)(idx & 15) * 2u;
         pk = pk_; lim = lim_;
-        cur = ((uint64_t)pk[w0] | ((uint64_t)pk[w0 + 1] << 32)) >> sh;
+        cur = ((uint64_t)(w0 < lim ? pk[w0] : 0u) | ((uint64_t)(w0 + 1u < lim ? pk[w0 + 1u] : 0u) << 32)) >> sh;      // (words from `lim` on: see LaneStreamL::init)
         have = 32 - (int32_t)(idx & 15);
         w = w0 + 2;
         pend = pk[w < lim ? w : lim - 1u];
@@ -1157,36 +1157,33 @@ struct LaneStream {                // upcoming bases of one sequence, per lane: 
     __device__ __forceinline__ void drop(uint32_t en) { cur >>= 2u * en; have -= (int32_t)en; }
 };
 
-#ifndef FZP_SWB_RING      // (build-time experiments: -DFZP_SWB_RING=32 -DFZP_SWB_HOLD=8 -DFZP_SWB_GROUP=4 -DFZP_SWB_WAVES=2; the defaults are the measured best)
-#define FZP_SWB_RING 64
-#endif
-#ifndef FZP_SWB_HOLD
-#define FZP_SWB_HOLD 16
-#endif
-#ifndef FZP_SWB_GROUP
-#define FZP_SWB_GROUP 8
-#endif
-constexpr int SWB_RING = FZP_SWB_RING;                // words per lane in a stream's ring
-constexpr int SWB_HOLD = FZP_SWB_HOLD;                // words a bulk load brings
-constexpr int SWB_BULK_STEPS = 16 * SWB_HOLD;         // steps between bulk loads (a step takes at most one base: SWB_HOLD words at most leave the ring in between)
+// The bit-sliced kernel exists in two register budgets, both compiled in (r6; until r5 the second was a build-time experiment):
+//   one wave per SIMD  (RINGW 64, HOLDW 16, GRP 8: ~330 registers) -- the step with the fewest instructions,
+//   two waves per SIMD (RINGW 32, HOLDW  8, GRP 4: <= 256 registers, 16 KB of LDS per wave) -- a step takes ~1.4 x as long but two run side by side.
+// RINGW: words per lane in a stream's ring; HOLDW: words a bulk load brings; GRP: steps whose mask records leave together.
+template <int RINGW, int HOLDW>
 struct LaneStreamL {
+    static constexpr int BULK_STEPS = 16 * HOLDW;      // steps between bulk loads (a step takes at most one base: HOLDW words at most leave the ring in between)
     const uint32_t *pk;            // the sequence's words
     uint32_t *ring;                // this lane's column of its stream's ring
     uint64_t cur;
     uint32_t pend, rd, wr, gw, lim;
-    uint32_t hold[SWB_HOLD], hold_base;  // sixteen words on their way from HBM to the ring (bulk)
+    uint32_t hold[HOLDW], hold_base;     // HOLDW words on their way from HBM to the ring (bulk)
     bool held;
     int32_t have;
+    // idx: the next base the stream hands out.  (Also called when a work unit picks a piece up in the middle, r6: then idx may lie at or past the sequence's end -- words from
+    // `lim` on read as zero, exactly what the ring hands out there when the stream gets that far by itself.)
     __device__ __forceinline__ void init(const uint32_t *pk_, int64_t idx, uint32_t lim_, uint32_t *ring_) {
         pk = pk_; ring = ring_; lim = lim_; held = false; hold_base = 0;
 #pragma unroll
-        for (int q = 0; q < SWB_HOLD; q++) hold[q] = 0u;
+        for (int q = 0; q < HOLDW; q++) hold[q] = 0u;
         const uint32_t w = (uint32_t)(idx >> 4);
         const uint32_t sh = (uint32_t)(idx & 15) * 2u;
-        cur = ((uint64_t)pk[w] | ((uint64_t)pk[w + 1] << 32)) >> sh;
+        const uint32_t a0 = w < lim ? pk[w] : 0u, a1 = w + 1u < lim ? pk[w + 1u] : 0u;
+        cur = ((uint64_t)a0 | ((uint64_t)a1 << 32)) >> sh;
         have = 32 - (int32_t)(idx & 15);
         gw = w + 2;
-        for (int q0 = 0; q0 < SWB_RING; q0 += 16) {
+        for (int q0 = 0; q0 < RINGW; q0 += 16) {
             uint32_t v[16];
 #pragma unroll
             for (int q = 0; q < 16; q++) v[q] = 0u;
@@ -1197,7 +1194,7 @@ struct LaneStreamL {
 #pragma unroll
             for (int q = 0; q < 16; q++) ring[(q0 + q) * 64] = gw + q0 + q < lim ? v[q] : 0u;
         }
-        gw += SWB_RING; wr = SWB_RING; rd = 1;
+        gw += RINGW; wr = RINGW; rd = 1;
         pend = ring[0];
     }
     __device__ __forceinline__ void refill(const int32_t popped) {      // popped: bases taken since the last call (the kernel knows from the moves: pop() does not count)
@@ -1205,24 +1202,24 @@ struct LaneStreamL {
         const bool m = have <= 16;
         cur |= m ? (uint64_t)pend << (2 * have) : 0ull;
         have += m ? 16 : 0;
-        const uint32_t nx = ring[(rd & (uint32_t)(SWB_RING - 1)) * 64];
+        const uint32_t nx = ring[(rd & (uint32_t)(RINGW - 1)) * 64];
         pend = m ? nx : pend;
         rd += m ? 1u : 0u;
     }
-    // every SWB_BULK_STEPS steps (at most SWB_HOLD words leave the ring in between).  What a call loads goes into the ring at the NEXT call: by then more than 63 vector-memory operations
+    // every BULK_STEPS steps (at most HOLDW words leave the ring in between).  What a call loads goes into the ring at the NEXT call: by then more than 63 vector-memory operations
     // have been issued behind the loads, which is more than can be outstanding -- no wait is needed to use them, and none is spent behind the mask stores.
     __device__ __forceinline__ void bulk() {
         if (held) {
 #pragma unroll
-            for (int q = 0; q < SWB_HOLD; q++) ring[((wr + q) & (uint32_t)(SWB_RING - 1)) * 64] = hold_base + q < lim ? hold[q] : 0u;
-            wr += (uint32_t)SWB_HOLD;
+            for (int q = 0; q < HOLDW; q++) ring[((wr + q) & (uint32_t)(RINGW - 1)) * 64] = hold_base + q < lim ? hold[q] : 0u;
+            wr += (uint32_t)HOLDW;
         }
-        held = wr - rd <= (uint32_t)(SWB_RING - 2 * SWB_HOLD);      // (room for these words when they arrive, and for what may still be on its way)
+        held = wr - rd <= (uint32_t)(RINGW - 2 * HOLDW);      // (room for these words when they arrive, and for what may still be on its way)
         if (held) {
             hold_base = gw;
 #pragma unroll
-            for (int q = 0; q < SWB_HOLD; q++) { const uint32_t ix = gw + q; hold[q] = pk[ix < lim ? ix : lim - 1u]; }
-            gw += (uint32_t)SWB_HOLD;
+            for (int q = 0; q < HOLDW; q++) { const uint32_t ix = gw + q; hold[q] = pk[ix < lim ? ix : lim - 1u]; }
+            gw += (uint32_t)HOLDW;
         }
     }
     __device__ __forceinline__ uint32_t peek() const { return (uint32_t)cur; }      // the next base in bits 1:0
@@ -1300,38 +1297,132 @@ __device__ __forceinline__ void swb_step(LANE &L, const int32_t t, const int s8,
     L.down = (CHECKED && (t + 1) < 64) ? (uint32_t)(((t + 1) & 1) == 0) : ((uint32_t)L.E2 >> 31) ^ 1u;      // DOWN while lane 63's cell scores at least lane 0's
 }
 
-constexpr int SWB_GROUP = FZP_SWB_GROUP;      // steps whose mask records leave together (64 B per lane)
-constexpr int SWB_WAVES_PER_SIMD = (FZP_SWB_GROUP <= 4 && FZP_SWB_RING <= 32 && FZP_SWB_HOLD <= 8) ? 2 : 1;      // what the register and LDS budget of the build admits (checked with -Rpass-analysis=kernel-resource-usage)
-// RING: the base streams through rings in LDS (LaneStreamL) or straight from HBM (LaneStream; FZP_SWB_NO_RING, for comparisons)
-#ifdef FZP_SWB_WAVES
-#define SWB_OCC __attribute__((amdgpu_waves_per_eu(FZP_SWB_WAVES, FZP_SWB_WAVES)))
-#else
-#define SWB_OCC
-#endif
-template <bool RING>
-__global__ void SWB_OCC __launch_bounds__(256) k_swb(const uint64_t *__restrict__ n_b_dev, const uint32_t *__restrict__ list, const Slot *__restrict__ slots,
-                                             const uint32_t *__restrict__ read_pk, const uint32_t *__restrict__ read_rc, const int64_t *__restrict__ read_woff,
-                                             const uint32_t *__restrict__ ctg_pk, const uint32_t *__restrict__ ctg_rc, const int64_t *__restrict__ ctg_woff,
-                                             const int64_t *__restrict__ tbo, const int64_t *__restrict__ mvo, uint2 *__restrict__ tb, ulonglong2 *__restrict__ mvw,
-                                             DpInfo *__restrict__ info, int dbg, uint64_t *__restrict__ wave_log, unsigned long long *__restrict__ next_group) {
-    using namespace swb;
-    __shared__ uint32_t srng[RING ? 2 * SWB_RING * 64 : 1];                // the two streams' rings
-    // PERSISTENT waves (r5): the launch has as many one-wave workgroups as the chip has wave slots for this kernel, and a wave PULLS launch groups of 64 slots -- the list is in
-    // decreasing length -- until none is left.  (A grid of one workgroup per group left the slots of the last round half empty: 3 536 groups on 1 024 slots ran at 926 busy
-    // slots on average, tools/runs/swb_waves.py; with work pulled the waves end within one short group of each other.)
+// ---- work units (r6).  A launch group is 64 slots of about one length, and until r5 a persistent wave pulled whole groups: 3 568 groups of two lengths on 1 024 (or, with
+// the two-wave budget, 2 048) wave slots end in a round that leaves half of the chip idle, and the longest group of all is a chain of 13 000 steps that must not start
+// late or share its SIMD badly (profiles/r5_swb_waves_one_vs_two.txt, profiles/r6_swb_units.txt).  Now the kernel runs a group in UNITS of `ub` 64-step blocks and
+// schedules LONGEST REMAINING FIRST: a group's level is the number of units it still has; at every unit boundary the wave looks whether work of a higher level waits
+// -- a group nobody has started, or one another wave has parked -- and if so parks its own group and takes that one; otherwise it carries on, at no cost.  Parking is
+// cheap because the state of a piece between two blocks is small -- two x three difference planes, four base-window planes, the steering and terminal scalars: 30
+// words per lane; the base streams are found again from (i0, t) -- 8 KB per group in HBM.  So the long chains run without a break from the start, groups of one length
+// take turns, and the launch ends within a unit on every wave.  Results do not depend on the cuts: a block's outcome is a function of the state at its first step.
+//   level k's work: the FRESH groups of exactly k units -- a run [c[k+1], c[k]) of the sorted list, handed out by a counter -- and a bag of PARKED groups (at most
+//   c[k+1] entries: a group is parked at a level at most once), filled behind a tail counter and counted in `avail`; a taker first takes one off `avail` -- and gives
+//   it back if there was none -- and only then a ticket of the head counter: nobody ever holds a ticket for an entry that no push has been started for, so no wait
+//   depends on work that may never come.  (A compare-and-swap on the head counter, the first form, let 2 048 waves retry against each other: 50 ms.)
+// How a parked group's state is ordered: the state words and the bag entry are agent-scope RELAXED atomics -- stores that write through and loads that read past an XCD's
+// own L2 --, the writer waits for its stores (s_waitcnt) before it posts the entry, the reader looks at the state only after it has seen the entry.  Release / acquire
+// FENCES are the textbook form and were measured first: at agent scope each one writes back / invalidates the XCD's whole L2, and ~40 000 of them per launch took
+// the launch from 6 to 15 ms.
+constexpr int SWB_MAX_LEVELS = 64;                     // a wave looks at all levels at once, one per lane
+constexpr int SWB_STATE_WORDS = 32;                    // per lane and group (30 used)
+constexpr uint32_t SWB_NONE = 0xffffffffu;
+struct SwbUnitPlan {
+    uint32_t n_groups, nk_max, ub, hyst;
+    uint32_t c[SWB_MAX_LEVELS + 2];                    // c[k] = groups of at least k units (c[0] = c[1] = all); the fresh groups of level k are [c[k+1], c[k])
+    uint32_t bag_off[SWB_MAX_LEVELS + 2];              // where level k's bag of parked groups begins
+};
+struct SwbUnitCtr { uint32_t fresh[SWB_MAX_LEVELS + 2], head[SWB_MAX_LEVELS + 2], tail[SWB_MAX_LEVELS + 2]; int32_t avail[SWB_MAX_LEVELS + 2]; uint32_t done, n_log, pad_[2]; };      // zeroed per launch
+__global__ void __launch_bounds__(256) k_swb_units(const uint64_t *__restrict__ n_b_dev, const uint32_t *__restrict__ gq, uint32_t ub_req, uint32_t hyst, SwbUnitPlan *__restrict__ plan) {
+    __shared__ uint32_t cc[SWB_MAX_LEVELS + 2];
     const uint32_t n_groups = (uint32_t)((*n_b_dev + 63) / 64);
+    const uint32_t g0 = n_groups ? gq[0] : 0u;                                   // blocks of the longest group (gq does not increase)
+    uint32_t ub = ub_req ? ub_req : 1u;
+    if ((g0 + ub - 1) / ub > (uint32_t)SWB_MAX_LEVELS) ub = (g0 + SWB_MAX_LEVELS - 1) / SWB_MAX_LEVELS;
+    const uint32_t nk_max = (g0 + ub - 1) / ub;
+    for (uint32_t k = threadIdx.x; k <= (uint32_t)SWB_MAX_LEVELS + 1; k += 256) {
+        uint32_t lo = 0;
+        if (k <= nk_max) {
+            const uint32_t thr = k ? (k - 1) * ub : 0u;                          // groups of more than thr blocks have at least k units
+            uint32_t hi = n_groups;                                              // first g with gq[g] <= thr
+            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (gq[mid] > thr) lo = mid + 1; else hi = mid; }
+        }
+        cc[k] = lo;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t acc = 0;
+        for (uint32_t k = 0; k <= (uint32_t)SWB_MAX_LEVELS + 1; k++) { plan->c[k] = cc[k]; plan->bag_off[k] = acc; acc += k <= (uint32_t)SWB_MAX_LEVELS ? cc[k + 1] : 0u; }
+        plan->n_groups = n_groups; plan->nk_max = nk_max; plan->ub = ub; plan->hyst = hyst;
+    }
+}
+
+// a wave claims the best waiting work of a level >= min_level: returns the level (0: none), the group, and whether it is fresh.  All lanes take part (lane x looks at level
+// nk_max - x); the claim itself is lane 0's.
+__device__ __forceinline__ uint32_t swb_claim(const SwbUnitPlan *__restrict__ plan, SwbUnitCtr *ctr, uint32_t *bag, const uint32_t nk_max, const uint32_t min_level, uint32_t &grp, bool &fresh) {
+    const uint32_t lane = threadIdx.x;
+    for (;;) {
+        const uint32_t k = nk_max > lane ? nk_max - lane : 0u;
+        bool av_f = false, av_p = false;
+        if (k >= min_level && k >= 1u) {
+            const uint32_t nf = plan->c[k] - plan->c[k + 1];
+            av_f = __hip_atomic_load(&ctr->fresh[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nf;
+            av_p = __hip_atomic_load(&ctr->avail[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0;
+        }
+        const uint64_t m = __ballot(av_f || av_p);
+        if (!m) return 0u;
+        const int src = __builtin_ctzll(m);                                      // the highest level with something waiting
+        const uint32_t kk = nk_max - (uint32_t)src;
+        const bool use_p = __builtin_amdgcn_readlane((int32_t)av_p, src) != 0;   // parked first: its state is waiting in HBM
+        uint32_t got = SWB_NONE;
+        if (lane == 0) {
+            if (use_p) {
+                if (atomicAdd(&ctr->avail[kk], -1) > 0) {
+                    uint32_t *e = bag + plan->bag_off[kk] + atomicAdd(&ctr->head[kk], 1u);
+                    for (;;) { got = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (got != SWB_NONE) break; __builtin_amdgcn_s_sleep(1); }      // (its push is between the tail counter and this store)
+                } else atomicAdd(&ctr->avail[kk], 1);
+            } else {
+                const uint32_t nf = plan->c[kk] - plan->c[kk + 1];
+                const uint32_t tk = atomicAdd(&ctr->fresh[kk], 1u);
+                if (tk < nf) got = plan->c[kk + 1] + tk;
+            }
+        }
+        got = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)got);
+        if (got != SWB_NONE) { grp = got; fresh = !use_p; return kk; }
+        // somebody else was faster: look again
+    }
+}
+
+// RING: the base streams through rings in LDS (LaneStreamL) or straight from HBM (LaneStream; FZP_SWB_NO_RING, for comparisons)
+template <bool RING, int RINGW, int HOLDW, int GRP, int WPS>
+__global__ void __attribute__((amdgpu_waves_per_eu(WPS))) __launch_bounds__(256)
+k_swb(const uint64_t *__restrict__ n_b_dev, const uint32_t *__restrict__ list, const Slot *__restrict__ slots,
+      const uint32_t *__restrict__ read_pk, const uint32_t *__restrict__ read_rc, const int64_t *__restrict__ read_woff,
+      const uint32_t *__restrict__ ctg_pk, const uint32_t *__restrict__ ctg_rc, const int64_t *__restrict__ ctg_woff,
+      const int64_t *__restrict__ tbo, const int64_t *__restrict__ mvo, uint2 *__restrict__ tb, ulonglong2 *__restrict__ mvw,
+      DpInfo *__restrict__ info, int dbg, uint64_t *__restrict__ wave_log,
+      const SwbUnitPlan *__restrict__ plan, SwbUnitCtr *ctr, uint32_t *bag, uint32_t *ustate) {
+    using namespace swb;
+    typedef LaneStreamL<RINGW, HOLDW> StreamL;
+    __shared__ uint32_t srng[RING ? 2 * RINGW * 64 : 1];                   // the two streams' rings
+    // PERSISTENT waves (r5): the launch has as many one-wave workgroups as the chip has wave slots for this kernel, and a wave PULLS work -- since r6 by the level
+    // scheme above -- until every group is done.
+    const uint32_t n_groups = plan->n_groups, nk_max = plan->nk_max, ub = plan->ub, hyst = plan->hyst;
+    const int64_t n_b = (int64_t)*n_b_dev;
+    uint32_t c_level = 0, c_grp = 0;      // work claimed at a unit boundary, to be taken up next
+    bool c_fresh = false;
+    // two waves of this kernel on a SIMD do not share it evenly: the arbiter takes the older wave whenever it is ready, and the younger one runs at 800 ns per step beside
+    // the older one's 340 (profiles/r6_swb_units.txt).  dbg bit 2: the two take turns at the higher issue priority, ~20 us each by the shared clock
+    uint32_t wid = 0;
+    if (dbg & 4) { uint32_t hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); wid = hw & 1u; }
   for (;;) {
-    uint32_t grp = 0;
-    if (threadIdx.x == 0) grp = (uint32_t)atomicAdd(next_group, 1ull);
-    grp = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)grp);
-    if (grp >= n_groups) break;
-    // wave_log (FZP_SWB_WAVE_LOG, a measurement aid): per launch group {start, end} of the 100 MHz counter, the hardware id, the steps it ran
+    if (!c_level) {
+        c_level = swb_claim(plan, ctr, bag, nk_max, 1u, c_grp, c_fresh);
+        if (!c_level) {      // nothing waits: other waves are still running groups and may park one for a longer chain (they will not while nothing waits, but the counters are read one by one)
+            if (__hip_atomic_load(&ctr->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n_groups) break;
+            __builtin_amdgcn_s_sleep(64);
+            continue;
+        }
+    }
+    const uint32_t grp = c_grp;
+    uint32_t level = c_level;
+    const bool fresh = c_fresh;
+    c_level = 0;
+    // wave_log (FZP_SWB_WAVE_LOG, a measurement aid): per stretch a wave spent on a group {start, end} of the 100 MHz counter, the hardware id and the group, the steps it ran
     const uint64_t t_begin = wave_log ? __builtin_amdgcn_s_memrealtime() : 0ull;
     // dbg: MEASUREMENT switches (FZP_SWB_DBG, tools/runs/swb_probe.py; the results of such a run are not used): bit 0 = no mask stores, bit 1 = no stream refills
     // (workgroups of one wave: four-wave workgroups, which suit k_swb2, put 256 mask streams on a CU and cost this kernel 10 % -- address translation again)
     const int64_t li = (int64_t)grp * 64 + threadIdx.x;
-    bool active = li < (int64_t)*n_b_dev;
-    if (!__ballot(active)) continue;
+    bool active = li < n_b;
     const uint32_t sl = list[active ? li : 0];      // the lane's slot; the lanes of a wave stand side by side in the launch list, and so do their mask streams
     const Slot S = slots[sl];
     // (64 streams scattered over the buffer cost twice the time in address translation alone: the plan interleaves a wave's streams block by block, stride 4 096 records)
@@ -1343,55 +1434,75 @@ __global__ void SWB_OCC __launch_bounds__(256) k_swb(const uint64_t *__restrict_
     const uint32_t *tpk = ((S.flags & SLOT_TRC) ? ctg_rc : ctg_pk) + ctg_woff[S.ctg];
     const int64_t qb = S.qb, tbase = S.tb;
     const int32_t max_steps = nq + nt + 2;
-    SwbLaneT<typename std::conditional<RING, LaneStreamL, LaneStream>::type> L;
-    // step -1: the anti-diagonal i + j = -1 of the virtual border, lane k = cell (k - 33, 32 - k): Pv = 0 where j >= 0 (k <= 32) else 4, Qv = 0 where i >= 0 (k >= 33) else 4
-    L.P = {0, 0, ~0ull << 33}; L.Q = {0, 0, (1ull << 33) - 1};
-    L.R0 = L.R1 = L.C0 = L.C1 = 0;
-    for (int k = 33; k < 64; k++) { const uint32_t c = base_at(qpk, qb + (k - 33)); L.R0 |= (uint64_t)(c & 1u) << k; L.R1 |= (uint64_t)(c >> 1) << k; }
-    for (int k = 0; k <= 32; k++) { const uint32_t c = base_at(tpk, tbase + (32 - k)); L.C0 |= (uint64_t)(c & 1u) << k; L.C1 |= (uint64_t)(c >> 1) << k; }
-    if constexpr (RING) {
-        L.qs.init(qpk, qb + 31, (uint32_t)((qb + nq + 15) >> 4) + 1u, srng + threadIdx.x);
-        L.ts.init(tpk, tbase + 33, (uint32_t)((tbase + nt + 15) >> 4) + 1u, srng + SWB_RING * 64 + threadIdx.x);
-    } else {
-        L.qs.init(qpk, qb + 31, (uint32_t)((qb + nq + 15) >> 4) + 1u);
-        L.ts.init(tpk, tbase + 33, (uint32_t)((tbase + nt + 15) >> 4) + 1u);
-    }
-    L.i0 = -33; L.E2 = 8; L.sv0 = 0;                            // at step -1 from the border's closed form: lane 0's cell scores -259, lane 63's -243
-    L.down = 1; L.pdown = 0;
+    const uint32_t qlim = (uint32_t)((qb + nq + 15) >> 4) + 1u, tlim = (uint32_t)((tbase + nt + 15) >> 4) + 1u;
+    SwbLaneT<typename std::conditional<RING, StreamL, LaneStream>::type> L;
     bool row_on = false, col_on = false;
     int32_t Hrow = 0, Hcol = 0, best = NEGV, bt = -1, bl = 0, steps = 0;
     int32_t t = 0;                                            // wave-uniform
+    uint32_t *const ust = ustate + (size_t)grp * (SWB_STATE_WORDS * 64) + threadIdx.x;      // the group's state while it is parked: word w of lane x at [w * 64 + x]
+    if (fresh) {
+        // step -1: the anti-diagonal i + j = -1 of the virtual border, lane k = cell (k - 33, 32 - k): Pv = 0 where j >= 0 (k <= 32) else 4, Qv = 0 where i >= 0 (k >= 33) else 4
+        L.P = {0, 0, ~0ull << 33}; L.Q = {0, 0, (1ull << 33) - 1};
+        L.R0 = L.R1 = L.C0 = L.C1 = 0;
+        for (int k = 33; k < 64; k++) { const uint32_t c = base_at(qpk, qb + (k - 33)); L.R0 |= (uint64_t)(c & 1u) << k; L.R1 |= (uint64_t)(c >> 1) << k; }
+        for (int k = 0; k <= 32; k++) { const uint32_t c = base_at(tpk, tbase + (32 - k)); L.C0 |= (uint64_t)(c & 1u) << k; L.C1 |= (uint64_t)(c >> 1) << k; }
+        L.i0 = -33; L.E2 = 8; L.sv0 = 0;                            // at step -1 from the border's closed form: lane 0's cell scores -259, lane 63's -243
+        L.down = 1; L.pdown = 0;
+    } else {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");      // (orders the compiler: no instruction)
+        auto ld = [&](int w) { return __hip_atomic_load(ust + w * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+        auto ld64 = [&](int w) { return (uint64_t)ld(w) | ((uint64_t)ld(w + 1) << 32); };
+        L.P = {ld64(0), ld64(2), ld64(4)}; L.Q = {ld64(6), ld64(8), ld64(10)};
+        L.R0 = ld64(12); L.R1 = ld64(14); L.C0 = ld64(16); L.C1 = ld64(18);
+        L.i0 = (int32_t)ld(20); L.E2 = (int32_t)ld(21); L.sv0 = (int32_t)ld(22);
+        const uint32_t fl = ld(23);
+        L.down = fl & 1u; L.pdown = (fl >> 1) & 1u; active = (fl & 4u) != 0; row_on = (fl & 8u) != 0; col_on = (fl & 16u) != 0;
+        Hrow = (int32_t)ld(24); Hcol = (int32_t)ld(25); best = (int32_t)ld(26); bt = (int32_t)ld(27); bl = (int32_t)ld(28); steps = (int32_t)ld(29);
+        t = (int32_t)__builtin_amdgcn_readfirstlane((int32_t)ld(30));
+    }
+    const int32_t t_first = t;
+    // the streams: the next read base to enter is i0 + 64 of the piece (31 at the start), the next contig base t - i0 (33 at the start)
+    if constexpr (RING) {
+        L.qs.init(qpk, qb + L.i0 + 64, qlim, srng + threadIdx.x);
+        L.ts.init(tpk, tbase + t - L.i0, tlim, srng + RINGW * 64 + threadIdx.x);
+    } else {
+        L.qs.init(qpk, qb + L.i0 + 64, qlim);
+        L.ts.init(tpk, tbase + t - L.i0, tlim);
+    }
     int32_t i0_ref = L.i0;                                    // i0 when the streams were last topped up
-    while (__ballot(active)) {
+    for (;;) {      // unit after unit of this group, until it ends or longer work waits
+        const int32_t t_end = t + (int32_t)(ub * 64u);
+    while (t < t_end && __ballot(active)) {
         const bool blk_active = active;
         const int32_t i0_blk = L.i0, e2_blk = L.E2;      // (E2 at the block's first step rides in the move word's spare half: where in the band the path is likely to be)
         L.mvacc = 0;
+        if (dbg & 4) { if ((((uint32_t)__builtin_amdgcn_s_memrealtime() >> 11) ^ wid) & 1u) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
         // an interior block?  every running lane more than 64 steps away from its last row and its last column (a step brings either one closer by at most one)
         const bool far = !active || (nq - 1 - (L.i0 + 63) > 64 && nt - 1 - (t - L.i0) > 64);
         const bool interior = t >= 64 && __ballot(!far) == 0ull;
-        if constexpr (RING) { if ((t & (SWB_BULK_STEPS - 1)) == 0 && t > 0) { L.qs.bulk(); L.ts.bulk(); } }
-        for (int g8 = 0; g8 < 64 / SWB_GROUP; g8++) {
+        if constexpr (RING) { if ((t & (StreamL::BULK_STEPS - 1)) == 0 && t > 0) { L.qs.bulk(); L.ts.bulk(); } }
+        for (int g8 = 0; g8 < 64 / GRP; g8++) {
             const bool grp_active = active;
-            uint2 rec[SWB_GROUP];
+            uint2 rec[GRP];
             uint32_t mv8 = 0;
             if (interior) {
 #pragma unroll
-                for (int s8 = 0; s8 < SWB_GROUP; s8++) { swb_step<false>(L, t, s8, mv8, rec[s8], nq, nt, max_steps, inner, active, row_on, col_on, Hrow, Hcol, best, bt, bl, steps); t++; }
+                for (int s8 = 0; s8 < GRP; s8++) { swb_step<false>(L, t, s8, mv8, rec[s8], nq, nt, max_steps, inner, active, row_on, col_on, Hrow, Hcol, best, bt, bl, steps); t++; }
             } else {
 #pragma unroll
-                for (int s8 = 0; s8 < SWB_GROUP; s8++) { swb_step<true>(L, t, s8, mv8, rec[s8], nq, nt, max_steps, inner, active, row_on, col_on, Hrow, Hcol, best, bt, bl, steps); t++; }
+                for (int s8 = 0; s8 < GRP; s8++) { swb_step<true>(L, t, s8, mv8, rec[s8], nq, nt, max_steps, inner, active, row_on, col_on, Hrow, Hcol, best, bt, bl, steps); t++; }
             }
-            L.mvacc |= (uint64_t)mv8 << ((t - SWB_GROUP) & 63);
+            L.mvacc |= (uint64_t)mv8 << ((t - GRP) & 63);
             // the streams top up every 16 steps, and they do it HERE, ahead of a group's stores: taking the word loaded 16 steps ago means waiting on the vector-memory
             // counter, which also counts the mask stores -- at this point the youngest of those are 8 steps old and done, right behind a group they would be in flight
-            if ((g8 & (16 / SWB_GROUP - 1)) == 16 / SWB_GROUP - 1 && !(dbg & 2)) {
+            if ((g8 & (16 / GRP - 1)) == 16 / GRP - 1 && !(dbg & 2)) {
                 if constexpr (RING) { const int32_t dq = L.i0 - i0_ref; L.qs.refill(dq); L.ts.refill(16 - dq); i0_ref = L.i0; }      // (16 steps: one base each, a read base on a DOWN move)
                 else { L.qs.refill(); L.ts.refill(); }
             }
             if (grp_active && !(dbg & 1)) {      // what leaves is the middle of the band: lanes 16..47 of D and of G, 8 B per step (the walker says so if its path ever needs more)
 #pragma unroll
-                for (int s8 = 0; s8 < SWB_GROUP; s8 += 2)
-                    *(uint4 *)(tbr + swb_rec(t - SWB_GROUP) + s8) = make_uint4(rec[s8].x, rec[s8].y, rec[s8 + 1].x, rec[s8 + 1].y);
+                for (int s8 = 0; s8 < GRP; s8 += 2)
+                    *(uint4 *)(tbr + swb_rec(t - GRP) + s8) = make_uint4(rec[s8].x, rec[s8].y, rec[s8 + 1].x, rec[s8 + 1].y);
             }
         }
         if (blk_active) {
@@ -1399,11 +1510,37 @@ __global__ void SWB_OCC __launch_bounds__(256) k_swb(const uint64_t *__restrict_
             if (!active) info[sl] = DpInfo{steps, bt, bl, bt >= 0 ? best : NEGV};
         }
     }
+        if (!__ballot(active)) {      // the group has ended
+            if (threadIdx.x == 0) atomicAdd(&ctr->done, 1u);
+            break;
+        }
+        level = level > 1u ? level - 1u : 1u;
+        // does a longer chain wait?  (hyst: by how many units longer it has to be)
+        c_level = swb_claim(plan, ctr, bag, nk_max, level + 1u + hyst, c_grp, c_fresh);
+        if (!c_level) continue;
+        {   // park this group at its level
+            auto sv = [&](int w, uint32_t v) { __hip_atomic_store(ust + w * 64, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+            auto sv64 = [&](int w, uint64_t v) { sv(w, (uint32_t)v); sv(w + 1, (uint32_t)(v >> 32)); };
+            sv64(0, L.P.v0); sv64(2, L.P.v1); sv64(4, L.P.v2); sv64(6, L.Q.v0); sv64(8, L.Q.v1); sv64(10, L.Q.v2);
+            sv64(12, L.R0); sv64(14, L.R1); sv64(16, L.C0); sv64(18, L.C1);
+            sv(20, (uint32_t)L.i0); sv(21, (uint32_t)L.E2); sv(22, (uint32_t)L.sv0);
+            sv(23, L.down | (L.pdown << 1) | (active ? 4u : 0u) | (row_on ? 8u : 0u) | (col_on ? 16u : 0u));
+            sv(24, (uint32_t)Hrow); sv(25, (uint32_t)Hcol); sv(26, (uint32_t)best); sv(27, (uint32_t)bt); sv(28, (uint32_t)bl); sv(29, (uint32_t)steps); sv(30, (uint32_t)t);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // (orders the compiler)
+            __builtin_amdgcn_s_waitcnt(0);                               // every store of this wave has been written through
+            if (threadIdx.x == 0) {
+                const uint32_t at = atomicAdd(&ctr->tail[level], 1u);
+                __hip_atomic_store(bag + plan->bag_off[level] + at, grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                atomicAdd(&ctr->avail[level], 1);
+            }
+        }
+        break;
+    }
     if (wave_log && threadIdx.x == 0) {
         uint32_t hw;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        uint64_t *o = wave_log + 4 * (size_t)grp;
-        o[0] = t_begin; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = hw; o[3] = (uint64_t)t;
+        uint64_t *o = wave_log + 4 * (size_t)atomicAdd(&ctr->n_log, 1u);
+        o[0] = t_begin; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = (uint64_t)hw | ((uint64_t)grp << 32); o[3] = (uint64_t)(t - t_first);
     }
   }
 }
@@ -2583,6 +2720,10 @@ struct ChunkBufs {
     DevBuf<ulonglong2> mvw;                      // move words, one per 64 steps
     DevBuf<uint32_t> raw;                        // 2-bit op streams per slot (the walks); the reads' joined streams live with the job (opk)
     DevBuf<ReadPath> rpath;
+    // k_swb's work units (r6): the unit plan, per launch group how many of its units are done, and the group's state between two units (8 KB per group)
+    DevBuf<SwbUnitPlan> uplan;
+    DevBuf<SwbUnitCtr> uctr;
+    DevBuf<uint32_t> ubag, ustate;
 };
 
 struct fzp_alnjob {
@@ -2994,20 +3135,46 @@ static int align_run(fzp_ctx *ctx, fzp_alnjob *j, bool defer_overflow) {
                     // every slot goes to one of the two DP kernels (k_route): the bit-sliced one (a slot per lane) takes those that span the band on both sides, the
                     // wave-per-slot one the rest -- mostly backward extensions of a few dozen bases -- beside it on a stream of its own
                     const bool swb64 = swb_force ? swb_force == 64 : !((int64_t)ns / 32 <= (int64_t)ctx->n_cu * 4);
+                    // the bit-sliced kernel's two register budgets (FZP_SWB_WAVES = 1 | 2), its work units (FZP_SWB_UNIT: 64-step blocks per unit; FZP_SWB_HYST: by how many
+                    // units waiting work has to be longer before a wave parks its group for it) and the SIMD-sharing switch (FZP_SWB_DBG bit 2).  DEFAULT: one wave per SIMD,
+                    // whole groups -- r5's schedule, through the same code (one level, every group fresh).  What r6 built and measured (profiles/r6_swb_units.txt): with units
+                    // the launch IS uniform (2 047 of 2 048 slots busy until its last 0.6 ms), but the second wave of a SIMD gets 0.42 of the first one's issue rate, two
+                    // waves together 1.18 x one wave's throughput, not the 1.4 x the median step time had suggested: two waves + units of 16 blocks + turns at the priority
+                    // run the bench step's launch in 5.34 ms against 5.83 in a loop of K1 runs, in 5.9 against 6.0 ms inside the whole step, and in 6.35 against 5.39 ms
+                    // on reads of real shape -- so they stay switches.
+                    int swb_wps = 1;
+                    if (const char *e = getenv("FZP_SWB_WAVES")) { const int g = atoi(e); if (g == 1 || g == 2) swb_wps = g; }
+                    unsigned swb_slots = (unsigned)ctx->n_cu * 4u * (unsigned)swb_wps;      // persistent waves: as many as the chip holds of this kernel, no more than there are groups
+                    if (const char *e = getenv("FZP_SWB_GRID")) { const long g = atol(e); if (g > 0) swb_slots = (unsigned)std::min<long>(g, swb_slots); }      // (tests: few waves, so that a small job's groups wait for each other)
+                    uint32_t ub_req = 1u << 20;
+                    if (const char *e = getenv("FZP_SWB_UNIT")) { const long g = atol(e); if (g > 0) ub_req = (uint32_t)std::min<long>(g, 1l << 20); }
+                    if (ngrp <= swb_slots) ub_req = 1u << 20;      // (no more groups than slots: every group in one piece -- its waves all start at once, cutting would only add hand-overs)
+                    uint32_t swb_hyst = 0;
+                    if (const char *e = getenv("FZP_SWB_HYST")) { const long g = atol(e); if (g >= 0 && g < 64) swb_hyst = (uint32_t)g; }
+                    const int swb_dbg = getenv("FZP_SWB_DBG") ? atoi(getenv("FZP_SWB_DBG")) : 0;
                     uint64_t *wave_log = nullptr;
-                    if (getenv("FZP_SWB_WAVE_LOG")) { FZP_TRY(j->wave_log.alloc((size_t)4 * ((ns + 63) / 64) + 4)); FZP_TRY(j->wave_log.zero((size_t)4 * ((ns + 63) / 64) + 4, st)); wave_log = j->wave_log.p; j->wave_log_n = (ns + 63) / 64; }
+                    if (use_bits && swb64) {
+                        const size_t n_bag = (size_t)(capq / ub_req) + ngrp + 64;      // every (group, level) pair at most once
+                        FZP_TRY(B.uplan.alloc(1)); FZP_TRY(B.uctr.alloc(1)); FZP_TRY(B.ubag.alloc(n_bag)); FZP_TRY(B.ustate.alloc((size_t)ngrp * SWB_STATE_WORDS * 64));
+                        { const fzp_fill_piece fl[2] = {{B.uctr.p, sizeof(SwbUnitCtr), 0u}, {B.ubag.p, n_bag * 4, 0xffffffffu}}; FZP_TRY(fzp_fill(ctx, st, fl, 2)); }
+                        hipLaunchKernelGGL(k_swb_units, dim3(1), dim3(256), 0, st, (const uint64_t *)B.ptot.p, (const uint32_t *)B.gq.p, ub_req, swb_hyst, B.uplan.p);
+                        if (getenv("FZP_SWB_WAVE_LOG")) {
+                            const size_t nlog = 2 * n_bag + 64;
+                            FZP_TRY(j->wave_log.alloc(4 * nlog)); FZP_TRY(j->wave_log.zero(4 * nlog, st)); wave_log = j->wave_log.p; j->wave_log_n = (int64_t)nlog;
+                        }
+                    }
                     FZP_HIP(hipEventRecord(j->ev_l[0], st));
                     if (use_bits && !swb64)
                         hipLaunchKernelGGL(k_swb2, dim3((ns + 127) / 128), dim3(256), 0, st, (const uint64_t *)B.ptot.p, (const uint32_t *)B.list.p, (const Slot *)B.slots.p,
                                            (const uint32_t *)j->read_pk.p, (const uint32_t *)j->read_rc.p, (const int64_t *)j->read_woff.p, (const uint32_t *)j->ctg_pk.p, (const uint32_t *)j->ctg_rc.p,
                                            (const int64_t *)j->ctg_woff.p, (const int64_t *)B.tbo.p, (const int64_t *)B.mvo.p, B.tb.p, B.mvw.p, B.info.p);
-                    // persistent waves: as many as the chip holds of this kernel (one per SIMD at the default register budget, two with the -DFZP_SWB_* two-wave build), no more than there are groups
-                    const unsigned swb_slots = (unsigned)ctx->n_cu * 4u * (unsigned)SWB_WAVES_PER_SIMD;
-                    if (use_bits && swb64)
-                        hipLaunchKernelGGL(swb_ring ? k_swb<true> : k_swb<false>, dim3(std::min<unsigned>((ns + 63) / 64, swb_slots)), dim3(64), 0, st, (const uint64_t *)B.ptot.p, (const uint32_t *)B.list.p,
+                    if (use_bits && swb64) {
+                        auto kfn = swb_wps == 2 ? (swb_ring ? k_swb<true, 32, 8, 4, 2> : k_swb<false, 32, 8, 4, 2>) : (swb_ring ? k_swb<true, 64, 16, 8, 1> : k_swb<false, 64, 16, 8, 1>);
+                        hipLaunchKernelGGL(kfn, dim3(std::min<unsigned>(ngrp, swb_slots)), dim3(64), 0, st, (const uint64_t *)B.ptot.p, (const uint32_t *)B.list.p,
                                            (const Slot *)B.slots.p, (const uint32_t *)j->read_pk.p, (const uint32_t *)j->read_rc.p, (const int64_t *)j->read_woff.p, (const uint32_t *)j->ctg_pk.p,
                                            (const uint32_t *)j->ctg_rc.p, (const int64_t *)j->ctg_woff.p, (const int64_t *)B.tbo.p, (const int64_t *)B.mvo.p, B.tb.p, B.mvw.p, B.info.p,
-                                           getenv("FZP_SWB_DBG") ? atoi(getenv("FZP_SWB_DBG")) : 0, wave_log, (unsigned long long *)(B.ptot.p + 5));
+                                           swb_dbg, wave_log, (const SwbUnitPlan *)B.uplan.p, B.uctr.p, B.ubag.p, B.ustate.p);
+                    }
                     hipStream_t st_sw = getenv("FZP_SW_SERIAL") ? st : st3;      // (comparison switch: the wave-per-piece kernel behind the bit-sliced one instead of beside it)
                     if (st_sw == st3) FZP_HIP(hipStreamWaitEvent(st3, j->ev_l[0], 0));
                     hipLaunchKernelGGL(k_sw<true>, dim3((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(ns, rtot[3]))), dim3(64), 0, st_sw, (const uint64_t *)B.ptot.p, (const uint64_t *)nullptr, ns, /* (no chunk has more such slots than the run) */ (const uint32_t *)B.list.p, (const Slot *)B.slots.p,

@@ -512,7 +512,12 @@ def test_the_three_dp_kernels_agree(eng, oracle, monkeypatch):
     got = {}
     for mode, env in (("default", {}), ("wave_per_read", {"FZP_SW_NO_BITS": "1"}), ("lane64", {"FZP_SWB_64": "1"}), ("pair", {"FZP_SWB_PAIR": "1"}),
                       ("pair_short_limit", {"FZP_SWB_PAIR": "1", "FZP_SWB_MAX_STEPS": "9000"}), ("three_chunks", {"FZP_SW_CHUNKS": "3"}), ("bases_from_hbm", {"FZP_SWB_NO_RING": "1", "FZP_SWB_64": "1"}),
-                      ("walk16", {"FZP_TBW_OLD": "1"})):      # (the 16-walkers-per-wave walk on the records laid out for the 32-walker one)
+                      ("walk16", {"FZP_TBW_OLD": "1"}),       # (the 16-walkers-per-wave walk on the records laid out for the 32-walker one)
+                      # r6: k_swb's groups cut into work units of 2 / 3 blocks that waves park and pick up (longest remaining first), with both register budgets, with and
+                      # without the turns at the issue priority, on a handful of waves (FZP_SWB_GRID) so that the job's ~30 groups wait for each other -- hundreds of hand-overs through HBM, the same bits
+                      ("units_one_wave", {"FZP_SWB_64": "1", "FZP_SWB_WAVES": "1", "FZP_SWB_UNIT": "2", "FZP_SWB_GRID": "5"}),
+                      ("units_two_waves", {"FZP_SWB_64": "1", "FZP_SWB_WAVES": "2", "FZP_SWB_UNIT": "3", "FZP_SWB_GRID": "8", "FZP_SWB_DBG": "4"}),
+                      ("units_hysteresis", {"FZP_SWB_64": "1", "FZP_SWB_WAVES": "2", "FZP_SWB_UNIT": "1", "FZP_SWB_HYST": "2", "FZP_SWB_GRID": "3"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         job = _lib.align_job_raw(eng, [ctg], blob, off, np.zeros(n, np.int32))

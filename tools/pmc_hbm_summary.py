@@ -22,7 +22,7 @@ def kernel_key(name):
 
 
 # kernels whose reads are wide and wave-contiguous (16 B or 8 B per lane, consecutive lanes consecutive addresses): FETCH_SIZE x 2
-WIDE_READERS = {"k_tb_walk", "k_gather16", "k_gather", "k_index_build", "k_join", "k_apply_u32", "k_apply_u64", "k_tile_sums", "k_tile_sums_u64", "k_site_flag", "k_site_emit",
+WIDE_READERS = {"k_tb_walk", "k_tb_walk_h", "k_gather16", "k_gather", "k_index_build", "k_join", "k_apply_u32", "k_apply_u64", "k_tile_sums", "k_tile_sums_u64", "k_site_flag", "k_site_emit",
                 "k_upper", "k_pack", "k_pack2", "k_revcomp", "__amd_rocclr_copyBuffer"}
 
 
