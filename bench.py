@@ -304,6 +304,24 @@ def roofline(cells_per_launch, sw_avg_ms, sw_launches, dp_gcells, traffic):
                          "note": "SURVEY 8d: 12 int ops per cell against 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (the bit-sliced kernel spends ~2 lane-ops per cell)"}}
 
 
+def polish_leg(eng, contigs, blob, off, read_ctg):
+    """fzp_polish_tigs on the step's own inputs: every contig a tig, its reads the tig's pile -- K1 aligns them, K6's packed tally calls the whole tig (the consensus role of
+    run_quiver.py:82-97 per tig).  Reported beside `value`: tigs per second, template bases per second."""
+    from falcon_unzip_amd import _lib
+    walls, n_rec, n_out = [], 0, 0
+    for _ in range(3):
+        t0 = time.perf_counter()
+        t = _lib.polish_tigs(eng, contigs, blob, off, read_ctg)
+        walls.append(time.perf_counter() - t0)
+        n_rec, n_out = int(t.tigs["n_records"].sum()), int(t.tigs["seq_len"].sum())
+        t.close()
+    w = min(walls[1:])
+    return {"tigs": len(contigs), "template_mb": round(sum(len(c) for c in contigs) / 1e6, 1), "reads": int(len(read_ctg)), "records_in_piles": n_rec, "bases_out": n_out,
+            "ms_per_call": round(w * 1e3, 2), "first_call_ms": round(walls[0] * 1e3, 2), "tigs_per_s": round(len(contigs) / w, 1), "template_mb_per_s": round(sum(len(c) for c in contigs) / 1e6 / w, 1),
+            "reads_per_s": round(len(read_ctg) / w, 1),
+            "what": "fzp_polish_tigs from host buffers (upload, pack, index, K1, packed hand-off, K6 over every whole tig, download): every contig of the step as a tig with its own reads"}
+
+
 def shaped_leg(eng, inp):
     """K1 alone on the same contigs with reads of real CLR shape (fzalign v1.6 cuts every read into pieces of ~3 kb, so uneven read lengths no longer
     shape the DP launch: one figure, where r3 compared launch orders)."""
@@ -525,6 +543,7 @@ def main():
     ap.add_argument("--no-two-core", action="store_true", help="skip two_core_step_ms (the resident step in a child confined to two CPUs with LOCAL_WORLD_SIZE=8)")
     ap.add_argument("--e2e-lanes", type=int, default=2)
     ap.add_argument("--e2e-group-contigs", type=int, default=10)
+    ap.add_argument("--with-polish", action="store_true", help="also time fzp_polish_tigs on the step's inputs (every contig a tig, its reads the pile): tigs/s beside `value`")
     ap.add_argument("--with-consensus", action="store_true", help="also run K6 (phased-pile consensus, BASELINE config 4) inside every step")
     ap.add_argument("--out-root", default=None, help="where the per-step output trees go (default: a scratch directory under $TMPDIR)")
     ap.add_argument("--gen-workers", type=int, default=0, help="processes for input generation (0 = auto; forced to 1 under rocprofv3)")
@@ -723,6 +742,7 @@ def main():
     if shaped_inp is not None:
         shaped = shaped_leg(eng, shaped_inp)
         shaped_inp = None
+    polish = polish_leg(eng, contigs, blob, off, read_ctg) if (args.with_polish and rank == 0 and n_reads) else None
     strong = None
     if world > 1 and not args.strong and args.strong_leg_contigs > 0:
         strong = strong_leg(args, rank, world, eng, comm, coll_dev, s_inp, out_root)
@@ -884,6 +904,8 @@ def main():
             out["cpu_baseline"] = cpu
         if shaped is not None:
             out["k1_on_real_read_shape"] = shaped
+        if polish is not None:
+            out["polish_tigs"] = polish
         if strong is not None:
             out["strong_cfg3"] = strong
         print(json.dumps(out), flush=True)

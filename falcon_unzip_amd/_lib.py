@@ -190,6 +190,7 @@ def load():
         "fzp_align_destroy": (None, [VP, VP]),
         "fzp_batch_consensus": (C.c_int, [VP, VP, VP]),
         "fzp_batch_consensus_v": (C.c_int, [VP, VP, C.c_int, VP]),
+        "fzp_polish_tigs": (C.c_int, [VP, I32, VP, VP, I64, VP, VP, CP, VP, VP]),
         "fzp_tigs_free": (None, [VP]),
         "fzp_format_tigs": (C.c_int, [VP, I32, CP, PP, PSZ]),
         "fzp_format_bam": (C.c_int, [VP, CP, I64, VP, PP, PSZ, PP, PSZ]),
@@ -587,6 +588,24 @@ def align_job(eng, contigs, reads, read_ctg=None, params=None) -> AlignJob:
     p = C.c_void_p()
     _check(lib.fzp_align_create(eng._p, nc, cptr, clen, nr, _ptr(rc), _ptr(off), blob, C.byref(P), C.byref(p)))
     return AlignJob(eng, p.value, nr, nc)
+
+
+def polish_tigs(eng, tigs, read_blob: bytes, read_off, read_tig, params=None) -> "Tigs":
+    """fzp_polish_tigs: every read (read_blob[read_off[r]:read_off[r + 1]], as sequenced) aligned to ITS tig (tigs[read_tig[r]]) by K1, the whole tig called as one pile
+    by K6 (fzcns v3) -- the consensus role of run_quiver.py:82-97.  -> Tigs with one entry per input tig, input order (n_records = 0: no read aligned, the tig as it came)."""
+    lib = load()
+    nt = len(tigs)
+    read_off = np.ascontiguousarray(read_off, dtype=np.int64)
+    nr = len(read_off) - 1
+    cbufs, cptr, clen = _contig_ptrs(tigs)
+    rt = np.ascontiguousarray(read_tig, dtype=np.int32)
+    P = AlignParams()
+    lib.fzp_align_params_default(C.byref(P))
+    for k, v in (params or {}).items():
+        setattr(P, k, v)
+    ts = TigsStruct()
+    _check(lib.fzp_polish_tigs(eng._p, nt, cptr, clen, nr, _ptr(rt), _ptr(read_off), read_blob, C.byref(P), C.byref(ts)))
+    return Tigs(ts)
 
 
 def align_job_raw(eng, contigs, read_blob: bytes, read_off, read_ctg, params=None) -> AlignJob:

@@ -3285,6 +3285,7 @@ int fetch_summaries(fzp_ctx *ctx, fzp_alnjob *j) {
 }  // namespace
 
 extern "C" int64_t fzp_align_n_second(const fzp_alnjob *j) { return j ? j->n_second : 0; }
+void fzp_align_templates(const fzp_alnjob *j, const uint8_t **ascii, const int64_t **aoff) { *ascii = j->ctg_ascii.p; *aoff = j->ctg_aoff.p; }
 // measurement aid (tools/runs/tb_window_stats.py): with FZP_TB_STATS set, the walkers' window statistics summed over the job's runs (16 counters)
 extern "C" int fzp_debug_tb_stats(fzp_ctx *ctx, fzp_alnjob *j, unsigned long long *out) {
     if (!ctx || !j || !j->tb_stats.p || fzp_bind(ctx) != FZP_OK) return FZP_EINVAL;

@@ -126,6 +126,10 @@ struct fzp_batch {
     DevBuf<int32_t> errflag;
 };
 
+// polishing (fzp_polish_tigs, fzp_cns.hip): the templates as the alnjob keeps them on the device (upper-cased ASCII, contig c at ref + ref_off[c]) and their lengths (host)
+struct fzp_cns_polish { const uint8_t *ref = nullptr; const int64_t *ref_off = nullptr; const int64_t *len = nullptr; };
+void fzp_align_templates(const fzp_alnjob *job, const uint8_t **ascii, const int64_t **aoff);      // (fzp_align.hip)
+
 // stage drivers (fzp_phase.hip)
 int fzp_align_run_deferred(fzp_ctx *ctx, fzp_alnjob *job);   // fzp_align_run whose fail-list overflow question is answered by the fzp_align_to_batch that follows (fzp_align.hip)
 int fzp_batch_result_begin(fzp_ctx *ctx, fzp_batch *b);     // the record copies fzp_batch_result_all waits for, started now on the main stream (fzp_api.hip)

@@ -546,6 +546,14 @@ __global__ void k_cns_first(int n_blk, const int64_t *__restrict__ cnt_off, cons
     const int64_t len = cnt_off[g + 1] - cnt_off[g];
     first[i] = len > 0 ? off[2 * cnt_off[g] + (int64_t)ph * len] : total;
 }
+// polishing (fzp_polish_tigs): every aligned read of a tig is a member of the tig's one pile -- a phased_reads row (q_id, block 1, phase 0) per q_id, so that the
+// tally's look-up finds what K5 would have written
+__global__ void __launch_bounds__(256) k_polish_preads(int n_ctg, const int64_t *__restrict__ qoff, fzp_pread *__restrict__ preads) {
+    const int c = blockIdx.y;
+    if (c >= n_ctg) return;
+    const int64_t a = qoff[c], n = qoff[c + 1] - a;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < n; q += (int64_t)gridDim.x * 256) preads[a + q] = fzp_pread{(int32_t)q, 1, 0, 0, 0};
+}
 __global__ void k_fill32(int32_t *p, int64_t n, int32_t v) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -563,10 +571,12 @@ extern "C" int fzp_batch_consensus(fzp_ctx *ctx, fzp_batch *b, fzp_tigs *out) { 
 
 // The consensus with its sequence bytes left ON THE DEVICE (r5; fzp_pipe.hip copies them into the pinned block its write tasks own, under whatever runs next, and the
 // tasks write every tig from where it lies -- the C-ABI entry below downloads them as before): the tig table (seq_off / seq_len into `seq`) comes back on the host.
-int fzp_batch_consensus_dev(fzp_ctx *ctx, fzp_batch *b, int version, std::vector<fzp_tig> &tigs, DevBuf<uint8_t> &seq, uint64_t *n_seq) {
+// polish != nullptr (fzp_polish_tigs): the TEMPLATE is the pile's span -- one block per contig that has records, [0, its length), every record a member, the
+// position's own base read from the whole template (the batch's ref holds only the prefix K2 evaluates).
+int fzp_batch_consensus_dev(fzp_ctx *ctx, fzp_batch *b, int version, std::vector<fzp_tig> &tigs, DevBuf<uint8_t> &seq, uint64_t *n_seq, const fzp_cns_polish *polish) {
     if (!ctx || !b || version < 1 || version > 3) { fzp_set_error("fzp_batch_consensus: bad arguments"); return FZP_EINVAL; }
     tigs.clear(); *n_seq = 0;
-    if (!b->have_aln || !b->have_blocks || !b->have_preads || !b->have_sites) { fzp_set_error("fzp_batch_consensus: run FZP_STAGE_ALL on a batch with alignment records first"); return FZP_EINVAL; }
+    if (!b->have_aln || (!polish && (!b->have_blocks || !b->have_preads || !b->have_sites))) { fzp_set_error("fzp_batch_consensus: run FZP_STAGE_ALL on a batch with alignment records first"); return FZP_EINVAL; }
     FZP_TRY(fzp_bind(ctx));
     // a packed batch (fzp_align_to_batch) is tallied as it is by fzcns v3 (k_cns_tiles_pk); versions 1 and 2 walk the run-length records, which are made now (FZP_K6_BYTES: v3 too)
     const bool packed = b->packed && !b->have_bytes && version >= 3 && getenv("FZP_K6_BYTES") == nullptr;
@@ -575,25 +585,38 @@ int fzp_batch_consensus_dev(fzp_ctx *ctx, fzp_batch *b, int version, std::vector
     const int nc = b->n_ctg;
     // ---- blocks per contig and their spans
     DevBuf<int32_t> d_nblk, d_base, d_lo, d_hi, d_bctg;
-    FZP_TRY(d_nblk.alloc((size_t)nc));
-    hipLaunchKernelGGL(k_cns_nblk, dim3(nblocks(nc, 64)), dim3(64), 0, st, nc, b->pvar_begin.p, b->pvars.p, d_nblk.p);
+    DevBuf<fzp_pread> p_preads;
     std::vector<int32_t> nblk((size_t)nc), base((size_t)nc + 1, 0);
-    FZP_TRY(d_nblk.download(nblk.data(), (size_t)nc, st));
-    FZP_HIP(hipStreamSynchronize(st));
+    if (polish) {
+        for (int c = 0; c < nc; c++) nblk[(size_t)c] = b->h_rec_begin[(size_t)c + 1] > b->h_rec_begin[(size_t)c] ? 1 : 0;
+    } else {
+        FZP_TRY(d_nblk.alloc((size_t)nc));
+        hipLaunchKernelGGL(k_cns_nblk, dim3(nblocks(nc, 64)), dim3(64), 0, st, nc, b->pvar_begin.p, b->pvars.p, d_nblk.p);
+        FZP_TRY(d_nblk.download(nblk.data(), (size_t)nc, st));
+        FZP_HIP(hipStreamSynchronize(st));
+    }
     for (int c = 0; c < nc; c++) base[(size_t)c + 1] = base[(size_t)c] + nblk[(size_t)c];
     const int NB = base[(size_t)nc];
-    if (NB == 0 || b->n_pvars == 0) return FZP_OK;
+    if (NB == 0 || (!polish && b->n_pvars == 0)) return FZP_OK;
     std::vector<int32_t> bctg((size_t)NB);
     for (int c = 0; c < nc; c++) for (int k = base[(size_t)c]; k < base[(size_t)c + 1]; k++) bctg[(size_t)k] = c;
     FZP_TRY(d_base.upload(base.data(), (size_t)nc + 1, st));
     FZP_TRY(d_bctg.upload(bctg.data(), (size_t)NB, st));
     FZP_TRY(d_lo.alloc((size_t)NB)); FZP_TRY(d_hi.alloc((size_t)NB));
-    hipLaunchKernelGGL(k_fill32, dim3(nblocks(NB, 256)), dim3(256), 0, st, d_lo.p, (int64_t)NB, 0x7fffffff);
-    hipLaunchKernelGGL(k_fill32, dim3(nblocks(NB, 256)), dim3(256), 0, st, d_hi.p, (int64_t)NB, -1);
-    hipLaunchKernelGGL(k_cns_extent, dim3(nblocks(b->n_pvars, 256)), dim3(256), 0, st, b->n_pvars, b->pvars.p, b->sites.p, b->site_ctg.p, d_base.p, d_lo.p, d_hi.p);
     std::vector<int32_t> lo((size_t)NB), hi((size_t)NB);
-    FZP_TRY(d_lo.download(lo.data(), (size_t)NB, st)); FZP_TRY(d_hi.download(hi.data(), (size_t)NB, st));
-    FZP_HIP(hipStreamSynchronize(st));
+    if (polish) {
+        for (int g = 0; g < NB; g++) { lo[(size_t)g] = 0; hi[(size_t)g] = (int32_t)(polish->len[bctg[(size_t)g]] - 1); }
+        FZP_TRY(d_lo.upload(lo.data(), (size_t)NB, st)); FZP_TRY(d_hi.upload(hi.data(), (size_t)NB, st));
+        FZP_TRY(p_preads.alloc((size_t)std::max<int64_t>(b->n_qid, 1)));
+        hipLaunchKernelGGL(k_polish_preads, dim3(64, (unsigned)nc), dim3(256), 0, st, nc, (const int64_t *)b->ctg_qoff.p, p_preads.p);
+        FZP_HIP(hipStreamSynchronize(st));      // (lo / hi go out of this frame's vectors into the device arrays)
+    } else {
+        hipLaunchKernelGGL(k_fill32, dim3(nblocks(NB, 256)), dim3(256), 0, st, d_lo.p, (int64_t)NB, 0x7fffffff);
+        hipLaunchKernelGGL(k_fill32, dim3(nblocks(NB, 256)), dim3(256), 0, st, d_hi.p, (int64_t)NB, -1);
+        hipLaunchKernelGGL(k_cns_extent, dim3(nblocks(b->n_pvars, 256)), dim3(256), 0, st, b->n_pvars, b->pvars.p, b->sites.p, b->site_ctg.p, d_base.p, d_lo.p, d_hi.p);
+        FZP_TRY(d_lo.download(lo.data(), (size_t)NB, st)); FZP_TRY(d_hi.download(hi.data(), (size_t)NB, st));
+        FZP_HIP(hipStreamSynchronize(st));
+    }
     std::vector<int64_t> cnt_off((size_t)NB + 1, 0);
     for (int g = 0; g < NB; g++) cnt_off[(size_t)g + 1] = cnt_off[(size_t)g] + (hi[(size_t)g] >= lo[(size_t)g] ? (int64_t)hi[(size_t)g] - lo[(size_t)g] + 1 : 0);
     const int64_t n_slots = 2 * cnt_off[(size_t)NB];
@@ -611,7 +634,7 @@ int fzp_batch_consensus_dev(fzp_ctx *ctx, fzp_batch *b, int version, std::vector
     FZP_TRY(cnt.alloc((size_t)n_slots * CN));
     FZP_TRY(n_records.alloc((size_t)NB * 2)); FZP_TRY(n_records.zero((size_t)NB * 2, st));
     CnsView v = {b->rec_pos.p, b->rec_qid.p, b->rec_ctg.p, b->rec_span.p, b->cig_off.p, b->seq_off.p, b->ck_off.p, b->ck_ref.p, b->ck_q.p, b->cigar.p, b->seq.p,
-                 b->preads.p, b->pread_begin.p, d_base.p, d_lo.p, d_hi.p, d_cnt_off.p, b->n_rec};
+                 polish ? p_preads.p : b->preads.p, polish ? b->ctg_qoff.p : b->pread_begin.p, d_base.p, d_lo.p, d_hi.p, d_cnt_off.p, b->n_rec};
     RecView rv = {b->rec_pos.p, b->rec_qid.p, b->rec_ctg.p, b->cig_off.p, b->seq_off.p, b->cigar.p, b->seq.p, b->ctg_goff.p, b->ctg_limit.p, b->n_rec};
     std::vector<int32_t> tblk, tstart;                    // tiles never span blocks
     for (int g = 0; g < NB; g++)
@@ -644,7 +667,7 @@ int fzp_batch_consensus_dev(fzp_ctx *ctx, fzp_batch *b, int version, std::vector
     FZP_TRY(ins_code.alloc((size_t)n_slots)); FZP_TRY(total.alloc(1));
     {
         ProfScope ps(ctx, "k6_call");
-        hipLaunchKernelGGL(k_cns_call, dim3(nblocks(n_slots, 256)), dim3(256), 0, st, n_slots, NB, d_cnt_off.p, d_lo.p, d_hi.p, d_bctg.p, b->ctg_goff.p, b->ref.p, cnt.p, n_records.p,
+        hipLaunchKernelGGL(k_cns_call, dim3(nblocks(n_slots, 256)), dim3(256), 0, st, n_slots, NB, d_cnt_off.p, d_lo.p, d_hi.p, d_bctg.p, polish ? polish->ref_off : b->ctg_goff.p, polish ? polish->ref : b->ref.p, cnt.p, n_records.p,
                            version, base0.p, ins_len.p, ins_code.p, version >= 3 ? n_out.p : (uint32_t *)nullptr);
     }
     if (version >= 3) {
@@ -724,7 +747,7 @@ extern "C" int fzp_batch_consensus_v(fzp_ctx *ctx, fzp_batch *b, int version, fz
     std::vector<fzp_tig> tigs;
     DevBuf<uint8_t> seq;
     uint64_t tot = 0;
-    FZP_TRY(fzp_batch_consensus_dev(ctx, b, version, tigs, seq, &tot));
+    FZP_TRY(fzp_batch_consensus_dev(ctx, b, version, tigs, seq, &tot, nullptr));
     uint8_t *hseq = (uint8_t *)malloc((size_t)(tot ? tot : 1));
     if (!hseq) return FZP_ENOMEM;
     if (tot && (hipMemcpyAsync(hseq, seq.p, (size_t)tot, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)) {
@@ -735,6 +758,65 @@ extern "C" int fzp_batch_consensus_v(fzp_ctx *ctx, fzp_batch *b, int version, fz
     if (!out->tigs) { free(hseq); return FZP_ENOMEM; }
     if (!tigs.empty()) memcpy(out->tigs, tigs.data(), tigs.size() * sizeof(fzp_tig));
     out->seq = hseq; out->n_seq = (int64_t)tot;
+    return FZP_OK;
+}
+
+// ---- polishing: a tig as the template (the consensus role of run_quiver.py:82-97 -- `pbalign` of a tig's routed reads to the tig, then `variantCaller`'s per-tig call --
+// with this repo's own aligner and pile vote: K1 aligns every read to ITS tig, K6's packed tally (fzcns v3, the insertion rule unchanged) runs over the whole tig as one
+// pile).  The tigs are the layout's (graphs_to_h_tigs.py:406-410,558-562: p_ctg.<ctg>.fa / h_ctg_all.<ctg>.fa), the reads what fzp_track_reads / fzp_bam_route assign to them.
+// Every input tig comes back, in input order: block 1, phase 0, [0, len); a tig no read aligned to comes back as it went in (upper-cased), n_records = 0.
+extern "C" int fzp_polish_tigs(fzp_ctx *ctx, int32_t n_tigs, const uint8_t *const *tig_seq, const int64_t *tig_len, int64_t n_reads, const int32_t *read_tig,
+                               const int64_t *read_off, const uint8_t *read_seq, const fzp_align_params *params, fzp_tigs *out) {
+    if (!ctx || n_tigs <= 0 || !tig_seq || !tig_len || n_reads < 0 || (n_reads && (!read_tig || !read_off || !read_seq)) || !out) { fzp_set_error("fzp_polish_tigs: bad arguments"); return FZP_EINVAL; }
+    memset(out, 0, sizeof *out);
+    fzp_alnjob *job = nullptr;
+    fzp_batch *b = nullptr;
+    std::vector<fzp_tig> tigs;
+    DevBuf<uint8_t> seq;
+    uint64_t tot = 0;
+    int rc = fzp_align_create(ctx, n_tigs, tig_seq, tig_len, n_reads, read_tig, read_off, read_seq, params, &job);
+    if (rc == FZP_OK) rc = fzp_align_run(ctx, job);
+    if (rc == FZP_OK) rc = fzp_align_to_batch(ctx, job, &b);
+    std::vector<uint8_t> hseq;
+    if (rc == FZP_OK) {
+        fzp_cns_polish P;
+        P.len = tig_len;
+        fzp_align_templates(job, &P.ref, &P.ref_off);
+        rc = fzp_batch_consensus_dev(ctx, b, 3, tigs, seq, &tot, &P);
+        if (rc == FZP_OK && tot) {
+            hseq.resize((size_t)tot);
+            if (hipMemcpyAsync(hseq.data(), seq.p, (size_t)tot, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+                (void)hipGetLastError(); fzp_set_error("fzp_polish_tigs: consensus download failed"); rc = FZP_EDEVICE;
+            }
+        }
+    }
+    if (b) fzp_batch_destroy(ctx, b);
+    if (job) fzp_align_destroy(ctx, job);
+    if (rc != FZP_OK) return rc;
+    // every tig once, input order; the ones without a pile as they came
+    int64_t total = 0;
+    std::vector<const fzp_tig *> of((size_t)n_tigs, nullptr);
+    for (const auto &t : tigs) of[(size_t)t.ctg] = &t;
+    for (int c = 0; c < n_tigs; c++) total += of[(size_t)c] ? of[(size_t)c]->seq_len : tig_len[c];
+    out->tigs = (fzp_tig *)malloc((size_t)n_tigs * sizeof(fzp_tig));
+    out->seq = (uint8_t *)malloc((size_t)(total ? total : 1));
+    if (!out->tigs || !out->seq) { free(out->tigs); free(out->seq); memset(out, 0, sizeof *out); return FZP_ENOMEM; }
+    int64_t at = 0;
+    for (int c = 0; c < n_tigs; c++) {
+        fzp_tig t;
+        memset(&t, 0, sizeof t);
+        t.ctg = c; t.block = 1; t.phase = 0; t.lo = 0; t.hi = (int32_t)(tig_len[c] - 1); t.seq_off = at;
+        if (of[(size_t)c]) {
+            t.n_records = of[(size_t)c]->n_records; t.seq_len = of[(size_t)c]->seq_len;
+            memcpy(out->seq + at, hseq.data() + of[(size_t)c]->seq_off, (size_t)t.seq_len);
+        } else {
+            t.seq_len = tig_len[c];
+            for (int64_t i = 0; i < tig_len[c]; i++) { const uint8_t ch = tig_seq[c][i]; out->seq[at + i] = (ch >= 'a' && ch <= 'z') ? (uint8_t)(ch - 32) : ch; }
+        }
+        at += t.seq_len;
+        out->tigs[c] = t;
+    }
+    out->n_tigs = n_tigs; out->n_seq = total;
     return FZP_OK;
 }
 

@@ -32,7 +32,7 @@
 #include "fzp_batch.h"
 
 int fzp_batch_text_dev(fzp_ctx *ctx, fzp_batch *b, int what, DevBuf<char> &text, size_t *bytes, std::vector<int64_t> &ctg_begin);
-int fzp_batch_consensus_dev(fzp_ctx *ctx, fzp_batch *b, int version, std::vector<fzp_tig> &tigs, DevBuf<uint8_t> &seq, uint64_t *n_seq);      // K6 with the sequence bytes left on the device (fzp_cns.hip)
+int fzp_batch_consensus_dev(fzp_ctx *ctx, fzp_batch *b, int version, std::vector<fzp_tig> &tigs, DevBuf<uint8_t> &seq, uint64_t *n_seq, const fzp_cns_polish *polish = nullptr);      // K6 with the sequence bytes left on the device (fzp_cns.hip)
 int fzp_batch_texts_dev(fzp_ctx *ctx, fzp_batch *b, DevBuf<char> &t_vmap, size_t *n_vmap, std::vector<int64_t> &vb, DevBuf<char> &t_atab, size_t *n_atab, std::vector<int64_t> &ab);      // both, one wait (fzp_text.hip)
 
 // ---- background file writes (FZP_PIPE_ASYNC_WRITES): a few threads per ctx drain a queue of per-contig write tasks, so that the

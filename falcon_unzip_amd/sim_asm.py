@@ -15,8 +15,10 @@ import numpy as np
 from . import sim
 
 
-def make_locus(rng, segments, read_len=8000, step=3000, het_rate=1.0 / 300, rid_base=0):
+def make_locus(rng, segments, read_len=8000, step=3000, het_rate=1.0 / 300, rid_base=0, pread_sub=0.0, err_rng=None):
     """segments: list of ('hom' | 'het' | 'tie', length).  -> dict with haplotypes, reads, phases, graph edge lists.
+    pread_sub > 0: every p-read carries substitution errors at that rate (drawn from err_rng, a generator of its own: the locus is the same with and without them;
+    substitutions only -- the string graph's edge coordinates are read offsets, an indel would move them), so the tigs the layout spells carry their reads' errors.
     'tie': a bubble like 'het' whose reads were NOT phased (no block for them in rid_to_phase): both branches score alike, the layout has to
     break a tie between them"""
     L = sum(n for _, n in segments)
@@ -79,6 +81,15 @@ def make_locus(rng, segments, read_len=8000, step=3000, het_rate=1.0 / 300, rid_
         for r in path:
             seqs[r[0]] = sim.codes_to_str(hapB[r[2]:r[3]])
 
+    if pread_sub > 0:
+        lut = np.zeros(256, np.uint8)
+        lut[[65, 67, 71, 84]] = [0, 1, 2, 3]
+        for rid_ in sorted(seqs):
+            codes = lut[np.frombuffer(seqs[rid_].encode(), np.uint8)]
+            hit = np.flatnonzero(err_rng.random(codes.size) < pread_sub)
+            codes[hit] = (codes[hit] + err_rng.integers(1, 4, size=hit.size, dtype=np.uint8)) & 3
+            seqs[rid_] = sim.codes_to_str(codes)
+
     def edge_pair(x, y):
         """forward edge X:E -> Y:E and its dual Y:B -> X:B"""
         ovl = x[3] - y[2]
@@ -124,13 +135,14 @@ def write_assembly(asm_dir, loci_edges, contigs):
                                                           "|".join("%s~%s~%s" % (u[0], u[1], u[-1]) for u in utgs)))
 
 
-def make_case(root, seed, layouts):
+def make_case(root, seed, layouts, pread_sub=0.0):
     """layouts: list of (ctg_id, segments).  Writes <root>/{2-asm-falcon,1-hasm}/..., preads4falcon.fasta, rid_to_phase.all;
-    returns the loci (for truth checks)."""
+    returns the loci (for truth checks).  pread_sub: substitution errors in the p-reads (make_locus)."""
     rng = np.random.Generator(np.random.PCG64(seed))
+    err_rng = np.random.Generator(np.random.PCG64(seed + 7919))
     loci, rid = [], 0
     for ctg_id, segments in layouts:
-        loc = make_locus(rng, segments, rid_base=rid)
+        loc = make_locus(rng, segments, rid_base=rid, pread_sub=pread_sub, err_rng=err_rng)
         rid = loc["next_rid"]
         loc["ctg_id"] = ctg_id
         loci.append(loc)

@@ -303,6 +303,15 @@ int fzp_batch_consensus(fzp_ctx *ctx, fzp_batch *b, fzp_tigs *out);             
  * the coverage carrying an I op of at least l bases (one base only with a majority for the same base) -- then its bases level by level among the I ops long enough
  * to have one: an inserted het that noisy reads spell as 2, 3, 4 or 5 bases is still called */
 int fzp_batch_consensus_v(fzp_ctx *ctx, fzp_batch *b, int version, fzp_tigs *out);
+
+/* Polishing: a tig as the template -- the consensus ROLE of run_quiver.py:82-97 (`pbalign` of a tig's routed reads to that tig, then `variantCaller`'s per-tig call; both
+ * external and closed here, so this is the repo's own aligner + pile vote: parity unpinned, twin = oracle/cns_oracle.c over one pile per tig).  tig_seq[c] / tig_len[c]:
+ * the layout's tigs (graphs_to_h_tigs.py:406-410,558-562: the records of p_ctg.<ctg>.fa / h_ctg_all.<ctg>.fa); read r = read_seq[read_off[r], read_off[r + 1]) belongs to
+ * tig read_tig[r] (what fzp_track_reads / fzp_bam_route assigned it).  K1 aligns every read to its tig, K6's packed tally (fzcns v3) runs over the whole tig as ONE pile.
+ * out: every tig once, input order (ctg = its index, block 1, phase 0, lo 0, hi len - 1, n_records = its aligned reads that passed the record filters); a tig without
+ * records comes back upper-cased and otherwise unchanged.  Release with fzp_tigs_free. */
+int fzp_polish_tigs(fzp_ctx *ctx, int32_t n_tigs, const uint8_t *const *tig_seq, const int64_t *tig_len, int64_t n_reads, const int32_t *read_tig,
+                    const int64_t *read_off, const uint8_t *read_seq, const fzp_align_params *params, fzp_tigs *out);
 void fzp_tigs_free(fzp_tigs *t);     /* frees the arrays, not the struct */
 /* FASTA of one contig's tigs: ">{ctg_id}_{block:03d}_{phase} {lo+1} {hi+1} {n_records}\n{sequence}\n" */
 int fzp_format_tigs(const fzp_tigs *t, int32_t ctg, const char *ctg_id, char **text, size_t *len);

@@ -298,3 +298,33 @@ int orc_consensus_v1(const char *sam, size_t sam_len, const char *ref_seq, size_
                      const char *phased_variants, size_t pv_len, const char *ctg_id, char **out_txt, size_t *out_len) {
     return orc_consensus_v(1, sam, sam_len, ref_seq, ref_len, phased_reads, pr_len, phased_variants, pv_len, ctg_id, out_txt, out_len);
 }
+
+/* ---- the twin with a TEMPLATE argument (fzp_polish_tigs: the consensus role of run_quiver.py:82-97 with a tig as the template).  The pile is every accepted record
+ * of the SAM text (the tig's reads aligned to the tig), the span the whole tig: one block [1, tig_len], every q_id a member of (block 1, phase 0) -- the same tally,
+ * the same fzcns v3 call.  Output: the polished sequence alone (no header); a tig without an accepted record comes back as it is. */
+int orc_polish(const char *sam, size_t sam_len, const char *tig, size_t tig_len, char **out_txt, size_t *out_len) {
+    size_t n_lines = 1;
+    for (size_t i = 0; i < sam_len; i++) n_lines += sam[i] == '\n';
+    char *pr = (char *)malloc(n_lines * 40 + 64), pv[96];
+    size_t n_pr = 0;
+    for (size_t q = 0; q < n_lines; q++) n_pr += (size_t)sprintf(pr + n_pr, "%zu tig 1 0 0 0 r\n", q);      /* (more q_ids than the text has names: the extra rows match nothing) */
+    const int n_pv = sprintf(pv, "P 1 1 %zu %zu 1 1.0\n", tig_len, tig_len);
+    char *fa = NULL;
+    size_t n_fa = 0;
+    const int rc = orc_consensus_v(3, sam, sam_len, tig, tig_len, pr, n_pr, pv, (size_t)n_pv, "tig", &fa, &n_fa);
+    free(pr);
+    if (rc) return rc;
+    char *out = (char *)malloc(tig_len + n_fa + 1);
+    size_t n_out = 0;
+    const char *nl = n_fa ? (const char *)memchr(fa, '\n', n_fa) : NULL;
+    if (nl) {      /* >tig_001_0 1 L n \n sequence \n */
+        const char *s = nl + 1, *e = (const char *)memchr(s, '\n', n_fa - (size_t)(s - fa));
+        n_out = e ? (size_t)(e - s) : n_fa - (size_t)(s - fa);
+        memcpy(out, s, n_out);
+    } else {       /* no pile: the template */
+        for (size_t i = 0; i < tig_len; i++) out[n_out++] = (char)toupper((unsigned char)tig[i]);
+    }
+    free(fa);
+    *out_txt = out; *out_len = n_out;
+    return 0;
+}

@@ -213,6 +213,11 @@ def consensus(orc, sam: bytes, ref_seq: bytes, phased_reads: bytes, phased_varia
     return orc._call({1: "orc_consensus_v1", 2: "orc_consensus_v2", 3: "orc_consensus"}[version], [sam, ref_seq, phased_reads, phased_variants], 1, extra=[ctg_id.encode()])[0]
 
 
+def polish(orc, sam: bytes, tig: bytes):
+    """oracle/cns_oracle.c: orc_polish -> the tig called over the pile of the SAM text's accepted records (fzcns v3, the whole tig one block)"""
+    return orc._call("orc_polish", [sam, tig], 1)[0]
+
+
 def track_reads(orc, files, phased_reads: bytes, read_to_contig_map: bytes, rawread_ids: bytes, min_len: int, bestn: int):
     """oracle/track_oracle.c: orc_track_reads -> rawread_to_contigs text in canonical order"""
     lib = orc.lib

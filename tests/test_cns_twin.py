@@ -28,3 +28,27 @@ def test_twin_recovers_the_haplotypes(oracle):
         assert own <= 0.004 * span, (h, d)                  # >= 99.6 % identical to one haplotype ...
         assert max(d) >= own + 0.6 * n_het, (h, d, n_het)   # ... and clearly not the other one
     assert all((b, 0) in seen and (b, 1) in seen for b, _ in seen)
+
+
+def test_twin_with_a_template_polishes_a_tig(oracle):
+    """orc_polish (the twin of fzp_polish_tigs): the whole tig one pile of every accepted record.  Reads simulated against the TRUE sequence and handed over with their true
+    alignments -- to a template that IS the truth -- give the truth back; a tig without records comes back upper-cased and unchanged."""
+    from falcon_unzip_amd import sim
+    rng = np.random.Generator(np.random.PCG64(12))
+    hap = rng.integers(0, 4, 30000, dtype=np.uint8)
+    tig = sim.codes_to_str(hap).encode()
+    reads = sim.simulate_reads(hap, hap, 120, 8000, rng)
+    sam = ("\n".join(sim.sam_lines(reads, "tig", header=False)) + "\n").encode()
+    got = oracle_lib.polish(oracle, sam, tig)
+    # (reads start uniformly inside the tig: its first and last few hundred bases see little coverage -- the interior is what a pile of 30 x decides; the simulator's own
+    #  alignments put an inserted base anywhere inside a run of its kind, so a vote over them is noisier than over an aligner's consistently placed gaps: 1 error per kb here,
+    #  none in 2 kb with K1's records, tests/test_gpu_polish.py)
+    d0 = cns_util.banded_edit_distance(got[1500:-1500], tig[1500:-1500], band=100)
+    assert d0 <= 0.0015 * len(tig), d0
+    assert oracle_lib.polish(oracle, b"", tig.lower()) == tig
+    # a template that differs from what the reads say is called towards the reads: 40 substitutions planted in the template's interior are gone
+    bad = bytearray(tig)
+    for p in rng.choice(np.arange(3000, 27000), 40, replace=False):
+        bad[p] = b"ACGT"[(b"ACGT".index(bad[p]) + 1) % 4]
+    fixed = oracle_lib.polish(oracle, sam, bytes(bad))
+    assert cns_util.banded_edit_distance(fixed[1500:-1500], tig[1500:-1500], band=100) <= d0 + 2
