@@ -5,6 +5,7 @@ Records cross the boundary as numpy structured arrays whose dtypes mirror the C 
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 import os
 
 import numpy as np
@@ -496,8 +497,15 @@ class AlignJob:
 
     def __init__(self, eng, ptr, n_reads, n_ctg):
         self.eng, self._p, self.n_reads, self.n_ctg = eng, ptr, n_reads, n_ctg
+        self._batches = []      # weak references to the batches to_batch made: they read this job's packed records in place (include/fzphase.h, fzp_align_to_batch)
+
+    def _open_batches(self):
+        self._batches = [w for w in self._batches if w() is not None and w()._p]
+        return len(self._batches)
 
     def run(self):
+        if self._open_batches():
+            raise FzpError(-1, "AlignJob.run: a Batch made by to_batch() is still open -- it reads this job's records in place; close it first")
         _check(load().fzp_align_run(self.eng._p, self._p))
 
     def n_second(self):
@@ -552,9 +560,12 @@ class AlignJob:
         _check(load().fzp_align_to_batch(self.eng._p, self._p, C.byref(p)))
         b = Batch(self.eng, p.value, [None] * self.n_ctg)
         b._job = self      # the batch reads this job's packed records (2-bit op streams, 2-bit reads) where they lie: the job stays alive as long as the batch does
+        self._batches.append(weakref.ref(b))
         return b
 
     def close(self):
+        if self._p and self._open_batches():
+            raise FzpError(-1, "AlignJob.close: a Batch made by to_batch() is still open -- close it first")
         if self._p:
             load().fzp_align_destroy(self.eng._p, self._p)
             self._p = None

@@ -2782,6 +2782,7 @@ struct fzp_alnjob {
     hipEvent_t ev_sw[2] = {nullptr, nullptr}, ev_tb[2] = {nullptr, nullptr}, ev_l[2] = {nullptr, nullptr};
     DevBuf<fzp_aln_summary> summ;
     bool done = false;
+    std::shared_ptr<fzp_job_life> life = std::make_shared<fzp_job_life>();      // shared with the batches fzp_align_to_batch makes (fzp_batch.h)
 };
 
 extern "C" void fzp_align_params_default(fzp_align_params *p) {
@@ -2795,6 +2796,7 @@ extern "C" void fzp_align_params_default(fzp_align_params *p) {
 extern "C" void fzp_align_destroy(fzp_ctx *ctx, fzp_alnjob *job) {
     if (!job) return;
     if (ctx) { (void)fzp_bind(ctx); (void)hipStreamSynchronize(ctx->stream); (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamSynchronize(ctx->stream3); }
+    if (job->life->batches.load() > 0) job->life->dead.store(true);      // (a batch made from this job is still open: whatever it is asked next fails instead of reading freed memory)
     for (int k = 0; k < 2; k++) { if (job->ev_sw[k]) (void)hipEventDestroy(job->ev_sw[k]); if (job->ev_tb[k]) (void)hipEventDestroy(job->ev_tb[k]); if (job->ev_l[k]) (void)hipEventDestroy(job->ev_l[k]); }
     delete job;
 }
@@ -2971,8 +2973,13 @@ extern "C" int fzp_align_invalidate_index(fzp_alnjob *j) {
 // defer_overflow (fzp_pipe.hip, through fzp_align_run_deferred): the run's one question to the device that nothing before fzp_align_to_batch needs answered -- "did the
 // fail list overflow?" -- rides in that call's fetch instead of costing the step a read-back of its own; fzp_align_to_batch does the retry when the answer is yes.
 static int align_run(fzp_ctx *ctx, fzp_alnjob *j, bool defer_overflow);
-extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) { return align_run(ctx, j, false); }
-int fzp_align_run_deferred(fzp_ctx *ctx, fzp_alnjob *j) { return align_run(ctx, j, true); }
+// (a run rewrites the packed records a batch of this job reads in place: not while one is open)
+static int no_open_batch(const fzp_alnjob *j) {
+    if (j && j->life->batches.load() > 0) { fzp_set_error("fzp_align_run: a batch made by fzp_align_to_batch from this job is still open -- it reads the job's packed records where they lie; destroy it first"); return FZP_EINVAL; }
+    return FZP_OK;
+}
+extern "C" int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *j) { FZP_TRY(no_open_batch(j)); return align_run(ctx, j, false); }
+int fzp_align_run_deferred(fzp_ctx *ctx, fzp_alnjob *j) { FZP_TRY(no_open_batch(j)); return align_run(ctx, j, true); }
 static int align_run(fzp_ctx *ctx, fzp_alnjob *j, bool defer_overflow) {
     if (!ctx || !j) return FZP_EINVAL;
     j->overflow_unchecked = false;
@@ -3655,6 +3662,8 @@ extern "C" int fzp_align_to_batch(fzp_ctx *ctx, fzp_alnjob *j, fzp_batch **out) 
                                          (const int32_t *)b->ctg_limit.p, b->ref.p);      // evaluated prefix of every contig, device to device
     FZP_HIP(hipGetLastError());      // (no wait here: what was uploaded lives in the batch, and whoever runs the batch next is on the same stream)
     b->have_aln = true;
+    b->life = j->life;
+    j->life->batches.fetch_add(1);
     guard.p = nullptr;
     *out = b;
     return FZP_OK;

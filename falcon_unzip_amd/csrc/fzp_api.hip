@@ -137,6 +137,7 @@ extern "C" void fzp_batch_destroy(fzp_ctx *ctx, fzp_batch *b) {
 
 extern "C" int fzp_batch_run(fzp_ctx *ctx, fzp_batch *b, unsigned stages) {
     if (!ctx || !b) return FZP_EINVAL;
+    FZP_TRY(fzp_batch_source_ok(b));
     FZP_TRY(fzp_bind(ctx));
     if (stages & FZP_STAGE_HET) {
         if (!b->have_aln) { fzp_set_error("batch holds no alignment records"); return FZP_EINVAL; }

@@ -16,6 +16,8 @@
 #pragma once
 #include <functional>
 
+#include <atomic>
+#include <memory>
 #include "fzp_common.h"
 
 // ---- the packed hand-off K1 -> K2 (r5; unzip.py:86-91 <-> phasing.py:27,42-96 without the BAM, the SAM text, the byte SEQ or the run-length CIGAR in between).
@@ -38,8 +40,14 @@ struct PkSrc {
 constexpr int FZP_POS_TILE = 2048;
 inline int64_t fzp_pos_pad(int64_t limit) { return (limit + FZP_POS_TILE - 1) / FZP_POS_TILE * FZP_POS_TILE; }
 
+// A batch made by fzp_align_to_batch BORROWS device memory of its alnjob (PkSrc below, and make_bytes): the job has to stay as it is while the batch lives.  The two share
+// this record: fzp_align_run refuses while a batch is open, fzp_align_destroy marks the record dead, and every entry point that reads the borrowed memory asks
+// fzp_batch_source_ok first (the rule was neither written down nor enforced).
+struct fzp_job_life { std::atomic<int> batches{0}; std::atomic<bool> dead{false}; };
+
 struct fzp_batch {
     int32_t n_ctg = 0;
+    std::shared_ptr<fzp_job_life> life;      // set by fzp_align_to_batch
     // host mirrors
     std::vector<int64_t> h_rec_begin, h_goff, h_qid_off, h_ref_len;
     std::vector<int32_t> h_limit;
@@ -120,7 +128,7 @@ struct fzp_batch {
     // fzp_batch_result_begin: the block and read records are on their way (main stream); fzp_batch_result_all then only waits
     bool late_begun = false, late_early = false, late_event = false;
     size_t late_off[5] = {0, 0, 0, 0, 0};
-    ~fzp_batch() { if (pin) fzp_pinned_release(pin_ctx, pin); }
+    ~fzp_batch() { if (pin) fzp_pinned_release(pin_ctx, pin); if (life) life->batches.fetch_sub(1); }
     // scratch
     DevBuf<uint64_t> totals;          // a few device u64 scalars
     DevBuf<int32_t> errflag;
@@ -129,6 +137,11 @@ struct fzp_batch {
 // polishing (fzp_polish_tigs, fzp_cns.hip): the templates as the alnjob keeps them on the device (upper-cased ASCII, contig c at ref + ref_off[c]) and their lengths (host)
 struct fzp_cns_polish { const uint8_t *ref = nullptr; const int64_t *ref_off = nullptr; const int64_t *len = nullptr; };
 void fzp_align_templates(const fzp_alnjob *job, const uint8_t **ascii, const int64_t **aoff);      // (fzp_align.hip)
+
+inline int fzp_batch_source_ok(const fzp_batch *b) {
+    if (b->life && b->life->dead.load()) { fzp_set_error("this batch reads the packed records of an alignment job that has been destroyed (fzp_align_destroy before fzp_batch_destroy)"); return FZP_EINVAL; }
+    return FZP_OK;
+}
 
 // stage drivers (fzp_phase.hip)
 int fzp_align_run_deferred(fzp_ctx *ctx, fzp_alnjob *job);   // fzp_align_run whose fail-list overflow question is answered by the fzp_align_to_batch that follows (fzp_align.hip)

@@ -456,13 +456,23 @@ int fzp_k4_blocks(fzp_ctx *ctx, fzp_batch *b) {
                                       fzp_ones(b->fr2, (size_t)ns)};
         FZP_TRY(fzp_fill(ctx, st, fl, 5));      // one launch (the runtime made twelve fills of these five)
     }
-    // the links: at most the rows, so everything that holds them is sized by the rows and the kernels read their number from where the scan left it (r5: one read-back less)
-    FZP_TRY(b->lk_i1.alloc((size_t)na)); FZP_TRY(b->lk_i2.alloc((size_t)na));
-    FZP_TRY(b->lk_cis.alloc((size_t)na)); FZP_TRY(b->lk_trans.alloc((size_t)na)); FZP_TRY(b->left_lk.alloc((size_t)na));
-    FZP_TRY(b->left_pk.alloc((size_t)na));
+    // the links: at most the rows, so everything that holds them is sized by the rows and the kernels read their number from where the scan left it (r5: one read-back
+    // less) -- while the rows are few (8 M: 36 B of link arrays per row = 288 MB; the bench step has 0.66 M).  A genome-scale group asks for the real number (ADVICE r5:
+    // six arrays sized by the rows in every lane's pool where the exact sizing fitted)
+    int64_t n_link_room = na;
     if (na > 0) {
         hipLaunchKernelGGL(k_link_flag, dim3(grid_for(na, 256, 1 << 30)), dim3(256), 0, st, b->arows.p, na, b->lk_flag.p);
         FZP_TRY(fzp_exclusive_scan_u32(ctx, b->lk_flag.p, b->lk_flag.p, (size_t)na, b->totals.p + 4));
+        if (na > (8ll << 20)) {
+            uint64_t nl = 0;
+            FZP_TRY(fzp_fetch(ctx, st, &nl, b->totals.p + 4, sizeof(uint64_t)));
+            n_link_room = (int64_t)std::min<uint64_t>(nl, (uint64_t)na);
+        }
+    }
+    FZP_TRY(b->lk_i1.alloc((size_t)n_link_room)); FZP_TRY(b->lk_i2.alloc((size_t)n_link_room));
+    FZP_TRY(b->lk_cis.alloc((size_t)n_link_room)); FZP_TRY(b->lk_trans.alloc((size_t)n_link_room)); FZP_TRY(b->left_lk.alloc((size_t)n_link_room));
+    FZP_TRY(b->left_pk.alloc((size_t)n_link_room));
+    if (na > 0) {
         ProfScope ps(ctx, "k4_links");
         hipLaunchKernelGGL(k_link_emit, dim3(grid_for(na, 256, 1 << 30)), dim3(256), 0, st, b->arows.p, na, b->lk_flag.p, b->totals.p + 4, b->lk_i1.p, b->lk_i2.p,
                            b->lk_cis.p, b->lk_trans.p, b->left_n.p, b->right_n.p, b->fr2.p);

@@ -576,6 +576,7 @@ extern "C" int fzp_batch_consensus(fzp_ctx *ctx, fzp_batch *b, fzp_tigs *out) { 
 int fzp_batch_consensus_dev(fzp_ctx *ctx, fzp_batch *b, int version, std::vector<fzp_tig> &tigs, DevBuf<uint8_t> &seq, uint64_t *n_seq, const fzp_cns_polish *polish) {
     if (!ctx || !b || version < 1 || version > 3) { fzp_set_error("fzp_batch_consensus: bad arguments"); return FZP_EINVAL; }
     tigs.clear(); *n_seq = 0;
+    FZP_TRY(fzp_batch_source_ok(b));
     if (!b->have_aln || (!polish && (!b->have_blocks || !b->have_preads || !b->have_sites))) { fzp_set_error("fzp_batch_consensus: run FZP_STAGE_ALL on a batch with alignment records first"); return FZP_EINVAL; }
     FZP_TRY(fzp_bind(ctx));
     // a packed batch (fzp_align_to_batch) is tallied as it is by fzcns v3 (k_cns_tiles_pk); versions 1 and 2 walk the run-length records, which are made now (FZP_K6_BYTES: v3 too)

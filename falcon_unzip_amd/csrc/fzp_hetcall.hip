@@ -647,6 +647,7 @@ static int k2_checkpoints(fzp_ctx *ctx, fzp_batch *b) {
 // the D / I ops) asks here, once.
 int fzp_batch_need_bytes(fzp_ctx *ctx, fzp_batch *b) {
     if (!b->packed || b->have_bytes) return FZP_OK;
+    FZP_TRY(fzp_batch_source_ok(b));
     if (!b->make_bytes) { fzp_set_error("packed batch without a source job"); return FZP_EINVAL; }
     FZP_TRY(b->make_bytes(ctx, b));
     if (b->n_rec > 0 && b->n_pos > 0) FZP_TRY(k2_checkpoints(ctx, b));
@@ -781,9 +782,10 @@ int fzp_k3_assoc(fzp_ctx *ctx, fzp_batch *b) {
         hipLaunchKernelGGL(k_cand, dim3(grid_for(ns, 256, 1 << 30)), dim3(256), 0, st, b->site_g.p, b->site_ctg.p, b->site_begin.p, ns, b->cand_n.p, b->cap_off.p);
         FZP_TRY(fzp_exclusive_scan_u32(ctx, b->cap_off.p, b->cap_off.p, (size_t)ns, b->totals.p + 2));
         // room for the candidate rows: a site has at most 501 of them (k_cand), so 501 per site is room enough and the host need not ask how many there are (r5: one
-        // read-back less) -- unless that bound is itself too large a block (64 M rows), then it asks
+        // read-back less) -- while that bound is a small block: 8 M rows = 192 MB (the bench step: 16 000 sites).  Beyond that it asks (the bound is 1.5 GB per
+        // context at 64 M rows whatever the real count, kept in the context's pool, and several lanes of a genome-scale job each hold one)
         const uint64_t bound = (uint64_t)ns * 501ull;
-        if (bound <= (64ull << 20)) tot[0] = bound;
+        if (bound <= (8ull << 20)) tot[0] = bound;
         else {
             FZP_TRY(fzp_fetch(ctx, st, tot, b->totals.p + 2, sizeof(uint64_t)));
             if (tot[0] >= (1ull << 31)) { fzp_set_error("association table bound %llu rows (> 2^31)", (unsigned long long)tot[0]); return FZP_EINVAL; }

@@ -277,7 +277,11 @@ int fzp_align_alnset(fzp_ctx *ctx, fzp_alnjob *job, int32_t ctg, const int64_t *
  * number its q_ids differently */
 int fzp_align_alnset_all(fzp_ctx *ctx, fzp_alnjob *job, int32_t ctg, const int64_t *name_off, const char *names,
                          fzp_alnset **out, int64_t **read_index);
-/* hand the aligned records of all contigs to the phasing stages without leaving the device */
+/* hand the aligned records of all contigs to the phasing stages without leaving the device.
+ * LIFETIME: the batch BORROWS the job's device memory -- it reads the alignments' packed op streams and the packed reads where K1 left them -- so the job has to stay as
+ * it is while the batch lives: destroy the batch (fzp_batch_destroy) before the job is run again or destroyed.  Enforced: fzp_align_run returns FZP_EINVAL while a batch
+ * made from the job is open; after fzp_align_destroy of its job every entry point that would read the borrowed memory (fzp_batch_run, fzp_batch_consensus*) returns
+ * FZP_EINVAL -- results already computed stay readable (fzp_batch_result*), and fzp_batch_destroy is always valid. */
 int fzp_align_to_batch(fzp_ctx *ctx, fzp_alnjob *job, fzp_batch **out);
 void fzp_align_destroy(fzp_ctx *ctx, fzp_alnjob *job);
 /* SAM text of an alnset (what `samtools view` would print), for users who want the alignments */

@@ -734,3 +734,34 @@ def test_packed_hand_off_equals_the_byte_hand_off(eng, monkeypatch):
         assert np.array_equal(getattr(a, f), getattr(c, f)), f
     assert len(a.sites) > 100 and len(a.vmap_qid) > 2000 and len(a.preads) > 300
     job.close()
+
+
+def test_a_batch_borrows_its_job(eng):
+    """fzp_align_to_batch's lifetime rule (include/fzphase.h): the batch reads the job's packed records in place, so the job may neither run again nor go away under it.
+    The binding refuses both; the library itself refuses the run and, once the job IS destroyed, fails the batch's next stage instead of reading freed memory."""
+    from falcon_unzip_amd import _lib
+    import ctypes as C
+    ctg, blob, off, *_ = _shaped(77, 200_000, 60, length_model={"median": 5000, "sigma": 0.5, "lo": 3000, "hi": 9000})
+    job = _lib.align_job_raw(eng, [ctg], blob, off, np.zeros(60, np.int32))
+    job.run()
+    b = job.to_batch()
+    with pytest.raises(_lib.FzpError):
+        job.run()
+    with pytest.raises(_lib.FzpError):
+        job.close()
+    lib = _lib.load()
+    assert lib.fzp_align_run(eng._p, job._p) != 0 and b"still open" in lib.fzp_last_error()
+    b.run(_lib.STAGE_HET)                                   # the batch itself is fine
+    lib.fzp_align_destroy(eng._p, job._p)                   # (past the binding: what a C caller could do)
+    job._p = None
+    with pytest.raises(_lib.FzpError, match="destroyed"):
+        b.run(_lib.STAGE_ALL)
+    b.close()
+    # the right order: batch first, then the job runs again
+    job = _lib.align_job_raw(eng, [ctg], blob, off, np.zeros(60, np.int32))
+    job.run()
+    b = job.to_batch()
+    b.run(_lib.STAGE_ALL)
+    b.close()
+    job.run()
+    job.close()
