@@ -2827,11 +2827,22 @@ static int build_index(fzp_ctx *ctx, fzp_alnjob *j) {
     return FZP_OK;
 }
 
+// contigs that lie in a device buffer (dev mode below) into the job's 16-byte aligned segments
+__global__ void __launch_bounds__(256) k_copy_spans(const uint8_t *__restrict__ src, const int64_t *__restrict__ be, const int64_t *__restrict__ doff, uint8_t *__restrict__ dst) {
+    const int c = blockIdx.y;
+    const int64_t b = be[2 * c], n = be[2 * c + 1] - b;
+    const uint8_t *s = src + b;
+    uint8_t *d = dst + doff[c];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) d[i] = s[i];
+}
+
 // reads given as spans of one host buffer: read r = buf[read_be[2r], read_be[2r + 1]).  What lies between the spans travels with them (the bytes from the first span's
 // begin to the last span's end go to the device in one piece), so the caller can hand over a FASTA file's bytes as they are: headers and line ends stay behind at the pack.
-extern "C" int fzp_align_create_spans(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *const *ctg_seq, const int64_t *ctg_len, int64_t n_reads, const int32_t *read_ctg,
-                                      const int64_t *read_be, const uint8_t *buf, const fzp_align_params *params, fzp_alnjob **out) {
-    if (!ctx || !out || n_ctg <= 0 || !ctg_seq || !ctg_len || n_reads < 0 || (n_reads && (!read_ctg || !read_be || !buf))) {
+// dev != nullptr (r6, fzp_phase_contigs_files): the bytes are on the device already and so are the spans -- contig c = d_raw[d_ctg_be[2c], d_ctg_be[2c + 1]), read r
+// likewise from d_read_be (fzp_fasta.hip found them there); the host brings only the lengths (ctg_len, read_len).  Nothing is uploaded but the small tables.
+static int align_create_core(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *const *ctg_seq, const int64_t *ctg_len, int64_t n_reads, const int32_t *read_ctg,
+                             const int64_t *read_be, const uint8_t *buf, const fzp_align_params *params, fzp_alnjob **out, const fzp_aln_dev_src *dev, const int64_t *read_len) {
+    if (!ctx || !out || n_ctg <= 0 || (!dev && !ctg_seq) || !ctg_len || n_reads < 0 || (n_reads && (!read_ctg || (!dev && (!read_be || !buf)) || (dev && !read_len)))) {
         fzp_set_error("fzp_align_create: bad arguments");
         return FZP_EINVAL;
     }
@@ -2868,9 +2879,9 @@ extern "C" int fzp_align_create_spans(fzp_ctx *ctx, int32_t n_ctg, const uint8_t
     j->h_cig_off.assign(1, 0);
     int64_t span_lo = INT64_MAX, span_hi = 0;
     for (int64_t r = 0; r < n_reads; r++) {
-        int64_t n = read_be[2 * r + 1] - read_be[2 * r];
-        if (n < 0 || n > 0x3fff0000LL || read_be[2 * r] < 0 || read_ctg[r] < 0 || read_ctg[r] >= n_ctg) { delete j; fzp_set_error("read %lld: bad length/contig", (long long)r); return FZP_EINVAL; }
-        span_lo = std::min(span_lo, read_be[2 * r]); span_hi = std::max(span_hi, read_be[2 * r + 1]);
+        int64_t n = dev ? read_len[r] : read_be[2 * r + 1] - read_be[2 * r];
+        if (n < 0 || n > 0x3fff0000LL || (!dev && read_be[2 * r] < 0) || read_ctg[r] < 0 || read_ctg[r] >= n_ctg) { delete j; fzp_set_error("read %lld: bad length/contig", (long long)r); return FZP_EINVAL; }
+        if (!dev) { span_lo = std::min(span_lo, read_be[2 * r]); span_hi = std::max(span_hi, read_be[2 * r + 1]); }
         if (n * (int64_t)j->P.match >= (1LL << 26) - (1 << 20)) {   // biased score << 5 must fit 32 bits (k_sw best-cell key)
             delete j; fzp_set_error("read %lld: %lld bases x match %d exceeds the score range of the DP kernel", (long long)r, (long long)n, j->P.match); return FZP_EINVAL;
         }
@@ -2888,7 +2899,8 @@ extern "C" int fzp_align_create_spans(fzp_ctx *ctx, int32_t n_ctg, const uint8_t
             (rc = j->ctg_woff.upload(j->h_ctg_woff.data(), j->h_ctg_woff.size(), st)) || (rc = j->ctg_len.upload(j->h_ctg_len.data(), j->h_ctg_len.size(), st)) ||
             (rc = j->idx_off.upload(j->h_idx_off.data(), j->h_idx_off.size(), st)) || (rc = j->idx_bits.upload(j->h_idx_bits.data(), j->h_idx_bits.size(), st)))
             break;
-        {
+        if (dev) hipLaunchKernelGGL(k_copy_spans, dim3(64, (unsigned)n_ctg), dim3(256), 0, st, dev->d_raw, dev->d_ctg_be, (const int64_t *)d_off.p, j->ctg_ascii.p);
+        else {
             std::vector<const void *> srcs; std::vector<size_t> dsts, lens;
             for (int c = 0; c < n_ctg; c++) { srcs.push_back(ctg_seq[c]); dsts.push_back((size_t)coff[(size_t)c]); lens.push_back((size_t)ctg_len[c]); }
             if ((rc = fzp_upload_segments(ctx, j->ctg_ascii.p, srcs, dsts, lens, st))) break;
@@ -2907,20 +2919,21 @@ extern "C" int fzp_align_create_spans(fzp_ctx *ctx, int32_t n_ctg, const uint8_t
         if ((rc = j->ctg_aoff.upload(coff.data(), coff.size(), st))) break;
         if (hipStreamSynchronize(st) != hipSuccess) { rc = FZP_EDEVICE; break; }
         if (n_reads) {
-            const size_t rbytes = (size_t)(span_hi - span_lo);
-            if ((rc = j->read_pk.alloc((size_t)j->read_words + 8)) || (rc = j->read_rc.alloc((size_t)j->read_words + 8)) || (rc = d_ascii.alloc(rbytes + 32)))
+            const size_t rbytes = dev ? 0 : (size_t)(span_hi - span_lo);
+            if ((rc = j->read_pk.alloc((size_t)j->read_words + 8)) || (rc = j->read_rc.alloc((size_t)j->read_words + 8)) || (!dev && (rc = d_ascii.alloc(rbytes + 32))))
                 break;
-            {
+            if (!dev) {
                 std::vector<const void *> srcs(1, buf + span_lo); std::vector<size_t> dsts(1, 0), lens(1, rbytes);
                 if ((rc = fzp_upload_segments(ctx, d_ascii.p, srcs, dsts, lens, st))) break;
+                std::vector<int64_t> rbe((size_t)n_reads * 2);
+                for (int64_t r = 0; r < 2 * n_reads; r++) rbe[(size_t)r] = read_be[r] - span_lo;
+                if ((rc = d_off.upload(rbe.data(), rbe.size(), st))) break;
             }
-            std::vector<int64_t> rbe((size_t)n_reads * 2);
-            for (int64_t r = 0; r < 2 * n_reads; r++) rbe[(size_t)r] = read_be[r] - span_lo;
-            if ((rc = d_off.upload(rbe.data(), rbe.size(), st)) || (rc = j->read_woff.upload(j->h_read_woff.data(), j->h_read_woff.size(), st)) ||
+            if ((rc = j->read_woff.upload(j->h_read_woff.data(), j->h_read_woff.size(), st)) ||
                 (rc = j->read_len.upload(j->h_read_len.data(), j->h_read_len.size(), st)) || (rc = j->read_ctg.upload(j->h_read_ctg.data(), j->h_read_ctg.size(), st)) ||
                 (rc = j->cig_off.upload(j->h_cig_off.data(), j->h_cig_off.size(), st)))
                 break;
-            hipLaunchKernelGGL(k_pack, dim3((unsigned)n_reads, 1), dim3(256), 0, st, d_ascii.p, d_off.p, j->read_woff.p, j->read_pk.p);
+            hipLaunchKernelGGL(k_pack, dim3((unsigned)n_reads, 1), dim3(256), 0, st, dev ? dev->d_raw : (const uint8_t *)d_ascii.p, dev ? dev->d_read_be : (const int64_t *)d_off.p, j->read_woff.p, j->read_pk.p);
             hipLaunchKernelGGL(k_revcomp<int32_t>, dim3((unsigned)n_reads, 1), dim3(256), 0, st, (const uint32_t *)j->read_pk.p, (const int64_t *)j->read_woff.p, (const int32_t *)j->read_len.p, j->read_rc.p);
             if (hipStreamSynchronize(st) != hipSuccess) { rc = FZP_EDEVICE; break; }
         }
@@ -2952,6 +2965,16 @@ extern "C" int fzp_align_create_spans(fzp_ctx *ctx, int32_t n_ctg, const uint8_t
     if (rc) { if (rc == FZP_EDEVICE) fzp_set_error("fzp_align_create: device error"); delete j; return rc; }
     *out = j;
     return FZP_OK;
+}
+
+extern "C" int fzp_align_create_spans(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *const *ctg_seq, const int64_t *ctg_len, int64_t n_reads, const int32_t *read_ctg,
+                                      const int64_t *read_be, const uint8_t *buf, const fzp_align_params *params, fzp_alnjob **out) {
+    return align_create_core(ctx, n_ctg, ctg_seq, ctg_len, n_reads, read_ctg, read_be, buf, params, out, nullptr, nullptr);
+}
+int fzp_align_create_dev(fzp_ctx *ctx, int32_t n_ctg, const int64_t *ctg_len, int64_t n_reads, const int32_t *read_ctg, const int64_t *read_len, const fzp_aln_dev_src *dev,
+                         const fzp_align_params *params, fzp_alnjob **out) {
+    if (!dev || !dev->d_raw || !dev->d_ctg_be || (n_reads && !dev->d_read_be)) { fzp_set_error("fzp_align_create_dev: bad arguments"); return FZP_EINVAL; }
+    return align_create_core(ctx, n_ctg, nullptr, ctg_len, n_reads, read_ctg, nullptr, nullptr, params, out, dev, read_len);
 }
 
 // the reads back to back in one buffer: read r = read_seq[read_off[r], read_off[r + 1])

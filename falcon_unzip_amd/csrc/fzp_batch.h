@@ -134,6 +134,12 @@ struct fzp_batch {
     DevBuf<int32_t> errflag;
 };
 
+// sequences that are on the device already (fzp_phase_contigs_files, r6: the group's files uploaded as they are, records found by fzp_fasta.hip): contig c =
+// d_raw[d_ctg_be[2c], d_ctg_be[2c + 1]), read r = d_raw[d_read_be[2r], d_read_be[2r + 1]) (device arrays)
+struct fzp_aln_dev_src { const uint8_t *d_raw = nullptr; const int64_t *d_ctg_be = nullptr, *d_read_be = nullptr; };
+int fzp_align_create_dev(fzp_ctx *ctx, int32_t n_ctg, const int64_t *ctg_len, int64_t n_reads, const int32_t *read_ctg, const int64_t *read_len, const fzp_aln_dev_src *dev,
+                         const fzp_align_params *params, fzp_alnjob **out);      // (fzp_align.hip)
+
 // polishing (fzp_polish_tigs, fzp_cns.hip): the templates as the alnjob keeps them on the device (upper-cased ASCII, contig c at ref + ref_off[c]) and their lengths (host)
 struct fzp_cns_polish { const uint8_t *ref = nullptr; const int64_t *ref_off = nullptr; const int64_t *len = nullptr; };
 void fzp_align_templates(const fzp_alnjob *job, const uint8_t **ascii, const int64_t **aoff);      // (fzp_align.hip)

@@ -30,6 +30,7 @@
 #include <unordered_map>
 
 #include "fzp_batch.h"
+#include "fzp_fasta.h"
 
 int fzp_batch_text_dev(fzp_ctx *ctx, fzp_batch *b, int what, DevBuf<char> &text, size_t *bytes, std::vector<int64_t> &ctg_begin);
 int fzp_batch_consensus_dev(fzp_ctx *ctx, fzp_batch *b, int version, std::vector<fzp_tig> &tigs, DevBuf<uint8_t> &seq, uint64_t *n_seq, const fzp_cns_polish *polish = nullptr);      // K6 with the sequence bytes left on the device (fzp_cns.hip)
@@ -1008,8 +1009,17 @@ struct GroupIn {
     std::vector<int32_t> read_ctg;
     RawBuf names;
     bool in_place = false;                       // the reads are spans of `raw`
+    // r6, the default: the files as they are in ONE pinned block (a '\n' behind every file), records found on the device (fzp_fasta.hip)
+    fzp_ctx *pin_ctx = nullptr;
+    uint8_t *pin = nullptr;
+    int64_t pin_bytes = 0;
+    std::vector<int64_t> foff;                   // [2 gc + 1] file t (reads files first, then the contig files) at pin + foff[t]
+    bool dev_parse = false;
+    double ms_read = 0;
     int rc = FZP_OK;
     std::string err;
+    void drop_pin() { if (pin) { fzp_pinned_release(pin_ctx, pin); pin = nullptr; } }
+    ~GroupIn() { drop_pin(); }
 };
 struct GroupPool {
     std::mutex mu;
@@ -1256,6 +1266,119 @@ void load_group(const std::string &dir, const char *const *ctg_id, int c0, int c
     if (timing) fprintf(stderr, "[load_group] %d contigs, %lld reads, %.1f MB on %d threads: read + line ends by %.2f ms, records by %.2f, %s by %.2f\n", gc, (long long)nr,
                         (double)p_base.back() / 1e6, n_threads, t_map, t_scan, in_place ? "spans (reads used in place)" : "reads joined", ms_since(t_0));
 }
+// r6: the loader that only READS.  The group's files go as they are into one pinned block -- 4 MB pieces, pread by all of the rank's threads -- with a '\n' behind every
+// file (no line runs from one file into the next; an empty line more is nothing to a FASTA reader).  Line ends, records, lengths, names' places: fzp_fasta.hip, on the
+// device, once the block is there (one DMA from pinned memory).  The host parser above stays as the checker (FZP_FASTA_HOST=1, tests).
+void load_group_raw(fzp_ctx *ctx, const std::string &dir, const char *const *ctg_id, int c0, int c1, int n_threads, GroupIn &G) {
+    const int gc = c1 - c0, nf = 2 * gc;
+    G.rc = FZP_OK; G.err.clear(); G.dev_parse = true;
+    G.drop_pin();
+    const auto t_0 = clk::now();
+    auto path_of = [&](int t) { return dir + "/" + ctg_id[c0 + (t < gc ? t : t - gc)] + (t < gc ? "_reads.fa" : "_ref.fa"); };
+    std::vector<int> fds((size_t)nf, -1);
+    std::vector<size_t> fsz((size_t)nf, 0);
+    auto close_all = [&]() { for (int &fd : fds) if (fd >= 0) { close(fd); fd = -1; } };
+    G.foff.assign((size_t)nf + 1, 0);
+    for (int t = 0; t < nf; t++) {
+        const std::string path = path_of(t);
+        fds[(size_t)t] = open(path.c_str(), O_RDONLY);
+        struct stat sb;
+        if (fds[(size_t)t] < 0 || fstat(fds[(size_t)t], &sb) != 0) { G.rc = FZP_EIO; G.err = path + ": " + strerror(errno); close_all(); return; }
+        fsz[(size_t)t] = (size_t)sb.st_size;
+        G.foff[(size_t)t + 1] = G.foff[(size_t)t] + (int64_t)fsz[(size_t)t] + 1;      // + the '\n' behind it
+    }
+    G.pin_bytes = G.foff[(size_t)nf];
+    G.pin_ctx = ctx;
+    G.pin = (uint8_t *)fzp_pinned_acquire(ctx, (size_t)G.pin_bytes + 64, nullptr);
+    if (!G.pin) { G.rc = FZP_ENOMEM; G.err = "pinned host memory for the group's files"; close_all(); return; }
+    struct Piece { int t; size_t a, b; };
+    std::vector<Piece> pieces;
+    size_t PIECE = 4u << 20;
+    if (const char *e = getenv("FZP_FASTA_PIECE")) { const long v = atol(e); if (v > 0) PIECE = (size_t)v; }
+    for (int t = 0; t < nf; t++) {
+        for (size_t a = 0; a < fsz[(size_t)t]; a += PIECE) pieces.push_back({t, a, std::min(fsz[(size_t)t], a + PIECE)});
+        G.pin[G.foff[(size_t)t] + (int64_t)fsz[(size_t)t]] = '\n';
+    }
+    std::vector<std::string> errs((size_t)nf);
+    std::mutex err_mu;
+    std::atomic<int> next{0};
+    auto work = [&]() {
+        for (int k; (k = next.fetch_add(1)) < (int)pieces.size();) {
+            const Piece &P = pieces[(size_t)k];
+            size_t at = P.a;
+            while (at < P.b) {
+                const ssize_t got = pread(fds[(size_t)P.t], G.pin + G.foff[(size_t)P.t] + at, P.b - at, (off_t)at);
+                if (got <= 0) {
+                    const std::string why = path_of(P.t) + ": " + (got < 0 ? strerror(errno) : "file shrank while it was read");
+                    std::lock_guard<std::mutex> lk(err_mu);
+                    if (errs[(size_t)P.t].empty()) errs[(size_t)P.t] = why;
+                    break;
+                }
+                at += (size_t)got;
+            }
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        const int T = (int)std::min<size_t>((size_t)std::max(1, n_threads), std::max<size_t>(1, pieces.size()));
+        for (int i = 1; i < T; i++) th.emplace_back(work);
+        work();
+        for (auto &x : th) x.join();
+    }
+    close_all();
+    for (int t = 0; t < nf; t++) if (!errs[(size_t)t].empty()) { G.rc = FZP_EIO; G.err = errs[(size_t)t]; return; }
+    G.ms_read = ms_since(t_0);
+    if (getenv("FZP_PIPE_TIMING")) fprintf(stderr, "[load_group_raw] %d contigs, %.1f MB in %zu pieces on %d threads: %.2f ms\n", gc, (double)G.pin_bytes / 1e6, pieces.size(), n_threads, G.ms_read);
+}
+
+// the group on the device: its bytes (one DMA), its records (fzp_fasta.hip), and from those what the aligner and the writers need -- which records are reads (the reads
+// files come first: a prefix), every read's contig and length, the names cut from the host's own copy, and per contig the LAST record of <ctg>_ref.fa named <ctg>
+// (the loop at phasing.py:490-494 leaves that one; none: an empty contig)
+struct GroupDev {
+    DevBuf<uint8_t> d_raw;
+    FaIndex X;
+    DevBuf<int64_t> d_ctg_be;
+    std::vector<int64_t> ctg_len, read_len;
+    std::vector<int64_t> ctg_rec;      // per contig: the record it is (-1: none)
+    int64_t n_reads = 0;
+};
+int group_to_device(fzp_ctx *lc, GroupIn &G, const char *const *ctg_id, int c0, int gc, GroupDev &D, std::mutex &up_mu) {
+    hipStream_t st = lc->stream;
+    const int nf = 2 * gc;
+    FZP_TRY(D.d_raw.alloc((size_t)G.pin_bytes + 64));
+    {   // one upload at a time (see fzp_phase_contigs)
+        std::lock_guard<std::mutex> lk(up_mu);
+        FZP_HIP(hipMemcpyAsync(D.d_raw.p, G.pin, (size_t)G.pin_bytes, hipMemcpyHostToDevice, st));
+        FZP_HIP(hipMemsetAsync(D.d_raw.p + G.pin_bytes, 0, 64, st));
+        FZP_HIP(hipStreamSynchronize(st));
+    }
+    FZP_TRY(fzp_fasta_index_dev(lc, st, D.d_raw.p, G.pin_bytes, G.foff.data(), nf, D.X));
+    const FaIndex &X = D.X;
+    int64_t nr = 0;
+    while (nr < X.n_rec && X.h_file[(size_t)nr] < gc) nr++;
+    D.n_reads = nr;
+    G.read_ctg.resize((size_t)nr); D.read_len.resize((size_t)nr); G.noff.resize((size_t)nr + 1);
+    G.noff[0] = 0;
+    for (int64_t r = 0; r < nr; r++) { G.read_ctg[(size_t)r] = X.h_file[(size_t)r]; D.read_len[(size_t)r] = X.h_len[(size_t)r]; G.noff[(size_t)r + 1] = G.noff[(size_t)r] + (X.h_name_e[(size_t)r] - X.h_name_b[(size_t)r]); }
+    if (!G.names.need((size_t)G.noff[(size_t)nr] + 1)) { fzp_set_error("host memory for the group's read names"); return FZP_ENOMEM; }
+    for (int64_t r = 0; r < nr; r++) memcpy(G.names.data() + G.noff[(size_t)r], G.pin + X.h_name_b[(size_t)r], (size_t)(G.noff[(size_t)r + 1] - G.noff[(size_t)r]));
+    D.ctg_rec.assign((size_t)gc, -1);
+    for (int64_t r = nr; r < X.n_rec; r++) {
+        const int c = X.h_file[(size_t)r] - gc;
+        const size_t want = strlen(ctg_id[c0 + c]);
+        if ((size_t)(X.h_name_e[(size_t)r] - X.h_name_b[(size_t)r]) == want && memcmp(G.pin + X.h_name_b[(size_t)r], ctg_id[c0 + c], want) == 0) D.ctg_rec[(size_t)c] = r;
+    }
+    D.ctg_len.assign((size_t)gc, 0);
+    FZP_TRY(D.d_ctg_be.alloc((size_t)2 * gc));
+    FZP_HIP(hipMemsetAsync(D.d_ctg_be.p, 0, (size_t)2 * gc * sizeof(int64_t), st));
+    for (int c = 0; c < gc; c++)
+        if (D.ctg_rec[(size_t)c] >= 0) {
+            D.ctg_len[(size_t)c] = X.h_len[(size_t)D.ctg_rec[(size_t)c]];
+            FZP_HIP(hipMemcpyAsync(D.d_ctg_be.p + 2 * c, X.d_be.p + 2 * D.ctg_rec[(size_t)c], 2 * sizeof(int64_t), hipMemcpyDeviceToDevice, st));
+        }
+    G.drop_pin();      // (the names are out: the block serves the next group)
+    return FZP_OK;
+}
 }  // namespace
 
 // test hook (tests/test_host_logic.py, CPU only): what the FASTA reader makes of <reads_dir>/<ctg>_{ref,reads}.fa of the given contigs -- one group, as fzp_phase_contigs_files
@@ -1279,6 +1402,37 @@ extern "C" int fzp_debug_load_fasta_group(const char *reads_dir, const char *con
         *ref = rb; *ref_off = (int64_t *)dup(ro.data(), ro.size() * 8);
         *blob = bb; *off = (int64_t *)dup(o.data(), o.size() * 8);
     }
+    *names = (char *)dup(G.names.data(), (size_t)G.noff[nr]); *name_off = (int64_t *)dup(G.noff.data(), (nr + 1) * 8);
+    *read_ctg = (int32_t *)dup(G.read_ctg.data(), nr * 4);
+    *n_reads = (int64_t)nr;
+    return FZP_OK;
+}
+
+// the same through the r6 reader (tests/test_gpu_pipe.py): the files read as they are, uploaded, indexed on the device (fzp_fasta.hip) -- and what the packer would read
+// brought back as bytes, to be held against the host reader's output above, hostile files included
+extern "C" int fzp_debug_load_fasta_group_dev(fzp_ctx *ctx, const char *reads_dir, const char *const *ctg_id, int32_t n_ctg, int32_t n_threads, uint8_t **ref, int64_t **ref_off, uint8_t **blob,
+                                              int64_t **off, char **names, int64_t **name_off, int32_t **read_ctg, int64_t *n_reads) {
+    if (!ctx || !reads_dir || !ctg_id || n_ctg <= 0 || !ref || !ref_off || !blob || !off || !names || !name_off || !read_ctg || !n_reads) { fzp_set_error("fzp_debug_load_fasta_group_dev: bad arguments"); return FZP_EINVAL; }
+    FZP_TRY(fzp_bind(ctx));
+    GroupIn G;
+    load_group_raw(ctx, reads_dir, ctg_id, 0, n_ctg, n_threads > 0 ? n_threads : std::min(32, cores_per_rank()), G);
+    if (G.rc != FZP_OK) { fzp_set_error("%s", G.err.c_str()); return G.rc; }
+    GroupDev D;
+    std::mutex mu;
+    FZP_TRY(group_to_device(ctx, G, ctg_id, 0, n_ctg, D, mu));
+    auto dup = [](const void *p, size_t bytes) { void *q = malloc(bytes ? bytes : 1); if (q && bytes) memcpy(q, p, bytes); return q; };
+    const size_t nr = (size_t)D.n_reads;
+    std::vector<int64_t> ro((size_t)n_ctg + 1, 0), o(nr + 1, 0);
+    for (int c = 0; c < n_ctg; c++) ro[(size_t)c + 1] = ro[(size_t)c] + D.ctg_len[(size_t)c];
+    for (size_t r = 0; r < nr; r++) o[r + 1] = o[r] + D.read_len[r];
+    uint8_t *rb = (uint8_t *)malloc((size_t)ro[(size_t)n_ctg] + 1), *bb = (uint8_t *)malloc((size_t)o[nr] + 1);
+    if (!rb || !bb) { free(rb); free(bb); fzp_set_error("fzp_debug_load_fasta_group_dev: host memory"); return FZP_ENOMEM; }
+    int rc = fzp_fasta_fetch_seqs(ctx, ctx->stream, D.d_raw.p, D.X, 0, (int64_t)nr, bb);
+    for (int c = 0; c < n_ctg && rc == FZP_OK; c++)
+        if (D.ctg_rec[(size_t)c] >= 0) rc = fzp_fasta_fetch_seqs(ctx, ctx->stream, D.d_raw.p, D.X, D.ctg_rec[(size_t)c], 1, rb + ro[(size_t)c]);
+    if (rc != FZP_OK) { free(rb); free(bb); return rc; }
+    *ref = rb; *ref_off = (int64_t *)dup(ro.data(), ro.size() * 8);
+    *blob = bb; *off = (int64_t *)dup(o.data(), o.size() * 8);
     *names = (char *)dup(G.names.data(), (size_t)G.noff[nr]); *name_off = (int64_t *)dup(G.noff.data(), (nr + 1) * 8);
     *read_ctg = (int32_t *)dup(G.read_ctg.data(), nr * 4);
     *n_reads = (int64_t)nr;
@@ -1334,6 +1488,7 @@ extern "C" int fzp_phase_contigs_files(fzp_ctx *ctx, const char *reads_dir, cons
         ctx->lanes.push_back(lc);
     }
     const int host_threads = o.n_threads > 0 ? o.n_threads : std::min(32, cores_per_rank());
+    const bool fa_host = getenv("FZP_FASTA_HOST") != nullptr;      // (the r5 reader: host threads find line ends and records; kept as the checker)
     // the loader: group g's files are parsed when a lane takes group g - 1 at the latest (one group ahead of every lane; each load uses every host thread, so
     // loads run one after the other, in group order: the first group is there as soon as it can be)
     if (!ctx->gpool) ctx->gpool = new GroupPool();
@@ -1353,7 +1508,8 @@ extern "C" int fzp_phase_contigs_files(fzp_ctx *ctx, const char *reads_dir, cons
             const Group gr = groups[g];
             loading[g] = std::async(std::launch::async, [&, G, gr, g]() {
                 { std::unique_lock<std::mutex> lk(ld_serial); ld_turn.wait(lk, [&] { return ld_next == g; }); }
-                load_group(dir, nm->ctg_id, gr.c0, gr.c1, host_threads, *G);
+                if (fa_host) load_group(dir, nm->ctg_id, gr.c0, gr.c1, host_threads, *G);
+                else load_group_raw(ctx, dir, nm->ctg_id, gr.c0, gr.c1, host_threads, *G);
                 { std::lock_guard<std::mutex> lk(ld_serial); ld_next = g + 1; }
                 ld_turn.notify_all();
             });
@@ -1388,13 +1544,24 @@ extern "C" int fzp_phase_contigs_files(fzp_ctx *ctx, const char *reads_dir, cons
             int rc = G->rc;
             if (rc != FZP_OK) { errs[(size_t)li] = G->err; rcs[(size_t)li] = rc; break; }
             const int gc = Gr.c1 - Gr.c0;
-            const int64_t gr_n = (int64_t)G->read_ctg.size();
-            std::vector<const uint8_t *> cptr((size_t)gc);
-            std::vector<int64_t> clen((size_t)gc);
-            for (int c = 0; c < gc; c++) { clen[(size_t)c] = G->ctg_len[(size_t)c]; cptr[(size_t)c] = G->ctg_ptr[(size_t)c]; }
             t0 = clk::now();
             fzp_alnjob *job = nullptr;
-            {   // one upload at a time (see fzp_phase_contigs)
+            int64_t gr_n = 0;
+            if (G->dev_parse) {      // r6: the bytes as they are, the records found on the device
+                GroupDev D;
+                rc = group_to_device(lc, *G, nm->ctg_id, Gr.c0, gc, D, up_mu);
+                gr_n = D.n_reads;
+                if (rc == FZP_OK) {
+                    fzp_aln_dev_src src;
+                    src.d_raw = D.d_raw.p; src.d_ctg_be = D.d_ctg_be.p; src.d_read_be = D.X.d_be.p;
+                    rc = fzp_align_create_dev(lc, gc, D.ctg_len.data(), gr_n, G->read_ctg.data(), D.read_len.data(), &src, &o.align, &job);
+                }
+            } else {
+                gr_n = (int64_t)G->read_ctg.size();
+                std::vector<const uint8_t *> cptr((size_t)gc);
+                std::vector<int64_t> clen((size_t)gc);
+                for (int c = 0; c < gc; c++) { clen[(size_t)c] = G->ctg_len[(size_t)c]; cptr[(size_t)c] = G->ctg_ptr[(size_t)c]; }
+                // one upload at a time (see fzp_phase_contigs)
                 std::lock_guard<std::mutex> lk(up_mu);
                 rc = fzp_align_create_spans(lc, gc, cptr.data(), clen.data(), gr_n, G->read_ctg.data(), G->be.data(), G->seq_base, &o.align, &job);
             }

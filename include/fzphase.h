@@ -380,6 +380,9 @@ void fzp_pipe_out_free(fzp_pipe_out *o);
 /* test hook (CPU only): the FASTA reader's view of one contig group -- what fzp_phase_contigs_files hands to fzp_align_create; outputs malloc'ed (fzp_free) */
 int fzp_debug_load_fasta_group(const char *reads_dir, const char *const *ctg_id, int32_t n_ctg, int32_t n_threads, uint8_t **ref, int64_t **ref_off, uint8_t **blob,
                                int64_t **off, char **names, int64_t **name_off, int32_t **read_ctg, int64_t *n_reads);
+/* the same through the r6 reader: the files read as they are, uploaded, their records found on the device (csrc/fzp_fasta.hip); what the packer would read comes back as bytes */
+int fzp_debug_load_fasta_group_dev(fzp_ctx *ctx, const char *reads_dir, const char *const *ctg_id, int32_t n_ctg, int32_t n_threads, uint8_t **ref, int64_t **ref_off, uint8_t **blob,
+                               int64_t **off, char **names, int64_t **name_off, int32_t **read_ctg, int64_t *n_reads);
 /* test hook (CPU only): one contig's read map as fzp_job_phase_write makes it -- from phased-read records and the q_id name table (name q = names[name_off[q], name_off[q + 1]))
  * -- to be held against fzp_readmap, which works from the files' text; outputs malloc'ed (fzp_free) */
 int fzp_debug_readmap_records(const char *rawread_ids, size_t rr_len, const char *pread_ids, size_t pi_len, const char *pread_to_contigs, size_t pc_len, const char *ctg_id,

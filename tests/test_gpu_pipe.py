@@ -286,3 +286,25 @@ def test_bam_and_sentinels_from_the_same_pass(eng, tmp_path, async_writes):
     assert ids[1] in str(ei.value) and "Success" not in str(ei.value)
     assert os.path.exists(os.path.join(out3, ids[1], "phasing", "p_%s_done.exit" % ids[1])) and not os.path.exists(os.path.join(out3, ids[1], "phasing", "p_%s_done" % ids[1]))
     assert os.path.exists(os.path.join(out3, ids[1], "blasr", "aln_%s_done" % ids[1]))          # the BAM itself was fine
+
+
+def test_device_fasta_reader_equals_the_host_reader_on_hostile_files(eng, tmp_path, monkeypatch):
+    """r6: fzp_phase_contigs_files reads its files as they are and finds the records ON THE DEVICE (csrc/fzp_fasta.hip).  The same hostile directory the host reader is held
+    against the Python reader on (tests/test_host_logic.py: CRLF, blank lines, wrapped and one-line records, text before the first header, no newline at the end, empty
+    files, several / no records of the contig's name): record for record what the host reader makes of it -- contigs, reads, names, the contig each read belongs to."""
+    from falcon_unzip_amd import _lib
+    from tests.test_host_logic import _load_group, hostile_fasta_dir
+    d = tmp_path / "reads"
+    ids, ref_a = hostile_fasta_dir(d)
+    exp_ctgs, exp_reads = _load_group(_lib, str(d), ids, 3)
+    for threads, piece in ((0, None), (2, "4099"), (5, "61")):
+        if piece:
+            monkeypatch.setenv("FZP_FASTA_PIECE", piece)       # (the pieces the host threads pread: smaller than a line, than a header)
+        ctgs, reads = _load_group(_lib, str(d), ids, threads, eng=eng)
+        assert ctgs == exp_ctgs, threads
+        assert len(reads) == len(exp_reads) > 2200 and reads == exp_reads, threads
+    assert ctgs[0] == ref_a and ctgs[2] == b"" and ctgs[3] == b""
+    monkeypatch.delenv("FZP_FASTA_PIECE")
+    with pytest.raises(_lib.FzpError) as e:
+        _load_group(_lib, str(d), ids + ["999999F"], eng=eng)
+    assert "999999F" in str(e.value)

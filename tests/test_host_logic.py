@@ -211,18 +211,18 @@ def test_unzip_config_hook_and_gpu_phasing_task(tmp_path):
     assert "--nproc-per-node 8" in script and "fc_unzip_phase_gpu.py --unzip_dir %s --read_map_dir %s" % (unzip, tmp_path / "read_maps") in script
 
 
-def _load_group(lib, reads_dir, ids, threads=0):
-    """fzp_debug_load_fasta_group -> (contigs, [(ctg index, name, seq)])"""
+def _load_group(lib, reads_dir, ids, threads=0, eng=None):
+    """fzp_debug_load_fasta_group -> (contigs, [(ctg index, name, seq)]); eng: through the device reader instead (fzp_debug_load_fasta_group_dev: tests/test_gpu_pipe.py)"""
     C = ctypes
     so = lib.load()
-    f = so.fzp_debug_load_fasta_group
+    f = so.fzp_debug_load_fasta_group_dev if eng is not None else so.fzp_debug_load_fasta_group
     f.restype = C.c_int
     P = C.POINTER
-    f.argtypes = [C.c_char_p, P(C.c_char_p), C.c_int32, C.c_int32] + [P(C.c_void_p)] * 7 + [P(C.c_int64)]
+    f.argtypes = ([C.c_void_p] if eng is not None else []) + [C.c_char_p, P(C.c_char_p), C.c_int32, C.c_int32] + [P(C.c_void_p)] * 7 + [P(C.c_int64)]
     arr = (C.c_char_p * len(ids))(*[i.encode() for i in ids])
     out = [C.c_void_p() for _ in range(7)]
     n = C.c_int64()
-    rc = f(reads_dir.encode(), arr, len(ids), threads, *[C.byref(o) for o in out], C.byref(n))
+    rc = f(*([eng._p] if eng is not None else []), reads_dir.encode(), arr, len(ids), threads, *[C.byref(o) for o in out], C.byref(n))
     if rc != 0:
         raise lib.FzpError(rc, so.fzp_last_error().decode())
     nr, nc = n.value, len(ids)
@@ -238,15 +238,10 @@ def _load_group(lib, reads_dir, ids, threads=0):
     return [ref[ref_off[c]:ref_off[c + 1]] for c in range(nc)], [(int(rctg[r]), names[noff[r]:noff[r + 1]], blob[off[r]:off[r + 1]]) for r in range(nr)]
 
 
-def test_fasta_reader_equals_the_python_reader_on_hostile_files(lib, tmp_path, monkeypatch):
-    """The library's FASTA reader (fzp_phase_contigs_files: files read in 4 MB pieces, records scanned and copied by several threads) against pipeline.read_fasta, the
-    reader the in-memory path uses (falcon_kit's FastaReader as phasing.py:489-494 uses it): CRLF, blank lines, wrapped and unwrapped sequences, headers with descriptions,
-    empty sequences, text before the first header, no newline at the end, an empty file, a reference file with several records (the LAST one named <ctg> is the contig) or
-    none, and files several pieces long whose records straddle the piece boundaries."""
-    from falcon_unzip_amd import pipeline
+def hostile_fasta_dir(d):
+    """<d>/<ctg>_{reads,ref}.fa of four contigs with everything a FASTA reader must not stumble over (see the test below) -> (ids, the first contig's true sequence)"""
     rng = np.random.Generator(np.random.PCG64(4242))
     acgt = np.frombuffer(b"ACGTacgtN", np.uint8)
-    d = tmp_path / "reads"
     d.mkdir()
     ids = ["000000F", "000001F", "000002F", "000003F"]
 
@@ -281,6 +276,17 @@ def test_fasta_reader_equals_the_python_reader_on_hostile_files(lib, tmp_path, m
     (d / "000002F_ref.fa").write_bytes(b">000002F_not_it\n" + ref_b + b"\n")      # no record of that name: an empty contig
     (d / "000003F_ref.fa").write_bytes(b">000003F")                                # a header and nothing else
     write_reads(d / "000003F_reads.fa", 5, 200, 3)
+    return ids, ref_a
+
+
+def test_fasta_reader_equals_the_python_reader_on_hostile_files(lib, tmp_path, monkeypatch):
+    """The library's FASTA reader (fzp_phase_contigs_files: files read in 4 MB pieces, records scanned and copied by several threads) against pipeline.read_fasta, the
+    reader the in-memory path uses (falcon_kit's FastaReader as phasing.py:489-494 uses it): CRLF, blank lines, wrapped and unwrapped sequences, headers with descriptions,
+    empty sequences, text before the first header, no newline at the end, an empty file, a reference file with several records (the LAST one named <ctg> is the contig) or
+    none, and files several pieces long whose records straddle the piece boundaries."""
+    from falcon_unzip_amd import pipeline
+    d = tmp_path / "reads"
+    ids, ref_a = hostile_fasta_dir(d)
     for threads, piece in ((1, None), (3, None), (0, None), (4, "4099"), (2, "61"), (5, "17")):
         if piece:
             monkeypatch.setenv("FZP_FASTA_PIECE", piece)       # pieces smaller than a line, than a header
