@@ -138,6 +138,24 @@ def tree_digest(root):
     return h.hexdigest()
 
 
+def cgroup_throttle():
+    """{nr_throttled, throttled_ms} of this process's CPU cgroup (v2 cpu.stat, v1 cpu,cpuacct/cpu.stat), None where neither exists: a rank behind a CPU quota that wants
+    more than its share shows up here as periods in which it was stopped, which a wall clock alone cannot tell from a slow kernel"""
+    for path in ("/sys/fs/cgroup/cpu.stat", "/sys/fs/cgroup/cpu,cpuacct/cpu.stat", "/sys/fs/cgroup/cpu/cpu.stat"):
+        try:
+            kv = dict(l.split()[:2] for l in open(path).read().splitlines() if len(l.split()) >= 2)
+        except OSError:
+            continue
+        if "nr_throttled" in kv:
+            us = float(kv.get("throttled_usec", 0)) if "throttled_usec" in kv else float(kv.get("throttled_time", 0)) / 1e3
+            return {"nr_throttled": int(kv["nr_throttled"]), "throttled_ms": round(us / 1e3, 2)}
+    return None
+
+
+def throttle_delta(a, b):
+    return None if (a is None or b is None) else {"nr_throttled": b["nr_throttled"] - a["nr_throttled"], "throttled_ms": round(b["throttled_ms"] - a["throttled_ms"], 2)}
+
+
 def thread_cpu():
     """{tid: (name, user + system seconds, system seconds)} of this process's threads (/proc/self/task)"""
     out = {}
@@ -443,11 +461,13 @@ def constrained_child(args, n_cores, contigs, blob, off, read_ctg, ids, name_tab
                 one(k)
             eng.synchronize(); eng.pipe_flush()
             th0 = thread_cpu()
+            cg0 = cgroup_throttle()
             t0, c0 = time.perf_counter(), time.process_time()
             for k in range(n_steps):
                 one(3 + k)
             eng.synchronize(); eng.pipe_flush()
             dt, cpu = time.perf_counter() - t0, time.process_time() - c0
+            cg_step = throttle_delta(cg0, cgroup_throttle())
             th1 = thread_cpu()
             by_name = {}      # who burns the rank's two cores: CPU ms per step by thread name (the runtime's own threads carry the process's name)
             for tid, (nm, tot, sy) in th1.items():
@@ -455,10 +475,19 @@ def constrained_child(args, n_cores, contigs, blob, off, read_ctg, ids, name_tab
                 key = nm.rstrip("0123456789") if nm.startswith("fzp-") else ("main" if tid == os.getpid() else "runtime/" + nm)
                 by_name[key] = by_name.get(key, 0.0) + d
             by_name = {k: round(v / n_steps * 1e3, 2) for k, v in sorted(by_name.items(), key=lambda kv: -kv[1]) if v / n_steps * 1e3 >= 0.05}
-            job.close(); eng.close()
+            job.close()
+            ff = None
+            if not args.no_from_files:      # the same two cores reading the step's FASTA files: what the reader, the copies and the lanes' launch threads need side by side
+                try:
+                    gcf, lanesf = args.e2e_group_contigs, args.e2e_lanes
+                    t_b, st_b, _, _, mb = files_leg(args, eng, contigs, blob, off, read_ctg, ids, name_tab, maps, mine, root, gcf, lanesf)
+                    ff = {"ms": round(t_b * 1e3, 2), "host_cpu_ms": st_b.get("host_cpu_ms"), "cgroup": st_b.get("cgroup"), "lanes": lanesf, "groups": int(st_b["n_groups"])}
+                except Exception as e:      # noqa: BLE001 -- reported in the line
+                    ff = {"error": repr(e)}
+            eng.close()
             shutil.rmtree(root, ignore_errors=True)
             os.write(wr, json.dumps({"ms_per_step": round(dt / n_steps * 1e3, 3), "host_cpu_ms_per_step": round(cpu / n_steps * 1e3, 2), "steps": n_steps, "cpus": n_cores,
-                                     "local_world_size": 8, "cpu_ms_per_step_by_thread": by_name}).encode())
+                                     "local_world_size": 8, "cpu_ms_per_step_by_thread": by_name, "cgroup": cg_step, "from_files": ff}).encode())
             code = 0
         except BaseException as e:      # noqa: BLE001 -- reported by the parent
             try:
@@ -494,9 +523,12 @@ def files_leg(args, eng, contigs, blob, off, read_ctg, ids, name_tab, maps, mine
         for k in range(3):
             if sync:
                 sync()
-            t1 = time.perf_counter()
+            t1, c1, th1 = time.perf_counter(), time.process_time(), cgroup_throttle()
             st, recs_f = _lib.phase_contigs_files(eng, reads_dir, ids, out_dir=os.path.join(out_root, "files_%d" % k), read_maps=maps, ctg_index=mine, n_lanes=lanes, group_bases=gb,
                                                   consensus=args.with_consensus, async_writes=True)
+            st = dict(st)
+            st["host_cpu_ms"] = round((time.process_time() - c1) * 1e3, 2)      # user + system time of every thread of the rank during the call (readers, launch threads, writers, the runtime's)
+            st["cgroup"] = throttle_delta(th1, cgroup_throttle())
             runs.append((time.perf_counter() - t1, st))
         best = min(runs[1:], key=lambda x: x[0])
         mb = sum(os.path.getsize(os.path.join(reads_dir, f)) for f in os.listdir(reads_dir)) / 1e6
@@ -781,8 +813,11 @@ def main():
             same = bool(np.array_equal(recs_f, recs_m)) and tree_digest(last_dir) == tree_digest(os.path.join(out_root, "files_ref"))
             from_files = {"reads_per_s": round(n_reads / t_best, 1), "ms": round(t_best * 1e3, 2), "lanes": lanes, "groups": int(st_best["n_groups"]),
                           "vs_end_to_end": round(t_best * 1e3 / e2e["ms"], 3), "same_bytes_as_from_memory": same, "input_mb": round(mb, 1),
-                          "note": "fzp_phase_contigs_files: <ctg>_ref.fa / <ctg>_reads.fa on a memory file system -> FASTA parsing by the library's host threads -> H2D -> pack -> K1..K5 "
-                                  "-> texts -> files; reported beside `value`, never as it"}
+                          "host_cpu_ms": st_best.get("host_cpu_ms"), "cgroup": st_best.get("cgroup"), "reader": "host" if os.environ.get("FZP_FASTA_HOST") else "device",
+                          "h2d_floor_ms": round(mb / 37.0, 1),
+                          "note": "fzp_phase_contigs_files: <ctg>_ref.fa / <ctg>_reads.fa on a memory file system -> pread into a pinned block, every 4 MB piece handed to the copy engine "
+                                  "as it lands -> records found on the device (csrc/fzp_fasta.hip) -> pack -> K1..K5 -> texts -> files; reported beside `value`, never as it.  "
+                                  "h2d_floor_ms: the files' bytes at the ~37 GB/s this host-to-device link sustains -- the last group's kernels cannot start before it"}
         except Exception as e:      # noqa: BLE001 -- reported in the line
             from_files = {"error": repr(e)}
     if world > 1 and not args.strong and not args.no_from_files:
@@ -893,7 +928,10 @@ def main():
             "index_ms": round(prof_all.get("k1_index", (0.0, 0))[0] / max(1, n_instr), 3) if not args.index_at_create else round(index_ms_at_create, 3),
             "value_from_files": from_files.get("reads_per_s") if from_files else None,      # SURVEY 8d's "reads phased/sec (end-to-end incl. host I/O)": FASTA files in, files out
             "two_core_step_ms": two_core.get("ms_per_step") if two_core else None,           # the resident step on TWO CPUs with LOCAL_WORLD_SIZE=8 (a rank's share of a 16-CPU, 8-GPU node)
-            "two_core": dict(two_core, vs_unconstrained=round(two_core["ms_per_step"] / ms_per_step, 3)) if (two_core and "ms_per_step" in two_core) else two_core,
+            "two_core": dict(two_core, vs_unconstrained=round(two_core["ms_per_step"] / ms_per_step, 3),
+                             from_files_vs_unconstrained=(round(two_core["from_files"]["ms"] / from_files["ms"], 3)
+                                                          if (two_core.get("from_files") and "ms" in two_core["from_files"] and from_files and "ms" in from_files) else None))
+            if (two_core and "ms_per_step" in two_core) else two_core,
             "value_end_to_end": e2e["reads_per_s"] if e2e else None,       # host ASCII in, PCIe + packing + index inside (SURVEY 8d's reads-phased/sec); `value` keeps inputs resident (bench contract)
             "end_to_end": e2e,
             "from_files": from_files,

@@ -997,6 +997,7 @@ struct RawBuf {
     }
     uint8_t *data() { return p; }
 };
+constexpr int FA_UP_STREAMS = 4;               // upload streams of the files loader: one stream keeps one copy engine busy (~35 GB/s here), the pieces are dealt over several
 struct GroupIn {
     RawBuf raw;                                  // the group's files as they are: the reads files first, contig after contig, then the contig files
     RawBuf ref;                                  // contigs whose FASTA record is not one plain line, joined (normally empty: the others are used where they lie in `raw`)
@@ -1016,12 +1017,34 @@ struct GroupIn {
     std::vector<int64_t> foff;                   // [2 gc + 1] file t (reads files first, then the contig files) at pin + foff[t]
     bool dev_parse = false;
     double ms_read = 0;
+    // ... and on their way to the device while the rest is still being read: every 4 MB piece is handed to the DMA engine by the thread that read it (upload stream of the
+    // pool), the lane waits for ev_up on its own stream
+    DevBuf<uint8_t> d_raw;
+    hipEvent_t ev_up[FA_UP_STREAMS] = {};
+    bool streamed = false;
+    int n_up = 0;
     int rc = FZP_OK;
     std::string err;
-    void drop_pin() { if (pin) { fzp_pinned_release(pin_ctx, pin); pin = nullptr; } }
-    ~GroupIn() { drop_pin(); }
+    std::vector<void *> maps;                    // FZP_FASTA_MMAP: the files mapped instead of read (the names are cut from the mappings)
+    std::vector<size_t> map_len;
+    const uint8_t *host_at(int64_t off) const {  // the host's copy of buffer offset `off` (inside one file)
+        if (maps.empty()) return pin + off;
+        size_t t = (size_t)(std::upper_bound(foff.begin(), foff.end(), off) - foff.begin()) - 1;
+        return (const uint8_t *)maps[t] + (off - foff[t]);
+    }
+    void drop_pin() {
+        if (pin) { fzp_pinned_release(pin_ctx, pin); pin = nullptr; }
+        for (size_t t = 0; t < maps.size(); t++) if (maps[t]) munmap(maps[t], map_len[t]);
+        maps.clear(); map_len.clear();
+    }
+    ~GroupIn() { drop_pin(); for (auto e : ev_up) if (e) (void)hipEventDestroy(e); }
 };
 struct GroupPool {
+    hipStream_t up[FA_UP_STREAMS] = {};          // the loader's upload streams (pieces of a group's files, pinned -> device)
+    int n_up = 0;
+    hipEvent_t prev[FA_UP_STREAMS] = {};         // where the previous group's copies end on every stream: a group's copies start behind ALL of them (group order on the link)
+    bool have_prev = false;
+    ~GroupPool() { for (auto u : up) if (u) (void)hipStreamDestroy(u); for (auto e : prev) if (e) (void)hipEventDestroy(e); }
     std::mutex mu;
     std::vector<std::unique_ptr<GroupIn>> idle;
     std::unique_ptr<GroupIn> take() {
@@ -1269,10 +1292,11 @@ void load_group(const std::string &dir, const char *const *ctg_id, int c0, int c
 // r6: the loader that only READS.  The group's files go as they are into one pinned block -- 4 MB pieces, pread by all of the rank's threads -- with a '\n' behind every
 // file (no line runs from one file into the next; an empty line more is nothing to a FASTA reader).  Line ends, records, lengths, names' places: fzp_fasta.hip, on the
 // device, once the block is there (one DMA from pinned memory).  The host parser above stays as the checker (FZP_FASTA_HOST=1, tests).
-void load_group_raw(fzp_ctx *ctx, const std::string &dir, const char *const *ctg_id, int c0, int c1, int n_threads, GroupIn &G) {
+void load_group_raw(fzp_ctx *ctx, const std::string &dir, const char *const *ctg_id, int c0, int c1, int n_threads, GroupIn &G, const hipStream_t *ups, int n_up, GroupPool *gp = nullptr) {
     const int gc = c1 - c0, nf = 2 * gc;
-    G.rc = FZP_OK; G.err.clear(); G.dev_parse = true;
+    G.rc = FZP_OK; G.err.clear(); G.dev_parse = true; G.streamed = false;
     G.drop_pin();
+    if (fzp_bind(ctx) != FZP_OK) { G.rc = FZP_EDEVICE; G.err = fzp_last_error(); return; }
     const auto t_0 = clk::now();
     auto path_of = [&](int t) { return dir + "/" + ctg_id[c0 + (t < gc ? t : t - gc)] + (t < gc ? "_reads.fa" : "_ref.fa"); };
     std::vector<int> fds((size_t)nf, -1);
@@ -1291,6 +1315,15 @@ void load_group_raw(fzp_ctx *ctx, const std::string &dir, const char *const *ctg
     G.pin_ctx = ctx;
     G.pin = (uint8_t *)fzp_pinned_acquire(ctx, (size_t)G.pin_bytes + 64, nullptr);
     if (!G.pin) { G.rc = FZP_ENOMEM; G.err = "pinned host memory for the group's files"; close_all(); return; }
+    if (G.d_raw.alloc((size_t)G.pin_bytes + 64) != FZP_OK) { G.rc = FZP_ENOMEM; G.err = "device memory for the group's files"; close_all(); return; }
+    for (int u = 0; u < n_up; u++)
+        if (!G.ev_up[u] && hipEventCreateWithFlags(&G.ev_up[u], hipEventDisableTiming) != hipSuccess) { G.rc = FZP_EDEVICE; G.err = "hipEventCreate"; close_all(); return; }
+    hipStream_t up = ups[0];
+    // several streams keep several copy engines busy, but the link is one: without an order the next group's pieces (read while this group's are still on their way) would
+    // share it with them and BOTH groups would arrive late.  Every stream first waits for the end of the previous group's copies on every stream.
+    if (gp && n_up > 1 && gp->have_prev)
+        for (int u = 0; u < n_up; u++) for (int v = 0; v < n_up; v++) (void)hipStreamWaitEvent(ups[u], gp->prev[v], 0);
+    std::atomic<int> hip_bad{0};
     struct Piece { int t; size_t a, b; };
     std::vector<Piece> pieces;
     size_t PIECE = 4u << 20;
@@ -1299,12 +1332,34 @@ void load_group_raw(fzp_ctx *ctx, const std::string &dir, const char *const *ctg
         for (size_t a = 0; a < fsz[(size_t)t]; a += PIECE) pieces.push_back({t, a, std::min(fsz[(size_t)t], a + PIECE)});
         G.pin[G.foff[(size_t)t] + (int64_t)fsz[(size_t)t]] = '\n';
     }
+    // (the separators and the buffer's tail: small copies of their own, so that every file piece below is exactly what one pread filled)
+    for (int t = 0; t < nf; t++)
+        if (hipMemcpyAsync(G.d_raw.p + G.foff[(size_t)t] + (int64_t)fsz[(size_t)t], G.pin + G.foff[(size_t)t] + (int64_t)fsz[(size_t)t], 1, hipMemcpyHostToDevice, up) != hipSuccess) hip_bad.store(1);
+    if (hipMemsetAsync(G.d_raw.p + G.pin_bytes, 0, 64, up) != hipSuccess) hip_bad.store(1);
     std::vector<std::string> errs((size_t)nf);
     std::mutex err_mu;
     std::atomic<int> next{0};
+    // FZP_FASTA_MMAP=1 (an experiment, profiles/r6_from_files.txt): no pread -- the pieces go to the copy engine straight from a mapping of the file (the runtime's pageable
+    // path); the pinned block is then filled only where names are cut from (never: the names come from the mapping)
+    const bool use_mmap = getenv("FZP_FASTA_MMAP") != nullptr;
+    std::vector<void *> &maps = G.maps;
+    if (use_mmap) {
+        maps.assign((size_t)nf, nullptr); G.map_len.assign(fsz.begin(), fsz.end());
+        for (int t = 0; t < nf; t++)
+            if (fsz[(size_t)t]) {
+                void *m = mmap(nullptr, fsz[(size_t)t], PROT_READ, MAP_SHARED | MAP_POPULATE, fds[(size_t)t], 0);
+                if (m == MAP_FAILED) { G.rc = FZP_EIO; G.err = path_of(t) + ": mmap: " + strerror(errno); G.drop_pin(); close_all(); return; }
+                maps[(size_t)t] = m;
+            }
+    }
     auto work = [&]() {
+        if (fzp_bind(ctx) != FZP_OK) { hip_bad.store(1); return; }
         for (int k; (k = next.fetch_add(1)) < (int)pieces.size();) {
             const Piece &P = pieces[(size_t)k];
+            if (use_mmap) {
+                if (hipMemcpyAsync(G.d_raw.p + G.foff[(size_t)P.t] + (int64_t)P.a, (const char *)maps[(size_t)P.t] + P.a, P.b - P.a, hipMemcpyHostToDevice, ups[k % n_up]) != hipSuccess) hip_bad.store(1);
+                continue;
+            }
             size_t at = P.a;
             while (at < P.b) {
                 const ssize_t got = pread(fds[(size_t)P.t], G.pin + G.foff[(size_t)P.t] + at, P.b - at, (off_t)at);
@@ -1316,17 +1371,38 @@ void load_group_raw(fzp_ctx *ctx, const std::string &dir, const char *const *ctg
                 }
                 at += (size_t)got;
             }
+            // the piece is in pinned memory: on its way while the next one is read
+            if (at == P.b && hipMemcpyAsync(G.d_raw.p + G.foff[(size_t)P.t] + (int64_t)P.a, G.pin + G.foff[(size_t)P.t] + (int64_t)P.a, P.b - P.a, hipMemcpyHostToDevice, ups[k % n_up]) != hipSuccess) hip_bad.store(1);
         }
     };
     {
         std::vector<std::thread> th;
-        const int T = (int)std::min<size_t>((size_t)std::max(1, n_threads), std::max<size_t>(1, pieces.size()));
+        int cap = 8;      // readers: eight keep ahead of the link (each moves 5-7 GB/s out of the page cache, the link takes ~37); sixteen only contend (profiles/r6_from_files.txt)
+        if (const char *e = getenv("FZP_FASTA_READERS")) { const int g = atoi(e); if (g >= 1) cap = g; }
+        const int T = (int)std::min<size_t>((size_t)std::max(1, std::min(n_threads, cap)), std::max<size_t>(1, pieces.size()));
         for (int i = 1; i < T; i++) th.emplace_back(work);
         work();
         for (auto &x : th) x.join();
     }
     close_all();
-    for (int t = 0; t < nf; t++) if (!errs[(size_t)t].empty()) { G.rc = FZP_EIO; G.err = errs[(size_t)t]; return; }
+    bool bad = hip_bad.load() != 0;
+    for (int t = 0; t < nf; t++) if (!errs[(size_t)t].empty()) { G.rc = FZP_EIO; G.err = errs[(size_t)t]; bad = true; break; }
+    for (int u = 0; u < n_up && !bad; u++) if (hipEventRecord(G.ev_up[u], ups[u]) != hipSuccess) bad = true;
+    G.n_up = n_up;
+    if (gp && n_up > 1 && !bad) {
+        for (int u = 0; u < n_up; u++) {
+            if (!gp->prev[u] && hipEventCreateWithFlags(&gp->prev[u], hipEventDisableTiming) != hipSuccess) { bad = true; break; }
+            if (hipEventRecord(gp->prev[u], ups[u]) != hipSuccess) { bad = true; break; }
+        }
+        gp->have_prev = !bad;
+    }
+    if (bad) {      // (copies out of the pinned block may still be under way: not before they are done may it serve another group)
+        for (int u = 0; u < n_up; u++) (void)hipStreamSynchronize(ups[u]);
+        (void)hipGetLastError();
+        if (G.rc == FZP_OK) { G.rc = FZP_EDEVICE; G.err = "upload of the group's files failed"; }
+        return;
+    }
+    G.streamed = true;
     G.ms_read = ms_since(t_0);
     if (getenv("FZP_PIPE_TIMING")) fprintf(stderr, "[load_group_raw] %d contigs, %.1f MB in %zu pieces on %d threads: %.2f ms\n", gc, (double)G.pin_bytes / 1e6, pieces.size(), n_threads, G.ms_read);
 }
@@ -1335,7 +1411,7 @@ void load_group_raw(fzp_ctx *ctx, const std::string &dir, const char *const *ctg
 // files come first: a prefix), every read's contig and length, the names cut from the host's own copy, and per contig the LAST record of <ctg>_ref.fa named <ctg>
 // (the loop at phasing.py:490-494 leaves that one; none: an empty contig)
 struct GroupDev {
-    DevBuf<uint8_t> d_raw;
+    const uint8_t *d_raw = nullptr;      // (the GroupIn's: uploaded by its loader)
     FaIndex X;
     DevBuf<int64_t> d_ctg_be;
     std::vector<int64_t> ctg_len, read_len;
@@ -1345,14 +1421,11 @@ struct GroupDev {
 int group_to_device(fzp_ctx *lc, GroupIn &G, const char *const *ctg_id, int c0, int gc, GroupDev &D, std::mutex &up_mu) {
     hipStream_t st = lc->stream;
     const int nf = 2 * gc;
-    FZP_TRY(D.d_raw.alloc((size_t)G.pin_bytes + 64));
-    {   // one upload at a time (see fzp_phase_contigs)
-        std::lock_guard<std::mutex> lk(up_mu);
-        FZP_HIP(hipMemcpyAsync(D.d_raw.p, G.pin, (size_t)G.pin_bytes, hipMemcpyHostToDevice, st));
-        FZP_HIP(hipMemsetAsync(D.d_raw.p + G.pin_bytes, 0, 64, st));
-        FZP_HIP(hipStreamSynchronize(st));
-    }
-    FZP_TRY(fzp_fasta_index_dev(lc, st, D.d_raw.p, G.pin_bytes, G.foff.data(), nf, D.X));
+    (void)up_mu;
+    if (!G.streamed || !G.d_raw.p) { fzp_set_error("group_to_device: the group's files are not on their way to the device"); return FZP_EINVAL; }
+    for (int u = 0; u < G.n_up; u++) FZP_HIP(hipStreamWaitEvent(st, G.ev_up[u], 0));      // the loader's copies (its own streams)
+    D.d_raw = G.d_raw.p;
+    FZP_TRY(fzp_fasta_index_dev(lc, st, D.d_raw, G.pin_bytes, G.foff.data(), nf, D.X));
     const FaIndex &X = D.X;
     int64_t nr = 0;
     while (nr < X.n_rec && X.h_file[(size_t)nr] < gc) nr++;
@@ -1361,12 +1434,12 @@ int group_to_device(fzp_ctx *lc, GroupIn &G, const char *const *ctg_id, int c0, 
     G.noff[0] = 0;
     for (int64_t r = 0; r < nr; r++) { G.read_ctg[(size_t)r] = X.h_file[(size_t)r]; D.read_len[(size_t)r] = X.h_len[(size_t)r]; G.noff[(size_t)r + 1] = G.noff[(size_t)r] + (X.h_name_e[(size_t)r] - X.h_name_b[(size_t)r]); }
     if (!G.names.need((size_t)G.noff[(size_t)nr] + 1)) { fzp_set_error("host memory for the group's read names"); return FZP_ENOMEM; }
-    for (int64_t r = 0; r < nr; r++) memcpy(G.names.data() + G.noff[(size_t)r], G.pin + X.h_name_b[(size_t)r], (size_t)(G.noff[(size_t)r + 1] - G.noff[(size_t)r]));
+    for (int64_t r = 0; r < nr; r++) memcpy(G.names.data() + G.noff[(size_t)r], G.host_at(X.h_name_b[(size_t)r]), (size_t)(G.noff[(size_t)r + 1] - G.noff[(size_t)r]));
     D.ctg_rec.assign((size_t)gc, -1);
     for (int64_t r = nr; r < X.n_rec; r++) {
         const int c = X.h_file[(size_t)r] - gc;
         const size_t want = strlen(ctg_id[c0 + c]);
-        if ((size_t)(X.h_name_e[(size_t)r] - X.h_name_b[(size_t)r]) == want && memcmp(G.pin + X.h_name_b[(size_t)r], ctg_id[c0 + c], want) == 0) D.ctg_rec[(size_t)c] = r;
+        if ((size_t)(X.h_name_e[(size_t)r] - X.h_name_b[(size_t)r]) == want && memcmp(G.host_at(X.h_name_b[(size_t)r]), ctg_id[c0 + c], want) == 0) D.ctg_rec[(size_t)c] = r;
     }
     D.ctg_len.assign((size_t)gc, 0);
     FZP_TRY(D.d_ctg_be.alloc((size_t)2 * gc));
@@ -1415,7 +1488,7 @@ extern "C" int fzp_debug_load_fasta_group_dev(fzp_ctx *ctx, const char *reads_di
     if (!ctx || !reads_dir || !ctg_id || n_ctg <= 0 || !ref || !ref_off || !blob || !off || !names || !name_off || !read_ctg || !n_reads) { fzp_set_error("fzp_debug_load_fasta_group_dev: bad arguments"); return FZP_EINVAL; }
     FZP_TRY(fzp_bind(ctx));
     GroupIn G;
-    load_group_raw(ctx, reads_dir, ctg_id, 0, n_ctg, n_threads > 0 ? n_threads : std::min(32, cores_per_rank()), G);
+    load_group_raw(ctx, reads_dir, ctg_id, 0, n_ctg, n_threads > 0 ? n_threads : std::min(32, cores_per_rank()), G, &ctx->stream2, 1);
     if (G.rc != FZP_OK) { fzp_set_error("%s", G.err.c_str()); return G.rc; }
     GroupDev D;
     std::mutex mu;
@@ -1427,9 +1500,9 @@ extern "C" int fzp_debug_load_fasta_group_dev(fzp_ctx *ctx, const char *reads_di
     for (size_t r = 0; r < nr; r++) o[r + 1] = o[r] + D.read_len[r];
     uint8_t *rb = (uint8_t *)malloc((size_t)ro[(size_t)n_ctg] + 1), *bb = (uint8_t *)malloc((size_t)o[nr] + 1);
     if (!rb || !bb) { free(rb); free(bb); fzp_set_error("fzp_debug_load_fasta_group_dev: host memory"); return FZP_ENOMEM; }
-    int rc = fzp_fasta_fetch_seqs(ctx, ctx->stream, D.d_raw.p, D.X, 0, (int64_t)nr, bb);
+    int rc = fzp_fasta_fetch_seqs(ctx, ctx->stream, D.d_raw, D.X, 0, (int64_t)nr, bb);
     for (int c = 0; c < n_ctg && rc == FZP_OK; c++)
-        if (D.ctg_rec[(size_t)c] >= 0) rc = fzp_fasta_fetch_seqs(ctx, ctx->stream, D.d_raw.p, D.X, D.ctg_rec[(size_t)c], 1, rb + ro[(size_t)c]);
+        if (D.ctg_rec[(size_t)c] >= 0) rc = fzp_fasta_fetch_seqs(ctx, ctx->stream, D.d_raw, D.X, D.ctg_rec[(size_t)c], 1, rb + ro[(size_t)c]);
     if (rc != FZP_OK) { free(rb); free(bb); return rc; }
     *ref = rb; *ref_off = (int64_t *)dup(ro.data(), ro.size() * 8);
     *blob = bb; *off = (int64_t *)dup(o.data(), o.size() * 8);
@@ -1493,6 +1566,12 @@ extern "C" int fzp_phase_contigs_files(fzp_ctx *ctx, const char *reads_dir, cons
     // loads run one after the other, in group order: the first group is there as soon as it can be)
     if (!ctx->gpool) ctx->gpool = new GroupPool();
     GroupPool *pool = ctx->gpool;
+    if (!pool->n_up) {
+        int want = 1;      // (measured: 2 and 4 streams, with and without group order on the link, are within the noise of one -- 32-36 ms -- and cost the host more: profiles/r6_from_files.txt)
+        if (const char *e = getenv("FZP_FASTA_UP_STREAMS")) { const int g = atoi(e); if (g >= 1 && g <= FA_UP_STREAMS) want = g; }
+        for (int u = 0; u < want; u++) FZP_HIP(hipStreamCreateWithFlags(&pool->up[u], hipStreamNonBlocking));
+        pool->n_up = want;
+    }
     std::vector<std::unique_ptr<GroupIn>> gin(groups.size());
     std::vector<std::future<void>> loading(groups.size());
     std::mutex ld_mu, ld_serial;
@@ -1509,7 +1588,7 @@ extern "C" int fzp_phase_contigs_files(fzp_ctx *ctx, const char *reads_dir, cons
             loading[g] = std::async(std::launch::async, [&, G, gr, g]() {
                 { std::unique_lock<std::mutex> lk(ld_serial); ld_turn.wait(lk, [&] { return ld_next == g; }); }
                 if (fa_host) load_group(dir, nm->ctg_id, gr.c0, gr.c1, host_threads, *G);
-                else load_group_raw(ctx, dir, nm->ctg_id, gr.c0, gr.c1, host_threads, *G);
+                else load_group_raw(ctx, dir, nm->ctg_id, gr.c0, gr.c1, host_threads, *G, pool->up, pool->n_up, pool);
                 { std::lock_guard<std::mutex> lk(ld_serial); ld_next = g + 1; }
                 ld_turn.notify_all();
             });
@@ -1551,9 +1630,10 @@ extern "C" int fzp_phase_contigs_files(fzp_ctx *ctx, const char *reads_dir, cons
                 GroupDev D;
                 rc = group_to_device(lc, *G, nm->ctg_id, Gr.c0, gc, D, up_mu);
                 gr_n = D.n_reads;
+                if (timing) fprintf(stderr, "[lane %d group %zu] +%.2f ms: files on the device and indexed (%lld records, %lld lines, %lld joined bytes)\n", li, g, ms_since(t_call), (long long)D.X.n_rec, (long long)D.X.n_lines, (long long)D.X.join_bytes);
                 if (rc == FZP_OK) {
                     fzp_aln_dev_src src;
-                    src.d_raw = D.d_raw.p; src.d_ctg_be = D.d_ctg_be.p; src.d_read_be = D.X.d_be.p;
+                    src.d_raw = D.d_raw; src.d_ctg_be = D.d_ctg_be.p; src.d_read_be = D.X.d_be.p;
                     rc = fzp_align_create_dev(lc, gc, D.ctg_len.data(), gr_n, G->read_ctg.data(), D.read_len.data(), &src, &o.align, &job);
                 }
             } else {
@@ -1566,6 +1646,7 @@ extern "C" int fzp_phase_contigs_files(fzp_ctx *ctx, const char *reads_dir, cons
                 rc = fzp_align_create_spans(lc, gc, cptr.data(), clen.data(), gr_n, G->read_ctg.data(), G->be.data(), G->seq_base, &o.align, &job);
             }
             po.ms_upload += ms_since(t0);
+            if (timing) fprintf(stderr, "[lane %d group %zu] +%.2f ms: alignment job created (packed, index built)\n", li, g, ms_since(t_call));
             if (rc == FZP_OK) {
                 fzp_names gn;
                 gn.n_ctg = gc; gn.ctg_id = nm->ctg_id + Gr.c0;
@@ -1574,6 +1655,7 @@ extern "C" int fzp_phase_contigs_files(fzp_ctx *ctx, const char *reads_dir, cons
                 std::vector<int32_t> gi;
                 for (int c = Gr.c0; c < Gr.c1; c++) gi.push_back(o.ctg_index ? o.ctg_index[c] : c);
                 rc = job_phase_write(lc, job, &gn, &o, mh, gi.data(), &po, r2p_g[g]);
+                if (timing) fprintf(stderr, "[lane %d group %zu] +%.2f ms: phased, write tasks queued\n", li, g, ms_since(t_call));
                 if (rc == FZP_OK) {
                     std::vector<fzp_aln_summary> sm((size_t)gr_n);
                     if (gr_n && fzp_align_summaries(lc, job, sm.data()) == FZP_OK) for (auto &s : sm) po.dp_cells += (double)s.cells;
@@ -1581,6 +1663,7 @@ extern "C" int fzp_phase_contigs_files(fzp_ctx *ctx, const char *reads_dir, cons
             }
             if (rc != FZP_OK) errs[(size_t)li] = fzp_last_error();
             fzp_align_destroy(lc, job);
+            if (timing) fprintf(stderr, "[lane %d group %zu] +%.2f ms: summaries read, job destroyed\n", li, g, ms_since(t_call));
             po.n_reads += gr_n;
             { std::lock_guard<std::mutex> lk(ld_mu); pool->give(std::move(gin[g])); }      // its buffers serve a later group (of this call or the next)
             if (rc != FZP_OK) { rcs[(size_t)li] = rc; break; }
