@@ -89,9 +89,15 @@ __global__ void __launch_bounds__(256) k_pack(const uint8_t *__restrict__ ascii,
 
 __device__ __forceinline__ uint32_t base_at(const uint32_t *__restrict__ pk, int64_t i) { return (pk[i >> 4] >> ((i & 15) * 2)) & 3u; }
 
+// the k-mer at base p: a 32-bit window over two adjacent words, by ONE funnel shift (v_alignbit_b32: ({hi, lo} >> shift) for shift 0..31).
+// r6: until r5 this made a 64-bit word of the two and shifted that.  In k_revcomp's first word-at-a-time form the compiler turned that into global_load_dwordx2 +
+// v_lshrrev_b64 with a per-lane shift register, and whole rows of 16 lanes came back shifted by the low bits of their STORE ADDRESS instead -- the right two words under
+// the wrong shift, other rows every run, gone with any change to the sequence (the shift amount pinned, in an SGPR, 32-bit shifts, one register more); the unaligned 8-byte
+// load itself is clean (67 M pairs, four access orders): tools/ubench/unaligned_pair.hip, profiles/r6_kmer_at_anomaly.txt.  Whatever the cause -- it is not in the source --
+// a form without a 64-bit variable shift cannot produce that sequence, and it is one instruction where the other was three.
 __device__ __forceinline__ uint32_t kmer_at(const uint32_t *__restrict__ pk, int64_t p, int k) {
-    uint64_t w = (uint64_t)pk[p >> 4] | ((uint64_t)pk[(p >> 4) + 1] << 32);
-    uint32_t key = (uint32_t)(w >> ((p & 15) * 2));
+    const uint32_t lo = pk[p >> 4], hi = pk[(p >> 4) + 1];
+    const uint32_t key = __builtin_amdgcn_alignbit(hi, lo, (uint32_t)(p & 15) * 2u);
     return k < 16 ? (key & ((1u << (2 * k)) - 1u)) : key;
 }
 // reverse-complement of a k-mer key (base m at bits 2m)
@@ -3328,6 +3334,67 @@ extern "C" int64_t fzp_debug_swb_waves(fzp_ctx *ctx, fzp_alnjob *j, uint64_t *ou
     if (n > 0 && (hipMemcpy(out, j->wave_log.p, (size_t)n * 32, hipMemcpyDeviceToHost) != hipSuccess)) return 0;
     return n;
 }
+// ---- K1's intermediates for the checker (tests/test_gpu_align.py; VERDICT r5: "no test compares the k-mer table or the hit lists with the twin's")
+// the index of contig `ctg` as a sorted list of its entries (key << 32 | position << 1 | "the canonical form is the reverse complement"): what the twin's sorted (key, pos)
+// table holds -- WHICH slot an entry sits in is a race between inserts (it never decides what a look-up finds), the multiset is not
+extern "C" int fzp_debug_index_entries(fzp_ctx *ctx, fzp_alnjob *j, int32_t ctg, uint64_t **entries, int64_t *n) {
+    if (!ctx || !j || ctg < 0 || ctg >= j->n_ctg || !entries || !n || !j->index_built) { fzp_set_error("fzp_debug_index_entries: bad arguments (or no index built)"); return FZP_EINVAL; }
+    FZP_TRY(fzp_bind(ctx));
+    const size_t slots = (size_t)1 << j->h_idx_bits[(size_t)ctg];
+    std::vector<uint64_t> t(slots);
+    FZP_HIP(hipStreamSynchronize(ctx->stream));
+    FZP_HIP(hipMemcpy(t.data(), j->table.p + j->h_idx_off[(size_t)ctg], slots * 8, hipMemcpyDeviceToHost));
+    size_t m = 0;
+    for (size_t i = 0; i < slots; i++) if (t[i] != EMPTY) t[m++] = t[i];
+    std::sort(t.begin(), t.begin() + (long)m);
+    uint64_t *o = (uint64_t *)malloc((m ? m : 1) * 8);
+    if (!o) return FZP_ENOMEM;
+    memcpy(o, t.data(), m * 8);
+    *entries = o; *n = (int64_t)m;
+    return FZP_OK;
+}
+__global__ void __launch_bounds__(256) k_table_fingerprint(const uint64_t *__restrict__ table, int64_t slots, unsigned long long *__restrict__ out) {
+    unsigned long long cnt = 0, sum = 0, x = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < slots; i += (int64_t)gridDim.x * 256) {
+        const uint64_t e = table[i];
+        if (e != EMPTY) { const uint64_t h = mix64(e); cnt++; sum += h; x ^= h; }
+    }
+    for (int d = 32; d >= 1; d >>= 1) { cnt += __shfl_xor(cnt, d, 64); sum += __shfl_xor(sum, d, 64); x ^= __shfl_xor(x, d, 64); }
+    if (lane_id() == 0) { atomicAdd(out, cnt); atomicAdd(out + 1, sum); atomicXor(out + 2, x); }
+}
+// an order-free fingerprint of ALL contigs' tables: {entries, sum and xor of mix64(entry)} -- the same whatever slots the entries landed in
+extern "C" int fzp_debug_index_fingerprint(fzp_ctx *ctx, fzp_alnjob *j, uint64_t *out3) {
+    if (!ctx || !j || !out3 || !j->index_built) { fzp_set_error("fzp_debug_index_fingerprint: bad arguments (or no index built)"); return FZP_EINVAL; }
+    FZP_TRY(fzp_bind(ctx));
+    DevBuf<unsigned long long> d;
+    FZP_TRY(d.alloc(3)); FZP_TRY(d.zero(3, ctx->stream));
+    hipLaunchKernelGGL(k_table_fingerprint, dim3(2048), dim3(256), 0, ctx->stream, (const uint64_t *)j->table.p, j->idx_slots, d.p);
+    FZP_HIP(hipMemcpyAsync(out3, d.p, 24, hipMemcpyDeviceToHost, ctx->stream));
+    FZP_HIP(hipStreamSynchronize(ctx->stream));
+    return FZP_OK;
+}
+// the k-mer tables again, now (what a run does when the job's index was invalidated; the race between inserts runs again)
+extern "C" int fzp_debug_rebuild_index(fzp_ctx *ctx, fzp_alnjob *j) {
+    if (!ctx || !j) return FZP_EINVAL;
+    FZP_TRY(fzp_bind(ctx));
+    FZP_TRY(build_index(ctx, j));
+    FZP_HIP(hipStreamSynchronize(ctx->stream));
+    return FZP_OK;
+}
+// the hit list of read `read` as the last run's seeding left it: n_hits pairs (strand << 31 | oriented read offset, contig position), spec order (sample, then position)
+extern "C" int fzp_debug_read_hits(fzp_ctx *ctx, fzp_alnjob *j, int64_t read, uint32_t *out, int32_t *n_hits) {
+    if (!ctx || !j || !j->done || read < 0 || read >= j->n_reads || !out || !n_hits) { fzp_set_error("fzp_debug_read_hits: bad arguments (run the job first)"); return FZP_EINVAL; }
+    if (j->n_reads > 65536) { fzp_set_error("fzp_debug_read_hits: jobs of up to 65 536 reads (one seeding launch: the hit lists of earlier launches are gone)"); return FZP_EINVAL; }
+    FZP_TRY(fzp_bind(ctx));
+    SeedWin w;
+    FZP_HIP(hipStreamSynchronize(ctx->stream));
+    FZP_HIP(hipMemcpy(&w, j->win.p + read, sizeof w, hipMemcpyDeviceToHost));
+    const int32_t nh = std::min<int32_t>(std::max<int32_t>(w.n_hits, 0), HIT_CAP);
+    if (nh) FZP_HIP(hipMemcpy(out, j->hits.p + (size_t)read * HIT_CAP, (size_t)nh * 8, hipMemcpyDeviceToHost));
+    *n_hits = nh;
+    return FZP_OK;
+}
+
 extern "C" int fzp_align_cigar_hashes(fzp_ctx *ctx, fzp_alnjob *j, uint64_t *out) {
     if (!ctx || !j || !j->done || !out) { fzp_set_error("fzp_align_cigar_hashes: run the job first"); return FZP_EINVAL; }
     FZP_TRY(fzp_bind(ctx));

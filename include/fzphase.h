@@ -261,6 +261,13 @@ int fzp_align_create_spans(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *const *ct
 int fzp_align_run(fzp_ctx *ctx, fzp_alnjob *job);
 /* forget the k-mer tables fzp_align_create built: the next fzp_align_run builds them again, inside the run */
 int fzp_align_invalidate_index(fzp_alnjob *job);
+/* K1's intermediates, for checkers (tests/test_gpu_align.py): the k-mer table of a contig as a sorted list of entries (key << 32 | position << 1 | strand bit;
+ * malloc'ed, fzp_free), an order-free fingerprint of all tables {entries, sum, xor of a 64-bit mix of every entry}, the tables built again, and a read's hit list as the
+ * last run's seeding left it (out: room for 2 x 4 096 words; pairs (strand << 31 | oriented read offset, contig position) in spec order) */
+int fzp_debug_index_entries(fzp_ctx *ctx, fzp_alnjob *job, int32_t ctg, uint64_t **entries, int64_t *n);
+int fzp_debug_index_fingerprint(fzp_ctx *ctx, fzp_alnjob *job, uint64_t *out3);
+int fzp_debug_rebuild_index(fzp_ctx *ctx, fzp_alnjob *job);
+int fzp_debug_read_hits(fzp_ctx *ctx, fzp_alnjob *job, int64_t read, uint32_t *out, int32_t *n_hits);
 int fzp_align_summaries(fzp_ctx *ctx, fzp_alnjob *job, fzp_aln_summary *out /* [n_reads] */);
 /* a 64-bit fingerprint of every read's CIGAR as the device keeps it (runs of M / I / D / S, the clips included): sum over the words of
  * splitmix64(index << 32 | word), 0 for a read without an alignment.  Lets a checker hold every CIGAR of a large run against another aligner's -- gap placement and

@@ -177,6 +177,8 @@ static void push(u32vec *v, uint32_t x) {
 }
 
 typedef struct { int32_t s; int64_t i, cp, dv; } hit_t;
+static hit_t *g_dbg_hits;      /* seed_candidates copies its hit list here when set (orc_debug_hits, a single-threaded test hook) */
+static int64_t g_dbg_nh;
 typedef struct { int strand; int64_t i_a, c_a; int n_wp; int64_t wi[MAX_WP], wc[MAX_WP]; } anchor_t;      /* (wi[0], wc[0]) = the anchor */
 static inline int64_t piece_len(int64_t n) { const int64_t p = (n + MAX_WP - 2) / (MAX_WP - 1); return p > PIECE_LEN ? p : PIECE_LEN; }
 
@@ -233,6 +235,7 @@ static int seed_candidates(const ctg_index *ix, const uint8_t *fwd, int64_t n, c
             votes[s * NB + ((cp - i + n) >> shift)]++;
         }
     }
+    if (g_dbg_hits) { memcpy(g_dbg_hits, hits, (size_t)nh * sizeof(hit_t)); g_dbg_nh = nh; }
     int n_cand = 0;
     uint32_t w1 = 0; int s1 = 0; int64_t b1 = 0;
     for (int s = 0; s < 2; s++)
@@ -667,6 +670,39 @@ static void *mt_worker(void *vp) {
 }
 /* test hook (tests/: the spec-independent full-matrix check needs the origin an extension started from; since v1.3 the reported alignment
  * no longer reveals it): the candidate origins of one read as seed_candidates finds them, out[c] = {strand, i_a, c_a, forward terminal score, backward terminal score (or -2^26)}; returns their number */
+/* test hooks (tests/test_gpu_align.py: K1's intermediates on the device against these): the index as sorted entries key << 32 | (position << 1 | strand bit) -- the device
+ * table's own entry format --, and a read's hit list in spec order as pairs (strand << 31 | oriented offset, contig position) */
+int orc_debug_index(const uint8_t *ctg_ascii, int64_t ctg_len, const orc_align_params *P, uint64_t **entries, int64_t *n) {
+    ctg_index ix;
+    uint8_t *codes = (uint8_t *)malloc((size_t)(ctg_len ? ctg_len : 1));
+    for (int64_t i = 0; i < ctg_len; i++) codes[i] = (uint8_t)code_of(ctg_ascii[i]);
+    ix.codes = codes; ix.len = ctg_len;
+    build_index_entries(&ix, codes, ctg_len, P);
+    uint64_t *o = (uint64_t *)malloc((size_t)(ix.n ? ix.n : 1) * 8);
+    for (int64_t q = 0; q < ix.n; q++) o[q] = ((uint64_t)ix.kp[q].key << 32) | (uint32_t)ix.kp[q].pos;
+    *entries = o; *n = ix.n;
+    free(ix.kp); free(codes);
+    return 0;
+}
+int orc_debug_hits(const uint8_t *ctg_ascii, int64_t ctg_len, const uint8_t *read_ascii, int64_t n, const orc_align_params *P, uint32_t *out, int64_t *n_hits) {
+    ctg_index ix;
+    uint8_t *codes = (uint8_t *)malloc((size_t)(ctg_len ? ctg_len : 1));
+    for (int64_t i = 0; i < ctg_len; i++) codes[i] = (uint8_t)code_of(ctg_ascii[i]);
+    ix.codes = codes; ix.len = ctg_len;
+    build_index_entries(&ix, codes, ctg_len, P);
+    uint8_t *fwd = (uint8_t *)malloc((size_t)(n ? n : 1));
+    for (int64_t i = 0; i < n; i++) fwd[i] = (uint8_t)code_of(read_ascii[i]);
+    anchor_t cand[2];
+    g_dbg_hits = (hit_t *)malloc((size_t)HIT_CAP * sizeof(hit_t)); g_dbg_nh = 0;
+    if (n >= P->kmer && ix.len >= P->kmer) (void)seed_candidates(&ix, fwd, n, P, cand);
+    for (int64_t h = 0; h < g_dbg_nh; h++) { out[2 * h] = ((uint32_t)g_dbg_hits[h].s << 31) | (uint32_t)g_dbg_hits[h].i; out[2 * h + 1] = (uint32_t)g_dbg_hits[h].cp; }
+    *n_hits = g_dbg_nh;
+    free(g_dbg_hits); g_dbg_hits = NULL;
+    scratch_release();
+    free(fwd); free(ix.kp); free(codes);
+    return 0;
+}
+
 int orc_align_origins(const uint8_t *ctg_ascii, int64_t ctg_len, const uint8_t *read_ascii, int64_t n, const orc_align_params *P, int64_t *out) {
     if (P->kmer < 8 || P->kmer > 16 || P->seed_stride < 1) return -1;
     ctg_index ix;

@@ -237,3 +237,38 @@ def track_reads(orc, files, phased_reads: bytes, read_to_contig_map: bytes, rawr
     out = C.string_at(p, q.value)
     lib.orc_free(p)
     return out
+
+
+def debug_index(orc, ctg: bytes, params=None):
+    """oracle/align_oracle.c: orc_debug_index -> the contig's k-mer index as sorted uint64 entries (key << 32 | position << 1 | strand bit), the device table's entry format"""
+    import numpy as np
+    P = AlignParams()
+    orc.lib.orc_align_params_default(C.byref(P))
+    for k, v in (params or {}).items():
+        setattr(P, k, v)
+    p, n = C.c_void_p(), C.c_int64()
+    f = orc.lib.orc_debug_index
+    f.restype = C.c_int
+    f.argtypes = [C.c_char_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+    if f(ctg, len(ctg), C.byref(P), C.byref(p), C.byref(n)) != 0:
+        raise OracleError("orc_debug_index failed")
+    out = np.frombuffer(C.string_at(p, 8 * n.value), np.uint64).copy()
+    orc.lib.orc_free(p)
+    return out
+
+
+def debug_hits(orc, ctg: bytes, read: bytes, params=None):
+    """oracle/align_oracle.c: orc_debug_hits -> the read's hit list in spec order, uint32 [n, 2]: (strand << 31 | oriented read offset, contig position)"""
+    import numpy as np
+    P = AlignParams()
+    orc.lib.orc_align_params_default(C.byref(P))
+    for k, v in (params or {}).items():
+        setattr(P, k, v)
+    out = np.zeros((4096, 2), np.uint32)
+    n = C.c_int64()
+    f = orc.lib.orc_debug_hits
+    f.restype = C.c_int
+    f.argtypes = [C.c_char_p, C.c_int64, C.c_char_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+    if f(ctg, len(ctg), read, len(read), C.byref(P), out.ctypes.data_as(C.c_void_p), C.byref(n)) != 0:
+        raise OracleError("orc_debug_hits failed")
+    return out[:n.value].copy()

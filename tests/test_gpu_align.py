@@ -765,3 +765,95 @@ def test_a_batch_borrows_its_job(eng):
     b.close()
     job.run()
     job.close()
+
+
+def _dev_index(eng, job, ctg):
+    import ctypes as C
+    from falcon_unzip_amd import _lib
+    lib = _lib.load()
+    p, n = C.c_void_p(), C.c_int64()
+    f = lib.fzp_debug_index_entries
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+    assert f(eng._p, job._p, ctg, C.byref(p), C.byref(n)) == 0, lib.fzp_last_error()
+    out = np.frombuffer(C.string_at(p, 8 * n.value), np.uint64).copy()
+    lib.fzp_free(p)
+    return out
+
+
+def _dev_hits(eng, job, r):
+    import ctypes as C
+    from falcon_unzip_amd import _lib
+    lib = _lib.load()
+    out = np.zeros((4096, 2), np.uint32)
+    n = C.c_int32()
+    f = lib.fzp_debug_read_hits
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+    assert f(eng._p, job._p, r, out.ctypes.data_as(C.c_void_p), C.byref(n)) == 0, lib.fzp_last_error()
+    return out[:n.value].copy()
+
+
+def _dev_fingerprint(eng, job, rebuild=False):
+    import ctypes as C
+    from falcon_unzip_amd import _lib
+    lib = _lib.load()
+    if rebuild:
+        f = lib.fzp_debug_rebuild_index
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_void_p]
+        assert f(eng._p, job._p) == 0, lib.fzp_last_error()
+    out = np.zeros(3, np.uint64)
+    f = lib.fzp_debug_index_fingerprint
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    assert f(eng._p, job._p, out.ctypes.data_as(C.c_void_p)) == 0, lib.fzp_last_error()
+    return tuple(int(x) for x in out)
+
+
+def test_kmer_table_and_hit_lists_equal_the_twins(eng, oracle):
+    """K1's INTERMEDIATES (seeding is redundant by design -- ~85 hits per read --, so a few wrong k-mers need not move an alignment, and no test looked at
+    them).  The k-mer table of every contig, as a sorted list of entries, and the hit list of every one of 2 000 reads, in spec order: equal to the twin's, entry for entry.
+    Both samplings (v1.7's anchored k-mers, v1.6's strides), contigs whose lengths put the last k-mers at every offset of a packed word."""
+    from falcon_unzip_amd import _lib, sim
+    rng = np.random.Generator(np.random.PCG64(4711))
+    ctgs, blobs, offs, rctg = [], [], [np.zeros(1, np.int64)], []
+    base = 0
+    for c, L in enumerate((300_000, 300_007, 123_461, 77_777)):
+        hap0, hap1, _ = sim.make_diploid(L, rng)
+        codes, off, *_ = sim.simulate_raw_reads_bulk(hap0, hap1, 500, 9000, rng)
+        ctgs.append(sim.ACGT[hap0].tobytes()); blobs.append(sim.ACGT[codes].tobytes())
+        offs.append(off[1:] + base); base += int(off[-1]); rctg.append(np.full(500, c, np.int32))
+    blob, off, rctg = b"".join(blobs), np.concatenate(offs), np.concatenate(rctg)
+    for params in ({}, {"seed_anchored": 0}):
+        job = _lib.align_job_raw(eng, ctgs, blob, off, rctg, params=params)
+        job.run()
+        for c, ctg in enumerate(ctgs):
+            dev, twin = _dev_index(eng, job, c), oracle_lib.debug_index(oracle, ctg, params)
+            assert len(dev) == len(twin) > len(ctg) // 20 and np.array_equal(dev, twin), (params, c, len(dev), len(twin))
+        n_hits = 0
+        for r in range(len(rctg)):
+            dev = _dev_hits(eng, job, r)
+            twin = oracle_lib.debug_hits(oracle, ctgs[rctg[r]], blob[off[r]:off[r + 1]], params)
+            assert dev.shape == twin.shape and np.array_equal(dev, twin), (params, r, dev.shape, twin.shape)
+            n_hits += len(dev)
+        assert n_hits > 40 * len(rctg)
+        job.close()
+
+
+def test_ten_builds_of_the_bench_index_are_the_same_table(eng):
+    """The k-mer tables of the bench step's contigs (20 x 5 Mb) built ten times: which slot an entry lands in is a race between inserts, WHAT is in the table is not -- the
+    number of entries and an order-free 128-bit fingerprint of them (sum and xor of a 64-bit mix of every entry) stay the same; and one contig's sorted entries, downloaded
+    after the first and after the last build, are equal word for word."""
+    from falcon_unzip_amd import _lib, sim
+    rng = np.random.Generator(np.random.PCG64(20260002))
+    ctgs = [sim.ACGT[rng.integers(0, 4, 5_000_000, dtype=np.uint8)].tobytes() for _ in range(20)]
+    rd = ctgs[0][1000:9000]
+    job = _lib.align_job_raw(eng, ctgs, rd, np.array([0, len(rd)], np.int64), np.zeros(1, np.int32))
+    first = _dev_fingerprint(eng, job)
+    assert first[0] > 20 * 5_000_000 // 10                      # about an eighth of the positions are anchored k-mers
+    e0 = _dev_index(eng, job, 7)
+    for _ in range(9):
+        assert _dev_fingerprint(eng, job, rebuild=True) == first
+    assert np.array_equal(_dev_index(eng, job, 7), e0)
+    job.close()
