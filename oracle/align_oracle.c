@@ -84,14 +84,16 @@
 #include <string.h>
 #include <time.h>
 
-#define W 64
+#define W 64             /* room for the widest band; the band itself is a parameter since v1.8 (orc_align_params.band: 64 or 32, 0 = FZP_ALIGN_BAND or the default) */
+#define ORC_DEFAULT_BAND 64
 #define NEG (-(1 << 26))
 
 typedef struct {
     int32_t kmer, seed_stride, match, mismatch, gap, min_seed_hits;
     int32_t min_pct_identity;            /* 70 = blasr --minPctIdentity 70.0 (unzip.py:87); 0 disables the gate */
     int32_t seed_anchored;               /* v1.7 (default 1): index and samples are the ANCHORED k-mers (start with AC or end with GT); 0 = v1.6's fixed strides (every 2nd contig position, every stride-th read k-mer) */
-    int32_t reserved[8];
+    int32_t band;                        /* v1.8: cells of the adaptive band, 64 or 32 (tools/runs/band32_go_nogo.py: on every test set the 32-cell band finds the same scores) */
+    int32_t reserved[7];
 } orc_align_params;
 
 typedef struct {
@@ -311,7 +313,8 @@ static int seed_candidates(const ctg_index *ix, const uint8_t *fwd, int64_t n, c
 
 /* ---- the banded extension DP from the origin cell (-1, -1) of q[0..nq) x t[0..nt): fills the masks / moves of its scratch set `sb`
  * (arrays sb, sb+1, sb+2), finds the best valid cell.  Used forward from the anchor and, on reversed sequences, backward from it. */
-typedef struct { int64_t steps; int32_t score; int64_t ts, lane; uint64_t *tbD, *tbU; uint8_t *mv; } dp_t;
+typedef struct { int64_t steps; int32_t score; int64_t ts, lane; uint64_t *tbD, *tbU; uint8_t *mv; int band; } dp_t;
+static inline int band_of(const orc_align_params *P) { return P->band == 32 ? 32 : 64; }
 /* inner (v1.6): the extension has to arrive at the sub-matrix's corner (nq-1, nt-1): a border cell is valued H - gap * (its distance to the corner) */
 static dp_t dp_extend(const uint8_t *q, int64_t nq, const uint8_t *t, int64_t nt, const orc_align_params *P, int sb, int inner) {
     dp_t R;
@@ -323,11 +326,13 @@ static dp_t dp_extend(const uint8_t *q, int64_t nq, const uint8_t *t, int64_t nt
 #define TC(j) (((j) >= 0 && (j) < nt) ? t[j] : 5)
     int32_t Hp[W], X[W], H[W], bsc[W]; int64_t bt[W];
     int qc[W], tc[W];
-    int64_t i0 = -33;
-    for (int kk = 0; kk < W; kk++) {
-        X[kk] = kk == 32 ? 0 : NEG;      /* H(-2), in the lane layout before the virtual RIGHT move of step -1 */
-        Hp[kk] = (kk == 32 || kk == 33) ? -P->gap : NEG;
-        int64_t i = kk - 33, j = 32 - kk;
+    const int Wb = band_of(P), HB = Wb / 2;      /* lanes 0 .. Wb - 1; the origin's neighbours sit in lanes HB and HB + 1 */
+    R.band = Wb;
+    int64_t i0 = -(HB + 1);
+    for (int kk = 0; kk < Wb; kk++) {
+        X[kk] = kk == HB ? 0 : NEG;      /* H(-2), in the lane layout before the virtual RIGHT move of step -1 */
+        Hp[kk] = (kk == HB || kk == HB + 1) ? -P->gap : NEG;
+        int64_t i = kk - (HB + 1), j = HB - kk;
         qc[kk] = QC(i); tc[kk] = TC(j);
         bsc[kk] = NEG; bt[kk] = -1;
     }
@@ -335,24 +340,24 @@ static dp_t dp_extend(const uint8_t *q, int64_t nq, const uint8_t *t, int64_t nt
     int prev_down = 0;                   /* move of step -1 (virtual RIGHT) */
     int64_t tt = 0;
     for (;;) {
-        int down = tt < 64 ? ((tt & 1) == 0) : steer;
+        int down = tt < Wb ? ((tt & 1) == 0) : steer;
         int32_t A[W], B[W], dg[W], Xn[W];   /* A: previous step, same lane; B: previous step, neighbour lane (both minus gap) */
         if (down) {
             i0++;
-            for (int kk = 0; kk < W - 1; kk++) qc[kk] = qc[kk + 1];
-            qc[W - 1] = QC(i0 + 63);
-            for (int kk = 0; kk < W; kk++) { A[kk] = Hp[kk] - P->gap; B[kk] = (kk < W - 1 ? Hp[kk + 1] : NEG) - P->gap; }
+            for (int kk = 0; kk < Wb - 1; kk++) qc[kk] = qc[kk + 1];
+            qc[Wb - 1] = QC(i0 + Wb - 1);
+            for (int kk = 0; kk < Wb; kk++) { A[kk] = Hp[kk] - P->gap; B[kk] = (kk < Wb - 1 ? Hp[kk + 1] : NEG) - P->gap; }
             /* X = H(t-2) in ITS lane layout; the two moves since shift the diagonal predecessor of lane kk to
              * lane kk - 1 + (#DOWN among them): DOWN,DOWN -> kk+1; one of each -> kk; RIGHT,RIGHT -> kk-1 */
-            for (int kk = 0; kk < W; kk++) { int s_ = kk + prev_down; dg[kk] = s_ < W ? X[s_] : NEG; Xn[kk] = Hp[kk]; }
+            for (int kk = 0; kk < Wb; kk++) { int s_ = kk + prev_down; dg[kk] = s_ < Wb ? X[s_] : NEG; Xn[kk] = Hp[kk]; }
         } else {
-            for (int kk = W - 1; kk > 0; kk--) tc[kk] = tc[kk - 1];
+            for (int kk = Wb - 1; kk > 0; kk--) tc[kk] = tc[kk - 1];
             tc[0] = TC(tt - i0);
-            for (int kk = 0; kk < W; kk++) { A[kk] = Hp[kk] - P->gap; B[kk] = (kk > 0 ? Hp[kk - 1] : NEG) - P->gap; }
-            for (int kk = 0; kk < W; kk++) { int s_ = kk - 1 + prev_down; dg[kk] = s_ >= 0 ? X[s_] : NEG; Xn[kk] = Hp[kk]; }
+            for (int kk = 0; kk < Wb; kk++) { A[kk] = Hp[kk] - P->gap; B[kk] = (kk > 0 ? Hp[kk - 1] : NEG) - P->gap; }
+            for (int kk = 0; kk < Wb; kk++) { int s_ = kk - 1 + prev_down; dg[kk] = s_ >= 0 ? X[s_] : NEG; Xn[kk] = Hp[kk]; }
         }
         uint64_t D = 0, U = 0;
-        for (int kk = 0; kk < W; kk++) {
+        for (int kk = 0; kk < Wb; kk++) {
             int32_t s = qc[kk] == tc[kk] ? P->match : -P->mismatch;
             int32_t hd = dg[kk] + s;
             int32_t h = hd > A[kk] ? hd : A[kk]; if (B[kk] > h) h = B[kk];
@@ -367,12 +372,12 @@ static dp_t dp_extend(const uint8_t *q, int64_t nq, const uint8_t *t, int64_t nt
             }
         }
         tbD[tt] = D; tbU[tt] = U; mv[tt] = (uint8_t)down;
-        steer = !(H[0] > H[W - 1]);
+        steer = !(H[0] > H[Wb - 1]);
         prev_down = down;
         memcpy(X, Xn, sizeof X); memcpy(Hp, H, sizeof H);
         tt++;
         if (i0 > nq - 1) break;
-        if ((tt - 1) - (i0 + 63) > nt - 1) break;
+        if ((tt - 1) - (i0 + Wb - 1) > nt - 1) break;
         if (tt >= max_steps) break;
     }
 #undef QC
@@ -380,7 +385,7 @@ static dp_t dp_extend(const uint8_t *q, int64_t nq, const uint8_t *t, int64_t nt
     R.steps = tt; R.tbD = tbD; R.tbU = tbU; R.mv = mv;
     /* terminal: max score among the valid border cells, then earliest step, then lowest lane */
     int bk = -1;
-    for (int kk = 0; kk < W; kk++) {
+    for (int kk = 0; kk < Wb; kk++) {
         if (bt[kk] < 0) continue;
         if (bk < 0 || bsc[kk] > bsc[bk] || (bsc[kk] == bsc[bk] && bt[kk] < bt[bk])) bk = kk;
     }
@@ -392,7 +397,7 @@ static dp_t dp_extend(const uint8_t *q, int64_t nq, const uint8_t *t, int64_t nt
  * the best cell; *i_stop, *j_stop = where the walk left the matrix (one of them is -1).  Scratch array `sb` holds i0 per step. */
 static int64_t dp_walk(const dp_t *R, int sb, uint8_t *ops, int64_t *i_end, int64_t *j_end, int64_t *i_stop, int64_t *j_stop) {
     int64_t *i0s = (int64_t *)scratch_get(sb, (size_t)R->steps * 8);
-    int64_t cur = -33;
+    int64_t cur = -(R->band / 2 + 1);
     for (int64_t s2 = 0; s2 < R->steps; s2++) { cur += R->mv[s2]; i0s[s2] = cur; }
     int64_t ts = R->ts;
     int64_t i = i0s[ts] + R->lane, j = ts - i, n = 0;
@@ -433,7 +438,7 @@ static path_t build_path(const ctg_index *ix, const uint8_t *r, int64_t n, const
             nt = Lc - oc; if (nt > nq + nq / 4 + 64) nt = nq + nq / 4 + 64;
         }
         const dp_t F = dp_extend(r + oi, nq, ix->codes + oc, nt, P, 0, inner);
-        R.cells += F.steps * W;
+        R.cells += F.steps * band_of(P);
         if (F.lane < 0) { R.ok = 0; R.fwd_score = NEG; break; }          /* (no valid border cell: cannot happen for nq, nt >= 1) */
         R.fwd_score += F.score;
         po = (uint8_t *)scratch_get(15, (size_t)(nq + nt + 64));
@@ -456,7 +461,7 @@ static path_t build_path(const ctg_index *ix, const uint8_t *r, int64_t n, const
         for (int64_t x = 0; x < nqb; x++) qb[x] = r[i_a - 1 - x];
         for (int64_t x = 0; x < ntb; x++) tb[x] = ix->codes[c_a - 1 - x];
         const dp_t B = dp_extend(qb, nqb, tb, ntb, P, 8, 0);
-        R.cells += B.steps * W;
+        R.cells += B.steps * band_of(P);
         if (B.lane >= 0 && R.ok) {
             R.back_score = B.score;
             po = (uint8_t *)scratch_get(15, (size_t)(nqb + ntb + 64));
@@ -602,6 +607,8 @@ void orc_align_params_default(orc_align_params *p) {
     p->min_pct_identity = 70;
     p->seed_anchored = 1;
     { const char *e = getenv("FZP_SEED_ANCHORED"); if (e) p->seed_anchored = atoi(e) != 0; }      /* (A/B runs: the same switch as the library's) */
+    p->band = ORC_DEFAULT_BAND;
+    { const char *e = getenv("FZP_ALIGN_BAND"); if (e && (atoi(e) == 32 || atoi(e) == 64)) p->band = atoi(e); }
 }
 
 /* the contig's index entries, sorted by (key, position): v1.6 every 2nd position, v1.7 the contig's selected (anchored) k-mers */
