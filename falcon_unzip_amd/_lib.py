@@ -95,7 +95,7 @@ class OvlpParams(C.Structure):
 
 class AlignParams(C.Structure):
     _fields_ = [("kmer", C.c_int32), ("seed_stride", C.c_int32), ("match", C.c_int32), ("mismatch", C.c_int32),
-                ("gap", C.c_int32), ("min_seed_hits", C.c_int32), ("min_pct_identity", C.c_int32), ("seed_anchored", C.c_int32), ("reserved", C.c_int32 * 8)]
+                ("gap", C.c_int32), ("min_seed_hits", C.c_int32), ("min_pct_identity", C.c_int32), ("seed_anchored", C.c_int32), ("band", C.c_int32), ("reserved", C.c_int32 * 7)]
 
 
 _lib = None

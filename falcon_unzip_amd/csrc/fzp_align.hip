@@ -126,6 +126,7 @@ constexpr int LONG_READ = 8192, LONG_STRIDE = 3;      // v1.6: reads of at least
 constexpr int LONG_MS = 3, SAMPLE_CAP = 8192;         // v1.7: of a long read's selected k-mers every LONG_MS-th (x 2, x 3 .. per further 131 072 bases) is looked up, SAMPLE_CAP at most
 constexpr int ANCH_DIV = 8;                           // v1.7: table slots are sized for 2 x (k-mer positions / ANCH_DIV) entries (an eighth of the positions is selected on random sequence)
 constexpr int PIECE_LEN = 3072;        // v1.6: read bases between waypoints (at least)
+constexpr int FZP_DEFAULT_BAND = 64;   // v1.8: cells of the adaptive band (fzp_align_params.band: 64 or 32; the twin's ORC_DEFAULT_BAND says the same)
 constexpr int MAX_WP = 31;             // waypoints per candidate: a read has at most 2 x (MAX_WP + 1) = 64 slots, one per lane of k_join
 __host__ __device__ __forceinline__ int32_t piece_len(int64_t n) { const int64_t p = (n + MAX_WP - 2) / (MAX_WP - 1); return (int32_t)(p > PIECE_LEN ? p : PIECE_LEN); }
 __device__ __forceinline__ uint32_t canonical(uint32_t key, int k, uint32_t *is_rc) {
@@ -693,7 +694,7 @@ __global__ void __launch_bounds__(256) k_slot_count(int64_t nr, const Anchor *__
         uint32_t k = 0, cq = 0;
         const int32_t n = read_len[r], c = read_ctg[r];
         const int64_t Lc = ctg_len[c];
-        auto tally = [&](const Slot &sl) { k++; cq += (uint32_t)(sl.cap >> 6); if (!(use_bits && sl.nq >= 64 && sl.nt >= 64 && sl.nq + sl.nt + 2 <= swb_max_steps)) { wq += (uint32_t)(sl.cap >> 6); wn++; } };
+        auto tally = [&](const Slot &sl) { k++; cq += (uint32_t)(sl.cap >> 6); if (!(use_bits && sl.nq >= use_bits && sl.nt >= use_bits && sl.nq + sl.nt + 2 <= swb_max_steps)) { wq += (uint32_t)(sl.cap >> 6); wn++; } };      // (use_bits: the band's cells when the bit-sliced kernel runs, else 0)
         cand_slots(anc[r], 0, n_wp[2 * r], wps + (size_t)(2 * r) * MAX_WP, (int32_t)r, n, c, Lc, tally);
         cand_slots(ancB[r], 1, n_wp[2 * r + 1], wps + (size_t)(2 * r + 1) * MAX_WP, (int32_t)r, n, c, Lc, tally);
         cnt[r] = k; capq[r] = cq;
@@ -746,7 +747,7 @@ __global__ void __launch_bounds__(256) k_route(uint32_t ns, const Slot *__restri
     const uint32_t x = blockIdx.x * 256 + threadIdx.x;
     if (x >= ns) return;
     const Slot sl = slots[sorted[x]];
-    fits[x] = (use_bits && sl.nq >= 64 && sl.nt >= 64 && sl.nq + sl.nt + 2 <= swb_max_steps) ? 1u : 0u;
+    fits[x] = (use_bits && sl.nq >= use_bits && sl.nt >= use_bits && sl.nq + sl.nt + 2 <= swb_max_steps) ? 1u : 0u;      // (use_bits: the band's cells, or 0)
 }
 // the launch lists: list[0, n_b) = the bit-sliced kernel's slots, list[n_b, ns) the others', both in sorted order; lq[y] = cap / 64 of list[y]; gq[g] = cap / 64 of the
 // first (longest) slot of the g-th group of 64 bit-sliced slots = what every stream of that group's interleaved region gets
@@ -876,12 +877,12 @@ __device__ __forceinline__ void scalar_store16(void *base, uint32_t byte_off, ui
         bs = upd ? val : bs;                                                                               \
         bt = upd ? t : bt;                                                                                 \
         mvacc |= (uint64_t)(down ? 1 : 0) << (t & 63);                                                     \
-        const int32_t top = __builtin_amdgcn_readlane(Hn, 0), bot = __builtin_amdgcn_readlane(Hn, 63);     \
+        const int32_t top = __builtin_amdgcn_readlane(Hn, 0), bot = __builtin_amdgcn_readlane(Hn, BAND - 1); \
         X = H;            /* H(t-2) stays in its own lane layout: the next step shifts it as its two moves say */ \
         H = Hn;                                                                                            \
         pdown = down;                                                                                      \
         t++;                                                                                               \
-        down = t < 64 ? ((t & 1) == 0) : !(top > bot);                                                     \
+        down = t < BAND ? ((t & 1) == 0) : !(top > bot);                                                   \
     }
 
 // after step t-1 completed a 64-step chunk (or at the very end): the chunk's move record
@@ -911,13 +912,13 @@ __device__ __forceinline__ void scalar_store16(void *base, uint32_t byte_off, ui
 // one DOWN step.  HC: operand holding H of the previous step; XC: operand holding H of two steps ago, receives the new H;
 // HDADD: the add that forms the diagonal operand (shifted by what the last two moves say); NP: parity after this step;
 // the step ends by jumping to the variant (NP, previous = DOWN, next move) or to the exit of parity NP.
-#define SWB_DOWN(LBL, HC, XC, HDADD, NP, KB, ST)                                                       \
+#define SWB_DOWN(LBL, HC, XC, HDADD, NP, KB, ST, LN)                                                   \
     "Lsw%=_" LBL ":\n\t"                                                                          \
     "s_bfe_u64 s[56:57], %[qb], %[qsel]\n\t"                                                      \
     "v_mov_b32_dpp %[qc], %[qc] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"                        \
     "s_add_u32 %[qsel], %[qsel], 2\n\t"                                                           \
     "v_max_i32_dpp %[mm], " HC ", " HC SWB_DPP_SHL "\n\t"                                         \
-    "v_writelane_b32 %[qc], s56, 63\n\t"                                                          \
+    "v_writelane_b32 %[qc], s56, " LN "\n\t"                                                      \
     "v_cmp_eq_i32_e64 s[62:63], %[mm], " HC "\n\t"                                                \
     "v_cmp_eq_u32_e32 vcc, %[qc], %[tc]\n\t"                                                      \
     "v_cndmask_b32_e32 %[sc], %[vmis], %[vmat], vcc\n\t"                                          \
@@ -929,13 +930,13 @@ __device__ __forceinline__ void scalar_store16(void *base, uint32_t byte_off, ui
     KB                                                      \
     "v_readlane_b32 %[top], " XC ", 0\n\t"                                                        \
     ST                                                                                            \
-    "v_readlane_b32 %[bot], " XC ", 63\n\t"                                                       \
+    "v_readlane_b32 %[bot], " XC ", " LN "\n\t"                                                   \
     "s_addk_i32 %[soff], 16\n\t"                                                                  \
     "s_cbranch_scc1 Lsw%=_end" NP "\n\t"                                                          \
     "s_cmp_gt_i32 %[top], %[bot]\n\t"                                                             \
     "s_cbranch_scc1 Lsw%=_p" NP "DR\n\t"                                                          \
     "s_branch Lsw%=_p" NP "DD\n"
-#define SWB_RIGHT(LBL, HC, XC, HDADD, NP, KB, ST)                                                       \
+#define SWB_RIGHT(LBL, HC, XC, HDADD, NP, KB, ST, LN)                                                   \
     "Lsw%=_" LBL ":\n\t"                                                                          \
     "s_bfe_u64 s[56:57], %[tb], %[tsel]\n\t"                                                      \
     "v_mov_b32_dpp %[tc], %[tc] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"                        \
@@ -953,7 +954,7 @@ __device__ __forceinline__ void scalar_store16(void *base, uint32_t byte_off, ui
     KB                                                      \
     "v_readlane_b32 %[top], " XC ", 0\n\t"                                                        \
     ST                                                                                            \
-    "v_readlane_b32 %[bot], " XC ", 63\n\t"                                                       \
+    "v_readlane_b32 %[bot], " XC ", " LN "\n\t"                                                   \
     "s_addk_i32 %[soff], 16\n\t"                                                                  \
     "s_cbranch_scc1 Lsw%=_end" NP "\n\t"                                                          \
     "s_cmp_gt_i32 %[top], %[bot]\n\t"                                                             \
@@ -961,7 +962,7 @@ __device__ __forceinline__ void scalar_store16(void *base, uint32_t byte_off, ui
     "s_branch Lsw%=_p" NP "RD\n"
 // label "pPab": parity P (0: H in %[H], X in %[X]; 1: swapped), a = previous move, b = this move
 // the diagonal predecessor of lane k is lane k - 1 + (DOWN moves among the last two) of H(t-2)
-#define SW_BLOCK_ASM(ST)                                                                            \
+#define SW_BLOCK_ASM(ST, LN)                                                                        \
     asm volatile(                                                                                                                                                                   \
         "s_nop 1\n\t"                                                                                                                                                               \
         "s_cmp_eq_u32 %[dn], 0\n\t"                                                                                                                                                 \
@@ -974,14 +975,14 @@ __device__ __forceinline__ void scalar_store16(void *base, uint32_t byte_off, ui
         "s_cbranch_scc1 Lsw%=_p0RR\n\t"                                                                                                                                             \
         "s_branch Lsw%=_p0DR\n"                                                                                                                                                     \
                                                                                                                                                                                     \
-        SWB_DOWN("p0DD", "%[H]", "%[X]", "v_add_u32_dpp %[hd], %[X], %[sc]" SWB_DPP_SHL, "1", "", ST)                                                                               \
-        SWB_DOWN("p0RD", "%[H]", "%[X]", "v_add_u32_e32 %[hd], %[X], %[sc]", "1", "", ST)                                                                                           \
-        SWB_RIGHT("p0DR", "%[H]", "%[X]", "v_add_u32_e32 %[hd], %[X], %[sc]", "1", "", ST)                                                                                          \
-        SWB_RIGHT("p0RR", "%[H]", "%[X]", "v_add_u32_dpp %[hd], %[X], %[sc]" SWB_DPP_SHR, "1", "", ST)                                                                              \
-        SWB_DOWN("p1DD", "%[X]", "%[H]", "v_add_u32_dpp %[hd], %[H], %[sc]" SWB_DPP_SHL, "0", "", ST)                                        \
-        SWB_DOWN("p1RD", "%[X]", "%[H]", "v_add_u32_e32 %[hd], %[H], %[sc]", "0", "", ST)                                                    \
-        SWB_RIGHT("p1DR", "%[X]", "%[H]", "v_add_u32_e32 %[hd], %[H], %[sc]", "0", "", ST)                                                   \
-        SWB_RIGHT("p1RR", "%[X]", "%[H]", "v_add_u32_dpp %[hd], %[H], %[sc]" SWB_DPP_SHR, "0", "", ST)                                       \
+        SWB_DOWN("p0DD", "%[H]", "%[X]", "v_add_u32_dpp %[hd], %[X], %[sc]" SWB_DPP_SHL, "1", "", ST, LN)                                                                               \
+        SWB_DOWN("p0RD", "%[H]", "%[X]", "v_add_u32_e32 %[hd], %[X], %[sc]", "1", "", ST, LN)                                                                                           \
+        SWB_RIGHT("p0DR", "%[H]", "%[X]", "v_add_u32_e32 %[hd], %[X], %[sc]", "1", "", ST, LN)                                                                                          \
+        SWB_RIGHT("p0RR", "%[H]", "%[X]", "v_add_u32_dpp %[hd], %[X], %[sc]" SWB_DPP_SHR, "1", "", ST, LN)                                                                              \
+        SWB_DOWN("p1DD", "%[X]", "%[H]", "v_add_u32_dpp %[hd], %[H], %[sc]" SWB_DPP_SHL, "0", "", ST, LN)                                        \
+        SWB_DOWN("p1RD", "%[X]", "%[H]", "v_add_u32_e32 %[hd], %[H], %[sc]", "0", "", ST, LN)                                                    \
+        SWB_RIGHT("p1DR", "%[X]", "%[H]", "v_add_u32_e32 %[hd], %[H], %[sc]", "0", "", ST, LN)                                                   \
+        SWB_RIGHT("p1RR", "%[X]", "%[H]", "v_add_u32_dpp %[hd], %[H], %[sc]" SWB_DPP_SHR, "0", "", ST, LN)                                       \
         "Lsw%=_end1:\n\t"                                                                                                                                                           \
         "v_swap_b32 %[H], %[X]\n"                                                                                                                                                   \
         "Lsw%=_end0:\n\t"                                                                                                                                                           \
@@ -992,13 +993,16 @@ __device__ __forceinline__ void scalar_store16(void *base, uint32_t byte_off, ui
         : [gap] "s"(gapS), [vmat] "v"(vmatS), [vmis] "v"(vmisS), [qb] "s"(qbits), [tb] "s"(tbits), [tbp] "s"(tbp)                                                                   \
         : "vcc", "scc", "s56", "s57", "s60", "s61", "s62", "s63", "memory");
 #define SWB_STORE "s_store_dwordx4 s[60:63], %[tbp], %[soff]\n\t"
-template <bool STORE>
+template <bool STORE, int BAND>
 __device__ __forceinline__ void sw_block(int32_t &H, int32_t &X, int32_t &qc, int32_t &tc, const uint64_t qbits, const uint64_t tbits, int32_t &kb,
                                          void *tbp, uint32_t &soff, uint32_t &mv, int32_t &dn, int32_t &pm, const int32_t gapS,
                                          const int32_t vmatS, const int32_t vmisS) {
     int32_t hd, mm, sc, top, bot;
     uint32_t qsel = 2u << 16, tsel = 2u << 16;   // s_bfe_u64 operand: width 2, offset 0
-    if constexpr (STORE) { SW_BLOCK_ASM(SWB_STORE) } else { SW_BLOCK_ASM("") }     // the variant without mask stores exists for one measurement (FZP_SW_NO_MASKS)
+    // (the band's last lane enters the asm as a literal: 63, or 31 in the 32-cell band of v1.8 -- there lanes 32..63 of the wave are switched off, and what a DPP shift
+    //  would fetch from them reads as zero, which in the biased scores IS "outside the band")
+    if constexpr (BAND == 64) { if constexpr (STORE) { SW_BLOCK_ASM(SWB_STORE, "63") } else { SW_BLOCK_ASM("", "63") } }
+    else { if constexpr (STORE) { SW_BLOCK_ASM(SWB_STORE, "31") } else { SW_BLOCK_ASM("", "31") } }
 }
 #undef SW_BLOCK_ASM
 #undef SWB_DOWN
@@ -1016,7 +1020,7 @@ __device__ __forceinline__ uint64_t base_window(const uint32_t *__restrict__ pk,
     return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)v);
 }
 
-template <bool STORE>
+template <bool STORE, int BAND>
 __global__ void __launch_bounds__(64) k_sw(const uint64_t *__restrict__ lo_dev, const uint64_t *__restrict__ hi_dev, uint32_t hi_host, const uint32_t *__restrict__ list, const Slot *__restrict__ slots,
                                             const uint32_t *__restrict__ read_pk, const uint32_t *__restrict__ read_rc, const int64_t *__restrict__ read_woff,
                                             const uint32_t *__restrict__ ctg_pk, const uint32_t *__restrict__ ctg_rc, const int64_t *__restrict__ ctg_woff,
@@ -1040,33 +1044,37 @@ __global__ void __launch_bounds__(64) k_sw(const uint64_t *__restrict__ lo_dev, 
     const uint32_t *tpk = ((S.flags & SLOT_TRC) ? ctg_rc : ctg_pk) + ctg_woff[S.ctg];
     const int64_t qb = S.qb, tbase = S.tb;
     const int32_t max_steps = nq + nt + 2;
+    // v1.8: the band is 64 or 32 cells.  With 32 the wave's upper half is switched off for good: every lane shift below then finds "no lane" (DPP: the fill value /
+    // zero) where the band ends, ballots come back with their upper halves clear, and the lane reads and writes name lane BAND - 1.
+    constexpr int HB = BAND / 2;
+    if (BAND == 32 && lane >= 32) return;
 
     // state before step 0 (biased): H(-1), and X = H(-2) in the lane layout it was computed in
-    int32_t H = (lane == 32 || lane == 33) ? SW_BIAS - gap : 0;
-    int32_t X = lane == 32 ? SW_BIAS : 0;
+    int32_t H = (lane == HB || lane == HB + 1) ? SW_BIAS - gap : 0;
+    int32_t X = lane == HB ? SW_BIAS : 0;
     bool pdown = false;                                // move of the (virtual) step -1: RIGHT
     int32_t qc, tc;
     {
-        int32_t i = lane - 33, j = 32 - lane;
+        int32_t i = lane - (HB + 1), j = HB - lane;
         qc = (i >= 0 && i < nq) ? (int32_t)base_at(qpk, qb + i) : 4;
         tc = (j >= 0 && j < nt) ? (int32_t)base_at(tpk, tbase + j) : 5;
     }
     int32_t bs = 0, bt = -1;
-    int32_t i0 = -33, t = 0, qpos = 31, tpos = 33;
+    int32_t i0 = -(HB + 1), t = 0, qpos = HB - 1, tpos = HB + 1;
     uint64_t mvacc = 0;
     bool down = true;
     BaseStream qs, ts;
-    qs.init(qpk, qb + 31);
-    ts.init(tpk, tbase + 33);
+    qs.init(qpk, qb + (HB - 1));
+    ts.init(tpk, tbase + (HB + 1));
     bool done = false;
     while (!done) {
         t = __builtin_amdgcn_readfirstlane(t); i0 = __builtin_amdgcn_readfirstlane(i0);
         // how many steps can run with every lane strictly inside the matrix?  Each step advances i0 or
         // lane 0's column by one, so min(rows left, columns left) steps are safe once the band is inside.
-        int32_t safe = swb::sw_interior_safe(t, i0, nq, nt);      // (fzp_swb_core.h: shared with the host test that pins it)
+        int32_t safe = swb::sw_interior_safe(t, i0, nq, nt, BAND);      // (fzp_swb_core.h: shared with the host test that pins it)
         if (safe > 0) {
             // ---- interior: asm blocks of <= 32 steps
-            int32_t qpos_i = i0 + 64, tpos_i = t - i0;                 // next bases to enter at lane 63 / lane 0
+            int32_t qpos_i = i0 + BAND, tpos_i = t - i0;               // next bases to enter at the band's last lane / lane 0
             const int32_t vmatS = match, vmisS = -mismatch;
             const int32_t gapS = __builtin_amdgcn_readfirstlane(gap);
             int32_t dn = down ? 1 : 0;
@@ -1086,7 +1094,7 @@ __global__ void __launch_bounds__(64) k_sw(const uint64_t *__restrict__ lo_dev, 
                 uint32_t soff = 0x80000000u - 16u * (uint32_t)n_steps;
                 const int32_t t_ = __builtin_amdgcn_readfirstlane(t);      // (a block never crosses a multiple of 32 steps: its records are contiguous)
                 void *tbp = (void *)((char *)tbr + (((int64_t)(t_ >> 6) * stride + (t_ & 63)) * 16 - (int64_t)soff));
-                sw_block<STORE>(H, X, qc, tc, qbits, tbits, kb, tbp, soff, mv, dn, pm, gapS, vmatS, vmisS);
+                sw_block<STORE, BAND>(H, X, qc, tc, qbits, tbits, kb, tbp, soff, mv, dn, pm, gapS, vmatS, vmisS);
                 // (v1.5: no cell of an interior block is a border cell, so the block has no terminal candidates to report)
                 pm = (int32_t)(mv & 1u);                                 // the block's last move (the steps no longer keep it up to date)
                 const int32_t nd = __popc(mv);                          // DOWN moves of the block (mv holds exactly n_steps bits)
@@ -1099,13 +1107,13 @@ __global__ void __launch_bounds__(64) k_sw(const uint64_t *__restrict__ lo_dev, 
             down = dn != 0;
             pdown = pm != 0;
             // back to the checked variant: scalar base streams resume at the current positions
-            qpos = i0 + 64; tpos = t - i0;
+            qpos = i0 + BAND; tpos = t - i0;
             qs.init(qpk, qb + qpos);
             ts.init(tpk, tbase + tpos);
         } else {
             SW_STEP()
             if ((t & 63) == 0) SW_FLUSH(false)
-            if (i0 > nq - 1 || (t - 1) - (i0 + 63) > nt - 1 || t >= max_steps) done = true;
+            if (i0 > nq - 1 || (t - 1) - (i0 + BAND - 1) > nt - 1 || t >= max_steps) done = true;
         }
     }
     if ((t & 63) != 0) SW_FLUSH(true)
@@ -1113,7 +1121,7 @@ __global__ void __launch_bounds__(64) k_sw(const uint64_t *__restrict__ lo_dev, 
     // best cell: max score, then earliest step, then lowest lane
     int32_t s_b = bs, t_b = bt < 0 ? 0x7fffffff : bt, l_b = lane;
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
+    for (int d = BAND / 2; d >= 1; d >>= 1) {      // (over the band's lanes: the switched-off half of a 32-cell band has nothing to say)
         int32_t so = __shfl_xor(s_b, d, 64), to = __shfl_xor(t_b, d, 64), lo = __shfl_xor(l_b, d, 64);
         bool take = so > s_b || (so == s_b && (to < t_b || (to == t_b && lo < l_b)));
         if (take) { s_b = so; t_b = to; l_b = lo; }
@@ -1232,10 +1240,10 @@ struct LaneStreamL {
     __device__ __forceinline__ void drop(uint32_t en) { cur >>= 2u * en; }           // en = 1: that base is taken
 };
 
-template <class STREAM>
-struct SwbLaneT {                  // one extension's state (a lane's registers)
-    swb::Planes P, Q;              // difference planes of the previous anti-diagonal
-    uint64_t R0, R1, C0, C1;       // base windows as bit planes: bit k = read base i0 + k / contig base t - i0 - k
+template <class STREAM, class BW = uint64_t>
+struct SwbLaneT {                  // one extension's state (a lane's registers); BW: a word as wide as the band (v1.8: 64 or 32 cells)
+    swb::PlanesT<BW> P, Q;         // difference planes of the previous anti-diagonal
+    BW R0, R1, C0, C1;             // base windows as bit planes: bit k = read base i0 + k / contig base t - i0 - k
     STREAM qs, ts;
     int32_t i0, E2, sv0;           // E2 = (score of lane 63's cell - score of lane 0's) / 2;  sv0 = sum of lane 0's difference codes: its score is -259 + 2 sv0 - 3 (t + 1)
     uint32_t down, pdown;
@@ -1245,6 +1253,59 @@ struct SwbLaneT {                  // one extension's state (a lane's registers)
 // one DP step of every lane's extension.  CHECKED = false: the 64 steps of an interior block -- no lane of the wave can reach a border of its matrix in them, so
 // there is nothing to validate, no terminal candidate and no end; lanes whose extension is over run along on their stale state (nothing of theirs is stored).
 // CHECKED = true: validity of the bases near the ends, terminal candidates, the end of the extension.
+// ---- the same step on a band of 32 cells (fzalign v1.8): every plane and window ONE register, the record the WHOLE masks.  Everything else as in swb_step below (the
+// comments there): with lane W - 1 = 31 for 63, the border's closed form S(lane 0) = -3 - 8 * 16 = -131 for -259.
+template <bool CHECKED, class LANE>
+__device__ __forceinline__ void swb_step32(LANE &L, const int32_t t, const int s8, uint32_t &mv8, uint2 &rec, const int32_t nq, const int32_t nt, const int32_t max_steps, const bool inner, bool &active,
+                                           bool &row_on, bool &col_on, int32_t &Hrow, int32_t &Hcol, int32_t &best, int32_t &bt, int32_t &bl, int32_t &steps) {
+    using namespace swb;
+    const uint32_t sd = L.down, sr = 1u - sd;
+    L.i0 += (int32_t)sd;
+    {
+        const uint32_t wq = L.qs.peek(), wt = L.ts.peek();
+        L.R0 = __builtin_amdgcn_alignbit(wq, L.R0, sd);
+        L.R1 = __builtin_amdgcn_alignbit(wq >> 1, L.R1, sd);
+        L.C0 = (L.C0 << sr) | (wt & sr); L.C1 = (L.C1 << sr) | ((wt >> 1) & sr);
+        L.qs.drop(sd); L.ts.drop(sr);
+    }
+    const Planes32 p = {L.P.v0 << sr, L.P.v1 << sr, L.P.v2 << sr}, q = {L.Q.v0 >> sd, L.Q.v1 >> sd, L.Q.v2 >> sd};
+    uint32_t xm = lut3<(uint8_t)((TA ^ TB) | TC)>(L.R0, L.C0, L.R1 ^ L.C1);
+    const int32_t kr = nq - 1 - L.i0, kc = t - (nt - 1) - L.i0;      // lanes of the last row / the last column
+    if (CHECKED) {
+        const int32_t nv = kr + 1;
+        const uint32_t bad_r = nv >= 32 ? 0u : (nv <= 0 ? ~0u : ~0u << nv);
+        const uint32_t bad_c = kc <= 0 ? 0u : (kc >= 32 ? ~0u : ~(~0u << kc));
+        xm |= bad_r | bad_c;
+    }
+    const uint32_t f = ((sd & L.pdown) << 31) | lut3<(uint8_t)(TA & ~TB)>(sr, L.pdown, 0u);
+    uint32_t D, G;
+    cells<uint32_t>(xm, f, 0u - sd, p, q, &L.P, &L.Q, &D, &G);
+    rec = make_uint2(D, G);                                          // the whole band
+    mv8 |= sd << s8;
+    constexpr uint8_t SEL = (uint8_t)((TA & TB) | (~TA & TC));
+    const uint32_t dm = 0u - sd;
+    const uint32_t x0 = lut3<SEL>(dm, L.Q.v0, L.P.v0), x1 = lut3<SEL>(dm, L.Q.v1, L.P.v1), x2 = lut3<SEL>(dm, L.Q.v2, L.P.v2);
+    const int32_t v0 = (int32_t)(lut3<SEL>(3u, lut3<SEL>(1u, x0, x1 << 1), x2 << 2) & 7u);
+    const int32_t v31 = (int32_t)lut3<SEL>(3u, lut3<SEL>(1u, x0 >> 31, x1 >> 30), x2 >> 29);
+    L.sv0 += v0;
+    L.E2 += v31 - v0;
+    if (CHECKED) {
+        if (active) {
+            const int32_t S0 = -131 + 2 * L.sv0 - 3 * (t + 1);
+            const bool kc_in = kc >= 0 && kc <= 31, kr_in = kr >= 0 && kr <= 31;
+            const bool col_start = !col_on && sr && kc == 0, row_start = !row_on && sd && kr == 31;
+            if (col_start) Hcol = S0; else if (col_on && kc_in) Hcol += 2 * value_at(L.Q, kc & 31) - 3;
+            if (row_start) Hrow = S0 + 2 * L.E2; else if (row_on && kr_in) Hrow += 2 * value_at(L.P, kr & 31) - 3;
+            col_on = col_on || col_start; row_on = row_on || row_start;
+            { const int32_t i = L.i0 + kc, vc = inner ? Hcol - 3 * (nq - 1 - i) : Hcol; if (col_on && kc_in && i >= 0 && i < nq && vc > best) { best = vc; bt = t; bl = kc; } }
+            { const int32_t jj = t - (nq - 1), vr = inner ? Hrow - 3 * (nt - 1 - jj) : Hrow; if (row_on && kr_in && jj >= 0 && jj < nt && vr > best) { best = vr; bt = t; bl = kr; } }
+            if (L.i0 > nq - 1 || t - (L.i0 + 31) > nt - 1 || t + 1 >= max_steps) { active = false; steps = t + 1; }
+        }
+    }
+    L.pdown = sd;
+    L.down = (CHECKED && (t + 1) < 32) ? (uint32_t)(((t + 1) & 1) == 0) : ((uint32_t)L.E2 >> 31) ^ 1u;
+}
+
 template <bool CHECKED, class LANE>
 __device__ __forceinline__ void swb_step(LANE &L, const int32_t t, const int s8, uint32_t &mv8, uint2 &rec, const int32_t nq, const int32_t nt, const int32_t max_steps, const bool inner, bool &active,
                                          bool &row_on, bool &col_on, int32_t &Hrow, int32_t &Hcol, int32_t &best, int32_t &bt, int32_t &bl, int32_t &steps) {
@@ -1389,7 +1450,7 @@ __device__ __forceinline__ uint32_t swb_claim(const SwbUnitPlan *__restrict__ pl
 }
 
 // RING: the base streams through rings in LDS (LaneStreamL) or straight from HBM (LaneStream; FZP_SWB_NO_RING, for comparisons)
-template <bool RING, int RINGW, int HOLDW, int GRP, int WPS>
+template <bool RING, int RINGW, int HOLDW, int GRP, int WPS, int BAND = 64>
 __global__ void __attribute__((amdgpu_waves_per_eu(WPS))) __launch_bounds__(256)
 k_swb(const uint64_t *__restrict__ n_b_dev, const uint32_t *__restrict__ list, const Slot *__restrict__ slots,
       const uint32_t *__restrict__ read_pk, const uint32_t *__restrict__ read_rc, const int64_t *__restrict__ read_woff,
@@ -1441,25 +1502,28 @@ k_swb(const uint64_t *__restrict__ n_b_dev, const uint32_t *__restrict__ list, c
     const int64_t qb = S.qb, tbase = S.tb;
     const int32_t max_steps = nq + nt + 2;
     const uint32_t qlim = (uint32_t)((qb + nq + 15) >> 4) + 1u, tlim = (uint32_t)((tbase + nt + 15) >> 4) + 1u;
-    SwbLaneT<typename std::conditional<RING, StreamL, LaneStream>::type> L;
+    typedef typename std::conditional<BAND == 64, uint64_t, uint32_t>::type BW;      // a word as wide as the band
+    constexpr int HB = BAND / 2;
+    SwbLaneT<typename std::conditional<RING, StreamL, LaneStream>::type, BW> L;
     bool row_on = false, col_on = false;
     int32_t Hrow = 0, Hcol = 0, best = NEGV, bt = -1, bl = 0, steps = 0;
     int32_t t = 0;                                            // wave-uniform
     uint32_t *const ust = ustate + (size_t)grp * (SWB_STATE_WORDS * 64) + threadIdx.x;      // the group's state while it is parked: word w of lane x at [w * 64 + x]
     if (fresh) {
-        // step -1: the anti-diagonal i + j = -1 of the virtual border, lane k = cell (k - 33, 32 - k): Pv = 0 where j >= 0 (k <= 32) else 4, Qv = 0 where i >= 0 (k >= 33) else 4
-        L.P = {0, 0, ~0ull << 33}; L.Q = {0, 0, (1ull << 33) - 1};
+        // step -1: the anti-diagonal i + j = -1 of the virtual border, lane k = cell (k - HB - 1, HB - k) (HB = 32: (k - 33, 32 - k)): Pv = 0 where j >= 0 (k <= HB) else 4,
+        // Qv = 0 where i >= 0 (k > HB) else 4
+        L.P = {0, 0, (BW)(~(BW)0 << (HB + 1))}; L.Q = {0, 0, (BW)(((BW)1 << (HB + 1)) - 1)};
         L.R0 = L.R1 = L.C0 = L.C1 = 0;
-        for (int k = 33; k < 64; k++) { const uint32_t c = base_at(qpk, qb + (k - 33)); L.R0 |= (uint64_t)(c & 1u) << k; L.R1 |= (uint64_t)(c >> 1) << k; }
-        for (int k = 0; k <= 32; k++) { const uint32_t c = base_at(tpk, tbase + (32 - k)); L.C0 |= (uint64_t)(c & 1u) << k; L.C1 |= (uint64_t)(c >> 1) << k; }
-        L.i0 = -33; L.E2 = 8; L.sv0 = 0;                            // at step -1 from the border's closed form: lane 0's cell scores -259, lane 63's -243
+        for (int k = HB + 1; k < BAND; k++) { const uint32_t c = base_at(qpk, qb + (k - HB - 1)); L.R0 |= (BW)(c & 1u) << k; L.R1 |= (BW)(c >> 1) << k; }
+        for (int k = 0; k <= HB; k++) { const uint32_t c = base_at(tpk, tbase + (HB - k)); L.C0 |= (BW)(c & 1u) << k; L.C1 |= (BW)(c >> 1) << k; }
+        L.i0 = -(HB + 1); L.E2 = 8; L.sv0 = 0;                      // at step -1 from the border's closed form: lane 0's cell scores -3 - 8 HB (-259 / -131), the last lane's 16 more
         L.down = 1; L.pdown = 0;
     } else {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");      // (orders the compiler: no instruction)
         auto ld = [&](int w) { return __hip_atomic_load(ust + w * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
         auto ld64 = [&](int w) { return (uint64_t)ld(w) | ((uint64_t)ld(w + 1) << 32); };
-        L.P = {ld64(0), ld64(2), ld64(4)}; L.Q = {ld64(6), ld64(8), ld64(10)};
-        L.R0 = ld64(12); L.R1 = ld64(14); L.C0 = ld64(16); L.C1 = ld64(18);
+        L.P = {(BW)ld64(0), (BW)ld64(2), (BW)ld64(4)}; L.Q = {(BW)ld64(6), (BW)ld64(8), (BW)ld64(10)};      // (a 32-cell band leaves the slots' upper words unused)
+        L.R0 = (BW)ld64(12); L.R1 = (BW)ld64(14); L.C0 = (BW)ld64(16); L.C1 = (BW)ld64(18);
         L.i0 = (int32_t)ld(20); L.E2 = (int32_t)ld(21); L.sv0 = (int32_t)ld(22);
         const uint32_t fl = ld(23);
         L.down = fl & 1u; L.pdown = (fl >> 1) & 1u; active = (fl & 4u) != 0; row_on = (fl & 8u) != 0; col_on = (fl & 16u) != 0;
@@ -1467,12 +1531,12 @@ k_swb(const uint64_t *__restrict__ n_b_dev, const uint32_t *__restrict__ list, c
         t = (int32_t)__builtin_amdgcn_readfirstlane((int32_t)ld(30));
     }
     const int32_t t_first = t;
-    // the streams: the next read base to enter is i0 + 64 of the piece (31 at the start), the next contig base t - i0 (33 at the start)
+    // the streams: the next read base to enter is i0 + BAND of the piece (HB - 1 at the start), the next contig base t - i0 (HB + 1 at the start)
     if constexpr (RING) {
-        L.qs.init(qpk, qb + L.i0 + 64, qlim, srng + threadIdx.x);
+        L.qs.init(qpk, qb + L.i0 + BAND, qlim, srng + threadIdx.x);
         L.ts.init(tpk, tbase + t - L.i0, tlim, srng + RINGW * 64 + threadIdx.x);
     } else {
-        L.qs.init(qpk, qb + L.i0 + 64, qlim);
+        L.qs.init(qpk, qb + L.i0 + BAND, qlim);
         L.ts.init(tpk, tbase + t - L.i0, tlim);
     }
     int32_t i0_ref = L.i0;                                    // i0 when the streams were last topped up
@@ -1484,7 +1548,7 @@ k_swb(const uint64_t *__restrict__ n_b_dev, const uint32_t *__restrict__ list, c
         L.mvacc = 0;
         if (dbg & 4) { if ((((uint32_t)__builtin_amdgcn_s_memrealtime() >> 11) ^ wid) & 1u) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
         // an interior block?  every running lane more than 64 steps away from its last row and its last column (a step brings either one closer by at most one)
-        const bool far = !active || (nq - 1 - (L.i0 + 63) > 64 && nt - 1 - (t - L.i0) > 64);
+        const bool far = !active || (nq - 1 - (L.i0 + BAND - 1) > 64 && nt - 1 - (t - L.i0) > 64);
         const bool interior = t >= 64 && __ballot(!far) == 0ull;
         if constexpr (RING) { if ((t & (StreamL::BULK_STEPS - 1)) == 0 && t > 0) { L.qs.bulk(); L.ts.bulk(); } }
         for (int g8 = 0; g8 < 64 / GRP; g8++) {
@@ -1493,10 +1557,18 @@ k_swb(const uint64_t *__restrict__ n_b_dev, const uint32_t *__restrict__ list, c
             uint32_t mv8 = 0;
             if (interior) {
 #pragma unroll
-                for (int s8 = 0; s8 < GRP; s8++) { swb_step<false>(L, t, s8, mv8, rec[s8], nq, nt, max_steps, inner, active, row_on, col_on, Hrow, Hcol, best, bt, bl, steps); t++; }
+                for (int s8 = 0; s8 < GRP; s8++) {
+                    if constexpr (BAND == 64) swb_step<false>(L, t, s8, mv8, rec[s8], nq, nt, max_steps, inner, active, row_on, col_on, Hrow, Hcol, best, bt, bl, steps);
+                    else swb_step32<false>(L, t, s8, mv8, rec[s8], nq, nt, max_steps, inner, active, row_on, col_on, Hrow, Hcol, best, bt, bl, steps);
+                    t++;
+                }
             } else {
 #pragma unroll
-                for (int s8 = 0; s8 < GRP; s8++) { swb_step<true>(L, t, s8, mv8, rec[s8], nq, nt, max_steps, inner, active, row_on, col_on, Hrow, Hcol, best, bt, bl, steps); t++; }
+                for (int s8 = 0; s8 < GRP; s8++) {
+                    if constexpr (BAND == 64) swb_step<true>(L, t, s8, mv8, rec[s8], nq, nt, max_steps, inner, active, row_on, col_on, Hrow, Hcol, best, bt, bl, steps);
+                    else swb_step32<true>(L, t, s8, mv8, rec[s8], nq, nt, max_steps, inner, active, row_on, col_on, Hrow, Hcol, best, bt, bl, steps);
+                    t++;
+                }
             }
             L.mvacc |= (uint64_t)mv8 << ((t - GRP) & 63);
             // the streams top up every 16 steps, and they do it HERE, ahead of a group's stores: taking the word loaded 16 steps ago means waiting on the vector-memory
@@ -1527,8 +1599,8 @@ k_swb(const uint64_t *__restrict__ n_b_dev, const uint32_t *__restrict__ list, c
         {   // park this group at its level
             auto sv = [&](int w, uint32_t v) { __hip_atomic_store(ust + w * 64, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
             auto sv64 = [&](int w, uint64_t v) { sv(w, (uint32_t)v); sv(w + 1, (uint32_t)(v >> 32)); };
-            sv64(0, L.P.v0); sv64(2, L.P.v1); sv64(4, L.P.v2); sv64(6, L.Q.v0); sv64(8, L.Q.v1); sv64(10, L.Q.v2);
-            sv64(12, L.R0); sv64(14, L.R1); sv64(16, L.C0); sv64(18, L.C1);
+            sv64(0, (uint64_t)L.P.v0); sv64(2, (uint64_t)L.P.v1); sv64(4, (uint64_t)L.P.v2); sv64(6, (uint64_t)L.Q.v0); sv64(8, (uint64_t)L.Q.v1); sv64(10, (uint64_t)L.Q.v2);
+            sv64(12, (uint64_t)L.R0); sv64(14, (uint64_t)L.R1); sv64(16, (uint64_t)L.C0); sv64(18, (uint64_t)L.C1);
             sv(20, (uint32_t)L.i0); sv(21, (uint32_t)L.E2); sv(22, (uint32_t)L.sv0);
             sv(23, L.down | (L.pdown << 1) | (active ? 4u : 0u) | (row_on ? 8u : 0u) | (col_on ? 16u : 0u));
             sv(24, (uint32_t)Hrow); sv(25, (uint32_t)Hcol); sv(26, (uint32_t)best); sv(27, (uint32_t)bt); sv(28, (uint32_t)bl); sv(29, (uint32_t)steps); sv(30, (uint32_t)t);
@@ -1725,7 +1797,7 @@ __global__ void __launch_bounds__(64 * TBW_WPG) k_tb_walk(const uint32_t *__rest
                                                 const DpInfo *__restrict__ info, const int64_t *__restrict__ tbo, const int64_t *__restrict__ mvo, const int32_t *__restrict__ tbs,
                                                 const void *__restrict__ tb_, const ulonglong2 *__restrict__ mvw, uint32_t *__restrict__ raw,
                                                 WalkOut *__restrict__ wout, unsigned long long *__restrict__ stats, uint32_t *__restrict__ fail_list, uint64_t *__restrict__ n_fail,
-                                                uint32_t fail_cap, int32_t win_half) {
+                                                uint32_t fail_cap, int32_t win_half, int32_t band) {
     // TBW_WPG independent waves per workgroup: every wave has its own slice of the LDS buffer and never waits for another
     __shared__ __attribute__((aligned(16))) uint8_t lds_all[TBW_WPG * TBW_RPW * TBW_STRIDE];
     uint8_t *lds = lds_all + (threadIdx.x >> 6) * (TBW_RPW * TBW_STRIDE);
@@ -1759,17 +1831,19 @@ __global__ void __launch_bounds__(64 * TBW_WPG) k_tb_walk(const uint32_t *__rest
     active = active && i >= 0 && ts - i >= 0;
     const bool walked = active;
     bool failed = false;
-    const int32_t wlo = 32 - win_half;                                       // FULL = false: the path may use band lanes [wlo, wlo + 2 win_half) (16..47; tests narrow it)
+    // v1.8: the band has 64 or 32 cells; the 8-byte records hold lanes rec_lo .. rec_lo + 31 of it -- the middle of a 64-cell band, the whole of a 32-cell one
+    const int32_t rec_lo = band == 64 ? 16 : 0;
+    const int32_t wlo = band / 2 - win_half;                                 // FULL = false: the path may use band lanes [wlo, wlo + 2 win_half) (all the record holds; tests narrow it)
     const uint32_t wn = 2u * (uint32_t)win_half;
     int32_t ncol = 0, n_ops = 0, nw = 0;
     uint32_t rawacc = 0, nb = 0;
     const int32_t plo = (int32_t)(uint32_t)(uint64_t)tbr, phi = (int32_t)((uint64_t)tbr >> 32);
     const int32_t rstride = have ? tbs[sl] : 64;      // records from one 64-step chunk of the slot's masks to the next
     uint8_t *mine = lds + lane * TBW_STRIDE;
-    int32_t cur_chunk = -2, sh_cur = FULL ? 0 : 16;
+    int32_t cur_chunk = -2, sh_cur = FULL ? 0 : rec_lo;
     uint32_t st_fixed = 0, st_adapt = 0, st_steps = 0, st_maxdev = 0;      // STATS: steps outside lanes [16, 48) / outside the adaptive window
     int32_t st_centre = 32;
-    int32_t pref_chunk = active ? ts >> 6 : -1, pref_sh = FULL ? min(max(k - 16, 0), 32) : 16;
+    int32_t pref_chunk = active ? ts >> 6 : -1, pref_sh = FULL ? min(max(k - 16, 0), 32) : rec_lo;
     typedef typename std::conditional<FULL, uint4, uint2>::type rec_t;
     rec_t pf[TBW_RPW];
     const int32_t lane_rec = FULL ? lane : (lane & 31) + (lane >> 5) * 2048;      // step `lane` of a 64-step block: whole masks lie step by step, the bit-sliced kernel's in two halves (swb_rec)
@@ -1802,7 +1876,7 @@ __global__ void __launch_bounds__(64 * TBW_WPG) k_tb_walk(const uint32_t *__rest
     };
     TBW_ISSUE()
     for (;;) {
-        if ((uint32_t)k >= 64u) active = false;      // (masks that are not a DP's: a walk that has left the band ends here, marked by i, ts >= 0, instead of spinning on reloads)
+        if ((uint32_t)k >= (uint32_t)band) active = false;      // (masks that are not a DP's: a walk that has left the band ends here, marked by i, ts >= 0, instead of spinning on reloads)
         if (!FULL && active && (uint32_t)(k - wlo) >= wn) { active = false; failed = true; }      // the path needs a lane the 8-byte records do not hold
         if (!__any(active)) break;
         const int32_t need = active ? ts >> 6 : -1;
@@ -1819,7 +1893,7 @@ __global__ void __launch_bounds__(64 * TBW_WPG) k_tb_walk(const uint32_t *__rest
         const uint64_t redo = __ballot(active && !ok);
         if (redo) {   // rare: the path left the staged lanes, or stalled inside its chunk
             if (active && !ok) {
-                cur_chunk = need; sh_cur = FULL ? min(max(k - 16, 0), 32) : 16;
+                cur_chunk = need; sh_cur = FULL ? min(max(k - 16, 0), 32) : rec_lo;
                 w_cur = mvr[need].x; w_prev = need > 0 ? mvr[need - 1].x : 0ull;
             }
             for (int l = 0; l < TBW_RPW; l++) {
@@ -1832,7 +1906,7 @@ __global__ void __launch_bounds__(64 * TBW_WPG) k_tb_walk(const uint32_t *__rest
         }
         // next prefetch: the chunk below, centred on where the path is now
         pref_chunk = (active && cur_chunk > 0) ? cur_chunk - 1 : -1;
-        pref_sh = FULL ? min(max(k - 16, 0), 32) : 16;
+        pref_sh = FULL ? min(max(k - 16, 0), 32) : rec_lo;
         if (pref_chunk > 0) pref_word = mvr[pref_chunk - 1].x; else pref_word = 0ull;
         TBW_ISSUE()
         TBW_WAVE_SYNC();
@@ -1916,7 +1990,7 @@ constexpr int TBH_STRIDE = TBH_SUB * 8 + 8;      // bytes per walker: +8 stagger
 __global__ void __launch_bounds__(64) k_tb_walk_h(const uint32_t *__restrict__ order, const uint64_t *__restrict__ hi_dev, const DpInfo *__restrict__ info, const int64_t *__restrict__ tbo,
                                                   const int64_t *__restrict__ mvo, const void *__restrict__ tb_, const ulonglong2 *__restrict__ mvw,
                                                   uint32_t *__restrict__ raw, WalkOut *__restrict__ wout, uint32_t *__restrict__ fail_list, uint64_t *__restrict__ n_fail, uint32_t fail_cap,
-                                                  int32_t win_half, uint64_t *__restrict__ wlog) {
+                                                  int32_t win_half, int32_t band, uint64_t *__restrict__ wlog) {
     // wlog (builds with -DFZP_TBH_LOG, FZP_TBH_WAVE_LOG=1; tools/runs/tbh_waves.py): per wave {start, end of the 100 MHz counter, shader cycles inside the step loops,
     // shader cycles between "park" and the walk (the prefetch's arrival, the move words, the next prefetch's issue)}
 #ifdef FZP_TBH_LOG
@@ -1963,7 +2037,9 @@ __global__ void __launch_bounds__(64) k_tb_walk_h(const uint32_t *__restrict__ o
     active = active && i >= 0 && ts - i >= 0;
     const bool walked = active;
     bool failed = false;
-    const int32_t wlo = 32 - win_half;                                        // the path may use band lanes [wlo, wlo + 2 win_half) (16..47; tests narrow it)
+    // v1.8: the band has 64 or 32 cells; the records hold lanes rec_lo .. rec_lo + 31 of it -- the middle of a 64-cell band, the WHOLE of a 32-cell one (no path can need more)
+    const int32_t rec_lo = band == 64 ? 16 : 0;
+    const int32_t wlo = band / 2 - win_half;                                  // the path may use band lanes [wlo, wlo + 2 win_half) (all the record holds; tests narrow it)
     const uint32_t wn = 2u * (uint32_t)win_half;
     int32_t nw = 0;
     uint32_t rawacc = 0, nb = 0;
@@ -1991,7 +2067,7 @@ __global__ void __launch_bounds__(64) k_tb_walk_h(const uint32_t *__restrict__ o
     }
     if (sc >= 0) TBH_ISSUE(sc)
     for (; sc >= 0; sc--) {
-        if ((uint32_t)k >= 64u) active = false;      // (masks that are not a DP's: a walk that has left the band ends here)
+        if ((uint32_t)k >= (uint32_t)band) active = false;      // (masks that are not a DP's: a walk that has left the band ends here)
         if (active && (uint32_t)(k - wlo) >= wn) { active = false; failed = true; }      // the path needs a lane the 8-byte records do not hold
         if (!__any(active)) break;
         // park the half-block (every walker is done with the old contents)
@@ -2022,8 +2098,8 @@ __global__ void __launch_bounds__(64) k_tb_walk_h(const uint32_t *__restrict__ o
         }
         const int32_t c_lo = sc << 5;
         // (the loop's own variables: kk = k - 16 is the bit the step looks at, p16 the address of the record two below the current one -- both reads of a step hang off it)
-        int32_t kk = k - 16;
-        const int32_t kw_lo = wlo - 16, kw_hi = wlo + (int32_t)wn - 17;
+        int32_t kk = k - rec_lo;
+        const int32_t kw_lo = wlo - rec_lo, kw_hi = wlo + (int32_t)wn - 1 - rec_lo;
         const uint8_t *p16 = mine + (ts & (TBH_SUB - 1)) * 8 - 16;
         int32_t bad = (now ? 0 : -1) | i | (ts - i) | (ts - c_lo) | (kk - kw_lo) | (kw_hi - kk);
         uint64_t acc = 0;                  // this piece's ops, the OLDEST in the top bits (turned round behind the loop)
@@ -2054,7 +2130,7 @@ __global__ void __launch_bounds__(64) k_tb_walk_h(const uint32_t *__restrict__ o
             m = db ? n2 : n1;
             bad = i | (ts - i) | (ts - c_lo) | (kk - kw_lo) | (kw_hi - kk);
         }
-        k = kk + 16;
+        k = kk + rec_lo;
 #ifdef FZP_TBH_LOG
         lg_inner += TBH_CLK() - lg_b;
 #endif
@@ -2118,7 +2194,7 @@ __global__ void __launch_bounds__(64) k_tb_cigar(int64_t first, int64_t count, c
                                                  int64_t *__restrict__ cig_start, fzp_aln_summary *__restrict__ summ, int match, int mismatch, int gap,
                                                  int min_pct_identity, const uint32_t *__restrict__ read_pk, const uint32_t *__restrict__ read_rc, const int64_t *__restrict__ read_woff,
                                                  const int32_t *__restrict__ read_ctg, const uint32_t *__restrict__ ctg_pk, const int64_t *__restrict__ ctg_woff,
-                                                 PkRec *__restrict__ pkrec, int2 *__restrict__ pck) {
+                                                 PkRec *__restrict__ pkrec, int2 *__restrict__ pck, int band) {
     const int lane = lane_id();
     const int64_t wv = blockIdx.x;
     if (wv >= count) return;
@@ -2131,7 +2207,7 @@ __global__ void __launch_bounds__(64) k_tb_cigar(int64_t first, int64_t count, c
     const int32_t n = read_len[r];
     fzp_aln_summary out;
     memset(&out, 0, sizeof out);
-    out.cells = rp.steps * 64;
+    out.cells = rp.steps * band;
     if (lane == 0) cig_start[r] = cig_off[r];
     if (!w.ok) { if (lane == 0) summ[r] = out; return; }
     uint32_t *rg = raw + 4 * (size_t)(rcapq_scan[r] - rcapq_scan[first]);    // the read's op stream (pass 0 drops the ops before the alignment's end from it)
@@ -2797,6 +2873,8 @@ extern "C" void fzp_align_params_default(fzp_align_params *p) {
     p->min_pct_identity = 70;
     p->seed_anchored = 1;
     if (const char *e = getenv("FZP_SEED_ANCHORED")) p->seed_anchored = atoi(e) != 0;      // (A/B runs: v1.6's fixed strides without touching the caller)
+    p->band = FZP_DEFAULT_BAND;
+    if (const char *e = getenv("FZP_ALIGN_BAND")) { const int g = atoi(e); if (g == 32 || g == 64) p->band = g; }      // (the twin reads the same switch)
 }
 
 extern "C" void fzp_align_destroy(fzp_ctx *ctx, fzp_alnjob *job) {
@@ -2856,8 +2934,9 @@ static int align_create_core(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *const *
     FZP_TRY(fzp_bind(ctx));
     fzp_alnjob *j = new fzp_alnjob();
     if (params) j->P = *params; else fzp_align_params_default(&j->P);
+    if (j->P.band == 0) j->P.band = FZP_DEFAULT_BAND;      // (a caller's zeroed struct)
     if (j->P.kmer < 8 || j->P.kmer > 16 || j->P.seed_stride < 1 || j->P.match <= 0 || j->P.mismatch < 0 || j->P.gap <= 0 || j->P.min_pct_identity < 0 ||
-        j->P.min_pct_identity > 100) {
+        j->P.min_pct_identity > 100 || (j->P.band != 32 && j->P.band != 64)) {
         delete j; fzp_set_error("fzp_align_create: bad parameters"); return FZP_EINVAL;
     }
     j->n_ctg = n_ctg; j->n_reads = n_reads;
@@ -3040,6 +3119,8 @@ static int align_run(fzp_ctx *ctx, fzp_alnjob *j, bool defer_overflow) {
             }
         }
         // ---- which DP kernel runs which slot (fzalign scores 2 / -4 / -3 are built into the bit-sliced one's cell function)
+        const int band = P.band == 32 ? 32 : 64;      // fzalign v1.8: the band's cells
+        auto ksw = band == 32 ? k_sw<true, 32> : k_sw<true, 64>;
         const bool use_bits = getenv("FZP_SW_NO_BITS") == nullptr && P.match == 2 && P.mismatch == 4 && P.gap == 3 && !j->whole_masks_only;
         // the bit-sliced kernel has two forms.  A pair of lanes per slot (k_swb2) has the shorter step but twice the waves, and its instruction mix issues at ~4.5 cycles per
         // SIMD however many waves share it: two such waves on one SIMD run at half speed each.  So it is taken when its waves get a SIMD each; else the whole band sits in one
@@ -3053,7 +3134,7 @@ static int align_run(fzp_ctx *ctx, fzp_alnjob *j, bool defer_overflow) {
         {
             ProfScope ps(ctx, "k1_plan_dp");
             hipLaunchKernelGGL(k_slot_count, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, st, nr, j->anc.p, j->ancB.p, j->n_wp.p, j->wps.p, j->read_len.p, j->read_ctg.p, j->ctg_len.p,
-                               j->r_cnt.p, j->r_capq.p, j->n_sec.p, (int32_t)swb_max_steps, use_bits ? 1 : 0, (unsigned long long *)(j->rtot.p + 2));
+                               j->r_cnt.p, j->r_capq.p, j->n_sec.p, (int32_t)swb_max_steps, use_bits ? band : 0, (unsigned long long *)(j->rtot.p + 2));
         }
         FZP_TRY(fzp_exclusive_scan_u32(ctx, j->r_cnt.p, j->slot_base.p, (size_t)nr, j->rtot.p + 0));
         FZP_TRY(fzp_exclusive_scan_u32(ctx, j->r_capq.p, j->rcapq_scan.p, (size_t)nr, j->rtot.p + 1));
@@ -3142,7 +3223,7 @@ static int align_run(fzp_ctx *ctx, fzp_alnjob *j, bool defer_overflow) {
                 {
                     ProfScope ps(ctx, "k1_plan_dp");
                     hipLaunchKernelGGL(k_sort_scatter, dim3(nblk), dim3(256), 0, st, ns, nblk, (const Slot *)B.slots.p, (const uint32_t *)B.bh.p, B.sorted.p);
-                    hipLaunchKernelGGL(k_route, dim3(nblk), dim3(256), 0, st, ns, (const Slot *)B.slots.p, (const uint32_t *)B.sorted.p, (int32_t)swb_max_steps, use_bits ? 1 : 0, B.fits.p);
+                    hipLaunchKernelGGL(k_route, dim3(nblk), dim3(256), 0, st, ns, (const Slot *)B.slots.p, (const uint32_t *)B.sorted.p, (int32_t)swb_max_steps, use_bits ? band : 0, B.fits.p);
                 }
                 FZP_TRY(fzp_exclusive_scan_u32(ctx, B.fits.p, B.pos_b.p, ns, B.ptot.p + 0));
                 {
@@ -3170,7 +3251,7 @@ static int align_run(fzp_ctx *ctx, fzp_alnjob *j, bool defer_overflow) {
                     ProfScope ps(ctx, "k1_sw");
                     // every slot goes to one of the two DP kernels (k_route): the bit-sliced one (a slot per lane) takes those that span the band on both sides, the
                     // wave-per-slot one the rest -- mostly backward extensions of a few dozen bases -- beside it on a stream of its own
-                    const bool swb64 = swb_force ? swb_force == 64 : !((int64_t)ns / 32 <= (int64_t)ctx->n_cu * 4);
+                    const bool swb64 = band == 32 || (swb_force ? swb_force == 64 : !((int64_t)ns / 32 <= (int64_t)ctx->n_cu * 4));      // (the pair-of-lanes form exists for the 64-cell band only: a lane of the 32-cell band already holds one register per plane)
                     // the bit-sliced kernel's two register budgets (FZP_SWB_WAVES = 1 | 2), its work units (FZP_SWB_UNIT: 64-step blocks per unit; FZP_SWB_HYST: by how many
                     // units waiting work has to be longer before a wave parks its group for it) and the SIMD-sharing switch (FZP_SWB_DBG bit 2).  DEFAULT: one wave per SIMD,
                     // whole groups -- r5's schedule, through the same code (one level, every group fresh).  What r6 built and measured (profiles/r6_swb_units.txt): with units
@@ -3205,7 +3286,8 @@ static int align_run(fzp_ctx *ctx, fzp_alnjob *j, bool defer_overflow) {
                                            (const uint32_t *)j->read_pk.p, (const uint32_t *)j->read_rc.p, (const int64_t *)j->read_woff.p, (const uint32_t *)j->ctg_pk.p, (const uint32_t *)j->ctg_rc.p,
                                            (const int64_t *)j->ctg_woff.p, (const int64_t *)B.tbo.p, (const int64_t *)B.mvo.p, B.tb.p, B.mvw.p, B.info.p);
                     if (use_bits && swb64) {
-                        auto kfn = swb_wps == 2 ? (swb_ring ? k_swb<true, 32, 8, 4, 2> : k_swb<false, 32, 8, 4, 2>) : (swb_ring ? k_swb<true, 64, 16, 8, 1> : k_swb<false, 64, 16, 8, 1>);
+                        auto kfn = band == 32 ? (swb_wps == 2 ? (swb_ring ? k_swb<true, 32, 8, 4, 2, 32> : k_swb<false, 32, 8, 4, 2, 32>) : (swb_ring ? k_swb<true, 64, 16, 8, 1, 32> : k_swb<false, 64, 16, 8, 1, 32>))
+                                              : (swb_wps == 2 ? (swb_ring ? k_swb<true, 32, 8, 4, 2> : k_swb<false, 32, 8, 4, 2>) : (swb_ring ? k_swb<true, 64, 16, 8, 1> : k_swb<false, 64, 16, 8, 1>));
                         hipLaunchKernelGGL(kfn, dim3(std::min<unsigned>(ngrp, swb_slots)), dim3(64), 0, st, (const uint64_t *)B.ptot.p, (const uint32_t *)B.list.p,
                                            (const Slot *)B.slots.p, (const uint32_t *)j->read_pk.p, (const uint32_t *)j->read_rc.p, (const int64_t *)j->read_woff.p, (const uint32_t *)j->ctg_pk.p,
                                            (const uint32_t *)j->ctg_rc.p, (const int64_t *)j->ctg_woff.p, (const int64_t *)B.tbo.p, (const int64_t *)B.mvo.p, B.tb.p, B.mvw.p, B.info.p,
@@ -3213,7 +3295,7 @@ static int align_run(fzp_ctx *ctx, fzp_alnjob *j, bool defer_overflow) {
                     }
                     hipStream_t st_sw = getenv("FZP_SW_SERIAL") ? st : st3;      // (comparison switch: the wave-per-piece kernel behind the bit-sliced one instead of beside it)
                     if (st_sw == st3) FZP_HIP(hipStreamWaitEvent(st3, j->ev_l[0], 0));
-                    hipLaunchKernelGGL(k_sw<true>, dim3((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(ns, rtot[3]))), dim3(64), 0, st_sw, (const uint64_t *)B.ptot.p, (const uint64_t *)nullptr, ns, /* (no chunk has more such slots than the run) */ (const uint32_t *)B.list.p, (const Slot *)B.slots.p,
+                    hipLaunchKernelGGL(ksw, dim3((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(ns, rtot[3]))), dim3(64), 0, st_sw, (const uint64_t *)B.ptot.p, (const uint64_t *)nullptr, ns, /* (no chunk has more such slots than the run) */ (const uint32_t *)B.list.p, (const Slot *)B.slots.p,
                                        (const uint32_t *)j->read_pk.p, (const uint32_t *)j->read_rc.p, (const int64_t *)j->read_woff.p, (const uint32_t *)j->ctg_pk.p, (const uint32_t *)j->ctg_rc.p,
                                        (const int64_t *)j->ctg_woff.p, (const int64_t *)B.tbo.p, (const int64_t *)B.mvo.p, (const int32_t *)B.tbs.p, (uint2 *)B.tbw.p, B.mvw.p, P.match, P.mismatch, P.gap, B.info.p);
                     if (st_sw == st3) { FZP_HIP(hipEventRecord(j->ev_l[1], st3)); FZP_HIP(hipStreamWaitEvent(st, j->ev_l[1], 0)); }
@@ -3246,23 +3328,23 @@ static int align_run(fzp_ctx *ctx, fzp_alnjob *j, bool defer_overflow) {
                 if (tb_stats || walk_old)
                     hipLaunchKernelGGL(kw_mid, dim3(wg), dim3(64 * TBW_WPG), 0, st2, (const uint32_t *)B.list.p, (const uint64_t *)nullptr, (const uint64_t *)B.ptot.p, 0u,
                                        (const DpInfo *)B.info.p, (const int64_t *)B.tbo.p, (const int64_t *)B.mvo.p, (const int32_t *)B.tbs.p, (const void *)B.tb.p, (const ulonglong2 *)B.mvw.p, B.raw.p, B.wout.p,
-                                       (unsigned long long *)j->tb_stats.p, B.fail_list.p, B.ptot.p + 3, (uint32_t)FAIL_CAP, win_half);
+                                       (unsigned long long *)j->tb_stats.p, B.fail_list.p, B.ptot.p + 3, (uint32_t)FAIL_CAP, win_half, band);
                 else
                     hipLaunchKernelGGL(k_tb_walk_h, dim3((ns + TBH_RPW - 1) / TBH_RPW), dim3(64), 0, st2, (const uint32_t *)B.list.p, (const uint64_t *)B.ptot.p, (const DpInfo *)B.info.p,
                                        (const int64_t *)B.tbo.p, (const int64_t *)B.mvo.p, (const void *)B.tb.p, (const ulonglong2 *)B.mvw.p, B.raw.p, B.wout.p,
-                                       B.fail_list.p, B.ptot.p + 3, (uint32_t)FAIL_CAP, win_half, tbh_log);
+                                       B.fail_list.p, B.ptot.p + 3, (uint32_t)FAIL_CAP, win_half, band, tbh_log);
                 hipLaunchKernelGGL(kw_full, dim3(wg), dim3(64 * TBW_WPG), 0, st2, (const uint32_t *)B.list.p, (const uint64_t *)B.ptot.p, (const uint64_t *)nullptr, ns,
                                    (const DpInfo *)B.info.p, (const int64_t *)B.tbo.p, (const int64_t *)B.mvo.p, (const int32_t *)B.tbs.p, (const void *)B.tbw.p, (const ulonglong2 *)B.mvw.p, B.raw.p, B.wout.p,
-                                   (unsigned long long *)nullptr, (uint32_t *)nullptr, (uint64_t *)nullptr, 0u, 16);
+                                   (unsigned long long *)nullptr, (uint32_t *)nullptr, (uint64_t *)nullptr, 0u, 16, band);
                 // slots whose path left the recorded lanes (normally none: these launches find an empty list): whole masks from the wave-per-slot kernel, walked again
                 hipLaunchKernelGGL(k_fail_plan, dim3(FAIL_CAP / 256), dim3(256), 0, st2, (const uint32_t *)B.fail_list.p, (const uint64_t *)(B.ptot.p + 3), (uint32_t)FAIL_CAP, (const Slot *)B.slots.p,
                                    (unsigned long long *)(B.ptot.p + 4), (uint64_t)tbw_room, B.tbo.p, B.tbs.p, j->fb_overflow.p);
-                hipLaunchKernelGGL(k_sw<true>, dim3(FAIL_CAP), dim3(64), 0, st2, (const uint64_t *)nullptr, (const uint64_t *)(B.ptot.p + 3), (uint32_t)FAIL_CAP, (const uint32_t *)B.fail_list.p, (const Slot *)B.slots.p,
+                hipLaunchKernelGGL(ksw, dim3(FAIL_CAP), dim3(64), 0, st2, (const uint64_t *)nullptr, (const uint64_t *)(B.ptot.p + 3), (uint32_t)FAIL_CAP, (const uint32_t *)B.fail_list.p, (const Slot *)B.slots.p,
                                    (const uint32_t *)j->read_pk.p, (const uint32_t *)j->read_rc.p, (const int64_t *)j->read_woff.p, (const uint32_t *)j->ctg_pk.p, (const uint32_t *)j->ctg_rc.p,
                                    (const int64_t *)j->ctg_woff.p, (const int64_t *)B.tbo.p, (const int64_t *)B.mvo.p, (const int32_t *)B.tbs.p, (uint2 *)B.tbw.p, B.mvw.p, P.match, P.mismatch, P.gap, B.info.p);
                 hipLaunchKernelGGL(kw_full, dim3(FAIL_CAP / (TBW_RPW * TBW_WPG)), dim3(64 * TBW_WPG), 0, st2, (const uint32_t *)B.fail_list.p, (const uint64_t *)nullptr, (const uint64_t *)(B.ptot.p + 3), (uint32_t)FAIL_CAP,
                                    (const DpInfo *)B.info.p, (const int64_t *)B.tbo.p, (const int64_t *)B.mvo.p, (const int32_t *)B.tbs.p, (const void *)B.tbw.p, (const ulonglong2 *)B.mvw.p, B.raw.p, B.wout.p,
-                                   (unsigned long long *)nullptr, (uint32_t *)nullptr, (uint64_t *)nullptr, 0u, 16);
+                                   (unsigned long long *)nullptr, (uint32_t *)nullptr, (uint64_t *)nullptr, 0u, 16, band);
             }
             {
                 ProfScope ps(ctx, "k1_join", st2);
@@ -3274,7 +3356,7 @@ static int align_run(fzp_ctx *ctx, fzp_alnjob *j, bool defer_overflow) {
                 hipLaunchKernelGGL(k_tb_cigar, dim3((unsigned)cnt), dim3(64), 0, st2, first, cnt, j->read_len.p, (const ReadPath *)B.rpath.p, (const uint32_t *)j->rcapq_scan.p, rraw,
                                    j->cig_off.p, j->cig.p, j->cig_start.p, j->summ.p, P.match, P.mismatch, P.gap, P.min_pct_identity,
                                    (const uint32_t *)j->read_pk.p, (const uint32_t *)j->read_rc.p, (const int64_t *)j->read_woff.p, j->read_ctg.p, (const uint32_t *)j->ctg_pk.p, (const int64_t *)j->ctg_woff.p,
-                                   j->pkrec.p, j->pck.p);
+                                   j->pkrec.p, j->pck.p, band);
             }
             FZP_HIP(hipEventRecord(j->ev_tb[bi], st2));
             used[bi] = true;

@@ -137,9 +137,9 @@ FZP_HD int32_t half_edge(const Half &h, const uint32_t my) {
 // on the matrix's last row or last column -- the terminal candidates, which only the checked steps look at -- whatever the moves?  A DOWN brings lane 63 one row nearer
 // the last row, a RIGHT lane 0 one column nearer the last column: one step less than the smaller of the two distances.  (Without the "- 1" -- r3 -- the block's last step
 // could put lane 63 ON the last row unseen: ADVICE r3; pinned by the host test, which that form fails.)  0: the band is not yet inside the matrix.
-FZP_HD int32_t sw_interior_safe(int32_t t, int32_t i0, int32_t nq, int32_t nt) {
-    if (!(t >= 64 && i0 >= 0 && (t - 1) - (i0 + 63) >= 0)) return 0;
-    const int32_t rows_left = nq - 1 - (i0 + 63), cols_left = nt - 1 - ((t - 1) - i0);
+FZP_HD int32_t sw_interior_safe(int32_t t, int32_t i0, int32_t nq, int32_t nt, int32_t band = 64) {      // band: the band's cells (v1.8: 64 or 32)
+    if (!(t >= band && i0 >= 0 && (t - 1) - (i0 + band - 1) >= 0)) return 0;
+    const int32_t rows_left = nq - 1 - (i0 + band - 1), cols_left = nt - 1 - ((t - 1) - i0);
     return (rows_left < cols_left ? rows_left : cols_left) - 1;
 }
 }   // namespace swb

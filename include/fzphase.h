@@ -226,7 +226,9 @@ typedef struct {
     int32_t min_seed_hits;   /* reads with fewer votes in the best window are unaligned, default 8 */
     int32_t min_pct_identity; /* alignments below this identity are dropped (blasr --minPctIdentity 70.0, unzip.py:87); default 70, 0 = off */
     int32_t seed_anchored;   /* 1 (default, v1.7): index and look-ups use the anchored k-mers; 0: v1.6's fixed strides (every 2nd contig position, every seed_stride-th read k-mer) */
-    int32_t reserved[8];
+    int32_t band;            /* fzalign v1.8: cells of the adaptive band, 64 or 32 (0: the default).  On every test set the 32-cell band finds the same scores (profiles/r6_band32_go_nogo.txt)
+                              * at about half the DP's instructions: planes and windows are one register instead of two, and the 8-byte trace-back record is the whole mask */
+    int32_t reserved[7];
 } fzp_align_params;
 void fzp_align_params_default(fzp_align_params *p);
 
