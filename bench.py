@@ -283,7 +283,7 @@ def cpu_baseline(contigs, blob, off, read_ctg, ids, job, hip_summ, budget_s=30.0
             "k1_fields_differing_from_hip": mismatched, "k1_cigars_differing_from_hip": cig_diff}
 
 
-def roofline(cells_per_launch, sw_avg_ms, sw_launches, dp_gcells, traffic):
+def roofline(cells_per_launch, sw_avg_ms, sw_launches, dp_gcells, traffic, band=32):
     """k1_sw, the dominant stage: the banded DP of every extension piece of the step in ONE launch pair (k_swb, bit-sliced, one piece per lane; k_sw, one wave per
     piece, for the pieces narrower than the band -- DESIGN section 5).  What binds it is VALU issue, so that is the headline: wave64 VALU instructions per second
     (SQ_INSTS_VALU from profiles/, named in `counter_source`) against the chip's issue peak, 256 CU x 4 SIMD x 2.4 GHz / 2 cycles per wave64 instruction on a SIMD-32
@@ -297,11 +297,14 @@ def roofline(cells_per_launch, sw_avg_ms, sw_launches, dp_gcells, traffic):
     per_step = float(counters["valu_per_step"])
     # the committed counter files belong to a particular kernel and workload: say so when this run no longer looks like the one they were taken on
     stale = []
-    if counters.get("band_steps_per_bench_step") and abs(counters["band_steps_per_bench_step"] * 64.0 / max(cells_per_launch, 1.0) - 1.0) > 0.02:
-        stale.append("counters: %.4g band steps per launch when they were taken, %.4g now" % (counters["band_steps_per_bench_step"], cells_per_launch / 64.0))
-    if traffic and abs(traffic / max(cells_per_launch * 0.125, 1.0) - 1.0) > 0.25:
-        stale.append("traffic: %.3g B per launch on file, %.3g B of mask records planned by this run" % (traffic, cells_per_launch * 0.125))
-    steps_per_s = dp_gcells * 1e9 / 64.0
+    moved_per_cell = 8.0 / band      # 8 B of mask record per band step: the band's middle 32 lanes of v1.7's 64-cell band, the WHOLE mask of v1.8's 32-cell band
+    if counters.get("band", 64) != band:
+        stale.append("counters: taken with a band of %d cells, this run's has %d" % (counters.get("band", 64), band))
+    if counters.get("band_steps_per_bench_step") and abs(counters["band_steps_per_bench_step"] * float(band) / max(cells_per_launch, 1.0) - 1.0) > 0.02:
+        stale.append("counters: %.4g band steps per launch when they were taken, %.4g now" % (counters["band_steps_per_bench_step"], cells_per_launch / float(band)))
+    if traffic and abs(traffic / max(cells_per_launch * moved_per_cell, 1.0) - 1.0) > 0.25:
+        stale.append("traffic: %.3g B per launch on file, %.3g B of mask records planned by this run" % (traffic, cells_per_launch * moved_per_cell))
+    steps_per_s = dp_gcells * 1e9 / float(band)
     valu = steps_per_s * per_step / 1e9
     valu_peak = N_SIMD * CLK_GHZ / 2.0
     secs = sw_avg_ms * 1e-3 if sw_avg_ms else 0.0
@@ -309,17 +312,15 @@ def roofline(cells_per_launch, sw_avg_ms, sw_launches, dp_gcells, traffic):
     gbs_moved = (traffic / secs / 1e9) if (traffic and secs) else None
     return {"bound": "valu", "kernel": "k1_sw (k_swb + k_sw)", "achieved": round(valu, 2), "peak": round(valu_peak, 1), "unit": "G wave64-inst/s", "frac": round(valu / valu_peak, 4),
             "traffic": traffic, "profile_files_stale": stale or None, "avg_launch_ms": round(sw_avg_ms, 3), "launches": int(sw_launches),
-            "valu_insts_per_band_step": per_step, "counter_source": counters.get("source"),
+            "valu_insts_per_band_step": per_step, "counter_source": counters.get("source"), "band_cells": band,
             "note": "the DP stage keeps every SIMD busy with one wave (~3 500 waves of 64 pieces on 1 024 SIMDs) and is bound by VALU issue: wave64 VALU instructions per second "
                     "(SQ_INSTS_VALU of the committed counter pass x this run's band steps per second) against 256 CU x 4 SIMD x 2.4 GHz / 2 cycles per instruction.  The two HBM "
                     "views sit beside it: `hbm_algorithmic` prices SURVEY 8d's 0.25 B per cell (the 2 trace-back bits of every cell), `hbm_moved` what the kernel really moves "
-                    "(`traffic`: band lanes 16..47 only, 0.125 B per cell + the base streams)",
+                    "(`traffic`: 8 B of mask record per band step -- with fzalign v1.8's 32-cell band the whole mask -- + the base streams).  (SURVEY 8d's third view, 12 integer "
+                    "ops per cell, is not priced any more: a bit-parallel kernel spends ~2 lane-operations per cell, the 'fraction' came out at 2.0.)",
             "hbm_algorithmic": {"achieved": round(gbs_alg, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs_alg / HBM_PEAK_GBS, 4), "bytes_per_cell": SW_BYTES_PER_CELL},
             "hbm_moved": {"achieved": round(gbs_moved, 2) if gbs_moved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs_moved / HBM_PEAK_GBS, 4) if gbs_moved else None,
-                          "bytes_per_cell": 0.125, "bytes_per_launch": traffic},
-            "ops_view": {"int_ops_per_cell": 12, "achieved_tlaneop": round(dp_gcells * 12 / 1e3, 2), "peak_tlaneop": round(256 * 4 * 32 * CLK_GHZ / 1e3, 2),
-                         "frac": round(dp_gcells * 12 / (256 * 4 * 32 * CLK_GHZ), 4),
-                         "note": "SURVEY 8d: 12 int ops per cell against 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (the bit-sliced kernel spends ~2 lane-ops per cell)"}}
+                          "bytes_per_cell": moved_per_cell, "bytes_per_launch": traffic}}
 
 
 def polish_leg(eng, contigs, blob, off, read_ctg):
@@ -936,7 +937,7 @@ def main():
             "end_to_end": e2e,
             "from_files": from_files,
             "two_steps_in_flight": pipelined,
-            "roofline": roofline(cells_per_launch, sw_avg_ms, sw_launches, dp_gcells, traffic),
+            "roofline": roofline(cells_per_launch, sw_avg_ms, sw_launches, dp_gcells, traffic, band=_lib.align_band()),
         }
         if cpu is not None:
             out["cpu_baseline"] = cpu

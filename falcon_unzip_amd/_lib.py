@@ -601,6 +601,13 @@ def align_job(eng, contigs, reads, read_ctg=None, params=None) -> AlignJob:
     return AlignJob(eng, p.value, nr, nc)
 
 
+def align_band() -> int:
+    """cells of K1's adaptive band under the default parameters (fzalign v1.8: 32; FZP_ALIGN_BAND=64 brings v1.7's band back): a read's `cells` = its DP steps x this"""
+    P = AlignParams()
+    load().fzp_align_params_default(C.byref(P))
+    return int(P.band)
+
+
 def polish_tigs(eng, tigs, read_blob: bytes, read_off, read_tig, params=None) -> "Tigs":
     """fzp_polish_tigs: every read (read_blob[read_off[r]:read_off[r + 1]], as sequenced) aligned to ITS tig (tigs[read_tig[r]]) by K1, the whole tig called as one pile
     by K6 (fzcns v3) -- the consensus role of run_quiver.py:82-97.  -> Tigs with one entry per input tig, input order (n_records = 0: no read aligned, the tig as it came)."""

@@ -126,7 +126,7 @@ constexpr int LONG_READ = 8192, LONG_STRIDE = 3;      // v1.6: reads of at least
 constexpr int LONG_MS = 3, SAMPLE_CAP = 8192;         // v1.7: of a long read's selected k-mers every LONG_MS-th (x 2, x 3 .. per further 131 072 bases) is looked up, SAMPLE_CAP at most
 constexpr int ANCH_DIV = 8;                           // v1.7: table slots are sized for 2 x (k-mer positions / ANCH_DIV) entries (an eighth of the positions is selected on random sequence)
 constexpr int PIECE_LEN = 3072;        // v1.6: read bases between waypoints (at least)
-constexpr int FZP_DEFAULT_BAND = 64;   // v1.8: cells of the adaptive band (fzp_align_params.band: 64 or 32; the twin's ORC_DEFAULT_BAND says the same)
+constexpr int FZP_DEFAULT_BAND = 32;   // v1.8: cells of the adaptive band (fzp_align_params.band: 64 or 32; the twin's ORC_DEFAULT_BAND says the same)
 constexpr int MAX_WP = 31;             // waypoints per candidate: a read has at most 2 x (MAX_WP + 1) = 64 slots, one per lane of k_join
 __host__ __device__ __forceinline__ int32_t piece_len(int64_t n) { const int64_t p = (n + MAX_WP - 2) / (MAX_WP - 1); return (int32_t)(p > PIECE_LEN ? p : PIECE_LEN); }
 __device__ __forceinline__ uint32_t canonical(uint32_t key, int k, uint32_t *is_rc) {

@@ -85,7 +85,7 @@
 #include <time.h>
 
 #define W 64             /* room for the widest band; the band itself is a parameter since v1.8 (orc_align_params.band: 64 or 32, 0 = FZP_ALIGN_BAND or the default) */
-#define ORC_DEFAULT_BAND 64
+#define ORC_DEFAULT_BAND 32
 #define NEG (-(1 << 26))
 
 typedef struct {

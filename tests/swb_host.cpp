@@ -5,74 +5,83 @@
 #include <cstring>
 #include "../falcon_unzip_amd/csrc/fzp_swb_core.h"
 
-extern "C" int swb_extend_host(const uint8_t *q, int64_t nq, const uint8_t *t, int64_t nt, uint64_t *tbD, uint64_t *tbG, uint8_t *mv, int64_t *out, int inner) {
+// BAND: the band's cells (fzalign v1.8: 64 or 32), BW: a word that wide.  k_swb runs the 64-cell form as written in swb_step, the 32-cell form as in swb_step32.
+template <class BW, int BAND>
+static int swb_extend_host_t(const uint8_t *q, int64_t nq, const uint8_t *t, int64_t nt, uint64_t *tbD, uint64_t *tbG, uint8_t *mv, int64_t *out, int inner) {
     using namespace swb;
-    if (nq < 64 || nt < 64) return -1;                        // (the kernel leaves such extensions to k_sw)
+    constexpr int HB = BAND / 2, LAST = BAND - 1;
+    if (nq < BAND || nt < BAND) return -1;                    // (the kernel leaves such extensions to k_sw)
     const int64_t max_steps = nq + nt + 2;
-    // step -1: the anti-diagonal i + j = -1 of the virtual border, lane k = cell (k - 33, 32 - k):  Pv = 0 where j >= 0 (k <= 32) else 4, Qv = 0 where i >= 0 (k >= 33) else 4
-    Planes P = {0, 0, ~0ull << 33}, Q = {0, 0, (1ull << 33) - 1};
-    uint64_t R0 = 0, R1 = 0, C0 = 0, C1 = 0;                   // windows: bit k = read base i0 + k / contig base t - i0 - k (bit planes of the 2-bit codes)
-    for (int k = 0; k < 64; k++) {
-        const int64_t i = k - 33, j = 32 - k;
-        if (i >= 0 && i < nq) { R0 |= (uint64_t)(q[i] & 1) << k; R1 |= (uint64_t)(q[i] >> 1) << k; }
-        if (j >= 0 && j < nt) { C0 |= (uint64_t)(t[j] & 1) << k; C1 |= (uint64_t)(t[j] >> 1) << k; }
+    // step -1: the anti-diagonal i + j = -1 of the virtual border, lane k = cell (k - HB - 1, HB - k):  Pv = 0 where j >= 0 (k <= HB) else 4, Qv = 0 where i >= 0 (k > HB) else 4
+    PlanesT<BW> P = {0, 0, (BW)(~(BW)0 << (HB + 1))}, Q = {0, 0, (BW)(((BW)1 << (HB + 1)) - 1)};
+    BW R0 = 0, R1 = 0, C0 = 0, C1 = 0;                        // windows: bit k = read base i0 + k / contig base t - i0 - k (bit planes of the 2-bit codes)
+    for (int k = 0; k < BAND; k++) {
+        const int64_t i = k - (HB + 1), j = HB - k;
+        if (i >= 0 && i < nq) { R0 |= (BW)(q[i] & 1) << k; R1 |= (BW)(q[i] >> 1) << k; }
+        if (j >= 0 && j < nt) { C0 |= (BW)(t[j] & 1) << k; C1 |= (BW)(t[j] >> 1) << k; }
     }
-    int64_t i0 = -33, tt = 0;
-    int32_t S0 = -259, E2 = 8;                                 // score of lane 0's cell; (score of lane 63's - S0) / 2 -- at step -1 from the border's closed form
+    int64_t i0 = -(HB + 1), tt = 0;
+    int32_t S0 = -3 - 8 * HB, E2 = 8;                         // score of lane 0's cell (-259 / -131); (score of the last lane's - S0) / 2 -- at step -1 from the border's closed form
     bool down = true, pdown = false;
     bool row_on = false, col_on = false;
     int32_t Hrow = 0, Hcol = 0, best = -(1 << 26);
     int64_t bt = -1, bl = -1;
     for (;;) {
-        Planes p, qq;
+        PlanesT<BW> p, qq;
         if (down) {
             i0++;
             R0 >>= 1; R1 >>= 1;
-            const int64_t i = i0 + 63;
-            if (i >= 0 && i < nq) { R0 |= (uint64_t)(q[i] & 1) << 63; R1 |= (uint64_t)(q[i] >> 1) << 63; }
-            p = P; qq = {Q.v0 >> 1, Q.v1 >> 1, Q.v2 >> 1};
+            const int64_t i = i0 + LAST;
+            if (i >= 0 && i < nq) { R0 |= (BW)(q[i] & 1) << LAST; R1 |= (BW)(q[i] >> 1) << LAST; }
+            p = P; qq = {(BW)(Q.v0 >> 1), (BW)(Q.v1 >> 1), (BW)(Q.v2 >> 1)};
         } else {
             C0 <<= 1; C1 <<= 1;
             const int64_t j = tt - i0;
-            if (j >= 0 && j < nt) { C0 |= (uint64_t)(t[j] & 1); C1 |= (uint64_t)(t[j] >> 1); }
-            p = {P.v0 << 1, P.v1 << 1, P.v2 << 1}; qq = Q;
+            if (j >= 0 && j < nt) { C0 |= (BW)(t[j] & 1); C1 |= (BW)(t[j] >> 1); }
+            p = {(BW)(P.v0 << 1), (BW)(P.v1 << 1), (BW)(P.v2 << 1)}; qq = Q;
         }
-        uint64_t xm = (R0 ^ C0) | (R1 ^ C1);
+        BW xm = (R0 ^ C0) | (R1 ^ C1);
         {   // bases past the read's / the window's end never match (tail of the extension only)
             const int64_t nv = nq - i0;                                                 // lanes k < nv hold read bases
-            if (nv < 64) xm |= nv <= 0 ? ~0ull : ~((1ull << nv) - 1);
+            if (nv < BAND) xm |= nv <= 0 ? ~(BW)0 : (BW)~(((BW)1 << nv) - 1);
             const int64_t kmin = tt - i0 - nt + 1;                                      // lanes k >= kmin hold contig bases
-            if (kmin > 0) xm |= kmin >= 64 ? ~0ull : (1ull << kmin) - 1;
+            if (kmin > 0) xm |= kmin >= BAND ? ~(BW)0 : (BW)(((BW)1 << kmin) - 1);
         }
-        const uint64_t f = (down && pdown) ? 1ull << 63 : ((!down && !pdown) ? 1ull : 0ull);
-        uint64_t D, G;
-        cells<uint64_t>(xm, f, down ? ~(uint64_t)0 : (uint64_t)0, p, qq, &P, &Q, &D, &G);
-        tbD[tt] = D; tbG[tt] = G; mv[tt] = down ? 1 : 0;
+        const BW f = (down && pdown) ? (BW)1 << LAST : ((!down && !pdown) ? (BW)1 : (BW)0);
+        BW D, G;
+        cells<BW>(xm, f, down ? ~(BW)0 : (BW)0, p, qq, &P, &Q, &D, &G);
+        tbD[tt] = (uint64_t)D; tbG[tt] = (uint64_t)G; mv[tt] = down ? 1 : 0;
         // edge scores: every lane's cell moved down (vertical difference) or right (horizontal)
-        const Planes &X = down ? Q : P;
-        const int32_t v0 = value_at(X, 0), v63 = value_at(X, 63);
+        const PlanesT<BW> &X = down ? Q : P;
+        const int32_t v0 = value_at(X, 0), vl = value_at(X, LAST);
         S0 += 2 * v0 - 3;
-        E2 += v63 - v0;
+        E2 += vl - v0;
         // terminal: best valid cell of the last row / the last column, by differences along them
         {
             const int64_t kc = tt - (nt - 1) - i0, kr = nq - 1 - i0;
             if (!col_on && !down && kc == 0) { col_on = true; Hcol = S0; }
-            else if (col_on && kc >= 0 && kc <= 63) Hcol += 2 * value_at(Q, (int)kc) - 3;
-            if (!row_on && down && kr == 63) { row_on = true; Hrow = S0 + 2 * E2; }
-            else if (row_on && kr >= 0 && kr <= 63) Hrow += 2 * value_at(P, (int)kr) - 3;
+            else if (col_on && kc >= 0 && kc <= LAST) Hcol += 2 * value_at(Q, (int)kc) - 3;
+            if (!row_on && down && kr == LAST) { row_on = true; Hrow = S0 + 2 * E2; }
+            else if (row_on && kr >= 0 && kr <= LAST) Hrow += 2 * value_at(P, (int)kr) - 3;
             // (inner pieces, fzalign v1.6: a border cell is valued by the global alignment through it -- minus the gap moves from it to the corner)
-            if (col_on && kc >= 0 && kc <= 63) { const int64_t i = i0 + kc; const int32_t vc = inner ? Hcol - 3 * (int32_t)(nq - 1 - i) : Hcol; if (i >= 0 && i < nq && vc > best) { best = vc; bt = tt; bl = kc; } }
-            if (row_on && kr >= 0 && kr <= 63) { const int64_t j = tt - (nq - 1); const int32_t vr = inner ? Hrow - 3 * (int32_t)(nt - 1 - j) : Hrow; if (j >= 0 && j < nt && vr > best) { best = vr; bt = tt; bl = kr; } }
+            if (col_on && kc >= 0 && kc <= LAST) { const int64_t i = i0 + kc; const int32_t vc = inner ? Hcol - 3 * (int32_t)(nq - 1 - i) : Hcol; if (i >= 0 && i < nq && vc > best) { best = vc; bt = tt; bl = kc; } }
+            if (row_on && kr >= 0 && kr <= LAST) { const int64_t j = tt - (nq - 1); const int32_t vr = inner ? Hrow - 3 * (int32_t)(nt - 1 - j) : Hrow; if (j >= 0 && j < nt && vr > best) { best = vr; bt = tt; bl = kr; } }
         }
         pdown = down;
         tt++;
-        down = tt < 64 ? ((tt & 1) == 0) : (E2 >= 0);
+        down = tt < BAND ? ((tt & 1) == 0) : (E2 >= 0);
         if (i0 > nq - 1) break;
-        if ((tt - 1) - (i0 + 63) > nt - 1) break;
+        if ((tt - 1) - (i0 + LAST) > nt - 1) break;
         if (tt >= max_steps) break;
     }
     out[0] = tt; out[1] = bl >= 0 ? best : -(1 << 26); out[2] = bt; out[3] = bl;
     return 0;
+}
+extern "C" int swb_extend_host(const uint8_t *q, int64_t nq, const uint8_t *t, int64_t nt, uint64_t *tbD, uint64_t *tbG, uint8_t *mv, int64_t *out, int inner) {
+    return swb_extend_host_t<uint64_t, 64>(q, nq, t, nt, tbD, tbG, mv, out, inner);
+}
+extern "C" int swb_extend_host32(const uint8_t *q, int64_t nq, const uint8_t *t, int64_t nt, uint64_t *tbD, uint64_t *tbG, uint8_t *mv, int64_t *out, int inner) {
+    return swb_extend_host_t<uint32_t, 32>(q, nq, t, nt, tbD, tbG, mv, out, inner);
 }
 
 

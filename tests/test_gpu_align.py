@@ -510,8 +510,11 @@ def test_the_three_dp_kernels_agree(eng, oracle, monkeypatch):
     ctg, blob, off, *_ = _shaped(51, 800_000, n, length_model={"median": 4000, "sigma": 1.3, "lo": 70, "hi": 30000})
     reads = [blob[off[i]:off[i + 1]] for i in range(n)]
     got = {}
-    for mode, env in (("default", {}), ("wave_per_read", {"FZP_SW_NO_BITS": "1"}), ("lane64", {"FZP_SWB_64": "1"}), ("pair", {"FZP_SWB_PAIR": "1"}),
-                      ("pair_short_limit", {"FZP_SWB_PAIR": "1", "FZP_SWB_MAX_STEPS": "9000"}), ("three_chunks", {"FZP_SW_CHUNKS": "3"}), ("bases_from_hbm", {"FZP_SWB_NO_RING": "1", "FZP_SWB_64": "1"}),
+    B64 = {"FZP_ALIGN_BAND": "64"}      # (fzalign v1.8: the default band has 32 cells; the 64-cell band and its kernels -- the pair-of-lanes form exists for it alone -- stay selectable)
+    for mode, env in (("default", {}), ("wave_per_read", {"FZP_SW_NO_BITS": "1"}), ("lane64", {"FZP_SWB_64": "1"}), ("three_chunks", {"FZP_SW_CHUNKS": "3"}),
+                      ("bases_from_hbm", {"FZP_SWB_NO_RING": "1", "FZP_SWB_64": "1"}),
+                      ("band64", dict(B64)), ("band64_wave_per_read", dict(B64, FZP_SW_NO_BITS="1")), ("band64_lane64", dict(B64, FZP_SWB_64="1")), ("band64_pair", dict(B64, FZP_SWB_PAIR="1")),
+                      ("band64_pair_short_limit", dict(B64, FZP_SWB_PAIR="1", FZP_SWB_MAX_STEPS="9000")), ("band64_units_two_waves", dict(B64, FZP_SWB_64="1", FZP_SWB_WAVES="2", FZP_SWB_UNIT="3", FZP_SWB_GRID="8")),
                       ("walk16", {"FZP_TBW_OLD": "1"}),       # (the 16-walkers-per-wave walk on the records laid out for the 32-walker one)
                       # r6: k_swb's groups cut into work units of 2 / 3 blocks that waves park and pick up (longest remaining first), with both register budgets, with and
                       # without the turns at the issue priority, on a handful of waves (FZP_SWB_GRID) so that the job's ~30 groups wait for each other -- hundreds of hand-overs through HBM, the same bits
@@ -527,11 +530,14 @@ def test_the_three_dp_kernels_agree(eng, oracle, monkeypatch):
         job.close()
         for k in env:
             monkeypatch.delenv(k)
-    exp, _ = oracle_lib.align_reads(oracle, ctg, reads, n_threads=8)
+    exp = {32: oracle_lib.align_reads(oracle, ctg, reads, {"band": 32}, n_threads=8)[0], 64: oracle_lib.align_reads(oracle, ctg, reads, {"band": 64}, n_threads=8)[0]}
+    both = (exp[32]["aligned"] == 1) & (exp[64]["aligned"] == 1)
+    assert np.mean(exp[32]["score"][both] >= exp[64]["score"][both]) >= 0.97 and not np.array_equal(exp[32]["cells"], exp[64]["cells"])      # (on nearly every read the narrower band finds the same score)
     for mode, (s, cg) in got.items():
+        band = 64 if mode.startswith("band64") else 32
         for f in FIELDS:
-            assert np.array_equal(s[f], exp[f]), (mode, f, np.flatnonzero(s[f] != exp[f])[:5])
-        assert cg == got["default"][1], mode
+            assert np.array_equal(s[f], exp[band][f]), (mode, f, np.flatnonzero(s[f] != exp[band][f])[:5])
+        assert cg == got["band64" if band == 64 else "default"][1], mode
     assert got["default"][0]["aligned"].mean() > 0.8            # (reads of a few hundred bases rarely gather 8 seed votes)
 
 

@@ -312,7 +312,7 @@ def test_whole_mask_mode_in_chunks_stays_inside_its_budget(monkeypatch):
     job = _lib.align_job_raw(e1, contigs, blob, off, rctg)
     job.run()
     s0, h0 = job.summaries().copy(), job.cigar_hashes().copy()
-    steps = int(s0["cells"].sum()) // 64
+    steps = int(s0["cells"].sum()) // _lib.align_band()
     job.close(); e1.close()
     monkeypatch.setenv("FZP_SW_NO_BITS", "1")
     monkeypatch.setenv("FZP_TB_BUDGET_GB", "1")

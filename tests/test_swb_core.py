@@ -37,13 +37,16 @@ def _mutate(rng, seq, sub, ins, dele):
     return np.array(out, np.uint8)
 
 
-def _both(oracle, swb, q, t, inner=0):
+def _both(oracle, swb, q, t, inner=0, band=64):
+    """-> [twin, host loop of the one-lane form, host loop of the pair form] for the 64-cell band; [twin, host loop of swb_step32's form] for the 32-cell one (fzalign v1.8)"""
     nq, nt = len(q), len(t)
     cap = nq + nt + 8
     P = oracle_lib.AlignParams()
     oracle.lib.orc_align_params_default(C.byref(P))
+    P.band = band
     res = []
-    for fn, extra in ((oracle.lib.orc_dp_extend_raw, True), (swb.swb_extend_host, False), (swb.swb_extend_pair_host, False)):
+    forms = ((oracle.lib.orc_dp_extend_raw, True), (swb.swb_extend_host, False), (swb.swb_extend_pair_host, False)) if band == 64 else ((oracle.lib.orc_dp_extend_raw, True), (swb.swb_extend_host32, False))
+    for fn, extra in forms:
         D = np.zeros(cap, np.uint64); G = np.zeros(cap, np.uint64); mv = np.zeros(cap, np.uint8); out = np.zeros(4, np.int64)
         fn.restype = C.c_int
         args = [q.ctypes.data_as(C.c_void_p), C.c_int64(nq), t.ctypes.data_as(C.c_void_p), C.c_int64(nt)]
@@ -55,14 +58,14 @@ def _both(oracle, swb, q, t, inner=0):
     return res
 
 
-def _compare(a, b, nq, nt):
+def _compare(a, b, nq, nt, band=64):
     (D0, G0, m0, o0), (D1, G1, m1, o1) = a, b
     assert tuple(o0) == tuple(o1), (tuple(o0), tuple(o1))
     steps = int(o0[0])
     assert np.array_equal(m0[:steps], m1[:steps])
-    i0 = -33 + np.cumsum(m0[:steps].astype(np.int64))
+    i0 = -(band // 2 + 1) + np.cumsum(m0[:steps].astype(np.int64))
     tt = np.arange(steps, dtype=np.int64)
-    k = np.arange(64, dtype=np.int64)
+    k = np.arange(band, dtype=np.int64)
     i = i0[:, None] + k[None, :]
     j = tt[:, None] - i
     real = (i >= 0) & (i < nq) & (j >= 0) & (j < nt)                 # the cells a walk can visit
@@ -93,6 +96,10 @@ def test_masks_moves_terminal_equal_the_twin(oracle, swb, seed, L, sub, ins, del
         a, b, c = _both(oracle, swb, q, t, inner=1)
         _compare(a, b, nq, nt)
         _compare(a, c, nq, nt)
+        # fzalign v1.8: the 32-cell band (one register per plane: swb_step32's form) against the twin with band = 32, free and inner
+        for inner in (0, 1):
+            a, b = _both(oracle, swb, q, t, inner=inner, band=32)
+            _compare(a, b, nq, nt, band=32)
 
 
 def test_unrelated_sequences_and_low_complexity(oracle, swb):
@@ -106,6 +113,8 @@ def test_unrelated_sequences_and_low_complexity(oracle, swb):
         a, b, c = _both(oracle, swb, q, t)
         _compare(a, b, len(q), len(t))
         _compare(a, c, len(q), len(t))
+        a, b = _both(oracle, swb, q, t, band=32)
+        _compare(a, b, len(q), len(t), band=32)
 
 
 def test_interior_block_never_touches_a_border(swb):

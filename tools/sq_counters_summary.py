@@ -23,10 +23,11 @@ def main():
         line = json.load(open(sys.argv[3]))
         # band steps of ONE bench step: forward extensions of all candidates + the backward extensions (fzp_aln_summary.cells counts them all); the counter pass
         # ran exactly one step (bench.py --steps 1 --warmup 0), so the sums over every k_sw launch of the pass belong to these steps
-        steps = line["dp_cells_per_step"] / 64.0
+        band = line.get("roofline", {}).get("band_cells", 64)      # fzalign v1.8: 32 cells per band step (v1.7: 64)
+        steps = line["dp_cells_per_step"] / float(band)
         sw = tot["k_sw"] + tot["k_swb"]          # the two DP kernels: the bit-sliced one (a read per lane) and the wave-per-read one
         calls["k_sw"] += calls["k_swb"]
-        json.dump({"kernel": "k_swb + k_sw", "band_steps_per_bench_step": steps, "valu_k_swb": tot["k_swb"]["SQ_INSTS_VALU"], "valu_k_sw": tot["k_sw"]["SQ_INSTS_VALU"], "valu_per_step": round(sw["SQ_INSTS_VALU"] / steps, 3),
+        json.dump({"kernel": "k_swb + k_sw", "band": band, "band_steps_per_bench_step": steps, "valu_k_swb": tot["k_swb"]["SQ_INSTS_VALU"], "valu_k_sw": tot["k_sw"]["SQ_INSTS_VALU"], "valu_per_step": round(sw["SQ_INSTS_VALU"] / steps, 3),
                    "salu_per_step": round(sw["SQ_INSTS_SALU"] / steps, 3), "smem_per_step": round(sw["SQ_INSTS_SMEM"] / steps, 3),
                    "launches_counted": calls["k_sw"], "source": sys.argv[5] if len(sys.argv) > 5 else sys.argv[2]}, open(sys.argv[4], "w"), indent=1)
 
