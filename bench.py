@@ -706,6 +706,24 @@ def main():
         for k in sect:
             sect[k] += st[k]
 
+    # N > 1: what ONE of these GPUs does on its own, on this node, in this process group -- rank 0 alone runs a few steps (no collective: nobody else is there) while the
+    # others wait at the barrier; `scaling_estimate` in the line holds the N-rank rate against it, so that a sub-linear SCALE curve can be read off ONE line
+    solo_ms = None
+    if world > 1 and not args.strong:
+        barrier()
+        if rank == 0 and job is not None:
+            def solo(k):
+                st_, _ = job.phase_write(ids, names=name_tab, out_dir=os.path.join(out_root, "solo%02d" % k), read_maps=maps, ctg_index=mine, consensus=args.with_consensus,
+                                         async_writes=True, rebuild_index=not args.index_at_create)
+            for k in range(2):
+                solo(k)
+            eng.synchronize(); eng.pipe_flush()
+            t_s = time.perf_counter()
+            for k in range(5):
+                solo(2 + k)
+            eng.synchronize(); eng.pipe_flush()
+            solo_ms = (time.perf_counter() - t_s) / 5 * 1e3
+        barrier()
     for _ in range(args.warmup):
         step()
     for k in host_t:
@@ -716,6 +734,7 @@ def main():
     eng.prof_enable(2 if prof_on else 0)      # the timed steps bracket the DP stage only (what the roofline needs); every other kernel's time comes from an instrumented pass below
     barrier()
     thr0 = thread_cpu() if os.environ.get("FZP_BENCH_THREAD_CPU") else None
+    cg0 = cgroup_throttle()
     t0 = time.perf_counter()
     cpu0 = time.process_time()
     for _ in range(args.steps):
@@ -723,6 +742,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     cpu_ms_per_step = (time.process_time() - cpu0) / args.steps * 1e3      # user + system time of every thread of this rank (launch thread, host workers, file writers)
+    cg_steps = throttle_delta(cg0, cgroup_throttle())
     if thr0 is not None and rank == 0:                                     # measurement aid: which threads that time belongs to
         thr1 = thread_cpu()
         rows = sorted(((thr1[t][1] - thr0.get(t, (thr1[t][0], 0.0, 0.0))[1], thr1[t][2] - thr0.get(t, (thr1[t][0], 0.0, 0.0))[2], thr1[t][0], t) for t in thr1), reverse=True)
@@ -752,11 +772,24 @@ def main():
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         dist.all_reduce(tt, op=dist.ReduceOp.SUM)
         my_dt, dt, n_total = dt, float(mx[0].item()), int(tt[1].item())
-        per_rank = [torch.zeros(2, dtype=torch.float64, device=coll_dev) for _ in range(world)]
-        dist.all_gather(per_rank, torch.tensor([my_dt, float(n_reads)], dtype=torch.float64, device=coll_dev))
-        rank_load = [{"rank": r, "reads": int(p[1].item()), "ms_per_step": round(float(p[0].item()) / args.steps * 1e3, 3)} for r, p in enumerate(per_rank)]
+        # every rank says what ITS steps were made of: a slow rank then names its cause in the one line rank 0 prints (host CPU per step, the calling thread's time in
+        # phase_write and in the gather, its longest kernel bracket, how often its cgroup stopped it)
+        slowest_k = max(((v[0] / max(1, v[1]), k) for k, v in prof.items()), default=(0.0, ""))
+        knames = sorted(prof)
+        mine_v = [my_dt, float(n_reads), cpu_ms_per_step, host_t["phase_write"] / args.steps * 1e3, host_t["allgather"] / args.steps * 1e3, slowest_k[0],
+                  float(knames.index(slowest_k[1])) if slowest_k[1] in knames else -1.0,
+                  float(cg_steps["nr_throttled"]) if cg_steps else -1.0, float(cg_steps["throttled_ms"]) if cg_steps else -1.0]
+        per_rank = [torch.zeros(len(mine_v), dtype=torch.float64, device=coll_dev) for _ in range(world)]
+        dist.all_gather(per_rank, torch.tensor(mine_v, dtype=torch.float64, device=coll_dev))
+        rank_load = [{"rank": r, "reads": int(p[1].item()), "ms_per_step": round(float(p[0].item()) / args.steps * 1e3, 3), "host_cpu_ms_per_step": round(float(p[2].item()), 2),
+                      "phase_write_ms": round(float(p[3].item()), 3), "gather_ms": round(float(p[4].item()), 3),
+                      "slowest_bracket": {"name": knames[int(p[6].item())] if 0 <= int(p[6].item()) < len(knames) else None, "ms": round(float(p[5].item()), 3)},
+                      "cgroup": None if p[7].item() < 0 else {"nr_throttled": int(p[7].item()), "throttled_ms": round(float(p[8].item()), 2)}} for r, p in enumerate(per_rank)]
     else:
-        rank_load = [{"rank": 0, "reads": n_reads, "ms_per_step": round(dt / args.steps * 1e3, 3)}]
+        slowest_k = max(((v[0] / max(1, v[1]), k) for k, v in prof.items()), default=(0.0, ""))
+        rank_load = [{"rank": 0, "reads": n_reads, "ms_per_step": round(dt / args.steps * 1e3, 3), "host_cpu_ms_per_step": round(cpu_ms_per_step, 2),
+                      "phase_write_ms": round(host_t["phase_write"] / args.steps * 1e3, 3), "gather_ms": round(host_t["allgather"] / args.steps * 1e3, 3),
+                      "slowest_bracket": {"name": slowest_k[1] or None, "ms": round(slowest_k[0], 3)}, "cgroup": cg_steps}]
 
     summ = job.summaries() if job is not None else np.zeros(0, dtype=[("cells", "<i8"), ("aligned", "<i4")])
     cells_per_step = float(summ["cells"].sum())
@@ -921,6 +954,12 @@ def main():
             "out_fs": fs_of(out_root), "sched_flag_rc": _lib.sched_status(),      # 0: the runtime took the blocking-sync scheduling flag
             "host_wall_ms_per_step": dict({k: round(v / args.steps * 1e3, 3) for k, v in host_t_timed.items()}, **{k[3:]: round(v / args.steps, 3) for k, v in sect_timed.items()}),
             "rank_load": rank_load,
+            # N > 1: this run's rate against rank 0 running the same step ALONE on its GPU a moment earlier (same node, same process group): what the driver's SCALE curve
+            # will show for this N, from one line -- with rank_load saying which rank held the others up and with what
+            "scaling_estimate": ({"solo_ms_per_step": round(solo_ms, 3), "solo_reads_per_s": round(n_reads / (solo_ms * 1e-3), 1), "n_gpus": world,
+                                  "speedup_vs_one_gpu": round((n_total / (dt / args.steps)) / (n_reads / (solo_ms * 1e-3)), 3),
+                                  "slowest_rank": max(rank_load, key=lambda r: r["ms_per_step"])["rank"], "out_fs": out_root}
+                                 if (solo_ms and world > 1) else None),
             "gather": "fzp_allgather_rid_to_phase (RCCL, C-ABI)" if comm is not None else ("torch.distributed all_gather (%s)" % backend if world > 1 else "none (1 rank)"),
             "rccl_ranks": comm.ranks()[1] if comm is not None else 0,      # size of the RCCL communicator as ncclCommCount reports it (0: no RCCL communicator in this run)
             "gather_fallback": gather_note,                                  # why the C-ABI RCCL gather was not used (the library's own error text inside), or None

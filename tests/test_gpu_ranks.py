@@ -251,6 +251,11 @@ def test_eight_rank_dry_run_of_the_bench():
     assert d["n_gpus"] == 8 and d["scaling"] == "weak" and len(d["rank_load"]) == 8 and d["stage_counts"]["r2p_records"] == 8 * 120
     assert d["config"]["reads_total"] == 960 and all(r["reads"] == 120 for r in d["rank_load"])
     assert "rccl_path" in d and "rccl_version" in d and d["gather_fallback"] is None and "error" not in d["from_files"] and d["from_files"]["n_gpus"] == 8
+    # r6: the line says what every rank's step was made of, and how the N ranks compare with one of them running alone a moment earlier
+    for r in d["rank_load"]:
+        assert {"host_cpu_ms_per_step", "phase_write_ms", "gather_ms", "slowest_bracket", "cgroup"} <= set(r) and r["slowest_bracket"]["name"] and r["host_cpu_ms_per_step"] > 0
+    se = d["scaling_estimate"]
+    assert se["n_gpus"] == 8 and se["solo_ms_per_step"] > 0 and 0 < se["speedup_vs_one_gpu"] < 16 and 0 <= se["slowest_rank"] < 8
     sc = d["strong_cfg3"]
     assert "error" not in sc, sc
     assert sc["n_gpus"] == 8 and sum(r["contigs"] for r in sc["rank_load"]) == 12 and sc["reads_total"] == sc["r2p_records"]
