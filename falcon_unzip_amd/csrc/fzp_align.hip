@@ -1,5 +1,5 @@
 // fzp_align.hip -- K1: read -> contig alignment on gfx950 (the role of blasr + samtools sort,
-// falcon_unzip/unzip.py:86-91).  Spec "fzalign v1.6": oracle/align_oracle.c is its scalar twin and the
+// falcon_unzip/unzip.py:86-91).  Spec "fzalign v1.8" (anchored k-mers since v1.7, a band of 32 cells since v1.8; 64 selectable): oracle/align_oracle.c is its scalar twin and the
 // kernels here match it bit-for-bit (summaries, CIGAR words, DP cell counts).  Parity vs blasr itself
 // is UNPINNED (third-party binary, not vendored).
 //
@@ -9,8 +9,8 @@
 //   k_chain       per (read, window): the longest chain of hits (strict links, bridges over seedless stretches) -> anchor + WAYPOINTS every >= `piece` bases
 //   k_slot_*      per read: its extension PIECES (waypoint to waypoint, the free end, the backward extension; both candidates) as DP slots;
 //   k_sort_*, k_route, k_lists, k_plan_final: slots by decreasing length, dealt to the two DP kernels, their mask streams planned in launch order -- all on the device
-//   k_swb / k_swb2 the banded DP, bit-sliced: one slot per lane (per pair of lanes); k_sw: one wave per slot (slots narrower than the band).  Per step two
-//                 64-bit trace-back masks go to HBM.  Integer VALU-bound, no MFMA.
+//   k_swb / k_swb2 the banded DP, bit-sliced: one slot per lane (per pair of lanes); k_sw: one wave per slot (slots narrower than the band).  Per step the
+//                 D and G trace-back masks go to HBM (8 bytes: at band 32 the whole masks, at band 64 their middle 32 lanes).  Integer VALU-bound, no MFMA.
 //   k_tb_walk     per slot, one lane: walks the masks back from the terminal, emits a 2-bit op stream
 //   k_join        per read, one wave: candidate selection, the winner's pieces joined into one op stream
 //   k_tb_cigar    per read, one wave: best sub-path, op stream -> forward run-length CIGAR, clips, summary
@@ -904,7 +904,7 @@ __device__ __forceinline__ void scalar_store16(void *base, uint32_t byte_off, ui
 //   * bases entering the band come from two 64-bit SGPR windows (32 bases each, enough for a whole block):
 //     s_bfe_u64 picks the next one, v_writelane drops it into lane 63 (DOWN) / lane 0 (RIGHT);
 //   * moves are collected in a 32-bit shift register (first step of the block ends up in the highest used bit); its bit 0 is the block's last
-//     move, so the steps do not keep a "previous move" register up to date (one SALU less per step: the scalar port has no slack).
+//     move, so the steps do not keep a "previous move" register up to date (one SALU less per step: the scalar port has no slack, see HISTORY.md section 14).
 // The store offset is the step counter: it enters 16 * steps below 2^31 and the signed overflow of its increment ends the block.
 // No DPP source is written fewer than two instructions before it is read (gfx9 DPP hazard).
 #define SWB_DPP_SHL " wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0"
@@ -1544,7 +1544,7 @@ k_swb(const uint64_t *__restrict__ n_b_dev, const uint32_t *__restrict__ list, c
         const int32_t t_end = t + (int32_t)(ub * 64u);
     while (t < t_end && __ballot(active)) {
         const bool blk_active = active;
-        const int32_t i0_blk = L.i0, e2_blk = L.E2;      // (E2 at the block's first step rides in the move word's spare half: where in the band the path is likely to be)
+        const int32_t i0_blk = L.i0, e2_blk = L.E2;      // (E2 at the block's first step rides in the move word's spare half: where in the band the path is likely to be, HISTORY.md section 14)
         L.mvacc = 0;
         if (dbg & 4) { if ((((uint32_t)__builtin_amdgcn_s_memrealtime() >> 11) ^ wid) & 1u) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
         // an interior block?  every running lane more than 64 steps away from its last row and its last column (a step brings either one closer by at most one)
@@ -2781,7 +2781,7 @@ __global__ void __launch_bounds__(256) k_gather16(int64_t n_rec, const int64_t *
 
 // ================================================================================ job
 // One forward DP at a time per device.  The DP kernels of two jobs (two contexts in one process: the lanes of fzp_phase_contigs, two steps in flight) running side by side
-// land on each other's SIMDs and both run at little more than half speed; queued one behind the other each has the chip to itself, and everything else
+// land on each other's SIMDs and both run at little more than half speed (HISTORY.md section 14); queued one behind the other each has the chip to itself, and everything else
 // of the two jobs still overlaps.  The chain is made of events: a job's DP launches wait for the event the previous job recorded behind its own (no host thread ever blocks).
 static std::mutex g_dp_mu;
 static std::map<int, hipEvent_t> g_dp_last;

@@ -4,16 +4,18 @@
  * PARITY UNPINNED vs the reference: FALCON_unzip shells out to `blasr` (falcon_unzip/unzip.py:86-88),
  * a third-party C++ aligner that is not vendored under /root/reference and whose results
  * (placement, clipping, `--hitPolicy randombest --randomSeed 42` tie-breaks) cannot be reproduced
- * here.  This file therefore DEFINES the aligner ("fzalign v1.7"); the HIP kernels in
+ * here.  This file therefore DEFINES the aligner ("fzalign v1.8"); the HIP kernels in
  * falcon_unzip_amd/csrc/fzp_align.hip must match it bit-for-bit (summaries, CIGARs, DP cell counts),
  * and its quality is judged against the simulator's true alignments.
  *
- * fzalign v1.7  (v1.1: one index position per k-mer, one candidate placement per read, no identity gate; v1.2: multi-position index, two
+ * fzalign v1.8  (v1.1: one index position per k-mer, one candidate placement per read, no identity gate; v1.2: multi-position index, two
  *               candidates, chains; v1.3: best-start soft clip; v1.4: anchor = the chain's first hit, extension forward AND backward from it;
  *               v1.5: an extension runs to the matrix BORDER, the alignment is the best-scoring stretch of the joined path;
  *               v1.6: the chain's hits every >= PIECE read bases are WAYPOINTS, the forward extension is a sequence of independent banded DPs from one
  *               waypoint to the next (what blasr does between the anchors of its chain, unzip.py:86-88), free ends are limited;
- *               v1.7: index and look-ups use the ANCHORED k-mers -- those that start with AC or end with GT -- instead of fixed strides)
+ *               v1.7: index and look-ups use the ANCHORED k-mers -- those that start with AC or end with GT -- instead of fixed strides;
+ *               v1.8: the DP band is a parameter, 32 cells by default (orc_align_params.band, FZP_ALIGN_BAND; 64 = v1.7's): same scores on every compared read,
+ *               profiles/r6_band32_go_nogo.txt)
  *   bases     A/a C/c G/g T/t -> 0..3, anything else -> 0
  *   selected  (v1.7) a k-mer position p is SELECTED iff bases p, p+1 are A, C or bases p+k-2, p+k-1 are G, T: about an eighth of the positions, decided by the
  *             k-mer alone -- the contig and a read select the same k-mers wherever they agree, on either strand (a k-mer ends with GT exactly when its reverse
@@ -65,12 +67,12 @@
  *             over the alignment (exact); the alignment is dropped (unaligned) when
  *             100*n_match < 70*(columns + inserted + deleted bases of the trimmed alignment)
  *             (blasr --minPctIdentity 70.0, unzip.py:87).
- *   extension adaptive anti-diagonal band of 64 cells (Suzuki-Kasahara style) from the cell before the anchor
+ *   extension adaptive anti-diagonal band of B cells (B = 32 since v1.8, 64 before; Suzuki-Kasahara style) from the cell before the anchor
  *             (origin (-1, -1) of the anchor-relative matrix): linear gaps, H = max(diag + (match | -mismatch), up - gap, left - gap), no zero
- *             floor; the first 64 steps alternate down/right, afterwards the band moves RIGHT when
- *             H[lane 0] > H[lane 63], else DOWN.  The diagonal operand is H of two steps ago in that
+ *             floor; the first B steps alternate down/right, afterwards the band moves RIGHT when
+ *             H[lane 0] > H[lane B-1], else DOWN.  The diagonal operand is H of two steps ago in that
  *             step's own lane layout: the predecessor of lane k sits in lane k - 1 + (number of DOWN
- *             moves among the last two); a lane outside 0..63 reads as minus infinity.  The extension's TERMINAL is the best-scoring valid cell
+ *             moves among the last two); a lane outside 0..B-1 reads as minus infinity.  The extension's TERMINAL is the best-scoring valid cell
  *             of the matrix border -- the read's last row or the window's last column -- (first in step order, then lowest lane): the
  *             DP needs no score of any other cell, only which of the three moves won (v1.5).  Trace-back priority: diagonal, then the gap whose source is the
  *             same lane of the previous step (the cell above after a DOWN move, the cell to the left

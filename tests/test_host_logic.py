@@ -388,3 +388,14 @@ def test_bench_scratch_choice_and_step_timeline(tmp_path):
                          capture_output=True, text=True, check=True).stdout
     assert "3 launches" in out and "40.0  k_swb<true> -> k_tb_walk_h" in out
     assert "k_tb_walk_h" in (tmp_path / "l.txt").read_text()
+
+
+def test_design_is_the_short_current_state_document_with_a_generated_kernel_table():
+    """DESIGN.md <= 30 KB, its kernel table = what tools/design_kernel_table.py makes of the last profiles/r6?_* set; the log lives in HISTORY.md."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert os.path.getsize(os.path.join(root, "DESIGN.md")) <= 30 * 1024
+    assert os.path.exists(os.path.join(root, "HISTORY.md"))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "design_kernel_table.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""The go / no-go table of a 32-cell band (fzalign v1.8; VERDICT r5 item 3's fallback): the TWIN first, no kernel touched.  The scalar twin with
+"""The go / no-go table of a 32-cell band (fzalign v1.8; VERDICT r5 item 3's fallback, HISTORY.md section 14): the TWIN first, no kernel touched.  The scalar twin with
 `band` = 64 and = 32 (orc_align_params.band), same reads, the quantities the GPU tests hold the aligner to:
     python3 tools/runs/band32_go_nogo.py > profiles/r6_band32_go_nogo.txt
 CPU only (a few minutes on 8 cores)."""

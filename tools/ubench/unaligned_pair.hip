@@ -1,5 +1,5 @@
 // Why did k_revcomp's first word-at-a-time form (its 16-base window through kmer_at: two adjacent 32-bit words as one 64-bit window) return wrong UPPER halves in ~0.2 % of the
-// words, different ones every run?  This probe runs (a) that exact form again and says WHERE the bad words are -- the byte address of the window's
+// words, different ones every run (HISTORY.md section 14, r5)?  This probe runs (a) that exact form again and says WHERE the bad words are -- the byte address of the window's
 // low word modulo 4096 -- and (b) the bare pattern: every 4-byte-aligned pair of a buffer whose word i holds i, read as the compiler reads kmer_at's two words, checked in place.
 // Build: hipcc --offload-arch=gfx950 -O3 --save-temps -o unaligned_pair unaligned_pair.hip   (the .s beside it shows what the two loads became)
 #include <hip/hip_runtime.h>
