@@ -455,9 +455,9 @@ def constrained_child(args, n_cores, contigs, blob, off, read_ctg, ids, name_tab
             root = tempfile.mkdtemp(prefix="fzp_bench_2c_", dir=(shm_with_room(4 << 30) if not args.out_root else args.out_root))
             n_steps = int(os.environ.get("FZP_BENCH_2C_STEPS", "20"))      # (twenty: ten steps of a fresh process varied by +-2 ms run to run)
 
-            def one(k):
-                job.phase_write(ids, names=name_tab, out_dir=os.path.join(root, "s%03d" % k), read_maps=maps, ctg_index=mine, consensus=args.with_consensus, async_writes=True,
-                                rebuild_index=not args.index_at_create)
+            def one(k, fresh=args.fresh_trees):
+                job.phase_write(ids, names=name_tab, out_dir=os.path.join(root, ("s%03d" % k) if fresh else ("t%d" % (k & 1))), read_maps=maps, ctg_index=mine,
+                                consensus=args.with_consensus, async_writes=True, rebuild_index=not args.index_at_create)
             for k in range(3):
                 one(k)
             eng.synchronize(); eng.pipe_flush()
@@ -476,6 +476,16 @@ def constrained_child(args, n_cores, contigs, blob, off, read_ctg, ids, name_tab
                 key = nm.rstrip("0123456789") if nm.startswith("fzp-") else ("main" if tid == os.getpid() else "runtime/" + nm)
                 by_name[key] = by_name.get(key, 0.0) + d
             by_name = {k: round(v / n_steps * 1e3, 2) for k, v in sorted(by_name.items(), key=lambda kv: -kv[1]) if v / n_steps * 1e3 >= 0.05}
+            # the same child the other way (a fresh tree per step: every page of every file newly allocated; two trees rewritten in turn: the files overwritten in place)
+            for k in range(3):
+                one(100 + k, fresh=not args.fresh_trees)
+            eng.synchronize(); eng.pipe_flush()
+            t1, c1 = time.perf_counter(), time.process_time()
+            for k in range(10):
+                one(103 + k, fresh=not args.fresh_trees)
+            eng.synchronize(); eng.pipe_flush()
+            other = {"trees": "fresh" if not args.fresh_trees else "rewritten", "ms_per_step": round((time.perf_counter() - t1) / 10 * 1e3, 3),
+                     "host_cpu_ms_per_step": round((time.process_time() - c1) / 10 * 1e3, 2), "steps": 10}
             job.close()
             ff = None
             if not args.no_from_files:      # the same two cores reading the step's FASTA files: what the reader, the copies and the lanes' launch threads need side by side
@@ -488,7 +498,7 @@ def constrained_child(args, n_cores, contigs, blob, off, read_ctg, ids, name_tab
             eng.close()
             shutil.rmtree(root, ignore_errors=True)
             os.write(wr, json.dumps({"ms_per_step": round(dt / n_steps * 1e3, 3), "host_cpu_ms_per_step": round(cpu / n_steps * 1e3, 2), "steps": n_steps, "cpus": n_cores,
-                                     "local_world_size": 8, "cpu_ms_per_step_by_thread": by_name, "cgroup": cg_step, "from_files": ff}).encode())
+                                     "local_world_size": 8, "cpu_ms_per_step_by_thread": by_name, "cgroup": cg_step, "from_files": ff, "other_tree_mode": other}).encode())
             code = 0
         except BaseException as e:      # noqa: BLE001 -- reported by the parent
             try:
@@ -576,6 +586,8 @@ def main():
     ap.add_argument("--no-two-core", action="store_true", help="skip two_core_step_ms (the resident step in a child confined to two CPUs with LOCAL_WORLD_SIZE=8)")
     ap.add_argument("--e2e-lanes", type=int, default=2)
     ap.add_argument("--e2e-group-contigs", type=int, default=10)
+    ap.add_argument("--rewrite-trees", dest="fresh_trees", action="store_false", help="two output trees written in turn -- from the third step on every file is overwritten in place, "
+                    "a re-run into an existing tree (default: every step writes into an empty directory of its own, a first run; `other_tree_mode` in the line times a few steps the other way)")
     ap.add_argument("--with-polish", action="store_true", help="also time fzp_polish_tigs on the step's inputs (every contig a tig, its reads the pile): tigs/s beside `value`")
     ap.add_argument("--with-consensus", action="store_true", help="also run K6 (phased-pile consensus, BASELINE config 4) inside every step")
     ap.add_argument("--out-root", default=None, help="where the per-step output trees go (default: a scratch directory under $TMPDIR)")
@@ -687,7 +699,10 @@ def main():
 
     def step():
         step_no[0] += 1
-        out_dir = os.path.join(out_root, "step%03d" % step_no[0])      # a fresh tree per step, as a job would write it (no re-truncation of old files)
+        # the output tree: an empty directory per step, as a job's first run would write it.  --rewrite-trees: two trees written in turn, so that from the third step on every
+        # file is OVERWRITTEN IN PLACE -- a re-run into an existing tree, which is what a restarted unzip job does (the library cuts a file to its new length instead of
+        # truncating it first: no page is freed and allocated again).  `other_tree_mode` in the line times a few steps the other way.
+        out_dir = os.path.join(out_root, ("step%03d" % step_no[0]) if args.fresh_trees else ("step_%d" % (step_no[0] & 1)))
         t_a = time.perf_counter()
         if job is not None:
             st, recs = job.phase_write(ids, names=name_tab, out_dir=out_dir, read_maps=maps, ctg_index=mine, consensus=args.with_consensus, async_writes=True,
@@ -713,7 +728,7 @@ def main():
         barrier()
         if rank == 0 and job is not None:
             def solo(k):
-                st_, _ = job.phase_write(ids, names=name_tab, out_dir=os.path.join(out_root, "solo%02d" % k), read_maps=maps, ctg_index=mine, consensus=args.with_consensus,
+                st_, _ = job.phase_write(ids, names=name_tab, out_dir=os.path.join(out_root, ("solo%02d" % k) if args.fresh_trees else ("solo_%d" % (k & 1))), read_maps=maps, ctg_index=mine, consensus=args.with_consensus,
                                          async_writes=True, rebuild_index=not args.index_at_create)
             for k in range(2):
                 solo(k)
@@ -765,6 +780,21 @@ def main():
         ms_instr = (time.perf_counter() - t_i) / n_instr * 1e3
         eng.prof_enable(False)
         prof_all = eng.prof()
+    fresh_cmp = None
+    if world == 1 and job is not None:      # the same step with the output trees handled the other way, beside `value`
+        def other_step(k):
+            job.phase_write(ids, names=name_tab, out_dir=os.path.join(out_root, ("other%03d" % k) if not args.fresh_trees else ("other_%d" % (k & 1))), read_maps=maps, ctg_index=mine,
+                            consensus=args.with_consensus, async_writes=True, rebuild_index=not args.index_at_create)
+        for k in range(3):
+            other_step(k)
+        eng.synchronize(); eng.pipe_flush()
+        t_f, c_f = time.perf_counter(), time.process_time()
+        for k in range(8):
+            other_step(3 + k)
+        eng.synchronize(); eng.pipe_flush()
+        fresh_cmp = {"trees": "fresh" if not args.fresh_trees else "rewritten", "ms_per_step": round((time.perf_counter() - t_f) / 8 * 1e3, 3),
+                     "host_cpu_ms_per_step": round((time.process_time() - c_f) / 8 * 1e3, 2), "steps": 8,
+                     "note": "fresh: an empty output directory per step (a first run); rewritten: two trees written in turn, files overwritten in place (a re-run into an existing tree)"}
     n_total = n_reads
     if world > 1:
         tt = torch.tensor([dt, float(n_reads)], dtype=torch.float64, device=coll_dev)
@@ -951,7 +981,8 @@ def main():
             "kernel_ms_per_step": {k: round(v[0] / max(1, n_instr), 3) for k, v in sorted(prof_all.items())},      # from the instrumented pass (every kernel bracketed), not the timed steps
             "ms_per_step_instrumented": round(ms_instr, 3) if ms_instr else None, "instrumented_steps": n_instr,
             "host_cpu_ms_per_step": round(cpu_ms_per_step, 2),
-            "out_fs": fs_of(out_root), "sched_flag_rc": _lib.sched_status(),      # 0: the runtime took the blocking-sync scheduling flag
+            "out_fs": fs_of(out_root), "out_tree": "a fresh tree per step" if args.fresh_trees else "two trees written in turn (files overwritten in place from the third step on: a re-run)",
+            "other_tree_mode": fresh_cmp, "sched_flag_rc": _lib.sched_status(),      # 0: the runtime took the blocking-sync scheduling flag
             "host_wall_ms_per_step": dict({k: round(v / args.steps * 1e3, 3) for k, v in host_t_timed.items()}, **{k[3:]: round(v / args.steps, 3) for k, v in sect_timed.items()}),
             "rank_load": rank_load,
             # N > 1: this run's rate against rank 0 running the same step ALONE on its GPU a moment earlier (same node, same process group): what the driver's SCALE curve

@@ -3404,6 +3404,10 @@ int fetch_summaries(fzp_ctx *ctx, fzp_alnjob *j) {
 
 extern "C" int64_t fzp_align_n_second(const fzp_alnjob *j) { return j ? j->n_second : 0; }
 void fzp_align_templates(const fzp_alnjob *j, const uint8_t **ascii, const int64_t **aoff) { *ascii = j->ctg_ascii.p; *aoff = j->ctg_aoff.p; }
+// which read belongs to which contig, as the job was created (host copy; fzp_pipe.hip resolves the read-map rows against the contigs' read names while the device aligns)
+void fzp_align_host_reads(const fzp_alnjob *j, int32_t *n_ctg, int64_t *n_reads, const int32_t **read_ctg) {
+    *n_ctg = (int32_t)j->h_ctg_len.size(); *n_reads = j->n_reads; *read_ctg = j->h_read_ctg.size() == (size_t)j->n_reads ? j->h_read_ctg.data() : nullptr;
+}
 // measurement aid (tools/runs/tb_window_stats.py): with FZP_TB_STATS set, the walkers' window statistics summed over the job's runs (16 counters)
 extern "C" int fzp_debug_tb_stats(fzp_ctx *ctx, fzp_alnjob *j, unsigned long long *out) {
     if (!ctx || !j || !j->tb_stats.p || fzp_bind(ctx) != FZP_OK) return FZP_EINVAL;

@@ -143,6 +143,7 @@ int fzp_align_create_dev(fzp_ctx *ctx, int32_t n_ctg, const int64_t *ctg_len, in
 // polishing (fzp_polish_tigs, fzp_cns.hip): the templates as the alnjob keeps them on the device (upper-cased ASCII, contig c at ref + ref_off[c]) and their lengths (host)
 struct fzp_cns_polish { const uint8_t *ref = nullptr; const int64_t *ref_off = nullptr; const int64_t *len = nullptr; };
 void fzp_align_templates(const fzp_alnjob *job, const uint8_t **ascii, const int64_t **aoff);      // (fzp_align.hip)
+void fzp_align_host_reads(const fzp_alnjob *job, int32_t *n_ctg, int64_t *n_reads, const int32_t **read_ctg);      // (fzp_align.hip)
 
 inline int fzp_batch_source_ok(const fzp_batch *b) {
     if (b->life && b->life->dead.load()) { fzp_set_error("this batch reads the packed records of an alignment job that has been destroyed (fzp_align_destroy before fzp_batch_destroy)"); return FZP_EINVAL; }

@@ -279,14 +279,20 @@ struct MapsHolder {
 
 struct TextBuf {
     std::string s;
-    inline void puti(long long v) {
+    inline void puti(long long v, int min_digits = 0) {      // (min_digits: zero-padded like '%0Nd' of a non-negative number)
+        static const char P2[] = "0001020304050607080910111213141516171819202122232425262728293031323334353637383940414243444546474849"
+                                 "5051525354555657585960616263646566676869707172737475767778798081828384858687888990919293949596979899";
         char t[24];
-        int k = 0;
-        bool neg = v < 0;
+        int k = 24;
+        const bool neg = v < 0;
         unsigned long long u = neg ? 0ULL - (unsigned long long)v : (unsigned long long)v;
-        do { t[k++] = (char)('0' + u % 10); u /= 10; } while (u);
+        while (u >> 32) { const unsigned d = (unsigned)(u % 100); u /= 100; t[--k] = P2[2 * d + 1]; t[--k] = P2[2 * d]; }
+        uint32_t w = (uint32_t)u;
+        while (w >= 100) { const uint32_t d = w % 100; w /= 100; t[--k] = P2[2 * d + 1]; t[--k] = P2[2 * d]; }
+        if (w >= 10) { t[--k] = P2[2 * w + 1]; t[--k] = P2[2 * w]; } else t[--k] = (char)('0' + w);
+        while (24 - k < min_digits && k > 1) t[--k] = '0';
         if (neg) s.push_back('-');
-        while (k) s.push_back(t[--k]);
+        s.append(t + k, (size_t)(24 - k));
     }
 };
 
@@ -306,15 +312,17 @@ inline uint64_t name_hash(const char *s, size_t n) {      // FNV-1a, folded
     for (size_t i = 0; i < n; i++) { h ^= (uint8_t)s[i]; h *= 1099511628211ull; }
     return h ^ (h >> 29);
 }
-int readmap_rows(const ReadMaps &m, const char *ctg_id, const std::vector<int64_t> &qoff, const std::string &qnames, ReadmapRows &R, std::string &err) {
+// (r6) The name table need not be the q_id table: readmap_fill only asks "the name id of q" and "the name id of a row's raw read", so the rows can be resolved against the names
+// of ALL reads of the contig -- known before the device has aligned anything -- and `name_of_q` filled in from the q_id -> read table afterwards (job_phase_write does that: the
+// 2.4 ms of CPU per bench step this costs used to fall into the 2 ms in which the phasing kernels are launched, and a rank with two cores felt it).
+template <class NameOf>
+int readmap_rows_t(const ReadMaps &m, const char *ctg_id, size_t nq, NameOf name_of, ReadmapRows &R, std::string &err) {
     if (m.short_row) { err = "pread_to_contigs: short row"; return FZP_EINVAL; }
-    const size_t nq = qoff.size() - 1;
     // the contig's distinct read names: an open-addressing table of q ids (no node per name: twenty of these run side by side)
     size_t cap = 16;
     while (cap < 2 * nq + 2) cap <<= 1;
     std::vector<int32_t> slot(cap, -1);                                    // -> the first q_id of the name
     std::vector<int32_t> id_of_q(nq, 0);
-    auto name_of = [&](size_t q) { return std::string_view(qnames.data() + qoff[q], (size_t)(qoff[q + 1] - qoff[q])); };
     auto find = [&](std::string_view nm) -> int32_t {                      // the slot of the name, or of the free place it would take
         size_t h = (size_t)name_hash(nm.data(), nm.size()) & (cap - 1);
         while (slot[h] >= 0 && name_of((size_t)slot[h]) != nm) h = (h + 1) & (cap - 1);
@@ -377,15 +385,18 @@ int readmap_rows(const ReadMaps &m, const char *ctg_id, const std::vector<int64_
         if (i + 1 == out.size() || out[i + 1].pid != out[i].pid) { R.pid.push_back(out[i].pid); R.nid.push_back(out[i].nid); }
     return FZP_OK;
 }
+int readmap_rows(const ReadMaps &m, const char *ctg_id, const std::vector<int64_t> &qoff, const std::string &qnames, ReadmapRows &R, std::string &err) {
+    return readmap_rows_t(m, ctg_id, qoff.size() - 1, [&](size_t q) { return std::string_view(qnames.data() + qoff[q], (size_t)(qoff[q + 1] - qoff[q])); }, R, err);
+}
 // the records first (they are what the caller's gather needs), the text from them (lines 49-51) -- by a write task when the files are written in the background
 void readmap_text(const fzp_r2p *recs, size_t n, const char *ctg_id, std::string &text) {
     const size_t cn = strlen(ctg_id);
     TextBuf b;
     b.s.reserve(n * (cn + 20));
     for (size_t i = 0; i < n; i++) {
-        char key[32];
-        snprintf(key, sizeof key, "%09lld", (long long)recs[i].arid);
-        b.s += key; b.s.push_back(' '); b.s.append(ctg_id, cn); b.s.push_back(' ');
+        if (recs[i].arid >= 0) b.puti((long long)recs[i].arid, 9);      // '%09d' (phasing_readmap.py:49-51)
+        else { char key[32]; snprintf(key, sizeof key, "%09lld", (long long)recs[i].arid); b.s += key; }
+        b.s.push_back(' '); b.s.append(ctg_id, cn); b.s.push_back(' ');
         b.puti(recs[i].block); b.s.push_back(' '); b.puti(recs[i].phase); b.s.push_back('\n');
     }
     text.swap(b.s);
@@ -413,6 +424,9 @@ bool mkdir_p(const std::string &path) {
 }
 // A contig's files are made relative to ONE handle of its directory (mkdirat / openat): twenty writers that each resolved seven full paths -- and three mkdir -p walks
 // from the root -- took turns on the locks of the ancestors they all share; now a contig touches its parent once (mkdir of its own directory) and after that only itself.
+// measurement aid (FZP_PIPE_TIMING): CPU time of the write tasks by what they do, summed over the threads that ran them; printed and cleared by fzp_pipe_flush
+std::atomic<int64_t> g_wt_fmt_ns{0}, g_wt_wait_ns{0}, g_wt_dir_ns{0}, g_wt_big_ns{0}, g_wt_small_ns{0}, g_wt_tasks{0};
+inline int64_t thread_cpu_ns() { struct timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); return (int64_t)ts.tv_sec * 1000000000ll + ts.tv_nsec; }
 struct DirWriter {
     int fd = -1;
     ~DirWriter() { if (fd >= 0) close(fd); }
@@ -422,8 +436,19 @@ struct DirWriter {
         return fd >= 0;
     }
     bool subdir(const char *name) { return mkdirat(fd, name, 0777) == 0 || errno == EEXIST; }
+    // A file that is already there (a re-run into the same tree: what a restarted unzip job does, and what every bench step after the first does) is OVERWRITTEN IN PLACE and cut
+    // to its new length afterwards instead of being truncated first: O_TRUNC hands every page of the old file back and the writes then allocate, clear and charge as many
+    // new ones -- on a memory file system that was most of a writer's CPU time (r6: 13 ms per bench step for 39.5 MB in 140 files).  A fresh file costs what it did.
+    // FZP_PIPE_TRUNC=1 restores the truncating open.
+    static bool trunc_first() { static const bool t = [] { const char *e = getenv("FZP_PIPE_TRUNC"); return e && atoi(e) != 0; }(); return t; }
+    static bool cut_to(int f, int64_t n) {
+        if (trunc_first()) return true;
+        struct stat sb;
+        if (fstat(f, &sb) != 0) return false;
+        return sb.st_size <= n || ftruncate(f, (off_t)n) == 0;
+    }
     bool file(const char *rel, const char *data, size_t n, std::atomic<int64_t> &bytes) {
-        const int f = openat(fd, rel, O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);
+        const int f = openat(fd, rel, O_WRONLY | O_CREAT | O_CLOEXEC | (trunc_first() ? O_TRUNC : 0), 0666);
         if (f < 0) return false;
         size_t off = 0;
         while (off < n) {
@@ -431,13 +456,14 @@ struct DirWriter {
             if (w < 0) { if (errno == EINTR) continue; const int e = errno; close(f); errno = e; return false; }
             off += (size_t)w;
         }
+        if (!cut_to(f, (int64_t)n)) { const int e = errno; close(f); errno = e; return false; }
         close(f);
         bytes += (int64_t)n;
         return true;
     }
     // the same from pieces that lie where they lie (a contig's tigs in the pinned block, their headers beside them): writev, IOV_MAX pieces per call
     bool filev(const char *rel, std::vector<struct iovec> &iov, std::atomic<int64_t> &bytes) {
-        const int f = openat(fd, rel, O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);
+        const int f = openat(fd, rel, O_WRONLY | O_CREAT | O_CLOEXEC | (trunc_first() ? O_TRUNC : 0), 0666);
         if (f < 0) return false;
         size_t k = 0;
         int64_t total = 0;
@@ -450,6 +476,7 @@ struct DirWriter {
             while (k < iov.size() && left >= iov[k].iov_len) { left -= iov[k].iov_len; k++; }
             if (left) { iov[k].iov_base = (char *)iov[k].iov_base + left; iov[k].iov_len -= left; }
         }
+        if (!cut_to(f, total)) { const int e = errno; close(f); errno = e; return false; }
         close(f);
         bytes += total;
         return true;
@@ -502,8 +529,55 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
     FZP_TRY(fzp_bind(ctx));
     auto t0 = clk::now();
     const auto t_body = t0;
+    // ---- (r6) while the device aligns: every contig's rows of pread_to_contigs resolved against the names of the contig's READS (readmap_rows_t's note).  The job knows which
+    // read belongs to which contig; the names are the caller's.
+    int32_t njc = 0;
+    int64_t njr = 0;
+    const int32_t *j_read_ctg = nullptr;
+    fzp_align_host_reads(job, &njc, &njr, &j_read_ctg);
+    int T = o->n_threads > 0 ? o->n_threads : std::min(64, std::max(2, cores_per_rank()));      // (the cores this rank may use, not the machine's: a rank of eight behind a 16-CPU quota has two)
+    if (!ctx->workers || ctx->workers->size() < std::min(T, (int)njc)) {        // grown on demand, kept for the next call
+        delete ctx->workers;
+        ctx->workers = new WorkPool();
+        ctx->workers->start(std::max(0, std::min(T, std::max((int)njc, 8)) - 1), ctx->device);
+    }
+    struct EarlyRows { ReadmapRows rows; int rc = FZP_OK; std::string err; };
+    std::vector<EarlyRows> erows;
+    std::vector<int32_t> local_of;                 // per read of the job: its place among its contig's reads
+    std::vector<int64_t> rd_first;                 // per contig: where its reads begin in rd_list
+    std::vector<int64_t> rd_list;
+    const bool rows_early = mh.have && nm->names && nm->name_off && j_read_ctg && njc > 0;
+    std::thread rows_thread;
+    if (rows_early) {
+        rd_first.assign((size_t)njc + 1, 0);
+        for (int64_t r = 0; r < njr; r++) if (j_read_ctg[r] >= 0 && j_read_ctg[r] < njc) rd_first[(size_t)j_read_ctg[r] + 1]++;
+        for (int32_t c = 0; c < njc; c++) rd_first[(size_t)c + 1] += rd_first[(size_t)c];
+        rd_list.resize((size_t)rd_first[(size_t)njc]);
+        local_of.assign((size_t)njr, -1);
+        {
+            std::vector<int64_t> at(rd_first.begin(), rd_first.end() - 1);
+            for (int64_t r = 0; r < njr; r++) if (j_read_ctg[r] >= 0 && j_read_ctg[r] < njc) { const int32_t c = j_read_ctg[r]; local_of[(size_t)r] = (int32_t)(at[(size_t)c] - rd_first[(size_t)c]); rd_list[(size_t)at[(size_t)c]++] = r; }
+        }
+        erows.resize((size_t)njc);
+    }
+    struct JoinRows { std::thread &t; ~JoinRows() { if (t.joinable()) t.join(); } } rows_join{rows_thread};      // (declared after everything the thread touches)
     if (o->flags & FZP_PIPE_REBUILD_INDEX) FZP_TRY(fzp_align_invalidate_index(job));
     FZP_TRY(fzp_align_run_deferred(ctx, job));      // (whether the fail list overflowed is asked by fzp_align_to_batch, in the fetch it makes anyway)
+    // (K1's kernels are queued: this thread now sleeps until they are through -- the DP and the walk, 7 ms of the bench step --, which is when a rank with two cores has one to spare)
+    if (rows_early) {
+        rows_thread = std::thread([&, T]() {
+            (void)pthread_setname_np(pthread_self(), "fzp-rows");
+            const ReadMaps *mp = mh.get();
+            if (!mp) return;
+            const std::function<void(int, int)> w = [&](int, int c) {
+                const int64_t *rl = rd_list.data() + rd_first[(size_t)c];
+                erows[(size_t)c].rc = readmap_rows_t(*mp, nm->ctg_id[c], (size_t)(rd_first[(size_t)c + 1] - rd_first[(size_t)c]),
+                                                     [&](size_t k) { const int64_t r = rl[k]; return std::string_view(nm->names + nm->name_off[r], (size_t)(nm->name_off[r + 1] - nm->name_off[r])); },
+                                                     erows[(size_t)c].rows, erows[(size_t)c].err);
+            };
+            ctx->workers->run((int)njc, w, std::min(std::max(1, std::min(T, (int)njc)), 6));
+        });
+    }
     fzp_batch *b = nullptr;
     FZP_TRY(fzp_align_to_batch(ctx, job, &b));
     struct BG { fzp_ctx *c; fzp_batch *b; ~BG() { fzp_batch_destroy(c, b); } } bg{ctx, b};
@@ -512,12 +586,7 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
     const int nc = b->n_ctg;
     static const bool timing = getenv("FZP_PIPE_TIMING") != nullptr;
     std::atomic<int64_t> us_names{0}, us_fmt{0}, us_map{0}, us_write{0};
-    int T = o->n_threads > 0 ? o->n_threads : std::min(64, std::max(2, cores_per_rank()));      // (the cores this rank may use, not the machine's: a rank of eight behind a 16-CPU quota has two)
-    if (!ctx->workers || ctx->workers->size() < std::min(T, nc)) {        // grown on demand, kept for the next call
-        delete ctx->workers;
-        ctx->workers = new WorkPool();
-        ctx->workers->start(std::max(0, std::min(T, std::max(nc, 8)) - 1), ctx->device);
-    }
+    if (nc != njc) { fzp_set_error("fzp_job_phase_write: the batch has %d contigs, its job %d", nc, (int)njc); return FZP_EINVAL; }
     const int want_threads = std::max(1, std::min(T, nc));
     T = ctx->workers->size();
     // ---- what K1 alone decides goes to the host threads NOW, under the phasing kernels: the q_id -> read table comes over, and per contig the q_id names, q_id_map and the
@@ -560,13 +629,26 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
             P.qmap.swap(tb.s);
         }
         us_fmt += (int64_t)(ms_since(tq) * 1e3); tq = clk::now();
-        if (const ReadMaps *mp = mh.get()) P.rc = readmap_rows(*mp, nm->ctg_id[c], P.qoff, P.qn, P.rows, P.err);
+        if (rows_early) {                                   // the rows are resolved (above); what K1 adds is which read every q_id is
+            EarlyRows &E = erows[(size_t)c];
+            P.rc = E.rc; P.err = E.err;
+            std::vector<int32_t> name_of_read;
+            name_of_read.swap(E.rows.name_of_q);
+            P.rows = std::move(E.rows);
+            P.rows.name_of_q.resize((size_t)nq);
+            for (int64_t q = 0; q < nq && P.rc == FZP_OK; q++) {
+                const int32_t k = qr[q] >= 0 && qr[q] < njr ? local_of[(size_t)qr[q]] : -1;
+                if (k < 0 || (size_t)k >= name_of_read.size() || j_read_ctg[qr[q]] != c) { P.rc = FZP_EINVAL; P.err = "q_id table names a read of another contig"; break; }
+                P.rows.name_of_q[(size_t)q] = name_of_read[(size_t)k];
+            }
+        } else if (const ReadMaps *mp = mh.get()) P.rc = readmap_rows(*mp, nm->ctg_id[c], P.qoff, P.qn, P.rows, P.err);
         us_map += (int64_t)(ms_since(tq) * 1e3);
     };
     std::string early_err;
     std::thread early([&]() {
         (void)pthread_setname_np(pthread_self(), "fzp-early");
         if (hipSetDevice(ctx->device) != hipSuccess || hipEventSynchronize(ev_q.e) != hipSuccess) { (void)hipGetLastError(); early_err = "the q_id table did not arrive"; return; }
+        if (rows_thread.joinable()) rows_thread.join();      // (one run at a time per pool; the rows have had all of K1 to get done)
         ctx->workers->run(nc, pre_work, std::min(want_threads, 6));      // (a few threads: there are milliseconds to do this in, and the thread that launches the kernels wants a core)
     });
     struct Join { std::thread &t; ~Join() { if (t.joinable()) t.join(); } } early_join{early};      // (declared after everything the thread touches)
@@ -718,13 +800,18 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
             size_t len[3] = {0, 0, 0};
             struct FreeTxt { char **t; ~FreeTxt() { for (int i = 0; i < 3; i++) free(t[i]); } } free_txt{txt};
             const int64_t nq = (int64_t)pre_p->qoff.size() - 1;
+            int64_t tc0 = thread_cpu_ns(), tc1;
+            auto lap = [&](std::atomic<int64_t> &acc) { tc1 = thread_cpu_ns(); acc += tc1 - tc0; tc0 = tc1; };
             int rc = fzp_format_variant_pos(owned->sites + s0, s1 - s0, &txt[0], &len[0]);
             if (rc == FZP_OK) rc = fzp_format_phased_variants(owned->sites, owned->pvars + p0, p1 - p0, &txt[1], &len[1]);       // pvars carry batch-wide site indices
             if (rc == FZP_OK) rc = fzp_format_phased_reads(owned->preads + r0, r1 - r0, ctg_s.c_str(), pre_p->qoff.data(), pre_p->qn.data(), (int32_t)nq, &txt[2], &len[2]);
             if (rc != FZP_OK) return failed(fzp_last_error());
+            lap(g_wt_fmt_ns);
             if (!owned->texts_there()) { (void)hipGetLastError(); return failed("the device-made texts of " + ctg_s + " did not arrive"); }
+            lap(g_wt_wait_ns);
             std::string r2p_text;
             if (have_r2p) readmap_text(recs_p->data(), recs_p->size(), ctg_s.c_str(), r2p_text);
+            lap(g_wt_fmt_ns);
             DirWriter dw;
             if (!dw.open_base(base)) return failed("cannot create " + base + ": " + strerror(errno));
             if (bam) {                                           // <ctg>_sorted.bam + index, then the blasr task's sentinels
@@ -747,10 +834,15 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
                 }
             }
             bool ok = dw.subdir("het_call") && dw.subdir("g_atable") && dw.subdir("get_phased_blocks");
-            ok = ok && dw.file("het_call/variant_pos", txt[0], len[0], bt) && dw.file("het_call/variant_map", pv, lv, bt) &&
-                 dw.file("het_call/q_id_map", pre_p->qmap.data(), pre_p->qmap.size(), bt) && dw.file("g_atable/atable", pa, la, bt) &&
+            lap(g_wt_dir_ns);
+            ok = ok && dw.file("het_call/variant_map", pv, lv, bt) && dw.file("g_atable/atable", pa, la, bt);
+            lap(g_wt_big_ns);
+            ok = ok && dw.file("het_call/variant_pos", txt[0], len[0], bt) &&
+                 dw.file("het_call/q_id_map", pre_p->qmap.data(), pre_p->qmap.size(), bt) &&
                  dw.file("get_phased_blocks/phased_variants", txt[1], len[1], bt) && dw.file("phased_reads", txt[2], len[2], bt);
             if (ok && have_r2p) ok = dw.file(("rid_to_phase." + ctg_s).c_str(), r2p_text.data(), r2p_text.size(), bt);
+            lap(g_wt_small_ns);
+            g_wt_tasks++;
             if (ok && want_cns) {
                 std::vector<struct iovec> iov;
                 iov.reserve(3 * cns_p->hdr.size());
@@ -1701,6 +1793,12 @@ extern "C" int fzp_pipe_flush(fzp_ctx *ctx) {
     std::string err;
     if (ctx->writer) err = ctx->writer->drain();
     for (auto l : ctx->lanes) if (l->writer) { const std::string e = l->writer->drain(); if (err.empty()) err = e; }
+    static const bool timing = getenv("FZP_PIPE_TIMING") != nullptr;
+    if (timing && g_wt_tasks.load()) {
+        const double n = (double)g_wt_tasks.exchange(0);
+        fprintf(stderr, "[fzp_pipe] write tasks: %.0f; CPU ms per task: small texts %.3f, wait for the big texts %.3f, directories %.3f, the two big files %.3f, the small files %.3f\n", n,
+                g_wt_fmt_ns.exchange(0) / 1e6 / n, g_wt_wait_ns.exchange(0) / 1e6 / n, g_wt_dir_ns.exchange(0) / 1e6 / n, g_wt_big_ns.exchange(0) / 1e6 / n, g_wt_small_ns.exchange(0) / 1e6 / n);
+    }
     if (!err.empty()) { fzp_set_error("%s", err.c_str()); return FZP_EINVAL; }
     return FZP_OK;
 }

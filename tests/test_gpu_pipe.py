@@ -209,6 +209,36 @@ def test_async_writes_are_complete_after_flush(eng, tmp_path):
         eng.pipe_flush()
 
 
+def test_a_rerun_into_an_existing_tree_leaves_the_files_of_a_first_run(eng, tmp_path, monkeypatch):
+    """r6: a file that exists is overwritten in place and cut to its new length afterwards (no O_TRUNC: the old pages are reused).  A tree whose files are LONGER than the new
+    ones (and hold other bytes), a tree whose files are shorter, and an untouched one all end up byte-identical (sync and async writes)."""
+    from falcon_unzip_amd import _lib
+    contigs, blob, off, read_ctg, names, ids = _make_job(n_ctg=2)
+    maps = _read_maps(names, read_ctg, ids)
+    job = _lib.align_job_raw(eng, contigs, blob, off, read_ctg)
+    first = str(tmp_path / "first")
+    job.phase_write(ids, names=names, out_dir=first, read_maps=maps, consensus=True)
+    files = {}
+    for ctg in ids:
+        for d, _, fs in os.walk(os.path.join(first, ctg)):
+            for f in fs:
+                rel = os.path.relpath(os.path.join(d, f), first)
+                files[rel] = open(os.path.join(first, rel), "rb").read()
+    assert len(files) >= 2 * 8 and sum(map(len, files.values())) > 100000
+    for tag, make in (("longer", lambda b: b"#" * (len(b) + 4097) + b"tail"), ("shorter", lambda b: b[: len(b) // 3]), ("same", lambda b: bytes(len(b)))):
+        root = str(tmp_path / tag)
+        for rel, data in files.items():
+            os.makedirs(os.path.dirname(os.path.join(root, rel)), exist_ok=True)
+            with open(os.path.join(root, rel), "wb") as f:
+                f.write(make(data))
+        for asyn in (False, True):
+            job.phase_write(ids, names=names, out_dir=root, read_maps=maps, consensus=True, async_writes=asyn)
+            eng.pipe_flush()
+            for rel, data in files.items():
+                assert open(os.path.join(root, rel), "rb").read() == data, (tag, asyn, rel)
+    job.close()
+
+
 def test_pipeline_edge_cases(eng, tmp_path):
     """no reads at all; a malformed read map (the reference raises while reading it, whatever the contig); an unwritable target"""
     from falcon_unzip_amd import _lib

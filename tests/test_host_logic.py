@@ -399,3 +399,19 @@ def test_design_is_the_short_current_state_document_with_a_generated_kernel_tabl
     assert os.path.exists(os.path.join(root, "HISTORY.md"))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "design_kernel_table.py"), "--check"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_integer_formatting_of_the_serialisers(lib):
+    """the serialisers write their numbers two digits per division (r6): every digit count, negative values, 2^31 - 1 and beyond (no GPU needed: host code of the library)"""
+    from falcon_unzip_amd import _lib
+    rng = np.random.default_rng(5)
+    vals = [0, 9, 10, 99, 100, 999, 1000, 65535, 99999, 100000, 2147483646] + [int(x) for x in rng.integers(0, 2**31 - 2, 200)] + [int(10 ** k) for k in range(1, 10)] + [int(10 ** k - 1) for k in range(1, 10)]
+    S = np.zeros(len(vals), _lib.SITE)
+    for i, v in enumerate(vals):
+        S[i]["pos"] = v
+        S[i]["total"] = vals[-1 - i]
+        S[i]["count"] = [v % 1000, -(v % 77), vals[(i * 7) % len(vals)], 0]
+        S[i]["ref_base"] = 65
+        S[i]["base"] = [65, 67, 71, 84]
+    exp = "".join("%d A %d A %d C %d G %d T %d\n" % (v + 1, vals[-1 - i], v % 1000, -(v % 77), vals[(i * 7) % len(vals)], 0) for i, v in enumerate(vals))
+    assert _lib.format_variant_pos(S).decode() == exp
