@@ -2222,49 +2222,100 @@ __global__ void __launch_bounds__(64) k_tb_cigar(int64_t first, int64_t count, c
     // pass 0 (fzalign v1.5, "best sub-path"): P(k) = score of ops 0..k-1 of the stream (op 0 leaves the forward terminal, the last op reaches the backward
     // one); the alignment is ops e..s with the largest P(s+1) - P(e) (ties: the smallest s, then the largest e) -- both ends are match columns -- and what the
     // walks found outside it (a tail dragged to the matrix border through noise, a head likewise) becomes soft clip.  A lane scores a word: its 16 ops consume at
-    // most 16 read and 16 contig bases going down from the word's first cell, which exclusive scans of the words' consumption counts give.  Two sweeps over the
-    // word's ops: the first leaves its score, the lowest prefix inside it and which ops are matching columns; a min-scan over the lanes (and the chunks before)
-    // then gives every word the lowest prefix before it, and the second sweep finds its best (e, s).
+    // most 16 read and 16 contig bases going down from the word's first cell, which exclusive scans of the words' consumption counts give.  One sweep over the
+    // word's ops (r6; r3-r5: two) leaves its score, the lowest prefix inside it, its highest prefix and its best inner (e, s); a min-scan over the lanes (and the chunks
+    // before) gives every word the lowest prefix before it, and the word's best (e, s) follows from those without a second look at the ops.
     int32_t S_star = 0;
+    int32_t pM_hi = -1, pM_lo = 0x7fffffff;      // highest / lowest stream position holding an aligned column (of the kept stream: found on the way through it below)
     {
         const uint32_t *qpk = (rp.strand ? read_rc : read_pk) + read_woff[r];
         const uint32_t *tpk = ctg_pk + ctg_woff[read_ctg[r]];
         auto scan_incl = [&](int32_t v) -> int32_t { return (int32_t)wave_incl_scan_u32_dpp((uint32_t)v); };      // (on the DPP network: __shfl_up is a trip through the LDS pipeline per step)
-        auto window = [&](const uint32_t *pk, int64_t idx_hi, int64_t &lo_idx) -> uint64_t {     // the 32 bases ending in the u32 word of idx_hi
-            const int64_t w1 = idx_hi >> 4;
-            lo_idx = (w1 - 1) * 16;
-            return ((uint64_t)pk[w1] << 32) | (w1 > 0 ? pk[w1 - 1] : 0u);
-        };
         int32_t base_S = 0, base_i = 0, base_j = 0, bestS = 0, bestP = -1, bestE = 0;
         int32_t base_min = 0, base_min_pos = 0;                  // lowest prefix P(e) over the chunks so far (P(0) = 0 at e = 0), the largest such e
+        // r6: ONE sweep over a word's ops, no branches.  (a) Which of its aligned columns match comes from whole-word operations: the 16 read bases and the 16 contig bases
+        // going DOWN from the word's first cell (field k = base i - k / j - k), shifted up by two bits per D op / I op before a field -- an I op consumes no contig base, so the
+        // contig lags one field further from there on --, six instructions per indel (a word holds two on average), one xor.  (b) The sweep keeps everything in scaled keys
+        // (prefix x 256, positions in the low byte) so that "lowest prefix, latest position", "highest prefix, earliest position" and "largest gain, earliest end" are one
+        // v_min / v_max each: per op 11 instructions where the two branchy sweeps of r3-r5 spent 80.  (c) What a word needs from outside is the lowest prefix BEFORE it (the
+        // min-scan, as before); with G that prefix, B the word's highest prefix-after-an-op and A its best (end - start inside the word), the serial rule "P(s+1) - min(G,
+        // lowest prefix inside up to s)" has the value max(A, B - G) -- and its tie rules (smallest s, then largest e; a prefix inside the word wins a tie against G)
+        // come out as: A's pair if A > B - G, or if they tie and A's s is not behind B's.  Ops past the stream's end are scored as gaps: prefixes only fall behind the last
+        // op, so no position there can win anything (gap > 0).  The scores times 4 096 have to fit the keys: fzp_align_create checks match, mismatch, gap <= 4 096.
+        auto desc16 = [&](const uint32_t *pk, int32_t hi) -> uint32_t {      // bases hi, hi - 1, .., hi - 15 in fields 0..15 (a base below 0: 0)
+            uint32_t W = 0;
+            const int32_t p0 = hi - 15;
+            if (hi >= 0) {
+                if (p0 >= 0) { const int32_t wl = p0 >> 4; const uint32_t sh = 2u * (uint32_t)(p0 & 15); W = __builtin_amdgcn_alignbit(sh ? pk[wl + 1] : 0u, pk[wl], sh); }
+                else W = pk[0] << (2u * (uint32_t)(-p0));
+            }
+            const uint32_t rv = __builtin_bitreverse32(W);                     // field 15 - k with its two bits swapped
+            return ((rv >> 1) & EVEN) | ((rv & EVEN) << 1);
+        };
+        const int32_t cE = 256 * (match + mismatch), cG = 256 * (mismatch - gap), cX = 256 * mismatch;
+        // the table of the four-op groups: entry c = the sweep over ops c & 3, (c >> 2) & 3, .. (0 mismatching column, 1 matching column, 2 / 3 gap) from prefix 0, positions 0..3:
+        // x = their score x 256; y = lowest (prefix x 256 | 3 - o) BEFORE an op (equal prefixes: the later op); z = highest (prefix x 256 | 16 x (3 - o) + 15) AFTER an op
+        // (equal: the earlier); w = best 256 x (prefix after s - prefix before e) + 16 x (3 - s) + e over e <= s.  A word adds 12 - 4 g to the position fields of group g.
+        __shared__ int4 lut[256];
+        for (int c = lane; c < 256; c += 64) {
+            int32_t pp = 0, km = 0x7fffffff, xB = (int32_t)0x80000000, xA = (int32_t)0x80000000;
+#pragma unroll
+            for (int o = 0; o < 4; o++) {
+                km = min(km, pp | (3 - o));
+                const int32_t code = (c >> (2 * o)) & 3;
+                pp += code == 1 ? cE - cX : (code == 0 ? -cX : cG - cX);
+                const int32_t tB = pp | ((3 - o) * 16 + 15);
+                xB = max(xB, tB);
+                xA = max(xA, tB - km);
+            }
+            lut[c] = make_int4(pp, km, xB, xA);
+        }
+        __syncthreads();
+        // (r6: with a third of the instructions the kernel waits for its loads -- a wave makes ~120 dependent round trips per read; every loop over the stream now asks for
+        // the next chunk's words before it works on this one's)
+        uint32_t x_next = lane < nW ? rg[lane] : 0u;
         for (int32_t wb = 0; wb < nW; wb += 64) {
             const int32_t wi = wb + lane;
-            const uint32_t x = wi < nW ? rg[wi] : 0u, vm = wi < nW ? valid_mask(wi) : 0u;
+            const uint32_t x = x_next, vm = wi < nW ? valid_mask(wi) : 0u;
+            x_next = wi + 64 < nW ? rg[wi + 64] : 0u;
             const uint32_t fM = ~(x | (x >> 1)) & vm, fI = (x & ~(x >> 1)) & vm, fD = (~x & (x >> 1)) & vm;
             const int32_t ci = __popc(fM | fI), cj = __popc(fM | fD);
             const int32_t si = scan_incl(ci), sj = scan_incl(cj);
-            int32_t i = w.i_end - (base_i + si - ci), j = w.j_end - (base_j + sj - cj);       // the cell the word's first op leaves
-            int64_t qlo = 0, tlo = 0;
-            const uint64_t qw = (ci && (int64_t)a.i_a + i >= 0) ? window(qpk, (int64_t)a.i_a + i, qlo) : 0ull;     // (i, j are relative to the anchor: negative in the backward part)
-            const uint64_t tw = (cj && (int64_t)a.c_a + j >= 0) ? window(tpk, (int64_t)a.c_a + j, tlo) : 0ull;
-            int32_t sl = 0, lmin = 0x3fffffff, lpos = 0;
-            uint32_t eq = 0;                                       // even bit of op o: a matching column
-#pragma unroll
-            for (int o = 0; o < 16; o++) {
-                if ((vm >> (2 * o)) & 1u) {
-                    if (sl <= lmin) { lmin = sl; lpos = o; }       // prefix BEFORE op o ('<=': the largest e)
-                    const uint32_t op = (x >> (2 * o)) & 3u;
-                    if (op == 0u) {
-                        const uint32_t qb_ = (uint32_t)(qw >> (2 * (uint32_t)((int64_t)a.i_a + i - qlo))) & 3u, tb_ = (uint32_t)(tw >> (2 * (uint32_t)((int64_t)a.c_a + j - tlo))) & 3u;
-                        if (qb_ == tb_) { sl += match; eq |= 1u << (2 * o); } else sl -= mismatch;
-                        i--; j--;
-                    } else { sl -= gap; if (op == 1u) i--; else j--; }
-                }
+            const int32_t i = w.i_end - (base_i + si - ci), j = w.j_end - (base_j + sj - cj);       // the cell the word's first op leaves (relative to the anchor: negative in the backward part)
+            const uint32_t Dq = ci ? desc16(qpk, a.i_a + i) : 0u, Dt = cj ? desc16(tpk, a.c_a + j) : 0u;
+            // a D op leaves its read base to the next op: every field above it takes the field below (a two-bit hole opens at the op); an I op does the same to the contig's
+            // bases.  The k-th D and the k-th I of a word in the same turn, as many turns as the wave's busiest word needs (a word that is through changes nothing)
+            uint32_t Qs = Dq, Ts = Dt;
+            for (uint32_t rd = fD, ri = fI; __builtin_amdgcn_ballot_w64((rd | ri) != 0u);) {
+                const uint32_t lowd = rd & (0u - rd), bd = lowd - 1u, lowi = ri & (0u - ri), bi = lowi - 1u;      // (none left: the mask is every bit, the word stays)
+                Qs = (Qs & bd) | ((Qs << 2) & ~bd);
+                Ts = (Ts & bi) | ((Ts << 2) & ~bi);
+                rd ^= lowd; ri ^= lowi;
             }
+            const uint32_t E = Qs ^ Ts;                            // per field: read base xor contig base
+            const uint32_t eqw = fM & ~(E | (E >> 1));             // even bit of op o: a matching column
+            const uint32_t gapw = fI | fD | (EVEN & ~vm);
+            // four ops at a time: the table (filled above, one entry per spelling of four ops) holds what a sweep over them leaves -- their score, the lowest prefix before
+            // one of them, the highest prefix behind one, their best inner (e, s) --, and a group joins the word's running values in eight instructions
+            const uint32_t cw = eqw | (gapw << 1);                 // per op: 0 a mismatching column, 1 a matching one, 2 a gap
+            int32_t pk_ = 0, kmin = 15, bA = (int32_t)0x80000000, bB = (int32_t)0x80000000;      // (15: the prefix before op 0)
+            int4 ent[4];
+#pragma unroll
+            for (int g = 0; g < 4; g++) ent[g] = lut[(cw >> (8 * g)) & 255u];
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int32_t t1 = pk_ + ent[g].z + ((12 - 4 * g) * 16);                         // the group's highest prefix-after-an-op, as a word-level key
+                bA = max(bA, max(t1 - kmin, ent[g].w + ((12 - 4 * g) * 16 + 4 * g - 12)));       // ... against the lowest prefix BEFORE the group; the group's own best pair (its e field holds e + 12: 15 - (3 - e))
+                bB = max(bB, t1);
+                kmin = min(kmin, pk_ + ent[g].y + (12 - 4 * g));
+                pk_ += ent[g].x;
+            }
+            const int32_t sl = pk_ >> 8, lmin = kmin >> 8, lpos = 15 - (kmin & 15);
+            const int32_t Bv = bB >> 8, sB = 15 - ((bB >> 4) & 15), Av = bA >> 8, sA = 15 - ((bA >> 4) & 15), eA = bA & 15;
             const int32_t ss = scan_incl(sl);
             const int32_t start = base_S + ss - sl;                // P(16 * wi)
             // lowest prefix over the words up to and including this one: (value, position), later positions win ties
-            int32_t mv_ = vm ? start + lmin : 0x3fffffff, mp_ = 16 * wi + lpos;
+            int32_t mv_ = start + lmin, mp_ = 16 * wi + lpos;
             {   // inclusive (min, position) scan over the lanes on the DPP network: four shifts inside each row of 16, then the row ends passed on (row_bcast 15 / 31); a lane
                 // without a source sees (+inf, -): "ov_ < mv_" then never holds.  (r5: twelve __shfl_up per chunk -- LDS-pipeline round trips on the wave's critical path -- gone)
 #define MINPOS_STEP(ctrl, row_mask)                                                                                                        \
@@ -2277,16 +2328,10 @@ __global__ void __launch_bounds__(64) k_tb_cigar(int64_t first, int64_t count, c
             int32_t gm = wave_shr1(mv_, 0x3fffffff), gp = wave_shr1(mp_, 0);      // ... before this word (lane 0 takes the chunks before, below)
             if (lane == 0 || base_min < gm) { gm = base_min; gp = base_min_pos; }      // (the chunks before hold earlier positions: they win only when strictly lower)
             {
-                int32_t Pk = start;
-#pragma unroll
-                for (int o = 0; o < 16; o++) {
-                    if ((vm >> (2 * o)) & 1u) {
-                        if (Pk <= gm) { gm = Pk; gp = 16 * wi + o; }
-                        const uint32_t op = (x >> (2 * o)) & 3u;
-                        Pk += op == 0u ? (((eq >> (2 * o)) & 1u) ? match : -mismatch) : -gap;
-                        if (Pk - gm > bestS) { bestS = Pk - gm; bestP = 16 * wi + o; bestE = gp; }      // words ascend within a lane: '>' keeps the smallest s
-                    }
-                }
+                const int32_t Bg = Bv + start - gm;
+                const bool takeA = Av > Bg || (Av == Bg && sA <= sB);
+                const int32_t V = takeA ? Av : Bg;
+                if (wi < nW && V > bestS) { bestS = V; bestP = 16 * wi + (takeA ? sA : sB); bestE = takeA ? 16 * wi + eA : gp; }      // words ascend within a lane: '>' keeps the smallest s
             }
             {
                 const int32_t cm = __builtin_amdgcn_readlane(mv_, 63), cp = __builtin_amdgcn_readlane(mp_, 63);
@@ -2323,13 +2368,12 @@ __global__ void __launch_bounds__(64) k_tb_cigar(int64_t first, int64_t count, c
             w.i_end -= __builtin_amdgcn_readfirstlane(ce_i); w.j_end -= __builtin_amdgcn_readfirstlane(ce_j);
             const int32_t Ln = s0 - e0 + 1, nWn = (Ln + 15) >> 4;
             const uint32_t sh = 2u * (uint32_t)(e0 & 15);
+            uint32_t lo_n = lane < nWn ? rg[we + lane] : 0u, hi_n = (lane < nWn && we + lane + 1 < nW) ? rg[we + lane + 1] : 0u;
             for (int32_t wb = 0; wb < nWn; wb += 64) {
                 const int32_t wi = wb + lane;
-                uint32_t v = 0;
-                if (wi < nWn) {
-                    const uint32_t lo = rg[we + wi], hi = we + wi + 1 < nW ? rg[we + wi + 1] : 0u;
-                    v = sh ? (lo >> sh) | (hi << (32u - sh)) : lo;
-                }
+                const uint32_t lo = lo_n, hi = hi_n;
+                if (wi + 64 < nWn) { lo_n = rg[we + wi + 64]; hi_n = we + wi + 65 < nW ? rg[we + wi + 65] : 0u; }      // (the next chunk's words, all above what this chunk writes)
+                const uint32_t v = sh ? (lo >> sh) | (hi << (32u - sh)) : lo;
                 __builtin_amdgcn_wave_barrier();
                 if (wi < nWn) rg[wi] = v;
             }
@@ -2340,13 +2384,19 @@ __global__ void __launch_bounds__(64) k_tb_cigar(int64_t first, int64_t count, c
         // a checkpoint of the packed hand-off to K2 (fzp_batch.h: PkSrc; the stream itself stays where it is, in the job's op buffer)
         int32_t ci2 = 0, cj2 = 0, nm2 = 0;
         int2 *ckp = pck + ((size_t)(rcapq_scan[r] >> 2) + (size_t)r);
+        __builtin_amdgcn_wave_barrier();
+        x_next = lane < nW ? rg[lane] : 0u;
         for (int32_t wb = 0; wb < nW; wb += 64) {
             const int32_t wi = wb + lane;
             uint32_t ci = 0, cj = 0;
+            const uint32_t x = x_next;
+            x_next = wi + 64 < nW ? rg[wi + 64] : 0u;
             if (wi < nW) {
-                const uint32_t x = rg[wi], vm = valid_mask(wi);
+                const uint32_t vm = valid_mask(wi);
                 const uint32_t fM = ~(x | (x >> 1)) & vm, fI = (x & ~(x >> 1)) & vm, fD = (~x & (x >> 1)) & vm;
                 ci = (uint32_t)__popc(fM | fI); cj = (uint32_t)__popc(fM | fD); nm2 += __popc(fM);
+                // (pass A of r1-r5, a loop of its own: the highest / lowest stream position holding an aligned column)
+                if (fM) { pM_hi = max(pM_hi, 16 * wi + ((31 - __builtin_clz(fM)) >> 1)); pM_lo = min(pM_lo, 16 * wi + (__builtin_ctz(fM) >> 1)); }
             }
             const uint32_t si = wave_incl_scan_u32_dpp(ci), sj = wave_incl_scan_u32_dpp(cj);
             if (wi < nW && (wi & 15) == 0) ckp[wi >> 4] = make_int2(ci2 + (int32_t)(si - ci), cj2 + (int32_t)(sj - cj));
@@ -2359,16 +2409,6 @@ __global__ void __launch_bounds__(64) k_tb_cigar(int64_t first, int64_t count, c
         w.ncol = nm2;
         w.n_ops = L;
     }
-    // pass A: highest / lowest stream position holding an aligned column
-    int32_t pM_hi = -1, pM_lo = 0x7fffffff;
-    for (int32_t wb = 0; wb < nW; wb += 64) {
-        const int32_t wi = wb + lane;
-        if (wi < nW) {
-            const uint32_t x = rg[wi];
-            const uint32_t mf = ~(x | (x >> 1)) & valid_mask(wi);
-            if (mf) { pM_hi = max(pM_hi, 16 * wi + ((31 - __builtin_clz(mf)) >> 1)); pM_lo = min(pM_lo, 16 * wi + (__builtin_ctz(mf) >> 1)); }
-        }
-    }
     pM_hi = wave_max_i32(pM_hi);
     pM_lo = wave_min_i32(pM_lo);
     // pass B: runs, from the top of the stream (= the alignment's start) down
@@ -2376,13 +2416,16 @@ __global__ void __launch_bounds__(64) k_tb_cigar(int64_t first, int64_t count, c
     int32_t n_starts = 0;                 // starts seen in higher chunks
     int32_t low_start = 0x7fffffff;       // lowest of them
     int32_t leadI = 0, leadD = 0, trailI = 0, trailD = 0, lead_runs = 0, trail_runs = 0;
+    uint32_t xb_n = nW - 1 - lane >= 0 ? rg[nW - 1 - lane] : 0u, nxb_n = (nW - 1 - lane >= 0 && lane > 0) ? rg[nW - lane] : 0u;      // (wi + 1 < nW: every lane but the top word's)
     for (int32_t wtop = nW; wtop > 0; wtop -= 64) {
         const int32_t wi = wtop - 1 - lane;               // lane 0 = highest word of the chunk: "the words above this one" are the lanes below, and the scans over them run
                                                           // as prefix scans on the DPP network (r5: twelve __shfl_down per chunk were LDS-pipeline round trips)
         uint32_t sflag = 0, x = 0, above = 0;
+        const uint32_t xb = xb_n, nxb = nxb_n;
+        if (wi - 64 >= 0) { xb_n = rg[wi - 64]; nxb_n = rg[wi - 63]; }      // the next chunk down
         if (wi >= 0) {
-            x = rg[wi];
-            const uint32_t nx = wi + 1 < nW ? rg[wi + 1] : 0u;
+            x = xb;
+            const uint32_t nx = wi + 1 < nW ? nxb : 0u;
             above = (x >> 2) | (nx << 30);                // op(p+1) lined up with op(p)
             const uint32_t d = x ^ above;
             const uint32_t vm = valid_mask(wi);
@@ -2935,7 +2978,7 @@ static int align_create_core(fzp_ctx *ctx, int32_t n_ctg, const uint8_t *const *
     fzp_alnjob *j = new fzp_alnjob();
     if (params) j->P = *params; else fzp_align_params_default(&j->P);
     if (j->P.band == 0) j->P.band = FZP_DEFAULT_BAND;      // (a caller's zeroed struct)
-    if (j->P.kmer < 8 || j->P.kmer > 16 || j->P.seed_stride < 1 || j->P.match <= 0 || j->P.mismatch < 0 || j->P.gap <= 0 || j->P.min_pct_identity < 0 ||
+    if (j->P.kmer < 8 || j->P.kmer > 16 || j->P.seed_stride < 1 || j->P.match <= 0 || j->P.mismatch < 0 || j->P.gap <= 0 || j->P.match > 4096 || j->P.mismatch > 4096 || j->P.gap > 4096 || j->P.min_pct_identity < 0 ||
         j->P.min_pct_identity > 100 || (j->P.band != 32 && j->P.band != 64)) {
         delete j; fzp_set_error("fzp_align_create: bad parameters"); return FZP_EINVAL;
     }
