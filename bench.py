@@ -588,6 +588,7 @@ def main():
     ap.add_argument("--e2e-group-contigs", type=int, default=10)
     ap.add_argument("--rewrite-trees", dest="fresh_trees", action="store_false", help="two output trees written in turn -- from the third step on every file is overwritten in place, "
                     "a re-run into an existing tree (default: every step writes into an empty directory of its own, a first run; `other_tree_mode` in the line times a few steps the other way)")
+    ap.add_argument("--no-tree-compare", action="store_true", help="skip `other_tree_mode` (eleven more steps behind the timed ones; counter-collection runs want exactly the timed steps' launches)")
     ap.add_argument("--with-polish", action="store_true", help="also time fzp_polish_tigs on the step's inputs (every contig a tig, its reads the pile): tigs/s beside `value`")
     ap.add_argument("--with-consensus", action="store_true", help="also run K6 (phased-pile consensus, BASELINE config 4) inside every step")
     ap.add_argument("--out-root", default=None, help="where the per-step output trees go (default: a scratch directory under $TMPDIR)")
@@ -781,7 +782,7 @@ def main():
         eng.prof_enable(False)
         prof_all = eng.prof()
     fresh_cmp = None
-    if world == 1 and job is not None:      # the same step with the output trees handled the other way, beside `value`
+    if world == 1 and job is not None and not args.no_tree_compare:      # the same step with the output trees handled the other way, beside `value`
         def other_step(k):
             job.phase_write(ids, names=name_tab, out_dir=os.path.join(out_root, ("other%03d" % k) if not args.fresh_trees else ("other_%d" % (k & 1))), read_maps=maps, ctg_index=mine,
                             consensus=args.with_consensus, async_writes=True, rebuild_index=not args.index_at_create)

@@ -23,6 +23,7 @@
 
 #include "fzp_batch.h"
 #include "fzp_swb_core.h"
+#include "fzp_cigar_core.h"
 
 namespace {
 constexpr int32_t NEGV = -(1 << 26);
@@ -2249,26 +2250,13 @@ __global__ void __launch_bounds__(64) k_tb_cigar(int64_t first, int64_t count, c
                 if (p0 >= 0) { const int32_t wl = p0 >> 4; const uint32_t sh = 2u * (uint32_t)(p0 & 15); W = __builtin_amdgcn_alignbit(sh ? pk[wl + 1] : 0u, pk[wl], sh); }
                 else W = pk[0] << (2u * (uint32_t)(-p0));
             }
-            const uint32_t rv = __builtin_bitreverse32(W);                     // field 15 - k with its two bits swapped
-            return ((rv >> 1) & EVEN) | ((rv & EVEN) << 1);
+            return cigc::fields_of_reversed_bits(__builtin_bitreverse32(W));     // (field 15 - k with its two bits swapped, put right)
         };
-        const int32_t cE = 256 * (match + mismatch), cG = 256 * (mismatch - gap), cX = 256 * mismatch;
-        // the table of the four-op groups: entry c = the sweep over ops c & 3, (c >> 2) & 3, .. (0 mismatching column, 1 matching column, 2 / 3 gap) from prefix 0, positions 0..3:
-        // x = their score x 256; y = lowest (prefix x 256 | 3 - o) BEFORE an op (equal prefixes: the later op); z = highest (prefix x 256 | 16 x (3 - o) + 15) AFTER an op
-        // (equal: the earlier); w = best 256 x (prefix after s - prefix before e) + 16 x (3 - s) + e over e <= s.  A word adds 12 - 4 g to the position fields of group g.
-        __shared__ int4 lut[256];
-        for (int c = lane; c < 256; c += 64) {
-            int32_t pp = 0, km = 0x7fffffff, xB = (int32_t)0x80000000, xA = (int32_t)0x80000000;
-#pragma unroll
-            for (int o = 0; o < 4; o++) {
-                km = min(km, pp | (3 - o));
-                const int32_t code = (c >> (2 * o)) & 3;
-                pp += code == 1 ? cE - cX : (code == 0 ? -cX : cG - cX);
-                const int32_t tB = pp | ((3 - o) * 16 + 15);
-                xB = max(xB, tB);
-                xA = max(xA, tB - km);
-            }
-            lut[c] = make_int4(pp, km, xB, xA);
+        // the table of the four-op groups (fzp_cigar_core.h: what a lane does with its word is plain C++ there, held against the serial rule on the host by tests/test_cigar_core.py)
+        __shared__ cigc::Ent lut[256];
+        {
+            const cigc::Scores sc = cigc::scores_of(match, mismatch, gap);
+            for (int c = lane; c < 256; c += 64) lut[c] = cigc::lut_entry(c, sc);
         }
         __syncthreads();
         // (r6: with a third of the instructions the kernel waits for its loads -- a wave makes ~120 dependent round trips per read; every loop over the stream now asks for
@@ -2286,32 +2274,21 @@ __global__ void __launch_bounds__(64) k_tb_cigar(int64_t first, int64_t count, c
             // a D op leaves its read base to the next op: every field above it takes the field below (a two-bit hole opens at the op); an I op does the same to the contig's
             // bases.  The k-th D and the k-th I of a word in the same turn, as many turns as the wave's busiest word needs (a word that is through changes nothing)
             uint32_t Qs = Dq, Ts = Dt;
-            for (uint32_t rd = fD, ri = fI; __builtin_amdgcn_ballot_w64((rd | ri) != 0u);) {
-                const uint32_t lowd = rd & (0u - rd), bd = lowd - 1u, lowi = ri & (0u - ri), bi = lowi - 1u;      // (none left: the mask is every bit, the word stays)
-                Qs = (Qs & bd) | ((Qs << 2) & ~bd);
-                Ts = (Ts & bi) | ((Ts << 2) & ~bi);
-                rd ^= lowd; ri ^= lowi;
-            }
+            for (uint32_t rd = fD, ri = fI; __builtin_amdgcn_ballot_w64((rd | ri) != 0u);) { cigc::hole_turn(Qs, rd); cigc::hole_turn(Ts, ri); }
             const uint32_t E = Qs ^ Ts;                            // per field: read base xor contig base
             const uint32_t eqw = fM & ~(E | (E >> 1));             // even bit of op o: a matching column
             const uint32_t gapw = fI | fD | (EVEN & ~vm);
             // four ops at a time: the table (filled above, one entry per spelling of four ops) holds what a sweep over them leaves -- their score, the lowest prefix before
             // one of them, the highest prefix behind one, their best inner (e, s) --, and a group joins the word's running values in eight instructions
             const uint32_t cw = eqw | (gapw << 1);                 // per op: 0 a mismatching column, 1 a matching one, 2 a gap
-            int32_t pk_ = 0, kmin = 15, bA = (int32_t)0x80000000, bB = (int32_t)0x80000000;      // (15: the prefix before op 0)
-            int4 ent[4];
+            cigc::Ent ent[4];
 #pragma unroll
             for (int g = 0; g < 4; g++) ent[g] = lut[(cw >> (8 * g)) & 255u];
+            cigc::Word W = cigc::word_begin();
 #pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const int32_t t1 = pk_ + ent[g].z + ((12 - 4 * g) * 16);                         // the group's highest prefix-after-an-op, as a word-level key
-                bA = max(bA, max(t1 - kmin, ent[g].w + ((12 - 4 * g) * 16 + 4 * g - 12)));       // ... against the lowest prefix BEFORE the group; the group's own best pair (its e field holds e + 12: 15 - (3 - e))
-                bB = max(bB, t1);
-                kmin = min(kmin, pk_ + ent[g].y + (12 - 4 * g));
-                pk_ += ent[g].x;
-            }
-            const int32_t sl = pk_ >> 8, lmin = kmin >> 8, lpos = 15 - (kmin & 15);
-            const int32_t Bv = bB >> 8, sB = 15 - ((bB >> 4) & 15), Av = bA >> 8, sA = 15 - ((bA >> 4) & 15), eA = bA & 15;
+            for (int g = 0; g < 4; g++) cigc::word_join(W, ent[g], g);
+            const cigc::WordOut O = cigc::word_end(W);
+            const int32_t sl = O.tot, lmin = O.lmin, lpos = O.lpos;
             const int32_t ss = scan_incl(sl);
             const int32_t start = base_S + ss - sl;                // P(16 * wi)
             // lowest prefix over the words up to and including this one: (value, position), later positions win ties
@@ -2328,10 +2305,8 @@ __global__ void __launch_bounds__(64) k_tb_cigar(int64_t first, int64_t count, c
             int32_t gm = wave_shr1(mv_, 0x3fffffff), gp = wave_shr1(mp_, 0);      // ... before this word (lane 0 takes the chunks before, below)
             if (lane == 0 || base_min < gm) { gm = base_min; gp = base_min_pos; }      // (the chunks before hold earlier positions: they win only when strictly lower)
             {
-                const int32_t Bg = Bv + start - gm;
-                const bool takeA = Av > Bg || (Av == Bg && sA <= sB);
-                const int32_t V = takeA ? Av : Bg;
-                if (wi < nW && V > bestS) { bestS = V; bestP = 16 * wi + (takeA ? sA : sB); bestE = takeA ? 16 * wi + eA : gp; }      // words ascend within a lane: '>' keeps the smallest s
+                const cigc::Pick pick = cigc::word_pick(O, start, gm, gp, wi);
+                if (wi < nW && pick.V > bestS) { bestS = pick.V; bestP = pick.s; bestE = pick.e; }      // words ascend within a lane: '>' keeps the smallest s
             }
             {
                 const int32_t cm = __builtin_amdgcn_readlane(mv_, 63), cp = __builtin_amdgcn_readlane(mp_, 63);

@@ -548,18 +548,6 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
     std::vector<int64_t> rd_list;
     const bool rows_early = mh.have && nm->names && nm->name_off && j_read_ctg && njc > 0;
     std::thread rows_thread;
-    if (rows_early) {
-        rd_first.assign((size_t)njc + 1, 0);
-        for (int64_t r = 0; r < njr; r++) if (j_read_ctg[r] >= 0 && j_read_ctg[r] < njc) rd_first[(size_t)j_read_ctg[r] + 1]++;
-        for (int32_t c = 0; c < njc; c++) rd_first[(size_t)c + 1] += rd_first[(size_t)c];
-        rd_list.resize((size_t)rd_first[(size_t)njc]);
-        local_of.assign((size_t)njr, -1);
-        {
-            std::vector<int64_t> at(rd_first.begin(), rd_first.end() - 1);
-            for (int64_t r = 0; r < njr; r++) if (j_read_ctg[r] >= 0 && j_read_ctg[r] < njc) { const int32_t c = j_read_ctg[r]; local_of[(size_t)r] = (int32_t)(at[(size_t)c] - rd_first[(size_t)c]); rd_list[(size_t)at[(size_t)c]++] = r; }
-        }
-        erows.resize((size_t)njc);
-    }
     struct JoinRows { std::thread &t; ~JoinRows() { if (t.joinable()) t.join(); } } rows_join{rows_thread};      // (declared after everything the thread touches)
     if (o->flags & FZP_PIPE_REBUILD_INDEX) FZP_TRY(fzp_align_invalidate_index(job));
     FZP_TRY(fzp_align_run_deferred(ctx, job));      // (whether the fail list overflowed is asked by fzp_align_to_batch, in the fetch it makes anyway)
@@ -567,6 +555,17 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
     if (rows_early) {
         rows_thread = std::thread([&, T]() {
             (void)pthread_setname_np(pthread_self(), "fzp-rows");
+            // which reads a contig has, in input order (here and not on the calling thread: nothing of this may stand between a step's last copy and the next step's first kernel)
+            rd_first.assign((size_t)njc + 1, 0);
+            for (int64_t r = 0; r < njr; r++) if (j_read_ctg[r] >= 0 && j_read_ctg[r] < njc) rd_first[(size_t)j_read_ctg[r] + 1]++;
+            for (int32_t c = 0; c < njc; c++) rd_first[(size_t)c + 1] += rd_first[(size_t)c];
+            rd_list.resize((size_t)rd_first[(size_t)njc]);
+            local_of.assign((size_t)njr, -1);
+            {
+                std::vector<int64_t> at(rd_first.begin(), rd_first.end() - 1);
+                for (int64_t r = 0; r < njr; r++) if (j_read_ctg[r] >= 0 && j_read_ctg[r] < njc) { const int32_t c = j_read_ctg[r]; local_of[(size_t)r] = (int32_t)(at[(size_t)c] - rd_first[(size_t)c]); rd_list[(size_t)at[(size_t)c]++] = r; }
+            }
+            erows.resize((size_t)njc);
             const ReadMaps *mp = mh.get();
             if (!mp) return;
             const std::function<void(int, int)> w = [&](int, int c) {

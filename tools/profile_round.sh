@@ -1,12 +1,12 @@
 #!/bin/bash
 # usage (on the GPU box, from the repo root): bash tools/profile_round.sh <tag>
 # kernel-trace stats of the bench, the two HBM counter passes and the SQ issue counters (each in its own rocprofv3 run, counters only;
-# the program sits directly after `--` and never forks: --gen-workers 1), then the default bench line
+# the program sits directly after `--` and never forks: --gen-workers 1 --no-tree-compare), then the default bench line
 tag=$1
 export TMPDIR=/tmp
 out=gpurun_out/prof_$tag
 mkdir -p $out
-B="--no-cpu-baseline --no-end-to-end --no-shaped-leg --gen-workers 1"
+B="--no-cpu-baseline --no-end-to-end --no-shaped-leg --gen-workers 1 --no-tree-compare"
 C="$B --no-kernel-breakdown"      # counter passes: exactly the launches of ONE step
 rocprofv3 --kernel-trace --stats -d $out/kt -o kt --output-format csv -- python3 bench.py --steps 2 --warmup 1 $B > $out/kt_bench_line.json 2> $out/kt.log
 rocprofv3 --pmc FETCH_SIZE -d $out/fetch -o p --output-format csv -- python3 bench.py --steps 1 --warmup 0 $C > /dev/null 2> $out/fetch.log

@@ -3,7 +3,7 @@
 tag=$1; ctrs=$2; pat=${3:-k_}
 export TMPDIR=/tmp
 out=gpurun_out/pmc_$tag; mkdir -p $out
-C="--no-cpu-baseline --no-end-to-end --no-shaped-leg --gen-workers 1 --no-kernel-breakdown --no-two-core"
+C="--no-cpu-baseline --no-end-to-end --no-shaped-leg --gen-workers 1 --no-tree-compare --no-kernel-breakdown --no-two-core"
 rocprofv3 --pmc $ctrs -d $out/p -o p --output-format csv -- python3 bench.py --steps 1 --warmup 0 $C > /dev/null 2> $out/log.txt
 python3 - <<PY
 import csv, glob, collections, re

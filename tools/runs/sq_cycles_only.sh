@@ -5,7 +5,7 @@ for kv in "$@"; do export "$kv"; done
 export TMPDIR=/tmp
 out=gpurun_out/sqc_$tag
 mkdir -p $out
-C="--no-cpu-baseline --no-end-to-end --no-shaped-leg --gen-workers 1 --no-kernel-breakdown --no-two-core"
+C="--no-cpu-baseline --no-end-to-end --no-shaped-leg --gen-workers 1 --no-tree-compare --no-kernel-breakdown --no-two-core"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY -d $out/sq2 -o p --output-format csv -- python3 bench.py --steps 1 --warmup 0 $C > /dev/null 2> $out/sq2.log
 rocprofv3 --pmc SQ_WAIT_ANY SQ_INSTS_LDS SQ_INSTS_VALU SQ_WAVES -d $out/sq3 -o p --output-format csv -- python3 bench.py --steps 1 --warmup 0 $C > /dev/null 2> $out/sq3.log
 cat $(find $out/sq2 -name '*counter_collection.csv') > $out/a.csv; cat $(find $out/sq3 -name '*counter_collection.csv') > $out/b.csv
