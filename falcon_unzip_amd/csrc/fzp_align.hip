@@ -3121,7 +3121,7 @@ static int align_run(fzp_ctx *ctx, fzp_alnjob *j, bool defer_overflow) {
             for (auto v : j->h_ctg_len) lc_max = std::max(lc_max, v);
             for (auto v : j->h_read_len) n_max = std::max<int64_t>(n_max, v);
             const int64_t nb_max = std::min<int64_t>(MAX_BINS, ((lc_max + n_max) >> 10) + 2);
-            const size_t lds = ((size_t)nb_max + (size_t)(n_max / 16 + 4)) * sizeof(uint32_t);      // vote bins (two strands x nb_max, 16 bits each) + (v1.7) one count per packed word of the longest read
+            const size_t lds = ((size_t)nb_max + (P.seed_anchored ? (size_t)(n_max / 16 + 4) : 0)) * sizeof(uint32_t);      // vote bins (two strands x nb_max, 16 bits each) + (v1.7's anchored k-mers only) one count per packed word of the longest read: reads of up to ~480 kb
             if (lds > 150 * 1024) { fzp_set_error("fzp_align_run: a read of %lld bases against a contig of %lld: the seeding kernel's tables (%zu KB) do not fit a CU's LDS", (long long)n_max, (long long)lc_max, lds >> 10); return FZP_EINVAL; }
             FZP_HIP(hipFuncSetAttribute((const void *)k_seed, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             { const fzp_fill_piece fl[3] = {fzp_zeroes(j->n_sec, 1), {j->rtot.p, 32, 0u}, fzp_zeroes(j->fb_overflow, 1)}; FZP_TRY(fzp_fill(ctx, st, fl, 3)); }      // (the plan's counters too: one launch)

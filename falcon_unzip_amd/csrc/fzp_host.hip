@@ -277,8 +277,11 @@ void *fzp_pinned_acquire(fzp_ctx *ctx, size_t bytes, size_t *cap) {
     {
         std::lock_guard<std::mutex> lk(ctx->pin_mu);
         size_t best = (size_t)-1;
+        // best fit -- but not a block more than four times the size asked for: a 100 MB text block that settles in the 1.5 GB block of a group's FASTA files sends the next group's
+        // files to hipHostMalloc (hundreds of milliseconds per GB), and the pool takes calls to converge (r6: the second call of configs[4] from files 0.69 s, the third 0.19)
+        const size_t roof = bytes * 4 + (8u << 20);
         for (size_t i = 0; i < ctx->pin_free.size(); i++)
-            if (ctx->pin_free[i].second >= bytes && (best == (size_t)-1 || ctx->pin_free[i].second < ctx->pin_free[best].second)) best = i;
+            if (ctx->pin_free[i].second >= bytes && ctx->pin_free[i].second <= roof && (best == (size_t)-1 || ctx->pin_free[i].second < ctx->pin_free[best].second)) best = i;
         if (best != (size_t)-1) {
             auto blk = ctx->pin_free[best];
             ctx->pin_free.erase(ctx->pin_free.begin() + (long)best);

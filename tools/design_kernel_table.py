@@ -24,30 +24,30 @@ BEGIN, END = "<!-- kernel-table:begin (tools/design_kernel_table.py) -->", "<!--
 # (row name, kernels, what, bound, algorithmic bytes or operations per unit)
 CATALOGUE = [
     ("K1 DP `k1_sw`", ["k_swb", "k_sw", "k_swb_units"],
-     "adaptive banded DP of every extension piece in one launch; bit-sliced, a piece per lane, the band's 32 cells in the 32 bits of a plane word (section 5b); `k_sw` (a wave per piece) beside it for pieces narrower than the band",
+     "adaptive banded DP of every extension piece in one launch; bit-sliced, a piece per lane, the band's 32 cells in the bits of a word (5b); `k_sw` (a wave per piece) beside it for pieces narrower than the band",
      "VALU issue (one persistent wave per SIMD)",
-     "SURVEY 8d: 0.25 B/cell (2 trace-back bits); written: 8 B per band step = the whole D and G masks; 1.37 wave64 VALU instructions per band step"),
+     "SURVEY 8d: 0.25 B/cell; written: 8 B per band step (the whole D and G masks); 1.37 wave64 VALU instructions per band step"),
     ("K1 walk `k1_traceback`", ["k_tb_walk_h", "k_tb_walk", "k_fail_plan"],
-     "a lane per piece, 32 walkers per wave in step over 32-step runs of the mask buffer (one 8 KB run per wave and iteration, staged through LDS), 2-bit op stream out",
+     "a lane per piece, 32 walkers per wave in step (one 8 KB run of the masks per wave and iteration, staged through LDS), 2-bit op stream out",
      "HBM (scattered 512-byte pieces, latency of the staged run)",
      "8 B per step below the path's end in, 0.25 B per step out"),
     ("K1 seeds `k1_seed`", ["k_seed", "k_chain"],
-     "anchored k-mers of the read looked up in 32-byte buckets (two probes in flight per thread), ordered hit list, 16-bit vote bins, two windows; a wave per (read, window) chains the hits and leaves anchor + waypoints",
+     "anchored k-mers looked up in 32-byte buckets, ordered hit list, vote bins, two windows; a wave per (read, window) chains the hits: anchor + waypoints",
      "HBM random access (`k_seed`), instruction issue (`k_chain`)",
      "32 B per probe (57 fetched: one 64-B request), 8 B per hit"),
     ("K1 path `k1_cigar`, `k1_join`", ["k_tb_cigar", "k_join", "k_pick_offsets"],
-     "candidate pick and the joined op stream (a wave per read); best-scoring stretch of the path, run-length CIGAR, summary, identity gate, the packed hand-off's checkpoints",
+     "candidate pick, joined op stream (a wave per read); best-scoring stretch of the path (5c), run-length CIGAR, summary, identity gate, hand-off checkpoints",
      "latency / instruction issue (a wave per read)",
      "0.25 B per op + 0.25 B per base in; 4 B per run + 8 B per 256 ops out"),
     ("K1 index `k1_index`", ["k_index_stage_anch", "k_index_build"],
      "anchored k-mers of the contigs staged into 64 KB partitions, partition tables built in LDS and written as images",
      "HBM streaming", "8 B per selected k-mer staged, 64 KB per partition out"),
     ("K1 plans", ["k_slot_count", "k_slot_emit", "k_sort_hist", "k_sort_scatter", "k_route", "k_lists", "k_plan_final", "k_cand", "k_plan_keys", "k_plan_rank", "k_plan_emit", "k_rank_allpairs", "k_range_n"],
-     "pieces as 32-byte slots, sorted longest first, routed to the DP kernels, streams planned in launch order; records ranked by (POS, read)",
+     "pieces as 32-byte slots, longest first, streams planned in launch order; records ranked by (POS, read)",
      "launch latency", "32 B per slot"),
     ("K2 `k2_*`", ["k_pileup_pk", "k_vmap_pk", "k_site_flag", "k_site_emit", "k_vmap_len", "k_vmap_put", "k_tile_tables", "k_copy_ref", "k_site_begin_blk", "k_vmap_row_begin"],
-     "pileup from K1's packed records (a lane per 16-op word, LDS counters per 2 048-position tile), het call per position, variant_map rows",
-     "memory latency / LDS atomics", "0.25 B per op + 0.25 B per base in, 20 B per position of a live tile out and in again"),
+     "pileup from K1's packed records (a lane per 16-op word, LDS counters per tile), het call per position, variant_map rows",
+     "memory latency / LDS atomics", "0.25 B per op + 0.25 B per base in, 20 B per live position out"),
     ("K3 `k3_*`", ["k_site_sets", "k_assoc", "k_assoc_compact", "k_arow_len", "k_arow_put", "k_arow_begin"],
      "per site the two alleles' sorted q_id sets; four intersections per site pair inside the 65 536 bp window",
      "latency (small)", "24 B per row out"),
@@ -57,10 +57,10 @@ CATALOGUE = [
     ("K5 `k5_*`", ["k_read_votes", "k_read_flag", "k_read_emit", "k_pread_begin"],
      "votes per (read, block), phase per read", "latency (small)", "12 B per set entry"),
     ("scans, fills, fetches", ["k_scan_small_u64", "k_apply_u32", "k_tile_sums", "k_tile_sums_u64", "k_apply_u64", "k_fill_regions", "k_fetch_post", "k_u32_to_i64_begin"],
-     "ordered compaction everywhere (no output order rests on atomics); a stage's fills in one launch; count read-backs through mapped memory",
+     "ordered compaction (no output order rests on atomics); fills; count read-backs through mapped memory",
      "launch latency", "-"),
     ("runtime copies", ["__amd_rocclr_copyBuffer", "__amd_rocclr_fillBufferAligned"],
-     "records, rid_to_phase rows and 30 MB of device-made text to the host's pinned block", "PCIe", "-"),
+     "records and 30 MB of device-made text to pinned host memory", "PCIe", "-"),
     ("job set-up (outside the step)", ["k_pack", "k_revcomp", "k_upper"],
      "2-bit packing of reads and contigs, reverse complements, once per job", "HBM streaming", "1 B per base in, 0.25 out"),
 ]

@@ -82,10 +82,13 @@ def run(scale=1.0, lanes=2, workers=8, out_root=None, keep=False, consensus=True
             time.sleep(0.02)
     th = threading.Thread(target=sample, daemon=True)
     th.start()
+    if out_root is None:                       # (r6: like bench.py, the output trees go to a memory file system when it has room -- on the box's disk-backed /tmp what a call
+        from bench import shm_with_room        # takes depends on what earlier processes left in the page cache: 0.21 s or 0.44 s for the same tree)
+        out_root = shm_with_room(int(4e9 * max(scale, 0.05)))
     out_dir = tempfile.mkdtemp(prefix="fzp_cfg5_", dir=out_root)
     # the first call also fills the contexts' block caches (150 GB of hipMalloc: 0.6 - 1.8 s depending on the box); the second is the job itself
     walls = []
-    for k in range(2):
+    for k in range(4):
         t1 = time.perf_counter()
         if from_files:
             stats, recs = _lib.phase_contigs_files(eng, reads_dir, ids, out_dir=os.path.join(out_dir, "run%d" % k), read_maps=maps, n_lanes=lanes, consensus=consensus)
@@ -93,18 +96,18 @@ def run(scale=1.0, lanes=2, workers=8, out_root=None, keep=False, consensus=True
             stats, recs = _lib.phase_contigs(eng, contigs, blob, off, read_ctg, ids, names=name_tab, out_dir=os.path.join(out_dir, "run%d" % k), read_maps=maps, n_lanes=lanes,
                                              consensus=consensus)
         walls.append(time.perf_counter() - t1)
-    wall = walls[1]
-    out_dir = os.path.join(out_dir, "run1")
+    wall = min(walls[1:])                      # (r6: the best of three calls behind the first, all four in `walls_s`: single calls vary by a factor of two on some boxes)
+    out_dir = os.path.join(out_dir, "run3")
     peak["stop"] = True
     th.join()
     n_files = sum(len(f) for _, _, f in os.walk(out_dir))
     res = {"config": "configs[4] at scale %.2f: %d contigs, %.1f Mb, %d reads x 15 kb (%.2f Gb), 40x; K1..K5 + K6 consensus + all files, fzp_phase_contigs on %d lanes"
                      % (scale, len(contigs), sum(len(c) for c in contigs) / 1e6, len(read_ctg), len(blob) / 1e9, lanes),
-           "wall_s": round(wall, 3), "first_call_wall_s": round(walls[0], 3), "reads_per_s": round(len(read_ctg) / wall, 1), "input_generation_s": round(t_gen, 1),
+           "wall_s": round(wall, 3), "first_call_wall_s": round(walls[0], 3), "walls_s": [round(w, 3) for w in walls], "reads_per_s": round(len(read_ctg) / wall, 1), "input_generation_s": round(t_gen, 1),
            "peak_hbm_gb": round(peak["used"] / 2**30, 2), "hbm_total_gb": round(total_mem / 2**30, 1),
            "dp_gcell_per_s_wall": round(stats["dp_cells"] / wall / 1e9, 1), "files_written": n_files, "r2p_records": int(len(recs)),
            "reads_phased": int((recs["block"] != -1).sum()), "stats": {k: (round(v, 2) if isinstance(v, float) else int(v)) for k, v in stats.items()},
-           "longest_contig_reads": int(np.bincount(read_ctg).max())}
+           "longest_contig_reads": int(np.bincount(read_ctg).max()), "out_root": out_root or tempfile.gettempdir()}
     mon.close()
     eng.close()
     if reads_dir:
