@@ -232,8 +232,17 @@ def _take(ptr, n, dtype):
     n = int(n)
     if not ptr:
         return np.zeros(0, dtype=dtype)
-    arr = np.frombuffer(C.string_at(ptr, n * np.dtype(dtype).itemsize), dtype=dtype).copy() if n else np.zeros(0, dtype=dtype)
+    arr = _copy_in(ptr, n, dtype)
     lib.fzp_free(ptr)
+    return arr
+
+
+def _copy_in(ptr, n, dtype):
+    """n records at `ptr` into a fresh numpy array with ONE memmove.  (np.frombuffer(...).copy() of a structured dtype goes field by field: 0.3 ms for 40 000 rid_to_phase
+    records, 2 ms for the 320 000 an eight-rank gather returns -- per step.)"""
+    arr = np.empty(int(n), dtype=dtype)
+    if n:
+        C.memmove(arr.ctypes.data, ptr, int(n) * arr.dtype.itemsize)
     return arr
 
 
@@ -733,7 +742,7 @@ def _pipe_args(ctg_ids, names, out_dir, read_maps, ctg_index, n_threads, n_lanes
 
 
 def _pipe_result(out):
-    recs = np.frombuffer(C.string_at(out.r2p, int(out.n_r2p) * R2P.itemsize), dtype=R2P).copy() if out.n_r2p else np.zeros(0, R2P)
+    recs = _copy_in(out.r2p, out.n_r2p, R2P) if out.n_r2p else np.zeros(0, R2P)
     stats = {k: getattr(out, k) for k, _ in PipeOut._fields_ if k not in ("r2p",)}
     load().fzp_pipe_out_free(C.byref(out))
     return stats, recs

@@ -220,7 +220,22 @@ extern "C" int fzp_allgather_rid_to_phase(fzp_comm *c, const fzp_r2p *local, int
     }
     { const int wrc = wait_stream(st, "ncclAllGather(records)"); if (wrc != FZP_OK) { free(out); return wrc; } }
     // 3. the order of rid_to_phase.all: sorted per-contig paths (unzip.py:306-307) = contig index, then pread id
-    std::sort(out, out + total, [](const fzp_r2p &a, const fzp_r2p &b) { return a.ctg != b.ctg ? a.ctg < b.ctg : a.arid < b.arid; });
+    // (r6: a rank's records arrive in that order, and ranks that hold consecutive contig ranges -- the usual deal -- arrive in order as a whole: look first, then merge the
+    // ranks' runs, and sort only what is left.  Eight ranks x 40 000 records: std::sort took ~10 ms of every step on every rank.)
+    {
+        const auto less = [](const fzp_r2p &a, const fzp_r2p &b) { return a.ctg != b.ctg ? a.ctg < b.ctg : a.arid < b.arid; };
+        if (!std::is_sorted(out, out + total, less)) {
+            std::vector<size_t> cut{0};
+            for (int r = 0; r < W; r++) cut.push_back(cut.back() + (size_t)cnts[(size_t)r]);
+            bool runs_sorted = true;
+            for (int r = 0; r < W && runs_sorted; r++) runs_sorted = std::is_sorted(out + cut[(size_t)r], out + cut[(size_t)r + 1], less);
+            if (runs_sorted) {
+                for (size_t width = 1; width < (size_t)W; width *= 2)
+                    for (size_t r = 0; r + width < (size_t)W; r += 2 * width)
+                        std::inplace_merge(out + cut[r], out + cut[r + width], out + cut[std::min(r + 2 * width, (size_t)W)], less);
+            } else std::sort(out, out + total, less);
+        }
+    }
     *all = out;
     *n_all = (int64_t)total;
     return FZP_OK;

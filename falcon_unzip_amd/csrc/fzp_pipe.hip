@@ -865,6 +865,7 @@ static int job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_names *nm, c
             if (failed.load() >= 0) { fzp_set_error("%s", whys[(size_t)failed.load()]->c_str()); return FZP_EIO; }
         }
     }
+    { size_t tot = r2p.size(); for (int c = 0; c < nc; c++) tot += recs[(size_t)c].size(); r2p.reserve(tot); }      // (one block, not a doubling series of them)
     for (int c = 0; c < nc; c++) r2p.insert(r2p.end(), recs[(size_t)c].begin(), recs[(size_t)c].end());
     out->ms_text += ms_since(t0);
     if (timing) fprintf(stderr, "[fzp_pipe] host section %.2f ms on %d threads; summed over contigs: names %.2f fmt %.2f readmap %.2f write %.2f ms\n", ms_since(t0), T,
