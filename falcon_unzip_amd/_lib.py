@@ -71,11 +71,21 @@ class Tigs:
     def __init__(self, ts: TigsStruct):
         self._ts = ts
         n = int(ts.n_tigs)
-        self.tigs = np.frombuffer(C.string_at(ts.tigs, n * TIG.itemsize), dtype=TIG).copy() if n else np.zeros(0, TIG)
-        self.seq = C.string_at(ts.seq, int(ts.n_seq)) if ts.n_seq else b""
+        self.tigs = _copy_in(ts.tigs, n, TIG) if n else np.zeros(0, TIG)
+        self._seq = None      # (the bases stay in the library's block until somebody asks: a polished genome is hundreds of megabytes, copied into fresh pages at 4 GB/s)
+
+    @property
+    def seq(self):
+        if self._seq is None:
+            if self._ts is None:
+                raise FzpError(-1, "Tigs: closed")
+            self._seq = C.string_at(self._ts.seq, int(self._ts.n_seq)) if self._ts.n_seq else b""
+        return self._seq
 
     def sequence(self, i):
         t = self.tigs[i]
+        if self._seq is None and self._ts is not None:
+            return C.string_at(self._ts.seq + int(t["seq_off"]), int(t["seq_len"])) if t["seq_len"] else b""
         return self.seq[int(t["seq_off"]):int(t["seq_off"] + t["seq_len"])]
 
     def fasta(self, ctg, ctg_id: str):

@@ -18,6 +18,7 @@
 // HBM-bound integer work: 1 B symbol + 4 B/op in, 40 B of counters per (position, phase) touched by atomics, 1 B out.
 #include <algorithm>
 #include "fzp_expand.h"
+#include <chrono>
 #include "fzp_pk.h"
 
 namespace {
@@ -775,48 +776,57 @@ extern "C" int fzp_polish_tigs(fzp_ctx *ctx, int32_t n_tigs, const uint8_t *cons
     std::vector<fzp_tig> tigs;
     DevBuf<uint8_t> seq;
     uint64_t tot = 0;
+    static const bool timing = getenv("FZP_PIPE_TIMING") != nullptr;
+    const auto t_0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) { if (timing) fprintf(stderr, "[fzp_polish_tigs] +%.2f ms: %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_0).count(), what); };
     int rc = fzp_align_create(ctx, n_tigs, tig_seq, tig_len, n_reads, read_tig, read_off, read_seq, params, &job);
+    lap("alignment job created (upload, pack, index)");
     if (rc == FZP_OK) rc = fzp_align_run(ctx, job);
     if (rc == FZP_OK) rc = fzp_align_to_batch(ctx, job, &b);
-    std::vector<uint8_t> hseq;
+    lap("reads aligned");
     if (rc == FZP_OK) {
         fzp_cns_polish P;
         P.len = tig_len;
         fzp_align_templates(job, &P.ref, &P.ref_off);
         rc = fzp_batch_consensus_dev(ctx, b, 3, tigs, seq, &tot, &P);
-        if (rc == FZP_OK && tot) {
-            hseq.resize((size_t)tot);
-            if (hipMemcpyAsync(hseq.data(), seq.p, (size_t)tot, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
-                (void)hipGetLastError(); fzp_set_error("fzp_polish_tigs: consensus download failed"); rc = FZP_EDEVICE;
+        lap("piles called");
+    }
+    // every tig once, input order; the ones without a pile as they came.  (r6: a tig's bases come straight from the device to their place in the caller's block -- through
+    // a zero-filled vector and a second copy the 100 Mb of the bench's twenty tigs cost 50 ms of a 100 ms call)
+    int64_t total = 0;
+    std::vector<const fzp_tig *> of((size_t)n_tigs, nullptr);
+    if (rc == FZP_OK) {
+        for (const auto &t : tigs) of[(size_t)t.ctg] = &t;
+        for (int c = 0; c < n_tigs; c++) total += of[(size_t)c] ? of[(size_t)c]->seq_len : tig_len[c];
+        out->tigs = (fzp_tig *)malloc((size_t)n_tigs * sizeof(fzp_tig));
+        out->seq = (uint8_t *)malloc((size_t)(total ? total : 1));
+        if (!out->tigs || !out->seq) rc = FZP_ENOMEM;
+    }
+    if (rc == FZP_OK) {
+        int64_t at = 0;
+        for (int c = 0; c < n_tigs && rc == FZP_OK; c++) {
+            fzp_tig t;
+            memset(&t, 0, sizeof t);
+            t.ctg = c; t.block = 1; t.phase = 0; t.lo = 0; t.hi = (int32_t)(tig_len[c] - 1); t.seq_off = at;
+            if (of[(size_t)c]) {
+                t.n_records = of[(size_t)c]->n_records; t.seq_len = of[(size_t)c]->seq_len;
+                if (t.seq_len && hipMemcpyAsync(out->seq + at, seq.p + of[(size_t)c]->seq_off, (size_t)t.seq_len, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) {
+                    (void)hipGetLastError(); fzp_set_error("fzp_polish_tigs: consensus download failed"); rc = FZP_EDEVICE;
+                }
+            } else {
+                t.seq_len = tig_len[c];
+                for (int64_t i = 0; i < tig_len[c]; i++) { const uint8_t ch = tig_seq[c][i]; out->seq[at + i] = (ch >= 'a' && ch <= 'z') ? (uint8_t)(ch - 32) : ch; }
             }
+            at += t.seq_len;
+            out->tigs[c] = t;
         }
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess && rc == FZP_OK) { (void)hipGetLastError(); fzp_set_error("fzp_polish_tigs: consensus download failed"); rc = FZP_EDEVICE; }
+        lap("sequences on the host");
     }
     if (b) fzp_batch_destroy(ctx, b);
     if (job) fzp_align_destroy(ctx, job);
-    if (rc != FZP_OK) return rc;
-    // every tig once, input order; the ones without a pile as they came
-    int64_t total = 0;
-    std::vector<const fzp_tig *> of((size_t)n_tigs, nullptr);
-    for (const auto &t : tigs) of[(size_t)t.ctg] = &t;
-    for (int c = 0; c < n_tigs; c++) total += of[(size_t)c] ? of[(size_t)c]->seq_len : tig_len[c];
-    out->tigs = (fzp_tig *)malloc((size_t)n_tigs * sizeof(fzp_tig));
-    out->seq = (uint8_t *)malloc((size_t)(total ? total : 1));
-    if (!out->tigs || !out->seq) { free(out->tigs); free(out->seq); memset(out, 0, sizeof *out); return FZP_ENOMEM; }
-    int64_t at = 0;
-    for (int c = 0; c < n_tigs; c++) {
-        fzp_tig t;
-        memset(&t, 0, sizeof t);
-        t.ctg = c; t.block = 1; t.phase = 0; t.lo = 0; t.hi = (int32_t)(tig_len[c] - 1); t.seq_off = at;
-        if (of[(size_t)c]) {
-            t.n_records = of[(size_t)c]->n_records; t.seq_len = of[(size_t)c]->seq_len;
-            memcpy(out->seq + at, hseq.data() + of[(size_t)c]->seq_off, (size_t)t.seq_len);
-        } else {
-            t.seq_len = tig_len[c];
-            for (int64_t i = 0; i < tig_len[c]; i++) { const uint8_t ch = tig_seq[c][i]; out->seq[at + i] = (ch >= 'a' && ch <= 'z') ? (uint8_t)(ch - 32) : ch; }
-        }
-        at += t.seq_len;
-        out->tigs[c] = t;
-    }
+    lap("job destroyed");
+    if (rc != FZP_OK) { free(out->tigs); free(out->seq); memset(out, 0, sizeof *out); return rc; }
     out->n_tigs = n_tigs; out->n_seq = total;
     return FZP_OK;
 }
