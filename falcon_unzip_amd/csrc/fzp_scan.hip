@@ -109,6 +109,31 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_apply_u32(const uint32_t *in, 
     }
 }
 
+// r6: the middle launch folded away.  A tile's offset is the sum of the tile sums before it -- at most 2 048 of them, which a workgroup adds up itself in the time a launch
+// takes to start (a step's eighteen scans were fifty-four launches of 4.5 us each; now thirty-six, and a scan that fits one tile is one).  The last tile leaves the total.
+__global__ void __launch_bounds__(SCAN_THREADS) k_apply_sums_u32(const uint32_t *in, uint32_t *out, size_t n, const uint64_t *tile_sums, uint64_t *total) {
+    uint64_t part = 0;
+    for (unsigned i = threadIdx.x; i < blockIdx.x; i += SCAN_THREADS) part += tile_sums[i];
+    uint64_t before;
+    (void)block_excl_scan_u64(part, &before);
+    size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
+    uint32_t x[SCAN_ITEMS];
+    uint64_t s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        x[i] = (base + i < n) ? in[base + i] : 0;
+        s += x[i];
+    }
+    uint64_t tot;
+    uint64_t off = block_excl_scan_u64(s, &tot) + before;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        if (base + i < n) out[base + i] = (uint32_t)off;
+        off += x[i];
+    }
+    if (total && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total = before + tot;
+}
+
 int scan_u64_inplace(fzp_ctx *ctx, uint64_t *v, size_t n, uint64_t *total_dev, int level) {
     if (n <= (size_t)SCAN_TILE) {
         hipLaunchKernelGGL(k_scan_small_u64, dim3(1), dim3(SCAN_THREADS), 0, ctx->stream, v, n, total_dev);
@@ -135,6 +160,18 @@ int fzp_exclusive_scan_u32(fzp_ctx *ctx, const uint32_t *in, uint32_t *out, size
     }
     ProfScope ps(ctx, "scan");
     size_t tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+    static const bool three_pass = getenv("FZP_SCAN_3PASS") != nullptr;      // (A/B runs: the r1-r5 form)
+    if (tiles <= (size_t)SCAN_TILE && !three_pass) {
+        uint64_t *sums = nullptr;
+        if (tiles > 1) {
+            FZP_TRY(ctx->scan_tmp[0].alloc(tiles));
+            sums = ctx->scan_tmp[0].p;
+            hipLaunchKernelGGL(k_tile_sums, dim3((unsigned)tiles), dim3(SCAN_THREADS), 0, ctx->stream, in, n, sums);
+        }
+        hipLaunchKernelGGL(k_apply_sums_u32, dim3((unsigned)tiles), dim3(SCAN_THREADS), 0, ctx->stream, in, out, n, sums, total_dev);
+        FZP_HIP(hipGetLastError());
+        return FZP_OK;
+    }
     FZP_TRY(ctx->scan_tmp[0].alloc(tiles));
     uint64_t *sums = ctx->scan_tmp[0].p;
     hipLaunchKernelGGL(k_tile_sums, dim3((unsigned)tiles), dim3(SCAN_THREADS), 0, ctx->stream, in, n, sums);

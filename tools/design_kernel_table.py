@@ -56,7 +56,7 @@ CATALOGUE = [
      "latency (a contig is a few waves)", "16 B per link"),
     ("K5 `k5_*`", ["k_read_votes", "k_read_flag", "k_read_emit", "k_pread_begin"],
      "votes per (read, block), phase per read", "latency (small)", "12 B per set entry"),
-    ("scans, fills, fetches", ["k_scan_small_u64", "k_apply_u32", "k_tile_sums", "k_tile_sums_u64", "k_apply_u64", "k_fill_regions", "k_fetch_post", "k_u32_to_i64_begin"],
+    ("scans, fills, fetches", ["k_scan_small_u64", "k_apply_u32", "k_apply_sums_u32", "k_tile_sums", "k_tile_sums_u64", "k_apply_u64", "k_fill_regions", "k_fetch_post", "k_u32_to_i64_begin"],
      "ordered compaction (no output order rests on atomics); fills; count read-backs through mapped memory",
      "launch latency", "-"),
     ("runtime copies", ["__amd_rocclr_copyBuffer", "__amd_rocclr_fillBufferAligned"],
