@@ -3124,7 +3124,8 @@ static int align_run(fzp_ctx *ctx, fzp_alnjob *j, bool defer_overflow) {
             const size_t lds = ((size_t)nb_max + (P.seed_anchored ? (size_t)(n_max / 16 + 4) : 0)) * sizeof(uint32_t);      // vote bins (two strands x nb_max, 16 bits each) + (v1.7's anchored k-mers only) one count per packed word of the longest read: reads of up to ~480 kb
             if (lds > 150 * 1024) { fzp_set_error("fzp_align_run: a read of %lld bases against a contig of %lld: the seeding kernel's tables (%zu KB) do not fit a CU's LDS", (long long)n_max, (long long)lc_max, lds >> 10); return FZP_EINVAL; }
             FZP_HIP(hipFuncSetAttribute((const void *)k_seed, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            { const fzp_fill_piece fl[3] = {fzp_zeroes(j->n_sec, 1), {j->rtot.p, 32, 0u}, fzp_zeroes(j->fb_overflow, 1)}; FZP_TRY(fzp_fill(ctx, st, fl, 3)); }      // (the plan's counters too: one launch)
+            FZP_TRY(j->pkrec.alloc((size_t)nr));      // (the packed hand-off's per-read records: zeroed here, with the counters, instead of by a runtime fill of its own behind the plan's read-back)
+            { const fzp_fill_piece fl[4] = {fzp_zeroes(j->n_sec, 1), {j->rtot.p, 32, 0u}, fzp_zeroes(j->fb_overflow, 1), fzp_zeroes(j->pkrec, (size_t)nr)}; FZP_TRY(fzp_fill(ctx, st, fl, 4)); }      // (the plan's counters too: one launch)
             const int64_t seed_chunk = 65536;            // reads per seeding launch: HIT_CAP x 12 B of hit list and waypoint links each (3 GiB)
             FZP_TRY(j->hits.alloc((size_t)std::min<int64_t>(nr, seed_chunk) * HIT_CAP));
             FZP_TRY(j->wpp.alloc((size_t)std::min<int64_t>(nr, seed_chunk) * 2 * HIT_CAP));
@@ -3154,8 +3155,8 @@ static int align_run(fzp_ctx *ctx, fzp_alnjob *j, bool defer_overflow) {
             hipLaunchKernelGGL(k_slot_count, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, st, nr, j->anc.p, j->ancB.p, j->n_wp.p, j->wps.p, j->read_len.p, j->read_ctg.p, j->ctg_len.p,
                                j->r_cnt.p, j->r_capq.p, j->n_sec.p, (int32_t)swb_max_steps, use_bits ? band : 0, (unsigned long long *)(j->rtot.p + 2));
         }
-        FZP_TRY(fzp_exclusive_scan_u32(ctx, j->r_cnt.p, j->slot_base.p, (size_t)nr, j->rtot.p + 0));
-        FZP_TRY(fzp_exclusive_scan_u32(ctx, j->r_capq.p, j->rcapq_scan.p, (size_t)nr, j->rtot.p + 1));
+        FZP_TRY(fzp_exclusive_scan_u32_end(ctx, j->r_cnt.p, j->slot_base.p, (size_t)nr, j->rtot.p + 0));       // (r6: the arrays' closing entries come from the scans -- two 4-byte uploads
+        FZP_TRY(fzp_exclusive_scan_u32_end(ctx, j->r_capq.p, j->rcapq_scan.p, (size_t)nr, j->rtot.p + 1));     //  from the stack stood here, each a runtime copy with 20-40 us of idle device around it)
         uint32_t n2 = 0;
         int32_t ovf = 0;
         uint64_t rtot[4] = {0, 0, 0, 0};
@@ -3166,14 +3167,10 @@ static int align_run(fzp_ctx *ctx, fzp_alnjob *j, bool defer_overflow) {
         if (ovf) { fzp_set_error("k-mer index: a table partition overflowed (more than %d distinct k-mers hash into one 64 KB partition)", 4 << PART_BITS); return FZP_EINVAL; }
         if (rtot[0] >= (1ull << 31) || rtot[1] >= (1ull << 31)) { fzp_set_error("fzp_align_run: %llu extension pieces / %llu x 64 DP steps in one job (limit 2^31 each)", (unsigned long long)rtot[0], (unsigned long long)rtot[1]); return FZP_EINVAL; }
         const uint32_t end_sb = (uint32_t)rtot[0], end_cq = (uint32_t)rtot[1];
-        FZP_HIP(hipMemcpyAsync(j->slot_base.p + nr, &end_sb, 4, hipMemcpyHostToDevice, st));      // (4 bytes from the stack: the runtime copies them at the call)
-        FZP_HIP(hipMemcpyAsync(j->rcapq_scan.p + nr, &end_cq, 4, hipMemcpyHostToDevice, st));
         j->n_second = n2;
         // the run's joined op streams + what K2 needs to read them (the packed hand-off): 16 B per 64 DP steps of capacity, 16 B per read, 8 B per 256 ops
         FZP_TRY(j->opk.alloc((size_t)rtot[1] * 4 + 128));
-        FZP_TRY(j->pkrec.alloc((size_t)nr));
         FZP_TRY(j->pck.alloc((size_t)(rtot[1] >> 2) + (size_t)nr + 2));
-        FZP_HIP(hipMemsetAsync(j->pkrec.p, 0, (size_t)nr * sizeof(PkRec), st));
         // Trace-back masks live in HBM (8 B per DP step).  Reads go through in chunks: the DP of chunk k+1 runs on `stream` while the trace-back of chunk k
         // runs on `stream2`; two sets of buffers alternate.
         int64_t budget_steps = (int64_t)48 << 30 >> 3;   // 48 GiB of 8-byte steps over both buffers

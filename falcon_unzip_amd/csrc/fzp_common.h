@@ -172,6 +172,7 @@ void fzp_alnset_split_eqx(fzp_alnset *a, const uint8_t *ref);
 // ---------------------------------------------------------------- scans (fzp_scan.hip)
 // out[i] = sum_{j<i} in[j] over n uint32 items (in may alias out); *total_dev (device u64) gets the sum.
 int fzp_exclusive_scan_u32(fzp_ctx *ctx, const uint32_t *in, uint32_t *out, size_t n, uint64_t *total_dev);
+int fzp_exclusive_scan_u32_end(fzp_ctx *ctx, const uint32_t *in, uint32_t *out, size_t n, uint64_t *total_dev);      // ... and out[n] = the total: a CSR's closing offset without a copy of its own
 int fzp_exclusive_scan_u64_inplace(fzp_ctx *ctx, uint64_t *v, size_t n, uint64_t *total_dev);
 
 // ---------------------------------------------------------------- wave helpers (device)

@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_apply_u32(const uint32_t *in, 
 
 // r6: the middle launch folded away.  A tile's offset is the sum of the tile sums before it -- at most 2 048 of them, which a workgroup adds up itself in the time a launch
 // takes to start (a step's eighteen scans were fifty-four launches of 4.5 us each; now thirty-six, and a scan that fits one tile is one).  The last tile leaves the total.
-__global__ void __launch_bounds__(SCAN_THREADS) k_apply_sums_u32(const uint32_t *in, uint32_t *out, size_t n, const uint64_t *tile_sums, uint64_t *total) {
+__global__ void __launch_bounds__(SCAN_THREADS) k_apply_sums_u32(const uint32_t *in, uint32_t *out, size_t n, const uint64_t *tile_sums, uint64_t *total, int with_end) {
     uint64_t part = 0;
     for (unsigned i = threadIdx.x; i < blockIdx.x; i += SCAN_THREADS) part += tile_sums[i];
     uint64_t before;
@@ -131,7 +131,10 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_apply_sums_u32(const uint32_t 
         if (base + i < n) out[base + i] = (uint32_t)off;
         off += x[i];
     }
-    if (total && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total = before + tot;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        if (total) *total = before + tot;
+        if (with_end) out[n] = (uint32_t)(before + tot);      // (a CSR's closing offset: the caller gave the array n + 1 places)
+    }
 }
 
 int scan_u64_inplace(fzp_ctx *ctx, uint64_t *v, size_t n, uint64_t *total_dev, int level) {
@@ -153,9 +156,17 @@ int scan_u64_inplace(fzp_ctx *ctx, uint64_t *v, size_t n, uint64_t *total_dev, i
 }
 }  // namespace
 
-int fzp_exclusive_scan_u32(fzp_ctx *ctx, const uint32_t *in, uint32_t *out, size_t n, uint64_t *total_dev) {
+static int scan_u32(fzp_ctx *ctx, const uint32_t *in, uint32_t *out, size_t n, uint64_t *total_dev, bool with_end);
+int fzp_exclusive_scan_u32(fzp_ctx *ctx, const uint32_t *in, uint32_t *out, size_t n, uint64_t *total_dev) { return scan_u32(ctx, in, out, n, total_dev, false); }
+// ... and out[n] = the total (as 32 bits): the array has n + 1 places, total_dev is asked for
+int fzp_exclusive_scan_u32_end(fzp_ctx *ctx, const uint32_t *in, uint32_t *out, size_t n, uint64_t *total_dev) {
+    if (!total_dev) { fzp_set_error("scan: the closing offset comes from the total"); return FZP_EINVAL; }
+    return scan_u32(ctx, in, out, n, total_dev, true);
+}
+static int scan_u32(fzp_ctx *ctx, const uint32_t *in, uint32_t *out, size_t n, uint64_t *total_dev, bool with_end) {
     if (n == 0) {
         if (total_dev) FZP_HIP(hipMemsetAsync(total_dev, 0, sizeof(uint64_t), ctx->stream));
+        if (with_end) FZP_HIP(hipMemsetAsync(out, 0, sizeof(uint32_t), ctx->stream));
         return FZP_OK;
     }
     ProfScope ps(ctx, "scan");
@@ -168,7 +179,7 @@ int fzp_exclusive_scan_u32(fzp_ctx *ctx, const uint32_t *in, uint32_t *out, size
             sums = ctx->scan_tmp[0].p;
             hipLaunchKernelGGL(k_tile_sums, dim3((unsigned)tiles), dim3(SCAN_THREADS), 0, ctx->stream, in, n, sums);
         }
-        hipLaunchKernelGGL(k_apply_sums_u32, dim3((unsigned)tiles), dim3(SCAN_THREADS), 0, ctx->stream, in, out, n, sums, total_dev);
+        hipLaunchKernelGGL(k_apply_sums_u32, dim3((unsigned)tiles), dim3(SCAN_THREADS), 0, ctx->stream, in, out, n, sums, total_dev, with_end ? 1 : 0);
         FZP_HIP(hipGetLastError());
         return FZP_OK;
     }
@@ -177,6 +188,7 @@ int fzp_exclusive_scan_u32(fzp_ctx *ctx, const uint32_t *in, uint32_t *out, size
     hipLaunchKernelGGL(k_tile_sums, dim3((unsigned)tiles), dim3(SCAN_THREADS), 0, ctx->stream, in, n, sums);
     FZP_TRY(scan_u64_inplace(ctx, sums, tiles, total_dev, 1));
     hipLaunchKernelGGL(k_apply_u32, dim3((unsigned)tiles), dim3(SCAN_THREADS), 0, ctx->stream, in, out, n, sums);
+    if (with_end) FZP_HIP(hipMemcpyAsync(out + n, total_dev, sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));      // (the total's low word: little-endian)
     FZP_HIP(hipGetLastError());
     return FZP_OK;
 }
