@@ -1136,6 +1136,8 @@ struct GroupPool {
     int n_up = 0;
     hipEvent_t prev[FA_UP_STREAMS] = {};         // where the previous group's copies end on every stream: a group's copies start behind ALL of them (group order on the link)
     bool have_prev = false;
+    size_t pin_floor = 0;                        // every group's pinned block is asked for at the size of the call's LARGEST group: any block then serves any group (blocks of a
+                                                 // group's own size sent one call in two to hipHostMalloc for 1.6 GB -- 250 ms during which the other lane's launches stood still too)
     ~GroupPool() { for (auto u : up) if (u) (void)hipStreamDestroy(u); for (auto e : prev) if (e) (void)hipEventDestroy(e); }
     std::mutex mu;
     std::vector<std::unique_ptr<GroupIn>> idle;
@@ -1405,7 +1407,7 @@ void load_group_raw(fzp_ctx *ctx, const std::string &dir, const char *const *ctg
     }
     G.pin_bytes = G.foff[(size_t)nf];
     G.pin_ctx = ctx;
-    G.pin = (uint8_t *)fzp_pinned_acquire(ctx, (size_t)G.pin_bytes + 64, nullptr);
+    G.pin = (uint8_t *)fzp_pinned_acquire(ctx, std::max((size_t)G.pin_bytes + 64, gp ? gp->pin_floor : (size_t)0), nullptr);
     if (!G.pin) { G.rc = FZP_ENOMEM; G.err = "pinned host memory for the group's files"; close_all(); return; }
     if (G.d_raw.alloc((size_t)G.pin_bytes + 64) != FZP_OK) { G.rc = FZP_ENOMEM; G.err = "device memory for the group's files"; close_all(); return; }
     for (int u = 0; u < n_up; u++)
@@ -1658,6 +1660,11 @@ extern "C" int fzp_phase_contigs_files(fzp_ctx *ctx, const char *reads_dir, cons
     // loads run one after the other, in group order: the first group is there as soon as it can be)
     if (!ctx->gpool) ctx->gpool = new GroupPool();
     GroupPool *pool = ctx->gpool;
+    {   // (the reads files by their sizes, the contig files by their sequence ~ a contig is a fortieth of its reads at the coverage the pipeline runs at; 5 % on top)
+        int64_t mx = 0;
+        for (const Group &g : groups) { int64_t a = 0; for (int c = g.c0; c < g.c1; c++) a += bases[(size_t)c]; mx = std::max(mx, a); }
+        pool->pin_floor = fa_host ? 0 : (size_t)(mx + mx / 10) + (1u << 20);
+    }
     if (!pool->n_up) {
         int want = 1;      // (measured: 2 and 4 streams, with and without group order on the link, are within the noise of one -- 32-36 ms -- and cost the host more: profiles/r6_from_files.txt)
         if (const char *e = getenv("FZP_FASTA_UP_STREAMS")) { const int g = atoi(e); if (g >= 1 && g <= FA_UP_STREAMS) want = g; }
