@@ -7,6 +7,9 @@ struct FaIndex {
     // per record, file order (host): the file it lies in, its bases, where its name (the header's first word) stands in the raw buffer
     std::vector<int32_t> h_file;
     std::vector<int64_t> h_len, h_name_b, h_name_e;
+    // the names themselves, back to back (record r at h_names[h_noff[r] .. h_noff[r + 1])): gathered on the device, so that the host needs no copy of the files' bytes
+    std::vector<int64_t> h_noff;
+    std::vector<char> h_names;
     // per record (device): begin / end of its bases as offsets from the raw buffer's first byte -- into the raw buffer where the record is one line, else into d_join
     DevBuf<int64_t> d_be;
     DevBuf<uint8_t> d_join;

@@ -157,6 +157,15 @@ __global__ void __launch_bounds__(64) k_fa_join(const uint8_t *__restrict__ raw,
     const uint8_t *src = raw + l_u[i];
     for (int64_t k = threadIdx.x; k < len; k += 64) dst[k] = src[k];
 }
+// every record's name (the header's first word) to its place in one block: a thread a record, names are a few dozen bytes
+__global__ void __launch_bounds__(256) k_fa_names(const uint8_t *__restrict__ raw, const int64_t *__restrict__ nb, const int64_t *__restrict__ noff, int64_t n, uint8_t *__restrict__ dst) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    const uint8_t *s = raw + nb[r];
+    uint8_t *d = dst + noff[r];
+    const int64_t len = noff[r + 1] - noff[r];
+    for (int64_t i = 0; i < len; i++) d[i] = s[i];
+}
 // records `first` .. `first + n` joined back to back (test hook: what the packer would read, as bytes)
 __global__ void __launch_bounds__(256) k_fa_gather(const uint8_t *__restrict__ raw, const int64_t *__restrict__ be, int64_t first, const int64_t *__restrict__ doff, uint8_t *__restrict__ dst) {
     const int64_t r = first + blockIdx.y;
@@ -185,7 +194,7 @@ int fzp_fasta_fetch_seqs(fzp_ctx *ctx, hipStream_t st, const uint8_t *d_raw, con
 
 int fzp_fasta_index_dev(fzp_ctx *ctx, hipStream_t st, const uint8_t *d_raw, int64_t n_bytes, const int64_t *foff, int nf, FaIndex &X) {
     X.n_rec = 0; X.n_lines = 0; X.join_bytes = 0;
-    X.h_file.clear(); X.h_len.clear(); X.h_name_b.clear(); X.h_name_e.clear();
+    X.h_file.clear(); X.h_len.clear(); X.h_name_b.clear(); X.h_name_e.clear(); X.h_noff.assign(1, 0); X.h_names.clear();
     if (n_bytes <= 0 || nf <= 0) return FZP_OK;
     ProfScope ps(ctx, "fa_index");
     const int64_t n_tiles = (n_bytes + FA_TILE - 1) / FA_TILE;
@@ -243,6 +252,23 @@ int fzp_fasta_index_dev(fzp_ctx *ctx, hipStream_t st, const uint8_t *d_raw, int6
     FZP_TRY(r_file.download(X.h_file.data(), nr, st)); FZP_TRY(r_len.download(X.h_len.data(), nr, st));
     FZP_TRY(r_nb.download(X.h_name_b.data(), nr, st)); FZP_TRY(r_ne.download(X.h_name_e.data(), nr, st));
     FZP_HIP(hipStreamSynchronize(st));
+    // the names: their lengths are on the host now; one more kernel puts them side by side, one copy brings them over (r6: the host kept the files' bytes for this alone)
+    X.h_noff.assign(nr + 1, 0);
+    for (size_t r = 0; r < nr; r++) {
+        const int64_t l = X.h_name_e[r] - X.h_name_b[r];
+        if (l < 0) { fzp_set_error("FASTA index: a record's name ends before it begins"); return FZP_EINVAL; }
+        X.h_noff[r + 1] = X.h_noff[r] + l;
+    }
+    X.h_names.resize((size_t)X.h_noff[nr]);
+    if (X.h_noff[nr] > 0) {
+        DevBuf<int64_t> d_noff;
+        DevBuf<uint8_t> d_names;
+        FZP_TRY(d_noff.upload(X.h_noff.data(), nr + 1, st));
+        FZP_TRY(d_names.alloc((size_t)X.h_noff[nr]));
+        hipLaunchKernelGGL(k_fa_names, dim3(gr), dim3(256), 0, st, d_raw, (const int64_t *)r_nb.p, (const int64_t *)d_noff.p, (int64_t)nr, d_names.p);
+        FZP_HIP(hipMemcpyAsync(X.h_names.data(), d_names.p, (size_t)X.h_noff[nr], hipMemcpyDeviceToHost, st));
+        FZP_HIP(hipStreamSynchronize(st));
+    }
     FZP_HIP(hipGetLastError());
     return FZP_OK;
 }

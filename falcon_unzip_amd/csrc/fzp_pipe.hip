@@ -1102,11 +1102,9 @@ struct GroupIn {
     std::vector<int32_t> read_ctg;
     RawBuf names;
     bool in_place = false;                       // the reads are spans of `raw`
-    // r6, the default: the files as they are in ONE pinned block (a '\n' behind every file), records found on the device (fzp_fasta.hip)
-    fzp_ctx *pin_ctx = nullptr;
-    uint8_t *pin = nullptr;
-    int64_t pin_bytes = 0;
-    std::vector<int64_t> foff;                   // [2 gc + 1] file t (reads files first, then the contig files) at pin + foff[t]
+    // r6, the default: the files as they are in ONE device block (a '\n' behind every file), records found on the device (fzp_fasta.hip); the host keeps no copy
+    int64_t pin_bytes = 0;                       // the block's bytes
+    std::vector<int64_t> foff;                   // [2 gc + 1] file t (reads files first, then the contig files) at d_raw + foff[t]
     bool dev_parse = false;
     double ms_read = 0;
     // ... and on their way to the device while the rest is still being read: every 4 MB piece is handed to the DMA engine by the thread that read it (upload stream of the
@@ -1117,28 +1115,40 @@ struct GroupIn {
     int n_up = 0;
     int rc = FZP_OK;
     std::string err;
-    std::vector<void *> maps;                    // FZP_FASTA_MMAP: the files mapped instead of read (the names are cut from the mappings)
-    std::vector<size_t> map_len;
-    const uint8_t *host_at(int64_t off) const {  // the host's copy of buffer offset `off` (inside one file)
-        if (maps.empty()) return pin + off;
-        size_t t = (size_t)(std::upper_bound(foff.begin(), foff.end(), off) - foff.begin()) - 1;
-        return (const uint8_t *)maps[t] + (off - foff[t]);
-    }
-    void drop_pin() {
-        if (pin) { fzp_pinned_release(pin_ctx, pin); pin = nullptr; }
-        for (size_t t = 0; t < maps.size(); t++) if (maps[t]) munmap(maps[t], map_len[t]);
-        maps.clear(); map_len.clear();
-    }
-    ~GroupIn() { drop_pin(); for (auto e : ev_up) if (e) (void)hipEventDestroy(e); }
+    ~GroupIn() { for (auto e : ev_up) if (e) (void)hipEventDestroy(e); }
 };
 struct GroupPool {
     hipStream_t up[FA_UP_STREAMS] = {};          // the loader's upload streams (pieces of a group's files, pinned -> device)
     int n_up = 0;
     hipEvent_t prev[FA_UP_STREAMS] = {};         // where the previous group's copies end on every stream: a group's copies start behind ALL of them (group order on the link)
     bool have_prev = false;
-    size_t pin_floor = 0;                        // every group's pinned block is asked for at the size of the call's LARGEST group: any block then serves any group (blocks of a
-                                                 // group's own size sent one call in two to hipHostMalloc for 1.6 GB -- 250 ms during which the other lane's launches stood still too)
-    ~GroupPool() { for (auto u : up) if (u) (void)hipStreamDestroy(u); for (auto e : prev) if (e) (void)hipEventDestroy(e); }
+    // The pieces' way to the device: two pinned buffers of one piece per reader thread, filled and sent in turn (a buffer is free again when the copy out of it is through).
+    // r6 first pinned a group's files WHOLE (1.2-1.6 GB a group at genome scale): hipHostMalloc takes ~0.2 s per GB, stalls the other lane's launches while it runs, and the
+    // pool of such blocks took three calls to settle (configs[4] from files: 1.0 / 0.41 / 0.42 / 0.24 s).  The host needs the bytes for nothing: names come back from the device.
+    fzp_ctx *stage_ctx = nullptr;
+    std::vector<uint8_t *> stage;
+    std::vector<hipEvent_t> stage_ev;
+    std::vector<char> stage_used;
+    size_t stage_bytes = 0;
+    int ensure_stage(fzp_ctx *ctx, int n_bufs, size_t bytes) {
+        if (stage_ctx == ctx && (int)stage.size() >= n_bufs && stage_bytes >= bytes) return FZP_OK;
+        for (int u = 0; u < n_up; u++) (void)hipStreamSynchronize(up[u]);      // (nothing may still be on its way out of a buffer that goes back)
+        drop_stage();
+        stage_ctx = ctx; stage_bytes = bytes;
+        for (int i = 0; i < n_bufs; i++) {
+            uint8_t *b = (uint8_t *)fzp_pinned_acquire(ctx, bytes, nullptr);
+            hipEvent_t e = nullptr;
+            if (!b || hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { if (b) fzp_pinned_release(ctx, b); (void)hipGetLastError(); return FZP_ENOMEM; }
+            stage.push_back(b); stage_ev.push_back(e); stage_used.push_back(0);
+        }
+        return FZP_OK;
+    }
+    void drop_stage() {
+        for (auto b : stage) fzp_pinned_release(stage_ctx, b);
+        for (auto e : stage_ev) if (e) (void)hipEventDestroy(e);
+        stage.clear(); stage_ev.clear(); stage_used.clear(); stage_bytes = 0;
+    }
+    ~GroupPool() { drop_stage(); for (auto u : up) if (u) (void)hipStreamDestroy(u); for (auto e : prev) if (e) (void)hipEventDestroy(e); }
     std::mutex mu;
     std::vector<std::unique_ptr<GroupIn>> idle;
     std::unique_ptr<GroupIn> take() {
@@ -1383,13 +1393,12 @@ void load_group(const std::string &dir, const char *const *ctg_id, int c0, int c
     if (timing) fprintf(stderr, "[load_group] %d contigs, %lld reads, %.1f MB on %d threads: read + line ends by %.2f ms, records by %.2f, %s by %.2f\n", gc, (long long)nr,
                         (double)p_base.back() / 1e6, n_threads, t_map, t_scan, in_place ? "spans (reads used in place)" : "reads joined", ms_since(t_0));
 }
-// r6: the loader that only READS.  The group's files go as they are into one pinned block -- 4 MB pieces, pread by all of the rank's threads -- with a '\n' behind every
-// file (no line runs from one file into the next; an empty line more is nothing to a FASTA reader).  Line ends, records, lengths, names' places: fzp_fasta.hip, on the
-// device, once the block is there (one DMA from pinned memory).  The host parser above stays as the checker (FZP_FASTA_HOST=1, tests).
+// r6: the loader that only READS.  The group's files go as they are into one DEVICE block -- 4 MB pieces, pread by the rank's threads into pinned staging buffers and sent
+// from there -- with a '\n' behind every file (no line runs from one file into the next; an empty line more is nothing to a FASTA reader).  Line ends, records, lengths,
+// names: fzp_fasta.hip, on the device.  The host parser above stays as the checker (FZP_FASTA_HOST=1, tests).
 void load_group_raw(fzp_ctx *ctx, const std::string &dir, const char *const *ctg_id, int c0, int c1, int n_threads, GroupIn &G, const hipStream_t *ups, int n_up, GroupPool *gp = nullptr) {
     const int gc = c1 - c0, nf = 2 * gc;
     G.rc = FZP_OK; G.err.clear(); G.dev_parse = true; G.streamed = false;
-    G.drop_pin();
     if (fzp_bind(ctx) != FZP_OK) { G.rc = FZP_EDEVICE; G.err = fzp_last_error(); return; }
     const auto t_0 = clk::now();
     auto path_of = [&](int t) { return dir + "/" + ctg_id[c0 + (t < gc ? t : t - gc)] + (t < gc ? "_reads.fa" : "_ref.fa"); };
@@ -1406,9 +1415,6 @@ void load_group_raw(fzp_ctx *ctx, const std::string &dir, const char *const *ctg
         G.foff[(size_t)t + 1] = G.foff[(size_t)t] + (int64_t)fsz[(size_t)t] + 1;      // + the '\n' behind it
     }
     G.pin_bytes = G.foff[(size_t)nf];
-    G.pin_ctx = ctx;
-    G.pin = (uint8_t *)fzp_pinned_acquire(ctx, std::max((size_t)G.pin_bytes + 64, gp ? gp->pin_floor : (size_t)0), nullptr);
-    if (!G.pin) { G.rc = FZP_ENOMEM; G.err = "pinned host memory for the group's files"; close_all(); return; }
     if (G.d_raw.alloc((size_t)G.pin_bytes + 64) != FZP_OK) { G.rc = FZP_ENOMEM; G.err = "device memory for the group's files"; close_all(); return; }
     for (int u = 0; u < n_up; u++)
         if (!G.ev_up[u] && hipEventCreateWithFlags(&G.ev_up[u], hipEventDisableTiming) != hipSuccess) { G.rc = FZP_EDEVICE; G.err = "hipEventCreate"; close_all(); return; }
@@ -1422,41 +1428,32 @@ void load_group_raw(fzp_ctx *ctx, const std::string &dir, const char *const *ctg
     std::vector<Piece> pieces;
     size_t PIECE = 4u << 20;
     if (const char *e = getenv("FZP_FASTA_PIECE")) { const long v = atol(e); if (v > 0) PIECE = (size_t)v; }
-    for (int t = 0; t < nf; t++) {
-        for (size_t a = 0; a < fsz[(size_t)t]; a += PIECE) pieces.push_back({t, a, std::min(fsz[(size_t)t], a + PIECE)});
-        G.pin[G.foff[(size_t)t] + (int64_t)fsz[(size_t)t]] = '\n';
-    }
-    // (the separators and the buffer's tail: small copies of their own, so that every file piece below is exactly what one pread filled)
+    for (int t = 0; t < nf; t++) for (size_t a = 0; a < fsz[(size_t)t]; a += PIECE) pieces.push_back({t, a, std::min(fsz[(size_t)t], a + PIECE)});
+    // (the separators and the buffer's tail: fills of their own, so that every file piece below is exactly what one pread filled)
     for (int t = 0; t < nf; t++)
-        if (hipMemcpyAsync(G.d_raw.p + G.foff[(size_t)t] + (int64_t)fsz[(size_t)t], G.pin + G.foff[(size_t)t] + (int64_t)fsz[(size_t)t], 1, hipMemcpyHostToDevice, up) != hipSuccess) hip_bad.store(1);
+        if (hipMemsetAsync(G.d_raw.p + G.foff[(size_t)t] + (int64_t)fsz[(size_t)t], '\n', 1, up) != hipSuccess) hip_bad.store(1);
     if (hipMemsetAsync(G.d_raw.p + G.pin_bytes, 0, 64, up) != hipSuccess) hip_bad.store(1);
+    int cap = 8;      // readers: eight keep ahead of the link (each moves 5-7 GB/s out of the page cache, the link takes ~37); sixteen only contend (profiles/r6_from_files.txt)
+    if (const char *e = getenv("FZP_FASTA_READERS")) { const int g = atoi(e); if (g >= 1) cap = g; }
+    const int T = (int)std::min<size_t>((size_t)std::max(1, std::min(n_threads, cap)), std::max<size_t>(1, pieces.size()));
+    GroupPool own;      // (a call without a pool -- the test hook -- stages through buffers of its own)
+    GroupPool *sp = gp ? gp : &own;
+    if (!gp) { own.n_up = 0; }
+    if (sp->ensure_stage(ctx, 2 * std::max(T, 8), PIECE) != FZP_OK) { G.rc = FZP_ENOMEM; G.err = "pinned staging buffers for the group's files"; close_all(); return; }
     std::vector<std::string> errs((size_t)nf);
     std::mutex err_mu;
     std::atomic<int> next{0};
-    // FZP_FASTA_MMAP=1 (an experiment, profiles/r6_from_files.txt): no pread -- the pieces go to the copy engine straight from a mapping of the file (the runtime's pageable
-    // path); the pinned block is then filled only where names are cut from (never: the names come from the mapping)
-    const bool use_mmap = getenv("FZP_FASTA_MMAP") != nullptr;
-    std::vector<void *> &maps = G.maps;
-    if (use_mmap) {
-        maps.assign((size_t)nf, nullptr); G.map_len.assign(fsz.begin(), fsz.end());
-        for (int t = 0; t < nf; t++)
-            if (fsz[(size_t)t]) {
-                void *m = mmap(nullptr, fsz[(size_t)t], PROT_READ, MAP_SHARED | MAP_POPULATE, fds[(size_t)t], 0);
-                if (m == MAP_FAILED) { G.rc = FZP_EIO; G.err = path_of(t) + ": mmap: " + strerror(errno); G.drop_pin(); close_all(); return; }
-                maps[(size_t)t] = m;
-            }
-    }
-    auto work = [&]() {
+    auto work = [&](int tid) {
         if (fzp_bind(ctx) != FZP_OK) { hip_bad.store(1); return; }
-        for (int k; (k = next.fetch_add(1)) < (int)pieces.size();) {
+        int turn = 0;
+        for (int k; (k = next.fetch_add(1)) < (int)pieces.size(); turn ^= 1) {
             const Piece &P = pieces[(size_t)k];
-            if (use_mmap) {
-                if (hipMemcpyAsync(G.d_raw.p + G.foff[(size_t)P.t] + (int64_t)P.a, (const char *)maps[(size_t)P.t] + P.a, P.b - P.a, hipMemcpyHostToDevice, ups[k % n_up]) != hipSuccess) hip_bad.store(1);
-                continue;
-            }
+            const size_t bi = (size_t)(2 * tid + turn);
+            uint8_t *buf = sp->stage[bi];
+            if (sp->stage_used[bi] && hipEventSynchronize(sp->stage_ev[bi]) != hipSuccess) { hip_bad.store(1); break; }      // the copy that last left this buffer (this group's or the one before)
             size_t at = P.a;
             while (at < P.b) {
-                const ssize_t got = pread(fds[(size_t)P.t], G.pin + G.foff[(size_t)P.t] + at, P.b - at, (off_t)at);
+                const ssize_t got = pread(fds[(size_t)P.t], buf + (at - P.a), P.b - at, (off_t)at);
                 if (got <= 0) {
                     const std::string why = path_of(P.t) + ": " + (got < 0 ? strerror(errno) : "file shrank while it was read");
                     std::lock_guard<std::mutex> lk(err_mu);
@@ -1465,17 +1462,17 @@ void load_group_raw(fzp_ctx *ctx, const std::string &dir, const char *const *ctg
                 }
                 at += (size_t)got;
             }
+            if (at != P.b) continue;
             // the piece is in pinned memory: on its way while the next one is read
-            if (at == P.b && hipMemcpyAsync(G.d_raw.p + G.foff[(size_t)P.t] + (int64_t)P.a, G.pin + G.foff[(size_t)P.t] + (int64_t)P.a, P.b - P.a, hipMemcpyHostToDevice, ups[k % n_up]) != hipSuccess) hip_bad.store(1);
+            hipStream_t us = ups[k % n_up];
+            if (hipMemcpyAsync(G.d_raw.p + G.foff[(size_t)P.t] + (int64_t)P.a, buf, P.b - P.a, hipMemcpyHostToDevice, us) != hipSuccess || hipEventRecord(sp->stage_ev[bi], us) != hipSuccess) { hip_bad.store(1); break; }
+            sp->stage_used[bi] = 1;
         }
     };
     {
         std::vector<std::thread> th;
-        int cap = 8;      // readers: eight keep ahead of the link (each moves 5-7 GB/s out of the page cache, the link takes ~37); sixteen only contend (profiles/r6_from_files.txt)
-        if (const char *e = getenv("FZP_FASTA_READERS")) { const int g = atoi(e); if (g >= 1) cap = g; }
-        const int T = (int)std::min<size_t>((size_t)std::max(1, std::min(n_threads, cap)), std::max<size_t>(1, pieces.size()));
-        for (int i = 1; i < T; i++) th.emplace_back(work);
-        work();
+        for (int i = 1; i < T; i++) th.emplace_back(work, i);
+        work(0);
         for (auto &x : th) x.join();
     }
     close_all();
@@ -1490,15 +1487,17 @@ void load_group_raw(fzp_ctx *ctx, const std::string &dir, const char *const *ctg
         }
         gp->have_prev = !bad;
     }
-    if (bad) {      // (copies out of the pinned block may still be under way: not before they are done may it serve another group)
+    if (bad || !gp) {      // (a failed load, or buffers of this call's own: nothing may still be on its way out of them when they go)
         for (int u = 0; u < n_up; u++) (void)hipStreamSynchronize(ups[u]);
-        (void)hipGetLastError();
-        if (G.rc == FZP_OK) { G.rc = FZP_EDEVICE; G.err = "upload of the group's files failed"; }
-        return;
+        if (bad) {
+            (void)hipGetLastError();
+            if (G.rc == FZP_OK) { G.rc = FZP_EDEVICE; G.err = "upload of the group's files failed"; }
+            return;
+        }
     }
     G.streamed = true;
     G.ms_read = ms_since(t_0);
-    if (getenv("FZP_PIPE_TIMING")) fprintf(stderr, "[load_group_raw] %d contigs, %.1f MB in %zu pieces on %d threads: %.2f ms\n", gc, (double)G.pin_bytes / 1e6, pieces.size(), n_threads, G.ms_read);
+    if (getenv("FZP_PIPE_TIMING")) fprintf(stderr, "[load_group_raw] %d contigs, %.1f MB in %zu pieces on %d threads: %.2f ms\n", gc, (double)G.pin_bytes / 1e6, pieces.size(), T, G.ms_read);
 }
 
 // the group on the device: its bytes (one DMA), its records (fzp_fasta.hip), and from those what the aligner and the writers need -- which records are reads (the reads
@@ -1528,12 +1527,12 @@ int group_to_device(fzp_ctx *lc, GroupIn &G, const char *const *ctg_id, int c0, 
     G.noff[0] = 0;
     for (int64_t r = 0; r < nr; r++) { G.read_ctg[(size_t)r] = X.h_file[(size_t)r]; D.read_len[(size_t)r] = X.h_len[(size_t)r]; G.noff[(size_t)r + 1] = G.noff[(size_t)r] + (X.h_name_e[(size_t)r] - X.h_name_b[(size_t)r]); }
     if (!G.names.need((size_t)G.noff[(size_t)nr] + 1)) { fzp_set_error("host memory for the group's read names"); return FZP_ENOMEM; }
-    for (int64_t r = 0; r < nr; r++) memcpy(G.names.data() + G.noff[(size_t)r], G.host_at(X.h_name_b[(size_t)r]), (size_t)(G.noff[(size_t)r + 1] - G.noff[(size_t)r]));
+    if (nr) memcpy(G.names.data(), X.h_names.data(), (size_t)G.noff[(size_t)nr]);      // (the reads' records come first: their names are the block's beginning)
     D.ctg_rec.assign((size_t)gc, -1);
     for (int64_t r = nr; r < X.n_rec; r++) {
         const int c = X.h_file[(size_t)r] - gc;
         const size_t want = strlen(ctg_id[c0 + c]);
-        if ((size_t)(X.h_name_e[(size_t)r] - X.h_name_b[(size_t)r]) == want && memcmp(G.host_at(X.h_name_b[(size_t)r]), ctg_id[c0 + c], want) == 0) D.ctg_rec[(size_t)c] = r;
+        if ((size_t)(X.h_name_e[(size_t)r] - X.h_name_b[(size_t)r]) == want && memcmp(X.h_names.data() + X.h_noff[(size_t)r], ctg_id[c0 + c], want) == 0) D.ctg_rec[(size_t)c] = r;
     }
     D.ctg_len.assign((size_t)gc, 0);
     FZP_TRY(D.d_ctg_be.alloc((size_t)2 * gc));
@@ -1543,7 +1542,6 @@ int group_to_device(fzp_ctx *lc, GroupIn &G, const char *const *ctg_id, int c0, 
             D.ctg_len[(size_t)c] = X.h_len[(size_t)D.ctg_rec[(size_t)c]];
             FZP_HIP(hipMemcpyAsync(D.d_ctg_be.p + 2 * c, X.d_be.p + 2 * D.ctg_rec[(size_t)c], 2 * sizeof(int64_t), hipMemcpyDeviceToDevice, st));
         }
-    G.drop_pin();      // (the names are out: the block serves the next group)
     return FZP_OK;
 }
 }  // namespace
@@ -1660,11 +1658,6 @@ extern "C" int fzp_phase_contigs_files(fzp_ctx *ctx, const char *reads_dir, cons
     // loads run one after the other, in group order: the first group is there as soon as it can be)
     if (!ctx->gpool) ctx->gpool = new GroupPool();
     GroupPool *pool = ctx->gpool;
-    {   // (the reads files by their sizes, the contig files by their sequence ~ a contig is a fortieth of its reads at the coverage the pipeline runs at; 5 % on top)
-        int64_t mx = 0;
-        for (const Group &g : groups) { int64_t a = 0; for (int c = g.c0; c < g.c1; c++) a += bases[(size_t)c]; mx = std::max(mx, a); }
-        pool->pin_floor = fa_host ? 0 : (size_t)(mx + mx / 10) + (1u << 20);
-    }
     if (!pool->n_up) {
         int want = 1;      // (measured: 2 and 4 streams, with and without group order on the link, are within the noise of one -- 32-36 ms -- and cost the host more: profiles/r6_from_files.txt)
         if (const char *e = getenv("FZP_FASTA_UP_STREAMS")) { const int g = atoi(e); if (g >= 1 && g <= FA_UP_STREAMS) want = g; }
