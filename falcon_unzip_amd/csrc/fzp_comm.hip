@@ -97,6 +97,7 @@ struct fzp_comm {
     fzp_ctx *ctx = nullptr;
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
+    bool dead = false;      // a collective of this communicator ran into FZP_COMM_TIMEOUT_S: it may still be in flight -- the communicator is not used again, its buffers are not given back
 };
 
 extern "C" int fzp_comm_unique_id(char id[FZP_COMM_ID_BYTES]) {
@@ -166,7 +167,7 @@ extern "C" int fzp_comm_ranks(fzp_comm *c, int *rank, int *world) {
 extern "C" void fzp_comm_destroy(fzp_comm *c) {
     if (!c) return;
     Rccl *R = rccl();
-    if (R && c->comm) { (void)fzp_bind(c->ctx); (void)hipStreamSynchronize(c->ctx->stream); (void)R->CommDestroy(c->comm); }
+    if (R && c->comm && !c->dead) { (void)fzp_bind(c->ctx); (void)hipStreamSynchronize(c->ctx->stream); (void)R->CommDestroy(c->comm); }      // (a dead one is left where it is: its collective may never end)
     delete c;
 }
 
@@ -180,15 +181,21 @@ static int wait_stream(hipStream_t st, const char *what) {
         if (e == hipSuccess) return FZP_OK;
         if (e != hipErrorNotReady) { (void)hipGetLastError(); fzp_set_error("%s: %s", what, hipGetErrorString(e)); return FZP_EDEVICE; }
         (void)hipGetLastError();
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(limit)) { fzp_set_error("%s did not finish within %d s (FZP_COMM_TIMEOUT_S): a peer never joined the collective", what, limit); return FZP_EDEVICE; }
-        std::this_thread::sleep_for(std::chrono::microseconds(200));
+        const auto waited = std::chrono::steady_clock::now() - t0;
+        if (waited > std::chrono::seconds(limit)) { fzp_set_error("%s did not finish within %d s (FZP_COMM_TIMEOUT_S): a peer never joined the collective", what, limit); return FZP_EDEVICE; }
+        // (r6: a gather of a few megabytes is through in tens of microseconds -- look again at once for the first 300 us, then every 50; ADVICE r5: naps of 200 us from the
+        //  first look on added their length to every gather of every step)
+        if (waited > std::chrono::microseconds(300)) std::this_thread::sleep_for(std::chrono::microseconds(50));
     }
 }
 extern "C" int fzp_allgather_rid_to_phase(fzp_comm *c, const fzp_r2p *local, int64_t n_local, fzp_r2p **all, int64_t *n_all) {
     if (!c || !all || !n_all || n_local < 0 || (n_local && !local)) { fzp_set_error("fzp_allgather_rid_to_phase: bad arguments"); return FZP_EINVAL; }
     Rccl *R = rccl();
     if (!R) { fzp_set_error("RCCL could not be loaded"); return FZP_ENODEVICE; }
+    if (c->dead) { fzp_set_error("fzp_allgather_rid_to_phase: an earlier collective of this communicator timed out; it is not used again"); return FZP_EDEVICE; }
     fzp_ctx *ctx = c->ctx;
+    // what a timed-out collective may still be writing is never handed back to the pool: the buffers are dropped where they are, the communicator is marked
+    auto give_up = [&](auto &...bufs) { c->dead = true; ((bufs.p = nullptr, bufs.n = 0), ...); };
     FZP_TRY(fzp_bind(ctx));
     hipStream_t st = ctx->stream;
     const int W = c->world;
@@ -201,7 +208,7 @@ extern "C" int fzp_allgather_rid_to_phase(fzp_comm *c, const fzp_r2p *local, int
     if (rc) return nccl_fail(R, "ncclAllGather(counts)", rc);
     std::vector<uint64_t> cnts((size_t)W);
     FZP_TRY(d_cnts.download(cnts.data(), (size_t)W, st));
-    FZP_TRY(wait_stream(st, "ncclAllGather(counts)"));
+    { const int wrc = wait_stream(st, "ncclAllGather(counts)"); if (wrc != FZP_OK) { give_up(d_cnt, d_cnts); return wrc; } }
     uint64_t mx = 1, total = 0;
     for (auto v : cnts) { mx = std::max(mx, v); total += v; }
     // 2. payload, padded to the largest shard
@@ -218,7 +225,7 @@ extern "C" int fzp_allgather_rid_to_phase(fzp_comm *c, const fzp_r2p *local, int
         if (cnts[(size_t)r] && hipMemcpyAsync(out + at, d_all.p + (size_t)r * mx, (size_t)cnts[(size_t)r] * sizeof(fzp_r2p), hipMemcpyDeviceToHost, st) != hipSuccess) { free(out); fzp_set_error("D2H copy failed"); return FZP_EDEVICE; }
         at += (size_t)cnts[(size_t)r];
     }
-    { const int wrc = wait_stream(st, "ncclAllGather(records)"); if (wrc != FZP_OK) { free(out); return wrc; } }
+    { const int wrc = wait_stream(st, "ncclAllGather(records)"); if (wrc != FZP_OK) { give_up(d_cnt, d_cnts, d_loc, d_all); return wrc; } }      // (`out` too: copies into it may still be queued)
     // 3. the order of rid_to_phase.all: sorted per-contig paths (unzip.py:306-307) = contig index, then pread id
     // (r6: a rank's records arrive in that order, and ranks that hold consecutive contig ranges -- the usual deal -- arrive in order as a whole: look first, then merge the
     // ranks' runs, and sort only what is left.  Eight ranks x 40 000 records: std::sort took ~10 ms of every step on every rank.)
