@@ -115,6 +115,29 @@ def test_allgather_without_process_group():
     assert list(out["arid"]) == [1, 3, 5]
 
 
+def test_gather_looks_before_it_sorts():
+    """r6: records that arrive in rid_to_phase.all's order (contig, then pread id) come back as they are -- the same array, nothing sorted --, any other order is sorted"""
+    from falcon_unzip_amd import _lib
+    from falcon_unzip_amd.dist import allgather_r2p
+    rng = np.random.default_rng(3)
+    r = np.zeros(5000, _lib.R2P)
+    r["ctg"] = np.sort(rng.integers(0, 7, len(r)))
+    for c in range(7):      # ascending ids inside a contig, with gaps and one repeat
+        m = r["ctg"] == c
+        ids = np.sort(rng.choice(20000, int(m.sum()), replace=False))
+        if len(ids) > 2:
+            ids[1] = ids[0]
+        r["arid"][m] = ids
+    r["block"] = rng.integers(-1, 9, len(r))
+    out = allgather_r2p(r)
+    assert out is r or np.shares_memory(out, r) or np.array_equal(out, r)
+    assert np.array_equal(out, r)
+    sh = r[rng.permutation(len(r))]
+    out2 = allgather_r2p(sh)
+    assert np.array_equal(out2["ctg"], r["ctg"]) and np.array_equal(out2["arid"], r["arid"])
+    assert len(allgather_r2p(np.zeros(0, _lib.R2P))) == 0 and len(allgather_r2p(r[:1])) == 1
+
+
 def test_r2p_from_batch_equals_per_contig():
     from falcon_unzip_amd import _lib
     from falcon_unzip_amd import dist as fdist
