@@ -3183,9 +3183,6 @@ static int align_run(fzp_ctx *ctx, fzp_alnjob *j, bool defer_overflow) {
         if (!j->ev_sw[0]) for (int k = 0; k < 2; k++) { FZP_HIP(hipEventCreateWithFlags(&j->ev_l[k], hipEventDisableTiming)); FZP_HIP(hipEventCreateWithFlags(&j->ev_sw[k], hipEventDisableTiming)); FZP_HIP(hipEventCreateWithFlags(&j->ev_tb[k], hipEventDisableTiming)); }
         // one chunk for the whole run (the usual case): the scans stay on the device.  Otherwise they come over, to be cut where the mask budget says
         const bool one_chunk = total_steps <= chunk_steps;
-        // (one chunk -- the usual case -- has nothing to overlap: the walk and what follows it go onto the DP's own stream, where a kernel starts when the one before it ends;
-        //  across two streams every hand-over is an event the runtime resolves on the host side, 25-30 us each.  FZP_TB_STREAM2=1: the chunked form's streams)
-        if (one_chunk && !getenv("FZP_TB_STREAM2")) st2 = st;
         std::vector<uint32_t> h_sb, h_cq;
         if (!one_chunk) {
             h_sb.resize((size_t)nr + 1); h_cq.resize((size_t)nr + 1);
