@@ -1122,31 +1122,42 @@ struct GroupPool {
     int n_up = 0;
     hipEvent_t prev[FA_UP_STREAMS] = {};         // where the previous group's copies end on every stream: a group's copies start behind ALL of them (group order on the link)
     bool have_prev = false;
-    // The pieces' way to the device: two pinned buffers of one piece per reader thread, filled and sent in turn (a buffer is free again when the copy out of it is through).
+    // The pieces' way to the device: a ring of pinned buffers of one piece each, taken in the order the pieces are handed out (a buffer is free again when the copy out of
+    // it is through; 64 of them: the readers, a little faster than the link, run up to 256 MB ahead before one of them has to wait -- two buffers per reader had every
+    // reader waiting for its own last copy, 0.3 ms of spinning each time: the bench's from-files leg 31 -> 35 ms, its host CPU 150 -> 225 ms).
     // r6 first pinned a group's files WHOLE (1.2-1.6 GB a group at genome scale): hipHostMalloc takes ~0.2 s per GB, stalls the other lane's launches while it runs, and the
     // pool of such blocks took three calls to settle (configs[4] from files: 1.0 / 0.41 / 0.42 / 0.24 s).  The host needs the bytes for nothing: names come back from the device.
     fzp_ctx *stage_ctx = nullptr;
     std::vector<uint8_t *> stage;
     std::vector<hipEvent_t> stage_ev;
     std::vector<char> stage_used;
+    uint8_t *nl_line = nullptr;                               // 64 pinned '\n'
+    std::unique_ptr<std::atomic<int64_t>[]> stage_turn;      // per buffer: the ticket that may fill it next (the one before has queued its copy)
+    int64_t stage_ticket = 0;                                 // tickets handed out so far (a group takes a run of them)
     size_t stage_bytes = 0;
     int ensure_stage(fzp_ctx *ctx, int n_bufs, size_t bytes) {
         if (stage_ctx == ctx && (int)stage.size() >= n_bufs && stage_bytes >= bytes) return FZP_OK;
         for (int u = 0; u < n_up; u++) (void)hipStreamSynchronize(up[u]);      // (nothing may still be on its way out of a buffer that goes back)
         drop_stage();
         stage_ctx = ctx; stage_bytes = bytes;
+        nl_line = (uint8_t *)fzp_pinned_acquire(ctx, 4096, nullptr);
+        if (!nl_line) return FZP_ENOMEM;
+        memset(nl_line, '\n', 64);
         for (int i = 0; i < n_bufs; i++) {
             uint8_t *b = (uint8_t *)fzp_pinned_acquire(ctx, bytes, nullptr);
             hipEvent_t e = nullptr;
             if (!b || hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { if (b) fzp_pinned_release(ctx, b); (void)hipGetLastError(); return FZP_ENOMEM; }
             stage.push_back(b); stage_ev.push_back(e); stage_used.push_back(0);
         }
+        stage_turn.reset(new std::atomic<int64_t>[(size_t)n_bufs]);
+        for (int i = 0; i < n_bufs; i++) stage_turn[(size_t)i].store(stage_ticket + ((i - stage_ticket % n_bufs) % n_bufs + n_bufs) % n_bufs);      // the next ticket that maps to buffer i
         return FZP_OK;
     }
     void drop_stage() {
         for (auto b : stage) fzp_pinned_release(stage_ctx, b);
+        if (nl_line) { fzp_pinned_release(stage_ctx, nl_line); nl_line = nullptr; }
         for (auto e : stage_ev) if (e) (void)hipEventDestroy(e);
-        stage.clear(); stage_ev.clear(); stage_used.clear(); stage_bytes = 0;
+        stage.clear(); stage_ev.clear(); stage_used.clear(); stage_turn.reset(); stage_bytes = 0;
     }
     ~GroupPool() { drop_stage(); for (auto u : up) if (u) (void)hipStreamDestroy(u); for (auto e : prev) if (e) (void)hipEventDestroy(e); }
     std::mutex mu;
@@ -1429,9 +1440,6 @@ void load_group_raw(fzp_ctx *ctx, const std::string &dir, const char *const *ctg
     size_t PIECE = 4u << 20;
     if (const char *e = getenv("FZP_FASTA_PIECE")) { const long v = atol(e); if (v > 0) PIECE = (size_t)v; }
     for (int t = 0; t < nf; t++) for (size_t a = 0; a < fsz[(size_t)t]; a += PIECE) pieces.push_back({t, a, std::min(fsz[(size_t)t], a + PIECE)});
-    // (the separators and the buffer's tail: fills of their own, so that every file piece below is exactly what one pread filled)
-    for (int t = 0; t < nf; t++)
-        if (hipMemsetAsync(G.d_raw.p + G.foff[(size_t)t] + (int64_t)fsz[(size_t)t], '\n', 1, up) != hipSuccess) hip_bad.store(1);
     if (hipMemsetAsync(G.d_raw.p + G.pin_bytes, 0, 64, up) != hipSuccess) hip_bad.store(1);
     int cap = 8;      // readers: eight keep ahead of the link (each moves 5-7 GB/s out of the page cache, the link takes ~37); sixteen only contend (profiles/r6_from_files.txt)
     if (const char *e = getenv("FZP_FASTA_READERS")) { const int g = atoi(e); if (g >= 1) cap = g; }
@@ -1439,18 +1447,28 @@ void load_group_raw(fzp_ctx *ctx, const std::string &dir, const char *const *ctg
     GroupPool own;      // (a call without a pool -- the test hook -- stages through buffers of its own)
     GroupPool *sp = gp ? gp : &own;
     if (!gp) { own.n_up = 0; }
-    if (sp->ensure_stage(ctx, 2 * std::max(T, 8), PIECE) != FZP_OK) { G.rc = FZP_ENOMEM; G.err = "pinned staging buffers for the group's files"; close_all(); return; }
+    int ring = 64;
+    if (const char *e = getenv("FZP_FASTA_RING")) { const int g = atoi(e); if (g >= 2 * T && g <= 1024) ring = g; }
+    ring = std::max(ring, 2 * T);
+    if (sp->ensure_stage(ctx, ring, PIECE) != FZP_OK) { G.rc = FZP_ENOMEM; G.err = "pinned staging buffers for the group's files"; close_all(); return; }
     std::vector<std::string> errs((size_t)nf);
     std::mutex err_mu;
     std::atomic<int> next{0};
-    auto work = [&](int tid) {
+    // (the separators: one-byte copies out of a pinned line of them -- copies like the pieces, so that the stream stays on the copy engine; fills are kernels)
+    for (int t = 0; t < nf; t++)
+        if (hipMemcpyAsync(G.d_raw.p + G.foff[(size_t)t] + (int64_t)fsz[(size_t)t], sp->nl_line, 1, hipMemcpyHostToDevice, up) != hipSuccess) hip_bad.store(1);
+    const int64_t ticket0 = sp->stage_ticket;
+    const int64_t R = (int64_t)sp->stage.size();
+    sp->stage_ticket += (int64_t)pieces.size();
+    auto work = [&](int) {
         if (fzp_bind(ctx) != FZP_OK) { hip_bad.store(1); return; }
-        int turn = 0;
-        for (int k; (k = next.fetch_add(1)) < (int)pieces.size(); turn ^= 1) {
+        for (int k; (k = next.fetch_add(1)) < (int)pieces.size();) {
             const Piece &P = pieces[(size_t)k];
-            const size_t bi = (size_t)(2 * tid + turn);
+            const int64_t tk = ticket0 + k;
+            const size_t bi = (size_t)(tk % R);
             uint8_t *buf = sp->stage[bi];
-            if (sp->stage_used[bi] && hipEventSynchronize(sp->stage_ev[bi]) != hipSuccess) { hip_bad.store(1); break; }      // the copy that last left this buffer (this group's or the one before)
+            while (sp->stage_turn[bi].load(std::memory_order_acquire) != tk) std::this_thread::yield();      // (the ticket a ring before this one has not queued its copy yet: a reader that fell far behind)
+            if (sp->stage_used[bi] && hipEventSynchronize(sp->stage_ev[bi]) != hipSuccess) { hip_bad.store(1); sp->stage_turn[bi].store(tk + R, std::memory_order_release); break; }      // the copy that last left this buffer
             size_t at = P.a;
             while (at < P.b) {
                 const ssize_t got = pread(fds[(size_t)P.t], buf + (at - P.a), P.b - at, (off_t)at);
@@ -1462,11 +1480,13 @@ void load_group_raw(fzp_ctx *ctx, const std::string &dir, const char *const *ctg
                 }
                 at += (size_t)got;
             }
-            if (at != P.b) continue;
+            if (at != P.b) { sp->stage_turn[bi].store(tk + R, std::memory_order_release); continue; }
             // the piece is in pinned memory: on its way while the next one is read
             hipStream_t us = ups[k % n_up];
-            if (hipMemcpyAsync(G.d_raw.p + G.foff[(size_t)P.t] + (int64_t)P.a, buf, P.b - P.a, hipMemcpyHostToDevice, us) != hipSuccess || hipEventRecord(sp->stage_ev[bi], us) != hipSuccess) { hip_bad.store(1); break; }
-            sp->stage_used[bi] = 1;
+            const bool ok = hipMemcpyAsync(G.d_raw.p + G.foff[(size_t)P.t] + (int64_t)P.a, buf, P.b - P.a, hipMemcpyHostToDevice, us) == hipSuccess && hipEventRecord(sp->stage_ev[bi], us) == hipSuccess;
+            if (ok) sp->stage_used[bi] = 1;
+            sp->stage_turn[bi].store(tk + R, std::memory_order_release);      // the buffer's next ticket may come (it waits for the event first)
+            if (!ok) { hip_bad.store(1); break; }
         }
     };
     {
@@ -1491,6 +1511,8 @@ void load_group_raw(fzp_ctx *ctx, const std::string &dir, const char *const *ctg
         for (int u = 0; u < n_up; u++) (void)hipStreamSynchronize(ups[u]);
         if (bad) {
             (void)hipGetLastError();
+            // (readers that gave up may have left tickets nobody took: the ring starts afresh at the next ticket -- every copy out of it is through)
+            for (int64_t i = 0; i < R; i++) sp->stage_turn[(size_t)i].store(sp->stage_ticket + ((i - sp->stage_ticket % R) % R + R) % R);
             if (G.rc == FZP_OK) { G.rc = FZP_EDEVICE; G.err = "upload of the group's files failed"; }
             return;
         }
