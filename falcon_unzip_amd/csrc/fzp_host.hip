@@ -852,9 +852,13 @@ extern "C" int fzp_format_phased_variants(const fzp_site *s, const fzp_pvar *v, 
             if (!b.reserve(200)) return FZP_ENOMEM;
             long long p = (long long)s[v[k].site].pos + 1;
             char rb = (char)s[v[k].site].ref_base;
-            b.put("V ", 2); b.puti(v[k].block); b.putc_(' '); b.puti(p); b.putc_(' ');
-            b.puti(p); b.putc_('_'); b.putc_(rb); b.putc_('_'); b.putc_((char)v[k].b1); b.putc_(' ');
-            b.puti(p); b.putc_('_'); b.putc_(rb); b.putc_('_'); b.putc_((char)v[k].b2); b.putc_(' ');
+            b.put("V ", 2); b.puti(v[k].block); b.putc_(' ');
+            const size_t p_at = b.n;                       // (the position stands three times in the row: spelled once, copied twice)
+            b.puti(p);
+            const size_t p_n = b.n - p_at;
+            b.putc_(' ');
+            b.put(b.p + p_at, p_n); b.putc_('_'); b.putc_(rb); b.putc_('_'); b.putc_((char)v[k].b1); b.putc_(' ');
+            b.put(b.p + p_at, p_n); b.putc_('_'); b.putc_(rb); b.putc_('_'); b.putc_((char)v[k].b2); b.putc_(' ');
             b.puti(v[k].lext); b.putc_(' '); b.puti(v[k].rext); b.putc_(' '); b.puti(v[k].lscore); b.putc_(' '); b.puti(v[k].rscore);
             b.putc_('\n');
         }
