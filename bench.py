@@ -318,6 +318,10 @@ def roofline(cells_per_launch, sw_avg_ms, sw_launches, dp_gcells, traffic, band=
                     "views sit beside it: `hbm_algorithmic` prices SURVEY 8d's 0.25 B per cell (the 2 trace-back bits of every cell), `hbm_moved` what the kernel really moves "
                     "(`traffic`: 8 B of mask record per band step -- with fzalign v1.8's 32-cell band the whole mask -- + the base streams).  (SURVEY 8d's third view, 12 integer "
                     "ops per cell, is not priced any more: a bit-parallel kernel spends ~2 lane-operations per cell, the 'fraction' came out at 2.0.)",
+            # the kernel holds ONE wave per SIMD (265 registers a lane); a lone wave issues a VALU instruction every 4 cycles at best (the guide's figure; measured 4.8-6.6 for
+            # this mix, tools/ubench/bitops_issue) -- the ceiling of that shape, beside the chip's
+            "one_wave_per_simd": {"peak": round(valu_peak / 2.0, 1), "frac": round(valu / (valu_peak / 2.0), 4), "unit": "G wave64-inst/s",
+                                  "note": "1 024 SIMDs x 2.4 GHz / 4 cycles per instruction of a lone wave; a second wave per SIMD was built and measured slower (profiles/r6_swb_units.txt, r6_not_kept.txt)"},
             "hbm_algorithmic": {"achieved": round(gbs_alg, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs_alg / HBM_PEAK_GBS, 4), "bytes_per_cell": SW_BYTES_PER_CELL},
             "hbm_moved": {"achieved": round(gbs_moved, 2) if gbs_moved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs_moved / HBM_PEAK_GBS, 4) if gbs_moved else None,
                           "bytes_per_cell": moved_per_cell, "bytes_per_launch": traffic}}
