@@ -274,14 +274,24 @@ void parse_maps(const fzp_pipe_opts *o, ReadMaps &m) {
 
 // the read maps are parsed on their own thread while the device works (2 ms for 40 000 reads); whoever needs them first waits
 struct MapsHolder {
-    ReadMaps maps;
+    mutable ReadMaps maps;
     std::shared_future<void> ready;
     bool have = false;
+    // lazy (r6, fzp_job_phase_write): parsed by whoever asks first -- the thread that resolves the read-map rows, once K1's kernels are queued.  A thread of its own from the
+    // call's first instruction on took a core from the launch thread exactly while it had K1's plan to launch (a rank with two cores: +0.3-0.9 ms of K1)
+    const fzp_pipe_opts *lazy_opts = nullptr;
+    mutable std::once_flag lazy_once;
     void start(const fzp_pipe_opts *o) {
         have = o->pread_to_contigs != nullptr;
         if (have) ready = std::async(std::launch::async, [this, o]() { parse_maps(o, maps); }).share();
     }
-    const ReadMaps *get() const { if (!have) return nullptr; ready.wait(); return &maps; }
+    void start_lazy(const fzp_pipe_opts *o) { have = o->pread_to_contigs != nullptr; lazy_opts = o; }
+    const ReadMaps *get() const {
+        if (!have) return nullptr;
+        if (lazy_opts) std::call_once(lazy_once, [this]() { parse_maps(lazy_opts, maps); });
+        else ready.wait();
+        return &maps;
+    }
 };
 
 struct TextBuf {
@@ -893,7 +903,7 @@ extern "C" int fzp_job_phase_write(fzp_ctx *ctx, fzp_alnjob *job, const fzp_name
     memset(out, 0, sizeof *out);
     const auto t_call = clk::now();
     MapsHolder mh;
-    mh.start(&o);
+    mh.start_lazy(&o);
     std::vector<fzp_r2p> r2p;
     FZP_TRY(job_phase_write(ctx, job, nm, &o, mh, o.ctg_index, out, r2p));
     if (getenv("FZP_PIPE_TIMING")) fprintf(stderr, "[fzp_job_phase_write] %.2f ms in the call: k1 %.2f phase %.2f results %.2f text %.2f\n", ms_since(t_call), out->ms_k1, out->ms_phase,
